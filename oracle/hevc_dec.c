@@ -1,0 +1,866 @@
+/* oracle/hevc_dec.c -- see hevc_dec.h.  Test infrastructure: a from-the-standard HEVC decoder
+ * used as the CPU checker for the decode half of the hot path
+ * (/root/reference/src/media/processing/openhevcfilter.cpp:103-239). */
+#include "hevc_dec.h"
+#include "hevc_bits.h"
+#include "hevc_cabac.h"
+#include "hevc_ps.h"
+#include "hevc_pic.h"
+#include "hevc_intra.h"
+#include "hevc_inter.h"
+#include "hevc_transform.h"
+#include "hevc_deblock.h"
+#include "hevc_mvpred.h"
+#include <stdio.h>
+
+#define MAX_DPB 17
+#define ERR_UNSUPPORTED (-2)
+#define ERR_INVALID (-1)
+
+struct orc_decoder {
+  orc_vps vps[16]; orc_sps sps[16]; orc_pps pps[64];
+  orc_pic dpb[MAX_DPB];
+  orc_pic *cur;
+  const orc_sps *s; const orc_pps *p;
+  orc_slice_hdr sh;
+  int nal_type;
+  int prev_tid0_poc;
+  int seen_irap;
+  orc_pic *ref_list0[16]; int ref_poc[16]; int num_ref;
+  int ctbs_decoded; int pic_active;
+  uint8_t *bs_v, *bs_h; size_t bs_cap;
+  pixel *predeblock[3]; size_t predeblock_cap;
+  orc_pic *out_queue[MAX_DPB + 1]; int out_n;
+  orc_pic *last_output;
+  uint8_t *rbsp; size_t rbsp_cap;
+  int64_t cur_pts;
+  /* tile / slice maps for the current picture */
+  int32_t *ctb_slice; int16_t *ctb_tile; int *ts_to_rs, *rs_to_ts; int *tile_first_x; size_t ctb_cap;
+  int col_bd[34], row_bd[34];
+  /* slice decoding state */
+  orc_cabac_dec cabac; orc_ctx wpp_ctx[CTX_COUNT];
+  orc_avail_ctx av;
+  int cu_transquant_bypass;
+  int is_cu_qp_delta_coded, cu_qp_delta_val;
+  int qp_y, last_qp_y, qg_x, qg_y, qp_y_pred;
+  int intra_chroma_pred_mode;
+  int max_trafo_depth, intra_split;
+  int cu_pred_mode, part_mode;
+  int err;
+  int last_slice_type;
+};
+
+/* ------------------------------------------------------------------ helpers */
+static inline int b4(const orc_pic *p, int x, int y) { return (y >> 2) * p->b4_w + (x >> 2); }
+static void fill_b4_u8(orc_pic *p, uint8_t *arr, int x0, int y0, int w, int h, int v)
+{
+  for (int y = y0; y < y0 + h && y < p->h; y += 4)
+    for (int x = x0; x < x0 + w && x < p->w; x += 4) arr[b4(p, x, y)] = (uint8_t)v;
+}
+
+orc_decoder *orc_dec_open(void)
+{
+  orc_decoder *d = (orc_decoder *)calloc(1, sizeof(*d));
+  orc_tables_init();
+  return d;
+}
+void orc_dec_close(orc_decoder *d)
+{
+  if (!d) return;
+  for (int i = 0; i < MAX_DPB; i++) if (d->dpb[i].plane[0]) orc_pic_free(&d->dpb[i]);
+  free(d->bs_v); free(d->bs_h); free(d->rbsp);
+  for (int i = 0; i < 3; i++) free(d->predeblock[i]);
+  free(d->ctb_slice); free(d->ctb_tile); free(d->ts_to_rs); free(d->rs_to_ts); free(d->tile_first_x);
+  free(d->sh.entry_point_offset);
+  free(d);
+}
+const pixel *orc_dec_predeblock_plane(orc_decoder *d, int c) { return d->predeblock[c]; }
+
+/* ------------------------------------------------------------------ residual_coding, 7.3.8.11 */
+static int decode_last_prefix(orc_decoder *d, int base, int log2, int cidx)
+{
+  int off, sh, max = (log2 << 1) - 1, v = 0;
+  if (cidx == 0) { off = 3 * (log2 - 2) + ((log2 - 1) >> 2); sh = (log2 + 1) >> 2; }
+  else { off = 15; sh = log2 - 2; }
+  while (v < max && orc_cdec_bin(&d->cabac, base + off + (v >> sh))) v++;
+  return v;
+}
+
+static int decode_abs_remaining(orc_decoder *d, int rice)
+{
+  int prefix = 0;
+  while (prefix < 32 && orc_cdec_bypass(&d->cabac)) prefix++;
+  if (prefix >= 32) { d->err = ERR_INVALID; return 0; }
+  if (prefix <= 3) return (prefix << rice) + (int)orc_cdec_bypass_bits(&d->cabac, rice);
+  return (((1 << (prefix - 3)) + 3 - 1) << rice) + (int)orc_cdec_bypass_bits(&d->cabac, prefix - 3 + rice);
+}
+
+static const uint8_t ctx_idx_map_4x4[16] = { 0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8 };
+
+/* Parses one transform block into coeff[n*n] (row-major, [y][x]); returns transform_skip_flag. */
+static int residual_coding(orc_decoder *d, int log2, int cidx, int scan_idx, int16_t *coeff)
+{
+  orc_cabac_dec *c = &d->cabac;
+  int n = 1 << log2, ts = 0;
+  uint8_t csbf[8][8];
+  memset(coeff, 0, sizeof(int16_t) * (size_t)n * n);
+  memset(csbf, 0, sizeof(csbf));
+  if (d->p->transform_skip_enabled && !d->cu_transquant_bypass && log2 <= 2)
+    ts = orc_cdec_bin(c, CTX_TS_FLAG + (cidx ? 1 : 0));
+  int lx = decode_last_prefix(d, CTX_LAST_X, log2, cidx);
+  int ly = decode_last_prefix(d, CTX_LAST_Y, log2, cidx);
+  if (lx > 3) { int nb = (lx >> 1) - 1; lx = (1 << nb) * (2 + (lx & 1)) + (int)orc_cdec_bypass_bits(c, nb); }
+  if (ly > 3) { int nb = (ly >> 1) - 1; ly = (1 << nb) * (2 + (ly & 1)) + (int)orc_cdec_bypass_bits(c, nb); }
+  if (scan_idx == 2) { int t = lx; lx = ly; ly = t; }
+  int sb_log2 = log2 - 2, nsb = 1 << sb_log2;
+  const uint8_t *sbx = orc_scan_x[scan_idx][sb_log2], *sby = orc_scan_y[scan_idx][sb_log2];
+  const uint8_t *px = orc_scan_x[scan_idx][2], *py = orc_scan_y[scan_idx][2];
+  int last_sb = (1 << (2 * sb_log2)) - 1, last_pos = 16;
+  for (;;) {
+    if (last_pos == 0) { last_pos = 16; last_sb--; if (last_sb < 0) { d->err = ERR_INVALID; return ts; } }
+    last_pos--;
+    int xc = (sbx[last_sb] << 2) + px[last_pos], yc = (sby[last_sb] << 2) + py[last_pos];
+    if (xc == lx && yc == ly) break;
+  }
+  int c1 = 1;   /* greater1Ctx carried across sub-blocks, 9.3.4.2.6 */
+  for (int i = last_sb; i >= 0; i--) {
+    int xs = sbx[i], ys = sby[i];
+    int infer_dc = 0;
+    int right = (xs < nsb - 1) ? csbf[ys][xs + 1] : 0, below = (ys < nsb - 1) ? csbf[ys + 1][xs] : 0;
+    if (i < last_sb && i > 0) {
+      csbf[ys][xs] = (uint8_t)orc_cdec_bin(c, CTX_CSBF + ((right | below) ? 1 : 0) + (cidx ? 2 : 0));
+      infer_dc = 1;
+    } else csbf[ys][xs] = 1;
+    uint8_t sig[16]; memset(sig, 0, sizeof(sig));
+    int start = (i == last_sb) ? last_pos - 1 : 15;
+    if (i == last_sb) sig[last_pos] = 1;
+    int prev_csbf = right | (below << 1);
+    for (int k = start; k >= 0; k--) {
+      int xp = px[k], yp = py[k], xc = (xs << 2) + xp, yc = (ys << 2) + yp;
+      if (csbf[ys][xs] && (k > 0 || !infer_dc)) {
+        int sc;
+        if (log2 == 2) sc = ctx_idx_map_4x4[(yc << 2) + xc];
+        else if (xc + yc == 0) sc = 0;
+        else {
+          if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
+          else if (prev_csbf == 1) sc = (yp == 0) ? 2 : (yp == 1) ? 1 : 0;
+          else if (prev_csbf == 2) sc = (xp == 0) ? 2 : (xp == 1) ? 1 : 0;
+          else sc = 2;
+          if (cidx == 0) {
+            if (i > 0) sc += 3;
+            sc += (log2 == 3) ? ((scan_idx == 0) ? 9 : 15) : 21;
+          } else {
+            sc += (log2 == 3) ? 9 : 12;
+          }
+        }
+        sig[k] = (uint8_t)orc_cdec_bin(c, CTX_SIG + (cidx ? 27 : 0) + sc);
+        if (sig[k]) infer_dc = 0;
+      } else if (k == 0 && csbf[ys][xs] && infer_dc) {
+        sig[0] = 1;
+      }
+    }
+    int nsig = 0; for (int k = 0; k < 16; k++) nsig += sig[k];
+    if (!nsig) continue;
+    /* greater1 / greater2 flags */
+    int ctx_set = (i > 0 && cidx == 0) ? 2 : 0;
+    if (c1 == 0) ctx_set++;
+    c1 = 1;
+    uint8_t g1[16], g2[16]; memset(g1, 0, sizeof(g1)); memset(g2, 0, sizeof(g2));
+    int first_sig = 16, last_sig = -1, ng1 = 0, last_g1_pos = -1;
+    for (int k = 15; k >= 0; k--) if (sig[k]) {
+      if (ng1 < 8) {
+        g1[k] = (uint8_t)orc_cdec_bin(c, CTX_GT1 + (cidx ? 16 : 0) + ctx_set * 4 + c1);
+        ng1++;
+        if (g1[k]) { c1 = 0; if (last_g1_pos == -1) last_g1_pos = k; }
+        else if (c1 > 0 && c1 < 3) c1++;
+      }
+      if (last_sig == -1) last_sig = k;
+      first_sig = k;
+    }
+    int sign_hidden = d->p->sign_data_hiding && !d->cu_transquant_bypass && (last_sig - first_sig > 3);
+    if (last_g1_pos != -1) g2[last_g1_pos] = (uint8_t)orc_cdec_bin(c, CTX_GT2 + (cidx ? 4 : 0) + ctx_set);
+    uint8_t sign[16]; memset(sign, 0, sizeof(sign));
+    for (int k = 15; k >= 0; k--) if (sig[k] && (!sign_hidden || k != first_sig)) sign[k] = (uint8_t)orc_cdec_bypass(c);
+    int num_sig = 0, sum_abs = 0, rice = 0;
+    for (int k = 15; k >= 0; k--) if (sig[k]) {
+      int base = 1 + g1[k] + g2[k];
+      int absv = base;
+      if (base == ((num_sig < 8) ? ((k == last_g1_pos) ? 3 : 2) : 1)) {
+        int rem = decode_abs_remaining(d, rice);
+        absv = base + rem;
+        if (absv > 3 * (1 << rice)) rice = ORC_MIN(rice + 1, 4);
+      }
+      int v = sign[k] ? -absv : absv;
+      if (sign_hidden) { sum_abs += absv; if (k == first_sig && (sum_abs & 1)) v = -v; }
+      int xc = (xs << 2) + px[k], yc = (ys << 2) + py[k];
+      coeff[yc * n + xc] = (int16_t)orc_clip3(-32768, 32767, v);
+      num_sig++;
+    }
+  }
+  return ts;
+}
+
+/* ------------------------------------------------------------------ reconstruction of one TB */
+static void recon_tb(orc_decoder *d, int cidx, int x0, int y0, int log2, const int16_t *level, int ts, int qp, int dst_mode)
+{
+  /* x0,y0 in component samples */
+  orc_pic *pic = d->cur;
+  int n = 1 << log2;
+  int16_t coeff[32 * 32], res[32 * 32];
+  if (d->cu_transquant_bypass) {
+    memcpy(res, level, sizeof(int16_t) * (size_t)n * n);
+  } else {
+    orc_dequant(level, coeff, n, qp);
+    if (ts) { for (int i = 0; i < n * n; i++) res[i] = (int16_t)((((int)coeff[i] << 7) + (1 << 11)) >> 12); }
+    else orc_inv_transform(coeff, res, n, dst_mode);
+  }
+  pixel *dst = pic->plane[cidx] + y0 * pic->stride[cidx] + x0;
+  for (int y = 0; y < n; y++)
+    for (int x = 0; x < n; x++) dst[y * pic->stride[cidx] + x] = (pixel)orc_clip_pixel(dst[y * pic->stride[cidx] + x] + res[y * n + x]);
+}
+
+static void intra_pred_tb(orc_decoder *d, int cidx, int x0, int y0, int log2, int mode)
+{
+  orc_pic *pic = d->cur;
+  int n = 1 << log2;
+  pixel left[65 + 64], top[65 + 64];
+  orc_intra_refs(&d->av, pic->plane[cidx], pic->stride[cidx], cidx, x0, y0, n, left, top);
+  orc_intra_predict(left, top, n, cidx, mode, d->s->strong_intra_smoothing,
+                    pic->plane[cidx] + y0 * pic->stride[cidx] + x0, pic->stride[cidx]);
+}
+
+/* ------------------------------------------------------------------ QP derivation 8.6.1 */
+static void derive_qp_pred(orc_decoder *d, int xqg, int yqg, int first_qg_in_ctb_row_or_slice)
+{
+  orc_pic *pic = d->cur;
+  int prev = first_qg_in_ctb_row_or_slice ? d->sh.slice_qp : d->last_qp_y;
+  int ctb = d->s->ctb_log2;
+  int qa = prev, qb = prev;
+  if (orc_available(&d->av, xqg, yqg, xqg - 1, yqg) && ((xqg - 1) >> ctb) == (xqg >> ctb))
+    qa = pic->qp_y[b4(pic, xqg - 1, yqg)];
+  if (orc_available(&d->av, xqg, yqg, xqg, yqg - 1) && ((yqg - 1) >> ctb) == (yqg >> ctb))
+    qb = pic->qp_y[b4(pic, xqg, yqg - 1)];
+  d->qp_y_pred = (qa + qb + 1) >> 1;
+}
+
+/* ------------------------------------------------------------------ transform tree */
+typedef struct { int x0, y0, log2cb; int intra_modes[4]; int chroma_mode; } cu_info;
+
+static int scan_idx_for(int pred_intra, int log2, int cidx, int mode)
+{
+  /* 7.4.9.11: mode dependent scan for intra 4x4 (luma+chroma) and luma 8x8 */
+  if (!pred_intra) return 0;
+  if (log2 == 2 || (log2 == 3 && cidx == 0)) {
+    if (mode >= 6 && mode <= 14) return 2;
+    if (mode >= 22 && mode <= 30) return 1;
+  }
+  return 0;
+}
+
+static void transform_unit(orc_decoder *d, const cu_info *cu, int x0, int y0, int xbase, int ybase, int log2, int depth, int blk,
+                           int cbf_luma, int cbf_cb, int cbf_cr, int cbf_cb_parent, int cbf_cr_parent)
+{
+  orc_pic *pic = d->cur;
+  orc_cabac_dec *c = &d->cabac;
+  int intra = d->cu_pred_mode == MODE_INTRA;
+  int n = 1 << log2;
+  int chroma_here = log2 > 2, chroma_parent = (log2 == 2 && blk == 3);
+  int ccb = chroma_here ? cbf_cb : (chroma_parent ? cbf_cb_parent : 0);
+  int ccr = chroma_here ? cbf_cr : (chroma_parent ? cbf_cr_parent : 0);
+  int cbf_chroma_any = (log2 > 2) ? (cbf_cb || cbf_cr) : (cbf_cb_parent || cbf_cr_parent);
+  int16_t lev[32 * 32];
+  (void)depth;
+  if (cbf_luma || cbf_chroma_any) {
+    if (d->p->cu_qp_delta_enabled && !d->is_cu_qp_delta_coded) {
+      int v = 0;
+      while (v < 5 && orc_cdec_bin(c, CTX_CU_QP_DELTA + (v ? 1 : 0))) v++;
+      if (v == 5) { int k = 0; while (k < 16 && orc_cdec_bypass(c)) { v += 1 << k; k++; } v += (int)orc_cdec_bypass_bits(c, k); }
+      if (v && orc_cdec_bypass(c)) v = -v;
+      d->is_cu_qp_delta_coded = 1; d->cu_qp_delta_val = v;
+      d->qp_y = ((d->qp_y_pred + v + 52) % 52);
+    }
+  }
+  int qp_y = d->qp_y;
+  int qp_cb = orc_chroma_qp(qp_y, d->p->cb_qp_offset + d->sh.slice_cb_qp_offset);
+  int qp_cr = orc_chroma_qp(qp_y, d->p->cr_qp_offset + d->sh.slice_cr_qp_offset);
+  /* luma */
+  int lmode = 0;
+  if (intra) {
+    lmode = pic->intra_mode[b4(pic, x0, y0)];
+    intra_pred_tb(d, 0, x0, y0, log2, lmode);
+  }
+  if (cbf_luma) {
+    int ts = residual_coding(d, log2, 0, scan_idx_for(intra, log2, 0, lmode), lev);
+    recon_tb(d, 0, x0, y0, log2, lev, ts, qp_y, intra && log2 == 2);
+    fill_b4_u8(pic, pic->tu_nz, x0, y0, n, n, 1);
+  }
+  /* chroma */
+  if (chroma_here || chroma_parent) {
+    int cx = (chroma_here ? x0 : xbase) >> 1, cy = (chroma_here ? y0 : ybase) >> 1;
+    int clog2 = chroma_here ? log2 - 1 : 2;
+    int cmode = cu->chroma_mode;
+    for (int ci = 1; ci <= 2; ci++) {
+      if (intra) intra_pred_tb(d, ci, cx, cy, clog2, cmode);
+      if (ci == 1 ? ccb : ccr) {
+        int ts = residual_coding(d, clog2, ci, scan_idx_for(intra, clog2, ci, cmode), lev);
+        recon_tb(d, ci, cx, cy, clog2, lev, ts, ci == 1 ? qp_cb : qp_cr, 0);
+      }
+    }
+  }
+}
+
+static void transform_tree(orc_decoder *d, const cu_info *cu, int x0, int y0, int xbase, int ybase, int log2, int depth, int blk,
+                           int cbf_cb_parent, int cbf_cr_parent)
+{
+  orc_pic *pic = d->cur;
+  orc_cabac_dec *c = &d->cabac;
+  const orc_sps *s = d->s;
+  int split;
+  if (d->err) return;
+  if (log2 <= s->log2_max_tb && log2 > s->log2_min_tb && depth < d->max_trafo_depth && !(d->intra_split && depth == 0))
+    split = orc_cdec_bin(c, CTX_SPLIT_TRANSFORM + 5 - log2);
+  else {
+    int inter_split = (s->max_th_depth_inter == 0 && d->cu_pred_mode == MODE_INTER && d->part_mode != PART_2Nx2N && depth == 0);
+    split = (log2 > s->log2_max_tb || (d->intra_split && depth == 0) || inter_split) ? 1 : 0;
+  }
+  int cbf_cb = 0, cbf_cr = 0;
+  if (log2 > 2) {
+    if (depth == 0 || cbf_cb_parent) cbf_cb = orc_cdec_bin(c, CTX_CBF_CHROMA + depth);
+    if (depth == 0 || cbf_cr_parent) cbf_cr = orc_cdec_bin(c, CTX_CBF_CHROMA + depth);
+  } else { cbf_cb = cbf_cb_parent; cbf_cr = cbf_cr_parent; }   /* 7.4.9.8: inferred from parent for 4x4 luma */
+  if (split) {
+    int h = 1 << (log2 - 1);
+    transform_tree(d, cu, x0, y0, x0, y0, log2 - 1, depth + 1, 0, cbf_cb, cbf_cr);
+    transform_tree(d, cu, x0 + h, y0, x0, y0, log2 - 1, depth + 1, 1, cbf_cb, cbf_cr);
+    transform_tree(d, cu, x0, y0 + h, x0, y0, log2 - 1, depth + 1, 2, cbf_cb, cbf_cr);
+    transform_tree(d, cu, x0 + h, y0 + h, x0, y0, log2 - 1, depth + 1, 3, cbf_cb, cbf_cr);
+  } else {
+    int cbf_luma = 1;
+    if (d->cu_pred_mode == MODE_INTRA || depth != 0 || cbf_cb || cbf_cr)
+      cbf_luma = orc_cdec_bin(c, CTX_CBF_LUMA + (depth == 0 ? 1 : 0));
+    /* transform block edges for deblocking */
+    int n = 1 << log2;
+    for (int i = 0; i < n; i += 4) {
+      if (y0 + i < pic->h) pic->edge_v[b4(pic, x0, y0 + i)] |= 1;
+      if (x0 + i < pic->w) pic->edge_h[b4(pic, x0 + i, y0)] |= 1;
+    }
+    transform_unit(d, cu, x0, y0, xbase, ybase, log2, depth, blk, cbf_luma,
+                   log2 > 2 ? cbf_cb : 0, log2 > 2 ? cbf_cr : 0, cbf_cb_parent, cbf_cr_parent);
+  }
+}
+
+/* ------------------------------------------------------------------ prediction units */
+static int decode_mvd_comp_abs(orc_decoder *d, int gt0, int gt1)
+{
+  if (!gt0) return 0;
+  if (!gt1) return 1;
+  /* abs_mvd_minus2: EG1 */
+  int k = 1, v = 0;
+  while (k < 32 && orc_cdec_bypass(&d->cabac)) { v += 1 << k; k++; }
+  if (k >= 32) { d->err = ERR_INVALID; return 0; }
+  v += (int)orc_cdec_bypass_bits(&d->cabac, k);
+  return v + 2;
+}
+
+static void mc_pu(orc_decoder *d, int xp, int yp, int w, int h, const int16_t mv[2], int ref_idx)
+{
+  orc_pic *pic = d->cur, *ref = d->ref_list0[ref_idx];
+  int16_t tmp[64 * 64];
+  orc_mc_luma(ref->plane[0], ref->stride[0], ref->w, ref->h, xp, yp, w, h, mv[0], mv[1], tmp, 64);
+  orc_pred_uni(tmp, 64, pic->plane[0] + yp * pic->stride[0] + xp, pic->stride[0], w, h);
+  for (int ci = 1; ci <= 2; ci++) {
+    orc_mc_chroma(ref->plane[ci], ref->stride[ci], ref->w / 2, ref->h / 2, xp / 2, yp / 2, w / 2, h / 2, mv[0], mv[1], tmp, 64);
+    orc_pred_uni(tmp, 64, pic->plane[ci] + (yp / 2) * pic->stride[ci] + xp / 2, pic->stride[ci], w / 2, h / 2);
+  }
+}
+
+static void prediction_unit(orc_decoder *d, int xcb, int ycb, int ncbs, int xp, int yp, int w, int h, int part_idx, int skip, int *merge_flag_out)
+{
+  orc_cabac_dec *c = &d->cabac;
+  orc_pic *pic = d->cur;
+  orc_mvpred_ctx mc;
+  mc.pic = pic; mc.av = d->av; mc.log2_par_mrg_level = d->p->log2_parallel_merge_level;
+  mc.max_num_merge_cand = d->sh.max_num_merge_cand; mc.num_ref_idx = d->sh.num_ref_idx_l0;
+  mc.cur_poc = pic->poc; memcpy(mc.ref_poc, d->ref_poc, sizeof(mc.ref_poc));
+  int merge = skip ? 1 : orc_cdec_bin(c, CTX_MERGE_FLAG);
+  if (merge_flag_out) *merge_flag_out = merge;
+  int16_t mv[2]; int ref_idx = 0;
+  if (merge) {
+    int idx = 0;
+    if (d->sh.max_num_merge_cand > 1) {
+      if (orc_cdec_bin(c, CTX_MERGE_IDX)) { idx = 1; while (idx < d->sh.max_num_merge_cand - 1 && orc_cdec_bypass(c)) idx++; }
+    }
+    orc_mvcand cand[5];
+    orc_merge_candidates(&mc, xcb, ycb, ncbs, xp, yp, w, h, part_idx, d->part_mode, cand);
+    mv[0] = cand[idx].mv[0]; mv[1] = cand[idx].mv[1]; ref_idx = cand[idx].ref_idx;
+  } else {
+    if (d->sh.num_ref_idx_l0 > 1) {
+      int mx = d->sh.num_ref_idx_l0 - 1;
+      while (ref_idx < mx && ref_idx < 2 && orc_cdec_bin(c, CTX_REF_IDX + ref_idx)) ref_idx++;
+      if (ref_idx == 2) while (ref_idx < mx && orc_cdec_bypass(c)) ref_idx++;
+    }
+    int gt0x = orc_cdec_bin(c, CTX_MVD_GT0), gt0y = orc_cdec_bin(c, CTX_MVD_GT0);
+    int gt1x = gt0x ? orc_cdec_bin(c, CTX_MVD_GT1) : 0, gt1y = gt0y ? orc_cdec_bin(c, CTX_MVD_GT1) : 0;
+    int mvdx = decode_mvd_comp_abs(d, gt0x, gt1x); if (gt0x && orc_cdec_bypass(c)) mvdx = -mvdx;
+    int mvdy = decode_mvd_comp_abs(d, gt0y, gt1y); if (gt0y && orc_cdec_bypass(c)) mvdy = -mvdy;
+    int mvp = orc_cdec_bin(c, CTX_MVP_FLAG);
+    int16_t cand[2][2];
+    orc_amvp_candidates(&mc, xcb, ycb, ncbs, xp, yp, w, h, part_idx, ref_idx, cand);
+    /* 8.5.3.2.6: uLX = (mvp + mvd + 2^16) % 2^16, wrapped to int16 */
+    mv[0] = (int16_t)(uint16_t)(cand[mvp][0] + mvdx);
+    mv[1] = (int16_t)(uint16_t)(cand[mvp][1] + mvdy);
+  }
+  if (ref_idx >= d->num_ref || !d->ref_list0[ref_idx]) { d->err = ERR_INVALID; return; }
+  for (int y = yp; y < yp + h; y += 4)
+    for (int x = xp; x < xp + w; x += 4) {
+      orc_mvinfo *m = &pic->mvf[b4(pic, x, y)];
+      m->mv[0] = mv[0]; m->mv[1] = mv[1]; m->ref_idx = (int8_t)ref_idx;
+    }
+  /* prediction block edges for deblocking */
+  for (int i = 0; i < h; i += 4) pic->edge_v[b4(pic, xp, yp + i)] |= 2;
+  for (int i = 0; i < w; i += 4) pic->edge_h[b4(pic, xp + i, yp)] |= 2;
+  mc_pu(d, xp, yp, w, h, mv, ref_idx);
+}
+
+/* ------------------------------------------------------------------ coding unit */
+static void coding_unit(orc_decoder *d, int x0, int y0, int log2cb, int ct_depth)
+{
+  orc_cabac_dec *c = &d->cabac;
+  orc_pic *pic = d->cur;
+  const orc_sps *s = d->s;
+  int n = 1 << log2cb;
+  cu_info cu; memset(&cu, 0, sizeof(cu));
+  cu.x0 = x0; cu.y0 = y0; cu.log2cb = log2cb;
+  d->cu_transquant_bypass = 0;
+  if (d->p->transquant_bypass_enabled) d->cu_transquant_bypass = orc_cdec_bin(c, CTX_TQ_BYPASS);
+  int skip = 0;
+  if (d->sh.slice_type != SLICE_I) {
+    int l = orc_available(&d->av, x0, y0, x0 - 1, y0) && pic->pred_mode[b4(pic, x0 - 1, y0)] == MODE_SKIP;
+    int a = orc_available(&d->av, x0, y0, x0, y0 - 1) && pic->pred_mode[b4(pic, x0, y0 - 1)] == MODE_SKIP;
+    skip = orc_cdec_bin(c, CTX_SKIP + l + a);
+  }
+  d->part_mode = PART_2Nx2N; d->intra_split = 0;
+  int rqt_root_cbf = 1, merge_2nx2n = 0;
+  fill_b4_u8(pic, pic->ct_depth, x0, y0, n, n, ct_depth);
+  fill_b4_u8(pic, pic->no_filter, x0, y0, n, n, d->cu_transquant_bypass);
+  if (skip) {
+    d->cu_pred_mode = MODE_INTER;
+    fill_b4_u8(pic, pic->pred_mode, x0, y0, n, n, MODE_SKIP);
+    prediction_unit(d, x0, y0, n, x0, y0, n, n, 0, 1, NULL);
+    rqt_root_cbf = 0;
+  } else {
+    d->cu_pred_mode = MODE_INTRA;
+    if (d->sh.slice_type != SLICE_I) d->cu_pred_mode = orc_cdec_bin(c, CTX_PRED_MODE) ? MODE_INTRA : MODE_INTER;
+    if (d->cu_pred_mode != MODE_INTRA || log2cb == s->log2_min_cb) {
+      /* part_mode binarisation, 9.3.3.7 */
+      if (d->cu_pred_mode == MODE_INTRA) {
+        d->part_mode = orc_cdec_bin(c, CTX_PART_MODE) ? PART_2Nx2N : PART_NxN;
+      } else if (orc_cdec_bin(c, CTX_PART_MODE)) {
+        d->part_mode = PART_2Nx2N;
+      } else if (log2cb == s->log2_min_cb) {
+        if (orc_cdec_bin(c, CTX_PART_MODE + 1)) d->part_mode = PART_2NxN;
+        else if (log2cb == 3) d->part_mode = PART_Nx2N;
+        else d->part_mode = orc_cdec_bin(c, CTX_PART_MODE + 2) ? PART_Nx2N : PART_NxN;
+      } else if (!s->amp_enabled) {
+        d->part_mode = orc_cdec_bin(c, CTX_PART_MODE + 1) ? PART_2NxN : PART_Nx2N;
+      } else {
+        int horiz = orc_cdec_bin(c, CTX_PART_MODE + 1);
+        if (orc_cdec_bin(c, CTX_PART_MODE + 3)) d->part_mode = horiz ? PART_2NxN : PART_Nx2N;
+        else {
+          int b = orc_cdec_bypass(c);
+          d->part_mode = horiz ? (b ? PART_2NxnD : PART_2NxnU) : (b ? PART_nRx2N : PART_nLx2N);
+        }
+      }
+    }
+    fill_b4_u8(pic, pic->pred_mode, x0, y0, n, n, d->cu_pred_mode);
+    if (d->cu_pred_mode == MODE_INTRA) {
+      d->intra_split = (d->part_mode == PART_NxN);
+      int parts = d->intra_split ? 2 : 1, pb = n / parts;
+      int prev[4], k = 0;
+      for (int j = 0; j < parts; j++) for (int i = 0; i < parts; i++) prev[k++] = orc_cdec_bin(c, CTX_PREV_INTRA);
+      k = 0;
+      for (int j = 0; j < parts; j++)
+        for (int i = 0; i < parts; i++, k++) {
+          int xp = x0 + i * pb, yp = y0 + j * pb;
+          /* 8.4.2 candidate modes */
+          int ca = 1, cb = 1;
+          if (orc_available(&d->av, xp, yp, xp - 1, yp) && pic->pred_mode[b4(pic, xp - 1, yp)] == MODE_INTRA) ca = pic->intra_mode[b4(pic, xp - 1, yp)];
+          if (orc_available(&d->av, xp, yp, xp, yp - 1) && pic->pred_mode[b4(pic, xp, yp - 1)] == MODE_INTRA &&
+              (yp - 1) >= ((yp >> s->ctb_log2) << s->ctb_log2)) cb = pic->intra_mode[b4(pic, xp, yp - 1)];
+          int cand[3];
+          if (ca == cb) {
+            if (ca < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
+            else { cand[0] = ca; cand[1] = 2 + ((ca + 29) % 32); cand[2] = 2 + ((ca - 2 + 1) % 32); }
+          } else {
+            cand[0] = ca; cand[1] = cb;
+            if (ca != 0 && cb != 0) cand[2] = 0; else if (ca != 1 && cb != 1) cand[2] = 1; else cand[2] = 26;
+          }
+          int mode;
+          if (prev[k]) {
+            int idx = 0;
+            if (orc_cdec_bypass(c)) { idx = 1; if (orc_cdec_bypass(c)) idx = 2; }
+            mode = cand[idx];
+          } else {
+            mode = (int)orc_cdec_bypass_bits(c, 5);
+            if (cand[0] > cand[1]) { int t = cand[0]; cand[0] = cand[1]; cand[1] = t; }
+            if (cand[0] > cand[2]) { int t = cand[0]; cand[0] = cand[2]; cand[2] = t; }
+            if (cand[1] > cand[2]) { int t = cand[1]; cand[1] = cand[2]; cand[2] = t; }
+            for (int q = 0; q < 3; q++) if (mode >= cand[q]) mode++;
+          }
+          cu.intra_modes[k] = mode;
+          fill_b4_u8(pic, pic->intra_mode, xp, yp, pb, pb, mode);
+        }
+      int icpm = 4;
+      if (orc_cdec_bin(c, CTX_CHROMA_MODE)) icpm = (int)orc_cdec_bypass_bits(c, 2);
+      static const int cm[4] = { 0, 26, 10, 1 };
+      if (icpm == 4) cu.chroma_mode = cu.intra_modes[0];
+      else { cu.chroma_mode = cm[icpm]; if (cu.chroma_mode == cu.intra_modes[0]) cu.chroma_mode = 34; }
+    } else {
+      int h = n / 2, q = n / 4, mf = 0;
+      switch (d->part_mode) {
+      case PART_2Nx2N: prediction_unit(d, x0, y0, n, x0, y0, n, n, 0, 0, &merge_2nx2n); break;
+      case PART_2NxN:  prediction_unit(d, x0, y0, n, x0, y0, n, h, 0, 0, &mf); prediction_unit(d, x0, y0, n, x0, y0 + h, n, h, 1, 0, &mf); break;
+      case PART_Nx2N:  prediction_unit(d, x0, y0, n, x0, y0, h, n, 0, 0, &mf); prediction_unit(d, x0, y0, n, x0 + h, y0, h, n, 1, 0, &mf); break;
+      case PART_2NxnU: prediction_unit(d, x0, y0, n, x0, y0, n, q, 0, 0, &mf); prediction_unit(d, x0, y0, n, x0, y0 + q, n, n - q, 1, 0, &mf); break;
+      case PART_2NxnD: prediction_unit(d, x0, y0, n, x0, y0, n, n - q, 0, 0, &mf); prediction_unit(d, x0, y0, n, x0, y0 + n - q, n, q, 1, 0, &mf); break;
+      case PART_nLx2N: prediction_unit(d, x0, y0, n, x0, y0, q, n, 0, 0, &mf); prediction_unit(d, x0, y0, n, x0 + q, y0, n - q, n, 1, 0, &mf); break;
+      case PART_nRx2N: prediction_unit(d, x0, y0, n, x0, y0, n - q, n, 0, 0, &mf); prediction_unit(d, x0, y0, n, x0 + n - q, y0, q, n, 1, 0, &mf); break;
+      default: /* NxN */
+        prediction_unit(d, x0, y0, n, x0, y0, h, h, 0, 0, &mf); prediction_unit(d, x0, y0, n, x0 + h, y0, h, h, 1, 0, &mf);
+        prediction_unit(d, x0, y0, n, x0, y0 + h, h, h, 2, 0, &mf); prediction_unit(d, x0, y0, n, x0 + h, y0 + h, h, h, 3, 0, &mf); break;
+      }
+      if (!(d->part_mode == PART_2Nx2N && merge_2nx2n)) rqt_root_cbf = orc_cdec_bin(c, CTX_RQT_ROOT_CBF);
+    }
+  }
+  if (d->err) return;
+  /* coding block edges are both transform and prediction edges */
+  for (int i = 0; i < n; i += 4) {
+    if (y0 + i < pic->h) pic->edge_v[b4(pic, x0, y0 + i)] |= 3;
+    if (x0 + i < pic->w) pic->edge_h[b4(pic, x0 + i, y0)] |= 3;
+  }
+  d->qp_y = d->qp_y_pred + d->cu_qp_delta_val;   /* CuQpDeltaVal of the current quantisation group so far */
+  d->qp_y = (d->qp_y + 52) % 52;
+  if (rqt_root_cbf) {
+    d->max_trafo_depth = (d->cu_pred_mode == MODE_INTRA) ? s->max_th_depth_intra + d->intra_split : s->max_th_depth_inter;
+    transform_tree(d, &cu, x0, y0, x0, y0, log2cb, 0, 0, 0, 0);
+  }
+  for (int y = y0; y < y0 + n && y < pic->h; y += 4)
+    for (int x = x0; x < x0 + n && x < pic->w; x += 4) pic->qp_y[b4(pic, x, y)] = (int8_t)d->qp_y;
+  d->last_qp_y = d->qp_y;
+}
+
+static void coding_quadtree(orc_decoder *d, int x0, int y0, int log2cb, int depth)
+{
+  orc_cabac_dec *c = &d->cabac;
+  orc_pic *pic = d->cur;
+  const orc_sps *s = d->s;
+  int n = 1 << log2cb, split;
+  if (d->err) return;
+  if (x0 + n <= s->width && y0 + n <= s->height && log2cb > s->log2_min_cb) {
+    int l = orc_available(&d->av, x0, y0, x0 - 1, y0) && pic->ct_depth[b4(pic, x0 - 1, y0)] > depth;
+    int a = orc_available(&d->av, x0, y0, x0, y0 - 1) && pic->ct_depth[b4(pic, x0, y0 - 1)] > depth;
+    split = orc_cdec_bin(c, CTX_SPLIT_CU + l + a);
+  } else split = (log2cb > s->log2_min_cb);
+  int log2_qg = s->ctb_log2 - d->p->diff_cu_qp_delta_depth;
+  if (d->p->cu_qp_delta_enabled && log2cb >= log2_qg) {
+    d->is_cu_qp_delta_coded = 0; d->cu_qp_delta_val = 0;
+    d->qg_x = x0; d->qg_y = y0;
+    derive_qp_pred(d, x0, y0, 0);
+  }
+  if (split) {
+    int h = n >> 1;
+    coding_quadtree(d, x0, y0, log2cb - 1, depth + 1);
+    if (x0 + h < s->width) coding_quadtree(d, x0 + h, y0, log2cb - 1, depth + 1);
+    if (y0 + h < s->height) coding_quadtree(d, x0, y0 + h, log2cb - 1, depth + 1);
+    if (x0 + h < s->width && y0 + h < s->height) coding_quadtree(d, x0 + h, y0 + h, log2cb - 1, depth + 1);
+  } else {
+    coding_unit(d, x0, y0, log2cb, depth);
+  }
+}
+
+/* ------------------------------------------------------------------ picture management */
+static orc_pic *find_poc(orc_decoder *d, int poc)
+{
+  for (int i = 0; i < MAX_DPB; i++) if (d->dpb[i].in_use && d->dpb[i].is_ref && d->dpb[i].poc == poc && &d->dpb[i] != d->cur) return &d->dpb[i];
+  return NULL;
+}
+
+static orc_pic *alloc_pic(orc_decoder *d, int w, int h)
+{
+  for (int i = 0; i < MAX_DPB; i++) {
+    orc_pic *p = &d->dpb[i];
+    if (p->in_use && (p->is_ref || p->needed_for_output || p == d->last_output)) continue;
+    if (p->plane[0] && (p->w != w || p->h != h)) orc_pic_free(p);
+    if (!p->plane[0]) { if (orc_pic_alloc(p, w, h)) return NULL; }
+    else orc_pic_reset_side(p);
+    p->in_use = 1;
+    return p;
+  }
+  return NULL;
+}
+
+static void setup_tiles(orc_decoder *d)
+{
+  const orc_sps *s = d->s; const orc_pps *p = d->p;
+  int wc = s->pic_w_ctbs, hc = s->pic_h_ctbs, nc = p->num_tile_columns, nr = p->num_tile_rows;
+  size_t n = (size_t)wc * hc;
+  if (n > d->ctb_cap) {
+    d->ctb_slice = (int32_t *)realloc(d->ctb_slice, n * sizeof(int32_t));
+    d->ctb_tile = (int16_t *)realloc(d->ctb_tile, n * sizeof(int16_t));
+    d->ts_to_rs = (int *)realloc(d->ts_to_rs, n * sizeof(int));
+    d->rs_to_ts = (int *)realloc(d->rs_to_ts, n * sizeof(int));
+    d->tile_first_x = (int *)realloc(d->tile_first_x, n * sizeof(int));
+    d->ctb_cap = n;
+  }
+  /* 6.5.1 */
+  d->col_bd[0] = 0; d->row_bd[0] = 0;
+  for (int i = 0; i < nc; i++) {
+    int wcol = p->uniform_spacing ? ((i + 1) * wc) / nc - (i * wc) / nc : (i < nc - 1 ? p->column_width[i] : wc - d->col_bd[i]);
+    d->col_bd[i + 1] = d->col_bd[i] + wcol;
+  }
+  for (int j = 0; j < nr; j++) {
+    int hr = p->uniform_spacing ? ((j + 1) * hc) / nr - (j * hc) / nr : (j < nr - 1 ? p->row_height[j] : hc - d->row_bd[j]);
+    d->row_bd[j + 1] = d->row_bd[j] + hr;
+  }
+  int ts = 0;
+  for (int j = 0; j < nr; j++)
+    for (int i = 0; i < nc; i++)
+      for (int y = d->row_bd[j]; y < d->row_bd[j + 1]; y++)
+        for (int x = d->col_bd[i]; x < d->col_bd[i + 1]; x++) {
+          int rs = y * wc + x;
+          d->ts_to_rs[ts] = rs; d->rs_to_ts[rs] = ts; d->ctb_tile[rs] = (int16_t)(j * nc + i);
+          d->tile_first_x[rs] = d->col_bd[i];
+          ts++;
+        }
+  for (size_t i = 0; i < n; i++) d->ctb_slice[i] = -1;
+}
+
+static int start_picture(orc_decoder *d)
+{
+  const orc_sps *s = d->s; orc_slice_hdr *sh = &d->sh;
+  int irap = d->nal_type >= NAL_BLA_W_LP && d->nal_type <= NAL_RSV_IRAP_VCL23;
+  int idr = d->nal_type == NAL_IDR_W_RADL || d->nal_type == NAL_IDR_N_LP;
+  if (!d->seen_irap && !irap) return 0;           /* cannot start decoding before a random access point */
+  /* 8.3.1 picture order count */
+  int poc;
+  int max_lsb = 1 << s->log2_max_poc_lsb;
+  if (idr) poc = 0;
+  else {
+    int prev_lsb = d->prev_tid0_poc & (max_lsb - 1), prev_msb = d->prev_tid0_poc - prev_lsb, msb;
+    if (irap && !d->seen_irap) msb = 0;
+    else if (sh->poc_lsb < prev_lsb && prev_lsb - sh->poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
+    else if (sh->poc_lsb > prev_lsb && sh->poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
+    else msb = prev_msb;
+    poc = msb + sh->poc_lsb;
+  }
+  if (idr) {
+    for (int i = 0; i < MAX_DPB; i++) d->dpb[i].is_ref = 0;
+  }
+  d->seen_irap = 1;
+  d->prev_tid0_poc = poc;      /* TemporalId 0 only in this oracle's streams; RASL/RADL not produced */
+  d->cur = alloc_pic(d, s->width, s->height);
+  if (!d->cur) return ERR_INVALID;
+  d->cur->poc = poc; d->cur->pts = d->cur_pts;
+  d->cur->is_ref = 1; d->cur->needed_for_output = sh->pic_output_flag;
+  /* 8.3.2 reference picture set: everything not in the RPS is marked unused */
+  if (!idr) {
+    for (int i = 0; i < MAX_DPB; i++) {
+      orc_pic *q = &d->dpb[i];
+      if (!q->in_use || !q->is_ref || q == d->cur) continue;
+      int keep = 0;
+      for (int k = 0; k < sh->st_rps.num_negative; k++) if (q->poc == poc + sh->st_rps.delta_poc_s0[k]) keep = 1;
+      for (int k = 0; k < sh->st_rps.num_positive; k++) if (q->poc == poc + sh->st_rps.delta_poc_s1[k]) keep = 1;
+      if (!keep) q->is_ref = 0;
+    }
+  }
+  size_t need_v = (size_t)(s->width / 8) * (s->height / 4), need_h = (size_t)(s->width / 4) * (s->height / 8);
+  if (need_v + need_h > d->bs_cap) {
+    d->bs_v = (uint8_t *)realloc(d->bs_v, need_v); d->bs_h = (uint8_t *)realloc(d->bs_h, need_h); d->bs_cap = need_v + need_h;
+  }
+  size_t pc = (size_t)s->width * s->height;
+  if (pc > d->predeblock_cap) {
+    d->predeblock[0] = (pixel *)realloc(d->predeblock[0], pc);
+    d->predeblock[1] = (pixel *)realloc(d->predeblock[1], pc / 4);
+    d->predeblock[2] = (pixel *)realloc(d->predeblock[2], pc / 4);
+    d->predeblock_cap = pc;
+  }
+  setup_tiles(d);
+  d->ctbs_decoded = 0;
+  d->pic_active = 1;
+  return 1;
+}
+
+static int build_ref_list(orc_decoder *d)
+{
+  orc_slice_hdr *sh = &d->sh;
+  d->num_ref = 0;
+  if (sh->slice_type == SLICE_I) return 0;
+  orc_pic *cand[32]; int nc = 0;
+  int poc = d->cur->poc;
+  for (int k = 0; k < sh->st_rps.num_negative; k++) if (sh->st_rps.used_s0[k]) cand[nc++] = find_poc(d, poc + sh->st_rps.delta_poc_s0[k]);
+  for (int k = 0; k < sh->st_rps.num_positive; k++) if (sh->st_rps.used_s1[k]) cand[nc++] = find_poc(d, poc + sh->st_rps.delta_poc_s1[k]);
+  if (nc == 0) return ERR_INVALID;
+  for (int i = 0; i < sh->num_ref_idx_l0; i++) {
+    d->ref_list0[i] = cand[i % nc];
+    if (!d->ref_list0[i]) return ERR_INVALID;      /* missing reference picture */
+    d->ref_poc[i] = d->ref_list0[i]->poc;
+  }
+  d->num_ref = sh->num_ref_idx_l0;
+  return 0;
+}
+
+static void finish_picture(orc_decoder *d)
+{
+  orc_pic *pic = d->cur;
+  const orc_sps *s = d->s;
+  for (int ci = 0; ci < 3; ci++) {
+    size_t n = (size_t)(ci ? s->width / 2 : s->width) * (ci ? s->height / 2 : s->height);
+    memcpy(d->predeblock[ci], pic->plane[ci], n);
+  }
+  if (!d->sh.slice_deblocking_disabled) {
+    orc_deblock_ctx db; memset(&db, 0, sizeof(db));
+    orc_compute_bs(pic, d->bs_v, d->bs_h);
+    db.w = pic->w; db.h = pic->h;
+    for (int i = 0; i < 3; i++) { db.plane[i] = pic->plane[i]; db.stride[i] = pic->stride[i]; }
+    db.bs_v = d->bs_v; db.bs_stride_v = pic->w / 8; db.bs_h = d->bs_h; db.bs_stride_h = pic->w / 4;
+    db.qp_y = pic->qp_y; db.qp_stride = pic->b4_w;
+    db.no_filter = pic->no_filter; db.nf_stride = pic->b4_w;
+    db.beta_offset_div2 = d->sh.beta_offset_div2; db.tc_offset_div2 = d->sh.tc_offset_div2;
+    db.cb_qp_offset = d->p->cb_qp_offset; db.cr_qp_offset = d->p->cr_qp_offset;
+    orc_deblock_picture(&db);
+  }
+  d->pic_active = 0;
+  if (pic->needed_for_output) d->out_queue[d->out_n++] = pic;   /* low-delay streams: output order == decode order */
+}
+
+/* ------------------------------------------------------------------ slice data 7.3.8.1 */
+static int decode_slice_data(orc_decoder *d, const uint8_t *data, size_t len)
+{
+  const orc_sps *s = d->s; const orc_pps *p = d->p; orc_slice_hdr *sh = &d->sh;
+  orc_pic *pic = d->cur;
+  int wc = s->pic_w_ctbs, total = wc * s->pic_h_ctbs;
+  int init_type = sh->slice_type == SLICE_I ? 0 : (sh->slice_type == SLICE_P ? (sh->cabac_init_flag ? 2 : 1) : (sh->cabac_init_flag ? 1 : 2));
+  size_t pos = 0;
+  int ts = d->rs_to_ts[sh->slice_segment_address];
+  int slice_addr = sh->slice_segment_address;
+  int first = 1;
+  memset(&d->av, 0, sizeof(d->av));
+  d->av.pic_w = s->width; d->av.pic_h = s->height; d->av.ctb_log2 = s->ctb_log2; d->av.pic_w_ctbs = wc;
+  d->av.ctb_slice = d->ctb_slice; d->av.ctb_tile = d->ctb_tile;
+  orc_cdec_start(&d->cabac, data, len);
+  for (;;) {
+    if (ts >= total) return ERR_INVALID;
+    int rs = d->ts_to_rs[ts], cx = rs % wc, cy = rs / wc;
+    int first_in_tile = (ts == 0) || d->ctb_tile[rs] != d->ctb_tile[d->ts_to_rs[ts - 1]];
+    int row_start = (cx == d->tile_first_x[rs]);
+    d->ctb_slice[rs] = slice_addr;
+    int new_qg_row = 0;
+    if (first || first_in_tile) {
+      orc_cabac_init_contexts(d->cabac.ctx, init_type, sh->slice_qp);
+      new_qg_row = 1;
+    } else if (p->entropy_coding_sync_enabled && row_start) {
+      int xt = ((cx + 1) << s->ctb_log2), yt = ((cy - 1) << s->ctb_log2);
+      if (orc_available(&d->av, cx << s->ctb_log2, cy << s->ctb_log2, xt, yt)) memcpy(d->cabac.ctx, d->wpp_ctx, sizeof(d->wpp_ctx));
+      else orc_cabac_init_contexts(d->cabac.ctx, init_type, sh->slice_qp);
+      new_qg_row = 1;
+    }
+    if (new_qg_row) d->last_qp_y = sh->slice_qp;      /* qPY_PREV at first QG of slice / tile / CTB row (WPP) */
+    first = 0;
+    if (!p->cu_qp_delta_enabled) { d->qp_y_pred = sh->slice_qp; d->cu_qp_delta_val = 0; }
+    /* coding_tree_unit(): no SAO syntax (unsupported when enabled) */
+    coding_quadtree(d, cx << s->ctb_log2, cy << s->ctb_log2, s->ctb_log2, 0);
+    if (d->err) return d->err;
+    if (d->cabac.br.error) return ERR_INVALID;
+    d->ctbs_decoded++;
+    if (p->entropy_coding_sync_enabled && cx == d->tile_first_x[rs] + 1 - 0 && (cx - d->tile_first_x[rs]) == 1)
+      memcpy(d->wpp_ctx, d->cabac.ctx, sizeof(d->wpp_ctx));
+    int end_of_slice = orc_cdec_terminate(&d->cabac);
+    ts++;
+    if (end_of_slice) break;
+    if (ts >= total) return ERR_INVALID;
+    int nrs = d->ts_to_rs[ts];
+    int tile_change = d->ctb_tile[nrs] != d->ctb_tile[rs];
+    if ((p->tiles_enabled && tile_change) ||
+        (p->entropy_coding_sync_enabled && (tile_change || (nrs % wc) == d->tile_first_x[nrs]))) {
+      if (!orc_cdec_terminate(&d->cabac)) return ERR_INVALID;     /* end_of_subset_one_bit */
+      pos += orc_cdec_bytes_consumed(&d->cabac);
+      if (pos >= len) return ERR_INVALID;
+      orc_ctx keep[CTX_COUNT]; memcpy(keep, d->cabac.ctx, sizeof(keep));
+      orc_cdec_start(&d->cabac, data + pos, len - pos);
+      memcpy(d->cabac.ctx, keep, sizeof(keep));
+    }
+  }
+  (void)pic;
+  return 0;
+}
+
+/* ------------------------------------------------------------------ NAL entry */
+int orc_dec_decode_nal(orc_decoder *d, const uint8_t *data, size_t len, int64_t pts)
+{
+  /* strip Annex-B start code if present */
+  size_t i = 0;
+  while (i + 2 < len && data[i] == 0) i++;
+  if (i >= 2 && i < len && data[i] == 1) { data += i + 1; len -= i + 1; }
+  if (len < 3) return ERR_INVALID;
+  if (data[0] & 0x80) return ERR_INVALID;
+  int nal_type = (data[0] >> 1) & 0x3f;
+  int layer = ((data[0] & 1) << 5) | (data[1] >> 3);
+  if (layer != 0) return 0;
+  if (len > d->rbsp_cap) { d->rbsp = (uint8_t *)realloc(d->rbsp, len); d->rbsp_cap = len; }
+  size_t rlen = orc_unescape(data + 2, len - 2, d->rbsp, NULL, 0, NULL);
+  orc_bitr br; orc_br_init(&br, d->rbsp, rlen);
+  d->cur_pts = pts;
+  if (nal_type == NAL_VPS) { orc_vps v; int r = orc_parse_vps(&br, &v); if (r) return r; d->vps[v.vps_id] = v; return 0; }
+  if (nal_type == NAL_SPS) { orc_sps s; int r = orc_parse_sps(&br, &s); if (r) return r; if (s.pcm_enabled) return ERR_UNSUPPORTED; d->sps[s.sps_id] = s; return 0; }
+  if (nal_type == NAL_PPS) { orc_pps p; int r = orc_parse_pps(&br, &p); if (r) return r; d->pps[p.pps_id] = p; return 0; }
+  if (nal_type > 31) return 0;                        /* AUD, SEI, EOS, ... ignored */
+  if ((nal_type > NAL_TRAIL_R + 8 && nal_type < NAL_BLA_W_LP) || nal_type > NAL_CRA) return 0;   /* reserved */
+  free(d->sh.entry_point_offset); d->sh.entry_point_offset = NULL;
+  d->nal_type = nal_type;
+  int r = orc_parse_slice_header(&br, &d->sh, nal_type, d->sps, d->pps);
+  if (r) return r;
+  d->p = &d->pps[d->sh.pps_id]; d->s = &d->sps[d->p->sps_id];
+  if (d->sh.slice_type == SLICE_B) return ERR_UNSUPPORTED;
+  if (d->sh.slice_temporal_mvp_enabled) return ERR_UNSUPPORTED;
+  if (d->sh.sao_luma || d->sh.sao_chroma) return ERR_UNSUPPORTED;
+  if (d->sh.first_slice_segment_in_pic) {
+    if (d->pic_active) finish_picture(d);             /* previous picture was incomplete */
+    r = start_picture(d);
+    if (r <= 0) return r;
+  } else if (!d->pic_active) return 0;
+  r = build_ref_list(d);
+  if (r) { d->pic_active = 0; d->cur->is_ref = 0; d->cur->needed_for_output = 0; return r; }
+  d->err = 0;
+  d->last_slice_type = d->sh.slice_type;
+  size_t hdr_bytes = br.pos >> 3;
+  r = decode_slice_data(d, d->rbsp + hdr_bytes, rlen - hdr_bytes);
+  if (r) { d->pic_active = 0; d->cur->is_ref = 0; d->cur->needed_for_output = 0; return r; }
+  if (d->ctbs_decoded >= d->s->pic_w_ctbs * d->s->pic_h_ctbs) { finish_picture(d); return d->out_n > 0 ? 1 : 0; }
+  return 0;
+}
+
+int orc_dec_get_frame(orc_decoder *d, orc_dec_frame *out)
+{
+  if (d->out_n == 0) return 0;
+  orc_pic *pic = d->out_queue[0];
+  for (int i = 1; i < d->out_n; i++) d->out_queue[i - 1] = d->out_queue[i];
+  d->out_n--;
+  pic->needed_for_output = 0;
+  d->last_output = pic;
+  const orc_sps *s = d->s;
+  int cl = s->conf_win_flag ? s->conf_left * 2 : 0, cr = s->conf_win_flag ? s->conf_right * 2 : 0;
+  int ct = s->conf_win_flag ? s->conf_top * 2 : 0, cb = s->conf_win_flag ? s->conf_bottom * 2 : 0;
+  out->coded_width = pic->w; out->coded_height = pic->h;
+  out->width = pic->w - cl - cr; out->height = pic->h - ct - cb;
+  out->plane[0] = pic->plane[0] + ct * pic->stride[0] + cl;
+  out->plane[1] = pic->plane[1] + (ct / 2) * pic->stride[1] + cl / 2;
+  out->plane[2] = pic->plane[2] + (ct / 2) * pic->stride[2] + cl / 2;
+  for (int i = 0; i < 3; i++) out->stride[i] = pic->stride[i];
+  out->poc = pic->poc; out->pts = pic->pts;
+  out->slice_type = d->last_slice_type;
+  const orc_vps *v = &d->vps[s->vps_id];
+  out->fps_num = out->fps_den = 0;
+  if (s->vui_timing_present) { out->fps_num = s->vui_time_scale; out->fps_den = s->vui_num_units_in_tick; }
+  else if (v->valid && v->timing_info_present) { out->fps_num = v->time_scale; out->fps_den = v->num_units_in_tick; }
+  return 1;
+}

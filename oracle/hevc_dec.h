@@ -1,0 +1,37 @@
+/* oracle/hevc_dec.h -- HEVC decoder restated from ITU-T H.265 (decoding process clauses 8.x,
+ * parsing 9.3, syntax 7.3).  This is the CPU checker for what uvgComm's OpenHEVCFilter gets
+ * from libOpenHevcDecode / libOpenHevcGetOutput
+ * (/root/reference/src/media/processing/openhevcfilter.cpp:145-146,195-229).
+ * Supported: Main profile 8-bit 4:2:0, I and P slices (list 0), all CB/TB sizes and
+ * partitionings, transform skip, sign data hiding, cu_qp_delta, transquant bypass, WPP/tiles
+ * entry points, multiple independent slices, deblocking.  Unsupported (returns < 0): B slices,
+ * temporal MVP, weighted prediction, SAO, scaling lists, PCM, long-term refs, dependent slice
+ * segments.  Test infrastructure. */
+#ifndef ORC_HEVC_DEC_H
+#define ORC_HEVC_DEC_H
+#include "hevc_common.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct orc_decoder orc_decoder;
+typedef struct {
+  const pixel *plane[3]; int stride[3];
+  int width, height;            /* cropped (conformance window) luma size */
+  int coded_width, coded_height;
+  int poc; int64_t pts;
+  uint32_t fps_num, fps_den;    /* from VPS/VUI timing (time_scale / num_units_in_tick), 0 if absent */
+  int slice_type;
+} orc_dec_frame;
+
+orc_decoder *orc_dec_open(void);
+void orc_dec_close(orc_decoder *d);
+/* One NAL unit per call, with or without its Annex-B start code.
+ * Returns <0 on error/unsupported, 0 when no picture became available, 1 when one did. */
+int orc_dec_decode_nal(orc_decoder *d, const uint8_t *data, size_t len, int64_t pts);
+int orc_dec_get_frame(orc_decoder *d, orc_dec_frame *out);   /* 1 = filled, 0 = none */
+/* debug: copy of the last picture before deblocking (same geometry as coded picture) */
+const pixel *orc_dec_predeblock_plane(orc_decoder *d, int c);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,763 @@
+/* oracle/hevc_enc.c -- see hevc_enc.h.  Test infrastructure: the CPU statement of the encoder
+ * algorithm the HIP path implements (encode half of the hot path,
+ * /root/reference/src/media/processing/kvazaarfilter.cpp:374-484). */
+#include "hevc_enc.h"
+#include "hevc_bits.h"
+#include "hevc_cabac.h"
+#include "hevc_ps.h"
+#include "hevc_pic.h"
+#include "hevc_intra.h"
+#include "hevc_inter.h"
+#include "hevc_transform.h"
+#include "hevc_deblock.h"
+#include "hevc_mvpred.h"
+
+#define SPLIT_BITS 8          /* rate charged for splitting a CU one level, in bins */
+#define ME_PAD 64             /* padding of the reference copy used by the motion search */
+
+const uint16_t orc_lambda_q4[52] = {
+  3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 17, 19, 22, 24, 27, 30, 34, 38, 43, 48, 54,
+  61, 68, 77, 86, 97, 108, 122, 137, 153, 172, 193, 217, 244, 273, 307, 344, 387, 434, 487, 547,
+  614, 689, 773, 868, 974, 1093 };
+
+struct orc_encoder {
+  orc_enc_config cfg;
+  int cw, ch, b8w, b8h;
+  int frame_idx, poc, intra_count;
+  orc_vps vps; orc_sps sps; orc_pps pps;
+  orc_pic pics[2]; orc_pic *cur, *ref;
+  pixel *src[3];
+  int16_t *coef[3];
+  pixel *predeblock[3];
+  pixel *refpad; int refpad_stride;
+  uint8_t *cu_log2, *cu_intra, *cu_flags, *cu_merge_idx, *cu_mvp_idx, *cu_intra_mode, *cu_cbf;
+  int16_t *cu_mv, *cu_mvd;
+  uint8_t *bs_v, *bs_h;
+  /* intra analysis scratch: best mode and cost for each 8x8 / 16x16 / 32x32 block */
+  uint8_t *im8, *im16, *im32; uint32_t *ic8, *ic16, *ic32;
+  orc_bitw au;
+  orc_avail_ctx av;
+  int is_intra;
+  uint64_t bins;
+};
+
+void orc_enc_default_config(orc_enc_config *c)
+{
+  memset(c, 0, sizeof(*c));
+  c->qp = 32; c->intra_period = 64; c->vps_period = 1; c->search_range = 16;
+  c->fps_num = 30; c->fps_den = 1; c->wpp = 1; c->deblock = 1;
+}
+
+int orc_mvd_bits(int q)
+{
+  int a = q < 0 ? -q : q;
+  if (a == 0) return 1;
+  if (a == 1) return 3;
+  int x = a - 2, k = 1, len = 0;
+  while (x >= (1 << k)) { x -= 1 << k; k++; len++; }
+  return 2 + len + 1 + k + 1;
+}
+
+static int level_for(int w, int h)
+{
+  long px = (long)w * h;
+  if (px <= 2228224) return 123;      /* 4.1 */
+  if (px <= 8912896) return 153;      /* 5.1 */
+  return 183;                          /* 6.1 */
+}
+
+orc_encoder *orc_enc_open(const orc_enc_config *c)
+{
+  if (c->width < 16 || c->height < 16 || (c->width & 1) || (c->height & 1) || c->qp < 0 || c->qp > 51 ||
+      c->search_range < 0 || c->search_range > 32) return NULL;
+  orc_encoder *e = (orc_encoder *)calloc(1, sizeof(*e));
+  orc_tables_init();
+  e->cfg = *c;
+  e->cw = (c->width + 63) & ~63; e->ch = (c->height + 63) & ~63;
+  if (e->cw < 128) e->cw = 128;                 /* WPP context hand-over needs two CTUs per row */
+  e->b8w = e->cw / 8; e->b8h = e->ch / 8;
+  size_t nb8 = (size_t)e->b8w * e->b8h, npx = (size_t)e->cw * e->ch;
+  for (int i = 0; i < 2; i++) if (orc_pic_alloc(&e->pics[i], e->cw, e->ch)) return NULL;
+  e->cur = &e->pics[0]; e->ref = &e->pics[1];
+  for (int i = 0; i < 3; i++) {
+    size_t n = i ? npx / 4 : npx;
+    e->src[i] = (pixel *)malloc(n); e->coef[i] = (int16_t *)calloc(n, sizeof(int16_t)); e->predeblock[i] = (pixel *)malloc(n);
+  }
+  e->refpad_stride = e->cw + 2 * ME_PAD;
+  e->refpad = (pixel *)malloc((size_t)e->refpad_stride * (e->ch + 2 * ME_PAD));
+  e->cu_log2 = (uint8_t *)calloc(nb8, 1); e->cu_intra = (uint8_t *)calloc(nb8, 1); e->cu_flags = (uint8_t *)calloc(nb8, 1);
+  e->cu_merge_idx = (uint8_t *)calloc(nb8, 1); e->cu_mvp_idx = (uint8_t *)calloc(nb8, 1); e->cu_intra_mode = (uint8_t *)calloc(nb8, 1);
+  e->cu_cbf = (uint8_t *)calloc(nb8, 1); e->cu_mv = (int16_t *)calloc(nb8 * 2, sizeof(int16_t)); e->cu_mvd = (int16_t *)calloc(nb8 * 2, sizeof(int16_t));
+  e->bs_v = (uint8_t *)malloc((size_t)(e->cw / 8) * (e->ch / 4)); e->bs_h = (uint8_t *)malloc((size_t)(e->cw / 4) * (e->ch / 8));
+  e->im8 = (uint8_t *)malloc(nb8); e->ic8 = (uint32_t *)malloc(nb8 * 4);
+  e->im16 = (uint8_t *)malloc(nb8 / 4); e->ic16 = (uint32_t *)malloc(nb8);
+  e->im32 = (uint8_t *)malloc(nb8 / 16); e->ic32 = (uint32_t *)malloc(nb8 / 4);
+  orc_bw_init(&e->au);
+
+  orc_sps *s = &e->sps; memset(s, 0, sizeof(*s));
+  s->general_profile_idc = 1; s->general_level_idc = level_for(e->cw, e->ch);
+  s->chroma_format_idc = 1; s->width = e->cw; s->height = e->ch;
+  s->conf_win_flag = (e->cw != c->width || e->ch != c->height);
+  s->conf_right = (e->cw - c->width) / 2; s->conf_bottom = (e->ch - c->height) / 2;
+  s->bit_depth_luma = s->bit_depth_chroma = 8; s->log2_max_poc_lsb = 8;
+  s->max_dec_pic_buffering = 2; s->max_num_reorder = 0; s->max_latency_increase_plus1 = 0;
+  s->log2_min_cb = 3; s->log2_diff_max_min_cb = 3; s->log2_min_tb = 2; s->log2_diff_max_min_tb = 3;
+  s->max_th_depth_inter = 0; s->max_th_depth_intra = 0;
+  s->amp_enabled = 0; s->sao_enabled = 0;
+  s->num_st_rps = 1; s->st_rps[0].num_negative = 1; s->st_rps[0].delta_poc_s0[0] = -1; s->st_rps[0].used_s0[0] = 1;
+  s->temporal_mvp_enabled = 0; s->strong_intra_smoothing = 1;
+  s->vui_present = 1; s->vui_timing_present = 1; s->vui_num_units_in_tick = (uint32_t)c->fps_den; s->vui_time_scale = (uint32_t)c->fps_num;
+  orc_sps_derive(s);
+  orc_vps *v = &e->vps; memset(v, 0, sizeof(*v));
+  v->timing_info_present = 1; v->num_units_in_tick = (uint32_t)c->fps_den; v->time_scale = (uint32_t)c->fps_num;
+  orc_pps *p = &e->pps; memset(p, 0, sizeof(*p));
+  p->num_ref_idx_l0_default = 1; p->num_ref_idx_l1_default = 1; p->init_qp = c->qp;
+  p->entropy_coding_sync_enabled = c->wpp; p->loop_filter_across_slices = 1;
+  p->deblocking_filter_control_present = !c->deblock; p->pps_deblocking_disabled = !c->deblock;
+  p->log2_parallel_merge_level = 2; p->num_tile_columns = p->num_tile_rows = 1; p->uniform_spacing = 1;
+
+  memset(&e->av, 0, sizeof(e->av));
+  e->av.pic_w = e->cw; e->av.pic_h = e->ch; e->av.ctb_log2 = 6; e->av.pic_w_ctbs = e->cw / 64;
+  return e;
+}
+
+void orc_enc_close(orc_encoder *e)
+{
+  if (!e) return;
+  for (int i = 0; i < 2; i++) orc_pic_free(&e->pics[i]);
+  for (int i = 0; i < 3; i++) { free(e->src[i]); free(e->coef[i]); free(e->predeblock[i]); }
+  free(e->refpad);
+  free(e->cu_log2); free(e->cu_intra); free(e->cu_flags); free(e->cu_merge_idx); free(e->cu_mvp_idx);
+  free(e->cu_intra_mode); free(e->cu_cbf); free(e->cu_mv); free(e->cu_mvd); free(e->bs_v); free(e->bs_h);
+  free(e->im8); free(e->im16); free(e->im32); free(e->ic8); free(e->ic16); free(e->ic32);
+  orc_bw_free(&e->au);
+  free(e);
+}
+
+/* ------------------------------------------------------------------ input */
+static void load_input(orc_encoder *e, const pixel *y, const pixel *u, const pixel *v)
+{
+  const pixel *in[3] = { y, u, v };
+  for (int c = 0; c < 3; c++) {
+    int w = c ? e->cfg.width / 2 : e->cfg.width, h = c ? e->cfg.height / 2 : e->cfg.height;
+    int cw = c ? e->cw / 2 : e->cw, ch = c ? e->ch / 2 : e->ch;
+    for (int yy = 0; yy < ch; yy++) {
+      const pixel *srow = in[c] + (size_t)ORC_MIN(yy, h - 1) * w;
+      pixel *drow = e->src[c] + (size_t)yy * cw;
+      memcpy(drow, srow, (size_t)w);
+      for (int xx = w; xx < cw; xx++) drow[xx] = srow[w - 1];
+    }
+  }
+}
+
+static inline int b8i(const orc_encoder *e, int x, int y) { return (y >> 3) * e->b8w + (x >> 3); }
+static void set_cu(orc_encoder *e, uint8_t *arr, int x0, int y0, int n, int v)
+{
+  for (int y = y0; y < y0 + n; y += 8) for (int x = x0; x < x0 + n; x += 8) arr[b8i(e, x, y)] = (uint8_t)v;
+}
+static void fill_b4(orc_pic *p, uint8_t *arr, int x0, int y0, int n, int v)
+{
+  for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) arr[(y >> 2) * p->b4_w + (x >> 2)] = (uint8_t)v;
+}
+
+/* common side-info of a CU whose TU == CU */
+static void mark_cu(orc_encoder *e, int x0, int y0, int log2, int pred_mode)
+{
+  orc_pic *p = e->cur; int n = 1 << log2;
+  fill_b4(p, p->pred_mode, x0, y0, n, pred_mode);
+  fill_b4(p, p->ct_depth, x0, y0, n, 6 - log2);
+  for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) p->qp_y[(y >> 2) * p->b4_w + (x >> 2)] = (int8_t)e->cfg.qp;
+  for (int i = 0; i < n; i += 4) {
+    p->edge_v[((y0 + i) >> 2) * p->b4_w + (x0 >> 2)] |= 3;
+    p->edge_h[(y0 >> 2) * p->b4_w + ((x0 + i) >> 2)] |= 3;
+  }
+}
+
+/* residual -> levels (stored plane-shaped) -> reconstruction.  Returns cbf. */
+static int code_block(orc_encoder *e, int cidx, int x0, int y0, int n, int qp, int intra)
+{
+  orc_pic *p = e->cur;
+  int stride = p->stride[cidx];
+  pixel *rec = p->plane[cidx] + y0 * stride + x0;            /* holds the prediction on entry */
+  const pixel *src = e->src[cidx] + y0 * stride + x0;
+  int16_t res[32 * 32], cf[32 * 32], lv[32 * 32];
+  for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) res[y * n + x] = (int16_t)(src[y * stride + x] - rec[y * stride + x]);
+  orc_fwd_transform(res, cf, n, 0);
+  int nz = orc_quant(cf, lv, n, qp, intra);
+  int16_t *cp = e->coef[cidx] + y0 * stride + x0;
+  for (int y = 0; y < n; y++) memcpy(cp + y * stride, lv + y * n, sizeof(int16_t) * (size_t)n);
+  if (nz) {
+    orc_dequant(lv, cf, n, qp);
+    orc_inv_transform(cf, res, n, 0);
+    for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) rec[y * stride + x] = (pixel)orc_clip_pixel(rec[y * stride + x] + res[y * n + x]);
+  }
+  return nz != 0;
+}
+
+/* ------------------------------------------------------------------ intra pictures */
+static uint32_t sad_block(const pixel *a, int as, const pixel *b, int bs, int n)
+{
+  uint32_t s = 0;
+  for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) s += (uint32_t)orc_abs(a[y * as + x] - b[y * bs + x]);
+  return s;
+}
+
+/* Mode decision from SOURCE samples: for every aligned n x n block the mode with the least SAD
+ * between the source block and its prediction from source neighbours (ties: lowest mode). */
+static void intra_analyse_size(orc_encoder *e, int n, uint8_t *best_mode, uint32_t *best_cost)
+{
+  int bw = e->cw / n, bh = e->ch / n;
+  pixel left[129], top[129], pred[32 * 32];
+  for (int by = 0; by < bh; by++)
+    for (int bx = 0; bx < bw; bx++) {
+      int x0 = bx * n, y0 = by * n;
+      orc_intra_refs(&e->av, e->src[0], e->cw, 0, x0, y0, n, left, top);
+      uint32_t bc = 0xffffffffu; int bm = 0;
+      for (int m = 0; m < 35; m++) {
+        orc_intra_predict(left, top, n, 0, m, 1, pred, n);
+        uint32_t c = sad_block(e->src[0] + y0 * e->cw + x0, e->cw, pred, n, n);
+        if (c < bc) { bc = c; bm = m; }
+      }
+      best_mode[by * bw + bx] = (uint8_t)bm; best_cost[by * bw + bx] = bc;
+    }
+}
+
+static void intra_decide(orc_encoder *e)
+{
+  uint32_t pen = ((uint32_t)orc_lambda_q4[e->cfg.qp] * SPLIT_BITS) >> 4;
+  intra_analyse_size(e, 8, e->im8, e->ic8);
+  intra_analyse_size(e, 16, e->im16, e->ic16);
+  intra_analyse_size(e, 32, e->im32, e->ic32);
+  int w8 = e->cw / 8, w16 = e->cw / 16, w32 = e->cw / 32;
+  for (int y32 = 0; y32 < e->ch / 32; y32++)
+    for (int x32 = 0; x32 < w32; x32++) {
+      uint32_t c16sum = 0; int split16[4];
+      for (int k = 0; k < 4; k++) {
+        int x16 = x32 * 2 + (k & 1), y16 = y32 * 2 + (k >> 1);
+        uint32_t c8 = pen;
+        for (int j = 0; j < 4; j++) c8 += e->ic8[(y16 * 2 + (j >> 1)) * w8 + x16 * 2 + (j & 1)];
+        uint32_t c16 = e->ic16[y16 * w16 + x16];
+        split16[k] = c8 < c16;
+        c16sum += split16[k] ? c8 : c16;
+      }
+      int split32 = (c16sum + pen) < e->ic32[y32 * w32 + x32];
+      int x0 = x32 * 32, y0 = y32 * 32;
+      if (!split32) {
+        set_cu(e, e->cu_log2, x0, y0, 32, 5); set_cu(e, e->cu_intra_mode, x0, y0, 32, e->im32[y32 * w32 + x32]);
+      } else for (int k = 0; k < 4; k++) {
+        int x16 = x32 * 2 + (k & 1), y16 = y32 * 2 + (k >> 1);
+        if (!split16[k]) {
+          set_cu(e, e->cu_log2, x16 * 16, y16 * 16, 16, 4); set_cu(e, e->cu_intra_mode, x16 * 16, y16 * 16, 16, e->im16[y16 * w16 + x16]);
+        } else for (int j = 0; j < 4; j++) {
+          int x8 = x16 * 2 + (j & 1), y8 = y16 * 2 + (j >> 1);
+          e->cu_log2[y8 * w8 + x8] = 3; e->cu_intra_mode[y8 * w8 + x8] = e->im8[y8 * w8 + x8];
+        }
+      }
+    }
+}
+
+static void intra_recon_cu(orc_encoder *e, int x0, int y0, int log2)
+{
+  orc_pic *p = e->cur;
+  int n = 1 << log2, mode = e->cu_intra_mode[b8i(e, x0, y0)];
+  pixel left[129], top[129];
+  int qpc = orc_chroma_qp(e->cfg.qp, 0);
+  mark_cu(e, x0, y0, log2, MODE_INTRA);
+  fill_b4(p, p->intra_mode, x0, y0, n, mode);
+  orc_intra_refs(&e->av, p->plane[0], p->stride[0], 0, x0, y0, n, left, top);
+  orc_intra_predict(left, top, n, 0, mode, 1, p->plane[0] + y0 * p->stride[0] + x0, p->stride[0]);
+  int cbf = code_block(e, 0, x0, y0, n, e->cfg.qp, 1);
+  fill_b4(p, p->tu_nz, x0, y0, n, cbf);
+  for (int c = 1; c <= 2; c++) {
+    int cx = x0 / 2, cy = y0 / 2, cn = n / 2;
+    orc_intra_refs(&e->av, p->plane[c], p->stride[c], c, cx, cy, cn, left, top);
+    orc_intra_predict(left, top, cn, c, mode, 1, p->plane[c] + cy * p->stride[c] + cx, p->stride[c]);
+    cbf |= code_block(e, c, cx, cy, cn, qpc, 1) << c;
+  }
+  set_cu(e, e->cu_cbf, x0, y0, n, cbf);
+  set_cu(e, e->cu_intra, x0, y0, n, 1);
+  set_cu(e, e->cu_flags, x0, y0, n, 0);
+}
+
+static void intra_recon_tree(orc_encoder *e, int x0, int y0, int log2)
+{
+  int cl = e->cu_log2[b8i(e, x0, y0)];
+  if (cl >= log2) { intra_recon_cu(e, x0, y0, log2); return; }
+  int h = 1 << (log2 - 1);
+  intra_recon_tree(e, x0, y0, log2 - 1); intra_recon_tree(e, x0 + h, y0, log2 - 1);
+  intra_recon_tree(e, x0, y0 + h, log2 - 1); intra_recon_tree(e, x0 + h, y0 + h, log2 - 1);
+}
+
+static void encode_intra_picture(orc_encoder *e)
+{
+  intra_decide(e);
+  for (int cy = 0; cy < e->ch; cy += 64)
+    for (int cx = 0; cx < e->cw; cx += 64)
+      for (int k = 0; k < 4; k++) intra_recon_tree(e, cx + (k & 1) * 32, cy + (k >> 1) * 32, 5);
+}
+
+/* ------------------------------------------------------------------ inter pictures */
+static void build_refpad(orc_encoder *e)
+{
+  int st = e->refpad_stride;
+  for (int y = -ME_PAD; y < e->ch + ME_PAD; y++) {
+    const pixel *srow = e->ref->plane[0] + (size_t)orc_clip3(0, e->ch - 1, y) * e->ref->stride[0];
+    pixel *drow = e->refpad + (size_t)(y + ME_PAD) * st;
+    for (int x = -ME_PAD; x < e->cw + ME_PAD; x++) drow[x + ME_PAD] = srow[orc_clip3(0, e->cw - 1, x)];
+  }
+}
+
+static inline uint32_t sad16(const pixel *a, int as, const pixel *b, int bs)
+{
+  uint32_t s = 0;
+  for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) s += (uint32_t)orc_abs(a[y * as + x] - b[y * bs + x]);
+  return s;
+}
+
+/* Full search for one 32x32 block: candidates in raster order (dy outer, dx inner),
+ * cost = SAD + (lambda * bits(mv as mvd from zero)) >> 4, key = cost << 13 | candidate index. */
+static void me_block32(orc_encoder *e, int x0, int y0)
+{
+  int R = e->cfg.search_range, st = e->refpad_stride;
+  uint32_t lam = orc_lambda_q4[e->cfg.qp];
+  uint32_t best16[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu }, best32 = 0xffffffffu;
+  int idx = 0;
+  for (int dy = -R; dy <= R; dy++)
+    for (int dx = -R; dx <= R; dx++, idx++) {
+      uint32_t rate = (lam * (uint32_t)(orc_mvd_bits(dx * 4) + orc_mvd_bits(dy * 4))) >> 4;
+      uint32_t s32 = 0;
+      for (int k = 0; k < 4; k++) {
+        int bx = x0 + (k & 1) * 16, by = y0 + (k >> 1) * 16;
+        uint32_t s = sad16(e->src[0] + by * e->cw + bx, e->cw, e->refpad + (size_t)(by + dy + ME_PAD) * st + bx + dx + ME_PAD, st);
+        s32 += s;
+        uint32_t key = ((s + rate) << 13) | (uint32_t)idx;
+        if (key < best16[k]) best16[k] = key;
+      }
+      uint32_t key = ((s32 + rate) << 13) | (uint32_t)idx;
+      if (key < best32) best32 = key;
+    }
+  uint32_t pen = (lam * SPLIT_BITS) >> 4;
+  uint32_t csplit = pen;
+  for (int k = 0; k < 4; k++) csplit += best16[k] >> 13;
+  int W = 2 * R + 1;
+  if (csplit < (best32 >> 13)) {
+    for (int k = 0; k < 4; k++) {
+      int bx = x0 + (k & 1) * 16, by = y0 + (k >> 1) * 16, ci = (int)(best16[k] & 0x1fff);
+      set_cu(e, e->cu_log2, bx, by, 16, 4);
+      for (int y = by; y < by + 16; y += 8) for (int x = bx; x < bx + 16; x += 8) {
+        e->cu_mv[b8i(e, x, y) * 2] = (int16_t)(((ci % W) - R) * 4); e->cu_mv[b8i(e, x, y) * 2 + 1] = (int16_t)(((ci / W) - R) * 4);
+      }
+    }
+  } else {
+    int ci = (int)(best32 & 0x1fff);
+    set_cu(e, e->cu_log2, x0, y0, 32, 5);
+    for (int y = y0; y < y0 + 32; y += 8) for (int x = x0; x < x0 + 32; x += 8) {
+      e->cu_mv[b8i(e, x, y) * 2] = (int16_t)(((ci % W) - R) * 4); e->cu_mv[b8i(e, x, y) * 2 + 1] = (int16_t)(((ci / W) - R) * 4);
+    }
+  }
+}
+
+static void inter_recon_cu(orc_encoder *e, int x0, int y0, int log2)
+{
+  orc_pic *p = e->cur, *r = e->ref;
+  int n = 1 << log2;
+  int16_t mv[2] = { e->cu_mv[b8i(e, x0, y0) * 2], e->cu_mv[b8i(e, x0, y0) * 2 + 1] };
+  int16_t tmp[32 * 32];
+  int qpc = orc_chroma_qp(e->cfg.qp, 0);
+  mark_cu(e, x0, y0, log2, MODE_INTER);
+  for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) {
+    orc_mvinfo *m = &p->mvf[(y >> 2) * p->b4_w + (x >> 2)];
+    m->mv[0] = mv[0]; m->mv[1] = mv[1]; m->ref_idx = 0;
+  }
+  orc_mc_luma(r->plane[0], r->stride[0], r->w, r->h, x0, y0, n, n, mv[0], mv[1], tmp, 32);
+  orc_pred_uni(tmp, 32, p->plane[0] + y0 * p->stride[0] + x0, p->stride[0], n, n);
+  int cbf = code_block(e, 0, x0, y0, n, e->cfg.qp, 0);
+  fill_b4(p, p->tu_nz, x0, y0, n, cbf);
+  for (int c = 1; c <= 2; c++) {
+    int cx = x0 / 2, cy = y0 / 2, cn = n / 2;
+    orc_mc_chroma(r->plane[c], r->stride[c], r->w / 2, r->h / 2, cx, cy, cn, cn, mv[0], mv[1], tmp, 32);
+    orc_pred_uni(tmp, 32, p->plane[c] + cy * p->stride[c] + cx, p->stride[c], cn, cn);
+    cbf |= code_block(e, c, cx, cy, cn, qpc, 0) << c;
+  }
+  set_cu(e, e->cu_cbf, x0, y0, n, cbf);
+  set_cu(e, e->cu_intra, x0, y0, n, 0);
+}
+
+/* merge / skip / AMVP signalling decided from the FINAL motion field of the picture */
+static void inter_decide_signalling(orc_encoder *e, int x0, int y0, int log2)
+{
+  orc_pic *p = e->cur; int n = 1 << log2, bi = b8i(e, x0, y0);
+  orc_mvpred_ctx mc; memset(&mc, 0, sizeof(mc));
+  mc.pic = p; mc.av = e->av; mc.log2_par_mrg_level = 2; mc.max_num_merge_cand = 5; mc.num_ref_idx = 1;
+  mc.cur_poc = e->poc; mc.ref_poc[0] = e->poc - 1;
+  int16_t mvx = e->cu_mv[bi * 2], mvy = e->cu_mv[bi * 2 + 1];
+  orc_mvcand cand[5];
+  orc_merge_candidates(&mc, x0, y0, n, x0, y0, n, n, 0, PART_2Nx2N, cand);
+  int flags = 0, midx = 0, mvp = 0; int16_t mvdx = 0, mvdy = 0;
+  for (int k = 0; k < 5; k++) if (cand[k].ref_idx == 0 && cand[k].mv[0] == mvx && cand[k].mv[1] == mvy) { flags = 2; midx = k; break; }
+  if (flags && e->cu_cbf[bi] == 0) flags |= 1;
+  if (!flags) {
+    int16_t ac[2][2];
+    orc_amvp_candidates(&mc, x0, y0, n, x0, y0, n, n, 0, 0, ac);
+    int b0 = orc_mvd_bits(mvx - ac[0][0]) + orc_mvd_bits(mvy - ac[0][1]);
+    int b1 = orc_mvd_bits(mvx - ac[1][0]) + orc_mvd_bits(mvy - ac[1][1]);
+    mvp = b1 < b0;
+    mvdx = (int16_t)(mvx - ac[mvp][0]); mvdy = (int16_t)(mvy - ac[mvp][1]);
+  }
+  for (int y = y0; y < y0 + n; y += 8) for (int x = x0; x < x0 + n; x += 8) {
+    int i = b8i(e, x, y);
+    e->cu_flags[i] = (uint8_t)flags; e->cu_merge_idx[i] = (uint8_t)midx; e->cu_mvp_idx[i] = (uint8_t)mvp;
+    e->cu_mvd[i * 2] = mvdx; e->cu_mvd[i * 2 + 1] = mvdy;
+  }
+  if (flags & 1) fill_b4(p, p->pred_mode, x0, y0, n, MODE_SKIP);
+}
+
+static void encode_inter_picture(orc_encoder *e)
+{
+  build_refpad(e);
+  for (int y = 0; y < e->ch; y += 32) for (int x = 0; x < e->cw; x += 32) me_block32(e, x, y);
+  for (int y = 0; y < e->ch; y += 32) for (int x = 0; x < e->cw; x += 32) {
+    if (e->cu_log2[b8i(e, x, y)] == 5) inter_recon_cu(e, x, y, 5);
+    else for (int k = 0; k < 4; k++) inter_recon_cu(e, x + (k & 1) * 16, y + (k >> 1) * 16, 4);
+  }
+  for (int y = 0; y < e->ch; y += 32) for (int x = 0; x < e->cw; x += 32) {
+    if (e->cu_log2[b8i(e, x, y)] == 5) inter_decide_signalling(e, x, y, 5);
+    else for (int k = 0; k < 4; k++) inter_decide_signalling(e, x + (k & 1) * 16, y + (k >> 1) * 16, 4);
+  }
+}
+
+/* ------------------------------------------------------------------ entropy coding */
+static void enc_last_prefix(orc_cabac_enc *c, int base, int log2, int cidx, int prefix)
+{
+  int off, sh, max = (log2 << 1) - 1;
+  if (cidx == 0) { off = 3 * (log2 - 2) + ((log2 - 1) >> 2); sh = (log2 + 1) >> 2; }
+  else { off = 15; sh = log2 - 2; }
+  for (int i = 0; i < prefix; i++) orc_cenc_bin(c, base + off + (i >> sh), 1);
+  if (prefix < max) orc_cenc_bin(c, base + off + (prefix >> sh), 0);
+}
+static void last_bin(int v, int *prefix, int *nb, int *suffix)
+{
+  if (v < 4) { *prefix = v; *nb = 0; *suffix = 0; return; }
+  int len = orc_log2((unsigned)v);
+  *prefix = 2 * len + ((v >> (len - 1)) & 1); *nb = len - 1; *suffix = v & ((1 << (len - 1)) - 1);
+}
+static void enc_abs_remaining(orc_cabac_enc *c, int v, int rice)
+{
+  if ((v >> rice) < 4) {
+    int q = v >> rice;
+    for (int i = 0; i < q; i++) orc_cenc_bypass(c, 1);
+    orc_cenc_bypass(c, 0);
+    orc_cenc_bypass_bits(c, (uint32_t)(v & ((1 << rice) - 1)), rice);
+  } else {
+    int x = v - (4 << rice), k = rice + 1;
+    for (int i = 0; i < 4; i++) orc_cenc_bypass(c, 1);
+    while (x >= (1 << k)) { orc_cenc_bypass(c, 1); x -= 1 << k; k++; }
+    orc_cenc_bypass(c, 0);
+    orc_cenc_bypass_bits(c, (uint32_t)x, k);
+  }
+}
+
+static const uint8_t ctx_idx_map_4x4[16] = { 0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8 };
+
+/* 7.3.8.11 residual_coding for a block with at least one non-zero level; lv is plane-shaped */
+static void enc_residual(orc_cabac_enc *c, const int16_t *lv, int stride, int log2, int cidx, int scan_idx)
+{
+  int sb_log2 = log2 - 2, nsb = 1 << sb_log2;
+  const uint8_t *sbx = orc_scan_x[scan_idx][sb_log2], *sby = orc_scan_y[scan_idx][sb_log2];
+  const uint8_t *px = orc_scan_x[scan_idx][2], *py = orc_scan_y[scan_idx][2];
+  uint8_t csbf[8][8]; memset(csbf, 0, sizeof(csbf));
+  int last_sb = -1, last_pos = -1;
+  for (int i = (1 << (2 * sb_log2)) - 1; i >= 0 && last_sb < 0; i--)
+    for (int k = 15; k >= 0; k--)
+      if (lv[((sby[i] << 2) + py[k]) * stride + (sbx[i] << 2) + px[k]]) { last_sb = i; last_pos = k; break; }
+  for (int i = 0; i <= last_sb; i++) {
+    int any = 0;
+    for (int k = 0; k < 16 && !any; k++) any = lv[((sby[i] << 2) + py[k]) * stride + (sbx[i] << 2) + px[k]] != 0;
+    csbf[sby[i]][sbx[i]] = (uint8_t)any;
+  }
+  int lx = (sbx[last_sb] << 2) + px[last_pos], ly = (sby[last_sb] << 2) + py[last_pos];
+  if (scan_idx == 2) { int t = lx; lx = ly; ly = t; }
+  int pxv, nbx, sfx, pyv, nby, sfy;
+  last_bin(lx, &pxv, &nbx, &sfx); last_bin(ly, &pyv, &nby, &sfy);
+  enc_last_prefix(c, CTX_LAST_X, log2, cidx, pxv);
+  enc_last_prefix(c, CTX_LAST_Y, log2, cidx, pyv);
+  if (pxv > 3) orc_cenc_bypass_bits(c, (uint32_t)sfx, nbx);
+  if (pyv > 3) orc_cenc_bypass_bits(c, (uint32_t)sfy, nby);
+  int c1 = 1;
+  for (int i = last_sb; i >= 0; i--) {
+    int xs = sbx[i], ys = sby[i], infer_dc = 0;
+    int right = (xs < nsb - 1) ? csbf[ys][xs + 1] : 0, below = (ys < nsb - 1) ? csbf[ys + 1][xs] : 0;
+    if (i < last_sb && i > 0) {
+      orc_cenc_bin(c, CTX_CSBF + ((right | below) ? 1 : 0) + (cidx ? 2 : 0), csbf[ys][xs]);
+      infer_dc = 1;
+    } else csbf[ys][xs] = 1;      /* inferred for the last and the DC sub-block (affects neighbour contexts) */
+    if (!csbf[ys][xs]) continue;
+    int16_t v[16]; int nsig = 0;
+    for (int k = 0; k < 16; k++) { v[k] = lv[((ys << 2) + py[k]) * stride + (xs << 2) + px[k]]; nsig += v[k] != 0; }
+    int start = (i == last_sb) ? last_pos - 1 : 15;
+    int prev_csbf = right | (below << 1);
+    for (int k = start; k >= 0; k--) {
+      int xp = px[k], yp = py[k], xc = (xs << 2) + xp, yc = (ys << 2) + yp;
+      if (k > 0 || !infer_dc) {
+        int sc;
+        if (log2 == 2) sc = ctx_idx_map_4x4[(yc << 2) + xc];
+        else if (xc + yc == 0) sc = 0;
+        else {
+          if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
+          else if (prev_csbf == 1) sc = (yp == 0) ? 2 : (yp == 1) ? 1 : 0;
+          else if (prev_csbf == 2) sc = (xp == 0) ? 2 : (xp == 1) ? 1 : 0;
+          else sc = 2;
+          if (cidx == 0) { if (i > 0) sc += 3; sc += (log2 == 3) ? ((scan_idx == 0) ? 9 : 15) : 21; }
+          else sc += (log2 == 3) ? 9 : 12;
+        }
+        orc_cenc_bin(c, CTX_SIG + (cidx ? 27 : 0) + sc, v[k] != 0);
+        if (v[k]) infer_dc = 0;
+      }
+    }
+    if (!nsig) continue;
+    int ctx_set = (i > 0 && cidx == 0) ? 2 : 0;
+    if (c1 == 0) ctx_set++;
+    c1 = 1;
+    int ng1 = 0, last_g1_pos = -1;
+    for (int k = 15; k >= 0; k--) if (v[k]) {
+      if (ng1 < 8) {
+        int g1 = orc_abs(v[k]) > 1;
+        orc_cenc_bin(c, CTX_GT1 + (cidx ? 16 : 0) + ctx_set * 4 + c1, g1);
+        ng1++;
+        if (g1) { c1 = 0; if (last_g1_pos == -1) last_g1_pos = k; }
+        else if (c1 > 0 && c1 < 3) c1++;
+      }
+    }
+    if (last_g1_pos != -1) orc_cenc_bin(c, CTX_GT2 + (cidx ? 4 : 0) + ctx_set, orc_abs(v[last_g1_pos]) > 2);
+    for (int k = 15; k >= 0; k--) if (v[k]) orc_cenc_bypass(c, v[k] < 0);      /* sign_data_hiding off */
+    int num_sig = 0, rice = 0;
+    for (int k = 15; k >= 0; k--) if (v[k]) {
+      int a = orc_abs(v[k]);
+      int base = (num_sig < 8) ? ((k == last_g1_pos) ? 3 : 2) : 1;
+      if (a >= base) {
+        enc_abs_remaining(c, a - base, rice);
+        if (a > 3 * (1 << rice)) rice = ORC_MIN(rice + 1, 4);
+      }
+      num_sig++;
+    }
+  }
+}
+
+static int scan_idx_for(int intra, int log2, int cidx, int mode)
+{
+  if (!intra) return 0;
+  if (log2 == 2 || (log2 == 3 && cidx == 0)) {
+    if (mode >= 6 && mode <= 14) return 2;
+    if (mode >= 22 && mode <= 30) return 1;
+  }
+  return 0;
+}
+
+static void enc_mvd(orc_cabac_enc *c, int dx, int dy)
+{
+  int ax = orc_abs(dx), ay = orc_abs(dy);
+  orc_cenc_bin(c, CTX_MVD_GT0, ax > 0); orc_cenc_bin(c, CTX_MVD_GT0, ay > 0);
+  if (ax > 0) orc_cenc_bin(c, CTX_MVD_GT1, ax > 1);
+  if (ay > 0) orc_cenc_bin(c, CTX_MVD_GT1, ay > 1);
+  for (int k = 0; k < 2; k++) {
+    int a = k ? ay : ax, s = (k ? dy : dx) < 0;
+    if (a == 0) continue;
+    if (a > 1) {   /* abs_mvd_minus2, EG1 */
+      int x = a - 2, kk = 1;
+      while (x >= (1 << kk)) { orc_cenc_bypass(c, 1); x -= 1 << kk; kk++; }
+      orc_cenc_bypass(c, 0);
+      orc_cenc_bypass_bits(c, (uint32_t)x, kk);
+    }
+    orc_cenc_bypass(c, s);
+  }
+}
+
+static void enc_cu(orc_encoder *e, orc_cabac_enc *c, int x0, int y0, int log2)
+{
+  orc_pic *p = e->cur;
+  int bi = b8i(e, x0, y0), n = 1 << log2;
+  int intra = e->cu_intra[bi], flags = e->cu_flags[bi], cbf = e->cu_cbf[bi];
+  if (!e->is_intra) {
+    int l = orc_available(&e->av, x0, y0, x0 - 1, y0) && p->pred_mode[(y0 >> 2) * p->b4_w + ((x0 - 1) >> 2)] == MODE_SKIP;
+    int a = orc_available(&e->av, x0, y0, x0, y0 - 1) && p->pred_mode[((y0 - 1) >> 2) * p->b4_w + (x0 >> 2)] == MODE_SKIP;
+    orc_cenc_bin(c, CTX_SKIP + l + a, flags & 1);
+    if (flags & 1) {
+      int idx = e->cu_merge_idx[bi];
+      orc_cenc_bin(c, CTX_MERGE_IDX, idx > 0);
+      if (idx > 0) for (int i = 1; i < 4; i++) { orc_cenc_bypass(c, idx > i); if (idx <= i) break; }
+      return;
+    }
+    orc_cenc_bin(c, CTX_PRED_MODE, intra);
+  }
+  if (!intra || log2 == 3) orc_cenc_bin(c, CTX_PART_MODE, 1);      /* PART_2Nx2N */
+  int mode = 0;
+  if (intra) {
+    mode = e->cu_intra_mode[bi];
+    int ca = 1, cb = 1;
+    if (orc_available(&e->av, x0, y0, x0 - 1, y0) && p->pred_mode[(y0 >> 2) * p->b4_w + ((x0 - 1) >> 2)] == MODE_INTRA)
+      ca = p->intra_mode[(y0 >> 2) * p->b4_w + ((x0 - 1) >> 2)];
+    if (orc_available(&e->av, x0, y0, x0, y0 - 1) && p->pred_mode[((y0 - 1) >> 2) * p->b4_w + (x0 >> 2)] == MODE_INTRA && (y0 - 1) >= ((y0 >> 6) << 6))
+      cb = p->intra_mode[((y0 - 1) >> 2) * p->b4_w + (x0 >> 2)];
+    int cand[3];
+    if (ca == cb) {
+      if (ca < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
+      else { cand[0] = ca; cand[1] = 2 + ((ca + 29) % 32); cand[2] = 2 + ((ca - 2 + 1) % 32); }
+    } else {
+      cand[0] = ca; cand[1] = cb;
+      if (ca != 0 && cb != 0) cand[2] = 0; else if (ca != 1 && cb != 1) cand[2] = 1; else cand[2] = 26;
+    }
+    int mpm = -1;
+    for (int k = 0; k < 3; k++) if (cand[k] == mode) { mpm = k; break; }
+    orc_cenc_bin(c, CTX_PREV_INTRA, mpm >= 0);
+    if (mpm >= 0) { orc_cenc_bypass(c, mpm > 0); if (mpm > 0) orc_cenc_bypass(c, mpm > 1); }
+    else {
+      if (cand[0] > cand[1]) { int t = cand[0]; cand[0] = cand[1]; cand[1] = t; }
+      if (cand[0] > cand[2]) { int t = cand[0]; cand[0] = cand[2]; cand[2] = t; }
+      if (cand[1] > cand[2]) { int t = cand[1]; cand[1] = cand[2]; cand[2] = t; }
+      int rem = mode;
+      for (int k = 2; k >= 0; k--) if (rem > cand[k]) rem--;
+      orc_cenc_bypass_bits(c, (uint32_t)rem, 5);
+    }
+    orc_cenc_bin(c, CTX_CHROMA_MODE, 0);                             /* intra_chroma_pred_mode = 4 (DM) */
+  } else {
+    orc_cenc_bin(c, CTX_MERGE_FLAG, (flags >> 1) & 1);
+    if (flags & 2) {
+      int idx = e->cu_merge_idx[bi];
+      orc_cenc_bin(c, CTX_MERGE_IDX, idx > 0);
+      if (idx > 0) for (int i = 1; i < 4; i++) { orc_cenc_bypass(c, idx > i); if (idx <= i) break; }
+    } else {
+      enc_mvd(c, e->cu_mvd[bi * 2], e->cu_mvd[bi * 2 + 1]);
+      orc_cenc_bin(c, CTX_MVP_FLAG, e->cu_mvp_idx[bi]);
+      orc_cenc_bin(c, CTX_RQT_ROOT_CBF, cbf != 0);
+    }
+    if (!cbf) return;
+  }
+  /* transform_tree at depth 0, no split: cbf_cb, cbf_cr, [cbf_luma], residuals */
+  orc_cenc_bin(c, CTX_CBF_CHROMA + 0, (cbf >> 1) & 1);
+  orc_cenc_bin(c, CTX_CBF_CHROMA + 0, (cbf >> 2) & 1);
+  if (intra || (cbf & 6)) orc_cenc_bin(c, CTX_CBF_LUMA + 1, cbf & 1);
+  if (cbf & 1) enc_residual(c, e->coef[0] + y0 * e->cw + x0, e->cw, log2, 0, scan_idx_for(intra, log2, 0, mode));
+  for (int ci = 1; ci <= 2; ci++)
+    if ((cbf >> ci) & 1)
+      enc_residual(c, e->coef[ci] + (y0 / 2) * (e->cw / 2) + x0 / 2, e->cw / 2, log2 - 1, ci, scan_idx_for(intra, log2 - 1, ci, mode));
+  (void)n;
+}
+
+static void enc_quadtree(orc_encoder *e, orc_cabac_enc *c, int x0, int y0, int log2, int depth)
+{
+  orc_pic *p = e->cur;
+  int cl = e->cu_log2[b8i(e, x0, y0)];
+  int split = cl < log2;
+  if (log2 > 3) {
+    int l = orc_available(&e->av, x0, y0, x0 - 1, y0) && p->ct_depth[(y0 >> 2) * p->b4_w + ((x0 - 1) >> 2)] > depth;
+    int a = orc_available(&e->av, x0, y0, x0, y0 - 1) && p->ct_depth[((y0 - 1) >> 2) * p->b4_w + (x0 >> 2)] > depth;
+    orc_cenc_bin(c, CTX_SPLIT_CU + l + a, split);
+  }
+  if (split) {
+    int h = 1 << (log2 - 1);
+    enc_quadtree(e, c, x0, y0, log2 - 1, depth + 1); enc_quadtree(e, c, x0 + h, y0, log2 - 1, depth + 1);
+    enc_quadtree(e, c, x0, y0 + h, log2 - 1, depth + 1); enc_quadtree(e, c, x0 + h, y0 + h, log2 - 1, depth + 1);
+  } else enc_cu(e, c, x0, y0, log2);
+}
+
+static void write_picture(orc_encoder *e, int write_ps)
+{
+  orc_bitw ps, hdr, *rows;
+  int wc = e->cw / 64, hc = e->ch / 64;
+  int nal = e->is_intra ? NAL_IDR_W_RADL : NAL_TRAIL_R;
+  e->au.len = 0; e->au.nbits = 0; e->au.cur = 0;
+  if (write_ps) {
+    orc_bw_init(&ps); orc_write_vps(&ps, &e->vps, &e->sps); orc_write_nal(&e->au, NAL_VPS, 0, ps.buf, ps.len, 1); orc_bw_free(&ps);
+    orc_bw_init(&ps); orc_write_sps(&ps, &e->sps); orc_write_nal(&e->au, NAL_SPS, 0, ps.buf, ps.len, 1); orc_bw_free(&ps);
+    orc_bw_init(&ps); orc_write_pps(&ps, &e->pps); orc_write_nal(&e->au, NAL_PPS, 0, ps.buf, ps.len, 1); orc_bw_free(&ps);
+  }
+  /* slice data: one substream per CTU row with WPP, otherwise a single one */
+  int nsub = e->cfg.wpp ? hc : 1;
+  rows = (orc_bitw *)calloc((size_t)nsub, sizeof(orc_bitw));
+  orc_cabac_enc c; memset(&c, 0, sizeof(c));
+  orc_ctx saved[CTX_COUNT];
+  int init_type = e->is_intra ? 0 : 1;
+  for (int cy = 0; cy < hc; cy++) {
+    if (cy == 0 || e->cfg.wpp) {
+      int sub = e->cfg.wpp ? cy : 0;
+      orc_bw_init(&rows[sub]);
+      orc_cenc_start(&c, &rows[sub]);
+      if (cy == 0) orc_cabac_init_contexts(c.ctx, init_type, e->cfg.qp);
+      else memcpy(c.ctx, saved, sizeof(saved));       /* WPP: state after the 2nd CTU of the row above */
+    }
+    for (int cx = 0; cx < wc; cx++) {
+      enc_quadtree(e, &c, cx * 64, cy * 64, 6, 0);
+      if (e->cfg.wpp && cx == 1) memcpy(saved, c.ctx, sizeof(saved));
+      int last = (cy == hc - 1 && cx == wc - 1);
+      orc_cenc_terminate(&c, last);                   /* end_of_slice_segment_flag */
+      if (!last && e->cfg.wpp && cx == wc - 1) orc_cenc_terminate(&c, 1);   /* end_of_subset_one_bit */
+      if (last || (e->cfg.wpp && cx == wc - 1)) orc_bw_align_zero(c.bw);
+    }
+  }
+  e->bins = c.bins;
+  orc_slice_hdr sh; memset(&sh, 0, sizeof(sh));
+  sh.first_slice_segment_in_pic = 1; sh.slice_type = e->is_intra ? SLICE_I : SLICE_P; sh.pic_output_flag = 1;
+  sh.poc_lsb = e->poc & 255; sh.short_term_ref_pic_set_sps_flag = 1;
+  sh.num_ref_idx_l0 = 1; sh.num_ref_idx_l1 = 1; sh.max_num_merge_cand = 5; sh.collocated_from_l0 = 1;
+  sh.slice_deblocking_disabled = !e->cfg.deblock;
+  sh.loop_filter_across_slices = 1;
+  uint32_t *ep = (uint32_t *)calloc((size_t)nsub, sizeof(uint32_t));
+  sh.num_entry_points = nsub - 1; sh.entry_point_offset = ep;
+  for (int i = 0; i < nsub - 1; i++) ep[i] = (uint32_t)orc_escaped_size(rows[i].buf, rows[i].len);
+  orc_bw_init(&hdr);
+  orc_write_slice_header(&hdr, &sh, &e->sps, &e->pps, nal);
+  for (int i = 0; i < nsub; i++) { orc_bw_bytes(&hdr, rows[i].buf, rows[i].len); orc_bw_free(&rows[i]); }
+  orc_write_nal(&e->au, nal, 0, hdr.buf, hdr.len, 1);
+  orc_bw_free(&hdr); free(rows); free(ep);
+}
+
+/* ------------------------------------------------------------------ top level */
+size_t orc_enc_encode(orc_encoder *e, const pixel *y, const pixel *u, const pixel *v, const uint8_t **au)
+{
+  int period = e->cfg.intra_period;
+  e->is_intra = (e->frame_idx == 0) || (period > 0 && (e->frame_idx % period) == 0);
+  if (e->is_intra) e->poc = 0; else e->poc++;
+  load_input(e, y, u, v);
+  orc_pic_reset_side(e->cur);
+  for (int c = 0; c < 3; c++) memset(e->coef[c], 0, sizeof(int16_t) * (size_t)(c ? e->cw * e->ch / 4 : e->cw * e->ch));
+  if (e->is_intra) encode_intra_picture(e); else encode_inter_picture(e);
+  for (int c = 0; c < 3; c++) memcpy(e->predeblock[c], e->cur->plane[c], (size_t)(c ? e->cw * e->ch / 4 : e->cw * e->ch));
+  orc_compute_bs(e->cur, e->bs_v, e->bs_h);
+  if (e->cfg.deblock) {
+    orc_deblock_ctx db; memset(&db, 0, sizeof(db));
+    db.w = e->cw; db.h = e->ch;
+    for (int i = 0; i < 3; i++) { db.plane[i] = e->cur->plane[i]; db.stride[i] = e->cur->stride[i]; }
+    db.bs_v = e->bs_v; db.bs_stride_v = e->cw / 8; db.bs_h = e->bs_h; db.bs_stride_h = e->cw / 4;
+    db.qp_y = e->cur->qp_y; db.qp_stride = e->cur->b4_w;
+    orc_deblock_picture(&db);
+  }
+  int write_ps = 0;
+  if (e->is_intra) {
+    write_ps = (e->intra_count == 0) || (e->cfg.vps_period > 0 && (e->intra_count % e->cfg.vps_period) == 0);
+    e->intra_count++;
+  }
+  write_picture(e, write_ps);
+  e->frame_idx++;
+  orc_pic *t = e->cur; e->cur = e->ref; e->ref = t;     /* e->ref now holds the picture just coded */
+  *au = e->au.buf;
+  return e->au.len;
+}
+
+void orc_enc_get_debug(orc_encoder *e, orc_enc_debug *d)
+{
+  memset(d, 0, sizeof(*d));
+  d->coded_w = e->cw; d->coded_h = e->ch; d->is_intra = e->is_intra; d->poc = e->poc;
+  d->cu_log2 = e->cu_log2; d->cu_intra = e->cu_intra; d->cu_flags = e->cu_flags; d->cu_merge_idx = e->cu_merge_idx;
+  d->cu_mvp_idx = e->cu_mvp_idx; d->cu_intra_mode = e->cu_intra_mode; d->cu_cbf = e->cu_cbf; d->cu_mv = e->cu_mv;
+  for (int i = 0; i < 3; i++) { d->coef[i] = e->coef[i]; d->predeblock[i] = e->predeblock[i]; d->recon[i] = e->ref->plane[i]; }
+  d->bs_v = e->bs_v; d->bs_h = e->bs_h; d->bins = e->bins;
+}
+
+void orc_enc_get_recon(orc_encoder *e, pixel *y, pixel *u, pixel *v)
+{
+  pixel *out[3] = { y, u, v };
+  for (int c = 0; c < 3; c++) {
+    int w = c ? e->cfg.width / 2 : e->cfg.width, h = c ? e->cfg.height / 2 : e->cfg.height;
+    for (int yy = 0; yy < h; yy++) memcpy(out[c] + (size_t)yy * w, e->ref->plane[c] + (size_t)yy * e->ref->stride[c], (size_t)w);
+  }
+}

@@ -1,0 +1,66 @@
+/* oracle/hevc_enc.h -- the encoder the HIP path must match bit for bit ("uvgx encoder algorithm
+ * v1").  It is the CPU checker for what uvgComm's KvazaarFilter gets from
+ * kvz_api->encoder_encode (/root/reference/src/media/processing/kvazaarfilter.cpp:435-448):
+ * one access unit of Annex-B NAL units per input picture plus the reconstructed picture.
+ *
+ * Kvazaar's own search heuristics are not available (source absent), so the
+ * decisions below are this project's, chosen to be data-parallel; everything normative
+ * (prediction, transforms, deblocking, CABAC, syntax) follows H.265.  PARITY UNPINNED vs Kvazaar.
+ *
+ * Tool set (mirrors Kvazaar preset=ultrafast as far as SURVEY.md Appendix A records it):
+ *   CTU 64, CUs 32/16 (inter, 2Nx2N) and 32/16/8 (intra, 2Nx2N), TU = CU (chroma half),
+ *   integer-sample full-search motion estimation over +-range, 1 reference (previous picture),
+ *   merge/skip with 5 candidates, AMVP, no TMVP, plain dead-zone quantiser, deblocking on,
+ *   SAO off, sign hiding off, transform skip off, WPP on, one slice per picture,
+ *   IDR every `period` pictures with VPS/SPS/PPS, constant QP.
+ * Test infrastructure. */
+#ifndef ORC_HEVC_ENC_H
+#define ORC_HEVC_ENC_H
+#include "hevc_common.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct orc_encoder orc_encoder;
+
+typedef struct {
+  int width, height;          /* input luma size (multiple of 2) */
+  int qp;                     /* 0..51 */
+  int intra_period;           /* 0: only the first picture is intra; 1: all intra; n: every n-th */
+  int vps_period;             /* 0: parameter sets only with the first picture; n: with every n-th intra */
+  int search_range;           /* integer samples, <= 32 */
+  int fps_num, fps_den;
+  int wpp;                    /* entropy_coding_sync_enabled_flag */
+  int deblock;                /* 1 = enabled */
+} orc_enc_config;
+
+typedef struct {
+  /* geometry of the coded (padded) picture */
+  int coded_w, coded_h;
+  int is_intra, poc;
+  /* per 8x8 block arrays, stride coded_w/8 */
+  const uint8_t *cu_log2, *cu_intra, *cu_flags /* bit0 skip, bit1 merge */, *cu_merge_idx, *cu_mvp_idx,
+                *cu_intra_mode, *cu_cbf /* bit0 Y, bit1 Cb, bit2 Cr */;
+  const int16_t *cu_mv;       /* [b8][2], quarter samples */
+  const int16_t *coef[3];     /* quantised levels, plane shaped */
+  const pixel *predeblock[3]; /* reconstruction before deblocking */
+  const pixel *recon[3];      /* final reconstruction (coded size) */
+  const uint8_t *bs_v, *bs_h;
+  uint64_t bins;              /* CABAC bins in this picture */
+} orc_enc_debug;
+
+void orc_enc_default_config(orc_enc_config *c);
+orc_encoder *orc_enc_open(const orc_enc_config *c);
+void orc_enc_close(orc_encoder *e);
+/* Encodes one picture given as three packed planes (stride = width, width/2).  The returned
+ * buffer is owned by the encoder and valid until the next call.  Returns AU size in bytes. */
+size_t orc_enc_encode(orc_encoder *e, const pixel *y, const pixel *u, const pixel *v, const uint8_t **au);
+void orc_enc_get_debug(orc_encoder *e, orc_enc_debug *dbg);
+/* copy cropped reconstruction (width x height I420, packed) */
+void orc_enc_get_recon(orc_encoder *e, pixel *y, pixel *u, pixel *v);
+
+extern const uint16_t orc_lambda_q4[52];   /* 16 * sqrt(0.57 * 2^((qp-12)/3)), rounded */
+int orc_mvd_bits(int q);                   /* bins to code one mvd component (quarter samples) */
+#ifdef __cplusplus
+}
+#endif
+#endif

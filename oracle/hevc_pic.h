@@ -1,0 +1,44 @@
+/* oracle/hevc_pic.h -- picture + per-4x4 side information shared by the oracle's encoder and
+ * decoder (reconstruction, merge/AMVP derivation, boundary strength).  Test infrastructure. */
+#ifndef ORC_HEVC_PIC_H
+#define ORC_HEVC_PIC_H
+#include "hevc_common.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  int16_t mv[2];        /* L0 motion vector, quarter luma samples */
+  int8_t  ref_idx;      /* L0 reference index, -1 = not inter predicted */
+  int8_t  pad;
+} orc_mvinfo;
+
+typedef struct {
+  int w, h;                          /* coded luma size */
+  pixel *plane[3]; int stride[3];
+  int poc;
+  int is_ref, needed_for_output, in_use;
+  int64_t pts;
+  /* per 4x4 luma block side info, stride b4_stride */
+  int b4_w, b4_h;
+  uint8_t *pred_mode;                /* MODE_INTRA / MODE_INTER / MODE_SKIP; 255 = not yet decoded */
+  uint8_t *ct_depth;                 /* coding quadtree depth */
+  uint8_t *intra_mode;               /* IntraPredModeY */
+  int8_t  *qp_y;
+  uint8_t *tu_nz;                    /* luma TB of this 4x4 has non-zero coefficients */
+  uint8_t *edge_v, *edge_h;          /* bit0: transform edge at left/top of this 4x4, bit1: prediction edge */
+  uint8_t *no_filter;                /* cu_transquant_bypass / pcm with loop filter disabled */
+  orc_mvinfo *mvf;
+} orc_pic;
+
+int  orc_pic_alloc(orc_pic *p, int w, int h);
+void orc_pic_free(orc_pic *p);
+void orc_pic_reset_side(orc_pic *p);
+
+/* H.265 8.7.2.4: boundary strengths from the side info. bs_v: [(h/4) x (w/8)], bs_h: [(h/8) x (w/4)].
+ * Picture edges get 0.  (Single slice, single tile, or filtering across them enabled.) */
+void orc_compute_bs(const orc_pic *p, uint8_t *bs_v, uint8_t *bs_h);
+#ifdef __cplusplus
+}
+#endif
+#endif

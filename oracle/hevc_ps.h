@@ -1,0 +1,105 @@
+/* oracle/hevc_ps.h -- parameter sets and slice segment header: structs, writer, parser.
+ * H.265 7.3.2.1 (VPS), 7.3.2.2 (SPS), 7.3.2.3 (PPS), 7.3.3 (profile_tier_level),
+ * 7.3.6.1 (slice_segment_header), 7.3.7 (st_ref_pic_set), E.2.1 (VUI timing subset).
+ * Test infrastructure. */
+#ifndef ORC_HEVC_PS_H
+#define ORC_HEVC_PS_H
+#include "hevc_common.h"
+#include "hevc_bits.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  int num_negative, num_positive;
+  int delta_poc_s0[16], used_s0[16];    /* negative pics: delta (negative numbers) */
+  int delta_poc_s1[16], used_s1[16];
+} orc_st_rps;
+
+typedef struct {
+  int valid;
+  int vps_id, max_sub_layers, temporal_id_nesting;
+  int timing_info_present; uint32_t num_units_in_tick, time_scale;
+} orc_vps;
+
+typedef struct {
+  int valid;
+  int sps_id, vps_id, max_sub_layers;
+  int general_profile_idc, general_level_idc;
+  int chroma_format_idc;
+  int width, height;                       /* pic_width/height_in_luma_samples */
+  int conf_win_flag, conf_left, conf_right, conf_top, conf_bottom;   /* in chroma units (x2 luma for 4:2:0) */
+  int bit_depth_luma, bit_depth_chroma;
+  int log2_max_poc_lsb;
+  int max_dec_pic_buffering, max_num_reorder, max_latency_increase_plus1;
+  int log2_min_cb, log2_diff_max_min_cb, log2_min_tb, log2_diff_max_min_tb;
+  int max_th_depth_inter, max_th_depth_intra;
+  int scaling_list_enabled, amp_enabled, sao_enabled, pcm_enabled;
+  int pcm_bit_depth_luma, pcm_bit_depth_chroma, log2_min_pcm_cb, log2_diff_max_min_pcm_cb, pcm_loop_filter_disabled;
+  int num_st_rps; orc_st_rps st_rps[65];
+  int long_term_ref_pics_present;
+  int temporal_mvp_enabled, strong_intra_smoothing;
+  int vui_present, vui_timing_present; uint32_t vui_num_units_in_tick, vui_time_scale;
+  /* derived */
+  int ctb_log2, ctb_size, pic_w_ctbs, pic_h_ctbs, log2_max_tb;
+} orc_sps;
+
+typedef struct {
+  int valid;
+  int pps_id, sps_id;
+  int dependent_slice_segments_enabled, output_flag_present, num_extra_slice_header_bits;
+  int sign_data_hiding, cabac_init_present;
+  int num_ref_idx_l0_default, num_ref_idx_l1_default;
+  int init_qp;                              /* 26 + init_qp_minus26 */
+  int constrained_intra_pred, transform_skip_enabled;
+  int cu_qp_delta_enabled, diff_cu_qp_delta_depth;
+  int cb_qp_offset, cr_qp_offset, slice_chroma_qp_offsets_present;
+  int weighted_pred, weighted_bipred, transquant_bypass_enabled;
+  int tiles_enabled, entropy_coding_sync_enabled;
+  int num_tile_columns, num_tile_rows, uniform_spacing;
+  int column_width[32], row_height[32];
+  int loop_filter_across_tiles;
+  int loop_filter_across_slices;
+  int deblocking_filter_control_present, deblocking_filter_override_enabled;
+  int pps_deblocking_disabled, pps_beta_offset_div2, pps_tc_offset_div2;
+  int scaling_list_data_present, lists_modification_present;
+  int log2_parallel_merge_level;
+  int slice_header_extension_present;
+} orc_pps;
+
+typedef struct {
+  int first_slice_segment_in_pic, no_output_of_prior_pics;
+  int pps_id, dependent_slice_segment, slice_segment_address;
+  int slice_type, pic_output_flag;
+  int poc_lsb;
+  int short_term_ref_pic_set_sps_flag, short_term_rps_idx;
+  orc_st_rps st_rps;                       /* active RPS (copied from SPS or parsed) */
+  int slice_temporal_mvp_enabled;
+  int sao_luma, sao_chroma;
+  int num_ref_idx_l0, num_ref_idx_l1;
+  int mvd_l1_zero, cabac_init_flag, collocated_from_l0, collocated_ref_idx;
+  int max_num_merge_cand;
+  int slice_qp_delta, slice_cb_qp_offset, slice_cr_qp_offset;
+  int deblocking_filter_override, slice_deblocking_disabled, beta_offset_div2, tc_offset_div2;
+  int loop_filter_across_slices;
+  int num_entry_points; uint32_t *entry_point_offset;   /* offset_minus1 + 1, malloc'ed by parser */
+  int slice_qp;
+} orc_slice_hdr;
+
+void orc_write_vps(orc_bitw *w, const orc_vps *v, const orc_sps *s);
+void orc_write_sps(orc_bitw *w, const orc_sps *s);
+void orc_write_pps(orc_bitw *w, const orc_pps *p);
+/* writes header incl. entry points and byte_alignment() */
+void orc_write_slice_header(orc_bitw *w, const orc_slice_hdr *h, const orc_sps *s, const orc_pps *p, int nal_type);
+
+/* parsers return 0 on success, <0 on unsupported/invalid */
+int orc_parse_vps(orc_bitr *r, orc_vps *v);
+int orc_parse_sps(orc_bitr *r, orc_sps *s);
+int orc_parse_pps(orc_bitr *r, orc_pps *p);
+/* sps_tab/pps_tab: arrays indexed by id (16 / 64 entries) */
+int orc_parse_slice_header(orc_bitr *r, orc_slice_hdr *h, int nal_type, const orc_sps *sps_tab, const orc_pps *pps_tab);
+void orc_sps_derive(orc_sps *s);
+#ifdef __cplusplus
+}
+#endif
+#endif

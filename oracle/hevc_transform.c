@@ -1,0 +1,87 @@
+/* oracle/hevc_transform.c -- see hevc_transform.h.  Test infrastructure. */
+#include "hevc_transform.h"
+
+static inline int tcoef(int n, int dst_mode, int k, int i)
+{
+  if (dst_mode) return orc_dst_mat[k][i];
+  return orc_dct_mat[k * (32 / n)][i];
+}
+
+/* Forward: stage 1 transforms rows (horizontal), shift log2N + BitDepth - 9;
+ * stage 2 transforms columns (vertical), shift log2N + 6.   */
+void orc_fwd_transform(const int16_t *resid, int16_t *coeff, int n, int dst_mode)
+{
+  int32_t tmp[32 * 32];
+  int l2 = orc_log2((unsigned)n);
+  int s1 = l2 + 8 - 9, s2 = l2 + 6;
+  int r1 = s1 > 0 ? (1 << (s1 - 1)) : 0, r2 = 1 << (s2 - 1);
+  orc_tables_init();
+  for (int y = 0; y < n; y++)
+    for (int k = 0; k < n; k++) {
+      int32_t acc = 0;
+      for (int x = 0; x < n; x++) acc += tcoef(n, dst_mode, k, x) * resid[y * n + x];
+      tmp[y * n + k] = (acc + r1) >> s1;
+    }
+  for (int x = 0; x < n; x++)
+    for (int k = 0; k < n; k++) {
+      int32_t acc = 0;
+      for (int y = 0; y < n; y++) acc += tcoef(n, dst_mode, k, y) * tmp[y * n + x];
+      coeff[k * n + x] = (int16_t)orc_clip3(-32768, 32767, (acc + r2) >> s2);
+    }
+}
+
+/* H.265 8.6.4.2: columns first (shift 7, clip to 16 bit), then rows (shift 20 - BitDepth). */
+void orc_inv_transform(const int16_t *coeff, int16_t *resid, int n, int dst_mode)
+{
+  int32_t g[32 * 32];
+  orc_tables_init();
+  for (int x = 0; x < n; x++)
+    for (int y = 0; y < n; y++) {
+      int32_t acc = 0;
+      for (int k = 0; k < n; k++) acc += tcoef(n, dst_mode, k, y) * coeff[k * n + x];
+      g[y * n + x] = orc_clip3(-32768, 32767, (acc + 64) >> 7);
+    }
+  for (int y = 0; y < n; y++)
+    for (int x = 0; x < n; x++) {
+      int32_t acc = 0;
+      for (int k = 0; k < n; k++) acc += tcoef(n, dst_mode, k, x) * g[y * n + k];
+      resid[y * n + x] = (int16_t)orc_clip3(-32768, 32767, (acc + (1 << 11)) >> 12);
+    }
+}
+
+/* Encoder scalar quantiser with dead zone (HM/Kvazaar convention, flat scaling):
+ * level = sign * ((|c| * f[qp%6] + offset) >> (14 + qp/6 + ts)), ts = 15 - BitDepth - log2N,
+ * offset = (171 intra | 85 inter) << (shift - 9). */
+int orc_quant(const int16_t *coeff, int16_t *level, int n, int qp, int intra)
+{
+  int l2 = orc_log2((unsigned)n);
+  int shift = 14 + qp / 6 + (15 - 8 - l2);
+  int64_t off = (int64_t)(intra ? 171 : 85) << (shift - 9);
+  int f = orc_quant_scale[qp % 6], nz = 0;
+  for (int i = 0; i < n * n; i++) {
+    int c = coeff[i], a = c < 0 ? -c : c;
+    int64_t q = ((int64_t)a * f + off) >> shift;
+    if (q > 32767) q = 32767;
+    level[i] = (int16_t)(c < 0 ? -q : q);
+    nz += (q != 0);
+  }
+  return nz;
+}
+
+/* H.265 8.6.3 with m = 16 (scaling_list_enabled_flag == 0): bdShift = BitDepth + log2N - 5 */
+void orc_dequant(const int16_t *level, int16_t *coeff, int n, int qp)
+{
+  int l2 = orc_log2((unsigned)n);
+  int bd = 8 + l2 - 5;
+  int scale = orc_level_scale[qp % 6] << (qp / 6);
+  for (int i = 0; i < n * n; i++) {
+    int64_t v = ((int64_t)level[i] * 16 * scale + ((int64_t)1 << (bd - 1))) >> bd;
+    coeff[i] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+  }
+}
+
+int orc_chroma_qp(int qp_y, int offset)
+{
+  int qpi = orc_clip3(0, 57, qp_y + offset);
+  return orc_chroma_qp_table[qpi];
+}

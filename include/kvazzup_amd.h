@@ -1,0 +1,61 @@
+/*
+ * include/kvazzup_amd.h -- extensions next to the two drop-in ABIs (kvazaar.h, openHevcWrapper.h):
+ * device-resident entry points used by bench.py (inputs already in HBM), per-kernel timing taken
+ * with HIP events on the library's own stream, and debug read-back used by the parity tests.
+ * uvgComm itself needs none of these; they exist because its boundary hands over host buffers
+ * (/root/reference/src/media/processing/kvazaarfilter.cpp:410-418 memcpy into kvz_picture,
+ * openhevcfilter.cpp:218-229 memcpy out of the decoder's frame).
+ */
+#ifndef KVAZZUP_AMD_EXT_H_
+#define KVAZZUP_AMD_EXT_H_
+#include "kvazaar.h"
+#include "openHevcWrapper.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+KVZ_PUBLIC const char *kvzx_version(void);
+/* number of HIP devices visible (0 when the runtime cannot be initialised); touches the GPU */
+KVZ_PUBLIC int kvzx_device_count(void);
+
+/* ---- encoder ---- */
+/* Encode one picture given as packed I420 (width*height*3/2 bytes) in DEVICE memory of the
+ * encoder's GPU.  The access unit is written to au_buf (host).  Returns 1 on success, 0 on
+ * failure or when au_cap is too small (*len_out still receives the needed size). */
+KVZ_PUBLIC int kvzx_encoder_encode_device(kvz_encoder *enc, const void *d_i420, uint8_t *au_buf, uint32_t au_cap,
+                                          uint32_t *len_out, kvz_frame_info *info_out);
+/* Same with host planes (stride = width), without going through kvz_picture / chunk lists. */
+KVZ_PUBLIC int kvzx_encoder_encode_host(kvz_encoder *enc, const uint8_t *y, const uint8_t *u, const uint8_t *v,
+                                        uint8_t *au_buf, uint32_t au_cap, uint32_t *len_out, kvz_frame_info *info_out);
+KVZ_PUBLIC int kvzx_encoder_coded_size(kvz_encoder *enc, int *coded_w, int *coded_h);
+/* cropped reconstruction of the last coded picture into host planes (stride = width) */
+KVZ_PUBLIC int kvzx_encoder_download_recon(kvz_encoder *enc, uint8_t *y, uint8_t *u, uint8_t *v);
+/* device pointers (coded size, pitch = coded width [/2]) of the last reconstruction */
+KVZ_PUBLIC int kvzx_encoder_recon_device(kvz_encoder *enc, const void **planes /*[3]*/);
+/* debug read-back of an internal array of the last coded picture: "cu_log2", "cu_intra", "cu_flags",
+ * "cu_merge_idx", "cu_mvp_idx", "cu_intra_mode", "cu_cbf" (one byte per 8x8 block), "cu_mv", "cu_mvd"
+ * (two int16 per 8x8 block), "coef0".."coef2" (int16 planes), "rec0".."rec2", "src0".."src2" */
+KVZ_PUBLIC int kvzx_encoder_debug_copy(kvz_encoder *enc, const char *what, void *dst, size_t bytes);
+KVZ_PUBLIC void kvzx_encoder_set_profiling(kvz_encoder *enc, int on);
+#define KVZX_MAX_KERNELS 16
+/* accumulated HIP-event time (ms) and launch count per kernel id since the last reset */
+KVZ_PUBLIC int kvzx_encoder_kernel_times(kvz_encoder *enc, double *ms, uint64_t *launches, int reset);
+KVZ_PUBLIC const char *kvzx_encoder_kernel_name(int id);       /* NULL past the last id */
+KVZ_PUBLIC uint64_t kvzx_encoder_last_bins(kvz_encoder *enc);  /* CABAC bins of the last picture */
+
+/* ---- decoder ---- */
+/* Decode one NAL unit whose OUTPUT is wanted in device memory: like libOpenHevcDecode. */
+KVZ_PUBLIC int kvzx_decoder_last_error(OpenHevc_Handle h);
+/* device pointers (pitch = coded width [/2]) of the picture returned by the last libOpenHevcGetOutput */
+KVZ_PUBLIC int kvzx_decoder_output_device(OpenHevc_Handle h, const void **planes /*[3]*/, int *pitches /*[3]*/);
+/* when 0, libOpenHevcDecode leaves the picture in HBM and libOpenHevcGetOutput returns NULL planes */
+KVZ_PUBLIC void kvzx_decoder_set_download(OpenHevc_Handle h, int on);
+KVZ_PUBLIC void kvzx_decoder_set_profiling(OpenHevc_Handle h, int on);
+KVZ_PUBLIC int kvzx_decoder_kernel_times(OpenHevc_Handle h, double *ms, uint64_t *launches, int reset);
+KVZ_PUBLIC const char *kvzx_decoder_kernel_name(int id);
+KVZ_PUBLIC int kvzx_decoder_debug_copy(OpenHevc_Handle h, const char *what, void *dst, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

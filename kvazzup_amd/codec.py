@@ -1,0 +1,140 @@
+"""Thin Python drivers over the C ABI, used by tests/ and bench.py.  They perform exactly the
+call sequences of uvgComm's filters (kvazaarfilter.cpp:145-299,407-476; openhevcfilter.cpp:36-56,
+112-172,194-237); the C++ mirrors of those filters live in csrc/filters.hip."""
+import ctypes as C
+import numpy as np
+from . import _native as N
+
+DEFAULT_OPTIONS = (("preset", "ultrafast"), ("threads", "0"), ("owf", "0"), ("wpp", "1"), ("qp", "32"), ("period", "64"),
+                   ("vps-period", "1"), ("intra-bits", ""), ("gop", "lp-g4d3t1"), ("scaling-list", "off"), ("mv-constraint", "none"))
+
+
+class Encoder:
+    """kvz_api driven the way KvazaarFilter::init / feedInput drive it."""
+
+    def __init__(self, width, height, fps=(30, 1), options=(), fields=None):
+        self.lib = N.load_library()
+        self.api = self.lib.kvz_api_get(8).contents
+        self.w, self.h = width, height
+        self.cfg = self.api.config_alloc()
+        if not self.cfg:
+            raise RuntimeError("config_alloc failed")
+        self.api.config_init(self.cfg)
+        opts = dict(DEFAULT_OPTIONS)
+        opts["input-res"] = "%dx%d" % (width, height)
+        opts["input-fps"] = "%d/%d" % fps
+        for k, v in options:
+            opts[k] = str(v)
+        self.rejected = []
+        for k, v in opts.items():
+            if self.api.config_parse(self.cfg, k.encode(), v.encode()) != 1:
+                self.rejected.append(k)
+        self.cfg.contents.target_bitrate = 0
+        self.cfg.contents.hash = 0
+        for k, v in (fields or {}).items():
+            setattr(self.cfg.contents, k, v)
+        self.enc = self.api.encoder_open(self.cfg)
+        if not self.enc:
+            self.api.config_destroy(self.cfg)
+            self.cfg = None
+            raise RuntimeError("kvz_api.encoder_open failed (no usable HIP device? there is no CPU fallback)")
+        self.pic = self.api.picture_alloc(width, height)
+        self.pts = 0
+        self._au = np.empty(width * height * 3 + (1 << 20), dtype=np.uint8)
+
+    # -- the reference call sequence: memcpy into kvz_picture, encoder_encode, drain chunks
+    def encode(self, i420, want_recon=True):
+        i420 = np.ascontiguousarray(i420, dtype=np.uint8)
+        ny = self.w * self.h
+        p = self.pic.contents
+        C.memmove(p.y, i420.ctypes.data, ny)
+        C.memmove(p.u, i420.ctypes.data + ny, ny // 4)
+        C.memmove(p.v, i420.ctypes.data + ny + ny // 4, ny // 4)
+        p.pts = self.pts
+        self.pts += 1
+        chunks = C.POINTER(N.KvzDataChunk)()
+        length = C.c_uint32(0)
+        recon = C.POINTER(N.KvzPicture)()
+        info = N.KvzFrameInfo()
+        ok = self.api.encoder_encode(self.enc, self.pic, C.byref(chunks), C.byref(length), C.byref(recon) if want_recon else None, None, C.byref(info))
+        if not ok or not chunks:
+            raise RuntimeError("encoder_encode failed")
+        parts = []
+        c = chunks
+        while c:
+            parts.append(bytes(c.contents.data[:c.contents.len]))
+            c = c.contents.next
+        self.api.chunk_free(chunks)
+        au = b"".join(parts)
+        assert len(au) == length.value
+        rec = None
+        if want_recon and recon:
+            r = recon.contents
+            rec = np.concatenate([np.frombuffer((C.c_char * n).from_address(ptr), dtype=np.uint8).copy()
+                                  for ptr, n in ((r.y, ny), (r.u, ny // 4), (r.v, ny // 4))])
+            self.api.picture_free(recon)
+        self.info = {"poc": info.poc, "qp": info.qp, "nal_unit_type": info.nal_unit_type, "slice_type": info.slice_type}
+        return au, rec
+
+    # -- extension entry points
+    def encode_device(self, dptr):
+        n = C.c_uint32(0)
+        info = N.KvzFrameInfo()
+        ok = self.lib.kvzx_encoder_encode_device(self.enc, dptr, self._au.ctypes.data, len(self._au), C.byref(n), C.byref(info))
+        if not ok:
+            raise RuntimeError("kvzx_encoder_encode_device failed")
+        return bytes(self._au[:n.value])
+
+    def coded_size(self):
+        a, b = C.c_int(), C.c_int()
+        self.lib.kvzx_encoder_coded_size(self.enc, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def debug(self, what, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        if not self.lib.kvzx_encoder_debug_copy(self.enc, what.encode(), out.ctypes.data, out.nbytes):
+            raise RuntimeError("debug_copy(%s) failed" % what)
+        return out
+
+    def debug_all(self):
+        cw, ch = self.coded_size()
+        b8 = (ch // 8, cw // 8)
+        d = {"coded_w": cw, "coded_h": ch}
+        for k in ("cu_log2", "cu_intra", "cu_flags", "cu_merge_idx", "cu_mvp_idx", "cu_intra_mode", "cu_cbf"):
+            d[k] = self.debug(k, np.uint8, b8)
+        d["cu_mv"] = self.debug("cu_mv", np.int16, b8 + (2,))
+        for c in range(3):
+            shp = (ch, cw) if c == 0 else (ch // 2, cw // 2)
+            d["coef%d" % c] = self.debug("coef%d" % c, np.int16, shp)
+            d["rec%d" % c] = self.debug("rec%d" % c, np.uint8, shp)
+            d["src%d" % c] = self.debug("src%d" % c, np.uint8, shp)
+        return d
+
+    def set_profiling(self, on):
+        self.lib.kvzx_encoder_set_profiling(self.enc, int(on))
+
+    def kernel_times(self, reset=True):
+        ms = (C.c_double * 16)()
+        n = (C.c_uint64 * 16)()
+        k = self.lib.kvzx_encoder_kernel_times(self.enc, ms, n, int(reset))
+        return {self.lib.kvzx_encoder_kernel_name(i).decode(): (ms[i], n[i]) for i in range(k)}
+
+    def last_bins(self):
+        return self.lib.kvzx_encoder_last_bins(self.enc)
+
+    def close(self):
+        if getattr(self, "enc", None):
+            self.api.encoder_close(self.enc)
+            self.enc = None
+        if getattr(self, "pic", None):
+            self.api.picture_free(self.pic)
+            self.pic = None
+        if getattr(self, "cfg", None):
+            self.api.config_destroy(self.cfg)
+            self.cfg = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

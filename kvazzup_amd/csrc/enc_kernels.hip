@@ -1,0 +1,607 @@
+// kvazzup_amd/csrc/enc_kernels.hip -- CDNA4 (gfx950) kernels of the HEVC encoder hot path.
+//
+// What they replace: the work Kvazaar does inside kvz_api->encoder_encode
+// (/root/reference/src/media/processing/kvazaarfilter.cpp:435-438): motion search, prediction,
+// transform/quantisation, reconstruction, deblocking and CABAC.  The arithmetic is checked
+// against oracle/ (tests/); the decisions follow "uvgx encoder algorithm v1" (oracle/hevc_enc.h).
+//
+// Launch geometry (coded size is a multiple of 64):
+//   k_me            one 256-thread workgroup per 32x32 luma block; search window staged in LDS,
+//                   SADs by v_sad_u8 on dwords, wave-level min-reduction of (cost << 13 | index)
+//   k_inter_recon   one workgroup per 32x32 block: MC, residual, DCT, quant, dequant, IDCT, recon
+//   k_inter_signal  one thread per 16x16 block: merge / skip / AMVP signalling
+//   k_intra_analyse one workgroup per 32x32 block: 35-mode SAD search on source samples
+//   k_intra_recon   one workgroup per CTU row, wavefront over rows through progress counters
+//   k_deblock_v/h   one thread per 4-sample edge segment
+//   k_entropy       one workgroup per CTU row (WPP substream), lane 0 runs CABAC; context
+//                   hand-over between rows through agent-scope release/acquire flags
+#include <hip/hip_runtime.h>
+#include "hevc_core.h"
+#include "enc_kernels.h"
+
+namespace kvzx {
+
+#define SPLIT_BITS 8
+
+// ---------------------------------------------------------------------------------------------
+// inter-workgroup progress counters (cdna_hip_programming.md section 6, Guideline 16):
+// producer: stores -> __syncthreads -> lane 0: release fence + s_waitcnt + relaxed agent store
+// consumer: lane 0 polls relaxed, then ONE acquire fence, then __syncthreads
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void publish_progress(uint32_t *ctr, uint32_t value)
+{
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ void wait_progress(const uint32_t *ctr, uint32_t at_least, uint32_t *err)
+{
+  if (threadIdx.x == 0) {
+    uint32_t spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < at_least) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 26)) { atomicOr(err, 1u); break; }       // bounded spin: never hang the GPU
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+// =============================================================================================
+// Motion estimation
+// =============================================================================================
+#define ME_MAXR 32
+#define ME_WPITCH 100      // bytes per window row in LDS: 32 + 2*32 = 96, + 4 so the 9th dword read stays inside
+
+__global__ __launch_bounds__(256) void k_me(EncFrame f)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t win[(32 + 2 * ME_MAXR) * ME_WPITCH + 16];
+  __shared__ __attribute__((aligned(16))) uint32_t cur[32 * 8];
+  __shared__ uint32_t red[5];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  const int R = f.range, W = 2 * R + 1, WW = 32 + 2 * R;
+  const uint8_t *ref = f.ref[0], *src = f.src[0];
+  for (int i = tid; i < WW * WW; i += 256) {
+    int wy = i / WW, wx = i - wy * WW;
+    int gx = clip3(0, f.cw - 1, x0 - R + wx), gy = clip3(0, f.ch - 1, y0 - R + wy);
+    win[wy * ME_WPITCH + wx] = ref[gy * f.cw + gx];
+  }
+  {
+    int r = tid >> 3, c = tid & 7;
+    cur[tid] = *reinterpret_cast<const uint32_t *>(src + (y0 + r) * f.cw + x0 + c * 4);
+  }
+  if (tid < 5) red[tid] = 0xffffffffu;
+  __syncthreads();
+  const uint32_t lam = (uint32_t)f.lambda_q4;
+  uint32_t best[5] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  for (int cand = tid; cand < W * W; cand += 256) {
+    int dyi = cand / W, dxi = cand - dyi * W;
+    uint32_t s[4] = {0, 0, 0, 0};
+    for (int r = 0; r < 32; r++) {
+      int off = (dyi + r) * ME_WPITCH + dxi;
+      const uint32_t *wp = reinterpret_cast<const uint32_t *>(win + (off & ~3));
+      int sh = off & 3;
+      uint32_t d[9];
+#pragma unroll
+      for (int j = 0; j < 9; j++) d[j] = wp[j];
+      uint32_t sl = 0, sr = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) sl = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(d[j + 1], d[j], sh), cur[r * 8 + j], sl);
+#pragma unroll
+      for (int j = 4; j < 8; j++) sr = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(d[j + 1], d[j], sh), cur[r * 8 + j], sr);
+      if (r < 16) { s[0] += sl; s[1] += sr; } else { s[2] += sl; s[3] += sr; }
+    }
+    uint32_t rate = (lam * (uint32_t)(mvd_bits((dxi - R) * 4) + mvd_bits((dyi - R) * 4))) >> 4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) best[k] = min(best[k], ((s[k] + rate) << 13) | (uint32_t)cand);
+    best[4] = min(best[4], ((s[0] + s[1] + s[2] + s[3] + rate) << 13) | (uint32_t)cand);
+  }
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    uint32_t v = best[k];
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
+    if ((tid & 63) == 0) atomicMin(&red[k], v);
+  }
+  __syncthreads();
+  if (tid < 16) {
+    uint32_t pen = (lam * SPLIT_BITS) >> 4;
+    uint32_t csplit = pen + (red[0] >> 13) + (red[1] >> 13) + (red[2] >> 13) + (red[3] >> 13);
+    bool split = csplit < (red[4] >> 13);
+    int bx = tid & 3, by = tid >> 2;                     // 8x8 block inside the 32x32 block
+    int k = (by >> 1) * 2 + (bx >> 1);
+    uint32_t ci = (split ? red[k] : red[4]) & 0x1fff;
+    int i = b8idx(f, x0 + bx * 8, y0 + by * 8);
+    f.cu_log2[i] = split ? 4 : 5;
+    f.cu_intra[i] = 0;
+    f.cu_mv[i * 2] = (int16_t)(((int)(ci % W) - R) * 4);
+    f.cu_mv[i * 2 + 1] = (int16_t)(((int)(ci / W) - R) * 4);
+  }
+}
+
+// =============================================================================================
+// Workgroup-cooperative separable transforms on blocks held in LDS.
+// A "group" is ntu blocks of n x n samples stored TU-major: idx = tu * n*n + row * n + col.
+//   ROW op: out[i][j] = sum_m in[i][m] * M[j][m]      COL op: out[i][j] = sum_m M[i][m] * in[m][j]
+// with M[a][b] = C[a * 32/n][b] (TRANS = false) or C[b * 32/n][a] (TRANS = true).
+// =============================================================================================
+template <bool ROW, bool TRANS, bool CLIP16>
+__device__ __forceinline__ void transform_stage(const int *in, int *out, const int8_t (*C)[33], int log2n, int total,
+                                                int shift, int nthreads, int tid)
+{
+  const int n = 1 << log2n, st = 32 >> log2n, rnd = shift > 0 ? (1 << (shift - 1)) : 0;
+  for (int o = tid; o < total; o += nthreads) {
+    int tu = o >> (2 * log2n), rem = o & (n * n - 1), i = rem >> log2n, j = rem & (n - 1);
+    const int *base = in + (tu << (2 * log2n));
+    int acc = 0;
+    for (int m = 0; m < n; m++) {
+      int mat = ROW ? (TRANS ? C[m * st][j] : C[j * st][m]) : (TRANS ? C[m * st][i] : C[i * st][m]);
+      int v = ROW ? base[i * n + m] : base[m * n + j];
+      acc += mat * v;
+    }
+    acc = (acc + rnd) >> shift;
+    if (CLIP16) acc = clip3(-32768, 32767, acc);
+    out[o] = acc;
+  }
+}
+
+// forward (res -> coef), quantise, dequantise, inverse (-> res) for one group held in `a` (in/out),
+// with scratch `b`.  Levels are left in `lev` (int16).  Returns through `nz_flags` (LDS) a bit
+// per TU that has non-zero levels.  All threads of the workgroup must call this.
+__device__ __forceinline__ void code_group(int *a, int *b, int16_t *lev, const int8_t (*C)[33], int log2n, int ntu,
+                                           int qp, int intra, uint32_t *nz_flags, int nthreads, int tid)
+{
+  const int total = ntu << (2 * log2n);
+  transform_stage<true, false, false>(a, b, C, log2n, total, log2n + 8 - 9, nthreads, tid);        // rows
+  __syncthreads();
+  transform_stage<false, false, true>(b, a, C, log2n, total, log2n + 6, nthreads, tid);            // columns
+  __syncthreads();
+  for (int o = tid; o < total; o += nthreads) {
+    int l = quant_level(a[o], qp, log2n, intra);
+    lev[o] = (int16_t)l;
+    if (l) atomicOr(nz_flags, 1u << (o >> (2 * log2n)));
+    b[o] = dequant_coef(l, qp, log2n);
+  }
+  __syncthreads();
+  transform_stage<false, true, true>(b, a, C, log2n, total, 7, nthreads, tid);                     // columns, inverse
+  __syncthreads();
+  transform_stage<true, true, false>(a, b, C, log2n, total, 12, nthreads, tid);                    // rows, inverse
+  __syncthreads();
+}
+
+__device__ __forceinline__ void load_dct_matrix(int8_t (*C)[33], int tid, int nthreads)
+{
+  for (int i = tid; i < 1024; i += nthreads) C[i >> 5][i & 31] = kDct32[i >> 5][i & 31];
+}
+
+// =============================================================================================
+// Inter reconstruction of one 32x32 block (one 32x32 CU or four 16x16 CUs)
+// =============================================================================================
+__device__ __forceinline__ int ref_at(const uint8_t *p, int w, int h, int x, int y)
+{
+  return p[clip3(0, h - 1, y) * w + clip3(0, w - 1, x)];
+}
+// chroma sample predicted with the 4-tap filters of H.265 8.5.3.3.3.2; mv in 1/8 chroma samples
+__device__ __forceinline__ int mc_chroma_sample(const uint8_t *p, int w, int h, int x, int y, int mvx, int mvy)
+{
+  int xf = mvx & 7, yf = mvy & 7, xi = x + (mvx >> 3), yi = y + (mvy >> 3), v;
+  if (!xf && !yf) v = ref_at(p, w, h, xi, yi) << 6;
+  else if (!yf) { v = 0; for (int i = 0; i < 4; i++) v += kChromaFilter[xf][i] * ref_at(p, w, h, xi + i - 1, yi); }
+  else if (!xf) { v = 0; for (int i = 0; i < 4; i++) v += kChromaFilter[yf][i] * ref_at(p, w, h, xi, yi + i - 1); }
+  else {
+    v = 0;
+    for (int j = 0; j < 4; j++) {
+      int t = 0;
+      for (int i = 0; i < 4; i++) t += kChromaFilter[xf][i] * ref_at(p, w, h, xi + i - 1, yi + j - 1);
+      v += kChromaFilter[yf][j] * t;
+    }
+    v >>= 6;
+  }
+  return clip8((v + 32) >> 6);
+}
+// luma sample with the 8-tap filters of 8.5.3.3.3.1; mv in quarter samples
+__device__ __forceinline__ int mc_luma_sample(const uint8_t *p, int w, int h, int x, int y, int mvx, int mvy)
+{
+  int xf = mvx & 3, yf = mvy & 3, xi = x + (mvx >> 2), yi = y + (mvy >> 2), v;
+  if (!xf && !yf) return ref_at(p, w, h, xi, yi);
+  if (!yf) { v = 0; for (int i = 0; i < 8; i++) v += kLumaFilter[xf][i] * ref_at(p, w, h, xi + i - 3, yi); }
+  else if (!xf) { v = 0; for (int i = 0; i < 8; i++) v += kLumaFilter[yf][i] * ref_at(p, w, h, xi, yi + i - 3); }
+  else {
+    v = 0;
+    for (int j = 0; j < 8; j++) {
+      int t = 0;
+      for (int i = 0; i < 8; i++) t += kLumaFilter[xf][i] * ref_at(p, w, h, xi + i - 3, yi + j - 3);
+      v += kLumaFilter[yf][j] * t;
+    }
+    v >>= 6;
+  }
+  return clip8((v + 32) >> 6);
+}
+
+__global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
+{
+  __shared__ int a[1024], b[1024];
+  __shared__ int16_t lev[1024];
+  __shared__ uint8_t pred[1024];
+  __shared__ int8_t C[32][33];
+  __shared__ uint32_t nz[3];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  const int bi0 = b8idx(f, x0, y0);
+  const bool split = f.cu_log2[bi0] == 4;
+  const int cw2 = f.cw >> 1, ch2 = f.ch >> 1;
+  load_dct_matrix(C, tid, 256);
+  if (tid < 3) nz[tid] = 0;
+  // ---- luma: prediction and residual, TU-major layout
+  const int l2 = split ? 4 : 5, n = 1 << l2;
+  for (int o = tid; o < 1024; o += 256) {
+    int y = o >> 5, x = o & 31;
+    int bi = b8idx(f, x0 + x, y0 + y);
+    int p = mc_luma_sample(f.ref[0], f.cw, f.ch, x0 + x, y0 + y, f.cu_mv[bi * 2], f.cu_mv[bi * 2 + 1]);
+    int tu = split ? ((y >> 4) * 2 + (x >> 4)) : 0;
+    int idx = (tu << (2 * l2)) + ((y & (n - 1)) << l2) + (x & (n - 1));
+    pred[idx] = (uint8_t)p;
+    a[idx] = (int)f.src[0][(y0 + y) * f.cw + x0 + x] - p;
+  }
+  __syncthreads();
+  code_group(a, b, lev, C, l2, split ? 4 : 1, f.qp, 0, &nz[0], 256, tid);
+  for (int o = tid; o < 1024; o += 256) {
+    int tu = o >> (2 * l2), rem = o & (n * n - 1), r = rem >> l2, c = rem & (n - 1);
+    int x = (split ? (tu & 1) * 16 : 0) + c, y = (split ? (tu >> 1) * 16 : 0) + r;
+    bool has = (nz[0] >> tu) & 1;
+    int g = (y0 + y) * f.cw + x0 + x;
+    f.rec[0][g] = (uint8_t)(has ? clip8(pred[o] + b[o]) : pred[o]);
+    if (has) f.coef[0][g] = lev[o];
+  }
+  __syncthreads();
+  // ---- chroma: Cb and Cr together (512 samples): plane-major, then TU-major
+  const int cl2 = l2 - 1, cn = 1 << cl2;
+  for (int o = tid; o < 512; o += 256) {
+    int pl = o >> 8, y = (o >> 4) & 15, x = o & 15;
+    int cx = (x0 >> 1) + x, cy = (y0 >> 1) + y;
+    int bi = b8idx(f, x0 + 2 * x, y0 + 2 * y);
+    int p = mc_chroma_sample(f.ref[1 + pl], cw2, ch2, cx, cy, f.cu_mv[bi * 2], f.cu_mv[bi * 2 + 1]);
+    int tu = pl * (split ? 4 : 1) + (split ? ((y >> 3) * 2 + (x >> 3)) : 0);
+    int idx = (tu << (2 * cl2)) + ((y & (cn - 1)) << cl2) + (x & (cn - 1));
+    pred[idx] = (uint8_t)p;
+    a[idx] = (int)f.src[1 + pl][cy * cw2 + cx] - p;
+  }
+  __syncthreads();
+  code_group(a, b, lev, C, cl2, split ? 8 : 2, f.qpc, 0, &nz[1], 256, tid);
+  for (int o = tid; o < 512; o += 256) {
+    int tu = o >> (2 * cl2), rem = o & (cn * cn - 1), r = rem >> cl2, c = rem & (cn - 1);
+    int pl = split ? (tu >> 2) : tu, st = split ? (tu & 3) : 0;
+    int x = (split ? (st & 1) * 8 : 0) + c, y = (split ? (st >> 1) * 8 : 0) + r;
+    bool has = (nz[1] >> tu) & 1;
+    int g = ((y0 >> 1) + y) * cw2 + (x0 >> 1) + x;
+    f.rec[1 + pl][g] = (uint8_t)(has ? clip8(pred[o] + b[o]) : pred[o]);
+    if (has) f.coef[1 + pl][g] = lev[o];
+  }
+  __syncthreads();
+  if (tid < 16) {
+    int bx = tid & 3, by = tid >> 2, k = split ? ((by >> 1) * 2 + (bx >> 1)) : 0;
+    int cbf = (int)((nz[0] >> k) & 1);
+    if (split) cbf |= (int)((nz[1] >> k) & 1) << 1 | (int)((nz[1] >> (4 + k)) & 1) << 2;
+    else cbf |= (int)(nz[1] & 1) << 1 | (int)((nz[1] >> 1) & 1) << 2;
+    f.cu_cbf[b8idx(f, x0 + bx * 8, y0 + by * 8)] = (uint8_t)cbf;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_inter_signal(EncFrame f)
+{
+  int bx = blockIdx.x * blockDim.x + threadIdx.x;       // 16x16 block index
+  int w16 = f.cw >> 4, h16 = f.ch >> 4;
+  if (bx >= w16 * h16) return;
+  int x0 = (bx % w16) * 16, y0 = (bx / w16) * 16;
+  int cl = f.cu_log2[b8idx(f, x0, y0)];
+  if (cl == 5 && ((x0 | y0) & 31)) return;              // not the first 16x16 of a 32x32 CU
+  decide_signalling(f, x0, y0, cl);
+}
+
+// =============================================================================================
+// Intra: reference sample construction shared by analysis (source samples) and reconstruction
+// =============================================================================================
+// Builds left[0..2n] / top[0..2n] (8.4.4.2.2) of the n x n block at (x0, y0) (component samples)
+// from plane `p` (pitch pw); availability by picture bounds and z-scan order.  Uses raw[] / av[]
+// as LDS scratch of 4n+1 entries.  Must be called by all `nthreads` threads; ends synchronised.
+__device__ __forceinline__ void build_intra_refs(const uint8_t *p, int pw, int cidx, int cw, int ch, int x0, int y0, int n,
+                                                 uint8_t *raw, uint8_t *av, uint8_t *left, uint8_t *top, int tid, int nthreads)
+{
+  const int total = 4 * n + 1, sh = cidx ? 1 : 0;
+  for (int i = tid; i < total; i += nthreads) {
+    int x, y; intra_ref_coord(x0, y0, n, i, x, y);
+    bool ok = avail64(cw, ch, x0 << sh, y0 << sh, x << sh, y << sh);
+    av[i] = ok;
+    raw[i] = ok ? p[y * pw + x] : 0;
+  }
+  __syncthreads();
+  for (int i = tid; i < total; i += nthreads) {
+    int j = i;
+    while (j >= 0 && !av[j]) j--;
+    if (j < 0) { j = 0; while (j < total && !av[j]) j++; }
+    uint8_t v = (j < total) ? raw[j] : 128;
+    if (i < 2 * n) left[2 * n - i] = v;
+    else if (i == 2 * n) { left[0] = v; top[0] = v; }
+    else top[i - 2 * n] = v;
+  }
+  __syncthreads();
+}
+
+// filtered copies (8.4.4.2.3) of the reference arrays
+__device__ __forceinline__ void filter_intra_refs(const uint8_t *left, const uint8_t *top, int n, uint8_t *lf, uint8_t *tf, int tid, int nthreads)
+{
+  bool strong = intra_strong_filter(left, top, n);
+  for (int i = tid; i <= 2 * n; i += nthreads) {
+    lf[i] = (uint8_t)intra_filtered_ref(left, top, n, i, strong);
+    tf[i] = (uint8_t)intra_filtered_ref(top, left, n, i, strong);
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ int intra_dc_value(const uint8_t *left, const uint8_t *top, int n, int log2n)
+{
+  int s = n;
+  for (int i = 0; i < n; i++) s += left[1 + i] + top[1 + i];
+  return s >> (log2n + 1);
+}
+
+__global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
+{
+  __shared__ uint8_t raw[132], av[132], left[68], top[68], lf[68], tf[68];
+  __shared__ uint32_t cost[35];
+  const int tid = threadIdx.x;
+  const int X0 = blockIdx.x * 32, Y0 = blockIdx.y * 32;
+  const uint8_t *src = f.src[0];
+  for (int l2 = 3; l2 <= 5; l2++) {
+    const int n = 1 << l2, nb = 32 >> l2;
+    for (int blk = 0; blk < nb * nb; blk++) {
+      const int x0 = X0 + (blk % nb) * n, y0 = Y0 + (blk / nb) * n;
+      build_intra_refs(src, f.cw, 0, f.cw, f.ch, x0, y0, n, raw, av, left, top, tid, 256);
+      if (n > 4) filter_intra_refs(left, top, n, lf, tf, tid, 256);
+      if (tid < 35) cost[tid] = 0;
+      __syncthreads();
+      const int dc = intra_dc_value(left, top, n, l2);
+      const int npx = n * n;
+      for (int w = tid; w < 35 * npx; w += 256) {
+        int m = w / npx, pxi = w - m * npx, y = pxi >> l2, x = pxi & (n - 1);
+        bool filt = intra_filter_needed(n, 0, m);
+        int p = intra_pred_sample(filt ? lf : left, filt ? tf : top, n, l2, 0, m, dc, x, y);
+        uint32_t d = (uint32_t)iabs((int)src[(y0 + y) * f.cw + x0 + x] - p);
+        // lanes of one wave may belong to different modes when npx < 64 is impossible (npx >= 64)
+        for (int o = 32; o > 0; o >>= 1) d += (uint32_t)__shfl_xor((int)d, o);
+        if ((tid & 63) == 0) atomicAdd(&cost[m], d);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t bc = 0xffffffffu; int bm = 0;
+        for (int m = 0; m < 35; m++) if (cost[m] < bc) { bc = cost[m]; bm = m; }
+        int bw = f.cw >> l2, ib = (y0 >> l2) * bw + (x0 >> l2);
+        if (l2 == 3) { f.im8[ib] = (uint8_t)bm; f.ic8[ib] = bc; }
+        else if (l2 == 4) { f.im16[ib] = (uint8_t)bm; f.ic16[ib] = bc; }
+        else { f.im32[ib] = (uint8_t)bm; f.ic32[ib] = bc; }
+      }
+      __syncthreads();
+    }
+  }
+  // bottom-up split decision for this 32x32 block
+  if (tid == 0) {
+    uint32_t pen = ((uint32_t)f.lambda_q4 * SPLIT_BITS) >> 4;
+    int w8 = f.cw >> 3, w16 = f.cw >> 4, w32 = f.cw >> 5, x32 = X0 >> 5, y32 = Y0 >> 5;
+    uint32_t c16sum = 0; bool split16[4];
+    for (int k = 0; k < 4; k++) {
+      int x16 = x32 * 2 + (k & 1), y16 = y32 * 2 + (k >> 1);
+      uint32_t c8 = pen;
+      for (int j = 0; j < 4; j++) c8 += f.ic8[(y16 * 2 + (j >> 1)) * w8 + x16 * 2 + (j & 1)];
+      uint32_t c16 = f.ic16[y16 * w16 + x16];
+      split16[k] = c8 < c16;
+      c16sum += split16[k] ? c8 : c16;
+    }
+    bool split32 = (c16sum + pen) < f.ic32[y32 * w32 + x32];
+    for (int j = 0; j < 16; j++) {
+      int bx = j & 3, by = j >> 2, k = (by >> 1) * 2 + (bx >> 1);
+      int x8 = (X0 >> 3) + bx, y8 = (Y0 >> 3) + by, i = y8 * w8 + x8;
+      int l2, mode;
+      if (!split32) { l2 = 5; mode = f.im32[y32 * w32 + x32]; }
+      else if (!split16[k]) { l2 = 4; mode = f.im16[(y8 >> 1) * w16 + (x8 >> 1)]; }
+      else { l2 = 3; mode = f.im8[i]; }
+      f.cu_log2[i] = (uint8_t)l2; f.cu_intra_mode[i] = (uint8_t)mode; f.cu_intra[i] = 1; f.cu_flags[i] = 0;
+    }
+  }
+}
+
+// Reconstruct one intra TU (plane cidx, component coordinates) and return whether it has levels.
+// All 256 threads participate.
+struct IntraScratch {
+  uint8_t raw[132], av[132], left[68], top[68], lf[68], tf[68];
+  int a[1024], b[1024];
+  int16_t lev[1024];
+  uint8_t pred[1024];
+  int8_t C[32][33];
+  uint32_t nz;
+};
+
+__device__ __forceinline__ bool intra_recon_tu(const EncFrame &f, IntraScratch &s, int cidx, int x0, int y0, int l2, int mode, int qp, int tid)
+{
+  const int n = 1 << l2, pw = cidx ? (f.cw >> 1) : f.cw;
+  uint8_t *rec = f.rec[cidx];
+  build_intra_refs(rec, pw, cidx, f.cw, f.ch, x0, y0, n, s.raw, s.av, s.left, s.top, tid, 256);
+  const bool filt = intra_filter_needed(n, cidx, mode);
+  if (filt) filter_intra_refs(s.left, s.top, n, s.lf, s.tf, tid, 256);
+  const int dc = (mode == 1) ? intra_dc_value(s.left, s.top, n, l2) : 0;
+  if (tid == 0) s.nz = 0;
+  for (int o = tid; o < n * n; o += 256) {
+    int y = o >> l2, x = o & (n - 1);
+    int p = intra_pred_sample(filt ? s.lf : s.left, filt ? s.tf : s.top, n, l2, cidx, mode, dc, x, y);
+    s.pred[o] = (uint8_t)p;
+    s.a[o] = (int)f.src[cidx][(y0 + y) * pw + x0 + x] - p;
+  }
+  __syncthreads();
+  code_group(s.a, s.b, s.lev, s.C, l2, 1, qp, 1, &s.nz, 256, tid);
+  const bool has = s.nz != 0;
+  for (int o = tid; o < n * n; o += 256) {
+    int y = o >> l2, x = o & (n - 1), g = (y0 + y) * pw + x0 + x;
+    rec[g] = (uint8_t)(has ? clip8(s.pred[o] + s.b[o]) : s.pred[o]);
+    if (has) f.coef[cidx][g] = s.lev[o];
+  }
+  __syncthreads();
+  return has;
+}
+
+__global__ __launch_bounds__(256) void k_intra_recon(EncFrame f)
+{
+  __shared__ IntraScratch s;
+  const int tid = threadIdx.x, row = blockIdx.x, wc = f.cw >> 6;
+  load_dct_matrix(s.C, tid, 256);
+  __syncthreads();
+  for (int cx = 0; cx < wc; cx++) {
+    if (row > 0) wait_progress(&f.sync[row - 1], (uint32_t)imin(cx + 2, wc), f.err);
+    for (int z = 0; z < 64;) {
+      int xi = 0, yi = 0;
+      for (int bb = 0; bb < 3; bb++) { xi |= ((z >> (2 * bb)) & 1) << bb; yi |= ((z >> (2 * bb + 1)) & 1) << bb; }
+      int x0 = cx * 64 + xi * 8, y0 = row * 64 + yi * 8;
+      int bi = b8idx(f, x0, y0);
+      int l2 = f.cu_log2[bi], mode = f.cu_intra_mode[bi];
+      int cbf = intra_recon_tu(f, s, 0, x0, y0, l2, mode, f.qp, tid) ? 1 : 0;
+      cbf |= intra_recon_tu(f, s, 1, x0 >> 1, y0 >> 1, l2 - 1, mode, f.qpc, tid) ? 2 : 0;
+      cbf |= intra_recon_tu(f, s, 2, x0 >> 1, y0 >> 1, l2 - 1, mode, f.qpc, tid) ? 4 : 0;
+      int nb = 1 << (l2 - 3);
+      if (tid < nb * nb) f.cu_cbf[b8idx(f, x0 + (tid % nb) * 8, y0 + (tid / nb) * 8)] = (uint8_t)cbf;
+      z += 1 << (2 * (l2 - 3));
+    }
+    publish_progress(&f.sync[row], (uint32_t)(cx + 1));
+  }
+}
+
+// =============================================================================================
+// Deblocking: all vertical edges of the picture, then (second launch) all horizontal edges
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_deblock_v(EncFrame f)
+{
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int ne = (f.cw >> 3) - 1, ns = f.ch >> 2;            // edges per row of segments, segment rows
+  if (t >= ne * ns) return;
+  int x = ((t % ne) + 1) * 8, y = (t / ne) * 4;
+  if (!is_cu_edge_v(f, x, y)) return;
+  int bs = edge_bs(f, x - 1, y, x, y);
+  if (!bs) return;
+  deblock_luma_segment(f.rec[0] + y * f.cw + x, 1, f.cw, bs, f.qp);
+  if (bs == 2 && (x & 15) == 0) {
+    int cw2 = f.cw >> 1;
+    deblock_chroma_segment(f.rec[1] + (y >> 1) * cw2 + (x >> 1), 1, cw2, 2, f.qp);
+    deblock_chroma_segment(f.rec[2] + (y >> 1) * cw2 + (x >> 1), 1, cw2, 2, f.qp);
+  }
+}
+__global__ __launch_bounds__(256) void k_deblock_h(EncFrame f)
+{
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int ns = f.cw >> 2, ne = (f.ch >> 3) - 1;
+  if (t >= ne * ns) return;
+  int x = (t % ns) * 4, y = ((t / ns) + 1) * 8;
+  if (!is_cu_edge_h(f, x, y)) return;
+  int bs = edge_bs(f, x, y - 1, x, y);
+  if (!bs) return;
+  deblock_luma_segment(f.rec[0] + y * f.cw + x, f.cw, 1, bs, f.qp);
+  if (bs == 2 && (y & 15) == 0) {
+    int cw2 = f.cw >> 1;
+    deblock_chroma_segment(f.rec[1] + (y >> 1) * cw2 + (x >> 1), cw2, 1, 2, f.qp);
+    deblock_chroma_segment(f.rec[2] + (y >> 1) * cw2 + (x >> 1), cw2, 1, 2, f.qp);
+  }
+}
+
+// =============================================================================================
+// Entropy coding: one workgroup (one wave, lane 0 active) per CTU row / WPP substream
+// =============================================================================================
+__global__ __launch_bounds__(64) void k_entropy(EncFrame f)
+{
+  __shared__ uint8_t ctx[CTX_COUNT];
+  const int row = blockIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
+  if (threadIdx.x != 0) return;
+  CabacEnc c; c.nbins = 0;
+  const int init_type = f.is_intra ? 0 : 1;
+  if (f.wpp) {
+    cabac_start(c, f.row_buf + (size_t)row * f.row_cap, f.row_cap, ctx);
+    if (row == 0) cabac_init_contexts(ctx, init_type, f.qp);
+    else {
+      uint32_t spins = 0;
+      while (__hip_atomic_load(&f.sync[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 26)) { atomicOr(f.err, 2u); break; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const uint8_t *saved = f.wpp_ctx + (size_t)(row - 1) * CTX_COUNT;
+      for (int i = 0; i < CTX_COUNT; i++) ctx[i] = saved[i];
+    }
+    for (int cx = 0; cx < wc; cx++) {
+      enc_ctu(f, c, cx * 64, row * 64);
+      if (cx == 1) {
+        uint8_t *dst = f.wpp_ctx + (size_t)row * CTX_COUNT;
+        for (int i = 0; i < CTX_COUNT; i++) dst[i] = ctx[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&f.sync[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      bool last = (row == hc - 1 && cx == wc - 1);
+      cabac_terminate(c, last);                                  // end_of_slice_segment_flag
+      if (!last && cx == wc - 1) cabac_terminate(c, 1);          // end_of_subset_one_bit
+    }
+    cabac_finish(c);
+    f.row_len[row] = c.pos;
+    if (c.pos > c.cap) atomicOr(f.err, 4u);
+  } else {
+    if (row != 0) return;
+    cabac_start(c, f.row_buf, f.row_cap * hc, ctx);
+    cabac_init_contexts(ctx, init_type, f.qp);
+    for (int cy = 0; cy < hc; cy++)
+      for (int cx = 0; cx < wc; cx++) {
+        enc_ctu(f, c, cx * 64, cy * 64);
+        cabac_terminate(c, cy == hc - 1 && cx == wc - 1);
+      }
+    cabac_finish(c);
+    f.row_len[0] = c.pos;
+    if (c.pos > c.cap) atomicOr(f.err, 4u);
+  }
+  if (f.bins) atomicAdd((unsigned long long *)f.bins, (unsigned long long)c.nbins);
+}
+
+// =============================================================================================
+// Input staging: packed I420 picture (w x h) -> coded planes padded to (cw x ch) by edge
+// replication (what the oracle's load_input does)
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_pad_input(const uint8_t *in, int w, int h, uint8_t *dst, int cw, int ch)
+{
+  int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+  if (x >= cw || y >= ch) return;
+  const uint8_t *row = in + (size_t)imin(y, h - 1) * w;
+  uint32_t v = 0;
+  for (int i = 0; i < 4; i++) v |= (uint32_t)row[imin(x + i, w - 1)] << (8 * i);
+  *reinterpret_cast<uint32_t *>(dst + (size_t)y * cw + x) = v;
+}
+
+// =============================================================================================
+// launch wrappers
+// =============================================================================================
+void launch_pad_input(const uint8_t *in, int w, int h, uint8_t *dst, int cw, int ch, hipStream_t st)
+{
+  dim3 g((cw / 4 + 255) / 256, ch);
+  hipLaunchKernelGGL(k_pad_input, g, dim3(256), 0, st, in, w, h, dst, cw, ch);
+}
+void launch_me(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_me, dim3(f.cw / 32, f.ch / 32), dim3(256), 0, st, f); }
+void launch_inter_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_inter_recon, dim3(f.cw / 32, f.ch / 32), dim3(256), 0, st, f); }
+void launch_inter_signal(const EncFrame &f, hipStream_t st)
+{
+  int n = (f.cw / 16) * (f.ch / 16);
+  hipLaunchKernelGGL(k_inter_signal, dim3((n + 255) / 256), dim3(256), 0, st, f);
+}
+void launch_intra_analyse(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_analyse, dim3(f.cw / 32, f.ch / 32), dim3(256), 0, st, f); }
+void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_recon, dim3(f.ch / 64), dim3(256), 0, st, f); }
+void launch_deblock(const EncFrame &f, hipStream_t st)
+{
+  int nv = ((f.cw >> 3) - 1) * (f.ch >> 2), nh = (f.cw >> 2) * ((f.ch >> 3) - 1);
+  hipLaunchKernelGGL(k_deblock_v, dim3((nv + 255) / 256), dim3(256), 0, st, f);
+  hipLaunchKernelGGL(k_deblock_h, dim3((nh + 255) / 256), dim3(256), 0, st, f);
+}
+void launch_entropy(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_entropy, dim3(f.ch / 64), dim3(64), 0, st, f); }
+
+}  // namespace kvzx

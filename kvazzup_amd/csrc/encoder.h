@@ -1,0 +1,86 @@
+// kvazzup_amd/csrc/encoder.h -- host engine of the HIP encoder: owns the device buffers and the
+// HIP stream, runs the per-picture kernel pipeline and assembles the access unit.
+// This is what sits behind kvz_api->encoder_open / encoder_encode / encoder_close
+// (/root/reference/src/media/processing/kvazaarfilter.cpp:291,435-448,317).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "hevc_core.h"
+#include "hevc_headers.h"
+
+namespace kvzx {
+
+enum KernelId { K_PAD = 0, K_ME, K_INTER_RECON, K_INTER_SIGNAL, K_INTRA_ANALYSE, K_INTRA_RECON, K_DEBLOCK, K_ENTROPY, K_COUNT };
+
+struct EncoderConfig {
+  int width = 0, height = 0;
+  int qp = 32, intra_period = 64, vps_period = 1;
+  int me_range = 16;
+  int fps_num = 30, fps_den = 1;
+  int wpp = 1, deblock = 1;
+  int device = 0;
+};
+
+struct EncodedPicture {
+  std::vector<uint8_t> au;
+  int poc = 0; bool is_intra = false;
+  uint64_t bins = 0;
+};
+
+class Encoder {
+ public:
+  static Encoder *create(const EncoderConfig &cfg, std::string *error);
+  ~Encoder();
+  // picture as three host planes (stride = width)
+  bool encode_host(const uint8_t *y, const uint8_t *u, const uint8_t *v, EncodedPicture *out);
+  // picture as packed I420 in device memory (w*h*3/2 bytes)
+  bool encode_device(const uint8_t *d_i420, EncodedPicture *out);
+  // cropped reconstruction of the last coded picture -> host planes (stride = width)
+  bool download_recon(uint8_t *y, uint8_t *u, uint8_t *v);
+  // debug: copy an internal device array of the last coded picture to the host
+  //   "cu_log2","cu_intra","cu_flags","cu_merge_idx","cu_mvp_idx","cu_intra_mode","cu_cbf" (b8 bytes),
+  //   "cu_mv" (b8 * 2 int16), "coef0..2" (int16 planes), "rec0..2" (coded planes), "src0..2"
+  bool debug_copy(const char *what, void *dst, size_t bytes);
+  int coded_width() const { return cw_; }
+  int coded_height() const { return ch_; }
+  const EncoderConfig &config() const { return cfg_; }
+  void set_profiling(bool on) { profiling_ = on; }
+  // accumulated kernel time (ms) and launch count per KernelId since the last reset
+  void get_kernel_times(double *ms, uint64_t *launches, bool reset);
+  const uint8_t *device_recon(int plane) const { return rec_[ref_idx_][plane]; }
+  hipStream_t stream() const { return stream_; }
+
+ private:
+  Encoder() {}
+  bool init(const EncoderConfig &cfg, std::string *error);
+  bool run_picture(EncodedPicture *out);
+  void timed(KernelId id, const std::function<void()> &launch);
+
+  EncoderConfig cfg_;
+  int cw_ = 0, ch_ = 0, rows_ = 0;
+  hipStream_t stream_ = nullptr;
+  EncFrame f_{};
+  uint8_t *d_in_ = nullptr;              // packed input staging (device)
+  uint8_t *h_in_ = nullptr;              // pinned host staging
+  uint8_t *src_[3] = {nullptr, nullptr, nullptr};
+  uint8_t *rec_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  int cur_idx_ = 0, ref_idx_ = 1;
+  int16_t *coef_[3] = {nullptr, nullptr, nullptr};
+  uint8_t *cu_bytes_ = nullptr;          // 7 byte arrays back to back
+  int16_t *cu_mv_ = nullptr, *cu_mvd_ = nullptr;
+  uint8_t *intra_scratch_ = nullptr;
+  uint8_t *row_buf_ = nullptr; int row_cap_ = 0;
+  int32_t *row_len_ = nullptr; uint8_t *wpp_ctx_ = nullptr; uint32_t *sync_ = nullptr; uint32_t *err_ = nullptr;
+  uint64_t *bins_ = nullptr;
+  int32_t *h_row_len_ = nullptr; uint8_t *h_rows_ = nullptr; uint32_t *h_err_ = nullptr; uint64_t *h_bins_ = nullptr;
+  int frame_idx_ = 0, poc_ = 0, intra_count_ = 0;
+  bool profiling_ = false;
+  struct EvPair { hipEvent_t a, b; KernelId id; };
+  std::vector<EvPair> ev_pool_; size_t ev_used_ = 0;
+  double k_ms_[K_COUNT] = {0}; uint64_t k_n_[K_COUNT] = {0};
+  StreamParams sp_{};
+};
+
+}  // namespace kvzx

@@ -1,0 +1,738 @@
+// kvazzup_amd/csrc/hevc_core.h -- per-thread building blocks of the HIP encoder/decoder that
+// are serial by nature (CABAC, CU syntax, merge/AMVP signalling, intra sample prediction,
+// deblocking of one edge segment).  Written as host+device inline functions so the same code
+// runs inside the kernels (enc_kernels.hip / dec_kernels.hip) and can be unit-tested on the
+// host (tests/hostcheck).  No HIP intrinsics in this file.
+//
+// The path being replaced: everything inside kvz_api->encoder_encode
+// (/root/reference/src/media/processing/kvazaarfilter.cpp:435-438) and libOpenHevcDecode
+// (/root/reference/src/media/processing/openhevcfilter.cpp:145-146).
+#pragma once
+#include "hevc_tables.h"
+
+namespace kvzx {
+
+KVZ_HD int iabs(int v) { return v < 0 ? -v : v; }
+KVZ_HD int imin(int a, int b) { return a < b ? a : b; }
+KVZ_HD int imax(int a, int b) { return a > b ? a : b; }
+KVZ_HD int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+KVZ_HD int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+KVZ_HD int ilog2(unsigned v) { int n = 0; while (v > 1) { v >>= 1; n++; } return n; }
+
+// ---------------------------------------------------------------------------------------------
+// Frame state shared by all encoder kernels.  All pointers are device memory (or host memory in
+// the host unit tests).  Planes have pitch = coded width (luma) / coded width / 2 (chroma);
+// the coded size is a multiple of 64 (CTU), so every CTU is complete.
+// Per-CU arrays are indexed per 8x8 luma block ("b8"), pitch b8w = cw / 8; every 8x8 block of
+// a CU carries the CU's values.
+// ---------------------------------------------------------------------------------------------
+struct EncFrame {
+  int cw, ch, b8w, b8h;
+  int qp, qpc, lambda_q4, range;
+  int is_intra, poc;
+  int wpp;
+  const uint8_t *src[3];
+  uint8_t *rec[3];
+  const uint8_t *ref[3];
+  int16_t *coef[3];
+  uint8_t *cu_log2, *cu_intra, *cu_flags, *cu_merge_idx, *cu_mvp_idx, *cu_intra_mode, *cu_cbf;
+  int16_t *cu_mv, *cu_mvd;      // [b8][2]
+  // intra analysis scratch
+  uint8_t *im8, *im16, *im32; uint32_t *ic8, *ic16, *ic32;
+  // entropy coding output: one buffer per CTU row (or one for the picture without WPP)
+  uint8_t *row_buf; int row_cap; int32_t *row_len;
+  uint8_t *wpp_ctx;             // [rows][CTX_COUNT] saved context states
+  uint32_t *sync;               // [rows] progress counters (intra recon / entropy wavefront)
+  uint32_t *err;                // device-side error flags
+  uint64_t *bins;               // statistics (optional)
+};
+
+enum { CU_SKIP = 1, CU_MERGE = 2 };
+
+KVZ_HD int b8idx(const EncFrame &f, int x, int y) { return (y >> 3) * f.b8w + (x >> 3); }
+
+// z-scan order address of the 4x4 block holding luma sample (x, y), CTU = 64 (H.265 6.5.2)
+KVZ_HD uint32_t zaddr64(int x, int y, int w_ctbs)
+{
+  uint32_t ctb = (uint32_t)((y >> 6) * w_ctbs + (x >> 6));
+  uint32_t xi = (uint32_t)(x & 63) >> 2, yi = (uint32_t)(y & 63) >> 2, z = 0;
+  for (int b = 0; b < 4; b++) z |= ((xi >> b) & 1u) << (2 * b) | ((yi >> b) & 1u) << (2 * b + 1);
+  return (ctb << 8) | z;
+}
+// H.265 6.4.1 for one slice, one tile
+KVZ_HD bool avail64(int cw, int ch, int xc, int yc, int xn, int yn)
+{
+  if (xn < 0 || yn < 0 || xn >= cw || yn >= ch) return false;
+  return zaddr64(xn, yn, cw >> 6) <= zaddr64(xc, yc, cw >> 6);
+}
+
+// ---------------------------------------------------------------------------------------------
+// CABAC encoder (H.265 9.3.4, arithmetic encoder with a 32-bit low register and byte output)
+// ---------------------------------------------------------------------------------------------
+enum {
+  CTX_SAO_MERGE = 0, CTX_SAO_TYPE = 1, CTX_SPLIT_CU = 2, CTX_TQ_BYPASS = 5, CTX_SKIP = 6, CTX_PRED_MODE = 9,
+  CTX_PART_MODE = 10, CTX_PREV_INTRA = 14, CTX_CHROMA_MODE = 15, CTX_RQT_ROOT_CBF = 16, CTX_MERGE_FLAG = 17,
+  CTX_MERGE_IDX = 18, CTX_INTER_PRED_IDC = 19, CTX_REF_IDX = 24, CTX_MVP_FLAG = 26, CTX_SPLIT_TRANSFORM = 27,
+  CTX_CBF_LUMA = 30, CTX_CBF_CHROMA = 32, CTX_MVD_GT0 = 36, CTX_MVD_GT1 = 37, CTX_CU_QP_DELTA = 38, CTX_TS_FLAG = 40,
+  CTX_LAST_X = 42, CTX_LAST_Y = 60, CTX_CSBF = 78, CTX_SIG = 82, CTX_GT1 = 124, CTX_GT2 = 148, CTX_COUNT = 154
+};
+
+#define KVZ_CNU 154
+// H.265 Tables 9-5..9-37 initValue per initType (0: I, 1: P, 2: B), in CTX_* order
+KVZ_CONST uint8_t kCabacInit[3][CTX_COUNT] = {
+ {153, 200, 139,141,157, 154, KVZ_CNU,KVZ_CNU,KVZ_CNU, KVZ_CNU, 184,KVZ_CNU,KVZ_CNU,KVZ_CNU, 184, 63, KVZ_CNU, KVZ_CNU, KVZ_CNU,
+  KVZ_CNU,KVZ_CNU,KVZ_CNU,KVZ_CNU,KVZ_CNU, KVZ_CNU,KVZ_CNU, KVZ_CNU, 153,138,138, 111,141, 94,138,182,154, KVZ_CNU,KVZ_CNU, 154,154, 139,139,
+  110,110,124,125,140,153,125,127,140,109,111,143,127,111,79,108,123,63,
+  110,110,124,125,140,153,125,127,140,109,111,143,127,111,79,108,123,63,
+  91,171,134,141,
+  111,111,125,110,110,94,124,108,124,107,125,141,179,153,125,107,125,141,179,153,125,107,125,141,179,153,125,
+  140,139,182,182,152,136,152,136,153,136,139,111,136,139,111,
+  140,92,137,138,140,152,138,139,153,74,149,92,139,107,122,152, 140,179,166,182,140,227,122,197,
+  138,153,136,167,152,152},
+ {153, 185, 107,139,126, 154, 197,185,201, 149, 154,139,154,154, 154, 152, 79, 110, 122,
+  95,79,63,31,31, 153,153, 168, 124,138,94, 153,111, 149,107,167,154, 140,198, 154,154, 139,139,
+  125,110,94,110,95,79,125,111,110,78,110,111,111,95,94,108,123,108,
+  125,110,94,110,95,79,125,111,110,78,110,111,111,95,94,108,123,108,
+  121,140,61,154,
+  155,154,139,153,139,123,123,63,153,166,183,140,136,153,154,166,183,140,136,153,154,166,183,140,136,153,154,
+  170,153,123,123,107,121,107,121,167,151,183,140,151,183,140,
+  154,196,196,167,154,152,167,182,182,134,149,136,153,121,136,137, 169,194,166,167,154,167,137,182,
+  107,167,91,122,107,167},
+ {153, 160, 107,139,126, 154, 197,185,201, 134, 154,139,154,154, 183, 152, 79, 154, 137,
+  95,79,63,31,31, 153,153, 168, 224,167,122, 153,111, 149,92,167,154, 169,198, 154,154, 139,139,
+  125,110,124,110,95,94,125,111,111,79,125,126,111,111,79,108,123,93,
+  125,110,124,110,95,94,125,111,111,79,125,126,111,111,79,108,123,93,
+  121,140,61,154,
+  170,154,139,153,139,123,123,63,124,166,183,140,136,153,154,166,183,140,136,153,154,166,183,140,136,153,154,
+  170,153,138,138,122,121,122,121,167,151,183,140,151,183,140,
+  154,196,167,167,154,152,167,182,182,134,149,136,153,121,136,122, 169,208,166,167,154,152,167,182,
+  107,167,91,107,107,167}};
+
+// context variable = (pStateIdx << 1) | valMps
+KVZ_HD void cabac_init_contexts(uint8_t *ctx, int init_type, int qp)
+{
+  qp = clip3(0, 51, qp);
+  for (int i = 0; i < CTX_COUNT; i++) {
+    int v = kCabacInit[init_type][i];
+    int slope = (v >> 4) * 5 - 45, offs = ((v & 15) << 3) - 16;
+    int pre = clip3(1, 126, ((slope * qp) >> 4) + offs);
+    int mps = pre <= 63 ? 0 : 1;
+    ctx[i] = (uint8_t)(((mps ? pre - 64 : 63 - pre) << 1) | mps);
+  }
+}
+
+struct CabacEnc {
+  uint32_t low, range;
+  int bits_left, num_buffered, buffered_byte;
+  uint8_t *buf; int pos, cap;
+  uint8_t *ctx;
+  uint32_t nbins;
+};
+
+KVZ_HD void cabac_put_byte(CabacEnc &c, int b) { if (c.pos < c.cap) c.buf[c.pos] = (uint8_t)b; c.pos++; }
+
+KVZ_HD void cabac_start(CabacEnc &c, uint8_t *buf, int cap, uint8_t *ctx)
+{
+  c.low = 0; c.range = 510; c.bits_left = 23; c.num_buffered = 0; c.buffered_byte = 0xff;
+  c.buf = buf; c.pos = 0; c.cap = cap; c.ctx = ctx;
+}
+
+KVZ_HD void cabac_write_out(CabacEnc &c)
+{
+  uint32_t lead = c.low >> (24 - c.bits_left);
+  c.bits_left += 8;
+  c.low &= 0xffffffffu >> c.bits_left;
+  if (lead == 0xff) { c.num_buffered++; return; }
+  if (c.num_buffered > 0) {
+    uint32_t carry = lead >> 8;
+    cabac_put_byte(c, (int)(c.buffered_byte + carry));
+    c.buffered_byte = (int)(lead & 0xff);
+    int fill = (int)((0xff + carry) & 0xff);
+    while (c.num_buffered > 1) { cabac_put_byte(c, fill); c.num_buffered--; }
+  } else {
+    c.num_buffered = 1; c.buffered_byte = (int)lead;
+  }
+}
+
+KVZ_HD void cabac_bin(CabacEnc &c, int ci, int bin)
+{
+  uint8_t s = c.ctx[ci];
+  int state = s >> 1, mps = s & 1;
+  uint32_t lps = kRangeLps[state][(c.range >> 6) & 3];
+  c.nbins++;
+  c.range -= lps;
+  if (bin != mps) {
+    int nb = 0; uint32_t t = lps;          // renormalisation shift: range becomes >= 256
+    while (t < 256) { t <<= 1; nb++; }
+    c.low = (c.low + c.range) << nb;
+    c.range = t;
+    if (state == 0) mps ^= 1;
+    c.ctx[ci] = (uint8_t)((kNextLps[state] << 1) | mps);
+    c.bits_left -= nb;
+  } else {
+    c.ctx[ci] = (uint8_t)(((state < 62 ? state + 1 : state) << 1) | mps);
+    if (c.range >= 256) return;
+    c.low <<= 1; c.range <<= 1; c.bits_left--;
+  }
+  if (c.bits_left < 12) cabac_write_out(c);
+}
+
+KVZ_HD void cabac_bypass(CabacEnc &c, int bin)
+{
+  c.nbins++;
+  c.low <<= 1;
+  if (bin) c.low += c.range;
+  c.bits_left--;
+  if (c.bits_left < 12) cabac_write_out(c);
+}
+
+KVZ_HD void cabac_bypass_bits(CabacEnc &c, uint32_t val, int n)
+{
+  c.nbins += (uint32_t)n;
+  while (n > 8) {
+    n -= 8;
+    uint32_t pat = val >> n;
+    c.low = (c.low << 8) + c.range * pat;
+    val -= pat << n;
+    c.bits_left -= 8;
+    if (c.bits_left < 12) cabac_write_out(c);
+  }
+  c.low = (c.low << n) + c.range * val;
+  c.bits_left -= n;
+  if (c.bits_left < 12) cabac_write_out(c);
+}
+
+KVZ_HD void cabac_terminate(CabacEnc &c, int bin)
+{
+  c.nbins++;
+  c.range -= 2;
+  if (bin) {
+    c.low += c.range;
+    c.low <<= 7; c.range = 2 << 7; c.bits_left -= 7;
+  } else if (c.range >= 256) {
+    return;
+  } else {
+    c.low <<= 1; c.range <<= 1; c.bits_left--;
+  }
+  if (c.bits_left < 12) cabac_write_out(c);
+}
+
+// Flush after a terminating bin equal to 1: remaining bits, then the stop bit '1' and zero bits
+// up to the byte boundary (rbsp_slice_segment_trailing_bits / byte_alignment).
+KVZ_HD void cabac_finish(CabacEnc &c)
+{
+  if (c.low >> (32 - c.bits_left)) {
+    cabac_put_byte(c, c.buffered_byte + 1);
+    while (c.num_buffered > 1) { cabac_put_byte(c, 0x00); c.num_buffered--; }
+    c.low -= 1u << (32 - c.bits_left);
+  } else {
+    if (c.num_buffered > 0) cabac_put_byte(c, c.buffered_byte);
+    while (c.num_buffered > 1) { cabac_put_byte(c, 0xff); c.num_buffered--; }
+  }
+  // remaining (24 - bits_left) bits of low >> 8, followed by '1' and alignment zeros
+  int nbits = 24 - c.bits_left;
+  uint32_t v = ((c.low >> 8) << 1) | 1u; nbits += 1;          // append the stop bit
+  int pad = (8 - (nbits & 7)) & 7;
+  v <<= pad; nbits += pad;
+  for (int sh = nbits - 8; sh >= 0; sh -= 8) cabac_put_byte(c, (int)((v >> sh) & 0xff));
+}
+
+// ---------------------------------------------------------------------------------------------
+// residual_coding (H.265 7.3.8.11) for the encoder's tool set: diagonal / horizontal / vertical
+// scans, no transform skip, no sign hiding.  `lv` points at the block's top-left level inside a
+// plane-shaped level array with pitch `stride`.  The block has at least one non-zero level.
+// ---------------------------------------------------------------------------------------------
+KVZ_HD void scan_pos(int scan_idx, int log2blk, int i, int &x, int &y)
+{
+  // position i of the scan of a (1 << log2blk)^2 block (log2blk 0..3)
+  int n = 1 << log2blk;
+  if (scan_idx == 1) { x = i & (n - 1); y = i >> log2blk; return; }
+  if (scan_idx == 2) { y = i & (n - 1); x = i >> log2blk; return; }
+  if (log2blk == 2) { x = kDiag4x[i]; y = kDiag4y[i]; }
+  else if (log2blk == 3) { x = kDiag8x[i]; y = kDiag8y[i]; }
+  else if (log2blk == 1) { x = kDiag2x[i]; y = kDiag2y[i]; }
+  else { x = 0; y = 0; }
+}
+
+KVZ_HD void enc_last_prefix(CabacEnc &c, int base, int log2, int cidx, int prefix)
+{
+  int off, sh, mx = (log2 << 1) - 1;
+  if (cidx == 0) { off = 3 * (log2 - 2) + ((log2 - 1) >> 2); sh = (log2 + 1) >> 2; }
+  else { off = 15; sh = log2 - 2; }
+  for (int i = 0; i < prefix; i++) cabac_bin(c, base + off + (i >> sh), 1);
+  if (prefix < mx) cabac_bin(c, base + off + (prefix >> sh), 0);
+}
+
+KVZ_HD void enc_abs_remaining(CabacEnc &c, int v, int rice)
+{
+  int q = v >> rice;
+  if (q < 4) {
+    cabac_bypass_bits(c, (1u << (q + 1)) - 2u, q + 1);                 // q ones and a zero
+    if (rice) cabac_bypass_bits(c, (uint32_t)(v & ((1 << rice) - 1)), rice);
+  } else {
+    int x = v - (4 << rice), k = rice + 1, ones = 4;
+    while (x >= (1 << k)) { x -= 1 << k; k++; ones++; }
+    cabac_bypass_bits(c, (1u << (ones + 1)) - 2u, ones + 1);
+    cabac_bypass_bits(c, (uint32_t)x, k);
+  }
+}
+
+KVZ_HD void enc_residual(CabacEnc &c, const int16_t *lv, int stride, int log2, int cidx, int scan_idx)
+{
+  const int sbl = log2 - 2, nsb = 1 << sbl, nsb2 = 1 << (2 * sbl);
+  uint64_t csbf = 0;                         // bit (ys * 8 + xs)
+  int last_sb = -1, last_pos = -1;
+  for (int i = nsb2 - 1; i >= 0; i--) {
+    int xs, ys; scan_pos(scan_idx, sbl, i, xs, ys);
+    int any = 0, lp = -1;
+    for (int k = 15; k >= 0; k--) {
+      int xp, yp; scan_pos(scan_idx, 2, k, xp, yp);
+      if (lv[((ys << 2) + yp) * stride + (xs << 2) + xp]) { any = 1; if (lp < 0) lp = k; }
+    }
+    if (any) { csbf |= 1ull << (ys * 8 + xs); if (last_sb < 0) { last_sb = i; last_pos = lp; } }
+  }
+  int xs0, ys0, xp0, yp0;
+  scan_pos(scan_idx, sbl, last_sb, xs0, ys0); scan_pos(scan_idx, 2, last_pos, xp0, yp0);
+  int lx = (xs0 << 2) + xp0, ly = (ys0 << 2) + yp0;
+  if (scan_idx == 2) { int t = lx; lx = ly; ly = t; }
+  int pfx[2], nbs[2], sfx[2];
+  for (int d = 0; d < 2; d++) {
+    int v = d ? ly : lx;
+    if (v < 4) { pfx[d] = v; nbs[d] = 0; sfx[d] = 0; }
+    else { int len = ilog2((unsigned)v); pfx[d] = 2 * len + ((v >> (len - 1)) & 1); nbs[d] = len - 1; sfx[d] = v & ((1 << (len - 1)) - 1); }
+  }
+  enc_last_prefix(c, CTX_LAST_X, log2, cidx, pfx[0]);
+  enc_last_prefix(c, CTX_LAST_Y, log2, cidx, pfx[1]);
+  if (pfx[0] > 3) cabac_bypass_bits(c, (uint32_t)sfx[0], nbs[0]);
+  if (pfx[1] > 3) cabac_bypass_bits(c, (uint32_t)sfx[1], nbs[1]);
+  int c1 = 1;
+  for (int i = last_sb; i >= 0; i--) {
+    int xs, ys; scan_pos(scan_idx, sbl, i, xs, ys);
+    int right = (xs < nsb - 1) ? (int)((csbf >> (ys * 8 + xs + 1)) & 1) : 0;
+    int below = (ys < nsb - 1) ? (int)((csbf >> ((ys + 1) * 8 + xs)) & 1) : 0;
+    int coded = (int)((csbf >> (ys * 8 + xs)) & 1), infer_dc = 0;
+    if (i < last_sb && i > 0) {
+      cabac_bin(c, CTX_CSBF + ((right | below) ? 1 : 0) + (cidx ? 2 : 0), coded);
+      infer_dc = 1;
+    } else {
+      csbf |= 1ull << (ys * 8 + xs);       // inferred 1 for the last and the DC sub-block
+      coded = 1;
+    }
+    if (!coded) continue;
+    int16_t v[16]; int nsig = 0;
+    for (int k = 0; k < 16; k++) {
+      int xp, yp; scan_pos(scan_idx, 2, k, xp, yp);
+      v[k] = lv[((ys << 2) + yp) * stride + (xs << 2) + xp]; nsig += v[k] != 0;
+    }
+    int prev_csbf = right | (below << 1);
+    for (int k = (i == last_sb) ? last_pos - 1 : 15; k >= 0; k--) {
+      if (k > 0 || !infer_dc) {
+        int xp, yp; scan_pos(scan_idx, 2, k, xp, yp);
+        int xc = (xs << 2) + xp, yc = (ys << 2) + yp, sc;
+        if (log2 == 2) sc = kCtxIdxMap4x4[(yc << 2) + xc];
+        else if (xc + yc == 0) sc = 0;
+        else {
+          if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
+          else if (prev_csbf == 1) sc = (yp == 0) ? 2 : (yp == 1) ? 1 : 0;
+          else if (prev_csbf == 2) sc = (xp == 0) ? 2 : (xp == 1) ? 1 : 0;
+          else sc = 2;
+          if (cidx == 0) { if (i > 0) sc += 3; sc += (log2 == 3) ? ((scan_idx == 0) ? 9 : 15) : 21; }
+          else sc += (log2 == 3) ? 9 : 12;
+        }
+        cabac_bin(c, CTX_SIG + (cidx ? 27 : 0) + sc, v[k] != 0);
+        if (v[k]) infer_dc = 0;
+      }
+    }
+    if (!nsig) continue;
+    int ctx_set = (i > 0 && cidx == 0) ? 2 : 0;
+    if (c1 == 0) ctx_set++;
+    c1 = 1;
+    int ng1 = 0, g1pos = -1;
+    uint32_t signs = 0; int nsigns = 0;
+    for (int k = 15; k >= 0; k--) if (v[k]) {
+      if (ng1 < 8) {
+        int g1 = iabs(v[k]) > 1;
+        cabac_bin(c, CTX_GT1 + (cidx ? 16 : 0) + ctx_set * 4 + c1, g1);
+        ng1++;
+        if (g1) { c1 = 0; if (g1pos < 0) g1pos = k; }
+        else if (c1 > 0 && c1 < 3) c1++;
+      }
+      signs = (signs << 1) | (v[k] < 0 ? 1u : 0u); nsigns++;
+    }
+    if (g1pos >= 0) cabac_bin(c, CTX_GT2 + (cidx ? 4 : 0) + ctx_set, iabs(v[g1pos]) > 2);
+    cabac_bypass_bits(c, signs, nsigns);
+    int num_sig = 0, rice = 0;
+    for (int k = 15; k >= 0; k--) if (v[k]) {
+      int a = iabs(v[k]);
+      int base = (num_sig < 8) ? ((k == g1pos) ? 3 : 2) : 1;
+      if (a >= base) {
+        enc_abs_remaining(c, a - base, rice);
+        if (a > 3 * (1 << rice)) rice = imin(rice + 1, 4);
+      }
+      num_sig++;
+    }
+  }
+}
+
+KVZ_HD int intra_scan_idx(int intra, int log2, int cidx, int mode)
+{
+  if (!intra) return 0;
+  if (log2 == 2 || (log2 == 3 && cidx == 0)) {
+    if (mode >= 6 && mode <= 14) return 2;
+    if (mode >= 22 && mode <= 30) return 1;
+  }
+  return 0;
+}
+
+KVZ_HD void enc_mvd(CabacEnc &c, int dx, int dy)
+{
+  int ax = iabs(dx), ay = iabs(dy);
+  cabac_bin(c, CTX_MVD_GT0, ax > 0); cabac_bin(c, CTX_MVD_GT0, ay > 0);
+  if (ax > 0) cabac_bin(c, CTX_MVD_GT1, ax > 1);
+  if (ay > 0) cabac_bin(c, CTX_MVD_GT1, ay > 1);
+  for (int d = 0; d < 2; d++) {
+    int a = d ? ay : ax, neg = (d ? dy : dx) < 0;
+    if (!a) continue;
+    if (a > 1) {                              // abs_mvd_minus2: EG1
+      int x = a - 2, k = 1, ones = 0;
+      while (x >= (1 << k)) { x -= 1 << k; k++; ones++; }
+      cabac_bypass_bits(c, (1u << (ones + 1)) - 2u, ones + 1);
+      cabac_bypass_bits(c, (uint32_t)x, k);
+    }
+    cabac_bypass(c, neg);
+  }
+}
+
+KVZ_HD void enc_merge_idx(CabacEnc &c, int idx)
+{
+  cabac_bin(c, CTX_MERGE_IDX, idx > 0);
+  for (int i = 1; i < 4 && idx >= i; i++) cabac_bypass(c, idx > i);
+}
+
+// Intra MPM candidates (H.265 8.4.2) for the CU at (x0, y0)
+KVZ_HD void intra_mpm(const EncFrame &f, int x0, int y0, int cand[3])
+{
+  int ca = 1, cb = 1;
+  if (avail64(f.cw, f.ch, x0, y0, x0 - 1, y0) && f.cu_intra[b8idx(f, x0 - 1, y0)]) ca = f.cu_intra_mode[b8idx(f, x0 - 1, y0)];
+  if (avail64(f.cw, f.ch, x0, y0, x0, y0 - 1) && f.cu_intra[b8idx(f, x0, y0 - 1)] && (y0 - 1) >= ((y0 >> 6) << 6))
+    cb = f.cu_intra_mode[b8idx(f, x0, y0 - 1)];
+  if (ca == cb) {
+    if (ca < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
+    else { cand[0] = ca; cand[1] = 2 + ((ca + 29) % 32); cand[2] = 2 + ((ca - 2 + 1) % 32); }
+  } else {
+    cand[0] = ca; cand[1] = cb;
+    cand[2] = (ca != 0 && cb != 0) ? 0 : ((ca != 1 && cb != 1) ? 1 : 26);
+  }
+}
+
+// coding_unit() + its transform_tree (TU == CU) for the CU at (x0, y0), H.265 7.3.8.5-7.3.8.10
+KVZ_HD void enc_cu(const EncFrame &f, CabacEnc &c, int x0, int y0, int log2)
+{
+  const int bi = b8idx(f, x0, y0);
+  const int intra = f.cu_intra[bi], flags = f.cu_flags[bi], cbf = f.cu_cbf[bi];
+  if (!f.is_intra) {
+    int l = avail64(f.cw, f.ch, x0, y0, x0 - 1, y0) && (f.cu_flags[b8idx(f, x0 - 1, y0)] & CU_SKIP);
+    int a = avail64(f.cw, f.ch, x0, y0, x0, y0 - 1) && (f.cu_flags[b8idx(f, x0, y0 - 1)] & CU_SKIP);
+    cabac_bin(c, CTX_SKIP + l + a, flags & CU_SKIP);
+    if (flags & CU_SKIP) { enc_merge_idx(c, f.cu_merge_idx[bi]); return; }
+    cabac_bin(c, CTX_PRED_MODE, intra);
+  }
+  if (!intra || log2 == 3) cabac_bin(c, CTX_PART_MODE, 1);        // PART_2Nx2N
+  int mode = 0;
+  if (intra) {
+    mode = f.cu_intra_mode[bi];
+    int cand[3]; intra_mpm(f, x0, y0, cand);
+    int mpm = -1;
+    for (int k = 0; k < 3; k++) if (cand[k] == mode) { mpm = k; break; }
+    cabac_bin(c, CTX_PREV_INTRA, mpm >= 0);
+    if (mpm >= 0) { cabac_bypass(c, mpm > 0); if (mpm > 0) cabac_bypass(c, mpm > 1); }
+    else {
+      int t;
+      if (cand[0] > cand[1]) { t = cand[0]; cand[0] = cand[1]; cand[1] = t; }
+      if (cand[0] > cand[2]) { t = cand[0]; cand[0] = cand[2]; cand[2] = t; }
+      if (cand[1] > cand[2]) { t = cand[1]; cand[1] = cand[2]; cand[2] = t; }
+      int rem = mode;
+      for (int k = 2; k >= 0; k--) if (rem > cand[k]) rem--;
+      cabac_bypass_bits(c, (uint32_t)rem, 5);
+    }
+    cabac_bin(c, CTX_CHROMA_MODE, 0);                               // intra_chroma_pred_mode = 4
+  } else {
+    cabac_bin(c, CTX_MERGE_FLAG, (flags & CU_MERGE) ? 1 : 0);
+    if (flags & CU_MERGE) enc_merge_idx(c, f.cu_merge_idx[bi]);
+    else {
+      enc_mvd(c, f.cu_mvd[bi * 2], f.cu_mvd[bi * 2 + 1]);
+      cabac_bin(c, CTX_MVP_FLAG, f.cu_mvp_idx[bi]);
+      cabac_bin(c, CTX_RQT_ROOT_CBF, cbf != 0);
+    }
+    if (!cbf) return;
+  }
+  cabac_bin(c, CTX_CBF_CHROMA, (cbf >> 1) & 1);
+  cabac_bin(c, CTX_CBF_CHROMA, (cbf >> 2) & 1);
+  if (intra || (cbf & 6)) cabac_bin(c, CTX_CBF_LUMA + 1, cbf & 1);
+  if (cbf & 1) enc_residual(c, f.coef[0] + y0 * f.cw + x0, f.cw, log2, 0, intra_scan_idx(intra, log2, 0, mode));
+  for (int ci = 1; ci <= 2; ci++)
+    if ((cbf >> ci) & 1)
+      enc_residual(c, f.coef[ci] + (y0 >> 1) * (f.cw >> 1) + (x0 >> 1), f.cw >> 1, log2 - 1, ci, intra_scan_idx(intra, log2 - 1, ci, mode));
+}
+
+// coding_quadtree() of one 64x64 CTU, iterative over the up-to-64 8x8 positions in z-order
+KVZ_HD void enc_ctu(const EncFrame &f, CabacEnc &c, int cx, int cy)
+{
+  // z-order walk: a CU starts at every z-position that is aligned to its own size
+  for (int z = 0; z < 64;) {
+    int xi = 0, yi = 0;
+    for (int b = 0; b < 3; b++) { xi |= ((z >> (2 * b)) & 1) << b; yi |= ((z >> (2 * b + 1)) & 1) << b; }
+    int x0 = cx + xi * 8, y0 = cy + yi * 8;
+    int cl = f.cu_log2[b8idx(f, x0, y0)];
+    // split_cu_flag for every ancestor level whose block starts here, from 64 down to the CU size
+    for (int l2 = 6; l2 > 3; l2--) {
+      int zmask = (1 << (2 * (l2 - 3))) - 1;
+      if (z & zmask) continue;                         // this level's block does not start at z
+      if (l2 < cl) break;
+      int depth = 6 - l2;
+      int l = avail64(f.cw, f.ch, x0, y0, x0 - 1, y0) && (6 - f.cu_log2[b8idx(f, x0 - 1, y0)]) > depth;
+      int a = avail64(f.cw, f.ch, x0, y0, x0, y0 - 1) && (6 - f.cu_log2[b8idx(f, x0, y0 - 1)]) > depth;
+      cabac_bin(c, CTX_SPLIT_CU + l + a, cl < l2);
+      if (cl >= l2) break;
+    }
+    enc_cu(f, c, x0, y0, cl);
+    z += 1 << (2 * (cl - 3));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Merge / AMVP signalling of one inter 2Nx2N CU from the final motion field of a P picture with
+// one reference picture and no intra CUs... (intra neighbours are treated as unavailable).
+// H.265 8.5.3.2.2-8.5.3.2.7 specialised: Log2ParMrgLevel = 2, MaxNumMergeCand = 5, no TMVP.
+// ---------------------------------------------------------------------------------------------
+KVZ_HD int mvd_bits(int q)
+{
+  int a = iabs(q);
+  if (a == 0) return 1;
+  if (a == 1) return 3;
+  int x = a - 2, k = 1, len = 0;
+  while (x >= (1 << k)) { x -= 1 << k; k++; len++; }
+  return 2 + len + 1 + k + 1;
+}
+
+struct NbMv { bool ok; int mx, my; };
+KVZ_HD NbMv nb_mv(const EncFrame &f, int xc, int yc, int xn, int yn)
+{
+  NbMv r; r.ok = false; r.mx = r.my = 0;
+  if (!avail64(f.cw, f.ch, xc, yc, xn, yn)) return r;
+  int i = b8idx(f, xn, yn);
+  if (f.cu_intra[i]) return r;
+  r.ok = true; r.mx = f.cu_mv[i * 2]; r.my = f.cu_mv[i * 2 + 1];
+  return r;
+}
+KVZ_HD bool same_mv(const NbMv &a, const NbMv &b) { return a.mx == b.mx && a.my == b.my; }
+
+KVZ_HD void decide_signalling(const EncFrame &f, int x0, int y0, int log2)
+{
+  const int n = 1 << log2, bi = b8idx(f, x0, y0);
+  const int mvx = f.cu_mv[bi * 2], mvy = f.cu_mv[bi * 2 + 1];
+  NbMv A1 = nb_mv(f, x0, y0, x0 - 1, y0 + n - 1), B1 = nb_mv(f, x0, y0, x0 + n - 1, y0 - 1);
+  NbMv B0 = nb_mv(f, x0, y0, x0 + n, y0 - 1), A0 = nb_mv(f, x0, y0, x0 - 1, y0 + n), B2 = nb_mv(f, x0, y0, x0 - 1, y0 - 1);
+  bool fA1 = A1.ok;
+  bool fB1 = B1.ok && !(A1.ok && same_mv(A1, B1));
+  bool fB0 = B0.ok && !(B1.ok && same_mv(B1, B0));
+  bool fA0 = A0.ok && !(A1.ok && same_mv(A1, A0));
+  bool fB2 = B2.ok && !(A1.ok && same_mv(A1, B2)) && !(B1.ok && same_mv(B1, B2)) && !(fA0 && fA1 && fB0 && fB1);
+  int cmx[5], cmy[5], nc = 0;
+  if (fA1) { cmx[nc] = A1.mx; cmy[nc] = A1.my; nc++; }
+  if (fB1) { cmx[nc] = B1.mx; cmy[nc] = B1.my; nc++; }
+  if (fB0) { cmx[nc] = B0.mx; cmy[nc] = B0.my; nc++; }
+  if (fA0) { cmx[nc] = A0.mx; cmy[nc] = A0.my; nc++; }
+  if (fB2 && nc < 5) { cmx[nc] = B2.mx; cmy[nc] = B2.my; nc++; }
+  while (nc < 5) { cmx[nc] = 0; cmy[nc] = 0; nc++; }        // zero candidates (refIdx 0 for one reference)
+  int flags = 0, midx = 0, mvp = 0, mvdx = 0, mvdy = 0;
+  for (int k = 0; k < 5; k++) if (cmx[k] == mvx && cmy[k] == mvy) { flags = CU_MERGE; midx = k; break; }
+  if (flags && f.cu_cbf[bi] == 0) flags |= CU_SKIP;
+  if (!flags) {
+    // AMVP: A = first of A0, A1; B = first of B0, B1, B2 (same reference picture everywhere)
+    bool haveA = A0.ok || A1.ok, haveB = B0.ok || B1.ok || B2.ok;
+    NbMv a = A0.ok ? A0 : A1, b = B0.ok ? B0 : (B1.ok ? B1 : B2);
+    if (!haveA && haveB) { a = b; haveA = true; }          // isScaledFlag == 0: A takes B's vector
+    int px[2], py[2], np = 0;
+    if (haveA) { px[np] = a.mx; py[np] = a.my; np++; }
+    if (haveB && !(haveA && a.mx == b.mx && a.my == b.my)) { px[np] = b.mx; py[np] = b.my; np++; }
+    while (np < 2) { px[np] = 0; py[np] = 0; np++; }
+    int b0 = mvd_bits(mvx - px[0]) + mvd_bits(mvy - py[0]);
+    int b1 = mvd_bits(mvx - px[1]) + mvd_bits(mvy - py[1]);
+    mvp = b1 < b0;
+    mvdx = mvx - px[mvp]; mvdy = mvy - py[mvp];
+  }
+  for (int y = y0; y < y0 + n; y += 8)
+    for (int x = x0; x < x0 + n; x += 8) {
+      int i = b8idx(f, x, y);
+      f.cu_flags[i] = (uint8_t)flags; f.cu_merge_idx[i] = (uint8_t)midx; f.cu_mvp_idx[i] = (uint8_t)mvp;
+      f.cu_mvd[i * 2] = (int16_t)mvdx; f.cu_mvd[i * 2 + 1] = (int16_t)mvdy;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Intra sample prediction (H.265 8.4.4.2).  `left[0]` = `top[0]` = p[-1][-1], left[1+i] = p[-1][i],
+// top[1+i] = p[i][-1], i < 2n.  The arrays passed to intra_pred_sample() are the ones selected by
+// the filtering decision of 8.4.4.2.3.
+// ---------------------------------------------------------------------------------------------
+KVZ_HD bool intra_filter_needed(int n, int cidx, int mode)
+{
+  if (cidx != 0 || mode == 1 || n == 4) return false;
+  int d = imin(iabs(mode - 26), iabs(mode - 10));
+  int thr = (n == 8) ? 7 : (n == 16) ? 1 : 0;
+  return d > thr;
+}
+KVZ_HD bool intra_strong_filter(const uint8_t *left, const uint8_t *top, int n)
+{
+  if (n != 32) return false;
+  int c = left[0];
+  return iabs(c + top[2 * n] - 2 * top[n]) < 8 && iabs(c + left[2 * n] - 2 * left[n]) < 8;
+}
+// filtered value of reference index i (0..2n) of `a`, where b is the other array (for the corner)
+KVZ_HD int intra_filtered_ref(const uint8_t *a, const uint8_t *b, int n, int i, bool strong)
+{
+  if (strong) {
+    if (i == 0 || i == 64) return a[i];
+    return ((64 - i) * a[0] + i * a[64] + 32) >> 6;
+  }
+  if (i == 0) return (a[1] + 2 * a[0] + b[1] + 2) >> 2;
+  if (i == 2 * n) return a[i];
+  return (a[i + 1] + 2 * a[i] + a[i - 1] + 2) >> 2;
+}
+
+KVZ_HD int intra_ref_main(const uint8_t *main, const uint8_t *side, int inv, int i)
+{
+  // ref[i] for the angular modes: i >= 0 -> main[i]; i < 0 -> projected from the side array
+  return i >= 0 ? main[i] : side[(i * inv + 128) >> 8];
+}
+
+KVZ_HD int intra_pred_sample(const uint8_t *left, const uint8_t *top, int n, int log2n, int cidx, int mode, int dc, int x, int y)
+{
+  if (mode == 0) {
+    return ((n - 1 - x) * left[1 + y] + (x + 1) * top[1 + n] + (n - 1 - y) * top[1 + x] + (y + 1) * left[1 + n] + n) >> (log2n + 1);
+  }
+  if (mode == 1) {
+    if (cidx == 0 && n < 32) {
+      if (x == 0 && y == 0) return (left[1] + 2 * dc + top[1] + 2) >> 2;
+      if (y == 0) return (top[1 + x] + 3 * dc + 2) >> 2;
+      if (x == 0) return (left[1 + y] + 3 * dc + 2) >> 2;
+    }
+    return dc;
+  }
+  const int angle = kIntraAngle[mode], inv = kInvAngle[mode];
+  if (mode >= 18) {
+    if (mode == 26 && cidx == 0 && n < 32 && x == 0) return clip8(top[1] + ((left[1 + y] - left[0]) >> 1));
+    int idx = ((y + 1) * angle) >> 5, fact = ((y + 1) * angle) & 31;
+    int r0 = intra_ref_main(top, left, inv, x + idx + 1);
+    if (!fact) return r0;
+    int r1 = intra_ref_main(top, left, inv, x + idx + 2);
+    return ((32 - fact) * r0 + fact * r1 + 16) >> 5;
+  } else {
+    if (mode == 10 && cidx == 0 && n < 32 && y == 0) return clip8(left[1] + ((top[1 + x] - left[0]) >> 1));
+    int idx = ((x + 1) * angle) >> 5, fact = ((x + 1) * angle) & 31;
+    int r0 = intra_ref_main(left, top, inv, y + idx + 1);
+    if (!fact) return r0;
+    int r1 = intra_ref_main(left, top, inv, y + idx + 2);
+    return ((32 - fact) * r0 + fact * r1 + 16) >> 5;
+  }
+}
+
+// reference sample i of the 4n+1 samples in the order of 8.4.4.2.2 (i = 0: p[-1][2n-1] ...
+// i = 2n: corner ... i = 4n: p[2n-1][-1]) -> component-sample coordinates
+KVZ_HD void intra_ref_coord(int x0, int y0, int n, int i, int &x, int &y)
+{
+  if (i < 2 * n) { x = x0 - 1; y = y0 + 2 * n - 1 - i; }
+  else if (i == 2 * n) { x = x0 - 1; y = y0 - 1; }
+  else { x = x0 + (i - 2 * n - 1); y = y0 - 1; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deblocking (H.265 8.7.2): one 4-line luma edge segment / the chroma lines below it.
+// q0 points at sample q0 of line 0, xs steps across the edge, ls along it.
+// ---------------------------------------------------------------------------------------------
+KVZ_HD void deblock_luma_segment(uint8_t *q0p, int xs, int ls, int bs, int qp)
+{
+  int beta = kBetaTable[clip3(0, 51, qp)];
+  int tc = kTcTable[clip3(0, 53, qp + 2 * (bs - 1))];
+#define P_(i, l) q0p[-((i) + 1) * xs + (l) * ls]
+#define Q_(i, l) q0p[(i) * xs + (l) * ls]
+  int dp0 = iabs(P_(2, 0) - 2 * P_(1, 0) + P_(0, 0)), dp3 = iabs(P_(2, 3) - 2 * P_(1, 3) + P_(0, 3));
+  int dq0 = iabs(Q_(2, 0) - 2 * Q_(1, 0) + Q_(0, 0)), dq3 = iabs(Q_(2, 3) - 2 * Q_(1, 3) + Q_(0, 3));
+  int dpq0 = dp0 + dq0, dpq3 = dp3 + dq3, dp = dp0 + dp3, dq = dq0 + dq3;
+  if (dpq0 + dpq3 >= beta) return;
+  bool s0 = (2 * dpq0 < (beta >> 2)) && (iabs(P_(3, 0) - P_(0, 0)) + iabs(Q_(0, 0) - Q_(3, 0)) < (beta >> 3)) && (iabs(P_(0, 0) - Q_(0, 0)) < ((5 * tc + 1) >> 1));
+  bool s3 = (2 * dpq3 < (beta >> 2)) && (iabs(P_(3, 3) - P_(0, 3)) + iabs(Q_(0, 3) - Q_(3, 3)) < (beta >> 3)) && (iabs(P_(0, 3) - Q_(0, 3)) < ((5 * tc + 1) >> 1));
+  bool strong = s0 && s3;
+  bool dep = dp < ((beta + (beta >> 1)) >> 3), deq = dq < ((beta + (beta >> 1)) >> 3);
+  for (int l = 0; l < 4; l++) {
+    int p0 = P_(0, l), p1 = P_(1, l), p2 = P_(2, l), p3 = P_(3, l), q0 = Q_(0, l), q1 = Q_(1, l), q2 = Q_(2, l), q3 = Q_(3, l);
+    if (strong) {
+      P_(0, l) = (uint8_t)clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+      P_(1, l) = (uint8_t)clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2);
+      P_(2, l) = (uint8_t)clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+      Q_(0, l) = (uint8_t)clip3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+      Q_(1, l) = (uint8_t)clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2);
+      Q_(2, l) = (uint8_t)clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3);
+    } else {
+      int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+      if (iabs(delta) < tc * 10) {
+        delta = clip3(-tc, tc, delta);
+        P_(0, l) = (uint8_t)clip8(p0 + delta);
+        Q_(0, l) = (uint8_t)clip8(q0 - delta);
+        if (dep) P_(1, l) = (uint8_t)clip8(p1 + clip3(-(tc >> 1), tc >> 1, (((p2 + p0 + 1) >> 1) - p1 + delta) >> 1));
+        if (deq) Q_(1, l) = (uint8_t)clip8(q1 + clip3(-(tc >> 1), tc >> 1, (((q2 + q0 + 1) >> 1) - q1 - delta) >> 1));
+      }
+    }
+  }
+#undef P_
+#undef Q_
+}
+
+KVZ_HD void deblock_chroma_segment(uint8_t *q0p, int xs, int ls, int nlines, int qp_luma)
+{
+  int qpc = kChromaQp[clip3(0, 57, qp_luma)];
+  int tc = kTcTable[clip3(0, 53, qpc + 2)];
+  for (int l = 0; l < nlines; l++) {
+    uint8_t *q = q0p + l * ls;
+    int p0 = q[-xs], p1 = q[-2 * xs], q0 = q[0], q1 = q[xs];
+    int delta = clip3(-tc, tc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+    q[-xs] = (uint8_t)clip8(p0 + delta);
+    q[0] = (uint8_t)clip8(q0 - delta);
+  }
+}
+
+// Boundary strength (H.265 8.7.2.4) of the edge between the 8x8 blocks containing samples
+// (xp, yp) and (xq, yq); the caller has established that it is a CU (= TU = PU) boundary.
+KVZ_HD int edge_bs(const EncFrame &f, int xp, int yp, int xq, int yq)
+{
+  int ip = b8idx(f, xp, yp), iq = b8idx(f, xq, yq);
+  if (f.cu_intra[ip] || f.cu_intra[iq]) return 2;
+  if ((f.cu_cbf[ip] & 1) || (f.cu_cbf[iq] & 1)) return 1;
+  if (iabs(f.cu_mv[ip * 2] - f.cu_mv[iq * 2]) >= 4 || iabs(f.cu_mv[ip * 2 + 1] - f.cu_mv[iq * 2 + 1]) >= 4) return 1;
+  return 0;
+}
+// is luma column x (multiple of 8) a CU boundary at row y?  (CUs are aligned to their size)
+KVZ_HD bool is_cu_edge_v(const EncFrame &f, int x, int y) { return (x & ((1 << f.cu_log2[b8idx(f, x, y)]) - 1)) == 0; }
+KVZ_HD bool is_cu_edge_h(const EncFrame &f, int x, int y) { return (y & ((1 << f.cu_log2[b8idx(f, x, y)]) - 1)) == 0; }
+
+// ---------------------------------------------------------------------------------------------
+// scalar quantiser / dequantiser (flat scaling; see oracle/hevc_transform.c for the statement)
+// ---------------------------------------------------------------------------------------------
+KVZ_HD int quant_level(int coef, int qp, int log2n, int intra)
+{
+  int shift = 14 + qp / 6 + (15 - 8 - log2n);
+  int64_t off = (int64_t)(intra ? 171 : 85) << (shift - 9);
+  int a = coef < 0 ? -coef : coef;
+  int64_t q = ((int64_t)a * kQuantScale[qp % 6] + off) >> shift;
+  if (q > 32767) q = 32767;
+  return (int)(coef < 0 ? -q : q);
+}
+KVZ_HD int dequant_coef(int level, int qp, int log2n)
+{
+  int bd = 8 + log2n - 5;
+  int scale = kLevelScale[qp % 6] << (qp / 6);
+  int64_t v = ((int64_t)level * 16 * scale + ((int64_t)1 << (bd - 1))) >> bd;
+  return (int)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+}
+
+}  // namespace kvzx

@@ -1,0 +1,164 @@
+// kvazzup_amd/csrc/hevc_headers.h -- host-side bit writer, parameter sets (H.265 7.3.2), slice
+// segment header (7.3.6.1) and NAL framing (7.3.1.1, Annex B) for the encoder's fixed tool set.
+// Replaces the bitstream assembly Kvazaar does at the end of encoder_encode
+// (/root/reference/src/media/processing/kvazaarfilter.cpp:435-438,469-474 consume its chunks).
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+namespace kvzx {
+
+class BitWriter {
+ public:
+  void put(uint32_t v, int n) { for (int i = n - 1; i >= 0; i--) bit((v >> i) & 1u); }
+  void bit(uint32_t b) { cur_ = (cur_ << 1) | (b & 1u); if (++n_ == 8) { buf_.push_back((uint8_t)cur_); cur_ = 0; n_ = 0; } }
+  void ue(uint32_t v) { uint32_t x = v + 1; int len = 0; while ((x >> len) > 1) len++; put(0, len); put(x, len + 1); }
+  void se(int32_t v) { ue(v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v)); }
+  void trailing() { bit(1); while (n_) bit(0); }
+  bool aligned() const { return n_ == 0; }
+  void bytes(const uint8_t *p, size_t n) { buf_.insert(buf_.end(), p, p + n); }
+  std::vector<uint8_t> &data() { return buf_; }
+ private:
+  std::vector<uint8_t> buf_; uint32_t cur_ = 0; int n_ = 0;
+};
+
+struct StreamParams {
+  int cw, ch;               // coded size
+  int width, height;        // display size (conformance window)
+  int qp, wpp, deblock;
+  int fps_num, fps_den;
+};
+
+inline int level_idc_for(int w, int h)
+{
+  long px = (long)w * h;
+  return px <= 2228224 ? 123 : (px <= 8912896 ? 153 : 183);
+}
+
+inline void write_ptl(BitWriter &w, int level)
+{
+  w.put(0, 2); w.put(0, 1); w.put(1, 5);                         // profile space, tier, Main
+  for (int j = 0; j < 32; j++) w.bit(j == 1 || j == 2);
+  w.bit(1); w.bit(0); w.bit(0); w.bit(1);                        // progressive, interlaced, non-packed, frame-only
+  w.put(0, 32); w.put(0, 11); w.bit(0);
+  w.put((uint32_t)level, 8);
+}
+
+inline void write_vps(BitWriter &w, const StreamParams &s)
+{
+  w.put(0, 4); w.put(3, 2); w.put(0, 6); w.put(0, 3); w.bit(1); w.put(0xffff, 16);
+  write_ptl(w, level_idc_for(s.cw, s.ch));
+  w.bit(1); w.ue(1); w.ue(0); w.ue(0);                           // ordering info: dpb 2, no reorder
+  w.put(0, 6); w.ue(0);
+  w.bit(1); w.put((uint32_t)s.fps_den, 32); w.put((uint32_t)s.fps_num, 32); w.bit(0); w.ue(0);
+  w.bit(0);
+  w.trailing();
+}
+
+inline void write_sps(BitWriter &w, const StreamParams &s)
+{
+  w.put(0, 4); w.put(0, 3); w.bit(1);
+  write_ptl(w, level_idc_for(s.cw, s.ch));
+  w.ue(0); w.ue(1); w.ue((uint32_t)s.cw); w.ue((uint32_t)s.ch);
+  bool crop = s.cw != s.width || s.ch != s.height;
+  w.bit(crop);
+  if (crop) { w.ue(0); w.ue((uint32_t)(s.cw - s.width) / 2); w.ue(0); w.ue((uint32_t)(s.ch - s.height) / 2); }
+  w.ue(0); w.ue(0); w.ue(4);                                     // 8-bit, log2_max_poc_lsb 8
+  w.bit(1); w.ue(1); w.ue(0); w.ue(0);
+  w.ue(0); w.ue(3); w.ue(0); w.ue(3);                            // CB 8..64, TB 4..32
+  w.ue(0); w.ue(0);                                              // transform hierarchy depths
+  w.bit(0); w.bit(0); w.bit(0); w.bit(0);                        // scaling list, amp, sao, pcm
+  w.ue(1); w.ue(1); w.ue(0); w.ue(0); w.bit(1);                  // one short-term RPS: previous picture
+  w.bit(0); w.bit(0); w.bit(1);                                  // long-term, tmvp, strong intra smoothing
+  w.bit(1);                                                      // VUI: timing only
+  w.put(0, 8);
+  w.bit(1); w.put((uint32_t)s.fps_den, 32); w.put((uint32_t)s.fps_num, 32); w.bit(0); w.bit(0);
+  w.bit(0);
+  w.bit(0);
+  w.trailing();
+}
+
+inline void write_pps(BitWriter &w, const StreamParams &s)
+{
+  w.ue(0); w.ue(0);
+  w.bit(0); w.bit(0); w.put(0, 3); w.bit(0); w.bit(0);
+  w.ue(0); w.ue(0);
+  w.se(s.qp - 26);
+  w.bit(0); w.bit(0); w.bit(0);                                  // constrained intra, transform skip, cu_qp_delta
+  w.se(0); w.se(0); w.bit(0);
+  w.bit(0); w.bit(0); w.bit(0);
+  w.bit(0); w.bit(s.wpp);                                        // tiles, entropy_coding_sync
+  w.bit(1);                                                      // loop filter across slices
+  w.bit(!s.deblock);
+  if (!s.deblock) { w.bit(0); w.bit(1); }
+  w.bit(0); w.bit(0); w.ue(0); w.bit(0); w.bit(0);
+  w.trailing();
+}
+
+inline size_t escaped_size(const uint8_t *p, size_t n)
+{
+  size_t out = 0; int zeros = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (zeros >= 2 && p[i] <= 3) { out++; zeros = 0; }
+    out++; zeros = p[i] == 0 ? zeros + 1 : 0;
+  }
+  return out;
+}
+
+inline void write_slice_header(BitWriter &w, const StreamParams &s, bool idr, int poc, const std::vector<uint32_t> &entry_sizes)
+{
+  w.bit(1);
+  if (idr) w.bit(0);
+  w.ue(0);
+  w.ue(idr ? 2 : 1);
+  if (!idr) { w.put((uint32_t)poc & 255, 8); w.bit(1); }
+  if (!idr) { w.bit(0); w.ue(0); }                               // num_ref_idx override, five_minus_max_num_merge_cand
+  w.se(0);
+  // (deblocking override not enabled; slice_loop_filter_across_slices_enabled_flag present when deblocking is on)
+  if (s.deblock) w.bit(1);
+  if (s.wpp) {
+    w.ue((uint32_t)entry_sizes.size());
+    if (!entry_sizes.empty()) {
+      uint32_t mx = 0; for (uint32_t e : entry_sizes) if (e - 1 > mx) mx = e - 1;
+      int len = 1; while (len < 32 && (mx >> len)) len++;
+      w.ue((uint32_t)len - 1);
+      for (uint32_t e : entry_sizes) w.put(e - 1, len);
+    }
+  }
+  w.trailing();
+}
+
+// Append a NAL unit with a 4-byte start code and emulation prevention.
+inline void append_nal(std::vector<uint8_t> &out, int nal_type, const uint8_t *rbsp, size_t n)
+{
+  out.push_back(0); out.push_back(0); out.push_back(0); out.push_back(1);
+  out.push_back((uint8_t)(nal_type << 1)); out.push_back(1);
+  int zeros = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (zeros >= 2 && rbsp[i] <= 3) { out.push_back(3); zeros = 0; }
+    out.push_back(rbsp[i]);
+    zeros = rbsp[i] == 0 ? zeros + 1 : 0;
+  }
+}
+
+// One access unit: [VPS SPS PPS] + slice NAL whose data are the `nsub` substreams (CTU rows with
+// WPP, otherwise one) found at rows + r * row_pitch with lengths lens[r].
+inline void assemble_access_unit(std::vector<uint8_t> &au, const StreamParams &sp, bool idr, int poc, bool write_ps,
+                                 const uint8_t *rows, size_t row_pitch, const int32_t *lens, int nsub)
+{
+  au.clear();
+  if (write_ps) {
+    BitWriter a, b, c;
+    write_vps(a, sp); append_nal(au, 32, a.data().data(), a.data().size());
+    write_sps(b, sp); append_nal(au, 33, b.data().data(), b.data().size());
+    write_pps(c, sp); append_nal(au, 34, c.data().data(), c.data().size());
+  }
+  std::vector<uint32_t> entry;
+  for (int r = 0; r + 1 < nsub; r++) entry.push_back((uint32_t)escaped_size(rows + (size_t)r * row_pitch, (size_t)lens[r]));
+  BitWriter sh;
+  write_slice_header(sh, sp, idr, poc, entry);
+  for (int r = 0; r < nsub; r++) sh.bytes(rows + (size_t)r * row_pitch, (size_t)lens[r]);
+  append_nal(au, idr ? 19 : 1, sh.data().data(), sh.data().size());
+}
+
+}  // namespace kvzx

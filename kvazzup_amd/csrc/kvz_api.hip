@@ -1,0 +1,378 @@
+// kvazzup_amd/csrc/kvz_api.hip -- the kvz_api function table (include/kvazaar.h) and the encoder
+// extensions (include/kvazzup_amd.h) on top of kvzx::Encoder.
+// Drop-in for the calls uvgComm makes at /root/reference/src/media/processing/kvazaarfilter.cpp:
+// 145-299 (configuration), 407-449 (encode loop), 456-476 (chunk / recon hand-back), 313-329 (close).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include "../../include/kvazzup_amd.h"
+#include "encoder.h"
+
+using kvzx::Encoder;
+using kvzx::EncoderConfig;
+using kvzx::EncodedPicture;
+
+struct kvz_encoder {
+  Encoder *impl;
+  kvz_config cfg;
+  uint64_t last_bins;
+  int warned_rc;
+};
+
+namespace {
+
+// ----------------------------------------------------------------------------- config
+kvz_config *config_alloc(void) { return (kvz_config *)calloc(1, sizeof(kvz_config)); }
+int config_destroy(kvz_config *cfg) { free(cfg); return 1; }
+
+int config_init(kvz_config *cfg)
+{
+  if (!cfg) return 0;
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->qp = 22; cfg->intra_period = 64; cfg->vps_period = 0;
+  cfg->framerate = 25.0; cfg->framerate_num = 25; cfg->framerate_denom = 1;
+  cfg->deblock_enable = 1; cfg->sao_type = KVZ_SAO_OFF;
+  cfg->ime_algorithm = KVZ_IME_HEXBS; cfg->fme_level = 0; cfg->ref_frames = 1;
+  cfg->tiles_width_count = 1; cfg->tiles_height_count = 1;
+  cfg->wpp = 1; cfg->owf = 0; cfg->max_merge = 5; cfg->early_skip = 1;
+  cfg->gop_lowdelay = 1; cfg->gop_len = 0; cfg->gop_lp_ref_depth = 1; cfg->gop_lp_temporal_layers = 1;
+  cfg->mv_constraint = KVZ_MV_CONSTRAIN_NONE; cfg->hash = KVZ_HASH_NONE;
+  cfg->pu_depth_inter_min = 1; cfg->pu_depth_inter_max = 2; cfg->pu_depth_intra_min = 1; cfg->pu_depth_intra_max = 3;
+  cfg->me_range = 16; cfg->gpu_device = 0; cfg->recon_output = 1;
+  return 1;
+}
+
+bool parse_bool(const char *v, int *out)
+{
+  if (!strcmp(v, "1") || !strcmp(v, "true") || !strcmp(v, "yes") || !strcmp(v, "on")) { *out = 1; return true; }
+  if (!strcmp(v, "0") || !strcmp(v, "false") || !strcmp(v, "no") || !strcmp(v, "off")) { *out = 0; return true; }
+  return false;
+}
+bool parse_int(const char *v, int *out)
+{
+  char *end = nullptr; long x = strtol(v, &end, 10);
+  if (end == v || *end) return false;
+  *out = (int)x; return true;
+}
+
+int config_parse(kvz_config *cfg, const char *name, const char *value)
+{
+  if (!cfg || !name) return 0;
+  if (!value) value = "true";
+  std::string n(name);
+  int iv = 0;
+#define INT_OPT(key, field, lo, hi) if (n == key) { if (!parse_int(value, &iv) || iv < (lo) || iv > (hi)) return 0; cfg->field = iv; return 1; }
+#define BOOL_OPT(key, field) if (n == key) { if (!parse_bool(value, &iv)) { cfg->field = 0; return *value ? 0 : 1; } cfg->field = iv; return 1; }
+  if (n == "preset") {
+    static const char *presets[] = {"ultrafast", "superfast", "veryfast", "faster", "fast", "medium", "slow", "slower", "veryslow", "placebo"};
+    for (const char *p : presets) if (!strcmp(value, p)) return 1;    // every preset maps onto the one GPU tool set
+    return 0;
+  }
+  if (n == "input-res") {
+    int w = 0, h = 0;
+    if (sscanf(value, "%dx%d", &w, &h) != 2 || w <= 0 || h <= 0) return 0;
+    cfg->width = w; cfg->height = h; return 1;
+  }
+  if (n == "input-fps") {
+    int a = 0, b = 1;
+    if (sscanf(value, "%d/%d", &a, &b) == 2 && a > 0 && b > 0) { cfg->framerate_num = a; cfg->framerate_denom = b; cfg->framerate = (double)a / b; return 1; }
+    double f = atof(value);
+    if (f <= 0) return 0;
+    cfg->framerate = f; cfg->framerate_num = (int)(f * 1000 + 0.5); cfg->framerate_denom = 1000;
+    if (cfg->framerate_num % 1000 == 0) { cfg->framerate_num /= 1000; cfg->framerate_denom = 1; }
+    return 1;
+  }
+  if (n == "threads") { if (!strcmp(value, "auto")) { cfg->threads = -1; return 1; } INT_OPT("threads", threads, -1, 4096) }
+  INT_OPT("owf", owf, 0, 64)
+  BOOL_OPT("wpp", wpp)
+  if (n == "tiles") {
+    int a = 0, b = 0;
+    if (sscanf(value, "%dx%d", &a, &b) != 2 || a < 1 || b < 1) return 0;
+    cfg->tiles_width_count = a; cfg->tiles_height_count = b;
+    return (a == 1 && b == 1) ? 1 : 0;            // tile partitioning is not implemented
+  }
+  if (n == "slices") {
+    if (!strcmp(value, "wpp")) { cfg->slices = KVZ_SLICES_WPP; return 1; }
+    if (!strcmp(value, "tiles")) { cfg->slices = KVZ_SLICES_TILES; return 1; }
+    if (!strcmp(value, "none") || !strcmp(value, "0")) { cfg->slices = KVZ_SLICES_NONE; return 1; }
+    return 0;
+  }
+  INT_OPT("qp", qp, 0, 51)
+  INT_OPT("period", intra_period, 0, 1 << 30)
+  INT_OPT("vps-period", vps_period, 0, 1 << 30)
+  INT_OPT("bitrate", target_bitrate, 0, 1 << 30)
+  if (n == "rc-algorithm") {
+    if (!strcmp(value, "lambda")) { cfg->rc_algorithm = KVZ_LAMBDA; return 1; }
+    if (!strcmp(value, "oba")) { cfg->rc_algorithm = KVZ_OBA; return 1; }
+    if (!strcmp(value, "no-rc") || !strcmp(value, "0")) { cfg->rc_algorithm = KVZ_NO_RC; return 1; }
+    return 0;
+  }
+  BOOL_OPT("intra-bits", intra_bits)
+  if (n == "gop") {
+    int g = 0, d = 0, t = 0;
+    if (sscanf(value, "lp-g%dd%dt%d", &g, &d, &t) == 3 && g >= 1 && g <= KVZ_MAX_GOP_LENGTH && d >= 1 && t >= 1) {
+      cfg->gop_lowdelay = 1; cfg->gop_len = g; cfg->gop_lp_ref_depth = d; cfg->gop_lp_temporal_layers = t; return 1;
+    }
+    if (!strcmp(value, "0")) { cfg->gop_len = 0; cfg->gop_lowdelay = 1; return 1; }
+    return 0;                                      // hierarchical-B GOPs are not implemented
+  }
+  if (n == "scaling-list") {
+    if (!strcmp(value, "off") || !strcmp(value, "0")) { cfg->scaling_list = KVZ_SCALING_LIST_OFF; return 1; }
+    return 0;
+  }
+  if (n == "mv-constraint") {
+    if (!*value || !strcmp(value, "none")) { cfg->mv_constraint = KVZ_MV_CONSTRAIN_NONE; return 1; }
+    if (!strcmp(value, "frame")) { cfg->mv_constraint = KVZ_MV_CONSTRAIN_FRAME; return 1; }
+    if (!strcmp(value, "tile")) { cfg->mv_constraint = KVZ_MV_CONSTRAIN_TILE; return 1; }
+    if (!strcmp(value, "frametile")) { cfg->mv_constraint = KVZ_MV_CONSTRAIN_FRAME_AND_TILE; return 1; }
+    if (!strcmp(value, "frametilemargin")) { cfg->mv_constraint = KVZ_MV_CONSTRAIN_FRAME_AND_TILE_MARGIN; return 1; }
+    return 0;
+  }
+  INT_OPT("vaq", vaq, 0, 20)
+  if (n == "deblock") {
+    int b = 0, t = 0;
+    if (sscanf(value, "%d:%d", &b, &t) == 2) { cfg->deblock_enable = 1; cfg->deblock_beta = b; cfg->deblock_tc = t; return (b == 0 && t == 0) ? 1 : 0; }
+    if (parse_bool(value, &iv)) { cfg->deblock_enable = iv; return 1; }
+    return 0;
+  }
+  if (n == "sao") {
+    if (!strcmp(value, "off") || !strcmp(value, "0") || !strcmp(value, "false")) { cfg->sao_type = KVZ_SAO_OFF; return 1; }
+    return 0;
+  }
+  if (n == "me") {
+    static const char *names[] = {"hexbs", "tz", "full", "full8", "full16", "full32", "full64", "dia"};
+    for (int i = 0; i < 8; i++) if (!strcmp(value, names[i])) { cfg->ime_algorithm = (kvz_ime_algorithm)i; return 1; }
+    return 0;
+  }
+  INT_OPT("subme", fme_level, 0, 4)
+  INT_OPT("rd", rdo, 0, 3)
+  INT_OPT("ref", ref_frames, 1, 15)
+  INT_OPT("max-merge", max_merge, 1, 5)
+  INT_OPT("me-steps", me_max_steps, -1, 1 << 20)
+  INT_OPT("fast-residual-cost", fast_residual_cost_limit, 0, 51)
+  INT_OPT("me-range", me_range, 1, 32)
+  INT_OPT("gpu", gpu_device, 0, 64)
+  BOOL_OPT("recon-output", recon_output)
+  BOOL_OPT("rdoq", rdoq_enable) BOOL_OPT("signhide", signhide_enable) BOOL_OPT("smp", smp_enable) BOOL_OPT("amp", amp_enable)
+  BOOL_OPT("bipred", bipred) BOOL_OPT("tmvp", tmvp_enable) BOOL_OPT("transform-skip", trskip_enable)
+  BOOL_OPT("full-intra-search", full_intra_search) BOOL_OPT("mv-rdo", mv_rdo) BOOL_OPT("rdoq-skip", rdoq_skip)
+  BOOL_OPT("early-skip", early_skip) BOOL_OPT("intra-rdo-et", intra_rdo_et) BOOL_OPT("lossless", lossless)
+  BOOL_OPT("set-qp-in-cu", set_qp_in_cu) BOOL_OPT("psnr", calc_psnr) BOOL_OPT("cpuid", cpuid) BOOL_OPT("implicit-rdpcm", implicit_rdpcm)
+  if (n == "cu-split-termination") { cfg->cu_split_termination = !strcmp(value, "off"); return (!strcmp(value, "zero") || !strcmp(value, "off")) ? 1 : 0; }
+  if (n == "me-early-termination") {
+    if (!strcmp(value, "off")) cfg->me_early_termination = 0; else if (!strcmp(value, "on")) cfg->me_early_termination = 1;
+    else if (!strcmp(value, "sensitive")) cfg->me_early_termination = 2; else return 0;
+    return 1;
+  }
+  if (n == "hash") {
+    if (!strcmp(value, "none")) { cfg->hash = KVZ_HASH_NONE; return 1; }
+    return 0;
+  }
+  if (n == "pu-depth-inter" || n == "pu-depth-intra") {
+    int a = 0, b = 0;
+    if (sscanf(value, "%d-%d", &a, &b) != 2 || a < 0 || b > 4 || a > b) return 0;
+    if (n == "pu-depth-inter") { cfg->pu_depth_inter_min = a; cfg->pu_depth_inter_max = b; }
+    else { cfg->pu_depth_intra_min = a; cfg->pu_depth_intra_max = b; }
+    return 1;
+  }
+  if (n == "info" || n == "aud" || n == "open-gop") return parse_bool(value, &iv) ? 1 : 0;
+#undef INT_OPT
+#undef BOOL_OPT
+  return 0;     // unknown option (kvazaarfilter.cpp:363-367 logs these)
+}
+
+// ----------------------------------------------------------------------------- pictures, chunks
+kvz_picture *picture_alloc_csp(enum kvz_chroma_format csp, int32_t width, int32_t height)
+{
+  if (csp != KVZ_CSP_420 || width <= 0 || height <= 0 || (width & 1) || (height & 1)) return nullptr;
+  kvz_picture *p = (kvz_picture *)calloc(1, sizeof(kvz_picture));
+  if (!p) return nullptr;
+  size_t ny = (size_t)width * height;
+  p->fulldata_buf = (kvz_pixel *)malloc(ny * 3 / 2 + 64);
+  if (!p->fulldata_buf) { free(p); return nullptr; }
+  p->fulldata = p->fulldata_buf;
+  p->y = p->data[0] = p->fulldata; p->u = p->data[1] = p->fulldata + ny; p->v = p->data[2] = p->fulldata + ny + ny / 4;
+  p->width = width; p->height = height; p->stride = width;
+  p->refcount = 1; p->chroma_format = KVZ_CSP_420; p->interlacing = KVZ_INTERLACING_NONE;
+  return p;
+}
+kvz_picture *picture_alloc(int32_t width, int32_t height) { return picture_alloc_csp(KVZ_CSP_420, width, height); }
+void picture_free(kvz_picture *pic)
+{
+  if (!pic) return;
+  if (--pic->refcount > 0) return;
+  free(pic->fulldata_buf);
+  free(pic);      // roi.roi_array belongs to the caller (kvazaarfilter.cpp:53,459-463)
+}
+void chunk_free(kvz_data_chunk *chunk)
+{
+  while (chunk) { kvz_data_chunk *n = chunk->next; free(chunk); chunk = n; }
+}
+kvz_data_chunk *make_chunks(const uint8_t *data, size_t len)
+{
+  kvz_data_chunk *head = nullptr, *tail = nullptr;
+  for (size_t pos = 0; pos < len || !head; pos += KVZ_DATA_CHUNK_SIZE) {
+    kvz_data_chunk *c = (kvz_data_chunk *)malloc(sizeof(kvz_data_chunk));
+    if (!c) { chunk_free(head); return nullptr; }
+    size_t n = len - pos < KVZ_DATA_CHUNK_SIZE ? len - pos : KVZ_DATA_CHUNK_SIZE;
+    memcpy(c->data, data + pos, n); c->len = (uint32_t)n; c->next = nullptr;
+    if (tail) tail->next = c; else head = c;
+    tail = c;
+    if (len == 0) break;
+  }
+  return head;
+}
+
+// ----------------------------------------------------------------------------- encoder
+kvz_encoder *encoder_open(const kvz_config *cfg)
+{
+  if (!cfg) return nullptr;
+  if (cfg->lossless) { fprintf(stderr, "kvazzup_amd: lossless coding is not implemented\n"); return nullptr; }
+  if (cfg->tiles_width_count != 1 || cfg->tiles_height_count != 1) { fprintf(stderr, "kvazzup_amd: tiles are not implemented\n"); return nullptr; }
+  EncoderConfig ec;
+  ec.width = cfg->width; ec.height = cfg->height; ec.qp = cfg->qp; ec.intra_period = cfg->intra_period; ec.vps_period = cfg->vps_period;
+  ec.me_range = cfg->me_range; ec.fps_num = cfg->framerate_num; ec.fps_den = cfg->framerate_denom;
+  ec.wpp = cfg->wpp ? 1 : 0; ec.deblock = cfg->deblock_enable ? 1 : 0; ec.device = cfg->gpu_device;
+  std::string err;
+  Encoder *impl = Encoder::create(ec, &err);
+  if (!impl) { fprintf(stderr, "kvazzup_amd: encoder_open failed: %s\n", err.c_str()); return nullptr; }
+  kvz_encoder *e = new kvz_encoder();
+  e->impl = impl; e->cfg = *cfg; e->last_bins = 0; e->warned_rc = 0;
+  if (cfg->target_bitrate != 0) {
+    fprintf(stderr, "kvazzup_amd: rate control is not implemented; coding at constant QP %d\n", cfg->qp);
+    e->warned_rc = 1;
+  }
+  return e;
+}
+void encoder_close(kvz_encoder *e)
+{
+  if (!e) return;
+  delete e->impl;
+  delete e;
+}
+
+void fill_info(kvz_encoder *e, const EncodedPicture &ep, kvz_frame_info *info)
+{
+  if (!info) return;
+  memset(info, 0, sizeof(*info));
+  info->poc = ep.poc; info->qp = (int8_t)e->cfg.qp;
+  info->nal_unit_type = ep.is_intra ? KVZ_NAL_IDR_W_RADL : KVZ_NAL_TRAIL_R;
+  info->slice_type = ep.is_intra ? KVZ_SLICE_I : KVZ_SLICE_P;
+  if (!ep.is_intra) { info->ref_list_len[0] = 1; info->ref_list[0][0] = ep.poc - 1; }
+}
+
+int encoder_headers(kvz_encoder *e, kvz_data_chunk **data_out, uint32_t *len_out)
+{
+  if (!e || !data_out) return 0;
+  kvzx::StreamParams sp;
+  const EncoderConfig &c = e->impl->config();
+  sp.cw = e->impl->coded_width(); sp.ch = e->impl->coded_height(); sp.width = c.width; sp.height = c.height; sp.qp = c.qp;
+  sp.wpp = c.wpp; sp.deblock = c.deblock; sp.fps_num = c.fps_num; sp.fps_den = c.fps_den;
+  std::vector<uint8_t> out;
+  kvzx::BitWriter a, b, d;
+  kvzx::write_vps(a, sp); kvzx::append_nal(out, 32, a.data().data(), a.data().size());
+  kvzx::write_sps(b, sp); kvzx::append_nal(out, 33, b.data().data(), b.data().size());
+  kvzx::write_pps(d, sp); kvzx::append_nal(out, 34, d.data().data(), d.data().size());
+  *data_out = make_chunks(out.data(), out.size());
+  if (len_out) *len_out = (uint32_t)out.size();
+  return *data_out ? 1 : 0;
+}
+
+int encoder_encode(kvz_encoder *e, kvz_picture *pic_in, kvz_data_chunk **data_out, uint32_t *len_out,
+                   kvz_picture **pic_out, kvz_picture **src_out, kvz_frame_info *info_out)
+{
+  if (data_out) *data_out = nullptr;
+  if (len_out) *len_out = 0;
+  if (pic_out) *pic_out = nullptr;
+  if (src_out) *src_out = nullptr;
+  if (!e) return 0;
+  if (!pic_in) return 1;                       // flush: pictures are never held back, nothing is pending
+  if (pic_in->width != e->cfg.width || pic_in->height != e->cfg.height || !pic_in->y || !pic_in->u || !pic_in->v) return 0;
+  EncodedPicture ep;
+  if (!e->impl->encode_host(pic_in->y, pic_in->u, pic_in->v, &ep)) return 0;
+  e->last_bins = ep.bins;
+  if (data_out) { *data_out = make_chunks(ep.au.data(), ep.au.size()); if (!*data_out) return 0; }
+  if (len_out) *len_out = (uint32_t)ep.au.size();
+  if (pic_out && e->cfg.recon_output) {
+    kvz_picture *r = picture_alloc(e->cfg.width, e->cfg.height);
+    if (!r || !e->impl->download_recon(r->y, r->u, r->v)) { picture_free(r); return 0; }
+    r->pts = pic_in->pts; r->dts = pic_in->dts;
+    *pic_out = r;
+  }
+  if (src_out) { pic_in->refcount++; *src_out = pic_in; }
+  fill_info(e, ep, info_out);
+  return 1;
+}
+
+const kvz_api kApi = {
+  config_alloc, config_destroy, config_init, config_parse,
+  picture_alloc, picture_free, chunk_free,
+  encoder_open, encoder_close, encoder_headers, encoder_encode, picture_alloc_csp,
+};
+
+}  // namespace
+
+extern "C" {
+
+const kvz_api *kvz_api_get(int bit_depth) { return bit_depth == 8 ? &kApi : nullptr; }
+
+const char *kvzx_version(void) { return "kvazzup_amd 0.1 (gfx950)"; }
+int kvzx_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+
+static int finish_raw(kvz_encoder *e, const EncodedPicture &ep, uint8_t *au_buf, uint32_t au_cap, uint32_t *len_out, kvz_frame_info *info)
+{
+  e->last_bins = ep.bins;
+  if (len_out) *len_out = (uint32_t)ep.au.size();
+  fill_info(e, ep, info);
+  if (ep.au.size() > au_cap || !au_buf) return 0;
+  memcpy(au_buf, ep.au.data(), ep.au.size());
+  return 1;
+}
+int kvzx_encoder_encode_device(kvz_encoder *e, const void *d_i420, uint8_t *au_buf, uint32_t au_cap, uint32_t *len_out, kvz_frame_info *info)
+{
+  if (!e || !d_i420) return 0;
+  EncodedPicture ep;
+  if (!e->impl->encode_device((const uint8_t *)d_i420, &ep)) return 0;
+  return finish_raw(e, ep, au_buf, au_cap, len_out, info);
+}
+int kvzx_encoder_encode_host(kvz_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v, uint8_t *au_buf, uint32_t au_cap,
+                             uint32_t *len_out, kvz_frame_info *info)
+{
+  if (!e || !y || !u || !v) return 0;
+  EncodedPicture ep;
+  if (!e->impl->encode_host(y, u, v, &ep)) return 0;
+  return finish_raw(e, ep, au_buf, au_cap, len_out, info);
+}
+int kvzx_encoder_coded_size(kvz_encoder *e, int *cw, int *ch)
+{
+  if (!e) return 0;
+  if (cw) *cw = e->impl->coded_width();
+  if (ch) *ch = e->impl->coded_height();
+  return 1;
+}
+int kvzx_encoder_download_recon(kvz_encoder *e, uint8_t *y, uint8_t *u, uint8_t *v) { return e && e->impl->download_recon(y, u, v) ? 1 : 0; }
+int kvzx_encoder_recon_device(kvz_encoder *e, const void **planes)
+{
+  if (!e || !planes) return 0;
+  for (int c = 0; c < 3; c++) planes[c] = e->impl->device_recon(c);
+  return 1;
+}
+int kvzx_encoder_debug_copy(kvz_encoder *e, const char *what, void *dst, size_t bytes) { return e && what && e->impl->debug_copy(what, dst, bytes) ? 1 : 0; }
+void kvzx_encoder_set_profiling(kvz_encoder *e, int on) { if (e) e->impl->set_profiling(on != 0); }
+int kvzx_encoder_kernel_times(kvz_encoder *e, double *ms, uint64_t *launches, int reset)
+{
+  if (!e) return 0;
+  double m[kvzx::K_COUNT]; uint64_t n[kvzx::K_COUNT];
+  e->impl->get_kernel_times(m, n, reset != 0);
+  for (int i = 0; i < kvzx::K_COUNT; i++) { if (ms) ms[i] = m[i]; if (launches) launches[i] = n[i]; }
+  return kvzx::K_COUNT;
+}
+const char *kvzx_encoder_kernel_name(int id)
+{
+  static const char *names[kvzx::K_COUNT] = {"k_pad_input", "k_me", "k_inter_recon", "k_inter_signal", "k_intra_analyse", "k_intra_recon", "k_deblock", "k_entropy"};
+  return (id >= 0 && id < kvzx::K_COUNT) ? names[id] : nullptr;
+}
+uint64_t kvzx_encoder_last_bins(kvz_encoder *e) { return e ? e->last_bins : 0; }
+
+}  // extern "C"

@@ -60,3 +60,27 @@ int orc_api_closed_loop(int w, int h, int frames, int qp, int period, int range,
   free(in); free(rec); orc_enc_close(e); orc_dec_close(d);
   return bad;
 }
+
+/* ---- thin wrappers for ctypes ---- */
+orc_encoder *orc_api_enc_open(int w, int h, int qp, int period, int vps_period, int range, int fps_num, int fps_den, int wpp, int deblock)
+{
+  orc_enc_config c; orc_enc_default_config(&c);
+  c.width = w; c.height = h; c.qp = qp; c.intra_period = period; c.vps_period = vps_period; c.search_range = range;
+  c.fps_num = fps_num; c.fps_den = fps_den; c.wpp = wpp; c.deblock = deblock;
+  return orc_enc_open(&c);
+}
+/* returns AU size; copies it to out when it fits */
+long orc_api_enc_encode(orc_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v, uint8_t *out, long cap)
+{
+  const uint8_t *au; size_t n = orc_enc_encode(e, y, u, v, &au);
+  if ((long)n <= cap) memcpy(out, au, n);
+  return (long)n;
+}
+/* split an Annex-B access unit into NAL units (4-byte start codes): writes offsets, returns count */
+int orc_api_split_nals(const uint8_t *au, long n, long *offsets, int max)
+{
+  int cnt = 0;
+  for (long i = 0; i + 3 < n; i++)
+    if (au[i] == 0 && au[i + 1] == 0 && au[i + 2] == 0 && au[i + 3] == 1) { if (cnt < max) offsets[cnt] = i; cnt++; i += 3; }
+  return cnt;
+}

@@ -1,0 +1,153 @@
+// tests/hostcheck/hostcheck.cpp -- TEST-ONLY host build of the serial building blocks of the HIP
+// path (kvazzup_amd/csrc/hevc_core.h, hevc_headers.h) so that `pytest -m "not gpu"` can check the
+// product's CABAC writer, CU syntax, merge/AMVP signalling, intra prediction and deblocking
+// against oracle/ without a GPU.  Nothing in the product links this file; the product has no CPU
+// path (kvzx::Encoder::create fails without a HIP device).
+#include <cstring>
+#include <vector>
+#include "../../kvazzup_amd/csrc/hevc_core.h"
+#include "../../kvazzup_amd/csrc/hevc_headers.h"
+
+using namespace kvzx;
+
+extern "C" {
+
+// copy of a normative table for cross-checks: which = 0 dct32 (1024 int8), 1 rangeLps (256), 2 nextLps (64),
+// 3 cabac init values (3*CTX_COUNT), 4 lambda (52 u16)
+int hc_table(int which, void *dst)
+{
+  switch (which) {
+    case 0: memcpy(dst, kDct32, sizeof(kDct32)); return (int)sizeof(kDct32);
+    case 1: memcpy(dst, kRangeLps, sizeof(kRangeLps)); return (int)sizeof(kRangeLps);
+    case 2: memcpy(dst, kNextLps, sizeof(kNextLps)); return (int)sizeof(kNextLps);
+    case 3: memcpy(dst, kCabacInit, sizeof(kCabacInit)); return (int)sizeof(kCabacInit);
+    case 4: memcpy(dst, kLambdaQ4, sizeof(kLambdaQ4)); return (int)sizeof(kLambdaQ4);
+  }
+  return 0;
+}
+
+struct HcFrame {
+  int cw, ch, width, height, qp, is_intra, poc, wpp, deblock, fps_num, fps_den, write_ps;
+  uint8_t *cu_log2, *cu_intra, *cu_flags, *cu_merge_idx, *cu_mvp_idx, *cu_intra_mode, *cu_cbf;
+  int16_t *cu_mv, *cu_mvd;
+  int16_t *coef[3];
+};
+
+static void fill(EncFrame &f, const HcFrame &h)
+{
+  memset(&f, 0, sizeof(f));
+  f.cw = h.cw; f.ch = h.ch; f.b8w = h.cw / 8; f.b8h = h.ch / 8; f.qp = h.qp; f.qpc = kChromaQp[h.qp];
+  f.lambda_q4 = kLambdaQ4[h.qp]; f.is_intra = h.is_intra; f.poc = h.poc; f.wpp = h.wpp;
+  f.cu_log2 = h.cu_log2; f.cu_intra = h.cu_intra; f.cu_flags = h.cu_flags; f.cu_merge_idx = h.cu_merge_idx;
+  f.cu_mvp_idx = h.cu_mvp_idx; f.cu_intra_mode = h.cu_intra_mode; f.cu_cbf = h.cu_cbf; f.cu_mv = h.cu_mv; f.cu_mvd = h.cu_mvd;
+  for (int c = 0; c < 3; c++) f.coef[c] = h.coef[c];
+}
+
+// Runs decide_signalling() for every inter CU: fills cu_flags / cu_merge_idx / cu_mvp_idx / cu_mvd.
+void hc_inter_signal(HcFrame *h)
+{
+  EncFrame f; fill(f, *h);
+  for (int y = 0; y < f.ch; y += 16)
+    for (int x = 0; x < f.cw; x += 16) {
+      int cl = f.cu_log2[b8idx(f, x, y)];
+      if (cl == 5 && ((x | y) & 31)) continue;
+      decide_signalling(f, x, y, cl);
+    }
+}
+
+// Entropy-codes the picture described by the arrays (what k_entropy does, rows in sequence) and
+// assembles the access unit.  Returns its size (or -needed if cap is too small).
+int hc_encode_au(HcFrame *h, uint8_t *out, int cap, unsigned long long *bins)
+{
+  EncFrame f; fill(f, *h);
+  const int wc = f.cw / 64, hc = f.ch / 64, nsub = f.wpp ? hc : 1;
+  const int row_cap = f.cw * 64 * 3;
+  std::vector<uint8_t> rows((size_t)row_cap * hc);
+  std::vector<int32_t> lens(hc, 0);
+  uint8_t ctx[CTX_COUNT], saved[CTX_COUNT];
+  CabacEnc c; c.nbins = 0;
+  const int init_type = f.is_intra ? 0 : 1;
+  if (f.wpp) {
+    for (int row = 0; row < hc; row++) {
+      cabac_start(c, rows.data() + (size_t)row * row_cap, row_cap, ctx);
+      if (row == 0) cabac_init_contexts(ctx, init_type, f.qp); else memcpy(ctx, saved, sizeof(saved));
+      for (int cx = 0; cx < wc; cx++) {
+        enc_ctu(f, c, cx * 64, row * 64);
+        if (cx == 1) memcpy(saved, ctx, sizeof(saved));
+        bool last = (row == hc - 1 && cx == wc - 1);
+        cabac_terminate(c, last);
+        if (!last && cx == wc - 1) cabac_terminate(c, 1);
+      }
+      cabac_finish(c);
+      lens[row] = c.pos;
+    }
+  } else {
+    cabac_start(c, rows.data(), row_cap * hc, ctx);
+    cabac_init_contexts(ctx, init_type, f.qp);
+    for (int cy = 0; cy < hc; cy++)
+      for (int cx = 0; cx < wc; cx++) { enc_ctu(f, c, cx * 64, cy * 64); cabac_terminate(c, cy == hc - 1 && cx == wc - 1); }
+    cabac_finish(c);
+    lens[0] = c.pos;
+  }
+  if (bins) *bins = c.nbins;
+  StreamParams sp; sp.cw = f.cw; sp.ch = f.ch; sp.width = h->width; sp.height = h->height; sp.qp = f.qp; sp.wpp = f.wpp;
+  sp.deblock = h->deblock; sp.fps_num = h->fps_num; sp.fps_den = h->fps_den;
+  std::vector<uint8_t> au;
+  assemble_access_unit(au, sp, f.is_intra != 0, f.poc, h->write_ps != 0, rows.data(), (size_t)row_cap, lens.data(), nsub);
+  if ((int)au.size() > cap) return -(int)au.size();
+  memcpy(out, au.data(), au.size());
+  return (int)au.size();
+}
+
+// Intra prediction of one n x n block from explicit reference arrays (left/top as in hevc_core.h)
+void hc_intra_predict(const uint8_t *left, const uint8_t *top, int n, int cidx, int mode, uint8_t *pred)
+{
+  int l2 = ilog2((unsigned)n);
+  uint8_t lf[65], tf[65];
+  bool filt = intra_filter_needed(n, cidx, mode);
+  if (filt) {
+    bool strong = intra_strong_filter(left, top, n);
+    for (int i = 0; i <= 2 * n; i++) { lf[i] = (uint8_t)intra_filtered_ref(left, top, n, i, strong); tf[i] = (uint8_t)intra_filtered_ref(top, left, n, i, strong); }
+  }
+  int s = n; for (int i = 0; i < n; i++) s += left[1 + i] + top[1 + i];
+  int dc = s >> (l2 + 1);
+  for (int y = 0; y < n; y++) for (int x = 0; x < n; x++)
+    pred[y * n + x] = (uint8_t)intra_pred_sample(filt ? lf : left, filt ? tf : top, n, l2, cidx, mode, dc, x, y);
+}
+
+// Deblocking of a whole picture with the product's segment filters and on-the-fly boundary
+// strengths (what k_deblock_v / k_deblock_h do), in place on rec planes (pitch cw, cw/2).
+void hc_deblock(HcFrame *h, uint8_t *y, uint8_t *u, uint8_t *v)
+{
+  EncFrame f; fill(f, *h);
+  f.rec[0] = y; f.rec[1] = u; f.rec[2] = v;
+  int cw2 = f.cw >> 1;
+  for (int yy = 0; yy < f.ch; yy += 4)
+    for (int x = 8; x < f.cw; x += 8) {
+      if (!is_cu_edge_v(f, x, yy)) continue;
+      int bs = edge_bs(f, x - 1, yy, x, yy);
+      if (!bs) continue;
+      deblock_luma_segment(f.rec[0] + yy * f.cw + x, 1, f.cw, bs, f.qp);
+      if (bs == 2 && (x & 15) == 0) {
+        deblock_chroma_segment(f.rec[1] + (yy >> 1) * cw2 + (x >> 1), 1, cw2, 2, f.qp);
+        deblock_chroma_segment(f.rec[2] + (yy >> 1) * cw2 + (x >> 1), 1, cw2, 2, f.qp);
+      }
+    }
+  for (int yy = 8; yy < f.ch; yy += 8)
+    for (int x = 0; x < f.cw; x += 4) {
+      if (!is_cu_edge_h(f, x, yy)) continue;
+      int bs = edge_bs(f, x, yy - 1, x, yy);
+      if (!bs) continue;
+      deblock_luma_segment(f.rec[0] + yy * f.cw + x, f.cw, 1, bs, f.qp);
+      if (bs == 2 && (yy & 15) == 0) {
+        deblock_chroma_segment(f.rec[1] + (yy >> 1) * cw2 + (x >> 1), cw2, 1, 2, f.qp);
+        deblock_chroma_segment(f.rec[2] + (yy >> 1) * cw2 + (x >> 1), cw2, 1, 2, f.qp);
+      }
+    }
+}
+
+int hc_quant(int coef, int qp, int log2n, int intra) { return quant_level(coef, qp, log2n, intra); }
+int hc_dequant(int level, int qp, int log2n) { return dequant_coef(level, qp, log2n); }
+int hc_mvd_bits(int q) { return mvd_bits(q); }
+
+}  // extern "C"

@@ -138,3 +138,107 @@ class Encoder:
             self.close()
         except Exception:
             pass
+
+
+def split_nals(au):
+    """Annex-B access unit -> list of NAL units, each with its 4-byte start code (what uvgRTP hands to
+    OpenHEVCFilter one by one, /root/reference/src/media/delivery/uvgrtpreceiver.cpp:86-112)."""
+    au = bytes(au)
+    starts = []
+    i = 0
+    while True:
+        j = au.find(b"\x00\x00\x00\x01", i)
+        if j < 0:
+            break
+        starts.append(j)
+        i = j + 4
+    starts.append(len(au))
+    return [au[starts[k]:starts[k + 1]] for k in range(len(starts) - 1)]
+
+
+class Decoder:
+    """libOpenHevc* driven the way OpenHEVCFilter::init / process / sendDecodedOutput drive it."""
+
+    OH_THREAD_SLICE = 2
+
+    def __init__(self, threads=1, download=True):
+        self.lib = N.load_library()
+        self.h = self.lib.libOpenHevcInit(threads, self.OH_THREAD_SLICE)
+        if self.lib.libOpenHevcStartDecoder(self.h) == -1:
+            self.lib.libOpenHevcClose(self.h)
+            self.h = None
+            raise RuntimeError("libOpenHevcStartDecoder failed (no usable HIP device? there is no CPU fallback)")
+        self.lib.libOpenHevcSetTemporalLayer_id(self.h, 0)
+        self.lib.libOpenHevcSetActiveDecoders(self.h, 0)
+        self.lib.libOpenHevcSetViewLayers(self.h, 0)
+        self.download = download
+        if not download:
+            self.lib.kvzx_decoder_set_download(self.h, 0)
+        self.vps = self.sps = self.pps = False
+
+    def decode_nal(self, nal, pts=0):
+        """returns None or a dict with the packed I420 picture (the row-wise copy of sendDecodedOutput)"""
+        nal = bytes(nal)
+        t = nal[4] >> 1
+        self.vps |= t == 32
+        self.sps |= t == 33
+        self.pps |= t == 34
+        vcl = t <= 31
+        if not ((self.vps and self.sps and self.pps) or not vcl):
+            return None
+        buf = (C.c_ubyte * len(nal)).from_buffer_copy(nal)
+        got = self.lib.libOpenHevcDecode(self.h, buf, len(nal), pts)
+        if got < 0:
+            raise RuntimeError("libOpenHevcDecode error %d" % got)
+        if got == 0:
+            return None
+        fr = N.OpenHevcFrame()
+        if self.lib.libOpenHevcGetOutput(self.h, got, C.byref(fr)) <= 0:
+            return None
+        self.lib.libOpenHevcGetPictureInfo(self.h, C.byref(fr.frameInfo))
+        info = fr.frameInfo
+        w, h = info.nWidth, info.nHeight
+        out = {"width": w, "height": h, "fps": (info.frameRate.num, info.frameRate.den), "pts": info.nTimeStamp}
+        if self.download:
+            ys, qs = info.nYPitch, info.nUPitch // 2
+            y = np.empty((h, w), np.uint8)
+            u = np.empty((h // 2, w // 2), np.uint8)
+            v = np.empty((h // 2, w // 2), np.uint8)
+            for i in range(h):                              # openhevcfilter.cpp:218-229
+                y[i] = np.frombuffer((C.c_char * w).from_address(fr.pvY + i * ys), dtype=np.uint8)
+                if i % 2 == 0:
+                    u[i // 2] = np.frombuffer((C.c_char * (w // 2)).from_address(fr.pvU + i * qs), dtype=np.uint8)
+                    v[i // 2] = np.frombuffer((C.c_char * (w // 2)).from_address(fr.pvV + i * qs), dtype=np.uint8)
+            out["i420"] = np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)])
+        return out
+
+    def decode_au(self, au, pts=0):
+        return [f for f in (self.decode_nal(n, pts) for n in split_nals(au)) if f is not None]
+
+    def output_device(self):
+        planes = (C.c_void_p * 3)()
+        pitches = (C.c_int * 3)()
+        if not self.lib.kvzx_decoder_output_device(self.h, planes, pitches):
+            return None
+        return list(planes), list(pitches)
+
+    def set_profiling(self, on):
+        self.lib.kvzx_decoder_set_profiling(self.h, int(on))
+
+    def kernel_times(self, reset=True):
+        ms = (C.c_double * 16)()
+        n = (C.c_uint64 * 16)()
+        k = self.lib.kvzx_decoder_kernel_times(self.h, ms, n, int(reset))
+        return {self.lib.kvzx_decoder_kernel_name(i).decode(): (ms[i], n[i]) for i in range(k)}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.libOpenHevcFlush(self.h)
+            self.lib.libOpenHevcClose(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

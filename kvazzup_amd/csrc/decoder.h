@@ -1,0 +1,102 @@
+// kvazzup_amd/csrc/decoder.h -- host engine of the HIP decoder behind libOpenHevc*
+// (/root/reference/src/media/processing/openhevcfilter.cpp:36-56,145-146,195-199).
+//
+// Division of labour: the host parses NAL units and runs CABAC decoding (bit-serial, one
+// substream per CTU row), which yields per-CU records, motion vectors and the levels of the coded
+// transform blocks; those are uploaded and the GPU does everything that touches samples:
+// motion-compensated / intra prediction, dequantisation + inverse DCT, reconstruction and
+// deblocking (dec variants of the encoder kernels, enc_kernels.hip).
+//
+// Supported streams (round 1): the tool set this project's encoder emits -- Main profile 8-bit
+// 4:2:0, CTB 64, coded size a multiple of 64 and at least 128 wide, 2Nx2N CUs of 8/16/32 (intra)
+// and 16/32 (inter) with one transform unit each, I and P slices with the previous picture as
+// the only reference, arbitrary quarter-sample motion vectors, merge/AMVP without TMVP, WPP or
+// plain slice data, one slice per picture, deblocking on/off.  Anything else is rejected with
+// a negative return value (oracle/hevc_dec.c is the general CPU checker).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "hevc_core.h"
+#include "enc_kernels.h"
+
+namespace kvzx {
+
+enum DecKernelId { DK_SCATTER = 0, DK_INTER_RECON, DK_INTRA_RECON, DK_DEBLOCK, DK_COUNT };
+
+struct DecSps {
+  bool valid = false;
+  int width = 0, height = 0;          // coded size
+  int crop_r = 0, crop_b = 0, crop_l = 0, crop_t = 0;   // luma samples
+  int log2_max_poc_lsb = 8;
+  int num_st_rps = 0; int rps_neg[64], rps_used[64];      // first negative entry of each SPS RPS (subset check)
+  uint32_t fps_num = 0, fps_den = 0;
+  int strong_intra = 0;
+};
+struct DecPps {
+  bool valid = false;
+  int init_qp = 26, wpp = 0, deblock_control = 0, deblock_disabled = 0, loop_filter_across_slices = 1, cabac_init_present = 0;
+};
+
+struct DecodedPicture {
+  int width = 0, height = 0;          // cropped
+  int coded_w = 0, coded_h = 0;
+  const uint8_t *host[3] = {nullptr, nullptr, nullptr}; int host_pitch[3] = {0, 0, 0};
+  const uint8_t *dev[3] = {nullptr, nullptr, nullptr}; int dev_pitch[3] = {0, 0, 0};
+  int poc = 0; int64_t pts = 0; uint32_t fps_num = 0, fps_den = 0; bool is_intra = false;
+};
+
+class Decoder {
+ public:
+  explicit Decoder(int device) : device_(device) {}
+  ~Decoder();
+  bool start(std::string *error);           // checks the HIP device; no CPU fallback
+  // One NAL unit (with or without start code).  <0 error/unsupported, 0 nothing to output, 1 picture ready.
+  int decode_nal(const uint8_t *data, size_t len, int64_t pts);
+  bool get_picture(DecodedPicture *out);   // the picture announced by the last decode_nal() == 1
+  void set_download(bool on) { download_ = on; }
+  void set_profiling(bool on) { profiling_ = on; }
+  void get_kernel_times(double *ms, uint64_t *launches, bool reset);
+  bool debug_copy(const char *what, void *dst, size_t bytes);
+  int last_error() const { return last_error_; }
+  void flush() {}
+
+ private:
+  bool ensure_buffers(int cw, int ch);
+  void free_buffers();
+  int decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t pts);
+  int parse_slice_data(const uint8_t *data, size_t len, int slice_qp, bool is_intra, int max_merge);
+  int run_gpu(bool is_intra, int slice_qp, bool deblock);
+
+  int device_; bool started_ = false;
+  hipStream_t stream_ = nullptr;
+  DecSps sps_[16]; DecPps pps_[64]; uint32_t vps_fps_num_ = 0, vps_fps_den_ = 0;
+  int cw_ = 0, ch_ = 0;
+  // host side picture description (pinned), same layout as the encoder's per-8x8 arrays
+  uint8_t *h_cu_ = nullptr; int16_t *h_mv_ = nullptr;
+  std::vector<int16_t> levels_; std::vector<TuDesc> tus_;
+  int16_t *h_levels_ = nullptr; size_t h_levels_cap_ = 0; TuDesc *h_tus_ = nullptr; size_t h_tus_cap_ = 0;
+  EncFrame hf_{};                          // host view (pointers into h_cu_ / h_mv_)
+  // device side
+  EncFrame f_{};
+  uint8_t *d_cu_ = nullptr; int16_t *d_mv_ = nullptr, *d_mvd_ = nullptr;
+  uint8_t *rec_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  int16_t *coef_[3] = {nullptr, nullptr, nullptr};
+  int16_t *d_levels_ = nullptr; size_t d_levels_cap_ = 0; TuDesc *d_tus_ = nullptr; size_t d_tus_cap_ = 0;
+  uint32_t *sync_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
+  uint8_t *h_out_ = nullptr; size_t h_out_cap_ = 0;
+  int cur_idx_ = 0, ref_idx_ = 1; bool have_ref_ = false;
+  int poc_ = 0, prev_poc_ = 0;
+  bool download_ = true, profiling_ = false;
+  bool pic_ready_ = false; DecodedPicture out_;
+  const DecSps *active_sps_ = nullptr;
+  int last_error_ = 0;
+  std::vector<uint8_t> rbsp_;
+  struct EvPair { hipEvent_t a, b; int id; };
+  std::vector<EvPair> ev_pool_; size_t ev_used_ = 0;
+  double k_ms_[DK_COUNT] = {0}; uint64_t k_n_[DK_COUNT] = {0};
+  template <class F> void timed(int id, F &&launch);
+};
+
+}  // namespace kvzx

@@ -1,0 +1,655 @@
+// kvazzup_amd/csrc/decoder.hip -- see decoder.h
+#include <cstdio>
+#include <cstring>
+#include "decoder.h"
+
+namespace kvzx {
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "kvazzup_amd: %s failed: %s\n", #expr, hipGetErrorString(e_)); return false; } } while (0)
+enum { DEC_ERR_INVALID = -1, DEC_ERR_UNSUPPORTED = -2, DEC_ERR_GPU = -3 };
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ bits
+struct BitReader {
+  const uint8_t *p; size_t n, pos = 0; bool err = false;
+  BitReader(const uint8_t *b, size_t len) : p(b), n(len) {}
+  uint32_t bit() { if (pos >= n * 8) { err = true; pos++; return 0; } uint32_t b = (p[pos >> 3] >> (7 - (pos & 7))) & 1; pos++; return b; }
+  uint32_t get(int k) { uint32_t v = 0; for (int i = 0; i < k; i++) v = (v << 1) | bit(); return v; }
+  uint32_t ue() { int z = 0; while (!bit()) { if (++z > 32 || err) { err = true; return 0; } } return z ? ((1u << z) - 1) + get(z) : 0; }
+  int32_t se() { uint32_t k = ue(); return (k & 1) ? (int32_t)((k + 1) >> 1) : -(int32_t)(k >> 1); }
+};
+
+bool skip_ptl(BitReader &r, int max_sub_layers_minus1)
+{
+  r.get(8); r.get(32); r.get(4); r.get(32); r.get(11); r.get(1); r.get(8);
+  int pp[8], lp[8];
+  for (int i = 0; i < max_sub_layers_minus1; i++) { pp[i] = r.get(1); lp[i] = r.get(1); }
+  if (max_sub_layers_minus1 > 0) for (int i = max_sub_layers_minus1; i < 8; i++) r.get(2);
+  for (int i = 0; i < max_sub_layers_minus1; i++) { if (pp[i]) { r.get(32); r.get(32); r.get(24); } if (lp[i]) r.get(8); }
+  return !r.err;
+}
+
+// ------------------------------------------------------------------------------------------ CABAC decoding (H.265 9.3.4.3)
+struct CabacDec {
+  const uint8_t *buf = nullptr; size_t len = 0, pos = 0;     // pos in bits; buf is padded with >= 8 readable bytes
+  uint32_t range = 510, offset = 0;
+  uint8_t ctx[CTX_COUNT];
+  uint32_t read(int n)
+  {
+    if (n == 0) return 0;
+    size_t byte = pos >> 3; int sh = (int)(pos & 7);
+    uint32_t w = ((uint32_t)buf[byte] << 24) | ((uint32_t)buf[byte + 1] << 16) | ((uint32_t)buf[byte + 2] << 8) | buf[byte + 3];
+    pos += (size_t)n;
+    return (w << sh) >> (32 - n);
+  }
+  bool overrun() const { return pos > len * 8 + 16; }
+  void start(const uint8_t *b, size_t l) { buf = b; len = l; pos = 0; range = 510; offset = read(9); }
+  int bin(int ci)
+  {
+    uint8_t s = ctx[ci]; int state = s >> 1, mps = s & 1;
+    uint32_t lps = kRangeLps[state][(range >> 6) & 3];
+    range -= lps;
+    if (offset >= range) {
+      offset -= range; range = lps;
+      int b = mps ^ 1;
+      if (!state) mps ^= 1;
+      ctx[ci] = (uint8_t)((kNextLps[state] << 1) | mps);
+      int n = __builtin_clz(range) - 23;
+      range <<= n; offset = (offset << n) | read(n);
+      return b;
+    }
+    ctx[ci] = (uint8_t)(((state < 62 ? state + 1 : state) << 1) | mps);
+    if (range < 256) { range <<= 1; offset = (offset << 1) | read(1); }
+    return mps;
+  }
+  int bypass() { offset = (offset << 1) | read(1); if (offset >= range) { offset -= range; return 1; } return 0; }
+  uint32_t bypass_bits(int n) { uint32_t v = 0; for (int i = 0; i < n; i++) v = (v << 1) | (uint32_t)bypass(); return v; }
+  int terminate()
+  {
+    range -= 2;
+    if (offset >= range) return 1;
+    if (range < 256) { range <<= 1; offset = (offset << 1) | read(1); }
+    return 0;
+  }
+  size_t bytes_consumed() const { return (pos + 7) >> 3; }
+};
+
+CoreTabs g_tabs;
+bool g_tabs_ready = false;
+const CoreTabs *host_tabs()
+{
+  if (!g_tabs_ready) { for (int i = 0; i < 64; i++) core_tabs_fill_entry(g_tabs, i); g_tabs_ready = true; }
+  return &g_tabs;
+}
+
+// residual_coding() (7.3.8.11) without transform skip / sign hiding; writes n*n levels row-major
+bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, int16_t *out)
+{
+  const CoreTabs *t = host_tabs();
+  const int n = 1 << log2, sbl = log2 - 2, nsb = 1 << sbl;
+  uint8_t csbf[8][8]; memset(csbf, 0, sizeof(csbf));
+  memset(out, 0, sizeof(int16_t) * (size_t)n * n);
+  int pre[2];
+  for (int d = 0; d < 2; d++) {
+    int off, sh, mx = (log2 << 1) - 1, v = 0;
+    if (cidx == 0) { off = 3 * (log2 - 2) + ((log2 - 1) >> 2); sh = (log2 + 1) >> 2; } else { off = 15; sh = log2 - 2; }
+    while (v < mx && c.bin((d ? CTX_LAST_Y : CTX_LAST_X) + off + (v >> sh))) v++;
+    pre[d] = v;
+  }
+  int lx = pre[0], ly = pre[1];
+  if (lx > 3) { int nb = (lx >> 1) - 1; lx = (1 << nb) * (2 + (lx & 1)) + (int)c.bypass_bits(nb); }
+  if (ly > 3) { int nb = (ly >> 1) - 1; ly = (1 << nb) * (2 + (ly & 1)) + (int)c.bypass_bits(nb); }
+  if (scan_idx == 2) { int tt = lx; lx = ly; ly = tt; }
+  if (lx >= n || ly >= n) return false;
+  int last_sb = (1 << (2 * sbl)) - 1, last_pos = 16;
+  for (;;) {
+    if (last_pos == 0) { last_pos = 16; if (--last_sb < 0) return false; }
+    last_pos--;
+    int xs, ys, xp, yp; scan_pos(t, scan_idx, sbl, last_sb, xs, ys); scan_pos(t, scan_idx, 2, last_pos, xp, yp);
+    if ((xs << 2) + xp == lx && (ys << 2) + yp == ly) break;
+  }
+  int c1 = 1;
+  for (int i = last_sb; i >= 0; i--) {
+    int xs, ys; scan_pos(t, scan_idx, sbl, i, xs, ys);
+    int right = (xs < nsb - 1) ? csbf[ys][xs + 1] : 0, below = (ys < nsb - 1) ? csbf[ys + 1][xs] : 0, infer_dc = 0;
+    if (i < last_sb && i > 0) { csbf[ys][xs] = (uint8_t)c.bin(CTX_CSBF + ((right | below) ? 1 : 0) + (cidx ? 2 : 0)); infer_dc = 1; }
+    else csbf[ys][xs] = 1;
+    if (!csbf[ys][xs]) continue;
+    uint32_t sig = 0;
+    if (i == last_sb) sig |= 1u << last_pos;
+    const int prev_csbf = right | (below << 1);
+    for (int k = (i == last_sb) ? last_pos - 1 : 15; k >= 0; k--) {
+      if (k > 0 || !infer_dc) {
+        int xp, yp; scan_pos(t, scan_idx, 2, k, xp, yp);
+        int xc = (xs << 2) + xp, yc = (ys << 2) + yp, sc;
+        if (log2 == 2) sc = t->ctxmap4x4[(yc << 2) + xc];
+        else if (xc + yc == 0) sc = 0;
+        else {
+          if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
+          else if (prev_csbf == 1) sc = (yp == 0) ? 2 : (yp == 1) ? 1 : 0;
+          else if (prev_csbf == 2) sc = (xp == 0) ? 2 : (xp == 1) ? 1 : 0;
+          else sc = 2;
+          if (cidx == 0) { if (i > 0) sc += 3; sc += (log2 == 3) ? ((scan_idx == 0) ? 9 : 15) : 21; }
+          else sc += (log2 == 3) ? 9 : 12;
+        }
+        if (c.bin(CTX_SIG + (cidx ? 27 : 0) + sc)) { sig |= 1u << k; infer_dc = 0; }
+      } else sig |= 1u;            // k == 0 with every other flag of a coded sub-block zero: inferred
+    }
+    if (!sig) continue;
+    int ctx_set = (i > 0 && cidx == 0) ? 2 : 0;
+    if (c1 == 0) ctx_set++;
+    c1 = 1;
+    int pos[16], lev[16], nsig = 0, g1idx = -1;
+    for (int k = 15; k >= 0; k--) if ((sig >> k) & 1) pos[nsig++] = k;
+    for (int j = 0; j < nsig; j++) lev[j] = 1;
+    for (int j = 0; j < nsig && j < 8; j++) {
+      int g1 = c.bin(CTX_GT1 + (cidx ? 16 : 0) + ctx_set * 4 + c1);
+      if (g1) { lev[j] = 2; c1 = 0; if (g1idx < 0) g1idx = j; }
+      else if (c1 > 0 && c1 < 3) c1++;
+    }
+    if (g1idx >= 0 && c.bin(CTX_GT2 + (cidx ? 4 : 0) + ctx_set)) lev[g1idx] = 3;
+    uint32_t signs = c.bypass_bits(nsig);
+    int rice = 0;
+    for (int j = 0; j < nsig; j++) {
+      int base = (j < 8) ? ((j == g1idx) ? 3 : 2) : 1;
+      if (lev[j] == base) {
+        int prefix = 0;
+        while (prefix < 32 && c.bypass()) prefix++;
+        if (prefix >= 32) return false;
+        int rem = prefix <= 3 ? (prefix << rice) + (int)c.bypass_bits(rice)
+                              : (((1 << (prefix - 3)) + 3 - 1) << rice) + (int)c.bypass_bits(prefix - 3 + rice);
+        lev[j] = base + rem;
+        if (lev[j] > 3 * (1 << rice)) rice = imin(rice + 1, 4);
+      }
+      int v = ((signs >> (nsig - 1 - j)) & 1) ? -lev[j] : lev[j];
+      int xp, yp; scan_pos(t, scan_idx, 2, pos[j], xp, yp);
+      out[((ys << 2) + yp) * n + (xs << 2) + xp] = (int16_t)clip3(-32768, 32767, v);
+    }
+  }
+  return !c.overrun();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ lifecycle
+Decoder::~Decoder()
+{
+  if (stream_) hipStreamSynchronize(stream_);
+  for (auto &e : ev_pool_) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  free_buffers();
+  if (h_levels_) hipHostFree(h_levels_);
+  if (h_tus_) hipHostFree(h_tus_);
+  if (d_levels_) hipFree(d_levels_);
+  if (d_tus_) hipFree(d_tus_);
+  if (h_err_) hipHostFree(h_err_);
+  if (err_) hipFree(err_);
+  if (stream_) hipStreamDestroy(stream_);
+}
+
+bool Decoder::start(std::string *error)
+{
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_) {
+    if (error) *error = "no usable HIP device (this library has no CPU fallback)";
+    return false;
+  }
+  HIP_TRY(hipSetDevice(device_));
+  HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  HIP_TRY(hipMalloc(&err_, sizeof(uint32_t)));
+  HIP_TRY(hipMemset(err_, 0, sizeof(uint32_t)));
+  HIP_TRY(hipHostMalloc(&h_err_, sizeof(uint32_t), hipHostMallocDefault));
+  started_ = true;
+  return true;
+}
+
+void Decoder::free_buffers()
+{
+  if (h_cu_) hipHostFree(h_cu_);
+  if (h_mv_) hipHostFree(h_mv_);
+  if (h_out_) hipHostFree(h_out_);
+  hipFree(d_cu_); hipFree(d_mv_); hipFree(d_mvd_); hipFree(sync_);
+  for (int c = 0; c < 3; c++) { hipFree(rec_[0][c]); hipFree(rec_[1][c]); hipFree(coef_[c]); rec_[0][c] = rec_[1][c] = nullptr; coef_[c] = nullptr; }
+  h_cu_ = nullptr; h_mv_ = nullptr; h_out_ = nullptr; d_cu_ = nullptr; d_mv_ = nullptr; d_mvd_ = nullptr; sync_ = nullptr;
+  cw_ = ch_ = 0;
+}
+
+bool Decoder::ensure_buffers(int cw, int ch)
+{
+  if (cw == cw_ && ch == ch_) return true;
+  hipStreamSynchronize(stream_);
+  free_buffers();
+  const size_t npx = (size_t)cw * ch, nb8 = npx / 64;
+  HIP_TRY(hipHostMalloc(&h_cu_, nb8 * 7, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc(&h_mv_, nb8 * 2 * sizeof(int16_t), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc(&h_out_, npx * 3 / 2, hipHostMallocDefault));
+  h_out_cap_ = npx * 3 / 2;
+  memset(h_cu_, 0, nb8 * 7); memset(h_mv_, 0, nb8 * 4);
+  HIP_TRY(hipMalloc(&d_cu_, nb8 * 7));
+  HIP_TRY(hipMalloc(&d_mv_, nb8 * 2 * sizeof(int16_t)));
+  HIP_TRY(hipMalloc(&d_mvd_, nb8 * 2 * sizeof(int16_t)));
+  HIP_TRY(hipMalloc(&sync_, sizeof(uint32_t) * (size_t)(ch / 64)));
+  for (int c = 0; c < 3; c++) {
+    size_t n = c ? npx / 4 : npx;
+    HIP_TRY(hipMalloc(&rec_[0][c], n)); HIP_TRY(hipMalloc(&rec_[1][c], n));
+    HIP_TRY(hipMemset(rec_[0][c], 128, n)); HIP_TRY(hipMemset(rec_[1][c], 128, n));
+    HIP_TRY(hipMalloc(&coef_[c], n * sizeof(int16_t)));
+  }
+  cw_ = cw; ch_ = ch;
+  auto fill = [&](EncFrame &f, uint8_t *cu, int16_t *mv) {
+    memset(&f, 0, sizeof(f));
+    f.cw = cw; f.ch = ch; f.b8w = cw / 8; f.b8h = ch / 8; f.wpp = 0;
+    f.cu_log2 = cu; f.cu_intra = cu + nb8; f.cu_flags = cu + 2 * nb8; f.cu_merge_idx = cu + 3 * nb8;
+    f.cu_mvp_idx = cu + 4 * nb8; f.cu_intra_mode = cu + 5 * nb8; f.cu_cbf = cu + 6 * nb8; f.cu_mv = mv;
+  };
+  fill(hf_, h_cu_, h_mv_);
+  fill(f_, d_cu_, d_mv_);
+  f_.cu_mvd = d_mvd_;
+  for (int c = 0; c < 3; c++) f_.coef[c] = coef_[c];
+  f_.sync = sync_; f_.err = err_;
+  have_ref_ = false;
+  return true;
+}
+
+template <class F> void Decoder::timed(int id, F &&launch)
+{
+  if (!profiling_) { launch(); return; }
+  if (ev_used_ == ev_pool_.size()) { EvPair p; hipEventCreate(&p.a); hipEventCreate(&p.b); p.id = id; ev_pool_.push_back(p); }
+  EvPair &p = ev_pool_[ev_used_++]; p.id = id;
+  hipEventRecord(p.a, stream_); launch(); hipEventRecord(p.b, stream_);
+}
+void Decoder::get_kernel_times(double *ms, uint64_t *launches, bool reset)
+{
+  for (int i = 0; i < DK_COUNT; i++) { if (ms) ms[i] = k_ms_[i]; if (launches) launches[i] = k_n_[i]; }
+  if (reset) for (int i = 0; i < DK_COUNT; i++) { k_ms_[i] = 0; k_n_[i] = 0; }
+}
+
+// ------------------------------------------------------------------------------------------ NAL units
+int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
+{
+  pic_ready_ = false;
+  if (!started_) return last_error_ = DEC_ERR_GPU;
+  size_t i = 0;
+  while (i + 2 < len && data[i] == 0) i++;
+  if (i >= 2 && i < len && data[i] == 1) { data += i + 1; len -= i + 1; }
+  if (len < 3 || (data[0] & 0x80)) return last_error_ = DEC_ERR_INVALID;
+  const int nal_type = (data[0] >> 1) & 0x3f, layer = ((data[0] & 1) << 5) | (data[1] >> 3);
+  if (layer != 0) return 0;
+  rbsp_.assign(len + 16, 0);
+  size_t n = 0; int zeros = 0;
+  for (size_t k = 2; k < len; k++) {
+    if (zeros >= 2 && data[k] == 3) { zeros = 0; continue; }
+    rbsp_[n++] = data[k]; zeros = data[k] == 0 ? zeros + 1 : 0;
+  }
+  BitReader r(rbsp_.data(), n);
+  if (nal_type == 32) {                                          // VPS: only the timing information is used
+    r.get(4); r.get(2); r.get(6); int msl = r.get(3); r.get(1); r.get(16);
+    if (!skip_ptl(r, msl)) return last_error_ = DEC_ERR_INVALID;
+    int oi = r.get(1);
+    for (int k = oi ? 0 : msl; k <= msl; k++) { r.ue(); r.ue(); r.ue(); }
+    int max_layer_id = r.get(6); int nls = r.ue() + 1;
+    for (int a = 1; a < nls; a++) for (int b = 0; b <= max_layer_id; b++) r.get(1);
+    if (r.get(1)) { vps_fps_den_ = r.get(32); vps_fps_num_ = r.get(32); }
+    return r.err ? (last_error_ = DEC_ERR_INVALID) : 0;
+  }
+  if (nal_type == 33) {                                          // SPS (7.3.2.2)
+    DecSps s;
+    r.get(4); int msl = r.get(3); r.get(1);
+    if (!skip_ptl(r, msl)) return last_error_ = DEC_ERR_INVALID;
+    int id = r.ue(); if (id > 15) return last_error_ = DEC_ERR_INVALID;
+    if (r.ue() != 1) return last_error_ = DEC_ERR_UNSUPPORTED;   // 4:2:0 only
+    s.width = r.ue(); s.height = r.ue();
+    if (r.get(1)) { s.crop_l = 2 * r.ue(); s.crop_r = 2 * r.ue(); s.crop_t = 2 * r.ue(); s.crop_b = 2 * r.ue(); }
+    if (r.ue() != 0 || r.ue() != 0) return last_error_ = DEC_ERR_UNSUPPORTED;   // 8 bit only
+    s.log2_max_poc_lsb = r.ue() + 4;
+    int oi = r.get(1);
+    for (int k = oi ? 0 : msl; k <= msl; k++) { r.ue(); r.ue(); r.ue(); }
+    int log2_min_cb = r.ue() + 3, diff_cb = r.ue(), log2_min_tb = r.ue() + 2, diff_tb = r.ue(), dinter = r.ue(), dintra = r.ue();
+    int scaling = r.get(1); int amp = r.get(1), sao = r.get(1), pcm = r.get(1);
+    if (scaling || amp || sao || pcm || log2_min_cb != 3 || diff_cb != 3 || log2_min_tb != 2 || diff_tb != 3 || dinter != 0 || dintra != 0)
+      return last_error_ = DEC_ERR_UNSUPPORTED;
+    s.num_st_rps = r.ue();
+    if (s.num_st_rps > 64) return last_error_ = DEC_ERR_INVALID;
+    for (int k = 0; k < s.num_st_rps; k++) {
+      if (k != 0 && r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;            // inter RPS prediction
+      int nneg = r.ue(), npos = r.ue();
+      if (nneg != 1 || npos != 0) return last_error_ = DEC_ERR_UNSUPPORTED;        // exactly one (previous) reference
+      s.rps_neg[k] = -(int)(r.ue() + 1); s.rps_used[k] = r.get(1);
+    }
+    if (r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;      // long-term references
+    if (r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;      // temporal MVP
+    s.strong_intra = r.get(1);
+    if (!s.strong_intra) return last_error_ = DEC_ERR_UNSUPPORTED;   // kernels assume strong_intra_smoothing_enabled_flag = 1
+    if (r.get(1)) {                                               // VUI: timing only
+      if (r.get(1)) { if (r.get(8) == 255) { r.get(16); r.get(16); } }
+      if (r.get(1)) r.get(1);
+      if (r.get(1)) { r.get(4); if (r.get(1)) r.get(24); }
+      if (r.get(1)) { r.ue(); r.ue(); }
+      r.get(3);
+      if (r.get(1)) { r.ue(); r.ue(); r.ue(); r.ue(); }
+      if (r.get(1)) { s.fps_den = r.get(32); s.fps_num = r.get(32); }
+    }
+    if (r.err) return last_error_ = DEC_ERR_INVALID;
+    if ((s.width & 63) || (s.height & 63) || s.width < 128 || s.height < 64) return last_error_ = DEC_ERR_UNSUPPORTED;
+    s.valid = true; sps_[id] = s;
+    return 0;
+  }
+  if (nal_type == 34) {                                          // PPS (7.3.2.3)
+    DecPps p;
+    int id = r.ue(), sid = r.ue();
+    if (id > 63 || sid != 0) return last_error_ = (id > 63 ? DEC_ERR_INVALID : DEC_ERR_UNSUPPORTED);
+    int dep = r.get(1), outflag = r.get(1), extra = r.get(3), signhide = r.get(1);
+    p.cabac_init_present = r.get(1);
+    int l0 = r.ue(), l1 = r.ue(); (void)l1;
+    p.init_qp = 26 + r.se();
+    int cip = r.get(1), tskip = r.get(1), cuqpd = r.get(1);
+    if (cuqpd) r.ue();
+    int cbo = r.se(), cro = r.se(), sco = r.get(1), wp = r.get(1), wbp = r.get(1), tqb = r.get(1), tiles = r.get(1);
+    p.wpp = r.get(1);
+    if (dep || outflag || extra || signhide || p.cabac_init_present || l0 != 0 || cip || tskip || cuqpd || cbo || cro || sco || wp || wbp || tqb || tiles)
+      return last_error_ = DEC_ERR_UNSUPPORTED;
+    p.loop_filter_across_slices = r.get(1);
+    p.deblock_control = r.get(1);
+    if (p.deblock_control) {
+      if (r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;    // deblocking_filter_override_enabled_flag
+      p.deblock_disabled = r.get(1);
+      if (!p.deblock_disabled && (r.se() != 0 || r.se() != 0)) return last_error_ = DEC_ERR_UNSUPPORTED;
+    }
+    if (r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;      // scaling list data
+    if (r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;      // lists_modification_present_flag
+    if (r.ue() != 0) return last_error_ = DEC_ERR_UNSUPPORTED;   // log2_parallel_merge_level_minus2
+    if (r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;      // slice header extension
+    if (r.err) return last_error_ = DEC_ERR_INVALID;
+    p.valid = true; pps_[id] = p;
+    return 0;
+  }
+  if (nal_type > 31) return 0;                                    // AUD / SEI / ...
+  if (!(nal_type == 0 || nal_type == 1 || nal_type == 19 || nal_type == 20)) return last_error_ = DEC_ERR_UNSUPPORTED;
+  int rc = decode_slice(rbsp_.data(), n, nal_type, pts);
+  if (rc < 0) last_error_ = rc;
+  return rc;
+}
+
+int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t pts)
+{
+  BitReader r(rbsp, len);
+  const bool idr = nal_type == 19 || nal_type == 20;
+  if (!r.get(1)) return DEC_ERR_UNSUPPORTED;                     // one slice per picture
+  if (idr) r.get(1);
+  int pps_id = r.ue();
+  if (pps_id > 63 || !pps_[pps_id].valid || !sps_[0].valid) return DEC_ERR_INVALID;
+  const DecPps &p = pps_[pps_id]; const DecSps &s = sps_[0];
+  int slice_type = r.ue();
+  if (slice_type != 1 && slice_type != 2) return DEC_ERR_UNSUPPORTED;
+  const bool is_intra = slice_type == 2;
+  if (!is_intra && idr) return DEC_ERR_INVALID;
+  int poc = 0;
+  if (!idr) {
+    int lsb = r.get(s.log2_max_poc_lsb), max_lsb = 1 << s.log2_max_poc_lsb;
+    int prev_lsb = prev_poc_ & (max_lsb - 1), prev_msb = prev_poc_ - prev_lsb, msb;
+    if (lsb < prev_lsb && prev_lsb - lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
+    else if (lsb > prev_lsb && lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
+    else msb = prev_msb;
+    poc = msb + lsb;
+    int neg = 0, used = 0;
+    if (r.get(1)) {
+      int idx = 0, bits = 0; while ((1 << bits) < s.num_st_rps) bits++;
+      if (s.num_st_rps == 0) return DEC_ERR_INVALID;
+      if (bits) idx = r.get(bits);
+      if (idx >= s.num_st_rps) return DEC_ERR_INVALID;
+      neg = s.rps_neg[idx]; used = s.rps_used[idx];
+    } else {
+      if (s.num_st_rps != 0 && r.get(1)) return DEC_ERR_UNSUPPORTED;
+      if (r.ue() != 1 || r.ue() != 0) return DEC_ERR_UNSUPPORTED;
+      neg = -(int)(r.ue() + 1); used = r.get(1);
+    }
+    if (!is_intra && (neg != -1 || !used || !have_ref_ || poc - 1 != prev_poc_)) return DEC_ERR_UNSUPPORTED;   // reference = previous picture
+  }
+  int max_merge = 5;
+  if (!is_intra) {
+    if (r.get(1)) { if (r.ue() != 0) return DEC_ERR_UNSUPPORTED; }        // num_ref_idx_active override: still one reference
+    max_merge = 5 - (int)r.ue();
+    if (max_merge < 1 || max_merge > 5) return DEC_ERR_INVALID;
+  }
+  const int slice_qp = p.init_qp + r.se();
+  if (slice_qp < 0 || slice_qp > 51) return DEC_ERR_INVALID;
+  const bool deblock = !p.deblock_disabled;
+  if (p.loop_filter_across_slices && deblock) r.get(1);
+  if (p.wpp) {
+    int nep = r.ue();
+    if (nep > 0) { int bits = r.ue() + 1; if (bits > 32) return DEC_ERR_INVALID; for (int k = 0; k < nep; k++) r.get(bits); }
+  }
+  if (!r.get(1)) return DEC_ERR_INVALID;                         // byte_alignment()
+  while (r.pos & 7) r.get(1);
+  if (r.err) return DEC_ERR_INVALID;
+  if (!ensure_buffers(s.width, s.height)) return DEC_ERR_GPU;
+  active_sps_ = &s;
+  hf_.is_intra = is_intra; hf_.wpp = p.wpp; hf_.qp = slice_qp;
+  int rc = parse_slice_data(rbsp + (r.pos >> 3), len - (r.pos >> 3), slice_qp, is_intra, max_merge);
+  if (rc < 0) return rc;
+  rc = run_gpu(is_intra, slice_qp, deblock);
+  if (rc < 0) return rc;
+  poc_ = poc; prev_poc_ = poc;
+  // output description
+  out_ = DecodedPicture();
+  out_.coded_w = cw_; out_.coded_h = ch_;
+  out_.width = cw_ - s.crop_l - s.crop_r; out_.height = ch_ - s.crop_t - s.crop_b;
+  out_.poc = poc; out_.pts = pts; out_.is_intra = is_intra;
+  out_.fps_num = s.fps_num ? s.fps_num : vps_fps_num_; out_.fps_den = s.fps_num ? s.fps_den : vps_fps_den_;
+  for (int c = 0; c < 3; c++) {
+    int pw = c ? cw_ / 2 : cw_, ox = c ? s.crop_l / 2 : s.crop_l, oy = c ? s.crop_t / 2 : s.crop_t;
+    out_.dev[c] = rec_[ref_idx_][c] + (size_t)oy * pw + ox; out_.dev_pitch[c] = pw;
+  }
+  if (download_) {
+    // Host pitches are kept even and aligned like a software decoder's line sizes: the reference
+    // addresses chroma row i/2 as pvU + i * (nUPitch / 2) (openhevcfilter.cpp:209,224-227).
+    size_t off = 0;
+    const int ypitch = (out_.width + 63) & ~63;
+    for (int c = 0; c < 3; c++) {
+      int w = c ? out_.width / 2 : out_.width, h = c ? out_.height / 2 : out_.height, pitch = c ? ypitch / 2 : ypitch;
+      if (hipMemcpy2DAsync(h_out_ + off, (size_t)pitch, out_.dev[c], (size_t)out_.dev_pitch[c], (size_t)w, (size_t)h, hipMemcpyDeviceToHost, stream_) != hipSuccess) return DEC_ERR_GPU;
+      out_.host[c] = h_out_ + off; out_.host_pitch[c] = pitch;
+      off += (size_t)pitch * h;
+    }
+    if (hipStreamSynchronize(stream_) != hipSuccess) return DEC_ERR_GPU;
+  }
+  pic_ready_ = true;
+  return 1;
+}
+
+// ------------------------------------------------------------------------------------------ slice data (7.3.8)
+int Decoder::parse_slice_data(const uint8_t *data, size_t len, int slice_qp, bool is_intra, int max_merge)
+{
+  const int wc = cw_ / 64, hc = ch_ / 64;
+  EncFrame &f = hf_;
+  FrameView v; v.f = &f;
+  CabacDec c; uint8_t saved[CTX_COUNT];
+  levels_.clear(); tus_.clear();
+  size_t base = 0;
+  c.start(data, len);
+  cabac_init_contexts(c.ctx, is_intra ? 0 : 1, slice_qp);
+  int16_t blk[32 * 32];
+  for (int cy = 0; cy < hc; cy++) {
+    if (cy > 0 && f.wpp) memcpy(c.ctx, saved, sizeof(saved));
+    for (int cx = 0; cx < wc; cx++) {
+      // coding_quadtree, iteratively in z-order over the 8x8 grid of the CTU
+      for (int z = 0; z < 64;) {
+        int xi, yi; ctu_z_to_xy(z, xi, yi);
+        const int x0 = cx * 64 + xi * 8, y0 = cy * 64 + yi * 8;
+        int log2 = 6;
+        for (; log2 > 3; log2--) {                 // split_cu_flag at every level whose block starts here
+          if (z & ((1 << (2 * (log2 - 3))) - 1)) continue;
+          int depth = 6 - log2;
+          int l = avail64(cw_, ch_, x0, y0, x0 - 1, y0) && (6 - f.cu_log2[b8idx(f, x0 - 1, y0)]) > depth;
+          int a = avail64(cw_, ch_, x0, y0, x0, y0 - 1) && (6 - f.cu_log2[b8idx(f, x0, y0 - 1)]) > depth;
+          if (!c.bin(CTX_SPLIT_CU + l + a)) break;
+        }
+        // blocks larger than the first level starting at z cannot occur: the loop above stops at the coded size
+        if (log2 == 6) return DEC_ERR_UNSUPPORTED;  // 64x64 coding units
+        const int n = 1 << log2;
+        int skip = 0, intra = is_intra ? 1 : 0, flags = 0, mode = 0, cbf = 0, mvx = 0, mvy = 0;
+        if (!is_intra) {
+          int l = avail64(cw_, ch_, x0, y0, x0 - 1, y0) && (f.cu_flags[b8idx(f, x0 - 1, y0)] & CU_SKIP);
+          int a = avail64(cw_, ch_, x0, y0, x0, y0 - 1) && (f.cu_flags[b8idx(f, x0, y0 - 1)] & CU_SKIP);
+          skip = c.bin(CTX_SKIP + l + a);
+          if (!skip) intra = c.bin(CTX_PRED_MODE);
+        }
+        if (!is_intra && intra) return DEC_ERR_UNSUPPORTED;       // intra CUs in P pictures
+        if (!intra && log2 == 3) return DEC_ERR_UNSUPPORTED;      // 8x8 inter CUs
+        if (!skip && (!intra || log2 == 3) && !c.bin(CTX_PART_MODE)) return DEC_ERR_UNSUPPORTED;   // only PART_2Nx2N
+        bool root_cbf = true;
+        if (intra) {
+          int prev = c.bin(CTX_PREV_INTRA);
+          int cand[3]; intra_mpm(v, cw_, ch_, x0, y0, cand);
+          if (prev) { int idx = 0; if (c.bypass()) { idx = 1; if (c.bypass()) idx = 2; } mode = cand[idx]; }
+          else {
+            mode = (int)c.bypass_bits(5);
+            int t;
+            if (cand[0] > cand[1]) { t = cand[0]; cand[0] = cand[1]; cand[1] = t; }
+            if (cand[0] > cand[2]) { t = cand[0]; cand[0] = cand[2]; cand[2] = t; }
+            if (cand[1] > cand[2]) { t = cand[1]; cand[1] = cand[2]; cand[2] = t; }
+            for (int q = 0; q < 3; q++) if (mode >= cand[q]) mode++;
+          }
+          if (c.bin(CTX_CHROMA_MODE)) return DEC_ERR_UNSUPPORTED; // chroma mode other than "derived from luma"
+        } else {
+          int merge = skip ? 1 : c.bin(CTX_MERGE_FLAG);
+          if (merge) {
+            int idx = 0;
+            if (max_merge > 1 && c.bin(CTX_MERGE_IDX)) { idx = 1; while (idx < max_merge - 1 && c.bypass()) idx++; }
+            int cmx[5], cmy[5]; merge_cand_list(f, x0, y0, n, cmx, cmy);
+            mvx = cmx[idx]; mvy = cmy[idx];
+            flags = CU_MERGE | (skip ? CU_SKIP : 0);
+            root_cbf = !skip;
+          } else {
+            int g0x = c.bin(CTX_MVD_GT0), g0y = c.bin(CTX_MVD_GT0);
+            int g1x = g0x ? c.bin(CTX_MVD_GT1) : 0, g1y = g0y ? c.bin(CTX_MVD_GT1) : 0;
+            int d[2];
+            for (int k = 0; k < 2; k++) {
+              int g0 = k ? g0y : g0x, g1 = k ? g1y : g1x, a = 0;
+              if (g0) {
+                a = 1;
+                if (g1) { int kk = 1, vv = 0; while (kk < 32 && c.bypass()) { vv += 1 << kk; kk++; } if (kk >= 32) return DEC_ERR_INVALID; vv += (int)c.bypass_bits(kk); a = vv + 2; }
+                if (c.bypass()) a = -a;
+              }
+              d[k] = a;
+            }
+            int mvp = c.bin(CTX_MVP_FLAG);
+            int px[2], py[2]; amvp_cand_list(f, x0, y0, n, px, py);
+            mvx = (int16_t)(uint16_t)(px[mvp] + d[0]); mvy = (int16_t)(uint16_t)(py[mvp] + d[1]);
+            root_cbf = c.bin(CTX_RQT_ROOT_CBF) != 0;
+          }
+        }
+        // the CU record must be visible to its own transform coding (scan choice) and to later CUs
+        if (intra || root_cbf) {
+          int cb = c.bin(CTX_CBF_CHROMA), cr = c.bin(CTX_CBF_CHROMA);
+          int luma = (intra || cb || cr) ? c.bin(CTX_CBF_LUMA + 1) : 1;
+          cbf = luma | (cb << 1) | (cr << 2);
+          for (int ci = 0; ci < 3; ci++) {
+            if (!((cbf >> ci) & 1)) continue;
+            int l2 = ci ? log2 - 1 : log2, nn = 1 << l2;
+            if (!parse_residual(c, l2, ci, intra_scan_idx(intra, l2, ci, mode), blk)) return DEC_ERR_INVALID;
+            TuDesc td; td.x = (uint16_t)(ci ? x0 >> 1 : x0); td.y = (uint16_t)(ci ? y0 >> 1 : y0); td.plane = (uint8_t)ci; td.log2 = (uint8_t)l2;
+            td.pad = 0; td.offset = (uint32_t)levels_.size();
+            tus_.push_back(td);
+            levels_.insert(levels_.end(), blk, blk + nn * nn);
+          }
+        }
+        for (int yy = y0; yy < y0 + n; yy += 8)
+          for (int xx = x0; xx < x0 + n; xx += 8) {
+            int i = b8idx(f, xx, yy);
+            f.cu_log2[i] = (uint8_t)log2; f.cu_intra[i] = (uint8_t)intra; f.cu_flags[i] = (uint8_t)flags;
+            f.cu_intra_mode[i] = (uint8_t)mode; f.cu_cbf[i] = (uint8_t)cbf;
+            f.cu_mv[i * 2] = (int16_t)mvx; f.cu_mv[i * 2 + 1] = (int16_t)mvy;
+          }
+        if (c.overrun()) return DEC_ERR_INVALID;
+        z += 1 << (2 * (log2 - 3));
+      }
+      if (f.wpp && cx == 1) memcpy(saved, c.ctx, sizeof(saved));
+      const bool last = (cy == hc - 1 && cx == wc - 1);
+      int end = c.terminate();
+      if (end != (last ? 1 : 0)) return DEC_ERR_UNSUPPORTED;      // slice must cover the whole picture
+      if (!last && f.wpp && cx == wc - 1) {
+        if (!c.terminate()) return DEC_ERR_INVALID;               // end_of_subset_one_bit
+        base += c.bytes_consumed();
+        if (base >= len) return DEC_ERR_INVALID;
+        uint8_t keep[CTX_COUNT]; memcpy(keep, c.ctx, sizeof(keep));
+        c.start(data + base, len - base);
+        memcpy(c.ctx, keep, sizeof(keep));
+      }
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ GPU reconstruction
+int Decoder::run_gpu(bool is_intra, int slice_qp, bool deblock)
+{
+  if (hipSetDevice(device_) != hipSuccess) return DEC_ERR_GPU;
+  const size_t nb8 = (size_t)cw_ * ch_ / 64;
+  const size_t nlev = levels_.size(), ntu = tus_.size();
+  if (nlev > h_levels_cap_) {
+    if (h_levels_) hipHostFree(h_levels_);
+    if (d_levels_) hipFree(d_levels_);
+    h_levels_cap_ = nlev * 2 + 4096;
+    if (hipHostMalloc(&h_levels_, h_levels_cap_ * sizeof(int16_t), hipHostMallocDefault) != hipSuccess) return DEC_ERR_GPU;
+    if (hipMalloc(&d_levels_, h_levels_cap_ * sizeof(int16_t)) != hipSuccess) return DEC_ERR_GPU;
+    d_levels_cap_ = h_levels_cap_;
+  }
+  if (ntu > h_tus_cap_) {
+    if (h_tus_) hipHostFree(h_tus_);
+    if (d_tus_) hipFree(d_tus_);
+    h_tus_cap_ = ntu * 2 + 256;
+    if (hipHostMalloc(&h_tus_, h_tus_cap_ * sizeof(TuDesc), hipHostMallocDefault) != hipSuccess) return DEC_ERR_GPU;
+    if (hipMalloc(&d_tus_, h_tus_cap_ * sizeof(TuDesc)) != hipSuccess) return DEC_ERR_GPU;
+    d_tus_cap_ = h_tus_cap_;
+  }
+  if (nlev) memcpy(h_levels_, levels_.data(), nlev * sizeof(int16_t));
+  if (ntu) memcpy(h_tus_, tus_.data(), ntu * sizeof(TuDesc));
+  hipError_t e = hipSuccess;
+  e = hipMemcpyAsync(d_cu_, h_cu_, nb8 * 7, hipMemcpyHostToDevice, stream_); if (e != hipSuccess) return DEC_ERR_GPU;
+  e = hipMemcpyAsync(d_mv_, h_mv_, nb8 * 4, hipMemcpyHostToDevice, stream_); if (e != hipSuccess) return DEC_ERR_GPU;
+  if (nlev) { e = hipMemcpyAsync(d_levels_, h_levels_, nlev * sizeof(int16_t), hipMemcpyHostToDevice, stream_); if (e != hipSuccess) return DEC_ERR_GPU; }
+  if (ntu) { e = hipMemcpyAsync(d_tus_, h_tus_, ntu * sizeof(TuDesc), hipMemcpyHostToDevice, stream_); if (e != hipSuccess) return DEC_ERR_GPU; }
+  f_.qp = slice_qp; f_.qpc = kChromaQp[slice_qp]; f_.is_intra = is_intra;
+  for (int c = 0; c < 3; c++) { f_.rec[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
+  const EncFrame f = f_;
+  timed(DK_SCATTER, [&] { launch_scatter_levels(f, d_tus_, (int)ntu, d_levels_, stream_); });
+  if (is_intra) {
+    if (hipMemsetAsync(sync_, 0, sizeof(uint32_t) * (size_t)(ch_ / 64), stream_) != hipSuccess) return DEC_ERR_GPU;
+    timed(DK_INTRA_RECON, [&] { launch_dec_intra_recon(f, stream_); });
+  } else {
+    timed(DK_INTER_RECON, [&] { launch_dec_inter_recon(f, stream_); });
+  }
+  if (deblock) timed(DK_DEBLOCK, [&] { launch_deblock(f, stream_); });
+  if (hipMemcpyAsync(h_err_, err_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_) != hipSuccess) return DEC_ERR_GPU;
+  if (hipStreamSynchronize(stream_) != hipSuccess) return DEC_ERR_GPU;
+  if (*h_err_) { fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x\n", *h_err_); return DEC_ERR_GPU; }
+  if (profiling_) {
+    for (size_t i = 0; i < ev_used_; i++) { float ms = 0; hipEventElapsedTime(&ms, ev_pool_[i].a, ev_pool_[i].b); k_ms_[ev_pool_[i].id] += ms; k_n_[ev_pool_[i].id]++; }
+    ev_used_ = 0;
+  }
+  int t = cur_idx_; cur_idx_ = ref_idx_; ref_idx_ = t;          // rec_[ref_idx_] = picture just decoded
+  have_ref_ = true;
+  return 0;
+}
+
+bool Decoder::get_picture(DecodedPicture *out)
+{
+  if (!pic_ready_) return false;
+  *out = out_;
+  return true;
+}
+
+bool Decoder::debug_copy(const char *what, void *dst, size_t bytes)
+{
+  if (!cw_) return false;
+  const size_t npx = (size_t)cw_ * ch_;
+  std::string w(what);
+  for (int c = 0; c < 3; c++) {
+    size_t n = c ? npx / 4 : npx;
+    if (w == std::string("rec") + char('0' + c)) { if (bytes > n) return false; return hipMemcpy(dst, rec_[ref_idx_][c], bytes, hipMemcpyDeviceToHost) == hipSuccess; }
+  }
+  return false;
+}
+
+}  // namespace kvzx

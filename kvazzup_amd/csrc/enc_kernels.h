@@ -10,5 +10,11 @@ void launch_inter_signal(const EncFrame &f, hipStream_t st);
 void launch_intra_analyse(const EncFrame &f, hipStream_t st);
 void launch_intra_recon(const EncFrame &f, hipStream_t st);
 void launch_deblock(const EncFrame &f, hipStream_t st);
+// decoder variants: levels + cbf given (coef planes / cu_cbf), prediction + residual only
+void launch_dec_inter_recon(const EncFrame &f, hipStream_t st);
+void launch_dec_intra_recon(const EncFrame &f, hipStream_t st);
+// scatter packed levels (TU descriptors) into the plane-shaped level arrays
+struct TuDesc { uint16_t x, y; uint8_t plane, log2; uint16_t pad; uint32_t offset; };
+void launch_scatter_levels(const EncFrame &f, const TuDesc *tus, int ntu, const int16_t *packed, hipStream_t st);
 void launch_entropy(const EncFrame &f, hipStream_t st);
 }  // namespace kvzx

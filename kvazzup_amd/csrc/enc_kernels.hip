@@ -148,6 +148,15 @@ __device__ __forceinline__ void transform_stage(const int *in, int *out, const i
   }
 }
 
+// inverse transform (H.265 8.6.4.2) of the dequantised coefficients in `b`; residual returned in `b`
+__device__ __forceinline__ void inverse_group(int *a, int *b, const int8_t (*C)[33], int log2n, int total, int nthreads, int tid)
+{
+  transform_stage<false, true, true>(b, a, C, log2n, total, 7, nthreads, tid);                     // columns
+  __syncthreads();
+  transform_stage<true, true, false>(a, b, C, log2n, total, 12, nthreads, tid);                    // rows
+  __syncthreads();
+}
+
 // forward (res -> coef), quantise, dequantise, inverse (-> res) for one group held in `a` (in/out),
 // with scratch `b`.  Levels are left in `lev` (int16).  Returns through `nz_flags` (LDS) a bit
 // per TU that has non-zero levels.  All threads of the workgroup must call this.
@@ -166,10 +175,7 @@ __device__ __forceinline__ void code_group(int *a, int *b, int16_t *lev, const i
     b[o] = dequant_coef(l, qp, log2n);
   }
   __syncthreads();
-  transform_stage<false, true, true>(b, a, C, log2n, total, 7, nthreads, tid);                     // columns, inverse
-  __syncthreads();
-  transform_stage<true, true, false>(a, b, C, log2n, total, 12, nthreads, tid);                    // rows, inverse
-  __syncthreads();
+  inverse_group(a, b, C, log2n, total, nthreads, tid);
 }
 
 __device__ __forceinline__ void load_dct_matrix(int8_t (*C)[33], int tid, int nthreads)
@@ -221,6 +227,9 @@ __device__ __forceinline__ int mc_luma_sample(const uint8_t *p, int w, int h, in
   return clip8((v + 32) >> 6);
 }
 
+// DEC = false: encoder (residual from the source picture, levels written out).
+// DEC = true: decoder (levels and cbf given, prediction + residual only).
+template <bool DEC>
 __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
 {
   __shared__ int a[1024], b[1024];
@@ -235,6 +244,7 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
   const int cw2 = f.cw >> 1, ch2 = f.ch >> 1;
   load_dct_matrix(C, tid, 256);
   if (tid < 3) nz[tid] = 0;
+  __syncthreads();
   // ---- luma: prediction and residual, TU-major layout
   const int l2 = split ? 4 : 5, n = 1 << l2;
   for (int o = tid; o < 1024; o += 256) {
@@ -244,17 +254,22 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
     int tu = split ? ((y >> 4) * 2 + (x >> 4)) : 0;
     int idx = (tu << (2 * l2)) + ((y & (n - 1)) << l2) + (x & (n - 1));
     pred[idx] = (uint8_t)p;
-    a[idx] = (int)f.src[0][(y0 + y) * f.cw + x0 + x] - p;
+    if (DEC) {
+      bool has = f.cu_cbf[bi] & 1;
+      b[idx] = has ? dequant_coef(f.coef[0][(y0 + y) * f.cw + x0 + x], f.qp, l2) : 0;
+      if (has) atomicOr(&nz[0], 1u << tu);
+    } else a[idx] = (int)f.src[0][(y0 + y) * f.cw + x0 + x] - p;
   }
   __syncthreads();
-  code_group(a, b, lev, C, l2, split ? 4 : 1, f.qp, 0, &nz[0], 256, tid);
+  if (DEC) inverse_group(a, b, C, l2, 1024, 256, tid);
+  else code_group(a, b, lev, C, l2, split ? 4 : 1, f.qp, 0, &nz[0], 256, tid);
   for (int o = tid; o < 1024; o += 256) {
     int tu = o >> (2 * l2), rem = o & (n * n - 1), r = rem >> l2, c = rem & (n - 1);
     int x = (split ? (tu & 1) * 16 : 0) + c, y = (split ? (tu >> 1) * 16 : 0) + r;
     bool has = (nz[0] >> tu) & 1;
     int g = (y0 + y) * f.cw + x0 + x;
     f.rec[0][g] = (uint8_t)(has ? clip8(pred[o] + b[o]) : pred[o]);
-    if (has) f.coef[0][g] = lev[o];
+    if (has && !DEC) f.coef[0][g] = lev[o];
   }
   __syncthreads();
   // ---- chroma: Cb and Cr together (512 samples): plane-major, then TU-major
@@ -267,10 +282,15 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
     int tu = pl * (split ? 4 : 1) + (split ? ((y >> 3) * 2 + (x >> 3)) : 0);
     int idx = (tu << (2 * cl2)) + ((y & (cn - 1)) << cl2) + (x & (cn - 1));
     pred[idx] = (uint8_t)p;
-    a[idx] = (int)f.src[1 + pl][cy * cw2 + cx] - p;
+    if (DEC) {
+      bool has = (f.cu_cbf[bi] >> (1 + pl)) & 1;
+      b[idx] = has ? dequant_coef(f.coef[1 + pl][cy * cw2 + cx], f.qpc, cl2) : 0;
+      if (has) atomicOr(&nz[1], 1u << tu);
+    } else a[idx] = (int)f.src[1 + pl][cy * cw2 + cx] - p;
   }
   __syncthreads();
-  code_group(a, b, lev, C, cl2, split ? 8 : 2, f.qpc, 0, &nz[1], 256, tid);
+  if (DEC) inverse_group(a, b, C, cl2, 512, 256, tid);
+  else code_group(a, b, lev, C, cl2, split ? 8 : 2, f.qpc, 0, &nz[1], 256, tid);
   for (int o = tid; o < 512; o += 256) {
     int tu = o >> (2 * cl2), rem = o & (cn * cn - 1), r = rem >> cl2, c = rem & (cn - 1);
     int pl = split ? (tu >> 2) : tu, st = split ? (tu & 3) : 0;
@@ -278,10 +298,10 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
     bool has = (nz[1] >> tu) & 1;
     int g = ((y0 >> 1) + y) * cw2 + (x0 >> 1) + x;
     f.rec[1 + pl][g] = (uint8_t)(has ? clip8(pred[o] + b[o]) : pred[o]);
-    if (has) f.coef[1 + pl][g] = lev[o];
+    if (has && !DEC) f.coef[1 + pl][g] = lev[o];
   }
   __syncthreads();
-  if (tid < 16) {
+  if (!DEC && tid < 16) {
     int bx = tid & 3, by = tid >> 2, k = split ? ((by >> 1) * 2 + (bx >> 1)) : 0;
     int cbf = (int)((nz[0] >> k) & 1);
     if (split) cbf |= (int)((nz[1] >> k) & 1) << 1 | (int)((nz[1] >> (4 + k)) & 1) << 2;
@@ -422,7 +442,8 @@ struct IntraScratch {
   uint32_t nz;
 };
 
-__device__ __forceinline__ bool intra_recon_tu(const EncFrame &f, IntraScratch &s, int cidx, int x0, int y0, int l2, int mode, int qp, int tid)
+template <bool DEC>
+__device__ __forceinline__ bool intra_recon_tu(const EncFrame &f, IntraScratch &s, int cidx, int x0, int y0, int l2, int mode, int qp, bool dec_has, int tid)
 {
   const int n = 1 << l2, pw = cidx ? (f.cw >> 1) : f.cw;
   uint8_t *rec = f.rec[cidx];
@@ -435,20 +456,23 @@ __device__ __forceinline__ bool intra_recon_tu(const EncFrame &f, IntraScratch &
     int y = o >> l2, x = o & (n - 1);
     int p = intra_pred_sample(filt ? s.lf : s.left, filt ? s.tf : s.top, n, l2, cidx, mode, dc, x, y);
     s.pred[o] = (uint8_t)p;
-    s.a[o] = (int)f.src[cidx][(y0 + y) * pw + x0 + x] - p;
+    if (DEC) s.b[o] = dec_has ? dequant_coef(f.coef[cidx][(y0 + y) * pw + x0 + x], qp, l2) : 0;
+    else s.a[o] = (int)f.src[cidx][(y0 + y) * pw + x0 + x] - p;
   }
   __syncthreads();
-  code_group(s.a, s.b, s.lev, s.C, l2, 1, qp, 1, &s.nz, 256, tid);
-  const bool has = s.nz != 0;
+  if (DEC) { if (dec_has) inverse_group(s.a, s.b, s.C, l2, n * n, 256, tid); }
+  else code_group(s.a, s.b, s.lev, s.C, l2, 1, qp, 1, &s.nz, 256, tid);
+  const bool has = DEC ? dec_has : (s.nz != 0);
   for (int o = tid; o < n * n; o += 256) {
     int y = o >> l2, x = o & (n - 1), g = (y0 + y) * pw + x0 + x;
     rec[g] = (uint8_t)(has ? clip8(s.pred[o] + s.b[o]) : s.pred[o]);
-    if (has) f.coef[cidx][g] = s.lev[o];
+    if (has && !DEC) f.coef[cidx][g] = s.lev[o];
   }
   __syncthreads();
   return has;
 }
 
+template <bool DEC>
 __global__ __launch_bounds__(256) void k_intra_recon(EncFrame f)
 {
   __shared__ IntraScratch s;
@@ -463,11 +487,12 @@ __global__ __launch_bounds__(256) void k_intra_recon(EncFrame f)
       int x0 = cx * 64 + xi * 8, y0 = row * 64 + yi * 8;
       int bi = b8idx(f, x0, y0);
       int l2 = f.cu_log2[bi], mode = f.cu_intra_mode[bi];
-      int cbf = intra_recon_tu(f, s, 0, x0, y0, l2, mode, f.qp, tid) ? 1 : 0;
-      cbf |= intra_recon_tu(f, s, 1, x0 >> 1, y0 >> 1, l2 - 1, mode, f.qpc, tid) ? 2 : 0;
-      cbf |= intra_recon_tu(f, s, 2, x0 >> 1, y0 >> 1, l2 - 1, mode, f.qpc, tid) ? 4 : 0;
+      const int given = DEC ? f.cu_cbf[bi] : 0;
+      int cbf = intra_recon_tu<DEC>(f, s, 0, x0, y0, l2, mode, f.qp, given & 1, tid) ? 1 : 0;
+      cbf |= intra_recon_tu<DEC>(f, s, 1, x0 >> 1, y0 >> 1, l2 - 1, mode, f.qpc, (given >> 1) & 1, tid) ? 2 : 0;
+      cbf |= intra_recon_tu<DEC>(f, s, 2, x0 >> 1, y0 >> 1, l2 - 1, mode, f.qpc, (given >> 2) & 1, tid) ? 4 : 0;
       int nb = 1 << (l2 - 3);
-      if (tid < nb * nb) f.cu_cbf[b8idx(f, x0 + (tid % nb) * 8, y0 + (tid / nb) * 8)] = (uint8_t)cbf;
+      if (!DEC && tid < nb * nb) f.cu_cbf[b8idx(f, x0 + (tid % nb) * 8, y0 + (tid / nb) * 8)] = (uint8_t)cbf;
       z += 1 << (2 * (l2 - 3));
     }
     publish_progress(&f.sync[row], (uint32_t)(cx + 1));
@@ -511,58 +536,124 @@ __global__ __launch_bounds__(256) void k_deblock_h(EncFrame f)
 }
 
 // =============================================================================================
-// Entropy coding: one workgroup (one wave, lane 0 active) per CTU row / WPP substream
+// Entropy coding: one workgroup (one wave) per CTU row / WPP substream.  The wave stages what
+// the coder needs in LDS with coalesced parallel loads -- the per-CU records of the CTU and its
+// left / above neighbours, and each transform block as a TuDigest (one lane per 4x4 sub-block)
+// -- and lane 0 runs the serial CABAC engine on that staged data.
 // =============================================================================================
+struct TileView {
+  const CuRec *tile;                 // [9][9] records: b8 (bx0 + tx, by0 + ty)
+  int bx0, by0;
+  __device__ CuRec at(int x, int y) const { return tile[((y >> 3) - by0) * 9 + ((x >> 3) - bx0)]; }
+};
+
+__device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d, const int16_t *lv, int stride, int log2, int scan_idx, int lane)
+{
+  const int sbl = log2 - 2, nsb2 = 1 << (2 * sbl);
+  d.csbf[lane] = 0;
+  __syncthreads();
+  bool nz = false;
+  if (lane < nsb2) {
+    int xs, ys; scan_pos(t, scan_idx, sbl, lane, xs, ys);
+    const int16_t *p = lv + (ys << 2) * stride + (xs << 2);
+    uint2 r0 = *reinterpret_cast<const uint2 *>(p), r1 = *reinterpret_cast<const uint2 *>(p + stride);
+    uint2 r2 = *reinterpret_cast<const uint2 *>(p + 2 * stride), r3 = *reinterpret_cast<const uint2 *>(p + 3 * stride);
+    uint2 *dst = reinterpret_cast<uint2 *>(&d.raster[lane * 16]);
+    dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+    uint32_t w[8] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y};
+    uint32_t rm = 0;                                   // raster-order non-zero mask
+#pragma unroll
+    for (int i = 0; i < 8; i++) { if (w[i] & 0xffffu) rm |= 1u << (2 * i); if (w[i] >> 16) rm |= 1u << (2 * i + 1); }
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) if ((rm >> scan_raster4(t, scan_idx, k)) & 1) m |= 1u << k;
+    d.mask[lane] = (uint16_t)m;
+    nz = m != 0;
+    if (nz) d.csbf[ys * 8 + xs] = 1;
+  }
+  uint64_t sb = __ballot(nz);
+  if (lane == 0) d.sbmask = sb;
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(64) void k_entropy(EncFrame f)
 {
-  __shared__ uint8_t ctx[CTX_COUNT];
-  const int row = blockIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
-  if (threadIdx.x != 0) return;
-  CabacEnc c; c.nbins = 0;
+  __shared__ uint8_t ctx[CTX_COUNT + 6];
+  __shared__ CuRec tile[81];
+  __shared__ __attribute__((aligned(16))) TuDigest dg;
+  __shared__ CoreTabs tabs;
+  const int row = blockIdx.x, lane = threadIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
+  core_tabs_fill_entry(tabs, lane);
   const int init_type = f.is_intra ? 0 : 1;
-  if (f.wpp) {
-    cabac_start(c, f.row_buf + (size_t)row * f.row_cap, f.row_cap, ctx);
-    if (row == 0) cabac_init_contexts(ctx, init_type, f.qp);
-    else {
-      uint32_t spins = 0;
-      while (__hip_atomic_load(&f.sync[row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 26)) { atomicOr(f.err, 2u); break; }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      const uint8_t *saved = f.wpp_ctx + (size_t)(row - 1) * CTX_COUNT;
-      for (int i = 0; i < CTX_COUNT; i++) ctx[i] = saved[i];
-    }
+  const int nrows = f.wpp ? 1 : hc;                   // CTU rows coded by this workgroup
+  if (!f.wpp && row != 0) return;
+  CabacEnc c; c.nbins = 0;
+  cabac_start(c, f.row_buf + (size_t)row * f.row_cap, f.wpp ? f.row_cap : f.row_cap * hc, ctx, &tabs);
+  if (row == 0) { if (lane == 0) cabac_init_contexts(ctx, init_type, f.qp); }
+  else {
+    wait_progress(&f.sync[row - 1], 1u, f.err);
+    const uint8_t *saved = f.wpp_ctx + (size_t)(row - 1) * CTX_COUNT;
+    for (int i = lane; i < CTX_COUNT; i += 64) ctx[i] = saved[i];
+  }
+  __syncthreads();
+  for (int ry = 0; ry < nrows; ry++) {
+    const int cy = row + ry;
     for (int cx = 0; cx < wc; cx++) {
-      enc_ctu(f, c, cx * 64, row * 64);
-      if (cx == 1) {
-        uint8_t *dst = f.wpp_ctx + (size_t)row * CTX_COUNT;
-        for (int i = 0; i < CTX_COUNT; i++) dst[i] = ctx[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&f.sync[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // stage the CU records of this CTU plus one 8x8 column to the left and one row above
+      const int bx0 = cx * 8 - 1, by0 = cy * 8 - 1;
+      for (int i = lane; i < 81; i += 64) {
+        int bx = bx0 + i % 9, by = by0 + i / 9;
+        CuRec r; r.log2 = 0; r.intra = 0; r.flags = 0; r.merge_idx = 0; r.mvp_idx = 0; r.intra_mode = 0; r.cbf = 0; r.pad = 0; r.mvdx = 0; r.mvdy = 0;
+        if (bx >= 0 && by >= 0) {
+          int g = by * f.b8w + bx;
+          r.log2 = f.cu_log2[g]; r.intra = f.cu_intra[g]; r.flags = f.cu_flags[g]; r.merge_idx = f.cu_merge_idx[g];
+          r.mvp_idx = f.cu_mvp_idx[g]; r.intra_mode = f.cu_intra_mode[g]; r.cbf = f.cu_cbf[g];
+          r.mvdx = f.cu_mvd[g * 2]; r.mvdy = f.cu_mvd[g * 2 + 1];
+        }
+        tile[i] = r;
       }
-      bool last = (row == hc - 1 && cx == wc - 1);
-      cabac_terminate(c, last);                                  // end_of_slice_segment_flag
-      if (!last && cx == wc - 1) cabac_terminate(c, 1);          // end_of_subset_one_bit
+      __syncthreads();
+      TileView v; v.tile = tile; v.bx0 = bx0; v.by0 = by0;
+      for (int z = 0; z < 64;) {
+        int xi, yi; ctu_z_to_xy(z, xi, yi);
+        const int x0 = cx * 64 + xi * 8, y0 = cy * 64 + yi * 8;
+        const CuRec cu = v.at(x0, y0);
+        if (lane == 0) {
+          enc_split_flags(v, c, f.cw, f.ch, x0, y0, z, cu.log2);
+          enc_cu_header(v, c, f.cw, f.ch, f.is_intra != 0, x0, y0, cu);
+        }
+        const int cbf = (cu.flags & CU_SKIP) ? 0 : cu.cbf;        // wave-uniform
+        for (int ci = 0; ci < 3; ci++) {
+          if (!((cbf >> ci) & 1)) continue;
+          const int l2 = ci ? cu.log2 - 1 : cu.log2, pw = ci ? (f.cw >> 1) : f.cw;
+          const int px = ci ? (x0 >> 1) : x0, py = ci ? (y0 >> 1) : y0;
+          const int scan = intra_scan_idx(cu.intra, l2, ci, cu.intra_mode);
+          digest_build_wave(&tabs, dg, f.coef[ci] + py * pw + px, pw, l2, scan, lane);
+          if (lane == 0) enc_residual_digest(c, dg, l2, ci, scan);
+          __syncthreads();
+        }
+        z += 1 << (2 * (cu.log2 - 3));
+      }
+      if (f.wpp && cx == 1) {
+        __syncthreads();
+        uint8_t *dst = f.wpp_ctx + (size_t)row * CTX_COUNT;
+        for (int i = lane; i < CTX_COUNT; i += 64) dst[i] = ctx[i];
+        publish_progress(&f.sync[row], 1u);
+      }
+      if (lane == 0) {
+        bool last = (cy == hc - 1 && cx == wc - 1);
+        cabac_terminate(c, last);                                  // end_of_slice_segment_flag
+        if (f.wpp && !last && cx == wc - 1) cabac_terminate(c, 1); // end_of_subset_one_bit
+      }
+      __syncthreads();
     }
+  }
+  if (lane == 0) {
     cabac_finish(c);
     f.row_len[row] = c.pos;
     if (c.pos > c.cap) atomicOr(f.err, 4u);
-  } else {
-    if (row != 0) return;
-    cabac_start(c, f.row_buf, f.row_cap * hc, ctx);
-    cabac_init_contexts(ctx, init_type, f.qp);
-    for (int cy = 0; cy < hc; cy++)
-      for (int cx = 0; cx < wc; cx++) {
-        enc_ctu(f, c, cx * 64, cy * 64);
-        cabac_terminate(c, cy == hc - 1 && cx == wc - 1);
-      }
-    cabac_finish(c);
-    f.row_len[0] = c.pos;
-    if (c.pos > c.cap) atomicOr(f.err, 4u);
+    if (f.bins) atomicAdd((unsigned long long *)f.bins, (unsigned long long)c.nbins);
   }
-  if (f.bins) atomicAdd((unsigned long long *)f.bins, (unsigned long long)c.nbins);
 }
 
 // =============================================================================================
@@ -580,22 +671,41 @@ __global__ __launch_bounds__(256) void k_pad_input(const uint8_t *in, int w, int
 }
 
 // =============================================================================================
+// Decoder input: levels of the coded transform blocks arrive packed (block after block, row-major
+// inside a block); this kernel writes them to their place in the plane-shaped level arrays.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_scatter_levels(EncFrame f, const TuDesc *tus, const int16_t *packed)
+{
+  const TuDesc d = tus[blockIdx.x];
+  const int n = 1 << d.log2, pw = d.plane ? (f.cw >> 1) : f.cw;
+  int16_t *dst = f.coef[d.plane] + (size_t)d.y * pw + d.x;
+  const int16_t *src = packed + d.offset;
+  for (int o = threadIdx.x; o < n * n; o += 256) dst[(o >> d.log2) * pw + (o & (n - 1))] = src[o];
+}
+
+// =============================================================================================
 // launch wrappers
 // =============================================================================================
+void launch_scatter_levels(const EncFrame &f, const TuDesc *tus, int ntu, const int16_t *packed, hipStream_t st)
+{
+  if (ntu > 0) hipLaunchKernelGGL(k_scatter_levels, dim3(ntu), dim3(256), 0, st, f, tus, packed);
+}
 void launch_pad_input(const uint8_t *in, int w, int h, uint8_t *dst, int cw, int ch, hipStream_t st)
 {
   dim3 g((cw / 4 + 255) / 256, ch);
   hipLaunchKernelGGL(k_pad_input, g, dim3(256), 0, st, in, w, h, dst, cw, ch);
 }
 void launch_me(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_me, dim3(f.cw / 32, f.ch / 32), dim3(256), 0, st, f); }
-void launch_inter_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_inter_recon, dim3(f.cw / 32, f.ch / 32), dim3(256), 0, st, f); }
+void launch_inter_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_inter_recon<false>, dim3(f.cw / 32, f.ch / 32), dim3(256), 0, st, f); }
+void launch_dec_inter_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_inter_recon<true>, dim3(f.cw / 32, f.ch / 32), dim3(256), 0, st, f); }
 void launch_inter_signal(const EncFrame &f, hipStream_t st)
 {
   int n = (f.cw / 16) * (f.ch / 16);
   hipLaunchKernelGGL(k_inter_signal, dim3((n + 255) / 256), dim3(256), 0, st, f);
 }
 void launch_intra_analyse(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_analyse, dim3(f.cw / 32, f.ch / 32), dim3(256), 0, st, f); }
-void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_recon, dim3(f.ch / 64), dim3(256), 0, st, f); }
+void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_recon<false>, dim3(f.ch / 64), dim3(256), 0, st, f); }
+void launch_dec_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_recon<true>, dim3(f.ch / 64), dim3(256), 0, st, f); }
 void launch_deblock(const EncFrame &f, hipStream_t st)
 {
   int nv = ((f.cw >> 3) - 1) * (f.ch >> 2), nh = (f.cw >> 2) * ((f.ch >> 3) - 1);

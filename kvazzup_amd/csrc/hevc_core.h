@@ -121,7 +121,26 @@ KVZ_HD void cabac_init_contexts(uint8_t *ctx, int init_type, int qp)
   }
 }
 
+// Small tables the serial coder touches for every bin, gathered so that the entropy kernel can
+// keep one copy in LDS (a dependent global-memory lookup per bin is what made the first version
+// latency bound); the host tests use a static copy.
+struct CoreTabs {
+  uint32_t lps4[64];                 // rangeTabLps row packed little-endian: byte q = range for quarter q
+  uint8_t next_lps[64];
+  uint8_t diag4x[16], diag4y[16], diag8x[64], diag8y[64], diag2x[4], diag2y[4];
+  uint8_t ctxmap4x4[16];
+};
+KVZ_HD void core_tabs_fill_entry(CoreTabs &t, int i)     // i in [0, 64): callers may spread i over lanes
+{
+  t.lps4[i] = (uint32_t)kRangeLps[i][0] | ((uint32_t)kRangeLps[i][1] << 8) | ((uint32_t)kRangeLps[i][2] << 16) | ((uint32_t)kRangeLps[i][3] << 24);
+  t.next_lps[i] = kNextLps[i];
+  t.diag8x[i] = kDiag8x[i]; t.diag8y[i] = kDiag8y[i];
+  if (i < 16) { t.diag4x[i] = kDiag4x[i]; t.diag4y[i] = kDiag4y[i]; t.ctxmap4x4[i] = kCtxIdxMap4x4[i]; }
+  if (i < 4) { t.diag2x[i] = kDiag2x[i]; t.diag2y[i] = kDiag2y[i]; }
+}
+
 struct CabacEnc {
+  const CoreTabs *tabs;
   uint32_t low, range;
   int bits_left, num_buffered, buffered_byte;
   uint8_t *buf; int pos, cap;
@@ -131,8 +150,9 @@ struct CabacEnc {
 
 KVZ_HD void cabac_put_byte(CabacEnc &c, int b) { if (c.pos < c.cap) c.buf[c.pos] = (uint8_t)b; c.pos++; }
 
-KVZ_HD void cabac_start(CabacEnc &c, uint8_t *buf, int cap, uint8_t *ctx)
+KVZ_HD void cabac_start(CabacEnc &c, uint8_t *buf, int cap, uint8_t *ctx, const CoreTabs *tabs)
 {
+  c.tabs = tabs;
   c.low = 0; c.range = 510; c.bits_left = 23; c.num_buffered = 0; c.buffered_byte = 0xff;
   c.buf = buf; c.pos = 0; c.cap = cap; c.ctx = ctx;
 }
@@ -158,7 +178,7 @@ KVZ_HD void cabac_bin(CabacEnc &c, int ci, int bin)
 {
   uint8_t s = c.ctx[ci];
   int state = s >> 1, mps = s & 1;
-  uint32_t lps = kRangeLps[state][(c.range >> 6) & 3];
+  uint32_t lps = (c.tabs->lps4[state] >> (((c.range >> 6) & 3) * 8)) & 0xffu;
   c.nbins++;
   c.range -= lps;
   if (bin != mps) {
@@ -167,7 +187,7 @@ KVZ_HD void cabac_bin(CabacEnc &c, int ci, int bin)
     c.low = (c.low + c.range) << nb;
     c.range = t;
     if (state == 0) mps ^= 1;
-    c.ctx[ci] = (uint8_t)((kNextLps[state] << 1) | mps);
+    c.ctx[ci] = (uint8_t)((c.tabs->next_lps[state] << 1) | mps);
     c.bits_left -= nb;
   } else {
     c.ctx[ci] = (uint8_t)(((state < 62 ? state + 1 : state) << 1) | mps);
@@ -242,15 +262,15 @@ KVZ_HD void cabac_finish(CabacEnc &c)
 // scans, no transform skip, no sign hiding.  `lv` points at the block's top-left level inside a
 // plane-shaped level array with pitch `stride`.  The block has at least one non-zero level.
 // ---------------------------------------------------------------------------------------------
-KVZ_HD void scan_pos(int scan_idx, int log2blk, int i, int &x, int &y)
+KVZ_HD void scan_pos(const CoreTabs *t, int scan_idx, int log2blk, int i, int &x, int &y)
 {
   // position i of the scan of a (1 << log2blk)^2 block (log2blk 0..3)
   int n = 1 << log2blk;
   if (scan_idx == 1) { x = i & (n - 1); y = i >> log2blk; return; }
   if (scan_idx == 2) { y = i & (n - 1); x = i >> log2blk; return; }
-  if (log2blk == 2) { x = kDiag4x[i]; y = kDiag4y[i]; }
-  else if (log2blk == 3) { x = kDiag8x[i]; y = kDiag8y[i]; }
-  else if (log2blk == 1) { x = kDiag2x[i]; y = kDiag2y[i]; }
+  if (log2blk == 2) { x = t->diag4x[i]; y = t->diag4y[i]; }
+  else if (log2blk == 3) { x = t->diag8x[i]; y = t->diag8y[i]; }
+  else if (log2blk == 1) { x = t->diag2x[i]; y = t->diag2y[i]; }
   else { x = 0; y = 0; }
 }
 
@@ -277,29 +297,57 @@ KVZ_HD void enc_abs_remaining(CabacEnc &c, int v, int rice)
   }
 }
 
-KVZ_HD void enc_residual(CabacEnc &c, const int16_t *lv, int stride, int log2, int cidx, int scan_idx)
+// A transform block prepared for entropy coding: levels of every 4x4 sub-block in raster order
+// inside the sub-block (sub-blocks indexed by their position i in the sub-block scan), a 16-bit
+// significance mask per sub-block with bit k = scan position k, a per-sub-block coded flag
+// addressed by (ys * 8 + xs), and the mask of non-empty sub-blocks (bit i).  On the GPU one wave
+// builds it cooperatively in LDS (one lane per sub-block); digest_build_serial is the host twin.
+struct TuDigest {
+  int16_t raster[64 * 16];
+  uint16_t mask[64];
+  uint8_t csbf[64];
+  uint64_t sbmask;
+};
+
+KVZ_HD int scan_raster4(const CoreTabs *t, int scan_idx, int k)
 {
-  const int sbl = log2 - 2, nsb = 1 << sbl, nsb2 = 1 << (2 * sbl);
-  uint64_t csbf = 0;                         // bit (ys * 8 + xs)
-  int last_sb = -1, last_pos = -1;
-  for (int i = nsb2 - 1; i >= 0; i--) {
-    int xs, ys; scan_pos(scan_idx, sbl, i, xs, ys);
-    int any = 0, lp = -1;
-    for (int k = 15; k >= 0; k--) {
-      int xp, yp; scan_pos(scan_idx, 2, k, xp, yp);
-      if (lv[((ys << 2) + yp) * stride + (xs << 2) + xp]) { any = 1; if (lp < 0) lp = k; }
-    }
-    if (any) { csbf |= 1ull << (ys * 8 + xs); if (last_sb < 0) { last_sb = i; last_pos = lp; } }
+  int x, y; scan_pos(t, scan_idx, 2, k, x, y);
+  return y * 4 + x;
+}
+
+KVZ_HD void digest_build_serial(const CoreTabs *t, TuDigest &d, const int16_t *lv, int stride, int log2, int scan_idx)
+{
+  const int sbl = log2 - 2, nsb2 = 1 << (2 * sbl);
+  d.sbmask = 0;
+  for (int i = 0; i < 64; i++) d.csbf[i] = 0;
+  for (int i = 0; i < nsb2; i++) {
+    int xs, ys; scan_pos(t, scan_idx, sbl, i, xs, ys);
+    for (int r = 0; r < 16; r++) d.raster[i * 16 + r] = lv[((ys << 2) + (r >> 2)) * stride + (xs << 2) + (r & 3)];
+    uint32_t m = 0;
+    for (int k = 0; k < 16; k++) if (d.raster[i * 16 + scan_raster4(t, scan_idx, k)]) m |= 1u << k;
+    d.mask[i] = (uint16_t)m;
+    d.csbf[ys * 8 + xs] = m != 0;
+    if (m) d.sbmask |= 1ull << i;
   }
+}
+
+KVZ_HD void enc_residual_digest(CabacEnc &c, TuDigest &d, int log2, int cidx, int scan_idx)
+{
+  const int sbl = log2 - 2, nsb = 1 << sbl;
+  const CoreTabs *t = c.tabs;
+  int last_sb = 63;
+  while (!((d.sbmask >> last_sb) & 1)) last_sb--;
+  int last_pos = 15;
+  { uint32_t m = d.mask[last_sb]; while (!((m >> last_pos) & 1)) last_pos--; }
   int xs0, ys0, xp0, yp0;
-  scan_pos(scan_idx, sbl, last_sb, xs0, ys0); scan_pos(scan_idx, 2, last_pos, xp0, yp0);
+  scan_pos(t, scan_idx, sbl, last_sb, xs0, ys0); scan_pos(t, scan_idx, 2, last_pos, xp0, yp0);
   int lx = (xs0 << 2) + xp0, ly = (ys0 << 2) + yp0;
   if (scan_idx == 2) { int t = lx; lx = ly; ly = t; }
   int pfx[2], nbs[2], sfx[2];
-  for (int d = 0; d < 2; d++) {
-    int v = d ? ly : lx;
-    if (v < 4) { pfx[d] = v; nbs[d] = 0; sfx[d] = 0; }
-    else { int len = ilog2((unsigned)v); pfx[d] = 2 * len + ((v >> (len - 1)) & 1); nbs[d] = len - 1; sfx[d] = v & ((1 << (len - 1)) - 1); }
+  for (int dd = 0; dd < 2; dd++) {
+    int v = dd ? ly : lx;
+    if (v < 4) { pfx[dd] = v; nbs[dd] = 0; sfx[dd] = 0; }
+    else { int len = ilog2((unsigned)v); pfx[dd] = 2 * len + ((v >> (len - 1)) & 1); nbs[dd] = len - 1; sfx[dd] = v & ((1 << (len - 1)) - 1); }
   }
   enc_last_prefix(c, CTX_LAST_X, log2, cidx, pfx[0]);
   enc_last_prefix(c, CTX_LAST_Y, log2, cidx, pfx[1]);
@@ -307,29 +355,25 @@ KVZ_HD void enc_residual(CabacEnc &c, const int16_t *lv, int stride, int log2, i
   if (pfx[1] > 3) cabac_bypass_bits(c, (uint32_t)sfx[1], nbs[1]);
   int c1 = 1;
   for (int i = last_sb; i >= 0; i--) {
-    int xs, ys; scan_pos(scan_idx, sbl, i, xs, ys);
-    int right = (xs < nsb - 1) ? (int)((csbf >> (ys * 8 + xs + 1)) & 1) : 0;
-    int below = (ys < nsb - 1) ? (int)((csbf >> ((ys + 1) * 8 + xs)) & 1) : 0;
-    int coded = (int)((csbf >> (ys * 8 + xs)) & 1), infer_dc = 0;
+    int xs, ys; scan_pos(t, scan_idx, sbl, i, xs, ys);
+    int right = (xs < nsb - 1) ? d.csbf[ys * 8 + xs + 1] : 0;
+    int below = (ys < nsb - 1) ? d.csbf[(ys + 1) * 8 + xs] : 0;
+    const uint32_t m = d.mask[i];
+    int coded = m != 0, infer_dc = 0;
     if (i < last_sb && i > 0) {
       cabac_bin(c, CTX_CSBF + ((right | below) ? 1 : 0) + (cidx ? 2 : 0), coded);
       infer_dc = 1;
     } else {
-      csbf |= 1ull << (ys * 8 + xs);       // inferred 1 for the last and the DC sub-block
+      d.csbf[ys * 8 + xs] = 1;              // inferred 1 for the last and the DC sub-block
       coded = 1;
     }
     if (!coded) continue;
-    int16_t v[16]; int nsig = 0;
-    for (int k = 0; k < 16; k++) {
-      int xp, yp; scan_pos(scan_idx, 2, k, xp, yp);
-      v[k] = lv[((ys << 2) + yp) * stride + (xs << 2) + xp]; nsig += v[k] != 0;
-    }
-    int prev_csbf = right | (below << 1);
+    const int prev_csbf = right | (below << 1);
     for (int k = (i == last_sb) ? last_pos - 1 : 15; k >= 0; k--) {
       if (k > 0 || !infer_dc) {
-        int xp, yp; scan_pos(scan_idx, 2, k, xp, yp);
+        int xp, yp; scan_pos(t, scan_idx, 2, k, xp, yp);
         int xc = (xs << 2) + xp, yc = (ys << 2) + yp, sc;
-        if (log2 == 2) sc = kCtxIdxMap4x4[(yc << 2) + xc];
+        if (log2 == 2) sc = t->ctxmap4x4[(yc << 2) + xc];
         else if (xc + yc == 0) sc = 0;
         else {
           if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
@@ -339,39 +383,48 @@ KVZ_HD void enc_residual(CabacEnc &c, const int16_t *lv, int stride, int log2, i
           if (cidx == 0) { if (i > 0) sc += 3; sc += (log2 == 3) ? ((scan_idx == 0) ? 9 : 15) : 21; }
           else sc += (log2 == 3) ? 9 : 12;
         }
-        cabac_bin(c, CTX_SIG + (cidx ? 27 : 0) + sc, v[k] != 0);
-        if (v[k]) infer_dc = 0;
+        int sig = (m >> k) & 1;
+        cabac_bin(c, CTX_SIG + (cidx ? 27 : 0) + sc, sig);
+        if (sig) infer_dc = 0;
       }
     }
-    if (!nsig) continue;
+    if (!m) continue;
     int ctx_set = (i > 0 && cidx == 0) ? 2 : 0;
     if (c1 == 0) ctx_set++;
     c1 = 1;
-    int ng1 = 0, g1pos = -1;
-    uint32_t signs = 0; int nsigns = 0;
-    for (int k = 15; k >= 0; k--) if (v[k]) {
-      if (ng1 < 8) {
-        int g1 = iabs(v[k]) > 1;
-        cabac_bin(c, CTX_GT1 + (cidx ? 16 : 0) + ctx_set * 4 + c1, g1);
-        ng1++;
-        if (g1) { c1 = 0; if (g1pos < 0) g1pos = k; }
-        else if (c1 > 0 && c1 < 3) c1++;
-      }
-      signs = (signs << 1) | (v[k] < 0 ? 1u : 0u); nsigns++;
+    // levels of the significant coefficients in coding order (scan position 15 .. 0)
+    int16_t lev[16]; int nsig = 0, g1idx = -1;
+    uint32_t signs = 0;
+    for (int k = 15; k >= 0; k--) if ((m >> k) & 1) {
+      int v = d.raster[i * 16 + scan_raster4(t, scan_idx, k)];
+      signs = (signs << 1) | (v < 0 ? 1u : 0u);
+      lev[nsig++] = (int16_t)iabs(v);
     }
-    if (g1pos >= 0) cabac_bin(c, CTX_GT2 + (cidx ? 4 : 0) + ctx_set, iabs(v[g1pos]) > 2);
-    cabac_bypass_bits(c, signs, nsigns);
-    int num_sig = 0, rice = 0;
-    for (int k = 15; k >= 0; k--) if (v[k]) {
-      int a = iabs(v[k]);
-      int base = (num_sig < 8) ? ((k == g1pos) ? 3 : 2) : 1;
+    for (int j = 0; j < nsig && j < 8; j++) {
+      int g1 = lev[j] > 1;
+      cabac_bin(c, CTX_GT1 + (cidx ? 16 : 0) + ctx_set * 4 + c1, g1);
+      if (g1) { c1 = 0; if (g1idx < 0) g1idx = j; }
+      else if (c1 > 0 && c1 < 3) c1++;
+    }
+    if (g1idx >= 0) cabac_bin(c, CTX_GT2 + (cidx ? 4 : 0) + ctx_set, lev[g1idx] > 2);
+    cabac_bypass_bits(c, signs, nsig);
+    int rice = 0;
+    for (int j = 0; j < nsig; j++) {
+      int a = lev[j];
+      int base = (j < 8) ? ((j == g1idx) ? 3 : 2) : 1;
       if (a >= base) {
         enc_abs_remaining(c, a - base, rice);
         if (a > 3 * (1 << rice)) rice = imin(rice + 1, 4);
       }
-      num_sig++;
     }
   }
+}
+
+KVZ_HD void enc_residual(CabacEnc &c, const int16_t *lv, int stride, int log2, int cidx, int scan_idx)
+{
+  TuDigest d;
+  digest_build_serial(c.tabs, d, lv, stride, log2, scan_idx);
+  enc_residual_digest(c, d, log2, cidx, scan_idx);
 }
 
 KVZ_HD int intra_scan_idx(int intra, int log2, int cidx, int mode)
@@ -409,13 +462,33 @@ KVZ_HD void enc_merge_idx(CabacEnc &c, int idx)
   for (int i = 1; i < 4 && idx >= i; i++) cabac_bypass(c, idx > i);
 }
 
+// Per-CU record as the entropy coder sees it.  A "view" type V provides `CuRec at(int x, int y)`
+// for any luma position of the current CTU and its left / above neighbours: FrameView reads the
+// per-8x8 arrays directly (host tests), the entropy kernel uses a tile staged in LDS.
+struct CuRec {
+  uint8_t log2, intra, flags, merge_idx, mvp_idx, intra_mode, cbf, pad;
+  int16_t mvdx, mvdy;
+};
+struct FrameView {
+  const EncFrame *f;
+  KVZ_HD CuRec at(int x, int y) const
+  {
+    int i = b8idx(*f, x, y);
+    CuRec r;
+    r.log2 = f->cu_log2[i]; r.intra = f->cu_intra[i]; r.flags = f->cu_flags[i]; r.merge_idx = f->cu_merge_idx[i];
+    r.mvp_idx = f->cu_mvp_idx[i]; r.intra_mode = f->cu_intra_mode[i]; r.cbf = f->cu_cbf[i]; r.pad = 0;
+    r.mvdx = f->cu_mvd[i * 2]; r.mvdy = f->cu_mvd[i * 2 + 1];
+    return r;
+  }
+};
+
 // Intra MPM candidates (H.265 8.4.2) for the CU at (x0, y0)
-KVZ_HD void intra_mpm(const EncFrame &f, int x0, int y0, int cand[3])
+template <class V>
+KVZ_HD void intra_mpm(const V &v, int cw, int ch, int x0, int y0, int cand[3])
 {
   int ca = 1, cb = 1;
-  if (avail64(f.cw, f.ch, x0, y0, x0 - 1, y0) && f.cu_intra[b8idx(f, x0 - 1, y0)]) ca = f.cu_intra_mode[b8idx(f, x0 - 1, y0)];
-  if (avail64(f.cw, f.ch, x0, y0, x0, y0 - 1) && f.cu_intra[b8idx(f, x0, y0 - 1)] && (y0 - 1) >= ((y0 >> 6) << 6))
-    cb = f.cu_intra_mode[b8idx(f, x0, y0 - 1)];
+  if (avail64(cw, ch, x0, y0, x0 - 1, y0)) { CuRec n = v.at(x0 - 1, y0); if (n.intra) ca = n.intra_mode; }
+  if (avail64(cw, ch, x0, y0, x0, y0 - 1) && (y0 - 1) >= ((y0 >> 6) << 6)) { CuRec n = v.at(x0, y0 - 1); if (n.intra) cb = n.intra_mode; }
   if (ca == cb) {
     if (ca < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
     else { cand[0] = ca; cand[1] = 2 + ((ca + 29) % 32); cand[2] = 2 + ((ca - 2 + 1) % 32); }
@@ -425,23 +498,39 @@ KVZ_HD void intra_mpm(const EncFrame &f, int x0, int y0, int cand[3])
   }
 }
 
-// coding_unit() + its transform_tree (TU == CU) for the CU at (x0, y0), H.265 7.3.8.5-7.3.8.10
-KVZ_HD void enc_cu(const EncFrame &f, CabacEnc &c, int x0, int y0, int log2)
+// split_cu_flag bins (7.3.8.4) for every quadtree level whose block starts at z-order index z
+// (in 8x8 units) of the CTU at (cx, cy), down to the CU of size (1 << cl) that starts there.
+template <class V>
+KVZ_HD void enc_split_flags(const V &v, CabacEnc &c, int cw, int ch, int x0, int y0, int z, int cl)
 {
-  const int bi = b8idx(f, x0, y0);
-  const int intra = f.cu_intra[bi], flags = f.cu_flags[bi], cbf = f.cu_cbf[bi];
-  if (!f.is_intra) {
-    int l = avail64(f.cw, f.ch, x0, y0, x0 - 1, y0) && (f.cu_flags[b8idx(f, x0 - 1, y0)] & CU_SKIP);
-    int a = avail64(f.cw, f.ch, x0, y0, x0, y0 - 1) && (f.cu_flags[b8idx(f, x0, y0 - 1)] & CU_SKIP);
+  for (int l2 = 6; l2 > 3; l2--) {
+    int zmask = (1 << (2 * (l2 - 3))) - 1;
+    if (z & zmask) continue;
+    int depth = 6 - l2;
+    int l = avail64(cw, ch, x0, y0, x0 - 1, y0) && (6 - v.at(x0 - 1, y0).log2) > depth;
+    int a = avail64(cw, ch, x0, y0, x0, y0 - 1) && (6 - v.at(x0, y0 - 1).log2) > depth;
+    cabac_bin(c, CTX_SPLIT_CU + l + a, cl < l2);
+    if (cl >= l2) break;
+  }
+}
+
+// coding_unit() up to and including the cbf flags of its single transform unit (7.3.8.5-7.3.8.10).
+// Returns the cbf bits (bit0 Y, bit1 Cb, bit2 Cr) whose residual_coding() must follow, 0 if none.
+template <class V>
+KVZ_HD int enc_cu_header(const V &v, CabacEnc &c, int cw, int ch, bool pic_intra, int x0, int y0, const CuRec &cu)
+{
+  const int intra = cu.intra, flags = cu.flags, cbf = cu.cbf, log2 = cu.log2;
+  if (!pic_intra) {
+    int l = avail64(cw, ch, x0, y0, x0 - 1, y0) && (v.at(x0 - 1, y0).flags & CU_SKIP);
+    int a = avail64(cw, ch, x0, y0, x0, y0 - 1) && (v.at(x0, y0 - 1).flags & CU_SKIP);
     cabac_bin(c, CTX_SKIP + l + a, flags & CU_SKIP);
-    if (flags & CU_SKIP) { enc_merge_idx(c, f.cu_merge_idx[bi]); return; }
+    if (flags & CU_SKIP) { enc_merge_idx(c, cu.merge_idx); return 0; }
     cabac_bin(c, CTX_PRED_MODE, intra);
   }
   if (!intra || log2 == 3) cabac_bin(c, CTX_PART_MODE, 1);        // PART_2Nx2N
-  int mode = 0;
   if (intra) {
-    mode = f.cu_intra_mode[bi];
-    int cand[3]; intra_mpm(f, x0, y0, cand);
+    int mode = cu.intra_mode;
+    int cand[3]; intra_mpm(v, cw, ch, x0, y0, cand);
     int mpm = -1;
     for (int k = 0; k < 3; k++) if (cand[k] == mode) { mpm = k; break; }
     cabac_bin(c, CTX_PREV_INTRA, mpm >= 0);
@@ -458,45 +547,42 @@ KVZ_HD void enc_cu(const EncFrame &f, CabacEnc &c, int x0, int y0, int log2)
     cabac_bin(c, CTX_CHROMA_MODE, 0);                               // intra_chroma_pred_mode = 4
   } else {
     cabac_bin(c, CTX_MERGE_FLAG, (flags & CU_MERGE) ? 1 : 0);
-    if (flags & CU_MERGE) enc_merge_idx(c, f.cu_merge_idx[bi]);
+    if (flags & CU_MERGE) enc_merge_idx(c, cu.merge_idx);
     else {
-      enc_mvd(c, f.cu_mvd[bi * 2], f.cu_mvd[bi * 2 + 1]);
-      cabac_bin(c, CTX_MVP_FLAG, f.cu_mvp_idx[bi]);
+      enc_mvd(c, cu.mvdx, cu.mvdy);
+      cabac_bin(c, CTX_MVP_FLAG, cu.mvp_idx);
       cabac_bin(c, CTX_RQT_ROOT_CBF, cbf != 0);
     }
-    if (!cbf) return;
+    if (!cbf) return 0;
   }
   cabac_bin(c, CTX_CBF_CHROMA, (cbf >> 1) & 1);
   cabac_bin(c, CTX_CBF_CHROMA, (cbf >> 2) & 1);
   if (intra || (cbf & 6)) cabac_bin(c, CTX_CBF_LUMA + 1, cbf & 1);
-  if (cbf & 1) enc_residual(c, f.coef[0] + y0 * f.cw + x0, f.cw, log2, 0, intra_scan_idx(intra, log2, 0, mode));
-  for (int ci = 1; ci <= 2; ci++)
-    if ((cbf >> ci) & 1)
-      enc_residual(c, f.coef[ci] + (y0 >> 1) * (f.cw >> 1) + (x0 >> 1), f.cw >> 1, log2 - 1, ci, intra_scan_idx(intra, log2 - 1, ci, mode));
+  return cbf;
 }
 
-// coding_quadtree() of one 64x64 CTU, iterative over the up-to-64 8x8 positions in z-order
+KVZ_HD void ctu_z_to_xy(int z, int &xi, int &yi)
+{
+  xi = 0; yi = 0;
+  for (int b = 0; b < 3; b++) { xi |= ((z >> (2 * b)) & 1) << b; yi |= ((z >> (2 * b + 1)) & 1) << b; }
+}
+
+// coding_quadtree() of one 64x64 CTU (serial reference form used by the host tests; the entropy
+// kernel walks the same way but stages data in LDS with the whole wave)
 KVZ_HD void enc_ctu(const EncFrame &f, CabacEnc &c, int cx, int cy)
 {
-  // z-order walk: a CU starts at every z-position that is aligned to its own size
+  FrameView v; v.f = &f;
   for (int z = 0; z < 64;) {
-    int xi = 0, yi = 0;
-    for (int b = 0; b < 3; b++) { xi |= ((z >> (2 * b)) & 1) << b; yi |= ((z >> (2 * b + 1)) & 1) << b; }
+    int xi, yi; ctu_z_to_xy(z, xi, yi);
     int x0 = cx + xi * 8, y0 = cy + yi * 8;
-    int cl = f.cu_log2[b8idx(f, x0, y0)];
-    // split_cu_flag for every ancestor level whose block starts here, from 64 down to the CU size
-    for (int l2 = 6; l2 > 3; l2--) {
-      int zmask = (1 << (2 * (l2 - 3))) - 1;
-      if (z & zmask) continue;                         // this level's block does not start at z
-      if (l2 < cl) break;
-      int depth = 6 - l2;
-      int l = avail64(f.cw, f.ch, x0, y0, x0 - 1, y0) && (6 - f.cu_log2[b8idx(f, x0 - 1, y0)]) > depth;
-      int a = avail64(f.cw, f.ch, x0, y0, x0, y0 - 1) && (6 - f.cu_log2[b8idx(f, x0, y0 - 1)]) > depth;
-      cabac_bin(c, CTX_SPLIT_CU + l + a, cl < l2);
-      if (cl >= l2) break;
-    }
-    enc_cu(f, c, x0, y0, cl);
-    z += 1 << (2 * (cl - 3));
+    CuRec cu = v.at(x0, y0);
+    enc_split_flags(v, c, f.cw, f.ch, x0, y0, z, cu.log2);
+    int cbf = enc_cu_header(v, c, f.cw, f.ch, f.is_intra != 0, x0, y0, cu);
+    if (cbf & 1) enc_residual(c, f.coef[0] + y0 * f.cw + x0, f.cw, cu.log2, 0, intra_scan_idx(cu.intra, cu.log2, 0, cu.intra_mode));
+    for (int ci = 1; ci <= 2; ci++)
+      if ((cbf >> ci) & 1)
+        enc_residual(c, f.coef[ci] + (y0 >> 1) * (f.cw >> 1) + (x0 >> 1), f.cw >> 1, cu.log2 - 1, ci, intra_scan_idx(cu.intra, cu.log2 - 1, ci, cu.intra_mode));
+    z += 1 << (2 * (cu.log2 - 3));
   }
 }
 
@@ -527,10 +613,9 @@ KVZ_HD NbMv nb_mv(const EncFrame &f, int xc, int yc, int xn, int yn)
 }
 KVZ_HD bool same_mv(const NbMv &a, const NbMv &b) { return a.mx == b.mx && a.my == b.my; }
 
-KVZ_HD void decide_signalling(const EncFrame &f, int x0, int y0, int log2)
+// the five merge candidates (8.5.3.2.2-8.5.3.2.5) of the 2Nx2N PU at (x0, y0), size n
+KVZ_HD void merge_cand_list(const EncFrame &f, int x0, int y0, int n, int cmx[5], int cmy[5])
 {
-  const int n = 1 << log2, bi = b8idx(f, x0, y0);
-  const int mvx = f.cu_mv[bi * 2], mvy = f.cu_mv[bi * 2 + 1];
   NbMv A1 = nb_mv(f, x0, y0, x0 - 1, y0 + n - 1), B1 = nb_mv(f, x0, y0, x0 + n - 1, y0 - 1);
   NbMv B0 = nb_mv(f, x0, y0, x0 + n, y0 - 1), A0 = nb_mv(f, x0, y0, x0 - 1, y0 + n), B2 = nb_mv(f, x0, y0, x0 - 1, y0 - 1);
   bool fA1 = A1.ok;
@@ -538,25 +623,40 @@ KVZ_HD void decide_signalling(const EncFrame &f, int x0, int y0, int log2)
   bool fB0 = B0.ok && !(B1.ok && same_mv(B1, B0));
   bool fA0 = A0.ok && !(A1.ok && same_mv(A1, A0));
   bool fB2 = B2.ok && !(A1.ok && same_mv(A1, B2)) && !(B1.ok && same_mv(B1, B2)) && !(fA0 && fA1 && fB0 && fB1);
-  int cmx[5], cmy[5], nc = 0;
+  int nc = 0;
   if (fA1) { cmx[nc] = A1.mx; cmy[nc] = A1.my; nc++; }
   if (fB1) { cmx[nc] = B1.mx; cmy[nc] = B1.my; nc++; }
   if (fB0) { cmx[nc] = B0.mx; cmy[nc] = B0.my; nc++; }
   if (fA0) { cmx[nc] = A0.mx; cmy[nc] = A0.my; nc++; }
   if (fB2 && nc < 5) { cmx[nc] = B2.mx; cmy[nc] = B2.my; nc++; }
   while (nc < 5) { cmx[nc] = 0; cmy[nc] = 0; nc++; }        // zero candidates (refIdx 0 for one reference)
+}
+// the two AMVP candidates (8.5.3.2.6-8.5.3.2.7); every neighbour refers to the same picture
+KVZ_HD void amvp_cand_list(const EncFrame &f, int x0, int y0, int n, int px[2], int py[2])
+{
+  NbMv A0 = nb_mv(f, x0, y0, x0 - 1, y0 + n), A1 = nb_mv(f, x0, y0, x0 - 1, y0 + n - 1);
+  NbMv B0 = nb_mv(f, x0, y0, x0 + n, y0 - 1), B1 = nb_mv(f, x0, y0, x0 + n - 1, y0 - 1), B2 = nb_mv(f, x0, y0, x0 - 1, y0 - 1);
+  bool haveA = A0.ok || A1.ok, haveB = B0.ok || B1.ok || B2.ok;
+  NbMv a = A0.ok ? A0 : A1, b = B0.ok ? B0 : (B1.ok ? B1 : B2);
+  if (!haveA && haveB) { a = b; haveA = true; }          // isScaledFlag == 0: A takes B's vector
+  int np = 0;
+  if (haveA) { px[np] = a.mx; py[np] = a.my; np++; }
+  if (haveB && !(haveA && a.mx == b.mx && a.my == b.my)) { px[np] = b.mx; py[np] = b.my; np++; }
+  while (np < 2) { px[np] = 0; py[np] = 0; np++; }
+}
+
+KVZ_HD void decide_signalling(const EncFrame &f, int x0, int y0, int log2)
+{
+  const int n = 1 << log2, bi = b8idx(f, x0, y0);
+  const int mvx = f.cu_mv[bi * 2], mvy = f.cu_mv[bi * 2 + 1];
+  int cmx[5], cmy[5];
+  merge_cand_list(f, x0, y0, n, cmx, cmy);
   int flags = 0, midx = 0, mvp = 0, mvdx = 0, mvdy = 0;
   for (int k = 0; k < 5; k++) if (cmx[k] == mvx && cmy[k] == mvy) { flags = CU_MERGE; midx = k; break; }
   if (flags && f.cu_cbf[bi] == 0) flags |= CU_SKIP;
   if (!flags) {
-    // AMVP: A = first of A0, A1; B = first of B0, B1, B2 (same reference picture everywhere)
-    bool haveA = A0.ok || A1.ok, haveB = B0.ok || B1.ok || B2.ok;
-    NbMv a = A0.ok ? A0 : A1, b = B0.ok ? B0 : (B1.ok ? B1 : B2);
-    if (!haveA && haveB) { a = b; haveA = true; }          // isScaledFlag == 0: A takes B's vector
-    int px[2], py[2], np = 0;
-    if (haveA) { px[np] = a.mx; py[np] = a.my; np++; }
-    if (haveB && !(haveA && a.mx == b.mx && a.my == b.my)) { px[np] = b.mx; py[np] = b.my; np++; }
-    while (np < 2) { px[np] = 0; py[np] = 0; np++; }
+    int px[2], py[2];
+    amvp_cand_list(f, x0, y0, n, px, py);
     int b0 = mvd_bits(mvx - px[0]) + mvd_bits(mvy - py[0]);
     int b1 = mvd_bits(mvx - px[1]) + mvd_bits(mvy - py[1]);
     mvp = b1 < b0;

@@ -1,0 +1,137 @@
+// kvazzup_amd/csrc/openhevc_api.hip -- the libOpenHevc* C ABI (include/openHevcWrapper.h) and the
+// decoder extensions (include/kvazzup_amd.h) on top of kvzx::Decoder.
+// Drop-in for the calls uvgComm makes at /root/reference/src/media/processing/openhevcfilter.cpp:
+// 36-56 (init), 145-146 (decode), 195-199 (output), 81-82 (flush/close).
+#include <cstdio>
+#include <cstring>
+#include "../../include/kvazzup_amd.h"
+#include "decoder.h"
+
+using kvzx::Decoder;
+using kvzx::DecodedPicture;
+
+namespace {
+struct Handle {
+  Decoder *dec = nullptr;
+  int threads = 1, thread_type = 0;
+  bool started = false;
+  DecodedPicture pic; bool have_pic = false;
+  const uint8_t *planes[3] = {nullptr, nullptr, nullptr};
+};
+Handle *H(OpenHevc_Handle h) { return (Handle *)h; }
+void fill_info(const DecodedPicture &p, OpenHevc_FrameInfo *info, bool host)
+{
+  memset(info, 0, sizeof(*info));
+  info->nYPitch = host ? p.host_pitch[0] : p.dev_pitch[0];
+  info->nUPitch = host ? p.host_pitch[1] : p.dev_pitch[1];
+  info->nVPitch = host ? p.host_pitch[2] : p.dev_pitch[2];
+  info->nBitDepth = 8; info->nWidth = p.width; info->nHeight = p.height; info->chromat_format = YUV420;
+  info->sample_aspect_ratio.num = 1; info->sample_aspect_ratio.den = 1;
+  info->frameRate.num = (int)p.fps_num; info->frameRate.den = (int)p.fps_den;
+  info->display_picture_number = p.poc; info->flag = 0; info->nTimeStamp = p.pts;
+}
+}  // namespace
+
+extern "C" {
+
+OpenHevc_Handle libOpenHevcInit(int nb_pthreads, int thread_type)
+{
+  Handle *h = new Handle();
+  h->threads = nb_pthreads; h->thread_type = thread_type;       // accepted; the GPU does the sample work
+  h->dec = new Decoder(0);
+  return (OpenHevc_Handle)h;
+}
+int libOpenHevcStartDecoder(OpenHevc_Handle hh)
+{
+  Handle *h = H(hh);
+  if (!h) return -1;
+  std::string err;
+  if (!h->dec->start(&err)) { fprintf(stderr, "kvazzup_amd: libOpenHevcStartDecoder failed: %s\n", err.c_str()); return -1; }
+  h->started = true;
+  return 0;
+}
+int libOpenHevcDecode(OpenHevc_Handle hh, const unsigned char *buff, int nal_len, int64_t pts)
+{
+  Handle *h = H(hh);
+  if (!h || !h->started || !buff || nal_len <= 0) return -1;
+  h->have_pic = false;
+  int rc = h->dec->decode_nal(buff, (size_t)nal_len, pts);
+  if (rc > 0) h->have_pic = h->dec->get_picture(&h->pic);
+  return rc;
+}
+int libOpenHevcGetOutput(OpenHevc_Handle hh, int got_picture, OpenHevc_Frame *frame)
+{
+  Handle *h = H(hh);
+  if (!h || !frame || got_picture <= 0 || !h->have_pic) return 0;
+  frame->pvY = (void **)h->pic.host[0]; frame->pvU = (void **)h->pic.host[1]; frame->pvV = (void **)h->pic.host[2];
+  fill_info(h->pic, &frame->frameInfo, true);
+  return 1;
+}
+int libOpenHevcGetOutputCpy(OpenHevc_Handle hh, int got_picture, OpenHevc_Frame_cpy *frame)
+{
+  Handle *h = H(hh);
+  if (!h || !frame || got_picture <= 0 || !h->have_pic || !h->pic.host[0]) return 0;
+  const DecodedPicture &p = h->pic;
+  void *dst[3] = {frame->pvY, frame->pvU, frame->pvV};
+  for (int c = 0; c < 3; c++) {
+    int w = c ? p.width / 2 : p.width, hh2 = c ? p.height / 2 : p.height;
+    if (!dst[c]) return 0;
+    for (int y = 0; y < hh2; y++) memcpy((uint8_t *)dst[c] + (size_t)y * w, p.host[c] + (size_t)y * p.host_pitch[c], (size_t)w);
+  }
+  fill_info(p, &frame->frameInfo, true);
+  return 1;
+}
+void libOpenHevcGetPictureInfo(OpenHevc_Handle hh, OpenHevc_FrameInfo *info)
+{
+  Handle *h = H(hh);
+  if (!h || !info) return;
+  if (h->have_pic) fill_info(h->pic, info, true); else memset(info, 0, sizeof(*info));
+}
+void libOpenHevcGetPictureSize2(OpenHevc_Handle hh, OpenHevc_FrameInfo *info) { libOpenHevcGetPictureInfo(hh, info); }
+void libOpenHevcSetCheckMD5(OpenHevc_Handle, int) {}
+void libOpenHevcSetDebugMode(OpenHevc_Handle, int) {}
+void libOpenHevcSetTemporalLayer_id(OpenHevc_Handle, int) {}
+void libOpenHevcSetNoCropping(OpenHevc_Handle, int) {}
+void libOpenHevcSetActiveDecoders(OpenHevc_Handle, int) {}
+void libOpenHevcSetViewLayers(OpenHevc_Handle, int) {}
+void libOpenHevcFlush(OpenHevc_Handle hh) { Handle *h = H(hh); if (h && h->dec) h->dec->flush(); }
+void libOpenHevcClose(OpenHevc_Handle hh)
+{
+  Handle *h = H(hh);
+  if (!h) return;
+  delete h->dec;
+  delete h;
+}
+const char *libOpenHevcVersion(OpenHevc_Handle) { return "kvazzup_amd-hevc-dec 0.1 (gfx950)"; }
+
+int kvzx_decoder_last_error(OpenHevc_Handle hh) { Handle *h = H(hh); return h ? h->dec->last_error() : -1; }
+int kvzx_decoder_output_device(OpenHevc_Handle hh, const void **planes, int *pitches)
+{
+  Handle *h = H(hh);
+  if (!h || !h->have_pic) return 0;
+  for (int c = 0; c < 3; c++) { if (planes) planes[c] = h->pic.dev[c]; if (pitches) pitches[c] = h->pic.dev_pitch[c]; }
+  return 1;
+}
+void kvzx_decoder_set_download(OpenHevc_Handle hh, int on) { Handle *h = H(hh); if (h) h->dec->set_download(on != 0); }
+void kvzx_decoder_set_profiling(OpenHevc_Handle hh, int on) { Handle *h = H(hh); if (h) h->dec->set_profiling(on != 0); }
+int kvzx_decoder_kernel_times(OpenHevc_Handle hh, double *ms, uint64_t *launches, int reset)
+{
+  Handle *h = H(hh);
+  if (!h) return 0;
+  double m[kvzx::DK_COUNT]; uint64_t n[kvzx::DK_COUNT];
+  h->dec->get_kernel_times(m, n, reset != 0);
+  for (int i = 0; i < kvzx::DK_COUNT; i++) { if (ms) ms[i] = m[i]; if (launches) launches[i] = n[i]; }
+  return kvzx::DK_COUNT;
+}
+const char *kvzx_decoder_kernel_name(int id)
+{
+  static const char *names[kvzx::DK_COUNT] = {"k_scatter_levels", "k_inter_recon<dec>", "k_intra_recon<dec>", "k_deblock"};
+  return (id >= 0 && id < kvzx::DK_COUNT) ? names[id] : nullptr;
+}
+int kvzx_decoder_debug_copy(OpenHevc_Handle hh, const char *what, void *dst, size_t bytes)
+{
+  Handle *h = H(hh);
+  return h && what && h->dec->debug_copy(what, dst, bytes) ? 1 : 0;
+}
+
+}  // extern "C"

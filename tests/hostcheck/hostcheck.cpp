@@ -65,11 +65,12 @@ int hc_encode_au(HcFrame *h, uint8_t *out, int cap, unsigned long long *bins)
   std::vector<uint8_t> rows((size_t)row_cap * hc);
   std::vector<int32_t> lens(hc, 0);
   uint8_t ctx[CTX_COUNT], saved[CTX_COUNT];
+  static CoreTabs tabs; for (int i = 0; i < 64; i++) core_tabs_fill_entry(tabs, i);
   CabacEnc c; c.nbins = 0;
   const int init_type = f.is_intra ? 0 : 1;
   if (f.wpp) {
     for (int row = 0; row < hc; row++) {
-      cabac_start(c, rows.data() + (size_t)row * row_cap, row_cap, ctx);
+      cabac_start(c, rows.data() + (size_t)row * row_cap, row_cap, ctx, &tabs);
       if (row == 0) cabac_init_contexts(ctx, init_type, f.qp); else memcpy(ctx, saved, sizeof(saved));
       for (int cx = 0; cx < wc; cx++) {
         enc_ctu(f, c, cx * 64, row * 64);
@@ -82,7 +83,7 @@ int hc_encode_au(HcFrame *h, uint8_t *out, int cap, unsigned long long *bins)
       lens[row] = c.pos;
     }
   } else {
-    cabac_start(c, rows.data(), row_cap * hc, ctx);
+    cabac_start(c, rows.data(), row_cap * hc, ctx, &tabs);
     cabac_init_contexts(ctx, init_type, f.qp);
     for (int cy = 0; cy < hc; cy++)
       for (int cx = 0; cx < wc; cx++) { enc_ctu(f, c, cx * 64, cy * 64); cabac_terminate(c, cy == hc - 1 && cx == wc - 1); }

@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: HEVC encode+decode fps on synthetic YUV420 (uvgx-synth-v1).
+
+A "step" is one picture through the hot path: kvz_api-side encode (HIP kernels; input picture
+already resident in HBM) followed by libOpenHevc-side decode of the access unit just produced
+(host CABAC parse + HIP reconstruction, output left in HBM).  N > 1 runs one independent stream
+per GPU (BASELINE configs[3]: multi-party call, no collective on the data path), weak scaling.
+
+Prints ONE JSON line on rank 0 (see the contract in the task description / DESIGN.md section 6).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: 1080p, preset=ultrafast, intra period 64, encode + decode on one GPU
+    "1080p": dict(w=1920, h=1080, name="1080p-yuv420-ultrafast-p64-qp32-encode+decode", cfg_index=2),
+    # configs[2]: 4K encode (decode is run too; reported in the same fps)
+    "4k": dict(w=3840, h=2160, name="2160p-yuv420-ultrafast-p64-qp32-encode+decode", cfg_index=3),
+    "720p": dict(w=1280, h=720, name="720p-yuv420-ultrafast-p64-qp32-encode+decode", cfg_index=2),
+}
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes(kernel, cw, ch, me_range):
+    """Compulsory bytes of ONE launch, P = coded luma samples."""
+    P = cw * ch
+    if kernel == "k_me":                          # current block once + its search window once, per 32x32 block
+        return (P // 1024) * (1024 + (32 + 2 * me_range) ** 2)
+    if kernel in ("k_inter_recon", "k_inter_recon<dec>"):
+        return int(4.5 * P) if kernel == "k_inter_recon" else int(3.0 * P)
+    if kernel in ("k_intra_recon", "k_intra_recon<dec>"):
+        return int(3.0 * P) if kernel == "k_intra_recon" else int(1.5 * P)
+    if kernel == "k_intra_analyse":
+        return P
+    if kernel == "k_deblock":
+        return int(3.0 * P)
+    if kernel == "k_entropy":                     # every level of the picture once (int16) -- an upper bound
+        return int(3.0 * P)
+    if kernel == "k_pad_input":
+        return int(3.0 * P)
+    if kernel == "k_inter_signal":
+        return (P // 64) * 16
+    if kernel == "k_scatter_levels":
+        return int(3.0 * P)
+    return P
+
+
+def cpu_baseline(w, h, frames, me_range):
+    """The CPU checker (oracle/, a scalar C port of the same algorithm) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    oe = orc.OracleEncoder(w, h, qp=32, period=64, me_range=me_range)
+    od = orc.OracleDecoder()
+    clip = [orc.synth_frame(0, 0x5EED0002, w, h, t) for t in range(frames)]
+    t0 = time.time()
+    n = 0
+    for t, fr in enumerate(clip):
+        au = oe.encode(fr)
+        n += len(od.decode_au(au, t))
+    dt = time.time() - t0
+    oe.close()
+    od.close()
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d pictures %dx%d (1 intra + %d inter, search range %d), encode+decode by oracle/ (scalar C, one thread)" % (frames, w, h, frames - 1, me_range)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--me-range", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=6)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from kvazzup_amd import synth
+    from kvazzup_amd.codec import Decoder, Encoder
+
+    wl = WORKLOADS[args.workload]
+    w, h = wl["w"], wl["h"]
+    total = args.warmup + args.steps
+    seed = 0x5EED0000 + wl["cfg_index"] + 16 * rank
+    # synthetic clip generated directly in HBM (inputs resident before the timed region)
+    clip = [synth.frame_torch(synth.MOVING, seed, w, h, t, dev) for t in range(total)]
+    torch.cuda.synchronize()
+
+    enc = Encoder(w, h, options=(("qp", 32), ("period", 64), ("vps-period", 1), ("me-range", args.me_range), ("gpu", local_rank)))
+    dec = Decoder(download=False, device=local_rank)
+    cw, ch = enc.coded_size()
+
+    def step(t):
+        au = enc.encode_device(clip[t].data_ptr())
+        pics = dec.decode_au(au, t)
+        if len(pics) != 1:
+            raise RuntimeError("decoder returned %d pictures for one access unit" % len(pics))
+        return len(au)
+
+    for t in range(args.warmup):
+        step(t)
+    enc.set_profiling(True)
+    dec.set_profiling(True)
+    enc.kernel_times(reset=True)
+    dec.kernel_times(reset=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    nbytes = 0
+    for t in range(args.warmup, total):
+        nbytes += step(t)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    kt = dict(enc.kernel_times(reset=False))
+    kt.update({k: v for k, v in dec.kernel_times(reset=False).items() if k != "k_deblock"})
+    kd = dec.kernel_times(reset=False).get("k_deblock", (0.0, 0))
+    if "k_deblock" in kt:
+        kt["k_deblock"] = (kt["k_deblock"][0] + kd[0], kt["k_deblock"][1] + kd[1])
+    enc.close()
+    dec.close()
+
+    if rank == 0:
+        fps = world * args.steps / elapsed
+        dom = max((k for k in kt if kt[k][1] > 0), key=lambda k: kt[k][0])
+        avg_s = kt[dom][0] / kt[dom][1] / 1e3
+        ab = algorithmic_bytes(dom, cw, ch, args.me_range)
+        achieved = ab / avg_s / 1e9
+        out = {
+            "metric": "hevc_encode_decode_fps", "value": round(fps, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": wl["name"], "width": w, "height": h, "coded_width": cw, "coded_height": ch,
+                       "frames_per_gpu": args.steps, "intra_period": 64, "qp": 32, "me_range": args.me_range,
+                       "streams": world, "bytes_per_frame": round(nbytes / args.steps, 1),
+                       "input": "I420 resident in HBM", "output": "Annex-B AU on host + decoded I420 in HBM"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(avg_s * 1e6, 2)},
+            "kernels_us": {k: round(v[0] / v[1] * 1e3, 2) for k, v in kt.items() if v[1]},
+            "kernel_share_of_step": {k: round(v[0] / (elapsed * 1e3), 4) for k, v in kt.items() if v[1]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(w, h, args.cpu_frames, args.me_range)
+            except Exception as e:       # the checker library is test infrastructure; report, do not fail the bench
+                out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "failed: %s" % e}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,9 @@ KVZ_PUBLIC uint64_t kvzx_encoder_last_bins(kvz_encoder *enc);  /* CABAC bins of 
 
 /* ---- decoder ---- */
 /* Decode one NAL unit whose OUTPUT is wanted in device memory: like libOpenHevcDecode. */
+/* select the HIP device ordinal; call between libOpenHevcInit and libOpenHevcStartDecoder (default 0,
+ * or the environment variable KVAZZUP_AMD_DEVICE) */
+KVZ_PUBLIC int kvzx_decoder_set_device(OpenHevc_Handle h, int device);
 KVZ_PUBLIC int kvzx_decoder_last_error(OpenHevc_Handle h);
 /* device pointers (pitch = coded width [/2]) of the picture returned by the last libOpenHevcGetOutput */
 KVZ_PUBLIC int kvzx_decoder_output_device(OpenHevc_Handle h, const void **planes /*[3]*/, int *pitches /*[3]*/);

@@ -104,7 +104,7 @@ DECODER_EXPORTS = ["libOpenHevcInit", "libOpenHevcStartDecoder", "libOpenHevcDec
                    "libOpenHevcGetPictureSize2", "libOpenHevcGetOutput", "libOpenHevcGetOutputCpy", "libOpenHevcSetCheckMD5",
                    "libOpenHevcSetDebugMode", "libOpenHevcSetTemporalLayer_id", "libOpenHevcSetNoCropping", "libOpenHevcSetActiveDecoders",
                    "libOpenHevcSetViewLayers", "libOpenHevcClose", "libOpenHevcFlush", "libOpenHevcVersion",
-                   "kvzx_decoder_last_error", "kvzx_decoder_output_device", "kvzx_decoder_set_download", "kvzx_decoder_set_profiling",
+                   "kvzx_decoder_set_device", "kvzx_decoder_last_error", "kvzx_decoder_output_device", "kvzx_decoder_set_download", "kvzx_decoder_set_profiling",
                    "kvzx_decoder_kernel_times", "kvzx_decoder_kernel_name", "kvzx_decoder_debug_copy"]
 
 
@@ -148,6 +148,7 @@ def load_library():
         L.libOpenHevcFlush.argtypes = [C.c_void_p]
         L.libOpenHevcVersion.restype = C.c_char_p
         L.libOpenHevcVersion.argtypes = [C.c_void_p]
+        L.kvzx_decoder_set_device.argtypes = [C.c_void_p, C.c_int]
         L.kvzx_decoder_last_error.argtypes = [C.c_void_p]
         L.kvzx_decoder_output_device.argtypes = [C.c_void_p, _P(C.c_void_p), _P(C.c_int)]
         L.kvzx_decoder_set_download.argtypes = [C.c_void_p, C.c_int]

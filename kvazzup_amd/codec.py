@@ -161,9 +161,11 @@ class Decoder:
 
     OH_THREAD_SLICE = 2
 
-    def __init__(self, threads=1, download=True):
+    def __init__(self, threads=1, download=True, device=None):
         self.lib = N.load_library()
         self.h = self.lib.libOpenHevcInit(threads, self.OH_THREAD_SLICE)
+        if device is not None:
+            self.lib.kvzx_decoder_set_device(self.h, device)
         if self.lib.libOpenHevcStartDecoder(self.h) == -1:
             self.lib.libOpenHevcClose(self.h)
             self.h = None

@@ -16,5 +16,5 @@ void launch_dec_intra_recon(const EncFrame &f, hipStream_t st);
 // scatter packed levels (TU descriptors) into the plane-shaped level arrays
 struct TuDesc { uint16_t x, y; uint8_t plane, log2; uint16_t pad; uint32_t offset; };
 void launch_scatter_levels(const EncFrame &f, const TuDesc *tus, int ntu, const int16_t *packed, hipStream_t st);
-void launch_entropy(const EncFrame &f, hipStream_t st);
+void launch_tokenize(const EncFrame &f, hipStream_t st);   // k_tokenize + k_tok_scan + k_tok_compact
 }  // namespace kvzx

@@ -13,8 +13,9 @@
 //   k_intra_analyse one workgroup per 32x32 block: 35-mode SAD search on source samples
 //   k_intra_recon   one workgroup per CTU row, wavefront over rows through progress counters
 //   k_deblock_v/h   one thread per 4-sample edge segment
-//   k_entropy       one workgroup per CTU row (WPP substream), lane 0 runs CABAC; context
-//                   hand-over between rows through agent-scope release/acquire flags
+//   k_tokenize      one wave per CTU: binarisation + context selection of every syntax element
+//                   (one lane per 4x4 sub-block of a transform block) -> bins as 16-bit tokens;
+//                   k_tok_scan / k_tok_compact pack them for the host arithmetic coder
 #include <hip/hip_runtime.h>
 #include "hevc_core.h"
 #include "enc_kernels.h"
@@ -536,10 +537,12 @@ __global__ __launch_bounds__(256) void k_deblock_h(EncFrame f)
 }
 
 // =============================================================================================
-// Entropy coding: one workgroup (one wave) per CTU row / WPP substream.  The wave stages what
-// the coder needs in LDS with coalesced parallel loads -- the per-CU records of the CTU and its
-// left / above neighbours, and each transform block as a TuDigest (one lane per 4x4 sub-block)
-// -- and lane 0 runs the serial CABAC engine on that staged data.
+// Entropy coding, parallel half: one wave per CTU turns the CTU's syntax elements into the list
+// of CABAC bins in coding order (16-bit tokens, hevc_core.h TokOut).  The wave stages the per-CU
+// records of the CTU and its left / above neighbours in LDS, lane 0 emits the (short) CU headers,
+// and every transform block is tokenised by all lanes at once: one lane per 4x4 sub-block, whose
+// only cross-sub-block dependency (the greater1 context set) is resolved from a ballot of
+// "has a level > 1".  The serial arithmetic coder runs on host threads (entropy_host.h).
 // =============================================================================================
 struct TileView {
   const CuRec *tile;                 // [9][9] records: b8 (bx0 + tx, by0 + ty)
@@ -576,84 +579,122 @@ __device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d
   __syncthreads();
 }
 
-__global__ __launch_bounds__(64) void k_entropy(EncFrame f)
+#define TOK_LANE_CAP 128       // tokens one 4x4 sub-block can produce at most (worst case ~108)
+#define TOK_HDR_CAP 96
+
+__global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
 {
-  __shared__ uint8_t ctx[CTX_COUNT + 6];
   __shared__ CuRec tile[81];
   __shared__ __attribute__((aligned(16))) TuDigest dg;
   __shared__ CoreTabs tabs;
-  const int row = blockIdx.x, lane = threadIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
+  __shared__ uint16_t hdr[TOK_HDR_CAP];
+  __shared__ uint16_t ltok[64][TOK_LANE_CAP];
+  __shared__ int hdr_n;
+  const int cx = blockIdx.x, cy = blockIdx.y, lane = threadIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
+  const int ctu = cy * wc + cx;
+  uint16_t *out = f.tok_buf + (size_t)ctu * f.tok_cap;
+  int ntok = 0;                                        // wave-uniform running count
   core_tabs_fill_entry(tabs, lane);
-  const int init_type = f.is_intra ? 0 : 1;
-  const int nrows = f.wpp ? 1 : hc;                   // CTU rows coded by this workgroup
-  if (!f.wpp && row != 0) return;
-  CabacEnc c; c.nbins = 0;
-  cabac_start(c, f.row_buf + (size_t)row * f.row_cap, f.wpp ? f.row_cap : f.row_cap * hc, ctx, &tabs);
-  if (row == 0) { if (lane == 0) cabac_init_contexts(ctx, init_type, f.qp); }
-  else {
-    wait_progress(&f.sync[row - 1], 1u, f.err);
-    const uint8_t *saved = f.wpp_ctx + (size_t)(row - 1) * CTX_COUNT;
-    for (int i = lane; i < CTX_COUNT; i += 64) ctx[i] = saved[i];
+  const int bx0 = cx * 8 - 1, by0 = cy * 8 - 1;
+  for (int i = lane; i < 81; i += 64) {
+    int bx = bx0 + i % 9, by = by0 + i / 9;
+    CuRec r; r.log2 = 0; r.intra = 0; r.flags = 0; r.merge_idx = 0; r.mvp_idx = 0; r.intra_mode = 0; r.cbf = 0; r.pad = 0; r.mvdx = 0; r.mvdy = 0;
+    if (bx >= 0 && by >= 0 && bx < f.b8w) {
+      int g = by * f.b8w + bx;
+      r.log2 = f.cu_log2[g]; r.intra = f.cu_intra[g]; r.flags = f.cu_flags[g]; r.merge_idx = f.cu_merge_idx[g];
+      r.mvp_idx = f.cu_mvp_idx[g]; r.intra_mode = f.cu_intra_mode[g]; r.cbf = f.cu_cbf[g];
+      r.mvdx = f.cu_mvd[g * 2]; r.mvdy = f.cu_mvd[g * 2 + 1];
+    }
+    tile[i] = r;
   }
   __syncthreads();
-  for (int ry = 0; ry < nrows; ry++) {
-    const int cy = row + ry;
-    for (int cx = 0; cx < wc; cx++) {
-      // stage the CU records of this CTU plus one 8x8 column to the left and one row above
-      const int bx0 = cx * 8 - 1, by0 = cy * 8 - 1;
-      for (int i = lane; i < 81; i += 64) {
-        int bx = bx0 + i % 9, by = by0 + i / 9;
-        CuRec r; r.log2 = 0; r.intra = 0; r.flags = 0; r.merge_idx = 0; r.mvp_idx = 0; r.intra_mode = 0; r.cbf = 0; r.pad = 0; r.mvdx = 0; r.mvdy = 0;
-        if (bx >= 0 && by >= 0) {
-          int g = by * f.b8w + bx;
-          r.log2 = f.cu_log2[g]; r.intra = f.cu_intra[g]; r.flags = f.cu_flags[g]; r.merge_idx = f.cu_merge_idx[g];
-          r.mvp_idx = f.cu_mvp_idx[g]; r.intra_mode = f.cu_intra_mode[g]; r.cbf = f.cu_cbf[g];
-          r.mvdx = f.cu_mvd[g * 2]; r.mvdy = f.cu_mvd[g * 2 + 1];
-        }
-        tile[i] = r;
+  TileView v; v.tile = tile; v.bx0 = bx0; v.by0 = by0;
+  for (int z = 0; z < 64;) {
+    int xi, yi; ctu_z_to_xy(z, xi, yi);
+    const int x0 = cx * 64 + xi * 8, y0 = cy * 64 + yi * 8;
+    const CuRec cu = v.at(x0, y0);
+    if (lane == 0) {
+      TokOut t; t.tabs = &tabs; t.p = hdr; t.n = 0; t.cap = TOK_HDR_CAP;
+      enc_split_flags(v, t, f.cw, f.ch, x0, y0, z, cu.log2);
+      enc_cu_header(v, t, f.cw, f.ch, f.is_intra != 0, x0, y0, cu);
+      hdr_n = t.n;
+    }
+    __syncthreads();
+    { const int n = hdr_n; for (int i = lane; i < n; i += 64) if (ntok + i < f.tok_cap) out[ntok + i] = hdr[i]; ntok += n; }
+    const int cbf = (cu.flags & CU_SKIP) ? 0 : cu.cbf;          // wave-uniform
+    for (int ci = 0; ci < 3; ci++) {
+      if (!((cbf >> ci) & 1)) continue;
+      const int l2 = ci ? cu.log2 - 1 : cu.log2, pw = ci ? (f.cw >> 1) : f.cw;
+      const int px = ci ? (x0 >> 1) : x0, py = ci ? (y0 >> 1) : y0;
+      const int scan = intra_scan_idx(cu.intra, l2, ci, cu.intra_mode);
+      digest_build_wave(&tabs, dg, f.coef[ci] + py * pw + px, pw, l2, scan, lane);   // ends with a barrier: hdr[] is free again
+      const uint64_t sbm = dg.sbmask;
+      const int last_sb = 63 - __builtin_clzll(sbm);
+      const int last_pos = 31 - __builtin_clz((uint32_t)dg.mask[last_sb]);
+      if (lane == 0) {
+        TokOut t; t.tabs = &tabs; t.p = hdr; t.n = 0; t.cap = TOK_HDR_CAP;
+        int a, b; enc_last_pos(t, dg, l2, ci, scan, a, b);
+        hdr_n = t.n;
+      }
+      // greater1 context-set carry: sub-block i inherits from the next non-empty sub-block above it
+      const bool nzsb = (sbm >> lane) & 1;
+      const bool g1 = nzsb && subblock_g1_any(&tabs, dg, lane, scan);
+      const uint64_t g1m = __ballot(g1);
+      int n_l = 0;
+      if (lane <= last_sb) {
+        uint64_t above = (lane < 63) ? (sbm >> (lane + 1)) : 0;      // non-empty sub-blocks coded before this one
+        bool prev_g1 = false;
+        if (above) { int j = lane + 1 + __builtin_ctzll(above); prev_g1 = (g1m >> j) & 1; }
+        TokOut t; t.tabs = &tabs; t.p = ltok[lane]; t.n = 0; t.cap = TOK_LANE_CAP;
+        enc_subblock(t, dg, lane, last_sb, last_pos, prev_g1, l2, ci, scan);
+        n_l = t.n;
+        if (n_l > TOK_LANE_CAP) { atomicOr(f.err, 8u); n_l = TOK_LANE_CAP; }
       }
       __syncthreads();
-      TileView v; v.tile = tile; v.bx0 = bx0; v.by0 = by0;
-      for (int z = 0; z < 64;) {
-        int xi, yi; ctu_z_to_xy(z, xi, yi);
-        const int x0 = cx * 64 + xi * 8, y0 = cy * 64 + yi * 8;
-        const CuRec cu = v.at(x0, y0);
-        if (lane == 0) {
-          enc_split_flags(v, c, f.cw, f.ch, x0, y0, z, cu.log2);
-          enc_cu_header(v, c, f.cw, f.ch, f.is_intra != 0, x0, y0, cu);
-        }
-        const int cbf = (cu.flags & CU_SKIP) ? 0 : cu.cbf;        // wave-uniform
-        for (int ci = 0; ci < 3; ci++) {
-          if (!((cbf >> ci) & 1)) continue;
-          const int l2 = ci ? cu.log2 - 1 : cu.log2, pw = ci ? (f.cw >> 1) : f.cw;
-          const int px = ci ? (x0 >> 1) : x0, py = ci ? (y0 >> 1) : y0;
-          const int scan = intra_scan_idx(cu.intra, l2, ci, cu.intra_mode);
-          digest_build_wave(&tabs, dg, f.coef[ci] + py * pw + px, pw, l2, scan, lane);
-          if (lane == 0) enc_residual_digest(c, dg, l2, ci, scan);
-          __syncthreads();
-        }
-        z += 1 << (2 * (cu.log2 - 3));
-      }
-      if (f.wpp && cx == 1) {
-        __syncthreads();
-        uint8_t *dst = f.wpp_ctx + (size_t)row * CTX_COUNT;
-        for (int i = lane; i < CTX_COUNT; i += 64) dst[i] = ctx[i];
-        publish_progress(&f.sync[row], 1u);
-      }
-      if (lane == 0) {
-        bool last = (cy == hc - 1 && cx == wc - 1);
-        cabac_terminate(c, last);                                  // end_of_slice_segment_flag
-        if (f.wpp && !last && cx == wc - 1) cabac_terminate(c, 1); // end_of_subset_one_bit
-      }
+      { const int n = hdr_n; for (int i = lane; i < n; i += 64) if (ntok + i < f.tok_cap) out[ntok + i] = hdr[i]; ntok += n; }
+      // offsets in coding order: sub-block last_sb first, then downwards
+      int suffix = n_l;
+      for (int o = 1; o < 64; o <<= 1) { int other = __shfl_down(suffix, o); if (lane + o < 64) suffix += other; }
+      const int total = __shfl(suffix, 0);
+      const int off = suffix - n_l;                                 // tokens of all sub-blocks with a higher index
+      for (int i = 0; i < n_l; i++) if (ntok + off + i < f.tok_cap) out[ntok + off + i] = ltok[lane][i];
+      ntok += total;
       __syncthreads();
     }
+    z += 1 << (2 * (cu.log2 - 3));
   }
   if (lane == 0) {
-    cabac_finish(c);
-    f.row_len[row] = c.pos;
-    if (c.pos > c.cap) atomicOr(f.err, 4u);
-    if (f.bins) atomicAdd((unsigned long long *)f.bins, (unsigned long long)c.nbins);
+    const bool last = (cy == hc - 1 && cx == wc - 1);
+    if (ntok < f.tok_cap) out[ntok] = (uint16_t)(0xC000u | (last ? 1u : 0u));          // end_of_slice_segment_flag
+    ntok++;
+    if (f.wpp && !last && cx == wc - 1) { if (ntok < f.tok_cap) out[ntok] = 0xC001u; ntok++; }   // end_of_subset_one_bit
+    if (ntok > f.tok_cap) { atomicOr(f.err, 16u); ntok = f.tok_cap; }
+    f.tok_count[ctu] = ntok;
   }
+}
+
+// exclusive prefix sum of the per-CTU token counts (single workgroup), then a dense copy
+__global__ __launch_bounds__(256) void k_tok_scan(EncFrame f, int nctu)
+{
+  __shared__ uint32_t part[256];
+  const int tid = threadIdx.x, per = (nctu + 255) / 256, lo = tid * per, hi = min(nctu, lo + per);
+  uint32_t s = 0;
+  for (int i = lo; i < hi; i++) s += (uint32_t)f.tok_count[i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) { uint32_t a = 0; for (int i = 0; i < 256; i++) { uint32_t t = part[i]; part[i] = a; a += t; } f.tok_off[nctu] = a; }
+  __syncthreads();
+  uint32_t a = part[tid];
+  for (int i = lo; i < hi; i++) { f.tok_off[i] = a; a += (uint32_t)f.tok_count[i]; }
+}
+__global__ __launch_bounds__(256) void k_tok_compact(EncFrame f)
+{
+  const int ctu = blockIdx.x, n = f.tok_count[ctu];
+  const uint16_t *src = f.tok_buf + (size_t)ctu * f.tok_cap;
+  uint16_t *dst = f.tok_dense + f.tok_off[ctu];
+  if (f.tok_off[ctu] + (uint32_t)n > f.tok_dense_cap) { if (threadIdx.x == 0) { atomicOr(f.err, 32u); f.tok_count_out[ctu] = 0; } return; }
+  for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+  if (threadIdx.x == 0) f.tok_count_out[ctu] = n;
 }
 
 // =============================================================================================
@@ -712,6 +753,12 @@ void launch_deblock(const EncFrame &f, hipStream_t st)
   hipLaunchKernelGGL(k_deblock_v, dim3((nv + 255) / 256), dim3(256), 0, st, f);
   hipLaunchKernelGGL(k_deblock_h, dim3((nh + 255) / 256), dim3(256), 0, st, f);
 }
-void launch_entropy(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_entropy, dim3(f.ch / 64), dim3(64), 0, st, f); }
+void launch_tokenize(const EncFrame &f, hipStream_t st)
+{
+  const int wc = f.cw / 64, hc = f.ch / 64;
+  hipLaunchKernelGGL(k_tokenize, dim3(wc, hc), dim3(64), 0, st, f);
+  hipLaunchKernelGGL(k_tok_scan, dim3(1), dim3(256), 0, st, f, wc * hc);
+  hipLaunchKernelGGL(k_tok_compact, dim3(wc * hc), dim3(256), 0, st, f);
+}
 
 }  // namespace kvzx

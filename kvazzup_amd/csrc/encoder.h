@@ -9,10 +9,12 @@
 #include <vector>
 #include "hevc_core.h"
 #include "hevc_headers.h"
+#include "entropy_host.h"
 
 namespace kvzx {
 
-enum KernelId { K_PAD = 0, K_ME, K_INTER_RECON, K_INTER_SIGNAL, K_INTRA_ANALYSE, K_INTRA_RECON, K_DEBLOCK, K_ENTROPY, K_COUNT };
+// K_HOST_ARITH is not a kernel: wall time of the host arithmetic-coding stage (entropy_host.h)
+enum KernelId { K_PAD = 0, K_ME, K_INTER_RECON, K_INTER_SIGNAL, K_INTRA_ANALYSE, K_INTRA_RECON, K_DEBLOCK, K_TOKENIZE, K_HOST_ARITH, K_COUNT };
 
 struct EncoderConfig {
   int width = 0, height = 0;
@@ -21,6 +23,7 @@ struct EncoderConfig {
   int fps_num = 30, fps_den = 1;
   int wpp = 1, deblock = 1;
   int device = 0;
+  int entropy_threads = 16;   // host threads of the arithmetic-coding stage
 };
 
 struct EncodedPicture {
@@ -71,10 +74,11 @@ class Encoder {
   uint8_t *cu_bytes_ = nullptr;          // 7 byte arrays back to back
   int16_t *cu_mv_ = nullptr, *cu_mvd_ = nullptr;
   uint8_t *intra_scratch_ = nullptr;
-  uint8_t *row_buf_ = nullptr; int row_cap_ = 0;
-  int32_t *row_len_ = nullptr; uint8_t *wpp_ctx_ = nullptr; uint32_t *sync_ = nullptr; uint32_t *err_ = nullptr;
-  uint64_t *bins_ = nullptr;
-  int32_t *h_row_len_ = nullptr; uint8_t *h_rows_ = nullptr; uint32_t *h_err_ = nullptr; uint64_t *h_bins_ = nullptr;
+  uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_off_ = nullptr;
+  uint16_t *h_tok_dense_ = nullptr; size_t tok_dense_cap_ = 0; int32_t *h_tok_count_ = nullptr;   // host-mapped pinned
+  uint32_t *sync_ = nullptr; uint32_t *err_ = nullptr; uint32_t *h_err_ = nullptr;
+  EntropyHost *entropy_ = nullptr;
+  std::vector<std::vector<uint8_t>> rows_out_;
   int frame_idx_ = 0, poc_ = 0, intra_count_ = 0;
   bool profiling_ = false;
   struct EvPair { hipEvent_t a, b; KernelId id; };

@@ -1,4 +1,5 @@
 // kvazzup_amd/csrc/encoder.hip -- see encoder.h
+#include <chrono>
 #include <functional>
 #include <cstdio>
 #include <cstring>
@@ -50,17 +51,19 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   // intra scratch: ic8 (nb8 u32) | ic16 (nb8/4 u32) | ic32 (nb8/16 u32) | im8 | im16 | im32
   size_t isz = nb8 * 4 + nb8 + nb8 / 4 + nb8 + nb8 / 4 + nb8 / 16 + 64;
   HIP_OK(hipMalloc(&intra_scratch_, isz));
-  row_cap_ = cw_ * 64 * 3;                         // twice the raw size of a CTU row
-  HIP_OK(hipMalloc(&row_buf_, (size_t)row_cap_ * rows_));
-  HIP_OK(hipMalloc(&row_len_, sizeof(int32_t) * rows_));
-  HIP_OK(hipMalloc(&wpp_ctx_, (size_t)CTX_COUNT * rows_));
+  const int nctu = (cw_ / 64) * rows_;
+  tok_cap_ = 49152;                                // tokens per CTU slot (worst case of a 64x64 CTU is ~43k)
+  HIP_OK(hipMalloc(&tok_buf_, (size_t)nctu * tok_cap_ * sizeof(uint16_t)));
+  HIP_OK(hipMalloc(&tok_count_, sizeof(int32_t) * nctu));
+  HIP_OK(hipMalloc(&tok_off_, sizeof(uint32_t) * (nctu + 1)));
+  tok_dense_cap_ = (size_t)nctu * tok_cap_;
+  if (tok_dense_cap_ > ((size_t)1 << 27)) tok_dense_cap_ = (size_t)1 << 27;
+  HIP_OK(hipHostMalloc(&h_tok_dense_, tok_dense_cap_ * sizeof(uint16_t), hipHostMallocMapped));
+  HIP_OK(hipHostMalloc(&h_tok_count_, sizeof(int32_t) * nctu, hipHostMallocMapped));
   HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * rows_));
   HIP_OK(hipMalloc(&err_, sizeof(uint32_t))); HIP_OK(hipMemset(err_, 0, sizeof(uint32_t)));
-  HIP_OK(hipMalloc(&bins_, sizeof(uint64_t)));
-  HIP_OK(hipHostMalloc(&h_row_len_, sizeof(int32_t) * rows_, hipHostMallocDefault));
-  HIP_OK(hipHostMalloc(&h_rows_, (size_t)row_cap_ * rows_, hipHostMallocDefault));
   HIP_OK(hipHostMalloc(&h_err_, sizeof(uint32_t), hipHostMallocDefault));
-  HIP_OK(hipHostMalloc(&h_bins_, sizeof(uint64_t), hipHostMallocDefault));
+  entropy_ = new EntropyHost(cfg.entropy_threads < rows_ ? cfg.entropy_threads : rows_);
 
   memset(&f_, 0, sizeof(f_));
   f_.cw = cw_; f_.ch = ch_; f_.b8w = cw_ / 8; f_.b8h = ch_ / 8;
@@ -73,7 +76,11 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   uint8_t *p = intra_scratch_;
   f_.ic8 = (uint32_t *)p; p += nb8 * 4; f_.ic16 = (uint32_t *)p; p += nb8; f_.ic32 = (uint32_t *)p; p += nb8 / 4;
   f_.im8 = p; p += nb8; f_.im16 = p; p += nb8 / 4; f_.im32 = p;
-  f_.row_buf = row_buf_; f_.row_cap = row_cap_; f_.row_len = row_len_; f_.wpp_ctx = wpp_ctx_; f_.sync = sync_; f_.err = err_; f_.bins = bins_;
+  f_.tok_buf = tok_buf_; f_.tok_cap = tok_cap_; f_.tok_count = tok_count_; f_.tok_off = tok_off_;
+  void *dp = nullptr;
+  HIP_OK(hipHostGetDevicePointer(&dp, h_tok_dense_, 0)); f_.tok_dense = (uint16_t *)dp; f_.tok_dense_cap = (uint32_t)tok_dense_cap_;
+  HIP_OK(hipHostGetDevicePointer(&dp, h_tok_count_, 0)); f_.tok_count_out = (int32_t *)dp;
+  f_.sync = sync_; f_.err = err_;
 
   sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp;
   sp_.deblock = cfg.deblock; sp_.fps_num = cfg.fps_num; sp_.fps_den = cfg.fps_den;
@@ -89,8 +96,9 @@ Encoder::~Encoder()
   hipFree(d_in_); hipHostFree(h_in_);
   for (int c = 0; c < 3; c++) { hipFree(src_[c]); hipFree(rec_[0][c]); hipFree(rec_[1][c]); hipFree(coef_[c]); }
   hipFree(cu_bytes_); hipFree(cu_mv_); hipFree(cu_mvd_); hipFree(intra_scratch_);
-  hipFree(row_buf_); hipFree(row_len_); hipFree(wpp_ctx_); hipFree(sync_); hipFree(err_); hipFree(bins_);
-  hipHostFree(h_row_len_); hipHostFree(h_rows_); hipHostFree(h_err_); hipHostFree(h_bins_);
+  delete entropy_;
+  hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_off_); hipFree(sync_); hipFree(err_);
+  hipHostFree(h_tok_dense_); hipHostFree(h_tok_count_); hipHostFree(h_err_);
   if (stream_) hipStreamDestroy(stream_);
 }
 
@@ -151,25 +159,10 @@ bool Encoder::run_picture(EncodedPicture *out)
     timed(K_INTER_SIGNAL, [&] { launch_inter_signal(f, stream_); });
   }
   if (cfg_.deblock) timed(K_DEBLOCK, [&] { launch_deblock(f, stream_); });
-  HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * rows_, stream_));
-  HIP_CHECK(hipMemsetAsync(bins_, 0, sizeof(uint64_t), stream_));
-  timed(K_ENTROPY, [&] { launch_entropy(f, stream_); });
-  HIP_CHECK(hipMemcpyAsync(h_row_len_, row_len_, sizeof(int32_t) * rows_, hipMemcpyDeviceToHost, stream_));
+  timed(K_TOKENIZE, [&] { launch_tokenize(f, stream_); });
   HIP_CHECK(hipMemcpyAsync(h_err_, err_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
-  HIP_CHECK(hipMemcpyAsync(h_bins_, bins_, sizeof(uint64_t), hipMemcpyDeviceToHost, stream_));
   HIP_CHECK(hipStreamSynchronize(stream_));
-  if (*h_err_) { fprintf(stderr, "kvazzup_amd: device error flags 0x%x\n", *h_err_); return false; }
-  const int nsub = cfg_.wpp ? rows_ : 1;
-  int maxlen = 0;
-  for (int r = 0; r < nsub; r++) { if (h_row_len_[r] > maxlen) maxlen = h_row_len_[r]; }
-  if (cfg_.wpp) {
-    if (maxlen > row_cap_) { fprintf(stderr, "kvazzup_amd: substream buffer overflow\n"); return false; }
-    HIP_CHECK(hipMemcpy2DAsync(h_rows_, (size_t)row_cap_, row_buf_, (size_t)row_cap_, (size_t)maxlen, (size_t)nsub, hipMemcpyDeviceToHost, stream_));
-  } else {
-    if ((size_t)maxlen > (size_t)row_cap_ * rows_) { fprintf(stderr, "kvazzup_amd: bitstream buffer overflow\n"); return false; }
-    HIP_CHECK(hipMemcpyAsync(h_rows_, row_buf_, (size_t)maxlen, hipMemcpyDeviceToHost, stream_));
-  }
-  HIP_CHECK(hipStreamSynchronize(stream_));
+  if (*h_err_) { fprintf(stderr, "kvazzup_amd: device error flags 0x%x (8/16/32: token buffer overflow)\n", *h_err_); return false; }
   if (profiling_) {
     for (size_t i = 0; i < ev_used_; i++) {
       float ms = 0; hipEventElapsedTime(&ms, ev_pool_[i].a, ev_pool_[i].b);
@@ -177,14 +170,20 @@ bool Encoder::run_picture(EncodedPicture *out)
     }
     ev_used_ = 0;
   }
+  // ---- serial half of entropy coding: host threads turn the bins into the WPP substreams
+  const int nsub = cfg_.wpp ? rows_ : 1;
+  uint64_t bins = 0;
+  auto t0 = std::chrono::steady_clock::now();
+  entropy_->code_picture(h_tok_dense_, h_tok_count_, cw_ / 64, rows_, cfg_.wpp != 0, intra ? 0 : 1, cfg_.qp, rows_out_, &bins);
+  if (profiling_) { k_ms_[K_HOST_ARITH] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); k_n_[K_HOST_ARITH]++; }
   // ---- access unit assembly (host): parameter sets with IDR pictures, then the slice NAL
-  out->poc = poc_; out->is_intra = intra; out->bins = *h_bins_;
+  out->poc = poc_; out->is_intra = intra; out->bins = bins;
   bool write_ps = false;
   if (intra) {
     write_ps = (intra_count_ == 0) || (cfg_.vps_period > 0 && (intra_count_ % cfg_.vps_period) == 0);
     intra_count_++;
   }
-  assemble_access_unit(out->au, sp_, intra, poc_, write_ps, h_rows_, (size_t)row_cap_, h_row_len_, nsub);
+  assemble_access_unit(out->au, sp_, intra, poc_, write_ps, rows_out_, nsub);
   frame_idx_++;
   int t = cur_idx_; cur_idx_ = ref_idx_; ref_idx_ = t;     // rec_[ref_idx_] now holds the picture just coded
   return true;

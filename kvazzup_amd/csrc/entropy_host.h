@@ -1,0 +1,132 @@
+// kvazzup_amd/csrc/entropy_host.h -- the serial half of entropy coding, on host threads.
+//
+// Binarisation and context selection -- everything in CABAC that can be done in parallel -- runs
+// on the GPU (k_tokenize, enc_kernels.hip) and produces, per CTU, the list of bins in coding
+// order as 16-bit tokens.  What is left is the arithmetic coder proper: one state machine per
+// WPP substream (CTU row), each bin depending on the previous one.  A GPU lane does that at
+// ~80 ns per bin; a host core at ~8 ns.  So the rows of a picture are coded here by a small pool
+// of host threads (the reference's encoder does its CABAC on host threads too: Kvazaar's WPP
+// worker pool behind kvz_api->encoder_encode, kvazaarfilter.cpp:176-194 "threads"/"wpp").
+// Row r starts from the context states row r-1 had after its second CTU (H.265 9.3.2.2).
+#pragma once
+#include <atomic>
+#include <cstring>
+#include <memory>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include "hevc_core.h"
+
+namespace kvzx {
+
+class EntropyHost {
+ public:
+  explicit EntropyHost(int max_threads)
+  {
+    int hw = (int)std::thread::hardware_concurrency();
+    nthreads_ = max_threads;
+    if (hw > 0 && nthreads_ > hw) nthreads_ = hw;
+    if (nthreads_ < 1) nthreads_ = 1;
+    for (int i = 0; i < 64; i++) core_tabs_fill_entry(tabs_, i);
+    for (int i = 0; i < nthreads_; i++) workers_.emplace_back([this] { worker(); });
+  }
+  ~EntropyHost()
+  {
+    { std::lock_guard<std::mutex> l(m_); quit_ = true; gen_++; }
+    cv_.notify_all();
+    for (auto &t : workers_) t.join();
+  }
+  // Codes one picture.  tokens: dense token array, CTU after CTU in raster order; count[ctu] tokens each.
+  // rows_out[r] receives the bytes of substream r (one per CTU row with WPP, else a single one).
+  void code_picture(const uint16_t *tokens, const int32_t *count, int wc, int hc, bool wpp, int init_type, int qp,
+                    std::vector<std::vector<uint8_t>> &rows_out, uint64_t *bins)
+  {
+    while (active_.load(std::memory_order_acquire) != 0) std::this_thread::yield();   // stragglers of the previous picture
+    tokens_ = tokens; count_ = count; wc_ = wc; hc_ = hc; wpp_ = wpp; init_type_ = init_type; qp_ = qp;
+    const int nsub = wpp ? hc : 1;
+    rows_out.resize((size_t)nsub);
+    rows_ = &rows_out;
+    offsets_.resize((size_t)wc * hc + 1);
+    size_t acc = 0;
+    for (int i = 0; i < wc * hc; i++) { offsets_[(size_t)i] = acc; acc += (size_t)count[i]; }
+    offsets_[(size_t)wc * hc] = acc;
+    saved_.resize((size_t)hc * CTX_COUNT);
+    ready_.reset(new std::atomic<int>[(size_t)hc]);
+    for (int r = 0; r < hc; r++) ready_[(size_t)r].store(0, std::memory_order_relaxed);
+    bins_.store(0);
+    done_rows_.store(0);
+    total_rows_ = nsub;
+    next_row_.store(0, std::memory_order_release);
+    { std::lock_guard<std::mutex> l(m_); gen_++; }
+    cv_.notify_all();
+    run_rows();                                   // the calling thread helps
+    std::unique_lock<std::mutex> l(m_);
+    done_cv_.wait(l, [this] { return done_rows_.load() == total_rows_; });
+    if (bins) *bins = bins_.load();
+  }
+
+ private:
+  void worker()
+  {
+    uint64_t seen = 0;
+    for (;;) {
+      { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return gen_ != seen; }); seen = gen_; if (quit_) return; }
+      run_rows();
+    }
+  }
+  void run_rows()
+  {
+    active_.fetch_add(1, std::memory_order_acq_rel);
+    for (;;) {
+      int r = next_row_.fetch_add(1, std::memory_order_acq_rel);
+      if (r >= total_rows_) { active_.fetch_sub(1, std::memory_order_acq_rel); return; }
+      code_row(r);
+      if (done_rows_.fetch_add(1) + 1 == total_rows_) { std::lock_guard<std::mutex> l(m_); done_cv_.notify_all(); }
+    }
+  }
+  void code_row(int r)
+  {
+    uint8_t ctx[CTX_COUNT];
+    std::vector<uint8_t> &out = (*rows_)[(size_t)r];
+    const int first_cy = wpp_ ? r : 0, ncy = wpp_ ? 1 : hc_;
+    size_t ntok = 0;
+    for (int cy = first_cy; cy < first_cy + ncy; cy++) ntok += offsets_[(size_t)(cy + 1) * wc_] - offsets_[(size_t)cy * wc_];
+    out.resize(ntok * 2 + 64);                    // a token never produces more than two bytes
+    CabacEnc c; c.nbins = 0;
+    cabac_start(c, out.data(), (int)out.size(), ctx, &tabs_);
+    if (r == 0 || !wpp_) cabac_init_contexts(ctx, init_type_, qp_);
+    else {
+      while (!ready_[(size_t)(r - 1)].load(std::memory_order_acquire)) std::this_thread::yield();
+      memcpy(ctx, &saved_[(size_t)(r - 1) * CTX_COUNT], CTX_COUNT);
+    }
+    for (int cy = first_cy; cy < first_cy + ncy; cy++)
+      for (int cx = 0; cx < wc_; cx++) {
+        const size_t ctu = (size_t)cy * wc_ + cx;
+        cabac_play_tokens(c, tokens_ + offsets_[ctu], count_[ctu]);
+        if (wpp_ && cx == 1) {
+          memcpy(&saved_[(size_t)r * CTX_COUNT], ctx, CTX_COUNT);
+          ready_[(size_t)r].store(1, std::memory_order_release);
+        }
+      }
+    cabac_finish(c);
+    out.resize((size_t)c.pos);
+    bins_.fetch_add(c.nbins);
+  }
+
+  int nthreads_;
+  std::vector<std::thread> workers_;
+  std::mutex m_; std::condition_variable cv_, done_cv_;
+  uint64_t gen_ = 0; bool quit_ = false;
+  CoreTabs tabs_;
+  const uint16_t *tokens_ = nullptr; const int32_t *count_ = nullptr;
+  int wc_ = 0, hc_ = 0, init_type_ = 0, qp_ = 0; std::atomic<int> total_rows_{0}; bool wpp_ = true;
+  std::vector<size_t> offsets_;
+  std::vector<uint8_t> saved_;
+  std::unique_ptr<std::atomic<int>[]> ready_;
+  std::vector<std::vector<uint8_t>> *rows_ = nullptr;
+  std::atomic<int> next_row_{1 << 30}, done_rows_{0}, active_{0};
+  std::atomic<uint64_t> bins_{0};
+};
+
+}  // namespace kvzx

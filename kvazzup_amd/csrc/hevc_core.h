@@ -39,12 +39,13 @@ struct EncFrame {
   int16_t *cu_mv, *cu_mvd;      // [b8][2]
   // intra analysis scratch
   uint8_t *im8, *im16, *im32; uint32_t *ic8, *ic16, *ic32;
-  // entropy coding output: one buffer per CTU row (or one for the picture without WPP)
-  uint8_t *row_buf; int row_cap; int32_t *row_len;
-  uint8_t *wpp_ctx;             // [rows][CTX_COUNT] saved context states
-  uint32_t *sync;               // [rows] progress counters (intra recon / entropy wavefront)
+  // entropy coding, GPU half: per-CTU token lists (tok_cap tokens each), their counts, the
+  // exclusive prefix sum of the counts and the dense copy the host arithmetic coder reads
+  // (tok_dense / tok_count_out live in host-mapped pinned memory)
+  uint16_t *tok_buf; int tok_cap; int32_t *tok_count; uint32_t *tok_off;
+  uint16_t *tok_dense; uint32_t tok_dense_cap; int32_t *tok_count_out;
+  uint32_t *sync;               // [rows] progress counters (intra reconstruction wavefront)
   uint32_t *err;                // device-side error flags
-  uint64_t *bins;               // statistics (optional)
 };
 
 enum { CU_SKIP = 1, CU_MERGE = 2 };
@@ -258,6 +259,39 @@ KVZ_HD void cabac_finish(CabacEnc &c)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Token sink: the GPU does binarisation and context selection for every syntax element in
+// parallel (k_tokenize) and emits 16-bit tokens in coding order; the strictly serial arithmetic
+// coder then only walks the token list (entropy_host.h).  The syntax functions below are templates
+// over the sink, so the same code drives a CabacEnc directly (host reference path / tests).
+//   0b0ccccccccb              context-coded bin: ctx index c, value b
+//   0b10nnnn vvvvvvvvvv       bypass string of n+1 (1..10) bits, value v, MSB first
+//   0b11.............b        terminating bin b
+// ---------------------------------------------------------------------------------------------
+struct TokOut {
+  const CoreTabs *tabs;
+  uint16_t *p; int n, cap;
+};
+KVZ_HD void tok_push(TokOut &t, uint32_t v) { if (t.n < t.cap) t.p[t.n] = (uint16_t)v; t.n++; }
+KVZ_HD void cabac_bin(TokOut &t, int ci, int bin) { tok_push(t, ((uint32_t)ci << 1) | (uint32_t)(bin ? 1 : 0)); }
+KVZ_HD void cabac_bypass(TokOut &t, int bin) { tok_push(t, 0x8000u | (uint32_t)(bin ? 1 : 0)); }
+KVZ_HD void cabac_bypass_bits(TokOut &t, uint32_t val, int n)
+{
+  while (n > 10) { n -= 10; tok_push(t, 0x8000u | (9u << 10) | ((val >> n) & 0x3ffu)); }
+  if (n > 0) tok_push(t, 0x8000u | ((uint32_t)(n - 1) << 10) | (val & ((1u << n) - 1u)));
+}
+KVZ_HD void cabac_terminate(TokOut &t, int bin) { tok_push(t, 0xC000u | (uint32_t)(bin ? 1 : 0)); }
+// replay of a token list into the arithmetic coder
+KVZ_HD void cabac_play_tokens(CabacEnc &c, const uint16_t *tok, int n)
+{
+  for (int i = 0; i < n; i++) {
+    uint32_t t = tok[i];
+    if (!(t & 0x8000u)) cabac_bin(c, (int)(t >> 1), (int)(t & 1));
+    else if (!(t & 0x4000u)) cabac_bypass_bits(c, t & 0x3ffu, (int)((t >> 10) & 15) + 1);
+    else cabac_terminate(c, (int)(t & 1));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // residual_coding (H.265 7.3.8.11) for the encoder's tool set: diagonal / horizontal / vertical
 // scans, no transform skip, no sign hiding.  `lv` points at the block's top-left level inside a
 // plane-shaped level array with pitch `stride`.  The block has at least one non-zero level.
@@ -274,7 +308,8 @@ KVZ_HD void scan_pos(const CoreTabs *t, int scan_idx, int log2blk, int i, int &x
   else { x = 0; y = 0; }
 }
 
-KVZ_HD void enc_last_prefix(CabacEnc &c, int base, int log2, int cidx, int prefix)
+template <class S>
+KVZ_HD void enc_last_prefix(S &c, int base, int log2, int cidx, int prefix)
 {
   int off, sh, mx = (log2 << 1) - 1;
   if (cidx == 0) { off = 3 * (log2 - 2) + ((log2 - 1) >> 2); sh = (log2 + 1) >> 2; }
@@ -283,7 +318,8 @@ KVZ_HD void enc_last_prefix(CabacEnc &c, int base, int log2, int cidx, int prefi
   if (prefix < mx) cabac_bin(c, base + off + (prefix >> sh), 0);
 }
 
-KVZ_HD void enc_abs_remaining(CabacEnc &c, int v, int rice)
+template <class S>
+KVZ_HD void enc_abs_remaining(S &c, int v, int rice)
 {
   int q = v >> rice;
   if (q < 4) {
@@ -331,18 +367,20 @@ KVZ_HD void digest_build_serial(const CoreTabs *t, TuDigest &d, const int16_t *l
   }
 }
 
-KVZ_HD void enc_residual_digest(CabacEnc &c, TuDigest &d, int log2, int cidx, int scan_idx)
+// last_sig_coeff_{x,y}_{prefix,suffix}; returns the last sub-block / position through the references
+template <class S>
+KVZ_HD void enc_last_pos(S &c, const TuDigest &d, int log2, int cidx, int scan_idx, int &last_sb, int &last_pos)
 {
-  const int sbl = log2 - 2, nsb = 1 << sbl;
+  const int sbl = log2 - 2;
   const CoreTabs *t = c.tabs;
-  int last_sb = 63;
+  last_sb = 63;
   while (!((d.sbmask >> last_sb) & 1)) last_sb--;
-  int last_pos = 15;
+  last_pos = 15;
   { uint32_t m = d.mask[last_sb]; while (!((m >> last_pos) & 1)) last_pos--; }
   int xs0, ys0, xp0, yp0;
   scan_pos(t, scan_idx, sbl, last_sb, xs0, ys0); scan_pos(t, scan_idx, 2, last_pos, xp0, yp0);
   int lx = (xs0 << 2) + xp0, ly = (ys0 << 2) + yp0;
-  if (scan_idx == 2) { int t = lx; lx = ly; ly = t; }
+  if (scan_idx == 2) { int tt = lx; lx = ly; ly = tt; }
   int pfx[2], nbs[2], sfx[2];
   for (int dd = 0; dd < 2; dd++) {
     int v = dd ? ly : lx;
@@ -353,74 +391,104 @@ KVZ_HD void enc_residual_digest(CabacEnc &c, TuDigest &d, int log2, int cidx, in
   enc_last_prefix(c, CTX_LAST_Y, log2, cidx, pfx[1]);
   if (pfx[0] > 3) cabac_bypass_bits(c, (uint32_t)sfx[0], nbs[0]);
   if (pfx[1] > 3) cabac_bypass_bits(c, (uint32_t)sfx[1], nbs[1]);
+}
+
+// does sub-block i contain, among its first 8 coefficients in coding order, one with |level| > 1?
+// (that is exactly "greater1Ctx ended at 0", the only state the next sub-block inherits, 9.3.4.2.6)
+KVZ_HD bool subblock_g1_any(const CoreTabs *t, const TuDigest &d, int i, int scan_idx)
+{
+  const uint32_t m = d.mask[i];
+  int seen = 0;
+  for (int k = 15; k >= 0 && seen < 8; k--) if ((m >> k) & 1) {
+    int v = d.raster[i * 16 + scan_raster4(t, scan_idx, k)];
+    if (v > 1 || v < -1) return true;
+    seen++;
+  }
+  return false;
+}
+
+// All syntax elements of sub-block i (coded_sub_block_flag .. coeff_abs_level_remaining).
+// prev_g1: the previous non-empty sub-block in coding order ended with greater1Ctx == 0.
+template <class S>
+KVZ_HD void enc_subblock(S &c, const TuDigest &d, int i, int last_sb, int last_pos, bool prev_g1, int log2, int cidx, int scan_idx)
+{
+  const int sbl = log2 - 2, nsb = 1 << sbl;
+  const CoreTabs *t = c.tabs;
+  int xs, ys; scan_pos(t, scan_idx, sbl, i, xs, ys);
+  const int right = (xs < nsb - 1) ? d.csbf[ys * 8 + xs + 1] : 0;
+  const int below = (ys < nsb - 1) ? d.csbf[(ys + 1) * 8 + xs] : 0;
+  const uint32_t m = d.mask[i];
+  int coded = m != 0, infer_dc = 0;
+  if (i < last_sb && i > 0) {
+    cabac_bin(c, CTX_CSBF + ((right | below) ? 1 : 0) + (cidx ? 2 : 0), coded);
+    infer_dc = 1;
+  } else coded = 1;                        // inferred 1 for the last and the DC sub-block
+  if (!coded) return;
+  const int prev_csbf = right | (below << 1);
+  for (int k = (i == last_sb) ? last_pos - 1 : 15; k >= 0; k--) {
+    if (k > 0 || !infer_dc) {
+      int xp, yp; scan_pos(t, scan_idx, 2, k, xp, yp);
+      int xc = (xs << 2) + xp, yc = (ys << 2) + yp, sc;
+      if (log2 == 2) sc = t->ctxmap4x4[(yc << 2) + xc];
+      else if (xc + yc == 0) sc = 0;
+      else {
+        if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
+        else if (prev_csbf == 1) sc = (yp == 0) ? 2 : (yp == 1) ? 1 : 0;
+        else if (prev_csbf == 2) sc = (xp == 0) ? 2 : (xp == 1) ? 1 : 0;
+        else sc = 2;
+        if (cidx == 0) { if (i > 0) sc += 3; sc += (log2 == 3) ? ((scan_idx == 0) ? 9 : 15) : 21; }
+        else sc += (log2 == 3) ? 9 : 12;
+      }
+      int sig = (m >> k) & 1;
+      cabac_bin(c, CTX_SIG + (cidx ? 27 : 0) + sc, sig);
+      if (sig) infer_dc = 0;
+    }
+  }
+  if (!m) return;
+  int ctx_set = (i > 0 && cidx == 0) ? 2 : 0;
+  if (prev_g1) ctx_set++;
   int c1 = 1;
-  for (int i = last_sb; i >= 0; i--) {
-    int xs, ys; scan_pos(t, scan_idx, sbl, i, xs, ys);
-    int right = (xs < nsb - 1) ? d.csbf[ys * 8 + xs + 1] : 0;
-    int below = (ys < nsb - 1) ? d.csbf[(ys + 1) * 8 + xs] : 0;
-    const uint32_t m = d.mask[i];
-    int coded = m != 0, infer_dc = 0;
-    if (i < last_sb && i > 0) {
-      cabac_bin(c, CTX_CSBF + ((right | below) ? 1 : 0) + (cidx ? 2 : 0), coded);
-      infer_dc = 1;
-    } else {
-      d.csbf[ys * 8 + xs] = 1;              // inferred 1 for the last and the DC sub-block
-      coded = 1;
-    }
-    if (!coded) continue;
-    const int prev_csbf = right | (below << 1);
-    for (int k = (i == last_sb) ? last_pos - 1 : 15; k >= 0; k--) {
-      if (k > 0 || !infer_dc) {
-        int xp, yp; scan_pos(t, scan_idx, 2, k, xp, yp);
-        int xc = (xs << 2) + xp, yc = (ys << 2) + yp, sc;
-        if (log2 == 2) sc = t->ctxmap4x4[(yc << 2) + xc];
-        else if (xc + yc == 0) sc = 0;
-        else {
-          if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
-          else if (prev_csbf == 1) sc = (yp == 0) ? 2 : (yp == 1) ? 1 : 0;
-          else if (prev_csbf == 2) sc = (xp == 0) ? 2 : (xp == 1) ? 1 : 0;
-          else sc = 2;
-          if (cidx == 0) { if (i > 0) sc += 3; sc += (log2 == 3) ? ((scan_idx == 0) ? 9 : 15) : 21; }
-          else sc += (log2 == 3) ? 9 : 12;
-        }
-        int sig = (m >> k) & 1;
-        cabac_bin(c, CTX_SIG + (cidx ? 27 : 0) + sc, sig);
-        if (sig) infer_dc = 0;
-      }
-    }
-    if (!m) continue;
-    int ctx_set = (i > 0 && cidx == 0) ? 2 : 0;
-    if (c1 == 0) ctx_set++;
-    c1 = 1;
-    // levels of the significant coefficients in coding order (scan position 15 .. 0)
-    int16_t lev[16]; int nsig = 0, g1idx = -1;
-    uint32_t signs = 0;
-    for (int k = 15; k >= 0; k--) if ((m >> k) & 1) {
-      int v = d.raster[i * 16 + scan_raster4(t, scan_idx, k)];
-      signs = (signs << 1) | (v < 0 ? 1u : 0u);
-      lev[nsig++] = (int16_t)iabs(v);
-    }
-    for (int j = 0; j < nsig && j < 8; j++) {
-      int g1 = lev[j] > 1;
-      cabac_bin(c, CTX_GT1 + (cidx ? 16 : 0) + ctx_set * 4 + c1, g1);
-      if (g1) { c1 = 0; if (g1idx < 0) g1idx = j; }
-      else if (c1 > 0 && c1 < 3) c1++;
-    }
-    if (g1idx >= 0) cabac_bin(c, CTX_GT2 + (cidx ? 4 : 0) + ctx_set, lev[g1idx] > 2);
-    cabac_bypass_bits(c, signs, nsig);
-    int rice = 0;
-    for (int j = 0; j < nsig; j++) {
-      int a = lev[j];
-      int base = (j < 8) ? ((j == g1idx) ? 3 : 2) : 1;
-      if (a >= base) {
-        enc_abs_remaining(c, a - base, rice);
-        if (a > 3 * (1 << rice)) rice = imin(rice + 1, 4);
-      }
+  // levels of the significant coefficients in coding order (scan position 15 .. 0)
+  int16_t lev[16]; int nsig = 0, g1idx = -1;
+  uint32_t signs = 0;
+  for (int k = 15; k >= 0; k--) if ((m >> k) & 1) {
+    int v = d.raster[i * 16 + scan_raster4(t, scan_idx, k)];
+    signs = (signs << 1) | (v < 0 ? 1u : 0u);
+    lev[nsig++] = (int16_t)iabs(v);
+  }
+  for (int j = 0; j < nsig && j < 8; j++) {
+    int g1 = lev[j] > 1;
+    cabac_bin(c, CTX_GT1 + (cidx ? 16 : 0) + ctx_set * 4 + c1, g1);
+    if (g1) { c1 = 0; if (g1idx < 0) g1idx = j; }
+    else if (c1 > 0 && c1 < 3) c1++;
+  }
+  if (g1idx >= 0) cabac_bin(c, CTX_GT2 + (cidx ? 4 : 0) + ctx_set, lev[g1idx] > 2);
+  cabac_bypass_bits(c, signs, nsig);
+  int rice = 0;
+  for (int j = 0; j < nsig; j++) {
+    int a = lev[j];
+    int base = (j < 8) ? ((j == g1idx) ? 3 : 2) : 1;
+    if (a >= base) {
+      enc_abs_remaining(c, a - base, rice);
+      if (a > 3 * (1 << rice)) rice = imin(rice + 1, 4);
     }
   }
 }
 
-KVZ_HD void enc_residual(CabacEnc &c, const int16_t *lv, int stride, int log2, int cidx, int scan_idx)
+template <class S>
+KVZ_HD void enc_residual_digest(S &c, const TuDigest &d, int log2, int cidx, int scan_idx)
+{
+  int last_sb, last_pos;
+  enc_last_pos(c, d, log2, cidx, scan_idx, last_sb, last_pos);
+  bool prev_g1 = false;
+  for (int i = last_sb; i >= 0; i--) {
+    enc_subblock(c, d, i, last_sb, last_pos, prev_g1, log2, cidx, scan_idx);
+    if (d.mask[i]) prev_g1 = subblock_g1_any(c.tabs, d, i, scan_idx);
+  }
+}
+
+template <class S>
+KVZ_HD void enc_residual(S &c, const int16_t *lv, int stride, int log2, int cidx, int scan_idx)
 {
   TuDigest d;
   digest_build_serial(c.tabs, d, lv, stride, log2, scan_idx);
@@ -437,7 +505,8 @@ KVZ_HD int intra_scan_idx(int intra, int log2, int cidx, int mode)
   return 0;
 }
 
-KVZ_HD void enc_mvd(CabacEnc &c, int dx, int dy)
+template <class S>
+KVZ_HD void enc_mvd(S &c, int dx, int dy)
 {
   int ax = iabs(dx), ay = iabs(dy);
   cabac_bin(c, CTX_MVD_GT0, ax > 0); cabac_bin(c, CTX_MVD_GT0, ay > 0);
@@ -456,7 +525,8 @@ KVZ_HD void enc_mvd(CabacEnc &c, int dx, int dy)
   }
 }
 
-KVZ_HD void enc_merge_idx(CabacEnc &c, int idx)
+template <class S>
+KVZ_HD void enc_merge_idx(S &c, int idx)
 {
   cabac_bin(c, CTX_MERGE_IDX, idx > 0);
   for (int i = 1; i < 4 && idx >= i; i++) cabac_bypass(c, idx > i);
@@ -500,8 +570,8 @@ KVZ_HD void intra_mpm(const V &v, int cw, int ch, int x0, int y0, int cand[3])
 
 // split_cu_flag bins (7.3.8.4) for every quadtree level whose block starts at z-order index z
 // (in 8x8 units) of the CTU at (cx, cy), down to the CU of size (1 << cl) that starts there.
-template <class V>
-KVZ_HD void enc_split_flags(const V &v, CabacEnc &c, int cw, int ch, int x0, int y0, int z, int cl)
+template <class V, class S>
+KVZ_HD void enc_split_flags(const V &v, S &c, int cw, int ch, int x0, int y0, int z, int cl)
 {
   for (int l2 = 6; l2 > 3; l2--) {
     int zmask = (1 << (2 * (l2 - 3))) - 1;
@@ -516,8 +586,8 @@ KVZ_HD void enc_split_flags(const V &v, CabacEnc &c, int cw, int ch, int x0, int
 
 // coding_unit() up to and including the cbf flags of its single transform unit (7.3.8.5-7.3.8.10).
 // Returns the cbf bits (bit0 Y, bit1 Cb, bit2 Cr) whose residual_coding() must follow, 0 if none.
-template <class V>
-KVZ_HD int enc_cu_header(const V &v, CabacEnc &c, int cw, int ch, bool pic_intra, int x0, int y0, const CuRec &cu)
+template <class V, class S>
+KVZ_HD int enc_cu_header(const V &v, S &c, int cw, int ch, bool pic_intra, int x0, int y0, const CuRec &cu)
 {
   const int intra = cu.intra, flags = cu.flags, cbf = cu.cbf, log2 = cu.log2;
   if (!pic_intra) {

@@ -142,9 +142,9 @@ inline void append_nal(std::vector<uint8_t> &out, int nal_type, const uint8_t *r
 }
 
 // One access unit: [VPS SPS PPS] + slice NAL whose data are the `nsub` substreams (CTU rows with
-// WPP, otherwise one) found at rows + r * row_pitch with lengths lens[r].
+// WPP, otherwise one) rows[r].
 inline void assemble_access_unit(std::vector<uint8_t> &au, const StreamParams &sp, bool idr, int poc, bool write_ps,
-                                 const uint8_t *rows, size_t row_pitch, const int32_t *lens, int nsub)
+                                 const std::vector<std::vector<uint8_t>> &rows, int nsub)
 {
   au.clear();
   if (write_ps) {
@@ -154,10 +154,10 @@ inline void assemble_access_unit(std::vector<uint8_t> &au, const StreamParams &s
     write_pps(c, sp); append_nal(au, 34, c.data().data(), c.data().size());
   }
   std::vector<uint32_t> entry;
-  for (int r = 0; r + 1 < nsub; r++) entry.push_back((uint32_t)escaped_size(rows + (size_t)r * row_pitch, (size_t)lens[r]));
+  for (int r = 0; r + 1 < nsub; r++) entry.push_back((uint32_t)escaped_size(rows[(size_t)r].data(), rows[(size_t)r].size()));
   BitWriter sh;
   write_slice_header(sh, sp, idr, poc, entry);
-  for (int r = 0; r < nsub; r++) sh.bytes(rows + (size_t)r * row_pitch, (size_t)lens[r]);
+  for (int r = 0; r < nsub; r++) sh.bytes(rows[(size_t)r].data(), rows[(size_t)r].size());
   append_nal(au, idr ? 19 : 1, sh.data().data(), sh.data().size());
 }
 

@@ -4,6 +4,7 @@
 // 36-56 (init), 145-146 (decode), 195-199 (output), 81-82 (flush/close).
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include "../../include/kvazzup_amd.h"
 #include "decoder.h"
 
@@ -38,7 +39,8 @@ OpenHevc_Handle libOpenHevcInit(int nb_pthreads, int thread_type)
 {
   Handle *h = new Handle();
   h->threads = nb_pthreads; h->thread_type = thread_type;       // accepted; the GPU does the sample work
-  h->dec = new Decoder(0);
+  const char *env = getenv("KVAZZUP_AMD_DEVICE");
+  h->dec = new Decoder(env ? atoi(env) : 0);
   return (OpenHevc_Handle)h;
 }
 int libOpenHevcStartDecoder(OpenHevc_Handle hh)
@@ -104,6 +106,14 @@ void libOpenHevcClose(OpenHevc_Handle hh)
 }
 const char *libOpenHevcVersion(OpenHevc_Handle) { return "kvazzup_amd-hevc-dec 0.1 (gfx950)"; }
 
+int kvzx_decoder_set_device(OpenHevc_Handle hh, int device)
+{
+  Handle *h = H(hh);
+  if (!h || h->started || device < 0) return 0;
+  delete h->dec;
+  h->dec = new Decoder(device);
+  return 1;
+}
 int kvzx_decoder_last_error(OpenHevc_Handle hh) { Handle *h = H(hh); return h ? h->dec->last_error() : -1; }
 int kvzx_decoder_output_device(OpenHevc_Handle hh, const void **planes, int *pitches)
 {

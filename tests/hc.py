@@ -21,6 +21,7 @@ def lib():
         subprocess.run(["make", "-s", "-C", d], check=True, stdout=subprocess.DEVNULL)
         L = C.CDLL(os.path.join(d, "build", "libhostcheck.so"))
         L.hc_encode_au.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.hc_encode_au_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.hc_inter_signal.argtypes = [C.c_void_p]
         L.hc_deblock.argtypes = [C.c_void_p] * 4
         L.hc_intra_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -50,3 +51,11 @@ def encode_au(f):
     n = lib().hc_encode_au(C.byref(f), out.ctypes.data, len(out), C.byref(bins))
     assert n > 0
     return bytes(out[:n]), bins.value
+
+
+def encode_au_tokens(f):
+    out = np.empty(f.cw * f.ch * 3 + (1 << 16), dtype=np.uint8)
+    nt = C.c_ulonglong()
+    n = lib().hc_encode_au_tokens(C.byref(f), out.ctypes.data, len(out), C.byref(nt))
+    assert n > 0, n
+    return bytes(out[:n]), nt.value

@@ -64,6 +64,7 @@ int hc_encode_au(HcFrame *h, uint8_t *out, int cap, unsigned long long *bins)
   const int row_cap = f.cw * 64 * 3;
   std::vector<uint8_t> rows((size_t)row_cap * hc);
   std::vector<int32_t> lens(hc, 0);
+  std::vector<std::vector<uint8_t>> rowv;
   uint8_t ctx[CTX_COUNT], saved[CTX_COUNT];
   static CoreTabs tabs; for (int i = 0; i < 64; i++) core_tabs_fill_entry(tabs, i);
   CabacEnc c; c.nbins = 0;
@@ -94,7 +95,83 @@ int hc_encode_au(HcFrame *h, uint8_t *out, int cap, unsigned long long *bins)
   StreamParams sp; sp.cw = f.cw; sp.ch = f.ch; sp.width = h->width; sp.height = h->height; sp.qp = f.qp; sp.wpp = f.wpp;
   sp.deblock = h->deblock; sp.fps_num = h->fps_num; sp.fps_den = h->fps_den;
   std::vector<uint8_t> au;
-  assemble_access_unit(au, sp, f.is_intra != 0, f.poc, h->write_ps != 0, rows.data(), (size_t)row_cap, lens.data(), nsub);
+  for (int r = 0; r < nsub; r++) rowv.emplace_back(rows.begin() + (size_t)r * row_cap, rows.begin() + (size_t)r * row_cap + lens[r]);
+  assemble_access_unit(au, sp, f.is_intra != 0, f.poc, h->write_ps != 0, rowv, nsub);
+  if ((int)au.size() > cap) return -(int)au.size();
+  memcpy(out, au.data(), au.size());
+  return (int)au.size();
+}
+
+// Same picture through the two-stage path of the product: every CTU is first turned into bin
+// tokens the way k_tokenize does it (CU headers, then per transform block the last position and
+// the sub-blocks, each sub-block tokenised independently with the greater1 carry taken from the
+// next non-empty sub-block above it), then the tokens are replayed into the arithmetic coder the
+// way entropy_host.h does it.  Must give the same access unit as hc_encode_au().
+int hc_encode_au_tokens(HcFrame *h, uint8_t *out, int cap, unsigned long long *ntokens)
+{
+  EncFrame f; fill(f, *h);
+  const int wc = f.cw / 64, hc = f.ch / 64, nsub = f.wpp ? hc : 1;
+  static CoreTabs tabs; for (int i = 0; i < 64; i++) core_tabs_fill_entry(tabs, i);
+  std::vector<std::vector<uint16_t>> ctu_tok((size_t)wc * hc);
+  FrameView v; v.f = &f;
+  unsigned long long total = 0;
+  for (int cy = 0; cy < hc; cy++)
+    for (int cx = 0; cx < wc; cx++) {
+      std::vector<uint16_t> buf(65536);
+      TokOut t; t.tabs = &tabs; t.p = buf.data(); t.n = 0; t.cap = (int)buf.size();
+      for (int z = 0; z < 64;) {
+        int xi, yi; ctu_z_to_xy(z, xi, yi);
+        int x0 = cx * 64 + xi * 8, y0 = cy * 64 + yi * 8;
+        CuRec cu = v.at(x0, y0);
+        enc_split_flags(v, t, f.cw, f.ch, x0, y0, z, cu.log2);
+        int cbf = enc_cu_header(v, t, f.cw, f.ch, f.is_intra != 0, x0, y0, cu);
+        for (int ci = 0; ci < 3; ci++) {
+          if (!((cbf >> ci) & 1)) continue;
+          int l2 = ci ? cu.log2 - 1 : cu.log2, pw = ci ? f.cw / 2 : f.cw, px = ci ? x0 / 2 : x0, py = ci ? y0 / 2 : y0;
+          int scan = intra_scan_idx(cu.intra, l2, ci, cu.intra_mode);
+          TuDigest d; digest_build_serial(&tabs, d, f.coef[ci] + py * pw + px, pw, l2, scan);
+          int last_sb, last_pos; enc_last_pos(t, d, l2, ci, scan, last_sb, last_pos);
+          // independent per sub-block tokenisation, concatenated from last_sb downwards
+          for (int i = last_sb; i >= 0; i--) {
+            bool prev_g1 = false;
+            uint64_t above = (i < 63) ? (d.sbmask >> (i + 1)) : 0;
+            if (above) { int j = i + 1 + __builtin_ctzll(above); prev_g1 = subblock_g1_any(&tabs, d, j, scan); }
+            uint16_t lt[160]; TokOut s2; s2.tabs = &tabs; s2.p = lt; s2.n = 0; s2.cap = 160;
+            enc_subblock(s2, d, i, last_sb, last_pos, prev_g1, l2, ci, scan);
+            if (s2.n > 128) return -1000000;                 // TOK_LANE_CAP of the kernel
+            for (int k = 0; k < s2.n; k++) tok_push(t, lt[k]);
+          }
+        }
+        z += 1 << (2 * (cu.log2 - 3));
+      }
+      bool last = (cy == hc - 1 && cx == wc - 1);
+      cabac_terminate(t, last);
+      if (f.wpp && !last && cx == wc - 1) cabac_terminate(t, 1);
+      if (t.n > t.cap) return -2000000;
+      buf.resize((size_t)t.n); total += (unsigned long long)t.n;
+      ctu_tok[(size_t)cy * wc + cx] = buf;
+    }
+  if (ntokens) *ntokens = total;
+  std::vector<std::vector<uint8_t>> rows((size_t)nsub);
+  uint8_t ctx[CTX_COUNT], saved[CTX_COUNT];
+  for (int r = 0; r < nsub; r++) {
+    rows[(size_t)r].resize((size_t)f.cw * 64 * 3 * (f.wpp ? 1 : hc));
+    CabacEnc c; c.nbins = 0;
+    cabac_start(c, rows[(size_t)r].data(), (int)rows[(size_t)r].size(), ctx, &tabs);
+    if (r == 0) cabac_init_contexts(ctx, f.is_intra ? 0 : 1, f.qp); else memcpy(ctx, saved, sizeof(saved));
+    for (int cy = f.wpp ? r : 0; cy < (f.wpp ? r + 1 : hc); cy++)
+      for (int cx = 0; cx < wc; cx++) {
+        const std::vector<uint16_t> &tk = ctu_tok[(size_t)cy * wc + cx];
+        cabac_play_tokens(c, tk.data(), (int)tk.size());
+        if (f.wpp && cx == 1) memcpy(saved, ctx, sizeof(saved));
+      }
+    cabac_finish(c);
+    rows[(size_t)r].resize((size_t)c.pos);
+  }
+  StreamParams sp; sp.cw = f.cw; sp.ch = f.ch; sp.width = h->width; sp.height = h->height; sp.qp = f.qp; sp.wpp = f.wpp;
+  sp.deblock = h->deblock; sp.fps_num = h->fps_num; sp.fps_den = h->fps_den;
+  std::vector<uint8_t> au;
+  assemble_access_unit(au, sp, f.is_intra != 0, f.poc, h->write_ps != 0, rows, nsub);
   if ((int)au.size() > cap) return -(int)au.size();
   memcpy(out, au.data(), au.size());
   return (int)au.size();

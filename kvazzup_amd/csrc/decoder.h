@@ -17,13 +17,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <atomic>
+#include <memory>
 #include <vector>
 #include "hevc_core.h"
+#include "host_pool.h"
 #include "enc_kernels.h"
 
 namespace kvzx {
 
-enum DecKernelId { DK_SCATTER = 0, DK_INTER_RECON, DK_INTRA_RECON, DK_DEBLOCK, DK_COUNT };
+// DK_HOST_PARSE is not a kernel: wall time of the host CABAC parsing stage
+enum DecKernelId { DK_SCATTER = 0, DK_INTER_RECON, DK_INTRA_RECON, DK_DEBLOCK, DK_HOST_PARSE, DK_COUNT };
 
 struct DecSps {
   bool valid = false;
@@ -57,6 +61,7 @@ class Decoder {
   bool get_picture(DecodedPicture *out);   // the picture announced by the last decode_nal() == 1
   void set_download(bool on) { download_ = on; }
   void set_profiling(bool on) { profiling_ = on; }
+  void set_parse_threads(int n) { if (!pool_) parse_threads_ = n < 1 ? 1 : n; }
   void get_kernel_times(double *ms, uint64_t *launches, bool reset);
   bool debug_copy(const char *what, void *dst, size_t bytes);
   int last_error() const { return last_error_; }
@@ -66,7 +71,9 @@ class Decoder {
   bool ensure_buffers(int cw, int ch);
   void free_buffers();
   int decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t pts);
+  struct RowState { std::vector<int16_t> levels; std::vector<TuDesc> tus; int rc = 0; };
   int parse_slice_data(const uint8_t *data, size_t len, int slice_qp, bool is_intra, int max_merge);
+  int parse_row(int row, const uint8_t *data, size_t len, int slice_qp, bool is_intra, int max_merge, RowState &rs);
   int run_gpu(bool is_intra, int slice_qp, bool deblock);
 
   int device_; bool started_ = false;
@@ -93,6 +100,13 @@ class Decoder {
   const DecSps *active_sps_ = nullptr;
   int last_error_ = 0;
   std::vector<uint8_t> rbsp_;
+  std::vector<size_t> epb_;                // unescaped payload offset of every removed emulation prevention byte
+  std::vector<size_t> sub_start_;          // start of every WPP substream inside the unescaped slice data
+  std::vector<RowState> rows_;
+  std::vector<uint8_t> wpp_saved_;
+  struct alignas(64) Progress { std::atomic<int> v{0}; char pad[60]; };   // one cache line per row: no false sharing between pollers
+  std::unique_ptr<Progress[]> row_progress_; int row_progress_n_ = 0;
+  std::unique_ptr<OrderedPool> pool_; int parse_threads_ = 16;
   struct EvPair { hipEvent_t a, b; int id; };
   std::vector<EvPair> ev_pool_; size_t ev_used_ = 0;
   double k_ms_[DK_COUNT] = {0}; uint64_t k_n_[DK_COUNT] = {0};

@@ -1,5 +1,7 @@
 // kvazzup_amd/csrc/decoder.hip -- see decoder.h
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "decoder.h"
 
@@ -75,6 +77,7 @@ struct CabacDec {
   size_t bytes_consumed() const { return (pos + 7) >> 3; }
 };
 
+std::atomic<long> g_yields{0};
 CoreTabs g_tabs;
 bool g_tabs_ready = false;
 const CoreTabs *host_tabs()
@@ -276,9 +279,10 @@ int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
   const int nal_type = (data[0] >> 1) & 0x3f, layer = ((data[0] & 1) << 5) | (data[1] >> 3);
   if (layer != 0) return 0;
   rbsp_.assign(len + 16, 0);
+  epb_.clear();
   size_t n = 0; int zeros = 0;
   for (size_t k = 2; k < len; k++) {
-    if (zeros >= 2 && data[k] == 3) { zeros = 0; continue; }
+    if (zeros >= 2 && data[k] == 3) { zeros = 0; epb_.push_back(n); continue; }
     rbsp_[n++] = data[k]; zeros = data[k] == 0 ? zeros + 1 : 0;
   }
   BitReader r(rbsp_.data(), n);
@@ -415,17 +419,37 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   if (slice_qp < 0 || slice_qp > 51) return DEC_ERR_INVALID;
   const bool deblock = !p.deblock_disabled;
   if (p.loop_filter_across_slices && deblock) r.get(1);
+  std::vector<uint32_t> entry;
   if (p.wpp) {
     int nep = r.ue();
-    if (nep > 0) { int bits = r.ue() + 1; if (bits > 32) return DEC_ERR_INVALID; for (int k = 0; k < nep; k++) r.get(bits); }
+    if (nep < 0 || nep > 1024) return DEC_ERR_INVALID;
+    if (nep > 0) { int bits = r.ue() + 1; if (bits > 32) return DEC_ERR_INVALID; for (int k = 0; k < nep; k++) entry.push_back(r.get(bits) + 1); }
+    if (nep != s.height / 64 - 1) return DEC_ERR_UNSUPPORTED;    // one substream per CTU row
   }
   if (!r.get(1)) return DEC_ERR_INVALID;                         // byte_alignment()
   while (r.pos & 7) r.get(1);
   if (r.err) return DEC_ERR_INVALID;
+  // Substream starts inside the unescaped slice data.  entry_point offsets count bytes of the NAL
+  // unit payload INCLUDING emulation prevention bytes (7.4.7.1); epb_[] holds, for every removed
+  // byte, how many unescaped payload bytes preceded it.
+  {
+    const size_t hdr = r.pos >> 3;
+    sub_start_.assign(1, 0);
+    size_t esc = hdr;                                            // escaped offset of the slice data in the payload
+    for (size_t k = 0; k < epb_.size(); k++) if (epb_[k] < hdr) esc++;
+    for (uint32_t e : entry) {
+      esc += e;
+      size_t removed = 0;
+      for (size_t k = 0; k < epb_.size(); k++) if (epb_[k] + k < esc) removed++;     // epb k sits at escaped offset epb_[k] + k
+      sub_start_.push_back(esc - removed - hdr);
+    }
+  }
   if (!ensure_buffers(s.width, s.height)) return DEC_ERR_GPU;
   active_sps_ = &s;
   hf_.is_intra = is_intra; hf_.wpp = p.wpp; hf_.qp = slice_qp;
+  auto t0 = std::chrono::steady_clock::now();
   int rc = parse_slice_data(rbsp + (r.pos >> 3), len - (r.pos >> 3), slice_qp, is_intra, max_merge);
+  if (profiling_) { k_ms_[DK_HOST_PARSE] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); k_n_[DK_HOST_PARSE]++; }
   if (rc < 0) return rc;
   rc = run_gpu(is_intra, slice_qp, deblock);
   if (rc < 0) return rc;
@@ -458,20 +482,40 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
 }
 
 // ------------------------------------------------------------------------------------------ slice data (7.3.8)
-int Decoder::parse_slice_data(const uint8_t *data, size_t len, int slice_qp, bool is_intra, int max_merge)
+// One task per WPP substream (CTU row), run by a pool of host threads.  Row r follows row r-1 at
+// a distance of two CTUs: it starts from the context states saved after the second CTU of the row
+// above and needs that row's CU records up to the above-right CTU.
+int Decoder::parse_row(int row, const uint8_t *data, size_t len, int slice_qp, bool is_intra, int max_merge, RowState &rs)
 {
   const int wc = cw_ / 64, hc = ch_ / 64;
   EncFrame &f = hf_;
   FrameView v; v.f = &f;
-  CabacDec c; uint8_t saved[CTX_COUNT];
-  levels_.clear(); tus_.clear();
-  size_t base = 0;
+  CabacDec c;
+  const bool wpp = f.wpp != 0;
+  const int first_cy = wpp ? row : 0, ncy = wpp ? 1 : hc;
+  int seen_above = 0;                                  // last observed progress of the row above (monotonic)
+  auto wait_above = [&](int cy, int need) {            // CTUs of row cy-1 that must be complete
+    if (!wpp || cy == 0) return true;
+    if (need > wc) need = wc;
+    if (seen_above < need) {
+      std::atomic<int> &p = row_progress_[(size_t)(cy - 1)].v;
+      int spins = 0;
+      while ((seen_above = p.load(std::memory_order_acquire)) < need) {
+        if (++spins < 2000) __builtin_ia32_pause(); else { g_yields.fetch_add(1, std::memory_order_relaxed); std::this_thread::yield(); }
+      }
+    }
+    return seen_above < (1 << 29);                     // >= 1 << 29: that row failed
+  };
   c.start(data, len);
-  cabac_init_contexts(c.ctx, is_intra ? 0 : 1, slice_qp);
+  if (row == 0 || !wpp) cabac_init_contexts(c.ctx, is_intra ? 0 : 1, slice_qp);
+  else {
+    if (!wait_above(row, 2)) return DEC_ERR_INVALID;
+    memcpy(c.ctx, &wpp_saved_[(size_t)(row - 1) * CTX_COUNT], CTX_COUNT);
+  }
   int16_t blk[32 * 32];
-  for (int cy = 0; cy < hc; cy++) {
-    if (cy > 0 && f.wpp) memcpy(c.ctx, saved, sizeof(saved));
+  for (int cy = first_cy; cy < first_cy + ncy; cy++) {
     for (int cx = 0; cx < wc; cx++) {
+      if (!wait_above(cy, cx + 2)) return DEC_ERR_INVALID;
       // coding_quadtree, iteratively in z-order over the 8x8 grid of the CTU
       for (int z = 0; z < 64;) {
         int xi, yi; ctu_z_to_xy(z, xi, yi);
@@ -484,7 +528,6 @@ int Decoder::parse_slice_data(const uint8_t *data, size_t len, int slice_qp, boo
           int a = avail64(cw_, ch_, x0, y0, x0, y0 - 1) && (6 - f.cu_log2[b8idx(f, x0, y0 - 1)]) > depth;
           if (!c.bin(CTX_SPLIT_CU + l + a)) break;
         }
-        // blocks larger than the first level starting at z cannot occur: the loop above stops at the coded size
         if (log2 == 6) return DEC_ERR_UNSUPPORTED;  // 64x64 coding units
         const int n = 1 << log2;
         int skip = 0, intra = is_intra ? 1 : 0, flags = 0, mode = 0, cbf = 0, mvx = 0, mvy = 0;
@@ -539,7 +582,6 @@ int Decoder::parse_slice_data(const uint8_t *data, size_t len, int slice_qp, boo
             root_cbf = c.bin(CTX_RQT_ROOT_CBF) != 0;
           }
         }
-        // the CU record must be visible to its own transform coding (scan choice) and to later CUs
         if (intra || root_cbf) {
           int cb = c.bin(CTX_CBF_CHROMA), cr = c.bin(CTX_CBF_CHROMA);
           int luma = (intra || cb || cr) ? c.bin(CTX_CBF_LUMA + 1) : 1;
@@ -549,9 +591,9 @@ int Decoder::parse_slice_data(const uint8_t *data, size_t len, int slice_qp, boo
             int l2 = ci ? log2 - 1 : log2, nn = 1 << l2;
             if (!parse_residual(c, l2, ci, intra_scan_idx(intra, l2, ci, mode), blk)) return DEC_ERR_INVALID;
             TuDesc td; td.x = (uint16_t)(ci ? x0 >> 1 : x0); td.y = (uint16_t)(ci ? y0 >> 1 : y0); td.plane = (uint8_t)ci; td.log2 = (uint8_t)l2;
-            td.pad = 0; td.offset = (uint32_t)levels_.size();
-            tus_.push_back(td);
-            levels_.insert(levels_.end(), blk, blk + nn * nn);
+            td.pad = 0; td.offset = (uint32_t)rs.levels.size();
+            rs.tus.push_back(td);
+            rs.levels.insert(rs.levels.end(), blk, blk + nn * nn);
           }
         }
         for (int yy = y0; yy < y0 + n; yy += 8)
@@ -564,19 +606,50 @@ int Decoder::parse_slice_data(const uint8_t *data, size_t len, int slice_qp, boo
         if (c.overrun()) return DEC_ERR_INVALID;
         z += 1 << (2 * (log2 - 3));
       }
-      if (f.wpp && cx == 1) memcpy(saved, c.ctx, sizeof(saved));
+      if (wpp && cx == 1) memcpy(&wpp_saved_[(size_t)cy * CTX_COUNT], c.ctx, CTX_COUNT);
+      if (wpp) row_progress_[(size_t)cy].v.store(cx + 1, std::memory_order_release);
       const bool last = (cy == hc - 1 && cx == wc - 1);
       int end = c.terminate();
       if (end != (last ? 1 : 0)) return DEC_ERR_UNSUPPORTED;      // slice must cover the whole picture
-      if (!last && f.wpp && cx == wc - 1) {
-        if (!c.terminate()) return DEC_ERR_INVALID;               // end_of_subset_one_bit
-        base += c.bytes_consumed();
-        if (base >= len) return DEC_ERR_INVALID;
-        uint8_t keep[CTX_COUNT]; memcpy(keep, c.ctx, sizeof(keep));
-        c.start(data + base, len - base);
-        memcpy(c.ctx, keep, sizeof(keep));
-      }
+      if (!last && wpp && cx == wc - 1 && !c.terminate()) return DEC_ERR_INVALID;   // end_of_subset_one_bit
     }
+  }
+  return 0;
+}
+
+int Decoder::parse_slice_data(const uint8_t *data, size_t len, int slice_qp, bool is_intra, int max_merge)
+{
+  const int hc = ch_ / 64, nsub = hf_.wpp ? hc : 1;
+  if ((int)sub_start_.size() != nsub) return DEC_ERR_INVALID;
+  for (int r = 0; r < nsub; r++) if (sub_start_[(size_t)r] >= len) return DEC_ERR_INVALID;
+  rows_.resize((size_t)nsub);
+  for (auto &r : rows_) { r.levels.clear(); r.tus.clear(); r.rc = 0; }
+  wpp_saved_.resize((size_t)hc * CTX_COUNT);
+  if (!row_progress_ || row_progress_n_ < hc) { row_progress_.reset(new Progress[(size_t)hc]); row_progress_n_ = hc; }
+  for (int r = 0; r < hc; r++) row_progress_[(size_t)r].v.store(0, std::memory_order_relaxed);
+  if (!pool_) { const char *e = getenv("KVAZZUP_AMD_PARSE_THREADS"); if (e) parse_threads_ = atoi(e) < 1 ? 1 : atoi(e); pool_.reset(new OrderedPool(parse_threads_)); }
+  static const bool trace = getenv("KVAZZUP_AMD_TRACE") != nullptr;
+  std::vector<double> busy((size_t)nsub, 0.0), t_start((size_t)nsub, 0.0);
+  auto tp0 = std::chrono::steady_clock::now();
+  pool_->run(nsub, [&](int r) {
+    auto ta = std::chrono::steady_clock::now();
+    size_t start = sub_start_[(size_t)r], end = (r + 1 < nsub) ? sub_start_[(size_t)r + 1] : len;
+    int rc = parse_row(r, data + start, end - start, slice_qp, is_intra, max_merge, rows_[(size_t)r]);
+    if (trace) { busy[(size_t)r] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta).count(); t_start[(size_t)r] = std::chrono::duration<double, std::micro>(ta - tp0).count(); }
+    rows_[(size_t)r].rc = rc;
+    if (rc < 0 && hf_.wpp) row_progress_[(size_t)r].v.store(1 << 30, std::memory_order_release);   // release any waiter
+  });
+  if (trace) {
+    double wall = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp0).count(), sum = 0, mx = 0;
+    for (double b : busy) { sum += b; if (b > mx) mx = b; }
+    fprintf(stderr, "[trace] parse: wall %.0f us, rows %d, busy sum %.0f max %.0f, start of last row %.0f us, bytes %zu | row0 %.0f row1 %.0f row8 %.0f yields %ld\n", wall, nsub, sum, mx, t_start[(size_t)nsub - 1], len, busy[0], nsub > 1 ? busy[1] : 0.0, nsub > 8 ? busy[8] : 0.0, (long)g_yields.exchange(0));
+  }
+  levels_.clear(); tus_.clear();
+  for (auto &r : rows_) {
+    if (r.rc < 0) return r.rc;
+    uint32_t base = (uint32_t)levels_.size();
+    for (TuDesc td : r.tus) { td.offset += base; tus_.push_back(td); }
+    levels_.insert(levels_.end(), r.levels.begin(), r.levels.end());
   }
   return 0;
 }

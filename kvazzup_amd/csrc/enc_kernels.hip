@@ -537,17 +537,17 @@ __global__ __launch_bounds__(256) void k_deblock_h(EncFrame f)
 }
 
 // =============================================================================================
-// Entropy coding, parallel half: one wave per CTU turns the CTU's syntax elements into the list
+// Entropy coding, parallel half: one wave per 16x16 block turns its coding unit(s) into the list
 // of CABAC bins in coding order (16-bit tokens, hevc_core.h TokOut).  The wave stages the per-CU
-// records of the CTU and its left / above neighbours in LDS, lane 0 emits the (short) CU headers,
+// records of the block and its left / above neighbours in LDS, lane 0 emits the (short) CU headers,
 // and every transform block is tokenised by all lanes at once: one lane per 4x4 sub-block, whose
 // only cross-sub-block dependency (the greater1 context set) is resolved from a ballot of
 // "has a level > 1".  The serial arithmetic coder runs on host threads (entropy_host.h).
 // =============================================================================================
 struct TileView {
-  const CuRec *tile;                 // [9][9] records: b8 (bx0 + tx, by0 + ty)
+  const CuRec *tile;                 // [3][3] records: b8 (bx0 + tx, by0 + ty): the unit and its left / above neighbours
   int bx0, by0;
-  __device__ CuRec at(int x, int y) const { return tile[((y >> 3) - by0) * 9 + ((x >> 3) - bx0)]; }
+  __device__ CuRec at(int x, int y) const { return tile[((y >> 3) - by0) * 3 + ((x >> 3) - bx0)]; }
 };
 
 __device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d, const int16_t *lv, int stride, int log2, int scan_idx, int lane)
@@ -581,38 +581,51 @@ __device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d
 
 #define TOK_LANE_CAP 128       // tokens one 4x4 sub-block can produce at most (worst case ~108)
 #define TOK_HDR_CAP 96
+#define TOK_ARENA 12800        // tokens one 16x16 unit (at most one 32x32 CU) can produce
 
+// One wave per 16x16 luma block ("unit").  A unit owns the CU that starts at its origin (32x32 or
+// 16x16) or the four 8x8 CUs inside it; units covered by a 32x32 CU that starts elsewhere emit
+// nothing.  The unit's tokens are built in LDS, then appended to the CTU's slot at an offset
+// reserved with one atomicAdd; k_tok_compact restores z-order from the (offset, length) segments.
 __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
 {
-  __shared__ CuRec tile[81];
+  __shared__ CuRec tile[9];
   __shared__ __attribute__((aligned(16))) TuDigest dg;
   __shared__ CoreTabs tabs;
   __shared__ uint16_t hdr[TOK_HDR_CAP];
   __shared__ uint16_t ltok[64][TOK_LANE_CAP];
+  __shared__ uint16_t arena[TOK_ARENA];
   __shared__ int hdr_n;
-  const int cx = blockIdx.x, cy = blockIdx.y, lane = threadIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
-  const int ctu = cy * wc + cx;
-  uint16_t *out = f.tok_buf + (size_t)ctu * f.tok_cap;
-  int ntok = 0;                                        // wave-uniform running count
+  __shared__ uint32_t slot_off;
+  const int ux = blockIdx.x, uy = blockIdx.y, lane = threadIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
+  const int cx = ux >> 2, cy = uy >> 2, ctu = cy * wc + cx;
+  const int X0 = ux * 16, Y0 = uy * 16;
+  int z4 = 0;                                          // z-order index of the unit inside its CTU
+  for (int b = 0; b < 2; b++) z4 |= (((ux & 3) >> b) & 1) << (2 * b) | (((uy & 3) >> b) & 1) << (2 * b + 1);
+  int ntok = 0;                                        // wave-uniform count of tokens in the arena
   core_tabs_fill_entry(tabs, lane);
-  const int bx0 = cx * 8 - 1, by0 = cy * 8 - 1;
-  for (int i = lane; i < 81; i += 64) {
-    int bx = bx0 + i % 9, by = by0 + i / 9;
+  const int bx0 = ux * 2 - 1, by0 = uy * 2 - 1;
+  if (lane < 9) {
+    int bx = bx0 + lane % 3, by = by0 + lane / 3;
     CuRec r; r.log2 = 0; r.intra = 0; r.flags = 0; r.merge_idx = 0; r.mvp_idx = 0; r.intra_mode = 0; r.cbf = 0; r.pad = 0; r.mvdx = 0; r.mvdy = 0;
-    if (bx >= 0 && by >= 0 && bx < f.b8w) {
+    if (bx >= 0 && by >= 0) {
       int g = by * f.b8w + bx;
       r.log2 = f.cu_log2[g]; r.intra = f.cu_intra[g]; r.flags = f.cu_flags[g]; r.merge_idx = f.cu_merge_idx[g];
       r.mvp_idx = f.cu_mvp_idx[g]; r.intra_mode = f.cu_intra_mode[g]; r.cbf = f.cu_cbf[g];
       r.mvdx = f.cu_mvd[g * 2]; r.mvdy = f.cu_mvd[g * 2 + 1];
     }
-    tile[i] = r;
+    tile[lane] = r;
   }
   __syncthreads();
   TileView v; v.tile = tile; v.bx0 = bx0; v.by0 = by0;
-  for (int z = 0; z < 64;) {
-    int xi, yi; ctu_z_to_xy(z, xi, yi);
-    const int x0 = cx * 64 + xi * 8, y0 = cy * 64 + yi * 8;
+  const int cl0 = v.at(X0, Y0).log2;
+  const bool owner = !(cl0 == 5 && ((X0 | Y0) & 31));
+  const int ncu = owner ? (cl0 == 3 ? 4 : 1) : 0;
+  for (int k = 0; k < ncu; k++) {
+    const int x0 = X0 + ((cl0 == 3) ? (k & 1) * 8 : 0), y0 = Y0 + ((cl0 == 3) ? (k >> 1) * 8 : 0);
     const CuRec cu = v.at(x0, y0);
+    int z = 0;                                         // z-order index (8x8 units) of the CU origin inside the CTU
+    for (int b = 0; b < 3; b++) z |= ((((x0 & 63) >> 3) >> b) & 1) << (2 * b) | ((((y0 & 63) >> 3) >> b) & 1) << (2 * b + 1);
     if (lane == 0) {
       TokOut t; t.tabs = &tabs; t.p = hdr; t.n = 0; t.cap = TOK_HDR_CAP;
       enc_split_flags(v, t, f.cw, f.ch, x0, y0, z, cu.log2);
@@ -620,7 +633,7 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
       hdr_n = t.n;
     }
     __syncthreads();
-    { const int n = hdr_n; for (int i = lane; i < n; i += 64) if (ntok + i < f.tok_cap) out[ntok + i] = hdr[i]; ntok += n; }
+    { const int n = hdr_n; for (int i = lane; i < n; i += 64) if (ntok + i < TOK_ARENA) arena[ntok + i] = hdr[i]; ntok += n; }
     const int cbf = (cu.flags & CU_SKIP) ? 0 : cu.cbf;          // wave-uniform
     for (int ci = 0; ci < 3; ci++) {
       if (!((cbf >> ci) & 1)) continue;
@@ -651,50 +664,67 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
         if (n_l > TOK_LANE_CAP) { atomicOr(f.err, 8u); n_l = TOK_LANE_CAP; }
       }
       __syncthreads();
-      { const int n = hdr_n; for (int i = lane; i < n; i += 64) if (ntok + i < f.tok_cap) out[ntok + i] = hdr[i]; ntok += n; }
+      { const int n = hdr_n; for (int i = lane; i < n; i += 64) if (ntok + i < TOK_ARENA) arena[ntok + i] = hdr[i]; ntok += n; }
       // offsets in coding order: sub-block last_sb first, then downwards
       int suffix = n_l;
       for (int o = 1; o < 64; o <<= 1) { int other = __shfl_down(suffix, o); if (lane + o < 64) suffix += other; }
       const int total = __shfl(suffix, 0);
       const int off = suffix - n_l;                                 // tokens of all sub-blocks with a higher index
-      for (int i = 0; i < n_l; i++) if (ntok + off + i < f.tok_cap) out[ntok + off + i] = ltok[lane][i];
+      for (int i = 0; i < n_l; i++) if (ntok + off + i < TOK_ARENA) arena[ntok + off + i] = ltok[lane][i];
       ntok += total;
       __syncthreads();
     }
-    z += 1 << (2 * (cu.log2 - 3));
   }
-  if (lane == 0) {
+  if (z4 == 15) {                                      // the last unit of the CTU closes it
     const bool last = (cy == hc - 1 && cx == wc - 1);
-    if (ntok < f.tok_cap) out[ntok] = (uint16_t)(0xC000u | (last ? 1u : 0u));          // end_of_slice_segment_flag
-    ntok++;
-    if (f.wpp && !last && cx == wc - 1) { if (ntok < f.tok_cap) out[ntok] = 0xC001u; ntok++; }   // end_of_subset_one_bit
-    if (ntok > f.tok_cap) { atomicOr(f.err, 16u); ntok = f.tok_cap; }
-    f.tok_count[ctu] = ntok;
+    if (lane == 0) {
+      if (ntok < TOK_ARENA) arena[ntok] = (uint16_t)(0xC000u | (last ? 1u : 0u));     // end_of_slice_segment_flag
+      if (f.wpp && !last && cx == wc - 1 && ntok + 1 < TOK_ARENA) arena[ntok + 1] = 0xC001u;   // end_of_subset_one_bit
+    }
+    ntok += 1 + ((f.wpp && !last && cx == wc - 1) ? 1 : 0);
   }
+  if (ntok > TOK_ARENA) { if (lane == 0) atomicOr(f.err, 16u); ntok = TOK_ARENA; }
+  __syncthreads();
+  if (lane == 0) {
+    uint32_t o = ntok ? atomicAdd(&f.tok_cursor[ctu], (uint32_t)ntok) : 0u;
+    if (o + (uint32_t)ntok > (uint32_t)f.tok_cap) { atomicOr(f.err, 16u); o = 0; ntok = 0; }
+    slot_off = o;
+    f.tok_seg[(ctu * 16 + z4) * 2] = o; f.tok_seg[(ctu * 16 + z4) * 2 + 1] = (uint32_t)ntok;
+  }
+  __syncthreads();
+  const int n = (int)f.tok_seg[(ctu * 16 + z4) * 2 + 1];       // written by lane 0 above (zero on overflow)
+  uint16_t *out = f.tok_buf + (size_t)ctu * f.tok_cap + slot_off;
+  if (slot_off + (uint32_t)n <= (uint32_t)f.tok_cap) for (int i = lane; i < n; i += 64) out[i] = arena[i];
 }
 
-// exclusive prefix sum of the per-CTU token counts (single workgroup), then a dense copy
+// exclusive prefix sum of the per-CTU token counts (single workgroup), then a dense copy in z-order
 __global__ __launch_bounds__(256) void k_tok_scan(EncFrame f, int nctu)
 {
   __shared__ uint32_t part[256];
   const int tid = threadIdx.x, per = (nctu + 255) / 256, lo = tid * per, hi = min(nctu, lo + per);
   uint32_t s = 0;
-  for (int i = lo; i < hi; i++) s += (uint32_t)f.tok_count[i];
+  for (int i = lo; i < hi; i++) s += f.tok_cursor[i];
   part[tid] = s;
   __syncthreads();
   if (tid == 0) { uint32_t a = 0; for (int i = 0; i < 256; i++) { uint32_t t = part[i]; part[i] = a; a += t; } f.tok_off[nctu] = a; }
   __syncthreads();
   uint32_t a = part[tid];
-  for (int i = lo; i < hi; i++) { f.tok_off[i] = a; a += (uint32_t)f.tok_count[i]; }
+  for (int i = lo; i < hi; i++) { f.tok_off[i] = a; a += f.tok_cursor[i]; }
 }
 __global__ __launch_bounds__(256) void k_tok_compact(EncFrame f)
 {
-  const int ctu = blockIdx.x, n = f.tok_count[ctu];
-  const uint16_t *src = f.tok_buf + (size_t)ctu * f.tok_cap;
-  uint16_t *dst = f.tok_dense + f.tok_off[ctu];
-  if (f.tok_off[ctu] + (uint32_t)n > f.tok_dense_cap) { if (threadIdx.x == 0) { atomicOr(f.err, 32u); f.tok_count_out[ctu] = 0; } return; }
-  for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
-  if (threadIdx.x == 0) f.tok_count_out[ctu] = n;
+  const int ctu = blockIdx.x;
+  const uint32_t n = f.tok_cursor[ctu], base = f.tok_off[ctu];
+  if (base + n > f.tok_dense_cap) { if (threadIdx.x == 0) { atomicOr(f.err, 32u); f.tok_count_out[ctu] = 0; } return; }
+  const uint16_t *slot = f.tok_buf + (size_t)ctu * f.tok_cap;
+  uint16_t *dst = f.tok_dense + base;
+  uint32_t run = 0;
+  for (int u = 0; u < 16; u++) {
+    const uint32_t so = f.tok_seg[(ctu * 16 + u) * 2], sl = f.tok_seg[(ctu * 16 + u) * 2 + 1];
+    for (uint32_t i = threadIdx.x; i < sl; i += 256) dst[run + i] = slot[so + i];
+    run += sl;
+  }
+  if (threadIdx.x == 0) f.tok_count_out[ctu] = (int32_t)n;
 }
 
 // =============================================================================================
@@ -756,7 +786,8 @@ void launch_deblock(const EncFrame &f, hipStream_t st)
 void launch_tokenize(const EncFrame &f, hipStream_t st)
 {
   const int wc = f.cw / 64, hc = f.ch / 64;
-  hipLaunchKernelGGL(k_tokenize, dim3(wc, hc), dim3(64), 0, st, f);
+  hipMemsetAsync(f.tok_cursor, 0, sizeof(uint32_t) * (size_t)(wc * hc), st);
+  hipLaunchKernelGGL(k_tokenize, dim3(f.cw / 16, f.ch / 16), dim3(64), 0, st, f);
   hipLaunchKernelGGL(k_tok_scan, dim3(1), dim3(256), 0, st, f, wc * hc);
   hipLaunchKernelGGL(k_tok_compact, dim3(wc * hc), dim3(256), 0, st, f);
 }

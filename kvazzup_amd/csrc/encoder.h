@@ -74,7 +74,7 @@ class Encoder {
   uint8_t *cu_bytes_ = nullptr;          // 7 byte arrays back to back
   int16_t *cu_mv_ = nullptr, *cu_mvd_ = nullptr;
   uint8_t *intra_scratch_ = nullptr;
-  uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_off_ = nullptr;
+  uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; uint32_t *tok_off_ = nullptr;
   uint16_t *h_tok_dense_ = nullptr; size_t tok_dense_cap_ = 0; int32_t *h_tok_count_ = nullptr;   // host-mapped pinned
   uint32_t *sync_ = nullptr; uint32_t *err_ = nullptr; uint32_t *h_err_ = nullptr;
   EntropyHost *entropy_ = nullptr;

@@ -54,7 +54,8 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   const int nctu = (cw_ / 64) * rows_;
   tok_cap_ = 49152;                                // tokens per CTU slot (worst case of a 64x64 CTU is ~43k)
   HIP_OK(hipMalloc(&tok_buf_, (size_t)nctu * tok_cap_ * sizeof(uint16_t)));
-  HIP_OK(hipMalloc(&tok_count_, sizeof(int32_t) * nctu));
+  HIP_OK(hipMalloc(&tok_count_, sizeof(uint32_t) * nctu));
+  HIP_OK(hipMalloc(&tok_seg_, sizeof(uint32_t) * nctu * 32));
   HIP_OK(hipMalloc(&tok_off_, sizeof(uint32_t) * (nctu + 1)));
   tok_dense_cap_ = (size_t)nctu * tok_cap_;
   if (tok_dense_cap_ > ((size_t)1 << 27)) tok_dense_cap_ = (size_t)1 << 27;
@@ -76,7 +77,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   uint8_t *p = intra_scratch_;
   f_.ic8 = (uint32_t *)p; p += nb8 * 4; f_.ic16 = (uint32_t *)p; p += nb8; f_.ic32 = (uint32_t *)p; p += nb8 / 4;
   f_.im8 = p; p += nb8; f_.im16 = p; p += nb8 / 4; f_.im32 = p;
-  f_.tok_buf = tok_buf_; f_.tok_cap = tok_cap_; f_.tok_count = tok_count_; f_.tok_off = tok_off_;
+  f_.tok_buf = tok_buf_; f_.tok_cap = tok_cap_; f_.tok_cursor = (uint32_t *)tok_count_; f_.tok_seg = tok_seg_; f_.tok_off = tok_off_;
   void *dp = nullptr;
   HIP_OK(hipHostGetDevicePointer(&dp, h_tok_dense_, 0)); f_.tok_dense = (uint16_t *)dp; f_.tok_dense_cap = (uint32_t)tok_dense_cap_;
   HIP_OK(hipHostGetDevicePointer(&dp, h_tok_count_, 0)); f_.tok_count_out = (int32_t *)dp;
@@ -97,7 +98,7 @@ Encoder::~Encoder()
   for (int c = 0; c < 3; c++) { hipFree(src_[c]); hipFree(rec_[0][c]); hipFree(rec_[1][c]); hipFree(coef_[c]); }
   hipFree(cu_bytes_); hipFree(cu_mv_); hipFree(cu_mvd_); hipFree(intra_scratch_);
   delete entropy_;
-  hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_off_); hipFree(sync_); hipFree(err_);
+  hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(tok_off_); hipFree(sync_); hipFree(err_);
   hipHostFree(h_tok_dense_); hipHostFree(h_tok_count_); hipHostFree(h_err_);
   if (stream_) hipStreamDestroy(stream_);
 }

@@ -12,37 +12,21 @@
 #include <atomic>
 #include <cstring>
 #include <memory>
-#include <condition_variable>
-#include <mutex>
 #include <thread>
 #include <vector>
 #include "hevc_core.h"
+#include "host_pool.h"
 
 namespace kvzx {
 
 class EntropyHost {
  public:
-  explicit EntropyHost(int max_threads)
-  {
-    int hw = (int)std::thread::hardware_concurrency();
-    nthreads_ = max_threads;
-    if (hw > 0 && nthreads_ > hw) nthreads_ = hw;
-    if (nthreads_ < 1) nthreads_ = 1;
-    for (int i = 0; i < 64; i++) core_tabs_fill_entry(tabs_, i);
-    for (int i = 0; i < nthreads_; i++) workers_.emplace_back([this] { worker(); });
-  }
-  ~EntropyHost()
-  {
-    { std::lock_guard<std::mutex> l(m_); quit_ = true; gen_++; }
-    cv_.notify_all();
-    for (auto &t : workers_) t.join();
-  }
+  explicit EntropyHost(int max_threads) : pool_(max_threads) { for (int i = 0; i < 64; i++) core_tabs_fill_entry(tabs_, i); }
   // Codes one picture.  tokens: dense token array, CTU after CTU in raster order; count[ctu] tokens each.
   // rows_out[r] receives the bytes of substream r (one per CTU row with WPP, else a single one).
   void code_picture(const uint16_t *tokens, const int32_t *count, int wc, int hc, bool wpp, int init_type, int qp,
                     std::vector<std::vector<uint8_t>> &rows_out, uint64_t *bins)
   {
-    while (active_.load(std::memory_order_acquire) != 0) std::this_thread::yield();   // stragglers of the previous picture
     tokens_ = tokens; count_ = count; wc_ = wc; hc_ = hc; wpp_ = wpp; init_type_ = init_type; qp_ = qp;
     const int nsub = wpp ? hc : 1;
     rows_out.resize((size_t)nsub);
@@ -55,36 +39,11 @@ class EntropyHost {
     ready_.reset(new std::atomic<int>[(size_t)hc]);
     for (int r = 0; r < hc; r++) ready_[(size_t)r].store(0, std::memory_order_relaxed);
     bins_.store(0);
-    done_rows_.store(0);
-    total_rows_ = nsub;
-    next_row_.store(0, std::memory_order_release);
-    { std::lock_guard<std::mutex> l(m_); gen_++; }
-    cv_.notify_all();
-    run_rows();                                   // the calling thread helps
-    std::unique_lock<std::mutex> l(m_);
-    done_cv_.wait(l, [this] { return done_rows_.load() == total_rows_; });
+    pool_.run(nsub, [this](int r) { code_row(r); });
     if (bins) *bins = bins_.load();
   }
 
  private:
-  void worker()
-  {
-    uint64_t seen = 0;
-    for (;;) {
-      { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return gen_ != seen; }); seen = gen_; if (quit_) return; }
-      run_rows();
-    }
-  }
-  void run_rows()
-  {
-    active_.fetch_add(1, std::memory_order_acq_rel);
-    for (;;) {
-      int r = next_row_.fetch_add(1, std::memory_order_acq_rel);
-      if (r >= total_rows_) { active_.fetch_sub(1, std::memory_order_acq_rel); return; }
-      code_row(r);
-      if (done_rows_.fetch_add(1) + 1 == total_rows_) { std::lock_guard<std::mutex> l(m_); done_cv_.notify_all(); }
-    }
-  }
   void code_row(int r)
   {
     uint8_t ctx[CTX_COUNT];
@@ -114,18 +73,14 @@ class EntropyHost {
     bins_.fetch_add(c.nbins);
   }
 
-  int nthreads_;
-  std::vector<std::thread> workers_;
-  std::mutex m_; std::condition_variable cv_, done_cv_;
-  uint64_t gen_ = 0; bool quit_ = false;
+  OrderedPool pool_;
   CoreTabs tabs_;
   const uint16_t *tokens_ = nullptr; const int32_t *count_ = nullptr;
-  int wc_ = 0, hc_ = 0, init_type_ = 0, qp_ = 0; std::atomic<int> total_rows_{0}; bool wpp_ = true;
+  int wc_ = 0, hc_ = 0, init_type_ = 0, qp_ = 0; bool wpp_ = true;
   std::vector<size_t> offsets_;
   std::vector<uint8_t> saved_;
   std::unique_ptr<std::atomic<int>[]> ready_;
   std::vector<std::vector<uint8_t>> *rows_ = nullptr;
-  std::atomic<int> next_row_{1 << 30}, done_rows_{0}, active_{0};
   std::atomic<uint64_t> bins_{0};
 };
 

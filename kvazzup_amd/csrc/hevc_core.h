@@ -39,10 +39,11 @@ struct EncFrame {
   int16_t *cu_mv, *cu_mvd;      // [b8][2]
   // intra analysis scratch
   uint8_t *im8, *im16, *im32; uint32_t *ic8, *ic16, *ic32;
-  // entropy coding, GPU half: per-CTU token lists (tok_cap tokens each), their counts, the
-  // exclusive prefix sum of the counts and the dense copy the host arithmetic coder reads
+  // entropy coding, GPU half: per-CTU token slots (tok_cap tokens each) filled by 16 units per CTU
+  // (tok_cursor: tokens used per slot, tok_seg: [ctu][unit] {offset, length}), the exclusive
+  // prefix sum of the per-CTU counts and the dense z-ordered copy the host arithmetic coder reads
   // (tok_dense / tok_count_out live in host-mapped pinned memory)
-  uint16_t *tok_buf; int tok_cap; int32_t *tok_count; uint32_t *tok_off;
+  uint16_t *tok_buf; int tok_cap; uint32_t *tok_cursor; uint32_t *tok_seg; uint32_t *tok_off;
   uint16_t *tok_dense; uint32_t tok_dense_cap; int32_t *tok_count_out;
   uint32_t *sync;               // [rows] progress counters (intra reconstruction wavefront)
   uint32_t *err;                // device-side error flags
@@ -56,9 +57,10 @@ KVZ_HD int b8idx(const EncFrame &f, int x, int y) { return (y >> 3) * f.b8w + (x
 KVZ_HD uint32_t zaddr64(int x, int y, int w_ctbs)
 {
   uint32_t ctb = (uint32_t)((y >> 6) * w_ctbs + (x >> 6));
-  uint32_t xi = (uint32_t)(x & 63) >> 2, yi = (uint32_t)(y & 63) >> 2, z = 0;
-  for (int b = 0; b < 4; b++) z |= ((xi >> b) & 1u) << (2 * b) | ((yi >> b) & 1u) << (2 * b + 1);
-  return (ctb << 8) | z;
+  uint32_t xi = (uint32_t)(x & 63) >> 2, yi = (uint32_t)(y & 63) >> 2;
+  xi = (xi | (xi << 2)) & 0x33u; xi = (xi | (xi << 1)) & 0x55u;      // spread the 4 bits of each coordinate
+  yi = (yi | (yi << 2)) & 0x33u; yi = (yi | (yi << 1)) & 0x55u;
+  return (ctb << 8) | xi | (yi << 1);
 }
 // H.265 6.4.1 for one slice, one tile
 KVZ_HD bool avail64(int cw, int ch, int xc, int yc, int xn, int yn)

@@ -1,0 +1,70 @@
+// kvazzup_amd/csrc/host_pool.h -- a small persistent pool of host threads that hands out the
+// tasks of one job in increasing index order (task r may wait for task r-1, which is therefore
+// always already running: the CTU-row wavefront of WPP, H.265 9.3.2.2).  Used by the host halves
+// of entropy coding (entropy_host.h) and entropy decoding (decoder.hip).
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace kvzx {
+
+class OrderedPool {
+ public:
+  explicit OrderedPool(int threads)
+  {
+    int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && threads > hw) threads = hw;
+    if (threads < 1) threads = 1;
+    for (int i = 0; i + 1 < threads; i++) workers_.emplace_back([this] { worker(); });   // the caller is the last worker
+  }
+  ~OrderedPool()
+  {
+    { std::lock_guard<std::mutex> l(m_); quit_ = true; gen_++; }
+    cv_.notify_all();
+    for (auto &t : workers_) t.join();
+  }
+  // Runs fn(0) .. fn(n - 1); returns when all have finished.
+  void run(int n, const std::function<void(int)> &fn)
+  {
+    while (active_.load(std::memory_order_acquire) != 0) std::this_thread::yield();   // stragglers of the previous job
+    fn_ = &fn;
+    done_.store(0, std::memory_order_relaxed);
+    total_.store(n, std::memory_order_relaxed);
+    next_.store(0, std::memory_order_release);
+    if (n > 1 && !workers_.empty()) { { std::lock_guard<std::mutex> l(m_); gen_++; } cv_.notify_all(); }
+    drain();
+    while (done_.load(std::memory_order_acquire) != n) std::this_thread::yield();
+  }
+
+ private:
+  void worker()
+  {
+    uint64_t seen = 0;
+    for (;;) {
+      { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return gen_ != seen; }); seen = gen_; if (quit_) return; }
+      drain();
+    }
+  }
+  void drain()
+  {
+    active_.fetch_add(1, std::memory_order_acq_rel);
+    for (;;) {
+      int r = next_.fetch_add(1, std::memory_order_acq_rel);
+      if (r >= total_.load(std::memory_order_acquire)) break;
+      (*fn_)(r);
+      done_.fetch_add(1, std::memory_order_acq_rel);
+    }
+    active_.fetch_sub(1, std::memory_order_acq_rel);
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_; std::condition_variable cv_;
+  uint64_t gen_ = 0; bool quit_ = false;
+  const std::function<void(int)> *fn_ = nullptr;
+  std::atomic<int> next_{1 << 30}, total_{0}, done_{0}, active_{0};
+};
+
+}  // namespace kvzx

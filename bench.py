@@ -2,8 +2,11 @@
 """bench.py -- BASELINE.json metric: HEVC encode+decode fps on synthetic YUV420 (uvgx-synth-v1).
 
 A "step" is one picture through the hot path: kvz_api-side encode (HIP kernels; input picture
-already resident in HBM) followed by libOpenHevc-side decode of the access unit just produced
-(host CABAC parse + HIP reconstruction, output left in HBM).  N > 1 runs one independent stream
+already resident in HBM) and libOpenHevc-side decode of the access unit it produced (host CABAC
+parse + HIP reconstruction, output left in HBM).  The two codecs sit in the C++ mirrors of
+uvgComm's KvazaarFilter and OpenHEVCFilter, each on its own thread as in the reference's filter
+graph, so picture t+1 is encoded while picture t is decoded; the timed region starts with the first
+push and ends when the last decoded picture has left the decoder.  N > 1 runs one independent stream
 per GPU (BASELINE configs[3]: multi-party call, no collective on the data path), weak scaling.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description / DESIGN.md section 6).
@@ -93,7 +96,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from kvazzup_amd import synth
-    from kvazzup_amd.codec import Decoder, Encoder
+    from kvazzup_amd import _native as N
+    from kvazzup_amd.pipeline import Pipeline
+    import ctypes as C
 
     wl = WORKLOADS[args.workload]
     w, h = wl["w"], wl["h"]
@@ -103,30 +108,47 @@ def main():
     clip = [synth.frame_torch(synth.MOVING, seed, w, h, t, dev) for t in range(total)]
     torch.cuda.synchronize()
 
-    enc = Encoder(w, h, options=(("qp", 32), ("period", 64), ("vps-period", 1), ("me-range", args.me_range), ("gpu", local_rank)))
-    dec = Decoder(download=False, device=local_rank)
-    cw, ch = enc.coded_size()
+    # source -> KvazaarFilter -> WireAdapter -> OpenHEVCFilter -> sink, one thread per filter (csrc/filters.hip)
+    pl = Pipeline(w, h, settings={"video/QP": 32, "video/Intra": 64, "video/VPS": 1, "uvgx/gpu": local_rank, "uvgx/decoderDownload": 0},
+                  custom=(("me-range", args.me_range), ("gpu", local_rank)), loopback=True, keep_outputs=False)
+    lib = pl.lib
+    enc_h, dec_h = pl.encoder_handle(), pl.decoder_handle()
+    cw, ch = C.c_int(), C.c_int()
+    lib.kvzx_encoder_coded_size(enc_h, C.byref(cw), C.byref(ch))
+    cw, ch = cw.value, ch.value
 
-    def step(t):
-        au = enc.encode_device(clip[t].data_ptr())
-        pics = dec.decode_au(au, t)
-        if len(pics) != 1:
-            raise RuntimeError("decoder returned %d pictures for one access unit" % len(pics))
-        return len(au)
+    def run(first, count):
+        """push pictures first .. first+count-1, at most 6 in flight (a filter drops inputs when its buffer overflows)"""
+        for g in range(first, first + count):
+            if g >= 6 and not pl.wait(g - 5, 20000):
+                raise RuntimeError("pipeline stalled at picture %d" % g)
+            pl.push_device(clip[g].data_ptr())
+        if not pl.wait(first + count, 120000):
+            raise RuntimeError("pipeline did not deliver %d pictures" % (first + count))
 
-    for t in range(args.warmup):
-        step(t)
-    enc.set_profiling(True)
-    dec.set_profiling(True)
-    enc.kernel_times(reset=True)
-    dec.kernel_times(reset=True)
+    def times(reset):
+        ms = (C.c_double * 16)()
+        n = (C.c_uint64 * 16)()
+        out = {}
+        k = lib.kvzx_encoder_kernel_times(enc_h, ms, n, int(reset))
+        for i in range(k):
+            out[lib.kvzx_encoder_kernel_name(i).decode()] = (ms[i], n[i])
+        k = lib.kvzx_decoder_kernel_times(dec_h, ms, n, int(reset))
+        for i in range(k):
+            name = lib.kvzx_decoder_kernel_name(i).decode()
+            a = out.get(name, (0.0, 0))
+            out[name] = (a[0] + ms[i], a[1] + n[i])
+        return out
+
+    run(0, args.warmup)
+    lib.kvzx_encoder_set_profiling(enc_h, 1)
+    lib.kvzx_decoder_set_profiling(dec_h, 1)
+    times(True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    nbytes = 0
-    for t in range(args.warmup, total):
-        nbytes += step(t)
+    run(args.warmup, args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -135,18 +157,16 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-
-    kt = dict(enc.kernel_times(reset=False))
-    kt.update({k: v for k, v in dec.kernel_times(reset=False).items() if k != "k_deblock"})
-    kd = dec.kernel_times(reset=False).get("k_deblock", (0.0, 0))
-    if "k_deblock" in kt:
-        kt["k_deblock"] = (kt["k_deblock"][0] + kd[0], kt["k_deblock"][1] + kd[1])
-    enc.close()
-    dec.close()
+    kt = times(False)
+    st = pl.stats()
+    nbytes = st["encoded_bytes"] * args.steps / max(1, st["encoded_pictures"])
+    if st["decoded_pictures"] != total or st["dropped"]:
+        raise RuntimeError("pipeline lost pictures: %r" % (st,))
+    pl.close()
 
     if rank == 0:
         fps = world * args.steps / elapsed
-        dom = max((k for k in kt if kt[k][1] > 0), key=lambda k: kt[k][0])
+        dom = max((k for k in kt if kt[k][1] > 0 and k.startswith("k_")), key=lambda k: kt[k][0])
         avg_s = kt[dom][0] / kt[dom][1] / 1e3
         ab = algorithmic_bytes(dom, cw, ch, args.me_range)
         achieved = ab / avg_s / 1e9

@@ -58,6 +58,23 @@ KVZ_PUBLIC int kvzx_decoder_kernel_times(OpenHevc_Handle h, double *ms, uint64_t
 KVZ_PUBLIC const char *kvzx_decoder_kernel_name(int id);
 KVZ_PUBLIC int kvzx_decoder_debug_copy(OpenHevc_Handle h, const char *what, void *dst, size_t bytes);
 
+/* ---- filter-graph harness (kvazzup_amd/csrc/filters.h): KvazaarFilter -> [WireAdapter -> OpenHEVCFilter] ----
+ * A Qt-free restatement of the two uvgComm filters on this path, each on its own thread with the
+ * reference's input-buffer contract (src/media/processing/filter.cpp:151-222,364-417), driven through the
+ * two ABIs above.  settings_text: "key=value" lines, key names of src/settingskeys.h:36-67 ("video/QP",
+ * "video/Intra", "video/ResolutionWidth" ...) plus "uvgx/gpu", "uvgx/decoderDownload", "parameters/<i>/Name|Value". */
+KVZ_PUBLIC void *uvgx_pipeline_create(const char *settings_text, int loopback_decode, int keep_outputs);
+KVZ_PUBLIC int uvgx_pipeline_push_host(void *p, const uint8_t *i420, int w, int h, int fps_num, int fps_den, int64_t pts);
+KVZ_PUBLIC int uvgx_pipeline_push_device(void *p, const void *d_i420, int w, int h, int fps_num, int fps_den, int64_t pts);
+KVZ_PUBLIC int uvgx_pipeline_wait(void *p, uint64_t n_outputs, int timeout_ms);
+KVZ_PUBLIC uint32_t uvgx_pipeline_encoder_backlog(void *p);
+KVZ_PUBLIC int uvgx_pipeline_pop_encoded(void *p, uint8_t *buf, uint32_t cap, uint32_t *size, int64_t *pts);
+KVZ_PUBLIC int uvgx_pipeline_pop_decoded(void *p, uint8_t *buf, uint32_t cap, uint32_t *size, int *w, int *h, int64_t *pts);
+KVZ_PUBLIC void uvgx_pipeline_stats(void *p, uint64_t *out8);
+KVZ_PUBLIC void *uvgx_pipeline_encoder(void *p);     /* kvz_encoder* of the KvazaarFilter */
+KVZ_PUBLIC void *uvgx_pipeline_decoder(void *p);     /* OpenHevc_Handle of the OpenHEVCFilter (NULL without loop-back) */
+KVZ_PUBLIC void uvgx_pipeline_destroy(void *p);
+
 #ifdef __cplusplus
 }
 #endif

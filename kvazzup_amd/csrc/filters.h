@@ -1,0 +1,179 @@
+// kvazzup_amd/csrc/filters.h -- Qt-free C++ mirror of the part of uvgComm's filter graph that sits
+// on the hot path: the Filter runtime contract (one thread per filter, bounded input deque with the
+// HEVC-aware overflow drop, fan-out with deep copies) and the two filters that call the codecs.
+//
+//   uvgx::Data / VideoInfo / DataType   <- /root/reference/src/media/processing/filter.h:27-92
+//   uvgx::Filter                         <- filter.h:97-261, filter.cpp:151-222 (putInput), :297-306 (getInput),
+//                                           :364-417 (sendOutput), :425-443 (run), :516-532 (isHEVCIntra/Inter)
+//   uvgx::KvazaarFilter                  <- kvazaarfilter.cpp:122-311 (init), :374-450 (feedInput), :453-495
+//   uvgx::OpenHEVCFilter                 <- openhevcfilter.cpp:28-74 (init), :103-189 (process), :192-239
+//   uvgx::WireAdapter                    <- uvgrtpsender.cpp:104-117 + uvgrtpreceiver.cpp:54-116 (row f2 of
+//                                           whole AU out, one NAL with 4-byte start code in)
+// The filters talk to the codecs only through include/kvazaar.h and include/openHevcWrapper.h, exactly
+// like the reference; QSettings("uvgComm.ini") is replaced by a string map with the same key names
+// (src/settingskeys.h:36-67).
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include <stdint.h>
+#include "../../include/kvazzup_amd.h"
+
+namespace uvgx {
+
+enum DataType { DT_NONE = 0, DT_YUV420VIDEO = 1, DT_RGB32VIDEO = (1 << 10), DT_HEVCVIDEO = (1 << 14) };
+enum DataSource { DS_UNKNOWN, DS_LOCAL, DS_REMOTE };
+enum HEVC_NAL_UNIT_TYPE { TRAIL_R = 1, IDR_W_RADL = 19, VPS_NUT = 32, SPS_NUT = 33, PPS_NUT = 34 };
+
+struct RoiMap { int width = 0, height = 0; std::unique_ptr<int8_t[]> data; };
+
+struct VideoInfo {
+  int16_t width = 0, height = 0;
+  int32_t framerateNumerator = 0, framerateDenominator = 0;
+  bool flippedVertically = false, flippedHorizontally = false;
+  RoiMap roi;
+};
+
+struct Data {
+  DataSource source = DS_UNKNOWN;
+  DataType type = DT_NONE;
+  std::unique_ptr<uint8_t[]> data;
+  uint32_t data_size = 0;
+  int64_t creationTimestamp = -1, presentationTimestamp = -1;
+  std::unique_ptr<VideoInfo> vInfo;
+  // extension (not in the reference): picture already resident in HBM (packed I420); data stays empty
+  const void *device_data = nullptr;
+};
+
+// Counterpart of StatisticsInterface (src/statisticsinterface.h:40,52,59): only what the two filters report
+struct Stats {
+  std::atomic<uint64_t> encodedPackets{0}, encodedBytes{0}, receivedPackets{0}, receivedBytes{0}, droppedPackets{0};
+  std::atomic<uint64_t> encodingDelaySumMs{0};
+};
+
+using Settings = std::map<std::string, std::string>;
+int64_t now_ms();
+
+class Filter {
+ public:
+  Filter(std::string id, std::string name, Stats *stats, DataType input, DataType output);
+  virtual ~Filter();
+  virtual bool init() { return true; }
+  virtual void updateSettings() {}
+  void addOutConnection(Filter *out) { std::lock_guard<std::mutex> l(connectionMutex_); outConnections_.push_back(out); }
+  void addDataOutCallback(std::function<void(std::unique_ptr<Data>)> cb) { std::lock_guard<std::mutex> l(connectionMutex_); outDataCallbacks_.push_back(std::move(cb)); }
+  void putInput(std::unique_ptr<Data> data);       // any thread
+  void start();
+  void stop();
+  bool isRunning() const { return threadRunning_; }
+  DataType inputType() const { return input_; }
+  DataType outputType() const { return output_; }
+  const std::string &name() const { return name_; }
+  uint32_t bufferedInputs();
+  uint64_t inputDiscarded() const { return inputDiscarded_; }
+
+ protected:
+  virtual void process() = 0;
+  std::unique_ptr<Data> getInput();
+  void sendOutput(std::unique_ptr<Data> output);
+  static Data *deepDataCopy(const Data *original);
+  static bool isHEVCIntra(const unsigned char *buff) { return buff[0] == 0 && buff[1] == 0 && buff[2] == 0 && buff[3] == 1 && (buff[4] >> 1) == IDR_W_RADL; }
+  static bool isHEVCInter(const unsigned char *buff) { return buff[0] == 0 && buff[1] == 0 && buff[2] == 0 && buff[3] == 1 && (buff[4] >> 1) == TRAIL_R; }
+  Stats *getStats() { return stats_; }
+  int maxBufferSize_ = 10;                        // -1 = unlimited
+
+ private:
+  void run();
+  std::string id_, name_;
+  Stats *stats_;
+  DataType input_, output_;
+  std::mutex bufferMutex_, connectionMutex_;
+  std::condition_variable hasInput_;
+  std::deque<std::unique_ptr<Data>> inBuffer_;
+  std::vector<Filter *> outConnections_;
+  std::vector<std::function<void(std::unique_ptr<Data>)>> outDataCallbacks_;
+  std::thread thread_;
+  std::atomic<bool> running_{false}, threadRunning_{false};
+  uint64_t inputTaken_ = 0, inputDiscarded_ = 0;
+};
+
+class KvazaarFilter : public Filter {
+ public:
+  KvazaarFilter(std::string id, Stats *stats, const Settings *settings);
+  ~KvazaarFilter() override;
+  bool init() override;
+  void updateSettings() override;
+  void close();
+  kvz_encoder *encoder() { return enc_; }          // tests / bench: profiling hooks of include/kvazzup_amd.h
+
+ protected:
+  void process() override;
+
+ private:
+  void customParameters();
+  void feedInput(std::unique_ptr<Data> input);
+  void parseEncodedFrame(kvz_data_chunk *data_out, uint32_t len_out, kvz_picture *recon_pic);
+  void sendEncodedFrame(std::unique_ptr<Data> input, std::unique_ptr<uint8_t[]> hevc_frame, uint32_t dataWritten);
+  void createInputVector(int size);
+  void cleanupInputVector();
+  void addInputPic(int index);
+  kvz_picture *getNextPic();
+  std::string setting(const std::string &key, const std::string &def = "") const;
+
+  const Settings *settings_;
+  const kvz_api *api_ = nullptr;
+  kvz_config *config_ = nullptr;
+  kvz_encoder *enc_ = nullptr;
+  int64_t pts_ = 0;
+  std::vector<kvz_picture *> inputPics_;
+  int nextInputPic_ = -1;
+  std::mutex settingsMutex_;
+  struct FrameInfo { std::unique_ptr<Data> data; int8_t *roi_array; };
+  std::deque<FrameInfo> encodingFrames_;
+  std::vector<uint8_t> au_;                        // device-input path: access unit buffer
+};
+
+class OpenHEVCFilter : public Filter {
+ public:
+  OpenHEVCFilter(uint32_t sessionID, Stats *stats, const Settings *settings);
+  ~OpenHEVCFilter() override;
+  bool init() override;
+  void uninit();
+  void updateSettings() override;
+  OpenHevc_Handle handle() { return handle_; }
+
+ protected:
+  void process() override;
+
+ private:
+  void sendDecodedOutput(int &gotPicture);
+  const Settings *settings_;
+  OpenHevc_Handle handle_ = nullptr;
+  bool vpsReceived_ = false, spsReceived_ = false, ppsReceived_ = false;
+  uint32_t sessionID_;
+  int threads_ = -1;
+  std::string parallelizationMode_ = "Slice";
+  std::deque<std::unique_ptr<Data>> decodingFrames_;
+  std::mutex settingsMutex_;
+  uint32_t discardedFrames_ = 0;
+  bool download_ = true;
+};
+
+// Row f2: what uvgRTP does between the two filters in a loop-back: the sender pushes the whole access
+// unit (uvgrtpsender.cpp:106), the receiver hands one NAL unit at a time to the decoder, each with a
+// 4-byte start code (uvgrtpreceiver.cpp:86-112).
+class WireAdapter : public Filter {
+ public:
+  WireAdapter(std::string id, Stats *stats) : Filter(std::move(id), "WireAdapter", stats, DT_HEVCVIDEO, DT_HEVCVIDEO) { maxBufferSize_ = -1; }
+ protected:
+  void process() override;
+};
+
+}  // namespace uvgx

@@ -1,0 +1,598 @@
+// kvazzup_amd/csrc/filters.hip -- see filters.h.  Host-only C++ (compiled with the rest of the
+// library).  Each function cites the reference lines whose observable behaviour it reproduces.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include "filters.h"
+
+namespace uvgx {
+
+int64_t now_ms()
+{
+  return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
+
+// ----------------------------------------------------------------------------------------------- Filter
+Filter::Filter(std::string id, std::string name, Stats *stats, DataType input, DataType output)
+    : id_(std::move(id)), name_(std::move(name)), stats_(stats), input_(input), output_(output) {}
+
+Filter::~Filter() { stop(); }
+
+void Filter::start()
+{
+  if (threadRunning_) return;
+  running_ = true;
+  threadRunning_ = true;
+  thread_ = std::thread([this] { run(); threadRunning_ = false; });
+}
+
+void Filter::stop()                                        // filter.cpp:419-423
+{
+  running_ = false;
+  { std::lock_guard<std::mutex> l(bufferMutex_); }
+  hasInput_.notify_all();
+  if (thread_.joinable()) thread_.join();
+}
+
+void Filter::run()                                         // filter.cpp:425-443
+{
+  while (running_) {
+    {
+      std::unique_lock<std::mutex> l(bufferMutex_);
+      hasInput_.wait(l, [this] { return !running_ || !inBuffer_.empty(); });
+    }
+    if (!running_) break;
+    process();
+  }
+}
+
+uint32_t Filter::bufferedInputs() { std::lock_guard<std::mutex> l(bufferMutex_); return (uint32_t)inBuffer_.size(); }
+
+void Filter::putInput(std::unique_ptr<Data> data)          // filter.cpp:151-222
+{
+  if (!data) return;
+  std::lock_guard<std::mutex> l(bufferMutex_);
+  ++inputTaken_;
+  inBuffer_.push_back(std::move(data));
+  if (maxBufferSize_ != -1 && inBuffer_.size() >= (uint32_t)maxBufferSize_) {
+    if (inBuffer_[0]->type == DT_HEVCVIDEO) {
+      // search for intra frames and discard everything up to it (filter.cpp:179-196)
+      for (uint32_t i = 0; i < inBuffer_.size(); ++i) {
+        const unsigned char *buff = inBuffer_.at(i)->data.get();
+        if (!isHEVCIntra(buff)) {
+          for (int j = (int)i; j != 0; --j) inBuffer_.pop_front();
+          break;
+        }
+      }
+    } else {
+      inBuffer_.pop_front();                               // discard the oldest
+    }
+    ++inputDiscarded_;
+    if (stats_) stats_->droppedPackets++;
+  }
+  hasInput_.notify_one();
+}
+
+std::unique_ptr<Data> Filter::getInput()                   // filter.cpp:297-306
+{
+  std::lock_guard<std::mutex> l(bufferMutex_);
+  std::unique_ptr<Data> r;
+  if (!inBuffer_.empty()) { r = std::move(inBuffer_.front()); inBuffer_.pop_front(); }
+  return r;
+}
+
+Data *Filter::deepDataCopy(const Data *o)
+{
+  Data *c = new Data;
+  c->source = o->source; c->type = o->type; c->data_size = o->data_size;
+  c->creationTimestamp = o->creationTimestamp; c->presentationTimestamp = o->presentationTimestamp;
+  c->device_data = o->device_data;
+  if (o->data) { c->data.reset(new uint8_t[o->data_size]); memcpy(c->data.get(), o->data.get(), o->data_size); }
+  if (o->vInfo) {
+    c->vInfo.reset(new VideoInfo);
+    c->vInfo->width = o->vInfo->width; c->vInfo->height = o->vInfo->height;
+    c->vInfo->framerateNumerator = o->vInfo->framerateNumerator; c->vInfo->framerateDenominator = o->vInfo->framerateDenominator;
+    c->vInfo->flippedVertically = o->vInfo->flippedVertically; c->vInfo->flippedHorizontally = o->vInfo->flippedHorizontally;
+    c->vInfo->roi.width = o->vInfo->roi.width; c->vInfo->roi.height = o->vInfo->roi.height;
+    if (o->vInfo->roi.data) {
+      size_t n = (size_t)o->vInfo->roi.width * o->vInfo->roi.height;
+      c->vInfo->roi.data.reset(new int8_t[n]); memcpy(c->vInfo->roi.data.get(), o->vInfo->roi.data.get(), n);
+    }
+  }
+  return c;
+}
+
+void Filter::sendOutput(std::unique_ptr<Data> output)      // filter.cpp:364-417
+{
+  if (!output) return;
+  std::lock_guard<std::mutex> l(connectionMutex_);
+  if (outDataCallbacks_.empty() && outConnections_.empty()) return;
+  if (!outDataCallbacks_.empty()) {
+    for (size_t i = 0; i + 1 < outDataCallbacks_.size(); ++i) outDataCallbacks_[i](std::unique_ptr<Data>(deepDataCopy(output.get())));
+    if (!outConnections_.empty()) outDataCallbacks_.back()(std::unique_ptr<Data>(deepDataCopy(output.get())));
+    else { outDataCallbacks_.back()(std::move(output)); return; }
+  }
+  if (!outConnections_.empty()) {
+    for (size_t i = 0; i + 1 < outConnections_.size(); ++i) outConnections_[i]->putInput(std::unique_ptr<Data>(deepDataCopy(output.get())));
+    outConnections_.back()->putInput(std::move(output));   // always move the last out connection
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- KvazaarFilter
+KvazaarFilter::KvazaarFilter(std::string id, Stats *stats, const Settings *settings)
+    : Filter(std::move(id), "Kvazaar", stats, DT_YUV420VIDEO, DT_HEVCVIDEO), settings_(settings)
+{
+  maxBufferSize_ = 30;                                     // kvazaarfilter.cpp:28
+}
+KvazaarFilter::~KvazaarFilter() { stop(); close(); }
+
+std::string KvazaarFilter::setting(const std::string &key, const std::string &def) const
+{
+  auto it = settings_->find(key);
+  return it == settings_->end() ? def : it->second;
+}
+
+void KvazaarFilter::createInputVector(int size)            // kvazaarfilter.cpp:32-42
+{
+  cleanupInputVector();
+  for (int i = 0; i < size; ++i) addInputPic((int)inputPics_.size());
+  nextInputPic_ = 0;
+}
+void KvazaarFilter::cleanupInputVector()                   // kvazaarfilter.cpp:45-59
+{
+  if (!api_) return;
+  for (auto pic : inputPics_) { pic->roi.roi_array = nullptr; api_->picture_free(pic); }
+  inputPics_.clear();
+  nextInputPic_ = -1;
+}
+void KvazaarFilter::addInputPic(int index)                 // kvazaarfilter.cpp:61-74
+{
+  if (!api_ || !config_) return;
+  kvz_picture *pic = api_->picture_alloc(config_->width, config_->height);
+  if (pic) inputPics_.insert(inputPics_.begin() + index, pic);
+}
+kvz_picture *KvazaarFilter::getNextPic()                   // kvazaarfilter.cpp:76-88
+{
+  if (encodingFrames_.size() == inputPics_.size()) addInputPic(nextInputPic_);
+  kvz_picture *inputPic = inputPics_.at((size_t)nextInputPic_);
+  nextInputPic_ = (nextInputPic_ + 1) % (int)inputPics_.size();
+  return inputPic;
+}
+
+void KvazaarFilter::updateSettings()                       // kvazaarfilter.cpp:91-119
+{
+  stop();
+  close();
+  {
+    std::lock_guard<std::mutex> l(settingsMutex_);
+    init();
+    encodingFrames_.clear();
+  }
+  start();
+}
+
+bool KvazaarFilter::init()                                 // kvazaarfilter.cpp:122-311, same order of calls
+{
+  if (!inputPics_.empty() || api_) return true;
+  const int w = atoi(setting("video/ResolutionWidth").c_str()), h = atoi(setting("video/ResolutionHeight").c_str());
+  const int fn = atoi(setting("video/FramerateNumerator").c_str()), fd = atoi(setting("video/FramerateDenominator").c_str());
+  if (w == 0 || h == 0 || fn == 0 || fd == 0) { fprintf(stderr, "KvazaarFilter: invalid values in settings\n"); return false; }
+  api_ = kvz_api_get(8);
+  if (!api_) return false;
+  config_ = api_->config_alloc();
+  enc_ = nullptr;
+  if (!config_) return false;
+  api_->config_init(config_);
+  const std::string res = std::to_string(w) + "x" + std::to_string(h), fps = std::to_string(fn) + "/" + std::to_string(fd);
+  api_->config_parse(config_, "preset", setting("video/Preset", "ultrafast").c_str());
+  api_->config_parse(config_, "input-res", res.c_str());
+  api_->config_parse(config_, "input-fps", fps.c_str());
+  std::string threads = setting("video/kvzThreads", "auto");
+  if (threads == "auto") threads = std::to_string(std::thread::hardware_concurrency());
+  else if (threads == "Main") threads = "0";
+  api_->config_parse(config_, "threads", threads.c_str());
+  api_->config_parse(config_, "owf", setting("video/OWF", "0").c_str());
+  api_->config_parse(config_, "wpp", setting("video/WPP", "1").c_str());
+  const bool tiles = atoi(setting("video/Tiles", "0").c_str()) != 0;
+  if (tiles) api_->config_parse(config_, "tiles", setting("video/tileDimensions", "2x2").c_str());
+  if (atoi(setting("video/Slices", "0").c_str()) == 1) {
+    if (config_->wpp) api_->config_parse(config_, "slices", "wpp");
+    else if (tiles) api_->config_parse(config_, "slices", "tiles");
+  }
+  api_->config_parse(config_, "qp", setting("video/QP", "32").c_str());
+  api_->config_parse(config_, "period", setting("video/Intra", "64").c_str());
+  api_->config_parse(config_, "vps-period", setting("video/VPS", "1").c_str());
+  config_->target_bitrate = atoi(setting("video/bitrate", "0").c_str());
+  if (config_->target_bitrate != 0) api_->config_parse(config_, "rc-algorithm", setting("video/rcAlgorithm", "lambda").c_str());
+  api_->config_parse(config_, "intra-bits", "");
+  api_->config_parse(config_, "gop", "lp-g4d3t1");
+  if (atoi(setting("video/scalingList", "0").c_str()) == 0) api_->config_parse(config_, "scaling-list", "off");
+  else api_->config_parse(config_, "scaling-list", "default");
+  config_->lossless = atoi(setting("video/lossless", "0").c_str());
+  const std::string constraint = setting("video/mvConstraint", "none");
+  if (constraint == "frame" || constraint == "frametile" || constraint == "frametilemargin") api_->config_parse(config_, "mv-constraint", "");
+  else api_->config_parse(config_, "mv-constraint", "none");
+  if (constraint == "frame") config_->mv_constraint = KVZ_MV_CONSTRAIN_FRAME;
+  else if (constraint == "tile") config_->mv_constraint = KVZ_MV_CONSTRAIN_TILE;
+  else if (constraint == "frametile") config_->mv_constraint = KVZ_MV_CONSTRAIN_FRAME_AND_TILE;
+  else if (constraint == "frametilemargin") config_->mv_constraint = KVZ_MV_CONSTRAIN_FRAME_AND_TILE_MARGIN;
+  else config_->mv_constraint = KVZ_MV_CONSTRAIN_NONE;
+  config_->set_qp_in_cu = atoi(setting("video/qpInCU", "0").c_str());
+  const int vaq = atoi(setting("video/vaq", "0").c_str());
+  if (vaq > 0 && vaq <= 20) api_->config_parse(config_, "vaq", setting("video/vaq").c_str());
+  customParameters();
+  config_->hash = KVZ_HASH_NONE;
+  enc_ = api_->encoder_open(config_);
+  if (!enc_) { fprintf(stderr, "KvazaarFilter: failed to open the encoder\n"); return false; }
+  createInputVector(config_->owf + 1);
+  return !inputPics_.empty();
+}
+
+void KvazaarFilter::customParameters()                     // kvazaarfilter.cpp:351-371: INI array "parameters"
+{
+  const int size = atoi(setting("parameters/size", "0").c_str());
+  for (int i = 1; i <= size; ++i) {
+    const std::string name = setting("parameters/" + std::to_string(i) + "/Name"), value = setting("parameters/" + std::to_string(i) + "/Value");
+    if (api_->config_parse(config_, name.c_str(), value.c_str()) != 1)
+      fprintf(stderr, "KvazaarFilter: invalid custom parameter %s=%s\n", name.c_str(), value.c_str());
+  }
+}
+
+void KvazaarFilter::close()                                // kvazaarfilter.cpp:313-329
+{
+  if (api_) {
+    api_->encoder_close(enc_);
+    api_->config_destroy(config_);
+    enc_ = nullptr; config_ = nullptr;
+    cleanupInputVector();
+    api_ = nullptr;
+  }
+  pts_ = 0;
+}
+
+void KvazaarFilter::process()                              // kvazaarfilter.cpp:331-349
+{
+  std::unique_ptr<Data> input = getInput();
+  while (input) {
+    if (inputPics_.empty()) break;
+    {
+      std::lock_guard<std::mutex> l(settingsMutex_);
+      feedInput(std::move(input));
+    }
+    input = getInput();
+  }
+}
+
+void KvazaarFilter::feedInput(std::unique_ptr<Data> input) // kvazaarfilter.cpp:374-450
+{
+  kvz_picture *recon_pic = nullptr;
+  kvz_frame_info frame_info;
+  kvz_data_chunk *data_out = nullptr;
+  uint32_t len_out = 0;
+  if (config_->width != input->vInfo->width || config_->height != input->vInfo->height ||
+      config_->framerate_num != input->vInfo->framerateNumerator || config_->framerate_denom != input->vInfo->framerateDenominator) {
+    fprintf(stderr, "KvazaarFilter: input resolution or framerate differs from settings\n");
+    return;
+  }
+  if (nextInputPic_ == -1 || nextInputPic_ >= (int)inputPics_.size()) return;
+  if (input->device_data) {
+    // extension: the picture is already in HBM -- no kvz_picture copy, no chunk list (include/kvazzup_amd.h)
+    const size_t cap = (size_t)config_->width * config_->height * 3 + (1 << 20);
+    if (au_.size() < cap) au_.resize(cap);
+    uint32_t n = 0;
+    ++pts_;
+    if (!kvzx_encoder_encode_device(enc_, input->device_data, au_.data(), (uint32_t)au_.size(), &n, &frame_info)) return;
+    std::unique_ptr<uint8_t[]> hevc_frame(new uint8_t[n]);
+    memcpy(hevc_frame.get(), au_.data(), n);
+    if (getStats()) { getStats()->encodingDelaySumMs += (uint64_t)(now_ms() - input->creationTimestamp); getStats()->encodedPackets++; getStats()->encodedBytes += n; }
+    input->device_data = nullptr;
+    sendEncodedFrame(std::move(input), std::move(hevc_frame), n);
+    return;
+  }
+  kvz_picture *inputPic = getNextPic();
+  const size_t ny = (size_t)input->vInfo->width * input->vInfo->height;
+  memcpy(inputPic->y, input->data.get(), ny);
+  memcpy(inputPic->u, &(input->data.get()[ny]), ny / 4);
+  memcpy(inputPic->v, &(input->data.get()[ny + ny / 4]), ny / 4);
+  inputPic->pts = pts_;
+  ++pts_;
+  if (config_->target_bitrate == 0) {
+    inputPic->roi.width = input->vInfo->roi.width;
+    inputPic->roi.height = input->vInfo->roi.height;
+    inputPic->roi.roi_array = input->vInfo->roi.data.release();      // deleted after the frame's output
+  }
+  encodingFrames_.push_front({std::move(input), inputPic->roi.roi_array});
+  api_->encoder_encode(enc_, inputPic, &data_out, &len_out, &recon_pic, nullptr, &frame_info);
+  while (data_out != nullptr) {
+    parseEncodedFrame(data_out, len_out, recon_pic);
+    api_->encoder_encode(enc_, nullptr, &data_out, &len_out, &recon_pic, nullptr, &frame_info);
+  }
+}
+
+void KvazaarFilter::parseEncodedFrame(kvz_data_chunk *data_out, uint32_t len_out, kvz_picture *recon_pic)   // kvazaarfilter.cpp:453-484
+{
+  FrameInfo info = std::move(encodingFrames_.back());
+  encodingFrames_.pop_back();
+  if (info.roi_array) { delete[] info.roi_array; info.roi_array = nullptr; }
+  std::unique_ptr<uint8_t[]> hevc_frame(new uint8_t[len_out]);
+  uint8_t *writer = hevc_frame.get();
+  uint32_t dataWritten = 0;
+  for (kvz_data_chunk *chunk = data_out; chunk != nullptr; chunk = chunk->next) {
+    memcpy(writer, chunk->data, chunk->len);
+    writer += chunk->len; dataWritten += chunk->len;
+  }
+  api_->chunk_free(data_out);
+  api_->picture_free(recon_pic);
+  if (getStats()) { getStats()->encodingDelaySumMs += (uint64_t)(now_ms() - info.data->creationTimestamp); getStats()->encodedPackets++; getStats()->encodedBytes += len_out; }
+  sendEncodedFrame(std::move(info.data), std::move(hevc_frame), dataWritten);
+}
+
+void KvazaarFilter::sendEncodedFrame(std::unique_ptr<Data> input, std::unique_ptr<uint8_t[]> hevc_frame, uint32_t dataWritten)   // :487-495
+{
+  input->type = DT_HEVCVIDEO;
+  input->data_size = dataWritten;
+  input->data = std::move(hevc_frame);
+  sendOutput(std::move(input));
+}
+
+// ----------------------------------------------------------------------------------------------- OpenHEVCFilter
+enum OHThreadType { OH_THREAD_FRAME = 1, OH_THREAD_SLICE = 2, OH_THREAD_FRAMESLICE = 3 };
+
+OpenHEVCFilter::OpenHEVCFilter(uint32_t sessionID, Stats *stats, const Settings *settings)
+    : Filter(std::to_string(sessionID), "OpenHEVC", stats, DT_HEVCVIDEO, DT_YUV420VIDEO), settings_(settings), sessionID_(sessionID) {}
+OpenHEVCFilter::~OpenHEVCFilter() { stop(); if (handle_) uninit(); }
+
+bool OpenHEVCFilter::init()                                // openhevcfilter.cpp:28-74
+{
+  auto get = [&](const char *k, const char *d) { auto it = settings_->find(k); return it == settings_->end() ? std::string(d) : it->second; };
+  threads_ = atoi(get("video/OPENHEVC_threads", "1").c_str());
+  parallelizationMode_ = get("video/OH_parallelization", "Slice");
+  if (parallelizationMode_ == "Slice") handle_ = libOpenHevcInit(threads_, OH_THREAD_SLICE);
+  else if (parallelizationMode_ == "Frame") handle_ = libOpenHevcInit(threads_, OH_THREAD_FRAME);
+  else handle_ = libOpenHevcInit(threads_, OH_THREAD_FRAMESLICE);
+  const std::string dev = get("uvgx/gpu", "");
+  if (!dev.empty()) kvzx_decoder_set_device(handle_, atoi(dev.c_str()));
+  if (libOpenHevcStartDecoder(handle_) == -1) { fprintf(stderr, "OpenHEVCFilter: failed to start decoder\n"); return false; }
+  libOpenHevcSetTemporalLayer_id(handle_, 0);
+  libOpenHevcSetActiveDecoders(handle_, 0);
+  libOpenHevcSetViewLayers(handle_, 0);
+  download_ = atoi(get("uvgx/decoderDownload", "1").c_str()) != 0;
+  if (!download_) kvzx_decoder_set_download(handle_, 0);   // extension: leave decoded pictures in HBM
+  decodingFrames_.clear();
+  maxBufferSize_ = -1;                                     // no buffer limit (openhevcfilter.cpp:68)
+  vpsReceived_ = spsReceived_ = ppsReceived_ = false;
+  return true;
+}
+
+void OpenHEVCFilter::uninit()                              // openhevcfilter.cpp:77-83
+{
+  libOpenHevcFlush(handle_);
+  libOpenHevcClose(handle_);
+  handle_ = nullptr;
+}
+
+void OpenHEVCFilter::updateSettings()                      // openhevcfilter.cpp:86-100
+{
+  auto get = [&](const char *k, const char *d) { auto it = settings_->find(k); return it == settings_->end() ? std::string(d) : it->second; };
+  if (atoi(get("video/OPENHEVC_threads", "1").c_str()) != threads_ || get("video/OH_parallelization", "Slice") != parallelizationMode_) {
+    std::lock_guard<std::mutex> l(settingsMutex_);
+    uninit();
+    init();
+  }
+}
+
+void OpenHEVCFilter::process()                             // openhevcfilter.cpp:103-189
+{
+  std::unique_ptr<Data> input = getInput();
+  while (input) {
+    if (getStats()) { getStats()->receivedPackets++; getStats()->receivedBytes += input->data_size; }
+    {
+      std::lock_guard<std::mutex> l(settingsMutex_);
+      const unsigned char *buff = input->data.get();
+      uint8_t nalType = (buff[4] >> 1);
+      if (!vpsReceived_ && nalType == VPS_NUT) vpsReceived_ = true;
+      if (!spsReceived_ && nalType == SPS_NUT) spsReceived_ = true;
+      if (!ppsReceived_ && nalType == PPS_NUT) ppsReceived_ = true;
+      bool vcl = nalType <= 31;
+      if ((vpsReceived_ && spsReceived_ && ppsReceived_) || !vcl) {
+        discardedFrames_ = 0;
+        int gotPicture = libOpenHevcDecode(handle_, input->data.get(), (int)input->data_size, input->presentationTimestamp);
+        if (vcl) decodingFrames_.push_front(std::move(input));
+        if (gotPicture <= -1) fprintf(stderr, "OpenHEVCFilter: error while decoding (%d)\n", kvzx_decoder_last_error(handle_));
+        else if (gotPicture > 0) sendDecodedOutput(gotPicture);
+      } else {
+        ++discardedFrames_;
+      }
+    }
+    input = getInput();
+  }
+}
+
+void OpenHEVCFilter::sendDecodedOutput(int &gotPicture)    // openhevcfilter.cpp:192-239
+{
+  OpenHevc_Frame openHevcFrame;
+  if ((gotPicture = libOpenHevcGetOutput(handle_, gotPicture, &openHevcFrame)) > 0) {
+    std::unique_ptr<Data> decodedFrame = std::move(decodingFrames_.back());
+    decodingFrames_.pop_back();
+    libOpenHevcGetPictureInfo(handle_, &openHevcFrame.frameInfo);
+    decodedFrame->vInfo->width = (int16_t)openHevcFrame.frameInfo.nWidth;
+    decodedFrame->vInfo->height = (int16_t)openHevcFrame.frameInfo.nHeight;
+    const int W = decodedFrame->vInfo->width, H = decodedFrame->vInfo->height;
+    decodedFrame->type = DT_YUV420VIDEO;
+    decodedFrame->vInfo->framerateNumerator = openHevcFrame.frameInfo.frameRate.num;
+    decodedFrame->vInfo->framerateDenominator = openHevcFrame.frameInfo.frameRate.den;
+    if (!download_) {
+      // extension: the picture stays in HBM; hand its device pointer on instead of copying rows
+      const void *planes[3]; int pitches[3];
+      kvzx_decoder_output_device(handle_, planes, pitches);
+      decodedFrame->device_data = planes[0];
+      decodedFrame->data.reset();
+      decodedFrame->data_size = 0;
+      sendOutput(std::move(decodedFrame));
+      return;
+    }
+    uint32_t finalDataSize = (uint32_t)(W * H + W * H / 2);
+    std::unique_ptr<uint8_t[]> yuv_frame(new uint8_t[finalDataSize]);
+    uint8_t *pY = yuv_frame.get(), *pU = yuv_frame.get() + W * H, *pV = yuv_frame.get() + W * H + W * H / 4;
+    uint32_t s_stride = (uint32_t)openHevcFrame.frameInfo.nYPitch, qs_stride = (uint32_t)openHevcFrame.frameInfo.nUPitch / 2;
+    uint32_t d_stride = (uint32_t)W / 2, dd_stride = (uint32_t)W;
+    for (int i = 0; i < H; i++) {
+      memcpy(pY, (uint8_t *)openHevcFrame.pvY + i * s_stride, dd_stride);
+      pY += dd_stride;
+      if (!(i % 2)) {
+        memcpy(pU, (uint8_t *)openHevcFrame.pvU + i * qs_stride, d_stride); pU += d_stride;
+        memcpy(pV, (uint8_t *)openHevcFrame.pvV + i * qs_stride, d_stride); pV += d_stride;
+      }
+    }
+    decodedFrame->data_size = finalDataSize;
+    decodedFrame->data = std::move(yuv_frame);
+    sendOutput(std::move(decodedFrame));
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- WireAdapter (row f2)
+void WireAdapter::process()
+{
+  std::unique_ptr<Data> input = getInput();
+  while (input) {
+    const uint8_t *p = input->data.get(); const uint32_t n = input->data_size;
+    std::vector<uint32_t> starts;
+    for (uint32_t i = 0; i + 3 < n; i++) if (p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 0 && p[i + 3] == 1) { starts.push_back(i); i += 3; }
+    starts.push_back(n);
+    for (size_t k = 0; k + 1 < starts.size(); k++) {
+      std::unique_ptr<Data> nal(new Data);
+      nal->source = DS_REMOTE; nal->type = DT_HEVCVIDEO;
+      nal->data_size = starts[k + 1] - starts[k];
+      nal->data.reset(new uint8_t[nal->data_size]);
+      memcpy(nal->data.get(), p + starts[k], nal->data_size);
+      nal->creationTimestamp = input->creationTimestamp;
+      nal->presentationTimestamp = input->presentationTimestamp;
+      nal->vInfo.reset(new VideoInfo);                     // resolution unknown until decoded (filter.cpp initializeData)
+      sendOutput(std::move(nal));
+    }
+    input = getInput();
+  }
+}
+
+}  // namespace uvgx
+
+// ----------------------------------------------------------------------------------------------- C shim for tests / bench
+using namespace uvgx;
+
+struct UvgxPipeline {
+  Settings settings;
+  Stats stats;
+  std::unique_ptr<KvazaarFilter> enc;
+  std::unique_ptr<WireAdapter> wire;
+  std::unique_ptr<OpenHEVCFilter> dec;
+  std::mutex m; std::condition_variable cv;
+  std::deque<std::unique_ptr<Data>> encoded, decoded;
+  uint64_t n_encoded = 0, n_decoded = 0, decoded_bytes = 0;
+  bool keep = true, loopback = true;
+};
+
+extern "C" {
+
+// settings_text: "key=value" lines with the key names of src/settingskeys.h (plus uvgx/* extensions).
+KVZ_PUBLIC void *uvgx_pipeline_create(const char *settings_text, int loopback_decode, int keep_outputs)
+{
+  UvgxPipeline *p = new UvgxPipeline();
+  p->keep = keep_outputs != 0; p->loopback = loopback_decode != 0;
+  std::string s(settings_text ? settings_text : "");
+  size_t pos = 0;
+  while (pos < s.size()) {
+    size_t e = s.find('\n', pos); if (e == std::string::npos) e = s.size();
+    std::string line = s.substr(pos, e - pos); pos = e + 1;
+    size_t eq = line.find('=');
+    if (eq != std::string::npos) p->settings[line.substr(0, eq)] = line.substr(eq + 1);
+  }
+  p->enc.reset(new KvazaarFilter("uvgx", &p->stats, &p->settings));
+  if (!p->enc->init()) { delete p; return nullptr; }
+  p->enc->addDataOutCallback([p](std::unique_ptr<Data> d) {
+    std::lock_guard<std::mutex> l(p->m);
+    p->n_encoded++;
+    if (p->keep) p->encoded.push_back(std::move(d));
+    p->cv.notify_all();
+  });
+  if (p->loopback) {
+    p->wire.reset(new WireAdapter("uvgx", &p->stats));
+    p->dec.reset(new OpenHEVCFilter(1, &p->stats, &p->settings));
+    if (!p->dec->init()) { delete p; return nullptr; }
+    p->enc->addOutConnection(p->wire.get());
+    p->wire->addOutConnection(p->dec.get());
+    p->dec->addDataOutCallback([p](std::unique_ptr<Data> d) {
+      std::lock_guard<std::mutex> l(p->m);
+      p->n_decoded++; p->decoded_bytes += d->data_size;
+      if (p->keep) p->decoded.push_back(std::move(d));
+      p->cv.notify_all();
+    });
+    p->wire->start();
+    p->dec->start();
+  }
+  p->enc->start();
+  return p;
+}
+
+static int push(UvgxPipeline *p, const uint8_t *host, const void *dev, int w, int h, int fn, int fd, int64_t pts)
+{
+  std::unique_ptr<Data> d(new Data);
+  d->source = DS_LOCAL; d->type = DT_YUV420VIDEO;
+  d->creationTimestamp = now_ms(); d->presentationTimestamp = pts;
+  d->vInfo.reset(new VideoInfo);
+  d->vInfo->width = (int16_t)w; d->vInfo->height = (int16_t)h; d->vInfo->framerateNumerator = fn; d->vInfo->framerateDenominator = fd;
+  if (host) { d->data_size = (uint32_t)(w * h * 3 / 2); d->data.reset(new uint8_t[d->data_size]); memcpy(d->data.get(), host, d->data_size); }
+  d->device_data = dev;
+  p->enc->putInput(std::move(d));
+  return 1;
+}
+KVZ_PUBLIC int uvgx_pipeline_push_host(void *pp, const uint8_t *i420, int w, int h, int fn, int fd, int64_t pts) { return pp && i420 ? push((UvgxPipeline *)pp, i420, nullptr, w, h, fn, fd, pts) : 0; }
+KVZ_PUBLIC int uvgx_pipeline_push_device(void *pp, const void *d_i420, int w, int h, int fn, int fd, int64_t pts) { return pp && d_i420 ? push((UvgxPipeline *)pp, nullptr, d_i420, w, h, fn, fd, pts) : 0; }
+
+// wait until `n` pictures have left the last filter (decoder when looped back, else encoder); 1 = reached
+KVZ_PUBLIC int uvgx_pipeline_wait(void *pp, uint64_t n, int timeout_ms)
+{
+  UvgxPipeline *p = (UvgxPipeline *)pp;
+  std::unique_lock<std::mutex> l(p->m);
+  return p->cv.wait_for(l, std::chrono::milliseconds(timeout_ms), [&] { return (p->loopback ? p->n_decoded : p->n_encoded) >= n; }) ? 1 : 0;
+}
+KVZ_PUBLIC uint32_t uvgx_pipeline_encoder_backlog(void *pp) { return ((UvgxPipeline *)pp)->enc->bufferedInputs(); }
+
+static int pop(UvgxPipeline *p, std::deque<std::unique_ptr<Data>> &q, uint8_t *buf, uint32_t cap, uint32_t *size, int *w, int *h, int64_t *pts)
+{
+  std::lock_guard<std::mutex> l(p->m);
+  if (q.empty()) return 0;
+  Data *d = q.front().get();
+  if (size) *size = d->data_size;
+  if (w) *w = d->vInfo ? d->vInfo->width : 0;
+  if (h) *h = d->vInfo ? d->vInfo->height : 0;
+  if (pts) *pts = d->presentationTimestamp;
+  if (d->data_size > cap) return -1;
+  if (d->data) memcpy(buf, d->data.get(), d->data_size);
+  q.pop_front();
+  return 1;
+}
+KVZ_PUBLIC int uvgx_pipeline_pop_encoded(void *pp, uint8_t *buf, uint32_t cap, uint32_t *size, int64_t *pts) { UvgxPipeline *p = (UvgxPipeline *)pp; return pop(p, p->encoded, buf, cap, size, nullptr, nullptr, pts); }
+KVZ_PUBLIC int uvgx_pipeline_pop_decoded(void *pp, uint8_t *buf, uint32_t cap, uint32_t *size, int *w, int *h, int64_t *pts) { UvgxPipeline *p = (UvgxPipeline *)pp; return pop(p, p->decoded, buf, cap, size, w, h, pts); }
+
+// out[0..7]: encoded pictures, encoded bytes, NAL units received by the decoder, their bytes, dropped inputs,
+// decoded pictures, sum of encoding delays (ms), decoder-side discarded inputs
+KVZ_PUBLIC void uvgx_pipeline_stats(void *pp, uint64_t *out)
+{
+  UvgxPipeline *p = (UvgxPipeline *)pp;
+  std::lock_guard<std::mutex> l(p->m);
+  out[0] = p->stats.encodedPackets; out[1] = p->stats.encodedBytes; out[2] = p->stats.receivedPackets; out[3] = p->stats.receivedBytes;
+  out[4] = p->stats.droppedPackets; out[5] = p->n_decoded; out[6] = p->stats.encodingDelaySumMs; out[7] = p->enc->inputDiscarded();
+}
+KVZ_PUBLIC void *uvgx_pipeline_encoder(void *pp) { return ((UvgxPipeline *)pp)->enc->encoder(); }
+KVZ_PUBLIC void *uvgx_pipeline_decoder(void *pp) { UvgxPipeline *p = (UvgxPipeline *)pp; return p->dec ? p->dec->handle() : nullptr; }
+KVZ_PUBLIC void uvgx_pipeline_destroy(void *pp)
+{
+  UvgxPipeline *p = (UvgxPipeline *)pp;
+  if (!p) return;
+  p->enc->stop();
+  if (p->wire) p->wire->stop();
+  if (p->dec) p->dec->stop();
+  delete p;
+}
+
+}  // extern "C"

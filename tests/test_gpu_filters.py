@@ -1,0 +1,52 @@
+"""GPU: the C++ mirrors of KvazaarFilter / OpenHEVCFilter (csrc/filters.hip), threads and queues
+included, give the same access units as the CPU checker and decode them back to its reconstruction."""
+import numpy as np
+import pytest
+
+import orc
+
+SEED = 0x5EED0000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,qp,period", [(320, 240, 32, 64), (416, 240, 27, 4)])
+def test_filter_chain_matches_oracle(gpu, w, h, qp, period):
+    from kvazzup_amd.pipeline import Pipeline
+    frames = 8
+    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=16)
+    pl = Pipeline(w, h, settings={"video/QP": qp, "video/Intra": period}, custom=(("me-range", 16),))
+    try:
+        clip = [orc.synth_frame(0, SEED, w, h, t) for t in range(frames)]
+        for f in clip:
+            pl.push(f)
+        assert pl.wait(frames, 60000)
+        for t in range(frames):
+            au_o = oe.encode(clip[t])
+            au_g, pts = pl.pop_encoded()
+            assert pts == t and au_g == au_o, "AU %d differs" % t
+            d = pl.pop_decoded()
+            assert d["width"] == w and d["height"] == h and d["pts"] == t
+            assert np.array_equal(d["i420"], oe.recon()), "decoded picture %d differs from the reconstruction" % t
+        st = pl.stats()
+        assert st["encoded_pictures"] == frames and st["decoded_pictures"] == frames and st["dropped"] == 0
+        # every AU reaches the decoder as single NAL units: 3 parameter sets + 1 slice for IDR pictures, 1 slice otherwise
+        n_idr = sum(1 for t in range(frames) if t % period == 0)
+        assert st["received_nals"] == frames + 3 * n_idr
+    finally:
+        pl.close()
+        oe.close()
+
+
+@pytest.mark.gpu
+def test_encoder_rejects_mismatching_input_and_unknown_option(gpu):
+    from kvazzup_amd.pipeline import Pipeline
+    pl = Pipeline(256, 128, custom=(("no-such-option", 1),))     # logged as invalid custom parameter, like kvazaarfilter.cpp:363-367
+    try:
+        pl.push(orc.synth_frame(0, SEED, 256, 128, 0))
+        assert pl.wait(1, 30000)
+        pl.lib.uvgx_pipeline_push_host(pl.p, np.zeros(128 * 64 * 3 // 2, np.uint8).ctypes.data, 128, 64, 30, 1, 99)   # wrong size: dropped (kvazaarfilter.cpp:381-399)
+        pl.push(orc.synth_frame(0, SEED, 256, 128, 1))
+        assert pl.wait(2, 30000)
+        assert pl.stats()["encoded_pictures"] == 2
+    finally:
+        pl.close()

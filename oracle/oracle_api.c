@@ -84,3 +84,76 @@ int orc_api_split_nals(const uint8_t *au, long n, long *offsets, int max)
     if (au[i] == 0 && au[i + 1] == 0 && au[i + 2] == 0 && au[i + 3] == 1) { if (cnt < max) offsets[cnt] = i; cnt++; i += 3; }
   return cnt;
 }
+
+/* ---- stage-level entry points for the unit tests ---- */
+void orc_api_tables(int which, void *dst)
+{
+  orc_tables_init();
+  switch (which) {
+    case 0: memcpy(dst, orc_dct_mat, 32 * 32); break;
+    case 1: memcpy(dst, orc_range_tab_lps, 256); break;
+    case 2: memcpy(dst, orc_trans_idx_lps, 64); break;
+    case 3: memcpy(dst, orc_cabac_init_values, 3 * CTX_COUNT); break;
+    case 4: memcpy(dst, orc_lambda_q4, 52 * 2); break;
+    case 5: memcpy(dst, orc_dst_mat, 16); break;
+    case 6: memcpy(dst, orc_beta_table, 52); break;
+    case 7: memcpy(dst, orc_tc_table, 54); break;
+    case 8: memcpy(dst, orc_chroma_qp_table, 58); break;
+    case 9: memcpy(dst, orc_intra_angle, 35); break;
+    case 10: memcpy(dst, orc_inv_angle, 35 * 2); break;
+    case 11: memcpy(dst, orc_luma_filter, 32); break;
+    case 12: memcpy(dst, orc_chroma_filter, 32); break;
+    case 13: memcpy(dst, orc_trans_idx_mps, 64); break;
+  }
+}
+void orc_api_intra_predict(const uint8_t *left, const uint8_t *top, int n, int cidx, int mode, int strong, uint8_t *pred)
+{
+  orc_intra_predict(left, top, n, cidx, mode, strong, pred, n);
+}
+/* deblock a coded-size picture in place given explicit bS maps and a constant QP */
+void orc_api_deblock(int w, int h, uint8_t *y, uint8_t *u, uint8_t *v, const uint8_t *bs_v, const uint8_t *bs_h, int qp)
+{
+  orc_deblock_ctx d; memset(&d, 0, sizeof(d));
+  int8_t *qpm = (int8_t *)malloc((size_t)(w / 4) * (h / 4));
+  memset(qpm, qp, (size_t)(w / 4) * (h / 4));
+  d.w = w; d.h = h; d.plane[0] = y; d.plane[1] = u; d.plane[2] = v; d.stride[0] = w; d.stride[1] = d.stride[2] = w / 2;
+  d.bs_v = bs_v; d.bs_stride_v = w / 8; d.bs_h = bs_h; d.bs_stride_h = w / 4; d.qp_y = qpm; d.qp_stride = w / 4;
+  orc_deblock_picture(&d);
+  free(qpm);
+}
+/* CABAC context initialisation (9.3.2.2): out[i] = state << 1 | mps */
+void orc_api_cabac_init(int init_type, int qp, uint8_t *out)
+{
+  orc_ctx c[CTX_COUNT];
+  orc_cabac_init_contexts(c, init_type, qp);
+  for (int i = 0; i < CTX_COUNT; i++) out[i] = (uint8_t)((c[i].state << 1) | c[i].mps);
+}
+/* encode a bin string with the spec-literal arithmetic coder and decode it again: kinds 0 ctx (ci), 1 bypass, 2 terminate */
+long orc_api_cabac_roundtrip(const uint8_t *kinds, const uint8_t *ci, const uint8_t *bins, long n, int qp, uint8_t *out, long cap, uint8_t *decoded)
+{
+  orc_bitw bw; orc_bw_init(&bw);
+  orc_cabac_enc e; memset(&e, 0, sizeof(e));
+  orc_cenc_start(&e, &bw);
+  orc_cabac_init_contexts(e.ctx, 0, qp);
+  for (long i = 0; i < n; i++) {
+    if (kinds[i] == 0) orc_cenc_bin(&e, ci[i], bins[i]);
+    else if (kinds[i] == 1) orc_cenc_bypass(&e, bins[i]);
+    else orc_cenc_terminate(&e, 0);
+  }
+  orc_cenc_terminate(&e, 1);
+  orc_bw_align_zero(&bw);
+  long len = (long)bw.len;
+  if (len <= cap) memcpy(out, bw.buf, bw.len);
+  orc_cabac_dec d; memset(&d, 0, sizeof(d));
+  orc_cdec_start(&d, bw.buf, bw.len);
+  orc_cabac_init_contexts(d.ctx, 0, qp);
+  for (long i = 0; i < n; i++) {
+    if (kinds[i] == 0) decoded[i] = (uint8_t)orc_cdec_bin(&d, ci[i]);
+    else if (kinds[i] == 1) decoded[i] = (uint8_t)orc_cdec_bypass(&d);
+    else decoded[i] = (uint8_t)orc_cdec_terminate(&d);
+  }
+  int term = orc_cdec_terminate(&d);
+  long consumed = (long)orc_cdec_bytes_consumed(&d);
+  orc_bw_free(&bw);
+  return (term == 1 && consumed == len) ? len : -len;
+}

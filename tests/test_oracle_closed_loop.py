@@ -1,0 +1,70 @@
+"""Closed loop of the CPU checker: every stream its encoder writes decodes, NAL by NAL, to exactly the
+encoder's reconstruction.  Covers intra / inter, WPP on and off, picture sizes
+that need a conformance window, flat and noise content, QP extremes, long GOPs with POC wrap."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+
+
+def closed_loop(w, h, frames, qp, period, rng, kind, wpp=1, seed=0x5EED0000):
+    b, bins = C.c_uint64(), C.c_uint64()
+    r = orc.lib().orc_api_closed_loop(w, h, frames, qp, period, rng, kind, seed, wpp, C.byref(b), C.byref(bins))
+    return r, b.value
+
+
+@pytest.mark.parametrize("cfg", [
+    (128, 64, 2, 32, 1, 8, 0, 1), (256, 192, 6, 32, 64, 16, 0, 1), (320, 240, 4, 22, 64, 8, 2, 1), (320, 240, 4, 40, 2, 8, 2, 1),
+    (192, 128, 4, 10, 64, 8, 2, 1), (192, 128, 3, 32, 64, 8, 1, 1), (416, 240, 8, 32, 4, 32, 0, 0), (130, 70, 3, 0, 64, 1, 2, 1),
+    (702, 394, 3, 51, 64, 4, 0, 1), (16, 16, 3, 30, 64, 4, 2, 1),
+])
+def test_closed_loop(cfg):
+    bad, nbytes = closed_loop(*cfg)
+    assert bad == 0 and nbytes > 0
+
+
+def test_poc_wraps_beyond_the_lsb_range():
+    # 8-bit pic_order_cnt_lsb with intra period 0: POC runs past 255 and must keep decoding
+    bad, _ = closed_loop(128, 64, 262, 40, 0, 2, 1)
+    assert bad == 0
+
+
+def test_flat_content_is_all_skip():
+    e = orc.OracleEncoder(256, 128, qp=32, period=64, me_range=8)
+    e.encode(orc.synth_frame(1, 1, 256, 128, 0))
+    au = e.encode(orc.synth_frame(1, 1, 256, 128, 1))
+    d = e.debug()
+    assert (d["cu_flags"] & 1).all() and (d["cu_log2"] == 5).all() and (d["cu_mv"] == 0).all()
+    assert len(au) < 40
+
+
+def test_parameter_sets_and_nal_structure():
+    e = orc.OracleEncoder(320, 240, qp=32, period=2, vps_period=1, me_range=4, fps=(25, 1))
+    d = orc.OracleDecoder()
+    types = []
+    for t in range(4):
+        au = e.encode(orc.synth_frame(0, 3, 320, 240, t))
+        nals = orc.split_nals(au)
+        types.append([n[4] >> 1 for n in nals])
+        fr = d.decode_au(au, t)
+        assert fr[0]["fps"] == (25, 1) and fr[0]["width"] == 320 and fr[0]["height"] == 240
+    assert types == [[32, 33, 34, 19], [1], [32, 33, 34, 19], [1]]
+
+
+def test_motion_is_found_and_signalled():
+    w, h = 256, 128
+    e = orc.OracleEncoder(w, h, qp=30, period=64, me_range=16)
+    rng = np.random.default_rng(3)
+    tex = rng.integers(30, 220, (h + 64, w + 64)).astype(np.uint8)
+
+    def frame(dx, dy):
+        y = tex[32 + dy:32 + dy + h, 32 + dx:32 + dx + w]
+        return np.concatenate([y.reshape(-1), np.full(w * h // 2, 128, np.uint8)])
+    e.encode(frame(0, 0))
+    e.encode(frame(5, -3))
+    d = e.debug()
+    inner = d["cu_mv"][2:-2, 2:-2]
+    assert (inner[..., 0] == 5 * 4).mean() > 0.9 and (inner[..., 1] == -3 * 4).mean() > 0.9
+    assert (d["cu_flags"][2:-2, 2:-2] & 2).mean() > 0.8          # neighbours share the vector: merge mode

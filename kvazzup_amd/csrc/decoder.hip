@@ -33,48 +33,84 @@ bool skip_ptl(BitReader &r, int max_sub_layers_minus1)
 }
 
 // ------------------------------------------------------------------------------------------ CABAC decoding (H.265 9.3.4.3)
-struct CabacDec {
-  const uint8_t *buf = nullptr; size_t len = 0, pos = 0;     // pos in bits; buf is padded with >= 8 readable bytes
-  uint32_t range = 510, offset = 0;
-  uint8_t ctx[CTX_COUNT];
-  uint32_t read(int n)
-  {
-    if (n == 0) return 0;
-    size_t byte = pos >> 3; int sh = (int)(pos & 7);
-    uint32_t w = ((uint32_t)buf[byte] << 24) | ((uint32_t)buf[byte + 1] << 16) | ((uint32_t)buf[byte + 2] << 8) | buf[byte + 3];
-    pos += (size_t)n;
-    return (w << sh) >> (32 - n);
-  }
-  bool overrun() const { return pos > len * 8 + 16; }
-  void start(const uint8_t *b, size_t l) { buf = b; len = l; pos = 0; range = 510; offset = read(9); }
-  int bin(int ci)
-  {
-    uint8_t s = ctx[ci]; int state = s >> 1, mps = s & 1;
-    uint32_t lps = kRangeLps[state][(range >> 6) & 3];
-    range -= lps;
-    if (offset >= range) {
-      offset -= range; range = lps;
-      int b = mps ^ 1;
-      if (!state) mps ^= 1;
-      ctx[ci] = (uint8_t)((kNextLps[state] << 1) | mps);
-      int n = __builtin_clz(range) - 23;
-      range <<= n; offset = (offset << n) | read(n);
-      return b;
+// Arithmetic decoder with the offset kept scaled in a 64-bit register: value = offset << bits | next
+// `bits` stream bits, so a renormalisation by n is just bits -= n and the stream is touched 32 bits at
+// a time.  Context variable = pStateIdx << 1 | valMps with precomputed transitions.
+struct StateTabs { uint8_t next_mps[128], next_lps[128]; };
+const StateTabs &state_tabs()
+{
+  static StateTabs t;
+  static bool ready = false;
+  if (!ready) {
+    for (int s = 0; s < 128; s++) {
+      int st = s >> 1, mps = s & 1;
+      t.next_mps[s] = (uint8_t)(((st < 62 ? st + 1 : st) << 1) | mps);
+      t.next_lps[s] = (uint8_t)((kNextLps[st] << 1) | (st == 0 ? mps ^ 1 : mps));
     }
-    ctx[ci] = (uint8_t)(((state < 62 ? state + 1 : state) << 1) | mps);
-    if (range < 256) { range <<= 1; offset = (offset << 1) | read(1); }
-    return mps;
+    ready = true;
   }
-  int bypass() { offset = (offset << 1) | read(1); if (offset >= range) { offset -= range; return 1; } return 0; }
-  uint32_t bypass_bits(int n) { uint32_t v = 0; for (int i = 0; i < n; i++) v = (v << 1) | (uint32_t)bypass(); return v; }
+  return t;
+}
+struct CabacDec {
+  const uint8_t *buf = nullptr, *p = nullptr; size_t len = 0;   // buf is padded with >= 16 readable bytes
+  uint64_t value = 0; int bits = 0;
+  uint32_t range = 510;
+  const StateTabs *st = nullptr;
+  uint8_t ctx[CTX_COUNT];
+  inline void refill()
+  {
+    if (bits < 16) {
+      uint32_t w = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+      value = (value << 32) | w; p += 4; bits += 32;
+    }
+  }
+  bool overrun() const { return (size_t)(p - buf) > len + 12; }
+  void start(const uint8_t *b, size_t l)
+  {
+    buf = b; p = b; len = l; st = &state_tabs(); range = 510;
+    value = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+    p += 4; bits = 32 - 9;
+    refill();
+  }
+  inline int bin(int ci)
+  {
+    const uint8_t s = ctx[ci];
+    const uint32_t lps = kRangeLps[s >> 1][(range >> 6) & 3];
+    range -= lps;
+    const uint64_t scaled = (uint64_t)range << bits;
+    int b = s & 1;
+    if (value >= scaled) {
+      value -= scaled; range = lps; b ^= 1;
+      ctx[ci] = st->next_lps[s];
+      const int n = __builtin_clz(range) - 23;
+      range <<= n; bits -= n;
+    } else {
+      ctx[ci] = st->next_mps[s];
+      if (range < 256) { range <<= 1; bits--; }
+    }
+    refill();
+    return b;
+  }
+  inline int bypass()
+  {
+    bits--;
+    const uint64_t scaled = (uint64_t)range << bits;
+    int b = 0;
+    if (value >= scaled) { value -= scaled; b = 1; }
+    refill();
+    return b;
+  }
+  inline uint32_t bypass_bits(int n) { uint32_t v = 0; for (int i = 0; i < n; i++) v = (v << 1) | (uint32_t)bypass(); return v; }
   int terminate()
   {
     range -= 2;
-    if (offset >= range) return 1;
-    if (range < 256) { range <<= 1; offset = (offset << 1) | read(1); }
+    if (value >= ((uint64_t)range << bits)) return 1;
+    if (range < 256) { range <<= 1; bits--; }
+    refill();
     return 0;
   }
-  size_t bytes_consumed() const { return (pos + 7) >> 3; }
+  // bytes from the start of the substream up to and including the byte holding the last consumed bit
+  size_t bytes_consumed() const { size_t consumed_bits = (size_t)(p - buf) * 8 - (size_t)bits; return (consumed_bits + 7) >> 3; }
 };
 
 std::atomic<long> g_yields{0};
@@ -86,11 +122,29 @@ const CoreTabs *host_tabs()
   return &g_tabs;
 }
 
+// scan position -> (x, y) for the three scans and block sizes 1..8 (H.265 6.5.3-6.5.5)
+struct ScanTabs { uint8_t x[3][4][64], y[3][4][64]; };
+const ScanTabs &scan_tabs()
+{
+  static ScanTabs t;
+  static bool ready = false;
+  if (!ready) {
+    const CoreTabs *ct = host_tabs();
+    for (int sc = 0; sc < 3; sc++) for (int l2 = 0; l2 < 4; l2++) for (int i = 0; i < (1 << (2 * l2)); i++) {
+      int x, y; scan_pos(ct, sc, l2, i, x, y); t.x[sc][l2][i] = (uint8_t)x; t.y[sc][l2][i] = (uint8_t)y;
+    }
+    ready = true;
+  }
+  return t;
+}
+
 // residual_coding() (7.3.8.11) without transform skip / sign hiding; writes n*n levels row-major
 bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, int16_t *out)
 {
   const CoreTabs *t = host_tabs();
+  const ScanTabs &S = scan_tabs();
   const int n = 1 << log2, sbl = log2 - 2, nsb = 1 << sbl;
+  const uint8_t *SX = S.x[scan_idx][sbl], *SY = S.y[scan_idx][sbl], *PX = S.x[scan_idx][2], *PY = S.y[scan_idx][2];
   uint8_t csbf[8][8]; memset(csbf, 0, sizeof(csbf));
   memset(out, 0, sizeof(int16_t) * (size_t)n * n);
   int pre[2];
@@ -109,12 +163,12 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, int16_t *out)
   for (;;) {
     if (last_pos == 0) { last_pos = 16; if (--last_sb < 0) return false; }
     last_pos--;
-    int xs, ys, xp, yp; scan_pos(t, scan_idx, sbl, last_sb, xs, ys); scan_pos(t, scan_idx, 2, last_pos, xp, yp);
+    const int xs = SX[last_sb], ys = SY[last_sb], xp = PX[last_pos], yp = PY[last_pos];
     if ((xs << 2) + xp == lx && (ys << 2) + yp == ly) break;
   }
   int c1 = 1;
   for (int i = last_sb; i >= 0; i--) {
-    int xs, ys; scan_pos(t, scan_idx, sbl, i, xs, ys);
+    const int xs = SX[i], ys = SY[i];
     int right = (xs < nsb - 1) ? csbf[ys][xs + 1] : 0, below = (ys < nsb - 1) ? csbf[ys + 1][xs] : 0, infer_dc = 0;
     if (i < last_sb && i > 0) { csbf[ys][xs] = (uint8_t)c.bin(CTX_CSBF + ((right | below) ? 1 : 0) + (cidx ? 2 : 0)); infer_dc = 1; }
     else csbf[ys][xs] = 1;
@@ -124,7 +178,7 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, int16_t *out)
     const int prev_csbf = right | (below << 1);
     for (int k = (i == last_sb) ? last_pos - 1 : 15; k >= 0; k--) {
       if (k > 0 || !infer_dc) {
-        int xp, yp; scan_pos(t, scan_idx, 2, k, xp, yp);
+        const int xp = PX[k], yp = PY[k];
         int xc = (xs << 2) + xp, yc = (ys << 2) + yp, sc;
         if (log2 == 2) sc = t->ctxmap4x4[(yc << 2) + xc];
         else if (xc + yc == 0) sc = 0;
@@ -166,7 +220,7 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, int16_t *out)
         if (lev[j] > 3 * (1 << rice)) rice = imin(rice + 1, 4);
       }
       int v = ((signs >> (nsig - 1 - j)) & 1) ? -lev[j] : lev[j];
-      int xp, yp; scan_pos(t, scan_idx, 2, pos[j], xp, yp);
+      const int xp = PX[pos[j]], yp = PY[pos[j]];
       out[((ys << 2) + yp) * n + (xs << 2) + xp] = (int16_t)clip3(-32768, 32767, v);
     }
   }
@@ -278,7 +332,7 @@ int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
   if (len < 3 || (data[0] & 0x80)) return last_error_ = DEC_ERR_INVALID;
   const int nal_type = (data[0] >> 1) & 0x3f, layer = ((data[0] & 1) << 5) | (data[1] >> 3);
   if (layer != 0) return 0;
-  rbsp_.assign(len + 16, 0);
+  rbsp_.assign(len + 32, 0);
   epb_.clear();
   size_t n = 0; int zeros = 0;
   for (size_t k = 2; k < len; k++) {

@@ -432,68 +432,129 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
   }
 }
 
-// Reconstruct one intra TU (plane cidx, component coordinates) and return whether it has levels.
-// All 256 threads participate.
-struct IntraScratch {
-  uint8_t raw[132], av[132], left[68], top[68], lf[68], tf[68];
+// Intra reconstruction keeps the CTU being coded, the row of samples above it (above + above-right CTU)
+// and the column to its left in LDS, so the reference samples of every block come from LDS instead of
+// a global-memory round trip per block; Cb and Cr are coded together as one two-block group.
+struct IntraLds {
+  uint8_t cur0[64 * 64], cur1[32 * 32], cur2[32 * 32];   // reconstruction of the current CTU
+  uint8_t top0[132], top1[68], top2[68];                 // [0] = above-left corner, [1 + x] = sample above, x < 2S
+  uint8_t lft0[64], lft1[32], lft2[32];                  // column left of the CTU
+  uint8_t raw[2][132], av[2][132], left[2][68], top[2][68], lf[2][68], tf[2][68];
   int a[1024], b[1024];
   int16_t lev[1024];
   uint8_t pred[1024];
   int8_t C[32][33];
   uint32_t nz;
 };
+__device__ __forceinline__ uint8_t *lds_cur(IntraLds &s, int c) { return c == 0 ? s.cur0 : (c == 1 ? s.cur1 : s.cur2); }
+__device__ __forceinline__ uint8_t *lds_top(IntraLds &s, int c) { return c == 0 ? s.top0 : (c == 1 ? s.top1 : s.top2); }
+__device__ __forceinline__ uint8_t *lds_lft(IntraLds &s, int c) { return c == 0 ? s.lft0 : (c == 1 ? s.lft1 : s.lft2); }
 
-template <bool DEC>
-__device__ __forceinline__ bool intra_recon_tu(const EncFrame &f, IntraScratch &s, int cidx, int x0, int y0, int l2, int mode, int qp, bool dec_has, int tid)
+// sample at CTU-relative component coordinates (x, y), x, y >= -1, from the LDS copies
+__device__ __forceinline__ int lds_sample(IntraLds &s, int c, int S, int x, int y)
 {
-  const int n = 1 << l2, pw = cidx ? (f.cw >> 1) : f.cw;
-  uint8_t *rec = f.rec[cidx];
-  build_intra_refs(rec, pw, cidx, f.cw, f.ch, x0, y0, n, s.raw, s.av, s.left, s.top, tid, 256);
-  const bool filt = intra_filter_needed(n, cidx, mode);
-  if (filt) filter_intra_refs(s.left, s.top, n, s.lf, s.tf, tid, 256);
-  const int dc = (mode == 1) ? intra_dc_value(s.left, s.top, n, l2) : 0;
+  if (y < 0) return lds_top(s, c)[x + 1];
+  if (x < 0) return lds_lft(s, c)[y];
+  return lds_cur(s, c)[y * S + x];
+}
+
+// Codes `npl` planes (first plane c0; 1 = luma alone, 2 = Cb and Cr together) of the CU at luma (X, Y),
+// block size n = 1 << l2 in component samples.  Returns the cbf bits of those planes (bit i = plane c0 + i).
+template <bool DEC>
+__device__ __forceinline__ int intra_recon_planes(const EncFrame &f, IntraLds &s, int c0, int npl, int X, int Y, int l2, int mode, int qp, int dec_cbf, int tid)
+{
+  const int n = 1 << l2, sh = c0 ? 1 : 0, S = c0 ? 32 : 64, pw = c0 ? (f.cw >> 1) : f.cw;
+  const int x0 = X >> sh, y0 = Y >> sh;                  // component coordinates in the picture
+  const int rx = x0 & (S - 1), ry = y0 & (S - 1);        // ... relative to the CTU
+  const int total = 4 * n + 1;
+  // ---- reference samples (8.4.4.2.2) from LDS
+  for (int w = tid; w < npl * total; w += 256) {
+    int pl = w / total, i = w - pl * total, x, y;
+    intra_ref_coord(x0, y0, n, i, x, y);
+    bool ok = avail64(f.cw, f.ch, X, Y, x << sh, y << sh);
+    s.av[pl][i] = ok;
+    s.raw[pl][i] = ok ? (uint8_t)lds_sample(s, c0 + pl, S, x - (x0 - rx), y - (y0 - ry)) : 0;
+  }
+  __syncthreads();
+  for (int w = tid; w < npl * total; w += 256) {
+    int pl = w / total, i = w - pl * total, j = i;
+    while (j >= 0 && !s.av[pl][j]) j--;
+    if (j < 0) { j = 0; while (j < total && !s.av[pl][j]) j++; }
+    uint8_t v = (j < total) ? s.raw[pl][j] : 128;
+    if (i < 2 * n) s.left[pl][2 * n - i] = v;
+    else if (i == 2 * n) { s.left[pl][0] = v; s.top[pl][0] = v; }
+    else s.top[pl][i - 2 * n] = v;
+  }
+  __syncthreads();
+  const bool filt = intra_filter_needed(n, c0, mode);    // luma only
+  if (filt) filter_intra_refs(s.left[0], s.top[0], n, s.lf[0], s.tf[0], tid, 256);
   if (tid == 0) s.nz = 0;
-  for (int o = tid; o < n * n; o += 256) {
-    int y = o >> l2, x = o & (n - 1);
-    int p = intra_pred_sample(filt ? s.lf : s.left, filt ? s.tf : s.top, n, l2, cidx, mode, dc, x, y);
+  int dcv[2] = {0, 0};
+  if (mode == 1) for (int pl = 0; pl < npl; pl++) dcv[pl] = intra_dc_value(s.left[pl], s.top[pl], n, l2);   // DC is never filtered
+  // ---- prediction and residual (encoder) / dequantised levels (decoder)
+  for (int o = tid; o < npl * n * n; o += 256) {
+    int pl = o >> (2 * l2), r = o & (n * n - 1), y = r >> l2, x = r & (n - 1);
+    const uint8_t *L = filt ? s.lf[0] : s.left[pl], *T = filt ? s.tf[0] : s.top[pl];
+    int p = intra_pred_sample(L, T, n, l2, c0, mode, pl ? dcv[1] : dcv[0], x, y);
     s.pred[o] = (uint8_t)p;
-    if (DEC) s.b[o] = dec_has ? dequant_coef(f.coef[cidx][(y0 + y) * pw + x0 + x], qp, l2) : 0;
-    else s.a[o] = (int)f.src[cidx][(y0 + y) * pw + x0 + x] - p;
+    int g = (y0 + y) * pw + x0 + x;
+    if (DEC) s.b[o] = ((dec_cbf >> pl) & 1) ? dequant_coef(f.coef[c0 + pl][g], qp, l2) : 0;
+    else s.a[o] = (int)f.src[c0 + pl][g] - p;
   }
   __syncthreads();
-  if (DEC) { if (dec_has) inverse_group(s.a, s.b, s.C, l2, n * n, 256, tid); }
-  else code_group(s.a, s.b, s.lev, s.C, l2, 1, qp, 1, &s.nz, 256, tid);
-  const bool has = DEC ? dec_has : (s.nz != 0);
-  for (int o = tid; o < n * n; o += 256) {
-    int y = o >> l2, x = o & (n - 1), g = (y0 + y) * pw + x0 + x;
-    rec[g] = (uint8_t)(has ? clip8(s.pred[o] + s.b[o]) : s.pred[o]);
-    if (has && !DEC) f.coef[cidx][g] = s.lev[o];
+  if (DEC) { if (dec_cbf) inverse_group(s.a, s.b, s.C, l2, npl * n * n, 256, tid); }
+  else code_group(s.a, s.b, s.lev, s.C, l2, npl, qp, 1, &s.nz, 256, tid);
+  const int cbf = DEC ? dec_cbf : (int)s.nz;
+  for (int o = tid; o < npl * n * n; o += 256) {
+    int pl = o >> (2 * l2), r = o & (n * n - 1), y = r >> l2, x = r & (n - 1);
+    bool has = (cbf >> pl) & 1;
+    uint8_t v = (uint8_t)(has ? clip8(s.pred[o] + s.b[o]) : s.pred[o]);
+    int g = (y0 + y) * pw + x0 + x;
+    f.rec[c0 + pl][g] = v;
+    lds_cur(s, c0 + pl)[(ry + y) * S + rx + x] = v;
+    if (has && !DEC) f.coef[c0 + pl][g] = s.lev[o];
   }
   __syncthreads();
-  return has;
+  return cbf;
 }
 
 template <bool DEC>
 __global__ __launch_bounds__(256) void k_intra_recon(EncFrame f)
 {
-  __shared__ IntraScratch s;
+  __shared__ IntraLds s;
   const int tid = threadIdx.x, row = blockIdx.x, wc = f.cw >> 6;
   load_dct_matrix(s.C, tid, 256);
   __syncthreads();
   for (int cx = 0; cx < wc; cx++) {
-    if (row > 0) wait_progress(&f.sync[row - 1], (uint32_t)imin(cx + 2, wc), f.err);
+    // left border <- right column of the CTU just finished (before it is overwritten)
+    if (cx > 0) {
+      for (int i = tid; i < 128; i += 256) {
+        if (i < 64) s.lft0[i] = s.cur0[i * 64 + 63];
+        else if (i < 96) s.lft1[i - 64] = s.cur1[(i - 64) * 32 + 31];
+        else s.lft2[i - 96] = s.cur2[(i - 96) * 32 + 31];
+      }
+    }
+    if (row > 0) {
+      wait_progress(&f.sync[row - 1], (uint32_t)imin(cx + 2, wc), f.err);
+      // top border <- last row of the CTU row above (above-left corner, above, above-right), clipped to the picture
+      for (int i = tid; i < 129 + 65 + 65; i += 256) {
+        int c = i < 129 ? 0 : (i < 194 ? 1 : 2), k = i < 129 ? i : (i < 194 ? i - 129 : i - 194);
+        int S = c ? 32 : 64, pw = c ? (f.cw >> 1) : f.cw;
+        int x = cx * S - 1 + k, y = row * S - 1;
+        if (x >= 0 && x < pw) lds_top(s, c)[k] = f.rec[c][y * pw + x];
+      }
+    }
+    __syncthreads();
     for (int z = 0; z < 64;) {
-      int xi = 0, yi = 0;
-      for (int bb = 0; bb < 3; bb++) { xi |= ((z >> (2 * bb)) & 1) << bb; yi |= ((z >> (2 * bb + 1)) & 1) << bb; }
-      int x0 = cx * 64 + xi * 8, y0 = row * 64 + yi * 8;
-      int bi = b8idx(f, x0, y0);
-      int l2 = f.cu_log2[bi], mode = f.cu_intra_mode[bi];
+      int xi, yi; ctu_z_to_xy(z, xi, yi);
+      const int X = cx * 64 + xi * 8, Y = row * 64 + yi * 8;
+      const int bi = b8idx(f, X, Y);
+      const int l2 = f.cu_log2[bi], mode = f.cu_intra_mode[bi];
       const int given = DEC ? f.cu_cbf[bi] : 0;
-      int cbf = intra_recon_tu<DEC>(f, s, 0, x0, y0, l2, mode, f.qp, given & 1, tid) ? 1 : 0;
-      cbf |= intra_recon_tu<DEC>(f, s, 1, x0 >> 1, y0 >> 1, l2 - 1, mode, f.qpc, (given >> 1) & 1, tid) ? 2 : 0;
-      cbf |= intra_recon_tu<DEC>(f, s, 2, x0 >> 1, y0 >> 1, l2 - 1, mode, f.qpc, (given >> 2) & 1, tid) ? 4 : 0;
+      int cbf = intra_recon_planes<DEC>(f, s, 0, 1, X, Y, l2, mode, f.qp, given & 1, tid);
+      cbf |= intra_recon_planes<DEC>(f, s, 1, 2, X, Y, l2 - 1, mode, f.qpc, (given >> 1) & 3, tid) << 1;
       int nb = 1 << (l2 - 3);
-      if (!DEC && tid < nb * nb) f.cu_cbf[b8idx(f, x0 + (tid % nb) * 8, y0 + (tid / nb) * 8)] = (uint8_t)cbf;
+      if (!DEC && tid < nb * nb) f.cu_cbf[b8idx(f, X + (tid % nb) * 8, Y + (tid / nb) * 8)] = (uint8_t)cbf;
       z += 1 << (2 * (l2 - 3));
     }
     publish_progress(&f.sync[row], (uint32_t)(cx + 1));

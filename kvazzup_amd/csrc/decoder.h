@@ -18,7 +18,12 @@
 #include <stdint.h>
 #include <string>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 #include "hevc_core.h"
 #include "host_pool.h"
@@ -51,9 +56,31 @@ struct DecodedPicture {
   int poc = 0; int64_t pts = 0; uint32_t fps_num = 0, fps_den = 0; bool is_intra = false;
 };
 
+// worker threads that parse whole pictures concurrently (frame threading)
+class FrameWorkers {
+ public:
+  explicit FrameWorkers(int n) { for (int i = 0; i < n; i++) t_.emplace_back([this] { run(); }); }
+  ~FrameWorkers() { { std::lock_guard<std::mutex> l(m_); quit_ = true; } cv_.notify_all(); for (auto &t : t_) t.join(); }
+  void submit(std::function<void()> f) { { std::lock_guard<std::mutex> l(m_); q_.push_back(std::move(f)); } cv_.notify_one(); }
+ private:
+  void run()
+  {
+    for (;;) {
+      std::function<void()> f;
+      { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [this] { return quit_ || !q_.empty(); }); if (q_.empty()) return; f = std::move(q_.front()); q_.pop_front(); }
+      f();
+    }
+  }
+  std::vector<std::thread> t_; std::mutex m_; std::condition_variable cv_; std::deque<std::function<void()>> q_; bool quit_ = false;
+};
+
 class Decoder {
  public:
   explicit Decoder(int device) : device_(device) {}
+  // frame threading: up to n pictures are parsed concurrently and the output is delayed by n - 1 pictures
+  // (libOpenHevcInit(nb_threads, OH_THREAD_FRAME / OH_THREAD_FRAMESLICE)); call before the first picture
+  void set_frame_threads(int n) { if (jobs_.empty()) frame_threads_ = n < 1 ? 1 : (n > 16 ? 16 : n); }
+  int frame_threads() const { return frame_threads_; }
   ~Decoder();
   bool start(std::string *error);           // checks the HIP device; no CPU fallback
   // One NAL unit (with or without start code).  <0 error/unsupported, 0 nothing to output, 1 picture ready.
@@ -66,25 +93,42 @@ class Decoder {
   bool debug_copy(const char *what, void *dst, size_t bytes);
   int last_error() const { return last_error_; }
   void flush() {}
+  int pending() const { return (int)(job_head_ - job_tail_); }
 
  private:
   bool ensure_buffers(int cw, int ch);
   void free_buffers();
   int decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t pts);
   struct RowState { std::vector<int16_t> levels; std::vector<TuDesc> tus; int rc = 0; };
-  int parse_slice_data(const uint8_t *data, size_t len, int slice_qp, bool is_intra, int max_merge);
-  int parse_row(int row, const uint8_t *data, size_t len, int slice_qp, bool is_intra, int max_merge, RowState &rs);
-  int run_gpu(bool is_intra, int slice_qp, bool deblock);
+  struct alignas(64) Progress { std::atomic<int> v{0}; char pad[60]; };   // one cache line per row: no false sharing between pollers
+  // everything one picture needs between its slice header and its reconstruction
+  struct PicJob {
+    std::vector<uint8_t> rbsp; size_t data_off = 0, data_len = 0;
+    std::vector<size_t> sub_start;
+    int slice_qp = 0, max_merge = 5, poc = 0; bool is_intra = false, deblock = true; int64_t pts = 0;
+    int crop[4] = {0, 0, 0, 0}; uint32_t fps_num = 0, fps_den = 0;
+    uint8_t *h_cu = nullptr; int16_t *h_mv = nullptr;        // pinned; same layout as the encoder's per-8x8 arrays
+    EncFrame hf{};
+    std::vector<int16_t> levels; std::vector<TuDesc> tus;
+    std::vector<RowState> rows; std::vector<uint8_t> wpp_saved;
+    std::unique_ptr<Progress[]> row_progress; int row_progress_n = 0;
+    std::atomic<int> state{0}; int rc = 0; double parse_ms = 0;
+    PicJob() {}
+    PicJob(const PicJob &) {}                                  // (vector<PicJob> construction only)
+  };
+  int parse_job(PicJob &job, bool row_parallel);
+  int parse_row(PicJob &job, int row, const uint8_t *data, size_t len, RowState &rs);
+  int finish_oldest();
+  void drop_pending();
+  int run_gpu(PicJob &job);
 
   int device_; bool started_ = false;
   hipStream_t stream_ = nullptr;
   DecSps sps_[16]; DecPps pps_[64]; uint32_t vps_fps_num_ = 0, vps_fps_den_ = 0;
   int cw_ = 0, ch_ = 0;
-  // host side picture description (pinned), same layout as the encoder's per-8x8 arrays
-  uint8_t *h_cu_ = nullptr; int16_t *h_mv_ = nullptr;
-  std::vector<int16_t> levels_; std::vector<TuDesc> tus_;
+  std::vector<PicJob> jobs_; int frame_threads_ = 1; long job_head_ = 0, job_tail_ = 0;
+  std::unique_ptr<FrameWorkers> workers_;
   int16_t *h_levels_ = nullptr; size_t h_levels_cap_ = 0; TuDesc *h_tus_ = nullptr; size_t h_tus_cap_ = 0;
-  EncFrame hf_{};                          // host view (pointers into h_cu_ / h_mv_)
   // device side
   EncFrame f_{};
   uint8_t *d_cu_ = nullptr; int16_t *d_mv_ = nullptr, *d_mvd_ = nullptr;
@@ -102,10 +146,6 @@ class Decoder {
   std::vector<uint8_t> rbsp_;
   std::vector<size_t> epb_;                // unescaped payload offset of every removed emulation prevention byte
   std::vector<size_t> sub_start_;          // start of every WPP substream inside the unescaped slice data
-  std::vector<RowState> rows_;
-  std::vector<uint8_t> wpp_saved_;
-  struct alignas(64) Progress { std::atomic<int> v{0}; char pad[60]; };   // one cache line per row: no false sharing between pollers
-  std::unique_ptr<Progress[]> row_progress_; int row_progress_n_ = 0;
   std::unique_ptr<OrderedPool> pool_; int parse_threads_ = 16;
   struct EvPair { hipEvent_t a, b; int id; };
   std::vector<EvPair> ev_pool_; size_t ev_used_ = 0;

@@ -230,8 +230,20 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, int16_t *out)
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ lifecycle
+// Pictures still being parsed by frame workers are waited for and dropped (close / resolution change).
+void Decoder::drop_pending()
+{
+  for (; job_tail_ != job_head_; job_tail_++) {
+    PicJob &job = jobs_[(size_t)(job_tail_ % frame_threads_)];
+    while (job.state.load(std::memory_order_acquire) != 2) std::this_thread::yield();
+    job.state.store(0, std::memory_order_relaxed);
+  }
+}
+
 Decoder::~Decoder()
 {
+  drop_pending();
+  workers_.reset();
   if (stream_) hipStreamSynchronize(stream_);
   for (auto &e : ev_pool_) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   free_buffers();
@@ -262,26 +274,29 @@ bool Decoder::start(std::string *error)
 
 void Decoder::free_buffers()
 {
-  if (h_cu_) hipHostFree(h_cu_);
-  if (h_mv_) hipHostFree(h_mv_);
+  for (auto &j : jobs_) { if (j.h_cu) hipHostFree(j.h_cu); if (j.h_mv) hipHostFree(j.h_mv); j.h_cu = nullptr; j.h_mv = nullptr; }
   if (h_out_) hipHostFree(h_out_);
   hipFree(d_cu_); hipFree(d_mv_); hipFree(d_mvd_); hipFree(sync_);
   for (int c = 0; c < 3; c++) { hipFree(rec_[0][c]); hipFree(rec_[1][c]); hipFree(coef_[c]); rec_[0][c] = rec_[1][c] = nullptr; coef_[c] = nullptr; }
-  h_cu_ = nullptr; h_mv_ = nullptr; h_out_ = nullptr; d_cu_ = nullptr; d_mv_ = nullptr; d_mvd_ = nullptr; sync_ = nullptr;
+  h_out_ = nullptr; d_cu_ = nullptr; d_mv_ = nullptr; d_mvd_ = nullptr; sync_ = nullptr;
   cw_ = ch_ = 0;
 }
 
 bool Decoder::ensure_buffers(int cw, int ch)
 {
   if (cw == cw_ && ch == ch_) return true;
+  drop_pending();                                          // (resolution change: pictures not yet output are dropped)
   hipStreamSynchronize(stream_);
   free_buffers();
   const size_t npx = (size_t)cw * ch, nb8 = npx / 64;
-  HIP_TRY(hipHostMalloc(&h_cu_, nb8 * 7, hipHostMallocDefault));
-  HIP_TRY(hipHostMalloc(&h_mv_, nb8 * 2 * sizeof(int16_t), hipHostMallocDefault));
+  if (jobs_.empty()) jobs_ = std::vector<PicJob>((size_t)frame_threads_);
+  for (auto &j : jobs_) {
+    HIP_TRY(hipHostMalloc(&j.h_cu, nb8 * 7, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&j.h_mv, nb8 * 2 * sizeof(int16_t), hipHostMallocDefault));
+    memset(j.h_cu, 0, nb8 * 7); memset(j.h_mv, 0, nb8 * 4);
+  }
   HIP_TRY(hipHostMalloc(&h_out_, npx * 3 / 2, hipHostMallocDefault));
   h_out_cap_ = npx * 3 / 2;
-  memset(h_cu_, 0, nb8 * 7); memset(h_mv_, 0, nb8 * 4);
   HIP_TRY(hipMalloc(&d_cu_, nb8 * 7));
   HIP_TRY(hipMalloc(&d_mv_, nb8 * 2 * sizeof(int16_t)));
   HIP_TRY(hipMalloc(&d_mvd_, nb8 * 2 * sizeof(int16_t)));
@@ -299,7 +314,7 @@ bool Decoder::ensure_buffers(int cw, int ch)
     f.cu_log2 = cu; f.cu_intra = cu + nb8; f.cu_flags = cu + 2 * nb8; f.cu_merge_idx = cu + 3 * nb8;
     f.cu_mvp_idx = cu + 4 * nb8; f.cu_intra_mode = cu + 5 * nb8; f.cu_cbf = cu + 6 * nb8; f.cu_mv = mv;
   };
-  fill(hf_, h_cu_, h_mv_);
+  for (auto &j : jobs_) fill(j.hf, j.h_cu, j.h_mv);
   fill(f_, d_cu_, d_mv_);
   f_.cu_mvd = d_mvd_;
   for (int c = 0; c < 3; c++) f_.coef[c] = coef_[c];
@@ -329,7 +344,7 @@ int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
   size_t i = 0;
   while (i + 2 < len && data[i] == 0) i++;
   if (i >= 2 && i < len && data[i] == 1) { data += i + 1; len -= i + 1; }
-  if (len < 3 || (data[0] & 0x80)) return last_error_ = DEC_ERR_INVALID;
+  if (len < 2 || (data[0] & 0x80)) return last_error_ = DEC_ERR_INVALID;      // EOS / EOB are header-only
   const int nal_type = (data[0] >> 1) & 0x3f, layer = ((data[0] & 1) << 5) | (data[1] >> 3);
   if (layer != 0) return 0;
   rbsp_.assign(len + 32, 0);
@@ -421,6 +436,7 @@ int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
     p.valid = true; pps_[id] = p;
     return 0;
   }
+  if (nal_type == 36 || nal_type == 37) { int rc = finish_oldest(); if (rc < 0) last_error_ = rc; return rc; }   // EOS / EOB: drain one delayed picture
   if (nal_type > 31) return 0;                                    // AUD / SEI / ...
   if (!(nal_type == 0 || nal_type == 1 || nal_type == 19 || nal_type == 20)) return last_error_ = DEC_ERR_UNSUPPORTED;
   int rc = decode_slice(rbsp_.data(), n, nal_type, pts);
@@ -500,22 +516,60 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   }
   if (!ensure_buffers(s.width, s.height)) return DEC_ERR_GPU;
   active_sps_ = &s;
-  hf_.is_intra = is_intra; hf_.wpp = p.wpp; hf_.qp = slice_qp;
-  auto t0 = std::chrono::steady_clock::now();
-  int rc = parse_slice_data(rbsp + (r.pos >> 3), len - (r.pos >> 3), slice_qp, is_intra, max_merge);
-  if (profiling_) { k_ms_[DK_HOST_PARSE] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); k_n_[DK_HOST_PARSE]++; }
+  // ---- hand the picture to a parse job.  With frame threads (libOpenHevcInit thread_type FRAME / FRAMESLICE)
+  // up to `frame_threads_` pictures are parsed concurrently on worker threads -- CABAC parsing of a picture
+  // needs nothing from other pictures -- and the output is delayed accordingly, like OpenHEVC's frame threading.
+  PicJob &job = jobs_[(size_t)(job_head_ % frame_threads_)];
+  job.rbsp.assign(rbsp, rbsp + len + 32);                        // keeps the zero padding the CABAC reader relies on
+  job.data_off = r.pos >> 3; job.data_len = len - (r.pos >> 3);
+  job.sub_start = sub_start_;
+  job.slice_qp = slice_qp; job.is_intra = is_intra; job.max_merge = max_merge; job.deblock = deblock; job.poc = poc; job.pts = pts;
+  job.crop[0] = s.crop_l; job.crop[1] = s.crop_r; job.crop[2] = s.crop_t; job.crop[3] = s.crop_b;
+  job.fps_num = s.fps_num ? s.fps_num : vps_fps_num_; job.fps_den = s.fps_num ? s.fps_den : vps_fps_den_;
+  job.hf.is_intra = is_intra; job.hf.wpp = p.wpp; job.hf.qp = slice_qp;
+  job.rc = 0;
+  prev_poc_ = poc; have_ref_ = true;                             // header checks of the next picture run before this one is reconstructed
+  job_head_++;
+  if (frame_threads_ == 1) {
+    auto t0 = std::chrono::steady_clock::now();
+    job.rc = parse_job(job, true);
+    if (profiling_) { k_ms_[DK_HOST_PARSE] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); k_n_[DK_HOST_PARSE]++; }
+    job.state.store(2, std::memory_order_release);
+  } else {
+    job.state.store(1, std::memory_order_release);
+    if (!workers_) workers_.reset(new FrameWorkers(frame_threads_));
+    PicJob *jp = &job;
+    workers_->submit([this, jp] {
+      auto t0 = std::chrono::steady_clock::now();
+      jp->rc = parse_job(*jp, false);
+      jp->parse_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      jp->state.store(2, std::memory_order_release);
+    });
+  }
+  if (job_head_ - job_tail_ < frame_threads_) return 0;          // pipeline still filling: no output for this NAL
+  return finish_oldest();
+}
+
+// Waits for the oldest submitted picture to be parsed, reconstructs it on the GPU and makes it the output.
+int Decoder::finish_oldest()
+{
+  if (job_head_ == job_tail_) return 0;
+  PicJob &job = jobs_[(size_t)(job_tail_ % frame_threads_)];
+  job_tail_++;
+  while (job.state.load(std::memory_order_acquire) != 2) std::this_thread::yield();
+  job.state.store(0, std::memory_order_relaxed);
+  if (frame_threads_ > 1 && profiling_) { k_ms_[DK_HOST_PARSE] += job.parse_ms; k_n_[DK_HOST_PARSE]++; }
+  if (job.rc < 0) return job.rc;
+  int rc = run_gpu(job);
   if (rc < 0) return rc;
-  rc = run_gpu(is_intra, slice_qp, deblock);
-  if (rc < 0) return rc;
-  poc_ = poc; prev_poc_ = poc;
-  // output description
+  poc_ = job.poc;
   out_ = DecodedPicture();
   out_.coded_w = cw_; out_.coded_h = ch_;
-  out_.width = cw_ - s.crop_l - s.crop_r; out_.height = ch_ - s.crop_t - s.crop_b;
-  out_.poc = poc; out_.pts = pts; out_.is_intra = is_intra;
-  out_.fps_num = s.fps_num ? s.fps_num : vps_fps_num_; out_.fps_den = s.fps_num ? s.fps_den : vps_fps_den_;
+  out_.width = cw_ - job.crop[0] - job.crop[1]; out_.height = ch_ - job.crop[2] - job.crop[3];
+  out_.poc = job.poc; out_.pts = job.pts; out_.is_intra = job.is_intra;
+  out_.fps_num = job.fps_num; out_.fps_den = job.fps_den;
   for (int c = 0; c < 3; c++) {
-    int pw = c ? cw_ / 2 : cw_, ox = c ? s.crop_l / 2 : s.crop_l, oy = c ? s.crop_t / 2 : s.crop_t;
+    int pw = c ? cw_ / 2 : cw_, ox = c ? job.crop[0] / 2 : job.crop[0], oy = c ? job.crop[2] / 2 : job.crop[2];
     out_.dev[c] = rec_[ref_idx_][c] + (size_t)oy * pw + ox; out_.dev_pitch[c] = pw;
   }
   if (download_) {
@@ -539,10 +593,11 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
 // One task per WPP substream (CTU row), run by a pool of host threads.  Row r follows row r-1 at
 // a distance of two CTUs: it starts from the context states saved after the second CTU of the row
 // above and needs that row's CU records up to the above-right CTU.
-int Decoder::parse_row(int row, const uint8_t *data, size_t len, int slice_qp, bool is_intra, int max_merge, RowState &rs)
+int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, RowState &rs)
 {
   const int wc = cw_ / 64, hc = ch_ / 64;
-  EncFrame &f = hf_;
+  const int slice_qp = job.slice_qp, max_merge = job.max_merge; const bool is_intra = job.is_intra;
+  EncFrame &f = job.hf;
   FrameView v; v.f = &f;
   CabacDec c;
   const bool wpp = f.wpp != 0;
@@ -552,7 +607,7 @@ int Decoder::parse_row(int row, const uint8_t *data, size_t len, int slice_qp, b
     if (!wpp || cy == 0) return true;
     if (need > wc) need = wc;
     if (seen_above < need) {
-      std::atomic<int> &p = row_progress_[(size_t)(cy - 1)].v;
+      std::atomic<int> &p = job.row_progress[(size_t)(cy - 1)].v;
       int spins = 0;
       while ((seen_above = p.load(std::memory_order_acquire)) < need) {
         if (++spins < 2000) __builtin_ia32_pause(); else { g_yields.fetch_add(1, std::memory_order_relaxed); std::this_thread::yield(); }
@@ -564,7 +619,7 @@ int Decoder::parse_row(int row, const uint8_t *data, size_t len, int slice_qp, b
   if (row == 0 || !wpp) cabac_init_contexts(c.ctx, is_intra ? 0 : 1, slice_qp);
   else {
     if (!wait_above(row, 2)) return DEC_ERR_INVALID;
-    memcpy(c.ctx, &wpp_saved_[(size_t)(row - 1) * CTX_COUNT], CTX_COUNT);
+    memcpy(c.ctx, &job.wpp_saved[(size_t)(row - 1) * CTX_COUNT], CTX_COUNT);
   }
   int16_t blk[32 * 32];
   for (int cy = first_cy; cy < first_cy + ncy; cy++) {
@@ -660,8 +715,8 @@ int Decoder::parse_row(int row, const uint8_t *data, size_t len, int slice_qp, b
         if (c.overrun()) return DEC_ERR_INVALID;
         z += 1 << (2 * (log2 - 3));
       }
-      if (wpp && cx == 1) memcpy(&wpp_saved_[(size_t)cy * CTX_COUNT], c.ctx, CTX_COUNT);
-      if (wpp) row_progress_[(size_t)cy].v.store(cx + 1, std::memory_order_release);
+      if (wpp && cx == 1) memcpy(&job.wpp_saved[(size_t)cy * CTX_COUNT], c.ctx, CTX_COUNT);
+      if (wpp) job.row_progress[(size_t)cy].v.store(cx + 1, std::memory_order_release);
       const bool last = (cy == hc - 1 && cx == wc - 1);
       int end = c.terminate();
       if (end != (last ? 1 : 0)) return DEC_ERR_UNSUPPORTED;      // slice must cover the whole picture
@@ -671,46 +726,45 @@ int Decoder::parse_row(int row, const uint8_t *data, size_t len, int slice_qp, b
   return 0;
 }
 
-int Decoder::parse_slice_data(const uint8_t *data, size_t len, int slice_qp, bool is_intra, int max_merge)
+int Decoder::parse_job(PicJob &job, bool row_parallel)
 {
-  const int hc = ch_ / 64, nsub = hf_.wpp ? hc : 1;
-  if ((int)sub_start_.size() != nsub) return DEC_ERR_INVALID;
-  for (int r = 0; r < nsub; r++) if (sub_start_[(size_t)r] >= len) return DEC_ERR_INVALID;
-  rows_.resize((size_t)nsub);
-  for (auto &r : rows_) { r.levels.clear(); r.tus.clear(); r.rc = 0; }
-  wpp_saved_.resize((size_t)hc * CTX_COUNT);
-  if (!row_progress_ || row_progress_n_ < hc) { row_progress_.reset(new Progress[(size_t)hc]); row_progress_n_ = hc; }
-  for (int r = 0; r < hc; r++) row_progress_[(size_t)r].v.store(0, std::memory_order_relaxed);
-  if (!pool_) { const char *e = getenv("KVAZZUP_AMD_PARSE_THREADS"); if (e) parse_threads_ = atoi(e) < 1 ? 1 : atoi(e); pool_.reset(new OrderedPool(parse_threads_)); }
-  static const bool trace = getenv("KVAZZUP_AMD_TRACE") != nullptr;
-  std::vector<double> busy((size_t)nsub, 0.0), t_start((size_t)nsub, 0.0);
-  auto tp0 = std::chrono::steady_clock::now();
-  pool_->run(nsub, [&](int r) {
-    auto ta = std::chrono::steady_clock::now();
-    size_t start = sub_start_[(size_t)r], end = (r + 1 < nsub) ? sub_start_[(size_t)r + 1] : len;
-    int rc = parse_row(r, data + start, end - start, slice_qp, is_intra, max_merge, rows_[(size_t)r]);
-    if (trace) { busy[(size_t)r] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta).count(); t_start[(size_t)r] = std::chrono::duration<double, std::micro>(ta - tp0).count(); }
-    rows_[(size_t)r].rc = rc;
-    if (rc < 0 && hf_.wpp) row_progress_[(size_t)r].v.store(1 << 30, std::memory_order_release);   // release any waiter
-  });
-  if (trace) {
-    double wall = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp0).count(), sum = 0, mx = 0;
-    for (double b : busy) { sum += b; if (b > mx) mx = b; }
-    fprintf(stderr, "[trace] parse: wall %.0f us, rows %d, busy sum %.0f max %.0f, start of last row %.0f us, bytes %zu | row0 %.0f row1 %.0f row8 %.0f yields %ld\n", wall, nsub, sum, mx, t_start[(size_t)nsub - 1], len, busy[0], nsub > 1 ? busy[1] : 0.0, nsub > 8 ? busy[8] : 0.0, (long)g_yields.exchange(0));
+  const uint8_t *data = job.rbsp.data() + job.data_off; const size_t len = job.data_len;
+  const int hc = ch_ / 64, nsub = job.hf.wpp ? hc : 1;
+  if ((int)job.sub_start.size() != nsub) return DEC_ERR_INVALID;
+  for (int r = 0; r < nsub; r++) if (job.sub_start[(size_t)r] >= len) return DEC_ERR_INVALID;
+  job.rows.resize((size_t)nsub);
+  for (auto &r : job.rows) { r.levels.clear(); r.tus.clear(); r.rc = 0; }
+  job.wpp_saved.resize((size_t)hc * CTX_COUNT);
+  if (!job.row_progress || job.row_progress_n < hc) { job.row_progress.reset(new Progress[(size_t)hc]); job.row_progress_n = hc; }
+  for (int r = 0; r < hc; r++) job.row_progress[(size_t)r].v.store(0, std::memory_order_relaxed);
+  auto one = [&](int r) {
+    size_t start = job.sub_start[(size_t)r], end = (r + 1 < nsub) ? job.sub_start[(size_t)r + 1] : len;
+    int rc = parse_row(job, r, data + start, end - start, job.rows[(size_t)r]);
+    job.rows[(size_t)r].rc = rc;
+    if (rc < 0 && job.hf.wpp) job.row_progress[(size_t)r].v.store(1 << 30, std::memory_order_release);   // release any waiter
+  };
+  if (row_parallel && nsub > 1) {
+    if (!pool_) { const char *e = getenv("KVAZZUP_AMD_PARSE_THREADS"); if (e) parse_threads_ = atoi(e) < 1 ? 1 : atoi(e); pool_.reset(new OrderedPool(parse_threads_)); }
+    pool_->run(nsub, one);
+  } else {
+    for (int r = 0; r < nsub; r++) one(r);              // frame-parallel mode: rows in sequence on this worker
   }
-  levels_.clear(); tus_.clear();
-  for (auto &r : rows_) {
+  job.levels.clear(); job.tus.clear();
+  for (auto &r : job.rows) {
     if (r.rc < 0) return r.rc;
-    uint32_t base = (uint32_t)levels_.size();
-    for (TuDesc td : r.tus) { td.offset += base; tus_.push_back(td); }
-    levels_.insert(levels_.end(), r.levels.begin(), r.levels.end());
+    uint32_t base = (uint32_t)job.levels.size();
+    for (TuDesc td : r.tus) { td.offset += base; job.tus.push_back(td); }
+    job.levels.insert(job.levels.end(), r.levels.begin(), r.levels.end());
   }
   return 0;
 }
 
 // ------------------------------------------------------------------------------------------ GPU reconstruction
-int Decoder::run_gpu(bool is_intra, int slice_qp, bool deblock)
+int Decoder::run_gpu(PicJob &job)
 {
+  const bool is_intra = job.is_intra, deblock = job.deblock; const int slice_qp = job.slice_qp;
+  std::vector<int16_t> &levels_ = job.levels; std::vector<TuDesc> &tus_ = job.tus;
+  uint8_t *h_cu_ = job.h_cu; int16_t *h_mv_ = job.h_mv;
   if (hipSetDevice(device_) != hipSuccess) return DEC_ERR_GPU;
   const size_t nb8 = (size_t)cw_ * ch_ / 64;
   const size_t nlev = levels_.size(), ntu = tus_.size();
@@ -756,7 +810,6 @@ int Decoder::run_gpu(bool is_intra, int slice_qp, bool deblock)
     ev_used_ = 0;
   }
   int t = cur_idx_; cur_idx_ = ref_idx_; ref_idx_ = t;          // rec_[ref_idx_] = picture just decoded
-  have_ref_ = true;
   return 0;
 }
 

@@ -41,6 +41,7 @@ OpenHevc_Handle libOpenHevcInit(int nb_pthreads, int thread_type)
   h->threads = nb_pthreads; h->thread_type = thread_type;       // accepted; the GPU does the sample work
   const char *env = getenv("KVAZZUP_AMD_DEVICE");
   h->dec = new Decoder(env ? atoi(env) : 0);
+  if ((thread_type & 1) && nb_pthreads > 1) h->dec->set_frame_threads(nb_pthreads);   // OH_THREAD_FRAME / OH_THREAD_FRAMESLICE
   return (OpenHevc_Handle)h;
 }
 int libOpenHevcStartDecoder(OpenHevc_Handle hh)
@@ -110,8 +111,10 @@ int kvzx_decoder_set_device(OpenHevc_Handle hh, int device)
 {
   Handle *h = H(hh);
   if (!h || h->started || device < 0) return 0;
+  int ft = h->dec->frame_threads();
   delete h->dec;
   h->dec = new Decoder(device);
+  h->dec->set_frame_threads(ft);
   return 1;
 }
 int kvzx_decoder_last_error(OpenHevc_Handle hh) { Handle *h = H(hh); return h ? h->dec->last_error() : -1; }

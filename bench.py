@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=6)
     ap.add_argument("--decoder-frame-threads", type=int, default=4,
                     help="OpenHEVC 'Frame' parallelisation (uvgComm setting video/OH_parallelization): pictures parsed concurrently; 1 = off")
+    ap.add_argument("--owf", type=int, default=1,
+                    help="uvgComm setting video/OWF (kvazaar owf): 1 = host arithmetic coding of picture t overlaps the kernels of t + 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,7 +108,7 @@ def main():
     w, h = wl["w"], wl["h"]
     total = args.warmup + args.steps
     D = max(1, args.decoder_frame_threads)
-    extra = D - 1                    # pictures pushed after the timed ones so that the frame-threaded decoder delivers the last timed picture
+    extra = D - 1 + (1 if args.owf > 0 else 0)   # pictures pushed after the timed ones: the encoder (owf) and the frame-threaded decoder deliver with a lag
     seed = 0x5EED0000 + wl["cfg_index"] + 16 * rank
     # synthetic clip generated directly in HBM (inputs resident before the timed region)
     clip = [synth.frame_torch(synth.MOVING, seed, w, h, t, dev) for t in range(total + extra)]
@@ -114,7 +116,7 @@ def main():
 
     # source -> KvazaarFilter -> WireAdapter -> OpenHEVCFilter -> sink, one thread per filter (csrc/filters.hip)
     pl = Pipeline(w, h, settings={"video/QP": 32, "video/Intra": 64, "video/VPS": 1, "uvgx/gpu": local_rank, "uvgx/decoderDownload": 0,
-                                  "video/OPENHEVC_threads": D, "video/OH_parallelization": "Frame" if D > 1 else "Slice"},
+                                  "video/OWF": args.owf, "video/OPENHEVC_threads": D, "video/OH_parallelization": "Frame" if D > 1 else "Slice"},
                   custom=(("me-range", args.me_range), ("gpu", local_rank)), loopback=True, keep_outputs=False)
     lib = pl.lib
     enc_h, dec_h = pl.encoder_handle(), pl.decoder_handle()
@@ -185,7 +187,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl["name"], "width": w, "height": h, "coded_width": cw, "coded_height": ch,
                        "frames_per_gpu": args.steps, "intra_period": 64, "qp": 32, "me_range": args.me_range,
-                       "streams": world, "bytes_per_frame": round(nbytes / args.steps, 1), "decoder_frame_threads": D,
+                       "streams": world, "bytes_per_frame": round(nbytes / args.steps, 1), "decoder_frame_threads": D, "owf": args.owf,
                        "input": "I420 resident in HBM", "output": "Annex-B AU on host + decoded I420 in HBM"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,

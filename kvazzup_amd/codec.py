@@ -44,21 +44,27 @@ class Encoder:
 
     # -- the reference call sequence: memcpy into kvz_picture, encoder_encode, drain chunks
     def encode(self, i420, want_recon=True):
-        i420 = np.ascontiguousarray(i420, dtype=np.uint8)
+        """i420 = None flushes (pic_in == NULL).  Returns (None, None) when the call produced no output
+        (owf >= 1: the first call, or a flush with nothing in flight)."""
         ny = self.w * self.h
-        p = self.pic.contents
-        C.memmove(p.y, i420.ctypes.data, ny)
-        C.memmove(p.u, i420.ctypes.data + ny, ny // 4)
-        C.memmove(p.v, i420.ctypes.data + ny + ny // 4, ny // 4)
-        p.pts = self.pts
-        self.pts += 1
+        if i420 is not None:
+            i420 = np.ascontiguousarray(i420, dtype=np.uint8)
+            p = self.pic.contents
+            C.memmove(p.y, i420.ctypes.data, ny)
+            C.memmove(p.u, i420.ctypes.data + ny, ny // 4)
+            C.memmove(p.v, i420.ctypes.data + ny + ny // 4, ny // 4)
+            p.pts = self.pts
+            self.pts += 1
         chunks = C.POINTER(N.KvzDataChunk)()
         length = C.c_uint32(0)
         recon = C.POINTER(N.KvzPicture)()
         info = N.KvzFrameInfo()
-        ok = self.api.encoder_encode(self.enc, self.pic, C.byref(chunks), C.byref(length), C.byref(recon) if want_recon else None, None, C.byref(info))
-        if not ok or not chunks:
+        ok = self.api.encoder_encode(self.enc, self.pic if i420 is not None else None, C.byref(chunks), C.byref(length),
+                                     C.byref(recon) if want_recon else None, None, C.byref(info))
+        if not ok:
             raise RuntimeError("encoder_encode failed")
+        if not chunks:
+            return None, None
         parts = []
         c = chunks
         while c:

@@ -24,9 +24,12 @@ struct EncoderConfig {
   int wpp = 1, deblock = 1;
   int device = 0;
   int entropy_threads = 16;   // host threads of the arithmetic-coding stage
+  int owf = 0;                // kvazaar "owf": 0 = encode() returns its own picture; >= 1 = output lags one picture and
+                              // the host coding of picture t overlaps the kernels of picture t + 1
 };
 
 struct EncodedPicture {
+  bool valid = false;         // false: nothing was output by this call (pipeline filling, owf >= 1)
   std::vector<uint8_t> au;
   int poc = 0; bool is_intra = false;
   uint64_t bins = 0;
@@ -40,6 +43,9 @@ class Encoder {
   bool encode_host(const uint8_t *y, const uint8_t *u, const uint8_t *v, EncodedPicture *out);
   // picture as packed I420 in device memory (w*h*3/2 bytes)
   bool encode_device(const uint8_t *d_i420, EncodedPicture *out);
+  // owf >= 1: outputs the picture still in flight, if any (kvz_api encoder_encode with pic_in == NULL)
+  bool flush(EncodedPicture *out);
+  int pending() const { return (int)(submitted_ - collected_); }
   // cropped reconstruction of the last coded picture -> host planes (stride = width)
   bool download_recon(uint8_t *y, uint8_t *u, uint8_t *v);
   // debug: copy an internal device array of the last coded picture to the host
@@ -52,13 +58,14 @@ class Encoder {
   void set_profiling(bool on) { profiling_ = on; }
   // accumulated kernel time (ms) and launch count per KernelId since the last reset
   void get_kernel_times(double *ms, uint64_t *launches, bool reset);
-  const uint8_t *device_recon(int plane) const { return rec_[ref_idx_][plane]; }
+  const uint8_t *device_recon(int plane) const { return rec_[out_idx_][plane]; }   // picture last output
   hipStream_t stream() const { return stream_; }
 
  private:
   Encoder() {}
   bool init(const EncoderConfig &cfg, std::string *error);
-  bool run_picture(EncodedPicture *out);
+  bool submit(const uint8_t *d_i420, bool via_staging);
+  bool collect(EncodedPicture *out);
   void timed(KernelId id, const std::function<void()> &launch);
 
   EncoderConfig cfg_;
@@ -69,20 +76,30 @@ class Encoder {
   uint8_t *h_in_ = nullptr;              // pinned host staging
   uint8_t *src_[3] = {nullptr, nullptr, nullptr};
   uint8_t *rec_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-  int cur_idx_ = 0, ref_idx_ = 1;
+  int cur_idx_ = 0, ref_idx_ = 1, out_idx_ = 1;
   int16_t *coef_[3] = {nullptr, nullptr, nullptr};
   uint8_t *cu_bytes_ = nullptr;          // 7 byte arrays back to back
   int16_t *cu_mv_ = nullptr, *cu_mvd_ = nullptr;
   uint8_t *intra_scratch_ = nullptr;
   uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; uint32_t *tok_off_ = nullptr;
-  uint16_t *h_tok_dense_ = nullptr; size_t tok_dense_cap_ = 0; int32_t *h_tok_count_ = nullptr;   // host-mapped pinned
-  uint32_t *sync_ = nullptr; uint32_t *err_ = nullptr; uint32_t *h_err_ = nullptr;
+  size_t tok_dense_cap_ = 0;
+  uint32_t *sync_ = nullptr; uint32_t *err_ = nullptr;
+  // one slot per picture in flight: the host-visible results of its kernels and what collect() needs to finish it
+  struct EvPair { hipEvent_t a, b; KernelId id; };
+  struct Slot {
+    uint16_t *h_tok_dense = nullptr, *d_tok_dense = nullptr; int32_t *h_tok_count = nullptr, *d_tok_count = nullptr;   // host-mapped pinned
+    uint32_t *h_err = nullptr;
+    hipEvent_t done = nullptr;
+    int poc = 0, rec_idx = 0; bool intra = false, write_ps = false;
+    std::vector<EvPair> ev; size_t ev_used = 0;
+  };
+  Slot slot_[2]; Slot *cur_slot_ = nullptr;
+  long submitted_ = 0, collected_ = 0;
+  hipEvent_t in_done_ = nullptr; bool in_pending_ = false;   // input picture consumed (staging buffer / caller's device buffer reusable)
   EntropyHost *entropy_ = nullptr;
   std::vector<std::vector<uint8_t>> rows_out_;
   int frame_idx_ = 0, poc_ = 0, intra_count_ = 0;
   bool profiling_ = false;
-  struct EvPair { hipEvent_t a, b; KernelId id; };
-  std::vector<EvPair> ev_pool_; size_t ev_used_ = 0;
   double k_ms_[K_COUNT] = {0}; uint64_t k_n_[K_COUNT] = {0};
   StreamParams sp_{};
 };

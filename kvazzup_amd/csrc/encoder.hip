@@ -59,11 +59,19 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   HIP_OK(hipMalloc(&tok_off_, sizeof(uint32_t) * (nctu + 1)));
   tok_dense_cap_ = (size_t)nctu * tok_cap_;
   if (tok_dense_cap_ > ((size_t)1 << 27)) tok_dense_cap_ = (size_t)1 << 27;
-  HIP_OK(hipHostMalloc(&h_tok_dense_, tok_dense_cap_ * sizeof(uint16_t), hipHostMallocMapped));
-  HIP_OK(hipHostMalloc(&h_tok_count_, sizeof(int32_t) * nctu, hipHostMallocMapped));
+  for (int i = 0; i < (cfg.owf > 0 ? 2 : 1); i++) {
+    Slot &sl = slot_[i];
+    void *dp = nullptr;
+    HIP_OK(hipHostMalloc(&sl.h_tok_dense, tok_dense_cap_ * sizeof(uint16_t), hipHostMallocMapped));
+    HIP_OK(hipHostMalloc(&sl.h_tok_count, sizeof(int32_t) * nctu, hipHostMallocMapped));
+    HIP_OK(hipHostGetDevicePointer(&dp, sl.h_tok_dense, 0)); sl.d_tok_dense = (uint16_t *)dp;
+    HIP_OK(hipHostGetDevicePointer(&dp, sl.h_tok_count, 0)); sl.d_tok_count = (int32_t *)dp;
+    HIP_OK(hipHostMalloc(&sl.h_err, sizeof(uint32_t), hipHostMallocDefault));
+    HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  }
+  HIP_OK(hipEventCreateWithFlags(&in_done_, hipEventDisableTiming));
   HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * rows_));
   HIP_OK(hipMalloc(&err_, sizeof(uint32_t))); HIP_OK(hipMemset(err_, 0, sizeof(uint32_t)));
-  HIP_OK(hipHostMalloc(&h_err_, sizeof(uint32_t), hipHostMallocDefault));
   entropy_ = new EntropyHost(cfg.entropy_threads < rows_ ? cfg.entropy_threads : rows_);
 
   memset(&f_, 0, sizeof(f_));
@@ -78,9 +86,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   f_.ic8 = (uint32_t *)p; p += nb8 * 4; f_.ic16 = (uint32_t *)p; p += nb8; f_.ic32 = (uint32_t *)p; p += nb8 / 4;
   f_.im8 = p; p += nb8; f_.im16 = p; p += nb8 / 4; f_.im32 = p;
   f_.tok_buf = tok_buf_; f_.tok_cap = tok_cap_; f_.tok_cursor = (uint32_t *)tok_count_; f_.tok_seg = tok_seg_; f_.tok_off = tok_off_;
-  void *dp = nullptr;
-  HIP_OK(hipHostGetDevicePointer(&dp, h_tok_dense_, 0)); f_.tok_dense = (uint16_t *)dp; f_.tok_dense_cap = (uint32_t)tok_dense_cap_;
-  HIP_OK(hipHostGetDevicePointer(&dp, h_tok_count_, 0)); f_.tok_count_out = (int32_t *)dp;
+  f_.tok_dense_cap = (uint32_t)tok_dense_cap_;
   f_.sync = sync_; f_.err = err_;
 
   sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp;
@@ -93,23 +99,30 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
 Encoder::~Encoder()
 {
   if (stream_) hipStreamSynchronize(stream_);
-  for (auto &e : ev_pool_) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  for (Slot &sl : slot_) {
+    for (auto &e : sl.ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    if (sl.h_tok_dense) hipHostFree(sl.h_tok_dense);
+    if (sl.h_tok_count) hipHostFree(sl.h_tok_count);
+    if (sl.h_err) hipHostFree(sl.h_err);
+    if (sl.done) hipEventDestroy(sl.done);
+  }
+  if (in_done_) hipEventDestroy(in_done_);
   hipFree(d_in_); hipHostFree(h_in_);
   for (int c = 0; c < 3; c++) { hipFree(src_[c]); hipFree(rec_[0][c]); hipFree(rec_[1][c]); hipFree(coef_[c]); }
   hipFree(cu_bytes_); hipFree(cu_mv_); hipFree(cu_mvd_); hipFree(intra_scratch_);
   delete entropy_;
   hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(tok_off_); hipFree(sync_); hipFree(err_);
-  hipHostFree(h_tok_dense_); hipHostFree(h_tok_count_); hipHostFree(h_err_);
   if (stream_) hipStreamDestroy(stream_);
 }
 
 void Encoder::timed(KernelId id, const std::function<void()> &launch)
 {
   if (!profiling_) { launch(); return; }
-  if (ev_used_ == ev_pool_.size()) {
-    EvPair p; hipEventCreate(&p.a); hipEventCreate(&p.b); p.id = id; ev_pool_.push_back(p);
+  Slot &sl = *cur_slot_;
+  if (sl.ev_used == sl.ev.size()) {
+    EvPair p; hipEventCreate(&p.a); hipEventCreate(&p.b); p.id = id; sl.ev.push_back(p);
   }
-  EvPair &p = ev_pool_[ev_used_++]; p.id = id;
+  EvPair &p = sl.ev[sl.ev_used++]; p.id = id;
   hipEventRecord(p.a, stream_);
   launch();
   hipEventRecord(p.b, stream_);
@@ -121,9 +134,14 @@ void Encoder::get_kernel_times(double *ms, uint64_t *launches, bool reset)
   if (reset) for (int i = 0; i < K_COUNT; i++) { k_ms_[i] = 0; k_n_[i] = 0; }
 }
 
+// encode = submit the picture's kernels, then finish ("collect") the oldest picture in flight.  With
+// owf == 0 that is the picture just submitted; with owf >= 1 it is the previous one, whose arithmetic
+// coding on the host then runs while the GPU works on the new picture.
 bool Encoder::encode_host(const uint8_t *y, const uint8_t *u, const uint8_t *v, EncodedPicture *out)
 {
   const size_t ny = (size_t)cfg_.width * cfg_.height;
+  HIP_CHECK(hipSetDevice(cfg_.device));
+  if (in_pending_) { HIP_CHECK(hipEventSynchronize(in_done_)); in_pending_ = false; }
   memcpy(h_in_, y, ny); memcpy(h_in_ + ny, u, ny / 4); memcpy(h_in_ + ny + ny / 4, v, ny / 4);
   HIP_CHECK(hipMemcpyAsync(d_in_, h_in_, ny * 3 / 2, hipMemcpyHostToDevice, stream_));
   return encode_device(d_in_, out);
@@ -132,23 +150,42 @@ bool Encoder::encode_host(const uint8_t *y, const uint8_t *u, const uint8_t *v, 
 bool Encoder::encode_device(const uint8_t *d_i420, EncodedPicture *out)
 {
   HIP_CHECK(hipSetDevice(cfg_.device));
+  out->valid = false; out->au.clear();
+  if (!submit(d_i420, d_i420 == d_in_)) return false;
+  bool ok = true;
+  if (pending() > (cfg_.owf > 0 ? 1 : 0)) ok = collect(out);
+  // the caller may reuse its input buffer when this returns (the pad kernel is first in the picture's queue,
+  // and by now it has had the whole host coding stage of the previous picture to run)
+  if (in_pending_) { HIP_CHECK(hipEventSynchronize(in_done_)); in_pending_ = false; }
+  return ok;
+}
+
+bool Encoder::flush(EncodedPicture *out)
+{
+  out->valid = false; out->au.clear();
+  if (!pending()) return true;
+  HIP_CHECK(hipSetDevice(cfg_.device));
+  return collect(out);
+}
+
+bool Encoder::submit(const uint8_t *d_i420, bool)
+{
   const size_t ny = (size_t)cfg_.width * cfg_.height;
   const int w = cfg_.width, h = cfg_.height;
+  Slot &sl = slot_[cfg_.owf > 0 ? (submitted_ & 1) : 0];
+  cur_slot_ = &sl;
   timed(K_PAD, [&] {
     launch_pad_input(d_i420, w, h, src_[0], cw_, ch_, stream_);
     launch_pad_input(d_i420 + ny, w / 2, h / 2, src_[1], cw_ / 2, ch_ / 2, stream_);
     launch_pad_input(d_i420 + ny + ny / 4, w / 2, h / 2, src_[2], cw_ / 2, ch_ / 2, stream_);
   });
-  return run_picture(out);
-}
-
-bool Encoder::run_picture(EncodedPicture *out)
-{
+  HIP_CHECK(hipEventRecord(in_done_, stream_)); in_pending_ = true;
   const int period = cfg_.intra_period;
   const bool intra = (frame_idx_ == 0) || (period > 0 && (frame_idx_ % period) == 0);
   if (intra) poc_ = 0; else poc_++;
   f_.is_intra = intra; f_.poc = poc_;
   for (int c = 0; c < 3; c++) { f_.rec[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
+  f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count;
   const EncFrame f = f_;
   if (intra) {
     timed(K_INTRA_ANALYSE, [&] { launch_intra_analyse(f, stream_); });
@@ -161,32 +198,42 @@ bool Encoder::run_picture(EncodedPicture *out)
   }
   if (cfg_.deblock) timed(K_DEBLOCK, [&] { launch_deblock(f, stream_); });
   timed(K_TOKENIZE, [&] { launch_tokenize(f, stream_); });
-  HIP_CHECK(hipMemcpyAsync(h_err_, err_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
-  HIP_CHECK(hipStreamSynchronize(stream_));
-  if (*h_err_) { fprintf(stderr, "kvazzup_amd: device error flags 0x%x (8/16/32: token buffer overflow)\n", *h_err_); return false; }
-  if (profiling_) {
-    for (size_t i = 0; i < ev_used_; i++) {
-      float ms = 0; hipEventElapsedTime(&ms, ev_pool_[i].a, ev_pool_[i].b);
-      k_ms_[ev_pool_[i].id] += ms; k_n_[ev_pool_[i].id]++;
+  HIP_CHECK(hipMemcpyAsync(sl.h_err, err_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipEventRecord(sl.done, stream_));
+  sl.poc = poc_; sl.intra = intra; sl.rec_idx = cur_idx_; sl.write_ps = false;
+  if (intra) {
+    sl.write_ps = (intra_count_ == 0) || (cfg_.vps_period > 0 && (intra_count_ % cfg_.vps_period) == 0);
+    intra_count_++;
+  }
+  frame_idx_++;
+  int t = cur_idx_; cur_idx_ = ref_idx_; ref_idx_ = t;     // rec_[ref_idx_] holds the picture just submitted
+  submitted_++;
+  return true;
+}
+
+bool Encoder::collect(EncodedPicture *out)
+{
+  Slot &sl = slot_[cfg_.owf > 0 ? (collected_ & 1) : 0];
+  collected_++;
+  HIP_CHECK(hipEventSynchronize(sl.done));
+  if (*sl.h_err) { fprintf(stderr, "kvazzup_amd: device error flags 0x%x (8/16/32: token buffer overflow)\n", *sl.h_err); return false; }
+  if (profiling_ || sl.ev_used) {
+    for (size_t i = 0; i < sl.ev_used; i++) {
+      float ms = 0; hipEventElapsedTime(&ms, sl.ev[i].a, sl.ev[i].b);
+      k_ms_[sl.ev[i].id] += ms; k_n_[sl.ev[i].id]++;
     }
-    ev_used_ = 0;
+    sl.ev_used = 0;
   }
   // ---- serial half of entropy coding: host threads turn the bins into the WPP substreams
   const int nsub = cfg_.wpp ? rows_ : 1;
   uint64_t bins = 0;
   auto t0 = std::chrono::steady_clock::now();
-  entropy_->code_picture(h_tok_dense_, h_tok_count_, cw_ / 64, rows_, cfg_.wpp != 0, intra ? 0 : 1, cfg_.qp, rows_out_, &bins);
+  entropy_->code_picture(sl.h_tok_dense, sl.h_tok_count, cw_ / 64, rows_, cfg_.wpp != 0, sl.intra ? 0 : 1, cfg_.qp, rows_out_, &bins);
   if (profiling_) { k_ms_[K_HOST_ARITH] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); k_n_[K_HOST_ARITH]++; }
   // ---- access unit assembly (host): parameter sets with IDR pictures, then the slice NAL
-  out->poc = poc_; out->is_intra = intra; out->bins = bins;
-  bool write_ps = false;
-  if (intra) {
-    write_ps = (intra_count_ == 0) || (cfg_.vps_period > 0 && (intra_count_ % cfg_.vps_period) == 0);
-    intra_count_++;
-  }
-  assemble_access_unit(out->au, sp_, intra, poc_, write_ps, rows_out_, nsub);
-  frame_idx_++;
-  int t = cur_idx_; cur_idx_ = ref_idx_; ref_idx_ = t;     // rec_[ref_idx_] now holds the picture just coded
+  out->valid = true; out->poc = sl.poc; out->is_intra = sl.intra; out->bins = bins;
+  assemble_access_unit(out->au, sp_, sl.intra, sl.poc, sl.write_ps, rows_out_, nsub);
+  out_idx_ = sl.rec_idx;
   return true;
 }
 
@@ -195,7 +242,7 @@ bool Encoder::download_recon(uint8_t *y, uint8_t *u, uint8_t *v)
   uint8_t *dst[3] = {y, u, v};
   for (int c = 0; c < 3; c++) {
     int w = c ? cfg_.width / 2 : cfg_.width, h = c ? cfg_.height / 2 : cfg_.height, pw = c ? cw_ / 2 : cw_;
-    HIP_CHECK(hipMemcpy2DAsync(dst[c], (size_t)w, rec_[ref_idx_][c], (size_t)pw, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipMemcpy2DAsync(dst[c], (size_t)w, rec_[out_idx_][c], (size_t)pw, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, stream_));
   }
   HIP_CHECK(hipStreamSynchronize(stream_));
   return true;
@@ -213,7 +260,7 @@ bool Encoder::debug_copy(const char *what, void *dst, size_t bytes)
   for (int c = 0; c < 3; c++) {
     size_t n = c ? npx / 4 : npx;
     if (w == std::string("coef") + char('0' + c)) { src = coef_[c]; have = n * 2; }
-    if (w == std::string("rec") + char('0' + c)) { src = rec_[ref_idx_][c]; have = n; }
+    if (w == std::string("rec") + char('0' + c)) { src = rec_[out_idx_][c]; have = n; }
     if (w == std::string("src") + char('0' + c)) { src = src_[c]; have = n; }
   }
   if (!src || bytes > have) return false;

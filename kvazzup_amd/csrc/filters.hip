@@ -281,12 +281,18 @@ void KvazaarFilter::feedInput(std::unique_ptr<Data> input) // kvazaarfilter.cpp:
     if (au_.size() < cap) au_.resize(cap);
     uint32_t n = 0;
     ++pts_;
-    if (!kvzx_encoder_encode_device(enc_, input->device_data, au_.data(), (uint32_t)au_.size(), &n, &frame_info)) return;
+    const void *dptr = input->device_data;
+    input->device_data = nullptr;
+    encodingFrames_.push_front({std::move(input), nullptr});
+    // with video/OWF >= 1 the access unit that comes back belongs to the previous picture (n == 0 on the first call)
+    if (!kvzx_encoder_encode_device(enc_, dptr, au_.data(), (uint32_t)au_.size(), &n, &frame_info)) { encodingFrames_.pop_front(); return; }
+    if (n == 0) return;
+    FrameInfo info = std::move(encodingFrames_.back());
+    encodingFrames_.pop_back();
     std::unique_ptr<uint8_t[]> hevc_frame(new uint8_t[n]);
     memcpy(hevc_frame.get(), au_.data(), n);
-    if (getStats()) { getStats()->encodingDelaySumMs += (uint64_t)(now_ms() - input->creationTimestamp); getStats()->encodedPackets++; getStats()->encodedBytes += n; }
-    input->device_data = nullptr;
-    sendEncodedFrame(std::move(input), std::move(hevc_frame), n);
+    if (getStats()) { getStats()->encodingDelaySumMs += (uint64_t)(now_ms() - info.data->creationTimestamp); getStats()->encodedPackets++; getStats()->encodedBytes += n; }
+    sendEncodedFrame(std::move(info.data), std::move(hevc_frame), n);
     return;
   }
   kvz_picture *inputPic = getNextPic();

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <string>
 #include "../../include/kvazzup_amd.h"
+#include <deque>
 #include "encoder.h"
 
 using kvzx::Encoder;
@@ -18,6 +19,7 @@ struct kvz_encoder {
   kvz_config cfg;
   uint64_t last_bins;
   int warned_rc;
+  std::deque<kvz_picture *> *in_flight;      // source pictures whose output has not been returned yet (owf >= 1)
 };
 
 namespace {
@@ -233,12 +235,12 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   EncoderConfig ec;
   ec.width = cfg->width; ec.height = cfg->height; ec.qp = cfg->qp; ec.intra_period = cfg->intra_period; ec.vps_period = cfg->vps_period;
   ec.me_range = cfg->me_range; ec.fps_num = cfg->framerate_num; ec.fps_den = cfg->framerate_denom;
-  ec.wpp = cfg->wpp ? 1 : 0; ec.deblock = cfg->deblock_enable ? 1 : 0; ec.device = cfg->gpu_device;
+  ec.wpp = cfg->wpp ? 1 : 0; ec.deblock = cfg->deblock_enable ? 1 : 0; ec.device = cfg->gpu_device; ec.owf = cfg->owf > 0 ? 1 : 0;
   std::string err;
   Encoder *impl = Encoder::create(ec, &err);
   if (!impl) { fprintf(stderr, "kvazzup_amd: encoder_open failed: %s\n", err.c_str()); return nullptr; }
   kvz_encoder *e = new kvz_encoder();
-  e->impl = impl; e->cfg = *cfg; e->last_bins = 0; e->warned_rc = 0;
+  e->impl = impl; e->cfg = *cfg; e->last_bins = 0; e->warned_rc = 0; e->in_flight = new std::deque<kvz_picture *>();
   if (cfg->target_bitrate != 0) {
     fprintf(stderr, "kvazzup_amd: rate control is not implemented; coding at constant QP %d\n", cfg->qp);
     e->warned_rc = 1;
@@ -249,6 +251,8 @@ void encoder_close(kvz_encoder *e)
 {
   if (!e) return;
   delete e->impl;
+  for (kvz_picture *p : *e->in_flight) picture_free(p);
+  delete e->in_flight;
   delete e;
 }
 
@@ -279,6 +283,9 @@ int encoder_headers(kvz_encoder *e, kvz_data_chunk **data_out, uint32_t *len_out
   return *data_out ? 1 : 0;
 }
 
+// With owf == 0 the output belongs to pic_in.  With owf >= 1 (kvazaarfilter.cpp:193) the output is the
+// picture of the previous call (len_out == 0 on the first one), and a call with pic_in == NULL returns the
+// picture still in flight -- the loop in KvazaarFilter::feedInput (kvazaarfilter.cpp:440-448) relies on that.
 int encoder_encode(kvz_encoder *e, kvz_picture *pic_in, kvz_data_chunk **data_out, uint32_t *len_out,
                    kvz_picture **pic_out, kvz_picture **src_out, kvz_frame_info *info_out)
 {
@@ -287,22 +294,30 @@ int encoder_encode(kvz_encoder *e, kvz_picture *pic_in, kvz_data_chunk **data_ou
   if (pic_out) *pic_out = nullptr;
   if (src_out) *src_out = nullptr;
   if (!e) return 0;
-  if (!pic_in) return 1;                       // flush: pictures are never held back, nothing is pending
-  if (pic_in->width != e->cfg.width || pic_in->height != e->cfg.height || !pic_in->y || !pic_in->u || !pic_in->v) return 0;
   EncodedPicture ep;
-  if (!e->impl->encode_host(pic_in->y, pic_in->u, pic_in->v, &ep)) return 0;
-  e->last_bins = ep.bins;
-  if (data_out) { *data_out = make_chunks(ep.au.data(), ep.au.size()); if (!*data_out) return 0; }
-  if (len_out) *len_out = (uint32_t)ep.au.size();
-  if (pic_out && e->cfg.recon_output) {
-    kvz_picture *r = picture_alloc(e->cfg.width, e->cfg.height);
-    if (!r || !e->impl->download_recon(r->y, r->u, r->v)) { picture_free(r); return 0; }
-    r->pts = pic_in->pts; r->dts = pic_in->dts;
-    *pic_out = r;
+  if (!pic_in) {
+    if (!e->impl->flush(&ep)) return 0;
+  } else {
+    if (pic_in->width != e->cfg.width || pic_in->height != e->cfg.height || !pic_in->y || !pic_in->u || !pic_in->v) return 0;
+    if (!e->impl->encode_host(pic_in->y, pic_in->u, pic_in->v, &ep)) return 0;
+    pic_in->refcount++;
+    e->in_flight->push_back(pic_in);
   }
-  if (src_out) { pic_in->refcount++; *src_out = pic_in; }
+  if (!ep.valid) return 1;
+  kvz_picture *src = e->in_flight->front();
+  e->in_flight->pop_front();
+  e->last_bins = ep.bins;
+  bool ok = true;
+  if (data_out) { *data_out = make_chunks(ep.au.data(), ep.au.size()); ok = *data_out != nullptr; }
+  if (len_out) *len_out = (uint32_t)ep.au.size();
+  if (ok && pic_out && e->cfg.recon_output) {
+    kvz_picture *r = picture_alloc(e->cfg.width, e->cfg.height);
+    if (!r || !e->impl->download_recon(r->y, r->u, r->v)) { picture_free(r); ok = false; }
+    else { r->pts = src->pts; r->dts = src->dts; *pic_out = r; }
+  }
+  if (src_out && ok) *src_out = src; else picture_free(src);
   fill_info(e, ep, info_out);
-  return 1;
+  return ok ? 1 : 0;
 }
 
 const kvz_api kApi = {
@@ -322,6 +337,8 @@ int kvzx_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSucc
 
 static int finish_raw(kvz_encoder *e, const EncodedPicture &ep, uint8_t *au_buf, uint32_t au_cap, uint32_t *len_out, kvz_frame_info *info)
 {
+  if (len_out) *len_out = 0;
+  if (!ep.valid) return 1;                     // owf >= 1: nothing output by this call
   e->last_bins = ep.bins;
   if (len_out) *len_out = (uint32_t)ep.au.size();
   fill_info(e, ep, info);
@@ -331,9 +348,10 @@ static int finish_raw(kvz_encoder *e, const EncodedPicture &ep, uint8_t *au_buf,
 }
 int kvzx_encoder_encode_device(kvz_encoder *e, const void *d_i420, uint8_t *au_buf, uint32_t au_cap, uint32_t *len_out, kvz_frame_info *info)
 {
-  if (!e || !d_i420) return 0;
+  if (!e) return 0;
   EncodedPicture ep;
-  if (!e->impl->encode_device((const uint8_t *)d_i420, &ep)) return 0;
+  if (!d_i420) { if (!e->impl->flush(&ep)) return 0; }          // NULL input: return the picture in flight (owf >= 1)
+  else if (!e->impl->encode_device((const uint8_t *)d_i420, &ep)) return 0;
   return finish_raw(e, ep, au_buf, au_cap, len_out, info);
 }
 int kvzx_encoder_encode_host(kvz_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v, uint8_t *au_buf, uint32_t au_cap,

@@ -65,3 +65,25 @@ def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_pic
 ])
 def test_encoder_matches_oracle(gpu, cfg):
     run_clip(**cfg)
+
+
+@pytest.mark.gpu
+def test_owf_lags_output_by_one_picture_and_flushes(gpu):
+    """video/OWF >= 1 (kvazaarfilter.cpp:193): the access unit returned by call t is picture t - 1, a NULL
+    picture flushes the last one; the bytes and reconstructions are those of the synchronous encoder."""
+    from kvazzup_amd.codec import Encoder
+    w, h, frames = 320, 192, 7
+    clip = [orc.synth_frame(0, SEED, w, h, t) for t in range(frames)]
+    opts = (("qp", 30), ("period", 4), ("me-range", 8))
+    e0 = Encoder(w, h, options=opts)
+    want = [e0.encode(f) for f in clip]
+    e0.close()
+    e1 = Encoder(w, h, options=opts + (("owf", 1),))
+    got = [e1.encode(f) for f in clip]
+    assert got[0] == (None, None)
+    got.append(e1.encode(None))
+    assert e1.encode(None) == (None, None)
+    e1.close()
+    for t in range(frames):
+        assert got[t + 1][0] == want[t][0], t
+        assert np.array_equal(got[t + 1][1], want[t][1]), t

@@ -300,7 +300,7 @@ bool Decoder::ensure_buffers(int cw, int ch)
   HIP_TRY(hipMalloc(&d_cu_, nb8 * 7));
   HIP_TRY(hipMalloc(&d_mv_, nb8 * 2 * sizeof(int16_t)));
   HIP_TRY(hipMalloc(&d_mvd_, nb8 * 2 * sizeof(int16_t)));
-  HIP_TRY(hipMalloc(&sync_, sizeof(uint32_t) * (size_t)(ch / 64)));
+  HIP_TRY(hipMalloc(&sync_, sizeof(uint32_t) * 3 * (size_t)(ch / 64)));
   for (int c = 0; c < 3; c++) {
     size_t n = c ? npx / 4 : npx;
     HIP_TRY(hipMalloc(&rec_[0][c], n)); HIP_TRY(hipMalloc(&rec_[1][c], n));
@@ -796,7 +796,7 @@ int Decoder::run_gpu(PicJob &job)
   const EncFrame f = f_;
   timed(DK_SCATTER, [&] { launch_scatter_levels(f, d_tus_, (int)ntu, d_levels_, stream_); });
   if (is_intra) {
-    if (hipMemsetAsync(sync_, 0, sizeof(uint32_t) * (size_t)(ch_ / 64), stream_) != hipSuccess) return DEC_ERR_GPU;
+    if (hipMemsetAsync(sync_, 0, sizeof(uint32_t) * 3 * (size_t)(ch_ / 64), stream_) != hipSuccess) return DEC_ERR_GPU;
     timed(DK_INTRA_RECON, [&] { launch_dec_intra_recon(f, stream_); });
   } else {
     timed(DK_INTER_RECON, [&] { launch_dec_inter_recon(f, stream_); });

@@ -11,7 +11,7 @@
 //   k_inter_recon   one workgroup per 32x32 block: MC, residual, DCT, quant, dequant, IDCT, recon
 //   k_inter_signal  one thread per 16x16 block: merge / skip / AMVP signalling
 //   k_intra_analyse one workgroup per 32x32 block: 35-mode SAD search on source samples
-//   k_intra_recon   one workgroup per CTU row, wavefront over rows through progress counters
+//   k_intra_recon   one wave per (CTU row, colour plane), wavefront over rows through progress counters
 //   k_deblock_v/h   one thread per 4-sample edge segment
 //   k_tokenize      one wave per CTU: binarisation + context selection of every syntax element
 //                   (one lane per 4x4 sub-block of a transform block) -> bins as 16-bit tokens;
@@ -432,132 +432,276 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
   }
 }
 
-// Intra reconstruction keeps the CTU being coded, the row of samples above it (above + above-right CTU)
-// and the column to its left in LDS, so the reference samples of every block come from LDS instead of
-// a global-memory round trip per block; Cb and Cr are coded together as one two-block group.
-struct IntraLds {
-  uint8_t cur0[64 * 64], cur1[32 * 32], cur2[32 * 32];   // reconstruction of the current CTU
-  uint8_t top0[132], top1[68], top2[68];                 // [0] = above-left corner, [1 + x] = sample above, x < 2S
-  uint8_t lft0[64], lft1[32], lft2[32];                  // column left of the CTU
-  uint8_t raw[2][132], av[2][132], left[2][68], top[2][68], lf[2][68], tf[2][68];
-  int a[1024], b[1024];
-  int16_t lev[1024];
-  uint8_t pred[1024];
-  int8_t C[32][33];
-  uint32_t nz;
-};
-__device__ __forceinline__ uint8_t *lds_cur(IntraLds &s, int c) { return c == 0 ? s.cur0 : (c == 1 ? s.cur1 : s.cur2); }
-__device__ __forceinline__ uint8_t *lds_top(IntraLds &s, int c) { return c == 0 ? s.top0 : (c == 1 ? s.top1 : s.top2); }
-__device__ __forceinline__ uint8_t *lds_lft(IntraLds &s, int c) { return c == 0 ? s.lft0 : (c == 1 ? s.lft1 : s.lft2); }
-
-// sample at CTU-relative component coordinates (x, y), x, y >= -1, from the LDS copies
-__device__ __forceinline__ int lds_sample(IntraLds &s, int c, int S, int x, int y)
+// =============================================================================================
+// Intra reconstruction.  Intra prediction of a block needs the reconstructed samples of its left /
+// above neighbours, so inside one colour plane the blocks of a picture form a dependency chain:
+// z-order inside a CTU, a two-CTU lag between CTU rows.  What is independent is the three colour
+// planes (DM chroma uses the luma *mode*, not luma samples).  So: one WAVE per (CTU row, plane),
+// launched as a 64-thread workgroup; nothing inside the chain ever waits for another wave, the
+// steps of a block talk through LDS under wave-local barriers, and rows hand over through agent
+// -scope progress counters (one per row and plane).  The CTU being coded, its borders, its source
+// samples and its levels stay in LDS; global memory is touched once per CTU on the way in and out.
+//
+// Transforms: one primitive, P(X, T)[j][i] = sum_m X[i][m] * T[j][m] (rows of X times rows of T,
+// result stored transposed), run four times -- forward rows, forward columns, inverse columns,
+// inverse rows -- on int16 data with v_dot2_i32_i16.  A lane owns a pair of rows of X and OPL
+// outputs of each, so the matrix rows it reads are shared by both rows and every LDS write is a
+// packed pair.  Quantisation and dequantisation are the epilogue of the second forward stage, the
+// reconstruction is the epilogue of the last inverse stage.
+// =============================================================================================
+typedef short kv_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot2_i16(uint32_t a, uint32_t b, int c)
 {
-  if (y < 0) return lds_top(s, c)[x + 1];
-  if (x < 0) return lds_lft(s, c)[y];
-  return lds_cur(s, c)[y * S + x];
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(kv_short2, a), __builtin_bit_cast(kv_short2, b), c, false);
+}
+__device__ __forceinline__ uint32_t pack_i16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+
+struct IntraWaveLds {
+  alignas(16) uint8_t cur[64 * 64];          // reconstruction of the current CTU (plane pitch S)
+  alignas(16) uint8_t src[64 * 64];          // encoder: source samples of the CTU
+  alignas(16) int16_t lev[64 * 64];          // encoder: levels produced; decoder: levels to reconstruct from
+  alignas(16) int16_t A[32 * 32], B[32 * 32];
+  alignas(16) int16_t M[2][1360];            // [0]: M_n[j][m], [1]: its transpose; n = 4, 8, 16, 32 at 0, 16, 80, 336
+  alignas(16) uint8_t topb[144];             // [0] = above-left corner, [1 + x] = sample above, x < 2S
+  alignas(16) uint8_t lftb[64];              // column left of the CTU
+  alignas(16) uint8_t refl[96], reft[96], reflf[96], reftf[96];   // left[k] lives at refl[15 + k] (left[1] is 16-byte aligned)
+};
+__device__ __forceinline__ int matrix_offset(int l2) { return l2 == 2 ? 0 : (l2 == 3 ? 16 : (l2 == 4 ? 80 : 336)); }
+
+template <int L2> struct XF {
+  static constexpr int N = 1 << L2, OPL = (L2 == 5) ? 8 : (L2 == 4 ? 2 : 1), G = N / OPL, LANES = (N / 2) * G;
+};
+
+// raw sums of P for the lane's two rows (2rp, 2rp + 1) and its OPL outputs g * OPL + o
+template <int L2>
+__device__ __forceinline__ void xf_sums(const int16_t *in, const int16_t *T, int rp, int g, int (&acc)[2][XF<L2>::OPL])
+{
+  constexpr int N = XF<L2>::N, OPL = XF<L2>::OPL, H = N / 2;
+  const uint32_t *r0 = (const uint32_t *)(in + 2 * rp * N);
+  uint32_t a0[H], a1[H];
+#pragma unroll
+  for (int m = 0; m < H; m++) { a0[m] = r0[m]; a1[m] = r0[H + m]; }
+#pragma unroll
+  for (int o = 0; o < OPL; o++) {
+    const uint32_t *t = (const uint32_t *)(T + (g * OPL + o) * N);
+    int s0 = 0, s1 = 0;
+#pragma unroll
+    for (int m = 0; m < H; m++) { uint32_t tv = t[m]; s0 = dot2_i16(a0[m], tv, s0); s1 = dot2_i16(a1[m], tv, s1); }
+    acc[0][o] = s0; acc[1][o] = s1;
+  }
+}
+// plain stage: out[j][i] = clip16((sum + rnd) >> shift), stored as packed row pairs
+template <int L2>
+__device__ __forceinline__ void xf_stage(const int16_t *in, int16_t *out, const int16_t *T, int shift, int lane)
+{
+  constexpr int N = XF<L2>::N, OPL = XF<L2>::OPL, G = XF<L2>::G;
+  if (lane >= XF<L2>::LANES) return;
+  const int rp = lane / G, g = lane % G, rnd = 1 << (shift - 1);
+  int acc[2][OPL];
+  xf_sums<L2>(in, T, rp, g, acc);
+#pragma unroll
+  for (int o = 0; o < OPL; o++) {
+    int v0 = clip3(-32768, 32767, (acc[0][o] + rnd) >> shift), v1 = clip3(-32768, 32767, (acc[1][o] + rnd) >> shift);
+    ((uint32_t *)out)[((g * OPL + o) * N) / 2 + rp] = pack_i16(v0, v1);
+  }
 }
 
-// Codes `npl` planes (first plane c0; 1 = luma alone, 2 = Cb and Cr together) of the CU at luma (X, Y),
-// block size n = 1 << l2 in component samples.  Returns the cbf bits of those planes (bit i = plane c0 + i).
-template <bool DEC>
-__device__ __forceinline__ int intra_recon_planes(const EncFrame &f, IntraLds &s, int c0, int npl, int X, int Y, int l2, int mode, int qp, int dec_cbf, int tid)
+// One plane of one CU: block of n = 1 << L2 component samples at CTU-relative (rx, ry); (X, Y) = luma position
+// of the CU in the picture.  Returns whether the block has non-zero levels (encoder) / echoes has_levels (decoder).
+template <bool DEC, int L2>
+__device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, int cidx, int S, int X, int Y, int rx, int ry,
+                                            int mode, int qp, bool has_levels, int lane)
 {
-  const int n = 1 << l2, sh = c0 ? 1 : 0, S = c0 ? 32 : 64, pw = c0 ? (f.cw >> 1) : f.cw;
-  const int x0 = X >> sh, y0 = Y >> sh;                  // component coordinates in the picture
-  const int rx = x0 & (S - 1), ry = y0 & (S - 1);        // ... relative to the CTU
-  const int total = 4 * n + 1;
-  // ---- reference samples (8.4.4.2.2) from LDS
-  for (int w = tid; w < npl * total; w += 256) {
-    int pl = w / total, i = w - pl * total, x, y;
-    intra_ref_coord(x0, y0, n, i, x, y);
-    bool ok = avail64(f.cw, f.ch, X, Y, x << sh, y << sh);
-    s.av[pl][i] = ok;
-    s.raw[pl][i] = ok ? (uint8_t)lds_sample(s, c0 + pl, S, x - (x0 - rx), y - (y0 - ry)) : 0;
+  constexpr int N = XF<L2>::N, OPL = XF<L2>::OPL, G = XF<L2>::G;
+  const int sh = cidx ? 1 : 0, nl = N << sh;
+  uint8_t *left = s.refl + 15, *top = s.reft + 15;
+  // ---- reference samples (8.4.4.2.2).  Availability is decided per group of n samples (below-left, left, corner,
+  // above, above-right): each group lies in one block of this block's size, which precedes it in z-order or does not.
+  {
+    const bool aL = X > 0, aT = Y > 0;
+    uint32_t am = (aL && avail64(f.cw, f.ch, X, Y, X - 1, Y + nl) ? 1u : 0u) | (aL ? 2u : 0u) | (aL && aT ? 4u : 0u) | (aT ? 8u : 0u) |
+                  (aT && avail64(f.cw, f.ch, X, Y, X + nl, Y - 1) ? 16u : 0u);
+    for (int i = lane; i <= 4 * N; i += 64) {
+      const int grp = i < N ? 0 : (i < 2 * N ? 1 : (i == 2 * N ? 2 : (i <= 3 * N ? 3 : 4)));
+      int j = i, v = 128;
+      if (!((am >> grp) & 1)) {
+        const uint32_t below = am & ((1u << grp) - 1u);
+        if (below) { int gb = 31 - __builtin_clz(below); j = gb == 0 ? N - 1 : (gb == 1 ? 2 * N - 1 : (gb == 2 ? 2 * N : 3 * N)); }
+        else if (am) { int ga = __builtin_ctz(am); j = ga == 1 ? N : (ga == 2 ? 2 * N : (ga == 3 ? 2 * N + 1 : 3 * N + 1)); }
+        else j = -1;
+      }
+      if (j >= 0) {
+        int x, y;                                        // CTU-relative component coordinates of reference j
+        if (j < 2 * N) { x = rx - 1; y = ry + 2 * N - 1 - j; } else if (j == 2 * N) { x = rx - 1; y = ry - 1; } else { x = rx + (j - 2 * N - 1); y = ry - 1; }
+        v = y < 0 ? s.topb[x + 1] : (x < 0 ? s.lftb[y] : s.cur[y * S + x]);
+      }
+      if (i < 2 * N) left[2 * N - i] = (uint8_t)v;
+      else if (i == 2 * N) { left[0] = (uint8_t)v; top[0] = (uint8_t)v; }
+      else top[i - 2 * N] = (uint8_t)v;
+    }
   }
   __syncthreads();
-  for (int w = tid; w < npl * total; w += 256) {
-    int pl = w / total, i = w - pl * total, j = i;
-    while (j >= 0 && !s.av[pl][j]) j--;
-    if (j < 0) { j = 0; while (j < total && !s.av[pl][j]) j++; }
-    uint8_t v = (j < total) ? s.raw[pl][j] : 128;
-    if (i < 2 * n) s.left[pl][2 * n - i] = v;
-    else if (i == 2 * n) { s.left[pl][0] = v; s.top[pl][0] = v; }
-    else s.top[pl][i - 2 * n] = v;
+  const uint8_t *Lp = left, *Tp = top;
+  if (intra_filter_needed(N, cidx, mode)) {
+    const bool strong = intra_strong_filter(left, top, N);
+    for (int i = lane; i <= 2 * N; i += 64) {
+      s.reflf[15 + i] = (uint8_t)intra_filtered_ref(left, top, N, i, strong);
+      s.reftf[15 + i] = (uint8_t)intra_filtered_ref(top, left, N, i, strong);
+    }
+    Lp = s.reflf + 15; Tp = s.reftf + 15;
+    __syncthreads();
   }
-  __syncthreads();
-  const bool filt = intra_filter_needed(n, c0, mode);    // luma only
-  if (filt) filter_intra_refs(s.left[0], s.top[0], n, s.lf[0], s.tf[0], tid, 256);
-  if (tid == 0) s.nz = 0;
-  int dcv[2] = {0, 0};
-  if (mode == 1) for (int pl = 0; pl < npl; pl++) dcv[pl] = intra_dc_value(s.left[pl], s.top[pl], n, l2);   // DC is never filtered
-  // ---- prediction and residual (encoder) / dequantised levels (decoder)
-  for (int o = tid; o < npl * n * n; o += 256) {
-    int pl = o >> (2 * l2), r = o & (n * n - 1), y = r >> l2, x = r & (n - 1);
-    const uint8_t *L = filt ? s.lf[0] : s.left[pl], *T = filt ? s.tf[0] : s.top[pl];
-    int p = intra_pred_sample(L, T, n, l2, c0, mode, pl ? dcv[1] : dcv[0], x, y);
-    s.pred[o] = (uint8_t)p;
-    int g = (y0 + y) * pw + x0 + x;
-    if (DEC) s.b[o] = ((dec_cbf >> pl) & 1) ? dequant_coef(f.coef[c0 + pl][g], qp, l2) : 0;
-    else s.a[o] = (int)f.src[c0 + pl][g] - p;
+  int dcv = 0;
+  if (mode == 1) {                                       // every lane sums the 2n references itself: no reduction step
+    const uint32_t *l4 = (const uint32_t *)(left + 1), *t4 = (const uint32_t *)(top + 1);
+    uint32_t acc = N;
+#pragma unroll
+    for (int k = 0; k < N / 4; k++) { acc = __builtin_amdgcn_sad_u8(l4[k], 0u, acc); acc = __builtin_amdgcn_sad_u8(t4[k], 0u, acc); }
+    dcv = (int)(acc >> (L2 + 1));
   }
-  __syncthreads();
-  if (DEC) { if (dec_cbf) inverse_group(s.a, s.b, s.C, l2, npl * n * n, 256, tid); }
-  else code_group(s.a, s.b, s.lev, s.C, l2, npl, qp, 1, &s.nz, 256, tid);
-  const int cbf = DEC ? dec_cbf : (int)s.nz;
-  for (int o = tid; o < npl * n * n; o += 256) {
-    int pl = o >> (2 * l2), r = o & (n * n - 1), y = r >> l2, x = r & (n - 1);
-    bool has = (cbf >> pl) & 1;
-    uint8_t v = (uint8_t)(has ? clip8(s.pred[o] + s.b[o]) : s.pred[o]);
-    int g = (y0 + y) * pw + x0 + x;
-    f.rec[c0 + pl][g] = v;
-    lds_cur(s, c0 + pl)[(ry + y) * S + rx + x] = v;
-    if (has && !DEC) f.coef[c0 + pl][g] = s.lev[o];
+  // ---- prediction for the lane's samples: rows 2rp, 2rp + 1, columns g * OPL .. + OPL - 1
+  const bool active = lane < XF<L2>::LANES;
+  const int rp = lane / G, g = lane % G;
+  int pred[2][OPL];
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+#pragma unroll
+      for (int o = 0; o < OPL; o++) pred[e][o] = intra_pred_sample(Lp, Tp, N, L2, cidx, mode, dcv, g * OPL + o, 2 * rp + e);
+  }
+  bool cbf = has_levels;
+  if (!DEC) {
+    // ---- residual -> A, forward rows -> B, forward columns + quantisation: levels -> s.lev, dequantised (transposed) -> A
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int o = 0; o < OPL; o++) {
+          int y = 2 * rp + e, x = g * OPL + o;
+          s.A[y * N + x] = (int16_t)((int)s.src[(ry + y) * S + rx + x] - pred[e][o]);
+        }
+    }
+    __syncthreads();
+    const int16_t *Mf = s.M[0] + matrix_offset(L2);
+    xf_stage<L2>(s.A, s.B, Mf, L2 - 1, lane);
+    __syncthreads();
+    bool nz = false;
+    if (active) {
+      int acc[2][OPL];
+      xf_sums<L2>(s.B, Mf, rp, g, acc);
+      const int shift = L2 + 6, rnd = 1 << (shift - 1);
+#pragma unroll
+      for (int o = 0; o < OPL; o++) {
+        int lv[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          int c = clip3(-32768, 32767, (acc[e][o] + rnd) >> shift);
+          lv[e] = quant_level(c, qp, L2, 1);
+          nz |= lv[e] != 0;
+          s.A[(2 * rp + e) * N + g * OPL + o] = (int16_t)dequant_coef(lv[e], qp, L2);      // Dt[i'][j']
+        }
+        *(uint32_t *)&s.lev[(ry + g * OPL + o) * S + rx + 2 * rp] = pack_i16(lv[0], lv[1]);   // level (row j', columns i', i' + 1)
+      }
+    }
+    cbf = __ballot(nz) != 0;
+    __syncthreads();
+  } else if (has_levels) {
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int o = 0; o < OPL; o++) {
+          int y = 2 * rp + e, x = g * OPL + o;               // level at row y, column x -> Dt[x][y]
+          s.A[x * N + y] = (int16_t)dequant_coef(s.lev[(ry + y) * S + rx + x], qp, L2);
+        }
+    }
+    __syncthreads();
+  }
+  // ---- inverse columns -> B, inverse rows + reconstruction
+  if (cbf) {
+    const int16_t *Mt = s.M[1] + matrix_offset(L2);
+    xf_stage<L2>(s.A, s.B, Mt, 7, lane);
+    __syncthreads();
+    if (active) {
+      int acc[2][OPL];
+      xf_sums<L2>(s.B, Mt, rp, g, acc);
+#pragma unroll
+      for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int o = 0; o < OPL; o++) pred[e][o] = clip8(pred[e][o] + ((acc[e][o] + 2048) >> 12));
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+#pragma unroll
+      for (int o = 0; o < OPL; o++) s.cur[(ry + 2 * rp + e) * S + rx + g * OPL + o] = (uint8_t)pred[e][o];
   }
   __syncthreads();
   return cbf;
 }
 
 template <bool DEC>
-__global__ __launch_bounds__(256) void k_intra_recon(EncFrame f)
+__global__ __launch_bounds__(64) void k_intra_recon(EncFrame f)
 {
-  __shared__ IntraLds s;
-  const int tid = threadIdx.x, row = blockIdx.x, wc = f.cw >> 6;
-  load_dct_matrix(s.C, tid, 256);
-  __syncthreads();
+  __shared__ IntraWaveLds s;
+  const int lane = threadIdx.x, row = blockIdx.x / 3, c = blockIdx.x % 3, wc = f.cw >> 6;
+  const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, qp = c ? f.qpc : f.qp;
+  uint32_t *my_ctr = f.sync + row * 3 + c;
+  const uint32_t *up_ctr = f.sync + (row - 1) * 3 + c;
+  for (int i = lane; i < 1360; i += 64) {
+    int l2 = i < 16 ? 2 : (i < 80 ? 3 : (i < 336 ? 4 : 5)), k = i - matrix_offset(l2), j = k >> l2, m = k & ((1 << l2) - 1);
+    s.M[0][i] = kDct32[j << (5 - l2)][m];
+    s.M[1][i] = kDct32[m << (5 - l2)][j];
+  }
+  int zx, zy; ctu_z_to_xy(lane, zx, zy);                  // this lane's 8x8 luma block of the CTU, in z-order
   for (int cx = 0; cx < wc; cx++) {
-    // left border <- right column of the CTU just finished (before it is overwritten)
-    if (cx > 0) {
-      for (int i = tid; i < 128; i += 256) {
-        if (i < 64) s.lft0[i] = s.cur0[i * 64 + 63];
-        else if (i < 96) s.lft1[i - 64] = s.cur1[(i - 64) * 32 + 31];
-        else s.lft2[i - 96] = s.cur2[(i - 96) * 32 + 31];
-      }
+    const int bi = b8idx(f, cx * 64 + zx * 8, row * 64 + zy * 8);
+    const int my_l2 = f.cu_log2[bi], my_mode = f.cu_intra_mode[bi], my_given = DEC ? f.cu_cbf[bi] : 0;
+    const uint8_t *gsrc = DEC ? nullptr : f.src[c] + (size_t)(row * S) * pw + cx * S;
+    uint8_t *grec = f.rec[c] + (size_t)(row * S) * pw + cx * S;
+    int16_t *gcoef = f.coef[c] + (size_t)(row * S) * pw + cx * S;
+    // left border <- right column of the CTU just finished
+    if (cx > 0 && lane < S) s.lftb[lane] = s.cur[lane * S + S - 1];
+    // CTU inputs -> LDS (16-byte pieces)
+    if (!DEC) {
+      for (int k = lane; k < S * S / 16; k += 64) { int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&s.src[y * S + xq * 16] = *(const uint4 *)&gsrc[(size_t)y * pw + xq * 16]; }
+    } else {
+      for (int k = lane; k < S * S / 8; k += 64) { int y = k / (S / 8), xq = k % (S / 8); *(uint4 *)&s.lev[y * S + xq * 8] = *(const uint4 *)&gcoef[(size_t)y * pw + xq * 8]; }
     }
     if (row > 0) {
-      wait_progress(&f.sync[row - 1], (uint32_t)imin(cx + 2, wc), f.err);
-      // top border <- last row of the CTU row above (above-left corner, above, above-right), clipped to the picture
-      for (int i = tid; i < 129 + 65 + 65; i += 256) {
-        int c = i < 129 ? 0 : (i < 194 ? 1 : 2), k = i < 129 ? i : (i < 194 ? i - 129 : i - 194);
-        int S = c ? 32 : 64, pw = c ? (f.cw >> 1) : f.cw;
-        int x = cx * S - 1 + k, y = row * S - 1;
-        if (x >= 0 && x < pw) lds_top(s, c)[k] = f.rec[c][y * pw + x];
+      wait_progress(up_ctr, (uint32_t)imin(cx + 2, wc), f.err);
+      // top border <- last sample row of the CTU row above: corner, above, above-right, clipped to the picture
+      for (int k = lane; k < 2 * S + 1; k += 64) {
+        int x = cx * S - 1 + k;
+        if (x >= 0 && x < pw) s.topb[k] = f.rec[c][(size_t)(row * S - 1) * pw + x];
       }
     }
     __syncthreads();
+    uint32_t my_cbf = 0;
     for (int z = 0; z < 64;) {
+      const int l2 = __shfl(my_l2, z), mode = __shfl(my_mode, z), given = __shfl(my_given, z);
       int xi, yi; ctu_z_to_xy(z, xi, yi);
-      const int X = cx * 64 + xi * 8, Y = row * 64 + yi * 8;
-      const int bi = b8idx(f, X, Y);
-      const int l2 = f.cu_log2[bi], mode = f.cu_intra_mode[bi];
-      const int given = DEC ? f.cu_cbf[bi] : 0;
-      int cbf = intra_recon_planes<DEC>(f, s, 0, 1, X, Y, l2, mode, f.qp, given & 1, tid);
-      cbf |= intra_recon_planes<DEC>(f, s, 1, 2, X, Y, l2 - 1, mode, f.qpc, (given >> 1) & 3, tid) << 1;
-      int nb = 1 << (l2 - 3);
-      if (!DEC && tid < nb * nb) f.cu_cbf[b8idx(f, X + (tid % nb) * 8, Y + (tid / nb) * 8)] = (uint8_t)cbf;
-      z += 1 << (2 * (l2 - 3));
+      const int X = cx * 64 + xi * 8, Y = row * 64 + yi * 8, rx = (xi * 8) >> sh, ry = (yi * 8) >> sh;
+      const bool has = DEC && ((given >> c) & 1);
+      bool cbf;
+      switch (l2 - sh) {
+        case 2: cbf = intra_block<DEC, 2>(f, s, c, S, X, Y, rx, ry, mode, qp, has, lane); break;
+        case 3: cbf = intra_block<DEC, 3>(f, s, c, S, X, Y, rx, ry, mode, qp, has, lane); break;
+        case 4: cbf = intra_block<DEC, 4>(f, s, c, S, X, Y, rx, ry, mode, qp, has, lane); break;
+        default: cbf = intra_block<DEC, 5>(f, s, c, S, X, Y, rx, ry, mode, qp, has, lane); break;
+      }
+      const int cnt = 1 << (2 * (l2 - 3));
+      if (cbf && lane >= z && lane < z + cnt) my_cbf = 1u << c;
+      z += cnt;
     }
-    publish_progress(&f.sync[row], (uint32_t)(cx + 1));
+    // CTU results -> global memory
+    for (int k = lane; k < S * S / 16; k += 64) { int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&grec[(size_t)y * pw + xq * 16] = *(const uint4 *)&s.cur[y * S + xq * 16]; }
+    if (!DEC) {
+      for (int k = lane; k < S * S / 8; k += 64) { int y = k / (S / 8), xq = k % (S / 8); *(uint4 *)&gcoef[(size_t)y * pw + xq * 8] = *(const uint4 *)&s.lev[y * S + xq * 8]; }
+      if (my_cbf) atomicOr((uint32_t *)(f.cu_cbf + (bi & ~3)), my_cbf << (8 * (bi & 3)));   // the three planes own one bit each of the byte
+    }
+    publish_progress(my_ctr, (uint32_t)(cx + 1));
   }
 }
 
@@ -836,8 +980,8 @@ void launch_inter_signal(const EncFrame &f, hipStream_t st)
   hipLaunchKernelGGL(k_inter_signal, dim3((n + 255) / 256), dim3(256), 0, st, f);
 }
 void launch_intra_analyse(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_analyse, dim3(f.cw / 32, f.ch / 32), dim3(256), 0, st, f); }
-void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_recon<false>, dim3(f.ch / 64), dim3(256), 0, st, f); }
-void launch_dec_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_recon<true>, dim3(f.ch / 64), dim3(256), 0, st, f); }
+void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_recon<false>, dim3(3 * (f.ch / 64)), dim3(64), 0, st, f); }
+void launch_dec_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_recon<true>, dim3(3 * (f.ch / 64)), dim3(64), 0, st, f); }
 void launch_deblock(const EncFrame &f, hipStream_t st)
 {
   int nv = ((f.cw >> 3) - 1) * (f.ch >> 2), nh = (f.cw >> 2) * ((f.ch >> 3) - 1);

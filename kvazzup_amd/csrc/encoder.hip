@@ -70,7 +70,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
     HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   }
   HIP_OK(hipEventCreateWithFlags(&in_done_, hipEventDisableTiming));
-  HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * rows_));
+  HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * rows_ * 3));       // one progress counter per CTU row and colour plane
   HIP_OK(hipMalloc(&err_, sizeof(uint32_t))); HIP_OK(hipMemset(err_, 0, sizeof(uint32_t)));
   entropy_ = new EntropyHost(cfg.entropy_threads < rows_ ? cfg.entropy_threads : rows_);
 
@@ -189,7 +189,8 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   const EncFrame f = f_;
   if (intra) {
     timed(K_INTRA_ANALYSE, [&] { launch_intra_analyse(f, stream_); });
-    HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * rows_, stream_));
+    HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * rows_ * 3, stream_));
+    HIP_CHECK(hipMemsetAsync(f_.cu_cbf, 0, (size_t)f_.b8w * f_.b8h, stream_));     // the three plane waves OR their bit in
     timed(K_INTRA_RECON, [&] { launch_intra_recon(f, stream_); });
   } else {
     timed(K_ME, [&] { launch_me(f, stream_); });

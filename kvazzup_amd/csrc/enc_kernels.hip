@@ -449,6 +449,12 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
 // packed pair.  Quantisation and dequantisation are the epilogue of the second forward stage, the
 // reconstruction is the epilogue of the last inverse stage.
 // =============================================================================================
+#ifdef KVZ_PROF     // scratch/intra_bench.hip: cycle attribution inside the chain (never defined in the product build)
+__shared__ long long g_prof[16];
+#define PROF(k) do { if (threadIdx.x == 0) { long long t_ = clock64(); g_prof[k] += t_ - g_prof[15]; g_prof[15] = t_; } } while (0)
+#else
+#define PROF(k) do { } while (0)
+#endif
 typedef short kv_short2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int dot2_i16(uint32_t a, uint32_t b, int c)
 {
@@ -457,14 +463,18 @@ __device__ __forceinline__ int dot2_i16(uint32_t a, uint32_t b, int c)
 __device__ __forceinline__ uint32_t pack_i16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
 
 struct IntraWaveLds {
-  alignas(16) uint8_t cur[64 * 64];          // reconstruction of the current CTU (plane pitch S)
+  // The CTU being reconstructed with its borders, as one padded picture: row 0 = the sample row above the CTU
+  // (above-left corner, above, above-right), column 15 = the sample column to its left, sample (x, y) of the
+  // CTU at pic[(y + 1) * P + 16 + x], P = 16 + 2S.
+  alignas(16) uint8_t pic[65 * 144];
   alignas(16) uint8_t src[64 * 64];          // encoder: source samples of the CTU
   alignas(16) int16_t lev[64 * 64];          // encoder: levels produced; decoder: levels to reconstruct from
   alignas(16) int16_t A[32 * 32], B[32 * 32];
   alignas(16) int16_t M[2][1360];            // [0]: M_n[j][m], [1]: its transpose; n = 4, 8, 16, 32 at 0, 16, 80, 336
-  alignas(16) uint8_t topb[144];             // [0] = above-left corner, [1 + x] = sample above, x < 2S
-  alignas(16) uint8_t lftb[64];              // column left of the CTU
-  alignas(16) uint8_t refl[96], reft[96], reflf[96], reftf[96];   // left[k] lives at refl[15 + k] (left[1] is 16-byte aligned)
+  // reference samples of the current block in the scan order of 8.4.4.2.2 (index 0 = bottom of the below-left
+  // group, 2n = corner, 4n = end of above-right): [0] as built, [1] filtered (8.4.4.2.3).  Sample i sits at
+  // byte 3 + i, which makes the "above" run (2n + 1 ...) dword aligned.  left[k] = R[2n - k], top[k] = R[2n + k].
+  alignas(16) uint8_t R[2][144];
 };
 __device__ __forceinline__ int matrix_offset(int l2) { return l2 == 2 ? 0 : (l2 == 3 ? 16 : (l2 == 4 ? 80 : 336)); }
 
@@ -506,69 +516,113 @@ __device__ __forceinline__ void xf_stage(const int16_t *in, int16_t *out, const 
   }
 }
 
+// Intra sample prediction (8.4.4.2.4-6) from the reference array R (scan order, see IntraWaveLds); the same
+// arithmetic as intra_pred_sample() of hevc_core.h, indexed for R.  s = +1 / -1 walks the main side.
+template <int L2>
+__device__ __forceinline__ int pred_planar(const uint8_t *R, int x, int y)
+{
+  constexpr int N = 1 << L2;
+  return ((N - 1 - x) * R[2 * N - 1 - y] + (x + 1) * R[3 * N + 1] + (N - 1 - y) * R[2 * N + 1 + x] + (y + 1) * R[N - 1] + N) >> (L2 + 1);
+}
+template <int L2>
+__device__ __forceinline__ int pred_dc(const uint8_t *R, bool edge, int dc, int x, int y)
+{
+  constexpr int N = 1 << L2;
+  if (edge) {
+    if (x == 0 && y == 0) return (R[2 * N - 1] + 2 * dc + R[2 * N + 1] + 2) >> 2;
+    if (y == 0) return (R[2 * N + 1 + x] + 3 * dc + 2) >> 2;
+    if (x == 0) return (R[2 * N - 1 - y] + 3 * dc + 2) >> 2;
+  }
+  return dc;
+}
+template <int L2>
+__device__ __forceinline__ int pred_angular(const uint8_t *R, bool vert, bool edge, int angle, int inv, int x, int y)
+{
+  constexpr int N = 1 << L2;
+  const int a = vert ? x : y, b = vert ? y : x, sgn = vert ? 1 : -1;        // a runs along the main reference side
+  if (edge && a == 0) return clip8(R[2 * N + sgn] + ((R[2 * N - sgn * (1 + b)] - R[2 * N]) >> 1));
+  const int t = (b + 1) * angle, k0 = a + (t >> 5) + 1, k1 = k0 + 1, fact = t & 31;
+  const int i0 = k0 >= 0 ? k0 : -((k0 * inv + 128) >> 8), i1 = k1 >= 0 ? k1 : -((k1 * inv + 128) >> 8);
+  return ((32 - fact) * R[2 * N + sgn * i0] + fact * R[2 * N + sgn * i1] + 16) >> 5;
+}
+
 // One plane of one CU: block of n = 1 << L2 component samples at CTU-relative (rx, ry); (X, Y) = luma position
 // of the CU in the picture.  Returns whether the block has non-zero levels (encoder) / echoes has_levels (decoder).
 template <bool DEC, int L2>
 __device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, int cidx, int S, int X, int Y, int rx, int ry,
-                                            int mode, int qp, bool has_levels, int lane)
+                                            int mode, int angle, int inv, int qp, bool has_levels, int lane)
 {
   constexpr int N = XF<L2>::N, OPL = XF<L2>::OPL, G = XF<L2>::G;
-  const int sh = cidx ? 1 : 0, nl = N << sh;
-  uint8_t *left = s.refl + 15, *top = s.reft + 15;
-  // ---- reference samples (8.4.4.2.2).  Availability is decided per group of n samples (below-left, left, corner,
-  // above, above-right): each group lies in one block of this block's size, which precedes it in z-order or does not.
+  const int sh = cidx ? 1 : 0, nl = N << sh, P = 16 + 2 * S;
+  const bool filt = intra_filter_needed(N, cidx, mode);
+  // ---- reference samples (8.4.4.2.2) and their filtered version (8.4.4.2.3).  Availability is decided per group
+  // of n samples (below-left, left, corner, above, above-right): each group lies in one block of this block's size,
+  // which either precedes this block in z-order or does not.  The available groups are contiguous in scan order,
+  // so the substitution process is a clamp of the scan index into [lo, hi].
   {
     const bool aL = X > 0, aT = Y > 0;
-    uint32_t am = (aL && avail64(f.cw, f.ch, X, Y, X - 1, Y + nl) ? 1u : 0u) | (aL ? 2u : 0u) | (aL && aT ? 4u : 0u) | (aT ? 8u : 0u) |
-                  (aT && avail64(f.cw, f.ch, X, Y, X + nl, Y - 1) ? 16u : 0u);
+    const bool aBL = aL && avail64(f.cw, f.ch, X, Y, X - 1, Y + nl), aTR = aT && avail64(f.cw, f.ch, X, Y, X + nl, Y - 1);
+    const int lo = aBL ? 0 : (aL ? N : 2 * N + 1), hi = aTR ? 4 * N : (aT ? 3 * N : (aL ? 2 * N - 1 : -1));
+    auto fetch = [&](int i) -> int {
+      const int j = imin(imax(i, lo), hi);
+      const int col = j < 2 * N ? rx - 1 : rx + j - 2 * N - 1, rowp = j < 2 * N ? ry + 2 * N - j : ry;    // rowp = y + 1
+      return s.pic[rowp * P + 16 + col];
+    };
+    int c0 = 0, e0 = 0, e1 = 0; bool strong = false;
+    if (filt && N == 32 && hi >= 0) {
+      c0 = fetch(2 * N); e0 = fetch(0); e1 = fetch(4 * N);
+      strong = iabs(c0 + e1 - 2 * fetch(3 * N)) < 8 && iabs(c0 + e0 - 2 * fetch(N)) < 8;
+    }
     for (int i = lane; i <= 4 * N; i += 64) {
-      const int grp = i < N ? 0 : (i < 2 * N ? 1 : (i == 2 * N ? 2 : (i <= 3 * N ? 3 : 4)));
-      int j = i, v = 128;
-      if (!((am >> grp) & 1)) {
-        const uint32_t below = am & ((1u << grp) - 1u);
-        if (below) { int gb = 31 - __builtin_clz(below); j = gb == 0 ? N - 1 : (gb == 1 ? 2 * N - 1 : (gb == 2 ? 2 * N : 3 * N)); }
-        else if (am) { int ga = __builtin_ctz(am); j = ga == 1 ? N : (ga == 2 ? 2 * N : (ga == 3 ? 2 * N + 1 : 3 * N + 1)); }
-        else j = -1;
+      int v = 128, fv = 128;
+      if (hi >= 0) {
+        v = fetch(i); fv = v;
+        if (filt && i != 0 && i != 4 * N) {
+          if (strong) { if (i != 2 * N) { int k = i < 2 * N ? 2 * N - i : i - 2 * N; fv = ((64 - k) * c0 + k * (i < 2 * N ? e0 : e1) + 32) >> 6; } }
+          else fv = (fetch(i - 1) + 2 * v + fetch(i + 1) + 2) >> 2;
+        }
       }
-      if (j >= 0) {
-        int x, y;                                        // CTU-relative component coordinates of reference j
-        if (j < 2 * N) { x = rx - 1; y = ry + 2 * N - 1 - j; } else if (j == 2 * N) { x = rx - 1; y = ry - 1; } else { x = rx + (j - 2 * N - 1); y = ry - 1; }
-        v = y < 0 ? s.topb[x + 1] : (x < 0 ? s.lftb[y] : s.cur[y * S + x]);
-      }
-      if (i < 2 * N) left[2 * N - i] = (uint8_t)v;
-      else if (i == 2 * N) { left[0] = (uint8_t)v; top[0] = (uint8_t)v; }
-      else top[i - 2 * N] = (uint8_t)v;
+      s.R[0][3 + i] = (uint8_t)v;
+      if (filt) s.R[1][3 + i] = (uint8_t)fv;
     }
   }
   __syncthreads();
-  const uint8_t *Lp = left, *Tp = top;
-  if (intra_filter_needed(N, cidx, mode)) {
-    const bool strong = intra_strong_filter(left, top, N);
-    for (int i = lane; i <= 2 * N; i += 64) {
-      s.reflf[15 + i] = (uint8_t)intra_filtered_ref(left, top, N, i, strong);
-      s.reftf[15 + i] = (uint8_t)intra_filtered_ref(top, left, N, i, strong);
-    }
-    Lp = s.reflf + 15; Tp = s.reftf + 15;
-    __syncthreads();
-  }
+  PROF(3);
+  const uint8_t *R = s.R[filt ? 1 : 0] + 3;
   int dcv = 0;
-  if (mode == 1) {                                       // every lane sums the 2n references itself: no reduction step
-    const uint32_t *l4 = (const uint32_t *)(left + 1), *t4 = (const uint32_t *)(top + 1);
-    uint32_t acc = N;
+  if (mode == 1) {                                       // every lane sums the references itself: no reduction step
+    const uint32_t *r4 = (const uint32_t *)(s.R[0] + 3 + N + 1);           // dwords covering R[n + 1 .. 3n]
+    uint32_t acc = N + s.R[0][3 + N] - s.R[0][3 + 2 * N];                  // + left[n], - corner
 #pragma unroll
-    for (int k = 0; k < N / 4; k++) { acc = __builtin_amdgcn_sad_u8(l4[k], 0u, acc); acc = __builtin_amdgcn_sad_u8(t4[k], 0u, acc); }
+    for (int k = 0; k < N / 2; k++) acc = __builtin_amdgcn_sad_u8(r4[k], 0u, acc);
     dcv = (int)(acc >> (L2 + 1));
   }
+  PROF(4);
   // ---- prediction for the lane's samples: rows 2rp, 2rp + 1, columns g * OPL .. + OPL - 1
   const bool active = lane < XF<L2>::LANES;
   const int rp = lane / G, g = lane % G;
+  const bool edge = cidx == 0 && N < 32;                 // boundary smoothing of DC / pure horizontal / pure vertical
   int pred[2][OPL];
   if (active) {
+    if (mode == 0) {
 #pragma unroll
-    for (int e = 0; e < 2; e++)
+      for (int e = 0; e < 2; e++)
 #pragma unroll
-      for (int o = 0; o < OPL; o++) pred[e][o] = intra_pred_sample(Lp, Tp, N, L2, cidx, mode, dcv, g * OPL + o, 2 * rp + e);
+        for (int o = 0; o < OPL; o++) pred[e][o] = pred_planar<L2>(R, g * OPL + o, 2 * rp + e);
+    } else if (mode == 1) {
+#pragma unroll
+      for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int o = 0; o < OPL; o++) pred[e][o] = pred_dc<L2>(R, edge, dcv, g * OPL + o, 2 * rp + e);
+    } else {
+      const bool vert = mode >= 18, e2 = edge && (mode == 26 || mode == 10);
+#pragma unroll
+      for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int o = 0; o < OPL; o++) pred[e][o] = pred_angular<L2>(R, vert, e2, angle, inv, g * OPL + o, 2 * rp + e);
+    }
   }
+  PROF(5);
   bool cbf = has_levels;
   if (!DEC) {
     // ---- residual -> A, forward rows -> B, forward columns + quantisation: levels -> s.lev, dequantised (transposed) -> A
@@ -585,6 +639,7 @@ __device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, 
     const int16_t *Mf = s.M[0] + matrix_offset(L2);
     xf_stage<L2>(s.A, s.B, Mf, L2 - 1, lane);
     __syncthreads();
+    PROF(6);
     bool nz = false;
     if (active) {
       int acc[2][OPL];
@@ -605,6 +660,7 @@ __device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, 
     }
     cbf = __ballot(nz) != 0;
     __syncthreads();
+    PROF(7);
   } else if (has_levels) {
     if (active) {
 #pragma unroll
@@ -622,6 +678,7 @@ __device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, 
     const int16_t *Mt = s.M[1] + matrix_offset(L2);
     xf_stage<L2>(s.A, s.B, Mt, 7, lane);
     __syncthreads();
+    PROF(8);
     if (active) {
       int acc[2][OPL];
       xf_sums<L2>(s.B, Mt, rp, g, acc);
@@ -635,9 +692,10 @@ __device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, 
 #pragma unroll
     for (int e = 0; e < 2; e++)
 #pragma unroll
-      for (int o = 0; o < OPL; o++) s.cur[(ry + 2 * rp + e) * S + rx + g * OPL + o] = (uint8_t)pred[e][o];
+      for (int o = 0; o < OPL; o++) s.pic[(ry + 2 * rp + e + 1) * P + 16 + rx + g * OPL + o] = (uint8_t)pred[e][o];
   }
   __syncthreads();
+  PROF(9);
   return cbf;
 }
 
@@ -646,7 +704,7 @@ __global__ __launch_bounds__(64) void k_intra_recon(EncFrame f)
 {
   __shared__ IntraWaveLds s;
   const int lane = threadIdx.x, row = blockIdx.x / 3, c = blockIdx.x % 3, wc = f.cw >> 6;
-  const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, qp = c ? f.qpc : f.qp;
+  const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, qp = c ? f.qpc : f.qp, P = 16 + 2 * S;
   uint32_t *my_ctr = f.sync + row * 3 + c;
   const uint32_t *up_ctr = f.sync + (row - 1) * 3 + c;
   for (int i = lane; i < 1360; i += 64) {
@@ -655,54 +713,70 @@ __global__ __launch_bounds__(64) void k_intra_recon(EncFrame f)
     s.M[1][i] = kDct32[m << (5 - l2)][j];
   }
   int zx, zy; ctu_z_to_xy(lane, zx, zy);                  // this lane's 8x8 luma block of the CTU, in z-order
+#ifdef KVZ_PROF
+  if (lane < 16) g_prof[lane] = 0;
+  __syncthreads();
+  if (lane == 0) g_prof[15] = clock64();
+#endif
   for (int cx = 0; cx < wc; cx++) {
+    PROF(10);
+    // per-CU parameters: lane z holds those of the CU covering the z-th 8x8 block
     const int bi = b8idx(f, cx * 64 + zx * 8, row * 64 + zy * 8);
     const int my_l2 = f.cu_log2[bi], my_mode = f.cu_intra_mode[bi], my_given = DEC ? f.cu_cbf[bi] : 0;
+    const int my_angle = kIntraAngle[my_mode], my_inv = kInvAngle[my_mode];
     const uint8_t *gsrc = DEC ? nullptr : f.src[c] + (size_t)(row * S) * pw + cx * S;
     uint8_t *grec = f.rec[c] + (size_t)(row * S) * pw + cx * S;
     int16_t *gcoef = f.coef[c] + (size_t)(row * S) * pw + cx * S;
     // left border <- right column of the CTU just finished
-    if (cx > 0 && lane < S) s.lftb[lane] = s.cur[lane * S + S - 1];
+    if (cx > 0 && lane < S) s.pic[(lane + 1) * P + 15] = s.pic[(lane + 1) * P + 16 + S - 1];
     // CTU inputs -> LDS (16-byte pieces)
     if (!DEC) {
       for (int k = lane; k < S * S / 16; k += 64) { int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&s.src[y * S + xq * 16] = *(const uint4 *)&gsrc[(size_t)y * pw + xq * 16]; }
     } else {
       for (int k = lane; k < S * S / 8; k += 64) { int y = k / (S / 8), xq = k % (S / 8); *(uint4 *)&s.lev[y * S + xq * 8] = *(const uint4 *)&gcoef[(size_t)y * pw + xq * 8]; }
     }
+    PROF(0);
     if (row > 0) {
       wait_progress(up_ctr, (uint32_t)imin(cx + 2, wc), f.err);
       // top border <- last sample row of the CTU row above: corner, above, above-right, clipped to the picture
       for (int k = lane; k < 2 * S + 1; k += 64) {
         int x = cx * S - 1 + k;
-        if (x >= 0 && x < pw) s.topb[k] = f.rec[c][(size_t)(row * S - 1) * pw + x];
+        if (x >= 0 && x < pw) s.pic[15 + k] = f.rec[c][(size_t)(row * S - 1) * pw + x];
       }
     }
     __syncthreads();
+    PROF(1);
     uint32_t my_cbf = 0;
     for (int z = 0; z < 64;) {
-      const int l2 = __shfl(my_l2, z), mode = __shfl(my_mode, z), given = __shfl(my_given, z);
+      const int l2 = __builtin_amdgcn_readlane(my_l2, z), mode = __builtin_amdgcn_readlane(my_mode, z), given = __builtin_amdgcn_readlane(my_given, z);
+      const int angle = __builtin_amdgcn_readlane(my_angle, z), inv = __builtin_amdgcn_readlane(my_inv, z);
       int xi, yi; ctu_z_to_xy(z, xi, yi);
       const int X = cx * 64 + xi * 8, Y = row * 64 + yi * 8, rx = (xi * 8) >> sh, ry = (yi * 8) >> sh;
       const bool has = DEC && ((given >> c) & 1);
+      PROF(2);
       bool cbf;
       switch (l2 - sh) {
-        case 2: cbf = intra_block<DEC, 2>(f, s, c, S, X, Y, rx, ry, mode, qp, has, lane); break;
-        case 3: cbf = intra_block<DEC, 3>(f, s, c, S, X, Y, rx, ry, mode, qp, has, lane); break;
-        case 4: cbf = intra_block<DEC, 4>(f, s, c, S, X, Y, rx, ry, mode, qp, has, lane); break;
-        default: cbf = intra_block<DEC, 5>(f, s, c, S, X, Y, rx, ry, mode, qp, has, lane); break;
+        case 2: cbf = intra_block<DEC, 2>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, has, lane); break;
+        case 3: cbf = intra_block<DEC, 3>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, has, lane); break;
+        case 4: cbf = intra_block<DEC, 4>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, has, lane); break;
+        default: cbf = intra_block<DEC, 5>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, has, lane); break;
       }
       const int cnt = 1 << (2 * (l2 - 3));
       if (cbf && lane >= z && lane < z + cnt) my_cbf = 1u << c;
       z += cnt;
     }
     // CTU results -> global memory
-    for (int k = lane; k < S * S / 16; k += 64) { int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&grec[(size_t)y * pw + xq * 16] = *(const uint4 *)&s.cur[y * S + xq * 16]; }
+    for (int k = lane; k < S * S / 16; k += 64) { int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&grec[(size_t)y * pw + xq * 16] = *(const uint4 *)&s.pic[(y + 1) * P + 16 + xq * 16]; }
     if (!DEC) {
       for (int k = lane; k < S * S / 8; k += 64) { int y = k / (S / 8), xq = k % (S / 8); *(uint4 *)&gcoef[(size_t)y * pw + xq * 8] = *(const uint4 *)&s.lev[y * S + xq * 8]; }
       if (my_cbf) atomicOr((uint32_t *)(f.cu_cbf + (bi & ~3)), my_cbf << (8 * (bi & 3)));   // the three planes own one bit each of the byte
     }
     publish_progress(my_ctr, (uint32_t)(cx + 1));
   }
+#ifdef KVZ_PROF
+  __syncthreads();
+  if (lane < 16 && blockIdx.x == gridDim.x / 2 / 3 * 3) ((long long *)f.tok_seg)[lane] = g_prof[lane];
+#endif
 }
 
 // =============================================================================================

@@ -124,92 +124,77 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
 }
 
 // =============================================================================================
-// Workgroup-cooperative separable transforms on blocks held in LDS.
-// A "group" is ntu blocks of n x n samples stored TU-major: idx = tu * n*n + row * n + col.
-//   ROW op: out[i][j] = sum_m in[i][m] * M[j][m]      COL op: out[i][j] = sum_m M[i][m] * in[m][j]
-// with M[a][b] = C[a * 32/n][b] (TRANS = false) or C[b * 32/n][a] (TRANS = true).
+// Transforms.  One primitive, P(X, T)[j][i] = sum_m X[i][m] * T[j][m] (rows of X times rows of T, the
+// result stored transposed), run four times per block -- forward rows, forward columns, inverse
+// columns, inverse rows -- on int16 data with v_dot2_i32_i16 (every intermediate of the 8-bit HEVC
+// transforms fits 16 bits).  A lane owns a PAIR of rows of X and OPL outputs of each, so the matrix
+// rows it reads serve both rows and every LDS store is a packed pair.  Quantisation + dequantisation
+// are the epilogue of the second forward stage, reconstruction the epilogue of the last inverse one.
+// Matrices live in LDS as int16: M[0] = M_n[j][m] (n-point DCT = rows of kDct32 subsampled),
+// M[1] = its transpose, for n = 4, 8, 16, 32 at matrix_offset(log2 n).
 // =============================================================================================
-template <bool ROW, bool TRANS, bool CLIP16>
-__device__ __forceinline__ void transform_stage(const int *in, int *out, const int8_t (*C)[33], int log2n, int total,
-                                                int shift, int nthreads, int tid)
+typedef short kv_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot2_i16(uint32_t a, uint32_t b, int c)
 {
-  const int n = 1 << log2n, st = 32 >> log2n, rnd = shift > 0 ? (1 << (shift - 1)) : 0;
-  for (int o = tid; o < total; o += nthreads) {
-    int tu = o >> (2 * log2n), rem = o & (n * n - 1), i = rem >> log2n, j = rem & (n - 1);
-    const int *base = in + (tu << (2 * log2n));
-    int acc = 0;
-    for (int m = 0; m < n; m++) {
-      int mat = ROW ? (TRANS ? C[m * st][j] : C[j * st][m]) : (TRANS ? C[m * st][i] : C[i * st][m]);
-      int v = ROW ? base[i * n + m] : base[m * n + j];
-      acc += mat * v;
-    }
-    acc = (acc + rnd) >> shift;
-    if (CLIP16) acc = clip3(-32768, 32767, acc);
-    out[o] = acc;
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(kv_short2, a), __builtin_bit_cast(kv_short2, b), c, false);
+}
+__device__ __forceinline__ uint32_t pack_i16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+__device__ __forceinline__ int matrix_offset(int l2) { return l2 == 2 ? 0 : (l2 == 3 ? 16 : (l2 == 4 ? 80 : 336)); }
+#define KV_MATRIX_ENTRIES 1360
+// fills entries [first, first + count) of both matrix sets (all sizes: first = 0, count = KV_MATRIX_ENTRIES)
+__device__ __forceinline__ void load_matrices(int16_t (*M)[KV_MATRIX_ENTRIES], int first, int count, int tid, int nthreads)
+{
+  for (int i = first + tid; i < first + count; i += nthreads) {
+    int l2 = i < 16 ? 2 : (i < 80 ? 3 : (i < 336 ? 4 : 5)), k = i - matrix_offset(l2), j = k >> l2, m = k & ((1 << l2) - 1);
+    M[0][i] = kDct32[j << (5 - l2)][m];
+    M[1][i] = kDct32[m << (5 - l2)][j];
   }
 }
 
-// inverse transform (H.265 8.6.4.2) of the dequantised coefficients in `b`; residual returned in `b`
-__device__ __forceinline__ void inverse_group(int *a, int *b, const int8_t (*C)[33], int log2n, int total, int nthreads, int tid)
-{
-  transform_stage<false, true, true>(b, a, C, log2n, total, 7, nthreads, tid);                     // columns
-  __syncthreads();
-  transform_stage<true, true, false>(a, b, C, log2n, total, 12, nthreads, tid);                    // rows
-  __syncthreads();
-}
+// lanes that share one n x n block: (n / 2) row pairs x (n / OPL) output groups
+template <int L2, int OPL> struct XF { static constexpr int N = 1 << L2, G = N / OPL, LANES = (N / 2) * G; };
 
-// forward (res -> coef), quantise, dequantise, inverse (-> res) for one group held in `a` (in/out),
-// with scratch `b`.  Levels are left in `lev` (int16).  Returns through `nz_flags` (LDS) a bit
-// per TU that has non-zero levels.  All threads of the workgroup must call this.
-__device__ __forceinline__ void code_group(int *a, int *b, int16_t *lev, const int8_t (*C)[33], int log2n, int ntu,
-                                           int qp, int intra, uint32_t *nz_flags, int nthreads, int tid)
+// raw sums of P for the lane's two rows (2rp, 2rp + 1) and its OPL outputs g * OPL + o
+template <int L2, int OPL>
+__device__ __forceinline__ void xf_sums(const int16_t *in, const int16_t *T, int rp, int g, int (&acc)[2][OPL])
 {
-  const int total = ntu << (2 * log2n);
-  transform_stage<true, false, false>(a, b, C, log2n, total, log2n + 8 - 9, nthreads, tid);        // rows
-  __syncthreads();
-  transform_stage<false, false, true>(b, a, C, log2n, total, log2n + 6, nthreads, tid);            // columns
-  __syncthreads();
-  for (int o = tid; o < total; o += nthreads) {
-    int l = quant_level(a[o], qp, log2n, intra);
-    lev[o] = (int16_t)l;
-    if (l) atomicOr(nz_flags, 1u << (o >> (2 * log2n)));
-    b[o] = dequant_coef(l, qp, log2n);
+  constexpr int N = 1 << L2, H = N / 2;
+  const uint32_t *r0 = (const uint32_t *)(in + 2 * rp * N);
+  uint32_t a0[H], a1[H];
+#pragma unroll
+  for (int m = 0; m < H; m++) { a0[m] = r0[m]; a1[m] = r0[H + m]; }
+#pragma unroll
+  for (int o = 0; o < OPL; o++) {
+    const uint32_t *t = (const uint32_t *)(T + (g * OPL + o) * N);
+    int s0 = 0, s1 = 0;
+#pragma unroll
+    for (int m = 0; m < H; m++) { uint32_t tv = t[m]; s0 = dot2_i16(a0[m], tv, s0); s1 = dot2_i16(a1[m], tv, s1); }
+    acc[0][o] = s0; acc[1][o] = s1;
   }
-  __syncthreads();
-  inverse_group(a, b, C, log2n, total, nthreads, tid);
 }
-
-__device__ __forceinline__ void load_dct_matrix(int8_t (*C)[33], int tid, int nthreads)
+// plain stage: out[j][i] = clip16((sum + rnd) >> shift), stored as packed row pairs
+template <int L2, int OPL>
+__device__ __forceinline__ void xf_stage(const int16_t *in, int16_t *out, const int16_t *T, int shift, int rp, int g)
 {
-  for (int i = tid; i < 1024; i += nthreads) C[i >> 5][i & 31] = kDct32[i >> 5][i & 31];
+  constexpr int N = 1 << L2;
+  const int rnd = 1 << (shift - 1);
+  int acc[2][OPL];
+  xf_sums<L2, OPL>(in, T, rp, g, acc);
+#pragma unroll
+  for (int o = 0; o < OPL; o++) {
+    int v0 = clip3(-32768, 32767, (acc[0][o] + rnd) >> shift), v1 = clip3(-32768, 32767, (acc[1][o] + rnd) >> shift);
+    ((uint32_t *)out)[((g * OPL + o) * N) / 2 + rp] = pack_i16(v0, v1);
+  }
 }
 
 // =============================================================================================
-// Inter reconstruction of one 32x32 block (one 32x32 CU or four 16x16 CUs)
+// Inter reconstruction of one 32x32 block (one 32x32 CU or four 16x16 CUs), one workgroup each
 // =============================================================================================
 __device__ __forceinline__ int ref_at(const uint8_t *p, int w, int h, int x, int y)
 {
   return p[clip3(0, h - 1, y) * w + clip3(0, w - 1, x)];
 }
-// chroma sample predicted with the 4-tap filters of H.265 8.5.3.3.3.2; mv in 1/8 chroma samples
-__device__ __forceinline__ int mc_chroma_sample(const uint8_t *p, int w, int h, int x, int y, int mvx, int mvy)
-{
-  int xf = mvx & 7, yf = mvy & 7, xi = x + (mvx >> 3), yi = y + (mvy >> 3), v;
-  if (!xf && !yf) v = ref_at(p, w, h, xi, yi) << 6;
-  else if (!yf) { v = 0; for (int i = 0; i < 4; i++) v += kChromaFilter[xf][i] * ref_at(p, w, h, xi + i - 1, yi); }
-  else if (!xf) { v = 0; for (int i = 0; i < 4; i++) v += kChromaFilter[yf][i] * ref_at(p, w, h, xi, yi + i - 1); }
-  else {
-    v = 0;
-    for (int j = 0; j < 4; j++) {
-      int t = 0;
-      for (int i = 0; i < 4; i++) t += kChromaFilter[xf][i] * ref_at(p, w, h, xi + i - 1, yi + j - 1);
-      v += kChromaFilter[yf][j] * t;
-    }
-    v >>= 6;
-  }
-  return clip8((v + 32) >> 6);
-}
-// luma sample with the 8-tap filters of 8.5.3.3.3.1; mv in quarter samples
+// luma sample with the 8-tap filters of 8.5.3.3.3.1; mv in quarter samples (general path: fractional vectors)
 __device__ __forceinline__ int mc_luma_sample(const uint8_t *p, int w, int h, int x, int y, int mvx, int mvy)
 {
   int xf = mvx & 3, yf = mvy & 3, xi = x + (mvx >> 2), yi = y + (mvy >> 2), v;
@@ -227,86 +212,204 @@ __device__ __forceinline__ int mc_luma_sample(const uint8_t *p, int w, int h, in
   }
   return clip8((v + 32) >> 6);
 }
+// four luma samples (x .. x + 3, y) predicted with one vector, packed little-endian
+__device__ __forceinline__ uint32_t mc_luma4(const uint8_t *p, int w, int h, int x, int y, int mvx, int mvy)
+{
+  if (((mvx | mvy) & 3) == 0) {
+    const int xi = x + (mvx >> 2), yi = clip3(0, h - 1, y + (mvy >> 2));
+    const uint8_t *row = p + (size_t)yi * w;
+    if (xi >= 0 && xi + 3 < w) {
+      const uint32_t *q = (const uint32_t *)(row + (xi & ~3));                 // planes are 4-byte aligned, w is a multiple of 64
+      const uint32_t lo = q[0], hi = (xi & 3) ? q[1] : 0u;
+      return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(xi & 3));
+    }
+    uint32_t v = 0;
+    for (int i = 0; i < 4; i++) v |= (uint32_t)row[clip3(0, w - 1, xi + i)] << (8 * i);
+    return v;
+  }
+  uint32_t v = 0;
+  for (int i = 0; i < 4; i++) v |= (uint32_t)mc_luma_sample(p, w, h, x + i, y, mvx, mvy) << (8 * i);
+  return v;
+}
+
+struct InterLds {
+  alignas(16) int16_t A[1024], B[1024];
+  alignas(16) int16_t M[2][KV_MATRIX_ENTRIES];
+  alignas(16) uint8_t px[1024];            // prediction, then reconstruction: luma 32x32 raster; chroma 2 planes x 16x16
+  alignas(16) uint8_t win[2][4][11 * 12];  // chroma reference windows: plane x 8x8 sub-block, 11 x 11 samples each
+  uint32_t nz[2];
+  int mv[4][2];
+};
+
+// The four transform stages of `NTU` blocks of n = 1 << L2 held TU-major in s.A (encoder: residual, row-major;
+// decoder: dequantised levels, transposed), NTU * XF<L2, OPL>::LANES == 256.  Encoder: levels go to `coef`
+// for blocks that have any, *nz gets one bit per block.  Ends with the residual added into s.px.
+//   px_index(tu, y, x) -> index of sample (x, y) of block tu in s.px;  coef_at(tu, y, x) -> its level in the plane
+template <bool DEC, int L2, int OPL, class PX, class CI>
+__device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *nz, PX px_index, CI coef_at, int tid)
+{
+  constexpr int N = 1 << L2, G = XF<L2, OPL>::G, LPT = XF<L2, OPL>::LANES;
+  const int tu = tid / LPT, l = tid % LPT, rp = l / G, g = l % G;
+  int16_t *A = s.A + tu * N * N, *B = s.B + tu * N * N;
+  if (!DEC) {
+    const int16_t *Mf = s.M[0] + matrix_offset(L2);
+    xf_stage<L2, OPL>(A, B, Mf, L2 - 1, rp, g);
+    __syncthreads();
+    int acc[2][OPL], lv[2][OPL];
+    xf_sums<L2, OPL>(B, Mf, rp, g, acc);
+    const int shift = L2 + 6, rnd = 1 << (shift - 1);
+    bool any = false;
+#pragma unroll
+    for (int o = 0; o < OPL; o++)
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        int c = clip3(-32768, 32767, (acc[e][o] + rnd) >> shift);
+        lv[e][o] = quant_level(c, qp, L2, 0);
+        any |= lv[e][o] != 0;
+        A[(2 * rp + e) * N + g * OPL + o] = (int16_t)dequant_coef(lv[e][o], qp, L2);        // transposed: [column][row]
+      }
+    if (any) atomicOr(nz, 1u << tu);
+    __syncthreads();
+    if ((*nz >> tu) & 1) {
+#pragma unroll
+      for (int o = 0; o < OPL; o++) *(uint32_t *)coef_at(tu, g * OPL + o, 2 * rp) = pack_i16(lv[0][o], lv[1][o]);   // row g*OPL+o, columns 2rp, 2rp+1
+    }
+  }
+  const bool has = (*nz >> tu) & 1;
+  const int16_t *Mt = s.M[1] + matrix_offset(L2);
+  if (has) xf_stage<L2, OPL>(A, B, Mt, 7, rp, g);
+  __syncthreads();
+  if (has) {
+    int acc[2][OPL];
+    xf_sums<L2, OPL>(B, Mt, rp, g, acc);
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+#pragma unroll
+      for (int o = 0; o < OPL; o++) {
+        uint8_t *q = &s.px[px_index(tu, 2 * rp + e, g * OPL + o)];
+        *q = (uint8_t)clip8(*q + ((acc[e][o] + 2048) >> 12));
+      }
+  }
+  __syncthreads();
+}
 
 // DEC = false: encoder (residual from the source picture, levels written out).
 // DEC = true: decoder (levels and cbf given, prediction + residual only).
 template <bool DEC>
 __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
 {
-  __shared__ int a[1024], b[1024];
-  __shared__ int16_t lev[1024];
-  __shared__ uint8_t pred[1024];
-  __shared__ int8_t C[32][33];
-  __shared__ uint32_t nz[3];
+  __shared__ InterLds s;
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
   const int bi0 = b8idx(f, x0, y0);
   const bool split = f.cu_log2[bi0] == 4;
   const int cw2 = f.cw >> 1, ch2 = f.ch >> 1;
-  load_dct_matrix(C, tid, 256);
-  if (tid < 3) nz[tid] = 0;
+  // matrices of the two block sizes in use (luma n, chroma n / 2): adjacent in the table
+  if (split) load_matrices(s.M, 16, 64 + 256, tid, 256); else load_matrices(s.M, 80, 256 + 1024, tid, 256);
+  if (tid < 2) s.nz[tid] = 0;
+  if (tid < 4) {
+    int bi = b8idx(f, x0 + (tid & 1) * 16, y0 + (tid >> 1) * 16);
+    s.mv[tid][0] = f.cu_mv[bi * 2]; s.mv[tid][1] = f.cu_mv[bi * 2 + 1];
+  }
   __syncthreads();
-  // ---- luma: prediction and residual, TU-major layout
-  const int l2 = split ? 4 : 5, n = 1 << l2;
-  for (int o = tid; o < 1024; o += 256) {
-    int y = o >> 5, x = o & 31;
-    int bi = b8idx(f, x0 + x, y0 + y);
-    int p = mc_luma_sample(f.ref[0], f.cw, f.ch, x0 + x, y0 + y, f.cu_mv[bi * 2], f.cu_mv[bi * 2 + 1]);
-    int tu = split ? ((y >> 4) * 2 + (x >> 4)) : 0;
-    int idx = (tu << (2 * l2)) + ((y & (n - 1)) << l2) + (x & (n - 1));
-    pred[idx] = (uint8_t)p;
+  // ---- luma: prediction (four samples per thread), residual / dequantised levels TU-major into s.A
+  {
+    const int y = tid >> 3, x = (tid & 7) * 4, k = (y >> 4) * 2 + (x >> 4);
+    const int l2 = split ? 4 : 5, n = 1 << l2, tu = split ? k : 0;
+    const uint32_t p4 = mc_luma4(f.ref[0], f.cw, f.ch, x0 + x, y0 + y, s.mv[k][0], s.mv[k][1]);
+    *(uint32_t *)&s.px[y * 32 + x] = p4;
+    const size_t g = (size_t)(y0 + y) * f.cw + x0 + x;
+    int16_t *A = s.A + (tu << (2 * l2));
+    const int ty = y & (n - 1), tx = x & (n - 1);
     if (DEC) {
-      bool has = f.cu_cbf[bi] & 1;
-      b[idx] = has ? dequant_coef(f.coef[0][(y0 + y) * f.cw + x0 + x], f.qp, l2) : 0;
-      if (has) atomicOr(&nz[0], 1u << tu);
-    } else a[idx] = (int)f.src[0][(y0 + y) * f.cw + x0 + x] - p;
+      const bool has = f.cu_cbf[b8idx(f, x0 + x, y0 + y)] & 1;
+      if (has) {
+        atomicOr(&s.nz[0], 1u << tu);
+        const uint2 l4 = *(const uint2 *)&f.coef[0][g];
+        const int lv[4] = {(int16_t)(l4.x & 0xffff), (int16_t)(l4.x >> 16), (int16_t)(l4.y & 0xffff), (int16_t)(l4.y >> 16)};
+        for (int i = 0; i < 4; i++) A[(tx + i) * n + ty] = (int16_t)dequant_coef(lv[i], f.qp, l2);
+      }
+    } else {
+      const uint32_t s4 = *(const uint32_t *)&f.src[0][g];
+      int r[4];
+      for (int i = 0; i < 4; i++) r[i] = (int)((s4 >> (8 * i)) & 255) - (int)((p4 >> (8 * i)) & 255);
+      *(uint2 *)&A[ty * n + tx] = make_uint2(pack_i16(r[0], r[1]), pack_i16(r[2], r[3]));
+    }
   }
   __syncthreads();
-  if (DEC) inverse_group(a, b, C, l2, 1024, 256, tid);
-  else code_group(a, b, lev, C, l2, split ? 4 : 1, f.qp, 0, &nz[0], 256, tid);
-  for (int o = tid; o < 1024; o += 256) {
-    int tu = o >> (2 * l2), rem = o & (n * n - 1), r = rem >> l2, c = rem & (n - 1);
-    int x = (split ? (tu & 1) * 16 : 0) + c, y = (split ? (tu >> 1) * 16 : 0) + r;
-    bool has = (nz[0] >> tu) & 1;
-    int g = (y0 + y) * f.cw + x0 + x;
-    f.rec[0][g] = (uint8_t)(has ? clip8(pred[o] + b[o]) : pred[o]);
-    if (has && !DEC) f.coef[0][g] = lev[o];
+  {
+    auto px32 = [](int, int y, int x) { return y * 32 + x; };
+    auto px16 = [](int tu, int y, int x) { return ((tu >> 1) * 16 + y) * 32 + (tu & 1) * 16 + x; };
+    const int cw = f.cw; int16_t *base = f.coef[0] + (size_t)y0 * cw + x0;
+    auto ci32 = [=](int, int y, int x) { return base + (size_t)y * cw + x; };
+    auto ci16 = [=](int tu, int y, int x) { return base + (size_t)((tu >> 1) * 16 + y) * cw + (tu & 1) * 16 + x; };
+    if (split) inter_transform<DEC, 4, 2>(s, f.qp, &s.nz[0], px16, ci16, tid);
+    else inter_transform<DEC, 5, 2>(s, f.qp, &s.nz[0], px32, ci32, tid);
   }
-  __syncthreads();
-  // ---- chroma: Cb and Cr together (512 samples): plane-major, then TU-major
-  const int cl2 = l2 - 1, cn = 1 << cl2;
-  for (int o = tid; o < 512; o += 256) {
-    int pl = o >> 8, y = (o >> 4) & 15, x = o & 15;
-    int cx = (x0 >> 1) + x, cy = (y0 >> 1) + y;
-    int bi = b8idx(f, x0 + 2 * x, y0 + 2 * y);
-    int p = mc_chroma_sample(f.ref[1 + pl], cw2, ch2, cx, cy, f.cu_mv[bi * 2], f.cu_mv[bi * 2 + 1]);
-    int tu = pl * (split ? 4 : 1) + (split ? ((y >> 3) * 2 + (x >> 3)) : 0);
-    int idx = (tu << (2 * cl2)) + ((y & (cn - 1)) << cl2) + (x & (cn - 1));
-    pred[idx] = (uint8_t)p;
+  *(uint32_t *)&f.rec[0][(size_t)(y0 + (tid >> 3)) * f.cw + x0 + (tid & 7) * 4] = *(const uint32_t *)&s.px[(tid >> 3) * 32 + (tid & 7) * 4];
+  // ---- chroma: reference windows of the eight 8x8 sub-blocks (plane x quadrant) -> LDS; mv in 1/8 samples
+  for (int i = tid; i < 8 * 121; i += 256) {
+    const int w8 = i / 121, r = i - w8 * 121, wy = r / 11, wx = r - wy * 11, pl = w8 >> 2, sub = w8 & 3, k = split ? sub : 0;
+    const int xi = (x0 >> 1) + (sub & 1) * 8 + (s.mv[k][0] >> 3) + wx - 1, yi = (y0 >> 1) + (sub >> 1) * 8 + (s.mv[k][1] >> 3) + wy - 1;
+    s.win[pl][sub][wy * 12 + wx] = f.ref[1 + pl][(size_t)clip3(0, ch2 - 1, yi) * cw2 + clip3(0, cw2 - 1, xi)];
+  }
+  __syncthreads();                           // (also: every thread has copied its luma samples out of s.px)
+  {
+    // two samples per thread; the separable 4-tap form with the {0, 64, 0, 0} filter at fraction 0 covers every case of
+    // 8.5.3.3.3.2 exactly: (64 * t) >> 6 == t
+    const int pl = tid >> 7, y = (tid >> 3) & 15, x = (tid & 7) * 2, sub = (y >> 3) * 2 + (x >> 3), k = split ? sub : 0;
+    const int xf = s.mv[k][0] & 7, yf = s.mv[k][1] & 7;
+    const uint8_t *w = &s.win[pl][sub][(y & 7) * 12 + (x & 7)];
+    int v0 = 0, v1 = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int c[5];
+#pragma unroll
+      for (int i = 0; i < 5; i++) c[i] = w[j * 12 + i];
+      int t0 = 0, t1 = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) { t0 += kChromaFilter[xf][i] * c[i]; t1 += kChromaFilter[xf][i] * c[i + 1]; }
+      v0 += kChromaFilter[yf][j] * t0; v1 += kChromaFilter[yf][j] * t1;
+    }
+    const int p0 = clip8(((v0 >> 6) + 32) >> 6), p1 = clip8(((v1 >> 6) + 32) >> 6);
+    *(uint16_t *)&s.px[pl * 256 + y * 16 + x] = (uint16_t)(p0 | (p1 << 8));
+    const int cl2 = split ? 3 : 4, cn = 1 << cl2, tu = pl * (split ? 4 : 1) + (split ? sub : 0);
+    const size_t g = (size_t)((y0 >> 1) + y) * cw2 + (x0 >> 1) + x;
+    int16_t *A = s.A + (tu << (2 * cl2));
+    const int ty = y & (cn - 1), tx = x & (cn - 1);
     if (DEC) {
-      bool has = (f.cu_cbf[bi] >> (1 + pl)) & 1;
-      b[idx] = has ? dequant_coef(f.coef[1 + pl][cy * cw2 + cx], f.qpc, cl2) : 0;
-      if (has) atomicOr(&nz[1], 1u << tu);
-    } else a[idx] = (int)f.src[1 + pl][cy * cw2 + cx] - p;
+      const bool has = (f.cu_cbf[b8idx(f, x0 + 2 * x, y0 + 2 * y)] >> (1 + pl)) & 1;
+      if (has) {
+        atomicOr(&s.nz[1], 1u << tu);
+        const uint32_t l2v = *(const uint32_t *)&f.coef[1 + pl][g];
+        A[tx * cn + ty] = (int16_t)dequant_coef((int16_t)(l2v & 0xffff), f.qpc, cl2);
+        A[(tx + 1) * cn + ty] = (int16_t)dequant_coef((int16_t)(l2v >> 16), f.qpc, cl2);
+      }
+    } else {
+      const uint32_t s2 = *(const uint16_t *)&f.src[1 + pl][g];
+      *(uint32_t *)&A[ty * cn + tx] = pack_i16((int)(s2 & 255) - p0, (int)(s2 >> 8) - p1);
+    }
   }
   __syncthreads();
-  if (DEC) inverse_group(a, b, C, cl2, 512, 256, tid);
-  else code_group(a, b, lev, C, cl2, split ? 8 : 2, f.qpc, 0, &nz[1], 256, tid);
-  for (int o = tid; o < 512; o += 256) {
-    int tu = o >> (2 * cl2), rem = o & (cn * cn - 1), r = rem >> cl2, c = rem & (cn - 1);
-    int pl = split ? (tu >> 2) : tu, st = split ? (tu & 3) : 0;
-    int x = (split ? (st & 1) * 8 : 0) + c, y = (split ? (st >> 1) * 8 : 0) + r;
-    bool has = (nz[1] >> tu) & 1;
-    int g = ((y0 >> 1) + y) * cw2 + (x0 >> 1) + x;
-    f.rec[1 + pl][g] = (uint8_t)(has ? clip8(pred[o] + b[o]) : pred[o]);
-    if (has && !DEC) f.coef[1 + pl][g] = lev[o];
+  {
+    auto px1 = [](int tu, int y, int x) { return tu * 256 + y * 16 + x; };
+    auto px4 = [](int tu, int y, int x) { return (tu >> 2) * 256 + (((tu >> 1) & 1) * 8 + y) * 16 + (tu & 1) * 8 + x; };
+    const size_t base = (size_t)(y0 >> 1) * cw2 + (x0 >> 1);
+    int16_t *cb = f.coef[1] + base, *cr = f.coef[2] + base;
+    auto ci1 = [=](int tu, int y, int x) { return (tu ? cr : cb) + (size_t)y * cw2 + x; };
+    auto ci4 = [=](int tu, int y, int x) { return ((tu >> 2) ? cr : cb) + (size_t)(((tu >> 1) & 1) * 8 + y) * cw2 + (tu & 1) * 8 + x; };
+    if (split) inter_transform<DEC, 3, 1>(s, f.qpc, &s.nz[1], px4, ci4, tid);
+    else inter_transform<DEC, 4, 1>(s, f.qpc, &s.nz[1], px1, ci1, tid);
   }
-  __syncthreads();
+  if (tid < 128) {
+    const int pl = tid >> 6, y = (tid >> 2) & 15, x = (tid & 3) * 4;
+    *(uint32_t *)&f.rec[1 + pl][(size_t)((y0 >> 1) + y) * cw2 + (x0 >> 1) + x] = *(const uint32_t *)&s.px[pl * 256 + y * 16 + x];
+  }
   if (!DEC && tid < 16) {
     int bx = tid & 3, by = tid >> 2, k = split ? ((by >> 1) * 2 + (bx >> 1)) : 0;
-    int cbf = (int)((nz[0] >> k) & 1);
-    if (split) cbf |= (int)((nz[1] >> k) & 1) << 1 | (int)((nz[1] >> (4 + k)) & 1) << 2;
-    else cbf |= (int)(nz[1] & 1) << 1 | (int)((nz[1] >> 1) & 1) << 2;
+    int cbf = (int)((s.nz[0] >> k) & 1);
+    if (split) cbf |= (int)((s.nz[1] >> k) & 1) << 1 | (int)((s.nz[1] >> (4 + k)) & 1) << 2;
+    else cbf |= (int)(s.nz[1] & 1) << 1 | (int)((s.nz[1] >> 1) & 1) << 2;
     f.cu_cbf[b8idx(f, x0 + bx * 8, y0 + by * 8)] = (uint8_t)cbf;
   }
 }
@@ -455,13 +558,6 @@ __shared__ long long g_prof[16];
 #else
 #define PROF(k) do { } while (0)
 #endif
-typedef short kv_short2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int dot2_i16(uint32_t a, uint32_t b, int c)
-{
-  return __builtin_amdgcn_sdot2(__builtin_bit_cast(kv_short2, a), __builtin_bit_cast(kv_short2, b), c, false);
-}
-__device__ __forceinline__ uint32_t pack_i16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
-
 struct IntraWaveLds {
   // The CTU being reconstructed with its borders, as one padded picture: row 0 = the sample row above the CTU
   // (above-left corner, above, above-right), column 15 = the sample column to its left, sample (x, y) of the
@@ -470,51 +566,16 @@ struct IntraWaveLds {
   alignas(16) uint8_t src[64 * 64];          // encoder: source samples of the CTU
   alignas(16) int16_t lev[64 * 64];          // encoder: levels produced; decoder: levels to reconstruct from
   alignas(16) int16_t A[32 * 32], B[32 * 32];
-  alignas(16) int16_t M[2][1360];            // [0]: M_n[j][m], [1]: its transpose; n = 4, 8, 16, 32 at 0, 16, 80, 336
+  alignas(16) int16_t M[2][KV_MATRIX_ENTRIES];
   // reference samples of the current block in the scan order of 8.4.4.2.2 (index 0 = bottom of the below-left
   // group, 2n = corner, 4n = end of above-right): [0] as built, [1] filtered (8.4.4.2.3).  Sample i sits at
   // byte 3 + i, which makes the "above" run (2n + 1 ...) dword aligned.  left[k] = R[2n - k], top[k] = R[2n + k].
   alignas(16) uint8_t R[2][144];
 };
-__device__ __forceinline__ int matrix_offset(int l2) { return l2 == 2 ? 0 : (l2 == 3 ? 16 : (l2 == 4 ? 80 : 336)); }
-
-template <int L2> struct XF {
+// lane layout of one block inside the 64-lane wave
+template <int L2> struct XW {
   static constexpr int N = 1 << L2, OPL = (L2 == 5) ? 8 : (L2 == 4 ? 2 : 1), G = N / OPL, LANES = (N / 2) * G;
 };
-
-// raw sums of P for the lane's two rows (2rp, 2rp + 1) and its OPL outputs g * OPL + o
-template <int L2>
-__device__ __forceinline__ void xf_sums(const int16_t *in, const int16_t *T, int rp, int g, int (&acc)[2][XF<L2>::OPL])
-{
-  constexpr int N = XF<L2>::N, OPL = XF<L2>::OPL, H = N / 2;
-  const uint32_t *r0 = (const uint32_t *)(in + 2 * rp * N);
-  uint32_t a0[H], a1[H];
-#pragma unroll
-  for (int m = 0; m < H; m++) { a0[m] = r0[m]; a1[m] = r0[H + m]; }
-#pragma unroll
-  for (int o = 0; o < OPL; o++) {
-    const uint32_t *t = (const uint32_t *)(T + (g * OPL + o) * N);
-    int s0 = 0, s1 = 0;
-#pragma unroll
-    for (int m = 0; m < H; m++) { uint32_t tv = t[m]; s0 = dot2_i16(a0[m], tv, s0); s1 = dot2_i16(a1[m], tv, s1); }
-    acc[0][o] = s0; acc[1][o] = s1;
-  }
-}
-// plain stage: out[j][i] = clip16((sum + rnd) >> shift), stored as packed row pairs
-template <int L2>
-__device__ __forceinline__ void xf_stage(const int16_t *in, int16_t *out, const int16_t *T, int shift, int lane)
-{
-  constexpr int N = XF<L2>::N, OPL = XF<L2>::OPL, G = XF<L2>::G;
-  if (lane >= XF<L2>::LANES) return;
-  const int rp = lane / G, g = lane % G, rnd = 1 << (shift - 1);
-  int acc[2][OPL];
-  xf_sums<L2>(in, T, rp, g, acc);
-#pragma unroll
-  for (int o = 0; o < OPL; o++) {
-    int v0 = clip3(-32768, 32767, (acc[0][o] + rnd) >> shift), v1 = clip3(-32768, 32767, (acc[1][o] + rnd) >> shift);
-    ((uint32_t *)out)[((g * OPL + o) * N) / 2 + rp] = pack_i16(v0, v1);
-  }
-}
 
 // Intra sample prediction (8.4.4.2.4-6) from the reference array R (scan order, see IntraWaveLds); the same
 // arithmetic as intra_pred_sample() of hevc_core.h, indexed for R.  s = +1 / -1 walks the main side.
@@ -552,7 +613,7 @@ template <bool DEC, int L2>
 __device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, int cidx, int S, int X, int Y, int rx, int ry,
                                             int mode, int angle, int inv, int qp, bool has_levels, int lane)
 {
-  constexpr int N = XF<L2>::N, OPL = XF<L2>::OPL, G = XF<L2>::G;
+  constexpr int N = XW<L2>::N, OPL = XW<L2>::OPL, G = XW<L2>::G;
   const int sh = cidx ? 1 : 0, nl = N << sh, P = 16 + 2 * S;
   const bool filt = intra_filter_needed(N, cidx, mode);
   // ---- reference samples (8.4.4.2.2) and their filtered version (8.4.4.2.3).  Availability is decided per group
@@ -599,7 +660,7 @@ __device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, 
   }
   PROF(4);
   // ---- prediction for the lane's samples: rows 2rp, 2rp + 1, columns g * OPL .. + OPL - 1
-  const bool active = lane < XF<L2>::LANES;
+  const bool active = lane < XW<L2>::LANES;
   const int rp = lane / G, g = lane % G;
   const bool edge = cidx == 0 && N < 32;                 // boundary smoothing of DC / pure horizontal / pure vertical
   int pred[2][OPL];
@@ -637,13 +698,13 @@ __device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, 
     }
     __syncthreads();
     const int16_t *Mf = s.M[0] + matrix_offset(L2);
-    xf_stage<L2>(s.A, s.B, Mf, L2 - 1, lane);
+    if (active) xf_stage<L2, OPL>(s.A, s.B, Mf, L2 - 1, rp, g);
     __syncthreads();
     PROF(6);
     bool nz = false;
     if (active) {
       int acc[2][OPL];
-      xf_sums<L2>(s.B, Mf, rp, g, acc);
+      xf_sums<L2, OPL>(s.B, Mf, rp, g, acc);
       const int shift = L2 + 6, rnd = 1 << (shift - 1);
 #pragma unroll
       for (int o = 0; o < OPL; o++) {
@@ -676,12 +737,12 @@ __device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, 
   // ---- inverse columns -> B, inverse rows + reconstruction
   if (cbf) {
     const int16_t *Mt = s.M[1] + matrix_offset(L2);
-    xf_stage<L2>(s.A, s.B, Mt, 7, lane);
+    if (active) xf_stage<L2, OPL>(s.A, s.B, Mt, 7, rp, g);
     __syncthreads();
     PROF(8);
     if (active) {
       int acc[2][OPL];
-      xf_sums<L2>(s.B, Mt, rp, g, acc);
+      xf_sums<L2, OPL>(s.B, Mt, rp, g, acc);
 #pragma unroll
       for (int e = 0; e < 2; e++)
 #pragma unroll
@@ -707,11 +768,7 @@ __global__ __launch_bounds__(64) void k_intra_recon(EncFrame f)
   const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, qp = c ? f.qpc : f.qp, P = 16 + 2 * S;
   uint32_t *my_ctr = f.sync + row * 3 + c;
   const uint32_t *up_ctr = f.sync + (row - 1) * 3 + c;
-  for (int i = lane; i < 1360; i += 64) {
-    int l2 = i < 16 ? 2 : (i < 80 ? 3 : (i < 336 ? 4 : 5)), k = i - matrix_offset(l2), j = k >> l2, m = k & ((1 << l2) - 1);
-    s.M[0][i] = kDct32[j << (5 - l2)][m];
-    s.M[1][i] = kDct32[m << (5 - l2)][j];
-  }
+  load_matrices(s.M, 0, KV_MATRIX_ENTRIES, lane, 64);
   int zx, zy; ctu_z_to_xy(lane, zx, zy);                  // this lane's 8x8 luma block of the CTU, in z-order
 #ifdef KVZ_PROF
   if (lane < 16) g_prof[lane] = 0;

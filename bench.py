@@ -43,8 +43,8 @@ def algorithmic_bytes(kernel, cw, ch, me_range):
         return P
     if kernel == "k_deblock":
         return int(3.0 * P)
-    if kernel == "k_entropy":                     # every level of the picture once (int16) -- an upper bound
-        return int(3.0 * P)
+    if kernel == "k_tokenize":                    # every level of the picture once (int16) + the per-8x8 CU records; tokens out not counted
+        return int(3.0 * P) + (P // 64) * 11
     if kernel == "k_pad_input":
         return int(3.0 * P)
     if kernel == "k_inter_signal":
@@ -82,8 +82,9 @@ def main():
     ap.add_argument("--me-range", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
-    ap.add_argument("--decoder-frame-threads", type=int, default=4,
+    ap.add_argument("--decoder-frame-threads", type=int, default=6,
                     help="OpenHEVC 'Frame' parallelisation (uvgComm setting video/OH_parallelization): pictures parsed concurrently; 1 = off")
+    ap.add_argument("--profile-every", type=int, default=8, help="kernel timing with HIP events on every n-th picture")
     ap.add_argument("--owf", type=int, default=1,
                     help="uvgComm setting video/OWF (kvazaar owf): 1 = host arithmetic coding of picture t overlaps the kernels of t + 1")
     args = ap.parse_args()
@@ -108,7 +109,7 @@ def main():
     w, h = wl["w"], wl["h"]
     total = args.warmup + args.steps
     D = max(1, args.decoder_frame_threads)
-    extra = D - 1 + (1 if args.owf > 0 else 0)   # pictures pushed after the timed ones: the encoder (owf) and the frame-threaded decoder deliver with a lag
+    extra = (D if D > 1 else 0) + (1 if args.owf > 0 else 0)   # pictures pushed after the timed ones: the encoder (owf) and the frame-threaded decoder deliver with a lag
     seed = 0x5EED0000 + wl["cfg_index"] + 16 * rank
     # synthetic clip generated directly in HBM (inputs resident before the timed region)
     clip = [synth.frame_torch(synth.MOVING, seed, w, h, t, dev) for t in range(total + extra)]
@@ -125,11 +126,14 @@ def main():
     cw, ch = cw.value, ch.value
 
     def run(first, count):
-        """push pictures until `first + count` have been DECODED; at most D + 5 in flight (a filter drops inputs when its buffer overflows)"""
+        """push pictures until `first + count` have been DECODED.  The feeder keeps the encoder filter's input buffer
+        short of its overflow threshold (a uvgComm filter drops inputs at 10 buffered, filter.cpp:151-222)."""
         g = pl.pushed
-        while g < min(first + count + extra, total + extra):
-            if g >= D + 5 and not pl.wait(g - D - 4, 20000):
-                raise RuntimeError("pipeline stalled at picture %d" % g)
+        last = min(first + count + extra, total + extra)
+        while g < last:
+            if pl.backlog() >= 6:
+                pl.wait(pl.stats()["decoded_pictures"] + 1, 50)     # sleep until the pipeline has moved on
+                continue
             pl.push_device(clip[g].data_ptr())
             g += 1
         if not pl.wait(first + count, 120000):
@@ -150,8 +154,11 @@ def main():
         return out
 
     run(0, args.warmup)
-    lib.kvzx_encoder_set_profiling(enc_h, 1)
-    lib.kvzx_decoder_set_profiling(dec_h, 1)
+    # HIP events around every kernel of every 8th picture of the timed region (IDR pictures fall on multiples of 8)
+    prof = 0 if os.environ.get("KVAZZUP_BENCH_NOPROF") else args.profile_every
+    lib.kvzx_encoder_set_profiling(enc_h, prof)
+    lib.kvzx_decoder_set_profiling(dec_h, prof)
+    busy0 = pl.busy_ms()
     times(True)
     torch.cuda.synchronize()
     if world > 1:
@@ -167,6 +174,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kt = times(False)
+    busy = [round((b - a) / args.steps, 4) for a, b in zip(busy0, pl.busy_ms())]
     st = pl.stats()
     nbytes = st["encoded_bytes"] * args.steps / max(1, st["encoded_pictures"])
     if st["decoded_pictures"] < total or st["dropped"]:
@@ -175,7 +183,18 @@ def main():
 
     if rank == 0:
         fps = world * args.steps / elapsed
-        dom = max((k for k in kt if kt[k][1] > 0 and k.startswith("k_")), key=lambda k: kt[k][0])
+        if not any(v[1] for v in kt.values()):
+            kt = {"k_none": (1e-9, 1)}          # KVAZZUP_BENCH_NOPROF=1: throughput-only run (no roofline)
+        # dominant kernel = largest share of the timed region: average launch time x launches in the region (the
+        # events sample every n-th picture, so the launch counts come from the picture types, not from the samples)
+        n_idr = sum(1 for t in range(args.warmup, total) if t % 64 == 0)
+        def launches(k):
+            if k.startswith("k_intra"):
+                return n_idr
+            if k in ("k_me", "k_inter_recon", "k_inter_signal", "k_inter_recon<dec>"):
+                return args.steps - n_idr
+            return args.steps
+        dom = max((k for k in kt if kt[k][1] > 0 and k.startswith("k_")), key=lambda k: kt[k][0] / kt[k][1] * launches(k))
         avg_s = kt[dom][0] / kt[dom][1] / 1e3
         ab = algorithmic_bytes(dom, cw, ch, args.me_range)
         achieved = ab / avg_s / 1e9
@@ -193,7 +212,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(avg_s * 1e6, 2)},
             "kernels_us": {k: round(v[0] / v[1] * 1e3, 2) for k, v in kt.items() if v[1]},
-            "kernel_share_of_step": {k: round(v[0] / (elapsed * 1e3), 4) for k, v in kt.items() if v[1]},
+            "filter_busy_ms_per_step": {"KvazaarFilter": busy[0], "WireAdapter": busy[1], "OpenHEVCFilter": busy[2]},
+            "kernel_share_of_step": {k: round(v[0] / v[1] * launches(k) / (elapsed * 1e3), 4) for k, v in kt.items() if v[1]},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

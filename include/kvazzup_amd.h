@@ -36,7 +36,7 @@ KVZ_PUBLIC int kvzx_encoder_recon_device(kvz_encoder *enc, const void **planes /
  * "cu_merge_idx", "cu_mvp_idx", "cu_intra_mode", "cu_cbf" (one byte per 8x8 block), "cu_mv", "cu_mvd"
  * (two int16 per 8x8 block), "coef0".."coef2" (int16 planes), "rec0".."rec2", "src0".."src2" */
 KVZ_PUBLIC int kvzx_encoder_debug_copy(kvz_encoder *enc, const char *what, void *dst, size_t bytes);
-KVZ_PUBLIC void kvzx_encoder_set_profiling(kvz_encoder *enc, int on);
+KVZ_PUBLIC void kvzx_encoder_set_profiling(kvz_encoder *enc, int every);   /* 0 off, 1 every picture, n every n-th picture */
 #define KVZX_MAX_KERNELS 16
 /* accumulated HIP-event time (ms) and launch count per kernel id since the last reset */
 KVZ_PUBLIC int kvzx_encoder_kernel_times(kvz_encoder *enc, double *ms, uint64_t *launches, int reset);
@@ -53,7 +53,7 @@ KVZ_PUBLIC int kvzx_decoder_last_error(OpenHevc_Handle h);
 KVZ_PUBLIC int kvzx_decoder_output_device(OpenHevc_Handle h, const void **planes /*[3]*/, int *pitches /*[3]*/);
 /* when 0, libOpenHevcDecode leaves the picture in HBM and libOpenHevcGetOutput returns NULL planes */
 KVZ_PUBLIC void kvzx_decoder_set_download(OpenHevc_Handle h, int on);
-KVZ_PUBLIC void kvzx_decoder_set_profiling(OpenHevc_Handle h, int on);
+KVZ_PUBLIC void kvzx_decoder_set_profiling(OpenHevc_Handle h, int every);
 KVZ_PUBLIC int kvzx_decoder_kernel_times(OpenHevc_Handle h, double *ms, uint64_t *launches, int reset);
 KVZ_PUBLIC const char *kvzx_decoder_kernel_name(int id);
 KVZ_PUBLIC int kvzx_decoder_debug_copy(OpenHevc_Handle h, const char *what, void *dst, size_t bytes);
@@ -71,6 +71,7 @@ KVZ_PUBLIC uint32_t uvgx_pipeline_encoder_backlog(void *p);
 KVZ_PUBLIC int uvgx_pipeline_pop_encoded(void *p, uint8_t *buf, uint32_t cap, uint32_t *size, int64_t *pts);
 KVZ_PUBLIC int uvgx_pipeline_pop_decoded(void *p, uint8_t *buf, uint32_t cap, uint32_t *size, int *w, int *h, int64_t *pts);
 KVZ_PUBLIC void uvgx_pipeline_stats(void *p, uint64_t *out8);
+KVZ_PUBLIC void uvgx_pipeline_busy_ms(void *p, double *out3);   /* time inside process(): encoder, wire adapter, decoder filter */
 KVZ_PUBLIC void *uvgx_pipeline_encoder(void *p);     /* kvz_encoder* of the KvazaarFilter */
 KVZ_PUBLIC void *uvgx_pipeline_decoder(void *p);     /* OpenHevc_Handle of the OpenHEVCFilter (NULL without loop-back) */
 KVZ_PUBLIC void uvgx_pipeline_destroy(void *p);

@@ -77,7 +77,7 @@ class FrameWorkers {
 class Decoder {
  public:
   explicit Decoder(int device) : device_(device) {}
-  // frame threading: up to n pictures are parsed concurrently and the output is delayed by n - 1 pictures
+  // frame threading: up to n pictures are parsed concurrently while one more is reconstructed on the GPU; the output is delayed by n pictures
   // (libOpenHevcInit(nb_threads, OH_THREAD_FRAME / OH_THREAD_FRAMESLICE)); call before the first picture
   void set_frame_threads(int n) { if (jobs_.empty()) frame_threads_ = n < 1 ? 1 : (n > 16 ? 16 : n); }
   int frame_threads() const { return frame_threads_; }
@@ -87,13 +87,13 @@ class Decoder {
   int decode_nal(const uint8_t *data, size_t len, int64_t pts);
   bool get_picture(DecodedPicture *out);   // the picture announced by the last decode_nal() == 1
   void set_download(bool on) { download_ = on; }
-  void set_profiling(bool on) { profiling_ = on; }
+  void set_profiling(int every) { profiling_ = every > 0; prof_every_ = every > 0 ? every : 1; }   // n: every n-th picture
   void set_parse_threads(int n) { if (!pool_) parse_threads_ = n < 1 ? 1 : n; }
   void get_kernel_times(double *ms, uint64_t *launches, bool reset);
   bool debug_copy(const char *what, void *dst, size_t bytes);
   int last_error() const { return last_error_; }
   void flush() {}
-  int pending() const { return (int)(job_head_ - job_tail_); }
+  int pending() const { return (int)(job_head_ - job_tail_) + (gpu_job_ ? 1 : 0); }
 
  private:
   bool ensure_buffers(int cw, int ch);
@@ -112,7 +112,7 @@ class Decoder {
     std::vector<int16_t> levels; std::vector<TuDesc> tus;
     std::vector<RowState> rows; std::vector<uint8_t> wpp_saved;
     std::unique_ptr<Progress[]> row_progress; int row_progress_n = 0;
-    std::atomic<int> state{0}; int rc = 0; double parse_ms = 0;
+    std::atomic<int> state{0}; int rc = 0; double parse_ms = 0; int rec_idx = 0;
     PicJob() {}
     PicJob(const PicJob &) {}                                  // (vector<PicJob> construction only)
   };
@@ -120,7 +120,8 @@ class Decoder {
   int parse_row(PicJob &job, int row, const uint8_t *data, size_t len, RowState &rs);
   int finish_oldest();
   void drop_pending();
-  int run_gpu(PicJob &job);
+  int launch_gpu(PicJob &job);
+  int complete_gpu();
 
   int device_; bool started_ = false;
   hipStream_t stream_ = nullptr;
@@ -132,17 +133,19 @@ class Decoder {
   // device side
   EncFrame f_{};
   uint8_t *d_cu_ = nullptr; int16_t *d_mv_ = nullptr, *d_mvd_ = nullptr;
-  uint8_t *rec_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  uint8_t *rec_[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   int16_t *coef_[3] = {nullptr, nullptr, nullptr};
   int16_t *d_levels_ = nullptr; size_t d_levels_cap_ = 0; TuDesc *d_tus_ = nullptr; size_t d_tus_cap_ = 0;
   uint32_t *sync_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
   uint8_t *h_out_ = nullptr; size_t h_out_cap_ = 0;
-  int cur_idx_ = 0, ref_idx_ = 1; bool have_ref_ = false;
+  long launched_ = 0; int out_idx_ = 0; bool have_ref_ = false;
+  PicJob *gpu_job_ = nullptr;             // picture whose kernels are in flight (frame-threaded mode)
   int poc_ = 0, prev_poc_ = 0;
-  bool download_ = true, profiling_ = false;
+  bool download_ = true, profiling_ = false, prof_now_ = false; int prof_every_ = 1;
   bool pic_ready_ = false; DecodedPicture out_;
   const DecSps *active_sps_ = nullptr;
   int last_error_ = 0;
+  double t_nal_ = 0, t_wait_ = 0, t_stage_ = 0, t_api_ = 0, t_sync_ = 0;     // decoder-thread time split (KVAZZUP_AMD_TRACE)
   std::vector<uint8_t> rbsp_;
   std::vector<size_t> epb_;                // unescaped payload offset of every removed emulation prevention byte
   std::vector<size_t> sub_start_;          // start of every WPP substream inside the unescaped slice data

@@ -114,6 +114,7 @@ struct CabacDec {
 };
 
 std::atomic<long> g_yields{0};
+struct Tick { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } };
 CoreTabs g_tabs;
 bool g_tabs_ready = false;
 const CoreTabs *host_tabs()
@@ -233,8 +234,9 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, int16_t *out)
 // Pictures still being parsed by frame workers are waited for and dropped (close / resolution change).
 void Decoder::drop_pending()
 {
+  if (gpu_job_) { hipStreamSynchronize(stream_); gpu_job_ = nullptr; ev_used_ = 0; }
   for (; job_tail_ != job_head_; job_tail_++) {
-    PicJob &job = jobs_[(size_t)(job_tail_ % frame_threads_)];
+    PicJob &job = jobs_[(size_t)(job_tail_ % (frame_threads_ + 1))];
     while (job.state.load(std::memory_order_acquire) != 2) std::this_thread::yield();
     job.state.store(0, std::memory_order_relaxed);
   }
@@ -242,6 +244,7 @@ void Decoder::drop_pending()
 
 Decoder::~Decoder()
 {
+  if (getenv("KVAZZUP_AMD_TRACE")) fprintf(stderr, "kvazzup_amd decoder thread ms: nal %.1f  wait_parse %.1f  stage %.1f  gpu_api %.1f  gpu_sync %.1f  (pictures %ld)\n", t_nal_, t_wait_, t_stage_, t_api_, t_sync_, job_tail_);
   drop_pending();
   workers_.reset();
   if (stream_) hipStreamSynchronize(stream_);
@@ -277,7 +280,7 @@ void Decoder::free_buffers()
   for (auto &j : jobs_) { if (j.h_cu) hipHostFree(j.h_cu); if (j.h_mv) hipHostFree(j.h_mv); j.h_cu = nullptr; j.h_mv = nullptr; }
   if (h_out_) hipHostFree(h_out_);
   hipFree(d_cu_); hipFree(d_mv_); hipFree(d_mvd_); hipFree(sync_);
-  for (int c = 0; c < 3; c++) { hipFree(rec_[0][c]); hipFree(rec_[1][c]); hipFree(coef_[c]); rec_[0][c] = rec_[1][c] = nullptr; coef_[c] = nullptr; }
+  for (int c = 0; c < 3; c++) { for (int b = 0; b < 3; b++) { hipFree(rec_[b][c]); rec_[b][c] = nullptr; } hipFree(coef_[c]); coef_[c] = nullptr; }
   h_out_ = nullptr; d_cu_ = nullptr; d_mv_ = nullptr; d_mvd_ = nullptr; sync_ = nullptr;
   cw_ = ch_ = 0;
 }
@@ -289,7 +292,7 @@ bool Decoder::ensure_buffers(int cw, int ch)
   hipStreamSynchronize(stream_);
   free_buffers();
   const size_t npx = (size_t)cw * ch, nb8 = npx / 64;
-  if (jobs_.empty()) jobs_ = std::vector<PicJob>((size_t)frame_threads_);
+  if (jobs_.empty()) jobs_ = std::vector<PicJob>((size_t)frame_threads_ + 1);   // parse ring + the picture in flight on the GPU
   for (auto &j : jobs_) {
     HIP_TRY(hipHostMalloc(&j.h_cu, nb8 * 7, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(&j.h_mv, nb8 * 2 * sizeof(int16_t), hipHostMallocDefault));
@@ -303,8 +306,7 @@ bool Decoder::ensure_buffers(int cw, int ch)
   HIP_TRY(hipMalloc(&sync_, sizeof(uint32_t) * 3 * (size_t)(ch / 64)));
   for (int c = 0; c < 3; c++) {
     size_t n = c ? npx / 4 : npx;
-    HIP_TRY(hipMalloc(&rec_[0][c], n)); HIP_TRY(hipMalloc(&rec_[1][c], n));
-    HIP_TRY(hipMemset(rec_[0][c], 128, n)); HIP_TRY(hipMemset(rec_[1][c], 128, n));
+    for (int b = 0; b < 3; b++) { HIP_TRY(hipMalloc(&rec_[b][c], n)); HIP_TRY(hipMemset(rec_[b][c], 128, n)); }
     HIP_TRY(hipMalloc(&coef_[c], n * sizeof(int16_t)));
   }
   cw_ = cw; ch_ = ch;
@@ -325,7 +327,7 @@ bool Decoder::ensure_buffers(int cw, int ch)
 
 template <class F> void Decoder::timed(int id, F &&launch)
 {
-  if (!profiling_) { launch(); return; }
+  if (!prof_now_) { launch(); return; }
   if (ev_used_ == ev_pool_.size()) { EvPair p; hipEventCreate(&p.a); hipEventCreate(&p.b); p.id = id; ev_pool_.push_back(p); }
   EvPair &p = ev_pool_[ev_used_++]; p.id = id;
   hipEventRecord(p.a, stream_); launch(); hipEventRecord(p.b, stream_);
@@ -339,6 +341,8 @@ void Decoder::get_kernel_times(double *ms, uint64_t *launches, bool reset)
 // ------------------------------------------------------------------------------------------ NAL units
 int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
 {
+  Tick tk_nal;
+  struct Acc { double &d; Tick &t; double &w, &s, &a, &y; double w0, s0, a0, y0; ~Acc() { d += t.ms() - ((w - w0) + (s - s0) + (a - a0) + (y - y0)); } } acc_{t_nal_, tk_nal, t_wait_, t_stage_, t_api_, t_sync_, t_wait_, t_stage_, t_api_, t_sync_};
   pic_ready_ = false;
   if (!started_) return last_error_ = DEC_ERR_GPU;
   size_t i = 0;
@@ -519,7 +523,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   // ---- hand the picture to a parse job.  With frame threads (libOpenHevcInit thread_type FRAME / FRAMESLICE)
   // up to `frame_threads_` pictures are parsed concurrently on worker threads -- CABAC parsing of a picture
   // needs nothing from other pictures -- and the output is delayed accordingly, like OpenHEVC's frame threading.
-  PicJob &job = jobs_[(size_t)(job_head_ % frame_threads_)];
+  PicJob &job = jobs_[(size_t)(job_head_ % (frame_threads_ + 1))];
   job.rbsp.assign(rbsp, rbsp + len + 32);                        // keeps the zero padding the CABAC reader relies on
   job.data_off = r.pos >> 3; job.data_len = len - (r.pos >> 3);
   job.sub_start = sub_start_;
@@ -551,26 +555,47 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
 }
 
 // Waits for the oldest submitted picture to be parsed, reconstructs it on the GPU and makes it the output.
+// Output stage.  Synchronous mode (frame_threads_ == 1): the picture just parsed is reconstructed and output.
+// Frame-threaded mode: first the picture launched by the previous call is completed and becomes the output,
+// then the oldest parsed picture is launched -- its kernels run while this thread goes on parsing headers.
 int Decoder::finish_oldest()
 {
-  if (job_head_ == job_tail_) return 0;
-  PicJob &job = jobs_[(size_t)(job_tail_ % frame_threads_)];
-  job_tail_++;
-  while (job.state.load(std::memory_order_acquire) != 2) std::this_thread::yield();
-  job.state.store(0, std::memory_order_relaxed);
-  if (frame_threads_ > 1 && profiling_) { k_ms_[DK_HOST_PARSE] += job.parse_ms; k_n_[DK_HOST_PARSE]++; }
-  if (job.rc < 0) return job.rc;
-  int rc = run_gpu(job);
-  if (rc < 0) return rc;
+  int produced = 0;
+  if (gpu_job_) { int rc = complete_gpu(); if (rc < 0) return rc; produced = 1; }
+  if (job_head_ != job_tail_) {
+    PicJob &job = jobs_[(size_t)(job_tail_ % (frame_threads_ + 1))];
+    job_tail_++;
+    { Tick tk; while (job.state.load(std::memory_order_acquire) != 2) std::this_thread::yield(); t_wait_ += tk.ms(); }
+    job.state.store(0, std::memory_order_relaxed);
+    if (frame_threads_ > 1 && profiling_) { k_ms_[DK_HOST_PARSE] += job.parse_ms; k_n_[DK_HOST_PARSE]++; }
+    if (job.rc < 0) return job.rc;
+    int rc = launch_gpu(job);
+    if (rc < 0) return rc;
+    if (frame_threads_ == 1) { rc = complete_gpu(); if (rc < 0) return rc; produced = 1; }
+  }
+  return produced;
+}
+
+int Decoder::complete_gpu()
+{
+  PicJob &job = *gpu_job_;
+  gpu_job_ = nullptr;
+  { Tick tk; if (hipStreamSynchronize(stream_) != hipSuccess) return DEC_ERR_GPU; t_sync_ += tk.ms(); }
+  if (*h_err_) { fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x\n", *h_err_); return DEC_ERR_GPU; }
+  if (ev_used_) {
+    for (size_t i = 0; i < ev_used_; i++) { float ms = 0; hipEventElapsedTime(&ms, ev_pool_[i].a, ev_pool_[i].b); k_ms_[ev_pool_[i].id] += ms; k_n_[ev_pool_[i].id]++; }
+    ev_used_ = 0;
+  }
   poc_ = job.poc;
   out_ = DecodedPicture();
   out_.coded_w = cw_; out_.coded_h = ch_;
   out_.width = cw_ - job.crop[0] - job.crop[1]; out_.height = ch_ - job.crop[2] - job.crop[3];
   out_.poc = job.poc; out_.pts = job.pts; out_.is_intra = job.is_intra;
   out_.fps_num = job.fps_num; out_.fps_den = job.fps_den;
+  out_idx_ = job.rec_idx;
   for (int c = 0; c < 3; c++) {
     int pw = c ? cw_ / 2 : cw_, ox = c ? job.crop[0] / 2 : job.crop[0], oy = c ? job.crop[2] / 2 : job.crop[2];
-    out_.dev[c] = rec_[ref_idx_][c] + (size_t)oy * pw + ox; out_.dev_pitch[c] = pw;
+    out_.dev[c] = rec_[out_idx_][c] + (size_t)oy * pw + ox; out_.dev_pitch[c] = pw;
   }
   if (download_) {
     // Host pitches are kept even and aligned like a software decoder's line sizes: the reference
@@ -760,7 +785,7 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
 }
 
 // ------------------------------------------------------------------------------------------ GPU reconstruction
-int Decoder::run_gpu(PicJob &job)
+int Decoder::launch_gpu(PicJob &job)
 {
   const bool is_intra = job.is_intra, deblock = job.deblock; const int slice_qp = job.slice_qp;
   std::vector<int16_t> &levels_ = job.levels; std::vector<TuDesc> &tus_ = job.tus;
@@ -784,15 +809,20 @@ int Decoder::run_gpu(PicJob &job)
     if (hipMalloc(&d_tus_, h_tus_cap_ * sizeof(TuDesc)) != hipSuccess) return DEC_ERR_GPU;
     d_tus_cap_ = h_tus_cap_;
   }
+  prof_now_ = profiling_ && (launched_ % prof_every_) == 0;
+  Tick tk_stage;
   if (nlev) memcpy(h_levels_, levels_.data(), nlev * sizeof(int16_t));
   if (ntu) memcpy(h_tus_, tus_.data(), ntu * sizeof(TuDesc));
+  t_stage_ += tk_stage.ms();
+  Tick tk_api;
   hipError_t e = hipSuccess;
   e = hipMemcpyAsync(d_cu_, h_cu_, nb8 * 7, hipMemcpyHostToDevice, stream_); if (e != hipSuccess) return DEC_ERR_GPU;
   e = hipMemcpyAsync(d_mv_, h_mv_, nb8 * 4, hipMemcpyHostToDevice, stream_); if (e != hipSuccess) return DEC_ERR_GPU;
   if (nlev) { e = hipMemcpyAsync(d_levels_, h_levels_, nlev * sizeof(int16_t), hipMemcpyHostToDevice, stream_); if (e != hipSuccess) return DEC_ERR_GPU; }
   if (ntu) { e = hipMemcpyAsync(d_tus_, h_tus_, ntu * sizeof(TuDesc), hipMemcpyHostToDevice, stream_); if (e != hipSuccess) return DEC_ERR_GPU; }
   f_.qp = slice_qp; f_.qpc = kChromaQp[slice_qp]; f_.is_intra = is_intra;
-  for (int c = 0; c < 3; c++) { f_.rec[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
+  const int cur = (int)(launched_ % 3), ref = (int)((launched_ + 2) % 3);     // three buffers: the picture output by the previous call stays intact
+  for (int c = 0; c < 3; c++) { f_.rec[c] = rec_[cur][c]; f_.ref[c] = rec_[ref][c]; }
   const EncFrame f = f_;
   timed(DK_SCATTER, [&] { launch_scatter_levels(f, d_tus_, (int)ntu, d_levels_, stream_); });
   if (is_intra) {
@@ -803,13 +833,10 @@ int Decoder::run_gpu(PicJob &job)
   }
   if (deblock) timed(DK_DEBLOCK, [&] { launch_deblock(f, stream_); });
   if (hipMemcpyAsync(h_err_, err_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_) != hipSuccess) return DEC_ERR_GPU;
-  if (hipStreamSynchronize(stream_) != hipSuccess) return DEC_ERR_GPU;
-  if (*h_err_) { fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x\n", *h_err_); return DEC_ERR_GPU; }
-  if (profiling_) {
-    for (size_t i = 0; i < ev_used_; i++) { float ms = 0; hipEventElapsedTime(&ms, ev_pool_[i].a, ev_pool_[i].b); k_ms_[ev_pool_[i].id] += ms; k_n_[ev_pool_[i].id]++; }
-    ev_used_ = 0;
-  }
-  int t = cur_idx_; cur_idx_ = ref_idx_; ref_idx_ = t;          // rec_[ref_idx_] = picture just decoded
+  t_api_ += tk_api.ms();
+  job.rec_idx = cur;
+  launched_++;
+  gpu_job_ = &job;
   return 0;
 }
 
@@ -827,7 +854,7 @@ bool Decoder::debug_copy(const char *what, void *dst, size_t bytes)
   std::string w(what);
   for (int c = 0; c < 3; c++) {
     size_t n = c ? npx / 4 : npx;
-    if (w == std::string("rec") + char('0' + c)) { if (bytes > n) return false; return hipMemcpy(dst, rec_[ref_idx_][c], bytes, hipMemcpyDeviceToHost) == hipSuccess; }
+    if (w == std::string("rec") + char('0' + c)) { if (bytes > n) return false; return hipMemcpy(dst, rec_[out_idx_][c], bytes, hipMemcpyDeviceToHost) == hipSuccess; }
   }
   return false;
 }

@@ -55,7 +55,8 @@ class Encoder {
   int coded_width() const { return cw_; }
   int coded_height() const { return ch_; }
   const EncoderConfig &config() const { return cfg_; }
-  void set_profiling(bool on) { profiling_ = on; }
+  // every = 0: off; 1: every picture; n: every n-th picture (sampling keeps the event overhead out of the throughput)
+  void set_profiling(int every) { profiling_ = every > 0; prof_every_ = every > 0 ? every : 1; }
   // accumulated kernel time (ms) and launch count per KernelId since the last reset
   void get_kernel_times(double *ms, uint64_t *launches, bool reset);
   const uint8_t *device_recon(int plane) const { return rec_[out_idx_][plane]; }   // picture last output
@@ -99,7 +100,7 @@ class Encoder {
   EntropyHost *entropy_ = nullptr;
   std::vector<std::vector<uint8_t>> rows_out_;
   int frame_idx_ = 0, poc_ = 0, intra_count_ = 0;
-  bool profiling_ = false;
+  bool profiling_ = false, prof_now_ = false; int prof_every_ = 1;
   double k_ms_[K_COUNT] = {0}; uint64_t k_n_[K_COUNT] = {0};
   StreamParams sp_{};
 };

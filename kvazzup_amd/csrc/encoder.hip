@@ -117,7 +117,7 @@ Encoder::~Encoder()
 
 void Encoder::timed(KernelId id, const std::function<void()> &launch)
 {
-  if (!profiling_) { launch(); return; }
+  if (!prof_now_) { launch(); return; }
   Slot &sl = *cur_slot_;
   if (sl.ev_used == sl.ev.size()) {
     EvPair p; hipEventCreate(&p.a); hipEventCreate(&p.b); p.id = id; sl.ev.push_back(p);
@@ -174,6 +174,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   const int w = cfg_.width, h = cfg_.height;
   Slot &sl = slot_[cfg_.owf > 0 ? (submitted_ & 1) : 0];
   cur_slot_ = &sl;
+  prof_now_ = profiling_ && (frame_idx_ % prof_every_) == 0;
   timed(K_PAD, [&] {
     launch_pad_input(d_i420, w, h, src_[0], cw_, ch_, stream_);
     launch_pad_input(d_i420 + ny, w / 2, h / 2, src_[1], cw_ / 2, ch_ / 2, stream_);

@@ -78,6 +78,7 @@ class Filter {
   const std::string &name() const { return name_; }
   uint32_t bufferedInputs();
   uint64_t inputDiscarded() const { return inputDiscarded_; }
+  uint64_t busyNs() const { return busyNs_; }             // time spent inside process() (harness statistics)
 
  protected:
   virtual void process() = 0;
@@ -102,6 +103,7 @@ class Filter {
   std::thread thread_;
   std::atomic<bool> running_{false}, threadRunning_{false};
   uint64_t inputTaken_ = 0, inputDiscarded_ = 0;
+  std::atomic<uint64_t> busyNs_{0};
 };
 
 class KvazaarFilter : public Filter {

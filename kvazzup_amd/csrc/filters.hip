@@ -42,7 +42,9 @@ void Filter::run()                                         // filter.cpp:425-443
       hasInput_.wait(l, [this] { return !running_ || !inBuffer_.empty(); });
     }
     if (!running_) break;
+    const auto t0 = std::chrono::steady_clock::now();
     process();
+    busyNs_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
   }
 }
 
@@ -588,6 +590,11 @@ KVZ_PUBLIC void uvgx_pipeline_stats(void *pp, uint64_t *out)
   std::lock_guard<std::mutex> l(p->m);
   out[0] = p->stats.encodedPackets; out[1] = p->stats.encodedBytes; out[2] = p->stats.receivedPackets; out[3] = p->stats.receivedBytes;
   out[4] = p->stats.droppedPackets; out[5] = p->n_decoded; out[6] = p->stats.encodingDelaySumMs; out[7] = p->enc->inputDiscarded();
+}
+KVZ_PUBLIC void uvgx_pipeline_busy_ms(void *pp, double *out3)
+{
+  UvgxPipeline *p = (UvgxPipeline *)pp;
+  out3[0] = p->enc->busyNs() * 1e-6; out3[1] = p->wire ? p->wire->busyNs() * 1e-6 : 0.0; out3[2] = p->dec ? p->dec->busyNs() * 1e-6 : 0.0;
 }
 KVZ_PUBLIC void *uvgx_pipeline_encoder(void *pp) { return ((UvgxPipeline *)pp)->enc->encoder(); }
 KVZ_PUBLIC void *uvgx_pipeline_decoder(void *pp) { UvgxPipeline *p = (UvgxPipeline *)pp; return p->dec ? p->dec->handle() : nullptr; }

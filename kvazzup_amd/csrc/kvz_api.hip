@@ -377,7 +377,7 @@ int kvzx_encoder_recon_device(kvz_encoder *e, const void **planes)
   return 1;
 }
 int kvzx_encoder_debug_copy(kvz_encoder *e, const char *what, void *dst, size_t bytes) { return e && what && e->impl->debug_copy(what, dst, bytes) ? 1 : 0; }
-void kvzx_encoder_set_profiling(kvz_encoder *e, int on) { if (e) e->impl->set_profiling(on != 0); }
+void kvzx_encoder_set_profiling(kvz_encoder *e, int every) { if (e) e->impl->set_profiling(every); }
 int kvzx_encoder_kernel_times(kvz_encoder *e, double *ms, uint64_t *launches, int reset)
 {
   if (!e) return 0;

@@ -126,7 +126,7 @@ int kvzx_decoder_output_device(OpenHevc_Handle hh, const void **planes, int *pit
   return 1;
 }
 void kvzx_decoder_set_download(OpenHevc_Handle hh, int on) { Handle *h = H(hh); if (h) h->dec->set_download(on != 0); }
-void kvzx_decoder_set_profiling(OpenHevc_Handle hh, int on) { Handle *h = H(hh); if (h) h->dec->set_profiling(on != 0); }
+void kvzx_decoder_set_profiling(OpenHevc_Handle hh, int every) { Handle *h = H(hh); if (h) h->dec->set_profiling(every); }
 int kvzx_decoder_kernel_times(OpenHevc_Handle hh, double *ms, uint64_t *launches, int reset)
 {
   Handle *h = H(hh);

@@ -20,6 +20,7 @@ def _bind(lib):
     lib.uvgx_pipeline_pop_decoded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int),
                                               C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     lib.uvgx_pipeline_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.uvgx_pipeline_busy_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.uvgx_pipeline_encoder.restype = C.c_void_p
     lib.uvgx_pipeline_encoder.argtypes = [C.c_void_p]
     lib.uvgx_pipeline_decoder.restype = C.c_void_p
@@ -87,6 +88,12 @@ class Pipeline:
         self.lib.uvgx_pipeline_stats(self.p, out)
         keys = ("encoded_pictures", "encoded_bytes", "received_nals", "received_bytes", "dropped", "decoded_pictures", "encoding_delay_ms_sum", "encoder_inputs_discarded")
         return dict(zip(keys, [int(v) for v in out]))
+
+    def busy_ms(self):
+        """milliseconds each filter thread has spent inside process(): (encoder, wire adapter, decoder)"""
+        out = (C.c_double * 3)()
+        self.lib.uvgx_pipeline_busy_ms(self.p, out)
+        return tuple(float(v) for v in out)
 
     def encoder_handle(self):
         return self.lib.uvgx_pipeline_encoder(self.p)

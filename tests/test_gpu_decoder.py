@@ -90,8 +90,9 @@ def test_decoder_gates_until_parameter_sets_and_rejects_garbage(gpu):
 @pytest.mark.gpu
 @pytest.mark.parametrize("threads", [2, 4])
 def test_frame_threaded_decoder_delays_output_and_drains_on_eos(gpu, threads):
-    """libOpenHevcInit(n, OH_THREAD_FRAME): pictures are parsed concurrently, output lags n - 1 pictures,
-    end-of-sequence NAL units drain the rest; decoded pictures are identical to the synchronous decoder's."""
+    """libOpenHevcInit(n, OH_THREAD_FRAME): n pictures are parsed concurrently while one more is reconstructed,
+    so the output lags n pictures; end-of-sequence NAL units drain the rest; the decoded pictures are
+    identical to the synchronous decoder's."""
     from kvazzup_amd import _native as N
     from kvazzup_amd.codec import Decoder
     w, h, frames = 320, 240, 9
@@ -109,10 +110,10 @@ def test_frame_threaded_decoder_delays_output_and_drains_on_eos(gpu, threads):
     out = []
     for t, au in enumerate(aus):
         got = gd.decode_au(au, t)
-        assert len(got) == (1 if t >= threads - 1 else 0), (t, len(got))
+        assert len(got) == (1 if t >= threads else 0), (t, len(got))
         out += got
     eos = bytes([0, 0, 0, 1, 36 << 1, 1])
-    for _ in range(threads - 1):
+    for _ in range(threads):
         out.append(gd.decode_nal(eos))
     assert gd.decode_nal(eos) is None                               # nothing left
     assert [o["pts"] for o in out] == list(range(frames))

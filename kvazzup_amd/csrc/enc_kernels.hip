@@ -915,31 +915,38 @@ __device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d
   __syncthreads();
 }
 
-#define TOK_LANE_CAP 128       // tokens one 4x4 sub-block can produce at most (worst case ~108)
-#define TOK_HDR_CAP 96
-#define TOK_ARENA 12800        // tokens one 16x16 unit (at most one 32x32 CU) can produce
+#define TOK_HDR_CAP 192        // split flags + CU header + last-position bins waiting for the piece they open
+#define TOK_ARENA 3072         // tokens of one piece staged in LDS (larger pieces are written straight to the slot)
+#define TOK_PIECES 17          // pieces one unit can produce: 4 CUs x (header-only | one per coded component) + the CTU's terminating bins
 
-// One wave per 16x16 luma block ("unit").  A unit owns the CU that starts at its origin (32x32 or
+// One wave per 16x16 luma block ("unit") and colour component (the luma wave also codes the CU headers).
+// A unit owns the CU that starts at its origin (32x32 or
 // 16x16) or the four 8x8 CUs inside it; units covered by a 32x32 CU that starts elsewhere emit
-// nothing.  The unit's tokens are built in LDS, then appended to the CTU's slot at an offset
-// reserved with one atomicAdd; k_tok_compact restores z-order from the (offset, length) segments.
+// nothing.  The tokens leave the unit in PIECES: one per coded transform block (preceded by whatever
+// header bins are pending), or the header alone for a CU without residual.  For each piece the
+// lanes first COUNT the tokens of their 4x4 sub-blocks (the emitters run with a zero-capacity
+// sink), the piece reserves its place in the CTU's slot with one atomicAdd, and a second run of the
+// emitters writes the tokens at their final offsets -- through a small LDS arena when the piece
+// fits, which keeps the kernel at ~10 KB of LDS per wave.  k_tok_compact restores coding order
+// from the (offset, length) table [ctu][unit][piece].
 __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
 {
   __shared__ CuRec tile[9];
   __shared__ __attribute__((aligned(16))) TuDigest dg;
   __shared__ CoreTabs tabs;
   __shared__ uint16_t hdr[TOK_HDR_CAP];
-  __shared__ uint16_t ltok[64][TOK_LANE_CAP];
   __shared__ uint16_t arena[TOK_ARENA];
   __shared__ int hdr_n;
-  __shared__ uint32_t slot_off;
-  const int ux = blockIdx.x, uy = blockIdx.y, lane = threadIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
+  __shared__ uint32_t piece_off;
+  __shared__ uint32_t seg[TOK_PIECES][2];
+  const int ux = blockIdx.x, uy = blockIdx.y, comp = blockIdx.z, lane = threadIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
   const int cx = ux >> 2, cy = uy >> 2, ctu = cy * wc + cx;
   const int X0 = ux * 16, Y0 = uy * 16;
   int z4 = 0;                                          // z-order index of the unit inside its CTU
   for (int b = 0; b < 2; b++) z4 |= (((ux & 3) >> b) & 1) << (2 * b) | (((uy & 3) >> b) & 1) << (2 * b + 1);
-  int ntok = 0;                                        // wave-uniform count of tokens in the arena
   core_tabs_fill_entry(tabs, lane);
+  if (lane < TOK_PIECES) { seg[lane][0] = 0; seg[lane][1] = 0; }
+  if (lane == 0) hdr_n = 0;
   const int bx0 = ux * 2 - 1, by0 = uy * 2 - 1;
   if (lane < 9) {
     int bx = bx0 + lane % 3, by = by0 + lane / 3;
@@ -953,6 +960,19 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
     tile[lane] = r;
   }
   __syncthreads();
+  uint16_t *slot = f.tok_buf + (size_t)ctu * f.tok_cap;
+  int np = 0;                                          // piece being produced (wave-uniform): CU k, component c -> 4k + c; 16 = terminators
+  // reserve `total` tokens of the CTU's slot for piece np; all lanes get the offset (or ~0u when the slot is full)
+  auto reserve = [&](int total) -> uint32_t {
+    if (lane == 0) {
+      uint32_t o = atomicAdd(&f.tok_cursor[ctu], (uint32_t)total);
+      if (o + (uint32_t)total > (uint32_t)f.tok_cap) { atomicOr(f.err, 16u); o = ~0u; }
+      else { seg[np][0] = o; seg[np][1] = (uint32_t)total; }
+      piece_off = o;
+    }
+    __syncthreads();
+    return piece_off;
+  };
   TileView v; v.tile = tile; v.bx0 = bx0; v.by0 = by0;
   const int cl0 = v.at(X0, Y0).log2;
   const bool owner = !(cl0 == 5 && ((X0 | Y0) & 31));
@@ -962,78 +982,100 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
     const CuRec cu = v.at(x0, y0);
     int z = 0;                                         // z-order index (8x8 units) of the CU origin inside the CTU
     for (int b = 0; b < 3; b++) z |= ((((x0 & 63) >> 3) >> b) & 1) << (2 * b) | ((((y0 & 63) >> 3) >> b) & 1) << (2 * b + 1);
-    if (lane == 0) {
+    if (lane == 0 && comp == 0) {
       TokOut t; t.tabs = &tabs; t.p = hdr; t.n = 0; t.cap = TOK_HDR_CAP;
       enc_split_flags(v, t, f.cw, f.ch, x0, y0, z, cu.log2);
       enc_cu_header(v, t, f.cw, f.ch, f.is_intra != 0, x0, y0, cu);
       hdr_n = t.n;
     }
-    __syncthreads();
-    { const int n = hdr_n; for (int i = lane; i < n; i += 64) if (ntok + i < TOK_ARENA) arena[ntok + i] = hdr[i]; ntok += n; }
     const int cbf = (cu.flags & CU_SKIP) ? 0 : cu.cbf;          // wave-uniform
-    for (int ci = 0; ci < 3; ci++) {
-      if (!((cbf >> ci) & 1)) continue;
-      const int l2 = ci ? cu.log2 - 1 : cu.log2, pw = ci ? (f.cw >> 1) : f.cw;
-      const int px = ci ? (x0 >> 1) : x0, py = ci ? (y0 >> 1) : y0;
-      const int scan = intra_scan_idx(cu.intra, l2, ci, cu.intra_mode);
-      digest_build_wave(&tabs, dg, f.coef[ci] + py * pw + px, pw, l2, scan, lane);   // ends with a barrier: hdr[] is free again
-      const uint64_t sbm = dg.sbmask;
-      const int last_sb = 63 - __builtin_clzll(sbm);
-      const int last_pos = 31 - __builtin_clz((uint32_t)dg.mask[last_sb]);
-      if (lane == 0) {
-        TokOut t; t.tabs = &tabs; t.p = hdr; t.n = 0; t.cap = TOK_HDR_CAP;
-        int a, b; enc_last_pos(t, dg, l2, ci, scan, a, b);
-        hdr_n = t.n;
-      }
-      // greater1 context-set carry: sub-block i inherits from the next non-empty sub-block above it
-      const bool nzsb = (sbm >> lane) & 1;
-      const bool g1 = nzsb && subblock_g1_any(&tabs, dg, lane, scan);
-      const uint64_t g1m = __ballot(g1);
-      int n_l = 0;
-      if (lane <= last_sb) {
-        uint64_t above = (lane < 63) ? (sbm >> (lane + 1)) : 0;      // non-empty sub-blocks coded before this one
+    {
+      const int ci = comp;
+      np = 4 * k + ci;
+      if ((cbf >> ci) & 1) {
+        const int l2 = ci ? cu.log2 - 1 : cu.log2, pw = ci ? (f.cw >> 1) : f.cw;
+        const int px = ci ? (x0 >> 1) : x0, py = ci ? (y0 >> 1) : y0;
+        const int scan = intra_scan_idx(cu.intra, l2, ci, cu.intra_mode);
+        digest_build_wave(&tabs, dg, f.coef[ci] + py * pw + px, pw, l2, scan, lane);   // ends with a barrier
+        const uint64_t sbm = dg.sbmask;
+        const int last_sb = 63 - __builtin_clzll(sbm);
+        const int last_pos = 31 - __builtin_clz((uint32_t)dg.mask[last_sb]);
+        if (lane == 0) {
+          TokOut t; t.tabs = &tabs; t.p = hdr; t.n = hdr_n; t.cap = TOK_HDR_CAP;
+          int a, b; enc_last_pos(t, dg, l2, ci, scan, a, b);
+          hdr_n = t.n;
+        }
+        // greater1 context-set carry: sub-block i inherits from the next non-empty sub-block above it
+        const bool nzsb = (sbm >> lane) & 1;
+        const bool g1 = nzsb && subblock_g1_any(&tabs, dg, lane, scan);
+        const uint64_t g1m = __ballot(g1);
         bool prev_g1 = false;
-        if (above) { int j = lane + 1 + __builtin_ctzll(above); prev_g1 = (g1m >> j) & 1; }
-        TokOut t; t.tabs = &tabs; t.p = ltok[lane]; t.n = 0; t.cap = TOK_LANE_CAP;
-        enc_subblock(t, dg, lane, last_sb, last_pos, prev_g1, l2, ci, scan);
-        n_l = t.n;
-        if (n_l > TOK_LANE_CAP) { atomicOr(f.err, 8u); n_l = TOK_LANE_CAP; }
+        if (lane <= last_sb) {
+          uint64_t above = (lane < 63) ? (sbm >> (lane + 1)) : 0;      // non-empty sub-blocks coded before this one
+          if (above) { int j = lane + 1 + __builtin_ctzll(above); prev_g1 = (g1m >> j) & 1; }
+        }
+        // pass 1: count
+        int n_l = 0;
+        if (lane <= last_sb) {
+          TokCount t; t.tabs = &tabs; t.n = 0;
+          enc_subblock(t, dg, lane, last_sb, last_pos, prev_g1, l2, ci, scan);
+          n_l = t.n;
+        }
+        // offsets in coding order: sub-block last_sb first, then downwards
+        int suffix = n_l;
+        for (int o = 1; o < 64; o <<= 1) { int other = __shfl_down(suffix, o); if (lane + o < 64) suffix += other; }
+        const int body = __shfl(suffix, 0);
+        const int off = suffix - n_l;                                 // tokens of all sub-blocks with a higher index
+        __syncthreads();                                              // hdr_n of lane 0 visible
+        const int hn = hdr_n > TOK_HDR_CAP ? TOK_HDR_CAP : hdr_n, total = hn + body;
+        if (hdr_n > TOK_HDR_CAP && lane == 0) atomicOr(f.err, 8u);
+        const uint32_t o = reserve(total);
+        if (o != ~0u) {
+          const bool staged = total <= TOK_ARENA;
+          uint16_t *dst = staged ? arena : slot + o;
+          for (int i = lane; i < hn; i += 64) dst[i] = hdr[i];
+          if (lane <= last_sb && n_l) {                               // pass 2: the same emitters, now writing at the final offsets
+            TokOut t; t.tabs = &tabs; t.p = dst + hn + off; t.n = 0; t.cap = n_l;
+            enc_subblock(t, dg, lane, last_sb, last_pos, prev_g1, l2, ci, scan);
+          }
+          if (staged) {
+            __syncthreads();
+            for (int i = lane; i < total; i += 64) slot[o + i] = arena[i];
+          }
+        }
+        __syncthreads();
+        if (lane == 0) hdr_n = 0;
       }
+    }
+    __syncthreads();
+    if (hdr_n) {                                                     // CU without luma residual: the header is its own piece
+      const int hn = hdr_n > TOK_HDR_CAP ? TOK_HDR_CAP : hdr_n;
+      const uint32_t o = reserve(hn);
+      if (o != ~0u) for (int i = lane; i < hn; i += 64) slot[o + i] = hdr[i];
       __syncthreads();
-      { const int n = hdr_n; for (int i = lane; i < n; i += 64) if (ntok + i < TOK_ARENA) arena[ntok + i] = hdr[i]; ntok += n; }
-      // offsets in coding order: sub-block last_sb first, then downwards
-      int suffix = n_l;
-      for (int o = 1; o < 64; o <<= 1) { int other = __shfl_down(suffix, o); if (lane + o < 64) suffix += other; }
-      const int total = __shfl(suffix, 0);
-      const int off = suffix - n_l;                                 // tokens of all sub-blocks with a higher index
-      for (int i = 0; i < n_l; i++) if (ntok + off + i < TOK_ARENA) arena[ntok + off + i] = ltok[lane][i];
-      ntok += total;
-      __syncthreads();
+      if (lane == 0) hdr_n = 0;
     }
   }
-  if (z4 == 15) {                                      // the last unit of the CTU closes it
+  if (z4 == 15 && comp == 0) {                                      // the last unit of the CTU closes it
     const bool last = (cy == hc - 1 && cx == wc - 1);
-    if (lane == 0) {
-      if (ntok < TOK_ARENA) arena[ntok] = (uint16_t)(0xC000u | (last ? 1u : 0u));     // end_of_slice_segment_flag
-      if (f.wpp && !last && cx == wc - 1 && ntok + 1 < TOK_ARENA) arena[ntok + 1] = 0xC001u;   // end_of_subset_one_bit
+    const int n = 1 + ((f.wpp && !last && cx == wc - 1) ? 1 : 0);
+    __syncthreads();
+    np = 16;
+    const uint32_t o = reserve(n);
+    if (o != ~0u && lane == 0) {
+      slot[o] = (uint16_t)(0xC000u | (last ? 1u : 0u));             // end_of_slice_segment_flag
+      if (n == 2) slot[o + 1] = 0xC001u;                            // end_of_subset_one_bit
     }
-    ntok += 1 + ((f.wpp && !last && cx == wc - 1) ? 1 : 0);
-  }
-  if (ntok > TOK_ARENA) { if (lane == 0) atomicOr(f.err, 16u); ntok = TOK_ARENA; }
-  __syncthreads();
-  if (lane == 0) {
-    uint32_t o = ntok ? atomicAdd(&f.tok_cursor[ctu], (uint32_t)ntok) : 0u;
-    if (o + (uint32_t)ntok > (uint32_t)f.tok_cap) { atomicOr(f.err, 16u); o = 0; ntok = 0; }
-    slot_off = o;
-    f.tok_seg[(ctu * 16 + z4) * 2] = o; f.tok_seg[(ctu * 16 + z4) * 2 + 1] = (uint32_t)ntok;
   }
   __syncthreads();
-  const int n = (int)f.tok_seg[(ctu * 16 + z4) * 2 + 1];       // written by lane 0 above (zero on overflow)
-  uint16_t *out = f.tok_buf + (size_t)ctu * f.tok_cap + slot_off;
-  if (slot_off + (uint32_t)n <= (uint32_t)f.tok_cap) for (int i = lane; i < n; i += 64) out[i] = arena[i];
+  // every table entry of the unit is written by exactly one of its three waves: 4k + c by component c, 4k + 3 and 16 by luma
+  if (lane < TOK_PIECES && ((lane == 16 || (lane & 3) == 3) ? 0 : (lane & 3)) == comp) {
+    uint32_t *e = f.tok_seg + ((size_t)(ctu * 16 + z4) * TOK_PIECES + lane) * 2;
+    e[0] = seg[lane][0]; e[1] = seg[lane][1];
+  }
 }
 
-// exclusive prefix sum of the per-CTU token counts (single workgroup), then a dense copy in z-order
+// exclusive prefix sum of the per-CTU token counts (single workgroup), then a dense copy in coding order
 __global__ __launch_bounds__(256) void k_tok_scan(EncFrame f, int nctu)
 {
   __shared__ uint32_t part[256];
@@ -1047,20 +1089,34 @@ __global__ __launch_bounds__(256) void k_tok_scan(EncFrame f, int nctu)
   uint32_t a = part[tid];
   for (int i = lo; i < hi; i++) { f.tok_off[i] = a; a += f.tok_cursor[i]; }
 }
+// one workgroup per CTU: the pieces of its 16 units in z-order, piece after piece -> the dense token array
 __global__ __launch_bounds__(256) void k_tok_compact(EncFrame f)
 {
-  const int ctu = blockIdx.x;
+  constexpr int NSEG = 16 * TOK_PIECES;
+  __shared__ uint32_t soff[NSEG], start[NSEG + 1], utot[17];
+  const int ctu = blockIdx.x, tid = threadIdx.x;
   const uint32_t n = f.tok_cursor[ctu], base = f.tok_off[ctu];
-  if (base + n > f.tok_dense_cap) { if (threadIdx.x == 0) { atomicOr(f.err, 32u); f.tok_count_out[ctu] = 0; } return; }
+  if (base + n > f.tok_dense_cap) { if (tid == 0) { atomicOr(f.err, 32u); f.tok_count_out[ctu] = 0; } return; }
+  const uint32_t *tab = f.tok_seg + (size_t)ctu * NSEG * 2;
+  for (int i = tid; i < NSEG; i += 256) { soff[i] = tab[i * 2]; start[i] = tab[i * 2 + 1]; }        // start[] holds lengths for now
+  __syncthreads();
+  if (tid < 16) { uint32_t a = 0; for (int p = 0; p < TOK_PIECES; p++) { uint32_t l = start[tid * TOK_PIECES + p]; start[tid * TOK_PIECES + p] = a; a += l; } utot[tid] = a; }
+  __syncthreads();
+  if (tid == 0) { uint32_t a = 0; for (int u = 0; u < 16; u++) { uint32_t t = utot[u]; utot[u] = a; a += t; } utot[16] = a; }
+  __syncthreads();
+  for (int i = tid; i < NSEG; i += 256) start[i] += utot[i / TOK_PIECES];
+  if (tid == 0) start[NSEG] = utot[16];
+  __syncthreads();
+  const uint32_t total = start[NSEG];
+  if (total != n) { if (tid == 0) { atomicOr(f.err, 32u); f.tok_count_out[ctu] = 0; } return; }
   const uint16_t *slot = f.tok_buf + (size_t)ctu * f.tok_cap;
   uint16_t *dst = f.tok_dense + base;
-  uint32_t run = 0;
-  for (int u = 0; u < 16; u++) {
-    const uint32_t so = f.tok_seg[(ctu * 16 + u) * 2], sl = f.tok_seg[(ctu * 16 + u) * 2 + 1];
-    for (uint32_t i = threadIdx.x; i < sl; i += 256) dst[run + i] = slot[so + i];
-    run += sl;
+  for (uint32_t i = tid; i < n; i += 256) {
+    int lo = 0, hi = NSEG;                              // last segment with start <= i (empty segments share a start: take the last)
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (start[mid] <= i) lo = mid; else hi = mid; }
+    dst[i] = slot[soff[lo] + (i - start[lo])];
   }
-  if (threadIdx.x == 0) f.tok_count_out[ctu] = (int32_t)n;
+  if (tid == 0) f.tok_count_out[ctu] = (int32_t)n;
 }
 
 // =============================================================================================
@@ -1123,7 +1179,7 @@ void launch_tokenize(const EncFrame &f, hipStream_t st)
 {
   const int wc = f.cw / 64, hc = f.ch / 64;
   hipMemsetAsync(f.tok_cursor, 0, sizeof(uint32_t) * (size_t)(wc * hc), st);
-  hipLaunchKernelGGL(k_tokenize, dim3(f.cw / 16, f.ch / 16), dim3(64), 0, st, f);
+  hipLaunchKernelGGL(k_tokenize, dim3(f.cw / 16, f.ch / 16, 3), dim3(64), 0, st, f);
   hipLaunchKernelGGL(k_tok_scan, dim3(1), dim3(256), 0, st, f, wc * hc);
   hipLaunchKernelGGL(k_tok_compact, dim3(wc * hc), dim3(256), 0, st, f);
 }

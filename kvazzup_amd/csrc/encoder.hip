@@ -55,7 +55,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   tok_cap_ = 49152;                                // tokens per CTU slot (worst case of a 64x64 CTU is ~43k)
   HIP_OK(hipMalloc(&tok_buf_, (size_t)nctu * tok_cap_ * sizeof(uint16_t)));
   HIP_OK(hipMalloc(&tok_count_, sizeof(uint32_t) * nctu));
-  HIP_OK(hipMalloc(&tok_seg_, sizeof(uint32_t) * nctu * 32));
+  HIP_OK(hipMalloc(&tok_seg_, sizeof(uint32_t) * nctu * 16 * 17 * 2));       // [ctu][unit][piece] {offset, length}
   HIP_OK(hipMalloc(&tok_off_, sizeof(uint32_t) * (nctu + 1)));
   tok_dense_cap_ = (size_t)nctu * tok_cap_;
   if (tok_dense_cap_ > ((size_t)1 << 27)) tok_dense_cap_ = (size_t)1 << 27;

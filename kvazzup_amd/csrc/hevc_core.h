@@ -282,6 +282,16 @@ KVZ_HD void cabac_bypass_bits(TokOut &t, uint32_t val, int n)
   if (n > 0) tok_push(t, 0x8000u | ((uint32_t)(n - 1) << 10) | (val & ((1u << n) - 1u)));
 }
 KVZ_HD void cabac_terminate(TokOut &t, int bin) { tok_push(t, 0xC000u | (uint32_t)(bin ? 1 : 0)); }
+// a sink that only counts the tokens TokOut would receive (contexts and values are never formed: the
+// compiler drops their computation from the counting instantiation of the emitters)
+struct TokCount {
+  const CoreTabs *tabs;
+  int n;
+};
+KVZ_HD void cabac_bin(TokCount &t, int, int) { t.n++; }
+KVZ_HD void cabac_bypass(TokCount &t, int) { t.n++; }
+KVZ_HD void cabac_bypass_bits(TokCount &t, uint32_t, int n) { t.n += (n + 9) / 10; }
+KVZ_HD void cabac_terminate(TokCount &t, int) { t.n++; }
 // replay of a token list into the arithmetic coder
 KVZ_HD void cabac_play_tokens(CabacEnc &c, const uint16_t *tok, int n)
 {

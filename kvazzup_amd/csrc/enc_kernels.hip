@@ -57,49 +57,93 @@ __device__ __forceinline__ void wait_progress(const uint32_t *ctr, uint32_t at_l
 #define ME_MAXR 32
 #define ME_WPITCH 100      // bytes per window row in LDS: 32 + 2*32 = 96, + 4 so the 9th dword read stays inside
 
+// Full search over (2R+1)^2 integer displacements for one 32x32 block, with the four 16x16 quarters
+// kept apart.  The search window sits in LDS.  A work item is a QUAD of horizontally adjacent
+// candidates times a PAIR of vertically adjacent ones: v_qsad_pk_u16_u8 produces the four SADs of a
+// quad against four current samples in one instruction (16-bit accumulators: a 16x16 quarter sums
+// to at most 65280), and each window row read from LDS serves both candidates of the pair.
+// (Measured on MI355X: v_qsad_pk_u16_u8 issues at ~24 cycles per wave, v_sad_u8 at ~4.7; the quad form
+// still wins because it needs no v_alignbyte to line the window up with the candidate.)
 __global__ __launch_bounds__(256) void k_me(EncFrame f)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t win[(32 + 2 * ME_MAXR) * ME_WPITCH + 16];
+  __shared__ __attribute__((aligned(16))) uint8_t win[(32 + 2 * ME_MAXR + 1) * ME_WPITCH + 16];
   __shared__ __attribute__((aligned(16))) uint32_t cur[32 * 8];
   __shared__ uint32_t red[5];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
   const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
   const int R = f.range, W = 2 * R + 1, WW = 32 + 2 * R;
   const uint8_t *ref = f.ref[0], *src = f.src[0];
-  for (int i = tid; i < WW * WW; i += 256) {
-    int wy = i / WW, wx = i - wy * WW;
-    int gx = clip3(0, f.cw - 1, x0 - R + wx), gy = clip3(0, f.ch - 1, y0 - R + wy);
-    win[wy * ME_WPITCH + wx] = ref[gy * f.cw + gx];
+  for (int i = tid; i < (WW + 1) * (ME_WPITCH / 4); i += nthreads) {   // four window samples per thread; columns >= WW and row WW are padding
+    const int wy = i / (ME_WPITCH / 4), wx = (i - wy * (ME_WPITCH / 4)) * 4;
+    const int gy = clip3(0, f.ch - 1, y0 - R + wy), gx = x0 - R + wx;
+    const uint8_t *row = ref + (size_t)gy * f.cw;
+    uint32_t v;
+    if (gx >= 0 && gx + 7 < f.cw) {
+      const uint32_t *q = (const uint32_t *)(row + (gx & ~3));
+      v = __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(gx & 3));
+    } else {
+      v = 0;
+      for (int k = 0; k < 4; k++) v |= (uint32_t)row[clip3(0, f.cw - 1, gx + k)] << (8 * k);
+    }
+    *(uint32_t *)&win[wy * ME_WPITCH + wx] = v;
   }
-  {
-    int r = tid >> 3, c = tid & 7;
-    cur[tid] = *reinterpret_cast<const uint32_t *>(src + (y0 + r) * f.cw + x0 + c * 4);
-  }
+  for (int i = tid; i < 256; i += nthreads) cur[i] = *reinterpret_cast<const uint32_t *>(src + (y0 + (i >> 3)) * f.cw + x0 + (i & 7) * 4);
   if (tid < 5) red[tid] = 0xffffffffu;
   __syncthreads();
   const uint32_t lam = (uint32_t)f.lambda_q4;
   uint32_t best[5] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-  for (int cand = tid; cand < W * W; cand += 256) {
-    int dyi = cand / W, dxi = cand - dyi * W;
-    uint32_t s[4] = {0, 0, 0, 0};
-    for (int r = 0; r < 32; r++) {
-      int off = (dyi + r) * ME_WPITCH + dxi;
-      const uint32_t *wp = reinterpret_cast<const uint32_t *>(win + (off & ~3));
-      int sh = off & 3;
-      uint32_t d[9];
+  const int NQ = (W + 3) >> 2, NG = (W + 1) >> 1;
+  for (int item = tid; item < NQ * NG; item += nthreads) {
+    const int g = item / NQ, q = item - g * NQ, dy0 = 2 * g;
+    uint64_t acc[2][4];                                          // [candidate of the pair][quarter]: four u16 sums, one per candidate of the quad
+    const uint8_t *wbase = win + dy0 * ME_WPITCH + 4 * q;
 #pragma unroll
-      for (int j = 0; j < 9; j++) d[j] = wp[j];
-      uint32_t sl = 0, sr = 0;
+    for (int half = 0; half < 2; half++) {
+      uint64_t al = 0, ar = 0, bl = 0, br = 0;                   // left / right quarter of this half, candidates A and B
+#pragma unroll 1
+      for (int rr = 0; rr < 17; rr++) {
+        // window row dy0 + wr is row wr of candidate A (dy0) and row wr - 1 of candidate B (dy0 + 1); each half covers
+        // the rows of both candidates that fall into its quarters: rows half*16 .. +15
+        const int wr = half * 16 + rr;
+        const uint32_t *wp = (const uint32_t *)(wbase + wr * ME_WPITCH);
+        uint32_t d[9];
 #pragma unroll
-      for (int j = 0; j < 4; j++) sl = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(d[j + 1], d[j], sh), cur[r * 8 + j], sl);
+        for (int j = 0; j < 9; j++) d[j] = wp[j];
+        uint64_t p[8];
 #pragma unroll
-      for (int j = 4; j < 8; j++) sr = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(d[j + 1], d[j], sh), cur[r * 8 + j], sr);
-      if (r < 16) { s[0] += sl; s[1] += sr; } else { s[2] += sl; s[3] += sr; }
+        for (int j = 0; j < 8; j++) p[j] = ((uint64_t)d[j + 1] << 32) | d[j];
+        if (rr < 16) {
+          const uint32_t *c = &cur[wr * 8];
+#pragma unroll
+          for (int j = 0; j < 4; j++) { al = __builtin_amdgcn_qsad_pk_u16_u8(p[j], c[j], al); ar = __builtin_amdgcn_qsad_pk_u16_u8(p[j + 4], c[j + 4], ar); }
+        }
+        if (rr > 0) {
+          const uint32_t *c = &cur[(wr - 1) * 8];
+#pragma unroll
+          for (int j = 0; j < 4; j++) { bl = __builtin_amdgcn_qsad_pk_u16_u8(p[j], c[j], bl); br = __builtin_amdgcn_qsad_pk_u16_u8(p[j + 4], c[j + 4], br); }
+        }
+      }
+      acc[0][half * 2] = al; acc[0][half * 2 + 1] = ar; acc[1][half * 2] = bl; acc[1][half * 2 + 1] = br;
     }
-    uint32_t rate = (lam * (uint32_t)(mvd_bits((dxi - R) * 4) + mvd_bits((dyi - R) * 4))) >> 4;
 #pragma unroll
-    for (int k = 0; k < 4; k++) best[k] = min(best[k], ((s[k] + rate) << 13) | (uint32_t)cand);
-    best[4] = min(best[4], ((s[0] + s[1] + s[2] + s[3] + rate) << 13) | (uint32_t)cand);
+    for (int e = 0; e < 2; e++) {
+      const int dyi = dy0 + e;
+      if (dyi >= W) continue;
+      const int ry = mvd_bits((dyi - R) * 4);
+#pragma unroll
+      for (int k4 = 0; k4 < 4; k4++) {
+        const int dxi = 4 * q + k4;
+        if (dxi >= W) continue;
+        const uint32_t cand = (uint32_t)(dyi * W + dxi);
+        const uint32_t rate = (lam * (uint32_t)(mvd_bits((dxi - R) * 4) + ry)) >> 4;
+        uint32_t sq[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) sq[k] = (uint32_t)(acc[e][k] >> (16 * k4)) & 0xffffu;
+#pragma unroll
+        for (int k = 0; k < 4; k++) best[k] = min(best[k], ((sq[k] + rate) << 13) | cand);
+        best[4] = min(best[4], ((sq[0] + sq[1] + sq[2] + sq[3] + rate) << 13) | cand);
+      }
+    }
   }
 #pragma unroll
   for (int k = 0; k < 5; k++) {
@@ -1158,7 +1202,12 @@ void launch_pad_input(const uint8_t *in, int w, int h, uint8_t *dst, int cw, int
   dim3 g((cw / 4 + 255) / 256, ch);
   hipLaunchKernelGGL(k_pad_input, g, dim3(256), 0, st, in, w, h, dst, cw, ch);
 }
-void launch_me(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_me, dim3(f.cw / 32, f.ch / 32), dim3(256), 0, st, f); }
+void launch_me(const EncFrame &f, hipStream_t st)
+{
+  const int W = 2 * f.range + 1, items = ((W + 3) / 4) * ((W + 1) / 2);          // quads x pairs; R = 16: 153 items -> 192 threads
+  const int threads = items >= 256 ? 256 : ((items + 63) / 64) * 64;
+  hipLaunchKernelGGL(k_me, dim3(f.cw / 32, f.ch / 32), dim3(threads), 0, st, f);
+}
 void launch_inter_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_inter_recon<false>, dim3(f.cw / 32, f.ch / 32), dim3(256), 0, st, f); }
 void launch_dec_inter_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_inter_recon<true>, dim3(f.cw / 32, f.ch / 32), dim3(256), 0, st, f); }
 void launch_inter_signal(const EncFrame &f, hipStream_t st)

@@ -99,7 +99,7 @@ class Decoder {
   bool ensure_buffers(int cw, int ch);
   void free_buffers();
   int decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t pts);
-  struct RowState { std::vector<int16_t> levels; std::vector<TuDesc> tus; int rc = 0; };
+  struct RowState { std::vector<uint32_t> levels; std::vector<TuDesc> tus; int rc = 0; };     // levels: (position << 16 | level) words
   struct alignas(64) Progress { std::atomic<int> v{0}; char pad[60]; };   // one cache line per row: no false sharing between pollers
   // everything one picture needs between its slice header and its reconstruction
   struct PicJob {
@@ -107,9 +107,10 @@ class Decoder {
     std::vector<size_t> sub_start;
     int slice_qp = 0, max_merge = 5, poc = 0; bool is_intra = false, deblock = true; int64_t pts = 0;
     int crop[4] = {0, 0, 0, 0}; uint32_t fps_num = 0, fps_den = 0;
-    uint8_t *h_cu = nullptr; int16_t *h_mv = nullptr;        // pinned; same layout as the encoder's per-8x8 arrays
-    EncFrame hf{};
-    std::vector<int16_t> levels; std::vector<TuDesc> tus;
+    // Everything the GPU needs for the picture, in one pinned block that goes over in one copy:
+    // [ CU records: 7 byte arrays of b8 entries | motion vectors: b8 x 2 int16 | TuDesc x ntu | level words x nlev ]
+    uint8_t *h_in = nullptr; size_t h_in_cap = 0; size_t ntu = 0, nlev = 0;
+    EncFrame hf{};                                             // host view of the CU / motion arrays inside h_in
     std::vector<RowState> rows; std::vector<uint8_t> wpp_saved;
     std::unique_ptr<Progress[]> row_progress; int row_progress_n = 0;
     std::atomic<int> state{0}; int rc = 0; double parse_ms = 0; int rec_idx = 0;
@@ -120,6 +121,9 @@ class Decoder {
   int parse_row(PicJob &job, int row, const uint8_t *data, size_t len, RowState &rs);
   int finish_oldest();
   void drop_pending();
+  size_t fixed_bytes() const { return (size_t)cw_ * ch_ / 64 * 11; }   // CU records + motion vectors
+  bool grow_job_input(PicJob &job, size_t bytes);
+  void bind_views(EncFrame &f, uint8_t *base);
   int launch_gpu(PicJob &job);
   int complete_gpu();
 
@@ -129,13 +133,12 @@ class Decoder {
   int cw_ = 0, ch_ = 0;
   std::vector<PicJob> jobs_; int frame_threads_ = 1; long job_head_ = 0, job_tail_ = 0;
   std::unique_ptr<FrameWorkers> workers_;
-  int16_t *h_levels_ = nullptr; size_t h_levels_cap_ = 0; TuDesc *h_tus_ = nullptr; size_t h_tus_cap_ = 0;
   // device side
   EncFrame f_{};
-  uint8_t *d_cu_ = nullptr; int16_t *d_mv_ = nullptr, *d_mvd_ = nullptr;
+  uint8_t *d_in_ = nullptr; size_t d_in_cap_ = 0;          // device copy of PicJob::h_in
+  int16_t *d_mvd_ = nullptr;
   uint8_t *rec_[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   int16_t *coef_[3] = {nullptr, nullptr, nullptr};
-  int16_t *d_levels_ = nullptr; size_t d_levels_cap_ = 0; TuDesc *d_tus_ = nullptr; size_t d_tus_cap_ = 0;
   uint32_t *sync_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
   uint8_t *h_out_ = nullptr; size_t h_out_cap_ = 0;
   long launched_ = 0; int out_idx_ = 0; bool have_ref_ = false;

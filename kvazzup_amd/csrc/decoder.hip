@@ -114,6 +114,8 @@ struct CabacDec {
 };
 
 std::atomic<long> g_yields{0};
+std::atomic<uint64_t> g_tc[6];
+#define TSC() __builtin_ia32_rdtsc()
 struct Tick { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } };
 CoreTabs g_tabs;
 bool g_tabs_ready = false;
@@ -140,14 +142,13 @@ const ScanTabs &scan_tabs()
 }
 
 // residual_coding() (7.3.8.11) without transform skip / sign hiding; writes n*n levels row-major
-bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, int16_t *out)
+bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, std::vector<uint32_t> &out)
 {
   const CoreTabs *t = host_tabs();
   const ScanTabs &S = scan_tabs();
   const int n = 1 << log2, sbl = log2 - 2, nsb = 1 << sbl;
   const uint8_t *SX = S.x[scan_idx][sbl], *SY = S.y[scan_idx][sbl], *PX = S.x[scan_idx][2], *PY = S.y[scan_idx][2];
   uint8_t csbf[8][8]; memset(csbf, 0, sizeof(csbf));
-  memset(out, 0, sizeof(int16_t) * (size_t)n * n);
   int pre[2];
   for (int d = 0; d < 2; d++) {
     int off, sh, mx = (log2 << 1) - 1, v = 0;
@@ -222,7 +223,7 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, int16_t *out)
       }
       int v = ((signs >> (nsig - 1 - j)) & 1) ? -lev[j] : lev[j];
       const int xp = PX[pos[j]], yp = PY[pos[j]];
-      out[((ys << 2) + yp) * n + (xs << 2) + xp] = (int16_t)clip3(-32768, 32767, v);
+      out.push_back((uint32_t)((((ys << 2) + yp) * n + (xs << 2) + xp) << 16) | ((uint32_t)clip3(-32768, 32767, v) & 0xffffu));
     }
   }
   return !c.overrun();
@@ -244,16 +245,13 @@ void Decoder::drop_pending()
 
 Decoder::~Decoder()
 {
+  if (getenv("KVAZZUP_AMD_TRACE")) fprintf(stderr, "kvazzup_amd parse Mcycles: split %.1f  skip/pred %.1f  intra/merge/amvp %.1f  residual %.1f  records %.1f  ctu-end %.1f\n", g_tc[0] * 1e-6, g_tc[1] * 1e-6, g_tc[2] * 1e-6, g_tc[3] * 1e-6, g_tc[4] * 1e-6, g_tc[5] * 1e-6);
   if (getenv("KVAZZUP_AMD_TRACE")) fprintf(stderr, "kvazzup_amd decoder thread ms: nal %.1f  wait_parse %.1f  stage %.1f  gpu_api %.1f  gpu_sync %.1f  (pictures %ld)\n", t_nal_, t_wait_, t_stage_, t_api_, t_sync_, job_tail_);
   drop_pending();
   workers_.reset();
   if (stream_) hipStreamSynchronize(stream_);
   for (auto &e : ev_pool_) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   free_buffers();
-  if (h_levels_) hipHostFree(h_levels_);
-  if (h_tus_) hipHostFree(h_tus_);
-  if (d_levels_) hipFree(d_levels_);
-  if (d_tus_) hipFree(d_tus_);
   if (h_err_) hipHostFree(h_err_);
   if (err_) hipFree(err_);
   if (stream_) hipStreamDestroy(stream_);
@@ -277,12 +275,41 @@ bool Decoder::start(std::string *error)
 
 void Decoder::free_buffers()
 {
-  for (auto &j : jobs_) { if (j.h_cu) hipHostFree(j.h_cu); if (j.h_mv) hipHostFree(j.h_mv); j.h_cu = nullptr; j.h_mv = nullptr; }
+  for (auto &j : jobs_) { if (j.h_in) hipHostFree(j.h_in); j.h_in = nullptr; j.h_in_cap = 0; }
   if (h_out_) hipHostFree(h_out_);
-  hipFree(d_cu_); hipFree(d_mv_); hipFree(d_mvd_); hipFree(sync_);
+  hipFree(d_in_); hipFree(d_mvd_); hipFree(sync_);
   for (int c = 0; c < 3; c++) { for (int b = 0; b < 3; b++) { hipFree(rec_[b][c]); rec_[b][c] = nullptr; } hipFree(coef_[c]); coef_[c] = nullptr; }
-  h_out_ = nullptr; d_cu_ = nullptr; d_mv_ = nullptr; d_mvd_ = nullptr; sync_ = nullptr;
+  h_out_ = nullptr; d_in_ = nullptr; d_in_cap_ = 0; d_mvd_ = nullptr; sync_ = nullptr;
   cw_ = ch_ = 0;
+}
+
+// EncFrame view of the CU records and motion vectors at the start of an input block (host or device)
+void Decoder::bind_views(EncFrame &f, uint8_t *base)
+{
+  const size_t nb8 = (size_t)cw_ * ch_ / 64;
+  const int wpp = f.wpp, is_intra = f.is_intra, qp = f.qp;
+  EncFrame keep = f;
+  memset(&f, 0, sizeof(f));
+  f.cw = cw_; f.ch = ch_; f.b8w = cw_ / 8; f.b8h = ch_ / 8; f.wpp = wpp; f.is_intra = is_intra; f.qp = qp;
+  f.cu_log2 = base; f.cu_intra = base + nb8; f.cu_flags = base + 2 * nb8; f.cu_merge_idx = base + 3 * nb8;
+  f.cu_mvp_idx = base + 4 * nb8; f.cu_intra_mode = base + 5 * nb8; f.cu_cbf = base + 6 * nb8; f.cu_mv = (int16_t *)(base + 7 * nb8);
+  f.cu_mvd = keep.cu_mvd; f.sync = keep.sync; f.err = keep.err;
+  for (int c = 0; c < 3; c++) { f.coef[c] = keep.coef[c]; f.rec[c] = keep.rec[c]; f.ref[c] = keep.ref[c]; }
+}
+
+// pinned input block of a job: at least `bytes`; the CU / motion part written so far is kept.  Called from the
+// thread that owns the job (decoder thread at allocation, the job's parse worker later).
+bool Decoder::grow_job_input(PicJob &job, size_t bytes)
+{
+  if (bytes <= job.h_in_cap) return true;
+  if (hipSetDevice(device_) != hipSuccess) return false;
+  const size_t cap = bytes + bytes / 2;
+  uint8_t *p = nullptr;
+  if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return false;
+  if (job.h_in) { memcpy(p, job.h_in, fixed_bytes() < job.h_in_cap ? fixed_bytes() : job.h_in_cap); hipHostFree(job.h_in); }
+  job.h_in = p; job.h_in_cap = cap;
+  bind_views(job.hf, p);
+  return true;
 }
 
 bool Decoder::ensure_buffers(int cw, int ch)
@@ -293,15 +320,15 @@ bool Decoder::ensure_buffers(int cw, int ch)
   free_buffers();
   const size_t npx = (size_t)cw * ch, nb8 = npx / 64;
   if (jobs_.empty()) jobs_ = std::vector<PicJob>((size_t)frame_threads_ + 1);   // parse ring + the picture in flight on the GPU
+  cw_ = cw; ch_ = ch;
   for (auto &j : jobs_) {
-    HIP_TRY(hipHostMalloc(&j.h_cu, nb8 * 7, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(&j.h_mv, nb8 * 2 * sizeof(int16_t), hipHostMallocDefault));
-    memset(j.h_cu, 0, nb8 * 7); memset(j.h_mv, 0, nb8 * 4);
+    if (!grow_job_input(j, fixed_bytes() + (1 << 16))) return false;
+    memset(j.h_in, 0, fixed_bytes());
   }
   HIP_TRY(hipHostMalloc(&h_out_, npx * 3 / 2, hipHostMallocDefault));
   h_out_cap_ = npx * 3 / 2;
-  HIP_TRY(hipMalloc(&d_cu_, nb8 * 7));
-  HIP_TRY(hipMalloc(&d_mv_, nb8 * 2 * sizeof(int16_t)));
+  d_in_cap_ = fixed_bytes() + (1 << 20);
+  HIP_TRY(hipMalloc(&d_in_, d_in_cap_));
   HIP_TRY(hipMalloc(&d_mvd_, nb8 * 2 * sizeof(int16_t)));
   HIP_TRY(hipMalloc(&sync_, sizeof(uint32_t) * 3 * (size_t)(ch / 64)));
   for (int c = 0; c < 3; c++) {
@@ -309,15 +336,8 @@ bool Decoder::ensure_buffers(int cw, int ch)
     for (int b = 0; b < 3; b++) { HIP_TRY(hipMalloc(&rec_[b][c], n)); HIP_TRY(hipMemset(rec_[b][c], 128, n)); }
     HIP_TRY(hipMalloc(&coef_[c], n * sizeof(int16_t)));
   }
-  cw_ = cw; ch_ = ch;
-  auto fill = [&](EncFrame &f, uint8_t *cu, int16_t *mv) {
-    memset(&f, 0, sizeof(f));
-    f.cw = cw; f.ch = ch; f.b8w = cw / 8; f.b8h = ch / 8; f.wpp = 0;
-    f.cu_log2 = cu; f.cu_intra = cu + nb8; f.cu_flags = cu + 2 * nb8; f.cu_merge_idx = cu + 3 * nb8;
-    f.cu_mvp_idx = cu + 4 * nb8; f.cu_intra_mode = cu + 5 * nb8; f.cu_cbf = cu + 6 * nb8; f.cu_mv = mv;
-  };
-  for (auto &j : jobs_) fill(j.hf, j.h_cu, j.h_mv);
-  fill(f_, d_cu_, d_mv_);
+  for (auto &j : jobs_) bind_views(j.hf, j.h_in);
+  bind_views(f_, d_in_);
   f_.cu_mvd = d_mvd_;
   for (int c = 0; c < 3; c++) f_.coef[c] = coef_[c];
   f_.sync = sync_; f_.err = err_;
@@ -646,7 +666,8 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
     if (!wait_above(row, 2)) return DEC_ERR_INVALID;
     memcpy(c.ctx, &job.wpp_saved[(size_t)(row - 1) * CTX_COUNT], CTX_COUNT);
   }
-  int16_t blk[32 * 32];
+  uint64_t tc[6] = {0, 0, 0, 0, 0, 0}, t0 = TSC(), t1;
+#define LAP(k) do { t1 = TSC(); tc[k] += t1 - t0; t0 = t1; } while (0)
   for (int cy = first_cy; cy < first_cy + ncy; cy++) {
     for (int cx = 0; cx < wc; cx++) {
       if (!wait_above(cy, cx + 2)) return DEC_ERR_INVALID;
@@ -662,6 +683,7 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
           int a = avail64(cw_, ch_, x0, y0, x0, y0 - 1) && (6 - f.cu_log2[b8idx(f, x0, y0 - 1)]) > depth;
           if (!c.bin(CTX_SPLIT_CU + l + a)) break;
         }
+        LAP(0);
         if (log2 == 6) return DEC_ERR_UNSUPPORTED;  // 64x64 coding units
         const int n = 1 << log2;
         int skip = 0, intra = is_intra ? 1 : 0, flags = 0, mode = 0, cbf = 0, mvx = 0, mvy = 0;
@@ -674,6 +696,7 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
         if (!is_intra && intra) return DEC_ERR_UNSUPPORTED;       // intra CUs in P pictures
         if (!intra && log2 == 3) return DEC_ERR_UNSUPPORTED;      // 8x8 inter CUs
         if (!skip && (!intra || log2 == 3) && !c.bin(CTX_PART_MODE)) return DEC_ERR_UNSUPPORTED;   // only PART_2Nx2N
+        LAP(1);
         bool root_cbf = true;
         if (intra) {
           int prev = c.bin(CTX_PREV_INTRA);
@@ -716,20 +739,22 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
             root_cbf = c.bin(CTX_RQT_ROOT_CBF) != 0;
           }
         }
+        LAP(2);
         if (intra || root_cbf) {
           int cb = c.bin(CTX_CBF_CHROMA), cr = c.bin(CTX_CBF_CHROMA);
           int luma = (intra || cb || cr) ? c.bin(CTX_CBF_LUMA + 1) : 1;
           cbf = luma | (cb << 1) | (cr << 2);
           for (int ci = 0; ci < 3; ci++) {
             if (!((cbf >> ci) & 1)) continue;
-            int l2 = ci ? log2 - 1 : log2, nn = 1 << l2;
-            if (!parse_residual(c, l2, ci, intra_scan_idx(intra, l2, ci, mode), blk)) return DEC_ERR_INVALID;
+            const int l2 = ci ? log2 - 1 : log2;
             TuDesc td; td.x = (uint16_t)(ci ? x0 >> 1 : x0); td.y = (uint16_t)(ci ? y0 >> 1 : y0); td.plane = (uint8_t)ci; td.log2 = (uint8_t)l2;
-            td.pad = 0; td.offset = (uint32_t)rs.levels.size();
+            td.offset = (uint32_t)rs.levels.size();
+            if (!parse_residual(c, l2, ci, intra_scan_idx(intra, l2, ci, mode), rs.levels)) return DEC_ERR_INVALID;
+            td.count = (uint16_t)(rs.levels.size() - td.offset);
             rs.tus.push_back(td);
-            rs.levels.insert(rs.levels.end(), blk, blk + nn * nn);
           }
         }
+        LAP(3);
         for (int yy = y0; yy < y0 + n; yy += 8)
           for (int xx = x0; xx < x0 + n; xx += 8) {
             int i = b8idx(f, xx, yy);
@@ -737,6 +762,7 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
             f.cu_intra_mode[i] = (uint8_t)mode; f.cu_cbf[i] = (uint8_t)cbf;
             f.cu_mv[i * 2] = (int16_t)mvx; f.cu_mv[i * 2 + 1] = (int16_t)mvy;
           }
+        LAP(4);
         if (c.overrun()) return DEC_ERR_INVALID;
         z += 1 << (2 * (log2 - 3));
       }
@@ -746,8 +772,10 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
       int end = c.terminate();
       if (end != (last ? 1 : 0)) return DEC_ERR_UNSUPPORTED;      // slice must cover the whole picture
       if (!last && wpp && cx == wc - 1 && !c.terminate()) return DEC_ERR_INVALID;   // end_of_subset_one_bit
+      LAP(5);
     }
   }
+  for (int k = 0; k < 6; k++) g_tc[k] += tc[k];
   return 0;
 }
 
@@ -774,13 +802,19 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
   } else {
     for (int r = 0; r < nsub; r++) one(r);              // frame-parallel mode: rows in sequence on this worker
   }
-  job.levels.clear(); job.tus.clear();
+  // the rows' transform blocks and level words follow the CU records in the job's input block
+  size_t ntu = 0, nlev = 0;
+  for (auto &r : job.rows) { if (r.rc < 0) return r.rc; ntu += r.tus.size(); nlev += r.levels.size(); }
+  const size_t tu_off = (fixed_bytes() + 15) & ~(size_t)15, lev_off = (tu_off + ntu * sizeof(TuDesc) + 15) & ~(size_t)15;
+  if (!grow_job_input(job, lev_off + nlev * sizeof(uint32_t))) return DEC_ERR_GPU;
+  TuDesc *tus = (TuDesc *)(job.h_in + tu_off); uint32_t *lev = (uint32_t *)(job.h_in + lev_off);
+  size_t t = 0, l = 0;
   for (auto &r : job.rows) {
-    if (r.rc < 0) return r.rc;
-    uint32_t base = (uint32_t)job.levels.size();
-    for (TuDesc td : r.tus) { td.offset += base; job.tus.push_back(td); }
-    job.levels.insert(job.levels.end(), r.levels.begin(), r.levels.end());
+    for (TuDesc td : r.tus) { td.offset += (uint32_t)l; tus[t++] = td; }
+    if (!r.levels.empty()) memcpy(lev + l, r.levels.data(), r.levels.size() * sizeof(uint32_t));
+    l += r.levels.size();
   }
+  job.ntu = ntu; job.nlev = nlev;
   return 0;
 }
 
@@ -788,43 +822,25 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
 int Decoder::launch_gpu(PicJob &job)
 {
   const bool is_intra = job.is_intra, deblock = job.deblock; const int slice_qp = job.slice_qp;
-  std::vector<int16_t> &levels_ = job.levels; std::vector<TuDesc> &tus_ = job.tus;
-  uint8_t *h_cu_ = job.h_cu; int16_t *h_mv_ = job.h_mv;
   if (hipSetDevice(device_) != hipSuccess) return DEC_ERR_GPU;
-  const size_t nb8 = (size_t)cw_ * ch_ / 64;
-  const size_t nlev = levels_.size(), ntu = tus_.size();
-  if (nlev > h_levels_cap_) {
-    if (h_levels_) hipHostFree(h_levels_);
-    if (d_levels_) hipFree(d_levels_);
-    h_levels_cap_ = nlev * 2 + 4096;
-    if (hipHostMalloc(&h_levels_, h_levels_cap_ * sizeof(int16_t), hipHostMallocDefault) != hipSuccess) return DEC_ERR_GPU;
-    if (hipMalloc(&d_levels_, h_levels_cap_ * sizeof(int16_t)) != hipSuccess) return DEC_ERR_GPU;
-    d_levels_cap_ = h_levels_cap_;
-  }
-  if (ntu > h_tus_cap_) {
-    if (h_tus_) hipHostFree(h_tus_);
-    if (d_tus_) hipFree(d_tus_);
-    h_tus_cap_ = ntu * 2 + 256;
-    if (hipHostMalloc(&h_tus_, h_tus_cap_ * sizeof(TuDesc), hipHostMallocDefault) != hipSuccess) return DEC_ERR_GPU;
-    if (hipMalloc(&d_tus_, h_tus_cap_ * sizeof(TuDesc)) != hipSuccess) return DEC_ERR_GPU;
-    d_tus_cap_ = h_tus_cap_;
-  }
+  const size_t ntu = job.ntu, nlev = job.nlev;
+  const size_t tu_off = (fixed_bytes() + 15) & ~(size_t)15, lev_off = (tu_off + ntu * sizeof(TuDesc) + 15) & ~(size_t)15;
+  const size_t bytes = lev_off + nlev * sizeof(uint32_t);
   prof_now_ = profiling_ && (launched_ % prof_every_) == 0;
-  Tick tk_stage;
-  if (nlev) memcpy(h_levels_, levels_.data(), nlev * sizeof(int16_t));
-  if (ntu) memcpy(h_tus_, tus_.data(), ntu * sizeof(TuDesc));
-  t_stage_ += tk_stage.ms();
   Tick tk_api;
-  hipError_t e = hipSuccess;
-  e = hipMemcpyAsync(d_cu_, h_cu_, nb8 * 7, hipMemcpyHostToDevice, stream_); if (e != hipSuccess) return DEC_ERR_GPU;
-  e = hipMemcpyAsync(d_mv_, h_mv_, nb8 * 4, hipMemcpyHostToDevice, stream_); if (e != hipSuccess) return DEC_ERR_GPU;
-  if (nlev) { e = hipMemcpyAsync(d_levels_, h_levels_, nlev * sizeof(int16_t), hipMemcpyHostToDevice, stream_); if (e != hipSuccess) return DEC_ERR_GPU; }
-  if (ntu) { e = hipMemcpyAsync(d_tus_, h_tus_, ntu * sizeof(TuDesc), hipMemcpyHostToDevice, stream_); if (e != hipSuccess) return DEC_ERR_GPU; }
+  if (bytes > d_in_cap_) {                               // (the stream is idle here: the previous picture has been completed)
+    hipFree(d_in_);
+    d_in_cap_ = bytes + bytes / 2;
+    if (hipMalloc(&d_in_, d_in_cap_) != hipSuccess) { d_in_ = nullptr; d_in_cap_ = 0; return DEC_ERR_GPU; }
+    bind_views(f_, d_in_);
+  }
+  if (hipMemcpyAsync(d_in_, job.h_in, bytes, hipMemcpyHostToDevice, stream_) != hipSuccess) return DEC_ERR_GPU;
+  const TuDesc *d_tus = (const TuDesc *)(d_in_ + tu_off); const uint32_t *d_lev = (const uint32_t *)(d_in_ + lev_off);
   f_.qp = slice_qp; f_.qpc = kChromaQp[slice_qp]; f_.is_intra = is_intra;
   const int cur = (int)(launched_ % 3), ref = (int)((launched_ + 2) % 3);     // three buffers: the picture output by the previous call stays intact
   for (int c = 0; c < 3; c++) { f_.rec[c] = rec_[cur][c]; f_.ref[c] = rec_[ref][c]; }
   const EncFrame f = f_;
-  timed(DK_SCATTER, [&] { launch_scatter_levels(f, d_tus_, (int)ntu, d_levels_, stream_); });
+  timed(DK_SCATTER, [&] { launch_scatter_levels(f, d_tus, (int)ntu, d_lev, stream_); });
   if (is_intra) {
     if (hipMemsetAsync(sync_, 0, sizeof(uint32_t) * 3 * (size_t)(ch_ / 64), stream_) != hipSuccess) return DEC_ERR_GPU;
     timed(DK_INTRA_RECON, [&] { launch_dec_intra_recon(f, stream_); });

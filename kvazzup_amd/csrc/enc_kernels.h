@@ -14,7 +14,9 @@ void launch_deblock(const EncFrame &f, hipStream_t st);
 void launch_dec_inter_recon(const EncFrame &f, hipStream_t st);
 void launch_dec_intra_recon(const EncFrame &f, hipStream_t st);
 // scatter packed levels (TU descriptors) into the plane-shaped level arrays
-struct TuDesc { uint16_t x, y; uint8_t plane, log2; uint16_t pad; uint32_t offset; };
-void launch_scatter_levels(const EncFrame &f, const TuDesc *tus, int ntu, const int16_t *packed, hipStream_t st);
+// one coded transform block of a picture being decoded: position (component samples), plane, size and its non-zero
+// levels as `count` words (raster position inside the block << 16 | level & 0xffff) starting at word `offset`
+struct TuDesc { uint16_t x, y; uint8_t plane, log2; uint16_t count; uint32_t offset; };
+void launch_scatter_levels(const EncFrame &f, const TuDesc *tus, int ntu, const uint32_t *pairs, hipStream_t st);
 void launch_tokenize(const EncFrame &f, hipStream_t st);   // k_tokenize + k_tok_scan + k_tok_compact
 }  // namespace kvzx

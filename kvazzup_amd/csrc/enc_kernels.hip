@@ -1181,21 +1181,26 @@ __global__ __launch_bounds__(256) void k_pad_input(const uint8_t *in, int w, int
 // Decoder input: levels of the coded transform blocks arrive packed (block after block, row-major
 // inside a block); this kernel writes them to their place in the plane-shaped level arrays.
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_scatter_levels(EncFrame f, const TuDesc *tus, const int16_t *packed)
+__global__ __launch_bounds__(256) void k_scatter_levels(EncFrame f, const TuDesc *tus, const uint32_t *pairs)
 {
   const TuDesc d = tus[blockIdx.x];
   const int n = 1 << d.log2, pw = d.plane ? (f.cw >> 1) : f.cw;
   int16_t *dst = f.coef[d.plane] + (size_t)d.y * pw + d.x;
-  const int16_t *src = packed + d.offset;
-  for (int o = threadIdx.x; o < n * n; o += 256) dst[(o >> d.log2) * pw + (o & (n - 1))] = src[o];
+  for (int o = threadIdx.x; o < n * n / 4; o += 256) *(uint2 *)&dst[((o * 4) >> d.log2) * pw + ((o * 4) & (n - 1))] = make_uint2(0u, 0u);
+  __syncthreads();
+  const uint32_t *src = pairs + d.offset;
+  for (int i = threadIdx.x; i < d.count; i += 256) {
+    const uint32_t pr = src[i], pos = pr >> 16;
+    dst[(pos >> d.log2) * pw + (pos & (n - 1))] = (int16_t)(pr & 0xffffu);
+  }
 }
 
 // =============================================================================================
 // launch wrappers
 // =============================================================================================
-void launch_scatter_levels(const EncFrame &f, const TuDesc *tus, int ntu, const int16_t *packed, hipStream_t st)
+void launch_scatter_levels(const EncFrame &f, const TuDesc *tus, int ntu, const uint32_t *pairs, hipStream_t st)
 {
-  if (ntu > 0) hipLaunchKernelGGL(k_scatter_levels, dim3(ntu), dim3(256), 0, st, f, tus, packed);
+  if (ntu > 0) hipLaunchKernelGGL(k_scatter_levels, dim3(ntu), dim3(256), 0, st, f, tus, pairs);
 }
 void launch_pad_input(const uint8_t *in, int w, int h, uint8_t *dst, int cw, int ch, hipStream_t st)
 {

@@ -101,6 +101,7 @@ class Encoder {
   std::vector<std::vector<uint8_t>> rows_out_;
   int frame_idx_ = 0, poc_ = 0, intra_count_ = 0;
   bool profiling_ = false, prof_now_ = false; int prof_every_ = 1;
+  double t_submit_ = 0, t_wait_ = 0, t_arith_ = 0, t_asm_ = 0, t_in_ = 0;   // encoder-thread time split (KVAZZUP_AMD_TRACE)
   double k_ms_[K_COUNT] = {0}; uint64_t k_n_[K_COUNT] = {0};
   StreamParams sp_{};
 };

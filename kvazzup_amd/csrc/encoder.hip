@@ -2,6 +2,7 @@
 #include <chrono>
 #include <functional>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "encoder.h"
 #include "enc_kernels.h"
@@ -96,8 +97,11 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   return true;
 }
 
+namespace { struct Tick { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } }; }
+
 Encoder::~Encoder()
 {
+  if (getenv("KVAZZUP_AMD_TRACE")) fprintf(stderr, "kvazzup_amd encoder thread ms: submit %.1f  wait_gpu %.1f  arith %.1f  assemble %.1f  wait_input %.1f  (pictures %ld)\n", t_submit_, t_wait_, t_arith_, t_asm_, t_in_, collected_);
   if (stream_) hipStreamSynchronize(stream_);
   for (Slot &sl : slot_) {
     for (auto &e : sl.ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -151,12 +155,12 @@ bool Encoder::encode_device(const uint8_t *d_i420, EncodedPicture *out)
 {
   HIP_CHECK(hipSetDevice(cfg_.device));
   out->valid = false; out->au.clear();
-  if (!submit(d_i420, d_i420 == d_in_)) return false;
+  { Tick tk; if (!submit(d_i420, d_i420 == d_in_)) return false; t_submit_ += tk.ms(); }
   bool ok = true;
   if (pending() > (cfg_.owf > 0 ? 1 : 0)) ok = collect(out);
   // the caller may reuse its input buffer when this returns (the pad kernel is first in the picture's queue,
   // and by now it has had the whole host coding stage of the previous picture to run)
-  if (in_pending_) { HIP_CHECK(hipEventSynchronize(in_done_)); in_pending_ = false; }
+  if (in_pending_) { Tick tk; HIP_CHECK(hipEventSynchronize(in_done_)); in_pending_ = false; t_in_ += tk.ms(); }
   return ok;
 }
 
@@ -217,7 +221,7 @@ bool Encoder::collect(EncodedPicture *out)
 {
   Slot &sl = slot_[cfg_.owf > 0 ? (collected_ & 1) : 0];
   collected_++;
-  HIP_CHECK(hipEventSynchronize(sl.done));
+  { Tick tk; HIP_CHECK(hipEventSynchronize(sl.done)); t_wait_ += tk.ms(); }
   if (*sl.h_err) { fprintf(stderr, "kvazzup_amd: device error flags 0x%x (8/16/32: token buffer overflow)\n", *sl.h_err); return false; }
   if (profiling_ || sl.ev_used) {
     for (size_t i = 0; i < sl.ev_used; i++) {
@@ -230,11 +234,13 @@ bool Encoder::collect(EncodedPicture *out)
   const int nsub = cfg_.wpp ? rows_ : 1;
   uint64_t bins = 0;
   auto t0 = std::chrono::steady_clock::now();
+  Tick tk_ar;
   entropy_->code_picture(sl.h_tok_dense, sl.h_tok_count, cw_ / 64, rows_, cfg_.wpp != 0, sl.intra ? 0 : 1, cfg_.qp, rows_out_, &bins);
   if (profiling_) { k_ms_[K_HOST_ARITH] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); k_n_[K_HOST_ARITH]++; }
   // ---- access unit assembly (host): parameter sets with IDR pictures, then the slice NAL
   out->valid = true; out->poc = sl.poc; out->is_intra = sl.intra; out->bins = bins;
-  assemble_access_unit(out->au, sp_, sl.intra, sl.poc, sl.write_ps, rows_out_, nsub);
+  t_arith_ += tk_ar.ms();
+  { Tick tk; assemble_access_unit(out->au, sp_, sl.intra, sl.poc, sl.write_ps, rows_out_, nsub); t_asm_ += tk.ms(); }
   out_idx_ = sl.rec_idx;
   return true;
 }

@@ -82,11 +82,12 @@ def main():
     ap.add_argument("--me-range", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
-    ap.add_argument("--decoder-frame-threads", type=int, default=6,
+    ap.add_argument("--decoder-frame-threads", type=int, default=8,
                     help="OpenHEVC 'Frame' parallelisation (uvgComm setting video/OH_parallelization): pictures parsed concurrently; 1 = off")
     ap.add_argument("--profile-every", type=int, default=8, help="kernel timing with HIP events on every n-th picture")
-    ap.add_argument("--owf", type=int, default=1,
-                    help="uvgComm setting video/OWF (kvazaar owf): 1 = host arithmetic coding of picture t overlaps the kernels of t + 1")
+    ap.add_argument("--owf", type=int, default=2,
+                    help="uvgComm setting video/OWF (kvazaar owf): 1 = host arithmetic coding of picture t overlaps the kernels of t + 1; "
+                         "2 = it runs on a background thread and the output lags two pictures")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,7 +110,7 @@ def main():
     w, h = wl["w"], wl["h"]
     total = args.warmup + args.steps
     D = max(1, args.decoder_frame_threads)
-    extra = (D if D > 1 else 0) + (1 if args.owf > 0 else 0)   # pictures pushed after the timed ones: the encoder (owf) and the frame-threaded decoder deliver with a lag
+    extra = (D if D > 1 else 0) + min(max(args.owf, 0), 2)   # pictures pushed after the timed ones: the encoder (owf) and the frame-threaded decoder deliver with a lag
     seed = 0x5EED0000 + wl["cfg_index"] + 16 * rank
     # synthetic clip generated directly in HBM (inputs resident before the timed region)
     clip = [synth.frame_torch(synth.MOVING, seed, w, h, t, dev) for t in range(total + extra)]

@@ -5,7 +5,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "hevc_core.h"
 #include "hevc_headers.h"
@@ -24,8 +28,9 @@ struct EncoderConfig {
   int wpp = 1, deblock = 1;
   int device = 0;
   int entropy_threads = 16;   // host threads of the arithmetic-coding stage
-  int owf = 0;                // kvazaar "owf": 0 = encode() returns its own picture; >= 1 = output lags one picture and
-                              // the host coding of picture t overlaps the kernels of picture t + 1
+  int owf = 0;                // kvazaar "owf": 0 = encode() returns its own picture; 1 = output lags one picture and the host
+                              // coding of picture t overlaps the kernels of t + 1; >= 2 = output lags two pictures and the host
+                              // coding runs on a background thread, so the calling thread only launches kernels
 };
 
 struct EncodedPicture {
@@ -67,6 +72,9 @@ class Encoder {
   bool init(const EncoderConfig &cfg, std::string *error);
   bool submit(const uint8_t *d_i420, bool via_staging);
   bool collect(EncodedPicture *out);
+  struct Slot;
+  bool finish_slot(Slot &sl, EncodedPicture *out);   // wait for the slot's kernels, arithmetic coding, access unit
+  void background();
   void timed(KernelId id, const std::function<void()> &launch);
 
   EncoderConfig cfg_;
@@ -76,8 +84,9 @@ class Encoder {
   uint8_t *d_in_ = nullptr;              // packed input staging (device)
   uint8_t *h_in_ = nullptr;              // pinned host staging
   uint8_t *src_[3] = {nullptr, nullptr, nullptr};
-  uint8_t *rec_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-  int cur_idx_ = 0, ref_idx_ = 1, out_idx_ = 1;
+  // reconstruction ring: the picture being coded, its reference, and (owf >= 2) the one still waiting to be output
+  uint8_t *rec_[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  int cur_idx_ = 0, ref_idx_ = 2, out_idx_ = 2;
   int16_t *coef_[3] = {nullptr, nullptr, nullptr};
   uint8_t *cu_bytes_ = nullptr;          // 7 byte arrays back to back
   int16_t *cu_mv_ = nullptr, *cu_mvd_ = nullptr;
@@ -93,8 +102,11 @@ class Encoder {
     hipEvent_t done = nullptr;
     int poc = 0, rec_idx = 0; bool intra = false, write_ps = false;
     std::vector<EvPair> ev; size_t ev_used = 0;
+    EncodedPicture result; bool ready = false, ok = true;   // owf >= 2: filled by the background thread
   };
-  Slot slot_[2]; Slot *cur_slot_ = nullptr;
+  Slot slot_[3]; Slot *cur_slot_ = nullptr; int nslots_ = 1, depth_ = 0;
+  std::thread bg_; std::mutex bm_; std::condition_variable bcv_; std::deque<int> bq_; bool bquit_ = false;
+  std::mutex stat_m_;
   long submitted_ = 0, collected_ = 0;
   hipEvent_t in_done_ = nullptr; bool in_pending_ = false;   // input picture consumed (staging buffer / caller's device buffer reusable)
   EntropyHost *entropy_ = nullptr;

@@ -41,8 +41,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   for (int c = 0; c < 3; c++) {
     size_t n = c ? npx / 4 : npx;
     HIP_OK(hipMalloc(&src_[c], n));
-    HIP_OK(hipMalloc(&rec_[0][c], n)); HIP_OK(hipMalloc(&rec_[1][c], n));
-    HIP_OK(hipMemset(rec_[0][c], 0, n)); HIP_OK(hipMemset(rec_[1][c], 0, n));
+    for (int b = 0; b < 3; b++) { HIP_OK(hipMalloc(&rec_[b][c], n)); HIP_OK(hipMemset(rec_[b][c], 0, n)); }
     HIP_OK(hipMalloc(&coef_[c], n * sizeof(int16_t)));
     HIP_OK(hipMemset(coef_[c], 0, n * sizeof(int16_t)));
   }
@@ -60,7 +59,9 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   HIP_OK(hipMalloc(&tok_off_, sizeof(uint32_t) * (nctu + 1)));
   tok_dense_cap_ = (size_t)nctu * tok_cap_;
   if (tok_dense_cap_ > ((size_t)1 << 27)) tok_dense_cap_ = (size_t)1 << 27;
-  for (int i = 0; i < (cfg.owf > 0 ? 2 : 1); i++) {
+  depth_ = cfg.owf >= 2 ? 2 : (cfg.owf == 1 ? 1 : 0);
+  nslots_ = depth_ + 1;
+  for (int i = 0; i < nslots_; i++) {
     Slot &sl = slot_[i];
     void *dp = nullptr;
     HIP_OK(hipHostMalloc(&sl.h_tok_dense, tok_dense_cap_ * sizeof(uint16_t), hipHostMallocMapped));
@@ -94,6 +95,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   sp_.deblock = cfg.deblock; sp_.fps_num = cfg.fps_num; sp_.fps_den = cfg.fps_den;
   HIP_OK(hipStreamSynchronize(stream_));
   HIP_OK(hipDeviceSynchronize());
+  if (depth_ >= 2) bg_ = std::thread([this] { background(); });
   return true;
 }
 
@@ -102,6 +104,7 @@ namespace { struct Tick { std::chrono::steady_clock::time_point t0 = std::chrono
 Encoder::~Encoder()
 {
   if (getenv("KVAZZUP_AMD_TRACE")) fprintf(stderr, "kvazzup_amd encoder thread ms: submit %.1f  wait_gpu %.1f  arith %.1f  assemble %.1f  wait_input %.1f  (pictures %ld)\n", t_submit_, t_wait_, t_arith_, t_asm_, t_in_, collected_);
+  if (bg_.joinable()) { { std::lock_guard<std::mutex> l(bm_); bquit_ = true; } bcv_.notify_all(); bg_.join(); }
   if (stream_) hipStreamSynchronize(stream_);
   for (Slot &sl : slot_) {
     for (auto &e : sl.ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -112,7 +115,7 @@ Encoder::~Encoder()
   }
   if (in_done_) hipEventDestroy(in_done_);
   hipFree(d_in_); hipHostFree(h_in_);
-  for (int c = 0; c < 3; c++) { hipFree(src_[c]); hipFree(rec_[0][c]); hipFree(rec_[1][c]); hipFree(coef_[c]); }
+  for (int c = 0; c < 3; c++) { hipFree(src_[c]); for (int b = 0; b < 3; b++) hipFree(rec_[b][c]); hipFree(coef_[c]); }
   hipFree(cu_bytes_); hipFree(cu_mv_); hipFree(cu_mvd_); hipFree(intra_scratch_);
   delete entropy_;
   hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(tok_off_); hipFree(sync_); hipFree(err_);
@@ -134,6 +137,7 @@ void Encoder::timed(KernelId id, const std::function<void()> &launch)
 
 void Encoder::get_kernel_times(double *ms, uint64_t *launches, bool reset)
 {
+  std::lock_guard<std::mutex> l(stat_m_);
   for (int i = 0; i < K_COUNT; i++) { if (ms) ms[i] = k_ms_[i]; if (launches) launches[i] = k_n_[i]; }
   if (reset) for (int i = 0; i < K_COUNT; i++) { k_ms_[i] = 0; k_n_[i] = 0; }
 }
@@ -157,7 +161,7 @@ bool Encoder::encode_device(const uint8_t *d_i420, EncodedPicture *out)
   out->valid = false; out->au.clear();
   { Tick tk; if (!submit(d_i420, d_i420 == d_in_)) return false; t_submit_ += tk.ms(); }
   bool ok = true;
-  if (pending() > (cfg_.owf > 0 ? 1 : 0)) ok = collect(out);
+  if (pending() > depth_) ok = collect(out);
   // the caller may reuse its input buffer when this returns (the pad kernel is first in the picture's queue,
   // and by now it has had the whole host coding stage of the previous picture to run)
   if (in_pending_) { Tick tk; HIP_CHECK(hipEventSynchronize(in_done_)); in_pending_ = false; t_in_ += tk.ms(); }
@@ -176,7 +180,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
 {
   const size_t ny = (size_t)cfg_.width * cfg_.height;
   const int w = cfg_.width, h = cfg_.height;
-  Slot &sl = slot_[cfg_.owf > 0 ? (submitted_ & 1) : 0];
+  Slot &sl = slot_[submitted_ % nslots_];
   cur_slot_ = &sl;
   prof_now_ = profiling_ && (frame_idx_ % prof_every_) == 0;
   timed(K_PAD, [&] {
@@ -212,18 +216,53 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
     intra_count_++;
   }
   frame_idx_++;
-  int t = cur_idx_; cur_idx_ = ref_idx_; ref_idx_ = t;     // rec_[ref_idx_] holds the picture just submitted
+  ref_idx_ = cur_idx_; cur_idx_ = (cur_idx_ + 1) % 3;      // rec_[ref_idx_] holds the picture just submitted
   submitted_++;
+  if (depth_ >= 2) {
+    { std::lock_guard<std::mutex> l(bm_); sl.ready = false; bq_.push_back((int)((submitted_ - 1) % nslots_)); }
+    bcv_.notify_all();
+  }
   return true;
 }
 
 bool Encoder::collect(EncodedPicture *out)
 {
-  Slot &sl = slot_[cfg_.owf > 0 ? (collected_ & 1) : 0];
+  Slot &sl = slot_[collected_ % nslots_];
   collected_++;
-  { Tick tk; HIP_CHECK(hipEventSynchronize(sl.done)); t_wait_ += tk.ms(); }
+  bool ok;
+  if (depth_ >= 2) {
+    Tick tk;
+    std::unique_lock<std::mutex> l(bm_);
+    bcv_.wait(l, [&] { return sl.ready; });
+    t_wait_ += tk.ms();
+    ok = sl.ok;
+    std::swap(*out, sl.result);
+  } else ok = finish_slot(sl, out);
+  out_idx_ = sl.rec_idx;
+  return ok;
+}
+
+// owf >= 2: pictures are finished here, in submission order, while the calling thread keeps launching kernels
+void Encoder::background()
+{
+  hipSetDevice(cfg_.device);
+  for (;;) {
+    int idx;
+    { std::unique_lock<std::mutex> l(bm_); bcv_.wait(l, [&] { return bquit_ || !bq_.empty(); }); if (bq_.empty()) return; idx = bq_.front(); bq_.pop_front(); }
+    Slot &sl = slot_[idx];
+    const bool ok = finish_slot(sl, &sl.result);
+    { std::lock_guard<std::mutex> l(bm_); sl.ok = ok; sl.ready = true; }
+    bcv_.notify_all();
+  }
+}
+
+bool Encoder::finish_slot(Slot &sl, EncodedPicture *out)
+{
+  out->valid = false; out->au.clear();
+  { Tick tk; HIP_CHECK(hipEventSynchronize(sl.done)); if (depth_ < 2) t_wait_ += tk.ms(); }
   if (*sl.h_err) { fprintf(stderr, "kvazzup_amd: device error flags 0x%x (8/16/32: token buffer overflow)\n", *sl.h_err); return false; }
-  if (profiling_ || sl.ev_used) {
+  if (sl.ev_used) {
+    std::lock_guard<std::mutex> l(stat_m_);
     for (size_t i = 0; i < sl.ev_used; i++) {
       float ms = 0; hipEventElapsedTime(&ms, sl.ev[i].a, sl.ev[i].b);
       k_ms_[sl.ev[i].id] += ms; k_n_[sl.ev[i].id]++;
@@ -233,15 +272,14 @@ bool Encoder::collect(EncodedPicture *out)
   // ---- serial half of entropy coding: host threads turn the bins into the WPP substreams
   const int nsub = cfg_.wpp ? rows_ : 1;
   uint64_t bins = 0;
-  auto t0 = std::chrono::steady_clock::now();
   Tick tk_ar;
   entropy_->code_picture(sl.h_tok_dense, sl.h_tok_count, cw_ / 64, rows_, cfg_.wpp != 0, sl.intra ? 0 : 1, cfg_.qp, rows_out_, &bins);
-  if (profiling_) { k_ms_[K_HOST_ARITH] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); k_n_[K_HOST_ARITH]++; }
+  const double ar = tk_ar.ms();
+  if (profiling_) { std::lock_guard<std::mutex> l(stat_m_); k_ms_[K_HOST_ARITH] += ar; k_n_[K_HOST_ARITH]++; }
+  t_arith_ += ar;
   // ---- access unit assembly (host): parameter sets with IDR pictures, then the slice NAL
   out->valid = true; out->poc = sl.poc; out->is_intra = sl.intra; out->bins = bins;
-  t_arith_ += tk_ar.ms();
   { Tick tk; assemble_access_unit(out->au, sp_, sl.intra, sl.poc, sl.write_ps, rows_out_, nsub); t_asm_ += tk.ms(); }
-  out_idx_ = sl.rec_idx;
   return true;
 }
 

@@ -68,9 +68,11 @@ def test_encoder_matches_oracle(gpu, cfg):
 
 
 @pytest.mark.gpu
-def test_owf_lags_output_by_one_picture_and_flushes(gpu):
-    """video/OWF >= 1 (kvazaarfilter.cpp:193): the access unit returned by call t is picture t - 1, a NULL
-    picture flushes the last one; the bytes and reconstructions are those of the synchronous encoder."""
+@pytest.mark.parametrize("owf", [1, 2])
+def test_owf_lags_output_and_flushes(gpu, owf):
+    """video/OWF = n (kvazaarfilter.cpp:193): the access unit returned by call t is picture t - n (n = 2: the
+    host coding stage runs on a background thread), NULL pictures flush the rest; the bytes and
+    reconstructions are those of the synchronous encoder."""
     from kvazzup_amd.codec import Encoder
     w, h, frames = 320, 192, 7
     clip = [orc.synth_frame(0, SEED, w, h, t) for t in range(frames)]
@@ -78,12 +80,13 @@ def test_owf_lags_output_by_one_picture_and_flushes(gpu):
     e0 = Encoder(w, h, options=opts)
     want = [e0.encode(f) for f in clip]
     e0.close()
-    e1 = Encoder(w, h, options=opts + (("owf", 1),))
+    e1 = Encoder(w, h, options=opts + (("owf", owf),))
     got = [e1.encode(f) for f in clip]
-    assert got[0] == (None, None)
-    got.append(e1.encode(None))
+    assert got[:owf] == [(None, None)] * owf
+    for _ in range(owf):
+        got.append(e1.encode(None))
     assert e1.encode(None) == (None, None)
     e1.close()
     for t in range(frames):
-        assert got[t + 1][0] == want[t][0], t
-        assert np.array_equal(got[t + 1][1], want[t][1]), t
+        assert got[t + owf][0] == want[t][0], t
+        assert np.array_equal(got[t + owf][1], want[t][1]), t

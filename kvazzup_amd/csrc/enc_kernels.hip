@@ -989,6 +989,7 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
   int z4 = 0;                                          // z-order index of the unit inside its CTU
   for (int b = 0; b < 2; b++) z4 |= (((ux & 3) >> b) & 1) << (2 * b) | (((uy & 3) >> b) & 1) << (2 * b + 1);
   core_tabs_fill_entry(tabs, lane);
+  if (lane == 0 && (ux | uy | comp) == 0) *f.tok_total = 0;           // dense-array cursor of this picture's k_tok_compact
   if (lane < TOK_PIECES) { seg[lane][0] = 0; seg[lane][1] = 0; }
   if (lane == 0) hdr_n = 0;
   const int bx0 = ux * 2 - 1, by0 = uy * 2 - 1;
@@ -1119,28 +1120,22 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
   }
 }
 
-// exclusive prefix sum of the per-CTU token counts (single workgroup), then a dense copy in coding order
-__global__ __launch_bounds__(256) void k_tok_scan(EncFrame f, int nctu)
-{
-  __shared__ uint32_t part[256];
-  const int tid = threadIdx.x, per = (nctu + 255) / 256, lo = tid * per, hi = min(nctu, lo + per);
-  uint32_t s = 0;
-  for (int i = lo; i < hi; i++) s += f.tok_cursor[i];
-  part[tid] = s;
-  __syncthreads();
-  if (tid == 0) { uint32_t a = 0; for (int i = 0; i < 256; i++) { uint32_t t = part[i]; part[i] = a; a += t; } f.tok_off[nctu] = a; }
-  __syncthreads();
-  uint32_t a = part[tid];
-  for (int i = lo; i < hi; i++) { f.tok_off[i] = a; a += f.tok_cursor[i]; }
-}
 // one workgroup per CTU: the pieces of its 16 units in z-order, piece after piece -> the dense token array
+// (tok_count_out[ctu] < 0 tells the host that the CTU did not fit or its table was inconsistent)
 __global__ __launch_bounds__(256) void k_tok_compact(EncFrame f)
 {
   constexpr int NSEG = 16 * TOK_PIECES;
   __shared__ uint32_t soff[NSEG], start[NSEG + 1], utot[17];
+  __shared__ uint32_t base_s;
   const int ctu = blockIdx.x, tid = threadIdx.x;
-  const uint32_t n = f.tok_cursor[ctu], base = f.tok_off[ctu];
-  if (base + n > f.tok_dense_cap) { if (tid == 0) { atomicOr(f.err, 32u); f.tok_count_out[ctu] = 0; } return; }
+  const uint32_t n = f.tok_cursor[ctu];
+  // a place in the dense array (CTUs land in completion order: the host gets each CTU's offset), the slot's
+  // cursor back to zero for the next picture, and the device error word over to the host
+  if (tid == 0) { base_s = atomicAdd(f.tok_total, n); if (ctu == 0) *f.err_out = *f.err; }
+  __syncthreads();
+  const uint32_t base = base_s;
+  if (tid == 0) f.tok_cursor[ctu] = 0;
+  if (base + n > f.tok_dense_cap) { if (tid == 0) f.tok_count_out[ctu] = -1; return; }
   const uint32_t *tab = f.tok_seg + (size_t)ctu * NSEG * 2;
   for (int i = tid; i < NSEG; i += 256) { soff[i] = tab[i * 2]; start[i] = tab[i * 2 + 1]; }        // start[] holds lengths for now
   __syncthreads();
@@ -1152,7 +1147,7 @@ __global__ __launch_bounds__(256) void k_tok_compact(EncFrame f)
   if (tid == 0) start[NSEG] = utot[16];
   __syncthreads();
   const uint32_t total = start[NSEG];
-  if (total != n) { if (tid == 0) { atomicOr(f.err, 32u); f.tok_count_out[ctu] = 0; } return; }
+  if (total != n) { if (tid == 0) f.tok_count_out[ctu] = -1; return; }
   const uint16_t *slot = f.tok_buf + (size_t)ctu * f.tok_cap;
   uint16_t *dst = f.tok_dense + base;
   for (uint32_t i = tid; i < n; i += 256) {
@@ -1160,21 +1155,27 @@ __global__ __launch_bounds__(256) void k_tok_compact(EncFrame f)
     while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (start[mid] <= i) lo = mid; else hi = mid; }
     dst[i] = slot[soff[lo] + (i - start[lo])];
   }
-  if (tid == 0) f.tok_count_out[ctu] = (int32_t)n;
+  if (tid == 0) { f.tok_off_out[ctu] = base; f.tok_count_out[ctu] = (int32_t)n; }
 }
 
 // =============================================================================================
 // Input staging: packed I420 picture (w x h) -> coded planes padded to (cw x ch) by edge
 // replication (what the oracle's load_input does)
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_pad_input(const uint8_t *in, int w, int h, uint8_t *dst, int cw, int ch)
+__global__ __launch_bounds__(256) void k_pad_input(const uint8_t *in, int w, int h, uint8_t *dy, uint8_t *du, uint8_t *dv, int cw, int ch)
 {
-  int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
-  if (x >= cw || y >= ch) return;
-  const uint8_t *row = in + (size_t)imin(y, h - 1) * w;
+  // blockIdx.y: luma rows, then Cb rows, then Cr rows (packed I420 input: Y, U, V planes back to back)
+  int y = blockIdx.y, plane = 0;
+  if (y >= ch) { y -= ch; plane = 1; if (y >= ch / 2) { y -= ch / 2; plane = 2; } }
+  const int pw = plane ? w / 2 : w, ph = plane ? h / 2 : h, pcw = plane ? cw / 2 : cw;
+  const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (x >= pcw) return;
+  const uint8_t *src = in + (plane == 0 ? 0 : (plane == 1 ? (size_t)w * h : (size_t)w * h + (size_t)(w / 2) * (h / 2)));
+  uint8_t *dst = plane == 0 ? dy : (plane == 1 ? du : dv);
+  const uint8_t *row = src + (size_t)imin(y, ph - 1) * pw;
   uint32_t v = 0;
-  for (int i = 0; i < 4; i++) v |= (uint32_t)row[imin(x + i, w - 1)] << (8 * i);
-  *reinterpret_cast<uint32_t *>(dst + (size_t)y * cw + x) = v;
+  for (int i = 0; i < 4; i++) v |= (uint32_t)row[imin(x + i, pw - 1)] << (8 * i);
+  *reinterpret_cast<uint32_t *>(dst + (size_t)y * pcw + x) = v;
 }
 
 // =============================================================================================
@@ -1202,10 +1203,10 @@ void launch_scatter_levels(const EncFrame &f, const TuDesc *tus, int ntu, const 
 {
   if (ntu > 0) hipLaunchKernelGGL(k_scatter_levels, dim3(ntu), dim3(256), 0, st, f, tus, pairs);
 }
-void launch_pad_input(const uint8_t *in, int w, int h, uint8_t *dst, int cw, int ch, hipStream_t st)
+void launch_pad_input(const uint8_t *in, int w, int h, uint8_t *dy, uint8_t *du, uint8_t *dv, int cw, int ch, hipStream_t st)
 {
-  dim3 g((cw / 4 + 255) / 256, ch);
-  hipLaunchKernelGGL(k_pad_input, g, dim3(256), 0, st, in, w, h, dst, cw, ch);
+  dim3 g((cw / 4 + 255) / 256, ch * 2);
+  hipLaunchKernelGGL(k_pad_input, g, dim3(256), 0, st, in, w, h, dy, du, dv, cw, ch);
 }
 void launch_me(const EncFrame &f, hipStream_t st)
 {
@@ -1232,9 +1233,7 @@ void launch_deblock(const EncFrame &f, hipStream_t st)
 void launch_tokenize(const EncFrame &f, hipStream_t st)
 {
   const int wc = f.cw / 64, hc = f.ch / 64;
-  hipMemsetAsync(f.tok_cursor, 0, sizeof(uint32_t) * (size_t)(wc * hc), st);
-  hipLaunchKernelGGL(k_tokenize, dim3(f.cw / 16, f.ch / 16, 3), dim3(64), 0, st, f);
-  hipLaunchKernelGGL(k_tok_scan, dim3(1), dim3(256), 0, st, f, wc * hc);
+  hipLaunchKernelGGL(k_tokenize, dim3(f.cw / 16, f.ch / 16, 3), dim3(64), 0, st, f);     // (tok_cursor is zero: k_tok_compact leaves it so)
   hipLaunchKernelGGL(k_tok_compact, dim3(wc * hc), dim3(256), 0, st, f);
 }
 

@@ -91,14 +91,15 @@ class Encoder {
   uint8_t *cu_bytes_ = nullptr;          // 7 byte arrays back to back
   int16_t *cu_mv_ = nullptr, *cu_mvd_ = nullptr;
   uint8_t *intra_scratch_ = nullptr;
-  uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; uint32_t *tok_off_ = nullptr;
+  uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; uint32_t *tok_total_ = nullptr;
   size_t tok_dense_cap_ = 0;
   uint32_t *sync_ = nullptr; uint32_t *err_ = nullptr;
   // one slot per picture in flight: the host-visible results of its kernels and what collect() needs to finish it
   struct EvPair { hipEvent_t a, b; KernelId id; };
   struct Slot {
     uint16_t *h_tok_dense = nullptr, *d_tok_dense = nullptr; int32_t *h_tok_count = nullptr, *d_tok_count = nullptr;   // host-mapped pinned
-    uint32_t *h_err = nullptr;
+    uint32_t *h_tok_off = nullptr, *d_tok_off = nullptr;
+    uint32_t *h_err = nullptr, *d_err = nullptr;
     hipEvent_t done = nullptr;
     int poc = 0, rec_idx = 0; bool intra = false, write_ps = false;
     std::vector<EvPair> ev; size_t ev_used = 0;

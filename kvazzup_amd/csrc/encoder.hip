@@ -56,7 +56,8 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   HIP_OK(hipMalloc(&tok_buf_, (size_t)nctu * tok_cap_ * sizeof(uint16_t)));
   HIP_OK(hipMalloc(&tok_count_, sizeof(uint32_t) * nctu));
   HIP_OK(hipMalloc(&tok_seg_, sizeof(uint32_t) * nctu * 16 * 17 * 2));       // [ctu][unit][piece] {offset, length}
-  HIP_OK(hipMalloc(&tok_off_, sizeof(uint32_t) * (nctu + 1)));
+  HIP_OK(hipMalloc(&tok_total_, sizeof(uint32_t))); HIP_OK(hipMemset(tok_total_, 0, sizeof(uint32_t)));
+  HIP_OK(hipMemset(tok_count_, 0, sizeof(uint32_t) * nctu));
   tok_dense_cap_ = (size_t)nctu * tok_cap_;
   if (tok_dense_cap_ > ((size_t)1 << 27)) tok_dense_cap_ = (size_t)1 << 27;
   depth_ = cfg.owf >= 2 ? 2 : (cfg.owf == 1 ? 1 : 0);
@@ -68,7 +69,10 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
     HIP_OK(hipHostMalloc(&sl.h_tok_count, sizeof(int32_t) * nctu, hipHostMallocMapped));
     HIP_OK(hipHostGetDevicePointer(&dp, sl.h_tok_dense, 0)); sl.d_tok_dense = (uint16_t *)dp;
     HIP_OK(hipHostGetDevicePointer(&dp, sl.h_tok_count, 0)); sl.d_tok_count = (int32_t *)dp;
-    HIP_OK(hipHostMalloc(&sl.h_err, sizeof(uint32_t), hipHostMallocDefault));
+    HIP_OK(hipHostMalloc(&sl.h_tok_off, sizeof(uint32_t) * nctu, hipHostMallocMapped));
+    HIP_OK(hipHostGetDevicePointer(&dp, sl.h_tok_off, 0)); sl.d_tok_off = (uint32_t *)dp;
+    HIP_OK(hipHostMalloc(&sl.h_err, sizeof(uint32_t), hipHostMallocMapped)); *sl.h_err = 0;
+    HIP_OK(hipHostGetDevicePointer(&dp, sl.h_err, 0)); sl.d_err = (uint32_t *)dp;
     HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   }
   HIP_OK(hipEventCreateWithFlags(&in_done_, hipEventDisableTiming));
@@ -87,7 +91,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   uint8_t *p = intra_scratch_;
   f_.ic8 = (uint32_t *)p; p += nb8 * 4; f_.ic16 = (uint32_t *)p; p += nb8; f_.ic32 = (uint32_t *)p; p += nb8 / 4;
   f_.im8 = p; p += nb8; f_.im16 = p; p += nb8 / 4; f_.im32 = p;
-  f_.tok_buf = tok_buf_; f_.tok_cap = tok_cap_; f_.tok_cursor = (uint32_t *)tok_count_; f_.tok_seg = tok_seg_; f_.tok_off = tok_off_;
+  f_.tok_buf = tok_buf_; f_.tok_cap = tok_cap_; f_.tok_cursor = (uint32_t *)tok_count_; f_.tok_seg = tok_seg_; f_.tok_total = tok_total_;
   f_.tok_dense_cap = (uint32_t)tok_dense_cap_;
   f_.sync = sync_; f_.err = err_;
 
@@ -111,6 +115,7 @@ Encoder::~Encoder()
     if (sl.h_tok_dense) hipHostFree(sl.h_tok_dense);
     if (sl.h_tok_count) hipHostFree(sl.h_tok_count);
     if (sl.h_err) hipHostFree(sl.h_err);
+    if (sl.h_tok_off) hipHostFree(sl.h_tok_off);
     if (sl.done) hipEventDestroy(sl.done);
   }
   if (in_done_) hipEventDestroy(in_done_);
@@ -118,7 +123,7 @@ Encoder::~Encoder()
   for (int c = 0; c < 3; c++) { hipFree(src_[c]); for (int b = 0; b < 3; b++) hipFree(rec_[b][c]); hipFree(coef_[c]); }
   hipFree(cu_bytes_); hipFree(cu_mv_); hipFree(cu_mvd_); hipFree(intra_scratch_);
   delete entropy_;
-  hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(tok_off_); hipFree(sync_); hipFree(err_);
+  hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(tok_total_); hipFree(sync_); hipFree(err_);
   if (stream_) hipStreamDestroy(stream_);
 }
 
@@ -178,15 +183,12 @@ bool Encoder::flush(EncodedPicture *out)
 
 bool Encoder::submit(const uint8_t *d_i420, bool)
 {
-  const size_t ny = (size_t)cfg_.width * cfg_.height;
   const int w = cfg_.width, h = cfg_.height;
   Slot &sl = slot_[submitted_ % nslots_];
   cur_slot_ = &sl;
   prof_now_ = profiling_ && (frame_idx_ % prof_every_) == 0;
   timed(K_PAD, [&] {
-    launch_pad_input(d_i420, w, h, src_[0], cw_, ch_, stream_);
-    launch_pad_input(d_i420 + ny, w / 2, h / 2, src_[1], cw_ / 2, ch_ / 2, stream_);
-    launch_pad_input(d_i420 + ny + ny / 4, w / 2, h / 2, src_[2], cw_ / 2, ch_ / 2, stream_);
+    launch_pad_input(d_i420, w, h, src_[0], src_[1], src_[2], cw_, ch_, stream_);
   });
   HIP_CHECK(hipEventRecord(in_done_, stream_)); in_pending_ = true;
   const int period = cfg_.intra_period;
@@ -194,7 +196,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   if (intra) poc_ = 0; else poc_++;
   f_.is_intra = intra; f_.poc = poc_;
   for (int c = 0; c < 3; c++) { f_.rec[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
-  f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count;
+  f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err;
   const EncFrame f = f_;
   if (intra) {
     timed(K_INTRA_ANALYSE, [&] { launch_intra_analyse(f, stream_); });
@@ -208,7 +210,6 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   }
   if (cfg_.deblock) timed(K_DEBLOCK, [&] { launch_deblock(f, stream_); });
   timed(K_TOKENIZE, [&] { launch_tokenize(f, stream_); });
-  HIP_CHECK(hipMemcpyAsync(sl.h_err, err_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
   HIP_CHECK(hipEventRecord(sl.done, stream_));
   sl.poc = poc_; sl.intra = intra; sl.rec_idx = cur_idx_; sl.write_ps = false;
   if (intra) {
@@ -273,7 +274,8 @@ bool Encoder::finish_slot(Slot &sl, EncodedPicture *out)
   const int nsub = cfg_.wpp ? rows_ : 1;
   uint64_t bins = 0;
   Tick tk_ar;
-  entropy_->code_picture(sl.h_tok_dense, sl.h_tok_count, cw_ / 64, rows_, cfg_.wpp != 0, sl.intra ? 0 : 1, cfg_.qp, rows_out_, &bins);
+  for (int i = 0, n = (cw_ / 64) * rows_; i < n; i++) if (sl.h_tok_count[i] < 0) { fprintf(stderr, "kvazzup_amd: token array overflow (CTU %d)\n", i); return false; }
+  entropy_->code_picture(sl.h_tok_dense, sl.h_tok_count, sl.h_tok_off, cw_ / 64, rows_, cfg_.wpp != 0, sl.intra ? 0 : 1, cfg_.qp, rows_out_, &bins);
   const double ar = tk_ar.ms();
   if (profiling_) { std::lock_guard<std::mutex> l(stat_m_); k_ms_[K_HOST_ARITH] += ar; k_n_[K_HOST_ARITH]++; }
   t_arith_ += ar;

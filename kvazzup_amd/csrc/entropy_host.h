@@ -22,19 +22,15 @@ namespace kvzx {
 class EntropyHost {
  public:
   explicit EntropyHost(int max_threads) : pool_(max_threads) { for (int i = 0; i < 64; i++) core_tabs_fill_entry(tabs_, i); }
-  // Codes one picture.  tokens: dense token array, CTU after CTU in raster order; count[ctu] tokens each.
+  // Codes one picture.  tokens: dense token array; CTU i has count[i] tokens starting at offset[i].
   // rows_out[r] receives the bytes of substream r (one per CTU row with WPP, else a single one).
-  void code_picture(const uint16_t *tokens, const int32_t *count, int wc, int hc, bool wpp, int init_type, int qp,
+  void code_picture(const uint16_t *tokens, const int32_t *count, const uint32_t *offset, int wc, int hc, bool wpp, int init_type, int qp,
                     std::vector<std::vector<uint8_t>> &rows_out, uint64_t *bins)
   {
-    tokens_ = tokens; count_ = count; wc_ = wc; hc_ = hc; wpp_ = wpp; init_type_ = init_type; qp_ = qp;
+    tokens_ = tokens; count_ = count; offset_ = offset; wc_ = wc; hc_ = hc; wpp_ = wpp; init_type_ = init_type; qp_ = qp;
     const int nsub = wpp ? hc : 1;
     rows_out.resize((size_t)nsub);
     rows_ = &rows_out;
-    offsets_.resize((size_t)wc * hc + 1);
-    size_t acc = 0;
-    for (int i = 0; i < wc * hc; i++) { offsets_[(size_t)i] = acc; acc += (size_t)count[i]; }
-    offsets_[(size_t)wc * hc] = acc;
     saved_.resize((size_t)hc * CTX_COUNT);
     ready_.reset(new std::atomic<int>[(size_t)hc]);
     for (int r = 0; r < hc; r++) ready_[(size_t)r].store(0, std::memory_order_relaxed);
@@ -50,7 +46,7 @@ class EntropyHost {
     std::vector<uint8_t> &out = (*rows_)[(size_t)r];
     const int first_cy = wpp_ ? r : 0, ncy = wpp_ ? 1 : hc_;
     size_t ntok = 0;
-    for (int cy = first_cy; cy < first_cy + ncy; cy++) ntok += offsets_[(size_t)(cy + 1) * wc_] - offsets_[(size_t)cy * wc_];
+    for (int cy = first_cy; cy < first_cy + ncy; cy++) for (int cx = 0; cx < wc_; cx++) ntok += (size_t)count_[(size_t)cy * wc_ + cx];
     out.resize(ntok * 2 + 64);                    // a token never produces more than two bytes
     CabacEnc c; c.nbins = 0;
     cabac_start(c, out.data(), (int)out.size(), ctx, &tabs_);
@@ -62,7 +58,7 @@ class EntropyHost {
     for (int cy = first_cy; cy < first_cy + ncy; cy++)
       for (int cx = 0; cx < wc_; cx++) {
         const size_t ctu = (size_t)cy * wc_ + cx;
-        cabac_play_tokens(c, tokens_ + offsets_[ctu], count_[ctu]);
+        cabac_play_tokens(c, tokens_ + offset_[ctu], count_[ctu]);
         if (wpp_ && cx == 1) {
           memcpy(&saved_[(size_t)r * CTX_COUNT], ctx, CTX_COUNT);
           ready_[(size_t)r].store(1, std::memory_order_release);
@@ -75,9 +71,8 @@ class EntropyHost {
 
   OrderedPool pool_;
   CoreTabs tabs_;
-  const uint16_t *tokens_ = nullptr; const int32_t *count_ = nullptr;
+  const uint16_t *tokens_ = nullptr; const int32_t *count_ = nullptr; const uint32_t *offset_ = nullptr;
   int wc_ = 0, hc_ = 0, init_type_ = 0, qp_ = 0; bool wpp_ = true;
-  std::vector<size_t> offsets_;
   std::vector<uint8_t> saved_;
   std::unique_ptr<std::atomic<int>[]> ready_;
   std::vector<std::vector<uint8_t>> *rows_ = nullptr;

@@ -40,11 +40,11 @@ struct EncFrame {
   // intra analysis scratch
   uint8_t *im8, *im16, *im32; uint32_t *ic8, *ic16, *ic32;
   // entropy coding, GPU half: per-CTU token slots (tok_cap tokens each) filled by 16 units per CTU
-  // (tok_cursor: tokens used per slot, tok_seg: [ctu][unit] {offset, length}), the exclusive
+  // (tok_cursor: tokens used per slot, tok_seg: [ctu][unit][piece] {offset, length}), the
   // prefix sum of the per-CTU counts and the dense z-ordered copy the host arithmetic coder reads
   // (tok_dense / tok_count_out live in host-mapped pinned memory)
-  uint16_t *tok_buf; int tok_cap; uint32_t *tok_cursor; uint32_t *tok_seg; uint32_t *tok_off;
-  uint16_t *tok_dense; uint32_t tok_dense_cap; int32_t *tok_count_out;
+  uint16_t *tok_buf; int tok_cap; uint32_t *tok_cursor; uint32_t *tok_seg; uint32_t *tok_total;
+  uint16_t *tok_dense; uint32_t tok_dense_cap; int32_t *tok_count_out; uint32_t *tok_off_out; uint32_t *err_out;   // host-mapped pinned
   uint32_t *sync;               // [rows] progress counters (intra reconstruction wavefront)
   uint32_t *err;                // device-side error flags
 };

@@ -615,10 +615,12 @@ struct IntraWaveLds {
   // group, 2n = corner, 4n = end of above-right): [0] as built, [1] filtered (8.4.4.2.3).  Sample i sits at
   // byte 3 + i, which makes the "above" run (2n + 1 ...) dword aligned.  left[k] = R[2n - k], top[k] = R[2n + k].
   alignas(16) uint8_t R[2][144];
+  uint32_t nzflag;                           // workgroups of more than one wave: "the block has non-zero levels"
 };
-// lane layout of one block inside the 64-lane wave
-template <int L2> struct XW {
-  static constexpr int N = 1 << L2, OPL = (L2 == 5) ? 8 : (L2 == 4 ? 2 : 1), G = N / OPL, LANES = (N / 2) * G;
+// thread layout of one block inside a workgroup of T threads (64: one wave, 256: four): OPL outputs per thread so that
+// (n / 2) row pairs x (n / OPL) output groups fit
+template <int L2, int T> struct XW {
+  static constexpr int N = 1 << L2, OPL = (N * N / 2 + T - 1) / T < 1 ? 1 : (N * N / 2 + T - 1) / T, G = N / OPL, LANES = (N / 2) * G;
 };
 
 // Intra sample prediction (8.4.4.2.4-6) from the reference array R (scan order, see IntraWaveLds); the same
@@ -653,13 +655,14 @@ __device__ __forceinline__ int pred_angular(const uint8_t *R, bool vert, bool ed
 
 // One plane of one CU: block of n = 1 << L2 component samples at CTU-relative (rx, ry); (X, Y) = luma position
 // of the CU in the picture.  Returns whether the block has non-zero levels (encoder) / echoes has_levels (decoder).
-template <bool DEC, int L2>
+template <bool DEC, int L2, int T>
 __device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, int cidx, int S, int X, int Y, int rx, int ry,
                                             int mode, int angle, int inv, int qp, bool has_levels, int lane)
 {
-  constexpr int N = XW<L2>::N, OPL = XW<L2>::OPL, G = XW<L2>::G;
+  constexpr int N = XW<L2, T>::N, OPL = XW<L2, T>::OPL, G = XW<L2, T>::G;
   const int sh = cidx ? 1 : 0, nl = N << sh, P = 16 + 2 * S;
   const bool filt = intra_filter_needed(N, cidx, mode);
+  if (T != 64 && lane == 0) s.nzflag = 0;                 // (a barrier follows before anyone sets it)
   // ---- reference samples (8.4.4.2.2) and their filtered version (8.4.4.2.3).  Availability is decided per group
   // of n samples (below-left, left, corner, above, above-right): each group lies in one block of this block's size,
   // which either precedes this block in z-order or does not.  The available groups are contiguous in scan order,
@@ -678,7 +681,7 @@ __device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, 
       c0 = fetch(2 * N); e0 = fetch(0); e1 = fetch(4 * N);
       strong = iabs(c0 + e1 - 2 * fetch(3 * N)) < 8 && iabs(c0 + e0 - 2 * fetch(N)) < 8;
     }
-    for (int i = lane; i <= 4 * N; i += 64) {
+    for (int i = lane; i <= 4 * N; i += T) {
       int v = 128, fv = 128;
       if (hi >= 0) {
         v = fetch(i); fv = v;
@@ -704,7 +707,7 @@ __device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, 
   }
   PROF(4);
   // ---- prediction for the lane's samples: rows 2rp, 2rp + 1, columns g * OPL .. + OPL - 1
-  const bool active = lane < XW<L2>::LANES;
+  const bool active = lane < XW<L2, T>::LANES;
   const int rp = lane / G, g = lane % G;
   const bool edge = cidx == 0 && N < 32;                 // boundary smoothing of DC / pure horizontal / pure vertical
   int pred[2][OPL];
@@ -763,8 +766,10 @@ __device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, 
         *(uint32_t *)&s.lev[(ry + g * OPL + o) * S + rx + 2 * rp] = pack_i16(lv[0], lv[1]);   // level (row j', columns i', i' + 1)
       }
     }
-    cbf = __ballot(nz) != 0;
+    if (T == 64) cbf = __ballot(nz) != 0;
+    else { if (nz) s.nzflag = 1; }
     __syncthreads();
+    if (T != 64) cbf = s.nzflag != 0;
     PROF(7);
   } else if (has_levels) {
     if (active) {
@@ -804,16 +809,16 @@ __device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, 
   return cbf;
 }
 
-template <bool DEC>
-__global__ __launch_bounds__(64) void k_intra_recon(EncFrame f)
+template <bool DEC, int T>
+__global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
 {
   __shared__ IntraWaveLds s;
-  const int lane = threadIdx.x, row = blockIdx.x / 3, c = blockIdx.x % 3, wc = f.cw >> 6;
+  const int lane = threadIdx.x, wl = threadIdx.x & 63, row = blockIdx.x / 3, c = blockIdx.x % 3, wc = f.cw >> 6;
   const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, qp = c ? f.qpc : f.qp, P = 16 + 2 * S;
   uint32_t *my_ctr = f.sync + row * 3 + c;
   const uint32_t *up_ctr = f.sync + (row - 1) * 3 + c;
-  load_matrices(s.M, 0, KV_MATRIX_ENTRIES, lane, 64);
-  int zx, zy; ctu_z_to_xy(lane, zx, zy);                  // this lane's 8x8 luma block of the CTU, in z-order
+  load_matrices(s.M, 0, KV_MATRIX_ENTRIES, lane, T);
+  int zx, zy; ctu_z_to_xy(wl, zx, zy);                    // this lane's 8x8 luma block of the CTU, in z-order (every wave holds all 64)
 #ifdef KVZ_PROF
   if (lane < 16) g_prof[lane] = 0;
   __syncthreads();
@@ -832,15 +837,15 @@ __global__ __launch_bounds__(64) void k_intra_recon(EncFrame f)
     if (cx > 0 && lane < S) s.pic[(lane + 1) * P + 15] = s.pic[(lane + 1) * P + 16 + S - 1];
     // CTU inputs -> LDS (16-byte pieces)
     if (!DEC) {
-      for (int k = lane; k < S * S / 16; k += 64) { int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&s.src[y * S + xq * 16] = *(const uint4 *)&gsrc[(size_t)y * pw + xq * 16]; }
+      for (int k = lane; k < S * S / 16; k += T) { int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&s.src[y * S + xq * 16] = *(const uint4 *)&gsrc[(size_t)y * pw + xq * 16]; }
     } else {
-      for (int k = lane; k < S * S / 8; k += 64) { int y = k / (S / 8), xq = k % (S / 8); *(uint4 *)&s.lev[y * S + xq * 8] = *(const uint4 *)&gcoef[(size_t)y * pw + xq * 8]; }
+      for (int k = lane; k < S * S / 8; k += T) { int y = k / (S / 8), xq = k % (S / 8); *(uint4 *)&s.lev[y * S + xq * 8] = *(const uint4 *)&gcoef[(size_t)y * pw + xq * 8]; }
     }
     PROF(0);
     if (row > 0) {
       wait_progress(up_ctr, (uint32_t)imin(cx + 2, wc), f.err);
       // top border <- last sample row of the CTU row above: corner, above, above-right, clipped to the picture
-      for (int k = lane; k < 2 * S + 1; k += 64) {
+      for (int k = lane; k < 2 * S + 1; k += T) {
         int x = cx * S - 1 + k;
         if (x >= 0 && x < pw) s.pic[15 + k] = f.rec[c][(size_t)(row * S - 1) * pw + x];
       }
@@ -857,19 +862,19 @@ __global__ __launch_bounds__(64) void k_intra_recon(EncFrame f)
       PROF(2);
       bool cbf;
       switch (l2 - sh) {
-        case 2: cbf = intra_block<DEC, 2>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, has, lane); break;
-        case 3: cbf = intra_block<DEC, 3>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, has, lane); break;
-        case 4: cbf = intra_block<DEC, 4>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, has, lane); break;
-        default: cbf = intra_block<DEC, 5>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, has, lane); break;
+        case 2: cbf = intra_block<DEC, 2, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, has, lane); break;
+        case 3: cbf = intra_block<DEC, 3, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, has, lane); break;
+        case 4: cbf = intra_block<DEC, 4, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, has, lane); break;
+        default: cbf = intra_block<DEC, 5, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, has, lane); break;
       }
       const int cnt = 1 << (2 * (l2 - 3));
       if (cbf && lane >= z && lane < z + cnt) my_cbf = 1u << c;
       z += cnt;
     }
     // CTU results -> global memory
-    for (int k = lane; k < S * S / 16; k += 64) { int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&grec[(size_t)y * pw + xq * 16] = *(const uint4 *)&s.pic[(y + 1) * P + 16 + xq * 16]; }
+    for (int k = lane; k < S * S / 16; k += T) { int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&grec[(size_t)y * pw + xq * 16] = *(const uint4 *)&s.pic[(y + 1) * P + 16 + xq * 16]; }
     if (!DEC) {
-      for (int k = lane; k < S * S / 8; k += 64) { int y = k / (S / 8), xq = k % (S / 8); *(uint4 *)&gcoef[(size_t)y * pw + xq * 8] = *(const uint4 *)&s.lev[y * S + xq * 8]; }
+      for (int k = lane; k < S * S / 8; k += T) { int y = k / (S / 8), xq = k % (S / 8); *(uint4 *)&gcoef[(size_t)y * pw + xq * 8] = *(const uint4 *)&s.lev[y * S + xq * 8]; }
       if (my_cbf) atomicOr((uint32_t *)(f.cu_cbf + (bi & ~3)), my_cbf << (8 * (bi & 3)));   // the three planes own one bit each of the byte
     }
     publish_progress(my_ctr, (uint32_t)(cx + 1));
@@ -1222,8 +1227,11 @@ void launch_inter_signal(const EncFrame &f, hipStream_t st)
   hipLaunchKernelGGL(k_inter_signal, dim3((n + 255) / 256), dim3(256), 0, st, f);
 }
 void launch_intra_analyse(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_analyse, dim3(f.cw / 32, f.ch / 32), dim3(256), 0, st, f); }
-void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_recon<false>, dim3(3 * (f.ch / 64)), dim3(64), 0, st, f); }
-void launch_dec_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_recon<true>, dim3(3 * (f.ch / 64)), dim3(64), 0, st, f); }
+#ifndef KVZ_INTRA_THREADS
+#define KVZ_INTRA_THREADS 256
+#endif
+void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL((k_intra_recon<false, KVZ_INTRA_THREADS>), dim3(3 * (f.ch / 64)), dim3(KVZ_INTRA_THREADS), 0, st, f); }
+void launch_dec_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL((k_intra_recon<true, KVZ_INTRA_THREADS>), dim3(3 * (f.ch / 64)), dim3(KVZ_INTRA_THREADS), 0, st, f); }
 void launch_deblock(const EncFrame &f, hipStream_t st)
 {
   int nv = ((f.cw >> 3) - 1) * (f.ch >> 2), nh = (f.cw >> 2) * ((f.ch >> 3) - 1);

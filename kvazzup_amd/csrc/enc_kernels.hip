@@ -843,11 +843,13 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
     }
     PROF(0);
     if (row > 0) {
-      wait_progress(up_ctr, (uint32_t)imin(cx + 2, wc), f.err);
-      // top border <- last sample row of the CTU row above: corner, above, above-right, clipped to the picture
-      for (int k = lane; k < 2 * S + 1; k += T) {
+      // The CTU above must be finished before this one starts; the CTU above-right only before the block in the top
+      // right corner of this CTU (the only one whose above-right references reach into it) -- waited for there,
+      // which shortens the lag between CTU rows from two CTUs to about one and a half.
+      wait_progress(up_ctr, (uint32_t)(cx + 1), f.err);
+      for (int k = lane; k < S + 1; k += T) {              // corner + the S samples above
         int x = cx * S - 1 + k;
-        if (x >= 0 && x < pw) s.pic[15 + k] = f.rec[c][(size_t)(row * S - 1) * pw + x];
+        if (x >= 0) s.pic[15 + k] = f.rec[c][(size_t)(row * S - 1) * pw + x];
       }
     }
     __syncthreads();
@@ -859,6 +861,11 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
       int xi, yi; ctu_z_to_xy(z, xi, yi);
       const int X = cx * 64 + xi * 8, Y = row * 64 + yi * 8, rx = (xi * 8) >> sh, ry = (yi * 8) >> sh;
       const bool has = DEC && ((given >> c) & 1);
+      if (row > 0 && cx + 1 < wc && ry == 0 && rx + (1 << (l2 - sh)) == S) {       // wave-uniform: the top-right block
+        wait_progress(up_ctr, (uint32_t)(cx + 2), f.err);
+        for (int k = lane; k < S; k += T) s.pic[15 + S + 1 + k] = f.rec[c][(size_t)(row * S - 1) * pw + (cx + 1) * S + k];
+        __syncthreads();
+      }
       PROF(2);
       bool cbf;
       switch (l2 - sh) {

@@ -75,7 +75,7 @@ class Encoder {
   struct Slot;
   bool finish_slot(Slot &sl, EncodedPicture *out);   // wait for the slot's kernels, arithmetic coding, access unit
   void background();
-  void timed(KernelId id, const std::function<void()> &launch);
+  void timed(KernelId id, hipStream_t st, const std::function<void()> &launch);
 
   EncoderConfig cfg_;
   int cw_ = 0, ch_ = 0, rows_ = 0;
@@ -87,9 +87,15 @@ class Encoder {
   // reconstruction ring: the picture being coded, its reference, and (owf >= 2) the one still waiting to be output
   uint8_t *rec_[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   int cur_idx_ = 0, ref_idx_ = 2, out_idx_ = 2;
-  int16_t *coef_[3] = {nullptr, nullptr, nullptr};
-  uint8_t *cu_bytes_ = nullptr;          // 7 byte arrays back to back
-  int16_t *cu_mv_ = nullptr, *cu_mvd_ = nullptr;
+  // Two sets of everything the tokenizer reads (levels and CU records): picture t is tokenised on the second stream
+  // from set t & 1 while the kernels of picture t + 1 fill the other one.
+  int16_t *coef_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  uint8_t *cu_bytes_[2] = {nullptr, nullptr};          // 7 byte arrays back to back
+  int16_t *cu_mv_[2] = {nullptr, nullptr}, *cu_mvd_[2] = {nullptr, nullptr};
+  int set_ = 0, out_set_ = 0;
+  hipStream_t stream_tok_ = nullptr;     // tokenizer + compaction
+  hipEvent_t ev_signalled_ = nullptr, ev_tok_done_[2] = {nullptr, nullptr}; bool tok_pending_[2] = {false, false};
+  void bind_set(int k);
   uint8_t *intra_scratch_ = nullptr;
   uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; uint32_t *tok_total_ = nullptr;
   size_t tok_dense_cap_ = 0;
@@ -100,8 +106,8 @@ class Encoder {
     uint16_t *h_tok_dense = nullptr, *d_tok_dense = nullptr; int32_t *h_tok_count = nullptr, *d_tok_count = nullptr;   // host-mapped pinned
     uint32_t *h_tok_off = nullptr, *d_tok_off = nullptr;
     uint32_t *h_err = nullptr, *d_err = nullptr;
-    hipEvent_t done = nullptr;
-    int poc = 0, rec_idx = 0; bool intra = false, write_ps = false;
+    hipEvent_t done = nullptr, rec_done = nullptr;       // tokens delivered (stream_tok_) / reconstruction final (stream_)
+    int poc = 0, rec_idx = 0, set = 0; bool intra = false, write_ps = false;
     std::vector<EvPair> ev; size_t ev_used = 0;
     EncodedPicture result; bool ready = false, ok = true;   // owf >= 2: filled by the background thread
   };

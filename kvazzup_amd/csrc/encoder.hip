@@ -42,12 +42,16 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
     size_t n = c ? npx / 4 : npx;
     HIP_OK(hipMalloc(&src_[c], n));
     for (int b = 0; b < 3; b++) { HIP_OK(hipMalloc(&rec_[b][c], n)); HIP_OK(hipMemset(rec_[b][c], 0, n)); }
-    HIP_OK(hipMalloc(&coef_[c], n * sizeof(int16_t)));
-    HIP_OK(hipMemset(coef_[c], 0, n * sizeof(int16_t)));
+    for (int k = 0; k < 2; k++) { HIP_OK(hipMalloc(&coef_[k][c], n * sizeof(int16_t))); HIP_OK(hipMemset(coef_[k][c], 0, n * sizeof(int16_t))); }
   }
-  HIP_OK(hipMalloc(&cu_bytes_, nb8 * 7)); HIP_OK(hipMemset(cu_bytes_, 0, nb8 * 7));
-  HIP_OK(hipMalloc(&cu_mv_, nb8 * 2 * sizeof(int16_t))); HIP_OK(hipMemset(cu_mv_, 0, nb8 * 2 * sizeof(int16_t)));
-  HIP_OK(hipMalloc(&cu_mvd_, nb8 * 2 * sizeof(int16_t))); HIP_OK(hipMemset(cu_mvd_, 0, nb8 * 2 * sizeof(int16_t)));
+  for (int k = 0; k < 2; k++) {
+    HIP_OK(hipMalloc(&cu_bytes_[k], nb8 * 7)); HIP_OK(hipMemset(cu_bytes_[k], 0, nb8 * 7));
+    HIP_OK(hipMalloc(&cu_mv_[k], nb8 * 2 * sizeof(int16_t))); HIP_OK(hipMemset(cu_mv_[k], 0, nb8 * 2 * sizeof(int16_t)));
+    HIP_OK(hipMalloc(&cu_mvd_[k], nb8 * 2 * sizeof(int16_t))); HIP_OK(hipMemset(cu_mvd_[k], 0, nb8 * 2 * sizeof(int16_t)));
+    HIP_OK(hipEventCreateWithFlags(&ev_tok_done_[k], hipEventDisableTiming));
+  }
+  HIP_OK(hipStreamCreateWithFlags(&stream_tok_, hipStreamNonBlocking));
+  HIP_OK(hipEventCreateWithFlags(&ev_signalled_, hipEventDisableTiming));
   // intra scratch: ic8 (nb8 u32) | ic16 (nb8/4 u32) | ic32 (nb8/16 u32) | im8 | im16 | im32
   size_t isz = nb8 * 4 + nb8 + nb8 / 4 + nb8 + nb8 / 4 + nb8 / 16 + 64;
   HIP_OK(hipMalloc(&intra_scratch_, isz));
@@ -74,6 +78,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
     HIP_OK(hipHostMalloc(&sl.h_err, sizeof(uint32_t), hipHostMallocMapped)); *sl.h_err = 0;
     HIP_OK(hipHostGetDevicePointer(&dp, sl.h_err, 0)); sl.d_err = (uint32_t *)dp;
     HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&sl.rec_done, hipEventDisableTiming));
   }
   HIP_OK(hipEventCreateWithFlags(&in_done_, hipEventDisableTiming));
   HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * rows_ * 3));       // one progress counter per CTU row and colour plane
@@ -84,10 +89,8 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   f_.cw = cw_; f_.ch = ch_; f_.b8w = cw_ / 8; f_.b8h = ch_ / 8;
   f_.qp = cfg.qp; f_.qpc = kChromaQp[cfg.qp]; f_.lambda_q4 = kLambdaQ4[cfg.qp]; f_.range = cfg.me_range;
   f_.wpp = cfg.wpp;
-  for (int c = 0; c < 3; c++) { f_.src[c] = src_[c]; f_.coef[c] = coef_[c]; }
-  f_.cu_log2 = cu_bytes_; f_.cu_intra = cu_bytes_ + nb8; f_.cu_flags = cu_bytes_ + 2 * nb8; f_.cu_merge_idx = cu_bytes_ + 3 * nb8;
-  f_.cu_mvp_idx = cu_bytes_ + 4 * nb8; f_.cu_intra_mode = cu_bytes_ + 5 * nb8; f_.cu_cbf = cu_bytes_ + 6 * nb8;
-  f_.cu_mv = cu_mv_; f_.cu_mvd = cu_mvd_;
+  for (int c = 0; c < 3; c++) f_.src[c] = src_[c];
+  bind_set(0);
   uint8_t *p = intra_scratch_;
   f_.ic8 = (uint32_t *)p; p += nb8 * 4; f_.ic16 = (uint32_t *)p; p += nb8; f_.ic32 = (uint32_t *)p; p += nb8 / 4;
   f_.im8 = p; p += nb8; f_.im16 = p; p += nb8 / 4; f_.im32 = p;
@@ -105,11 +108,22 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
 
 namespace { struct Tick { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } }; }
 
+void Encoder::bind_set(int k)
+{
+  const size_t nb8 = (size_t)cw_ * ch_ / 64;
+  uint8_t *cu = cu_bytes_[k];
+  for (int c = 0; c < 3; c++) f_.coef[c] = coef_[k][c];
+  f_.cu_log2 = cu; f_.cu_intra = cu + nb8; f_.cu_flags = cu + 2 * nb8; f_.cu_merge_idx = cu + 3 * nb8;
+  f_.cu_mvp_idx = cu + 4 * nb8; f_.cu_intra_mode = cu + 5 * nb8; f_.cu_cbf = cu + 6 * nb8;
+  f_.cu_mv = cu_mv_[k]; f_.cu_mvd = cu_mvd_[k];
+}
+
 Encoder::~Encoder()
 {
   if (getenv("KVAZZUP_AMD_TRACE")) fprintf(stderr, "kvazzup_amd encoder thread ms: submit %.1f  wait_gpu %.1f  arith %.1f  assemble %.1f  wait_input %.1f  (pictures %ld)\n", t_submit_, t_wait_, t_arith_, t_asm_, t_in_, collected_);
   if (bg_.joinable()) { { std::lock_guard<std::mutex> l(bm_); bquit_ = true; } bcv_.notify_all(); bg_.join(); }
   if (stream_) hipStreamSynchronize(stream_);
+  if (stream_tok_) hipStreamSynchronize(stream_tok_);
   for (Slot &sl : slot_) {
     for (auto &e : sl.ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     if (sl.h_tok_dense) hipHostFree(sl.h_tok_dense);
@@ -117,17 +131,21 @@ Encoder::~Encoder()
     if (sl.h_err) hipHostFree(sl.h_err);
     if (sl.h_tok_off) hipHostFree(sl.h_tok_off);
     if (sl.done) hipEventDestroy(sl.done);
+    if (sl.rec_done) hipEventDestroy(sl.rec_done);
   }
   if (in_done_) hipEventDestroy(in_done_);
   hipFree(d_in_); hipHostFree(h_in_);
-  for (int c = 0; c < 3; c++) { hipFree(src_[c]); for (int b = 0; b < 3; b++) hipFree(rec_[b][c]); hipFree(coef_[c]); }
-  hipFree(cu_bytes_); hipFree(cu_mv_); hipFree(cu_mvd_); hipFree(intra_scratch_);
+  for (int c = 0; c < 3; c++) { hipFree(src_[c]); for (int b = 0; b < 3; b++) hipFree(rec_[b][c]); hipFree(coef_[0][c]); hipFree(coef_[1][c]); }
+  for (int k = 0; k < 2; k++) { hipFree(cu_bytes_[k]); hipFree(cu_mv_[k]); hipFree(cu_mvd_[k]); if (ev_tok_done_[k]) hipEventDestroy(ev_tok_done_[k]); }
+  if (ev_signalled_) hipEventDestroy(ev_signalled_);
+  if (stream_tok_) hipStreamDestroy(stream_tok_);
+  hipFree(intra_scratch_);
   delete entropy_;
   hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(tok_total_); hipFree(sync_); hipFree(err_);
   if (stream_) hipStreamDestroy(stream_);
 }
 
-void Encoder::timed(KernelId id, const std::function<void()> &launch)
+void Encoder::timed(KernelId id, hipStream_t st, const std::function<void()> &launch)
 {
   if (!prof_now_) { launch(); return; }
   Slot &sl = *cur_slot_;
@@ -135,9 +153,9 @@ void Encoder::timed(KernelId id, const std::function<void()> &launch)
     EvPair p; hipEventCreate(&p.a); hipEventCreate(&p.b); p.id = id; sl.ev.push_back(p);
   }
   EvPair &p = sl.ev[sl.ev_used++]; p.id = id;
-  hipEventRecord(p.a, stream_);
+  hipEventRecord(p.a, st);
   launch();
-  hipEventRecord(p.b, stream_);
+  hipEventRecord(p.b, st);
 }
 
 void Encoder::get_kernel_times(double *ms, uint64_t *launches, bool reset)
@@ -187,9 +205,13 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   Slot &sl = slot_[submitted_ % nslots_];
   cur_slot_ = &sl;
   prof_now_ = profiling_ && (frame_idx_ % prof_every_) == 0;
-  timed(K_PAD, [&] {
-    launch_pad_input(d_i420, w, h, src_[0], src_[1], src_[2], cw_, ch_, stream_);
-  });
+  // Two HIP streams per picture t.  stream_: input padding, decisions, reconstruction, deblocking -- the chain picture t + 1
+  // depends on.  stream_tok_: tokenizer + compaction, which only feed the host; they read set t & 1 of the level / CU
+  // arrays while stream_ already fills the other set for t + 1.
+  set_ = (int)(submitted_ & 1);
+  bind_set(set_);
+  if (tok_pending_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_, ev_tok_done_[set_], 0)); tok_pending_[set_] = false; }   // tokenizer of t - 2 done with this set
+  timed(K_PAD, stream_, [&] { launch_pad_input(d_i420, w, h, src_[0], src_[1], src_[2], cw_, ch_, stream_); });
   HIP_CHECK(hipEventRecord(in_done_, stream_)); in_pending_ = true;
   const int period = cfg_.intra_period;
   const bool intra = (frame_idx_ == 0) || (period > 0 && (frame_idx_ % period) == 0);
@@ -199,19 +221,24 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err;
   const EncFrame f = f_;
   if (intra) {
-    timed(K_INTRA_ANALYSE, [&] { launch_intra_analyse(f, stream_); });
+    timed(K_INTRA_ANALYSE, stream_, [&] { launch_intra_analyse(f, stream_); });
     HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * rows_ * 3, stream_));
     HIP_CHECK(hipMemsetAsync(f_.cu_cbf, 0, (size_t)f_.b8w * f_.b8h, stream_));     // the three plane waves OR their bit in
-    timed(K_INTRA_RECON, [&] { launch_intra_recon(f, stream_); });
+    timed(K_INTRA_RECON, stream_, [&] { launch_intra_recon(f, stream_); });
   } else {
-    timed(K_ME, [&] { launch_me(f, stream_); });
-    timed(K_INTER_RECON, [&] { launch_inter_recon(f, stream_); });
-    timed(K_INTER_SIGNAL, [&] { launch_inter_signal(f, stream_); });
+    timed(K_ME, stream_, [&] { launch_me(f, stream_); });
+    timed(K_INTER_RECON, stream_, [&] { launch_inter_recon(f, stream_); });
+    timed(K_INTER_SIGNAL, stream_, [&] { launch_inter_signal(f, stream_); });
   }
-  if (cfg_.deblock) timed(K_DEBLOCK, [&] { launch_deblock(f, stream_); });
-  timed(K_TOKENIZE, [&] { launch_tokenize(f, stream_); });
-  HIP_CHECK(hipEventRecord(sl.done, stream_));
-  sl.poc = poc_; sl.intra = intra; sl.rec_idx = cur_idx_; sl.write_ps = false;
+  HIP_CHECK(hipEventRecord(ev_signalled_, stream_));             // levels and CU records of the picture are final
+  if (cfg_.deblock) timed(K_DEBLOCK, stream_, [&] { launch_deblock(f, stream_); });
+  HIP_CHECK(hipStreamWaitEvent(stream_tok_, ev_signalled_, 0));
+  timed(K_TOKENIZE, stream_tok_, [&] { launch_tokenize(f, stream_tok_); });
+  HIP_CHECK(hipEventRecord(ev_tok_done_[set_], stream_tok_)); tok_pending_[set_] = true;
+  // the slot is complete when both streams are: the tokens (stream_tok_) and the reconstruction (stream_)
+  HIP_CHECK(hipEventRecord(sl.done, stream_tok_));
+  HIP_CHECK(hipEventRecord(sl.rec_done, stream_));
+  sl.poc = poc_; sl.intra = intra; sl.rec_idx = cur_idx_; sl.set = set_; sl.write_ps = false;
   if (intra) {
     sl.write_ps = (intra_count_ == 0) || (cfg_.vps_period > 0 && (intra_count_ % cfg_.vps_period) == 0);
     intra_count_++;
@@ -239,7 +266,7 @@ bool Encoder::collect(EncodedPicture *out)
     ok = sl.ok;
     std::swap(*out, sl.result);
   } else ok = finish_slot(sl, out);
-  out_idx_ = sl.rec_idx;
+  out_idx_ = sl.rec_idx; out_set_ = sl.set;
   return ok;
 }
 
@@ -260,7 +287,7 @@ void Encoder::background()
 bool Encoder::finish_slot(Slot &sl, EncodedPicture *out)
 {
   out->valid = false; out->au.clear();
-  { Tick tk; HIP_CHECK(hipEventSynchronize(sl.done)); if (depth_ < 2) t_wait_ += tk.ms(); }
+  { Tick tk; HIP_CHECK(hipEventSynchronize(sl.done)); HIP_CHECK(hipEventSynchronize(sl.rec_done)); if (depth_ < 2) t_wait_ += tk.ms(); }
   if (*sl.h_err) { fprintf(stderr, "kvazzup_amd: device error flags 0x%x (8/16/32: token buffer overflow)\n", *sl.h_err); return false; }
   if (sl.ev_used) {
     std::lock_guard<std::mutex> l(stat_m_);
@@ -302,12 +329,12 @@ bool Encoder::debug_copy(const char *what, void *dst, size_t bytes)
   const void *src = nullptr; size_t have = 0;
   std::string w(what);
   static const char *names[7] = {"cu_log2", "cu_intra", "cu_flags", "cu_merge_idx", "cu_mvp_idx", "cu_intra_mode", "cu_cbf"};
-  for (int i = 0; i < 7; i++) if (w == names[i]) { src = cu_bytes_ + i * nb8; have = nb8; }
-  if (w == "cu_mv") { src = cu_mv_; have = nb8 * 4; }
-  if (w == "cu_mvd") { src = cu_mvd_; have = nb8 * 4; }
+  for (int i = 0; i < 7; i++) if (w == names[i]) { src = cu_bytes_[out_set_] + i * nb8; have = nb8; }
+  if (w == "cu_mv") { src = cu_mv_[out_set_]; have = nb8 * 4; }
+  if (w == "cu_mvd") { src = cu_mvd_[out_set_]; have = nb8 * 4; }
   for (int c = 0; c < 3; c++) {
     size_t n = c ? npx / 4 : npx;
-    if (w == std::string("coef") + char('0' + c)) { src = coef_[c]; have = n * 2; }
+    if (w == std::string("coef") + char('0' + c)) { src = coef_[out_set_][c]; have = n * 2; }
     if (w == std::string("rec") + char('0' + c)) { src = rec_[out_idx_][c]; have = n; }
     if (w == std::string("src") + char('0' + c)) { src = src_[c]; have = n; }
   }

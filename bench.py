@@ -199,6 +199,15 @@ def main():
         avg_s = kt[dom][0] / kt[dom][1] / 1e3
         ab = algorithmic_bytes(dom, cw, ch, args.me_range)
         achieved = ab / avg_s / 1e9
+        # HBM traffic per launch: from the committed PMC passes of this same command (rocprofv3 --pmc cannot run inside
+        # the bench); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  null when no pass exists.
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.workload)))
+            traffic = pmc["kernels"][dom]["traffic_bytes"]
+            traffic_src = "profiles/r01_pmc_traffic_%s.json" % args.workload
+        except Exception:
+            pass
         out = {
             "metric": "hevc_encode_decode_fps", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -210,7 +219,7 @@ def main():
                        "streams": world, "bytes_per_frame": round(nbytes / args.steps, 1), "decoder_frame_threads": D, "owf": args.owf,
                        "input": "I420 resident in HBM", "output": "Annex-B AU on host + decoded I420 in HBM"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(avg_s * 1e6, 2)},
             "kernels_us": {k: round(v[0] / v[1] * 1e3, 2) for k, v in kt.items() if v[1]},
             "filter_busy_ms_per_step": {"KvazaarFilter": busy[0], "WireAdapter": busy[1], "OpenHEVCFilter": busy[2]},

@@ -58,6 +58,19 @@ KVZ_PUBLIC int kvzx_decoder_kernel_times(OpenHevc_Handle h, double *ms, uint64_t
 KVZ_PUBLIC const char *kvzx_decoder_kernel_name(int id);
 KVZ_PUBLIC int kvzx_decoder_debug_copy(OpenHevc_Handle h, const char *what, void *dst, size_t bytes);
 
+/* ---- row f1: I420 -> RGB32, the conversion uvgComm runs on every decoded picture before display
+ * (YUVtoRGB32::process, src/media/processing/yuvtorgb32.cpp:29-64 -> yuv420_to_rgb_i_{avx2_mt,avx2,sse41,c},
+ * src/media/processing/yuvconversions.cpp:72-493).  The reference has two arithmetics; `variant` picks:
+ *   0 = what the filter picks on an AVX2/SSE4.1 host: the SIMD arithmetic when width % 16 == 0, else the scalar one
+ *   1 = yuv420_to_rgb_i_c (every fourth output byte left as found), 2 = the SIMD converters (fourth byte 0; width % 8 == 0)
+ * Planes and output in device memory; returns 1 when the kernel was launched on `hip_stream`. */
+KVZ_PUBLIC int kvzx_yuv420_to_rgb32_device(const void *d_y, const void *d_u, const void *d_v, int y_pitch, int c_pitch, void *d_rgb32,
+                                            int width, int height, int variant, void *hip_stream);
+/* host buffers in and out, like yuv420_to_rgb_i_*(input, output, width, height): upload, convert, download */
+KVZ_PUBLIC int kvzx_yuv420_to_rgb32(const uint8_t *i420, uint8_t *rgb32, int width, int height, int variant);
+/* the picture returned by the last libOpenHevcGetOutput, converted where it lies in HBM (no host copy); synchronous */
+KVZ_PUBLIC int kvzx_decoder_output_rgb32_device(OpenHevc_Handle h, void *d_rgb32, int variant);
+
 /* ---- filter-graph harness (kvazzup_amd/csrc/filters.h): KvazaarFilter -> [WireAdapter -> OpenHEVCFilter] ----
  * A Qt-free restatement of the two uvgComm filters on this path, each on its own thread with the
  * reference's input-buffer contract (src/media/processing/filter.cpp:151-222,364-417), driven through the

@@ -50,6 +50,7 @@ struct Data {
   std::unique_ptr<VideoInfo> vInfo;
   // extension (not in the reference): picture already resident in HBM (packed I420); data stays empty
   const void *device_data = nullptr;
+  const void *device_planes[3] = {nullptr, nullptr, nullptr}; int device_pitch[3] = {0, 0, 0};   // decoded I420 left in HBM
 };
 
 // Counterpart of StatisticsInterface (src/statisticsinterface.h:40,52,59): only what the two filters report
@@ -166,6 +167,19 @@ class OpenHEVCFilter : public Filter {
   std::mutex settingsMutex_;
   uint32_t discardedFrames_ = 0;
   bool download_ = true;
+};
+
+// Row f1: the conversion filter the graph inserts after the decoder (yuvtorgb32.cpp:29-64).  Host pictures go through
+// kvzx_yuv420_to_rgb32; pictures the decoder left in HBM are converted there into a small ring of device buffers.
+class YUVtoRGB32 : public Filter {
+ public:
+  YUVtoRGB32(std::string id, Stats *stats) : Filter(std::move(id), "YUVtoRGB32", stats, DT_YUV420VIDEO, DT_RGB32VIDEO) {}
+  ~YUVtoRGB32() override;
+ protected:
+  void process() override;
+ private:
+  static const int kRing = 4;
+  void *ring_[kRing] = {nullptr, nullptr, nullptr, nullptr}; size_t ring_bytes_ = 0; int next_ = 0;
 };
 
 // Row f2: what uvgRTP does between the two filters in a loop-back: the sender pushes the whole access

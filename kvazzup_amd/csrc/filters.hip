@@ -3,6 +3,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <hip/hip_runtime.h>
 #include "filters.h"
 
 namespace uvgx {
@@ -89,6 +90,7 @@ Data *Filter::deepDataCopy(const Data *o)
   c->source = o->source; c->type = o->type; c->data_size = o->data_size;
   c->creationTimestamp = o->creationTimestamp; c->presentationTimestamp = o->presentationTimestamp;
   c->device_data = o->device_data;
+  for (int i = 0; i < 3; i++) { c->device_planes[i] = o->device_planes[i]; c->device_pitch[i] = o->device_pitch[i]; }
   if (o->data) { c->data.reset(new uint8_t[o->data_size]); memcpy(c->data.get(), o->data.get(), o->data_size); }
   if (o->vInfo) {
     c->vInfo.reset(new VideoInfo);
@@ -434,6 +436,7 @@ void OpenHEVCFilter::sendDecodedOutput(int &gotPicture)    // openhevcfilter.cpp
       const void *planes[3]; int pitches[3];
       kvzx_decoder_output_device(handle_, planes, pitches);
       decodedFrame->device_data = planes[0];
+      for (int i = 0; i < 3; i++) { decodedFrame->device_planes[i] = planes[i]; decodedFrame->device_pitch[i] = pitches[i]; }
       decodedFrame->data.reset();
       decodedFrame->data_size = 0;
       sendOutput(std::move(decodedFrame));
@@ -482,17 +485,56 @@ void WireAdapter::process()
   }
 }
 
+// ----------------------------------------------------------------------------------------------- YUVtoRGB32
+YUVtoRGB32::~YUVtoRGB32() { stop(); for (void *p : ring_) if (p) hipFree(p); }
+
+void YUVtoRGB32::process()                                  // yuvtorgb32.cpp:29-64
+{
+  std::unique_ptr<Data> input = getInput();
+  while (input) {
+    const int W = input->vInfo->width, H = input->vInfo->height;
+    const uint32_t finalDataSize = (uint32_t)(W * H * 4);
+    if (input->device_planes[0]) {
+      // the decoder left the picture in HBM: convert it there
+      if (ring_bytes_ != finalDataSize) {
+        for (void *&p : ring_) { if (p) hipFree(p); p = nullptr; }
+        ring_bytes_ = finalDataSize;
+      }
+      void *&dst = ring_[next_]; next_ = (next_ + 1) % kRing;
+      if (!dst && hipMalloc(&dst, ring_bytes_) != hipSuccess) { dst = nullptr; input = getInput(); continue; }
+      if (!kvzx_yuv420_to_rgb32_device(input->device_planes[0], input->device_planes[1], input->device_planes[2], input->device_pitch[0],
+                                       input->device_pitch[1], dst, W, H, 0, nullptr) || hipStreamSynchronize(nullptr) != hipSuccess) {
+        fprintf(stderr, "YUVtoRGB32: conversion failed\n");
+        input = getInput();
+        continue;
+      }
+      input->device_data = dst;
+      for (int i = 0; i < 3; i++) { input->device_planes[i] = nullptr; input->device_pitch[i] = 0; }
+      input->data.reset(); input->data_size = 0;
+    } else {
+      std::unique_ptr<uint8_t[]> rgb32_frame(new uint8_t[finalDataSize]);
+      if (!kvzx_yuv420_to_rgb32(input->data.get(), rgb32_frame.get(), W, H, 0)) { fprintf(stderr, "YUVtoRGB32: conversion failed\n"); input = getInput(); continue; }
+      input->data = std::move(rgb32_frame);
+      input->data_size = finalDataSize;
+    }
+    input->type = DT_RGB32VIDEO;
+    sendOutput(std::move(input));
+    input = getInput();
+  }
+}
+
 }  // namespace uvgx
 
-// ----------------------------------------------------------------------------------------------- C shim for tests / bench
 using namespace uvgx;
 
+// ----------------------------------------------------------------------------------------------- C shim for tests / bench
 struct UvgxPipeline {
   Settings settings;
   Stats stats;
   std::unique_ptr<KvazaarFilter> enc;
   std::unique_ptr<WireAdapter> wire;
   std::unique_ptr<OpenHEVCFilter> dec;
+  std::unique_ptr<YUVtoRGB32> rgb;                         // settings uvgx/rgb32Output=1: the display-side conversion
   std::mutex m; std::condition_variable cv;
   std::deque<std::unique_ptr<Data>> encoded, decoded;
   uint64_t n_encoded = 0, n_decoded = 0, decoded_bytes = 0;
@@ -528,7 +570,14 @@ KVZ_PUBLIC void *uvgx_pipeline_create(const char *settings_text, int loopback_de
     if (!p->dec->init()) { delete p; return nullptr; }
     p->enc->addOutConnection(p->wire.get());
     p->wire->addOutConnection(p->dec.get());
-    p->dec->addDataOutCallback([p](std::unique_ptr<Data> d) {
+    Filter *last = p->dec.get();
+    auto it = p->settings.find("uvgx/rgb32Output");
+    if (it != p->settings.end() && atoi(it->second.c_str()) != 0) {
+      p->rgb.reset(new YUVtoRGB32("uvgx", &p->stats));
+      p->dec->addOutConnection(p->rgb.get());
+      last = p->rgb.get();
+    }
+    last->addDataOutCallback([p](std::unique_ptr<Data> d) {
       std::lock_guard<std::mutex> l(p->m);
       p->n_decoded++; p->decoded_bytes += d->data_size;
       if (p->keep) p->decoded.push_back(std::move(d));
@@ -536,6 +585,7 @@ KVZ_PUBLIC void *uvgx_pipeline_create(const char *settings_text, int loopback_de
     });
     p->wire->start();
     p->dec->start();
+    if (p->rgb) p->rgb->start();
   }
   p->enc->start();
   return p;
@@ -605,6 +655,7 @@ KVZ_PUBLIC void uvgx_pipeline_destroy(void *pp)
   p->enc->stop();
   if (p->wire) p->wire->stop();
   if (p->dec) p->dec->stop();
+  if (p->rgb) p->rgb->stop();
   delete p;
 }
 

@@ -125,6 +125,14 @@ int kvzx_decoder_output_device(OpenHevc_Handle hh, const void **planes, int *pit
   for (int c = 0; c < 3; c++) { if (planes) planes[c] = h->pic.dev[c]; if (pitches) pitches[c] = h->pic.dev_pitch[c]; }
   return 1;
 }
+int kvzx_decoder_output_rgb32_device(OpenHevc_Handle hh, void *d_rgb32, int variant)
+{
+  Handle *h = H(hh);
+  if (!h || !h->have_pic || !d_rgb32) return 0;
+  const DecodedPicture &p = h->pic;
+  if (!kvzx_yuv420_to_rgb32_device(p.dev[0], p.dev[1], p.dev[2], p.dev_pitch[0], p.dev_pitch[1], d_rgb32, p.width, p.height, variant, nullptr)) return 0;
+  return hipStreamSynchronize(nullptr) == hipSuccess ? 1 : 0;
+}
 void kvzx_decoder_set_download(OpenHevc_Handle hh, int on) { Handle *h = H(hh); if (h) h->dec->set_download(on != 0); }
 void kvzx_decoder_set_profiling(OpenHevc_Handle hh, int every) { Handle *h = H(hh); if (h) h->dec->set_profiling(every); }
 int kvzx_decoder_kernel_times(OpenHevc_Handle hh, double *ms, uint64_t *launches, int reset)

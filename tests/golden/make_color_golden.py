@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/color_i420_to_rgb32.npz: inputs and the outputs of the REFERENCE's converters
+(oracle/_ref/libyuvconversions_ref.so, built by __graft_entry__.build() from
+/root/reference/src/media/processing/yuvconversions.cpp) for small pictures.  Run in the build container."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import refcolor
+
+cases = {}
+for name, (w, h, variant) in {"simd_64x32": (64, 32, "avx2_mt"), "simd_48x16": (48, 16, "sse41"), "c_34x18": (34, 18, "c"), "c_64x32": (64, 32, "c")}.items():
+    src = refcolor.random_i420(0xC0101 + w + h, w, h)
+    cases[name + "_in"] = src
+    cases[name + "_out"] = refcolor.reference(variant, src, w, h)
+    cases[name + "_dims"] = np.array([w, h], dtype=np.int32)
+np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "color_i420_to_rgb32.npz"), **cases)
+print("wrote", len(cases) // 3, "cases")

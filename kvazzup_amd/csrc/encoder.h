@@ -28,6 +28,7 @@ struct EncoderConfig {
   int wpp = 1, deblock = 1;
   int device = 0;
   int entropy_threads = 16;   // host threads of the arithmetic-coding stage
+  int bitrate = 0;            // bits per second; 0 = constant QP, > 0 = "uvgx rate control v1" (oracle/hevc_enc.c rate_control())
   int owf = 0;                // kvazaar "owf": 0 = encode() returns its own picture; 1 = output lags one picture and the host
                               // coding of picture t overlaps the kernels of t + 1; >= 2 = output lags two pictures and the host
                               // coding runs on a background thread, so the calling thread only launches kernels
@@ -36,7 +37,7 @@ struct EncoderConfig {
 struct EncodedPicture {
   bool valid = false;         // false: nothing was output by this call (pipeline filling, owf >= 1)
   std::vector<uint8_t> au;
-  int poc = 0; bool is_intra = false;
+  int poc = 0, qp = 0; bool is_intra = false;
   uint64_t bins = 0;
 };
 
@@ -93,6 +94,8 @@ class Encoder {
   uint8_t *cu_bytes_[2] = {nullptr, nullptr};          // 7 byte arrays back to back
   int16_t *cu_mv_[2] = {nullptr, nullptr}, *cu_mvd_[2] = {nullptr, nullptr};
   int set_ = 0, out_set_ = 0;
+  int qp_cur_ = 0; int64_t rc_debt_ = 0; uint32_t rc_bytes_[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rate control state (calling thread)
+  void rate_control();
   hipStream_t stream_tok_ = nullptr;     // tokenizer + compaction
   hipEvent_t ev_signalled_ = nullptr, ev_tok_done_[2] = {nullptr, nullptr}; bool tok_pending_[2] = {false, false};
   void bind_set(int k);
@@ -107,7 +110,7 @@ class Encoder {
     uint32_t *h_tok_off = nullptr, *d_tok_off = nullptr;
     uint32_t *h_err = nullptr, *d_err = nullptr;
     hipEvent_t done = nullptr, rec_done = nullptr;       // tokens delivered (stream_tok_) / reconstruction final (stream_)
-    int poc = 0, rec_idx = 0, set = 0; bool intra = false, write_ps = false;
+    int poc = 0, rec_idx = 0, set = 0, qp = 0; bool intra = false, write_ps = false;
     std::vector<EvPair> ev; size_t ev_used = 0;
     EncodedPicture result; bool ready = false, ok = true;   // owf >= 2: filled by the background thread
   };

@@ -26,6 +26,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   }
   if (cfg.qp < 0 || cfg.qp > 51 || cfg.me_range < 1 || cfg.me_range > 32) { if (error) *error = "qp or me-range out of range"; return false; }
   cfg_ = cfg;
+  qp_cur_ = cfg.qp;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg.device) {
     if (error) *error = "no usable HIP device (this library has no CPU fallback)"; return false;
@@ -199,6 +200,19 @@ bool Encoder::flush(EncodedPicture *out)
   return collect(out);
 }
 
+// picture-level rate control: the statement of record is rate_control() in oracle/hevc_enc.c
+void Encoder::rate_control()
+{
+  if (cfg_.bitrate <= 0 || frame_idx_ < 3) return;
+  const int64_t T = ((int64_t)cfg_.bitrate * cfg_.fps_den) / (cfg_.fps_num > 0 ? cfg_.fps_num : 1);
+  const int64_t trend = (int64_t)8 * rc_bytes_[(frame_idx_ - 3) & 7] - T;
+  rc_debt_ += trend;
+  int step = 0;
+  if (rc_debt_ > 4 * T && trend > 0) step = rc_debt_ > 16 * T ? 2 : 1;
+  if (rc_debt_ < -4 * T && trend < 0) step = rc_debt_ < -16 * T ? -2 : -1;
+  qp_cur_ = clip3(10, 51, qp_cur_ + step);
+}
+
 bool Encoder::submit(const uint8_t *d_i420, bool)
 {
   const int w = cfg_.width, h = cfg_.height;
@@ -216,6 +230,8 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   const int period = cfg_.intra_period;
   const bool intra = (frame_idx_ == 0) || (period > 0 && (frame_idx_ % period) == 0);
   if (intra) poc_ = 0; else poc_++;
+  rate_control();
+  f_.qp = qp_cur_; f_.qpc = kChromaQp[qp_cur_]; f_.lambda_q4 = kLambdaQ4[qp_cur_];
   f_.is_intra = intra; f_.poc = poc_;
   for (int c = 0; c < 3; c++) { f_.rec[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
   f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err;
@@ -238,7 +254,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   // the slot is complete when both streams are: the tokens (stream_tok_) and the reconstruction (stream_)
   HIP_CHECK(hipEventRecord(sl.done, stream_tok_));
   HIP_CHECK(hipEventRecord(sl.rec_done, stream_));
-  sl.poc = poc_; sl.intra = intra; sl.rec_idx = cur_idx_; sl.set = set_; sl.write_ps = false;
+  sl.poc = poc_; sl.intra = intra; sl.rec_idx = cur_idx_; sl.set = set_; sl.qp = qp_cur_; sl.write_ps = false;
   if (intra) {
     sl.write_ps = (intra_count_ == 0) || (cfg_.vps_period > 0 && (intra_count_ % cfg_.vps_period) == 0);
     intra_count_++;
@@ -267,6 +283,7 @@ bool Encoder::collect(EncodedPicture *out)
     std::swap(*out, sl.result);
   } else ok = finish_slot(sl, out);
   out_idx_ = sl.rec_idx; out_set_ = sl.set;
+  rc_bytes_[(collected_ - 1) & 7] = (uint32_t)out->au.size();   // (collected_ - 1 = index of this picture)
   return ok;
 }
 
@@ -302,13 +319,13 @@ bool Encoder::finish_slot(Slot &sl, EncodedPicture *out)
   uint64_t bins = 0;
   Tick tk_ar;
   for (int i = 0, n = (cw_ / 64) * rows_; i < n; i++) if (sl.h_tok_count[i] < 0) { fprintf(stderr, "kvazzup_amd: token array overflow (CTU %d)\n", i); return false; }
-  entropy_->code_picture(sl.h_tok_dense, sl.h_tok_count, sl.h_tok_off, cw_ / 64, rows_, cfg_.wpp != 0, sl.intra ? 0 : 1, cfg_.qp, rows_out_, &bins);
+  entropy_->code_picture(sl.h_tok_dense, sl.h_tok_count, sl.h_tok_off, cw_ / 64, rows_, cfg_.wpp != 0, sl.intra ? 0 : 1, sl.qp, rows_out_, &bins);
   const double ar = tk_ar.ms();
   if (profiling_) { std::lock_guard<std::mutex> l(stat_m_); k_ms_[K_HOST_ARITH] += ar; k_n_[K_HOST_ARITH]++; }
   t_arith_ += ar;
   // ---- access unit assembly (host): parameter sets with IDR pictures, then the slice NAL
-  out->valid = true; out->poc = sl.poc; out->is_intra = sl.intra; out->bins = bins;
-  { Tick tk; assemble_access_unit(out->au, sp_, sl.intra, sl.poc, sl.write_ps, rows_out_, nsub); t_asm_ += tk.ms(); }
+  out->valid = true; out->poc = sl.poc; out->qp = sl.qp; out->is_intra = sl.intra; out->bins = bins;
+  { Tick tk; assemble_access_unit(out->au, sp_, sl.intra, sl.poc, sl.write_ps, rows_out_, nsub, sl.qp - cfg_.qp); t_asm_ += tk.ms(); }
   return true;
 }
 

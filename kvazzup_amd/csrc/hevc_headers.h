@@ -105,7 +105,7 @@ inline size_t escaped_size(const uint8_t *p, size_t n)
   return out;
 }
 
-inline void write_slice_header(BitWriter &w, const StreamParams &s, bool idr, int poc, const std::vector<uint32_t> &entry_sizes)
+inline void write_slice_header(BitWriter &w, const StreamParams &s, bool idr, int poc, const std::vector<uint32_t> &entry_sizes, int slice_qp_delta = 0)
 {
   w.bit(1);
   if (idr) w.bit(0);
@@ -113,7 +113,7 @@ inline void write_slice_header(BitWriter &w, const StreamParams &s, bool idr, in
   w.ue(idr ? 2 : 1);
   if (!idr) { w.put((uint32_t)poc & 255, 8); w.bit(1); }
   if (!idr) { w.bit(0); w.ue(0); }                               // num_ref_idx override, five_minus_max_num_merge_cand
-  w.se(0);
+  w.se(slice_qp_delta);                                          // against the PPS init_qp (= the configured QP)
   // (deblocking override not enabled; slice_loop_filter_across_slices_enabled_flag present when deblocking is on)
   if (s.deblock) w.bit(1);
   if (s.wpp) {
@@ -144,7 +144,7 @@ inline void append_nal(std::vector<uint8_t> &out, int nal_type, const uint8_t *r
 // One access unit: [VPS SPS PPS] + slice NAL whose data are the `nsub` substreams (CTU rows with
 // WPP, otherwise one) rows[r].
 inline void assemble_access_unit(std::vector<uint8_t> &au, const StreamParams &sp, bool idr, int poc, bool write_ps,
-                                 const std::vector<std::vector<uint8_t>> &rows, int nsub)
+                                 const std::vector<std::vector<uint8_t>> &rows, int nsub, int slice_qp_delta = 0)
 {
   au.clear();
   if (write_ps) {
@@ -156,7 +156,7 @@ inline void assemble_access_unit(std::vector<uint8_t> &au, const StreamParams &s
   std::vector<uint32_t> entry;
   for (int r = 0; r + 1 < nsub; r++) entry.push_back((uint32_t)escaped_size(rows[(size_t)r].data(), rows[(size_t)r].size()));
   BitWriter sh;
-  write_slice_header(sh, sp, idr, poc, entry);
+  write_slice_header(sh, sp, idr, poc, entry, slice_qp_delta);
   for (int r = 0; r < nsub; r++) sh.bytes(rows[(size_t)r].data(), rows[(size_t)r].size());
   append_nal(au, idr ? 19 : 1, sh.data().data(), sh.data().size());
 }

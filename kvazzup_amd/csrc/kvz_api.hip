@@ -236,15 +236,12 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.width = cfg->width; ec.height = cfg->height; ec.qp = cfg->qp; ec.intra_period = cfg->intra_period; ec.vps_period = cfg->vps_period;
   ec.me_range = cfg->me_range; ec.fps_num = cfg->framerate_num; ec.fps_den = cfg->framerate_denom;
   ec.wpp = cfg->wpp ? 1 : 0; ec.deblock = cfg->deblock_enable ? 1 : 0; ec.device = cfg->gpu_device; ec.owf = cfg->owf > 2 ? 2 : cfg->owf;
+  ec.bitrate = cfg->target_bitrate > 0 ? cfg->target_bitrate : 0;      // any rc-algorithm value selects the one picture-level controller
   std::string err;
   Encoder *impl = Encoder::create(ec, &err);
   if (!impl) { fprintf(stderr, "kvazzup_amd: encoder_open failed: %s\n", err.c_str()); return nullptr; }
   kvz_encoder *e = new kvz_encoder();
   e->impl = impl; e->cfg = *cfg; e->last_bins = 0; e->warned_rc = 0; e->in_flight = new std::deque<kvz_picture *>();
-  if (cfg->target_bitrate != 0) {
-    fprintf(stderr, "kvazzup_amd: rate control is not implemented; coding at constant QP %d\n", cfg->qp);
-    e->warned_rc = 1;
-  }
   return e;
 }
 void encoder_close(kvz_encoder *e)
@@ -260,7 +257,7 @@ void fill_info(kvz_encoder *e, const EncodedPicture &ep, kvz_frame_info *info)
 {
   if (!info) return;
   memset(info, 0, sizeof(*info));
-  info->poc = ep.poc; info->qp = (int8_t)e->cfg.qp;
+  info->poc = ep.poc; info->qp = (int8_t)ep.qp;
   info->nal_unit_type = ep.is_intra ? KVZ_NAL_IDR_W_RADL : KVZ_NAL_TRAIL_R;
   info->slice_type = ep.is_intra ? KVZ_SLICE_I : KVZ_SLICE_P;
   if (!ep.is_intra) { info->ref_list_len[0] = 1; info->ref_list[0][0] = ep.poc - 1; }

@@ -24,6 +24,8 @@ struct orc_encoder {
   orc_enc_config cfg;
   int cw, ch, b8w, b8h;
   int frame_idx, poc, intra_count;
+  int qp;                              /* QP of the picture being coded (== cfg.qp without rate control) */
+  int64_t rc_debt; uint32_t rc_bytes[8];  /* rate control: bits spent above target so far; sizes of the last access units */
   orc_vps vps; orc_sps sps; orc_pps pps;
   orc_pic pics[2]; orc_pic *cur, *ref;
   pixel *src[3];
@@ -73,6 +75,7 @@ orc_encoder *orc_enc_open(const orc_enc_config *c)
   orc_encoder *e = (orc_encoder *)calloc(1, sizeof(*e));
   orc_tables_init();
   e->cfg = *c;
+  e->qp = c->qp;
   e->cw = (c->width + 63) & ~63; e->ch = (c->height + 63) & ~63;
   if (e->cw < 128) e->cw = 128;                 /* WPP context hand-over needs two CTUs per row */
   e->b8w = e->cw / 8; e->b8h = e->ch / 8;
@@ -166,7 +169,7 @@ static void mark_cu(orc_encoder *e, int x0, int y0, int log2, int pred_mode)
   orc_pic *p = e->cur; int n = 1 << log2;
   fill_b4(p, p->pred_mode, x0, y0, n, pred_mode);
   fill_b4(p, p->ct_depth, x0, y0, n, 6 - log2);
-  for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) p->qp_y[(y >> 2) * p->b4_w + (x >> 2)] = (int8_t)e->cfg.qp;
+  for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) p->qp_y[(y >> 2) * p->b4_w + (x >> 2)] = (int8_t)e->qp;
   for (int i = 0; i < n; i += 4) {
     p->edge_v[((y0 + i) >> 2) * p->b4_w + (x0 >> 2)] |= 3;
     p->edge_h[(y0 >> 2) * p->b4_w + ((x0 + i) >> 2)] |= 3;
@@ -224,7 +227,7 @@ static void intra_analyse_size(orc_encoder *e, int n, uint8_t *best_mode, uint32
 
 static void intra_decide(orc_encoder *e)
 {
-  uint32_t pen = ((uint32_t)orc_lambda_q4[e->cfg.qp] * SPLIT_BITS) >> 4;
+  uint32_t pen = ((uint32_t)orc_lambda_q4[e->qp] * SPLIT_BITS) >> 4;
   intra_analyse_size(e, 8, e->im8, e->ic8);
   intra_analyse_size(e, 16, e->im16, e->ic16);
   intra_analyse_size(e, 32, e->im32, e->ic32);
@@ -261,12 +264,12 @@ static void intra_recon_cu(orc_encoder *e, int x0, int y0, int log2)
   orc_pic *p = e->cur;
   int n = 1 << log2, mode = e->cu_intra_mode[b8i(e, x0, y0)];
   pixel left[129], top[129];
-  int qpc = orc_chroma_qp(e->cfg.qp, 0);
+  int qpc = orc_chroma_qp(e->qp, 0);
   mark_cu(e, x0, y0, log2, MODE_INTRA);
   fill_b4(p, p->intra_mode, x0, y0, n, mode);
   orc_intra_refs(&e->av, p->plane[0], p->stride[0], 0, x0, y0, n, left, top);
   orc_intra_predict(left, top, n, 0, mode, 1, p->plane[0] + y0 * p->stride[0] + x0, p->stride[0]);
-  int cbf = code_block(e, 0, x0, y0, n, e->cfg.qp, 1);
+  int cbf = code_block(e, 0, x0, y0, n, e->qp, 1);
   fill_b4(p, p->tu_nz, x0, y0, n, cbf);
   for (int c = 1; c <= 2; c++) {
     int cx = x0 / 2, cy = y0 / 2, cn = n / 2;
@@ -319,7 +322,7 @@ static inline uint32_t sad16(const pixel *a, int as, const pixel *b, int bs)
 static void me_block32(orc_encoder *e, int x0, int y0)
 {
   int R = e->cfg.search_range, st = e->refpad_stride;
-  uint32_t lam = orc_lambda_q4[e->cfg.qp];
+  uint32_t lam = orc_lambda_q4[e->qp];
   uint32_t best16[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu }, best32 = 0xffffffffu;
   int idx = 0;
   for (int dy = -R; dy <= R; dy++)
@@ -363,7 +366,7 @@ static void inter_recon_cu(orc_encoder *e, int x0, int y0, int log2)
   int n = 1 << log2;
   int16_t mv[2] = { e->cu_mv[b8i(e, x0, y0) * 2], e->cu_mv[b8i(e, x0, y0) * 2 + 1] };
   int16_t tmp[32 * 32];
-  int qpc = orc_chroma_qp(e->cfg.qp, 0);
+  int qpc = orc_chroma_qp(e->qp, 0);
   mark_cu(e, x0, y0, log2, MODE_INTER);
   for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) {
     orc_mvinfo *m = &p->mvf[(y >> 2) * p->b4_w + (x >> 2)];
@@ -371,7 +374,7 @@ static void inter_recon_cu(orc_encoder *e, int x0, int y0, int log2)
   }
   orc_mc_luma(r->plane[0], r->stride[0], r->w, r->h, x0, y0, n, n, mv[0], mv[1], tmp, 32);
   orc_pred_uni(tmp, 32, p->plane[0] + y0 * p->stride[0] + x0, p->stride[0], n, n);
-  int cbf = code_block(e, 0, x0, y0, n, e->cfg.qp, 0);
+  int cbf = code_block(e, 0, x0, y0, n, e->qp, 0);
   fill_b4(p, p->tu_nz, x0, y0, n, cbf);
   for (int c = 1; c <= 2; c++) {
     int cx = x0 / 2, cy = y0 / 2, cn = n / 2;
@@ -682,7 +685,7 @@ static void write_picture(orc_encoder *e, int write_ps)
       int sub = e->cfg.wpp ? cy : 0;
       orc_bw_init(&rows[sub]);
       orc_cenc_start(&c, &rows[sub]);
-      if (cy == 0) orc_cabac_init_contexts(c.ctx, init_type, e->cfg.qp);
+      if (cy == 0) orc_cabac_init_contexts(c.ctx, init_type, e->qp);
       else memcpy(c.ctx, saved, sizeof(saved));       /* WPP: state after the 2nd CTU of the row above */
     }
     for (int cx = 0; cx < wc; cx++) {
@@ -697,6 +700,7 @@ static void write_picture(orc_encoder *e, int write_ps)
   e->bins = c.bins;
   orc_slice_hdr sh; memset(&sh, 0, sizeof(sh));
   sh.first_slice_segment_in_pic = 1; sh.slice_type = e->is_intra ? SLICE_I : SLICE_P; sh.pic_output_flag = 1;
+  sh.slice_qp_delta = e->qp - e->cfg.qp;            /* PPS init_qp is the configured QP */
   sh.poc_lsb = e->poc & 255; sh.short_term_ref_pic_set_sps_flag = 1;
   sh.num_ref_idx_l0 = 1; sh.num_ref_idx_l1 = 1; sh.max_num_merge_cand = 5; sh.collocated_from_l0 = 1;
   sh.slice_deblocking_disabled = !e->cfg.deblock;
@@ -712,11 +716,29 @@ static void write_picture(orc_encoder *e, int write_ps)
 }
 
 /* ------------------------------------------------------------------ top level */
+/* "uvgx rate control v1": picture-level, deterministic, with a fixed feedback delay of three pictures so that an
+ * encoder that pipelines pictures (owf <= 2) decides exactly like one that does not.  T = bits per picture at the
+ * target rate.  Before picture t (t >= 3) the size of access unit t - 3 is booked: debt += bits(t-3) - T.  The QP
+ * moves one step (two when |debt| > 16 T) towards paying the debt back, but only while the booked picture was still
+ * on the wrong side of T -- which damps the oscillation the delay would otherwise cause.  QP stays in [10, 51]. */
+static void rate_control(orc_encoder *e)
+{
+  if (e->cfg.bitrate <= 0 || e->frame_idx < 3) return;
+  const int64_t T = ((int64_t)e->cfg.bitrate * e->cfg.fps_den) / (e->cfg.fps_num > 0 ? e->cfg.fps_num : 1);
+  const int64_t trend = (int64_t)8 * e->rc_bytes[(e->frame_idx - 3) & 7] - T;
+  e->rc_debt += trend;
+  int step = 0;
+  if (e->rc_debt > 4 * T && trend > 0) step = e->rc_debt > 16 * T ? 2 : 1;
+  if (e->rc_debt < -4 * T && trend < 0) step = e->rc_debt < -16 * T ? -2 : -1;
+  e->qp = orc_clip3(10, 51, e->qp + step);
+}
+
 size_t orc_enc_encode(orc_encoder *e, const pixel *y, const pixel *u, const pixel *v, const uint8_t **au)
 {
   int period = e->cfg.intra_period;
   e->is_intra = (e->frame_idx == 0) || (period > 0 && (e->frame_idx % period) == 0);
   if (e->is_intra) e->poc = 0; else e->poc++;
+  rate_control(e);
   load_input(e, y, u, v);
   orc_pic_reset_side(e->cur);
   for (int c = 0; c < 3; c++) memset(e->coef[c], 0, sizeof(int16_t) * (size_t)(c ? e->cw * e->ch / 4 : e->cw * e->ch));
@@ -737,6 +759,7 @@ size_t orc_enc_encode(orc_encoder *e, const pixel *y, const pixel *u, const pixe
     e->intra_count++;
   }
   write_picture(e, write_ps);
+  e->rc_bytes[e->frame_idx & 7] = (uint32_t)e->au.len;
   e->frame_idx++;
   orc_pic *t = e->cur; e->cur = e->ref; e->ref = t;     /* e->ref now holds the picture just coded */
   *au = e->au.buf;

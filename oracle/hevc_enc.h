@@ -12,7 +12,7 @@
  *   integer-sample full-search motion estimation over +-range, 1 reference (previous picture),
  *   merge/skip with 5 candidates, AMVP, no TMVP, plain dead-zone quantiser, deblocking on,
  *   SAO off, sign hiding off, transform skip off, WPP on, one slice per picture,
- *   IDR every `period` pictures with VPS/SPS/PPS, constant QP.
+ *   IDR every `period` pictures with VPS/SPS/PPS, constant QP or picture-level rate control (bitrate > 0).
  * Test infrastructure. */
 #ifndef ORC_HEVC_ENC_H
 #define ORC_HEVC_ENC_H
@@ -31,6 +31,7 @@ typedef struct {
   int fps_num, fps_den;
   int wpp;                    /* entropy_coding_sync_enabled_flag */
   int deblock;                /* 1 = enabled */
+  int bitrate;                /* bits per second; 0 = constant QP.  > 0: "uvgx rate control v1" (see hevc_enc.c) */
 } orc_enc_config;
 
 typedef struct {

@@ -69,6 +69,14 @@ orc_encoder *orc_api_enc_open(int w, int h, int qp, int period, int vps_period, 
   c.fps_num = fps_num; c.fps_den = fps_den; c.wpp = wpp; c.deblock = deblock;
   return orc_enc_open(&c);
 }
+/* same with picture-level rate control (bits per second) */
+orc_encoder *orc_api_enc_open_rc(int w, int h, int qp, int period, int vps_period, int range, int fps_num, int fps_den, int wpp, int deblock, int bitrate)
+{
+  orc_enc_config c; orc_enc_default_config(&c);
+  c.width = w; c.height = h; c.qp = qp; c.intra_period = period; c.vps_period = vps_period; c.search_range = range;
+  c.fps_num = fps_num; c.fps_den = fps_den; c.wpp = wpp; c.deblock = deblock; c.bitrate = bitrate;
+  return orc_enc_open(&c);
+}
 /* returns AU size; copies it to out when it fits */
 long orc_api_enc_encode(orc_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v, uint8_t *out, long cap)
 {

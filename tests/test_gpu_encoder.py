@@ -90,3 +90,29 @@ def test_owf_lags_output_and_flushes(gpu, owf):
     for t in range(frames):
         assert got[t + owf][0] == want[t][0], t
         assert np.array_equal(got[t + owf][1], want[t][1]), t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bitrate,owf", [(200000, 0), (1000000, 2)])
+def test_rate_control_matches_the_checker_picture_for_picture(gpu, bitrate, owf):
+    """video/bitrate != 0 (kvazaarfilter.cpp:223-228): picture-level rate control.  Its decisions depend on the sizes of
+    earlier access units, with a fixed three-picture delay, so the pipelined encoder (owf 2) and the checker agree on
+    every QP; one differing byte anywhere would make the streams diverge."""
+    from kvazzup_amd.codec import Decoder, Encoder
+    w, h, frames = 320, 192, 40
+    clip = [orc.synth_frame(0, SEED, w, h, t) for t in range(frames)]
+    oe = orc.OracleEncoder(w, h, qp=32, period=16, me_range=8, bitrate=bitrate)
+    want = [oe.encode(f) for f in clip]
+    ge = Encoder(w, h, options=(("qp", 32), ("period", 16), ("me-range", 8), ("owf", owf)), fields={"target_bitrate": bitrate})
+    got = [ge.encode(f, want_recon=False)[0] for f in clip]
+    for _ in range(owf):
+        got.append(ge.encode(None, want_recon=False)[0])
+    got = got[owf:]
+    assert got == want
+    qps = set()
+    gd = Decoder()
+    for t, au in enumerate(got):
+        assert len(gd.decode_au(au, t)) == 1
+    kbps = sum(len(a) for a in got) * 8 * 30 / frames / 1000
+    assert 0.7 * bitrate / 1000 < kbps < 1.4 * bitrate / 1000, kbps
+    ge.close(); gd.close(); oe.close()

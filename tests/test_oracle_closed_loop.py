@@ -68,3 +68,21 @@ def test_motion_is_found_and_signalled():
     inner = d["cu_mv"][2:-2, 2:-2]
     assert (inner[..., 0] == 5 * 4).mean() > 0.9 and (inner[..., 1] == -3 * 4).mean() > 0.9
     assert (d["cu_flags"][2:-2, 2:-2] & 2).mean() > 0.8          # neighbours share the vector: merge mode
+
+
+def test_rate_control_tracks_the_target_and_decodes():
+    """picture-level rate control of the checker: the stream still decodes to the encoder's reconstruction (slice QP
+    deltas), and the produced rate lands near the target"""
+    w, h, frames = 320, 192, 40
+    for bitrate in (200000, 1000000):
+        oe = orc.OracleEncoder(w, h, qp=32, period=16, me_range=8, bitrate=bitrate)
+        od = orc.OracleDecoder()
+        total = 0
+        for t in range(frames):
+            au = oe.encode(orc.synth_frame(0, 7, w, h, t))
+            total += len(au)
+            d = od.decode_au(au, t)
+            assert len(d) == 1 and np.array_equal(d[0]["i420"], oe.recon()), t
+        kbps = total * 8 * 30 / frames / 1000
+        assert 0.7 * bitrate / 1000 < kbps < 1.4 * bitrate / 1000, (bitrate, kbps)
+        oe.close(); od.close()

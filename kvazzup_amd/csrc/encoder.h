@@ -84,7 +84,7 @@ class Encoder {
   EncFrame f_{};
   uint8_t *d_in_ = nullptr;              // packed input staging (device)
   uint8_t *h_in_ = nullptr;              // pinned host staging
-  uint8_t *src_[3] = {nullptr, nullptr, nullptr};
+  uint8_t *src_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // padded source planes, one set per picture parity
   // reconstruction ring: the picture being coded, its reference, and (owf >= 2) the one still waiting to be output
   uint8_t *rec_[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   int cur_idx_ = 0, ref_idx_ = 2, out_idx_ = 2;
@@ -96,7 +96,9 @@ class Encoder {
   int set_ = 0, out_set_ = 0;
   int qp_cur_ = 0; int64_t rc_debt_ = 0; uint32_t rc_bytes_[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rate control state (calling thread)
   void rate_control();
-  hipStream_t stream_tok_ = nullptr;     // tokenizer + compaction
+  hipStream_t stream_tok_ = nullptr;     // signalling decisions, tokenizer, compaction
+  hipStream_t stream_in_ = nullptr;      // input padding (runs ahead of the previous picture's kernels)
+  hipEvent_t ev_padded_ = nullptr, ev_src_free_[2] = {nullptr, nullptr}; bool src_busy_[2] = {false, false};
   hipEvent_t ev_signalled_ = nullptr, ev_tok_done_[2] = {nullptr, nullptr}; bool tok_pending_[2] = {false, false};
   void bind_set(int k);
   uint8_t *intra_scratch_ = nullptr;

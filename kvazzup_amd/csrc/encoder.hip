@@ -41,7 +41,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   HIP_OK(hipHostMalloc(&h_in_, in_bytes, hipHostMallocDefault));
   for (int c = 0; c < 3; c++) {
     size_t n = c ? npx / 4 : npx;
-    HIP_OK(hipMalloc(&src_[c], n));
+    HIP_OK(hipMalloc(&src_[0][c], n)); HIP_OK(hipMalloc(&src_[1][c], n));
     for (int b = 0; b < 3; b++) { HIP_OK(hipMalloc(&rec_[b][c], n)); HIP_OK(hipMemset(rec_[b][c], 0, n)); }
     for (int k = 0; k < 2; k++) { HIP_OK(hipMalloc(&coef_[k][c], n * sizeof(int16_t))); HIP_OK(hipMemset(coef_[k][c], 0, n * sizeof(int16_t))); }
   }
@@ -52,6 +52,9 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
     HIP_OK(hipEventCreateWithFlags(&ev_tok_done_[k], hipEventDisableTiming));
   }
   HIP_OK(hipStreamCreateWithFlags(&stream_tok_, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&stream_in_, hipStreamNonBlocking));
+  HIP_OK(hipEventCreateWithFlags(&ev_padded_, hipEventDisableTiming));
+  for (int k = 0; k < 2; k++) HIP_OK(hipEventCreateWithFlags(&ev_src_free_[k], hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&ev_signalled_, hipEventDisableTiming));
   // intra scratch: ic8 (nb8 u32) | ic16 (nb8/4 u32) | ic32 (nb8/16 u32) | im8 | im16 | im32
   size_t isz = nb8 * 4 + nb8 + nb8 / 4 + nb8 + nb8 / 4 + nb8 / 16 + 64;
@@ -90,7 +93,6 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   f_.cw = cw_; f_.ch = ch_; f_.b8w = cw_ / 8; f_.b8h = ch_ / 8;
   f_.qp = cfg.qp; f_.qpc = kChromaQp[cfg.qp]; f_.lambda_q4 = kLambdaQ4[cfg.qp]; f_.range = cfg.me_range;
   f_.wpp = cfg.wpp;
-  for (int c = 0; c < 3; c++) f_.src[c] = src_[c];
   bind_set(0);
   uint8_t *p = intra_scratch_;
   f_.ic8 = (uint32_t *)p; p += nb8 * 4; f_.ic16 = (uint32_t *)p; p += nb8; f_.ic32 = (uint32_t *)p; p += nb8 / 4;
@@ -113,7 +115,7 @@ void Encoder::bind_set(int k)
 {
   const size_t nb8 = (size_t)cw_ * ch_ / 64;
   uint8_t *cu = cu_bytes_[k];
-  for (int c = 0; c < 3; c++) f_.coef[c] = coef_[k][c];
+  for (int c = 0; c < 3; c++) { f_.coef[c] = coef_[k][c]; f_.src[c] = src_[k][c]; }
   f_.cu_log2 = cu; f_.cu_intra = cu + nb8; f_.cu_flags = cu + 2 * nb8; f_.cu_merge_idx = cu + 3 * nb8;
   f_.cu_mvp_idx = cu + 4 * nb8; f_.cu_intra_mode = cu + 5 * nb8; f_.cu_cbf = cu + 6 * nb8;
   f_.cu_mv = cu_mv_[k]; f_.cu_mvd = cu_mvd_[k];
@@ -125,6 +127,7 @@ Encoder::~Encoder()
   if (bg_.joinable()) { { std::lock_guard<std::mutex> l(bm_); bquit_ = true; } bcv_.notify_all(); bg_.join(); }
   if (stream_) hipStreamSynchronize(stream_);
   if (stream_tok_) hipStreamSynchronize(stream_tok_);
+  if (stream_in_) hipStreamSynchronize(stream_in_);
   for (Slot &sl : slot_) {
     for (auto &e : sl.ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     if (sl.h_tok_dense) hipHostFree(sl.h_tok_dense);
@@ -136,10 +139,13 @@ Encoder::~Encoder()
   }
   if (in_done_) hipEventDestroy(in_done_);
   hipFree(d_in_); hipHostFree(h_in_);
-  for (int c = 0; c < 3; c++) { hipFree(src_[c]); for (int b = 0; b < 3; b++) hipFree(rec_[b][c]); hipFree(coef_[0][c]); hipFree(coef_[1][c]); }
+  for (int c = 0; c < 3; c++) { hipFree(src_[0][c]); hipFree(src_[1][c]); for (int b = 0; b < 3; b++) hipFree(rec_[b][c]); hipFree(coef_[0][c]); hipFree(coef_[1][c]); }
   for (int k = 0; k < 2; k++) { hipFree(cu_bytes_[k]); hipFree(cu_mv_[k]); hipFree(cu_mvd_[k]); if (ev_tok_done_[k]) hipEventDestroy(ev_tok_done_[k]); }
   if (ev_signalled_) hipEventDestroy(ev_signalled_);
+  if (ev_padded_) hipEventDestroy(ev_padded_);
+  for (int k = 0; k < 2; k++) if (ev_src_free_[k]) hipEventDestroy(ev_src_free_[k]);
   if (stream_tok_) hipStreamDestroy(stream_tok_);
+  if (stream_in_) hipStreamDestroy(stream_in_);
   hipFree(intra_scratch_);
   delete entropy_;
   hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(tok_total_); hipFree(sync_); hipFree(err_);
@@ -175,7 +181,7 @@ bool Encoder::encode_host(const uint8_t *y, const uint8_t *u, const uint8_t *v, 
   HIP_CHECK(hipSetDevice(cfg_.device));
   if (in_pending_) { HIP_CHECK(hipEventSynchronize(in_done_)); in_pending_ = false; }
   memcpy(h_in_, y, ny); memcpy(h_in_ + ny, u, ny / 4); memcpy(h_in_ + ny + ny / 4, v, ny / 4);
-  HIP_CHECK(hipMemcpyAsync(d_in_, h_in_, ny * 3 / 2, hipMemcpyHostToDevice, stream_));
+  HIP_CHECK(hipMemcpyAsync(d_in_, h_in_, ny * 3 / 2, hipMemcpyHostToDevice, stream_in_));
   return encode_device(d_in_, out);
 }
 
@@ -219,14 +225,18 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   Slot &sl = slot_[submitted_ % nslots_];
   cur_slot_ = &sl;
   prof_now_ = profiling_ && (frame_idx_ % prof_every_) == 0;
-  // Two HIP streams per picture t.  stream_: input padding, decisions, reconstruction, deblocking -- the chain picture t + 1
-  // depends on.  stream_tok_: tokenizer + compaction, which only feed the host; they read set t & 1 of the level / CU
-  // arrays while stream_ already fills the other set for t + 1.
+  // Three HIP streams per picture t.
+  //   stream_in_:  input padding into source set t & 1 -- runs while stream_ still works on picture t - 1.
+  //   stream_:     motion search / intra decisions, reconstruction, deblocking: the chain picture t + 1 depends on.
+  //   stream_tok_: merge/AMVP signalling, tokenizer, compaction, which only feed the host; they read set t & 1 of the
+  //                level / CU arrays while stream_ already fills the other set for t + 1.
   set_ = (int)(submitted_ & 1);
   bind_set(set_);
+  if (src_busy_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_src_free_[set_], 0)); src_busy_[set_] = false; }   // reconstruction of t - 2 has read this source set
+  timed(K_PAD, stream_in_, [&] { launch_pad_input(d_i420, w, h, src_[set_][0], src_[set_][1], src_[set_][2], cw_, ch_, stream_in_); });
+  HIP_CHECK(hipEventRecord(in_done_, stream_in_)); in_pending_ = true;
+  HIP_CHECK(hipStreamWaitEvent(stream_, in_done_, 0));
   if (tok_pending_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_, ev_tok_done_[set_], 0)); tok_pending_[set_] = false; }   // tokenizer of t - 2 done with this set
-  timed(K_PAD, stream_, [&] { launch_pad_input(d_i420, w, h, src_[0], src_[1], src_[2], cw_, ch_, stream_); });
-  HIP_CHECK(hipEventRecord(in_done_, stream_)); in_pending_ = true;
   const int period = cfg_.intra_period;
   const bool intra = (frame_idx_ == 0) || (period > 0 && (frame_idx_ % period) == 0);
   if (intra) poc_ = 0; else poc_++;
@@ -244,11 +254,12 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   } else {
     timed(K_ME, stream_, [&] { launch_me(f, stream_); });
     timed(K_INTER_RECON, stream_, [&] { launch_inter_recon(f, stream_); });
-    timed(K_INTER_SIGNAL, stream_, [&] { launch_inter_signal(f, stream_); });
   }
-  HIP_CHECK(hipEventRecord(ev_signalled_, stream_));             // levels and CU records of the picture are final
+  HIP_CHECK(hipEventRecord(ev_signalled_, stream_));             // levels, cbf and motion of the picture are final; source set read
+  HIP_CHECK(hipEventRecord(ev_src_free_[set_], stream_)); src_busy_[set_] = true;
   if (cfg_.deblock) timed(K_DEBLOCK, stream_, [&] { launch_deblock(f, stream_); });
   HIP_CHECK(hipStreamWaitEvent(stream_tok_, ev_signalled_, 0));
+  if (!intra) timed(K_INTER_SIGNAL, stream_tok_, [&] { launch_inter_signal(f, stream_tok_); });
   timed(K_TOKENIZE, stream_tok_, [&] { launch_tokenize(f, stream_tok_); });
   HIP_CHECK(hipEventRecord(ev_tok_done_[set_], stream_tok_)); tok_pending_[set_] = true;
   // the slot is complete when both streams are: the tokens (stream_tok_) and the reconstruction (stream_)
@@ -353,7 +364,7 @@ bool Encoder::debug_copy(const char *what, void *dst, size_t bytes)
     size_t n = c ? npx / 4 : npx;
     if (w == std::string("coef") + char('0' + c)) { src = coef_[out_set_][c]; have = n * 2; }
     if (w == std::string("rec") + char('0' + c)) { src = rec_[out_idx_][c]; have = n; }
-    if (w == std::string("src") + char('0' + c)) { src = src_[c]; have = n; }
+    if (w == std::string("src") + char('0' + c)) { src = src_[out_set_][c]; have = n; }
   }
   if (!src || bytes > have) return false;
   HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));

@@ -953,15 +953,18 @@ __device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d
     const int16_t *p = lv + (ys << 2) * stride + (xs << 2);
     uint2 r0 = *reinterpret_cast<const uint2 *>(p), r1 = *reinterpret_cast<const uint2 *>(p + stride);
     uint2 r2 = *reinterpret_cast<const uint2 *>(p + 2 * stride), r3 = *reinterpret_cast<const uint2 *>(p + 3 * stride);
-    uint2 *dst = reinterpret_cast<uint2 *>(&d.raster[lane * 16]);
+    // the lane's 32 bytes of the digest: first the sub-block in raster order, then, read back through the scan table,
+    // the same levels in scan order (all reads are done before the first write of the second form)
+    uint2 *dst = reinterpret_cast<uint2 *>(&d.scan[lane * 16]);
     dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
-    uint32_t w[8] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, r3.x, r3.y};
-    uint32_t rm = 0;                                   // raster-order non-zero mask
-#pragma unroll
-    for (int i = 0; i < 8; i++) { if (w[i] & 0xffffu) rm |= 1u << (2 * i); if (w[i] >> 16) rm |= 1u << (2 * i + 1); }
+    const uint8_t *pos = t->pos4[scan_idx];
+    int v[16];
     uint32_t m = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) if ((rm >> scan_raster4(t, scan_idx, k)) & 1) m |= 1u << k;
+    for (int k = 0; k < 16; k++) { v[k] = d.scan[lane * 16 + pos[k]]; if (v[k]) m |= 1u << k; }
+    uint32_t *d32 = reinterpret_cast<uint32_t *>(&d.scan[lane * 16]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) d32[k] = ((uint32_t)v[2 * k] & 0xffffu) | ((uint32_t)v[2 * k + 1] << 16);
     d.mask[lane] = (uint16_t)m;
     nz = m != 0;
     if (nz) d.csbf[ys * 8 + xs] = 1;

@@ -18,6 +18,7 @@ KVZ_HD int imax(int a, int b) { return a > b ? a : b; }
 KVZ_HD int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 KVZ_HD int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 KVZ_HD int ilog2(unsigned v) { int n = 0; while (v > 1) { v >>= 1; n++; } return n; }
+KVZ_HD int kv_clz32(uint32_t v) { return __builtin_clz(v); }            // v != 0
 
 // ---------------------------------------------------------------------------------------------
 // Frame state shared by all encoder kernels.  All pointers are device memory (or host memory in
@@ -132,6 +133,8 @@ struct CoreTabs {
   uint8_t next_lps[64];
   uint8_t diag4x[16], diag4y[16], diag8x[64], diag8y[64], diag2x[4], diag2y[4];
   uint8_t ctxmap4x4[16];
+  uint8_t pos4[3][16];               // scan position k of a 4x4 block -> x | y << 2 (= raster index), per scan_idx
+  uint8_t sigpat[4][16];             // sig_coeff_flag context pattern (9.3.4.2.5) by prev_csbf and raster position
 };
 KVZ_HD void core_tabs_fill_entry(CoreTabs &t, int i)     // i in [0, 64): callers may spread i over lanes
 {
@@ -140,6 +143,16 @@ KVZ_HD void core_tabs_fill_entry(CoreTabs &t, int i)     // i in [0, 64): caller
   t.diag8x[i] = kDiag8x[i]; t.diag8y[i] = kDiag8y[i];
   if (i < 16) { t.diag4x[i] = kDiag4x[i]; t.diag4y[i] = kDiag4y[i]; t.ctxmap4x4[i] = kCtxIdxMap4x4[i]; }
   if (i < 4) { t.diag2x[i] = kDiag2x[i]; t.diag2y[i] = kDiag2y[i]; }
+  if (i < 16) {
+    t.pos4[0][i] = (uint8_t)(kDiag4x[i] | (kDiag4y[i] << 2));
+    t.pos4[1][i] = (uint8_t)i;                                   // horizontal scan: x = i & 3, y = i >> 2
+    t.pos4[2][i] = (uint8_t)((i >> 2) | ((i & 3) << 2));         // vertical scan: y = i & 3, x = i >> 2
+    const int xp = i & 3, yp = i >> 2;
+    t.sigpat[0][i] = (uint8_t)((xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0);
+    t.sigpat[1][i] = (uint8_t)((yp == 0) ? 2 : (yp == 1) ? 1 : 0);
+    t.sigpat[2][i] = (uint8_t)((xp == 0) ? 2 : (xp == 1) ? 1 : 0);
+    t.sigpat[3][i] = 2;
+  }
 }
 
 struct CabacEnc {
@@ -345,23 +358,19 @@ KVZ_HD void enc_abs_remaining(S &c, int v, int rice)
   }
 }
 
-// A transform block prepared for entropy coding: levels of every 4x4 sub-block in raster order
-// inside the sub-block (sub-blocks indexed by their position i in the sub-block scan), a 16-bit
+// A transform block prepared for entropy coding: the levels of every 4x4 sub-block in SCAN order
+// (scan[i * 16 + k] = level at scan position k of the sub-block at position i of the sub-block scan), a 16-bit
 // significance mask per sub-block with bit k = scan position k, a per-sub-block coded flag
 // addressed by (ys * 8 + xs), and the mask of non-empty sub-blocks (bit i).  On the GPU one wave
 // builds it cooperatively in LDS (one lane per sub-block); digest_build_serial is the host twin.
 struct TuDigest {
-  int16_t raster[64 * 16];
+  int16_t scan[64 * 16];
   uint16_t mask[64];
   uint8_t csbf[64];
   uint64_t sbmask;
 };
 
-KVZ_HD int scan_raster4(const CoreTabs *t, int scan_idx, int k)
-{
-  int x, y; scan_pos(t, scan_idx, 2, k, x, y);
-  return y * 4 + x;
-}
+KVZ_HD int scan_raster4(const CoreTabs *t, int scan_idx, int k) { return t->pos4[scan_idx][k]; }
 
 KVZ_HD void digest_build_serial(const CoreTabs *t, TuDigest &d, const int16_t *lv, int stride, int log2, int scan_idx)
 {
@@ -370,9 +379,13 @@ KVZ_HD void digest_build_serial(const CoreTabs *t, TuDigest &d, const int16_t *l
   for (int i = 0; i < 64; i++) d.csbf[i] = 0;
   for (int i = 0; i < nsb2; i++) {
     int xs, ys; scan_pos(t, scan_idx, sbl, i, xs, ys);
-    for (int r = 0; r < 16; r++) d.raster[i * 16 + r] = lv[((ys << 2) + (r >> 2)) * stride + (xs << 2) + (r & 3)];
     uint32_t m = 0;
-    for (int k = 0; k < 16; k++) if (d.raster[i * 16 + scan_raster4(t, scan_idx, k)]) m |= 1u << k;
+    for (int k = 0; k < 16; k++) {
+      const int r = t->pos4[scan_idx][k];
+      const int16_t v = lv[((ys << 2) + (r >> 2)) * stride + (xs << 2) + (r & 3)];
+      d.scan[i * 16 + k] = v;
+      if (v) m |= 1u << k;
+    }
     d.mask[i] = (uint16_t)m;
     d.csbf[ys * 8 + xs] = m != 0;
     if (m) d.sbmask |= 1ull << i;
@@ -407,14 +420,13 @@ KVZ_HD void enc_last_pos(S &c, const TuDigest &d, int log2, int cidx, int scan_i
 
 // does sub-block i contain, among its first 8 coefficients in coding order, one with |level| > 1?
 // (that is exactly "greater1Ctx ended at 0", the only state the next sub-block inherits, 9.3.4.2.6)
-KVZ_HD bool subblock_g1_any(const CoreTabs *t, const TuDigest &d, int i, int scan_idx)
+KVZ_HD bool subblock_g1_any(const CoreTabs *, const TuDigest &d, int i, int)
 {
-  const uint32_t m = d.mask[i];
-  int seen = 0;
-  for (int k = 15; k >= 0 && seen < 8; k--) if ((m >> k) & 1) {
-    int v = d.raster[i * 16 + scan_raster4(t, scan_idx, k)];
+  uint32_t mm = d.mask[i];
+  for (int seen = 0; mm && seen < 8; seen++) {
+    const int k = 31 - kv_clz32(mm); mm ^= 1u << k;
+    const int v = d.scan[i * 16 + k];
     if (v > 1 || v < -1) return true;
-    seen++;
   }
   return false;
 }
@@ -436,50 +448,47 @@ KVZ_HD void enc_subblock(S &c, const TuDigest &d, int i, int last_sb, int last_p
     infer_dc = 1;
   } else coded = 1;                        // inferred 1 for the last and the DC sub-block
   if (!coded) return;
-  const int prev_csbf = right | (below << 1);
+  // sig_coeff_flag: context = pattern by neighbouring coded flags and position + an offset per block kind (9.3.4.2.5)
+  const uint8_t *pat = t->sigpat[right | (below << 1)], *pos = t->pos4[scan_idx];
+  const int sigbase = CTX_SIG + (cidx ? 27 : 0);
+  const int off = cidx == 0 ? ((i > 0 ? 3 : 0) + ((log2 == 3) ? ((scan_idx == 0) ? 9 : 15) : 21)) : ((log2 == 3) ? 9 : 12);
   for (int k = (i == last_sb) ? last_pos - 1 : 15; k >= 0; k--) {
     if (k > 0 || !infer_dc) {
-      int xp, yp; scan_pos(t, scan_idx, 2, k, xp, yp);
-      int xc = (xs << 2) + xp, yc = (ys << 2) + yp, sc;
-      if (log2 == 2) sc = t->ctxmap4x4[(yc << 2) + xc];
-      else if (xc + yc == 0) sc = 0;
-      else {
-        if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
-        else if (prev_csbf == 1) sc = (yp == 0) ? 2 : (yp == 1) ? 1 : 0;
-        else if (prev_csbf == 2) sc = (xp == 0) ? 2 : (xp == 1) ? 1 : 0;
-        else sc = 2;
-        if (cidx == 0) { if (i > 0) sc += 3; sc += (log2 == 3) ? ((scan_idx == 0) ? 9 : 15) : 21; }
-        else sc += (log2 == 3) ? 9 : 12;
-      }
-      int sig = (m >> k) & 1;
-      cabac_bin(c, CTX_SIG + (cidx ? 27 : 0) + sc, sig);
+      const int p = pos[k];
+      int sc;
+      if (log2 == 2) sc = t->ctxmap4x4[p];
+      else if (i == 0 && k == 0) sc = 0;                             // the DC coefficient of the block
+      else sc = pat[p] + off;
+      const int sig = (m >> k) & 1;
+      cabac_bin(c, sigbase + sc, sig);
       if (sig) infer_dc = 0;
     }
   }
   if (!m) return;
   int ctx_set = (i > 0 && cidx == 0) ? 2 : 0;
   if (prev_g1) ctx_set++;
-  int c1 = 1;
-  // levels of the significant coefficients in coding order (scan position 15 .. 0)
-  int16_t lev[16]; int nsig = 0, g1idx = -1;
+  // greater1 flags of the first eight significant coefficients in coding order (scan position 15 .. 0); signs of all
+  const int16_t *lv = &d.scan[i * 16];
+  int c1 = 1, nsig = 0, g1idx = -1, g2 = 0;
   uint32_t signs = 0;
-  for (int k = 15; k >= 0; k--) if ((m >> k) & 1) {
-    int v = d.raster[i * 16 + scan_raster4(t, scan_idx, k)];
+  for (uint32_t mm = m; mm; nsig++) {
+    const int k = 31 - kv_clz32(mm); mm ^= 1u << k;
+    const int v = lv[k], a = v < 0 ? -v : v;
     signs = (signs << 1) | (v < 0 ? 1u : 0u);
-    lev[nsig++] = (int16_t)iabs(v);
+    if (nsig < 8) {
+      const int g1 = a > 1;
+      cabac_bin(c, CTX_GT1 + (cidx ? 16 : 0) + ctx_set * 4 + c1, g1);
+      if (g1) { c1 = 0; if (g1idx < 0) { g1idx = nsig; g2 = a > 2; } }
+      else if (c1 > 0 && c1 < 3) c1++;
+    }
   }
-  for (int j = 0; j < nsig && j < 8; j++) {
-    int g1 = lev[j] > 1;
-    cabac_bin(c, CTX_GT1 + (cidx ? 16 : 0) + ctx_set * 4 + c1, g1);
-    if (g1) { c1 = 0; if (g1idx < 0) g1idx = j; }
-    else if (c1 > 0 && c1 < 3) c1++;
-  }
-  if (g1idx >= 0) cabac_bin(c, CTX_GT2 + (cidx ? 4 : 0) + ctx_set, lev[g1idx] > 2);
+  if (g1idx >= 0) cabac_bin(c, CTX_GT2 + (cidx ? 4 : 0) + ctx_set, g2);
   cabac_bypass_bits(c, signs, nsig);
-  int rice = 0;
-  for (int j = 0; j < nsig; j++) {
-    int a = lev[j];
-    int base = (j < 8) ? ((j == g1idx) ? 3 : 2) : 1;
+  int rice = 0, j = 0;
+  for (uint32_t mm = m; mm; j++) {
+    const int k = 31 - kv_clz32(mm); mm ^= 1u << k;
+    const int v = lv[k], a = v < 0 ? -v : v;
+    const int base = (j < 8) ? ((j == g1idx) ? 3 : 2) : 1;
     if (a >= base) {
       enc_abs_remaining(c, a - base, rice);
       if (a > 3 * (1 << rice)) rice = imin(rice + 1, 4);

@@ -301,6 +301,8 @@ struct TokCount {
   const CoreTabs *tabs;
   int n;
 };
+template <class S> struct sink_counts_only { static constexpr bool value = false; };
+template <> struct sink_counts_only<TokCount> { static constexpr bool value = true; };
 KVZ_HD void cabac_bin(TokCount &t, int, int) { t.n++; }
 KVZ_HD void cabac_bypass(TokCount &t, int) { t.n++; }
 KVZ_HD void cabac_bypass_bits(TokCount &t, uint32_t, int n) { t.n += (n + 9) / 10; }
@@ -452,16 +454,23 @@ KVZ_HD void enc_subblock(S &c, const TuDigest &d, int i, int last_sb, int last_p
   const uint8_t *pat = t->sigpat[right | (below << 1)], *pos = t->pos4[scan_idx];
   const int sigbase = CTX_SIG + (cidx ? 27 : 0);
   const int off = cidx == 0 ? ((i > 0 ? 3 : 0) + ((log2 == 3) ? ((scan_idx == 0) ? 9 : 15) : 21)) : ((log2 == 3) ? 9 : 12);
-  for (int k = (i == last_sb) ? last_pos - 1 : 15; k >= 0; k--) {
-    if (k > 0 || !infer_dc) {
-      const int p = pos[k];
-      int sc;
-      if (log2 == 2) sc = t->ctxmap4x4[p];
-      else if (i == 0 && k == 0) sc = 0;                             // the DC coefficient of the block
-      else sc = pat[p] + off;
-      const int sig = (m >> k) & 1;
-      cabac_bin(c, sigbase + sc, sig);
-      if (sig) infer_dc = 0;
+  const int start = (i == last_sb) ? last_pos - 1 : 15;
+  if constexpr (sink_counts_only<S>::value) {
+    // number of sig_coeff_flags: positions start .. 0, minus the inferred DC flag of a coded sub-block whose other
+    // flags are all zero
+    if (start >= 0) c.n += start + 1 - ((infer_dc && (m >> 1) == 0) ? 1 : 0);
+  } else {
+    for (int k = start; k >= 0; k--) {
+      if (k > 0 || !infer_dc) {
+        const int p = pos[k];
+        int sc;
+        if (log2 == 2) sc = t->ctxmap4x4[p];
+        else if (i == 0 && k == 0) sc = 0;                           // the DC coefficient of the block
+        else sc = pat[p] + off;
+        const int sig = (m >> k) & 1;
+        cabac_bin(c, sigbase + sc, sig);
+        if (sig) infer_dc = 0;
+      }
     }
   }
   if (!m) return;

@@ -62,6 +62,8 @@ def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_pic
     dict(w=640, h=360, frames=4, qp=27, period=64, me_range=16, kind=0, deblock=0),
     dict(w=702, h=394, frames=3, qp=51, period=64, me_range=4, kind=0),     # odd-ish size (even), extreme QP
     dict(w=130, h=70, frames=3, qp=0, period=64, me_range=1, kind=2),
+    dict(w=16, h=16, frames=3, qp=30, period=64, me_range=8, kind=0),        # smallest input the ABI accepts (coded 128x64)
+    dict(w=3840, h=2160, frames=2, qp=32, period=64, me_range=16, kind=0),  # BASELINE configs[2] size: one IDR + one P against the checker
 ])
 def test_encoder_matches_oracle(gpu, cfg):
     run_clip(**cfg)
@@ -116,3 +118,10 @@ def test_rate_control_matches_the_checker_picture_for_picture(gpu, bitrate, owf)
     kbps = sum(len(a) for a in got) * 8 * 30 / frames / 1000
     assert 0.7 * bitrate / 1000 < kbps < 1.4 * bitrate / 1000, kbps
     ge.close(); gd.close(); oe.close()
+
+
+@pytest.mark.gpu
+def test_largest_size_8k_intra_and_inter_picture(gpu):
+    """7680x4320 (BASELINE configs[4] size, 120 x 68 CTUs): one IDR and one P picture, access units and
+    reconstruction bit-exact against the checker"""
+    run_clip(w=7680, h=4320, frames=2, qp=35, period=64, me_range=8, kind=0)

@@ -283,6 +283,8 @@ struct InterLds {
   alignas(16) uint8_t win[2][4][11 * 12];  // chroma reference windows: plane x 8x8 sub-block, 11 x 11 samples each
   uint32_t nz[2];
   int mv[4][2];
+  alignas(16) int8_t M8[2][32 * 32];       // the 32-point matrix and its transpose as int8: MFMA B operands
+  int rowsum[2][32];                       // sum over m of M8[.][j][m]
 };
 
 // The four transform stages of `NTU` blocks of n = 1 << L2 held TU-major in s.A (encoder: residual, row-major;
@@ -337,6 +339,93 @@ __device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *n
   __syncthreads();
 }
 
+// ---- the 32x32 transform on the matrix cores --------------------------------------------------------------------
+// One stage P(X, T)[j][i] = sum_m X[i][m] * T[j][m] of a 32x32 block is a 32x32x32 integer matrix product.  T fits
+// int8 (|coefficient| <= 90); X is int16, so it is split into bytes: x = 256 * hi + (lo - 128) + 128 with hi = x >> 8
+// and lo - 128 both in [-128, 127], giving
+//   sum_m x T = 256 * (hi . T) + ((lo - 128) . T) + 128 * rowsum(T)        -- two MFMAs, exact in int32.
+// Each of the four waves owns one 16x16 tile of the result (rows 16 * (w >> 1) .., columns 16 * (w & 1) ..) and uses
+// v_mfma_i32_16x16x64_i8 with the upper half of K zero: lane l < 32 holds row (l & 15), k = (l >> 4) * 16 .. + 15 of
+// its A tile (16 bytes) and the same k range of row (l & 15) of T for B; result: column l & 15, rows (l >> 4) * 4 + r.
+typedef int kv_i32x4 __attribute__((ext_vector_type(4)));
+
+// sums of the lane's four results: tile rows (lane >> 4) * 4 + r, tile column lane & 15
+__device__ __forceinline__ void mfma_tile_sums(const int16_t *X, const int8_t *T8, const int *rowsum, int wave, int lane, int (&acc)[4])
+{
+  const int ti = (wave >> 1) * 16, tj = (wave & 1) * 16, kb = (lane >> 4) * 16;
+  kv_i32x4 ahi = {0, 0, 0, 0}, alo = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+  if (lane < 32) {
+    const int16_t *xr = X + (ti + (lane & 15)) * 32 + kb;
+    const uint4 x0 = *(const uint4 *)xr, x1 = *(const uint4 *)(xr + 8);
+    const uint32_t d[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      ahi[q] = (int)__builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x07050301u);                  // high bytes of four int16
+      alo[q] = (int)(__builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x06040200u) ^ 0x80808080u);  // low bytes - 128
+    }
+    b = *(const kv_i32x4 *)(T8 + (tj + (lane & 15)) * 32 + kb);
+  }
+  kv_i32x4 chi = {0, 0, 0, 0}, clo = {0, 0, 0, 0};
+  chi = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, b, chi, 0, 0, 0);
+  clo = __builtin_amdgcn_mfma_i32_16x16x64_i8(alo, b, clo, 0, 0, 0);
+  const int bias = 128 * rowsum[tj + (lane & 15)];
+#pragma unroll
+  for (int r = 0; r < 4; r++) acc[r] = 256 * chi[r] + clo[r] + bias;
+}
+
+// plain stage: out[j][i] = clip16((sum + rnd) >> shift); the lane's column j is a row of `out`, its four rows i one store
+__device__ __forceinline__ void mfma_stage(const int16_t *X, int16_t *out, const int8_t *T8, const int *rowsum, int shift, int wave, int lane)
+{
+  int acc[4];
+  mfma_tile_sums(X, T8, rowsum, wave, lane, acc);
+  const int rnd = 1 << (shift - 1), j = (wave & 1) * 16 + (lane & 15), i0 = (wave >> 1) * 16 + (lane >> 4) * 4;
+  int v[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) v[e] = clip3(-32768, 32767, (acc[e] + rnd) >> shift);
+  *(uint2 *)&out[j * 32 + i0] = make_uint2(pack_i16(v[0], v[1]), pack_i16(v[2], v[3]));
+}
+
+// The 32x32 luma block of a 32x32 CU: same contract as inter_transform<DEC, 5, .>
+template <bool DEC>
+__device__ __forceinline__ void inter_transform_32(InterLds &s, int qp, uint32_t *nz, int16_t *coef, int cw, int tid)
+{
+  const int wave = tid >> 6, lane = tid & 63;
+  const int j = (wave & 1) * 16 + (lane & 15), i0 = (wave >> 1) * 16 + (lane >> 4) * 4;   // result column, first of four result rows
+  int lv[4];
+  if (!DEC) {
+    mfma_stage(s.A, s.B, s.M8[0], s.rowsum[0], 4, wave, lane);                             // forward rows (shift log2 n - 1)
+    __syncthreads();
+    {
+      int acc[4];
+      mfma_tile_sums(s.B, s.M8[0], s.rowsum[0], wave, lane, acc);                          // forward columns: coefficient (row j, columns i0 ..)
+      bool any = false;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int c = clip3(-32768, 32767, (acc[r] + 1024) >> 11);
+        lv[r] = quant_level(c, qp, 5, 0);
+        any |= lv[r] != 0;
+        s.A[(i0 + r) * 32 + j] = (int16_t)dequant_coef(lv[r], qp, 5);                      // transposed: [column][row]
+      }
+      if (any) atomicOr(nz, 1u);
+    }
+    __syncthreads();
+    if (*nz & 1) *(uint2 *)&coef[(size_t)j * cw + i0] = make_uint2(pack_i16(lv[0], lv[1]), pack_i16(lv[2], lv[3]));
+  }
+  const bool has = *nz & 1;
+  if (has) mfma_stage(s.A, s.B, s.M8[1], s.rowsum[1], 7, wave, lane);                      // inverse columns
+  __syncthreads();
+  if (has) {
+    int acc[4];
+    mfma_tile_sums(s.B, s.M8[1], s.rowsum[1], wave, lane, acc);                            // inverse rows: residual (rows i0 .., column j)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      uint8_t *q = &s.px[(i0 + r) * 32 + j];
+      *q = (uint8_t)clip8(*q + ((acc[r] + 2048) >> 12));
+    }
+  }
+  __syncthreads();
+}
+
 // DEC = false: encoder (residual from the source picture, levels written out).
 // DEC = true: decoder (levels and cbf given, prediction + residual only).
 template <bool DEC>
@@ -349,7 +438,12 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
   const bool split = f.cu_log2[bi0] == 4;
   const int cw2 = f.cw >> 1, ch2 = f.ch >> 1;
   // matrices of the two block sizes in use (luma n, chroma n / 2): adjacent in the table
-  if (split) load_matrices(s.M, 16, 64 + 256, tid, 256); else load_matrices(s.M, 80, 256 + 1024, tid, 256);
+  if (split) load_matrices(s.M, 16, 64 + 256, tid, 256);
+  else {
+    load_matrices(s.M, 80, 256, tid, 256);                       // chroma 16-point matrices (dot2 path)
+    for (int i = tid; i < 1024; i += 256) { s.M8[0][i] = kDct32[i >> 5][i & 31]; s.M8[1][i] = kDct32[i & 31][i >> 5]; }
+    if (tid < 64) { const int t = tid >> 5, j = tid & 31; int a = 0; for (int m = 0; m < 32; m++) a += t ? kDct32[m][j] : kDct32[j][m]; s.rowsum[t][j] = a; }
+  }
   if (tid < 2) s.nz[tid] = 0;
   if (tid < 4) {
     int bi = b8idx(f, x0 + (tid & 1) * 16, y0 + (tid >> 1) * 16);
@@ -382,13 +476,11 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
   }
   __syncthreads();
   {
-    auto px32 = [](int, int y, int x) { return y * 32 + x; };
     auto px16 = [](int tu, int y, int x) { return ((tu >> 1) * 16 + y) * 32 + (tu & 1) * 16 + x; };
     const int cw = f.cw; int16_t *base = f.coef[0] + (size_t)y0 * cw + x0;
-    auto ci32 = [=](int, int y, int x) { return base + (size_t)y * cw + x; };
     auto ci16 = [=](int tu, int y, int x) { return base + (size_t)((tu >> 1) * 16 + y) * cw + (tu & 1) * 16 + x; };
     if (split) inter_transform<DEC, 4, 2>(s, f.qp, &s.nz[0], px16, ci16, tid);
-    else inter_transform<DEC, 5, 2>(s, f.qp, &s.nz[0], px32, ci32, tid);
+    else inter_transform_32<DEC>(s, f.qp, &s.nz[0], base, cw, tid);
   }
   *(uint32_t *)&f.rec[0][(size_t)(y0 + (tid >> 3)) * f.cw + x0 + (tid & 7) * 4] = *(const uint32_t *)&s.px[(tid >> 3) * 32 + (tid & 7) * 4];
   // ---- chroma: reference windows of the eight 8x8 sub-blocks (plane x quadrant) -> LDS; mv in 1/8 samples

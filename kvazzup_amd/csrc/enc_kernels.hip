@@ -562,116 +562,6 @@ __global__ __launch_bounds__(256) void k_inter_signal(EncFrame f)
 }
 
 // =============================================================================================
-// Intra: reference sample construction shared by analysis (source samples) and reconstruction
-// =============================================================================================
-// Builds left[0..2n] / top[0..2n] (8.4.4.2.2) of the n x n block at (x0, y0) (component samples)
-// from plane `p` (pitch pw); availability by picture bounds and z-scan order.  Uses raw[] / av[]
-// as LDS scratch of 4n+1 entries.  Must be called by all `nthreads` threads; ends synchronised.
-__device__ __forceinline__ void build_intra_refs(const uint8_t *p, int pw, int cidx, int cw, int ch, int x0, int y0, int n,
-                                                 uint8_t *raw, uint8_t *av, uint8_t *left, uint8_t *top, int tid, int nthreads)
-{
-  const int total = 4 * n + 1, sh = cidx ? 1 : 0;
-  for (int i = tid; i < total; i += nthreads) {
-    int x, y; intra_ref_coord(x0, y0, n, i, x, y);
-    bool ok = avail64(cw, ch, x0 << sh, y0 << sh, x << sh, y << sh);
-    av[i] = ok;
-    raw[i] = ok ? p[y * pw + x] : 0;
-  }
-  __syncthreads();
-  for (int i = tid; i < total; i += nthreads) {
-    int j = i;
-    while (j >= 0 && !av[j]) j--;
-    if (j < 0) { j = 0; while (j < total && !av[j]) j++; }
-    uint8_t v = (j < total) ? raw[j] : 128;
-    if (i < 2 * n) left[2 * n - i] = v;
-    else if (i == 2 * n) { left[0] = v; top[0] = v; }
-    else top[i - 2 * n] = v;
-  }
-  __syncthreads();
-}
-
-// filtered copies (8.4.4.2.3) of the reference arrays
-__device__ __forceinline__ void filter_intra_refs(const uint8_t *left, const uint8_t *top, int n, uint8_t *lf, uint8_t *tf, int tid, int nthreads)
-{
-  bool strong = intra_strong_filter(left, top, n);
-  for (int i = tid; i <= 2 * n; i += nthreads) {
-    lf[i] = (uint8_t)intra_filtered_ref(left, top, n, i, strong);
-    tf[i] = (uint8_t)intra_filtered_ref(top, left, n, i, strong);
-  }
-  __syncthreads();
-}
-__device__ __forceinline__ int intra_dc_value(const uint8_t *left, const uint8_t *top, int n, int log2n)
-{
-  int s = n;
-  for (int i = 0; i < n; i++) s += left[1 + i] + top[1 + i];
-  return s >> (log2n + 1);
-}
-
-__global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
-{
-  __shared__ uint8_t raw[132], av[132], left[68], top[68], lf[68], tf[68];
-  __shared__ uint32_t cost[35];
-  const int tid = threadIdx.x;
-  const int X0 = blockIdx.x * 32, Y0 = blockIdx.y * 32;
-  const uint8_t *src = f.src[0];
-  for (int l2 = 3; l2 <= 5; l2++) {
-    const int n = 1 << l2, nb = 32 >> l2;
-    for (int blk = 0; blk < nb * nb; blk++) {
-      const int x0 = X0 + (blk % nb) * n, y0 = Y0 + (blk / nb) * n;
-      build_intra_refs(src, f.cw, 0, f.cw, f.ch, x0, y0, n, raw, av, left, top, tid, 256);
-      if (n > 4) filter_intra_refs(left, top, n, lf, tf, tid, 256);
-      if (tid < 35) cost[tid] = 0;
-      __syncthreads();
-      const int dc = intra_dc_value(left, top, n, l2);
-      const int npx = n * n;
-      for (int w = tid; w < 35 * npx; w += 256) {
-        int m = w / npx, pxi = w - m * npx, y = pxi >> l2, x = pxi & (n - 1);
-        bool filt = intra_filter_needed(n, 0, m);
-        int p = intra_pred_sample(filt ? lf : left, filt ? tf : top, n, l2, 0, m, dc, x, y);
-        uint32_t d = (uint32_t)iabs((int)src[(y0 + y) * f.cw + x0 + x] - p);
-        // lanes of one wave may belong to different modes when npx < 64 is impossible (npx >= 64)
-        for (int o = 32; o > 0; o >>= 1) d += (uint32_t)__shfl_xor((int)d, o);
-        if ((tid & 63) == 0) atomicAdd(&cost[m], d);
-      }
-      __syncthreads();
-      if (tid == 0) {
-        uint32_t bc = 0xffffffffu; int bm = 0;
-        for (int m = 0; m < 35; m++) if (cost[m] < bc) { bc = cost[m]; bm = m; }
-        int bw = f.cw >> l2, ib = (y0 >> l2) * bw + (x0 >> l2);
-        if (l2 == 3) { f.im8[ib] = (uint8_t)bm; f.ic8[ib] = bc; }
-        else if (l2 == 4) { f.im16[ib] = (uint8_t)bm; f.ic16[ib] = bc; }
-        else { f.im32[ib] = (uint8_t)bm; f.ic32[ib] = bc; }
-      }
-      __syncthreads();
-    }
-  }
-  // bottom-up split decision for this 32x32 block
-  if (tid == 0) {
-    uint32_t pen = ((uint32_t)f.lambda_q4 * SPLIT_BITS) >> 4;
-    int w8 = f.cw >> 3, w16 = f.cw >> 4, w32 = f.cw >> 5, x32 = X0 >> 5, y32 = Y0 >> 5;
-    uint32_t c16sum = 0; bool split16[4];
-    for (int k = 0; k < 4; k++) {
-      int x16 = x32 * 2 + (k & 1), y16 = y32 * 2 + (k >> 1);
-      uint32_t c8 = pen;
-      for (int j = 0; j < 4; j++) c8 += f.ic8[(y16 * 2 + (j >> 1)) * w8 + x16 * 2 + (j & 1)];
-      uint32_t c16 = f.ic16[y16 * w16 + x16];
-      split16[k] = c8 < c16;
-      c16sum += split16[k] ? c8 : c16;
-    }
-    bool split32 = (c16sum + pen) < f.ic32[y32 * w32 + x32];
-    for (int j = 0; j < 16; j++) {
-      int bx = j & 3, by = j >> 2, k = (by >> 1) * 2 + (bx >> 1);
-      int x8 = (X0 >> 3) + bx, y8 = (Y0 >> 3) + by, i = y8 * w8 + x8;
-      int l2, mode;
-      if (!split32) { l2 = 5; mode = f.im32[y32 * w32 + x32]; }
-      else if (!split16[k]) { l2 = 4; mode = f.im16[(y8 >> 1) * w16 + (x8 >> 1)]; }
-      else { l2 = 3; mode = f.im8[i]; }
-      f.cu_log2[i] = (uint8_t)l2; f.cu_intra_mode[i] = (uint8_t)mode; f.cu_intra[i] = 1; f.cu_flags[i] = 0;
-    }
-  }
-}
-
-// =============================================================================================
 // Intra reconstruction.  Intra prediction of a block needs the reconstructed samples of its left /
 // above neighbours, so inside one colour plane the blocks of a picture form a dependency chain:
 // z-order inside a CTU, a two-CTU lag between CTU rows.  What is independent is the three colour
@@ -743,6 +633,149 @@ __device__ __forceinline__ int pred_angular(const uint8_t *R, bool vert, bool ed
   const int t = (b + 1) * angle, k0 = a + (t >> 5) + 1, k1 = k0 + 1, fact = t & 31;
   const int i0 = k0 >= 0 ? k0 : -((k0 * inv + 128) >> 8), i1 = k1 >= 0 ? k1 : -((k1 * inv + 128) >> 8);
   return ((32 - fact) * R[2 * N + sgn * i0] + fact * R[2 * N + sgn * i1] + 16) >> 5;
+}
+
+// =============================================================================================
+// Intra analysis (IDR pictures): for every 8x8, 16x16 and 32x32 block of a 32x32 region the SAD of all 35
+// prediction modes against the SOURCE picture, predictions built from source neighbours (so nothing depends
+// on reconstruction and the whole picture is searched in parallel); then the bottom-up split decision.
+// The reference arrays of all 21 blocks are built once into LDS (scan order, as in the reconstruction
+// kernel); a work item is (block, mode), one wave each: the mode is wave-uniform, 64 samples per step, the
+// SAD is summed with DPP row operations.
+// =============================================================================================
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);   // row_mirror: every lane holds its row-of-16 sum
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+         (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+struct AnalyseLds {
+  alignas(16) uint8_t src[32 * 32];
+  // per block b (0..15: 8x8 raster, 16..19: 16x16 raster, 20: 32x32): unfiltered / filtered references, scan order, at
+  // R[f][roff(b)]; sizes 33 / 65 / 129 entries
+  alignas(16) uint8_t R[2][16 * 36 + 4 * 68 + 132];
+  int dc[21];
+  uint32_t cost[21][35];
+  uint32_t bestc[21]; int bestm[21];
+};
+__device__ __forceinline__ int an_roff(int b) { return b < 16 ? b * 36 : (b < 20 ? 16 * 36 + (b - 16) * 68 : 16 * 36 + 4 * 68); }
+
+template <int L2>
+__device__ __forceinline__ uint32_t analyse_item(const AnalyseLds &s, int b, int bx, int by, int mode, int lane)
+{
+  constexpr int N = 1 << L2;
+  const bool filt = intra_filter_needed(N, 0, mode);
+  const uint8_t *R = s.R[filt ? 1 : 0] + an_roff(b);
+  const int angle = kIntraAngle[mode], inv = kInvAngle[mode];
+  const bool edge = N < 32, vert = mode >= 18, e2 = edge && (mode == 26 || mode == 10);
+  const int dcv = s.dc[b];
+  uint32_t sad = 0;
+#pragma unroll
+  for (int it = 0; it < N * N / 64; it++) {
+    const int pxi = it * 64 + lane, y = pxi >> L2, x = pxi & (N - 1);
+    int p;
+    if (mode == 0) p = pred_planar<L2>(R, x, y);
+    else if (mode == 1) p = pred_dc<L2>(R, edge, dcv, x, y);
+    else p = pred_angular<L2>(R, vert, e2, angle, inv, x, y);
+    sad += (uint32_t)iabs((int)s.src[(by + y) * 32 + bx + x] - p);
+  }
+  return wave_sum_u32(sad);
+}
+
+__global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
+{
+  __shared__ AnalyseLds s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int X0 = blockIdx.x * 32, Y0 = blockIdx.y * 32;
+  const uint8_t *src = f.src[0];
+  *(uint32_t *)&s.src[tid * 4] = *(const uint32_t *)&src[(size_t)(Y0 + (tid >> 3)) * f.cw + X0 + (tid & 7) * 4];
+  // ---- references of the 21 blocks from the source picture (8.4.4.2.2 substitution as an index clamp: the available
+  // groups are contiguous in scan order; availability by picture bounds and z-scan order)
+  for (int e = tid; e < 16 * 33 + 4 * 65 + 129; e += 256) {
+    int b, i, l2;
+    if (e < 16 * 33) { b = e / 33; i = e - b * 33; l2 = 3; } else if (e < 16 * 33 + 4 * 65) { int r = e - 16 * 33; b = 16 + r / 65; i = r % 65; l2 = 4; } else { b = 20; i = e - 16 * 33 - 4 * 65; l2 = 5; }
+    const int n = 1 << l2, bi = b < 16 ? b : (b < 20 ? b - 16 : 0), nb = 32 >> l2;
+    const int x0 = X0 + (bi % nb) * n, y0 = Y0 + (bi / nb) * n;
+    const bool aL = x0 > 0, aT = y0 > 0;
+    const bool aBL = aL && avail64(f.cw, f.ch, x0, y0, x0 - 1, y0 + n), aTR = aT && avail64(f.cw, f.ch, x0, y0, x0 + n, y0 - 1);
+    const int lo = aBL ? 0 : (aL ? n : 2 * n + 1), hi = aTR ? 4 * n : (aT ? 3 * n : (aL ? 2 * n - 1 : -1));
+    int v = 128;
+    if (hi >= 0) {
+      const int j = imin(imax(i, lo), hi);
+      const int x = j < 2 * n ? x0 - 1 : x0 + j - 2 * n - 1, y = j < 2 * n ? y0 + 2 * n - 1 - j : y0 - 1;
+      v = src[(size_t)y * f.cw + x];
+    }
+    s.R[0][an_roff(b) + i] = (uint8_t)v;
+  }
+  __syncthreads();
+  // ---- filtered references (8.4.4.2.3) and DC values
+  for (int e = tid; e < 16 * 33 + 4 * 65 + 129; e += 256) {
+    int b, i, l2;
+    if (e < 16 * 33) { b = e / 33; i = e - b * 33; l2 = 3; } else if (e < 16 * 33 + 4 * 65) { int r = e - 16 * 33; b = 16 + r / 65; i = r % 65; l2 = 4; } else { b = 20; i = e - 16 * 33 - 4 * 65; l2 = 5; }
+    const int n = 1 << l2;
+    const uint8_t *R = s.R[0] + an_roff(b);
+    int fv = R[i];
+    if (i != 0 && i != 4 * n) {
+      const bool strong = n == 32 && iabs(R[2 * n] + R[4 * n] - 2 * R[3 * n]) < 8 && iabs(R[2 * n] + R[0] - 2 * R[n]) < 8;
+      if (strong) { if (i != 2 * n) { int k = i < 2 * n ? 2 * n - i : i - 2 * n; fv = ((64 - k) * R[2 * n] + k * (i < 2 * n ? R[0] : R[4 * n]) + 32) >> 6; } }
+      else fv = (R[i - 1] + 2 * R[i] + R[i + 1] + 2) >> 2;
+    }
+    s.R[1][an_roff(b) + i] = (uint8_t)fv;
+  }
+  if (tid < 21) {
+    const int l2 = tid < 16 ? 3 : (tid < 20 ? 4 : 5), n = 1 << l2;
+    const uint8_t *R = s.R[0] + an_roff(tid);
+    int a = n;
+    for (int i = n; i <= 3 * n; i++) a += R[i];
+    s.dc[tid] = (a - R[2 * n]) >> (l2 + 1);
+  }
+  __syncthreads();
+  // ---- SAD of every (block, mode)
+  for (int item = wave; item < 21 * 35; item += 4) {
+    const int b = item / 35, mode = item - b * 35;
+    uint32_t c;
+    if (b < 16) c = analyse_item<3>(s, b, (b & 3) * 8, (b >> 2) * 8, mode, lane);
+    else if (b < 20) c = analyse_item<4>(s, b, ((b - 16) & 1) * 16, ((b - 16) >> 1) * 16, mode, lane);
+    else c = analyse_item<5>(s, b, 0, 0, mode, lane);
+    if (lane == 0) s.cost[b][mode] = c;
+  }
+  __syncthreads();
+  if (tid < 21) {
+    uint32_t bc = 0xffffffffu; int bm = 0;
+    for (int m = 0; m < 35; m++) if (s.cost[tid][m] < bc) { bc = s.cost[tid][m]; bm = m; }
+    s.bestc[tid] = bc; s.bestm[tid] = bm;
+    const int l2 = tid < 16 ? 3 : (tid < 20 ? 4 : 5), n = 1 << l2, bi = tid < 16 ? tid : (tid < 20 ? tid - 16 : 0), nb = 32 >> l2;
+    const int x0 = X0 + (bi % nb) * n, y0 = Y0 + (bi / nb) * n;
+    const int bw = f.cw >> l2, ib = (y0 >> l2) * bw + (x0 >> l2);
+    if (l2 == 3) { f.im8[ib] = (uint8_t)bm; f.ic8[ib] = bc; }
+    else if (l2 == 4) { f.im16[ib] = (uint8_t)bm; f.ic16[ib] = bc; }
+    else { f.im32[ib] = (uint8_t)bm; f.ic32[ib] = bc; }
+  }
+  __syncthreads();
+  // ---- bottom-up split decision for this 32x32 block: thread per 8x8 cell
+  if (tid < 16) {
+    const uint32_t pen = ((uint32_t)f.lambda_q4 * SPLIT_BITS) >> 4;
+    uint32_t c16sum = 0; bool split16[4];
+    for (int k = 0; k < 4; k++) {
+      uint32_t c8 = pen;
+      for (int j = 0; j < 4; j++) c8 += s.bestc[((k >> 1) * 2 + (j >> 1)) * 4 + (k & 1) * 2 + (j & 1)];
+      const uint32_t c16 = s.bestc[16 + k];
+      split16[k] = c8 < c16;
+      c16sum += split16[k] ? c8 : c16;
+    }
+    const bool split32 = (c16sum + pen) < s.bestc[20];
+    const int bx = tid & 3, by = tid >> 2, k = (by >> 1) * 2 + (bx >> 1);
+    const int i = ((Y0 >> 3) + by) * (f.cw >> 3) + (X0 >> 3) + bx;
+    int l2, mode;
+    if (!split32) { l2 = 5; mode = s.bestm[20]; }
+    else if (!split16[k]) { l2 = 4; mode = s.bestm[16 + k]; }
+    else { l2 = 3; mode = s.bestm[tid]; }
+    f.cu_log2[i] = (uint8_t)l2; f.cu_intra_mode[i] = (uint8_t)mode; f.cu_intra[i] = 1; f.cu_flags[i] = 0;
+  }
 }
 
 // One plane of one CU: block of n = 1 << L2 component samples at CTU-relative (rx, ry); (X, Y) = luma position

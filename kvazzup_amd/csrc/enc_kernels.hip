@@ -92,6 +92,13 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
   __syncthreads();
   const uint32_t lam = (uint32_t)f.lambda_q4;
   uint32_t best[5] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  // tile constraint (statement: me_block32() in oracle/hevc_enc.c): the displaced 32x32 block, plus 4 rows each side for
+  // the chroma half-sample taps when the displacement is odd, stays inside its tile -- except across the picture's own edges
+  int ty0 = 0, ty1 = f.ch;
+  if (f.tile_rows > 1) {
+    const int hc = f.ch >> 6, tr = tile_row_of(hc, f.tile_rows, y0 >> 6);
+    ty0 = tile_row_first(hc, f.tile_rows, tr) * 64; ty1 = tile_row_first(hc, f.tile_rows, tr + 1) * 64;
+  }
   const int NQ = (W + 3) >> 2, NG = (W + 1) >> 1;
   for (int item = tid; item < NQ * NG; item += nthreads) {
     const int g = item / NQ, q = item - g * NQ, dy0 = 2 * g;
@@ -129,6 +136,7 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
     for (int e = 0; e < 2; e++) {
       const int dyi = dy0 + e;
       if (dyi >= W) continue;
+      { const int dy = dyi - R, m = (dy & 1) ? 4 : 0; if ((ty0 > 0 && y0 + dy - m < ty0) || (ty1 < f.ch && y0 + dy + 32 + m > ty1)) continue; }
       const int ry = mvd_bits((dyi - R) * 4);
 #pragma unroll
       for (int k4 = 0; k4 < 4; k4++) {
@@ -700,8 +708,8 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
     if (e < 16 * 33) { b = e / 33; i = e - b * 33; l2 = 3; } else if (e < 16 * 33 + 4 * 65) { int r = e - 16 * 33; b = 16 + r / 65; i = r % 65; l2 = 4; } else { b = 20; i = e - 16 * 33 - 4 * 65; l2 = 5; }
     const int n = 1 << l2, bi = b < 16 ? b : (b < 20 ? b - 16 : 0), nb = 32 >> l2;
     const int x0 = X0 + (bi % nb) * n, y0 = Y0 + (bi / nb) * n;
-    const bool aL = x0 > 0, aT = y0 > 0;
-    const bool aBL = aL && avail64(f.cw, f.ch, x0, y0, x0 - 1, y0 + n), aTR = aT && avail64(f.cw, f.ch, x0, y0, x0 + n, y0 - 1);
+    const bool aL = x0 > 0, aT = avail64(f.cw, f.chp, x0, y0, x0, y0 - 1);
+    const bool aBL = aL && avail64(f.cw, f.chp, x0, y0, x0 - 1, y0 + n), aTR = aT && avail64(f.cw, f.chp, x0, y0, x0 + n, y0 - 1);
     const int lo = aBL ? 0 : (aL ? n : 2 * n + 1), hi = aTR ? 4 * n : (aT ? 3 * n : (aL ? 2 * n - 1 : -1));
     int v = 128;
     if (hi >= 0) {
@@ -793,8 +801,8 @@ __device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, 
   // which either precedes this block in z-order or does not.  The available groups are contiguous in scan order,
   // so the substitution process is a clamp of the scan index into [lo, hi].
   {
-    const bool aL = X > 0, aT = Y > 0;
-    const bool aBL = aL && avail64(f.cw, f.ch, X, Y, X - 1, Y + nl), aTR = aT && avail64(f.cw, f.ch, X, Y, X + nl, Y - 1);
+    const bool aL = X > 0, aT = avail64(f.cw, f.chp, X, Y, X, Y - 1);
+    const bool aBL = aL && avail64(f.cw, f.chp, X, Y, X - 1, Y + nl), aTR = aT && avail64(f.cw, f.chp, X, Y, X + nl, Y - 1);
     const int lo = aBL ? 0 : (aL ? N : 2 * N + 1), hi = aTR ? 4 * N : (aT ? 3 * N : (aL ? 2 * N - 1 : -1));
     auto fetch = [&](int i) -> int {
       const int j = imin(imax(i, lo), hi);
@@ -967,7 +975,8 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
       for (int k = lane; k < S * S / 8; k += T) { int y = k / (S / 8), xq = k % (S / 8); *(uint4 *)&s.lev[y * S + xq * 8] = *(const uint4 *)&gcoef[(size_t)y * pw + xq * 8]; }
     }
     PROF(0);
-    if (row > 0) {
+    const bool has_above = row > 0 && !tile_row_starts_at(f.ch >> 6, f.tile_rows, row);
+    if (has_above) {
       // The CTU above must be finished before this one starts; the CTU above-right only before the block in the top
       // right corner of this CTU (the only one whose above-right references reach into it) -- waited for there,
       // which shortens the lag between CTU rows from two CTUs to about one and a half.
@@ -986,7 +995,7 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
       int xi, yi; ctu_z_to_xy(z, xi, yi);
       const int X = cx * 64 + xi * 8, Y = row * 64 + yi * 8, rx = (xi * 8) >> sh, ry = (yi * 8) >> sh;
       const bool has = DEC && ((given >> c) & 1);
-      if (row > 0 && cx + 1 < wc && ry == 0 && rx + (1 << (l2 - sh)) == S) {       // wave-uniform: the top-right block
+      if (has_above && cx + 1 < wc && ry == 0 && rx + (1 << (l2 - sh)) == S) {       // wave-uniform: the top-right block
         wait_progress(up_ctr, (uint32_t)(cx + 2), f.err);
         for (int k = lane; k < S; k += T) s.pic[15 + S + 1 + k] = f.rec[c][(size_t)(row * S - 1) * pw + (cx + 1) * S + k];
         __syncthreads();
@@ -1169,8 +1178,8 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
     for (int b = 0; b < 3; b++) z |= ((((x0 & 63) >> 3) >> b) & 1) << (2 * b) | ((((y0 & 63) >> 3) >> b) & 1) << (2 * b + 1);
     if (lane == 0 && comp == 0) {
       TokOut t; t.tabs = &tabs; t.p = hdr; t.n = 0; t.cap = TOK_HDR_CAP;
-      enc_split_flags(v, t, f.cw, f.ch, x0, y0, z, cu.log2);
-      enc_cu_header(v, t, f.cw, f.ch, f.is_intra != 0, x0, y0, cu);
+      enc_split_flags(v, t, f.cw, f.chp, x0, y0, z, cu.log2);
+      enc_cu_header(v, t, f.cw, f.chp, f.is_intra != 0, x0, y0, cu);
       hdr_n = t.n;
     }
     const int cbf = (cu.flags & CU_SKIP) ? 0 : cu.cbf;          // wave-uniform
@@ -1243,7 +1252,8 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
   }
   if (z4 == 15 && comp == 0) {                                      // the last unit of the CTU closes it
     const bool last = (cy == hc - 1 && cx == wc - 1);
-    const int n = 1 + ((f.wpp && !last && cx == wc - 1) ? 1 : 0);
+    const bool sub_end = cx == wc - 1 && (f.wpp || tile_row_ends_at(hc, f.tile_rows, cy));
+    const int n = 1 + ((sub_end && !last) ? 1 : 0);
     __syncthreads();
     np = 16;
     const uint32_t o = reserve(n);

@@ -26,6 +26,7 @@ struct EncoderConfig {
   int me_range = 16;
   int fps_num = 30, fps_den = 1;
   int wpp = 1, deblock = 1;
+  int tile_rows = 1;          // full-width tile rows (kvazaar "tiles" 1xN), uniform spacing, loop filter across tiles on
   int device = 0;
   int entropy_threads = 16;   // host threads of the arithmetic-coding stage
   int bitrate = 0;            // bits per second; 0 = constant QP, > 0 = "uvgx rate control v1" (oracle/hevc_enc.c rate_control())

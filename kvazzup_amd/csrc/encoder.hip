@@ -25,6 +25,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
     if (error) *error = "unsupported picture size"; return false;
   }
   if (cfg.qp < 0 || cfg.qp > 51 || cfg.me_range < 1 || cfg.me_range > 32) { if (error) *error = "qp or me-range out of range"; return false; }
+  if (cfg.tile_rows < 1 || cfg.tile_rows > (cfg.height + 63) / 64) { if (error) *error = "tile rows out of range"; return false; }
   cfg_ = cfg;
   qp_cur_ = cfg.qp;
   int ndev = 0;
@@ -91,6 +92,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
 
   memset(&f_, 0, sizeof(f_));
   f_.cw = cw_; f_.ch = ch_; f_.b8w = cw_ / 8; f_.b8h = ch_ / 8;
+  f_.tile_rows = cfg.tile_rows; f_.chp = pack_height(ch_, cfg.tile_rows);
   f_.qp = cfg.qp; f_.qpc = kChromaQp[cfg.qp]; f_.lambda_q4 = kLambdaQ4[cfg.qp]; f_.range = cfg.me_range;
   f_.wpp = cfg.wpp;
   bind_set(0);
@@ -101,7 +103,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   f_.tok_dense_cap = (uint32_t)tok_dense_cap_;
   f_.sync = sync_; f_.err = err_;
 
-  sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp;
+  sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp; sp_.tile_rows = cfg.tile_rows;
   sp_.deblock = cfg.deblock; sp_.fps_num = cfg.fps_num; sp_.fps_den = cfg.fps_den;
   HIP_OK(hipStreamSynchronize(stream_));
   HIP_OK(hipDeviceSynchronize());
@@ -326,11 +328,11 @@ bool Encoder::finish_slot(Slot &sl, EncodedPicture *out)
     sl.ev_used = 0;
   }
   // ---- serial half of entropy coding: host threads turn the bins into the WPP substreams
-  const int nsub = cfg_.wpp ? rows_ : 1;
+  const int nsub = cfg_.wpp ? rows_ : cfg_.tile_rows;
   uint64_t bins = 0;
   Tick tk_ar;
   for (int i = 0, n = (cw_ / 64) * rows_; i < n; i++) if (sl.h_tok_count[i] < 0) { fprintf(stderr, "kvazzup_amd: token array overflow (CTU %d)\n", i); return false; }
-  entropy_->code_picture(sl.h_tok_dense, sl.h_tok_count, sl.h_tok_off, cw_ / 64, rows_, cfg_.wpp != 0, sl.intra ? 0 : 1, sl.qp, rows_out_, &bins);
+  entropy_->code_picture(sl.h_tok_dense, sl.h_tok_count, sl.h_tok_off, cw_ / 64, rows_, cfg_.wpp != 0, cfg_.tile_rows, sl.intra ? 0 : 1, sl.qp, rows_out_, &bins);
   const double ar = tk_ar.ms();
   if (profiling_) { std::lock_guard<std::mutex> l(stat_m_); k_ms_[K_HOST_ARITH] += ar; k_n_[K_HOST_ARITH]++; }
   t_arith_ += ar;

@@ -24,11 +24,11 @@ class EntropyHost {
   explicit EntropyHost(int max_threads) : pool_(max_threads) { for (int i = 0; i < 64; i++) core_tabs_fill_entry(tabs_, i); }
   // Codes one picture.  tokens: dense token array; CTU i has count[i] tokens starting at offset[i].
   // rows_out[r] receives the bytes of substream r (one per CTU row with WPP, else a single one).
-  void code_picture(const uint16_t *tokens, const int32_t *count, const uint32_t *offset, int wc, int hc, bool wpp, int init_type, int qp,
+  void code_picture(const uint16_t *tokens, const int32_t *count, const uint32_t *offset, int wc, int hc, bool wpp, int tile_rows, int init_type, int qp,
                     std::vector<std::vector<uint8_t>> &rows_out, uint64_t *bins)
   {
-    tokens_ = tokens; count_ = count; offset_ = offset; wc_ = wc; hc_ = hc; wpp_ = wpp; init_type_ = init_type; qp_ = qp;
-    const int nsub = wpp ? hc : 1;
+    tokens_ = tokens; count_ = count; offset_ = offset; wc_ = wc; hc_ = hc; wpp_ = wpp; tiles_ = tile_rows < 1 ? 1 : tile_rows; init_type_ = init_type; qp_ = qp;
+    const int nsub = wpp ? hc : tiles_;
     rows_out.resize((size_t)nsub);
     rows_ = &rows_out;
     saved_.resize((size_t)hc * CTX_COUNT);
@@ -40,17 +40,20 @@ class EntropyHost {
   }
 
  private:
+  // substream r: CTU row r with WPP, else tile row r (all of its CTU rows)
   void code_row(int r)
   {
     uint8_t ctx[CTX_COUNT];
     std::vector<uint8_t> &out = (*rows_)[(size_t)r];
-    const int first_cy = wpp_ ? r : 0, ncy = wpp_ ? 1 : hc_;
+    const int first_cy = wpp_ ? r : tile_row_first(hc_, tiles_, r), ncy = wpp_ ? 1 : tile_row_first(hc_, tiles_, r + 1) - first_cy;
     size_t ntok = 0;
     for (int cy = first_cy; cy < first_cy + ncy; cy++) for (int cx = 0; cx < wc_; cx++) ntok += (size_t)count_[(size_t)cy * wc_ + cx];
     out.resize(ntok * 2 + 64);                    // a token never produces more than two bytes
     CabacEnc c; c.nbins = 0;
     cabac_start(c, out.data(), (int)out.size(), ctx, &tabs_);
-    if (r == 0 || !wpp_) cabac_init_contexts(ctx, init_type_, qp_);
+    // contexts: initialised at the first CTU of a tile (9.3.1), else (WPP) inherited from the row above after its second CTU
+    const bool fresh = !wpp_ || tile_row_starts_at(hc_, tiles_, r);
+    if (fresh) cabac_init_contexts(ctx, init_type_, qp_);
     else {
       while (!ready_[(size_t)(r - 1)].load(std::memory_order_acquire)) std::this_thread::yield();
       memcpy(ctx, &saved_[(size_t)(r - 1) * CTX_COUNT], CTX_COUNT);
@@ -72,7 +75,7 @@ class EntropyHost {
   OrderedPool pool_;
   CoreTabs tabs_;
   const uint16_t *tokens_ = nullptr; const int32_t *count_ = nullptr; const uint32_t *offset_ = nullptr;
-  int wc_ = 0, hc_ = 0, init_type_ = 0, qp_ = 0; bool wpp_ = true;
+  int wc_ = 0, hc_ = 0, tiles_ = 1, init_type_ = 0, qp_ = 0; bool wpp_ = true;
   std::vector<uint8_t> saved_;
   std::unique_ptr<std::atomic<int>[]> ready_;
   std::vector<std::vector<uint8_t>> *rows_ = nullptr;

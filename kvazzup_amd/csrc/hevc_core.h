@@ -32,6 +32,8 @@ struct EncFrame {
   int qp, qpc, lambda_q4, range;
   int is_intra, poc;
   int wpp;
+  int tile_rows;            // 1: no tiles; n: n full-width tile rows, uniform spacing (6.5.1)
+  int chp;                  // ch | tile rows << 20: the `ch` argument of avail64() and of everything that forwards to it
   const uint8_t *src[3];
   uint8_t *rec[3];
   const uint8_t *ref[3];
@@ -63,10 +65,18 @@ KVZ_HD uint32_t zaddr64(int x, int y, int w_ctbs)
   yi = (yi | (yi << 2)) & 0x33u; yi = (yi | (yi << 1)) & 0x55u;
   return (ctb << 8) | xi | (yi << 1);
 }
-// H.265 6.4.1 for one slice, one tile
-KVZ_HD bool avail64(int cw, int ch, int xc, int yc, int xn, int yn)
+// Tiles are full-width rows with uniform spacing: tile row i starts at CTB row (i * hc) / T (6.5.1).
+KVZ_HD int tile_row_of(int hc, int T, int cy) { return ((cy + 1) * T - 1) / hc; }
+KVZ_HD int tile_row_first(int hc, int T, int i) { return (i * hc) / T; }
+KVZ_HD bool tile_row_starts_at(int hc, int T, int cy) { return T <= 1 ? cy == 0 : tile_row_first(hc, T, tile_row_of(hc, T, cy)) == cy; }
+KVZ_HD bool tile_row_ends_at(int hc, int T, int cy) { return T <= 1 ? cy == hc - 1 : (cy == hc - 1 || tile_row_of(hc, T, cy + 1) != tile_row_of(hc, T, cy)); }
+KVZ_HD int pack_height(int ch, int tile_rows) { return ch | ((tile_rows > 1 ? tile_rows : 0) << 20); }
+// H.265 6.4.1 for one slice; chp = coded height | tile rows << 20 (pack_height): a neighbour in another tile is unavailable
+KVZ_HD bool avail64(int cw, int chp, int xc, int yc, int xn, int yn)
 {
+  const int ch = chp & 0xfffff, T = chp >> 20;
   if (xn < 0 || yn < 0 || xn >= cw || yn >= ch) return false;
+  if (T > 1 && tile_row_of(ch >> 6, T, yn >> 6) != tile_row_of(ch >> 6, T, yc >> 6)) return false;
   return zaddr64(xn, yn, cw >> 6) <= zaddr64(xc, yc, cw >> 6);
 }
 
@@ -676,8 +686,8 @@ KVZ_HD void enc_ctu(const EncFrame &f, CabacEnc &c, int cx, int cy)
     int xi, yi; ctu_z_to_xy(z, xi, yi);
     int x0 = cx + xi * 8, y0 = cy + yi * 8;
     CuRec cu = v.at(x0, y0);
-    enc_split_flags(v, c, f.cw, f.ch, x0, y0, z, cu.log2);
-    int cbf = enc_cu_header(v, c, f.cw, f.ch, f.is_intra != 0, x0, y0, cu);
+    enc_split_flags(v, c, f.cw, f.chp, x0, y0, z, cu.log2);
+    int cbf = enc_cu_header(v, c, f.cw, f.chp, f.is_intra != 0, x0, y0, cu);
     if (cbf & 1) enc_residual(c, f.coef[0] + y0 * f.cw + x0, f.cw, cu.log2, 0, intra_scan_idx(cu.intra, cu.log2, 0, cu.intra_mode));
     for (int ci = 1; ci <= 2; ci++)
       if ((cbf >> ci) & 1)
@@ -705,7 +715,7 @@ struct NbMv { bool ok; int mx, my; };
 KVZ_HD NbMv nb_mv(const EncFrame &f, int xc, int yc, int xn, int yn)
 {
   NbMv r; r.ok = false; r.mx = r.my = 0;
-  if (!avail64(f.cw, f.ch, xc, yc, xn, yn)) return r;
+  if (!avail64(f.cw, f.chp, xc, yc, xn, yn)) return r;
   int i = b8idx(f, xn, yn);
   if (f.cu_intra[i]) return r;
   r.ok = true; r.mx = f.cu_mv[i * 2]; r.my = f.cu_mv[i * 2 + 1];

@@ -27,6 +27,7 @@ struct StreamParams {
   int width, height;        // display size (conformance window)
   int qp, wpp, deblock;
   int fps_num, fps_den;
+  int tile_rows = 1;        // > 1: tiles_enabled_flag, one column, uniform spacing, loop filter across tiles on
 };
 
 inline int level_idc_for(int w, int h)
@@ -87,7 +88,8 @@ inline void write_pps(BitWriter &w, const StreamParams &s)
   w.bit(0); w.bit(0); w.bit(0);                                  // constrained intra, transform skip, cu_qp_delta
   w.se(0); w.se(0); w.bit(0);
   w.bit(0); w.bit(0); w.bit(0);
-  w.bit(0); w.bit(s.wpp);                                        // tiles, entropy_coding_sync
+  w.bit(s.tile_rows > 1); w.bit(s.wpp);                          // tiles, entropy_coding_sync
+  if (s.tile_rows > 1) { w.ue(0); w.ue((uint32_t)s.tile_rows - 1); w.bit(1); w.bit(1); }   // columns - 1, rows - 1, uniform spacing, loop filter across tiles
   w.bit(1);                                                      // loop filter across slices
   w.bit(!s.deblock);
   if (!s.deblock) { w.bit(0); w.bit(1); }
@@ -116,7 +118,7 @@ inline void write_slice_header(BitWriter &w, const StreamParams &s, bool idr, in
   w.se(slice_qp_delta);                                          // against the PPS init_qp (= the configured QP)
   // (deblocking override not enabled; slice_loop_filter_across_slices_enabled_flag present when deblocking is on)
   if (s.deblock) w.bit(1);
-  if (s.wpp) {
+  if (s.wpp || s.tile_rows > 1) {
     w.ue((uint32_t)entry_sizes.size());
     if (!entry_sizes.empty()) {
       uint32_t mx = 0; for (uint32_t e : entry_sizes) if (e - 1 > mx) mx = e - 1;

@@ -92,7 +92,7 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
     int a = 0, b = 0;
     if (sscanf(value, "%dx%d", &a, &b) != 2 || a < 1 || b < 1) return 0;
     cfg->tiles_width_count = a; cfg->tiles_height_count = b;
-    return (a == 1 && b == 1) ? 1 : 0;            // tile partitioning is not implemented
+    return a == 1 ? 1 : 0;                        // tile ROWS (1xN, uniform spacing) are implemented, tile columns are not
   }
   if (n == "slices") {
     if (!strcmp(value, "wpp")) { cfg->slices = KVZ_SLICES_WPP; return 1; }
@@ -231,11 +231,12 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
 {
   if (!cfg) return nullptr;
   if (cfg->lossless) { fprintf(stderr, "kvazzup_amd: lossless coding is not implemented\n"); return nullptr; }
-  if (cfg->tiles_width_count != 1 || cfg->tiles_height_count != 1) { fprintf(stderr, "kvazzup_amd: tiles are not implemented\n"); return nullptr; }
+  if (cfg->tiles_width_count > 1) { fprintf(stderr, "kvazzup_amd: tile columns are not implemented (use tiles=1xN)\n"); return nullptr; }
   EncoderConfig ec;
   ec.width = cfg->width; ec.height = cfg->height; ec.qp = cfg->qp; ec.intra_period = cfg->intra_period; ec.vps_period = cfg->vps_period;
   ec.me_range = cfg->me_range; ec.fps_num = cfg->framerate_num; ec.fps_den = cfg->framerate_denom;
   ec.wpp = cfg->wpp ? 1 : 0; ec.deblock = cfg->deblock_enable ? 1 : 0; ec.device = cfg->gpu_device; ec.owf = cfg->owf > 2 ? 2 : cfg->owf;
+  ec.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1;
   ec.bitrate = cfg->target_bitrate > 0 ? cfg->target_bitrate : 0;      // any rc-algorithm value selects the one picture-level controller
   std::string err;
   Encoder *impl = Encoder::create(ec, &err);
@@ -269,7 +270,7 @@ int encoder_headers(kvz_encoder *e, kvz_data_chunk **data_out, uint32_t *len_out
   kvzx::StreamParams sp;
   const EncoderConfig &c = e->impl->config();
   sp.cw = e->impl->coded_width(); sp.ch = e->impl->coded_height(); sp.width = c.width; sp.height = c.height; sp.qp = c.qp;
-  sp.wpp = c.wpp; sp.deblock = c.deblock; sp.fps_num = c.fps_num; sp.fps_den = c.fps_den;
+  sp.wpp = c.wpp; sp.deblock = c.deblock; sp.fps_num = c.fps_num; sp.fps_den = c.fps_den; sp.tile_rows = c.tile_rows;
   std::vector<uint8_t> out;
   kvzx::BitWriter a, b, d;
   kvzx::write_vps(a, sp); kvzx::append_nal(out, 32, a.data().data(), a.data().size());

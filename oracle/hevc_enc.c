@@ -39,6 +39,8 @@ struct orc_encoder {
   uint8_t *im8, *im16, *im32; uint32_t *ic8, *ic16, *ic32;
   orc_bitw au;
   orc_avail_ctx av;
+  int16_t *ctb_tile;                   /* tile id of every CTB (raster); NULL without tiles */
+  int *tile_row_bd;                    /* first CTB row of tile row i, i = 0 .. tile_rows */
   int is_intra;
   uint64_t bins;
 };
@@ -47,7 +49,7 @@ void orc_enc_default_config(orc_enc_config *c)
 {
   memset(c, 0, sizeof(*c));
   c->qp = 32; c->intra_period = 64; c->vps_period = 1; c->search_range = 16;
-  c->fps_num = 30; c->fps_den = 1; c->wpp = 1; c->deblock = 1;
+  c->fps_num = 30; c->fps_den = 1; c->wpp = 1; c->deblock = 1; c->tile_rows = 1;
 }
 
 int orc_mvd_bits(int q)
@@ -71,7 +73,7 @@ static int level_for(int w, int h)
 orc_encoder *orc_enc_open(const orc_enc_config *c)
 {
   if (c->width < 16 || c->height < 16 || (c->width & 1) || (c->height & 1) || c->qp < 0 || c->qp > 51 ||
-      c->search_range < 0 || c->search_range > 32) return NULL;
+      c->search_range < 0 || c->search_range > 32 || c->tile_rows < 1 || c->tile_rows > (c->height + 63) / 64) return NULL;
   orc_encoder *e = (orc_encoder *)calloc(1, sizeof(*e));
   orc_tables_init();
   e->cfg = *c;
@@ -121,6 +123,18 @@ orc_encoder *orc_enc_open(const orc_enc_config *c)
 
   memset(&e->av, 0, sizeof(e->av));
   e->av.pic_w = e->cw; e->av.pic_h = e->ch; e->av.ctb_log2 = 6; e->av.pic_w_ctbs = e->cw / 64;
+  /* tiles: n full-width rows, uniform spacing (6.5.1: rowBd[i] = (i * PicHeightInCtbs) / n) */
+  {
+    int n = c->tile_rows, wc = e->cw / 64, hc = e->ch / 64;
+    e->tile_row_bd = (int *)calloc((size_t)n + 1, sizeof(int));
+    for (int i = 0; i <= n; i++) e->tile_row_bd[i] = (i * hc) / n;
+    if (n > 1) {
+      p->tiles_enabled = 1; p->num_tile_columns = 1; p->num_tile_rows = n; p->uniform_spacing = 1; p->loop_filter_across_tiles = 1;
+      e->ctb_tile = (int16_t *)calloc((size_t)wc * hc, sizeof(int16_t));
+      for (int i = 0; i < n; i++) for (int cy = e->tile_row_bd[i]; cy < e->tile_row_bd[i + 1]; cy++) for (int cx = 0; cx < wc; cx++) e->ctb_tile[cy * wc + cx] = (int16_t)i;
+      e->av.ctb_tile = e->ctb_tile;
+    }
+  }
   return e;
 }
 
@@ -325,8 +339,14 @@ static void me_block32(orc_encoder *e, int x0, int y0)
   uint32_t lam = orc_lambda_q4[e->qp];
   uint32_t best16[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu }, best32 = 0xffffffffu;
   int idx = 0;
+  /* Tile constraint: the 32x32 block displaced by dy (plus 4 rows each side for the chroma half-sample taps when dy is
+   * odd) must stay inside its tile, except across the picture's own top and bottom edges where padding is normative. */
+  int ty0 = 0, ty1 = e->ch;
+  for (int i = 0; i < e->cfg.tile_rows; i++) if ((y0 >> 6) >= e->tile_row_bd[i] && (y0 >> 6) < e->tile_row_bd[i + 1]) { ty0 = e->tile_row_bd[i] * 64; ty1 = e->tile_row_bd[i + 1] * 64; }
   for (int dy = -R; dy <= R; dy++)
     for (int dx = -R; dx <= R; dx++, idx++) {
+      int m = (dy & 1) ? 4 : 0;
+      if ((ty0 > 0 && y0 + dy - m < ty0) || (ty1 < e->ch && y0 + dy + 32 + m > ty1)) continue;
       uint32_t rate = (lam * (uint32_t)(orc_mvd_bits(dx * 4) + orc_mvd_bits(dy * 4))) >> 4;
       uint32_t s32 = 0;
       for (int k = 0; k < 4; k++) {
@@ -674,27 +694,30 @@ static void write_picture(orc_encoder *e, int write_ps)
     orc_bw_init(&ps); orc_write_sps(&ps, &e->sps); orc_write_nal(&e->au, NAL_SPS, 0, ps.buf, ps.len, 1); orc_bw_free(&ps);
     orc_bw_init(&ps); orc_write_pps(&ps, &e->pps); orc_write_nal(&e->au, NAL_PPS, 0, ps.buf, ps.len, 1); orc_bw_free(&ps);
   }
-  /* slice data: one substream per CTU row with WPP, otherwise a single one */
-  int nsub = e->cfg.wpp ? hc : 1;
+  /* slice data: one substream per CTU row with WPP, else one per tile (full-width tile rows: coding order = raster) */
+  int nsub = e->cfg.wpp ? hc : e->cfg.tile_rows;
   rows = (orc_bitw *)calloc((size_t)nsub, sizeof(orc_bitw));
   orc_cabac_enc c; memset(&c, 0, sizeof(c));
   orc_ctx saved[CTX_COUNT];
-  int init_type = e->is_intra ? 0 : 1;
+  int init_type = e->is_intra ? 0 : 1, sub = -1;
   for (int cy = 0; cy < hc; cy++) {
-    if (cy == 0 || e->cfg.wpp) {
-      int sub = e->cfg.wpp ? cy : 0;
+    int tile_start = 0, tile_end = 0;
+    for (int i = 0; i < e->cfg.tile_rows; i++) { if (cy == e->tile_row_bd[i]) tile_start = 1; if (cy + 1 == e->tile_row_bd[i + 1]) tile_end = 1; }
+    if (tile_start || e->cfg.wpp) {
+      sub++;
       orc_bw_init(&rows[sub]);
       orc_cenc_start(&c, &rows[sub]);
-      if (cy == 0) orc_cabac_init_contexts(c.ctx, init_type, e->qp);
+      if (tile_start) orc_cabac_init_contexts(c.ctx, init_type, e->qp);   /* 9.3.1: first CTB of a tile */
       else memcpy(c.ctx, saved, sizeof(saved));       /* WPP: state after the 2nd CTU of the row above */
     }
     for (int cx = 0; cx < wc; cx++) {
       enc_quadtree(e, &c, cx * 64, cy * 64, 6, 0);
       if (e->cfg.wpp && cx == 1) memcpy(saved, c.ctx, sizeof(saved));
       int last = (cy == hc - 1 && cx == wc - 1);
+      int sub_end = cx == wc - 1 && (e->cfg.wpp || tile_end);
       orc_cenc_terminate(&c, last);                   /* end_of_slice_segment_flag */
-      if (!last && e->cfg.wpp && cx == wc - 1) orc_cenc_terminate(&c, 1);   /* end_of_subset_one_bit */
-      if (last || (e->cfg.wpp && cx == wc - 1)) orc_bw_align_zero(c.bw);
+      if (!last && sub_end) orc_cenc_terminate(&c, 1);   /* end_of_subset_one_bit */
+      if (last || sub_end) orc_bw_align_zero(c.bw);
     }
   }
   e->bins = c.bins;

@@ -31,6 +31,8 @@ typedef struct {
   int fps_num, fps_den;
   int wpp;                    /* entropy_coding_sync_enabled_flag */
   int deblock;                /* 1 = enabled */
+  int tile_rows;              /* 1 = no tiles; n > 1: n full-width tile rows, uniform spacing, loop filter across tiles on,
+                               * motion vectors constrained to the tile (see me_block32) */
   int bitrate;                /* bits per second; 0 = constant QP.  > 0: "uvgx rate control v1" (see hevc_enc.c) */
 } orc_enc_config;
 

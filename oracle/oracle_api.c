@@ -69,10 +69,16 @@ orc_encoder *orc_api_enc_open(int w, int h, int qp, int period, int vps_period, 
   c.fps_num = fps_num; c.fps_den = fps_den; c.wpp = wpp; c.deblock = deblock;
   return orc_enc_open(&c);
 }
+orc_encoder *orc_api_enc_open_ex(int w, int h, int qp, int period, int vps_period, int range, int fps_num, int fps_den, int wpp, int deblock, int bitrate, int tile_rows);
 /* same with picture-level rate control (bits per second) */
 orc_encoder *orc_api_enc_open_rc(int w, int h, int qp, int period, int vps_period, int range, int fps_num, int fps_den, int wpp, int deblock, int bitrate)
 {
-  orc_enc_config c; orc_enc_default_config(&c);
+  return orc_api_enc_open_ex(w, h, qp, period, vps_period, range, fps_num, fps_den, wpp, deblock, bitrate, 1);
+}
+/* ... and tile rows */
+orc_encoder *orc_api_enc_open_ex(int w, int h, int qp, int period, int vps_period, int range, int fps_num, int fps_den, int wpp, int deblock, int bitrate, int tile_rows)
+{
+  orc_enc_config c; orc_enc_default_config(&c); c.tile_rows = tile_rows;
   c.width = w; c.height = h; c.qp = qp; c.intra_period = period; c.vps_period = vps_period; c.search_range = range;
   c.fps_num = fps_num; c.fps_den = fps_den; c.wpp = wpp; c.deblock = deblock; c.bitrate = bitrate;
   return orc_enc_open(&c);

@@ -36,7 +36,7 @@ struct HcFrame {
 static void fill(EncFrame &f, const HcFrame &h)
 {
   memset(&f, 0, sizeof(f));
-  f.cw = h.cw; f.ch = h.ch; f.b8w = h.cw / 8; f.b8h = h.ch / 8; f.qp = h.qp; f.qpc = kChromaQp[h.qp];
+  f.cw = h.cw; f.ch = h.ch; f.tile_rows = 1; f.chp = pack_height(h.ch, 1); f.b8w = h.cw / 8; f.b8h = h.ch / 8; f.qp = h.qp; f.qpc = kChromaQp[h.qp];
   f.lambda_q4 = kLambdaQ4[h.qp]; f.is_intra = h.is_intra; f.poc = h.poc; f.wpp = h.wpp;
   f.cu_log2 = h.cu_log2; f.cu_intra = h.cu_intra; f.cu_flags = h.cu_flags; f.cu_merge_idx = h.cu_merge_idx;
   f.cu_mvp_idx = h.cu_mvp_idx; f.cu_intra_mode = h.cu_intra_mode; f.cu_cbf = h.cu_cbf; f.cu_mv = h.cu_mv; f.cu_mvd = h.cu_mvd;
@@ -123,8 +123,8 @@ int hc_encode_au_tokens(HcFrame *h, uint8_t *out, int cap, unsigned long long *n
         int xi, yi; ctu_z_to_xy(z, xi, yi);
         int x0 = cx * 64 + xi * 8, y0 = cy * 64 + yi * 8;
         CuRec cu = v.at(x0, y0);
-        enc_split_flags(v, t, f.cw, f.ch, x0, y0, z, cu.log2);
-        int cbf = enc_cu_header(v, t, f.cw, f.ch, f.is_intra != 0, x0, y0, cu);
+        enc_split_flags(v, t, f.cw, f.chp, x0, y0, z, cu.log2);
+        int cbf = enc_cu_header(v, t, f.cw, f.chp, f.is_intra != 0, x0, y0, cu);
         for (int ci = 0; ci < 3; ci++) {
           if (!((cbf >> ci) & 1)) continue;
           int l2 = ci ? cu.log2 - 1 : cu.log2, pw = ci ? f.cw / 2 : f.cw, px = ci ? x0 / 2 : x0, py = ci ? y0 / 2 : y0;

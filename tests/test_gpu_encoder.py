@@ -29,10 +29,10 @@ def _diagnose(dbg_o, dbg_g):
     return "; ".join(msgs) if msgs else "no stage-level difference found (entropy coding / assembly?)"
 
 
-def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_picture=True):
+def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_picture=True, tile_rows=1):
     from kvazzup_amd.codec import Encoder
-    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock)
-    ge = Encoder(w, h, options=(("qp", qp), ("period", period), ("me-range", me_range), ("wpp", wpp), ("deblock", deblock)))
+    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows)
+    ge = Encoder(w, h, options=(("qp", qp), ("period", period), ("me-range", me_range), ("wpp", wpp), ("deblock", deblock), ("tiles", "1x%d" % tile_rows)))
     assert not ge.rejected, ge.rejected
     try:
         for t in range(frames):
@@ -125,3 +125,17 @@ def test_largest_size_8k_intra_and_inter_picture(gpu):
     """7680x4320 (BASELINE configs[4] size, 120 x 68 CTUs): one IDR and one P picture, access units and
     reconstruction bit-exact against the checker"""
     run_clip(w=7680, h=4320, frames=2, qp=35, period=64, me_range=8, kind=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(w=320, h=256, frames=5, qp=30, period=3, me_range=16, kind=0, tile_rows=2),            # tiles + WPP
+    dict(w=320, h=256, frames=4, qp=30, period=64, me_range=16, kind=0, tile_rows=4),           # one CTU row per tile
+    dict(w=320, h=256, frames=4, qp=27, period=2, me_range=8, kind=2, tile_rows=2, wpp=0),      # tiles without WPP: one substream per tile
+    dict(w=256, h=448, frames=5, qp=32, period=4, me_range=32, kind=0, tile_rows=3),            # uneven rows (2, 2, 3), long vectors against the constraint
+    dict(w=1920, h=1080, frames=3, qp=32, period=64, me_range=16, kind=0, tile_rows=4),
+])
+def test_tile_rows_match_oracle(gpu, cfg):
+    """kvazaar "tiles" 1xN (kvazaarfilter.cpp:196-202): full-width tile rows with uniform spacing, prediction and
+    entropy contexts confined to the tile, motion vectors constrained to it, deblocking across the boundaries"""
+    run_clip(**cfg)

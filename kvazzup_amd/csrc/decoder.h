@@ -45,6 +45,7 @@ struct DecSps {
 };
 struct DecPps {
   bool valid = false;
+  int tile_rows = 1;                  // full-width tile rows with uniform spacing (everything else about tiles is rejected)
   int init_qp = 26, wpp = 0, deblock_control = 0, deblock_disabled = 0, loop_filter_across_slices = 1, cabac_init_present = 0;
 };
 
@@ -105,6 +106,7 @@ class Decoder {
   struct PicJob {
     std::vector<uint8_t> rbsp; size_t data_off = 0, data_len = 0;
     std::vector<size_t> sub_start;
+    int tile_rows = 1;
     int slice_qp = 0, max_merge = 5, poc = 0; bool is_intra = false, deblock = true; int64_t pts = 0;
     int crop[4] = {0, 0, 0, 0}; uint32_t fps_num = 0, fps_den = 0;
     // Everything the GPU needs for the picture, in one pinned block that goes over in one copy:

@@ -287,10 +287,11 @@ void Decoder::free_buffers()
 void Decoder::bind_views(EncFrame &f, uint8_t *base)
 {
   const size_t nb8 = (size_t)cw_ * ch_ / 64;
-  const int wpp = f.wpp, is_intra = f.is_intra, qp = f.qp;
+  const int wpp = f.wpp, is_intra = f.is_intra, qp = f.qp, tile_rows = f.tile_rows > 0 ? f.tile_rows : 1;
   EncFrame keep = f;
   memset(&f, 0, sizeof(f));
   f.cw = cw_; f.ch = ch_; f.b8w = cw_ / 8; f.b8h = ch_ / 8; f.wpp = wpp; f.is_intra = is_intra; f.qp = qp;
+  f.tile_rows = tile_rows; f.chp = pack_height(ch_, tile_rows);
   f.cu_log2 = base; f.cu_intra = base + nb8; f.cu_flags = base + 2 * nb8; f.cu_merge_idx = base + 3 * nb8;
   f.cu_mvp_idx = base + 4 * nb8; f.cu_intra_mode = base + 5 * nb8; f.cu_cbf = base + 6 * nb8; f.cu_mv = (int16_t *)(base + 7 * nb8);
   f.cu_mvd = keep.cu_mvd; f.sync = keep.sync; f.err = keep.err;
@@ -443,8 +444,14 @@ int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
     if (cuqpd) r.ue();
     int cbo = r.se(), cro = r.se(), sco = r.get(1), wp = r.get(1), wbp = r.get(1), tqb = r.get(1), tiles = r.get(1);
     p.wpp = r.get(1);
-    if (dep || outflag || extra || signhide || p.cabac_init_present || l0 != 0 || cip || tskip || cuqpd || cbo || cro || sco || wp || wbp || tqb || tiles)
+    if (dep || outflag || extra || signhide || p.cabac_init_present || l0 != 0 || cip || tskip || cuqpd || cbo || cro || sco || wp || wbp || tqb)
       return last_error_ = DEC_ERR_UNSUPPORTED;
+    if (tiles) {                                                 // supported: one column, uniform spacing, loop filter across tiles on
+      const int cols = r.ue() + 1, rows = r.ue() + 1, uniform = r.get(1);
+      if (cols != 1 || !uniform || rows > 1024) return last_error_ = DEC_ERR_UNSUPPORTED;
+      if (!r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;   // loop_filter_across_tiles_enabled_flag
+      p.tile_rows = rows;
+    }
     p.loop_filter_across_slices = r.get(1);
     p.deblock_control = r.get(1);
     if (p.deblock_control) {
@@ -514,11 +521,11 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   const bool deblock = !p.deblock_disabled;
   if (p.loop_filter_across_slices && deblock) r.get(1);
   std::vector<uint32_t> entry;
-  if (p.wpp) {
+  if (p.wpp || p.tile_rows > 1) {
     int nep = r.ue();
     if (nep < 0 || nep > 1024) return DEC_ERR_INVALID;
     if (nep > 0) { int bits = r.ue() + 1; if (bits > 32) return DEC_ERR_INVALID; for (int k = 0; k < nep; k++) entry.push_back(r.get(bits) + 1); }
-    if (nep != s.height / 64 - 1) return DEC_ERR_UNSUPPORTED;    // one substream per CTU row
+    if (nep != (p.wpp ? s.height / 64 : p.tile_rows) - 1) return DEC_ERR_UNSUPPORTED;    // one substream per CTU row (WPP) or per tile
   }
   if (!r.get(1)) return DEC_ERR_INVALID;                         // byte_alignment()
   while (r.pos & 7) r.get(1);
@@ -551,6 +558,8 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   job.crop[0] = s.crop_l; job.crop[1] = s.crop_r; job.crop[2] = s.crop_t; job.crop[3] = s.crop_b;
   job.fps_num = s.fps_num ? s.fps_num : vps_fps_num_; job.fps_den = s.fps_num ? s.fps_den : vps_fps_den_;
   job.hf.is_intra = is_intra; job.hf.wpp = p.wpp; job.hf.qp = slice_qp;
+  if (p.tile_rows > s.height / 64) return DEC_ERR_INVALID;
+  job.tile_rows = p.tile_rows; job.hf.tile_rows = p.tile_rows; job.hf.chp = pack_height(ch_, p.tile_rows);
   job.rc = 0;
   prev_poc_ = poc; have_ref_ = true;                             // header checks of the next picture run before this one is reconstructed
   job_head_++;
@@ -646,10 +655,11 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
   FrameView v; v.f = &f;
   CabacDec c;
   const bool wpp = f.wpp != 0;
-  const int first_cy = wpp ? row : 0, ncy = wpp ? 1 : hc;
+  const int T = job.tile_rows, chp = f.chp;
+  const int first_cy = wpp ? row : tile_row_first(hc, T, row), ncy = wpp ? 1 : tile_row_first(hc, T, row + 1) - first_cy;
   int seen_above = 0;                                  // last observed progress of the row above (monotonic)
   auto wait_above = [&](int cy, int need) {            // CTUs of row cy-1 that must be complete
-    if (!wpp || cy == 0) return true;
+    if (!wpp || tile_row_starts_at(hc, T, cy)) return true;       // nothing above inside the tile
     if (need > wc) need = wc;
     if (seen_above < need) {
       std::atomic<int> &p = job.row_progress[(size_t)(cy - 1)].v;
@@ -661,7 +671,7 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
     return seen_above < (1 << 29);                     // >= 1 << 29: that row failed
   };
   c.start(data, len);
-  if (row == 0 || !wpp) cabac_init_contexts(c.ctx, is_intra ? 0 : 1, slice_qp);
+  if (!wpp || tile_row_starts_at(hc, T, row)) cabac_init_contexts(c.ctx, is_intra ? 0 : 1, slice_qp);   // first CTU of a tile (9.3.1)
   else {
     if (!wait_above(row, 2)) return DEC_ERR_INVALID;
     memcpy(c.ctx, &job.wpp_saved[(size_t)(row - 1) * CTX_COUNT], CTX_COUNT);
@@ -679,8 +689,8 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
         for (; log2 > 3; log2--) {                 // split_cu_flag at every level whose block starts here
           if (z & ((1 << (2 * (log2 - 3))) - 1)) continue;
           int depth = 6 - log2;
-          int l = avail64(cw_, ch_, x0, y0, x0 - 1, y0) && (6 - f.cu_log2[b8idx(f, x0 - 1, y0)]) > depth;
-          int a = avail64(cw_, ch_, x0, y0, x0, y0 - 1) && (6 - f.cu_log2[b8idx(f, x0, y0 - 1)]) > depth;
+          int l = avail64(cw_, chp, x0, y0, x0 - 1, y0) && (6 - f.cu_log2[b8idx(f, x0 - 1, y0)]) > depth;
+          int a = avail64(cw_, chp, x0, y0, x0, y0 - 1) && (6 - f.cu_log2[b8idx(f, x0, y0 - 1)]) > depth;
           if (!c.bin(CTX_SPLIT_CU + l + a)) break;
         }
         LAP(0);
@@ -688,8 +698,8 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
         const int n = 1 << log2;
         int skip = 0, intra = is_intra ? 1 : 0, flags = 0, mode = 0, cbf = 0, mvx = 0, mvy = 0;
         if (!is_intra) {
-          int l = avail64(cw_, ch_, x0, y0, x0 - 1, y0) && (f.cu_flags[b8idx(f, x0 - 1, y0)] & CU_SKIP);
-          int a = avail64(cw_, ch_, x0, y0, x0, y0 - 1) && (f.cu_flags[b8idx(f, x0, y0 - 1)] & CU_SKIP);
+          int l = avail64(cw_, chp, x0, y0, x0 - 1, y0) && (f.cu_flags[b8idx(f, x0 - 1, y0)] & CU_SKIP);
+          int a = avail64(cw_, chp, x0, y0, x0, y0 - 1) && (f.cu_flags[b8idx(f, x0, y0 - 1)] & CU_SKIP);
           skip = c.bin(CTX_SKIP + l + a);
           if (!skip) intra = c.bin(CTX_PRED_MODE);
         }
@@ -700,7 +710,7 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
         bool root_cbf = true;
         if (intra) {
           int prev = c.bin(CTX_PREV_INTRA);
-          int cand[3]; intra_mpm(v, cw_, ch_, x0, y0, cand);
+          int cand[3]; intra_mpm(v, cw_, chp, x0, y0, cand);
           if (prev) { int idx = 0; if (c.bypass()) { idx = 1; if (c.bypass()) idx = 2; } mode = cand[idx]; }
           else {
             mode = (int)c.bypass_bits(5);
@@ -771,7 +781,7 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
       const bool last = (cy == hc - 1 && cx == wc - 1);
       int end = c.terminate();
       if (end != (last ? 1 : 0)) return DEC_ERR_UNSUPPORTED;      // slice must cover the whole picture
-      if (!last && wpp && cx == wc - 1 && !c.terminate()) return DEC_ERR_INVALID;   // end_of_subset_one_bit
+      if (!last && cx == wc - 1 && (wpp || tile_row_ends_at(hc, T, cy)) && !c.terminate()) return DEC_ERR_INVALID;   // end_of_subset_one_bit
       LAP(5);
     }
   }
@@ -782,7 +792,7 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
 int Decoder::parse_job(PicJob &job, bool row_parallel)
 {
   const uint8_t *data = job.rbsp.data() + job.data_off; const size_t len = job.data_len;
-  const int hc = ch_ / 64, nsub = job.hf.wpp ? hc : 1;
+  const int hc = ch_ / 64, nsub = job.hf.wpp ? hc : job.tile_rows;                 // one substream per CTU row (WPP) or per tile
   if ((int)job.sub_start.size() != nsub) return DEC_ERR_INVALID;
   for (int r = 0; r < nsub; r++) if (job.sub_start[(size_t)r] >= len) return DEC_ERR_INVALID;
   job.rows.resize((size_t)nsub);
@@ -837,6 +847,7 @@ int Decoder::launch_gpu(PicJob &job)
   if (hipMemcpyAsync(d_in_, job.h_in, bytes, hipMemcpyHostToDevice, stream_) != hipSuccess) return DEC_ERR_GPU;
   const TuDesc *d_tus = (const TuDesc *)(d_in_ + tu_off); const uint32_t *d_lev = (const uint32_t *)(d_in_ + lev_off);
   f_.qp = slice_qp; f_.qpc = kChromaQp[slice_qp]; f_.is_intra = is_intra;
+  f_.tile_rows = job.tile_rows; f_.chp = pack_height(ch_, job.tile_rows);
   const int cur = (int)(launched_ % 3), ref = (int)((launched_ + 2) % 3);     // three buffers: the picture output by the previous call stays intact
   for (int c = 0; c < 3; c++) { f_.rec[c] = rec_[cur][c]; f_.ref[c] = rec_[ref][c]; }
   const EncFrame f = f_;

@@ -8,9 +8,9 @@ import orc
 SEED = 0x5EED0000
 
 
-def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1):
+def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, tile_rows=1, threads=1):
     from kvazzup_amd.codec import Decoder
-    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock)
+    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows)
     od = orc.OracleDecoder()
     gd = Decoder()
     try:
@@ -120,3 +120,15 @@ def test_frame_threaded_decoder_delays_output_and_drains_on_eos(gpu, threads):
     for t in range(frames):
         assert np.array_equal(out[t]["i420"], recs[t]), t
     gd.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(w=320, h=256, frames=5, qp=30, period=3, me_range=16, kind=0, tile_rows=2),
+    dict(w=320, h=256, frames=4, qp=27, period=2, me_range=8, kind=2, tile_rows=2, wpp=0),
+    dict(w=256, h=448, frames=5, qp=32, period=4, me_range=32, kind=0, tile_rows=3),
+    dict(w=1920, h=1080, frames=3, qp=32, period=64, me_range=16, kind=0, tile_rows=4),
+])
+def test_decoder_tile_rows(gpu, cfg):
+    """streams with full-width tile rows (uniform spacing, with and without WPP) from the checker's encoder"""
+    run_clip(**cfg)

@@ -9,12 +9,15 @@ SEED = 0x5EED0000
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,qp,period", [(320, 240, 32, 64), (416, 240, 27, 4)])
-def test_filter_chain_matches_oracle(gpu, w, h, qp, period):
+@pytest.mark.parametrize("w,h,qp,period,tile_rows", [(320, 240, 32, 64, 1), (416, 240, 27, 4, 1), (320, 256, 30, 4, 2)])
+def test_filter_chain_matches_oracle(gpu, w, h, qp, period, tile_rows):
     from kvazzup_amd.pipeline import Pipeline
     frames = 8
-    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=16)
-    pl = Pipeline(w, h, settings={"video/QP": qp, "video/Intra": period}, custom=(("me-range", 16),))
+    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=16, tile_rows=tile_rows)
+    settings = {"video/QP": qp, "video/Intra": period}
+    if tile_rows > 1:                                   # uvgComm settings video/Tiles + video/tileDimensions (kvazaarfilter.cpp:196-202)
+        settings.update({"video/Tiles": 1, "video/tileDimensions": "1x%d" % tile_rows})
+    pl = Pipeline(w, h, settings=settings, custom=(("me-range", 16),))
     try:
         clip = [orc.synth_frame(0, SEED, w, h, t) for t in range(frames)]
         for f in clip:

@@ -86,3 +86,16 @@ def test_rate_control_tracks_the_target_and_decodes():
         kbps = total * 8 * 30 / frames / 1000
         assert 0.7 * bitrate / 1000 < kbps < 1.4 * bitrate / 1000, (bitrate, kbps)
         oe.close(); od.close()
+
+
+@pytest.mark.parametrize("w,h,tile_rows,wpp", [(320, 256, 2, 1), (320, 256, 4, 1), (320, 256, 2, 0), (256, 448, 3, 1), (256, 448, 7, 0)])
+def test_tile_rows_closed_loop(w, h, tile_rows, wpp):
+    """full-width tile rows: the checker's encoder (tile-confined prediction, contexts per tile, constrained vectors)
+    against the checker's general decoder, which implements tiles from 6.4.1 / 6.5.1 / 9.3.1 independently"""
+    oe = orc.OracleEncoder(w, h, qp=30, period=4, me_range=16, tile_rows=tile_rows, wpp=wpp)
+    od = orc.OracleDecoder()
+    for t in range(6):
+        au = oe.encode(orc.synth_frame(0, 7, w, h, t))
+        d = od.decode_au(au, t)
+        assert len(d) == 1 and np.array_equal(d[0]["i420"], oe.recon()), t
+    oe.close(); od.close()

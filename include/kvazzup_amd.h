@@ -58,6 +58,21 @@ KVZ_PUBLIC int kvzx_decoder_kernel_times(OpenHevc_Handle h, double *ms, uint64_t
 KVZ_PUBLIC const char *kvzx_decoder_kernel_name(int id);
 KVZ_PUBLIC int kvzx_decoder_debug_copy(OpenHevc_Handle h, const char *what, void *dst, size_t bytes);
 
+/* ---- tile-row split of ONE picture over several encoders, one per GPU / process (BASELINE configs[4]).
+ * Every encoder is opened with the same configuration plus "tiles" = 1xN and "band-row0" / "band-rows" (CTU rows, whole
+ * tiles).  Per picture and rank: phase1 (input, decisions, reconstruction, vertical-edge deblocking of the band) ->
+ * export_halo -> exchange with rank - 1 (gets `up`) and rank + 1 (gets `down`), e.g. RCCL send/recv of the two device
+ * blocks -> import_halo (NULL where there is no neighbour) -> phase2 (horizontal edges incl. the band's boundary edges,
+ * tokenizer, arithmetic coding): the band's substreams, back to back in buf with sizes[].  Rank 0 gathers all substreams in
+ * picture order and calls kvzx_assemble_access_unit (host only).  kvazzup_amd/tilesplit.py drives this over torch.distributed. */
+KVZ_PUBLIC int kvzx_encoder_band_phase1(kvz_encoder *enc, const void *d_i420);
+KVZ_PUBLIC size_t kvzx_encoder_band_halo_bytes(kvz_encoder *enc);
+KVZ_PUBLIC int kvzx_encoder_band_export_halo(kvz_encoder *enc, void *d_up, void *d_down);
+KVZ_PUBLIC int kvzx_encoder_band_import_halo(kvz_encoder *enc, const void *d_from_up, const void *d_from_down);
+KVZ_PUBLIC int kvzx_encoder_band_phase2(kvz_encoder *enc, uint8_t *buf, uint32_t cap, uint32_t *sizes, int max_sub, int *nsub_out, kvz_frame_info *info);
+KVZ_PUBLIC int kvzx_assemble_access_unit(const kvz_config *cfg, int idr, int poc, int write_parameter_sets, int slice_qp, const uint8_t *data,
+                                          const uint32_t *sizes, int nsub, uint8_t *out, uint32_t cap, uint32_t *len_out);
+
 /* ---- row f1: I420 -> RGB32, the conversion uvgComm runs on every decoded picture before display
  * (YUVtoRGB32::process, src/media/processing/yuvtorgb32.cpp:29-64 -> yuv420_to_rgb_i_{avx2_mt,avx2,sse41,c},
  * src/media/processing/yuvconversions.cpp:72-493).  The reference has two arithmetics; `variant` picks:

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
   __shared__ __attribute__((aligned(16))) uint32_t cur[32 * 8];
   __shared__ uint32_t red[5];
   const int tid = threadIdx.x, nthreads = blockDim.x;
-  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32 + f.row0 * 64;
   const int R = f.range, W = 2 * R + 1, WW = 32 + 2 * R;
   const uint8_t *ref = f.ref[0], *src = f.src[0];
   for (int i = tid; i < (WW + 1) * (ME_WPITCH / 4); i += nthreads) {   // four window samples per thread; columns >= WW and row WW are padding
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
 {
   __shared__ InterLds s;
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32 + f.row0 * 64;
   const int bi0 = b8idx(f, x0, y0);
   const bool split = f.cu_log2[bi0] == 4;
   const int cw2 = f.cw >> 1, ch2 = f.ch >> 1;
@@ -561,9 +561,9 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
 __global__ __launch_bounds__(256) void k_inter_signal(EncFrame f)
 {
   int bx = blockIdx.x * blockDim.x + threadIdx.x;       // 16x16 block index
-  int w16 = f.cw >> 4, h16 = f.ch >> 4;
+  int w16 = f.cw >> 4, h16 = band_rows(f) * 4;
   if (bx >= w16 * h16) return;
-  int x0 = (bx % w16) * 16, y0 = (bx / w16) * 16;
+  int x0 = (bx % w16) * 16, y0 = (bx / w16) * 16 + f.row0 * 64;
   int cl = f.cu_log2[b8idx(f, x0, y0)];
   if (cl == 5 && ((x0 | y0) & 31)) return;              // not the first 16x16 of a 32x32 CU
   decide_signalling(f, x0, y0, cl);
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
 {
   __shared__ AnalyseLds s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int X0 = blockIdx.x * 32, Y0 = blockIdx.y * 32;
+  const int X0 = blockIdx.x * 32, Y0 = blockIdx.y * 32 + f.row0 * 64;
   const uint8_t *src = f.src[0];
   *(uint32_t *)&s.src[tid * 4] = *(const uint32_t *)&src[(size_t)(Y0 + (tid >> 3)) * f.cw + X0 + (tid & 7) * 4];
   // ---- references of the 21 blocks from the source picture (8.4.4.2.2 substitution as an index clamp: the available
@@ -946,7 +946,7 @@ template <bool DEC, int T>
 __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
 {
   __shared__ IntraWaveLds s;
-  const int lane = threadIdx.x, wl = threadIdx.x & 63, row = blockIdx.x / 3, c = blockIdx.x % 3, wc = f.cw >> 6;
+  const int lane = threadIdx.x, wl = threadIdx.x & 63, row = f.row0 + blockIdx.x / 3, c = blockIdx.x % 3, wc = f.cw >> 6;
   const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, qp = c ? f.qpc : f.qp, P = 16 + 2 * S;
   uint32_t *my_ctr = f.sync + row * 3 + c;
   const uint32_t *up_ctr = f.sync + (row - 1) * 3 + c;
@@ -1032,9 +1032,9 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
 __global__ __launch_bounds__(256) void k_deblock_v(EncFrame f)
 {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
-  int ne = (f.cw >> 3) - 1, ns = f.ch >> 2;            // edges per row of segments, segment rows
+  int ne = (f.cw >> 3) - 1, ns = band_rows(f) * 16;    // edges per row of segments, segment rows of the band
   if (t >= ne * ns) return;
-  int x = ((t % ne) + 1) * 8, y = (t / ne) * 4;
+  int x = ((t % ne) + 1) * 8, y = (t / ne) * 4 + f.row0 * 64;
   if (!is_cu_edge_v(f, x, y)) return;
   int bs = edge_bs(f, x - 1, y, x, y);
   if (!bs) return;
@@ -1048,9 +1048,12 @@ __global__ __launch_bounds__(256) void k_deblock_v(EncFrame f)
 __global__ __launch_bounds__(256) void k_deblock_h(EncFrame f)
 {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
-  int ns = f.cw >> 2, ne = (f.ch >> 3) - 1;
+  // horizontal edges of the band: every 8 rows from its first row (when that is not the picture's) to its end (likewise);
+  // the two boundary edges are filtered by both neighbours, each keeping its own side (halo rows hold the other's samples)
+  const int ylo = imax(8, f.row0 * 64), yhi = imin(f.ch - 8, (f.row0 + band_rows(f)) * 64);
+  int ns = f.cw >> 2, ne = (yhi - ylo) / 8 + 1;
   if (t >= ne * ns) return;
-  int x = (t % ns) * 4, y = ((t / ns) + 1) * 8;
+  int x = (t % ns) * 4, y = ylo + (t / ns) * 8;
   if (!is_cu_edge_h(f, x, y)) return;
   int bs = edge_bs(f, x, y - 1, x, y);
   if (!bs) return;
@@ -1132,13 +1135,13 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
   __shared__ int hdr_n;
   __shared__ uint32_t piece_off;
   __shared__ uint32_t seg[TOK_PIECES][2];
-  const int ux = blockIdx.x, uy = blockIdx.y, comp = blockIdx.z, lane = threadIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
+  const int ux = blockIdx.x, uy = blockIdx.y + f.row0 * 4, comp = blockIdx.z, lane = threadIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
   const int cx = ux >> 2, cy = uy >> 2, ctu = cy * wc + cx;
   const int X0 = ux * 16, Y0 = uy * 16;
   int z4 = 0;                                          // z-order index of the unit inside its CTU
   for (int b = 0; b < 2; b++) z4 |= (((ux & 3) >> b) & 1) << (2 * b) | (((uy & 3) >> b) & 1) << (2 * b + 1);
   core_tabs_fill_entry(tabs, lane);
-  if (lane == 0 && (ux | uy | comp) == 0) *f.tok_total = 0;           // dense-array cursor of this picture's k_tok_compact
+  if (lane == 0 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0) *f.tok_total = 0;           // dense-array cursor of this picture's k_tok_compact
   if (lane < TOK_PIECES) { seg[lane][0] = 0; seg[lane][1] = 0; }
   if (lane == 0) hdr_n = 0;
   const int bx0 = ux * 2 - 1, by0 = uy * 2 - 1;
@@ -1277,11 +1280,11 @@ __global__ __launch_bounds__(256) void k_tok_compact(EncFrame f)
   constexpr int NSEG = 16 * TOK_PIECES;
   __shared__ uint32_t soff[NSEG], start[NSEG + 1], utot[17];
   __shared__ uint32_t base_s;
-  const int ctu = blockIdx.x, tid = threadIdx.x;
+  const int ctu = blockIdx.x + f.row0 * (f.cw >> 6), tid = threadIdx.x;
   const uint32_t n = f.tok_cursor[ctu];
   // a place in the dense array (CTUs land in completion order: the host gets each CTU's offset), the slot's
   // cursor back to zero for the next picture, and the device error word over to the host
-  if (tid == 0) { base_s = atomicAdd(f.tok_total, n); if (ctu == 0) *f.err_out = *f.err; }
+  if (tid == 0) { base_s = atomicAdd(f.tok_total, n); if (blockIdx.x == 0) *f.err_out = *f.err; }
   __syncthreads();
   const uint32_t base = base_s;
   if (tid == 0) f.tok_cursor[ctu] = 0;
@@ -1362,32 +1365,38 @@ void launch_me(const EncFrame &f, hipStream_t st)
 {
   const int W = 2 * f.range + 1, items = ((W + 3) / 4) * ((W + 1) / 2);          // quads x pairs; R = 16: 153 items -> 192 threads
   const int threads = items >= 256 ? 256 : ((items + 63) / 64) * 64;
-  hipLaunchKernelGGL(k_me, dim3(f.cw / 32, f.ch / 32), dim3(threads), 0, st, f);
+  hipLaunchKernelGGL(k_me, dim3(f.cw / 32, band_rows(f) * 2), dim3(threads), 0, st, f);
 }
-void launch_inter_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_inter_recon<false>, dim3(f.cw / 32, f.ch / 32), dim3(256), 0, st, f); }
-void launch_dec_inter_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_inter_recon<true>, dim3(f.cw / 32, f.ch / 32), dim3(256), 0, st, f); }
+void launch_inter_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_inter_recon<false>, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f); }
+void launch_dec_inter_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_inter_recon<true>, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f); }
 void launch_inter_signal(const EncFrame &f, hipStream_t st)
 {
-  int n = (f.cw / 16) * (f.ch / 16);
+  int n = (f.cw / 16) * (band_rows(f) * 4);
   hipLaunchKernelGGL(k_inter_signal, dim3((n + 255) / 256), dim3(256), 0, st, f);
 }
-void launch_intra_analyse(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_analyse, dim3(f.cw / 32, f.ch / 32), dim3(256), 0, st, f); }
+void launch_intra_analyse(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_analyse, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f); }
 #ifndef KVZ_INTRA_THREADS
 #define KVZ_INTRA_THREADS 256
 #endif
-void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL((k_intra_recon<false, KVZ_INTRA_THREADS>), dim3(3 * (f.ch / 64)), dim3(KVZ_INTRA_THREADS), 0, st, f); }
-void launch_dec_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL((k_intra_recon<true, KVZ_INTRA_THREADS>), dim3(3 * (f.ch / 64)), dim3(KVZ_INTRA_THREADS), 0, st, f); }
-void launch_deblock(const EncFrame &f, hipStream_t st)
+void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL((k_intra_recon<false, KVZ_INTRA_THREADS>), dim3(3 * band_rows(f)), dim3(KVZ_INTRA_THREADS), 0, st, f); }
+void launch_dec_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL((k_intra_recon<true, KVZ_INTRA_THREADS>), dim3(3 * band_rows(f)), dim3(KVZ_INTRA_THREADS), 0, st, f); }
+void launch_deblock_v(const EncFrame &f, hipStream_t st)
 {
-  int nv = ((f.cw >> 3) - 1) * (f.ch >> 2), nh = (f.cw >> 2) * ((f.ch >> 3) - 1);
+  int nv = ((f.cw >> 3) - 1) * (band_rows(f) * 16);
   hipLaunchKernelGGL(k_deblock_v, dim3((nv + 255) / 256), dim3(256), 0, st, f);
+}
+void launch_deblock_h(const EncFrame &f, hipStream_t st)
+{
+  const int ylo = imax(8, f.row0 * 64), yhi = imin(f.ch - 8, (f.row0 + band_rows(f)) * 64);
+  int nh = (f.cw >> 2) * ((yhi - ylo) / 8 + 1);
   hipLaunchKernelGGL(k_deblock_h, dim3((nh + 255) / 256), dim3(256), 0, st, f);
 }
+void launch_deblock(const EncFrame &f, hipStream_t st) { launch_deblock_v(f, st); launch_deblock_h(f, st); }
 void launch_tokenize(const EncFrame &f, hipStream_t st)
 {
-  const int wc = f.cw / 64, hc = f.ch / 64;
-  hipLaunchKernelGGL(k_tokenize, dim3(f.cw / 16, f.ch / 16, 3), dim3(64), 0, st, f);     // (tok_cursor is zero: k_tok_compact leaves it so)
-  hipLaunchKernelGGL(k_tok_compact, dim3(wc * hc), dim3(256), 0, st, f);
+  const int wc = f.cw / 64;
+  hipLaunchKernelGGL(k_tokenize, dim3(f.cw / 16, band_rows(f) * 4, 3), dim3(64), 0, st, f);     // (tok_cursor is zero: k_tok_compact leaves it so)
+  hipLaunchKernelGGL(k_tok_compact, dim3(wc * band_rows(f)), dim3(256), 0, st, f);
 }
 
 }  // namespace kvzx

@@ -26,6 +26,9 @@ struct EncoderConfig {
   int me_range = 16;
   int fps_num = 30, fps_den = 1;
   int wpp = 1, deblock = 1;
+  // Tile-row split of one picture over several encoder instances (one per GPU): this instance codes CTU
+  // rows [band_row0, band_row0 + band_rows) only -- whole tiles -- through band_phase1 / halo exchange / band_phase2.
+  int band_row0 = 0, band_rows = 0;   // band_rows == 0: the whole picture (normal operation)
   int tile_rows = 1;          // full-width tile rows (kvazaar "tiles" 1xN), uniform spacing, loop filter across tiles on
   int device = 0;
   int entropy_threads = 16;   // host threads of the arithmetic-coding stage
@@ -52,6 +55,14 @@ class Encoder {
   bool encode_device(const uint8_t *d_i420, EncodedPicture *out);
   // owf >= 1: outputs the picture still in flight, if any (kvz_api encoder_encode with pic_in == NULL)
   bool flush(EncodedPicture *out);
+  // ---- band mode (cfg.band_rows > 0); every call is synchronous.  Per picture: band_phase1, export the halos, exchange them
+  // with the neighbouring bands' encoders (rank - 1 gets `up`, rank + 1 gets `down`), import theirs, band_phase2.
+  bool band_phase1(const uint8_t *d_i420);                       // input, decisions, reconstruction, vertical-edge deblocking of the band
+  size_t halo_bytes() const;                                     // size of one halo block
+  bool band_export_halo(uint8_t *d_up, uint8_t *d_down);         // the band's first / last 4 luma + 2 x 2 chroma rows (vertical edges filtered) and CU records of its first / last 8x8 row
+  bool band_import_halo(const uint8_t *d_from_up, const uint8_t *d_from_down);   // nullptr: no neighbour on that side
+  // horizontal-edge deblocking (boundary edges included), tokenizer, arithmetic coding: one substream per CTU row (WPP) or tile of the band
+  bool band_phase2(std::vector<std::vector<uint8_t>> *substreams, EncodedPicture *info);
   int pending() const { return (int)(submitted_ - collected_); }
   // cropped reconstruction of the last coded picture -> host planes (stride = width)
   bool download_recon(uint8_t *y, uint8_t *u, uint8_t *v);
@@ -97,6 +108,8 @@ class Encoder {
   int set_ = 0, out_set_ = 0;
   int qp_cur_ = 0; int64_t rc_debt_ = 0; uint32_t rc_bytes_[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rate control state (calling thread)
   void rate_control();
+  bool band_picture_setup();
+  bool band_intra_ = false;
   hipStream_t stream_tok_ = nullptr;     // signalling decisions, tokenizer, compaction
   hipStream_t stream_in_ = nullptr;      // input padding (runs ahead of the previous picture's kernels)
   hipEvent_t ev_padded_ = nullptr, ev_src_free_[2] = {nullptr, nullptr}; bool src_busy_[2] = {false, false};

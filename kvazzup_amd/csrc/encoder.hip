@@ -26,6 +26,12 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   }
   if (cfg.qp < 0 || cfg.qp > 51 || cfg.me_range < 1 || cfg.me_range > 32) { if (error) *error = "qp or me-range out of range"; return false; }
   if (cfg.tile_rows < 1 || cfg.tile_rows > (cfg.height + 63) / 64) { if (error) *error = "tile rows out of range"; return false; }
+  if (cfg.band_rows > 0) {
+    const int hc = (cfg.height + 63) / 64, T = cfg.tile_rows;
+    const bool ok = cfg.band_row0 >= 0 && cfg.band_row0 + cfg.band_rows <= hc && tile_row_starts_at(hc, T, cfg.band_row0) &&
+                    tile_row_ends_at(hc, T, cfg.band_row0 + cfg.band_rows - 1) && cfg.bitrate == 0;
+    if (!ok) { if (error) *error = "a band must consist of whole tile rows (and rate control is not available in band mode)"; return false; }
+  }
   cfg_ = cfg;
   qp_cur_ = cfg.qp;
   int ndev = 0;
@@ -93,6 +99,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   memset(&f_, 0, sizeof(f_));
   f_.cw = cw_; f_.ch = ch_; f_.b8w = cw_ / 8; f_.b8h = ch_ / 8;
   f_.tile_rows = cfg.tile_rows; f_.chp = pack_height(ch_, cfg.tile_rows);
+  f_.row0 = cfg.band_rows > 0 ? cfg.band_row0 : 0; f_.nrows = cfg.band_rows > 0 ? cfg.band_rows : 0;
   f_.qp = cfg.qp; f_.qpc = kChromaQp[cfg.qp]; f_.lambda_q4 = kLambdaQ4[cfg.qp]; f_.range = cfg.me_range;
   f_.wpp = cfg.wpp;
   bind_set(0);
@@ -339,6 +346,112 @@ bool Encoder::finish_slot(Slot &sl, EncodedPicture *out)
   // ---- access unit assembly (host): parameter sets with IDR pictures, then the slice NAL
   out->valid = true; out->poc = sl.poc; out->qp = sl.qp; out->is_intra = sl.intra; out->bins = bins;
   { Tick tk; assemble_access_unit(out->au, sp_, sl.intra, sl.poc, sl.write_ps, rows_out_, nsub, sl.qp - cfg_.qp); t_asm_ += tk.ms(); }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Band mode: this encoder codes CTU rows [row0, row0 + nrows) of every picture; its neighbours (other processes /
+// GPUs) code the rest.  Everything up to deblocking is confined to the band by the tile rules; deblocking across the
+// band's boundaries needs the neighbour's boundary rows, which arrive through the halo blocks.
+// ---------------------------------------------------------------------------------------------------------------
+bool Encoder::band_picture_setup()
+{
+  HIP_CHECK(hipSetDevice(cfg_.device));
+  set_ = 0; bind_set(0);
+  cur_slot_ = &slot_[0];
+  prof_now_ = false;
+  const int period = cfg_.intra_period;
+  band_intra_ = (frame_idx_ == 0) || (period > 0 && (frame_idx_ % period) == 0);
+  if (band_intra_) poc_ = 0; else poc_++;
+  f_.qp = qp_cur_; f_.qpc = kChromaQp[qp_cur_]; f_.lambda_q4 = kLambdaQ4[qp_cur_];
+  f_.is_intra = band_intra_; f_.poc = poc_;
+  for (int c = 0; c < 3; c++) { f_.rec[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
+  Slot &sl = slot_[0];
+  f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err;
+  return true;
+}
+
+bool Encoder::band_phase1(const uint8_t *d_i420)
+{
+  if (cfg_.band_rows <= 0 || !d_i420) return false;
+  if (!band_picture_setup()) return false;
+  const EncFrame f = f_;
+  launch_pad_input(d_i420, cfg_.width, cfg_.height, src_[0][0], src_[0][1], src_[0][2], cw_, ch_, stream_);
+  if (band_intra_) {
+    launch_intra_analyse(f, stream_);
+    HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * rows_ * 3, stream_));
+    HIP_CHECK(hipMemsetAsync(f_.cu_cbf + (size_t)f.row0 * 8 * f.b8w, 0, (size_t)f.b8w * 8 * band_rows(f), stream_));
+    launch_intra_recon(f, stream_);
+  } else {
+    launch_me(f, stream_);
+    launch_inter_recon(f, stream_);
+    launch_inter_signal(f, stream_);
+  }
+  if (cfg_.deblock) launch_deblock_v(f, stream_);
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  return true;
+}
+
+// one halo block: [luma 4 rows | Cb 2 rows | Cr 2 rows | cu_log2 | cu_intra | cu_cbf (one 8x8 row each) | cu_mv (one 8x8 row)]
+size_t Encoder::halo_bytes() const { return (size_t)cw_ * 4 + (size_t)(cw_ / 2) * 2 * 2 + (size_t)(cw_ / 8) * 3 + (size_t)(cw_ / 8) * 4; }
+
+bool Encoder::band_export_halo(uint8_t *d_up, uint8_t *d_down)
+{
+  const int Y0 = f_.row0 * 64, Y1 = (f_.row0 + band_rows(f_)) * 64, b8w = f_.b8w, cw2 = cw_ / 2;
+  for (int side = 0; side < 2; side++) {
+    uint8_t *dst = side ? d_down : d_up;
+    if (!dst) continue;
+    const int y = side ? Y1 - 4 : Y0, b8y = side ? Y1 / 8 - 1 : Y0 / 8;        // first luma row of the 4-row strip; CU row
+    size_t o = 0;
+    HIP_CHECK(hipMemcpyAsync(dst + o, f_.rec[0] + (size_t)y * cw_, (size_t)cw_ * 4, hipMemcpyDeviceToDevice, stream_)); o += (size_t)cw_ * 4;
+    for (int c = 1; c < 3; c++) { HIP_CHECK(hipMemcpyAsync(dst + o, f_.rec[c] + (size_t)(y / 2) * cw2, (size_t)cw2 * 2, hipMemcpyDeviceToDevice, stream_)); o += (size_t)cw2 * 2; }
+    const uint8_t *arr[3] = {f_.cu_log2, f_.cu_intra, f_.cu_cbf};
+    for (int k = 0; k < 3; k++) { HIP_CHECK(hipMemcpyAsync(dst + o, arr[k] + (size_t)b8y * b8w, (size_t)b8w, hipMemcpyDeviceToDevice, stream_)); o += (size_t)b8w; }
+    HIP_CHECK(hipMemcpyAsync(dst + o, f_.cu_mv + (size_t)b8y * b8w * 2, (size_t)b8w * 4, hipMemcpyDeviceToDevice, stream_));
+  }
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  return true;
+}
+
+bool Encoder::band_import_halo(const uint8_t *d_from_up, const uint8_t *d_from_down)
+{
+  const int Y0 = f_.row0 * 64, Y1 = (f_.row0 + band_rows(f_)) * 64, b8w = f_.b8w, cw2 = cw_ / 2;
+  for (int side = 0; side < 2; side++) {
+    const uint8_t *src = side ? d_from_down : d_from_up;
+    if (!src) continue;
+    // from above: the neighbour's LAST rows land just above this band; from below: its FIRST rows just below
+    const int y = side ? Y1 : Y0 - 4, b8y = side ? Y1 / 8 : Y0 / 8 - 1;
+    if (y < 0 || y + 4 > ch_) return false;
+    size_t o = 0;
+    HIP_CHECK(hipMemcpyAsync(f_.rec[0] + (size_t)y * cw_, src + o, (size_t)cw_ * 4, hipMemcpyDeviceToDevice, stream_)); o += (size_t)cw_ * 4;
+    for (int c = 1; c < 3; c++) { HIP_CHECK(hipMemcpyAsync(f_.rec[c] + (size_t)(y / 2) * cw2, src + o, (size_t)cw2 * 2, hipMemcpyDeviceToDevice, stream_)); o += (size_t)cw2 * 2; }
+    uint8_t *arr[3] = {f_.cu_log2, f_.cu_intra, f_.cu_cbf};
+    for (int k = 0; k < 3; k++) { HIP_CHECK(hipMemcpyAsync(arr[k] + (size_t)b8y * b8w, src + o, (size_t)b8w, hipMemcpyDeviceToDevice, stream_)); o += (size_t)b8w; }
+    HIP_CHECK(hipMemcpyAsync(f_.cu_mv + (size_t)b8y * b8w * 2, src + o, (size_t)b8w * 4, hipMemcpyDeviceToDevice, stream_));
+  }
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  return true;
+}
+
+bool Encoder::band_phase2(std::vector<std::vector<uint8_t>> *substreams, EncodedPicture *info)
+{
+  if (cfg_.band_rows <= 0 || !substreams) return false;
+  HIP_CHECK(hipSetDevice(cfg_.device));
+  const EncFrame f = f_;
+  Slot &sl = slot_[0];
+  if (cfg_.deblock) launch_deblock_h(f, stream_);
+  launch_tokenize(f, stream_);
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  if (*sl.h_err) { fprintf(stderr, "kvazzup_amd: device error flags 0x%x\n", *sl.h_err); return false; }
+  const int wc = cw_ / 64;
+  for (int i = f.row0 * wc; i < (f.row0 + band_rows(f)) * wc; i++) if (sl.h_tok_count[i] < 0) { fprintf(stderr, "kvazzup_amd: token array overflow (CTU %d)\n", i); return false; }
+  uint64_t bins = 0;
+  entropy_->code_band(sl.h_tok_dense, sl.h_tok_count, sl.h_tok_off, wc, rows_, cfg_.wpp != 0, cfg_.tile_rows, band_intra_ ? 0 : 1, qp_cur_,
+                      f.row0, band_rows(f), *substreams, &bins);
+  if (info) { info->valid = true; info->poc = poc_; info->qp = qp_cur_; info->is_intra = band_intra_; info->bins = bins; info->au.clear(); }
+  frame_idx_++;
+  if (band_intra_) intra_count_++;
+  ref_idx_ = cur_idx_; cur_idx_ = (cur_idx_ + 1) % 3; out_idx_ = ref_idx_;
   return true;
 }
 

@@ -38,6 +38,25 @@ class EntropyHost {
     pool_.run(nsub, [this](int r) { code_row(r); });
     if (bins) *bins = bins_.load();
   }
+  // The substreams of CTU rows [row0, row0 + nrows) only (whole tiles): rows_out[k] = substream of CTU row row0 + k with WPP,
+  // else of the k-th tile of the band.  Arrays are indexed by picture CTU as in code_picture().
+  void code_band(const uint16_t *tokens, const int32_t *count, const uint32_t *offset, int wc, int hc, bool wpp, int tile_rows, int init_type, int qp,
+                 int row0, int nrows, std::vector<std::vector<uint8_t>> &rows_out, uint64_t *bins)
+  {
+    tokens_ = tokens; count_ = count; offset_ = offset; wc_ = wc; hc_ = hc; wpp_ = wpp; tiles_ = tile_rows < 1 ? 1 : tile_rows; init_type_ = init_type; qp_ = qp;
+    const int first = wpp ? row0 : tile_row_of(hc, tiles_, row0);
+    const int nsub = wpp ? nrows : tile_row_of(hc, tiles_, row0 + nrows - 1) - first + 1;
+    all_rows_.resize((size_t)(wpp ? hc : tiles_));
+    rows_ = &all_rows_;
+    saved_.resize((size_t)hc * CTX_COUNT);
+    ready_.reset(new std::atomic<int>[(size_t)hc]);
+    for (int r = 0; r < hc; r++) ready_[(size_t)r].store(0, std::memory_order_relaxed);
+    bins_.store(0);
+    pool_.run(nsub, [this, first](int k) { code_row(first + k); });
+    rows_out.resize((size_t)nsub);
+    for (int k = 0; k < nsub; k++) rows_out[(size_t)k].swap(all_rows_[(size_t)(first + k)]);
+    if (bins) *bins = bins_.load();
+  }
 
  private:
   // substream r: CTU row r with WPP, else tile row r (all of its CTU rows)
@@ -79,6 +98,7 @@ class EntropyHost {
   std::vector<uint8_t> saved_;
   std::unique_ptr<std::atomic<int>[]> ready_;
   std::vector<std::vector<uint8_t>> *rows_ = nullptr;
+  std::vector<std::vector<uint8_t>> all_rows_;
   std::atomic<uint64_t> bins_{0};
 };
 

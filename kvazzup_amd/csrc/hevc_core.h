@@ -33,6 +33,7 @@ struct EncFrame {
   int is_intra, poc;
   int wpp;
   int tile_rows;            // 1: no tiles; n: n full-width tile rows, uniform spacing (6.5.1)
+  int row0, nrows;          // band of CTU rows the encoder kernels work on (nrows == 0: the whole picture); a band starts and ends on tile boundaries
   int chp;                  // ch | tile rows << 20: the `ch` argument of avail64() and of everything that forwards to it
   const uint8_t *src[3];
   uint8_t *rec[3];
@@ -54,6 +55,7 @@ struct EncFrame {
 
 enum { CU_SKIP = 1, CU_MERGE = 2 };
 
+KVZ_HD int band_rows(const EncFrame &f) { return f.nrows > 0 ? f.nrows : (f.ch >> 6); }
 KVZ_HD int b8idx(const EncFrame &f, int x, int y) { return (y >> 3) * f.b8w + (x >> 3); }
 
 // z-scan order address of the 4x4 block holding luma sample (x, y), CTU = 64 (H.265 6.5.2)

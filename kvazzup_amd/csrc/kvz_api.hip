@@ -156,6 +156,8 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
   INT_OPT("me-range", me_range, 1, 32)
   INT_OPT("gpu", gpu_device, 0, 64)
   BOOL_OPT("recon-output", recon_output)
+  INT_OPT("band-row0", band_row0, 0, 4096)
+  INT_OPT("band-rows", band_rows, 0, 4096)
   BOOL_OPT("rdoq", rdoq_enable) BOOL_OPT("signhide", signhide_enable) BOOL_OPT("smp", smp_enable) BOOL_OPT("amp", amp_enable)
   BOOL_OPT("bipred", bipred) BOOL_OPT("tmvp", tmvp_enable) BOOL_OPT("transform-skip", trskip_enable)
   BOOL_OPT("full-intra-search", full_intra_search) BOOL_OPT("mv-rdo", mv_rdo) BOOL_OPT("rdoq-skip", rdoq_skip)
@@ -237,6 +239,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.me_range = cfg->me_range; ec.fps_num = cfg->framerate_num; ec.fps_den = cfg->framerate_denom;
   ec.wpp = cfg->wpp ? 1 : 0; ec.deblock = cfg->deblock_enable ? 1 : 0; ec.device = cfg->gpu_device; ec.owf = cfg->owf > 2 ? 2 : cfg->owf;
   ec.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1;
+  ec.band_row0 = cfg->band_row0; ec.band_rows = cfg->band_rows;
   ec.bitrate = cfg->target_bitrate > 0 ? cfg->target_bitrate : 0;      // any rc-algorithm value selects the one picture-level controller
   std::string err;
   Encoder *impl = Encoder::create(ec, &err);
@@ -390,5 +393,49 @@ const char *kvzx_encoder_kernel_name(int id)
   return (id >= 0 && id < kvzx::K_COUNT) ? names[id] : nullptr;
 }
 uint64_t kvzx_encoder_last_bins(kvz_encoder *e) { return e ? e->last_bins : 0; }
+
+// ---- tile-row split of one picture over several encoders (include/kvazzup_amd.h) ----
+int kvzx_encoder_band_phase1(kvz_encoder *e, const void *d_i420) { return e && e->impl->band_phase1((const uint8_t *)d_i420) ? 1 : 0; }
+size_t kvzx_encoder_band_halo_bytes(kvz_encoder *e) { return e ? e->impl->halo_bytes() : 0; }
+int kvzx_encoder_band_export_halo(kvz_encoder *e, void *d_up, void *d_down) { return e && e->impl->band_export_halo((uint8_t *)d_up, (uint8_t *)d_down) ? 1 : 0; }
+int kvzx_encoder_band_import_halo(kvz_encoder *e, const void *d_from_up, const void *d_from_down) { return e && e->impl->band_import_halo((const uint8_t *)d_from_up, (const uint8_t *)d_from_down) ? 1 : 0; }
+int kvzx_encoder_band_phase2(kvz_encoder *e, uint8_t *buf, uint32_t cap, uint32_t *sizes, int max_sub, int *nsub_out, kvz_frame_info *info)
+{
+  if (!e || !buf || !sizes || !nsub_out) return 0;
+  std::vector<std::vector<uint8_t>> subs; EncodedPicture ep;
+  if (!e->impl->band_phase2(&subs, &ep)) return 0;
+  if ((int)subs.size() > max_sub) return 0;
+  size_t o = 0;
+  for (size_t k = 0; k < subs.size(); k++) {
+    if (o + subs[k].size() > cap) return 0;
+    memcpy(buf + o, subs[k].data(), subs[k].size()); o += subs[k].size(); sizes[k] = (uint32_t)subs[k].size();
+  }
+  *nsub_out = (int)subs.size();
+  e->last_bins = ep.bins;
+  fill_info(e, ep, info);
+  return 1;
+}
+// Host only (no GPU): the access unit from the substreams of all bands in picture order, as rank 0 does after gathering them.
+// cfg: the configuration every band encoder was opened with; data: the substreams back to back, sizes[nsub] their lengths.
+int kvzx_assemble_access_unit(const kvz_config *cfg, int idr, int poc, int write_parameter_sets, int slice_qp, const uint8_t *data, const uint32_t *sizes, int nsub,
+                              uint8_t *out, uint32_t cap, uint32_t *len_out)
+{
+  if (!cfg || !data || !sizes || nsub < 1 || !out || !len_out) return 0;
+  kvzx::StreamParams sp;
+  sp.width = cfg->width; sp.height = cfg->height; sp.cw = (cfg->width + 63) & ~63; sp.ch = (cfg->height + 63) & ~63;
+  if (sp.cw < 128) sp.cw = 128;
+  sp.qp = cfg->qp; sp.wpp = cfg->wpp ? 1 : 0; sp.deblock = cfg->deblock_enable ? 1 : 0; sp.fps_num = cfg->framerate_num; sp.fps_den = cfg->framerate_denom;
+  sp.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1;
+  if (nsub != (sp.wpp ? sp.ch / 64 : sp.tile_rows)) return 0;
+  std::vector<std::vector<uint8_t>> rows((size_t)nsub);
+  size_t o = 0;
+  for (int k = 0; k < nsub; k++) { rows[(size_t)k].assign(data + o, data + o + sizes[k]); o += sizes[k]; }
+  std::vector<uint8_t> au;
+  kvzx::assemble_access_unit(au, sp, idr != 0, poc, write_parameter_sets != 0, rows, nsub, slice_qp - cfg->qp);
+  *len_out = (uint32_t)au.size();
+  if (au.size() > cap) return 0;
+  memcpy(out, au.data(), au.size());
+  return 1;
+}
 
 }  // extern "C"

@@ -1,0 +1,156 @@
+"""Tile-row split of ONE picture stream over several processes, one GPU each (BASELINE configs[4]).
+
+Every rank opens an encoder on its own device with the same configuration, `tiles = 1xN` and its band of CTU rows
+(whole tile rows).  Per picture: band_phase1 on every rank; the two halo blocks (4 luma + 2 x 2 chroma rows with their
+vertical edges filtered, and the CU records of one 8x8 row) go to rank - 1 / rank + 1 -- the one exchange step on the
+data path, ~7 bytes per luma column and boundary; band_phase2; the substreams are gathered on rank 0, which assembles
+the access unit.  torch.distributed is the transport: backend "nccl" (= RCCL over xGMI) moves the device blocks
+directly; with "gloo" (CPU tests, several ranks sharing one GPU) they are staged through host memory.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+def band_partition(ctu_rows, tile_rows, world):
+    """contiguous whole tile rows per rank: [(first CTU row, CTU rows)] * world; tiles follow H.265 6.5.1 uniform spacing"""
+    if tile_rows < world or tile_rows % world:
+        raise ValueError("tile rows (%d) must be a multiple of the number of ranks (%d)" % (tile_rows, world))
+    bd = [(i * ctu_rows) // tile_rows for i in range(tile_rows + 1)]
+    per = tile_rows // world
+    return [(bd[r * per], bd[(r + 1) * per] - bd[r * per]) for r in range(world)]
+
+
+class BandEncoder:
+    """one rank's share of the split encoder; `dist` is torch.distributed (initialised) or None for a single process"""
+
+    def __init__(self, width, height, tile_rows, rank, world, options=(), device=0, dist=None):
+        self.torch, self.dist = None, dist
+        if world > 1:
+            import torch                        # (import torch before this library is first loaded in a process: two HIP runtimes)
+            self.torch = torch
+        self.lib = N.load_library()
+        self.api = self.lib.kvz_api_get(8).contents
+        self.w, self.h, self.rank, self.world = width, height, rank, world
+        self.ctu_rows = (height + 63) // 64
+        self.row0, self.nrows = band_partition(self.ctu_rows, tile_rows, world)[rank]
+        self.cfg = self.api.config_alloc()
+        self.api.config_init(self.cfg)
+        opts = {"preset": "ultrafast", "input-res": "%dx%d" % (width, height), "input-fps": "30/1", "vps-period": "1", "tiles": "1x%d" % tile_rows, "gpu": str(device),
+                "band-row0": str(self.row0), "band-rows": str(self.nrows)}
+        opts.update({k: str(v) for k, v in options})
+        for k, v in opts.items():
+            if self.api.config_parse(self.cfg, k.encode(), v.encode()) != 1 and k != "preset":
+                raise ValueError("option %s=%s rejected" % (k, v))
+        self.cfg.contents.target_bitrate = 0
+        self.enc = self.api.encoder_open(self.cfg)
+        if not self.enc:
+            raise RuntimeError("encoder_open failed (no usable HIP device? there is no CPU fallback)")
+        L = self.lib
+        L.kvzx_encoder_band_halo_bytes.restype = C.c_size_t
+        L.kvzx_encoder_band_halo_bytes.argtypes = [C.c_void_p]
+        L.kvzx_encoder_band_phase1.argtypes = [C.c_void_p, C.c_void_p]
+        L.kvzx_encoder_band_export_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kvzx_encoder_band_import_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kvzx_encoder_band_phase2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        nh = int(L.kvzx_encoder_band_halo_bytes(self.enc))
+        self.halo_out = self.halo_in = None
+        if world > 1:
+            torch = self.torch
+            self.dev = torch.device("cuda", device)
+            self.halo_out = [torch.empty(nh, dtype=torch.uint8, device=self.dev) for _ in range(2)]    # up, down
+            self.halo_in = [torch.empty(nh, dtype=torch.uint8, device=self.dev) for _ in range(2)]     # from up, from down
+        self.buf = np.empty(width * height * 3 + (1 << 20), dtype=np.uint8)
+        self.sizes = np.zeros(self.ctu_rows, dtype=np.uint32)
+        self.halo_bytes_exchanged = 0
+
+    # ---- the exchange step
+    def _exchange(self):
+        d, t = self.dist, self.torch
+        up, down = self.rank - 1, self.rank + 1
+        have_up, have_down = up >= 0, down < self.world
+        if d is None or self.world == 1:
+            return have_up, have_down
+        staged = d.get_backend() != "nccl"
+        send = [x.cpu() if staged else x for x in self.halo_out]
+        recv = [t.empty_like(x) for x in send]
+        ops = []
+        if have_up:
+            ops += [d.P2POp(d.isend, send[0], up), d.P2POp(d.irecv, recv[0], up)]
+        if have_down:
+            ops += [d.P2POp(d.isend, send[1], down), d.P2POp(d.irecv, recv[1], down)]
+        if ops:
+            for r in d.batch_isend_irecv(ops):
+                r.wait()
+        for i, have in enumerate((have_up, have_down)):
+            if have:
+                self.halo_in[i].copy_(recv[i])
+                self.halo_bytes_exchanged += 2 * recv[i].numel()
+        if not staged:
+            t.cuda.synchronize(self.dev)
+        return have_up, have_down
+
+    def encode(self, d_i420_ptr):
+        """one picture; returns the access unit on rank 0 (None elsewhere)"""
+        L = self.lib
+        if not L.kvzx_encoder_band_phase1(self.enc, d_i420_ptr):
+            raise RuntimeError("band_phase1 failed")
+        if self.world > 1 and not L.kvzx_encoder_band_export_halo(self.enc, self.halo_out[0].data_ptr() if self.rank > 0 else None,
+                                                                  self.halo_out[1].data_ptr() if self.rank + 1 < self.world else None):
+            raise RuntimeError("band_export_halo failed")
+        have_up, have_down = self._exchange()
+        if self.world > 1 and not L.kvzx_encoder_band_import_halo(self.enc, self.halo_in[0].data_ptr() if have_up else None, self.halo_in[1].data_ptr() if have_down else None):
+            raise RuntimeError("band_import_halo failed")
+        nsub = C.c_int(0)
+        info = N.KvzFrameInfo()
+        if not L.kvzx_encoder_band_phase2(self.enc, self.buf.ctypes.data, len(self.buf), self.sizes.ctypes.data, len(self.sizes), C.byref(nsub), C.byref(info)):
+            raise RuntimeError("band_phase2 failed")
+        sizes = [int(x) for x in self.sizes[:nsub.value]]
+        data = bytes(self.buf[:sum(sizes)])
+        mine = (sizes, data, info.poc, info.qp, info.nal_unit_type)
+        if self.dist is not None and self.world > 1:
+            parts = [None] * self.world if self.rank == 0 else None
+            self.dist.gather_object(mine, parts, dst=0)
+        else:
+            parts = [mine]
+        if self.rank != 0:
+            return None
+        return assemble(self.lib, self.cfg, parts)
+
+    def close(self):
+        if self.enc:
+            self.api.encoder_close(self.enc)
+            self.enc = None
+        if self.cfg:
+            self.api.config_destroy(self.cfg)
+            self.cfg = None
+
+
+_intra_count = {}
+
+
+def assemble(lib, cfg, parts, write_parameter_sets=None):
+    """rank 0: substreams of all bands in picture order -> one access unit (host only, no GPU)"""
+    sizes = [s for p in parts for s in p[0]]
+    data = b"".join(p[1] for p in parts)
+    poc, qp, nal = parts[0][2], parts[0][3], parts[0][4]
+    idr = nal == 19
+    if write_parameter_sets is None:                 # parameter sets with every vps-period-th IDR, as the single encoder does
+        key = C.addressof(cfg.contents)
+        n = _intra_count.get(key, 0)
+        vp = cfg.contents.vps_period
+        write_parameter_sets = idr and (n == 0 or (vp > 0 and n % vp == 0))
+        if idr:
+            _intra_count[key] = n + 1
+    lib.kvzx_assemble_access_unit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
+    sz = np.array(sizes, dtype=np.uint32)
+    src = np.frombuffer(data, dtype=np.uint8) if data else np.zeros(1, np.uint8)
+    out = np.empty(len(data) * 2 + 4096, dtype=np.uint8)
+    n = C.c_uint32(0)
+    ok = lib.kvzx_assemble_access_unit(cfg, int(idr), int(poc), int(bool(write_parameter_sets)), int(qp), src.ctypes.data, sz.ctypes.data, len(sizes),
+                                       out.ctypes.data, len(out), C.byref(n))
+    if not ok:
+        raise RuntimeError("kvzx_assemble_access_unit failed (substream count %d)" % len(sizes))
+    return bytes(out[:n.value])

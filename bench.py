@@ -26,6 +26,8 @@ WORKLOADS = {
     # configs[2]: 4K encode (decode is run too; reported in the same fps)
     "4k": dict(w=3840, h=2160, name="2160p-yuv420-ultrafast-p64-qp32-encode+decode", cfg_index=3),
     "720p": dict(w=1280, h=720, name="720p-yuv420-ultrafast-p64-qp32-encode+decode", cfg_index=2),
+    # configs[4]: ONE 8K stream, its 8 tile rows split over the ranks (strong scaling; see tilesplit_main)
+    "8k-tilesplit": dict(w=7680, h=4320, name="4320p-yuv420-ultrafast-p64-qp32-encode-tile-row-split", cfg_index=5),
 }
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -73,6 +75,62 @@ def cpu_baseline(w, h, frames, me_range):
             "sample": "%d pictures %dx%d (1 intra + %d inter, search range %d), encode+decode by oracle/ (scalar C, one thread)" % (frames, w, h, frames - 1, me_range)}
 
 
+def tilesplit_main(args):
+    """BASELINE configs[4]: a single 8K picture stream, 8 full-width tile rows, split over the ranks (whole tile rows per
+    rank); the only exchange on the data path is the deblock halo (kvazzup_amd/tilesplit.py).  Encode only; strong scaling."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    from kvazzup_amd import synth
+    from kvazzup_amd.tilesplit import BandEncoder
+    wl = WORKLOADS["8k-tilesplit"]
+    w, h, tile_rows = wl["w"], wl["h"], 8
+    total = args.warmup + args.steps
+    clip = [synth.frame_torch(synth.MOVING, 0x5EED0005, w, h, t, dev) for t in range(total)]     # every rank holds the stream (a band only reads its rows)
+    torch.cuda.synchronize()
+    be = BandEncoder(w, h, tile_rows, rank, world, options=(("qp", 32), ("period", 64), ("me-range", args.me_range)), device=local_rank,
+                     dist=dist if world > 1 else None)
+    nbytes = 0
+    for t in range(args.warmup):
+        be.encode(clip[t].data_ptr())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, total):
+        au = be.encode(clip[t].data_ptr())
+        if au is not None:
+            nbytes += len(au)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "hevc_encode_fps_one_stream_tile_row_split", "value": round(args.steps / elapsed, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": wl["name"], "width": w, "height": h, "tile_rows": tile_rows, "ranks": world, "ctu_rows_rank0": be.nrows,
+                       "intra_period": 64, "qp": 32, "me_range": args.me_range, "bytes_per_frame": round(nbytes / args.steps, 1),
+                       "halo_bytes_per_picture_and_rank": round(be.halo_bytes_exchanged / max(1, total), 1),
+                       "exchange": "2 halo blocks per internal boundary and picture (4 luma + 2x2 chroma rows + CU records), RCCL send/recv"},
+            "roofline": None, "cpu_baseline": None}))
+    be.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +147,8 @@ def main():
                     help="uvgComm setting video/OWF (kvazaar owf): 1 = host arithmetic coding of picture t overlaps the kernels of t + 1; "
                          "2 = it runs on a background thread and the output lags two pictures")
     args = ap.parse_args()
+    if args.workload == "8k-tilesplit":
+        return tilesplit_main(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -65,6 +65,9 @@ KVZ_PUBLIC int kvzx_decoder_debug_copy(OpenHevc_Handle h, const char *what, void
  * blocks -> import_halo (NULL where there is no neighbour) -> phase2 (horizontal edges incl. the band's boundary edges,
  * tokenizer, arithmetic coding): the band's substreams, back to back in buf with sizes[].  Rank 0 gathers all substreams in
  * picture order and calls kvzx_assemble_access_unit (host only).  kvazzup_amd/tilesplit.py drives this over torch.distributed. */
+/* delta-QP map for the pictures submitted through the device entry point (the host entry point takes it from kvz_picture.roi,
+ * kvazaarfilter.cpp:423-431): w x h int8 cells over the picture, w == 0 removes it; needs "set-qp-in-cu" = 1 */
+KVZ_PUBLIC void kvzx_encoder_set_roi(kvz_encoder *enc, int w, int h, const int8_t *map);
 KVZ_PUBLIC int kvzx_encoder_band_phase1(kvz_encoder *enc, const void *d_i420);
 KVZ_PUBLIC size_t kvzx_encoder_band_halo_bytes(kvz_encoder *enc);
 KVZ_PUBLIC int kvzx_encoder_band_export_halo(kvz_encoder *enc, void *d_up, void *d_down);

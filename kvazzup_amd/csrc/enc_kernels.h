@@ -18,6 +18,7 @@ void launch_dec_intra_recon(const EncFrame &f, hipStream_t st);
 // levels as `count` words (raster position inside the block << 16 | level & 0xffff) starting at word `offset`
 struct TuDesc { uint16_t x, y; uint8_t plane, log2; uint16_t count; uint32_t offset; };
 void launch_scatter_levels(const EncFrame &f, const TuDesc *tus, int ntu, const uint32_t *pairs, hipStream_t st);
+void launch_qp_resolve(const EncFrame &f, hipStream_t st);  // per-CTU QP: first coded CU, QpY, delta (no-op without a QP map)
 void launch_deblock_v(const EncFrame &f, hipStream_t st);   // vertical edges of the band
 void launch_deblock_h(const EncFrame &f, hipStream_t st);   // horizontal edges of the band, its two boundary edges included
 void launch_tokenize(const EncFrame &f, hipStream_t st);   // k_tokenize + k_tok_scan + k_tok_compact

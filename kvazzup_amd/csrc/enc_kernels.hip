@@ -445,6 +445,7 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
   const int bi0 = b8idx(f, x0, y0);
   const bool split = f.cu_log2[bi0] == 4;
   const int cw2 = f.cw >> 1, ch2 = f.ch >> 1;
+  const int qp = ctu_quant_qp(f, x0, y0), qpc = kChromaQp[qp];       // the 32x32 block lies inside one CTU
   // matrices of the two block sizes in use (luma n, chroma n / 2): adjacent in the table
   if (split) load_matrices(s.M, 16, 64 + 256, tid, 256);
   else {
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
         atomicOr(&s.nz[0], 1u << tu);
         const uint2 l4 = *(const uint2 *)&f.coef[0][g];
         const int lv[4] = {(int16_t)(l4.x & 0xffff), (int16_t)(l4.x >> 16), (int16_t)(l4.y & 0xffff), (int16_t)(l4.y >> 16)};
-        for (int i = 0; i < 4; i++) A[(tx + i) * n + ty] = (int16_t)dequant_coef(lv[i], f.qp, l2);
+        for (int i = 0; i < 4; i++) A[(tx + i) * n + ty] = (int16_t)dequant_coef(lv[i], qp, l2);
       }
     } else {
       const uint32_t s4 = *(const uint32_t *)&f.src[0][g];
@@ -487,8 +488,8 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
     auto px16 = [](int tu, int y, int x) { return ((tu >> 1) * 16 + y) * 32 + (tu & 1) * 16 + x; };
     const int cw = f.cw; int16_t *base = f.coef[0] + (size_t)y0 * cw + x0;
     auto ci16 = [=](int tu, int y, int x) { return base + (size_t)((tu >> 1) * 16 + y) * cw + (tu & 1) * 16 + x; };
-    if (split) inter_transform<DEC, 4, 2>(s, f.qp, &s.nz[0], px16, ci16, tid);
-    else inter_transform_32<DEC>(s, f.qp, &s.nz[0], base, cw, tid);
+    if (split) inter_transform<DEC, 4, 2>(s, qp, &s.nz[0], px16, ci16, tid);
+    else inter_transform_32<DEC>(s, qp, &s.nz[0], base, cw, tid);
   }
   *(uint32_t *)&f.rec[0][(size_t)(y0 + (tid >> 3)) * f.cw + x0 + (tid & 7) * 4] = *(const uint32_t *)&s.px[(tid >> 3) * 32 + (tid & 7) * 4];
   // ---- chroma: reference windows of the eight 8x8 sub-blocks (plane x quadrant) -> LDS; mv in 1/8 samples
@@ -526,8 +527,8 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
       if (has) {
         atomicOr(&s.nz[1], 1u << tu);
         const uint32_t l2v = *(const uint32_t *)&f.coef[1 + pl][g];
-        A[tx * cn + ty] = (int16_t)dequant_coef((int16_t)(l2v & 0xffff), f.qpc, cl2);
-        A[(tx + 1) * cn + ty] = (int16_t)dequant_coef((int16_t)(l2v >> 16), f.qpc, cl2);
+        A[tx * cn + ty] = (int16_t)dequant_coef((int16_t)(l2v & 0xffff), qpc, cl2);
+        A[(tx + 1) * cn + ty] = (int16_t)dequant_coef((int16_t)(l2v >> 16), qpc, cl2);
       }
     } else {
       const uint32_t s2 = *(const uint16_t *)&f.src[1 + pl][g];
@@ -542,8 +543,8 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
     int16_t *cb = f.coef[1] + base, *cr = f.coef[2] + base;
     auto ci1 = [=](int tu, int y, int x) { return (tu ? cr : cb) + (size_t)y * cw2 + x; };
     auto ci4 = [=](int tu, int y, int x) { return ((tu >> 2) ? cr : cb) + (size_t)(((tu >> 1) & 1) * 8 + y) * cw2 + (tu & 1) * 8 + x; };
-    if (split) inter_transform<DEC, 3, 1>(s, f.qpc, &s.nz[1], px4, ci4, tid);
-    else inter_transform<DEC, 4, 1>(s, f.qpc, &s.nz[1], px1, ci1, tid);
+    if (split) inter_transform<DEC, 3, 1>(s, qpc, &s.nz[1], px4, ci4, tid);
+    else inter_transform<DEC, 4, 1>(s, qpc, &s.nz[1], px1, ci1, tid);
   }
   if (tid < 128) {
     const int pl = tid >> 6, y = (tid >> 2) & 15, x = (tid & 3) * 4;
@@ -947,7 +948,7 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
 {
   __shared__ IntraWaveLds s;
   const int lane = threadIdx.x, wl = threadIdx.x & 63, row = f.row0 + blockIdx.x / 3, c = blockIdx.x % 3, wc = f.cw >> 6;
-  const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, qp = c ? f.qpc : f.qp, P = 16 + 2 * S;
+  const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, P = 16 + 2 * S;
   uint32_t *my_ctr = f.sync + row * 3 + c;
   const uint32_t *up_ctr = f.sync + (row - 1) * 3 + c;
   load_matrices(s.M, 0, KV_MATRIX_ENTRIES, lane, T);
@@ -959,6 +960,7 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
 #endif
   for (int cx = 0; cx < wc; cx++) {
     PROF(10);
+    const int qpl = ctu_quant_qp(f, cx * 64, row * 64), qp = c ? kChromaQp[qpl] : qpl;
     // per-CU parameters: lane z holds those of the CU covering the z-th 8x8 block
     const int bi = b8idx(f, cx * 64 + zx * 8, row * 64 + zy * 8);
     const int my_l2 = f.cu_log2[bi], my_mode = f.cu_intra_mode[bi], my_given = DEC ? f.cu_cbf[bi] : 0;
@@ -1027,6 +1029,41 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
 }
 
 // =============================================================================================
+// Per-CTU QP (delta-QP map): after reconstruction, which CU of every CTU is the first with residual, and from that the
+// QpY every CU ends up with (H.265 8.6.1, quantisation group = CTU: the prediction is the QpY of the previous CTU in
+// decoding order, or the slice QP at the start of a tile and -- with WPP -- of a CTU row).  Statement: roi_resolve() in
+// oracle/hevc_enc.c.
+// =============================================================================================
+__global__ __launch_bounds__(64) void k_qp_first(EncFrame f)                // one wave per CTU of the band
+{
+  const int wc = f.cw >> 6, ctu = blockIdx.x + f.row0 * wc, cx = ctu % wc, cy = ctu / wc, lane = threadIdx.x;
+  int xi, yi; ctu_z_to_xy(lane, xi, yi);
+  const int x = cx * 64 + xi * 8, y = cy * 64 + yi * 8, bi = b8idx(f, x, y), n = 1 << f.cu_log2[bi];
+  const bool coded_origin = !((x | y) & (n - 1)) && f.cu_cbf[bi] != 0;
+  const uint64_t m = __ballot(coded_origin);
+  if (lane == 0) f.ctu_first[ctu] = (uint8_t)(m ? __builtin_ctzll(m) : 64);
+}
+__global__ __launch_bounds__(256) void k_qp_chain(EncFrame f)                // one thread per CTU of the band
+{
+  const int wc = f.cw >> 6, hc = f.ch >> 6, t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= wc * band_rows(f)) return;
+  const int ctu = t + f.row0 * wc, cx = ctu % wc, cy = ctu / wc;
+  // QpY of the nearest CTU at or before this one in its chain that codes a delta; the chain starts at the CTU row (WPP) or the tile
+  const int first_cy = f.wpp ? cy : tile_row_first(hc, f.tile_rows, tile_row_of(hc, f.tile_rows, cy));
+  int qy = f.qp, prev = f.qp; bool have = false, have_prev = false;
+  for (int c = ctu; c >= first_cy * wc; c--) {
+    if (f.ctu_first[c] < 64) {
+      if (c == ctu) { qy = f.ctu_qt[c]; have = true; }
+      else { prev = f.ctu_qt[c]; have_prev = true; break; }
+    }
+  }
+  (void)have_prev;
+  if (!have) qy = prev;
+  f.ctu_qy[ctu] = (int8_t)qy;
+  f.ctu_delta[ctu] = (int8_t)(have ? qy - prev : 0);
+}
+
+// =============================================================================================
 // Deblocking: all vertical edges of the picture, then (second launch) all horizontal edges
 // =============================================================================================
 __global__ __launch_bounds__(256) void k_deblock_v(EncFrame f)
@@ -1038,11 +1075,12 @@ __global__ __launch_bounds__(256) void k_deblock_v(EncFrame f)
   if (!is_cu_edge_v(f, x, y)) return;
   int bs = edge_bs(f, x - 1, y, x, y);
   if (!bs) return;
-  deblock_luma_segment(f.rec[0] + y * f.cw + x, 1, f.cw, bs, f.qp);
+  const int qp = (cu_qpy(f, x - 1, y) + cu_qpy(f, x, y) + 1) >> 1;            // QpP and QpQ averaged (8.7.2.5.3)
+  deblock_luma_segment(f.rec[0] + y * f.cw + x, 1, f.cw, bs, qp);
   if (bs == 2 && (x & 15) == 0) {
     int cw2 = f.cw >> 1;
-    deblock_chroma_segment(f.rec[1] + (y >> 1) * cw2 + (x >> 1), 1, cw2, 2, f.qp);
-    deblock_chroma_segment(f.rec[2] + (y >> 1) * cw2 + (x >> 1), 1, cw2, 2, f.qp);
+    deblock_chroma_segment(f.rec[1] + (y >> 1) * cw2 + (x >> 1), 1, cw2, 2, qp);
+    deblock_chroma_segment(f.rec[2] + (y >> 1) * cw2 + (x >> 1), 1, cw2, 2, qp);
   }
 }
 __global__ __launch_bounds__(256) void k_deblock_h(EncFrame f)
@@ -1057,11 +1095,12 @@ __global__ __launch_bounds__(256) void k_deblock_h(EncFrame f)
   if (!is_cu_edge_h(f, x, y)) return;
   int bs = edge_bs(f, x, y - 1, x, y);
   if (!bs) return;
-  deblock_luma_segment(f.rec[0] + y * f.cw + x, f.cw, 1, bs, f.qp);
+  const int qp = (cu_qpy(f, x, y - 1) + cu_qpy(f, x, y) + 1) >> 1;
+  deblock_luma_segment(f.rec[0] + y * f.cw + x, f.cw, 1, bs, qp);
   if (bs == 2 && (y & 15) == 0) {
     int cw2 = f.cw >> 1;
-    deblock_chroma_segment(f.rec[1] + (y >> 1) * cw2 + (x >> 1), cw2, 1, 2, f.qp);
-    deblock_chroma_segment(f.rec[2] + (y >> 1) * cw2 + (x >> 1), cw2, 1, 2, f.qp);
+    deblock_chroma_segment(f.rec[1] + (y >> 1) * cw2 + (x >> 1), cw2, 1, 2, qp);
+    deblock_chroma_segment(f.rec[2] + (y >> 1) * cw2 + (x >> 1), cw2, 1, 2, qp);
   }
 }
 
@@ -1183,6 +1222,8 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
       TokOut t; t.tabs = &tabs; t.p = hdr; t.n = 0; t.cap = TOK_HDR_CAP;
       enc_split_flags(v, t, f.cw, f.chp, x0, y0, z, cu.log2);
       enc_cu_header(v, t, f.cw, f.chp, f.is_intra != 0, x0, y0, cu);
+      // the quantisation group's (= CTU's) delta QP goes with its first CU that has residual, right after the cbf flags
+      if (f.ctu_qy && !(cu.flags & CU_SKIP) && cu.cbf && z == f.ctu_first[ctu]) enc_cu_qp_delta(t, f.ctu_delta[ctu]);
       hdr_n = t.n;
     }
     const int cbf = (cu.flags & CU_SKIP) ? 0 : cu.cbf;          // wave-uniform
@@ -1380,6 +1421,13 @@ void launch_intra_analyse(const EncFrame &f, hipStream_t st) { hipLaunchKernelGG
 #endif
 void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL((k_intra_recon<false, KVZ_INTRA_THREADS>), dim3(3 * band_rows(f)), dim3(KVZ_INTRA_THREADS), 0, st, f); }
 void launch_dec_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL((k_intra_recon<true, KVZ_INTRA_THREADS>), dim3(3 * band_rows(f)), dim3(KVZ_INTRA_THREADS), 0, st, f); }
+void launch_qp_resolve(const EncFrame &f, hipStream_t st)
+{
+  if (!f.ctu_qy) return;
+  const int n = (f.cw / 64) * band_rows(f);
+  hipLaunchKernelGGL(k_qp_first, dim3(n), dim3(64), 0, st, f);
+  hipLaunchKernelGGL(k_qp_chain, dim3((n + 255) / 256), dim3(256), 0, st, f);
+}
 void launch_deblock_v(const EncFrame &f, hipStream_t st)
 {
   int nv = ((f.cw >> 3) - 1) * (band_rows(f) * 16);

@@ -32,6 +32,7 @@ struct EncoderConfig {
   int tile_rows = 1;          // full-width tile rows (kvazaar "tiles" 1xN), uniform spacing, loop filter across tiles on
   int device = 0;
   int entropy_threads = 16;   // host threads of the arithmetic-coding stage
+  int qp_in_cu = 0;           // kvazaar "set-qp-in-cu": cu_qp_delta_enabled_flag; a delta-QP map (set_roi, kvz_picture.roi) then gives every CTU its own QP
   int bitrate = 0;            // bits per second; 0 = constant QP, > 0 = "uvgx rate control v1" (oracle/hevc_enc.c rate_control())
   int owf = 0;                // kvazaar "owf": 0 = encode() returns its own picture; 1 = output lags one picture and the host
                               // coding of picture t overlaps the kernels of t + 1; >= 2 = output lags two pictures and the host
@@ -55,6 +56,9 @@ class Encoder {
   bool encode_device(const uint8_t *d_i420, EncodedPicture *out);
   // owf >= 1: outputs the picture still in flight, if any (kvz_api encoder_encode with pic_in == NULL)
   bool flush(EncodedPicture *out);
+  // delta-QP map for the following pictures (kvz_picture.roi, kvazaarfilter.cpp:423-431): w x h int8 cells spread uniformly over
+  // the picture, clamped to [-12, 12]; w == 0 removes it.  Needs cfg.qp_in_cu.  Statement: roi_targets() in oracle/hevc_enc.c.
+  void set_roi(int w, int h, const int8_t *map);
   // ---- band mode (cfg.band_rows > 0); every call is synchronous.  Per picture: band_phase1, export the halos, exchange them
   // with the neighbouring bands' encoders (rank - 1 gets `up`, rank + 1 gets `down`), import theirs, band_phase2.
   bool band_phase1(const uint8_t *d_i420);                       // input, decisions, reconstruction, vertical-edge deblocking of the band
@@ -106,6 +110,10 @@ class Encoder {
   uint8_t *cu_bytes_[2] = {nullptr, nullptr};          // 7 byte arrays back to back
   int16_t *cu_mv_[2] = {nullptr, nullptr}, *cu_mvd_[2] = {nullptr, nullptr};
   int set_ = 0, out_set_ = 0;
+  std::vector<int8_t> roi_; int roi_w_ = 0, roi_h_ = 0;
+  int8_t *ctu_qt_[2] = {nullptr, nullptr}, *ctu_qy_[2] = {nullptr, nullptr}, *ctu_delta_[2] = {nullptr, nullptr}; uint8_t *ctu_first_[2] = {nullptr, nullptr};   // per picture parity
+  int8_t *h_ctu_qt_[2] = {nullptr, nullptr};   // pinned staging of the target map
+  bool upload_qp_targets();
   int qp_cur_ = 0; int64_t rc_debt_ = 0; uint32_t rc_bytes_[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rate control state (calling thread)
   void rate_control();
   bool band_picture_setup();

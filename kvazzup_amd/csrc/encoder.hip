@@ -58,6 +58,13 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
     HIP_OK(hipMalloc(&cu_mvd_[k], nb8 * 2 * sizeof(int16_t))); HIP_OK(hipMemset(cu_mvd_[k], 0, nb8 * 2 * sizeof(int16_t)));
     HIP_OK(hipEventCreateWithFlags(&ev_tok_done_[k], hipEventDisableTiming));
   }
+  if (cfg.qp_in_cu) {
+    const size_t nctu = (size_t)(cw_ / 64) * rows_;
+    for (int k = 0; k < 2; k++) {
+      HIP_OK(hipMalloc(&ctu_qt_[k], nctu)); HIP_OK(hipMalloc(&ctu_qy_[k], nctu)); HIP_OK(hipMalloc(&ctu_delta_[k], nctu)); HIP_OK(hipMalloc(&ctu_first_[k], nctu));
+      HIP_OK(hipHostMalloc(&h_ctu_qt_[k], nctu, hipHostMallocDefault));
+    }
+  }
   HIP_OK(hipStreamCreateWithFlags(&stream_tok_, hipStreamNonBlocking));
   HIP_OK(hipStreamCreateWithFlags(&stream_in_, hipStreamNonBlocking));
   HIP_OK(hipEventCreateWithFlags(&ev_padded_, hipEventDisableTiming));
@@ -110,7 +117,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   f_.tok_dense_cap = (uint32_t)tok_dense_cap_;
   f_.sync = sync_; f_.err = err_;
 
-  sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp; sp_.tile_rows = cfg.tile_rows;
+  sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp; sp_.tile_rows = cfg.tile_rows; sp_.qp_in_cu = cfg.qp_in_cu;
   sp_.deblock = cfg.deblock; sp_.fps_num = cfg.fps_num; sp_.fps_den = cfg.fps_den;
   HIP_OK(hipStreamSynchronize(stream_));
   HIP_OK(hipDeviceSynchronize());
@@ -128,6 +135,7 @@ void Encoder::bind_set(int k)
   f_.cu_log2 = cu; f_.cu_intra = cu + nb8; f_.cu_flags = cu + 2 * nb8; f_.cu_merge_idx = cu + 3 * nb8;
   f_.cu_mvp_idx = cu + 4 * nb8; f_.cu_intra_mode = cu + 5 * nb8; f_.cu_cbf = cu + 6 * nb8;
   f_.cu_mv = cu_mv_[k]; f_.cu_mvd = cu_mvd_[k];
+  f_.ctu_qt = ctu_qt_[k]; f_.ctu_qy = ctu_qy_[k]; f_.ctu_delta = ctu_delta_[k]; f_.ctu_first = ctu_first_[k];     // all NULL without qp_in_cu
 }
 
 Encoder::~Encoder()
@@ -149,6 +157,7 @@ Encoder::~Encoder()
   if (in_done_) hipEventDestroy(in_done_);
   hipFree(d_in_); hipHostFree(h_in_);
   for (int c = 0; c < 3; c++) { hipFree(src_[0][c]); hipFree(src_[1][c]); for (int b = 0; b < 3; b++) hipFree(rec_[b][c]); hipFree(coef_[0][c]); hipFree(coef_[1][c]); }
+  for (int k = 0; k < 2; k++) { hipFree(ctu_qt_[k]); hipFree(ctu_qy_[k]); hipFree(ctu_delta_[k]); hipFree(ctu_first_[k]); if (h_ctu_qt_[k]) hipHostFree(h_ctu_qt_[k]); }
   for (int k = 0; k < 2; k++) { hipFree(cu_bytes_[k]); hipFree(cu_mv_[k]); hipFree(cu_mvd_[k]); if (ev_tok_done_[k]) hipEventDestroy(ev_tok_done_[k]); }
   if (ev_signalled_) hipEventDestroy(ev_signalled_);
   if (ev_padded_) hipEventDestroy(ev_padded_);
@@ -215,6 +224,27 @@ bool Encoder::flush(EncodedPicture *out)
   return collect(out);
 }
 
+void Encoder::set_roi(int w, int h, const int8_t *map)
+{
+  roi_.clear(); roi_w_ = roi_h_ = 0;
+  if (w > 0 && h > 0 && map) { roi_.assign(map, map + (size_t)w * h); roi_w_ = w; roi_h_ = h; }
+}
+
+// target QP of every CTU of the picture being submitted (set set_): host map -> pinned -> device, on stream_
+bool Encoder::upload_qp_targets()
+{
+  if (!cfg_.qp_in_cu) return true;
+  const int wc = cw_ / 64, hc = rows_;
+  int8_t *h = h_ctu_qt_[set_];
+  for (int cy = 0; cy < hc; cy++) for (int cx = 0; cx < wc; cx++) {
+    int d = 0;
+    if (!roi_.empty()) d = clip3(-12, 12, (int)roi_[(size_t)(cy * roi_h_ / hc) * roi_w_ + (cx * roi_w_ / wc)]);
+    h[cy * wc + cx] = (int8_t)clip3(0, 51, qp_cur_ + d);
+  }
+  HIP_CHECK(hipMemcpyAsync(ctu_qt_[set_], h, (size_t)wc * hc, hipMemcpyHostToDevice, stream_));
+  return true;
+}
+
 // picture-level rate control: the statement of record is rate_control() in oracle/hevc_enc.c
 void Encoder::rate_control()
 {
@@ -251,6 +281,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   if (intra) poc_ = 0; else poc_++;
   rate_control();
   f_.qp = qp_cur_; f_.qpc = kChromaQp[qp_cur_]; f_.lambda_q4 = kLambdaQ4[qp_cur_];
+  if (!upload_qp_targets()) return false;
   f_.is_intra = intra; f_.poc = poc_;
   for (int c = 0; c < 3; c++) { f_.rec[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
   f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err;
@@ -264,6 +295,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
     timed(K_ME, stream_, [&] { launch_me(f, stream_); });
     timed(K_INTER_RECON, stream_, [&] { launch_inter_recon(f, stream_); });
   }
+  launch_qp_resolve(f, stream_);                                 // per-CTU QP: which CU carries the delta, QpY for deblocking
   HIP_CHECK(hipEventRecord(ev_signalled_, stream_));             // levels, cbf and motion of the picture are final; source set read
   HIP_CHECK(hipEventRecord(ev_src_free_[set_], stream_)); src_busy_[set_] = true;
   if (cfg_.deblock) timed(K_DEBLOCK, stream_, [&] { launch_deblock(f, stream_); });
@@ -375,6 +407,7 @@ bool Encoder::band_phase1(const uint8_t *d_i420)
 {
   if (cfg_.band_rows <= 0 || !d_i420) return false;
   if (!band_picture_setup()) return false;
+  if (!upload_qp_targets()) return false;
   const EncFrame f = f_;
   launch_pad_input(d_i420, cfg_.width, cfg_.height, src_[0][0], src_[0][1], src_[0][2], cw_, ch_, stream_);
   if (band_intra_) {
@@ -387,6 +420,7 @@ bool Encoder::band_phase1(const uint8_t *d_i420)
     launch_inter_recon(f, stream_);
     launch_inter_signal(f, stream_);
   }
+  launch_qp_resolve(f, stream_);
   if (cfg_.deblock) launch_deblock_v(f, stream_);
   HIP_CHECK(hipStreamSynchronize(stream_));
   return true;

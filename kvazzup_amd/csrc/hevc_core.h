@@ -49,12 +49,28 @@ struct EncFrame {
   // (tok_dense / tok_count_out live in host-mapped pinned memory)
   uint16_t *tok_buf; int tok_cap; uint32_t *tok_cursor; uint32_t *tok_seg; uint32_t *tok_total;
   uint16_t *tok_dense; uint32_t tok_dense_cap; int32_t *tok_count_out; uint32_t *tok_off_out; uint32_t *err_out;   // host-mapped pinned
+  // Per-CTU QP (cu_qp_delta_enabled_flag, quantisation group = CTU; NULL pointers = one QP per picture):
+  //   ctu_qt: QP the CTU's blocks are quantised / dequantised with; ctu_qy: QpY of its CUs from the first one with residual
+  //   on (8.6.1), ctu_delta: the coded CuQpDeltaVal (QpY of the CUs before that one = ctu_qy - ctu_delta), ctu_first: z index
+  //   (8x8 units) of that first CU, 64 = none
+  const int8_t *ctu_qt; int8_t *ctu_qy, *ctu_delta; uint8_t *ctu_first;
   uint32_t *sync;               // [rows] progress counters (intra reconstruction wavefront)
   uint32_t *err;                // device-side error flags
 };
 
 enum { CU_SKIP = 1, CU_MERGE = 2 };
 
+// quantiser QP of the CTU holding luma sample (x, y)
+KVZ_HD int ctu_quant_qp(const EncFrame &f, int x, int y) { return f.ctu_qt ? f.ctu_qt[(y >> 6) * (f.cw >> 6) + (x >> 6)] : f.qp; }
+// QpY of the CU holding luma sample (x, y) (deblocking, 8.7.2.5.3)
+KVZ_HD int cu_qpy(const EncFrame &f, int x, int y)
+{
+  if (!f.ctu_qy) return f.qp;
+  const int ctu = (y >> 6) * (f.cw >> 6) + (x >> 6), xi = (x & 63) >> 3, yi = (y & 63) >> 3;
+  int z = 0;
+  for (int b = 0; b < 3; b++) z |= ((xi >> b) & 1) << (2 * b) | ((yi >> b) & 1) << (2 * b + 1);
+  return z >= f.ctu_first[ctu] ? f.ctu_qy[ctu] : f.ctu_qy[ctu] - f.ctu_delta[ctu];
+}
 KVZ_HD int band_rows(const EncFrame &f) { return f.nrows > 0 ? f.nrows : (f.ch >> 6); }
 KVZ_HD int b8idx(const EncFrame &f, int x, int y) { return (y >> 3) * f.b8w + (x >> 3); }
 
@@ -515,6 +531,18 @@ KVZ_HD void enc_subblock(S &c, const TuDigest &d, int i, int last_sb, int last_p
       if (a > 3 * (1 << rice)) rice = imin(rice + 1, 4);
     }
   }
+}
+
+// cu_qp_delta_abs (prefix: truncated unary cMax 5, first bin context 0, the others 1; suffix EG0) and cu_qp_delta_sign_flag
+template <class S>
+KVZ_HD void enc_cu_qp_delta(S &c, int d)
+{
+  const int a = d < 0 ? -d : d;
+  int v = 0;
+  while (v < 5 && v < a) { cabac_bin(c, CTX_CU_QP_DELTA + (v ? 1 : 0), 1); v++; }
+  if (a < 5) cabac_bin(c, CTX_CU_QP_DELTA + (a ? 1 : 0), 0);
+  else { int x = a - 5, k = 0; while (x >= (1 << k)) { cabac_bypass(c, 1); x -= 1 << k; k++; } cabac_bypass(c, 0); cabac_bypass_bits(c, (uint32_t)x, k); }
+  if (a) cabac_bypass(c, d < 0);
 }
 
 template <class S>

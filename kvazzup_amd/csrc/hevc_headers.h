@@ -27,6 +27,7 @@ struct StreamParams {
   int width, height;        // display size (conformance window)
   int qp, wpp, deblock;
   int fps_num, fps_den;
+  int qp_in_cu = 0;         // cu_qp_delta_enabled_flag with diff_cu_qp_delta_depth 0 (quantisation group = CTU)
   int tile_rows = 1;        // > 1: tiles_enabled_flag, one column, uniform spacing, loop filter across tiles on
 };
 
@@ -85,7 +86,8 @@ inline void write_pps(BitWriter &w, const StreamParams &s)
   w.bit(0); w.bit(0); w.put(0, 3); w.bit(0); w.bit(0);
   w.ue(0); w.ue(0);
   w.se(s.qp - 26);
-  w.bit(0); w.bit(0); w.bit(0);                                  // constrained intra, transform skip, cu_qp_delta
+  w.bit(0); w.bit(0); w.bit(s.qp_in_cu != 0);                    // constrained intra, transform skip, cu_qp_delta
+  if (s.qp_in_cu) w.ue(0);                                       // diff_cu_qp_delta_depth
   w.se(0); w.se(0); w.bit(0);
   w.bit(0); w.bit(0); w.bit(0);
   w.bit(s.tile_rows > 1); w.bit(s.wpp);                          // tiles, entropy_coding_sync

@@ -240,6 +240,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.wpp = cfg->wpp ? 1 : 0; ec.deblock = cfg->deblock_enable ? 1 : 0; ec.device = cfg->gpu_device; ec.owf = cfg->owf > 2 ? 2 : cfg->owf;
   ec.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1;
   ec.band_row0 = cfg->band_row0; ec.band_rows = cfg->band_rows;
+  ec.qp_in_cu = cfg->set_qp_in_cu ? 1 : 0;
   ec.bitrate = cfg->target_bitrate > 0 ? cfg->target_bitrate : 0;      // any rc-algorithm value selects the one picture-level controller
   std::string err;
   Encoder *impl = Encoder::create(ec, &err);
@@ -273,7 +274,7 @@ int encoder_headers(kvz_encoder *e, kvz_data_chunk **data_out, uint32_t *len_out
   kvzx::StreamParams sp;
   const EncoderConfig &c = e->impl->config();
   sp.cw = e->impl->coded_width(); sp.ch = e->impl->coded_height(); sp.width = c.width; sp.height = c.height; sp.qp = c.qp;
-  sp.wpp = c.wpp; sp.deblock = c.deblock; sp.fps_num = c.fps_num; sp.fps_den = c.fps_den; sp.tile_rows = c.tile_rows;
+  sp.wpp = c.wpp; sp.deblock = c.deblock; sp.fps_num = c.fps_num; sp.fps_den = c.fps_den; sp.tile_rows = c.tile_rows; sp.qp_in_cu = c.qp_in_cu;
   std::vector<uint8_t> out;
   kvzx::BitWriter a, b, d;
   kvzx::write_vps(a, sp); kvzx::append_nal(out, 32, a.data().data(), a.data().size());
@@ -300,6 +301,9 @@ int encoder_encode(kvz_encoder *e, kvz_picture *pic_in, kvz_data_chunk **data_ou
     if (!e->impl->flush(&ep)) return 0;
   } else {
     if (pic_in->width != e->cfg.width || pic_in->height != e->cfg.height || !pic_in->y || !pic_in->u || !pic_in->v) return 0;
+    // delta-QP map of this picture (kvazaarfilter.cpp:423-431); honoured when set-qp-in-cu enabled the signalling
+    if (pic_in->roi.roi_array && pic_in->roi.width > 0 && pic_in->roi.height > 0) e->impl->set_roi(pic_in->roi.width, pic_in->roi.height, pic_in->roi.roi_array);
+    else e->impl->set_roi(0, 0, nullptr);
     if (!e->impl->encode_host(pic_in->y, pic_in->u, pic_in->v, &ep)) return 0;
     pic_in->refcount++;
     e->in_flight->push_back(pic_in);
@@ -393,6 +397,7 @@ const char *kvzx_encoder_kernel_name(int id)
   return (id >= 0 && id < kvzx::K_COUNT) ? names[id] : nullptr;
 }
 uint64_t kvzx_encoder_last_bins(kvz_encoder *e) { return e ? e->last_bins : 0; }
+void kvzx_encoder_set_roi(kvz_encoder *e, int w, int h, const int8_t *map) { if (e) e->impl->set_roi(w, h, map); }
 
 // ---- tile-row split of one picture over several encoders (include/kvazzup_amd.h) ----
 int kvzx_encoder_band_phase1(kvz_encoder *e, const void *d_i420) { return e && e->impl->band_phase1((const uint8_t *)d_i420) ? 1 : 0; }
@@ -425,7 +430,7 @@ int kvzx_assemble_access_unit(const kvz_config *cfg, int idr, int poc, int write
   sp.width = cfg->width; sp.height = cfg->height; sp.cw = (cfg->width + 63) & ~63; sp.ch = (cfg->height + 63) & ~63;
   if (sp.cw < 128) sp.cw = 128;
   sp.qp = cfg->qp; sp.wpp = cfg->wpp ? 1 : 0; sp.deblock = cfg->deblock_enable ? 1 : 0; sp.fps_num = cfg->framerate_num; sp.fps_den = cfg->framerate_denom;
-  sp.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1;
+  sp.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1; sp.qp_in_cu = cfg->set_qp_in_cu ? 1 : 0;
   if (nsub != (sp.wpp ? sp.ch / 64 : sp.tile_rows)) return 0;
   std::vector<std::vector<uint8_t>> rows((size_t)nsub);
   size_t o = 0;

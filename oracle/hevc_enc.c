@@ -40,6 +40,8 @@ struct orc_encoder {
   orc_bitw au;
   orc_avail_ctx av;
   int16_t *ctb_tile;                   /* tile id of every CTB (raster); NULL without tiles */
+  int roi_w, roi_h; int8_t *roi;       /* delta-QP map (orc_enc_set_roi) */
+  int8_t *ctu_qt, *ctu_qy, *ctu_delta; uint8_t *ctu_first;   /* per CTU: target QP, actual QpY, coded CuQpDeltaVal, z index (8x8 units) of the first CU with residual (64: none) */
   int *tile_row_bd;                    /* first CTB row of tile row i, i = 0 .. tile_rows */
   int is_intra;
   uint64_t bins;
@@ -120,6 +122,9 @@ orc_encoder *orc_enc_open(const orc_enc_config *c)
   p->entropy_coding_sync_enabled = c->wpp; p->loop_filter_across_slices = 1;
   p->deblocking_filter_control_present = !c->deblock; p->pps_deblocking_disabled = !c->deblock;
   p->log2_parallel_merge_level = 2; p->num_tile_columns = p->num_tile_rows = 1; p->uniform_spacing = 1;
+  p->cu_qp_delta_enabled = c->qp_in_cu ? 1 : 0; p->diff_cu_qp_delta_depth = 0;
+  { size_t nctu = (size_t)(e->cw / 64) * (e->ch / 64);
+    e->ctu_qt = (int8_t *)calloc(nctu, 1); e->ctu_qy = (int8_t *)calloc(nctu, 1); e->ctu_delta = (int8_t *)calloc(nctu, 1); e->ctu_first = (uint8_t *)calloc(nctu, 1); }
 
   memset(&e->av, 0, sizeof(e->av));
   e->av.pic_w = e->cw; e->av.pic_h = e->ch; e->av.ctb_log2 = 6; e->av.pic_w_ctbs = e->cw / 64;
@@ -191,6 +196,8 @@ static void mark_cu(orc_encoder *e, int x0, int y0, int log2, int pred_mode)
 }
 
 /* residual -> levels (stored plane-shaped) -> reconstruction.  Returns cbf. */
+static int ctu_target_qp(const orc_encoder *e, int x_luma, int y_luma) { return e->ctu_qt[(y_luma >> 6) * (e->cw / 64) + (x_luma >> 6)]; }
+
 static int code_block(orc_encoder *e, int cidx, int x0, int y0, int n, int qp, int intra)
 {
   orc_pic *p = e->cur;
@@ -278,12 +285,12 @@ static void intra_recon_cu(orc_encoder *e, int x0, int y0, int log2)
   orc_pic *p = e->cur;
   int n = 1 << log2, mode = e->cu_intra_mode[b8i(e, x0, y0)];
   pixel left[129], top[129];
-  int qpc = orc_chroma_qp(e->qp, 0);
+  int qpl = ctu_target_qp(e, x0, y0), qpc = orc_chroma_qp(qpl, 0);
   mark_cu(e, x0, y0, log2, MODE_INTRA);
   fill_b4(p, p->intra_mode, x0, y0, n, mode);
   orc_intra_refs(&e->av, p->plane[0], p->stride[0], 0, x0, y0, n, left, top);
   orc_intra_predict(left, top, n, 0, mode, 1, p->plane[0] + y0 * p->stride[0] + x0, p->stride[0]);
-  int cbf = code_block(e, 0, x0, y0, n, e->qp, 1);
+  int cbf = code_block(e, 0, x0, y0, n, qpl, 1);
   fill_b4(p, p->tu_nz, x0, y0, n, cbf);
   for (int c = 1; c <= 2; c++) {
     int cx = x0 / 2, cy = y0 / 2, cn = n / 2;
@@ -386,7 +393,7 @@ static void inter_recon_cu(orc_encoder *e, int x0, int y0, int log2)
   int n = 1 << log2;
   int16_t mv[2] = { e->cu_mv[b8i(e, x0, y0) * 2], e->cu_mv[b8i(e, x0, y0) * 2 + 1] };
   int16_t tmp[32 * 32];
-  int qpc = orc_chroma_qp(e->qp, 0);
+  int qpc = orc_chroma_qp(ctu_target_qp(e, x0, y0), 0);
   mark_cu(e, x0, y0, log2, MODE_INTER);
   for (int y = y0; y < y0 + n; y += 4) for (int x = x0; x < x0 + n; x += 4) {
     orc_mvinfo *m = &p->mvf[(y >> 2) * p->b4_w + (x >> 2)];
@@ -394,7 +401,7 @@ static void inter_recon_cu(orc_encoder *e, int x0, int y0, int log2)
   }
   orc_mc_luma(r->plane[0], r->stride[0], r->w, r->h, x0, y0, n, n, mv[0], mv[1], tmp, 32);
   orc_pred_uni(tmp, 32, p->plane[0] + y0 * p->stride[0] + x0, p->stride[0], n, n);
-  int cbf = code_block(e, 0, x0, y0, n, e->qp, 0);
+  int cbf = code_block(e, 0, x0, y0, n, ctu_target_qp(e, x0, y0), 0);
   fill_b4(p, p->tu_nz, x0, y0, n, cbf);
   for (int c = 1; c <= 2; c++) {
     int cx = x0 / 2, cy = y0 / 2, cn = n / 2;
@@ -659,6 +666,17 @@ static void enc_cu(orc_encoder *e, orc_cabac_enc *c, int x0, int y0, int log2)
   orc_cenc_bin(c, CTX_CBF_CHROMA + 0, (cbf >> 1) & 1);
   orc_cenc_bin(c, CTX_CBF_CHROMA + 0, (cbf >> 2) & 1);
   if (intra || (cbf & 6)) orc_cenc_bin(c, CTX_CBF_LUMA + 1, cbf & 1);
+  if (e->cfg.qp_in_cu && cbf) {                      /* transform_unit(): cu_qp_delta once per quantisation group (= CTU), in its first TU with a coded block */
+    int ctu = (y0 >> 6) * (e->cw / 64) + (x0 >> 6);
+    int z = 0; for (int b = 0; b < 3; b++) z |= ((((x0 & 63) >> 3) >> b) & 1) << (2 * b) | ((((y0 & 63) >> 3) >> b) & 1) << (2 * b + 1);
+    if (e->ctu_first[ctu] == z) {
+      int d = e->ctu_delta[ctu], a = orc_abs(d), v = 0;
+      while (v < 5 && v < a) { orc_cenc_bin(c, CTX_CU_QP_DELTA + (v ? 1 : 0), 1); v++; }      /* prefix: truncated unary, cMax 5 */
+      if (a < 5) orc_cenc_bin(c, CTX_CU_QP_DELTA + (a ? 1 : 0), 0);
+      else { int x = a - 5, k = 0; while (x >= (1 << k)) { orc_cenc_bypass(c, 1); x -= 1 << k; k++; } orc_cenc_bypass(c, 0); orc_cenc_bypass_bits(c, (uint32_t)x, k); }   /* suffix EG0 */
+      if (a) orc_cenc_bypass(c, d < 0);
+    }
+  }
   if (cbf & 1) enc_residual(c, e->coef[0] + y0 * e->cw + x0, e->cw, log2, 0, scan_idx_for(intra, log2, 0, mode));
   for (int ci = 1; ci <= 2; ci++)
     if ((cbf >> ci) & 1)
@@ -756,16 +774,66 @@ static void rate_control(orc_encoder *e)
   e->qp = orc_clip3(10, 51, e->qp + step);
 }
 
+void orc_enc_set_roi(orc_encoder *e, int w, int h, const int8_t *map)
+{
+  free(e->roi); e->roi = NULL; e->roi_w = e->roi_h = 0;
+  if (w > 0 && h > 0 && map) { e->roi = (int8_t *)malloc((size_t)w * h); memcpy(e->roi, map, (size_t)w * h); e->roi_w = w; e->roi_h = h; }
+}
+
+/* target QP of every CTU for this picture */
+static void roi_targets(orc_encoder *e)
+{
+  int wc = e->cw / 64, hc = e->ch / 64;
+  for (int cy = 0; cy < hc; cy++) for (int cx = 0; cx < wc; cx++) {
+    int d = 0;
+    if (e->cfg.qp_in_cu && e->roi) d = orc_clip3(-12, 12, e->roi[(cy * e->roi_h / hc) * e->roi_w + (cx * e->roi_w / wc)]);
+    e->ctu_qt[cy * wc + cx] = (int8_t)orc_clip3(0, 51, e->qp + d);
+  }
+}
+
+/* After reconstruction: which CTUs code a delta, their actual QpY (8.6.1 with quantisation group = CTU: the prediction is the
+ * QpY of the previous CTU in decoding order, or the slice QP at the start of a slice, a tile or -- with WPP -- a CTU row). */
+static void roi_resolve(orc_encoder *e)
+{
+  orc_pic *p = e->cur;
+  int wc = e->cw / 64, hc = e->ch / 64, prev = e->qp;
+  for (int cy = 0; cy < hc; cy++) {
+    int tile_start = 0; for (int i = 0; i < e->cfg.tile_rows; i++) if (cy == e->tile_row_bd[i]) tile_start = 1;
+    if (e->cfg.wpp || tile_start) prev = e->qp;
+    for (int cx = 0; cx < wc; cx++) {
+      int ctu = cy * wc + cx, first = 64;
+      for (int z = 63; z >= 0; z--) {
+        int xi = 0, yi = 0; for (int b = 0; b < 3; b++) { xi |= ((z >> (2 * b)) & 1) << b; yi |= ((z >> (2 * b + 1)) & 1) << b; }
+        int x = cx * 64 + xi * 8, y = cy * 64 + yi * 8, bi = b8i(e, x, y), n = 1 << e->cu_log2[bi];
+        if ((x & (n - 1)) || (y & (n - 1))) continue;          /* not a CU origin */
+        if (e->cu_cbf[bi]) first = z;
+      }
+      int qy = (first < 64 && e->cfg.qp_in_cu) ? e->ctu_qt[ctu] : prev;
+      e->ctu_first[ctu] = (uint8_t)first; e->ctu_qy[ctu] = (int8_t)qy; e->ctu_delta[ctu] = (int8_t)(qy - prev);
+      prev = qy;
+      /* CUs decoded before the delta arrives keep the predicted QP (CuQpDeltaVal is still 0 for them, 8.6.1) */
+      for (int z = 0; z < 64; z++) {
+        int xi = 0, yi = 0; for (int b = 0; b < 3; b++) { xi |= ((z >> (2 * b)) & 1) << b; yi |= ((z >> (2 * b + 1)) & 1) << b; }
+        int q = (z >= first) ? qy : (qy - e->ctu_delta[ctu]);
+        for (int y = cy * 64 + yi * 8; y < cy * 64 + yi * 8 + 8; y += 4) for (int x = cx * 64 + xi * 8; x < cx * 64 + xi * 8 + 8; x += 4)
+          p->qp_y[(y >> 2) * p->b4_w + (x >> 2)] = (int8_t)q;
+      }
+    }
+  }
+}
+
 size_t orc_enc_encode(orc_encoder *e, const pixel *y, const pixel *u, const pixel *v, const uint8_t **au)
 {
   int period = e->cfg.intra_period;
   e->is_intra = (e->frame_idx == 0) || (period > 0 && (e->frame_idx % period) == 0);
   if (e->is_intra) e->poc = 0; else e->poc++;
   rate_control(e);
+  roi_targets(e);
   load_input(e, y, u, v);
   orc_pic_reset_side(e->cur);
   for (int c = 0; c < 3; c++) memset(e->coef[c], 0, sizeof(int16_t) * (size_t)(c ? e->cw * e->ch / 4 : e->cw * e->ch));
   if (e->is_intra) encode_intra_picture(e); else encode_inter_picture(e);
+  roi_resolve(e);
   for (int c = 0; c < 3; c++) memcpy(e->predeblock[c], e->cur->plane[c], (size_t)(c ? e->cw * e->ch / 4 : e->cw * e->ch));
   orc_compute_bs(e->cur, e->bs_v, e->bs_h);
   if (e->cfg.deblock) {

@@ -33,6 +33,8 @@ typedef struct {
   int deblock;                /* 1 = enabled */
   int tile_rows;              /* 1 = no tiles; n > 1: n full-width tile rows, uniform spacing, loop filter across tiles on,
                                * motion vectors constrained to the tile (see me_block32) */
+  int qp_in_cu;               /* 1: cu_qp_delta_enabled_flag, quantisation group = CTU: a delta-QP map set with orc_enc_set_roi()
+                               * gives every CTU its own QP (kvz_picture.roi, kvazaarfilter.cpp:423-431) */
   int bitrate;                /* bits per second; 0 = constant QP.  > 0: "uvgx rate control v1" (see hevc_enc.c) */
 } orc_enc_config;
 
@@ -56,6 +58,9 @@ orc_encoder *orc_enc_open(const orc_enc_config *c);
 void orc_enc_close(orc_encoder *e);
 /* Encodes one picture given as three packed planes (stride = width, width/2).  The returned
  * buffer is owned by the encoder and valid until the next call.  Returns AU size in bytes. */
+/* delta-QP map for the following pictures: w x h cells spread uniformly over the picture, one int8 per cell (clamped to
+ * [-12, 12]); w == 0 removes it.  CTU (cx, cy) uses cell (cx * w / ctus_x, cy * h / ctus_y).  Needs cfg.qp_in_cu. */
+void orc_enc_set_roi(orc_encoder *e, int w, int h, const int8_t *map);
 size_t orc_enc_encode(orc_encoder *e, const pixel *y, const pixel *u, const pixel *v, const uint8_t **au);
 void orc_enc_get_debug(orc_encoder *e, orc_enc_debug *dbg);
 /* copy cropped reconstruction (width x height I420, packed) */

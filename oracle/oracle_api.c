@@ -75,14 +75,15 @@ orc_encoder *orc_api_enc_open_rc(int w, int h, int qp, int period, int vps_perio
 {
   return orc_api_enc_open_ex(w, h, qp, period, vps_period, range, fps_num, fps_den, wpp, deblock, bitrate, 1);
 }
-/* ... and tile rows */
+/* ... tile rows; qp_in_cu packed into bit 16 of tile_rows keeps the ctypes signature short */
 orc_encoder *orc_api_enc_open_ex(int w, int h, int qp, int period, int vps_period, int range, int fps_num, int fps_den, int wpp, int deblock, int bitrate, int tile_rows)
 {
-  orc_enc_config c; orc_enc_default_config(&c); c.tile_rows = tile_rows;
+  orc_enc_config c; orc_enc_default_config(&c); c.tile_rows = tile_rows & 0xffff; c.qp_in_cu = (tile_rows >> 16) & 1;
   c.width = w; c.height = h; c.qp = qp; c.intra_period = period; c.vps_period = vps_period; c.search_range = range;
   c.fps_num = fps_num; c.fps_den = fps_den; c.wpp = wpp; c.deblock = deblock; c.bitrate = bitrate;
   return orc_enc_open(&c);
 }
+void orc_api_enc_set_roi(orc_encoder *e, int w, int h, const int8_t *map) { orc_enc_set_roi(e, w, h, map); }
 /* returns AU size; copies it to out when it fits */
 long orc_api_enc_encode(orc_encoder *e, const uint8_t *y, const uint8_t *u, const uint8_t *v, uint8_t *out, long cap)
 {

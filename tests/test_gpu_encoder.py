@@ -139,3 +139,37 @@ def test_tile_rows_match_oracle(gpu, cfg):
     """kvazaar "tiles" 1xN (kvazaarfilter.cpp:196-202): full-width tile rows with uniform spacing, prediction and
     entropy contexts confined to the tile, motion vectors constrained to it, deblocking across the boundaries"""
     run_clip(**cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,wpp,tile_rows", [(320, 256, 1, 1), (320, 256, 0, 1), (448, 320, 1, 2), (1280, 720, 1, 1)])
+def test_roi_delta_qp_map_matches_oracle(gpu, w, h, wpp, tile_rows):
+    """kvz_picture.roi (kvazaarfilter.cpp:423-431) with set-qp-in-cu: every CTU quantised with its own QP, cu_qp_delta coded with
+    the CTU's first residual, QpY prediction along the CTU row, deblocking with the averaged QpY -- the map changes, is clamped
+    and is removed again during the clip"""
+    import ctypes as C
+    from kvazzup_amd.codec import Encoder
+    rng = np.random.default_rng(3)
+    oe = orc.OracleEncoder(w, h, qp=30, period=4, me_range=16, wpp=wpp, tile_rows=tile_rows, qp_in_cu=1)
+    ge = Encoder(w, h, options=(("qp", 30), ("period", 4), ("me-range", 16), ("wpp", wpp), ("tiles", "1x%d" % tile_rows), ("set-qp-in-cu", 1)))
+    assert not ge.rejected, ge.rejected
+    maps = {1: (4, 3, rng.integers(-12, 13, 12)), 3: (7, 5, rng.integers(-30, 31, 35)), 5: (0, 0, None)}
+    cur = None
+    for t in range(7):
+        if t in maps:
+            rw, rh, m = maps[t]
+            oe.set_roi(rw, rh, m)
+            cur = None if not rw else (rw, rh, np.ascontiguousarray(m, dtype=np.int8))
+        p = ge.pic.contents
+        if cur:
+            p.roi.width, p.roi.height = cur[0], cur[1]
+            p.roi.roi_array = cur[2].ctypes.data_as(C.POINTER(C.c_int8))
+        else:
+            p.roi.width = p.roi.height = 0
+            p.roi.roi_array = None
+        frame = orc.synth_frame(0 if t < 6 else 2, 7, w, h, t)
+        au_o = oe.encode(frame)
+        au_g, rec_g = ge.encode(frame)
+        assert au_g == au_o, "picture %d: %d vs %d bytes" % (t, len(au_g), len(au_o))
+        assert np.array_equal(rec_g, oe.recon()), t
+    ge.close(); oe.close()

@@ -45,6 +45,7 @@ struct DecSps {
 };
 struct DecPps {
   bool valid = false;
+  int qp_in_cu = 0;                   // cu_qp_delta_enabled_flag with diff_cu_qp_delta_depth == 0 (quantisation group = CTU)
   int tile_rows = 1;                  // full-width tile rows with uniform spacing (everything else about tiles is rejected)
   int init_qp = 26, wpp = 0, deblock_control = 0, deblock_disabled = 0, loop_filter_across_slices = 1, cabac_init_present = 0;
 };
@@ -106,11 +107,11 @@ class Decoder {
   struct PicJob {
     std::vector<uint8_t> rbsp; size_t data_off = 0, data_len = 0;
     std::vector<size_t> sub_start;
-    int tile_rows = 1;
+    int tile_rows = 1, qp_in_cu = 0;
     int slice_qp = 0, max_merge = 5, poc = 0; bool is_intra = false, deblock = true; int64_t pts = 0;
     int crop[4] = {0, 0, 0, 0}; uint32_t fps_num = 0, fps_den = 0;
     // Everything the GPU needs for the picture, in one pinned block that goes over in one copy:
-    // [ CU records: 7 byte arrays of b8 entries | motion vectors: b8 x 2 int16 | TuDesc x ntu | level words x nlev ]
+    // [ CU records: 7 byte arrays of b8 entries | motion vectors: b8 x 2 int16 | per CTU: QpY, delta, first coded CU | TuDesc x ntu | level words x nlev ]
     uint8_t *h_in = nullptr; size_t h_in_cap = 0; size_t ntu = 0, nlev = 0;
     EncFrame hf{};                                             // host view of the CU / motion arrays inside h_in
     std::vector<RowState> rows; std::vector<uint8_t> wpp_saved;
@@ -123,7 +124,7 @@ class Decoder {
   int parse_row(PicJob &job, int row, const uint8_t *data, size_t len, RowState &rs);
   int finish_oldest();
   void drop_pending();
-  size_t fixed_bytes() const { return (size_t)cw_ * ch_ / 64 * 11; }   // CU records + motion vectors
+  size_t fixed_bytes() const { return (size_t)cw_ * ch_ / 64 * 11 + (size_t)(cw_ / 64) * (ch_ / 64) * 3; }   // CU records + motion vectors + per-CTU QpY / delta / first coded CU
   bool grow_job_input(PicJob &job, size_t bytes);
   void bind_views(EncFrame &f, uint8_t *base);
   int launch_gpu(PicJob &job);

@@ -296,6 +296,15 @@ void Decoder::bind_views(EncFrame &f, uint8_t *base)
   f.cu_mvp_idx = base + 4 * nb8; f.cu_intra_mode = base + 5 * nb8; f.cu_cbf = base + 6 * nb8; f.cu_mv = (int16_t *)(base + 7 * nb8);
   f.cu_mvd = keep.cu_mvd; f.sync = keep.sync; f.err = keep.err;
   for (int c = 0; c < 3; c++) { f.coef[c] = keep.coef[c]; f.rec[c] = keep.rec[c]; f.ref[c] = keep.ref[c]; }
+  // per-CTU QP arrays follow the motion vectors; the frame's pointers are switched on per picture (PPS cu_qp_delta_enabled_flag)
+}
+
+// pointers of the per-CTU QP arrays inside an input block
+static inline void bind_qp_arrays(EncFrame &f, uint8_t *base, int cw, int ch, bool on)
+{
+  const size_t nb8 = (size_t)cw * ch / 64, nctu = (size_t)(cw / 64) * (ch / 64);
+  int8_t *q = (int8_t *)(base + 11 * nb8);
+  f.ctu_qy = on ? q : nullptr; f.ctu_qt = on ? q : nullptr; f.ctu_delta = on ? q + nctu : nullptr; f.ctu_first = on ? (uint8_t *)(q + 2 * nctu) : nullptr;
 }
 
 // pinned input block of a job: at least `bytes`; the CU / motion part written so far is kept.  Called from the
@@ -441,10 +450,10 @@ int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
     int l0 = r.ue(), l1 = r.ue(); (void)l1;
     p.init_qp = 26 + r.se();
     int cip = r.get(1), tskip = r.get(1), cuqpd = r.get(1);
-    if (cuqpd) r.ue();
+    if (cuqpd) { if (r.ue() != 0) return last_error_ = DEC_ERR_UNSUPPORTED; p.qp_in_cu = 1; }   // quantisation group = CTU only
     int cbo = r.se(), cro = r.se(), sco = r.get(1), wp = r.get(1), wbp = r.get(1), tqb = r.get(1), tiles = r.get(1);
     p.wpp = r.get(1);
-    if (dep || outflag || extra || signhide || p.cabac_init_present || l0 != 0 || cip || tskip || cuqpd || cbo || cro || sco || wp || wbp || tqb)
+    if (dep || outflag || extra || signhide || p.cabac_init_present || l0 != 0 || cip || tskip || cbo || cro || sco || wp || wbp || tqb)
       return last_error_ = DEC_ERR_UNSUPPORTED;
     if (tiles) {                                                 // supported: one column, uniform spacing, loop filter across tiles on
       const int cols = r.ue() + 1, rows = r.ue() + 1, uniform = r.get(1);
@@ -560,6 +569,8 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   job.hf.is_intra = is_intra; job.hf.wpp = p.wpp; job.hf.qp = slice_qp;
   if (p.tile_rows > s.height / 64) return DEC_ERR_INVALID;
   job.tile_rows = p.tile_rows; job.hf.tile_rows = p.tile_rows; job.hf.chp = pack_height(ch_, p.tile_rows);
+  job.qp_in_cu = p.qp_in_cu;
+  bind_qp_arrays(job.hf, job.h_in, cw_, ch_, true);               // the parser always fills them (one QP everywhere without cu_qp_delta)
   job.rc = 0;
   prev_poc_ = poc; have_ref_ = true;                             // header checks of the next picture run before this one is reconstructed
   job_head_++;
@@ -670,6 +681,7 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
     }
     return seen_above < (1 << 29);                     // >= 1 << 29: that row failed
   };
+  int prev_qy = slice_qp;                              // qPY_PREV: slice QP at the start of a substream (tile, or CTU row with WPP)
   c.start(data, len);
   if (!wpp || tile_row_starts_at(hc, T, row)) cabac_init_contexts(c.ctx, is_intra ? 0 : 1, slice_qp);   // first CTU of a tile (9.3.1)
   else {
@@ -681,6 +693,7 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
   for (int cy = first_cy; cy < first_cy + ncy; cy++) {
     for (int cx = 0; cx < wc; cx++) {
       if (!wait_above(cy, cx + 2)) return DEC_ERR_INVALID;
+      int ctu_qy = prev_qy, ctu_first = 64;                // quantisation group = CTU (8.6.1)
       // coding_quadtree, iteratively in z-order over the 8x8 grid of the CTU
       for (int z = 0; z < 64;) {
         int xi, yi; ctu_z_to_xy(z, xi, yi);
@@ -754,6 +767,15 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
           int cb = c.bin(CTX_CBF_CHROMA), cr = c.bin(CTX_CBF_CHROMA);
           int luma = (intra || cb || cr) ? c.bin(CTX_CBF_LUMA + 1) : 1;
           cbf = luma | (cb << 1) | (cr << 2);
+          if (cbf && job.qp_in_cu && ctu_first == 64) {             // cu_qp_delta_abs / sign: once per CTU, in its first TU with a coded block
+            int v = 0;
+            while (v < 5 && c.bin(CTX_CU_QP_DELTA + (v ? 1 : 0))) v++;
+            if (v == 5) { int k = 0; while (k < 16 && c.bypass()) { v += 1 << k; k++; } if (k >= 16) return DEC_ERR_INVALID; v += (int)c.bypass_bits(k); }
+            if (v && c.bypass()) v = -v;
+            if (v < -26 || v > 25) return DEC_ERR_INVALID;
+            ctu_qy = (prev_qy + v + 52) % 52;
+            ctu_first = z;
+          }
           for (int ci = 0; ci < 3; ci++) {
             if (!((cbf >> ci) & 1)) continue;
             const int l2 = ci ? log2 - 1 : log2;
@@ -776,6 +798,7 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
         if (c.overrun()) return DEC_ERR_INVALID;
         z += 1 << (2 * (log2 - 3));
       }
+      { const int ctu = cy * wc + cx; f.ctu_qy[ctu] = (int8_t)ctu_qy; f.ctu_delta[ctu] = (int8_t)(ctu_qy - prev_qy); f.ctu_first[ctu] = (uint8_t)ctu_first; prev_qy = ctu_qy; }
       if (wpp && cx == 1) memcpy(&job.wpp_saved[(size_t)cy * CTX_COUNT], c.ctx, CTX_COUNT);
       if (wpp) job.row_progress[(size_t)cy].v.store(cx + 1, std::memory_order_release);
       const bool last = (cy == hc - 1 && cx == wc - 1);
@@ -848,6 +871,7 @@ int Decoder::launch_gpu(PicJob &job)
   const TuDesc *d_tus = (const TuDesc *)(d_in_ + tu_off); const uint32_t *d_lev = (const uint32_t *)(d_in_ + lev_off);
   f_.qp = slice_qp; f_.qpc = kChromaQp[slice_qp]; f_.is_intra = is_intra;
   f_.tile_rows = job.tile_rows; f_.chp = pack_height(ch_, job.tile_rows);
+  bind_qp_arrays(f_, d_in_, cw_, ch_, job.qp_in_cu != 0);
   const int cur = (int)(launched_ % 3), ref = (int)((launched_ + 2) % 3);     // three buffers: the picture output by the previous call stays intact
   for (int c = 0; c < 3; c++) { f_.rec[c] = rec_[cur][c]; f_.ref[c] = rec_[ref][c]; }
   const EncFrame f = f_;

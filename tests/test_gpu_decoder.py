@@ -132,3 +132,22 @@ def test_frame_threaded_decoder_delays_output_and_drains_on_eos(gpu, threads):
 def test_decoder_tile_rows(gpu, cfg):
     """streams with full-width tile rows (uniform spacing, with and without WPP) from the checker's encoder"""
     run_clip(**cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,wpp,tile_rows", [(320, 256, 1, 1), (320, 256, 0, 1), (448, 320, 1, 2), (1280, 720, 1, 1)])
+def test_decoder_cu_qp_delta(gpu, w, h, wpp, tile_rows):
+    """streams with cu_qp_delta (quantisation group = CTU) from the checker's encoder with a changing delta-QP map: per-CTU
+    dequantisation, QpY prediction chain, deblocking with the averaged QpY"""
+    from kvazzup_amd.codec import Decoder
+    rng = np.random.default_rng(3)
+    oe = orc.OracleEncoder(w, h, qp=30, period=4, me_range=16, wpp=wpp, tile_rows=tile_rows, qp_in_cu=1)
+    gd = Decoder()
+    for t in range(7):
+        if t == 1: oe.set_roi(4, 3, rng.integers(-12, 13, 12))
+        if t == 3: oe.set_roi(7, 5, rng.integers(-30, 31, 35))
+        if t == 5: oe.set_roi(0, 0, None)
+        au = oe.encode(orc.synth_frame(0 if t < 6 else 2, 7, w, h, t))
+        got = gd.decode_au(au, t)
+        assert len(got) == 1 and np.array_equal(got[0]["i420"], oe.recon()), t
+    gd.close(); oe.close()

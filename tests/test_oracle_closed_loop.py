@@ -99,3 +99,22 @@ def test_tile_rows_closed_loop(w, h, tile_rows, wpp):
         d = od.decode_au(au, t)
         assert len(d) == 1 and np.array_equal(d[0]["i420"], oe.recon()), t
     oe.close(); od.close()
+
+
+@pytest.mark.parametrize("w,h,wpp,tile_rows", [(320, 256, 1, 1), (320, 256, 0, 1), (448, 320, 1, 2), (448, 320, 0, 2)])
+def test_delta_qp_map_closed_loop(w, h, wpp, tile_rows):
+    """per-CTU QP from a delta-QP map (cu_qp_delta, quantisation group = CTU): the checker's encoder against the checker's
+    general decoder, which derives QpY from 8.6.1 on its own; the map changes, gets clamped and is removed during the clip"""
+    rng = np.random.default_rng(3)
+    oe = orc.OracleEncoder(w, h, qp=30, period=4, me_range=16, wpp=wpp, tile_rows=tile_rows, qp_in_cu=1)
+    od = orc.OracleDecoder()
+    sizes = []
+    for t in range(7):
+        if t == 1: oe.set_roi(4, 3, rng.integers(-12, 13, 12))
+        if t == 3: oe.set_roi(7, 5, rng.integers(-30, 31, 35))
+        if t == 5: oe.set_roi(0, 0, None)
+        au = oe.encode(orc.synth_frame(0 if t < 6 else 2, 7, w, h, t))
+        sizes.append(len(au))
+        d = od.decode_au(au, t)
+        assert len(d) == 1 and np.array_equal(d[0]["i420"], oe.recon()), t
+    oe.close(); od.close()

@@ -193,13 +193,42 @@ __device__ __forceinline__ int dot2_i16(uint32_t a, uint32_t b, int c)
 __device__ __forceinline__ uint32_t pack_i16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
 __device__ __forceinline__ int matrix_offset(int l2) { return l2 == 2 ? 0 : (l2 == 3 ? 16 : (l2 == 4 ? 80 : 336)); }
 #define KV_MATRIX_ENTRIES 1360
-// fills entries [first, first + count) of both matrix sets (all sizes: first = 0, count = KV_MATRIX_ENTRIES)
+// Both matrix sets, the 32-point matrix as int8 (MFMA operand) with its row sums: built at compile time, so a kernel
+// fetches what it needs with one 16-byte load per thread instead of recomputing entries from kDct32.
+struct alignas(16) XfTables {
+  int16_t M[2][KV_MATRIX_ENTRIES];
+  int8_t M8[2][32 * 32];
+  int rowsum[2][32];
+};
+constexpr XfTables make_xf_tables()
+{
+  XfTables t{};
+  for (int i = 0; i < KV_MATRIX_ENTRIES; i++) {
+    const int l2 = i < 16 ? 2 : (i < 80 ? 3 : (i < 336 ? 4 : 5)), first = l2 == 2 ? 0 : (l2 == 3 ? 16 : (l2 == 4 ? 80 : 336));
+    const int k = i - first, j = k >> l2, m = k & ((1 << l2) - 1);
+    t.M[0][i] = kDct32[j << (5 - l2)][m];
+    t.M[1][i] = kDct32[m << (5 - l2)][j];
+  }
+  for (int j = 0; j < 32; j++) {
+    int a0 = 0, a1 = 0;
+    for (int m = 0; m < 32; m++) {
+      t.M8[0][j * 32 + m] = kDct32[j][m]; t.M8[1][j * 32 + m] = kDct32[m][j];
+      a0 += kDct32[j][m]; a1 += kDct32[m][j];
+    }
+    t.rowsum[0][j] = a0; t.rowsum[1][j] = a1;
+  }
+  return t;
+}
+__device__ const XfTables g_xf = make_xf_tables();
+
+// fills entries [first, first + count) of both matrix sets (all sizes: first = 0, count = KV_MATRIX_ENTRIES); both
+// multiples of 8
 __device__ __forceinline__ void load_matrices(int16_t (*M)[KV_MATRIX_ENTRIES], int first, int count, int tid, int nthreads)
 {
-  for (int i = first + tid; i < first + count; i += nthreads) {
-    int l2 = i < 16 ? 2 : (i < 80 ? 3 : (i < 336 ? 4 : 5)), k = i - matrix_offset(l2), j = k >> l2, m = k & ((1 << l2) - 1);
-    M[0][i] = kDct32[j << (5 - l2)][m];
-    M[1][i] = kDct32[m << (5 - l2)][j];
+  const int per = count >> 3;
+  for (int i = tid; i < 2 * per; i += nthreads) {
+    const int t = i >= per, k = first + ((i - t * per) << 3);
+    *(uint4 *)&M[t][k] = *(const uint4 *)&g_xf.M[t][k];
   }
 }
 
@@ -450,8 +479,8 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
   if (split) load_matrices(s.M, 16, 64 + 256, tid, 256);
   else {
     load_matrices(s.M, 80, 256, tid, 256);                       // chroma 16-point matrices (dot2 path)
-    for (int i = tid; i < 1024; i += 256) { s.M8[0][i] = kDct32[i >> 5][i & 31]; s.M8[1][i] = kDct32[i & 31][i >> 5]; }
-    if (tid < 64) { const int t = tid >> 5, j = tid & 31; int a = 0; for (int m = 0; m < 32; m++) a += t ? kDct32[m][j] : kDct32[j][m]; s.rowsum[t][j] = a; }
+    if (tid >= 64 && tid < 192) ((uint4 *)s.M8)[tid - 64] = ((const uint4 *)g_xf.M8)[tid - 64];
+    else if (tid >= 192 && tid < 208) ((uint4 *)s.rowsum)[tid - 192] = ((const uint4 *)g_xf.rowsum)[tid - 192];
   }
   if (tid < 2) s.nz[tid] = 0;
   if (tid < 4) {

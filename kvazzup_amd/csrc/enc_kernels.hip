@@ -1208,8 +1208,26 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
   const int X0 = ux * 16, Y0 = uy * 16;
   int z4 = 0;                                          // z-order index of the unit inside its CTU
   for (int b = 0; b < 2; b++) z4 |= (((ux & 3) >> b) & 1) << (2 * b) | (((uy & 3) >> b) & 1) << (2 * b + 1);
-  core_tabs_fill_entry(tabs, lane);
   if (lane == 0 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0) *f.tok_total = 0;           // dense-array cursor of this picture's k_tok_compact
+  // Most waves of an inter picture have nothing to say (units inside a 32x32 CU that starts elsewhere, chroma of CUs without
+  // chroma residual): they find that out from three bytes and leave with their table entries zeroed.
+  if (!(comp == 0 && z4 == 15)) {
+    const int g0 = (uy * 2) * f.b8w + ux * 2, l0 = f.cu_log2[g0];
+    bool work = !(l0 == 5 && ((X0 | Y0) & 31));
+    if (work && comp) {
+      bool c = false;
+      if (lane < (l0 == 3 ? 4 : 1)) { const int g = g0 + (lane >> 1) * f.b8w + (lane & 1); c = !(f.cu_flags[g] & CU_SKIP) && ((f.cu_cbf[g] >> comp) & 1); }
+      work = __ballot(c) != 0;
+    }
+    if (!work) {
+      if (lane < TOK_PIECES && ((lane == 16 || (lane & 3) == 3) ? 0 : (lane & 3)) == comp) {
+        uint32_t *e = f.tok_seg + ((size_t)(ctu * 16 + z4) * TOK_PIECES + lane) * 2;
+        e[0] = 0; e[1] = 0;
+      }
+      return;
+    }
+  }
+  core_tabs_fill_entry(tabs, lane);
   if (lane < TOK_PIECES) { seg[lane][0] = 0; seg[lane][1] = 0; }
   if (lane == 0) hdr_n = 0;
   const int bx0 = ux * 2 - 1, by0 = uy * 2 - 1;

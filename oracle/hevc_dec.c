@@ -10,6 +10,7 @@
 #include "hevc_inter.h"
 #include "hevc_transform.h"
 #include "hevc_deblock.h"
+#include "hevc_sao.h"
 #include "hevc_mvpred.h"
 #include <stdio.h>
 
@@ -35,6 +36,7 @@ struct orc_decoder {
   uint8_t *rbsp; size_t rbsp_cap;
   int64_t cur_pts;
   /* tile / slice maps for the current picture */
+  orc_sao_params *sao; int sao_used; pixel *sao_in[3];
   int32_t *ctb_slice; int16_t *ctb_tile; int *ts_to_rs, *rs_to_ts; int *tile_first_x; size_t ctb_cap;
   int col_bd[34], row_bd[34];
   /* slice decoding state */
@@ -70,6 +72,7 @@ void orc_dec_close(orc_decoder *d)
   for (int i = 0; i < MAX_DPB; i++) if (d->dpb[i].plane[0]) orc_pic_free(&d->dpb[i]);
   free(d->bs_v); free(d->bs_h); free(d->rbsp);
   for (int i = 0; i < 3; i++) free(d->predeblock[i]);
+  free(d->sao); for (int i = 0; i < 3; i++) free(d->sao_in[i]);
   free(d->ctb_slice); free(d->ctb_tile); free(d->ts_to_rs); free(d->rs_to_ts); free(d->tile_first_x);
   free(d->sh.entry_point_offset);
   free(d);
@@ -605,6 +608,7 @@ static void setup_tiles(orc_decoder *d)
   int wc = s->pic_w_ctbs, hc = s->pic_h_ctbs, nc = p->num_tile_columns, nr = p->num_tile_rows;
   size_t n = (size_t)wc * hc;
   if (n > d->ctb_cap) {
+    d->sao = (orc_sao_params *)realloc(d->sao, n * sizeof(orc_sao_params));
     d->ctb_slice = (int32_t *)realloc(d->ctb_slice, n * sizeof(int32_t));
     d->ctb_tile = (int16_t *)realloc(d->ctb_tile, n * sizeof(int16_t));
     d->ts_to_rs = (int *)realloc(d->ts_to_rs, n * sizeof(int));
@@ -633,6 +637,7 @@ static void setup_tiles(orc_decoder *d)
           ts++;
         }
   for (size_t i = 0; i < n; i++) d->ctb_slice[i] = -1;
+  d->sao_used = 0;
 }
 
 static int start_picture(orc_decoder *d)
@@ -729,6 +734,19 @@ static void finish_picture(orc_decoder *d)
     db.cb_qp_offset = d->p->cb_qp_offset; db.cr_qp_offset = d->p->cr_qp_offset;
     orc_deblock_picture(&db);
   }
+  if (s->sao_enabled && d->sao_used) {                /* 8.7.3 on the deblocked picture */
+    orc_sao_ctx sc; memset(&sc, 0, sizeof(sc));
+    sc.w = pic->w; sc.h = pic->h; sc.ctb_log2 = s->ctb_log2; sc.pic_w_ctbs = s->pic_w_ctbs; sc.params = d->sao;
+    sc.ctb_slice = d->ctb_slice; sc.ctb_tile = d->ctb_tile;
+    sc.across_slices = d->sh.loop_filter_across_slices; sc.across_tiles = d->p->loop_filter_across_tiles;
+    sc.no_filter = pic->no_filter; sc.nf_stride = pic->b4_w;
+    for (int i = 0; i < 3; i++) {
+      size_t n = (size_t)pic->stride[i] * (i ? pic->h / 2 : pic->h);
+      d->sao_in[i] = (pixel *)realloc(d->sao_in[i], n); memcpy(d->sao_in[i], pic->plane[i], n);
+      sc.src[i] = d->sao_in[i]; sc.dst[i] = pic->plane[i]; sc.stride[i] = pic->stride[i];
+    }
+    orc_sao_picture(&sc);
+  }
   d->pic_active = 0;
   if (pic->needed_for_output) d->out_queue[d->out_n++] = pic;   /* low-delay streams: output order == decode order */
 }
@@ -767,7 +785,13 @@ static int decode_slice_data(orc_decoder *d, const uint8_t *data, size_t len)
     if (new_qg_row) d->last_qp_y = sh->slice_qp;      /* qPY_PREV at first QG of slice / tile / CTB row (WPP) */
     first = 0;
     if (!p->cu_qp_delta_enabled) { d->qp_y_pred = sh->slice_qp; d->cu_qp_delta_val = 0; }
-    /* coding_tree_unit(): no SAO syntax (unsupported when enabled) */
+    if (sh->sao_luma || sh->sao_chroma) {              /* 7.3.8.2: sao() before the coding quadtree */
+      const orc_sao_params *left = NULL, *up = NULL;
+      if (cx > 0 && d->ctb_slice[rs - 1] == slice_addr && d->ctb_tile[rs - 1] == d->ctb_tile[rs]) left = &d->sao[rs - 1];
+      if (cy > 0 && d->ctb_slice[rs - wc] == slice_addr && d->ctb_tile[rs - wc] == d->ctb_tile[rs]) up = &d->sao[rs - wc];
+      orc_sao_parse(&d->cabac, &d->sao[rs], left, up, sh->sao_luma, sh->sao_chroma);
+      d->sao_used = 1;
+    } else memset(&d->sao[rs], 0, sizeof(d->sao[rs]));
     coding_quadtree(d, cx << s->ctb_log2, cy << s->ctb_log2, s->ctb_log2, 0);
     if (d->err) return d->err;
     if (d->cabac.br.error) return ERR_INVALID;
@@ -822,7 +846,6 @@ int orc_dec_decode_nal(orc_decoder *d, const uint8_t *data, size_t len, int64_t 
   d->p = &d->pps[d->sh.pps_id]; d->s = &d->sps[d->p->sps_id];
   if (d->sh.slice_type == SLICE_B) return ERR_UNSUPPORTED;
   if (d->sh.slice_temporal_mvp_enabled) return ERR_UNSUPPORTED;
-  if (d->sh.sao_luma || d->sh.sao_chroma) return ERR_UNSUPPORTED;
   if (d->sh.first_slice_segment_in_pic) {
     if (d->pic_active) finish_picture(d);             /* previous picture was incomplete */
     r = start_picture(d);

@@ -11,6 +11,7 @@
 #include "hevc_transform.h"
 #include "hevc_deblock.h"
 #include "hevc_mvpred.h"
+#include "hevc_sao.h"
 
 #define SPLIT_BITS 8          /* rate charged for splitting a CU one level, in bins */
 #define ME_PAD 64             /* padding of the reference copy used by the motion search */
@@ -43,6 +44,7 @@ struct orc_encoder {
   int roi_w, roi_h; int8_t *roi;       /* delta-QP map (orc_enc_set_roi) */
   int8_t *ctu_qt, *ctu_qy, *ctu_delta; uint8_t *ctu_first;   /* per CTU: target QP, actual QpY, coded CuQpDeltaVal, z index (8x8 units) of the first CU with residual (64: none) */
   int *tile_row_bd;                    /* first CTB row of tile row i, i = 0 .. tile_rows */
+  orc_sao_params *sao; pixel *sao_in[3];   /* cfg.sao: parameters of every CTU; copy of the deblocked picture */
   int is_intra;
   uint64_t bins;
 };
@@ -110,7 +112,7 @@ orc_encoder *orc_enc_open(const orc_enc_config *c)
   s->max_dec_pic_buffering = 2; s->max_num_reorder = 0; s->max_latency_increase_plus1 = 0;
   s->log2_min_cb = 3; s->log2_diff_max_min_cb = 3; s->log2_min_tb = 2; s->log2_diff_max_min_tb = 3;
   s->max_th_depth_inter = 0; s->max_th_depth_intra = 0;
-  s->amp_enabled = 0; s->sao_enabled = 0;
+  s->amp_enabled = 0; s->sao_enabled = c->sao ? 1 : 0;
   s->num_st_rps = 1; s->st_rps[0].num_negative = 1; s->st_rps[0].delta_poc_s0[0] = -1; s->st_rps[0].used_s0[0] = 1;
   s->temporal_mvp_enabled = 0; s->strong_intra_smoothing = 1;
   s->vui_present = 1; s->vui_timing_present = 1; s->vui_num_units_in_tick = (uint32_t)c->fps_den; s->vui_time_scale = (uint32_t)c->fps_num;
@@ -124,6 +126,7 @@ orc_encoder *orc_enc_open(const orc_enc_config *c)
   p->log2_parallel_merge_level = 2; p->num_tile_columns = p->num_tile_rows = 1; p->uniform_spacing = 1;
   p->cu_qp_delta_enabled = c->qp_in_cu ? 1 : 0; p->diff_cu_qp_delta_depth = 0;
   { size_t nctu = (size_t)(e->cw / 64) * (e->ch / 64);
+    if (c->sao) { e->sao = (orc_sao_params *)calloc(nctu, sizeof(orc_sao_params)); for (int i = 0; i < 3; i++) e->sao_in[i] = (pixel *)malloc(i ? npx / 4 : npx); }
     e->ctu_qt = (int8_t *)calloc(nctu, 1); e->ctu_qy = (int8_t *)calloc(nctu, 1); e->ctu_delta = (int8_t *)calloc(nctu, 1); e->ctu_first = (uint8_t *)calloc(nctu, 1); }
 
   memset(&e->av, 0, sizeof(e->av));
@@ -148,7 +151,7 @@ void orc_enc_close(orc_encoder *e)
   if (!e) return;
   for (int i = 0; i < 2; i++) orc_pic_free(&e->pics[i]);
   for (int i = 0; i < 3; i++) { free(e->src[i]); free(e->coef[i]); free(e->predeblock[i]); }
-  free(e->refpad);
+  free(e->refpad); free(e->sao); for (int i = 0; i < 3; i++) free(e->sao_in[i]);
   free(e->cu_log2); free(e->cu_intra); free(e->cu_flags); free(e->cu_merge_idx); free(e->cu_mvp_idx);
   free(e->cu_intra_mode); free(e->cu_cbf); free(e->cu_mv); free(e->cu_mvd); free(e->bs_v); free(e->bs_h);
   free(e->im8); free(e->im16); free(e->im32); free(e->ic8); free(e->ic16); free(e->ic32);
@@ -729,6 +732,8 @@ static void write_picture(orc_encoder *e, int write_ps)
       else memcpy(c.ctx, saved, sizeof(saved));       /* WPP: state after the 2nd CTU of the row above */
     }
     for (int cx = 0; cx < wc; cx++) {
+      if (e->cfg.sao) orc_sao_write(&c, &e->sao[cy * wc + cx], cx > 0 ? &e->sao[cy * wc + cx - 1] : NULL,
+                                    (cy > 0 && !tile_start) ? &e->sao[(cy - 1) * wc + cx] : NULL, 1, 1);
       enc_quadtree(e, &c, cx * 64, cy * 64, 6, 0);
       if (e->cfg.wpp && cx == 1) memcpy(saved, c.ctx, sizeof(saved));
       int last = (cy == hc - 1 && cx == wc - 1);
@@ -746,6 +751,7 @@ static void write_picture(orc_encoder *e, int write_ps)
   sh.num_ref_idx_l0 = 1; sh.num_ref_idx_l1 = 1; sh.max_num_merge_cand = 5; sh.collocated_from_l0 = 1;
   sh.slice_deblocking_disabled = !e->cfg.deblock;
   sh.loop_filter_across_slices = 1;
+  sh.sao_luma = sh.sao_chroma = e->cfg.sao ? 1 : 0;
   uint32_t *ep = (uint32_t *)calloc((size_t)nsub, sizeof(uint32_t));
   sh.num_entry_points = nsub - 1; sh.entry_point_offset = ep;
   for (int i = 0; i < nsub - 1; i++) ep[i] = (uint32_t)orc_escaped_size(rows[i].buf, rows[i].len);
@@ -843,6 +849,18 @@ size_t orc_enc_encode(orc_encoder *e, const pixel *y, const pixel *u, const pixe
     db.bs_v = e->bs_v; db.bs_stride_v = e->cw / 8; db.bs_h = e->bs_h; db.bs_stride_h = e->cw / 4;
     db.qp_y = e->cur->qp_y; db.qp_stride = e->cur->b4_w;
     orc_deblock_picture(&db);
+  }
+  if (e->cfg.sao) {                                   /* 8.7.3 on the deblocked picture, parameters from the decision below */
+    int wc = e->cw / 64, hc = e->ch / 64;
+    const pixel *deb[3], *org[3];
+    for (int i = 0; i < 3; i++) { memcpy(e->sao_in[i], e->cur->plane[i], (size_t)e->cur->stride[i] * (i ? e->ch / 2 : e->ch)); deb[i] = e->sao_in[i]; org[i] = e->src[i]; }
+    if (e->cur->stride[0] != e->cw || e->cur->stride[1] != e->cw / 2) abort();
+    for (int cy = 0; cy < hc; cy++) for (int cx = 0; cx < wc; cx++)
+      orc_sao_decide_ctu(deb, org, e->cur->stride, e->cw, e->ch, cx, cy, orc_lambda_q4[e->qp], &e->sao[cy * wc + cx]);
+    orc_sao_ctx sc; memset(&sc, 0, sizeof(sc));
+    sc.w = e->cw; sc.h = e->ch; sc.ctb_log2 = 6; sc.pic_w_ctbs = wc; sc.params = e->sao; sc.across_slices = sc.across_tiles = 1;
+    for (int i = 0; i < 3; i++) { sc.src[i] = e->sao_in[i]; sc.dst[i] = e->cur->plane[i]; sc.stride[i] = e->cur->stride[i]; }
+    orc_sao_picture(&sc);
   }
   int write_ps = 0;
   if (e->is_intra) {

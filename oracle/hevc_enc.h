@@ -36,6 +36,7 @@ typedef struct {
   int qp_in_cu;               /* 1: cu_qp_delta_enabled_flag, quantisation group = CTU: a delta-QP map set with orc_enc_set_roi()
                                * gives every CTU its own QP (kvz_picture.roi, kvazaarfilter.cpp:423-431) */
   int bitrate;                /* bits per second; 0 = constant QP.  > 0: "uvgx rate control v1" (see hevc_enc.c) */
+  int sao;                    /* 1: sample adaptive offset on, parameters by "uvgx SAO decision v1" (hevc_sao.c) */
 } orc_enc_config;
 
 typedef struct {

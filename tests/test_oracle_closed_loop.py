@@ -118,3 +118,22 @@ def test_delta_qp_map_closed_loop(w, h, wpp, tile_rows):
         d = od.decode_au(au, t)
         assert len(d) == 1 and np.array_equal(d[0]["i420"], oe.recon()), t
     oe.close(); od.close()
+
+
+@pytest.mark.parametrize("w,h,qp,kind,wpp,tile_rows", [(320, 256, 32, 0, 1, 1), (320, 256, 37, 2, 0, 1), (448, 320, 22, 0, 1, 2),
+                                                      (256, 448, 30, 2, 0, 3), (130, 70, 27, 0, 1, 1)])
+def test_sao_closed_loop(w, h, qp, kind, wpp, tile_rows):
+    """sample adaptive offset on ("uvgx SAO decision v1", oracle/hevc_sao.c): the checker's decoder parses sao() of every CTU
+    (merge left / up, band and edge offsets) and reproduces the encoder's filtered picture; the filter lowers the error"""
+    def run(sao):
+        oe = orc.OracleEncoder(w, h, qp=qp, period=4, me_range=16, wpp=wpp, tile_rows=tile_rows, sao=sao)
+        od = orc.OracleDecoder()
+        sse = 0.0
+        for t in range(6):
+            fr = orc.synth_frame(kind, 7, w, h, t)
+            got = od.decode_au(oe.encode(fr), t)
+            assert len(got) == 1 and np.array_equal(got[0]["i420"], oe.recon()), (sao, t)
+            sse += float(np.sum((fr.astype(np.int64) - oe.recon()) ** 2))
+        oe.close(); od.close()
+        return sse
+    assert run(1) < run(0)

@@ -80,7 +80,7 @@ typedef struct kvz_config {
   int32_t framerate_num;      /* "input-fps" */
   int32_t framerate_denom;
   int32_t deblock_enable;     /* "deblock" */
-  enum kvz_sao sao_type;      /* "sao" (only off is implemented) */
+  enum kvz_sao sao_type;      /* "sao": off, or full (edge and band offsets) */
   int32_t rdoq_enable, signhide_enable, smp_enable, amp_enable;
   int32_t rdo;                /* "rd" */
   int32_t full_intra_search, trskip_enable, tr_depth_intra;

@@ -1267,6 +1267,14 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
     for (int b = 0; b < 3; b++) z |= ((((x0 & 63) >> 3) >> b) & 1) << (2 * b) | ((((y0 & 63) >> 3) >> b) & 1) << (2 * b + 1);
     if (lane == 0 && comp == 0) {
       TokOut t; t.tabs = &tabs; t.p = hdr; t.n = 0; t.cap = TOK_HDR_CAP;
+      if (f.sao && z4 == 0 && k == 0) {                 // coding_tree_unit() starts with sao()
+        const SaoParams sp = f.sao[ctu];
+        SaoParams sl, su;
+        const bool hl = cx > 0, hu = cy > 0 && !tile_row_starts_at(hc, f.tile_rows, cy);
+        if (hl) sl = f.sao[ctu - 1];
+        if (hu) su = f.sao[ctu - wc];
+        enc_sao(t, sp, hl ? &sl : nullptr, hu ? &su : nullptr);
+      }
       enc_split_flags(v, t, f.cw, f.chp, x0, y0, z, cu.log2);
       enc_cu_header(v, t, f.cw, f.chp, f.is_intra != 0, x0, y0, cu);
       // the quantisation group's (= CTU's) delta QP goes with its first CU that has residual, right after the cbf flags
@@ -1438,6 +1446,140 @@ __global__ __launch_bounds__(256) void k_scatter_levels(EncFrame f, const TuDesc
 }
 
 // =============================================================================================
+// Sample adaptive offset (8.7.3).  One workgroup per CTU: the deblocked CTU with a one-sample border goes to LDS for all
+// three components.  Encoder: statistics against the source picture and "uvgx SAO decision v1" (statement of record:
+// oracle/hevc_sao.c), parameters out; decoder: parameters in.  Both: the filtered CTU goes to the output picture.
+// =============================================================================================
+struct SaoLds {
+  alignas(4) uint8_t win[66 * 68];            // luma: rows -1 .. 64, columns -1 .. 64 (pitch 68)
+  alignas(4) uint8_t winc[2][34 * 36];        // chroma: rows / columns -1 .. 32 (pitch 36)
+  int en[3][4][5], es[3][4][5], bn[3][32], bs[3][32];
+  int eo_off[3][4][4], eo_dist[3][4][4], bo_off[3][32], bo_gain[3][32];
+  int cand_dist[3][5], cand_bins[3][5], cand_band[3];
+  SaoParams p;
+};
+__device__ __forceinline__ int sao_edge_idx(int c, int a, int b)
+{
+  const int e = 2 + ((c > a) - (c < a)) + ((c > b) - (c < b));
+  return e == 2 ? 0 : (e < 2 ? e + 1 : e);
+}
+__device__ __forceinline__ int sao_rdiv(int a, int b) { return b == 0 ? 0 : (a >= 0 ? (2 * a + b) / (2 * b) : -((-2 * a + b) / (2 * b))); }
+__device__ __forceinline__ int sao_off_bins(int o) { const int a = o < 0 ? -o : o; return a < 7 ? a + 1 : 7; }
+
+template <bool DEC>
+__global__ __launch_bounds__(256) void k_sao(EncFrame f)
+{
+  __shared__ SaoLds s;
+  const int tid = threadIdx.x, wc = f.cw >> 6, ctu = blockIdx.x, cx = ctu % wc, cy = ctu / wc;
+  auto W = [&](int c, int x, int y) -> int { return c ? s.winc[c - 1][(y + 1) * 36 + x + 1] : s.win[(y + 1) * 68 + x + 1]; };
+  for (int c = 0; c < 3; c++) {
+    const int sh = c ? 1 : 0, n = 64 >> sh, m = n + 2, pw = f.cw >> sh, ph = f.ch >> sh, X0 = cx * n - 1, Y0 = cy * n - 1;
+    uint8_t *w = c ? s.winc[c - 1] : s.win; const int pitch = c ? 36 : 68;
+    for (int i = tid; i < m * m; i += 256) {
+      const int y = i / m, x = i - y * m;
+      w[y * pitch + x] = f.rec[c][(size_t)clip3(0, ph - 1, Y0 + y) * pw + clip3(0, pw - 1, X0 + x)];
+    }
+  }
+  if (DEC) { if (tid == 0) s.p = f.sao[ctu]; }
+  else for (int i = tid; i < (int)((sizeof(s.en) + sizeof(s.es) + sizeof(s.bn) + sizeof(s.bs)) / sizeof(int)); i += 256) (&s.en[0][0][0])[i] = 0;
+  __syncthreads();
+  if (!DEC) {
+    for (int c = 0; c < 3; c++) {
+      const int sh = c ? 1 : 0, l2n = 6 - sh, n = 1 << l2n, pw = f.cw >> sh, ph = f.ch >> sh, X0 = cx * n, Y0 = cy * n;
+      for (int i = tid; i < n * n; i += 256) {
+        const int y = i >> l2n, x = i & (n - 1), v = W(c, x, y);
+        const int d = (int)f.src[c][(size_t)(Y0 + y) * pw + X0 + x] - v;
+        atomicAdd(&s.bn[c][v >> 3], 1); atomicAdd(&s.bs[c][v >> 3], d);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int xa = X0 + x + kSaoDx[e][0], ya = Y0 + y + kSaoDy[e][0], xb = X0 + x + kSaoDx[e][1], yb = Y0 + y + kSaoDy[e][1];
+          if (xa < 0 || ya < 0 || xa >= pw || ya >= ph || xb < 0 || yb < 0 || xb >= pw || yb >= ph) continue;
+          const int k = sao_edge_idx(v, W(c, x + kSaoDx[e][0], y + kSaoDy[e][0]), W(c, x + kSaoDx[e][1], y + kSaoDy[e][1]));
+          if (k) { atomicAdd(&s.en[c][e][k], 1); atomicAdd(&s.es[c][e][k], d); }
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 48) {                                       // edge offsets: component x class x category
+      const int c = tid >> 4, e = (tid >> 2) & 3, k = (tid & 3) + 1, N = s.en[c][e][k], S = s.es[c][e][k];
+      int o = sao_rdiv(S, N);
+      o = k <= 2 ? clip3(0, 7, o) : clip3(-7, 0, o);
+      s.eo_off[c][e][k - 1] = o; s.eo_dist[c][e][k - 1] = N * o * o - 2 * o * S;
+    } else if (tid >= 64 && tid < 160) {                  // band offsets: component x band
+      const int c = (tid - 64) >> 5, b = (tid - 64) & 31, N = s.bn[c][b], S = s.bs[c][b];
+      const int o = clip3(-7, 7, sao_rdiv(S, N));
+      s.bo_off[c][b] = o; s.bo_gain[c][b] = N * o * o - 2 * o * S;
+    }
+    __syncthreads();
+    if (tid < 15) {                                       // candidates: component x [EO 0..3, BO]
+      const int c = tid / 5, j = tid - c * 5;
+      int dist = 0, bins = 0;
+      if (j < 4) { for (int k = 0; k < 4; k++) { dist += s.eo_dist[c][j][k]; bins += sao_off_bins(s.eo_off[c][j][k]); } }
+      else {
+        int best = 0;
+        for (int st = 0; st <= 28; st++) {
+          const int g = s.bo_gain[c][st] + s.bo_gain[c][st + 1] + s.bo_gain[c][st + 2] + s.bo_gain[c][st + 3];
+          if (st == 0 || g < dist) { dist = g; best = st; }
+        }
+        bins = 5;
+        for (int k = 0; k < 4; k++) { const int o = s.bo_off[c][best + k]; bins += sao_off_bins(o) + (o != 0); }
+        s.cand_band[c] = best;
+      }
+      s.cand_dist[c][j] = dist; s.cand_bins[c][j] = bins;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const long long l2 = (long long)f.lambda_q4 * f.lambda_q4;
+      int pick[2] = {0, 0};
+      long long best = l2;
+      for (int t = 1; t <= 5; t++) {
+        const long long cost = 256LL * s.cand_dist[0][t - 1] + l2 * (2 + s.cand_bins[0][t - 1] + (t <= 4 ? 2 : 0));
+        if (cost < best) { best = cost; pick[0] = t; }
+      }
+      best = l2;
+      for (int t = 1; t <= 5; t++) {
+        const long long cost = 256LL * ((long long)s.cand_dist[1][t - 1] + s.cand_dist[2][t - 1]) + l2 * (2 + s.cand_bins[1][t - 1] + s.cand_bins[2][t - 1] + (t <= 4 ? 2 : 0));
+        if (cost < best) { best = cost; pick[1] = t; }
+      }
+      SaoParams p;
+      for (int c = 0; c < 3; c++) {
+        const int t = pick[c ? 1 : 0];
+        p.type[c] = t == 0 ? 0 : (t == 5 ? 1 : 2);
+        p.eo_class[c] = (t >= 1 && t <= 4) ? (uint8_t)(t - 1) : 0;
+        p.band_pos[c] = t == 5 ? (uint8_t)s.cand_band[c] : 0;
+        for (int k = 0; k < 4; k++) p.offset[c][k] = (int8_t)(t == 0 ? 0 : (t == 5 ? s.bo_off[c][s.cand_band[c] + k] : s.eo_off[c][t - 1][k]));
+      }
+      s.p = p; f.sao[ctu] = p;
+    }
+  }
+  __syncthreads();
+  // ---- the filter: four samples of a row per thread
+  for (int c = 0; c < 3; c++) {
+    const int sh = c ? 1 : 0, l2n = 6 - sh, n = 1 << l2n, pw = f.cw >> sh, ph = f.ch >> sh, X0 = cx * n, Y0 = cy * n;
+    const int type = s.p.type[c], e = s.p.eo_class[c], bp = s.p.band_pos[c];
+    for (int q = tid; q < n * n / 4; q += 256) {
+      const int y = q >> (l2n - 2), x4 = (q & ((n >> 2) - 1)) * 4;
+      uint32_t out = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int x = x4 + i, v = W(c, x, y);
+        int o = v;
+        if (type == 1) { const int k = ((v >> 3) - bp) & 31; if (k < 4) o = clip8(v + s.p.offset[c][k]); }
+        else if (type == 2) {
+          const int xa = X0 + x + kSaoDx[e][0], ya = Y0 + y + kSaoDy[e][0], xb = X0 + x + kSaoDx[e][1], yb = Y0 + y + kSaoDy[e][1];
+          if (!(xa < 0 || ya < 0 || xa >= pw || ya >= ph || xb < 0 || yb < 0 || xb >= pw || yb >= ph)) {
+            const int k = sao_edge_idx(v, W(c, x + kSaoDx[e][0], y + kSaoDy[e][0]), W(c, x + kSaoDx[e][1], y + kSaoDy[e][1]));
+            if (k) o = clip8(v + s.p.offset[c][k - 1]);
+          }
+        }
+        out |= (uint32_t)o << (8 * i);
+      }
+      *(uint32_t *)&f.sao_out[c][(size_t)(Y0 + y) * pw + X0 + x4] = out;
+    }
+  }
+}
+
+// =============================================================================================
 // launch wrappers
 // =============================================================================================
 void launch_scatter_levels(const EncFrame &f, const TuDesc *tus, int ntu, const uint32_t *pairs, hipStream_t st)
@@ -1487,6 +1629,8 @@ void launch_deblock_h(const EncFrame &f, hipStream_t st)
   hipLaunchKernelGGL(k_deblock_h, dim3((nh + 255) / 256), dim3(256), 0, st, f);
 }
 void launch_deblock(const EncFrame &f, hipStream_t st) { launch_deblock_v(f, st); launch_deblock_h(f, st); }
+void launch_sao(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_sao<false>, dim3((f.cw / 64) * (f.ch / 64)), dim3(256), 0, st, f); }
+void launch_dec_sao(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_sao<true>, dim3((f.cw / 64) * (f.ch / 64)), dim3(256), 0, st, f); }
 void launch_tokenize(const EncFrame &f, hipStream_t st)
 {
   const int wc = f.cw / 64;

@@ -18,7 +18,7 @@
 namespace kvzx {
 
 // K_HOST_ARITH is not a kernel: wall time of the host arithmetic-coding stage (entropy_host.h)
-enum KernelId { K_PAD = 0, K_ME, K_INTER_RECON, K_INTER_SIGNAL, K_INTRA_ANALYSE, K_INTRA_RECON, K_DEBLOCK, K_TOKENIZE, K_HOST_ARITH, K_COUNT };
+enum KernelId { K_PAD = 0, K_ME, K_INTER_RECON, K_INTER_SIGNAL, K_INTRA_ANALYSE, K_INTRA_RECON, K_DEBLOCK, K_TOKENIZE, K_HOST_ARITH, K_SAO, K_COUNT };
 
 struct EncoderConfig {
   int width = 0, height = 0;
@@ -34,6 +34,7 @@ struct EncoderConfig {
   int entropy_threads = 16;   // host threads of the arithmetic-coding stage
   int qp_in_cu = 0;           // kvazaar "set-qp-in-cu": cu_qp_delta_enabled_flag; a delta-QP map (set_roi, kvz_picture.roi) then gives every CTU its own QP
   int bitrate = 0;            // bits per second; 0 = constant QP, > 0 = "uvgx rate control v1" (oracle/hevc_enc.c rate_control())
+  int sao = 0;                // kvazaar "sao": sample adaptive offset, parameters by "uvgx SAO decision v1" (oracle/hevc_sao.c)
   int owf = 0;                // kvazaar "owf": 0 = encode() returns its own picture; 1 = output lags one picture and the host
                               // coding of picture t overlaps the kernels of t + 1; >= 2 = output lags two pictures and the host
                               // coding runs on a background thread, so the calling thread only launches kernels
@@ -121,6 +122,9 @@ class Encoder {
   hipStream_t stream_tok_ = nullptr;     // signalling decisions, tokenizer, compaction
   hipStream_t stream_in_ = nullptr;      // input padding (runs ahead of the previous picture's kernels)
   hipEvent_t ev_padded_ = nullptr, ev_src_free_[2] = {nullptr, nullptr}; bool src_busy_[2] = {false, false};
+  uint8_t *work_[3] = {nullptr, nullptr, nullptr};   // SAO on: the picture up to deblocking (rec_[] then holds the filtered pictures)
+  SaoParams *sao_[2] = {nullptr, nullptr};            // per CTU, one array per set
+  hipEvent_t ev_sao_ = nullptr;
   hipEvent_t ev_signalled_ = nullptr, ev_tok_done_[2] = {nullptr, nullptr}; bool tok_pending_[2] = {false, false};
   void bind_set(int k);
   uint8_t *intra_scratch_ = nullptr;

@@ -29,8 +29,8 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   if (cfg.band_rows > 0) {
     const int hc = (cfg.height + 63) / 64, T = cfg.tile_rows;
     const bool ok = cfg.band_row0 >= 0 && cfg.band_row0 + cfg.band_rows <= hc && tile_row_starts_at(hc, T, cfg.band_row0) &&
-                    tile_row_ends_at(hc, T, cfg.band_row0 + cfg.band_rows - 1) && cfg.bitrate == 0;
-    if (!ok) { if (error) *error = "a band must consist of whole tile rows (and rate control is not available in band mode)"; return false; }
+                    tile_row_ends_at(hc, T, cfg.band_row0 + cfg.band_rows - 1) && cfg.bitrate == 0 && !cfg.sao;
+    if (!ok) { if (error) *error = "a band must consist of whole tile rows (and rate control and SAO are not available in band mode)"; return false; }
   }
   cfg_ = cfg;
   qp_cur_ = cfg.qp;
@@ -64,6 +64,11 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
       HIP_OK(hipMalloc(&ctu_qt_[k], nctu)); HIP_OK(hipMalloc(&ctu_qy_[k], nctu)); HIP_OK(hipMalloc(&ctu_delta_[k], nctu)); HIP_OK(hipMalloc(&ctu_first_[k], nctu));
       HIP_OK(hipHostMalloc(&h_ctu_qt_[k], nctu, hipHostMallocDefault));
     }
+  }
+  if (cfg.sao) {
+    for (int c = 0; c < 3; c++) HIP_OK(hipMalloc(&work_[c], c ? npx / 4 : npx));
+    for (int k = 0; k < 2; k++) HIP_OK(hipMalloc(&sao_[k], sizeof(SaoParams) * (size_t)(cw_ / 64) * rows_));
+    HIP_OK(hipEventCreateWithFlags(&ev_sao_, hipEventDisableTiming));
   }
   HIP_OK(hipStreamCreateWithFlags(&stream_tok_, hipStreamNonBlocking));
   HIP_OK(hipStreamCreateWithFlags(&stream_in_, hipStreamNonBlocking));
@@ -117,7 +122,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   f_.tok_dense_cap = (uint32_t)tok_dense_cap_;
   f_.sync = sync_; f_.err = err_;
 
-  sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp; sp_.tile_rows = cfg.tile_rows; sp_.qp_in_cu = cfg.qp_in_cu;
+  sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp; sp_.tile_rows = cfg.tile_rows; sp_.qp_in_cu = cfg.qp_in_cu; sp_.sao = cfg.sao;
   sp_.deblock = cfg.deblock; sp_.fps_num = cfg.fps_num; sp_.fps_den = cfg.fps_den;
   HIP_OK(hipStreamSynchronize(stream_));
   HIP_OK(hipDeviceSynchronize());
@@ -135,6 +140,7 @@ void Encoder::bind_set(int k)
   f_.cu_log2 = cu; f_.cu_intra = cu + nb8; f_.cu_flags = cu + 2 * nb8; f_.cu_merge_idx = cu + 3 * nb8;
   f_.cu_mvp_idx = cu + 4 * nb8; f_.cu_intra_mode = cu + 5 * nb8; f_.cu_cbf = cu + 6 * nb8;
   f_.cu_mv = cu_mv_[k]; f_.cu_mvd = cu_mvd_[k];
+  f_.sao = sao_[k];                                    // NULL without SAO
   f_.ctu_qt = ctu_qt_[k]; f_.ctu_qy = ctu_qy_[k]; f_.ctu_delta = ctu_delta_[k]; f_.ctu_first = ctu_first_[k];     // all NULL without qp_in_cu
 }
 
@@ -159,6 +165,9 @@ Encoder::~Encoder()
   for (int c = 0; c < 3; c++) { hipFree(src_[0][c]); hipFree(src_[1][c]); for (int b = 0; b < 3; b++) hipFree(rec_[b][c]); hipFree(coef_[0][c]); hipFree(coef_[1][c]); }
   for (int k = 0; k < 2; k++) { hipFree(ctu_qt_[k]); hipFree(ctu_qy_[k]); hipFree(ctu_delta_[k]); hipFree(ctu_first_[k]); if (h_ctu_qt_[k]) hipHostFree(h_ctu_qt_[k]); }
   for (int k = 0; k < 2; k++) { hipFree(cu_bytes_[k]); hipFree(cu_mv_[k]); hipFree(cu_mvd_[k]); if (ev_tok_done_[k]) hipEventDestroy(ev_tok_done_[k]); }
+  for (int c = 0; c < 3; c++) hipFree(work_[c]);
+  for (int k = 0; k < 2; k++) hipFree(sao_[k]);
+  if (ev_sao_) hipEventDestroy(ev_sao_);
   if (ev_signalled_) hipEventDestroy(ev_signalled_);
   if (ev_padded_) hipEventDestroy(ev_padded_);
   for (int k = 0; k < 2; k++) if (ev_src_free_[k]) hipEventDestroy(ev_src_free_[k]);
@@ -283,7 +292,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   f_.qp = qp_cur_; f_.qpc = kChromaQp[qp_cur_]; f_.lambda_q4 = kLambdaQ4[qp_cur_];
   if (!upload_qp_targets()) return false;
   f_.is_intra = intra; f_.poc = poc_;
-  for (int c = 0; c < 3; c++) { f_.rec[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
+  for (int c = 0; c < 3; c++) { f_.rec[c] = cfg_.sao ? work_[c] : rec_[cur_idx_][c]; f_.sao_out[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
   f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err;
   const EncFrame f = f_;
   if (intra) {
@@ -299,8 +308,10 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   HIP_CHECK(hipEventRecord(ev_signalled_, stream_));             // levels, cbf and motion of the picture are final; source set read
   HIP_CHECK(hipEventRecord(ev_src_free_[set_], stream_)); src_busy_[set_] = true;
   if (cfg_.deblock) timed(K_DEBLOCK, stream_, [&] { launch_deblock(f, stream_); });
+  if (cfg_.sao) { timed(K_SAO, stream_, [&] { launch_sao(f, stream_); }); HIP_CHECK(hipEventRecord(ev_sao_, stream_)); }
   HIP_CHECK(hipStreamWaitEvent(stream_tok_, ev_signalled_, 0));
   if (!intra) timed(K_INTER_SIGNAL, stream_tok_, [&] { launch_inter_signal(f, stream_tok_); });
+  if (cfg_.sao) HIP_CHECK(hipStreamWaitEvent(stream_tok_, ev_sao_, 0));      // the tokenizer codes the CTUs' SAO parameters
   timed(K_TOKENIZE, stream_tok_, [&] { launch_tokenize(f, stream_tok_); });
   HIP_CHECK(hipEventRecord(ev_tok_done_[set_], stream_tok_)); tok_pending_[set_] = true;
   // the slot is complete when both streams are: the tokens (stream_tok_) and the reconstruction (stream_)

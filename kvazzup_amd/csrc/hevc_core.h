@@ -27,6 +27,13 @@ KVZ_HD int kv_clz32(uint32_t v) { return __builtin_clz(v); }            // v != 
 // Per-CU arrays are indexed per 8x8 luma block ("b8"), pitch b8w = cw / 8; every 8x8 block of
 // a CU carries the CU's values.
 // ---------------------------------------------------------------------------------------------
+// sample adaptive offset parameters of one CTU (7.3.8.3): type 0 off, 1 band, 2 edge (Cr shares Cb's type and class);
+// offset[c][k] = SaoOffsetVal[k + 1].  Same layout as the checker's orc_sao_params.
+struct SaoParams {
+  uint8_t type[3], eo_class[3], band_pos[3];
+  int8_t offset[3][4];
+};
+
 struct EncFrame {
   int cw, ch, b8w, b8h;
   int qp, qpc, lambda_q4, range;
@@ -54,6 +61,9 @@ struct EncFrame {
   //   on (8.6.1), ctu_delta: the coded CuQpDeltaVal (QpY of the CUs before that one = ctu_qy - ctu_delta), ctu_first: z index
   //   (8x8 units) of that first CU, 64 = none
   const int8_t *ctu_qt; int8_t *ctu_qy, *ctu_delta; uint8_t *ctu_first;
+  // sample adaptive offset (NULL = off): rec[] is then the picture up to deblocking, sao_out[] the filtered picture that is
+  // output and referenced; sao[] the per-CTU parameters (encoder: decided by k_sao, decoder: parsed)
+  SaoParams *sao; uint8_t *sao_out[3];
   uint32_t *sync;               // [rows] progress counters (intra reconstruction wavefront)
   uint32_t *err;                // device-side error flags
 };
@@ -343,6 +353,41 @@ KVZ_HD void cabac_play_tokens(CabacEnc &c, const uint16_t *tok, int n)
     if (!(t & 0x8000u)) cabac_bin(c, (int)(t >> 1), (int)(t & 1));
     else if (!(t & 0x4000u)) cabac_bypass_bits(c, t & 0x3ffu, (int)((t >> 10) & 15) + 1);
     else cabac_terminate(c, (int)(t & 1));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sao() (H.265 7.3.8.3): merge flags are pure syntax -- left when the left CTU has identical parameters, else up likewise
+// (`left` / `up`: the neighbours that may be merged from, else NULL).  sao_offset_abs is TR with cMax 7, all bypass.
+// ---------------------------------------------------------------------------------------------
+KVZ_HD bool sao_same(const SaoParams &a, const SaoParams &b)
+{
+  bool eq = true;
+  for (int c = 0; c < 3; c++) {
+    eq = eq && a.type[c] == b.type[c] && a.eo_class[c] == b.eo_class[c] && a.band_pos[c] == b.band_pos[c];
+    for (int k = 0; k < 4; k++) eq = eq && a.offset[c][k] == b.offset[c][k];
+  }
+  return eq;
+}
+template <class S>
+KVZ_HD void enc_sao(S &t, const SaoParams &p, const SaoParams *left, const SaoParams *up)
+{
+  if (left) { const bool m = sao_same(p, *left); cabac_bin(t, CTX_SAO_MERGE, m); if (m) return; }
+  if (up) { const bool m = sao_same(p, *up); cabac_bin(t, CTX_SAO_MERGE, m); if (m) return; }
+  for (int ci = 0; ci < 3; ci++) {
+    if (ci < 2) {
+      cabac_bin(t, CTX_SAO_TYPE, p.type[ci] != 0);
+      if (p.type[ci]) cabac_bypass(t, p.type[ci] == 2);
+    }
+    if (!p.type[ci]) continue;
+    for (int i = 0; i < 4; i++) {
+      const int a = p.offset[ci][i] < 0 ? -p.offset[ci][i] : p.offset[ci][i];
+      if (a < 7) cabac_bypass_bits(t, ((1u << a) - 1u) << 1, a + 1); else cabac_bypass_bits(t, 127u, 7);
+    }
+    if (p.type[ci] == 1) {
+      for (int i = 0; i < 4; i++) if (p.offset[ci][i]) cabac_bypass(t, p.offset[ci][i] < 0);
+      cabac_bypass_bits(t, p.band_pos[ci], 5);
+    } else if (ci < 2) cabac_bypass_bits(t, p.eo_class[ci], 2);
   }
 }
 

@@ -29,6 +29,7 @@ struct StreamParams {
   int fps_num, fps_den;
   int qp_in_cu = 0;         // cu_qp_delta_enabled_flag with diff_cu_qp_delta_depth 0 (quantisation group = CTU)
   int tile_rows = 1;        // > 1: tiles_enabled_flag, one column, uniform spacing, loop filter across tiles on
+  int sao = 0;              // sample_adaptive_offset_enabled_flag; every slice: slice_sao_luma_flag = slice_sao_chroma_flag = 1
 };
 
 inline int level_idc_for(int w, int h)
@@ -69,7 +70,7 @@ inline void write_sps(BitWriter &w, const StreamParams &s)
   w.bit(1); w.ue(1); w.ue(0); w.ue(0);
   w.ue(0); w.ue(3); w.ue(0); w.ue(3);                            // CB 8..64, TB 4..32
   w.ue(0); w.ue(0);                                              // transform hierarchy depths
-  w.bit(0); w.bit(0); w.bit(0); w.bit(0);                        // scaling list, amp, sao, pcm
+  w.bit(0); w.bit(0); w.bit(s.sao != 0); w.bit(0);               // scaling list, amp, sao, pcm
   w.ue(1); w.ue(1); w.ue(0); w.ue(0); w.bit(1);                  // one short-term RPS: previous picture
   w.bit(0); w.bit(0); w.bit(1);                                  // long-term, tmvp, strong intra smoothing
   w.bit(1);                                                      // VUI: timing only
@@ -116,10 +117,11 @@ inline void write_slice_header(BitWriter &w, const StreamParams &s, bool idr, in
   w.ue(0);
   w.ue(idr ? 2 : 1);
   if (!idr) { w.put((uint32_t)poc & 255, 8); w.bit(1); }
+  if (s.sao) { w.bit(1); w.bit(1); }                             // slice_sao_luma_flag, slice_sao_chroma_flag
   if (!idr) { w.bit(0); w.ue(0); }                               // num_ref_idx override, five_minus_max_num_merge_cand
   w.se(slice_qp_delta);                                          // against the PPS init_qp (= the configured QP)
-  // (deblocking override not enabled; slice_loop_filter_across_slices_enabled_flag present when deblocking is on)
-  if (s.deblock) w.bit(1);
+  // (deblocking override not enabled; slice_loop_filter_across_slices_enabled_flag present when deblocking or SAO is on)
+  if (s.deblock || s.sao) w.bit(1);
   if (s.wpp || s.tile_rows > 1) {
     w.ue((uint32_t)entry_sizes.size());
     if (!entry_sizes.empty()) {

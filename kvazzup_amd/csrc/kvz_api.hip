@@ -140,7 +140,8 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
   }
   if (n == "sao") {
     if (!strcmp(value, "off") || !strcmp(value, "0") || !strcmp(value, "false")) { cfg->sao_type = KVZ_SAO_OFF; return 1; }
-    return 0;
+    if (!strcmp(value, "full") || !strcmp(value, "1") || !strcmp(value, "true")) { cfg->sao_type = KVZ_SAO_FULL; return 1; }
+    return 0;                                           // "edge" / "band" alone: not implemented
   }
   if (n == "me") {
     static const char *names[] = {"hexbs", "tz", "full", "full8", "full16", "full32", "full64", "dia"};
@@ -241,6 +242,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1;
   ec.band_row0 = cfg->band_row0; ec.band_rows = cfg->band_rows;
   ec.qp_in_cu = cfg->set_qp_in_cu ? 1 : 0;
+  ec.sao = cfg->sao_type == KVZ_SAO_FULL;
   ec.bitrate = cfg->target_bitrate > 0 ? cfg->target_bitrate : 0;      // any rc-algorithm value selects the one picture-level controller
   std::string err;
   Encoder *impl = Encoder::create(ec, &err);
@@ -393,7 +395,7 @@ int kvzx_encoder_kernel_times(kvz_encoder *e, double *ms, uint64_t *launches, in
 }
 const char *kvzx_encoder_kernel_name(int id)
 {
-  static const char *names[kvzx::K_COUNT] = {"k_pad_input", "k_me", "k_inter_recon", "k_inter_signal", "k_intra_analyse", "k_intra_recon", "k_deblock", "k_tokenize", "host_arith_coder"};
+  static const char *names[kvzx::K_COUNT] = {"k_pad_input", "k_me", "k_inter_recon", "k_inter_signal", "k_intra_analyse", "k_intra_recon", "k_deblock", "k_tokenize", "host_arith_coder", "k_sao"};
   return (id >= 0 && id < kvzx::K_COUNT) ? names[id] : nullptr;
 }
 uint64_t kvzx_encoder_last_bins(kvz_encoder *e) { return e ? e->last_bins : 0; }

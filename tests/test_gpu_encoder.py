@@ -29,10 +29,11 @@ def _diagnose(dbg_o, dbg_g):
     return "; ".join(msgs) if msgs else "no stage-level difference found (entropy coding / assembly?)"
 
 
-def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_picture=True, tile_rows=1):
+def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_picture=True, tile_rows=1, sao=0):
     from kvazzup_amd.codec import Encoder
-    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows)
-    ge = Encoder(w, h, options=(("qp", qp), ("period", period), ("me-range", me_range), ("wpp", wpp), ("deblock", deblock), ("tiles", "1x%d" % tile_rows)))
+    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows, sao=sao)
+    ge = Encoder(w, h, options=(("qp", qp), ("period", period), ("me-range", me_range), ("wpp", wpp), ("deblock", deblock), ("tiles", "1x%d" % tile_rows),
+                                ("sao", "full" if sao else "off")))
     assert not ge.rejected, ge.rejected
     try:
         for t in range(frames):
@@ -173,3 +174,18 @@ def test_roi_delta_qp_map_matches_oracle(gpu, w, h, wpp, tile_rows):
         assert au_g == au_o, "picture %d: %d vs %d bytes" % (t, len(au_g), len(au_o))
         assert np.array_equal(rec_g, oe.recon()), t
     ge.close(); oe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(w=320, h=256, frames=6, qp=32, period=4, me_range=16, kind=0, sao=1),
+    dict(w=320, h=256, frames=4, qp=37, period=2, me_range=8, kind=2, sao=1, wpp=0),            # noise: band offsets, one substream
+    dict(w=448, h=320, frames=5, qp=22, period=3, me_range=16, kind=0, sao=1, tile_rows=2),     # no merge-up across the tile boundary
+    dict(w=130, h=70, frames=3, qp=27, period=64, me_range=8, kind=0, sao=1),                   # conformance window
+    dict(w=640, h=360, frames=3, qp=30, period=64, me_range=16, kind=0, sao=1, deblock=0),      # SAO straight on the reconstruction
+    dict(w=1920, h=1080, frames=3, qp=32, period=64, me_range=16, kind=0, sao=1),
+])
+def test_sao_matches_oracle(gpu, cfg):
+    """kvazaar "sao" (off at the ultrafast preset, on for the slower ones): statistics, "uvgx SAO decision v1", the filter
+    (H.265 8.7.3) and sao() of every CTU, bit-exact against the checker -- access units and filtered reconstruction"""
+    run_clip(**cfg)

@@ -32,7 +32,7 @@
 namespace kvzx {
 
 // DK_HOST_PARSE is not a kernel: wall time of the host CABAC parsing stage
-enum DecKernelId { DK_SCATTER = 0, DK_INTER_RECON, DK_INTRA_RECON, DK_DEBLOCK, DK_HOST_PARSE, DK_COUNT };
+enum DecKernelId { DK_SCATTER = 0, DK_INTER_RECON, DK_INTRA_RECON, DK_DEBLOCK, DK_HOST_PARSE, DK_SAO, DK_COUNT };
 
 struct DecSps {
   bool valid = false;
@@ -42,6 +42,7 @@ struct DecSps {
   int num_st_rps = 0; int rps_neg[64], rps_used[64];      // first negative entry of each SPS RPS (subset check)
   uint32_t fps_num = 0, fps_den = 0;
   int strong_intra = 0;
+  int sao = 0;                        // sample_adaptive_offset_enabled_flag
 };
 struct DecPps {
   bool valid = false;
@@ -108,10 +109,11 @@ class Decoder {
     std::vector<uint8_t> rbsp; size_t data_off = 0, data_len = 0;
     std::vector<size_t> sub_start;
     int tile_rows = 1, qp_in_cu = 0;
+    int sao_luma = 0, sao_chroma = 0;                          // slice_sao_luma_flag / slice_sao_chroma_flag
     int slice_qp = 0, max_merge = 5, poc = 0; bool is_intra = false, deblock = true; int64_t pts = 0;
     int crop[4] = {0, 0, 0, 0}; uint32_t fps_num = 0, fps_den = 0;
     // Everything the GPU needs for the picture, in one pinned block that goes over in one copy:
-    // [ CU records: 7 byte arrays of b8 entries | motion vectors: b8 x 2 int16 | per CTU: QpY, delta, first coded CU | TuDesc x ntu | level words x nlev ]
+    // [ CU records: 7 byte arrays of b8 entries | motion vectors: b8 x 2 int16 | per CTU: QpY, delta, first coded CU | per CTU: SaoParams | TuDesc x ntu | level words x nlev ]
     uint8_t *h_in = nullptr; size_t h_in_cap = 0; size_t ntu = 0, nlev = 0;
     EncFrame hf{};                                             // host view of the CU / motion arrays inside h_in
     std::vector<RowState> rows; std::vector<uint8_t> wpp_saved;
@@ -124,7 +126,8 @@ class Decoder {
   int parse_row(PicJob &job, int row, const uint8_t *data, size_t len, RowState &rs);
   int finish_oldest();
   void drop_pending();
-  size_t fixed_bytes() const { return (size_t)cw_ * ch_ / 64 * 11 + (size_t)(cw_ / 64) * (ch_ / 64) * 3; }   // CU records + motion vectors + per-CTU QpY / delta / first coded CU
+  size_t sao_offset() const { return (size_t)cw_ * ch_ / 64 * 11 + (size_t)(cw_ / 64) * (ch_ / 64) * 3; }
+  size_t fixed_bytes() const { return sao_offset() + (size_t)(cw_ / 64) * (ch_ / 64) * sizeof(SaoParams); }   // CU records + motion vectors + per-CTU QpY / delta / first coded CU + per-CTU SAO parameters
   bool grow_job_input(PicJob &job, size_t bytes);
   void bind_views(EncFrame &f, uint8_t *base);
   int launch_gpu(PicJob &job);
@@ -141,6 +144,7 @@ class Decoder {
   uint8_t *d_in_ = nullptr; size_t d_in_cap_ = 0;          // device copy of PicJob::h_in
   int16_t *d_mvd_ = nullptr;
   uint8_t *rec_[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  uint8_t *work_[3] = {nullptr, nullptr, nullptr};          // pictures with SAO: reconstruction and deblocking happen here, the filter writes into rec_
   int16_t *coef_[3] = {nullptr, nullptr, nullptr};
   uint32_t *sync_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
   uint8_t *h_out_ = nullptr; size_t h_out_cap_ = 0;

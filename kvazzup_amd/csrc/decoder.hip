@@ -142,6 +142,30 @@ const ScanTabs &scan_tabs()
 }
 
 // residual_coding() (7.3.8.11) without transform skip / sign hiding; writes n*n levels row-major
+// sao() of one CTU (7.3.8.3); `left` / `up`: the neighbours that may be merged from
+void parse_sao(CabacDec &c, SaoParams &p, const SaoParams *left, const SaoParams *up, bool luma, bool chroma)
+{
+  memset(&p, 0, sizeof(p));
+  if (left && c.bin(CTX_SAO_MERGE)) { p = *left; return; }
+  if (up && c.bin(CTX_SAO_MERGE)) { p = *up; return; }
+  for (int ci = 0; ci < 3; ci++) {
+    if (!(ci ? chroma : luma)) continue;
+    if (ci < 2) p.type[ci] = (uint8_t)(c.bin(CTX_SAO_TYPE) ? (c.bypass() ? 2 : 1) : 0);
+    else { p.type[2] = p.type[1]; p.eo_class[2] = p.eo_class[1]; }
+    if (!p.type[ci]) continue;
+    int a[4];
+    for (int i = 0; i < 4; i++) { a[i] = 0; while (a[i] < 7 && c.bypass()) a[i]++; }
+    if (p.type[ci] == 1) {
+      for (int i = 0; i < 4; i++) if (a[i] && c.bypass()) a[i] = -a[i];
+      p.band_pos[ci] = (uint8_t)c.bypass_bits(5);
+    } else {
+      if (ci < 2) p.eo_class[ci] = (uint8_t)c.bypass_bits(2);
+      a[2] = -a[2]; a[3] = -a[3];                                  // edge offsets: categories 1, 2 positive, 3, 4 negative
+    }
+    for (int i = 0; i < 4; i++) p.offset[ci][i] = (int8_t)a[i];
+  }
+}
+
 bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, std::vector<uint32_t> &out)
 {
   const CoreTabs *t = host_tabs();
@@ -278,7 +302,7 @@ void Decoder::free_buffers()
   for (auto &j : jobs_) { if (j.h_in) hipHostFree(j.h_in); j.h_in = nullptr; j.h_in_cap = 0; }
   if (h_out_) hipHostFree(h_out_);
   hipFree(d_in_); hipFree(d_mvd_); hipFree(sync_);
-  for (int c = 0; c < 3; c++) { for (int b = 0; b < 3; b++) { hipFree(rec_[b][c]); rec_[b][c] = nullptr; } hipFree(coef_[c]); coef_[c] = nullptr; }
+  for (int c = 0; c < 3; c++) { for (int b = 0; b < 3; b++) { hipFree(rec_[b][c]); rec_[b][c] = nullptr; } hipFree(work_[c]); work_[c] = nullptr; hipFree(coef_[c]); coef_[c] = nullptr; }
   h_out_ = nullptr; d_in_ = nullptr; d_in_cap_ = 0; d_mvd_ = nullptr; sync_ = nullptr;
   cw_ = ch_ = 0;
 }
@@ -344,6 +368,7 @@ bool Decoder::ensure_buffers(int cw, int ch)
   for (int c = 0; c < 3; c++) {
     size_t n = c ? npx / 4 : npx;
     for (int b = 0; b < 3; b++) { HIP_TRY(hipMalloc(&rec_[b][c], n)); HIP_TRY(hipMemset(rec_[b][c], 128, n)); }
+    HIP_TRY(hipMalloc(&work_[c], n));
     HIP_TRY(hipMalloc(&coef_[c], n * sizeof(int16_t)));
   }
   for (auto &j : jobs_) bind_views(j.hf, j.h_in);
@@ -413,7 +438,8 @@ int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
     for (int k = oi ? 0 : msl; k <= msl; k++) { r.ue(); r.ue(); r.ue(); }
     int log2_min_cb = r.ue() + 3, diff_cb = r.ue(), log2_min_tb = r.ue() + 2, diff_tb = r.ue(), dinter = r.ue(), dintra = r.ue();
     int scaling = r.get(1); int amp = r.get(1), sao = r.get(1), pcm = r.get(1);
-    if (scaling || amp || sao || pcm || log2_min_cb != 3 || diff_cb != 3 || log2_min_tb != 2 || diff_tb != 3 || dinter != 0 || dintra != 0)
+    s.sao = sao;
+    if (scaling || amp || pcm || log2_min_cb != 3 || diff_cb != 3 || log2_min_tb != 2 || diff_tb != 3 || dinter != 0 || dintra != 0)
       return last_error_ = DEC_ERR_UNSUPPORTED;
     s.num_st_rps = r.ue();
     if (s.num_st_rps > 64) return last_error_ = DEC_ERR_INVALID;
@@ -519,6 +545,8 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     }
     if (!is_intra && (neg != -1 || !used || !have_ref_ || poc - 1 != prev_poc_)) return DEC_ERR_UNSUPPORTED;   // reference = previous picture
   }
+  int sao_luma = 0, sao_chroma = 0;
+  if (s.sao) { sao_luma = r.get(1); sao_chroma = r.get(1); }
   int max_merge = 5;
   if (!is_intra) {
     if (r.get(1)) { if (r.ue() != 0) return DEC_ERR_UNSUPPORTED; }        // num_ref_idx_active override: still one reference
@@ -528,7 +556,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   const int slice_qp = p.init_qp + r.se();
   if (slice_qp < 0 || slice_qp > 51) return DEC_ERR_INVALID;
   const bool deblock = !p.deblock_disabled;
-  if (p.loop_filter_across_slices && deblock) r.get(1);
+  if (p.loop_filter_across_slices && (deblock || sao_luma || sao_chroma)) r.get(1);
   std::vector<uint32_t> entry;
   if (p.wpp || p.tile_rows > 1) {
     int nep = r.ue();
@@ -570,6 +598,8 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   if (p.tile_rows > s.height / 64) return DEC_ERR_INVALID;
   job.tile_rows = p.tile_rows; job.hf.tile_rows = p.tile_rows; job.hf.chp = pack_height(ch_, p.tile_rows);
   job.qp_in_cu = p.qp_in_cu;
+  job.sao_luma = sao_luma; job.sao_chroma = sao_chroma;
+  job.hf.sao = (sao_luma || sao_chroma) ? (SaoParams *)(job.h_in + sao_offset()) : nullptr;
   bind_qp_arrays(job.hf, job.h_in, cw_, ch_, true);               // the parser always fills them (one QP everywhere without cu_qp_delta)
   job.rc = 0;
   prev_poc_ = poc; have_ref_ = true;                             // header checks of the next picture run before this one is reconstructed
@@ -694,6 +724,11 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
     for (int cx = 0; cx < wc; cx++) {
       if (!wait_above(cy, cx + 2)) return DEC_ERR_INVALID;
       int ctu_qy = prev_qy, ctu_first = 64;                // quantisation group = CTU (8.6.1)
+      if (f.sao) {                                         // sao() (7.3.8.3) opens the CTU
+        SaoParams *sp = &f.sao[cy * wc + cx];
+        const SaoParams *left = cx > 0 ? sp - 1 : nullptr, *up = (cy > 0 && !tile_row_starts_at(hc, T, cy)) ? sp - wc : nullptr;
+        parse_sao(c, *sp, left, up, job.sao_luma != 0, job.sao_chroma != 0);
+      }
       // coding_quadtree, iteratively in z-order over the 8x8 grid of the CTU
       for (int z = 0; z < 64;) {
         int xi, yi; ctu_z_to_xy(z, xi, yi);
@@ -873,7 +908,9 @@ int Decoder::launch_gpu(PicJob &job)
   f_.tile_rows = job.tile_rows; f_.chp = pack_height(ch_, job.tile_rows);
   bind_qp_arrays(f_, d_in_, cw_, ch_, job.qp_in_cu != 0);
   const int cur = (int)(launched_ % 3), ref = (int)((launched_ + 2) % 3);     // three buffers: the picture output by the previous call stays intact
-  for (int c = 0; c < 3; c++) { f_.rec[c] = rec_[cur][c]; f_.ref[c] = rec_[ref][c]; }
+  const bool sao = job.sao_luma || job.sao_chroma;                            // the picture is then built in work_ and filtered into the ring
+  for (int c = 0; c < 3; c++) { f_.rec[c] = sao ? work_[c] : rec_[cur][c]; f_.sao_out[c] = rec_[cur][c]; f_.ref[c] = rec_[ref][c]; }
+  f_.sao = sao ? (SaoParams *)(d_in_ + sao_offset()) : nullptr;
   const EncFrame f = f_;
   timed(DK_SCATTER, [&] { launch_scatter_levels(f, d_tus, (int)ntu, d_lev, stream_); });
   if (is_intra) {
@@ -883,6 +920,7 @@ int Decoder::launch_gpu(PicJob &job)
     timed(DK_INTER_RECON, [&] { launch_dec_inter_recon(f, stream_); });
   }
   if (deblock) timed(DK_DEBLOCK, [&] { launch_deblock(f, stream_); });
+  if (sao) timed(DK_SAO, [&] { launch_dec_sao(f, stream_); });
   if (hipMemcpyAsync(h_err_, err_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_) != hipSuccess) return DEC_ERR_GPU;
   t_api_ += tk_api.ms();
   job.rec_idx = cur;

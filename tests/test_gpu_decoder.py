@@ -8,9 +8,9 @@ import orc
 SEED = 0x5EED0000
 
 
-def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, tile_rows=1, threads=1):
+def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, tile_rows=1, threads=1, sao=0):
     from kvazzup_amd.codec import Decoder
-    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows)
+    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows, sao=sao)
     od = orc.OracleDecoder()
     gd = Decoder()
     try:
@@ -196,3 +196,49 @@ def test_decoder_survives_corrupted_streams(gpu):
         got = gd.decode_au(aus[t], t)
         assert len(got) == 1 and np.array_equal(got[0]["i420"], recs[t]), t
     gd.close(); oe.close(); oe2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(w=320, h=256, frames=6, qp=32, period=4, me_range=16, kind=0, sao=1),
+    dict(w=320, h=256, frames=4, qp=37, period=2, me_range=8, kind=2, sao=1, wpp=0),
+    dict(w=448, h=320, frames=5, qp=22, period=3, me_range=16, kind=0, sao=1, tile_rows=2),
+    dict(w=130, h=70, frames=3, qp=27, period=64, me_range=8, kind=0, sao=1),
+    dict(w=640, h=360, frames=3, qp=30, period=64, me_range=16, kind=0, sao=1, deblock=0),
+    dict(w=1920, h=1080, frames=3, qp=32, period=64, me_range=16, kind=0, sao=1),
+])
+def test_decoder_sao(gpu, cfg):
+    """streams with sample adaptive offset from the checker's encoder: sao() parsed per CTU (merge left / up, band and edge
+    offsets), the filter (8.7.3) after deblocking, filtered pictures as references"""
+    run_clip(**cfg)
+
+
+@pytest.mark.gpu
+def test_sao_stream_through_frame_threads_and_filters(gpu):
+    """GPU encoder with sao=full -> GPU decoder with frame threads: decoded pictures equal the encoder's reconstruction"""
+    from kvazzup_amd import _native as N
+    from kvazzup_amd.codec import Decoder, Encoder
+    w, h, frames = 640, 384, 8
+    ge = Encoder(w, h, options=(("qp", 30), ("period", 4), ("me-range", 16), ("sao", "full"), ("owf", 2)))
+    assert not ge.rejected, ge.rejected
+    clip = [orc.synth_frame(0, SEED, w, h, t) for t in range(frames)]
+    outs = [ge.encode(f) for f in clip] + [ge.encode(None) for _ in range(2)]
+    outs = [o for o in outs if o[0] is not None]
+    assert len(outs) == frames
+    gd = Decoder.__new__(Decoder)
+    gd.lib = N.load_library()
+    gd.h = gd.lib.libOpenHevcInit(3, 1)
+    assert gd.lib.libOpenHevcStartDecoder(gd.h) == 0
+    gd.download = True; gd.vps = gd.sps = gd.pps = False
+    dec = []
+    for t, (au, _) in enumerate(outs):
+        dec += gd.decode_au(au, t)
+    eos = bytes([0, 0, 0, 1, 36 << 1, 1])
+    for _ in range(3):
+        d = gd.decode_nal(eos)
+        if d is not None:
+            dec.append(d)
+    assert len(dec) == frames
+    for t in range(frames):
+        assert np.array_equal(dec[t]["i420"], outs[t][1]), t
+    gd.close(); ge.close()

@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--decoder-frame-threads", type=int, default=8,
                     help="OpenHEVC 'Frame' parallelisation (uvgComm setting video/OH_parallelization): pictures parsed concurrently; 1 = off")
     ap.add_argument("--profile-every", type=int, default=8, help="kernel timing with HIP events on every n-th picture")
+    ap.add_argument("--sao", action="store_true", help="kvazaar sao=full (off at the ultrafast preset the headline workload uses)")
     ap.add_argument("--owf", type=int, default=2,
                     help="uvgComm setting video/OWF (kvazaar owf): 1 = host arithmetic coding of picture t overlaps the kernels of t + 1; "
                          "2 = it runs on a background thread and the output lags two pictures")
@@ -179,7 +180,7 @@ def main():
     # source -> KvazaarFilter -> WireAdapter -> OpenHEVCFilter -> sink, one thread per filter (csrc/filters.hip)
     pl = Pipeline(w, h, settings={"video/QP": 32, "video/Intra": 64, "video/VPS": 1, "uvgx/gpu": local_rank, "uvgx/decoderDownload": 0,
                                   "video/OWF": args.owf, "video/OPENHEVC_threads": D, "video/OH_parallelization": "Frame" if D > 1 else "Slice"},
-                  custom=(("me-range", args.me_range), ("gpu", local_rank)), loopback=True, keep_outputs=False)
+                  custom=(("me-range", args.me_range), ("gpu", local_rank)) + ((("sao", "full"),) if args.sao else ()), loopback=True, keep_outputs=False)
     lib = pl.lib
     enc_h, dec_h = pl.encoder_handle(), pl.decoder_handle()
     cw, ch = C.c_int(), C.c_int()
@@ -276,7 +277,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl["name"], "width": w, "height": h, "coded_width": cw, "coded_height": ch,
                        "frames_per_gpu": args.steps, "intra_period": 64, "qp": 32, "me_range": args.me_range,
-                       "streams": world, "bytes_per_frame": round(nbytes / args.steps, 1), "decoder_frame_threads": D, "owf": args.owf,
+                       "streams": world, "bytes_per_frame": round(nbytes / args.steps, 1), "decoder_frame_threads": D, "owf": args.owf, "sao": bool(args.sao),
                        "input": "I420 resident in HBM", "output": "Annex-B AU on host + decoded I420 in HBM"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,

@@ -1451,8 +1451,10 @@ __global__ __launch_bounds__(256) void k_scatter_levels(EncFrame f, const TuDesc
 // oracle/hevc_sao.c), parameters out; decoder: parameters in.  Both: the filtered CTU goes to the output picture.
 // =============================================================================================
 struct SaoLds {
-  alignas(4) uint8_t win[66 * 68];            // luma: rows -1 .. 64, columns -1 .. 64 (pitch 68)
-  alignas(4) uint8_t winc[2][34 * 36];        // chroma: rows / columns -1 .. 32 (pitch 36)
+  // the deblocked CTU with a one-sample border, one padded picture per component: sample (x, y), x and y in -1 .. n, at
+  // [(y + 1) * pitch + 4 + x]; pitch 72 / 40 keeps the CTB's own samples dword aligned
+  alignas(4) uint8_t win[66 * 72];
+  alignas(4) uint8_t winc[2][34 * 40];
   int en[3][4][5], es[3][4][5], bn[3][32], bs[3][32];
   int eo_off[3][4][4], eo_dist[3][4][4], bo_off[3][32], bo_gain[3][32];
   int cand_dist[3][5], cand_bins[3][5], cand_band[3];
@@ -1471,33 +1473,76 @@ __global__ __launch_bounds__(256) void k_sao(EncFrame f)
 {
   __shared__ SaoLds s;
   const int tid = threadIdx.x, wc = f.cw >> 6, ctu = blockIdx.x, cx = ctu % wc, cy = ctu / wc;
-  auto W = [&](int c, int x, int y) -> int { return c ? s.winc[c - 1][(y + 1) * 36 + x + 1] : s.win[(y + 1) * 68 + x + 1]; };
+  // ---- window: the CTB's samples as dwords, the border ring byte by byte (clamped at the picture edges; those samples are
+  // never used: a neighbour outside the picture switches the edge offset off)
+#pragma unroll
   for (int c = 0; c < 3; c++) {
-    const int sh = c ? 1 : 0, n = 64 >> sh, m = n + 2, pw = f.cw >> sh, ph = f.ch >> sh, X0 = cx * n - 1, Y0 = cy * n - 1;
-    uint8_t *w = c ? s.winc[c - 1] : s.win; const int pitch = c ? 36 : 68;
-    for (int i = tid; i < m * m; i += 256) {
-      const int y = i / m, x = i - y * m;
-      w[y * pitch + x] = f.rec[c][(size_t)clip3(0, ph - 1, Y0 + y) * pw + clip3(0, pw - 1, X0 + x)];
+    const int sh = c ? 1 : 0, l2n = 6 - sh, n = 1 << l2n, pw = f.cw >> sh, ph = f.ch >> sh, X0 = cx * n, Y0 = cy * n;
+    uint8_t *w = c ? s.winc[c - 1] : s.win; const int pitch = c ? 40 : 72;
+    const uint8_t *src = f.rec[c];
+#pragma unroll
+    for (int i = tid; i < n * n / 4; i += 256) {
+      const int y = i >> (l2n - 2), x = (i & ((n >> 2) - 1)) * 4;
+      *(uint32_t *)&w[(y + 1) * pitch + 4 + x] = *(const uint32_t *)&src[(size_t)(Y0 + y) * pw + X0 + x];
+    }
+    for (int q = tid; q < 4 * n + 4; q += 256) {
+      int x, y;
+      if (q < n + 2) { x = q - 1; y = -1; } else if (q < 2 * n + 4) { x = q - (n + 2) - 1; y = n; }
+      else if (q < 3 * n + 4) { x = -1; y = q - (2 * n + 4); } else { x = n; y = q - (3 * n + 4); }
+      w[(y + 1) * pitch + 4 + x] = src[(size_t)clip3(0, ph - 1, Y0 + y) * pw + clip3(0, pw - 1, X0 + x)];
     }
   }
   if (DEC) { if (tid == 0) s.p = f.sao[ctu]; }
   else for (int i = tid; i < (int)((sizeof(s.en) + sizeof(s.es) + sizeof(s.bn) + sizeof(s.bs)) / sizeof(int)); i += 256) (&s.en[0][0][0])[i] = 0;
   __syncthreads();
   if (!DEC) {
+    // Statistics.  A thread walks down a piece of a column of the CTB (luma 16 rows, chroma 4) with the 3 x 3 neighbourhood
+    // in registers.  Edge classes: per class one 64-bit accumulator with four 16-bit fields (sum of d + 256 per category) and
+    // one 32-bit accumulator with four 8-bit counts, reduced over the wave with DPP at the end -- one LDS atomic per wave and
+    // statistic.  Bands: runs of equal band index along the column are summed in registers and flushed when the band changes.
+#pragma unroll
     for (int c = 0; c < 3; c++) {
       const int sh = c ? 1 : 0, l2n = 6 - sh, n = 1 << l2n, pw = f.cw >> sh, ph = f.ch >> sh, X0 = cx * n, Y0 = cy * n;
-      for (int i = tid; i < n * n; i += 256) {
-        const int y = i >> l2n, x = i & (n - 1), v = W(c, x, y);
-        const int d = (int)f.src[c][(size_t)(Y0 + y) * pw + X0 + x] - v;
-        atomicAdd(&s.bn[c][v >> 3], 1); atomicAdd(&s.bs[c][v >> 3], d);
+      const uint8_t *w = c ? s.winc[c - 1] : s.win; const int pitch = c ? 40 : 72;
+      const int rows = c ? 4 : 16, x = tid & (n - 1), ys = (tid >> l2n) * rows;
+      const bool okh = X0 + x - 1 >= 0 && X0 + x + 1 < pw;
+      const uint8_t *col = w + 4 + x - 1;                                   // column x - 1 of window row 0 (= sample row -1)
+      int r0[3], r1[3], r2[3];
+      for (int k = 0; k < 3; k++) { r0[k] = col[ys * pitch + k]; r1[k] = col[(ys + 1) * pitch + k]; }
+      uint64_t sacc[4] = {0, 0, 0, 0}; uint32_t cacc[4] = {0, 0, 0, 0};
+      int run_b = -1, run_n = 0, run_s = 0;
+      const uint8_t *org = f.src[c] + (size_t)(Y0 + ys) * pw + X0 + x;
+      int o8[16];                                                           // the source column: all loads in flight at once
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const int xa = X0 + x + kSaoDx[e][0], ya = Y0 + y + kSaoDy[e][0], xb = X0 + x + kSaoDx[e][1], yb = Y0 + y + kSaoDy[e][1];
-          if (xa < 0 || ya < 0 || xa >= pw || ya >= ph || xb < 0 || yb < 0 || xb >= pw || yb >= ph) continue;
-          const int k = sao_edge_idx(v, W(c, x + kSaoDx[e][0], y + kSaoDy[e][0]), W(c, x + kSaoDx[e][1], y + kSaoDy[e][1]));
-          if (k) { atomicAdd(&s.en[c][e][k], 1); atomicAdd(&s.es[c][e][k], d); }
+      for (int j = 0; j < rows; j++) o8[j] = org[(size_t)j * pw];
+#pragma unroll
+      for (int j = 0; j < rows; j++) {
+        const int y = ys + j;
+        for (int k = 0; k < 3; k++) r2[k] = col[(y + 2) * pitch + k];
+        const int v = r1[1], d = o8[j] - v, b = v >> 3;
+        if (b != run_b) {
+          if (run_n) { atomicAdd(&s.bn[c][run_b], run_n); atomicAdd(&s.bs[c][run_b], run_s); }
+          run_b = b; run_n = 0; run_s = 0;
         }
+        run_n++; run_s += d;
+        const bool okv = Y0 + y - 1 >= 0 && Y0 + y + 1 < ph;
+        const int ka = okh ? sao_edge_idx(v, r1[0], r1[2]) : 0, kb = okv ? sao_edge_idx(v, r0[1], r2[1]) : 0;
+        const int kc = (okh && okv) ? sao_edge_idx(v, r0[0], r2[2]) : 0, kd = (okh && okv) ? sao_edge_idx(v, r0[2], r2[0]) : 0;
+        const int kk[4] = {ka, kb, kc, kd};
+#pragma unroll
+        for (int e = 0; e < 4; e++) if (kk[e]) { sacc[e] += (uint64_t)(uint32_t)(d + 256) << (16 * (kk[e] - 1)); cacc[e] += 1u << (8 * (kk[e] - 1)); }
+        for (int k = 0; k < 3; k++) { r0[k] = r1[k]; r1[k] = r2[k]; }
       }
+      if (run_n) { atomicAdd(&s.bn[c][run_b], run_n); atomicAdd(&s.bs[c][run_b], run_s); }
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int k = 1; k <= 4; k++) {
+          // one reduction for both: the wave's count (<= 1024) above bit 20, its biased sum (<= 64 * 16 * 511) below
+          const uint32_t cnt = (cacc[e] >> (8 * (k - 1))) & 0xffu, sum = (uint32_t)(sacc[e] >> (16 * (k - 1))) & 0xffffu;
+          const uint32_t r = wave_sum_u32((cnt << 20) | sum), N = r >> 20, S = r & 0xfffffu;
+          if ((tid & 63) == 0) { atomicAdd(&s.en[c][e][k], (int)N); atomicAdd(&s.es[c][e][k], (int)S - 256 * (int)N); }
+        }
     }
     __syncthreads();
     if (tid < 48) {                                       // edge offsets: component x class x category
@@ -1553,26 +1598,44 @@ __global__ __launch_bounds__(256) void k_sao(EncFrame f)
     }
   }
   __syncthreads();
-  // ---- the filter: four samples of a row per thread
+  // ---- the filter: four samples of a row per thread, the rows above and below as 6-byte spans (samples x - 1 .. x + 4)
+#pragma unroll
   for (int c = 0; c < 3; c++) {
     const int sh = c ? 1 : 0, l2n = 6 - sh, n = 1 << l2n, pw = f.cw >> sh, ph = f.ch >> sh, X0 = cx * n, Y0 = cy * n;
+    const uint8_t *w = c ? s.winc[c - 1] : s.win; const int pitch = c ? 40 : 72;
     const int type = s.p.type[c], e = s.p.eo_class[c], bp = s.p.band_pos[c];
+    int off[4];
+    for (int k = 0; k < 4; k++) off[k] = s.p.offset[c][k];
+#pragma unroll
     for (int q = tid; q < n * n / 4; q += 256) {
       const int y = q >> (l2n - 2), x4 = (q & ((n >> 2) - 1)) * 4;
-      uint32_t out = 0;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int x = x4 + i, v = W(c, x, y);
-        int o = v;
-        if (type == 1) { const int k = ((v >> 3) - bp) & 31; if (k < 4) o = clip8(v + s.p.offset[c][k]); }
-        else if (type == 2) {
-          const int xa = X0 + x + kSaoDx[e][0], ya = Y0 + y + kSaoDy[e][0], xb = X0 + x + kSaoDx[e][1], yb = Y0 + y + kSaoDy[e][1];
-          if (!(xa < 0 || ya < 0 || xa >= pw || ya >= ph || xb < 0 || yb < 0 || xb >= pw || yb >= ph)) {
-            const int k = sao_edge_idx(v, W(c, x + kSaoDx[e][0], y + kSaoDy[e][0]), W(c, x + kSaoDx[e][1], y + kSaoDy[e][1]));
-            if (k) o = clip8(v + s.p.offset[c][k - 1]);
-          }
+      const uint32_t *row = (const uint32_t *)&w[(y + 1) * pitch + x4];        // dword holding samples x4 - 4 .. x4 - 1
+      uint32_t out = row[1];
+      if (type == 1) {
+        uint32_t o = 0;
+        for (int i = 0; i < 4; i++) {
+          const int v = (out >> (8 * i)) & 255, k = ((v >> 3) - bp) & 31;
+          o |= (uint32_t)(k < 4 ? clip8(v + off[k]) : v) << (8 * i);
         }
-        out |= (uint32_t)o << (8 * i);
+        out = o;
+      } else if (type == 2) {
+        auto span = [&](const uint32_t *r) -> uint64_t { return ((uint64_t)r[0] >> 24) | ((uint64_t)r[1] << 8) | ((uint64_t)(r[2] & 255u) << 40); };
+        const int dq = pitch >> 2;
+        const uint64_t mid = span(row), up = span(row - dq), dn = span(row + dq);
+        const bool okv = Y0 + y - 1 >= 0 && Y0 + y + 1 < ph;
+        uint32_t o = 0;
+        for (int i = 0; i < 4; i++) {
+          const int v = (int)((mid >> (8 * (i + 1))) & 255);
+          int a, b; bool ok;
+          const bool okh = X0 + x4 + i - 1 >= 0 && X0 + x4 + i + 1 < pw;
+          if (e == 0) { a = (int)((mid >> (8 * i)) & 255); b = (int)((mid >> (8 * (i + 2))) & 255); ok = okh; }
+          else if (e == 1) { a = (int)((up >> (8 * (i + 1))) & 255); b = (int)((dn >> (8 * (i + 1))) & 255); ok = okv; }
+          else if (e == 2) { a = (int)((up >> (8 * i)) & 255); b = (int)((dn >> (8 * (i + 2))) & 255); ok = okh && okv; }
+          else { a = (int)((up >> (8 * (i + 2))) & 255); b = (int)((dn >> (8 * i)) & 255); ok = okh && okv; }
+          const int k = ok ? sao_edge_idx(v, a, b) : 0;
+          o |= (uint32_t)(k ? clip8(v + off[k - 1]) : v) << (8 * i);
+        }
+        out = o;
       }
       *(uint32_t *)&f.sao_out[c][(size_t)(Y0 + y) * pw + X0 + x4] = out;
     }

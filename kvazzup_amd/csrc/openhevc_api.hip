@@ -146,7 +146,7 @@ int kvzx_decoder_kernel_times(OpenHevc_Handle hh, double *ms, uint64_t *launches
 }
 const char *kvzx_decoder_kernel_name(int id)
 {
-  static const char *names[kvzx::DK_COUNT] = {"k_scatter_levels", "k_inter_recon<dec>", "k_intra_recon<dec>", "k_deblock", "host_cabac_parse", "k_sao"};
+  static const char *names[kvzx::DK_COUNT] = {"k_scatter_levels", "k_inter_recon<dec>", "k_intra_recon<dec>", "k_deblock", "host_cabac_parse", "k_sao<dec>"};
   return (id >= 0 && id < kvzx::DK_COUNT) ? names[id] : nullptr;
 }
 int kvzx_decoder_debug_copy(OpenHevc_Handle hh, const char *what, void *dst, size_t bytes)

@@ -52,7 +52,7 @@ def test_kvz_api_table_and_config_parsing(lib):
     c = cfg.contents
     assert (c.width, c.height, c.framerate_num, c.framerate_denom, c.qp, c.intra_period, c.vps_period, c.owf, c.wpp) == (1920, 1080, 30, 1, 32, 64, 1, 2, 1)
     # rejected: unknown names and values outside the implemented tool set (kvazaarfilter.cpp:363-367 logs these)
-    for k, v in (("no-such-option", "1"), ("qp", "99"), ("input-res", "axb"), ("tiles", "2x2"), ("scaling-list", "default"), ("gop", "8"), ("preset", "warp9"), ("sao", "full")):
+    for k, v in (("no-such-option", "1"), ("qp", "99"), ("input-res", "axb"), ("tiles", "2x2"), ("scaling-list", "default"), ("gop", "8"), ("preset", "warp9"), ("sao", "edge")):
         assert ok(k, v) == 0, (k, v)
     c.target_bitrate = 0
     c.mv_constraint = 4

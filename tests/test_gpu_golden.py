@@ -19,7 +19,8 @@ def test_golden_streams(gpu):
         gold = json.load(f)
     for case in gold["cases"]:
         c = case["config"]
-        ge = Encoder(c["w"], c["h"], options=(("qp", c["qp"]), ("period", c["period"]), ("me-range", c["me_range"]), ("wpp", c["wpp"]), ("deblock", c["deblock"])))
+        ge = Encoder(c["w"], c["h"], options=(("qp", c["qp"]), ("period", c["period"]), ("me-range", c["me_range"]), ("wpp", c["wpp"]), ("deblock", c["deblock"]),
+                                            ("tiles", "1x%d" % c.get("tile_rows", 1)), ("sao", "full" if c.get("sao") else "off")))
         gd = Decoder()
         for t, want in enumerate(case["frames"]):
             au, rec = ge.encode(synth.frame(c["kind"], c["seed"], c["w"], c["h"], t))

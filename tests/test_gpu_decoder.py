@@ -154,15 +154,20 @@ def test_decoder_cu_qp_delta(gpu, w, h, wpp, tile_rows):
 
 
 @pytest.mark.gpu
-def test_decoder_survives_corrupted_streams(gpu):
+@pytest.mark.parametrize("extra", [dict(), dict(sao=1, tile_rows=2), dict(qp_in_cu=1, wpp=0)])
+def test_decoder_survives_corrupted_streams(gpu, extra):
     """bit flips, truncations and garbage in the slice data: every call returns (a picture or an error code), nothing hangs
     or crashes, and the decoder is usable again from the next IDR picture"""
     from kvazzup_amd.codec import Decoder, split_nals
     w, h = 320, 256
-    oe = orc.OracleEncoder(w, h, qp=28, period=3, me_range=16)
+    oe = orc.OracleEncoder(w, h, qp=28, period=3, me_range=16, **extra)
+    if extra.get("qp_in_cu"):
+        oe.set_roi(3, 2, [-6, 0, 5, 9, -3, 2])
     aus = [oe.encode(orc.synth_frame(0 if t % 2 else 2, SEED, w, h, t)) for t in range(6)]
     recs = []
-    oe2 = orc.OracleEncoder(w, h, qp=28, period=3, me_range=16)
+    oe2 = orc.OracleEncoder(w, h, qp=28, period=3, me_range=16, **extra)
+    if extra.get("qp_in_cu"):
+        oe2.set_roi(3, 2, [-6, 0, 5, 9, -3, 2])
     for t in range(6):
         oe2.encode(orc.synth_frame(0 if t % 2 else 2, SEED, w, h, t)); recs.append(oe2.recon())
     rng = np.random.default_rng(12345)

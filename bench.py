@@ -47,6 +47,10 @@ def algorithmic_bytes(kernel, cw, ch, me_range):
         return int(3.0 * P)
     if kernel == "k_tokenize":                    # every level of the picture once (int16) + the per-8x8 CU records; tokens out not counted
         return int(3.0 * P) + (P // 64) * 11
+    if kernel == "k_tok_compact":                 # the piece table of every CTU ([16 units][17 pieces] {offset, length}); tokens not counted
+        return (P // 4096) * 16 * 17 * 8
+    if kernel in ("k_sao", "k_sao<dec>"):         # deblocked picture in, filtered picture out (+ the source picture for the statistics)
+        return int(4.5 * P) if kernel == "k_sao" else int(3.0 * P)
     if kernel == "k_pad_input":
         return int(3.0 * P)
     if kernel == "k_inter_signal":

@@ -23,5 +23,6 @@ void launch_scatter_levels(const EncFrame &f, const TuDesc *tus, int ntu, const 
 void launch_qp_resolve(const EncFrame &f, hipStream_t st);  // per-CTU QP: first coded CU, QpY, delta (no-op without a QP map)
 void launch_deblock_v(const EncFrame &f, hipStream_t st);   // vertical edges of the band
 void launch_deblock_h(const EncFrame &f, hipStream_t st);   // horizontal edges of the band, its two boundary edges included
-void launch_tokenize(const EncFrame &f, hipStream_t st);   // k_tokenize + k_tok_scan + k_tok_compact
+void launch_tokenize(const EncFrame &f, hipStream_t st);    // k_tokenize: bins of every CTU into its slot, pieces in completion order
+void launch_tok_compact(const EncFrame &f, hipStream_t st); // k_tok_compact: coding order restored, dense copy to host-mapped memory
 }  // namespace kvzx

@@ -22,6 +22,23 @@
 
 namespace kvzx {
 
+// Workgroups are observed to land on the eight XCDs round-robin (workgroup b -> XCD b % 8), each XCD with its own L2.  A raster
+// of small blocks dealt out that way makes every XCD fetch every 128-byte line its neighbours also fetch (a 32-sample block
+// row is a quarter of a line).  This permutation of the linear workgroup id gives each XCD one contiguous run of the raster
+// instead.  Speed only: any placement computes the same result.
+__device__ __forceinline__ int xcd_contiguous(int lin, int total)
+{
+  const int q = total >> 3, r = total & 7, xcd = lin & 7;
+  return xcd * q + (xcd < r ? xcd : r) + (lin >> 3);
+}
+// the same for a two-dimensional grid of blocks: (bx, by) of this workgroup after the permutation
+__device__ __forceinline__ void xcd_block_2d(int &bx, int &by)
+{
+  const int gx = (int)gridDim.x, lin = xcd_contiguous((int)(blockIdx.y * gridDim.x + blockIdx.x), gx * (int)gridDim.y);
+  by = lin / gx; bx = lin - by * gx;
+}
+
+
 #define SPLIT_BITS 8
 
 // ---------------------------------------------------------------------------------------------
@@ -70,7 +87,8 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
   __shared__ __attribute__((aligned(16))) uint32_t cur[32 * 8];
   __shared__ uint32_t red[5];
   const int tid = threadIdx.x, nthreads = blockDim.x;
-  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32 + f.row0 * 64;
+  int bx_, by_; xcd_block_2d(bx_, by_);
+  const int x0 = bx_ * 32, y0 = by_ * 32 + f.row0 * 64;
   const int R = f.range, W = 2 * R + 1, WW = 32 + 2 * R;
   const uint8_t *ref = f.ref[0], *src = f.src[0];
   for (int i = tid; i < (WW + 1) * (ME_WPITCH / 4); i += nthreads) {   // four window samples per thread; columns >= WW and row WW are padding
@@ -470,7 +488,8 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
 {
   __shared__ InterLds s;
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32 + f.row0 * 64;
+  int bx_, by_; xcd_block_2d(bx_, by_);
+  const int x0 = bx_ * 32, y0 = by_ * 32 + f.row0 * 64;
   const int bi0 = b8idx(f, x0, y0);
   const bool split = f.cu_log2[bi0] == 4;
   const int cw2 = f.cw >> 1, ch2 = f.ch >> 1;
@@ -728,7 +747,8 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
 {
   __shared__ AnalyseLds s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int X0 = blockIdx.x * 32, Y0 = blockIdx.y * 32 + f.row0 * 64;
+  int bx_, by_; xcd_block_2d(bx_, by_);
+  const int X0 = bx_ * 32, Y0 = by_ * 32 + f.row0 * 64;
   const uint8_t *src = f.src[0];
   *(uint32_t *)&s.src[tid * 4] = *(const uint32_t *)&src[(size_t)(Y0 + (tid >> 3)) * f.cw + X0 + (tid & 7) * 4];
   // ---- references of the 21 blocks from the source picture (8.4.4.2.2 substitution as an index clamp: the available
@@ -1472,7 +1492,7 @@ template <bool DEC>
 __global__ __launch_bounds__(256) void k_sao(EncFrame f)
 {
   __shared__ SaoLds s;
-  const int tid = threadIdx.x, wc = f.cw >> 6, ctu = blockIdx.x, cx = ctu % wc, cy = ctu / wc;
+  const int tid = threadIdx.x, wc = f.cw >> 6, ctu = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), cx = ctu % wc, cy = ctu / wc;
   // ---- window: the CTB's samples as dwords, the border ring byte by byte (clamped at the picture edges; those samples are
   // never used: a neighbour outside the picture switches the edge offset off)
 #pragma unroll
@@ -1696,9 +1716,11 @@ void launch_sao(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_sao<fa
 void launch_dec_sao(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_sao<true>, dim3((f.cw / 64) * (f.ch / 64)), dim3(256), 0, st, f); }
 void launch_tokenize(const EncFrame &f, hipStream_t st)
 {
-  const int wc = f.cw / 64;
   hipLaunchKernelGGL(k_tokenize, dim3(f.cw / 16, band_rows(f) * 4, 3), dim3(64), 0, st, f);     // (tok_cursor is zero: k_tok_compact leaves it so)
-  hipLaunchKernelGGL(k_tok_compact, dim3(wc * band_rows(f)), dim3(256), 0, st, f);
+}
+void launch_tok_compact(const EncFrame &f, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_tok_compact, dim3((f.cw / 64) * band_rows(f)), dim3(256), 0, st, f);
 }
 
 }  // namespace kvzx

@@ -18,7 +18,7 @@
 namespace kvzx {
 
 // K_HOST_ARITH is not a kernel: wall time of the host arithmetic-coding stage (entropy_host.h)
-enum KernelId { K_PAD = 0, K_ME, K_INTER_RECON, K_INTER_SIGNAL, K_INTRA_ANALYSE, K_INTRA_RECON, K_DEBLOCK, K_TOKENIZE, K_HOST_ARITH, K_SAO, K_COUNT };
+enum KernelId { K_PAD = 0, K_ME, K_INTER_RECON, K_INTER_SIGNAL, K_INTRA_ANALYSE, K_INTRA_RECON, K_DEBLOCK, K_TOKENIZE, K_HOST_ARITH, K_SAO, K_TOK_COMPACT, K_COUNT };
 
 struct EncoderConfig {
   int width = 0, height = 0;

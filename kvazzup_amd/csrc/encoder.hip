@@ -313,6 +313,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   if (!intra) timed(K_INTER_SIGNAL, stream_tok_, [&] { launch_inter_signal(f, stream_tok_); });
   if (cfg_.sao) HIP_CHECK(hipStreamWaitEvent(stream_tok_, ev_sao_, 0));      // the tokenizer codes the CTUs' SAO parameters
   timed(K_TOKENIZE, stream_tok_, [&] { launch_tokenize(f, stream_tok_); });
+  timed(K_TOK_COMPACT, stream_tok_, [&] { launch_tok_compact(f, stream_tok_); });
   HIP_CHECK(hipEventRecord(ev_tok_done_[set_], stream_tok_)); tok_pending_[set_] = true;
   // the slot is complete when both streams are: the tokens (stream_tok_) and the reconstruction (stream_)
   HIP_CHECK(hipEventRecord(sl.done, stream_tok_));
@@ -485,7 +486,7 @@ bool Encoder::band_phase2(std::vector<std::vector<uint8_t>> *substreams, Encoded
   const EncFrame f = f_;
   Slot &sl = slot_[0];
   if (cfg_.deblock) launch_deblock_h(f, stream_);
-  launch_tokenize(f, stream_);
+  launch_tokenize(f, stream_); launch_tok_compact(f, stream_);
   HIP_CHECK(hipStreamSynchronize(stream_));
   if (*sl.h_err) { fprintf(stderr, "kvazzup_amd: device error flags 0x%x\n", *sl.h_err); return false; }
   const int wc = cw_ / 64;

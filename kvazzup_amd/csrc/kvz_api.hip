@@ -395,7 +395,7 @@ int kvzx_encoder_kernel_times(kvz_encoder *e, double *ms, uint64_t *launches, in
 }
 const char *kvzx_encoder_kernel_name(int id)
 {
-  static const char *names[kvzx::K_COUNT] = {"k_pad_input", "k_me", "k_inter_recon", "k_inter_signal", "k_intra_analyse", "k_intra_recon", "k_deblock", "k_tokenize", "host_arith_coder", "k_sao"};
+  static const char *names[kvzx::K_COUNT] = {"k_pad_input", "k_me", "k_inter_recon", "k_inter_signal", "k_intra_analyse", "k_intra_recon", "k_deblock", "k_tokenize", "host_arith_coder", "k_sao", "k_tok_compact"};
   return (id >= 0 && id < kvzx::K_COUNT) ? names[id] : nullptr;
 }
 uint64_t kvzx_encoder_last_bins(kvz_encoder *e) { return e ? e->last_bins : 0; }

@@ -91,8 +91,8 @@ class Encoder {
   bool submit(const uint8_t *d_i420, bool via_staging);
   bool collect(EncodedPicture *out);
   struct Slot;
-  bool finish_slot(Slot &sl, EncodedPicture *out);   // wait for the slot's kernels, arithmetic coding, access unit
-  void background();
+  bool finish_slot(Slot &sl, EncodedPicture *out, int worker = 0);   // wait for the slot's kernels, arithmetic coding, access unit
+  void background(int worker);
   void timed(KernelId id, hipStream_t st, const std::function<void()> &launch);
 
   EncoderConfig cfg_;
@@ -143,12 +143,14 @@ class Encoder {
     EncodedPicture result; bool ready = false, ok = true;   // owf >= 2: filled by the background thread
   };
   Slot slot_[3]; Slot *cur_slot_ = nullptr; int nslots_ = 1, depth_ = 0;
-  std::thread bg_; std::mutex bm_; std::condition_variable bcv_; std::deque<int> bq_; bool bquit_ = false;
+  std::thread bg_[2]; std::mutex bm_; std::condition_variable bcv_; std::deque<int> bq_; bool bquit_ = false;
   std::mutex stat_m_;
   long submitted_ = 0, collected_ = 0;
   hipEvent_t in_done_ = nullptr; bool in_pending_ = false;   // input picture consumed (staging buffer / caller's device buffer reusable)
-  EntropyHost *entropy_ = nullptr;
-  std::vector<std::vector<uint8_t>> rows_out_;
+  // owf >= 2: two background workers, each with its own coder pool, finish two pictures side by side (the substreams of one
+  // picture start one after the other -- WPP context hand-over -- so one picture alone cannot keep the pool busy)
+  EntropyHost *entropy_ = nullptr, *entropy2_ = nullptr;
+  std::vector<std::vector<uint8_t>> rows_out_, rows_out2_;
   int frame_idx_ = 0, poc_ = 0, intra_count_ = 0;
   bool profiling_ = false, prof_now_ = false; int prof_every_ = 1;
   double t_submit_ = 0, t_wait_ = 0, t_arith_ = 0, t_asm_ = 0, t_in_ = 0;   // encoder-thread time split (KVAZZUP_AMD_TRACE)

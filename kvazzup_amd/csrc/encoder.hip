@@ -106,7 +106,12 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   HIP_OK(hipEventCreateWithFlags(&in_done_, hipEventDisableTiming));
   HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * rows_ * 3));       // one progress counter per CTU row and colour plane
   HIP_OK(hipMalloc(&err_, sizeof(uint32_t))); HIP_OK(hipMemset(err_, 0, sizeof(uint32_t)));
-  entropy_ = new EntropyHost(cfg.entropy_threads < rows_ ? cfg.entropy_threads : rows_);
+  int eth = cfg.entropy_threads;
+  if (const char *e = getenv("KVAZZUP_AMD_ENTROPY_THREADS")) eth = atoi(e) < 1 ? 1 : atoi(e);     // tuning knob (containers with a small CPU quota)
+  if (cfg.owf >= 2 && eth >= 4) {                        // two pictures side by side, half the threads each
+    entropy_ = new EntropyHost((eth + 1) / 2 < rows_ ? (eth + 1) / 2 : rows_);
+    entropy2_ = new EntropyHost(eth / 2 < rows_ ? eth / 2 : rows_);
+  } else entropy_ = new EntropyHost(eth < rows_ ? eth : rows_);
 
   memset(&f_, 0, sizeof(f_));
   f_.cw = cw_; f_.ch = ch_; f_.b8w = cw_ / 8; f_.b8h = ch_ / 8;
@@ -126,7 +131,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   sp_.deblock = cfg.deblock; sp_.fps_num = cfg.fps_num; sp_.fps_den = cfg.fps_den;
   HIP_OK(hipStreamSynchronize(stream_));
   HIP_OK(hipDeviceSynchronize());
-  if (depth_ >= 2) bg_ = std::thread([this] { background(); });
+  if (depth_ >= 2) { bg_[0] = std::thread([this] { background(0); }); if (entropy2_) bg_[1] = std::thread([this] { background(1); }); }
   return true;
 }
 
@@ -147,7 +152,9 @@ void Encoder::bind_set(int k)
 Encoder::~Encoder()
 {
   if (getenv("KVAZZUP_AMD_TRACE")) fprintf(stderr, "kvazzup_amd encoder thread ms: submit %.1f  wait_gpu %.1f  arith %.1f  assemble %.1f  wait_input %.1f  (pictures %ld)\n", t_submit_, t_wait_, t_arith_, t_asm_, t_in_, collected_);
-  if (bg_.joinable()) { { std::lock_guard<std::mutex> l(bm_); bquit_ = true; } bcv_.notify_all(); bg_.join(); }
+  { std::lock_guard<std::mutex> l(bm_); bquit_ = true; }
+  bcv_.notify_all();
+  for (auto &t : bg_) if (t.joinable()) t.join();
   if (stream_) hipStreamSynchronize(stream_);
   if (stream_tok_) hipStreamSynchronize(stream_tok_);
   if (stream_in_) hipStreamSynchronize(stream_in_);
@@ -174,7 +181,7 @@ Encoder::~Encoder()
   if (stream_tok_) hipStreamDestroy(stream_tok_);
   if (stream_in_) hipStreamDestroy(stream_in_);
   hipFree(intra_scratch_);
-  delete entropy_;
+  delete entropy_; delete entropy2_;
   hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(tok_total_); hipFree(sync_); hipFree(err_);
   if (stream_) hipStreamDestroy(stream_);
 }
@@ -352,20 +359,20 @@ bool Encoder::collect(EncodedPicture *out)
 }
 
 // owf >= 2: pictures are finished here, in submission order, while the calling thread keeps launching kernels
-void Encoder::background()
+void Encoder::background(int worker)
 {
   hipSetDevice(cfg_.device);
   for (;;) {
     int idx;
     { std::unique_lock<std::mutex> l(bm_); bcv_.wait(l, [&] { return bquit_ || !bq_.empty(); }); if (bq_.empty()) return; idx = bq_.front(); bq_.pop_front(); }
     Slot &sl = slot_[idx];
-    const bool ok = finish_slot(sl, &sl.result);
+    const bool ok = finish_slot(sl, &sl.result, worker);
     { std::lock_guard<std::mutex> l(bm_); sl.ok = ok; sl.ready = true; }
     bcv_.notify_all();
   }
 }
 
-bool Encoder::finish_slot(Slot &sl, EncodedPicture *out)
+bool Encoder::finish_slot(Slot &sl, EncodedPicture *out, int worker)
 {
   out->valid = false; out->au.clear();
   { Tick tk; HIP_CHECK(hipEventSynchronize(sl.done)); HIP_CHECK(hipEventSynchronize(sl.rec_done)); if (depth_ < 2) t_wait_ += tk.ms(); }
@@ -383,13 +390,15 @@ bool Encoder::finish_slot(Slot &sl, EncodedPicture *out)
   uint64_t bins = 0;
   Tick tk_ar;
   for (int i = 0, n = (cw_ / 64) * rows_; i < n; i++) if (sl.h_tok_count[i] < 0) { fprintf(stderr, "kvazzup_amd: token array overflow (CTU %d)\n", i); return false; }
-  entropy_->code_picture(sl.h_tok_dense, sl.h_tok_count, sl.h_tok_off, cw_ / 64, rows_, cfg_.wpp != 0, cfg_.tile_rows, sl.intra ? 0 : 1, sl.qp, rows_out_, &bins);
+  EntropyHost *coder = worker ? entropy2_ : entropy_;
+  std::vector<std::vector<uint8_t>> &rows_out = worker ? rows_out2_ : rows_out_;
+  coder->code_picture(sl.h_tok_dense, sl.h_tok_count, sl.h_tok_off, cw_ / 64, rows_, cfg_.wpp != 0, cfg_.tile_rows, sl.intra ? 0 : 1, sl.qp, rows_out, &bins);
   const double ar = tk_ar.ms();
   if (profiling_) { std::lock_guard<std::mutex> l(stat_m_); k_ms_[K_HOST_ARITH] += ar; k_n_[K_HOST_ARITH]++; }
-  t_arith_ += ar;
+  { std::lock_guard<std::mutex> l(stat_m_); t_arith_ += ar; }
   // ---- access unit assembly (host): parameter sets with IDR pictures, then the slice NAL
   out->valid = true; out->poc = sl.poc; out->qp = sl.qp; out->is_intra = sl.intra; out->bins = bins;
-  { Tick tk; assemble_access_unit(out->au, sp_, sl.intra, sl.poc, sl.write_ps, rows_out_, nsub, sl.qp - cfg_.qp); t_asm_ += tk.ms(); }
+  { Tick tk; assemble_access_unit(out->au, sp_, sl.intra, sl.poc, sl.write_ps, rows_out, nsub, sl.qp - cfg_.qp); const double a = tk.ms(); std::lock_guard<std::mutex> l(stat_m_); t_asm_ += a; }
   return true;
 }
 

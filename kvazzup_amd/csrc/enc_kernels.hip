@@ -1200,10 +1200,11 @@ __device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d
 }
 
 #define TOK_HDR_CAP 192        // split flags + CU header + last-position bins waiting for the piece they open
-#define TOK_ARENA 3072         // tokens of one piece staged in LDS (larger pieces are written straight to the slot)
+#define TOK_ARENA 512          // tokens of one piece staged in LDS (larger pieces are written straight to the slot)
 #define TOK_PIECES 17          // pieces one unit can produce: 4 CUs x (header-only | one per coded component) + the CTU's terminating bins
 
-// One wave per 16x16 luma block ("unit") and colour component (the luma wave also codes the CU headers).
+// One wave per 16x16 luma block ("unit") and colour component (the luma wave also codes the CU headers) -- or, ALLC, one
+// wave per unit that takes the three components in turn.
 // A unit owns the CU that starts at its origin (32x32 or
 // 16x16) or the four 8x8 CUs inside it; units covered by a 32x32 CU that starts elsewhere emit
 // nothing.  The tokens leave the unit in PIECES: one per coded transform block (preceded by whatever
@@ -1213,6 +1214,7 @@ __device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d
 // emitters writes the tokens at their final offsets -- through a small LDS arena when the piece
 // fits, which keeps the kernel at ~10 KB of LDS per wave.  k_tok_compact restores coding order
 // from the (offset, length) table [ctu][unit][piece].
+template <bool ALLC>
 __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
 {
   __shared__ CuRec tile[9];
@@ -1223,27 +1225,25 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
   __shared__ int hdr_n;
   __shared__ uint32_t piece_off;
   __shared__ uint32_t seg[TOK_PIECES][2];
-  const int ux = blockIdx.x, uy = blockIdx.y + f.row0 * 4, comp = blockIdx.z, lane = threadIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
+  const int ux = blockIdx.x, uy = blockIdx.y + f.row0 * 4, comp = ALLC ? 0 : (int)blockIdx.z, lane = threadIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
   const int cx = ux >> 2, cy = uy >> 2, ctu = cy * wc + cx;
   const int X0 = ux * 16, Y0 = uy * 16;
   int z4 = 0;                                          // z-order index of the unit inside its CTU
   for (int b = 0; b < 2; b++) z4 |= (((ux & 3) >> b) & 1) << (2 * b) | (((uy & 3) >> b) & 1) << (2 * b + 1);
   if (lane == 0 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0) *f.tok_total = 0;           // dense-array cursor of this picture's k_tok_compact
   // Most waves of an inter picture have nothing to say (units inside a 32x32 CU that starts elsewhere, chroma of CUs without
-  // chroma residual): they find that out from three bytes and leave with their table entries zeroed.
+  // chroma residual): they find that out from a few bytes and leave with their table entries zeroed.
+  auto mine = [&](int piece) { return ALLC || ((piece == 16 || (piece & 3) == 3) ? 0 : (piece & 3)) == comp; };   // table entries this wave writes
   if (!(comp == 0 && z4 == 15)) {
     const int g0 = (uy * 2) * f.b8w + ux * 2, l0 = f.cu_log2[g0];
     bool work = !(l0 == 5 && ((X0 | Y0) & 31));
-    if (work && comp) {
+    if (!ALLC && work && comp) {
       bool c = false;
       if (lane < (l0 == 3 ? 4 : 1)) { const int g = g0 + (lane >> 1) * f.b8w + (lane & 1); c = !(f.cu_flags[g] & CU_SKIP) && ((f.cu_cbf[g] >> comp) & 1); }
       work = __ballot(c) != 0;
     }
     if (!work) {
-      if (lane < TOK_PIECES && ((lane == 16 || (lane & 3) == 3) ? 0 : (lane & 3)) == comp) {
-        uint32_t *e = f.tok_seg + ((size_t)(ctu * 16 + z4) * TOK_PIECES + lane) * 2;
-        e[0] = 0; e[1] = 0;
-      }
+      if (lane < TOK_PIECES && mine(lane)) { uint32_t *e = f.tok_seg + ((size_t)(ctu * 16 + z4) * TOK_PIECES + lane) * 2; e[0] = 0; e[1] = 0; }
       return;
     }
   }
@@ -1302,8 +1302,7 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
       hdr_n = t.n;
     }
     const int cbf = (cu.flags & CU_SKIP) ? 0 : cu.cbf;          // wave-uniform
-    {
-      const int ci = comp;
+    for (int ci = ALLC ? 0 : comp; ci < (ALLC ? 3 : comp + 1); ci++) {   // the CU's transform blocks: luma, Cb, Cr (ALLC) or this wave's component
       np = 4 * k + ci;
       if ((cbf >> ci) & 1) {
         const int l2 = ci ? cu.log2 - 1 : cu.log2, pw = ci ? (f.cw >> 1) : f.cw;
@@ -1359,14 +1358,15 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
         __syncthreads();
         if (lane == 0) hdr_n = 0;
       }
-    }
-    __syncthreads();
-    if (hdr_n) {                                                     // CU without luma residual: the header is its own piece
-      const int hn = hdr_n > TOK_HDR_CAP ? TOK_HDR_CAP : hdr_n;
-      const uint32_t o = reserve(hn);
-      if (o != ~0u) for (int i = lane; i < hn; i += 64) slot[o + i] = hdr[i];
       __syncthreads();
-      if (lane == 0) hdr_n = 0;
+      if (ci == 0 && hdr_n) {                                        // CU without luma residual: the header is its own piece (4k + 0)
+        const int hn = hdr_n > TOK_HDR_CAP ? TOK_HDR_CAP : hdr_n;
+        const uint32_t o = reserve(hn);
+        if (o != ~0u) for (int i = lane; i < hn; i += 64) slot[o + i] = hdr[i];
+        __syncthreads();
+        if (lane == 0) hdr_n = 0;
+        __syncthreads();
+      }
     }
   }
   if (z4 == 15 && comp == 0) {                                      // the last unit of the CTU closes it
@@ -1382,8 +1382,7 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
     }
   }
   __syncthreads();
-  // every table entry of the unit is written by exactly one of its three waves: 4k + c by component c, 4k + 3 and 16 by luma
-  if (lane < TOK_PIECES && ((lane == 16 || (lane & 3) == 3) ? 0 : (lane & 3)) == comp) {
+  if (lane < TOK_PIECES && mine(lane)) {
     uint32_t *e = f.tok_seg + ((size_t)(ctu * 16 + z4) * TOK_PIECES + lane) * 2;
     e[0] = seg[lane][0]; e[1] = seg[lane][1];
   }
@@ -1716,7 +1715,12 @@ void launch_sao(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_sao<fa
 void launch_dec_sao(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_sao<true>, dim3((f.cw / 64) * (f.ch / 64)), dim3(256), 0, st, f); }
 void launch_tokenize(const EncFrame &f, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_tokenize, dim3(f.cw / 16, band_rows(f) * 4, 3), dim3(64), 0, st, f);     // (tok_cursor is zero: k_tok_compact leaves it so)
+  // One wave per unit and colour component keeps the longest wave short: right while the grid is a few waves per SIMD and the
+  // kernel lasts as long as its slowest wave.  On large pictures the waves that only find out they have nothing to do dominate:
+  // there one wave per unit takes the three components in turn (76 vs 137 us at 2160p; 51 vs 32 us at 1080p).
+  const int units = (f.cw / 16) * band_rows(f) * 4;
+  if (units >= 16384) hipLaunchKernelGGL(k_tokenize<true>, dim3(f.cw / 16, band_rows(f) * 4), dim3(64), 0, st, f);
+  else hipLaunchKernelGGL(k_tokenize<false>, dim3(f.cw / 16, band_rows(f) * 4, 3), dim3(64), 0, st, f);     // (tok_cursor is zero: k_tok_compact leaves it so)
 }
 void launch_tok_compact(const EncFrame &f, hipStream_t st)
 {

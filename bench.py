@@ -292,6 +292,16 @@ def main():
             "filter_busy_ms_per_step": {"KvazaarFilter": busy[0], "WireAdapter": busy[1], "OpenHEVCFilter": busy[2]},
             "kernel_share_of_step": {k: round(v[0] / v[1] * launches(k) / (elapsed * 1e3), 4) for k, v in kt.items() if v[1]},
         }
+        if "k_me" in kt and kt["k_me"][1]:
+            # The motion search is integer VALU work, not streaming: its own ceiling is the issue rate of v_qsad_pk_u16_u8
+            # (four 4-sample SADs per lane; measured ~24 cycles per wave instruction on gfx950, scratch/qsad_bench2.hip):
+            # 1024 SIMDs x 2.4 GHz / 24 x 64 lanes x 16 sample differences.  Reported beside the HBM roofline the contract asks for.
+            W = 2 * args.me_range + 1
+            sads = (cw * ch // 1024) * W * W * 1024
+            me_s = kt["k_me"][0] / kt["k_me"][1] / 1e3
+            peak = 1024 * 2.4e9 / 24 * 64 * 16
+            out["roofline_valu"] = {"kernel": "k_me", "bound": "valu (v_qsad_pk_u16_u8 issue rate)", "achieved": round(sads / me_s / 1e12, 2),
+                                    "peak": round(peak / 1e12, 2), "unit": "T sample-differences/s", "frac": round(sads / me_s / peak, 4)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(w, h, args.cpu_frames, args.me_range)

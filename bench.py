@@ -60,6 +60,19 @@ def algorithmic_bytes(kernel, cw, ch, me_range):
     return P
 
 
+def _thread_cpu():
+    """{tid: (name, CPU seconds)} of this process's threads"""
+    out = {}
+    for t in os.listdir("/proc/self/task"):
+        try:
+            f = open("/proc/self/task/%s/stat" % t).read()
+            rest = f[f.rindex(")") + 2:].split()
+            out[int(t)] = (f[f.index("(") + 1:f.rindex(")")], (int(rest[11]) + int(rest[12])) / os.sysconf("SC_CLK_TCK"))
+        except Exception:
+            pass
+    return out
+
+
 def cpu_baseline(w, h, frames, me_range):
     """The CPU checker (oracle/, a scalar C port of the same algorithm) on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -230,6 +243,7 @@ def main():
     if world > 1:
         dist.barrier()
     cpu0 = time.process_time()
+    _thr0 = _thread_cpu() if os.environ.get("KVAZZUP_BENCH_THREADS") else None
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
     torch.cuda.synchronize()
@@ -237,6 +251,12 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     host_cores = (time.process_time() - cpu0) / elapsed        # CPU seconds of all threads of this rank per second of the timed region
+    if _thr0 is not None:                                       # KVAZZUP_BENCH_THREADS=1: CPU time per thread over the timed region (stderr)
+        _thr1 = _thread_cpu()
+        rows = sorted(((_thr1[t][1] - _thr0.get(t, ("", 0.0))[1], t, _thr1[t][0]) for t in _thr1), reverse=True)
+        for dt, t, name in rows[:40]:
+            if dt > 0:
+                print("thread %7d %-16s %.3f s (%.2f cores)" % (t, name, dt, dt / elapsed), file=sys.stderr)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -62,7 +62,7 @@ struct DecodedPicture {
 // worker threads that parse whole pictures concurrently (frame threading)
 class FrameWorkers {
  public:
-  explicit FrameWorkers(int n) { for (int i = 0; i < n; i++) t_.emplace_back([this] { run(); }); }
+  explicit FrameWorkers(int n) { for (int i = 0; i < n; i++) t_.emplace_back([this] { name_this_thread("kvzx-parse"); run(); }); }
   ~FrameWorkers() { { std::lock_guard<std::mutex> l(m_); quit_ = true; } cv_.notify_all(); for (auto &t : t_) t.join(); }
   void submit(std::function<void()> f) { { std::lock_guard<std::mutex> l(m_); q_.push_back(std::move(f)); } cv_.notify_one(); }
  private:

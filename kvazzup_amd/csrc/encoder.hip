@@ -131,7 +131,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   sp_.deblock = cfg.deblock; sp_.fps_num = cfg.fps_num; sp_.fps_den = cfg.fps_den;
   HIP_OK(hipStreamSynchronize(stream_));
   HIP_OK(hipDeviceSynchronize());
-  if (depth_ >= 2) { bg_[0] = std::thread([this] { background(0); }); if (entropy2_) bg_[1] = std::thread([this] { background(1); }); }
+  if (depth_ >= 2) { bg_[0] = std::thread([this] { name_this_thread("kvzx-enc-bg0"); background(0); }); if (entropy2_) bg_[1] = std::thread([this] { name_this_thread("kvzx-enc-bg1"); background(1); }); }
   return true;
 }
 

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include "filters.h"
+#include "host_pool.h"
 
 namespace uvgx {
 
@@ -24,7 +25,7 @@ void Filter::start()
   if (threadRunning_) return;
   running_ = true;
   threadRunning_ = true;
-  thread_ = std::thread([this] { run(); threadRunning_ = false; });
+  thread_ = std::thread([this] { kvzx::name_this_thread(("kvzx-" + name_).substr(0, 15).c_str()); run(); threadRunning_ = false; });
 }
 
 void Filter::stop()                                        // filter.cpp:419-423

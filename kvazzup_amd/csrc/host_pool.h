@@ -9,8 +9,12 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <pthread.h>
 
 namespace kvzx {
+
+// thread names show up in top -H / perf / /proc/<pid>/task/*/comm (15 characters)
+inline void name_this_thread(const char *name) { pthread_setname_np(pthread_self(), name); }
 
 class OrderedPool {
  public:
@@ -19,7 +23,7 @@ class OrderedPool {
     int hw = (int)std::thread::hardware_concurrency();
     if (hw > 0 && threads > hw) threads = hw;
     if (threads < 1) threads = 1;
-    for (int i = 0; i + 1 < threads; i++) workers_.emplace_back([this] { worker(); });   // the caller is the last worker
+    for (int i = 0; i + 1 < threads; i++) workers_.emplace_back([this] { name_this_thread("kvzx-pool"); worker(); });   // the caller is the last worker
   }
   ~OrderedPool()
   {

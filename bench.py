@@ -161,9 +161,10 @@ def main():
                     help="OpenHEVC 'Frame' parallelisation (uvgComm setting video/OH_parallelization): pictures parsed concurrently; 1 = off")
     ap.add_argument("--profile-every", type=int, default=8, help="kernel timing with HIP events on every n-th picture")
     ap.add_argument("--sao", action="store_true", help="kvazaar sao=full (off at the ultrafast preset the headline workload uses)")
-    ap.add_argument("--owf", type=int, default=2,
+    ap.add_argument("--owf", type=int, default=3,
                     help="uvgComm setting video/OWF (kvazaar owf): 1 = host arithmetic coding of picture t overlaps the kernels of t + 1; "
-                         "2 = it runs on a background thread and the output lags two pictures")
+                         "2 = it runs on background threads and the output lags two pictures; 3 = one more picture in flight "
+                         "(the settings UI offers 0 .. core count, videosettings.cpp:488-493)")
     args = ap.parse_args()
     if args.workload == "8k-tilesplit":
         return tilesplit_main(args)
@@ -188,7 +189,7 @@ def main():
     w, h = wl["w"], wl["h"]
     total = args.warmup + args.steps
     D = max(1, args.decoder_frame_threads)
-    extra = (D if D > 1 else 0) + min(max(args.owf, 0), 2)   # pictures pushed after the timed ones: the encoder (owf) and the frame-threaded decoder deliver with a lag
+    extra = (D if D > 1 else 0) + min(max(args.owf, 0), 3)   # pictures pushed after the timed ones: the encoder (owf) and the frame-threaded decoder deliver with a lag
     seed = 0x5EED0000 + wl["cfg_index"] + 16 * rank
     # synthetic clip generated directly in HBM (inputs resident before the timed region)
     clip = [synth.frame_torch(synth.MOVING, seed, w, h, t, dev) for t in range(total + extra)]

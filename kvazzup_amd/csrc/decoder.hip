@@ -289,7 +289,13 @@ bool Decoder::start(std::string *error)
     return false;
   }
   HIP_TRY(hipSetDevice(device_));
-  HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  {
+    const char *prio = getenv("KVAZZUP_AMD_PRIO"); int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
+    const char lv = (prio && strlen(prio) >= 4) ? prio[3] : 'n';
+    if (lv == 'h') HIP_TRY(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
+    else if (lv == 'l') HIP_TRY(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, lo));
+    else HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  }
   HIP_TRY(hipMalloc(&err_, sizeof(uint32_t)));
   HIP_TRY(hipMemset(err_, 0, sizeof(uint32_t)));
   HIP_TRY(hipHostMalloc(&h_err_, sizeof(uint32_t), hipHostMallocDefault));

@@ -103,7 +103,8 @@ class Encoder {
   uint8_t *h_in_ = nullptr;              // pinned host staging
   uint8_t *src_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // padded source planes, one set per picture parity
   // reconstruction ring: the picture being coded, its reference, and (owf >= 2) the one still waiting to be output
-  uint8_t *rec_[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  uint8_t *rec_[4][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  int nrec_ = 3;                // reconstruction ring: the picture being written, its reference, and the ones whose output is still owed (owf)
   int cur_idx_ = 0, ref_idx_ = 2, out_idx_ = 2;
   // Two sets of everything the tokenizer reads (levels and CU records): picture t is tokenised on the second stream
   // from set t & 1 while the kernels of picture t + 1 fill the other one.
@@ -142,7 +143,7 @@ class Encoder {
     std::vector<EvPair> ev; size_t ev_used = 0;
     EncodedPicture result; bool ready = false, ok = true;   // owf >= 2: filled by the background thread
   };
-  Slot slot_[3]; Slot *cur_slot_ = nullptr; int nslots_ = 1, depth_ = 0;
+  Slot slot_[4]; Slot *cur_slot_ = nullptr; int nslots_ = 1, depth_ = 0;
   std::thread bg_[2]; std::mutex bm_; std::condition_variable bcv_; std::deque<int> bq_; bool bquit_ = false;
   std::mutex stat_m_;
   long submitted_ = 0, collected_ = 0;

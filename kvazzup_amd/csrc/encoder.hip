@@ -19,8 +19,20 @@ Encoder *Encoder::create(const EncoderConfig &cfg, std::string *error)
   return e;
 }
 
+// stream with one of the device's priority levels: 'h' most urgent, 'l' least, anything else the default
+static hipError_t create_stream(hipStream_t *st, char level)
+{
+  int lo = 0, hi = 0;
+  hipDeviceGetStreamPriorityRange(&lo, &hi);            // (hi is the numerically smallest = most urgent)
+  if (level == 'h') return hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi);
+  if (level == 'l') return hipStreamCreateWithPriority(st, hipStreamNonBlocking, lo);
+  return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+
 bool Encoder::init(const EncoderConfig &cfg, std::string *error)
 {
+  const char *prio = getenv("KVAZZUP_AMD_PRIO"); if (!prio || strlen(prio) < 4) prio = "hnnn";   // main, tokenizer, input, decoder: the chain the next picture waits for is the urgent one (+6 % at 1080p; any explicit priority also gives the stream a hardware queue of its own)
+
   if (cfg.width < 16 || cfg.height < 16 || (cfg.width & 1) || (cfg.height & 1) || cfg.width > 16384 || cfg.height > 16384) {
     if (error) *error = "unsupported picture size"; return false;
   }
@@ -42,14 +54,15 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   cw_ = (cfg.width + 63) & ~63; ch_ = (cfg.height + 63) & ~63;
   if (cw_ < 128) cw_ = 128;
   rows_ = ch_ / 64;
-  HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  nrec_ = (cfg.owf >= 3 && cfg.bitrate == 0) ? 4 : 3;
+  HIP_OK(create_stream(&stream_, prio[0]));
   const size_t npx = (size_t)cw_ * ch_, nb8 = npx / 64, in_bytes = (size_t)cfg.width * cfg.height * 3 / 2;
   HIP_OK(hipMalloc(&d_in_, in_bytes));
   HIP_OK(hipHostMalloc(&h_in_, in_bytes, hipHostMallocDefault));
   for (int c = 0; c < 3; c++) {
     size_t n = c ? npx / 4 : npx;
     HIP_OK(hipMalloc(&src_[0][c], n)); HIP_OK(hipMalloc(&src_[1][c], n));
-    for (int b = 0; b < 3; b++) { HIP_OK(hipMalloc(&rec_[b][c], n)); HIP_OK(hipMemset(rec_[b][c], 0, n)); }
+    for (int b = 0; b < nrec_; b++) { HIP_OK(hipMalloc(&rec_[b][c], n)); HIP_OK(hipMemset(rec_[b][c], 0, n)); }
     for (int k = 0; k < 2; k++) { HIP_OK(hipMalloc(&coef_[k][c], n * sizeof(int16_t))); HIP_OK(hipMemset(coef_[k][c], 0, n * sizeof(int16_t))); }
   }
   for (int k = 0; k < 2; k++) {
@@ -70,8 +83,8 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
     for (int k = 0; k < 2; k++) HIP_OK(hipMalloc(&sao_[k], sizeof(SaoParams) * (size_t)(cw_ / 64) * rows_));
     HIP_OK(hipEventCreateWithFlags(&ev_sao_, hipEventDisableTiming));
   }
-  HIP_OK(hipStreamCreateWithFlags(&stream_tok_, hipStreamNonBlocking));
-  HIP_OK(hipStreamCreateWithFlags(&stream_in_, hipStreamNonBlocking));
+  HIP_OK(create_stream(&stream_tok_, prio[1]));
+  HIP_OK(create_stream(&stream_in_, prio[2]));
   HIP_OK(hipEventCreateWithFlags(&ev_padded_, hipEventDisableTiming));
   for (int k = 0; k < 2; k++) HIP_OK(hipEventCreateWithFlags(&ev_src_free_[k], hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&ev_signalled_, hipEventDisableTiming));
@@ -87,7 +100,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   HIP_OK(hipMemset(tok_count_, 0, sizeof(uint32_t) * nctu));
   tok_dense_cap_ = (size_t)nctu * tok_cap_;
   if (tok_dense_cap_ > ((size_t)1 << 27)) tok_dense_cap_ = (size_t)1 << 27;
-  depth_ = cfg.owf >= 2 ? 2 : (cfg.owf == 1 ? 1 : 0);
+  depth_ = cfg.owf >= 3 && cfg.bitrate == 0 ? 3 : (cfg.owf >= 2 ? 2 : (cfg.owf == 1 ? 1 : 0));   // (rate control books picture t - 3 before picture t: lag <= 2)
   nslots_ = depth_ + 1;
   for (int i = 0; i < nslots_; i++) {
     Slot &sl = slot_[i];
@@ -169,7 +182,7 @@ Encoder::~Encoder()
   }
   if (in_done_) hipEventDestroy(in_done_);
   hipFree(d_in_); hipHostFree(h_in_);
-  for (int c = 0; c < 3; c++) { hipFree(src_[0][c]); hipFree(src_[1][c]); for (int b = 0; b < 3; b++) hipFree(rec_[b][c]); hipFree(coef_[0][c]); hipFree(coef_[1][c]); }
+  for (int c = 0; c < 3; c++) { hipFree(src_[0][c]); hipFree(src_[1][c]); for (int b = 0; b < 4; b++) hipFree(rec_[b][c]); hipFree(coef_[0][c]); hipFree(coef_[1][c]); }
   for (int k = 0; k < 2; k++) { hipFree(ctu_qt_[k]); hipFree(ctu_qy_[k]); hipFree(ctu_delta_[k]); hipFree(ctu_first_[k]); if (h_ctu_qt_[k]) hipHostFree(h_ctu_qt_[k]); }
   for (int k = 0; k < 2; k++) { hipFree(cu_bytes_[k]); hipFree(cu_mv_[k]); hipFree(cu_mvd_[k]); if (ev_tok_done_[k]) hipEventDestroy(ev_tok_done_[k]); }
   for (int c = 0; c < 3; c++) hipFree(work_[c]);
@@ -331,7 +344,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
     intra_count_++;
   }
   frame_idx_++;
-  ref_idx_ = cur_idx_; cur_idx_ = (cur_idx_ + 1) % 3;      // rec_[ref_idx_] holds the picture just submitted
+  ref_idx_ = cur_idx_; cur_idx_ = (cur_idx_ + 1) % nrec_;      // rec_[ref_idx_] holds the picture just submitted
   submitted_++;
   if (depth_ >= 2) {
     { std::lock_guard<std::mutex> l(bm_); sl.ready = false; bq_.push_back((int)((submitted_ - 1) % nslots_)); }
@@ -506,7 +519,7 @@ bool Encoder::band_phase2(std::vector<std::vector<uint8_t>> *substreams, Encoded
   if (info) { info->valid = true; info->poc = poc_; info->qp = qp_cur_; info->is_intra = band_intra_; info->bins = bins; info->au.clear(); }
   frame_idx_++;
   if (band_intra_) intra_count_++;
-  ref_idx_ = cur_idx_; cur_idx_ = (cur_idx_ + 1) % 3; out_idx_ = ref_idx_;
+  ref_idx_ = cur_idx_; cur_idx_ = (cur_idx_ + 1) % nrec_; out_idx_ = ref_idx_;
   return true;
 }
 

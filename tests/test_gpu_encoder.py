@@ -71,10 +71,10 @@ def test_encoder_matches_oracle(gpu, cfg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("owf", [1, 2])
+@pytest.mark.parametrize("owf", [1, 2, 3])
 def test_owf_lags_output_and_flushes(gpu, owf):
-    """video/OWF = n (kvazaarfilter.cpp:193): the access unit returned by call t is picture t - n (n = 2: the
-    host coding stage runs on a background thread), NULL pictures flush the rest; the bytes and
+    """video/OWF = n (kvazaarfilter.cpp:193): the access unit returned by call t is picture t - n (n >= 2: the
+    host coding stage runs on background threads; n = 3 keeps one more picture in flight), NULL pictures flush the rest; the bytes and
     reconstructions are those of the synchronous encoder."""
     from kvazzup_amd.codec import Encoder
     w, h, frames = 320, 192, 7

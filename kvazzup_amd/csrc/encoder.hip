@@ -300,23 +300,28 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   //                level / CU arrays while stream_ already fills the other set for t + 1.
   set_ = (int)(submitted_ & 1);
   bind_set(set_);
-  if (src_busy_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_src_free_[set_], 0)); src_busy_[set_] = false; }   // reconstruction of t - 2 has read this source set
-  timed(K_PAD, stream_in_, [&] { launch_pad_input(d_i420, w, h, src_[set_][0], src_[set_][1], src_[set_][2], cw_, ch_, stream_in_); });
-  HIP_CHECK(hipEventRecord(in_done_, stream_in_)); in_pending_ = true;
-  HIP_CHECK(hipStreamWaitEvent(stream_, in_done_, 0));
-  if (tok_pending_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_, ev_tok_done_[set_], 0)); tok_pending_[set_] = false; }   // tokenizer of t - 2 done with this set
   const int period = cfg_.intra_period;
   const bool intra = (frame_idx_ == 0) || (period > 0 && (frame_idx_ % period) == 0);
   if (intra) poc_ = 0; else poc_++;
   rate_control();
   f_.qp = qp_cur_; f_.qpc = kChromaQp[qp_cur_]; f_.lambda_q4 = kLambdaQ4[qp_cur_];
-  if (!upload_qp_targets()) return false;
   f_.is_intra = intra; f_.poc = poc_;
   for (int c = 0; c < 3; c++) { f_.rec[c] = cfg_.sao ? work_[c] : rec_[cur_idx_][c]; f_.sao_out[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
   f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err;
   const EncFrame f = f_;
+  if (src_busy_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_src_free_[set_], 0)); src_busy_[set_] = false; }   // reconstruction of t - 2 has read this source set
+  timed(K_PAD, stream_in_, [&] { launch_pad_input(d_i420, w, h, src_[set_][0], src_[set_][1], src_[set_][2], cw_, ch_, stream_in_); });
   if (intra) {
-    timed(K_INTRA_ANALYSE, stream_, [&] { launch_intra_analyse(f, stream_); });
+    // The intra decisions need the source picture only: they run on the input stream, beside what is left of picture t - 1
+    // on the main stream (they write the CU arrays of this set: the tokenizer of t - 2 must be done with them).
+    if (tok_pending_[set_]) HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_tok_done_[set_], 0));
+    timed(K_INTRA_ANALYSE, stream_in_, [&] { launch_intra_analyse(f, stream_in_); });
+  }
+  HIP_CHECK(hipEventRecord(in_done_, stream_in_)); in_pending_ = true;
+  HIP_CHECK(hipStreamWaitEvent(stream_, in_done_, 0));
+  if (tok_pending_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_, ev_tok_done_[set_], 0)); tok_pending_[set_] = false; }   // tokenizer of t - 2 done with this set
+  if (!upload_qp_targets()) return false;
+  if (intra) {
     HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * rows_ * 3, stream_));
     HIP_CHECK(hipMemsetAsync(f_.cu_cbf, 0, (size_t)f_.b8w * f_.b8h, stream_));     // the three plane waves OR their bit in
     timed(K_INTRA_RECON, stream_, [&] { launch_intra_recon(f, stream_); });

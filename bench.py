@@ -60,6 +60,20 @@ def algorithmic_bytes(kernel, cw, ch, me_range):
     return P
 
 
+def cpu_budget(world):
+    """CPU cores this rank may use: the container's CFS quota (cgroup v2 cpu.max) or the visible cores, shared by the ranks of
+    the node.  One stream needs ~13 cores at full rate (8 CABAC parse workers, 16 arithmetic-coder workers, the filter and
+    synchronisation threads); with less, the pools are sized down instead of letting the kernel throttle the whole job."""
+    cores = float(len(os.sched_getaffinity(0)))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = min(cores, float(q) / float(per))
+    except Exception:
+        pass
+    return cores / max(1, world)
+
+
 def _thread_cpu():
     """{tid: (name, CPU seconds)} of this process's threads"""
     out = {}
@@ -189,6 +203,10 @@ def main():
     w, h = wl["w"], wl["h"]
     total = args.warmup + args.steps
     D = max(1, args.decoder_frame_threads)
+    budget = cpu_budget(world)
+    if budget < 13.0:                                # not enough host CPU for the full thread complement: shrink the pools
+        D = max(1, min(D, int(budget * 0.4)))
+        os.environ.setdefault("KVAZZUP_AMD_ENTROPY_THREADS", str(max(2, min(16, int(budget * 0.4)))))
     extra = (D if D > 1 else 0) + min(max(args.owf, 0), 3)   # pictures pushed after the timed ones: the encoder (owf) and the frame-threaded decoder deliver with a lag
     seed = 0x5EED0000 + wl["cfg_index"] + 16 * rank
     # synthetic clip generated directly in HBM (inputs resident before the timed region)
@@ -304,7 +322,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl["name"], "width": w, "height": h, "coded_width": cw, "coded_height": ch,
                        "frames_per_gpu": args.steps, "intra_period": 64, "qp": 32, "me_range": args.me_range,
-                       "streams": world, "bytes_per_frame": round(nbytes / args.steps, 1), "decoder_frame_threads": D, "owf": args.owf, "sao": bool(args.sao), "host_cpu_cores_busy": round(host_cores, 2),
+                       "streams": world, "bytes_per_frame": round(nbytes / args.steps, 1), "decoder_frame_threads": D, "owf": args.owf, "sao": bool(args.sao), "host_cpu_cores_busy": round(host_cores, 2), "host_cpu_budget_cores": round(budget, 1),
                        "input": "I420 resident in HBM", "output": "Annex-B AU on host + decoded I420 in HBM"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,

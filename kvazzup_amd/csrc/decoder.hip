@@ -656,7 +656,13 @@ int Decoder::complete_gpu()
 {
   PicJob &job = *gpu_job_;
   gpu_job_ = nullptr;
-  { Tick tk; if (hipStreamSynchronize(stream_) != hipSuccess) return DEC_ERR_GPU; t_sync_ += tk.ms(); }
+  {
+    Tick tk;
+    if (frame_threads_ > 1 && !getenv("KVAZZUP_AMD_SPIN")) {   // the output lags anyway: nap between queries instead of polling (see nap_until)
+      if (!nap_until([&] { hipError_t r = hipStreamQuery(stream_); return r == hipSuccess ? 1 : (r == hipErrorNotReady ? 0 : -1); })) return DEC_ERR_GPU;
+    } else if (hipStreamSynchronize(stream_) != hipSuccess) return DEC_ERR_GPU;
+    t_sync_ += tk.ms();
+  }
   if (*h_err_) { fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x\n", *h_err_); return DEC_ERR_GPU; }
   if (ev_used_) {
     for (size_t i = 0; i < ev_used_; i++) { float ms = 0; hipEventElapsedTime(&ms, ev_pool_[i].a, ev_pool_[i].b); k_ms_[ev_pool_[i].id] += ms; k_n_[ev_pool_[i].id]++; }

@@ -393,7 +393,14 @@ void Encoder::background(int worker)
 bool Encoder::finish_slot(Slot &sl, EncodedPicture *out, int worker)
 {
   out->valid = false; out->au.clear();
-  { Tick tk; HIP_CHECK(hipEventSynchronize(sl.done)); HIP_CHECK(hipEventSynchronize(sl.rec_done)); if (depth_ < 2) t_wait_ += tk.ms(); }
+  {
+    Tick tk;
+    if (depth_ >= 2 && !getenv("KVAZZUP_AMD_SPIN")) {          // background worker: naps between queries (see nap_until)
+      auto q = [&](hipEvent_t e) { return nap_until([&] { hipError_t r = hipEventQuery(e); return r == hipSuccess ? 1 : (r == hipErrorNotReady ? 0 : -1); }); };
+      if (!q(sl.done) || !q(sl.rec_done)) return false;
+    } else { HIP_CHECK(hipEventSynchronize(sl.done)); HIP_CHECK(hipEventSynchronize(sl.rec_done)); }
+    if (depth_ < 2) t_wait_ += tk.ms();
+  }
   if (*sl.h_err) { fprintf(stderr, "kvazzup_amd: device error flags 0x%x (8/16/32: token buffer overflow)\n", *sl.h_err); return false; }
   if (sl.ev_used) {
     std::lock_guard<std::mutex> l(stat_m_);

@@ -4,6 +4,7 @@
 // of entropy coding (entropy_host.h) and entropy decoding (decoder.hip).
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -15,6 +16,18 @@ namespace kvzx {
 
 // thread names show up in top -H / perf / /proc/<pid>/task/*/comm (15 characters)
 inline void name_this_thread(const char *name) { pthread_setname_np(pthread_self(), name); }
+
+// Waiting for the GPU without burning a core: hipEventSynchronize / hipStreamSynchronize poll (the blocking-sync event flag makes
+// no difference on this stack), which costs a full core per waiting thread.  Where a lag hides the wake-up -- the encoder's
+// background workers, the frame-threaded decoder -- the thread sleeps in short naps between queries instead.
+template <class Query> inline bool nap_until(Query &&done, int nap_us = 25)
+{
+  for (;;) {
+    const int r = done();                    // 1 done, 0 not yet, < 0 error
+    if (r) return r > 0;
+    std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
+  }
+}
 
 class OrderedPool {
  public:

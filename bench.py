@@ -229,10 +229,8 @@ def main():
         g = pl.pushed
         last = min(first + count + extra, total + extra)
         while g < last:
-            if pl.backlog() >= 6:
-                pl.wait(pl.stats()["decoded_pictures"] + 1, 50)     # sleep until the pipeline has moved on
-                continue
-            pl.push_device(clip[g].data_ptr())
+            if not pl.push_device_paced(clip[g].data_ptr(), 6, 120000):
+                raise RuntimeError("pipeline stalled")
             g += 1
         if not pl.wait(first + count, 120000):
             raise RuntimeError("pipeline did not deliver %d pictures" % (first + count))

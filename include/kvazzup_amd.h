@@ -98,6 +98,9 @@ KVZ_PUBLIC void *uvgx_pipeline_create(const char *settings_text, int loopback_de
 KVZ_PUBLIC int uvgx_pipeline_push_host(void *p, const uint8_t *i420, int w, int h, int fps_num, int fps_den, int64_t pts);
 KVZ_PUBLIC int uvgx_pipeline_push_device(void *p, const void *d_i420, int w, int h, int fps_num, int fps_den, int64_t pts);
 KVZ_PUBLIC int uvgx_pipeline_wait(void *p, uint64_t n_outputs, int timeout_ms);
+/* push_device for a source that paces itself: sleeps until the encoder filter buffers fewer than max_backlog pictures (uvgComm filters
+ * drop inputs at 10 buffered, filter.cpp:151-222); 0 = timed out or rejected */
+KVZ_PUBLIC int uvgx_pipeline_push_device_paced(void *p, const void *d_i420, int w, int h, int fps_num, int fps_den, int64_t pts, uint32_t max_backlog, int timeout_ms);
 KVZ_PUBLIC uint32_t uvgx_pipeline_encoder_backlog(void *p);
 KVZ_PUBLIC int uvgx_pipeline_pop_encoded(void *p, uint8_t *buf, uint32_t cap, uint32_t *size, int64_t *pts);
 KVZ_PUBLIC int uvgx_pipeline_pop_decoded(void *p, uint8_t *buf, uint32_t cap, uint32_t *size, int *w, int *h, int64_t *pts);

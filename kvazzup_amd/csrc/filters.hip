@@ -615,6 +615,19 @@ KVZ_PUBLIC int uvgx_pipeline_wait(void *pp, uint64_t n, int timeout_ms)
   return p->cv.wait_for(l, std::chrono::milliseconds(timeout_ms), [&] { return (p->loopback ? p->n_decoded : p->n_encoded) >= n; }) ? 1 : 0;
 }
 KVZ_PUBLIC uint32_t uvgx_pipeline_encoder_backlog(void *pp) { return ((UvgxPipeline *)pp)->enc->bufferedInputs(); }
+// a source that paces itself: sleeps until the encoder filter buffers fewer than `max_backlog` pictures (a uvgComm filter drops
+// inputs at 10 buffered, filter.cpp:151-222), then pushes; 0 = timed out or push failed
+KVZ_PUBLIC int uvgx_pipeline_push_device_paced(void *pp, const void *d_i420, int w, int h, int fn, int fd, int64_t pts, uint32_t max_backlog, int timeout_ms)
+{
+  UvgxPipeline *p = (UvgxPipeline *)pp;
+  if (!p || !d_i420) return 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  while (p->enc->bufferedInputs() >= max_backlog) {
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) return 0;
+    std::this_thread::sleep_for(std::chrono::microseconds(100));
+  }
+  return push(p, nullptr, d_i420, w, h, fn, fd, pts);
+}
 
 static int pop(UvgxPipeline *p, std::deque<std::unique_ptr<Data>> &q, uint8_t *buf, uint32_t cap, uint32_t *size, int *w, int *h, int64_t *pts)
 {

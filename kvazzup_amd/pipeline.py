@@ -14,6 +14,7 @@ def _bind(lib):
     lib.uvgx_pipeline_push_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64]
     lib.uvgx_pipeline_push_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64]
     lib.uvgx_pipeline_wait.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
+    lib.uvgx_pipeline_push_device_paced.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint32, C.c_int]
     lib.uvgx_pipeline_encoder_backlog.restype = C.c_uint32
     lib.uvgx_pipeline_encoder_backlog.argtypes = [C.c_void_p]
     lib.uvgx_pipeline_pop_encoded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]
@@ -66,6 +67,12 @@ class Pipeline:
     def push_device(self, dptr, pts=None):
         self.lib.uvgx_pipeline_push_device(self.p, dptr, self.w, self.h, self.fps[0], self.fps[1], self.pushed if pts is None else pts)
         self.pushed += 1
+
+    def push_device_paced(self, dptr, max_backlog=6, timeout_ms=60000, pts=None):
+        """push_device that sleeps (in C) until the encoder filter buffers fewer than max_backlog pictures"""
+        ok = self.lib.uvgx_pipeline_push_device_paced(self.p, dptr, self.w, self.h, self.fps[0], self.fps[1], self.pushed if pts is None else pts, max_backlog, timeout_ms)
+        self.pushed += 1 if ok else 0
+        return bool(ok)
 
     def wait(self, n, timeout_ms=60000):
         return bool(self.lib.uvgx_pipeline_wait(self.p, n, timeout_ms))

@@ -189,3 +189,55 @@ def test_sao_matches_oracle(gpu, cfg):
     """kvazaar "sao" (off at the ultrafast preset, on for the slower ones): statistics, "uvgx SAO decision v1", the filter
     (H.265 8.7.3) and sao() of every CTU, bit-exact against the checker -- access units and filtered reconstruction"""
     run_clip(**cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("KVZ_SWEEP_SEEDS", "16")))))
+def test_random_tool_combinations_match_oracle(gpu, seed):
+    """a seeded sweep over tool combinations (size, QP, period, range, WPP, tile rows, SAO, deblocking, delta-QP map, output
+    lag): encoder and decoder against the checker, every picture -- catches interactions the single-feature tests cannot"""
+    import ctypes as C
+    from kvazzup_amd.codec import Decoder, Encoder
+    rng = np.random.default_rng(1000 + seed)
+    w, h = int(rng.integers(8, 60)) * 8, int(rng.integers(8, 48)) * 8
+    hc = (h + 63) // 64
+    cfg = dict(qp=int(rng.integers(8, 46)), period=int(rng.choice([1, 2, 3, 5, 64])), me_range=int(rng.choice([1, 4, 8, 16, 32])),
+               wpp=int(rng.integers(0, 2)), deblock=int(rng.integers(0, 2)), tile_rows=int(rng.integers(1, min(hc, 3) + 1)),
+               sao=int(rng.integers(0, 2)), qp_in_cu=int(rng.integers(0, 2)), bitrate=int(rng.choice([0, 0, 0, 150000, 2000000])))
+    owf = int(rng.choice([0, 1, 2, 3]))
+    kind = int(rng.choice([0, 2]))
+    frames = 9 if cfg["bitrate"] else 5              # (the rate controller starts moving the QP at the fourth picture)
+    oe = orc.OracleEncoder(w, h, **cfg)
+    od = orc.OracleDecoder()
+    ge = Encoder(w, h, options=(("qp", cfg["qp"]), ("period", cfg["period"]), ("me-range", cfg["me_range"]), ("wpp", cfg["wpp"]),
+                                ("deblock", cfg["deblock"]), ("tiles", "1x%d" % cfg["tile_rows"]), ("sao", "full" if cfg["sao"] else "off"),
+                                ("set-qp-in-cu", cfg["qp_in_cu"]), ("owf", owf)), fields={"target_bitrate": cfg["bitrate"]})
+    assert not ge.rejected, (cfg, ge.rejected)
+    gd = Decoder()
+    roi = None
+    if cfg["qp_in_cu"]:
+        rw, rh = int(rng.integers(1, 6)), int(rng.integers(1, 5))
+        roi = (rw, rh, np.ascontiguousarray(rng.integers(-14, 15, rw * rh), dtype=np.int8))
+        oe.set_roi(*roi)
+    want, got = [], []
+    for t in range(frames + owf):
+        if t < frames:
+            fr = orc.synth_frame(kind, 77 + seed, w, h, t)
+            want.append((oe.encode(fr), oe.recon()))
+            p = ge.pic.contents
+            if roi:
+                p.roi.width, p.roi.height = roi[0], roi[1]
+                p.roi.roi_array = roi[2].ctypes.data_as(C.POINTER(C.c_int8))
+            out = ge.encode(fr)
+        else:
+            out = ge.encode(None)
+        if out[0] is not None:
+            got.append(out)
+    assert len(got) == frames, (cfg, owf, len(got))
+    for t in range(frames):
+        assert got[t][0] == want[t][0], (cfg, owf, t, len(got[t][0]), len(want[t][0]))
+        assert np.array_equal(got[t][1], want[t][1]), (cfg, owf, t)
+        dec = gd.decode_au(got[t][0], t)
+        ref = od.decode_au(want[t][0], t)
+        assert len(dec) == 1 and len(ref) == 1 and np.array_equal(dec[0]["i420"], ref[0]["i420"]) and np.array_equal(dec[0]["i420"], want[t][1]), (cfg, t)
+    ge.close(); gd.close(); oe.close(); od.close()

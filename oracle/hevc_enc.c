@@ -388,6 +388,20 @@ static void me_block32(orc_encoder *e, int x0, int y0)
       e->cu_mv[b8i(e, x, y) * 2] = (int16_t)(((ci % W) - R) * 4); e->cu_mv[b8i(e, x, y) * 2 + 1] = (int16_t)(((ci / W) - R) * 4);
     }
   }
+  if (e->cfg.test_mv_jitter && e->cfg.tile_rows == 1) {          /* test hook: fractional vectors for the decoder tests */
+    for (int y = y0; y < y0 + 32; y += 8) for (int x = x0; x < x0 + 32; x += 8) {
+      int n = 1 << e->cu_log2[b8i(e, x, y)], ox = x & ~(n - 1), oy = y & ~(n - 1);
+      uint32_t hsh = (uint32_t)(ox * 73856093) ^ (uint32_t)(oy * 19349663) ^ (uint32_t)(e->frame_idx * 83492791);
+      hsh ^= hsh >> 13; hsh *= 0x5bd1e995u; hsh ^= hsh >> 15;
+      if (x == ox && y == oy) {                                    /* once per CU: every 8x8 cell of the CU gets the same vector */
+        int jx = (int)(hsh % 7) - 3, jy = (int)((hsh >> 8) % 7) - 3;
+        for (int yy = oy; yy < oy + n; yy += 8) for (int xx = ox; xx < ox + n; xx += 8) {
+          e->cu_mv[b8i(e, xx, yy) * 2] = (int16_t)(e->cu_mv[b8i(e, xx, yy) * 2] + jx);
+          e->cu_mv[b8i(e, xx, yy) * 2 + 1] = (int16_t)(e->cu_mv[b8i(e, xx, yy) * 2 + 1] + jy);
+        }
+      }
+    }
+  }
 }
 
 static void inter_recon_cu(orc_encoder *e, int x0, int y0, int log2)

@@ -36,6 +36,9 @@ typedef struct {
   int qp_in_cu;               /* 1: cu_qp_delta_enabled_flag, quantisation group = CTU: a delta-QP map set with orc_enc_set_roi()
                                * gives every CTU its own QP (kvz_picture.roi, kvazaarfilter.cpp:423-431) */
   int bitrate;                /* bits per second; 0 = constant QP.  > 0: "uvgx rate control v1" (see hevc_enc.c) */
+  int test_mv_jitter;         /* TEST HOOK (decoder tests): after the integer search every block's vector gets a pseudo-random
+                               * offset of -3..3 quarter samples per component, so that the stream exercises fractional-sample
+                               * interpolation (8.5.3.3.3) -- the encoder algorithm proper never produces fractional vectors */
   int sao;                    /* 1: sample adaptive offset on, parameters by "uvgx SAO decision v1" (hevc_sao.c) */
 } orc_enc_config;
 

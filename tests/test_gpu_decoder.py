@@ -8,9 +8,9 @@ import orc
 SEED = 0x5EED0000
 
 
-def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, tile_rows=1, threads=1, sao=0):
+def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, tile_rows=1, threads=1, sao=0, mv_jitter=0):
     from kvazzup_amd.codec import Decoder
-    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows, sao=sao)
+    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows, sao=sao, mv_jitter=mv_jitter)
     od = orc.OracleDecoder()
     gd = Decoder()
     try:
@@ -247,3 +247,17 @@ def test_sao_stream_through_frame_threads_and_filters(gpu):
     for t in range(frames):
         assert np.array_equal(dec[t]["i420"], outs[t][1]), t
     gd.close(); ge.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(w=320, h=256, frames=6, qp=30, period=8, me_range=8, kind=0, mv_jitter=1),
+    dict(w=416, h=240, frames=6, qp=24, period=64, me_range=16, kind=2, mv_jitter=1, wpp=0),          # noise: every block coded on top of the interpolation
+    dict(w=130, h=70, frames=5, qp=35, period=64, me_range=32, kind=0, mv_jitter=1),                  # long vectors + fractions across the picture edges
+    dict(w=640, h=360, frames=4, qp=32, period=64, me_range=16, kind=0, mv_jitter=1, sao=1, deblock=0),
+    dict(w=1920, h=1080, frames=3, qp=32, period=64, me_range=16, kind=0, mv_jitter=1),
+])
+def test_decoder_fractional_motion_vectors(gpu, cfg):
+    """streams whose vectors have quarter-sample fractions (the checker's encoder with its test hook: the product's encoder
+    searches integer positions only): 8-tap luma / 4-tap chroma interpolation (8.5.3.3.3), all 16 x 64 fraction pairs occur"""
+    run_clip(**cfg)

@@ -137,3 +137,18 @@ def test_sao_closed_loop(w, h, qp, kind, wpp, tile_rows):
         oe.close(); od.close()
         return sse
     assert run(1) < run(0)
+
+
+@pytest.mark.parametrize("w,h,kind,wpp", [(320, 256, 0, 1), (256, 192, 2, 0)])
+def test_fractional_vectors_closed_loop(w, h, kind, wpp):
+    """the encoder's test hook for the decoder tests (cfg.test_mv_jitter): vectors with quarter-sample fractions, decoded by the
+    checker's general decoder to the encoder's own reconstruction"""
+    oe = orc.OracleEncoder(w, h, qp=30, period=8, me_range=8, wpp=wpp, mv_jitter=1)
+    od = orc.OracleDecoder()
+    fractional = 0
+    for t in range(5):
+        got = od.decode_au(oe.encode(orc.synth_frame(kind, 3, w, h, t)), t)
+        assert len(got) == 1 and np.array_equal(got[0]["i420"], oe.recon()), t
+        fractional += int(np.count_nonzero(oe.debug()["cu_mv"] & 3))
+    assert fractional > 100
+    oe.close(); od.close()

@@ -340,6 +340,10 @@ struct InterLds {
   int mv[4][2];
   alignas(16) int8_t M8[2][32 * 32];       // the 32-point matrix and its transpose as int8: MFMA B operands
   int rowsum[2][32];                       // sum over m of M8[.][j][m]
+  // fractional-sample luma interpolation (decoder: streams of other encoders), per 16x16 quadrant: the 23 x 23 reference
+  // window and the horizontally filtered rows (8.5.3.3.3.1)
+  alignas(16) uint8_t lwin[4][23 * 24];
+  alignas(16) int ltmp[4][23 * 16];        // (32-bit on purpose: with int16 entries hipcc 7.2 mis-extends the upper halves of the packed loads)
 };
 
 // The four transform stages of `NTU` blocks of n = 1 << L2 held TU-major in s.A (encoder: residual, row-major;
@@ -507,11 +511,43 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
     s.mv[tid][0] = f.cu_mv[bi * 2]; s.mv[tid][1] = f.cu_mv[bi * 2 + 1];
   }
   __syncthreads();
+  // ---- luma with fractional vectors (never the encoder's own streams): window -> LDS, horizontal pass -> LDS
+  const bool anyfrac = DEC && (((s.mv[0][0] | s.mv[0][1] | s.mv[1][0] | s.mv[1][1] | s.mv[2][0] | s.mv[2][1] | s.mv[3][0] | s.mv[3][1]) & 3) != 0);
+  if (anyfrac) {
+    for (int i = tid; i < 4 * 23 * 23; i += 256) {
+      const int k = i / 529, r = i - k * 529, wy = r / 23, wx = r - wy * 23;
+      const int gx = x0 + (k & 1) * 16 + (s.mv[k][0] >> 2) - 3 + wx, gy = y0 + (k >> 1) * 16 + (s.mv[k][1] >> 2) - 3 + wy;
+      s.lwin[k][wy * 24 + wx] = f.ref[0][(size_t)clip3(0, f.ch - 1, gy) * f.cw + clip3(0, f.cw - 1, gx)];
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * 23 * 16; i += 256) {
+      const int k = i / 368, r = i - k * 368, wy = r >> 4, c = r & 15, xf = s.mv[k][0] & 3;
+      const uint8_t *wp = &s.lwin[k][wy * 24 + c];
+      int v = wp[3];
+      if (xf) { v = 0; for (int t = 0; t < 8; t++) v += kLumaFilter[xf][t] * wp[t]; }
+      s.ltmp[k][wy * 16 + c] = v;
+    }
+    __syncthreads();
+  }
   // ---- luma: prediction (four samples per thread), residual / dequantised levels TU-major into s.A
   {
     const int y = tid >> 3, x = (tid & 7) * 4, k = (y >> 4) * 2 + (x >> 4);
     const int l2 = split ? 4 : 5, n = 1 << l2, tu = split ? k : 0;
-    const uint32_t p4 = mc_luma4(f.ref[0], f.cw, f.ch, x0 + x, y0 + y, s.mv[k][0], s.mv[k][1]);
+    uint32_t p4 = 0;
+    if (anyfrac) {                             // (block-uniform) separable 8-tap interpolation through LDS; decoder only: p4 is not used again
+      const int mvx = s.mv[k][0], mvy = s.mv[k][1], xf = mvx & 3, yf = mvy & 3;
+      const int *tp = &s.ltmp[k][(y & 15) * 16 + (x & 15)];
+#pragma unroll 1
+      for (int i = 0; i < 4; i++) {            // (kept rolled: the unrolled form came out wrong for the third and fourth sample with hipcc 7.2)
+        int v;
+        if (yf) {
+          int a = 0;
+          for (int j = 0; j < 8; j++) a += (int)kLumaFilter[yf][j] * tp[j * 16 + i];
+          v = xf ? (a >> 6) : a;
+        } else v = xf ? tp[3 * 16 + i] : tp[3 * 16 + i] * 64;
+        p4 |= (uint32_t)clip8((v + 32) >> 6) << (8 * i);
+      }
+    } else p4 = mc_luma4(f.ref[0], f.cw, f.ch, x0 + x, y0 + y, s.mv[k][0], s.mv[k][1]);
     *(uint32_t *)&s.px[y * 32 + x] = p4;
     const size_t g = (size_t)(y0 + y) * f.cw + x0 + x;
     int16_t *A = s.A + (tu << (2 * l2));

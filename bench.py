@@ -207,6 +207,7 @@ def main():
     if budget < 13.0:                                # not enough host CPU for the full thread complement: shrink the pools
         D = max(1, min(D, int(budget * 0.4)))
         os.environ.setdefault("KVAZZUP_AMD_ENTROPY_THREADS", str(max(2, min(16, int(budget * 0.4)))))
+        os.environ.setdefault("KVAZZUP_AMD_PARSE_THREADS", str(max(1, min(16, int(budget * 0.4)))))       # (row-parallel parser of the synchronous decoder)
     extra = (D if D > 1 else 0) + min(max(args.owf, 0), 3)   # pictures pushed after the timed ones: the encoder (owf) and the frame-threaded decoder deliver with a lag
     seed = 0x5EED0000 + wl["cfg_index"] + 16 * rank
     # synthetic clip generated directly in HBM (inputs resident before the timed region)

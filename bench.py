@@ -203,9 +203,9 @@ def main():
     w, h = wl["w"], wl["h"]
     total = args.warmup + args.steps
     D = max(1, args.decoder_frame_threads)
-    budget = cpu_budget(world)
+    budget = float(os.environ.get("KVAZZUP_BENCH_CPU_BUDGET", 0)) or cpu_budget(world)
     if budget < 13.0:                                # not enough host CPU for the full thread complement: shrink the pools
-        D = max(1, min(D, int(budget * 0.4)))
+        D = max(1, min(D, int(budget * 0.45 + 0.5)))
         os.environ.setdefault("KVAZZUP_AMD_ENTROPY_THREADS", str(max(2, min(16, int(budget * 0.4)))))
         os.environ.setdefault("KVAZZUP_AMD_PARSE_THREADS", str(max(1, min(16, int(budget * 0.4)))))       # (row-parallel parser of the synchronous decoder)
     extra = (D if D > 1 else 0) + min(max(args.owf, 0), 3)   # pictures pushed after the timed ones: the encoder (owf) and the frame-threaded decoder deliver with a lag

@@ -202,21 +202,15 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, std::vector<u
     uint32_t sig = 0;
     if (i == last_sb) sig |= 1u << last_pos;
     const int prev_csbf = right | (below << 1);
+    // sig_coeff_flag contexts (9.3.4.2.5) from tables: pattern by the neighbouring sub-blocks' flags and the position inside
+    // the sub-block, plus an offset that is constant over the sub-block
+    const uint8_t *pat = log2 == 2 ? t->ctxmap4x4 : t->sigpat[prev_csbf], *rp = t->pos4[scan_idx];
+    const int sig_base = CTX_SIG + (cidx ? 27 : 0);
+    const int sig_off = log2 == 2 ? 0 : (cidx == 0 ? ((i > 0 ? 3 : 0) + ((log2 == 3) ? ((scan_idx == 0) ? 9 : 15) : 21)) : ((log2 == 3) ? 9 : 12));
     for (int k = (i == last_sb) ? last_pos - 1 : 15; k >= 0; k--) {
       if (k > 0 || !infer_dc) {
-        const int xp = PX[k], yp = PY[k];
-        int xc = (xs << 2) + xp, yc = (ys << 2) + yp, sc;
-        if (log2 == 2) sc = t->ctxmap4x4[(yc << 2) + xc];
-        else if (xc + yc == 0) sc = 0;
-        else {
-          if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
-          else if (prev_csbf == 1) sc = (yp == 0) ? 2 : (yp == 1) ? 1 : 0;
-          else if (prev_csbf == 2) sc = (xp == 0) ? 2 : (xp == 1) ? 1 : 0;
-          else sc = 2;
-          if (cidx == 0) { if (i > 0) sc += 3; sc += (log2 == 3) ? ((scan_idx == 0) ? 9 : 15) : 21; }
-          else sc += (log2 == 3) ? 9 : 12;
-        }
-        if (c.bin(CTX_SIG + (cidx ? 27 : 0) + sc)) { sig |= 1u << k; infer_dc = 0; }
+        const int sc = (k == 0 && i == 0 && log2 != 2) ? 0 : pat[rp[k]] + sig_off;      // (the DC coefficient of the block has its own context)
+        if (c.bin(sig_base + sc)) { sig |= 1u << k; infer_dc = 0; }
       } else sig |= 1u;            // k == 0 with every other flag of a coded sub-block zero: inferred
     }
     if (!sig) continue;

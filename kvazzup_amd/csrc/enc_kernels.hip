@@ -155,11 +155,13 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
       const int dyi = dy0 + e;
       if (dyi >= W) continue;
       { const int dy = dyi - R, m = (dy & 1) ? 4 : 0; if ((ty0 > 0 && y0 + dy - m < ty0) || (ty1 < f.ch && y0 + dy + 32 + m > ty1)) continue; }
+      if (f.mv_frame) { const int dy = dyi - R, my = (f.mv_frame == 2 && (dy & 1)) ? 4 : 0; if (y0 + dy - my < 0 || y0 + dy + 32 + my > f.ch) continue; }
       const int ry = mvd_bits((dyi - R) * 4);
 #pragma unroll
       for (int k4 = 0; k4 < 4; k4++) {
         const int dxi = 4 * q + k4;
         if (dxi >= W) continue;
+        if (f.mv_frame) { const int dx = dxi - R, mx = (f.mv_frame == 2 && (dx & 1)) ? 4 : 0; if (x0 + dx - mx < 0 || x0 + dx + 32 + mx > f.cw) continue; }
         const uint32_t cand = (uint32_t)(dyi * W + dxi);
         const uint32_t rate = (lam * (uint32_t)(mvd_bits((dxi - R) * 4) + ry)) >> 4;
         uint32_t sq[4];

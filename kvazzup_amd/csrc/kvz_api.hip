@@ -243,6 +243,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.band_row0 = cfg->band_row0; ec.band_rows = cfg->band_rows;
   ec.qp_in_cu = cfg->set_qp_in_cu ? 1 : 0;
   ec.sao = cfg->sao_type == KVZ_SAO_FULL;
+  ec.mv_frame = cfg->mv_constraint == KVZ_MV_CONSTRAIN_FRAME || cfg->mv_constraint == KVZ_MV_CONSTRAIN_FRAME_AND_TILE ? 1 : (cfg->mv_constraint == KVZ_MV_CONSTRAIN_FRAME_AND_TILE_MARGIN ? 2 : 0);   // (tile rows always confine vectors to the tile)
   ec.bitrate = cfg->target_bitrate > 0 ? cfg->target_bitrate : 0;      // any rc-algorithm value selects the one picture-level controller
   std::string err;
   Encoder *impl = Encoder::create(ec, &err);

@@ -357,6 +357,10 @@ static void me_block32(orc_encoder *e, int x0, int y0)
     for (int dx = -R; dx <= R; dx++, idx++) {
       int m = (dy & 1) ? 4 : 0;
       if ((ty0 > 0 && y0 + dy - m < ty0) || (ty1 < e->ch && y0 + dy + 32 + m > ty1)) continue;
+      if (e->cfg.mv_frame) {                                   /* mv-constraint frame: the displaced block stays inside the picture */
+        int my = (e->cfg.mv_frame == 2 && (dy & 1)) ? 4 : 0, mx = (e->cfg.mv_frame == 2 && (dx & 1)) ? 4 : 0;
+        if (x0 + dx - mx < 0 || x0 + dx + 32 + mx > e->cw || y0 + dy - my < 0 || y0 + dy + 32 + my > e->ch) continue;
+      }
       uint32_t rate = (lam * (uint32_t)(orc_mvd_bits(dx * 4) + orc_mvd_bits(dy * 4))) >> 4;
       uint32_t s32 = 0;
       for (int k = 0; k < 4; k++) {

@@ -29,11 +29,11 @@ def _diagnose(dbg_o, dbg_g):
     return "; ".join(msgs) if msgs else "no stage-level difference found (entropy coding / assembly?)"
 
 
-def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_picture=True, tile_rows=1, sao=0):
+def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_picture=True, tile_rows=1, sao=0, mv_frame=0):
     from kvazzup_amd.codec import Encoder
-    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows, sao=sao)
+    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows, sao=sao, mv_frame=mv_frame)
     ge = Encoder(w, h, options=(("qp", qp), ("period", period), ("me-range", me_range), ("wpp", wpp), ("deblock", deblock), ("tiles", "1x%d" % tile_rows),
-                                ("sao", "full" if sao else "off")))
+                                ("sao", "full" if sao else "off"), ("mv-constraint", ("none", "frame", "frametilemargin")[mv_frame])))
     assert not ge.rejected, ge.rejected
     try:
         for t in range(frames):
@@ -203,7 +203,7 @@ def test_random_tool_combinations_match_oracle(gpu, seed):
     hc = (h + 63) // 64
     cfg = dict(qp=int(rng.integers(8, 46)), period=int(rng.choice([1, 2, 3, 5, 64])), me_range=int(rng.choice([1, 4, 8, 16, 32])),
                wpp=int(rng.integers(0, 2)), deblock=int(rng.integers(0, 2)), tile_rows=int(rng.integers(1, min(hc, 3) + 1)),
-               sao=int(rng.integers(0, 2)), qp_in_cu=int(rng.integers(0, 2)), bitrate=int(rng.choice([0, 0, 0, 150000, 2000000])))
+               sao=int(rng.integers(0, 2)), qp_in_cu=int(rng.integers(0, 2)), bitrate=int(rng.choice([0, 0, 0, 150000, 2000000])), mv_frame=int(rng.choice([0, 0, 1, 2])))
     owf = int(rng.choice([0, 1, 2, 3]))
     kind = int(rng.choice([0, 2]))
     frames = 9 if cfg["bitrate"] else 5              # (the rate controller starts moving the QP at the fourth picture)
@@ -211,7 +211,8 @@ def test_random_tool_combinations_match_oracle(gpu, seed):
     od = orc.OracleDecoder()
     ge = Encoder(w, h, options=(("qp", cfg["qp"]), ("period", cfg["period"]), ("me-range", cfg["me_range"]), ("wpp", cfg["wpp"]),
                                 ("deblock", cfg["deblock"]), ("tiles", "1x%d" % cfg["tile_rows"]), ("sao", "full" if cfg["sao"] else "off"),
-                                ("set-qp-in-cu", cfg["qp_in_cu"]), ("owf", owf)), fields={"target_bitrate": cfg["bitrate"]})
+                                ("set-qp-in-cu", cfg["qp_in_cu"]), ("owf", owf),
+                                ("mv-constraint", ("none", "frame", "frametilemargin")[cfg["mv_frame"]])), fields={"target_bitrate": cfg["bitrate"]})
     assert not ge.rejected, (cfg, ge.rejected)
     gd = Decoder()
     roi = None
@@ -241,3 +242,25 @@ def test_random_tool_combinations_match_oracle(gpu, seed):
         ref = od.decode_au(want[t][0], t)
         assert len(dec) == 1 and len(ref) == 1 and np.array_equal(dec[0]["i420"], ref[0]["i420"]) and np.array_equal(dec[0]["i420"], want[t][1]), (cfg, t)
     ge.close(); gd.close(); oe.close(); od.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2])
+def test_mv_constraint_frame_matches_oracle_and_keeps_blocks_inside(gpu, mode):
+    """uvgComm's mv-constraint setting (kvazaarfilter.cpp:246-276) frame / frametile (1) and frametilemargin (2): candidates
+    whose displaced block leaves the picture are not searched; long vectors at the picture edges are what it removes"""
+    from kvazzup_amd.codec import Encoder
+    w, h = 320, 192
+    run_clip(w=w, h=h, frames=5, qp=30, period=64, me_range=32, kind=2, mv_frame=mode)
+    run_clip(w=448, h=320, frames=4, qp=30, period=64, me_range=16, kind=0, mv_frame=mode, tile_rows=2)
+    ge = Encoder(w, h, options=(("qp", 30), ("period", 64), ("me-range", 32), ("mv-constraint", ("frame", "frametilemargin")[mode - 1])))
+    for t in range(3):
+        ge.encode(orc.synth_frame(2, SEED, w, h, t))
+    d = ge.debug_all()
+    cw, ch = d["coded_w"], d["coded_h"]
+    mv, l2 = d["cu_mv"].astype(int) // 4, d["cu_log2"]
+    for by in range(ch // 8):
+        for bx in range(cw // 8):
+            n = 1 << int(l2[by, bx]); x0, y0 = (bx * 8) & ~31, (by * 8) & ~31       # the constraint is applied to the 32x32 search block
+            assert 0 <= x0 + mv[by, bx, 0] and x0 + mv[by, bx, 0] + 32 <= cw and 0 <= y0 + mv[by, bx, 1] and y0 + mv[by, bx, 1] + 32 <= ch
+    ge.close()

@@ -152,3 +152,30 @@ def test_fractional_vectors_closed_loop(w, h, kind, wpp):
         fractional += int(np.count_nonzero(oe.debug()["cu_mv"] & 3))
     assert fractional > 100
     oe.close(); od.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_mv_constraint_frame_closed_loop(mode):
+    """mv-constraint frame (1) / with margin (2): no vector moves its 32x32 search block out of the picture; the stream decodes
+    to the encoder's reconstruction; the unconstrained encoder does use such vectors on this clip"""
+    w, h = 320, 192
+    def run(mf):
+        oe = orc.OracleEncoder(w, h, qp=30, period=64, me_range=32, mv_frame=mf)
+        od = orc.OracleDecoder()
+        outside = 0
+        for t in range(4):
+            got = od.decode_au(oe.encode(orc.synth_frame(2, 11, w, h, t)), t)
+            assert len(got) == 1 and np.array_equal(got[0]["i420"], oe.recon()), t
+            d = oe.debug()
+            if not d["is_intra"]:
+                mv = d["cu_mv"].astype(int) // 4
+                ys, xs = np.mgrid[0:d["coded_h"] // 8, 0:d["coded_w"] // 8]
+                x0, y0 = (xs * 8) & ~31, (ys * 8) & ~31
+                m = 4 if mf == 2 else 0
+                mx = np.where(mv[..., 0] & 1, m, 0); my = np.where(mv[..., 1] & 1, m, 0)
+                bad = (x0 + mv[..., 0] - mx < 0) | (x0 + mv[..., 0] + 32 + mx > d["coded_w"]) | (y0 + mv[..., 1] - my < 0) | (y0 + mv[..., 1] + 32 + my > d["coded_h"])
+                outside += int(np.count_nonzero(bad))
+        oe.close(); od.close()
+        return outside
+    assert run(mode) == 0
+    assert run(0) > 0

@@ -10,6 +10,7 @@ void launch_inter_signal(const EncFrame &f, hipStream_t st);
 void launch_intra_analyse(const EncFrame &f, hipStream_t st);
 void launch_intra_recon(const EncFrame &f, hipStream_t st);
 void launch_deblock(const EncFrame &f, hipStream_t st);
+void launch_vaq(const EncFrame &f, int vaq, int *act, int *sum, hipStream_t st);   // VAQ: f.ctu_qt holds ROI deltas on entry, target QPs on exit
 void launch_sao(const EncFrame &f, hipStream_t st);        // SAO decision + filter: f.rec (deblocked) -> f.sao_out, parameters -> f.sao
 void launch_dec_sao(const EncFrame &f, hipStream_t st);    // SAO filter with the parsed parameters in f.sao
 // decoder variants: levels + cbf given (coef planes / cu_cbf), prediction + residual only

@@ -1700,6 +1700,47 @@ __global__ __launch_bounds__(256) void k_sao(EncFrame f)
 }
 
 // =============================================================================================
+// Variance adaptive quantisation, "uvgx VAQ v1" (statement of record: vaq_deltas() in oracle/hevc_enc.c).
+// k_vaq_stats: one workgroup per CTU -- sum and sum of squares of its 64x64 source luma samples, activity e = log2 of the
+// variance in 1/16 steps, e to act[ctu] and into the picture's sum.  k_vaq_apply: the picture mean, the CTU's delta, and the
+// target QP = clip(qp + clip(roi delta + vaq delta)) written over the ROI delta the host put into ctu_qt.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_vaq_stats(EncFrame f, int *act, int *sum)
+{
+  __shared__ uint32_t p1[4], p2[4];
+  const int tid = threadIdx.x, wc = f.cw >> 6, cx = blockIdx.x % wc, cy = blockIdx.x / wc;
+  const uint8_t *src = f.src[0] + (size_t)(cy * 64) * f.cw + cx * 64;
+  uint32_t s1 = 0, s2 = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {                                     // 1024 dwords of the CTU, four per thread
+    const int i = tid + 256 * k, y = i >> 4, x = (i & 15) * 4;
+    const uint32_t v = *(const uint32_t *)&src[(size_t)y * f.cw + x];
+#pragma unroll
+    for (int b = 0; b < 4; b++) { const uint32_t px = (v >> (8 * b)) & 255u; s1 += px; s2 += px * px; }
+  }
+  s1 = wave_sum_u32(s1); s2 = wave_sum_u32(s2);
+  if ((tid & 63) == 0) { p1[tid >> 6] = s1; p2[tid >> 6] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t a = p1[0] + p1[1] + p1[2] + p1[3], b = p2[0] + p2[1] + p2[2] + p2[3];
+    const uint64_t var = ((uint64_t)b * 4096 - (uint64_t)a * a) >> 24;
+    const uint32_t v1 = (uint32_t)var + 1;
+    const int l = 31 - __builtin_clz(v1), e = 16 * l + (int)(((v1 << 4) >> l) & 15);
+    act[blockIdx.x] = e;
+    atomicAdd(sum, e);
+  }
+}
+__global__ __launch_bounds__(256) void k_vaq_apply(EncFrame f, int vaq, const int *act, const int *sum, int nctu)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nctu) return;
+  const int mean = (int)(((long long)*sum + nctu / 2) / nctu);
+  const int d = vaq * (act[i] - mean), delta = d >= 0 ? d / 48 : -((-d) / 48);
+  int8_t *qt = const_cast<int8_t *>(f.ctu_qt);
+  qt[i] = (int8_t)clip3(0, 51, f.qp + clip3(-12, 12, (int)qt[i] + delta));      // qt[i] holds the (clamped) ROI delta on entry
+}
+
+// =============================================================================================
 // launch wrappers
 // =============================================================================================
 void launch_scatter_levels(const EncFrame &f, const TuDesc *tus, int ntu, const uint32_t *pairs, hipStream_t st)
@@ -1749,6 +1790,13 @@ void launch_deblock_h(const EncFrame &f, hipStream_t st)
   hipLaunchKernelGGL(k_deblock_h, dim3((nh + 255) / 256), dim3(256), 0, st, f);
 }
 void launch_deblock(const EncFrame &f, hipStream_t st) { launch_deblock_v(f, st); launch_deblock_h(f, st); }
+void launch_vaq(const EncFrame &f, int vaq, int *act, int *sum, hipStream_t st)
+{
+  const int nctu = (f.cw / 64) * (f.ch / 64);
+  hipMemsetAsync(sum, 0, sizeof(int), st);
+  hipLaunchKernelGGL(k_vaq_stats, dim3(nctu), dim3(256), 0, st, f, act, sum);
+  hipLaunchKernelGGL(k_vaq_apply, dim3((nctu + 255) / 256), dim3(256), 0, st, f, vaq, (const int *)act, (const int *)sum, nctu);
+}
 void launch_sao(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_sao<false>, dim3((f.cw / 64) * (f.ch / 64)), dim3(256), 0, st, f); }
 void launch_dec_sao(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_sao<true>, dim3((f.cw / 64) * (f.ch / 64)), dim3(256), 0, st, f); }
 void launch_tokenize(const EncFrame &f, hipStream_t st)

@@ -34,6 +34,7 @@ struct EncoderConfig {
   int entropy_threads = 16;   // host threads of the arithmetic-coding stage
   int qp_in_cu = 0;           // kvazaar "set-qp-in-cu": cu_qp_delta_enabled_flag; a delta-QP map (set_roi, kvz_picture.roi) then gives every CTU its own QP
   int bitrate = 0;            // bits per second; 0 = constant QP, > 0 = "uvgx rate control v1" (oracle/hevc_enc.c rate_control())
+  int vaq = 0;                // kvazaar "vaq" 1..20: "uvgx VAQ v1" (oracle/hevc_enc.c vaq_deltas()); implies qp_in_cu
   int mv_frame = 0;           // kvazaar "mv-constraint" frame / frametile (1), frametilemargin (2): vectors keep the block inside the picture
   int sao = 0;                // kvazaar "sao": sample adaptive offset, parameters by "uvgx SAO decision v1" (oracle/hevc_sao.c)
   int owf = 0;                // kvazaar "owf": 0 = encode() returns its own picture; 1 = output lags one picture and the host
@@ -116,6 +117,7 @@ class Encoder {
   std::vector<int8_t> roi_; int roi_w_ = 0, roi_h_ = 0;
   int8_t *ctu_qt_[2] = {nullptr, nullptr}, *ctu_qy_[2] = {nullptr, nullptr}, *ctu_delta_[2] = {nullptr, nullptr}; uint8_t *ctu_first_[2] = {nullptr, nullptr};   // per picture parity
   int8_t *h_ctu_qt_[2] = {nullptr, nullptr};   // pinned staging of the target map
+  int *vaq_act_ = nullptr, *vaq_sum_ = nullptr; // VAQ: activity of every CTU, its sum over the picture
   bool upload_qp_targets();
   int qp_cur_ = 0; int64_t rc_debt_ = 0; uint32_t rc_bytes_[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rate control state (calling thread)
   void rate_control();

@@ -29,8 +29,11 @@ static hipError_t create_stream(hipStream_t *st, char level)
   return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }
 
-bool Encoder::init(const EncoderConfig &cfg, std::string *error)
+bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
 {
+  EncoderConfig cfg = cfg_in;
+  if (cfg.vaq > 0) cfg.qp_in_cu = 1;                       // the deltas travel as cu_qp_delta
+
   const char *prio = getenv("KVAZZUP_AMD_PRIO"); if (!prio || strlen(prio) < 4) prio = "hnnn";   // main, tokenizer, input, decoder: the chain the next picture waits for is the urgent one (+6 % at 1080p; any explicit priority also gives the stream a hardware queue of its own)
 
   if (cfg.width < 16 || cfg.height < 16 || (cfg.width & 1) || (cfg.height & 1) || cfg.width > 16384 || cfg.height > 16384) {
@@ -41,8 +44,8 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
   if (cfg.band_rows > 0) {
     const int hc = (cfg.height + 63) / 64, T = cfg.tile_rows;
     const bool ok = cfg.band_row0 >= 0 && cfg.band_row0 + cfg.band_rows <= hc && tile_row_starts_at(hc, T, cfg.band_row0) &&
-                    tile_row_ends_at(hc, T, cfg.band_row0 + cfg.band_rows - 1) && cfg.bitrate == 0 && !cfg.sao;
-    if (!ok) { if (error) *error = "a band must consist of whole tile rows (and rate control and SAO are not available in band mode)"; return false; }
+                    tile_row_ends_at(hc, T, cfg.band_row0 + cfg.band_rows - 1) && cfg.bitrate == 0 && !cfg.sao && cfg.vaq == 0;
+    if (!ok) { if (error) *error = "a band must consist of whole tile rows (and rate control, SAO and VAQ are not available in band mode)"; return false; }
   }
   cfg_ = cfg;
   qp_cur_ = cfg.qp;
@@ -77,6 +80,7 @@ bool Encoder::init(const EncoderConfig &cfg, std::string *error)
       HIP_OK(hipMalloc(&ctu_qt_[k], nctu)); HIP_OK(hipMalloc(&ctu_qy_[k], nctu)); HIP_OK(hipMalloc(&ctu_delta_[k], nctu)); HIP_OK(hipMalloc(&ctu_first_[k], nctu));
       HIP_OK(hipHostMalloc(&h_ctu_qt_[k], nctu, hipHostMallocDefault));
     }
+    if (cfg.vaq > 0) { HIP_OK(hipMalloc(&vaq_act_, nctu * sizeof(int))); HIP_OK(hipMalloc(&vaq_sum_, sizeof(int))); }
   }
   if (cfg.sao) {
     for (int c = 0; c < 3; c++) HIP_OK(hipMalloc(&work_[c], c ? npx / 4 : npx));
@@ -183,6 +187,7 @@ Encoder::~Encoder()
   if (in_done_) hipEventDestroy(in_done_);
   hipFree(d_in_); hipHostFree(h_in_);
   for (int c = 0; c < 3; c++) { hipFree(src_[0][c]); hipFree(src_[1][c]); for (int b = 0; b < 4; b++) hipFree(rec_[b][c]); hipFree(coef_[0][c]); hipFree(coef_[1][c]); }
+  hipFree(vaq_act_); hipFree(vaq_sum_);
   for (int k = 0; k < 2; k++) { hipFree(ctu_qt_[k]); hipFree(ctu_qy_[k]); hipFree(ctu_delta_[k]); hipFree(ctu_first_[k]); if (h_ctu_qt_[k]) hipHostFree(h_ctu_qt_[k]); }
   for (int k = 0; k < 2; k++) { hipFree(cu_bytes_[k]); hipFree(cu_mv_[k]); hipFree(cu_mvd_[k]); if (ev_tok_done_[k]) hipEventDestroy(ev_tok_done_[k]); }
   for (int c = 0; c < 3; c++) hipFree(work_[c]);
@@ -268,9 +273,10 @@ bool Encoder::upload_qp_targets()
   for (int cy = 0; cy < hc; cy++) for (int cx = 0; cx < wc; cx++) {
     int d = 0;
     if (!roi_.empty()) d = clip3(-12, 12, (int)roi_[(size_t)(cy * roi_h_ / hc) * roi_w_ + (cx * roi_w_ / wc)]);
-    h[cy * wc + cx] = (int8_t)clip3(0, 51, qp_cur_ + d);
+    h[cy * wc + cx] = (int8_t)(cfg_.vaq > 0 ? d : clip3(0, 51, qp_cur_ + d));      // with VAQ the device adds its delta and the picture QP
   }
   HIP_CHECK(hipMemcpyAsync(ctu_qt_[set_], h, (size_t)wc * hc, hipMemcpyHostToDevice, stream_));
+  if (cfg_.vaq > 0) launch_vaq(f_, cfg_.vaq, vaq_act_, vaq_sum_, stream_);          // (f_.qp, f_.src and f_.ctu_qt of this picture are set; the source is padded: stream_ waits for in_done_)
   return true;
 }
 

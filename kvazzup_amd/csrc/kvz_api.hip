@@ -241,7 +241,8 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.wpp = cfg->wpp ? 1 : 0; ec.deblock = cfg->deblock_enable ? 1 : 0; ec.device = cfg->gpu_device; ec.owf = cfg->owf > 3 ? 3 : cfg->owf;
   ec.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1;
   ec.band_row0 = cfg->band_row0; ec.band_rows = cfg->band_rows;
-  ec.qp_in_cu = cfg->set_qp_in_cu ? 1 : 0;
+  ec.vaq = cfg->vaq > 0 ? cfg->vaq : 0;
+  ec.qp_in_cu = (cfg->set_qp_in_cu || ec.vaq > 0) ? 1 : 0;
   ec.sao = cfg->sao_type == KVZ_SAO_FULL;
   ec.mv_frame = cfg->mv_constraint == KVZ_MV_CONSTRAIN_FRAME || cfg->mv_constraint == KVZ_MV_CONSTRAIN_FRAME_AND_TILE ? 1 : (cfg->mv_constraint == KVZ_MV_CONSTRAIN_FRAME_AND_TILE_MARGIN ? 2 : 0);   // (tile rows always confine vectors to the tile)
   ec.bitrate = cfg->target_bitrate > 0 ? cfg->target_bitrate : 0;      // any rc-algorithm value selects the one picture-level controller
@@ -433,7 +434,7 @@ int kvzx_assemble_access_unit(const kvz_config *cfg, int idr, int poc, int write
   sp.width = cfg->width; sp.height = cfg->height; sp.cw = (cfg->width + 63) & ~63; sp.ch = (cfg->height + 63) & ~63;
   if (sp.cw < 128) sp.cw = 128;
   sp.qp = cfg->qp; sp.wpp = cfg->wpp ? 1 : 0; sp.deblock = cfg->deblock_enable ? 1 : 0; sp.fps_num = cfg->framerate_num; sp.fps_den = cfg->framerate_denom;
-  sp.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1; sp.qp_in_cu = cfg->set_qp_in_cu ? 1 : 0;
+  sp.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1; sp.qp_in_cu = (cfg->set_qp_in_cu || cfg->vaq > 0) ? 1 : 0;
   if (nsub != (sp.wpp ? sp.ch / 64 : sp.tile_rows)) return 0;
   std::vector<std::vector<uint8_t>> rows((size_t)nsub);
   size_t o = 0;

@@ -81,6 +81,7 @@ orc_encoder *orc_enc_open(const orc_enc_config *c)
   orc_encoder *e = (orc_encoder *)calloc(1, sizeof(*e));
   orc_tables_init();
   e->cfg = *c;
+  if (e->cfg.vaq > 0) e->cfg.qp_in_cu = 1;                 /* the deltas travel as cu_qp_delta */
   e->qp = c->qp;
   e->cw = (c->width + 63) & ~63; e->ch = (c->height + 63) & ~63;
   if (e->cw < 128) e->cw = 128;                 /* WPP context hand-over needs two CTUs per row */
@@ -124,7 +125,7 @@ orc_encoder *orc_enc_open(const orc_enc_config *c)
   p->entropy_coding_sync_enabled = c->wpp; p->loop_filter_across_slices = 1;
   p->deblocking_filter_control_present = !c->deblock; p->pps_deblocking_disabled = !c->deblock;
   p->log2_parallel_merge_level = 2; p->num_tile_columns = p->num_tile_rows = 1; p->uniform_spacing = 1;
-  p->cu_qp_delta_enabled = c->qp_in_cu ? 1 : 0; p->diff_cu_qp_delta_depth = 0;
+  p->cu_qp_delta_enabled = e->cfg.qp_in_cu ? 1 : 0; p->diff_cu_qp_delta_depth = 0;
   { size_t nctu = (size_t)(e->cw / 64) * (e->ch / 64);
     if (c->sao) { e->sao = (orc_sao_params *)calloc(nctu, sizeof(orc_sao_params)); for (int i = 0; i < 3; i++) e->sao_in[i] = (pixel *)malloc(i ? npx / 4 : npx); }
     e->ctu_qt = (int8_t *)calloc(nctu, 1); e->ctu_qy = (int8_t *)calloc(nctu, 1); e->ctu_delta = (int8_t *)calloc(nctu, 1); e->ctu_first = (uint8_t *)calloc(nctu, 1); }
@@ -804,15 +805,42 @@ void orc_enc_set_roi(orc_encoder *e, int w, int h, const int8_t *map)
   if (w > 0 && h > 0 && map) { e->roi = (int8_t *)malloc((size_t)w * h); memcpy(e->roi, map, (size_t)w * h); e->roi_w = w; e->roi_h = h; }
 }
 
-/* target QP of every CTU for this picture */
+/* "uvgx VAQ v1" (kvazaar "vaq", uvgComm video/VAQ 1..20, kvazaarfilter.cpp:280-284).  Per CTU, over the 64x64 luma samples of the
+ * padded source: S1 = sum x, S2 = sum x^2, variance v = (4096 S2 - S1^2) >> 24.  Activity e = 16 floor(log2(v + 1)) + the next four
+ * bits of v + 1 below its leading one (log2 in 1/16 steps, piecewise linear).  With E = round(mean of e over the picture's CTUs):
+ * delta = trunc(vaq * (e - E) / 48) towards zero, later clamped together with the ROI delta to [-12, 12]. */
+static int vaq_activity(const pixel *p, int stride)
+{
+  uint32_t s1 = 0, s2 = 0;
+  for (int y = 0; y < 64; y++) for (int x = 0; x < 64; x++) { uint32_t v = p[y * stride + x]; s1 += v; s2 += v * v; }
+  uint64_t var = ((uint64_t)s2 * 4096 - (uint64_t)s1 * s1) >> 24;
+  uint32_t v1 = (uint32_t)var + 1;
+  int l = orc_log2(v1);
+  return 16 * l + (int)(((v1 << 4) >> l) & 15);
+}
+static void vaq_deltas(orc_encoder *e, int *delta)
+{
+  int wc = e->cw / 64, hc = e->ch / 64, n = wc * hc;
+  int64_t sum = 0;
+  for (int cy = 0; cy < hc; cy++) for (int cx = 0; cx < wc; cx++) { delta[cy * wc + cx] = vaq_activity(e->src[0] + (size_t)cy * 64 * e->cw + cx * 64, e->cw); sum += delta[cy * wc + cx]; }
+  int mean = (int)((sum + n / 2) / n);
+  for (int i = 0; i < n; i++) { int d = e->cfg.vaq * (delta[i] - mean); delta[i] = d >= 0 ? d / 48 : -((-d) / 48); }
+}
+
+/* target QP of every CTU for this picture (after the source picture has been loaded) */
 static void roi_targets(orc_encoder *e)
 {
   int wc = e->cw / 64, hc = e->ch / 64;
+  int *vd = NULL;
+  if (e->cfg.vaq > 0) { vd = (int *)calloc((size_t)wc * hc, sizeof(int)); vaq_deltas(e, vd); }
   for (int cy = 0; cy < hc; cy++) for (int cx = 0; cx < wc; cx++) {
     int d = 0;
-    if (e->cfg.qp_in_cu && e->roi) d = orc_clip3(-12, 12, e->roi[(cy * e->roi_h / hc) * e->roi_w + (cx * e->roi_w / wc)]);
+    if (e->cfg.qp_in_cu && e->roi) d = e->roi[(cy * e->roi_h / hc) * e->roi_w + (cx * e->roi_w / wc)];
+    d = orc_clip3(-12, 12, d);
+    if (vd) d = orc_clip3(-12, 12, d + vd[cy * wc + cx]);
     e->ctu_qt[cy * wc + cx] = (int8_t)orc_clip3(0, 51, e->qp + d);
   }
+  free(vd);
 }
 
 /* After reconstruction: which CTUs code a delta, their actual QpY (8.6.1 with quantisation group = CTU: the prediction is the
@@ -852,8 +880,8 @@ size_t orc_enc_encode(orc_encoder *e, const pixel *y, const pixel *u, const pixe
   e->is_intra = (e->frame_idx == 0) || (period > 0 && (e->frame_idx % period) == 0);
   if (e->is_intra) e->poc = 0; else e->poc++;
   rate_control(e);
-  roi_targets(e);
   load_input(e, y, u, v);
+  roi_targets(e);
   orc_pic_reset_side(e->cur);
   for (int c = 0; c < 3; c++) memset(e->coef[c], 0, sizeof(int16_t) * (size_t)(c ? e->cw * e->ch / 4 : e->cw * e->ch));
   if (e->is_intra) encode_intra_picture(e); else encode_inter_picture(e);

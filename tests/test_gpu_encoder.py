@@ -29,11 +29,11 @@ def _diagnose(dbg_o, dbg_g):
     return "; ".join(msgs) if msgs else "no stage-level difference found (entropy coding / assembly?)"
 
 
-def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_picture=True, tile_rows=1, sao=0, mv_frame=0):
+def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_picture=True, tile_rows=1, sao=0, mv_frame=0, vaq=0):
     from kvazzup_amd.codec import Encoder
-    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows, sao=sao, mv_frame=mv_frame)
+    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows, sao=sao, mv_frame=mv_frame, vaq=vaq)
     ge = Encoder(w, h, options=(("qp", qp), ("period", period), ("me-range", me_range), ("wpp", wpp), ("deblock", deblock), ("tiles", "1x%d" % tile_rows),
-                                ("sao", "full" if sao else "off"), ("mv-constraint", ("none", "frame", "frametilemargin")[mv_frame])))
+                                ("sao", "full" if sao else "off"), ("mv-constraint", ("none", "frame", "frametilemargin")[mv_frame])) + ((('vaq', vaq),) if vaq else ()))
     assert not ge.rejected, ge.rejected
     try:
         for t in range(frames):
@@ -203,7 +203,7 @@ def test_random_tool_combinations_match_oracle(gpu, seed):
     hc = (h + 63) // 64
     cfg = dict(qp=int(rng.integers(8, 46)), period=int(rng.choice([1, 2, 3, 5, 64])), me_range=int(rng.choice([1, 4, 8, 16, 32])),
                wpp=int(rng.integers(0, 2)), deblock=int(rng.integers(0, 2)), tile_rows=int(rng.integers(1, min(hc, 3) + 1)),
-               sao=int(rng.integers(0, 2)), qp_in_cu=int(rng.integers(0, 2)), bitrate=int(rng.choice([0, 0, 0, 150000, 2000000])), mv_frame=int(rng.choice([0, 0, 1, 2])))
+               sao=int(rng.integers(0, 2)), qp_in_cu=int(rng.integers(0, 2)), bitrate=int(rng.choice([0, 0, 0, 150000, 2000000])), mv_frame=int(rng.choice([0, 0, 1, 2])), vaq=int(rng.choice([0, 0, 3, 12])))
     owf = int(rng.choice([0, 1, 2, 3]))
     kind = int(rng.choice([0, 2]))
     frames = 9 if cfg["bitrate"] else 5              # (the rate controller starts moving the QP at the fourth picture)
@@ -212,11 +212,11 @@ def test_random_tool_combinations_match_oracle(gpu, seed):
     ge = Encoder(w, h, options=(("qp", cfg["qp"]), ("period", cfg["period"]), ("me-range", cfg["me_range"]), ("wpp", cfg["wpp"]),
                                 ("deblock", cfg["deblock"]), ("tiles", "1x%d" % cfg["tile_rows"]), ("sao", "full" if cfg["sao"] else "off"),
                                 ("set-qp-in-cu", cfg["qp_in_cu"]), ("owf", owf),
-                                ("mv-constraint", ("none", "frame", "frametilemargin")[cfg["mv_frame"]])), fields={"target_bitrate": cfg["bitrate"]})
+                                ("mv-constraint", ("none", "frame", "frametilemargin")[cfg["mv_frame"]])) + ((("vaq", cfg["vaq"]),) if cfg["vaq"] else ()), fields={"target_bitrate": cfg["bitrate"]})
     assert not ge.rejected, (cfg, ge.rejected)
     gd = Decoder()
     roi = None
-    if cfg["qp_in_cu"]:
+    if cfg["qp_in_cu"] or cfg["vaq"]:
         rw, rh = int(rng.integers(1, 6)), int(rng.integers(1, 5))
         roi = (rw, rh, np.ascontiguousarray(rng.integers(-14, 15, rw * rh), dtype=np.int8))
         oe.set_roi(*roi)
@@ -264,3 +264,16 @@ def test_mv_constraint_frame_matches_oracle_and_keeps_blocks_inside(gpu, mode):
             n = 1 << int(l2[by, bx]); x0, y0 = (bx * 8) & ~31, (by * 8) & ~31       # the constraint is applied to the 32x32 search block
             assert 0 <= x0 + mv[by, bx, 0] and x0 + mv[by, bx, 0] + 32 <= cw and 0 <= y0 + mv[by, bx, 1] and y0 + mv[by, bx, 1] + 32 <= ch
     ge.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(w=448, h=320, frames=6, qp=30, period=4, me_range=16, kind=0, vaq=5),
+    dict(w=320, h=256, frames=4, qp=36, period=64, me_range=8, kind=2, vaq=20, wpp=0),
+    dict(w=640, h=384, frames=4, qp=26, period=3, me_range=16, kind=0, vaq=10, tile_rows=2, sao=1),
+    dict(w=1920, h=1080, frames=3, qp=32, period=64, me_range=16, kind=0, vaq=8),
+])
+def test_vaq_matches_oracle(gpu, cfg):
+    """uvgComm video/VAQ (kvazaar "vaq" 1..20, kvazaarfilter.cpp:280-284): per-CTU QP from the CTU's luma variance against the
+    picture's average ("uvgx VAQ v1"), carried as cu_qp_delta; k_vaq_stats / k_vaq_apply against the checker"""
+    run_clip(**cfg)

@@ -179,3 +179,16 @@ def test_mv_constraint_frame_closed_loop(mode):
         return outside
     assert run(mode) == 0
     assert run(0) > 0
+
+
+@pytest.mark.parametrize("vaq,wpp,tile_rows", [(5, 1, 1), (20, 0, 2)])
+def test_vaq_closed_loop(vaq, wpp, tile_rows):
+    """variance adaptive quantisation ("uvgx VAQ v1"): the per-CTU deltas travel as cu_qp_delta, the checker's decoder follows
+    them; flat CTUs end up with a lower QP than textured ones"""
+    w, h = 448, 320
+    oe = orc.OracleEncoder(w, h, qp=30, period=4, me_range=8, wpp=wpp, tile_rows=tile_rows, vaq=vaq)
+    od = orc.OracleDecoder()
+    for t in range(5):
+        got = od.decode_au(oe.encode(orc.synth_frame(0, 9, w, h, t)), t)
+        assert len(got) == 1 and np.array_equal(got[0]["i420"], oe.recon()), t
+    oe.close(); od.close()

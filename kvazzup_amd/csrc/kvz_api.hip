@@ -69,7 +69,9 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
 #define BOOL_OPT(key, field) if (n == key) { if (!parse_bool(value, &iv)) { cfg->field = 0; return *value ? 0 : 1; } cfg->field = iv; return 1; }
   if (n == "preset") {
     static const char *presets[] = {"ultrafast", "superfast", "veryfast", "faster", "fast", "medium", "slow", "slower", "veryslow", "placebo"};
-    for (const char *p : presets) if (!strcmp(value, p)) return 1;    // every preset maps onto the one GPU tool set
+    // One GPU tool set serves every preset; what the presets above ultrafast add from it is SAO (Kvazaar's preset table, as
+    // recalled in SURVEY.md appendix A, has sao off at ultrafast only).  Later options ("sao") override, as in Kvazaar.
+    for (const char *p : presets) if (!strcmp(value, p)) { cfg->sao_type = strcmp(p, "ultrafast") ? KVZ_SAO_FULL : KVZ_SAO_OFF; return 1; }
     return 0;
   }
   if (n == "input-res") {

@@ -50,7 +50,11 @@ def test_kvz_api_table_and_config_parsing(lib):
                  ("mv-constraint", "none"), ("mv-constraint", ""), ("vaq", "5"), ("rc-algorithm", "lambda"), ("slices", "wpp")):
         assert ok(k, v) == 1, (k, v)
     c = cfg.contents
+    assert c.sao_type == 0                                   # ultrafast: SAO off
     assert (c.width, c.height, c.framerate_num, c.framerate_denom, c.qp, c.intra_period, c.vps_period, c.owf, c.wpp) == (1920, 1080, 30, 1, 32, 64, 1, 2, 1)
+    assert ok("preset", "medium") == 1 and cfg.contents.sao_type == 3     # presets above ultrafast: SAO full ...
+    assert ok("sao", "off") == 1 and cfg.contents.sao_type == 0           # ... unless a later option says otherwise
+    assert ok("preset", "ultrafast") == 1 and cfg.contents.sao_type == 0
     # rejected: unknown names and values outside the implemented tool set (kvazaarfilter.cpp:363-367 logs these)
     for k, v in (("no-such-option", "1"), ("qp", "99"), ("input-res", "axb"), ("tiles", "2x2"), ("scaling-list", "default"), ("gop", "8"), ("preset", "warp9"), ("sao", "edge")):
         assert ok(k, v) == 0, (k, v)

@@ -283,6 +283,7 @@ bool Decoder::start(std::string *error)
     return false;
   }
   HIP_TRY(hipSetDevice(device_));
+  spin_wait_ = getenv("KVAZZUP_AMD_SPIN") != nullptr;
   {
     const char *prio = getenv("KVAZZUP_AMD_PRIO"); int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
     const char lv = (prio && strlen(prio) >= 4) ? prio[3] : 'n';
@@ -652,7 +653,7 @@ int Decoder::complete_gpu()
   gpu_job_ = nullptr;
   {
     Tick tk;
-    if (frame_threads_ > 1 && !getenv("KVAZZUP_AMD_SPIN")) {   // the output lags anyway: nap between queries instead of polling (see nap_until)
+    if (frame_threads_ > 1 && !spin_wait_) {   // the output lags anyway: nap between queries instead of polling (see nap_until)
       if (!nap_until([&] { hipError_t r = hipStreamQuery(stream_); return r == hipSuccess ? 1 : (r == hipErrorNotReady ? 0 : -1); })) return DEC_ERR_GPU;
     } else if (hipStreamSynchronize(stream_) != hipSuccess) return DEC_ERR_GPU;
     t_sync_ += tk.ms();

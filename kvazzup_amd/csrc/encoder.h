@@ -106,6 +106,7 @@ class Encoder {
   uint8_t *src_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // padded source planes, one set per picture parity
   // reconstruction ring: the picture being coded, its reference, and (owf >= 2) the one still waiting to be output
   uint8_t *rec_[4][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  bool spin_wait_ = false;      // KVAZZUP_AMD_SPIN: poll the GPU instead of napping between queries
   int nrec_ = 3;                // reconstruction ring: the picture being written, its reference, and the ones whose output is still owed (owf)
   int cur_idx_ = 0, ref_idx_ = 2, out_idx_ = 2;
   // Two sets of everything the tokenizer reads (levels and CU records): picture t is tokenised on the second stream

@@ -104,6 +104,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   HIP_OK(hipMemset(tok_count_, 0, sizeof(uint32_t) * nctu));
   tok_dense_cap_ = (size_t)nctu * tok_cap_;
   if (tok_dense_cap_ > ((size_t)1 << 27)) tok_dense_cap_ = (size_t)1 << 27;
+  spin_wait_ = getenv("KVAZZUP_AMD_SPIN") != nullptr;
   depth_ = cfg.owf >= 3 && cfg.bitrate == 0 ? 3 : (cfg.owf >= 2 ? 2 : (cfg.owf == 1 ? 1 : 0));   // (rate control books picture t - 3 before picture t: lag <= 2)
   nslots_ = depth_ + 1;
   for (int i = 0; i < nslots_; i++) {
@@ -401,7 +402,7 @@ bool Encoder::finish_slot(Slot &sl, EncodedPicture *out, int worker)
   out->valid = false; out->au.clear();
   {
     Tick tk;
-    if (depth_ >= 2 && !getenv("KVAZZUP_AMD_SPIN")) {          // background worker: naps between queries (see nap_until)
+    if (depth_ >= 2 && !spin_wait_) {          // background worker: naps between queries (see nap_until)
       auto q = [&](hipEvent_t e) { return nap_until([&] { hipError_t r = hipEventQuery(e); return r == hipSuccess ? 1 : (r == hipErrorNotReady ? 0 : -1); }); };
       if (!q(sl.done) || !q(sl.rec_done)) return false;
     } else { HIP_CHECK(hipEventSynchronize(sl.done)); HIP_CHECK(hipEventSynchronize(sl.rec_done)); }

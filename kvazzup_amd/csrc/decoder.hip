@@ -37,18 +37,17 @@ bool skip_ptl(BitReader &r, int max_sub_layers_minus1)
 // `bits` stream bits, so a renormalisation by n is just bits -= n and the stream is touched 32 bits at
 // a time.  Context variable = pStateIdx << 1 | valMps with precomputed transitions.
 struct StateTabs { uint8_t next_mps[128], next_lps[128]; };
-const StateTabs &state_tabs()
+const StateTabs &state_tabs()               // (function-local statics: initialised once, thread-safe -- parse workers race to the first call)
 {
-  static StateTabs t;
-  static bool ready = false;
-  if (!ready) {
+  static const StateTabs t = [] {
+    StateTabs t;
     for (int s = 0; s < 128; s++) {
       int st = s >> 1, mps = s & 1;
       t.next_mps[s] = (uint8_t)(((st < 62 ? st + 1 : st) << 1) | mps);
       t.next_lps[s] = (uint8_t)((kNextLps[st] << 1) | (st == 0 ? mps ^ 1 : mps));
     }
-    ready = true;
-  }
+    return t;
+  }();
   return t;
 }
 struct CabacDec {
@@ -117,27 +116,24 @@ std::atomic<long> g_yields{0};
 std::atomic<uint64_t> g_tc[6];
 #define TSC() __builtin_ia32_rdtsc()
 struct Tick { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } };
-CoreTabs g_tabs;
-bool g_tabs_ready = false;
 const CoreTabs *host_tabs()
 {
-  if (!g_tabs_ready) { for (int i = 0; i < 64; i++) core_tabs_fill_entry(g_tabs, i); g_tabs_ready = true; }
-  return &g_tabs;
+  static const CoreTabs t = [] { CoreTabs t; for (int i = 0; i < 64; i++) core_tabs_fill_entry(t, i); return t; }();
+  return &t;
 }
 
 // scan position -> (x, y) for the three scans and block sizes 1..8 (H.265 6.5.3-6.5.5)
 struct ScanTabs { uint8_t x[3][4][64], y[3][4][64]; };
 const ScanTabs &scan_tabs()
 {
-  static ScanTabs t;
-  static bool ready = false;
-  if (!ready) {
+  static const ScanTabs t = [] {
+    ScanTabs t;
     const CoreTabs *ct = host_tabs();
     for (int sc = 0; sc < 3; sc++) for (int l2 = 0; l2 < 4; l2++) for (int i = 0; i < (1 << (2 * l2)); i++) {
       int x, y; scan_pos(ct, sc, l2, i, x, y); t.x[sc][l2][i] = (uint8_t)x; t.y[sc][l2][i] = (uint8_t)y;
     }
-    ready = true;
-  }
+    return t;
+  }();
   return t;
 }
 

@@ -173,7 +173,7 @@ def test_decoder_survives_corrupted_streams(gpu, extra):
     rng = np.random.default_rng(12345)
     gd = Decoder()
     errors = pictures = 0
-    for trial in range(120):
+    for trial in range(int(__import__("os").environ.get("KVZ_FUZZ_TRIALS", "120"))):
         t = int(rng.integers(0, 6))
         au = bytearray(aus[t])
         kind = trial % 4
@@ -261,3 +261,54 @@ def test_decoder_fractional_motion_vectors(gpu, cfg):
     """streams whose vectors have quarter-sample fractions (the checker's encoder with its test hook: the product's encoder
     searches integer positions only): 8-tap luma / 4-tap chroma interpolation (8.5.3.3.3), all 16 x 64 fraction pairs occur"""
     run_clip(**cfg)
+
+
+@pytest.mark.gpu
+def test_frame_threaded_decoder_survives_corrupted_streams(gpu):
+    """the same abuse with libOpenHevcInit(4, OH_THREAD_FRAME): errors surface with the delayed picture they belong to, nothing
+    hangs, and after draining a clean IDR and its followers decode exactly"""
+    from kvazzup_amd import _native as N
+    from kvazzup_amd.codec import Decoder, split_nals
+    w, h = 320, 256
+    oe = orc.OracleEncoder(w, h, qp=28, period=3, me_range=16)
+    aus, recs = [], []
+    for t in range(6):
+        aus.append(oe.encode(orc.synth_frame(0 if t % 2 else 2, SEED, w, h, t))); recs.append(oe.recon())
+    rng = np.random.default_rng(777)
+    gd = Decoder.__new__(Decoder)
+    gd.lib = N.load_library()
+    gd.h = gd.lib.libOpenHevcInit(4, 1)
+    assert gd.lib.libOpenHevcStartDecoder(gd.h) == 0
+    gd.download = True; gd.vps = gd.sps = gd.pps = False
+    errors = 0
+    for trial in range(int(__import__("os").environ.get("KVZ_FUZZ_TRIALS", "120"))):
+        t = int(rng.integers(0, 6))
+        au = bytearray(aus[t])
+        if trial % 3 == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                au[min(40 + int(rng.integers(0, max(len(au) - 40, 1))), len(au) - 1)] ^= 1 << int(rng.integers(0, 8))
+        elif trial % 3 == 1:
+            au = au[:max(8, int(rng.integers(8, len(au))))]
+        for nal in split_nals(bytes(au)):
+            try:
+                gd.decode_nal(nal, t)
+            except RuntimeError:
+                errors += 1
+    eos = bytes([0, 0, 0, 1, 36 << 1, 1])
+    for _ in range(8):                                   # drain whatever is still in flight (errors included)
+        try:
+            gd.decode_nal(eos)
+        except RuntimeError:
+            errors += 1
+    assert errors > 0
+    out = []
+    for t in (3, 4, 5):
+        out += gd.decode_au(aus[t], t)
+    for _ in range(4):
+        d = gd.decode_nal(eos)
+        if d is not None:
+            out.append(d)
+    assert len(out) == 3
+    for k, t in enumerate((3, 4, 5)):
+        assert np.array_equal(out[k]["i420"], recs[t]), t
+    gd.close(); oe.close()

@@ -500,8 +500,12 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
   const bool split = f.cu_log2[bi0] == 4;
   const int cw2 = f.cw >> 1, ch2 = f.ch >> 1;
   const int qp = ctu_quant_qp(f, x0, y0), qpc = kChromaQp[qp];       // the 32x32 block lies inside one CTU
+  // Decoder: most blocks of an inter picture carry no residual at all -- they skip the matrices, the transform stages and all
+  // but two barriers (prediction straight to the picture).  `coded` is uniform over the workgroup.
+  const bool coded = DEC ? __syncthreads_or(tid < 16 ? (int)(f.cu_cbf[b8idx(f, x0 + (tid & 3) * 8, y0 + (tid >> 2) * 8)] & 7) : 0) != 0 : true;
   // matrices of the two block sizes in use (luma n, chroma n / 2): adjacent in the table
-  if (split) load_matrices(s.M, 16, 64 + 256, tid, 256);
+  if (!coded) { }
+  else if (split) load_matrices(s.M, 16, 64 + 256, tid, 256);
   else {
     load_matrices(s.M, 80, 256, tid, 256);                       // chroma 16-point matrices (dot2 path)
     if (tid >= 64 && tid < 192) ((uint4 *)s.M8)[tid - 64] = ((const uint4 *)g_xf.M8)[tid - 64];
@@ -550,8 +554,9 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
         p4 |= (uint32_t)clip8((v + 32) >> 6) << (8 * i);
       }
     } else p4 = mc_luma4(f.ref[0], f.cw, f.ch, x0 + x, y0 + y, s.mv[k][0], s.mv[k][1]);
-    *(uint32_t *)&s.px[y * 32 + x] = p4;
     const size_t g = (size_t)(y0 + y) * f.cw + x0 + x;
+    if (!coded) *(uint32_t *)&f.rec[0][g] = p4;
+    *(uint32_t *)&s.px[y * 32 + x] = p4;
     int16_t *A = s.A + (tu << (2 * l2));
     const int ty = y & (n - 1), tx = x & (n - 1);
     if (DEC) {
@@ -569,15 +574,15 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
       *(uint2 *)&A[ty * n + tx] = make_uint2(pack_i16(r[0], r[1]), pack_i16(r[2], r[3]));
     }
   }
-  __syncthreads();
-  {
+  if (coded) {
+    __syncthreads();
     auto px16 = [](int tu, int y, int x) { return ((tu >> 1) * 16 + y) * 32 + (tu & 1) * 16 + x; };
     const int cw = f.cw; int16_t *base = f.coef[0] + (size_t)y0 * cw + x0;
     auto ci16 = [=](int tu, int y, int x) { return base + (size_t)((tu >> 1) * 16 + y) * cw + (tu & 1) * 16 + x; };
     if (split) inter_transform<DEC, 4, 2>(s, qp, &s.nz[0], px16, ci16, tid);
     else inter_transform_32<DEC>(s, qp, &s.nz[0], base, cw, tid);
+    *(uint32_t *)&f.rec[0][(size_t)(y0 + (tid >> 3)) * f.cw + x0 + (tid & 7) * 4] = *(const uint32_t *)&s.px[(tid >> 3) * 32 + (tid & 7) * 4];
   }
-  *(uint32_t *)&f.rec[0][(size_t)(y0 + (tid >> 3)) * f.cw + x0 + (tid & 7) * 4] = *(const uint32_t *)&s.px[(tid >> 3) * 32 + (tid & 7) * 4];
   // ---- chroma: reference windows of the eight 8x8 sub-blocks (plane x quadrant) -> LDS; mv in 1/8 samples
   for (int i = tid; i < 8 * 121; i += 256) {
     const int w8 = i / 121, r = i - w8 * 121, wy = r / 11, wx = r - wy * 11, pl = w8 >> 2, sub = w8 & 3, k = split ? sub : 0;
@@ -606,6 +611,7 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
     *(uint16_t *)&s.px[pl * 256 + y * 16 + x] = (uint16_t)(p0 | (p1 << 8));
     const int cl2 = split ? 3 : 4, cn = 1 << cl2, tu = pl * (split ? 4 : 1) + (split ? sub : 0);
     const size_t g = (size_t)((y0 >> 1) + y) * cw2 + (x0 >> 1) + x;
+    if (!coded) *(uint16_t *)&f.rec[1 + pl][g] = (uint16_t)(p0 | (p1 << 8));
     int16_t *A = s.A + (tu << (2 * cl2));
     const int ty = y & (cn - 1), tx = x & (cn - 1);
     if (DEC) {
@@ -621,6 +627,7 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
       *(uint32_t *)&A[ty * cn + tx] = pack_i16((int)(s2 & 255) - p0, (int)(s2 >> 8) - p1);
     }
   }
+  if (!coded) return;                          // (decoder only; the encoder's cbf bookkeeping below never applies)
   __syncthreads();
   {
     auto px1 = [](int tu, int y, int x) { return tu * 256 + y * 16 + x; };

@@ -16,8 +16,8 @@ def short(name):
     if not m:
         return None
     k = m.group(1)
-    if m.group(2) and m.group(2).startswith("<true"):
-        k += "<dec>"
+    if m.group(2) and m.group(2).startswith("<true") and k in ("k_inter_recon", "k_intra_recon", "k_sao"):
+        k += "<dec>"                   # the decoder instantiations; k_tokenize<true> is the all-components variant of the same kernel
     return k
 
 

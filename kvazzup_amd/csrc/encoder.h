@@ -126,7 +126,7 @@ class Encoder {
   bool band_intra_ = false;
   hipStream_t stream_tok_ = nullptr;     // signalling decisions, tokenizer, compaction
   hipStream_t stream_in_ = nullptr;      // input padding (runs ahead of the previous picture's kernels)
-  hipEvent_t ev_padded_ = nullptr, ev_src_free_[2] = {nullptr, nullptr}; bool src_busy_[2] = {false, false};
+  hipEvent_t ev_src_free_[2] = {nullptr, nullptr}; bool src_busy_[2] = {false, false};
   uint8_t *work_[3] = {nullptr, nullptr, nullptr};   // SAO on: the picture up to deblocking (rec_[] then holds the filtered pictures)
   SaoParams *sao_[2] = {nullptr, nullptr};            // per CTU, one array per set
   hipEvent_t ev_sao_ = nullptr;

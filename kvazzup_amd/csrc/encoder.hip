@@ -89,7 +89,6 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   }
   HIP_OK(create_stream(&stream_tok_, prio[1]));
   HIP_OK(create_stream(&stream_in_, prio[2]));
-  HIP_OK(hipEventCreateWithFlags(&ev_padded_, hipEventDisableTiming));
   for (int k = 0; k < 2; k++) HIP_OK(hipEventCreateWithFlags(&ev_src_free_[k], hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&ev_signalled_, hipEventDisableTiming));
   // intra scratch: ic8 (nb8 u32) | ic16 (nb8/4 u32) | ic32 (nb8/16 u32) | im8 | im16 | im32
@@ -195,7 +194,6 @@ Encoder::~Encoder()
   for (int k = 0; k < 2; k++) hipFree(sao_[k]);
   if (ev_sao_) hipEventDestroy(ev_sao_);
   if (ev_signalled_) hipEventDestroy(ev_signalled_);
-  if (ev_padded_) hipEventDestroy(ev_padded_);
   for (int k = 0; k < 2; k++) if (ev_src_free_[k]) hipEventDestroy(ev_src_free_[k]);
   if (stream_tok_) hipStreamDestroy(stream_tok_);
   if (stream_in_) hipStreamDestroy(stream_in_);

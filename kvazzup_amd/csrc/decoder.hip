@@ -73,22 +73,19 @@ struct CabacDec {
   }
   inline int bin(int ci)
   {
-    const uint8_t s = ctx[ci];
+    // (both outcomes are computed and selected: the bin values of sig / greater1 flags are close to coin flips for a branch predictor)
+    const uint32_t s = ctx[ci];
     const uint32_t lps = kRangeLps[s >> 1][(range >> 6) & 3];
-    range -= lps;
-    const uint64_t scaled = (uint64_t)range << bits;
-    int b = s & 1;
-    if (value >= scaled) {
-      value -= scaled; range = lps; b ^= 1;
-      ctx[ci] = st->next_lps[s];
-      const int n = __builtin_clz(range) - 23;
-      range <<= n; bits -= n;
-    } else {
-      ctx[ci] = st->next_mps[s];
-      if (range < 256) { range <<= 1; bits--; }
-    }
+    const uint32_t rmps = range - lps;
+    const uint64_t scaled = (uint64_t)rmps << bits;
+    const bool isl = value >= scaled;
+    value -= isl ? scaled : 0;
+    const uint32_t r = isl ? lps : rmps;
+    ctx[ci] = isl ? st->next_lps[s] : st->next_mps[s];
+    const int n = __builtin_clz(r) - 23;                  // renormalisation: r in [1, 510] -> [256, 510]
+    range = r << n; bits -= n;
     refill();
-    return b;
+    return (int)((s & 1u) ^ (uint32_t)isl);
   }
   inline int bypass()
   {
@@ -206,7 +203,8 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, std::vector<u
     for (int k = (i == last_sb) ? last_pos - 1 : 15; k >= 0; k--) {
       if (k > 0 || !infer_dc) {
         const int sc = (k == 0 && i == 0 && log2 != 2) ? 0 : pat[rp[k]] + sig_off;      // (the DC coefficient of the block has its own context)
-        if (c.bin(sig_base + sc)) { sig |= 1u << k; infer_dc = 0; }
+        const int b = c.bin(sig_base + sc);
+        sig |= (uint32_t)b << k; infer_dc &= b ^ 1;
       } else sig |= 1u;            // k == 0 with every other flag of a coded sub-block zero: inferred
     }
     if (!sig) continue;

@@ -120,14 +120,14 @@ const CoreTabs *host_tabs()
 }
 
 // scan position -> (x, y) for the three scans and block sizes 1..8 (H.265 6.5.3-6.5.5)
-struct ScanTabs { uint8_t x[3][4][64], y[3][4][64]; };
+struct ScanTabs { uint8_t x[3][4][64], y[3][4][64], inv[3][4][64]; };     // inv[scan][log2 of the grid][y << log2 | x] = scan position
 const ScanTabs &scan_tabs()
 {
   static const ScanTabs t = [] {
     ScanTabs t;
     const CoreTabs *ct = host_tabs();
     for (int sc = 0; sc < 3; sc++) for (int l2 = 0; l2 < 4; l2++) for (int i = 0; i < (1 << (2 * l2)); i++) {
-      int x, y; scan_pos(ct, sc, l2, i, x, y); t.x[sc][l2][i] = (uint8_t)x; t.y[sc][l2][i] = (uint8_t)y;
+      int x, y; scan_pos(ct, sc, l2, i, x, y); t.x[sc][l2][i] = (uint8_t)x; t.y[sc][l2][i] = (uint8_t)y; t.inv[sc][l2][(y << l2) | x] = (uint8_t)i;
     }
     return t;
   }();
@@ -178,13 +178,8 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, std::vector<u
   if (ly > 3) { int nb = (ly >> 1) - 1; ly = (1 << nb) * (2 + (ly & 1)) + (int)c.bypass_bits(nb); }
   if (scan_idx == 2) { int tt = lx; lx = ly; ly = tt; }
   if (lx >= n || ly >= n) return false;
-  int last_sb = (1 << (2 * sbl)) - 1, last_pos = 16;
-  for (;;) {
-    if (last_pos == 0) { last_pos = 16; if (--last_sb < 0) return false; }
-    last_pos--;
-    const int xs = SX[last_sb], ys = SY[last_sb], xp = PX[last_pos], yp = PY[last_pos];
-    if ((xs << 2) + xp == lx && (ys << 2) + yp == ly) break;
-  }
+  // the last significant coefficient as (sub-block, position inside it) in scan order: inverse scan tables
+  const int last_sb = S.inv[scan_idx][sbl][((ly >> 2) << sbl) | (lx >> 2)], last_pos = S.inv[scan_idx][2][((ly & 3) << 2) | (lx & 3)];
   int c1 = 1;
   for (int i = last_sb; i >= 0; i--) {
     const int xs = SX[i], ys = SY[i];
@@ -212,7 +207,7 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, std::vector<u
     if (c1 == 0) ctx_set++;
     c1 = 1;
     int pos[16], lev[16], nsig = 0, g1idx = -1;
-    for (int k = 15; k >= 0; k--) if ((sig >> k) & 1) pos[nsig++] = k;
+    for (uint32_t m = sig; m;) { const int k = 31 - __builtin_clz(m); pos[nsig++] = k; m &= ~(1u << k); }     // highest scan position first
     for (int j = 0; j < nsig; j++) lev[j] = 1;
     for (int j = 0; j < nsig && j < 8; j++) {
       int g1 = c.bin(CTX_GT1 + (cidx ? 16 : 0) + ctx_set * 4 + c1);

@@ -74,6 +74,17 @@ def cpu_budget(world):
     return cores / max(1, world)
 
 
+def _throttled_us():
+    """time the container's CPU quota has stalled the job so far (cgroup v2 cpu.stat), microseconds; 0 when unknown"""
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            if line.startswith("throttled_usec"):
+                return int(line.split()[1])
+    except Exception:
+        pass
+    return 0
+
+
 def _thread_cpu():
     """{tid: (name, CPU seconds)} of this process's threads"""
     out = {}
@@ -261,6 +272,7 @@ def main():
     if world > 1:
         dist.barrier()
     cpu0 = time.process_time()
+    thr0 = _throttled_us()
     _thr0 = _thread_cpu() if os.environ.get("KVAZZUP_BENCH_THREADS") else None
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
@@ -268,6 +280,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    throttled_ms = (_throttled_us() - thr0) / 1e3              # summed over the job's threads: > 0 means the CPU quota, not the GPU, set the pace for a while
     host_cores = (time.process_time() - cpu0) / elapsed        # CPU seconds of all threads of this rank per second of the timed region
     if _thr0 is not None:                                       # KVAZZUP_BENCH_THREADS=1: CPU time per thread over the timed region (stderr)
         _thr1 = _thread_cpu()
@@ -321,7 +334,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl["name"], "width": w, "height": h, "coded_width": cw, "coded_height": ch,
                        "frames_per_gpu": args.steps, "intra_period": 64, "qp": 32, "me_range": args.me_range,
-                       "streams": world, "bytes_per_frame": round(nbytes / args.steps, 1), "decoder_frame_threads": D, "owf": args.owf, "sao": bool(args.sao), "host_cpu_cores_busy": round(host_cores, 2), "host_cpu_budget_cores": round(budget, 1),
+                       "streams": world, "bytes_per_frame": round(nbytes / args.steps, 1), "decoder_frame_threads": D, "owf": args.owf, "sao": bool(args.sao), "host_cpu_cores_busy": round(host_cores, 2), "host_cpu_budget_cores": round(budget, 1), "host_cpu_throttled_ms": round(throttled_ms, 1),
                        "input": "I420 resident in HBM", "output": "Annex-B AU on host + decoded I420 in HBM"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,

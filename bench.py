@@ -182,7 +182,7 @@ def main():
     ap.add_argument("--me-range", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
-    ap.add_argument("--decoder-frame-threads", type=int, default=8,
+    ap.add_argument("--decoder-frame-threads", type=int, default=12,
                     help="OpenHEVC 'Frame' parallelisation (uvgComm setting video/OH_parallelization): pictures parsed concurrently; 1 = off")
     ap.add_argument("--profile-every", type=int, default=8, help="kernel timing with HIP events on every n-th picture")
     ap.add_argument("--sao", action="store_true", help="kvazaar sao=full (off at the ultrafast preset the headline workload uses)")

@@ -96,7 +96,26 @@ struct CabacDec {
     refill();
     return b;
   }
-  inline uint32_t bypass_bits(int n) { uint32_t v = 0; for (int i = 0; i < n; i++) v = (v << 1) | (uint32_t)bypass(); return v; }
+  // n bypass bins at once: they are the n-bit quotient of value by range << (bits - n) (binary long division, one step per
+  // bin); refill() keeps bits >= 16, so up to 16 bins go in one division
+  inline uint32_t bypass_bits(int n)
+  {
+    uint32_t v = 0;
+    while (n > 0) {
+      const int m = n > 16 ? 16 : n;
+      if (m <= 2) { for (int i = 0; i < m; i++) v = (v << 1) | (uint32_t)bypass(); }
+      else {
+        bits -= m;
+        const uint64_t scaled = (uint64_t)range << bits;
+        const uint64_t q = value / scaled;
+        value -= q * scaled;
+        v = (v << m) | (uint32_t)q;
+        refill();
+      }
+      n -= m;
+    }
+    return v;
+  }
   int terminate()
   {
     range -= 2;
@@ -120,7 +139,7 @@ const CoreTabs *host_tabs()
 }
 
 // scan position -> (x, y) for the three scans and block sizes 1..8 (H.265 6.5.3-6.5.5)
-struct ScanTabs { uint8_t x[3][4][64], y[3][4][64], inv[3][4][64]; };     // inv[scan][log2 of the grid][y << log2 | x] = scan position
+struct ScanTabs { uint8_t x[3][4][64], y[3][4][64], inv[3][4][64], sigk[3][5][16]; };   // sigk[scan][prev_csbf, 4 = 4x4 block][scan position k] = context pattern     // inv[scan][log2 of the grid][y << log2 | x] = scan position
 const ScanTabs &scan_tabs()
 {
   static const ScanTabs t = [] {
@@ -128,6 +147,10 @@ const ScanTabs &scan_tabs()
     const CoreTabs *ct = host_tabs();
     for (int sc = 0; sc < 3; sc++) for (int l2 = 0; l2 < 4; l2++) for (int i = 0; i < (1 << (2 * l2)); i++) {
       int x, y; scan_pos(ct, sc, l2, i, x, y); t.x[sc][l2][i] = (uint8_t)x; t.y[sc][l2][i] = (uint8_t)y; t.inv[sc][l2][(y << l2) | x] = (uint8_t)i;
+    }
+    for (int sc = 0; sc < 3; sc++) for (int k = 0; k < 16; k++) {
+      for (int pc = 0; pc < 4; pc++) t.sigk[sc][pc][k] = ct->sigpat[pc][ct->pos4[sc][k]];
+      t.sigk[sc][4][k] = ct->ctxmap4x4[ct->pos4[sc][k]];
     }
     return t;
   }();
@@ -192,12 +215,12 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, std::vector<u
     const int prev_csbf = right | (below << 1);
     // sig_coeff_flag contexts (9.3.4.2.5) from tables: pattern by the neighbouring sub-blocks' flags and the position inside
     // the sub-block, plus an offset that is constant over the sub-block
-    const uint8_t *pat = log2 == 2 ? t->ctxmap4x4 : t->sigpat[prev_csbf], *rp = t->pos4[scan_idx];
+    const uint8_t *pk = S.sigk[scan_idx][log2 == 2 ? 4 : prev_csbf];
     const int sig_base = CTX_SIG + (cidx ? 27 : 0);
     const int sig_off = log2 == 2 ? 0 : (cidx == 0 ? ((i > 0 ? 3 : 0) + ((log2 == 3) ? ((scan_idx == 0) ? 9 : 15) : 21)) : ((log2 == 3) ? 9 : 12));
     for (int k = (i == last_sb) ? last_pos - 1 : 15; k >= 0; k--) {
       if (k > 0 || !infer_dc) {
-        const int sc = (k == 0 && i == 0 && log2 != 2) ? 0 : pat[rp[k]] + sig_off;      // (the DC coefficient of the block has its own context)
+        const int sc = (k == 0 && i == 0 && log2 != 2) ? 0 : pk[k] + sig_off;      // (the DC coefficient of the block has its own context)
         const int b = c.bin(sig_base + sc);
         sig |= (uint32_t)b << k; infer_dc &= b ^ 1;
       } else sig |= 1u;            // k == 0 with every other flag of a coded sub-block zero: inferred

@@ -1160,6 +1160,75 @@ __global__ __launch_bounds__(256) void k_qp_chain(EncFrame f)                // 
 // =============================================================================================
 // Deblocking: all vertical edges of the picture, then (second launch) all horizontal edges
 // =============================================================================================
+// Both deblocking passes in one launch (whole pictures; the band mode of the tile-row split keeps the two kernels below: it
+// exchanges halo rows between them).  A workgroup owns the 64x64 tile shifted by (-4, -4) against the CTU grid: every sample
+// a vertical edge x = 64 tx + 8 e or a horizontal edge y = 64 ty + 8 e of this CTU can modify (three each side) or read (four)
+// lies inside the tile, and the tiles partition the picture -- so the tile goes to LDS once, is filtered vertically, then
+// horizontally on the vertically filtered samples (8.7.2: the whole picture's vertical edges come first), and goes back.
+__global__ __launch_bounds__(256) void k_deblock_tile(EncFrame f)
+{
+  constexpr int P = 68, PC = 36;                           // (the last tile of a row / column is four samples larger: it takes the picture's last four columns / rows along)
+  __shared__ __attribute__((aligned(16))) uint8_t ty_[68 * P];
+  __shared__ __attribute__((aligned(16))) uint8_t tc_[2][34 * PC];
+  const int tid = threadIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
+  const int lin = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), tx = lin % wc, tyi = lin / wc;
+  const int X0 = tx * 64 - 4, Y0 = tyi * 64 - 4, CX0 = X0 >> 1, CY0 = Y0 >> 1, cw2 = f.cw >> 1;
+  const int TW = tx == wc - 1 ? 68 : 64, TH = tyi == hc - 1 ? 68 : 64;
+  // ---- tile in (luma as dwords: X0 is a multiple of 4; chroma as sample pairs)
+  for (int i = tid; i < TH * 17; i += 256) {
+    const int y = i / 17, x = (i - y * 17) * 4, gx = X0 + x, gy = Y0 + y;
+    if (x < TW && gx >= 0 && gy >= 0) *(uint32_t *)&ty_[y * P + x] = *(const uint32_t *)&f.rec[0][(size_t)gy * f.cw + gx];
+  }
+  for (int i = tid; i < 2 * (TH / 2) * 17; i += 256) {
+    const int pl = i / ((TH / 2) * 17), r = i - pl * ((TH / 2) * 17), y = r / 17, x = (r - y * 17) * 2, gx = CX0 + x, gy = CY0 + y;
+    if (x < TW / 2 && gx >= 0 && gy >= 0) *(uint16_t *)&tc_[pl][y * PC + x] = *(const uint16_t *)&f.rec[1 + pl][(size_t)gy * cw2 + gx];
+  }
+  __syncthreads();
+  // ---- vertical edges: 8 edges x 16 (17) four-row segments
+  if (tid < 8 * (TH / 4)) {
+    const int x = tx * 64 + (tid & 7) * 8, y = Y0 + (tid >> 3) * 4;
+    if (x > 0 && y >= 0 && is_cu_edge_v(f, x, y)) {
+      const int bs = edge_bs(f, x - 1, y, x, y);
+      if (bs) {
+        const int qp = (cu_qpy(f, x - 1, y) + cu_qpy(f, x, y) + 1) >> 1;            // QpP and QpQ averaged (8.7.2.5.3)
+        deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], 1, P, bs, qp);
+        if (bs == 2 && (x & 15) == 0) {
+          const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0);
+          deblock_chroma_segment(&tc_[0][o], 1, PC, 2, qp);
+          deblock_chroma_segment(&tc_[1][o], 1, PC, 2, qp);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- horizontal edges: 8 edges x 16 (17) four-column segments, on the vertically filtered samples
+  if (tid < 8 * (TW / 4)) {
+    const int y = tyi * 64 + (tid & 7) * 8, x = X0 + (tid >> 3) * 4;
+    if (y > 0 && x >= 0 && is_cu_edge_h(f, x, y)) {
+      const int bs = edge_bs(f, x, y - 1, x, y);
+      if (bs) {
+        const int qp = (cu_qpy(f, x, y - 1) + cu_qpy(f, x, y) + 1) >> 1;
+        deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], P, 1, bs, qp);
+        if (bs == 2 && (y & 15) == 0) {
+          const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0);
+          deblock_chroma_segment(&tc_[0][o], PC, 1, 2, qp);
+          deblock_chroma_segment(&tc_[1][o], PC, 1, 2, qp);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- tile out
+  for (int i = tid; i < TH * 17; i += 256) {
+    const int y = i / 17, x = (i - y * 17) * 4, gx = X0 + x, gy = Y0 + y;
+    if (x < TW && gx >= 0 && gy >= 0) *(uint32_t *)&f.rec[0][(size_t)gy * f.cw + gx] = *(const uint32_t *)&ty_[y * P + x];
+  }
+  for (int i = tid; i < 2 * (TH / 2) * 17; i += 256) {
+    const int pl = i / ((TH / 2) * 17), r = i - pl * ((TH / 2) * 17), y = r / 17, x = (r - y * 17) * 2, gx = CX0 + x, gy = CY0 + y;
+    if (x < TW / 2 && gx >= 0 && gy >= 0) *(uint16_t *)&f.rec[1 + pl][(size_t)gy * cw2 + gx] = *(const uint16_t *)&tc_[pl][y * PC + x];
+  }
+}
+
 __global__ __launch_bounds__(256) void k_deblock_v(EncFrame f)
 {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1796,7 +1865,11 @@ void launch_deblock_h(const EncFrame &f, hipStream_t st)
   int nh = (f.cw >> 2) * ((yhi - ylo) / 8 + 1);
   hipLaunchKernelGGL(k_deblock_h, dim3((nh + 255) / 256), dim3(256), 0, st, f);
 }
-void launch_deblock(const EncFrame &f, hipStream_t st) { launch_deblock_v(f, st); launch_deblock_h(f, st); }
+void launch_deblock(const EncFrame &f, hipStream_t st)
+{
+  if (f.nrows > 0) { launch_deblock_v(f, st); launch_deblock_h(f, st); return; }         // band of a tile-row split: two passes
+  hipLaunchKernelGGL(k_deblock_tile, dim3((f.cw / 64) * (f.ch / 64)), dim3(256), 0, st, f);
+}
 void launch_vaq(const EncFrame &f, int vaq, int *act, int *sum, hipStream_t st)
 {
   const int nctu = (f.cw / 64) * (f.ch / 64);

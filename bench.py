@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--decoder-frame-threads", type=int, default=12,
                     help="OpenHEVC 'Frame' parallelisation (uvgComm setting video/OH_parallelization): pictures parsed concurrently; 1 = off")
     ap.add_argument("--profile-every", type=int, default=8, help="kernel timing with HIP events on every n-th picture")
+    ap.add_argument("--full-search", action="store_true", help="me-early-termination=off: every 32x32 block is searched exhaustively (the k_me issue-rate roofline is reported for this case)")
     ap.add_argument("--sao", action="store_true", help="kvazaar sao=full (off at the ultrafast preset the headline workload uses)")
     ap.add_argument("--owf", type=int, default=3,
                     help="uvgComm setting video/OWF (kvazaar owf): 1 = host arithmetic coding of picture t overlaps the kernels of t + 1; "
@@ -228,7 +229,7 @@ def main():
     # source -> KvazaarFilter -> WireAdapter -> OpenHEVCFilter -> sink, one thread per filter (csrc/filters.hip)
     pl = Pipeline(w, h, settings={"video/QP": 32, "video/Intra": 64, "video/VPS": 1, "uvgx/gpu": local_rank, "uvgx/decoderDownload": 0,
                                   "video/OWF": args.owf, "video/OPENHEVC_threads": D, "video/OH_parallelization": "Frame" if D > 1 else "Slice"},
-                  custom=(("me-range", args.me_range), ("gpu", local_rank)) + ((("sao", "full"),) if args.sao else ()), loopback=True, keep_outputs=False)
+                  custom=(("me-range", args.me_range), ("gpu", local_rank)) + ((("sao", "full"),) if args.sao else ()) + ((("me-early-termination", "off"),) if args.full_search else ()), loopback=True, keep_outputs=False)
     lib = pl.lib
     enc_h, dec_h = pl.encoder_handle(), pl.decoder_handle()
     cw, ch = C.c_int(), C.c_int()
@@ -334,7 +335,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl["name"], "width": w, "height": h, "coded_width": cw, "coded_height": ch,
                        "frames_per_gpu": args.steps, "intra_period": 64, "qp": 32, "me_range": args.me_range,
-                       "streams": world, "bytes_per_frame": round(nbytes / args.steps, 1), "decoder_frame_threads": D, "owf": args.owf, "sao": bool(args.sao), "host_cpu_cores_busy": round(host_cores, 2), "host_cpu_budget_cores": round(budget, 1), "host_cpu_throttled_ms": round(throttled_ms, 1),
+                       "streams": world, "bytes_per_frame": round(nbytes / args.steps, 1), "decoder_frame_threads": D, "owf": args.owf, "sao": bool(args.sao), "me_early_termination": not args.full_search, "host_cpu_cores_busy": round(host_cores, 2), "host_cpu_budget_cores": round(budget, 1), "host_cpu_throttled_ms": round(throttled_ms, 1),
                        "input": "I420 resident in HBM", "output": "Annex-B AU on host + decoded I420 in HBM"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
@@ -343,7 +344,7 @@ def main():
             "filter_busy_ms_per_step": {"KvazaarFilter": busy[0], "WireAdapter": busy[1], "OpenHEVCFilter": busy[2]},
             "kernel_share_of_step": {k: round(v[0] / v[1] * launches(k) / (elapsed * 1e3), 4) for k, v in kt.items() if v[1]},
         }
-        if "k_me" in kt and kt["k_me"][1]:
+        if args.full_search and "k_me" in kt and kt["k_me"][1]:
             # The motion search is integer VALU work, not streaming: its own ceiling is the issue rate of v_qsad_pk_u16_u8
             # (four 4-sample SADs per lane; measured ~24 cycles per wave instruction on gfx950, scratch/qsad_bench2.hip):
             # 1024 SIMDs x 2.4 GHz / 24 x 64 lanes x 16 sample differences.  Reported beside the HBM roofline the contract asks for.

@@ -38,6 +38,17 @@ __device__ __forceinline__ void xcd_block_2d(int &bx, int &by)
   by = lin / gx; bx = lin - by * gx;
 }
 
+// sum over the 64 lanes of a wave (every lane gets it); all lanes must be active
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);   // row_mirror: every lane holds its row-of-16 sum
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+         (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
 
 #define SPLIT_BITS 8
 
@@ -91,6 +102,30 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
   const int x0 = bx_ * 32, y0 = by_ * 32 + f.row0 * 64;
   const int R = f.range, W = 2 * R + 1, WW = 32 + 2 * R;
   const uint8_t *ref = f.ref[0], *src = f.src[0];
+  const uint32_t lam = (uint32_t)f.lambda_q4;
+  // the block itself, and (me-early-termination) its SAD against the co-located block of the reference: a block that differs
+  // from it by no more than quantisation noise is coded unsplit with the zero vector, without a search
+  if (tid == 0) red[0] = 0;
+  __syncthreads();
+  {
+    uint32_t s0 = 0;
+    for (int i = tid; i < 256; i += nthreads) {
+      const size_t g = (size_t)(y0 + (i >> 3)) * f.cw + x0 + (i & 7) * 4;
+      const uint32_t c = *reinterpret_cast<const uint32_t *>(src + g);
+      cur[i] = c;
+      if (f.me_early) s0 = __builtin_amdgcn_sad_u8(c, *reinterpret_cast<const uint32_t *>(ref + g), s0);
+    }
+    if (f.me_early) { s0 = wave_sum_u32(s0); if ((tid & 63) == 0) atomicAdd(&red[0], s0); }
+  }
+  __syncthreads();
+  if (f.me_early && red[0] <= 64u * lam) {
+    if (tid < 16) {
+      const int i = b8idx(f, x0 + (tid & 3) * 8, y0 + (tid >> 2) * 8);
+      f.cu_log2[i] = 5; f.cu_intra[i] = 0; f.cu_mv[i * 2] = 0; f.cu_mv[i * 2 + 1] = 0;
+    }
+    return;
+  }
+  __syncthreads();                                                     // (red[] is about to be re-initialised)
   for (int i = tid; i < (WW + 1) * (ME_WPITCH / 4); i += nthreads) {   // four window samples per thread; columns >= WW and row WW are padding
     const int wy = i / (ME_WPITCH / 4), wx = (i - wy * (ME_WPITCH / 4)) * 4;
     const int gy = clip3(0, f.ch - 1, y0 - R + wy), gx = x0 - R + wx;
@@ -105,10 +140,8 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
     }
     *(uint32_t *)&win[wy * ME_WPITCH + wx] = v;
   }
-  for (int i = tid; i < 256; i += nthreads) cur[i] = *reinterpret_cast<const uint32_t *>(src + (y0 + (i >> 3)) * f.cw + x0 + (i & 7) * 4);
   if (tid < 5) red[tid] = 0xffffffffu;
   __syncthreads();
-  const uint32_t lam = (uint32_t)f.lambda_q4;
   uint32_t best[5] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
   // tile constraint (statement: me_block32() in oracle/hevc_enc.c): the displaced 32x32 block, plus 4 rows each side for
   // the chroma half-sample taps when the displacement is odd, stays inside its tile -- except across the picture's own edges
@@ -745,15 +778,6 @@ __device__ __forceinline__ int pred_angular(const uint8_t *R, bool vert, bool ed
 // kernel); a work item is (block, mode), one wave each: the mode is wave-uniform, 64 samples per step, the
 // SAD is summed with DPP row operations.
 // =============================================================================================
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
-{
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);   // row_half_mirror
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);   // row_mirror: every lane holds its row-of-16 sum
-  return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
-         (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-}
 
 struct AnalyseLds {
   alignas(16) uint8_t src[32 * 32];

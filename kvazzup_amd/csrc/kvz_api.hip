@@ -43,6 +43,7 @@ int config_init(kvz_config *cfg)
   cfg->pu_depth_inter_min = 1; cfg->pu_depth_inter_max = 2; cfg->pu_depth_intra_min = 1; cfg->pu_depth_intra_max = 3;
   cfg->me_range = 16; cfg->gpu_device = 0; cfg->recon_output = 1;
   cfg->threads = -1;                                    // auto, as in Kvazaar
+  cfg->me_early_termination = 1;                        // on, as in Kvazaar
   return 1;
 }
 
@@ -246,6 +247,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.band_row0 = cfg->band_row0; ec.band_rows = cfg->band_rows;
   // "threads" (uvgComm video/kvzThreads: auto = core count, Main = 0): what is threaded on the host here is the arithmetic coder
   ec.entropy_threads = cfg->threads < 0 ? 16 : (cfg->threads == 0 ? 1 : (cfg->threads > 16 ? 16 : cfg->threads));
+  ec.me_early = cfg->me_early_termination != 0;
   ec.vaq = cfg->vaq > 0 ? cfg->vaq : 0;
   ec.qp_in_cu = (cfg->set_qp_in_cu || ec.vaq > 0) ? 1 : 0;
   ec.sao = cfg->sao_type == KVZ_SAO_FULL;

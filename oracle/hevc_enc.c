@@ -53,7 +53,7 @@ void orc_enc_default_config(orc_enc_config *c)
 {
   memset(c, 0, sizeof(*c));
   c->qp = 32; c->intra_period = 64; c->vps_period = 1; c->search_range = 16;
-  c->fps_num = 30; c->fps_den = 1; c->wpp = 1; c->deblock = 1; c->tile_rows = 1;
+  c->fps_num = 30; c->fps_den = 1; c->wpp = 1; c->deblock = 1; c->tile_rows = 1; c->me_early = 1;
 }
 
 int orc_mvd_bits(int q)
@@ -350,6 +350,18 @@ static void me_block32(orc_encoder *e, int x0, int y0)
   uint32_t lam = orc_lambda_q4[e->qp];
   uint32_t best16[4] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu }, best32 = 0xffffffffu;
   int idx = 0;
+  if (e->cfg.me_early) {                              /* early termination: static content is not searched */
+    uint32_t s0 = 0;
+    for (int k = 0; k < 4; k++) {
+      int bx = x0 + (k & 1) * 16, by = y0 + (k >> 1) * 16;
+      s0 += sad16(e->src[0] + by * e->cw + bx, e->cw, e->refpad + (size_t)(by + ME_PAD) * st + bx + ME_PAD, st);
+    }
+    if (s0 <= 64u * lam) {
+      set_cu(e, e->cu_log2, x0, y0, 32, 5);
+      for (int y = y0; y < y0 + 32; y += 8) for (int x = x0; x < x0 + 32; x += 8) { e->cu_mv[b8i(e, x, y) * 2] = 0; e->cu_mv[b8i(e, x, y) * 2 + 1] = 0; }
+      return;
+    }
+  }
   /* Tile constraint: the 32x32 block displaced by dy (plus 4 rows each side for the chroma half-sample taps when dy is
    * odd) must stay inside its tile, except across the picture's own top and bottom edges where padding is normative. */
   int ty0 = 0, ty1 = e->ch;

@@ -36,6 +36,9 @@ typedef struct {
   int qp_in_cu;               /* 1: cu_qp_delta_enabled_flag, quantisation group = CTU: a delta-QP map set with orc_enc_set_roi()
                                * gives every CTU its own QP (kvz_picture.roi, kvazaarfilter.cpp:423-431) */
   int bitrate;                /* bits per second; 0 = constant QP.  > 0: "uvgx rate control v1" (see hevc_enc.c) */
+  int me_early;               /* kvazaar me-early-termination (on by default, as in Kvazaar): a 32x32 block whose SAD against the co-located
+                               * block of the reference is at most 64 * lambda_q4 (about what quantisation noise alone leaves at this QP) is
+                               * coded unsplit with the zero vector, without a search */
   int vaq;                    /* 0 off, 1..20: variance adaptive quantisation "uvgx VAQ v1" (see vaq_deltas() in hevc_enc.c): CTUs with less
                                * texture than the picture's average get a lower QP, busier ones a higher one; implies qp_in_cu */
   int mv_frame;               /* kvazaar mv-constraint frame / frametile (1) / frametilemargin (2): a candidate is dropped when the

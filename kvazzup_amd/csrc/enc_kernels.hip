@@ -5,17 +5,23 @@
 // transform/quantisation, reconstruction, deblocking and CABAC.  The arithmetic is checked
 // against oracle/ (tests/); the decisions follow "uvgx encoder algorithm v1" (oracle/hevc_enc.h).
 //
-// Launch geometry (coded size is a multiple of 64):
-//   k_me            one 256-thread workgroup per 32x32 luma block; search window staged in LDS,
-//                   SADs by v_sad_u8 on dwords, wave-level min-reduction of (cost << 13 | index)
-//   k_inter_recon   one workgroup per 32x32 block: MC, residual, DCT, quant, dequant, IDCT, recon
+// Launch geometry (coded size is a multiple of 64; DESIGN.md section 5 has the table with timings):
+//   k_pad_input     packed I420 -> padded planes, four samples per thread
+//   k_vaq_stats/apply  per-CTU luma variance -> delta QP (vaq only)
+//   k_me            one workgroup per 32x32 luma block (XCD-aware order): early termination on the co-located block, else the
+//                   search window staged in LDS, v_qsad_pk_u16_u8 on quads x pairs of candidates, wave min of (cost << 13 | index)
+//   k_inter_recon   one workgroup per 32x32 block: MC, residual, DCT (32x32: MFMA i8), quant, dequant, IDCT, reconstruction;
+//                   <true>: decoder (levels given; fractional vectors through a separable LDS pass; short path without residual)
 //   k_inter_signal  one thread per 16x16 block: merge / skip / AMVP signalling
 //   k_intra_analyse one workgroup per 32x32 block: 35-mode SAD search on source samples
-//   k_intra_recon   one wave per (CTU row, colour plane), wavefront over rows through progress counters
-//   k_deblock_v/h   one thread per 4-sample edge segment
-//   k_tokenize      one wave per CTU: binarisation + context selection of every syntax element
-//                   (one lane per 4x4 sub-block of a transform block) -> bins as 16-bit tokens;
-//                   k_tok_scan / k_tok_compact pack them for the host arithmetic coder
+//   k_intra_recon   one 256-thread workgroup per (CTU row, colour plane), wavefront over rows through progress counters
+//   k_qp_first/chain  per-CTU QP bookkeeping (cu_qp_delta)
+//   k_deblock_tile  one workgroup per 64x64 tile shifted by (-4, -4): vertical then horizontal edges in LDS
+//                   (k_deblock_v / k_deblock_h: one thread per 4-sample edge segment, band mode of the tile-row split)
+//   k_sao           one workgroup per CTU: statistics + decision (encoder) and the filter
+//   k_tokenize      one wave per 16x16 unit (and colour component): binarisation + context selection -> bins as 16-bit tokens;
+//   k_tok_compact   restores coding order per CTU, dense copy to host-mapped memory for the host arithmetic coder
+//   k_scatter_levels  decoder: packed level words -> plane-shaped level arrays
 #include <hip/hip_runtime.h>
 #include "hevc_core.h"
 #include "enc_kernels.h"

@@ -149,6 +149,7 @@ class Decoder {
   uint32_t *sync_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
   uint8_t *h_out_ = nullptr; size_t h_out_cap_ = 0;
   long launched_ = 0; int out_idx_ = 0; bool have_ref_ = false;
+  double t_parse_max_ = 0;                // trace: the longest parse of one picture (an IDR), ms
   bool spin_wait_ = false;                // KVAZZUP_AMD_SPIN: poll the GPU instead of napping between queries
   PicJob *gpu_job_ = nullptr;             // picture whose kernels are in flight (frame-threaded mode)
   int poc_ = 0, prev_poc_ = 0;

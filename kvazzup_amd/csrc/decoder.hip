@@ -276,7 +276,7 @@ void Decoder::drop_pending()
 Decoder::~Decoder()
 {
   if (getenv("KVAZZUP_AMD_TRACE")) fprintf(stderr, "kvazzup_amd parse Mcycles: split %.1f  skip/pred %.1f  intra/merge/amvp %.1f  residual %.1f  records %.1f  ctu-end %.1f\n", g_tc[0] * 1e-6, g_tc[1] * 1e-6, g_tc[2] * 1e-6, g_tc[3] * 1e-6, g_tc[4] * 1e-6, g_tc[5] * 1e-6);
-  if (getenv("KVAZZUP_AMD_TRACE")) fprintf(stderr, "kvazzup_amd decoder thread ms: nal %.1f  wait_parse %.1f  stage %.1f  gpu_api %.1f  gpu_sync %.1f  (pictures %ld)\n", t_nal_, t_wait_, t_stage_, t_api_, t_sync_, job_tail_);
+  if (getenv("KVAZZUP_AMD_TRACE")) fprintf(stderr, "kvazzup_amd decoder thread ms: nal %.1f  wait_parse %.1f  stage %.1f  gpu_api %.1f  gpu_sync %.1f  longest parse %.2f  (pictures %ld)\n", t_nal_, t_wait_, t_stage_, t_api_, t_sync_, t_parse_max_, job_tail_);
   drop_pending();
   workers_.reset();
   if (stream_) hipStreamSynchronize(stream_);
@@ -651,6 +651,7 @@ int Decoder::finish_oldest()
     { Tick tk; while (job.state.load(std::memory_order_acquire) != 2) std::this_thread::yield(); t_wait_ += tk.ms(); }
     job.state.store(0, std::memory_order_relaxed);
     if (frame_threads_ > 1 && profiling_) { k_ms_[DK_HOST_PARSE] += job.parse_ms; k_n_[DK_HOST_PARSE]++; }
+    if (job.parse_ms > t_parse_max_) t_parse_max_ = job.parse_ms;
     if (job.rc < 0) return job.rc;
     int rc = launch_gpu(job);
     if (rc < 0) return rc;

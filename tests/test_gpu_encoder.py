@@ -203,7 +203,7 @@ def test_random_tool_combinations_match_oracle(gpu, seed):
     hc = (h + 63) // 64
     cfg = dict(qp=int(rng.integers(8, 46)), period=int(rng.choice([1, 2, 3, 5, 64])), me_range=int(rng.choice([1, 4, 8, 16, 32])),
                wpp=int(rng.integers(0, 2)), deblock=int(rng.integers(0, 2)), tile_rows=int(rng.integers(1, min(hc, 3) + 1)),
-               sao=int(rng.integers(0, 2)), qp_in_cu=int(rng.integers(0, 2)), bitrate=int(rng.choice([0, 0, 0, 150000, 2000000])), mv_frame=int(rng.choice([0, 0, 1, 2])), vaq=int(rng.choice([0, 0, 3, 12])))
+               sao=int(rng.integers(0, 2)), qp_in_cu=int(rng.integers(0, 2)), bitrate=int(rng.choice([0, 0, 0, 150000, 2000000])), mv_frame=int(rng.choice([0, 0, 1, 2])), vaq=int(rng.choice([0, 0, 3, 12])), me_early=int(rng.integers(0, 2)))
     owf = int(rng.choice([0, 1, 2, 3]))
     kind = int(rng.choice([0, 2]))
     frames = 9 if cfg["bitrate"] else 5              # (the rate controller starts moving the QP at the fourth picture)
@@ -212,7 +212,7 @@ def test_random_tool_combinations_match_oracle(gpu, seed):
     ge = Encoder(w, h, options=(("qp", cfg["qp"]), ("period", cfg["period"]), ("me-range", cfg["me_range"]), ("wpp", cfg["wpp"]),
                                 ("deblock", cfg["deblock"]), ("tiles", "1x%d" % cfg["tile_rows"]), ("sao", "full" if cfg["sao"] else "off"),
                                 ("set-qp-in-cu", cfg["qp_in_cu"]), ("owf", owf),
-                                ("mv-constraint", ("none", "frame", "frametilemargin")[cfg["mv_frame"]])) + ((("vaq", cfg["vaq"]),) if cfg["vaq"] else ()), fields={"target_bitrate": cfg["bitrate"]})
+                                ("mv-constraint", ("none", "frame", "frametilemargin")[cfg["mv_frame"]])) + ((("vaq", cfg["vaq"]),) if cfg["vaq"] else ()) + (("me-early-termination", "on" if cfg["me_early"] else "off"),), fields={"target_bitrate": cfg["bitrate"]})
     assert not ge.rejected, (cfg, ge.rejected)
     gd = Decoder()
     roi = None

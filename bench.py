@@ -176,7 +176,7 @@ def tilesplit_main(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=1536)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--me-range", type=int, default=16)

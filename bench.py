@@ -1,25 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json metric: HEVC encode+decode fps on synthetic YUV420 (uvgx-synth-v1).
 
-A "step" is one picture through the hot path: kvz_api-side encode (HIP kernels; input picture
-already resident in HBM) and libOpenHevc-side decode of the access unit it produced (host CABAC
-parse + HIP reconstruction, output left in HBM).  The two codecs sit in the C++ mirrors of
-uvgComm's KvazaarFilter and OpenHEVCFilter, each on its own thread as in the reference's filter
-graph, so picture t+1 is encoded while picture t is decoded; the timed region starts with the first
-push and ends when the last decoded picture has left the decoder.  N > 1 runs one independent stream
-per GPU (BASELINE configs[3]: multi-party call, no collective on the data path), weak scaling.
+A "step" is ONE INTRA PERIOD -- 64 pictures, the first an IDR -- through the hot path: kvz_api-side
+encode (HIP kernels; input pictures already resident in HBM) and libOpenHevc-side decode of the access
+units (host CABAC parse + HIP reconstruction, output left in HBM).  The two codecs sit in the C++ mirrors
+of uvgComm's KvazaarFilter and OpenHEVCFilter, each on its own thread as in the reference's filter graph.
+Whatever --steps says, the timed region therefore holds IDR and P pictures in the workload's own
+proportion (1 : 63).  The clock starts on an EMPTY, flushed pipeline and stops when the last timed picture
+has left the decoder (the pipeline is flushed again): nothing is in flight across either end.
+`value` stays frames/s; `config.pictures_per_step` = 64.
+
+--gpus N (N > 1) without a torch.distributed environment: this process launches N fresh rank processes
+(before anything here touches torch or the GPU) and forwards rank 0's line.  N > 1 runs one independent
+stream per GPU (BASELINE configs[3]: multi-party call, no collective on the data path), weak scaling;
+with fewer devices than ranks the ranks share devices and the barrier / max-over-ranks go through gloo.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description / DESIGN.md section 6).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PERIOD = 64                    # pictures per step = the intra period of the named workloads
+CLIP_FRAMES = 128              # the named clips are 128 pictures long; longer runs cycle them (the wrap falls on an IDR)
 WORKLOADS = {
     # BASELINE.json configs[1]: 1080p, preset=ultrafast, intra period 64, encode + decode on one GPU
     "1080p": dict(w=1920, h=1080, name="1080p-yuv420-ultrafast-p64-qp32-encode+decode", cfg_index=2),
@@ -37,33 +46,30 @@ def algorithmic_bytes(kernel, cw, ch, me_range):
     P = cw * ch
     if kernel == "k_me":                          # current block once + its search window once, per 32x32 block
         return (P // 1024) * (1024 + (32 + 2 * me_range) ** 2)
-    if kernel in ("k_inter_recon", "k_inter_recon<dec>"):
+    if kernel in ("k_inter_recon", "k_dec_inter", "k_inter_recon<dec>"):
         return int(4.5 * P) if kernel == "k_inter_recon" else int(3.0 * P)
-    if kernel in ("k_intra_recon", "k_intra_recon<dec>"):
+    if kernel in ("k_intra_recon", "k_dec_intra", "k_intra_recon<dec>"):  # source in + reconstruction out (+ the level words, counted with k_tokenize)
         return int(3.0 * P) if kernel == "k_intra_recon" else int(1.5 * P)
     if kernel == "k_intra_analyse":
         return P
-    if kernel == "k_deblock":
+    if kernel in ("k_deblock", "k_dec_deblock"):
         return int(3.0 * P)
     if kernel == "k_tokenize":                    # every level of the picture once (int16) + the per-8x8 CU records; tokens out not counted
         return int(3.0 * P) + (P // 64) * 11
     if kernel == "k_tok_compact":                 # the piece table of every CTU ([16 units][17 pieces] {offset, length}); tokens not counted
         return (P // 4096) * 16 * 17 * 8
-    if kernel in ("k_sao", "k_sao<dec>"):         # deblocked picture in, filtered picture out (+ the source picture for the statistics)
+    if kernel in ("k_sao", "k_dec_sao", "k_sao<dec>"):          # deblocked picture in, filtered picture out (+ the source picture for the statistics)
         return int(4.5 * P) if kernel == "k_sao" else int(3.0 * P)
     if kernel == "k_pad_input":
         return int(3.0 * P)
     if kernel == "k_inter_signal":
         return (P // 64) * 16
-    if kernel == "k_scatter_levels":
-        return int(3.0 * P)
     return P
 
 
 def cpu_budget(world):
     """CPU cores this rank may use: the container's CFS quota (cgroup v2 cpu.max) or the visible cores, shared by the ranks of
-    the node.  One stream needs ~13 cores at full rate (8 CABAC parse workers, 16 arithmetic-coder workers, the filter and
-    synchronisation threads); with less, the pools are sized down instead of letting the kernel throttle the whole job."""
+    the node."""
     cores = float(len(os.sched_getaffinity(0)))
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -98,155 +104,196 @@ def _thread_cpu():
     return out
 
 
-def cpu_baseline(w, h, frames, me_range):
-    """The CPU checker (oracle/, a scalar C port of the same algorithm) on a bounded sample."""
+# ---------------------------------------------------------------------------------------------------------------
+# cpu_baseline: the CPU checker (oracle/, a scalar C port of the same algorithm) on ALL host cores -- one
+# independent clip per core, each in its own process (the port has no threads of its own; a multi-party call is
+# independent streams anyway).  This is the only place bench.py touches oracle/.
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_worker(w, h, frames, me_range, seed):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
     oe = orc.OracleEncoder(w, h, qp=32, period=64, me_range=me_range)
     od = orc.OracleDecoder()
-    clip = [orc.synth_frame(0, 0x5EED0002, w, h, t) for t in range(frames)]
+    clip = [orc.synth_frame(0, seed, w, h, t) for t in range(frames)]
+    print("ready", flush=True)
+    sys.stdin.readline()                      # all workers start together
     t0 = time.time()
     n = 0
     for t, fr in enumerate(clip):
         au = oe.encode(fr)
         n += len(od.decode_au(au, t))
-    dt = time.time() - t0
-    oe.close()
-    od.close()
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d pictures %dx%d (1 intra + %d inter, search range %d), encode+decode by oracle/ (scalar C, one thread)" % (frames, w, h, frames - 1, me_range)}
+    print("done %d %.6f" % (n, time.time() - t0), flush=True)
+
+
+def cpu_baseline(w, h, frames, me_range, cores):
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "%d,%d,%d,%d,%d" % (w, h, frames, me_range, 0x5EED0002 + 16 * i)],
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for i in range(cores)]
+    try:
+        for p in procs:
+            if p.stdout.readline().strip() != "ready":
+                raise RuntimeError("cpu worker failed to start")
+        t0 = time.time()
+        for p in procs:
+            p.stdin.write("go\n"); p.stdin.flush()
+        n = 0
+        for p in procs:
+            tok = p.stdout.readline().split()
+            if len(tok) != 3 or tok[0] != "done":
+                raise RuntimeError("cpu worker failed")
+            n += int(tok[1])
+        dt = time.time() - t0
+    finally:
+        for p in procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+            p.wait()
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d clips (one per core, one process each) x %d pictures %dx%d (1 intra + %d inter, search range %d), encode+decode by oracle/ (scalar C port)"
+                      % (cores, frames, w, h, frames - 1, me_range)}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv):
+    """--gpus N without a torch.distributed environment: N fresh processes, one per rank (this process has not imported torch
+    or touched the GPU); rank 0 prints the line."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def init_dist(world, local_rank):
+    """device of this rank and the process group that brackets the timed region (no collective on the data path)"""
+    import torch
+    import torch.distributed as dist
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise RuntimeError("no GPU visible: this library has no CPU fallback")
+    dev_index = local_rank % ndev
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
+    backend = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if ndev >= world:
+            backend = "nccl"
+            dist.init_process_group("nccl", device_id=dev)
+        else:                                                     # ranks share devices: RCCL wants one device per rank
+            backend = "gloo"
+            dist.init_process_group("gloo")
+    return torch, dist, dev, dev_index, backend
+
+
+def barrier_max(dist, backend, dev, torch, value=None):
+    """barrier (value None) or max over ranks of `value`"""
+    if backend is None:
+        return value
+    if value is None:
+        dist.barrier()
+        return None
+    tt = torch.tensor([value], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
 
 
 def tilesplit_main(args):
     """BASELINE configs[4]: a single 8K picture stream, 8 full-width tile rows, split over the ranks (whole tile rows per
-    rank); the only exchange on the data path is the deblock halo (kvazzup_amd/tilesplit.py).  Encode only; strong scaling."""
+    rank); the only exchange on the data path is the deblock halo (kvazzup_amd/tilesplit.py).  Encode only; strong scaling.
+    A step = one picture here (the configuration is 'one 7680x4320 frame, repeated for timing')."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    import torch.distributed as dist
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    torch, dist, dev, dev_index, backend = init_dist(world, local_rank)
     from kvazzup_amd import synth
     from kvazzup_amd.tilesplit import BandEncoder
     wl = WORKLOADS["8k-tilesplit"]
     w, h, tile_rows = wl["w"], wl["h"], 8
     total = args.warmup + args.steps
-    clip = [synth.frame_torch(synth.MOVING, 0x5EED0005, w, h, t, dev) for t in range(total)]     # every rank holds the stream (a band only reads its rows)
+    nclip = min(total, 32)
+    clip = [synth.frame_torch(synth.MOVING, 0x5EED0005, w, h, t, dev) for t in range(nclip)]     # every rank holds the stream (a band only reads its rows)
     torch.cuda.synchronize()
-    be = BandEncoder(w, h, tile_rows, rank, world, options=(("qp", 32), ("period", 64), ("me-range", args.me_range)), device=local_rank,
+    be = BandEncoder(w, h, tile_rows, rank, world, options=(("qp", 32), ("period", 64), ("me-range", args.me_range)), device=dev_index,
                      dist=dist if world > 1 else None)
     nbytes = 0
     for t in range(args.warmup):
-        be.encode(clip[t].data_ptr())
+        be.encode(clip[t % nclip].data_ptr())
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier_max(dist, backend, dev, torch)
     t0 = time.perf_counter()
     for t in range(args.warmup, total):
-        au = be.encode(clip[t].data_ptr())
+        au = be.encode(clip[t % nclip].data_ptr())
         if au is not None:
             nbytes += len(au)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    barrier_max(dist, backend, dev, torch)
+    elapsed = barrier_max(dist, backend, dev, torch, time.perf_counter() - t0)
     if rank == 0:
         print(json.dumps({
             "metric": "hevc_encode_fps_one_stream_tile_row_split", "value": round(args.steps / elapsed, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl["name"], "width": w, "height": h, "tile_rows": tile_rows, "ranks": world, "ctu_rows_rank0": be.nrows,
+                       "pictures_per_step": 1, "collective_backend": backend,
                        "intra_period": 64, "qp": 32, "me_range": args.me_range, "bytes_per_frame": round(nbytes / args.steps, 1),
                        "halo_bytes_per_picture_and_rank": round(be.halo_bytes_exchanged / max(1, total), 1),
-                       "exchange": "2 halo blocks per internal boundary and picture (4 luma + 2x2 chroma rows + CU records), RCCL send/recv"},
-            "roofline": None, "cpu_baseline": None}))
+                       "exchange": "2 halo blocks per internal boundary and picture (4 luma + 2x2 chroma rows + CU records), send/recv"},
+            "roofline": None, "cpu_baseline": None}), flush=True)
     be.close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1536)
-    ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
-    ap.add_argument("--me-range", type=int, default=16)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=6)
-    ap.add_argument("--decoder-frame-threads", type=int, default=12,
-                    help="OpenHEVC 'Frame' parallelisation (uvgComm setting video/OH_parallelization): pictures parsed concurrently; 1 = off")
-    ap.add_argument("--profile-every", type=int, default=8, help="kernel timing with HIP events on every n-th picture")
-    ap.add_argument("--full-search", action="store_true", help="me-early-termination=off: every 32x32 block is searched exhaustively (the k_me issue-rate roofline is reported for this case)")
-    ap.add_argument("--sao", action="store_true", help="kvazaar sao=full (off at the ultrafast preset the headline workload uses)")
-    ap.add_argument("--owf", type=int, default=3,
-                    help="uvgComm setting video/OWF (kvazaar owf): 1 = host arithmetic coding of picture t overlaps the kernels of t + 1; "
-                         "2 = it runs on background threads and the output lags two pictures; 3 = one more picture in flight "
-                         "(the settings UI offers 0 .. core count, videosettings.cpp:488-493)")
-    args = ap.parse_args()
-    if args.workload == "8k-tilesplit":
-        return tilesplit_main(args)
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    import torch
-    import torch.distributed as dist
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
+def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync, quality):
+    """K = steps intra periods of one stream through KvazaarFilter' -> WireAdapter -> OpenHEVCFilter' on this rank's GPU.
+    Returns a dict of measurements.  sync(value=None) = barrier / max over ranks."""
     from kvazzup_amd import synth
-    from kvazzup_amd import _native as N
     from kvazzup_amd.pipeline import Pipeline
     import ctypes as C
-
-    wl = WORKLOADS[args.workload]
     w, h = wl["w"], wl["h"]
-    total = args.warmup + args.steps
     D = max(1, args.decoder_frame_threads)
     budget = float(os.environ.get("KVAZZUP_BENCH_CPU_BUDGET", 0)) or cpu_budget(world)
     if budget < 13.0:                                # not enough host CPU for the full thread complement: shrink the pools
         D = max(1, min(D, int(budget * 0.45 + 0.5)))
-        os.environ.setdefault("KVAZZUP_AMD_ENTROPY_THREADS", str(max(2, min(16, int(budget * 0.4)))))
-        os.environ.setdefault("KVAZZUP_AMD_PARSE_THREADS", str(max(1, min(16, int(budget * 0.4)))))       # (row-parallel parser of the synchronous decoder)
-    extra = (D if D > 1 else 0) + min(max(args.owf, 0), 3)   # pictures pushed after the timed ones: the encoder (owf) and the frame-threaded decoder deliver with a lag
+        os.environ["KVAZZUP_AMD_ENTROPY_THREADS"] = str(max(2, min(16, int(budget * 0.4))))
+        os.environ["KVAZZUP_AMD_PARSE_THREADS"] = str(max(1, min(16, int(budget * 0.4))))       # (row-parallel parser of the synchronous decoder)
     seed = 0x5EED0000 + wl["cfg_index"] + 16 * rank
     # synthetic clip generated directly in HBM (inputs resident before the timed region)
-    clip = [synth.frame_torch(synth.MOVING, seed, w, h, t, dev) for t in range(total + extra)]
+    clip = [synth.frame_torch(synth.MOVING, seed, w, h, t, dev) for t in range(CLIP_FRAMES)]
     torch.cuda.synchronize()
 
+    def make(keep, download):
+        return Pipeline(w, h, settings={"video/QP": 32, "video/Intra": PERIOD, "video/VPS": 1, "uvgx/gpu": dev_index, "uvgx/decoderDownload": int(download),
+                                        "video/OWF": args.owf, "video/OPENHEVC_threads": D, "video/OH_parallelization": "Frame" if D > 1 else "Slice"},
+                        custom=(("me-range", args.me_range), ("gpu", dev_index)) + ((("sao", "full"),) if args.sao else ()) + ((("me-early-termination", "off"),) if args.full_search else ()),
+                        loopback=True, keep_outputs=keep)
+
     # source -> KvazaarFilter -> WireAdapter -> OpenHEVCFilter -> sink, one thread per filter (csrc/filters.hip)
-    pl = Pipeline(w, h, settings={"video/QP": 32, "video/Intra": 64, "video/VPS": 1, "uvgx/gpu": local_rank, "uvgx/decoderDownload": 0,
-                                  "video/OWF": args.owf, "video/OPENHEVC_threads": D, "video/OH_parallelization": "Frame" if D > 1 else "Slice"},
-                  custom=(("me-range", args.me_range), ("gpu", local_rank)) + ((("sao", "full"),) if args.sao else ()) + ((("me-early-termination", "off"),) if args.full_search else ()), loopback=True, keep_outputs=False)
+    pl = make(False, False)
     lib = pl.lib
     enc_h, dec_h = pl.encoder_handle(), pl.decoder_handle()
     cw, ch = C.c_int(), C.c_int()
     lib.kvzx_encoder_coded_size(enc_h, C.byref(cw), C.byref(ch))
     cw, ch = cw.value, ch.value
 
-    def run(first, count):
-        """push pictures until `first + count` have been DECODED.  The feeder keeps the encoder filter's input buffer
-        short of its overflow threshold (a uvgComm filter drops inputs at 10 buffered, filter.cpp:151-222)."""
-        g = pl.pushed
-        last = min(first + count + extra, total + extra)
-        while g < last:
-            if not pl.push_device_paced(clip[g].data_ptr(), 6, 120000):
+    def run(npic):
+        """push `npic` more pictures, flush the pipeline, wait until every one of them has been decoded.  The feeder keeps the
+        encoder filter's input buffer short of its overflow threshold (a uvgComm filter drops inputs at 10 buffered, filter.cpp:151-222)."""
+        last = pl.pushed + npic
+        while pl.pushed < last:
+            if not pl.push_device_paced(clip[pl.pushed % CLIP_FRAMES].data_ptr(), 6, 120000):
                 raise RuntimeError("pipeline stalled")
-            g += 1
-        if not pl.wait(first + count, 120000):
-            raise RuntimeError("pipeline did not deliver %d pictures" % (first + count))
+        pl.flush()
+        if not pl.wait(last, 120000):
+            raise RuntimeError("pipeline did not deliver %d pictures: %r" % (last, pl.stats()))
 
     def times(reset):
         ms = (C.c_double * 16)()
@@ -262,24 +309,25 @@ def main():
             out[name] = (a[0] + ms[i], a[1] + n[i])
         return out
 
-    run(0, args.warmup)
+    run(max(1, warmup) * PERIOD if warmup > 0 else 8)         # warm-up: whole periods, so that the first timed picture is an IDR (8 pictures when --warmup 0: the pipeline must at least be built)
+    if pl.pushed % PERIOD:
+        run(PERIOD - pl.pushed % PERIOD)
     # HIP events around every kernel of every 8th picture of the timed region (IDR pictures fall on multiples of 8)
     prof = 0 if os.environ.get("KVAZZUP_BENCH_NOPROF") else args.profile_every
     lib.kvzx_encoder_set_profiling(enc_h, prof)
     lib.kvzx_decoder_set_profiling(dec_h, prof)
     busy0 = pl.busy_ms()
+    st0 = pl.stats()
     times(True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    torch.cuda.synchronize()                                   # the pipeline is empty: everything pushed so far has been decoded
+    sync()
     cpu0 = time.process_time()
     thr0 = _throttled_us()
     _thr0 = _thread_cpu() if os.environ.get("KVAZZUP_BENCH_THREADS") else None
     t0 = time.perf_counter()
-    run(args.warmup, args.steps)
+    run(steps * PERIOD)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    sync()
     elapsed = time.perf_counter() - t0
     throttled_ms = (_throttled_us() - thr0) / 1e3              # summed over the job's threads: > 0 means the CPU quota, not the GPU, set the pace for a while
     host_cores = (time.process_time() - cpu0) / elapsed        # CPU seconds of all threads of this rank per second of the timed region
@@ -289,77 +337,180 @@ def main():
         for dt, t, name in rows[:40]:
             if dt > 0:
                 print("thread %7d %-16s %.3f s (%.2f cores)" % (t, name, dt, dt / elapsed), file=sys.stderr)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = sync(elapsed)
     kt = times(False)
-    busy = [round((b - a) / args.steps, 4) for a, b in zip(busy0, pl.busy_ms())]
+    npic = steps * PERIOD
+    busy = [round((b - a) / npic, 4) for a, b in zip(busy0, pl.busy_ms())]
     st = pl.stats()
-    nbytes = st["encoded_bytes"] * args.steps / max(1, st["encoded_pictures"])
-    if st["decoded_pictures"] < total or st["dropped"]:
+    nbytes = st["encoded_bytes"] - st0["encoded_bytes"]
+    if st["decoded_pictures"] != pl.pushed or st["dropped"] or st["encoded_pictures"] - st0["encoded_pictures"] != npic:
         raise RuntimeError("pipeline lost pictures: %r" % (st,))
     pl.close()
 
-    if rank == 0:
-        fps = world * args.steps / elapsed
-        if not any(v[1] for v in kt.values()):
-            kt = {"k_none": (1e-9, 1)}          # KVAZZUP_BENCH_NOPROF=1: throughput-only run (no roofline)
-        # dominant kernel = largest share of the timed region: average launch time x launches in the region (the
-        # events sample every n-th picture, so the launch counts come from the picture types, not from the samples)
-        n_idr = sum(1 for t in range(args.warmup, total) if t % 64 == 0)
-        def launches(k):
-            if k.startswith("k_intra"):
-                return n_idr
-            if k in ("k_me", "k_inter_recon", "k_inter_signal", "k_inter_recon<dec>"):
-                return args.steps - n_idr
-            return args.steps
-        dom = max((k for k in kt if kt[k][1] > 0 and k.startswith("k_")), key=lambda k: kt[k][0] / kt[k][1] * launches(k))
-        avg_s = kt[dom][0] / kt[dom][1] / 1e3
-        ab = algorithmic_bytes(dom, cw, ch, args.me_range)
-        achieved = ab / avg_s / 1e9
-        # HBM traffic per launch: from the committed PMC passes of this same command (rocprofv3 --pmc cannot run inside
-        # the bench); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  null when no pass exists.
-        traffic, traffic_src = None, None
+    out = {"elapsed": elapsed, "pictures": npic, "cw": cw, "ch": ch, "kt": kt, "busy": busy, "bytes_per_picture": nbytes / npic, "D": D,
+           "host_cores": host_cores, "budget": budget, "throttled_ms": throttled_ms, "psnr_y": None}
+    if quality:
+        # Quality of what was just timed (untimed pass): one intra period through a second pipeline with the decoded pictures
+        # downloaded; luma PSNR of the decoder's output against the source, mean over the period's 64 pictures.
+        import numpy as np
+        q = make(True, True)
+        for t in range(PERIOD):
+            if not q.push_device_paced(clip[t].data_ptr(), 6, 120000):
+                raise RuntimeError("quality pass stalled")
+        q.flush()
+        if not q.wait(PERIOD, 120000):
+            raise RuntimeError("quality pass did not deliver")
+        ps = []
+        for t in range(PERIOD):
+            d = q.pop_decoded()
+            src = clip[t][:w * h].to(torch.int32)
+            dec = torch.from_numpy(np.ascontiguousarray(d["i420"][:w * h])).to(dev).to(torch.int32)
+            mse = float(((src - dec) ** 2).to(torch.float64).mean().item())
+            ps.append(99.0 if mse == 0 else 10.0 * float(np.log10(255.0 * 255.0 / mse)))
+        q.close()
+        out["psnr_y"] = round(sum(ps) / len(ps), 3)
+    return out
+
+
+def roofline_of(m, steps, me_range, workload_key):
+    """dominant kernel = largest share of the timed region: average launch time x launches in the region (the events sample
+    every n-th picture, so the launch counts come from the picture types, not from the samples)"""
+    kt, cw, ch = m["kt"], m["cw"], m["ch"]
+    if not any(v[1] for v in kt.values()):
+        return None, {}, {}            # KVAZZUP_BENCH_NOPROF=1: throughput-only run
+    n_idr, npic = steps, steps * PERIOD
+
+    def launches(k):
+        if k in ("k_intra_analyse", "k_intra_recon", "k_dec_intra", "k_intra_recon<dec>"):
+            return n_idr
+        if k in ("k_me", "k_inter_recon", "k_inter_signal", "k_dec_inter", "k_inter_recon<dec>"):
+            return npic - n_idr
+        return npic
+    kern = [k for k in kt if kt[k][1] > 0 and k.startswith("k_")]
+    dom = max(kern, key=lambda k: kt[k][0] / kt[k][1] * launches(k))
+    avg_s = kt[dom][0] / kt[dom][1] / 1e3
+    ab = algorithmic_bytes(dom, cw, ch, me_range)
+    achieved = ab / avg_s / 1e9
+    # HBM traffic per launch: from the committed PMC passes of this same command (rocprofv3 --pmc cannot run inside the bench);
+    # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  null when no pass exists.
+    traffic, traffic_src = None, None
+    for rnd in ("r02", "r01"):
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.workload)))
+            name = "profiles/%s_pmc_traffic_%s.json" % (rnd, workload_key)
+            pmc = json.load(open(os.path.join(ROOT, name)))
             traffic = pmc["kernels"][dom]["traffic_bytes"]
-            traffic_src = "profiles/r01_pmc_traffic_%s.json" % args.workload
+            traffic_src = name
+            break
         except Exception:
             pass
+    roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(avg_s * 1e6, 2)}
+    kernels_us = {k: round(v[0] / v[1] * 1e3, 2) for k, v in kt.items() if v[1]}
+    share = {k: round(v[0] / v[1] * launches(k) / (m["elapsed"] * 1e3), 4) for k, v in kt.items() if v[1]}
+    # every kernel against the HBM roofline (algorithmic bytes of one launch / its average duration)
+    per_kernel = {k: round(algorithmic_bytes(k, cw, ch, me_range) / (kt[k][0] / kt[k][1] / 1e3) / 1e9 / HBM_PEAK_GBS, 5) for k in kern}
+    roof["frac_by_kernel"] = per_kernel
+    return roof, kernels_us, share
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24, help="timed steps; a step = one intra period = 64 pictures")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up steps (intra periods)")
+    ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--me-range", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 4K line (configs[2], the north-star target) that a 1080p run appends as `secondary`")
+    ap.add_argument("--secondary-steps", type=int, default=8)
+    ap.add_argument("--cpu-frames", type=int, default=12, help="pictures per core in the cpu_baseline sample")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--decoder-frame-threads", type=int, default=12,
+                    help="OpenHEVC 'Frame' parallelisation (uvgComm setting video/OH_parallelization): pictures parsed concurrently; 1 = off")
+    ap.add_argument("--profile-every", type=int, default=8, help="kernel timing with HIP events on every n-th picture")
+    ap.add_argument("--full-search", action="store_true", help="me-early-termination=off: every 32x32 block is searched exhaustively (the k_me issue-rate roofline is reported for this case)")
+    ap.add_argument("--sao", action="store_true", help="kvazaar sao=full (off at the ultrafast preset the headline workload uses)")
+    ap.add_argument("--owf", type=int, default=3,
+                    help="uvgComm setting video/OWF (kvazaar owf): 1 = host arithmetic coding of picture t overlaps the kernels of t + 1; "
+                         "2 = it runs on background threads and the output lags two pictures; 3 = one more picture in flight "
+                         "(the settings UI offers 0 .. core count, videosettings.cpp:488-493)")
+    args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker(*[int(v) for v in args.cpu_worker.split(",")])
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.workload == "8k-tilesplit":
+        return tilesplit_main(args)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch, dist, dev, dev_index, backend = init_dist(world, local_rank)
+
+    def sync(value=None):
+        return barrier_max(dist, backend, dev, torch, value)
+
+    wl = WORKLOADS[args.workload]
+    w, h = wl["w"], wl["h"]
+    m = run_stream(args, wl, args.steps, args.warmup, torch, dev, dev_index, rank, world, sync, quality=(rank == 0))
+    sec = None
+    if world == 1 and args.workload == "1080p" and not args.no_secondary:
+        try:
+            sec = run_stream(args, WORKLOADS["4k"], max(1, min(args.steps, args.secondary_steps)), 1, torch, dev, dev_index, rank, world, sync, quality=True)
+        except Exception as e:       # the headline line must not be lost to the secondary one
+            sec = {"error": str(e)}
+
+    if rank == 0:
+        npic = args.steps * PERIOD
+        fps = world * npic / m["elapsed"]
+        roof, kernels_us, share = roofline_of(m, args.steps, args.me_range, args.workload)
         out = {
             "metric": "hevc_encode_decode_fps", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": round(m["elapsed"] / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": wl["name"], "width": w, "height": h, "coded_width": cw, "coded_height": ch,
-                       "frames_per_gpu": args.steps, "intra_period": 64, "qp": 32, "me_range": args.me_range,
-                       "streams": world, "bytes_per_frame": round(nbytes / args.steps, 1), "decoder_frame_threads": D, "owf": args.owf, "sao": bool(args.sao), "me_early_termination": not args.full_search, "host_cpu_cores_busy": round(host_cores, 2), "host_cpu_budget_cores": round(budget, 1), "host_cpu_throttled_ms": round(throttled_ms, 1),
+            "config": {"workload": wl["name"], "width": w, "height": h, "coded_width": m["cw"], "coded_height": m["ch"],
+                       "pictures_per_step": PERIOD, "step": "one intra period: 1 IDR + 63 P pictures, encode + decode", "pictures_per_gpu": npic,
+                       "ms_per_picture": round(m["elapsed"] / npic * 1e3, 5),
+                       "timed_region": "empty flushed pipeline -> last timed picture decoded and flushed out",
+                       "intra_period": PERIOD, "qp": 32, "me_range": args.me_range, "streams": world, "collective_backend": backend,
+                       "bits_per_picture": round(8 * m["bytes_per_picture"], 1), "psnr_y": m["psnr_y"],
+                       "decoder_frame_threads": m["D"], "owf": args.owf, "sao": bool(args.sao), "me_early_termination": not args.full_search,
+                       "host_cpu_cores_busy": round(m["host_cores"], 2), "host_cpu_budget_cores": round(m["budget"], 1), "host_cpu_throttled_ms": round(m["throttled_ms"], 1),
                        "input": "I420 resident in HBM", "output": "Annex-B AU on host + decoded I420 in HBM"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(avg_s * 1e6, 2)},
-            "kernels_us": {k: round(v[0] / v[1] * 1e3, 2) for k, v in kt.items() if v[1]},
-            "filter_busy_ms_per_step": {"KvazaarFilter": busy[0], "WireAdapter": busy[1], "OpenHEVCFilter": busy[2]},
-            "kernel_share_of_step": {k: round(v[0] / v[1] * launches(k) / (elapsed * 1e3), 4) for k, v in kt.items() if v[1]},
+            "roofline": roof,
+            "kernels_us": kernels_us,
+            "filter_busy_ms_per_picture": {"KvazaarFilter": m["busy"][0], "WireAdapter": m["busy"][1], "OpenHEVCFilter": m["busy"][2]},
+            "kernel_share_of_step": share,
         }
-        if args.full_search and "k_me" in kt and kt["k_me"][1]:
+        if sec is not None:
+            if "error" in sec:
+                out["secondary"] = {"workload": WORKLOADS["4k"]["name"], "error": sec["error"]}
+            else:
+                ssteps = max(1, min(args.steps, args.secondary_steps))
+                sroof, skern, _ = roofline_of(sec, ssteps, args.me_range, "4k")
+                out["secondary"] = {"workload": WORKLOADS["4k"]["name"], "value": round(sec["pictures"] / sec["elapsed"], 3), "unit": "frames/s",
+                                    "steps": ssteps, "pictures_per_step": PERIOD, "ms_per_step": round(sec["elapsed"] / ssteps * 1e3, 4),
+                                    "bits_per_picture": round(8 * sec["bytes_per_picture"], 1), "psnr_y": sec["psnr_y"],
+                                    "host_cpu_cores_busy": round(sec["host_cores"], 2), "roofline": sroof, "kernels_us": skern}
+        if args.full_search and "k_me" in m["kt"] and m["kt"]["k_me"][1]:
             # The motion search is integer VALU work, not streaming: its own ceiling is the issue rate of v_qsad_pk_u16_u8
-            # (four 4-sample SADs per lane; measured ~24 cycles per wave instruction on gfx950, scratch/qsad_bench2.hip):
-            # 1024 SIMDs x 2.4 GHz / 24 x 64 lanes x 16 sample differences.  Reported beside the HBM roofline the contract asks for.
+            # (four 4-sample SADs per lane; measured ~24 cycles per wave instruction on gfx950, tools/qsad_bench.hip ->
+            # profiles/r02_qsad_bench.txt): 1024 SIMDs x 2.4 GHz / 24 x 64 lanes x 16 sample differences.
             W = 2 * args.me_range + 1
-            sads = (cw * ch // 1024) * W * W * 1024
-            me_s = kt["k_me"][0] / kt["k_me"][1] / 1e3
+            sads = (m["cw"] * m["ch"] // 1024) * W * W * 1024
+            me_s = m["kt"]["k_me"][0] / m["kt"]["k_me"][1] / 1e3
             peak = 1024 * 2.4e9 / 24 * 64 * 16
             out["roofline_valu"] = {"kernel": "k_me", "bound": "valu (v_qsad_pk_u16_u8 issue rate)", "achieved": round(sads / me_s / 1e12, 2),
                                     "peak": round(peak / 1e12, 2), "unit": "T sample-differences/s", "frac": round(sads / me_s / peak, 4)}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(w, h, args.cpu_frames, args.me_range)
+                out["cpu_baseline"] = cpu_baseline(w, h, args.cpu_frames, args.me_range, max(1, int(cpu_budget(1))))
             except Exception as e:       # the checker library is test infrastructure; report, do not fail the bench
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "failed: %s" % e}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

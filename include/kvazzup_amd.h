@@ -102,6 +102,10 @@ KVZ_PUBLIC int uvgx_pipeline_wait(void *p, uint64_t n_outputs, int timeout_ms);
  * drop inputs at 10 buffered, filter.cpp:151-222); 0 = timed out or rejected */
 KVZ_PUBLIC int uvgx_pipeline_push_device_paced(void *p, const void *d_i420, int w, int h, int fps_num, int fps_den, int64_t pts, uint32_t max_backlog, int timeout_ms);
 KVZ_PUBLIC uint32_t uvgx_pipeline_encoder_backlog(void *p);
+/* harness only (uvgComm never flushes a running graph): the pictures held back by video/OWF and by the decoder's frame threads
+ * come out without further input -- the encoder filter runs its encoder_encode(NULL) loop to the end, the wire adapter sends
+ * end-of-sequence NAL units.  The next picture pushed should be an IDR. */
+KVZ_PUBLIC int uvgx_pipeline_flush(void *p);
 KVZ_PUBLIC int uvgx_pipeline_pop_encoded(void *p, uint8_t *buf, uint32_t cap, uint32_t *size, int64_t *pts);
 KVZ_PUBLIC int uvgx_pipeline_pop_decoded(void *p, uint8_t *buf, uint32_t cap, uint32_t *size, int *w, int *h, int64_t *pts);
 KVZ_PUBLIC void uvgx_pipeline_stats(void *p, uint64_t *out8);

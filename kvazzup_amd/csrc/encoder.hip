@@ -335,10 +335,12 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
     timed(K_INTER_RECON, stream_, [&] { launch_inter_recon(f, stream_); });
   }
   launch_qp_resolve(f, stream_);                                 // per-CTU QP: which CU carries the delta, QpY for deblocking
-  HIP_CHECK(hipEventRecord(ev_signalled_, stream_));             // levels, cbf and motion of the picture are final; source set read
-  HIP_CHECK(hipEventRecord(ev_src_free_[set_], stream_)); src_busy_[set_] = true;
+  HIP_CHECK(hipEventRecord(ev_signalled_, stream_));             // levels, cbf and motion of the picture are final
   if (cfg_.deblock) timed(K_DEBLOCK, stream_, [&] { launch_deblock(f, stream_); });
   if (cfg_.sao) { timed(K_SAO, stream_, [&] { launch_sao(f, stream_); }); HIP_CHECK(hipEventRecord(ev_sao_, stream_)); }
+  // Last reader of this set on the main stream: k_sao reads the source picture for its statistics, deblocking the CU records.
+  // Input padding and intra analysis of picture t + 2 (input stream) overwrite both and wait for this event.
+  HIP_CHECK(hipEventRecord(ev_src_free_[set_], stream_)); src_busy_[set_] = true;
   HIP_CHECK(hipStreamWaitEvent(stream_tok_, ev_signalled_, 0));
   if (!intra) timed(K_INTER_SIGNAL, stream_tok_, [&] { launch_inter_signal(f, stream_tok_); });
   if (cfg_.sao) HIP_CHECK(hipStreamWaitEvent(stream_tok_, ev_sao_, 0));      // the tokenizer codes the CTUs' SAO parameters

@@ -51,6 +51,9 @@ struct Data {
   // extension (not in the reference): picture already resident in HBM (packed I420); data stays empty
   const void *device_data = nullptr;
   const void *device_planes[3] = {nullptr, nullptr, nullptr}; int device_pitch[3] = {0, 0, 0};   // decoded I420 left in HBM
+  // extension (harness only; uvgComm never flushes a running graph): no payload -- the encoder filter outputs the pictures it
+  // still holds (video/OWF) and the wire adapter sends end-of-sequence NAL units, which drain the decoder's frame threads
+  bool flush_marker = false;
 };
 
 // Counterpart of StatisticsInterface (src/statisticsinterface.h:40,52,59): only what the two filters report
@@ -141,6 +144,8 @@ class KvazaarFilter : public Filter {
   struct FrameInfo { std::unique_ptr<Data> data; int8_t *roi_array; };
   std::deque<FrameInfo> encodingFrames_;
   std::vector<uint8_t> au_;                        // device-input path: access unit buffer
+  bool lastInputOnDevice_ = false;
+  void drain();
 };
 
 class OpenHEVCFilter : public Filter {

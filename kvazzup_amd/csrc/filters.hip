@@ -90,7 +90,7 @@ Data *Filter::deepDataCopy(const Data *o)
   Data *c = new Data;
   c->source = o->source; c->type = o->type; c->data_size = o->data_size;
   c->creationTimestamp = o->creationTimestamp; c->presentationTimestamp = o->presentationTimestamp;
-  c->device_data = o->device_data;
+  c->device_data = o->device_data; c->flush_marker = o->flush_marker;
   for (int i = 0; i < 3; i++) { c->device_planes[i] = o->device_planes[i]; c->device_pitch[i] = o->device_pitch[i]; }
   if (o->data) { c->data.reset(new uint8_t[o->data_size]); memcpy(c->data.get(), o->data.get(), o->data_size); }
   if (o->vInfo) {
@@ -274,6 +274,7 @@ void KvazaarFilter::feedInput(std::unique_ptr<Data> input) // kvazaarfilter.cpp:
   kvz_frame_info frame_info;
   kvz_data_chunk *data_out = nullptr;
   uint32_t len_out = 0;
+  if (input->flush_marker) { drain(); sendOutput(std::move(input)); return; }
   if (config_->width != input->vInfo->width || config_->height != input->vInfo->height ||
       config_->framerate_num != input->vInfo->framerateNumerator || config_->framerate_denom != input->vInfo->framerateDenominator) {
     fprintf(stderr, "KvazaarFilter: input resolution or framerate differs from settings\n");
@@ -288,6 +289,7 @@ void KvazaarFilter::feedInput(std::unique_ptr<Data> input) // kvazaarfilter.cpp:
     ++pts_;
     const void *dptr = input->device_data;
     input->device_data = nullptr;
+    lastInputOnDevice_ = true;
     encodingFrames_.push_front({std::move(input), nullptr});
     // with video/OWF >= 1 the access unit that comes back belongs to the previous picture (n == 0 on the first call)
     if (!kvzx_encoder_encode_device(enc_, dptr, au_.data(), (uint32_t)au_.size(), &n, &frame_info)) { encodingFrames_.pop_front(); return; }
@@ -300,6 +302,7 @@ void KvazaarFilter::feedInput(std::unique_ptr<Data> input) // kvazaarfilter.cpp:
     sendEncodedFrame(std::move(info.data), std::move(hevc_frame), n);
     return;
   }
+  lastInputOnDevice_ = false;
   kvz_picture *inputPic = getNextPic();
   const size_t ny = (size_t)input->vInfo->width * input->vInfo->height;
   memcpy(inputPic->y, input->data.get(), ny);
@@ -317,6 +320,30 @@ void KvazaarFilter::feedInput(std::unique_ptr<Data> input) // kvazaarfilter.cpp:
   while (data_out != nullptr) {
     parseEncodedFrame(data_out, len_out, recon_pic);
     api_->encoder_encode(enc_, nullptr, &data_out, &len_out, &recon_pic, nullptr, &frame_info);
+  }
+}
+
+// flush marker (harness extension): the pictures the encoder still holds (video/OWF) come out, like the reference's
+// encoder_encode(NULL) loop at kvazaarfilter.cpp:440-448 run to the end
+void KvazaarFilter::drain()
+{
+  kvz_frame_info frame_info;
+  while (!encodingFrames_.empty()) {
+    if (lastInputOnDevice_) {
+      uint32_t n = 0;
+      if (!kvzx_encoder_encode_device(enc_, nullptr, au_.data(), (uint32_t)au_.size(), &n, &frame_info) || n == 0) break;
+      FrameInfo info = std::move(encodingFrames_.back());
+      encodingFrames_.pop_back();
+      std::unique_ptr<uint8_t[]> hevc_frame(new uint8_t[n]);
+      memcpy(hevc_frame.get(), au_.data(), n);
+      if (getStats()) { getStats()->encodingDelaySumMs += (uint64_t)(now_ms() - info.data->creationTimestamp); getStats()->encodedPackets++; getStats()->encodedBytes += n; }
+      sendEncodedFrame(std::move(info.data), std::move(hevc_frame), n);
+    } else {
+      kvz_picture *recon_pic = nullptr; kvz_data_chunk *data_out = nullptr; uint32_t len_out = 0;
+      api_->encoder_encode(enc_, nullptr, &data_out, &len_out, &recon_pic, nullptr, &frame_info);
+      if (!data_out) break;
+      parseEncodedFrame(data_out, len_out, recon_pic);
+    }
   }
 }
 
@@ -467,6 +494,18 @@ void WireAdapter::process()
 {
   std::unique_ptr<Data> input = getInput();
   while (input) {
+    if (input->flush_marker) {
+      // end-of-sequence NAL units (type 36): each makes the decoder hand out one picture its frame threads still hold
+      for (int k = 0; k < 18; k++) {
+        std::unique_ptr<Data> nal(new Data);
+        nal->source = DS_REMOTE; nal->type = DT_HEVCVIDEO; nal->data_size = 6;
+        nal->data.reset(new uint8_t[6]{0, 0, 0, 1, 36 << 1, 1});
+        nal->vInfo.reset(new VideoInfo);
+        sendOutput(std::move(nal));
+      }
+      input = getInput();
+      continue;
+    }
     const uint8_t *p = input->data.get(); const uint32_t n = input->data_size;
     std::vector<uint32_t> starts;
     for (uint32_t i = 0; i + 3 < n; i++) if (p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 0 && p[i + 3] == 1) { starts.push_back(i); i += 3; }
@@ -560,6 +599,7 @@ KVZ_PUBLIC void *uvgx_pipeline_create(const char *settings_text, int loopback_de
   p->enc.reset(new KvazaarFilter("uvgx", &p->stats, &p->settings));
   if (!p->enc->init()) { delete p; return nullptr; }
   p->enc->addDataOutCallback([p](std::unique_ptr<Data> d) {
+    if (d->flush_marker) return;
     std::lock_guard<std::mutex> l(p->m);
     p->n_encoded++;
     if (p->keep) p->encoded.push_back(std::move(d));
@@ -613,6 +653,16 @@ KVZ_PUBLIC int uvgx_pipeline_wait(void *pp, uint64_t n, int timeout_ms)
   UvgxPipeline *p = (UvgxPipeline *)pp;
   std::unique_lock<std::mutex> l(p->m);
   return p->cv.wait_for(l, std::chrono::milliseconds(timeout_ms), [&] { return (p->loopback ? p->n_decoded : p->n_encoded) >= n; }) ? 1 : 0;
+}
+// everything pushed so far comes out without further input (then uvgx_pipeline_wait for the count)
+KVZ_PUBLIC int uvgx_pipeline_flush(void *pp)
+{
+  UvgxPipeline *p = (UvgxPipeline *)pp;
+  if (!p) return 0;
+  std::unique_ptr<Data> d(new Data);
+  d->flush_marker = true;
+  p->enc->putInput(std::move(d));
+  return 1;
 }
 KVZ_PUBLIC uint32_t uvgx_pipeline_encoder_backlog(void *pp) { return ((UvgxPipeline *)pp)->enc->bufferedInputs(); }
 // a source that paces itself: sleeps until the encoder filter buffers fewer than `max_backlog` pictures (a uvgComm filter drops

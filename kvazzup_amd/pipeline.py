@@ -15,6 +15,7 @@ def _bind(lib):
     lib.uvgx_pipeline_push_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64]
     lib.uvgx_pipeline_wait.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
     lib.uvgx_pipeline_push_device_paced.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint32, C.c_int]
+    lib.uvgx_pipeline_flush.argtypes = [C.c_void_p]
     lib.uvgx_pipeline_encoder_backlog.restype = C.c_uint32
     lib.uvgx_pipeline_encoder_backlog.argtypes = [C.c_void_p]
     lib.uvgx_pipeline_pop_encoded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]
@@ -73,6 +74,10 @@ class Pipeline:
         ok = self.lib.uvgx_pipeline_push_device_paced(self.p, dptr, self.w, self.h, self.fps[0], self.fps[1], self.pushed if pts is None else pts, max_backlog, timeout_ms)
         self.pushed += 1 if ok else 0
         return bool(ok)
+
+    def flush(self):
+        """everything pushed so far comes out without further input (harness only); the next picture pushed should be an IDR"""
+        self.lib.uvgx_pipeline_flush(self.p)
 
     def wait(self, n, timeout_ms=60000):
         return bool(self.lib.uvgx_pipeline_wait(self.p, n, timeout_ms))

@@ -53,6 +53,10 @@ KVZ_PUBLIC int kvzx_decoder_last_error(OpenHevc_Handle h);
 KVZ_PUBLIC int kvzx_decoder_output_device(OpenHevc_Handle h, const void **planes /*[3]*/, int *pitches /*[3]*/);
 /* when 0, libOpenHevcDecode leaves the picture in HBM and libOpenHevcGetOutput returns NULL planes */
 KVZ_PUBLIC void kvzx_decoder_set_download(OpenHevc_Handle h, int on);
+/* Lifetime of the device planes of kvzx_decoder_output_device (download off): they belong to the decoder's picture buffer and stay
+ * untouched -- read as a reference picture at most -- while the next `pictures` pictures are decoded (default 2, 1..8); after that the
+ * buffer may be reused.  A consumer that lags further must copy, or raise this. */
+KVZ_PUBLIC void kvzx_decoder_set_output_hold(OpenHevc_Handle h, int pictures);
 KVZ_PUBLIC void kvzx_decoder_set_profiling(OpenHevc_Handle h, int every);
 KVZ_PUBLIC int kvzx_decoder_kernel_times(OpenHevc_Handle h, double *ms, uint64_t *launches, int reset);
 KVZ_PUBLIC const char *kvzx_decoder_kernel_name(int id);

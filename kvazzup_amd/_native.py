@@ -105,7 +105,7 @@ DECODER_EXPORTS = ["libOpenHevcInit", "libOpenHevcStartDecoder", "libOpenHevcDec
                    "libOpenHevcGetPictureSize2", "libOpenHevcGetOutput", "libOpenHevcGetOutputCpy", "libOpenHevcSetCheckMD5",
                    "libOpenHevcSetDebugMode", "libOpenHevcSetTemporalLayer_id", "libOpenHevcSetNoCropping", "libOpenHevcSetActiveDecoders",
                    "libOpenHevcSetViewLayers", "libOpenHevcClose", "libOpenHevcFlush", "libOpenHevcVersion",
-                   "kvzx_decoder_set_device", "kvzx_decoder_last_error", "kvzx_decoder_output_device", "kvzx_decoder_set_download", "kvzx_decoder_set_profiling",
+                   "kvzx_decoder_set_device", "kvzx_decoder_last_error", "kvzx_decoder_output_device", "kvzx_decoder_set_download", "kvzx_decoder_set_output_hold", "kvzx_decoder_set_profiling",
                    "kvzx_decoder_kernel_times", "kvzx_decoder_kernel_name", "kvzx_decoder_debug_copy"]
 
 

@@ -165,11 +165,12 @@ def split_nals(au):
 class Decoder:
     """libOpenHevc* driven the way OpenHEVCFilter::init / process / sendDecodedOutput drive it."""
 
-    OH_THREAD_SLICE = 2
+    OH_THREAD_FRAME, OH_THREAD_SLICE = 1, 2
 
-    def __init__(self, threads=1, download=True, device=None):
+    def __init__(self, threads=1, download=True, device=None, frame_threads=False):
         self.lib = N.load_library()
-        self.h = self.lib.libOpenHevcInit(threads, self.OH_THREAD_SLICE)
+        self.threads, self.frame_threads = threads, bool(frame_threads) and threads > 1
+        self.h = self.lib.libOpenHevcInit(threads, self.OH_THREAD_FRAME if frame_threads else self.OH_THREAD_SLICE)
         if device is not None:
             self.lib.kvzx_decoder_set_device(self.h, device)
         if self.lib.libOpenHevcStartDecoder(self.h) == -1:
@@ -222,6 +223,17 @@ class Decoder:
 
     def decode_au(self, au, pts=0):
         return [f for f in (self.decode_nal(n, pts) for n in split_nals(au)) if f is not None]
+
+    def drain(self):
+        """frame threads: end-of-sequence NAL units hand out the pictures still held back"""
+        out = []
+        if self.frame_threads:
+            eos = bytes([0, 0, 0, 1, 36 << 1, 1])
+            for _ in range(self.threads + 1):
+                f = self.decode_nal(eos)
+                if f is not None:
+                    out.append(f)
+        return out
 
     def output_device(self):
         planes = (C.c_void_p * 3)()

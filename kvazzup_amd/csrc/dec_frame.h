@@ -1,0 +1,77 @@
+// kvazzup_amd/csrc/dec_frame.h -- what the host half of the decoder (CABAC parse, decoder.hip) hands to the device half
+// (dec_kernels.hip) for one picture.  The decoder sits behind libOpenHevcDecode, which uvgComm feeds with any peer's
+// stream (/root/reference/src/media/processing/openhevcfilter.cpp:134-172), so the layout is general for Main-profile
+// I / P pictures: any coding quadtree with CTB 64 and minimum CB 8, every partitioning, transform trees down to 4x4,
+// several reference pictures, coded sizes that are multiples of 8.
+//
+// Everything lives in ONE pinned host block per picture that goes to the GPU in one copy:
+//   [ B4Rec x (ph/4 * pw/4) | region table | CTU table | SaoParams x CTUs | DecTu x ntu | level words ]
+#pragma once
+#include <stdint.h>
+#include "hevc_core.h"
+
+namespace kvzx {
+
+// per 4x4 luma block (raster, pitch pw / 4): motion for prediction, and what deblocking needs to derive the boundary strength
+// (8.7.2.4) -- transform / prediction block edges on the 8x8 grid, "transform block has coefficients", QpY
+struct B4Rec {
+  int16_t mvx, mvy;        // quarter luma samples
+  int8_t ref_idx;          // index into RefPicList0; -1 = intra (host: also what merge candidates compare, 8.5.3.2.3)
+  uint8_t flags;           // B4_*
+  int8_t qp_y;             // QpY of the coding unit (8.6.1)
+  uint8_t slot;            // picture buffer of the reference picture: two indices naming one picture share it (8.7.2.4 compares pictures)
+};
+enum { B4_NZ = 1,          // the luma transform block covering this 4x4 has non-zero coefficients
+       B4_EDGE_V = 2,      // the left edge of this 4x4 is a transform-block or prediction-block edge
+       B4_TU_V = 4,        //   ... a transform-block edge
+       B4_EDGE_H = 8, B4_TU_H = 16 };      // the same for the top edge
+
+// one transform block, in decoding order.  Intra blocks are listed even without coefficients (count == 0): they are the unit
+// of intra prediction (8.4.4.1).  x, y in samples of the block's own plane.
+struct DecTu {
+  uint16_t x, y;
+  uint8_t plane, log2;
+  uint8_t flags;           // TU_*
+  uint8_t mode;            // intra prediction mode of this block (chroma: already derived, 8.4.3)
+  int8_t qp;               // quantisation parameter of this block's plane (qP of 8.6.2: Qp'Y, Qp'Cb or Qp'Cr)
+  uint8_t pad;
+  uint16_t count;          // non-zero levels: `count` words (raster position inside the block << 16 | level & 0xffff) from word `offset`
+  uint32_t offset;
+};
+enum { TU_INTRA = 1, TU_TSKIP = 2, TU_DST = 4 };
+
+struct TuRange { uint32_t first, count; };
+
+#define KVZ_DEC_MAX_REFS 16
+
+// kernel argument of every decoder kernel
+struct DecFrame {
+  int w, h;                 // coded luma size (multiples of 8)
+  int pw, ph;               // luma pitch and allocated rows (multiples of 64); chroma planes pw / 2 x ph / 2
+  int wc, hc;               // CTUs (64 x 64) per row / column, partial ones included
+  const B4Rec *b4;          // [ph / 4][pw / 4]
+  const TuRange *region;      // per 32x32 luma region (raster, pitch 2 * wc): {first transform block, count} in tus[]
+  const TuRange *ctu;        // per CTU (raster): {first transform block, count | intra-planes mask << 24}
+  const DecTu *tus; const uint32_t *lev;
+  const uint8_t *ctu_tile;  // tile id of every CTU (raster)
+  uint8_t *rec[3];          // the picture being reconstructed (and deblocked in place)
+  uint8_t *out[3];          // SAO output (== rec planes of the picture buffer when SAO runs from a work picture)
+  const uint8_t *ref[KVZ_DEC_MAX_REFS][3];   // picture buffers by slot
+  const SaoParams *sao;     // per CTU; NULL = off
+  uint32_t *progress;       // intra wavefront: [CTU][plane] = 8x8 luma units of the CTU whose intra blocks are final
+  uint32_t *err;
+  int8_t cb_qp_offset, cr_qp_offset;       // pps_cb/cr_qp_offset (deblocking uses these, 8.7.2.5.5)
+  int8_t beta_offset, tc_offset;           // slice_beta_offset_div2 * 2, slice_tc_offset_div2 * 2
+  uint8_t strong_intra, tiles;             // strong_intra_smoothing_enabled_flag; more than one tile
+  uint8_t pad_[2];
+};
+
+// z-order index (0..63) of the 8x8 luma unit at (xi, yi) of a CTU, xi, yi in 0..7
+KVZ_HD int zunit8(int xi, int yi)
+{
+  int z = 0;
+  for (int b = 0; b < 3; b++) z |= ((xi >> b) & 1) << (2 * b) | ((yi >> b) & 1) << (2 * b + 1);
+  return z;
+}
+
+}  // namespace kvzx

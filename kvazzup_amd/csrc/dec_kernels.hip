@@ -1,0 +1,728 @@
+// kvazzup_amd/csrc/dec_kernels.hip -- CDNA4 (gfx950) kernels of the HEVC decoder hot path: what OpenHEVC does inside
+// libOpenHevcDecode (/root/reference/src/media/processing/openhevcfilter.cpp:145-146) after entropy decoding, for ANY
+// Main-profile I / P picture (dec_frame.h).  The arithmetic is checked against oracle/hevc_dec.c (tests/).
+//
+//   k_dec_inter    one workgroup per 32x32 luma region: motion compensation of its inter blocks at 4x4 granularity (integer
+//                  vectors: aligned dwords + v_alignbyte; fractional: separable 8-/4-tap through LDS windows per 8x8 cell),
+//                  then every inter transform block of the region -- level words scattered straight into LDS, dequantised,
+//                  inverse DCT by size class (4x4 .. 16x16: int16 v_dot2; 32x32: v_mfma_i32_16x16x64_i8), reconstruction
+//   k_dec_intra    one wave per (CTU, colour plane): the CTU's intra transform blocks in decoding order (prediction from the
+//                  neighbours, residual, reconstruction); CTUs are coupled by progress counters with 8x8 granularity, so a CTU
+//                  starts as soon as the part of its left / upper neighbours it reads is final, not when they are complete
+//   k_dec_deblock  one workgroup per 64x64 tile shifted by (-4, -4): boundary strengths from the 4x4 records, vertical then
+//                  horizontal edges in LDS
+//   k_dec_sao      one workgroup per CTU
+#include <hip/hip_runtime.h>
+#include "dec_frame.h"
+#include "dec_kernels.h"
+#include "kernel_common.h"
+
+namespace kvzx {
+
+__device__ __forceinline__ int zorder3(int x, int y)      // 3 + 3 bits
+{
+  int z = 0;
+#pragma unroll
+  for (int b = 0; b < 3; b++) z |= ((x >> b) & 1) << (2 * b) | ((y >> b) & 1) << (2 * b + 1);
+  return z;
+}
+__device__ __forceinline__ void unzorder3(int z, int &x, int &y)
+{
+  x = 0; y = 0;
+#pragma unroll
+  for (int b = 0; b < 3; b++) { x |= ((z >> (2 * b)) & 1) << b; y |= ((z >> (2 * b + 1)) & 1) << b; }
+}
+
+// ---- motion compensation primitives (8.5.3.3.3): `pitch` = allocated row length, (w, h) = picture size for the padding clamp
+__device__ __forceinline__ int refpx(const uint8_t *p, int pitch, int w, int h, int x, int y)
+{
+  return p[(size_t)clip3(0, h - 1, y) * pitch + clip3(0, w - 1, x)];
+}
+__device__ __forceinline__ int mc_luma_px(const uint8_t *p, int pitch, int w, int h, int x, int y, int mvx, int mvy)
+{
+  const int xf = mvx & 3, yf = mvy & 3, xi = x + (mvx >> 2), yi = y + (mvy >> 2);
+  int v;
+  if (!xf && !yf) return refpx(p, pitch, w, h, xi, yi);
+  if (!yf) { v = 0; for (int i = 0; i < 8; i++) v += kLumaFilter[xf][i] * refpx(p, pitch, w, h, xi + i - 3, yi); }
+  else if (!xf) { v = 0; for (int i = 0; i < 8; i++) v += kLumaFilter[yf][i] * refpx(p, pitch, w, h, xi, yi + i - 3); }
+  else {
+    v = 0;
+    for (int j = 0; j < 8; j++) {
+      int t = 0;
+      for (int i = 0; i < 8; i++) t += kLumaFilter[xf][i] * refpx(p, pitch, w, h, xi + i - 3, yi + j - 3);
+      v += kLumaFilter[yf][j] * t;
+    }
+    v >>= 6;
+  }
+  return clip8((v + 32) >> 6);
+}
+// four luma samples (x .. x + 3, y) with one INTEGER vector, packed little-endian
+__device__ __forceinline__ uint32_t mc_luma4_int(const uint8_t *p, int pitch, int w, int h, int x, int y, int mvx, int mvy)
+{
+  const int xi = x + (mvx >> 2), yi = clip3(0, h - 1, y + (mvy >> 2));
+  const uint8_t *row = p + (size_t)yi * pitch;
+  if (xi >= 0 && xi + 3 < w) {
+    const uint32_t *q = (const uint32_t *)(row + (xi & ~3));                 // planes are 4-byte aligned, pitch a multiple of 64, w of 8
+    const uint32_t lo = q[0], hi = (xi & 3) ? q[1] : 0u;
+    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(xi & 3));
+  }
+  uint32_t v = 0;
+  for (int i = 0; i < 4; i++) v |= (uint32_t)row[clip3(0, w - 1, xi + i)] << (8 * i);
+  return v;
+}
+
+// =============================================================================================
+// Inter prediction + residual of one 32x32 luma region
+// =============================================================================================
+#define DEC_MAX_TU 96                 // transform blocks of one 32x32 region: 64 luma 4x4 + 32 chroma 4x4
+struct DecInterLds {
+  // coefficients of every coded inter block of the region, each block contiguous and TRANSPOSED ([column][row]) at 16 x the
+  // z-order index of its first 4x4 unit: luma units 0..63 at [0, 1024), Cb 0..15 at [1024, 1280), Cr at [1280, 1536)
+  alignas(16) int16_t C[1536], B[1024];
+  alignas(16) int16_t M[2][KV_MATRIX_ENTRIES];
+  alignas(16) int8_t M8[32 * 32]; int rowsum[32];        // transposed 32-point matrix as int8 + its row sums (MFMA operands)
+  alignas(16) uint8_t px[1024 + 512];                    // prediction, then reconstruction: luma 32x32 raster; Cb, Cr 16x16 each
+  B4Rec recs[64];
+  uint8_t cflag[16];                                     // per 8x8 cell: bit0 inter, bit1 one motion for the whole cell, bit2 fractional luma vector
+  alignas(16) uint8_t lwin[16][15 * 16];                 // fractional luma: per cell the 15 x 15 reference window ...
+  int ltmp[16][15 * 8];                                  // ... and its horizontally filtered rows (32-bit: see enc_kernels.hip InterLds)
+  alignas(4) uint8_t cwin[2][16][7 * 8];                 // chroma: per plane and cell the 7 x 7 window of its 4 x 4 samples
+  DecTu td[DEC_MAX_TU]; uint32_t tstart[DEC_MAX_TU + 1];
+  uint32_t mask[2][4][2];                                // [luma, chroma][log2 - 2][word]: coded blocks of the class, bit = block index
+};
+
+// inverse transform of the blocks of one size class whose bit is set in (mlo, mhi): block t at C0 + t * N * N
+template <int L2, int OPL, class PX>
+__device__ __forceinline__ void dec_itx_class(DecInterLds &s, int16_t *C0, uint32_t mlo, uint32_t mhi, PX px_index, int tid)
+{
+  constexpr int N = 1 << L2, G = XF<L2, OPL>::G, LPT = XF<L2, OPL>::LANES;
+  const int tu = tid / LPT, l = tid % LPT, rp = l / G, g = l % G;
+  const bool has = ((tu < 32 ? mlo : mhi) >> (tu & 31)) & 1;
+  int16_t *A = C0 + tu * N * N, *B = s.B + tu * N * N;
+  const int16_t *Mt = s.M[1] + matrix_offset(L2);
+  if (has) xf_stage<L2, OPL>(A, B, Mt, 7, rp, g);
+  __syncthreads();
+  if (has) {
+    int acc[2][OPL];
+    xf_sums<L2, OPL>(B, Mt, rp, g, acc);
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+#pragma unroll
+      for (int o = 0; o < OPL; o++) {
+        uint8_t *q = &s.px[px_index(tu, 2 * rp + e, g * OPL + o)];
+        *q = (uint8_t)clip8(*q + ((acc[e][o] + 2048) >> 12));
+      }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_dec_inter(DecFrame f)
+{
+  __shared__ DecInterLds s;
+  const int tid = threadIdx.x;
+  int bx, by; xcd_block_2d(bx, by);
+  const int x0 = bx * 32, y0 = by * 32;
+  if (x0 >= f.w || y0 >= f.h) return;
+  const int b4w = f.pw >> 2, cpitch = f.pw >> 1, wC = f.w >> 1, hC = f.h >> 1;
+  const TuRange reg = f.region[by * (2 * f.wc) + bx];
+  const int ntu = (int)(reg.count < DEC_MAX_TU ? reg.count : DEC_MAX_TU);
+  if (tid < 64) {
+    const int X = x0 + (tid & 7) * 4, Y = y0 + (tid >> 3) * 4;
+    B4Rec r; r.mvx = 0; r.mvy = 0; r.ref_idx = -1; r.flags = 0; r.qp_y = 0; r.slot = 0;
+    if (X < f.w && Y < f.h) r = f.b4[(size_t)(Y >> 2) * b4w + (X >> 2)];
+    s.recs[tid] = r;
+  }
+  if (tid >= 64 && tid < 80) ((uint32_t *)s.mask)[tid - 64] = 0;
+  __syncthreads();
+  bool my_coded = false;
+  if (tid < 16) {
+    const B4Rec *r = &s.recs[(tid >> 2) * 16 + (tid & 3) * 2];
+    const B4Rec a = r[0], b = r[1], c = r[8], d = r[9];
+    const bool inter = a.ref_idx >= 0;
+    const bool uni = a.mvx == b.mvx && a.mvx == c.mvx && a.mvx == d.mvx && a.mvy == b.mvy && a.mvy == c.mvy && a.mvy == d.mvy &&
+                     a.slot == b.slot && a.slot == c.slot && a.slot == d.slot;
+    const bool frac = ((a.mvx | a.mvy | b.mvx | b.mvy | c.mvx | c.mvy | d.mvx | d.mvy) & 3) != 0;
+    s.cflag[tid] = (uint8_t)((inter ? 1 : 0) | (uni ? 2 : 0) | (frac ? 4 : 0));
+  }
+  if (tid >= 64 && tid - 64 < ntu) {
+    const int t = tid - 64;
+    DecTu d = f.tus[reg.first + t];
+    if (d.flags & TU_INTRA) d.count = 0;                       // the intra kernel's business
+    s.td[t] = d;
+    if (d.count) {
+      my_coded = true;
+      if (!(d.flags & TU_TSKIP)) {
+        const int cls = d.log2 - 2;
+        int blk;
+        if (d.plane == 0) blk = zorder3((d.x - x0) >> 2, (d.y - y0) >> 2) >> (2 * cls);
+        else blk = (((d.plane - 1) << 4) | zorder3((d.x - (x0 >> 1)) >> 2, (d.y - (y0 >> 1)) >> 2)) >> (2 * cls);
+        atomicOr(&s.mask[d.plane ? 1 : 0][cls][blk >> 5], 1u << (blk & 31));
+      }
+    }
+  }
+  const bool any_inter = __syncthreads_or(tid < 16 && (s.cflag[tid] & 1));
+  if (!any_inter) return;
+  const bool coded = __syncthreads_or(my_coded);
+  const bool any_lwin = __syncthreads_or(tid < 16 && (s.cflag[tid] & 7) == 7);
+  // ---- fractional luma vectors, one motion per 8x8 cell: window -> LDS, horizontal pass -> LDS (8.5.3.3.3.1)
+  if (any_lwin) {
+    for (int i = tid; i < 16 * 225; i += 256) {
+      const int k = i / 225, r = i - k * 225;
+      if ((s.cflag[k] & 7) != 7) continue;
+      const int wy = r / 15, wx = r - wy * 15;
+      const B4Rec m = s.recs[(k >> 2) * 16 + (k & 3) * 2];
+      const int gx = x0 + (k & 3) * 8 + (m.mvx >> 2) - 3 + wx, gy = y0 + (k >> 2) * 8 + (m.mvy >> 2) - 3 + wy;
+      s.lwin[k][wy * 16 + wx] = (uint8_t)refpx(f.ref[m.slot & 15][0], f.pw, f.w, f.h, gx, gy);
+    }
+    __syncthreads();
+    for (int i = tid; i < 16 * 120; i += 256) {
+      const int k = i / 120, r = i - k * 120;
+      if ((s.cflag[k] & 7) != 7) continue;
+      const int wy = r >> 3, c = r & 7, xf = s.recs[(k >> 2) * 16 + (k & 3) * 2].mvx & 3;
+      const uint8_t *wp = &s.lwin[k][wy * 16 + c];
+      int v = wp[3];
+      if (xf) { v = 0; for (int t = 0; t < 8; t++) v += kLumaFilter[xf][t] * wp[t]; }
+      s.ltmp[k][wy * 8 + c] = v;
+    }
+    __syncthreads();
+  }
+  // ---- luma prediction: four samples of a row per thread, each 4x4 unit with its own motion
+  {
+    const int y = tid >> 3, x = (tid & 7) * 4, cell = (y >> 3) * 4 + (x >> 3), cf = s.cflag[cell];
+    const B4Rec m = s.recs[(y >> 2) * 8 + (x >> 2)];
+    uint32_t p4 = 0;
+    if (cf & 1) {
+      const uint8_t *rp = f.ref[m.slot & 15][0];
+      if (!((m.mvx | m.mvy) & 3)) p4 = mc_luma4_int(rp, f.pw, f.w, f.h, x0 + x, y0 + y, m.mvx, m.mvy);
+      else if ((cf & 6) == 6) {
+        const int xf = m.mvx & 3, yf = m.mvy & 3;
+        const int *tp = &s.ltmp[cell][(y & 7) * 8 + (x & 7)];
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) {            // (kept rolled: see enc_kernels.hip k_inter_recon)
+          int v;
+          if (yf) {
+            int a = 0;
+            for (int j = 0; j < 8; j++) a += (int)kLumaFilter[yf][j] * tp[j * 8 + i];
+            v = xf ? (a >> 6) : a;
+          } else v = xf ? tp[3 * 8 + i] : tp[3 * 8 + i] * 64;
+          p4 |= (uint32_t)clip8((v + 32) >> 6) << (8 * i);
+        }
+      } else {
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) p4 |= (uint32_t)mc_luma_px(rp, f.pw, f.w, f.h, x0 + x + i, y0 + y, m.mvx, m.mvy) << (8 * i);
+      }
+    }
+    *(uint32_t *)&s.px[y * 32 + x] = p4;
+  }
+  // ---- chroma: 7 x 7 windows of the cells with one motion -> LDS; vector in 1/8 samples
+  for (int i = tid; i < 2 * 16 * 49; i += 256) {
+    const int pl = i / 784, r = i - pl * 784, k = r / 49, q = r - k * 49;
+    if ((s.cflag[k] & 3) != 3) continue;
+    const int wy = q / 7, wx = q - wy * 7;
+    const B4Rec m = s.recs[(k >> 2) * 16 + (k & 3) * 2];
+    const int xi = (x0 >> 1) + (k & 3) * 4 + (m.mvx >> 3) + wx - 1, yi = (y0 >> 1) + (k >> 2) * 4 + (m.mvy >> 3) + wy - 1;
+    s.cwin[pl][k][wy * 8 + wx] = (uint8_t)refpx(f.ref[m.slot & 15][1 + pl], cpitch, wC, hC, xi, yi);
+  }
+  __syncthreads();
+  {
+    // two samples per thread; the separable 4-tap form with the {0, 64, 0, 0} filter at fraction 0 covers every case of
+    // 8.5.3.3.3.2 exactly: (64 * t) >> 6 == t
+    const int pl = tid >> 7, y = (tid >> 3) & 15, x = (tid & 7) * 2, cell = (y >> 2) * 4 + (x >> 2), cf = s.cflag[cell];
+    const B4Rec m = s.recs[(y >> 1) * 8 + (x >> 1)];
+    int p0 = 0, p1 = 0;
+    if (cf & 1) {
+      const int xf = m.mvx & 7, yf = m.mvy & 7;
+      int v0 = 0, v1 = 0;
+      const uint8_t *rp = f.ref[m.slot & 15][1 + pl];
+      const int gx = (x0 >> 1) + x + (m.mvx >> 3) - 1, gy = (y0 >> 1) + y + (m.mvy >> 3) - 1;
+      const uint8_t *w = &s.cwin[pl][cell][(y & 3) * 8 + (x & 3)];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        int c[5];
+        if (cf & 2) {
+#pragma unroll
+          for (int i = 0; i < 5; i++) c[i] = w[j * 8 + i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 5; i++) c[i] = refpx(rp, cpitch, wC, hC, gx + i, gy + j);
+        }
+        int t0 = 0, t1 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { t0 += kChromaFilter[xf][i] * c[i]; t1 += kChromaFilter[xf][i] * c[i + 1]; }
+        v0 += kChromaFilter[yf][j] * t0; v1 += kChromaFilter[yf][j] * t1;
+      }
+      p0 = clip8(((v0 >> 6) + 32) >> 6); p1 = clip8(((v1 >> 6) + 32) >> 6);
+    }
+    *(uint16_t *)&s.px[1024 + pl * 256 + y * 16 + x] = (uint16_t)(p0 | (p1 << 8));
+  }
+  // ---- residual of the coded inter blocks
+  if (coded) {
+    load_matrices(s.M, 0, KV_MATRIX_ENTRIES, tid, 256);
+    if (s.mask[0][3][0]) {
+      if (tid < 64) ((uint4 *)s.M8)[tid] = ((const uint4 *)g_xf.M8[1])[tid];
+      else if (tid < 72) ((uint4 *)s.rowsum)[tid - 64] = ((const uint4 *)g_xf.rowsum[1])[tid - 64];
+    }
+    for (int i = tid; i < 768; i += 256) ((uint32_t *)s.C)[i] = 0;
+    if (tid == 0) { uint32_t a = 0; for (int t = 0; t < ntu; t++) { s.tstart[t] = a; a += s.td[t].count; } s.tstart[ntu] = a; }
+    __syncthreads();
+    const uint32_t nwords = s.tstart[ntu];
+    for (uint32_t i = tid; i < nwords; i += 256) {
+      int lo = 0, hi = ntu;                               // last block with tstart <= i (empty blocks share a start: take the last)
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.tstart[mid] <= i) lo = mid; else hi = mid; }
+      const DecTu d = s.td[lo];
+      const uint32_t wd = f.lev[d.offset + (i - s.tstart[lo])];
+      const int n = 1 << d.log2, pos = (int)(wd >> 16) & (n * n - 1), row = pos >> d.log2, col = pos & (n - 1);
+      const int coef = dequant_coef((int16_t)(wd & 0xffffu), d.qp, d.log2);
+      const int lx = d.plane ? d.x - (x0 >> 1) : d.x - x0, ly = d.plane ? d.y - (y0 >> 1) : d.y - y0;
+      if (d.flags & TU_TSKIP) {                           // 8.6.4.2 with transform_skip_flag: residual = coefficient << 7, then the common shift
+        uint8_t *q = d.plane ? &s.px[1024 + (d.plane - 1) * 256 + (ly + row) * 16 + lx + col] : &s.px[(ly + row) * 32 + lx + col];
+        *q = (uint8_t)clip8(*q + (((coef << 7) + 2048) >> 12));
+      } else {
+        const int base = d.plane ? 1024 + (d.plane - 1) * 256 + zorder3(lx >> 2, ly >> 2) * 16 : zorder3(lx >> 2, ly >> 2) * 16;
+        s.C[base + col * n + row] = (int16_t)coef;
+      }
+    }
+    __syncthreads();
+    auto lpx = [](int cls) { return [cls](int t, int y, int x) { int ux, uy; unzorder3(t << (2 * cls), ux, uy); return (uy * 4 + y) * 32 + ux * 4 + x; }; };
+    auto cpx = [](int cls) { return [cls](int t, int y, int x) {
+      const int per = 16 >> (2 * cls), pl = t / per; int ux, uy; unzorder3((t - pl * per) << (2 * cls), ux, uy);
+      return 1024 + pl * 256 + (uy * 4 + y) * 16 + ux * 4 + x; }; };
+    if (s.mask[0][3][0]) {                                // the 32x32 block: the four stages' inverse half on the matrix cores
+      const int wave = tid >> 6, lane = tid & 63;
+      const int j = (wave & 1) * 16 + (lane & 15), i0 = (wave >> 1) * 16 + (lane >> 4) * 4;
+      mfma_stage(s.C, s.B, s.M8, s.rowsum, 7, wave, lane);
+      __syncthreads();
+      int acc[4];
+      mfma_tile_sums(s.B, s.M8, s.rowsum, wave, lane, acc);
+#pragma unroll
+      for (int r = 0; r < 4; r++) { uint8_t *q = &s.px[(i0 + r) * 32 + j]; *q = (uint8_t)clip8(*q + ((acc[r] + 2048) >> 12)); }
+      __syncthreads();
+    }
+    if (s.mask[0][2][0]) dec_itx_class<4, 2>(s, s.C, s.mask[0][2][0], 0u, lpx(2), tid);
+    if (s.mask[0][1][0]) dec_itx_class<3, 2>(s, s.C, s.mask[0][1][0], 0u, lpx(1), tid);
+    if (s.mask[0][0][0] | s.mask[0][0][1]) dec_itx_class<2, 2>(s, s.C, s.mask[0][0][0], s.mask[0][0][1], lpx(0), tid);
+    if (s.mask[1][2][0]) dec_itx_class<4, 1>(s, s.C + 1024, s.mask[1][2][0], 0u, cpx(2), tid);
+    if (s.mask[1][1][0]) dec_itx_class<3, 1>(s, s.C + 1024, s.mask[1][1][0], 0u, cpx(1), tid);
+    if (s.mask[1][0][0]) dec_itx_class<2, 1>(s, s.C + 1024, s.mask[1][0][0], 0u, cpx(0), tid);
+  } else __syncthreads();
+  // ---- region -> picture (intra blocks of the region hold nothing meaningful yet: the intra kernel writes them afterwards)
+  *(uint32_t *)&f.rec[0][(size_t)(y0 + (tid >> 3)) * f.pw + x0 + (tid & 7) * 4] = *(const uint32_t *)&s.px[(tid >> 3) * 32 + (tid & 7) * 4];
+  if (tid < 128) {
+    const int pl = tid >> 6, y = (tid >> 2) & 15, x = (tid & 3) * 4;
+    *(uint32_t *)&f.rec[1 + pl][(size_t)((y0 >> 1) + y) * cpitch + (x0 >> 1) + x] = *(const uint32_t *)&s.px[1024 + pl * 256 + y * 16 + x];
+  }
+}
+
+// =============================================================================================
+// Intra blocks: one wave per (CTU, colour plane)
+// =============================================================================================
+struct DecIntraLds {
+  // the CTU with its own samples only: sample (x, y) of the CTU at pic[y * 64 + x]; neighbours outside the CTU come from the picture
+  alignas(16) uint8_t pic[64 * 64];
+  alignas(16) int16_t A[1024], B[1024];
+  alignas(16) int16_t M[2][KV_MATRIX_ENTRIES];
+  alignas(16) uint8_t R[2][144];       // reference samples in the scan order of 8.4.4.2.2, as built / filtered (enc_kernels.hip IntraWaveLds)
+  DecTu list[256];                     // this plane's intra blocks of the CTU, decoding order (luma: at most 256 4x4 blocks)
+};
+
+// progress of a (CTU, plane) wave, counted in 8x8 luma units of the CTU in z-order: every intra block of the plane that starts in
+// a unit below the counter is final in the picture.  Published at the values the neighbours wait for.
+__device__ __forceinline__ int intra_milestone(int z)
+{
+  return z >= 64 ? 7 : (z >= 60 ? 6 : (z >= 56 ? 5 : (z >= 48 ? 4 : (z >= 44 ? 3 : (z >= 32 ? 2 : (z >= 24 ? 1 : 0))))));
+}
+__device__ __forceinline__ void wave_publish(uint32_t *ctr, uint32_t value)
+{
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// `seen`: the last value observed (wave-uniform), so that satisfied waits cost nothing
+__device__ __forceinline__ void wave_wait(const uint32_t *ctr, uint32_t need, uint32_t &seen, uint32_t *err)
+{
+  if (seen >= need) return;
+  uint32_t v = 0;
+  if (threadIdx.x == 0) {
+    uint32_t spins = 0;
+    while ((v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1u << 24)) { atomicOr(err, 1u); v = 64; break; }       // bounded spin: never hang the GPU
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+struct IntraNb { bool left, up, upright, upleft; };     // neighbouring CTUs in the same tile (and inside the picture)
+
+// 6.4.1 for one slice: inside the picture, same tile, not later in z-scan order (luma locations)
+__device__ __forceinline__ bool dec_avail(const DecFrame &f, int xc, int yc, int xn, int yn)
+{
+  if (xn < 0 || yn < 0 || xn >= f.w || yn >= f.h) return false;
+  if (f.tiles && f.ctu_tile[(yn >> 6) * f.wc + (xn >> 6)] != f.ctu_tile[(yc >> 6) * f.wc + (xc >> 6)]) return false;
+  return zaddr64(xn, yn, f.wc) <= zaddr64(xc, yc, f.wc);
+}
+
+// one intra transform block of plane c: N x N samples at (rx, ry) of the CTU (component samples)
+template <int L2>
+__device__ __forceinline__ void dec_intra_block(const DecFrame &f, DecIntraLds &s, const DecTu &d, int c, int cx, int cy, int rx, int ry, int lane)
+{
+  constexpr int N = XW<L2, 64>::N, OPL = XW<L2, 64>::OPL, G = XW<L2, 64>::G;
+  const int sh = c ? 1 : 0, S = 64 >> sh, nl = N << sh, cpitch = f.pw >> sh, wC = f.w >> sh, hC = f.h >> sh;
+  const int mode = d.mode, cidx = c ? 1 : 0;
+  const bool filt = intra_filter_needed(N, cidx, mode);
+  const int Xc = cx * S + rx, Yc = cy * S + ry, X = Xc << sh, Y = Yc << sh;
+  // ---- reference samples (8.4.4.2.2) and their filtered version (8.4.4.2.3).  The available samples are contiguous in scan
+  // order (one slice, tiles are full-width rows), so the substitution process is a clamp of the scan index into [lo, hi].
+  {
+    const bool aL = dec_avail(f, X, Y, X - 1, Y), aT = dec_avail(f, X, Y, X, Y - 1), aTL = aL && aT && dec_avail(f, X, Y, X - 1, Y - 1);
+    const int nBL = (aL && dec_avail(f, X, Y, X - 1, Y + nl)) ? imin(N, hC - (Yc + N)) : 0;
+    const int nTR = (aT && dec_avail(f, X, Y, X + nl, Y - 1)) ? imin(N, wC - (Xc + N)) : 0;
+    const int lo = aL ? N - nBL : (aTL ? 2 * N : 2 * N + 1), hi = aT ? 3 * N + nTR : (aTL ? 2 * N : (aL ? 2 * N - 1 : -1));
+    const uint8_t *plane = f.rec[c];
+    auto fetch = [&](int i) -> int {
+      const int j = imin(imax(i, lo), hi);
+      const int col = j < 2 * N ? rx - 1 : rx + j - 2 * N - 1, row = j < 2 * N ? ry + 2 * N - 1 - j : ry - 1;
+      if (col >= 0 && row >= 0 && col < S && row < S) return s.pic[row * 64 + col];
+      return plane[(size_t)(cy * S + row) * cpitch + cx * S + col];
+    };
+    int c0 = 0, e0 = 0, e1 = 0; bool strong = false;
+    if (filt && N == 32 && hi >= 0 && f.strong_intra) {
+      c0 = fetch(2 * N); e0 = fetch(0); e1 = fetch(4 * N);
+      strong = iabs(c0 + e1 - 2 * fetch(3 * N)) < 8 && iabs(c0 + e0 - 2 * fetch(N)) < 8;
+    }
+    for (int i = lane; i <= 4 * N; i += 64) {
+      int v = 128, fv = 128;
+      if (hi >= lo && hi >= 0) {
+        v = fetch(i); fv = v;
+        if (filt && i != 0 && i != 4 * N) {
+          if (strong) { if (i != 2 * N) { int k = i < 2 * N ? 2 * N - i : i - 2 * N; fv = ((64 - k) * c0 + k * (i < 2 * N ? e0 : e1) + 32) >> 6; } }
+          else fv = (fetch(i - 1) + 2 * v + fetch(i + 1) + 2) >> 2;
+        }
+      }
+      s.R[0][3 + i] = (uint8_t)v;
+      if (filt) s.R[1][3 + i] = (uint8_t)fv;
+    }
+  }
+  // ---- levels -> dequantised coefficients, transposed ([column][row]), while the references settle
+  const bool has = d.count != 0, tskip = (d.flags & TU_TSKIP) != 0;
+  if (has) {
+    for (int i = lane; i < N * N / 2; i += 64) ((uint32_t *)s.A)[i] = 0;
+    __syncthreads();
+    for (int i = lane; i < (int)d.count; i += 64) {
+      const uint32_t wd = f.lev[d.offset + i];
+      const int pos = (int)(wd >> 16) & (N * N - 1), row = pos >> L2, col = pos & (N - 1);
+      s.A[col * N + row] = (int16_t)dequant_coef((int16_t)(wd & 0xffffu), d.qp, L2);
+    }
+  }
+  __syncthreads();
+  const uint8_t *R = s.R[filt ? 1 : 0] + 3;
+  int dcv = 0;
+  if (mode == 1) {
+    const uint32_t *r4 = (const uint32_t *)(s.R[0] + 3 + N + 1);
+    uint32_t acc = N + s.R[0][3 + N] - s.R[0][3 + 2 * N];
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) acc = __builtin_amdgcn_sad_u8(r4[k], 0u, acc);
+    dcv = (int)(acc >> (L2 + 1));
+  }
+  const bool active = lane < XW<L2, 64>::LANES;
+  const int rp = lane / G, g = lane % G;
+  const bool edge = cidx == 0 && N < 32;
+  int pred[2][OPL];
+  if (active) {
+    if (mode == 0) {
+#pragma unroll
+      for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int o = 0; o < OPL; o++) pred[e][o] = pred_planar<L2>(R, g * OPL + o, 2 * rp + e);
+    } else if (mode == 1) {
+#pragma unroll
+      for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int o = 0; o < OPL; o++) pred[e][o] = pred_dc<L2>(R, edge, dcv, g * OPL + o, 2 * rp + e);
+    } else {
+      const int angle = kIntraAngle[mode], inv = kInvAngle[mode];
+      const bool vert = mode >= 18, e2 = edge && (mode == 26 || mode == 10);
+#pragma unroll
+      for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int o = 0; o < OPL; o++) pred[e][o] = pred_angular<L2>(R, vert, e2, angle, inv, g * OPL + o, 2 * rp + e);
+    }
+  }
+  if (has) {
+    if (tskip) {
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+#pragma unroll
+          for (int o = 0; o < OPL; o++) pred[e][o] = clip8(pred[e][o] + ((((int)s.A[(g * OPL + o) * N + 2 * rp + e] << 7) + 2048) >> 12));
+      }
+    } else {
+      const int16_t *Mt = s.M[1] + ((L2 == 2 && (d.flags & TU_DST)) ? KV_DST_OFFSET : matrix_offset(L2));
+      if (active) xf_stage<L2, OPL>(s.A, s.B, Mt, 7, rp, g);
+      __syncthreads();
+      if (active) {
+        int acc[2][OPL];
+        xf_sums<L2, OPL>(s.B, Mt, rp, g, acc);
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+#pragma unroll
+          for (int o = 0; o < OPL; o++) pred[e][o] = clip8(pred[e][o] + ((acc[e][o] + 2048) >> 12));
+      }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+#pragma unroll
+      for (int o = 0; o < OPL; o++) s.pic[(ry + 2 * rp + e) * 64 + rx + g * OPL + o] = (uint8_t)pred[e][o];
+  }
+  __syncthreads();
+  // block -> picture (dwords)
+  {
+    uint8_t *dst = f.rec[c] + (size_t)Yc * cpitch + Xc;
+    for (int i = lane; i < N * N / 4; i += 64) {
+      const int y = i / (N / 4), x = (i - y * (N / 4)) * 4;
+      *(uint32_t *)&dst[(size_t)y * cpitch + x] = *(const uint32_t *)&s.pic[(ry + y) * 64 + rx + x];
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
+{
+  __shared__ DecIntraLds s;
+  const int lane = threadIdx.x, ctu = (int)blockIdx.x / 3, c = (int)blockIdx.x % 3, cx = ctu % f.wc, cy = ctu / f.wc;
+  const int sh = c ? 1 : 0, S = 64 >> sh;
+  uint32_t *my = f.progress + (size_t)ctu * 3 + c;
+  const TuRange ct = f.ctu[ctu];
+  const int count = (int)(ct.count & 0xffffffu);
+  if (!((ct.count >> (24 + c)) & 1)) {                  // no intra block of this plane in the CTU: nothing to wait for, nothing written
+    if (lane == 0) __hip_atomic_store(my, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  load_matrices(s.M, 0, KV_MATRIX_ENTRIES, lane, 64);
+  // the CTU as the inter kernel left it (its inter blocks are final, the intra ones get written below) -> LDS
+  {
+    const int cpitch = f.pw >> sh;
+    const uint8_t *src = f.rec[c] + (size_t)(cy * S) * cpitch + cx * S;
+    for (int i = lane; i < S * S / 16; i += 64) { const int y = i / (S / 16), xq = i % (S / 16); *(uint4 *)&s.pic[y * 64 + xq * 16] = *(const uint4 *)&src[(size_t)y * cpitch + xq * 16]; }
+  }
+  // this plane's intra blocks, compacted in order (one pass over the CTU's list, 64 descriptors at a time)
+  int nlist = 0;
+  for (int base = 0; base < count; base += 64) {
+    DecTu d; d.plane = 255; d.flags = 0;
+    if (base + lane < count) d = f.tus[ct.first + base + lane];
+    const bool keep = d.plane == c && (d.flags & TU_INTRA);
+    const uint64_t m = __ballot(keep);
+    const int at = nlist + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep && at < 256) s.list[at] = d;
+    nlist += __popcll(m);
+  }
+  if (nlist > 256) nlist = 256;
+  IntraNb nb;
+  {
+    const int t = f.ctu_tile[ctu];
+    nb.left = cx > 0 && f.ctu_tile[ctu - 1] == t;
+    nb.up = cy > 0 && f.ctu_tile[ctu - f.wc] == t;
+    nb.upright = cy > 0 && cx + 1 < f.wc && f.ctu_tile[ctu - f.wc + 1] == t;
+    nb.upleft = cy > 0 && cx > 0 && f.ctu_tile[ctu - f.wc - 1] == t;
+  }
+  const uint32_t *pl = my - 3, *pu = my - 3 * f.wc, *pur = pu + 3, *pul = pu - 3;
+  uint32_t seen_l = 0, seen_u = 0, seen_ur = 0, seen_ul = 0;
+  int published = 0;
+  __syncthreads();
+  for (int k = 0; k < nlist; k++) {
+    const DecTu d = s.list[k];
+    const int rx = d.x - cx * S, ry = d.y - cy * S, N = 1 << d.log2;
+    const int zu = zunit8((rx << sh) >> 3, (ry << sh) >> 3);
+    if (intra_milestone(zu) > intra_milestone(published)) { wave_publish(my, (uint32_t)zu); published = zu; }
+    // the parts of the neighbouring CTUs this block reads must be final (8x8 units of those CTUs, z-order)
+    if (rx == 0 && nb.left) wave_wait(pl, (uint32_t)zunit8(7, ((imin(S, ry + 2 * N) - 1) << sh) >> 3) + 1, seen_l, f.err);
+    if (ry == 0 && nb.up) wave_wait(pu, (uint32_t)zunit8(((imin(S, rx + 2 * N) - 1) << sh) >> 3, 7) + 1, seen_u, f.err);
+    if (ry == 0 && nb.upright && rx + 2 * N > S) wave_wait(pur, (uint32_t)zunit8(((rx + 2 * N - S - 1) << sh) >> 3, 7) + 1, seen_ur, f.err);
+    if (rx == 0 && ry == 0 && nb.upleft) wave_wait(pul, 64u, seen_ul, f.err);
+    switch (d.log2) {
+      case 2: dec_intra_block<2>(f, s, d, c, cx, cy, rx, ry, lane); break;
+      case 3: dec_intra_block<3>(f, s, d, c, cx, cy, rx, ry, lane); break;
+      case 4: dec_intra_block<4>(f, s, d, c, cx, cy, rx, ry, lane); break;
+      default: dec_intra_block<5>(f, s, d, c, cx, cy, rx, ry, lane); break;
+    }
+  }
+  wave_publish(my, 64u);
+}
+
+// =============================================================================================
+// Deblocking (8.7.2): both passes in one launch, one workgroup per 64x64 tile shifted by (-4, -4) against the CTU grid
+// (enc_kernels.hip k_deblock_tile has the geometry argument); boundary strengths from the 4x4 records
+// =============================================================================================
+__device__ __forceinline__ int dec_bs(const B4Rec &p, const B4Rec &q, bool tu_edge)
+{
+  if (p.ref_idx < 0 || q.ref_idx < 0) return 2;
+  if (tu_edge && ((p.flags | q.flags) & B4_NZ)) return 1;
+  if (p.slot != q.slot) return 1;                          // different reference pictures
+  if (iabs(p.mvx - q.mvx) >= 4 || iabs(p.mvy - q.mvy) >= 4) return 1;
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void k_dec_deblock(DecFrame f)
+{
+  constexpr int P = 68, PC = 36;
+  __shared__ __attribute__((aligned(16))) uint8_t ty_[68 * P];
+  __shared__ __attribute__((aligned(16))) uint8_t tc_[2][34 * PC];
+  const int tid = threadIdx.x, wc = f.wc, hc = f.hc, b4w = f.pw >> 2;
+  const int lin = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), tx = lin % wc, tyi = lin / wc;
+  const int X0 = tx * 64 - 4, Y0 = tyi * 64 - 4, CX0 = X0 >> 1, CY0 = Y0 >> 1, cw2 = f.pw >> 1;
+  const int TW = tx == wc - 1 ? 68 : 64, TH = tyi == hc - 1 ? 68 : 64;
+  for (int i = tid; i < TH * 17; i += 256) {
+    const int y = i / 17, x = (i - y * 17) * 4, gx = X0 + x, gy = Y0 + y;
+    if (x < TW && gx >= 0 && gy >= 0) *(uint32_t *)&ty_[y * P + x] = *(const uint32_t *)&f.rec[0][(size_t)gy * f.pw + gx];
+  }
+  for (int i = tid; i < 2 * (TH / 2) * 17; i += 256) {
+    const int pl = i / ((TH / 2) * 17), r = i - pl * ((TH / 2) * 17), y = r / 17, x = (r - y * 17) * 2, gx = CX0 + x, gy = CY0 + y;
+    if (x < TW / 2 && gx >= 0 && gy >= 0) *(uint16_t *)&tc_[pl][y * PC + x] = *(const uint16_t *)&f.rec[1 + pl][(size_t)gy * cw2 + gx];
+  }
+  __syncthreads();
+  // ---- vertical edges: 8 edges x 16 (17) four-row segments
+  if (tid < 8 * (TH / 4)) {
+    const int x = tx * 64 + (tid & 7) * 8, y = Y0 + (tid >> 3) * 4;
+    if (x > 0 && x < f.w && y >= 0 && y < f.h) {
+      const B4Rec q = f.b4[(size_t)(y >> 2) * b4w + (x >> 2)], p = f.b4[(size_t)(y >> 2) * b4w + (x >> 2) - 1];
+      if (q.flags & B4_EDGE_V) {
+        const int bs = dec_bs(p, q, (q.flags & B4_TU_V) != 0);
+        if (bs) {
+          const int qp = (p.qp_y + q.qp_y + 1) >> 1;
+          deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], 1, P, bs, qp, f.beta_offset, f.tc_offset);
+          if (bs == 2 && (x & 15) == 0) {
+            const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0);
+            deblock_chroma_segment(&tc_[0][o], 1, PC, 2, qp, f.cb_qp_offset, f.tc_offset);
+            deblock_chroma_segment(&tc_[1][o], 1, PC, 2, qp, f.cr_qp_offset, f.tc_offset);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- horizontal edges on the vertically filtered samples
+  if (tid < 8 * (TW / 4)) {
+    const int y = tyi * 64 + (tid & 7) * 8, x = X0 + (tid >> 3) * 4;
+    if (y > 0 && y < f.h && x >= 0 && x < f.w) {
+      const B4Rec q = f.b4[(size_t)(y >> 2) * b4w + (x >> 2)], p = f.b4[(size_t)((y >> 2) - 1) * b4w + (x >> 2)];
+      if (q.flags & B4_EDGE_H) {
+        const int bs = dec_bs(p, q, (q.flags & B4_TU_H) != 0);
+        if (bs) {
+          const int qp = (p.qp_y + q.qp_y + 1) >> 1;
+          deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], P, 1, bs, qp, f.beta_offset, f.tc_offset);
+          if (bs == 2 && (y & 15) == 0) {
+            const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0);
+            deblock_chroma_segment(&tc_[0][o], PC, 1, 2, qp, f.cb_qp_offset, f.tc_offset);
+            deblock_chroma_segment(&tc_[1][o], PC, 1, 2, qp, f.cr_qp_offset, f.tc_offset);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < TH * 17; i += 256) {
+    const int y = i / 17, x = (i - y * 17) * 4, gx = X0 + x, gy = Y0 + y;
+    if (x < TW && gx >= 0 && gy >= 0) *(uint32_t *)&f.rec[0][(size_t)gy * f.pw + gx] = *(const uint32_t *)&ty_[y * P + x];
+  }
+  for (int i = tid; i < 2 * (TH / 2) * 17; i += 256) {
+    const int pl = i / ((TH / 2) * 17), r = i - pl * ((TH / 2) * 17), y = r / 17, x = (r - y * 17) * 2, gx = CX0 + x, gy = CY0 + y;
+    if (x < TW / 2 && gx >= 0 && gy >= 0) *(uint16_t *)&f.rec[1 + pl][(size_t)gy * cw2 + gx] = *(const uint16_t *)&tc_[pl][y * PC + x];
+  }
+}
+
+// =============================================================================================
+// Sample adaptive offset (8.7.3) with the parsed parameters: one workgroup per CTU, the deblocked CTU with a one-sample ring in LDS
+// =============================================================================================
+struct DecSaoLds {
+  alignas(4) uint8_t win[66 * 72];
+  alignas(4) uint8_t winc[2][34 * 40];
+  SaoParams p;
+};
+__device__ __forceinline__ int dsao_edge_idx(int c, int a, int b)
+{
+  const int e = 2 + ((c > a) - (c < a)) + ((c > b) - (c < b));
+  return e == 2 ? 0 : (e < 2 ? e + 1 : e);
+}
+
+__global__ __launch_bounds__(256) void k_dec_sao(DecFrame f)
+{
+  __shared__ DecSaoLds s;
+  const int tid = threadIdx.x, wc = f.wc, ctu = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), cx = ctu % wc, cy = ctu / wc;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const int sh = c ? 1 : 0, l2n = 6 - sh, n = 1 << l2n, pitch_g = f.pw >> sh, pwid = f.w >> sh, phei = f.h >> sh, X0 = cx * n, Y0 = cy * n;
+    uint8_t *w = c ? s.winc[c - 1] : s.win; const int pitch = c ? 40 : 72;
+    const uint8_t *src = f.rec[c];
+#pragma unroll
+    for (int i = tid; i < n * n / 4; i += 256) {
+      const int y = i >> (l2n - 2), x = (i & ((n >> 2) - 1)) * 4;
+      *(uint32_t *)&w[(y + 1) * pitch + 4 + x] = *(const uint32_t *)&src[(size_t)(Y0 + y) * pitch_g + X0 + x];   // (inside the padded allocation)
+    }
+    for (int q = tid; q < 4 * n + 4; q += 256) {
+      int x, y;
+      if (q < n + 2) { x = q - 1; y = -1; } else if (q < 2 * n + 4) { x = q - (n + 2) - 1; y = n; }
+      else if (q < 3 * n + 4) { x = -1; y = q - (2 * n + 4); } else { x = n; y = q - (3 * n + 4); }
+      w[(y + 1) * pitch + 4 + x] = src[(size_t)clip3(0, phei - 1, Y0 + y) * pitch_g + clip3(0, pwid - 1, X0 + x)];
+    }
+  }
+  if (tid == 0) s.p = f.sao[ctu];
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const int sh = c ? 1 : 0, l2n = 6 - sh, n = 1 << l2n, pitch_g = f.pw >> sh, pwid = f.w >> sh, phei = f.h >> sh, X0 = cx * n, Y0 = cy * n;
+    const uint8_t *w = c ? s.winc[c - 1] : s.win; const int pitch = c ? 40 : 72;
+    const int type = s.p.type[c], e = s.p.eo_class[c], bp = s.p.band_pos[c];
+    int off[4];
+    for (int k = 0; k < 4; k++) off[k] = s.p.offset[c][k];
+#pragma unroll
+    for (int q = tid; q < n * n / 4; q += 256) {
+      const int y = q >> (l2n - 2), x4 = (q & ((n >> 2) - 1)) * 4;
+      if (Y0 + y >= phei || X0 + x4 >= pwid) continue;                          // partial CTU: outside the picture
+      const uint32_t *row = (const uint32_t *)&w[(y + 1) * pitch + x4];
+      uint32_t out = row[1];
+      if (type == 1) {
+        uint32_t o = 0;
+        for (int i = 0; i < 4; i++) {
+          const int v = (out >> (8 * i)) & 255, k = ((v >> 3) - bp) & 31;
+          o |= (uint32_t)(k < 4 ? clip8(v + off[k]) : v) << (8 * i);
+        }
+        out = o;
+      } else if (type == 2) {
+        auto span = [&](const uint32_t *r) -> uint64_t { return ((uint64_t)r[0] >> 24) | ((uint64_t)r[1] << 8) | ((uint64_t)(r[2] & 255u) << 40); };
+        const int dq = pitch >> 2;
+        const uint64_t mid = span(row), up = span(row - dq), dn = span(row + dq);
+        const bool okv = Y0 + y - 1 >= 0 && Y0 + y + 1 < phei;
+        uint32_t o = 0;
+        for (int i = 0; i < 4; i++) {
+          const int v = (int)((mid >> (8 * (i + 1))) & 255);
+          int a, b; bool ok;
+          const bool okh = X0 + x4 + i - 1 >= 0 && X0 + x4 + i + 1 < pwid;
+          if (e == 0) { a = (int)((mid >> (8 * i)) & 255); b = (int)((mid >> (8 * (i + 2))) & 255); ok = okh; }
+          else if (e == 1) { a = (int)((up >> (8 * (i + 1))) & 255); b = (int)((dn >> (8 * (i + 1))) & 255); ok = okv; }
+          else if (e == 2) { a = (int)((up >> (8 * i)) & 255); b = (int)((dn >> (8 * (i + 2))) & 255); ok = okh && okv; }
+          else { a = (int)((up >> (8 * (i + 2))) & 255); b = (int)((dn >> (8 * i)) & 255); ok = okh && okv; }
+          const int k = ok ? dsao_edge_idx(v, a, b) : 0;
+          o |= (uint32_t)(k ? clip8(v + off[k - 1]) : v) << (8 * i);
+        }
+        out = o;
+      }
+      *(uint32_t *)&f.out[c][(size_t)(Y0 + y) * pitch_g + X0 + x4] = out;
+    }
+  }
+}
+
+// =============================================================================================
+// launch wrappers
+// =============================================================================================
+void launch_dec_inter(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_inter, dim3(f.wc * 2, f.hc * 2), dim3(256), 0, st, f); }
+void launch_dec_intra(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_intra, dim3(f.wc * f.hc * 3), dim3(64), 0, st, f); }
+void launch_dec_deblock(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_deblock, dim3(f.wc * f.hc), dim3(256), 0, st, f); }
+void launch_dec_sao(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_sao, dim3(f.wc * f.hc), dim3(256), 0, st, f); }
+
+}  // namespace kvzx

@@ -1,18 +1,19 @@
 // kvazzup_amd/csrc/decoder.h -- host engine of the HIP decoder behind libOpenHevc*
 // (/root/reference/src/media/processing/openhevcfilter.cpp:36-56,145-146,195-199).
 //
-// Division of labour: the host parses NAL units and runs CABAC decoding (bit-serial, one
-// substream per CTU row), which yields per-CU records, motion vectors and the levels of the coded
-// transform blocks; those are uploaded and the GPU does everything that touches samples:
-// motion-compensated / intra prediction, dequantisation + inverse DCT, reconstruction and
-// deblocking (dec variants of the encoder kernels, enc_kernels.hip).
+// Division of labour: the host parses NAL units and runs CABAC decoding (bit-serial, one substream per CTU row or tile),
+// which yields per-4x4 records (motion, edges, QpY), the transform blocks in decoding order and their non-zero levels
+// (dec_frame.h); those go to the GPU in one copy and the GPU does everything that touches samples: motion compensation,
+// intra prediction, dequantisation + inverse transforms, reconstruction, deblocking, SAO (dec_kernels.hip).
 //
-// Supported streams (round 1): the tool set this project's encoder emits -- Main profile 8-bit
-// 4:2:0, CTB 64, coded size a multiple of 64 and at least 128 wide, 2Nx2N CUs of 8/16/32 (intra)
-// and 16/32 (inter) with one transform unit each, I and P slices with the previous picture as
-// the only reference, arbitrary quarter-sample motion vectors, merge/AMVP without TMVP, WPP or
-// plain slice data, one slice per picture, deblocking on/off.  Anything else is rejected with
-// a negative return value (oracle/hevc_dec.c is the general CPU checker).
+// Supported streams: what a Main-profile encoder in a video call produces and OpenHEVC would be asked to decode -- 8-bit 4:2:0,
+// CTB 64 / minimum CB 8 / transform blocks 4..32 (Kvazaar's fixed geometry), coded sizes that are multiples of 8, I and P
+// slices, one slice per picture, every CU size and partitioning (AMP included), intra CUs in P pictures, NxN intra, all chroma
+// prediction modes, transform trees, several reference pictures (RPS in the SPS or the slice header, inter RPS prediction),
+// temporal motion vector prediction, merge levels, cu_qp_delta at any quantisation-group size, chroma QP offsets, sign data
+// hiding, transform skip, deblocking offsets / overrides, SAO, WPP, full-width tile rows.  Rejected with a negative return value
+// (kvzx_decoder_last_error): B slices, several slices per picture, tile columns, long-term references, reference list
+// modification, weighted prediction, scaling lists, PCM, lossless coding, constrained intra prediction, other CTB / CB / TB sizes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,28 +28,36 @@
 #include <vector>
 #include "hevc_core.h"
 #include "host_pool.h"
-#include "enc_kernels.h"
+#include "dec_frame.h"
+#include "dec_kernels.h"
 
 namespace kvzx {
 
 // DK_HOST_PARSE is not a kernel: wall time of the host CABAC parsing stage
-enum DecKernelId { DK_SCATTER = 0, DK_INTER_RECON, DK_INTRA_RECON, DK_DEBLOCK, DK_HOST_PARSE, DK_SAO, DK_COUNT };
+enum DecKernelId { DK_INTER = 0, DK_INTRA, DK_DEBLOCK, DK_HOST_PARSE, DK_SAO, DK_COUNT };
+
+// short-term reference picture set (7.4.8): negative deltas first (closest first), then positive ones
+struct StRps { int n_neg = 0, n_pos = 0; int dpoc[16]; uint8_t used[16]; };
 
 struct DecSps {
   bool valid = false;
   int width = 0, height = 0;          // coded size
   int crop_r = 0, crop_b = 0, crop_l = 0, crop_t = 0;   // luma samples
   int log2_max_poc_lsb = 8;
-  int num_st_rps = 0; int rps_neg[64], rps_used[64];      // first negative entry of each SPS RPS (subset check)
+  int num_st_rps = 0; StRps st_rps[65];
   uint32_t fps_num = 0, fps_den = 0;
-  int strong_intra = 0;
-  int sao = 0;                        // sample_adaptive_offset_enabled_flag
+  int strong_intra = 0, sao = 0, tmvp = 0, amp = 0, th_depth_inter = 0, th_depth_intra = 0;
 };
 struct DecPps {
   bool valid = false;
-  int qp_in_cu = 0;                   // cu_qp_delta_enabled_flag with diff_cu_qp_delta_depth == 0 (quantisation group = CTU)
-  int tile_rows = 1;                  // full-width tile rows with uniform spacing (everything else about tiles is rejected)
-  int init_qp = 26, wpp = 0, deblock_control = 0, deblock_disabled = 0, loop_filter_across_slices = 1, cabac_init_present = 0;
+  int sps_id = 0;
+  int sign_hiding = 0, cabac_init_present = 0, num_ref_idx_default = 1, init_qp = 26, tskip = 0;
+  int cu_qp_delta = 0, qp_delta_depth = 0, cb_qp_offset = 0, cr_qp_offset = 0, slice_chroma_offsets = 0;
+  int output_flag_present = 0, extra_header_bits = 0, header_extension = 0;
+  int wpp = 0, tile_rows = 1, row_bd[34];   // tile row i covers CTB rows [row_bd[i], row_bd[i + 1]); filled at slice time when uniform
+  int uniform_tiles = 1, row_height[33];
+  int deblock_control = 0, deblock_override = 0, deblock_disabled = 0, beta_offset_div2 = 0, tc_offset_div2 = 0, loop_filter_across_slices = 1;
+  int par_mrg_level = 2;
 };
 
 struct DecodedPicture {
@@ -77,6 +86,16 @@ class FrameWorkers {
   std::vector<std::thread> t_; std::mutex m_; std::condition_variable cv_; std::deque<std::function<void()>> q_; bool quit_ = false;
 };
 
+// motion of a decoded picture as later pictures see it for temporal prediction (8.5.3.2.8): one entry per 16x16 luma block, the
+// motion of its top-left 4x4.  Written by the picture's parser row by row, read by the parsers of following pictures (which may
+// run concurrently under frame threading: row_done[] orders them).
+struct ColMotion {
+  struct Mv { int16_t mvx, mvy; int32_t ref_poc; int32_t inter; };
+  int w16 = 0, h16 = 0, hc = 0, poc = 0;
+  std::vector<Mv> mv;
+  std::unique_ptr<std::atomic<uint8_t>[]> row_done;      // per CTU row
+};
+
 class Decoder {
  public:
   explicit Decoder(int device) : device_(device) {}
@@ -90,6 +109,9 @@ class Decoder {
   int decode_nal(const uint8_t *data, size_t len, int64_t pts);
   bool get_picture(DecodedPicture *out);   // the picture announced by the last decode_nal() == 1
   void set_download(bool on) { download_ = on; }
+  // device-resident output (set_download(false)): the planes handed out stay untouched while the next `n` pictures are decoded
+  // (they may be read as reference pictures, never written); default 2
+  void set_output_hold(int n) { output_hold_ = n < 1 ? 1 : (n > 8 ? 8 : n); }
   void set_profiling(int every) { profiling_ = every > 0; prof_every_ = every > 0 ? every : 1; }   // n: every n-th picture
   void set_parse_threads(int n) { if (!pool_) parse_threads_ = n < 1 ? 1 : n; }
   void get_kernel_times(double *ms, uint64_t *launches, bool reset);
@@ -98,69 +120,85 @@ class Decoder {
   void flush() {}
   int pending() const { return (int)(job_head_ - job_tail_) + (gpu_job_ ? 1 : 0); }
 
- private:
-  bool ensure_buffers(int cw, int ch);
-  void free_buffers();
-  int decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t pts);
-  struct RowState { std::vector<uint32_t> levels; std::vector<TuDesc> tus; int rc = 0; };     // levels: (position << 16 | level) words
+  // ---- per-picture state shared with the slice-data parser (decoder.hip)
+  struct SubOut { std::vector<uint32_t> levels; std::vector<DecTu> tus; int rc = 0; };     // one per substream
   struct alignas(64) Progress { std::atomic<int> v{0}; char pad[60]; };   // one cache line per row: no false sharing between pollers
+  struct SliceHdr {
+    bool is_intra = false; int poc = 0;
+    int tmvp = 0, collocated_ref_idx = 0, sao_luma = 0, sao_chroma = 0, num_ref_idx = 1, cabac_init_flag = 0, max_merge = 5;
+    int slice_qp = 26, cb_qp_offset = 0, cr_qp_offset = 0;      // offsets: PPS + slice
+    int deblock_disabled = 0, beta_offset_div2 = 0, tc_offset_div2 = 0;
+  };
   // everything one picture needs between its slice header and its reconstruction
   struct PicJob {
     std::vector<uint8_t> rbsp; size_t data_off = 0, data_len = 0;
     std::vector<size_t> sub_start;
-    int tile_rows = 1, qp_in_cu = 0;
-    int sao_luma = 0, sao_chroma = 0;                          // slice_sao_luma_flag / slice_sao_chroma_flag
-    int slice_qp = 0, max_merge = 5, poc = 0; bool is_intra = false, deblock = true; int64_t pts = 0;
-    int crop[4] = {0, 0, 0, 0}; uint32_t fps_num = 0, fps_den = 0;
-    // Everything the GPU needs for the picture, in one pinned block that goes over in one copy:
-    // [ CU records: 7 byte arrays of b8 entries | motion vectors: b8 x 2 int16 | per CTU: QpY, delta, first coded CU | per CTU: SaoParams | TuDesc x ntu | level words x nlev ]
+    SliceHdr sh; const DecSps *sps = nullptr; DecPps pps;        // (the PPS by value: a later PPS NAL may replace the table entry while this picture is still being parsed)
+    int64_t pts = 0; int crop[4] = {0, 0, 0, 0}; uint32_t fps_num = 0, fps_den = 0;
+    int slot = 0;                                                // picture buffer this picture is reconstructed into
+    int nref = 0; int ref_poc[16]; uint8_t ref_slot[16];        // RefPicList0
+    std::shared_ptr<ColMotion> col, own;                         // collocated picture's motion (NULL: no temporal candidates); this picture's
+    // the pinned input block (dec_frame.h) and the host views into it
     uint8_t *h_in = nullptr; size_t h_in_cap = 0; size_t ntu = 0, nlev = 0;
-    EncFrame hf{};                                             // host view of the CU / motion arrays inside h_in
-    std::vector<RowState> rows; std::vector<uint8_t> wpp_saved;
+    B4Rec *b4 = nullptr; TuRange *region = nullptr, *ctu = nullptr; uint8_t *ctu_tile = nullptr; SaoParams *sao = nullptr;
+    // host-only syntax state per 4x4: prediction mode (0 inter, 1 intra, 2 skip, 255 not decoded yet), coding quadtree depth, intra mode
+    std::vector<uint8_t> pred_mode, ct_depth, intra_mode;
+    std::vector<SubOut> subs; std::vector<uint8_t> wpp_saved;
     std::unique_ptr<Progress[]> row_progress; int row_progress_n = 0;
-    std::atomic<int> state{0}; int rc = 0; double parse_ms = 0; int rec_idx = 0;
+    bool any_intra = false, any_inter = false;
+    std::atomic<int> state{0}; int rc = 0; double parse_ms = 0;
     PicJob() {}
     PicJob(const PicJob &) {}                                  // (vector<PicJob> construction only)
   };
+  int pw() const { return pw_; }
+  int ph() const { return ph_; }
+
+ private:
+  bool ensure_buffers(int w, int h);
+  void free_buffers();
+  int decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t pts);
   int parse_job(PicJob &job, bool row_parallel);
-  int parse_row(PicJob &job, int row, const uint8_t *data, size_t len, RowState &rs);
+  int parse_substream(PicJob &job, int sub, const uint8_t *data, size_t len, SubOut &out);
   int finish_oldest();
   void drop_pending();
-  size_t sao_offset() const { return (size_t)cw_ * ch_ / 64 * 11 + (size_t)(cw_ / 64) * (ch_ / 64) * 3; }
-  size_t fixed_bytes() const { return sao_offset() + (size_t)(cw_ / 64) * (ch_ / 64) * sizeof(SaoParams); }   // CU records + motion vectors + per-CTU QpY / delta / first coded CU + per-CTU SAO parameters
+  // layout of the input block
+  size_t off_region() const { return (size_t)(pw_ / 4) * (ph_ / 4) * sizeof(B4Rec); }
+  size_t off_ctu() const { return off_region() + (size_t)(pw_ / 32) * (ph_ / 32) * sizeof(TuRange); }
+  size_t off_tile() const { return off_ctu() + (size_t)(pw_ / 64) * (ph_ / 64) * sizeof(TuRange); }
+  size_t off_sao() const { return (off_tile() + (size_t)(pw_ / 64) * (ph_ / 64) + 15) & ~(size_t)15; }
+  size_t fixed_bytes() const { return (off_sao() + (size_t)(pw_ / 64) * (ph_ / 64) * sizeof(SaoParams) + 15) & ~(size_t)15; }
   bool grow_job_input(PicJob &job, size_t bytes);
-  void bind_views(EncFrame &f, uint8_t *base);
+  void bind_job(PicJob &job);
   int launch_gpu(PicJob &job);
   int complete_gpu();
+  int alloc_slot();
 
   int device_; bool started_ = false;
   hipStream_t stream_ = nullptr;
   DecSps sps_[16]; DecPps pps_[64]; uint32_t vps_fps_num_ = 0, vps_fps_den_ = 0;
-  int cw_ = 0, ch_ = 0;
+  int w_ = 0, h_ = 0, pw_ = 0, ph_ = 0;
   std::vector<PicJob> jobs_; int frame_threads_ = 1; long job_head_ = 0, job_tail_ = 0;
   std::unique_ptr<FrameWorkers> workers_;
+  // decoded picture buffer: slot = device planes + what reference marking needs
+  struct DpbPic { uint8_t *plane[3] = {nullptr, nullptr, nullptr}; int poc = 0; bool is_ref = false, used = false; long decode_idx = -1000; std::shared_ptr<ColMotion> motion; };
+  DpbPic dpb_[KVZ_DEC_MAX_REFS];
   // device side
-  EncFrame f_{};
   uint8_t *d_in_ = nullptr; size_t d_in_cap_ = 0;          // device copy of PicJob::h_in
-  int16_t *d_mvd_ = nullptr;
-  uint8_t *rec_[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-  uint8_t *work_[3] = {nullptr, nullptr, nullptr};          // pictures with SAO: reconstruction and deblocking happen here, the filter writes into rec_
-  int16_t *coef_[3] = {nullptr, nullptr, nullptr};
-  uint32_t *sync_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
+  uint8_t *work_[3] = {nullptr, nullptr, nullptr};          // pictures with SAO: reconstruction and deblocking happen here, the filter writes into the slot
+  uint32_t *progress_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
   uint8_t *h_out_ = nullptr; size_t h_out_cap_ = 0;
-  long launched_ = 0; int out_idx_ = 0; bool have_ref_ = false;
+  long launched_ = 0; int out_slot_ = 0; int output_hold_ = 2;
   double t_parse_max_ = 0;                // trace: the longest parse of one picture (an IDR), ms
   bool spin_wait_ = false;                // KVAZZUP_AMD_SPIN: poll the GPU instead of napping between queries
   PicJob *gpu_job_ = nullptr;             // picture whose kernels are in flight (frame-threaded mode)
-  int poc_ = 0, prev_poc_ = 0;
+  int prev_poc_ = 0, cur_tid_ = 0; bool seen_irap_ = false;
   bool download_ = true, profiling_ = false, prof_now_ = false; int prof_every_ = 1;
   bool pic_ready_ = false; DecodedPicture out_;
-  const DecSps *active_sps_ = nullptr;
   int last_error_ = 0;
   double t_nal_ = 0, t_wait_ = 0, t_stage_ = 0, t_api_ = 0, t_sync_ = 0;     // decoder-thread time split (KVAZZUP_AMD_TRACE)
   std::vector<uint8_t> rbsp_;
   std::vector<size_t> epb_;                // unescaped payload offset of every removed emulation prevention byte
-  std::vector<size_t> sub_start_;          // start of every WPP substream inside the unescaped slice data
+  std::vector<size_t> sub_start_;          // start of every substream inside the unescaped slice data
   std::unique_ptr<OrderedPool> pool_; int parse_threads_ = 16;
   struct EvPair { hipEvent_t a, b; int id; };
   std::vector<EvPair> ev_pool_; size_t ev_used_ = 0;

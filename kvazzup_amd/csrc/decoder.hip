@@ -1,4 +1,5 @@
-// kvazzup_amd/csrc/decoder.hip -- see decoder.h
+// kvazzup_amd/csrc/decoder.hip -- see decoder.h.  Host half of the decoder: NAL units, parameter sets, slice headers,
+// reference picture management and the CABAC slice-data parser (H.265 7.3, 8.3, 9.3); the sample work is dec_kernels.hip.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -9,6 +10,8 @@ namespace kvzx {
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "kvazzup_amd: %s failed: %s\n", #expr, hipGetErrorString(e_)); return false; } } while (0)
 enum { DEC_ERR_INVALID = -1, DEC_ERR_UNSUPPORTED = -2, DEC_ERR_GPU = -3 };
+enum { PM_INTER = 0, PM_INTRA = 1, PM_SKIP = 2, PM_NONE = 255 };
+enum { PART_2Nx2N = 0, PART_2NxN, PART_Nx2N, PART_NxN, PART_2NxnU, PART_2NxnD, PART_nLx2N, PART_nRx2N };
 
 namespace {
 
@@ -32,6 +35,44 @@ bool skip_ptl(BitReader &r, int max_sub_layers_minus1)
   return !r.err;
 }
 
+// st_ref_pic_set(idx) (7.3.7, 7.4.8): explicit or predicted from an earlier set
+bool parse_st_rps(BitReader &r, int idx, int num_in_sps, const StRps *all, StRps &out)
+{
+  out = StRps();
+  int inter = 0;
+  if (idx != 0) inter = r.get(1);
+  if (inter) {
+    int delta_idx = 1;
+    if (idx == num_in_sps) delta_idx = (int)r.ue() + 1;
+    if (delta_idx > idx) return false;
+    const StRps &ref = all[idx - delta_idx];
+    const int sign = r.get(1), absd = (int)r.ue() + 1, drps = (1 - 2 * sign) * absd, nd = ref.n_neg + ref.n_pos;
+    int used[17], use_delta[17];
+    for (int j = 0; j <= nd; j++) { used[j] = r.get(1); use_delta[j] = 1; if (!used[j]) use_delta[j] = r.get(1); }
+    int s0[16], u0[16], s1[16], u1[16], n0 = 0, n1 = 0;
+    const int *rs0 = ref.dpoc, *rs1 = ref.dpoc + ref.n_neg; const uint8_t *unused = nullptr; (void)unused;
+    for (int j = ref.n_pos - 1; j >= 0; j--) { const int d = rs1[j] + drps; if (d < 0 && use_delta[ref.n_neg + j] && n0 < 16) { s0[n0] = d; u0[n0++] = used[ref.n_neg + j]; } }
+    if (drps < 0 && use_delta[nd] && n0 < 16) { s0[n0] = drps; u0[n0++] = used[nd]; }
+    for (int j = 0; j < ref.n_neg; j++) { const int d = rs0[j] + drps; if (d < 0 && use_delta[j] && n0 < 16) { s0[n0] = d; u0[n0++] = used[j]; } }
+    for (int j = ref.n_neg - 1; j >= 0; j--) { const int d = rs0[j] + drps; if (d > 0 && use_delta[j] && n1 < 16) { s1[n1] = d; u1[n1++] = used[j]; } }
+    if (drps > 0 && use_delta[nd] && n1 < 16) { s1[n1] = drps; u1[n1++] = used[nd]; }
+    for (int j = 0; j < ref.n_pos; j++) { const int d = rs1[j] + drps; if (d > 0 && use_delta[ref.n_neg + j] && n1 < 16) { s1[n1] = d; u1[n1++] = used[ref.n_neg + j]; } }
+    if (n0 + n1 > 16) return false;
+    out.n_neg = n0; out.n_pos = n1;
+    for (int j = 0; j < n0; j++) { out.dpoc[j] = s0[j]; out.used[j] = (uint8_t)u0[j]; }
+    for (int j = 0; j < n1; j++) { out.dpoc[n0 + j] = s1[j]; out.used[n0 + j] = (uint8_t)u1[j]; }
+  } else {
+    const int nneg = (int)r.ue(), npos = (int)r.ue();
+    if (nneg + npos > 16 || r.err) return false;
+    out.n_neg = nneg; out.n_pos = npos;
+    int prev = 0;
+    for (int j = 0; j < nneg; j++) { prev -= (int)r.ue() + 1; out.dpoc[j] = prev; out.used[j] = (uint8_t)r.get(1); }
+    prev = 0;
+    for (int j = 0; j < npos; j++) { prev += (int)r.ue() + 1; out.dpoc[nneg + j] = prev; out.used[nneg + j] = (uint8_t)r.get(1); }
+  }
+  return !r.err;
+}
+
 // ------------------------------------------------------------------------------------------ CABAC decoding (H.265 9.3.4.3)
 // Arithmetic decoder with the offset kept scaled in a 64-bit register: value = offset << bits | next
 // `bits` stream bits, so a renormalisation by n is just bits -= n and the stream is touched 32 bits at
@@ -51,24 +92,25 @@ const StateTabs &state_tabs()               // (function-local statics: initiali
   return t;
 }
 struct CabacDec {
-  const uint8_t *buf = nullptr, *p = nullptr; size_t len = 0;   // buf is padded with >= 16 readable bytes
+  const uint8_t *buf = nullptr, *p = nullptr, *end = nullptr;   // the substream; reads past `end` deliver zeros (a malformed NAL cannot walk off the buffer)
   uint64_t value = 0; int bits = 0;
-  uint32_t range = 510;
+  uint32_t range = 510; uint32_t past = 0;                      // 32-bit words fetched beyond the end
   const StateTabs *st = nullptr;
   uint8_t ctx[CTX_COUNT];
-  inline void refill()
+  inline uint32_t word()
   {
-    if (bits < 16) {
-      uint32_t w = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
-      value = (value << 32) | w; p += 4; bits += 32;
-    }
+    uint32_t w;
+    if (p + 4 <= end) w = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+    else { w = 0; for (int i = 0; i < 4; i++) w = (w << 8) | (p + i < end ? p[i] : 0u); past++; }
+    p += 4;
+    return w;
   }
-  bool overrun() const { return (size_t)(p - buf) > len + 12; }
+  inline void refill() { if (bits < 16) { value = (value << 32) | word(); bits += 32; } }
+  bool overrun() const { return past > 3; }
   void start(const uint8_t *b, size_t l)
   {
-    buf = b; p = b; len = l; st = &state_tabs(); range = 510;
-    value = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
-    p += 4; bits = 32 - 9;
+    buf = b; p = b; end = b + l; past = 0; st = &state_tabs(); range = 510;
+    value = word(); bits = 32 - 9;
     refill();
   }
   inline int bin(int ci)
@@ -109,7 +151,7 @@ struct CabacDec {
         const uint64_t scaled = (uint64_t)range << bits;
         const uint64_t q = value / scaled;
         value -= q * scaled;
-        v = (v << m) | (uint32_t)q;
+        v = (v << m) | (uint32_t)(q & 0xffffu);
         refill();
       }
       n -= m;
@@ -124,13 +166,12 @@ struct CabacDec {
     refill();
     return 0;
   }
-  // bytes from the start of the substream up to and including the byte holding the last consumed bit
-  size_t bytes_consumed() const { size_t consumed_bits = (size_t)(p - buf) * 8 - (size_t)bits; return (consumed_bits + 7) >> 3; }
+  // bytes from the start of the substream up to and including the byte holding the last consumed bit (after a terminating bin == 1:
+  // 9.3.2.5 reads rbsp_trailing / alignment, i.e. the arithmetic codeword ends at the byte boundary after the 7 bits it consumed last)
+  size_t bytes_consumed() const { const size_t consumed_bits = (size_t)(p - buf) * 8 - (size_t)bits; return (consumed_bits + 7) >> 3; }
 };
 
 std::atomic<long> g_yields{0};
-std::atomic<uint64_t> g_tc[6];
-#define TSC() __builtin_ia32_rdtsc()
 struct Tick { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } };
 const CoreTabs *host_tabs()
 {
@@ -139,7 +180,7 @@ const CoreTabs *host_tabs()
 }
 
 // scan position -> (x, y) for the three scans and block sizes 1..8 (H.265 6.5.3-6.5.5)
-struct ScanTabs { uint8_t x[3][4][64], y[3][4][64], inv[3][4][64], sigk[3][5][16]; };   // sigk[scan][prev_csbf, 4 = 4x4 block][scan position k] = context pattern     // inv[scan][log2 of the grid][y << log2 | x] = scan position
+struct ScanTabs { uint8_t x[3][4][64], y[3][4][64], inv[3][4][64], sigk[3][5][16]; };   // sigk[scan][prev_csbf, 4 = 4x4 block][scan position k] = context pattern; inv[scan][log2 of the grid][y << log2 | x] = scan position
 const ScanTabs &scan_tabs()
 {
   static const ScanTabs t = [] {
@@ -157,7 +198,6 @@ const ScanTabs &scan_tabs()
   return t;
 }
 
-// residual_coding() (7.3.8.11) without transform skip / sign hiding; writes n*n levels row-major
 // sao() of one CTU (7.3.8.3); `left` / `up`: the neighbours that may be merged from
 void parse_sao(CabacDec &c, SaoParams &p, const SaoParams *left, const SaoParams *up, bool luma, bool chroma)
 {
@@ -182,13 +222,14 @@ void parse_sao(CabacDec &c, SaoParams &p, const SaoParams *left, const SaoParams
   }
 }
 
-bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, std::vector<uint32_t> &out)
+// residual_coding() (7.3.8.11): appends (raster position << 16 | level) words; *tskip receives transform_skip_flag
+bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, bool sign_hiding, bool ts_enabled, int *tskip, std::vector<uint32_t> &out)
 {
-  const CoreTabs *t = host_tabs();
   const ScanTabs &S = scan_tabs();
   const int n = 1 << log2, sbl = log2 - 2, nsb = 1 << sbl;
   const uint8_t *SX = S.x[scan_idx][sbl], *SY = S.y[scan_idx][sbl], *PX = S.x[scan_idx][2], *PY = S.y[scan_idx][2];
   uint8_t csbf[8][8]; memset(csbf, 0, sizeof(csbf));
+  *tskip = (ts_enabled && log2 == 2) ? c.bin(CTX_TS_FLAG + (cidx ? 1 : 0)) : 0;
   int pre[2];
   for (int d = 0; d < 2; d++) {
     int off, sh, mx = (log2 << 1) - 1, v = 0;
@@ -238,8 +279,12 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, std::vector<u
       else if (c1 > 0 && c1 < 3) c1++;
     }
     if (g1idx >= 0 && c.bin(CTX_GT2 + (cidx ? 4 : 0) + ctx_set)) lev[g1idx] = 3;
-    uint32_t signs = c.bypass_bits(nsig);
-    int rice = 0;
+    // sign_data_hiding (7.3.8.11, 9.3.4.3): the sign of the sub-block's first coefficient in scan order is not sent when its
+    // first and last significant positions are more than three apart; it follows from the parity of the sum of the levels
+    const bool hidden = sign_hiding && (pos[0] - pos[nsig - 1] > 3);
+    const int nsigns = hidden ? nsig - 1 : nsig;
+    uint32_t signs = c.bypass_bits(nsigns) << (nsig - nsigns);
+    int rice = 0, sum = 0;
     for (int j = 0; j < nsig; j++) {
       int base = (j < 8) ? ((j == g1idx) ? 3 : 2) : 1;
       if (lev[j] == base) {
@@ -251,13 +296,436 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, std::vector<u
         lev[j] = base + rem;
         if (lev[j] > 3 * (1 << rice)) rice = imin(rice + 1, 4);
       }
-      int v = ((signs >> (nsig - 1 - j)) & 1) ? -lev[j] : lev[j];
+      sum += lev[j];
+    }
+    if (hidden && (sum & 1)) signs |= 1u;
+    for (int j = 0; j < nsig; j++) {
+      const int v = ((signs >> (nsig - 1 - j)) & 1) ? -lev[j] : lev[j];
       const int xp = PX[pos[j]], yp = PY[pos[j]];
       out.push_back((uint32_t)((((ys << 2) + yp) * n + (xs << 2) + xp) << 16) | ((uint32_t)clip3(-32768, 32767, v) & 0xffffu));
     }
+    if (c.overrun()) return false;
   }
   return !c.overrun();
 }
+
+// ------------------------------------------------------------------------------------------ slice data (7.3.8) of one substream
+struct MvCand { int mvx, mvy, ref_idx; };
+
+struct SliceParser {
+  Decoder::PicJob &job; Decoder::SubOut &out;
+  const DecSps &sps; const DecPps &pps; const Decoder::SliceHdr &sh;
+  CabacDec c;
+  const int w, h, b4w, wc, hc; const bool tiles;
+  B4Rec *b4; uint8_t *pm, *ctd, *im;
+  int err = 0;
+  // quantisation (8.6.1)
+  int qp_y = 0, qp_y_pred = 0, last_qp_y = 0, cu_qp_delta_val = 0, log2_qg = 6; bool qp_delta_coded = false;
+  // coding unit being parsed
+  int cu_pred_mode = 0, part_mode = 0, max_trafo_depth = 0, intra_modes[4] = {0, 0, 0, 0}, chroma_mode = 0; bool intra_split = false;
+  uint32_t ctu_intra_mask = 0;
+
+  SliceParser(Decoder::PicJob &j, Decoder::SubOut &o, int pw)
+      : job(j), out(o), sps(*j.sps), pps(j.pps), sh(j.sh), w(j.sps->width), h(j.sps->height), b4w(pw / 4), wc((j.sps->width + 63) / 64),
+        hc((j.sps->height + 63) / 64), tiles(j.pps.tile_rows > 1), b4(j.b4), pm(j.pred_mode.data()), ctd(j.ct_depth.data()), im(j.intra_mode.data())
+  { log2_qg = 6 - pps.qp_delta_depth; }
+
+  inline int bi(int x, int y) const { return (y >> 2) * b4w + (x >> 2); }
+  // 6.4.1 (one slice per picture): inside the picture, same tile, not later in z-scan order
+  inline bool avail(int xc, int yc, int xn, int yn) const
+  {
+    if (xn < 0 || yn < 0 || xn >= w || yn >= h) return false;
+    if (tiles && job.ctu_tile[(yn >> 6) * wc + (xn >> 6)] != job.ctu_tile[(yc >> 6) * wc + (xc >> 6)]) return false;
+    return zaddr64(xn, yn, wc) <= zaddr64(xc, yc, wc);
+  }
+  void fill_u8(uint8_t *arr, int x0, int y0, int bw, int bh, int v)
+  {
+    for (int y = y0; y < y0 + bh && y < h; y += 4) for (int x = x0; x < x0 + bw && x < w; x += 4) arr[bi(x, y)] = (uint8_t)v;
+  }
+  void emit_tu(const DecTu &td)
+  {
+    const int X = td.plane ? td.x * 2 : td.x, Y = td.plane ? td.y * 2 : td.y;
+    TuRange &r = job.region[(Y >> 5) * (2 * wc) + (X >> 5)];
+    if (!r.count) r.first = (uint32_t)out.tus.size();
+    r.count++;
+    out.tus.push_back(td);
+  }
+
+  // ---------------------------------------------------------------- motion vector prediction (8.5.3.2)
+  bool pb_avail(int xcb, int ycb, int ncbs, int xpb, int ypb, int npbw, int npbh, int part_idx, int xn, int yn) const
+  {
+    const bool same_cb = xcb <= xn && ycb <= yn && xcb + ncbs > xn && ycb + ncbs > yn;
+    bool a;
+    if (!same_cb) a = avail(xpb, ypb, xn, yn);
+    else a = !((npbw << 1) == ncbs && (npbh << 1) == ncbs && part_idx == 1 && (ycb + npbh <= yn) && (xcb + npbw > xn));
+    if (a && pm[bi(xn, yn)] == PM_INTRA) a = false;
+    return a;
+  }
+  static bool same_motion(const B4Rec &a, const B4Rec &b) { return a.ref_idx == b.ref_idx && a.mvx == b.mvx && a.mvy == b.mvy; }
+
+  // temporal candidate (8.5.3.2.8, 8.5.3.2.9); collocated pictures of P streams carry list-0 motion only
+  bool temporal_mv(int xpb, int ypb, int npbw, int npbh, int ref_idx, int &mvx, int &mvy)
+  {
+    ColMotion *col = job.col.get();
+    if (!col) return false;
+    const int cy = ypb >> 6;
+    if (cy < col->hc) {                                  // the collocated picture may still be in the hands of its own parser (frame threads)
+      std::atomic<uint8_t> &d = col->row_done[(size_t)cy];
+      int spins = 0;
+      while (!d.load(std::memory_order_acquire)) { if (++spins < 2000) __builtin_ia32_pause(); else std::this_thread::yield(); }
+    }
+    const int cand[2][2] = {{xpb + npbw, ypb + npbh}, {xpb + (npbw >> 1), ypb + (npbh >> 1)}};
+    for (int k = 0; k < 2; k++) {
+      int x = cand[k][0], y = cand[k][1];
+      if (k == 0 && !((ypb >> 6) == (y >> 6) && y < h && x < w)) continue;      // bottom right: same CTB row, inside the picture
+      x >>= 4; y >>= 4;
+      if (x >= col->w16 || y >= col->h16) continue;
+      const ColMotion::Mv &m = col->mv[(size_t)y * col->w16 + x];
+      if (!m.inter) continue;
+      const int col_diff = col->poc - m.ref_poc, cur_diff = sh.poc - job.ref_poc[ref_idx];
+      mvx = m.mvx; mvy = m.mvy;
+      if (col_diff != cur_diff && col_diff != 0) {
+        const int td = clip3(-128, 127, col_diff), tb = clip3(-128, 127, cur_diff);
+        const int tx = (16384 + (iabs(td) >> 1)) / td;
+        const int dsf = clip3(-4096, 4095, (tb * tx + 32) >> 6);
+        const int px = dsf * mvx, py = dsf * mvy;
+        mvx = clip3(-32768, 32767, (px < 0 ? -1 : 1) * ((iabs(px) + 127) >> 8));
+        mvy = clip3(-32768, 32767, (py < 0 ? -1 : 1) * ((iabs(py) + 127) >> 8));
+      }
+      return true;
+    }
+    return false;
+  }
+
+  void merge_candidates(int xcb, int ycb, int ncbs, int xpb, int ypb, int npbw, int npbh, int part_idx, int pmode, MvCand *cand)
+  {
+    const int lvl = pps.par_mrg_level;
+    int n = 0;
+    if (lvl > 2 && ncbs == 8) { xpb = xcb; ypb = ycb; npbw = npbh = ncbs; part_idx = 0; pmode = PART_2Nx2N; }
+    auto par = [&](int xn, int yn) { return ((xpb >> lvl) == (xn >> lvl)) && ((ypb >> lvl) == (yn >> lvl)); };
+    const int xa1 = xpb - 1, ya1 = ypb + npbh - 1, xb1 = xpb + npbw - 1, yb1 = ypb - 1, xb0 = xpb + npbw, yb0 = ypb - 1;
+    const int xa0 = xpb - 1, ya0 = ypb + npbh, xb2 = xpb - 1, yb2 = ypb - 1;
+    const bool part1 = part_idx == 1;
+    const bool nbA1 = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xa1, ya1) && !par(xa1, ya1) &&
+                      !(part1 && (pmode == PART_Nx2N || pmode == PART_nLx2N || pmode == PART_nRx2N));
+    const bool nbB1 = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xb1, yb1) && !par(xb1, yb1) &&
+                      !(part1 && (pmode == PART_2NxN || pmode == PART_2NxnU || pmode == PART_2NxnD));
+    const bool nbB0 = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xb0, yb0) && !par(xb0, yb0);
+    const bool nbA0 = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xa0, ya0) && !par(xa0, ya0);
+    const bool nbB2 = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xb2, yb2) && !par(xb2, yb2);
+    const B4Rec zero = B4Rec();
+    const B4Rec &A1 = nbA1 ? b4[bi(xa1, ya1)] : zero, &B1 = nbB1 ? b4[bi(xb1, yb1)] : zero, &B0 = nbB0 ? b4[bi(xb0, yb0)] : zero;
+    const B4Rec &A0 = nbA0 ? b4[bi(xa0, ya0)] : zero, &B2 = nbB2 ? b4[bi(xb2, yb2)] : zero;
+    const bool avA1 = nbA1, avB1 = nbB1 && !(nbA1 && same_motion(A1, B1)), avB0 = nbB0 && !(nbB1 && same_motion(B1, B0));
+    const bool avA0 = nbA0 && !(nbA1 && same_motion(A1, A0));
+    const bool avB2 = nbB2 && !(nbA1 && same_motion(A1, B2)) && !(nbB1 && same_motion(B1, B2)) && ((int)avA0 + avA1 + avB0 + avB1 != 4);
+    const int maxc = sh.max_merge;
+    auto add = [&](const B4Rec &m) { if (n < maxc) { cand[n].mvx = m.mvx; cand[n].mvy = m.mvy; cand[n].ref_idx = m.ref_idx; n++; } };
+    if (avA1) add(A1);
+    if (avB1) add(B1);
+    if (avB0) add(B0);
+    if (avA0) add(A0);
+    if (avB2) add(B2);
+    if (n < maxc) { int tx, ty; if (temporal_mv(xpb, ypb, npbw, npbh, 0, tx, ty)) { cand[n].mvx = tx; cand[n].mvy = ty; cand[n].ref_idx = 0; n++; } }
+    for (int zi = 0; n < maxc; n++, zi++) { cand[n].mvx = cand[n].mvy = 0; cand[n].ref_idx = zi < sh.num_ref_idx ? zi : 0; }     // 8.5.3.2.5, P slices
+  }
+
+  void scale_mv(int &mvx, int &mvy, int ref_a, int ref_target) const
+  {
+    const int td = clip3(-128, 127, sh.poc - job.ref_poc[ref_a]), tb = clip3(-128, 127, sh.poc - job.ref_poc[ref_target]);
+    if (td == 0) return;
+    const int tx = (16384 + (iabs(td) >> 1)) / td, dsf = clip3(-4096, 4095, (tb * tx + 32) >> 6);
+    const int px = dsf * mvx, py = dsf * mvy;
+    mvx = clip3(-32768, 32767, (px < 0 ? -1 : 1) * ((iabs(px) + 127) >> 8));
+    mvy = clip3(-32768, 32767, (py < 0 ? -1 : 1) * ((iabs(py) + 127) >> 8));
+  }
+
+  void amvp_candidates(int xcb, int ycb, int ncbs, int xpb, int ypb, int npbw, int npbh, int part_idx, int ref_idx, int cand[2][2])
+  {
+    const int xa[2] = {xpb - 1, xpb - 1}, ya[2] = {ypb + npbh, ypb + npbh - 1};                       // A0, A1
+    const int xb[3] = {xpb + npbw, xpb + npbw - 1, xpb - 1}, yb[3] = {ypb - 1, ypb - 1, ypb - 1};     // B0, B1, B2
+    bool avA[2], avB[3];
+    for (int k = 0; k < 2; k++) avA[k] = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xa[k], ya[k]);
+    for (int k = 0; k < 3; k++) avB[k] = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xb[k], yb[k]);
+    const bool is_scaled = avA[0] || avA[1];
+    bool flagA = false, flagB = false; int ax = 0, ay = 0, bx = 0, by = 0;
+    const int target = job.ref_poc[ref_idx];
+    for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) { const B4Rec &m = b4[bi(xa[k], ya[k])]; if (job.ref_poc[m.ref_idx & 15] == target) { flagA = true; ax = m.mvx; ay = m.mvy; } }
+    for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) { const B4Rec &m = b4[bi(xa[k], ya[k])]; flagA = true; ax = m.mvx; ay = m.mvy; scale_mv(ax, ay, m.ref_idx & 15, ref_idx); }
+    for (int k = 0; k < 3 && !flagB; k++) if (avB[k]) { const B4Rec &m = b4[bi(xb[k], yb[k])]; if (job.ref_poc[m.ref_idx & 15] == target) { flagB = true; bx = m.mvx; by = m.mvy; } }
+    if (!is_scaled && flagB) { flagA = true; ax = bx; ay = by; }
+    if (!is_scaled) {
+      flagB = false;
+      for (int k = 0; k < 3 && !flagB; k++) if (avB[k]) {
+        const B4Rec &m = b4[bi(xb[k], yb[k])];
+        flagB = true; bx = m.mvx; by = m.mvy;
+        if (job.ref_poc[m.ref_idx & 15] != target) scale_mv(bx, by, m.ref_idx & 15, ref_idx);
+      }
+    }
+    int n = 0;
+    if (flagA) { cand[n][0] = ax; cand[n][1] = ay; n++; }
+    if (flagB && !(flagA && ax == bx && ay == by)) { cand[n][0] = bx; cand[n][1] = by; n++; }
+    if (n < 2) { int tx, ty; if (temporal_mv(xpb, ypb, npbw, npbh, ref_idx, tx, ty)) { cand[n][0] = tx; cand[n][1] = ty; n++; } }
+    for (; n < 2; n++) cand[n][0] = cand[n][1] = 0;
+  }
+
+  int mvd_abs(int gt0, int gt1)
+  {
+    if (!gt0) return 0;
+    if (!gt1) return 1;
+    int k = 1, v = 0;
+    while (k < 32 && c.bypass()) { v += 1 << k; k++; }
+    if (k >= 32) { err = DEC_ERR_INVALID; return 0; }
+    return v + (int)c.bypass_bits(k) + 2;
+  }
+
+  void prediction_unit(int xcb, int ycb, int ncbs, int xp, int yp, int bw, int bh, int part_idx, bool skip, int *merge_out)
+  {
+    const int merge = skip ? 1 : c.bin(CTX_MERGE_FLAG);
+    if (merge_out) *merge_out = merge;
+    int mvx, mvy, ref_idx = 0;
+    if (merge) {
+      int idx = 0;
+      if (sh.max_merge > 1 && c.bin(CTX_MERGE_IDX)) { idx = 1; while (idx < sh.max_merge - 1 && c.bypass()) idx++; }
+      MvCand cand[5];
+      merge_candidates(xcb, ycb, ncbs, xp, yp, bw, bh, part_idx, part_mode, cand);
+      mvx = cand[idx].mvx; mvy = cand[idx].mvy; ref_idx = cand[idx].ref_idx;
+    } else {
+      if (sh.num_ref_idx > 1) {
+        const int mx = sh.num_ref_idx - 1;
+        while (ref_idx < mx && ref_idx < 2 && c.bin(CTX_REF_IDX + ref_idx)) ref_idx++;
+        if (ref_idx == 2) while (ref_idx < mx && c.bypass()) ref_idx++;
+      }
+      const int g0x = c.bin(CTX_MVD_GT0), g0y = c.bin(CTX_MVD_GT0);
+      const int g1x = g0x ? c.bin(CTX_MVD_GT1) : 0, g1y = g0y ? c.bin(CTX_MVD_GT1) : 0;
+      int dx = mvd_abs(g0x, g1x); if (g0x && c.bypass()) dx = -dx;
+      int dy = mvd_abs(g0y, g1y); if (g0y && c.bypass()) dy = -dy;
+      const int mvp = c.bin(CTX_MVP_FLAG);
+      int cand[2][2];
+      amvp_candidates(xcb, ycb, ncbs, xp, yp, bw, bh, part_idx, ref_idx, cand);
+      mvx = (int16_t)(uint16_t)(cand[mvp][0] + dx); mvy = (int16_t)(uint16_t)(cand[mvp][1] + dy);      // 8.5.3.2.6: modulo 2^16
+    }
+    if (ref_idx < 0 || ref_idx >= job.nref) { err = DEC_ERR_INVALID; ref_idx = 0; }
+    B4Rec r; r.mvx = (int16_t)mvx; r.mvy = (int16_t)mvy; r.ref_idx = (int8_t)ref_idx; r.flags = 0; r.qp_y = 0; r.slot = job.ref_slot[ref_idx];
+    for (int y = yp; y < yp + bh && y < h; y += 4) for (int x = xp; x < xp + bw && x < w; x += 4) b4[bi(x, y)] = r;
+    for (int i = 0; i < bh && yp + i < h; i += 4) b4[bi(xp, yp + i)].flags |= B4_EDGE_V;                // prediction block edges (deblocking)
+    for (int i = 0; i < bw && xp + i < w; i += 4) b4[bi(xp + i, yp)].flags |= B4_EDGE_H;
+  }
+
+  // ---------------------------------------------------------------- transform tree (7.3.8.8 - 7.3.8.10)
+  void transform_unit(int x0, int y0, int xbase, int ybase, int log2, int blk, int cbf_luma, int cbf_cb, int cbf_cr, int cbf_cb_parent, int cbf_cr_parent)
+  {
+    const bool intra = cu_pred_mode == PM_INTRA;
+    const bool chroma_here = log2 > 2, chroma_parent = log2 == 2 && blk == 3;
+    const int ccb = chroma_here ? cbf_cb : (chroma_parent ? cbf_cb_parent : 0), ccr = chroma_here ? cbf_cr : (chroma_parent ? cbf_cr_parent : 0);
+    const bool cbf_chroma_any = log2 > 2 ? (cbf_cb || cbf_cr) : (cbf_cb_parent || cbf_cr_parent);
+    if ((cbf_luma || cbf_chroma_any) && pps.cu_qp_delta && !qp_delta_coded) {
+      int v = 0;
+      while (v < 5 && c.bin(CTX_CU_QP_DELTA + (v ? 1 : 0))) v++;
+      if (v == 5) { int k = 0; while (k < 16 && c.bypass()) { v += 1 << k; k++; } if (k >= 16) { err = DEC_ERR_INVALID; return; } v += (int)c.bypass_bits(k); }
+      if (v && c.bypass()) v = -v;
+      if (v < -26 || v > 25) { err = DEC_ERR_INVALID; return; }
+      qp_delta_coded = true; cu_qp_delta_val = v;
+      qp_y = (qp_y_pred + v + 52) % 52;
+    }
+    const int n = 1 << log2;
+    DecTu td; td.pad = 0;
+    const int lmode = intra ? im[bi(x0, y0)] : 0;
+    if (intra || cbf_luma) {
+      td.x = (uint16_t)x0; td.y = (uint16_t)y0; td.plane = 0; td.log2 = (uint8_t)log2; td.mode = (uint8_t)lmode; td.qp = (int8_t)qp_y;
+      td.flags = (uint8_t)((intra ? TU_INTRA : 0) | ((intra && log2 == 2) ? TU_DST : 0));
+      td.offset = (uint32_t)out.levels.size(); td.count = 0;
+      if (cbf_luma) {
+        int ts;
+        if (!parse_residual(c, log2, 0, intra_scan_idx(intra, log2, 0, lmode), pps.sign_hiding != 0, pps.tskip != 0, &ts, out.levels)) { err = DEC_ERR_INVALID; return; }
+        td.count = (uint16_t)(out.levels.size() - td.offset);
+        if (ts) td.flags |= TU_TSKIP;
+        for (int y = y0; y < y0 + n && y < h; y += 4) for (int x = x0; x < x0 + n && x < w; x += 4) b4[bi(x, y)].flags |= B4_NZ;
+      }
+      emit_tu(td);
+      if (intra) ctu_intra_mask |= 1u;
+    }
+    if (chroma_here || chroma_parent) {
+      const int cx = (chroma_here ? x0 : xbase) >> 1, cy = (chroma_here ? y0 : ybase) >> 1, clog2 = chroma_here ? log2 - 1 : 2;
+      for (int ci = 1; ci <= 2; ci++) {
+        const int cbf = ci == 1 ? ccb : ccr;
+        if (!intra && !cbf) continue;
+        td.x = (uint16_t)cx; td.y = (uint16_t)cy; td.plane = (uint8_t)ci; td.log2 = (uint8_t)clog2; td.mode = (uint8_t)chroma_mode;
+        td.qp = (int8_t)kChromaQp[clip3(0, 57, qp_y + (ci == 1 ? sh.cb_qp_offset : sh.cr_qp_offset))];
+        td.flags = (uint8_t)(intra ? TU_INTRA : 0);
+        td.offset = (uint32_t)out.levels.size(); td.count = 0;
+        if (cbf) {
+          int ts;
+          if (!parse_residual(c, clog2, ci, intra_scan_idx(intra, clog2, ci, chroma_mode), pps.sign_hiding != 0, pps.tskip != 0, &ts, out.levels)) { err = DEC_ERR_INVALID; return; }
+          td.count = (uint16_t)(out.levels.size() - td.offset);
+          if (ts) td.flags |= TU_TSKIP;
+        }
+        emit_tu(td);
+        if (intra) ctu_intra_mask |= 1u << ci;
+      }
+    }
+  }
+
+  void transform_tree(int x0, int y0, int xbase, int ybase, int log2, int depth, int blk, int cbf_cb_parent, int cbf_cr_parent)
+  {
+    if (err) return;
+    int split;
+    if (log2 <= 5 && log2 > 2 && depth < max_trafo_depth && !(intra_split && depth == 0)) split = c.bin(CTX_SPLIT_TRANSFORM + 5 - log2);
+    else {
+      const bool inter_split = sps.th_depth_inter == 0 && cu_pred_mode == PM_INTER && part_mode != PART_2Nx2N && depth == 0;
+      split = (log2 > 5 || (intra_split && depth == 0) || inter_split) ? 1 : 0;
+    }
+    int cbf_cb = 0, cbf_cr = 0;
+    if (log2 > 2) {
+      if (depth == 0 || cbf_cb_parent) cbf_cb = c.bin(CTX_CBF_CHROMA + depth);
+      if (depth == 0 || cbf_cr_parent) cbf_cr = c.bin(CTX_CBF_CHROMA + depth);
+    } else { cbf_cb = cbf_cb_parent; cbf_cr = cbf_cr_parent; }
+    if (split) {
+      if (log2 <= 2) { err = DEC_ERR_INVALID; return; }
+      const int hh = 1 << (log2 - 1);
+      transform_tree(x0, y0, x0, y0, log2 - 1, depth + 1, 0, cbf_cb, cbf_cr);
+      transform_tree(x0 + hh, y0, x0, y0, log2 - 1, depth + 1, 1, cbf_cb, cbf_cr);
+      transform_tree(x0, y0 + hh, x0, y0, log2 - 1, depth + 1, 2, cbf_cb, cbf_cr);
+      transform_tree(x0 + hh, y0 + hh, x0, y0, log2 - 1, depth + 1, 3, cbf_cb, cbf_cr);
+    } else {
+      int cbf_luma = 1;
+      if (cu_pred_mode == PM_INTRA || depth != 0 || cbf_cb || cbf_cr) cbf_luma = c.bin(CTX_CBF_LUMA + (depth == 0 ? 1 : 0));
+      const int n = 1 << log2;
+      for (int i = 0; i < n; i += 4) {                     // transform block edges (deblocking)
+        if (y0 + i < h) b4[bi(x0, y0 + i)].flags |= B4_EDGE_V | B4_TU_V;
+        if (x0 + i < w) b4[bi(x0 + i, y0)].flags |= B4_EDGE_H | B4_TU_H;
+      }
+      transform_unit(x0, y0, xbase, ybase, log2, blk, cbf_luma, log2 > 2 ? cbf_cb : 0, log2 > 2 ? cbf_cr : 0, cbf_cb_parent, cbf_cr_parent);
+    }
+  }
+
+  // ---------------------------------------------------------------- coding unit (7.3.8.5)
+  void coding_unit(int x0, int y0, int log2cb, int depth)
+  {
+    const int n = 1 << log2cb;
+    int skip = 0;
+    if (!sh.is_intra) {
+      const int l = avail(x0, y0, x0 - 1, y0) && pm[bi(x0 - 1, y0)] == PM_SKIP, a = avail(x0, y0, x0, y0 - 1) && pm[bi(x0, y0 - 1)] == PM_SKIP;
+      skip = c.bin(CTX_SKIP + l + a);
+    }
+    part_mode = PART_2Nx2N; intra_split = false;
+    int rqt_root_cbf = 1, merge_2nx2n = 0;
+    fill_u8(ctd, x0, y0, n, n, depth);
+    if (skip) {
+      cu_pred_mode = PM_INTER;
+      fill_u8(pm, x0, y0, n, n, PM_SKIP);
+      prediction_unit(x0, y0, n, x0, y0, n, n, 0, true, nullptr);
+      rqt_root_cbf = 0;
+      job.any_inter = true;
+    } else {
+      cu_pred_mode = PM_INTRA;
+      if (!sh.is_intra) cu_pred_mode = c.bin(CTX_PRED_MODE) ? PM_INTRA : PM_INTER;
+      if (cu_pred_mode != PM_INTRA || log2cb == 3) {
+        if (cu_pred_mode == PM_INTRA) part_mode = c.bin(CTX_PART_MODE) ? PART_2Nx2N : PART_NxN;
+        else if (c.bin(CTX_PART_MODE)) part_mode = PART_2Nx2N;
+        else if (log2cb == 3) part_mode = c.bin(CTX_PART_MODE + 1) ? PART_2NxN : PART_Nx2N;            // (NxN inter is not allowed at 8x8)
+        else if (!sps.amp) part_mode = c.bin(CTX_PART_MODE + 1) ? PART_2NxN : PART_Nx2N;
+        else {
+          const int horiz = c.bin(CTX_PART_MODE + 1);
+          if (c.bin(CTX_PART_MODE + 3)) part_mode = horiz ? PART_2NxN : PART_Nx2N;
+          else { const int b = c.bypass(); part_mode = horiz ? (b ? PART_2NxnD : PART_2NxnU) : (b ? PART_nRx2N : PART_nLx2N); }
+        }
+      }
+      fill_u8(pm, x0, y0, n, n, cu_pred_mode);
+      if (cu_pred_mode == PM_INTRA) {
+        intra_split = part_mode == PART_NxN;
+        const int parts = intra_split ? 2 : 1, pb = n / parts;
+        int prev[4], k = 0;
+        for (int j = 0; j < parts * parts; j++) prev[j] = c.bin(CTX_PREV_INTRA);
+        for (int j = 0; j < parts; j++)
+          for (int i = 0; i < parts; i++, k++) {
+            const int xp = x0 + i * pb, yp = y0 + j * pb;
+            int ca = 1, cb = 1;                                   // 8.4.2 candidate modes
+            if (avail(xp, yp, xp - 1, yp) && pm[bi(xp - 1, yp)] == PM_INTRA) ca = im[bi(xp - 1, yp)];
+            if (avail(xp, yp, xp, yp - 1) && pm[bi(xp, yp - 1)] == PM_INTRA && (yp - 1) >= ((yp >> 6) << 6)) cb = im[bi(xp, yp - 1)];
+            int cand[3];
+            if (ca == cb) {
+              if (ca < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
+              else { cand[0] = ca; cand[1] = 2 + ((ca + 29) % 32); cand[2] = 2 + ((ca - 2 + 1) % 32); }
+            } else {
+              cand[0] = ca; cand[1] = cb;
+              cand[2] = (ca != 0 && cb != 0) ? 0 : ((ca != 1 && cb != 1) ? 1 : 26);
+            }
+            int mode;
+            if (prev[k]) { int idx = 0; if (c.bypass()) { idx = 1; if (c.bypass()) idx = 2; } mode = cand[idx]; }
+            else {
+              mode = (int)c.bypass_bits(5);
+              int t;
+              if (cand[0] > cand[1]) { t = cand[0]; cand[0] = cand[1]; cand[1] = t; }
+              if (cand[0] > cand[2]) { t = cand[0]; cand[0] = cand[2]; cand[2] = t; }
+              if (cand[1] > cand[2]) { t = cand[1]; cand[1] = cand[2]; cand[2] = t; }
+              for (int q = 0; q < 3; q++) if (mode >= cand[q]) mode++;
+            }
+            intra_modes[k] = mode;
+            fill_u8(im, xp, yp, pb, pb, mode);
+          }
+        int icpm = 4;
+        if (c.bin(CTX_CHROMA_MODE)) icpm = (int)c.bypass_bits(2);
+        static const int cm[4] = {0, 26, 10, 1};
+        if (icpm == 4) chroma_mode = intra_modes[0];
+        else { chroma_mode = cm[icpm]; if (chroma_mode == intra_modes[0]) chroma_mode = 34; }
+        B4Rec r; r.mvx = 0; r.mvy = 0; r.ref_idx = -1; r.flags = 0; r.qp_y = 0; r.slot = 0;
+        for (int y = y0; y < y0 + n && y < h; y += 4) for (int x = x0; x < x0 + n && x < w; x += 4) b4[bi(x, y)] = r;
+        job.any_intra = true;
+      } else {
+        const int hh = n / 2, q = n / 4; int mf = 0;
+        switch (part_mode) {
+          case PART_2Nx2N: prediction_unit(x0, y0, n, x0, y0, n, n, 0, false, &merge_2nx2n); break;
+          case PART_2NxN: prediction_unit(x0, y0, n, x0, y0, n, hh, 0, false, &mf); prediction_unit(x0, y0, n, x0, y0 + hh, n, hh, 1, false, &mf); break;
+          case PART_Nx2N: prediction_unit(x0, y0, n, x0, y0, hh, n, 0, false, &mf); prediction_unit(x0, y0, n, x0 + hh, y0, hh, n, 1, false, &mf); break;
+          case PART_2NxnU: prediction_unit(x0, y0, n, x0, y0, n, q, 0, false, &mf); prediction_unit(x0, y0, n, x0, y0 + q, n, n - q, 1, false, &mf); break;
+          case PART_2NxnD: prediction_unit(x0, y0, n, x0, y0, n, n - q, 0, false, &mf); prediction_unit(x0, y0, n, x0, y0 + n - q, n, q, 1, false, &mf); break;
+          case PART_nLx2N: prediction_unit(x0, y0, n, x0, y0, q, n, 0, false, &mf); prediction_unit(x0, y0, n, x0 + q, y0, n - q, n, 1, false, &mf); break;
+          default: prediction_unit(x0, y0, n, x0, y0, n - q, n, 0, false, &mf); prediction_unit(x0, y0, n, x0 + n - q, y0, q, n, 1, false, &mf); break;     // nRx2N
+        }
+        if (!(part_mode == PART_2Nx2N && merge_2nx2n)) rqt_root_cbf = c.bin(CTX_RQT_ROOT_CBF);
+        job.any_inter = true;
+      }
+    }
+    if (err) return;
+    for (int i = 0; i < n; i += 4) {                       // coding block edges are transform and prediction edges
+      if (y0 + i < h) b4[bi(x0, y0 + i)].flags |= B4_EDGE_V | B4_TU_V;
+      if (x0 + i < w) b4[bi(x0 + i, y0)].flags |= B4_EDGE_H | B4_TU_H;
+    }
+    qp_y = (qp_y_pred + cu_qp_delta_val + 52) % 52;          // CuQpDeltaVal of the quantisation group so far
+    if (rqt_root_cbf) {
+      max_trafo_depth = cu_pred_mode == PM_INTRA ? sps.th_depth_intra + (intra_split ? 1 : 0) : sps.th_depth_inter;
+      transform_tree(x0, y0, x0, y0, log2cb, 0, 0, 0, 0);
+    }
+    for (int y = y0; y < y0 + n && y < h; y += 4) for (int x = x0; x < x0 + n && x < w; x += 4) b4[bi(x, y)].qp_y = (int8_t)qp_y;
+    last_qp_y = qp_y;
+  }
+
+  void coding_quadtree(int x0, int y0, int log2cb, int depth)
+  {
+    if (err) return;
+    const int n = 1 << log2cb;
+    int split;
+    if (x0 + n <= w && y0 + n <= h && log2cb > 3) {
+      const int l = avail(x0, y0, x0 - 1, y0) && ctd[bi(x0 - 1, y0)] > depth, a = avail(x0, y0, x0, y0 - 1) && ctd[bi(x0, y0 - 1)] > depth;
+      split = c.bin(CTX_SPLIT_CU + l + a);
+    } else split = log2cb > 3;
+    if (pps.cu_qp_delta && log2cb >= log2_qg) {            // a quantisation group starts here (7.3.8.4, 8.6.1)
+      qp_delta_coded = false; cu_qp_delta_val = 0;
+      int qa = last_qp_y, qb = last_qp_y;
+      if (avail(x0, y0, x0 - 1, y0) && ((x0 - 1) >> 6) == (x0 >> 6)) qa = b4[bi(x0 - 1, y0)].qp_y;
+      if (avail(x0, y0, x0, y0 - 1) && ((y0 - 1) >> 6) == (y0 >> 6)) qb = b4[bi(x0, y0 - 1)].qp_y;
+      qp_y_pred = (qa + qb + 1) >> 1;
+    }
+    if (split) {
+      const int hh = n >> 1;
+      coding_quadtree(x0, y0, log2cb - 1, depth + 1);
+      if (x0 + hh < w) coding_quadtree(x0 + hh, y0, log2cb - 1, depth + 1);
+      if (y0 + hh < h) coding_quadtree(x0, y0 + hh, log2cb - 1, depth + 1);
+      if (x0 + hh < w && y0 + hh < h) coding_quadtree(x0 + hh, y0 + hh, log2cb - 1, depth + 1);
+    } else coding_unit(x0, y0, log2cb, depth);
+  }
+};
 
 }  // namespace
 
@@ -275,7 +743,6 @@ void Decoder::drop_pending()
 
 Decoder::~Decoder()
 {
-  if (getenv("KVAZZUP_AMD_TRACE")) fprintf(stderr, "kvazzup_amd parse Mcycles: split %.1f  skip/pred %.1f  intra/merge/amvp %.1f  residual %.1f  records %.1f  ctu-end %.1f\n", g_tc[0] * 1e-6, g_tc[1] * 1e-6, g_tc[2] * 1e-6, g_tc[3] * 1e-6, g_tc[4] * 1e-6, g_tc[5] * 1e-6);
   if (getenv("KVAZZUP_AMD_TRACE")) fprintf(stderr, "kvazzup_amd decoder thread ms: nal %.1f  wait_parse %.1f  stage %.1f  gpu_api %.1f  gpu_sync %.1f  longest parse %.2f  (pictures %ld)\n", t_nal_, t_wait_, t_stage_, t_api_, t_sync_, t_parse_max_, job_tail_);
   drop_pending();
   workers_.reset();
@@ -312,39 +779,24 @@ bool Decoder::start(std::string *error)
 
 void Decoder::free_buffers()
 {
-  for (auto &j : jobs_) { if (j.h_in) hipHostFree(j.h_in); j.h_in = nullptr; j.h_in_cap = 0; }
+  for (auto &j : jobs_) { if (j.h_in) hipHostFree(j.h_in); j.h_in = nullptr; j.h_in_cap = 0; j.col.reset(); j.own.reset(); }
   if (h_out_) hipHostFree(h_out_);
-  hipFree(d_in_); hipFree(d_mvd_); hipFree(sync_);
-  for (int c = 0; c < 3; c++) { for (int b = 0; b < 3; b++) { hipFree(rec_[b][c]); rec_[b][c] = nullptr; } hipFree(work_[c]); work_[c] = nullptr; hipFree(coef_[c]); coef_[c] = nullptr; }
-  h_out_ = nullptr; d_in_ = nullptr; d_in_cap_ = 0; d_mvd_ = nullptr; sync_ = nullptr;
-  cw_ = ch_ = 0;
+  hipFree(d_in_); hipFree(progress_);
+  for (auto &p : dpb_) { for (int c = 0; c < 3; c++) { hipFree(p.plane[c]); p.plane[c] = nullptr; } p = DpbPic(); }
+  for (int c = 0; c < 3; c++) { hipFree(work_[c]); work_[c] = nullptr; }
+  h_out_ = nullptr; d_in_ = nullptr; d_in_cap_ = 0; progress_ = nullptr;
+  w_ = h_ = pw_ = ph_ = 0;
 }
 
-// EncFrame view of the CU records and motion vectors at the start of an input block (host or device)
-void Decoder::bind_views(EncFrame &f, uint8_t *base)
+// host views into a job's input block
+void Decoder::bind_job(PicJob &job)
 {
-  const size_t nb8 = (size_t)cw_ * ch_ / 64;
-  const int wpp = f.wpp, is_intra = f.is_intra, qp = f.qp, tile_rows = f.tile_rows > 0 ? f.tile_rows : 1;
-  EncFrame keep = f;
-  memset(&f, 0, sizeof(f));
-  f.cw = cw_; f.ch = ch_; f.b8w = cw_ / 8; f.b8h = ch_ / 8; f.wpp = wpp; f.is_intra = is_intra; f.qp = qp;
-  f.tile_rows = tile_rows; f.chp = pack_height(ch_, tile_rows);
-  f.cu_log2 = base; f.cu_intra = base + nb8; f.cu_flags = base + 2 * nb8; f.cu_merge_idx = base + 3 * nb8;
-  f.cu_mvp_idx = base + 4 * nb8; f.cu_intra_mode = base + 5 * nb8; f.cu_cbf = base + 6 * nb8; f.cu_mv = (int16_t *)(base + 7 * nb8);
-  f.cu_mvd = keep.cu_mvd; f.sync = keep.sync; f.err = keep.err;
-  for (int c = 0; c < 3; c++) { f.coef[c] = keep.coef[c]; f.rec[c] = keep.rec[c]; f.ref[c] = keep.ref[c]; }
-  // per-CTU QP arrays follow the motion vectors; the frame's pointers are switched on per picture (PPS cu_qp_delta_enabled_flag)
+  uint8_t *p = job.h_in;
+  job.b4 = (B4Rec *)p; job.region = (TuRange *)(p + off_region()); job.ctu = (TuRange *)(p + off_ctu());
+  job.ctu_tile = p + off_tile(); job.sao = (SaoParams *)(p + off_sao());
 }
 
-// pointers of the per-CTU QP arrays inside an input block
-static inline void bind_qp_arrays(EncFrame &f, uint8_t *base, int cw, int ch, bool on)
-{
-  const size_t nb8 = (size_t)cw * ch / 64, nctu = (size_t)(cw / 64) * (ch / 64);
-  int8_t *q = (int8_t *)(base + 11 * nb8);
-  f.ctu_qy = on ? q : nullptr; f.ctu_qt = on ? q : nullptr; f.ctu_delta = on ? q + nctu : nullptr; f.ctu_first = on ? (uint8_t *)(q + 2 * nctu) : nullptr;
-}
-
-// pinned input block of a job: at least `bytes`; the CU / motion part written so far is kept.  Called from the
+// pinned input block of a job: at least `bytes`; the fixed part written so far is kept.  Called from the
 // thread that owns the job (decoder thread at allocation, the job's parse worker later).
 bool Decoder::grow_job_input(PicJob &job, size_t bytes)
 {
@@ -355,42 +807,49 @@ bool Decoder::grow_job_input(PicJob &job, size_t bytes)
   if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return false;
   if (job.h_in) { memcpy(p, job.h_in, fixed_bytes() < job.h_in_cap ? fixed_bytes() : job.h_in_cap); hipHostFree(job.h_in); }
   job.h_in = p; job.h_in_cap = cap;
-  bind_views(job.hf, p);
+  bind_job(job);
   return true;
 }
 
-bool Decoder::ensure_buffers(int cw, int ch)
+bool Decoder::ensure_buffers(int w, int h)
 {
-  if (cw == cw_ && ch == ch_) return true;
+  if (w == w_ && h == h_) return true;
   drop_pending();                                          // (resolution change: pictures not yet output are dropped)
   hipStreamSynchronize(stream_);
   free_buffers();
-  const size_t npx = (size_t)cw * ch, nb8 = npx / 64;
   if (jobs_.empty()) jobs_ = std::vector<PicJob>((size_t)frame_threads_ + 1);   // parse ring + the picture in flight on the GPU
-  cw_ = cw; ch_ = ch;
+  w_ = w; h_ = h; pw_ = (w + 63) & ~63; ph_ = (h + 63) & ~63;
+  const size_t npx = (size_t)pw_ * ph_, nb4 = npx / 16;
   for (auto &j : jobs_) {
     if (!grow_job_input(j, fixed_bytes() + (1 << 16))) return false;
     memset(j.h_in, 0, fixed_bytes());
+    j.pred_mode.assign(nb4, PM_NONE); j.ct_depth.assign(nb4, 0); j.intra_mode.assign(nb4, 1);
   }
   HIP_TRY(hipHostMalloc(&h_out_, npx * 3 / 2, hipHostMallocDefault));
   h_out_cap_ = npx * 3 / 2;
   d_in_cap_ = fixed_bytes() + (1 << 20);
   HIP_TRY(hipMalloc(&d_in_, d_in_cap_));
-  HIP_TRY(hipMalloc(&d_mvd_, nb8 * 2 * sizeof(int16_t)));
-  HIP_TRY(hipMalloc(&sync_, sizeof(uint32_t) * 3 * (size_t)(ch / 64)));
-  for (int c = 0; c < 3; c++) {
-    size_t n = c ? npx / 4 : npx;
-    for (int b = 0; b < 3; b++) { HIP_TRY(hipMalloc(&rec_[b][c], n)); HIP_TRY(hipMemset(rec_[b][c], 128, n)); }
-    HIP_TRY(hipMalloc(&work_[c], n));
-    HIP_TRY(hipMalloc(&coef_[c], n * sizeof(int16_t)));
-  }
-  for (auto &j : jobs_) bind_views(j.hf, j.h_in);
-  bind_views(f_, d_in_);
-  f_.cu_mvd = d_mvd_;
-  for (int c = 0; c < 3; c++) f_.coef[c] = coef_[c];
-  f_.sync = sync_; f_.err = err_;
-  have_ref_ = false;
+  HIP_TRY(hipMalloc(&progress_, sizeof(uint32_t) * 3 * (size_t)(pw_ / 64) * (ph_ / 64)));
+  for (int c = 0; c < 3; c++) HIP_TRY(hipMalloc(&work_[c], c ? npx / 4 : npx));
+  for (int s = 0; s < 6; s++) for (int c = 0; c < 3; c++) { const size_t n = c ? npx / 4 : npx; HIP_TRY(hipMalloc(&dpb_[s].plane[c], n)); HIP_TRY(hipMemset(dpb_[s].plane[c], 128, n)); }
+  seen_irap_ = false;
   return true;
+}
+
+// a picture buffer for the picture about to be decoded: not a reference any more and, if it was output, output long enough ago
+int Decoder::alloc_slot()
+{
+  for (int s = 0; s < KVZ_DEC_MAX_REFS; s++) {
+    DpbPic &p = dpb_[s];
+    if (p.is_ref || job_head_ - p.decode_idx <= output_hold_) continue;
+    if (!p.plane[0]) {
+      const size_t npx = (size_t)pw_ * ph_;
+      if (hipSetDevice(device_) != hipSuccess) return -1;
+      for (int c = 0; c < 3; c++) { const size_t n = c ? npx / 4 : npx; if (hipMalloc(&p.plane[c], n) != hipSuccess) return -1; hipMemset(p.plane[c], 128, n); }
+    }
+    return s;
+  }
+  return -1;
 }
 
 template <class F> void Decoder::timed(int id, F &&launch)
@@ -419,6 +878,7 @@ int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
   if (len < 2 || (data[0] & 0x80)) return last_error_ = DEC_ERR_INVALID;      // EOS / EOB are header-only
   const int nal_type = (data[0] >> 1) & 0x3f, layer = ((data[0] & 1) << 5) | (data[1] >> 3);
   if (layer != 0) return 0;
+  cur_tid_ = (data[1] & 7) - 1;
   rbsp_.assign(len + 32, 0);
   epb_.clear();
   size_t n = 0; int zeros = 0;
@@ -433,6 +893,7 @@ int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
     int oi = r.get(1);
     for (int k = oi ? 0 : msl; k <= msl; k++) { r.ue(); r.ue(); r.ue(); }
     int max_layer_id = r.get(6); int nls = r.ue() + 1;
+    if (nls > 1024) return last_error_ = DEC_ERR_INVALID;
     for (int a = 1; a < nls; a++) for (int b = 0; b <= max_layer_id; b++) r.get(1);
     if (r.get(1)) { vps_fps_den_ = r.get(32); vps_fps_num_ = r.get(32); }
     return r.err ? (last_error_ = DEC_ERR_INVALID) : 0;
@@ -447,25 +908,22 @@ int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
     if (r.get(1)) { s.crop_l = 2 * r.ue(); s.crop_r = 2 * r.ue(); s.crop_t = 2 * r.ue(); s.crop_b = 2 * r.ue(); }
     if (r.ue() != 0 || r.ue() != 0) return last_error_ = DEC_ERR_UNSUPPORTED;   // 8 bit only
     s.log2_max_poc_lsb = r.ue() + 4;
+    if (s.log2_max_poc_lsb > 16) return last_error_ = DEC_ERR_INVALID;
     int oi = r.get(1);
     for (int k = oi ? 0 : msl; k <= msl; k++) { r.ue(); r.ue(); r.ue(); }
-    int log2_min_cb = r.ue() + 3, diff_cb = r.ue(), log2_min_tb = r.ue() + 2, diff_tb = r.ue(), dinter = r.ue(), dintra = r.ue();
-    int scaling = r.get(1); int amp = r.get(1), sao = r.get(1), pcm = r.get(1);
-    s.sao = sao;
-    if (scaling || amp || pcm || log2_min_cb != 3 || diff_cb != 3 || log2_min_tb != 2 || diff_tb != 3 || dinter != 0 || dintra != 0)
+    int log2_min_cb = r.ue() + 3, diff_cb = r.ue(), log2_min_tb = r.ue() + 2, diff_tb = r.ue();
+    s.th_depth_inter = r.ue(); s.th_depth_intra = r.ue();
+    int scaling = r.get(1); s.amp = r.get(1); s.sao = r.get(1); int pcm = r.get(1);
+    if (r.err) return last_error_ = DEC_ERR_INVALID;
+    // coding geometry: CTB 64, coding blocks 8..64, transform blocks 4..32 -- what Kvazaar always writes
+    if (scaling || pcm || log2_min_cb != 3 || diff_cb != 3 || log2_min_tb != 2 || diff_tb != 3 || s.th_depth_inter > 4 || s.th_depth_intra > 4)
       return last_error_ = DEC_ERR_UNSUPPORTED;
     s.num_st_rps = r.ue();
     if (s.num_st_rps > 64) return last_error_ = DEC_ERR_INVALID;
-    for (int k = 0; k < s.num_st_rps; k++) {
-      if (k != 0 && r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;            // inter RPS prediction
-      int nneg = r.ue(), npos = r.ue();
-      if (nneg != 1 || npos != 0) return last_error_ = DEC_ERR_UNSUPPORTED;        // exactly one (previous) reference
-      s.rps_neg[k] = -(int)(r.ue() + 1); s.rps_used[k] = r.get(1);
-    }
+    for (int k = 0; k < s.num_st_rps; k++) if (!parse_st_rps(r, k, s.num_st_rps, s.st_rps, s.st_rps[k])) return last_error_ = DEC_ERR_INVALID;
     if (r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;      // long-term references
-    if (r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;      // temporal MVP
+    s.tmvp = r.get(1);
     s.strong_intra = r.get(1);
-    if (!s.strong_intra) return last_error_ = DEC_ERR_UNSUPPORTED;   // kernels assume strong_intra_smoothing_enabled_flag = 1
     if (r.get(1)) {                                               // VUI: timing only
       if (r.get(1)) { if (r.get(8) == 255) { r.get(16); r.get(16); } }
       if (r.get(1)) r.get(1);
@@ -476,48 +934,52 @@ int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
       if (r.get(1)) { s.fps_den = r.get(32); s.fps_num = r.get(32); }
     }
     if (r.err) return last_error_ = DEC_ERR_INVALID;
-    if ((s.width & 63) || (s.height & 63) || s.width < 128 || s.height < 64) return last_error_ = DEC_ERR_UNSUPPORTED;
+    // sizes: multiples of the minimum coding block; the upper bound is the encoder's (and keeps every index inside 32 bits)
+    if ((s.width & 7) || (s.height & 7) || s.width < 16 || s.height < 16 || s.width > 16384 || s.height > 16384) return last_error_ = DEC_ERR_UNSUPPORTED;
+    if (s.crop_l + s.crop_r >= s.width || s.crop_t + s.crop_b >= s.height) return last_error_ = DEC_ERR_INVALID;
     s.valid = true; sps_[id] = s;
     return 0;
   }
   if (nal_type == 34) {                                          // PPS (7.3.2.3)
     DecPps p;
-    int id = r.ue(), sid = r.ue();
-    if (id > 63 || sid != 0) return last_error_ = (id > 63 ? DEC_ERR_INVALID : DEC_ERR_UNSUPPORTED);
-    int dep = r.get(1), outflag = r.get(1), extra = r.get(3), signhide = r.get(1);
+    int id = r.ue(); p.sps_id = r.ue();
+    if (id > 63 || p.sps_id > 15) return last_error_ = DEC_ERR_INVALID;
+    int dep = r.get(1); p.output_flag_present = r.get(1); p.extra_header_bits = r.get(3); p.sign_hiding = r.get(1);
     p.cabac_init_present = r.get(1);
-    int l0 = r.ue(), l1 = r.ue(); (void)l1;
+    p.num_ref_idx_default = (int)r.ue() + 1; r.ue();
     p.init_qp = 26 + r.se();
-    int cip = r.get(1), tskip = r.get(1), cuqpd = r.get(1);
-    if (cuqpd) { if (r.ue() != 0) return last_error_ = DEC_ERR_UNSUPPORTED; p.qp_in_cu = 1; }   // quantisation group = CTU only
-    int cbo = r.se(), cro = r.se(), sco = r.get(1), wp = r.get(1), wbp = r.get(1), tqb = r.get(1), tiles = r.get(1);
+    int cip = r.get(1); p.tskip = r.get(1); p.cu_qp_delta = r.get(1);
+    if (p.cu_qp_delta) { p.qp_delta_depth = r.ue(); if (p.qp_delta_depth > 3) return last_error_ = DEC_ERR_INVALID; }
+    p.cb_qp_offset = r.se(); p.cr_qp_offset = r.se(); p.slice_chroma_offsets = r.get(1);
+    int wp = r.get(1), wbp = r.get(1), tqb = r.get(1), tiles = r.get(1);
     p.wpp = r.get(1);
-    if (dep || outflag || extra || signhide || p.cabac_init_present || l0 != 0 || cip || tskip || cbo || cro || sco || wp || wbp || tqb)
-      return last_error_ = DEC_ERR_UNSUPPORTED;
-    if (tiles) {                                                 // supported: one column, uniform spacing, loop filter across tiles on
-      const int cols = r.ue() + 1, rows = r.ue() + 1, uniform = r.get(1);
-      if (cols != 1 || !uniform || rows > 1024) return last_error_ = DEC_ERR_UNSUPPORTED;
+    if (r.err || p.num_ref_idx_default > 15 || p.cb_qp_offset < -12 || p.cb_qp_offset > 12 || p.cr_qp_offset < -12 || p.cr_qp_offset > 12) return last_error_ = DEC_ERR_INVALID;
+    if (dep || cip || wp || wbp || tqb) return last_error_ = DEC_ERR_UNSUPPORTED;   // dependent slices, constrained intra, weighted prediction, lossless
+    if (tiles) {                                                 // supported: one column; loop filter across tiles on
+      const int cols = r.ue() + 1, rows = r.ue() + 1; p.uniform_tiles = r.get(1);
+      if (cols != 1 || rows > 32) return last_error_ = DEC_ERR_UNSUPPORTED;
+      if (!p.uniform_tiles) for (int k = 0; k < rows - 1; k++) { p.row_height[k] = (int)r.ue() + 1; if (p.row_height[k] > 1024) return last_error_ = DEC_ERR_INVALID; }
       if (!r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;   // loop_filter_across_tiles_enabled_flag
       p.tile_rows = rows;
     }
     p.loop_filter_across_slices = r.get(1);
     p.deblock_control = r.get(1);
     if (p.deblock_control) {
-      if (r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;    // deblocking_filter_override_enabled_flag
+      p.deblock_override = r.get(1);
       p.deblock_disabled = r.get(1);
-      if (!p.deblock_disabled && (r.se() != 0 || r.se() != 0)) return last_error_ = DEC_ERR_UNSUPPORTED;
+      if (!p.deblock_disabled) { p.beta_offset_div2 = r.se(); p.tc_offset_div2 = r.se(); }
     }
     if (r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;      // scaling list data
     if (r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;      // lists_modification_present_flag
-    if (r.ue() != 0) return last_error_ = DEC_ERR_UNSUPPORTED;   // log2_parallel_merge_level_minus2
-    if (r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;      // slice header extension
-    if (r.err) return last_error_ = DEC_ERR_INVALID;
+    p.par_mrg_level = (int)r.ue() + 2;
+    p.header_extension = r.get(1);
+    if (r.err || p.par_mrg_level > 6 || p.beta_offset_div2 < -6 || p.beta_offset_div2 > 6 || p.tc_offset_div2 < -6 || p.tc_offset_div2 > 6) return last_error_ = DEC_ERR_INVALID;
     p.valid = true; pps_[id] = p;
     return 0;
   }
   if (nal_type == 36 || nal_type == 37) { int rc = finish_oldest(); if (rc < 0) last_error_ = rc; return rc; }   // EOS / EOB: drain one delayed picture
   if (nal_type > 31) return 0;                                    // AUD / SEI / ...
-  if (!(nal_type == 0 || nal_type == 1 || nal_type == 19 || nal_type == 20)) return last_error_ = DEC_ERR_UNSUPPORTED;
+  if (!(nal_type <= 9 || (nal_type >= 19 && nal_type <= 21))) return last_error_ = DEC_ERR_UNSUPPORTED;      // (BLA pictures, reserved types)
   int rc = decode_slice(rbsp_.data(), n, nal_type, pts);
   if (rc < 0) last_error_ = rc;
   return rc;
@@ -526,57 +988,77 @@ int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
 int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t pts)
 {
   BitReader r(rbsp, len);
-  const bool idr = nal_type == 19 || nal_type == 20;
-  if (!r.get(1)) return DEC_ERR_UNSUPPORTED;                     // one slice per picture
-  if (idr) r.get(1);
-  int pps_id = r.ue();
-  if (pps_id > 63 || !pps_[pps_id].valid || !sps_[0].valid) return DEC_ERR_INVALID;
-  const DecPps &p = pps_[pps_id]; const DecSps &s = sps_[0];
-  int slice_type = r.ue();
-  if (slice_type != 1 && slice_type != 2) return DEC_ERR_UNSUPPORTED;
-  const bool is_intra = slice_type == 2;
-  if (!is_intra && idr) return DEC_ERR_INVALID;
-  int poc = 0;
+  const bool idr = nal_type == 19 || nal_type == 20, irap = nal_type >= 16 && nal_type <= 23;
+  if (!r.get(1)) return DEC_ERR_UNSUPPORTED;                     // one slice per picture (the filter takes one picture per VCL NAL unit, openhevcfilter.cpp:149-152)
+  if (irap) r.get(1);
+  const int pps_id = r.ue();
+  if (pps_id > 63 || !pps_[pps_id].valid || !sps_[pps_[pps_id].sps_id].valid) return DEC_ERR_INVALID;
+  const DecPps &p = pps_[pps_id]; const DecSps &s = sps_[p.sps_id];
+  for (int k = 0; k < p.extra_header_bits; k++) r.get(1);
+  const int slice_type = r.ue();
+  if (slice_type != 1 && slice_type != 2) return r.err ? DEC_ERR_INVALID : DEC_ERR_UNSUPPORTED;      // B slices
+  SliceHdr sh;
+  sh.is_intra = slice_type == 2;
+  if (p.output_flag_present) r.get(1);
+  StRps rps;
   if (!idr) {
-    int lsb = r.get(s.log2_max_poc_lsb), max_lsb = 1 << s.log2_max_poc_lsb;
-    int prev_lsb = prev_poc_ & (max_lsb - 1), prev_msb = prev_poc_ - prev_lsb, msb;
+    const int lsb = r.get(s.log2_max_poc_lsb), max_lsb = 1 << s.log2_max_poc_lsb;
+    const int prev_lsb = prev_poc_ & (max_lsb - 1), prev_msb = prev_poc_ - prev_lsb;
+    int msb = prev_msb;
     if (lsb < prev_lsb && prev_lsb - lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
     else if (lsb > prev_lsb && lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
-    else msb = prev_msb;
-    poc = msb + lsb;
-    int neg = 0, used = 0;
+    if (irap && !seen_irap_) msb = 0;
+    sh.poc = msb + lsb;
     if (r.get(1)) {
       int idx = 0, bits = 0; while ((1 << bits) < s.num_st_rps) bits++;
       if (s.num_st_rps == 0) return DEC_ERR_INVALID;
       if (bits) idx = r.get(bits);
       if (idx >= s.num_st_rps) return DEC_ERR_INVALID;
-      neg = s.rps_neg[idx]; used = s.rps_used[idx];
-    } else {
-      if (s.num_st_rps != 0 && r.get(1)) return DEC_ERR_UNSUPPORTED;
-      if (r.ue() != 1 || r.ue() != 0) return DEC_ERR_UNSUPPORTED;
-      neg = -(int)(r.ue() + 1); used = r.get(1);
-    }
-    if (!is_intra && (neg != -1 || !used || !have_ref_ || poc - 1 != prev_poc_)) return DEC_ERR_UNSUPPORTED;   // reference = previous picture
+      rps = s.st_rps[idx];
+    } else if (!parse_st_rps(r, s.num_st_rps, s.num_st_rps, s.st_rps, rps)) return DEC_ERR_INVALID;
+    if (s.tmvp) sh.tmvp = r.get(1);
   }
-  int sao_luma = 0, sao_chroma = 0;
-  if (s.sao) { sao_luma = r.get(1); sao_chroma = r.get(1); }
-  int max_merge = 5;
-  if (!is_intra) {
-    if (r.get(1)) { if (r.ue() != 0) return DEC_ERR_UNSUPPORTED; }        // num_ref_idx_active override: still one reference
-    max_merge = 5 - (int)r.ue();
-    if (max_merge < 1 || max_merge > 5) return DEC_ERR_INVALID;
+  if (s.sao) { sh.sao_luma = r.get(1); sh.sao_chroma = r.get(1); }
+  sh.num_ref_idx = p.num_ref_idx_default;
+  if (!sh.is_intra) {
+    if (r.get(1)) sh.num_ref_idx = (int)r.ue() + 1;
+    if (sh.num_ref_idx < 1 || sh.num_ref_idx > 15) return DEC_ERR_INVALID;
+    if (p.cabac_init_present) sh.cabac_init_flag = r.get(1);
+    if (sh.tmvp && sh.num_ref_idx > 1) { sh.collocated_ref_idx = r.ue(); if (sh.collocated_ref_idx >= sh.num_ref_idx) return DEC_ERR_INVALID; }
+    sh.max_merge = 5 - (int)r.ue();
+    if (sh.max_merge < 1 || sh.max_merge > 5) return DEC_ERR_INVALID;
   }
-  const int slice_qp = p.init_qp + r.se();
-  if (slice_qp < 0 || slice_qp > 51) return DEC_ERR_INVALID;
-  const bool deblock = !p.deblock_disabled;
-  if (p.loop_filter_across_slices && (deblock || sao_luma || sao_chroma)) r.get(1);
+  sh.slice_qp = p.init_qp + r.se();
+  if (sh.slice_qp < 0 || sh.slice_qp > 51) return DEC_ERR_INVALID;
+  sh.cb_qp_offset = p.cb_qp_offset; sh.cr_qp_offset = p.cr_qp_offset;
+  if (p.slice_chroma_offsets) { sh.cb_qp_offset += r.se(); sh.cr_qp_offset += r.se(); }
+  if (sh.cb_qp_offset < -12 || sh.cb_qp_offset > 12 || sh.cr_qp_offset < -12 || sh.cr_qp_offset > 12) return DEC_ERR_INVALID;
+  sh.deblock_disabled = p.deblock_disabled; sh.beta_offset_div2 = p.beta_offset_div2; sh.tc_offset_div2 = p.tc_offset_div2;
+  if (p.deblock_override && r.get(1)) {
+    sh.deblock_disabled = r.get(1);
+    if (!sh.deblock_disabled) { sh.beta_offset_div2 = r.se(); sh.tc_offset_div2 = r.se(); }
+    if (sh.beta_offset_div2 < -6 || sh.beta_offset_div2 > 6 || sh.tc_offset_div2 < -6 || sh.tc_offset_div2 > 6) return DEC_ERR_INVALID;
+  }
+  if (p.loop_filter_across_slices && (!sh.deblock_disabled || sh.sao_luma || sh.sao_chroma)) r.get(1);
+  const int wc = (s.width + 63) / 64, hc = (s.height + 63) / 64;
+  if (p.tile_rows > hc) return DEC_ERR_INVALID;
+  DecPps pp = p;                                                 // tile row boundaries (6.5.1) for this picture size
+  pp.row_bd[0] = 0;
+  for (int k = 0; k < p.tile_rows; k++) {
+    const int hgt = p.uniform_tiles ? ((k + 1) * hc) / p.tile_rows - (k * hc) / p.tile_rows : (k < p.tile_rows - 1 ? p.row_height[k] : hc - pp.row_bd[k]);
+    if (hgt < 1) return DEC_ERR_INVALID;
+    pp.row_bd[k + 1] = pp.row_bd[k] + hgt;
+  }
+  if (pp.row_bd[p.tile_rows] != hc) return DEC_ERR_INVALID;
   std::vector<uint32_t> entry;
+  const int nsub = p.wpp ? hc : p.tile_rows;
   if (p.wpp || p.tile_rows > 1) {
-    int nep = r.ue();
+    const int nep = r.ue();
     if (nep < 0 || nep > 1024) return DEC_ERR_INVALID;
     if (nep > 0) { int bits = r.ue() + 1; if (bits > 32) return DEC_ERR_INVALID; for (int k = 0; k < nep; k++) entry.push_back(r.get(bits) + 1); }
-    if (nep != (p.wpp ? s.height / 64 : p.tile_rows) - 1) return DEC_ERR_UNSUPPORTED;    // one substream per CTU row (WPP) or per tile
+    if (nep != nsub - 1) return DEC_ERR_UNSUPPORTED;             // one substream per CTU row (WPP) or per tile
   }
+  if (p.header_extension) { const int n = r.ue(); if (n > 256) return DEC_ERR_INVALID; for (int k = 0; k < n; k++) r.get(8); }
   if (!r.get(1)) return DEC_ERR_INVALID;                         // byte_alignment()
   while (r.pos & 7) r.get(1);
   if (r.err) return DEC_ERR_INVALID;
@@ -595,27 +1077,56 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
       sub_start_.push_back(esc - removed - hdr);
     }
   }
+  if (!sh.is_intra && !seen_irap_) return DEC_ERR_INVALID;       // nothing to predict from before the first random access point
   if (!ensure_buffers(s.width, s.height)) return DEC_ERR_GPU;
-  active_sps_ = &s;
+  // ---- reference picture set (8.3.2) and RefPicList0 (8.3.4): pictures not in the set stop being references
+  if (idr) for (auto &d : dpb_) d.is_ref = false;
+  int nref = 0, ref_poc[16]; uint8_t ref_slot[16];
+  if (!idr) {
+    int cand_slot[16], nc = 0;
+    bool keep[KVZ_DEC_MAX_REFS] = {false};
+    for (int k = 0; k < rps.n_neg + rps.n_pos; k++) {
+      const int poc = sh.poc + rps.dpoc[k];
+      int found = -1;
+      for (int q = 0; q < KVZ_DEC_MAX_REFS; q++) if (dpb_[q].is_ref && dpb_[q].used && dpb_[q].poc == poc) found = q;
+      if (found >= 0) keep[found] = true;
+      if (rps.used[k]) { if (found < 0 && !sh.is_intra) return DEC_ERR_INVALID; if (found >= 0 && nc < 16) cand_slot[nc++] = found; }      // a missing reference picture (lost access unit)
+    }
+    for (int q = 0; q < KVZ_DEC_MAX_REFS; q++) if (!keep[q]) dpb_[q].is_ref = false;
+    if (!sh.is_intra) {
+      if (nc == 0) return DEC_ERR_INVALID;
+      nref = sh.num_ref_idx;
+      for (int k = 0; k < nref; k++) { ref_slot[k] = (uint8_t)cand_slot[k % nc]; ref_poc[k] = dpb_[ref_slot[k]].poc; }
+    }
+  }
+  const int slot = alloc_slot();
+  if (slot < 0) return DEC_ERR_GPU;
   // ---- hand the picture to a parse job.  With frame threads (libOpenHevcInit thread_type FRAME / FRAMESLICE)
-  // up to `frame_threads_` pictures are parsed concurrently on worker threads -- CABAC parsing of a picture
-  // needs nothing from other pictures -- and the output is delayed accordingly, like OpenHEVC's frame threading.
+  // up to `frame_threads_` pictures are parsed concurrently on worker threads and the output is delayed accordingly,
+  // like OpenHEVC's frame threading; temporal motion prediction makes a picture's parser follow the collocated
+  // picture's parser row by row (ColMotion::row_done).
   PicJob &job = jobs_[(size_t)(job_head_ % (frame_threads_ + 1))];
-  job.rbsp.assign(rbsp, rbsp + len + 32);                        // keeps the zero padding the CABAC reader relies on
+  job.rbsp.assign(rbsp, rbsp + len);
   job.data_off = r.pos >> 3; job.data_len = len - (r.pos >> 3);
   job.sub_start = sub_start_;
-  job.slice_qp = slice_qp; job.is_intra = is_intra; job.max_merge = max_merge; job.deblock = deblock; job.poc = poc; job.pts = pts;
+  job.sh = sh; job.sps = &s; job.pps = pp; job.pts = pts;
   job.crop[0] = s.crop_l; job.crop[1] = s.crop_r; job.crop[2] = s.crop_t; job.crop[3] = s.crop_b;
   job.fps_num = s.fps_num ? s.fps_num : vps_fps_num_; job.fps_den = s.fps_num ? s.fps_den : vps_fps_den_;
-  job.hf.is_intra = is_intra; job.hf.wpp = p.wpp; job.hf.qp = slice_qp;
-  if (p.tile_rows > s.height / 64) return DEC_ERR_INVALID;
-  job.tile_rows = p.tile_rows; job.hf.tile_rows = p.tile_rows; job.hf.chp = pack_height(ch_, p.tile_rows);
-  job.qp_in_cu = p.qp_in_cu;
-  job.sao_luma = sao_luma; job.sao_chroma = sao_chroma;
-  job.hf.sao = (sao_luma || sao_chroma) ? (SaoParams *)(job.h_in + sao_offset()) : nullptr;
-  bind_qp_arrays(job.hf, job.h_in, cw_, ch_, true);               // the parser always fills them (one QP everywhere without cu_qp_delta)
-  job.rc = 0;
-  prev_poc_ = poc; have_ref_ = true;                             // header checks of the next picture run before this one is reconstructed
+  job.slot = slot; job.nref = nref;
+  for (int k = 0; k < 16; k++) { job.ref_poc[k] = k < nref ? ref_poc[k] : sh.poc; job.ref_slot[k] = k < nref ? ref_slot[k] : 0; }
+  job.col.reset();
+  if (sh.tmvp && !sh.is_intra) job.col = dpb_[ref_slot[sh.collocated_ref_idx]].motion;
+  job.own = std::make_shared<ColMotion>();
+  job.own->w16 = (s.width + 15) / 16; job.own->h16 = (s.height + 15) / 16; job.own->hc = hc; job.own->poc = sh.poc;
+  job.own->mv.assign((size_t)job.own->w16 * job.own->h16, ColMotion::Mv{0, 0, 0, 0});
+  job.own->row_done.reset(new std::atomic<uint8_t>[(size_t)hc]);
+  for (int k = 0; k < hc; k++) job.own->row_done[(size_t)k].store(0, std::memory_order_relaxed);
+  for (int cy = 0, t = 0; cy < hc; cy++) { while (cy >= pp.row_bd[t + 1]) t++; memset(job.ctu_tile + (size_t)cy * wc, t, (size_t)wc); }
+  job.rc = 0; job.any_intra = job.any_inter = false;
+  DpbPic &d = dpb_[slot];
+  d.poc = sh.poc; d.is_ref = true; d.used = true; d.decode_idx = job_head_; d.motion = job.own;
+  if (cur_tid_ == 0 && (nal_type > 9 || ((nal_type & 1) && nal_type < 6))) prev_poc_ = sh.poc;   // prevTid0Pic (8.3.1): TemporalId 0, not RASL / RADL / sub-layer non-reference
+  if (irap) seen_irap_ = true;
   job_head_++;
   if (frame_threads_ == 1) {
     auto t0 = std::chrono::steady_clock::now();
@@ -676,16 +1187,15 @@ int Decoder::complete_gpu()
     for (size_t i = 0; i < ev_used_; i++) { float ms = 0; hipEventElapsedTime(&ms, ev_pool_[i].a, ev_pool_[i].b); k_ms_[ev_pool_[i].id] += ms; k_n_[ev_pool_[i].id]++; }
     ev_used_ = 0;
   }
-  poc_ = job.poc;
   out_ = DecodedPicture();
-  out_.coded_w = cw_; out_.coded_h = ch_;
-  out_.width = cw_ - job.crop[0] - job.crop[1]; out_.height = ch_ - job.crop[2] - job.crop[3];
-  out_.poc = job.poc; out_.pts = job.pts; out_.is_intra = job.is_intra;
+  out_.coded_w = w_; out_.coded_h = h_;
+  out_.width = w_ - job.crop[0] - job.crop[1]; out_.height = h_ - job.crop[2] - job.crop[3];
+  out_.poc = job.sh.poc; out_.pts = job.pts; out_.is_intra = job.sh.is_intra;
   out_.fps_num = job.fps_num; out_.fps_den = job.fps_den;
-  out_idx_ = job.rec_idx;
+  out_slot_ = job.slot;
   for (int c = 0; c < 3; c++) {
-    int pw = c ? cw_ / 2 : cw_, ox = c ? job.crop[0] / 2 : job.crop[0], oy = c ? job.crop[2] / 2 : job.crop[2];
-    out_.dev[c] = rec_[out_idx_][c] + (size_t)oy * pw + ox; out_.dev_pitch[c] = pw;
+    int pw = c ? pw_ / 2 : pw_, ox = c ? job.crop[0] / 2 : job.crop[0], oy = c ? job.crop[2] / 2 : job.crop[2];
+    out_.dev[c] = dpb_[out_slot_].plane[c] + (size_t)oy * pw + ox; out_.dev_pitch[c] = pw;
   }
   if (download_) {
     // Host pitches are kept even and aligned like a software decoder's line sizes: the reference
@@ -705,22 +1215,21 @@ int Decoder::complete_gpu()
 }
 
 // ------------------------------------------------------------------------------------------ slice data (7.3.8)
-// One task per WPP substream (CTU row), run by a pool of host threads.  Row r follows row r-1 at
-// a distance of two CTUs: it starts from the context states saved after the second CTU of the row
-// above and needs that row's CU records up to the above-right CTU.
-int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, RowState &rs)
+// One task per substream -- a CTU row with WPP, else a tile -- run by a pool of host threads.  With WPP row r follows row r-1
+// at a distance of two CTUs: it starts from the context states saved after the second CTU of the row above and needs that row's
+// records up to the above-right CTU.
+int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t len, SubOut &out)
 {
-  const int wc = cw_ / 64, hc = ch_ / 64;
-  const int slice_qp = job.slice_qp, max_merge = job.max_merge; const bool is_intra = job.is_intra;
-  EncFrame &f = job.hf;
-  FrameView v; v.f = &f;
-  CabacDec c;
-  const bool wpp = f.wpp != 0;
-  const int T = job.tile_rows, chp = f.chp;
-  const int first_cy = wpp ? row : tile_row_first(hc, T, row), ncy = wpp ? 1 : tile_row_first(hc, T, row + 1) - first_cy;
+  SliceParser sp(job, out, pw_);
+  const int wc = sp.wc, hc = sp.hc;
+  const DecPps &pps = job.pps; const SliceHdr &sh = job.sh;
+  const bool wpp = pps.wpp != 0;
+  const int first_cy = wpp ? sub : pps.row_bd[sub], ncy = wpp ? 1 : pps.row_bd[sub + 1] - first_cy;
+  auto tile_starts_at = [&](int cy) { for (int t = 0; t < pps.tile_rows; t++) if (pps.row_bd[t] == cy) return true; return false; };
+  auto tile_ends_at = [&](int cy) { for (int t = 0; t < pps.tile_rows; t++) if (pps.row_bd[t + 1] == cy + 1) return true; return false; };
   int seen_above = 0;                                  // last observed progress of the row above (monotonic)
   auto wait_above = [&](int cy, int need) {            // CTUs of row cy-1 that must be complete
-    if (!wpp || tile_row_starts_at(hc, T, cy)) return true;       // nothing above inside the tile
+    if (!wpp || tile_starts_at(cy)) return true;       // nothing above inside the tile
     if (need > wc) need = wc;
     if (seen_above < need) {
       std::atomic<int> &p = job.row_progress[(size_t)(cy - 1)].v;
@@ -731,176 +1240,105 @@ int Decoder::parse_row(PicJob &job, int row, const uint8_t *data, size_t len, Ro
     }
     return seen_above < (1 << 29);                     // >= 1 << 29: that row failed
   };
-  int prev_qy = slice_qp;                              // qPY_PREV: slice QP at the start of a substream (tile, or CTU row with WPP)
+  const int init_type = sh.is_intra ? 0 : (sh.cabac_init_flag ? 2 : 1);
+  CabacDec &c = sp.c;
   c.start(data, len);
-  if (!wpp || tile_row_starts_at(hc, T, row)) cabac_init_contexts(c.ctx, is_intra ? 0 : 1, slice_qp);   // first CTU of a tile (9.3.1)
-  else {
-    if (!wait_above(row, 2)) return DEC_ERR_INVALID;
-    memcpy(c.ctx, &job.wpp_saved[(size_t)(row - 1) * CTX_COUNT], CTX_COUNT);
+  // 9.3.1: the first CTB of a tile initialises the contexts; a WPP row takes them over from the row above after its second
+  // CTB when that CTB exists (pictures one CTB wide: it does not, and the row initialises afresh)
+  if (!wpp || tile_starts_at(sub) || wc < 2) {
+    cabac_init_contexts(c.ctx, init_type, sh.slice_qp);
+  } else {
+    if (!wait_above(sub, 2)) return DEC_ERR_INVALID;
+    memcpy(c.ctx, &job.wpp_saved[(size_t)(sub - 1) * CTX_COUNT], CTX_COUNT);
   }
-  uint64_t tc[6] = {0, 0, 0, 0, 0, 0}, t0 = TSC(), t1;
-#define LAP(k) do { t1 = TSC(); tc[k] += t1 - t0; t0 = t1; } while (0)
+  sp.last_qp_y = sh.slice_qp;                          // qPY_PREV at the start of a slice, a tile, a CTB row with WPP (8.6.1)
+  ColMotion *own = job.own.get();
   for (int cy = first_cy; cy < first_cy + ncy; cy++) {
     for (int cx = 0; cx < wc; cx++) {
       if (!wait_above(cy, cx + 2)) return DEC_ERR_INVALID;
-      int ctu_qy = prev_qy, ctu_first = 64;                // quantisation group = CTU (8.6.1)
-      if (f.sao) {                                         // sao() (7.3.8.3) opens the CTU
-        SaoParams *sp = &f.sao[cy * wc + cx];
-        const SaoParams *left = cx > 0 ? sp - 1 : nullptr, *up = (cy > 0 && !tile_row_starts_at(hc, T, cy)) ? sp - wc : nullptr;
-        parse_sao(c, *sp, left, up, job.sao_luma != 0, job.sao_chroma != 0);
+      const int ctu = cy * wc + cx;
+      const uint32_t tu0 = (uint32_t)out.tus.size();
+      sp.ctu_intra_mask = 0;
+      if (!pps.cu_qp_delta) { sp.qp_y_pred = sh.slice_qp; sp.cu_qp_delta_val = 0; }
+      if (sh.sao_luma || sh.sao_chroma) {                  // sao() (7.3.8.3) opens the CTU
+        SaoParams *s = &job.sao[ctu];
+        const SaoParams *left = cx > 0 ? s - 1 : nullptr, *up = (cy > 0 && !tile_starts_at(cy)) ? s - wc : nullptr;
+        parse_sao(c, *s, left, up, sh.sao_luma != 0, sh.sao_chroma != 0);
       }
-      // coding_quadtree, iteratively in z-order over the 8x8 grid of the CTU
-      for (int z = 0; z < 64;) {
-        int xi, yi; ctu_z_to_xy(z, xi, yi);
-        const int x0 = cx * 64 + xi * 8, y0 = cy * 64 + yi * 8;
-        int log2 = 6;
-        for (; log2 > 3; log2--) {                 // split_cu_flag at every level whose block starts here
-          if (z & ((1 << (2 * (log2 - 3))) - 1)) continue;
-          int depth = 6 - log2;
-          int l = avail64(cw_, chp, x0, y0, x0 - 1, y0) && (6 - f.cu_log2[b8idx(f, x0 - 1, y0)]) > depth;
-          int a = avail64(cw_, chp, x0, y0, x0, y0 - 1) && (6 - f.cu_log2[b8idx(f, x0, y0 - 1)]) > depth;
-          if (!c.bin(CTX_SPLIT_CU + l + a)) break;
-        }
-        LAP(0);
-        if (log2 == 6) return DEC_ERR_UNSUPPORTED;  // 64x64 coding units
-        const int n = 1 << log2;
-        int skip = 0, intra = is_intra ? 1 : 0, flags = 0, mode = 0, cbf = 0, mvx = 0, mvy = 0;
-        if (!is_intra) {
-          int l = avail64(cw_, chp, x0, y0, x0 - 1, y0) && (f.cu_flags[b8idx(f, x0 - 1, y0)] & CU_SKIP);
-          int a = avail64(cw_, chp, x0, y0, x0, y0 - 1) && (f.cu_flags[b8idx(f, x0, y0 - 1)] & CU_SKIP);
-          skip = c.bin(CTX_SKIP + l + a);
-          if (!skip) intra = c.bin(CTX_PRED_MODE);
-        }
-        if (!is_intra && intra) return DEC_ERR_UNSUPPORTED;       // intra CUs in P pictures
-        if (!intra && log2 == 3) return DEC_ERR_UNSUPPORTED;      // 8x8 inter CUs
-        if (!skip && (!intra || log2 == 3) && !c.bin(CTX_PART_MODE)) return DEC_ERR_UNSUPPORTED;   // only PART_2Nx2N
-        LAP(1);
-        bool root_cbf = true;
-        if (intra) {
-          int prev = c.bin(CTX_PREV_INTRA);
-          int cand[3]; intra_mpm(v, cw_, chp, x0, y0, cand);
-          if (prev) { int idx = 0; if (c.bypass()) { idx = 1; if (c.bypass()) idx = 2; } mode = cand[idx]; }
-          else {
-            mode = (int)c.bypass_bits(5);
-            int t;
-            if (cand[0] > cand[1]) { t = cand[0]; cand[0] = cand[1]; cand[1] = t; }
-            if (cand[0] > cand[2]) { t = cand[0]; cand[0] = cand[2]; cand[2] = t; }
-            if (cand[1] > cand[2]) { t = cand[1]; cand[1] = cand[2]; cand[2] = t; }
-            for (int q = 0; q < 3; q++) if (mode >= cand[q]) mode++;
-          }
-          if (c.bin(CTX_CHROMA_MODE)) return DEC_ERR_UNSUPPORTED; // chroma mode other than "derived from luma"
-        } else {
-          int merge = skip ? 1 : c.bin(CTX_MERGE_FLAG);
-          if (merge) {
-            int idx = 0;
-            if (max_merge > 1 && c.bin(CTX_MERGE_IDX)) { idx = 1; while (idx < max_merge - 1 && c.bypass()) idx++; }
-            int cmx[5], cmy[5]; merge_cand_list(f, x0, y0, n, cmx, cmy);
-            mvx = cmx[idx]; mvy = cmy[idx];
-            flags = CU_MERGE | (skip ? CU_SKIP : 0);
-            root_cbf = !skip;
-          } else {
-            int g0x = c.bin(CTX_MVD_GT0), g0y = c.bin(CTX_MVD_GT0);
-            int g1x = g0x ? c.bin(CTX_MVD_GT1) : 0, g1y = g0y ? c.bin(CTX_MVD_GT1) : 0;
-            int d[2];
-            for (int k = 0; k < 2; k++) {
-              int g0 = k ? g0y : g0x, g1 = k ? g1y : g1x, a = 0;
-              if (g0) {
-                a = 1;
-                if (g1) { int kk = 1, vv = 0; while (kk < 32 && c.bypass()) { vv += 1 << kk; kk++; } if (kk >= 32) return DEC_ERR_INVALID; vv += (int)c.bypass_bits(kk); a = vv + 2; }
-                if (c.bypass()) a = -a;
-              }
-              d[k] = a;
-            }
-            int mvp = c.bin(CTX_MVP_FLAG);
-            int px[2], py[2]; amvp_cand_list(f, x0, y0, n, px, py);
-            mvx = (int16_t)(uint16_t)(px[mvp] + d[0]); mvy = (int16_t)(uint16_t)(py[mvp] + d[1]);
-            root_cbf = c.bin(CTX_RQT_ROOT_CBF) != 0;
-          }
-        }
-        LAP(2);
-        if (intra || root_cbf) {
-          int cb = c.bin(CTX_CBF_CHROMA), cr = c.bin(CTX_CBF_CHROMA);
-          int luma = (intra || cb || cr) ? c.bin(CTX_CBF_LUMA + 1) : 1;
-          cbf = luma | (cb << 1) | (cr << 2);
-          if (cbf && job.qp_in_cu && ctu_first == 64) {             // cu_qp_delta_abs / sign: once per CTU, in its first TU with a coded block
-            int v = 0;
-            while (v < 5 && c.bin(CTX_CU_QP_DELTA + (v ? 1 : 0))) v++;
-            if (v == 5) { int k = 0; while (k < 16 && c.bypass()) { v += 1 << k; k++; } if (k >= 16) return DEC_ERR_INVALID; v += (int)c.bypass_bits(k); }
-            if (v && c.bypass()) v = -v;
-            if (v < -26 || v > 25) return DEC_ERR_INVALID;
-            ctu_qy = (prev_qy + v + 52) % 52;
-            ctu_first = z;
-          }
-          for (int ci = 0; ci < 3; ci++) {
-            if (!((cbf >> ci) & 1)) continue;
-            const int l2 = ci ? log2 - 1 : log2;
-            TuDesc td; td.x = (uint16_t)(ci ? x0 >> 1 : x0); td.y = (uint16_t)(ci ? y0 >> 1 : y0); td.plane = (uint8_t)ci; td.log2 = (uint8_t)l2;
-            td.offset = (uint32_t)rs.levels.size();
-            if (!parse_residual(c, l2, ci, intra_scan_idx(intra, l2, ci, mode), rs.levels)) return DEC_ERR_INVALID;
-            td.count = (uint16_t)(rs.levels.size() - td.offset);
-            rs.tus.push_back(td);
-          }
-        }
-        LAP(3);
-        for (int yy = y0; yy < y0 + n; yy += 8)
-          for (int xx = x0; xx < x0 + n; xx += 8) {
-            int i = b8idx(f, xx, yy);
-            f.cu_log2[i] = (uint8_t)log2; f.cu_intra[i] = (uint8_t)intra; f.cu_flags[i] = (uint8_t)flags;
-            f.cu_intra_mode[i] = (uint8_t)mode; f.cu_cbf[i] = (uint8_t)cbf;
-            f.cu_mv[i * 2] = (int16_t)mvx; f.cu_mv[i * 2 + 1] = (int16_t)mvy;
-          }
-        LAP(4);
-        if (c.overrun()) return DEC_ERR_INVALID;
-        z += 1 << (2 * (log2 - 3));
-      }
-      { const int ctu = cy * wc + cx; f.ctu_qy[ctu] = (int8_t)ctu_qy; f.ctu_delta[ctu] = (int8_t)(ctu_qy - prev_qy); f.ctu_first[ctu] = (uint8_t)ctu_first; prev_qy = ctu_qy; }
+      sp.coding_quadtree(cx * 64, cy * 64, 6, 0);
+      if (sp.err) return sp.err;
+      if (c.overrun()) return DEC_ERR_INVALID;
+      job.ctu[ctu].first = tu0;
+      job.ctu[ctu].count = ((uint32_t)out.tus.size() - tu0) | (sp.ctu_intra_mask << 24);
+      if (out.tus.size() - tu0 >= (1u << 24)) return DEC_ERR_INVALID;
       if (wpp && cx == 1) memcpy(&job.wpp_saved[(size_t)cy * CTX_COUNT], c.ctx, CTX_COUNT);
       if (wpp) job.row_progress[(size_t)cy].v.store(cx + 1, std::memory_order_release);
       const bool last = (cy == hc - 1 && cx == wc - 1);
-      int end = c.terminate();
-      if (end != (last ? 1 : 0)) return DEC_ERR_UNSUPPORTED;      // slice must cover the whole picture
-      if (!last && cx == wc - 1 && (wpp || tile_row_ends_at(hc, T, cy)) && !c.terminate()) return DEC_ERR_INVALID;   // end_of_subset_one_bit
-      LAP(5);
+      const int end = c.terminate();
+      if (end != (last ? 1 : 0)) return DEC_ERR_UNSUPPORTED;      // the slice must cover the whole picture
+      if (!last && cx == wc - 1 && (wpp || tile_ends_at(cy)) && !c.terminate()) return DEC_ERR_INVALID;   // end_of_subset_one_bit
     }
+    // this CTB row's motion as later pictures see it (one entry per 16x16 block)
+    for (int y16 = cy * 4; y16 < cy * 4 + 4 && y16 < own->h16; y16++)
+      for (int x16 = 0; x16 < own->w16; x16++) {
+        const B4Rec &m = job.b4[(size_t)(y16 * 4) * (pw_ / 4) + x16 * 4];
+        ColMotion::Mv &o = own->mv[(size_t)y16 * own->w16 + x16];
+        o.inter = m.ref_idx >= 0; o.mvx = m.mvx; o.mvy = m.mvy; o.ref_poc = m.ref_idx >= 0 ? job.ref_poc[m.ref_idx & 15] : 0;
+      }
+    own->row_done[(size_t)cy].store(1, std::memory_order_release);
   }
-  for (int k = 0; k < 6; k++) g_tc[k] += tc[k];
   return 0;
 }
 
 int Decoder::parse_job(PicJob &job, bool row_parallel)
 {
   const uint8_t *data = job.rbsp.data() + job.data_off; const size_t len = job.data_len;
-  const int hc = ch_ / 64, nsub = job.hf.wpp ? hc : job.tile_rows;                 // one substream per CTU row (WPP) or per tile
-  if ((int)job.sub_start.size() != nsub) return DEC_ERR_INVALID;
-  for (int r = 0; r < nsub; r++) if (job.sub_start[(size_t)r] >= len) return DEC_ERR_INVALID;
-  job.rows.resize((size_t)nsub);
-  for (auto &r : job.rows) { r.levels.clear(); r.tus.clear(); r.rc = 0; }
+  const int wc = (w_ + 63) / 64, hc = (h_ + 63) / 64, nsub = job.pps.wpp ? hc : job.pps.tile_rows;
+  auto release_all = [&] { for (int r = 0; r < hc; r++) job.own->row_done[(size_t)r].store(1, std::memory_order_release); };   // never leave a later picture's parser waiting
+  if ((int)job.sub_start.size() != nsub) { release_all(); return DEC_ERR_INVALID; }
+  for (int r = 0; r < nsub; r++) if (job.sub_start[(size_t)r] >= len) { release_all(); return DEC_ERR_INVALID; }
+  job.subs.resize((size_t)nsub);
+  for (auto &r : job.subs) { r.levels.clear(); r.tus.clear(); r.rc = 0; }
   job.wpp_saved.resize((size_t)hc * CTX_COUNT);
   if (!job.row_progress || job.row_progress_n < hc) { job.row_progress.reset(new Progress[(size_t)hc]); job.row_progress_n = hc; }
   for (int r = 0; r < hc; r++) job.row_progress[(size_t)r].v.store(0, std::memory_order_relaxed);
+  memset(job.region, 0, (size_t)(pw_ / 32) * (ph_ / 32) * sizeof(TuRange));
+  memset(job.ctu, 0, (size_t)(pw_ / 64) * (ph_ / 64) * sizeof(TuRange));
+  memset(job.pred_mode.data(), PM_NONE, job.pred_mode.size());
+  memset(job.intra_mode.data(), 1, job.intra_mode.size());
   auto one = [&](int r) {
     size_t start = job.sub_start[(size_t)r], end = (r + 1 < nsub) ? job.sub_start[(size_t)r + 1] : len;
-    int rc = parse_row(job, r, data + start, end - start, job.rows[(size_t)r]);
-    job.rows[(size_t)r].rc = rc;
-    if (rc < 0 && job.hf.wpp) job.row_progress[(size_t)r].v.store(1 << 30, std::memory_order_release);   // release any waiter
+    int rc = end > start ? parse_substream(job, r, data + start, end - start, job.subs[(size_t)r]) : DEC_ERR_INVALID;
+    job.subs[(size_t)r].rc = rc;
+    if (rc < 0 && job.pps.wpp) job.row_progress[(size_t)r].v.store(1 << 30, std::memory_order_release);   // release any waiter
+    if (rc < 0) release_all();
   };
   if (row_parallel && nsub > 1) {
     if (!pool_) { const char *e = getenv("KVAZZUP_AMD_PARSE_THREADS"); if (e) parse_threads_ = atoi(e) < 1 ? 1 : atoi(e); pool_.reset(new OrderedPool(parse_threads_)); }
     pool_->run(nsub, one);
   } else {
-    for (int r = 0; r < nsub; r++) one(r);              // frame-parallel mode: rows in sequence on this worker
+    for (int r = 0; r < nsub; r++) one(r);              // frame-parallel mode: substreams in sequence on this worker
   }
-  // the rows' transform blocks and level words follow the CU records in the job's input block
+  // the substreams' transform blocks and level words follow the fixed part of the job's input block; table entries and word
+  // offsets become picture-wide
   size_t ntu = 0, nlev = 0;
-  for (auto &r : job.rows) { if (r.rc < 0) return r.rc; ntu += r.tus.size(); nlev += r.levels.size(); }
-  const size_t tu_off = (fixed_bytes() + 15) & ~(size_t)15, lev_off = (tu_off + ntu * sizeof(TuDesc) + 15) & ~(size_t)15;
+  for (auto &r : job.subs) { if (r.rc < 0) return r.rc; ntu += r.tus.size(); nlev += r.levels.size(); }
+  const size_t tu_off = fixed_bytes(), lev_off = (tu_off + ntu * sizeof(DecTu) + 15) & ~(size_t)15;
   if (!grow_job_input(job, lev_off + nlev * sizeof(uint32_t))) return DEC_ERR_GPU;
-  TuDesc *tus = (TuDesc *)(job.h_in + tu_off); uint32_t *lev = (uint32_t *)(job.h_in + lev_off);
+  DecTu *tus = (DecTu *)(job.h_in + tu_off); uint32_t *lev = (uint32_t *)(job.h_in + lev_off);
   size_t t = 0, l = 0;
-  for (auto &r : job.rows) {
-    for (TuDesc td : r.tus) { td.offset += (uint32_t)l; tus[t++] = td; }
-    if (!r.levels.empty()) memcpy(lev + l, r.levels.data(), r.levels.size() * sizeof(uint32_t));
-    l += r.levels.size();
+  for (int r = 0; r < nsub; r++) {
+    SubOut &so = job.subs[(size_t)r];
+    const int cy0 = job.pps.wpp ? r : job.pps.row_bd[r], cy1 = job.pps.wpp ? r + 1 : job.pps.row_bd[r + 1];
+    if (t) {
+      for (int cy = cy0; cy < cy1; cy++) {
+        for (int cx = 0; cx < wc; cx++) if (job.ctu[cy * wc + cx].count & 0xffffffu) job.ctu[cy * wc + cx].first += (uint32_t)t;
+        for (int ry = 2 * cy; ry < 2 * cy + 2; ry++) for (int rx = 0; rx < 2 * wc; rx++) { TuRange &g = job.region[ry * 2 * wc + rx]; if (g.count) g.first += (uint32_t)t; }
+      }
+    }
+    for (DecTu td : so.tus) { td.offset += (uint32_t)l; tus[t++] = td; }
+    if (!so.levels.empty()) memcpy(lev + l, so.levels.data(), so.levels.size() * sizeof(uint32_t));
+    l += so.levels.size();
   }
   job.ntu = ntu; job.nlev = nlev;
   return 0;
@@ -909,10 +1347,9 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
 // ------------------------------------------------------------------------------------------ GPU reconstruction
 int Decoder::launch_gpu(PicJob &job)
 {
-  const bool is_intra = job.is_intra, deblock = job.deblock; const int slice_qp = job.slice_qp;
   if (hipSetDevice(device_) != hipSuccess) return DEC_ERR_GPU;
   const size_t ntu = job.ntu, nlev = job.nlev;
-  const size_t tu_off = (fixed_bytes() + 15) & ~(size_t)15, lev_off = (tu_off + ntu * sizeof(TuDesc) + 15) & ~(size_t)15;
+  const size_t tu_off = fixed_bytes(), lev_off = (tu_off + ntu * sizeof(DecTu) + 15) & ~(size_t)15;
   const size_t bytes = lev_off + nlev * sizeof(uint32_t);
   prof_now_ = profiling_ && (launched_ % prof_every_) == 0;
   Tick tk_api;
@@ -920,30 +1357,29 @@ int Decoder::launch_gpu(PicJob &job)
     hipFree(d_in_);
     d_in_cap_ = bytes + bytes / 2;
     if (hipMalloc(&d_in_, d_in_cap_) != hipSuccess) { d_in_ = nullptr; d_in_cap_ = 0; return DEC_ERR_GPU; }
-    bind_views(f_, d_in_);
   }
   if (hipMemcpyAsync(d_in_, job.h_in, bytes, hipMemcpyHostToDevice, stream_) != hipSuccess) return DEC_ERR_GPU;
-  const TuDesc *d_tus = (const TuDesc *)(d_in_ + tu_off); const uint32_t *d_lev = (const uint32_t *)(d_in_ + lev_off);
-  f_.qp = slice_qp; f_.qpc = kChromaQp[slice_qp]; f_.is_intra = is_intra;
-  f_.tile_rows = job.tile_rows; f_.chp = pack_height(ch_, job.tile_rows);
-  bind_qp_arrays(f_, d_in_, cw_, ch_, job.qp_in_cu != 0);
-  const int cur = (int)(launched_ % 3), ref = (int)((launched_ + 2) % 3);     // three buffers: the picture output by the previous call stays intact
-  const bool sao = job.sao_luma || job.sao_chroma;                            // the picture is then built in work_ and filtered into the ring
-  for (int c = 0; c < 3; c++) { f_.rec[c] = sao ? work_[c] : rec_[cur][c]; f_.sao_out[c] = rec_[cur][c]; f_.ref[c] = rec_[ref][c]; }
-  f_.sao = sao ? (SaoParams *)(d_in_ + sao_offset()) : nullptr;
-  const EncFrame f = f_;
-  timed(DK_SCATTER, [&] { launch_scatter_levels(f, d_tus, (int)ntu, d_lev, stream_); });
-  if (is_intra) {
-    if (hipMemsetAsync(sync_, 0, sizeof(uint32_t) * 3 * (size_t)(ch_ / 64), stream_) != hipSuccess) return DEC_ERR_GPU;
-    timed(DK_INTRA_RECON, [&] { launch_dec_intra_recon(f, stream_); });
-  } else {
-    timed(DK_INTER_RECON, [&] { launch_dec_inter_recon(f, stream_); });
+  DecFrame f; memset(&f, 0, sizeof(f));
+  f.w = w_; f.h = h_; f.pw = pw_; f.ph = ph_; f.wc = (w_ + 63) / 64; f.hc = (h_ + 63) / 64;
+  f.b4 = (const B4Rec *)d_in_; f.region = (const TuRange *)(d_in_ + off_region()); f.ctu = (const TuRange *)(d_in_ + off_ctu());
+  f.ctu_tile = d_in_ + off_tile(); f.tus = (const DecTu *)(d_in_ + tu_off); f.lev = (const uint32_t *)(d_in_ + lev_off);
+  const bool sao = job.sh.sao_luma || job.sh.sao_chroma;      // the picture is then built in work_ and filtered into its buffer
+  for (int c = 0; c < 3; c++) { f.rec[c] = sao ? work_[c] : dpb_[job.slot].plane[c]; f.out[c] = dpb_[job.slot].plane[c]; }
+  for (int k = 0; k < KVZ_DEC_MAX_REFS; k++) for (int c = 0; c < 3; c++) f.ref[k][c] = dpb_[k].plane[c];
+  f.sao = sao ? (const SaoParams *)(d_in_ + off_sao()) : nullptr;
+  f.progress = progress_; f.err = err_;
+  f.cb_qp_offset = (int8_t)job.pps.cb_qp_offset; f.cr_qp_offset = (int8_t)job.pps.cr_qp_offset;
+  f.beta_offset = (int8_t)(2 * job.sh.beta_offset_div2); f.tc_offset = (int8_t)(2 * job.sh.tc_offset_div2);
+  f.strong_intra = (uint8_t)job.sps->strong_intra; f.tiles = job.pps.tile_rows > 1;
+  if (job.any_inter) timed(DK_INTER, [&] { launch_dec_inter(f, stream_); });
+  if (job.any_intra) {
+    if (hipMemsetAsync(progress_, 0, sizeof(uint32_t) * 3 * (size_t)f.wc * f.hc, stream_) != hipSuccess) return DEC_ERR_GPU;
+    timed(DK_INTRA, [&] { launch_dec_intra(f, stream_); });
   }
-  if (deblock) timed(DK_DEBLOCK, [&] { launch_deblock(f, stream_); });
+  if (!job.sh.deblock_disabled) timed(DK_DEBLOCK, [&] { launch_dec_deblock(f, stream_); });
   if (sao) timed(DK_SAO, [&] { launch_dec_sao(f, stream_); });
   if (hipMemcpyAsync(h_err_, err_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_) != hipSuccess) return DEC_ERR_GPU;
   t_api_ += tk_api.ms();
-  job.rec_idx = cur;
   launched_++;
   gpu_job_ = &job;
   return 0;
@@ -958,12 +1394,12 @@ bool Decoder::get_picture(DecodedPicture *out)
 
 bool Decoder::debug_copy(const char *what, void *dst, size_t bytes)
 {
-  if (!cw_) return false;
-  const size_t npx = (size_t)cw_ * ch_;
+  if (!w_) return false;
+  const size_t npx = (size_t)pw_ * ph_;
   std::string w(what);
   for (int c = 0; c < 3; c++) {
     size_t n = c ? npx / 4 : npx;
-    if (w == std::string("rec") + char('0' + c)) { if (bytes > n) return false; return hipMemcpy(dst, rec_[out_idx_][c], bytes, hipMemcpyDeviceToHost) == hipSuccess; }
+    if (w == std::string("rec") + char('0' + c)) { if (bytes > n) return false; return hipMemcpy(dst, dpb_[out_slot_].plane[c], bytes, hipMemcpyDeviceToHost) == hipSuccess; }
   }
   return false;
 }

@@ -12,15 +12,6 @@ void launch_intra_recon(const EncFrame &f, hipStream_t st);
 void launch_deblock(const EncFrame &f, hipStream_t st);
 void launch_vaq(const EncFrame &f, int vaq, int *act, int *sum, hipStream_t st);   // VAQ: f.ctu_qt holds ROI deltas on entry, target QPs on exit
 void launch_sao(const EncFrame &f, hipStream_t st);        // SAO decision + filter: f.rec (deblocked) -> f.sao_out, parameters -> f.sao
-void launch_dec_sao(const EncFrame &f, hipStream_t st);    // SAO filter with the parsed parameters in f.sao
-// decoder variants: levels + cbf given (coef planes / cu_cbf), prediction + residual only
-void launch_dec_inter_recon(const EncFrame &f, hipStream_t st);
-void launch_dec_intra_recon(const EncFrame &f, hipStream_t st);
-// scatter packed levels (TU descriptors) into the plane-shaped level arrays
-// one coded transform block of a picture being decoded: position (component samples), plane, size and its non-zero
-// levels as `count` words (raster position inside the block << 16 | level & 0xffff) starting at word `offset`
-struct TuDesc { uint16_t x, y; uint8_t plane, log2; uint16_t count; uint32_t offset; };
-void launch_scatter_levels(const EncFrame &f, const TuDesc *tus, int ntu, const uint32_t *pairs, hipStream_t st);
 void launch_qp_resolve(const EncFrame &f, hipStream_t st);  // per-CTU QP: first coded CU, QpY, delta (no-op without a QP map)
 void launch_deblock_v(const EncFrame &f, hipStream_t st);   // vertical edges of the band
 void launch_deblock_h(const EncFrame &f, hipStream_t st);   // horizontal edges of the band, its two boundary edges included

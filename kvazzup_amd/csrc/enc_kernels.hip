@@ -25,65 +25,11 @@
 #include <hip/hip_runtime.h>
 #include "hevc_core.h"
 #include "enc_kernels.h"
+#include "kernel_common.h"
 
 namespace kvzx {
 
-// Workgroups are observed to land on the eight XCDs round-robin (workgroup b -> XCD b % 8), each XCD with its own L2.  A raster
-// of small blocks dealt out that way makes every XCD fetch every 128-byte line its neighbours also fetch (a 32-sample block
-// row is a quarter of a line).  This permutation of the linear workgroup id gives each XCD one contiguous run of the raster
-// instead.  Speed only: any placement computes the same result.
-__device__ __forceinline__ int xcd_contiguous(int lin, int total)
-{
-  const int q = total >> 3, r = total & 7, xcd = lin & 7;
-  return xcd * q + (xcd < r ? xcd : r) + (lin >> 3);
-}
-// the same for a two-dimensional grid of blocks: (bx, by) of this workgroup after the permutation
-__device__ __forceinline__ void xcd_block_2d(int &bx, int &by)
-{
-  const int gx = (int)gridDim.x, lin = xcd_contiguous((int)(blockIdx.y * gridDim.x + blockIdx.x), gx * (int)gridDim.y);
-  by = lin / gx; bx = lin - by * gx;
-}
-
-// sum over the 64 lanes of a wave (every lane gets it); all lanes must be active
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
-{
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);   // row_half_mirror
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);   // row_mirror: every lane holds its row-of-16 sum
-  return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
-         (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-}
-
-
 #define SPLIT_BITS 8
-
-// ---------------------------------------------------------------------------------------------
-// inter-workgroup progress counters (cdna_hip_programming.md section 6, Guideline 16):
-// producer: stores -> __syncthreads -> lane 0: release fence + s_waitcnt + relaxed agent store
-// consumer: lane 0 polls relaxed, then ONE acquire fence, then __syncthreads
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void publish_progress(uint32_t *ctr, uint32_t value)
-{
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-__device__ __forceinline__ void wait_progress(const uint32_t *ctr, uint32_t at_least, uint32_t *err)
-{
-  if (threadIdx.x == 0) {
-    uint32_t spins = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < at_least) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1u << 26)) { atomicOr(err, 1u); break; }       // bounded spin: never hang the GPU
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-}
 
 // =============================================================================================
 // Motion estimation
@@ -235,99 +181,6 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
 }
 
 // =============================================================================================
-// Transforms.  One primitive, P(X, T)[j][i] = sum_m X[i][m] * T[j][m] (rows of X times rows of T, the
-// result stored transposed), run four times per block -- forward rows, forward columns, inverse
-// columns, inverse rows -- on int16 data with v_dot2_i32_i16 (every intermediate of the 8-bit HEVC
-// transforms fits 16 bits).  A lane owns a PAIR of rows of X and OPL outputs of each, so the matrix
-// rows it reads serve both rows and every LDS store is a packed pair.  Quantisation + dequantisation
-// are the epilogue of the second forward stage, reconstruction the epilogue of the last inverse one.
-// Matrices live in LDS as int16: M[0] = M_n[j][m] (n-point DCT = rows of kDct32 subsampled),
-// M[1] = its transpose, for n = 4, 8, 16, 32 at matrix_offset(log2 n).
-// =============================================================================================
-typedef short kv_short2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int dot2_i16(uint32_t a, uint32_t b, int c)
-{
-  return __builtin_amdgcn_sdot2(__builtin_bit_cast(kv_short2, a), __builtin_bit_cast(kv_short2, b), c, false);
-}
-__device__ __forceinline__ uint32_t pack_i16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
-__device__ __forceinline__ int matrix_offset(int l2) { return l2 == 2 ? 0 : (l2 == 3 ? 16 : (l2 == 4 ? 80 : 336)); }
-#define KV_MATRIX_ENTRIES 1360
-// Both matrix sets, the 32-point matrix as int8 (MFMA operand) with its row sums: built at compile time, so a kernel
-// fetches what it needs with one 16-byte load per thread instead of recomputing entries from kDct32.
-struct alignas(16) XfTables {
-  int16_t M[2][KV_MATRIX_ENTRIES];
-  int8_t M8[2][32 * 32];
-  int rowsum[2][32];
-};
-constexpr XfTables make_xf_tables()
-{
-  XfTables t{};
-  for (int i = 0; i < KV_MATRIX_ENTRIES; i++) {
-    const int l2 = i < 16 ? 2 : (i < 80 ? 3 : (i < 336 ? 4 : 5)), first = l2 == 2 ? 0 : (l2 == 3 ? 16 : (l2 == 4 ? 80 : 336));
-    const int k = i - first, j = k >> l2, m = k & ((1 << l2) - 1);
-    t.M[0][i] = kDct32[j << (5 - l2)][m];
-    t.M[1][i] = kDct32[m << (5 - l2)][j];
-  }
-  for (int j = 0; j < 32; j++) {
-    int a0 = 0, a1 = 0;
-    for (int m = 0; m < 32; m++) {
-      t.M8[0][j * 32 + m] = kDct32[j][m]; t.M8[1][j * 32 + m] = kDct32[m][j];
-      a0 += kDct32[j][m]; a1 += kDct32[m][j];
-    }
-    t.rowsum[0][j] = a0; t.rowsum[1][j] = a1;
-  }
-  return t;
-}
-__device__ const XfTables g_xf = make_xf_tables();
-
-// fills entries [first, first + count) of both matrix sets (all sizes: first = 0, count = KV_MATRIX_ENTRIES); both
-// multiples of 8
-__device__ __forceinline__ void load_matrices(int16_t (*M)[KV_MATRIX_ENTRIES], int first, int count, int tid, int nthreads)
-{
-  const int per = count >> 3;
-  for (int i = tid; i < 2 * per; i += nthreads) {
-    const int t = i >= per, k = first + ((i - t * per) << 3);
-    *(uint4 *)&M[t][k] = *(const uint4 *)&g_xf.M[t][k];
-  }
-}
-
-// lanes that share one n x n block: (n / 2) row pairs x (n / OPL) output groups
-template <int L2, int OPL> struct XF { static constexpr int N = 1 << L2, G = N / OPL, LANES = (N / 2) * G; };
-
-// raw sums of P for the lane's two rows (2rp, 2rp + 1) and its OPL outputs g * OPL + o
-template <int L2, int OPL>
-__device__ __forceinline__ void xf_sums(const int16_t *in, const int16_t *T, int rp, int g, int (&acc)[2][OPL])
-{
-  constexpr int N = 1 << L2, H = N / 2;
-  const uint32_t *r0 = (const uint32_t *)(in + 2 * rp * N);
-  uint32_t a0[H], a1[H];
-#pragma unroll
-  for (int m = 0; m < H; m++) { a0[m] = r0[m]; a1[m] = r0[H + m]; }
-#pragma unroll
-  for (int o = 0; o < OPL; o++) {
-    const uint32_t *t = (const uint32_t *)(T + (g * OPL + o) * N);
-    int s0 = 0, s1 = 0;
-#pragma unroll
-    for (int m = 0; m < H; m++) { uint32_t tv = t[m]; s0 = dot2_i16(a0[m], tv, s0); s1 = dot2_i16(a1[m], tv, s1); }
-    acc[0][o] = s0; acc[1][o] = s1;
-  }
-}
-// plain stage: out[j][i] = clip16((sum + rnd) >> shift), stored as packed row pairs
-template <int L2, int OPL>
-__device__ __forceinline__ void xf_stage(const int16_t *in, int16_t *out, const int16_t *T, int shift, int rp, int g)
-{
-  constexpr int N = 1 << L2;
-  const int rnd = 1 << (shift - 1);
-  int acc[2][OPL];
-  xf_sums<L2, OPL>(in, T, rp, g, acc);
-#pragma unroll
-  for (int o = 0; o < OPL; o++) {
-    int v0 = clip3(-32768, 32767, (acc[0][o] + rnd) >> shift), v1 = clip3(-32768, 32767, (acc[1][o] + rnd) >> shift);
-    ((uint32_t *)out)[((g * OPL + o) * N) / 2 + rp] = pack_i16(v0, v1);
-  }
-}
-
-// =============================================================================================
 // Inter reconstruction of one 32x32 block (one 32x32 CU or four 16x16 CUs), one workgroup each
 // =============================================================================================
 __device__ __forceinline__ int ref_at(const uint8_t *p, int w, int h, int x, int y)
@@ -437,52 +290,6 @@ __device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *n
       }
   }
   __syncthreads();
-}
-
-// ---- the 32x32 transform on the matrix cores --------------------------------------------------------------------
-// One stage P(X, T)[j][i] = sum_m X[i][m] * T[j][m] of a 32x32 block is a 32x32x32 integer matrix product.  T fits
-// int8 (|coefficient| <= 90); X is int16, so it is split into bytes: x = 256 * hi + (lo - 128) + 128 with hi = x >> 8
-// and lo - 128 both in [-128, 127], giving
-//   sum_m x T = 256 * (hi . T) + ((lo - 128) . T) + 128 * rowsum(T)        -- two MFMAs, exact in int32.
-// Each of the four waves owns one 16x16 tile of the result (rows 16 * (w >> 1) .., columns 16 * (w & 1) ..) and uses
-// v_mfma_i32_16x16x64_i8 with the upper half of K zero: lane l < 32 holds row (l & 15), k = (l >> 4) * 16 .. + 15 of
-// its A tile (16 bytes) and the same k range of row (l & 15) of T for B; result: column l & 15, rows (l >> 4) * 4 + r.
-typedef int kv_i32x4 __attribute__((ext_vector_type(4)));
-
-// sums of the lane's four results: tile rows (lane >> 4) * 4 + r, tile column lane & 15
-__device__ __forceinline__ void mfma_tile_sums(const int16_t *X, const int8_t *T8, const int *rowsum, int wave, int lane, int (&acc)[4])
-{
-  const int ti = (wave >> 1) * 16, tj = (wave & 1) * 16, kb = (lane >> 4) * 16;
-  kv_i32x4 ahi = {0, 0, 0, 0}, alo = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-  if (lane < 32) {
-    const int16_t *xr = X + (ti + (lane & 15)) * 32 + kb;
-    const uint4 x0 = *(const uint4 *)xr, x1 = *(const uint4 *)(xr + 8);
-    const uint32_t d[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      ahi[q] = (int)__builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x07050301u);                  // high bytes of four int16
-      alo[q] = (int)(__builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x06040200u) ^ 0x80808080u);  // low bytes - 128
-    }
-    b = *(const kv_i32x4 *)(T8 + (tj + (lane & 15)) * 32 + kb);
-  }
-  kv_i32x4 chi = {0, 0, 0, 0}, clo = {0, 0, 0, 0};
-  chi = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, b, chi, 0, 0, 0);
-  clo = __builtin_amdgcn_mfma_i32_16x16x64_i8(alo, b, clo, 0, 0, 0);
-  const int bias = 128 * rowsum[tj + (lane & 15)];
-#pragma unroll
-  for (int r = 0; r < 4; r++) acc[r] = 256 * chi[r] + clo[r] + bias;
-}
-
-// plain stage: out[j][i] = clip16((sum + rnd) >> shift); the lane's column j is a row of `out`, its four rows i one store
-__device__ __forceinline__ void mfma_stage(const int16_t *X, int16_t *out, const int8_t *T8, const int *rowsum, int shift, int wave, int lane)
-{
-  int acc[4];
-  mfma_tile_sums(X, T8, rowsum, wave, lane, acc);
-  const int rnd = 1 << (shift - 1), j = (wave & 1) * 16 + (lane & 15), i0 = (wave >> 1) * 16 + (lane >> 4) * 4;
-  int v[4];
-#pragma unroll
-  for (int e = 0; e < 4; e++) v[e] = clip3(-32768, 32767, (acc[e] + rnd) >> shift);
-  *(uint2 *)&out[j * 32 + i0] = make_uint2(pack_i16(v[0], v[1]), pack_i16(v[2], v[3]));
 }
 
 // The 32x32 luma block of a 32x32 CU: same contract as inter_transform<DEC, 5, .>
@@ -740,41 +547,6 @@ struct IntraWaveLds {
   alignas(16) uint8_t R[2][144];
   uint32_t nzflag;                           // workgroups of more than one wave: "the block has non-zero levels"
 };
-// thread layout of one block inside a workgroup of T threads (64: one wave, 256: four): OPL outputs per thread so that
-// (n / 2) row pairs x (n / OPL) output groups fit
-template <int L2, int T> struct XW {
-  static constexpr int N = 1 << L2, OPL = (N * N / 2 + T - 1) / T < 1 ? 1 : (N * N / 2 + T - 1) / T, G = N / OPL, LANES = (N / 2) * G;
-};
-
-// Intra sample prediction (8.4.4.2.4-6) from the reference array R (scan order, see IntraWaveLds); the same
-// arithmetic as intra_pred_sample() of hevc_core.h, indexed for R.  s = +1 / -1 walks the main side.
-template <int L2>
-__device__ __forceinline__ int pred_planar(const uint8_t *R, int x, int y)
-{
-  constexpr int N = 1 << L2;
-  return ((N - 1 - x) * R[2 * N - 1 - y] + (x + 1) * R[3 * N + 1] + (N - 1 - y) * R[2 * N + 1 + x] + (y + 1) * R[N - 1] + N) >> (L2 + 1);
-}
-template <int L2>
-__device__ __forceinline__ int pred_dc(const uint8_t *R, bool edge, int dc, int x, int y)
-{
-  constexpr int N = 1 << L2;
-  if (edge) {
-    if (x == 0 && y == 0) return (R[2 * N - 1] + 2 * dc + R[2 * N + 1] + 2) >> 2;
-    if (y == 0) return (R[2 * N + 1 + x] + 3 * dc + 2) >> 2;
-    if (x == 0) return (R[2 * N - 1 - y] + 3 * dc + 2) >> 2;
-  }
-  return dc;
-}
-template <int L2>
-__device__ __forceinline__ int pred_angular(const uint8_t *R, bool vert, bool edge, int angle, int inv, int x, int y)
-{
-  constexpr int N = 1 << L2;
-  const int a = vert ? x : y, b = vert ? y : x, sgn = vert ? 1 : -1;        // a runs along the main reference side
-  if (edge && a == 0) return clip8(R[2 * N + sgn] + ((R[2 * N - sgn * (1 + b)] - R[2 * N]) >> 1));
-  const int t = (b + 1) * angle, k0 = a + (t >> 5) + 1, k1 = k0 + 1, fact = t & 31;
-  const int i0 = k0 >= 0 ? k0 : -((k0 * inv + 128) >> 8), i1 = k1 >= 0 ? k1 : -((k1 * inv + 128) >> 8);
-  return ((32 - fact) * R[2 * N + sgn * i0] + fact * R[2 * N + sgn * i1] + 16) >> 5;
-}
 
 // =============================================================================================
 // Intra analysis (IDR pictures): for every 8x8, 16x16 and 32x32 block of a 32x32 region the SAD of all 35
@@ -1591,24 +1363,6 @@ __global__ __launch_bounds__(256) void k_pad_input(const uint8_t *in, int w, int
 }
 
 // =============================================================================================
-// Decoder input: levels of the coded transform blocks arrive packed (block after block, row-major
-// inside a block); this kernel writes them to their place in the plane-shaped level arrays.
-// =============================================================================================
-__global__ __launch_bounds__(256) void k_scatter_levels(EncFrame f, const TuDesc *tus, const uint32_t *pairs)
-{
-  const TuDesc d = tus[blockIdx.x];
-  const int n = 1 << d.log2, pw = d.plane ? (f.cw >> 1) : f.cw;
-  int16_t *dst = f.coef[d.plane] + (size_t)d.y * pw + d.x;
-  for (int o = threadIdx.x; o < n * n / 4; o += 256) *(uint2 *)&dst[((o * 4) >> d.log2) * pw + ((o * 4) & (n - 1))] = make_uint2(0u, 0u);
-  __syncthreads();
-  const uint32_t *src = pairs + d.offset;
-  for (int i = threadIdx.x; i < d.count; i += 256) {
-    const uint32_t pr = src[i], pos = pr >> 16;
-    dst[(pos >> d.log2) * pw + (pos & (n - 1))] = (int16_t)(pr & 0xffffu);
-  }
-}
-
-// =============================================================================================
 // Sample adaptive offset (8.7.3).  One workgroup per CTU: the deblocked CTU with a one-sample border goes to LDS for all
 // three components.  Encoder: statistics against the source picture and "uvgx SAO decision v1" (statement of record:
 // oracle/hevc_sao.c), parameters out; decoder: parameters in.  Both: the filtered CTU goes to the output picture.
@@ -1849,10 +1603,6 @@ __global__ __launch_bounds__(256) void k_vaq_apply(EncFrame f, int vaq, const in
 // =============================================================================================
 // launch wrappers
 // =============================================================================================
-void launch_scatter_levels(const EncFrame &f, const TuDesc *tus, int ntu, const uint32_t *pairs, hipStream_t st)
-{
-  if (ntu > 0) hipLaunchKernelGGL(k_scatter_levels, dim3(ntu), dim3(256), 0, st, f, tus, pairs);
-}
 void launch_pad_input(const uint8_t *in, int w, int h, uint8_t *dy, uint8_t *du, uint8_t *dv, int cw, int ch, hipStream_t st)
 {
   dim3 g((cw / 4 + 255) / 256, ch * 2);
@@ -1865,7 +1615,6 @@ void launch_me(const EncFrame &f, hipStream_t st)
   hipLaunchKernelGGL(k_me, dim3(f.cw / 32, band_rows(f) * 2), dim3(threads), 0, st, f);
 }
 void launch_inter_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_inter_recon<false>, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f); }
-void launch_dec_inter_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_inter_recon<true>, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f); }
 void launch_inter_signal(const EncFrame &f, hipStream_t st)
 {
   int n = (f.cw / 16) * (band_rows(f) * 4);
@@ -1876,7 +1625,6 @@ void launch_intra_analyse(const EncFrame &f, hipStream_t st) { hipLaunchKernelGG
 #define KVZ_INTRA_THREADS 256
 #endif
 void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL((k_intra_recon<false, KVZ_INTRA_THREADS>), dim3(3 * band_rows(f)), dim3(KVZ_INTRA_THREADS), 0, st, f); }
-void launch_dec_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL((k_intra_recon<true, KVZ_INTRA_THREADS>), dim3(3 * band_rows(f)), dim3(KVZ_INTRA_THREADS), 0, st, f); }
 void launch_qp_resolve(const EncFrame &f, hipStream_t st)
 {
   if (!f.ctu_qy) return;
@@ -1908,7 +1656,6 @@ void launch_vaq(const EncFrame &f, int vaq, int *act, int *sum, hipStream_t st)
   hipLaunchKernelGGL(k_vaq_apply, dim3((nctu + 255) / 256), dim3(256), 0, st, f, vaq, (const int *)act, (const int *)sum, nctu);
 }
 void launch_sao(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_sao<false>, dim3((f.cw / 64) * (f.ch / 64)), dim3(256), 0, st, f); }
-void launch_dec_sao(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_sao<true>, dim3((f.cw / 64) * (f.ch / 64)), dim3(256), 0, st, f); }
 void launch_tokenize(const EncFrame &f, hipStream_t st)
 {
   // One wave per unit and colour component keeps the longest wave short: right while the grid is a few waves per SIMD and the

@@ -937,10 +937,11 @@ KVZ_HD void intra_ref_coord(int x0, int y0, int n, int i, int &x, int &y)
 // Deblocking (H.265 8.7.2): one 4-line luma edge segment / the chroma lines below it.
 // q0 points at sample q0 of line 0, xs steps across the edge, ls along it.
 // ---------------------------------------------------------------------------------------------
-KVZ_HD void deblock_luma_segment(uint8_t *q0p, int xs, int ls, int bs, int qp)
+// beta_off / tc_off: slice_beta_offset_div2 * 2, slice_tc_offset_div2 * 2 (8.7.2.5.3)
+KVZ_HD void deblock_luma_segment(uint8_t *q0p, int xs, int ls, int bs, int qp, int beta_off = 0, int tc_off = 0)
 {
-  int beta = kBetaTable[clip3(0, 51, qp)];
-  int tc = kTcTable[clip3(0, 53, qp + 2 * (bs - 1))];
+  int beta = kBetaTable[clip3(0, 51, qp + beta_off)];
+  int tc = kTcTable[clip3(0, 53, qp + 2 * (bs - 1) + tc_off)];
 #define P_(i, l) q0p[-((i) + 1) * xs + (l) * ls]
 #define Q_(i, l) q0p[(i) * xs + (l) * ls]
   int dp0 = iabs(P_(2, 0) - 2 * P_(1, 0) + P_(0, 0)), dp3 = iabs(P_(2, 3) - 2 * P_(1, 3) + P_(0, 3));
@@ -975,10 +976,11 @@ KVZ_HD void deblock_luma_segment(uint8_t *q0p, int xs, int ls, int bs, int qp)
 #undef Q_
 }
 
-KVZ_HD void deblock_chroma_segment(uint8_t *q0p, int xs, int ls, int nlines, int qp_luma)
+// c_off: pps_cb_qp_offset / pps_cr_qp_offset (cQpPicOffset of 8.7.2.5.5)
+KVZ_HD void deblock_chroma_segment(uint8_t *q0p, int xs, int ls, int nlines, int qp_luma, int c_off = 0, int tc_off = 0)
 {
-  int qpc = kChromaQp[clip3(0, 57, qp_luma)];
-  int tc = kTcTable[clip3(0, 53, qpc + 2)];
+  int qpc = kChromaQp[clip3(0, 57, qp_luma + c_off)];
+  int tc = kTcTable[clip3(0, 53, qpc + 2 + tc_off)];
   for (int l = 0; l < nlines; l++) {
     uint8_t *q = q0p + l * ls;
     int p0 = q[-xs], p1 = q[-2 * xs], q0 = q[0], q1 = q[xs];

@@ -133,6 +133,7 @@ int kvzx_decoder_output_rgb32_device(OpenHevc_Handle hh, void *d_rgb32, int vari
   if (!kvzx_yuv420_to_rgb32_device(p.dev[0], p.dev[1], p.dev[2], p.dev_pitch[0], p.dev_pitch[1], d_rgb32, p.width, p.height, variant, nullptr)) return 0;
   return hipStreamSynchronize(nullptr) == hipSuccess ? 1 : 0;
 }
+void kvzx_decoder_set_output_hold(OpenHevc_Handle hh, int pictures) { Handle *h = H(hh); if (h) h->dec->set_output_hold(pictures); }
 void kvzx_decoder_set_download(OpenHevc_Handle hh, int on) { Handle *h = H(hh); if (h) h->dec->set_download(on != 0); }
 void kvzx_decoder_set_profiling(OpenHevc_Handle hh, int every) { Handle *h = H(hh); if (h) h->dec->set_profiling(every); }
 int kvzx_decoder_kernel_times(OpenHevc_Handle hh, double *ms, uint64_t *launches, int reset)
@@ -146,7 +147,7 @@ int kvzx_decoder_kernel_times(OpenHevc_Handle hh, double *ms, uint64_t *launches
 }
 const char *kvzx_decoder_kernel_name(int id)
 {
-  static const char *names[kvzx::DK_COUNT] = {"k_scatter_levels", "k_inter_recon<dec>", "k_intra_recon<dec>", "k_deblock", "host_cabac_parse", "k_sao<dec>"};
+  static const char *names[kvzx::DK_COUNT] = {"k_dec_inter", "k_dec_intra", "k_dec_deblock", "host_cabac_parse", "k_dec_sao"};
   return (id >= 0 && id < kvzx::DK_COUNT) ? names[id] : nullptr;
 }
 int kvzx_decoder_debug_copy(OpenHevc_Handle hh, const char *what, void *dst, size_t bytes)

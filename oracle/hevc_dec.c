@@ -385,6 +385,7 @@ static void prediction_unit(orc_decoder *d, int xcb, int ycb, int ncbs, int xp, 
   mc.pic = pic; mc.av = d->av; mc.log2_par_mrg_level = d->p->log2_parallel_merge_level;
   mc.max_num_merge_cand = d->sh.max_num_merge_cand; mc.num_ref_idx = d->sh.num_ref_idx_l0;
   mc.cur_poc = pic->poc; memcpy(mc.ref_poc, d->ref_poc, sizeof(mc.ref_poc));
+  mc.col = (d->sh.slice_temporal_mvp_enabled && d->sh.collocated_ref_idx < d->num_ref) ? d->ref_list0[d->sh.collocated_ref_idx] : NULL;
   int merge = skip ? 1 : orc_cdec_bin(c, CTX_MERGE_FLAG);
   if (merge_flag_out) *merge_flag_out = merge;
   int16_t mv[2]; int ref_idx = 0;
@@ -699,7 +700,7 @@ static int build_ref_list(orc_decoder *d)
 {
   orc_slice_hdr *sh = &d->sh;
   d->num_ref = 0;
-  if (sh->slice_type == SLICE_I) return 0;
+  if (sh->slice_type == SLICE_I) { for (int i = 0; i < 16; i++) d->cur->ref_poc_list[i] = d->cur->poc; return 0; }
   orc_pic *cand[32]; int nc = 0;
   int poc = d->cur->poc;
   for (int k = 0; k < sh->st_rps.num_negative; k++) if (sh->st_rps.used_s0[k]) cand[nc++] = find_poc(d, poc + sh->st_rps.delta_poc_s0[k]);
@@ -711,6 +712,7 @@ static int build_ref_list(orc_decoder *d)
     d->ref_poc[i] = d->ref_list0[i]->poc;
   }
   d->num_ref = sh->num_ref_idx_l0;
+  for (int i = 0; i < 16; i++) d->cur->ref_poc_list[i] = i < d->num_ref ? d->ref_poc[i] : d->cur->poc;   /* unused entries: never compared */
   return 0;
 }
 
@@ -845,7 +847,6 @@ int orc_dec_decode_nal(orc_decoder *d, const uint8_t *data, size_t len, int64_t 
   if (r) return r;
   d->p = &d->pps[d->sh.pps_id]; d->s = &d->sps[d->p->sps_id];
   if (d->sh.slice_type == SLICE_B) return ERR_UNSUPPORTED;
-  if (d->sh.slice_temporal_mvp_enabled) return ERR_UNSUPPORTED;
   if (d->sh.first_slice_segment_in_pic) {
     if (d->pic_active) finish_picture(d);             /* previous picture was incomplete */
     r = start_picture(d);

@@ -895,6 +895,7 @@ size_t orc_enc_encode(orc_encoder *e, const pixel *y, const pixel *u, const pixe
   load_input(e, y, u, v);
   roi_targets(e);
   orc_pic_reset_side(e->cur);
+  for (int i = 0; i < 16; i++) e->cur->ref_poc_list[i] = e->poc - 1;       /* one reference picture */
   for (int c = 0; c < 3; c++) memset(e->coef[c], 0, sizeof(int16_t) * (size_t)(c ? e->cw * e->ch / 4 : e->cw * e->ch));
   if (e->is_intra) encode_intra_picture(e); else encode_inter_picture(e);
   roi_resolve(e);

@@ -1,0 +1,679 @@
+/* oracle/hevc_gen.c -- see hevc_gen.h.  Test infrastructure: a conformance-style stream SYNTHESISER.
+ *
+ * The product's decoder sits behind libOpenHevcDecode, which uvgComm feeds with whatever the remote
+ * peer's encoder produced (/root/reference/src/media/processing/openhevcfilter.cpp:134-172) -- normally
+ * Kvazaar with gop=lp-g4d3t1 (kvazaarfilter.cpp:233): several reference pictures, TMVP, intra CUs in P
+ * pictures, all CU sizes, picture sizes that are multiples of 8 only.  This project's own encoder emits
+ * a much narrower tool set, so it cannot exercise those paths.  This file writes syntactically valid
+ * Main-profile streams whose every decision is drawn from a seeded generator: random coding quadtrees
+ * (with the implicit splits of partial CTUs), prediction modes, partitionings, merge / AMVP data,
+ * reference indices, transform trees, residuals (sign hiding, transform skip, escape codes), cu_qp_delta,
+ * SAO parameters, deblocking overrides, tiles / WPP substreams.  No source picture is involved: what the
+ * pictures look like is whatever the syntax decodes to, and the general CPU decoder (hevc_dec.c) defines
+ * the expected result.  The generator only tracks what the SYNTAX depends on (split / skip contexts,
+ * intra modes for the MPM list and the scan order, cbf inheritance, IsCuQpDeltaCoded). */
+#include "hevc_gen.h"
+#include "hevc_bits.h"
+#include "hevc_cabac.h"
+#include "hevc_ps.h"
+#include "hevc_pic.h"
+#include "hevc_intra.h"
+#include "hevc_sao.h"
+
+struct orc_gen {
+  orc_gen_config cfg;
+  uint64_t rng;
+  orc_vps vps; orc_sps sps; orc_pps pps; orc_slice_hdr sh;
+  orc_pic side;                       /* per-4x4 syntax state of the picture being written (planes unused) */
+  orc_avail_ctx av; int16_t *ctb_tile; int32_t *ctb_slice;
+  int row_bd[34], nrows_t;
+  orc_sao_params *sao;
+  orc_cabac_enc c;
+  orc_bitw au;
+  int frame_idx, poc, since_idr;
+  int slice_is_intra;
+  /* coding-unit state */
+  int cu_qp_delta_coded, log2_qg;
+  int cu_pred_mode, part_mode, intra_split, max_trafo_depth;
+  int intra_modes[4], chroma_mode;
+};
+
+/* ------------------------------------------------------------------ random numbers */
+static uint32_t rnd(orc_gen *g)
+{
+  g->rng ^= g->rng << 13; g->rng ^= g->rng >> 7; g->rng ^= g->rng << 17;
+  return (uint32_t)(g->rng >> 16);
+}
+static int rrange(orc_gen *g, int lo, int hi) { return lo + (int)(rnd(g) % (uint32_t)(hi - lo + 1)); }   /* inclusive */
+static int rpct(orc_gen *g, int pct) { return (int)(rnd(g) % 100u) < pct; }
+/* configuration value: >= 0 as given, -1 = drawn once per stream from [lo, hi] */
+static int pick(orc_gen *g, int v, int lo, int hi) { return v >= 0 ? v : rrange(g, lo, hi); }
+
+static inline int b4(const orc_pic *p, int x, int y) { return (y >> 2) * p->b4_w + (x >> 2); }
+static void fill4(orc_pic *p, uint8_t *arr, int x0, int y0, int w, int h, int v)
+{
+  for (int y = y0; y < y0 + h && y < p->h; y += 4)
+    for (int x = x0; x < x0 + w && x < p->w; x += 4) arr[b4(p, x, y)] = (uint8_t)v;
+}
+
+void orc_gen_default_config(orc_gen_config *c)
+{
+  memset(c, 0xff, sizeof(*c));             /* every switch -1: drawn from the seed */
+  c->width = 416; c->height = 240; c->seed = 1; c->intra_period = 8; c->qp = 30;
+  c->density = 30;
+}
+
+orc_gen *orc_gen_open(const orc_gen_config *cfg)
+{
+  if (cfg->width < 16 || cfg->height < 16 || (cfg->width & 7) || (cfg->height & 7)) return NULL;
+  orc_gen *g = (orc_gen *)calloc(1, sizeof(*g));
+  orc_tables_init();
+  g->cfg = *cfg;
+  g->rng = 0x9E3779B97F4A7C15ull ^ ((uint64_t)(uint32_t)cfg->seed * 0xD1342543DE82EF95ull);
+  for (int i = 0; i < 8; i++) rnd(g);
+  orc_gen_config *c = &g->cfg;
+  c->num_refs = pick(g, c->num_refs, 1, 4);
+  c->tmvp = pick(g, c->tmvp, 0, 1);
+  c->amp = pick(g, c->amp, 0, 1);
+  c->sao = pick(g, c->sao, 0, 1);
+  c->strong_intra = pick(g, c->strong_intra, 0, 1);
+  c->sign_hiding = pick(g, c->sign_hiding, 0, 1);
+  c->transform_skip = pick(g, c->transform_skip, 0, 1);
+  c->cabac_init = pick(g, c->cabac_init, 0, 1);
+  c->wpp = pick(g, c->wpp, 0, 1);
+  c->tile_rows = pick(g, c->tile_rows, 1, 3);
+  c->th_depth_inter = pick(g, c->th_depth_inter, 0, 2);
+  c->th_depth_intra = pick(g, c->th_depth_intra, 0, 2);
+  c->qp_delta = pick(g, c->qp_delta, 0, 4);
+  c->chroma_qp_offsets = pick(g, c->chroma_qp_offsets, 0, 1);
+  c->deblock_mode = pick(g, c->deblock_mode, 0, 3);                 /* 0 default, 1 disabled in the PPS, 2 PPS offsets, 3 slice override */
+  c->par_mrg_level = pick(g, c->par_mrg_level, 2, 4);
+  c->intra_in_p = pick(g, c->intra_in_p, 0, 40);
+  c->all_part_modes = pick(g, c->all_part_modes, 0, 1);
+  c->chroma_modes = pick(g, c->chroma_modes, 0, 1);
+  c->nxn_intra = pick(g, c->nxn_intra, 0, 1);
+  c->max_cu_log2 = pick(g, c->max_cu_log2, 4, 6);
+  c->min_cu_log2 = pick(g, c->min_cu_log2, 3, 4);
+  if (c->min_cu_log2 > c->max_cu_log2) c->min_cu_log2 = c->max_cu_log2;
+  c->uniform_tiles = pick(g, c->uniform_tiles, 0, 1);
+  c->big_mvd = pick(g, c->big_mvd, 0, 1);
+  const int wc = (cfg->width + 63) / 64, hc = (cfg->height + 63) / 64;
+  if (c->tile_rows > hc) c->tile_rows = hc;
+  if (c->tile_rows < 1) c->tile_rows = 1;
+
+  orc_sps *s = &g->sps; memset(s, 0, sizeof(*s));
+  s->general_profile_idc = 1; s->general_level_idc = 153;
+  s->chroma_format_idc = 1; s->width = cfg->width; s->height = cfg->height;
+  s->bit_depth_luma = s->bit_depth_chroma = 8; s->log2_max_poc_lsb = pick(g, -1, 4, 8);
+  s->max_dec_pic_buffering = c->num_refs + 1; s->max_num_reorder = 0;
+  s->log2_min_cb = 3; s->log2_diff_max_min_cb = 3; s->log2_min_tb = 2; s->log2_diff_max_min_tb = 3;
+  s->max_th_depth_inter = c->th_depth_inter; s->max_th_depth_intra = c->th_depth_intra;
+  s->amp_enabled = c->amp; s->sao_enabled = c->sao;
+  s->num_st_rps = 0;
+  s->temporal_mvp_enabled = c->tmvp; s->strong_intra_smoothing = c->strong_intra;
+  s->vui_present = 1; s->vui_timing_present = 1; s->vui_num_units_in_tick = 1; s->vui_time_scale = 30;
+  orc_sps_derive(s);
+  orc_vps *v = &g->vps; memset(v, 0, sizeof(*v));
+  v->timing_info_present = 1; v->num_units_in_tick = 1; v->time_scale = 30;
+  orc_pps *p = &g->pps; memset(p, 0, sizeof(*p));
+  p->sign_data_hiding = c->sign_hiding; p->cabac_init_present = c->cabac_init;
+  p->num_ref_idx_l0_default = rrange(g, 1, c->num_refs); p->num_ref_idx_l1_default = 1; p->init_qp = cfg->qp;
+  p->transform_skip_enabled = c->transform_skip;
+  p->cu_qp_delta_enabled = c->qp_delta > 0; p->diff_cu_qp_delta_depth = c->qp_delta > 0 ? c->qp_delta - 1 : 0;
+  if (c->chroma_qp_offsets) { p->cb_qp_offset = rrange(g, -4, 4); p->cr_qp_offset = rrange(g, -4, 4); p->slice_chroma_qp_offsets_present = rpct(g, 50); }
+  p->entropy_coding_sync_enabled = c->wpp; p->loop_filter_across_slices = 1;
+  p->num_tile_columns = 1; p->num_tile_rows = 1; p->uniform_spacing = 1;
+  p->deblocking_filter_control_present = c->deblock_mode != 0;
+  p->pps_deblocking_disabled = c->deblock_mode == 1;
+  if (c->deblock_mode >= 2) { p->pps_beta_offset_div2 = rrange(g, -3, 3); p->pps_tc_offset_div2 = rrange(g, -3, 3); }
+  p->deblocking_filter_override_enabled = c->deblock_mode == 3;
+  p->log2_parallel_merge_level = c->par_mrg_level;
+  g->nrows_t = c->tile_rows;
+  for (int i = 0; i <= c->tile_rows; i++) g->row_bd[i] = (i * hc) / c->tile_rows;
+  if (c->tile_rows > 1) {
+    p->tiles_enabled = 1; p->num_tile_rows = c->tile_rows; p->loop_filter_across_tiles = 1; p->uniform_spacing = c->uniform_tiles;
+    if (!c->uniform_tiles) {                                /* explicit row heights: a random monotone partition */
+      int left = hc;
+      for (int i = 0; i < c->tile_rows - 1; i++) {
+        int maxh = left - (c->tile_rows - 1 - i), hgt = rrange(g, 1, maxh);
+        p->row_height[i] = hgt; g->row_bd[i + 1] = g->row_bd[i] + hgt; left -= hgt;
+      }
+      g->row_bd[c->tile_rows] = hc;
+    }
+    g->ctb_tile = (int16_t *)calloc((size_t)wc * hc, sizeof(int16_t));
+    for (int i = 0; i < c->tile_rows; i++) for (int cy = g->row_bd[i]; cy < g->row_bd[i + 1]; cy++) for (int cx = 0; cx < wc; cx++) g->ctb_tile[cy * wc + cx] = (int16_t)i;
+  }
+  if (orc_pic_alloc(&g->side, cfg->width, cfg->height)) { free(g); return NULL; }
+  memset(&g->av, 0, sizeof(g->av));
+  g->av.pic_w = cfg->width; g->av.pic_h = cfg->height; g->av.ctb_log2 = 6; g->av.pic_w_ctbs = wc; g->av.ctb_tile = g->ctb_tile;
+  g->sao = (orc_sao_params *)calloc((size_t)wc * hc, sizeof(orc_sao_params));
+  g->log2_qg = 6 - p->diff_cu_qp_delta_depth;
+  orc_bw_init(&g->au);
+  return g;
+}
+
+void orc_gen_close(orc_gen *g)
+{
+  if (!g) return;
+  orc_pic_free(&g->side); free(g->ctb_tile); free(g->sao); orc_bw_free(&g->au); free(g);
+}
+void orc_gen_get_config(const orc_gen *g, orc_gen_config *out) { *out = g->cfg; }
+
+/* ------------------------------------------------------------------ residual_coding, 7.3.8.11 */
+static void put_last_prefix(orc_cabac_enc *c, int base, int log2, int cidx, int prefix)
+{
+  int off, sh, max = (log2 << 1) - 1;
+  if (cidx == 0) { off = 3 * (log2 - 2) + ((log2 - 1) >> 2); sh = (log2 + 1) >> 2; }
+  else { off = 15; sh = log2 - 2; }
+  for (int i = 0; i < prefix; i++) orc_cenc_bin(c, base + off + (i >> sh), 1);
+  if (prefix < max) orc_cenc_bin(c, base + off + (prefix >> sh), 0);
+}
+static void last_bin(int v, int *prefix, int *nb, int *suffix)
+{
+  if (v < 4) { *prefix = v; *nb = 0; *suffix = 0; return; }
+  int len = orc_log2((unsigned)v);
+  *prefix = 2 * len + ((v >> (len - 1)) & 1); *nb = len - 1; *suffix = v & ((1 << (len - 1)) - 1);
+}
+static void put_abs_remaining(orc_cabac_enc *c, int v, int rice)
+{
+  if ((v >> rice) < 4) {
+    int q = v >> rice;
+    for (int i = 0; i < q; i++) orc_cenc_bypass(c, 1);
+    orc_cenc_bypass(c, 0);
+    orc_cenc_bypass_bits(c, (uint32_t)(v & ((1 << rice) - 1)), rice);
+  } else {
+    int x = v - (4 << rice), k = rice + 1;
+    for (int i = 0; i < 4; i++) orc_cenc_bypass(c, 1);
+    while (x >= (1 << k)) { orc_cenc_bypass(c, 1); x -= 1 << k; k++; }
+    orc_cenc_bypass(c, 0);
+    orc_cenc_bypass_bits(c, (uint32_t)x, k);
+  }
+}
+static const uint8_t ctx_idx_map_4x4[16] = { 0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8 };
+
+static int draw_abs_level(orc_gen *g)
+{
+  int r = (int)(rnd(g) % 100u);
+  if (r < 55) return 1;
+  if (r < 75) return 2;
+  if (r < 87) return 3;
+  if (r < 97) return rrange(g, 4, 24);
+  if (r < 99) return rrange(g, 25, 400);
+  return rrange(g, 401, 20000);                       /* long escape codes */
+}
+
+static void gen_residual(orc_gen *g, int log2, int cidx, int scan_idx)
+{
+  orc_cabac_enc *c = &g->c;
+  const int n = 1 << log2, sb_log2 = log2 - 2, nsb = 1 << sb_log2;
+  const uint8_t *sbx = orc_scan_x[scan_idx][sb_log2], *sby = orc_scan_y[scan_idx][sb_log2];
+  const uint8_t *px = orc_scan_x[scan_idx][2], *py = orc_scan_y[scan_idx][2];
+  uint8_t csbf[8][8]; memset(csbf, 0, sizeof(csbf));
+  if (g->pps.transform_skip_enabled && log2 <= 2) orc_cenc_bin(c, CTX_TS_FLAG + (cidx ? 1 : 0), rpct(g, 30));
+  /* the last significant coefficient: mostly in the low-frequency corner */
+  int last_sb, last_pos;
+  if (rpct(g, 60) || nsb == 1) { last_sb = 0; last_pos = rrange(g, 0, 15); }
+  else if (rpct(g, 70)) { last_sb = rrange(g, 0, ORC_MIN(3, nsb * nsb - 1)); last_pos = rrange(g, 0, 15); }
+  else { last_sb = rrange(g, 0, nsb * nsb - 1); last_pos = rrange(g, 0, 15); }
+  int lx = (sbx[last_sb] << 2) + px[last_pos], ly = (sby[last_sb] << 2) + py[last_pos];
+  if (scan_idx == 2) { int t = lx; lx = ly; ly = t; }
+  int pxv, nbx, sfx, pyv, nby, sfy;
+  last_bin(lx, &pxv, &nbx, &sfx); last_bin(ly, &pyv, &nby, &sfy);
+  put_last_prefix(c, CTX_LAST_X, log2, cidx, pxv);
+  put_last_prefix(c, CTX_LAST_Y, log2, cidx, pyv);
+  if (pxv > 3) orc_cenc_bypass_bits(c, (uint32_t)sfx, nbx);
+  if (pyv > 3) orc_cenc_bypass_bits(c, (uint32_t)sfy, nby);
+  const int dens = g->cfg.density;
+  int c1 = 1;
+  (void)n;
+  for (int i = last_sb; i >= 0; i--) {
+    int xs = sbx[i], ys = sby[i], infer_dc = 0;
+    int right = (xs < nsb - 1) ? csbf[ys][xs + 1] : 0, below = (ys < nsb - 1) ? csbf[ys + 1][xs] : 0;
+    if (i < last_sb && i > 0) {
+      csbf[ys][xs] = (uint8_t)rpct(g, 40);
+      orc_cenc_bin(c, CTX_CSBF + ((right | below) ? 1 : 0) + (cidx ? 2 : 0), csbf[ys][xs]);
+      infer_dc = 1;
+    } else csbf[ys][xs] = 1;
+    if (!csbf[ys][xs]) continue;
+    uint8_t sig[16]; memset(sig, 0, sizeof(sig));
+    int start = (i == last_sb) ? last_pos - 1 : 15;
+    if (i == last_sb) sig[last_pos] = 1;
+    int prev_csbf = right | (below << 1);
+    for (int k = start; k >= 0; k--) {
+      int xp = px[k], yp = py[k], xc = (xs << 2) + xp, yc = (ys << 2) + yp;
+      if (k > 0 || !infer_dc) {
+        int sc;
+        if (log2 == 2) sc = ctx_idx_map_4x4[(yc << 2) + xc];
+        else if (xc + yc == 0) sc = 0;
+        else {
+          if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
+          else if (prev_csbf == 1) sc = (yp == 0) ? 2 : (yp == 1) ? 1 : 0;
+          else if (prev_csbf == 2) sc = (xp == 0) ? 2 : (xp == 1) ? 1 : 0;
+          else sc = 2;
+          if (cidx == 0) { if (i > 0) sc += 3; sc += (log2 == 3) ? ((scan_idx == 0) ? 9 : 15) : 21; }
+          else sc += (log2 == 3) ? 9 : 12;
+        }
+        sig[k] = (uint8_t)rpct(g, dens);
+        orc_cenc_bin(c, CTX_SIG + (cidx ? 27 : 0) + sc, sig[k]);
+        if (sig[k]) infer_dc = 0;
+      } else sig[0] = 1;                                /* inferred: a coded sub-block whose other flags are all zero */
+    }
+    int nsig = 0; for (int k = 0; k < 16; k++) nsig += sig[k];
+    if (!nsig) continue;
+    int absv[16]; for (int k = 0; k < 16; k++) absv[k] = sig[k] ? draw_abs_level(g) : 0;
+    int ctx_set = (i > 0 && cidx == 0) ? 2 : 0;
+    if (c1 == 0) ctx_set++;
+    c1 = 1;
+    int ng1 = 0, last_g1_pos = -1, first_sig = 16, last_sig = -1;
+    for (int k = 15; k >= 0; k--) if (sig[k]) {
+      if (ng1 < 8) {
+        int g1 = absv[k] > 1;
+        orc_cenc_bin(c, CTX_GT1 + (cidx ? 16 : 0) + ctx_set * 4 + c1, g1);
+        ng1++;
+        if (g1) { c1 = 0; if (last_g1_pos == -1) last_g1_pos = k; }
+        else if (c1 > 0 && c1 < 3) c1++;
+      }
+      if (last_sig == -1) last_sig = k;
+      first_sig = k;
+    }
+    if (last_g1_pos != -1) orc_cenc_bin(c, CTX_GT2 + (cidx ? 4 : 0) + ctx_set, absv[last_g1_pos] > 2);
+    int sign_hidden = g->pps.sign_data_hiding && (last_sig - first_sig > 3);
+    for (int k = 15; k >= 0; k--) if (sig[k] && (!sign_hidden || k != first_sig)) orc_cenc_bypass(c, (int)(rnd(g) & 1u));
+    int num_sig = 0, rice = 0;
+    for (int k = 15; k >= 0; k--) if (sig[k]) {
+      int base = (num_sig < 8) ? ((k == last_g1_pos) ? 3 : 2) : 1;
+      if (absv[k] >= base) {
+        put_abs_remaining(c, absv[k] - base, rice);
+        if (absv[k] > 3 * (1 << rice)) rice = ORC_MIN(rice + 1, 4);
+      }
+      num_sig++;
+    }
+  }
+}
+
+static int scan_idx_for(int intra, int log2, int cidx, int mode)
+{
+  if (!intra) return 0;
+  if (log2 == 2 || (log2 == 3 && cidx == 0)) {
+    if (mode >= 6 && mode <= 14) return 2;
+    if (mode >= 22 && mode <= 30) return 1;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ transform tree, 7.3.8.8-7.3.8.10 */
+static void gen_transform_unit(orc_gen *g, int x0, int y0, int log2, int blk, int cbf_luma, int cbf_cb, int cbf_cr, int cbf_cb_parent, int cbf_cr_parent)
+{
+  orc_cabac_enc *c = &g->c;
+  const int intra = g->cu_pred_mode == MODE_INTRA;
+  const int chroma_here = log2 > 2, chroma_parent = (log2 == 2 && blk == 3);
+  const int ccb = chroma_here ? cbf_cb : (chroma_parent ? cbf_cb_parent : 0);
+  const int ccr = chroma_here ? cbf_cr : (chroma_parent ? cbf_cr_parent : 0);
+  const int cbf_chroma_any = (log2 > 2) ? (cbf_cb || cbf_cr) : (cbf_cb_parent || cbf_cr_parent);
+  if ((cbf_luma || cbf_chroma_any) && g->pps.cu_qp_delta_enabled && !g->cu_qp_delta_coded) {
+    int d = rpct(g, 50) ? 0 : (rpct(g, 85) ? rrange(g, -3, 3) : rrange(g, -26, 25));
+    int a = orc_abs(d), v = 0;
+    while (v < 5 && v < a) { orc_cenc_bin(c, CTX_CU_QP_DELTA + (v ? 1 : 0), 1); v++; }
+    if (a < 5) orc_cenc_bin(c, CTX_CU_QP_DELTA + (a ? 1 : 0), 0);
+    else { int x = a - 5, k = 0; while (x >= (1 << k)) { orc_cenc_bypass(c, 1); x -= 1 << k; k++; } orc_cenc_bypass(c, 0); orc_cenc_bypass_bits(c, (uint32_t)x, k); }
+    if (a) orc_cenc_bypass(c, d < 0);
+    g->cu_qp_delta_coded = 1;
+  }
+  const int lmode = intra ? g->side.intra_mode[b4(&g->side, x0, y0)] : 0;
+  if (cbf_luma) gen_residual(g, log2, 0, scan_idx_for(intra, log2, 0, lmode));
+  if (chroma_here || chroma_parent) {
+    const int clog2 = chroma_here ? log2 - 1 : 2;
+    if (ccb) gen_residual(g, clog2, 1, scan_idx_for(intra, clog2, 1, g->chroma_mode));
+    if (ccr) gen_residual(g, clog2, 2, scan_idx_for(intra, clog2, 2, g->chroma_mode));
+  }
+}
+
+static void gen_transform_tree(orc_gen *g, int x0, int y0, int log2, int depth, int blk, int cbf_cb_parent, int cbf_cr_parent)
+{
+  orc_cabac_enc *c = &g->c;
+  const orc_sps *s = &g->sps;
+  int split;
+  if (log2 <= s->log2_max_tb && log2 > s->log2_min_tb && depth < g->max_trafo_depth && !(g->intra_split && depth == 0)) {
+    split = rpct(g, 35);
+    orc_cenc_bin(c, CTX_SPLIT_TRANSFORM + 5 - log2, split);
+  } else {
+    int inter_split = (s->max_th_depth_inter == 0 && g->cu_pred_mode == MODE_INTER && g->part_mode != PART_2Nx2N && depth == 0);
+    split = (log2 > s->log2_max_tb || (g->intra_split && depth == 0) || inter_split) ? 1 : 0;
+  }
+  int cbf_cb = 0, cbf_cr = 0;
+  if (log2 > 2) {
+    if (depth == 0 || cbf_cb_parent) { cbf_cb = rpct(g, 35); orc_cenc_bin(c, CTX_CBF_CHROMA + depth, cbf_cb); }
+    if (depth == 0 || cbf_cr_parent) { cbf_cr = rpct(g, 35); orc_cenc_bin(c, CTX_CBF_CHROMA + depth, cbf_cr); }
+  } else { cbf_cb = cbf_cb_parent; cbf_cr = cbf_cr_parent; }
+  if (split) {
+    int h = 1 << (log2 - 1);
+    gen_transform_tree(g, x0, y0, log2 - 1, depth + 1, 0, cbf_cb, cbf_cr);
+    gen_transform_tree(g, x0 + h, y0, log2 - 1, depth + 1, 1, cbf_cb, cbf_cr);
+    gen_transform_tree(g, x0, y0 + h, log2 - 1, depth + 1, 2, cbf_cb, cbf_cr);
+    gen_transform_tree(g, x0 + h, y0 + h, log2 - 1, depth + 1, 3, cbf_cb, cbf_cr);
+  } else {
+    int cbf_luma = 1;
+    if (g->cu_pred_mode == MODE_INTRA || depth != 0 || cbf_cb || cbf_cr) {
+      cbf_luma = rpct(g, 55);
+      orc_cenc_bin(c, CTX_CBF_LUMA + (depth == 0 ? 1 : 0), cbf_luma);
+    }
+    gen_transform_unit(g, x0, y0, log2, blk, cbf_luma, log2 > 2 ? cbf_cb : 0, log2 > 2 ? cbf_cr : 0, cbf_cb_parent, cbf_cr_parent);
+  }
+}
+
+/* ------------------------------------------------------------------ prediction unit, 7.3.8.6 / 7.3.8.9 */
+static void put_mvd_comp_rest(orc_cabac_enc *c, int a)       /* abs_mvd_minus2 (EG1) for |mvd| > 1 */
+{
+  int x = a - 2, kk = 1;
+  while (x >= (1 << kk)) { orc_cenc_bypass(c, 1); x -= 1 << kk; kk++; }
+  orc_cenc_bypass(c, 0);
+  orc_cenc_bypass_bits(c, (uint32_t)x, kk);
+}
+static int draw_mvd(orc_gen *g)
+{
+  int r = (int)(rnd(g) % 100u), v;
+  if (r < 30) v = 0;
+  else if (r < 60) v = rrange(g, 1, 6);
+  else if (r < 90) v = rrange(g, 1, 40);
+  else if (r < 99 || !g->cfg.big_mvd) v = rrange(g, 1, 300);
+  else v = rrange(g, 300, 9000);
+  return (rnd(g) & 1u) ? -v : v;
+}
+static void put_merge_idx(orc_gen *g)
+{
+  orc_cabac_enc *c = &g->c;
+  const int mx = g->sh.max_num_merge_cand;
+  if (mx <= 1) return;
+  int idx = rpct(g, 50) ? 0 : rrange(g, 0, mx - 1);
+  orc_cenc_bin(c, CTX_MERGE_IDX, idx > 0);
+  if (idx > 0) for (int i = 1; i < mx - 1; i++) { orc_cenc_bypass(c, idx > i); if (idx <= i) break; }
+}
+static void gen_prediction_unit(orc_gen *g, int skip, int *merge_out)
+{
+  orc_cabac_enc *c = &g->c;
+  int merge = 1;
+  if (!skip) { merge = rpct(g, 45); orc_cenc_bin(c, CTX_MERGE_FLAG, merge); }
+  if (merge_out) *merge_out = merge;
+  if (merge) { put_merge_idx(g); return; }
+  if (g->sh.num_ref_idx_l0 > 1) {
+    const int mx = g->sh.num_ref_idx_l0 - 1, ref = rrange(g, 0, mx);
+    for (int i = 0; i < mx; i++) {                         /* truncated Rice, cMax = mx: first two bins context coded */
+      const int b = ref > i;
+      if (i < 2) orc_cenc_bin(c, CTX_REF_IDX + i, b); else orc_cenc_bypass(c, b);
+      if (!b) break;
+    }
+  }
+  const int dx = draw_mvd(g), dy = draw_mvd(g), ax = orc_abs(dx), ay = orc_abs(dy);
+  orc_cenc_bin(c, CTX_MVD_GT0, ax > 0); orc_cenc_bin(c, CTX_MVD_GT0, ay > 0);
+  if (ax > 0) orc_cenc_bin(c, CTX_MVD_GT1, ax > 1);
+  if (ay > 0) orc_cenc_bin(c, CTX_MVD_GT1, ay > 1);
+  if (ax > 0) { if (ax > 1) put_mvd_comp_rest(c, ax); orc_cenc_bypass(c, dx < 0); }
+  if (ay > 0) { if (ay > 1) put_mvd_comp_rest(c, ay); orc_cenc_bypass(c, dy < 0); }
+  orc_cenc_bin(c, CTX_MVP_FLAG, (int)(rnd(g) & 1u));
+}
+
+/* ------------------------------------------------------------------ coding unit, 7.3.8.5 */
+static void gen_coding_unit(orc_gen *g, int x0, int y0, int log2cb, int ct_depth)
+{
+  orc_cabac_enc *c = &g->c;
+  orc_pic *pic = &g->side;
+  const orc_sps *s = &g->sps;
+  const int n = 1 << log2cb;
+  int skip = 0;
+  if (!g->slice_is_intra) {
+    int l = orc_available(&g->av, x0, y0, x0 - 1, y0) && pic->pred_mode[b4(pic, x0 - 1, y0)] == MODE_SKIP;
+    int a = orc_available(&g->av, x0, y0, x0, y0 - 1) && pic->pred_mode[b4(pic, x0, y0 - 1)] == MODE_SKIP;
+    skip = rpct(g, 25);
+    orc_cenc_bin(c, CTX_SKIP + l + a, skip);
+  }
+  g->part_mode = PART_2Nx2N; g->intra_split = 0;
+  int rqt_root_cbf = 1, merge_2nx2n = 0;
+  fill4(pic, pic->ct_depth, x0, y0, n, n, ct_depth);
+  if (skip) {
+    g->cu_pred_mode = MODE_INTER;
+    fill4(pic, pic->pred_mode, x0, y0, n, n, MODE_SKIP);
+    gen_prediction_unit(g, 1, NULL);
+    rqt_root_cbf = 0;
+  } else {
+    g->cu_pred_mode = MODE_INTRA;
+    if (!g->slice_is_intra) {
+      g->cu_pred_mode = rpct(g, g->cfg.intra_in_p) ? MODE_INTRA : MODE_INTER;
+      orc_cenc_bin(c, CTX_PRED_MODE, g->cu_pred_mode == MODE_INTRA);
+    }
+    if (g->cu_pred_mode != MODE_INTRA || log2cb == s->log2_min_cb) {
+      /* part_mode, binarisation 9.3.3.7 */
+      if (g->cu_pred_mode == MODE_INTRA) {
+        g->part_mode = (g->cfg.nxn_intra && rpct(g, 50)) ? PART_NxN : PART_2Nx2N;
+        orc_cenc_bin(c, CTX_PART_MODE, g->part_mode == PART_2Nx2N);
+      } else {
+        int pm = PART_2Nx2N;
+        if (g->cfg.all_part_modes && rpct(g, 50)) {
+          if (log2cb == s->log2_min_cb) pm = rpct(g, 50) ? PART_2NxN : PART_Nx2N;      /* (NxN needs min CB > 8) */
+          else if (!s->amp_enabled) pm = rpct(g, 50) ? PART_2NxN : PART_Nx2N;
+          else { static const int m[6] = { PART_2NxN, PART_Nx2N, PART_2NxnU, PART_2NxnD, PART_nLx2N, PART_nRx2N }; pm = m[rrange(g, 0, 5)]; }
+        }
+        g->part_mode = pm;
+        if (pm == PART_2Nx2N) orc_cenc_bin(c, CTX_PART_MODE, 1);
+        else {
+          orc_cenc_bin(c, CTX_PART_MODE, 0);
+          const int horiz = (pm == PART_2NxN || pm == PART_2NxnU || pm == PART_2NxnD);
+          if (log2cb == s->log2_min_cb) {
+            orc_cenc_bin(c, CTX_PART_MODE + 1, horiz);             /* log2 == 3: '01' 2NxN, '00' Nx2N */
+          } else if (!s->amp_enabled) orc_cenc_bin(c, CTX_PART_MODE + 1, horiz);
+          else {
+            orc_cenc_bin(c, CTX_PART_MODE + 1, horiz);
+            const int sym = (pm == PART_2NxN || pm == PART_Nx2N);
+            orc_cenc_bin(c, CTX_PART_MODE + 3, sym);
+            if (!sym) orc_cenc_bypass(c, pm == PART_2NxnD || pm == PART_nRx2N);
+          }
+        }
+      }
+    }
+    fill4(pic, pic->pred_mode, x0, y0, n, n, g->cu_pred_mode);
+    if (g->cu_pred_mode == MODE_INTRA) {
+      g->intra_split = (g->part_mode == PART_NxN);
+      const int parts = g->intra_split ? 2 : 1, pb = n / parts;
+      int prev[4], np = parts * parts;
+      for (int k = 0; k < np; k++) { prev[k] = rpct(g, 50); orc_cenc_bin(c, CTX_PREV_INTRA, prev[k]); }
+      int k = 0;
+      for (int j = 0; j < parts; j++)
+        for (int i = 0; i < parts; i++, k++) {
+          const int xp = x0 + i * pb, yp = y0 + j * pb;
+          int ca = 1, cb = 1;                                   /* 8.4.2 candidate modes */
+          if (orc_available(&g->av, xp, yp, xp - 1, yp) && pic->pred_mode[b4(pic, xp - 1, yp)] == MODE_INTRA) ca = pic->intra_mode[b4(pic, xp - 1, yp)];
+          if (orc_available(&g->av, xp, yp, xp, yp - 1) && pic->pred_mode[b4(pic, xp, yp - 1)] == MODE_INTRA &&
+              (yp - 1) >= ((yp >> s->ctb_log2) << s->ctb_log2)) cb = pic->intra_mode[b4(pic, xp, yp - 1)];
+          int cand[3];
+          if (ca == cb) {
+            if (ca < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
+            else { cand[0] = ca; cand[1] = 2 + ((ca + 29) % 32); cand[2] = 2 + ((ca - 2 + 1) % 32); }
+          } else {
+            cand[0] = ca; cand[1] = cb;
+            if (ca != 0 && cb != 0) cand[2] = 0; else if (ca != 1 && cb != 1) cand[2] = 1; else cand[2] = 26;
+          }
+          int mode;
+          if (prev[k]) {
+            const int idx = rrange(g, 0, 2);
+            orc_cenc_bypass(c, idx > 0); if (idx > 0) orc_cenc_bypass(c, idx > 1);
+            mode = cand[idx];
+          } else {
+            const int rem = rrange(g, 0, 31);
+            orc_cenc_bypass_bits(c, (uint32_t)rem, 5);
+            mode = rem;
+            if (cand[0] > cand[1]) { int t = cand[0]; cand[0] = cand[1]; cand[1] = t; }
+            if (cand[0] > cand[2]) { int t = cand[0]; cand[0] = cand[2]; cand[2] = t; }
+            if (cand[1] > cand[2]) { int t = cand[1]; cand[1] = cand[2]; cand[2] = t; }
+            for (int q = 0; q < 3; q++) if (mode >= cand[q]) mode++;
+          }
+          g->intra_modes[k] = mode;
+          fill4(pic, pic->intra_mode, xp, yp, pb, pb, mode);
+        }
+      int icpm = 4;
+      if (g->cfg.chroma_modes && rpct(g, 60)) icpm = rrange(g, 0, 3);
+      orc_cenc_bin(c, CTX_CHROMA_MODE, icpm != 4);
+      if (icpm != 4) orc_cenc_bypass_bits(c, (uint32_t)icpm, 2);
+      static const int cm[4] = { 0, 26, 10, 1 };
+      if (icpm == 4) g->chroma_mode = g->intra_modes[0];
+      else { g->chroma_mode = cm[icpm]; if (g->chroma_mode == g->intra_modes[0]) g->chroma_mode = 34; }
+    } else {
+      int mf = 0;
+      const int npu = (g->part_mode == PART_2Nx2N) ? 1 : (g->part_mode == PART_NxN ? 4 : 2);
+      for (int i = 0; i < npu; i++) gen_prediction_unit(g, 0, i == 0 ? &merge_2nx2n : &mf);
+      if (!(g->part_mode == PART_2Nx2N && merge_2nx2n)) { rqt_root_cbf = rpct(g, 65); orc_cenc_bin(c, CTX_RQT_ROOT_CBF, rqt_root_cbf); }
+    }
+  }
+  if (rqt_root_cbf) {
+    g->max_trafo_depth = (g->cu_pred_mode == MODE_INTRA) ? s->max_th_depth_intra + g->intra_split : s->max_th_depth_inter;
+    gen_transform_tree(g, x0, y0, log2cb, 0, 0, 0, 0);
+  }
+}
+
+static void gen_coding_quadtree(orc_gen *g, int x0, int y0, int log2cb, int depth)
+{
+  orc_cabac_enc *c = &g->c;
+  orc_pic *pic = &g->side;
+  const orc_sps *s = &g->sps;
+  const int n = 1 << log2cb;
+  int split;
+  if (x0 + n <= s->width && y0 + n <= s->height && log2cb > s->log2_min_cb) {
+    int l = orc_available(&g->av, x0, y0, x0 - 1, y0) && pic->ct_depth[b4(pic, x0 - 1, y0)] > depth;
+    int a = orc_available(&g->av, x0, y0, x0, y0 - 1) && pic->ct_depth[b4(pic, x0, y0 - 1)] > depth;
+    if (log2cb > g->cfg.max_cu_log2) split = 1;
+    else if (log2cb <= g->cfg.min_cu_log2) split = 0;
+    else split = rpct(g, log2cb == 6 ? 70 : (log2cb == 5 ? 50 : 40));
+    orc_cenc_bin(c, CTX_SPLIT_CU + l + a, split);
+  } else split = (log2cb > s->log2_min_cb);
+  if (g->pps.cu_qp_delta_enabled && log2cb >= g->log2_qg) g->cu_qp_delta_coded = 0;
+  if (split) {
+    const int h = n >> 1;
+    gen_coding_quadtree(g, x0, y0, log2cb - 1, depth + 1);
+    if (x0 + h < s->width) gen_coding_quadtree(g, x0 + h, y0, log2cb - 1, depth + 1);
+    if (y0 + h < s->height) gen_coding_quadtree(g, x0, y0 + h, log2cb - 1, depth + 1);
+    if (x0 + h < s->width && y0 + h < s->height) gen_coding_quadtree(g, x0 + h, y0 + h, log2cb - 1, depth + 1);
+  } else gen_coding_unit(g, x0, y0, log2cb, depth);
+}
+
+/* ------------------------------------------------------------------ SAO parameters of one CTU */
+static void draw_sao(orc_gen *g, orc_sao_params *p, const orc_sao_params *left, const orc_sao_params *up, int luma, int chroma)
+{
+  memset(p, 0, sizeof(*p));
+  if (left && rpct(g, 25)) { *p = *left; return; }
+  if (up && rpct(g, 25)) { *p = *up; return; }
+  for (int ci = 0; ci < 3; ci++) {
+    if (!(ci ? chroma : luma)) continue;
+    if (ci == 2) { p->type[2] = p->type[1]; p->eo_class[2] = p->eo_class[1]; }
+    else { p->type[ci] = (uint8_t)(rpct(g, 30) ? 0 : rrange(g, 1, 2)); p->eo_class[ci] = (uint8_t)rrange(g, 0, 3); }
+    if (!p->type[ci]) { p->eo_class[ci] = 0; continue; }
+    for (int k = 0; k < 4; k++) {
+      int a = rpct(g, 40) ? 0 : rrange(g, 1, 7);
+      if (p->type[ci] == 1) p->offset[ci][k] = (int8_t)((rnd(g) & 1u) ? -a : a);
+      else p->offset[ci][k] = (int8_t)(k < 2 ? a : -a);
+    }
+    if (p->type[ci] == 1) { p->band_pos[ci] = (uint8_t)rrange(g, 0, 31); p->eo_class[ci] = 0; }
+  }
+  /* identical to a merge candidate by accident: the writer would code a merge -- fine, same parameters */
+}
+
+/* ------------------------------------------------------------------ one picture */
+static void write_picture(orc_gen *g, int idr, int write_ps)
+{
+  orc_bitw ps, hdr, *subs;
+  const orc_sps *s = &g->sps; orc_pps *p = &g->pps; orc_slice_hdr *sh = &g->sh;
+  const int wc = s->pic_w_ctbs, hc = s->pic_h_ctbs;
+  const int nal = idr ? NAL_IDR_W_RADL : NAL_TRAIL_R;
+  g->au.len = 0; g->au.nbits = 0; g->au.cur = 0;
+  if (write_ps) {
+    orc_bw_init(&ps); orc_write_vps(&ps, &g->vps, &g->sps); orc_write_nal(&g->au, NAL_VPS, 0, ps.buf, ps.len, 1); orc_bw_free(&ps);
+    orc_bw_init(&ps); orc_write_sps(&ps, &g->sps); orc_write_nal(&g->au, NAL_SPS, 0, ps.buf, ps.len, 1); orc_bw_free(&ps);
+    orc_bw_init(&ps); orc_write_pps(&ps, &g->pps); orc_write_nal(&g->au, NAL_PPS, 0, ps.buf, ps.len, 1); orc_bw_free(&ps);
+  }
+  /* ---- slice header */
+  memset(sh, 0, sizeof(*sh));
+  sh->first_slice_segment_in_pic = 1; sh->pic_output_flag = 1;
+  g->slice_is_intra = idr || g->since_idr == 0 || rpct(g, 8);
+  sh->slice_type = g->slice_is_intra ? SLICE_I : SLICE_P;
+  sh->poc_lsb = g->poc & ((1 << s->log2_max_poc_lsb) - 1);
+  if (!idr) {
+    /* reference picture set in the slice header, the way Kvazaar writes it: the previous pictures back to the IDR, at most num_refs */
+    const int nneg = ORC_MIN(g->cfg.num_refs, g->since_idr);
+    sh->short_term_ref_pic_set_sps_flag = 0;
+    sh->st_rps.num_negative = nneg;
+    int used = 0;
+    for (int i = 0; i < nneg; i++) { sh->st_rps.delta_poc_s0[i] = -(i + 1); sh->st_rps.used_s0[i] = (i == 0) ? 1 : rpct(g, 85); used += sh->st_rps.used_s0[i]; }
+    sh->num_ref_idx_l0 = g->slice_is_intra ? p->num_ref_idx_l0_default : rrange(g, 1, ORC_MIN(4, used + 1));   /* (more entries than pictures: the list wraps) */
+    sh->slice_temporal_mvp_enabled = s->temporal_mvp_enabled ? rpct(g, 80) : 0;
+    sh->collocated_from_l0 = 1;
+    sh->collocated_ref_idx = (sh->slice_temporal_mvp_enabled && !g->slice_is_intra) ? rrange(g, 0, sh->num_ref_idx_l0 - 1) : 0;
+  } else sh->num_ref_idx_l0 = p->num_ref_idx_l0_default;
+  sh->num_ref_idx_l1 = p->num_ref_idx_l1_default;
+  sh->cabac_init_flag = p->cabac_init_present ? rpct(g, 50) : 0;
+  sh->max_num_merge_cand = rrange(g, 1, 5);
+  sh->slice_qp_delta = rrange(g, -4, 4);
+  sh->slice_qp = p->init_qp + sh->slice_qp_delta;
+  if (p->slice_chroma_qp_offsets_present) { sh->slice_cb_qp_offset = rrange(g, -2, 2); sh->slice_cr_qp_offset = rrange(g, -2, 2); }
+  sh->slice_deblocking_disabled = p->pps_deblocking_disabled; sh->beta_offset_div2 = p->pps_beta_offset_div2; sh->tc_offset_div2 = p->pps_tc_offset_div2;
+  if (p->deblocking_filter_override_enabled && rpct(g, 60)) {
+    sh->deblocking_filter_override = 1;
+    sh->slice_deblocking_disabled = rpct(g, 25);
+    if (!sh->slice_deblocking_disabled) { sh->beta_offset_div2 = rrange(g, -6, 6); sh->tc_offset_div2 = rrange(g, -6, 6); }
+  }
+  sh->loop_filter_across_slices = 1;
+  if (s->sao_enabled) { sh->sao_luma = rpct(g, 80); sh->sao_chroma = rpct(g, 80); }
+  /* ---- slice data: one substream per CTU row with WPP, else one per tile */
+  const int wpp = p->entropy_coding_sync_enabled;
+  const int nsub = wpp ? hc : g->nrows_t;
+  subs = (orc_bitw *)calloc((size_t)nsub, sizeof(orc_bitw));
+  orc_ctx saved[CTX_COUNT];
+  const int init_type = g->slice_is_intra ? 0 : (sh->cabac_init_flag ? 2 : 1);
+  int sub = -1;
+  orc_pic_reset_side(&g->side);
+  memset(&g->c, 0, sizeof(g->c));
+  for (int cy = 0; cy < hc; cy++) {
+    int tile_start = 0, tile_end = 0;
+    for (int i = 0; i < g->nrows_t; i++) { if (cy == g->row_bd[i]) tile_start = 1; if (cy + 1 == g->row_bd[i + 1]) tile_end = 1; }
+    if (tile_start || wpp) {
+      sub++;
+      orc_bw_init(&subs[sub]);
+      orc_cenc_start(&g->c, &subs[sub]);
+      /* 9.3.1: first CTB of a tile initialises; a WPP row synchronises with the state after the 2nd CTB of the row above when
+       * that CTB exists (pictures one CTB wide: it does not, the row initialises afresh) */
+      if (tile_start || wc < 2) orc_cabac_init_contexts(g->c.ctx, init_type, sh->slice_qp);
+      else memcpy(g->c.ctx, saved, sizeof(saved));
+    }
+    for (int cx = 0; cx < wc; cx++) {
+      if (sh->sao_luma || sh->sao_chroma) {
+        orc_sao_params *sp = &g->sao[cy * wc + cx];
+        const orc_sao_params *left = cx > 0 ? sp - 1 : NULL, *up = (cy > 0 && !tile_start) ? sp - wc : NULL;
+        draw_sao(g, sp, left, up, sh->sao_luma, sh->sao_chroma);
+        orc_sao_write(&g->c, sp, left, up, sh->sao_luma, sh->sao_chroma);
+      }
+      gen_coding_quadtree(g, cx * 64, cy * 64, 6, 0);
+      if (wpp && cx == 1) memcpy(saved, g->c.ctx, sizeof(saved));
+      const int last = (cy == hc - 1 && cx == wc - 1);
+      const int sub_end = cx == wc - 1 && (wpp || tile_end);
+      orc_cenc_terminate(&g->c, last);                  /* end_of_slice_segment_flag */
+      if (!last && sub_end) orc_cenc_terminate(&g->c, 1);   /* end_of_subset_one_bit */
+      if (last || sub_end) orc_bw_align_zero(g->c.bw);
+    }
+  }
+  uint32_t *ep = (uint32_t *)calloc((size_t)nsub, sizeof(uint32_t));
+  sh->num_entry_points = nsub - 1; sh->entry_point_offset = ep;
+  for (int i = 0; i < nsub - 1; i++) ep[i] = (uint32_t)orc_escaped_size(subs[i].buf, subs[i].len);
+  orc_bw_init(&hdr);
+  orc_write_slice_header(&hdr, sh, s, p, nal);
+  for (int i = 0; i < nsub; i++) { orc_bw_bytes(&hdr, subs[i].buf, subs[i].len); orc_bw_free(&subs[i]); }
+  orc_write_nal(&g->au, nal, 0, hdr.buf, hdr.len, 1);
+  orc_bw_free(&hdr); free(subs); free(ep);
+  sh->entry_point_offset = NULL;
+}
+
+size_t orc_gen_picture(orc_gen *g, const uint8_t **au)
+{
+  const int period = g->cfg.intra_period;
+  const int idr = (g->frame_idx == 0) || (period > 0 && (g->frame_idx % period) == 0);
+  if (idr) { g->poc = 0; g->since_idr = 0; } else { g->poc++; g->since_idr++; }
+  write_picture(g, idr, idr);
+  g->frame_idx++;
+  *au = g->au.buf;
+  return g->au.len;
+}

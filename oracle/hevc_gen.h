@@ -1,0 +1,52 @@
+/* oracle/hevc_gen.h -- conformance-style HEVC stream synthesiser (see hevc_gen.c).  Test infrastructure:
+ * it produces the streams the product's decoder must accept from a foreign encoder (a Kvazaar peer,
+ * /root/reference/src/media/processing/openhevcfilter.cpp:134-172) but this project's own encoder never writes. */
+#ifndef ORC_HEVC_GEN_H
+#define ORC_HEVC_GEN_H
+#include "hevc_common.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct orc_gen orc_gen;
+
+/* Every switch: -1 = drawn from the seed, otherwise as given.  All int: tests pass the struct as a flat array. */
+typedef struct {
+  int width, height;          /* coded size: multiples of 8 (the minimum coding block), not necessarily of 64 */
+  int seed;
+  int intra_period;           /* IDR every n-th picture; other pictures are P slices (8 % of them I slices in TRAIL_R) */
+  int qp;                     /* PPS init_qp; slices add -4..4, CUs their cu_qp_delta */
+  int density;                /* probability (%) of a significant coefficient */
+  int num_refs;               /* 1..4 reference pictures kept (RPS in the slice header, Kvazaar style); active entries drawn per slice */
+  int tmvp;                   /* sps_temporal_mvp_enabled_flag (slices switch it on 80 % of the time, random collocated_ref_idx) */
+  int amp;                    /* amp_enabled_flag */
+  int sao;                    /* sample_adaptive_offset_enabled_flag */
+  int strong_intra;           /* strong_intra_smoothing_enabled_flag */
+  int sign_hiding;            /* sign_data_hiding_enabled_flag */
+  int transform_skip;         /* transform_skip_enabled_flag */
+  int cabac_init;             /* cabac_init_present_flag (cabac_init_flag per slice) */
+  int wpp;                    /* entropy_coding_sync_enabled_flag */
+  int tile_rows;              /* full-width tile rows, 1 = none */
+  int uniform_tiles;          /* uniform_spacing_flag (else explicit row heights) */
+  int th_depth_inter, th_depth_intra;   /* max_transform_hierarchy_depth_* 0..2 */
+  int qp_delta;               /* 0: cu_qp_delta off; 1..4: on with diff_cu_qp_delta_depth = value - 1 */
+  int chroma_qp_offsets;      /* pps_cb/cr_qp_offset (+ slice offsets half of the time) */
+  int deblock_mode;           /* 0 default, 1 disabled in the PPS, 2 PPS beta/tc offsets, 3 slice-level override */
+  int par_mrg_level;          /* Log2ParMrgLevel 2..4 */
+  int intra_in_p;             /* probability (%) of an intra CU in a P slice */
+  int all_part_modes;         /* inter partitionings other than 2Nx2N (2NxN, Nx2N, and the AMP ones with amp) */
+  int chroma_modes;           /* intra_chroma_pred_mode 0..3 besides 4 (derived) */
+  int nxn_intra;              /* PART_NxN intra at 8x8 */
+  int max_cu_log2, min_cu_log2;   /* coding block sizes used (the syntax allows 3..6 regardless) */
+  int big_mvd;                /* 1 % of the vector differences are huge (reference blocks far outside the picture) */
+} orc_gen_config;
+
+void orc_gen_default_config(orc_gen_config *c);    /* everything random, 416x240 */
+orc_gen *orc_gen_open(const orc_gen_config *c);
+void orc_gen_get_config(const orc_gen *g, orc_gen_config *out);   /* with the drawn values filled in */
+/* next access unit (parameter sets with every IDR); the buffer is owned by the generator and valid until the next call */
+size_t orc_gen_picture(orc_gen *g, const uint8_t **au);
+void orc_gen_close(orc_gen *g);
+#ifdef __cplusplus
+}
+#endif
+#endif

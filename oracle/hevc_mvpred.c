@@ -19,6 +19,37 @@ static int same_motion(const orc_mvinfo *a, const orc_mvinfo *b)
   return a->ref_idx == b->ref_idx && a->mv[0] == b->mv[0] && a->mv[1] == b->mv[1];
 }
 
+/* 8.5.3.2.8 / 8.5.3.2.9: temporal luma motion vector prediction for the prediction block (xpb, ypb, w x h) and target reference
+ * index ref_idx.  Collocated pictures of P streams carry list-0 motion only; no long-term pictures.  Returns availableFlagLXCol. */
+static int temporal_mv(const orc_mvpred_ctx *c, int xpb, int ypb, int npbw, int npbh, int ref_idx, int16_t mv[2])
+{
+  const orc_pic *col = c->col;
+  if (!col) return 0;
+  const int ctb = c->av.ctb_log2;
+  int cand[2][2] = { { xpb + npbw, ypb + npbh }, { xpb + (npbw >> 1), ypb + (npbh >> 1) } };
+  for (int k = 0; k < 2; k++) {
+    int x = cand[k][0], y = cand[k][1];
+    if (k == 0 && !((ypb >> ctb) == (y >> ctb) && y < c->av.pic_h && x < c->av.pic_w)) continue;   /* bottom right: same CTB row, inside the picture */
+    x = (x >> 4) << 4; y = (y >> 4) << 4;                        /* motion is stored at 16x16 granularity */
+    const int i = (y >> 2) * col->b4_w + (x >> 2);
+    if (col->pred_mode[i] == MODE_INTRA || col->pred_mode[i] == 255 || col->mvf[i].ref_idx < 0) continue;
+    const int col_poc_diff = col->poc - col->ref_poc_list[col->mvf[i].ref_idx & 15];
+    const int cur_poc_diff = c->cur_poc - c->ref_poc[ref_idx];
+    mv[0] = col->mvf[i].mv[0]; mv[1] = col->mvf[i].mv[1];
+    if (col_poc_diff != cur_poc_diff && col_poc_diff != 0) {
+      const int td = orc_clip3(-128, 127, col_poc_diff), tb = orc_clip3(-128, 127, cur_poc_diff);
+      const int tx = (16384 + (orc_abs(td) >> 1)) / td;
+      const int dsf = orc_clip3(-4096, 4095, (tb * tx + 32) >> 6);
+      for (int q = 0; q < 2; q++) {
+        const int prod = dsf * mv[q], sg = prod < 0 ? -1 : 1;
+        mv[q] = (int16_t)orc_clip3(-32768, 32767, sg * ((orc_abs(prod) + 127) >> 8));
+      }
+    }
+    return 1;
+  }
+  return 0;
+}
+
 void orc_merge_candidates(const orc_mvpred_ctx *c, int xcb, int ycb, int ncbs, int xpb, int ypb,
                           int npbw, int npbh, int part_idx, int part_mode, orc_mvcand *cand)
 {
@@ -57,6 +88,8 @@ void orc_merge_candidates(const orc_mvpred_ctx *c, int xcb, int ycb, int ncbs, i
   if (avA0) ADD(A0);
   if (avB2) ADD(B2);
 #undef ADD
+  { int16_t tmv[2];                               /* temporal candidate: refIdxL0Col = 0 (8.5.3.2.2 step 3-4) */
+    if (n < maxc && temporal_mv(c, xpb, ypb, npbw, npbh, 0, tmv)) { cand[n].mv[0] = tmv[0]; cand[n].mv[1] = tmv[1]; cand[n].ref_idx = 0; n++; } }
   /* 8.5.3.2.5 zero motion vector merging candidates (P slices) */
   int zero_idx = 0;
   while (n < maxc) {
@@ -120,6 +153,9 @@ void orc_amvp_candidates(const orc_mvpred_ctx *c, int xcb, int ycb, int ncbs, in
   int n = 0;
   if (flagA) { cand[n][0] = mvA[0]; cand[n][1] = mvA[1]; n++; }
   if (flagB && !(flagA && mvA[0] == mvB[0] && mvA[1] == mvB[1])) { cand[n][0] = mvB[0]; cand[n][1] = mvB[1]; n++; }
-  /* (temporal candidate would go here when fewer than two; not supported) */
+  if (n < 2 && !(flagA && flagB && n == 2)) {        /* temporal candidate unless A and B are both there and differ (8.5.3.2.6) */
+    int16_t tmv[2];
+    if (temporal_mv(c, xpb, ypb, npbw, npbh, ref_idx, tmv)) { cand[n][0] = tmv[0]; cand[n][1] = tmv[1]; n++; }
+  }
   while (n < 2) { cand[n][0] = cand[n][1] = 0; n++; }
 }

@@ -1,5 +1,5 @@
 /* oracle/hevc_mvpred.h -- merge candidates (H.265 8.5.3.2.2-8.5.3.2.5) and luma motion vector
- * prediction (8.5.3.2.6-8.5.3.2.7) for list-0 uni-prediction without temporal candidates.
+ * prediction (8.5.3.2.6-8.5.3.2.7) for list-0 uni-prediction, with the temporal candidate of 8.5.3.2.8-8.5.3.2.9.
  * Test infrastructure. */
 #ifndef ORC_HEVC_MVPRED_H
 #define ORC_HEVC_MVPRED_H
@@ -15,6 +15,7 @@ typedef struct {
   int max_num_merge_cand;
   int num_ref_idx;               /* num_ref_idx_l0_active */
   int cur_poc; int ref_poc[16];  /* POC of RefPicList0 entries */
+  const orc_pic *col;            /* collocated picture (slice_temporal_mvp_enabled_flag, collocated_ref_idx), NULL = no temporal candidates */
 } orc_mvpred_ctx;
 
 typedef struct { int16_t mv[2]; int8_t ref_idx; } orc_mvcand;

@@ -41,7 +41,7 @@ static int bs_pair(const orc_pic *p, int ip, int iq, int edge_bits)
   if ((edge_bits & 1) && (p->tu_nz[ip] || p->tu_nz[iq])) return 1;
   const orc_mvinfo *a = &p->mvf[ip], *b = &p->mvf[iq];
   /* uni-prediction from list 0 only in this oracle: compare reference picture and mv */
-  if (a->ref_idx != b->ref_idx) return 1;
+  if (p->ref_poc_list[a->ref_idx & 15] != p->ref_poc_list[b->ref_idx & 15]) return 1;      /* different reference pictures (two indices may name one picture) */
   if (orc_abs(a->mv[0] - b->mv[0]) >= 4 || orc_abs(a->mv[1] - b->mv[1]) >= 4) return 1;
   return 0;
 }

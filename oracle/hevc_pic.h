@@ -29,6 +29,8 @@ typedef struct {
   uint8_t *edge_v, *edge_h;          /* bit0: transform edge at left/top of this 4x4, bit1: prediction edge */
   uint8_t *no_filter;                /* cu_transquant_bypass / pcm with loop filter disabled */
   orc_mvinfo *mvf;
+  int ref_poc_list[16];              /* POC of RefPicList0[i] of the (single) slice of this picture: boundary strength compares reference PICTURES
+                                      * (8.7.2.4), temporal motion vector prediction scales by POC distances (8.5.3.2.9) */
 } orc_pic;
 
 int  orc_pic_alloc(orc_pic *p, int w, int h);

@@ -8,6 +8,7 @@
 #include "hevc_deblock.h"
 #include "hevc_cabac.h"
 #include "synth.h"
+#include "hevc_gen.h"
 
 int orc_api_version(void) { return 1; }
 
@@ -171,4 +172,26 @@ long orc_api_cabac_roundtrip(const uint8_t *kinds, const uint8_t *ci, const uint
   long consumed = (long)orc_cdec_bytes_consumed(&d);
   orc_bw_free(&bw);
   return (term == 1 && consumed == len) ? len : -len;
+}
+
+/* ---- stream synthesiser (hevc_gen.c): cfg = the orc_gen_config fields as a flat int array ---- */
+orc_gen *orc_api_gen_open(const int *cfg, int n)
+{
+  orc_gen_config c; orc_gen_default_config(&c);
+  int *f = (int *)&c;
+  for (int i = 0; i < n && i < (int)(sizeof(c) / sizeof(int)); i++) f[i] = cfg[i];
+  return orc_gen_open(&c);
+}
+int orc_api_gen_config(const orc_gen *g, int *out, int n)
+{
+  orc_gen_config c; orc_gen_get_config(g, &c);
+  const int *f = (const int *)&c, m = (int)(sizeof(c) / sizeof(int));
+  for (int i = 0; i < n && i < m; i++) out[i] = f[i];
+  return m;
+}
+long orc_api_gen_picture(orc_gen *g, uint8_t *out, long cap)
+{
+  const uint8_t *au; size_t n = orc_gen_picture(g, &au);
+  if ((long)n <= cap) memcpy(out, au, n);
+  return (long)n;
 }

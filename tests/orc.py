@@ -174,3 +174,50 @@ class OracleDecoder:
 
     def __del__(self):
         self.close()
+
+
+GEN_FIELDS = ("width", "height", "seed", "intra_period", "qp", "density", "num_refs", "tmvp", "amp", "sao", "strong_intra", "sign_hiding",
+              "transform_skip", "cabac_init", "wpp", "tile_rows", "uniform_tiles", "th_depth_inter", "th_depth_intra", "qp_delta",
+              "chroma_qp_offsets", "deblock_mode", "par_mrg_level", "intra_in_p", "all_part_modes", "chroma_modes", "nxn_intra",
+              "max_cu_log2", "min_cu_log2", "big_mvd")
+
+
+class OracleGen:
+    """conformance-style stream synthesiser (oracle/hevc_gen.c): random but valid Main-profile syntax covering the tools a foreign
+    encoder uses.  Keyword arguments are the orc_gen_config fields; anything not given is drawn from the seed."""
+
+    def __init__(self, width, height, seed=1, **kw):
+        cfg = {k: -1 for k in GEN_FIELDS}
+        cfg.update(width=width, height=height, seed=seed, intra_period=8, qp=30, density=30)
+        for k, v in kw.items():
+            if k not in cfg:
+                raise KeyError(k)
+            cfg[k] = v
+        arr = (C.c_int * len(GEN_FIELDS))(*[int(cfg[k]) for k in GEN_FIELDS])
+        L = lib()
+        L.orc_api_gen_open.restype = C.c_void_p
+        L.orc_api_gen_open.argtypes = [C.c_void_p, C.c_int]
+        L.orc_api_gen_picture.restype = C.c_long
+        L.orc_api_gen_picture.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        L.orc_api_gen_config.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_gen_close.argtypes = [C.c_void_p]
+        self.p = L.orc_api_gen_open(arr, len(GEN_FIELDS))
+        if not self.p:
+            raise RuntimeError("orc_gen_open failed")
+        self.buf = np.empty(width * height * 4 + (1 << 20), dtype=np.uint8)
+        out = (C.c_int * len(GEN_FIELDS))()
+        L.orc_api_gen_config(self.p, out, len(GEN_FIELDS))
+        self.config = dict(zip(GEN_FIELDS, [int(v) for v in out]))
+
+    def picture(self):
+        n = lib().orc_api_gen_picture(self.p, self.buf.ctypes.data, len(self.buf))
+        assert n <= len(self.buf)
+        return bytes(self.buf[:n])
+
+    def close(self):
+        if self.p:
+            lib().orc_gen_close(self.p)
+            self.p = None
+
+    def __del__(self):
+        self.close()

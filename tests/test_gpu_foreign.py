@@ -1,0 +1,104 @@
+"""GPU parity for streams this project's own encoder never writes: what libOpenHevcDecode gets from a foreign peer
+(/root/reference/src/media/processing/openhevcfilter.cpp:134-172 feeds arbitrary NAL units; the peer normally runs Kvazaar with
+gop=lp-g4d3t1, kvazaarfilter.cpp:233).  The streams come from the conformance-style synthesiser oracle/hevc_gen.c -- random but
+valid Main-profile syntax -- and the HIP decoder must reproduce the general CPU decoder (oracle/hevc_dec.c) bit for bit."""
+import numpy as np
+import pytest
+
+import orc
+
+
+def run_stream(w, h, pictures, threads=1, frame_threads=False, **cfg):
+    from kvazzup_amd.codec import Decoder
+    g = orc.OracleGen(w, h, **cfg)
+    od = orc.OracleDecoder()
+    gd = Decoder(threads=threads, frame_threads=frame_threads) if frame_threads else Decoder()
+    refs, got = [], []
+    try:
+        for t in range(pictures):
+            au = g.picture()
+            r = od.decode_au(au, t)
+            assert len(r) == 1, (t, g.config)
+            refs.append(r[0]["i420"])
+            got += gd.decode_au(au, t)
+        if frame_threads:
+            got += gd.drain()
+        assert len(got) == pictures, (len(got), g.config)
+        for t in range(pictures):
+            assert got[t]["width"] == w and got[t]["height"] == h
+            if not np.array_equal(got[t]["i420"], refs[t]):
+                d = np.flatnonzero(got[t]["i420"] != refs[t])
+                plane = "Y" if d[0] < w * h else "C"
+                pytest.fail("picture %d: %d samples differ, first at %d (%s, x=%d y=%d); config %r"
+                            % (t, len(d), d[0], plane, d[0] % w, d[0] // w, g.config))
+    finally:
+        gd.close()
+        od.close()
+        g.close()
+
+
+PLAIN = dict(num_refs=1, tmvp=0, amp=0, sao=0, strong_intra=1, sign_hiding=0, transform_skip=0, cabac_init=0, wpp=1, tile_rows=1, uniform_tiles=1,
+             th_depth_inter=0, th_depth_intra=0, qp_delta=0, chroma_qp_offsets=0, deblock_mode=0, par_mrg_level=2, intra_in_p=0, all_part_modes=0,
+             chroma_modes=0, nxn_intra=0, max_cu_log2=5, min_cu_log2=3, big_mvd=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("feature", [
+    dict(),                                             # all CU sizes 8..32, fractional vectors, merge / AMVP, nothing else
+    dict(max_cu_log2=6),                                # 64x64 CUs: four 32x32 transform blocks
+    dict(intra_in_p=30),                                # intra CUs in P pictures
+    dict(intra_in_p=30, nxn_intra=1),                   # 4x4 luma intra blocks (DST), chroma at the parent
+    dict(intra_in_p=30, chroma_modes=1),                # intra_chroma_pred_mode 0..3 (and mode 34)
+    dict(strong_intra=0, intra_in_p=40),
+    dict(all_part_modes=1),                             # 2NxN, Nx2N
+    dict(all_part_modes=1, amp=1),                      # asymmetric partitions
+    dict(th_depth_inter=2, th_depth_intra=2, intra_in_p=20),       # transform trees
+    dict(th_depth_inter=1, all_part_modes=1),
+    dict(num_refs=3),                                   # several reference pictures, list longer than the set
+    dict(tmvp=1),                                       # temporal candidates
+    dict(num_refs=4, tmvp=1, par_mrg_level=4),
+    dict(sign_hiding=1),
+    dict(transform_skip=1, th_depth_inter=2, th_depth_intra=2, nxn_intra=1, intra_in_p=20),
+    dict(qp_delta=1), dict(qp_delta=3), dict(qp_delta=4, chroma_qp_offsets=1),
+    dict(deblock_mode=1), dict(deblock_mode=2), dict(deblock_mode=3),
+    dict(sao=1),
+    dict(cabac_init=1),
+    dict(wpp=0), dict(wpp=0, tile_rows=3), dict(wpp=1, tile_rows=2, uniform_tiles=0),
+    dict(big_mvd=1),
+])
+def test_feature_matches_oracle(gpu, feature):
+    """one tool at a time on top of a plain stream; 416x240 (partial CTUs on both axes), 6 pictures"""
+    cfg = dict(PLAIN); cfg.update(feature)
+    run_stream(416, 240, 6, seed=7, **cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(1, 25))
+def test_random_streams_match_oracle(gpu, seed):
+    """every switch drawn from the seed"""
+    sizes = [(416, 240), (352, 288), (200, 136), (64, 64), (24, 16), (648, 360)]
+    w, h = sizes[seed % len(sizes)]
+    run_stream(w, h, 8, seed=seed)
+
+
+@pytest.mark.gpu
+def test_kvazaar_shaped_stream_1080p(gpu):
+    """the shape a Kvazaar peer with uvgComm's settings sends: 1080p (coded height 1080, not 1088), lp-g4d3t1-like reference structure
+    (3 pictures, RPS in the slice header), TMVP, intra CUs in P pictures, no strong intra smoothing, sign hiding, WPP"""
+    run_stream(1920, 1080, 6, seed=11, num_refs=3, tmvp=1, strong_intra=0, sign_hiding=1, wpp=1, tile_rows=1, intra_in_p=15,
+               all_part_modes=0, amp=0, sao=0, qp_delta=0, deblock_mode=0, th_depth_inter=0, th_depth_intra=0, max_cu_log2=6, min_cu_log2=3,
+               nxn_intra=1, chroma_modes=1, transform_skip=0, cabac_init=0, chroma_qp_offsets=0, par_mrg_level=2, big_mvd=0, uniform_tiles=1)
+
+
+@pytest.mark.gpu
+def test_everything_on_1080p(gpu):
+    run_stream(1920, 1080, 4, seed=5, num_refs=4, tmvp=1, amp=1, sao=1, strong_intra=0, sign_hiding=1, transform_skip=1, cabac_init=1, wpp=1,
+               tile_rows=3, uniform_tiles=0, th_depth_inter=2, th_depth_intra=2, qp_delta=3, chroma_qp_offsets=1, deblock_mode=3, par_mrg_level=3,
+               intra_in_p=25, all_part_modes=1, chroma_modes=1, nxn_intra=1, max_cu_log2=6, min_cu_log2=3, big_mvd=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3, 4])
+def test_frame_threaded_decoder_foreign_streams(gpu, seed):
+    """OpenHEVC 'Frame' parallelisation: pictures parsed concurrently; temporal prediction makes a parser follow the collocated picture's"""
+    run_stream(416, 240, 12, threads=4, frame_threads=True, seed=seed, tmvp=1, num_refs=3)

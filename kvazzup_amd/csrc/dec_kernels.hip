@@ -13,6 +13,7 @@
 //                  horizontal edges in LDS
 //   k_dec_sao      one workgroup per CTU
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "dec_frame.h"
 #include "dec_kernels.h"
 #include "kernel_common.h"
@@ -314,50 +315,19 @@ __global__ __launch_bounds__(256) void k_dec_inter(DecFrame f)
 }
 
 // =============================================================================================
-// Intra blocks: one wave per (CTU, colour plane)
+// Intra blocks: one workgroup of T threads per (CTU, colour plane)
 // =============================================================================================
+#define DI_P 144                       // pitch of the CTU picture in LDS
 struct DecIntraLds {
-  // the CTU with its own samples only: sample (x, y) of the CTU at pic[y * 64 + x]; neighbours outside the CTU come from the picture
-  alignas(16) uint8_t pic[64 * 64];
+  // The CTU with its borders as one padded picture (the layout of enc_kernels.hip IntraWaveLds): row 0 = the sample row above the
+  // CTU (corner at column 15, then above and above-right), column 15 = the sample column to its left, sample (x, y) of the CTU at
+  // pic[(y + 1) * DI_P + 16 + x].  The borders are copied from the picture piecewise, as the neighbouring CTUs publish them.
+  alignas(16) uint8_t pic[65 * DI_P];
   alignas(16) int16_t A[1024], B[1024];
   alignas(16) int16_t M[2][KV_MATRIX_ENTRIES];
-  alignas(16) uint8_t R[2][144];       // reference samples in the scan order of 8.4.4.2.2, as built / filtered (enc_kernels.hip IntraWaveLds)
+  alignas(16) uint8_t R[2][144];       // reference samples in the scan order of 8.4.4.2.2, as built / filtered
   DecTu list[256];                     // this plane's intra blocks of the CTU, decoding order (luma: at most 256 4x4 blocks)
 };
-
-// progress of a (CTU, plane) wave, counted in 8x8 luma units of the CTU in z-order: every intra block of the plane that starts in
-// a unit below the counter is final in the picture.  Published at the values the neighbours wait for.
-__device__ __forceinline__ int intra_milestone(int z)
-{
-  return z >= 64 ? 7 : (z >= 60 ? 6 : (z >= 56 ? 5 : (z >= 48 ? 4 : (z >= 44 ? 3 : (z >= 32 ? 2 : (z >= 24 ? 1 : 0))))));
-}
-__device__ __forceinline__ void wave_publish(uint32_t *ctr, uint32_t value)
-{
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-// `seen`: the last value observed (wave-uniform), so that satisfied waits cost nothing
-__device__ __forceinline__ void wave_wait(const uint32_t *ctr, uint32_t need, uint32_t &seen, uint32_t *err)
-{
-  if (seen >= need) return;
-  uint32_t v = 0;
-  if (threadIdx.x == 0) {
-    uint32_t spins = 0;
-    while ((v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1u << 24)) { atomicOr(err, 1u); v = 64; break; }       // bounded spin: never hang the GPU
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-  seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
-
-struct IntraNb { bool left, up, upright, upleft; };     // neighbouring CTUs in the same tile (and inside the picture)
 
 // 6.4.1 for one slice: inside the picture, same tile, not later in z-scan order (luma locations)
 __device__ __forceinline__ bool dec_avail(const DecFrame &f, int xc, int yc, int xn, int yn)
@@ -367,15 +337,17 @@ __device__ __forceinline__ bool dec_avail(const DecFrame &f, int xc, int yc, int
   return zaddr64(xn, yn, f.wc) <= zaddr64(xc, yc, f.wc);
 }
 
-// one intra transform block of plane c: N x N samples at (rx, ry) of the CTU (component samples)
-template <int L2>
-__device__ __forceinline__ void dec_intra_block(const DecFrame &f, DecIntraLds &s, const DecTu &d, int c, int cx, int cy, int rx, int ry, int lane)
+// one intra transform block of plane c: N x N samples at (rx, ry) of the CTU (component samples); its borders are in s.pic
+template <int L2, int T>
+__device__ __forceinline__ void dec_intra_block(const DecFrame &f, DecIntraLds &s, const DecTu &d, int c, int cx, int cy, int rx, int ry, int lane, const uint32_t (&wreg)[4])
 {
-  constexpr int N = XW<L2, 64>::N, OPL = XW<L2, 64>::OPL, G = XW<L2, 64>::G;
+  constexpr int N = XW<L2, T>::N, OPL = XW<L2, T>::OPL, G = XW<L2, T>::G;
   const int sh = c ? 1 : 0, S = 64 >> sh, nl = N << sh, cpitch = f.pw >> sh, wC = f.w >> sh, hC = f.h >> sh;
   const int mode = d.mode, cidx = c ? 1 : 0;
   const bool filt = intra_filter_needed(N, cidx, mode);
   const int Xc = cx * S + rx, Yc = cy * S + ry, X = Xc << sh, Y = Yc << sh;
+  // (the block's first 4 T level words arrive in wreg: loaded by the caller one block ahead)
+  const bool has = d.count != 0, tskip = (d.flags & TU_TSKIP) != 0;
   // ---- reference samples (8.4.4.2.2) and their filtered version (8.4.4.2.3).  The available samples are contiguous in scan
   // order (one slice, tiles are full-width rows), so the substitution process is a clamp of the scan index into [lo, hi].
   {
@@ -383,19 +355,17 @@ __device__ __forceinline__ void dec_intra_block(const DecFrame &f, DecIntraLds &
     const int nBL = (aL && dec_avail(f, X, Y, X - 1, Y + nl)) ? imin(N, hC - (Yc + N)) : 0;
     const int nTR = (aT && dec_avail(f, X, Y, X + nl, Y - 1)) ? imin(N, wC - (Xc + N)) : 0;
     const int lo = aL ? N - nBL : (aTL ? 2 * N : 2 * N + 1), hi = aT ? 3 * N + nTR : (aTL ? 2 * N : (aL ? 2 * N - 1 : -1));
-    const uint8_t *plane = f.rec[c];
     auto fetch = [&](int i) -> int {
       const int j = imin(imax(i, lo), hi);
-      const int col = j < 2 * N ? rx - 1 : rx + j - 2 * N - 1, row = j < 2 * N ? ry + 2 * N - 1 - j : ry - 1;
-      if (col >= 0 && row >= 0 && col < S && row < S) return s.pic[row * 64 + col];
-      return plane[(size_t)(cy * S + row) * cpitch + cx * S + col];
+      const int col = j < 2 * N ? rx - 1 : rx + j - 2 * N - 1, rowp = j < 2 * N ? ry + 2 * N - j : ry;    // rowp = y + 1
+      return s.pic[rowp * DI_P + 16 + col];
     };
     int c0 = 0, e0 = 0, e1 = 0; bool strong = false;
     if (filt && N == 32 && hi >= 0 && f.strong_intra) {
       c0 = fetch(2 * N); e0 = fetch(0); e1 = fetch(4 * N);
       strong = iabs(c0 + e1 - 2 * fetch(3 * N)) < 8 && iabs(c0 + e0 - 2 * fetch(N)) < 8;
     }
-    for (int i = lane; i <= 4 * N; i += 64) {
+    for (int i = lane; i <= 4 * N; i += T) {
       int v = 128, fv = 128;
       if (hi >= lo && hi >= 0) {
         v = fetch(i); fv = v;
@@ -408,16 +378,17 @@ __device__ __forceinline__ void dec_intra_block(const DecFrame &f, DecIntraLds &
       if (filt) s.R[1][3 + i] = (uint8_t)fv;
     }
   }
-  // ---- levels -> dequantised coefficients, transposed ([column][row]), while the references settle
-  const bool has = d.count != 0, tskip = (d.flags & TU_TSKIP) != 0;
+  // ---- levels -> dequantised coefficients, transposed ([column][row])
   if (has) {
-    for (int i = lane; i < N * N / 2; i += 64) ((uint32_t *)s.A)[i] = 0;
+    for (int i = lane; i < N * N / 2; i += T) ((uint32_t *)s.A)[i] = 0;
     __syncthreads();
-    for (int i = lane; i < (int)d.count; i += 64) {
-      const uint32_t wd = f.lev[d.offset + i];
+    auto put = [&](uint32_t wd) {
       const int pos = (int)(wd >> 16) & (N * N - 1), row = pos >> L2, col = pos & (N - 1);
       s.A[col * N + row] = (int16_t)dequant_coef((int16_t)(wd & 0xffffu), d.qp, L2);
-    }
+    };
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (lane + k * T < (int)d.count) put(wreg[k]);
+    for (int i = lane + 4 * T; i < (int)d.count; i += T) put(f.lev[d.offset + i]);
   }
   __syncthreads();
   const uint8_t *R = s.R[filt ? 1 : 0] + 3;
@@ -429,7 +400,7 @@ __device__ __forceinline__ void dec_intra_block(const DecFrame &f, DecIntraLds &
     for (int k = 0; k < N / 2; k++) acc = __builtin_amdgcn_sad_u8(r4[k], 0u, acc);
     dcv = (int)(acc >> (L2 + 1));
   }
-  const bool active = lane < XW<L2, 64>::LANES;
+  const bool active = lane < XW<L2, T>::LANES;
   const int rp = lane / G, g = lane % G;
   const bool edge = cidx == 0 && N < 32;
   int pred[2][OPL];
@@ -479,24 +450,20 @@ __device__ __forceinline__ void dec_intra_block(const DecFrame &f, DecIntraLds &
 #pragma unroll
     for (int e = 0; e < 2; e++)
 #pragma unroll
-      for (int o = 0; o < OPL; o++) s.pic[(ry + 2 * rp + e) * 64 + rx + g * OPL + o] = (uint8_t)pred[e][o];
+      for (int o = 0; o < OPL; o++) s.pic[(ry + 2 * rp + e + 1) * DI_P + 16 + rx + g * OPL + o] = (uint8_t)pred[e][o];
   }
   __syncthreads();
-  // block -> picture (dwords)
-  {
-    uint8_t *dst = f.rec[c] + (size_t)Yc * cpitch + Xc;
-    for (int i = lane; i < N * N / 4; i += 64) {
-      const int y = i / (N / 4), x = (i - y * (N / 4)) * 4;
-      *(uint32_t *)&dst[(size_t)y * cpitch + x] = *(const uint32_t *)&s.pic[(ry + y) * 64 + rx + x];
-    }
-  }
+  // block -> picture, write-through: neighbouring CTUs' workgroups read it from there (kernel_common.h, fence-free hand-off)
+  store_block_wt(f.rec[c] + (size_t)Yc * cpitch + Xc, cpitch, &s.pic[(ry + 1) * DI_P + 16 + rx], DI_P, N, lane, T);
 }
 
-__global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
+template <int T>
+__global__ __launch_bounds__(T) void k_dec_intra(DecFrame f)
 {
   __shared__ DecIntraLds s;
+  __shared__ uint32_t bcast, bc4[4];
   const int lane = threadIdx.x, ctu = (int)blockIdx.x / 3, c = (int)blockIdx.x % 3, cx = ctu % f.wc, cy = ctu / f.wc;
-  const int sh = c ? 1 : 0, S = 64 >> sh;
+  const int sh = c ? 1 : 0, S = 64 >> sh, cpitch = f.pw >> sh, wC = f.w >> sh;
   uint32_t *my = f.progress + (size_t)ctu * 3 + c;
   const TuRange ct = f.ctu[ctu];
   const int count = (int)(ct.count & 0xffffffu);
@@ -504,55 +471,66 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
     if (lane == 0) __hip_atomic_store(my, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  load_matrices(s.M, 0, KV_MATRIX_ENTRIES, lane, 64);
+  load_matrices(s.M, 0, KV_MATRIX_ENTRIES, lane, T);
+  const uint8_t *plane = f.rec[c];
   // the CTU as the inter kernel left it (its inter blocks are final, the intra ones get written below) -> LDS
   {
-    const int cpitch = f.pw >> sh;
-    const uint8_t *src = f.rec[c] + (size_t)(cy * S) * cpitch + cx * S;
-    for (int i = lane; i < S * S / 16; i += 64) { const int y = i / (S / 16), xq = i % (S / 16); *(uint4 *)&s.pic[y * 64 + xq * 16] = *(const uint4 *)&src[(size_t)y * cpitch + xq * 16]; }
+    const uint8_t *src = plane + (size_t)(cy * S) * cpitch + cx * S;
+    for (int i = lane; i < S * S / 16; i += T) { const int y = i / (S / 16), xq = i % (S / 16); *(uint4 *)&s.pic[(y + 1) * DI_P + 16 + xq * 16] = *(const uint4 *)&src[(size_t)y * cpitch + xq * 16]; }
   }
-  // this plane's intra blocks, compacted in order (one pass over the CTU's list, 64 descriptors at a time)
-  int nlist = 0;
-  for (int base = 0; base < count; base += 64) {
-    DecTu d; d.plane = 255; d.flags = 0;
-    if (base + lane < count) d = f.tus[ct.first + base + lane];
-    const bool keep = d.plane == c && (d.flags & TU_INTRA);
-    const uint64_t m = __ballot(keep);
-    const int at = nlist + __popcll(m & ((1ull << lane) - 1ull));
-    if (keep && at < 256) s.list[at] = d;
-    nlist += __popcll(m);
+  // this plane's intra blocks, compacted in order (wave 0: one pass over the CTU's list, 64 descriptors at a time)
+  if (lane < 64) {
+    int nl = 0;
+    for (int base = 0; base < count; base += 64) {
+      DecTu d; d.plane = 255; d.flags = 0;
+      if (base + lane < count) d = f.tus[ct.first + base + lane];
+      const bool keep = d.plane == c && (d.flags & TU_INTRA);
+      const uint64_t m = __ballot(keep);
+      const int at = nl + __popcll(m & ((1ull << lane) - 1ull));
+      if (keep && at < 256) s.list[at] = d;
+      nl += __popcll(m);
+    }
+    if (lane == 0) bcast = (uint32_t)(nl > 256 ? 256 : nl);
   }
-  if (nlist > 256) nlist = 256;
-  IntraNb nb;
-  {
-    const int t = f.ctu_tile[ctu];
-    nb.left = cx > 0 && f.ctu_tile[ctu - 1] == t;
-    nb.up = cy > 0 && f.ctu_tile[ctu - f.wc] == t;
-    nb.upright = cy > 0 && cx + 1 < f.wc && f.ctu_tile[ctu - f.wc + 1] == t;
-    nb.upleft = cy > 0 && cx > 0 && f.ctu_tile[ctu - f.wc - 1] == t;
-  }
-  const uint32_t *pl = my - 3, *pu = my - 3 * f.wc, *pur = pu + 3, *pul = pu - 3;
-  uint32_t seen_l = 0, seen_u = 0, seen_ur = 0, seen_ul = 0;
-  int published = 0;
   __syncthreads();
+  const int nlist = (int)bcast;
+  __syncthreads();
+  IntraBorders bd;
+  {
+    const int tile = f.ctu_tile[ctu];
+    bd.nb_left = cx > 0 && f.ctu_tile[ctu - 1] == tile; bd.nb_up = cy > 0 && f.ctu_tile[ctu - f.wc] == tile;
+    bd.nb_ur = cy > 0 && cx + 1 < f.wc && f.ctu_tile[ctu - f.wc + 1] == tile; bd.nb_ul = cy > 0 && cx > 0 && f.ctu_tile[ctu - f.wc - 1] == tile;
+    bd.pl = my - 3; bd.pu = my - 3 * f.wc; bd.pur = bd.pu + 3; bd.pul = bd.pu - 3;
+  }
+  borders_begin(bd, bc4);
+  int published = 0;
+  // level words are fetched one block ahead: the loads of block k + 1 are in flight while block k is reconstructed
+  uint32_t wnext[4] = {0, 0, 0, 0};
+  auto fetch_words = [&](int k) {
+    if (k >= nlist) return;
+    const uint32_t off = s.list[k].offset; const int cnt = s.list[k].count;
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (lane + q * T < cnt) wnext[q] = f.lev[off + lane + q * T];
+  };
+  fetch_words(0);
   for (int k = 0; k < nlist; k++) {
     const DecTu d = s.list[k];
+    uint32_t wreg[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) wreg[q] = wnext[q];
+    fetch_words(k + 1);
     const int rx = d.x - cx * S, ry = d.y - cy * S, N = 1 << d.log2;
     const int zu = zunit8((rx << sh) >> 3, (ry << sh) >> 3);
-    if (intra_milestone(zu) > intra_milestone(published)) { wave_publish(my, (uint32_t)zu); published = zu; }
-    // the parts of the neighbouring CTUs this block reads must be final (8x8 units of those CTUs, z-order)
-    if (rx == 0 && nb.left) wave_wait(pl, (uint32_t)zunit8(7, ((imin(S, ry + 2 * N) - 1) << sh) >> 3) + 1, seen_l, f.err);
-    if (ry == 0 && nb.up) wave_wait(pu, (uint32_t)zunit8(((imin(S, rx + 2 * N) - 1) << sh) >> 3, 7) + 1, seen_u, f.err);
-    if (ry == 0 && nb.upright && rx + 2 * N > S) wave_wait(pur, (uint32_t)zunit8(((rx + 2 * N - S - 1) << sh) >> 3, 7) + 1, seen_ur, f.err);
-    if (rx == 0 && ry == 0 && nb.upleft) wave_wait(pul, 64u, seen_ul, f.err);
+    if (kv_intra_milestone(zu) > kv_intra_milestone(published)) { publish_wt(my, (uint32_t)zu); published = zu; }
+    borders_need(bd, s.pic, DI_P, plane, cpitch, cx, cy, S, sh, wC - cx * S, rx, ry, N, &bcast, f.err, lane, T);
     switch (d.log2) {
-      case 2: dec_intra_block<2>(f, s, d, c, cx, cy, rx, ry, lane); break;
-      case 3: dec_intra_block<3>(f, s, d, c, cx, cy, rx, ry, lane); break;
-      case 4: dec_intra_block<4>(f, s, d, c, cx, cy, rx, ry, lane); break;
-      default: dec_intra_block<5>(f, s, d, c, cx, cy, rx, ry, lane); break;
+      case 2: dec_intra_block<2, T>(f, s, d, c, cx, cy, rx, ry, lane, wreg); break;
+      case 3: dec_intra_block<3, T>(f, s, d, c, cx, cy, rx, ry, lane, wreg); break;
+      case 4: dec_intra_block<4, T>(f, s, d, c, cx, cy, rx, ry, lane, wreg); break;
+      default: dec_intra_block<5, T>(f, s, d, c, cx, cy, rx, ry, lane, wreg); break;
     }
   }
-  wave_publish(my, 64u);
+  publish_wt(my, 64u);
 }
 
 // =============================================================================================
@@ -721,7 +699,15 @@ __global__ __launch_bounds__(256) void k_dec_sao(DecFrame f)
 // launch wrappers
 // =============================================================================================
 void launch_dec_inter(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_inter, dim3(f.wc * 2, f.hc * 2), dim3(256), 0, st, f); }
-void launch_dec_intra(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_intra, dim3(f.wc * f.hc * 3), dim3(64), 0, st, f); }
+#ifndef KVZ_DEC_INTRA_THREADS
+#define KVZ_DEC_INTRA_THREADS 256
+#endif
+void launch_dec_intra(const DecFrame &f, hipStream_t st)
+{
+  static const int t = [] { const char *e = getenv("KVAZZUP_AMD_DEC_INTRA_THREADS"); return e ? atoi(e) : KVZ_DEC_INTRA_THREADS; }();   // (tuning knob)
+  if (t == 64) hipLaunchKernelGGL(k_dec_intra<64>, dim3(f.wc * f.hc * 3), dim3(64), 0, st, f);
+  else hipLaunchKernelGGL(k_dec_intra<256>, dim3(f.wc * f.hc * 3), dim3(256), 0, st, f);
+}
 void launch_dec_deblock(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_deblock, dim3(f.wc * f.hc), dim3(256), 0, st, f); }
 void launch_dec_sao(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_sao, dim3(f.wc * f.hc), dim3(256), 0, st, f); }
 

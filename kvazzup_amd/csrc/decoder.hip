@@ -316,8 +316,9 @@ struct SliceParser {
   Decoder::PicJob &job; Decoder::SubOut &out;
   const DecSps &sps; const DecPps &pps; const Decoder::SliceHdr &sh;
   CabacDec c;
-  const int w, h, b4w, wc, hc; const bool tiles;
-  B4Rec *b4; uint8_t *pm, *ctd, *im;
+  const int w, h, b4w, b8w, wc, hc;
+  B4Rec *b4; uint8_t *pm, *ctd, *im;     // pm, ctd: per 8x8 (the minimum coding block); im: per 4x4 (NxN parts)
+  int tile_y0 = 0, tile_y1 = 1 << 30;    // luma rows of the tile being parsed: nothing outside is available (the next tile may be parsed concurrently)
   int err = 0;
   // quantisation (8.6.1)
   int qp_y = 0, qp_y_pred = 0, last_qp_y = 0, cu_qp_delta_val = 0, log2_qg = 6; bool qp_delta_coded = false;
@@ -326,21 +327,37 @@ struct SliceParser {
   uint32_t ctu_intra_mask = 0;
 
   SliceParser(Decoder::PicJob &j, Decoder::SubOut &o, int pw)
-      : job(j), out(o), sps(*j.sps), pps(j.pps), sh(j.sh), w(j.sps->width), h(j.sps->height), b4w(pw / 4), wc((j.sps->width + 63) / 64),
-        hc((j.sps->height + 63) / 64), tiles(j.pps.tile_rows > 1), b4(j.b4), pm(j.pred_mode.data()), ctd(j.ct_depth.data()), im(j.intra_mode.data())
+      : job(j), out(o), sps(*j.sps), pps(j.pps), sh(j.sh), w(j.sps->width), h(j.sps->height), b4w(pw / 4), b8w(pw / 8), wc((j.sps->width + 63) / 64),
+        hc((j.sps->height + 63) / 64), b4(j.b4), pm(j.pred_mode.data()), ctd(j.ct_depth.data()), im(j.intra_mode.data())
   { log2_qg = 6 - pps.qp_delta_depth; }
 
   inline int bi(int x, int y) const { return (y >> 2) * b4w + (x >> 2); }
-  // 6.4.1 (one slice per picture): inside the picture, same tile, not later in z-scan order
-  inline bool avail(int xc, int yc, int xn, int yn) const
+  inline int b8(int x, int y) const { return (y >> 3) * b8w + (x >> 3); }
+  // 6.4.1 (one slice per picture, tiles are full-width rows): inside the picture, inside the tile, already decoded.  "Already
+  // decoded" is read off the prediction-mode array, which starts every picture as PM_NONE: in decoding order a block is marked
+  // when its coding unit starts, and the WPP row hand-over (two CTUs behind the row above, parse_substream) guarantees that every
+  // neighbour that precedes the current block in z-scan order has been parsed while none that follows it has been.
+  inline bool avail(int, int, int xn, int yn) const
   {
-    if (xn < 0 || yn < 0 || xn >= w || yn >= h) return false;
-    if (tiles && job.ctu_tile[(yn >> 6) * wc + (xn >> 6)] != job.ctu_tile[(yc >> 6) * wc + (xc >> 6)]) return false;
-    return zaddr64(xn, yn, wc) <= zaddr64(xc, yc, wc);
+    return xn >= 0 && yn >= tile_y0 && xn < w && yn < h && yn < tile_y1 && pm[b8(xn, yn)] != PM_NONE;
   }
-  void fill_u8(uint8_t *arr, int x0, int y0, int bw, int bh, int v)
+  // coding-unit wide values of the per-8x8 arrays
+  void fill_cu8(uint8_t *arr, int x0, int y0, int n, int v)
   {
-    for (int y = y0; y < y0 + bh && y < h; y += 4) for (int x = x0; x < x0 + bw && x < w; x += 4) arr[bi(x, y)] = (uint8_t)v;
+    const int cols = imin(n, w - x0) >> 3;
+    for (int y = y0; y < y0 + n && y < h; y += 8) memset(arr + b8(x0, y), v, (size_t)cols);
+  }
+  void fill_u8(uint8_t *arr, int x0, int y0, int bw, int bh, int v)       // per-4x4 array
+  {
+    const int cols = imin(bw, w - x0) >> 2;
+    for (int y = y0; y < y0 + bh && y < h; y += 4) memset(arr + bi(x0, y), v, (size_t)cols);
+  }
+  // one record for every 4x4 unit of a rectangle
+  void fill_recs(int x0, int y0, int bw, int bh, const B4Rec &r)
+  {
+    uint64_t v; memcpy(&v, &r, 8);
+    const int cols = imin(bw, w - x0) >> 2;
+    for (int y = y0; y < y0 + bh && y < h; y += 4) { uint64_t *p = (uint64_t *)&b4[bi(x0, y)]; for (int i = 0; i < cols; i++) p[i] = v; }
   }
   void emit_tu(const DecTu &td)
   {
@@ -358,7 +375,7 @@ struct SliceParser {
     bool a;
     if (!same_cb) a = avail(xpb, ypb, xn, yn);
     else a = !((npbw << 1) == ncbs && (npbh << 1) == ncbs && part_idx == 1 && (ycb + npbh <= yn) && (xcb + npbw > xn));
-    if (a && pm[bi(xn, yn)] == PM_INTRA) a = false;
+    if (a && pm[b8(xn, yn)] == PM_INTRA) a = false;
     return a;
   }
   static bool same_motion(const B4Rec &a, const B4Rec &b) { return a.ref_idx == b.ref_idx && a.mvx == b.mvx && a.mvy == b.mvy; }
@@ -506,10 +523,12 @@ struct SliceParser {
       mvx = (int16_t)(uint16_t)(cand[mvp][0] + dx); mvy = (int16_t)(uint16_t)(cand[mvp][1] + dy);      // 8.5.3.2.6: modulo 2^16
     }
     if (ref_idx < 0 || ref_idx >= job.nref) { err = DEC_ERR_INVALID; ref_idx = 0; }
-    B4Rec r; r.mvx = (int16_t)mvx; r.mvy = (int16_t)mvy; r.ref_idx = (int8_t)ref_idx; r.flags = 0; r.qp_y = 0; r.slot = job.ref_slot[ref_idx];
-    for (int y = yp; y < yp + bh && y < h; y += 4) for (int x = xp; x < xp + bw && x < w; x += 4) b4[bi(x, y)] = r;
-    for (int i = 0; i < bh && yp + i < h; i += 4) b4[bi(xp, yp + i)].flags |= B4_EDGE_V;                // prediction block edges (deblocking)
-    for (int i = 0; i < bw && xp + i < w; i += 4) b4[bi(xp + i, yp)].flags |= B4_EDGE_H;
+    B4Rec r; r.mvx = (int16_t)mvx; r.mvy = (int16_t)mvy; r.ref_idx = (int8_t)ref_idx; r.flags = 0; r.qp_y = (int8_t)qp_y; r.slot = job.ref_slot[ref_idx];
+    fill_recs(xp, yp, bw, bh, r);
+    if (bw != ncbs || bh != ncbs) {                          // prediction block edges inside the coding block (deblocking); the block's own are set by coding_unit
+      for (int i = 0; i < bh && yp + i < h; i += 4) b4[bi(xp, yp + i)].flags |= B4_EDGE_V;
+      for (int i = 0; i < bw && xp + i < w; i += 4) b4[bi(xp + i, yp)].flags |= B4_EDGE_H;
+    }
   }
 
   // ---------------------------------------------------------------- transform tree (7.3.8.8 - 7.3.8.10)
@@ -590,10 +609,12 @@ struct SliceParser {
     } else {
       int cbf_luma = 1;
       if (cu_pred_mode == PM_INTRA || depth != 0 || cbf_cb || cbf_cr) cbf_luma = c.bin(CTX_CBF_LUMA + (depth == 0 ? 1 : 0));
-      const int n = 1 << log2;
-      for (int i = 0; i < n; i += 4) {                     // transform block edges (deblocking)
-        if (y0 + i < h) b4[bi(x0, y0 + i)].flags |= B4_EDGE_V | B4_TU_V;
-        if (x0 + i < w) b4[bi(x0 + i, y0)].flags |= B4_EDGE_H | B4_TU_H;
+      if (depth > 0) {                                     // transform block edges inside the coding block (deblocking)
+        const int n = 1 << log2;
+        for (int i = 0; i < n; i += 4) {
+          if (y0 + i < h) b4[bi(x0, y0 + i)].flags |= B4_EDGE_V | B4_TU_V;
+          if (x0 + i < w) b4[bi(x0 + i, y0)].flags |= B4_EDGE_H | B4_TU_H;
+        }
       }
       transform_unit(x0, y0, xbase, ybase, log2, blk, cbf_luma, log2 > 2 ? cbf_cb : 0, log2 > 2 ? cbf_cr : 0, cbf_cb_parent, cbf_cr_parent);
     }
@@ -605,15 +626,16 @@ struct SliceParser {
     const int n = 1 << log2cb;
     int skip = 0;
     if (!sh.is_intra) {
-      const int l = avail(x0, y0, x0 - 1, y0) && pm[bi(x0 - 1, y0)] == PM_SKIP, a = avail(x0, y0, x0, y0 - 1) && pm[bi(x0, y0 - 1)] == PM_SKIP;
+      const int l = avail(x0, y0, x0 - 1, y0) && pm[b8(x0 - 1, y0)] == PM_SKIP, a = avail(x0, y0, x0, y0 - 1) && pm[b8(x0, y0 - 1)] == PM_SKIP;
       skip = c.bin(CTX_SKIP + l + a);
     }
     part_mode = PART_2Nx2N; intra_split = false;
     int rqt_root_cbf = 1, merge_2nx2n = 0;
-    fill_u8(ctd, x0, y0, n, n, depth);
+    fill_cu8(ctd, x0, y0, n, depth);
+    qp_y = (qp_y_pred + cu_qp_delta_val + 52) % 52;          // CuQpDeltaVal of the quantisation group so far
     if (skip) {
       cu_pred_mode = PM_INTER;
-      fill_u8(pm, x0, y0, n, n, PM_SKIP);
+      fill_cu8(pm, x0, y0, n, PM_SKIP);
       prediction_unit(x0, y0, n, x0, y0, n, n, 0, true, nullptr);
       rqt_root_cbf = 0;
       job.any_inter = true;
@@ -631,7 +653,7 @@ struct SliceParser {
           else { const int b = c.bypass(); part_mode = horiz ? (b ? PART_2NxnD : PART_2NxnU) : (b ? PART_nRx2N : PART_nLx2N); }
         }
       }
-      fill_u8(pm, x0, y0, n, n, cu_pred_mode);
+      fill_cu8(pm, x0, y0, n, cu_pred_mode);
       if (cu_pred_mode == PM_INTRA) {
         intra_split = part_mode == PART_NxN;
         const int parts = intra_split ? 2 : 1, pb = n / parts;
@@ -641,8 +663,8 @@ struct SliceParser {
           for (int i = 0; i < parts; i++, k++) {
             const int xp = x0 + i * pb, yp = y0 + j * pb;
             int ca = 1, cb = 1;                                   // 8.4.2 candidate modes
-            if (avail(xp, yp, xp - 1, yp) && pm[bi(xp - 1, yp)] == PM_INTRA) ca = im[bi(xp - 1, yp)];
-            if (avail(xp, yp, xp, yp - 1) && pm[bi(xp, yp - 1)] == PM_INTRA && (yp - 1) >= ((yp >> 6) << 6)) cb = im[bi(xp, yp - 1)];
+            if (avail(xp, yp, xp - 1, yp) && pm[b8(xp - 1, yp)] == PM_INTRA) ca = im[bi(xp - 1, yp)];
+            if (avail(xp, yp, xp, yp - 1) && pm[b8(xp, yp - 1)] == PM_INTRA && (yp - 1) >= ((yp >> 6) << 6)) cb = im[bi(xp, yp - 1)];
             int cand[3];
             if (ca == cb) {
               if (ca < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
@@ -669,8 +691,8 @@ struct SliceParser {
         static const int cm[4] = {0, 26, 10, 1};
         if (icpm == 4) chroma_mode = intra_modes[0];
         else { chroma_mode = cm[icpm]; if (chroma_mode == intra_modes[0]) chroma_mode = 34; }
-        B4Rec r; r.mvx = 0; r.mvy = 0; r.ref_idx = -1; r.flags = 0; r.qp_y = 0; r.slot = 0;
-        for (int y = y0; y < y0 + n && y < h; y += 4) for (int x = x0; x < x0 + n && x < w; x += 4) b4[bi(x, y)] = r;
+        B4Rec r; r.mvx = 0; r.mvy = 0; r.ref_idx = -1; r.flags = 0; r.qp_y = (int8_t)qp_y; r.slot = 0;
+        fill_recs(x0, y0, n, n, r);
         job.any_intra = true;
       } else {
         const int hh = n / 2, q = n / 4; int mf = 0;
@@ -692,12 +714,13 @@ struct SliceParser {
       if (y0 + i < h) b4[bi(x0, y0 + i)].flags |= B4_EDGE_V | B4_TU_V;
       if (x0 + i < w) b4[bi(x0 + i, y0)].flags |= B4_EDGE_H | B4_TU_H;
     }
-    qp_y = (qp_y_pred + cu_qp_delta_val + 52) % 52;          // CuQpDeltaVal of the quantisation group so far
+    const int qp_before = qp_y;
     if (rqt_root_cbf) {
       max_trafo_depth = cu_pred_mode == PM_INTRA ? sps.th_depth_intra + (intra_split ? 1 : 0) : sps.th_depth_inter;
       transform_tree(x0, y0, x0, y0, log2cb, 0, 0, 0, 0);
     }
-    for (int y = y0; y < y0 + n && y < h; y += 4) for (int x = x0; x < x0 + n && x < w; x += 4) b4[bi(x, y)].qp_y = (int8_t)qp_y;
+    if (qp_y != qp_before)                                   // a cu_qp_delta arrived inside this unit: its QpY is the new one (8.6.1)
+      for (int y = y0; y < y0 + n && y < h; y += 4) for (int x = x0; x < x0 + n && x < w; x += 4) b4[bi(x, y)].qp_y = (int8_t)qp_y;
     last_qp_y = qp_y;
   }
 
@@ -707,7 +730,7 @@ struct SliceParser {
     const int n = 1 << log2cb;
     int split;
     if (x0 + n <= w && y0 + n <= h && log2cb > 3) {
-      const int l = avail(x0, y0, x0 - 1, y0) && ctd[bi(x0 - 1, y0)] > depth, a = avail(x0, y0, x0, y0 - 1) && ctd[bi(x0, y0 - 1)] > depth;
+      const int l = avail(x0, y0, x0 - 1, y0) && ctd[b8(x0 - 1, y0)] > depth, a = avail(x0, y0, x0, y0 - 1) && ctd[b8(x0, y0 - 1)] > depth;
       split = c.bin(CTX_SPLIT_CU + l + a);
     } else split = log2cb > 3;
     if (pps.cu_qp_delta && log2cb >= log2_qg) {            // a quantisation group starts here (7.3.8.4, 8.6.1)
@@ -823,7 +846,7 @@ bool Decoder::ensure_buffers(int w, int h)
   for (auto &j : jobs_) {
     if (!grow_job_input(j, fixed_bytes() + (1 << 16))) return false;
     memset(j.h_in, 0, fixed_bytes());
-    j.pred_mode.assign(nb4, PM_NONE); j.ct_depth.assign(nb4, 0); j.intra_mode.assign(nb4, 1);
+    j.pred_mode.assign(nb4 / 4, PM_NONE); j.ct_depth.assign(nb4 / 4, 0); j.intra_mode.assign(nb4, 1);
   }
   HIP_TRY(hipHostMalloc(&h_out_, npx * 3 / 2, hipHostMallocDefault));
   h_out_cap_ = npx * 3 / 2;
@@ -1116,11 +1139,14 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   for (int k = 0; k < 16; k++) { job.ref_poc[k] = k < nref ? ref_poc[k] : sh.poc; job.ref_slot[k] = k < nref ? ref_slot[k] : 0; }
   job.col.reset();
   if (sh.tmvp && !sh.is_intra) job.col = dpb_[ref_slot[sh.collocated_ref_idx]].motion;
-  job.own = std::make_shared<ColMotion>();
-  job.own->w16 = (s.width + 15) / 16; job.own->h16 = (s.height + 15) / 16; job.own->hc = hc; job.own->poc = sh.poc;
-  job.own->mv.assign((size_t)job.own->w16 * job.own->h16, ColMotion::Mv{0, 0, 0, 0});
-  job.own->row_done.reset(new std::atomic<uint8_t>[(size_t)hc]);
-  for (int k = 0; k < hc; k++) job.own->row_done[(size_t)k].store(0, std::memory_order_relaxed);
+  job.own.reset();
+  if (s.tmvp) {                                                  // (only streams with temporal prediction ever read it)
+    job.own = std::make_shared<ColMotion>();
+    job.own->w16 = (s.width + 15) / 16; job.own->h16 = (s.height + 15) / 16; job.own->hc = hc; job.own->poc = sh.poc;
+    job.own->mv.resize((size_t)job.own->w16 * job.own->h16);
+    job.own->row_done.reset(new std::atomic<uint8_t>[(size_t)hc]);
+    for (int k = 0; k < hc; k++) job.own->row_done[(size_t)k].store(0, std::memory_order_relaxed);
+  }
   for (int cy = 0, t = 0; cy < hc; cy++) { while (cy >= pp.row_bd[t + 1]) t++; memset(job.ctu_tile + (size_t)cy * wc, t, (size_t)wc); }
   job.rc = 0; job.any_intra = job.any_inter = false;
   DpbPic &d = dpb_[slot];
@@ -1252,6 +1278,7 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
     memcpy(c.ctx, &job.wpp_saved[(size_t)(sub - 1) * CTX_COUNT], CTX_COUNT);
   }
   sp.last_qp_y = sh.slice_qp;                          // qPY_PREV at the start of a slice, a tile, a CTB row with WPP (8.6.1)
+  for (int t = 0; t < pps.tile_rows; t++) if (first_cy >= pps.row_bd[t]) { sp.tile_y0 = pps.row_bd[t] * 64; sp.tile_y1 = pps.row_bd[t + 1] * 64; }
   ColMotion *own = job.own.get();
   for (int cy = first_cy; cy < first_cy + ncy; cy++) {
     for (int cx = 0; cx < wc; cx++) {
@@ -1279,6 +1306,7 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
       if (!last && cx == wc - 1 && (wpp || tile_ends_at(cy)) && !c.terminate()) return DEC_ERR_INVALID;   // end_of_subset_one_bit
     }
     // this CTB row's motion as later pictures see it (one entry per 16x16 block)
+    if (!own) continue;
     for (int y16 = cy * 4; y16 < cy * 4 + 4 && y16 < own->h16; y16++)
       for (int x16 = 0; x16 < own->w16; x16++) {
         const B4Rec &m = job.b4[(size_t)(y16 * 4) * (pw_ / 4) + x16 * 4];
@@ -1294,7 +1322,7 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
 {
   const uint8_t *data = job.rbsp.data() + job.data_off; const size_t len = job.data_len;
   const int wc = (w_ + 63) / 64, hc = (h_ + 63) / 64, nsub = job.pps.wpp ? hc : job.pps.tile_rows;
-  auto release_all = [&] { for (int r = 0; r < hc; r++) job.own->row_done[(size_t)r].store(1, std::memory_order_release); };   // never leave a later picture's parser waiting
+  auto release_all = [&] { if (job.own) for (int r = 0; r < hc; r++) job.own->row_done[(size_t)r].store(1, std::memory_order_release); };   // never leave a later picture's parser waiting
   if ((int)job.sub_start.size() != nsub) { release_all(); return DEC_ERR_INVALID; }
   for (int r = 0; r < nsub; r++) if (job.sub_start[(size_t)r] >= len) { release_all(); return DEC_ERR_INVALID; }
   job.subs.resize((size_t)nsub);
@@ -1305,7 +1333,6 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
   memset(job.region, 0, (size_t)(pw_ / 32) * (ph_ / 32) * sizeof(TuRange));
   memset(job.ctu, 0, (size_t)(pw_ / 64) * (ph_ / 64) * sizeof(TuRange));
   memset(job.pred_mode.data(), PM_NONE, job.pred_mode.size());
-  memset(job.intra_mode.data(), 1, job.intra_mode.size());
   auto one = [&](int r) {
     size_t start = job.sub_start[(size_t)r], end = (r + 1 < nsub) ? job.sub_start[(size_t)r + 1] : len;
     int rc = end > start ? parse_substream(job, r, data + start, end - start, job.subs[(size_t)r]) : DEC_ERR_INVALID;

@@ -14,7 +14,7 @@
 //                   <true>: decoder (levels given; fractional vectors through a separable LDS pass; short path without residual)
 //   k_inter_signal  one thread per 16x16 block: merge / skip / AMVP signalling
 //   k_intra_analyse one workgroup per 32x32 block: 35-mode SAD search on source samples
-//   k_intra_recon   one 256-thread workgroup per (CTU row, colour plane), wavefront over rows through progress counters
+//   k_intra_recon   one 256-thread workgroup per (CTU, colour plane), coupled by progress counters with 8x8 granularity
 //   k_qp_first/chain  per-CTU QP bookkeeping (cu_qp_delta)
 //   k_deblock_tile  one workgroup per 64x64 tile shifted by (-4, -4): vertical then horizontal edges in LDS
 //                   (k_deblock_v / k_deblock_h: one thread per 4-sample edge segment, band mode of the tile-row split)
@@ -549,10 +549,11 @@ struct IntraWaveLds {
 };
 
 // =============================================================================================
-// Intra analysis (IDR pictures): for every 8x8, 16x16 and 32x32 block of a 32x32 region the SAD of all 35
+// Intra analysis (IDR pictures): for every 8x8 and 16x16 block of a 32x32 region the SAD of all 35
 // prediction modes against the SOURCE picture, predictions built from source neighbours (so nothing depends
-// on reconstruction and the whole picture is searched in parallel); then the bottom-up split decision.
-// The reference arrays of all 21 blocks are built once into LDS (scan order, as in the reconstruction
+// on reconstruction and the whole picture is searched in parallel); then the bottom-up split decision.  Intra
+// coding units are 16x16 or 8x8 (Kvazaar's ultrafast shape; oracle/hevc_enc.c intra_decide() has the reason).
+// The reference arrays of all 20 blocks are built once into LDS (scan order, as in the reconstruction
 // kernel); a work item is (block, mode), one wave each: the mode is wave-uniform, 64 samples per step, the
 // SAD is summed with DPP row operations.
 // =============================================================================================
@@ -600,10 +601,10 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
   *(uint32_t *)&s.src[tid * 4] = *(const uint32_t *)&src[(size_t)(Y0 + (tid >> 3)) * f.cw + X0 + (tid & 7) * 4];
   // ---- references of the 21 blocks from the source picture (8.4.4.2.2 substitution as an index clamp: the available
   // groups are contiguous in scan order; availability by picture bounds and z-scan order)
-  for (int e = tid; e < 16 * 33 + 4 * 65 + 129; e += 256) {
+  for (int e = tid; e < 16 * 33 + 4 * 65; e += 256) {
     int b, i, l2;
-    if (e < 16 * 33) { b = e / 33; i = e - b * 33; l2 = 3; } else if (e < 16 * 33 + 4 * 65) { int r = e - 16 * 33; b = 16 + r / 65; i = r % 65; l2 = 4; } else { b = 20; i = e - 16 * 33 - 4 * 65; l2 = 5; }
-    const int n = 1 << l2, bi = b < 16 ? b : (b < 20 ? b - 16 : 0), nb = 32 >> l2;
+    if (e < 16 * 33) { b = e / 33; i = e - b * 33; l2 = 3; } else { int r = e - 16 * 33; b = 16 + r / 65; i = r % 65; l2 = 4; }
+    const int n = 1 << l2, bi = b < 16 ? b : b - 16, nb = 32 >> l2;
     const int x0 = X0 + (bi % nb) * n, y0 = Y0 + (bi / nb) * n;
     const bool aL = x0 > 0, aT = avail64(f.cw, f.chp, x0, y0, x0, y0 - 1);
     const bool aBL = aL && avail64(f.cw, f.chp, x0, y0, x0 - 1, y0 + n), aTR = aT && avail64(f.cw, f.chp, x0, y0, x0 + n, y0 - 1);
@@ -618,9 +619,9 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
   }
   __syncthreads();
   // ---- filtered references (8.4.4.2.3) and DC values
-  for (int e = tid; e < 16 * 33 + 4 * 65 + 129; e += 256) {
+  for (int e = tid; e < 16 * 33 + 4 * 65; e += 256) {
     int b, i, l2;
-    if (e < 16 * 33) { b = e / 33; i = e - b * 33; l2 = 3; } else if (e < 16 * 33 + 4 * 65) { int r = e - 16 * 33; b = 16 + r / 65; i = r % 65; l2 = 4; } else { b = 20; i = e - 16 * 33 - 4 * 65; l2 = 5; }
+    if (e < 16 * 33) { b = e / 33; i = e - b * 33; l2 = 3; } else { int r = e - 16 * 33; b = 16 + r / 65; i = r % 65; l2 = 4; }
     const int n = 1 << l2;
     const uint8_t *R = s.R[0] + an_roff(b);
     int fv = R[i];
@@ -631,8 +632,8 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
     }
     s.R[1][an_roff(b) + i] = (uint8_t)fv;
   }
-  if (tid < 21) {
-    const int l2 = tid < 16 ? 3 : (tid < 20 ? 4 : 5), n = 1 << l2;
+  if (tid < 20) {
+    const int l2 = tid < 16 ? 3 : 4, n = 1 << l2;
     const uint8_t *R = s.R[0] + an_roff(tid);
     int a = n;
     for (int i = n; i <= 3 * n; i++) a += R[i];
@@ -640,44 +641,38 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
   }
   __syncthreads();
   // ---- SAD of every (block, mode)
-  for (int item = wave; item < 21 * 35; item += 4) {
+  for (int item = wave; item < 20 * 35; item += 4) {
     const int b = item / 35, mode = item - b * 35;
     uint32_t c;
     if (b < 16) c = analyse_item<3>(s, b, (b & 3) * 8, (b >> 2) * 8, mode, lane);
-    else if (b < 20) c = analyse_item<4>(s, b, ((b - 16) & 1) * 16, ((b - 16) >> 1) * 16, mode, lane);
-    else c = analyse_item<5>(s, b, 0, 0, mode, lane);
+    else c = analyse_item<4>(s, b, ((b - 16) & 1) * 16, ((b - 16) >> 1) * 16, mode, lane);
     if (lane == 0) s.cost[b][mode] = c;
   }
   __syncthreads();
-  if (tid < 21) {
+  if (tid < 20) {
     uint32_t bc = 0xffffffffu; int bm = 0;
     for (int m = 0; m < 35; m++) if (s.cost[tid][m] < bc) { bc = s.cost[tid][m]; bm = m; }
     s.bestc[tid] = bc; s.bestm[tid] = bm;
-    const int l2 = tid < 16 ? 3 : (tid < 20 ? 4 : 5), n = 1 << l2, bi = tid < 16 ? tid : (tid < 20 ? tid - 16 : 0), nb = 32 >> l2;
+    const int l2 = tid < 16 ? 3 : 4, n = 1 << l2, bi = tid < 16 ? tid : tid - 16, nb = 32 >> l2;
     const int x0 = X0 + (bi % nb) * n, y0 = Y0 + (bi / nb) * n;
     const int bw = f.cw >> l2, ib = (y0 >> l2) * bw + (x0 >> l2);
     if (l2 == 3) { f.im8[ib] = (uint8_t)bm; f.ic8[ib] = bc; }
-    else if (l2 == 4) { f.im16[ib] = (uint8_t)bm; f.ic16[ib] = bc; }
-    else { f.im32[ib] = (uint8_t)bm; f.ic32[ib] = bc; }
+    else { f.im16[ib] = (uint8_t)bm; f.ic16[ib] = bc; }
   }
   __syncthreads();
   // ---- bottom-up split decision for this 32x32 block: thread per 8x8 cell
   if (tid < 16) {
     const uint32_t pen = ((uint32_t)f.lambda_q4 * SPLIT_BITS) >> 4;
-    uint32_t c16sum = 0; bool split16[4];
+    bool split16[4];
     for (int k = 0; k < 4; k++) {
       uint32_t c8 = pen;
       for (int j = 0; j < 4; j++) c8 += s.bestc[((k >> 1) * 2 + (j >> 1)) * 4 + (k & 1) * 2 + (j & 1)];
-      const uint32_t c16 = s.bestc[16 + k];
-      split16[k] = c8 < c16;
-      c16sum += split16[k] ? c8 : c16;
+      split16[k] = c8 < s.bestc[16 + k];
     }
-    const bool split32 = (c16sum + pen) < s.bestc[20];
     const int bx = tid & 3, by = tid >> 2, k = (by >> 1) * 2 + (bx >> 1);
     const int i = ((Y0 >> 3) + by) * (f.cw >> 3) + (X0 >> 3) + bx;
     int l2, mode;
-    if (!split32) { l2 = 5; mode = s.bestm[20]; }
-    else if (!split16[k]) { l2 = 4; mode = s.bestm[16 + k]; }
+    if (!split16[k]) { l2 = 4; mode = s.bestm[16 + k]; }
     else { l2 = 3; mode = s.bestm[tid]; }
     f.cu_log2[i] = (uint8_t)l2; f.cu_intra_mode[i] = (uint8_t)mode; f.cu_intra[i] = 1; f.cu_flags[i] = 0;
   }
@@ -839,89 +834,73 @@ __device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, 
   return cbf;
 }
 
-template <bool DEC, int T>
+// One workgroup of T threads per (CTU, colour plane).  The CTU's coding units are reconstructed in z-order; CTUs are coupled by
+// progress counters that count the CTU's finished 8x8 luma units (f.sync: [CTU][plane]), published at the values neighbours wait
+// for.  A block waits only for the part of the left / upper / upper-right CTU it reads -- with coding units of at most 16x16 a CTU
+// starts when half of its left neighbour is done, not when it is complete -- and the neighbours' samples are copied into the CTU
+// picture's borders piecewise, as far as their progress allows.  (The decoder's k_dec_intra is the same scheme driven by the
+// transform-block list.)  Workgroups are dispatched in CTU raster order, so whatever a workgroup waits for is already running.
+template <int T>
 __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
 {
   __shared__ IntraWaveLds s;
-  const int lane = threadIdx.x, wl = threadIdx.x & 63, row = f.row0 + blockIdx.x / 3, c = blockIdx.x % 3, wc = f.cw >> 6;
+  __shared__ uint32_t bcast, bc4[4];
+  __shared__ uint8_t cu_l2[64], cu_mode[64], cu_cbf_s[64];
+  const int lane = threadIdx.x, wc = f.cw >> 6, lin = (int)blockIdx.x / 3, c = (int)blockIdx.x % 3;
+  const int row = f.row0 + lin / wc, cx = lin % wc, ctu = row * wc + cx;
   const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, P = 16 + 2 * S;
-  uint32_t *my_ctr = f.sync + row * 3 + c;
-  const uint32_t *up_ctr = f.sync + (row - 1) * 3 + c;
+  uint32_t *my = f.sync + (size_t)ctu * 3 + c;
   load_matrices(s.M, 0, KV_MATRIX_ENTRIES, lane, T);
-  int zx, zy; ctu_z_to_xy(wl, zx, zy);                    // this lane's 8x8 luma block of the CTU, in z-order (every wave holds all 64)
-#ifdef KVZ_PROF
-  if (lane < 16) g_prof[lane] = 0;
-  __syncthreads();
-  if (lane == 0) g_prof[15] = clock64();
-#endif
-  for (int cx = 0; cx < wc; cx++) {
-    PROF(10);
-    const int qpl = ctu_quant_qp(f, cx * 64, row * 64), qp = c ? kChromaQp[qpl] : qpl;
-    // per-CU parameters: lane z holds those of the CU covering the z-th 8x8 block
+  const int qpl = ctu_quant_qp(f, cx * 64, row * 64), qp = c ? kChromaQp[qpl] : qpl;
+  if (lane < 64) {
+    int zx, zy; ctu_z_to_xy(lane, zx, zy);
     const int bi = b8idx(f, cx * 64 + zx * 8, row * 64 + zy * 8);
-    const int my_l2 = f.cu_log2[bi], my_mode = f.cu_intra_mode[bi], my_given = DEC ? f.cu_cbf[bi] : 0;
-    const int my_angle = kIntraAngle[my_mode], my_inv = kInvAngle[my_mode];
-    const uint8_t *gsrc = DEC ? nullptr : f.src[c] + (size_t)(row * S) * pw + cx * S;
-    uint8_t *grec = f.rec[c] + (size_t)(row * S) * pw + cx * S;
-    int16_t *gcoef = f.coef[c] + (size_t)(row * S) * pw + cx * S;
-    // left border <- right column of the CTU just finished
-    if (cx > 0 && lane < S) s.pic[(lane + 1) * P + 15] = s.pic[(lane + 1) * P + 16 + S - 1];
-    // CTU inputs -> LDS (16-byte pieces)
-    if (!DEC) {
-      for (int k = lane; k < S * S / 16; k += T) { int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&s.src[y * S + xq * 16] = *(const uint4 *)&gsrc[(size_t)y * pw + xq * 16]; }
-    } else {
-      for (int k = lane; k < S * S / 8; k += T) { int y = k / (S / 8), xq = k % (S / 8); *(uint4 *)&s.lev[y * S + xq * 8] = *(const uint4 *)&gcoef[(size_t)y * pw + xq * 8]; }
-    }
-    PROF(0);
-    const bool has_above = row > 0 && !tile_row_starts_at(f.ch >> 6, f.tile_rows, row);
-    if (has_above) {
-      // The CTU above must be finished before this one starts; the CTU above-right only before the block in the top
-      // right corner of this CTU (the only one whose above-right references reach into it) -- waited for there,
-      // which shortens the lag between CTU rows from two CTUs to about one and a half.
-      wait_progress(up_ctr, (uint32_t)(cx + 1), f.err);
-      for (int k = lane; k < S + 1; k += T) {              // corner + the S samples above
-        int x = cx * S - 1 + k;
-        if (x >= 0) s.pic[15 + k] = f.rec[c][(size_t)(row * S - 1) * pw + x];
-      }
-    }
-    __syncthreads();
-    PROF(1);
-    uint32_t my_cbf = 0;
-    for (int z = 0; z < 64;) {
-      const int l2 = __builtin_amdgcn_readlane(my_l2, z), mode = __builtin_amdgcn_readlane(my_mode, z), given = __builtin_amdgcn_readlane(my_given, z);
-      const int angle = __builtin_amdgcn_readlane(my_angle, z), inv = __builtin_amdgcn_readlane(my_inv, z);
-      int xi, yi; ctu_z_to_xy(z, xi, yi);
-      const int X = cx * 64 + xi * 8, Y = row * 64 + yi * 8, rx = (xi * 8) >> sh, ry = (yi * 8) >> sh;
-      const bool has = DEC && ((given >> c) & 1);
-      if (has_above && cx + 1 < wc && ry == 0 && rx + (1 << (l2 - sh)) == S) {       // wave-uniform: the top-right block
-        wait_progress(up_ctr, (uint32_t)(cx + 2), f.err);
-        for (int k = lane; k < S; k += T) s.pic[15 + S + 1 + k] = f.rec[c][(size_t)(row * S - 1) * pw + (cx + 1) * S + k];
-        __syncthreads();
-      }
-      PROF(2);
-      bool cbf;
-      switch (l2 - sh) {
-        case 2: cbf = intra_block<DEC, 2, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, has, lane); break;
-        case 3: cbf = intra_block<DEC, 3, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, has, lane); break;
-        case 4: cbf = intra_block<DEC, 4, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, has, lane); break;
-        default: cbf = intra_block<DEC, 5, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, has, lane); break;
-      }
-      const int cnt = 1 << (2 * (l2 - 3));
-      if (cbf && lane >= z && lane < z + cnt) my_cbf = 1u << c;
-      z += cnt;
-    }
-    // CTU results -> global memory
-    for (int k = lane; k < S * S / 16; k += T) { int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&grec[(size_t)y * pw + xq * 16] = *(const uint4 *)&s.pic[(y + 1) * P + 16 + xq * 16]; }
-    if (!DEC) {
-      for (int k = lane; k < S * S / 8; k += T) { int y = k / (S / 8), xq = k % (S / 8); *(uint4 *)&gcoef[(size_t)y * pw + xq * 8] = *(const uint4 *)&s.lev[y * S + xq * 8]; }
-      if (my_cbf) atomicOr((uint32_t *)(f.cu_cbf + (bi & ~3)), my_cbf << (8 * (bi & 3)));   // the three planes own one bit each of the byte
-    }
-    publish_progress(my_ctr, (uint32_t)(cx + 1));
+    cu_l2[lane] = f.cu_log2[bi]; cu_mode[lane] = f.cu_intra_mode[bi]; cu_cbf_s[lane] = 0;
   }
-#ifdef KVZ_PROF
+  const uint8_t *gsrc = f.src[c] + (size_t)(row * S) * pw + cx * S;
+  uint8_t *plane = f.rec[c];
+  uint8_t *grec = plane + (size_t)(row * S) * pw + cx * S;
+  int16_t *gcoef = f.coef[c] + (size_t)(row * S) * pw + cx * S;
+  for (int k = lane; k < S * S / 16; k += T) { int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&s.src[y * S + xq * 16] = *(const uint4 *)&gsrc[(size_t)y * pw + xq * 16]; }
+  const int hc = f.ch >> 6;
+  const bool nb_up = row > 0 && !tile_row_starts_at(hc, f.tile_rows, row), nb_left = cx > 0, nb_ur = nb_up && cx + 1 < wc, nb_ul = nb_up && cx > 0;
+  IntraBorders bd;
+  bd.nb_up = nb_up; bd.nb_left = nb_left; bd.nb_ur = nb_ur; bd.nb_ul = nb_ul;
+  bd.pl = my - 3; bd.pu = my - 3 * wc; bd.pur = bd.pu + 3; bd.pul = bd.pu - 3;
+  if (f.trace && lane == 0) f.trace[((size_t)ctu * 3 + c) * 4 + 0] = wall_clock64();
+  borders_begin(bd, bc4);
+  int published = 0;
+  for (int z = 0; z < 64;) {
+    const int l2 = cu_l2[z], mode = cu_mode[z], n = 1 << (l2 - sh);
+    const int angle = kIntraAngle[mode], inv = kInvAngle[mode];
+    int xi, yi; ctu_z_to_xy(z, xi, yi);
+    const int X = cx * 64 + xi * 8, Y = row * 64 + yi * 8, rx = (xi * 8) >> sh, ry = (yi * 8) >> sh;
+    if (kv_intra_milestone(z) > kv_intra_milestone(published)) { publish_wt(my, (uint32_t)z); published = z; }
+    // the neighbouring CTUs' samples this block reads: wait for them, copy them into the borders of the CTU picture
+    borders_need(bd, s.pic, P, plane, pw, cx, row, S, sh, 2 * S, rx, ry, n, &bcast, f.err, lane, T);
+    if (f.trace && lane == 0 && z == 0) f.trace[((size_t)ctu * 3 + c) * 4 + 1] = wall_clock64();
+    bool cbf;
+    switch (l2 - sh) {
+      case 2: cbf = intra_block<false, 2, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, false, lane); break;
+      case 3: cbf = intra_block<false, 3, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, false, lane); break;
+      case 4: cbf = intra_block<false, 4, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, false, lane); break;
+      default: cbf = intra_block<false, 5, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, false, lane); break;
+    }
+    // block -> picture, write-through: the neighbouring CTUs' workgroups read it from there
+    store_block_wt(grec + (size_t)ry * pw + rx, pw, &s.pic[(ry + 1) * P + 16 + rx], P, n, lane, T);
+    const int cnt = 1 << (2 * (l2 - 3));
+    if (cbf && lane < cnt) cu_cbf_s[z + lane] = 1;
+    z += cnt;
+  }
+  for (int k = lane; k < S * S / 8; k += T) { int y = k / (S / 8), xq = k % (S / 8); *(uint4 *)&gcoef[(size_t)y * pw + xq * 8] = *(const uint4 *)&s.lev[y * S + xq * 8]; }
   __syncthreads();
-  if (lane < 16 && blockIdx.x == gridDim.x / 2 / 3 * 3) ((long long *)f.tok_seg)[lane] = g_prof[lane];
-#endif
+  if (lane < 64 && cu_cbf_s[lane]) {
+    int zx, zy; ctu_z_to_xy(lane, zx, zy);
+    const int bi = b8idx(f, cx * 64 + zx * 8, row * 64 + zy * 8);
+    atomicOr((uint32_t *)(f.cu_cbf + (bi & ~3)), (1u << c) << (8 * (bi & 3)));   // the three planes own one bit each of the byte
+  }
+  publish_wt(my, 64u);
+  if (f.trace && lane == 0) f.trace[((size_t)ctu * 3 + c) * 4 + 2] = wall_clock64();
 }
 
 // =============================================================================================
@@ -1624,7 +1603,7 @@ void launch_intra_analyse(const EncFrame &f, hipStream_t st) { hipLaunchKernelGG
 #ifndef KVZ_INTRA_THREADS
 #define KVZ_INTRA_THREADS 256
 #endif
-void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL((k_intra_recon<false, KVZ_INTRA_THREADS>), dim3(3 * band_rows(f)), dim3(KVZ_INTRA_THREADS), 0, st, f); }
+void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL((k_intra_recon<KVZ_INTRA_THREADS>), dim3(3 * (f.cw / 64) * band_rows(f)), dim3(KVZ_INTRA_THREADS), 0, st, f); }
 void launch_qp_resolve(const EncFrame &f, hipStream_t st)
 {
   if (!f.ctu_qy) return;

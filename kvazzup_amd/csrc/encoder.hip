@@ -121,8 +121,9 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     HIP_OK(hipEventCreateWithFlags(&sl.rec_done, hipEventDisableTiming));
   }
   HIP_OK(hipEventCreateWithFlags(&in_done_, hipEventDisableTiming));
-  HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * rows_ * 3));       // one progress counter per CTU row and colour plane
+  HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * rows_ * (cw_ / 64) * 3));       // one progress counter per CTU and colour plane
   HIP_OK(hipMalloc(&err_, sizeof(uint32_t))); HIP_OK(hipMemset(err_, 0, sizeof(uint32_t)));
+  if (getenv("KVAZZUP_AMD_INTRA_TRACE")) { HIP_OK(hipMalloc(&trace_, sizeof(unsigned long long) * rows_ * (cw_ / 64) * 12)); HIP_OK(hipMemset(trace_, 0, sizeof(unsigned long long) * rows_ * (cw_ / 64) * 12)); }
   int eth = cfg.entropy_threads;
   if (const char *e = getenv("KVAZZUP_AMD_ENTROPY_THREADS")) eth = atoi(e) < 1 ? 1 : atoi(e);     // tuning knob (containers with a small CPU quota)
   if (cfg.owf >= 2 && eth >= 4) {                        // two pictures side by side, half the threads each
@@ -142,7 +143,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   f_.im8 = p; p += nb8; f_.im16 = p; p += nb8 / 4; f_.im32 = p;
   f_.tok_buf = tok_buf_; f_.tok_cap = tok_cap_; f_.tok_cursor = (uint32_t *)tok_count_; f_.tok_seg = tok_seg_; f_.tok_total = tok_total_;
   f_.tok_dense_cap = (uint32_t)tok_dense_cap_;
-  f_.sync = sync_; f_.err = err_;
+  f_.sync = sync_; f_.err = err_; f_.trace = trace_;
 
   sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp; sp_.tile_rows = cfg.tile_rows; sp_.qp_in_cu = cfg.qp_in_cu; sp_.sao = cfg.sao;
   sp_.deblock = cfg.deblock; sp_.fps_num = cfg.fps_num; sp_.fps_den = cfg.fps_den;
@@ -199,7 +200,7 @@ Encoder::~Encoder()
   if (stream_in_) hipStreamDestroy(stream_in_);
   hipFree(intra_scratch_);
   delete entropy_; delete entropy2_;
-  hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(tok_total_); hipFree(sync_); hipFree(err_);
+  hipFree(trace_); hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(tok_total_); hipFree(sync_); hipFree(err_);
   if (stream_) hipStreamDestroy(stream_);
 }
 
@@ -327,7 +328,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   if (tok_pending_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_, ev_tok_done_[set_], 0)); tok_pending_[set_] = false; }   // tokenizer of t - 2 done with this set
   if (!upload_qp_targets()) return false;
   if (intra) {
-    HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * rows_ * 3, stream_));
+    HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * rows_ * (cw_ / 64) * 3, stream_));
     HIP_CHECK(hipMemsetAsync(f_.cu_cbf, 0, (size_t)f_.b8w * f_.b8h, stream_));     // the three plane waves OR their bit in
     timed(K_INTRA_RECON, stream_, [&] { launch_intra_recon(f, stream_); });
   } else {
@@ -465,7 +466,7 @@ bool Encoder::band_phase1(const uint8_t *d_i420)
   launch_pad_input(d_i420, cfg_.width, cfg_.height, src_[0][0], src_[0][1], src_[0][2], cw_, ch_, stream_);
   if (band_intra_) {
     launch_intra_analyse(f, stream_);
-    HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * rows_ * 3, stream_));
+    HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * rows_ * (cw_ / 64) * 3, stream_));
     HIP_CHECK(hipMemsetAsync(f_.cu_cbf + (size_t)f.row0 * 8 * f.b8w, 0, (size_t)f.b8w * 8 * band_rows(f), stream_));
     launch_intra_recon(f, stream_);
   } else {
@@ -562,6 +563,7 @@ bool Encoder::debug_copy(const char *what, void *dst, size_t bytes)
   for (int i = 0; i < 7; i++) if (w == names[i]) { src = cu_bytes_[out_set_] + i * nb8; have = nb8; }
   if (w == "cu_mv") { src = cu_mv_[out_set_]; have = nb8 * 4; }
   if (w == "cu_mvd") { src = cu_mvd_[out_set_]; have = nb8 * 4; }
+  if (w == "trace" && trace_) { src = trace_; have = sizeof(unsigned long long) * rows_ * (cw_ / 64) * 12; }
   for (int c = 0; c < 3; c++) {
     size_t n = c ? npx / 4 : npx;
     if (w == std::string("coef") + char('0' + c)) { src = coef_[out_set_][c]; have = n * 2; }

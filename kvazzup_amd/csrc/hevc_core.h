@@ -66,8 +66,9 @@ struct EncFrame {
   // sample adaptive offset (NULL = off): rec[] is then the picture up to deblocking, sao_out[] the filtered picture that is
   // output and referenced; sao[] the per-CTU parameters (encoder: decided by k_sao, decoder: parsed)
   SaoParams *sao; uint8_t *sao_out[3];
-  uint32_t *sync;               // [rows] progress counters (intra reconstruction wavefront)
+  uint32_t *sync;               // [CTU][plane] progress counters (intra reconstruction wavefront: finished 8x8 units of the CTU)
   uint32_t *err;                // device-side error flags
+  unsigned long long *trace;    // KVAZZUP_AMD_INTRA_TRACE: per (CTU, plane) {start, first block, end, -} of k_intra_recon in 100 MHz ticks; else NULL
 };
 
 enum { CU_SKIP = 1, CU_MERGE = 2 };

@@ -126,6 +126,127 @@ __device__ __forceinline__ void load_matrices(int16_t (*M)[KV_MATRIX_ENTRIES], i
 // lanes that share one n x n block: (n / 2) row pairs x (n / OPL) output groups
 template <int L2, int OPL> struct XF { static constexpr int N = 1 << L2, G = N / OPL, LANES = (N / 2) * G; };
 
+
+// ---------------------------------------------------------------------------------------------
+// Fence-free hand-off between workgroups inside a launch (cdna_hip_programming.md section 6, Guideline 16, recipe R1): the
+// producer stores its payload WRITE-THROUGH (agent-scope relaxed atomic stores = `sc1`), every storing wave drains its stores,
+// one lane stores the flag; the consumer polls the flag relaxed and reads the payload with agent-scope relaxed loads (`sc1`:
+// served past the CU's L1).  No agent-scope release / acquire fence (1.7 .. 7 us each on gfx950) anywhere.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void st_wt_u32(void *p, uint32_t v) { __hip_atomic_store((uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_wt_u64(void *p, uint64_t v) { __hip_atomic_store((uint64_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_l2_u32(const void *p) { return __hip_atomic_load((const uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_l2_u8(const void *p) { return __hip_atomic_load((const uint8_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// every thread of the workgroup calls it after its write-through stores
+__device__ __forceinline__ void publish_wt(uint32_t *ctr, uint32_t value)
+{
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wait until *ctr >= need; `seen` = the last value observed (workgroup-uniform), so that satisfied waits cost nothing.
+// bcast: one LDS word.  The payload is then read with ld_l2_*.
+__device__ __forceinline__ uint32_t wait_wt(const uint32_t *ctr, uint32_t need, uint32_t seen, uint32_t *bcast, uint32_t *err)
+{
+  if (seen >= need) return seen;
+  if (threadIdx.x == 0) {
+    uint32_t spins = 0, v;
+    while ((v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 24)) { atomicOr(err, 1u); v = 64; break; }       // bounded spin: never hang the GPU
+    }
+    *bcast = v;
+  }
+  __syncthreads();
+  const uint32_t v = *bcast;
+  __syncthreads();                                       // (the word is reused by the next wait)
+  return v;
+}
+// rows of an n x n block of bytes from LDS (pitch lp) to the picture (pitch gp), write-through; n = 4, 8, 16, 32; x0 a multiple of n
+__device__ __forceinline__ void store_block_wt(uint8_t *g, int gp, const uint8_t *l, int lp, int n, int tid, int nthreads)
+{
+  if (n == 4) { if (tid < 4) st_wt_u32(g + (size_t)tid * gp, *(const uint32_t *)(l + tid * lp)); return; }
+  const int per = n >> 3;                                // 8-byte pieces per row
+  for (int i = tid; i < n * per; i += nthreads) { const int y = i / per, x = (i - y * per) * 8; st_wt_u64(g + (size_t)y * gp + x, *(const uint64_t *)(l + y * lp + x)); }
+}
+
+// Intra wavefront bookkeeping shared by the encoder's k_intra_recon and the decoder's k_dec_intra: progress of a (CTU, plane)
+// workgroup is counted in 8x8 luma units of the CTU in z-order -- every block that starts in a unit below the counter is final
+// in the picture -- and published at the values neighbours wait for.
+__device__ __forceinline__ int kv_zunit8(int xi, int yi)
+{
+  int z = 0;
+#pragma unroll
+  for (int b = 0; b < 3; b++) z |= ((xi >> b) & 1) << (2 * b) | ((yi >> b) & 1) << (2 * b + 1);
+  return z;
+}
+__device__ __forceinline__ int kv_intra_milestone(int z) { return z >= 64 ? 7 : (z >= 60 ? 6 : (z >= 56 ? 5 : (z >= 48 ? 4 : (z >= 44 ? 3 : (z >= 32 ? 2 : (z >= 24 ? 1 : 0)))))); }
+// 8x8 units of the bottom row (xi, 7) / right column (7, yi) of a CTU that are final at progress p, counted from 0
+__device__ __forceinline__ int kv_units_bottom(uint32_t p) { return p >= 64 ? 8 : (p >= 60 ? 6 : (p >= 48 ? 4 : (p >= 44 ? 2 : 0))); }
+__device__ __forceinline__ int kv_units_right(uint32_t p) { return p >= 64 ? 8 : (p >= 62 ? 7 : (p >= 56 ? 6 : (p >= 54 ? 5 : (p >= 32 ? 4 : (p >= 30 ? 3 : (p >= 24 ? 2 : (p >= 22 ? 1 : 0))))))); }
+
+// The borders of a CTU picture in LDS (row 0 / column 15 of the padded layout, pitch lp) are filled piecewise from the neighbouring
+// CTUs' samples in the picture, as far as those CTUs' progress allows.
+struct IntraBorders {
+  const uint32_t *pl, *pu, *pur, *pul;       // progress counters of the left / upper / upper-right / upper-left CTU (same plane)
+  bool nb_left, nb_up, nb_ur, nb_ul;         // which of them exist (inside the picture, same tile)
+  uint32_t seen_l, seen_u, seen_ur, seen_ul;
+  int top_loaded, left_loaded; bool corner_loaded;
+};
+// one round trip for all four counters (threads 0..3), then the borders everything seen so far allows
+__device__ __forceinline__ void borders_begin(IntraBorders &b, uint32_t *bc4)
+{
+  if (threadIdx.x < 4) {
+    const uint32_t *p = threadIdx.x == 0 ? b.pl : (threadIdx.x == 1 ? b.pu : (threadIdx.x == 2 ? b.pur : b.pul));
+    const bool on = threadIdx.x == 0 ? b.nb_left : (threadIdx.x == 1 ? b.nb_up : (threadIdx.x == 2 ? b.nb_ur : b.nb_ul));
+    bc4[threadIdx.x] = on ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  }
+  __syncthreads();
+  b.seen_l = bc4[0]; b.seen_u = bc4[1]; b.seen_ur = bc4[2]; b.seen_ul = bc4[3];
+  __syncthreads();
+  b.top_loaded = 0; b.left_loaded = 0; b.corner_loaded = false;
+}
+// make sure the borders the block at (rx, ry), size n, reads are in LDS.  S: CTU size in this plane's samples, sh: 1 for chroma,
+// lim_w: samples of the row above that exist (picture width, upper-right CTU); plane / gp: the picture plane and its pitch;
+// (cx, cy): CTU coordinates in units of S.  Ends with a barrier when anything was loaded.
+__device__ __forceinline__ void borders_need(IntraBorders &b, uint8_t *pic, int lp, const uint8_t *plane, int gp, int cx, int cy, int S, int sh,
+                                             int lim_w, int rx, int ry, int n, uint32_t *bcast, uint32_t *err, int tid, int nthreads)
+{
+  bool loaded = false;
+  if (rx == 0 && b.nb_left) {
+    const int need = imin(S, ry + 2 * n);
+    if (need > b.left_loaded) {
+      b.seen_l = wait_wt(b.pl, (uint32_t)kv_zunit8(7, ((need - 1) << sh) >> 3) + 1, b.seen_l, bcast, err);
+      const int upto = imax(need, imin(S, kv_units_right(b.seen_l) * (8 >> sh)));
+      for (int i = b.left_loaded + tid; i < upto; i += nthreads) pic[(i + 1) * lp + 15] = (uint8_t)ld_l2_u8(plane + (size_t)(cy * S + i) * gp + cx * S - 1);
+      b.left_loaded = upto; loaded = true;
+    }
+  }
+  if (ry == 0 && b.nb_up) {
+    const int lim = imin(lim_w, b.nb_ur ? 2 * S : S), need = imin(lim, rx + 2 * n);
+    if (need > b.top_loaded) {
+      int upto = need;
+      if (b.top_loaded < S) {
+        b.seen_u = wait_wt(b.pu, (uint32_t)kv_zunit8(((imin(S, need) - 1) << sh) >> 3, 7) + 1, b.seen_u, bcast, err);
+        upto = imax(upto, imin(imin(S, lim), kv_units_bottom(b.seen_u) * (8 >> sh)));
+      }
+      if (need > S) {
+        b.seen_ur = wait_wt(b.pur, (uint32_t)kv_zunit8(((need - S - 1) << sh) >> 3, 7) + 1, b.seen_ur, bcast, err);
+        upto = imax(upto, imin(lim, S + kv_units_bottom(b.seen_ur) * (8 >> sh)));
+      }
+      // (both ends are multiples of 4: block sizes, CTU sizes and picture widths are)
+      for (int i = b.top_loaded + 4 * tid; i < upto; i += 4 * nthreads) *(uint32_t *)&pic[16 + i] = ld_l2_u32(plane + (size_t)(cy * S - 1) * gp + cx * S + i);
+      b.top_loaded = upto; loaded = true;
+    }
+  }
+  if (rx == 0 && ry == 0 && b.nb_ul && !b.corner_loaded) {
+    b.seen_ul = wait_wt(b.pul, 64u, b.seen_ul, bcast, err);
+    if (tid == 0) pic[15] = (uint8_t)ld_l2_u8(plane + (size_t)(cy * S - 1) * gp + cx * S - 1);
+    b.corner_loaded = true; loaded = true;
+  }
+  if (loaded) __syncthreads();
+}
+
 // thread layout of one block inside a workgroup of T threads (64: one wave, 256: four): OPL outputs per thread so that
 // (n / 2) row pairs x (n / OPL) output groups fit
 template <int L2, int T> struct XW {

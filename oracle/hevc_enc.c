@@ -255,7 +255,9 @@ static void intra_decide(orc_encoder *e)
   uint32_t pen = ((uint32_t)orc_lambda_q4[e->qp] * SPLIT_BITS) >> 4;
   intra_analyse_size(e, 8, e->im8, e->ic8);
   intra_analyse_size(e, 16, e->im16, e->ic16);
-  intra_analyse_size(e, 32, e->im32, e->ic32);
+  /* Intra coding units are 16x16 or 8x8 -- Kvazaar's ultrafast shape (pu-depth-intra 2-3).  The reason here is
+   * the reconstruction chain: a 32x32 block reads 64 samples down the left CTU and along the upper one, so a CTU could only start when
+   * its neighbours are complete; with 16x16 blocks it starts when half of the left one is done (dec_kernels.hip k_dec_intra). */
   int w8 = e->cw / 8, w16 = e->cw / 16, w32 = e->cw / 32;
   for (int y32 = 0; y32 < e->ch / 32; y32++)
     for (int x32 = 0; x32 < w32; x32++) {
@@ -268,7 +270,7 @@ static void intra_decide(orc_encoder *e)
         split16[k] = c8 < c16;
         c16sum += split16[k] ? c8 : c16;
       }
-      int split32 = (c16sum + pen) < e->ic32[y32 * w32 + x32];
+      int split32 = 1; (void)c16sum;
       int x0 = x32 * 32, y0 = y32 * 32;
       if (!split32) {
         set_cu(e, e->cu_log2, x0, y0, 32, 5); set_cu(e, e->cu_intra_mode, x0, y0, 32, e->im32[y32 * w32 + x32]);

@@ -1,0 +1,36 @@
+"""Timeline of the encoder's intra reconstruction wavefront (KVAZZUP_AMD_INTRA_TRACE=1): when every (CTU, plane) workgroup of
+k_intra_recon started, ran its first block and finished.  GPU box only:  python tools/intra_timeline.py [w h]"""
+import os, sys
+os.environ["KVAZZUP_AMD_INTRA_TRACE"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ctypes as C
+import numpy as np
+from kvazzup_amd import synth
+from kvazzup_amd.codec import Encoder
+
+w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
+e = Encoder(w, h, options=(("qp", 32), ("period", 1), ("me-range", 16)))
+for t in range(3):
+    e.encode(synth.frame(synth.MOVING, 0x5EED0002, w, h, t))
+wc, hc = (w + 63) // 64, (h + 63) // 64
+buf = np.zeros(wc * hc * 12, dtype=np.uint64)
+assert e.lib.kvzx_encoder_debug_copy(e.enc, b"trace", buf.ctypes.data, buf.nbytes)
+tr = buf.reshape(hc, wc, 3, 4).astype(np.int64)
+t0 = tr[..., 0].min()
+us = (tr - t0) / 100.0
+for c in range(3):
+    st, fb, en = us[:, :, c, 0], us[:, :, c, 1], us[:, :, c, 2]
+    print("plane %d: kernel span %.0f us; busy per CTU (first block -> end) mean %.1f us, median %.1f; start->first block (waiting) mean %.0f us" %
+          (c, en.max() - st.min(), (en - fb).mean(), np.median(en - fb), (fb - st).mean()))
+    print("  first-block time along row 0 (every 4th CTU):", np.round(fb[0, ::4]).astype(int).tolist())
+    print("  first-block time down column 0:", np.round(fb[:, 0]).astype(int).tolist())
+    print("  lag to the left neighbour's first block, mean %.1f us; to the upper neighbour's, mean %.1f us" %
+          ((fb[:, 1:] - fb[:, :-1]).mean(), (fb[1:, :] - fb[:-1, :]).mean()))
+d = None
+lib = e.lib
+import ctypes
+log2 = np.zeros((((h + 63) // 64) * 8) * (((w + 63) // 64) * 8), dtype=np.uint8)
+lib.kvzx_encoder_debug_copy(e.enc, b"cu_log2", log2.ctypes.data, log2.nbytes)
+print("CU sizes (8x8 cells): 8x8 %.0f%%, 16x16 %.0f%%, 32x32 %.0f%%" % tuple(100.0 * (log2 == k).mean() for k in (3, 4, 5)))
+e.close()

@@ -867,18 +867,23 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
   IntraBorders bd;
   bd.nb_up = nb_up; bd.nb_left = nb_left; bd.nb_ur = nb_ur; bd.nb_ul = nb_ul;
   bd.pl = my - 3; bd.pu = my - 3 * wc; bd.pur = bd.pu + 3; bd.pul = bd.pu - 3;
-  if (f.trace && lane == 0) f.trace[((size_t)ctu * 3 + c) * 4 + 0] = wall_clock64();
+  if (f.trace && lane == 0) f.trace[((size_t)ctu * 3 + c) * 8 + 0] = wall_clock64();
   borders_begin(bd, bc4);
   int published = 0;
+  unsigned long long tb = 0, tk = 0, ts = 0, tp = 0, nblk = 0, tq = 0;       // trace: time in border waits / block / store / publish
+#define KV_LAP(acc) do { if (f.trace) { const unsigned long long n_ = wall_clock64(); acc += n_ - tq; tq = n_; } } while (0)
+  if (f.trace) tq = wall_clock64();
   for (int z = 0; z < 64;) {
     const int l2 = cu_l2[z], mode = cu_mode[z], n = 1 << (l2 - sh);
     const int angle = kIntraAngle[mode], inv = kInvAngle[mode];
     int xi, yi; ctu_z_to_xy(z, xi, yi);
     const int X = cx * 64 + xi * 8, Y = row * 64 + yi * 8, rx = (xi * 8) >> sh, ry = (yi * 8) >> sh;
     if (kv_intra_milestone(z) > kv_intra_milestone(published)) { publish_wt(my, (uint32_t)z); published = z; }
+    KV_LAP(tp);
     // the neighbouring CTUs' samples this block reads: wait for them, copy them into the borders of the CTU picture
     borders_need(bd, s.pic, P, plane, pw, cx, row, S, sh, 2 * S, rx, ry, n, &bcast, f.err, lane, T);
-    if (f.trace && lane == 0 && z == 0) f.trace[((size_t)ctu * 3 + c) * 4 + 1] = wall_clock64();
+    KV_LAP(tb);
+    if (f.trace && lane == 0 && z == 0) f.trace[((size_t)ctu * 3 + c) * 8 + 1] = wall_clock64();
     bool cbf;
     switch (l2 - sh) {
       case 2: cbf = intra_block<false, 2, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, false, lane); break;
@@ -886,8 +891,10 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
       case 4: cbf = intra_block<false, 4, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, false, lane); break;
       default: cbf = intra_block<false, 5, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, false, lane); break;
     }
+    KV_LAP(tk); nblk++;
     // block -> picture, write-through: the neighbouring CTUs' workgroups read it from there
     store_block_wt(grec + (size_t)ry * pw + rx, pw, &s.pic[(ry + 1) * P + 16 + rx], P, n, lane, T);
+    KV_LAP(ts);
     const int cnt = 1 << (2 * (l2 - 3));
     if (cbf && lane < cnt) cu_cbf_s[z + lane] = 1;
     z += cnt;
@@ -900,7 +907,7 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
     atomicOr((uint32_t *)(f.cu_cbf + (bi & ~3)), (1u << c) << (8 * (bi & 3)));   // the three planes own one bit each of the byte
   }
   publish_wt(my, 64u);
-  if (f.trace && lane == 0) f.trace[((size_t)ctu * 3 + c) * 4 + 2] = wall_clock64();
+  if (f.trace && lane == 0) { unsigned long long *t = f.trace + ((size_t)ctu * 3 + c) * 8; t[2] = wall_clock64(); t[3] = tb; t[4] = tk; t[5] = ts; t[6] = tp; t[7] = nblk; }
 }
 
 // =============================================================================================

@@ -68,7 +68,7 @@ struct EncFrame {
   SaoParams *sao; uint8_t *sao_out[3];
   uint32_t *sync;               // [CTU][plane] progress counters (intra reconstruction wavefront: finished 8x8 units of the CTU)
   uint32_t *err;                // device-side error flags
-  unsigned long long *trace;    // KVAZZUP_AMD_INTRA_TRACE: per (CTU, plane) {start, first block, end, -} of k_intra_recon in 100 MHz ticks; else NULL
+  unsigned long long *trace;    // KVAZZUP_AMD_INTRA_TRACE: per (CTU, plane) 8 words {start, first block, end, time in border waits, blocks, stores, publishes, number of blocks} of k_intra_recon, 100 MHz ticks; else NULL
 };
 
 enum { CU_SKIP = 1, CU_MERGE = 2 };

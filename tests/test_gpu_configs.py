@@ -1,0 +1,207 @@
+"""GPU parity at the shapes BASELINE.json names (configs[0] .. configs[4]), each through the C ABI:
+  configs[0]  1080p all-intra (period = 1), 30 pictures through the filter pipeline
+  configs[1]  plain 1080p / period 64 / QP 32 against the checker, and a 130-picture run (two IDRs, POC wrap at 256 is in test_long_run)
+  configs[3]  several independent streams at once (two pipelines on the one GPU of the test box)
+  configs[4]  7680x4320 with 8 tile rows in band mode against the checker; 8 ranks sharing the GPU with the halo exchange
+plus the pipelined encoder (owf 3) with SAO on the device path (the ordering the source-set events protect)."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEED = 0x5EED0002
+
+
+@pytest.mark.gpu
+def test_config1_plain_1080p_p64_qp32_matches_oracle(gpu):
+    """BASELINE configs[1] as it stands: 1920x1080, period 64, QP 32, search range 16, nothing else switched on: access units and
+    reconstruction of the HIP encoder == checker, HIP decoder == checker's decoder, 3 pictures (IDR + 2 P)"""
+    from kvazzup_amd.codec import Decoder, Encoder
+    w, h = 1920, 1080
+    oe = orc.OracleEncoder(w, h, qp=32, period=64, me_range=16)
+    od = orc.OracleDecoder()
+    ge = Encoder(w, h, options=(("qp", 32), ("period", 64), ("me-range", 16)))
+    gd = Decoder()
+    try:
+        for t in range(3):
+            fr = orc.synth_frame(0, SEED, w, h, t)
+            au_o = oe.encode(fr)
+            au_g, rec_g = ge.encode(fr)
+            assert au_g == au_o, t
+            assert np.array_equal(rec_g, oe.recon()), t
+            ref = od.decode_au(au_o, t); got = gd.decode_au(au_g, t)
+            assert len(ref) == 1 and len(got) == 1 and np.array_equal(got[0]["i420"], ref[0]["i420"]), t
+    finally:
+        ge.close(); gd.close(); oe.close(); od.close()
+
+
+@pytest.mark.gpu
+def test_config1_long_run_two_idrs(gpu):
+    """130 pictures of the 1080p / period-64 workload through the pipelined filters (owf 3, 12 frame threads, device-resident
+    input): three IDRs; every decoded picture equals what a fresh synchronous decoder produces from the same access units, and the
+    first pictures equal the checker's"""
+    from kvazzup_amd import synth
+    from kvazzup_amd.codec import Decoder
+    from kvazzup_amd.pipeline import Pipeline
+    w, h, n = 1920, 1080, 130
+    pl = Pipeline(w, h, settings={"video/QP": 32, "video/Intra": 64, "video/OWF": 3, "video/OPENHEVC_threads": 12, "video/OH_parallelization": "Frame"},
+                  custom=(("me-range", 16),))
+    clip = [synth.frame(synth.MOVING, SEED, w, h, t) for t in range(4)]
+    frames = [orc.synth_frame(0, SEED, w, h, t) for t in range(n)]
+    assert all(np.array_equal(clip[t], frames[t]) for t in range(4))          # numpy twin == C twin
+    for t in range(n):
+        while pl.backlog() >= 8:                      # a uvgComm filter drops inputs when its buffer overflows (filter.cpp:151-222): pace the source
+            time.sleep(0.001)
+        pl.push(frames[t], t)
+    pl.flush()
+    assert pl.wait(n, 120000), pl.stats()
+    aus = [pl.pop_encoded() for _ in range(n)]
+    dec = [pl.pop_decoded() for _ in range(n)]
+    pl.close()
+    assert all(a is not None for a in aus) and all(d is not None for d in dec)
+    assert [a[1] for a in aus] == list(range(n)) and [d["pts"] for d in dec] == list(range(n))
+    idr = [t for t in range(n) if (aus[t][0][4] >> 1) == 32]                  # access units that start with a VPS
+    assert idr == [0, 64, 128], idr
+    gd = Decoder()
+    oe = orc.OracleEncoder(w, h, qp=32, period=64, me_range=16)
+    try:
+        for t in range(n):
+            got = gd.decode_au(aus[t][0], t)
+            assert len(got) == 1 and np.array_equal(got[0]["i420"], dec[t]["i420"]), t
+            if t < 3:
+                assert oe.encode(frames[t]) == aus[t][0], t
+                assert np.array_equal(oe.recon(), dec[t]["i420"]), t
+    finally:
+        gd.close(); oe.close()
+
+
+@pytest.mark.gpu
+def test_config0_all_intra_1080p_30_pictures(gpu):
+    """BASELINE configs[0]: 1080p, period = 1, 30 pictures through KvazaarFilter' -> wire -> OpenHEVCFilter'; the first two
+    against the checker, all of them closed loop (decoded == a second decoder's output, PSNR sane)"""
+    from kvazzup_amd.codec import Decoder
+    from kvazzup_amd.pipeline import Pipeline
+    w, h, n = 1920, 1080, 30
+    pl = Pipeline(w, h, settings={"video/QP": 32, "video/Intra": 1}, custom=(("me-range", 16),))
+    frames = [orc.synth_frame(0, SEED, w, h, t) for t in range(n)]
+    for t in range(n):
+        pl.push(frames[t], t)
+        assert pl.wait(t + 1, 60000)
+    aus = [pl.pop_encoded() for _ in range(n)]
+    dec = [pl.pop_decoded() for _ in range(n)]
+    pl.close()
+    oe = orc.OracleEncoder(w, h, qp=32, period=1, me_range=16)
+    gd = Decoder()
+    try:
+        for t in range(n):
+            assert (aus[t][0][4] >> 1) == 32, t                               # every picture an IDR with parameter sets (vps-period 1)
+            if t < 2:
+                assert oe.encode(frames[t]) == aus[t][0], t
+                assert np.array_equal(oe.recon(), dec[t]["i420"]), t
+            got = gd.decode_au(aus[t][0], t)
+            assert len(got) == 1 and np.array_equal(got[0]["i420"], dec[t]["i420"]), t
+            mse = np.mean((frames[t][:w * h].astype(float) - dec[t]["i420"][:w * h]) ** 2)
+            assert 10 * np.log10(255.0 ** 2 / mse) > 33, t
+    finally:
+        gd.close(); oe.close()
+
+
+@pytest.mark.gpu
+def test_config3_two_streams_concurrently_on_one_gpu(gpu):
+    """BASELINE configs[3] in miniature: two independent 1080p streams (a two-party call), each with its own encoder and decoder
+    instance, running at the same time on the one GPU; both bit-exact against the checker"""
+    from kvazzup_amd.pipeline import Pipeline
+    w, h, n = 1920, 1080, 6
+    seeds = (SEED, SEED + 16)
+    pls = [Pipeline(w, h, settings={"video/QP": 32, "video/Intra": 64, "video/OWF": 2, "video/OPENHEVC_threads": 3, "video/OH_parallelization": "Frame"},
+                    custom=(("me-range", 16),)) for _ in seeds]
+    clips = [[orc.synth_frame(0, s, w, h, t) for t in range(n)] for s in seeds]
+    for t in range(n):
+        for k, pl in enumerate(pls):
+            pl.push(clips[k][t], t)
+    for pl in pls:
+        pl.flush()
+    for pl in pls:
+        assert pl.wait(n, 120000), pl.stats()
+    for k, pl in enumerate(pls):
+        oe = orc.OracleEncoder(w, h, qp=32, period=64, me_range=16)
+        for t in range(n):
+            au, pts = pl.pop_encoded()
+            d = pl.pop_decoded()
+            assert pts == t and d["pts"] == t
+            assert au == oe.encode(clips[k][t]), (k, t)
+            assert np.array_equal(d["i420"], oe.recon()), (k, t)
+        oe.close()
+        pl.close()
+
+
+@pytest.mark.gpu
+def test_config4_8k_eight_tile_rows_band_mode(gpu):
+    """BASELINE configs[4] at its own shape in one process: 7680x4320, tiles = 1x8, the band path (phase 1 / halo / phase 2) over the
+    whole picture; an IDR and a P picture against the checker's encoder with the same tiling"""
+    import ctypes as C
+    from kvazzup_amd.tilesplit import BandEncoder
+    w, h = 7680, 4320
+    hip = C.CDLL("libamdhip64.so")
+    dptr = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dptr), C.c_size_t(w * h * 3 // 2)) == 0
+    be = BandEncoder(w, h, 8, 0, 1, options=(("qp", 32), ("period", 64), ("me-range", 16)))
+    oe = orc.OracleEncoder(w, h, qp=32, period=64, me_range=16, tile_rows=8)
+    try:
+        for t in range(2):
+            fr = orc.synth_frame(0, 0x5EED0005, w, h, t)
+            assert hip.hipMemcpy(dptr, C.c_void_p(fr.ctypes.data), C.c_size_t(fr.size), 1) == 0
+            assert be.encode(dptr) == oe.encode(fr), t
+    finally:
+        be.close(); oe.close(); hip.hipFree(dptr)
+
+
+@pytest.mark.gpu
+def test_config4_eight_ranks_share_the_gpu(gpu):
+    """8 ranks (gloo, all on the test box's one GPU), one tile row each, with the halo exchange: 1920x1088, tiles 1x8"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29871", os.path.join(ROOT, "tests", "run_tilesplit.py"), "1920", "1088", "8", "4"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_pipelined_encoder_with_sao_on_device_path_matches_oracle(gpu):
+    """owf = 3 with sao = full at 1080p, pictures handed over in HBM back to back: k_sao of picture t reads the source picture while
+    the input stage already prepares picture t + 2 -- the access units must still be the checker's (synchronous) ones"""
+    import ctypes as C
+    from kvazzup_amd.codec import Encoder
+    w, h, n = 1920, 1080, 8
+    ge = Encoder(w, h, options=(("qp", 32), ("period", 64), ("me-range", 16), ("sao", "full"), ("owf", 3)))
+    oe = orc.OracleEncoder(w, h, qp=32, period=64, me_range=16, sao=1)
+    hip = C.CDLL("libamdhip64.so")
+    frames = [orc.synth_frame(0, SEED, w, h, t) for t in range(n)]
+    dptrs = []
+    for fr in frames:
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(fr.size)) == 0
+        assert hip.hipMemcpy(p, C.c_void_p(fr.ctypes.data), C.c_size_t(fr.size), 1) == 0
+        dptrs.append(p)
+    try:
+        aus = []
+        for t in range(n):
+            au = ge.encode_device(dptrs[t])
+            if au:
+                aus.append(au)
+        while len(aus) < n:
+            au = ge.encode_device(None)
+            assert au
+            aus.append(au)
+        for t in range(n):
+            assert aus[t] == oe.encode(frames[t]), t
+    finally:
+        ge.close(); oe.close()
+        for p in dptrs:
+            hip.hipFree(p)

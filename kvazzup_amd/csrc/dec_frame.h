@@ -59,6 +59,7 @@ struct DecFrame {
   const uint8_t *ref[KVZ_DEC_MAX_REFS][3];   // picture buffers by slot
   const SaoParams *sao;     // per CTU; NULL = off
   uint32_t *progress;       // intra wavefront: [CTU][plane] = 8x8 luma units of the CTU whose intra blocks are final
+  const uint32_t *intra_order;  // CTU handled by the k-th workgroup triple of k_dec_intra: anti-diagonal order (enc_kernels.hip k_intra_recon)
   uint32_t *err;
   int8_t cb_qp_offset, cr_qp_offset;       // pps_cb/cr_qp_offset (deblocking uses these, 8.7.2.5.5)
   int8_t beta_offset, tc_offset;           // slice_beta_offset_div2 * 2, slice_tc_offset_div2 * 2

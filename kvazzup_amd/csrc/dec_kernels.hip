@@ -462,7 +462,7 @@ __global__ __launch_bounds__(T) void k_dec_intra(DecFrame f)
 {
   __shared__ DecIntraLds s;
   __shared__ uint32_t bcast, bc4[4];
-  const int lane = threadIdx.x, ctu = (int)blockIdx.x / 3, c = (int)blockIdx.x % 3, cx = ctu % f.wc, cy = ctu / f.wc;
+  const int lane = threadIdx.x, ctu = (int)f.intra_order[blockIdx.x / 3], c = (int)blockIdx.x % 3, cx = ctu % f.wc, cy = ctu / f.wc;
   const int sh = c ? 1 : 0, S = 64 >> sh, cpitch = f.pw >> sh, wC = f.w >> sh;
   uint32_t *my = f.progress + (size_t)ctu * 3 + c;
   const TuRange ct = f.ctu[ctu];
@@ -548,34 +548,46 @@ __device__ __forceinline__ int dec_bs(const B4Rec &p, const B4Rec &q, bool tu_ed
 
 __global__ __launch_bounds__(256) void k_dec_deblock(DecFrame f)
 {
-  constexpr int P = 68, PC = 36;
+  constexpr int P = 80, PC = 48;                           // LDS pitches (enc_kernels.hip k_deblock_tile: same tile geometry and I/O)
   __shared__ __attribute__((aligned(16))) uint8_t ty_[68 * P];
   __shared__ __attribute__((aligned(16))) uint8_t tc_[2][34 * PC];
+  __shared__ B4Rec recs[18 * 18];                          // the tile's 4x4 records and one ring: units -1 .. 16 in both directions
   const int tid = threadIdx.x, wc = f.wc, hc = f.hc, b4w = f.pw >> 2;
   const int lin = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), tx = lin % wc, tyi = lin / wc;
   const int X0 = tx * 64 - 4, Y0 = tyi * 64 - 4, CX0 = X0 >> 1, CY0 = Y0 >> 1, cw2 = f.pw >> 1;
   const int TW = tx == wc - 1 ? 68 : 64, TH = tyi == hc - 1 ? 68 : 64;
-  for (int i = tid; i < TH * 17; i += 256) {
-    const int y = i / 17, x = (i - y * 17) * 4, gx = X0 + x, gy = Y0 + y;
-    if (x < TW && gx >= 0 && gy >= 0) *(uint32_t *)&ty_[y * P + x] = *(const uint32_t *)&f.rec[0][(size_t)gy * f.pw + gx];
+  for (int i = tid; i < TH * 5; i += 256) {
+    const int y = i / 5, k = i - y * 5, x = k * 16, gx = X0 + x, gy = Y0 + y;
+    if (gy < 0 || x >= TW) continue;
+    const uint8_t *g = &f.rec[0][(size_t)gy * f.pw + gx];
+    if (k < 4) { if (gx >= 0) *(kv_u32x4 *)&ty_[y * P + x] = *(const kv_u32x4 *)g; else { kv_u32x4 v; v.x = 0; v.y = *(const uint32_t *)(g + 4); v.z = *(const uint32_t *)(g + 8); v.w = *(const uint32_t *)(g + 12); *(kv_u32x4 *)&ty_[y * P + x] = v; } }
+    else *(uint32_t *)&ty_[y * P + x] = *(const uint32_t *)g;
   }
-  for (int i = tid; i < 2 * (TH / 2) * 17; i += 256) {
-    const int pl = i / ((TH / 2) * 17), r = i - pl * ((TH / 2) * 17), y = r / 17, x = (r - y * 17) * 2, gx = CX0 + x, gy = CY0 + y;
-    if (x < TW / 2 && gx >= 0 && gy >= 0) *(uint16_t *)&tc_[pl][y * PC + x] = *(const uint16_t *)&f.rec[1 + pl][(size_t)gy * cw2 + gx];
+  for (int i = tid; i < 2 * (TH / 2) * 9; i += 256) {
+    const int pl = i / ((TH / 2) * 9), r = i - pl * ((TH / 2) * 9), y = r / 9, k = r - y * 9, gx = CX0 - 2 + 4 * k, gy = CY0 + y;
+    if (gy >= 0 && gx >= 0) *(uint32_t *)&tc_[pl][y * PC + 4 * k] = *(const uint32_t *)&f.rec[1 + pl][(size_t)gy * cw2 + gx];
+  }
+  for (int i = tid; i < 18 * 18; i += 256) {
+    const int ux = tx * 16 - 1 + i % 18, uy = tyi * 16 - 1 + i / 18;
+    B4Rec r; r.mvx = 0; r.mvy = 0; r.ref_idx = -1; r.flags = 0; r.qp_y = 0; r.slot = 0;
+    if (ux >= 0 && uy >= 0 && ux * 4 < f.w && uy * 4 < f.h) r = f.b4[(size_t)uy * b4w + ux];
+    recs[i] = r;
   }
   __syncthreads();
+  auto unit = [&](int x, int y) { return ((y >> 2) - (tyi * 16 - 1)) * 18 + ((x >> 2) - (tx * 16 - 1)); };
   // ---- vertical edges: 8 edges x 16 (17) four-row segments
   if (tid < 8 * (TH / 4)) {
     const int x = tx * 64 + (tid & 7) * 8, y = Y0 + (tid >> 3) * 4;
     if (x > 0 && x < f.w && y >= 0 && y < f.h) {
-      const B4Rec q = f.b4[(size_t)(y >> 2) * b4w + (x >> 2)], p = f.b4[(size_t)(y >> 2) * b4w + (x >> 2) - 1];
+      const int uq = unit(x, y);
+      const B4Rec q = recs[uq], p = recs[uq - 1];
       if (q.flags & B4_EDGE_V) {
         const int bs = dec_bs(p, q, (q.flags & B4_TU_V) != 0);
         if (bs) {
           const int qp = (p.qp_y + q.qp_y + 1) >> 1;
           deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], 1, P, bs, qp, f.beta_offset, f.tc_offset);
           if (bs == 2 && (x & 15) == 0) {
-            const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0);
+            const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0) + 2;
             deblock_chroma_segment(&tc_[0][o], 1, PC, 2, qp, f.cb_qp_offset, f.tc_offset);
             deblock_chroma_segment(&tc_[1][o], 1, PC, 2, qp, f.cr_qp_offset, f.tc_offset);
           }
@@ -588,14 +600,15 @@ __global__ __launch_bounds__(256) void k_dec_deblock(DecFrame f)
   if (tid < 8 * (TW / 4)) {
     const int y = tyi * 64 + (tid & 7) * 8, x = X0 + (tid >> 3) * 4;
     if (y > 0 && y < f.h && x >= 0 && x < f.w) {
-      const B4Rec q = f.b4[(size_t)(y >> 2) * b4w + (x >> 2)], p = f.b4[(size_t)((y >> 2) - 1) * b4w + (x >> 2)];
+      const int uq = unit(x, y);
+      const B4Rec q = recs[uq], p = recs[uq - 18];
       if (q.flags & B4_EDGE_H) {
         const int bs = dec_bs(p, q, (q.flags & B4_TU_H) != 0);
         if (bs) {
           const int qp = (p.qp_y + q.qp_y + 1) >> 1;
           deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], P, 1, bs, qp, f.beta_offset, f.tc_offset);
           if (bs == 2 && (y & 15) == 0) {
-            const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0);
+            const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0) + 2;
             deblock_chroma_segment(&tc_[0][o], PC, 1, 2, qp, f.cb_qp_offset, f.tc_offset);
             deblock_chroma_segment(&tc_[1][o], PC, 1, 2, qp, f.cr_qp_offset, f.tc_offset);
           }
@@ -604,13 +617,23 @@ __global__ __launch_bounds__(256) void k_dec_deblock(DecFrame f)
     }
   }
   __syncthreads();
-  for (int i = tid; i < TH * 17; i += 256) {
-    const int y = i / 17, x = (i - y * 17) * 4, gx = X0 + x, gy = Y0 + y;
-    if (x < TW && gx >= 0 && gy >= 0) *(uint32_t *)&f.rec[0][(size_t)gy * f.pw + gx] = *(const uint32_t *)&ty_[y * P + x];
+  for (int i = tid; i < TH * 5; i += 256) {
+    const int y = i / 5, k = i - y * 5, x = k * 16, gx = X0 + x, gy = Y0 + y;
+    if (gy < 0 || x >= TW) continue;
+    uint8_t *g = &f.rec[0][(size_t)gy * f.pw + gx];
+    if (k < 4) {
+      const kv_u32x4 v = *(const kv_u32x4 *)&ty_[y * P + x];
+      if (gx >= 0) *(kv_u32x4 *)g = v; else { *(uint32_t *)(g + 4) = v.y; *(uint32_t *)(g + 8) = v.z; *(uint32_t *)(g + 12) = v.w; }
+    } else *(uint32_t *)g = *(const uint32_t *)&ty_[y * P + x];
   }
-  for (int i = tid; i < 2 * (TH / 2) * 17; i += 256) {
-    const int pl = i / ((TH / 2) * 17), r = i - pl * ((TH / 2) * 17), y = r / 17, x = (r - y * 17) * 2, gx = CX0 + x, gy = CY0 + y;
-    if (x < TW / 2 && gx >= 0 && gy >= 0) *(uint16_t *)&f.rec[1 + pl][(size_t)gy * cw2 + gx] = *(const uint16_t *)&tc_[pl][y * PC + x];
+  for (int i = tid; i < 2 * (TH / 2) * 9; i += 256) {
+    const int pl = i / ((TH / 2) * 9), r = i - pl * ((TH / 2) * 9), y = r / 9, k = r - y * 9, gx = CX0 - 2 + 4 * k, gy = CY0 + y;
+    if (gy < 0 || gx < 0) continue;
+    uint8_t *g = &f.rec[1 + pl][(size_t)gy * cw2 + gx];
+    const uint32_t v = *(const uint32_t *)&tc_[pl][y * PC + 4 * k];
+    if (k == 0) *(uint16_t *)(g + 2) = (uint16_t)(v >> 16);
+    else if (k == 8 && TW == 64) *(uint16_t *)g = (uint16_t)v;
+    else *(uint32_t *)g = v;
   }
 }
 

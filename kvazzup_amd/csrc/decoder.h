@@ -147,6 +147,8 @@ class Decoder {
     std::unique_ptr<Progress[]> row_progress; int row_progress_n = 0;
     bool any_intra = false, any_inter = false;
     std::atomic<int> state{0}; int rc = 0; double parse_ms = 0;
+    hipEvent_t done = nullptr;                                   // recorded behind the picture's last kernel
+    struct EvPair { hipEvent_t a, b; int id; }; std::vector<EvPair> ev; size_t ev_used = 0;     // kernel timing (set_profiling)
     PicJob() {}
     PicJob(const PicJob &) {}                                  // (vector<PicJob> construction only)
   };
@@ -170,11 +172,11 @@ class Decoder {
   bool grow_job_input(PicJob &job, size_t bytes);
   void bind_job(PicJob &job);
   int launch_gpu(PicJob &job);
-  int complete_gpu();
+  int complete_gpu(PicJob &job);
   int alloc_slot();
 
   int device_; bool started_ = false;
-  hipStream_t stream_ = nullptr;
+  hipStream_t stream_ = nullptr, stream_dl_ = nullptr;       // reconstruction; download of finished pictures (behind the picture's event, beside the next picture's kernels)
   DecSps sps_[16]; DecPps pps_[64]; uint32_t vps_fps_num_ = 0, vps_fps_den_ = 0;
   int w_ = 0, h_ = 0, pw_ = 0, ph_ = 0;
   std::vector<PicJob> jobs_; int frame_threads_ = 1; long job_head_ = 0, job_tail_ = 0;
@@ -185,7 +187,7 @@ class Decoder {
   // device side
   uint8_t *d_in_ = nullptr; size_t d_in_cap_ = 0;          // device copy of PicJob::h_in
   uint8_t *work_[3] = {nullptr, nullptr, nullptr};          // pictures with SAO: reconstruction and deblocking happen here, the filter writes into the slot
-  uint32_t *progress_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
+  uint32_t *progress_ = nullptr, *intra_order_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
   uint8_t *h_out_ = nullptr; size_t h_out_cap_ = 0;
   long launched_ = 0; int out_slot_ = 0; int output_hold_ = 2;
   double t_parse_max_ = 0;                // trace: the longest parse of one picture (an IDR), ms
@@ -200,8 +202,7 @@ class Decoder {
   std::vector<size_t> epb_;                // unescaped payload offset of every removed emulation prevention byte
   std::vector<size_t> sub_start_;          // start of every substream inside the unescaped slice data
   std::unique_ptr<OrderedPool> pool_; int parse_threads_ = 16;
-  struct EvPair { hipEvent_t a, b; int id; };
-  std::vector<EvPair> ev_pool_; size_t ev_used_ = 0;
+  PicJob *timed_job_ = nullptr;
   double k_ms_[DK_COUNT] = {0}; uint64_t k_n_[DK_COUNT] = {0};
   template <class F> void timed(int id, F &&launch);
 };

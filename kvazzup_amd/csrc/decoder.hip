@@ -756,9 +756,9 @@ struct SliceParser {
 // Pictures still being parsed by frame workers are waited for and dropped (close / resolution change).
 void Decoder::drop_pending()
 {
-  if (gpu_job_) { hipStreamSynchronize(stream_); gpu_job_ = nullptr; ev_used_ = 0; }
+  if (gpu_job_) { hipStreamSynchronize(stream_); gpu_job_->ev_used = 0; gpu_job_ = nullptr; }
   for (; job_tail_ != job_head_; job_tail_++) {
-    PicJob &job = jobs_[(size_t)(job_tail_ % (frame_threads_ + 1))];
+    PicJob &job = jobs_[(size_t)(job_tail_ % jobs_.size())];
     while (job.state.load(std::memory_order_acquire) != 2) std::this_thread::yield();
     job.state.store(0, std::memory_order_relaxed);
   }
@@ -770,8 +770,9 @@ Decoder::~Decoder()
   drop_pending();
   workers_.reset();
   if (stream_) hipStreamSynchronize(stream_);
-  for (auto &e : ev_pool_) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  for (auto &j : jobs_) { for (auto &e : j.ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); } if (j.done) hipEventDestroy(j.done); }
   free_buffers();
+  if (stream_dl_) hipStreamDestroy(stream_dl_);
   if (h_err_) hipHostFree(h_err_);
   if (err_) hipFree(err_);
   if (stream_) hipStreamDestroy(stream_);
@@ -793,6 +794,7 @@ bool Decoder::start(std::string *error)
     else if (lv == 'l') HIP_TRY(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, lo));
     else HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   }
+  HIP_TRY(hipStreamCreateWithFlags(&stream_dl_, hipStreamNonBlocking));
   HIP_TRY(hipMalloc(&err_, sizeof(uint32_t)));
   HIP_TRY(hipMemset(err_, 0, sizeof(uint32_t)));
   HIP_TRY(hipHostMalloc(&h_err_, sizeof(uint32_t), hipHostMallocDefault));
@@ -804,7 +806,7 @@ void Decoder::free_buffers()
 {
   for (auto &j : jobs_) { if (j.h_in) hipHostFree(j.h_in); j.h_in = nullptr; j.h_in_cap = 0; j.col.reset(); j.own.reset(); }
   if (h_out_) hipHostFree(h_out_);
-  hipFree(d_in_); hipFree(progress_);
+  hipFree(d_in_); hipFree(progress_); hipFree(intra_order_); intra_order_ = nullptr;
   for (auto &p : dpb_) { for (int c = 0; c < 3; c++) { hipFree(p.plane[c]); p.plane[c] = nullptr; } p = DpbPic(); }
   for (int c = 0; c < 3; c++) { hipFree(work_[c]); work_[c] = nullptr; }
   h_out_ = nullptr; d_in_ = nullptr; d_in_cap_ = 0; progress_ = nullptr;
@@ -840,7 +842,7 @@ bool Decoder::ensure_buffers(int w, int h)
   drop_pending();                                          // (resolution change: pictures not yet output are dropped)
   hipStreamSynchronize(stream_);
   free_buffers();
-  if (jobs_.empty()) jobs_ = std::vector<PicJob>((size_t)frame_threads_ + 1);   // parse ring + the picture in flight on the GPU
+  if (jobs_.empty()) jobs_ = std::vector<PicJob>((size_t)frame_threads_ + 2);   // parse ring + two pictures in flight on the GPU (one running, one being handed out)
   w_ = w; h_ = h; pw_ = (w + 63) & ~63; ph_ = (h + 63) & ~63;
   const size_t npx = (size_t)pw_ * ph_, nb4 = npx / 16;
   for (auto &j : jobs_) {
@@ -853,6 +855,14 @@ bool Decoder::ensure_buffers(int w, int h)
   d_in_cap_ = fixed_bytes() + (1 << 20);
   HIP_TRY(hipMalloc(&d_in_, d_in_cap_));
   HIP_TRY(hipMalloc(&progress_, sizeof(uint32_t) * 3 * (size_t)(pw_ / 64) * (ph_ / 64)));
+  {
+    // dispatch order of k_dec_intra's workgroups: CTUs by anti-diagonal cx + 2 cy (every CTU a block depends on comes earlier)
+    const int wc = pw_ / 64, hc = ph_ / 64;
+    std::vector<uint32_t> order;
+    for (int d = 0; d < wc + 2 * hc; d++) for (int cy = 0; cy < hc; cy++) { const int cx = d - 2 * cy; if (cx >= 0 && cx < wc) order.push_back((uint32_t)(cy * wc + cx)); }
+    HIP_TRY(hipMalloc(&intra_order_, sizeof(uint32_t) * order.size()));
+    HIP_TRY(hipMemcpy(intra_order_, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice));
+  }
   for (int c = 0; c < 3; c++) HIP_TRY(hipMalloc(&work_[c], c ? npx / 4 : npx));
   for (int s = 0; s < 6; s++) for (int c = 0; c < 3; c++) { const size_t n = c ? npx / 4 : npx; HIP_TRY(hipMalloc(&dpb_[s].plane[c], n)); HIP_TRY(hipMemset(dpb_[s].plane[c], 128, n)); }
   seen_irap_ = false;
@@ -878,8 +888,9 @@ int Decoder::alloc_slot()
 template <class F> void Decoder::timed(int id, F &&launch)
 {
   if (!prof_now_) { launch(); return; }
-  if (ev_used_ == ev_pool_.size()) { EvPair p; hipEventCreate(&p.a); hipEventCreate(&p.b); p.id = id; ev_pool_.push_back(p); }
-  EvPair &p = ev_pool_[ev_used_++]; p.id = id;
+  PicJob &j = *timed_job_;
+  if (j.ev_used == j.ev.size()) { PicJob::EvPair p; hipEventCreate(&p.a); hipEventCreate(&p.b); p.id = id; j.ev.push_back(p); }
+  PicJob::EvPair &p = j.ev[j.ev_used++]; p.id = id;
   hipEventRecord(p.a, stream_); launch(); hipEventRecord(p.b, stream_);
 }
 void Decoder::get_kernel_times(double *ms, uint64_t *launches, bool reset)
@@ -1128,7 +1139,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   // up to `frame_threads_` pictures are parsed concurrently on worker threads and the output is delayed accordingly,
   // like OpenHEVC's frame threading; temporal motion prediction makes a picture's parser follow the collocated
   // picture's parser row by row (ColMotion::row_done).
-  PicJob &job = jobs_[(size_t)(job_head_ % (frame_threads_ + 1))];
+  PicJob &job = jobs_[(size_t)(job_head_ % jobs_.size())];
   job.rbsp.assign(rbsp, rbsp + len);
   job.data_off = r.pos >> 3; job.data_len = len - (r.pos >> 3);
   job.sub_start = sub_start_;
@@ -1180,38 +1191,40 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
 // then the oldest parsed picture is launched -- its kernels run while this thread goes on parsing headers.
 int Decoder::finish_oldest()
 {
-  int produced = 0;
-  if (gpu_job_) { int rc = complete_gpu(); if (rc < 0) return rc; produced = 1; }
+  PicJob *prev = gpu_job_;
+  gpu_job_ = nullptr;
+  int rc_launch = 0;
   if (job_head_ != job_tail_) {
-    PicJob &job = jobs_[(size_t)(job_tail_ % (frame_threads_ + 1))];
+    PicJob &job = jobs_[(size_t)(job_tail_ % jobs_.size())];
     job_tail_++;
     { Tick tk; while (job.state.load(std::memory_order_acquire) != 2) std::this_thread::yield(); t_wait_ += tk.ms(); }
     job.state.store(0, std::memory_order_relaxed);
     if (frame_threads_ > 1 && profiling_) { k_ms_[DK_HOST_PARSE] += job.parse_ms; k_n_[DK_HOST_PARSE]++; }
     if (job.parse_ms > t_parse_max_) t_parse_max_ = job.parse_ms;
-    if (job.rc < 0) return job.rc;
-    int rc = launch_gpu(job);
-    if (rc < 0) return rc;
-    if (frame_threads_ == 1) { rc = complete_gpu(); if (rc < 0) return rc; produced = 1; }
+    // the next picture's kernels are queued BEFORE the previous picture is waited for: the GPU goes from one to the other without
+    // this thread's launch latency in between
+    rc_launch = job.rc < 0 ? job.rc : launch_gpu(job);
   }
+  int produced = 0;
+  if (prev) { const int rc = complete_gpu(*prev); if (rc < 0) return rc; produced = 1; }
+  if (rc_launch < 0) return rc_launch;
+  if (frame_threads_ == 1 && gpu_job_) { PicJob *j = gpu_job_; gpu_job_ = nullptr; const int rc = complete_gpu(*j); if (rc < 0) return rc; produced = 1; }
   return produced;
 }
 
-int Decoder::complete_gpu()
+int Decoder::complete_gpu(PicJob &job)
 {
-  PicJob &job = *gpu_job_;
-  gpu_job_ = nullptr;
   {
     Tick tk;
     if (frame_threads_ > 1 && !spin_wait_) {   // the output lags anyway: nap between queries instead of polling (see nap_until)
-      if (!nap_until([&] { hipError_t r = hipStreamQuery(stream_); return r == hipSuccess ? 1 : (r == hipErrorNotReady ? 0 : -1); })) return DEC_ERR_GPU;
-    } else if (hipStreamSynchronize(stream_) != hipSuccess) return DEC_ERR_GPU;
+      if (!nap_until([&] { hipError_t r = hipEventQuery(job.done); return r == hipSuccess ? 1 : (r == hipErrorNotReady ? 0 : -1); })) return DEC_ERR_GPU;
+    } else if (hipEventSynchronize(job.done) != hipSuccess) return DEC_ERR_GPU;
     t_sync_ += tk.ms();
   }
   if (*h_err_) { fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x\n", *h_err_); return DEC_ERR_GPU; }
-  if (ev_used_) {
-    for (size_t i = 0; i < ev_used_; i++) { float ms = 0; hipEventElapsedTime(&ms, ev_pool_[i].a, ev_pool_[i].b); k_ms_[ev_pool_[i].id] += ms; k_n_[ev_pool_[i].id]++; }
-    ev_used_ = 0;
+  if (job.ev_used) {
+    for (size_t i = 0; i < job.ev_used; i++) { float ms = 0; hipEventElapsedTime(&ms, job.ev[i].a, job.ev[i].b); k_ms_[job.ev[i].id] += ms; k_n_[job.ev[i].id]++; }
+    job.ev_used = 0;
   }
   out_ = DecodedPicture();
   out_.coded_w = w_; out_.coded_h = h_;
@@ -1230,11 +1243,11 @@ int Decoder::complete_gpu()
     const int ypitch = (out_.width + 63) & ~63;
     for (int c = 0; c < 3; c++) {
       int w = c ? out_.width / 2 : out_.width, h = c ? out_.height / 2 : out_.height, pitch = c ? ypitch / 2 : ypitch;
-      if (hipMemcpy2DAsync(h_out_ + off, (size_t)pitch, out_.dev[c], (size_t)out_.dev_pitch[c], (size_t)w, (size_t)h, hipMemcpyDeviceToHost, stream_) != hipSuccess) return DEC_ERR_GPU;
+      if (hipMemcpy2DAsync(h_out_ + off, (size_t)pitch, out_.dev[c], (size_t)out_.dev_pitch[c], (size_t)w, (size_t)h, hipMemcpyDeviceToHost, stream_dl_) != hipSuccess) return DEC_ERR_GPU;
       out_.host[c] = h_out_ + off; out_.host_pitch[c] = pitch;
       off += (size_t)pitch * h;
     }
-    if (hipStreamSynchronize(stream_) != hipSuccess) return DEC_ERR_GPU;
+    if (hipStreamSynchronize(stream_dl_) != hipSuccess) return DEC_ERR_GPU;
   }
   pic_ready_ = true;
   return 1;
@@ -1379,6 +1392,8 @@ int Decoder::launch_gpu(PicJob &job)
   const size_t tu_off = fixed_bytes(), lev_off = (tu_off + ntu * sizeof(DecTu) + 15) & ~(size_t)15;
   const size_t bytes = lev_off + nlev * sizeof(uint32_t);
   prof_now_ = profiling_ && (launched_ % prof_every_) == 0;
+  timed_job_ = &job; job.ev_used = 0;
+  if (!job.done && hipEventCreateWithFlags(&job.done, hipEventDisableTiming) != hipSuccess) return DEC_ERR_GPU;
   Tick tk_api;
   if (bytes > d_in_cap_) {                               // (the stream is idle here: the previous picture has been completed)
     hipFree(d_in_);
@@ -1394,7 +1409,7 @@ int Decoder::launch_gpu(PicJob &job)
   for (int c = 0; c < 3; c++) { f.rec[c] = sao ? work_[c] : dpb_[job.slot].plane[c]; f.out[c] = dpb_[job.slot].plane[c]; }
   for (int k = 0; k < KVZ_DEC_MAX_REFS; k++) for (int c = 0; c < 3; c++) f.ref[k][c] = dpb_[k].plane[c];
   f.sao = sao ? (const SaoParams *)(d_in_ + off_sao()) : nullptr;
-  f.progress = progress_; f.err = err_;
+  f.progress = progress_; f.intra_order = intra_order_; f.err = err_;
   f.cb_qp_offset = (int8_t)job.pps.cb_qp_offset; f.cr_qp_offset = (int8_t)job.pps.cr_qp_offset;
   f.beta_offset = (int8_t)(2 * job.sh.beta_offset_div2); f.tc_offset = (int8_t)(2 * job.sh.tc_offset_div2);
   f.strong_intra = (uint8_t)job.sps->strong_intra; f.tiles = job.pps.tile_rows > 1;
@@ -1406,6 +1421,7 @@ int Decoder::launch_gpu(PicJob &job)
   if (!job.sh.deblock_disabled) timed(DK_DEBLOCK, [&] { launch_dec_deblock(f, stream_); });
   if (sao) timed(DK_SAO, [&] { launch_dec_sao(f, stream_); });
   if (hipMemcpyAsync(h_err_, err_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_) != hipSuccess) return DEC_ERR_GPU;
+  if (hipEventRecord(job.done, stream_) != hipSuccess) return DEC_ERR_GPU;
   t_api_ += tk_api.ms();
   launched_++;
   gpu_job_ = &job;

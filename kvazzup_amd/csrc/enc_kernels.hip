@@ -6,7 +6,7 @@
 // against oracle/ (tests/); the decisions follow "uvgx encoder algorithm v1" (oracle/hevc_enc.h).
 //
 // Launch geometry (coded size is a multiple of 64; DESIGN.md section 5 has the table with timings):
-//   k_pad_input     packed I420 -> padded planes, four samples per thread
+//   k_pad_input     packed I420 -> padded planes, sixteen samples per thread
 //   k_vaq_stats/apply  per-CTU luma variance -> delta QP (vaq only)
 //   k_me            one workgroup per 32x32 luma block (XCD-aware order): early termination on the co-located block, else the
 //                   search window staged in LDS, v_qsad_pk_u16_u8 on quads x pairs of candidates, wave min of (cost << 13 | index)
@@ -846,8 +846,11 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
   __shared__ IntraWaveLds s;
   __shared__ uint32_t bcast, bc4[4];
   __shared__ uint8_t cu_l2[64], cu_mode[64], cu_cbf_s[64];
-  const int lane = threadIdx.x, wc = f.cw >> 6, lin = (int)blockIdx.x / 3, c = (int)blockIdx.x % 3;
-  const int row = f.row0 + lin / wc, cx = lin % wc, ctu = row * wc + cx;
+  // Workgroups are dispatched in blockIdx order and a picture has more of them than fit on the chip at once, so they are numbered
+  // the way the wavefront advances (f.intra_order: by cx + 2 cy -- every CTU a block depends on comes earlier) instead of in raster
+  // order, where the right ends of the upper rows would hold the slots the lower left needs.
+  const int lane = threadIdx.x, wc = f.cw >> 6, c = (int)blockIdx.x % 3, ctu = (int)f.intra_order[blockIdx.x / 3];
+  const int row = ctu / wc, cx = ctu % wc;
   const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, P = 16 + 2 * S;
   uint32_t *my = f.sync + (size_t)ctu * 3 + c;
   load_matrices(s.M, 0, KV_MATRIX_ENTRIES, lane, T);
@@ -955,35 +958,62 @@ __global__ __launch_bounds__(256) void k_qp_chain(EncFrame f)                // 
 // horizontally on the vertically filtered samples (8.7.2: the whole picture's vertical edges come first), and goes back.
 __global__ __launch_bounds__(256) void k_deblock_tile(EncFrame f)
 {
-  constexpr int P = 68, PC = 36;                           // (the last tile of a row / column is four samples larger: it takes the picture's last four columns / rows along)
+  constexpr int P = 80, PC = 48;                           // LDS pitches: 68 (36) used, multiples of 16 so that the 16-byte pieces stay aligned
   __shared__ __attribute__((aligned(16))) uint8_t ty_[68 * P];
   __shared__ __attribute__((aligned(16))) uint8_t tc_[2][34 * PC];
+  // the CU records of the tile's 8x8 cells and one ring around them (cells -1 .. 8 in both directions): everything the boundary
+  // strength needs, fetched in one go beside the samples instead of per edge segment
+  __shared__ uint8_t r_log2[100], r_intra[100], r_cbf[100]; __shared__ uint32_t r_mv[100];
   const int tid = threadIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
   const int lin = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), tx = lin % wc, tyi = lin / wc;
   const int X0 = tx * 64 - 4, Y0 = tyi * 64 - 4, CX0 = X0 >> 1, CY0 = Y0 >> 1, cw2 = f.cw >> 1;
   const int TW = tx == wc - 1 ? 68 : 64, TH = tyi == hc - 1 ? 68 : 64;
-  // ---- tile in (luma as dwords: X0 is a multiple of 4; chroma as sample pairs)
-  for (int i = tid; i < TH * 17; i += 256) {
-    const int y = i / 17, x = (i - y * 17) * 4, gx = X0 + x, gy = Y0 + y;
-    if (x < TW && gx >= 0 && gy >= 0) *(uint32_t *)&ty_[y * P + x] = *(const uint32_t *)&f.rec[0][(size_t)gy * f.cw + gx];
+  // ---- tile in: 16-byte pieces (X0 is 4-byte aligned: dwordx4 with dword alignment), the last piece of a 68-wide row 4 bytes
+  for (int i = tid; i < TH * 5; i += 256) {
+    const int y = i / 5, k = i - y * 5, x = k * 16, gx = X0 + x, gy = Y0 + y;
+    if (gy < 0 || x >= TW) continue;
+    const uint8_t *g = &f.rec[0][(size_t)gy * f.cw + gx];
+    if (k < 4) { if (gx >= 0) *(kv_u32x4 *)&ty_[y * P + x] = *(const kv_u32x4 *)g; else { kv_u32x4 v; v.x = 0; v.y = *(const uint32_t *)(g + 4); v.z = *(const uint32_t *)(g + 8); v.w = *(const uint32_t *)(g + 12); *(kv_u32x4 *)&ty_[y * P + x] = v; } }
+    else *(uint32_t *)&ty_[y * P + x] = *(const uint32_t *)g;
   }
-  for (int i = tid; i < 2 * (TH / 2) * 17; i += 256) {
-    const int pl = i / ((TH / 2) * 17), r = i - pl * ((TH / 2) * 17), y = r / 17, x = (r - y * 17) * 2, gx = CX0 + x, gy = CY0 + y;
-    if (x < TW / 2 && gx >= 0 && gy >= 0) *(uint16_t *)&tc_[pl][y * PC + x] = *(const uint16_t *)&f.rec[1 + pl][(size_t)gy * cw2 + gx];
+  // chroma: aligned dwords from two samples left of the tile (CX0 - 2 is a multiple of 4): sample x of the tile sits at LDS column x + 2
+  for (int i = tid; i < 2 * (TH / 2) * 9; i += 256) {
+    const int pl = i / ((TH / 2) * 9), r = i - pl * ((TH / 2) * 9), y = r / 9, k = r - y * 9, gx = CX0 - 2 + 4 * k, gy = CY0 + y;
+    if (gy >= 0 && gx >= 0) *(uint32_t *)&tc_[pl][y * PC + 4 * k] = *(const uint32_t *)&f.rec[1 + pl][(size_t)gy * cw2 + gx];
+  }
+  if (tid < 100) {
+    const int bx = tx * 8 - 1 + tid % 10, by = tyi * 8 - 1 + tid / 10;
+    uint32_t l2 = 6, in = 0, cb = 0, mv = 0;
+    if (bx >= 0 && by >= 0 && bx < f.b8w && by < f.b8h) {
+      const int i = by * f.b8w + bx;
+      l2 = f.cu_log2[i]; in = f.cu_intra[i]; cb = f.cu_cbf[i]; mv = *(const uint32_t *)&f.cu_mv[i * 2];
+    }
+    r_log2[tid] = (uint8_t)l2; r_intra[tid] = (uint8_t)in; r_cbf[tid] = (uint8_t)cb; r_mv[tid] = mv;
   }
   __syncthreads();
+  auto cell = [&](int x, int y) { return ((y >> 3) - (tyi * 8 - 1)) * 10 + ((x >> 3) - (tx * 8 - 1)); };
+  auto bs_of = [&](int cp, int cq) -> int {
+    if (r_intra[cp] | r_intra[cq]) return 2;
+    if ((r_cbf[cp] | r_cbf[cq]) & 1) return 1;
+    const uint32_t a = r_mv[cp], b = r_mv[cq];
+    if (iabs((int)(int16_t)(a & 0xffff) - (int)(int16_t)(b & 0xffff)) >= 4 || iabs((int)(int16_t)(a >> 16) - (int)(int16_t)(b >> 16)) >= 4) return 1;
+    return 0;
+  };
   // ---- vertical edges: 8 edges x 16 (17) four-row segments
   if (tid < 8 * (TH / 4)) {
     const int x = tx * 64 + (tid & 7) * 8, y = Y0 + (tid >> 3) * 4;
-    if (x > 0 && y >= 0 && is_cu_edge_v(f, x, y)) {
-      const int bs = edge_bs(f, x - 1, y, x, y);
-      if (bs) {
-        const int qp = (cu_qpy(f, x - 1, y) + cu_qpy(f, x, y) + 1) >> 1;            // QpP and QpQ averaged (8.7.2.5.3)
-        deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], 1, P, bs, qp);
-        if (bs == 2 && (x & 15) == 0) {
-          const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0);
-          deblock_chroma_segment(&tc_[0][o], 1, PC, 2, qp);
-          deblock_chroma_segment(&tc_[1][o], 1, PC, 2, qp);
+    if (x > 0 && y >= 0) {
+      const int cq = cell(x, y), cp = cq - 1;
+      if ((x & ((1 << r_log2[cq]) - 1)) == 0) {
+        const int bs = bs_of(cp, cq);
+        if (bs) {
+          const int qp = f.ctu_qy ? (cu_qpy(f, x - 1, y) + cu_qpy(f, x, y) + 1) >> 1 : f.qp;      // QpP and QpQ averaged (8.7.2.5.3)
+          deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], 1, P, bs, qp);
+          if (bs == 2 && (x & 15) == 0) {
+            const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0) + 2;
+            deblock_chroma_segment(&tc_[0][o], 1, PC, 2, qp);
+            deblock_chroma_segment(&tc_[1][o], 1, PC, 2, qp);
+          }
         }
       }
     }
@@ -992,28 +1022,41 @@ __global__ __launch_bounds__(256) void k_deblock_tile(EncFrame f)
   // ---- horizontal edges: 8 edges x 16 (17) four-column segments, on the vertically filtered samples
   if (tid < 8 * (TW / 4)) {
     const int y = tyi * 64 + (tid & 7) * 8, x = X0 + (tid >> 3) * 4;
-    if (y > 0 && x >= 0 && is_cu_edge_h(f, x, y)) {
-      const int bs = edge_bs(f, x, y - 1, x, y);
-      if (bs) {
-        const int qp = (cu_qpy(f, x, y - 1) + cu_qpy(f, x, y) + 1) >> 1;
-        deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], P, 1, bs, qp);
-        if (bs == 2 && (y & 15) == 0) {
-          const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0);
-          deblock_chroma_segment(&tc_[0][o], PC, 1, 2, qp);
-          deblock_chroma_segment(&tc_[1][o], PC, 1, 2, qp);
+    if (y > 0 && x >= 0) {
+      const int cq = cell(x, y), cp = cq - 10;
+      if ((y & ((1 << r_log2[cq]) - 1)) == 0) {
+        const int bs = bs_of(cp, cq);
+        if (bs) {
+          const int qp = f.ctu_qy ? (cu_qpy(f, x, y - 1) + cu_qpy(f, x, y) + 1) >> 1 : f.qp;
+          deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], P, 1, bs, qp);
+          if (bs == 2 && (y & 15) == 0) {
+            const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0) + 2;
+            deblock_chroma_segment(&tc_[0][o], PC, 1, 2, qp);
+            deblock_chroma_segment(&tc_[1][o], PC, 1, 2, qp);
+          }
         }
       }
     }
   }
   __syncthreads();
   // ---- tile out
-  for (int i = tid; i < TH * 17; i += 256) {
-    const int y = i / 17, x = (i - y * 17) * 4, gx = X0 + x, gy = Y0 + y;
-    if (x < TW && gx >= 0 && gy >= 0) *(uint32_t *)&f.rec[0][(size_t)gy * f.cw + gx] = *(const uint32_t *)&ty_[y * P + x];
+  for (int i = tid; i < TH * 5; i += 256) {
+    const int y = i / 5, k = i - y * 5, x = k * 16, gx = X0 + x, gy = Y0 + y;
+    if (gy < 0 || x >= TW) continue;
+    uint8_t *g = &f.rec[0][(size_t)gy * f.cw + gx];
+    if (k < 4) {
+      const kv_u32x4 v = *(const kv_u32x4 *)&ty_[y * P + x];
+      if (gx >= 0) *(kv_u32x4 *)g = v; else { *(uint32_t *)(g + 4) = v.y; *(uint32_t *)(g + 8) = v.z; *(uint32_t *)(g + 12) = v.w; }
+    } else *(uint32_t *)g = *(const uint32_t *)&ty_[y * P + x];
   }
-  for (int i = tid; i < 2 * (TH / 2) * 17; i += 256) {
-    const int pl = i / ((TH / 2) * 17), r = i - pl * ((TH / 2) * 17), y = r / 17, x = (r - y * 17) * 2, gx = CX0 + x, gy = CY0 + y;
-    if (x < TW / 2 && gx >= 0 && gy >= 0) *(uint16_t *)&f.rec[1 + pl][(size_t)gy * cw2 + gx] = *(const uint16_t *)&tc_[pl][y * PC + x];
+  for (int i = tid; i < 2 * (TH / 2) * 9; i += 256) {
+    const int pl = i / ((TH / 2) * 9), r = i - pl * ((TH / 2) * 9), y = r / 9, k = r - y * 9, gx = CX0 - 2 + 4 * k, gy = CY0 + y;
+    if (gy < 0 || gx < 0) continue;
+    uint8_t *g = &f.rec[1 + pl][(size_t)gy * cw2 + gx];
+    const uint32_t v = *(const uint32_t *)&tc_[pl][y * PC + 4 * k];
+    if (k == 0) *(uint16_t *)(g + 2) = (uint16_t)(v >> 16);                 // the first two bytes belong to the tile on the left
+    else if (k == 8 && TW == 64) *(uint16_t *)g = (uint16_t)v;              // ... the last two to the tile on the right
+    else *(uint32_t *)g = v;
   }
 }
 
@@ -1334,18 +1377,23 @@ __global__ __launch_bounds__(256) void k_tok_compact(EncFrame f)
 // =============================================================================================
 __global__ __launch_bounds__(256) void k_pad_input(const uint8_t *in, int w, int h, uint8_t *dy, uint8_t *du, uint8_t *dv, int cw, int ch)
 {
-  // blockIdx.y: luma rows, then Cb rows, then Cr rows (packed I420 input: Y, U, V planes back to back)
+  // blockIdx.y: luma rows, then Cb rows, then Cr rows (packed I420 input: Y, U, V planes back to back); 16 samples per thread
   int y = blockIdx.y, plane = 0;
   if (y >= ch) { y -= ch; plane = 1; if (y >= ch / 2) { y -= ch / 2; plane = 2; } }
   const int pw = plane ? w / 2 : w, ph = plane ? h / 2 : h, pcw = plane ? cw / 2 : cw;
-  const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
   if (x >= pcw) return;
   const uint8_t *src = in + (plane == 0 ? 0 : (plane == 1 ? (size_t)w * h : (size_t)w * h + (size_t)(w / 2) * (h / 2)));
   uint8_t *dst = plane == 0 ? dy : (plane == 1 ? du : dv);
   const uint8_t *row = src + (size_t)imin(y, ph - 1) * pw;
-  uint32_t v = 0;
-  for (int i = 0; i < 4; i++) v |= (uint32_t)row[imin(x + i, pw - 1)] << (8 * i);
-  *reinterpret_cast<uint32_t *>(dst + (size_t)y * pcw + x) = v;
+  kv_u32x4 v;
+  if (x + 16 <= pw && (((uintptr_t)(row + x)) & 3) == 0) v = *reinterpret_cast<const kv_u32x4 *>(row + x);      // the common case: one 16-byte load
+  else {                                                     // the picture's right edge (replicated) or an odd alignment: byte by byte
+    uint32_t q[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 16; i++) q[i >> 2] |= (uint32_t)row[imin(x + i, pw - 1)] << (8 * (i & 3));
+    v.x = q[0]; v.y = q[1]; v.z = q[2]; v.w = q[3];
+  }
+  *reinterpret_cast<kv_u32x4 *>(dst + (size_t)y * pcw + x) = v;          // coded widths are multiples of 64: 16-byte aligned
 }
 
 // =============================================================================================
@@ -1591,8 +1639,8 @@ __global__ __launch_bounds__(256) void k_vaq_apply(EncFrame f, int vaq, const in
 // =============================================================================================
 void launch_pad_input(const uint8_t *in, int w, int h, uint8_t *dy, uint8_t *du, uint8_t *dv, int cw, int ch, hipStream_t st)
 {
-  dim3 g((cw / 4 + 255) / 256, ch * 2);
-  hipLaunchKernelGGL(k_pad_input, g, dim3(256), 0, st, in, w, h, dy, du, dv, cw, ch);
+  dim3 g((cw / 16 + 63) / 64, ch * 2);
+  hipLaunchKernelGGL(k_pad_input, g, dim3(64), 0, st, in, w, h, dy, du, dv, cw, ch);
 }
 void launch_me(const EncFrame &f, hipStream_t st)
 {

@@ -136,7 +136,7 @@ class Encoder {
   uint8_t *intra_scratch_ = nullptr;
   uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; uint32_t *tok_total_ = nullptr;
   size_t tok_dense_cap_ = 0;
-  uint32_t *sync_ = nullptr; uint32_t *err_ = nullptr; unsigned long long *trace_ = nullptr;
+  uint32_t *sync_ = nullptr; uint32_t *intra_order_ = nullptr; uint32_t *err_ = nullptr; unsigned long long *trace_ = nullptr;
   // one slot per picture in flight: the host-visible results of its kernels and what collect() needs to finish it
   struct EvPair { hipEvent_t a, b; KernelId id; };
   struct Slot {

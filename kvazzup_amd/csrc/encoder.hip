@@ -122,6 +122,14 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   }
   HIP_OK(hipEventCreateWithFlags(&in_done_, hipEventDisableTiming));
   HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * rows_ * (cw_ / 64) * 3));       // one progress counter per CTU and colour plane
+  {
+    // dispatch order of the intra reconstruction's workgroups: the CTUs of the rows this instance codes, by anti-diagonal cx + 2 cy
+    const int wc = cw_ / 64, r0 = cfg.band_rows > 0 ? cfg.band_row0 : 0, nr = cfg.band_rows > 0 ? cfg.band_rows : rows_;
+    std::vector<uint32_t> order;
+    for (int d = 0; d < wc + 2 * nr; d++) for (int cy = 0; cy < nr; cy++) { const int cx = d - 2 * cy; if (cx >= 0 && cx < wc) order.push_back((uint32_t)((r0 + cy) * wc + cx)); }
+    HIP_OK(hipMalloc(&intra_order_, sizeof(uint32_t) * order.size()));
+    HIP_OK(hipMemcpy(intra_order_, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice));
+  }
   HIP_OK(hipMalloc(&err_, sizeof(uint32_t))); HIP_OK(hipMemset(err_, 0, sizeof(uint32_t)));
   if (getenv("KVAZZUP_AMD_INTRA_TRACE")) { HIP_OK(hipMalloc(&trace_, sizeof(unsigned long long) * rows_ * (cw_ / 64) * 24)); HIP_OK(hipMemset(trace_, 0, sizeof(unsigned long long) * rows_ * (cw_ / 64) * 24)); }
   int eth = cfg.entropy_threads;
@@ -143,7 +151,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   f_.im8 = p; p += nb8; f_.im16 = p; p += nb8 / 4; f_.im32 = p;
   f_.tok_buf = tok_buf_; f_.tok_cap = tok_cap_; f_.tok_cursor = (uint32_t *)tok_count_; f_.tok_seg = tok_seg_; f_.tok_total = tok_total_;
   f_.tok_dense_cap = (uint32_t)tok_dense_cap_;
-  f_.sync = sync_; f_.err = err_; f_.trace = trace_;
+  f_.sync = sync_; f_.err = err_; f_.trace = trace_; f_.intra_order = intra_order_;
 
   sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp; sp_.tile_rows = cfg.tile_rows; sp_.qp_in_cu = cfg.qp_in_cu; sp_.sao = cfg.sao;
   sp_.deblock = cfg.deblock; sp_.fps_num = cfg.fps_num; sp_.fps_den = cfg.fps_den;
@@ -200,7 +208,7 @@ Encoder::~Encoder()
   if (stream_in_) hipStreamDestroy(stream_in_);
   hipFree(intra_scratch_);
   delete entropy_; delete entropy2_;
-  hipFree(trace_); hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(tok_total_); hipFree(sync_); hipFree(err_);
+  hipFree(trace_); hipFree(intra_order_); hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(tok_total_); hipFree(sync_); hipFree(err_);
   if (stream_) hipStreamDestroy(stream_);
 }
 

@@ -68,6 +68,7 @@ struct EncFrame {
   SaoParams *sao; uint8_t *sao_out[3];
   uint32_t *sync;               // [CTU][plane] progress counters (intra reconstruction wavefront: finished 8x8 units of the CTU)
   uint32_t *err;                // device-side error flags
+  const uint32_t *intra_order;  // CTU (raster index) handled by the k-th workgroup triple of k_intra_recon: anti-diagonal wavefront order
   unsigned long long *trace;    // KVAZZUP_AMD_INTRA_TRACE: per (CTU, plane) 8 words {start, first block, end, time in border waits, blocks, stores, publishes, number of blocks} of k_intra_recon, 100 MHz ticks; else NULL
 };
 

@@ -7,6 +7,8 @@
 
 namespace kvzx {
 
+struct alignas(4) kv_u32x4 { uint32_t x, y, z, w; };          // 16 bytes with dword alignment: one global_load/store_dwordx4
+
 // Workgroups are observed to land on the eight XCDs round-robin (workgroup b -> XCD b % 8), each XCD with its own L2.  A raster
 // of small blocks dealt out that way makes every XCD fetch every 128-byte line its neighbours also fetch (a 32-sample block
 // row is a quarter of a line).  This permutation of the linear workgroup id gives each XCD one contiguous run of the raster

@@ -1,7 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r02_pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -5 gpurun_out/r02_pytest_gpu.log | cut -c1-600
-for t in 256 64; do
+for t in 256; do
 KVAZZUP_AMD_DEC_INTRA_THREADS=$t timeout 600 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --secondary-steps 4 > gpurun_out/r02_bench_t$t.json 2> gpurun_out/r02_bench_t$t.err; echo "bench rc $?"
 python - <<PY
 import json

@@ -93,6 +93,12 @@ KVZ_PUBLIC int kvzx_yuv420_to_rgb32(const uint8_t *i420, uint8_t *rgb32, int wid
 /* the picture returned by the last libOpenHevcGetOutput, converted where it lies in HBM (no host copy); synchronous */
 KVZ_PUBLIC int kvzx_decoder_output_rgb32_device(OpenHevc_Handle h, void *d_rgb32, int variant);
 
+/* RGB32 -> I420, the converters of src/media/processing/yuvconversions.cpp:634-797, bit for bit (their quirks included: see
+ * kvazzup_amd/csrc/color_kernels.hip).  variant 1 = rgb_to_yuv420_i_c, 2 = rgb_to_yuv420_i_sse41 (which turns the picture upside
+ * down).  width % 4 == 0, height % 2 == 0.  Output: packed I420 (width * height * 3 / 2 bytes). */
+KVZ_PUBLIC int kvzx_rgb32_to_yuv420_device(const void *d_rgb32, void *d_i420, int width, int height, int variant, void *hip_stream);
+KVZ_PUBLIC int kvzx_rgb32_to_yuv420(const uint8_t *rgb32, uint8_t *i420, int width, int height, int variant);
+
 /* ---- filter-graph harness (kvazzup_amd/csrc/filters.h): KvazaarFilter -> [WireAdapter -> OpenHEVCFilter] ----
  * A Qt-free restatement of the two uvgComm filters on this path, each on its own thread with the
  * reference's input-buffer contract (src/media/processing/filter.cpp:151-222,364-417), driven through the

@@ -98,7 +98,7 @@ class OpenHevcFrame(C.Structure):
     _fields_ = [("pvY", C.c_void_p), ("pvU", C.c_void_p), ("pvV", C.c_void_p), ("frameInfo", OpenHevcFrameInfo)]
 
 
-ENCODER_EXPORTS = ["kvz_api_get", "kvzx_version", "kvzx_device_count", "kvzx_encoder_encode_device", "kvzx_encoder_encode_host",
+ENCODER_EXPORTS = ["kvz_api_get", "kvzx_version", "kvzx_rgb32_to_yuv420", "kvzx_rgb32_to_yuv420_device", "kvzx_yuv420_to_rgb32", "kvzx_yuv420_to_rgb32_device", "uvgx_pipeline_flush", "kvzx_device_count", "kvzx_encoder_encode_device", "kvzx_encoder_encode_host",
                    "kvzx_encoder_coded_size", "kvzx_encoder_download_recon", "kvzx_encoder_recon_device", "kvzx_encoder_debug_copy",
                    "kvzx_encoder_set_profiling", "kvzx_encoder_kernel_times", "kvzx_encoder_kernel_name", "kvzx_encoder_last_bins"]
 DECODER_EXPORTS = ["libOpenHevcInit", "libOpenHevcStartDecoder", "libOpenHevcDecode", "libOpenHevcGetPictureInfo",

@@ -14,6 +14,7 @@
 //   k_dec_sao      one workgroup per CTU
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstring>
 #include "dec_frame.h"
 #include "dec_kernels.h"
 #include "kernel_common.h"
@@ -514,7 +515,14 @@ __global__ __launch_bounds__(T) void k_dec_intra(DecFrame f)
   };
   fetch_words(0);
   for (int k = 0; k < nlist; k++) {
-    const DecTu d = s.list[k];
+    DecTu d;                                            // wave-uniform copy: positions, availability, mode constants go to the scalar unit
+    {
+      const uint32_t *q = (const uint32_t *)&s.list[k];
+      uint32_t u[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) u[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q[i]);
+      memcpy(&d, u, sizeof(d));
+    }
     uint32_t wreg[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) wreg[q] = wnext[q];

@@ -871,13 +871,20 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
   bd.nb_up = nb_up; bd.nb_left = nb_left; bd.nb_ur = nb_ur; bd.nb_ul = nb_ul;
   bd.pl = my - 3; bd.pu = my - 3 * wc; bd.pur = bd.pu + 3; bd.pul = bd.pu - 3;
   if (f.trace && lane == 0) f.trace[((size_t)ctu * 3 + c) * 8 + 0] = wall_clock64();
+#ifdef KVZ_PROF
+  if (lane < 16) g_prof[lane] = 0;
+  __syncthreads();
+  if (lane == 0) g_prof[15] = clock64();
+#endif
   borders_begin(bd, bc4);
   int published = 0;
   unsigned long long tb = 0, tk = 0, ts = 0, tp = 0, nblk = 0, tq = 0;       // trace: time in border waits / block / store / publish
 #define KV_LAP(acc) do { if (f.trace) { const unsigned long long n_ = wall_clock64(); acc += n_ - tq; tq = n_; } } while (0)
   if (f.trace) tq = wall_clock64();
   for (int z = 0; z < 64;) {
-    const int l2 = cu_l2[z], mode = cu_mode[z], n = 1 << (l2 - sh);
+    // (made wave-uniform explicitly: everything derived from them -- positions, availability, the mode's constants -- then runs on
+    // the scalar unit instead of in every lane)
+    const int l2 = __builtin_amdgcn_readfirstlane((int)cu_l2[z]), mode = __builtin_amdgcn_readfirstlane((int)cu_mode[z]), n = 1 << (l2 - sh);
     const int angle = kIntraAngle[mode], inv = kInvAngle[mode];
     int xi, yi; ctu_z_to_xy(z, xi, yi);
     const int X = cx * 64 + xi * 8, Y = row * 64 + yi * 8, rx = (xi * 8) >> sh, ry = (yi * 8) >> sh;
@@ -886,6 +893,7 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
     // the neighbouring CTUs' samples this block reads: wait for them, copy them into the borders of the CTU picture
     borders_need(bd, s.pic, P, plane, pw, cx, row, S, sh, 2 * S, rx, ry, n, &bcast, f.err, lane, T);
     KV_LAP(tb);
+    PROF(2);
     if (f.trace && lane == 0 && z == 0) f.trace[((size_t)ctu * 3 + c) * 8 + 1] = wall_clock64();
     bool cbf;
     switch (l2 - sh) {
@@ -895,6 +903,7 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
       default: cbf = intra_block<false, 5, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, false, lane); break;
     }
     KV_LAP(tk); nblk++;
+    PROF(10);
     // block -> picture, write-through: the neighbouring CTUs' workgroups read it from there
     store_block_wt(grec + (size_t)ry * pw + rx, pw, &s.pic[(ry + 1) * P + 16 + rx], P, n, lane, T);
     KV_LAP(ts);
@@ -910,6 +919,11 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
     atomicOr((uint32_t *)(f.cu_cbf + (bi & ~3)), (1u << c) << (8 * (bi & 3)));   // the three planes own one bit each of the byte
   }
   publish_wt(my, 64u);
+#ifdef KVZ_PROF
+  __syncthreads();
+  if (f.trace && c == 0 && lane < 16) f.trace[((size_t)ctu * 3 + 1) * 8 + (lane & 7) + (lane >> 3) * 8] = (unsigned long long)g_prof[lane];   // (over the chroma planes' slots)
+  if (c) return;
+#endif
   if (f.trace && lane == 0) { unsigned long long *t = f.trace + ((size_t)ctu * 3 + c) * 8; t[2] = wall_clock64(); t[3] = tb; t[4] = tk; t[5] = ts; t[6] = tp; t[7] = nblk; }
 }
 

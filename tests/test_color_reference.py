@@ -32,3 +32,25 @@ def test_reference_object_code_matches_the_golden_vectors_and_its_simd_variants_
     # the two arithmetics really are different (the scalar fallback swaps the chroma planes and keeps byte 3)
     src = refcolor.random_i420(5, 64, 32)
     assert not np.array_equal(refcolor.reference("c", src, 64, 32), refcolor.reference("avx2", src, 64, 32))
+
+
+# ---- RGB32 -> I420 (rgb_to_yuv420_i_c / rgb_to_yuv420_i_sse41, yuvconversions.cpp:634-797)
+GOLD2 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "color_rgb32_to_i420.npz"))
+CASES2 = sorted(k[:-3] for k in GOLD2.files if k.endswith("_in"))
+
+
+@pytest.mark.parametrize("case", CASES2)
+def test_rgb2yuv_numpy_restatement_matches_the_golden_vectors(case):
+    w, h = (int(x) for x in GOLD2[case + "_dims"])
+    assert np.array_equal(refcolor.restatement_rgb2yuv("sse41" if case.startswith("sse41") else "c", GOLD2[case + "_in"], w, h), GOLD2[case + "_out"])
+
+
+@pytest.mark.skipif(not refcolor.available(), reason="oracle/_ref not built (needs /root/reference at build time)")
+def test_rgb2yuv_reference_object_code_matches_the_golden_vectors():
+    for case in CASES2:
+        w, h = (int(x) for x in GOLD2[case + "_dims"])
+        assert np.array_equal(refcolor.reference_rgb2yuv("sse41" if case.startswith("sse41") else "c", GOLD2[case + "_in"], w, h), GOLD2[case + "_out"]), case
+    # the two converters differ in more than rounding: the SSE one turns the picture upside down
+    src = refcolor.random_rgb32(9, 64, 32)
+    a, b = refcolor.reference_rgb2yuv("c", src, 64, 32), refcolor.reference_rgb2yuv("sse41", src, 64, 32)
+    assert not np.array_equal(a, b)

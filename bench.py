@@ -266,8 +266,15 @@ def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync
         os.environ["KVAZZUP_AMD_ENTROPY_THREADS"] = str(max(2, min(16, int(budget * 0.4))))
         os.environ["KVAZZUP_AMD_PARSE_THREADS"] = str(max(1, min(16, int(budget * 0.4))))       # (row-parallel parser of the synchronous decoder)
     seed = 0x5EED0000 + wl["cfg_index"] + 16 * rank
-    # synthetic clip generated directly in HBM (inputs resident before the timed region)
-    clip = [synth.frame_torch(synth.MOVING, seed, w, h, t, dev) for t in range(CLIP_FRAMES)]
+    # synthetic clip generated directly in HBM (inputs resident before the timed region).  KVAZZUP_BENCH_HOST_SYNTH=1 (counter
+    # passes: rocprofv3 --pmc crashes inside torch's elementwise kernels on this stack) makes the same clip with numpy and uploads
+    # it -- one intra period of it, cycled.
+    nclip = CLIP_FRAMES
+    if os.environ.get("KVAZZUP_BENCH_HOST_SYNTH"):
+        nclip = PERIOD
+        clip = [torch.from_numpy(synth.frame(synth.MOVING, seed, w, h, t)).to(dev) for t in range(nclip)]
+    else:
+        clip = [synth.frame_torch(synth.MOVING, seed, w, h, t, dev) for t in range(nclip)]
     torch.cuda.synchronize()
 
     def make(keep, download):
@@ -289,7 +296,7 @@ def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync
         encoder filter's input buffer short of its overflow threshold (a uvgComm filter drops inputs at 10 buffered, filter.cpp:151-222)."""
         last = pl.pushed + npic
         while pl.pushed < last:
-            if not pl.push_device_paced(clip[pl.pushed % CLIP_FRAMES].data_ptr(), 6, 120000):
+            if not pl.push_device_paced(clip[pl.pushed % nclip].data_ptr(), 6, 120000):
                 raise RuntimeError("pipeline stalled")
         pl.flush()
         if not pl.wait(last, 120000):

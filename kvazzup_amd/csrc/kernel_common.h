@@ -154,8 +154,8 @@ __device__ __forceinline__ uint32_t wait_wt(const uint32_t *ctr, uint32_t need, 
   if (threadIdx.x == 0) {
     uint32_t spins = 0, v;
     while ((v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 24)) { atomicOr(err, 1u); v = 64; break; }       // bounded spin: never hang the GPU
+      if (++spins < 16) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(16);      // (every poll is a trip to memory: back off once it is clear that the wait is long)
+      if (spins > (1u << 22)) { atomicOr(err, 1u); v = 64; break; }         // bounded spin: never hang the GPU
     }
     *bcast = v;
   }

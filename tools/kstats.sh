@@ -1,6 +1,7 @@
 #!/bin/bash
-# per-kernel statistics of one bench.py run (GPU box): tools/kstats.sh <out-dir> [bench args...]
-R=${GRAFT_REPO_ROOT:-$PWD}; out=$1; shift
+# per-kernel statistics of one (pipelined, default) bench.py run on the GPU box: tools/kstats.sh <tag> [bench args...]
+R=${GRAFT_REPO_ROOT:-$PWD}; tag=$1; shift
 cd /tmp; export TMPDIR=/tmp
-KVAZZUP_BENCH_NOPROF=1 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$out -o p -- python3 $R/bench.py "$@" > /dev/null 2>&1
-find $R/gpurun_out/$out -name "*kernel_stats.csv" | head -1 | xargs cut -d, -f1-4 | cut -c1-110
+KVAZZUP_BENCH_NOPROF=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -o p -- python3 $R/bench.py --no-cpu-baseline --no-secondary "$@" > $R/gpurun_out/prof_$tag.log 2>&1
+f=$(find $R/gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1); cp $f $R/gpurun_out/${tag}_kernel_stats.csv
+cut -d, -f1-4 $R/gpurun_out/${tag}_kernel_stats.csv | cut -c1-110 | head -20

@@ -16,9 +16,7 @@ def short(name):
     if not m:
         return None
     k = m.group(1)
-    if m.group(2) and m.group(2).startswith("<true") and k in ("k_inter_recon", "k_intra_recon", "k_sao"):
-        k += "<dec>"                   # the decoder instantiations; k_tokenize<true> is the all-components variant of the same kernel
-    return k
+    return {"k_deblock_tile": "k_deblock"}.get(k, k)     # (bench.py's name for the encoder's deblocking kernel; k_tokenize<true> is the all-components variant of the same kernel)
 
 
 def per_kernel(pass_name, counter):
@@ -45,7 +43,7 @@ for k in sorted(set(fetch) | set(write)):
     if k in mfma and mfma[k][1]:
         e["mfma_busy_cycles_per_launch"] = round(mfma[k][0] / mfma[k][1], 1)
     kernels[k] = e
-print(json.dumps({"command": "tools/pmc_traffic.sh %s  (rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE|SQ_VALU_MFMA_BUSY_CYCLES> --kernel-trace, three separate passes of bench.py --steps 24 --warmup 4)" % workload,
+print(json.dumps({"command": "tools/pmc_traffic.sh %s  (rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE|SQ_VALU_MFMA_BUSY_CYCLES> --kernel-trace, three separate passes of bench.py --steps 1 --warmup 1 --owf 0 --decoder-frame-threads 1)" % workload,
                   "workload": workload, "unit": "bytes per launch",
                   "correction": "MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled; WRITE_SIZE taken as reported (uncalibrated)",
                   "kernels": kernels}, indent=1))

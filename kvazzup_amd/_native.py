@@ -9,7 +9,8 @@ _LIB = None
 
 
 def library_path():
-    return os.path.join(_HERE, "libkvazzup_amd.so")
+    # (KVAZZUP_AMD_LIBRARY: an instrumented build of the same sources, tools/intra_prof.py)
+    return os.environ.get("KVAZZUP_AMD_LIBRARY") or os.path.join(_HERE, "libkvazzup_amd.so")
 
 
 def build_library(force=False):

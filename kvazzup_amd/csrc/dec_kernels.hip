@@ -320,14 +320,18 @@ __global__ __launch_bounds__(256) void k_dec_inter(DecFrame f)
 // =============================================================================================
 #define DI_P 144                       // pitch of the CTU picture in LDS
 struct DecIntraLds {
-  // The CTU with its borders as one padded picture (the layout of enc_kernels.hip IntraWaveLds): row 0 = the sample row above the
+  // The CTU with its borders as one padded picture (the layout of enc_kernels.hip IntraCtuLds): row 0 = the sample row above the
   // CTU (corner at column 15, then above and above-right), column 15 = the sample column to its left, sample (x, y) of the CTU at
   // pic[(y + 1) * DI_P + 16 + x].  The borders are copied from the picture piecewise, as the neighbouring CTUs publish them.
   alignas(16) uint8_t pic[65 * DI_P];
+  alignas(16) XfLaneF16 xf[4][64];     // matrix operands of the transform stages, per (transform, lane): blocks up to 16x16 (kernel_common.h)
+  alignas(16) IntraBlk blk[256];       // what the chain needs to know about each block of list[], worked out ahead of it
+  alignas(16) DecTu list[256];         // this plane's intra blocks of the CTU, decoding order (luma: at most 256 4x4 blocks)
+  uint32_t dq[256];                    // dequantiser constants of each block (dequant_pack)
+  // 32x32 blocks only (one wave running the workgroup-shaped code of the other sizes' predecessor):
   alignas(16) int16_t A[1024], B[1024];
   alignas(16) int16_t M[2][KV_MATRIX_ENTRIES];
   alignas(16) uint8_t R[2][144];       // reference samples in the scan order of 8.4.4.2.2, as built / filtered
-  DecTu list[256];                     // this plane's intra blocks of the CTU, decoding order (luma: at most 256 4x4 blocks)
 };
 
 // 6.4.1 for one slice: inside the picture, same tile, not later in z-scan order (luma locations)
@@ -458,13 +462,59 @@ __device__ __forceinline__ void dec_intra_block(const DecFrame &f, DecIntraLds &
   store_block_wt(f.rec[c] + (size_t)Yc * cpitch + Xc, cpitch, &s.pic[(ry + 1) * DI_P + 16 + rx], DI_P, N, lane, T);
 }
 
-template <int T>
-__global__ __launch_bounds__(T) void k_dec_intra(DecFrame f)
+// one intra transform block of at most 16x16 samples on one wave (kernel_common.h "One intra block per WAVE")
+template <int L2>
+__device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveScratch &ws, const IntraBlk &d, uint32_t dqc, int count, bool luma,
+                                                     uint8_t *gdst, int gp, int lane, const uint32_t (&wreg)[4])
 {
+  constexpr int N = 1 << L2;
+  const int g = lane >> 4, c = lane & 15, rx = d.rx, ry = d.ry;
+  const bool active = c < N && 4 * g < N;
+  // ---- levels -> dequantised coefficients, scattered so that lane (g, c) finds C'[u = 4g + r][j = c] at tr[c * 16 + 4g + r]
+  if (d.flags & IB_LEVELS) {
+    *(uint2 *)&ws.tr[lane * 4] = make_uint2(0u, 0u);
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (lane + k * 64 < count) {
+        const uint32_t wd = wreg[k];
+        const int pos = (int)(wd >> 16) & (N * N - 1);
+        ws.tr[(pos & (N - 1)) * 16 + (pos >> L2)] = (int16_t)dequant_coef_p((int16_t)(wd & 0xffffu), dqc);
+      }
+  }
+  int pred[4];
+  wave_intra_predict<L2>(s.pic, DI_P, ws, d, luma, lane, g, c, pred);     // (its wave_sync also orders the scatter above)
+  if (d.flags & IB_LEVELS) {
+    int res[4];
+    if (d.flags & IB_TSKIP) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) res[r] = (((int)ws.tr[(4 * g + r) * 16 + c] << 7) + 2048) >> 12;      // residual (x = 4g + r, y = c) = level at row c, column 4g + r
+      wave_sync();
+    } else {
+      const uint2 t = *(const uint2 *)&ws.tr[c * 16 + 4 * g];
+      const int dq[4] = {(int)(int16_t)(t.x & 0xffffu), (int)(int16_t)(t.x >> 16), (int)(int16_t)(t.y & 0xffffu), (int)(int16_t)(t.y >> 16)};
+      wave_inverse16(ws, kv_h4(s.xf[d.xf][lane].tb), dq, g, c, res);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) pred[r] = clip8(pred[r] + res[r]);
+  }
+  if (active) {
+    const uint32_t o = (uint32_t)pred[0] | ((uint32_t)pred[1] << 8) | ((uint32_t)pred[2] << 16) | ((uint32_t)pred[3] << 24);
+    *(uint32_t *)&s.pic[(ry + c + 1) * DI_P + 16 + rx + 4 * g] = o;
+    st_wt_u32(gdst + (size_t)(ry + c) * gp + rx + 4 * g, o);             // write-through: the neighbouring CTUs' workgroups read it from the picture
+  }
+  wave_sync();
+}
+
+// One workgroup (one wave) per (CTU, colour plane)
+__global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
+{
+  constexpr int T = 64;
   __shared__ DecIntraLds s;
+  __shared__ IntraWaveScratch ws;
   __shared__ uint32_t bcast, bc4[4];
   const int lane = threadIdx.x, ctu = (int)f.intra_order[blockIdx.x / 3], c = (int)blockIdx.x % 3, cx = ctu % f.wc, cy = ctu / f.wc;
-  const int sh = c ? 1 : 0, S = 64 >> sh, cpitch = f.pw >> sh, wC = f.w >> sh;
+  const int sh = c ? 1 : 0, S = 64 >> sh, cpitch = f.pw >> sh, wC = f.w >> sh, hC = f.h >> sh;
   uint32_t *my = f.progress + (size_t)ctu * 3 + c;
   const TuRange ct = f.ctu[ctu];
   const int count = (int)(ct.count & 0xffffffu);
@@ -472,30 +522,51 @@ __global__ __launch_bounds__(T) void k_dec_intra(DecFrame f)
     if (lane == 0) __hip_atomic_store(my, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  load_matrices(s.M, 0, KV_MATRIX_ENTRIES, lane, T);
-  const uint8_t *plane = f.rec[c];
+  for (int i = lane; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];
+  uint8_t *plane = f.rec[c];
   // the CTU as the inter kernel left it (its inter blocks are final, the intra ones get written below) -> LDS
   {
     const uint8_t *src = plane + (size_t)(cy * S) * cpitch + cx * S;
     for (int i = lane; i < S * S / 16; i += T) { const int y = i / (S / 16), xq = i % (S / 16); *(uint4 *)&s.pic[(y + 1) * DI_P + 16 + xq * 16] = *(const uint4 *)&src[(size_t)y * cpitch + xq * 16]; }
   }
-  // this plane's intra blocks, compacted in order (wave 0: one pass over the CTU's list, 64 descriptors at a time)
-  if (lane < 64) {
-    int nl = 0;
-    for (int base = 0; base < count; base += 64) {
-      DecTu d; d.plane = 255; d.flags = 0;
-      if (base + lane < count) d = f.tus[ct.first + base + lane];
-      const bool keep = d.plane == c && (d.flags & TU_INTRA);
-      const uint64_t m = __ballot(keep);
-      const int at = nl + __popcll(m & ((1ull << lane) - 1ull));
-      if (keep && at < 256) s.list[at] = d;
-      nl += __popcll(m);
-    }
-    if (lane == 0) bcast = (uint32_t)(nl > 256 ? 256 : nl);
+  // this plane's intra blocks, compacted in order (one pass over the CTU's list, 64 descriptors at a time)
+  int nlist = 0;
+  for (int base = 0; base < count; base += 64) {
+    DecTu d; d.plane = 255; d.flags = 0;
+    if (base + lane < count) d = f.tus[ct.first + base + lane];
+    const bool keep = d.plane == c && (d.flags & TU_INTRA);
+    const uint64_t m = __ballot(keep);
+    const int at = nlist + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep && at < 256) s.list[at] = d;
+    nlist += __popcll(m);
   }
+  nlist = nlist > 256 ? 256 : nlist;
   __syncthreads();
-  const int nlist = (int)bcast;
-  __syncthreads();
+  // ---- what the chain needs to know about each block, one lane per block: position, available reference samples (8.4.4.2.2:
+  // contiguous in scan order for one slice with full-width tiles), the mode's constants, the dequantiser's constants
+  bool any32 = false;
+  for (int k = lane; k < nlist; k += T) {
+    const DecTu t = s.list[k];
+    const int N = 1 << t.log2, nl = N << sh, Xc = t.x, Yc = t.y, X = Xc << sh, Y = Yc << sh, rx = Xc - cx * S, ry = Yc - cy * S;
+    const bool aL = dec_avail(f, X, Y, X - 1, Y), aT = dec_avail(f, X, Y, X, Y - 1), aTL = aL && aT && dec_avail(f, X, Y, X - 1, Y - 1);
+    const int nBL = (aL && dec_avail(f, X, Y, X - 1, Y + nl)) ? imin(N, hC - (Yc + N)) : 0;
+    const int nTR = (aT && dec_avail(f, X, Y, X + nl, Y - 1)) ? imin(N, wC - (Xc + N)) : 0;
+    const int lo = aL ? N - nBL : (aTL ? 2 * N : 2 * N + 1), hi = aT ? 3 * N + nTR : (aTL ? 2 * N : (aL ? 2 * N - 1 : 0));
+    const int zu = zunit8((rx << sh) >> 3, (ry << sh) >> 3);
+    int zprev = 0;
+    if (k > 0) { const DecTu p = s.list[k - 1]; zprev = zunit8(((p.x - cx * S) << sh) >> 3, ((p.y - cy * S) << sh) >> 3); }
+    IntraBlk d;
+    d.rx = (uint8_t)rx; d.ry = (uint8_t)ry; d.lo = (uint8_t)lo; d.hi = (uint8_t)hi; d.mode = t.mode; d.l2 = t.log2;
+    d.flags = (uint8_t)((intra_filter_needed(N, c ? 1 : 0, t.mode) ? IB_FILT : 0) | ((rx == 0 || ry == 0) ? IB_BORDER : 0) |
+                        (kv_intra_milestone(zu) > kv_intra_milestone(zprev) ? IB_PUBLISH : 0) | (t.count ? IB_LEVELS : 0) | ((t.flags & TU_TSKIP) ? IB_TSKIP : 0));
+    d.xf = (uint8_t)((t.log2 == 2 && (t.flags & TU_DST)) ? XF16_DST4 : (t.log2 - 1) & 3);
+    d.angle = (int16_t)kIntraAngle[t.mode]; d.inv = (int16_t)kInvAngle[t.mode];
+    d.zu = (uint16_t)zu; d.next = 0;
+    s.blk[k] = d;
+    s.dq[k] = dequant_pack(t.qp, t.log2);
+    any32 |= t.log2 == 5;
+  }
+  if (__ballot(any32) != 0) load_matrices(s.M, 0, KV_MATRIX_ENTRIES, lane, T);
   IntraBorders bd;
   {
     const int tile = f.ctu_tile[ctu];
@@ -503,8 +574,7 @@ __global__ __launch_bounds__(T) void k_dec_intra(DecFrame f)
     bd.nb_ur = cy > 0 && cx + 1 < f.wc && f.ctu_tile[ctu - f.wc + 1] == tile; bd.nb_ul = cy > 0 && cx > 0 && f.ctu_tile[ctu - f.wc - 1] == tile;
     bd.pl = my - 3; bd.pu = my - 3 * f.wc; bd.pur = bd.pu + 3; bd.pul = bd.pu - 3;
   }
-  borders_begin(bd, bc4);
-  int published = 0;
+  borders_begin(bd, bc4);                                  // (its barrier also publishes blk[] / dq[])
   // level words are fetched one block ahead: the loads of block k + 1 are in flight while block k is reconstructed
   uint32_t wnext[4] = {0, 0, 0, 0};
   auto fetch_words = [&](int k) {
@@ -514,28 +584,30 @@ __global__ __launch_bounds__(T) void k_dec_intra(DecFrame f)
     for (int q = 0; q < 4; q++) if (lane + q * T < cnt) wnext[q] = f.lev[off + lane + q * T];
   };
   fetch_words(0);
+  uint8_t *gdst = plane + (size_t)(cy * S) * cpitch + cx * S;
   for (int k = 0; k < nlist; k++) {
-    DecTu d;                                            // wave-uniform copy: positions, availability, mode constants go to the scalar unit
-    {
-      const uint32_t *q = (const uint32_t *)&s.list[k];
-      uint32_t u[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) u[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q[i]);
-      memcpy(&d, u, sizeof(d));
-    }
+    const IntraBlk d = wave_uniform(&s.blk[k]);            // (wave-uniform: what is derived from it runs on the scalar unit)
+    const uint32_t dqc = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.dq[k]);
+    const int cnt = __builtin_amdgcn_readfirstlane((int)s.list[k].count);
     uint32_t wreg[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) wreg[q] = wnext[q];
     fetch_words(k + 1);
-    const int rx = d.x - cx * S, ry = d.y - cy * S, N = 1 << d.log2;
-    const int zu = zunit8((rx << sh) >> 3, (ry << sh) >> 3);
-    if (kv_intra_milestone(zu) > kv_intra_milestone(published)) { publish_wt(my, (uint32_t)zu); published = zu; }
-    borders_need(bd, s.pic, DI_P, plane, cpitch, cx, cy, S, sh, wC - cx * S, rx, ry, N, &bcast, f.err, lane, T);
-    switch (d.log2) {
-      case 2: dec_intra_block<2, T>(f, s, d, c, cx, cy, rx, ry, lane, wreg); break;
-      case 3: dec_intra_block<3, T>(f, s, d, c, cx, cy, rx, ry, lane, wreg); break;
-      case 4: dec_intra_block<4, T>(f, s, d, c, cx, cy, rx, ry, lane, wreg); break;
-      default: dec_intra_block<5, T>(f, s, d, c, cx, cy, rx, ry, lane, wreg); break;
+    if (d.flags & IB_PUBLISH) publish_wt(my, (uint32_t)d.zu);
+    if (d.flags & IB_BORDER) borders_need(bd, s.pic, DI_P, plane, cpitch, cx, cy, S, sh, wC - cx * S, d.rx, d.ry, 1 << d.l2, &bcast, f.err, lane, T);
+    switch (d.l2) {
+      case 2: dec_intra_block_wave<2>(s, ws, d, dqc, cnt, c == 0, gdst, cpitch, lane, wreg); break;
+      case 3: dec_intra_block_wave<3>(s, ws, d, dqc, cnt, c == 0, gdst, cpitch, lane, wreg); break;
+      case 4: dec_intra_block_wave<4>(s, ws, d, dqc, cnt, c == 0, gdst, cpitch, lane, wreg); break;
+      default: {
+        DecTu t;
+        const uint32_t *q = (const uint32_t *)&s.list[k];
+        uint32_t u[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) u[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q[i]);
+        memcpy(&t, u, sizeof(t));
+        dec_intra_block<5, T>(f, s, t, c, cx, cy, d.rx, d.ry, lane, wreg);
+      }
     }
   }
   publish_wt(my, 64u);
@@ -730,15 +802,7 @@ __global__ __launch_bounds__(256) void k_dec_sao(DecFrame f)
 // launch wrappers
 // =============================================================================================
 void launch_dec_inter(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_inter, dim3(f.wc * 2, f.hc * 2), dim3(256), 0, st, f); }
-#ifndef KVZ_DEC_INTRA_THREADS
-#define KVZ_DEC_INTRA_THREADS 256
-#endif
-void launch_dec_intra(const DecFrame &f, hipStream_t st)
-{
-  static const int t = [] { const char *e = getenv("KVAZZUP_AMD_DEC_INTRA_THREADS"); return e ? atoi(e) : KVZ_DEC_INTRA_THREADS; }();   // (tuning knob)
-  if (t == 64) hipLaunchKernelGGL(k_dec_intra<64>, dim3(f.wc * f.hc * 3), dim3(64), 0, st, f);
-  else hipLaunchKernelGGL(k_dec_intra<256>, dim3(f.wc * f.hc * 3), dim3(256), 0, st, f);
-}
+void launch_dec_intra(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_intra, dim3(f.wc * f.hc * 3), dim3(64), 0, st, f); }
 void launch_dec_deblock(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_deblock, dim3(f.wc * f.hc), dim3(256), 0, st, f); }
 void launch_dec_sao(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_sao, dim3(f.wc * f.hc), dim3(256), 0, st, f); }
 

@@ -532,20 +532,14 @@ __shared__ long long g_prof[16];
 #else
 #define PROF(k) do { } while (0)
 #endif
-struct IntraWaveLds {
+struct IntraCtuLds {
   // The CTU being reconstructed with its borders, as one padded picture: row 0 = the sample row above the CTU
   // (above-left corner, above, above-right), column 15 = the sample column to its left, sample (x, y) of the
   // CTU at pic[(y + 1) * P + 16 + x], P = 16 + 2S.
   alignas(16) uint8_t pic[65 * 144];
-  alignas(16) uint8_t src[64 * 64];          // encoder: source samples of the CTU
-  alignas(16) int16_t lev[64 * 64];          // encoder: levels produced; decoder: levels to reconstruct from
-  alignas(16) int16_t A[32 * 32], B[32 * 32];
-  alignas(16) int16_t M[2][KV_MATRIX_ENTRIES];
-  // reference samples of the current block in the scan order of 8.4.4.2.2 (index 0 = bottom of the below-left
-  // group, 2n = corner, 4n = end of above-right): [0] as built, [1] filtered (8.4.4.2.3).  Sample i sits at
-  // byte 3 + i, which makes the "above" run (2n + 1 ...) dword aligned.  left[k] = R[2n - k], top[k] = R[2n + k].
-  alignas(16) uint8_t R[2][144];
-  uint32_t nzflag;                           // workgroups of more than one wave: "the block has non-zero levels"
+  alignas(16) uint8_t src[64 * 64];          // source samples of the CTU
+  alignas(16) int16_t lev[64 * 64];          // levels produced
+  alignas(16) XfLaneF16 xf[4][64];           // matrix operands of the transform stages, per (transform, lane)
 };
 
 // =============================================================================================
@@ -678,174 +672,75 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
   }
 }
 
-// One plane of one CU: block of n = 1 << L2 component samples at CTU-relative (rx, ry); (X, Y) = luma position
-// of the CU in the picture.  Returns whether the block has non-zero levels (encoder) / echoes has_levels (decoder).
-template <bool DEC, int L2, int T>
-__device__ __forceinline__ bool intra_block(const EncFrame &f, IntraWaveLds &s, int cidx, int S, int X, int Y, int rx, int ry,
-                                            int mode, int angle, int inv, int qp, bool has_levels, int lane)
+// One plane of one CU on one wave (kernel_common.h "One intra block per WAVE"): block of n = 1 << L2 component samples.
+// Returns whether the block has non-zero levels.
+template <int L2>
+__device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratch &ws, const IntraBlk &d, int cidx, int S, const QuantConst &q,
+                                                 uint8_t *gdst, int gp, int lane)
 {
-  constexpr int N = XW<L2, T>::N, OPL = XW<L2, T>::OPL, G = XW<L2, T>::G;
-  const int sh = cidx ? 1 : 0, nl = N << sh, P = 16 + 2 * S;
-  const bool filt = intra_filter_needed(N, cidx, mode);
-  if (T != 64 && lane == 0) s.nzflag = 0;                 // (a barrier follows before anyone sets it)
-  // ---- reference samples (8.4.4.2.2) and their filtered version (8.4.4.2.3).  Availability is decided per group
-  // of n samples (below-left, left, corner, above, above-right): each group lies in one block of this block's size,
-  // which either precedes this block in z-order or does not.  The available groups are contiguous in scan order,
-  // so the substitution process is a clamp of the scan index into [lo, hi].
-  {
-    const bool aL = X > 0, aT = avail64(f.cw, f.chp, X, Y, X, Y - 1);
-    const bool aBL = aL && avail64(f.cw, f.chp, X, Y, X - 1, Y + nl), aTR = aT && avail64(f.cw, f.chp, X, Y, X + nl, Y - 1);
-    const int lo = aBL ? 0 : (aL ? N : 2 * N + 1), hi = aTR ? 4 * N : (aT ? 3 * N : (aL ? 2 * N - 1 : -1));
-    auto fetch = [&](int i) -> int {
-      const int j = imin(imax(i, lo), hi);
-      const int col = j < 2 * N ? rx - 1 : rx + j - 2 * N - 1, rowp = j < 2 * N ? ry + 2 * N - j : ry;    // rowp = y + 1
-      return s.pic[rowp * P + 16 + col];
-    };
-    int c0 = 0, e0 = 0, e1 = 0; bool strong = false;
-    if (filt && N == 32 && hi >= 0) {
-      c0 = fetch(2 * N); e0 = fetch(0); e1 = fetch(4 * N);
-      strong = iabs(c0 + e1 - 2 * fetch(3 * N)) < 8 && iabs(c0 + e0 - 2 * fetch(N)) < 8;
-    }
-    for (int i = lane; i <= 4 * N; i += T) {
-      int v = 128, fv = 128;
-      if (hi >= 0) {
-        v = fetch(i); fv = v;
-        if (filt && i != 0 && i != 4 * N) {
-          if (strong) { if (i != 2 * N) { int k = i < 2 * N ? 2 * N - i : i - 2 * N; fv = ((64 - k) * c0 + k * (i < 2 * N ? e0 : e1) + 32) >> 6; } }
-          else fv = (fetch(i - 1) + 2 * v + fetch(i + 1) + 2) >> 2;
-        }
-      }
-      s.R[0][3 + i] = (uint8_t)v;
-      if (filt) s.R[1][3 + i] = (uint8_t)fv;
-    }
-  }
-  __syncthreads();
-  PROF(3);
-  const uint8_t *R = s.R[filt ? 1 : 0] + 3;
-  int dcv = 0;
-  if (mode == 1) {                                       // every lane sums the references itself: no reduction step
-    const uint32_t *r4 = (const uint32_t *)(s.R[0] + 3 + N + 1);           // dwords covering R[n + 1 .. 3n]
-    uint32_t acc = N + s.R[0][3 + N] - s.R[0][3 + 2 * N];                  // + left[n], - corner
-#pragma unroll
-    for (int k = 0; k < N / 2; k++) acc = __builtin_amdgcn_sad_u8(r4[k], 0u, acc);
-    dcv = (int)(acc >> (L2 + 1));
-  }
-  PROF(4);
-  // ---- prediction for the lane's samples: rows 2rp, 2rp + 1, columns g * OPL .. + OPL - 1
-  const bool active = lane < XW<L2, T>::LANES;
-  const int rp = lane / G, g = lane % G;
-  const bool edge = cidx == 0 && N < 32;                 // boundary smoothing of DC / pure horizontal / pure vertical
-  int pred[2][OPL];
+  constexpr int N = 1 << L2;
+  const int P = 16 + 2 * S, g = lane >> 4, c = lane & 15, rx = d.rx, ry = d.ry;
+  const bool active = c < N && 4 * g < N;
+  int pred[4], res[4] = {0, 0, 0, 0};
+  wave_intra_predict<L2>(s.pic, P, ws, d, cidx == 0, lane, g, c, pred);
   if (active) {
-    if (mode == 0) {
+    const uint32_t s4 = *(const uint32_t *)&s.src[(ry + c) * S + rx + 4 * g];
 #pragma unroll
-      for (int e = 0; e < 2; e++)
-#pragma unroll
-        for (int o = 0; o < OPL; o++) pred[e][o] = pred_planar<L2>(R, g * OPL + o, 2 * rp + e);
-    } else if (mode == 1) {
-#pragma unroll
-      for (int e = 0; e < 2; e++)
-#pragma unroll
-        for (int o = 0; o < OPL; o++) pred[e][o] = pred_dc<L2>(R, edge, dcv, g * OPL + o, 2 * rp + e);
-    } else {
-      const bool vert = mode >= 18, e2 = edge && (mode == 26 || mode == 10);
-#pragma unroll
-      for (int e = 0; e < 2; e++)
-#pragma unroll
-        for (int o = 0; o < OPL; o++) pred[e][o] = pred_angular<L2>(R, vert, e2, angle, inv, g * OPL + o, 2 * rp + e);
-    }
+    for (int r = 0; r < 4; r++) res[r] = (int)((s4 >> (8 * r)) & 255u) - pred[r];
   }
   PROF(5);
-  bool cbf = has_levels;
-  if (!DEC) {
-    // ---- residual -> A, forward rows -> B, forward columns + quantisation: levels -> s.lev, dequantised (transposed) -> A
-    if (active) {
+  // ---- forward rows, forward columns, quantiser; levels -> s.lev, dequantised coefficients stay in registers
+  const XfLaneF16 &xl = s.xf[d.xf][lane];
+  const kv_f16x4 ta = kv_h4(xl.ta), tb = kv_h4(xl.tb);
+  int y[4], co[4], dq[4] = {0, 0, 0, 0};
+  mfma16_data_a(res, ta, y);
 #pragma unroll
-      for (int e = 0; e < 2; e++)
-#pragma unroll
-        for (int o = 0; o < OPL; o++) {
-          int y = 2 * rp + e, x = g * OPL + o;
-          s.A[y * N + x] = (int16_t)((int)s.src[(ry + y) * S + rx + x] - pred[e][o]);
-        }
-    }
-    __syncthreads();
-    const int16_t *Mf = s.M[0] + matrix_offset(L2);
-    if (active) xf_stage<L2, OPL>(s.A, s.B, Mf, L2 - 1, rp, g);
-    __syncthreads();
-    PROF(6);
-    bool nz = false;
-    if (active) {
-      int acc[2][OPL];
-      xf_sums<L2, OPL>(s.B, Mf, rp, g, acc);
-      const int shift = L2 + 6, rnd = 1 << (shift - 1);
-#pragma unroll
-      for (int o = 0; o < OPL; o++) {
-        int lv[2];
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-          int c = clip3(-32768, 32767, (acc[e][o] + rnd) >> shift);
-          lv[e] = quant_level(c, qp, L2, 1);
-          nz |= lv[e] != 0;
-          s.A[(2 * rp + e) * N + g * OPL + o] = (int16_t)dequant_coef(lv[e], qp, L2);      // Dt[i'][j']
-        }
-        *(uint32_t *)&s.lev[(ry + g * OPL + o) * S + rx + 2 * rp] = pack_i16(lv[0], lv[1]);   // level (row j', columns i', i' + 1)
-      }
-    }
-    if (T == 64) cbf = __ballot(nz) != 0;
-    else { if (nz) s.nzflag = 1; }
-    __syncthreads();
-    if (T != 64) cbf = s.nzflag != 0;
-    PROF(7);
-  } else if (has_levels) {
-    if (active) {
-#pragma unroll
-      for (int e = 0; e < 2; e++)
-#pragma unroll
-        for (int o = 0; o < OPL; o++) {
-          int y = 2 * rp + e, x = g * OPL + o;               // level at row y, column x -> Dt[x][y]
-          s.A[x * N + y] = (int16_t)dequant_coef(s.lev[(ry + y) * S + rx + x], qp, L2);
-        }
-    }
-    __syncthreads();
-  }
-  // ---- inverse columns -> B, inverse rows + reconstruction
-  if (cbf) {
-    const int16_t *Mt = s.M[1] + matrix_offset(L2);
-    if (active) xf_stage<L2, OPL>(s.A, s.B, Mt, 7, rp, g);
-    __syncthreads();
-    PROF(8);
-    if (active) {
-      int acc[2][OPL];
-      xf_sums<L2, OPL>(s.B, Mt, rp, g, acc);
-#pragma unroll
-      for (int e = 0; e < 2; e++)
-#pragma unroll
-        for (int o = 0; o < OPL; o++) pred[e][o] = clip8(pred[e][o] + ((acc[e][o] + 2048) >> 12));
-    }
-  }
+  for (int r = 0; r < 4; r++) y[r] = (y[r] + (1 << (L2 - 2))) >> (L2 - 1);
+  mfma16_data_b(ta, y, co);
+  PROF(6);
+  bool nz = false;
   if (active) {
 #pragma unroll
-    for (int e = 0; e < 2; e++)
-#pragma unroll
-      for (int o = 0; o < OPL; o++) s.pic[(ry + 2 * rp + e + 1) * P + 16 + rx + g * OPL + o] = (uint8_t)pred[e][o];
+    for (int r = 0; r < 4; r++) {
+      const int cf = clip3(-32768, 32767, (co[r] + (1 << (L2 + 5))) >> (L2 + 6));
+      const int lv = quant_level_q(cf, q);
+      nz |= lv != 0;
+      dq[r] = dequant_coef_q(lv, q);
+      s.lev[(ry + 4 * g + r) * S + rx + c] = (int16_t)lv;
+    }
   }
-  __syncthreads();
+  const bool cbf = __ballot(nz) != 0;
+  PROF(7);
+  if (cbf) {
+    wave_inverse16(ws, tb, dq, g, c, res);
+#pragma unroll
+    for (int r = 0; r < 4; r++) pred[r] = clip8(pred[r] + res[r]);
+  }
+  PROF(8);
+  if (active) {
+    const uint32_t o = (uint32_t)pred[0] | ((uint32_t)pred[1] << 8) | ((uint32_t)pred[2] << 16) | ((uint32_t)pred[3] << 24);
+    *(uint32_t *)&s.pic[(ry + c + 1) * P + 16 + rx + 4 * g] = o;
+    st_wt_u32(gdst + (size_t)(ry + c) * gp + rx + 4 * g, o);             // write-through: the neighbouring CTUs' workgroups read it from the picture
+  }
+  wave_sync();
   PROF(9);
   return cbf;
 }
 
-// One workgroup of T threads per (CTU, colour plane).  The CTU's coding units are reconstructed in z-order; CTUs are coupled by
+// One workgroup (one wave) per (CTU, colour plane).  The CTU's coding units are reconstructed in z-order; CTUs are coupled by
 // progress counters that count the CTU's finished 8x8 luma units (f.sync: [CTU][plane]), published at the values neighbours wait
 // for.  A block waits only for the part of the left / upper / upper-right CTU it reads -- with coding units of at most 16x16 a CTU
 // starts when half of its left neighbour is done, not when it is complete -- and the neighbours' samples are copied into the CTU
 // picture's borders piecewise, as far as their progress allows.  (The decoder's k_dec_intra is the same scheme driven by the
-// transform-block list.)  Workgroups are dispatched in CTU raster order, so whatever a workgroup waits for is already running.
-template <int T>
-__global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
+// transform-block list.)
+__global__ __launch_bounds__(64) void k_intra_recon(EncFrame f)
 {
-  __shared__ IntraWaveLds s;
+  constexpr int T = 64;
+  __shared__ IntraCtuLds s;
+  __shared__ IntraWaveScratch ws;
   __shared__ uint32_t bcast, bc4[4];
-  __shared__ uint8_t cu_l2[64], cu_mode[64], cu_cbf_s[64];
+  __shared__ IntraBlk blk[64];                              // by z of the coding unit's first 8x8 unit
+  __shared__ uint8_t cu_cbf_s[64];
   // Workgroups are dispatched in blockIdx order and a picture has more of them than fit on the chip at once, so they are numbered
   // the way the wavefront advances (f.intra_order: by cx + 2 cy -- every CTU a block depends on comes earlier) instead of in raster
   // order, where the right ends of the upper rows would hold the slots the lower left needs.
@@ -853,12 +748,28 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
   const int row = ctu / wc, cx = ctu % wc;
   const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, P = 16 + 2 * S;
   uint32_t *my = f.sync + (size_t)ctu * 3 + c;
-  load_matrices(s.M, 0, KV_MATRIX_ENTRIES, lane, T);
+  for (int i = lane; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];
   const int qpl = ctu_quant_qp(f, cx * 64, row * 64), qp = c ? kChromaQp[qpl] : qpl;
-  if (lane < 64) {
+  // ---- everything the chain needs to know about the CTU's blocks, one lane per 8x8 unit (z-order)
+  {
     int zx, zy; ctu_z_to_xy(lane, zx, zy);
-    const int bi = b8idx(f, cx * 64 + zx * 8, row * 64 + zy * 8);
-    cu_l2[lane] = f.cu_log2[bi]; cu_mode[lane] = f.cu_intra_mode[bi]; cu_cbf_s[lane] = 0;
+    const int X = cx * 64 + zx * 8, Y = row * 64 + zy * 8, bi = b8idx(f, X, Y);
+    const int l2 = f.cu_log2[bi], mode = f.cu_intra_mode[bi], n = 1 << (l2 - sh), nl = 1 << l2;
+    cu_cbf_s[lane] = 0;
+    const bool aL = X > 0, aT = avail64(f.cw, f.chp, X, Y, X, Y - 1);
+    const bool aBL = aL && avail64(f.cw, f.chp, X, Y, X - 1, Y + nl), aTR = aT && avail64(f.cw, f.chp, X, Y, X + nl, Y - 1);
+    IntraBlk d;
+    d.rx = (uint8_t)((zx * 8) >> sh); d.ry = (uint8_t)((zy * 8) >> sh);
+    // availability is decided per group of n samples (below-left, left, corner, above, above-right): each group lies in one block
+    // of this block's size, which either precedes this block in z-order or does not; the available groups are contiguous
+    d.lo = (uint8_t)(aBL ? 0 : (aL ? n : 2 * n + 1)); d.hi = (uint8_t)(aTR ? 4 * n : (aT ? 3 * n : (aL ? 2 * n - 1 : 0)));      // (nothing available: lo = 2n + 1 > hi = 0)
+    d.mode = (uint8_t)mode; d.l2 = (uint8_t)(l2 - sh);
+    d.flags = (uint8_t)((intra_filter_needed(n, c ? 1 : 0, mode) ? IB_FILT : 0) | ((zx == 0 || zy == 0) ? IB_BORDER : 0) |
+                        ((lane == 24 || lane == 32 || lane == 44 || lane == 48 || lane == 56 || lane == 60) ? IB_PUBLISH : 0));
+    d.xf = (uint8_t)((l2 - sh == 2 && c == 0) ? XF16_DST4 : l2 - sh - 1);
+    d.angle = (int16_t)kIntraAngle[mode]; d.inv = (int16_t)kInvAngle[mode];
+    d.zu = (uint16_t)lane; d.next = (uint16_t)(lane + (1 << (2 * (l2 - 3))));
+    blk[lane] = d;
   }
   const uint8_t *gsrc = f.src[c] + (size_t)(row * S) * pw + cx * S;
   uint8_t *plane = f.rec[c];
@@ -877,39 +788,30 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
   if (lane == 0) g_prof[15] = clock64();
 #endif
   borders_begin(bd, bc4);
-  int published = 0;
   unsigned long long tb = 0, tk = 0, ts = 0, tp = 0, nblk = 0, tq = 0;       // trace: time in border waits / block / store / publish
 #define KV_LAP(acc) do { if (f.trace) { const unsigned long long n_ = wall_clock64(); acc += n_ - tq; tq = n_; } } while (0)
   if (f.trace) tq = wall_clock64();
+  const QuantConst q8 = quant_const(qp, 3 - sh, 1), q16 = quant_const(qp, 4 - sh, 1);      // (coding units are 8x8 or 16x16)
   for (int z = 0; z < 64;) {
-    // (made wave-uniform explicitly: everything derived from them -- positions, availability, the mode's constants -- then runs on
-    // the scalar unit instead of in every lane)
-    const int l2 = __builtin_amdgcn_readfirstlane((int)cu_l2[z]), mode = __builtin_amdgcn_readfirstlane((int)cu_mode[z]), n = 1 << (l2 - sh);
-    const int angle = kIntraAngle[mode], inv = kInvAngle[mode];
-    int xi, yi; ctu_z_to_xy(z, xi, yi);
-    const int X = cx * 64 + xi * 8, Y = row * 64 + yi * 8, rx = (xi * 8) >> sh, ry = (yi * 8) >> sh;
-    if (kv_intra_milestone(z) > kv_intra_milestone(published)) { publish_wt(my, (uint32_t)z); published = z; }
+    const IntraBlk d = wave_uniform(&blk[z]);              // (wave-uniform: what is derived from it runs on the scalar unit)
+    if (d.flags & IB_PUBLISH) { publish_wt(my, (uint32_t)z); if (f.trace && z == 32) ts = wall_clock64(); }
     KV_LAP(tp);
+    PROF(1);
     // the neighbouring CTUs' samples this block reads: wait for them, copy them into the borders of the CTU picture
-    borders_need(bd, s.pic, P, plane, pw, cx, row, S, sh, 2 * S, rx, ry, n, &bcast, f.err, lane, T);
+    if (d.flags & IB_BORDER) borders_need(bd, s.pic, P, plane, pw, cx, row, S, sh, 2 * S, d.rx, d.ry, 1 << d.l2, &bcast, f.err, lane, T);
     KV_LAP(tb);
     PROF(2);
     if (f.trace && lane == 0 && z == 0) f.trace[((size_t)ctu * 3 + c) * 8 + 1] = wall_clock64();
     bool cbf;
-    switch (l2 - sh) {
-      case 2: cbf = intra_block<false, 2, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, false, lane); break;
-      case 3: cbf = intra_block<false, 3, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, false, lane); break;
-      case 4: cbf = intra_block<false, 4, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, false, lane); break;
-      default: cbf = intra_block<false, 5, T>(f, s, c, S, X, Y, rx, ry, mode, angle, inv, qp, false, lane); break;
+    switch (d.l2) {
+      case 2: cbf = intra_block_wave<2>(s, ws, d, c, S, q8, grec, pw, lane); break;
+      case 3: cbf = intra_block_wave<3>(s, ws, d, c, S, c ? q16 : q8, grec, pw, lane); break;
+      default: cbf = intra_block_wave<4>(s, ws, d, c, S, q16, grec, pw, lane); break;
     }
     KV_LAP(tk); nblk++;
     PROF(10);
-    // block -> picture, write-through: the neighbouring CTUs' workgroups read it from there
-    store_block_wt(grec + (size_t)ry * pw + rx, pw, &s.pic[(ry + 1) * P + 16 + rx], P, n, lane, T);
-    KV_LAP(ts);
-    const int cnt = 1 << (2 * (l2 - 3));
-    if (cbf && lane < cnt) cu_cbf_s[z + lane] = 1;
-    z += cnt;
+    if (cbf && z + lane < d.next) cu_cbf_s[z + lane] = 1;
+    z = d.next;
   }
   for (int k = lane; k < S * S / 8; k += T) { int y = k / (S / 8), xq = k % (S / 8); *(uint4 *)&gcoef[(size_t)y * pw + xq * 8] = *(const uint4 *)&s.lev[y * S + xq * 8]; }
   __syncthreads();
@@ -921,8 +823,7 @@ __global__ __launch_bounds__(T) void k_intra_recon(EncFrame f)
   publish_wt(my, 64u);
 #ifdef KVZ_PROF
   __syncthreads();
-  if (f.trace && c == 0 && lane < 16) f.trace[((size_t)ctu * 3 + 1) * 8 + (lane & 7) + (lane >> 3) * 8] = (unsigned long long)g_prof[lane];   // (over the chroma planes' slots)
-  if (c) return;
+  if (f.trace && c == 0 && lane < 16) f.trace[(size_t)(f.cw / 64) * band_rows(f) * 24 + (size_t)ctu * 16 + lane] = (unsigned long long)g_prof[lane];   // (second half of the trace buffer)
 #endif
   if (f.trace && lane == 0) { unsigned long long *t = f.trace + ((size_t)ctu * 3 + c) * 8; t[2] = wall_clock64(); t[3] = tb; t[4] = tk; t[5] = ts; t[6] = tp; t[7] = nblk; }
 }
@@ -1669,10 +1570,7 @@ void launch_inter_signal(const EncFrame &f, hipStream_t st)
   hipLaunchKernelGGL(k_inter_signal, dim3((n + 255) / 256), dim3(256), 0, st, f);
 }
 void launch_intra_analyse(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_analyse, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f); }
-#ifndef KVZ_INTRA_THREADS
-#define KVZ_INTRA_THREADS 256
-#endif
-void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL((k_intra_recon<KVZ_INTRA_THREADS>), dim3(3 * (f.cw / 64) * band_rows(f)), dim3(KVZ_INTRA_THREADS), 0, st, f); }
+void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_recon, dim3(3 * (f.cw / 64) * band_rows(f)), dim3(64), 0, st, f); }
 void launch_qp_resolve(const EncFrame &f, hipStream_t st)
 {
   if (!f.ctu_qy) return;

@@ -367,4 +367,287 @@ __device__ __forceinline__ int pred_angular(const uint8_t *R, bool vert, bool ed
 }
 
 
+// =============================================================================================
+// One intra block per WAVE, transforms on the matrix cores.
+//
+// A block of n x n samples (n = 4, 8, 16) is handled by one wave with no workgroup barrier anywhere; lane (g, c) = (lane >> 4,
+// lane & 15) owns the four samples x = 4g .. 4g + 3 of row y = c ("row owner"; lanes outside the block idle).  The four
+// transform stages are 16x16x16 matrix products on v_mfma_f32_16x16x16_f16, exact because every operand is an integer of at
+// most 11 bits (matrix entries |t| <= 90, residuals |r| <= 255, 16-bit intermediates split into a signed high byte and an
+// unsigned low byte -> two products) and every sum stays below 2^24.  MFMA operand layouts (A[m][k]: lane holds m = c,
+// k = 4g + r; B[k][n]: k = 4g + r, n = c; D[m][n]: m = 4g + r, n = c) chain the stages through registers:
+//   forward rows      Y = X Tt      A = X (row owner)        B[k][n] = T[n][k]  (ta)      -> Y[y = 4g + r][j = c]
+//   forward columns   C = T Y       A[m][k] = T[m][k] (ta)   B = Y                        -> C[u = 4g + r][j = c]
+//   inverse columns   W = Tt C'     A[m][k] = T[k][m] (tb)   B = C'                       -> W[y = 4g + r][j = c]
+//   inverse rows      X't = Tt Wt   A[m][k] = T[k][m] (tb)   B = Wt                       -> X'[y = c][x = 4g + r]
+// and only W is transposed through LDS (256 int16 of per-wave scratch).  Smaller transforms are the 16-point product with the
+// matrix zero outside n x n.  ta / tb per lane: XfLaneF16, one table entry per (transform, lane).
+// =============================================================================================
+typedef _Float16 kv_f16x4 __attribute__((ext_vector_type(4)));
+typedef float kv_f32x4 __attribute__((ext_vector_type(4)));
+struct alignas(16) XfLaneF16 { uint16_t ta[4], tb[4]; };        // f16 bit patterns: T[c][4g + r], T[4g + r][c]
+enum { XF16_DST4 = 0, XF16_DCT4 = 1, XF16_DCT8 = 2, XF16_DCT16 = 3 };
+struct XfF16Tables { XfLaneF16 t[4][64]; };
+constexpr uint16_t f16_bits_of_int(int v)                       // |v| < 2048
+{
+  if (v == 0) return 0;
+  const uint16_t sign = v < 0 ? 0x8000 : 0;
+  const int a = v < 0 ? -v : v;
+  int e = 0;
+  while ((a >> (e + 1)) != 0) e++;
+  return (uint16_t)(sign | ((e + 15) << 10) | ((a << (10 - e)) & 0x3ff));
+}
+constexpr XfF16Tables make_xf_f16_tables()
+{
+  XfF16Tables t{};
+  for (int type = 0; type < 4; type++) {
+    const int l2 = type == XF16_DCT16 ? 4 : (type == XF16_DCT8 ? 3 : 2), n = 1 << l2;
+    for (int lane = 0; lane < 64; lane++) {
+      const int g = lane >> 4, c = lane & 15;
+      for (int r = 0; r < 4; r++) {
+        const int k = 4 * g + r;
+        int a = 0, b = 0;
+        if (c < n && k < n) {
+          a = type == XF16_DST4 ? kDst4[c][k] : kDct32[c << (5 - l2)][k];
+          b = type == XF16_DST4 ? kDst4[k][c] : kDct32[k << (5 - l2)][c];
+        }
+        t.t[type][lane].ta[r] = f16_bits_of_int(a); t.t[type][lane].tb[r] = f16_bits_of_int(b);
+      }
+    }
+  }
+  return t;
+}
+static __device__ const XfF16Tables g_xf16 = make_xf_f16_tables();
+
+struct alignas(16) IntraWaveScratch {
+  // what the prediction reads.  Planar / DC: the reference samples in the scan order of 8.4.4.2.2 (index 0 = bottom of the
+  // below-left group, 2n = corner, 4n = end of above-right; as built or filtered, 8.4.4.2.3), sample i at byte 3 + i, which makes
+  // the "above" run (2n + 1 ...) dword aligned: left[k] = R[2n - k], top[k] = R[2n + k].  Angular: the array ref[] of 8.4.4.2.6
+  // with its projected part, ref[k] at byte n + k, k = -n .. 2n.
+  uint8_t R[80];
+  int16_t tr[256];                    // W between the inverse stages; decoder: also where the level words are scattered to
+};
+
+// LDS traffic inside one wave needs no barrier instruction (a wave's LDS instructions execute in order); this keeps the compiler
+// from moving accesses across the point where lanes exchange data
+__device__ __forceinline__ void wave_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ kv_f16x4 kv_h4(const uint16_t (&b)[4])
+{
+  const uint2 u = *(const uint2 *)b;
+  return __builtin_bit_cast(kv_f16x4, u);
+}
+// D = A B with the DATA as B operand: 16-bit signed integers d[r] = B[4g + r][c]; A = matrix constants
+__device__ __forceinline__ void mfma16_data_b(kv_f16x4 a, const int (&d)[4], int (&out)[4])
+{
+  kv_f16x4 bh, bl;
+#pragma unroll
+  for (int r = 0; r < 4; r++) { bh[r] = (_Float16)(short)(d[r] >> 8); bl[r] = (_Float16)(unsigned short)(d[r] & 255); }
+  const kv_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const kv_f32x4 sh = __builtin_amdgcn_mfma_f32_16x16x16f16(a, bh, z, 0, 0, 0);
+  const kv_f32x4 sl = __builtin_amdgcn_mfma_f32_16x16x16f16(a, bl, z, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; r++) out[r] = ((int)sh[r] << 8) + (int)sl[r];
+}
+// D = A B with the DATA as A operand: integers of at most 11 bits d[r] = A[c][4g + r]
+__device__ __forceinline__ void mfma16_data_a(const int (&d)[4], kv_f16x4 b, int (&out)[4])
+{
+  kv_f16x4 a;
+#pragma unroll
+  for (int r = 0; r < 4; r++) a[r] = (_Float16)(short)d[r];
+  const kv_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const kv_f32x4 s = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, z, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; r++) out[r] = (int)s[r];
+}
+
+// What the serial chain of a (CTU, plane) needs to know about one intra block, worked out for all blocks of the CTU in parallel
+// before the chain starts (positions, availability of the neighbours, the mode's constants): the chain itself only reads it.
+struct alignas(16) IntraBlk {
+  uint8_t rx, ry;            // position in the CTU, samples of the block's plane
+  uint8_t lo, hi;            // the available reference samples are [lo, hi] in scan order (contiguous; hi < lo: none)
+  uint8_t mode, l2;          // prediction mode; log2 of the size in samples of the block's plane (2 .. 5)
+  uint8_t flags, xf;         // IB_*; transform table (XF16_*)
+  int16_t angle, inv;        // intraPredAngle, invAngle (8.4.4.2.6)
+  uint16_t zu, next;         // first 8x8 luma unit of the CTU the block lies in (z-order); encoder: z of the next block
+};
+enum { IB_FILT = 1,          // the filtered reference samples are used (8.4.4.2.3)
+       IB_BORDER = 2,        // the block touches the CTU's left or upper border (the neighbouring CTUs' samples may have to be waited for)
+       IB_PUBLISH = 4,       // progress `zu` is worth publishing before this block (a neighbour may be waiting for it)
+       IB_LEVELS = 8, IB_TSKIP = 16 };      // decoder: the block has levels; transform_skip_flag
+__device__ __forceinline__ IntraBlk wave_uniform(const IntraBlk *p)
+{
+  const uint4 u = *(const uint4 *)p;
+  uint32_t w[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)u.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)u.y),
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)u.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)u.w)};
+  IntraBlk d;
+  memcpy(&d, w, sizeof(d));
+  return d;
+}
+
+// Prediction of one block on one wave: pred[r] = sample (x = 4g + r, y = c) for the lanes inside the block.  `pic` is the CTU
+// picture with its borders (pitch P, sample (x, y) at pic[(y + 1) * P + 16 + x]).  Lane i first holds reference sample i of the
+// scan order (the substitution process of 8.4.4.2.2 is a clamp of the scan index into [lo, hi]; the [1 2 1] filter takes its
+// neighbours over DPP); what the mode reads is then laid out in ws.R -- the scan-order array for planar and DC, ref[] with the
+// projected side samples for the angular modes (lanes fetch their entry from the lane that holds it: ds_bpermute).
+template <int L2>
+__device__ __forceinline__ void wave_intra_predict(const uint8_t *pic, int P, IntraWaveScratch &ws, const IntraBlk &d, bool luma, int lane, int g, int c, int (&pred)[4])
+{
+  constexpr int N = 1 << L2;
+  const int rx = d.rx, ry = d.ry, lo = d.lo, hi = d.hi, mode = d.mode;
+  int v = 128, last = 128;
+  if (hi >= lo) {
+    auto at = [&](int i) -> int {
+      const int j = imin(imax(i, lo), hi);
+      const bool left = j < 2 * N;
+      return (left ? ry + 2 * N - j : ry) * P + 16 + (left ? rx - 1 : rx + j - 2 * N - 1);
+    };
+    v = pic[at(imin(lane, 4 * N))];
+    if (N == 16) last = pic[at(4 * N)];
+  }
+  if (d.flags & IB_FILT) {
+    const int prev = __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false);      // wave_shr:1 -- lane i <- lane i - 1
+    int next = __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false);            // wave_shl:1 -- lane i <- lane i + 1
+    if (N == 16 && lane == 63) next = last;
+    if (lane != 0 && lane < 4 * N) v = (prev + 2 * v + next + 2) >> 2;
+  }
+  if (mode >= 2) {
+    // ---- angular (8.4.4.2.6).  sgn walks the main side in scan order: +1 above (modes 18 ..), -1 left
+    const int angle = d.angle, inv = d.inv;
+    const bool vert = mode >= 18;
+    const int sgn = vert ? 1 : -1;
+    {
+      const int k = lane - N, i = 2 * N + sgn * (k >= 0 ? k : -((k * inv + 128) >> 8));
+      int e = __builtin_amdgcn_ds_bpermute(4 * i, v);
+      if (N == 16 && i == 64) e = last;
+      if (lane <= 3 * N) ws.R[lane] = (uint8_t)e;
+    }
+    int side = 0;
+    const bool edge = luma && angle == 0;                   // (n < 32) modes 10 and 26: the first column / row follows the side samples
+    if (edge) side = __builtin_amdgcn_ds_bpermute(4 * (2 * N - sgn * (1 + (vert ? c : 4 * g))), v);      // (unfiltered: these modes never filter)
+    wave_sync();
+    if (vert) {
+      const int t = (c + 1) * angle, f = t & 31;
+      const uint8_t *e = ws.R + N + 4 * g + (t >> 5) + 1;
+      int s[5];
+#pragma unroll
+      for (int r = 0; r < 5; r++) s[r] = e[r];
+#pragma unroll
+      for (int r = 0; r < 4; r++) pred[r] = ((32 - f) * s[r] + f * s[r + 1] + 16) >> 5;
+      if (edge && g == 0) pred[0] = clip8(ws.R[N + 1] + ((side - ws.R[N]) >> 1));
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int t = (4 * g + r + 1) * angle, f = t & 31;
+        const uint8_t *e = ws.R + N + c + (t >> 5) + 1;
+        pred[r] = ((32 - f) * e[0] + f * e[1] + 16) >> 5;
+      }
+      if (edge) {
+        // row 0 of mode 10 follows the above samples: side of lane (g, 0) = top[1 + 4g]; the other three come the same way
+        int sd[4] = {side, 0, 0, 0};
+#pragma unroll
+        for (int r = 1; r < 4; r++) sd[r] = __builtin_amdgcn_ds_bpermute(4 * (2 * N + 1 + 4 * g + r), v);
+        if (c == 0) {
+          const int corner = ws.R[N], first = ws.R[N + 1];
+#pragma unroll
+          for (int r = 0; r < 4; r++) pred[r] = clip8(first + ((sd[r] - corner) >> 1));
+        }
+      }
+    }
+  } else {
+    if (N == 16 || lane <= 4 * N) ws.R[3 + lane] = (uint8_t)v;
+    if (N == 16 && lane == 0) ws.R[3 + 64] = (uint8_t)last;
+    uint32_t dcv = 0;
+    if (mode == 1) {
+      const uint32_t part = (lane >= N && lane <= 3 * N && lane != 2 * N) ? (uint32_t)v : 0u;    // left[1 .. n] and top[1 .. n]
+      dcv = (wave_sum_u32(part) + N) >> (L2 + 1);
+    }
+    wave_sync();
+    const uint8_t *R = ws.R + 3;
+    const uint32_t top4 = *(const uint32_t *)(R + 2 * N + 1 + 4 * g);      // top[1 + 4g ..]
+    const int lft = R[2 * N - 1 - c];                                        // left[1 + y]
+    if (mode == 0) {
+      const int tr = R[3 * N + 1], bl = R[N - 1];
+      const int base = (c + 1) * bl + N;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int x = 4 * g + r;
+        pred[r] = ((N - 1 - x) * lft + (x + 1) * tr + (N - 1 - c) * (int)((top4 >> (8 * r)) & 255u) + base) >> (L2 + 1);
+      }
+    } else {
+      const int dc = (int)dcv;
+#pragma unroll
+      for (int r = 0; r < 4; r++) pred[r] = dc;
+      if (luma) {                                           // (n < 32) boundary smoothing
+        if (c == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) pred[r] = ((int)((top4 >> (8 * r)) & 255u) + 3 * dc + 2) >> 2;
+        }
+        if (g == 0) pred[0] = c == 0 ? (lft + 2 * dc + (int)(top4 & 255u) + 2) >> 2 : (lft + 3 * dc + 2) >> 2;
+      }
+    }
+  }
+}
+
+// per-block constants of the flat quantiser / dequantiser (hevc_core.h quant_level / dequant_coef, the same arithmetic in 32 bits
+// where that is exact: |coefficient| <= 32768 times a scale <= 26214 plus the offset stays below 2^31)
+struct QuantConst { int qscale, qshift, qoff, dscale, dsa, drnd, dsb; };
+__device__ __forceinline__ QuantConst quant_const(int qp, int log2n, int intra)
+{
+  QuantConst q;
+  q.qshift = 14 + qp / 6 + (15 - 8 - log2n);
+  q.qscale = kQuantScale[qp % 6];
+  q.qoff = (intra ? 171 : 85) << (q.qshift - 9);
+  // (level * 16 * (scale << qp / 6) + (1 << (bd - 1))) >> bd with bd = log2n + 3: either the left shift absorbs bd (no rounding
+  // happens) or the whole product stays below 2^31
+  const int s1 = 4 + qp / 6, bd = 8 + log2n - 5;
+  q.dscale = kLevelScale[qp % 6];
+  if (s1 >= bd) { q.dsa = s1 - bd; q.drnd = 0; q.dsb = 0; } else { q.dsa = s1; q.drnd = 1 << (bd - 1); q.dsb = bd; }
+  return q;
+}
+__device__ __forceinline__ int quant_level_q(int coef, const QuantConst &q)
+{
+  const uint32_t a = (uint32_t)iabs(coef);
+  const int lv = imin((int)((a * (uint32_t)q.qscale + (uint32_t)q.qoff) >> q.qshift), 32767);
+  return coef < 0 ? -lv : lv;
+}
+__device__ __forceinline__ int dequant_coef_q(int level, const QuantConst &q)      // level: 16 bits
+{
+  // |level * scale| < 2^22, shifted left by at most 7: 32 bits hold it
+  return clip3(-32768, 32767, (((level * q.dscale) << q.dsa) + q.drnd) >> q.dsb);
+}
+
+// the dequantiser's constants of one block in one word (decoder: per transform block, worked out ahead of the chain)
+__device__ __forceinline__ uint32_t dequant_pack(int qp, int log2n)
+{
+  const QuantConst q = quant_const(qp, log2n, 0);
+  return (uint32_t)q.dscale | ((uint32_t)q.dsa << 8) | ((uint32_t)q.dsb << 16);
+}
+__device__ __forceinline__ int dequant_coef_p(int level, uint32_t pk)
+{
+  const int dsb = (int)(pk >> 16) & 255;
+  return clip3(-32768, 32767, (((level * (int)(pk & 255u)) << ((pk >> 8) & 255u)) + (dsb ? 1 << (dsb - 1) : 0)) >> dsb);
+}
+
+// inverse transform of the dequantised coefficients dq[r] = C'[u = 4g + r][j = c] -> residual of the lane's samples (row owner)
+__device__ __forceinline__ void wave_inverse16(IntraWaveScratch &ws, kv_f16x4 tb, const int (&dq)[4], int g, int c, int (&res)[4])
+{
+  int w[4];
+  mfma16_data_b(tb, dq, w);
+#pragma unroll
+  for (int r = 0; r < 4; r++) ws.tr[(4 * g + r) * 16 + c] = (int16_t)clip3(-32768, 32767, (w[r] + 64) >> 7);
+  wave_sync();
+  const uint2 t = *(const uint2 *)&ws.tr[c * 16 + 4 * g];
+  const int wt[4] = {(int)(int16_t)(t.x & 0xffffu), (int)(int16_t)(t.x >> 16), (int)(int16_t)(t.y & 0xffffu), (int)(int16_t)(t.y >> 16)};
+  int x[4];
+  mfma16_data_b(tb, wt, x);
+#pragma unroll
+  for (int r = 0; r < 4; r++) res[r] = (x[r] + 2048) >> 12;
+  wave_sync();                                             // (ws.tr is free again)
+}
+
 }  // namespace kvzx

@@ -14,9 +14,9 @@ e = Encoder(w, h, options=(("qp", 32), ("period", 1), ("me-range", 16)))
 for t in range(3):
     e.encode(synth.frame(synth.MOVING, 0x5EED0002, w, h, t))
 wc, hc = (w + 63) // 64, (h + 63) // 64
-buf = np.zeros(wc * hc * 24, dtype=np.uint64)
+buf = np.zeros(wc * hc * 40, dtype=np.uint64)
 assert e.lib.kvzx_encoder_debug_copy(e.enc, b"trace", buf.ctypes.data, buf.nbytes)
-tr = buf.reshape(hc, wc, 3, 8).astype(np.int64)
+tr = buf[:wc * hc * 24].reshape(hc, wc, 3, 8).astype(np.int64)
 t0 = tr[..., 0].min()
 us = (tr - t0) / 100.0
 for c in range(3):
@@ -26,8 +26,11 @@ for c in range(3):
     print("  first-block time along row 0 (every 4th CTU):", np.round(fb[0, ::4]).astype(int).tolist())
     print("  first-block time down column 0:", np.round(fb[:, 0]).astype(int).tolist())
     nb = tr[:, :, c, 7].astype(float)
-    print("  per CTU: blocks %.1f; us in border waits %.1f, in blocks %.1f (%.2f per block), in stores %.1f, in publishes %.1f" %
+    print("  per CTU: blocks %.1f; us in border waits %.1f, in blocks %.1f (%.2f per block), (slot 5 %.1f), in publishes %.1f" %
           (nb.mean(), tr[:, :, c, 3].mean() / 100, tr[:, :, c, 4].mean() / 100, (tr[:, :, c, 4] / np.maximum(nb, 1)).mean() / 100, tr[:, :, c, 5].mean() / 100, tr[:, :, c, 6].mean() / 100))
+    p32 = us[:, :, c, 5]
+    print("  hand-off: first block after the left neighbour's publish(32): mean %.1f us, median %.1f; publish(32) after own first block: mean %.1f us" %
+          ((fb[:, 1:] - p32[:, :-1]).mean(), np.median(fb[:, 1:] - p32[:, :-1]), (p32 - fb).mean()))
     print("  lag to the left neighbour's first block, mean %.1f us; to the upper neighbour's, mean %.1f us" %
           ((fb[:, 1:] - fb[:, :-1]).mean(), (fb[1:, :] - fb[:-1, :]).mean()))
 d = None

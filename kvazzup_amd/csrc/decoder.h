@@ -201,7 +201,7 @@ class Decoder {
   std::vector<uint8_t> rbsp_;
   std::vector<size_t> epb_;                // unescaped payload offset of every removed emulation prevention byte
   std::vector<size_t> sub_start_;          // start of every substream inside the unescaped slice data
-  std::unique_ptr<OrderedPool> pool_; int parse_threads_ = 16;
+  std::unique_ptr<OrderedPool> pool_; int parse_threads_ = 16; std::mutex pool_mutex_;   // (frame workers: one picture at a time on the row pool)
   PicJob *timed_job_ = nullptr;
   double k_ms_[DK_COUNT] = {0}; uint64_t k_n_[DK_COUNT] = {0};
   template <class F> void timed(int id, F &&launch);

@@ -1176,9 +1176,15 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     PicJob *jp = &job;
     workers_->submit([this, jp] {
       auto t0 = std::chrono::steady_clock::now();
-      jp->rc = parse_job(*jp, false);
+      // a large picture (an intra picture: several milliseconds on one core, which the pictures behind it in the ring cannot
+      // hide) has its substreams parsed side by side on the row pool; small ones stay on this worker
+      bool rows = false;
+      if (jp->data_len > (64u << 10) && pool_mutex_.try_lock()) rows = true;
+      jp->rc = parse_job(*jp, rows);
+      if (rows) pool_mutex_.unlock();
       jp->parse_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       jp->state.store(2, std::memory_order_release);
+      futex_wake_all(jp->state);
     });
   }
   if (job_head_ - job_tail_ < frame_threads_) return 0;          // pipeline still filling: no output for this NAL
@@ -1197,7 +1203,7 @@ int Decoder::finish_oldest()
   if (job_head_ != job_tail_) {
     PicJob &job = jobs_[(size_t)(job_tail_ % jobs_.size())];
     job_tail_++;
-    { Tick tk; while (job.state.load(std::memory_order_acquire) != 2) std::this_thread::yield(); t_wait_ += tk.ms(); }
+    { Tick tk; for (int st; (st = job.state.load(std::memory_order_acquire)) != 2;) futex_wait(job.state, st); t_wait_ += tk.ms(); }
     job.state.store(0, std::memory_order_relaxed);
     if (frame_threads_ > 1 && profiling_) { k_ms_[DK_HOST_PARSE] += job.parse_ms; k_n_[DK_HOST_PARSE]++; }
     if (job.parse_ms > t_parse_max_) t_parse_max_ = job.parse_ms;

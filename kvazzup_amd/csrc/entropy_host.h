@@ -19,6 +19,57 @@
 
 namespace kvzx {
 
+// cabac_play_tokens() of hevc_core.h for the host: the same arithmetic with the coder's registers in locals (the context array is
+// written through a byte pointer, which the compiler must assume to alias the coder's own fields: kept in the struct they are
+// reloaded after every bin), the context update as one table look-up and the renormalisation shift from the leading-zero count.
+struct HostCabacTabs {
+  uint8_t next_mps[128], next_lps[128];     // context variable = pStateIdx << 1 | valMps
+  uint8_t lps[128][4];                      // rangeTabLps by context variable and (range >> 6) & 3
+  HostCabacTabs()
+  {
+    for (int s = 0; s < 128; s++) {
+      const int st = s >> 1, mps = s & 1;
+      next_mps[s] = (uint8_t)(((st < 62 ? st + 1 : st) << 1) | mps);
+      next_lps[s] = (uint8_t)((kNextLps[st] << 1) | (st == 0 ? mps ^ 1 : mps));
+      for (int q = 0; q < 4; q++) lps[s][q] = kRangeLps[st][q];
+    }
+  }
+};
+inline void cabac_play_tokens_host(CabacEnc &c, const HostCabacTabs &T, const uint16_t *tok, int n)
+{
+  uint32_t low = c.low, range = c.range; int bits_left = c.bits_left;
+  uint8_t *const ctx = c.ctx;
+  uint32_t nbins = 0;
+  auto spill = [&] { c.low = low; c.range = range; c.bits_left = bits_left; };
+  auto fill = [&] { low = c.low; range = c.range; bits_left = c.bits_left; };
+  for (int i = 0; i < n; i++) {
+    const uint32_t t = tok[i];
+    if (__builtin_expect(!(t & 0x8000u), 1)) {
+      const uint32_t ci = t >> 1, s = ctx[ci];
+      const uint32_t lps = T.lps[s][(range >> 6) & 3];
+      nbins++;
+      range -= lps;
+      if ((t ^ s) & 1u) {                                 // least probable symbol
+        const int nb = __builtin_clz(lps) - 23;            // lps in [6, 240] -> [256, 510]
+        low = (low + range) << nb; range = lps << nb; bits_left -= nb;
+        ctx[ci] = T.next_lps[s];
+      } else {
+        ctx[ci] = T.next_mps[s];
+        if (range >= 256) continue;
+        low <<= 1; range <<= 1; bits_left--;
+      }
+      if (bits_left < 12) { spill(); cabac_write_out(c); fill(); }
+    } else {
+      spill();
+      if (!(t & 0x4000u)) cabac_bypass_bits(c, t & 0x3ffu, (int)((t >> 10) & 15) + 1);
+      else cabac_terminate(c, (int)(t & 1));
+      fill();
+    }
+  }
+  spill();
+  c.nbins += nbins;
+}
+
 class EntropyHost {
  public:
   explicit EntropyHost(int max_threads) : pool_(max_threads) { for (int i = 0; i < 64; i++) core_tabs_fill_entry(tabs_, i); }
@@ -35,7 +86,7 @@ class EntropyHost {
     ready_.reset(new std::atomic<int>[(size_t)hc]);
     for (int r = 0; r < hc; r++) ready_[(size_t)r].store(0, std::memory_order_relaxed);
     bins_.store(0);
-    pool_.run(nsub, [this](int r) { code_row(r); });
+    run_rows(nsub, 0);
     if (bins) *bins = bins_.load();
   }
   // The substreams of CTU rows [row0, row0 + nrows) only (whole tiles): rows_out[k] = substream of CTU row row0 + k with WPP,
@@ -52,13 +103,24 @@ class EntropyHost {
     ready_.reset(new std::atomic<int>[(size_t)hc]);
     for (int r = 0; r < hc; r++) ready_[(size_t)r].store(0, std::memory_order_relaxed);
     bins_.store(0);
-    pool_.run(nsub, [this, first](int k) { code_row(first + k); });
+    run_rows(nsub, first);
     rows_out.resize((size_t)nsub);
     for (int k = 0; k < nsub; k++) rows_out[(size_t)k].swap(all_rows_[(size_t)(first + k)]);
     if (bins) *bins = bins_.load();
   }
 
  private:
+  // A picture with very few tokens (a still scene: all skip) is coded by the calling thread, row after row: handing
+  // few-microsecond rows to a pool costs more in wake-ups than the rows take.  Everything else goes to the pool, where row r
+  // follows row r - 1 at a distance of two CTUs (a 1080p inter picture of the benchmark clip has some 100 000 tokens, 0.8 ms
+  // of coding on one core).
+  void run_rows(int nsub, int first)
+  {
+    size_t ntok = 0;
+    for (int i = 0; i < wc_ * hc_; i++) ntok += (size_t)count_[i];
+    if (ntok < 16000) { for (int k = 0; k < nsub; k++) code_row(first + k); }
+    else pool_.run(nsub, [this, first](int k) { code_row(first + k); });
+  }
   // substream r: CTU row r with WPP, else tile row r (all of its CTU rows)
   void code_row(int r)
   {
@@ -74,13 +136,14 @@ class EntropyHost {
     const bool fresh = !wpp_ || tile_row_starts_at(hc_, tiles_, r);
     if (fresh) cabac_init_contexts(ctx, init_type_, qp_);
     else {
-      while (!ready_[(size_t)(r - 1)].load(std::memory_order_acquire)) std::this_thread::yield();
+      // (the row above is already running -- tasks are handed out in order -- and needs two CTUs' worth of time)
+      for (int spins = 0; !ready_[(size_t)(r - 1)].load(std::memory_order_acquire);) { if (++spins < 4000) __builtin_ia32_pause(); else std::this_thread::yield(); }
       memcpy(ctx, &saved_[(size_t)(r - 1) * CTX_COUNT], CTX_COUNT);
     }
     for (int cy = first_cy; cy < first_cy + ncy; cy++)
       for (int cx = 0; cx < wc_; cx++) {
         const size_t ctu = (size_t)cy * wc_ + cx;
-        cabac_play_tokens(c, tokens_ + offset_[ctu], count_[ctu]);
+        cabac_play_tokens_host(c, htabs_, tokens_ + offset_[ctu], count_[ctu]);
         if (wpp_ && cx == 1) {
           memcpy(&saved_[(size_t)r * CTX_COUNT], ctx, CTX_COUNT);
           ready_[(size_t)r].store(1, std::memory_order_release);
@@ -93,6 +156,7 @@ class EntropyHost {
 
   OrderedPool pool_;
   CoreTabs tabs_;
+  HostCabacTabs htabs_;
   const uint16_t *tokens_ = nullptr; const int32_t *count_ = nullptr; const uint32_t *offset_ = nullptr;
   int wc_ = 0, hc_ = 0, tiles_ = 1, init_type_ = 0, qp_ = 0; bool wpp_ = true;
   std::vector<uint8_t> saved_;

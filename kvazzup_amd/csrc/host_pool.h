@@ -11,11 +11,21 @@
 #include <thread>
 #include <vector>
 #include <pthread.h>
+#include <climits>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 namespace kvzx {
 
 // thread names show up in top -H / perf / /proc/<pid>/task/*/comm (15 characters)
 inline void name_this_thread(const char *name) { pthread_setname_np(pthread_self(), name); }
+
+// Sleeping on an atomic word (Linux futex) instead of spinning through sched_yield(): the waiter costs nothing while it waits and
+// the waker pays one system call.  wait: returns when woken or when the word no longer holds `seen`; callers re-check in a loop.
+inline void futex_wait(std::atomic<int> &a, int seen) { syscall(SYS_futex, reinterpret_cast<int *>(&a), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0); }
+inline void futex_wake_all(std::atomic<int> &a) { syscall(SYS_futex, reinterpret_cast<int *>(&a), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
+static_assert(sizeof(std::atomic<int>) == sizeof(int), "futex word");
 
 // Waiting for the GPU without burning a core: hipEventSynchronize / hipStreamSynchronize poll (the blocking-sync event flag makes
 // no difference on this stack), which costs a full core per waiting thread.  Where a lag hides the wake-up -- the encoder's
@@ -54,7 +64,7 @@ class OrderedPool {
     next_.store(0, std::memory_order_release);
     if (n > 1 && !workers_.empty()) { { std::lock_guard<std::mutex> l(m_); gen_++; } cv_.notify_all(); }
     drain();
-    while (done_.load(std::memory_order_acquire) != n) std::this_thread::yield();
+    for (int d; (d = done_.load(std::memory_order_acquire)) != n;) futex_wait(done_, d);      // (the worker that finishes the last task wakes it)
   }
 
  private:
@@ -73,7 +83,7 @@ class OrderedPool {
       int r = next_.fetch_add(1, std::memory_order_acq_rel);
       if (r >= total_.load(std::memory_order_acquire)) break;
       (*fn_)(r);
-      done_.fetch_add(1, std::memory_order_acq_rel);
+      if (done_.fetch_add(1, std::memory_order_acq_rel) + 1 == total_.load(std::memory_order_acquire)) futex_wake_all(done_);
     }
     active_.fetch_sub(1, std::memory_order_acq_rel);
   }

@@ -1,0 +1,68 @@
+"""Per-source-line histogram of tools/cpu_sampler.c samples that fall into one library (built with -g).
+   python tools/cpu_sampler_report.py gpurun_out/cpu_samples.txt kvazzup_amd/libkvazzup_amd_g.so [top]"""
+import collections, subprocess, sys
+path, lib = sys.argv[1], sys.argv[2]
+top = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+base = None
+name = lib.split("/")[-1]
+maps, samples = [], []
+for line in open(path):
+    if line.startswith("M "):
+        f = line.split()
+        lo, hi = (int(x, 16) for x in f[1].split("-"))
+        maps.append((lo, hi, int(f[3], 16), f[-1]))
+    elif line.startswith("S "):
+        samples.append(int(line.split()[1], 16))
+# file offset -> virtual address of the executable segment (what the symbolizer wants)
+delta = 0
+for line in subprocess.run(["readelf", "-lW", lib], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout.splitlines():
+    f = line.split()
+    if f and f[0] == "LOAD" and "E" in "".join(f[6:8]):
+        delta = int(f[2], 16) - int(f[1], 16)
+inlib = collections.Counter()
+other = collections.Counter()
+for pc in samples:
+    for lo, hi, off, nm in maps:
+        if lo <= pc < hi:
+            if nm.endswith(name):
+                inlib[pc - lo + off + delta] += 1
+            else:
+                other[nm.split("/")[-1]] += 1
+            break
+    else:
+        other["?"] += 1
+print("samples %d; in %s: %d" % (len(samples), name, sum(inlib.values())))
+for nm, n in other.most_common(12):
+    print("  %6d  %s" % (n, nm))
+addrs = list(inlib)
+SYM = "/opt/rocm/lib/llvm/bin/llvm-symbolizer"
+out = subprocess.run([SYM, "--obj=" + lib, "-f", "-C", "-i", "-a"] + [hex(a) for a in addrs], capture_output=True, text=True).stdout.splitlines()
+by_line, by_func, by_outer = collections.Counter(), collections.Counter(), collections.Counter()
+cur, frames = None, []
+def flush():
+    if cur is None or not frames:
+        return
+    n = inlib[cur]
+    fn, loc = frames[0]
+    by_line[(fn, ":".join(loc.split("/")[-1].split(":")[:2]))] += n
+    by_func[fn] += n
+    by_outer[frames[-1][0]] += n
+i = 0
+while i < len(out):
+    if out[i].startswith("0x"):
+        flush(); cur = int(out[i], 16); frames = []; i += 1
+    elif not out[i].strip():
+        i += 1
+    else:
+        frames.append((out[i], out[i + 1] if i + 1 < len(out) else "?")); i += 2
+flush()
+tot = sum(inlib.values())
+print("-- by outermost function")
+for k, n in by_outer.most_common(15):
+    print("  %5.1f%%  %s" % (100.0 * n / tot, k[:140]))
+print("-- by innermost (inlined) function")
+for k, n in by_func.most_common(top):
+    print("  %5.1f%%  %s" % (100.0 * n / tot, k[:140]))
+print("-- by line")
+for (fn, loc), n in by_line.most_common(top):
+    print("  %5.1f%%  %-28s %s" % (100.0 * n / tot, loc, fn[:100]))

@@ -176,6 +176,8 @@ class Decoder {
   int alloc_slot();
 
   int device_; bool started_ = false;
+  hipEvent_t err_ev_ = nullptr; bool err_pending_ = false;    // the error word's download (complete_gpu)
+  hipStream_t stream_up_ = nullptr; hipEvent_t up_done_[2] = {nullptr, nullptr};   // upload of the next picture's input block beside the current picture's kernels
   hipStream_t stream_ = nullptr, stream_dl_ = nullptr;       // reconstruction; download of finished pictures (behind the picture's event, beside the next picture's kernels)
   DecSps sps_[16]; DecPps pps_[64]; uint32_t vps_fps_num_ = 0, vps_fps_den_ = 0;
   int w_ = 0, h_ = 0, pw_ = 0, ph_ = 0;
@@ -185,7 +187,7 @@ class Decoder {
   struct DpbPic { uint8_t *plane[3] = {nullptr, nullptr, nullptr}; int poc = 0; bool is_ref = false, used = false; long decode_idx = -1000; std::shared_ptr<ColMotion> motion; };
   DpbPic dpb_[KVZ_DEC_MAX_REFS];
   // device side
-  uint8_t *d_in_ = nullptr; size_t d_in_cap_ = 0;          // device copy of PicJob::h_in
+  uint8_t *d_in_[2] = {nullptr, nullptr}; size_t d_in_cap_[2] = {0, 0};   // device copies of PicJob::h_in: pictures alternate between the two
   uint8_t *work_[3] = {nullptr, nullptr, nullptr};          // pictures with SAO: reconstruction and deblocking happen here, the filter writes into the slot
   uint32_t *progress_ = nullptr, *intra_order_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
   uint8_t *h_out_ = nullptr; size_t h_out_cap_ = 0;

@@ -96,7 +96,11 @@ struct CabacDec {
   uint64_t value = 0; int bits = 0;
   uint32_t range = 510; uint32_t past = 0;                      // 32-bit words fetched beyond the end
   const StateTabs *st = nullptr;
-  uint8_t ctx[CTX_COUNT];
+  // 16-bit entries: a byte store may alias anything, which would make the compiler reload value / bits / range from the struct
+  // after every context update; a uint16_t store cannot alias them
+  uint16_t ctx[CTX_COUNT];
+  void load_ctx(const uint8_t *src) { for (int i = 0; i < CTX_COUNT; i++) ctx[i] = src[i]; }
+  void save_ctx(uint8_t *dst) const { for (int i = 0; i < CTX_COUNT; i++) dst[i] = (uint8_t)ctx[i]; }
   inline uint32_t word()
   {
     uint32_t w;
@@ -770,9 +774,13 @@ Decoder::~Decoder()
   drop_pending();
   workers_.reset();
   if (stream_) hipStreamSynchronize(stream_);
+  if (err_pending_ && hipEventSynchronize(err_ev_) == hipSuccess && *h_err_) fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x (last picture)\n", *h_err_);
   for (auto &j : jobs_) { for (auto &e : j.ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); } if (j.done) hipEventDestroy(j.done); }
   free_buffers();
   if (stream_dl_) hipStreamDestroy(stream_dl_);
+  if (stream_up_) hipStreamDestroy(stream_up_);
+  for (auto &e : up_done_) if (e) hipEventDestroy(e);
+  if (err_ev_) hipEventDestroy(err_ev_);
   if (h_err_) hipHostFree(h_err_);
   if (err_) hipFree(err_);
   if (stream_) hipStreamDestroy(stream_);
@@ -795,6 +803,9 @@ bool Decoder::start(std::string *error)
     else HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   }
   HIP_TRY(hipStreamCreateWithFlags(&stream_dl_, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&stream_up_, hipStreamNonBlocking));
+  for (auto &e : up_done_) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&err_ev_, hipEventDisableTiming));
   HIP_TRY(hipMalloc(&err_, sizeof(uint32_t)));
   HIP_TRY(hipMemset(err_, 0, sizeof(uint32_t)));
   HIP_TRY(hipHostMalloc(&h_err_, sizeof(uint32_t), hipHostMallocDefault));
@@ -806,10 +817,10 @@ void Decoder::free_buffers()
 {
   for (auto &j : jobs_) { if (j.h_in) hipHostFree(j.h_in); j.h_in = nullptr; j.h_in_cap = 0; j.col.reset(); j.own.reset(); }
   if (h_out_) hipHostFree(h_out_);
-  hipFree(d_in_); hipFree(progress_); hipFree(intra_order_); intra_order_ = nullptr;
+  hipFree(d_in_[0]); hipFree(d_in_[1]); hipFree(progress_); hipFree(intra_order_); intra_order_ = nullptr;
   for (auto &p : dpb_) { for (int c = 0; c < 3; c++) { hipFree(p.plane[c]); p.plane[c] = nullptr; } p = DpbPic(); }
   for (int c = 0; c < 3; c++) { hipFree(work_[c]); work_[c] = nullptr; }
-  h_out_ = nullptr; d_in_ = nullptr; d_in_cap_ = 0; progress_ = nullptr;
+  h_out_ = nullptr; d_in_[0] = d_in_[1] = nullptr; d_in_cap_[0] = d_in_cap_[1] = 0; progress_ = nullptr;
   w_ = h_ = pw_ = ph_ = 0;
 }
 
@@ -852,8 +863,7 @@ bool Decoder::ensure_buffers(int w, int h)
   }
   HIP_TRY(hipHostMalloc(&h_out_, npx * 3 / 2, hipHostMallocDefault));
   h_out_cap_ = npx * 3 / 2;
-  d_in_cap_ = fixed_bytes() + (1 << 20);
-  HIP_TRY(hipMalloc(&d_in_, d_in_cap_));
+  for (int i = 0; i < 2; i++) { d_in_cap_[i] = fixed_bytes() + (1 << 20); HIP_TRY(hipMalloc(&d_in_[i], d_in_cap_[i])); }
   HIP_TRY(hipMalloc(&progress_, sizeof(uint32_t) * 3 * (size_t)(pw_ / 64) * (ph_ / 64)));
   {
     // dispatch order of k_dec_intra's workgroups: CTUs by anti-diagonal cx + 2 cy (every CTU a block depends on comes earlier)
@@ -1179,7 +1189,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
       // a large picture (an intra picture: several milliseconds on one core, which the pictures behind it in the ring cannot
       // hide) has its substreams parsed side by side on the row pool; small ones stay on this worker
       bool rows = false;
-      if (jp->data_len > (64u << 10) && pool_mutex_.try_lock()) rows = true;
+      if (jp->data_len > (192u << 10) && pool_mutex_.try_lock()) rows = true;
       jp->rc = parse_job(*jp, rows);
       if (rows) pool_mutex_.unlock();
       jp->parse_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1227,7 +1237,16 @@ int Decoder::complete_gpu(PicJob &job)
     } else if (hipEventSynchronize(job.done) != hipSuccess) return DEC_ERR_GPU;
     t_sync_ += tk.ms();
   }
-  if (*h_err_) { fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x\n", *h_err_); return DEC_ERR_GPU; }
+  // The kernels' error word (a wavefront that gave up waiting) comes down on the download stream, beside the next picture's
+  // kernels rather than between them, and is looked at when the NEXT picture completes (and when the decoder is drained): a
+  // device fault is reported one picture late instead of costing every picture a synchronous round trip.
+  if (err_pending_) {
+    if (hipEventSynchronize(err_ev_) != hipSuccess) return DEC_ERR_GPU;
+    err_pending_ = false;
+    if (*h_err_) { fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x\n", *h_err_); return DEC_ERR_GPU; }
+  }
+  if (hipMemcpyAsync(h_err_, err_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_dl_) != hipSuccess || hipEventRecord(err_ev_, stream_dl_) != hipSuccess) return DEC_ERR_GPU;
+  err_pending_ = true;
   if (job.ev_used) {
     for (size_t i = 0; i < job.ev_used; i++) { float ms = 0; hipEventElapsedTime(&ms, job.ev[i].a, job.ev[i].b); k_ms_[job.ev[i].id] += ms; k_n_[job.ev[i].id]++; }
     job.ev_used = 0;
@@ -1291,10 +1310,10 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
   // 9.3.1: the first CTB of a tile initialises the contexts; a WPP row takes them over from the row above after its second
   // CTB when that CTB exists (pictures one CTB wide: it does not, and the row initialises afresh)
   if (!wpp || tile_starts_at(sub) || wc < 2) {
-    cabac_init_contexts(c.ctx, init_type, sh.slice_qp);
+    { uint8_t init[CTX_COUNT]; cabac_init_contexts(init, init_type, sh.slice_qp); c.load_ctx(init); }
   } else {
     if (!wait_above(sub, 2)) return DEC_ERR_INVALID;
-    memcpy(c.ctx, &job.wpp_saved[(size_t)(sub - 1) * CTX_COUNT], CTX_COUNT);
+    c.load_ctx(&job.wpp_saved[(size_t)(sub - 1) * CTX_COUNT]);
   }
   sp.last_qp_y = sh.slice_qp;                          // qPY_PREV at the start of a slice, a tile, a CTB row with WPP (8.6.1)
   for (int t = 0; t < pps.tile_rows; t++) if (first_cy >= pps.row_bd[t]) { sp.tile_y0 = pps.row_bd[t] * 64; sp.tile_y1 = pps.row_bd[t + 1] * 64; }
@@ -1317,7 +1336,7 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
       job.ctu[ctu].first = tu0;
       job.ctu[ctu].count = ((uint32_t)out.tus.size() - tu0) | (sp.ctu_intra_mask << 24);
       if (out.tus.size() - tu0 >= (1u << 24)) return DEC_ERR_INVALID;
-      if (wpp && cx == 1) memcpy(&job.wpp_saved[(size_t)cy * CTX_COUNT], c.ctx, CTX_COUNT);
+      if (wpp && cx == 1) c.save_ctx(&job.wpp_saved[(size_t)cy * CTX_COUNT]);
       if (wpp) job.row_progress[(size_t)cy].v.store(cx + 1, std::memory_order_release);
       const bool last = (cy == hc - 1 && cx == wc - 1);
       const int end = c.terminate();
@@ -1401,12 +1420,18 @@ int Decoder::launch_gpu(PicJob &job)
   timed_job_ = &job; job.ev_used = 0;
   if (!job.done && hipEventCreateWithFlags(&job.done, hipEventDisableTiming) != hipSuccess) return DEC_ERR_GPU;
   Tick tk_api;
-  if (bytes > d_in_cap_) {                               // (the stream is idle here: the previous picture has been completed)
+  // The input block goes up on its own stream into one of two device buffers: the picture launched before this one may still be
+  // running (finish_oldest launches before it completes the previous picture) and reads the other buffer; the one before that
+  // has been completed, so this buffer is free.
+  const int ib = (int)(launched_ & 1);
+  uint8_t *&d_in_ = this->d_in_[ib];
+  if (bytes > d_in_cap_[ib]) {
     hipFree(d_in_);
-    d_in_cap_ = bytes + bytes / 2;
-    if (hipMalloc(&d_in_, d_in_cap_) != hipSuccess) { d_in_ = nullptr; d_in_cap_ = 0; return DEC_ERR_GPU; }
+    d_in_cap_[ib] = bytes + bytes / 2;
+    if (hipMalloc(&d_in_, d_in_cap_[ib]) != hipSuccess) { d_in_ = nullptr; d_in_cap_[ib] = 0; return DEC_ERR_GPU; }
   }
-  if (hipMemcpyAsync(d_in_, job.h_in, bytes, hipMemcpyHostToDevice, stream_) != hipSuccess) return DEC_ERR_GPU;
+  if (hipMemcpyAsync(d_in_, job.h_in, bytes, hipMemcpyHostToDevice, stream_up_) != hipSuccess) return DEC_ERR_GPU;
+  if (hipEventRecord(up_done_[ib], stream_up_) != hipSuccess || hipStreamWaitEvent(stream_, up_done_[ib], 0) != hipSuccess) return DEC_ERR_GPU;
   DecFrame f; memset(&f, 0, sizeof(f));
   f.w = w_; f.h = h_; f.pw = pw_; f.ph = ph_; f.wc = (w_ + 63) / 64; f.hc = (h_ + 63) / 64;
   f.b4 = (const B4Rec *)d_in_; f.region = (const TuRange *)(d_in_ + off_region()); f.ctu = (const TuRange *)(d_in_ + off_ctu());
@@ -1426,7 +1451,6 @@ int Decoder::launch_gpu(PicJob &job)
   }
   if (!job.sh.deblock_disabled) timed(DK_DEBLOCK, [&] { launch_dec_deblock(f, stream_); });
   if (sao) timed(DK_SAO, [&] { launch_dec_sao(f, stream_); });
-  if (hipMemcpyAsync(h_err_, err_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_) != hipSuccess) return DEC_ERR_GPU;
   if (hipEventRecord(job.done, stream_) != hipSuccess) return DEC_ERR_GPU;
   t_api_ += tk_api.ms();
   launched_++;

@@ -1,0 +1,119 @@
+"""The second, independently written decoder (tests/pyhevc.py: plain Python + numpy, from the standard's text) against the
+checker's decoder (oracle/hevc_dec.c) on streams of the checker's encoder (the golden configurations) and of the stream
+synthesiser (every partitioning, transform trees, several references, TMVP, cu_qp_delta, sign hiding, transform skip, SAO,
+tiles, WPP).  Pictures must match bit for bit.  CPU only."""
+import numpy as np
+import pytest
+
+import orc
+import pyhevc
+from test_oracle_kat import table
+
+
+def tabs():
+    return {"range_lps": table(1, np.uint8, (64, 4)), "trans_lps": table(2, np.uint8, (64,)), "trans_mps": table(13, np.uint8, (64,)),
+            "dct": table(0, np.int8, (32, 32)).astype(int), "dst": table(5, np.int8, (4, 4)).astype(int),
+            "luma_filter": table(11, np.int8, (4, 8)).astype(int), "chroma_filter": table(12, np.int8, (8, 4)).astype(int),
+            "beta": table(6, np.uint8, (52,)).astype(int), "tc": table(7, np.uint8, (54,)).astype(int),
+            "intra_angle": table(9, np.int8, (35,)).astype(int), "inv_angle": table(10, np.int16, (35,)).astype(int)}
+
+
+def test_context_init_values_agree_with_the_checker_and_the_product():
+    """the per-syntax-element initValue tables typed in pyhevc.py against the checker's table (its own context order)"""
+    init = table(3, np.uint8, (3, 154)).astype(int)
+    # order of the checker's / product's context indices (hevc_core.h CTX_*)
+    order = [("sao_merge", 1), ("sao_type", 1), ("split_cu", 3), (None, 1), ("skip", 3), ("pred_mode", 1), ("part_mode", 4), ("prev_intra", 1),
+             ("chroma_mode", 1), ("rqt_root", 1), ("merge_flag", 1), ("merge_idx", 1), (None, 5), ("ref_idx", 2), ("mvp", 1), ("split_tf", 3),
+             ("cbf_luma", 2), ("cbf_chroma", 4), ("mvd_gt0", 1), ("mvd_gt1", 1), ("qp_delta", 2), ("ts_flag", 2), ("last_x", 18), ("last_y", 18),
+             ("csbf", 4), ("sig", 42), ("gt1", 24), ("gt2", 6)]
+    at = 0
+    for name, n in order:
+        if name is not None:
+            for t in range(3):
+                vals = pyhevc.INIT[name][t]
+                if vals is None:
+                    continue
+                got = init[t, at:at + len(vals)].tolist()
+                assert got == vals, (name, t, got, vals)
+        at += n
+    assert at == 154
+
+
+def decode_both(aus):
+    od = orc.OracleDecoder()
+    want = []
+    for au in aus:
+        want += od.decode_au(au)
+    od.close()
+    pd = pyhevc.Decoder(tabs())
+    for au in aus:
+        pd.decode(au)
+    return want, pd.out
+
+
+def compare(aus):
+    want, got = decode_both(aus)
+    assert len(want) == len(got) and len(got) > 0
+    for k, (a, b) in enumerate(zip(want, got)):
+        assert (a["width"], a["height"], a["poc"]) == (b["width"], b["height"], b["poc"]), k
+        d = np.nonzero(a["i420"] != b["i420"])[0]
+        assert d.size == 0, "picture %d: %d samples differ, first at %d" % (k, d.size, d[0])
+
+
+CASES = [
+    dict(w=128, h=64, qp=32, period=1, me_range=8, kind=0, seed=0x5EED0001, wpp=1, deblock=1, frames=2),
+    dict(w=192, h=128, qp=30, period=64, me_range=8, kind=0, seed=0x5EED0002, wpp=1, deblock=1, frames=3),
+    dict(w=192, h=128, qp=22, period=64, me_range=8, kind=2, seed=0x5EED0003, wpp=0, deblock=1, frames=2),
+    dict(w=192, h=128, qp=40, period=64, me_range=8, kind=1, seed=0x5EED0005, wpp=1, deblock=0, frames=2),
+    dict(w=192, h=128, qp=30, period=3, me_range=8, kind=0, seed=0x5EED0006, wpp=1, deblock=1, frames=4, tile_rows=2, sao=1),
+    dict(w=128, h=128, qp=35, period=64, me_range=8, kind=2, seed=0x5EED0007, wpp=0, deblock=1, frames=2, sao=1, qp_in_cu=1),
+]
+
+
+@pytest.mark.parametrize("c", CASES, ids=lambda c: "%dx%d-qp%d-%x" % (c["w"], c["h"], c["qp"], c["seed"] & 0xff))
+def test_checker_encoder_streams(c):
+    e = orc.OracleEncoder(c["w"], c["h"], qp=c["qp"], period=c["period"], me_range=c["me_range"], wpp=c["wpp"], deblock=c["deblock"],
+                           tile_rows=c.get("tile_rows", 1), sao=c.get("sao", 0), qp_in_cu=c.get("qp_in_cu", 0), mv_jitter=c.get("mv_jitter", 0))
+    if c.get("qp_in_cu"):
+        e.set_roi(2, 2, [-4, 3, 6, -7])
+    aus = [e.encode(orc.synth_frame(c["kind"], c["seed"], c["w"], c["h"], t)) for t in range(c["frames"])]
+    e.close()
+    compare(aus)
+
+
+GEN = [
+    dict(width=64, height=64, seed=11, pictures=2),
+    dict(width=136, height=72, seed=12, pictures=3),
+    dict(width=128, height=128, seed=13, pictures=3, wpp=1),
+    dict(width=128, height=192, seed=14, pictures=3, tile_rows=2),
+    dict(width=96, height=80, seed=15, pictures=4, num_refs=3),
+    dict(width=128, height=64, seed=16, pictures=4, tmvp=1, num_refs=2),
+]
+
+
+@pytest.mark.parametrize("g", GEN, ids=lambda g: "gen%d" % g["seed"])
+def test_generator_streams(g):
+    g = dict(g)
+    n = g.pop("pictures")
+    gen = orc.OracleGen(**g)
+    aus = [gen.picture() for _ in range(n)]
+    gen.close()
+    compare(aus)
+
+
+@pytest.mark.parametrize("seed", range(200, 224))
+def test_generator_random_sweep(seed):
+    """everything drawn from the seed (orc_gen_config fields left at -1), odd sizes included"""
+    gen = orc.OracleGen(width=64 + 8 * (seed % 13), height=64 + 8 * (seed % 7), seed=seed, density=40)
+    aus = [gen.picture() for _ in range(5)]
+    gen.close()
+    compare(aus)
+
+
+def test_generator_everything_on():
+    gen = orc.OracleGen(width=200, height=136, seed=77, density=45, num_refs=4, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=1, cabac_init=1,
+                        wpp=1, tile_rows=2, th_depth_inter=2, th_depth_intra=2, qp_delta=2, chroma_qp_offsets=1, deblock_mode=2, par_mrg_level=3,
+                        intra_in_p=25, all_part_modes=1, chroma_modes=1, nxn_intra=1, big_mvd=1)
+    aus = [gen.picture() for _ in range(6)]
+    gen.close()
+    compare(aus)

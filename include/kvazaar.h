@@ -119,6 +119,7 @@ typedef struct kvz_config {
   int32_t me_range;           /* "me-range": exhaustive search radius in integer samples, 1..32 */
   int32_t gpu_device;         /* "gpu": HIP device ordinal */
   int32_t recon_output;       /* "recon-output": 0 = encoder_encode leaves *pic_out NULL (no download) */
+  int32_t intra_satd;         /* "intra-satd": 1 (default) = the intra mode search compares 8x8 Hadamard sums (SATD) like Kvazaar's rough search, 0 = SAD */
   int32_t band_row0, band_rows; /* "band-row0", "band-rows": tile-row split over several encoders (kvazzup_amd.h, kvzx_encoder_band_*); 0 rows = whole picture */
 } kvz_config;
 

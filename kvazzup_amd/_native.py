@@ -37,7 +37,7 @@ class KvzConfig(C.Structure):
                 ("gop_lp_temporal_layers", C.c_int32), ("set_qp_in_cu", C.c_int32), ("vaq", C.c_int32), ("scaling_list", C.c_int),
                 ("intra_bits", C.c_int32), ("me_max_steps", C.c_int32), ("fast_residual_cost_limit", C.c_int32),
                 ("pu_depth_inter_min", C.c_int32), ("pu_depth_inter_max", C.c_int32), ("pu_depth_intra_min", C.c_int32), ("pu_depth_intra_max", C.c_int32),
-                ("me_range", C.c_int32), ("gpu_device", C.c_int32), ("recon_output", C.c_int32),
+                ("me_range", C.c_int32), ("gpu_device", C.c_int32), ("recon_output", C.c_int32), ("intra_satd", C.c_int32),
                 ("band_row0", C.c_int32), ("band_rows", C.c_int32)]
 
 

@@ -585,6 +585,70 @@ __device__ __forceinline__ uint32_t analyse_item(const AnalyseLds &s, int b, int
   return wave_sum_u32(sad);
 }
 
+// SATD form of the search cost (f.satd): one item = (16x16 tile of the region, mode, kind) on one wave.  kind 0 predicts the tile as
+// one 16x16 block, kind 1 as its four 8x8 blocks; either way the tile's difference to the source goes through the 8x8 Hadamard
+// transform of each of its quadrants as ONE pair of matrix-core products: with H16 = H8 (+) H8 (block diagonal, entries +-1)
+//   Y = D H16^T    (A = the differences, lane (g, c) = (lane >> 4, lane & 15) owns x = 4g .. 4g + 3 of row y = c)
+//   Z = H16 Y      (B = Y, which the first product leaves in exactly the operand layout the second one reads)
+// on v_mfma_f32_16x16x16_f16 -- exact: |D| <= 255, |Y| <= 2040 < 2^11, |Z| <= 16320.  q[k] = sum |Z| over quadrant k (raster).
+__device__ __forceinline__ void analyse_tile_satd(const AnalyseLds &s, int tile, int kind, int mode, int lane, uint32_t (&q)[4])
+{
+  const int g = lane >> 4, c = lane & 15, tx = (tile & 1) * 16, ty = (tile >> 1) * 16;
+  const int angle = kIntraAngle[mode], inv = kInvAngle[mode];
+  const bool vert = mode >= 18;
+  int d[4];
+  {
+    const uint32_t s4 = *(const uint32_t *)&s.src[(ty + c) * 32 + tx + 4 * g];
+    if (kind == 0) {
+      const int b = 16 + tile;
+      const uint8_t *R = s.R[intra_filter_needed(16, 0, mode) ? 1 : 0] + an_roff(b);
+      const bool e2 = mode == 26 || mode == 10;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int x = 4 * g + r, y = c;
+        const int p = mode == 0 ? pred_planar<4>(R, x, y) : (mode == 1 ? pred_dc<4>(R, true, s.dc[b], x, y) : pred_angular<4>(R, vert, e2, angle, inv, x, y));
+        d[r] = (int)((s4 >> (8 * r)) & 255u) - p;
+      }
+    } else {
+      const int b = ((ty >> 3) + (c >> 3)) * 4 + (tx >> 3) + (g >> 1);
+      const uint8_t *R = s.R[intra_filter_needed(8, 0, mode) ? 1 : 0] + an_roff(b);
+      const bool e2 = mode == 26 || mode == 10;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int x = (4 * g + r) & 7, y = c & 7;
+        const int p = mode == 0 ? pred_planar<3>(R, x, y) : (mode == 1 ? pred_dc<3>(R, true, s.dc[b], x, y) : pred_angular<3>(R, vert, e2, angle, inv, x, y));
+        d[r] = (int)((s4 >> (8 * r)) & 255u) - p;
+      }
+    }
+  }
+  // H16[c][4g + r]: zero across the two 8x8 blocks, else the sign of the natural-ordered Hadamard matrix, (-1)^popcount(i & j)
+  kv_f16x4 h;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int j = 4 * g + r;
+    h[r] = ((c ^ j) & 8) ? (_Float16)0.f : ((__builtin_popcount((unsigned)(c & j & 7)) & 1) ? (_Float16)-1.f : (_Float16)1.f);
+  }
+  int y[4], z[4];
+  mfma16_data_a(d, h, y);
+  kv_f16x4 yb;
+#pragma unroll
+  for (int r = 0; r < 4; r++) yb[r] = (_Float16)(short)y[r];
+  const kv_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const kv_f32x4 zf = __builtin_amdgcn_mfma_f32_16x16x16f16(h, yb, zero, 0, 0, 0);
+  uint32_t a = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) { z[r] = (int)zf[r]; a += (uint32_t)iabs(z[r]); }
+  // sums over the 8-lane groups (three DPP steps), then the two groups of each quadrant: output (u = 4g + r, v = c) lies in quadrant
+  // (u >= 8) * 2 + (v >= 8)
+  a += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1, 0xf, 0xf, false);
+  a += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x4E, 0xf, 0xf, false);
+  a += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x141, 0xf, 0xf, false);
+  q[0] = (uint32_t)__builtin_amdgcn_readlane((int)a, 0) + (uint32_t)__builtin_amdgcn_readlane((int)a, 16);
+  q[1] = (uint32_t)__builtin_amdgcn_readlane((int)a, 8) + (uint32_t)__builtin_amdgcn_readlane((int)a, 24);
+  q[2] = (uint32_t)__builtin_amdgcn_readlane((int)a, 32) + (uint32_t)__builtin_amdgcn_readlane((int)a, 48);
+  q[3] = (uint32_t)__builtin_amdgcn_readlane((int)a, 40) + (uint32_t)__builtin_amdgcn_readlane((int)a, 56);
+}
+
 __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
 {
   __shared__ AnalyseLds s;
@@ -634,7 +698,21 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
     s.dc[tid] = (a - R[2 * n]) >> (l2 + 1);
   }
   __syncthreads();
-  // ---- SAD of every (block, mode)
+  // ---- cost of every (block, mode): 8x8 Hadamard sums, (sum + 2) >> 2 per 8x8 block (oracle/hevc_enc.c satd_block()), or SADs
+  if (f.satd) {
+    for (int item = wave; item < 4 * 35 * 2; item += 4) {
+      const int kind = item & 1, tile = (item >> 1) & 3, mode = item >> 3;
+      uint32_t q[4];
+      analyse_tile_satd(s, tile, kind, mode, lane, q);
+      if (lane == 0) {
+        if (kind == 0) s.cost[16 + tile][mode] = ((q[0] + 2) >> 2) + ((q[1] + 2) >> 2) + ((q[2] + 2) >> 2) + ((q[3] + 2) >> 2);
+        else {
+          const int b0 = (tile >> 1) * 8 + (tile & 1) * 2;           // first of the tile's four 8x8 blocks (raster of 4 x 4)
+          s.cost[b0][mode] = (q[0] + 2) >> 2; s.cost[b0 + 1][mode] = (q[1] + 2) >> 2; s.cost[b0 + 4][mode] = (q[2] + 2) >> 2; s.cost[b0 + 5][mode] = (q[3] + 2) >> 2;
+        }
+      }
+    }
+  } else
   for (int item = wave; item < 20 * 35; item += 4) {
     const int b = item / 35, mode = item - b * 35;
     uint32_t c;

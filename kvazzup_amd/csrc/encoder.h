@@ -34,6 +34,7 @@ struct EncoderConfig {
   int entropy_threads = 16;   // host threads of the arithmetic-coding stage
   int qp_in_cu = 0;           // kvazaar "set-qp-in-cu": cu_qp_delta_enabled_flag; a delta-QP map (set_roi, kvz_picture.roi) then gives every CTU its own QP
   int bitrate = 0;            // bits per second; 0 = constant QP, > 0 = "uvgx rate control v1" (oracle/hevc_enc.c rate_control())
+  int satd = 1;               // intra mode search cost: 8x8 Hadamard sums (1) or SAD (0)
   int me_early = 1;           // kvazaar "me-early-termination" (on / sensitive: 1, off: 0): static 32x32 blocks skip the motion search
   int vaq = 0;                // kvazaar "vaq" 1..20: "uvgx VAQ v1" (oracle/hevc_enc.c vaq_deltas()); implies qp_in_cu
   int mv_frame = 0;           // kvazaar "mv-constraint" frame / frametile (1), frametilemargin (2): vectors keep the block inside the picture

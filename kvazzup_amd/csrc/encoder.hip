@@ -144,7 +144,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   f_.tile_rows = cfg.tile_rows; f_.chp = pack_height(ch_, cfg.tile_rows);
   f_.row0 = cfg.band_rows > 0 ? cfg.band_row0 : 0; f_.nrows = cfg.band_rows > 0 ? cfg.band_rows : 0;
   f_.qp = cfg.qp; f_.qpc = kChromaQp[cfg.qp]; f_.lambda_q4 = kLambdaQ4[cfg.qp]; f_.range = cfg.me_range;
-  f_.wpp = cfg.wpp; f_.mv_frame = cfg.mv_frame; f_.me_early = cfg.me_early;
+  f_.wpp = cfg.wpp; f_.mv_frame = cfg.mv_frame; f_.me_early = cfg.me_early; f_.satd = cfg.satd;
   bind_set(0);
   uint8_t *p = intra_scratch_;
   f_.ic8 = (uint32_t *)p; p += nb8 * 4; f_.ic16 = (uint32_t *)p; p += nb8; f_.ic32 = (uint32_t *)p; p += nb8 / 4;

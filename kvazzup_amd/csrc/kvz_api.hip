@@ -44,6 +44,7 @@ int config_init(kvz_config *cfg)
   cfg->me_range = 16; cfg->gpu_device = 0; cfg->recon_output = 1;
   cfg->threads = -1;                                    // auto, as in Kvazaar
   cfg->me_early_termination = 1;                        // on, as in Kvazaar
+  cfg->intra_satd = 1;
   return 1;
 }
 
@@ -169,6 +170,7 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
   BOOL_OPT("early-skip", early_skip) BOOL_OPT("intra-rdo-et", intra_rdo_et) BOOL_OPT("lossless", lossless)
   BOOL_OPT("set-qp-in-cu", set_qp_in_cu) BOOL_OPT("psnr", calc_psnr) BOOL_OPT("cpuid", cpuid) BOOL_OPT("implicit-rdpcm", implicit_rdpcm)
   if (n == "cu-split-termination") { cfg->cu_split_termination = !strcmp(value, "off"); return (!strcmp(value, "zero") || !strcmp(value, "off")) ? 1 : 0; }
+  if (n == "intra-satd") return parse_bool(value, &cfg->intra_satd);
   if (n == "me-early-termination") {
     if (!strcmp(value, "off")) cfg->me_early_termination = 0; else if (!strcmp(value, "on")) cfg->me_early_termination = 1;
     else if (!strcmp(value, "sensitive")) cfg->me_early_termination = 2; else return 0;
@@ -248,6 +250,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   // "threads" (uvgComm video/kvzThreads: auto = core count, Main = 0): what is threaded on the host here is the arithmetic coder
   ec.entropy_threads = cfg->threads < 0 ? 16 : (cfg->threads == 0 ? 1 : (cfg->threads > 16 ? 16 : cfg->threads));
   ec.me_early = cfg->me_early_termination != 0;
+  ec.satd = cfg->intra_satd != 0;
   ec.vaq = cfg->vaq > 0 ? cfg->vaq : 0;
   ec.qp_in_cu = (cfg->set_qp_in_cu || ec.vaq > 0) ? 1 : 0;
   ec.sao = cfg->sao_type == KVZ_SAO_FULL;

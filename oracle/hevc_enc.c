@@ -53,7 +53,7 @@ void orc_enc_default_config(orc_enc_config *c)
 {
   memset(c, 0, sizeof(*c));
   c->qp = 32; c->intra_period = 64; c->vps_period = 1; c->search_range = 16;
-  c->fps_num = 30; c->fps_den = 1; c->wpp = 1; c->deblock = 1; c->tile_rows = 1; c->me_early = 1;
+  c->fps_num = 30; c->fps_den = 1; c->wpp = 1; c->deblock = 1; c->tile_rows = 1; c->me_early = 1; c->satd = 1;
 }
 
 int orc_mvd_bits(int q)
@@ -230,7 +230,35 @@ static uint32_t sad_block(const pixel *a, int as, const pixel *b, int bs, int n)
   return s;
 }
 
-/* Mode decision from SOURCE samples: for every aligned n x n block the mode with the least SAD
+/* Sum of absolute transformed differences: the 8x8 blocks of the n x n difference go through the 8x8 Hadamard transform (H d H^T, H of
+ * +-1 entries; which of the equivalent orderings of H's rows is used does not change the sum), a block's cost is (sum |coefficient| + 2)
+ * >> 2 -- HM's and Kvazaar's normalisation, comparable in size with a SAD -- and the costs of the blocks add up. */
+static uint32_t satd_block(const pixel *a, int as, const pixel *b, int bs, int n)
+{
+  uint32_t total = 0;
+  for (int by = 0; by < n; by += 8)
+    for (int bx = 0; bx < n; bx += 8) {
+      int d[8][8], t[8][8];
+      for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) d[y][x] = (int)a[(by + y) * as + bx + x] - (int)b[(by + y) * bs + bx + x];
+      for (int y = 0; y < 8; y++)                      /* rows */
+        for (int k = 0; k < 8; k++) {
+          int acc = 0;
+          for (int x = 0; x < 8; x++) acc += (__builtin_popcount((unsigned)(k & x)) & 1) ? -d[y][x] : d[y][x];
+          t[y][k] = acc;
+        }
+      uint32_t sum = 0;
+      for (int k = 0; k < 8; k++)                      /* columns */
+        for (int x = 0; x < 8; x++) {
+          int acc = 0;
+          for (int y = 0; y < 8; y++) acc += (__builtin_popcount((unsigned)(k & y)) & 1) ? -t[y][x] : t[y][x];
+          sum += (uint32_t)orc_abs(acc);
+        }
+      total += (sum + 2) >> 2;
+    }
+  return total;
+}
+
+/* Mode decision from SOURCE samples: for every aligned n x n block the mode with the least cost (SATD, or SAD with satd = 0)
  * between the source block and its prediction from source neighbours (ties: lowest mode). */
 static void intra_analyse_size(orc_encoder *e, int n, uint8_t *best_mode, uint32_t *best_cost)
 {
@@ -243,7 +271,7 @@ static void intra_analyse_size(orc_encoder *e, int n, uint8_t *best_mode, uint32
       uint32_t bc = 0xffffffffu; int bm = 0;
       for (int m = 0; m < 35; m++) {
         orc_intra_predict(left, top, n, 0, m, 1, pred, n);
-        uint32_t c = sad_block(e->src[0] + y0 * e->cw + x0, e->cw, pred, n, n);
+        uint32_t c = e->cfg.satd ? satd_block(e->src[0] + y0 * e->cw + x0, e->cw, pred, n, n) : sad_block(e->src[0] + y0 * e->cw + x0, e->cw, pred, n, n);
         if (c < bc) { bc = c; bm = m; }
       }
       best_mode[by * bw + bx] = (uint8_t)bm; best_cost[by * bw + bx] = bc;

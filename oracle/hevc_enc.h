@@ -36,6 +36,7 @@ typedef struct {
   int qp_in_cu;               /* 1: cu_qp_delta_enabled_flag, quantisation group = CTU: a delta-QP map set with orc_enc_set_roi()
                                * gives every CTU its own QP (kvz_picture.roi, kvazaarfilter.cpp:423-431) */
   int bitrate;                /* bits per second; 0 = constant QP.  > 0: "uvgx rate control v1" (see hevc_enc.c) */
+  int satd;                   /* 1 (default): the intra mode search compares 8x8 Hadamard sums (SATD), as Kvazaar's rough search does; 0: SAD */
   int me_early;               /* kvazaar me-early-termination (on by default, as in Kvazaar): a 32x32 block whose SAD against the co-located
                                * block of the reference is at most 64 * lambda_q4 (about what quantisation noise alone leaves at this QP) is
                                * coded unsplit with the zero vector, without a search */

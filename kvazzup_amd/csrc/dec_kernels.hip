@@ -465,7 +465,7 @@ __device__ __forceinline__ void dec_intra_block(const DecFrame &f, DecIntraLds &
 // one intra transform block of at most 16x16 samples on one wave (kernel_common.h "One intra block per WAVE")
 template <int L2>
 __device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveScratch &ws, const IntraBlk &d, uint32_t dqc, int count, bool luma,
-                                                     uint8_t *gdst, int gp, int lane, const uint32_t (&wreg)[4])
+                                                     uint8_t *gdst, int gp, int lane, const uint32_t (&wreg)[4], uint32_t *publish)
 {
   constexpr int N = 1 << L2;
   const int g = lane >> 4, c = lane & 15, rx = d.rx, ry = d.ry;
@@ -498,6 +498,8 @@ __device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveSc
 #pragma unroll
     for (int r = 0; r < 4; r++) pred[r] = clip8(pred[r] + res[r]);
   }
+  // (a progress value due before this block is published here, behind the block's computation: enc_kernels.hip intra_block_wave)
+  if (publish) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) __hip_atomic_store(publish, (uint32_t)d.zu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   if (active) {
     const uint32_t o = (uint32_t)pred[0] | ((uint32_t)pred[1] << 8) | ((uint32_t)pred[2] << 16) | ((uint32_t)pred[3] << 24);
     *(uint32_t *)&s.pic[(ry + c + 1) * DI_P + 16 + rx + 4 * g] = o;
@@ -593,12 +595,13 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
 #pragma unroll
     for (int q = 0; q < 4; q++) wreg[q] = wnext[q];
     fetch_words(k + 1);
-    if (d.flags & IB_PUBLISH) publish_wt(my, (uint32_t)d.zu);
+    uint32_t *pub = (d.flags & IB_PUBLISH) ? my : nullptr;
+    if (pub && d.l2 > 4) { publish_wt(my, (uint32_t)d.zu); pub = nullptr; }       // (32x32 blocks: the workgroup-shaped code publishes ahead)
     if (d.flags & IB_BORDER) borders_need(bd, s.pic, DI_P, plane, cpitch, cx, cy, S, sh, wC - cx * S, d.rx, d.ry, 1 << d.l2, &bcast, f.err, lane, T);
     switch (d.l2) {
-      case 2: dec_intra_block_wave<2>(s, ws, d, dqc, cnt, c == 0, gdst, cpitch, lane, wreg); break;
-      case 3: dec_intra_block_wave<3>(s, ws, d, dqc, cnt, c == 0, gdst, cpitch, lane, wreg); break;
-      case 4: dec_intra_block_wave<4>(s, ws, d, dqc, cnt, c == 0, gdst, cpitch, lane, wreg); break;
+      case 2: dec_intra_block_wave<2>(s, ws, d, dqc, cnt, c == 0, gdst, cpitch, lane, wreg, pub); break;
+      case 3: dec_intra_block_wave<3>(s, ws, d, dqc, cnt, c == 0, gdst, cpitch, lane, wreg, pub); break;
+      case 4: dec_intra_block_wave<4>(s, ws, d, dqc, cnt, c == 0, gdst, cpitch, lane, wreg, pub); break;
       default: {
         DecTu t;
         const uint32_t *q = (const uint32_t *)&s.list[k];

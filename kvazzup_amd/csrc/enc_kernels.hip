@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
 // Returns whether the block has non-zero levels.
 template <int L2>
 __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratch &ws, const IntraBlk &d, int cidx, int S, const QuantConst &q,
-                                                 uint8_t *gdst, int gp, int lane)
+                                                 uint8_t *gdst, int gp, int lane, uint32_t *publish)
 {
   constexpr int N = 1 << L2;
   const int P = 16 + 2 * S, g = lane >> 4, c = lane & 15, rx = d.rx, ry = d.ry;
@@ -795,6 +795,10 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
     for (int r = 0; r < 4; r++) pred[r] = clip8(pred[r] + res[r]);
   }
   PROF(8);
+  // A progress value that is due before this block (d.zu: everything in front of it is final) is published HERE: the write-through
+  // stores of the blocks in front have had this block's whole computation to be acknowledged, so the wait costs nothing, where
+  // publishing ahead of the block would stall the chain for a memory round trip (kernel_common.h, fence-free hand-off).
+  if (publish) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) __hip_atomic_store(publish, (uint32_t)d.zu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   if (active) {
     const uint32_t o = (uint32_t)pred[0] | ((uint32_t)pred[1] << 8) | ((uint32_t)pred[2] << 16) | ((uint32_t)pred[3] << 24);
     *(uint32_t *)&s.pic[(ry + c + 1) * P + 16 + rx + 4 * g] = o;
@@ -872,7 +876,7 @@ __global__ __launch_bounds__(64) void k_intra_recon(EncFrame f)
   const QuantConst q8 = quant_const(qp, 3 - sh, 1), q16 = quant_const(qp, 4 - sh, 1);      // (coding units are 8x8 or 16x16)
   for (int z = 0; z < 64;) {
     const IntraBlk d = wave_uniform(&blk[z]);              // (wave-uniform: what is derived from it runs on the scalar unit)
-    if (d.flags & IB_PUBLISH) { publish_wt(my, (uint32_t)z); if (f.trace && z == 32) ts = wall_clock64(); }
+    uint32_t *const pub = (d.flags & IB_PUBLISH) ? my : nullptr;
     KV_LAP(tp);
     PROF(1);
     // the neighbouring CTUs' samples this block reads: wait for them, copy them into the borders of the CTU picture
@@ -882,11 +886,12 @@ __global__ __launch_bounds__(64) void k_intra_recon(EncFrame f)
     if (f.trace && lane == 0 && z == 0) f.trace[((size_t)ctu * 3 + c) * 8 + 1] = wall_clock64();
     bool cbf;
     switch (d.l2) {
-      case 2: cbf = intra_block_wave<2>(s, ws, d, c, S, q8, grec, pw, lane); break;
-      case 3: cbf = intra_block_wave<3>(s, ws, d, c, S, c ? q16 : q8, grec, pw, lane); break;
-      default: cbf = intra_block_wave<4>(s, ws, d, c, S, q16, grec, pw, lane); break;
+      case 2: cbf = intra_block_wave<2>(s, ws, d, c, S, q8, grec, pw, lane, pub); break;
+      case 3: cbf = intra_block_wave<3>(s, ws, d, c, S, c ? q16 : q8, grec, pw, lane, pub); break;
+      default: cbf = intra_block_wave<4>(s, ws, d, c, S, q16, grec, pw, lane, pub); break;
     }
     KV_LAP(tk); nblk++;
+    if (f.trace && z == 32) ts = wall_clock64();
     PROF(10);
     if (cbf && z + lane < d.next) cu_cbf_s[z + lane] = 1;
     z = d.next;

@@ -809,106 +809,120 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
   return cbf;
 }
 
-// One workgroup (one wave) per (CTU, colour plane).  The CTU's coding units are reconstructed in z-order; CTUs are coupled by
-// progress counters that count the CTU's finished 8x8 luma units (f.sync: [CTU][plane]), published at the values neighbours wait
-// for.  A block waits only for the part of the left / upper / upper-right CTU it reads -- with coding units of at most 16x16 a CTU
-// starts when half of its left neighbour is done, not when it is complete -- and the neighbours' samples are copied into the CTU
-// picture's borders piecewise, as far as their progress allows.  (The decoder's k_dec_intra is the same scheme driven by the
-// transform-block list.)
-__global__ __launch_bounds__(64) void k_intra_recon(EncFrame f)
+// One workgroup of KVZ_INTRA_WAVES waves per (CTU, colour plane).  The CTU's coding units form a list in z-order; a wave takes the
+// next one, waits until the 8x8 units its reference samples lie in are final (kernel_common.h IntraChain: independent quadrants
+// run side by side), reconstructs it and marks its units.  CTUs are coupled by progress counters that count the CTU's leading
+// run of finished 8x8 luma units (f.sync: [CTU][plane]), published at the values neighbours wait for.  A block waits only for the
+// part of the left / upper / upper-right CTU it reads -- with coding units of at most 16x16 a CTU starts when half of its left
+// neighbour is done, not when it is complete -- and the neighbours' samples are copied into the CTU picture's borders piecewise, as
+// far as their progress allows.  (The decoder's k_dec_intra is the same scheme driven by the transform-block list.)
+#ifndef KVZ_INTRA_WAVES
+#define KVZ_INTRA_WAVES 4
+#endif
+__global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f)
 {
-  constexpr int T = 64;
+  constexpr int W = KVZ_INTRA_WAVES, T = 64 * W;
   __shared__ IntraCtuLds s;
-  __shared__ IntraWaveScratch ws;
-  __shared__ uint32_t bcast, bc4[4];
-  __shared__ IntraBlk blk[64];                              // by z of the coding unit's first 8x8 unit
+  __shared__ IntraWaveScratch wss[W];
+  __shared__ IntraChain ch;
+  __shared__ IntraBlk blk[64];                              // the CTU's coding units in z-order
+  __shared__ uint2 dep[64], cover[64];                      // per coding unit: units it waits for, units it finishes
+  __shared__ uint32_t nblk_s;
   __shared__ uint8_t cu_cbf_s[64];
   // Workgroups are dispatched in blockIdx order and a picture has more of them than fit on the chip at once, so they are numbered
   // the way the wavefront advances (f.intra_order: by cx + 2 cy -- every CTU a block depends on comes earlier) instead of in raster
   // order, where the right ends of the upper rows would hold the slots the lower left needs.
-  const int lane = threadIdx.x, wc = f.cw >> 6, c = (int)blockIdx.x % 3, ctu = (int)f.intra_order[blockIdx.x / 3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wc = f.cw >> 6, c = (int)blockIdx.x % 3, ctu = (int)f.intra_order[blockIdx.x / 3];
   const int row = ctu / wc, cx = ctu % wc;
   const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, P = 16 + 2 * S;
   uint32_t *my = f.sync + (size_t)ctu * 3 + c;
-  for (int i = lane; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];
+  for (int i = tid; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];
   const int qpl = ctu_quant_qp(f, cx * 64, row * 64), qp = c ? kChromaQp[qpl] : qpl;
-  // ---- everything the chain needs to know about the CTU's blocks, one lane per 8x8 unit (z-order)
-  {
+  const int hc = f.ch >> 6;
+  IntraNeighbours nb;
+  nb.nb_up = row > 0 && !tile_row_starts_at(hc, f.tile_rows, row); nb.nb_left = cx > 0; nb.nb_ur = nb.nb_up && cx + 1 < wc; nb.nb_ul = nb.nb_up && cx > 0;
+  nb.pl = my - 3; nb.pu = my - 3 * wc; nb.pur = nb.pu + 3; nb.pul = nb.pu - 3;
+  chain_init(ch, nb, 0u, 0u);
+  // ---- everything the chain needs to know about the CTU's coding units, one lane per 8x8 unit (z-order), compacted into a list
+  if (wave == 0) {
     int zx, zy; ctu_z_to_xy(lane, zx, zy);
     const int X = cx * 64 + zx * 8, Y = row * 64 + zy * 8, bi = b8idx(f, X, Y);
-    const int l2 = f.cu_log2[bi], mode = f.cu_intra_mode[bi], n = 1 << (l2 - sh), nl = 1 << l2;
+    const int l2 = f.cu_log2[bi], mode = f.cu_intra_mode[bi], n = 1 << (l2 - sh), nl = 1 << l2, su = nl >> 3;
     cu_cbf_s[lane] = 0;
-    const bool aL = X > 0, aT = avail64(f.cw, f.chp, X, Y, X, Y - 1);
-    const bool aBL = aL && avail64(f.cw, f.chp, X, Y, X - 1, Y + nl), aTR = aT && avail64(f.cw, f.chp, X, Y, X + nl, Y - 1);
-    IntraBlk d;
-    d.rx = (uint8_t)((zx * 8) >> sh); d.ry = (uint8_t)((zy * 8) >> sh);
-    // availability is decided per group of n samples (below-left, left, corner, above, above-right): each group lies in one block
-    // of this block's size, which either precedes this block in z-order or does not; the available groups are contiguous
-    d.lo = (uint8_t)(aBL ? 0 : (aL ? n : 2 * n + 1)); d.hi = (uint8_t)(aTR ? 4 * n : (aT ? 3 * n : (aL ? 2 * n - 1 : 0)));      // (nothing available: lo = 2n + 1 > hi = 0)
-    d.mode = (uint8_t)mode; d.l2 = (uint8_t)(l2 - sh);
-    d.flags = (uint8_t)((intra_filter_needed(n, c ? 1 : 0, mode) ? IB_FILT : 0) | ((zx == 0 || zy == 0) ? IB_BORDER : 0) |
-                        ((lane == 24 || lane == 32 || lane == 44 || lane == 48 || lane == 56 || lane == 60) ? IB_PUBLISH : 0));
-    d.xf = (uint8_t)((l2 - sh == 2 && c == 0) ? XF16_DST4 : l2 - sh - 1);
-    d.angle = (int16_t)kIntraAngle[mode]; d.inv = (int16_t)kInvAngle[mode];
-    d.zu = (uint16_t)lane; d.next = (uint16_t)(lane + (1 << (2 * (l2 - 3))));
-    blk[lane] = d;
+    const bool start = (lane & (su * su - 1)) == 0;
+    const uint64_t starts = __ballot(start);
+    const int k = __popcll(starts & ((1ull << lane) - 1ull));
+    if (start) {
+      const bool aL = X > 0, aT = avail64(f.cw, f.chp, X, Y, X, Y - 1);
+      const bool aBL = aL && avail64(f.cw, f.chp, X, Y, X - 1, Y + nl), aTR = aT && avail64(f.cw, f.chp, X, Y, X + nl, Y - 1);
+      IntraBlk d;
+      d.rx = (uint8_t)((zx * 8) >> sh); d.ry = (uint8_t)((zy * 8) >> sh);
+      // availability is decided per group of n samples (below-left, left, corner, above, above-right): each group lies in one block
+      // of this block's size, which either precedes this block in z-order or does not; the available groups are contiguous
+      d.lo = (uint8_t)(aBL ? 0 : (aL ? n : 2 * n + 1)); d.hi = (uint8_t)(aTR ? 4 * n : (aT ? 3 * n : (aL ? 2 * n - 1 : 0)));      // (nothing available: lo = 2n + 1 > hi = 0)
+      d.mode = (uint8_t)mode; d.l2 = (uint8_t)(l2 - sh);
+      d.flags = (uint8_t)((intra_filter_needed(n, c ? 1 : 0, mode) ? IB_FILT : 0) | ((zx == 0 || zy == 0) ? IB_BORDER : 0));
+      d.xf = (uint8_t)((l2 - sh == 2 && c == 0) ? XF16_DST4 : l2 - sh - 1);
+      d.angle = (int16_t)kIntraAngle[mode]; d.inv = (int16_t)kInvAngle[mode];
+      d.zu = (uint16_t)lane; d.next = (uint16_t)(lane + su * su);
+      blk[k] = d;
+      dep[k] = chain_dependencies(zx, zy, su);
+      cover[k] = chain_cover(lane, su);
+    }
+    if (lane == 0) nblk_s = (uint32_t)__popcll(starts);
   }
   const uint8_t *gsrc = f.src[c] + (size_t)(row * S) * pw + cx * S;
   uint8_t *plane = f.rec[c];
   uint8_t *grec = plane + (size_t)(row * S) * pw + cx * S;
   int16_t *gcoef = f.coef[c] + (size_t)(row * S) * pw + cx * S;
-  for (int k = lane; k < S * S / 16; k += T) { int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&s.src[y * S + xq * 16] = *(const uint4 *)&gsrc[(size_t)y * pw + xq * 16]; }
-  const int hc = f.ch >> 6;
-  const bool nb_up = row > 0 && !tile_row_starts_at(hc, f.tile_rows, row), nb_left = cx > 0, nb_ur = nb_up && cx + 1 < wc, nb_ul = nb_up && cx > 0;
-  IntraBorders bd;
-  bd.nb_up = nb_up; bd.nb_left = nb_left; bd.nb_ur = nb_ur; bd.nb_ul = nb_ul;
-  bd.pl = my - 3; bd.pu = my - 3 * wc; bd.pur = bd.pu + 3; bd.pul = bd.pu - 3;
-  if (f.trace && lane == 0) f.trace[((size_t)ctu * 3 + c) * 8 + 0] = wall_clock64();
-#ifdef KVZ_PROF
-  if (lane < 16) g_prof[lane] = 0;
+  for (int k = tid; k < S * S / 16; k += T) { int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&s.src[y * S + xq * 16] = *(const uint4 *)&gsrc[(size_t)y * pw + xq * 16]; }
+  if (f.trace && tid == 0) f.trace[((size_t)ctu * 3 + c) * 8 + 0] = wall_clock64();
   __syncthreads();
-  if (lane == 0) g_prof[15] = clock64();
-#endif
-  borders_begin(bd, bc4);
-  unsigned long long tb = 0, tk = 0, ts = 0, tp = 0, nblk = 0, tq = 0;       // trace: time in border waits / block / store / publish
-#define KV_LAP(acc) do { if (f.trace) { const unsigned long long n_ = wall_clock64(); acc += n_ - tq; tq = n_; } } while (0)
-  if (f.trace) tq = wall_clock64();
+  const int nblk = (int)nblk_s;
   const QuantConst q8 = quant_const(qp, 3 - sh, 1), q16 = quant_const(qp, 4 - sh, 1);      // (coding units are 8x8 or 16x16)
-  for (int z = 0; z < 64;) {
-    const IntraBlk d = wave_uniform(&blk[z]);              // (wave-uniform: what is derived from it runs on the scalar unit)
-    uint32_t *const pub = (d.flags & IB_PUBLISH) ? my : nullptr;
-    KV_LAP(tp);
-    PROF(1);
+  IntraWaveScratch &ws = wss[wave];
+  uint2 unacked = make_uint2(0u, 0u);                       // units this wave has finished but not yet drained its stores for
+  bool first = true;
+  for (;;) {
+    int k = 0;
+    if (lane == 0) k = (int)atomicAdd(&ch.claim, 1u);
+    k = __builtin_amdgcn_readfirstlane(k);
+    if (k >= nblk) break;
+    const IntraBlk d = wave_uniform(&blk[k]);              // (wave-uniform: what is derived from it runs on the scalar unit)
+    const uint2 dp = dep[k], cv = cover[k];
+    chain_wait_done(ch, make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)dp.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)dp.y)), f.err, lane);
     // the neighbouring CTUs' samples this block reads: wait for them, copy them into the borders of the CTU picture
-    if (d.flags & IB_BORDER) borders_need(bd, s.pic, P, plane, pw, cx, row, S, sh, 2 * S, d.rx, d.ry, 1 << d.l2, &bcast, f.err, lane, T);
-    KV_LAP(tb);
-    PROF(2);
-    if (f.trace && lane == 0 && z == 0) f.trace[((size_t)ctu * 3 + c) * 8 + 1] = wall_clock64();
+    if (d.flags & IB_BORDER) borders_need_wave(ch, nb, s.pic, P, plane, pw, cx, row, S, sh, 2 * S, d.rx, d.ry, 1 << d.l2, f.err, lane);
+    if (f.trace && first && k == 0 && lane == 0) f.trace[((size_t)ctu * 3 + c) * 8 + 1] = wall_clock64();
+    first = false;
     bool cbf;
     switch (d.l2) {
-      case 2: cbf = intra_block_wave<2>(s, ws, d, c, S, q8, grec, pw, lane, pub); break;
-      case 3: cbf = intra_block_wave<3>(s, ws, d, c, S, c ? q16 : q8, grec, pw, lane, pub); break;
-      default: cbf = intra_block_wave<4>(s, ws, d, c, S, q16, grec, pw, lane, pub); break;
+      case 2: cbf = intra_block_wave<2>(s, ws, d, c, S, q8, grec, pw, lane, nullptr); break;
+      case 3: cbf = intra_block_wave<3>(s, ws, d, c, S, c ? q16 : q8, grec, pw, lane, nullptr); break;
+      default: cbf = intra_block_wave<4>(s, ws, d, c, S, q16, grec, pw, lane, nullptr); break;
     }
-    KV_LAP(tk); nblk++;
-    if (f.trace && z == 32) ts = wall_clock64();
-    PROF(10);
-    if (cbf && z + lane < d.next) cu_cbf_s[z + lane] = 1;
-    z = d.next;
+    const uint2 cvu = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)cv.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)cv.y));
+    chain_mark_done(ch, cvu, lane);
+    // the stores of the block BEFORE this one have had this block's computation to be acknowledged: report them now
+    if (unacked.x | unacked.y) {
+      // (this block's own store was issued last: wait for all but the most recent store instruction)
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      chain_ack_publish(ch, unacked, my, lane);
+    }
+    unacked = cvu;
+    if (cbf && (int)d.zu + lane < (int)d.next) cu_cbf_s[d.zu + lane] = 1;
   }
-  for (int k = lane; k < S * S / 8; k += T) { int y = k / (S / 8), xq = k % (S / 8); *(uint4 *)&gcoef[(size_t)y * pw + xq * 8] = *(const uint4 *)&s.lev[y * S + xq * 8]; }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (unacked.x | unacked.y) chain_ack_publish(ch, unacked, my, lane);
   __syncthreads();
-  if (lane < 64 && cu_cbf_s[lane]) {
-    int zx, zy; ctu_z_to_xy(lane, zx, zy);
+  for (int k = tid; k < S * S / 8; k += T) { int y = k / (S / 8), xq = k % (S / 8); *(uint4 *)&gcoef[(size_t)y * pw + xq * 8] = *(const uint4 *)&s.lev[y * S + xq * 8]; }
+  if (tid < 64 && cu_cbf_s[tid]) {
+    int zx, zy; ctu_z_to_xy(tid, zx, zy);
     const int bi = b8idx(f, cx * 64 + zx * 8, row * 64 + zy * 8);
     atomicOr((uint32_t *)(f.cu_cbf + (bi & ~3)), (1u << c) << (8 * (bi & 3)));   // the three planes own one bit each of the byte
   }
-  publish_wt(my, 64u);
-#ifdef KVZ_PROF
-  __syncthreads();
-  if (f.trace && c == 0 && lane < 16) f.trace[(size_t)(f.cw / 64) * band_rows(f) * 24 + (size_t)ctu * 16 + lane] = (unsigned long long)g_prof[lane];   // (second half of the trace buffer)
-#endif
-  if (f.trace && lane == 0) { unsigned long long *t = f.trace + ((size_t)ctu * 3 + c) * 8; t[2] = wall_clock64(); t[3] = tb; t[4] = tk; t[5] = ts; t[6] = tp; t[7] = nblk; }
+  if (tid == 0) __hip_atomic_fetch_max(my, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (every wave has drained its stores: the barrier above)
+  if (f.trace && tid == 0) { unsigned long long *t = f.trace + ((size_t)ctu * 3 + c) * 8; t[2] = wall_clock64(); t[7] = (unsigned long long)nblk; }
 }
 
 // =============================================================================================
@@ -1653,7 +1667,7 @@ void launch_inter_signal(const EncFrame &f, hipStream_t st)
   hipLaunchKernelGGL(k_inter_signal, dim3((n + 255) / 256), dim3(256), 0, st, f);
 }
 void launch_intra_analyse(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_analyse, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f); }
-void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_recon, dim3(3 * (f.cw / 64) * band_rows(f)), dim3(64), 0, st, f); }
+void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_recon, dim3(3 * (f.cw / 64) * band_rows(f)), dim3(64 * KVZ_INTRA_WAVES), 0, st, f); }
 void launch_qp_resolve(const EncFrame &f, hipStream_t st)
 {
   if (!f.ctu_qy) return;

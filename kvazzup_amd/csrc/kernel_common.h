@@ -249,6 +249,155 @@ __device__ __forceinline__ void borders_need(IntraBorders &b, uint8_t *pic, int 
   if (loaded) __syncthreads();
 }
 
+// LDS traffic inside one wave needs no barrier instruction (a wave's LDS instructions execute in order); this keeps the compiler
+// from moving accesses across the point where lanes exchange data
+__device__ __forceinline__ void wave_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Several waves per (CTU, plane): blocks whose neighbours are final run side by side.  Inside a CTU a block depends only on the
+// blocks its reference samples lie in; in z-order that leaves independent chains -- the quadrant right of a finished quadrant
+// and the one below it, at every level -- so a CTU of sixty-four 8x8 blocks has a critical path of 36 blocks, not 64.  Waves take
+// blocks from the list in order (so whatever a wave waits for has been taken by another wave), wait on a mask of finished 8x8
+// units in LDS, and keep a second mask of units whose write-through stores have been acknowledged: its leading run of ones is
+// the progress the neighbouring CTUs may see.
+// ---------------------------------------------------------------------------------------------
+struct IntraChain {
+  uint32_t done[2];            // bit z: the 8x8 luma unit z (z-order) is final in the CTU picture in LDS
+  uint32_t acked[2];           // ... and in the picture in memory (the storing wave has drained its stores)
+  uint32_t claim;              // next list entry to be handed to a wave
+  uint32_t published;          // last progress value given to the neighbouring CTUs
+  int left_loaded, top_loaded, corner_loaded;       // how much of the borders has been copied into the CTU picture
+  uint32_t seen_l, seen_u, seen_ur, seen_ul;        // last observed progress of the neighbouring CTUs
+};
+struct IntraNeighbours {
+  const uint32_t *pl, *pu, *pur, *pul;       // progress counters of the left / upper / upper-right / upper-left CTU (same plane)
+  bool nb_left, nb_up, nb_ur, nb_ul;         // which of them exist (inside the picture, same tile)
+};
+__device__ __forceinline__ uint32_t lds_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int lds_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// thread 0 .. n of the workgroup; followed by a barrier in the caller
+__device__ __forceinline__ void chain_init(IntraChain &ch, const IntraNeighbours &nb, uint32_t done0, uint32_t done1)
+{
+  if (threadIdx.x == 0) {
+    ch.done[0] = done0; ch.done[1] = done1; ch.acked[0] = done0; ch.acked[1] = done1; ch.claim = 0; ch.published = 0;
+    ch.left_loaded = 0; ch.top_loaded = 0; ch.corner_loaded = 0;
+  }
+  if (threadIdx.x < 4) {
+    const uint32_t *p = threadIdx.x == 0 ? nb.pl : (threadIdx.x == 1 ? nb.pu : (threadIdx.x == 2 ? nb.pur : nb.pul));
+    const bool on = threadIdx.x == 0 ? nb.nb_left : (threadIdx.x == 1 ? nb.nb_up : (threadIdx.x == 2 ? nb.nb_ur : nb.nb_ul));
+    (&ch.seen_l)[threadIdx.x] = on ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  }
+}
+// one wave waits until *ctr >= need (last observed value cached in LDS for everybody); returns the value seen
+__device__ __forceinline__ uint32_t wave_wait_wt(const uint32_t *ctr, uint32_t need, uint32_t *seen, uint32_t *err, int lane)
+{
+  uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_load(seen));
+  if (v >= need) return v;
+  uint32_t spins = 0;
+  while ((v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+    if (++spins < 16) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(16);
+    if (spins > (1u << 22)) { if (lane == 0) atomicOr(err, 1u); v = 64; break; }           // bounded spin: never hang the GPU
+  }
+  v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+  if (lane == 0) atomicMax(seen, v);
+  return v;
+}
+// wave-level borders_need(): the borders the block at (rx, ry), size n, reads are in LDS when it returns.  Two waves may copy
+// overlapping pieces (the same bytes); the *_loaded marks only ever grow.
+__device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNeighbours &b, uint8_t *pic, int lp, const uint8_t *plane, int gp, int cx, int cy, int S, int sh,
+                                                  int lim_w, int rx, int ry, int n, uint32_t *err, int lane)
+{
+  if (rx == 0 && b.nb_left) {
+    const int need = imin(S, ry + 2 * n), have = __builtin_amdgcn_readfirstlane(lds_load(&ch.left_loaded));
+    if (need > have) {
+      const uint32_t seen = wave_wait_wt(b.pl, (uint32_t)kv_zunit8(7, ((need - 1) << sh) >> 3) + 1, &ch.seen_l, err, lane);
+      const int upto = imax(need, imin(S, kv_units_right(seen) * (8 >> sh)));
+      for (int i = have + lane; i < upto; i += 64) pic[(i + 1) * lp + 15] = (uint8_t)ld_l2_u8(plane + (size_t)(cy * S + i) * gp + cx * S - 1);
+      wave_sync();
+      if (lane == 0) atomicMax(&ch.left_loaded, upto);
+    }
+  }
+  if (ry == 0 && b.nb_up) {
+    const int lim = imin(lim_w, b.nb_ur ? 2 * S : S), need = imin(lim, rx + 2 * n), have = __builtin_amdgcn_readfirstlane(lds_load(&ch.top_loaded));
+    if (need > have) {
+      int upto = need;
+      if (have < S) {
+        const uint32_t seen = wave_wait_wt(b.pu, (uint32_t)kv_zunit8(((imin(S, need) - 1) << sh) >> 3, 7) + 1, &ch.seen_u, err, lane);
+        upto = imax(upto, imin(imin(S, lim), kv_units_bottom(seen) * (8 >> sh)));
+      }
+      if (need > S) {
+        const uint32_t seen = wave_wait_wt(b.pur, (uint32_t)kv_zunit8(((need - S - 1) << sh) >> 3, 7) + 1, &ch.seen_ur, err, lane);
+        upto = imax(upto, imin(lim, S + kv_units_bottom(seen) * (8 >> sh)));
+      }
+      // (both ends are multiples of 4: block sizes, CTU sizes and picture widths are)
+      for (int i = have + 4 * lane; i < upto; i += 4 * 64) *(uint32_t *)&pic[16 + i] = ld_l2_u32(plane + (size_t)(cy * S - 1) * gp + cx * S + i);
+      wave_sync();
+      if (lane == 0) atomicMax(&ch.top_loaded, upto);
+    }
+  }
+  if (rx == 0 && ry == 0 && b.nb_ul && !__builtin_amdgcn_readfirstlane(lds_load(&ch.corner_loaded))) {
+    wave_wait_wt(b.pul, 64u, &ch.seen_ul, err, lane);
+    if (lane == 0) { pic[15] = (uint8_t)ld_l2_u8(plane + (size_t)(cy * S - 1) * gp + cx * S - 1); }
+    wave_sync();
+    if (lane == 0) atomicMax(&ch.corner_loaded, 1);
+  }
+  wave_sync();
+}
+// 8x8 luma units (bits in z-order) the block with its first unit at (ux, uy), su x su units, reads reference samples from inside its
+// own CTU: the units left, below-left, above, above-right and above-left of it that precede it in z-order (inside a CTU:
+// precedes = available)
+__device__ __forceinline__ uint2 chain_dependencies(int ux, int uy, int su)
+{
+  const int z0 = kv_zunit8(ux, uy);
+  uint32_t m0 = 0, m1 = 0;
+  auto add = [&](int x, int y) {
+    if (x < 0 || y < 0 || x > 7 || y > 7) return;
+    const int z = kv_zunit8(x, y);
+    if (z >= z0) return;
+    if (z < 32) m0 |= 1u << z; else m1 |= 1u << (z - 32);
+  };
+  for (int i = -1; i < 2 * su; i++) { add(ux - 1, uy + i); add(ux + i, uy - 1); }
+  return make_uint2(m0, m1);
+}
+__device__ __forceinline__ uint2 chain_cover(int z0, int su)     // the su x su units starting at z0: a contiguous run in z-order
+{
+  const int n = su * su;
+  const unsigned long long m = (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) << z0;
+  return make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+}
+__device__ __forceinline__ void chain_wait_done(const IntraChain &ch, uint2 dep, uint32_t *err, int lane)
+{
+  uint32_t spins = 0;
+  for (;;) {
+    const uint32_t d0 = lds_load(&ch.done[0]), d1 = lds_load(&ch.done[1]);
+    if ((d0 & dep.x) == dep.x && (d1 & dep.y) == dep.y) break;
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 24)) { if (lane == 0) atomicOr(err, 2u); break; }
+  }
+}
+__device__ __forceinline__ void chain_mark_done(IntraChain &ch, uint2 cover, int lane)
+{
+  wave_sync();                                              // (the block's samples are in the CTU picture before the mark)
+  if (lane == 0) { if (cover.x) atomicOr(&ch.done[0], cover.x); if (cover.y) atomicOr(&ch.done[1], cover.y); }
+}
+// after the wave has drained its stores (s_waitcnt vmcnt(0)): the units in `cover` are final in memory; publishes the progress value
+// the leading run of acknowledged units amounts to when it passes a value neighbours wait for
+__device__ __forceinline__ void chain_ack_publish(IntraChain &ch, uint2 cover, uint32_t *ctr, int lane)
+{
+  if (lane != 0) return;
+  if (cover.x) atomicOr(&ch.acked[0], cover.x);
+  if (cover.y) atomicOr(&ch.acked[1], cover.y);
+  const uint32_t a0 = lds_load(&ch.acked[0]), a1 = lds_load(&ch.acked[1]);     // (re-read after both updates: whoever completes the masks sees them complete)
+  const int prefix = a0 != ~0u ? __builtin_ctz(~a0) : 32 + (a1 != ~0u ? __builtin_ctz(~a1) : 32);
+  const uint32_t m = prefix >= 64 ? 64u : (prefix >= 60 ? 60u : (prefix >= 56 ? 56u : (prefix >= 48 ? 48u : (prefix >= 44 ? 44u : (prefix >= 32 ? 32u : (prefix >= 24 ? 24u : 0u))))));
+  if (m && atomicMax(&ch.published, m) < m) __hip_atomic_fetch_max(ctr, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // thread layout of one block inside a workgroup of T threads (64: one wave, 256: four): OPL outputs per thread so that
 // (n / 2) row pairs x (n / OPL) output groups fit
 template <int L2, int T> struct XW {
@@ -427,14 +576,6 @@ struct alignas(16) IntraWaveScratch {
   uint8_t R[80];
   int16_t tr[256];                    // W between the inverse stages; decoder: also where the level words are scattered to
 };
-
-// LDS traffic inside one wave needs no barrier instruction (a wave's LDS instructions execute in order); this keeps the compiler
-// from moving accesses across the point where lanes exchange data
-__device__ __forceinline__ void wave_sync()
-{
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 
 __device__ __forceinline__ kv_f16x4 kv_h4(const uint16_t (&b)[4])
 {

@@ -222,7 +222,7 @@ def tilesplit_main(args):
     clip = [synth.frame_torch(synth.MOVING, 0x5EED0005, w, h, t, dev) for t in range(nclip)]     # every rank holds the stream (a band only reads its rows)
     torch.cuda.synchronize()
     be = BandEncoder(w, h, tile_rows, rank, world, options=(("qp", 32), ("period", 64), ("me-range", args.me_range)), device=dev_index,
-                     dist=dist if world > 1 else None)
+                     dist=dist if world > 1 else None, pipelined=True)     # the gather of picture t completes during picture t + 1
     nbytes = 0
     for t in range(args.warmup):
         be.encode(clip[t % nclip].data_ptr())
@@ -233,6 +233,9 @@ def tilesplit_main(args):
         au = be.encode(clip[t % nclip].data_ptr())
         if au is not None:
             nbytes += len(au)
+    au = be.flush()
+    if au is not None:
+        nbytes += len(au)
     torch.cuda.synchronize()
     barrier_max(dist, backend, dev, torch)
     elapsed = barrier_max(dist, backend, dev, torch, time.perf_counter() - t0)
@@ -245,7 +248,7 @@ def tilesplit_main(args):
                        "pictures_per_step": 1, "collective_backend": backend,
                        "intra_period": 64, "qp": 32, "me_range": args.me_range, "bytes_per_frame": round(nbytes / args.steps, 1),
                        "halo_bytes_per_picture_and_rank": round(be.halo_bytes_exchanged / max(1, total), 1),
-                       "exchange": "2 halo blocks per internal boundary and picture (4 luma + 2x2 chroma rows + CU records), send/recv"},
+                       "exchange": "2 halo blocks per internal boundary and picture (4 luma + 2x2 chroma rows + CU records), send/recv, in flight during the tokenizer and the arithmetic coder; substreams: fixed-size all_gather of the headers + padded gather of the payloads, completed during the next picture"},
             "roofline": None, "cpu_baseline": None}), flush=True)
     be.close()
     if world > 1:

@@ -77,6 +77,10 @@ KVZ_PUBLIC size_t kvzx_encoder_band_halo_bytes(kvz_encoder *enc);
 KVZ_PUBLIC int kvzx_encoder_band_export_halo(kvz_encoder *enc, void *d_up, void *d_down);
 KVZ_PUBLIC int kvzx_encoder_band_import_halo(kvz_encoder *enc, const void *d_from_up, const void *d_from_down);
 KVZ_PUBLIC int kvzx_encoder_band_phase2(kvz_encoder *enc, uint8_t *buf, uint32_t cap, uint32_t *sizes, int max_sub, int *nsub_out, kvz_frame_info *info);
+/* The same in two halves, so that the halo exchange runs beside the first: 2a (inner horizontal edges, tokenizer, arithmetic coder) needs
+ * nothing from the neighbouring bands and may be called BEFORE kvzx_encoder_band_import_halo; 2b (the band's two boundary edges) after it. */
+KVZ_PUBLIC int kvzx_encoder_band_phase2a(kvz_encoder *enc);
+KVZ_PUBLIC int kvzx_encoder_band_phase2b(kvz_encoder *enc, uint8_t *buf, uint32_t cap, uint32_t *sizes, int max_sub, int *nsub_out, kvz_frame_info *info);
 KVZ_PUBLIC int kvzx_assemble_access_unit(const kvz_config *cfg, int idr, int poc, int write_parameter_sets, int slice_qp, const uint8_t *data,
                                           const uint32_t *sizes, int nsub, uint8_t *out, uint32_t cap, uint32_t *len_out);
 

@@ -14,7 +14,7 @@ void launch_vaq(const EncFrame &f, int vaq, int *act, int *sum, hipStream_t st);
 void launch_sao(const EncFrame &f, hipStream_t st);        // SAO decision + filter: f.rec (deblocked) -> f.sao_out, parameters -> f.sao
 void launch_qp_resolve(const EncFrame &f, hipStream_t st);  // per-CTU QP: first coded CU, QpY, delta (no-op without a QP map)
 void launch_deblock_v(const EncFrame &f, hipStream_t st);   // vertical edges of the band
-void launch_deblock_h(const EncFrame &f, hipStream_t st);   // horizontal edges of the band, its two boundary edges included
+void launch_deblock_h(const EncFrame &f, hipStream_t st, int part = 0);   // part: 0 all horizontal edges of the band, 1 the inner ones, 2 its two boundary edges
 void launch_tokenize(const EncFrame &f, hipStream_t st);    // k_tokenize: bins of every CTU into its slot, pieces in completion order
 void launch_tok_compact(const EncFrame &f, hipStream_t st); // k_tok_compact: coding order restored, dense copy to host-mapped memory
 }  // namespace kvzx

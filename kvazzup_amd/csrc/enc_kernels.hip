@@ -1089,7 +1089,10 @@ __global__ __launch_bounds__(256) void k_deblock_v(EncFrame f)
     deblock_chroma_segment(f.rec[2] + (y >> 1) * cw2 + (x >> 1), 1, cw2, 2, qp);
   }
 }
-__global__ __launch_bounds__(256) void k_deblock_h(EncFrame f)
+// part: 0 = every horizontal edge of the band, 1 = the edges inside it (they need nothing from the neighbouring bands), 2 = its two
+// boundary edges (after the halo rows have arrived).  Horizontal edges lie 8 rows apart and change at most 3 rows on either side:
+// the order in which they are filtered does not matter.
+__global__ __launch_bounds__(256) void k_deblock_h(EncFrame f, int part)
 {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   // horizontal edges of the band: every 8 rows from its first row (when that is not the picture's) to its end (likewise);
@@ -1098,6 +1101,10 @@ __global__ __launch_bounds__(256) void k_deblock_h(EncFrame f)
   int ns = f.cw >> 2, ne = (yhi - ylo) / 8 + 1;
   if (t >= ne * ns) return;
   int x = (t % ns) * 4, y = ylo + (t / ns) * 8;
+  if (part) {
+    const bool boundary = y == f.row0 * 64 || y == (f.row0 + band_rows(f)) * 64;
+    if (boundary != (part == 2)) return;
+  }
   if (!is_cu_edge_h(f, x, y)) return;
   int bs = edge_bs(f, x, y - 1, x, y);
   if (!bs) return;
@@ -1680,15 +1687,15 @@ void launch_deblock_v(const EncFrame &f, hipStream_t st)
   int nv = ((f.cw >> 3) - 1) * (band_rows(f) * 16);
   hipLaunchKernelGGL(k_deblock_v, dim3((nv + 255) / 256), dim3(256), 0, st, f);
 }
-void launch_deblock_h(const EncFrame &f, hipStream_t st)
+void launch_deblock_h(const EncFrame &f, hipStream_t st, int part)
 {
   const int ylo = imax(8, f.row0 * 64), yhi = imin(f.ch - 8, (f.row0 + band_rows(f)) * 64);
   int nh = (f.cw >> 2) * ((yhi - ylo) / 8 + 1);
-  hipLaunchKernelGGL(k_deblock_h, dim3((nh + 255) / 256), dim3(256), 0, st, f);
+  hipLaunchKernelGGL(k_deblock_h, dim3((nh + 255) / 256), dim3(256), 0, st, f, part);
 }
 void launch_deblock(const EncFrame &f, hipStream_t st)
 {
-  if (f.nrows > 0) { launch_deblock_v(f, st); launch_deblock_h(f, st); return; }         // band of a tile-row split: two passes
+  if (f.nrows > 0) { launch_deblock_v(f, st); launch_deblock_h(f, st, 0); return; }         // band of a tile-row split: two passes
   hipLaunchKernelGGL(k_deblock_tile, dim3((f.cw / 64) * (f.ch / 64)), dim3(256), 0, st, f);
 }
 void launch_vaq(const EncFrame &f, int vaq, int *act, int *sum, hipStream_t st)

@@ -71,7 +71,9 @@ class Encoder {
   bool band_export_halo(uint8_t *d_up, uint8_t *d_down);         // the band's first / last 4 luma + 2 x 2 chroma rows (vertical edges filtered) and CU records of its first / last 8x8 row
   bool band_import_halo(const uint8_t *d_from_up, const uint8_t *d_from_down);   // nullptr: no neighbour on that side
   // horizontal-edge deblocking (boundary edges included), tokenizer, arithmetic coding: one substream per CTU row (WPP) or tile of the band
-  bool band_phase2(std::vector<std::vector<uint8_t>> *substreams, EncodedPicture *info);
+  bool band_phase2(std::vector<std::vector<uint8_t>> *substreams, EncodedPicture *info);      // = band_phase2a + band_phase2b
+  bool band_phase2a();                                            // what needs no halo: inner horizontal edges, tokenizer, arithmetic coder (may run beside the exchange, BEFORE band_import_halo)
+  bool band_phase2b(std::vector<std::vector<uint8_t>> *substreams, EncodedPicture *info);     // after band_import_halo: the band's two boundary edges; hands out the substreams
   int pending() const { return (int)(submitted_ - collected_); }
   // cropped reconstruction of the last coded picture -> host planes (stride = width)
   bool download_recon(uint8_t *y, uint8_t *u, uint8_t *v);
@@ -137,6 +139,7 @@ class Encoder {
   uint8_t *intra_scratch_ = nullptr;
   uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; uint32_t *tok_total_ = nullptr;
   size_t tok_dense_cap_ = 0;
+  std::vector<std::vector<uint8_t>> band_subs_; uint64_t band_bins_ = 0; bool band_coded_ = false;   // band mode: between phase 2a and 2b
   uint32_t *sync_ = nullptr; uint32_t *intra_order_ = nullptr; uint32_t *err_ = nullptr; unsigned long long *trace_ = nullptr;
   // one slot per picture in flight: the host-visible results of its kernels and what collect() needs to finish it
   struct EvPair { hipEvent_t a, b; KernelId id; };

@@ -529,27 +529,43 @@ bool Encoder::band_import_halo(const uint8_t *d_from_up, const uint8_t *d_from_d
   return true;
 }
 
-bool Encoder::band_phase2(std::vector<std::vector<uint8_t>> *substreams, EncodedPicture *info)
+// Second phase in two halves, so that the halo exchange can run beside the first: (a) needs nothing from the neighbouring bands --
+// the band's inner horizontal edges, the tokenizer, the host arithmetic coder (the tokens do not depend on deblocked samples) --
+// and (b), after the halo rows have been imported, filters the two boundary edges and closes the picture.
+bool Encoder::band_phase2a()
 {
-  if (cfg_.band_rows <= 0 || !substreams) return false;
+  if (cfg_.band_rows <= 0) return false;
   HIP_CHECK(hipSetDevice(cfg_.device));
   const EncFrame f = f_;
   Slot &sl = slot_[0];
-  if (cfg_.deblock) launch_deblock_h(f, stream_);
+  if (cfg_.deblock) launch_deblock_h(f, stream_, 1);
   launch_tokenize(f, stream_); launch_tok_compact(f, stream_);
   HIP_CHECK(hipStreamSynchronize(stream_));
   if (*sl.h_err) { fprintf(stderr, "kvazzup_amd: device error flags 0x%x\n", *sl.h_err); return false; }
   const int wc = cw_ / 64;
   for (int i = f.row0 * wc; i < (f.row0 + band_rows(f)) * wc; i++) if (sl.h_tok_count[i] < 0) { fprintf(stderr, "kvazzup_amd: token array overflow (CTU %d)\n", i); return false; }
-  uint64_t bins = 0;
+  band_bins_ = 0;
   entropy_->code_band(sl.h_tok_dense, sl.h_tok_count, sl.h_tok_off, wc, rows_, cfg_.wpp != 0, cfg_.tile_rows, band_intra_ ? 0 : 1, qp_cur_,
-                      f.row0, band_rows(f), *substreams, &bins);
-  if (info) { info->valid = true; info->poc = poc_; info->qp = qp_cur_; info->is_intra = band_intra_; info->bins = bins; info->au.clear(); }
+                      f.row0, band_rows(f), band_subs_, &band_bins_);
+  band_coded_ = true;
+  return true;
+}
+
+bool Encoder::band_phase2b(std::vector<std::vector<uint8_t>> *substreams, EncodedPicture *info)
+{
+  if (cfg_.band_rows <= 0 || !substreams || !band_coded_) return false;
+  HIP_CHECK(hipSetDevice(cfg_.device));
+  if (cfg_.deblock) { launch_deblock_h(f_, stream_, 2); HIP_CHECK(hipStreamSynchronize(stream_)); }
+  substreams->swap(band_subs_);
+  band_coded_ = false;
+  if (info) { info->valid = true; info->poc = poc_; info->qp = qp_cur_; info->is_intra = band_intra_; info->bins = band_bins_; info->au.clear(); }
   frame_idx_++;
   if (band_intra_) intra_count_++;
   ref_idx_ = cur_idx_; cur_idx_ = (cur_idx_ + 1) % nrec_; out_idx_ = ref_idx_;
   return true;
 }
+
+bool Encoder::band_phase2(std::vector<std::vector<uint8_t>> *substreams, EncodedPicture *info) { return band_phase2a() && band_phase2b(substreams, info); }
 
 bool Encoder::download_recon(uint8_t *y, uint8_t *u, uint8_t *v)
 {

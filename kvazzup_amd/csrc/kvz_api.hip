@@ -418,11 +418,15 @@ int kvzx_encoder_band_phase1(kvz_encoder *e, const void *d_i420) { return e && e
 size_t kvzx_encoder_band_halo_bytes(kvz_encoder *e) { return e ? e->impl->halo_bytes() : 0; }
 int kvzx_encoder_band_export_halo(kvz_encoder *e, void *d_up, void *d_down) { return e && e->impl->band_export_halo((uint8_t *)d_up, (uint8_t *)d_down) ? 1 : 0; }
 int kvzx_encoder_band_import_halo(kvz_encoder *e, const void *d_from_up, const void *d_from_down) { return e && e->impl->band_import_halo((const uint8_t *)d_from_up, (const uint8_t *)d_from_down) ? 1 : 0; }
-int kvzx_encoder_band_phase2(kvz_encoder *e, uint8_t *buf, uint32_t cap, uint32_t *sizes, int max_sub, int *nsub_out, kvz_frame_info *info)
+int kvzx_encoder_band_phase2a(kvz_encoder *e) { return e && e->impl->band_phase2a() ? 1 : 0; }
+static int band_phase2_out(kvz_encoder *e, bool both, uint8_t *buf, uint32_t cap, uint32_t *sizes, int max_sub, int *nsub_out, kvz_frame_info *info);
+int kvzx_encoder_band_phase2b(kvz_encoder *e, uint8_t *buf, uint32_t cap, uint32_t *sizes, int max_sub, int *nsub_out, kvz_frame_info *info) { return band_phase2_out(e, false, buf, cap, sizes, max_sub, nsub_out, info); }
+int kvzx_encoder_band_phase2(kvz_encoder *e, uint8_t *buf, uint32_t cap, uint32_t *sizes, int max_sub, int *nsub_out, kvz_frame_info *info) { return band_phase2_out(e, true, buf, cap, sizes, max_sub, nsub_out, info); }
+static int band_phase2_out(kvz_encoder *e, bool both, uint8_t *buf, uint32_t cap, uint32_t *sizes, int max_sub, int *nsub_out, kvz_frame_info *info)
 {
   if (!e || !buf || !sizes || !nsub_out) return 0;
   std::vector<std::vector<uint8_t>> subs; EncodedPicture ep;
-  if (!e->impl->band_phase2(&subs, &ep)) return 0;
+  if (!(both ? e->impl->band_phase2(&subs, &ep) : e->impl->band_phase2b(&subs, &ep))) return 0;
   if ((int)subs.size() > max_sub) return 0;
   size_t o = 0;
   for (size_t k = 0; k < subs.size(); k++) {

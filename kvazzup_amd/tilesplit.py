@@ -26,7 +26,7 @@ def band_partition(ctu_rows, tile_rows, world):
 class BandEncoder:
     """one rank's share of the split encoder; `dist` is torch.distributed (initialised) or None for a single process"""
 
-    def __init__(self, width, height, tile_rows, rank, world, options=(), device=0, dist=None):
+    def __init__(self, width, height, tile_rows, rank, world, options=(), device=0, dist=None, pipelined=False):
         self.torch, self.dist = None, dist
         if world > 1:
             import torch                        # (import torch before this library is first loaded in a process: two HIP runtimes)
@@ -55,6 +55,8 @@ class BandEncoder:
         L.kvzx_encoder_band_export_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.kvzx_encoder_band_import_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.kvzx_encoder_band_phase2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.kvzx_encoder_band_phase2a.argtypes = [C.c_void_p]
+        L.kvzx_encoder_band_phase2b.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         nh = int(L.kvzx_encoder_band_halo_bytes(self.enc))
         self.halo_out = self.halo_in = None
         if world > 1:
@@ -65,14 +67,17 @@ class BandEncoder:
         self.buf = np.empty(width * height * 3 + (1 << 20), dtype=np.uint8)
         self.sizes = np.zeros(self.ctu_rows, dtype=np.uint32)
         self.halo_bytes_exchanged = 0
+        self.pipelined, self.pending, self.intra_count = bool(pipelined), None, 0
+        self.dev = getattr(self, "dev", None)
 
-    # ---- the exchange step
-    def _exchange(self):
+    # ---- the exchange step, in two halves: the transfers are started, phase 2a (inner horizontal edges, tokenizer, host arithmetic
+    # coder -- nothing of it needs the neighbours) runs while they travel, then they are completed and imported
+    def _exchange_start(self):
         d, t = self.dist, self.torch
         up, down = self.rank - 1, self.rank + 1
         have_up, have_down = up >= 0, down < self.world
         if d is None or self.world == 1:
-            return have_up, have_down
+            return None
         staged = d.get_backend() != "nccl"
         send = [x.cpu() if staged else x for x in self.halo_out]
         recv = [t.empty_like(x) for x in send]
@@ -81,43 +86,105 @@ class BandEncoder:
             ops += [d.P2POp(d.isend, send[0], up), d.P2POp(d.irecv, recv[0], up)]
         if have_down:
             ops += [d.P2POp(d.isend, send[1], down), d.P2POp(d.irecv, recv[1], down)]
-        if ops:
-            for r in d.batch_isend_irecv(ops):
-                r.wait()
+        reqs = d.batch_isend_irecv(ops) if ops else []
+        return (reqs, send, recv, staged, have_up, have_down)
+
+    def _exchange_finish(self, st):
+        if st is None:
+            return False, False
+        reqs, _send, recv, staged, have_up, have_down = st
+        for r in reqs:
+            r.wait()
         for i, have in enumerate((have_up, have_down)):
             if have:
                 self.halo_in[i].copy_(recv[i])
                 self.halo_bytes_exchanged += 2 * recv[i].numel()
         if not staged:
-            t.cuda.synchronize(self.dev)
+            self.torch.cuda.synchronize(self.dev)
         return have_up, have_down
 
+    # ---- substreams to rank 0: fixed-size headers to everybody (every rank then knows the largest payload), payloads padded to that
+    # size to rank 0.  No pickling; with `pipelined` the payload gather of picture t completes during picture t + 1.
+    HDR = 4
+
+    def _gather_start(self, sizes, data, info):
+        d, t = self.dist, self.torch
+        mine = (sizes, data, info.poc, info.qp, info.nal_unit_type)
+        if d is None or self.world == 1:
+            return ("local", mine)
+        dev = self.dev if d.get_backend() == "nccl" else "cpu"
+        hdr = t.zeros(self.HDR + self.ctu_rows, dtype=t.int64, device=dev)
+        hdr[:self.HDR + len(sizes)] = t.tensor([len(sizes), info.poc, info.qp, info.nal_unit_type] + sizes, dtype=t.int64)
+        hdrs = [t.empty_like(hdr) for _ in range(self.world)]
+        d.all_gather(hdrs, hdr)
+        hdrs = [h.cpu().tolist() for h in hdrs]
+        totals = [sum(h[self.HDR:self.HDR + h[0]]) for h in hdrs]
+        cap = (max(totals) + 4095) & ~4095
+        pay = t.zeros(cap, dtype=t.uint8)
+        pay[:len(data)] = t.frombuffer(bytearray(data), dtype=t.uint8) if data else pay[:0]
+        pay = pay.to(dev)
+        outs = [t.empty_like(pay) for _ in range(self.world)] if self.rank == 0 else None
+        work = d.gather(pay, outs, dst=0, async_op=True)
+        return ("dist", work, hdrs, totals, outs, pay)
+
+    def _gather_finish(self, st):
+        if st[0] == "local":
+            parts = [st[1]]
+        else:
+            _, work, hdrs, totals, outs, _pay = st
+            work.wait()
+            if self.rank != 0:
+                return None
+            parts = []
+            for h, n, o in zip(hdrs, totals, outs):
+                parts.append(([int(x) for x in h[self.HDR:self.HDR + h[0]]], bytes(o[:n].cpu().numpy().tobytes()), h[1], h[2], h[3]))
+        if self.rank != 0:
+            return None
+        poc, nal = parts[0][2], parts[0][4]
+        idr = nal == 19
+        vp = self.cfg.contents.vps_period                 # parameter sets with every vps-period-th IDR, as the single encoder does
+        write_ps = idr and (self.intra_count == 0 or (vp > 0 and self.intra_count % vp == 0))
+        if idr:
+            self.intra_count += 1
+        return assemble(self.lib, self.cfg, parts, write_ps)
+
     def encode(self, d_i420_ptr):
-        """one picture; returns the access unit on rank 0 (None elsewhere)"""
+        """one picture; returns the access unit on rank 0 (None elsewhere).  With `pipelined` the access unit returned is the PREVIOUS
+        picture's (None for the first call); flush() returns the last one."""
         L = self.lib
         if not L.kvzx_encoder_band_phase1(self.enc, d_i420_ptr):
             raise RuntimeError("band_phase1 failed")
         if self.world > 1 and not L.kvzx_encoder_band_export_halo(self.enc, self.halo_out[0].data_ptr() if self.rank > 0 else None,
                                                                   self.halo_out[1].data_ptr() if self.rank + 1 < self.world else None):
             raise RuntimeError("band_export_halo failed")
-        have_up, have_down = self._exchange()
+        ex = self._exchange_start()
+        if not L.kvzx_encoder_band_phase2a(self.enc):          # runs while the halo blocks travel
+            raise RuntimeError("band_phase2a failed")
+        prev = None
+        if self.pending is not None:                            # the previous picture's payloads have had phase 1 and 2a of this one to arrive
+            prev = self._gather_finish(self.pending)
+            self.pending = None
+        have_up, have_down = self._exchange_finish(ex)
         if self.world > 1 and not L.kvzx_encoder_band_import_halo(self.enc, self.halo_in[0].data_ptr() if have_up else None, self.halo_in[1].data_ptr() if have_down else None):
             raise RuntimeError("band_import_halo failed")
         nsub = C.c_int(0)
         info = N.KvzFrameInfo()
-        if not L.kvzx_encoder_band_phase2(self.enc, self.buf.ctypes.data, len(self.buf), self.sizes.ctypes.data, len(self.sizes), C.byref(nsub), C.byref(info)):
-            raise RuntimeError("band_phase2 failed")
+        if not L.kvzx_encoder_band_phase2b(self.enc, self.buf.ctypes.data, len(self.buf), self.sizes.ctypes.data, len(self.sizes), C.byref(nsub), C.byref(info)):
+            raise RuntimeError("band_phase2b failed")
         sizes = [int(x) for x in self.sizes[:nsub.value]]
         data = bytes(self.buf[:sum(sizes)])
-        mine = (sizes, data, info.poc, info.qp, info.nal_unit_type)
-        if self.dist is not None and self.world > 1:
-            parts = [None] * self.world if self.rank == 0 else None
-            self.dist.gather_object(mine, parts, dst=0)
-        else:
-            parts = [mine]
-        if self.rank != 0:
+        st = self._gather_start(sizes, data, info)
+        if self.pipelined:
+            self.pending = st
+            return prev
+        return self._gather_finish(st)
+
+    def flush(self):
+        """pipelined mode: the access unit of the last picture (rank 0; None elsewhere or when nothing is pending)"""
+        if self.pending is None:
             return None
-        return assemble(self.lib, self.cfg, parts)
+        st, self.pending = self.pending, None
+        return self._gather_finish(st)
 
     def close(self):
         if self.enc:
@@ -128,22 +195,19 @@ class BandEncoder:
             self.cfg = None
 
 
-_intra_count = {}
-
-
-def assemble(lib, cfg, parts, write_parameter_sets=None):
+def assemble(lib, cfg, parts, write_parameter_sets=None, state=None):
     """rank 0: substreams of all bands in picture order -> one access unit (host only, no GPU)"""
     sizes = [s for p in parts for s in p[0]]
     data = b"".join(p[1] for p in parts)
     poc, qp, nal = parts[0][2], parts[0][3], parts[0][4]
     idr = nal == 19
-    if write_parameter_sets is None:                 # parameter sets with every vps-period-th IDR, as the single encoder does
-        key = C.addressof(cfg.contents)
-        n = _intra_count.get(key, 0)
+    if write_parameter_sets is None:                 # parameter sets with every vps-period-th IDR, as the single encoder does;
+        state = state if state is not None else {}  # `state`: the caller's own counter (a dict kept with its encoder), not anything keyed by an address
+        n = state.get("intra_count", 0)
         vp = cfg.contents.vps_period
         write_parameter_sets = idr and (n == 0 or (vp > 0 and n % vp == 0))
         if idr:
-            _intra_count[key] = n + 1
+            state["intra_count"] = n + 1
     lib.kvzx_assemble_access_unit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
     sz = np.array(sizes, dtype=np.uint32)
     src = np.frombuffer(data, dtype=np.uint8) if data else np.zeros(1, np.uint8)

@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     w, h, tile_rows, frames = (int(x) for x in sys.argv[1:5])
+    pipelined = len(sys.argv) > 5 and sys.argv[5] == "pipelined"        # access units arrive one picture late (the gather completes during the next picture)
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -24,16 +25,26 @@ def main():
     import numpy as np
     import orc
     opts = (("qp", 30), ("period", 4), ("me-range", 16))
-    be = BandEncoder(w, h, tile_rows, rank, world, options=opts, device=dev, dist=dist)
+    be = BandEncoder(w, h, tile_rows, rank, world, options=opts, device=dev, dist=dist, pipelined=pipelined)
     oe = orc.OracleEncoder(w, h, qp=30, period=4, me_range=16, tile_rows=tile_rows) if rank == 0 else None
     od = orc.OracleDecoder() if rank == 0 else None
     bad = 0
+    got = []
     for t in range(frames):
         frame = orc.synth_frame(0, 11, w, h, t)
         d = torch.from_numpy(frame).to("cuda:%d" % dev)
         au = be.encode(d.data_ptr())
-        if rank == 0:
+        if au is not None:
+            got.append(au)
+    au = be.flush()
+    if au is not None:
+        got.append(au)
+    if rank == 0:
+        assert len(got) == frames, (len(got), frames)
+        for t in range(frames):
+            frame = orc.synth_frame(0, 11, w, h, t)
             want = oe.encode(frame)
+            au = got[t]
             if au != want:
                 bad += 1
                 print("picture %d: split encoder %d bytes, checker %d bytes, equal=%s" % (t, len(au), len(want), au == want), flush=True)

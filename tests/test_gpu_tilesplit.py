@@ -32,10 +32,10 @@ def test_band_mode_single_process(gpu, w, h, tile_rows):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,tile_rows,ranks", [(320, 256, 2, 2), (256, 448, 4, 2), (1920, 1088, 4, 2)])
-def test_two_ranks_with_halo_exchange(gpu, w, h, tile_rows, ranks):
+@pytest.mark.parametrize("w,h,tile_rows,ranks,mode", [(320, 256, 2, 2, "sync"), (256, 448, 4, 2, "pipelined"), (1920, 1088, 4, 2, "pipelined")])
+def test_two_ranks_with_halo_exchange(gpu, w, h, tile_rows, ranks, mode):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
-           "--master-port", str(29500 + (w + h + tile_rows) % 400), os.path.join(ROOT, "tests", "run_tilesplit.py"), str(w), str(h), str(tile_rows), "6"]
+           "--master-port", str(29500 + (w + h + tile_rows) % 400), os.path.join(ROOT, "tests", "run_tilesplit.py"), str(w), str(h), str(tile_rows), "6", mode]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

@@ -221,7 +221,8 @@ def tilesplit_main(args):
     nclip = min(total, 32)
     clip = [synth.frame_torch(synth.MOVING, 0x5EED0005, w, h, t, dev) for t in range(nclip)]     # every rank holds the stream (a band only reads its rows)
     torch.cuda.synchronize()
-    be = BandEncoder(w, h, tile_rows, rank, world, options=(("qp", 32), ("period", 64), ("me-range", args.me_range)), device=dev_index,
+    coder_threads = max(1, min(16, int(cpu_budget(world)) - 1))     # the ranks of a node share its cores: each sizes its arithmetic-coder pool to its share
+    be = BandEncoder(w, h, tile_rows, rank, world, options=(("qp", 32), ("period", 64), ("me-range", args.me_range), ("threads", coder_threads)), device=dev_index,
                      dist=dist if world > 1 else None, pipelined=True)     # the gather of picture t completes during picture t + 1
     nbytes = 0
     for t in range(args.warmup):
@@ -250,6 +251,8 @@ def tilesplit_main(args):
                        "halo_bytes_per_picture_and_rank": round(be.halo_bytes_exchanged / max(1, total), 1),
                        "exchange": "2 halo blocks per internal boundary and picture (4 luma + 2x2 chroma rows + CU records), send/recv, in flight during the tokenizer and the arithmetic coder; substreams: fixed-size all_gather of the headers + padded gather of the payloads, completed during the next picture"},
             "roofline": None, "cpu_baseline": None}), flush=True)
+    if os.environ.get("KVAZZUP_BENCH_TILESPLIT_TIMES"):
+        print("rank %d seconds per phase over %d pictures: %s" % (rank, total, {k: round(v, 4) for k, v in getattr(be, "times", {}).items()}), file=sys.stderr, flush=True)
     be.close()
     if world > 1:
         dist.destroy_process_group()

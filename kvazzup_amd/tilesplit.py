@@ -152,28 +152,42 @@ class BandEncoder:
         """one picture; returns the access unit on rank 0 (None elsewhere).  With `pipelined` the access unit returned is the PREVIOUS
         picture's (None for the first call); flush() returns the last one."""
         L = self.lib
+        import time
+        T = self.times = getattr(self, "times", {})
+        def lap(name, t0):
+            T[name] = T.get(name, 0.0) + time.perf_counter() - t0
+            return time.perf_counter()
+        t0 = time.perf_counter()
         if not L.kvzx_encoder_band_phase1(self.enc, d_i420_ptr):
             raise RuntimeError("band_phase1 failed")
+        t0 = lap("phase1", t0)
         if self.world > 1 and not L.kvzx_encoder_band_export_halo(self.enc, self.halo_out[0].data_ptr() if self.rank > 0 else None,
                                                                   self.halo_out[1].data_ptr() if self.rank + 1 < self.world else None):
             raise RuntimeError("band_export_halo failed")
+        t0 = lap("export", t0)
         ex = self._exchange_start()
+        t0 = lap("exchange_start", t0)
         if not L.kvzx_encoder_band_phase2a(self.enc):          # runs while the halo blocks travel
             raise RuntimeError("band_phase2a failed")
+        t0 = lap("phase2a", t0)
         prev = None
         if self.pending is not None:                            # the previous picture's payloads have had phase 1 and 2a of this one to arrive
             prev = self._gather_finish(self.pending)
             self.pending = None
+        t0 = lap("gather_finish", t0)
         have_up, have_down = self._exchange_finish(ex)
+        t0 = lap("exchange_finish", t0)
         if self.world > 1 and not L.kvzx_encoder_band_import_halo(self.enc, self.halo_in[0].data_ptr() if have_up else None, self.halo_in[1].data_ptr() if have_down else None):
             raise RuntimeError("band_import_halo failed")
         nsub = C.c_int(0)
         info = N.KvzFrameInfo()
         if not L.kvzx_encoder_band_phase2b(self.enc, self.buf.ctypes.data, len(self.buf), self.sizes.ctypes.data, len(self.sizes), C.byref(nsub), C.byref(info)):
             raise RuntimeError("band_phase2b failed")
+        t0 = lap("import+phase2b", t0)
         sizes = [int(x) for x in self.sizes[:nsub.value]]
         data = bytes(self.buf[:sum(sizes)])
         st = self._gather_start(sizes, data, info)
+        t0 = lap("gather_start", t0)
         if self.pipelined:
             self.pending = st
             return prev

@@ -136,6 +136,26 @@ __global__ __launch_bounds__(256) void k_dec_inter(DecFrame f)
   }
   if (tid >= 64 && tid < 80) ((uint32_t *)s.mask)[tid - 64] = 0;
   __syncthreads();
+  // ---- the region of a still background: one motion for all of it, the zero vector, no transform block -- a copy of the
+  // reference region (most regions of a video call's inter pictures; everything below is for the others)
+  {
+    const B4Rec r0 = s.recs[0];
+    bool same = true;
+    if (tid < 64) { const B4Rec r = s.recs[tid]; same = r.ref_idx == r0.ref_idx && r.slot == r0.slot && r.mvx == 0 && r.mvy == 0; }
+    if (__syncthreads_and(same) && r0.ref_idx >= 0 && reg.count == 0) {
+      const int slot = r0.slot & 15;
+      {
+        const size_t o = (size_t)(y0 + (tid >> 3)) * f.pw + x0 + (tid & 7) * 4;
+        *(uint32_t *)&f.rec[0][o] = *(const uint32_t *)&f.ref[slot][0][o];
+      }
+      if (tid < 128) {
+        const int pl = 1 + (tid >> 6), y = (tid >> 2) & 15, x = (tid & 3) * 4;
+        const size_t o = (size_t)((y0 >> 1) + y) * cpitch + (x0 >> 1) + x;
+        *(uint32_t *)&f.rec[pl][o] = *(const uint32_t *)&f.ref[slot][pl][o];
+      }
+      return;
+    }
+  }
   bool my_coded = false;
   if (tid < 16) {
     const B4Rec *r = &s.recs[(tid >> 2) * 16 + (tid & 3) * 2];

@@ -17,4 +17,17 @@ void launch_deblock_v(const EncFrame &f, hipStream_t st);   // vertical edges of
 void launch_deblock_h(const EncFrame &f, hipStream_t st, int part = 0);   // part: 0 all horizontal edges of the band, 1 the inner ones, 2 its two boundary edges
 void launch_tokenize(const EncFrame &f, hipStream_t st);    // k_tokenize: bins of every CTU into its slot, pieces in completion order
 void launch_tok_compact(const EncFrame &f, hipStream_t st); // k_tok_compact: coding order restored, dense copy to host-mapped memory
+// k_cabac_rows (cabac_kernels.hip): the arithmetic coder proper on the GPU, one wave per substream
+struct CabacRowsArgs {
+  const uint16_t *tok; const int32_t *count; const uint32_t *off;   // dense tokens (device): CTU i has count[i] tokens at tok + off[i]
+  uint8_t *stage; uint32_t stage_cap;     // device: every substream codes into a range reserved for its worst case
+  uint8_t *out; uint32_t out_cap;         // host-mapped: the finished substreams, dense, in completion order
+  uint32_t *cursors;                      // device {staging bytes reserved, output bytes reserved}: zero before the launch (k_tok_compact)
+  uint32_t *sub_off, *sub_len, *sub_bins; // host-mapped, per substream of the launch: byte range in `out`, bins coded; sub_len == ~0u: did not fit
+  uint32_t *ctx_save, *ctx_ready;         // device [CTU rows][40] context words after the row's second CTU, [CTU rows] generation of that copy
+  uint32_t gen;                           // generation of this launch (differs from the previous launch with the same arrays)
+  uint32_t *err;                          // device error flags (64: a row waited for its upper neighbour in vain)
+  int wc, hc, wpp, tile_rows, init_type, qp, first_sub;
+};
+void launch_cabac_rows(const CabacRowsArgs &a, int nsub, hipStream_t st);
 }  // namespace kvzx

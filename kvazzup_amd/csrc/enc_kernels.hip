@@ -1363,7 +1363,7 @@ __global__ __launch_bounds__(256) void k_tok_compact(EncFrame f)
   const uint32_t n = f.tok_cursor[ctu];
   // a place in the dense array (CTUs land in completion order: the host gets each CTU's offset), the slot's
   // cursor back to zero for the next picture, and the device error word over to the host
-  if (tid == 0) { base_s = atomicAdd(f.tok_total, n); if (blockIdx.x == 0) *f.err_out = *f.err; }
+  if (tid == 0) { base_s = atomicAdd(f.tok_total, n); if (blockIdx.x == 0) { *f.err_out = *f.err; if (f.ent_cursors) { f.ent_cursors[0] = 0; f.ent_cursors[1] = 0; } } }
   __syncthreads();
   const uint32_t base = base_s;
   if (tid == 0) f.tok_cursor[ctu] = 0;

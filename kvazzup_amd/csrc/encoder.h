@@ -18,7 +18,7 @@
 namespace kvzx {
 
 // K_HOST_ARITH is not a kernel: wall time of the host arithmetic-coding stage (entropy_host.h)
-enum KernelId { K_PAD = 0, K_ME, K_INTER_RECON, K_INTER_SIGNAL, K_INTRA_ANALYSE, K_INTRA_RECON, K_DEBLOCK, K_TOKENIZE, K_HOST_ARITH, K_SAO, K_TOK_COMPACT, K_COUNT };
+enum KernelId { K_PAD = 0, K_ME, K_INTER_RECON, K_INTER_SIGNAL, K_INTRA_ANALYSE, K_INTRA_RECON, K_DEBLOCK, K_TOKENIZE, K_HOST_ARITH, K_SAO, K_TOK_COMPACT, K_CABAC_ROWS, K_COUNT };
 
 struct EncoderConfig {
   int width = 0, height = 0;
@@ -39,6 +39,7 @@ struct EncoderConfig {
   int vaq = 0;                // kvazaar "vaq" 1..20: "uvgx VAQ v1" (oracle/hevc_enc.c vaq_deltas()); implies qp_in_cu
   int mv_frame = 0;           // kvazaar "mv-constraint" frame / frametile (1), frametilemargin (2): vectors keep the block inside the picture
   int sao = 0;                // kvazaar "sao": sample adaptive offset, parameters by "uvgx SAO decision v1" (oracle/hevc_sao.c)
+  int entropy_gpu = 0;        // arithmetic coder: 1 = on the GPU (k_cabac_rows, cabac_kernels.hip), 0 = host thread pool (entropy_host.h); band mode always uses the host pool
   int owf = 0;                // kvazaar "owf": 0 = encode() returns its own picture; 1 = output lags one picture and the host
                               // coding of picture t overlaps the kernels of t + 1; >= 2 = output lags two pictures and the host
                               // coding runs on a background thread, so the calling thread only launches kernels
@@ -109,7 +110,7 @@ class Encoder {
   uint8_t *h_in_ = nullptr;              // pinned host staging
   uint8_t *src_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // padded source planes, one set per picture parity
   // reconstruction ring: the picture being coded, its reference, and (owf >= 2) the one still waiting to be output
-  uint8_t *rec_[4][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  uint8_t *rec_[10][3] = {};
   bool spin_wait_ = false;      // KVAZZUP_AMD_SPIN: poll the GPU instead of napping between queries
   int nrec_ = 3;                // reconstruction ring: the picture being written, its reference, and the ones whose output is still owed (owf)
   int cur_idx_ = 0, ref_idx_ = 2, out_idx_ = 2;
@@ -147,12 +148,19 @@ class Encoder {
     uint16_t *h_tok_dense = nullptr, *d_tok_dense = nullptr; int32_t *h_tok_count = nullptr, *d_tok_count = nullptr;   // host-mapped pinned
     uint32_t *h_tok_off = nullptr, *d_tok_off = nullptr;
     uint32_t *h_err = nullptr, *d_err = nullptr;
-    hipEvent_t done = nullptr, rec_done = nullptr;       // tokens delivered (stream_tok_) / reconstruction final (stream_)
+    // GPU arithmetic coder (cfg.entropy_gpu): dense tokens stay in device memory (d_tok_dense .. d_tok_off point there), the coder runs on the slot's own
+    // stream -- a substream is a ~0.1-1 ms serial chain, so several pictures' coders must be able to run side by side
+    uint16_t *g_tok = nullptr; int32_t *g_count = nullptr; uint32_t *g_off = nullptr;
+    uint8_t *g_stage = nullptr; uint32_t *g_cursors = nullptr, *g_ctx_save = nullptr, *g_ctx_ready = nullptr;
+    uint8_t *h_out = nullptr, *d_out = nullptr; uint32_t *h_sub = nullptr, *d_sub = nullptr;   // host-mapped: substream bytes; [3][nsub] offset, length, bins
+    hipStream_t ent_stream = nullptr; hipEvent_t tok_ev = nullptr; uint32_t gen = 0;
+    hipEvent_t done = nullptr, rec_done = nullptr;       // tokens / substreams delivered (stream_tok_ / ent_stream) / reconstruction final (stream_)
     int poc = 0, rec_idx = 0, set = 0, qp = 0; bool intra = false, write_ps = false;
     std::vector<EvPair> ev; size_t ev_used = 0;
     EncodedPicture result; bool ready = false, ok = true;   // owf >= 2: filled by the background thread
   };
-  Slot slot_[4]; Slot *cur_slot_ = nullptr; int nslots_ = 1, depth_ = 0;
+  Slot slot_[10]; Slot *cur_slot_ = nullptr; int nslots_ = 1, depth_ = 0;
+  size_t stage_cap_ = 0, out_cap_ = 0;
   std::thread bg_[2]; std::mutex bm_; std::condition_variable bcv_; std::deque<int> bq_; bool bquit_ = false;
   std::mutex stat_m_;
   long submitted_ = 0, collected_ = 0;

@@ -47,6 +47,8 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
                     tile_row_ends_at(hc, T, cfg.band_row0 + cfg.band_rows - 1) && cfg.bitrate == 0 && !cfg.sao && cfg.vaq == 0;
     if (!ok) { if (error) *error = "a band must consist of whole tile rows (and rate control, SAO and VAQ are not available in band mode)"; return false; }
   }
+  if (const char *e = getenv("KVAZZUP_AMD_ENTROPY")) cfg.entropy_gpu = strcmp(e, "gpu") == 0;    // A/B knob: host | gpu
+  if (cfg.band_rows > 0) cfg.entropy_gpu = 0;               // (band mode hands its substreams to the caller from the host pool)
   cfg_ = cfg;
   qp_cur_ = cfg.qp;
   int ndev = 0;
@@ -57,7 +59,10 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   cw_ = (cfg.width + 63) & ~63; ch_ = (cfg.height + 63) & ~63;
   if (cw_ < 128) cw_ = 128;
   rows_ = ch_ / 64;
-  nrec_ = (cfg.owf >= 3 && cfg.bitrate == 0) ? 4 : 3;
+  // pictures in flight behind the one being submitted (output lag).  Rate control books picture t - 3 before picture t: lag <= 2.  The GPU
+  // arithmetic coder is a longer stage than the host pool (a substream is one serial chain), so it profits from more pictures in flight.
+  depth_ = cfg.owf >= 3 && cfg.bitrate == 0 ? (cfg.entropy_gpu ? (cfg.owf > 8 ? 8 : cfg.owf) : 3) : (cfg.owf >= 2 ? 2 : (cfg.owf == 1 ? 1 : 0));
+  nrec_ = depth_ + 1 < 3 ? 3 : depth_ + 1;
   HIP_OK(create_stream(&stream_, prio[0]));
   const size_t npx = (size_t)cw_ * ch_, nb8 = npx / 64, in_bytes = (size_t)cfg.width * cfg.height * 3 / 2;
   HIP_OK(hipMalloc(&d_in_, in_bytes));
@@ -104,17 +109,34 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   tok_dense_cap_ = (size_t)nctu * tok_cap_;
   if (tok_dense_cap_ > ((size_t)1 << 27)) tok_dense_cap_ = (size_t)1 << 27;
   spin_wait_ = getenv("KVAZZUP_AMD_SPIN") != nullptr;
-  depth_ = cfg.owf >= 3 && cfg.bitrate == 0 ? 3 : (cfg.owf >= 2 ? 2 : (cfg.owf == 1 ? 1 : 0));   // (rate control books picture t - 3 before picture t: lag <= 2)
   nslots_ = depth_ + 1;
+  stage_cap_ = tok_dense_cap_ * 2 + 256 * (size_t)rows_; if (stage_cap_ > 0xfff00000u) stage_cap_ = 0xfff00000u;
+  out_cap_ = (size_t)cw_ * ch_ * 3 + 4096; if (out_cap_ > stage_cap_) out_cap_ = stage_cap_;       // twice the raw picture: a larger access unit is not a picture this encoder makes
   for (int i = 0; i < nslots_; i++) {
     Slot &sl = slot_[i];
     void *dp = nullptr;
-    HIP_OK(hipHostMalloc(&sl.h_tok_dense, tok_dense_cap_ * sizeof(uint16_t), hipHostMallocMapped));
-    HIP_OK(hipHostMalloc(&sl.h_tok_count, sizeof(int32_t) * nctu, hipHostMallocMapped));
-    HIP_OK(hipHostGetDevicePointer(&dp, sl.h_tok_dense, 0)); sl.d_tok_dense = (uint16_t *)dp;
-    HIP_OK(hipHostGetDevicePointer(&dp, sl.h_tok_count, 0)); sl.d_tok_count = (int32_t *)dp;
-    HIP_OK(hipHostMalloc(&sl.h_tok_off, sizeof(uint32_t) * nctu, hipHostMallocMapped));
-    HIP_OK(hipHostGetDevicePointer(&dp, sl.h_tok_off, 0)); sl.d_tok_off = (uint32_t *)dp;
+    if (cfg.entropy_gpu) {
+      HIP_OK(hipMalloc(&sl.g_tok, tok_dense_cap_ * sizeof(uint16_t)));
+      HIP_OK(hipMalloc(&sl.g_count, sizeof(int32_t) * nctu)); HIP_OK(hipMalloc(&sl.g_off, sizeof(uint32_t) * nctu));
+      sl.d_tok_dense = sl.g_tok; sl.d_tok_count = sl.g_count; sl.d_tok_off = sl.g_off;
+      HIP_OK(hipMalloc(&sl.g_stage, stage_cap_));
+      HIP_OK(hipMalloc(&sl.g_cursors, 2 * sizeof(uint32_t))); HIP_OK(hipMemset(sl.g_cursors, 0, 2 * sizeof(uint32_t)));
+      HIP_OK(hipMalloc(&sl.g_ctx_save, sizeof(uint32_t) * 40 * rows_));
+      HIP_OK(hipMalloc(&sl.g_ctx_ready, sizeof(uint32_t) * rows_)); HIP_OK(hipMemset(sl.g_ctx_ready, 0, sizeof(uint32_t) * rows_));
+      HIP_OK(hipHostMalloc(&sl.h_out, out_cap_, hipHostMallocMapped));
+      HIP_OK(hipHostGetDevicePointer(&dp, sl.h_out, 0)); sl.d_out = (uint8_t *)dp;
+      HIP_OK(hipHostMalloc(&sl.h_sub, sizeof(uint32_t) * 3 * rows_, hipHostMallocMapped));
+      HIP_OK(hipHostGetDevicePointer(&dp, sl.h_sub, 0)); sl.d_sub = (uint32_t *)dp;
+      HIP_OK(create_stream(&sl.ent_stream, 'l'));           // (streams of one priority level share that level's hardware queues: the long coder kernels get the lowest level to themselves)
+      HIP_OK(hipEventCreateWithFlags(&sl.tok_ev, hipEventDisableTiming));
+    } else {
+      HIP_OK(hipHostMalloc(&sl.h_tok_dense, tok_dense_cap_ * sizeof(uint16_t), hipHostMallocMapped));
+      HIP_OK(hipHostMalloc(&sl.h_tok_count, sizeof(int32_t) * nctu, hipHostMallocMapped));
+      HIP_OK(hipHostGetDevicePointer(&dp, sl.h_tok_dense, 0)); sl.d_tok_dense = (uint16_t *)dp;
+      HIP_OK(hipHostGetDevicePointer(&dp, sl.h_tok_count, 0)); sl.d_tok_count = (int32_t *)dp;
+      HIP_OK(hipHostMalloc(&sl.h_tok_off, sizeof(uint32_t) * nctu, hipHostMallocMapped));
+      HIP_OK(hipHostGetDevicePointer(&dp, sl.h_tok_off, 0)); sl.d_tok_off = (uint32_t *)dp;
+    }
     HIP_OK(hipHostMalloc(&sl.h_err, sizeof(uint32_t), hipHostMallocMapped)); *sl.h_err = 0;
     HIP_OK(hipHostGetDevicePointer(&dp, sl.h_err, 0)); sl.d_err = (uint32_t *)dp;
     HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
@@ -134,7 +156,8 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   if (getenv("KVAZZUP_AMD_INTRA_TRACE")) { HIP_OK(hipMalloc(&trace_, sizeof(unsigned long long) * rows_ * (cw_ / 64) * 40)); HIP_OK(hipMemset(trace_, 0, sizeof(unsigned long long) * rows_ * (cw_ / 64) * 40)); }
   int eth = cfg.entropy_threads;
   if (const char *e = getenv("KVAZZUP_AMD_ENTROPY_THREADS")) eth = atoi(e) < 1 ? 1 : atoi(e);     // tuning knob (containers with a small CPU quota)
-  if (cfg.owf >= 2 && eth >= 4) {                        // two pictures side by side, half the threads each
+  if (cfg.entropy_gpu) { entropy_ = nullptr; entropy2_ = nullptr; }
+  else if (cfg.owf >= 2 && eth >= 4) {                        // two pictures side by side, half the threads each
     entropy_ = new EntropyHost((eth + 1) / 2 < rows_ ? (eth + 1) / 2 : rows_);
     entropy2_ = new EntropyHost(eth / 2 < rows_ ? eth / 2 : rows_);
   } else entropy_ = new EntropyHost(eth < rows_ ? eth : rows_);
@@ -190,12 +213,17 @@ Encoder::~Encoder()
     if (sl.h_tok_count) hipHostFree(sl.h_tok_count);
     if (sl.h_err) hipHostFree(sl.h_err);
     if (sl.h_tok_off) hipHostFree(sl.h_tok_off);
+    if (sl.ent_stream) { hipStreamSynchronize(sl.ent_stream); hipStreamDestroy(sl.ent_stream); }
+    if (sl.tok_ev) hipEventDestroy(sl.tok_ev);
+    hipFree(sl.g_tok); hipFree(sl.g_count); hipFree(sl.g_off); hipFree(sl.g_stage); hipFree(sl.g_cursors); hipFree(sl.g_ctx_save); hipFree(sl.g_ctx_ready);
+    if (sl.h_out) hipHostFree(sl.h_out);
+    if (sl.h_sub) hipHostFree(sl.h_sub);
     if (sl.done) hipEventDestroy(sl.done);
     if (sl.rec_done) hipEventDestroy(sl.rec_done);
   }
   if (in_done_) hipEventDestroy(in_done_);
   hipFree(d_in_); hipHostFree(h_in_);
-  for (int c = 0; c < 3; c++) { hipFree(src_[0][c]); hipFree(src_[1][c]); for (int b = 0; b < 4; b++) hipFree(rec_[b][c]); hipFree(coef_[0][c]); hipFree(coef_[1][c]); }
+  for (int c = 0; c < 3; c++) { hipFree(src_[0][c]); hipFree(src_[1][c]); for (int b = 0; b < 10; b++) hipFree(rec_[b][c]); hipFree(coef_[0][c]); hipFree(coef_[1][c]); }
   hipFree(vaq_act_); hipFree(vaq_sum_);
   for (int k = 0; k < 2; k++) { hipFree(ctu_qt_[k]); hipFree(ctu_qy_[k]); hipFree(ctu_delta_[k]); hipFree(ctu_first_[k]); if (h_ctu_qt_[k]) hipHostFree(h_ctu_qt_[k]); }
   for (int k = 0; k < 2; k++) { hipFree(cu_bytes_[k]); hipFree(cu_mv_[k]); hipFree(cu_mvd_[k]); if (ev_tok_done_[k]) hipEventDestroy(ev_tok_done_[k]); }
@@ -321,7 +349,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   f_.qp = qp_cur_; f_.qpc = kChromaQp[qp_cur_]; f_.lambda_q4 = kLambdaQ4[qp_cur_];
   f_.is_intra = intra; f_.poc = poc_;
   for (int c = 0; c < 3; c++) { f_.rec[c] = cfg_.sao ? work_[c] : rec_[cur_idx_][c]; f_.sao_out[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
-  f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err;
+  f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err; f_.ent_cursors = sl.g_cursors;
   const EncFrame f = f_;
   if (src_busy_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_src_free_[set_], 0)); src_busy_[set_] = false; }   // reconstruction of t - 2 has read this source set
   timed(K_PAD, stream_in_, [&] { launch_pad_input(d_i420, w, h, src_[set_][0], src_[set_][1], src_[set_][2], cw_, ch_, stream_in_); });
@@ -357,6 +385,19 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   timed(K_TOK_COMPACT, stream_tok_, [&] { launch_tok_compact(f, stream_tok_); });
   HIP_CHECK(hipEventRecord(ev_tok_done_[set_], stream_tok_)); tok_pending_[set_] = true;
   // the slot is complete when both streams are: the tokens (stream_tok_) and the reconstruction (stream_)
+  if (cfg_.entropy_gpu) {
+    // arithmetic coding on the slot's own stream, behind the compaction: the coders of several pictures run side by side
+    HIP_CHECK(hipEventRecord(sl.tok_ev, stream_tok_));
+    HIP_CHECK(hipStreamWaitEvent(sl.ent_stream, sl.tok_ev, 0));
+    const int nsub = cfg_.wpp ? rows_ : cfg_.tile_rows;
+    CabacRowsArgs a;
+    a.tok = sl.g_tok; a.count = sl.g_count; a.off = sl.g_off; a.stage = sl.g_stage; a.stage_cap = (uint32_t)stage_cap_; a.out = sl.d_out; a.out_cap = (uint32_t)out_cap_;
+    a.cursors = sl.g_cursors; a.sub_off = sl.d_sub; a.sub_len = sl.d_sub + rows_; a.sub_bins = sl.d_sub + 2 * rows_;
+    a.ctx_save = sl.g_ctx_save; a.ctx_ready = sl.g_ctx_ready; a.gen = ++sl.gen; a.err = err_;
+    a.wc = cw_ / 64; a.hc = rows_; a.wpp = cfg_.wpp; a.tile_rows = cfg_.tile_rows; a.init_type = intra ? 0 : 1; a.qp = qp_cur_; a.first_sub = 0;
+    timed(K_CABAC_ROWS, sl.ent_stream, [&] { launch_cabac_rows(a, nsub, sl.ent_stream); });
+    HIP_CHECK(hipEventRecord(sl.done, sl.ent_stream));
+  } else
   HIP_CHECK(hipEventRecord(sl.done, stream_tok_));
   HIP_CHECK(hipEventRecord(sl.rec_done, stream_));
   sl.poc = poc_; sl.intra = intra; sl.rec_idx = cur_idx_; sl.set = set_; sl.qp = qp_cur_; sl.write_ps = false;
@@ -430,12 +471,23 @@ bool Encoder::finish_slot(Slot &sl, EncodedPicture *out, int worker)
   const int nsub = cfg_.wpp ? rows_ : cfg_.tile_rows;
   uint64_t bins = 0;
   Tick tk_ar;
-  for (int i = 0, n = (cw_ / 64) * rows_; i < n; i++) if (sl.h_tok_count[i] < 0) { fprintf(stderr, "kvazzup_amd: token array overflow (CTU %d)\n", i); return false; }
-  EntropyHost *coder = worker ? entropy2_ : entropy_;
   std::vector<std::vector<uint8_t>> &rows_out = worker ? rows_out2_ : rows_out_;
-  coder->code_picture(sl.h_tok_dense, sl.h_tok_count, sl.h_tok_off, cw_ / 64, rows_, cfg_.wpp != 0, cfg_.tile_rows, sl.intra ? 0 : 1, sl.qp, rows_out, &bins);
+  if (cfg_.entropy_gpu) {
+    // the substreams were coded on the GPU (k_cabac_rows) and lie in the slot's host-mapped buffer
+    rows_out.resize((size_t)nsub);
+    const uint32_t *off = sl.h_sub, *len = sl.h_sub + rows_, *nb = sl.h_sub + 2 * rows_;
+    for (int k = 0; k < nsub; k++) {
+      if (len[k] == ~0u || (size_t)off[k] + len[k] > out_cap_) { fprintf(stderr, "kvazzup_amd: substream %d was not coded (token or output buffer overflow)\n", k); return false; }
+      rows_out[(size_t)k].assign(sl.h_out + off[k], sl.h_out + off[k] + len[k]);
+      bins += nb[k];
+    }
+  } else {
+    for (int i = 0, n = (cw_ / 64) * rows_; i < n; i++) if (sl.h_tok_count[i] < 0) { fprintf(stderr, "kvazzup_amd: token array overflow (CTU %d)\n", i); return false; }
+    EntropyHost *coder = worker ? entropy2_ : entropy_;
+    coder->code_picture(sl.h_tok_dense, sl.h_tok_count, sl.h_tok_off, cw_ / 64, rows_, cfg_.wpp != 0, cfg_.tile_rows, sl.intra ? 0 : 1, sl.qp, rows_out, &bins);
+  }
   const double ar = tk_ar.ms();
-  if (profiling_) { std::lock_guard<std::mutex> l(stat_m_); k_ms_[K_HOST_ARITH] += ar; k_n_[K_HOST_ARITH]++; }
+  if (profiling_ && !cfg_.entropy_gpu) { std::lock_guard<std::mutex> l(stat_m_); k_ms_[K_HOST_ARITH] += ar; k_n_[K_HOST_ARITH]++; }
   { std::lock_guard<std::mutex> l(stat_m_); t_arith_ += ar; }
   // ---- access unit assembly (host): parameter sets with IDR pictures, then the slice NAL
   out->valid = true; out->poc = sl.poc; out->qp = sl.qp; out->is_intra = sl.intra; out->bins = bins;

@@ -44,7 +44,7 @@ int config_init(kvz_config *cfg)
   cfg->me_range = 16; cfg->gpu_device = 0; cfg->recon_output = 1;
   cfg->threads = -1;                                    // auto, as in Kvazaar
   cfg->me_early_termination = 1;                        // on, as in Kvazaar
-  cfg->intra_satd = 1;
+  cfg->intra_satd = 1; cfg->gpu_entropy = 0;
   return 1;
 }
 
@@ -171,6 +171,7 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
   BOOL_OPT("set-qp-in-cu", set_qp_in_cu) BOOL_OPT("psnr", calc_psnr) BOOL_OPT("cpuid", cpuid) BOOL_OPT("implicit-rdpcm", implicit_rdpcm)
   if (n == "cu-split-termination") { cfg->cu_split_termination = !strcmp(value, "off"); return (!strcmp(value, "zero") || !strcmp(value, "off")) ? 1 : 0; }
   if (n == "intra-satd") return parse_bool(value, &cfg->intra_satd);
+  if (n == "gpu-entropy") return parse_bool(value, &cfg->gpu_entropy);
   if (n == "me-early-termination") {
     if (!strcmp(value, "off")) cfg->me_early_termination = 0; else if (!strcmp(value, "on")) cfg->me_early_termination = 1;
     else if (!strcmp(value, "sensitive")) cfg->me_early_termination = 2; else return 0;
@@ -244,13 +245,14 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   EncoderConfig ec;
   ec.width = cfg->width; ec.height = cfg->height; ec.qp = cfg->qp; ec.intra_period = cfg->intra_period; ec.vps_period = cfg->vps_period;
   ec.me_range = cfg->me_range; ec.fps_num = cfg->framerate_num; ec.fps_den = cfg->framerate_denom;
-  ec.wpp = cfg->wpp ? 1 : 0; ec.deblock = cfg->deblock_enable ? 1 : 0; ec.device = cfg->gpu_device; ec.owf = cfg->owf > 3 ? 3 : cfg->owf;
+  ec.wpp = cfg->wpp ? 1 : 0; ec.deblock = cfg->deblock_enable ? 1 : 0; ec.device = cfg->gpu_device; ec.owf = cfg->owf > 8 ? 8 : cfg->owf;
   ec.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1;
   ec.band_row0 = cfg->band_row0; ec.band_rows = cfg->band_rows;
   // "threads" (uvgComm video/kvzThreads: auto = core count, Main = 0): what is threaded on the host here is the arithmetic coder
   ec.entropy_threads = cfg->threads < 0 ? 16 : (cfg->threads == 0 ? 1 : (cfg->threads > 16 ? 16 : cfg->threads));
   ec.me_early = cfg->me_early_termination != 0;
   ec.satd = cfg->intra_satd != 0;
+  ec.entropy_gpu = cfg->gpu_entropy != 0;
   ec.vaq = cfg->vaq > 0 ? cfg->vaq : 0;
   ec.qp_in_cu = (cfg->set_qp_in_cu || ec.vaq > 0) ? 1 : 0;
   ec.sao = cfg->sao_type == KVZ_SAO_FULL;
@@ -407,7 +409,7 @@ int kvzx_encoder_kernel_times(kvz_encoder *e, double *ms, uint64_t *launches, in
 }
 const char *kvzx_encoder_kernel_name(int id)
 {
-  static const char *names[kvzx::K_COUNT] = {"k_pad_input", "k_me", "k_inter_recon", "k_inter_signal", "k_intra_analyse", "k_intra_recon", "k_deblock", "k_tokenize", "host_arith_coder", "k_sao", "k_tok_compact"};
+  static const char *names[kvzx::K_COUNT] = {"k_pad_input", "k_me", "k_inter_recon", "k_inter_signal", "k_intra_analyse", "k_intra_recon", "k_deblock", "k_tokenize", "host_arith_coder", "k_sao", "k_tok_compact", "k_cabac_rows"};
   return (id >= 0 && id < kvzx::K_COUNT) ? names[id] : nullptr;
 }
 uint64_t kvzx_encoder_last_bins(kvz_encoder *e) { return e ? e->last_bins : 0; }

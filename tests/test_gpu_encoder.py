@@ -29,11 +29,11 @@ def _diagnose(dbg_o, dbg_g):
     return "; ".join(msgs) if msgs else "no stage-level difference found (entropy coding / assembly?)"
 
 
-def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_picture=True, tile_rows=1, sao=0, mv_frame=0, vaq=0):
+def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_picture=True, tile_rows=1, sao=0, mv_frame=0, vaq=0, gpu_entropy=0):
     from kvazzup_amd.codec import Encoder
     oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows, sao=sao, mv_frame=mv_frame, vaq=vaq)
     ge = Encoder(w, h, options=(("qp", qp), ("period", period), ("me-range", me_range), ("wpp", wpp), ("deblock", deblock), ("tiles", "1x%d" % tile_rows),
-                                ("sao", "full" if sao else "off"), ("mv-constraint", ("none", "frame", "frametilemargin")[mv_frame])) + ((('vaq', vaq),) if vaq else ()))
+                                ("sao", "full" if sao else "off"), ("mv-constraint", ("none", "frame", "frametilemargin")[mv_frame]), ("gpu-entropy", gpu_entropy)) + ((('vaq', vaq),) if vaq else ()))
     assert not ge.rejected, ge.rejected
     try:
         for t in range(frames):
@@ -68,6 +68,45 @@ def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_pic
 ])
 def test_encoder_matches_oracle(gpu, cfg):
     run_clip(**cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(w=256, h=192, frames=5, qp=32, period=64, me_range=16, kind=0),                          # I + P, WPP
+    dict(w=320, h=240, frames=3, qp=10, period=2, me_range=8, kind=2),                            # dense coefficients, escape codes, long 0xff runs
+    dict(w=192, h=128, frames=3, qp=32, period=64, me_range=8, kind=1),                           # everything skipped: substreams of a few bytes
+    dict(w=416, h=240, frames=4, qp=32, period=4, me_range=16, kind=0, wpp=0),                    # one substream for the whole picture
+    dict(w=320, h=256, frames=4, qp=30, period=3, me_range=16, kind=0, tile_rows=2),              # tiles + WPP: fresh contexts at tile starts
+    dict(w=320, h=256, frames=3, qp=27, period=2, me_range=8, kind=2, tile_rows=2, wpp=0),        # one substream per tile
+    dict(w=320, h=256, frames=3, qp=30, period=64, me_range=8, kind=0, sao=1, vaq=8),             # SAO syntax and cu_qp_delta bins in the token stream
+    dict(w=1920, h=1080, frames=3, qp=32, period=64, me_range=16, kind=0),                        # BASELINE configs[1] size
+])
+def test_gpu_arithmetic_coder_matches_oracle(gpu, cfg):
+    """gpu-entropy=1: the arithmetic coder proper on the GPU (k_cabac_rows, one wave per substream) instead of the host
+    thread pool: same access units, byte for byte, and the same bin counts."""
+    run_clip(gpu_entropy=1, **cfg)
+
+
+@pytest.mark.gpu
+def test_gpu_arithmetic_coder_pipelined(gpu):
+    """gpu-entropy=1 with owf 6: six pictures in flight, every slot's coder on its own stream; output lags six pictures."""
+    from kvazzup_amd.codec import Encoder
+    w, h, frames, owf = 640, 384, 20, 6
+    clip = [orc.synth_frame(0, SEED, w, h, t) for t in range(frames)]
+    opts = (("qp", 30), ("period", 8), ("me-range", 8))
+    e0 = Encoder(w, h, options=opts)
+    want = [e0.encode(f) for f in clip]
+    e0.close()
+    e1 = Encoder(w, h, options=opts + (("owf", owf), ("gpu-entropy", 1)))
+    got = [e1.encode(f) for f in clip]
+    assert got[:owf] == [(None, None)] * owf
+    for _ in range(owf):
+        got.append(e1.encode(None))
+    assert e1.encode(None) == (None, None)
+    e1.close()
+    for t in range(frames):
+        assert got[t + owf][0] == want[t][0], t
+        assert np.array_equal(got[t + owf][1], want[t][1]), t
 
 
 @pytest.mark.gpu

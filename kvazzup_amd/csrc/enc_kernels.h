@@ -5,6 +5,7 @@
 namespace kvzx {
 void launch_pad_input(const uint8_t *in, int w, int h, uint8_t *dy, uint8_t *du, uint8_t *dv, int cw, int ch, hipStream_t st);   // packed I420 -> padded planes
 void launch_me(const EncFrame &f, hipStream_t st);
+void launch_subpel(const EncFrame &f, hipStream_t st);     // k_subpel: fractional-sample refinement of the searched vectors (f.subme > 0)
 void launch_inter_recon(const EncFrame &f, hipStream_t st);
 void launch_inter_signal(const EncFrame &f, hipStream_t st);
 void launch_intra_analyse(const EncFrame &f, hipStream_t st);

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
     if (tid < 16) {
       const int i = b8idx(f, x0 + (tid & 3) * 8, y0 + (tid >> 2) * 8);
       f.cu_log2[i] = 5; f.cu_intra[i] = 0; f.cu_mv[i * 2] = 0; f.cu_mv[i * 2 + 1] = 0;
+      f.cu_mvp_idx[i] = 0;                               // mark for k_subpel: not searched (k_inter_signal writes the real value later)
     }
     return;
   }
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
     int i = b8idx(f, x0 + bx * 8, y0 + by * 8);
     f.cu_log2[i] = split ? 4 : 5;
     f.cu_intra[i] = 0;
+    f.cu_mvp_idx[i] = 1;                                 // mark for k_subpel: searched
     f.cu_mv[i * 2] = (int16_t)(((int)(ci % W) - R) * 4);
     f.cu_mv[i * 2 + 1] = (int16_t)(((int)(ci / W) - R) * 4);
   }
@@ -363,8 +365,8 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
     s.mv[tid][0] = f.cu_mv[bi * 2]; s.mv[tid][1] = f.cu_mv[bi * 2 + 1];
   }
   __syncthreads();
-  // ---- luma with fractional vectors (never the encoder's own streams): window -> LDS, horizontal pass -> LDS
-  const bool anyfrac = DEC && (((s.mv[0][0] | s.mv[0][1] | s.mv[1][0] | s.mv[1][1] | s.mv[2][0] | s.mv[2][1] | s.mv[3][0] | s.mv[3][1]) & 3) != 0);
+  // ---- luma with fractional vectors (the encoder's with subme > 0): window -> LDS, horizontal pass -> LDS
+  const bool anyfrac = (((s.mv[0][0] | s.mv[0][1] | s.mv[1][0] | s.mv[1][1] | s.mv[2][0] | s.mv[2][1] | s.mv[3][0] | s.mv[3][1]) & 3) != 0);
   if (anyfrac) {
     for (int i = tid; i < 4 * 23 * 23; i += 256) {
       const int k = i / 529, r = i - k * 529, wy = r / 23, wx = r - wy * 23;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
     const int y = tid >> 3, x = (tid & 7) * 4, k = (y >> 4) * 2 + (x >> 4);
     const int l2 = split ? 4 : 5, n = 1 << l2, tu = split ? k : 0;
     uint32_t p4 = 0;
-    if (anyfrac) {                             // (block-uniform) separable 8-tap interpolation through LDS; decoder only: p4 is not used again
+    if (anyfrac) {                             // (block-uniform) separable 8-tap interpolation through LDS
       const int mvx = s.mv[k][0], mvy = s.mv[k][1], xf = mvx & 3, yf = mvy & 3;
       const int *tp = &s.ltmp[k][(y & 15) * 16 + (x & 15)];
 #pragma unroll 1

@@ -18,7 +18,7 @@
 namespace kvzx {
 
 // K_HOST_ARITH is not a kernel: wall time of the host arithmetic-coding stage (entropy_host.h)
-enum KernelId { K_PAD = 0, K_ME, K_INTER_RECON, K_INTER_SIGNAL, K_INTRA_ANALYSE, K_INTRA_RECON, K_DEBLOCK, K_TOKENIZE, K_HOST_ARITH, K_SAO, K_TOK_COMPACT, K_CABAC_ROWS, K_COUNT };
+enum KernelId { K_PAD = 0, K_ME, K_INTER_RECON, K_INTER_SIGNAL, K_INTRA_ANALYSE, K_INTRA_RECON, K_DEBLOCK, K_TOKENIZE, K_HOST_ARITH, K_SAO, K_TOK_COMPACT, K_CABAC_ROWS, K_SUBPEL, K_COUNT };
 
 struct EncoderConfig {
   int width = 0, height = 0;
@@ -35,6 +35,7 @@ struct EncoderConfig {
   int qp_in_cu = 0;           // kvazaar "set-qp-in-cu": cu_qp_delta_enabled_flag; a delta-QP map (set_roi, kvz_picture.roi) then gives every CTU its own QP
   int bitrate = 0;            // bits per second; 0 = constant QP, > 0 = "uvgx rate control v1" (oracle/hevc_enc.c rate_control())
   int satd = 1;               // intra mode search cost: 8x8 Hadamard sums (1) or SAD (0)
+  int subme = 0;              // kvazaar "subme" 0..4: fractional-sample refinement of the searched vectors, "uvgx subme v1" (oracle/hevc_enc.c subme_refine())
   int me_early = 1;           // kvazaar "me-early-termination" (on / sensitive: 1, off: 0): static 32x32 blocks skip the motion search
   int vaq = 0;                // kvazaar "vaq" 1..20: "uvgx VAQ v1" (oracle/hevc_enc.c vaq_deltas()); implies qp_in_cu
   int mv_frame = 0;           // kvazaar "mv-constraint" frame / frametile (1), frametilemargin (2): vectors keep the block inside the picture

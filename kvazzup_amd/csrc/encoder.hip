@@ -167,7 +167,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   f_.tile_rows = cfg.tile_rows; f_.chp = pack_height(ch_, cfg.tile_rows);
   f_.row0 = cfg.band_rows > 0 ? cfg.band_row0 : 0; f_.nrows = cfg.band_rows > 0 ? cfg.band_rows : 0;
   f_.qp = cfg.qp; f_.qpc = kChromaQp[cfg.qp]; f_.lambda_q4 = kLambdaQ4[cfg.qp]; f_.range = cfg.me_range;
-  f_.wpp = cfg.wpp; f_.mv_frame = cfg.mv_frame; f_.me_early = cfg.me_early; f_.satd = cfg.satd;
+  f_.wpp = cfg.wpp; f_.mv_frame = cfg.mv_frame; f_.me_early = cfg.me_early; f_.satd = cfg.satd; f_.subme = cfg.subme;
   bind_set(0);
   uint8_t *p = intra_scratch_;
   f_.ic8 = (uint32_t *)p; p += nb8 * 4; f_.ic16 = (uint32_t *)p; p += nb8; f_.ic32 = (uint32_t *)p; p += nb8 / 4;
@@ -369,6 +369,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
     timed(K_INTRA_RECON, stream_, [&] { launch_intra_recon(f, stream_); });
   } else {
     timed(K_ME, stream_, [&] { launch_me(f, stream_); });
+    if (cfg_.subme > 0) timed(K_SUBPEL, stream_, [&] { launch_subpel(f, stream_); });
     timed(K_INTER_RECON, stream_, [&] { launch_inter_recon(f, stream_); });
   }
   launch_qp_resolve(f, stream_);                                 // per-CTU QP: which CU carries the delta, QpY for deblocking
@@ -531,6 +532,7 @@ bool Encoder::band_phase1(const uint8_t *d_i420)
     launch_intra_recon(f, stream_);
   } else {
     launch_me(f, stream_);
+    if (cfg_.subme > 0) launch_subpel(f, stream_);
     launch_inter_recon(f, stream_);
     launch_inter_signal(f, stream_);
   }

@@ -71,9 +71,14 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
 #define BOOL_OPT(key, field) if (n == key) { if (!parse_bool(value, &iv)) { cfg->field = 0; return *value ? 0 : 1; } cfg->field = iv; return 1; }
   if (n == "preset") {
     static const char *presets[] = {"ultrafast", "superfast", "veryfast", "faster", "fast", "medium", "slow", "slower", "veryslow", "placebo"};
-    // One GPU tool set serves every preset; what the presets above ultrafast add from it is SAO (Kvazaar's preset table, as
-    // recalled in SURVEY.md appendix A, has sao off at ultrafast only).  Later options ("sao") override, as in Kvazaar.
-    for (const char *p : presets) if (!strcmp(value, p)) { cfg->sao_type = strcmp(p, "ultrafast") ? KVZ_SAO_FULL : KVZ_SAO_OFF; return 1; }
+    // One GPU tool set serves every preset; what the presets above ultrafast add from it is SAO and the fractional-sample
+    // motion refinement (Kvazaar's preset table, as recalled in SURVEY.md appendix A: sao off and subme 0 at ultrafast only;
+    // subme 2 at superfast / veryfast, 4 from faster on).  Later options ("sao", "subme") override, as in Kvazaar.
+    for (int i = 0; i < 10; i++) if (!strcmp(value, presets[i])) {
+      cfg->sao_type = i ? KVZ_SAO_FULL : KVZ_SAO_OFF;
+      cfg->fme_level = i == 0 ? 0 : (i <= 2 ? 2 : 4);
+      return 1;
+    }
     return 0;
   }
   if (n == "input-res") {
@@ -252,6 +257,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.entropy_threads = cfg->threads < 0 ? 16 : (cfg->threads == 0 ? 1 : (cfg->threads > 16 ? 16 : cfg->threads));
   ec.me_early = cfg->me_early_termination != 0;
   ec.satd = cfg->intra_satd != 0;
+  ec.subme = cfg->fme_level < 0 ? 0 : (cfg->fme_level > 4 ? 4 : cfg->fme_level);
   ec.entropy_gpu = cfg->gpu_entropy != 0;
   ec.vaq = cfg->vaq > 0 ? cfg->vaq : 0;
   ec.qp_in_cu = (cfg->set_qp_in_cu || ec.vaq > 0) ? 1 : 0;
@@ -409,7 +415,7 @@ int kvzx_encoder_kernel_times(kvz_encoder *e, double *ms, uint64_t *launches, in
 }
 const char *kvzx_encoder_kernel_name(int id)
 {
-  static const char *names[kvzx::K_COUNT] = {"k_pad_input", "k_me", "k_inter_recon", "k_inter_signal", "k_intra_analyse", "k_intra_recon", "k_deblock", "k_tokenize", "host_arith_coder", "k_sao", "k_tok_compact", "k_cabac_rows"};
+  static const char *names[kvzx::K_COUNT] = {"k_pad_input", "k_me", "k_inter_recon", "k_inter_signal", "k_intra_analyse", "k_intra_recon", "k_deblock", "k_tokenize", "host_arith_coder", "k_sao", "k_tok_compact", "k_cabac_rows", "k_subpel"};
   return (id >= 0 && id < kvzx::K_COUNT) ? names[id] : nullptr;
 }
 uint64_t kvzx_encoder_last_bins(kvz_encoder *e) { return e ? e->last_bins : 0; }

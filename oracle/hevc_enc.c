@@ -372,6 +372,53 @@ static inline uint32_t sad16(const pixel *a, int as, const pixel *b, int bs)
   return s;
 }
 
+/* "uvgx subme v1" (kvazaar subme 1..4): fractional-sample refinement of one CU's vector after the integer search.  Two steps
+ * of eight neighbours each -- half-sample positions around the integer vector, then quarter-sample positions around the best
+ * so far -- of which subme switches on the horizontal / vertical four (1, 3) and the diagonal four (2, 4).  A candidate's cost
+ * is the SATD (satd_block) between the source block and the normative prediction (8.5.3.3.3 + 8.5.3.3.4.2) plus
+ * (lambda * bits of the vector coded as a difference from zero) >> 4, the same rate term as the integer search; the centre
+ * is re-priced the same way; ties go to the centre, then to the earlier candidate.  A fractional component needs reference
+ * rows / columns up to 4 away from the displaced block: candidates whose rows would leave the tile (or, with mv-constraint
+ * frame, whose rows or columns would leave the picture) are dropped. */
+static int subme_allowed(const orc_encoder *e, int x0, int y0, int n, int mvx, int mvy, int ty0, int ty1)
+{
+  int ix = mvx >> 2, iy = mvy >> 2, mx = (mvx & 7) ? 4 : 0, my = (mvy & 7) ? 4 : 0;
+  if ((ty0 > 0 && y0 + iy - my < ty0) || (ty1 < e->ch && y0 + iy + n + my > ty1)) return 0;
+  if (e->cfg.mv_frame) {
+    if (e->cfg.mv_frame == 1) { mx = (mvx & 3) ? 4 : 0; my = (mvy & 3) ? 4 : 0; }     /* plain frame constraint: integer vectors may touch the edge */
+    if (x0 + ix - mx < 0 || x0 + ix + n + mx > e->cw || y0 + iy - my < 0 || y0 + iy + n + my > e->ch) return 0;
+  }
+  return 1;
+}
+static uint32_t subme_cost(orc_encoder *e, int x0, int y0, int n, int mvx, int mvy)
+{
+  int16_t tmp[32 * 32]; pixel pred[32 * 32];
+  orc_pic *r = e->ref;
+  orc_mc_luma(r->plane[0], r->stride[0], r->w, r->h, x0, y0, n, n, mvx, mvy, tmp, 32);
+  orc_pred_uni(tmp, 32, pred, 32, n, n);
+  uint32_t rate = ((uint32_t)orc_lambda_q4[e->qp] * (uint32_t)(orc_mvd_bits(mvx) + orc_mvd_bits(mvy))) >> 4;
+  return satd_block(e->src[0] + y0 * e->cw + x0, e->cw, pred, 32, n) + rate;
+}
+static void subme_refine(orc_encoder *e, int x0, int y0, int n, int ty0, int ty1)
+{
+  static const int8_t off[8][2] = { {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1} };
+  int bi = b8i(e, x0, y0), cx = e->cu_mv[bi * 2], cy = e->cu_mv[bi * 2 + 1];
+  uint32_t best = subme_cost(e, x0, y0, n, cx, cy) << 4;                  /* key = cost << 4 | candidate (0 = centre) */
+  for (int step = 0; step < 2; step++) {
+    int scale = step ? 1 : 2, ncand = (e->cfg.subme >= (step ? 4 : 2)) ? 8 : ((e->cfg.subme >= (step ? 3 : 1)) ? 4 : 0);
+    uint32_t b = best & ~15u;
+    for (int k = 0; k < ncand; k++) {
+      int mx = cx + off[k][0] * scale, my = cy + off[k][1] * scale;
+      if (!subme_allowed(e, x0, y0, n, mx, my, ty0, ty1)) continue;
+      uint32_t key = (subme_cost(e, x0, y0, n, mx, my) << 4) | (uint32_t)(k + 1);
+      if (key < b) b = key;
+    }
+    if (b & 15u) { cx += off[(b & 15u) - 1][0] * scale; cy += off[(b & 15u) - 1][1] * scale; }
+    best = b & ~15u;
+  }
+  for (int y = y0; y < y0 + n; y += 8) for (int x = x0; x < x0 + n; x += 8) { e->cu_mv[b8i(e, x, y) * 2] = (int16_t)cx; e->cu_mv[b8i(e, x, y) * 2 + 1] = (int16_t)cy; }
+}
+
 /* Full search for one 32x32 block: candidates in raster order (dy outer, dx inner),
  * cost = SAD + (lambda * bits(mv as mvd from zero)) >> 4, key = cost << 13 | candidate index. */
 static void me_block32(orc_encoder *e, int x0, int y0)
@@ -434,6 +481,10 @@ static void me_block32(orc_encoder *e, int x0, int y0)
     for (int y = y0; y < y0 + 32; y += 8) for (int x = x0; x < x0 + 32; x += 8) {
       e->cu_mv[b8i(e, x, y) * 2] = (int16_t)(((ci % W) - R) * 4); e->cu_mv[b8i(e, x, y) * 2 + 1] = (int16_t)(((ci / W) - R) * 4);
     }
+  }
+  if (e->cfg.subme > 0) {                                        /* fractional-sample refinement of the CUs just decided */
+    if (e->cu_log2[b8i(e, x0, y0)] == 5) subme_refine(e, x0, y0, 32, ty0, ty1);
+    else for (int k = 0; k < 4; k++) subme_refine(e, x0 + (k & 1) * 16, y0 + (k >> 1) * 16, 16, ty0, ty1);
   }
   if (e->cfg.test_mv_jitter && e->cfg.tile_rows == 1) {          /* test hook: fractional vectors for the decoder tests */
     for (int y = y0; y < y0 + 32; y += 8) for (int x = x0; x < x0 + 32; x += 8) {

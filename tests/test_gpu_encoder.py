@@ -29,11 +29,11 @@ def _diagnose(dbg_o, dbg_g):
     return "; ".join(msgs) if msgs else "no stage-level difference found (entropy coding / assembly?)"
 
 
-def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_picture=True, tile_rows=1, sao=0, mv_frame=0, vaq=0, gpu_entropy=0):
+def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_picture=True, tile_rows=1, sao=0, mv_frame=0, vaq=0, gpu_entropy=0, subme=0, me_early=1):
     from kvazzup_amd.codec import Encoder
-    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows, sao=sao, mv_frame=mv_frame, vaq=vaq)
+    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows, sao=sao, mv_frame=mv_frame, vaq=vaq, subme=subme, me_early=me_early)
     ge = Encoder(w, h, options=(("qp", qp), ("period", period), ("me-range", me_range), ("wpp", wpp), ("deblock", deblock), ("tiles", "1x%d" % tile_rows),
-                                ("sao", "full" if sao else "off"), ("mv-constraint", ("none", "frame", "frametilemargin")[mv_frame]), ("gpu-entropy", gpu_entropy)) + ((('vaq', vaq),) if vaq else ()))
+                                ("sao", "full" if sao else "off"), ("mv-constraint", ("none", "frame", "frametilemargin")[mv_frame]), ("gpu-entropy", gpu_entropy), ("subme", subme), ("me-early-termination", "on" if me_early else "off")) + ((('vaq', vaq),) if vaq else ()))
     assert not ge.rejected, ge.rejected
     try:
         for t in range(frames):
@@ -85,6 +85,25 @@ def test_gpu_arithmetic_coder_matches_oracle(gpu, cfg):
     """gpu-entropy=1: the arithmetic coder proper on the GPU (k_cabac_rows, one wave per substream) instead of the host
     thread pool: same access units, byte for byte, and the same bin counts."""
     run_clip(gpu_entropy=1, **cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(w=320, h=256, frames=5, qp=30, period=64, me_range=16, kind=0, subme=4),                               # moving objects, both steps with diagonals
+    dict(w=320, h=256, frames=4, qp=30, period=64, me_range=8, kind=0, subme=1, me_early=0),                    # half-sample, horizontal / vertical only; every block searched
+    dict(w=320, h=256, frames=4, qp=27, period=64, me_range=8, kind=2, subme=2, me_early=0),                    # noise: ties and near-ties
+    dict(w=320, h=256, frames=4, qp=32, period=64, me_range=8, kind=0, subme=3, wpp=0),
+    dict(w=320, h=256, frames=5, qp=30, period=3, me_range=16, kind=0, subme=4, tile_rows=4, me_early=0),       # one CTU row per tile: most vertical candidates dropped
+    dict(w=416, h=240, frames=4, qp=30, period=64, me_range=32, kind=0, subme=4, mv_frame=1, me_early=0),       # frame constraint, vectors at the picture edge
+    dict(w=416, h=240, frames=4, qp=30, period=64, me_range=32, kind=2, subme=4, mv_frame=2, me_early=0),
+    dict(w=130, h=70, frames=3, qp=20, period=64, me_range=4, kind=0, subme=4, me_early=0),                     # windows across the padded edges
+    dict(w=320, h=256, frames=3, qp=30, period=64, me_range=8, kind=0, subme=4, sao=1, vaq=8),
+    dict(w=1920, h=1080, frames=3, qp=32, period=64, me_range=16, kind=0, subme=4),                             # BASELINE configs[1] size
+])
+def test_subme_matches_oracle(gpu, cfg):
+    """subme 1..4: k_subpel (fractional-sample refinement, SATD on the matrix cores) and the encoder's fractional-sample motion
+    compensation against subme_refine() of the checker: same vectors, same access units, same reconstruction"""
+    run_clip(**cfg)
 
 
 @pytest.mark.gpu

@@ -192,3 +192,59 @@ def test_vaq_closed_loop(vaq, wpp, tile_rows):
         got = od.decode_au(oe.encode(orc.synth_frame(0, 9, w, h, t)), t)
         assert len(got) == 1 and np.array_equal(got[0]["i420"], oe.recon()), t
     oe.close(); od.close()
+
+
+@pytest.mark.parametrize("subme,wpp,tile_rows,mv_frame", [(1, 1, 1, 0), (2, 1, 2, 0), (3, 0, 1, 2), (4, 1, 1, 0), (4, 1, 4, 1)])
+def test_subme_closed_loop(subme, wpp, tile_rows, mv_frame):
+    """kvazaar subme 1..4 ("uvgx subme v1", subme_refine() in oracle/hevc_enc.c): fractional-sample refinement of the searched
+    vectors.  The streams decode to the encoder's reconstruction; level 1 only produces half-sample vectors with one
+    fractional component, level 2 half-sample vectors, levels 3 and 4 quarter-sample ones; with tile rows no vector needs
+    reference rows of another tile."""
+    w, h = 320, 256
+    oe = orc.OracleEncoder(w, h, qp=30, period=8, me_range=8, wpp=wpp, tile_rows=tile_rows, mv_frame=mv_frame, subme=subme, me_early=0)
+    od = orc.OracleDecoder()
+    frac = quarter = 0
+    for t in range(5):
+        got = od.decode_au(oe.encode(orc.synth_frame(0, 21, w, h, t)), t)
+        assert len(got) == 1 and np.array_equal(got[0]["i420"], oe.recon()), t
+        d = oe.debug()
+        if d["is_intra"]:
+            continue
+        mv = d["cu_mv"].astype(int)
+        frac += int(np.count_nonzero((mv[..., 0] | mv[..., 1]) & 3))
+        quarter += int(np.count_nonzero((mv[..., 0] | mv[..., 1]) & 1))
+        if subme == 1:
+            assert not np.any((mv[..., 0] & 3) & (mv[..., 1] & 3))
+        if tile_rows > 1:
+            hc = d["coded_h"] // 64
+            bd = [(i * hc) // tile_rows * 64 for i in range(tile_rows + 1)]
+            ys = (np.mgrid[0:d["coded_h"] // 8, 0:d["coded_w"] // 8][0] * 8)
+            n = np.where(d["cu_log2"] == 5, 32, 16)
+            y0 = ys & ~(n - 1)
+            for i in range(tile_rows):
+                m = (y0 >= bd[i]) & (y0 < bd[i + 1])
+                my = np.where(mv[..., 1] & 7, 4, 0)
+                top = y0 + (mv[..., 1] >> 2) - my
+                bot = y0 + (mv[..., 1] >> 2) + n + my
+                assert not np.any(m & (bd[i] > 0) & (top < bd[i])) and not np.any(m & (bd[i + 1] < d["coded_h"]) & (bot > bd[i + 1]))
+    assert frac > 50
+    assert (quarter > 0) == (subme >= 3)
+    oe.close(); od.close()
+
+
+def test_subme_saves_bits_on_moving_content():
+    """the refinement pays: fewer bits at equal or better PSNR on the moving clip (sub-sample motion is what the synthetic
+    objects do)"""
+    w, h = 416, 240
+    def run(subme):
+        oe = orc.OracleEncoder(w, h, qp=30, period=64, me_range=16, subme=subme)
+        bits = sse = 0
+        for t in range(8):
+            f = orc.synth_frame(0, 5, w, h, t)
+            bits += 8 * len(oe.encode(f))
+            sse += float(np.sum((oe.recon()[:w * h].astype(np.int64) - f[:w * h]) ** 2))
+        oe.close()
+        return bits, sse
+    b0, s0 = run(0)
+    b4, s4 = run(4)
+    assert b4 < b0 and s4 <= s0 * 1.02, (b0, b4, s0, s4)

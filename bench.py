@@ -286,7 +286,7 @@ def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync
     def make(keep, download):
         return Pipeline(w, h, settings={"video/QP": 32, "video/Intra": PERIOD, "video/VPS": 1, "uvgx/gpu": dev_index, "uvgx/decoderDownload": int(download),
                                         "video/OWF": args.owf, "video/OPENHEVC_threads": D, "video/OH_parallelization": "Frame" if D > 1 else "Slice"},
-                        custom=(("me-range", args.me_range), ("gpu", dev_index)) + ((("sao", "full"),) if args.sao else ()) + ((("me-early-termination", "off"),) if args.full_search else ()) + ((("intra-satd", "0"),) if args.intra_sad else ()) + ((("gpu-entropy", "1"),) if args.gpu_entropy else ()),
+                        custom=(("me-range", args.me_range), ("gpu", dev_index)) + ((("sao", "full"),) if args.sao else ()) + ((("me-early-termination", "off"),) if args.full_search else ()) + ((("intra-satd", "0"),) if args.intra_sad else ()) + ((("gpu-entropy", "1"),) if args.gpu_entropy else ()) + ((("subme", str(args.subme)),) if args.subme else ()),
                         loopback=True, keep_outputs=keep)
 
     # source -> KvazaarFilter -> WireAdapter -> OpenHEVCFilter -> sink, one thread per filter (csrc/filters.hip)
@@ -444,6 +444,7 @@ def main():
     ap.add_argument("--profile-every", type=int, default=8, help="kernel timing with HIP events on every n-th picture")
     ap.add_argument("--intra-sad", action="store_true", help="intra-satd=0: the intra mode search compares SADs instead of 8x8 Hadamard sums (for the quality / rate comparison in DESIGN.md)")
     ap.add_argument("--full-search", action="store_true", help="me-early-termination=off: every 32x32 block is searched exhaustively (the k_me issue-rate roofline is reported for this case)")
+    ap.add_argument("--subme", type=int, default=0, help="kvazaar subme 0..4: fractional-sample motion refinement (0 at the ultrafast preset the headline workload uses; 2 / 4 at the presets above)")
     ap.add_argument("--gpu-entropy", action="store_true", help="gpu-entropy=1: the arithmetic coder on the GPU (k_cabac_rows) instead of the host thread pool (A/B measurement, DESIGN.md section 5)")
     ap.add_argument("--sao", action="store_true", help="kvazaar sao=full (off at the ultrafast preset the headline workload uses)")
     ap.add_argument("--owf", type=int, default=3,
@@ -492,7 +493,7 @@ def main():
                        "timed_region": "empty flushed pipeline -> last timed picture decoded and flushed out",
                        "intra_period": PERIOD, "qp": 32, "me_range": args.me_range, "streams": world, "collective_backend": backend,
                        "bits_per_picture": round(8 * m["bytes_per_picture"], 1), "psnr_y": m["psnr_y"],
-                       "decoder_frame_threads": m["D"], "owf": args.owf, "gpu_entropy": bool(args.gpu_entropy), "sao": bool(args.sao), "me_early_termination": not args.full_search, "intra_satd": not args.intra_sad,
+                       "decoder_frame_threads": m["D"], "owf": args.owf, "gpu_entropy": bool(args.gpu_entropy), "subme": args.subme, "sao": bool(args.sao), "me_early_termination": not args.full_search, "intra_satd": not args.intra_sad,
                        "host_cpu_cores_busy": round(m["host_cores"], 2), "host_cpu_budget_cores": round(m["budget"], 1), "host_cpu_throttled_ms": round(m["throttled_ms"], 1),
                        "input": "I420 resident in HBM", "output": "Annex-B AU on host + decoded I420 in HBM"},
             "roofline": roof,

@@ -659,6 +659,34 @@ __global__ __launch_bounds__(256) void k_dec_deblock(DecFrame f)
   const int lin = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), tx = lin % wc, tyi = lin / wc;
   const int X0 = tx * 64 - 4, Y0 = tyi * 64 - 4, CX0 = X0 >> 1, CY0 = Y0 >> 1, cw2 = f.pw >> 1;
   const int TW = tx == wc - 1 ? 68 : 64, TH = tyi == hc - 1 ? 68 : 64;
+  for (int i = tid; i < 18 * 18; i += 256) {
+    const int ux = tx * 16 - 1 + i % 18, uy = tyi * 16 - 1 + i / 18;
+    B4Rec r; r.mvx = 0; r.mvy = 0; r.ref_idx = -1; r.flags = 0; r.qp_y = 0; r.slot = 0;
+    if (ux >= 0 && uy >= 0 && ux * 4 < f.w && uy * 4 < f.h) r = f.b4[(size_t)uy * b4w + ux];
+    recs[i] = r;
+  }
+  __syncthreads();
+  auto unit = [&](int x, int y) { return ((y >> 2) - (tyi * 16 - 1)) * 18 + ((x >> 2) - (tx * 16 - 1)); };
+  // ---- boundary strengths of this thread's vertical and horizontal edge segment, from the records alone.  A tile none of whose
+  // segments is filtered (still background) leaves without touching a sample.
+  int bsv = 0, bsh = 0, qpv = 0, qph = 0;
+  if (tid < 8 * (TH / 4)) {
+    const int x = tx * 64 + (tid & 7) * 8, y = Y0 + (tid >> 3) * 4;
+    if (x > 0 && x < f.w && y >= 0 && y < f.h) {
+      const int uq = unit(x, y);
+      const B4Rec q = recs[uq], p = recs[uq - 1];
+      if (q.flags & B4_EDGE_V) { bsv = dec_bs(p, q, (q.flags & B4_TU_V) != 0); qpv = (p.qp_y + q.qp_y + 1) >> 1; }
+    }
+  }
+  if (tid < 8 * (TW / 4)) {
+    const int y = tyi * 64 + (tid & 7) * 8, x = X0 + (tid >> 3) * 4;
+    if (y > 0 && y < f.h && x >= 0 && x < f.w) {
+      const int uq = unit(x, y);
+      const B4Rec q = recs[uq], p = recs[uq - 18];
+      if (q.flags & B4_EDGE_H) { bsh = dec_bs(p, q, (q.flags & B4_TU_H) != 0); qph = (p.qp_y + q.qp_y + 1) >> 1; }
+    }
+  }
+  if (!__syncthreads_or(bsv | bsh)) return;
   for (int i = tid; i < TH * 5; i += 256) {
     const int y = i / 5, k = i - y * 5, x = k * 16, gx = X0 + x, gy = Y0 + y;
     if (gy < 0 || x >= TW) continue;
@@ -670,53 +698,26 @@ __global__ __launch_bounds__(256) void k_dec_deblock(DecFrame f)
     const int pl = i / ((TH / 2) * 9), r = i - pl * ((TH / 2) * 9), y = r / 9, k = r - y * 9, gx = CX0 - 2 + 4 * k, gy = CY0 + y;
     if (gy >= 0 && gx >= 0) *(uint32_t *)&tc_[pl][y * PC + 4 * k] = *(const uint32_t *)&f.rec[1 + pl][(size_t)gy * cw2 + gx];
   }
-  for (int i = tid; i < 18 * 18; i += 256) {
-    const int ux = tx * 16 - 1 + i % 18, uy = tyi * 16 - 1 + i / 18;
-    B4Rec r; r.mvx = 0; r.mvy = 0; r.ref_idx = -1; r.flags = 0; r.qp_y = 0; r.slot = 0;
-    if (ux >= 0 && uy >= 0 && ux * 4 < f.w && uy * 4 < f.h) r = f.b4[(size_t)uy * b4w + ux];
-    recs[i] = r;
-  }
   __syncthreads();
-  auto unit = [&](int x, int y) { return ((y >> 2) - (tyi * 16 - 1)) * 18 + ((x >> 2) - (tx * 16 - 1)); };
   // ---- vertical edges: 8 edges x 16 (17) four-row segments
-  if (tid < 8 * (TH / 4)) {
+  if (bsv) {
     const int x = tx * 64 + (tid & 7) * 8, y = Y0 + (tid >> 3) * 4;
-    if (x > 0 && x < f.w && y >= 0 && y < f.h) {
-      const int uq = unit(x, y);
-      const B4Rec q = recs[uq], p = recs[uq - 1];
-      if (q.flags & B4_EDGE_V) {
-        const int bs = dec_bs(p, q, (q.flags & B4_TU_V) != 0);
-        if (bs) {
-          const int qp = (p.qp_y + q.qp_y + 1) >> 1;
-          deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], 1, P, bs, qp, f.beta_offset, f.tc_offset);
-          if (bs == 2 && (x & 15) == 0) {
-            const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0) + 2;
-            deblock_chroma_segment(&tc_[0][o], 1, PC, 2, qp, f.cb_qp_offset, f.tc_offset);
-            deblock_chroma_segment(&tc_[1][o], 1, PC, 2, qp, f.cr_qp_offset, f.tc_offset);
-          }
-        }
-      }
+    deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], 1, P, bsv, qpv, f.beta_offset, f.tc_offset);
+    if (bsv == 2 && (x & 15) == 0) {
+      const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0) + 2;
+      deblock_chroma_segment(&tc_[0][o], 1, PC, 2, qpv, f.cb_qp_offset, f.tc_offset);
+      deblock_chroma_segment(&tc_[1][o], 1, PC, 2, qpv, f.cr_qp_offset, f.tc_offset);
     }
   }
   __syncthreads();
   // ---- horizontal edges on the vertically filtered samples
-  if (tid < 8 * (TW / 4)) {
+  if (bsh) {
     const int y = tyi * 64 + (tid & 7) * 8, x = X0 + (tid >> 3) * 4;
-    if (y > 0 && y < f.h && x >= 0 && x < f.w) {
-      const int uq = unit(x, y);
-      const B4Rec q = recs[uq], p = recs[uq - 18];
-      if (q.flags & B4_EDGE_H) {
-        const int bs = dec_bs(p, q, (q.flags & B4_TU_H) != 0);
-        if (bs) {
-          const int qp = (p.qp_y + q.qp_y + 1) >> 1;
-          deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], P, 1, bs, qp, f.beta_offset, f.tc_offset);
-          if (bs == 2 && (y & 15) == 0) {
-            const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0) + 2;
-            deblock_chroma_segment(&tc_[0][o], PC, 1, 2, qp, f.cb_qp_offset, f.tc_offset);
-            deblock_chroma_segment(&tc_[1][o], PC, 1, 2, qp, f.cr_qp_offset, f.tc_offset);
-          }
-        }
-      }
+    deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], P, 1, bsh, qph, f.beta_offset, f.tc_offset);
+    if (bsh == 2 && (y & 15) == 0) {
+      const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0) + 2;
+      deblock_chroma_segment(&tc_[0][o], PC, 1, 2, qph, f.cb_qp_offset, f.tc_offset);
+      deblock_chroma_segment(&tc_[1][o], PC, 1, 2, qph, f.cr_qp_offset, f.tc_offset);
     }
   }
   __syncthreads();

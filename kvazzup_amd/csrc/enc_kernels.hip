@@ -982,19 +982,6 @@ __global__ __launch_bounds__(256) void k_deblock_tile(EncFrame f)
   const int lin = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), tx = lin % wc, tyi = lin / wc;
   const int X0 = tx * 64 - 4, Y0 = tyi * 64 - 4, CX0 = X0 >> 1, CY0 = Y0 >> 1, cw2 = f.cw >> 1;
   const int TW = tx == wc - 1 ? 68 : 64, TH = tyi == hc - 1 ? 68 : 64;
-  // ---- tile in: 16-byte pieces (X0 is 4-byte aligned: dwordx4 with dword alignment), the last piece of a 68-wide row 4 bytes
-  for (int i = tid; i < TH * 5; i += 256) {
-    const int y = i / 5, k = i - y * 5, x = k * 16, gx = X0 + x, gy = Y0 + y;
-    if (gy < 0 || x >= TW) continue;
-    const uint8_t *g = &f.rec[0][(size_t)gy * f.cw + gx];
-    if (k < 4) { if (gx >= 0) *(kv_u32x4 *)&ty_[y * P + x] = *(const kv_u32x4 *)g; else { kv_u32x4 v; v.x = 0; v.y = *(const uint32_t *)(g + 4); v.z = *(const uint32_t *)(g + 8); v.w = *(const uint32_t *)(g + 12); *(kv_u32x4 *)&ty_[y * P + x] = v; } }
-    else *(uint32_t *)&ty_[y * P + x] = *(const uint32_t *)g;
-  }
-  // chroma: aligned dwords from two samples left of the tile (CX0 - 2 is a multiple of 4): sample x of the tile sits at LDS column x + 2
-  for (int i = tid; i < 2 * (TH / 2) * 9; i += 256) {
-    const int pl = i / ((TH / 2) * 9), r = i - pl * ((TH / 2) * 9), y = r / 9, k = r - y * 9, gx = CX0 - 2 + 4 * k, gy = CY0 + y;
-    if (gy >= 0 && gx >= 0) *(uint32_t *)&tc_[pl][y * PC + 4 * k] = *(const uint32_t *)&f.rec[1 + pl][(size_t)gy * cw2 + gx];
-  }
   if (tid < 100) {
     const int bx = tx * 8 - 1 + tid % 10, by = tyi * 8 - 1 + tid / 10;
     uint32_t l2 = 6, in = 0, cb = 0, mv = 0;
@@ -1013,43 +1000,63 @@ __global__ __launch_bounds__(256) void k_deblock_tile(EncFrame f)
     if (iabs((int)(int16_t)(a & 0xffff) - (int)(int16_t)(b & 0xffff)) >= 4 || iabs((int)(int16_t)(a >> 16) - (int)(int16_t)(b >> 16)) >= 4) return 1;
     return 0;
   };
-  // ---- vertical edges: 8 edges x 16 (17) four-row segments
+  // ---- boundary strengths of this thread's vertical and horizontal edge segment, from the records alone.  A tile none of whose
+  // segments is filtered (still background: large units, equal vectors, no coefficients) leaves without touching a sample.
+  int bsv = 0, bsh = 0, qpv = 0, qph = 0;
   if (tid < 8 * (TH / 4)) {
     const int x = tx * 64 + (tid & 7) * 8, y = Y0 + (tid >> 3) * 4;
     if (x > 0 && y >= 0) {
       const int cq = cell(x, y), cp = cq - 1;
       if ((x & ((1 << r_log2[cq]) - 1)) == 0) {
-        const int bs = bs_of(cp, cq);
-        if (bs) {
-          const int qp = f.ctu_qy ? (cu_qpy(f, x - 1, y) + cu_qpy(f, x, y) + 1) >> 1 : f.qp;      // QpP and QpQ averaged (8.7.2.5.3)
-          deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], 1, P, bs, qp);
-          if (bs == 2 && (x & 15) == 0) {
-            const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0) + 2;
-            deblock_chroma_segment(&tc_[0][o], 1, PC, 2, qp);
-            deblock_chroma_segment(&tc_[1][o], 1, PC, 2, qp);
-          }
-        }
+        bsv = bs_of(cp, cq);
+        if (bsv) qpv = f.ctu_qy ? (cu_qpy(f, x - 1, y) + cu_qpy(f, x, y) + 1) >> 1 : f.qp;      // QpP and QpQ averaged (8.7.2.5.3)
       }
     }
   }
-  __syncthreads();
-  // ---- horizontal edges: 8 edges x 16 (17) four-column segments, on the vertically filtered samples
   if (tid < 8 * (TW / 4)) {
     const int y = tyi * 64 + (tid & 7) * 8, x = X0 + (tid >> 3) * 4;
     if (y > 0 && x >= 0) {
       const int cq = cell(x, y), cp = cq - 10;
       if ((y & ((1 << r_log2[cq]) - 1)) == 0) {
-        const int bs = bs_of(cp, cq);
-        if (bs) {
-          const int qp = f.ctu_qy ? (cu_qpy(f, x, y - 1) + cu_qpy(f, x, y) + 1) >> 1 : f.qp;
-          deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], P, 1, bs, qp);
-          if (bs == 2 && (y & 15) == 0) {
-            const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0) + 2;
-            deblock_chroma_segment(&tc_[0][o], PC, 1, 2, qp);
-            deblock_chroma_segment(&tc_[1][o], PC, 1, 2, qp);
-          }
-        }
+        bsh = bs_of(cp, cq);
+        if (bsh) qph = f.ctu_qy ? (cu_qpy(f, x, y - 1) + cu_qpy(f, x, y) + 1) >> 1 : f.qp;
       }
+    }
+  }
+  if (!__syncthreads_or(bsv | bsh)) return;
+  // ---- tile in: 16-byte pieces (X0 is 4-byte aligned: dwordx4 with dword alignment), the last piece of a 68-wide row 4 bytes
+  for (int i = tid; i < TH * 5; i += 256) {
+    const int y = i / 5, k = i - y * 5, x = k * 16, gx = X0 + x, gy = Y0 + y;
+    if (gy < 0 || x >= TW) continue;
+    const uint8_t *g = &f.rec[0][(size_t)gy * f.cw + gx];
+    if (k < 4) { if (gx >= 0) *(kv_u32x4 *)&ty_[y * P + x] = *(const kv_u32x4 *)g; else { kv_u32x4 v; v.x = 0; v.y = *(const uint32_t *)(g + 4); v.z = *(const uint32_t *)(g + 8); v.w = *(const uint32_t *)(g + 12); *(kv_u32x4 *)&ty_[y * P + x] = v; } }
+    else *(uint32_t *)&ty_[y * P + x] = *(const uint32_t *)g;
+  }
+  // chroma: aligned dwords from two samples left of the tile (CX0 - 2 is a multiple of 4): sample x of the tile sits at LDS column x + 2
+  for (int i = tid; i < 2 * (TH / 2) * 9; i += 256) {
+    const int pl = i / ((TH / 2) * 9), r = i - pl * ((TH / 2) * 9), y = r / 9, k = r - y * 9, gx = CX0 - 2 + 4 * k, gy = CY0 + y;
+    if (gy >= 0 && gx >= 0) *(uint32_t *)&tc_[pl][y * PC + 4 * k] = *(const uint32_t *)&f.rec[1 + pl][(size_t)gy * cw2 + gx];
+  }
+  __syncthreads();
+  // ---- vertical edges: 8 edges x 16 (17) four-row segments
+  if (bsv) {
+    const int x = tx * 64 + (tid & 7) * 8, y = Y0 + (tid >> 3) * 4;
+    deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], 1, P, bsv, qpv);
+    if (bsv == 2 && (x & 15) == 0) {
+      const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0) + 2;
+      deblock_chroma_segment(&tc_[0][o], 1, PC, 2, qpv);
+      deblock_chroma_segment(&tc_[1][o], 1, PC, 2, qpv);
+    }
+  }
+  __syncthreads();
+  // ---- horizontal edges: 8 edges x 16 (17) four-column segments, on the vertically filtered samples
+  if (bsh) {
+    const int y = tyi * 64 + (tid & 7) * 8, x = X0 + (tid >> 3) * 4;
+    deblock_luma_segment(&ty_[(y - Y0) * P + (x - X0)], P, 1, bsh, qph);
+    if (bsh == 2 && (y & 15) == 0) {
+      const int o = ((y >> 1) - CY0) * PC + ((x >> 1) - CX0) + 2;
+      deblock_chroma_segment(&tc_[0][o], PC, 1, 2, qph);
+      deblock_chroma_segment(&tc_[1][o], PC, 1, 2, qph);
     }
   }
   __syncthreads();
@@ -1398,23 +1405,29 @@ __global__ __launch_bounds__(256) void k_tok_compact(EncFrame f)
 // =============================================================================================
 __global__ __launch_bounds__(256) void k_pad_input(const uint8_t *in, int w, int h, uint8_t *dy, uint8_t *du, uint8_t *dv, int cw, int ch)
 {
-  // blockIdx.y: luma rows, then Cb rows, then Cr rows (packed I420 input: Y, U, V planes back to back); 16 samples per thread
-  int y = blockIdx.y, plane = 0;
-  if (y >= ch) { y -= ch; plane = 1; if (y >= ch / 2) { y -= ch / 2; plane = 2; } }
+  // A workgroup moves 1024 bytes x 16 rows: thread (x, q) the 16-byte piece x of rows 4q .. 4q + 3 -- four loads in flight, then four
+  // stores.  blockIdx.y counts groups of 16 rows through luma, Cb, Cr (packed I420 input: Y, U, V planes back to back; the planes'
+  // coded heights are multiples of 32, so a group never straddles two planes).
+  int y0 = blockIdx.y * 16 + threadIdx.y * 4, plane = 0;
+  if (y0 >= ch) { y0 -= ch; plane = 1; if (y0 >= ch / 2) { y0 -= ch / 2; plane = 2; } }
   const int pw = plane ? w / 2 : w, ph = plane ? h / 2 : h, pcw = plane ? cw / 2 : cw;
-  const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  const int x = (blockIdx.x * 64 + threadIdx.x) * 16;
   if (x >= pcw) return;
   const uint8_t *src = in + (plane == 0 ? 0 : (plane == 1 ? (size_t)w * h : (size_t)w * h + (size_t)(w / 2) * (h / 2)));
   uint8_t *dst = plane == 0 ? dy : (plane == 1 ? du : dv);
-  const uint8_t *row = src + (size_t)imin(y, ph - 1) * pw;
-  kv_u32x4 v;
-  if (x + 16 <= pw && (((uintptr_t)(row + x)) & 3) == 0) v = *reinterpret_cast<const kv_u32x4 *>(row + x);      // the common case: one 16-byte load
-  else {                                                     // the picture's right edge (replicated) or an odd alignment: byte by byte
-    uint32_t q[4] = {0, 0, 0, 0};
-    for (int i = 0; i < 16; i++) q[i >> 2] |= (uint32_t)row[imin(x + i, pw - 1)] << (8 * (i & 3));
-    v.x = q[0]; v.y = q[1]; v.z = q[2]; v.w = q[3];
+  kv_u32x4 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint8_t *row = src + (size_t)imin(y0 + k, ph - 1) * pw;
+    if (x + 16 <= pw && (((uintptr_t)(row + x)) & 3) == 0) v[k] = *reinterpret_cast<const kv_u32x4 *>(row + x);      // the common case: one 16-byte load
+    else {                                                     // the picture's right edge (replicated) or an odd alignment: byte by byte
+      uint32_t q[4] = {0, 0, 0, 0};
+      for (int i = 0; i < 16; i++) q[i >> 2] |= (uint32_t)row[imin(x + i, pw - 1)] << (8 * (i & 3));
+      v[k].x = q[0]; v[k].y = q[1]; v[k].z = q[2]; v[k].w = q[3];
+    }
   }
-  *reinterpret_cast<kv_u32x4 *>(dst + (size_t)y * pcw + x) = v;          // coded widths are multiples of 64: 16-byte aligned
+#pragma unroll
+  for (int k = 0; k < 4; k++) *reinterpret_cast<kv_u32x4 *>(dst + (size_t)(y0 + k) * pcw + x) = v[k];          // coded widths are multiples of 64: 16-byte aligned
 }
 
 // =============================================================================================
@@ -1660,8 +1673,8 @@ __global__ __launch_bounds__(256) void k_vaq_apply(EncFrame f, int vaq, const in
 // =============================================================================================
 void launch_pad_input(const uint8_t *in, int w, int h, uint8_t *dy, uint8_t *du, uint8_t *dv, int cw, int ch, hipStream_t st)
 {
-  dim3 g((cw / 16 + 63) / 64, ch * 2);
-  hipLaunchKernelGGL(k_pad_input, g, dim3(64), 0, st, in, w, h, dy, du, dv, cw, ch);
+  dim3 g((cw / 16 + 63) / 64, ch * 2 / 16);
+  hipLaunchKernelGGL(k_pad_input, g, dim3(64, 4), 0, st, in, w, h, dy, du, dv, cw, ch);
 }
 void launch_me(const EncFrame &f, hipStream_t st)
 {

@@ -14,3 +14,4 @@ for pass in $passes; do
     python3 $R/bench.py --workload $wl --no-cpu-baseline --no-secondary --steps 1 --warmup 1 --owf 0 --decoder-frame-threads 1 "$@" > $out.$name.log 2>&1 || echo "pass $name failed (rc $?)"
 done
 python3 $R/tools/pmc_summarise.py $out $wl > $R/gpurun_out/pmc_traffic_$wl.json && tail -c 600 $R/gpurun_out/pmc_traffic_$wl.json
+rm -rf $out      # (per-dispatch counter tables are large: gpurun brings back at most 64 MiB)

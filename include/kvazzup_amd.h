@@ -72,6 +72,10 @@ KVZ_PUBLIC int kvzx_decoder_debug_copy(OpenHevc_Handle h, const char *what, void
 /* delta-QP map for the pictures submitted through the device entry point (the host entry point takes it from kvz_picture.roi,
  * kvazaarfilter.cpp:423-431): w x h int8 cells over the picture, w == 0 removes it; needs "set-qp-in-cu" = 1 */
 KVZ_PUBLIC void kvzx_encoder_set_roi(kvz_encoder *enc, int w, int h, const int8_t *map);
+/* Rate control ("bitrate" > 0) in band mode: every band's encoder runs the same picture-level controller, which books the size of access
+ * unit t - 3 before picture t; the caller tells EVERY encoder the size of each assembled access unit (picture = 0, 1, ...) before
+ * picture + 3 is started.  kvazzup_amd/tilesplit.py passes the sizes along with the substream headers it gathers anyway. */
+KVZ_PUBLIC void kvzx_encoder_band_report_au(kvz_encoder *enc, long picture, uint32_t bytes);
 KVZ_PUBLIC int kvzx_encoder_band_phase1(kvz_encoder *enc, const void *d_i420);
 KVZ_PUBLIC size_t kvzx_encoder_band_halo_bytes(kvz_encoder *enc);
 KVZ_PUBLIC int kvzx_encoder_band_export_halo(kvz_encoder *enc, void *d_up, void *d_down);

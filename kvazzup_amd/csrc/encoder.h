@@ -68,6 +68,7 @@ class Encoder {
   void set_roi(int w, int h, const int8_t *map);
   // ---- band mode (cfg.band_rows > 0); every call is synchronous.  Per picture: band_phase1, export the halos, exchange them
   // with the neighbouring bands' encoders (rank - 1 gets `up`, rank + 1 gets `down`), import theirs, band_phase2.
+  void band_report_au(long picture, uint32_t bytes);              // rate control in band mode: size of the assembled access unit of picture `picture` (every band's encoder is told; needed before picture + 3 starts)
   bool band_phase1(const uint8_t *d_i420);                       // input, decisions, reconstruction, vertical-edge deblocking of the band
   size_t halo_bytes() const;                                     // size of one halo block
   bool band_export_halo(uint8_t *d_up, uint8_t *d_down);         // the band's first / last 4 luma + 2 x 2 chroma rows (vertical edges filtered) and CU records of its first / last 8x8 row
@@ -126,7 +127,7 @@ class Encoder {
   int8_t *h_ctu_qt_[2] = {nullptr, nullptr};   // pinned staging of the target map
   int *vaq_act_ = nullptr, *vaq_sum_ = nullptr; // VAQ: activity of every CTU, its sum over the picture
   bool upload_qp_targets();
-  int qp_cur_ = 0; int64_t rc_debt_ = 0; uint32_t rc_bytes_[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rate control state (calling thread)
+  int qp_cur_ = 0; int64_t rc_debt_ = 0; uint32_t rc_bytes_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t rc_known_ = 0;   // rate control state (calling thread)
   void rate_control();
   bool band_picture_setup();
   bool band_intra_ = false;

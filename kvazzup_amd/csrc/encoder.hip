@@ -44,8 +44,8 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   if (cfg.band_rows > 0) {
     const int hc = (cfg.height + 63) / 64, T = cfg.tile_rows;
     const bool ok = cfg.band_row0 >= 0 && cfg.band_row0 + cfg.band_rows <= hc && tile_row_starts_at(hc, T, cfg.band_row0) &&
-                    tile_row_ends_at(hc, T, cfg.band_row0 + cfg.band_rows - 1) && cfg.bitrate == 0 && !cfg.sao && cfg.vaq == 0;
-    if (!ok) { if (error) *error = "a band must consist of whole tile rows (and rate control, SAO and VAQ are not available in band mode)"; return false; }
+                    tile_row_ends_at(hc, T, cfg.band_row0 + cfg.band_rows - 1) && !cfg.sao && cfg.vaq == 0;
+    if (!ok) { if (error) *error = "a band must consist of whole tile rows (and SAO and VAQ are not available in band mode)"; return false; }
   }
   if (const char *e = getenv("KVAZZUP_AMD_ENTROPY")) cfg.entropy_gpu = strcmp(e, "gpu") == 0;    // A/B knob: host | gpu
   if (cfg.band_rows > 0) cfg.entropy_gpu = 0;               // (band mode hands its substreams to the caller from the host pool)
@@ -510,6 +510,14 @@ bool Encoder::band_picture_setup()
   const int period = cfg_.intra_period;
   band_intra_ = (frame_idx_ == 0) || (period > 0 && (frame_idx_ % period) == 0);
   if (band_intra_) poc_ = 0; else poc_++;
+  // rate control: every band's encoder runs the same controller on the same access-unit sizes (band_report_au), so all of them
+  // arrive at the same QP without talking to each other
+  if (cfg_.bitrate > 0 && frame_idx_ >= 3 && !(rc_known_ & (1u << ((frame_idx_ - 3) & 7)))) {
+    fprintf(stderr, "kvazzup_amd: band mode with rate control: the size of access unit %d has not been reported (kvzx_encoder_band_report_au)\n", frame_idx_ - 3);
+    return false;
+  }
+  rate_control();
+  if (frame_idx_ >= 3) rc_known_ &= ~(1u << ((frame_idx_ - 3) & 7));
   f_.qp = qp_cur_; f_.qpc = kChromaQp[qp_cur_]; f_.lambda_q4 = kLambdaQ4[qp_cur_];
   f_.is_intra = band_intra_; f_.poc = poc_;
   for (int c = 0; c < 3; c++) { f_.rec[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
@@ -517,6 +525,9 @@ bool Encoder::band_picture_setup()
   f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err;
   return true;
 }
+
+// band mode: the size of a finished access unit (picture index = count of pictures before it), for the rate controller
+void Encoder::band_report_au(long picture, uint32_t bytes) { rc_bytes_[picture & 7] = bytes; rc_known_ |= 1u << (picture & 7); }
 
 bool Encoder::band_phase1(const uint8_t *d_i420)
 {

@@ -422,6 +422,7 @@ uint64_t kvzx_encoder_last_bins(kvz_encoder *e) { return e ? e->last_bins : 0; }
 void kvzx_encoder_set_roi(kvz_encoder *e, int w, int h, const int8_t *map) { if (e) e->impl->set_roi(w, h, map); }
 
 // ---- tile-row split of one picture over several encoders (include/kvazzup_amd.h) ----
+void kvzx_encoder_band_report_au(kvz_encoder *e, long picture, uint32_t bytes) { if (e) e->impl->band_report_au(picture, bytes); }
 int kvzx_encoder_band_phase1(kvz_encoder *e, const void *d_i420) { return e && e->impl->band_phase1((const uint8_t *)d_i420) ? 1 : 0; }
 size_t kvzx_encoder_band_halo_bytes(kvz_encoder *e) { return e ? e->impl->halo_bytes() : 0; }
 int kvzx_encoder_band_export_halo(kvz_encoder *e, void *d_up, void *d_down) { return e && e->impl->band_export_halo((uint8_t *)d_up, (uint8_t *)d_down) ? 1 : 0; }

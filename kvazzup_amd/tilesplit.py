@@ -44,7 +44,8 @@ class BandEncoder:
         for k, v in opts.items():
             if self.api.config_parse(self.cfg, k.encode(), v.encode()) != 1 and k != "preset":
                 raise ValueError("option %s=%s rejected" % (k, v))
-        self.cfg.contents.target_bitrate = 0
+        if "bitrate" not in opts:
+            self.cfg.contents.target_bitrate = 0
         self.enc = self.api.encoder_open(self.cfg)
         if not self.enc:
             raise RuntimeError("encoder_open failed (no usable HIP device? there is no CPU fallback)")
@@ -52,6 +53,8 @@ class BandEncoder:
         L.kvzx_encoder_band_halo_bytes.restype = C.c_size_t
         L.kvzx_encoder_band_halo_bytes.argtypes = [C.c_void_p]
         L.kvzx_encoder_band_phase1.argtypes = [C.c_void_p, C.c_void_p]
+        L.kvzx_encoder_band_report_au.restype = None
+        L.kvzx_encoder_band_report_au.argtypes = [C.c_void_p, C.c_long, C.c_uint32]
         L.kvzx_encoder_band_export_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.kvzx_encoder_band_import_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.kvzx_encoder_band_phase2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -68,6 +71,7 @@ class BandEncoder:
         self.sizes = np.zeros(self.ctu_rows, dtype=np.uint32)
         self.halo_bytes_exchanged = 0
         self.pipelined, self.pending, self.intra_count = bool(pipelined), None, 0
+        self.assembled, self.last_au, self.reported = 0, (-1, 0), -1      # rate control: access units assembled (rank 0), the latest (index, bytes), the latest index told to the encoder
         self.dev = getattr(self, "dev", None)
 
     # ---- the exchange step, in two halves: the transfers are started, phase 2a (inner horizontal edges, tokenizer, host arithmetic
@@ -105,7 +109,13 @@ class BandEncoder:
 
     # ---- substreams to rank 0: fixed-size headers to everybody (every rank then knows the largest payload), payloads padded to that
     # size to rank 0.  No pickling; with `pipelined` the payload gather of picture t completes during picture t + 1.
-    HDR = 4
+    HDR = 6            # substream count, POC, QP, NAL type, index and size of the latest access unit rank 0 has assembled (rate control)
+
+    def _report(self, index, nbytes):
+        """every rank tells its encoder the size of access unit `index` (the same numbers everywhere: the controllers stay in step)"""
+        if index > self.reported:
+            self.lib.kvzx_encoder_band_report_au(self.enc, index, nbytes)
+            self.reported = index
 
     def _gather_start(self, sizes, data, info):
         d, t = self.dist, self.torch
@@ -114,10 +124,12 @@ class BandEncoder:
             return ("local", mine)
         dev = self.dev if d.get_backend() == "nccl" else "cpu"
         hdr = t.zeros(self.HDR + self.ctu_rows, dtype=t.int64, device=dev)
-        hdr[:self.HDR + len(sizes)] = t.tensor([len(sizes), info.poc, info.qp, info.nal_unit_type] + sizes, dtype=t.int64)
+        hdr[:self.HDR + len(sizes)] = t.tensor([len(sizes), info.poc, info.qp, info.nal_unit_type, self.last_au[0], self.last_au[1]] + sizes, dtype=t.int64)
         hdrs = [t.empty_like(hdr) for _ in range(self.world)]
         d.all_gather(hdrs, hdr)
         hdrs = [h.cpu().tolist() for h in hdrs]
+        if hdrs[0][4] >= 0:
+            self._report(int(hdrs[0][4]), int(hdrs[0][5]))
         totals = [sum(h[self.HDR:self.HDR + h[0]]) for h in hdrs]
         cap = (max(totals) + 4095) & ~4095
         pay = t.zeros(cap, dtype=t.uint8)
@@ -146,7 +158,12 @@ class BandEncoder:
         write_ps = idr and (self.intra_count == 0 or (vp > 0 and self.intra_count % vp == 0))
         if idr:
             self.intra_count += 1
-        return assemble(self.lib, self.cfg, parts, write_ps)
+        au = assemble(self.lib, self.cfg, parts, write_ps)
+        self.last_au = (self.assembled, len(au))
+        self.assembled += 1
+        if self.world == 1:
+            self._report(*self.last_au)
+        return au
 
     def encode(self, d_i420_ptr):
         """one picture; returns the access unit on rank 0 (None elsewhere).  With `pipelined` the access unit returned is the PREVIOUS

@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     w, h, tile_rows, frames = (int(x) for x in sys.argv[1:5])
     pipelined = len(sys.argv) > 5 and sys.argv[5] == "pipelined"        # access units arrive one picture late (the gather completes during the next picture)
+    bitrate = int(sys.argv[6]) if len(sys.argv) > 6 else 0               # > 0: rate control, every rank's controller fed with the assembled sizes
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -24,9 +25,9 @@ def main():
     from kvazzup_amd.tilesplit import BandEncoder
     import numpy as np
     import orc
-    opts = (("qp", 30), ("period", 4), ("me-range", 16))
+    opts = (("qp", 30), ("period", 4), ("me-range", 16)) + ((("bitrate", bitrate),) if bitrate else ())
     be = BandEncoder(w, h, tile_rows, rank, world, options=opts, device=dev, dist=dist, pipelined=pipelined)
-    oe = orc.OracleEncoder(w, h, qp=30, period=4, me_range=16, tile_rows=tile_rows) if rank == 0 else None
+    oe = orc.OracleEncoder(w, h, qp=30, period=4, me_range=16, tile_rows=tile_rows, bitrate=bitrate) if rank == 0 else None
     od = orc.OracleDecoder() if rank == 0 else None
     bad = 0
     got = []

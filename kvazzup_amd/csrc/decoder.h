@@ -101,7 +101,7 @@ class Decoder {
   explicit Decoder(int device) : device_(device) {}
   // frame threading: up to n pictures are parsed concurrently while one more is reconstructed on the GPU; the output is delayed by n pictures
   // (libOpenHevcInit(nb_threads, OH_THREAD_FRAME / OH_THREAD_FRAMESLICE)); call before the first picture
-  void set_frame_threads(int n) { if (jobs_.empty()) frame_threads_ = n < 1 ? 1 : (n > 16 ? 16 : n); }
+  void set_frame_threads(int n) { if (jobs_.empty()) frame_threads_ = n < 1 ? 1 : (n > 32 ? 32 : n); }
   int frame_threads() const { return frame_threads_; }
   ~Decoder();
   bool start(std::string *error);           // checks the HIP device; no CPU fallback

@@ -1189,7 +1189,10 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
       // a large picture (an intra picture: several milliseconds on one core, which the pictures behind it in the ring cannot
       // hide) has its substreams parsed side by side on the row pool; small ones stay on this worker
       bool rows = false;
-      if (jp->data_len > (192u << 10) && pool_mutex_.try_lock()) rows = true;
+      // (64 KB: a 4K intra picture at QP 32 is ~125 KB and ~10 ms on one core -- longer than the eleven pictures behind it in a ring
+      // of twelve take -- a 1080p one ~37 KB and stays on its worker: at 1080p every core is busy anyway)
+      static const size_t row_parse_bytes = [] { const char *e = getenv("KVAZZUP_AMD_ROWPARSE_KB"); return (size_t)(e ? atoi(e) : 64) << 10; }();
+      if (jp->data_len > row_parse_bytes && pool_mutex_.try_lock()) rows = true;
       jp->rc = parse_job(*jp, rows);
       if (rows) pool_mutex_.unlock();
       jp->parse_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1379,7 +1382,12 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
     if (rc < 0) release_all();
   };
   if (row_parallel && nsub > 1) {
-    if (!pool_) { const char *e = getenv("KVAZZUP_AMD_PARSE_THREADS"); if (e) parse_threads_ = atoi(e) < 1 ? 1 : atoi(e); pool_.reset(new OrderedPool(parse_threads_)); }
+    if (!pool_) {
+      const char *e = getenv("KVAZZUP_AMD_PARSE_THREADS");
+      if (e) parse_threads_ = atoi(e) < 1 ? 1 : atoi(e);
+      else if (frame_threads_ > 1 && parse_threads_ > 8) parse_threads_ = 8;      // beside the frame workers: measured best at 4K (2231 against 2085 frames/s with 16)
+      pool_.reset(new OrderedPool(parse_threads_));
+    }
     pool_->run(nsub, one);
   } else {
     for (int r = 0; r < nsub; r++) one(r);              // frame-parallel mode: substreams in sequence on this worker

@@ -496,7 +496,7 @@ void WireAdapter::process()
   while (input) {
     if (input->flush_marker) {
       // end-of-sequence NAL units (type 36): each makes the decoder hand out one picture its frame threads still hold
-      for (int k = 0; k < 18; k++) {
+      for (int k = 0; k < 34; k++) {                     // (more than the decoder's largest ring: 32 frame threads)
         std::unique_ptr<Data> nal(new Data);
         nal->source = DS_REMOTE; nal->type = DT_HEVCVIDEO; nal->data_size = 6;
         nal->data.reset(new uint8_t[6]{0, 0, 0, 1, 36 << 1, 1});

@@ -14,6 +14,7 @@
 #include "hevc_core.h"
 #include "hevc_headers.h"
 #include "entropy_host.h"
+#include "enc_kernels.h"
 
 namespace kvzx {
 
@@ -34,6 +35,8 @@ struct EncoderConfig {
   int entropy_threads = 16;   // host threads of the arithmetic-coding stage
   int qp_in_cu = 0;           // kvazaar "set-qp-in-cu": cu_qp_delta_enabled_flag; a delta-QP map (set_roi, kvz_picture.roi) then gives every CTU its own QP
   int bitrate = 0;            // bits per second; 0 = constant QP, > 0 = "uvgx rate control v1" (oracle/hevc_enc.c rate_control())
+  int rc_bands = 0;           // with bitrate > 0: "uvgx rate control v2" -- a P picture's CTU rows are reconstructed in this many groups and the QP follows the level cost
+                              // between them, on the device (rc_kernels.hip; statement rc_band_decide() in oracle/hevc_enc.c); 0 = picture level only (v1); implies qp_in_cu
   int satd = 1;               // intra mode search cost: 8x8 Hadamard sums (1) or SAD (0)
   int subme = 0;              // kvazaar "subme" 0..4: fractional-sample refinement of the searched vectors, "uvgx subme v1" (oracle/hevc_enc.c subme_refine())
   int me_early = 1;           // kvazaar "me-early-termination" (on / sensitive: 1, off: 0): static 32x32 blocks skip the motion search
@@ -129,6 +132,7 @@ class Encoder {
   bool upload_qp_targets();
   int qp_cur_ = 0; int64_t rc_debt_ = 0; uint32_t rc_bytes_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t rc_known_ = 0;   // rate control state (calling thread)
   void rate_control();
+  RcState *rc_state_ = nullptr;                 // rate control v2: device-side state
   bool band_picture_setup();
   bool band_intra_ = false;
   hipStream_t stream_tok_ = nullptr;     // signalling decisions, tokenizer, compaction

@@ -33,6 +33,8 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
 {
   EncoderConfig cfg = cfg_in;
   if (cfg.vaq > 0) cfg.qp_in_cu = 1;                       // the deltas travel as cu_qp_delta
+  if (cfg.bitrate <= 0 || cfg.band_rows > 0) cfg.rc_bands = 0;
+  if (cfg.rc_bands > 0) cfg.qp_in_cu = 1;                  // ... and so do the steps of rate control v2
 
   const char *prio = getenv("KVAZZUP_AMD_PRIO"); if (!prio || strlen(prio) < 4) prio = "hnnn";   // main, tokenizer, input, decoder: the chain the next picture waits for is the urgent one (+6 % at 1080p; any explicit priority also gives the stream a hardware queue of its own)
 
@@ -92,6 +94,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     for (int k = 0; k < 2; k++) HIP_OK(hipMalloc(&sao_[k], sizeof(SaoParams) * (size_t)(cw_ / 64) * rows_));
     HIP_OK(hipEventCreateWithFlags(&ev_sao_, hipEventDisableTiming));
   }
+  if (cfg.rc_bands > 0) { HIP_OK(hipMalloc(&rc_state_, sizeof(RcState))); HIP_OK(hipMemset(rc_state_, 0, sizeof(RcState))); }
   HIP_OK(create_stream(&stream_tok_, prio[1]));
   HIP_OK(create_stream(&stream_in_, prio[2]));
   for (int k = 0; k < 2; k++) HIP_OK(hipEventCreateWithFlags(&ev_src_free_[k], hipEventDisableTiming));
@@ -224,7 +227,7 @@ Encoder::~Encoder()
   if (in_done_) hipEventDestroy(in_done_);
   hipFree(d_in_); hipHostFree(h_in_);
   for (int c = 0; c < 3; c++) { hipFree(src_[0][c]); hipFree(src_[1][c]); for (int b = 0; b < 10; b++) hipFree(rec_[b][c]); hipFree(coef_[0][c]); hipFree(coef_[1][c]); }
-  hipFree(vaq_act_); hipFree(vaq_sum_);
+  hipFree(vaq_act_); hipFree(vaq_sum_); hipFree(rc_state_);
   for (int k = 0; k < 2; k++) { hipFree(ctu_qt_[k]); hipFree(ctu_qy_[k]); hipFree(ctu_delta_[k]); hipFree(ctu_first_[k]); if (h_ctu_qt_[k]) hipHostFree(h_ctu_qt_[k]); }
   for (int k = 0; k < 2; k++) { hipFree(cu_bytes_[k]); hipFree(cu_mv_[k]); hipFree(cu_mvd_[k]); if (ev_tok_done_[k]) hipEventDestroy(ev_tok_done_[k]); }
   for (int c = 0; c < 3; c++) hipFree(work_[c]);
@@ -363,6 +366,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   HIP_CHECK(hipStreamWaitEvent(stream_, in_done_, 0));
   if (tok_pending_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_, ev_tok_done_[set_], 0)); tok_pending_[set_] = false; }   // tokenizer of t - 2 done with this set
   if (!upload_qp_targets()) return false;
+  if (rc_state_) launch_rc_begin(rc_state_, frame_idx_ >= 3 ? 8u * rc_bytes_[(frame_idx_ - 3) & 7] : 0u, (frame_idx_ - 3) & 7, frame_idx_ >= 3, stream_);
   if (intra) {
     HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * rows_ * (cw_ / 64) * 3, stream_));
     HIP_CHECK(hipMemsetAsync(f_.cu_cbf, 0, (size_t)f_.b8w * f_.b8h, stream_));     // the three plane waves OR their bit in
@@ -370,6 +374,17 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   } else {
     timed(K_ME, stream_, [&] { launch_me(f, stream_); });
     if (cfg_.subme > 0) timed(K_SUBPEL, stream_, [&] { launch_subpel(f, stream_); });
+    if (rc_state_) {
+      // rate control v2: the CTU rows in groups, the next group's QP decided on the device from the levels of the groups before
+      const int nb = cfg_.rc_bands < rows_ ? cfg_.rc_bands : rows_;
+      const long long T = ((long long)cfg_.bitrate * cfg_.fps_den) / (cfg_.fps_num > 0 ? cfg_.fps_num : 1);
+      for (int b = 0; b < nb; b++) {
+        EncFrame fb = f;
+        fb.row0 = (b * rows_) / nb; fb.nrows = ((b + 1) * rows_) / nb - fb.row0;
+        timed(K_INTER_RECON, stream_, [&] { launch_inter_recon(fb, stream_); });
+        launch_rc_band(fb, rc_state_, T, rows_, b + 1 < nb ? ((b + 2) * rows_) / nb : fb.row0 + fb.nrows, frame_idx_ & 7, stream_);
+      }
+    } else
     timed(K_INTER_RECON, stream_, [&] { launch_inter_recon(f, stream_); });
   }
   launch_qp_resolve(f, stream_);                                 // per-CTU QP: which CU carries the delta, QpY for deblocking

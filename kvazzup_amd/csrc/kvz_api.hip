@@ -263,7 +263,10 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.qp_in_cu = (cfg->set_qp_in_cu || ec.vaq > 0) ? 1 : 0;
   ec.sao = cfg->sao_type == KVZ_SAO_FULL;
   ec.mv_frame = cfg->mv_constraint == KVZ_MV_CONSTRAIN_FRAME || cfg->mv_constraint == KVZ_MV_CONSTRAIN_FRAME_AND_TILE ? 1 : (cfg->mv_constraint == KVZ_MV_CONSTRAIN_FRAME_AND_TILE_MARGIN ? 2 : 0);   // (tile rows always confine vectors to the tile)
-  ec.bitrate = cfg->target_bitrate > 0 ? cfg->target_bitrate : 0;      // any rc-algorithm value selects the one picture-level controller
+  ec.bitrate = cfg->target_bitrate > 0 ? cfg->target_bitrate : 0;
+  // rc-algorithm lambda / oba (uvgComm sets "lambda" with its bitrate, kvazaarfilter.cpp:225-228): the picture-level controller plus feedback
+  // inside the picture (rate control v2, four groups of CTU rows); left unset: the picture-level controller alone
+  ec.rc_bands = (ec.bitrate > 0 && cfg->rc_algorithm != KVZ_NO_RC) ? 4 : 0;
   std::string err;
   Encoder *impl = Encoder::create(ec, &err);
   if (!impl) { fprintf(stderr, "kvazzup_amd: encoder_open failed: %s\n", err.c_str()); return nullptr; }

@@ -27,6 +27,9 @@ struct orc_encoder {
   int frame_idx, poc, intra_count;
   int qp;                              /* QP of the picture being coded (== cfg.qp without rate control) */
   int64_t rc_debt; uint32_t rc_bytes[8];  /* rate control: bits spent above target so far; sizes of the last access units */
+  /* rate control v2 (rc_bands): bits per unit of level cost (Q8, smoothed), whether it has been measured yet, the level cost of the
+   * last eight pictures and whether they were P pictures coded in groups */
+  uint32_t rc_ratio_q8; int rc_ratio_valid; uint32_t rc_cost[8]; uint8_t rc_cost_valid[8];
   orc_vps vps; orc_sps sps; orc_pps pps;
   orc_pic pics[2]; orc_pic *cur, *ref;
   pixel *src[3];
@@ -82,6 +85,8 @@ orc_encoder *orc_enc_open(const orc_enc_config *c)
   orc_tables_init();
   e->cfg = *c;
   if (e->cfg.vaq > 0) e->cfg.qp_in_cu = 1;                 /* the deltas travel as cu_qp_delta */
+  if (e->cfg.bitrate <= 0) e->cfg.rc_bands = 0;
+  if (e->cfg.rc_bands > 0) e->cfg.qp_in_cu = 1;
   e->qp = c->qp;
   e->cw = (c->width + 63) & ~63; e->ch = (c->height + 63) & ~63;
   if (e->cw < 128) e->cw = 128;                 /* WPP context hand-over needs two CTUs per row */
@@ -557,13 +562,70 @@ static void inter_decide_signalling(orc_encoder *e, int x0, int y0, int log2)
   if (flags & 1) fill_b4(p, p->pred_mode, x0, y0, n, MODE_SKIP);
 }
 
+/* ---- "uvgx rate control v2": feedback inside the picture, on top of the picture-level controller (rate_control()).
+ * Level cost of a CTU = sum over its non-zero levels (all three planes) of 3 + 2 * floor(log2 |level|): about the bins a level takes
+ * (significance, greater-1 / greater-2 or remainder, sign).  One unit of it is worth rc_ratio_q8 / 256 bits, measured on the P
+ * pictures coded before (rc_picture_start).  After a group of CTU rows: estimated bits so far against the rows' share of the
+ * picture's target T; more than 9/8 of it -> the next group's QP one step up, less than 7/8 -> one step down; the offset stays
+ * within +-3 of the picture's QP.  Nothing moves until the ratio has been measured once. */
+static uint32_t rc_ctu_cost(const orc_encoder *e, int cx, int cy)
+{
+  uint32_t c = 0;
+  for (int pl = 0; pl < 3; pl++) {
+    int S = pl ? 32 : 64, pw = pl ? e->cw / 2 : e->cw;
+    const int16_t *p = e->coef[pl] + (size_t)(cy * S) * pw + cx * S;
+    for (int y = 0; y < S; y++) for (int x = 0; x < S; x++) { int l = p[y * pw + x]; if (l) c += 3u + 2u * (uint32_t)orc_log2((uint32_t)orc_abs(l)); }
+  }
+  return c;
+}
+static int rc_band_decide(int off, uint32_t cost, uint32_t ratio_q8, int64_t T, int rows_done, int rows_total)
+{
+  if (!ratio_q8) return off;
+  uint64_t est = ((uint64_t)cost * ratio_q8) >> 8, tgt = ((uint64_t)T * (uint64_t)rows_done) / (uint64_t)rows_total;
+  if (est * 8 > tgt * 9) off++; else if (est * 8 < tgt * 7) off--;
+  return orc_clip3(-3, 3, off);
+}
+/* before picture t: the size of access unit t - 3 is known (the delay of the picture-level controller); if that was a P picture coded in
+ * groups, its bits per unit of level cost update the ratio (new = (3 * old + measured + 2) >> 2; the first measurement is taken as is) */
+static void rc_picture_start(orc_encoder *e)
+{
+  if (e->cfg.rc_bands <= 0 || e->frame_idx < 3) return;
+  int s3 = (e->frame_idx - 3) & 7;
+  if (!e->rc_cost_valid[s3]) return;
+  e->rc_cost_valid[s3] = 0;
+  uint64_t r = ((uint64_t)8 * e->rc_bytes[s3] << 8) / (e->rc_cost[s3] ? e->rc_cost[s3] : 1);
+  if (r > (1u << 20)) r = 1u << 20;
+  if (r < 1) r = 1;
+  e->rc_ratio_q8 = e->rc_ratio_valid ? (uint32_t)((3 * (uint64_t)e->rc_ratio_q8 + r + 2) >> 2) : (uint32_t)r;
+  e->rc_ratio_valid = 1;
+}
+
 static void encode_inter_picture(orc_encoder *e)
 {
   build_refpad(e);
   for (int y = 0; y < e->ch; y += 32) for (int x = 0; x < e->cw; x += 32) me_block32(e, x, y);
-  for (int y = 0; y < e->ch; y += 32) for (int x = 0; x < e->cw; x += 32) {
-    if (e->cu_log2[b8i(e, x, y)] == 5) inter_recon_cu(e, x, y, 5);
-    else for (int k = 0; k < 4; k++) inter_recon_cu(e, x + (k & 1) * 16, y + (k >> 1) * 16, 4);
+  /* Reconstruction, in rc_bands groups of CTU rows when rate control v2 is on: after each group the level cost so far is priced
+   * against the share of the picture's target the rows done are entitled to, and the next group's QP follows (rc_band_decide). */
+  {
+    int hc = e->ch / 64, wc = e->cw / 64, nb = e->cfg.rc_bands > 0 ? (e->cfg.rc_bands < hc ? e->cfg.rc_bands : hc) : 1, off = 0;
+    uint32_t cost = 0;
+    const int64_t T = e->cfg.bitrate > 0 ? ((int64_t)e->cfg.bitrate * e->cfg.fps_den) / (e->cfg.fps_num > 0 ? e->cfg.fps_num : 1) : 0;
+    for (int b = 0; b < nb; b++) {
+      int r0 = (b * hc) / nb, r1 = ((b + 1) * hc) / nb;
+      for (int y = r0 * 64; y < r1 * 64; y += 32) for (int x = 0; x < e->cw; x += 32) {
+        if (e->cu_log2[b8i(e, x, y)] == 5) inter_recon_cu(e, x, y, 5);
+        else for (int k = 0; k < 4; k++) inter_recon_cu(e, x + (k & 1) * 16, y + (k >> 1) * 16, 4);
+      }
+      if (e->cfg.rc_bands > 0) {
+        for (int cy = r0; cy < r1; cy++) for (int cx = 0; cx < wc; cx++) cost += rc_ctu_cost(e, cx, cy);
+        if (b + 1 < nb) {
+          off = rc_band_decide(off, cost, e->rc_ratio_valid ? e->rc_ratio_q8 : 0, T, r1, hc);
+          int r2 = ((b + 2) * hc) / nb;
+          for (int cy = r1; cy < r2; cy++) for (int cx = 0; cx < wc; cx++) e->ctu_qt[cy * wc + cx] = (int8_t)orc_clip3(0, 51, e->ctu_qt[cy * wc + cx] + off);
+        }
+      }
+    }
+    if (e->cfg.rc_bands > 0) { e->rc_cost[e->frame_idx & 7] = cost; e->rc_cost_valid[e->frame_idx & 7] = 1; }
   }
   for (int y = 0; y < e->ch; y += 32) for (int x = 0; x < e->cw; x += 32) {
     if (e->cu_log2[b8i(e, x, y)] == 5) inter_decide_signalling(e, x, y, 5);
@@ -973,6 +1035,7 @@ size_t orc_enc_encode(orc_encoder *e, const pixel *y, const pixel *u, const pixe
   e->is_intra = (e->frame_idx == 0) || (period > 0 && (e->frame_idx % period) == 0);
   if (e->is_intra) e->poc = 0; else e->poc++;
   rate_control(e);
+  rc_picture_start(e);
   load_input(e, y, u, v);
   roi_targets(e);
   orc_pic_reset_side(e->cur);

@@ -49,6 +49,10 @@ typedef struct {
                                * offset of -3..3 quarter samples per component, so that the stream exercises fractional-sample
                                * interpolation (8.5.3.3.3) -- the encoder algorithm proper never produces fractional vectors */
   int sao;                    /* 1: sample adaptive offset on, parameters by "uvgx SAO decision v1" (hevc_sao.c) */
+  int rc_bands;               /* with bitrate > 0: "uvgx rate control v2" -- the CTU rows of a P picture are reconstructed in this many groups, one after
+                               * the other, and after each group the QP of the next one moves by at most one step (within +-3 of the picture's QP)
+                               * according to what the levels coded so far will cost against the picture's target (rc_band_decide() in hevc_enc.c);
+                               * 0 = picture-level control only (v1).  Implies qp_in_cu: the steps travel as cu_qp_delta */
   int subme;                  /* kvazaar subme 0..4: fractional-sample refinement of every searched CU's vector, "uvgx subme v1" (subme_refine()
                                * in hevc_enc.c): 0 off (Kvazaar's ultrafast), 1 half-sample positions left/right/above/below, 2 + the four
                                * half-sample diagonals, 3 + quarter-sample left/right/above/below of the best so far, 4 + its quarter-sample

@@ -154,6 +154,37 @@ def test_owf_lags_output_and_flushes(gpu, owf):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w,h,bitrate,owf,opts", [(320, 192, 200000, 0, {}), (640, 384, 900000, 2, {}), (640, 384, 400000, 1, dict(sao=1, subme=2)), (448, 320, 600000, 2, dict(vaq=6, tile_rows=2)),
+                                                  (1920, 1080, 3000000, 2, {})])
+def test_rate_control_v2_matches_the_checker(gpu, w, h, bitrate, owf, opts):
+    """rc-algorithm lambda (what uvgComm sets with its bitrate, kvazaarfilter.cpp:223-228): "uvgx rate control v2" -- the picture-level
+    controller plus feedback inside the picture: a P picture's CTU rows are reconstructed in four groups and the QP of the next group is
+    decided ON THE DEVICE from the levels of the groups before (k_rc_band), travelling as cu_qp_delta.  Access units identical to the
+    checker's (rc_band_decide() in oracle/hevc_enc.c), picture for picture; the streams decode; the rate lands near the target."""
+    from kvazzup_amd.codec import Decoder, Encoder
+    frames = 24 if w >= 1920 else 48
+    clip = [orc.synth_frame(0, SEED, w, h, t) for t in range(frames)]
+    oe = orc.OracleEncoder(w, h, qp=32, period=16, me_range=8, bitrate=bitrate, rc_bands=4, **opts)
+    want = [oe.encode(f) for f in clip]
+    o = (("qp", 32), ("period", 16), ("me-range", 8), ("owf", owf), ("bitrate", bitrate), ("rc-algorithm", "lambda"), ("sao", "full" if opts.get("sao") else "off"),
+         ("subme", opts.get("subme", 0)), ("tiles", "1x%d" % opts.get("tile_rows", 1))) + ((("vaq", opts["vaq"]),) if opts.get("vaq") else ())
+    ge = Encoder(w, h, options=o, fields={"target_bitrate": bitrate})
+    assert not ge.rejected, ge.rejected
+    got = [ge.encode(f, want_recon=False)[0] for f in clip]
+    for _ in range(owf):
+        got.append(ge.encode(None, want_recon=False)[0])
+    got = got[owf:]
+    for t in range(frames):
+        assert got[t] == want[t], (t, len(got[t]), len(want[t]))
+    gd = Decoder()
+    for t, au in enumerate(got):
+        assert len(gd.decode_au(au, t)) == 1
+    kbps = sum(len(a) for a in got) * 8 * 30 / frames / 1000
+    assert 0.6 * bitrate / 1000 < kbps < 1.5 * bitrate / 1000, kbps
+    ge.close(); gd.close(); oe.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("bitrate,owf", [(200000, 0), (1000000, 2)])
 def test_rate_control_matches_the_checker_picture_for_picture(gpu, bitrate, owf):
     """video/bitrate != 0 (kvazaarfilter.cpp:223-228): picture-level rate control.  Its decisions depend on the sizes of

@@ -248,3 +248,26 @@ def test_subme_saves_bits_on_moving_content():
     b0, s0 = run(0)
     b4, s4 = run(4)
     assert b4 < b0 and s4 <= s0 * 1.02, (b0, b4, s0, s4)
+
+
+@pytest.mark.parametrize("bitrate,wpp,tile_rows", [(400000, 1, 1), (1500000, 0, 2)])
+def test_rate_control_v2_closed_loop(bitrate, wpp, tile_rows):
+    """rate control v2 (rc_bands): QP steps between the groups of CTU rows of a P picture travel as cu_qp_delta; the streams decode to the
+    encoder's reconstruction, the rate lands near the target, and P pictures scatter less around it than with the picture-level controller"""
+    w, h = 640, 384
+    def run(nb):
+        oe = orc.OracleEncoder(w, h, qp=32, period=32, me_range=16, wpp=wpp, tile_rows=tile_rows, bitrate=bitrate, rc_bands=nb)
+        od = orc.OracleDecoder()
+        sizes = []
+        for t in range(72):
+            au = oe.encode(orc.synth_frame(0, 7, w, h, t))
+            sizes.append(len(au))
+            got = od.decode_au(au, t)
+            assert len(got) == 1 and np.array_equal(got[0]["i420"], oe.recon()), t
+        oe.close(); od.close()
+        p = np.array([8 * s for i, s in enumerate(sizes) if i % 32 and i > 8], dtype=float)
+        return sum(sizes) * 8 * 30 / 72, p.std()
+    rate0, std0 = run(0)
+    rate4, std4 = run(4)
+    assert 0.7 * bitrate < rate4 < 1.35 * bitrate, (rate0, rate4)
+    assert std4 < std0 * 1.1, (std0, std4)

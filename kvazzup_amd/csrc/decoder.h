@@ -68,6 +68,14 @@ struct DecodedPicture {
   int poc = 0; int64_t pts = 0; uint32_t fps_num = 0, fps_den = 0; bool is_intra = false;
 };
 
+// a finished picture that owns its samples: what is still in the frame-threaded ring when the stream changes its resolution is
+// completed and kept like this until the following calls have handed it out (the decoder's own buffers are re-sized meanwhile)
+struct OwnedPic {
+  DecodedPicture pic;
+  std::vector<uint8_t> host;          // download mode: the three planes, pitches as in pic.host_pitch
+  uint8_t *dev = nullptr;             // device-resident mode: one allocation holding the three planes
+};
+
 // worker threads that parse whole pictures concurrently (frame threading)
 class FrameWorkers {
  public:
@@ -133,7 +141,7 @@ class Decoder {
   struct PicJob {
     std::vector<uint8_t> rbsp; size_t data_off = 0, data_len = 0;
     std::vector<size_t> sub_start;
-    SliceHdr sh; const DecSps *sps = nullptr; DecPps pps;        // (the PPS by value: a later PPS NAL may replace the table entry while this picture is still being parsed)
+    SliceHdr sh; std::shared_ptr<const DecSps> sps; DecPps pps;  // (a later SPS / PPS NAL may replace the table entry while this picture is still being parsed: the job keeps the SPS it was coded with alive, the PPS by value)
     int64_t pts = 0; int crop[4] = {0, 0, 0, 0}; uint32_t fps_num = 0, fps_den = 0;
     int slot = 0;                                                // picture buffer this picture is reconstructed into
     int nref = 0; int ref_poc[16]; uint8_t ref_slot[16];        // RefPicList0
@@ -179,9 +187,12 @@ class Decoder {
   hipEvent_t err_ev_ = nullptr; bool err_pending_ = false;    // the error word's download (complete_gpu)
   hipStream_t stream_up_ = nullptr; hipEvent_t up_done_[2] = {nullptr, nullptr};   // upload of the next picture's input block beside the current picture's kernels
   hipStream_t stream_ = nullptr, stream_dl_ = nullptr;       // reconstruction; download of finished pictures (behind the picture's event, beside the next picture's kernels)
-  DecSps sps_[16]; DecPps pps_[64]; uint32_t vps_fps_num_ = 0, vps_fps_den_ = 0;
+  std::shared_ptr<const DecSps> sps_[16]; DecPps pps_[64]; uint32_t vps_fps_num_ = 0, vps_fps_den_ = 0;
   int w_ = 0, h_ = 0, pw_ = 0, ph_ = 0;
   std::vector<PicJob> jobs_; int frame_threads_ = 1; long job_head_ = 0, job_tail_ = 0;
+  std::deque<OwnedPic> ready_q_; OwnedPic cur_owned_;       // pictures completed ahead of their turn (resolution change), the one last handed out
+  int decode_nal_inner(const uint8_t *data, size_t len, int64_t pts);
+  bool queue_current_output();
   std::unique_ptr<FrameWorkers> workers_;
   // decoded picture buffer: slot = device planes + what reference marking needs
   struct DpbPic { uint8_t *plane[3] = {nullptr, nullptr, nullptr}; int poc = 0; bool is_ref = false, used = false; long decode_idx = -1000; std::shared_ptr<ColMotion> motion; };

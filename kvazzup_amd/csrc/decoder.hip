@@ -777,6 +777,8 @@ Decoder::~Decoder()
   if (err_pending_ && hipEventSynchronize(err_ev_) == hipSuccess && *h_err_) fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x (last picture)\n", *h_err_);
   for (auto &j : jobs_) { for (auto &e : j.ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); } if (j.done) hipEventDestroy(j.done); }
   free_buffers();
+  for (auto &o : ready_q_) if (o.dev) hipFree(o.dev);
+  if (cur_owned_.dev) hipFree(cur_owned_.dev);
   if (stream_dl_) hipStreamDestroy(stream_dl_);
   if (stream_up_) hipStreamDestroy(stream_up_);
   for (auto &e : up_done_) if (e) hipEventDestroy(e);
@@ -850,7 +852,13 @@ bool Decoder::grow_job_input(PicJob &job, size_t bytes)
 bool Decoder::ensure_buffers(int w, int h)
 {
   if (w == w_ && h == h_) return true;
-  drop_pending();                                          // (resolution change: pictures not yet output are dropped)
+  // Resolution change (a new SPS took effect at this IRAP picture): what the ring still holds is completed now and queued -- the
+  // following calls hand it out one picture at a time, as a software decoder's bumping process would -- before the buffers go
+  while (w_ && (gpu_job_ || job_tail_ != job_head_)) {
+    const int rc = finish_oldest();
+    if (rc < 0 || (rc > 0 && pic_ready_ && !queue_current_output())) { drop_pending(); break; }
+  }
+  drop_pending();
   hipStreamSynchronize(stream_);
   free_buffers();
   if (jobs_.empty()) jobs_ = std::vector<PicJob>((size_t)frame_threads_ + 2);   // parse ring + two pictures in flight on the GPU (one running, one being handed out)
@@ -910,7 +918,56 @@ void Decoder::get_kernel_times(double *ms, uint64_t *launches, bool reset)
 }
 
 // ------------------------------------------------------------------------------------------ NAL units
+// One picture out per call at most (the libOpenHevcDecode contract).  Pictures that were completed ahead of their turn -- the ring's
+// contents at a resolution change -- are handed out first, one per call, in order; a picture this call itself completes meanwhile joins
+// the end of that queue.
 int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
+{
+  const int rc = decode_nal_inner(data, len, pts);
+  if (ready_q_.empty()) return rc;
+  if (rc < 0) return rc;
+  if (pic_ready_ && !queue_current_output()) return last_error_ = DEC_ERR_GPU;
+  if (cur_owned_.dev) { hipFree(cur_owned_.dev); cur_owned_.dev = nullptr; }
+  cur_owned_ = std::move(ready_q_.front());
+  ready_q_.pop_front();
+  out_ = cur_owned_.pic;
+  size_t off = 0;
+  for (int c = 0; c < 3; c++) {
+    const int h = c ? out_.height / 2 : out_.height;
+    if (!cur_owned_.host.empty()) { out_.host[c] = cur_owned_.host.data() + off; off += (size_t)out_.host_pitch[c] * h; }
+  }
+  pic_ready_ = true;
+  return 1;
+}
+
+// the picture complete_gpu() just made the output, copied into storage of its own at the end of the queue
+bool Decoder::queue_current_output()
+{
+  OwnedPic o;
+  o.pic = out_;
+  if (download_) {
+    size_t total = 0;
+    for (int c = 0; c < 3; c++) total += (size_t)out_.host_pitch[c] * (c ? out_.height / 2 : out_.height);
+    o.host.assign(out_.host[0], out_.host[0] + total);            // (the three planes lie back to back in the download buffer)
+  }
+  {
+    // the device view: a dense copy (pitch = width), so that device-resident consumers keep working across the re-allocation
+    const size_t ny = (size_t)out_.width * out_.height;
+    if (hipMalloc(&o.dev, ny * 3 / 2) != hipSuccess) return false;
+    size_t off = 0;
+    for (int c = 0; c < 3; c++) {
+      const int w = c ? out_.width / 2 : out_.width, h = c ? out_.height / 2 : out_.height;
+      if (hipMemcpy2D(o.dev + off, (size_t)w, out_.dev[c], (size_t)out_.dev_pitch[c], (size_t)w, (size_t)h, hipMemcpyDeviceToDevice) != hipSuccess) { hipFree(o.dev); return false; }
+      o.pic.dev[c] = o.dev + off; o.pic.dev_pitch[c] = w;
+      off += (size_t)w * h;
+    }
+  }
+  ready_q_.push_back(std::move(o));
+  pic_ready_ = false;
+  return true;
+}
+
+int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
 {
   Tick tk_nal;
   struct Acc { double &d; Tick &t; double &w, &s, &a, &y; double w0, s0, a0, y0; ~Acc() { d += t.ms() - ((w - w0) + (s - s0) + (a - a0) + (y - y0)); } } acc_{t_nal_, tk_nal, t_wait_, t_stage_, t_api_, t_sync_, t_wait_, t_stage_, t_api_, t_sync_};
@@ -981,7 +1038,7 @@ int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
     // sizes: multiples of the minimum coding block; the upper bound is the encoder's (and keeps every index inside 32 bits)
     if ((s.width & 7) || (s.height & 7) || s.width < 16 || s.height < 16 || s.width > 16384 || s.height > 16384) return last_error_ = DEC_ERR_UNSUPPORTED;
     if (s.crop_l + s.crop_r >= s.width || s.crop_t + s.crop_b >= s.height) return last_error_ = DEC_ERR_INVALID;
-    s.valid = true; sps_[id] = s;
+    s.valid = true; sps_[id] = std::make_shared<const DecSps>(s);      // (a new object: pictures still being parsed keep the one they were coded with)
     return 0;
   }
   if (nal_type == 34) {                                          // PPS (7.3.2.3)
@@ -1036,8 +1093,8 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   if (!r.get(1)) return DEC_ERR_UNSUPPORTED;                     // one slice per picture (the filter takes one picture per VCL NAL unit, openhevcfilter.cpp:149-152)
   if (irap) r.get(1);
   const int pps_id = r.ue();
-  if (pps_id > 63 || !pps_[pps_id].valid || !sps_[pps_[pps_id].sps_id].valid) return DEC_ERR_INVALID;
-  const DecPps &p = pps_[pps_id]; const DecSps &s = sps_[p.sps_id];
+  if (pps_id > 63 || !pps_[pps_id].valid || !sps_[pps_[pps_id].sps_id] || !sps_[pps_[pps_id].sps_id]->valid) return DEC_ERR_INVALID;
+  const DecPps &p = pps_[pps_id]; const std::shared_ptr<const DecSps> sps_ref = sps_[p.sps_id]; const DecSps &s = *sps_ref;
   for (int k = 0; k < p.extra_header_bits; k++) r.get(1);
   const int slice_type = r.ue();
   if (slice_type != 1 && slice_type != 2) return r.err ? DEC_ERR_INVALID : DEC_ERR_UNSUPPORTED;      // B slices
@@ -1153,7 +1210,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   job.rbsp.assign(rbsp, rbsp + len);
   job.data_off = r.pos >> 3; job.data_len = len - (r.pos >> 3);
   job.sub_start = sub_start_;
-  job.sh = sh; job.sps = &s; job.pps = pp; job.pts = pts;
+  job.sh = sh; job.sps = sps_ref; job.pps = pp; job.pts = pts;
   job.crop[0] = s.crop_l; job.crop[1] = s.crop_r; job.crop[2] = s.crop_t; job.crop[3] = s.crop_b;
   job.fps_num = s.fps_num ? s.fps_num : vps_fps_num_; job.fps_den = s.fps_num ? s.fps_den : vps_fps_den_;
   job.slot = slot; job.nref = nref;

@@ -33,6 +33,36 @@ def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, tile_ro
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("threads,frame", [(1, False), (4, True)])
+def test_decoder_follows_a_resolution_change(gpu, threads, frame):
+    """a sender that changes its resolution mid-call (uvgComm re-opens Kvazaar: new VPS / SPS / PPS and an IDR picture): the decoder
+    re-sizes its buffers at the new SPS -- pictures of the old size still in the frame-threaded ring are output first -- and the
+    reported size follows; then back to the first size"""
+    from kvazzup_amd.codec import Decoder, Encoder
+    gd = Decoder(threads=threads, frame_threads=frame)
+    want, got = [], []
+    t = 0
+    for (w, h) in ((320, 192), (640, 384), (320, 192), (200, 120)):
+        ge = Encoder(w, h, options=(("qp", 30), ("period", 64), ("me-range", 8)))
+        for k in range(5):
+            au, rec = ge.encode(orc.synth_frame(0, SEED + w, w, h, k))
+            want.append((w, h, rec))
+            got += gd.decode_au(au, t)
+            t += 1
+        ge.close()
+    eos = bytes([0, 0, 0, 1, 36 << 1, 1])
+    for _ in range(threads if frame else 0):                       # end-of-sequence NAL units drain the frame-threaded ring
+        o = gd.decode_nal(eos)
+        if o is not None:
+            got.append(o)
+    assert len(got) == len(want), (len(got), len(want))
+    for i, (g, (w, h, rec)) in enumerate(zip(got, want)):
+        assert (g["width"], g["height"]) == (w, h), (i, g["width"], g["height"], w, h)
+        assert np.array_equal(g["i420"], rec), i
+    gd.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [
     dict(w=128, h=64, frames=2, qp=32, period=1, me_range=8, kind=0),
     dict(w=256, h=192, frames=5, qp=32, period=64, me_range=16, kind=0),

@@ -101,8 +101,13 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
   if (n == "tiles") {
     int a = 0, b = 0;
     if (sscanf(value, "%dx%d", &a, &b) != 2 || a < 1 || b < 1) return 0;
+    // Tile ROWS (1xN, uniform spacing) are implemented, tile columns are not.  A grid with columns -- uvgComm's tile dimension
+    // defaults are "2x2" .. "16x16" (src/ui/settings/defaultsettings.cpp:283-324) -- is coded as the same NUMBER of tiles, all of
+    // them full-width rows (capped at one tile per CTU row in encoder_open): a valid stream with the parallelism and the
+    // resynchronisation points asked for, instead of no stream.
+    if (a > 1) { fprintf(stderr, "kvazzup_amd: tiles=%dx%d: tile columns are not implemented, coding %d full-width tile rows instead\n", a, b, a * b); b = a * b; a = 1; }
     cfg->tiles_width_count = a; cfg->tiles_height_count = b;
-    return a == 1 ? 1 : 0;                        // tile ROWS (1xN, uniform spacing) are implemented, tile columns are not
+    return 1;
   }
   if (n == "slices") {
     if (!strcmp(value, "wpp")) { cfg->slices = KVZ_SLICES_WPP; return 1; }
@@ -252,6 +257,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.me_range = cfg->me_range; ec.fps_num = cfg->framerate_num; ec.fps_den = cfg->framerate_denom;
   ec.wpp = cfg->wpp ? 1 : 0; ec.deblock = cfg->deblock_enable ? 1 : 0; ec.device = cfg->gpu_device; ec.owf = cfg->owf > 8 ? 8 : cfg->owf;
   ec.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1;
+  if (ec.tile_rows > (cfg->height + 63) / 64) ec.tile_rows = (cfg->height + 63) / 64;          // at most one tile per CTU row
   ec.band_row0 = cfg->band_row0; ec.band_rows = cfg->band_rows;
   // "threads" (uvgComm video/kvzThreads: auto = core count, Main = 0): what is threaded on the host here is the arithmetic coder
   ec.entropy_threads = cfg->threads < 0 ? 16 : (cfg->threads == 0 ? 1 : (cfg->threads > 16 ? 16 : cfg->threads));

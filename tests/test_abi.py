@@ -56,7 +56,7 @@ def test_kvz_api_table_and_config_parsing(lib):
     assert ok("sao", "off") == 1 and cfg.contents.sao_type == 0           # ... unless a later option says otherwise
     assert ok("preset", "ultrafast") == 1 and cfg.contents.sao_type == 0
     # rejected: unknown names and values outside the implemented tool set (kvazaarfilter.cpp:363-367 logs these)
-    for k, v in (("no-such-option", "1"), ("qp", "99"), ("input-res", "axb"), ("tiles", "2x2"), ("scaling-list", "default"), ("gop", "8"), ("preset", "warp9"), ("sao", "edge")):
+    for k, v in (("no-such-option", "1"), ("qp", "99"), ("input-res", "axb"), ("tiles", "0x2"), ("scaling-list", "default"), ("gop", "8"), ("preset", "warp9"), ("sao", "edge")):
         assert ok(k, v) == 0, (k, v)
     c.target_bitrate = 0
     c.mv_constraint = 4

@@ -107,6 +107,23 @@ def test_subme_matches_oracle(gpu, cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dims,rows", [("2x2", 4), ("4x4", 5)])
+def test_tile_grid_with_columns_is_coded_as_tile_rows(gpu, dims, rows):
+    """uvgComm's video/tileDimensions defaults ("2x2" .. "16x16") have tile columns, which are not implemented: the same number of
+    tiles is coded as full-width rows (at most one per CTU row: 320 rows of luma = 5 CTU rows) -- the checker's stream for that tiling"""
+    from kvazzup_amd.codec import Encoder
+    w, h = 448, 320
+    oe = orc.OracleEncoder(w, h, qp=30, period=4, me_range=8, tile_rows=rows)
+    ge = Encoder(w, h, options=(("qp", 30), ("period", 4), ("me-range", 8), ("tiles", dims)))
+    assert not ge.rejected, ge.rejected
+    for t in range(5):
+        frame = orc.synth_frame(0, SEED, w, h, t)
+        au, rec = ge.encode(frame)
+        assert au == oe.encode(frame) and np.array_equal(rec, oe.recon()), t
+    ge.close(); oe.close()
+
+
+@pytest.mark.gpu
 def test_gpu_arithmetic_coder_pipelined(gpu):
     """gpu-entropy=1 with owf 6: six pictures in flight, every slot's coder on its own stream; output lags six pictures."""
     from kvazzup_amd.codec import Encoder

@@ -52,6 +52,7 @@ struct DecPps {
   bool valid = false;
   int sps_id = 0;
   int sign_hiding = 0, cabac_init_present = 0, num_ref_idx_default = 1, init_qp = 26, tskip = 0;
+  int dependent_slices = 0;
   int cu_qp_delta = 0, qp_delta_depth = 0, cb_qp_offset = 0, cr_qp_offset = 0, slice_chroma_offsets = 0;
   int output_flag_present = 0, extra_header_bits = 0, header_extension = 0;
   int wpp = 0, tile_rows = 1, row_bd[34];   // tile row i covers CTB rows [row_bd[i], row_bd[i + 1]); filled at slice time when uniform
@@ -141,6 +142,9 @@ class Decoder {
   struct PicJob {
     std::vector<uint8_t> rbsp; size_t data_off = 0, data_len = 0;
     std::vector<size_t> sub_start;
+    // slice segments (a picture in several NAL units): whether a segment ends with this CTU row (always for the last row); where, inside a
+    // substream that spans several rows (no WPP), a new segment's data starts at this row (SIZE_MAX: the row continues the stream)
+    std::vector<uint8_t> seg_end_row; std::vector<size_t> row_restart;
     SliceHdr sh; std::shared_ptr<const DecSps> sps; DecPps pps;  // (a later SPS / PPS NAL may replace the table entry while this picture is still being parsed: the job keeps the SPS it was coded with alive, the PPS by value)
     int64_t pts = 0; int crop[4] = {0, 0, 0, 0}; uint32_t fps_num = 0, fps_den = 0;
     int slot = 0;                                                // picture buffer this picture is reconstructed into
@@ -153,7 +157,7 @@ class Decoder {
     std::vector<uint8_t> pred_mode, ct_depth, intra_mode;
     std::vector<SubOut> subs; std::vector<uint8_t> wpp_saved;
     std::unique_ptr<Progress[]> row_progress; int row_progress_n = 0;
-    bool any_intra = false, any_inter = false;
+    bool any_intra = false, any_inter = false, across_slices = true;
     std::atomic<int> state{0}; int rc = 0; double parse_ms = 0;
     hipEvent_t done = nullptr;                                   // recorded behind the picture's last kernel
     struct EvPair { hipEvent_t a, b; int id; }; std::vector<EvPair> ev; size_t ev_used = 0;     // kernel timing (set_profiling)
@@ -190,6 +194,10 @@ class Decoder {
   std::shared_ptr<const DecSps> sps_[16]; DecPps pps_[64]; uint32_t vps_fps_num_ = 0, vps_fps_den_ = 0;
   int w_ = 0, h_ = 0, pw_ = 0, ph_ = 0;
   std::vector<PicJob> jobs_; int frame_threads_ = 1; long job_head_ = 0, job_tail_ = 0;
+  // a picture arriving in several slice segment NAL units: its job is filled segment by segment and submitted with the last one
+  bool asm_active_ = false; int asm_rows_ = 0, asm_pps_id_ = 0, asm_nal_type_ = 0; bool asm_irap_ = false;
+  int submit_job(PicJob &job, int nal_type, bool irap);
+  int append_segment(PicJob &job, size_t bitpos, const uint8_t *rbsp, size_t len, const DecPps &p, const DecPps &pp, int wc, int hc, int address, int64_t pts);
   std::deque<OwnedPic> ready_q_; OwnedPic cur_owned_;       // pictures completed ahead of their turn (resolution change), the one last handed out
   int decode_nal_inner(const uint8_t *data, size_t len, int64_t pts);
   bool queue_current_output();

@@ -1055,7 +1055,8 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     int wp = r.get(1), wbp = r.get(1), tqb = r.get(1), tiles = r.get(1);
     p.wpp = r.get(1);
     if (r.err || p.num_ref_idx_default > 15 || p.cb_qp_offset < -12 || p.cb_qp_offset > 12 || p.cr_qp_offset < -12 || p.cr_qp_offset > 12) return last_error_ = DEC_ERR_INVALID;
-    if (dep || cip || wp || wbp || tqb) return last_error_ = DEC_ERR_UNSUPPORTED;   // dependent slices, constrained intra, weighted prediction, lossless
+    p.dependent_slices = dep;
+    if (cip || wp || wbp || tqb) return last_error_ = DEC_ERR_UNSUPPORTED;   // constrained intra, weighted prediction, lossless
     if (tiles) {                                                 // supported: one column; loop filter across tiles on
       const int cols = r.ue() + 1, rows = r.ue() + 1; p.uniform_tiles = r.get(1);
       if (cols != 1 || rows > 32) return last_error_ = DEC_ERR_UNSUPPORTED;
@@ -1090,11 +1091,29 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
 {
   BitReader r(rbsp, len);
   const bool idr = nal_type == 19 || nal_type == 20, irap = nal_type >= 16 && nal_type <= 23;
-  if (!r.get(1)) return DEC_ERR_UNSUPPORTED;                     // one slice per picture (the filter takes one picture per VCL NAL unit, openhevcfilter.cpp:149-152)
+  // A picture may come in several slice segments, one NAL unit each -- the two ways a Kvazaar peer cuts them (uvgComm video/Slices,
+  // kvazaarfilter.cpp:205-215): a DEPENDENT slice segment per CTU row ("slices=wpp"), an independent slice per tile ("slices=tiles").
+  // Supported: segments that arrive in order and consist of whole CTU rows (WPP) or whole tiles; independent slices repeat the first
+  // one's header (the picture keeps one set of slice parameters).  The job is filled segment by segment and submitted with the last.
+  const bool first_seg = r.get(1) != 0;
   if (irap) r.get(1);
   const int pps_id = r.ue();
   if (pps_id > 63 || !pps_[pps_id].valid || !sps_[pps_[pps_id].sps_id] || !sps_[pps_[pps_id].sps_id]->valid) return DEC_ERR_INVALID;
   const DecPps &p = pps_[pps_id]; const std::shared_ptr<const DecSps> sps_ref = sps_[p.sps_id]; const DecSps &s = *sps_ref;
+  bool dependent = false; int seg_address = 0;
+  if (!first_seg) {
+    const int nctb = ((s.width + 63) / 64) * ((s.height + 63) / 64);
+    int bits = 0; while ((1 << bits) < nctb) bits++;
+    if (p.dependent_slices) dependent = r.get(1) != 0;
+    seg_address = r.get(bits);
+    if (!asm_active_ || pps_id != asm_pps_id_ || nal_type != asm_nal_type_) return DEC_ERR_INVALID;      // a segment without its picture's first one (lost), or of another picture
+  } else if (asm_active_) asm_active_ = false;                   // the previous picture never got its last segment: it is dropped
+  PicJob *const open_job = first_seg ? nullptr : &jobs_[(size_t)(job_head_ % jobs_.size())];
+  if (dependent) {
+    // 7.3.6.1: everything but the address and the entry points is taken over from the slice's first segment
+    const int wc = (s.width + 63) / 64, hc = (s.height + 63) / 64;
+    return append_segment(*open_job, r.pos, rbsp, len, p, open_job->pps, wc, hc, seg_address, pts);
+  }
   for (int k = 0; k < p.extra_header_bits; k++) r.get(1);
   const int slice_type = r.ue();
   if (slice_type != 1 && slice_type != 2) return r.err ? DEC_ERR_INVALID : DEC_ERR_UNSUPPORTED;      // B slices
@@ -1140,7 +1159,8 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     if (!sh.deblock_disabled) { sh.beta_offset_div2 = r.se(); sh.tc_offset_div2 = r.se(); }
     if (sh.beta_offset_div2 < -6 || sh.beta_offset_div2 > 6 || sh.tc_offset_div2 < -6 || sh.tc_offset_div2 > 6) return DEC_ERR_INVALID;
   }
-  if (p.loop_filter_across_slices && (!sh.deblock_disabled || sh.sao_luma || sh.sao_chroma)) r.get(1);
+  bool across_slices = p.loop_filter_across_slices != 0;
+  if (p.loop_filter_across_slices && (!sh.deblock_disabled || sh.sao_luma || sh.sao_chroma)) across_slices = r.get(1) != 0;
   const int wc = (s.width + 63) / 64, hc = (s.height + 63) / 64;
   if (p.tile_rows > hc) return DEC_ERR_INVALID;
   DecPps pp = p;                                                 // tile row boundaries (6.5.1) for this picture size
@@ -1151,32 +1171,14 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     pp.row_bd[k + 1] = pp.row_bd[k] + hgt;
   }
   if (pp.row_bd[p.tile_rows] != hc) return DEC_ERR_INVALID;
-  std::vector<uint32_t> entry;
-  const int nsub = p.wpp ? hc : p.tile_rows;
-  if (p.wpp || p.tile_rows > 1) {
-    const int nep = r.ue();
-    if (nep < 0 || nep > 1024) return DEC_ERR_INVALID;
-    if (nep > 0) { int bits = r.ue() + 1; if (bits > 32) return DEC_ERR_INVALID; for (int k = 0; k < nep; k++) entry.push_back(r.get(bits) + 1); }
-    if (nep != nsub - 1) return DEC_ERR_UNSUPPORTED;             // one substream per CTU row (WPP) or per tile
-  }
-  if (p.header_extension) { const int n = r.ue(); if (n > 256) return DEC_ERR_INVALID; for (int k = 0; k < n; k++) r.get(8); }
-  if (!r.get(1)) return DEC_ERR_INVALID;                         // byte_alignment()
-  while (r.pos & 7) r.get(1);
-  if (r.err) return DEC_ERR_INVALID;
-  // Substream starts inside the unescaped slice data.  entry_point offsets count bytes of the NAL
-  // unit payload INCLUDING emulation prevention bytes (7.4.7.1); epb_[] holds, for every removed
-  // byte, how many unescaped payload bytes preceded it.
-  {
-    const size_t hdr = r.pos >> 3;
-    sub_start_.assign(1, 0);
-    size_t esc = hdr;                                            // escaped offset of the slice data in the payload
-    for (size_t k = 0; k < epb_.size(); k++) if (epb_[k] < hdr) esc++;
-    for (uint32_t e : entry) {
-      esc += e;
-      size_t removed = 0;
-      for (size_t k = 0; k < epb_.size(); k++) if (epb_[k] + k < esc) removed++;     // epb k sits at escaped offset epb_[k] + k
-      sub_start_.push_back(esc - removed - hdr);
-    }
+  if (!first_seg) {
+    // an independent slice of a picture under way: the same slice parameters as the first (what this decoder keeps per picture)
+    const SliceHdr &a = open_job->sh;
+    if (sh.is_intra != a.is_intra || sh.poc != a.poc || sh.tmvp != a.tmvp || sh.collocated_ref_idx != a.collocated_ref_idx || sh.sao_luma != a.sao_luma ||
+        sh.sao_chroma != a.sao_chroma || sh.num_ref_idx != a.num_ref_idx || sh.cabac_init_flag != a.cabac_init_flag || sh.max_merge != a.max_merge ||
+        sh.slice_qp != a.slice_qp || sh.cb_qp_offset != a.cb_qp_offset || sh.cr_qp_offset != a.cr_qp_offset || sh.deblock_disabled != a.deblock_disabled ||
+        sh.beta_offset_div2 != a.beta_offset_div2 || sh.tc_offset_div2 != a.tc_offset_div2 || !across_slices) return DEC_ERR_UNSUPPORTED;
+    return append_segment(*open_job, r.pos, rbsp, len, p, pp, wc, hc, seg_address, pts);
   }
   if (!sh.is_intra && !seen_irap_) return DEC_ERR_INVALID;       // nothing to predict from before the first random access point
   if (!ensure_buffers(s.width, s.height)) return DEC_ERR_GPU;
@@ -1207,9 +1209,9 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   // like OpenHEVC's frame threading; temporal motion prediction makes a picture's parser follow the collocated
   // picture's parser row by row (ColMotion::row_done).
   PicJob &job = jobs_[(size_t)(job_head_ % jobs_.size())];
-  job.rbsp.assign(rbsp, rbsp + len);
-  job.data_off = r.pos >> 3; job.data_len = len - (r.pos >> 3);
-  job.sub_start = sub_start_;
+  job.rbsp.clear(); job.data_off = 0; job.data_len = 0; job.sub_start.clear();
+  job.seg_end_row.assign((size_t)hc, 0); job.row_restart.assign((size_t)hc, SIZE_MAX);
+  job.across_slices = across_slices;
   job.sh = sh; job.sps = sps_ref; job.pps = pp; job.pts = pts;
   job.crop[0] = s.crop_l; job.crop[1] = s.crop_r; job.crop[2] = s.crop_t; job.crop[3] = s.crop_b;
   job.fps_num = s.fps_num ? s.fps_num : vps_fps_num_; job.fps_den = s.fps_num ? s.fps_den : vps_fps_den_;
@@ -1227,7 +1229,79 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   }
   for (int cy = 0, t = 0; cy < hc; cy++) { while (cy >= pp.row_bd[t + 1]) t++; memset(job.ctu_tile + (size_t)cy * wc, t, (size_t)wc); }
   job.rc = 0; job.any_intra = job.any_inter = false;
-  DpbPic &d = dpb_[slot];
+  asm_active_ = true; asm_rows_ = 0; asm_pps_id_ = pps_id; asm_nal_type_ = nal_type; asm_irap_ = irap;
+  return append_segment(job, r.pos, rbsp, len, p, pp, wc, hc, 0, pts);
+}
+
+// The slice data of one segment joins the picture's job: entry points (the segment's substreams: whole CTU rows with WPP, else whole
+// tiles -- or, for a dependent segment without either, one run of CTU rows inside the current substream), then the bytes.  The last
+// segment submits the job.  `r` stands behind the part of the slice segment header that precedes the entry points.
+int Decoder::append_segment(PicJob &job, size_t bitpos, const uint8_t *rbsp, size_t len, const DecPps &p, const DecPps &pp, int wc, int hc, int address, int64_t pts)
+{
+  (void)pts;
+  BitReader r(rbsp, len); r.pos = bitpos;
+  auto fail = [&](int rc) { asm_active_ = false; return rc; };
+  if (address != asm_rows_ * wc) return fail(address % wc ? DEC_ERR_UNSUPPORTED : DEC_ERR_INVALID);     // whole CTU rows, in order
+  std::vector<uint32_t> entry;
+  if (p.wpp || p.tile_rows > 1) {
+    const int nep = r.ue();
+    if (nep < 0 || nep > 1024) return fail(DEC_ERR_INVALID);
+    if (nep > 0) { int bits = r.ue() + 1; if (bits > 32) return fail(DEC_ERR_INVALID); for (int k = 0; k < nep; k++) entry.push_back(r.get(bits) + 1); }
+  }
+  if (p.header_extension) { const int n = r.ue(); if (n > 256) return fail(DEC_ERR_INVALID); for (int k = 0; k < n; k++) r.get(8); }
+  if (!r.get(1)) return fail(DEC_ERR_INVALID);                   // byte_alignment()
+  while (r.pos & 7) r.get(1);
+  if (r.err) return fail(DEC_ERR_INVALID);
+  // CTU rows the segment covers
+  const int nss = (int)entry.size() + 1, row0 = asm_rows_;
+  int rows = 0;
+  bool mid_substream = false;                                    // no WPP, and the segment does not start a tile: it continues the tile's substream
+  if (p.wpp) rows = nss;
+  else {
+    int t = 0; while (t < pp.tile_rows && pp.row_bd[t] != row0) t++;
+    if (t < pp.tile_rows) { if (t + nss > pp.tile_rows) return fail(DEC_ERR_INVALID); rows = pp.row_bd[t + nss] - row0; }
+    else {
+      // inside a tile: only a dependent segment can start here; how many rows it holds is not in its header -- one (the form the
+      // synthesiser writes); a longer one fails at its first end_of_slice_segment_flag
+      if (nss != 1) return fail(DEC_ERR_UNSUPPORTED);
+      rows = 1; mid_substream = true;
+    }
+    if (!mid_substream && nss == 1 && pp.tile_rows == 1 && row0 == 0) {
+      // one tile, no WPP: the first segment's length is unknown as well: the whole picture unless dependent segments follow
+      rows = p.dependent_slices ? 1 : hc;
+    } else if (!mid_substream && nss == 1 && p.dependent_slices) rows = 1;      // a tile begun by one row; the rest follows as dependent segments
+  }
+  if (rows < 1 || row0 + rows > hc) return fail(DEC_ERR_INVALID);
+  // Substream starts inside the unescaped slice data.  entry_point offsets count bytes of the NAL
+  // unit payload INCLUDING emulation prevention bytes (7.4.7.1); epb_[] holds, for every removed
+  // byte, how many unescaped payload bytes preceded it.
+  const size_t hdr = r.pos >> 3, base = job.rbsp.size();
+  if (hdr > len) return fail(DEC_ERR_INVALID);
+  if (mid_substream) job.row_restart[(size_t)row0] = base;
+  else job.sub_start.push_back(base);
+  {
+    size_t esc = hdr;                                            // escaped offset of the slice data in the payload
+    for (size_t k = 0; k < epb_.size(); k++) if (epb_[k] < hdr) esc++;
+    for (uint32_t e : entry) {
+      esc += e;
+      size_t removed = 0;
+      for (size_t k = 0; k < epb_.size(); k++) if (epb_[k] + k < esc) removed++;     // epb k sits at escaped offset epb_[k] + k
+      job.sub_start.push_back(base + esc - removed - hdr);
+    }
+  }
+  job.rbsp.insert(job.rbsp.end(), rbsp + hdr, rbsp + len);
+  job.data_off = 0; job.data_len = job.rbsp.size();
+  asm_rows_ = row0 + rows;
+  job.seg_end_row[(size_t)(asm_rows_ - 1)] = 1;
+  if (asm_rows_ < hc) return 0;                                  // more segments to come: no output for this NAL unit
+  asm_active_ = false;
+  return submit_job(job, asm_nal_type_, asm_irap_);
+}
+
+int Decoder::submit_job(PicJob &job, int nal_type, bool irap)
+{
+  const SliceHdr &sh = job.sh;
+  DpbPic &d = dpb_[job.slot];
   d.poc = sh.poc; d.is_ref = true; d.used = true; d.decode_idx = job_head_; d.motion = job.own;
   if (cur_tid_ == 0 && (nal_type > 9 || ((nal_type & 1) && nal_type < 6))) prev_poc_ = sh.poc;   // prevTid0Pic (8.3.1): TemporalId 0, not RASL / RADL / sub-layer non-reference
   if (irap) seen_irap_ = true;
@@ -1379,6 +1453,12 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
   for (int t = 0; t < pps.tile_rows; t++) if (first_cy >= pps.row_bd[t]) { sp.tile_y0 = pps.row_bd[t] * 64; sp.tile_y1 = pps.row_bd[t + 1] * 64; }
   ColMotion *own = job.own.get();
   for (int cy = first_cy; cy < first_cy + ncy; cy++) {
+    if (cy > first_cy && job.row_restart[(size_t)cy] != SIZE_MAX) {
+      // a dependent slice segment begins inside this substream: new arithmetic codeword, the contexts go on (9.3.1)
+      const uint8_t *q = job.rbsp.data() + job.data_off + job.row_restart[(size_t)cy];
+      if (q < data || q >= data + len) return DEC_ERR_INVALID;
+      c.start(q, (size_t)(data + len - q));
+    }
     for (int cx = 0; cx < wc; cx++) {
       if (!wait_above(cy, cx + 2)) return DEC_ERR_INVALID;
       const int ctu = cy * wc + cx;
@@ -1398,10 +1478,12 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
       if (out.tus.size() - tu0 >= (1u << 24)) return DEC_ERR_INVALID;
       if (wpp && cx == 1) c.save_ctx(&job.wpp_saved[(size_t)cy * CTX_COUNT]);
       if (wpp) job.row_progress[(size_t)cy].v.store(cx + 1, std::memory_order_release);
-      const bool last = (cy == hc - 1 && cx == wc - 1);
+      // end_of_slice_segment_flag: 1 exactly where the picture's slice segments end (decode_slice noted the rows; one segment: the
+      // last CTU of the picture); inside a segment a substream ends with end_of_subset_one_bit
+      const bool seg_last = cx == wc - 1 && job.seg_end_row[(size_t)cy];
       const int end = c.terminate();
-      if (end != (last ? 1 : 0)) return DEC_ERR_UNSUPPORTED;      // the slice must cover the whole picture
-      if (!last && cx == wc - 1 && (wpp || tile_ends_at(cy)) && !c.terminate()) return DEC_ERR_INVALID;   // end_of_subset_one_bit
+      if (end != (seg_last ? 1 : 0)) return seg_last ? DEC_ERR_INVALID : DEC_ERR_UNSUPPORTED;      // (a segment that ends elsewhere: not whole CTU rows)
+      if (!seg_last && cx == wc - 1 && (wpp || tile_ends_at(cy)) && !c.terminate()) return DEC_ERR_INVALID;   // end_of_subset_one_bit
     }
     // this CTB row's motion as later pictures see it (one entry per 16x16 block)
     if (!own) continue;

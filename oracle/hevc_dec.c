@@ -38,6 +38,8 @@ struct orc_decoder {
   /* tile / slice maps for the current picture */
   orc_sao_params *sao; int sao_used; pixel *sao_in[3];
   int32_t *ctb_slice; int16_t *ctb_tile; int *ts_to_rs, *rs_to_ts; int *tile_first_x; size_t ctb_cap;
+  int slice_addr_rs;                      /* SliceAddrRs: address of the slice (= its first, independent segment) being decoded */
+  orc_ctx ds_ctx[CTX_COUNT];              /* TableStateIdxDs: contexts at the end of the previous slice segment (9.3.2.2) */
   int col_bd[34], row_bd[34];
   /* slice decoding state */
   orc_cabac_dec cabac; orc_ctx wpp_ctx[CTX_COUNT];
@@ -762,7 +764,8 @@ static int decode_slice_data(orc_decoder *d, const uint8_t *data, size_t len)
   int init_type = sh->slice_type == SLICE_I ? 0 : (sh->slice_type == SLICE_P ? (sh->cabac_init_flag ? 2 : 1) : (sh->cabac_init_flag ? 1 : 2));
   size_t pos = 0;
   int ts = d->rs_to_ts[sh->slice_segment_address];
-  int slice_addr = sh->slice_segment_address;
+  if (!sh->dependent_slice_segment) d->slice_addr_rs = sh->slice_segment_address;
+  int slice_addr = d->slice_addr_rs;
   int first = 1;
   memset(&d->av, 0, sizeof(d->av));
   d->av.pic_w = s->width; d->av.pic_h = s->height; d->av.ctb_log2 = s->ctb_log2; d->av.pic_w_ctbs = wc;
@@ -775,9 +778,11 @@ static int decode_slice_data(orc_decoder *d, const uint8_t *data, size_t len)
     int row_start = (cx == d->tile_first_x[rs]);
     d->ctb_slice[rs] = slice_addr;
     int new_qg_row = 0;
-    if (first || first_in_tile) {
+    if ((first && !sh->dependent_slice_segment) || first_in_tile) {
       orc_cabac_init_contexts(d->cabac.ctx, init_type, sh->slice_qp);
       new_qg_row = 1;
+    } else if (first && sh->dependent_slice_segment && !(p->entropy_coding_sync_enabled && row_start)) {
+      memcpy(d->cabac.ctx, d->ds_ctx, sizeof(d->ds_ctx));        /* 9.3.1: a dependent slice segment goes on where the previous segment stopped */
     } else if (p->entropy_coding_sync_enabled && row_start) {
       int xt = ((cx + 1) << s->ctb_log2), yt = ((cy - 1) << s->ctb_log2);
       if (orc_available(&d->av, cx << s->ctb_log2, cy << s->ctb_log2, xt, yt)) memcpy(d->cabac.ctx, d->wpp_ctx, sizeof(d->wpp_ctx));
@@ -802,7 +807,7 @@ static int decode_slice_data(orc_decoder *d, const uint8_t *data, size_t len)
       memcpy(d->wpp_ctx, d->cabac.ctx, sizeof(d->wpp_ctx));
     int end_of_slice = orc_cdec_terminate(&d->cabac);
     ts++;
-    if (end_of_slice) break;
+    if (end_of_slice) { memcpy(d->ds_ctx, d->cabac.ctx, sizeof(d->ds_ctx)); break; }
     if (ts >= total) return ERR_INVALID;
     int nrs = d->ts_to_rs[ts];
     int tile_change = d->ctb_tile[nrs] != d->ctb_tile[rs];

@@ -122,6 +122,8 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   p->cu_qp_delta_enabled = c->qp_delta > 0; p->diff_cu_qp_delta_depth = c->qp_delta > 0 ? c->qp_delta - 1 : 0;
   if (c->chroma_qp_offsets) { p->cb_qp_offset = rrange(g, -4, 4); p->cr_qp_offset = rrange(g, -4, 4); p->slice_chroma_qp_offsets_present = rpct(g, 50); }
   p->entropy_coding_sync_enabled = c->wpp; p->loop_filter_across_slices = 1;
+  if (c->slices < 0 || c->slices > 2) c->slices = 0;
+  p->dependent_slice_segments_enabled = c->slices == 1;
   p->num_tile_columns = 1; p->num_tile_rows = 1; p->uniform_spacing = 1;
   p->deblocking_filter_control_present = c->deblock_mode != 0;
   p->pps_deblocking_disabled = c->deblock_mode == 1;
@@ -619,10 +621,12 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
   }
   sh->loop_filter_across_slices = 1;
   if (s->sao_enabled) { sh->sao_luma = rpct(g, 80); sh->sao_chroma = rpct(g, 80); }
-  /* ---- slice data: one substream per CTU row with WPP, else one per tile */
-  const int wpp = p->entropy_coding_sync_enabled;
-  const int nsub = wpp ? hc : g->nrows_t;
+  /* ---- slice data: one substream per CTU row with WPP (or with a slice segment per row), else one per tile */
+  const int wpp = p->entropy_coding_sync_enabled, slices = g->cfg.slices;
+  const int row_subs = wpp || slices == 1;
+  const int nsub = row_subs ? hc : g->nrows_t;
   subs = (orc_bitw *)calloc((size_t)nsub, sizeof(orc_bitw));
+  int *seg_first = (int *)calloc((size_t)nsub + 1, sizeof(int)), *seg_addr = (int *)calloc((size_t)nsub + 1, sizeof(int)), nseg = 0;   /* slice segments: first substream, CTB address */
   orc_ctx saved[CTX_COUNT];
   const int init_type = g->slice_is_intra ? 0 : (sh->cabac_init_flag ? 2 : 1);
   int sub = -1;
@@ -631,14 +635,16 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
   for (int cy = 0; cy < hc; cy++) {
     int tile_start = 0, tile_end = 0;
     for (int i = 0; i < g->nrows_t; i++) { if (cy == g->row_bd[i]) tile_start = 1; if (cy + 1 == g->row_bd[i + 1]) tile_end = 1; }
-    if (tile_start || wpp) {
+    if (tile_start || row_subs) {
       sub++;
+      if (cy == 0 || slices == 1 || (slices == 2 && tile_start)) { seg_first[nseg] = sub; seg_addr[nseg] = cy * wc; nseg++; }
       orc_bw_init(&subs[sub]);
       orc_cenc_start(&g->c, &subs[sub]);
       /* 9.3.1: first CTB of a tile initialises; a WPP row synchronises with the state after the 2nd CTB of the row above when
-       * that CTB exists (pictures one CTB wide: it does not, the row initialises afresh) */
-      if (tile_start || wc < 2) orc_cabac_init_contexts(g->c.ctx, init_type, sh->slice_qp);
-      else memcpy(g->c.ctx, saved, sizeof(saved));
+       * that CTB exists (pictures one CTB wide: it does not, the row initialises afresh); a dependent slice segment that starts
+       * anywhere else goes on with the contexts the previous segment ended with (they are still in g->c.ctx) */
+      if (tile_start || (wpp && wc < 2)) orc_cabac_init_contexts(g->c.ctx, init_type, sh->slice_qp);
+      else if (wpp) memcpy(g->c.ctx, saved, sizeof(saved));
     }
     for (int cx = 0; cx < wc; cx++) {
       if (sh->sao_luma || sh->sao_chroma) {
@@ -650,20 +656,29 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
       gen_coding_quadtree(g, cx * 64, cy * 64, 6, 0);
       if (wpp && cx == 1) memcpy(saved, g->c.ctx, sizeof(saved));
       const int last = (cy == hc - 1 && cx == wc - 1);
-      const int sub_end = cx == wc - 1 && (wpp || tile_end);
-      orc_cenc_terminate(&g->c, last);                  /* end_of_slice_segment_flag */
-      if (!last && sub_end) orc_cenc_terminate(&g->c, 1);   /* end_of_subset_one_bit */
-      if (last || sub_end) orc_bw_align_zero(g->c.bw);
+      const int sub_end = cx == wc - 1 && (row_subs || tile_end);
+      const int seg_end = last || (cx == wc - 1 && (slices == 1 || (slices == 2 && tile_end)));
+      orc_cenc_terminate(&g->c, seg_end);               /* end_of_slice_segment_flag */
+      if (!seg_end && sub_end) orc_cenc_terminate(&g->c, 1);   /* end_of_subset_one_bit */
+      if (seg_end || sub_end) orc_bw_align_zero(g->c.bw);
     }
   }
-  uint32_t *ep = (uint32_t *)calloc((size_t)nsub, sizeof(uint32_t));
-  sh->num_entry_points = nsub - 1; sh->entry_point_offset = ep;
-  for (int i = 0; i < nsub - 1; i++) ep[i] = (uint32_t)orc_escaped_size(subs[i].buf, subs[i].len);
-  orc_bw_init(&hdr);
-  orc_write_slice_header(&hdr, sh, s, p, nal);
-  for (int i = 0; i < nsub; i++) { orc_bw_bytes(&hdr, subs[i].buf, subs[i].len); orc_bw_free(&subs[i]); }
-  orc_write_nal(&g->au, nal, 0, hdr.buf, hdr.len, 1);
-  orc_bw_free(&hdr); free(subs); free(ep);
+  seg_first[nseg] = nsub;
+  /* ---- one NAL unit per slice segment: the first carries the full header; a dependent segment only its address and entry points,
+   * an independent slice (slices = 2) the same header again with its own address */
+  for (int k = 0; k < nseg; k++) {
+    const int s0 = seg_first[k], n = seg_first[k + 1] - s0;
+    uint32_t *ep = (uint32_t *)calloc((size_t)n, sizeof(uint32_t));
+    sh->first_slice_segment_in_pic = k == 0; sh->slice_segment_address = seg_addr[k]; sh->dependent_slice_segment = (k > 0 && slices == 1);
+    sh->num_entry_points = n - 1; sh->entry_point_offset = ep;
+    for (int i = 0; i < n - 1; i++) ep[i] = (uint32_t)orc_escaped_size(subs[s0 + i].buf, subs[s0 + i].len);
+    orc_bw_init(&hdr);
+    orc_write_slice_header(&hdr, sh, s, p, nal);
+    for (int i = 0; i < n; i++) { orc_bw_bytes(&hdr, subs[s0 + i].buf, subs[s0 + i].len); orc_bw_free(&subs[s0 + i]); }
+    orc_write_nal(&g->au, nal, 0, hdr.buf, hdr.len, 1);
+    orc_bw_free(&hdr); free(ep);
+  }
+  free(subs); free(seg_first); free(seg_addr);
   sh->entry_point_offset = NULL;
 }
 

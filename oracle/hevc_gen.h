@@ -38,6 +38,9 @@ typedef struct {
   int nxn_intra;              /* PART_NxN intra at 8x8 */
   int max_cu_log2, min_cu_log2;   /* coding block sizes used (the syntax allows 3..6 regardless) */
   int big_mvd;                /* 1 % of the vector differences are huge (reference blocks far outside the picture) */
+  int slices;                 /* slice segments per picture, the two ways Kvazaar cuts them (uvgComm video/Slices, kvazaarfilter.cpp:205-215): 0 (also -1) one
+                               * slice; 1 = a DEPENDENT slice segment per CTU row (kvazaar slices=wpp; here with or without WPP); 2 = an independent
+                               * slice per tile (kvazaar slices=tiles; one slice when there are no tiles) */
 } orc_gen_config;
 
 void orc_gen_default_config(orc_gen_config *c);    /* everything random, 416x240 */

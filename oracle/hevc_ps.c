@@ -485,8 +485,11 @@ int orc_parse_pps(orc_bitr *r, orc_pps *p)
   return 0;
 }
 
+/* *h holds the previous slice segment's header on entry (entry_point_offset already released by the caller): a dependent slice
+ * segment (7.3.6.1) takes over everything but its address and its entry points from it */
 int orc_parse_slice_header(orc_bitr *r, orc_slice_hdr *h, int nal_type, const orc_sps *sps_tab, const orc_pps *pps_tab)
 {
+  const orc_slice_hdr prev = *h;
   memset(h, 0, sizeof(*h));
   h->first_slice_segment_in_pic = (int)orc_br_get(r, 1);
   if (nal_type >= NAL_BLA_W_LP && nal_type <= NAL_RSV_IRAP_VCL23) h->no_output_of_prior_pics = (int)orc_br_get(r, 1);
@@ -499,7 +502,14 @@ int orc_parse_slice_header(orc_bitr *r, orc_slice_hdr *h, int nal_type, const or
     if (p->dependent_slice_segments_enabled) h->dependent_slice_segment = (int)orc_br_get(r, 1);
     h->slice_segment_address = (int)orc_br_get(r, ceil_log2((unsigned)(s->pic_w_ctbs * s->pic_h_ctbs)));
   }
-  if (h->dependent_slice_segment) return -2;   /* dependent slice segments: unsupported by this oracle */
+  if (h->dependent_slice_segment) {
+    const int addr = h->slice_segment_address, pps_id = h->pps_id;
+    if (prev.pps_id != pps_id) return -1;
+    *h = prev;
+    h->first_slice_segment_in_pic = 0; h->dependent_slice_segment = 1; h->slice_segment_address = addr;
+    h->num_entry_points = 0; h->entry_point_offset = NULL;
+    goto entry_points;
+  }
   for (int i = 0; i < p->num_extra_slice_header_bits; i++) orc_br_get(r, 1);
   h->slice_type = (int)orc_br_ue(r);
   if (h->slice_type > 2) return -1;
@@ -553,6 +563,7 @@ int orc_parse_slice_header(orc_bitr *r, orc_slice_hdr *h, int nal_type, const or
   h->loop_filter_across_slices = p->loop_filter_across_slices;
   if (p->loop_filter_across_slices && (h->sao_luma || h->sao_chroma || !h->slice_deblocking_disabled))
     h->loop_filter_across_slices = (int)orc_br_get(r, 1);
+entry_points:
   if (p->tiles_enabled || p->entropy_coding_sync_enabled) {
     h->num_entry_points = (int)orc_br_ue(r);
     if (h->num_entry_points > 440 * 135) return -1;

@@ -102,3 +102,66 @@ def test_everything_on_1080p(gpu):
 def test_frame_threaded_decoder_foreign_streams(gpu, seed):
     """OpenHEVC 'Frame' parallelisation: pictures parsed concurrently; temporal prediction makes a parser follow the collocated picture's"""
     run_stream(416, 240, 12, threads=4, frame_threads=True, seed=seed, tmvp=1, num_refs=3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slices,wpp,tile_rows,frame", [(1, 1, 1, False), (1, 0, 1, False), (1, 1, 3, False), (1, 0, 2, False), (2, 1, 3, False), (2, 0, 4, False),
+                                                        (1, 1, 1, True), (2, 1, 2, True)])
+def test_pictures_in_several_slice_segments(gpu, slices, wpp, tile_rows, frame):
+    """uvgComm video/Slices (kvazaarfilter.cpp:205-215): a Kvazaar peer cuts every picture into slice segments, one NAL unit each -- a
+    dependent slice segment per CTU row (slices=wpp) or an independent slice per tile (slices=tiles).  libOpenHevcDecode gets them one by
+    one and hands out the picture with the last; same pictures as the checker's decoder."""
+    run_stream(200, 264, 10, threads=3 if frame else 1, frame_threads=frame, seed=31, density=35, num_refs=2, tmvp=1, sao=1, cabac_init=1, wpp=wpp, tile_rows=tile_rows,
+               uniform_tiles=1, qp_delta=2, intra_in_p=20, sign_hiding=1, slices=slices)
+
+
+@pytest.mark.gpu
+def test_slice_segments_1080p_kvazaar_shape(gpu):
+    """1080p, WPP, a dependent slice segment per CTU row (17 NAL units per picture), Kvazaar-like references"""
+    run_stream(1920, 1080, 4, seed=5, density=25, num_refs=2, tmvp=1, wpp=1, tile_rows=1, slices=1, intra_in_p=10, max_cu_log2=5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frame", [False, True])
+def test_lost_slice_segments(gpu, frame):
+    """packet loss with a picture in several NAL units: a missing segment costs its picture (and the pictures that refer to it) and
+    nothing else -- no crash, no stale segment joined to the wrong picture; from the next IDR picture on the output is exact again"""
+    from kvazzup_amd.codec import Decoder
+    w, h, period, pictures = 200, 264, 6, 24
+    g = orc.OracleGen(w, h, seed=9, density=30, intra_period=period, num_refs=1, tmvp=0, wpp=1, tile_rows=1, slices=1)
+    od = orc.OracleDecoder()
+    gd = Decoder(threads=3, frame_threads=True) if frame else Decoder()
+    rng = np.random.default_rng(3)
+    refs, got, clean_from = {}, {}, {}
+    damaged_period = set()
+    for t in range(pictures):
+        au = g.picture()
+        r = od.decode_au(au, t)
+        assert len(r) == 1
+        refs[t] = r[0]["i420"]
+        nals = [b"\x00\x00\x00\x01" + x for x in au.split(b"\x00\x00\x00\x01")[1:]]
+        vcl = [i for i, n in enumerate(nals) if (n[4] >> 1) < 32]
+        if t % period == 2 or t % period == 4:                     # lose one segment of this picture: the first, a middle one or the last
+            k = vcl[int(rng.integers(0, len(vcl)))] if t % period == 2 else vcl[0]
+            nals = nals[:k] + nals[k + 1:]
+            damaged_period.add(t // period)
+        for n in nals:
+            try:
+                o = gd.decode_nal(n, t)
+            except RuntimeError:                                    # a negative return: what OpenHEVCFilter::process logs (openhevcfilter.cpp:154-157)
+                o = None
+            if o is not None:
+                got[o["pts"]] = o["i420"]
+    if frame:
+        for _ in range(5):
+            try:
+                for o in gd.drain():
+                    got[o["pts"]] = o["i420"]
+                break
+            except RuntimeError:
+                pass
+    for t in range(pictures):
+        if t // period not in damaged_period or t % period < 2:    # periods without loss, and the pictures before the first loss of a period
+            assert t in got and np.array_equal(got[t], refs[t]), t
+    assert len(got) < pictures                                      # the damaged pictures did not come out as if nothing had happened
+    gd.close(); od.close(); g.close()

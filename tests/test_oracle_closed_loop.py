@@ -271,3 +271,27 @@ def test_rate_control_v2_closed_loop(bitrate, wpp, tile_rows):
     rate4, std4 = run(4)
     assert 0.7 * bitrate < rate4 < 1.35 * bitrate, (rate0, rate4)
     assert std4 < std0 * 1.1, (std0, std4)
+
+
+@pytest.mark.parametrize("slices,wpp,tile_rows", [(1, 1, 1), (1, 0, 1), (1, 1, 3), (1, 0, 2), (2, 1, 3), (2, 0, 4), (2, 0, 1)])
+def test_slice_segments_decode_like_one_slice(slices, wpp, tile_rows):
+    """The two ways a Kvazaar peer cuts a picture into slice segments (uvgComm video/Slices): a dependent slice segment per CTU row,
+    an independent slice per tile.  Neither changes what is coded below the slice level -- a dependent segment goes on with the
+    contexts the previous one ended with (or the WPP ones), a slice per tile starts where a tile starts anyway -- so the synthesiser's
+    stream for the same seed decodes to the same pictures with and without them (and the one-slice form is what the independent Python
+    decoder checks, tests/test_python_decoder.py)."""
+    w, h = 200, 264
+    kw = dict(seed=31, density=35, num_refs=2, tmvp=1, sao=1, cabac_init=1, wpp=wpp, tile_rows=tile_rows, uniform_tiles=1, qp_delta=2, intra_in_p=20, sign_hiding=1)
+    g0, g1 = orc.OracleGen(w, h, slices=0, **kw), orc.OracleGen(w, h, slices=slices, **kw)
+    d0, d1 = orc.OracleDecoder(), orc.OracleDecoder()
+    more_nals = 0
+    for t in range(10):
+        a0, a1 = g0.picture(), g1.picture()
+        more_nals += a1.count(b"\x00\x00\x01") - a0.count(b"\x00\x00\x01")
+        r0, r1 = d0.decode_au(a0, t), d1.decode_au(a1, t)
+        assert len(r0) == 1 and len(r1) == 1, t
+        assert np.array_equal(r0[0]["i420"], r1[0]["i420"]), t
+    hc = (h + 63) // 64
+    assert more_nals == 10 * ((hc if slices == 1 else tile_rows) - 1)
+    for o in (g0, g1, d0, d1):
+        o.close()

@@ -1345,12 +1345,13 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
   if (z4 == 15 && comp == 0) {                                      // the last unit of the CTU closes it
     const bool last = (cy == hc - 1 && cx == wc - 1);
     const bool sub_end = cx == wc - 1 && (f.wpp || tile_row_ends_at(hc, f.tile_rows, cy));
-    const int n = 1 + ((sub_end && !last) ? 1 : 0);
+    const bool seg_end = last || (cx == wc - 1 && (f.slices == 1 || (f.slices == 2 && tile_row_ends_at(hc, f.tile_rows, cy))));   // slice segments per CTU row / per tile
+    const int n = 1 + ((sub_end && !seg_end) ? 1 : 0);
     __syncthreads();
     np = 16;
     const uint32_t o = reserve(n);
     if (o != ~0u && lane == 0) {
-      slot[o] = (uint16_t)(0xC000u | (last ? 1u : 0u));             // end_of_slice_segment_flag
+      slot[o] = (uint16_t)(0xC000u | (seg_end ? 1u : 0u));          // end_of_slice_segment_flag
       if (n == 2) slot[o + 1] = 0xC001u;                            // end_of_subset_one_bit
     }
   }

@@ -42,6 +42,7 @@ struct EncFrame {
   int satd;                 // intra mode search: SATD (8x8 Hadamard) instead of SAD
   int me_early;             // me-early-termination: blocks that match the co-located reference block to within 64 * lambda_q4 are not searched
   int subme;                // fractional-sample refinement level 0..4 (k_subpel)
+  int slices;               // 1: a slice segment ends with every CTU row, 2: with every tile (kvazaar slices=wpp / tiles): what k_tokenize closes a CTU with
   int mv_frame;             // mv-constraint: 0 none, 1 the displaced block stays inside the picture, 2 the same with a 4-sample margin on odd displacements
   int tile_rows;            // 1: no tiles; n: n full-width tile rows, uniform spacing (6.5.1)
   int row0, nrows;          // band of CTU rows the encoder kernels work on (nrows == 0: the whole picture); a band starts and ends on tile boundaries

@@ -30,6 +30,7 @@ struct StreamParams {
   int qp_in_cu = 0;         // cu_qp_delta_enabled_flag with diff_cu_qp_delta_depth 0 (quantisation group = CTU)
   int tile_rows = 1;        // > 1: tiles_enabled_flag, one column, uniform spacing, loop filter across tiles on
   int sao = 0;              // sample_adaptive_offset_enabled_flag; every slice: slice_sao_luma_flag = slice_sao_chroma_flag = 1
+  int slices = 0;           // kvazaar slices: 1 = "wpp", a dependent slice segment per CTU row (dependent_slice_segments_enabled_flag); 2 = "tiles", a slice per tile
 };
 
 inline int level_idc_for(int w, int h)
@@ -84,7 +85,7 @@ inline void write_sps(BitWriter &w, const StreamParams &s)
 inline void write_pps(BitWriter &w, const StreamParams &s)
 {
   w.ue(0); w.ue(0);
-  w.bit(0); w.bit(0); w.put(0, 3); w.bit(0); w.bit(0);
+  w.bit(s.slices == 1); w.bit(0); w.put(0, 3); w.bit(0); w.bit(0);   // dependent_slice_segments_enabled_flag, output_flag_present, extra header bits, sign hiding, cabac_init_present
   w.ue(0); w.ue(0);
   w.se(s.qp - 26);
   w.bit(0); w.bit(0); w.bit(s.qp_in_cu != 0);                    // constrained intra, transform skip, cu_qp_delta
@@ -110,18 +111,29 @@ inline size_t escaped_size(const uint8_t *p, size_t n)
   return out;
 }
 
-inline void write_slice_header(BitWriter &w, const StreamParams &s, bool idr, int poc, const std::vector<uint32_t> &entry_sizes, int slice_qp_delta = 0)
+// slice segment header (7.3.6.1).  address < 0: the picture's first segment; else slice_segment_address of a further one, `dependent`
+// = a dependent slice segment (nothing but the address and the entry points)
+inline void write_slice_header(BitWriter &w, const StreamParams &s, bool idr, int poc, const std::vector<uint32_t> &entry_sizes, int slice_qp_delta = 0,
+                               int address = -1, bool dependent = false)
 {
-  w.bit(1);
+  w.bit(address < 0);
   if (idr) w.bit(0);
   w.ue(0);
-  w.ue(idr ? 2 : 1);
-  if (!idr) { w.put((uint32_t)poc & 255, 8); w.bit(1); }
-  if (s.sao) { w.bit(1); w.bit(1); }                             // slice_sao_luma_flag, slice_sao_chroma_flag
-  if (!idr) { w.bit(0); w.ue(0); }                               // num_ref_idx override, five_minus_max_num_merge_cand
-  w.se(slice_qp_delta);                                          // against the PPS init_qp (= the configured QP)
-  // (deblocking override not enabled; slice_loop_filter_across_slices_enabled_flag present when deblocking or SAO is on)
-  if (s.deblock || s.sao) w.bit(1);
+  if (address >= 0) {
+    if (s.slices == 1) w.bit(dependent);
+    const int nctb = (s.cw / 64) * (s.ch / 64);
+    int bits = 0; while ((1 << bits) < nctb) bits++;
+    w.put((uint32_t)address, bits);
+  }
+  if (!dependent) {
+    w.ue(idr ? 2 : 1);
+    if (!idr) { w.put((uint32_t)poc & 255, 8); w.bit(1); }
+    if (s.sao) { w.bit(1); w.bit(1); }                             // slice_sao_luma_flag, slice_sao_chroma_flag
+    if (!idr) { w.bit(0); w.ue(0); }                               // num_ref_idx override, five_minus_max_num_merge_cand
+    w.se(slice_qp_delta);                                          // against the PPS init_qp (= the configured QP)
+    // (deblocking override not enabled; slice_loop_filter_across_slices_enabled_flag present when deblocking or SAO is on)
+    if (s.deblock || s.sao) w.bit(1);
+  }
   if (s.wpp || s.tile_rows > 1) {
     w.ue((uint32_t)entry_sizes.size());
     if (!entry_sizes.empty()) {
@@ -159,12 +171,26 @@ inline void assemble_access_unit(std::vector<uint8_t> &au, const StreamParams &s
     write_sps(b, sp); append_nal(au, 33, b.data().data(), b.data().size());
     write_pps(c, sp); append_nal(au, 34, c.data().data(), c.data().size());
   }
-  std::vector<uint32_t> entry;
-  for (int r = 0; r + 1 < nsub; r++) entry.push_back((uint32_t)escaped_size(rows[(size_t)r].data(), rows[(size_t)r].size()));
-  BitWriter sh;
-  write_slice_header(sh, sp, idr, poc, entry, slice_qp_delta);
-  for (int r = 0; r < nsub; r++) sh.bytes(rows[(size_t)r].data(), rows[(size_t)r].size());
-  append_nal(au, idr ? 19 : 1, sh.data().data(), sh.data().size());
+  // slice segments, one NAL unit each: the whole picture; or (slices 1, WPP) a dependent slice segment per CTU row; or (slices 2) an
+  // independent slice per tile -- the tile's CTU rows with WPP, else its one substream
+  const int hc = sp.ch / 64, wc = sp.cw / 64;
+  for (int s0 = 0; s0 < nsub;) {
+    int n = nsub - s0, addr = -1;
+    if (sp.slices == 1) { n = 1; if (s0) addr = s0 * wc; }
+    else if (sp.slices == 2) {
+      int t, r;
+      if (sp.wpp) { r = s0; t = tile_row_of(hc, sp.tile_rows, r); n = tile_row_first(hc, sp.tile_rows, t + 1) - r; }
+      else { t = s0; r = tile_row_first(hc, sp.tile_rows, t); n = 1; }
+      if (s0) addr = r * wc;
+    }
+    std::vector<uint32_t> entry;
+    for (int r = 0; r + 1 < n; r++) entry.push_back((uint32_t)escaped_size(rows[(size_t)(s0 + r)].data(), rows[(size_t)(s0 + r)].size()));
+    BitWriter sh;
+    write_slice_header(sh, sp, idr, poc, entry, slice_qp_delta, addr, sp.slices == 1 && s0 > 0);
+    for (int r = 0; r < n; r++) sh.bytes(rows[(size_t)(s0 + r)].data(), rows[(size_t)(s0 + r)].size());
+    append_nal(au, idr ? 19 : 1, sh.data().data(), sh.data().size());
+    s0 += n;
+  }
 }
 
 }  // namespace kvzx

@@ -272,6 +272,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.bitrate = cfg->target_bitrate > 0 ? cfg->target_bitrate : 0;
   // rc-algorithm lambda / oba (uvgComm sets "lambda" with its bitrate, kvazaarfilter.cpp:225-228): the picture-level controller plus feedback
   // inside the picture (rate control v2, four groups of CTU rows); left unset: the picture-level controller alone
+  ec.slices = cfg->slices == KVZ_SLICES_WPP ? 1 : (cfg->slices == KVZ_SLICES_TILES ? 2 : 0);
   ec.rc_bands = (ec.bitrate > 0 && cfg->rc_algorithm != KVZ_NO_RC) ? 4 : 0;
   std::string err;
   Encoder *impl = Encoder::create(ec, &err);
@@ -467,6 +468,7 @@ int kvzx_assemble_access_unit(const kvz_config *cfg, int idr, int poc, int write
   if (sp.cw < 128) sp.cw = 128;
   sp.qp = cfg->qp; sp.wpp = cfg->wpp ? 1 : 0; sp.deblock = cfg->deblock_enable ? 1 : 0; sp.fps_num = cfg->framerate_num; sp.fps_den = cfg->framerate_denom;
   sp.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1; sp.qp_in_cu = (cfg->set_qp_in_cu || cfg->vaq > 0) ? 1 : 0;
+  sp.slices = (cfg->slices == KVZ_SLICES_WPP && cfg->wpp) ? 1 : ((cfg->slices == KVZ_SLICES_TILES && sp.tile_rows > 1) ? 2 : 0);
   if (nsub != (sp.wpp ? sp.ch / 64 : sp.tile_rows)) return 0;
   std::vector<std::vector<uint8_t>> rows((size_t)nsub);
   size_t o = 0;

@@ -86,6 +86,7 @@ orc_encoder *orc_enc_open(const orc_enc_config *c)
   e->cfg = *c;
   if (e->cfg.vaq > 0) e->cfg.qp_in_cu = 1;                 /* the deltas travel as cu_qp_delta */
   if (e->cfg.bitrate <= 0) e->cfg.rc_bands = 0;
+  if ((e->cfg.slices == 1 && !e->cfg.wpp) || (e->cfg.slices == 2 && e->cfg.tile_rows < 2) || e->cfg.slices < 0 || e->cfg.slices > 2) e->cfg.slices = 0;
   if (e->cfg.rc_bands > 0) e->cfg.qp_in_cu = 1;
   e->qp = c->qp;
   e->cw = (c->width + 63) & ~63; e->ch = (c->height + 63) & ~63;
@@ -131,6 +132,7 @@ orc_encoder *orc_enc_open(const orc_enc_config *c)
   p->deblocking_filter_control_present = !c->deblock; p->pps_deblocking_disabled = !c->deblock;
   p->log2_parallel_merge_level = 2; p->num_tile_columns = p->num_tile_rows = 1; p->uniform_spacing = 1;
   p->cu_qp_delta_enabled = e->cfg.qp_in_cu ? 1 : 0; p->diff_cu_qp_delta_depth = 0;
+  p->dependent_slice_segments_enabled = e->cfg.slices == 1;
   { size_t nctu = (size_t)(e->cw / 64) * (e->ch / 64);
     if (c->sao) { e->sao = (orc_sao_params *)calloc(nctu, sizeof(orc_sao_params)); for (int i = 0; i < 3; i++) e->sao_in[i] = (pixel *)malloc(i ? npx / 4 : npx); }
     e->ctu_qt = (int8_t *)calloc(nctu, 1); e->ctu_qy = (int8_t *)calloc(nctu, 1); e->ctu_delta = (int8_t *)calloc(nctu, 1); e->ctu_first = (uint8_t *)calloc(nctu, 1); }
@@ -912,28 +914,44 @@ static void write_picture(orc_encoder *e, int write_ps)
       if (e->cfg.wpp && cx == 1) memcpy(saved, c.ctx, sizeof(saved));
       int last = (cy == hc - 1 && cx == wc - 1);
       int sub_end = cx == wc - 1 && (e->cfg.wpp || tile_end);
-      orc_cenc_terminate(&c, last);                   /* end_of_slice_segment_flag */
-      if (!last && sub_end) orc_cenc_terminate(&c, 1);   /* end_of_subset_one_bit */
-      if (last || sub_end) orc_bw_align_zero(c.bw);
+      int seg_end = last || (cx == wc - 1 && (e->cfg.slices == 1 || (e->cfg.slices == 2 && tile_end)));
+      orc_cenc_terminate(&c, seg_end);                /* end_of_slice_segment_flag */
+      if (!seg_end && sub_end) orc_cenc_terminate(&c, 1);   /* end_of_subset_one_bit */
+      if (seg_end || sub_end) orc_bw_align_zero(c.bw);
     }
   }
   e->bins = c.bins;
   orc_slice_hdr sh; memset(&sh, 0, sizeof(sh));
-  sh.first_slice_segment_in_pic = 1; sh.slice_type = e->is_intra ? SLICE_I : SLICE_P; sh.pic_output_flag = 1;
+  sh.slice_type = e->is_intra ? SLICE_I : SLICE_P; sh.pic_output_flag = 1;
   sh.slice_qp_delta = e->qp - e->cfg.qp;            /* PPS init_qp is the configured QP */
   sh.poc_lsb = e->poc & 255; sh.short_term_ref_pic_set_sps_flag = 1;
   sh.num_ref_idx_l0 = 1; sh.num_ref_idx_l1 = 1; sh.max_num_merge_cand = 5; sh.collocated_from_l0 = 1;
   sh.slice_deblocking_disabled = !e->cfg.deblock;
   sh.loop_filter_across_slices = 1;
   sh.sao_luma = sh.sao_chroma = e->cfg.sao ? 1 : 0;
-  uint32_t *ep = (uint32_t *)calloc((size_t)nsub, sizeof(uint32_t));
-  sh.num_entry_points = nsub - 1; sh.entry_point_offset = ep;
-  for (int i = 0; i < nsub - 1; i++) ep[i] = (uint32_t)orc_escaped_size(rows[i].buf, rows[i].len);
-  orc_bw_init(&hdr);
-  orc_write_slice_header(&hdr, &sh, &e->sps, &e->pps, nal);
-  for (int i = 0; i < nsub; i++) { orc_bw_bytes(&hdr, rows[i].buf, rows[i].len); orc_bw_free(&rows[i]); }
-  orc_write_nal(&e->au, nal, 0, hdr.buf, hdr.len, 1);
-  orc_bw_free(&hdr); free(rows); free(ep);
+  /* slice segments, one NAL unit each: the whole picture; or a dependent segment per CTU row (its header: address and entry points
+   * only); or an independent slice per tile (the same header with its own address) */
+  for (int s0 = 0; s0 < nsub; ) {
+    int n = nsub - s0, addr = 0;
+    if (e->cfg.slices == 1) { n = 1; addr = s0 * wc; }                                    /* (wpp: substream = CTU row) */
+    if (e->cfg.slices == 2) {
+      int t = 0, r = 0;                                                                   /* tile and CTU row of substream s0 */
+      if (e->cfg.wpp) { r = s0; while (e->tile_row_bd[t + 1] <= r) t++; n = e->tile_row_bd[t + 1] - r; }
+      else { t = s0; r = e->tile_row_bd[t]; n = 1; }
+      addr = r * wc;
+    }
+    uint32_t *ep = (uint32_t *)calloc((size_t)n, sizeof(uint32_t));
+    sh.first_slice_segment_in_pic = s0 == 0; sh.dependent_slice_segment = (s0 > 0 && e->cfg.slices == 1); sh.slice_segment_address = addr;
+    sh.num_entry_points = n - 1; sh.entry_point_offset = ep;
+    for (int i = 0; i < n - 1; i++) ep[i] = (uint32_t)orc_escaped_size(rows[s0 + i].buf, rows[s0 + i].len);
+    orc_bw_init(&hdr);
+    orc_write_slice_header(&hdr, &sh, &e->sps, &e->pps, nal);
+    for (int i = 0; i < n; i++) { orc_bw_bytes(&hdr, rows[s0 + i].buf, rows[s0 + i].len); orc_bw_free(&rows[s0 + i]); }
+    orc_write_nal(&e->au, nal, 0, hdr.buf, hdr.len, 1);
+    orc_bw_free(&hdr); free(ep);
+    s0 += n;
+  }
+  free(rows);
 }
 
 /* ------------------------------------------------------------------ top level */

@@ -49,6 +49,9 @@ typedef struct {
                                * offset of -3..3 quarter samples per component, so that the stream exercises fractional-sample
                                * interpolation (8.5.3.3.3) -- the encoder algorithm proper never produces fractional vectors */
   int sao;                    /* 1: sample adaptive offset on, parameters by "uvgx SAO decision v1" (hevc_sao.c) */
+  int slices;                 /* kvazaar slices (uvgComm video/Slices, kvazaarfilter.cpp:205-215): 0 one slice per picture; 1 = "wpp": a DEPENDENT slice segment
+                               * per CTU row (needs wpp); 2 = "tiles": an independent slice per tile (needs tile_rows > 1).  One NAL unit per segment;
+                               * what is coded below the slice level does not change */
   int rc_bands;               /* with bitrate > 0: "uvgx rate control v2" -- the CTU rows of a P picture are reconstructed in this many groups, one after
                                * the other, and after each group the QP of the next one moves by at most one step (within +-3 of the picture's QP)
                                * according to what the levels coded so far will cost against the picture's target (rc_band_decide() in hevc_enc.c);

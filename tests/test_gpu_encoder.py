@@ -29,11 +29,11 @@ def _diagnose(dbg_o, dbg_g):
     return "; ".join(msgs) if msgs else "no stage-level difference found (entropy coding / assembly?)"
 
 
-def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_picture=True, tile_rows=1, sao=0, mv_frame=0, vaq=0, gpu_entropy=0, subme=0, me_early=1):
+def run_clip(w, h, frames, qp, period, me_range, kind, wpp=1, deblock=1, via_picture=True, tile_rows=1, sao=0, mv_frame=0, vaq=0, gpu_entropy=0, subme=0, me_early=1, slices=0):
     from kvazzup_amd.codec import Encoder
-    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows, sao=sao, mv_frame=mv_frame, vaq=vaq, subme=subme, me_early=me_early)
+    oe = orc.OracleEncoder(w, h, qp=qp, period=period, me_range=me_range, wpp=wpp, deblock=deblock, tile_rows=tile_rows, sao=sao, mv_frame=mv_frame, vaq=vaq, subme=subme, me_early=me_early, slices=slices)
     ge = Encoder(w, h, options=(("qp", qp), ("period", period), ("me-range", me_range), ("wpp", wpp), ("deblock", deblock), ("tiles", "1x%d" % tile_rows),
-                                ("sao", "full" if sao else "off"), ("mv-constraint", ("none", "frame", "frametilemargin")[mv_frame]), ("gpu-entropy", gpu_entropy), ("subme", subme), ("me-early-termination", "on" if me_early else "off")) + ((('vaq', vaq),) if vaq else ()))
+                                ("sao", "full" if sao else "off"), ("mv-constraint", ("none", "frame", "frametilemargin")[mv_frame]), ("gpu-entropy", gpu_entropy), ("slices", ("none", "wpp", "tiles")[slices]), ("subme", subme), ("me-early-termination", "on" if me_early else "off")) + ((('vaq', vaq),) if vaq else ()))
     assert not ge.rejected, ge.rejected
     try:
         for t in range(frames):
@@ -104,6 +104,32 @@ def test_subme_matches_oracle(gpu, cfg):
     """subme 1..4: k_subpel (fractional-sample refinement, SATD on the matrix cores) and the encoder's fractional-sample motion
     compensation against subme_refine() of the checker: same vectors, same access units, same reconstruction"""
     run_clip(**cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(w=320, h=256, frames=5, qp=30, period=3, me_range=16, kind=0, slices=1),                              # slices=wpp: a dependent slice segment per CTU row
+    dict(w=320, h=256, frames=4, qp=30, period=64, me_range=8, kind=0, slices=1, tile_rows=2, sao=1),
+    dict(w=320, h=256, frames=4, qp=27, period=2, me_range=8, kind=2, slices=2, tile_rows=2),                  # slices=tiles: an independent slice per tile, WPP rows inside
+    dict(w=320, h=256, frames=4, qp=27, period=64, me_range=8, kind=0, slices=2, tile_rows=4, wpp=0, vaq=6),   # one substream per slice
+    dict(w=320, h=256, frames=3, qp=30, period=64, me_range=8, kind=0, slices=1, gpu_entropy=1),               # the GPU arithmetic coder closes the rows the same way
+    dict(w=1920, h=1080, frames=3, qp=32, period=64, me_range=16, kind=0, slices=1),                           # 17 NAL units per picture
+])
+def test_slices_option_matches_oracle(gpu, cfg):
+    """uvgComm video/Slices (kvazaarfilter.cpp:205-215 -> kvazaar slices=wpp / tiles): one NAL unit per slice segment, the checker's
+    access units byte for byte; the HIP decoder puts the pictures together again"""
+    from kvazzup_amd.codec import Decoder, Encoder
+    run_clip(**cfg)
+    w, h = cfg["w"], cfg["h"]
+    ge = Encoder(w, h, options=(("qp", cfg["qp"]), ("period", cfg["period"]), ("me-range", cfg["me_range"]), ("wpp", cfg.get("wpp", 1)), ("tiles", "1x%d" % cfg.get("tile_rows", 1)),
+                                ("slices", ("none", "wpp", "tiles")[cfg["slices"]])))
+    gd = Decoder()
+    for t in range(3):
+        au, rec = ge.encode(orc.synth_frame(cfg["kind"], SEED, w, h, t))
+        assert au.count(b"\x00\x00\x00\x01") >= 2
+        got = gd.decode_au(au, t)
+        assert len(got) == 1 and np.array_equal(got[0]["i420"], rec), t
+    ge.close(); gd.close()
 
 
 @pytest.mark.gpu

@@ -7,6 +7,8 @@
 #include <vector>
 #include "../../kvazzup_amd/csrc/hevc_core.h"
 #include "../../kvazzup_amd/csrc/hevc_headers.h"
+#include "../../kvazzup_amd/csrc/entropy_host.h"
+#include <chrono>
 
 using namespace kvzx;
 
@@ -228,4 +230,78 @@ int hc_quant(int coef, int qp, int log2n, int intra) { return quant_level(coef, 
 int hc_dequant(int level, int qp, int log2n) { return dequant_coef(level, qp, log2n); }
 int hc_mvd_bits(int q) { return mvd_bits(q); }
 
+// Microbenchmark of the host arithmetic coder's bin loop (entropy_host.h cabac_play_tokens_host) on the tokens of one picture:
+// ns per token, all CTUs through one coder (contexts carried along; the byte output is discarded).  tools/arith_bench.py.
+double hc_bench_play_tokens(const uint16_t *tok, long n, int reps, int variant)
+{
+  static CoreTabs tabs; for (int i = 0; i < 64; i++) core_tabs_fill_entry(tabs, i);
+  static HostCabacTabs ht;
+  std::vector<uint8_t> out((size_t)n * 2 + 64);
+  uint8_t ctx[CTX_COUNT];
+  double best = 1e30;
+  for (int r = 0; r < reps; r++) {
+    CabacEnc c; c.nbins = 0;
+    cabac_start(c, out.data(), (int)out.size(), ctx, &tabs);
+    cabac_init_contexts(ctx, 1, 32);
+    auto t0 = std::chrono::steady_clock::now();
+    if (variant == 0) cabac_play_tokens(c, tok, (int)n); else cabac_play_tokens_host(c, ht, tok, (int)n);
+    const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
+    if (ns < best) best = ns;
+  }
+  return best / (double)n;
+}
+// the picture's tokens, CTU after CTU (what k_tok_compact delivers); returns the count (<= cap)
+long hc_picture_tokens(HcFrame *h, uint16_t *dst, long cap);
+
 }  // extern "C"
+
+extern "C" long hc_picture_tokens(HcFrame *h, uint16_t *dst, long cap)
+{
+  EncFrame f; fill(f, *h);
+  const int wc = f.cw / 64, hc = f.ch / 64;
+  static CoreTabs tabs; for (int i = 0; i < 64; i++) core_tabs_fill_entry(tabs, i);
+  std::vector<std::vector<uint16_t>> ctu_tok((size_t)wc * hc);
+  FrameView v; v.f = &f;
+  unsigned long long total = 0;
+  for (int cy = 0; cy < hc; cy++)
+    for (int cx = 0; cx < wc; cx++) {
+      std::vector<uint16_t> buf(65536);
+      TokOut t; t.tabs = &tabs; t.p = buf.data(); t.n = 0; t.cap = (int)buf.size();
+      for (int z = 0; z < 64;) {
+        int xi, yi; ctu_z_to_xy(z, xi, yi);
+        int x0 = cx * 64 + xi * 8, y0 = cy * 64 + yi * 8;
+        CuRec cu = v.at(x0, y0);
+        enc_split_flags(v, t, f.cw, f.chp, x0, y0, z, cu.log2);
+        int cbf = enc_cu_header(v, t, f.cw, f.chp, f.is_intra != 0, x0, y0, cu);
+        for (int ci = 0; ci < 3; ci++) {
+          if (!((cbf >> ci) & 1)) continue;
+          int l2 = ci ? cu.log2 - 1 : cu.log2, pw = ci ? f.cw / 2 : f.cw, px = ci ? x0 / 2 : x0, py = ci ? y0 / 2 : y0;
+          int scan = intra_scan_idx(cu.intra, l2, ci, cu.intra_mode);
+          TuDigest d; digest_build_serial(&tabs, d, f.coef[ci] + py * pw + px, pw, l2, scan);
+          int last_sb, last_pos; enc_last_pos(t, d, l2, ci, scan, last_sb, last_pos);
+          // independent per sub-block tokenisation, concatenated from last_sb downwards
+          for (int i = last_sb; i >= 0; i--) {
+            bool prev_g1 = false;
+            uint64_t above = (i < 63) ? (d.sbmask >> (i + 1)) : 0;
+            if (above) { int j = i + 1 + __builtin_ctzll(above); prev_g1 = subblock_g1_any(&tabs, d, j, scan); }
+            uint16_t lt[160]; TokOut s2; s2.tabs = &tabs; s2.p = lt; s2.n = 0; s2.cap = 160;
+            enc_subblock(s2, d, i, last_sb, last_pos, prev_g1, l2, ci, scan);
+            if (s2.n > 128) return -1000000;                 // TOK_LANE_CAP of the kernel
+            for (int k = 0; k < s2.n; k++) tok_push(t, lt[k]);
+          }
+        }
+        z += 1 << (2 * (cu.log2 - 3));
+      }
+      bool last = (cy == hc - 1 && cx == wc - 1);
+      cabac_terminate(t, last);
+      if (f.wpp && !last && cx == wc - 1) cabac_terminate(t, 1);
+      if (t.n > t.cap) return -2000000;
+      buf.resize((size_t)t.n); total += (unsigned long long)t.n;
+      ctu_tok[(size_t)cy * wc + cx] = buf;
+    }
+  long n = 0;
+  for (auto &v2 : ctu_tok) for (uint16_t t : v2) { if (n < cap) dst[n] = t; n++; }
+  (void)total;
+  return n;
+}
+

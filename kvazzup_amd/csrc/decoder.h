@@ -56,7 +56,8 @@ struct DecPps {
   int cu_qp_delta = 0, qp_delta_depth = 0, cb_qp_offset = 0, cr_qp_offset = 0, slice_chroma_offsets = 0;
   int output_flag_present = 0, extra_header_bits = 0, header_extension = 0;
   int wpp = 0, tile_rows = 1, row_bd[34];   // tile row i covers CTB rows [row_bd[i], row_bd[i + 1]); filled at slice time when uniform
-  int uniform_tiles = 1, row_height[33];
+  int tile_cols = 1, col_bd[34];            // tile column j covers CTB columns [col_bd[j], col_bd[j + 1])
+  int uniform_tiles = 1, row_height[33], col_width[33];
   int deblock_control = 0, deblock_override = 0, deblock_disabled = 0, beta_offset_div2 = 0, tc_offset_div2 = 0, loop_filter_across_slices = 1;
   int par_mrg_level = 2;
 };
@@ -103,6 +104,8 @@ struct ColMotion {
   int w16 = 0, h16 = 0, hc = 0, poc = 0;
   std::vector<Mv> mv;
   std::unique_ptr<std::atomic<uint8_t>[]> row_done;      // per CTU row
+  std::unique_ptr<std::atomic<uint8_t>[]> row_cols;      // tile columns of the row that have been parsed (row_done follows the last one)
+  int cols = 1;
 };
 
 class Decoder {
@@ -145,6 +148,10 @@ class Decoder {
     // slice segments (a picture in several NAL units): whether a segment ends with this CTU row (always for the last row); where, inside a
     // substream that spans several rows (no WPP), a new segment's data starts at this row (SIZE_MAX: the row continues the stream)
     std::vector<uint8_t> seg_end_row; std::vector<size_t> row_restart;
+    // the picture's substreams in decoding order: CTB rows [cy0, cy1) x columns [cx0, cx1) of one tile (one row with WPP), the tile's first row and id;
+    // with tile columns: whether a slice segment ends with substream k (seg_end_row is per CTU row and only used without tile columns)
+    struct SubGeom { int cy0, cy1, cx0, cx1, tile_cy0, tile_cy1, tc; };
+    std::vector<SubGeom> geom; std::vector<uint8_t> seg_end_sub;
     SliceHdr sh; std::shared_ptr<const DecSps> sps; DecPps pps;  // (a later SPS / PPS NAL may replace the table entry while this picture is still being parsed: the job keeps the SPS it was coded with alive, the PPS by value)
     int64_t pts = 0; int crop[4] = {0, 0, 0, 0}; uint32_t fps_num = 0, fps_den = 0;
     int slot = 0;                                                // picture buffer this picture is reconstructed into
@@ -195,8 +202,9 @@ class Decoder {
   int w_ = 0, h_ = 0, pw_ = 0, ph_ = 0;
   std::vector<PicJob> jobs_; int frame_threads_ = 1; long job_head_ = 0, job_tail_ = 0;
   // a picture arriving in several slice segment NAL units: its job is filled segment by segment and submitted with the last one
-  bool asm_active_ = false; int asm_rows_ = 0, asm_pps_id_ = 0, asm_nal_type_ = 0; bool asm_irap_ = false;
+  bool asm_active_ = false; int asm_subs_ = 0, asm_rows_ = 0, asm_pps_id_ = 0, asm_nal_type_ = 0; bool asm_irap_ = false;
   int submit_job(PicJob &job, int nal_type, bool irap);
+  int append_segment_tiles(PicJob &job, size_t bitpos, const uint8_t *rbsp, size_t len, const DecPps &p, const DecPps &pp, int wc, int hc, int address);
   int append_segment(PicJob &job, size_t bitpos, const uint8_t *rbsp, size_t len, const DecPps &p, const DecPps &pp, int wc, int hc, int address, int64_t pts);
   std::deque<OwnedPic> ready_q_; OwnedPic cur_owned_;       // pictures completed ahead of their turn (resolution change), the one last handed out
   int decode_nal_inner(const uint8_t *data, size_t len, int64_t pts);

@@ -322,7 +322,7 @@ struct SliceParser {
   CabacDec c;
   const int w, h, b4w, b8w, wc, hc;
   B4Rec *b4; uint8_t *pm, *ctd, *im;     // pm, ctd: per 8x8 (the minimum coding block); im: per 4x4 (NxN parts)
-  int tile_y0 = 0, tile_y1 = 1 << 30;    // luma rows of the tile being parsed: nothing outside is available (the next tile may be parsed concurrently)
+  int tile_y0 = 0, tile_y1 = 1 << 30, tile_x0 = 0, tile_x1 = 1 << 30;    // luma rows / columns of the tile being parsed: nothing outside is available (other tiles may be parsed concurrently)
   int err = 0;
   // quantisation (8.6.1)
   int qp_y = 0, qp_y_pred = 0, last_qp_y = 0, cu_qp_delta_val = 0, log2_qg = 6; bool qp_delta_coded = false;
@@ -343,7 +343,7 @@ struct SliceParser {
   // neighbour that precedes the current block in z-scan order has been parsed while none that follows it has been.
   inline bool avail(int, int, int xn, int yn) const
   {
-    return xn >= 0 && yn >= tile_y0 && xn < w && yn < h && yn < tile_y1 && pm[b8(xn, yn)] != PM_NONE;
+    return xn >= tile_x0 && yn >= tile_y0 && xn < w && yn < h && yn < tile_y1 && xn < tile_x1 && pm[b8(xn, yn)] != PM_NONE;
   }
   // coding-unit wide values of the per-8x8 arrays
   void fill_cu8(uint8_t *arr, int x0, int y0, int n, int v)
@@ -1057,12 +1057,15 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     if (r.err || p.num_ref_idx_default > 15 || p.cb_qp_offset < -12 || p.cb_qp_offset > 12 || p.cr_qp_offset < -12 || p.cr_qp_offset > 12) return last_error_ = DEC_ERR_INVALID;
     p.dependent_slices = dep;
     if (cip || wp || wbp || tqb) return last_error_ = DEC_ERR_UNSUPPORTED;   // constrained intra, weighted prediction, lossless
-    if (tiles) {                                                 // supported: one column; loop filter across tiles on
+    if (tiles) {                                                 // supported: up to 15 x 15 tiles; loop filter across tiles on
       const int cols = r.ue() + 1, rows = r.ue() + 1; p.uniform_tiles = r.get(1);
-      if (cols != 1 || rows > 32) return last_error_ = DEC_ERR_UNSUPPORTED;
-      if (!p.uniform_tiles) for (int k = 0; k < rows - 1; k++) { p.row_height[k] = (int)r.ue() + 1; if (p.row_height[k] > 1024) return last_error_ = DEC_ERR_INVALID; }
+      if (cols > 15 || rows > 15) return last_error_ = DEC_ERR_UNSUPPORTED;           // (tile ids are bytes)
+      if (!p.uniform_tiles) {
+        for (int k = 0; k < cols - 1; k++) { p.col_width[k] = (int)r.ue() + 1; if (p.col_width[k] > 1024) return last_error_ = DEC_ERR_INVALID; }
+        for (int k = 0; k < rows - 1; k++) { p.row_height[k] = (int)r.ue() + 1; if (p.row_height[k] > 1024) return last_error_ = DEC_ERR_INVALID; }
+      }
       if (!r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;   // loop_filter_across_tiles_enabled_flag
-      p.tile_rows = rows;
+      p.tile_rows = rows; p.tile_cols = cols;
     }
     p.loop_filter_across_slices = r.get(1);
     p.deblock_control = r.get(1);
@@ -1109,6 +1112,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     if (!asm_active_ || pps_id != asm_pps_id_ || nal_type != asm_nal_type_) return DEC_ERR_INVALID;      // a segment without its picture's first one (lost), or of another picture
   } else if (asm_active_) asm_active_ = false;                   // the previous picture never got its last segment: it is dropped
   PicJob *const open_job = first_seg ? nullptr : &jobs_[(size_t)(job_head_ % jobs_.size())];
+  if (dependent && open_job->pps.tile_cols > 1) { asm_active_ = false; return DEC_ERR_UNSUPPORTED; }     // (with tile columns: whole pictures or slices of whole tiles)
   if (dependent) {
     // 7.3.6.1: everything but the address and the entry points is taken over from the slice's first segment
     const int wc = (s.width + 63) / 64, hc = (s.height + 63) / 64;
@@ -1171,6 +1175,14 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     pp.row_bd[k + 1] = pp.row_bd[k] + hgt;
   }
   if (pp.row_bd[p.tile_rows] != hc) return DEC_ERR_INVALID;
+  if (p.tile_cols > wc) return DEC_ERR_INVALID;
+  pp.col_bd[0] = 0;
+  for (int k = 0; k < p.tile_cols; k++) {
+    const int wid = p.uniform_tiles ? ((k + 1) * wc) / p.tile_cols - (k * wc) / p.tile_cols : (k < p.tile_cols - 1 ? p.col_width[k] : wc - pp.col_bd[k]);
+    if (wid < 1) return DEC_ERR_INVALID;
+    pp.col_bd[k + 1] = pp.col_bd[k] + wid;
+  }
+  if (pp.col_bd[p.tile_cols] != wc) return DEC_ERR_INVALID;
   if (!first_seg) {
     // an independent slice of a picture under way: the same slice parameters as the first (what this decoder keeps per picture)
     const SliceHdr &a = open_job->sh;
@@ -1227,9 +1239,22 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     job.own->row_done.reset(new std::atomic<uint8_t>[(size_t)hc]);
     for (int k = 0; k < hc; k++) job.own->row_done[(size_t)k].store(0, std::memory_order_relaxed);
   }
-  for (int cy = 0, t = 0; cy < hc; cy++) { while (cy >= pp.row_bd[t + 1]) t++; memset(job.ctu_tile + (size_t)cy * wc, t, (size_t)wc); }
+  for (int cy = 0, t = 0; cy < hc; cy++) {
+    while (cy >= pp.row_bd[t + 1]) t++;
+    for (int tc = 0; tc < pp.tile_cols; tc++) memset(job.ctu_tile + (size_t)cy * wc + pp.col_bd[tc], t * pp.tile_cols + tc, (size_t)(pp.col_bd[tc + 1] - pp.col_bd[tc]));
+  }
+  // the substreams in decoding order (6.5.1 tile scan): tile after tile; with WPP every CTB row of a tile is one
+  job.geom.clear();
+  for (int tr = 0; tr < pp.tile_rows; tr++)
+    for (int tc = 0; tc < pp.tile_cols; tc++) {
+      PicJob::SubGeom g; g.tile_cy0 = pp.row_bd[tr]; g.tile_cy1 = pp.row_bd[tr + 1]; g.cx0 = pp.col_bd[tc]; g.cx1 = pp.col_bd[tc + 1]; g.tc = tc;
+      if (pp.wpp) for (int cy = g.tile_cy0; cy < g.tile_cy1; cy++) { g.cy0 = cy; g.cy1 = cy + 1; job.geom.push_back(g); }
+      else { g.cy0 = g.tile_cy0; g.cy1 = g.tile_cy1; job.geom.push_back(g); }
+    }
+  job.seg_end_sub.assign(job.geom.size(), 0);
+  if (job.own) { job.own->cols = pp.tile_cols; job.own->row_cols.reset(new std::atomic<uint8_t>[(size_t)hc]); for (int k = 0; k < hc; k++) job.own->row_cols[(size_t)k].store(0, std::memory_order_relaxed); }
   job.rc = 0; job.any_intra = job.any_inter = false;
-  asm_active_ = true; asm_rows_ = 0; asm_pps_id_ = pps_id; asm_nal_type_ = nal_type; asm_irap_ = irap;
+  asm_active_ = true; asm_rows_ = 0; asm_subs_ = 0; asm_pps_id_ = pps_id; asm_nal_type_ = nal_type; asm_irap_ = irap;
   return append_segment(job, r.pos, rbsp, len, p, pp, wc, hc, 0, pts);
 }
 
@@ -1241,6 +1266,7 @@ int Decoder::append_segment(PicJob &job, size_t bitpos, const uint8_t *rbsp, siz
   (void)pts;
   BitReader r(rbsp, len); r.pos = bitpos;
   auto fail = [&](int rc) { asm_active_ = false; return rc; };
+  if (pp.tile_cols > 1) return append_segment_tiles(job, r.pos, rbsp, len, p, pp, wc, hc, address);
   if (address != asm_rows_ * wc) return fail(address % wc ? DEC_ERR_UNSUPPORTED : DEC_ERR_INVALID);     // whole CTU rows, in order
   std::vector<uint32_t> entry;
   if (p.wpp || p.tile_rows > 1) {
@@ -1294,6 +1320,52 @@ int Decoder::append_segment(PicJob &job, size_t bitpos, const uint8_t *rbsp, siz
   asm_rows_ = row0 + rows;
   job.seg_end_row[(size_t)(asm_rows_ - 1)] = 1;
   if (asm_rows_ < hc) return 0;                                  // more segments to come: no output for this NAL unit
+  asm_active_ = false;
+  return submit_job(job, asm_nal_type_, asm_irap_);
+}
+
+// Tile columns: a slice segment is the whole picture or one or more whole tiles, in tile-scan order (independent slices; a Kvazaar
+// peer's slices=tiles).  Progress is counted in substreams.
+int Decoder::append_segment_tiles(PicJob &job, size_t bitpos, const uint8_t *rbsp, size_t len, const DecPps &p, const DecPps &pp, int wc, int hc, int address)
+{
+  (void)hc; (void)pp;
+  BitReader r(rbsp, len); r.pos = bitpos;
+  auto fail = [&](int rc) { asm_active_ = false; return rc; };
+  const int nsub = (int)job.geom.size();
+  if (asm_subs_ >= nsub) return fail(DEC_ERR_INVALID);
+  const PicJob::SubGeom &g0 = job.geom[(size_t)asm_subs_];
+  if (g0.cy0 != g0.tile_cy0 || address != g0.cy0 * wc + g0.cx0) return fail(DEC_ERR_UNSUPPORTED);        // segments start where a tile starts
+  std::vector<uint32_t> entry;
+  {
+    const int nep = r.ue();
+    if (nep < 0 || nep > 1024) return fail(DEC_ERR_INVALID);
+    if (nep > 0) { int bits = r.ue() + 1; if (bits > 32) return fail(DEC_ERR_INVALID); for (int k = 0; k < nep; k++) entry.push_back(r.get(bits) + 1); }
+  }
+  if (p.header_extension) { const int n = r.ue(); if (n > 256) return fail(DEC_ERR_INVALID); for (int k = 0; k < n; k++) r.get(8); }
+  if (!r.get(1)) return fail(DEC_ERR_INVALID);                   // byte_alignment()
+  while (r.pos & 7) r.get(1);
+  if (r.err) return fail(DEC_ERR_INVALID);
+  const int nss = (int)entry.size() + 1, last = asm_subs_ + nss - 1;
+  if (last >= nsub) return fail(DEC_ERR_INVALID);
+  if (job.geom[(size_t)last].cy1 != job.geom[(size_t)last].tile_cy1) return fail(DEC_ERR_UNSUPPORTED);   // ... and end where one ends
+  const size_t hdr = r.pos >> 3, base = job.rbsp.size();
+  if (hdr > len) return fail(DEC_ERR_INVALID);
+  job.sub_start.push_back(base);
+  {
+    size_t esc = hdr;
+    for (size_t k = 0; k < epb_.size(); k++) if (epb_[k] < hdr) esc++;
+    for (uint32_t e : entry) {
+      esc += e;
+      size_t removed = 0;
+      for (size_t k = 0; k < epb_.size(); k++) if (epb_[k] + k < esc) removed++;
+      job.sub_start.push_back(base + esc - removed - hdr);
+    }
+  }
+  job.rbsp.insert(job.rbsp.end(), rbsp + hdr, rbsp + len);
+  job.data_off = 0; job.data_len = job.rbsp.size();
+  asm_subs_ += nss;
+  job.seg_end_sub[(size_t)last] = 1;
+  if (asm_subs_ < nsub) return 0;
   asm_active_ = false;
   return submit_job(job, asm_nal_type_, asm_irap_);
 }
@@ -1419,18 +1491,19 @@ int Decoder::complete_gpu(PicJob &job)
 int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t len, SubOut &out)
 {
   SliceParser sp(job, out, pw_);
-  const int wc = sp.wc, hc = sp.hc;
+  const int wc = sp.wc;
   const DecPps &pps = job.pps; const SliceHdr &sh = job.sh;
   const bool wpp = pps.wpp != 0;
-  const int first_cy = wpp ? sub : pps.row_bd[sub], ncy = wpp ? 1 : pps.row_bd[sub + 1] - first_cy;
-  auto tile_starts_at = [&](int cy) { for (int t = 0; t < pps.tile_rows; t++) if (pps.row_bd[t] == cy) return true; return false; };
-  auto tile_ends_at = [&](int cy) { for (int t = 0; t < pps.tile_rows; t++) if (pps.row_bd[t + 1] == cy + 1) return true; return false; };
-  int seen_above = 0;                                  // last observed progress of the row above (monotonic)
-  auto wait_above = [&](int cy, int need) {            // CTUs of row cy-1 that must be complete
+  const PicJob::SubGeom g = job.geom[(size_t)sub];
+  const int first_cy = g.cy0, ncy = g.cy1 - g.cy0, cx0 = g.cx0, cx1 = g.cx1, tw = cx1 - cx0, cols = pps.tile_cols;
+  auto tile_starts_at = [&](int cy) { return cy == g.tile_cy0; };
+  auto tile_ends_at = [&](int cy) { return cy + 1 == g.tile_cy1; };
+  int seen_above = 0;                                  // last observed progress of the row above inside the tile (monotonic)
+  auto wait_above = [&](int cy, int need) {            // CTUs of the tile's row cy-1 that must be complete
     if (!wpp || tile_starts_at(cy)) return true;       // nothing above inside the tile
-    if (need > wc) need = wc;
+    if (need > tw) need = tw;
     if (seen_above < need) {
-      std::atomic<int> &p = job.row_progress[(size_t)(cy - 1)].v;
+      std::atomic<int> &p = job.row_progress[(size_t)(cy - 1) * cols + g.tc].v;
       int spins = 0;
       while ((seen_above = p.load(std::memory_order_acquire)) < need) {
         if (++spins < 2000) __builtin_ia32_pause(); else { g_yields.fetch_add(1, std::memory_order_relaxed); std::this_thread::yield(); }
@@ -1443,14 +1516,14 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
   c.start(data, len);
   // 9.3.1: the first CTB of a tile initialises the contexts; a WPP row takes them over from the row above after its second
   // CTB when that CTB exists (pictures one CTB wide: it does not, and the row initialises afresh)
-  if (!wpp || tile_starts_at(sub) || wc < 2) {
+  if (!wpp || tile_starts_at(first_cy) || tw < 2) {
     { uint8_t init[CTX_COUNT]; cabac_init_contexts(init, init_type, sh.slice_qp); c.load_ctx(init); }
   } else {
-    if (!wait_above(sub, 2)) return DEC_ERR_INVALID;
-    c.load_ctx(&job.wpp_saved[(size_t)(sub - 1) * CTX_COUNT]);
+    if (!wait_above(first_cy, 2)) return DEC_ERR_INVALID;
+    c.load_ctx(&job.wpp_saved[((size_t)(first_cy - 1) * cols + g.tc) * CTX_COUNT]);
   }
   sp.last_qp_y = sh.slice_qp;                          // qPY_PREV at the start of a slice, a tile, a CTB row with WPP (8.6.1)
-  for (int t = 0; t < pps.tile_rows; t++) if (first_cy >= pps.row_bd[t]) { sp.tile_y0 = pps.row_bd[t] * 64; sp.tile_y1 = pps.row_bd[t + 1] * 64; }
+  sp.tile_y0 = g.tile_cy0 * 64; sp.tile_y1 = g.tile_cy1 * 64; sp.tile_x0 = cx0 * 64; sp.tile_x1 = cx1 * 64;
   ColMotion *own = job.own.get();
   for (int cy = first_cy; cy < first_cy + ncy; cy++) {
     if (cy > first_cy && job.row_restart[(size_t)cy] != SIZE_MAX) {
@@ -1459,15 +1532,15 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
       if (q < data || q >= data + len) return DEC_ERR_INVALID;
       c.start(q, (size_t)(data + len - q));
     }
-    for (int cx = 0; cx < wc; cx++) {
-      if (!wait_above(cy, cx + 2)) return DEC_ERR_INVALID;
+    for (int cx = cx0; cx < cx1; cx++) {
+      if (!wait_above(cy, cx - cx0 + 2)) return DEC_ERR_INVALID;
       const int ctu = cy * wc + cx;
       const uint32_t tu0 = (uint32_t)out.tus.size();
       sp.ctu_intra_mask = 0;
       if (!pps.cu_qp_delta) { sp.qp_y_pred = sh.slice_qp; sp.cu_qp_delta_val = 0; }
       if (sh.sao_luma || sh.sao_chroma) {                  // sao() (7.3.8.3) opens the CTU
         SaoParams *s = &job.sao[ctu];
-        const SaoParams *left = cx > 0 ? s - 1 : nullptr, *up = (cy > 0 && !tile_starts_at(cy)) ? s - wc : nullptr;
+        const SaoParams *left = cx > cx0 ? s - 1 : nullptr, *up = (cy > 0 && !tile_starts_at(cy)) ? s - wc : nullptr;
         parse_sao(c, *s, left, up, sh.sao_luma != 0, sh.sao_chroma != 0);
       }
       sp.coding_quadtree(cx * 64, cy * 64, 6, 0);
@@ -1476,24 +1549,24 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
       job.ctu[ctu].first = tu0;
       job.ctu[ctu].count = ((uint32_t)out.tus.size() - tu0) | (sp.ctu_intra_mask << 24);
       if (out.tus.size() - tu0 >= (1u << 24)) return DEC_ERR_INVALID;
-      if (wpp && cx == 1) c.save_ctx(&job.wpp_saved[(size_t)cy * CTX_COUNT]);
-      if (wpp) job.row_progress[(size_t)cy].v.store(cx + 1, std::memory_order_release);
+      if (wpp && cx == cx0 + 1) c.save_ctx(&job.wpp_saved[((size_t)cy * cols + g.tc) * CTX_COUNT]);
+      if (wpp) job.row_progress[(size_t)cy * cols + g.tc].v.store(cx - cx0 + 1, std::memory_order_release);
       // end_of_slice_segment_flag: 1 exactly where the picture's slice segments end (decode_slice noted the rows; one segment: the
       // last CTU of the picture); inside a segment a substream ends with end_of_subset_one_bit
-      const bool seg_last = cx == wc - 1 && job.seg_end_row[(size_t)cy];
+      const bool seg_last = cx == cx1 - 1 && (cols > 1 ? (cy == g.cy1 - 1 && job.seg_end_sub[(size_t)sub]) : job.seg_end_row[(size_t)cy] != 0);
       const int end = c.terminate();
-      if (end != (seg_last ? 1 : 0)) return seg_last ? DEC_ERR_INVALID : DEC_ERR_UNSUPPORTED;      // (a segment that ends elsewhere: not whole CTU rows)
-      if (!seg_last && cx == wc - 1 && (wpp || tile_ends_at(cy)) && !c.terminate()) return DEC_ERR_INVALID;   // end_of_subset_one_bit
+      if (end != (seg_last ? 1 : 0)) return seg_last ? DEC_ERR_INVALID : DEC_ERR_UNSUPPORTED;      // (a segment that ends elsewhere: not whole CTU rows / tiles)
+      if (!seg_last && cx == cx1 - 1 && (wpp || tile_ends_at(cy)) && !c.terminate()) return DEC_ERR_INVALID;   // end_of_subset_one_bit
     }
-    // this CTB row's motion as later pictures see it (one entry per 16x16 block)
+    // this CTB row's motion (the tile's columns of it) as later pictures see it (one entry per 16x16 block)
     if (!own) continue;
     for (int y16 = cy * 4; y16 < cy * 4 + 4 && y16 < own->h16; y16++)
-      for (int x16 = 0; x16 < own->w16; x16++) {
+      for (int x16 = cx0 * 4; x16 < cx1 * 4 && x16 < own->w16; x16++) {
         const B4Rec &m = job.b4[(size_t)(y16 * 4) * (pw_ / 4) + x16 * 4];
         ColMotion::Mv &o = own->mv[(size_t)y16 * own->w16 + x16];
         o.inter = m.ref_idx >= 0; o.mvx = m.mvx; o.mvy = m.mvy; o.ref_poc = m.ref_idx >= 0 ? job.ref_poc[m.ref_idx & 15] : 0;
       }
-    own->row_done[(size_t)cy].store(1, std::memory_order_release);
+    if (own->row_cols[(size_t)cy].fetch_add(1, std::memory_order_acq_rel) + 1 >= own->cols) own->row_done[(size_t)cy].store(1, std::memory_order_release);
   }
   return 0;
 }
@@ -1501,15 +1574,15 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
 int Decoder::parse_job(PicJob &job, bool row_parallel)
 {
   const uint8_t *data = job.rbsp.data() + job.data_off; const size_t len = job.data_len;
-  const int wc = (w_ + 63) / 64, hc = (h_ + 63) / 64, nsub = job.pps.wpp ? hc : job.pps.tile_rows;
+  const int wc = (w_ + 63) / 64, hc = (h_ + 63) / 64, nsub = (int)job.geom.size(), cols = job.pps.tile_cols;
   auto release_all = [&] { if (job.own) for (int r = 0; r < hc; r++) job.own->row_done[(size_t)r].store(1, std::memory_order_release); };   // never leave a later picture's parser waiting
   if ((int)job.sub_start.size() != nsub) { release_all(); return DEC_ERR_INVALID; }
   for (int r = 0; r < nsub; r++) if (job.sub_start[(size_t)r] >= len) { release_all(); return DEC_ERR_INVALID; }
   job.subs.resize((size_t)nsub);
   for (auto &r : job.subs) { r.levels.clear(); r.tus.clear(); r.rc = 0; }
-  job.wpp_saved.resize((size_t)hc * CTX_COUNT);
-  if (!job.row_progress || job.row_progress_n < hc) { job.row_progress.reset(new Progress[(size_t)hc]); job.row_progress_n = hc; }
-  for (int r = 0; r < hc; r++) job.row_progress[(size_t)r].v.store(0, std::memory_order_relaxed);
+  job.wpp_saved.resize((size_t)hc * cols * CTX_COUNT);
+  if (!job.row_progress || job.row_progress_n < hc * cols) { job.row_progress.reset(new Progress[(size_t)hc * cols]); job.row_progress_n = hc * cols; }
+  for (int r = 0; r < hc * cols; r++) job.row_progress[(size_t)r].v.store(0, std::memory_order_relaxed);
   memset(job.region, 0, (size_t)(pw_ / 32) * (ph_ / 32) * sizeof(TuRange));
   memset(job.ctu, 0, (size_t)(pw_ / 64) * (ph_ / 64) * sizeof(TuRange));
   memset(job.pred_mode.data(), PM_NONE, job.pred_mode.size());
@@ -1517,7 +1590,7 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
     size_t start = job.sub_start[(size_t)r], end = (r + 1 < nsub) ? job.sub_start[(size_t)r + 1] : len;
     int rc = end > start ? parse_substream(job, r, data + start, end - start, job.subs[(size_t)r]) : DEC_ERR_INVALID;
     job.subs[(size_t)r].rc = rc;
-    if (rc < 0 && job.pps.wpp) job.row_progress[(size_t)r].v.store(1 << 30, std::memory_order_release);   // release any waiter
+    if (rc < 0 && job.pps.wpp) job.row_progress[(size_t)job.geom[(size_t)r].cy0 * cols + job.geom[(size_t)r].tc].v.store(1 << 30, std::memory_order_release);   // release any waiter
     if (rc < 0) release_all();
   };
   if (row_parallel && nsub > 1) {
@@ -1541,11 +1614,11 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
   size_t t = 0, l = 0;
   for (int r = 0; r < nsub; r++) {
     SubOut &so = job.subs[(size_t)r];
-    const int cy0 = job.pps.wpp ? r : job.pps.row_bd[r], cy1 = job.pps.wpp ? r + 1 : job.pps.row_bd[r + 1];
+    const int cy0 = job.geom[(size_t)r].cy0, cy1 = job.geom[(size_t)r].cy1, cx0 = job.geom[(size_t)r].cx0, cx1 = job.geom[(size_t)r].cx1;
     if (t) {
       for (int cy = cy0; cy < cy1; cy++) {
-        for (int cx = 0; cx < wc; cx++) if (job.ctu[cy * wc + cx].count & 0xffffffu) job.ctu[cy * wc + cx].first += (uint32_t)t;
-        for (int ry = 2 * cy; ry < 2 * cy + 2; ry++) for (int rx = 0; rx < 2 * wc; rx++) { TuRange &g = job.region[ry * 2 * wc + rx]; if (g.count) g.first += (uint32_t)t; }
+        for (int cx = cx0; cx < cx1; cx++) if (job.ctu[cy * wc + cx].count & 0xffffffu) job.ctu[cy * wc + cx].first += (uint32_t)t;
+        for (int ry = 2 * cy; ry < 2 * cy + 2; ry++) for (int rx = 2 * cx0; rx < 2 * cx1; rx++) { TuRange &g = job.region[ry * 2 * wc + rx]; if (g.count) g.first += (uint32_t)t; }
       }
     }
     for (DecTu td : so.tus) { td.offset += (uint32_t)l; tus[t++] = td; }
@@ -1590,7 +1663,7 @@ int Decoder::launch_gpu(PicJob &job)
   f.progress = progress_; f.intra_order = intra_order_; f.err = err_;
   f.cb_qp_offset = (int8_t)job.pps.cb_qp_offset; f.cr_qp_offset = (int8_t)job.pps.cr_qp_offset;
   f.beta_offset = (int8_t)(2 * job.sh.beta_offset_div2); f.tc_offset = (int8_t)(2 * job.sh.tc_offset_div2);
-  f.strong_intra = (uint8_t)job.sps->strong_intra; f.tiles = job.pps.tile_rows > 1;
+  f.strong_intra = (uint8_t)job.sps->strong_intra; f.tiles = job.pps.tile_rows > 1 || job.pps.tile_cols > 1;
   if (job.any_inter) timed(DK_INTER, [&] { launch_dec_inter(f, stream_); });
   if (job.any_intra) {
     if (hipMemsetAsync(progress_, 0, sizeof(uint32_t) * 3 * (size_t)f.wc * f.hc, stream_) != hipSuccess) return DEC_ERR_GPU;

@@ -26,7 +26,7 @@ struct orc_gen {
   orc_vps vps; orc_sps sps; orc_pps pps; orc_slice_hdr sh;
   orc_pic side;                       /* per-4x4 syntax state of the picture being written (planes unused) */
   orc_avail_ctx av; int16_t *ctb_tile; int32_t *ctb_slice;
-  int row_bd[34], nrows_t;
+  int row_bd[34], nrows_t, col_bd[34], ncols_t;
   orc_sao_params *sao;
   orc_cabac_enc c;
   orc_bitw au;
@@ -123,6 +123,9 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   if (c->chroma_qp_offsets) { p->cb_qp_offset = rrange(g, -4, 4); p->cr_qp_offset = rrange(g, -4, 4); p->slice_chroma_qp_offsets_present = rpct(g, 50); }
   p->entropy_coding_sync_enabled = c->wpp; p->loop_filter_across_slices = 1;
   if (c->slices < 0 || c->slices > 2) c->slices = 0;
+  if (c->tile_cols < 1) c->tile_cols = 1;
+  if (c->tile_cols > wc) c->tile_cols = wc;
+  if (c->tile_cols > 1 && c->slices == 1) c->slices = 0;
   p->dependent_slice_segments_enabled = c->slices == 1;
   p->num_tile_columns = 1; p->num_tile_rows = 1; p->uniform_spacing = 1;
   p->deblocking_filter_control_present = c->deblock_mode != 0;
@@ -130,10 +133,12 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   if (c->deblock_mode >= 2) { p->pps_beta_offset_div2 = rrange(g, -3, 3); p->pps_tc_offset_div2 = rrange(g, -3, 3); }
   p->deblocking_filter_override_enabled = c->deblock_mode == 3;
   p->log2_parallel_merge_level = c->par_mrg_level;
-  g->nrows_t = c->tile_rows;
+  g->nrows_t = c->tile_rows; g->ncols_t = c->tile_cols;
   for (int i = 0; i <= c->tile_rows; i++) g->row_bd[i] = (i * hc) / c->tile_rows;
-  if (c->tile_rows > 1) {
-    p->tiles_enabled = 1; p->num_tile_rows = c->tile_rows; p->loop_filter_across_tiles = 1; p->uniform_spacing = c->uniform_tiles;
+  for (int i = 0; i <= c->tile_cols; i++) g->col_bd[i] = (i * wc) / c->tile_cols;
+  if (c->tile_rows > 1 || c->tile_cols > 1) {
+    p->tiles_enabled = 1; p->num_tile_rows = c->tile_rows; p->num_tile_columns = c->tile_cols; p->loop_filter_across_tiles = 1; p->uniform_spacing = c->uniform_tiles;
+    if (!c->uniform_tiles) for (int i = 0; i < c->tile_cols - 1; i++) p->column_width[i] = g->col_bd[i + 1] - g->col_bd[i];   /* (explicit widths, the uniform values) */
     if (!c->uniform_tiles) {                                /* explicit row heights: a random monotone partition */
       int left = hc;
       for (int i = 0; i < c->tile_rows - 1; i++) {
@@ -143,7 +148,8 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
       g->row_bd[c->tile_rows] = hc;
     }
     g->ctb_tile = (int16_t *)calloc((size_t)wc * hc, sizeof(int16_t));
-    for (int i = 0; i < c->tile_rows; i++) for (int cy = g->row_bd[i]; cy < g->row_bd[i + 1]; cy++) for (int cx = 0; cx < wc; cx++) g->ctb_tile[cy * wc + cx] = (int16_t)i;
+    for (int i = 0; i < c->tile_rows; i++) for (int cy = g->row_bd[i]; cy < g->row_bd[i + 1]; cy++)
+      for (int j = 0; j < c->tile_cols; j++) for (int cx = g->col_bd[j]; cx < g->col_bd[j + 1]; cx++) g->ctb_tile[cy * wc + cx] = (int16_t)(i * c->tile_cols + j);
   }
   if (orc_pic_alloc(&g->side, cfg->width, cfg->height)) { free(g); return NULL; }
   memset(&g->av, 0, sizeof(g->av));
@@ -623,8 +629,8 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
   if (s->sao_enabled) { sh->sao_luma = rpct(g, 80); sh->sao_chroma = rpct(g, 80); }
   /* ---- slice data: one substream per CTU row with WPP (or with a slice segment per row), else one per tile */
   const int wpp = p->entropy_coding_sync_enabled, slices = g->cfg.slices;
-  const int row_subs = wpp || slices == 1;
-  const int nsub = row_subs ? hc : g->nrows_t;
+  const int row_subs = wpp || slices == 1, cols = g->ncols_t;
+  const int nsub = (row_subs ? hc : g->nrows_t) * cols;
   subs = (orc_bitw *)calloc((size_t)nsub, sizeof(orc_bitw));
   int *seg_first = (int *)calloc((size_t)nsub + 1, sizeof(int)), *seg_addr = (int *)calloc((size_t)nsub + 1, sizeof(int)), nseg = 0;   /* slice segments: first substream, CTB address */
   orc_ctx saved[CTX_COUNT];
@@ -632,35 +638,38 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
   int sub = -1;
   orc_pic_reset_side(&g->side);
   memset(&g->c, 0, sizeof(g->c));
-  for (int cy = 0; cy < hc; cy++) {
-    int tile_start = 0, tile_end = 0;
-    for (int i = 0; i < g->nrows_t; i++) { if (cy == g->row_bd[i]) tile_start = 1; if (cy + 1 == g->row_bd[i + 1]) tile_end = 1; }
-    if (tile_start || row_subs) {
-      sub++;
-      if (cy == 0 || slices == 1 || (slices == 2 && tile_start)) { seg_first[nseg] = sub; seg_addr[nseg] = cy * wc; nseg++; }
-      orc_bw_init(&subs[sub]);
-      orc_cenc_start(&g->c, &subs[sub]);
-      /* 9.3.1: first CTB of a tile initialises; a WPP row synchronises with the state after the 2nd CTB of the row above when
-       * that CTB exists (pictures one CTB wide: it does not, the row initialises afresh); a dependent slice segment that starts
-       * anywhere else goes on with the contexts the previous segment ended with (they are still in g->c.ctx) */
-      if (tile_start || (wpp && wc < 2)) orc_cabac_init_contexts(g->c.ctx, init_type, sh->slice_qp);
-      else if (wpp) memcpy(g->c.ctx, saved, sizeof(saved));
-    }
-    for (int cx = 0; cx < wc; cx++) {
-      if (sh->sao_luma || sh->sao_chroma) {
-        orc_sao_params *sp = &g->sao[cy * wc + cx];
-        const orc_sao_params *left = cx > 0 ? sp - 1 : NULL, *up = (cy > 0 && !tile_start) ? sp - wc : NULL;
-        draw_sao(g, sp, left, up, sh->sao_luma, sh->sao_chroma);
-        orc_sao_write(&g->c, sp, left, up, sh->sao_luma, sh->sao_chroma);
+  /* 6.5.1: tile after tile (raster order of tiles), the CTBs of a tile in raster order */
+  for (int tr = 0; tr < g->nrows_t; tr++) for (int tc = 0; tc < cols; tc++) {
+    const int x0 = g->col_bd[tc], x1 = g->col_bd[tc + 1], tw = x1 - x0;
+    for (int cy = g->row_bd[tr]; cy < g->row_bd[tr + 1]; cy++) {
+      const int tile_start = cy == g->row_bd[tr], tile_end = cy + 1 == g->row_bd[tr + 1];
+      if (tile_start || row_subs) {
+        sub++;
+        if (sub == 0 || slices == 1 || (slices == 2 && tile_start)) { seg_first[nseg] = sub; seg_addr[nseg] = cy * wc + x0; nseg++; }
+        orc_bw_init(&subs[sub]);
+        orc_cenc_start(&g->c, &subs[sub]);
+        /* 9.3.1: first CTB of a tile initialises; a WPP row synchronises with the state after the 2nd CTB of the row above inside the
+         * tile when that CTB exists (tiles one CTB wide: it does not, the row initialises afresh); a dependent slice segment that
+         * starts anywhere else goes on with the contexts the previous segment ended with (they are still in g->c.ctx) */
+        if (tile_start || (wpp && tw < 2)) orc_cabac_init_contexts(g->c.ctx, init_type, sh->slice_qp);
+        else if (wpp) memcpy(g->c.ctx, saved, sizeof(saved));
       }
-      gen_coding_quadtree(g, cx * 64, cy * 64, 6, 0);
-      if (wpp && cx == 1) memcpy(saved, g->c.ctx, sizeof(saved));
-      const int last = (cy == hc - 1 && cx == wc - 1);
-      const int sub_end = cx == wc - 1 && (row_subs || tile_end);
-      const int seg_end = last || (cx == wc - 1 && (slices == 1 || (slices == 2 && tile_end)));
-      orc_cenc_terminate(&g->c, seg_end);               /* end_of_slice_segment_flag */
-      if (!seg_end && sub_end) orc_cenc_terminate(&g->c, 1);   /* end_of_subset_one_bit */
-      if (seg_end || sub_end) orc_bw_align_zero(g->c.bw);
+      for (int cx = x0; cx < x1; cx++) {
+        if (sh->sao_luma || sh->sao_chroma) {
+          orc_sao_params *sp = &g->sao[cy * wc + cx];
+          const orc_sao_params *left = cx > x0 ? sp - 1 : NULL, *up = (cy > 0 && !tile_start) ? sp - wc : NULL;
+          draw_sao(g, sp, left, up, sh->sao_luma, sh->sao_chroma);
+          orc_sao_write(&g->c, sp, left, up, sh->sao_luma, sh->sao_chroma);
+        }
+        gen_coding_quadtree(g, cx * 64, cy * 64, 6, 0);
+        if (wpp && cx == x0 + 1) memcpy(saved, g->c.ctx, sizeof(saved));
+        const int last = (tr == g->nrows_t - 1 && tc == cols - 1 && tile_end && cx == x1 - 1);
+        const int sub_end = cx == x1 - 1 && (row_subs || tile_end);
+        const int seg_end = last || (cx == x1 - 1 && (slices == 1 || (slices == 2 && tile_end)));
+        orc_cenc_terminate(&g->c, seg_end);               /* end_of_slice_segment_flag */
+        if (!seg_end && sub_end) orc_cenc_terminate(&g->c, 1);   /* end_of_subset_one_bit */
+        if (seg_end || sub_end) orc_bw_align_zero(g->c.bw);
+      }
     }
   }
   seg_first[nseg] = nsub;

@@ -41,6 +41,7 @@ typedef struct {
   int slices;                 /* slice segments per picture, the two ways Kvazaar cuts them (uvgComm video/Slices, kvazaarfilter.cpp:205-215): 0 (also -1) one
                                * slice; 1 = a DEPENDENT slice segment per CTU row (kvazaar slices=wpp; here with or without WPP); 2 = an independent
                                * slice per tile (kvazaar slices=tiles; one slice when there are no tiles) */
+  int tile_cols;              /* tile columns (uniform spacing), 1 (also -1) = none; with columns the slice forms are 0 and 2 */
 } orc_gen_config;
 
 void orc_gen_default_config(orc_gen_config *c);    /* everything random, 416x240 */

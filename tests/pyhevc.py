@@ -5,7 +5,7 @@ merge and AMVP candidate derivation, cu_qp_delta and the QpY predictor, intra mo
 syntax, deblocking decisions.  tests/test_python_decoder.py decodes the checker's and the generator's streams with it and
 compares reconstructed pictures with oracle/hevc_dec.c bit for bit.
 
-Scope: 8-bit 4:2:0, CTB 16..64, one slice per picture, I and P slices, tiles as full-width rows, WPP, every CU size and
+Scope: 8-bit 4:2:0, CTB 16..64, one slice per picture, I and P slices, tile rows and columns, WPP, every CU size and
 partitioning, transform trees, several reference pictures (short-term RPS), TMVP, cu_qp_delta, sign data hiding, transform
 skip, deblocking with offsets, SAO.  No B slices, PCM, scaling lists, long-term pictures, weighted prediction.
 Normative tables are typed here per syntax element (initValue: Tables 9-5 .. 9-37); rangeTabLps and the state transition
@@ -226,16 +226,16 @@ def parse_pps(rbsp):
         raise ValueError("weighted prediction / transquant bypass")
     p["tiles"] = r.u(1)
     p["wpp"] = r.u(1)
-    p["tile_rows"] = 1
+    p["tile_rows"] = p["tile_cols"] = 1
     p["uniform"] = 1
-    p["row_heights"] = []
+    p["row_heights"] = p["col_widths"] = []
     p["lf_tiles"] = 1
     if p["tiles"]:
-        if r.ue() != 0:
-            raise ValueError("tile columns")
+        p["tile_cols"] = r.ue() + 1
         p["tile_rows"] = r.ue() + 1
         p["uniform"] = r.u(1)
         if not p["uniform"]:
+            p["col_widths"] = [r.ue() + 1 for _ in range(p["tile_cols"] - 1)]
             p["row_heights"] = [r.ue() + 1 for _ in range(p["tile_rows"] - 1)]
         p["lf_tiles"] = r.u(1)
     p["lf_slices"] = r.u(1)
@@ -645,6 +645,17 @@ class SliceDecoder:
             bd.append(self.hc)
         self.tile_bd = bd
         self.tile_of_row = [max(i for i in range(tr) if bd[i] <= cy) for cy in range(self.hc)]
+        # tile columns
+        tcn = pps["tile_cols"]
+        if pps["uniform"]:
+            cbd = [(i * self.wc) // tcn for i in range(tcn + 1)]
+        else:
+            cbd = [0]
+            for wid in pps["col_widths"]:
+                cbd.append(cbd[-1] + wid)
+            cbd.append(self.wc)
+        self.col_bd = cbd
+        self.tile_of_col = [max(i for i in range(tcn) if cbd[i] <= cx) for cx in range(self.wc)]
         self.log2_qg = self.ctb_log2 - pps["qg_depth"]
 
     # ------------------------------------------------------------------------------------------- availability (6.4.1)
@@ -659,7 +670,7 @@ class SliceDecoder:
     def avail(self, xc, yc, xn, yn):
         if xn < 0 or yn < 0 or xn >= self.w or yn >= self.h:
             return False
-        if self.tile_of_row[yn >> self.ctb_log2] != self.tile_of_row[yc >> self.ctb_log2]:
+        if self.tile_of_row[yn >> self.ctb_log2] != self.tile_of_row[yc >> self.ctb_log2] or self.tile_of_col[xn >> self.ctb_log2] != self.tile_of_col[xc >> self.ctb_log2]:
             return False
         return self.zaddr(xn, yn) <= self.zaddr(xc, yc) and self.cu_pred[yn >> self.sps["min_cb"], xn >> self.sps["min_cb"]] >= 0
 
@@ -670,37 +681,52 @@ class SliceDecoder:
         self.c = Cabac(self.t, self.data, init_type, sh["qp"])
         c = self.c
         sub = 0
-        saved = None
-        for cy in range(self.hc):
-            tile_start = cy in self.tile_bd[:-1]
-            for cx in range(self.wc):
-                if cx == 0 and (cy > 0):
-                    if tile_start:
-                        c.init_contexts()
-                    elif pps["wpp"]:
-                        if self.wc >= 2 and saved is not None:
-                            c.load(saved)
-                        else:
-                            c.init_contexts()
-                if cx == 0 and (cy == 0 or tile_start or pps["wpp"]):
-                    self.last_qp = sh["qp"]               # 8.6.1: the first quantisation group of a slice / tile / CTB row (WPP) predicts from SliceQpY
-                self.ctu(cx, cy)
-                end = c.terminate()
-                if pps["wpp"] and cx == 1:
-                    saved = c.save()
-                last_in_row = cx == self.wc - 1
-                row_ends_sub = last_in_row and (pps["wpp"] or (cy + 1 in self.tile_bd))
-                if end:
-                    if not (cy == self.hc - 1 and last_in_row):
-                        raise ValueError("early end of slice")
-                    break
-                if row_ends_sub:
-                    if not c.terminate():
-                        raise ValueError("end_of_subset_one_bit")
-                    sub += 1
-                    c.start(self.data[self.starts[sub]:] if sub < len(self.starts) else self.data[c.end_substream():])
-            if pps["wpp"] and self.wc < 2:
+        done = False
+        ntr, ntc = pps["tile_rows"], pps["tile_cols"]
+        # 6.5.1: tile after tile, the CTBs of a tile in raster order
+        for tr in range(ntr):
+            for tc in range(ntc):
+                x0, x1 = self.col_bd[tc], self.col_bd[tc + 1]
                 saved = None
+                for cy in range(self.tile_bd[tr], self.tile_bd[tr + 1]):
+                    tile_start = cy == self.tile_bd[tr]
+                    for cx in range(x0, x1):
+                        first = tr == 0 and tc == 0 and tile_start and cx == x0
+                        if cx == x0 and not first:
+                            if tile_start:
+                                c.init_contexts()
+                            elif pps["wpp"]:
+                                if x1 - x0 >= 2 and saved is not None:
+                                    c.load(saved)
+                                else:
+                                    c.init_contexts()
+                        if cx == x0 and (tile_start or pps["wpp"]):
+                            self.last_qp = sh["qp"]       # 8.6.1: the first quantisation group of a slice / tile / CTB row (WPP) predicts from SliceQpY
+                        self.ctu(cx, cy)
+                        end = c.terminate()
+                        if pps["wpp"] and cx == x0 + 1:
+                            saved = c.save()
+                        last_in_row = cx == x1 - 1
+                        tile_ends = cy + 1 == self.tile_bd[tr + 1]
+                        row_ends_sub = last_in_row and (pps["wpp"] or tile_ends)
+                        if end:
+                            if not (tr == ntr - 1 and tc == ntc - 1 and tile_ends and last_in_row):
+                                raise ValueError("early end of slice")
+                            done = True
+                            break
+                        if row_ends_sub:
+                            if not c.terminate():
+                                raise ValueError("end_of_subset_one_bit")
+                            sub += 1
+                            c.start(self.data[self.starts[sub]:] if sub < len(self.starts) else self.data[c.end_substream():])
+                    if done:
+                        break
+                    if pps["wpp"] and x1 - x0 < 2:
+                        saved = None
+                if done:
+                    break
+            if done:
+                break
         if not sh["dbk_disabled"]:
             self.deblock()
         if sh["sao_luma"] or sh["sao_chroma"]:
@@ -715,7 +741,7 @@ class SliceDecoder:
     # ------------------------------------------------------------------------------------------- SAO syntax (7.3.8.3)
     def parse_sao(self, cx, cy):
         c = self.c
-        left = cx > 0
+        left = cx > 0 and self.tile_of_col[cx - 1] == self.tile_of_col[cx]
         up = cy > 0 and self.tile_of_row[cy - 1] == self.tile_of_row[cy]
         if left and c.bin("sao_merge"):
             self.sao[(cx, cy)] = self.sao[(cx - 1, cy)]

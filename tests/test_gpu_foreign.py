@@ -165,3 +165,20 @@ def test_lost_slice_segments(gpu, frame):
             assert t in got and np.array_equal(got[t], refs[t]), t
     assert len(got) < pictures                                      # the damaged pictures did not come out as if nothing had happened
     gd.close(); od.close(); g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cols,rows,wpp,slices,frame,uniform", [(2, 1, 0, 0, False, 1), (2, 2, 1, 0, False, 1), (3, 2, 0, 2, False, 1), (4, 3, 1, 2, False, 0), (2, 2, 1, 0, True, 1),
+                                                               (5, 1, 1, 0, False, 1), (2, 2, 0, 2, True, 1)])
+def test_tile_columns(gpu, cols, rows, wpp, slices, frame, uniform):
+    """uvgComm video/Tiles with its tile dimension defaults ("2x2" .. "16x16", defaultsettings.cpp:283-324): a Kvazaar peer sends tile grids
+    with columns.  CTBs in tile-scan order, contexts and WPP hand-over per tile, nothing available across a tile boundary, one substream
+    per tile (or per CTB row of a tile with WPP), optionally a slice per tile."""
+    run_stream(328, 264, 8, threads=3 if frame else 1, frame_threads=frame, seed=5, density=30, num_refs=2, tmvp=1, sao=1, qp_delta=2, intra_in_p=20, cabac_init=1,
+               tile_cols=cols, tile_rows=rows, wpp=wpp, slices=slices, uniform_tiles=uniform)
+
+
+@pytest.mark.gpu
+def test_tile_grid_1080p(gpu):
+    """1080p in 4 x 4 tiles with WPP inside the tiles (68 substreams per picture), a slice per tile"""
+    run_stream(1920, 1080, 4, seed=6, density=25, num_refs=2, tmvp=1, wpp=1, tile_cols=4, tile_rows=4, slices=2, intra_in_p=10, max_cu_log2=5, sao=1)

@@ -117,3 +117,14 @@ def test_generator_everything_on():
     aus = [gen.picture() for _ in range(6)]
     gen.close()
     compare(aus)
+
+
+@pytest.mark.parametrize("cols,rows,wpp,uniform", [(2, 1, 0, 1), (2, 2, 1, 1), (3, 2, 0, 1), (4, 3, 1, 0), (5, 1, 1, 1)])
+def test_generator_tile_columns(cols, rows, wpp, uniform):
+    """tile grids with columns (what a Kvazaar peer with uvgComm's tile dimension defaults sends): tile-scan order, contexts and the WPP
+    hand-over per tile, nothing available across a tile boundary -- read here from the standard's text, independently of the checker"""
+    gen = orc.OracleGen(width=328, height=264, seed=5, density=30, num_refs=2, tmvp=1, sao=1, qp_delta=2, intra_in_p=20, cabac_init=1,
+                        tile_cols=cols, tile_rows=rows, wpp=wpp, uniform_tiles=uniform)
+    aus = [gen.picture() for _ in range(4)]
+    gen.close()
+    compare(aus)

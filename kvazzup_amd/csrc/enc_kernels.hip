@@ -98,10 +98,14 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
   uint32_t best[5] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
   // tile constraint (statement: me_block32() in oracle/hevc_enc.c): the displaced 32x32 block, plus 4 rows each side for
   // the chroma half-sample taps when the displacement is odd, stays inside its tile -- except across the picture's own edges
-  int ty0 = 0, ty1 = f.ch;
+  int ty0 = 0, ty1 = f.ch, tx0 = 0, tx1 = f.cw;
   if (f.tile_rows > 1) {
     const int hc = f.ch >> 6, tr = tile_row_of(hc, f.tile_rows, y0 >> 6);
     ty0 = tile_row_first(hc, f.tile_rows, tr) * 64; ty1 = tile_row_first(hc, f.tile_rows, tr + 1) * 64;
+  }
+  if (f.tile_cols > 1) {                                       // ... and in x with tile columns
+    const int wc = f.cw >> 6, tc = tile_col_of(wc, f.tile_cols, x0 >> 6);
+    tx0 = tile_col_first(wc, f.tile_cols, tc) * 64; tx1 = tile_col_first(wc, f.tile_cols, tc + 1) * 64;
   }
   const int NQ = (W + 3) >> 2, NG = (W + 1) >> 1;
   for (int item = tid; item < NQ * NG; item += nthreads) {
@@ -147,6 +151,7 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
       for (int k4 = 0; k4 < 4; k4++) {
         const int dxi = 4 * q + k4;
         if (dxi >= W) continue;
+        { const int dx = dxi - R, m = (dx & 1) ? 4 : 0; if ((tx0 > 0 && x0 + dx - m < tx0) || (tx1 < f.cw && x0 + dx + 32 + m > tx1)) continue; }
         if (f.mv_frame) { const int dx = dxi - R, mx = (f.mv_frame == 2 && (dx & 1)) ? 4 : 0; if (x0 + dx - mx < 0 || x0 + dx + 32 + mx > f.cw) continue; }
         const uint32_t cand = (uint32_t)(dyi * W + dxi);
         const uint32_t rate = (lam * (uint32_t)(mvd_bits((dxi - R) * 4) + ry)) >> 4;
@@ -666,7 +671,7 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
     if (e < 16 * 33) { b = e / 33; i = e - b * 33; l2 = 3; } else { int r = e - 16 * 33; b = 16 + r / 65; i = r % 65; l2 = 4; }
     const int n = 1 << l2, bi = b < 16 ? b : b - 16, nb = 32 >> l2;
     const int x0 = X0 + (bi % nb) * n, y0 = Y0 + (bi / nb) * n;
-    const bool aL = x0 > 0, aT = avail64(f.cw, f.chp, x0, y0, x0, y0 - 1);
+    const bool aL = avail64(f.cw, f.chp, x0, y0, x0 - 1, y0), aT = avail64(f.cw, f.chp, x0, y0, x0, y0 - 1);
     const bool aBL = aL && avail64(f.cw, f.chp, x0, y0, x0 - 1, y0 + n), aTR = aT && avail64(f.cw, f.chp, x0, y0, x0 + n, y0 - 1);
     const int lo = aBL ? 0 : (aL ? n : 2 * n + 1), hi = aTR ? 4 * n : (aT ? 3 * n : (aL ? 2 * n - 1 : -1));
     int v = 128;
@@ -842,7 +847,8 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   const int qpl = ctu_quant_qp(f, cx * 64, row * 64), qp = c ? kChromaQp[qpl] : qpl;
   const int hc = f.ch >> 6;
   IntraNeighbours nb;
-  nb.nb_up = row > 0 && !tile_row_starts_at(hc, f.tile_rows, row); nb.nb_left = cx > 0; nb.nb_ur = nb.nb_up && cx + 1 < wc; nb.nb_ul = nb.nb_up && cx > 0;
+  nb.nb_up = row > 0 && !tile_row_starts_at(hc, f.tile_rows, row); nb.nb_left = cx > 0 && !tile_col_starts_at(wc, f.tile_cols, cx);
+  nb.nb_ur = nb.nb_up && cx + 1 < wc && !tile_col_starts_at(wc, f.tile_cols, cx + 1); nb.nb_ul = nb.nb_up && nb.nb_left;
   nb.pl = my - 3; nb.pu = my - 3 * wc; nb.pur = nb.pu + 3; nb.pul = nb.pu - 3;
   chain_init(ch, nb, 0u, 0u);
   // ---- everything the chain needs to know about the CTU's coding units, one lane per 8x8 unit (z-order), compacted into a list
@@ -855,7 +861,7 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     const uint64_t starts = __ballot(start);
     const int k = __popcll(starts & ((1ull << lane) - 1ull));
     if (start) {
-      const bool aL = X > 0, aT = avail64(f.cw, f.chp, X, Y, X, Y - 1);
+      const bool aL = avail64(f.cw, f.chp, X, Y, X - 1, Y), aT = avail64(f.cw, f.chp, X, Y, X, Y - 1);
       const bool aBL = aL && avail64(f.cw, f.chp, X, Y, X - 1, Y + nl), aTR = aT && avail64(f.cw, f.chp, X, Y, X + nl, Y - 1);
       IntraBlk d;
       d.rx = (uint8_t)((zx * 8) >> sh); d.ry = (uint8_t)((zy * 8) >> sh);
@@ -947,15 +953,19 @@ __global__ __launch_bounds__(256) void k_qp_chain(EncFrame f)                // 
   const int wc = f.cw >> 6, hc = f.ch >> 6, t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= wc * band_rows(f)) return;
   const int ctu = t + f.row0 * wc, cx = ctu % wc, cy = ctu / wc;
-  // QpY of the nearest CTU at or before this one in its chain that codes a delta; the chain starts at the CTU row (WPP) or the tile
+  // QpY of the nearest CTU at or before this one in its chain that codes a delta; the chain runs in decoding order (tile scan) and
+  // starts at the CTU row of the tile (WPP) or at the tile
+  const int tc = tile_col_of(wc, f.tile_cols, cx), cx0 = tile_col_first(wc, f.tile_cols, tc), cx1 = tile_col_first(wc, f.tile_cols, tc + 1);
   const int first_cy = f.wpp ? cy : tile_row_first(hc, f.tile_rows, tile_row_of(hc, f.tile_rows, cy));
   int qy = f.qp, prev = f.qp; bool have = false, have_prev = false;
-  for (int c = ctu; c >= first_cy * wc; c--) {
-    if (f.ctu_first[c] < 64) {
-      if (c == ctu) { qy = f.ctu_qt[c]; have = true; }
-      else { prev = f.ctu_qt[c]; have_prev = true; break; }
+  for (int y = cy, x = cx; y >= first_cy && !have_prev; y--, x = cx1 - 1)
+    for (; x >= cx0; x--) {
+      const int c = y * wc + x;
+      if (f.ctu_first[c] < 64) {
+        if (c == ctu) { qy = f.ctu_qt[c]; have = true; }
+        else { prev = f.ctu_qt[c]; have_prev = true; break; }
+      }
     }
-  }
   (void)have_prev;
   if (!have) qy = prev;
   f.ctu_qy[ctu] = (int8_t)qy;
@@ -1263,7 +1273,7 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
       if (f.sao && z4 == 0 && k == 0) {                 // coding_tree_unit() starts with sao()
         const SaoParams sp = f.sao[ctu];
         SaoParams sl, su;
-        const bool hl = cx > 0, hu = cy > 0 && !tile_row_starts_at(hc, f.tile_rows, cy);
+        const bool hl = cx > 0 && !tile_col_starts_at(wc, f.tile_cols, cx), hu = cy > 0 && !tile_row_starts_at(hc, f.tile_rows, cy);
         if (hl) sl = f.sao[ctu - 1];
         if (hu) su = f.sao[ctu - wc];
         enc_sao(t, sp, hl ? &sl : nullptr, hu ? &su : nullptr);
@@ -1344,8 +1354,9 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
   }
   if (z4 == 15 && comp == 0) {                                      // the last unit of the CTU closes it
     const bool last = (cy == hc - 1 && cx == wc - 1);
-    const bool sub_end = cx == wc - 1 && (f.wpp || tile_row_ends_at(hc, f.tile_rows, cy));
-    const bool seg_end = last || (cx == wc - 1 && (f.slices == 1 || (f.slices == 2 && tile_row_ends_at(hc, f.tile_rows, cy))));   // slice segments per CTU row / per tile
+    const bool row_end = tile_col_ends_at(wc, f.tile_cols, cx);                                   // last CTU of its row inside the tile
+    const bool sub_end = row_end && (f.wpp || tile_row_ends_at(hc, f.tile_rows, cy));
+    const bool seg_end = last || (row_end && (f.slices == 1 || (f.slices == 2 && tile_row_ends_at(hc, f.tile_rows, cy))));   // slice segments per CTU row / per tile
     const int n = 1 + ((sub_end && !seg_end) ? 1 : 0);
     __syncthreads();
     np = 16;

@@ -30,7 +30,8 @@ struct EncoderConfig {
   // Tile-row split of one picture over several encoder instances (one per GPU): this instance codes CTU
   // rows [band_row0, band_row0 + band_rows) only -- whole tiles -- through band_phase1 / halo exchange / band_phase2.
   int band_row0 = 0, band_rows = 0;   // band_rows == 0: the whole picture (normal operation)
-  int tile_rows = 1;          // full-width tile rows (kvazaar "tiles" 1xN), uniform spacing, loop filter across tiles on
+  int tile_rows = 1;          // tile rows (kvazaar "tiles" CxR: R), uniform spacing, loop filter across tiles on
+  int tile_cols = 1;          // tile columns (C); band mode needs 1
   int device = 0;
   int entropy_threads = 16;   // host threads of the arithmetic-coding stage
   int qp_in_cu = 0;           // kvazaar "set-qp-in-cu": cu_qp_delta_enabled_flag; a delta-QP map (set_roi, kvz_picture.roi) then gives every CTU its own QP

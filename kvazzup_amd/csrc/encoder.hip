@@ -34,7 +34,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   EncoderConfig cfg = cfg_in;
   if (cfg.vaq > 0) cfg.qp_in_cu = 1;                       // the deltas travel as cu_qp_delta
   if (cfg.bitrate <= 0 || cfg.band_rows > 0) cfg.rc_bands = 0;
-  if ((cfg.slices == 1 && !cfg.wpp) || (cfg.slices == 2 && cfg.tile_rows < 2) || cfg.slices < 0 || cfg.slices > 2) cfg.slices = 0;
+  if ((cfg.slices == 1 && !cfg.wpp) || (cfg.slices == 2 && cfg.tile_rows * cfg.tile_cols < 2) || (cfg.slices == 1 && cfg.tile_cols > 1) || cfg.slices < 0 || cfg.slices > 2) cfg.slices = 0;
   if (cfg.rc_bands > 0) cfg.qp_in_cu = 1;                  // ... and so do the steps of rate control v2
 
   const char *prio = getenv("KVAZZUP_AMD_PRIO"); if (!prio || strlen(prio) < 4) prio = "hnnn";   // main, tokenizer, input, decoder: the chain the next picture waits for is the urgent one (+6 % at 1080p; any explicit priority also gives the stream a hardware queue of its own)
@@ -43,7 +43,11 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     if (error) *error = "unsupported picture size"; return false;
   }
   if (cfg.qp < 0 || cfg.qp > 51 || cfg.me_range < 1 || cfg.me_range > 32) { if (error) *error = "qp or me-range out of range"; return false; }
-  if (cfg.tile_rows < 1 || cfg.tile_rows > (cfg.height + 63) / 64) { if (error) *error = "tile rows out of range"; return false; }
+  if (cfg.tile_cols < 1) cfg.tile_cols = 1;
+  if (cfg.tile_rows < 1 || cfg.tile_rows > (cfg.height + 63) / 64 || cfg.tile_rows > 22 || cfg.tile_cols > 20 || cfg.tile_cols > (cfg.width + 63) / 64 || (cfg.band_rows > 0 && cfg.tile_cols > 1)) {
+    if (error) *error = "tile grid out of range (at most 20 x 22 tiles, none smaller than a CTU; band mode: full-width tile rows)"; return false;
+  }
+  if (cfg.tile_cols > 1) cfg.entropy_gpu = 0;                // (k_cabac_rows runs full-width substreams)
   if (cfg.band_rows > 0) {
     const int hc = (cfg.height + 63) / 64, T = cfg.tile_rows;
     const bool ok = cfg.band_row0 >= 0 && cfg.band_row0 + cfg.band_rows <= hc && tile_row_starts_at(hc, T, cfg.band_row0) &&
@@ -168,7 +172,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
 
   memset(&f_, 0, sizeof(f_));
   f_.cw = cw_; f_.ch = ch_; f_.b8w = cw_ / 8; f_.b8h = ch_ / 8;
-  f_.tile_rows = cfg.tile_rows; f_.chp = pack_height(ch_, cfg.tile_rows);
+  f_.tile_rows = cfg.tile_rows; f_.tile_cols = cfg.tile_cols; f_.chp = pack_height(ch_, cfg.tile_rows, cfg.tile_cols);
   f_.row0 = cfg.band_rows > 0 ? cfg.band_row0 : 0; f_.nrows = cfg.band_rows > 0 ? cfg.band_rows : 0;
   f_.qp = cfg.qp; f_.qpc = kChromaQp[cfg.qp]; f_.lambda_q4 = kLambdaQ4[cfg.qp]; f_.range = cfg.me_range;
   f_.wpp = cfg.wpp; f_.mv_frame = cfg.mv_frame; f_.me_early = cfg.me_early; f_.satd = cfg.satd; f_.subme = cfg.subme; f_.slices = cfg.slices;
@@ -180,7 +184,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   f_.tok_dense_cap = (uint32_t)tok_dense_cap_;
   f_.sync = sync_; f_.err = err_; f_.trace = trace_; f_.intra_order = intra_order_;
 
-  sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp; sp_.tile_rows = cfg.tile_rows; sp_.qp_in_cu = cfg.qp_in_cu; sp_.sao = cfg.sao; sp_.slices = cfg.slices;
+  sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp; sp_.tile_rows = cfg.tile_rows; sp_.tile_cols = cfg.tile_cols; sp_.qp_in_cu = cfg.qp_in_cu; sp_.sao = cfg.sao; sp_.slices = cfg.slices;
   sp_.deblock = cfg.deblock; sp_.fps_num = cfg.fps_num; sp_.fps_den = cfg.fps_den;
   HIP_OK(hipStreamSynchronize(stream_));
   HIP_OK(hipDeviceSynchronize());
@@ -485,7 +489,7 @@ bool Encoder::finish_slot(Slot &sl, EncodedPicture *out, int worker)
     sl.ev_used = 0;
   }
   // ---- serial half of entropy coding: host threads turn the bins into the WPP substreams
-  const int nsub = cfg_.wpp ? rows_ : cfg_.tile_rows;
+  const int nsub = (cfg_.wpp ? rows_ : cfg_.tile_rows) * cfg_.tile_cols;
   uint64_t bins = 0;
   Tick tk_ar;
   std::vector<std::vector<uint8_t>> &rows_out = worker ? rows_out2_ : rows_out_;
@@ -501,7 +505,7 @@ bool Encoder::finish_slot(Slot &sl, EncodedPicture *out, int worker)
   } else {
     for (int i = 0, n = (cw_ / 64) * rows_; i < n; i++) if (sl.h_tok_count[i] < 0) { fprintf(stderr, "kvazzup_amd: token array overflow (CTU %d)\n", i); return false; }
     EntropyHost *coder = worker ? entropy2_ : entropy_;
-    coder->code_picture(sl.h_tok_dense, sl.h_tok_count, sl.h_tok_off, cw_ / 64, rows_, cfg_.wpp != 0, cfg_.tile_rows, sl.intra ? 0 : 1, sl.qp, rows_out, &bins);
+    coder->code_picture(sl.h_tok_dense, sl.h_tok_count, sl.h_tok_off, cw_ / 64, rows_, cfg_.wpp != 0, cfg_.tile_rows, sl.intra ? 0 : 1, sl.qp, rows_out, &bins, cfg_.tile_cols);
   }
   const double ar = tk_ar.ms();
   if (profiling_ && !cfg_.entropy_gpu) { std::lock_guard<std::mutex> l(stat_m_); k_ms_[K_HOST_ARITH] += ar; k_n_[K_HOST_ARITH]++; }

@@ -76,15 +76,17 @@ class EntropyHost {
   // Codes one picture.  tokens: dense token array; CTU i has count[i] tokens starting at offset[i].
   // rows_out[r] receives the bytes of substream r (one per CTU row with WPP, else a single one).
   void code_picture(const uint16_t *tokens, const int32_t *count, const uint32_t *offset, int wc, int hc, bool wpp, int tile_rows, int init_type, int qp,
-                    std::vector<std::vector<uint8_t>> &rows_out, uint64_t *bins)
+                    std::vector<std::vector<uint8_t>> &rows_out, uint64_t *bins, int tile_cols = 1)
   {
     tokens_ = tokens; count_ = count; offset_ = offset; wc_ = wc; hc_ = hc; wpp_ = wpp; tiles_ = tile_rows < 1 ? 1 : tile_rows; init_type_ = init_type; qp_ = qp;
-    const int nsub = wpp ? hc : tiles_;
+    cols_ = tile_cols < 1 ? 1 : tile_cols;
+    build_geometry();
+    const int nsub = (int)geom_.size();
     rows_out.resize((size_t)nsub);
     rows_ = &rows_out;
-    saved_.resize((size_t)hc * CTX_COUNT);
-    ready_.reset(new std::atomic<int>[(size_t)hc]);
-    for (int r = 0; r < hc; r++) ready_[(size_t)r].store(0, std::memory_order_relaxed);
+    saved_.resize((size_t)hc * cols_ * CTX_COUNT);
+    ready_.reset(new std::atomic<int>[(size_t)hc * cols_]);
+    for (int r = 0; r < hc * cols_; r++) ready_[(size_t)r].store(0, std::memory_order_relaxed);
     bins_.store(0);
     run_rows(nsub, 0);
     if (bins) *bins = bins_.load();
@@ -95,6 +97,8 @@ class EntropyHost {
                  int row0, int nrows, std::vector<std::vector<uint8_t>> &rows_out, uint64_t *bins)
   {
     tokens_ = tokens; count_ = count; offset_ = offset; wc_ = wc; hc_ = hc; wpp_ = wpp; tiles_ = tile_rows < 1 ? 1 : tile_rows; init_type_ = init_type; qp_ = qp;
+    cols_ = 1;                                       // (bands are whole tile rows of full-width tiles)
+    build_geometry();
     const int first = wpp ? row0 : tile_row_of(hc, tiles_, row0);
     const int nsub = wpp ? nrows : tile_row_of(hc, tiles_, row0 + nrows - 1) - first + 1;
     all_rows_.resize((size_t)(wpp ? hc : tiles_));
@@ -121,32 +125,48 @@ class EntropyHost {
     if (ntok < 16000) { for (int k = 0; k < nsub; k++) code_row(first + k); }
     else pool_.run(nsub, [this, first](int k) { code_row(first + k); });
   }
-  // substream r: CTU row r with WPP, else tile row r (all of its CTU rows)
+  // the substreams in decoding order (6.5.1 tile scan: tile after tile; with WPP every CTU row of a tile is one)
+  struct Sub { int cy0, cy1, cx0, cx1, tile_cy0, tc; };
+  void build_geometry()
+  {
+    geom_.clear();
+    for (int tr = 0; tr < tiles_; tr++)
+      for (int tc = 0; tc < cols_; tc++) {
+        Sub g; g.tile_cy0 = tile_row_first(hc_, tiles_, tr); g.cx0 = tile_col_first(wc_, cols_, tc); g.cx1 = tile_col_first(wc_, cols_, tc + 1); g.tc = tc;
+        const int tile_cy1 = tile_row_first(hc_, tiles_, tr + 1);
+        if (wpp_) for (int cy = g.tile_cy0; cy < tile_cy1; cy++) { g.cy0 = cy; g.cy1 = cy + 1; geom_.push_back(g); }
+        else { g.cy0 = g.tile_cy0; g.cy1 = tile_cy1; geom_.push_back(g); }
+      }
+  }
+  // substream r of the geometry list: a CTU row of a tile with WPP, else a tile
   void code_row(int r)
   {
     uint8_t ctx[CTX_COUNT];
     std::vector<uint8_t> &out = (*rows_)[(size_t)r];
-    const int first_cy = wpp_ ? r : tile_row_first(hc_, tiles_, r), ncy = wpp_ ? 1 : tile_row_first(hc_, tiles_, r + 1) - first_cy;
+    const Sub g = geom_[(size_t)r];
     size_t ntok = 0;
-    for (int cy = first_cy; cy < first_cy + ncy; cy++) for (int cx = 0; cx < wc_; cx++) ntok += (size_t)count_[(size_t)cy * wc_ + cx];
+    for (int cy = g.cy0; cy < g.cy1; cy++) for (int cx = g.cx0; cx < g.cx1; cx++) ntok += (size_t)count_[(size_t)cy * wc_ + cx];
     out.resize(ntok * 2 + 64);                    // a token never produces more than two bytes
     CabacEnc c; c.nbins = 0;
     cabac_start(c, out.data(), (int)out.size(), ctx, &tabs_);
-    // contexts: initialised at the first CTU of a tile (9.3.1), else (WPP) inherited from the row above after its second CTU
-    const bool fresh = !wpp_ || tile_row_starts_at(hc_, tiles_, r);
+    // contexts: initialised at the first CTU of a tile (9.3.1), else (WPP) inherited from the row above inside the tile after its second
+    // CTU -- when the tile is at least two CTUs wide
+    const bool fresh = !wpp_ || g.cy0 == g.tile_cy0 || g.cx1 - g.cx0 < 2;
     if (fresh) cabac_init_contexts(ctx, init_type_, qp_);
     else {
       // (the row above is already running -- tasks are handed out in order -- and needs two CTUs' worth of time)
-      for (int spins = 0; !ready_[(size_t)(r - 1)].load(std::memory_order_acquire);) { if (++spins < 4000) __builtin_ia32_pause(); else std::this_thread::yield(); }
-      memcpy(ctx, &saved_[(size_t)(r - 1) * CTX_COUNT], CTX_COUNT);
+      const size_t above = (size_t)(g.cy0 - 1) * cols_ + g.tc;
+      for (int spins = 0; !ready_[above].load(std::memory_order_acquire);) { if (++spins < 4000) __builtin_ia32_pause(); else std::this_thread::yield(); }
+      memcpy(ctx, &saved_[above * CTX_COUNT], CTX_COUNT);
     }
-    for (int cy = first_cy; cy < first_cy + ncy; cy++)
-      for (int cx = 0; cx < wc_; cx++) {
+    for (int cy = g.cy0; cy < g.cy1; cy++)
+      for (int cx = g.cx0; cx < g.cx1; cx++) {
         const size_t ctu = (size_t)cy * wc_ + cx;
         cabac_play_tokens_host(c, htabs_, tokens_ + offset_[ctu], count_[ctu]);
-        if (wpp_ && cx == 1) {
-          memcpy(&saved_[(size_t)r * CTX_COUNT], ctx, CTX_COUNT);
-          ready_[(size_t)r].store(1, std::memory_order_release);
+        if (wpp_ && cx == g.cx0 + 1) {
+          const size_t me = (size_t)cy * cols_ + g.tc;
+          memcpy(&saved_[me * CTX_COUNT], ctx, CTX_COUNT);
+          ready_[me].store(1, std::memory_order_release);
         }
       }
     cabac_finish(c);
@@ -158,7 +178,8 @@ class EntropyHost {
   CoreTabs tabs_;
   HostCabacTabs htabs_;
   const uint16_t *tokens_ = nullptr; const int32_t *count_ = nullptr; const uint32_t *offset_ = nullptr;
-  int wc_ = 0, hc_ = 0, tiles_ = 1, init_type_ = 0, qp_ = 0; bool wpp_ = true;
+  int wc_ = 0, hc_ = 0, tiles_ = 1, cols_ = 1, init_type_ = 0, qp_ = 0; bool wpp_ = true;
+  std::vector<Sub> geom_;
   std::vector<uint8_t> saved_;
   std::unique_ptr<std::atomic<int>[]> ready_;
   std::vector<std::vector<uint8_t>> *rows_ = nullptr;

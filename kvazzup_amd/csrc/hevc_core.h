@@ -44,9 +44,10 @@ struct EncFrame {
   int subme;                // fractional-sample refinement level 0..4 (k_subpel)
   int slices;               // 1: a slice segment ends with every CTU row, 2: with every tile (kvazaar slices=wpp / tiles): what k_tokenize closes a CTU with
   int mv_frame;             // mv-constraint: 0 none, 1 the displaced block stays inside the picture, 2 the same with a 4-sample margin on odd displacements
-  int tile_rows;            // 1: no tiles; n: n full-width tile rows, uniform spacing (6.5.1)
+  int tile_rows;            // 1: no tiles; n: n tile rows, uniform spacing (6.5.1)
+  int tile_cols;            // 1: full-width tiles; n: n tile columns, uniform spacing
   int row0, nrows;          // band of CTU rows the encoder kernels work on (nrows == 0: the whole picture); a band starts and ends on tile boundaries
-  int chp;                  // ch | tile rows << 20: the `ch` argument of avail64() and of everything that forwards to it
+  int chp;                  // ch | tile rows << 20 | tile columns << 26: the `ch` argument of avail64() and of everything that forwards to it
   const uint8_t *src[3];
   uint8_t *rec[3];
   const uint8_t *ref[3];
@@ -106,13 +107,19 @@ KVZ_HD int tile_row_of(int hc, int T, int cy) { return ((cy + 1) * T - 1) / hc; 
 KVZ_HD int tile_row_first(int hc, int T, int i) { return (i * hc) / T; }
 KVZ_HD bool tile_row_starts_at(int hc, int T, int cy) { return T <= 1 ? cy == 0 : tile_row_first(hc, T, tile_row_of(hc, T, cy)) == cy; }
 KVZ_HD bool tile_row_ends_at(int hc, int T, int cy) { return T <= 1 ? cy == hc - 1 : (cy == hc - 1 || tile_row_of(hc, T, cy + 1) != tile_row_of(hc, T, cy)); }
-KVZ_HD int pack_height(int ch, int tile_rows) { return ch | ((tile_rows > 1 ? tile_rows : 0) << 20); }
-// H.265 6.4.1 for one slice; chp = coded height | tile rows << 20 (pack_height): a neighbour in another tile is unavailable
+// ... and the same for columns
+KVZ_HD int tile_col_of(int wc, int C, int cx) { return C <= 1 ? 0 : ((cx + 1) * C - 1) / wc; }
+KVZ_HD int tile_col_first(int wc, int C, int j) { return C <= 1 ? (j ? wc : 0) : (j * wc) / C; }
+KVZ_HD bool tile_col_starts_at(int wc, int C, int cx) { return C <= 1 ? cx == 0 : tile_col_first(wc, C, tile_col_of(wc, C, cx)) == cx; }
+KVZ_HD bool tile_col_ends_at(int wc, int C, int cx) { return C <= 1 ? cx == wc - 1 : (cx == wc - 1 || tile_col_of(wc, C, cx + 1) != tile_col_of(wc, C, cx)); }
+KVZ_HD int pack_height(int ch, int tile_rows, int tile_cols = 1) { return ch | ((tile_rows > 1 || tile_cols > 1 ? tile_rows : 0) << 20) | ((tile_cols > 1 ? tile_cols : 0) << 26); }
+// H.265 6.4.1 for one slice; chp = coded height | tile rows << 20 | tile columns << 26 (pack_height): a neighbour in another tile is unavailable
 KVZ_HD bool avail64(int cw, int chp, int xc, int yc, int xn, int yn)
 {
-  const int ch = chp & 0xfffff, T = chp >> 20;
+  const int ch = chp & 0xfffff, T = (chp >> 20) & 63, C = (chp >> 26) & 31;
   if (xn < 0 || yn < 0 || xn >= cw || yn >= ch) return false;
   if (T > 1 && tile_row_of(ch >> 6, T, yn >> 6) != tile_row_of(ch >> 6, T, yc >> 6)) return false;
+  if (C > 1 && tile_col_of(cw >> 6, C, xn >> 6) != tile_col_of(cw >> 6, C, xc >> 6)) return false;
   return zaddr64(xn, yn, cw >> 6) <= zaddr64(xc, yc, cw >> 6);
 }
 

@@ -28,7 +28,8 @@ struct StreamParams {
   int qp, wpp, deblock;
   int fps_num, fps_den;
   int qp_in_cu = 0;         // cu_qp_delta_enabled_flag with diff_cu_qp_delta_depth 0 (quantisation group = CTU)
-  int tile_rows = 1;        // > 1: tiles_enabled_flag, one column, uniform spacing, loop filter across tiles on
+  int tile_rows = 1;        // tile_rows * tile_cols > 1: tiles_enabled_flag, uniform spacing, loop filter across tiles on
+  int tile_cols = 1;
   int sao = 0;              // sample_adaptive_offset_enabled_flag; every slice: slice_sao_luma_flag = slice_sao_chroma_flag = 1
   int slices = 0;           // kvazaar slices: 1 = "wpp", a dependent slice segment per CTU row (dependent_slice_segments_enabled_flag); 2 = "tiles", a slice per tile
 };
@@ -92,8 +93,8 @@ inline void write_pps(BitWriter &w, const StreamParams &s)
   if (s.qp_in_cu) w.ue(0);                                       // diff_cu_qp_delta_depth
   w.se(0); w.se(0); w.bit(0);
   w.bit(0); w.bit(0); w.bit(0);
-  w.bit(s.tile_rows > 1); w.bit(s.wpp);                          // tiles, entropy_coding_sync
-  if (s.tile_rows > 1) { w.ue(0); w.ue((uint32_t)s.tile_rows - 1); w.bit(1); w.bit(1); }   // columns - 1, rows - 1, uniform spacing, loop filter across tiles
+  w.bit(s.tile_rows > 1 || s.tile_cols > 1); w.bit(s.wpp);       // tiles, entropy_coding_sync
+  if (s.tile_rows > 1 || s.tile_cols > 1) { w.ue((uint32_t)s.tile_cols - 1); w.ue((uint32_t)s.tile_rows - 1); w.bit(1); w.bit(1); }   // columns - 1, rows - 1, uniform spacing, loop filter across tiles
   w.bit(1);                                                      // loop filter across slices
   w.bit(!s.deblock);
   if (!s.deblock) { w.bit(0); w.bit(1); }
@@ -134,7 +135,7 @@ inline void write_slice_header(BitWriter &w, const StreamParams &s, bool idr, in
     // (deblocking override not enabled; slice_loop_filter_across_slices_enabled_flag present when deblocking or SAO is on)
     if (s.deblock || s.sao) w.bit(1);
   }
-  if (s.wpp || s.tile_rows > 1) {
+  if (s.wpp || s.tile_rows > 1 || s.tile_cols > 1) {
     w.ue((uint32_t)entry_sizes.size());
     if (!entry_sizes.empty()) {
       uint32_t mx = 0; for (uint32_t e : entry_sizes) if (e - 1 > mx) mx = e - 1;
@@ -174,15 +175,18 @@ inline void assemble_access_unit(std::vector<uint8_t> &au, const StreamParams &s
   // slice segments, one NAL unit each: the whole picture; or (slices 1, WPP) a dependent slice segment per CTU row; or (slices 2) an
   // independent slice per tile -- the tile's CTU rows with WPP, else its one substream
   const int hc = sp.ch / 64, wc = sp.cw / 64;
-  for (int s0 = 0; s0 < nsub;) {
-    int n = nsub - s0, addr = -1;
-    if (sp.slices == 1) { n = 1; if (s0) addr = s0 * wc; }
-    else if (sp.slices == 2) {
-      int t, r;
-      if (sp.wpp) { r = s0; t = tile_row_of(hc, sp.tile_rows, r); n = tile_row_first(hc, sp.tile_rows, t + 1) - r; }
-      else { t = s0; r = tile_row_first(hc, sp.tile_rows, t); n = 1; }
-      if (s0) addr = r * wc;
+  // the substreams come in decoding order (tile scan): for each, whether it starts a tile and its first CTB
+  std::vector<int> tile_first, addr_of;
+  for (int tr = 0; tr < sp.tile_rows; tr++)
+    for (int tc = 0; tc < sp.tile_cols; tc++) {
+      const int cy0 = tile_row_first(hc, sp.tile_rows, tr), cy1 = tile_row_first(hc, sp.tile_rows, tr + 1), cx0 = tile_col_first(wc, sp.tile_cols, tc);
+      for (int cy = cy0; cy < (sp.wpp ? cy1 : cy0 + 1); cy++) { tile_first.push_back(cy == cy0); addr_of.push_back(cy * wc + cx0); }
     }
+  if ((int)tile_first.size() != nsub) return;                      // (the caller's substream count does not fit the tiling)
+  for (int s0 = 0; s0 < nsub;) {
+    int n = nsub - s0, addr = s0 ? addr_of[(size_t)s0] : -1;
+    if (sp.slices == 1) n = 1;
+    else if (sp.slices == 2) { n = 1; while (s0 + n < nsub && !tile_first[(size_t)(s0 + n)]) n++; }
     std::vector<uint32_t> entry;
     for (int r = 0; r + 1 < n; r++) entry.push_back((uint32_t)escaped_size(rows[(size_t)(s0 + r)].data(), rows[(size_t)(s0 + r)].size()));
     BitWriter sh;

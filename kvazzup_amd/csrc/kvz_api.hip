@@ -101,11 +101,8 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
   if (n == "tiles") {
     int a = 0, b = 0;
     if (sscanf(value, "%dx%d", &a, &b) != 2 || a < 1 || b < 1) return 0;
-    // Tile ROWS (1xN, uniform spacing) are implemented, tile columns are not.  A grid with columns -- uvgComm's tile dimension
-    // defaults are "2x2" .. "16x16" (src/ui/settings/defaultsettings.cpp:283-324) -- is coded as the same NUMBER of tiles, all of
-    // them full-width rows (capped at one tile per CTU row in encoder_open): a valid stream with the parallelism and the
-    // resynchronisation points asked for, instead of no stream.
-    if (a > 1) { fprintf(stderr, "kvazzup_amd: tiles=%dx%d: tile columns are not implemented, coding %d full-width tile rows instead\n", a, b, a * b); b = a * b; a = 1; }
+    // kvazaar tiles=CxR: C columns x R rows, uniform spacing (at most 20 x 22, checked against the picture size in encoder_open)
+    if (a > 20 || b > 22) return 0;
     cfg->tiles_width_count = a; cfg->tiles_height_count = b;
     return 1;
   }
@@ -251,13 +248,15 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
 {
   if (!cfg) return nullptr;
   if (cfg->lossless) { fprintf(stderr, "kvazzup_amd: lossless coding is not implemented\n"); return nullptr; }
-  if (cfg->tiles_width_count > 1) { fprintf(stderr, "kvazzup_amd: tile columns are not implemented (use tiles=1xN)\n"); return nullptr; }
   EncoderConfig ec;
   ec.width = cfg->width; ec.height = cfg->height; ec.qp = cfg->qp; ec.intra_period = cfg->intra_period; ec.vps_period = cfg->vps_period;
   ec.me_range = cfg->me_range; ec.fps_num = cfg->framerate_num; ec.fps_den = cfg->framerate_denom;
   ec.wpp = cfg->wpp ? 1 : 0; ec.deblock = cfg->deblock_enable ? 1 : 0; ec.device = cfg->gpu_device; ec.owf = cfg->owf > 8 ? 8 : cfg->owf;
   ec.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1;
-  if (ec.tile_rows > (cfg->height + 63) / 64) ec.tile_rows = (cfg->height + 63) / 64;          // at most one tile per CTU row
+  ec.tile_cols = cfg->tiles_width_count > 1 ? cfg->tiles_width_count : 1;
+  // a grid finer than the CTU grid (uvgComm's "16x16" at 1080p: 17 CTU rows) is coded with as many tiles as there are CTUs in that direction
+  if (ec.tile_rows > (cfg->height + 63) / 64) ec.tile_rows = (cfg->height + 63) / 64;
+  if (ec.tile_cols > (cfg->width + 63) / 64) ec.tile_cols = (cfg->width + 63) / 64;
   ec.band_row0 = cfg->band_row0; ec.band_rows = cfg->band_rows;
   // "threads" (uvgComm video/kvzThreads: auto = core count, Main = 0): what is threaded on the host here is the arithmetic coder
   ec.entropy_threads = cfg->threads < 0 ? 16 : (cfg->threads == 0 ? 1 : (cfg->threads > 16 ? 16 : cfg->threads));
@@ -467,7 +466,7 @@ int kvzx_assemble_access_unit(const kvz_config *cfg, int idr, int poc, int write
   sp.width = cfg->width; sp.height = cfg->height; sp.cw = (cfg->width + 63) & ~63; sp.ch = (cfg->height + 63) & ~63;
   if (sp.cw < 128) sp.cw = 128;
   sp.qp = cfg->qp; sp.wpp = cfg->wpp ? 1 : 0; sp.deblock = cfg->deblock_enable ? 1 : 0; sp.fps_num = cfg->framerate_num; sp.fps_den = cfg->framerate_denom;
-  sp.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1; sp.qp_in_cu = (cfg->set_qp_in_cu || cfg->vaq > 0) ? 1 : 0;
+  sp.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1; sp.tile_cols = 1; sp.qp_in_cu = (cfg->set_qp_in_cu || cfg->vaq > 0) ? 1 : 0;
   sp.slices = (cfg->slices == KVZ_SLICES_WPP && cfg->wpp) ? 1 : ((cfg->slices == KVZ_SLICES_TILES && sp.tile_rows > 1) ? 2 : 0);
   if (nsub != (sp.wpp ? sp.ch / 64 : sp.tile_rows)) return 0;
   std::vector<std::vector<uint8_t>> rows((size_t)nsub);

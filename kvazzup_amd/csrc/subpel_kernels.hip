@@ -133,11 +133,12 @@ __device__ __forceinline__ uint32_t price(const int16_t *hp, uint32_t s4, int mv
 __device__ __forceinline__ int mvd_bits_fast(int q) { const int a = iabs(q); return a == 0 ? 1 : (a == 1 ? 3 : 2 * (31 - __builtin_clz((unsigned)a)) + 3); }
 
 // subme_allowed() of oracle/hevc_enc.c
-__device__ __forceinline__ bool allowed(const EncFrame &f, int x0, int y0, int n, int mvx, int mvy, int ty0, int ty1)
+__device__ __forceinline__ bool allowed(const EncFrame &f, int x0, int y0, int n, int mvx, int mvy, int ty0, int ty1, int tx0, int tx1)
 {
   const int ix = mvx >> 2, iy = mvy >> 2;
   int mx = (mvx & 7) ? 4 : 0, my = (mvy & 7) ? 4 : 0;
   if ((ty0 > 0 && y0 + iy - my < ty0) || (ty1 < f.ch && y0 + iy + n + my > ty1)) return false;
+  if ((tx0 > 0 && x0 + ix - mx < tx0) || (tx1 < f.cw && x0 + ix + n + mx > tx1)) return false;
   if (f.mv_frame) {
     if (f.mv_frame == 1) { mx = (mvx & 3) ? 4 : 0; my = (mvy & 3) ? 4 : 0; }
     if (x0 + ix - mx < 0 || x0 + ix + n + mx > f.cw || y0 + iy - my < 0 || y0 + iy + n + my > f.ch) return false;
@@ -173,6 +174,11 @@ __global__ __launch_bounds__(512) void k_subpel(EncFrame f)
   if (f.tile_rows > 1) {
     const int hc = f.ch >> 6, tr = tile_row_of(hc, f.tile_rows, y0 >> 6);
     ty0 = tile_row_first(hc, f.tile_rows, tr) * 64; ty1 = tile_row_first(hc, f.tile_rows, tr + 1) * 64;
+  }
+  int tx0 = 0, tx1 = f.cw;
+  if (f.tile_cols > 1) {
+    const int wc = f.cw >> 6, tc = tile_col_of(wc, f.tile_cols, x0 >> 6);
+    tx0 = tile_col_first(wc, f.tile_cols, tc) * 64; tx1 = tile_col_first(wc, f.tile_cols, tc + 1) * 64;
   }
   uint8_t *win = s.win[w];
   {
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(512) void k_subpel(EncFrame f)
     if (lane <= ncand && ncand) {
       const int k = lane - 1, mx = k < 0 ? cx : cx + offx[k & 7] * scale, my = k < 0 ? cy : cy + offy[k & 7] * scale;
       if (k < 0) key = step == 0 ? (unit_satd(0) + ((lam * (uint32_t)(mvd_bits_fast(cx) + mvd_bits_fast(cy))) >> 4)) << 4 : best;
-      else if (allowed(f, ux, uy, un, mx, my, ty0, ty1)) key = ((unit_satd(lane) + ((lam * (uint32_t)(mvd_bits_fast(mx) + mvd_bits_fast(my))) >> 4)) << 4) | (uint32_t)lane;
+      else if (allowed(f, ux, uy, un, mx, my, ty0, ty1, tx0, tx1)) key = ((unit_satd(lane) + ((lam * (uint32_t)(mvd_bits_fast(mx) + mvd_bits_fast(my))) >> 4)) << 4) | (uint32_t)lane;
     }
     // minimum over lanes 0 .. 8 (two rows of the DPP network: lanes 0-7 by quad / half-row steps, lane 8 read directly)
     uint32_t m = key;

@@ -47,6 +47,7 @@ struct orc_encoder {
   int roi_w, roi_h; int8_t *roi;       /* delta-QP map (orc_enc_set_roi) */
   int8_t *ctu_qt, *ctu_qy, *ctu_delta; uint8_t *ctu_first;   /* per CTU: target QP, actual QpY, coded CuQpDeltaVal, z index (8x8 units) of the first CU with residual (64: none) */
   int *tile_row_bd;                    /* first CTB row of tile row i, i = 0 .. tile_rows */
+  int tile_col_bd[34];                 /* first CTB column of tile column j, j = 0 .. tile_cols */
   orc_sao_params *sao; pixel *sao_in[3];   /* cfg.sao: parameters of every CTU; copy of the deblocked picture */
   int is_intra;
   uint64_t bins;
@@ -80,13 +81,14 @@ static int level_for(int w, int h)
 orc_encoder *orc_enc_open(const orc_enc_config *c)
 {
   if (c->width < 16 || c->height < 16 || (c->width & 1) || (c->height & 1) || c->qp < 0 || c->qp > 51 ||
-      c->search_range < 0 || c->search_range > 32 || c->tile_rows < 1 || c->tile_rows > (c->height + 63) / 64) return NULL;
+      c->search_range < 0 || c->search_range > 32 || c->tile_rows < 1 || c->tile_rows > (c->height + 63) / 64 || c->tile_cols > 31 || c->tile_cols > (c->width + 63) / 64) return NULL;
   orc_encoder *e = (orc_encoder *)calloc(1, sizeof(*e));
   orc_tables_init();
   e->cfg = *c;
+  if (e->cfg.tile_cols < 1) e->cfg.tile_cols = 1;
   if (e->cfg.vaq > 0) e->cfg.qp_in_cu = 1;                 /* the deltas travel as cu_qp_delta */
   if (e->cfg.bitrate <= 0) e->cfg.rc_bands = 0;
-  if ((e->cfg.slices == 1 && !e->cfg.wpp) || (e->cfg.slices == 2 && e->cfg.tile_rows < 2) || e->cfg.slices < 0 || e->cfg.slices > 2) e->cfg.slices = 0;
+  if ((e->cfg.slices == 1 && !e->cfg.wpp) || (e->cfg.slices == 2 && e->cfg.tile_rows * e->cfg.tile_cols < 2) || (e->cfg.slices == 1 && e->cfg.tile_cols > 1) || e->cfg.slices < 0 || e->cfg.slices > 2) e->cfg.slices = 0;
   if (e->cfg.rc_bands > 0) e->cfg.qp_in_cu = 1;
   e->qp = c->qp;
   e->cw = (c->width + 63) & ~63; e->ch = (c->height + 63) & ~63;
@@ -141,13 +143,15 @@ orc_encoder *orc_enc_open(const orc_enc_config *c)
   e->av.pic_w = e->cw; e->av.pic_h = e->ch; e->av.ctb_log2 = 6; e->av.pic_w_ctbs = e->cw / 64;
   /* tiles: n full-width rows, uniform spacing (6.5.1: rowBd[i] = (i * PicHeightInCtbs) / n) */
   {
-    int n = c->tile_rows, wc = e->cw / 64, hc = e->ch / 64;
+    int n = c->tile_rows, nc = e->cfg.tile_cols, wc = e->cw / 64, hc = e->ch / 64;
     e->tile_row_bd = (int *)calloc((size_t)n + 1, sizeof(int));
     for (int i = 0; i <= n; i++) e->tile_row_bd[i] = (i * hc) / n;
-    if (n > 1) {
-      p->tiles_enabled = 1; p->num_tile_columns = 1; p->num_tile_rows = n; p->uniform_spacing = 1; p->loop_filter_across_tiles = 1;
+    for (int j = 0; j <= nc; j++) e->tile_col_bd[j] = (j * wc) / nc;
+    if (n > 1 || nc > 1) {
+      p->tiles_enabled = 1; p->num_tile_columns = nc; p->num_tile_rows = n; p->uniform_spacing = 1; p->loop_filter_across_tiles = 1;
       e->ctb_tile = (int16_t *)calloc((size_t)wc * hc, sizeof(int16_t));
-      for (int i = 0; i < n; i++) for (int cy = e->tile_row_bd[i]; cy < e->tile_row_bd[i + 1]; cy++) for (int cx = 0; cx < wc; cx++) e->ctb_tile[cy * wc + cx] = (int16_t)i;
+      for (int i = 0; i < n; i++) for (int cy = e->tile_row_bd[i]; cy < e->tile_row_bd[i + 1]; cy++)
+        for (int j = 0; j < nc; j++) for (int cx = e->tile_col_bd[j]; cx < e->tile_col_bd[j + 1]; cx++) e->ctb_tile[cy * wc + cx] = (int16_t)(i * nc + j);
       e->av.ctb_tile = e->ctb_tile;
     }
   }
@@ -391,6 +395,11 @@ static int subme_allowed(const orc_encoder *e, int x0, int y0, int n, int mvx, i
 {
   int ix = mvx >> 2, iy = mvy >> 2, mx = (mvx & 7) ? 4 : 0, my = (mvy & 7) ? 4 : 0;
   if ((ty0 > 0 && y0 + iy - my < ty0) || (ty1 < e->ch && y0 + iy + n + my > ty1)) return 0;
+  {
+    int tx0 = 0, tx1 = e->cw;
+    for (int j = 0; j < e->cfg.tile_cols; j++) if ((x0 >> 6) >= e->tile_col_bd[j] && (x0 >> 6) < e->tile_col_bd[j + 1]) { tx0 = e->tile_col_bd[j] * 64; tx1 = e->tile_col_bd[j + 1] * 64; }
+    if ((tx0 > 0 && x0 + ix - mx < tx0) || (tx1 < e->cw && x0 + ix + n + mx > tx1)) return 0;
+  }
   if (e->cfg.mv_frame) {
     if (e->cfg.mv_frame == 1) { mx = (mvx & 3) ? 4 : 0; my = (mvy & 3) ? 4 : 0; }     /* plain frame constraint: integer vectors may touch the edge */
     if (x0 + ix - mx < 0 || x0 + ix + n + mx > e->cw || y0 + iy - my < 0 || y0 + iy + n + my > e->ch) return 0;
@@ -450,10 +459,13 @@ static void me_block32(orc_encoder *e, int x0, int y0)
    * odd) must stay inside its tile, except across the picture's own top and bottom edges where padding is normative. */
   int ty0 = 0, ty1 = e->ch;
   for (int i = 0; i < e->cfg.tile_rows; i++) if ((y0 >> 6) >= e->tile_row_bd[i] && (y0 >> 6) < e->tile_row_bd[i + 1]) { ty0 = e->tile_row_bd[i] * 64; ty1 = e->tile_row_bd[i + 1] * 64; }
+  int tx0 = 0, tx1 = e->cw;                                      /* ... and the same in x with tile columns */
+  for (int j = 0; j < e->cfg.tile_cols; j++) if ((x0 >> 6) >= e->tile_col_bd[j] && (x0 >> 6) < e->tile_col_bd[j + 1]) { tx0 = e->tile_col_bd[j] * 64; tx1 = e->tile_col_bd[j + 1] * 64; }
   for (int dy = -R; dy <= R; dy++)
     for (int dx = -R; dx <= R; dx++, idx++) {
-      int m = (dy & 1) ? 4 : 0;
+      int m = (dy & 1) ? 4 : 0, mxt = (dx & 1) ? 4 : 0;
       if ((ty0 > 0 && y0 + dy - m < ty0) || (ty1 < e->ch && y0 + dy + 32 + m > ty1)) continue;
+      if ((tx0 > 0 && x0 + dx - mxt < tx0) || (tx1 < e->cw && x0 + dx + 32 + mxt > tx1)) continue;
       if (e->cfg.mv_frame) {                                   /* mv-constraint frame: the displaced block stays inside the picture */
         int my = (e->cfg.mv_frame == 2 && (dy & 1)) ? 4 : 0, mx = (e->cfg.mv_frame == 2 && (dx & 1)) ? 4 : 0;
         if (x0 + dx - mx < 0 || x0 + dx + 32 + mx > e->cw || y0 + dy - my < 0 || y0 + dy + 32 + my > e->ch) continue;
@@ -891,33 +903,38 @@ static void write_picture(orc_encoder *e, int write_ps)
     orc_bw_init(&ps); orc_write_sps(&ps, &e->sps); orc_write_nal(&e->au, NAL_SPS, 0, ps.buf, ps.len, 1); orc_bw_free(&ps);
     orc_bw_init(&ps); orc_write_pps(&ps, &e->pps); orc_write_nal(&e->au, NAL_PPS, 0, ps.buf, ps.len, 1); orc_bw_free(&ps);
   }
-  /* slice data: one substream per CTU row with WPP, else one per tile (full-width tile rows: coding order = raster) */
-  int nsub = e->cfg.wpp ? hc : e->cfg.tile_rows;
+  /* slice data: tile after tile (6.5.1), the CTBs of a tile in raster order; one substream per tile, with WPP one per CTB row of a tile */
+  const int ncols = e->cfg.tile_cols, ntr = e->cfg.tile_rows;
+  int nsub = (e->cfg.wpp ? hc : ntr) * ncols;
   rows = (orc_bitw *)calloc((size_t)nsub, sizeof(orc_bitw));
+  int *sub_tile_first = (int *)calloc((size_t)nsub + 1, sizeof(int)), *sub_addr = (int *)calloc((size_t)nsub + 1, sizeof(int));   /* substream starts a tile; its first CTB */
   orc_cabac_enc c; memset(&c, 0, sizeof(c));
   orc_ctx saved[CTX_COUNT];
   int init_type = e->is_intra ? 0 : 1, sub = -1;
-  for (int cy = 0; cy < hc; cy++) {
-    int tile_start = 0, tile_end = 0;
-    for (int i = 0; i < e->cfg.tile_rows; i++) { if (cy == e->tile_row_bd[i]) tile_start = 1; if (cy + 1 == e->tile_row_bd[i + 1]) tile_end = 1; }
-    if (tile_start || e->cfg.wpp) {
-      sub++;
-      orc_bw_init(&rows[sub]);
-      orc_cenc_start(&c, &rows[sub]);
-      if (tile_start) orc_cabac_init_contexts(c.ctx, init_type, e->qp);   /* 9.3.1: first CTB of a tile */
-      else memcpy(c.ctx, saved, sizeof(saved));       /* WPP: state after the 2nd CTU of the row above */
-    }
-    for (int cx = 0; cx < wc; cx++) {
-      if (e->cfg.sao) orc_sao_write(&c, &e->sao[cy * wc + cx], cx > 0 ? &e->sao[cy * wc + cx - 1] : NULL,
-                                    (cy > 0 && !tile_start) ? &e->sao[(cy - 1) * wc + cx] : NULL, 1, 1);
-      enc_quadtree(e, &c, cx * 64, cy * 64, 6, 0);
-      if (e->cfg.wpp && cx == 1) memcpy(saved, c.ctx, sizeof(saved));
-      int last = (cy == hc - 1 && cx == wc - 1);
-      int sub_end = cx == wc - 1 && (e->cfg.wpp || tile_end);
-      int seg_end = last || (cx == wc - 1 && (e->cfg.slices == 1 || (e->cfg.slices == 2 && tile_end)));
-      orc_cenc_terminate(&c, seg_end);                /* end_of_slice_segment_flag */
-      if (!seg_end && sub_end) orc_cenc_terminate(&c, 1);   /* end_of_subset_one_bit */
-      if (seg_end || sub_end) orc_bw_align_zero(c.bw);
+  for (int tr = 0; tr < ntr; tr++) for (int tc = 0; tc < ncols; tc++) {
+    const int cx0 = e->tile_col_bd[tc], cx1 = e->tile_col_bd[tc + 1];
+    for (int cy = e->tile_row_bd[tr]; cy < e->tile_row_bd[tr + 1]; cy++) {
+      const int tile_start = cy == e->tile_row_bd[tr], tile_end = cy + 1 == e->tile_row_bd[tr + 1];
+      if (tile_start || e->cfg.wpp) {
+        sub++;
+        sub_tile_first[sub] = tile_start; sub_addr[sub] = cy * wc + cx0;
+        orc_bw_init(&rows[sub]);
+        orc_cenc_start(&c, &rows[sub]);
+        if (tile_start || cx1 - cx0 < 2) orc_cabac_init_contexts(c.ctx, init_type, e->qp);   /* 9.3.1: first CTB of a tile (or no second CTB above to take over from) */
+        else memcpy(c.ctx, saved, sizeof(saved));       /* WPP: state after the 2nd CTU of the row above inside the tile */
+      }
+      for (int cx = cx0; cx < cx1; cx++) {
+        if (e->cfg.sao) orc_sao_write(&c, &e->sao[cy * wc + cx], cx > cx0 ? &e->sao[cy * wc + cx - 1] : NULL,
+                                      (cy > 0 && !tile_start) ? &e->sao[(cy - 1) * wc + cx] : NULL, 1, 1);
+        enc_quadtree(e, &c, cx * 64, cy * 64, 6, 0);
+        if (e->cfg.wpp && cx == cx0 + 1) memcpy(saved, c.ctx, sizeof(saved));
+        int last = (tr == ntr - 1 && tc == ncols - 1 && tile_end && cx == cx1 - 1);
+        int sub_end = cx == cx1 - 1 && (e->cfg.wpp || tile_end);
+        int seg_end = last || (cx == cx1 - 1 && (e->cfg.slices == 1 || (e->cfg.slices == 2 && tile_end)));
+        orc_cenc_terminate(&c, seg_end);                /* end_of_slice_segment_flag */
+        if (!seg_end && sub_end) orc_cenc_terminate(&c, 1);   /* end_of_subset_one_bit */
+        if (seg_end || sub_end) orc_bw_align_zero(c.bw);
+      }
     }
   }
   e->bins = c.bins;
@@ -932,14 +949,9 @@ static void write_picture(orc_encoder *e, int write_ps)
   /* slice segments, one NAL unit each: the whole picture; or a dependent segment per CTU row (its header: address and entry points
    * only); or an independent slice per tile (the same header with its own address) */
   for (int s0 = 0; s0 < nsub; ) {
-    int n = nsub - s0, addr = 0;
-    if (e->cfg.slices == 1) { n = 1; addr = s0 * wc; }                                    /* (wpp: substream = CTU row) */
-    if (e->cfg.slices == 2) {
-      int t = 0, r = 0;                                                                   /* tile and CTU row of substream s0 */
-      if (e->cfg.wpp) { r = s0; while (e->tile_row_bd[t + 1] <= r) t++; n = e->tile_row_bd[t + 1] - r; }
-      else { t = s0; r = e->tile_row_bd[t]; n = 1; }
-      addr = r * wc;
-    }
+    int n = nsub - s0, addr = sub_addr[s0];
+    if (e->cfg.slices == 1) n = 1;                                                        /* (wpp, one tile column: substream = CTU row) */
+    if (e->cfg.slices == 2) { n = 1; while (s0 + n < nsub && !sub_tile_first[s0 + n]) n++; }   /* the tile's substreams */
     uint32_t *ep = (uint32_t *)calloc((size_t)n, sizeof(uint32_t));
     sh.first_slice_segment_in_pic = s0 == 0; sh.dependent_slice_segment = (s0 > 0 && e->cfg.slices == 1); sh.slice_segment_address = addr;
     sh.num_entry_points = n - 1; sh.entry_point_offset = ep;
@@ -951,7 +963,7 @@ static void write_picture(orc_encoder *e, int write_ps)
     orc_bw_free(&hdr); free(ep);
     s0 += n;
   }
-  free(rows);
+  free(rows); free(sub_tile_first); free(sub_addr);
 }
 
 /* ------------------------------------------------------------------ top level */
@@ -1021,11 +1033,12 @@ static void roi_targets(orc_encoder *e)
 static void roi_resolve(orc_encoder *e)
 {
   orc_pic *p = e->cur;
-  int wc = e->cw / 64, hc = e->ch / 64, prev = e->qp;
-  for (int cy = 0; cy < hc; cy++) {
-    int tile_start = 0; for (int i = 0; i < e->cfg.tile_rows; i++) if (cy == e->tile_row_bd[i]) tile_start = 1;
+  int wc = e->cw / 64, prev = e->qp;
+  for (int tr = 0; tr < e->cfg.tile_rows; tr++) for (int tc = 0; tc < e->cfg.tile_cols; tc++)
+  for (int cy = e->tile_row_bd[tr]; cy < e->tile_row_bd[tr + 1]; cy++) {
+    int tile_start = cy == e->tile_row_bd[tr];
     if (e->cfg.wpp || tile_start) prev = e->qp;
-    for (int cx = 0; cx < wc; cx++) {
+    for (int cx = e->tile_col_bd[tc]; cx < e->tile_col_bd[tc + 1]; cx++) {
       int ctu = cy * wc + cx, first = 64;
       for (int z = 63; z >= 0; z--) {
         int xi = 0, yi = 0; for (int b = 0; b < 3; b++) { xi |= ((z >> (2 * b)) & 1) << b; yi |= ((z >> (2 * b + 1)) & 1) << b; }

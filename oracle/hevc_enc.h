@@ -33,6 +33,8 @@ typedef struct {
   int deblock;                /* 1 = enabled */
   int tile_rows;              /* 1 = no tiles; n > 1: n full-width tile rows, uniform spacing, loop filter across tiles on,
                                * motion vectors constrained to the tile (see me_block32) */
+  int tile_cols;              /* 1 = none; n > 1: n tile columns, uniform spacing (kvazaar tiles=CxR): with tile_rows a C x R grid, coded in tile-scan order;
+                               * motion vectors are constrained to the tile in x as in y */
   int qp_in_cu;               /* 1: cu_qp_delta_enabled_flag, quantisation group = CTU: a delta-QP map set with orc_enc_set_roi()
                                * gives every CTU its own QP (kvz_picture.roi, kvazaarfilter.cpp:423-431) */
   int bitrate;                /* bits per second; 0 = constant QP.  > 0: "uvgx rate control v1" (see hevc_enc.c) */

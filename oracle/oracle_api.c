@@ -71,18 +71,23 @@ orc_encoder *orc_api_enc_open(int w, int h, int qp, int period, int vps_period, 
   return orc_enc_open(&c);
 }
 orc_encoder *orc_api_enc_open_ex(int w, int h, int qp, int period, int vps_period, int range, int fps_num, int fps_den, int wpp, int deblock, int bitrate, int tile_rows);
+orc_encoder *orc_api_enc_open_ex2(int w, int h, int qp, int period, int vps_period, int range, int fps_num, int fps_den, int wpp, int deblock, int bitrate, int tile_rows, int tile_cols);
 /* same with picture-level rate control (bits per second) */
 orc_encoder *orc_api_enc_open_rc(int w, int h, int qp, int period, int vps_period, int range, int fps_num, int fps_den, int wpp, int deblock, int bitrate)
 {
   return orc_api_enc_open_ex(w, h, qp, period, vps_period, range, fps_num, fps_den, wpp, deblock, bitrate, 1);
 }
 /* ... tile rows; qp_in_cu and sao packed into bits 16, 17 of tile_rows keep the ctypes signature short */
-orc_encoder *orc_api_enc_open_ex(int w, int h, int qp, int period, int vps_period, int range, int fps_num, int fps_den, int wpp, int deblock, int bitrate, int tile_rows)
+orc_encoder *orc_api_enc_open_ex2(int w, int h, int qp, int period, int vps_period, int range, int fps_num, int fps_den, int wpp, int deblock, int bitrate, int tile_rows, int tile_cols)
 {
-  orc_enc_config c; orc_enc_default_config(&c); c.tile_rows = tile_rows & 0xff; c.rc_bands = (tile_rows >> 8) & 0xf; c.slices = (tile_rows >> 12) & 3; c.qp_in_cu = (tile_rows >> 16) & 1; c.sao = (tile_rows >> 17) & 1; c.test_mv_jitter = (tile_rows >> 18) & 1; c.mv_frame = (tile_rows >> 19) & 3; c.vaq = (tile_rows >> 21) & 31; if ((tile_rows >> 26) & 1) c.me_early = 0; if ((tile_rows >> 27) & 1) c.satd = 0; c.subme = (tile_rows >> 28) & 7;
+  orc_enc_config c; orc_enc_default_config(&c); c.tile_cols = tile_cols; c.tile_rows = tile_rows & 0xff; c.rc_bands = (tile_rows >> 8) & 0xf; c.slices = (tile_rows >> 12) & 3; c.qp_in_cu = (tile_rows >> 16) & 1; c.sao = (tile_rows >> 17) & 1; c.test_mv_jitter = (tile_rows >> 18) & 1; c.mv_frame = (tile_rows >> 19) & 3; c.vaq = (tile_rows >> 21) & 31; if ((tile_rows >> 26) & 1) c.me_early = 0; if ((tile_rows >> 27) & 1) c.satd = 0; c.subme = (tile_rows >> 28) & 7;
   c.width = w; c.height = h; c.qp = qp; c.intra_period = period; c.vps_period = vps_period; c.search_range = range;
   c.fps_num = fps_num; c.fps_den = fps_den; c.wpp = wpp; c.deblock = deblock; c.bitrate = bitrate;
   return orc_enc_open(&c);
+}
+orc_encoder *orc_api_enc_open_ex(int w, int h, int qp, int period, int vps_period, int range, int fps_num, int fps_den, int wpp, int deblock, int bitrate, int tile_rows)
+{
+  return orc_api_enc_open_ex2(w, h, qp, period, vps_period, range, fps_num, fps_den, wpp, deblock, bitrate, tile_rows, 1);
 }
 void orc_api_enc_set_roi(orc_encoder *e, int w, int h, const int8_t *map) { orc_enc_set_roi(e, w, h, map); }
 /* returns AU size; copies it to out when it fits */

@@ -74,10 +74,10 @@ def split_nals(au):
 
 
 class OracleEncoder:
-    def __init__(self, w, h, qp=32, period=64, vps_period=1, me_range=16, fps=(30, 1), wpp=1, deblock=1, bitrate=0, tile_rows=1, qp_in_cu=0, sao=0, mv_jitter=0, mv_frame=0, vaq=0, me_early=1, satd=1, subme=0, rc_bands=0, slices=0):
+    def __init__(self, w, h, qp=32, period=64, vps_period=1, me_range=16, fps=(30, 1), wpp=1, deblock=1, bitrate=0, tile_rows=1, qp_in_cu=0, sao=0, mv_jitter=0, mv_frame=0, vaq=0, me_early=1, satd=1, subme=0, rc_bands=0, slices=0, tile_cols=1):
         self.w, self.h = w, h
-        lib().orc_api_enc_open_ex.restype = C.c_void_p
-        self.p = lib().orc_api_enc_open_ex(w, h, qp, period, vps_period, me_range, fps[0], fps[1], wpp, deblock, bitrate, (tile_rows & 0xff) | ((int(rc_bands) & 15) << 8) | ((int(slices) & 3) << 12) | (int(bool(qp_in_cu)) << 16) | (int(bool(sao)) << 17) | (int(bool(mv_jitter)) << 18) | ((int(mv_frame) & 3) << 19) | ((int(vaq) & 31) << 21) | ((0 if me_early else 1) << 26) | ((0 if satd else 1) << 27) | ((int(subme) & 7) << 28))
+        lib().orc_api_enc_open_ex2.restype = C.c_void_p
+        self.p = lib().orc_api_enc_open_ex2(w, h, qp, period, vps_period, me_range, fps[0], fps[1], wpp, deblock, bitrate, (tile_rows & 0xff) | ((int(rc_bands) & 15) << 8) | ((int(slices) & 3) << 12) | (int(bool(qp_in_cu)) << 16) | (int(bool(sao)) << 17) | (int(bool(mv_jitter)) << 18) | ((int(mv_frame) & 3) << 19) | ((int(vaq) & 31) << 21) | ((0 if me_early else 1) << 26) | ((0 if satd else 1) << 27) | ((int(subme) & 7) << 28), int(tile_cols))
         if not self.p:
             raise RuntimeError("orc_enc_open failed")
         self.buf = np.empty(w * h * 3 + (1 << 20), dtype=np.uint8)

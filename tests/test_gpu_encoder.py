@@ -133,20 +133,40 @@ def test_slices_option_matches_oracle(gpu, cfg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dims,rows", [("2x2", 4), ("4x4", 5)])
-def test_tile_grid_with_columns_is_coded_as_tile_rows(gpu, dims, rows):
-    """uvgComm's video/tileDimensions defaults ("2x2" .. "16x16") have tile columns, which are not implemented: the same number of
-    tiles is coded as full-width rows (at most one per CTU row: 320 rows of luma = 5 CTU rows) -- the checker's stream for that tiling"""
-    from kvazzup_amd.codec import Encoder
-    w, h = 448, 320
-    oe = orc.OracleEncoder(w, h, qp=30, period=4, me_range=8, tile_rows=rows)
-    ge = Encoder(w, h, options=(("qp", 30), ("period", 4), ("me-range", 8), ("tiles", dims)))
+@pytest.mark.parametrize("cfg", [
+    dict(w=448, h=320, dims="2x2", cols=2, rows=2, frames=5, qp=30, period=4, kind=0),                              # uvgComm's first tile dimension default
+    dict(w=448, h=320, dims="3x2", cols=3, rows=2, frames=4, qp=30, period=64, kind=0, wpp=0),                      # one substream per tile
+    dict(w=448, h=320, dims="2x2", cols=2, rows=2, frames=4, qp=28, period=2, kind=2, slices=2, sao=1, vaq=6),      # a slice per tile, SAO merge and the QP chain stop at tile borders
+    dict(w=448, h=320, dims="4x1", cols=4, rows=1, frames=4, qp=30, period=64, kind=0, subme=4, me_early=0),        # vectors confined in x: fractional candidates near the column borders
+    dict(w=448, h=320, dims="16x16", cols=7, rows=5, frames=3, qp=32, period=2, kind=0),                            # finer than the CTU grid: one tile per CTU (7 x 5)
+    dict(w=448, h=320, dims="2x3", cols=2, rows=3, frames=4, qp=30, period=1, kind=0, wpp=0, slices=2),             # all intra: the wavefront stops at tile borders
+    dict(w=1920, h=1080, dims="4x4", cols=4, rows=4, frames=3, qp=32, period=64, kind=0),                           # BASELINE configs[1] size
+    dict(w=640, h=384, dims="2x2", cols=2, rows=2, frames=24, qp=32, period=16, kind=0, bitrate=600000),            # rate control v2 over a tile grid
+])
+def test_tile_grid_matches_oracle(gpu, cfg):
+    """kvazaar tiles=CxR with columns (uvgComm video/Tiles + video/tileDimensions, kvazaarfilter.cpp:196-202; the defaults "2x2" .. "16x16" all
+    have columns): CTUs coded in tile-scan order, one substream per tile (per CTU row of a tile with WPP), contexts / WPP hand-over / availability /
+    motion vectors / the QP chain per tile -- the checker's access units byte for byte, and the HIP decoder decodes them"""
+    from kvazzup_amd.codec import Decoder, Encoder
+    w, h = cfg["w"], cfg["h"]
+    kw = dict(wpp=cfg.get("wpp", 1), sao=cfg.get("sao", 0), vaq=cfg.get("vaq", 0), subme=cfg.get("subme", 0), me_early=cfg.get("me_early", 1), slices=cfg.get("slices", 0))
+    br = cfg.get("bitrate", 0)
+    oe = orc.OracleEncoder(w, h, qp=cfg["qp"], period=cfg["period"], me_range=8, tile_rows=cfg["rows"], tile_cols=cfg["cols"], bitrate=br, rc_bands=4 if br else 0, **kw)
+    opts = (("qp", cfg["qp"]), ("period", cfg["period"]), ("me-range", 8), ("tiles", cfg["dims"]), ("wpp", kw["wpp"]), ("sao", "full" if kw["sao"] else "off"), ("subme", kw["subme"]),
+            ("me-early-termination", "on" if kw["me_early"] else "off"), ("slices", ("none", "wpp", "tiles")[kw["slices"]])) + ((("vaq", kw["vaq"]),) if kw["vaq"] else ()) + \
+           ((("bitrate", br), ("rc-algorithm", "lambda")) if br else ())
+    ge = Encoder(w, h, options=opts, fields={"target_bitrate": br})
     assert not ge.rejected, ge.rejected
-    for t in range(5):
-        frame = orc.synth_frame(0, SEED, w, h, t)
+    gd = Decoder()
+    for t in range(cfg["frames"]):
+        frame = orc.synth_frame(cfg["kind"], SEED, w, h, t)
         au, rec = ge.encode(frame)
-        assert au == oe.encode(frame) and np.array_equal(rec, oe.recon()), t
-    ge.close(); oe.close()
+        want = oe.encode(frame)
+        assert au == want, (t, len(au), len(want), _diagnose(oe.debug(), ge.debug_all()))
+        assert np.array_equal(rec, oe.recon()), t
+        got = gd.decode_au(au, t)
+        assert len(got) == 1 and np.array_equal(got[0]["i420"], rec), t
+    ge.close(); gd.close(); oe.close()
 
 
 @pytest.mark.gpu

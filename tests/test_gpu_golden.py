@@ -20,7 +20,8 @@ def test_golden_streams(gpu):
     for case in gold["cases"]:
         c = case["config"]
         ge = Encoder(c["w"], c["h"], options=(("qp", c["qp"]), ("period", c["period"]), ("me-range", c["me_range"]), ("wpp", c["wpp"]), ("deblock", c["deblock"]),
-                                            ("tiles", "1x%d" % c.get("tile_rows", 1)), ("sao", "full" if c.get("sao") else "off"), ("subme", c.get("subme", 0))))
+                                            ("tiles", "%dx%d" % (c.get("tile_cols", 1), c.get("tile_rows", 1))), ("sao", "full" if c.get("sao") else "off"), ("subme", c.get("subme", 0)),
+                                            ("slices", ("none", "wpp", "tiles")[c.get("slices", 0)])))
         gd = Decoder()
         for t, want in enumerate(case["frames"]):
             au, rec = ge.encode(synth.frame(c["kind"], c["seed"], c["w"], c["h"], t))

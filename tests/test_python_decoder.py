@@ -67,13 +67,16 @@ CASES = [
     dict(w=192, h=128, qp=40, period=64, me_range=8, kind=1, seed=0x5EED0005, wpp=1, deblock=0, frames=2),
     dict(w=192, h=128, qp=30, period=3, me_range=8, kind=0, seed=0x5EED0006, wpp=1, deblock=1, frames=4, tile_rows=2, sao=1),
     dict(w=128, h=128, qp=35, period=64, me_range=8, kind=2, seed=0x5EED0007, wpp=0, deblock=1, frames=2, sao=1, qp_in_cu=1),
+    dict(w=256, h=192, qp=30, period=3, me_range=8, kind=0, seed=0x5EED0008, wpp=1, deblock=1, frames=4, tile_rows=2, tile_cols=2, sao=1, subme=2),   # a tile grid, fractional vectors
+    dict(w=256, h=128, qp=32, period=64, me_range=8, kind=0, seed=0x5EED0009, wpp=0, deblock=1, frames=3, tile_rows=1, tile_cols=3, vaq=6),           # columns only, a QP chain per tile
 ]
 
 
 @pytest.mark.parametrize("c", CASES, ids=lambda c: "%dx%d-qp%d-%x" % (c["w"], c["h"], c["qp"], c["seed"] & 0xff))
 def test_checker_encoder_streams(c):
     e = orc.OracleEncoder(c["w"], c["h"], qp=c["qp"], period=c["period"], me_range=c["me_range"], wpp=c["wpp"], deblock=c["deblock"],
-                           tile_rows=c.get("tile_rows", 1), sao=c.get("sao", 0), qp_in_cu=c.get("qp_in_cu", 0), mv_jitter=c.get("mv_jitter", 0))
+                           tile_rows=c.get("tile_rows", 1), sao=c.get("sao", 0), qp_in_cu=c.get("qp_in_cu", 0), mv_jitter=c.get("mv_jitter", 0),
+                           tile_cols=c.get("tile_cols", 1), subme=c.get("subme", 0), vaq=c.get("vaq", 0))
     if c.get("qp_in_cu"):
         e.set_roi(2, 2, [-4, 3, 6, -7])
     aus = [e.encode(orc.synth_frame(c["kind"], c["seed"], c["w"], c["h"], t)) for t in range(c["frames"])]

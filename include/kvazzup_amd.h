@@ -88,6 +88,20 @@ KVZ_PUBLIC int kvzx_encoder_band_phase2b(kvz_encoder *enc, uint8_t *buf, uint32_
 KVZ_PUBLIC int kvzx_assemble_access_unit(const kvz_config *cfg, int idr, int poc, int write_parameter_sets, int slice_qp, const uint8_t *data,
                                           const uint32_t *sizes, int nsub, uint8_t *out, uint32_t cap, uint32_t *len_out);
 
+/* ---- the decoding side of the tile-row split: one decoder per GPU / process, each reconstructing CTU rows [row0, row0 + nrows) (whole tile rows)
+ * of a stream whose motion vectors stay inside their tiles (what the split encoder writes; no SAO, no temporal motion prediction; synchronous decoder).
+ * Every decoder gets every NAL unit and parses its own rows' substreams only.  Per picture: libOpenHevcDecode (returns 0 once the band is
+ * reconstructed) -> band_export(0, down) -> exchange: to rank + 1, from rank - 1 -> band_import(0, from_up) -> band_deblock -> band_export(1, up)
+ * -> exchange: to rank - 1, from rank + 1 -> band_import(1, from_down) -> band_finish (> 0: the picture is the output, this band's rows of it valid).
+ * Halo blocks are kvzx_decoder_band_halo_bytes() long, in device memory; the calls that have no neighbour on their side are skipped. */
+KVZ_PUBLIC int kvzx_decoder_set_band(OpenHevc_Handle h, int row0, int nrows);          /* before the first picture */
+KVZ_PUBLIC size_t kvzx_decoder_band_halo_bytes(OpenHevc_Handle h);                     /* after the first picture's parameter sets: 8 bytes per luma column */
+KVZ_PUBLIC int kvzx_decoder_band_export(OpenHevc_Handle h, int stage, void *d_buf);
+KVZ_PUBLIC int kvzx_decoder_band_import(OpenHevc_Handle h, int stage, const void *d_buf);
+KVZ_PUBLIC int kvzx_decoder_band_ready(OpenHevc_Handle h);      /* 1: the band of a picture is reconstructed and waits for the exchange (after the picture's last slice segment) */
+KVZ_PUBLIC int kvzx_decoder_band_deblock(OpenHevc_Handle h);
+KVZ_PUBLIC int kvzx_decoder_band_finish(OpenHevc_Handle h);
+
 /* ---- row f1: I420 -> RGB32, the conversion uvgComm runs on every decoded picture before display
  * (YUVtoRGB32::process, src/media/processing/yuvtorgb32.cpp:29-64 -> yuv420_to_rgb_i_{avx2_mt,avx2,sse41,c},
  * src/media/processing/yuvconversions.cpp:72-493).  The reference has two arithmetics; `variant` picks:

@@ -107,7 +107,8 @@ DECODER_EXPORTS = ["libOpenHevcInit", "libOpenHevcStartDecoder", "libOpenHevcDec
                    "libOpenHevcSetDebugMode", "libOpenHevcSetTemporalLayer_id", "libOpenHevcSetNoCropping", "libOpenHevcSetActiveDecoders",
                    "libOpenHevcSetViewLayers", "libOpenHevcClose", "libOpenHevcFlush", "libOpenHevcVersion",
                    "kvzx_decoder_set_device", "kvzx_decoder_last_error", "kvzx_decoder_output_device", "kvzx_decoder_set_download", "kvzx_decoder_set_output_hold", "kvzx_decoder_set_profiling",
-                   "kvzx_decoder_kernel_times", "kvzx_decoder_kernel_name", "kvzx_decoder_debug_copy"]
+                   "kvzx_decoder_kernel_times", "kvzx_decoder_kernel_name", "kvzx_decoder_debug_copy",
+                   "kvzx_decoder_set_band", "kvzx_decoder_band_halo_bytes", "kvzx_decoder_band_export", "kvzx_decoder_band_import", "kvzx_decoder_band_deblock", "kvzx_decoder_band_finish", "kvzx_decoder_band_ready"]
 
 
 def load_library():
@@ -154,6 +155,14 @@ def load_library():
         L.kvzx_decoder_last_error.argtypes = [C.c_void_p]
         L.kvzx_decoder_output_device.argtypes = [C.c_void_p, _P(C.c_void_p), _P(C.c_int)]
         L.kvzx_decoder_set_download.argtypes = [C.c_void_p, C.c_int]
+        L.kvzx_decoder_set_band.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.kvzx_decoder_band_halo_bytes.restype = C.c_size_t
+        L.kvzx_decoder_band_halo_bytes.argtypes = [C.c_void_p]
+        L.kvzx_decoder_band_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.kvzx_decoder_band_import.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.kvzx_decoder_band_deblock.argtypes = [C.c_void_p]
+        L.kvzx_decoder_band_finish.argtypes = [C.c_void_p]
+        L.kvzx_decoder_band_ready.argtypes = [C.c_void_p]
         L.kvzx_decoder_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.kvzx_decoder_kernel_times.argtypes = [C.c_void_p, _P(C.c_double), _P(C.c_uint64), C.c_int]
         L.kvzx_decoder_kernel_name.restype = C.c_char_p

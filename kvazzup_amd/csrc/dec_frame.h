@@ -49,6 +49,7 @@ struct DecFrame {
   int w, h;                 // coded luma size (multiples of 8)
   int pw, ph;               // luma pitch and allocated rows (multiples of 64); chroma planes pw / 2 x ph / 2
   int wc, hc;               // CTUs (64 x 64) per row / column, partial ones included
+  int row0, nrows;          // band of CTU rows the launch works on (nrows == 0: the whole picture): tile-row split over several decoders
   const B4Rec *b4;          // [ph / 4][pw / 4]
   const TuRange *region;      // per 32x32 luma region (raster, pitch 2 * wc): {first transform block, count} in tus[]
   const TuRange *ctu;        // per CTU (raster): {first transform block, count | intra-planes mask << 24}

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void k_dec_inter(DecFrame f)
   __shared__ DecInterLds s;
   const int tid = threadIdx.x;
   int bx, by; xcd_block_2d(bx, by);
+  by += f.row0 * 2;                                          // (band of CTU rows: the grid covers f.nrows of them)
   const int x0 = bx * 32, y0 = by * 32;
   if (x0 >= f.w || y0 >= f.h) return;
   const int b4w = f.pw >> 2, cpitch = f.pw >> 1, wC = f.w >> 1, hC = f.h >> 1;
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(256) void k_dec_deblock(DecFrame f)
   __shared__ __attribute__((aligned(16))) uint8_t tc_[2][34 * PC];
   __shared__ B4Rec recs[18 * 18];                          // the tile's 4x4 records and one ring: units -1 .. 16 in both directions
   const int tid = threadIdx.x, wc = f.wc, hc = f.hc, b4w = f.pw >> 2;
-  const int lin = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), tx = lin % wc, tyi = lin / wc;
+  const int lin = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), tx = lin % wc, tyi = lin / wc + f.row0;
   const int X0 = tx * 64 - 4, Y0 = tyi * 64 - 4, CX0 = X0 >> 1, CY0 = Y0 >> 1, cw2 = f.pw >> 1;
   const int TW = tx == wc - 1 ? 68 : 64, TH = tyi == hc - 1 ? 68 : 64;
   for (int i = tid; i < 18 * 18; i += 256) {
@@ -825,9 +826,10 @@ __global__ __launch_bounds__(256) void k_dec_sao(DecFrame f)
 // =============================================================================================
 // launch wrappers
 // =============================================================================================
-void launch_dec_inter(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_inter, dim3(f.wc * 2, f.hc * 2), dim3(256), 0, st, f); }
-void launch_dec_intra(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_intra, dim3(f.wc * f.hc * 3), dim3(64), 0, st, f); }
-void launch_dec_deblock(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_deblock, dim3(f.wc * f.hc), dim3(256), 0, st, f); }
+static inline int dec_rows(const DecFrame &f) { return f.nrows > 0 ? f.nrows : f.hc; }
+void launch_dec_inter(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_inter, dim3(f.wc * 2, dec_rows(f) * 2), dim3(256), 0, st, f); }
+void launch_dec_intra(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_intra, dim3(f.wc * dec_rows(f) * 3), dim3(64), 0, st, f); }     // (f.intra_order lists the band's CTUs)
+void launch_dec_deblock(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_deblock, dim3(f.wc * dec_rows(f)), dim3(256), 0, st, f); }
 void launch_dec_sao(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_sao, dim3(f.wc * f.hc), dim3(256), 0, st, f); }
 
 }  // namespace kvzx

@@ -171,6 +171,19 @@ class Decoder {
     PicJob() {}
     PicJob(const PicJob &) {}                                  // (vector<PicJob> construction only)
   };
+  // ---- tile-row split of ONE stream over several decoders, one per GPU (the decoding side of kvazzup_amd/tilesplit.py): this decoder
+  // reconstructs CTU rows [row0, row0 + nrows) only -- whole tile rows of a stream whose motion vectors stay inside their tiles (what the
+  // split ENCODER writes) -- and deblocking across the band's boundaries goes through two small exchanges with the neighbouring decoders.
+  // Synchronous decoder only (one frame thread), no SAO, no temporal motion prediction.  Per picture: decode_nal (returns 0: the band is
+  // reconstructed) -> band_export(0) -> [to rank + 1 / from rank - 1] -> band_import(0) -> band_deblock -> band_export(1) ->
+  // [to rank - 1 / from rank + 1] -> band_import(1) -> band_finish (the picture is the output; its band's rows are valid).
+  void set_band(int row0, int nrows) { if (jobs_.empty()) { band_row0_ = row0; band_nrows_ = nrows; } }
+  size_t band_halo_bytes() const { return (size_t)pw_ * 8; }
+  bool band_export(int stage, uint8_t *d_buf);     // stage 0: this band's LAST four luma rows (+ chroma) before deblocking and their 4x4 records, for the band below; stage 1: the four rows above this band, final, for the band above
+  bool band_import(int stage, const uint8_t *d_buf);   // stage 0: from the band above, into the rows above this band; stage 1: from the band below, this band's last four rows, final
+  bool band_ready() const { return band_nrows_ > 0 && gpu_job_ != nullptr; }     // a picture's band is reconstructed and waits for the exchange
+  bool band_deblock();
+  int band_finish();
   int pw() const { return pw_; }
   int ph() const { return ph_; }
 
@@ -219,6 +232,7 @@ class Decoder {
   uint32_t *progress_ = nullptr, *intra_order_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
   uint8_t *h_out_ = nullptr; size_t h_out_cap_ = 0;
   long launched_ = 0; int out_slot_ = 0; int output_hold_ = 2;
+  int band_row0_ = 0, band_nrows_ = 0; uint8_t *band_din_ = nullptr; DecFrame band_f_{};      // band mode: the picture between its reconstruction and band_finish
   double t_parse_max_ = 0;                // trace: the longest parse of one picture (an IDR), ms
   bool spin_wait_ = false;                // KVAZZUP_AMD_SPIN: poll the GPU instead of napping between queries
   PicJob *gpu_job_ = nullptr;             // picture whose kernels are in flight (frame-threaded mode)

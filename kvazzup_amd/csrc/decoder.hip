@@ -322,6 +322,7 @@ struct SliceParser {
   CabacDec c;
   const int w, h, b4w, b8w, wc, hc;
   B4Rec *b4; uint8_t *pm, *ctd, *im;     // pm, ctd: per 8x8 (the minimum coding block); im: per 4x4 (NxN parts)
+  int ref_y0 = -(1 << 30), ref_y1 = 1 << 30;                              // band mode: the luma rows of a reference picture this decoder holds (the picture's outer edges open)
   int tile_y0 = 0, tile_y1 = 1 << 30, tile_x0 = 0, tile_x1 = 1 << 30;    // luma rows / columns of the tile being parsed: nothing outside is available (other tiles may be parsed concurrently)
   int err = 0;
   // quantisation (8.6.1)
@@ -527,6 +528,12 @@ struct SliceParser {
       mvx = (int16_t)(uint16_t)(cand[mvp][0] + dx); mvy = (int16_t)(uint16_t)(cand[mvp][1] + dy);      // 8.5.3.2.6: modulo 2^16
     }
     if (ref_idx < 0 || ref_idx >= job.nref) { err = DEC_ERR_INVALID; ref_idx = 0; }
+    if (ref_y1 != (1 << 30) || ref_y0 != -(1 << 30)) {        // band mode: the vector must stay inside this decoder's rows (luma 8-tap, chroma 4-tap windows)
+      const int fy = mvy & 3, fc = mvy & 7;
+      const int top = imin(yp + (mvy >> 2) - (fy ? 3 : 0), 2 * ((yp >> 1) + (mvy >> 3) - (fc ? 1 : 0)));
+      const int bot = imax(yp + bh + (mvy >> 2) + (fy ? 4 : 0), 2 * ((yp >> 1) + (bh >> 1) + (mvy >> 3) + (fc ? 2 : 0)));
+      if (top < ref_y0 || bot > ref_y1) err = DEC_ERR_UNSUPPORTED;
+    }
     B4Rec r; r.mvx = (int16_t)mvx; r.mvy = (int16_t)mvy; r.ref_idx = (int8_t)ref_idx; r.flags = 0; r.qp_y = (int8_t)qp_y; r.slot = job.ref_slot[ref_idx];
     fill_recs(xp, yp, bw, bh, r);
     if (bw != ncbs || bh != ncbs) {                          // prediction block edges inside the coding block (deblocking); the block's own are set by coding_unit
@@ -877,7 +884,9 @@ bool Decoder::ensure_buffers(int w, int h)
     // dispatch order of k_dec_intra's workgroups: CTUs by anti-diagonal cx + 2 cy (every CTU a block depends on comes earlier)
     const int wc = pw_ / 64, hc = ph_ / 64;
     std::vector<uint32_t> order;
-    for (int d = 0; d < wc + 2 * hc; d++) for (int cy = 0; cy < hc; cy++) { const int cx = d - 2 * cy; if (cx >= 0 && cx < wc) order.push_back((uint32_t)(cy * wc + cx)); }
+    const int r0 = band_nrows_ > 0 ? band_row0_ : 0, nr = band_nrows_ > 0 ? band_nrows_ : hc;      // (band mode: this decoder's CTU rows)
+    if (r0 < 0 || r0 + nr > hc) return false;
+    for (int d = 0; d < wc + 2 * nr; d++) for (int cy = 0; cy < nr; cy++) { const int cx = d - 2 * cy; if (cx >= 0 && cx < wc) order.push_back((uint32_t)((r0 + cy) * wc + cx)); }
     HIP_TRY(hipMalloc(&intra_order_, sizeof(uint32_t) * order.size()));
     HIP_TRY(hipMemcpy(intra_order_, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice));
   }
@@ -1430,7 +1439,7 @@ int Decoder::finish_oldest()
   int produced = 0;
   if (prev) { const int rc = complete_gpu(*prev); if (rc < 0) return rc; produced = 1; }
   if (rc_launch < 0) return rc_launch;
-  if (frame_threads_ == 1 && gpu_job_) { PicJob *j = gpu_job_; gpu_job_ = nullptr; const int rc = complete_gpu(*j); if (rc < 0) return rc; produced = 1; }
+  if (frame_threads_ == 1 && gpu_job_ && band_nrows_ == 0) { PicJob *j = gpu_job_; gpu_job_ = nullptr; const int rc = complete_gpu(*j); if (rc < 0) return rc; produced = 1; }
   return produced;
 }
 
@@ -1524,6 +1533,10 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
   }
   sp.last_qp_y = sh.slice_qp;                          // qPY_PREV at the start of a slice, a tile, a CTB row with WPP (8.6.1)
   sp.tile_y0 = g.tile_cy0 * 64; sp.tile_y1 = g.tile_cy1 * 64; sp.tile_x0 = cx0 * 64; sp.tile_x1 = cx1 * 64;
+  if (band_nrows_ > 0) {
+    if (band_row0_ > 0) sp.ref_y0 = band_row0_ * 64 - 4;
+    if (band_row0_ + band_nrows_ < (h_ + 63) / 64) sp.ref_y1 = (band_row0_ + band_nrows_) * 64;
+  }
   ColMotion *own = job.own.get();
   for (int cy = first_cy; cy < first_cy + ncy; cy++) {
     if (cy > first_cy && job.row_restart[(size_t)cy] != SIZE_MAX) {
@@ -1587,6 +1600,7 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
   memset(job.ctu, 0, (size_t)(pw_ / 64) * (ph_ / 64) * sizeof(TuRange));
   memset(job.pred_mode.data(), PM_NONE, job.pred_mode.size());
   auto one = [&](int r) {
+    if (band_nrows_ > 0 && (job.geom[(size_t)r].cy0 < band_row0_ || job.geom[(size_t)r].cy1 > band_row0_ + band_nrows_)) { job.subs[(size_t)r].rc = 0; return; }   // another decoder's rows
     size_t start = job.sub_start[(size_t)r], end = (r + 1 < nsub) ? job.sub_start[(size_t)r + 1] : len;
     int rc = end > start ? parse_substream(job, r, data + start, end - start, job.subs[(size_t)r]) : DEC_ERR_INVALID;
     job.subs[(size_t)r].rc = rc;
@@ -1664,18 +1678,67 @@ int Decoder::launch_gpu(PicJob &job)
   f.cb_qp_offset = (int8_t)job.pps.cb_qp_offset; f.cr_qp_offset = (int8_t)job.pps.cr_qp_offset;
   f.beta_offset = (int8_t)(2 * job.sh.beta_offset_div2); f.tc_offset = (int8_t)(2 * job.sh.tc_offset_div2);
   f.strong_intra = (uint8_t)job.sps->strong_intra; f.tiles = job.pps.tile_rows > 1 || job.pps.tile_cols > 1;
+  if (band_nrows_ > 0) {
+    // a band starts and ends on tile boundaries of full-width tiles; no SAO, no temporal prediction (what the split encoder writes)
+    bool ok = !sao && !job.sps->tmvp && job.pps.tile_cols == 1 && frame_threads_ == 1, top = false, bottom = false;
+    for (int t = 0; t <= job.pps.tile_rows; t++) { top |= job.pps.row_bd[t] == band_row0_; bottom |= job.pps.row_bd[t] == band_row0_ + band_nrows_; }
+    if (!ok || !top || !bottom) return DEC_ERR_UNSUPPORTED;
+    f.row0 = band_row0_; f.nrows = band_nrows_;
+  }
   if (job.any_inter) timed(DK_INTER, [&] { launch_dec_inter(f, stream_); });
   if (job.any_intra) {
     if (hipMemsetAsync(progress_, 0, sizeof(uint32_t) * 3 * (size_t)f.wc * f.hc, stream_) != hipSuccess) return DEC_ERR_GPU;
     timed(DK_INTRA, [&] { launch_dec_intra(f, stream_); });
   }
-  if (!job.sh.deblock_disabled) timed(DK_DEBLOCK, [&] { launch_dec_deblock(f, stream_); });
+  if (band_nrows_ > 0) { band_f_ = f; band_din_ = d_in_; }       // deblocking follows the halo exchange (band_deblock)
+  else if (!job.sh.deblock_disabled) timed(DK_DEBLOCK, [&] { launch_dec_deblock(f, stream_); });
   if (sao) timed(DK_SAO, [&] { launch_dec_sao(f, stream_); });
   if (hipEventRecord(job.done, stream_) != hipSuccess) return DEC_ERR_GPU;
   t_api_ += tk_api.ms();
   launched_++;
   gpu_job_ = &job;
   return 0;
+}
+
+// ---- band mode (tile-row split): halo blocks are [luma 4 rows | Cb 2 rows | Cr 2 rows | the 4x4 records of one unit row], pw_ * 8 bytes
+bool Decoder::band_export(int stage, uint8_t *d_buf)
+{
+  if (band_nrows_ <= 0 || !gpu_job_ || !d_buf) return false;
+  PicJob &job = *gpu_job_;
+  const int y = stage == 0 ? (band_row0_ + band_nrows_) * 64 - 4 : band_row0_ * 64 - 4;     // first of the four luma rows
+  if (y < 0 || y + 4 > ph_) return false;
+  size_t o = 0;
+  if (hipMemcpyAsync(d_buf + o, dpb_[job.slot].plane[0] + (size_t)y * pw_, (size_t)pw_ * 4, hipMemcpyDeviceToDevice, stream_) != hipSuccess) return false;
+  o += (size_t)pw_ * 4;
+  for (int c = 1; c < 3; c++) { if (hipMemcpyAsync(d_buf + o, dpb_[job.slot].plane[c] + (size_t)(y / 2) * (pw_ / 2), (size_t)pw_, hipMemcpyDeviceToDevice, stream_) != hipSuccess) return false; o += (size_t)pw_; }
+  if (stage == 0 && hipMemcpyAsync(d_buf + o, band_din_ + (size_t)(y / 4) * (pw_ / 4) * sizeof(B4Rec), (size_t)(pw_ / 4) * sizeof(B4Rec), hipMemcpyDeviceToDevice, stream_) != hipSuccess) return false;
+  return hipStreamSynchronize(stream_) == hipSuccess;
+}
+bool Decoder::band_import(int stage, const uint8_t *d_buf)
+{
+  if (band_nrows_ <= 0 || !gpu_job_ || !d_buf) return false;
+  PicJob &job = *gpu_job_;
+  const int y = stage == 0 ? band_row0_ * 64 - 4 : (band_row0_ + band_nrows_) * 64 - 4;
+  if (y < 0 || y + 4 > ph_) return false;
+  size_t o = 0;
+  if (hipMemcpyAsync(dpb_[job.slot].plane[0] + (size_t)y * pw_, d_buf + o, (size_t)pw_ * 4, hipMemcpyDeviceToDevice, stream_) != hipSuccess) return false;
+  o += (size_t)pw_ * 4;
+  for (int c = 1; c < 3; c++) { if (hipMemcpyAsync(dpb_[job.slot].plane[c] + (size_t)(y / 2) * (pw_ / 2), d_buf + o, (size_t)pw_, hipMemcpyDeviceToDevice, stream_) != hipSuccess) return false; o += (size_t)pw_; }
+  if (stage == 0 && hipMemcpyAsync(band_din_ + (size_t)(y / 4) * (pw_ / 4) * sizeof(B4Rec), d_buf + o, (size_t)(pw_ / 4) * sizeof(B4Rec), hipMemcpyDeviceToDevice, stream_) != hipSuccess) return false;
+  return hipStreamSynchronize(stream_) == hipSuccess;
+}
+bool Decoder::band_deblock()
+{
+  if (band_nrows_ <= 0 || !gpu_job_) return false;
+  if (!gpu_job_->sh.deblock_disabled) launch_dec_deblock(band_f_, stream_);
+  return hipEventRecord(gpu_job_->done, stream_) == hipSuccess;
+}
+int Decoder::band_finish()
+{
+  if (band_nrows_ <= 0 || !gpu_job_) return 0;
+  PicJob *j = gpu_job_; gpu_job_ = nullptr;
+  if (hipEventRecord(j->done, stream_) != hipSuccess) return DEC_ERR_GPU;
+  return complete_gpu(*j);
 }
 
 bool Decoder::get_picture(DecodedPicture *out)

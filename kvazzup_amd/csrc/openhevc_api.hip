@@ -133,6 +133,22 @@ int kvzx_decoder_output_rgb32_device(OpenHevc_Handle hh, void *d_rgb32, int vari
   if (!kvzx_yuv420_to_rgb32_device(p.dev[0], p.dev[1], p.dev[2], p.dev_pitch[0], p.dev_pitch[1], d_rgb32, p.width, p.height, variant, nullptr)) return 0;
   return hipStreamSynchronize(nullptr) == hipSuccess ? 1 : 0;
 }
+// ---- tile-row split decoder (decoder.h "band mode")
+int kvzx_decoder_set_band(OpenHevc_Handle hh, int row0, int nrows) { Handle *h = H(hh); if (!h || row0 < 0 || nrows < 0) return 0; h->dec->set_band(row0, nrows); return 1; }
+size_t kvzx_decoder_band_halo_bytes(OpenHevc_Handle hh) { Handle *h = H(hh); return h ? h->dec->band_halo_bytes() : 0; }
+int kvzx_decoder_band_export(OpenHevc_Handle hh, int stage, void *d_buf) { Handle *h = H(hh); return h && h->dec->band_export(stage, (uint8_t *)d_buf) ? 1 : 0; }
+int kvzx_decoder_band_import(OpenHevc_Handle hh, int stage, const void *d_buf) { Handle *h = H(hh); return h && h->dec->band_import(stage, (const uint8_t *)d_buf) ? 1 : 0; }
+int kvzx_decoder_band_ready(OpenHevc_Handle hh) { Handle *h = H(hh); return h && h->dec->band_ready() ? 1 : 0; }
+int kvzx_decoder_band_deblock(OpenHevc_Handle hh) { Handle *h = H(hh); return h && h->dec->band_deblock() ? 1 : 0; }
+int kvzx_decoder_band_finish(OpenHevc_Handle hh)
+{
+  Handle *h = H(hh);
+  if (!h) return -1;
+  h->have_pic = false;
+  const int rc = h->dec->band_finish();
+  if (rc > 0) h->have_pic = h->dec->get_picture(&h->pic);
+  return rc;
+}
 void kvzx_decoder_set_output_hold(OpenHevc_Handle hh, int pictures) { Handle *h = H(hh); if (h) h->dec->set_output_hold(pictures); }
 void kvzx_decoder_set_download(OpenHevc_Handle hh, int on) { Handle *h = H(hh); if (h) h->dec->set_download(on != 0); }
 void kvzx_decoder_set_profiling(OpenHevc_Handle hh, int every) { Handle *h = H(hh); if (h) h->dec->set_profiling(every); }

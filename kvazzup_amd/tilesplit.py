@@ -226,6 +226,124 @@ class BandEncoder:
             self.cfg = None
 
 
+class BandDecoder:
+    """one rank's share of the split DECODER: every rank gets every NAL unit, parses its own tile rows' substreams and reconstructs its band
+    of CTU rows; deblocking across the band boundaries takes two small exchanges per picture with rank - 1 / rank + 1 (the band's last four
+    rows down before deblocking, the same rows back up afterwards).  `dist` is torch.distributed (initialised) or None for one process."""
+
+    def __init__(self, ctu_rows, tile_rows, rank, world, device=0, dist=None):
+        self.torch, self.dist = None, dist
+        if world > 1 and dist is not None:
+            import torch
+            self.torch = torch
+        self.lib = L = N.load_library()
+        self.rank, self.world = rank, world
+        self.row0, self.nrows = band_partition(ctu_rows, tile_rows, world)[rank]
+        self.h = L.libOpenHevcInit(1, 0)
+        L.kvzx_decoder_set_device(self.h, device)
+        if world > 1:
+            L.kvzx_decoder_set_band(self.h, self.row0, self.nrows)
+        L.kvzx_decoder_set_download(self.h, 1)
+        if L.libOpenHevcStartDecoder(self.h) == -1:
+            raise RuntimeError("libOpenHevcStartDecoder failed (no usable HIP device? there is no CPU fallback)")
+        self.device, self.halo = device, None
+
+    def feed(self, nal, pts=0):
+        """one NAL unit; returns True when the band of a picture has been reconstructed and waits for the exchange (world > 1), or the
+        decoded picture (dict) when this is the only decoder"""
+        buf = (C.c_ubyte * len(nal)).from_buffer_copy(nal)
+        rc = self.lib.libOpenHevcDecode(C.c_void_p(self.h), buf, len(nal), C.c_int64(pts))
+        if rc < 0:
+            raise RuntimeError("libOpenHevcDecode error %d" % rc)
+        if self.world == 1:
+            return self._output() if rc > 0 else None
+        return bool(self.lib.kvzx_decoder_band_ready(self.h))
+
+    def finish_exchange(self):
+        """the two exchanges and the deblocking in between, over torch.distributed; returns this rank's picture (its band's rows valid)"""
+        t, d, L = self.torch, self.dist, self.lib
+        if self.halo is None:
+            n = int(L.kvzx_decoder_band_halo_bytes(C.c_void_p(self.h)))
+            dev = t.device("cuda", self.device)
+            self.halo = [t.empty(n, dtype=t.uint8, device=dev) for _ in range(2)]      # out, in
+        up, down = self.rank - 1, self.rank + 1
+        staged = d.get_backend() != "nccl"
+        def swap(send_to, recv_from):
+            ops, s, r = [], None, None
+            if send_to is not None:
+                s = self.halo[0].cpu() if staged else self.halo[0]
+                ops.append(d.P2POp(d.isend, s, send_to))
+            if recv_from is not None:
+                r = t.empty_like(self.halo[1].cpu() if staged else self.halo[1])
+                ops.append(d.P2POp(d.irecv, r, recv_from))
+            for q in (d.batch_isend_irecv(ops) if ops else []):
+                q.wait()
+            if r is not None:
+                self.halo[1].copy_(r)
+                t.cuda.synchronize()
+        have_up, have_down = up >= 0, down < self.world
+        if have_down and not L.kvzx_decoder_band_export(C.c_void_p(self.h), 0, C.c_void_p(self.halo[0].data_ptr())):
+            raise RuntimeError("band_export(0) failed")
+        swap(down if have_down else None, up if have_up else None)
+        if have_up and not L.kvzx_decoder_band_import(C.c_void_p(self.h), 0, C.c_void_p(self.halo[1].data_ptr())):
+            raise RuntimeError("band_import(0) failed")
+        if not L.kvzx_decoder_band_deblock(C.c_void_p(self.h)):
+            raise RuntimeError("band_deblock failed")
+        if have_up and not L.kvzx_decoder_band_export(C.c_void_p(self.h), 1, C.c_void_p(self.halo[0].data_ptr())):
+            raise RuntimeError("band_export(1) failed")
+        swap(up if have_up else None, down if have_down else None)
+        if have_down and not L.kvzx_decoder_band_import(C.c_void_p(self.h), 1, C.c_void_p(self.halo[1].data_ptr())):
+            raise RuntimeError("band_import(1) failed")
+        if L.kvzx_decoder_band_finish(C.c_void_p(self.h)) <= 0:
+            raise RuntimeError("band_finish failed")
+        return self._output()
+
+    def _output(self):
+        L = self.lib
+        fr = N.OpenHevcFrame()
+        L.libOpenHevcGetPictureInfo(C.c_void_p(self.h), C.byref(fr.frameInfo))
+        w, h = fr.frameInfo.nWidth, fr.frameInfo.nHeight
+        buf = np.empty(w * h * 3 // 2, dtype=np.uint8)
+        fr.pvY = buf.ctypes.data; fr.pvU = buf.ctypes.data + w * h; fr.pvV = buf.ctypes.data + w * h + w * h // 4
+        if not L.libOpenHevcGetOutputCpy(C.c_void_p(self.h), 1, C.byref(fr)):
+            return None
+        return {"width": w, "height": h, "i420": buf, "rows": (self.row0 * 64, min(h, (self.row0 + self.nrows) * 64))}
+
+    def close(self):
+        if self.h:
+            self.lib.libOpenHevcClose(C.c_void_p(self.h))
+            self.h = None
+
+
+def finish_bands_local(decoders):
+    """the split decoder's per-picture protocol for BandDecoders living in ONE process (bands of one picture on one GPU, or a test):
+    the halo blocks go from decoder to decoder through a device buffer instead of torch.distributed.  Returns the decoders' pictures."""
+    hip = C.CDLL("libamdhip64.so")
+    L = decoders[0].lib
+    n = int(L.kvzx_decoder_band_halo_bytes(C.c_void_p(decoders[0].h)))
+    buf = C.c_void_p()
+    if hip.hipMalloc(C.byref(buf), C.c_size_t(n)) != 0:
+        raise RuntimeError("hipMalloc failed")
+    try:
+        for a, b in zip(decoders[:-1], decoders[1:]):                                   # unfiltered boundary rows and records, downwards
+            if not L.kvzx_decoder_band_export(C.c_void_p(a.h), 0, buf) or not L.kvzx_decoder_band_import(C.c_void_p(b.h), 0, buf):
+                raise RuntimeError("band halo, stage 0")
+        for d in decoders:
+            if not L.kvzx_decoder_band_deblock(C.c_void_p(d.h)):
+                raise RuntimeError("band_deblock failed")
+        for a, b in zip(decoders[:-1], decoders[1:]):                                   # the same rows, filtered, back upwards
+            if not L.kvzx_decoder_band_export(C.c_void_p(b.h), 1, buf) or not L.kvzx_decoder_band_import(C.c_void_p(a.h), 1, buf):
+                raise RuntimeError("band halo, stage 1")
+        out = []
+        for d in decoders:
+            if L.kvzx_decoder_band_finish(C.c_void_p(d.h)) <= 0:
+                raise RuntimeError("band_finish failed")
+            out.append(d._output())
+        return out
+    finally:
+        hip.hipFree(buf)
+
+
 def assemble(lib, cfg, parts, write_parameter_sets=None, state=None):
     """rank 0: substreams of all bands in picture order -> one access unit (host only, no GPU)"""
     sizes = [s for p in parts for s in p[0]]

@@ -1154,7 +1154,7 @@ __device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d
 {
   const int sbl = log2 - 2, nsb2 = 1 << (2 * sbl);
   d.csbf[lane] = 0;
-  __syncthreads();
+  wave_sync();
   bool nz = false;
   if (lane < nsb2) {
     int xs, ys; scan_pos(t, scan_idx, sbl, lane, xs, ys);
@@ -1179,7 +1179,7 @@ __device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d
   }
   uint64_t sb = __ballot(nz);
   if (lane == 0) d.sbmask = sb;
-  __syncthreads();
+  wave_sync();
 }
 
 #define TOK_HDR_CAP 192        // split flags + CU header + last-position bins waiting for the piece they open
@@ -1187,7 +1187,10 @@ __device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d
 #define TOK_PIECES 17          // pieces one unit can produce: 4 CUs x (header-only | one per coded component) + the CTU's terminating bins
 
 // One wave per 16x16 luma block ("unit") and colour component (the luma wave also codes the CU headers) -- or, ALLC, one
-// wave per unit that takes the three components in turn.
+// wave per unit that takes the three components in turn.  Every wave works on its own, with its own LDS state and no workgroup barrier
+// (NW waves per workgroup: NW = 4, the units of a 32x32 quadrant, was measured and is no faster than NW = 1 -- the kernel is bound by
+// the number of waves to start and by its longest waves, not by workgroup dispatch; 8 waves per SIMD -- 64 registers, the residual
+// path spills a little -- is: 4K 73 -> 65 us, profiles/r02_tokenizer_timeline.txt).
 // A unit owns the CU that starts at its origin (32x32 or
 // 16x16) or the four 8x8 CUs inside it; units covered by a 32x32 CU that starts elsewhere emit
 // nothing.  The tokens leave the unit in PIECES: one per coded transform block (preceded by whatever
@@ -1197,25 +1200,37 @@ __device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d
 // emitters writes the tokens at their final offsets -- through a small LDS arena when the piece
 // fits, which keeps the kernel at ~10 KB of LDS per wave.  k_tok_compact restores coding order
 // from the (offset, length) table [ctu][unit][piece].
-template <bool ALLC>
-__global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
+struct alignas(16) TokWave {
+  TuDigest dg;
+  CoreTabs tabs;
+  CuRec tile[9];
+  uint16_t hdr[TOK_HDR_CAP];
+  uint16_t arena[TOK_ARENA];
+  int hdr_n;
+  uint32_t piece_off;
+  uint32_t seg[TOK_PIECES][2];
+};
+template <bool ALLC, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8))) void k_tokenize(EncFrame f)
 {
-  __shared__ CuRec tile[9];
-  __shared__ __attribute__((aligned(16))) TuDigest dg;
-  __shared__ CoreTabs tabs;
-  __shared__ uint16_t hdr[TOK_HDR_CAP];
-  __shared__ uint16_t arena[TOK_ARENA];
-  __shared__ int hdr_n;
-  __shared__ uint32_t piece_off;
-  __shared__ uint32_t seg[TOK_PIECES][2];
-  const int ux = blockIdx.x, uy = blockIdx.y + f.row0 * 4, comp = ALLC ? 0 : (int)blockIdx.z, lane = threadIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
+  __shared__ TokWave tw[NW];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  TokWave &W = tw[wv];
+  CuRec *tile = W.tile; TuDigest &dg = W.dg; CoreTabs &tabs = W.tabs; uint16_t *hdr = W.hdr, *arena = W.arena;
+  int &hdr_n = W.hdr_n; uint32_t &piece_off = W.piece_off; uint32_t (&seg)[TOK_PIECES][2] = W.seg;
+  const int ux = NW == 4 ? blockIdx.x * 2 + (wv & 1) : blockIdx.x, uy = NW == 4 ? (blockIdx.y + f.row0 * 2) * 2 + (wv >> 1) : blockIdx.y + f.row0 * 4, comp = ALLC ? 0 : (int)blockIdx.z, wc = f.cw >> 6, hc = f.ch >> 6;
   const int cx = ux >> 2, cy = uy >> 2, ctu = cy * wc + cx;
   const int X0 = ux * 16, Y0 = uy * 16;
   int z4 = 0;                                          // z-order index of the unit inside its CTU
   for (int b = 0; b < 2; b++) z4 |= (((ux & 3) >> b) & 1) << (2 * b) | (((uy & 3) >> b) & 1) << (2 * b + 1);
-  if (lane == 0 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0) *f.tok_total = 0;           // dense-array cursor of this picture's k_tok_compact
   // Most waves of an inter picture have nothing to say (units inside a 32x32 CU that starts elsewhere, chroma of CUs without
   // chroma residual): they find that out from a few bytes and leave with their table entries zeroed.
+  unsigned long long *tr = (f.trace && comp == 0 && lane == 0 && (z4 == 0 || z4 == 15)) ? f.trace + (size_t)wc * hc * 32 + (size_t)ctu * 8 : nullptr;   // (tools/tok_timeline.py)
+  if (tr) tr[z4 == 0 ? 5 : 6] = wall_clock64();
+  // wave census (tools/tok_timeline.py): per class {left at once, header only, with residual} x {P, I}: waves and 10 ns ticks
+  unsigned long long *census = f.trace ? f.trace + (size_t)wc * hc * 40 + (size_t)ctu * 16 + (f.is_intra ? 6 : 0) : nullptr;
+  const unsigned long long t_begin = census ? wall_clock64() : 0;
+  int wave_class = 1;
   auto mine = [&](int piece) { return ALLC || ((piece == 16 || (piece & 3) == 3) ? 0 : (piece & 3)) == comp; };   // table entries this wave writes
   if (!(comp == 0 && z4 == 15)) {
     const int g0 = (uy * 2) * f.b8w + ux * 2, l0 = f.cu_log2[g0];
@@ -1227,6 +1242,7 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
     }
     if (!work) {
       if (lane < TOK_PIECES && mine(lane)) { uint32_t *e = f.tok_seg + ((size_t)(ctu * 16 + z4) * TOK_PIECES + lane) * 2; e[0] = 0; e[1] = 0; }
+      if (census && lane == 0) { atomicAdd(&census[0], 1ull); atomicAdd(&census[1], wall_clock64() - t_begin); }
       return;
     }
   }
@@ -1245,7 +1261,7 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
     }
     tile[lane] = r;
   }
-  __syncthreads();
+  wave_sync();
   uint16_t *slot = f.tok_buf + (size_t)ctu * f.tok_cap;
   int np = 0;                                          // piece being produced (wave-uniform): CU k, component c -> 4k + c; 16 = terminators
   // reserve `total` tokens of the CTU's slot for piece np; all lanes get the offset (or ~0u when the slot is full)
@@ -1256,7 +1272,7 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
       else { seg[np][0] = o; seg[np][1] = (uint32_t)total; }
       piece_off = o;
     }
-    __syncthreads();
+    wave_sync();
     return piece_off;
   };
   TileView v; v.tile = tile; v.bx0 = bx0; v.by0 = by0;
@@ -1271,12 +1287,8 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
     if (lane == 0 && comp == 0) {
       TokOut t; t.tabs = &tabs; t.p = hdr; t.n = 0; t.cap = TOK_HDR_CAP;
       if (f.sao && z4 == 0 && k == 0) {                 // coding_tree_unit() starts with sao()
-        const SaoParams sp = f.sao[ctu];
-        SaoParams sl, su;
         const bool hl = cx > 0 && !tile_col_starts_at(wc, f.tile_cols, cx), hu = cy > 0 && !tile_row_starts_at(hc, f.tile_rows, cy);
-        if (hl) sl = f.sao[ctu - 1];
-        if (hu) su = f.sao[ctu - wc];
-        enc_sao(t, sp, hl ? &sl : nullptr, hu ? &su : nullptr);
+        enc_sao(t, f.sao[ctu], hl ? &f.sao[ctu - 1] : nullptr, hu ? &f.sao[ctu - wc] : nullptr);     // (read where they lie: a local copy indexed at run time would live in scratch memory)
       }
       enc_split_flags(v, t, f.cw, f.chp, x0, y0, z, cu.log2);
       enc_cu_header(v, t, f.cw, f.chp, f.is_intra != 0, x0, y0, cu);
@@ -1288,6 +1300,7 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
     for (int ci = ALLC ? 0 : comp; ci < (ALLC ? 3 : comp + 1); ci++) {   // the CU's transform blocks: luma, Cb, Cr (ALLC) or this wave's component
       np = 4 * k + ci;
       if ((cbf >> ci) & 1) {
+        wave_class = 2;
         const int l2 = ci ? cu.log2 - 1 : cu.log2, pw = ci ? (f.cw >> 1) : f.cw;
         const int px = ci ? (x0 >> 1) : x0, py = ci ? (y0 >> 1) : y0;
         const int scan = intra_scan_idx(cu.intra, l2, ci, cu.intra_mode);
@@ -1321,7 +1334,7 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
         for (int o = 1; o < 64; o <<= 1) { int other = __shfl_down(suffix, o); if (lane + o < 64) suffix += other; }
         const int body = __shfl(suffix, 0);
         const int off = suffix - n_l;                                 // tokens of all sub-blocks with a higher index
-        __syncthreads();                                              // hdr_n of lane 0 visible
+        wave_sync();                                              // hdr_n of lane 0 visible
         const int hn = hdr_n > TOK_HDR_CAP ? TOK_HDR_CAP : hdr_n, total = hn + body;
         if (hdr_n > TOK_HDR_CAP && lane == 0) atomicOr(f.err, 8u);
         const uint32_t o = reserve(total);
@@ -1334,21 +1347,21 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
             enc_subblock(t, dg, lane, last_sb, last_pos, prev_g1, l2, ci, scan);
           }
           if (staged) {
-            __syncthreads();
+            wave_sync();
             for (int i = lane; i < total; i += 64) slot[o + i] = arena[i];
           }
         }
-        __syncthreads();
+        wave_sync();
         if (lane == 0) hdr_n = 0;
       }
-      __syncthreads();
+      wave_sync();
       if (ci == 0 && hdr_n) {                                        // CU without luma residual: the header is its own piece (4k + 0)
         const int hn = hdr_n > TOK_HDR_CAP ? TOK_HDR_CAP : hdr_n;
         const uint32_t o = reserve(hn);
         if (o != ~0u) for (int i = lane; i < hn; i += 64) slot[o + i] = hdr[i];
-        __syncthreads();
+        wave_sync();
         if (lane == 0) hdr_n = 0;
-        __syncthreads();
+        wave_sync();
       }
     }
   }
@@ -1358,7 +1371,7 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
     const bool sub_end = row_end && (f.wpp || tile_row_ends_at(hc, f.tile_rows, cy));
     const bool seg_end = last || (row_end && (f.slices == 1 || (f.slices == 2 && tile_row_ends_at(hc, f.tile_rows, cy))));   // slice segments per CTU row / per tile
     const int n = 1 + ((sub_end && !seg_end) ? 1 : 0);
-    __syncthreads();
+    wave_sync();
     np = 16;
     const uint32_t o = reserve(n);
     if (o != ~0u && lane == 0) {
@@ -1366,32 +1379,43 @@ __global__ __launch_bounds__(64) void k_tokenize(EncFrame f)
       if (n == 2) slot[o + 1] = 0xC001u;                            // end_of_subset_one_bit
     }
   }
-  __syncthreads();
+  wave_sync();
   if (lane < TOK_PIECES && mine(lane)) {
     uint32_t *e = f.tok_seg + ((size_t)(ctu * 16 + z4) * TOK_PIECES + lane) * 2;
     e[0] = seg[lane][0]; e[1] = seg[lane][1];
   }
+  if (tr && z4 == 15) tr[7] = wall_clock64();
+  if (census && lane == 0) { atomicAdd(&census[wave_class * 2], 1ull); atomicAdd(&census[wave_class * 2 + 1], wall_clock64() - t_begin); }
 }
 
-// one workgroup per CTU: the pieces of its 16 units in z-order, piece after piece -> the dense token array
+// one workgroup per CTU: the pieces of its 16 units in z-order, piece after piece -> the dense token array (CTUs in coding order)
 // (tok_count_out[ctu] < 0 tells the host that the CTU did not fit or its table was inconsistent)
 __global__ __launch_bounds__(256) void k_tok_compact(EncFrame f)
 {
   constexpr int NSEG = 16 * TOK_PIECES;
   __shared__ uint32_t soff[NSEG], start[NSEG + 1], utot[17];
-  __shared__ uint32_t base_s;
-  const int ctu = blockIdx.x + f.row0 * (f.cw >> 6), tid = threadIdx.x;
+  __shared__ uint32_t wsum[4];
+  const int first = f.row0 * (f.cw >> 6), ctu = blockIdx.x + first, tid = threadIdx.x;
+  unsigned long long *tr = f.trace ? f.trace + (size_t)(f.cw >> 6) * (f.ch >> 6) * 32 + (size_t)ctu * 8 : nullptr;     // (tools/tok_timeline.py)
+#define TC_STAMP(k) do { if (tr && tid == 0) tr[k] = wall_clock64(); } while (0)
+  TC_STAMP(0);
   const uint32_t n = f.tok_cursor[ctu];
-  // a place in the dense array (CTUs land in completion order: the host gets each CTU's offset), the slot's
-  // cursor back to zero for the next picture, and the device error word over to the host
-  if (tid == 0) { base_s = atomicAdd(f.tok_total, n); if (blockIdx.x == 0) { *f.err_out = *f.err; if (f.ent_cursors) { f.ent_cursors[0] = 0; f.ent_cursors[1] = 0; } } }
+  // The CTU's place in the dense array: the tokens of all CTUs before it (every workgroup adds up the counts itself -- a few KB out of
+  // L2 -- rather than queueing at one atomic counter: 2040 same-address atomics cost 25 ns each, which WAS this kernel's run time).
+  // The next picture's cursors (the other of two arrays) go back to zero, and the device error word over to the host.
+  uint32_t part = 0;
+  for (int i = first + tid; i < ctu; i += 256) part += f.tok_cursor[i];
+  part = wave_sum_u32(part);
+  if ((tid & 63) == 0) wsum[tid >> 6] = part;
+  if (tid == 0) { f.tok_cursor_next[ctu] = 0; if (blockIdx.x == 0) { *f.err_out = *f.err; if (f.ent_cursors) { f.ent_cursors[0] = 0; f.ent_cursors[1] = 0; } } }
   __syncthreads();
-  const uint32_t base = base_s;
-  if (tid == 0) f.tok_cursor[ctu] = 0;
+  const uint32_t base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  TC_STAMP(1);
   if (base + n > f.tok_dense_cap) { if (tid == 0) f.tok_count_out[ctu] = -1; return; }
   const uint32_t *tab = f.tok_seg + (size_t)ctu * NSEG * 2;
   for (int i = tid; i < NSEG; i += 256) { soff[i] = tab[i * 2]; start[i] = tab[i * 2 + 1]; }        // start[] holds lengths for now
   __syncthreads();
+  TC_STAMP(2);
   if (tid < 16) { uint32_t a = 0; for (int p = 0; p < TOK_PIECES; p++) { uint32_t l = start[tid * TOK_PIECES + p]; start[tid * TOK_PIECES + p] = a; a += l; } utot[tid] = a; }
   __syncthreads();
   if (tid == 0) { uint32_t a = 0; for (int u = 0; u < 16; u++) { uint32_t t = utot[u]; utot[u] = a; a += t; } utot[16] = a; }
@@ -1400,15 +1424,21 @@ __global__ __launch_bounds__(256) void k_tok_compact(EncFrame f)
   if (tid == 0) start[NSEG] = utot[16];
   __syncthreads();
   const uint32_t total = start[NSEG];
+  TC_STAMP(3);
   if (total != n) { if (tid == 0) f.tok_count_out[ctu] = -1; return; }
   const uint16_t *slot = f.tok_buf + (size_t)ctu * f.tok_cap;
   uint16_t *dst = f.tok_dense + base;
+  int lo = 0;                                           // last segment with start <= i (empty segments share a start: take the last)
   for (uint32_t i = tid; i < n; i += 256) {
-    int lo = 0, hi = NSEG;                              // last segment with start <= i (empty segments share a start: take the last)
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (start[mid] <= i) lo = mid; else hi = mid; }
+    if (start[lo + 1] <= i) {                           // past the segment of the previous round (long pieces: usually not)
+      int hi = NSEG;
+      while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (start[mid] <= i) lo = mid; else hi = mid; }
+    }
     dst[i] = slot[soff[lo] + (i - start[lo])];
   }
   if (tid == 0) { f.tok_off_out[ctu] = base; f.tok_count_out[ctu] = (int32_t)n; }
+  TC_STAMP(4);
+#undef TC_STAMP
 }
 
 // =============================================================================================
@@ -1739,8 +1769,8 @@ void launch_tokenize(const EncFrame &f, hipStream_t st)
   // kernel lasts as long as its slowest wave.  On large pictures the waves that only find out they have nothing to do dominate:
   // there one wave per unit takes the three components in turn (76 vs 137 us at 2160p; 51 vs 32 us at 1080p).
   const int units = (f.cw / 16) * band_rows(f) * 4;
-  if (units >= 16384) hipLaunchKernelGGL(k_tokenize<true>, dim3(f.cw / 16, band_rows(f) * 4), dim3(64), 0, st, f);
-  else hipLaunchKernelGGL(k_tokenize<false>, dim3(f.cw / 16, band_rows(f) * 4, 3), dim3(64), 0, st, f);     // (tok_cursor is zero: k_tok_compact leaves it so)
+  if (units >= 16384) hipLaunchKernelGGL((k_tokenize<true, 1>), dim3(f.cw / 16, band_rows(f) * 4), dim3(64), 0, st, f);
+  else hipLaunchKernelGGL((k_tokenize<false, 1>), dim3(f.cw / 16, band_rows(f) * 4, 3), dim3(64), 0, st, f);     // (tok_cursor is zero: the previous picture's k_tok_compact left it so)
 }
 void launch_tok_compact(const EncFrame &f, hipStream_t st)
 {

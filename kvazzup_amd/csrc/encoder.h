@@ -146,7 +146,7 @@ class Encoder {
   hipEvent_t ev_signalled_ = nullptr, ev_tok_done_[2] = {nullptr, nullptr}; bool tok_pending_[2] = {false, false};
   void bind_set(int k);
   uint8_t *intra_scratch_ = nullptr;
-  uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; uint32_t *tok_total_ = nullptr;
+  uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; int tok_nctu_ = 0;
   size_t tok_dense_cap_ = 0;
   std::vector<std::vector<uint8_t>> band_subs_; uint64_t band_bins_ = 0; bool band_coded_ = false;   // band mode: between phase 2a and 2b
   uint32_t *sync_ = nullptr; uint32_t *intra_order_ = nullptr; uint32_t *err_ = nullptr; unsigned long long *trace_ = nullptr;

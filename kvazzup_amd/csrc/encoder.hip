@@ -110,10 +110,9 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   const int nctu = (cw_ / 64) * rows_;
   tok_cap_ = 49152;                                // tokens per CTU slot (worst case of a 64x64 CTU is ~43k)
   HIP_OK(hipMalloc(&tok_buf_, (size_t)nctu * tok_cap_ * sizeof(uint16_t)));
-  HIP_OK(hipMalloc(&tok_count_, sizeof(uint32_t) * nctu));
+  HIP_OK(hipMalloc(&tok_count_, sizeof(uint32_t) * nctu * 2));        // two sets of cursors take turns (k_tok_compact)
   HIP_OK(hipMalloc(&tok_seg_, sizeof(uint32_t) * nctu * 16 * 17 * 2));       // [ctu][unit][piece] {offset, length}
-  HIP_OK(hipMalloc(&tok_total_, sizeof(uint32_t))); HIP_OK(hipMemset(tok_total_, 0, sizeof(uint32_t)));
-  HIP_OK(hipMemset(tok_count_, 0, sizeof(uint32_t) * nctu));
+  HIP_OK(hipMemset(tok_count_, 0, sizeof(uint32_t) * nctu * 2)); tok_nctu_ = nctu;
   tok_dense_cap_ = (size_t)nctu * tok_cap_;
   if (tok_dense_cap_ > ((size_t)1 << 27)) tok_dense_cap_ = (size_t)1 << 27;
   spin_wait_ = getenv("KVAZZUP_AMD_SPIN") != nullptr;
@@ -161,7 +160,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     HIP_OK(hipMemcpy(intra_order_, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice));
   }
   HIP_OK(hipMalloc(&err_, sizeof(uint32_t))); HIP_OK(hipMemset(err_, 0, sizeof(uint32_t)));
-  if (getenv("KVAZZUP_AMD_INTRA_TRACE")) { HIP_OK(hipMalloc(&trace_, sizeof(unsigned long long) * rows_ * (cw_ / 64) * 40)); HIP_OK(hipMemset(trace_, 0, sizeof(unsigned long long) * rows_ * (cw_ / 64) * 40)); }
+  if (getenv("KVAZZUP_AMD_INTRA_TRACE")) { HIP_OK(hipMalloc(&trace_, sizeof(unsigned long long) * (rows_ * (cw_ / 64) * 56))); HIP_OK(hipMemset(trace_, 0, sizeof(unsigned long long) * (rows_ * (cw_ / 64) * 56))); }
   int eth = cfg.entropy_threads;
   if (const char *e = getenv("KVAZZUP_AMD_ENTROPY_THREADS")) eth = atoi(e) < 1 ? 1 : atoi(e);     // tuning knob (containers with a small CPU quota)
   if (cfg.entropy_gpu) { entropy_ = nullptr; entropy2_ = nullptr; }
@@ -180,7 +179,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   uint8_t *p = intra_scratch_;
   f_.ic8 = (uint32_t *)p; p += nb8 * 4; f_.ic16 = (uint32_t *)p; p += nb8; f_.ic32 = (uint32_t *)p; p += nb8 / 4;
   f_.im8 = p; p += nb8; f_.im16 = p; p += nb8 / 4; f_.im32 = p;
-  f_.tok_buf = tok_buf_; f_.tok_cap = tok_cap_; f_.tok_cursor = (uint32_t *)tok_count_; f_.tok_seg = tok_seg_; f_.tok_total = tok_total_;
+  f_.tok_buf = tok_buf_; f_.tok_cap = tok_cap_; f_.tok_cursor = (uint32_t *)tok_count_; f_.tok_cursor_next = (uint32_t *)tok_count_ + tok_nctu_; f_.tok_seg = tok_seg_;
   f_.tok_dense_cap = (uint32_t)tok_dense_cap_;
   f_.sync = sync_; f_.err = err_; f_.trace = trace_; f_.intra_order = intra_order_;
 
@@ -244,7 +243,7 @@ Encoder::~Encoder()
   if (stream_in_) hipStreamDestroy(stream_in_);
   hipFree(intra_scratch_);
   delete entropy_; delete entropy2_;
-  hipFree(trace_); hipFree(intra_order_); hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(tok_total_); hipFree(sync_); hipFree(err_);
+  hipFree(trace_); hipFree(intra_order_); hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(sync_); hipFree(err_);
   if (stream_) hipStreamDestroy(stream_);
 }
 
@@ -358,6 +357,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   f_.is_intra = intra; f_.poc = poc_;
   for (int c = 0; c < 3; c++) { f_.rec[c] = cfg_.sao ? work_[c] : rec_[cur_idx_][c]; f_.sao_out[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
   f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err; f_.ent_cursors = sl.g_cursors;
+  f_.tok_cursor = (uint32_t *)tok_count_ + (size_t)(frame_idx_ & 1) * tok_nctu_; f_.tok_cursor_next = (uint32_t *)tok_count_ + (size_t)((frame_idx_ + 1) & 1) * tok_nctu_;
   const EncFrame f = f_;
   if (src_busy_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_src_free_[set_], 0)); src_busy_[set_] = false; }   // reconstruction of t - 2 has read this source set
   timed(K_PAD, stream_in_, [&] { launch_pad_input(d_i420, w, h, src_[set_][0], src_[set_][1], src_[set_][2], cw_, ch_, stream_in_); });
@@ -543,6 +543,7 @@ bool Encoder::band_picture_setup()
   for (int c = 0; c < 3; c++) { f_.rec[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
   Slot &sl = slot_[0];
   f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err;
+  f_.tok_cursor = (uint32_t *)tok_count_ + (size_t)(frame_idx_ & 1) * tok_nctu_; f_.tok_cursor_next = (uint32_t *)tok_count_ + (size_t)((frame_idx_ + 1) & 1) * tok_nctu_;
   return true;
 }
 
@@ -672,7 +673,7 @@ bool Encoder::debug_copy(const char *what, void *dst, size_t bytes)
   for (int i = 0; i < 7; i++) if (w == names[i]) { src = cu_bytes_[out_set_] + i * nb8; have = nb8; }
   if (w == "cu_mv") { src = cu_mv_[out_set_]; have = nb8 * 4; }
   if (w == "cu_mvd") { src = cu_mvd_[out_set_]; have = nb8 * 4; }
-  if (w == "trace" && trace_) { src = trace_; have = sizeof(unsigned long long) * rows_ * (cw_ / 64) * 40; }
+  if (w == "trace" && trace_) { src = trace_; have = sizeof(unsigned long long) * (rows_ * (cw_ / 64) * 56); }
   for (int c = 0; c < 3; c++) {
     size_t n = c ? npx / 4 : npx;
     if (w == std::string("coef") + char('0' + c)) { src = coef_[out_set_][c]; have = n * 2; }

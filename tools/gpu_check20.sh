@@ -1,0 +1,14 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_encoder.py tests/test_gpu_tilesplit.py tests/test_gpu_configs.py -m gpu -x -q 2>&1 | tail -3
+(python tools/tok_timeline.py 3840 2160; python tools/tok_timeline.py 1920 1080) > gpurun_out/r02_tokenizer_timeline.txt 2>&1; grep "span\|per workgroup" gpurun_out/r02_tokenizer_timeline.txt
+bash tools/kstats_iso.sh 4k t20_iso4k 2>&1 | grep "k_tok"
+bash tools/kstats_iso.sh 1080p t20_iso1080p 2>&1 | grep "k_tok"
+cd $R
+for wl in 4k 1080p; do timeout 600 python bench.py --workload $wl --gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/t20_$wl.json 2> gpurun_out/t20_$wl.err; python - <<PY
+import json
+try:
+    d=json.loads(open('gpurun_out/t20_$wl.json').read().strip().splitlines()[-1]); print('$wl', d['value'], d['config']['host_cpu_cores_busy'])
+except Exception as e: print('$wl failed', e); print(open('gpurun_out/t20_$wl.err').read()[-800:])
+PY
+done

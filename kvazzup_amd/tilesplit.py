@@ -231,8 +231,8 @@ class BandDecoder:
     of CTU rows; deblocking across the band boundaries takes two small exchanges per picture with rank - 1 / rank + 1 (the band's last four
     rows down before deblocking, the same rows back up afterwards).  `dist` is torch.distributed (initialised) or None for one process."""
 
-    def __init__(self, ctu_rows, tile_rows, rank, world, device=0, dist=None):
-        self.torch, self.dist = None, dist
+    def __init__(self, ctu_rows, tile_rows, rank, world, device=0, dist=None, download=True):
+        self.torch, self.dist, self.download = None, dist, download
         if world > 1 and dist is not None:
             import torch
             self.torch = torch
@@ -243,7 +243,7 @@ class BandDecoder:
         L.kvzx_decoder_set_device(self.h, device)
         if world > 1:
             L.kvzx_decoder_set_band(self.h, self.row0, self.nrows)
-        L.kvzx_decoder_set_download(self.h, 1)
+        L.kvzx_decoder_set_download(self.h, 1 if download else 0)       # (off: the picture stays in HBM, kvzx_decoder_output_device)
         if L.libOpenHevcStartDecoder(self.h) == -1:
             raise RuntimeError("libOpenHevcStartDecoder failed (no usable HIP device? there is no CPU fallback)")
         self.device, self.halo = device, None
@@ -303,6 +303,8 @@ class BandDecoder:
         fr = N.OpenHevcFrame()
         L.libOpenHevcGetPictureInfo(C.c_void_p(self.h), C.byref(fr.frameInfo))
         w, h = fr.frameInfo.nWidth, fr.frameInfo.nHeight
+        if not self.download:
+            return {"width": w, "height": h, "rows": (self.row0 * 64, min(h, (self.row0 + self.nrows) * 64))}
         buf = np.empty(w * h * 3 // 2, dtype=np.uint8)
         fr.pvY = buf.ctypes.data; fr.pvU = buf.ctypes.data + w * h; fr.pvV = buf.ctypes.data + w * h + w * h // 4
         if not L.libOpenHevcGetOutputCpy(C.c_void_p(self.h), 1, C.byref(fr)):

@@ -80,7 +80,7 @@ def _band_rows_equal(pic, want, w, h):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,tile_rows,bands,subme", [(320, 256, 2, 2, 0), (256, 448, 4, 2, 2), (256, 448, 3, 3, 4), (1920, 1088, 4, 4, 2)])
+@pytest.mark.parametrize("w,h,tile_rows,bands,subme", [(320, 256, 2, 2, 0), (256, 448, 4, 2, 2), (256, 448, 3, 3, 4), (1920, 1088, 4, 4, 2), (1920, 1088, 8, 8, 0)])
 def test_split_decoder_bands_in_one_process(gpu, w, h, tile_rows, bands, subme):
     """every band decoder gets every NAL unit, parses and reconstructs its own tile rows only; boundary rows go down before the
     deblocking and come back up after it.  Each band's rows equal the checker's reconstruction."""

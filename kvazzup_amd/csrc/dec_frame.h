@@ -54,6 +54,8 @@ struct DecFrame {
   const TuRange *region;      // per 32x32 luma region (raster, pitch 2 * wc): {first transform block, count} in tus[]
   const TuRange *ctu;        // per CTU (raster): {first transform block, count | intra-planes mask << 24}
   const DecTu *tus; const uint32_t *lev;
+  int ntu;                  // transform blocks in tus[]
+  int16_t *resid[3];        // residual of the intra transform blocks up to 16x16 (k_dec_intra_resid -> k_dec_intra), plane-shaped like rec[]
   const uint8_t *ctu_tile;  // tile id of every CTU (raster)
   uint8_t *rec[3];          // the picture being reconstructed (and deblocked in place)
   uint8_t *out[3];          // SAO output (== rec planes of the picture buffer when SAO runs from a work picture)

@@ -483,39 +483,59 @@ __device__ __forceinline__ void dec_intra_block(const DecFrame &f, DecIntraLds &
   store_block_wt(f.rec[c] + (size_t)Yc * cpitch + Xc, cpitch, &s.pic[(ry + 1) * DI_P + 16 + rx], DI_P, N, lane, T);
 }
 
-// one intra transform block of at most 16x16 samples on one wave (kernel_common.h "One intra block per WAVE")
+// The residual of an intra transform block does not depend on its prediction: all of a picture's are computed at once, one wave per
+// transform block (levels -> dequantised coefficients -> the two inverse stages on the matrix cores, or the transform-skip shift),
+// into plane-shaped int16 arrays.  The dependency chain of k_dec_intra then only predicts, adds and stores.  (32x32 blocks stay
+// with the chain's workgroup-shaped code.)  Lane (g, c) owns the four samples x = 4g .. 4g + 3 of row c, as in the chain.
+__global__ __launch_bounds__(256) void k_dec_intra_resid(DecFrame f)
+{
+  __shared__ IntraWaveScratch wsv[4];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, idx = (int)blockIdx.x * 4 + wv;
+  if (idx >= f.ntu) return;
+  const DecTu d = f.tus[idx];
+  if (!(d.flags & TU_INTRA) || !d.count || d.log2 > 4) return;
+  IntraWaveScratch &ws = wsv[wv];
+  const int L2 = d.log2, N = 1 << L2, g = lane >> 4, c = lane & 15;
+  const uint32_t dqc = dequant_pack(d.qp, L2);
+  *(uint2 *)&ws.tr[lane * 4] = make_uint2(0u, 0u);
+  wave_sync();
+  for (int i = lane; i < (int)d.count; i += 64) {
+    const uint32_t wd = f.lev[d.offset + i];
+    const int pos = (int)(wd >> 16) & (N * N - 1);
+    ws.tr[(pos & (N - 1)) * 16 + (pos >> L2)] = (int16_t)dequant_coef_p((int16_t)(wd & 0xffffu), dqc);
+  }
+  wave_sync();
+  int res[4];
+  if (d.flags & TU_TSKIP) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) res[r] = (((int)ws.tr[(4 * g + r) * 16 + c] << 7) + 2048) >> 12;      // residual (x = 4g + r, y = c) = level at row c, column 4g + r
+  } else {
+    const uint2 t = *(const uint2 *)&ws.tr[c * 16 + 4 * g];
+    const int dq[4] = {(int)(int16_t)(t.x & 0xffffu), (int)(int16_t)(t.x >> 16), (int)(int16_t)(t.y & 0xffffu), (int)(int16_t)(t.y >> 16)};
+    const int xf = (L2 == 2 && (d.flags & TU_DST)) ? XF16_DST4 : (L2 - 1) & 3;
+    wave_sync();
+    wave_inverse16(ws, kv_h4(g_xf16.t[xf][lane].tb), dq, g, c, res);
+  }
+  if (c < N && 4 * g < N) {
+    const int pitch = d.plane ? f.pw >> 1 : f.pw;
+    *(uint2 *)&f.resid[d.plane][(size_t)(d.y + c) * pitch + d.x + 4 * g] =
+        make_uint2(((uint32_t)res[0] & 0xffffu) | ((uint32_t)res[1] << 16), ((uint32_t)res[2] & 0xffffu) | ((uint32_t)res[3] << 16));
+  }
+}
+
+// one intra transform block of at most 16x16 samples on one wave (kernel_common.h "One intra block per WAVE"); `rres`: the lane's four
+// residual samples (k_dec_intra_resid), loaded by the caller one block ahead
 template <int L2>
-__device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveScratch &ws, const IntraBlk &d, uint32_t dqc, int count, bool luma,
-                                                     uint8_t *gdst, int gp, int lane, const uint32_t (&wreg)[4], uint32_t *publish)
+__device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveScratch &ws, const IntraBlk &d, bool luma,
+                                                     uint8_t *gdst, int gp, int lane, uint2 rres, uint32_t *publish)
 {
   constexpr int N = 1 << L2;
   const int g = lane >> 4, c = lane & 15, rx = d.rx, ry = d.ry;
   const bool active = c < N && 4 * g < N;
-  // ---- levels -> dequantised coefficients, scattered so that lane (g, c) finds C'[u = 4g + r][j = c] at tr[c * 16 + 4g + r]
-  if (d.flags & IB_LEVELS) {
-    *(uint2 *)&ws.tr[lane * 4] = make_uint2(0u, 0u);
-    wave_sync();
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (lane + k * 64 < count) {
-        const uint32_t wd = wreg[k];
-        const int pos = (int)(wd >> 16) & (N * N - 1);
-        ws.tr[(pos & (N - 1)) * 16 + (pos >> L2)] = (int16_t)dequant_coef_p((int16_t)(wd & 0xffffu), dqc);
-      }
-  }
   int pred[4];
-  wave_intra_predict<L2>(s.pic, DI_P, ws, d, luma, lane, g, c, pred);     // (its wave_sync also orders the scatter above)
+  wave_intra_predict<L2>(s.pic, DI_P, ws, d, luma, lane, g, c, pred);
   if (d.flags & IB_LEVELS) {
-    int res[4];
-    if (d.flags & IB_TSKIP) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) res[r] = (((int)ws.tr[(4 * g + r) * 16 + c] << 7) + 2048) >> 12;      // residual (x = 4g + r, y = c) = level at row c, column 4g + r
-      wave_sync();
-    } else {
-      const uint2 t = *(const uint2 *)&ws.tr[c * 16 + 4 * g];
-      const int dq[4] = {(int)(int16_t)(t.x & 0xffffu), (int)(int16_t)(t.x >> 16), (int)(int16_t)(t.y & 0xffffu), (int)(int16_t)(t.y >> 16)};
-      wave_inverse16(ws, kv_h4(s.xf[d.xf][lane].tb), dq, g, c, res);
-    }
+    const int res[4] = {(int)(int16_t)(rres.x & 0xffffu), (int)(int16_t)(rres.x >> 16), (int)(int16_t)(rres.y & 0xffffu), (int)(int16_t)(rres.y >> 16)};
 #pragma unroll
     for (int r = 0; r < 4; r++) pred[r] = clip8(pred[r] + res[r]);
   }
@@ -598,31 +618,40 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
     bd.pl = my - 3; bd.pu = my - 3 * f.wc; bd.pur = bd.pu + 3; bd.pul = bd.pu - 3;
   }
   borders_begin(bd, bc4);                                  // (its barrier also publishes blk[] / dq[])
-  // level words are fetched one block ahead: the loads of block k + 1 are in flight while block k is reconstructed
+  // what a block needs from memory is fetched one block ahead -- its residual samples (blocks up to 16x16: k_dec_intra_resid), or the
+  // first level words of a 32x32 block: the loads of block k + 1 are in flight while block k is reconstructed
   uint32_t wnext[4] = {0, 0, 0, 0};
-  auto fetch_words = [&](int k) {
+  uint2 rnext = make_uint2(0u, 0u);
+  const int16_t *rplane = f.resid[c] + (size_t)(cy * S) * cpitch + cx * S;
+  auto fetch_ahead = [&](int k) {
     if (k >= nlist) return;
-    const uint32_t off = s.list[k].offset; const int cnt = s.list[k].count;
+    const int l2 = s.blk[k].l2;
+    if (!(s.blk[k].flags & IB_LEVELS)) return;
+    if (l2 > 4) {
+      const uint32_t off = s.list[k].offset; const int cnt = s.list[k].count;
 #pragma unroll
-    for (int q = 0; q < 4; q++) if (lane + q * T < cnt) wnext[q] = f.lev[off + lane + q * T];
+      for (int q = 0; q < 4; q++) if (lane + q * T < cnt) wnext[q] = f.lev[off + lane + q * T];
+    } else {
+      const int n = 1 << l2, g = lane >> 4, r = lane & 15;
+      if (r < n && 4 * g < n) rnext = *(const uint2 *)&rplane[(size_t)(s.blk[k].ry + r) * cpitch + s.blk[k].rx + 4 * g];
+    }
   };
-  fetch_words(0);
+  fetch_ahead(0);
   uint8_t *gdst = plane + (size_t)(cy * S) * cpitch + cx * S;
   for (int k = 0; k < nlist; k++) {
     const IntraBlk d = wave_uniform(&s.blk[k]);            // (wave-uniform: what is derived from it runs on the scalar unit)
-    const uint32_t dqc = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.dq[k]);
-    const int cnt = __builtin_amdgcn_readfirstlane((int)s.list[k].count);
     uint32_t wreg[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) wreg[q] = wnext[q];
-    fetch_words(k + 1);
+    const uint2 rres = rnext;
+    fetch_ahead(k + 1);
     uint32_t *pub = (d.flags & IB_PUBLISH) ? my : nullptr;
     if (pub && d.l2 > 4) { publish_wt(my, (uint32_t)d.zu); pub = nullptr; }       // (32x32 blocks: the workgroup-shaped code publishes ahead)
     if (d.flags & IB_BORDER) borders_need(bd, s.pic, DI_P, plane, cpitch, cx, cy, S, sh, wC - cx * S, d.rx, d.ry, 1 << d.l2, &bcast, f.err, lane, T);
     switch (d.l2) {
-      case 2: dec_intra_block_wave<2>(s, ws, d, dqc, cnt, c == 0, gdst, cpitch, lane, wreg, pub); break;
-      case 3: dec_intra_block_wave<3>(s, ws, d, dqc, cnt, c == 0, gdst, cpitch, lane, wreg, pub); break;
-      case 4: dec_intra_block_wave<4>(s, ws, d, dqc, cnt, c == 0, gdst, cpitch, lane, wreg, pub); break;
+      case 2: dec_intra_block_wave<2>(s, ws, d, c == 0, gdst, cpitch, lane, rres, pub); break;
+      case 3: dec_intra_block_wave<3>(s, ws, d, c == 0, gdst, cpitch, lane, rres, pub); break;
+      case 4: dec_intra_block_wave<4>(s, ws, d, c == 0, gdst, cpitch, lane, rres, pub); break;
       default: {
         DecTu t;
         const uint32_t *q = (const uint32_t *)&s.list[k];
@@ -828,6 +857,7 @@ __global__ __launch_bounds__(256) void k_dec_sao(DecFrame f)
 // =============================================================================================
 static inline int dec_rows(const DecFrame &f) { return f.nrows > 0 ? f.nrows : f.hc; }
 void launch_dec_inter(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_inter, dim3(f.wc * 2, dec_rows(f) * 2), dim3(256), 0, st, f); }
+void launch_dec_intra_resid(const DecFrame &f, hipStream_t st) { if (f.ntu > 0) hipLaunchKernelGGL(k_dec_intra_resid, dim3((f.ntu + 3) / 4), dim3(256), 0, st, f); }
 void launch_dec_intra(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_intra, dim3(f.wc * dec_rows(f) * 3), dim3(64), 0, st, f); }     // (f.intra_order lists the band's CTUs)
 void launch_dec_deblock(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_deblock, dim3(f.wc * dec_rows(f)), dim3(256), 0, st, f); }
 void launch_dec_sao(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_sao, dim3(f.wc * f.hc), dim3(256), 0, st, f); }

@@ -228,6 +228,7 @@ class Decoder {
   DpbPic dpb_[KVZ_DEC_MAX_REFS];
   // device side
   uint8_t *d_in_[2] = {nullptr, nullptr}; size_t d_in_cap_[2] = {0, 0};   // device copies of PicJob::h_in: pictures alternate between the two
+  int16_t *resid_[3] = {nullptr, nullptr, nullptr};         // intra residuals between k_dec_intra_resid and k_dec_intra
   uint8_t *work_[3] = {nullptr, nullptr, nullptr};          // pictures with SAO: reconstruction and deblocking happen here, the filter writes into the slot
   uint32_t *progress_ = nullptr, *intra_order_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
   uint8_t *h_out_ = nullptr; size_t h_out_cap_ = 0;

@@ -828,7 +828,7 @@ void Decoder::free_buffers()
   if (h_out_) hipHostFree(h_out_);
   hipFree(d_in_[0]); hipFree(d_in_[1]); hipFree(progress_); hipFree(intra_order_); intra_order_ = nullptr;
   for (auto &p : dpb_) { for (int c = 0; c < 3; c++) { hipFree(p.plane[c]); p.plane[c] = nullptr; } p = DpbPic(); }
-  for (int c = 0; c < 3; c++) { hipFree(work_[c]); work_[c] = nullptr; }
+  for (int c = 0; c < 3; c++) { hipFree(work_[c]); work_[c] = nullptr; hipFree(resid_[c]); resid_[c] = nullptr; }
   h_out_ = nullptr; d_in_[0] = d_in_[1] = nullptr; d_in_cap_[0] = d_in_cap_[1] = 0; progress_ = nullptr;
   w_ = h_ = pw_ = ph_ = 0;
 }
@@ -891,6 +891,7 @@ bool Decoder::ensure_buffers(int w, int h)
     HIP_TRY(hipMemcpy(intra_order_, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice));
   }
   for (int c = 0; c < 3; c++) HIP_TRY(hipMalloc(&work_[c], c ? npx / 4 : npx));
+  for (int c = 0; c < 3; c++) HIP_TRY(hipMalloc(&resid_[c], sizeof(int16_t) * (c ? npx / 4 : npx)));
   for (int s = 0; s < 6; s++) for (int c = 0; c < 3; c++) { const size_t n = c ? npx / 4 : npx; HIP_TRY(hipMalloc(&dpb_[s].plane[c], n)); HIP_TRY(hipMemset(dpb_[s].plane[c], 128, n)); }
   seen_irap_ = false;
   return true;
@@ -1669,7 +1670,8 @@ int Decoder::launch_gpu(PicJob &job)
   DecFrame f; memset(&f, 0, sizeof(f));
   f.w = w_; f.h = h_; f.pw = pw_; f.ph = ph_; f.wc = (w_ + 63) / 64; f.hc = (h_ + 63) / 64;
   f.b4 = (const B4Rec *)d_in_; f.region = (const TuRange *)(d_in_ + off_region()); f.ctu = (const TuRange *)(d_in_ + off_ctu());
-  f.ctu_tile = d_in_ + off_tile(); f.tus = (const DecTu *)(d_in_ + tu_off); f.lev = (const uint32_t *)(d_in_ + lev_off);
+  f.ctu_tile = d_in_ + off_tile(); f.tus = (const DecTu *)(d_in_ + tu_off); f.lev = (const uint32_t *)(d_in_ + lev_off); f.ntu = (int)ntu;
+  for (int c = 0; c < 3; c++) f.resid[c] = resid_[c];
   const bool sao = job.sh.sao_luma || job.sh.sao_chroma;      // the picture is then built in work_ and filtered into its buffer
   for (int c = 0; c < 3; c++) { f.rec[c] = sao ? work_[c] : dpb_[job.slot].plane[c]; f.out[c] = dpb_[job.slot].plane[c]; }
   for (int k = 0; k < KVZ_DEC_MAX_REFS; k++) for (int c = 0; c < 3; c++) f.ref[k][c] = dpb_[k].plane[c];
@@ -1688,7 +1690,7 @@ int Decoder::launch_gpu(PicJob &job)
   if (job.any_inter) timed(DK_INTER, [&] { launch_dec_inter(f, stream_); });
   if (job.any_intra) {
     if (hipMemsetAsync(progress_, 0, sizeof(uint32_t) * 3 * (size_t)f.wc * f.hc, stream_) != hipSuccess) return DEC_ERR_GPU;
-    timed(DK_INTRA, [&] { launch_dec_intra(f, stream_); });
+    timed(DK_INTRA, [&] { launch_dec_intra_resid(f, stream_); launch_dec_intra(f, stream_); });
   }
   if (band_nrows_ > 0) { band_f_ = f; band_din_ = d_in_; }       // deblocking follows the halo exchange (band_deblock)
   else if (!job.sh.deblock_disabled) timed(DK_DEBLOCK, [&] { launch_dec_deblock(f, stream_); });

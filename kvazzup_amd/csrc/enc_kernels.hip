@@ -1193,8 +1193,8 @@ __device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d
 // One wave per 16x16 luma block ("unit") and colour component (the luma wave also codes the CU headers) -- or, ALLC, one
 // wave per unit that takes the three components in turn.  Every wave works on its own, with its own LDS state and no workgroup barrier
 // (NW waves per workgroup: NW = 4, the units of a 32x32 quadrant, was measured and is no faster than NW = 1 -- the kernel is bound by
-// the number of waves to start and by its longest waves, not by workgroup dispatch; 8 waves per SIMD -- 64 registers, the residual
-// path spills a little -- is: 4K 73 -> 65 us, profiles/r02_tokenizer_timeline.txt).
+// the number of waves to start and by its longest waves, not by workgroup dispatch; more waves per SIMD is: six -- 79 registers, the
+// most that needs no scratch memory; eight spill, 5 MB of extra traffic per 1080p picture -- 4K 73 -> 67 us, profiles/r02_tokenizer_timeline.txt).
 // A unit owns the CU that starts at its origin (32x32 or
 // 16x16) or the four 8x8 CUs inside it; units covered by a 32x32 CU that starts elsewhere emit
 // nothing.  The tokens leave the unit in PIECES: one per coded transform block (preceded by whatever
@@ -1215,7 +1215,7 @@ struct alignas(16) TokWave {
   uint32_t seg[TOK_PIECES][2];
 };
 template <bool ALLC, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8))) void k_tokenize(EncFrame f)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) void k_tokenize(EncFrame f)
 {
   __shared__ TokWave tw[NW];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -320,8 +320,8 @@ def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync
     import ctypes as C
     w, h = wl["w"], wl["h"]
     # pictures parsed concurrently (video/OPENHEVC_threads): the ring has to cover the parse of an intra picture -- ~10 ms on one core at
-    # 4K, where twelve pictures pass in 6 ms (measured: 2090 frames/s with 12, 2390 with 24; 1080p: 5700 / 5950, within the run-to-run scatter)
-    D = max(1, args.decoder_frame_threads or (24 if w * h > 1920 * 1088 else 12))
+    # 4K, where twelve pictures pass in 6 ms (measured: 2090 frames/s with 12, 2390 with 24; 1080p, 3.5 ms per intra picture: 5900-6170 / 6500-6700)
+    D = max(1, args.decoder_frame_threads or 24)
     budget = float(os.environ.get("KVAZZUP_BENCH_CPU_BUDGET", 0)) or cpu_budget(world)
     if budget < 13.0:                                # not enough host CPU for the full thread complement: shrink the pools
         D = max(1, min(D, int(budget * 0.45 + 0.5)))
@@ -497,16 +497,16 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=12, help="pictures per core in the cpu_baseline sample")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--decoder-frame-threads", type=int, default=0,
-                    help="OpenHEVC 'Frame' parallelisation (uvgComm setting video/OH_parallelization): pictures parsed concurrently; 1 = off; 0 (default) = 12 up to 1080p, 24 above")
+                    help="OpenHEVC 'Frame' parallelisation (uvgComm setting video/OH_parallelization): pictures parsed concurrently; 1 = off; 0 (default) = 24")
     ap.add_argument("--profile-every", type=int, default=8, help="kernel timing with HIP events on every n-th picture")
     ap.add_argument("--intra-sad", action="store_true", help="intra-satd=0: the intra mode search compares SADs instead of 8x8 Hadamard sums (for the quality / rate comparison in DESIGN.md)")
     ap.add_argument("--full-search", action="store_true", help="me-early-termination=off: every 32x32 block is searched exhaustively (the k_me issue-rate roofline is reported for this case)")
     ap.add_argument("--subme", type=int, default=0, help="kvazaar subme 0..4: fractional-sample motion refinement (0 at the ultrafast preset the headline workload uses; 2 / 4 at the presets above)")
     ap.add_argument("--gpu-entropy", action="store_true", help="gpu-entropy=1: the arithmetic coder on the GPU (k_cabac_rows) instead of the host thread pool (A/B measurement, DESIGN.md section 5)")
     ap.add_argument("--sao", action="store_true", help="kvazaar sao=full (off at the ultrafast preset the headline workload uses)")
-    ap.add_argument("--owf", type=int, default=3,
+    ap.add_argument("--owf", type=int, default=4,
                     help="uvgComm setting video/OWF (kvazaar owf): 1 = host arithmetic coding of picture t overlaps the kernels of t + 1; "
-                         "2 = it runs on background threads and the output lags two pictures; 3 = one more picture in flight "
+                         "2 = it runs on background threads and the output lags two pictures; 3 .. 8 = that many pictures in flight "
                          "(the settings UI offers 0 .. core count, videosettings.cpp:488-493)")
     args = ap.parse_args()
     if args.cpu_worker:

@@ -192,13 +192,13 @@ def test_gpu_arithmetic_coder_pipelined(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("owf", [1, 2, 3])
+@pytest.mark.parametrize("owf", [1, 2, 3, 4, 8])
 def test_owf_lags_output_and_flushes(gpu, owf):
     """video/OWF = n (kvazaarfilter.cpp:193): the access unit returned by call t is picture t - n (n >= 2: the
-    host coding stage runs on background threads; n = 3 keeps one more picture in flight), NULL pictures flush the rest; the bytes and
+    host coding stage runs on background threads; n = 3 .. 8 keep that many pictures in flight), NULL pictures flush the rest; the bytes and
     reconstructions are those of the synchronous encoder."""
     from kvazzup_amd.codec import Encoder
-    w, h, frames = 320, 192, 7
+    w, h, frames = 320, 192, 7 + owf
     clip = [orc.synth_frame(0, SEED, w, h, t) for t in range(frames)]
     opts = (("qp", 30), ("period", 4), ("me-range", 8))
     e0 = Encoder(w, h, options=opts)

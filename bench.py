@@ -393,11 +393,17 @@ def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync
     cpu0 = time.process_time()
     thr0 = _throttled_us()
     _thr0 = _thread_cpu() if os.environ.get("KVAZZUP_BENCH_THREADS") else None
+    _sampler = None
+    if os.environ.get("CPU_SAMPLER_REGION"):                  # tools/cpu_sampler.c preloaded: sample the timed region only
+        _sampler = C.CDLL(None)
+        _sampler.cpu_sampler_begin()
     t0 = time.perf_counter()
     run(steps * PERIOD)
     torch.cuda.synchronize()
     sync()
     elapsed = time.perf_counter() - t0
+    if _sampler is not None:
+        _sampler.cpu_sampler_end()
     throttled_ms = (_throttled_us() - thr0) / 1e3              # summed over the job's threads: > 0 means the CPU quota, not the GPU, set the pace for a while
     host_cores = (time.process_time() - cpu0) / elapsed        # CPU seconds of all threads of this rank per second of the timed region
     if _thr0 is not None:                                       # KVAZZUP_BENCH_THREADS=1: CPU time per thread over the timed region (stderr)

@@ -85,8 +85,6 @@ class EntropyHost {
     rows_out.resize((size_t)nsub);
     rows_ = &rows_out;
     saved_.resize((size_t)hc * cols_ * CTX_COUNT);
-    ready_.reset(new std::atomic<int>[(size_t)hc * cols_]);
-    for (int r = 0; r < hc * cols_; r++) ready_[(size_t)r].store(0, std::memory_order_relaxed);
     bins_.store(0);
     run_rows(nsub, 0);
     if (bins) *bins = bins_.load();
@@ -104,8 +102,6 @@ class EntropyHost {
     all_rows_.resize((size_t)(wpp ? hc : tiles_));
     rows_ = &all_rows_;
     saved_.resize((size_t)hc * CTX_COUNT);
-    ready_.reset(new std::atomic<int>[(size_t)hc]);
-    for (int r = 0; r < hc; r++) ready_[(size_t)r].store(0, std::memory_order_relaxed);
     bins_.store(0);
     run_rows(nsub, first);
     rows_out.resize((size_t)nsub);
@@ -118,8 +114,35 @@ class EntropyHost {
   // few-microsecond rows to a pool costs more in wake-ups than the rows take.  Everything else goes to the pool, where row r
   // follows row r - 1 at a distance of two CTUs (a 1080p inter picture of the benchmark clip has some 100 000 tokens, 0.8 ms
   // of coding on one core).
+  // WPP: the contexts every CTU row starts from (those of the row above after its second CTU) for ALL rows ahead of the coding, on the
+  // calling thread: a context variable follows the bin values alone, not the arithmetic coder's registers, so the hand-over chain is a
+  // replay of two CTUs' tokens per row through the state table (~10 us per 1080p picture).  The rows are then coded side by side
+  // without ever waiting for each other (before: every row's thread spun until the row above had coded two CTUs -- a quarter of
+  // the coder threads' CPU time went into that wait at 6000 frames/s).
+  void prepass_contexts(int nsub, int first)
+  {
+    uint8_t ctx[CTX_COUNT];
+    for (int k = 0; k < nsub; k++) {
+      const Sub g = geom_[(size_t)(first + k)];
+      if (g.cx1 - g.cx0 < 2) continue;                                   // (a one-CTU-wide tile: every row starts from the initial values)
+      if (g.cy0 == g.tile_cy0) cabac_init_contexts(ctx, init_type_, qp_);
+      else memcpy(ctx, &saved_[((size_t)(g.cy0 - 1) * cols_ + g.tc) * CTX_COUNT], CTX_COUNT);
+      for (int cx = g.cx0; cx < g.cx0 + 2; cx++) {
+        const size_t ctu = (size_t)g.cy0 * wc_ + cx;
+        const uint16_t *tok = tokens_ + offset_[ctu];
+        for (int i = 0, n = count_[ctu]; i < n; i++) {
+          const uint32_t t = tok[i];
+          if (t & 0x8000u) continue;                                     // bypass / terminating bins: no context
+          const uint32_t ci = t >> 1, s = ctx[ci];
+          ctx[ci] = ((t ^ s) & 1u) ? htabs_.next_lps[s] : htabs_.next_mps[s];
+        }
+      }
+      memcpy(&saved_[((size_t)g.cy0 * cols_ + g.tc) * CTX_COUNT], ctx, CTX_COUNT);
+    }
+  }
   void run_rows(int nsub, int first)
   {
+    if (wpp_) prepass_contexts(nsub, first);
     size_t ntok = 0;
     for (int i = 0; i < wc_ * hc_; i++) ntok += (size_t)count_[i];
     if (ntok < 16000) { for (int k = 0; k < nsub; k++) code_row(first + k); }
@@ -154,20 +177,13 @@ class EntropyHost {
     const bool fresh = !wpp_ || g.cy0 == g.tile_cy0 || g.cx1 - g.cx0 < 2;
     if (fresh) cabac_init_contexts(ctx, init_type_, qp_);
     else {
-      // (the row above is already running -- tasks are handed out in order -- and needs two CTUs' worth of time)
-      const size_t above = (size_t)(g.cy0 - 1) * cols_ + g.tc;
-      for (int spins = 0; !ready_[above].load(std::memory_order_acquire);) { if (++spins < 4000) __builtin_ia32_pause(); else std::this_thread::yield(); }
+      const size_t above = (size_t)(g.cy0 - 1) * cols_ + g.tc;                 // (prepass_contexts)
       memcpy(ctx, &saved_[above * CTX_COUNT], CTX_COUNT);
     }
     for (int cy = g.cy0; cy < g.cy1; cy++)
       for (int cx = g.cx0; cx < g.cx1; cx++) {
         const size_t ctu = (size_t)cy * wc_ + cx;
         cabac_play_tokens_host(c, htabs_, tokens_ + offset_[ctu], count_[ctu]);
-        if (wpp_ && cx == g.cx0 + 1) {
-          const size_t me = (size_t)cy * cols_ + g.tc;
-          memcpy(&saved_[me * CTX_COUNT], ctx, CTX_COUNT);
-          ready_[me].store(1, std::memory_order_release);
-        }
       }
     cabac_finish(c);
     out.resize((size_t)c.pos);
@@ -181,7 +197,6 @@ class EntropyHost {
   int wc_ = 0, hc_ = 0, tiles_ = 1, cols_ = 1, init_type_ = 0, qp_ = 0; bool wpp_ = true;
   std::vector<Sub> geom_;
   std::vector<uint8_t> saved_;
-  std::unique_ptr<std::atomic<int>[]> ready_;
   std::vector<std::vector<uint8_t>> *rows_ = nullptr;
   std::vector<std::vector<uint8_t>> all_rows_;
   std::atomic<uint64_t> bins_{0};

@@ -81,6 +81,7 @@ class Filter {
   DataType outputType() const { return output_; }
   const std::string &name() const { return name_; }
   uint32_t bufferedInputs();
+  bool waitBufferedBelow(uint32_t n, int timeout_ms);     // sleeps until fewer than n inputs are buffered (harness: a paced source)
   uint64_t inputDiscarded() const { return inputDiscarded_; }
   uint64_t busyNs() const { return busyNs_; }             // time spent inside process() (harness statistics)
 
@@ -100,7 +101,7 @@ class Filter {
   Stats *stats_;
   DataType input_, output_;
   std::mutex bufferMutex_, connectionMutex_;
-  std::condition_variable hasInput_;
+  std::condition_variable hasInput_, inputTaken_cv_;      // inputTaken_cv_: a source pacing itself waits here (waitBufferedBelow)
   std::deque<std::unique_ptr<Data>> inBuffer_;
   std::vector<Filter *> outConnections_;
   std::vector<std::function<void(std::unique_ptr<Data>)>> outDataCallbacks_;

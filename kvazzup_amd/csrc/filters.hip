@@ -51,6 +51,11 @@ void Filter::run()                                         // filter.cpp:425-443
 }
 
 uint32_t Filter::bufferedInputs() { std::lock_guard<std::mutex> l(bufferMutex_); return (uint32_t)inBuffer_.size(); }
+bool Filter::waitBufferedBelow(uint32_t n, int timeout_ms)
+{
+  std::unique_lock<std::mutex> l(bufferMutex_);
+  return inputTaken_cv_.wait_for(l, std::chrono::milliseconds(timeout_ms), [&] { return inBuffer_.size() < n; });
+}
 
 void Filter::putInput(std::unique_ptr<Data> data)          // filter.cpp:151-222
 {
@@ -81,7 +86,7 @@ std::unique_ptr<Data> Filter::getInput()                   // filter.cpp:297-306
 {
   std::lock_guard<std::mutex> l(bufferMutex_);
   std::unique_ptr<Data> r;
-  if (!inBuffer_.empty()) { r = std::move(inBuffer_.front()); inBuffer_.pop_front(); }
+  if (!inBuffer_.empty()) { r = std::move(inBuffer_.front()); inBuffer_.pop_front(); inputTaken_cv_.notify_all(); }
   return r;
 }
 
@@ -671,11 +676,7 @@ KVZ_PUBLIC int uvgx_pipeline_push_device_paced(void *pp, const void *d_i420, int
 {
   UvgxPipeline *p = (UvgxPipeline *)pp;
   if (!p || !d_i420) return 0;
-  const auto t0 = std::chrono::steady_clock::now();
-  while (p->enc->bufferedInputs() >= max_backlog) {
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) return 0;
-    std::this_thread::sleep_for(std::chrono::microseconds(100));
-  }
+  if (!p->enc->waitBufferedBelow(max_backlog, timeout_ms)) return 0;
   return push(p, nullptr, d_i420, w, h, fn, fd, pts);
 }
 

@@ -27,10 +27,26 @@ static void on_prof(int sig, siginfo_t *si, void *uc_)
   if (i < MAX_SAMPLES) { g_s[i].pc = (uint64_t)uc->uc_mcontext.gregs[REG_RIP]; g_s[i].tid = (int)syscall(SYS_gettid); }
 }
 
+/* cpu_sampler_begin() / cpu_sampler_end(): bracket a region (bench.py calls them around its timed region when CPU_SAMPLER_REGION is
+ * set): begin drops what was sampled so far and re-arms handler and timer (a library may have replaced either), end stops the timer */
+void cpu_sampler_end(void) { struct itimerval it; memset(&it, 0, sizeof(it)); setitimer(ITIMER_PROF, &it, NULL); }
+void cpu_sampler_begin(void)
+{
+  if (!g_s) return;
+  g_n = 0;
+  struct sigaction sa; memset(&sa, 0, sizeof(sa));
+  sa.sa_sigaction = on_prof; sa.sa_flags = SA_SIGINFO | SA_RESTART;
+  sigaction(SIGPROF, &sa, NULL);
+  const char *us = getenv("CPU_SAMPLER_US");
+  struct itimerval it; it.it_interval.tv_sec = 0; it.it_interval.tv_usec = us ? atoi(us) : 500; it.it_value = it.it_interval;
+  setitimer(ITIMER_PROF, &it, NULL);
+}
+
 __attribute__((constructor)) static void sampler_start(void)
 {
   if (getenv("CPU_SAMPLER_OFF")) return;
   g_s = calloc(MAX_SAMPLES, sizeof(*g_s));
+  if (getenv("CPU_SAMPLER_REGION")) return;      /* armed by cpu_sampler_begin() */
   struct sigaction sa; memset(&sa, 0, sizeof(sa));
   sa.sa_sigaction = on_prof; sa.sa_flags = SA_SIGINFO | SA_RESTART;
   sigaction(SIGPROF, &sa, NULL);
@@ -42,7 +58,7 @@ __attribute__((constructor)) static void sampler_start(void)
 __attribute__((destructor)) static void sampler_stop(void)
 {
   if (!g_s) return;
-  struct itimerval it; memset(&it, 0, sizeof(it)); setitimer(ITIMER_PROF, &it, NULL);
+  cpu_sampler_end();
   const char *path = getenv("CPU_SAMPLER_OUT"); if (!path) path = "gpurun_out/cpu_samples.txt";
   FILE *o = fopen(path, "w"); if (!o) return;
   FILE *m = fopen("/proc/self/maps", "r");

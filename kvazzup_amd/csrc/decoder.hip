@@ -303,10 +303,13 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, bool sign_hid
       sum += lev[j];
     }
     if (hidden && (sum & 1)) signs |= 1u;
+    const size_t o0 = out.size();
+    out.resize(o0 + (size_t)nsig);                       // (one capacity check per sub-block instead of one per level)
+    uint32_t *dst = out.data() + o0;
     for (int j = 0; j < nsig; j++) {
       const int v = ((signs >> (nsig - 1 - j)) & 1) ? -lev[j] : lev[j];
       const int xp = PX[pos[j]], yp = PY[pos[j]];
-      out.push_back((uint32_t)((((ys << 2) + yp) * n + (xs << 2) + xp) << 16) | ((uint32_t)clip3(-32768, 32767, v) & 0xffffu));
+      dst[j] = (uint32_t)((((ys << 2) + yp) * n + (xs << 2) + xp) << 16) | ((uint32_t)clip3(-32768, 32767, v) & 0xffffu);
     }
     if (c.overrun()) return false;
   }
@@ -419,7 +422,9 @@ struct SliceParser {
     return false;
   }
 
-  void merge_candidates(int xcb, int ycb, int ncbs, int xpb, int ypb, int npbw, int npbh, int part_idx, int pmode, MvCand *cand)
+  // `want`: the index the bitstream chose -- only cand[want] is read afterwards (merge_idx 0 with the left neighbour there, the common case of a
+  // skipped CU, needs one look-up instead of five and the pruning)
+  void merge_candidates(int xcb, int ycb, int ncbs, int xpb, int ypb, int npbw, int npbh, int part_idx, int pmode, MvCand *cand, int want)
   {
     const int lvl = pps.par_mrg_level;
     int n = 0;
@@ -430,6 +435,7 @@ struct SliceParser {
     const bool part1 = part_idx == 1;
     const bool nbA1 = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xa1, ya1) && !par(xa1, ya1) &&
                       !(part1 && (pmode == PART_Nx2N || pmode == PART_nLx2N || pmode == PART_nRx2N));
+    if (want == 0 && nbA1) { const B4Rec &m = b4[bi(xa1, ya1)]; cand[0].mvx = m.mvx; cand[0].mvy = m.mvy; cand[0].ref_idx = m.ref_idx; return; }
     const bool nbB1 = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xb1, yb1) && !par(xb1, yb1) &&
                       !(part1 && (pmode == PART_2NxN || pmode == PART_2NxnU || pmode == PART_2NxnD));
     const bool nbB0 = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xb0, yb0) && !par(xb0, yb0);
@@ -510,7 +516,7 @@ struct SliceParser {
       int idx = 0;
       if (sh.max_merge > 1 && c.bin(CTX_MERGE_IDX)) { idx = 1; while (idx < sh.max_merge - 1 && c.bypass()) idx++; }
       MvCand cand[5];
-      merge_candidates(xcb, ycb, ncbs, xp, yp, bw, bh, part_idx, part_mode, cand);
+      merge_candidates(xcb, ycb, ncbs, xp, yp, bw, bh, part_idx, part_mode, cand, idx);
       mvx = cand[idx].mvx; mvy = cand[idx].mvy; ref_idx = cand[idx].ref_idx;
     } else {
       if (sh.num_ref_idx > 1) {

@@ -348,7 +348,6 @@ struct DecIntraLds {
   alignas(16) XfLaneF16 xf[4][64];     // matrix operands of the transform stages, per (transform, lane): blocks up to 16x16 (kernel_common.h)
   alignas(16) IntraBlk blk[256];       // what the chain needs to know about each block of list[], worked out ahead of it
   alignas(16) DecTu list[256];         // this plane's intra blocks of the CTU, decoding order (luma: at most 256 4x4 blocks)
-  uint32_t dq[256];                    // dequantiser constants of each block (dequant_pack)
   // 32x32 blocks only (one wave running the workgroup-shaped code of the other sizes' predecessor):
   alignas(16) int16_t A[1024], B[1024];
   alignas(16) int16_t M[2][KV_MATRIX_ENTRIES];
@@ -586,7 +585,7 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
   nlist = nlist > 256 ? 256 : nlist;
   __syncthreads();
   // ---- what the chain needs to know about each block, one lane per block: position, available reference samples (8.4.4.2.2:
-  // contiguous in scan order for one slice with full-width tiles), the mode's constants, the dequantiser's constants
+  // contiguous in scan order for one slice with full-width tiles), the mode's constants
   bool any32 = false;
   for (int k = lane; k < nlist; k += T) {
     const DecTu t = s.list[k];
@@ -606,7 +605,6 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
     d.angle = (int16_t)kIntraAngle[t.mode]; d.inv = (int16_t)kInvAngle[t.mode];
     d.zu = (uint16_t)zu; d.next = 0;
     s.blk[k] = d;
-    s.dq[k] = dequant_pack(t.qp, t.log2);
     any32 |= t.log2 == 5;
   }
   if (__ballot(any32) != 0) load_matrices(s.M, 0, KV_MATRIX_ENTRIES, lane, T);

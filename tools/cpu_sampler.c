@@ -1,5 +1,7 @@
 /* tools/cpu_sampler.c -- a sampling CPU profiler for boxes without perf: LD_PRELOAD this library and every thread's program
- * counter is recorded on SIGPROF (ITIMER_PROF: delivered to running threads in proportion to the CPU time they use).  At exit the
+ * counter is recorded on SIGPROF.  Every thread gets a timer of its own on its CPU-time clock (pthread_create is interposed;
+ * timer_create with SIGEV_THREAD_ID), so a thread is sampled in proportion to the CPU time IT uses -- a process-wide ITIMER_PROF
+ * signal lands on the main thread nearly every time, whoever burnt the CPU.  At exit the
  * samples go to $CPU_SAMPLER_OUT (default gpurun_out/cpu_samples.txt) as "pc thread-name" lines preceded by /proc/self/maps;
  * tools/cpu_sampler_report.py turns them into a per-source-line histogram of a library built with -g.
  *   gcc -O2 -shared -fPIC -o tools/libcpusampler.so tools/cpu_sampler.c -lpthread */
@@ -14,45 +16,73 @@
 #include <sys/syscall.h>
 #include <ucontext.h>
 #include <unistd.h>
+#include <dlfcn.h>
+#include <time.h>
 
 #define MAX_SAMPLES (1 << 21)
 static struct { uint64_t pc; int tid; } *g_s;
 static volatile long g_n;
+static volatile int g_on;                  /* samples are kept only between begin and end (or always, without CPU_SAMPLER_REGION) */
 
 static void on_prof(int sig, siginfo_t *si, void *uc_)
 {
   (void)sig; (void)si;
   ucontext_t *uc = (ucontext_t *)uc_;
+  if (!g_on) return;
   long i = __sync_fetch_and_add(&g_n, 1);
   if (i < MAX_SAMPLES) { g_s[i].pc = (uint64_t)uc->uc_mcontext.gregs[REG_RIP]; g_s[i].tid = (int)syscall(SYS_gettid); }
 }
 
+/* ---- per-thread timers */
+static long sample_ns(void) { const char *us = getenv("CPU_SAMPLER_US"); return (us ? atol(us) : 500) * 1000L; }
+static void arm_this_thread(void)
+{
+  struct sigevent sev; memset(&sev, 0, sizeof(sev));
+  sev.sigev_notify = SIGEV_THREAD_ID; sev.sigev_signo = SIGPROF;
+  sev._sigev_un._tid = (int)syscall(SYS_gettid);
+  timer_t t;
+  if (timer_create(CLOCK_THREAD_CPUTIME_ID, &sev, &t) != 0) return;
+  struct itimerspec its; its.it_interval.tv_sec = 0; its.it_interval.tv_nsec = sample_ns(); its.it_value = its.it_interval;
+  timer_settime(t, 0, &its, NULL);
+}
+struct start_arg { void *(*fn)(void *); void *arg; };
+static void *thread_trampoline(void *p)
+{
+  struct start_arg a = *(struct start_arg *)p; free(p);
+  sigset_t ss; sigemptyset(&ss); sigaddset(&ss, SIGPROF); pthread_sigmask(SIG_UNBLOCK, &ss, NULL);
+  arm_this_thread();
+  return a.fn(a.arg);
+}
+int pthread_create(pthread_t *th, const pthread_attr_t *attr, void *(*fn)(void *), void *arg)
+{
+  static int (*real)(pthread_t *, const pthread_attr_t *, void *(*)(void *), void *);
+  if (!real) real = (int (*)(pthread_t *, const pthread_attr_t *, void *(*)(void *), void *))dlsym(RTLD_NEXT, "pthread_create");
+  if (!g_s) return real(th, attr, fn, arg);
+  struct start_arg *a = malloc(sizeof(*a)); a->fn = fn; a->arg = arg;
+  return real(th, attr, thread_trampoline, a);
+}
+
 /* cpu_sampler_begin() / cpu_sampler_end(): bracket a region (bench.py calls them around its timed region when CPU_SAMPLER_REGION is
  * set): begin drops what was sampled so far and re-arms handler and timer (a library may have replaced either), end stops the timer */
-void cpu_sampler_end(void) { struct itimerval it; memset(&it, 0, sizeof(it)); setitimer(ITIMER_PROF, &it, NULL); }
+void cpu_sampler_end(void) { g_on = 0; }
 void cpu_sampler_begin(void)
 {
   if (!g_s) return;
-  g_n = 0;
-  struct sigaction sa; memset(&sa, 0, sizeof(sa));
+  struct sigaction sa; memset(&sa, 0, sizeof(sa));          /* (a library may have replaced the handler) */
   sa.sa_sigaction = on_prof; sa.sa_flags = SA_SIGINFO | SA_RESTART;
   sigaction(SIGPROF, &sa, NULL);
-  const char *us = getenv("CPU_SAMPLER_US");
-  struct itimerval it; it.it_interval.tv_sec = 0; it.it_interval.tv_usec = us ? atoi(us) : 500; it.it_value = it.it_interval;
-  setitimer(ITIMER_PROF, &it, NULL);
+  g_n = 0; g_on = 1;
 }
 
 __attribute__((constructor)) static void sampler_start(void)
 {
   if (getenv("CPU_SAMPLER_OFF")) return;
   g_s = calloc(MAX_SAMPLES, sizeof(*g_s));
-  if (getenv("CPU_SAMPLER_REGION")) return;      /* armed by cpu_sampler_begin() */
   struct sigaction sa; memset(&sa, 0, sizeof(sa));
   sa.sa_sigaction = on_prof; sa.sa_flags = SA_SIGINFO | SA_RESTART;
   sigaction(SIGPROF, &sa, NULL);
-  const char *us = getenv("CPU_SAMPLER_US");
-  struct itimerval it; it.it_interval.tv_sec = 0; it.it_interval.tv_usec = us ? atoi(us) : 500; it.it_value = it.it_interval;
-  setitimer(ITIMER_PROF, &it, NULL);
+  arm_this_thread();                                       /* the main thread; the others as they are created */
+  g_on = getenv("CPU_SAMPLER_REGION") ? 0 : 1;             /* with a region: armed by cpu_sampler_begin() */
 }
 
 __attribute__((destructor)) static void sampler_stop(void)

@@ -34,8 +34,13 @@ for t, d in ev:
 wall = t1 - t0
 print("window %.1f ms, %d dispatches; sum of kernel durations %.1f ms (%.2f x wall); some kernel running %.1f %% of the wall" % (wall / 1e6, len(rows), tot / 1e6, tot / wall, 100.0 * busy / wall))
 print("time with k kernels in flight:", {k: "%.1f %%" % (100.0 * v / wall) for k, v in sorted(hist.items())})
-q = collections.Counter(r[3] for r in rows)
-print("queues:", dict(q))
+for qid in sorted(set(r[3] for r in rows)):
+    qr = [r for r in rows if r[3] == qid]
+    busyq = sum(e - s for s, e, _, _ in qr)
+    gaps = [b[0] - a[1] for a, b in zip(qr[:-1], qr[1:]) if b[0] > a[1]]
+    small = [g for g in gaps if g < 50_000]
+    names = collections.Counter(r[2] for r in qr).most_common(3)
+    print("queue %s: %d kernels, busy %.1f %% of the wall, %d gaps below 50 us averaging %.1f us; mostly %s" % (qid, len(qr), 100.0 * busyq / wall, len(small), sum(small) / max(1, len(small)) / 1e3, ", ".join(n for n, _ in names)))
 by = collections.defaultdict(lambda: [0, 0])
 for s, e, n, _ in rows: by[n][0] += 1; by[n][1] += e - s
 for n, (c, d) in sorted(by.items(), key=lambda x: -x[1][1])[:14]: print("  %-30s %6d x %8.1f us = %5.1f %% of wall" % (n[:30], c, d / c / 1e3, 100.0 * d / wall))

@@ -77,7 +77,7 @@ bool parse_st_rps(BitReader &r, int idx, int num_in_sps, const StRps *all, StRps
 // Arithmetic decoder with the offset kept scaled in a 64-bit register: value = offset << bits | next
 // `bits` stream bits, so a renormalisation by n is just bits -= n and the stream is touched 32 bits at
 // a time.  Context variable = pStateIdx << 1 | valMps with precomputed transitions.
-struct StateTabs { uint8_t next_mps[128], next_lps[128]; };
+struct StateTabs { uint8_t next_mps[128], next_lps[128]; uint8_t next[128][2]; uint8_t lps[128][4]; };    // next[variable][LPS decoded], lps[variable][(range >> 6) & 3]
 const StateTabs &state_tabs()               // (function-local statics: initialised once, thread-safe -- parse workers race to the first call)
 {
   static const StateTabs t = [] {
@@ -86,6 +86,8 @@ const StateTabs &state_tabs()               // (function-local statics: initiali
       int st = s >> 1, mps = s & 1;
       t.next_mps[s] = (uint8_t)(((st < 62 ? st + 1 : st) << 1) | mps);
       t.next_lps[s] = (uint8_t)((kNextLps[st] << 1) | (st == 0 ? mps ^ 1 : mps));
+      t.next[s][0] = t.next_mps[s]; t.next[s][1] = t.next_lps[s];
+      for (int q = 0; q < 4; q++) t.lps[s][q] = kRangeLps[st][q];
     }
     return t;
   }();
@@ -121,13 +123,13 @@ struct CabacDec {
   {
     // (both outcomes are computed and selected: the bin values of sig / greater1 flags are close to coin flips for a branch predictor)
     const uint32_t s = ctx[ci];
-    const uint32_t lps = kRangeLps[s >> 1][(range >> 6) & 3];
+    const uint32_t lps = st->lps[s][(range >> 6) & 3];
     const uint32_t rmps = range - lps;
     const uint64_t scaled = (uint64_t)rmps << bits;
     const bool isl = value >= scaled;
     value -= isl ? scaled : 0;
     const uint32_t r = isl ? lps : rmps;
-    ctx[ci] = isl ? st->next_lps[s] : st->next_mps[s];
+    ctx[ci] = st->next[s][isl];
     const int n = __builtin_clz(r) - 23;                  // renormalisation: r in [1, 510] -> [256, 510]
     range = r << n; bits -= n;
     refill();
@@ -263,12 +265,14 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, bool sign_hid
     const uint8_t *pk = S.sigk[scan_idx][log2 == 2 ? 4 : prev_csbf];
     const int sig_base = CTX_SIG + (cidx ? 27 : 0);
     const int sig_off = log2 == 2 ? 0 : (cidx == 0 ? ((i > 0 ? 3 : 0) + ((log2 == 3) ? ((scan_idx == 0) ? 9 : 15) : 21)) : ((log2 == 3) ? 9 : 12));
-    for (int k = (i == last_sb) ? last_pos - 1 : 15; k >= 0; k--) {
-      if (k > 0 || !infer_dc) {
-        const int sc = (k == 0 && i == 0 && log2 != 2) ? 0 : pk[k] + sig_off;      // (the DC coefficient of the block has its own context)
-        const int b = c.bin(sig_base + sc);
-        sig |= (uint32_t)b << k; infer_dc &= b ^ 1;
-      } else sig |= 1u;            // k == 0 with every other flag of a coded sub-block zero: inferred
+    {
+      const int k0 = (i == last_sb) ? last_pos - 1 : 15;
+      const int base = sig_base + sig_off;
+      for (int k = k0; k >= 1; k--) sig |= (uint32_t)c.bin(base + pk[k]) << k;      // (position 0 apart: no per-flag conditions in this loop)
+      if (k0 >= 0) {
+        if (infer_dc && !(sig >> 1)) sig |= 1u;            // every other flag of a coded sub-block zero: inferred
+        else sig |= (uint32_t)c.bin((i == 0 && log2 != 2) ? sig_base : base + pk[0]);      // (the DC coefficient of the block has its own context)
+      }
     }
     if (!sig) continue;
     int ctx_set = (i > 0 && cidx == 0) ? 2 : 0;
@@ -727,9 +731,11 @@ struct SliceParser {
       }
     }
     if (err) return;
-    for (int i = 0; i < n; i += 4) {                       // coding block edges are transform and prediction edges
-      if (y0 + i < h) b4[bi(x0, y0 + i)].flags |= B4_EDGE_V | B4_TU_V;
-      if (x0 + i < w) b4[bi(x0 + i, y0)].flags |= B4_EDGE_H | B4_TU_H;
+    {                                                      // coding block edges are transform and prediction edges
+      B4Rec *const r0 = &b4[bi(x0, y0)];
+      const int rows = (imin(n, h - y0) + 3) >> 2, cols = (imin(n, w - x0) + 3) >> 2;
+      for (int i = 0; i < rows; i++) r0[(size_t)i * b4w].flags |= B4_EDGE_V | B4_TU_V;
+      for (int i = 0; i < cols; i++) r0[i].flags |= B4_EDGE_H | B4_TU_H;
     }
     const int qp_before = qp_y;
     if (rqt_root_cbf) {

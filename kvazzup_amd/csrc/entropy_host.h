@@ -24,6 +24,7 @@ namespace kvzx {
 // reloaded after every bin), the context update as one table look-up and the renormalisation shift from the leading-zero count.
 struct HostCabacTabs {
   uint8_t next_mps[128], next_lps[128];     // context variable = pStateIdx << 1 | valMps
+  uint8_t next[128][2];                     // the same, indexed by [variable][least probable symbol coded]
   uint8_t lps[128][4];                      // rangeTabLps by context variable and (range >> 6) & 3
   HostCabacTabs()
   {
@@ -31,6 +32,7 @@ struct HostCabacTabs {
       const int st = s >> 1, mps = s & 1;
       next_mps[s] = (uint8_t)(((st < 62 ? st + 1 : st) << 1) | mps);
       next_lps[s] = (uint8_t)((kNextLps[st] << 1) | (st == 0 ? mps ^ 1 : mps));
+      next[s][0] = next_mps[s]; next[s][1] = next_lps[s];
       for (int q = 0; q < 4; q++) lps[s][q] = kRangeLps[st][q];
     }
   }
@@ -45,20 +47,18 @@ inline void cabac_play_tokens_host(CabacEnc &c, const HostCabacTabs &T, const ui
   for (int i = 0; i < n; i++) {
     const uint32_t t = tok[i];
     if (__builtin_expect(!(t & 0x8000u), 1)) {
+      // both outcomes computed and selected (the bin values of sig / greater1 flags are close to coin flips for a branch predictor):
+      // either way the new range is renormalised by its leading zeros
       const uint32_t ci = t >> 1, s = ctx[ci];
       const uint32_t lps = T.lps[s][(range >> 6) & 3];
+      const uint32_t rmps = range - lps;
+      const uint32_t isl = (t ^ s) & 1u;
+      const uint32_t r = isl ? lps : rmps;
+      const int nb = __builtin_clz(r) - 23;                               // r in [6, 510] -> [256, 510] (an MPS range is at least 128: one bit at most)
       nbins++;
-      range -= lps;
-      if ((t ^ s) & 1u) {                                 // least probable symbol
-        const int nb = __builtin_clz(lps) - 23;            // lps in [6, 240] -> [256, 510]
-        low = (low + range) << nb; range = lps << nb; bits_left -= nb;
-        ctx[ci] = T.next_lps[s];
-      } else {
-        ctx[ci] = T.next_mps[s];
-        if (range >= 256) continue;
-        low <<= 1; range <<= 1; bits_left--;
-      }
-      if (bits_left < 12) { spill(); cabac_write_out(c); fill(); }
+      low = (low + (isl ? rmps : 0u)) << nb; range = r << nb; bits_left -= nb;
+      ctx[ci] = T.next[s][isl];
+      if (__builtin_expect(bits_left < 12, 0)) { spill(); cabac_write_out(c); fill(); }
     } else {
       spill();
       if (!(t & 0x4000u)) cabac_bypass_bits(c, t & 0x3ffu, (int)((t >> 10) & 15) + 1);

@@ -3,6 +3,7 @@
 import collections, subprocess, sys
 path, lib = sys.argv[1], sys.argv[2]
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+only_tid = int(sys.argv[4]) if len(sys.argv) > 4 else None      # samples of one thread only
 base = None
 name = lib.split("/")[-1]
 maps, samples = [], []
@@ -12,7 +13,9 @@ for line in open(path):
         lo, hi = (int(x, 16) for x in f[1].split("-"))
         maps.append((lo, hi, int(f[3], 16), f[-1]))
     elif line.startswith("S "):
-        samples.append(int(line.split()[1], 16))
+        f = line.split()
+        if only_tid is None or int(f[2]) == only_tid:
+            samples.append(int(f[1], 16))
 # file offset -> virtual address of the executable segment (what the symbolizer wants)
 delta = 0
 for line in subprocess.run(["readelf", "-lW", lib], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout.splitlines():

@@ -115,7 +115,11 @@ class Encoder {
   EncFrame f_{};
   uint8_t *d_in_ = nullptr;              // packed input staging (device)
   uint8_t *h_in_ = nullptr;              // pinned host staging
-  uint8_t *src_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // padded source planes, one set per picture parity
+  // Per-picture working sets (padded source planes, level planes, CU arrays, per-CTU QP arrays, SAO parameters): kSets of them take turns, so the
+  // host can queue kSets - 1 pictures' kernels ahead of the one the GPU is working on without waiting for a set to come free (with two sets
+  // the input stage of picture t waited for the reconstruction of t - 2, and the calling thread with it: the main stream ran dry between pictures)
+  static constexpr int kSets = 8;
+  uint8_t *src_[kSets][3] = {};         // padded source planes
   // reconstruction ring: the picture being coded, its reference, and (owf >= 2) the one still waiting to be output
   uint8_t *rec_[10][3] = {};
   bool spin_wait_ = false;      // KVAZZUP_AMD_SPIN: poll the GPU instead of napping between queries
@@ -123,13 +127,13 @@ class Encoder {
   int cur_idx_ = 0, ref_idx_ = 2, out_idx_ = 2;
   // Two sets of everything the tokenizer reads (levels and CU records): picture t is tokenised on the second stream
   // from set t & 1 while the kernels of picture t + 1 fill the other one.
-  int16_t *coef_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-  uint8_t *cu_bytes_[2] = {nullptr, nullptr};          // 7 byte arrays back to back
-  int16_t *cu_mv_[2] = {nullptr, nullptr}, *cu_mvd_[2] = {nullptr, nullptr};
+  int16_t *coef_[kSets][3] = {};
+  uint8_t *cu_bytes_[kSets] = {};          // 7 byte arrays back to back
+  int16_t *cu_mv_[kSets] = {}, *cu_mvd_[kSets] = {};
   int set_ = 0, out_set_ = 0;
   std::vector<int8_t> roi_; int roi_w_ = 0, roi_h_ = 0;
-  int8_t *ctu_qt_[2] = {nullptr, nullptr}, *ctu_qy_[2] = {nullptr, nullptr}, *ctu_delta_[2] = {nullptr, nullptr}; uint8_t *ctu_first_[2] = {nullptr, nullptr};   // per picture parity
-  int8_t *h_ctu_qt_[2] = {nullptr, nullptr};   // pinned staging of the target map
+  int8_t *ctu_qt_[kSets] = {}, *ctu_qy_[kSets] = {}, *ctu_delta_[kSets] = {}; uint8_t *ctu_first_[kSets] = {};   // per set
+  int8_t *h_ctu_qt_[kSets] = {};   // pinned staging of the target map
   int *vaq_act_ = nullptr, *vaq_sum_ = nullptr; // VAQ: activity of every CTU, its sum over the picture
   bool upload_qp_targets();
   int qp_cur_ = 0; int64_t rc_debt_ = 0; uint32_t rc_bytes_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t rc_known_ = 0;   // rate control state (calling thread)
@@ -139,11 +143,11 @@ class Encoder {
   bool band_intra_ = false;
   hipStream_t stream_tok_ = nullptr;     // signalling decisions, tokenizer, compaction
   hipStream_t stream_in_ = nullptr;      // input padding (runs ahead of the previous picture's kernels)
-  hipEvent_t ev_src_free_[2] = {nullptr, nullptr}; bool src_busy_[2] = {false, false};
+  hipEvent_t ev_src_free_[kSets] = {}; bool src_busy_[kSets] = {};
   uint8_t *work_[3] = {nullptr, nullptr, nullptr};   // SAO on: the picture up to deblocking (rec_[] then holds the filtered pictures)
-  SaoParams *sao_[2] = {nullptr, nullptr};            // per CTU, one array per set
+  SaoParams *sao_[kSets] = {};            // per CTU, one array per set
   hipEvent_t ev_sao_ = nullptr;
-  hipEvent_t ev_signalled_ = nullptr, ev_tok_done_[2] = {nullptr, nullptr}; bool tok_pending_[2] = {false, false};
+  hipEvent_t ev_signalled_ = nullptr, ev_tok_done_[kSets] = {}; bool tok_pending_[kSets] = {};
   void bind_set(int k);
   uint8_t *intra_scratch_ = nullptr;
   uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; int tok_nctu_ = 0;

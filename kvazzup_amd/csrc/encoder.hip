@@ -78,11 +78,11 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   HIP_OK(hipHostMalloc(&h_in_, in_bytes, hipHostMallocDefault));
   for (int c = 0; c < 3; c++) {
     size_t n = c ? npx / 4 : npx;
-    HIP_OK(hipMalloc(&src_[0][c], n)); HIP_OK(hipMalloc(&src_[1][c], n));
+    for (int k = 0; k < kSets; k++) HIP_OK(hipMalloc(&src_[k][c], n));
     for (int b = 0; b < nrec_; b++) { HIP_OK(hipMalloc(&rec_[b][c], n)); HIP_OK(hipMemset(rec_[b][c], 0, n)); }
-    for (int k = 0; k < 2; k++) { HIP_OK(hipMalloc(&coef_[k][c], n * sizeof(int16_t))); HIP_OK(hipMemset(coef_[k][c], 0, n * sizeof(int16_t))); }
+    for (int k = 0; k < kSets; k++) { HIP_OK(hipMalloc(&coef_[k][c], n * sizeof(int16_t))); HIP_OK(hipMemset(coef_[k][c], 0, n * sizeof(int16_t))); }
   }
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < kSets; k++) {
     HIP_OK(hipMalloc(&cu_bytes_[k], nb8 * 7)); HIP_OK(hipMemset(cu_bytes_[k], 0, nb8 * 7));
     HIP_OK(hipMalloc(&cu_mv_[k], nb8 * 2 * sizeof(int16_t))); HIP_OK(hipMemset(cu_mv_[k], 0, nb8 * 2 * sizeof(int16_t)));
     HIP_OK(hipMalloc(&cu_mvd_[k], nb8 * 2 * sizeof(int16_t))); HIP_OK(hipMemset(cu_mvd_[k], 0, nb8 * 2 * sizeof(int16_t)));
@@ -90,7 +90,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   }
   if (cfg.qp_in_cu) {
     const size_t nctu = (size_t)(cw_ / 64) * rows_;
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < kSets; k++) {
       HIP_OK(hipMalloc(&ctu_qt_[k], nctu)); HIP_OK(hipMalloc(&ctu_qy_[k], nctu)); HIP_OK(hipMalloc(&ctu_delta_[k], nctu)); HIP_OK(hipMalloc(&ctu_first_[k], nctu));
       HIP_OK(hipHostMalloc(&h_ctu_qt_[k], nctu, hipHostMallocDefault));
     }
@@ -98,13 +98,13 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   }
   if (cfg.sao) {
     for (int c = 0; c < 3; c++) HIP_OK(hipMalloc(&work_[c], c ? npx / 4 : npx));
-    for (int k = 0; k < 2; k++) HIP_OK(hipMalloc(&sao_[k], sizeof(SaoParams) * (size_t)(cw_ / 64) * rows_));
+    for (int k = 0; k < kSets; k++) HIP_OK(hipMalloc(&sao_[k], sizeof(SaoParams) * (size_t)(cw_ / 64) * rows_));
     HIP_OK(hipEventCreateWithFlags(&ev_sao_, hipEventDisableTiming));
   }
   if (cfg.rc_bands > 0) { HIP_OK(hipMalloc(&rc_state_, sizeof(RcState))); HIP_OK(hipMemset(rc_state_, 0, sizeof(RcState))); }
   HIP_OK(create_stream(&stream_tok_, prio[1]));
   HIP_OK(create_stream(&stream_in_, prio[2]));
-  for (int k = 0; k < 2; k++) HIP_OK(hipEventCreateWithFlags(&ev_src_free_[k], hipEventDisableTiming));
+  for (int k = 0; k < kSets; k++) HIP_OK(hipEventCreateWithFlags(&ev_src_free_[k], hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&ev_signalled_, hipEventDisableTiming));
   // intra scratch: ic8 (nb8 u32) | ic16 (nb8/4 u32) | ic32 (nb8/16 u32) | im8 | im16 | im32
   size_t isz = nb8 * 4 + nb8 + nb8 / 4 + nb8 + nb8 / 4 + nb8 / 16 + 64;
@@ -232,15 +232,15 @@ Encoder::~Encoder()
   }
   if (in_done_) hipEventDestroy(in_done_);
   hipFree(d_in_); hipHostFree(h_in_);
-  for (int c = 0; c < 3; c++) { hipFree(src_[0][c]); hipFree(src_[1][c]); for (int b = 0; b < 10; b++) hipFree(rec_[b][c]); hipFree(coef_[0][c]); hipFree(coef_[1][c]); }
+  for (int c = 0; c < 3; c++) { for (int k = 0; k < kSets; k++) { hipFree(src_[k][c]); hipFree(coef_[k][c]); } for (int b = 0; b < 10; b++) hipFree(rec_[b][c]); }
   hipFree(vaq_act_); hipFree(vaq_sum_); hipFree(rc_state_);
-  for (int k = 0; k < 2; k++) { hipFree(ctu_qt_[k]); hipFree(ctu_qy_[k]); hipFree(ctu_delta_[k]); hipFree(ctu_first_[k]); if (h_ctu_qt_[k]) hipHostFree(h_ctu_qt_[k]); }
-  for (int k = 0; k < 2; k++) { hipFree(cu_bytes_[k]); hipFree(cu_mv_[k]); hipFree(cu_mvd_[k]); if (ev_tok_done_[k]) hipEventDestroy(ev_tok_done_[k]); }
+  for (int k = 0; k < kSets; k++) { hipFree(ctu_qt_[k]); hipFree(ctu_qy_[k]); hipFree(ctu_delta_[k]); hipFree(ctu_first_[k]); if (h_ctu_qt_[k]) hipHostFree(h_ctu_qt_[k]); }
+  for (int k = 0; k < kSets; k++) { hipFree(cu_bytes_[k]); hipFree(cu_mv_[k]); hipFree(cu_mvd_[k]); if (ev_tok_done_[k]) hipEventDestroy(ev_tok_done_[k]); }
   for (int c = 0; c < 3; c++) hipFree(work_[c]);
-  for (int k = 0; k < 2; k++) hipFree(sao_[k]);
+  for (int k = 0; k < kSets; k++) hipFree(sao_[k]);
   if (ev_sao_) hipEventDestroy(ev_sao_);
   if (ev_signalled_) hipEventDestroy(ev_signalled_);
-  for (int k = 0; k < 2; k++) if (ev_src_free_[k]) hipEventDestroy(ev_src_free_[k]);
+  for (int k = 0; k < kSets; k++) if (ev_src_free_[k]) hipEventDestroy(ev_src_free_[k]);
   if (stream_tok_) hipStreamDestroy(stream_tok_);
   if (stream_in_) hipStreamDestroy(stream_in_);
   hipFree(intra_scratch_);
@@ -349,7 +349,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   //   stream_:     motion search / intra decisions, reconstruction, deblocking: the chain picture t + 1 depends on.
   //   stream_tok_: merge/AMVP signalling, tokenizer, compaction, which only feed the host; they read set t & 1 of the
   //                level / CU arrays while stream_ already fills the other set for t + 1.
-  set_ = (int)(submitted_ & 1);
+  set_ = (int)(submitted_ % kSets);
   bind_set(set_);
   const int period = cfg_.intra_period;
   const bool intra = (frame_idx_ == 0) || (period > 0 && (frame_idx_ % period) == 0);
@@ -361,17 +361,17 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err; f_.ent_cursors = sl.g_cursors;
   f_.tok_cursor = (uint32_t *)tok_count_ + (size_t)(frame_idx_ & 1) * tok_nctu_; f_.tok_cursor_next = (uint32_t *)tok_count_ + (size_t)((frame_idx_ + 1) & 1) * tok_nctu_;
   const EncFrame f = f_;
-  if (src_busy_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_src_free_[set_], 0)); src_busy_[set_] = false; }   // reconstruction of t - 2 has read this source set
+  if (src_busy_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_src_free_[set_], 0)); src_busy_[set_] = false; }   // the last picture that used this set (t - kSets) has been reconstructed
   timed(K_PAD, stream_in_, [&] { launch_pad_input(d_i420, w, h, src_[set_][0], src_[set_][1], src_[set_][2], cw_, ch_, stream_in_); });
   if (intra) {
     // The intra decisions need the source picture only: they run on the input stream, beside what is left of picture t - 1
-    // on the main stream (they write the CU arrays of this set: the tokenizer of t - 2 must be done with them).
+    // on the main stream (they write the CU arrays of this set: the tokenizer of the set's previous picture must be done with them).
     if (tok_pending_[set_]) HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_tok_done_[set_], 0));
     timed(K_INTRA_ANALYSE, stream_in_, [&] { launch_intra_analyse(f, stream_in_); });
   }
   HIP_CHECK(hipEventRecord(in_done_, stream_in_)); in_pending_ = true;
   HIP_CHECK(hipStreamWaitEvent(stream_, in_done_, 0));
-  if (tok_pending_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_, ev_tok_done_[set_], 0)); tok_pending_[set_] = false; }   // tokenizer of t - 2 done with this set
+  if (tok_pending_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_, ev_tok_done_[set_], 0)); tok_pending_[set_] = false; }   // the tokenizer of the set's previous picture is done with it
   if (!upload_qp_targets()) return false;
   if (rc_state_) launch_rc_begin(rc_state_, frame_idx_ >= 3 ? 8u * rc_bytes_[(frame_idx_ - 3) & 7] : 0u, (frame_idx_ - 3) & 7, frame_idx_ >= 3, stream_);
   if (intra) {
@@ -399,7 +399,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   if (cfg_.deblock) timed(K_DEBLOCK, stream_, [&] { launch_deblock(f, stream_); });
   if (cfg_.sao) { timed(K_SAO, stream_, [&] { launch_sao(f, stream_); }); HIP_CHECK(hipEventRecord(ev_sao_, stream_)); }
   // Last reader of this set on the main stream: k_sao reads the source picture for its statistics, deblocking the CU records.
-  // Input padding and intra analysis of picture t + 2 (input stream) overwrite both and wait for this event.
+  // Input padding and intra analysis of the next picture with this set (input stream) overwrite both and wait for this event.
   HIP_CHECK(hipEventRecord(ev_src_free_[set_], stream_)); src_busy_[set_] = true;
   HIP_CHECK(hipStreamWaitEvent(stream_tok_, ev_signalled_, 0));
   if (!intra) timed(K_INTER_SIGNAL, stream_tok_, [&] { launch_inter_signal(f, stream_tok_); });

@@ -535,23 +535,10 @@ def main():
     m = run_stream(args, wl, args.steps, args.warmup, torch, dev, dev_index, rank, world, sync, quality=(rank == 0))
     sec = None
     if world == 1 and args.workload == "1080p" and not args.no_secondary:
-        # The 4K line is measured by a child process of its own: the streams of a second pipeline in THIS process land on other hardware
-        # queues than those of a first one (HIP hands its four queues per priority out in turn), which costs the 4K pipeline 15-20 %
-        # (KVAZZUP_AMD_PRIO layouts measured: DESIGN.md section 6); a fresh process gives what `bench.py --workload 4k` gives.  This
-        # process is idle meanwhile (its pipelines are closed).
-        ssteps = max(1, min(args.steps, args.secondary_steps))
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", "4k", "--gpus", "1", "--steps", str(ssteps), "--warmup", str(min(2, max(1, args.warmup))),
-               "--no-cpu-baseline", "--no-secondary", "--owf", str(args.owf), "--decoder-frame-threads", str(args.decoder_frame_threads),
-               "--me-range", str(args.me_range), "--profile-every", str(args.profile_every)]
-        cmd += (["--sao"] if args.sao else []) + (["--full-search"] if args.full_search else []) + (["--intra-sad"] if args.intra_sad else [])
-        cmd += (["--gpu-entropy"] if args.gpu_entropy else []) + (["--subme", str(args.subme)] if args.subme else [])
+        # (a second pipeline in this process inherits the first one's HIP streams -- csrc/stream_pool.h -- and with them its hardware-queue
+        # layout; before that pool the 4K leg ran 15-20 % slower here than in a process of its own)
         try:
-            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode != 0 or not line:
-                raise RuntimeError("secondary run failed (rc %d): %s" % (r.returncode, r.stderr[-400:]))
-            sec = json.loads(line[-1])
+            sec = run_stream(args, WORKLOADS["4k"], max(1, min(args.steps, args.secondary_steps)), min(2, max(1, args.warmup)), torch, dev, dev_index, rank, world, sync, quality=True)
         except Exception as e:       # the headline line must not be lost to the secondary one
             sec = {"error": str(e)}
 
@@ -583,10 +570,12 @@ def main():
             if "error" in sec:
                 out["secondary"] = {"workload": WORKLOADS["4k"]["name"], "error": sec["error"]}
             else:
-                out["secondary"] = {"workload": WORKLOADS["4k"]["name"], "value": sec["value"], "unit": "frames/s", "measured_by": "a child process of this run",
-                                    "steps": sec["steps"], "warmup": sec["warmup"], "pictures_per_step": PERIOD, "ms_per_step": sec["ms_per_step"],
-                                    "bits_per_picture": sec["config"]["bits_per_picture"], "psnr_y": sec["config"]["psnr_y"],
-                                    "host_cpu_cores_busy": sec["config"]["host_cpu_cores_busy"], "roofline": sec["roofline"], "kernels_us": sec["kernels_us"]}
+                ssteps = max(1, min(args.steps, args.secondary_steps))
+                sroof, skern, _ = roofline_of(sec, ssteps, args.me_range, "4k")
+                out["secondary"] = {"workload": WORKLOADS["4k"]["name"], "value": round(sec["pictures"] / sec["elapsed"], 3), "unit": "frames/s",
+                                    "steps": ssteps, "pictures_per_step": PERIOD, "ms_per_step": round(sec["elapsed"] / ssteps * 1e3, 4),
+                                    "bits_per_picture": round(8 * sec["bytes_per_picture"], 1), "psnr_y": sec["psnr_y"],
+                                    "host_cpu_cores_busy": round(sec["host_cores"], 2), "roofline": sroof, "kernels_us": skern}
         if args.full_search and "k_me" in m["kt"] and m["kt"]["k_me"][1]:
             # The motion search is integer VALU work, not streaming: its own ceiling is the issue rate of v_qsad_pk_u16_u8
             # (four 4-sample SADs per lane; measured ~24 cycles per wave instruction on gfx950, tools/qsad_bench.hip ->

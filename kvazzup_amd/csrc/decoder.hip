@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include "stream_pool.h"
 #include "decoder.h"
 
 namespace kvzx {
@@ -798,13 +799,13 @@ Decoder::~Decoder()
   free_buffers();
   for (auto &o : ready_q_) if (o.dev) hipFree(o.dev);
   if (cur_owned_.dev) hipFree(cur_owned_.dev);
-  if (stream_dl_) hipStreamDestroy(stream_dl_);
-  if (stream_up_) hipStreamDestroy(stream_up_);
+  stream_release(stream_dl_, device_, 'L', 'n');
+  stream_release(stream_up_, device_, 'U', 'n');
   for (auto &e : up_done_) if (e) hipEventDestroy(e);
   if (err_ev_) hipEventDestroy(err_ev_);
   if (h_err_) hipHostFree(h_err_);
   if (err_) hipFree(err_);
-  if (stream_) hipStreamDestroy(stream_);
+  stream_release(stream_, device_, 'D', prio_);
 }
 
 bool Decoder::start(std::string *error)
@@ -817,14 +818,12 @@ bool Decoder::start(std::string *error)
   HIP_TRY(hipSetDevice(device_));
   spin_wait_ = getenv("KVAZZUP_AMD_SPIN") != nullptr;
   {
-    const char *prio = getenv("KVAZZUP_AMD_PRIO"); int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
-    const char lv = (prio && strlen(prio) >= 4) ? prio[3] : 'n';
-    if (lv == 'h') HIP_TRY(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
-    else if (lv == 'l') HIP_TRY(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, lo));
-    else HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    const char *prio = getenv("KVAZZUP_AMD_PRIO");
+    prio_ = (prio && strlen(prio) >= 4) ? prio[3] : 'n';
+    HIP_TRY(stream_acquire(&stream_, device_, 'D', prio_));        // (stream_pool.h: a re-created decoder gets its predecessor's streams)
   }
-  HIP_TRY(hipStreamCreateWithFlags(&stream_dl_, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&stream_up_, hipStreamNonBlocking));
+  HIP_TRY(stream_acquire(&stream_dl_, device_, 'L', 'n'));
+  HIP_TRY(stream_acquire(&stream_up_, device_, 'U', 'n'));
   for (auto &e : up_done_) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&err_ev_, hipEventDisableTiming));
   HIP_TRY(hipMalloc(&err_, sizeof(uint32_t)));

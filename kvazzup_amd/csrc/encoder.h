@@ -131,6 +131,7 @@ class Encoder {
   uint8_t *cu_bytes_[kSets] = {};          // 7 byte arrays back to back
   int16_t *cu_mv_[kSets] = {}, *cu_mvd_[kSets] = {};
   int set_ = 0, out_set_ = 0;
+  char prio_[3] = {'h', 'n', 'n'};                      // priority levels of the main, tokenizer and input streams (stream_pool.h keys)
   std::vector<int8_t> roi_; int roi_w_ = 0, roi_h_ = 0;
   int8_t *ctu_qt_[kSets] = {}, *ctu_qy_[kSets] = {}, *ctu_delta_[kSets] = {}; uint8_t *ctu_first_[kSets] = {};   // per set
   int8_t *h_ctu_qt_[kSets] = {};   // pinned staging of the target map

@@ -6,6 +6,7 @@
 #include <cstring>
 #include "encoder.h"
 #include "enc_kernels.h"
+#include "stream_pool.h"
 
 namespace kvzx {
 
@@ -17,16 +18,6 @@ Encoder *Encoder::create(const EncoderConfig &cfg, std::string *error)
   Encoder *e = new Encoder();
   if (!e->init(cfg, error)) { delete e; return nullptr; }
   return e;
-}
-
-// stream with one of the device's priority levels: 'h' most urgent, 'l' least, anything else the default
-static hipError_t create_stream(hipStream_t *st, char level)
-{
-  int lo = 0, hi = 0;
-  hipDeviceGetStreamPriorityRange(&lo, &hi);            // (hi is the numerically smallest = most urgent)
-  if (level == 'h') return hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi);
-  if (level == 'l') return hipStreamCreateWithPriority(st, hipStreamNonBlocking, lo);
-  return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }
 
 bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
@@ -72,7 +63,8 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   // is a longer stage than the host pool (a substream is one serial chain) and profits from up to 8.
   depth_ = cfg.owf >= 3 && cfg.bitrate == 0 ? (cfg.owf > 8 ? 8 : cfg.owf) : (cfg.owf >= 2 ? 2 : (cfg.owf == 1 ? 1 : 0));
   nrec_ = depth_ + 1 < 3 ? 3 : depth_ + 1;
-  HIP_OK(create_stream(&stream_, prio[0]));
+  prio_[0] = prio[0]; prio_[1] = prio[1]; prio_[2] = prio[2];
+  HIP_OK(stream_acquire(&stream_, cfg.device, 'M', prio_[0]));
   const size_t npx = (size_t)cw_ * ch_, nb8 = npx / 64, in_bytes = (size_t)cfg.width * cfg.height * 3 / 2;
   HIP_OK(hipMalloc(&d_in_, in_bytes));
   HIP_OK(hipHostMalloc(&h_in_, in_bytes, hipHostMallocDefault));
@@ -102,8 +94,8 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     HIP_OK(hipEventCreateWithFlags(&ev_sao_, hipEventDisableTiming));
   }
   if (cfg.rc_bands > 0) { HIP_OK(hipMalloc(&rc_state_, sizeof(RcState))); HIP_OK(hipMemset(rc_state_, 0, sizeof(RcState))); }
-  HIP_OK(create_stream(&stream_tok_, prio[1]));
-  HIP_OK(create_stream(&stream_in_, prio[2]));
+  HIP_OK(stream_acquire(&stream_tok_, cfg.device, 'T', prio_[1]));
+  HIP_OK(stream_acquire(&stream_in_, cfg.device, 'I', prio_[2]));
   for (int k = 0; k < kSets; k++) HIP_OK(hipEventCreateWithFlags(&ev_src_free_[k], hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&ev_signalled_, hipEventDisableTiming));
   // intra scratch: ic8 (nb8 u32) | ic16 (nb8/4 u32) | ic32 (nb8/16 u32) | im8 | im16 | im32
@@ -136,7 +128,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
       HIP_OK(hipHostGetDevicePointer(&dp, sl.h_out, 0)); sl.d_out = (uint8_t *)dp;
       HIP_OK(hipHostMalloc(&sl.h_sub, sizeof(uint32_t) * 3 * rows_, hipHostMallocMapped));
       HIP_OK(hipHostGetDevicePointer(&dp, sl.h_sub, 0)); sl.d_sub = (uint32_t *)dp;
-      HIP_OK(create_stream(&sl.ent_stream, 'l'));           // (streams of one priority level share that level's hardware queues: the long coder kernels get the lowest level to themselves)
+      HIP_OK(stream_acquire(&sl.ent_stream, cfg.device, 'E', 'l'));           // (streams of one priority level share that level's hardware queues: the long coder kernels get the lowest level to themselves)
       HIP_OK(hipEventCreateWithFlags(&sl.tok_ev, hipEventDisableTiming));
     } else {
       HIP_OK(hipHostMalloc(&sl.h_tok_dense, tok_dense_cap_ * sizeof(uint16_t), hipHostMallocMapped));
@@ -222,7 +214,7 @@ Encoder::~Encoder()
     if (sl.h_tok_count) hipHostFree(sl.h_tok_count);
     if (sl.h_err) hipHostFree(sl.h_err);
     if (sl.h_tok_off) hipHostFree(sl.h_tok_off);
-    if (sl.ent_stream) { hipStreamSynchronize(sl.ent_stream); hipStreamDestroy(sl.ent_stream); }
+    stream_release(sl.ent_stream, cfg_.device, 'E', 'l');
     if (sl.tok_ev) hipEventDestroy(sl.tok_ev);
     hipFree(sl.g_tok); hipFree(sl.g_count); hipFree(sl.g_off); hipFree(sl.g_stage); hipFree(sl.g_cursors); hipFree(sl.g_ctx_save); hipFree(sl.g_ctx_ready);
     if (sl.h_out) hipHostFree(sl.h_out);
@@ -241,12 +233,12 @@ Encoder::~Encoder()
   if (ev_sao_) hipEventDestroy(ev_sao_);
   if (ev_signalled_) hipEventDestroy(ev_signalled_);
   for (int k = 0; k < kSets; k++) if (ev_src_free_[k]) hipEventDestroy(ev_src_free_[k]);
-  if (stream_tok_) hipStreamDestroy(stream_tok_);
-  if (stream_in_) hipStreamDestroy(stream_in_);
+  stream_release(stream_tok_, cfg_.device, 'T', prio_[1]);
+  stream_release(stream_in_, cfg_.device, 'I', prio_[2]);
   hipFree(intra_scratch_);
   delete entropy_; delete entropy2_;
   hipFree(trace_); hipFree(intra_order_); hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(sync_); hipFree(err_);
-  if (stream_) hipStreamDestroy(stream_);
+  stream_release(stream_, cfg_.device, 'M', prio_[0]);
 }
 
 void Encoder::timed(KernelId id, hipStream_t st, const std::function<void()> &launch)

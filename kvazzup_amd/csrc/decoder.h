@@ -233,6 +233,7 @@ class Decoder {
   uint32_t *progress_ = nullptr, *intra_order_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
   uint8_t *h_out_ = nullptr; size_t h_out_cap_ = 0;
   long launched_ = 0; int out_slot_ = 0; int output_hold_ = 2;
+  char prio_dl_ = 'n', prio_up_ = 'n';
   char prio_ = 'n';                                       // priority level of the main stream (stream_pool.h key)
   int band_row0_ = 0, band_nrows_ = 0; uint8_t *band_din_ = nullptr; DecFrame band_f_{};      // band mode: the picture between its reconstruction and band_finish
   double t_parse_max_ = 0;                // trace: the longest parse of one picture (an IDR), ms

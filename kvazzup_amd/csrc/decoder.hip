@@ -799,8 +799,8 @@ Decoder::~Decoder()
   free_buffers();
   for (auto &o : ready_q_) if (o.dev) hipFree(o.dev);
   if (cur_owned_.dev) hipFree(cur_owned_.dev);
-  stream_release(stream_dl_, device_, 'L', 'n');
-  stream_release(stream_up_, device_, 'U', 'n');
+  stream_release(stream_dl_, device_, 'L', prio_dl_);
+  stream_release(stream_up_, device_, 'U', prio_up_);
   for (auto &e : up_done_) if (e) hipEventDestroy(e);
   if (err_ev_) hipEventDestroy(err_ev_);
   if (h_err_) hipHostFree(h_err_);
@@ -822,8 +822,12 @@ bool Decoder::start(std::string *error)
     prio_ = (prio && strlen(prio) >= 4) ? prio[3] : 'n';
     HIP_TRY(stream_acquire(&stream_, device_, 'D', prio_));        // (stream_pool.h: a re-created decoder gets its predecessor's streams)
   }
-  HIP_TRY(stream_acquire(&stream_dl_, device_, 'L', 'n'));
-  HIP_TRY(stream_acquire(&stream_up_, device_, 'U', 'n'));
+  {
+    const char *prio = getenv("KVAZZUP_AMD_PRIO");          // (letters 5 and 6: the download and the upload stream)
+    prio_dl_ = (prio && strlen(prio) >= 5) ? prio[4] : 'n'; prio_up_ = (prio && strlen(prio) >= 6) ? prio[5] : 'n';
+  }
+  HIP_TRY(stream_acquire(&stream_dl_, device_, 'L', prio_dl_));
+  HIP_TRY(stream_acquire(&stream_up_, device_, 'U', prio_up_));
   for (auto &e : up_done_) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&err_ev_, hipEventDisableTiming));
   HIP_TRY(hipMalloc(&err_, sizeof(uint32_t)));

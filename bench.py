@@ -233,6 +233,8 @@ def tilesplit_main(args):
             aus.append(au)
     torch.cuda.synchronize()
     barrier_max(dist, backend, dev, torch)
+    if hasattr(be, "times"):
+        be.times.clear()                                              # (KVAZZUP_BENCH_TILESPLIT_TIMES: the timed pictures only)
     t0 = time.perf_counter()
     for t in range(args.warmup, total):
         au = be.encode(clip[t % nclip].data_ptr())
@@ -257,7 +259,7 @@ def tilesplit_main(args):
                        "exchange": "2 halo blocks per internal boundary and picture (4 luma + 2x2 chroma rows + CU records), send/recv, in flight during the tokenizer and the arithmetic coder; substreams: fixed-size all_gather of the headers + padded gather of the payloads, completed during the next picture"},
             "secondary": decode, "roofline": None, "cpu_baseline": None}), flush=True)
     if os.environ.get("KVAZZUP_BENCH_TILESPLIT_TIMES"):
-        print("rank %d seconds per phase over %d pictures: %s" % (rank, total, {k: round(v, 4) for k, v in getattr(be, "times", {}).items()}), file=sys.stderr, flush=True)
+        print("rank %d seconds per phase over %d pictures: %s" % (rank, args.steps, {k: round(v, 4) for k, v in getattr(be, "times", {}).items()}), file=sys.stderr, flush=True)
     be.close()
     if world > 1:
         dist.destroy_process_group()

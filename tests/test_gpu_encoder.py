@@ -429,3 +429,29 @@ def test_vaq_matches_oracle(gpu, cfg):
     """uvgComm video/VAQ (kvazaar "vaq" 1..20, kvazaarfilter.cpp:280-284): per-CTU QP from the CTU's luma variance against the
     picture's average ("uvgx VAQ v1"), carried as cu_qp_delta; k_vaq_stats / k_vaq_apply against the checker"""
     run_clip(**cfg)
+
+
+@pytest.mark.gpu
+def test_reopened_instances_reuse_streams_and_code_identically(gpu):
+    """uvgComm closes and re-opens its encoder and decoder on every settings change (kvazaarfilter.cpp:91-119): the library hands the HIP
+    streams of a closed instance to the next one (csrc/stream_pool.h); access units and decoded pictures stay those of the first instance"""
+    from kvazzup_amd.codec import Encoder, Decoder
+    w, h, frames = 640, 384, 5
+    clip = [orc.synth_frame(0, SEED, w, h, t) for t in range(frames)]
+    first = None
+    for cycle in range(4):
+        e = Encoder(w, h, options=(("qp", 30), ("period", 4), ("me-range", 8), ("owf", 2)))
+        d = Decoder()
+        aus = []
+        for f in clip + [None, None]:
+            au, _ = e.encode(f)
+            if au is not None:
+                aus.append(au)
+        pics = [p["i420"].copy() for au in aus for p in d.decode_au(au)]
+        e.close(); d.close()
+        assert len(aus) == frames and len(pics) == frames
+        if first is None:
+            first = (aus, pics)
+        else:
+            assert aus == first[0]
+            assert all(np.array_equal(a, b) for a, b in zip(pics, first[1]))

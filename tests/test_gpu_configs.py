@@ -42,15 +42,17 @@ def test_config1_plain_1080p_p64_qp32_matches_oracle(gpu):
 
 
 @pytest.mark.gpu
-def test_config1_long_run_two_idrs(gpu):
-    """130 pictures of the 1080p / period-64 workload through the pipelined filters (owf 3, 12 frame threads, device-resident
-    input): three IDRs; every decoded picture equals what a fresh synchronous decoder produces from the same access units, and the
+@pytest.mark.parametrize("owf,threads", [(3, 12), (6, 24)])
+def test_config1_long_run_two_idrs(gpu, owf, threads):
+    """130 pictures of the 1080p / period-64 workload through the pipelined filters (owf 3 with 12 frame threads; the benchmark's
+    owf 6 with 24: all eight working sets of the encoder in rotation, pictures queued behind the intra pictures' chains):
+    three IDRs; every decoded picture equals what a fresh synchronous decoder produces from the same access units, and the
     first pictures equal the checker's"""
     from kvazzup_amd import synth
     from kvazzup_amd.codec import Decoder
     from kvazzup_amd.pipeline import Pipeline
     w, h, n = 1920, 1080, 130
-    pl = Pipeline(w, h, settings={"video/QP": 32, "video/Intra": 64, "video/OWF": 3, "video/OPENHEVC_threads": 12, "video/OH_parallelization": "Frame"},
+    pl = Pipeline(w, h, settings={"video/QP": 32, "video/Intra": 64, "video/OWF": owf, "video/OPENHEVC_threads": threads, "video/OH_parallelization": "Frame"},
                   custom=(("me-range", 16),))
     clip = [synth.frame(synth.MOVING, SEED, w, h, t) for t in range(4)]
     frames = [orc.synth_frame(0, SEED, w, h, t) for t in range(n)]

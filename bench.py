@@ -314,8 +314,12 @@ def tilesplit_decode(args, aus, h, tile_rows, rank, world, torch, dist, dev, dev
             "ms_per_picture": round(elapsed / done * 1e3, 4), "exchange": "2 blocks of 8 x W bytes per internal boundary and picture, around the deblocking"}
 
 
-def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync, quality):
-    """K = steps intra periods of one stream through KvazaarFilter' -> WireAdapter -> OpenHEVCFilter' on this rank's GPU.
+def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync, quality, host_io=False, extra_custom=(), extra_settings=None):
+    """K = steps intra periods of one stream through KvazaarFilter' -> WireAdapter -> OpenHEVCFilter' on this rank's GPU, timed
+    args.repeats times (median of 3 runs); every repetition starts and ends on an empty, flushed pipeline.
+    host_io: the reference's own boundary -- pictures enter as HOST I420 through kvz_api->encoder_encode(kvz_picture*) (the filter's
+    memcpy into the kvz_picture included, kvazaarfilter.cpp:410-438) and leave through libOpenHevcGetOutput + the filter's row copy into
+    host memory (openhevcfilter.cpp:192-239): PCIe both ways inside the timed region.
     Returns a dict of measurements.  sync(value=None) = barrier / max over ranks."""
     from kvazzup_amd import synth
     from kvazzup_amd.pipeline import Pipeline
@@ -340,15 +344,18 @@ def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync
     else:
         clip = [synth.frame_torch(synth.MOVING, seed, w, h, t, dev) for t in range(nclip)]
     torch.cuda.synchronize()
+    host_clip = [c.cpu().numpy() for c in clip] if host_io else None       # pageable host memory, as a camera filter's frames are
 
     def make(keep, download):
-        return Pipeline(w, h, settings={"video/QP": 32, "video/Intra": PERIOD, "video/VPS": 1, "uvgx/gpu": dev_index, "uvgx/decoderDownload": int(download),
-                                        "video/OWF": args.owf, "video/OPENHEVC_threads": D, "video/OH_parallelization": "Frame" if D > 1 else "Slice"},
-                        custom=(("me-range", args.me_range), ("gpu", dev_index)) + ((("sao", "full"),) if args.sao else ()) + ((("me-early-termination", "off"),) if args.full_search else ()) + ((("intra-satd", "0"),) if args.intra_sad else ()) + ((("gpu-entropy", "1"),) if args.gpu_entropy else ()) + ((("subme", str(args.subme)),) if args.subme else ()),
+        st = {"video/QP": 32, "video/Intra": PERIOD, "video/VPS": 1, "uvgx/gpu": dev_index, "uvgx/decoderDownload": int(download),
+              "video/OWF": args.owf, "video/OPENHEVC_threads": D, "video/OH_parallelization": "Frame" if D > 1 else "Slice"}
+        st.update(extra_settings or {})
+        return Pipeline(w, h, settings=st,
+                        custom=(("me-range", args.me_range), ("gpu", dev_index)) + ((("sao", "full"),) if args.sao else ()) + ((("me-early-termination", "off"),) if args.full_search else ()) + ((("intra-satd", "0"),) if args.intra_sad else ()) + ((("gpu-entropy", "1"),) if args.gpu_entropy else ()) + ((("subme", str(args.subme)),) if args.subme else ()) + tuple(extra_custom),
                         loopback=True, keep_outputs=keep)
 
     # source -> KvazaarFilter -> WireAdapter -> OpenHEVCFilter -> sink, one thread per filter (csrc/filters.hip)
-    pl = make(False, False)
+    pl = make(False, host_io)
     lib = pl.lib
     enc_h, dec_h = pl.encoder_handle(), pl.decoder_handle()
     cw, ch = C.c_int(), C.c_int()
@@ -360,7 +367,8 @@ def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync
         encoder filter's input buffer short of its overflow threshold (a uvgComm filter drops inputs at 10 buffered, filter.cpp:151-222)."""
         last = pl.pushed + npic
         while pl.pushed < last:
-            if not pl.push_device_paced(clip[pl.pushed % nclip].data_ptr(), 6, 120000):
+            ok = pl.push_host_paced(host_clip[pl.pushed % nclip], 6, 120000) if host_io else pl.push_device_paced(clip[pl.pushed % nclip].data_ptr(), 6, 120000)
+            if not ok:
                 raise RuntimeError("pipeline stalled")
         pl.flush()
         if not pl.wait(last, 120000):
@@ -390,42 +398,50 @@ def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync
     busy0 = pl.busy_ms()
     st0 = pl.stats()
     times(True)
-    torch.cuda.synchronize()                                   # the pipeline is empty: everything pushed so far has been decoded
-    sync()
-    cpu0 = time.process_time()
-    thr0 = _throttled_us()
     _thr0 = _thread_cpu() if os.environ.get("KVAZZUP_BENCH_THREADS") else None
     _sampler = None
-    if os.environ.get("CPU_SAMPLER_REGION"):                  # tools/cpu_sampler.c preloaded: sample the timed region only
+    if os.environ.get("CPU_SAMPLER_REGION"):                  # tools/cpu_sampler.c preloaded: sample the timed regions only
         _sampler = C.CDLL(None)
-        _sampler.cpu_sampler_begin()
-    t0 = time.perf_counter()
-    run(steps * PERIOD)
-    torch.cuda.synchronize()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if _sampler is not None:
-        _sampler.cpu_sampler_end()
-    throttled_ms = (_throttled_us() - thr0) / 1e3              # summed over the job's threads: > 0 means the CPU quota, not the GPU, set the pace for a while
-    host_cores = (time.process_time() - cpu0) / elapsed        # CPU seconds of all threads of this rank per second of the timed region
-    if _thr0 is not None:                                       # KVAZZUP_BENCH_THREADS=1: CPU time per thread over the timed region (stderr)
+    reps = []
+    for rep in range(max(1, args.repeats)):
+        torch.cuda.synchronize()                               # the pipeline is empty: everything pushed so far has been decoded
+        sync()
+        cpu0 = time.process_time()
+        thr0 = _throttled_us()
+        if _sampler is not None:
+            _sampler.cpu_sampler_begin()
+        t0 = time.perf_counter()
+        run(steps * PERIOD)
+        torch.cuda.synchronize()
+        sync()
+        el = time.perf_counter() - t0
+        if _sampler is not None:
+            _sampler.cpu_sampler_end()
+        # throttled: summed over the job's threads: > 0 means the CPU quota, not the GPU, set the pace for a while; host cores: CPU
+        # seconds of all threads of this rank per second of the timed region
+        reps.append({"elapsed": sync(el), "throttled_ms": (_throttled_us() - thr0) / 1e3, "host_cores": (time.process_time() - cpu0) / el})
+    if _thr0 is not None:                                       # KVAZZUP_BENCH_THREADS=1: CPU time per thread over the timed regions (stderr)
         _thr1 = _thread_cpu()
+        tot = sum(r["elapsed"] for r in reps)
         rows = sorted(((_thr1[t][1] - _thr0.get(t, ("", 0.0))[1], t, _thr1[t][0]) for t in _thr1), reverse=True)
         for dt, t, name in rows[:40]:
             if dt > 0:
-                print("thread %7d %-16s %.3f s (%.2f cores)" % (t, name, dt, dt / elapsed), file=sys.stderr)
-    elapsed = sync(elapsed)
+                print("thread %7d %-16s %.3f s (%.2f cores)" % (t, name, dt, dt / tot), file=sys.stderr)
+    med = sorted(reps, key=lambda r: r["elapsed"])[len(reps) // 2]
+    elapsed, throttled_ms, host_cores = med["elapsed"], med["throttled_ms"], med["host_cores"]
     kt = times(False)
     npic = steps * PERIOD
-    busy = [round((b - a) / npic, 4) for a, b in zip(busy0, pl.busy_ms())]
+    nall = npic * len(reps)
+    busy = [round((b - a) / nall, 4) for a, b in zip(busy0, pl.busy_ms())]
     st = pl.stats()
     nbytes = st["encoded_bytes"] - st0["encoded_bytes"]
-    if st["decoded_pictures"] != pl.pushed or st["dropped"] or st["encoded_pictures"] - st0["encoded_pictures"] != npic:
+    if st["decoded_pictures"] != pl.pushed or st["dropped"] or st["encoded_pictures"] - st0["encoded_pictures"] != nall:
         raise RuntimeError("pipeline lost pictures: %r" % (st,))
     pl.close()
 
-    out = {"elapsed": elapsed, "pictures": npic, "cw": cw, "ch": ch, "kt": kt, "busy": busy, "bytes_per_picture": nbytes / npic, "D": D,
-           "host_cores": host_cores, "budget": budget, "throttled_ms": throttled_ms, "psnr_y": None}
+    out = {"elapsed": elapsed, "pictures": npic, "cw": cw, "ch": ch, "kt": kt, "busy": busy, "bytes_per_picture": nbytes / nall, "D": D,
+           "host_cores": host_cores, "budget": budget, "throttled_ms": throttled_ms, "psnr_y": None,
+           "runs_fps": [round(world * npic / r["elapsed"], 1) for r in reps]}
     if quality:
         # Quality of what was just timed (untimed pass): one intra period through a second pipeline with the decoded pictures
         # downloaded; luma PSNR of the decoder's output against the source, mean over the period's 64 pictures.
@@ -498,6 +514,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up steps (intra periods)")
     ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--me-range", type=int, default=16)
+    ap.add_argument("--repeats", type=int, default=3, help="the K-step timed region is run this many times; `value` is the median run (BASELINE.md: median of 3)")
+    ap.add_argument("--no-host-boundary", action="store_true", help="skip the `host_boundary` legs (host I420 in through kvz_api->encoder_encode, decoded I420 out into host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-decode", action="store_true", help="8k-tilesplit: skip the split decoder's leg (reported as `secondary`)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 4K line (configs[2], the north-star target) that a 1080p run appends as `secondary`")
@@ -534,13 +552,37 @@ def main():
 
     wl = WORKLOADS[args.workload]
     w, h = wl["w"], wl["h"]
-    m = run_stream(args, wl, args.steps, args.warmup, torch, dev, dev_index, rank, world, sync, quality=(rank == 0))
+    resident = (("input-hold", "1"),)       # the clip's device pictures stay untouched: encode_device returns without waiting for its input stage
+    m = run_stream(args, wl, args.steps, args.warmup, torch, dev, dev_index, rank, world, sync, quality=(rank == 0), extra_custom=resident)
+    def host_leg(wl_, steps_, warm_, resident):
+        """the same steps through the reference's own boundary (run_stream host_io); a dict for the JSON line"""
+        try:
+            hb = run_stream(args, wl_, steps_, warm_, torch, dev, dev_index, rank, world, sync, quality=False, host_io=True, extra_custom=(("recon-output", "0"),))
+        except Exception as e:
+            return {"error": str(e)}
+        fps_h = world * hb["pictures"] / hb["elapsed"]
+        pic = wl_["w"] * wl_["h"] * 3 // 2
+        return {"value": round(fps_h, 3), "unit": "frames/s", "runs": hb["runs_fps"], "of_resident": round(fps_h / resident, 4),
+                "h2d_GBps": round(fps_h * pic / 1e9 / world, 2), "d2h_GBps": round(fps_h * pic / 1e9 / world, 2),
+                "host_cpu_cores_busy": round(hb["host_cores"], 2),
+                "filter_busy_ms_per_picture": {"KvazaarFilter": hb["busy"][0], "WireAdapter": hb["busy"][1], "OpenHEVCFilter": hb["busy"][2]},
+                "boundary": "host I420 -> KvazaarFilter' (memcpy into a page-locked kvz_picture, kvz_api->encoder_encode; recon-output=0: uvgComm frees the "
+                            "reconstruction unread, kvazaarfilter.cpp:476) -> access units -> OpenHEVCFilter' (libOpenHevcDecode / GetOutput, row copy into host "
+                            "memory, openhevcfilter.cpp:192-239); uploads and downloads on their own HIP streams beside the kernels"}
+
+    hostb = None
+    if not args.no_host_boundary:
+        hostb = host_leg(wl, args.steps, args.warmup, world * args.steps * PERIOD / m["elapsed"])
     sec = None
+    sec_host = None
     if world == 1 and args.workload == "1080p" and not args.no_secondary:
         # (a second pipeline in this process inherits the first one's HIP streams -- csrc/stream_pool.h -- and with them its hardware-queue
         # layout; before that pool the 4K leg ran 15-20 % slower here than in a process of its own, DESIGN.md section 6)
         try:
-            sec = run_stream(args, WORKLOADS["4k"], max(1, min(args.steps, args.secondary_steps)), min(2, max(1, args.warmup)), torch, dev, dev_index, rank, world, sync, quality=True)
+            sec = run_stream(args, WORKLOADS["4k"], max(1, min(args.steps, args.secondary_steps)), min(2, max(1, args.warmup)), torch, dev, dev_index, rank, world, sync, quality=True, extra_custom=resident)
+            if not args.no_host_boundary:
+                ssteps_ = max(1, min(args.steps, args.secondary_steps))
+                sec_host = host_leg(WORKLOADS["4k"], ssteps_, 1, sec["pictures"] / sec["elapsed"])
         except Exception as e:       # the headline line must not be lost to the secondary one
             sec = {"error": str(e)}
 
@@ -562,7 +604,9 @@ def main():
                        "bits_per_picture": round(8 * m["bytes_per_picture"], 1), "psnr_y": m["psnr_y"],
                        "decoder_frame_threads": m["D"], "owf": args.owf, "gpu_entropy": bool(args.gpu_entropy), "subme": args.subme, "sao": bool(args.sao), "me_early_termination": not args.full_search, "intra_satd": not args.intra_sad,
                        "host_cpu_cores_busy": round(m["host_cores"], 2), "host_cpu_budget_cores": round(m["budget"], 1), "host_cpu_throttled_ms": round(m["throttled_ms"], 1),
-                       "input": "I420 resident in HBM", "output": "Annex-B AU on host + decoded I420 in HBM"},
+                       "input": "I420 resident in HBM", "output": "Annex-B AU on host + decoded I420 in HBM",
+                       "repeats": args.repeats, "runs_fps": m["runs_fps"], "value_is": "median run of `repeats` (BASELINE.md timing rule)"},
+            "host_boundary": hostb,
             "roofline": roof,
             "kernels_us": kernels_us,
             "filter_busy_ms_per_picture": {"KvazaarFilter": m["busy"][0], "WireAdapter": m["busy"][1], "OpenHEVCFilter": m["busy"][2]},
@@ -577,6 +621,7 @@ def main():
                 out["secondary"] = {"workload": WORKLOADS["4k"]["name"], "value": round(sec["pictures"] / sec["elapsed"], 3), "unit": "frames/s",
                                     "steps": ssteps, "pictures_per_step": PERIOD, "ms_per_step": round(sec["elapsed"] / ssteps * 1e3, 4),
                                     "bits_per_picture": round(8 * sec["bytes_per_picture"], 1), "psnr_y": sec["psnr_y"],
+                                    "runs_fps": sec["runs_fps"], "host_boundary": sec_host,
                                     "host_cpu_cores_busy": round(sec["host_cores"], 2), "roofline": sroof, "kernels_us": skern}
         if args.full_search and "k_me" in m["kt"] and m["kt"]["k_me"][1]:
             # The motion search is integer VALU work, not streaming: its own ceiling is the issue rate of v_qsad_pk_u16_u8

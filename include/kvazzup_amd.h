@@ -133,6 +133,9 @@ KVZ_PUBLIC int uvgx_pipeline_wait(void *p, uint64_t n_outputs, int timeout_ms);
 /* push_device for a source that paces itself: sleeps until the encoder filter buffers fewer than max_backlog pictures (uvgComm filters
  * drop inputs at 10 buffered, filter.cpp:151-222); 0 = timed out or rejected */
 KVZ_PUBLIC int uvgx_pipeline_push_device_paced(void *p, const void *d_i420, int w, int h, int fps_num, int fps_den, int64_t pts, uint32_t max_backlog, int timeout_ms);
+/* the same for a HOST picture -- the reference's own boundary: the encoder filter copies it into a kvz_picture and calls encoder_encode
+ * (kvazaarfilter.cpp:410-438).  borrow != 0: no copy into the Data object, the caller keeps i420 unchanged until the picture is encoded */
+KVZ_PUBLIC int uvgx_pipeline_push_host_paced(void *p, const uint8_t *i420, int w, int h, int fps_num, int fps_den, int64_t pts, uint32_t max_backlog, int timeout_ms, int borrow);
 KVZ_PUBLIC uint32_t uvgx_pipeline_encoder_backlog(void *p);
 /* harness only (uvgComm never flushes a running graph): the pictures held back by video/OWF and by the decoder's frame threads
  * come out without further input -- the encoder filter runs its encoder_encode(NULL) loop to the end, the wire adapter sends

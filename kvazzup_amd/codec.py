@@ -38,9 +38,17 @@ class Encoder:
             self.api.config_destroy(self.cfg)
             self.cfg = None
             raise RuntimeError("kvz_api.encoder_open failed (no usable HIP device? there is no CPU fallback)")
-        self.pic = self.api.picture_alloc(width, height)
+        # the ring of input pictures KvazaarFilter keeps (createInputVector(owf + 1), getNextPic: kvazaarfilter.cpp:32-42,76-88): the encoder
+        # reads a picture where it lies until its access unit has come back, so a picture is not written again before that
+        self.pics = [self.api.picture_alloc(width, height) for _ in range(int(self.cfg.contents.owf) + 1)]
+        self.next_pic = 0
         self.pts = 0
         self._au = np.empty(width * height * 3 + (1 << 20), dtype=np.uint8)
+
+    @property
+    def pic(self):
+        """the kvz_picture the next encode() call fills and hands over (tests set its roi fields, as KvazaarFilter::feedInput does)"""
+        return self.pics[self.next_pic]
 
     # -- the reference call sequence: memcpy into kvz_picture, encoder_encode, drain chunks
     def encode(self, i420, want_recon=True):
@@ -49,7 +57,9 @@ class Encoder:
         ny = self.w * self.h
         if i420 is not None:
             i420 = np.ascontiguousarray(i420, dtype=np.uint8)
-            p = self.pic.contents
+            pic = self.pics[self.next_pic]
+            self.next_pic = (self.next_pic + 1) % len(self.pics)
+            p = pic.contents
             C.memmove(p.y, i420.ctypes.data, ny)
             C.memmove(p.u, i420.ctypes.data + ny, ny // 4)
             C.memmove(p.v, i420.ctypes.data + ny + ny // 4, ny // 4)
@@ -59,7 +69,7 @@ class Encoder:
         length = C.c_uint32(0)
         recon = C.POINTER(N.KvzPicture)()
         info = N.KvzFrameInfo()
-        ok = self.api.encoder_encode(self.enc, self.pic if i420 is not None else None, C.byref(chunks), C.byref(length),
+        ok = self.api.encoder_encode(self.enc, pic if i420 is not None else None, C.byref(chunks), C.byref(length),
                                      C.byref(recon) if want_recon else None, None, C.byref(info))
         if not ok:
             raise RuntimeError("encoder_encode failed")
@@ -132,9 +142,9 @@ class Encoder:
         if getattr(self, "enc", None):
             self.api.encoder_close(self.enc)
             self.enc = None
-        if getattr(self, "pic", None):
-            self.api.picture_free(self.pic)
-            self.pic = None
+        for pic in getattr(self, "pics", []):
+            self.api.picture_free(pic)
+        self.pics = []
         if getattr(self, "cfg", None):
             self.api.config_destroy(self.cfg)
             self.cfg = None

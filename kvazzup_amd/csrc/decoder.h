@@ -167,6 +167,7 @@ class Decoder {
     bool any_intra = false, any_inter = false, across_slices = true;
     std::atomic<int> state{0}; int rc = 0; double parse_ms = 0;
     hipEvent_t done = nullptr;                                   // recorded behind the picture's last kernel
+    hipEvent_t dl_done = nullptr; int dl_buf = -1;               // download mode: the picture's copy into host buffer dl_buf, queued behind `done` on the download stream
     struct EvPair { hipEvent_t a, b; int id; }; std::vector<EvPair> ev; size_t ev_used = 0;     // kernel timing (set_profiling)
     PicJob() {}
     PicJob(const PicJob &) {}                                  // (vector<PicJob> construction only)
@@ -231,7 +232,13 @@ class Decoder {
   int16_t *resid_[3] = {nullptr, nullptr, nullptr};         // intra residuals between k_dec_intra_resid and k_dec_intra
   uint8_t *work_[3] = {nullptr, nullptr, nullptr};          // pictures with SAO: reconstruction and deblocking happen here, the filter writes into the slot
   uint32_t *progress_ = nullptr, *intra_order_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
-  uint8_t *h_out_ = nullptr; size_t h_out_cap_ = 0;
+  // download mode: three page-locked output buffers take turns -- one is what libOpenHevcGetOutput last handed out (valid until the next
+  // decode call, openhevcfilter.cpp:218-229 copies at once), one receives the picture whose kernels are running, queued behind them on
+  // the download stream at launch, so the copy over PCIe overlaps the next picture's kernels instead of stalling the calling thread
+  static constexpr int kOutRing = 3;
+  uint8_t *h_out_[kOutRing] = {nullptr, nullptr, nullptr}; size_t h_out_cap_ = 0;
+  void describe_output(const PicJob &job, DecodedPicture &o, int buf) const;
+  int queue_download(PicJob &job);
   long launched_ = 0; int out_slot_ = 0; int output_hold_ = 2;
   char prio_dl_ = 'n', prio_up_ = 'n';
   char prio_ = 'n';                                       // priority level of the main stream (stream_pool.h key)

@@ -795,7 +795,7 @@ Decoder::~Decoder()
   workers_.reset();
   if (stream_) hipStreamSynchronize(stream_);
   if (err_pending_ && hipEventSynchronize(err_ev_) == hipSuccess && *h_err_) fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x (last picture)\n", *h_err_);
-  for (auto &j : jobs_) { for (auto &e : j.ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); } if (j.done) hipEventDestroy(j.done); }
+  for (auto &j : jobs_) { for (auto &e : j.ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); } if (j.done) hipEventDestroy(j.done); if (j.dl_done) hipEventDestroy(j.dl_done); }
   free_buffers();
   for (auto &o : ready_q_) if (o.dev) hipFree(o.dev);
   if (cur_owned_.dev) hipFree(cur_owned_.dev);
@@ -840,11 +840,12 @@ bool Decoder::start(std::string *error)
 void Decoder::free_buffers()
 {
   for (auto &j : jobs_) { if (j.h_in) hipHostFree(j.h_in); j.h_in = nullptr; j.h_in_cap = 0; j.col.reset(); j.own.reset(); }
-  if (h_out_) hipHostFree(h_out_);
+  if (stream_dl_) hipStreamSynchronize(stream_dl_);
+  for (auto &p : h_out_) { if (p) hipHostFree(p); p = nullptr; }
   hipFree(d_in_[0]); hipFree(d_in_[1]); hipFree(progress_); hipFree(intra_order_); intra_order_ = nullptr;
   for (auto &p : dpb_) { for (int c = 0; c < 3; c++) { hipFree(p.plane[c]); p.plane[c] = nullptr; } p = DpbPic(); }
   for (int c = 0; c < 3; c++) { hipFree(work_[c]); work_[c] = nullptr; hipFree(resid_[c]); resid_[c] = nullptr; }
-  h_out_ = nullptr; d_in_[0] = d_in_[1] = nullptr; d_in_cap_[0] = d_in_cap_[1] = 0; progress_ = nullptr;
+  d_in_[0] = d_in_[1] = nullptr; d_in_cap_[0] = d_in_cap_[1] = 0; progress_ = nullptr;
   w_ = h_ = pw_ = ph_ = 0;
 }
 
@@ -891,8 +892,7 @@ bool Decoder::ensure_buffers(int w, int h)
     memset(j.h_in, 0, fixed_bytes());
     j.pred_mode.assign(nb4 / 4, PM_NONE); j.ct_depth.assign(nb4 / 4, 0); j.intra_mode.assign(nb4, 1);
   }
-  HIP_TRY(hipHostMalloc(&h_out_, npx * 3 / 2, hipHostMallocDefault));
-  h_out_cap_ = npx * 3 / 2;
+  h_out_cap_ = npx * 3 / 2;                              // (allocated by the first picture that is downloaded)
   for (int i = 0; i < 2; i++) { d_in_cap_[i] = fixed_bytes() + (1 << 20); HIP_TRY(hipMalloc(&d_in_[i], d_in_cap_[i])); }
   HIP_TRY(hipMalloc(&progress_, sizeof(uint32_t) * 3 * (size_t)(pw_ / 64) * (ph_ / 64)));
   {
@@ -1459,13 +1459,58 @@ int Decoder::finish_oldest()
   return produced;
 }
 
+// what libOpenHevcGetOutput / kvzx_decoder_output_device say about the picture of `job`; buf: its host buffer (download mode) or -1
+void Decoder::describe_output(const PicJob &job, DecodedPicture &o, int buf) const
+{
+  o = DecodedPicture();
+  o.coded_w = w_; o.coded_h = h_;
+  o.width = w_ - job.crop[0] - job.crop[1]; o.height = h_ - job.crop[2] - job.crop[3];
+  o.poc = job.sh.poc; o.pts = job.pts; o.is_intra = job.sh.is_intra;
+  o.fps_num = job.fps_num; o.fps_den = job.fps_den;
+  size_t off = 0;
+  // Host pitches are kept even and aligned like a software decoder's line sizes: the reference
+  // addresses chroma row i/2 as pvU + i * (nUPitch / 2) (openhevcfilter.cpp:209,224-227).
+  const int ypitch = (o.width + 63) & ~63;
+  for (int c = 0; c < 3; c++) {
+    const int pw = c ? pw_ / 2 : pw_, ox = c ? job.crop[0] / 2 : job.crop[0], oy = c ? job.crop[2] / 2 : job.crop[2];
+    o.dev[c] = dpb_[job.slot].plane[c] + (size_t)oy * pw + ox; o.dev_pitch[c] = pw;
+    if (buf >= 0) {
+      const int h = c ? o.height / 2 : o.height, pitch = c ? ypitch / 2 : ypitch;
+      o.host[c] = h_out_[buf] + off; o.host_pitch[c] = pitch;
+      off += (size_t)pitch * h;
+    }
+  }
+}
+
+// the picture's cropped planes -> host buffer job.dl_buf, on the download stream, behind the picture's last kernel
+int Decoder::queue_download(PicJob &job)
+{
+  job.dl_buf = (int)(launched_ % kOutRing);
+  if (!h_out_[job.dl_buf] && hipHostMalloc(&h_out_[job.dl_buf], h_out_cap_, hipHostMallocDefault) != hipSuccess) { h_out_[job.dl_buf] = nullptr; return DEC_ERR_GPU; }
+  if (!job.dl_done && hipEventCreateWithFlags(&job.dl_done, hipEventDisableTiming) != hipSuccess) return DEC_ERR_GPU;
+  if (hipStreamWaitEvent(stream_dl_, job.done, 0) != hipSuccess) return DEC_ERR_GPU;
+  DecodedPicture o;
+  describe_output(job, o, job.dl_buf);
+  for (int c = 0; c < 3; c++) {
+    const int w = c ? o.width / 2 : o.width, h = c ? o.height / 2 : o.height;
+    uint8_t *dst = const_cast<uint8_t *>(o.host[c]);
+    hipError_t e = (w == o.host_pitch[c] && w == o.dev_pitch[c])
+        ? hipMemcpyAsync(dst, o.dev[c], (size_t)w * h, hipMemcpyDeviceToHost, stream_dl_)       // one linear run (1080p, 4K: the coded width is the picture's)
+        : hipMemcpy2DAsync(dst, (size_t)o.host_pitch[c], o.dev[c], (size_t)o.dev_pitch[c], (size_t)w, (size_t)h, hipMemcpyDeviceToHost, stream_dl_);
+    if (e != hipSuccess) return DEC_ERR_GPU;
+  }
+  return hipEventRecord(job.dl_done, stream_dl_) == hipSuccess ? 0 : DEC_ERR_GPU;
+}
+
 int Decoder::complete_gpu(PicJob &job)
 {
+  if (download_ && job.dl_buf < 0) { const int rc = queue_download(job); if (rc < 0) return rc; }     // (band mode: `done` has only just been recorded)
   {
     Tick tk;
+    hipEvent_t last = download_ ? job.dl_done : job.done;
     if (frame_threads_ > 1 && !spin_wait_) {   // the output lags anyway: nap between queries instead of polling (see nap_until)
-      if (!nap_until([&] { hipError_t r = hipEventQuery(job.done); return r == hipSuccess ? 1 : (r == hipErrorNotReady ? 0 : -1); })) return DEC_ERR_GPU;
-    } else if (hipEventSynchronize(job.done) != hipSuccess) return DEC_ERR_GPU;
+      if (!nap_until([&] { hipError_t r = hipEventQuery(last); return r == hipSuccess ? 1 : (r == hipErrorNotReady ? 0 : -1); })) return DEC_ERR_GPU;
+    } else if (hipEventSynchronize(last) != hipSuccess) return DEC_ERR_GPU;
     t_sync_ += tk.ms();
   }
   // The kernels' error word (a wavefront that gave up waiting) comes down on the download stream, beside the next picture's
@@ -1482,29 +1527,9 @@ int Decoder::complete_gpu(PicJob &job)
     for (size_t i = 0; i < job.ev_used; i++) { float ms = 0; hipEventElapsedTime(&ms, job.ev[i].a, job.ev[i].b); k_ms_[job.ev[i].id] += ms; k_n_[job.ev[i].id]++; }
     job.ev_used = 0;
   }
-  out_ = DecodedPicture();
-  out_.coded_w = w_; out_.coded_h = h_;
-  out_.width = w_ - job.crop[0] - job.crop[1]; out_.height = h_ - job.crop[2] - job.crop[3];
-  out_.poc = job.sh.poc; out_.pts = job.pts; out_.is_intra = job.sh.is_intra;
-  out_.fps_num = job.fps_num; out_.fps_den = job.fps_den;
+  describe_output(job, out_, download_ ? job.dl_buf : -1);
   out_slot_ = job.slot;
-  for (int c = 0; c < 3; c++) {
-    int pw = c ? pw_ / 2 : pw_, ox = c ? job.crop[0] / 2 : job.crop[0], oy = c ? job.crop[2] / 2 : job.crop[2];
-    out_.dev[c] = dpb_[out_slot_].plane[c] + (size_t)oy * pw + ox; out_.dev_pitch[c] = pw;
-  }
-  if (download_) {
-    // Host pitches are kept even and aligned like a software decoder's line sizes: the reference
-    // addresses chroma row i/2 as pvU + i * (nUPitch / 2) (openhevcfilter.cpp:209,224-227).
-    size_t off = 0;
-    const int ypitch = (out_.width + 63) & ~63;
-    for (int c = 0; c < 3; c++) {
-      int w = c ? out_.width / 2 : out_.width, h = c ? out_.height / 2 : out_.height, pitch = c ? ypitch / 2 : ypitch;
-      if (hipMemcpy2DAsync(h_out_ + off, (size_t)pitch, out_.dev[c], (size_t)out_.dev_pitch[c], (size_t)w, (size_t)h, hipMemcpyDeviceToHost, stream_dl_) != hipSuccess) return DEC_ERR_GPU;
-      out_.host[c] = h_out_ + off; out_.host_pitch[c] = pitch;
-      off += (size_t)pitch * h;
-    }
-    if (hipStreamSynchronize(stream_dl_) != hipSuccess) return DEC_ERR_GPU;
-  }
+  job.dl_buf = -1;
   pic_ready_ = true;
   return 1;
 }
@@ -1711,6 +1736,8 @@ int Decoder::launch_gpu(PicJob &job)
   else if (!job.sh.deblock_disabled) timed(DK_DEBLOCK, [&] { launch_dec_deblock(f, stream_); });
   if (sao) timed(DK_SAO, [&] { launch_dec_sao(f, stream_); });
   if (hipEventRecord(job.done, stream_) != hipSuccess) return DEC_ERR_GPU;
+  job.dl_buf = -1;
+  if (download_ && band_nrows_ == 0) { const int rc = queue_download(job); if (rc < 0) return rc; }
   t_api_ += tk_api.ms();
   launched_++;
   gpu_job_ = &job;

@@ -45,6 +45,8 @@ struct EncoderConfig {
   int vaq = 0;                // kvazaar "vaq" 1..20: "uvgx VAQ v1" (oracle/hevc_enc.c vaq_deltas()); implies qp_in_cu
   int mv_frame = 0;           // kvazaar "mv-constraint" frame / frametile (1), frametilemargin (2): vectors keep the block inside the picture
   int sao = 0;                // kvazaar "sao": sample adaptive offset, parameters by "uvgx SAO decision v1" (oracle/hevc_sao.c)
+  int input_hold = 0;         // "input-hold" (extension): 1 = the caller leaves a DEVICE input picture unchanged until that picture's access unit has been returned --
+                              // what the kvz_api contract already demands of host pictures (kvazaarfilter.cpp:76-88); encode_device then returns without waiting for the input stage
   int entropy_gpu = 0;        // arithmetic coder: 1 = on the GPU (k_cabac_rows, cabac_kernels.hip), 0 = host thread pool (entropy_host.h); band mode always uses the host pool
   int owf = 0;                // kvazaar "owf": 0 = encode() returns its own picture; 1 = output lags one picture and the host
                               // coding of picture t overlaps the kernels of t + 1; >= 2 = output lags two pictures and the host
@@ -62,8 +64,10 @@ class Encoder {
  public:
   static Encoder *create(const EncoderConfig &cfg, std::string *error);
   ~Encoder();
-  // picture as three host planes (stride = width)
-  bool encode_host(const uint8_t *y, const uint8_t *u, const uint8_t *v, EncodedPicture *out);
+  // picture as three host planes (stride = width).  pinned: the three planes lie back to back in page-locked memory (a kvz_picture from
+  // picture_alloc) that the caller leaves alone until this picture's access unit has been returned (the kvz_api contract,
+  // kvazaarfilter.cpp:76-88): the upload then reads the caller's picture itself, without a staging copy
+  bool encode_host(const uint8_t *y, const uint8_t *u, const uint8_t *v, EncodedPicture *out, bool pinned = false);
   // picture as packed I420 in device memory (w*h*3/2 bytes)
   bool encode_device(const uint8_t *d_i420, EncodedPicture *out);
   // owf >= 1: outputs the picture still in flight, if any (kvz_api encoder_encode with pic_in == NULL)
@@ -82,7 +86,7 @@ class Encoder {
   bool band_phase2(std::vector<std::vector<uint8_t>> *substreams, EncodedPicture *info);      // = band_phase2a + band_phase2b
   bool band_phase2a();                                            // what needs no halo: inner horizontal edges, tokenizer, arithmetic coder (may run beside the exchange, BEFORE band_import_halo)
   bool band_phase2b(std::vector<std::vector<uint8_t>> *substreams, EncodedPicture *info);     // after band_import_halo: the band's two boundary edges; hands out the substreams
-  int pending() const { return (int)(submitted_ - collected_); }
+  int pending() const { return (int)(accepted_ - collected_); }
   // cropped reconstruction of the last coded picture -> host planes (stride = width)
   bool download_recon(uint8_t *y, uint8_t *u, uint8_t *v);
   // debug: copy an internal device array of the last coded picture to the host
@@ -102,7 +106,7 @@ class Encoder {
  private:
   Encoder() {}
   bool init(const EncoderConfig &cfg, std::string *error);
-  bool submit(const uint8_t *d_i420, bool via_staging);
+  bool submit(const uint8_t *d_i420, int in_ring);   // in_ring >= 0: the picture is being uploaded into d_in_[in_ring] (encode_host)
   bool collect(EncodedPicture *out);
   struct Slot;
   bool finish_slot(Slot &sl, EncodedPicture *out, int worker = 0);   // wait for the slot's kernels, arithmetic coding, access unit
@@ -113,8 +117,18 @@ class Encoder {
   int cw_ = 0, ch_ = 0, rows_ = 0;
   hipStream_t stream_ = nullptr;
   EncFrame f_{};
-  uint8_t *d_in_ = nullptr;              // packed input staging (device)
-  uint8_t *h_in_ = nullptr;              // pinned host staging
+  // Host pictures (kvz_api->encoder_encode, kvazaarfilter.cpp:435-438): a ring of packed device buffers filled by the copy engine on a
+  // stream of its own -- picture t + 1 travels over PCIe while the kernels of picture t run -- and, for callers whose planes are not
+  // page-locked, a ring of pinned staging buffers (allocated on first use)
+  // (twelve: more than the pictures that can be in flight -- owf <= 8 plus the submitter's hand -- so a copy never has to wait in the copy
+  // engine's queue for its buffer's previous reader; a waiting copy holds up every copy queued behind it on that engine, the decoder's included)
+  static constexpr int kInRing = 12;
+  uint8_t *d_in_[kInRing] = {};          // packed input (device)
+  uint8_t *h_in_[kInRing] = {};          // pinned host staging
+  hipStream_t stream_h2d_ = nullptr;
+  hipStream_t stream_rec_ = nullptr;     // download of reconstructions the caller asks for (encoder_encode's pic_out)
+  hipEvent_t ev_h2d_[kInRing] = {}, ev_pad_[kInRing] = {}; bool pad_pending_[kInRing] = {}, h2d_pending_[kInRing] = {};
+  long in_count_ = 0;
   // Per-picture working sets (padded source planes, level planes, CU arrays, per-CTU QP arrays, SAO parameters): kSets of them take turns, so the
   // host can queue kSets - 1 pictures' kernels ahead of the one the GPU is working on without waiting for a set to come free (with two sets
   // the input stage of picture t waited for the reconstruction of t - 2, and the calling thread with it: the main stream ran dry between pictures)
@@ -132,7 +146,8 @@ class Encoder {
   int16_t *cu_mv_[kSets] = {}, *cu_mvd_[kSets] = {};
   int set_ = 0, out_set_ = 0;
   char prio_[3] = {'h', 'n', 'n'};                      // priority levels of the main, tokenizer and input streams (stream_pool.h keys)
-  std::vector<int8_t> roi_; int roi_w_ = 0, roi_h_ = 0;
+  std::vector<int8_t> roi_; int roi_w_ = 0, roi_h_ = 0;           // as set by the caller (set_roi)
+  std::vector<int8_t> roi_sub_; int roi_sub_w_ = 0, roi_sub_h_ = 0;   // the map of the picture being submitted (it travels with the picture to the submitter thread)
   int8_t *ctu_qt_[kSets] = {}, *ctu_qy_[kSets] = {}, *ctu_delta_[kSets] = {}; uint8_t *ctu_first_[kSets] = {};   // per set
   int8_t *h_ctu_qt_[kSets] = {};   // pinned staging of the target map
   int *vaq_act_ = nullptr, *vaq_sum_ = nullptr; // VAQ: activity of every CTU, its sum over the picture
@@ -176,7 +191,16 @@ class Encoder {
   size_t stage_cap_ = 0, out_cap_ = 0;
   std::thread bg_[2]; std::mutex bm_; std::condition_variable bcv_; std::deque<int> bq_; bool bquit_ = false;
   std::mutex stat_m_;
-  long submitted_ = 0, collected_ = 0;
+  long submitted_ = 0, collected_ = 0, accepted_ = 0;    // pictures whose kernels have been queued / whose access unit has been returned / taken from the caller
+  // owf >= 2: the output lags anyway, so the calling thread (uvgComm's encoder filter thread) only hands the picture over; a submitter thread makes the
+  // ~20 HIP calls that queue its copy and kernels (~0.1 ms per picture, which at 1080p was most of what that thread had time for).  Applies where the
+  // input stays valid without the call waiting for it: page-locked host pictures (contract) and device pictures with input-hold.
+  struct SubmitJob { const uint8_t *src = nullptr; bool host = false; std::vector<int8_t> roi; int roi_w = 0, roi_h = 0; int slot = 0; };
+  std::thread sub_thread_; std::mutex sm_; std::condition_variable scv_; std::deque<SubmitJob> sq_; bool squit_ = false, sbusy_ = false;
+  void submitter();
+  void drain_submitter();
+  bool enqueue(const uint8_t *src, bool host, EncodedPicture *out);
+  bool upload_and_submit(const uint8_t *y, const uint8_t *u, const uint8_t *v, bool pinned);
   hipEvent_t in_done_ = nullptr; bool in_pending_ = false;   // input picture consumed (staging buffer / caller's device buffer reusable)
   // owf >= 2: two background workers, each with its own coder pool, finish two pictures side by side (the substreams of one
   // picture start one after the other -- WPP context hand-over -- so one picture alone cannot keep the pool busy)

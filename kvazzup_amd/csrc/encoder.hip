@@ -66,8 +66,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   prio_[0] = prio[0]; prio_[1] = prio[1]; prio_[2] = prio[2];
   HIP_OK(stream_acquire(&stream_, cfg.device, 'M', prio_[0]));
   const size_t npx = (size_t)cw_ * ch_, nb8 = npx / 64, in_bytes = (size_t)cfg.width * cfg.height * 3 / 2;
-  HIP_OK(hipMalloc(&d_in_, in_bytes));
-  HIP_OK(hipHostMalloc(&h_in_, in_bytes, hipHostMallocDefault));
+  (void)in_bytes;                                          // (the host-picture ring is allocated by the first encode_host)
   for (int c = 0; c < 3; c++) {
     size_t n = c ? npx / 4 : npx;
     for (int k = 0; k < kSets; k++) HIP_OK(hipMalloc(&src_[k][c], n));
@@ -182,6 +181,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   HIP_OK(hipStreamSynchronize(stream_));
   HIP_OK(hipDeviceSynchronize());
   if (depth_ >= 2) { bg_[0] = std::thread([this] { name_this_thread("kvzx-enc-bg0"); background(0); }); if (entropy2_) bg_[1] = std::thread([this] { name_this_thread("kvzx-enc-bg1"); background(1); }); }
+  if (depth_ >= 2 && cfg.band_rows == 0 && !getenv("KVAZZUP_AMD_SYNC_SUBMIT")) sub_thread_ = std::thread([this] { name_this_thread("kvzx-enc-sub"); submitter(); });
   return true;
 }
 
@@ -202,6 +202,9 @@ void Encoder::bind_set(int k)
 Encoder::~Encoder()
 {
   if (getenv("KVAZZUP_AMD_TRACE")) fprintf(stderr, "kvazzup_amd encoder thread ms: submit %.1f  wait_gpu %.1f  arith %.1f  assemble %.1f  wait_input %.1f  (pictures %ld)\n", t_submit_, t_wait_, t_arith_, t_asm_, t_in_, collected_);
+  { std::lock_guard<std::mutex> l(sm_); squit_ = true; }
+  scv_.notify_all();
+  if (sub_thread_.joinable()) sub_thread_.join();
   { std::lock_guard<std::mutex> l(bm_); bquit_ = true; }
   bcv_.notify_all();
   for (auto &t : bg_) if (t.joinable()) t.join();
@@ -223,7 +226,10 @@ Encoder::~Encoder()
     if (sl.rec_done) hipEventDestroy(sl.rec_done);
   }
   if (in_done_) hipEventDestroy(in_done_);
-  hipFree(d_in_); hipHostFree(h_in_);
+  if (stream_h2d_) hipStreamSynchronize(stream_h2d_);
+  for (int k = 0; k < kInRing; k++) { hipFree(d_in_[k]); if (h_in_[k]) hipHostFree(h_in_[k]); if (ev_h2d_[k]) hipEventDestroy(ev_h2d_[k]); if (ev_pad_[k]) hipEventDestroy(ev_pad_[k]); }
+  stream_release(stream_h2d_, cfg_.device, 'H', 'n');
+  stream_release(stream_rec_, cfg_.device, 'R', 'n');
   for (int c = 0; c < 3; c++) { for (int k = 0; k < kSets; k++) { hipFree(src_[k][c]); hipFree(coef_[k][c]); } for (int b = 0; b < 10; b++) hipFree(rec_[b][c]); }
   hipFree(vaq_act_); hipFree(vaq_sum_); hipFree(rc_state_);
   for (int k = 0; k < kSets; k++) { hipFree(ctu_qt_[k]); hipFree(ctu_qy_[k]); hipFree(ctu_delta_[k]); hipFree(ctu_first_[k]); if (h_ctu_qt_[k]) hipHostFree(h_ctu_qt_[k]); }
@@ -264,27 +270,106 @@ void Encoder::get_kernel_times(double *ms, uint64_t *launches, bool reset)
 // encode = submit the picture's kernels, then finish ("collect") the oldest picture in flight.  With
 // owf == 0 that is the picture just submitted; with owf >= 1 it is the previous one, whose arithmetic
 // coding on the host then runs while the GPU works on the new picture.
-bool Encoder::encode_host(const uint8_t *y, const uint8_t *u, const uint8_t *v, EncodedPicture *out)
+// Host picture in: the copy engine moves it into device buffer k = t mod kInRing on the upload stream while earlier pictures' kernels
+// run; the input stage of picture t (stream_in_) waits for that copy, the copy of picture t + kInRing for that input stage.  Nothing
+// here waits on the calling thread except a staging buffer coming free (callers without page-locked planes).
+bool Encoder::upload_and_submit(const uint8_t *y, const uint8_t *u, const uint8_t *v, bool pinned)
+{
+  const size_t ny = (size_t)cfg_.width * cfg_.height, bytes = ny * 3 / 2;
+  const int k = (int)(in_count_++ % kInRing);
+  if (!stream_h2d_) HIP_CHECK(stream_acquire(&stream_h2d_, cfg_.device, 'H', 'n'));
+  if (!d_in_[k]) {
+    HIP_CHECK(hipMalloc(&d_in_[k], bytes));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_h2d_[k], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_pad_[k], hipEventDisableTiming));
+  }
+  const uint8_t *src = y;
+  if (!pinned) {
+    if (!h_in_[k]) HIP_CHECK(hipHostMalloc(&h_in_[k], bytes, hipHostMallocDefault));
+    if (h2d_pending_[k]) { Tick tk; HIP_CHECK(hipEventSynchronize(ev_h2d_[k])); h2d_pending_[k] = false; t_in_ += tk.ms(); }   // the staging buffer's last upload
+    memcpy(h_in_[k], y, ny); memcpy(h_in_[k] + ny, u, ny / 4); memcpy(h_in_[k] + ny + ny / 4, v, ny / 4);
+    src = h_in_[k];
+  }
+  if (pad_pending_[k]) { HIP_CHECK(hipStreamWaitEvent(stream_h2d_, ev_pad_[k], 0)); pad_pending_[k] = false; }      // d_in_[k]'s last reader
+  HIP_CHECK(hipMemcpyAsync(d_in_[k], src, bytes, hipMemcpyHostToDevice, stream_h2d_));
+  HIP_CHECK(hipEventRecord(ev_h2d_[k], stream_h2d_)); h2d_pending_[k] = true;
+  HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_h2d_[k], 0));
+  { Tick tk; if (!submit(d_in_[k], k)) return false; t_submit_ += tk.ms(); }
+  in_pending_ = false;                               // (nobody but this ring reads d_in_[k])
+  return true;
+}
+
+bool Encoder::encode_host(const uint8_t *y, const uint8_t *u, const uint8_t *v, EncodedPicture *out, bool pinned)
 {
   const size_t ny = (size_t)cfg_.width * cfg_.height;
   HIP_CHECK(hipSetDevice(cfg_.device));
-  if (in_pending_) { HIP_CHECK(hipEventSynchronize(in_done_)); in_pending_ = false; }
-  memcpy(h_in_, y, ny); memcpy(h_in_ + ny, u, ny / 4); memcpy(h_in_ + ny + ny / 4, v, ny / 4);
-  HIP_CHECK(hipMemcpyAsync(d_in_, h_in_, ny * 3 / 2, hipMemcpyHostToDevice, stream_in_));
-  return encode_device(d_in_, out);
+  out->valid = false; out->au.clear();
+  pinned = pinned && u == y + ny && v == u + ny / 4;
+  if (pinned && sub_thread_.joinable()) return enqueue(y, true, out);
+  drain_submitter();
+  accepted_++;
+  roi_sub_ = roi_; roi_sub_w_ = roi_w_; roi_sub_h_ = roi_h_;
+  if (!upload_and_submit(y, u, v, pinned)) { accepted_--; return false; }
+  return pending() > depth_ ? collect(out) : true;
 }
 
 bool Encoder::encode_device(const uint8_t *d_i420, EncodedPicture *out)
 {
   HIP_CHECK(hipSetDevice(cfg_.device));
   out->valid = false; out->au.clear();
-  { Tick tk; if (!submit(d_i420, d_i420 == d_in_)) return false; t_submit_ += tk.ms(); }
+  if (cfg_.input_hold && sub_thread_.joinable()) return enqueue(d_i420, false, out);
+  drain_submitter();
+  accepted_++;
+  roi_sub_ = roi_; roi_sub_w_ = roi_w_; roi_sub_h_ = roi_h_;
+  { Tick tk; if (!submit(d_i420, -1)) { accepted_--; return false; } t_submit_ += tk.ms(); }
   bool ok = true;
   if (pending() > depth_) ok = collect(out);
   // the caller may reuse its input buffer when this returns (the pad kernel is first in the picture's queue,
   // and by now it has had the whole host coding stage of the previous picture to run)
   if (in_pending_) { Tick tk; HIP_CHECK(hipEventSynchronize(in_done_)); in_pending_ = false; t_in_ += tk.ms(); }
   return ok;
+}
+
+// owf >= 2: hand the picture to the submitter thread, then finish the oldest picture in flight if the pipeline is full
+bool Encoder::enqueue(const uint8_t *src, bool host, EncodedPicture *out)
+{
+  SubmitJob j; j.src = src; j.host = host; j.roi = roi_; j.roi_w = roi_w_; j.roi_h = roi_h_; j.slot = (int)(accepted_ % nslots_);
+  { std::lock_guard<std::mutex> l(bm_); slot_[j.slot].ready = false; slot_[j.slot].ok = true; }
+  accepted_++;
+  { std::lock_guard<std::mutex> l(sm_); sq_.push_back(std::move(j)); }
+  scv_.notify_one();
+  return pending() > depth_ ? collect(out) : true;
+}
+
+void Encoder::submitter()
+{
+  hipSetDevice(cfg_.device);
+  for (;;) {
+    SubmitJob j;
+    {
+      std::unique_lock<std::mutex> l(sm_);
+      sbusy_ = false; scv_.notify_all();
+      scv_.wait(l, [&] { return squit_ || !sq_.empty(); });
+      if (sq_.empty()) return;
+      j = std::move(sq_.front()); sq_.pop_front(); sbusy_ = true;
+    }
+    roi_sub_.swap(j.roi); roi_sub_w_ = j.roi_w; roi_sub_h_ = j.roi_h;
+    const size_t ny = (size_t)cfg_.width * cfg_.height;
+    bool ok;
+    if (j.host) ok = upload_and_submit(j.src, j.src + ny, j.src + ny + ny / 4, true);
+    else { Tick tk; ok = submit(j.src, -1); t_submit_ += tk.ms(); in_pending_ = false; }
+    if (!ok) {                                       // nothing was queued for this picture: its slot reports the failure
+      { std::lock_guard<std::mutex> l(bm_); slot_[j.slot].ok = false; slot_[j.slot].ready = true; }
+      bcv_.notify_all();
+    }
+  }
+}
+
+// a synchronous call after asynchronous ones: everything handed over so far has been queued on the GPU
+void Encoder::drain_submitter()
+{
+  if (!sub_thread_.joinable()) return;
+  std::unique_lock<std::mutex> l(sm_);
+  scv_.wait(l, [&] { return sq_.empty() && !sbusy_; });
 }
 
 bool Encoder::flush(EncodedPicture *out)
@@ -309,7 +394,7 @@ bool Encoder::upload_qp_targets()
   int8_t *h = h_ctu_qt_[set_];
   for (int cy = 0; cy < hc; cy++) for (int cx = 0; cx < wc; cx++) {
     int d = 0;
-    if (!roi_.empty()) d = clip3(-12, 12, (int)roi_[(size_t)(cy * roi_h_ / hc) * roi_w_ + (cx * roi_w_ / wc)]);
+    if (!roi_sub_.empty()) d = clip3(-12, 12, (int)roi_sub_[(size_t)(cy * roi_sub_h_ / hc) * roi_sub_w_ + (cx * roi_sub_w_ / wc)]);
     h[cy * wc + cx] = (int8_t)(cfg_.vaq > 0 ? d : clip3(0, 51, qp_cur_ + d));      // with VAQ the device adds its delta and the picture QP
   }
   HIP_CHECK(hipMemcpyAsync(ctu_qt_[set_], h, (size_t)wc * hc, hipMemcpyHostToDevice, stream_));
@@ -330,7 +415,7 @@ void Encoder::rate_control()
   qp_cur_ = clip3(10, 51, qp_cur_ + step);
 }
 
-bool Encoder::submit(const uint8_t *d_i420, bool)
+bool Encoder::submit(const uint8_t *d_i420, int in_ring)
 {
   const int w = cfg_.width, h = cfg_.height;
   Slot &sl = slot_[submitted_ % nslots_];
@@ -355,6 +440,7 @@ bool Encoder::submit(const uint8_t *d_i420, bool)
   const EncFrame f = f_;
   if (src_busy_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_src_free_[set_], 0)); src_busy_[set_] = false; }   // the last picture that used this set (t - kSets) has been reconstructed
   timed(K_PAD, stream_in_, [&] { launch_pad_input(d_i420, w, h, src_[set_][0], src_[set_][1], src_[set_][2], cw_, ch_, stream_in_); });
+  if (in_ring >= 0) { HIP_CHECK(hipEventRecord(ev_pad_[in_ring], stream_in_)); pad_pending_[in_ring] = true; }
   if (intra) {
     // The intra decisions need the source picture only: they run on the input stream, beside what is left of picture t - 1
     // on the main stream (they write the CU arrays of this set: the tokenizer of the set's previous picture must be done with them).
@@ -548,6 +634,7 @@ bool Encoder::band_phase1(const uint8_t *d_i420)
 {
   if (cfg_.band_rows <= 0 || !d_i420) return false;
   if (!band_picture_setup()) return false;
+  roi_sub_ = roi_; roi_sub_w_ = roi_w_; roi_sub_h_ = roi_h_;
   if (!upload_qp_targets()) return false;
   const EncFrame f = f_;
   launch_pad_input(d_i420, cfg_.width, cfg_.height, src_[0][0], src_[0][1], src_[0][2], cw_, ch_, stream_);
@@ -647,14 +734,21 @@ bool Encoder::band_phase2b(std::vector<std::vector<uint8_t>> *substreams, Encode
 
 bool Encoder::band_phase2(std::vector<std::vector<uint8_t>> *substreams, EncodedPicture *info) { return band_phase2a() && band_phase2b(substreams, info); }
 
+// The picture last output: its reconstruction is complete (collect waited for the slot's events) and its ring entry is not written again
+// before the next picture is submitted, so the copy goes on a stream of its own -- waiting on the main stream would wait for every
+// picture queued behind this one (owf).
 bool Encoder::download_recon(uint8_t *y, uint8_t *u, uint8_t *v)
 {
   uint8_t *dst[3] = {y, u, v};
+  HIP_CHECK(hipSetDevice(cfg_.device));
+  if (!stream_rec_) HIP_CHECK(stream_acquire(&stream_rec_, cfg_.device, 'R', 'n'));
+  if (pending() == 0) HIP_CHECK(hipStreamSynchronize(stream_));      // (band mode, debugging: nothing vouches for the picture but the main stream)
   for (int c = 0; c < 3; c++) {
     int w = c ? cfg_.width / 2 : cfg_.width, h = c ? cfg_.height / 2 : cfg_.height, pw = c ? cw_ / 2 : cw_;
-    HIP_CHECK(hipMemcpy2DAsync(dst[c], (size_t)w, rec_[out_idx_][c], (size_t)pw, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, stream_));
+    if (w == pw) HIP_CHECK(hipMemcpyAsync(dst[c], rec_[out_idx_][c], (size_t)w * h, hipMemcpyDeviceToHost, stream_rec_));
+    else HIP_CHECK(hipMemcpy2DAsync(dst[c], (size_t)w, rec_[out_idx_][c], (size_t)pw, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, stream_rec_));
   }
-  HIP_CHECK(hipStreamSynchronize(stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_rec_));
   return true;
 }
 

@@ -25,6 +25,7 @@
 #include <vector>
 #include <stdint.h>
 #include "../../include/kvazzup_amd.h"
+#include "host_pool.h"
 
 namespace uvgx {
 
@@ -51,6 +52,9 @@ struct Data {
   // extension (not in the reference): picture already resident in HBM (packed I420); data stays empty
   const void *device_data = nullptr;
   const void *device_planes[3] = {nullptr, nullptr, nullptr}; int device_pitch[3] = {0, 0, 0};   // decoded I420 left in HBM
+  // extension (harness only): the payload lies in memory the source keeps alive and unchanged until the picture has left the encoder
+  // filter (bench.py's clip) -- what a camera filter would hand over as `data`, without the harness copying it once more
+  const uint8_t *host_view = nullptr;
   // extension (harness only; uvgComm never flushes a running graph): no payload -- the encoder filter outputs the pictures it
   // still holds (video/OWF) and the wire adapter sends end-of-sequence NAL units, which drain the decoder's frame threads
   bool flush_marker = false;
@@ -144,6 +148,9 @@ class KvazaarFilter : public Filter {
   std::mutex settingsMutex_;
   struct FrameInfo { std::unique_ptr<Data> data; int8_t *roi_array; };
   std::deque<FrameInfo> encodingFrames_;
+  // harness setting uvgx/copyThreads (default 4; 1 = the reference's plain memcpy on the filter thread): cores that share the copy
+  // of a picture into the kvz_picture
+  std::unique_ptr<kvzx::CopyPool> copy_; std::vector<kvzx::CopyPool::Piece> pieces_;
   std::vector<uint8_t> au_;                        // device-input path: access unit buffer
   bool lastInputOnDevice_ = false;
   void drain();
@@ -173,6 +180,7 @@ class OpenHEVCFilter : public Filter {
   std::mutex settingsMutex_;
   uint32_t discardedFrames_ = 0;
   bool download_ = true;
+  std::unique_ptr<kvzx::CopyPool> copy_; std::vector<kvzx::CopyPool::Piece> pieces_;     // uvgx/copyThreads, as in KvazaarFilter
 };
 
 // Row f1: the conversion filter the graph inserts after the decoder (yuvtorgb32.cpp:29-64).  Host pictures go through

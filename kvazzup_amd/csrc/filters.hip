@@ -95,7 +95,7 @@ Data *Filter::deepDataCopy(const Data *o)
   Data *c = new Data;
   c->source = o->source; c->type = o->type; c->data_size = o->data_size;
   c->creationTimestamp = o->creationTimestamp; c->presentationTimestamp = o->presentationTimestamp;
-  c->device_data = o->device_data; c->flush_marker = o->flush_marker;
+  c->device_data = o->device_data; c->flush_marker = o->flush_marker; c->host_view = o->host_view;
   for (int i = 0; i < 3; i++) { c->device_planes[i] = o->device_planes[i]; c->device_pitch[i] = o->device_pitch[i]; }
   if (o->data) { c->data.reset(new uint8_t[o->data_size]); memcpy(c->data.get(), o->data.get(), o->data_size); }
   if (o->vInfo) {
@@ -235,6 +235,7 @@ bool KvazaarFilter::init()                                 // kvazaarfilter.cpp:
   enc_ = api_->encoder_open(config_);
   if (!enc_) { fprintf(stderr, "KvazaarFilter: failed to open the encoder\n"); return false; }
   createInputVector(config_->owf + 1);
+  { const int n = atoi(setting("uvgx/copyThreads", "4").c_str()); copy_.reset(n > 1 ? new kvzx::CopyPool(n > 16 ? 16 : n) : nullptr); }
   return !inputPics_.empty();
 }
 
@@ -310,9 +311,20 @@ void KvazaarFilter::feedInput(std::unique_ptr<Data> input) // kvazaarfilter.cpp:
   lastInputOnDevice_ = false;
   kvz_picture *inputPic = getNextPic();
   const size_t ny = (size_t)input->vInfo->width * input->vInfo->height;
-  memcpy(inputPic->y, input->data.get(), ny);
-  memcpy(inputPic->u, &(input->data.get()[ny]), ny / 4);
-  memcpy(inputPic->v, &(input->data.get()[ny + ny / 4]), ny / 4);
+  const uint8_t *in = input->data ? input->data.get() : input->host_view;
+  if (!in) return;
+  if (copy_) {                                             // kvazaarfilter.cpp:410-418, the three copies shared between cores
+    pieces_.clear();
+    kvzx::CopyPool::add_plane(pieces_, inputPic->y, in, ny, 1, ny, ny);
+    kvzx::CopyPool::add_plane(pieces_, inputPic->u, &(in[ny]), ny / 4, 1, ny / 4, ny / 4);
+    kvzx::CopyPool::add_plane(pieces_, inputPic->v, &(in[ny + ny / 4]), ny / 4, 1, ny / 4, ny / 4);
+    copy_->run(pieces_);
+  } else {
+    memcpy(inputPic->y, in, ny);                           // kvazaarfilter.cpp:410-418
+    memcpy(inputPic->u, &(in[ny]), ny / 4);
+    memcpy(inputPic->v, &(in[ny + ny / 4]), ny / 4);
+  }
+  input->host_view = nullptr;
   inputPic->pts = pts_;
   ++pts_;
   if (config_->target_bitrate == 0) {
@@ -400,6 +412,7 @@ bool OpenHEVCFilter::init()                                // openhevcfilter.cpp
   libOpenHevcSetActiveDecoders(handle_, 0);
   libOpenHevcSetViewLayers(handle_, 0);
   download_ = atoi(get("uvgx/decoderDownload", "1").c_str()) != 0;
+  { const int n = atoi(get("uvgx/copyThreads", "4").c_str()); copy_.reset(n > 1 && download_ ? new kvzx::CopyPool(n > 16 ? 16 : n) : nullptr); }
   if (!download_) kvzx_decoder_set_download(handle_, 0);   // extension: leave decoded pictures in HBM
   decodingFrames_.clear();
   maxBufferSize_ = -1;                                     // no buffer limit (openhevcfilter.cpp:68)
@@ -480,6 +493,13 @@ void OpenHEVCFilter::sendDecodedOutput(int &gotPicture)    // openhevcfilter.cpp
     uint8_t *pY = yuv_frame.get(), *pU = yuv_frame.get() + W * H, *pV = yuv_frame.get() + W * H + W * H / 4;
     uint32_t s_stride = (uint32_t)openHevcFrame.frameInfo.nYPitch, qs_stride = (uint32_t)openHevcFrame.frameInfo.nUPitch / 2;
     uint32_t d_stride = (uint32_t)W / 2, dd_stride = (uint32_t)W;
+    if (copy_) {                                           // the same rows (openhevcfilter.cpp:212-229), shared between cores
+      pieces_.clear();
+      kvzx::CopyPool::add_plane(pieces_, pY, (const uint8_t *)openHevcFrame.pvY, dd_stride, (size_t)H, dd_stride, s_stride);
+      kvzx::CopyPool::add_plane(pieces_, pU, (const uint8_t *)openHevcFrame.pvU, d_stride, (size_t)((H + 1) / 2), d_stride, 2 * qs_stride);
+      kvzx::CopyPool::add_plane(pieces_, pV, (const uint8_t *)openHevcFrame.pvV, d_stride, (size_t)((H + 1) / 2), d_stride, 2 * qs_stride);
+      copy_->run(pieces_);
+    } else
     for (int i = 0; i < H; i++) {
       memcpy(pY, (uint8_t *)openHevcFrame.pvY + i * s_stride, dd_stride);
       pY += dd_stride;
@@ -637,14 +657,15 @@ KVZ_PUBLIC void *uvgx_pipeline_create(const char *settings_text, int loopback_de
   return p;
 }
 
-static int push(UvgxPipeline *p, const uint8_t *host, const void *dev, int w, int h, int fn, int fd, int64_t pts)
+static int push(UvgxPipeline *p, const uint8_t *host, const void *dev, int w, int h, int fn, int fd, int64_t pts, bool borrow = false)
 {
   std::unique_ptr<Data> d(new Data);
   d->source = DS_LOCAL; d->type = DT_YUV420VIDEO;
   d->creationTimestamp = now_ms(); d->presentationTimestamp = pts;
   d->vInfo.reset(new VideoInfo);
   d->vInfo->width = (int16_t)w; d->vInfo->height = (int16_t)h; d->vInfo->framerateNumerator = fn; d->vInfo->framerateDenominator = fd;
-  if (host) { d->data_size = (uint32_t)(w * h * 3 / 2); d->data.reset(new uint8_t[d->data_size]); memcpy(d->data.get(), host, d->data_size); }
+  if (host && borrow) { d->data_size = (uint32_t)(w * h * 3 / 2); d->host_view = host; }
+  else if (host) { d->data_size = (uint32_t)(w * h * 3 / 2); d->data.reset(new uint8_t[d->data_size]); memcpy(d->data.get(), host, d->data_size); }
   d->device_data = dev;
   p->enc->putInput(std::move(d));
   return 1;
@@ -678,6 +699,16 @@ KVZ_PUBLIC int uvgx_pipeline_push_device_paced(void *pp, const void *d_i420, int
   if (!p || !d_i420) return 0;
   if (!p->enc->waitBufferedBelow(max_backlog, timeout_ms)) return 0;
   return push(p, nullptr, d_i420, w, h, fn, fd, pts);
+}
+
+// the same for a host picture (what uvgComm's graph hands the encoder filter).  borrow != 0: the Data refers to the caller's buffer, which must
+// stay unchanged until the picture has been encoded (the harness's clip); 0: the Data owns a copy, like a camera filter's output
+KVZ_PUBLIC int uvgx_pipeline_push_host_paced(void *pp, const uint8_t *i420, int w, int h, int fn, int fd, int64_t pts, uint32_t max_backlog, int timeout_ms, int borrow)
+{
+  UvgxPipeline *p = (UvgxPipeline *)pp;
+  if (!p || !i420) return 0;
+  if (!p->enc->waitBufferedBelow(max_backlog, timeout_ms)) return 0;
+  return push(p, i420, nullptr, w, h, fn, fd, pts, borrow != 0);
 }
 
 static int pop(UvgxPipeline *p, std::deque<std::unique_ptr<Data>> &q, uint8_t *buf, uint32_t cap, uint32_t *size, int *w, int *h, int64_t *pts)

@@ -12,7 +12,9 @@
 #include <vector>
 #include <pthread.h>
 #include <climits>
+#include <cstring>
 #include <linux/futex.h>
+#include <sys/prctl.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -32,6 +34,9 @@ static_assert(sizeof(std::atomic<int>) == sizeof(int), "futex word");
 // background workers, the frame-threaded decoder -- the thread sleeps in short naps between queries instead.
 template <class Query> inline bool nap_until(Query &&done, int nap_us = 25)
 {
+  // (a thread's sleeps are rounded up by its timer slack, 50 us by default -- three times the nap; 2 us makes a nap a nap)
+  static thread_local const bool slack_set = (prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0), true);
+  (void)slack_set;
   for (;;) {
     const int r = done();                    // 1 done, 0 not yet, < 0 error
     if (r) return r > 0;
@@ -92,6 +97,76 @@ class OrderedPool {
   uint64_t gen_ = 0; bool quit_ = false;
   const std::function<void(int)> *fn_ = nullptr;
   std::atomic<int> next_{1 << 30}, total_{0}, done_{0}, active_{0};
+};
+
+// Picture-sized host copies on several cores.  The reference's filters copy every picture once on their own thread (kvazaarfilter.cpp:
+// 410-418 into the kvz_picture, openhevcfilter.cpp:212-229 out of the decoder's frame): ~0.17 ms per 1080p picture on one core, which at
+// this library's rates is more than everything else the filter thread does.  A job is a list of 2-D pieces (rows x width bytes); helpers
+// and the caller take pieces off a shared counter, so a helper that wakes late just finds less to do.
+class CopyPool {
+ public:
+  struct Piece { uint8_t *dst; const uint8_t *src; size_t width, rows, dpitch, spitch; };
+  explicit CopyPool(int threads)
+  {
+    for (int i = 0; i + 1 < threads; i++) workers_.emplace_back([this] { name_this_thread("kvzx-copy"); worker(); });
+  }
+  ~CopyPool()
+  {
+    quit_.store(true, std::memory_order_release);
+    gen_.fetch_add(1, std::memory_order_acq_rel); futex_wake_all(gen_);
+    for (auto &t : workers_) t.join();
+  }
+  // one plane (rows x width, any pitches) cut into pieces of about `grain` bytes
+  static void add_plane(std::vector<Piece> &v, uint8_t *dst, const uint8_t *src, size_t width, size_t rows, size_t dpitch, size_t spitch, size_t grain = 256 << 10)
+  {
+    if (dpitch == width && spitch == width) { width *= rows; rows = 1; dpitch = spitch = width; }      // one run
+    if (rows == 1) { for (size_t o = 0; o < width; o += grain) v.push_back({dst + o, src + o, width - o < grain ? width - o : grain, 1, 0, 0}); return; }
+    const size_t step = grain / width ? grain / width : 1;
+    for (size_t r = 0; r < rows; r += step) v.push_back({dst + r * dpitch, src + r * spitch, width, rows - r < step ? rows - r : step, dpitch, spitch});
+  }
+  void run(const std::vector<Piece> &pieces)
+  {
+    if (workers_.empty() || pieces.size() < 2) { for (const Piece &p : pieces) one(p); return; }
+    while (active_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();      // stragglers of the previous job
+    job_ = &pieces;
+    done_.store(0, std::memory_order_relaxed);
+    total_.store((int)pieces.size(), std::memory_order_relaxed);
+    next_.store(0, std::memory_order_release);
+    gen_.fetch_add(1, std::memory_order_acq_rel); futex_wake_all(gen_);
+    drain();
+    const int n = (int)pieces.size();
+    for (int spins = 0; done_.load(std::memory_order_acquire) != n; spins++) { if (spins < 4000) __builtin_ia32_pause(); else std::this_thread::yield(); }
+  }
+
+ private:
+  static void one(const Piece &p) { for (size_t r = 0; r < p.rows; r++) memcpy(p.dst + r * p.dpitch, p.src + r * p.spitch, p.width); }
+  void worker()
+  {
+    int seen = gen_.load(std::memory_order_acquire);
+    for (;;) {
+      // a short spin first: at several thousand pictures per second the next job is ~100 us away and a futex wake-up costs a good part of that
+      for (int spins = 0; gen_.load(std::memory_order_acquire) == seen && spins < 2000; spins++) __builtin_ia32_pause();
+      while (gen_.load(std::memory_order_acquire) == seen) futex_wait(gen_, seen);
+      seen = gen_.load(std::memory_order_acquire);
+      if (quit_.load(std::memory_order_acquire)) return;
+      drain();
+    }
+  }
+  void drain()
+  {
+    active_.fetch_add(1, std::memory_order_acq_rel);
+    for (;;) {
+      const int r = next_.fetch_add(1, std::memory_order_acq_rel);
+      if (r >= total_.load(std::memory_order_acquire)) break;
+      one((*job_)[(size_t)r]);
+      done_.fetch_add(1, std::memory_order_acq_rel);
+    }
+    active_.fetch_sub(1, std::memory_order_acq_rel);
+  }
+  std::vector<std::thread> workers_;
+  const std::vector<Piece> *job_ = nullptr;
+  std::atomic<int> gen_{0}, next_{1 << 30}, total_{0}, done_{0}, active_{0};
+  std::atomic<bool> quit_{false};
 };
 
 }  // namespace kvzx

@@ -8,6 +8,8 @@
 #include <string>
 #include "../../include/kvazzup_amd.h"
 #include <deque>
+#include <mutex>
+#include <unordered_set>
 #include "encoder.h"
 
 using kvzx::Encoder;
@@ -169,6 +171,7 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
   INT_OPT("me-range", me_range, 1, 32)
   INT_OPT("gpu", gpu_device, 0, 64)
   BOOL_OPT("recon-output", recon_output)
+  BOOL_OPT("input-hold", input_hold)
   INT_OPT("band-row0", band_row0, 0, 4096)
   INT_OPT("band-rows", band_rows, 0, 4096)
   BOOL_OPT("rdoq", rdoq_enable) BOOL_OPT("signhide", signhide_enable) BOOL_OPT("smp", smp_enable) BOOL_OPT("amp", amp_enable)
@@ -202,13 +205,34 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
 }
 
 // ----------------------------------------------------------------------------- pictures, chunks
+// Pictures are page-locked when a HIP device is there: uvgComm copies every camera frame into a kvz_picture from picture_alloc
+// (kvazaarfilter.cpp:410-418) and hands that to encoder_encode, so the copy engine can read the caller's picture where it lies --
+// no second host copy into a staging buffer.  Without a device (header-only use, the CPU test suite) they are ordinary memory.
+// Freed page-locked pictures are kept (up to 16) for the next picture_alloc of the same size: encoder_encode hands out a fresh reconstruction
+// picture per access unit and uvgComm frees it at once (kvazaarfilter.cpp:476) -- page-locking memory costs milliseconds, a list look-up nothing.
+struct PinnedSet { std::mutex m; std::unordered_set<const void *> s; std::vector<std::pair<size_t, void *>> spare; };
+PinnedSet &pinned_set() { static PinnedSet *p = new PinnedSet(); return *p; }      // (never destroyed: pictures may be freed during exit)
+bool is_pinned(const void *buf) { PinnedSet &ps = pinned_set(); std::lock_guard<std::mutex> l(ps.m); return ps.s.count(buf) != 0; }
+
 kvz_picture *picture_alloc_csp(enum kvz_chroma_format csp, int32_t width, int32_t height)
 {
   if (csp != KVZ_CSP_420 || width <= 0 || height <= 0 || (width & 1) || (height & 1)) return nullptr;
   kvz_picture *p = (kvz_picture *)calloc(1, sizeof(kvz_picture));
   if (!p) return nullptr;
   size_t ny = (size_t)width * height;
-  p->fulldata_buf = (kvz_pixel *)malloc(ny * 3 / 2 + 64);
+  void *pin = nullptr;
+  int ndev = 0;
+  {
+    PinnedSet &ps = pinned_set(); std::lock_guard<std::mutex> l(ps.m);
+    for (size_t i = 0; i < ps.spare.size(); i++) if (ps.spare[i].first == ny) { pin = ps.spare[i].second; ps.spare.erase(ps.spare.begin() + (long)i); break; }
+  }
+  if (pin || (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipHostMalloc(&pin, ny * 3 / 2 + 64, hipHostMallocPortable) == hipSuccess && pin)) {
+    p->fulldata_buf = (kvz_pixel *)pin;
+    PinnedSet &ps = pinned_set(); std::lock_guard<std::mutex> l(ps.m); ps.s.insert(pin);
+  } else {
+    (void)hipGetLastError();
+    p->fulldata_buf = (kvz_pixel *)malloc(ny * 3 / 2 + 64);
+  }
   if (!p->fulldata_buf) { free(p); return nullptr; }
   p->fulldata = p->fulldata_buf;
   p->y = p->data[0] = p->fulldata; p->u = p->data[1] = p->fulldata + ny; p->v = p->data[2] = p->fulldata + ny + ny / 4;
@@ -221,7 +245,13 @@ void picture_free(kvz_picture *pic)
 {
   if (!pic) return;
   if (--pic->refcount > 0) return;
-  free(pic->fulldata_buf);
+  bool pinned, kept = false;
+  {
+    PinnedSet &ps = pinned_set(); std::lock_guard<std::mutex> l(ps.m);
+    pinned = ps.s.erase(pic->fulldata_buf) != 0;
+    if (pinned && ps.spare.size() < 16) { ps.spare.emplace_back((size_t)pic->width * pic->height, pic->fulldata_buf); kept = true; }
+  }
+  if (pinned) { if (!kept) hipHostFree(pic->fulldata_buf); } else free(pic->fulldata_buf);
   free(pic);      // roi.roi_array belongs to the caller (kvazaarfilter.cpp:53,459-463)
 }
 void chunk_free(kvz_data_chunk *chunk)
@@ -264,6 +294,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.satd = cfg->intra_satd != 0;
   ec.subme = cfg->fme_level < 0 ? 0 : (cfg->fme_level > 4 ? 4 : cfg->fme_level);
   ec.entropy_gpu = cfg->gpu_entropy != 0;
+  ec.input_hold = cfg->input_hold != 0;
   ec.vaq = cfg->vaq > 0 ? cfg->vaq : 0;
   ec.qp_in_cu = (cfg->set_qp_in_cu || ec.vaq > 0) ? 1 : 0;
   ec.sao = cfg->sao_type == KVZ_SAO_FULL;
@@ -335,7 +366,7 @@ int encoder_encode(kvz_encoder *e, kvz_picture *pic_in, kvz_data_chunk **data_ou
     // delta-QP map of this picture (kvazaarfilter.cpp:423-431); honoured when set-qp-in-cu enabled the signalling
     if (pic_in->roi.roi_array && pic_in->roi.width > 0 && pic_in->roi.height > 0) e->impl->set_roi(pic_in->roi.width, pic_in->roi.height, pic_in->roi.roi_array);
     else e->impl->set_roi(0, 0, nullptr);
-    if (!e->impl->encode_host(pic_in->y, pic_in->u, pic_in->v, &ep)) return 0;
+    if (!e->impl->encode_host(pic_in->y, pic_in->u, pic_in->v, &ep, pic_in->y == pic_in->fulldata_buf && is_pinned(pic_in->fulldata_buf))) return 0;
     pic_in->refcount++;
     e->in_flight->push_back(pic_in);
   }

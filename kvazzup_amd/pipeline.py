@@ -15,6 +15,7 @@ def _bind(lib):
     lib.uvgx_pipeline_push_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64]
     lib.uvgx_pipeline_wait.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
     lib.uvgx_pipeline_push_device_paced.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint32, C.c_int]
+    lib.uvgx_pipeline_push_host_paced.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint32, C.c_int, C.c_int]
     lib.uvgx_pipeline_flush.argtypes = [C.c_void_p]
     lib.uvgx_pipeline_encoder_backlog.restype = C.c_uint32
     lib.uvgx_pipeline_encoder_backlog.argtypes = [C.c_void_p]
@@ -72,6 +73,13 @@ class Pipeline:
     def push_device_paced(self, dptr, max_backlog=6, timeout_ms=60000, pts=None):
         """push_device that sleeps (in C) until the encoder filter buffers fewer than max_backlog pictures"""
         ok = self.lib.uvgx_pipeline_push_device_paced(self.p, dptr, self.w, self.h, self.fps[0], self.fps[1], self.pushed if pts is None else pts, max_backlog, timeout_ms)
+        self.pushed += 1 if ok else 0
+        return bool(ok)
+
+    def push_host_paced(self, i420, max_backlog=6, timeout_ms=60000, pts=None, borrow=True):
+        """a HOST picture (contiguous uint8 numpy array, w*h*3/2 bytes) through the reference's own boundary; with borrow the caller keeps
+        the array alive and unchanged until the picture has been encoded"""
+        ok = self.lib.uvgx_pipeline_push_host_paced(self.p, i420.ctypes.data, self.w, self.h, self.fps[0], self.fps[1], self.pushed if pts is None else pts, max_backlog, timeout_ms, int(borrow))
         self.pushed += 1 if ok else 0
         return bool(ok)
 

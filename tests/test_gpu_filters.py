@@ -53,3 +53,34 @@ def test_encoder_rejects_mismatching_input_and_unknown_option(gpu):
         assert pl.stats()["encoded_pictures"] == 2
     finally:
         pl.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,owf,threads,recon", [(320, 240, 0, 1, 1), (640, 368, 2, 4, 1), (1920, 1080, 6, 8, 0), (416, 240, 3, 3, 1)])
+def test_host_boundary_pipelined_matches_oracle(gpu, w, h, owf, threads, recon):
+    """The reference's own boundary with everything that overlaps it switched on: host pictures borrowed from the caller, copied into
+    page-locked kvz_pictures, uploaded on the encoder's copy stream (ring of device buffers), video/OWF pictures in flight; the decoder's
+    pictures come down on its download stream into the ring of host buffers behind libOpenHevcGetOutput.  Every access unit and every
+    decoded picture equals the CPU checker's (416x240: a host pitch wider than the picture)."""
+    from kvazzup_amd.pipeline import Pipeline
+    frames = 20 if w < 1000 else 10
+    oe = orc.OracleEncoder(w, h, qp=32, period=8, me_range=8)
+    pl = Pipeline(w, h, settings={"video/QP": 32, "video/Intra": 8, "video/OWF": owf, "video/OPENHEVC_threads": threads,
+                                  "video/OH_parallelization": "Frame" if threads > 1 else "Slice"},
+                  custom=(("me-range", 8), ("recon-output", recon)))
+    try:
+        clip = [orc.synth_frame(0, SEED + 3, w, h, t) for t in range(frames)]
+        for f in clip:
+            assert pl.push_host_paced(f, 6, 60000, borrow=True)
+        pl.flush()
+        assert pl.wait(frames, 120000)
+        for t in range(frames):
+            au_o = oe.encode(clip[t])
+            au_g, pts = pl.pop_encoded()
+            assert pts == t and au_g == au_o, "AU %d differs" % t
+            d = pl.pop_decoded()
+            assert d["width"] == w and d["height"] == h and d["pts"] == t
+            assert np.array_equal(d["i420"], oe.recon()), "decoded picture %d differs from the reconstruction" % t
+    finally:
+        pl.close()
+        oe.close()

@@ -516,6 +516,7 @@ def main():
     ap.add_argument("--me-range", type=int, default=16)
     ap.add_argument("--repeats", type=int, default=3, help="the K-step timed region is run this many times; `value` is the median run (BASELINE.md: median of 3)")
     ap.add_argument("--no-host-boundary", action="store_true", help="skip the `host_boundary` legs (host I420 in through kvz_api->encoder_encode, decoded I420 out into host memory)")
+    ap.add_argument("--host-io", action="store_true", help="profiling aid: the MAIN run goes through the host boundary (then `value` is the host-boundary rate and no separate leg is run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-decode", action="store_true", help="8k-tilesplit: skip the split decoder's leg (reported as `secondary`)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 4K line (configs[2], the north-star target) that a 1080p run appends as `secondary`")
@@ -545,6 +546,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("KVAZZUP_BENCH_LIB_FIRST"):
+        from kvazzup_amd import _native
+        _native.load_library()
     torch, dist, dev, dev_index, backend = init_dist(world, local_rank)
 
     def sync(value=None):
@@ -553,7 +557,11 @@ def main():
     wl = WORKLOADS[args.workload]
     w, h = wl["w"], wl["h"]
     resident = (("input-hold", "1"),)       # the clip's device pictures stay untouched: encode_device returns without waiting for its input stage
-    m = run_stream(args, wl, args.steps, args.warmup, torch, dev, dev_index, rank, world, sync, quality=(rank == 0), extra_custom=resident)
+    if args.host_io:
+        args.no_host_boundary = True
+        m = run_stream(args, wl, args.steps, args.warmup, torch, dev, dev_index, rank, world, sync, quality=False, host_io=True, extra_custom=(("recon-output", "0"),))
+    else:
+        m = run_stream(args, wl, args.steps, args.warmup, torch, dev, dev_index, rank, world, sync, quality=(rank == 0), extra_custom=resident)
     def host_leg(wl_, steps_, warm_, resident):
         """the same steps through the reference's own boundary (run_stream host_io); a dict for the JSON line"""
         try:
@@ -604,7 +612,8 @@ def main():
                        "bits_per_picture": round(8 * m["bytes_per_picture"], 1), "psnr_y": m["psnr_y"],
                        "decoder_frame_threads": m["D"], "owf": args.owf, "gpu_entropy": bool(args.gpu_entropy), "subme": args.subme, "sao": bool(args.sao), "me_early_termination": not args.full_search, "intra_satd": not args.intra_sad,
                        "host_cpu_cores_busy": round(m["host_cores"], 2), "host_cpu_budget_cores": round(m["budget"], 1), "host_cpu_throttled_ms": round(m["throttled_ms"], 1),
-                       "input": "I420 resident in HBM", "output": "Annex-B AU on host + decoded I420 in HBM",
+                       "input": "host I420 through kvz_api->encoder_encode" if args.host_io else "I420 resident in HBM",
+                       "output": "Annex-B AU on host + decoded I420 in " + ("host memory" if args.host_io else "HBM"),
                        "repeats": args.repeats, "runs_fps": m["runs_fps"], "value_is": "median run of `repeats` (BASELINE.md timing rule)"},
             "host_boundary": hostb,
             "roofline": roof,

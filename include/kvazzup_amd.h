@@ -145,6 +145,7 @@ KVZ_PUBLIC int uvgx_pipeline_pop_encoded(void *p, uint8_t *buf, uint32_t cap, ui
 KVZ_PUBLIC int uvgx_pipeline_pop_decoded(void *p, uint8_t *buf, uint32_t cap, uint32_t *size, int *w, int *h, int64_t *pts);
 KVZ_PUBLIC void uvgx_pipeline_stats(void *p, uint64_t *out8);
 KVZ_PUBLIC void uvgx_pipeline_busy_ms(void *p, double *out3);   /* time inside process(): encoder, wire adapter, decoder filter */
+KVZ_PUBLIC void uvgx_pipeline_avg_queue(void *p, double *out3); /* inputs found buffered by an arriving input, averaged: encoder, wire adapter, decoder filter */
 KVZ_PUBLIC void *uvgx_pipeline_encoder(void *p);     /* kvz_encoder* of the KvazaarFilter */
 KVZ_PUBLIC void *uvgx_pipeline_decoder(void *p);     /* OpenHevc_Handle of the OpenHEVCFilter (NULL without loop-back) */
 KVZ_PUBLIC void uvgx_pipeline_destroy(void *p);

@@ -130,7 +130,7 @@ class Decoder {
   bool debug_copy(const char *what, void *dst, size_t bytes);
   int last_error() const { return last_error_; }
   void flush() {}
-  int pending() const { return (int)(job_head_ - job_tail_) + (gpu_job_ ? 1 : 0); }
+  int pending() const { return (int)(job_head_ - job_tail_) + (gpu_job_ ? 1 : 0) + (int)gpu_q_.size(); }
 
   // ---- per-picture state shared with the slice-data parser (decoder.hip)
   struct SubOut { std::vector<uint32_t> levels; std::vector<DecTu> tus; int rc = 0; };     // one per substream
@@ -167,6 +167,7 @@ class Decoder {
     bool any_intra = false, any_inter = false, across_slices = true;
     std::atomic<int> state{0}; int rc = 0; double parse_ms = 0;
     hipEvent_t done = nullptr;                                   // recorded behind the picture's last kernel
+    long launch_idx = 0;                                         // count of pictures launched before this one
     hipEvent_t dl_done = nullptr; int dl_buf = -1;               // download mode: the picture's copy into host buffer dl_buf, queued behind `done` on the download stream
     struct EvPair { hipEvent_t a, b; int id; }; std::vector<EvPair> ev; size_t ev_used = 0;     // kernel timing (set_profiling)
     PicJob() {}
@@ -209,8 +210,7 @@ class Decoder {
   int alloc_slot();
 
   int device_; bool started_ = false;
-  hipEvent_t err_ev_ = nullptr; bool err_pending_ = false;    // the error word's download (complete_gpu)
-  hipStream_t stream_up_ = nullptr; hipEvent_t up_done_[2] = {nullptr, nullptr};   // upload of the next picture's input block beside the current picture's kernels
+  hipStream_t stream_up_ = nullptr; hipEvent_t up_done_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // upload of the next picture's input block beside the current picture's kernels
   hipStream_t stream_ = nullptr, stream_dl_ = nullptr;       // reconstruction; download of finished pictures (behind the picture's event, beside the next picture's kernels)
   std::shared_ptr<const DecSps> sps_[16]; DecPps pps_[64]; uint32_t vps_fps_num_ = 0, vps_fps_den_ = 0;
   int w_ = 0, h_ = 0, pw_ = 0, ph_ = 0;
@@ -225,20 +225,27 @@ class Decoder {
   bool queue_current_output();
   std::unique_ptr<FrameWorkers> workers_;
   // decoded picture buffer: slot = device planes + what reference marking needs
-  struct DpbPic { uint8_t *plane[3] = {nullptr, nullptr, nullptr}; int poc = 0; bool is_ref = false, used = false; long decode_idx = -1000; std::shared_ptr<ColMotion> motion; };
+  struct DpbPic { uint8_t *plane[3] = {nullptr, nullptr, nullptr}; int poc = 0; bool is_ref = false, used = false; long decode_idx = -1000; std::shared_ptr<ColMotion> motion;
+                  hipEvent_t last_dl = nullptr; };     // download mode: the copy of the picture last reconstructed here (a later picture's kernels wait for it before they write the buffer)
   DpbPic dpb_[KVZ_DEC_MAX_REFS];
   // device side
-  uint8_t *d_in_[2] = {nullptr, nullptr}; size_t d_in_cap_[2] = {0, 0};   // device copies of PicJob::h_in: pictures alternate between the two
+  // Frame-threaded mode keeps up to gpu_depth_ pictures queued on the GPU (launched, not yet completed): a picture's way through upload, kernels
+  // and the copy back to the host is ~0.2 ms at 1080p, and with only one picture launched ahead of the one being waited for the calling thread
+  // sat out most of that for every picture.  The output lag stays `frame_threads` pictures: the parse ring gives up what the GPU queue takes.
+  static constexpr int kMaxGpuDepth = 4;
+  int gpu_depth_ = 1; std::deque<PicJob *> gpu_q_;
+  uint8_t *d_in_[kMaxGpuDepth + 1] = {}; size_t d_in_cap_[kMaxGpuDepth + 1] = {};   // device copies of PicJob::h_in: the pictures in flight take turns
   int16_t *resid_[3] = {nullptr, nullptr, nullptr};         // intra residuals between k_dec_intra_resid and k_dec_intra
   uint8_t *work_[3] = {nullptr, nullptr, nullptr};          // pictures with SAO: reconstruction and deblocking happen here, the filter writes into the slot
   uint32_t *progress_ = nullptr, *intra_order_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
-  // download mode: three page-locked output buffers take turns -- one is what libOpenHevcGetOutput last handed out (valid until the next
+  // download mode: page-locked output buffers take turns -- one is what libOpenHevcGetOutput last handed out (valid until the next
   // decode call, openhevcfilter.cpp:218-229 copies at once), one receives the picture whose kernels are running, queued behind them on
   // the download stream at launch, so the copy over PCIe overlaps the next picture's kernels instead of stalling the calling thread
-  static constexpr int kOutRing = 3;
-  uint8_t *h_out_[kOutRing] = {nullptr, nullptr, nullptr}; size_t h_out_cap_ = 0;
+  static constexpr int kOutRing = 6;      // (pictures queued on the GPU + the one handed out + the one being launched)
+  uint8_t *h_out_[kOutRing] = {}; size_t h_out_cap_ = 0;
   void describe_output(const PicJob &job, DecodedPicture &o, int buf) const;
   int queue_download(PicJob &job);
+  int start_ready_downloads();
   long launched_ = 0; int out_slot_ = 0; int output_hold_ = 2;
   char prio_dl_ = 'n', prio_up_ = 'n';
   char prio_ = 'n';                                       // priority level of the main stream (stream_pool.h key)

@@ -780,7 +780,10 @@ struct SliceParser {
 // Pictures still being parsed by frame workers are waited for and dropped (close / resolution change).
 void Decoder::drop_pending()
 {
-  if (gpu_job_) { hipStreamSynchronize(stream_); gpu_job_->ev_used = 0; gpu_job_ = nullptr; }
+  if (gpu_job_ || !gpu_q_.empty()) { hipStreamSynchronize(stream_); if (stream_dl_) hipStreamSynchronize(stream_dl_); }
+  if (gpu_job_) { gpu_job_->ev_used = 0; gpu_job_->dl_buf = -1; gpu_job_ = nullptr; }
+  for (PicJob *j : gpu_q_) { j->ev_used = 0; j->dl_buf = -1; }
+  gpu_q_.clear();
   for (; job_tail_ != job_head_; job_tail_++) {
     PicJob &job = jobs_[(size_t)(job_tail_ % jobs_.size())];
     while (job.state.load(std::memory_order_acquire) != 2) std::this_thread::yield();
@@ -794,17 +797,14 @@ Decoder::~Decoder()
   drop_pending();
   workers_.reset();
   if (stream_) hipStreamSynchronize(stream_);
-  if (err_pending_ && hipEventSynchronize(err_ev_) == hipSuccess && *h_err_) fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x (last picture)\n", *h_err_);
+  if (h_err_ && *h_err_) fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x (last picture)\n", *h_err_);
   for (auto &j : jobs_) { for (auto &e : j.ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); } if (j.done) hipEventDestroy(j.done); if (j.dl_done) hipEventDestroy(j.dl_done); }
   free_buffers();
   for (auto &o : ready_q_) if (o.dev) hipFree(o.dev);
   if (cur_owned_.dev) hipFree(cur_owned_.dev);
-  stream_release(stream_dl_, device_, 'L', prio_dl_);
   stream_release(stream_up_, device_, 'U', prio_up_);
   for (auto &e : up_done_) if (e) hipEventDestroy(e);
-  if (err_ev_) hipEventDestroy(err_ev_);
   if (h_err_) hipHostFree(h_err_);
-  if (err_) hipFree(err_);
   stream_release(stream_, device_, 'D', prio_);
 }
 
@@ -826,13 +826,17 @@ bool Decoder::start(std::string *error)
     const char *prio = getenv("KVAZZUP_AMD_PRIO");          // (letters 5 and 6: the download and the upload stream)
     prio_dl_ = (prio && strlen(prio) >= 5) ? prio[4] : 'n'; prio_up_ = (prio && strlen(prio) >= 6) ? prio[5] : 'n';
   }
-  HIP_TRY(stream_acquire(&stream_dl_, device_, 'L', prio_dl_));
+  // ONE transfer stream: the input blocks go up and the finished pictures come down on it, all through the copy engine and none of them ever
+  // waiting inside the queue (a download is only queued once its picture's kernels are known to be done).  HIP spreads the streams of a priority
+  // level over four hardware queues; with encoder and decoder in one process every further stream shares a queue with one that matters.
   HIP_TRY(stream_acquire(&stream_up_, device_, 'U', prio_up_));
+  stream_dl_ = stream_up_;
   for (auto &e : up_done_) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&err_ev_, hipEventDisableTiming));
-  HIP_TRY(hipMalloc(&err_, sizeof(uint32_t)));
-  HIP_TRY(hipMemset(err_, 0, sizeof(uint32_t)));
-  HIP_TRY(hipHostMalloc(&h_err_, sizeof(uint32_t), hipHostMallocDefault));
+  // the kernels' error word (a wavefront that gave up waiting ORs a flag in) lives in host memory the device writes straight into, like the
+  // encoder's: looked at when a picture completes, no copy (a copy queued on the download stream waited behind the pictures' own downloads)
+  HIP_TRY(hipHostMalloc(&h_err_, sizeof(uint32_t), hipHostMallocMapped));
+  *h_err_ = 0;
+  { void *dp = nullptr; HIP_TRY(hipHostGetDevicePointer(&dp, h_err_, 0)); err_ = (uint32_t *)dp; }
   started_ = true;
   return true;
 }
@@ -842,10 +846,12 @@ void Decoder::free_buffers()
   for (auto &j : jobs_) { if (j.h_in) hipHostFree(j.h_in); j.h_in = nullptr; j.h_in_cap = 0; j.col.reset(); j.own.reset(); }
   if (stream_dl_) hipStreamSynchronize(stream_dl_);
   for (auto &p : h_out_) { if (p) hipHostFree(p); p = nullptr; }
-  hipFree(d_in_[0]); hipFree(d_in_[1]); hipFree(progress_); hipFree(intra_order_); intra_order_ = nullptr;
-  for (auto &p : dpb_) { for (int c = 0; c < 3; c++) { hipFree(p.plane[c]); p.plane[c] = nullptr; } p = DpbPic(); }
+  for (auto &p : d_in_) { hipFree(p); p = nullptr; }
+  for (auto &c : d_in_cap_) c = 0;
+  hipFree(progress_); hipFree(intra_order_); intra_order_ = nullptr;
+  for (auto &p : dpb_) { hipFree(p.plane[0]); p = DpbPic(); }      // (a buffer's three planes are one allocation)
   for (int c = 0; c < 3; c++) { hipFree(work_[c]); work_[c] = nullptr; hipFree(resid_[c]); resid_[c] = nullptr; }
-  d_in_[0] = d_in_[1] = nullptr; d_in_cap_[0] = d_in_cap_[1] = 0; progress_ = nullptr;
+  progress_ = nullptr;
   w_ = h_ = pw_ = ph_ = 0;
 }
 
@@ -877,14 +883,21 @@ bool Decoder::ensure_buffers(int w, int h)
   if (w == w_ && h == h_) return true;
   // Resolution change (a new SPS took effect at this IRAP picture): what the ring still holds is completed now and queued -- the
   // following calls hand it out one picture at a time, as a software decoder's bumping process would -- before the buffers go
-  while (w_ && (gpu_job_ || job_tail_ != job_head_)) {
+  while (w_ && (gpu_job_ || !gpu_q_.empty() || job_tail_ != job_head_)) {
     const int rc = finish_oldest();
     if (rc < 0 || (rc > 0 && pic_ready_ && !queue_current_output())) { drop_pending(); break; }
   }
   drop_pending();
   hipStreamSynchronize(stream_);
   free_buffers();
-  if (jobs_.empty()) jobs_ = std::vector<PicJob>((size_t)frame_threads_ + 2);   // parse ring + two pictures in flight on the GPU (one running, one being handed out)
+  if (jobs_.empty()) {
+    const char *e = getenv("KVAZZUP_AMD_DEC_GPU_DEPTH");
+    gpu_depth_ = e ? atoi(e) : (frame_threads_ >= 4 ? 3 : 1);
+    if (gpu_depth_ > kMaxGpuDepth) gpu_depth_ = kMaxGpuDepth;
+    if (gpu_depth_ > frame_threads_ - 1) gpu_depth_ = frame_threads_ - 1;
+    if (gpu_depth_ < 1 || band_nrows_ > 0) gpu_depth_ = 1;
+    jobs_ = std::vector<PicJob>((size_t)frame_threads_ + 2);   // the pictures being parsed and queued on the GPU (frame_threads_ of them), the one being handed out, the one being filled
+  }
   w_ = w; h_ = h; pw_ = (w + 63) & ~63; ph_ = (h + 63) & ~63;
   const size_t npx = (size_t)pw_ * ph_, nb4 = npx / 16;
   for (auto &j : jobs_) {
@@ -893,7 +906,7 @@ bool Decoder::ensure_buffers(int w, int h)
     j.pred_mode.assign(nb4 / 4, PM_NONE); j.ct_depth.assign(nb4 / 4, 0); j.intra_mode.assign(nb4, 1);
   }
   h_out_cap_ = npx * 3 / 2;                              // (allocated by the first picture that is downloaded)
-  for (int i = 0; i < 2; i++) { d_in_cap_[i] = fixed_bytes() + (1 << 20); HIP_TRY(hipMalloc(&d_in_[i], d_in_cap_[i])); }
+  for (int i = 0; i <= gpu_depth_; i++) { d_in_cap_[i] = fixed_bytes() + (1 << 20); HIP_TRY(hipMalloc(&d_in_[i], d_in_cap_[i])); }
   HIP_TRY(hipMalloc(&progress_, sizeof(uint32_t) * 3 * (size_t)(pw_ / 64) * (ph_ / 64)));
   {
     // dispatch order of k_dec_intra's workgroups: CTUs by anti-diagonal cx + 2 cy (every CTU a block depends on comes earlier)
@@ -907,7 +920,8 @@ bool Decoder::ensure_buffers(int w, int h)
   }
   for (int c = 0; c < 3; c++) HIP_TRY(hipMalloc(&work_[c], c ? npx / 4 : npx));
   for (int c = 0; c < 3; c++) HIP_TRY(hipMalloc(&resid_[c], sizeof(int16_t) * (c ? npx / 4 : npx)));
-  for (int s = 0; s < 6; s++) for (int c = 0; c < 3; c++) { const size_t n = c ? npx / 4 : npx; HIP_TRY(hipMalloc(&dpb_[s].plane[c], n)); HIP_TRY(hipMemset(dpb_[s].plane[c], 128, n)); }
+  // a picture buffer: Y | Cb | Cr back to back in one allocation (the whole picture goes to the host in ONE copy)
+  for (int s = 0; s < 6; s++) { HIP_TRY(hipMalloc(&dpb_[s].plane[0], npx * 3 / 2)); HIP_TRY(hipMemset(dpb_[s].plane[0], 128, npx * 3 / 2)); dpb_[s].plane[1] = dpb_[s].plane[0] + npx; dpb_[s].plane[2] = dpb_[s].plane[1] + npx / 4; }
   seen_irap_ = false;
   return true;
 }
@@ -917,11 +931,12 @@ int Decoder::alloc_slot()
 {
   for (int s = 0; s < KVZ_DEC_MAX_REFS; s++) {
     DpbPic &p = dpb_[s];
-    if (p.is_ref || job_head_ - p.decode_idx <= output_hold_) continue;
+    if (p.is_ref || job_head_ - p.decode_idx <= output_hold_ + (gpu_depth_ - 1)) continue;      // (pictures queued on the GPU behind the one handed out may already write their buffers)
     if (!p.plane[0]) {
       const size_t npx = (size_t)pw_ * ph_;
       if (hipSetDevice(device_) != hipSuccess) return -1;
-      for (int c = 0; c < 3; c++) { const size_t n = c ? npx / 4 : npx; if (hipMalloc(&p.plane[c], n) != hipSuccess) return -1; hipMemset(p.plane[c], 128, n); }
+      if (hipMalloc(&p.plane[0], npx * 3 / 2) != hipSuccess) { p.plane[0] = nullptr; return -1; }
+      hipMemset(p.plane[0], 128, npx * 3 / 2); p.plane[1] = p.plane[0] + npx; p.plane[2] = p.plane[1] + npx / 4;
     }
     return s;
   }
@@ -971,9 +986,10 @@ bool Decoder::queue_current_output()
   OwnedPic o;
   o.pic = out_;
   if (download_) {
-    size_t total = 0;
-    for (int c = 0; c < 3; c++) total += (size_t)out_.host_pitch[c] * (c ? out_.height / 2 : out_.height);
-    o.host.assign(out_.host[0], out_.host[0] + total);            // (the three planes lie back to back in the download buffer)
+    for (int c = 0; c < 3; c++) {                                 // plane after plane, pitch x rows each (decode_nal rebuilds the pointers the same way)
+      const uint8_t *p = out_.host[c];
+      o.host.insert(o.host.end(), p, p + (size_t)out_.host_pitch[c] * (c ? out_.height / 2 : out_.height));
+    }
   }
   {
     // the device view: a dense copy (pitch = width), so that device-resident consumers keep working across the re-allocation
@@ -1428,7 +1444,7 @@ int Decoder::submit_job(PicJob &job, int nal_type, bool irap)
       futex_wake_all(jp->state);
     });
   }
-  if (job_head_ - job_tail_ < frame_threads_) return 0;          // pipeline still filling: no output for this NAL
+  if (job_head_ - job_tail_ < frame_threads_ - (gpu_depth_ - 1)) return 0;          // pipeline still filling: no output for this NAL
   return finish_oldest();
 }
 
@@ -1438,9 +1454,8 @@ int Decoder::submit_job(PicJob &job, int nal_type, bool irap)
 // then the oldest parsed picture is launched -- its kernels run while this thread goes on parsing headers.
 int Decoder::finish_oldest()
 {
-  PicJob *prev = gpu_job_;
-  gpu_job_ = nullptr;
   int rc_launch = 0;
+  bool launched = false;
   if (job_head_ != job_tail_) {
     PicJob &job = jobs_[(size_t)(job_tail_ % jobs_.size())];
     job_tail_++;
@@ -1448,18 +1463,29 @@ int Decoder::finish_oldest()
     job.state.store(0, std::memory_order_relaxed);
     if (frame_threads_ > 1 && profiling_) { k_ms_[DK_HOST_PARSE] += job.parse_ms; k_n_[DK_HOST_PARSE]++; }
     if (job.parse_ms > t_parse_max_) t_parse_max_ = job.parse_ms;
-    // the next picture's kernels are queued BEFORE the previous picture is waited for: the GPU goes from one to the other without
+    // the next picture's kernels are queued BEFORE an earlier picture is waited for: the GPU goes from one to the other without
     // this thread's launch latency in between
     rc_launch = job.rc < 0 ? job.rc : launch_gpu(job);
+    launched = rc_launch >= 0;
   }
   int produced = 0;
-  if (prev) { const int rc = complete_gpu(*prev); if (rc < 0) return rc; produced = 1; }
+  { const int rc = start_ready_downloads(); if (rc < 0) return rc; }
+  // frame-threaded mode: gpu_depth_ pictures stay queued on the GPU; a call that launches nothing (end of sequence / drain) takes one out
+  if (!gpu_q_.empty() && (!launched || (int)gpu_q_.size() > gpu_depth_)) {
+    PicJob *j = gpu_q_.front(); gpu_q_.pop_front();
+    const int rc = complete_gpu(*j);
+    if (rc < 0) return rc;
+    produced = 1;
+  }
   if (rc_launch < 0) return rc_launch;
-  if (frame_threads_ == 1 && gpu_job_ && band_nrows_ == 0) { PicJob *j = gpu_job_; gpu_job_ = nullptr; const int rc = complete_gpu(*j); if (rc < 0) return rc; produced = 1; }
+  if (frame_threads_ == 1 && !gpu_q_.empty()) { PicJob *j = gpu_q_.front(); gpu_q_.pop_front(); const int rc = complete_gpu(*j); if (rc < 0) return rc; produced = 1; }
   return produced;
 }
 
-// what libOpenHevcGetOutput / kvzx_decoder_output_device say about the picture of `job`; buf: its host buffer (download mode) or -1
+// what libOpenHevcGetOutput / kvzx_decoder_output_device say about the picture of `job`; buf: its host buffer (download mode) or -1.
+// The host buffer holds the picture buffer as it is -- coded size, Y | Cb | Cr back to back, pitch = coded width -- so that it comes down in one
+// copy; the cropped picture is addressed through the plane pointers and pitches, as with any decoder's frame (openhevcfilter.cpp:209,224-227
+// reads chroma row i/2 at pvU + i * (nUPitch / 2): the pitches are even).
 void Decoder::describe_output(const PicJob &job, DecodedPicture &o, int buf) const
 {
   o = DecodedPicture();
@@ -1467,62 +1493,64 @@ void Decoder::describe_output(const PicJob &job, DecodedPicture &o, int buf) con
   o.width = w_ - job.crop[0] - job.crop[1]; o.height = h_ - job.crop[2] - job.crop[3];
   o.poc = job.sh.poc; o.pts = job.pts; o.is_intra = job.sh.is_intra;
   o.fps_num = job.fps_num; o.fps_den = job.fps_den;
-  size_t off = 0;
-  // Host pitches are kept even and aligned like a software decoder's line sizes: the reference
-  // addresses chroma row i/2 as pvU + i * (nUPitch / 2) (openhevcfilter.cpp:209,224-227).
-  const int ypitch = (o.width + 63) & ~63;
   for (int c = 0; c < 3; c++) {
     const int pw = c ? pw_ / 2 : pw_, ox = c ? job.crop[0] / 2 : job.crop[0], oy = c ? job.crop[2] / 2 : job.crop[2];
-    o.dev[c] = dpb_[job.slot].plane[c] + (size_t)oy * pw + ox; o.dev_pitch[c] = pw;
-    if (buf >= 0) {
-      const int h = c ? o.height / 2 : o.height, pitch = c ? ypitch / 2 : ypitch;
-      o.host[c] = h_out_[buf] + off; o.host_pitch[c] = pitch;
-      off += (size_t)pitch * h;
-    }
+    const size_t off = (size_t)oy * pw + ox;
+    o.dev[c] = dpb_[job.slot].plane[c] + off; o.dev_pitch[c] = pw;
+    if (buf >= 0) { o.host[c] = h_out_[buf] + (dpb_[job.slot].plane[c] - dpb_[job.slot].plane[0]) + off; o.host_pitch[c] = pw; }
   }
 }
 
-// the picture's cropped planes -> host buffer job.dl_buf, on the download stream, behind the picture's last kernel
+// The picture buffer of `job` -> host buffer job.dl_buf: one copy-engine transfer on the download stream.  Only called when the picture's
+// kernels are KNOWN to have finished (the caller has seen job.done): the copy command then carries no dependency, the copy engine takes
+// it at once and nothing waits inside a hardware queue.  (Copies that waited on an event in the stream were executed by the runtime as
+// blit kernels, four per picture with a barrier each; a kernel that stores across PCIe -- tried too -- slows every kernel running beside it
+// by a factor of two to ten, tools: scratch/pcie4.hip.  The copy engine disturbs nothing.)
 int Decoder::queue_download(PicJob &job)
 {
-  job.dl_buf = (int)(launched_ % kOutRing);
+  job.dl_buf = (int)(job.launch_idx % kOutRing);
   if (!h_out_[job.dl_buf] && hipHostMalloc(&h_out_[job.dl_buf], h_out_cap_, hipHostMallocDefault) != hipSuccess) { h_out_[job.dl_buf] = nullptr; return DEC_ERR_GPU; }
   if (!job.dl_done && hipEventCreateWithFlags(&job.dl_done, hipEventDisableTiming) != hipSuccess) return DEC_ERR_GPU;
-  if (hipStreamWaitEvent(stream_dl_, job.done, 0) != hipSuccess) return DEC_ERR_GPU;
-  DecodedPicture o;
-  describe_output(job, o, job.dl_buf);
-  for (int c = 0; c < 3; c++) {
-    const int w = c ? o.width / 2 : o.width, h = c ? o.height / 2 : o.height;
-    uint8_t *dst = const_cast<uint8_t *>(o.host[c]);
-    hipError_t e = (w == o.host_pitch[c] && w == o.dev_pitch[c])
-        ? hipMemcpyAsync(dst, o.dev[c], (size_t)w * h, hipMemcpyDeviceToHost, stream_dl_)       // one linear run (1080p, 4K: the coded width is the picture's)
-        : hipMemcpy2DAsync(dst, (size_t)o.host_pitch[c], o.dev[c], (size_t)o.dev_pitch[c], (size_t)w, (size_t)h, hipMemcpyDeviceToHost, stream_dl_);
-    if (e != hipSuccess) return DEC_ERR_GPU;
-  }
+  // rows above the crop window are not needed, rows below the picture's last row neither: the copy covers the planes from the first to the last row used
+  const size_t npx = (size_t)pw_ * ph_;
+  const size_t used = npx + npx / 4 + (size_t)(pw_ / 2) * ((h_ + 1) / 2);             // up to the end of the last Cr row
+  if (hipMemcpyAsync(h_out_[job.dl_buf], dpb_[job.slot].plane[0], used, hipMemcpyDeviceToHost, stream_dl_) != hipSuccess) return DEC_ERR_GPU;
+  dpb_[job.slot].last_dl = job.dl_done;
   return hipEventRecord(job.dl_done, stream_dl_) == hipSuccess ? 0 : DEC_ERR_GPU;
+}
+
+// frame-threaded download mode: start the copy of every queued picture whose kernels have finished (oldest first)
+int Decoder::start_ready_downloads()
+{
+  if (!download_) return 0;
+  for (PicJob *j : gpu_q_) {
+    if (j->dl_buf >= 0) continue;
+    const hipError_t r = hipEventQuery(j->done);
+    if (r == hipErrorNotReady) break;
+    if (r != hipSuccess) return DEC_ERR_GPU;
+    const int rc = queue_download(*j);
+    if (rc < 0) return rc;
+  }
+  return 0;
 }
 
 int Decoder::complete_gpu(PicJob &job)
 {
-  if (download_ && job.dl_buf < 0) { const int rc = queue_download(job); if (rc < 0) return rc; }     // (band mode: `done` has only just been recorded)
   {
     Tick tk;
-    hipEvent_t last = download_ ? job.dl_done : job.done;
-    if (frame_threads_ > 1 && !spin_wait_) {   // the output lags anyway: nap between queries instead of polling (see nap_until)
-      if (!nap_until([&] { hipError_t r = hipEventQuery(last); return r == hipSuccess ? 1 : (r == hipErrorNotReady ? 0 : -1); })) return DEC_ERR_GPU;
-    } else if (hipEventSynchronize(last) != hipSuccess) return DEC_ERR_GPU;
+    auto wait = [&](hipEvent_t ev) {
+      if (frame_threads_ > 1 && !spin_wait_)    // the output lags anyway: nap between queries instead of polling (see nap_until)
+        return nap_until([&] { hipError_t r = hipEventQuery(ev); return r == hipSuccess ? 1 : (r == hipErrorNotReady ? 0 : -1); });
+      return hipEventSynchronize(ev) == hipSuccess;
+    };
+    if (download_ && job.dl_buf < 0) {          // its copy has not been started yet (synchronous decoder; the GPU queue was short): kernels first
+      if (!wait(job.done)) return DEC_ERR_GPU;
+      const int rc = queue_download(job); if (rc < 0) return rc;
+    }
+    if (!wait(download_ ? job.dl_done : job.done)) return DEC_ERR_GPU;
     t_sync_ += tk.ms();
   }
-  // The kernels' error word (a wavefront that gave up waiting) comes down on the download stream, beside the next picture's
-  // kernels rather than between them, and is looked at when the NEXT picture completes (and when the decoder is drained): a
-  // device fault is reported one picture late instead of costing every picture a synchronous round trip.
-  if (err_pending_) {
-    if (hipEventSynchronize(err_ev_) != hipSuccess) return DEC_ERR_GPU;
-    err_pending_ = false;
-    if (*h_err_) { fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x\n", *h_err_); return DEC_ERR_GPU; }
-  }
-  if (hipMemcpyAsync(h_err_, err_, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_dl_) != hipSuccess || hipEventRecord(err_ev_, stream_dl_) != hipSuccess) return DEC_ERR_GPU;
-  err_pending_ = true;
+  if (*h_err_) { fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x\n", *h_err_); return DEC_ERR_GPU; }
   if (job.ev_used) {
     for (size_t i = 0; i < job.ev_used; i++) { float ms = 0; hipEventElapsedTime(&ms, job.ev[i].a, job.ev[i].b); k_ms_[job.ev[i].id] += ms; k_n_[job.ev[i].id]++; }
     job.ev_used = 0;
@@ -1695,10 +1723,10 @@ int Decoder::launch_gpu(PicJob &job)
   timed_job_ = &job; job.ev_used = 0;
   if (!job.done && hipEventCreateWithFlags(&job.done, hipEventDisableTiming) != hipSuccess) return DEC_ERR_GPU;
   Tick tk_api;
-  // The input block goes up on its own stream into one of two device buffers: the picture launched before this one may still be
-  // running (finish_oldest launches before it completes the previous picture) and reads the other buffer; the one before that
-  // has been completed, so this buffer is free.
-  const int ib = (int)(launched_ & 1);
+  // The input block goes up on its own stream into one of gpu_depth_ + 1 device buffers: the gpu_depth_ pictures launched before this
+  // one may still be running (finish_oldest launches before it completes the oldest of them) and read the other buffers; the one before
+  // those has been completed, so this buffer is free.
+  const int ib = (int)(launched_ % (gpu_depth_ + 1));
   uint8_t *&d_in_ = this->d_in_[ib];
   if (bytes > d_in_cap_[ib]) {
     hipFree(d_in_);
@@ -1727,6 +1755,8 @@ int Decoder::launch_gpu(PicJob &job)
     if (!ok || !top || !bottom) return DEC_ERR_UNSUPPORTED;
     f.row0 = band_row0_; f.nrows = band_nrows_;
   }
+  // the buffer the picture is built in: the copy to the host of the picture last reconstructed there (queued, maybe not yet run) comes first
+  if (dpb_[job.slot].last_dl) { if (hipStreamWaitEvent(stream_, dpb_[job.slot].last_dl, 0) != hipSuccess) return DEC_ERR_GPU; dpb_[job.slot].last_dl = nullptr; }
   if (job.any_inter) timed(DK_INTER, [&] { launch_dec_inter(f, stream_); });
   if (job.any_intra) {
     if (hipMemsetAsync(progress_, 0, sizeof(uint32_t) * 3 * (size_t)f.wc * f.hc, stream_) != hipSuccess) return DEC_ERR_GPU;
@@ -1736,11 +1766,10 @@ int Decoder::launch_gpu(PicJob &job)
   else if (!job.sh.deblock_disabled) timed(DK_DEBLOCK, [&] { launch_dec_deblock(f, stream_); });
   if (sao) timed(DK_SAO, [&] { launch_dec_sao(f, stream_); });
   if (hipEventRecord(job.done, stream_) != hipSuccess) return DEC_ERR_GPU;
-  job.dl_buf = -1;
-  if (download_ && band_nrows_ == 0) { const int rc = queue_download(job); if (rc < 0) return rc; }
+  job.dl_buf = -1; job.launch_idx = launched_;
   t_api_ += tk_api.ms();
   launched_++;
-  gpu_job_ = &job;
+  if (band_nrows_ > 0) gpu_job_ = &job; else gpu_q_.push_back(&job);
   return 0;
 }
 

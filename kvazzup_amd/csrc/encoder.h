@@ -119,16 +119,14 @@ class Encoder {
   EncFrame f_{};
   // Host pictures (kvz_api->encoder_encode, kvazaarfilter.cpp:435-438): a ring of packed device buffers filled by the copy engine on a
   // stream of its own -- picture t + 1 travels over PCIe while the kernels of picture t run -- and, for callers whose planes are not
-  // page-locked, a ring of pinned staging buffers (allocated on first use)
-  // (twelve: more than the pictures that can be in flight -- owf <= 8 plus the submitter's hand -- so a copy never has to wait in the copy
-  // engine's queue for its buffer's previous reader; a waiting copy holds up every copy queued behind it on that engine, the decoder's included)
+  // page-locked, a ring of pinned staging buffers (allocated on first use).  Twelve entries: more than the pictures that can be in flight
+  // (owf <= 8 plus the submitter's hand), so a copy never waits in the copy engine's queue for its buffer's previous reader.
   static constexpr int kInRing = 12;
   uint8_t *d_in_[kInRing] = {};          // packed input (device)
   uint8_t *h_in_[kInRing] = {};          // pinned host staging
-  hipStream_t stream_h2d_ = nullptr;
-  hipStream_t stream_rec_ = nullptr;     // download of reconstructions the caller asks for (encoder_encode's pic_out)
   hipEvent_t ev_h2d_[kInRing] = {}, ev_pad_[kInRing] = {}; bool pad_pending_[kInRing] = {}, h2d_pending_[kInRing] = {};
   long in_count_ = 0;
+  hipStream_t stream_rec_ = nullptr;     // download of reconstructions the caller asks for (encoder_encode's pic_out)
   // Per-picture working sets (padded source planes, level planes, CU arrays, per-CTU QP arrays, SAO parameters): kSets of them take turns, so the
   // host can queue kSets - 1 pictures' kernels ahead of the one the GPU is working on without waiting for a set to come free (with two sets
   // the input stage of picture t waited for the reconstruction of t - 2, and the calling thread with it: the main stream ran dry between pictures)

@@ -226,9 +226,7 @@ Encoder::~Encoder()
     if (sl.rec_done) hipEventDestroy(sl.rec_done);
   }
   if (in_done_) hipEventDestroy(in_done_);
-  if (stream_h2d_) hipStreamSynchronize(stream_h2d_);
   for (int k = 0; k < kInRing; k++) { hipFree(d_in_[k]); if (h_in_[k]) hipHostFree(h_in_[k]); if (ev_h2d_[k]) hipEventDestroy(ev_h2d_[k]); if (ev_pad_[k]) hipEventDestroy(ev_pad_[k]); }
-  stream_release(stream_h2d_, cfg_.device, 'H', 'n');
   stream_release(stream_rec_, cfg_.device, 'R', 'n');
   for (int c = 0; c < 3; c++) { for (int k = 0; k < kSets; k++) { hipFree(src_[k][c]); hipFree(coef_[k][c]); } for (int b = 0; b < 10; b++) hipFree(rec_[b][c]); }
   hipFree(vaq_act_); hipFree(vaq_sum_); hipFree(rc_state_);
@@ -271,13 +269,19 @@ void Encoder::get_kernel_times(double *ms, uint64_t *launches, bool reset)
 // owf == 0 that is the picture just submitted; with owf >= 1 it is the previous one, whose arithmetic
 // coding on the host then runs while the GPU works on the new picture.
 // Host picture in: the copy engine moves it into device buffer k = t mod kInRing on the upload stream while earlier pictures' kernels
-// run; the input stage of picture t (stream_in_) waits for that copy, the copy of picture t + kInRing for that input stage.  Nothing
-// here waits on the calling thread except a staging buffer coming free (callers without page-locked planes).
+// run; the input stage of picture t (stream_in_) waits for that copy.  The ring is longer than the pictures that can be in flight, so the
+// buffer's previous reader (the input stage of picture t - kInRing) has long finished and the copy command carries no dependency: the copy
+// engine takes it at once.  (A copy waiting inside the engine's queue holds up every copy behind it, the decoder's included; the input
+// kernel reading the host picture itself across PCIe -- tried -- slows the kernels running beside it 2-10x, scratch/pcie4.hip.)
+// Nothing here waits on the calling thread except a staging buffer coming free (callers without page-locked planes).
 bool Encoder::upload_and_submit(const uint8_t *y, const uint8_t *u, const uint8_t *v, bool pinned)
 {
   const size_t ny = (size_t)cfg_.width * cfg_.height, bytes = ny * 3 / 2;
   const int k = (int)(in_count_++ % kInRing);
-  if (!stream_h2d_) HIP_CHECK(stream_acquire(&stream_h2d_, cfg_.device, 'H', 'n'));
+  // The copy rides on the input stream itself, ahead of the picture's input kernel: a stream of its own would be one more stream than the
+  // device has hardware queues for (HIP spreads the streams of a priority level over four), and whichever stream it ended up sharing a
+  // queue with -- measured: the input stream behind the tokenizer's -- was serialised behind that stream's event waits.
+  hipStream_t stream_h2d_ = stream_in_;
   if (!d_in_[k]) {
     HIP_CHECK(hipMalloc(&d_in_[k], bytes));
     HIP_CHECK(hipEventCreateWithFlags(&ev_h2d_[k], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_pad_[k], hipEventDisableTiming));
@@ -289,10 +293,12 @@ bool Encoder::upload_and_submit(const uint8_t *y, const uint8_t *u, const uint8_
     memcpy(h_in_[k], y, ny); memcpy(h_in_[k] + ny, u, ny / 4); memcpy(h_in_[k] + ny + ny / 4, v, ny / 4);
     src = h_in_[k];
   }
-  if (pad_pending_[k]) { HIP_CHECK(hipStreamWaitEvent(stream_h2d_, ev_pad_[k], 0)); pad_pending_[k] = false; }      // d_in_[k]'s last reader
+  if (pad_pending_[k]) {                             // d_in_[k]'s last reader: done long ago, normally
+    if (hipEventQuery(ev_pad_[k]) != hipSuccess) HIP_CHECK(hipStreamWaitEvent(stream_h2d_, ev_pad_[k], 0));
+    pad_pending_[k] = false;
+  }
   HIP_CHECK(hipMemcpyAsync(d_in_[k], src, bytes, hipMemcpyHostToDevice, stream_h2d_));
-  HIP_CHECK(hipEventRecord(ev_h2d_[k], stream_h2d_)); h2d_pending_[k] = true;
-  HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_h2d_[k], 0));
+  HIP_CHECK(hipEventRecord(ev_h2d_[k], stream_h2d_)); h2d_pending_[k] = true;      // (for the staging buffer's next user)
   { Tick tk; if (!submit(d_in_[k], k)) return false; t_submit_ += tk.ms(); }
   in_pending_ = false;                               // (nobody but this ring reads d_in_[k])
   return true;

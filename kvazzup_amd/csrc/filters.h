@@ -88,6 +88,7 @@ class Filter {
   bool waitBufferedBelow(uint32_t n, int timeout_ms);     // sleeps until fewer than n inputs are buffered (harness: a paced source)
   uint64_t inputDiscarded() const { return inputDiscarded_; }
   uint64_t busyNs() const { return busyNs_; }             // time spent inside process() (harness statistics)
+  double avgQueue() const { return queueSamples_ ? (double)queueSum_ / queueSamples_ : 0.0; }   // inputs buffered, averaged over the arrivals (harness statistics: which filter is the slow one)
 
  protected:
   virtual void process() = 0;
@@ -111,7 +112,7 @@ class Filter {
   std::vector<std::function<void(std::unique_ptr<Data>)>> outDataCallbacks_;
   std::thread thread_;
   std::atomic<bool> running_{false}, threadRunning_{false};
-  uint64_t inputTaken_ = 0, inputDiscarded_ = 0;
+  uint64_t inputTaken_ = 0, inputDiscarded_ = 0, queueSum_ = 0, queueSamples_ = 0;
   std::atomic<uint64_t> busyNs_{0};
 };
 

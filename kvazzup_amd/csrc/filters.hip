@@ -62,6 +62,7 @@ void Filter::putInput(std::unique_ptr<Data> data)          // filter.cpp:151-222
   if (!data) return;
   std::lock_guard<std::mutex> l(bufferMutex_);
   ++inputTaken_;
+  queueSum_ += inBuffer_.size(); ++queueSamples_;
   inBuffer_.push_back(std::move(data));
   if (maxBufferSize_ != -1 && inBuffer_.size() >= (uint32_t)maxBufferSize_) {
     if (inBuffer_[0]->type == DT_HEVCVIDEO) {
@@ -741,6 +742,11 @@ KVZ_PUBLIC void uvgx_pipeline_busy_ms(void *pp, double *out3)
 {
   UvgxPipeline *p = (UvgxPipeline *)pp;
   out3[0] = p->enc->busyNs() * 1e-6; out3[1] = p->wire ? p->wire->busyNs() * 1e-6 : 0.0; out3[2] = p->dec ? p->dec->busyNs() * 1e-6 : 0.0;
+}
+KVZ_PUBLIC void uvgx_pipeline_avg_queue(void *pp, double *out3)
+{
+  UvgxPipeline *p = (UvgxPipeline *)pp;
+  out3[0] = p->enc->avgQueue(); out3[1] = p->wire ? p->wire->avgQueue() : 0.0; out3[2] = p->dec ? p->dec->avgQueue() : 0.0;
 }
 KVZ_PUBLIC void *uvgx_pipeline_encoder(void *pp) { return ((UvgxPipeline *)pp)->enc->encoder(); }
 KVZ_PUBLIC void *uvgx_pipeline_decoder(void *pp) { UvgxPipeline *p = (UvgxPipeline *)pp; return p->dec ? p->dec->handle() : nullptr; }

@@ -226,7 +226,7 @@ kvz_picture *picture_alloc_csp(enum kvz_chroma_format csp, int32_t width, int32_
     PinnedSet &ps = pinned_set(); std::lock_guard<std::mutex> l(ps.m);
     for (size_t i = 0; i < ps.spare.size(); i++) if (ps.spare[i].first == ny) { pin = ps.spare[i].second; ps.spare.erase(ps.spare.begin() + (long)i); break; }
   }
-  if (pin || (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipHostMalloc(&pin, ny * 3 / 2 + 64, hipHostMallocPortable) == hipSuccess && pin)) {
+  if (pin || (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipHostMalloc(&pin, ny * 3 / 2 + 64, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess && pin)) {
     p->fulldata_buf = (kvz_pixel *)pin;
     PinnedSet &ps = pinned_set(); std::lock_guard<std::mutex> l(ps.m); ps.s.insert(pin);
   } else {

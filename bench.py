@@ -38,7 +38,12 @@ WORKLOADS = {
     # configs[4]: ONE 8K stream, its 8 tile rows split over the ranks (strong scaling; see tilesplit_main)
     "8k-tilesplit": dict(w=7680, h=4320, name="4320p-yuv420-ultrafast-p64-qp32-encode-tile-row-split", cfg_index=5),
 }
-HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+# custom parameters of the host-boundary legs (uvgComm's INI list "parameters", kvazaarfilter.cpp:351-371): the reconstruction is not downloaded
+# (uvgComm frees it unread, :476) and encoder_encode(NULL) only returns pictures that are finished (the loop at :440-448 then keeps video/OWF
+# pictures in flight instead of emptying the pipeline after every picture) -- INTEGRATION.md
+HOST_CUSTOM = (("recon-output", "0"), ("null-input", "poll"))
+HBM_PEAK_GBS = 8000.0          # replaced by the device's own figure in main(); this is the guide's (MI355X_MICROARCH.md) and the fallback
+HBM_PEAK_SOURCE = "MI355X_MICROARCH.md (the runtime reported no memory clock / bus width)"          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
 def algorithmic_bytes(kernel, cw, ch, me_range):
@@ -172,7 +177,8 @@ def launch_ranks(n, argv):
 
 
 def init_dist(world, local_rank):
-    """device of this rank and the process group that brackets the timed region (no collective on the data path)"""
+    """device of this rank and the process group that brackets the timed region (no collective on the data path) -- tile-row split
+    workload: device tensors travel between the ranks, so this one runs on torch / RCCL"""
     import torch
     import torch.distributed as dist
     ndev = torch.cuda.device_count()
@@ -203,6 +209,77 @@ def barrier_max(dist, backend, dev, torch, value=None):
     tt = torch.tensor([value], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return float(tt.item())
+
+
+class StreamRanks:
+    """The stream workloads (one independent stream per rank, BASELINE configs[1..3]): nothing travels between the ranks, so the only
+    thing the process group does is bracket the timed region -- a barrier and a max over ranks, on CPU tensors over gloo.  torch.cuda is
+    never initialised here: the library is loaded FIRST and runs on the system's HIP runtime; the copy of the runtime that torch ships
+    stays dormant (with torch.cuda initialised this library would run on torch's copy, whose device-to-host copies are blit kernels that
+    slow every kernel beside them -- DESIGN.md section 6).  With one rank torch is not imported at all."""
+
+    def __init__(self, world, local_rank):
+        from kvazzup_amd import _native
+        self.lib = _native.load_library()                     # before any import of torch
+        ndev = self.lib.kvzx_device_count()
+        if ndev < 1:
+            raise RuntimeError("no GPU visible: this library has no CPU fallback")
+        self.dev_index = local_rank % ndev
+        self.backend, self.dist, self.torch = None, None, None
+        if world > 1:
+            import datetime
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+            self.backend, self.dist, self.torch = "gloo", dist, torch
+
+    def sync(self, value=None):
+        if self.backend is None:
+            return value
+        if value is None:
+            self.dist.barrier()
+            return None
+        tt = self.torch.tensor([value], dtype=self.torch.float64)
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+class DeviceClip:
+    """the synthetic clip in device memory (kvzx_harness_*: generated on the GPU, no tensor library)"""
+
+    def __init__(self, lib, dev_index, seed, w, h, frames):
+        import ctypes as C
+        lib.kvzx_harness_alloc.restype = C.c_void_p
+        lib.kvzx_harness_alloc.argtypes = [C.c_int, C.c_size_t]
+        lib.kvzx_harness_free.argtypes = [C.c_void_p]
+        lib.kvzx_harness_synth_frame.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int]
+        lib.kvzx_harness_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        self.lib, self.dev, self.w, self.h, self.n = lib, dev_index, w, h, w * h * 3 // 2
+        self.ptr = []
+        for t in range(frames):
+            p = lib.kvzx_harness_alloc(dev_index, self.n)
+            if not p or not lib.kvzx_harness_synth_frame(p, 0, seed & 0xFFFFFFFF, w, h, t):
+                raise RuntimeError("device clip: allocation or synthesis failed")
+            self.ptr.append(p)
+        if not lib.kvzx_harness_sync(dev_index):
+            raise RuntimeError("device clip: synthesis failed")
+
+    def host(self, t):
+        import numpy as np
+        a = np.empty(self.n, dtype=np.uint8)
+        if not self.lib.kvzx_harness_download(a.ctypes.data, self.ptr[t], self.n):
+            raise RuntimeError("device clip: download failed")
+        return a
+
+    def close(self):
+        for p in self.ptr:
+            self.lib.kvzx_harness_free(p)
+        self.ptr = []
 
 
 def tilesplit_main(args):
@@ -314,16 +391,16 @@ def tilesplit_decode(args, aus, h, tile_rows, rank, world, torch, dist, dev, dev
             "ms_per_picture": round(elapsed / done * 1e3, 4), "exchange": "2 blocks of 8 x W bytes per internal boundary and picture, around the deblocking"}
 
 
-def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync, quality, host_io=False, extra_custom=(), extra_settings=None):
+def run_stream(args, wl, steps, warmup, ranks, rank, world, quality, host_io=False, extra_custom=(), extra_settings=None):
     """K = steps intra periods of one stream through KvazaarFilter' -> WireAdapter -> OpenHEVCFilter' on this rank's GPU, timed
     args.repeats times (median of 3 runs); every repetition starts and ends on an empty, flushed pipeline.
     host_io: the reference's own boundary -- pictures enter as HOST I420 through kvz_api->encoder_encode(kvz_picture*) (the filter's
     memcpy into the kvz_picture included, kvazaarfilter.cpp:410-438) and leave through libOpenHevcGetOutput + the filter's row copy into
     host memory (openhevcfilter.cpp:192-239): PCIe both ways inside the timed region.
     Returns a dict of measurements.  sync(value=None) = barrier / max over ranks."""
-    from kvazzup_amd import synth
     from kvazzup_amd.pipeline import Pipeline
     import ctypes as C
+    dev_index, sync = ranks.dev_index, ranks.sync
     w, h = wl["w"], wl["h"]
     # pictures parsed concurrently (video/OPENHEVC_threads): the ring has to cover the parse of an intra picture -- ~10 ms on one core at
     # 4K, where twelve pictures pass in 6 ms (measured: 2090 frames/s with 12, 2390 with 24; 1080p, 3.5 ms per intra picture: 5900-6170 / 6500-6700)
@@ -334,17 +411,15 @@ def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync
         os.environ["KVAZZUP_AMD_ENTROPY_THREADS"] = str(max(2, min(16, int(budget * 0.4))))
         os.environ["KVAZZUP_AMD_PARSE_THREADS"] = str(max(1, min(16, int(budget * 0.4))))       # (row-parallel parser of the synchronous decoder)
     seed = 0x5EED0000 + wl["cfg_index"] + 16 * rank
-    # synthetic clip generated directly in HBM (inputs resident before the timed region).  KVAZZUP_BENCH_HOST_SYNTH=1 (counter
-    # passes: rocprofv3 --pmc crashes inside torch's elementwise kernels on this stack) makes the same clip with numpy and uploads
-    # it -- one intra period of it, cycled.
+    # synthetic clip generated directly in HBM (inputs resident before the timed region)
     nclip = CLIP_FRAMES
-    if os.environ.get("KVAZZUP_BENCH_HOST_SYNTH"):
-        nclip = PERIOD
-        clip = [torch.from_numpy(synth.frame(synth.MOVING, seed, w, h, t)).to(dev) for t in range(nclip)]
-    else:
-        clip = [synth.frame_torch(synth.MOVING, seed, w, h, t, dev) for t in range(nclip)]
-    torch.cuda.synchronize()
-    host_clip = [c.cpu().numpy() for c in clip] if host_io else None       # pageable host memory, as a camera filter's frames are
+    dclip = DeviceClip(ranks.lib, dev_index, seed, w, h, nclip)
+    clip = dclip.ptr
+    host_clip = [dclip.host(t) for t in range(nclip)] if host_io else None       # pageable host memory, as a camera filter's frames are
+
+    def device_sync():
+        if not ranks.lib.kvzx_harness_sync(dev_index):
+            raise RuntimeError("device synchronisation failed")
 
     def make(keep, download):
         st = {"video/QP": 32, "video/Intra": PERIOD, "video/VPS": 1, "uvgx/gpu": dev_index, "uvgx/decoderDownload": int(download),
@@ -367,7 +442,7 @@ def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync
         encoder filter's input buffer short of its overflow threshold (a uvgComm filter drops inputs at 10 buffered, filter.cpp:151-222)."""
         last = pl.pushed + npic
         while pl.pushed < last:
-            ok = pl.push_host_paced(host_clip[pl.pushed % nclip], 6, 120000) if host_io else pl.push_device_paced(clip[pl.pushed % nclip].data_ptr(), 6, 120000)
+            ok = pl.push_host_paced(host_clip[pl.pushed % nclip], 6, 120000) if host_io else pl.push_device_paced(clip[pl.pushed % nclip], 6, 120000)
             if not ok:
                 raise RuntimeError("pipeline stalled")
         pl.flush()
@@ -404,7 +479,7 @@ def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync
         _sampler = C.CDLL(None)
     reps = []
     for rep in range(max(1, args.repeats)):
-        torch.cuda.synchronize()                               # the pipeline is empty: everything pushed so far has been decoded
+        device_sync()                                          # the pipeline is empty: everything pushed so far has been decoded
         sync()
         cpu0 = time.process_time()
         thr0 = _throttled_us()
@@ -412,7 +487,7 @@ def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync
             _sampler.cpu_sampler_begin()
         t0 = time.perf_counter()
         run(steps * PERIOD)
-        torch.cuda.synchronize()
+        device_sync()
         sync()
         el = time.perf_counter() - t0
         if _sampler is not None:
@@ -448,7 +523,7 @@ def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync
         import numpy as np
         q = make(True, True)
         for t in range(PERIOD):
-            if not q.push_device_paced(clip[t].data_ptr(), 6, 120000):
+            if not q.push_device_paced(clip[t], 6, 120000):
                 raise RuntimeError("quality pass stalled")
         q.flush()
         if not q.wait(PERIOD, 120000):
@@ -456,12 +531,12 @@ def run_stream(args, wl, steps, warmup, torch, dev, dev_index, rank, world, sync
         ps = []
         for t in range(PERIOD):
             d = q.pop_decoded()
-            src = clip[t][:w * h].to(torch.int32)
-            dec = torch.from_numpy(np.ascontiguousarray(d["i420"][:w * h])).to(dev).to(torch.int32)
-            mse = float(((src - dec) ** 2).to(torch.float64).mean().item())
+            src = dclip.host(t)[:w * h].astype(np.int32)
+            mse = float(((src - d["i420"][:w * h].astype(np.int32)) ** 2).mean(dtype=np.float64))
             ps.append(99.0 if mse == 0 else 10.0 * float(np.log10(255.0 * 255.0 / mse)))
         q.close()
         out["psnr_y"] = round(sum(ps) / len(ps), 3)
+    dclip.close()
     return out
 
 
@@ -496,7 +571,7 @@ def roofline_of(m, steps, me_range, workload_key):
             break
         except Exception:
             pass
-    roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "peak_source": HBM_PEAK_SOURCE, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(avg_s * 1e6, 2)}
     kernels_us = {k: round(v[0] / v[1] * 1e3, 2) for k, v in kt.items() if v[1]}
@@ -546,26 +621,33 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if os.environ.get("KVAZZUP_BENCH_LIB_FIRST"):
-        from kvazzup_amd import _native
-        _native.load_library()
-    torch, dist, dev, dev_index, backend = init_dist(world, local_rank)
-
-    def sync(value=None):
-        return barrier_max(dist, backend, dev, torch, value)
+    ranks = StreamRanks(world, local_rank)
+    backend = ranks.backend
+    # HBM peak: from the device (hipDeviceProp: bus width x memory clock x 4, harness_kernels.hip); the guide's 8 TB/s only when the runtime does not report them
+    global HBM_PEAK_GBS, HBM_PEAK_SOURCE
+    import ctypes as C
+    ranks.lib.kvzx_harness_hbm_peak_gbs.restype = C.c_double
+    ranks.lib.kvzx_harness_hbm_peak_gbs.argtypes = [C.c_int]
+    name, cus, clk, mclk, bus = C.create_string_buffer(128), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    ranks.lib.kvzx_harness_device_info(ranks.dev_index, name, 128, C.byref(cus), C.byref(clk), C.byref(mclk), C.byref(bus))
+    pk = ranks.lib.kvzx_harness_hbm_peak_gbs(ranks.dev_index)
+    if pk > 0:
+        HBM_PEAK_GBS = round(pk, 1)
+        HBM_PEAK_SOURCE = "hipDeviceProp of %s: memoryBusWidth %d bit x memoryClockRate %d MHz x 4 transfers per clock (HBM3E) / 8" % (name.value.decode(), bus.value, mclk.value)
+    device_info = {"name": name.value.decode(), "compute_units": cus.value, "clock_mhz": clk.value, "memory_clock_mhz": mclk.value, "memory_bus_bits": bus.value}
 
     wl = WORKLOADS[args.workload]
     w, h = wl["w"], wl["h"]
     resident = (("input-hold", "1"),)       # the clip's device pictures stay untouched: encode_device returns without waiting for its input stage
     if args.host_io:
         args.no_host_boundary = True
-        m = run_stream(args, wl, args.steps, args.warmup, torch, dev, dev_index, rank, world, sync, quality=False, host_io=True, extra_custom=(("recon-output", "0"),))
+        m = run_stream(args, wl, args.steps, args.warmup, ranks, rank, world, quality=False, host_io=True, extra_custom=HOST_CUSTOM)
     else:
-        m = run_stream(args, wl, args.steps, args.warmup, torch, dev, dev_index, rank, world, sync, quality=(rank == 0), extra_custom=resident)
+        m = run_stream(args, wl, args.steps, args.warmup, ranks, rank, world, quality=(rank == 0), extra_custom=resident)
     def host_leg(wl_, steps_, warm_, resident):
         """the same steps through the reference's own boundary (run_stream host_io); a dict for the JSON line"""
         try:
-            hb = run_stream(args, wl_, steps_, warm_, torch, dev, dev_index, rank, world, sync, quality=False, host_io=True, extra_custom=(("recon-output", "0"),))
+            hb = run_stream(args, wl_, steps_, warm_, ranks, rank, world, quality=False, host_io=True, extra_custom=HOST_CUSTOM)
         except Exception as e:
             return {"error": str(e)}
         fps_h = world * hb["pictures"] / hb["elapsed"]
@@ -574,8 +656,8 @@ def main():
                 "h2d_GBps": round(fps_h * pic / 1e9 / world, 2), "d2h_GBps": round(fps_h * pic / 1e9 / world, 2),
                 "host_cpu_cores_busy": round(hb["host_cores"], 2),
                 "filter_busy_ms_per_picture": {"KvazaarFilter": hb["busy"][0], "WireAdapter": hb["busy"][1], "OpenHEVCFilter": hb["busy"][2]},
-                "boundary": "host I420 -> KvazaarFilter' (memcpy into a page-locked kvz_picture, kvz_api->encoder_encode; recon-output=0: uvgComm frees the "
-                            "reconstruction unread, kvazaarfilter.cpp:476) -> access units -> OpenHEVCFilter' (libOpenHevcDecode / GetOutput, row copy into host "
+                "boundary": "host I420 -> KvazaarFilter' (memcpy into a page-locked kvz_picture, kvz_api->encoder_encode; custom parameters recon-output=0: uvgComm frees the "
+                            "reconstruction unread, kvazaarfilter.cpp:476; null-input=poll: the loop at :440-448 collects finished pictures without emptying the pipeline) -> access units -> OpenHEVCFilter' (libOpenHevcDecode / GetOutput, row copy into host "
                             "memory, openhevcfilter.cpp:192-239); uploads and downloads on their own HIP streams beside the kernels"}
 
     hostb = None
@@ -587,7 +669,7 @@ def main():
         # (a second pipeline in this process inherits the first one's HIP streams -- csrc/stream_pool.h -- and with them its hardware-queue
         # layout; before that pool the 4K leg ran 15-20 % slower here than in a process of its own)
         try:
-            sec = run_stream(args, WORKLOADS["4k"], max(1, min(args.steps, args.secondary_steps)), min(2, max(1, args.warmup)), torch, dev, dev_index, rank, world, sync, quality=True, extra_custom=resident)
+            sec = run_stream(args, WORKLOADS["4k"], max(1, min(args.steps, args.secondary_steps)), min(2, max(1, args.warmup)), ranks, rank, world, quality=True, extra_custom=resident)
             if not args.no_host_boundary:
                 ssteps_ = max(1, min(args.steps, args.secondary_steps))
                 sec_host = host_leg(WORKLOADS["4k"], ssteps_, 1, sec["pictures"] / sec["elapsed"])
@@ -616,6 +698,7 @@ def main():
                        "output": "Annex-B AU on host + decoded I420 in " + ("host memory" if args.host_io else "HBM"),
                        "repeats": args.repeats, "runs_fps": m["runs_fps"], "value_is": "median run of `repeats` (BASELINE.md timing rule)"},
             "host_boundary": hostb,
+            "device": device_info,
             "roofline": roof,
             "kernels_us": kernels_us,
             "filter_busy_ms_per_picture": {"KvazaarFilter": m["busy"][0], "WireAdapter": m["busy"][1], "OpenHEVCFilter": m["busy"][2]},
@@ -648,8 +731,7 @@ def main():
             except Exception as e:       # the checker library is test infrastructure; report, do not fail the bench
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": "failed: %s" % e}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -42,6 +42,7 @@ KVZ_PUBLIC void kvzx_encoder_set_profiling(kvz_encoder *enc, int every);   /* 0 
 KVZ_PUBLIC int kvzx_encoder_kernel_times(kvz_encoder *enc, double *ms, uint64_t *launches, int reset);
 KVZ_PUBLIC const char *kvzx_encoder_kernel_name(int id);       /* NULL past the last id */
 KVZ_PUBLIC uint64_t kvzx_encoder_last_bins(kvz_encoder *enc);  /* CABAC bins of the last picture */
+KVZ_PUBLIC int kvzx_encoder_pending(kvz_encoder *enc);         /* pictures handed in whose access unit has not been returned yet */
 
 /* ---- decoder ---- */
 /* Decode one NAL unit whose OUTPUT is wanted in device memory: like libOpenHevcDecode. */
@@ -149,6 +150,22 @@ KVZ_PUBLIC void uvgx_pipeline_avg_queue(void *p, double *out3); /* inputs found 
 KVZ_PUBLIC void *uvgx_pipeline_encoder(void *p);     /* kvz_encoder* of the KvazaarFilter */
 KVZ_PUBLIC void *uvgx_pipeline_decoder(void *p);     /* OpenHevc_Handle of the OpenHEVCFilter (NULL without loop-back) */
 KVZ_PUBLIC void uvgx_pipeline_destroy(void *p);
+
+/* ---- measurement harness (kvazzup_amd/csrc/harness_kernels.hip): the synthetic clip of SURVEY.md 8(d) generated in device memory, the buffers to
+ * keep it in, a luma error sum -- so that bench.py needs no tensor library in the process (one that ships its own HIP runtime would replace the
+ * system's for this library too).  Nothing of the codec. */
+KVZ_PUBLIC void *kvzx_harness_alloc(int device, size_t bytes);           /* device memory; NULL on failure */
+KVZ_PUBLIC void kvzx_harness_free(void *p);
+KVZ_PUBLIC int kvzx_harness_sync(int device);                            /* hipDeviceSynchronize */
+KVZ_PUBLIC int kvzx_harness_download(void *host, const void *dev, size_t bytes);
+KVZ_PUBLIC int kvzx_harness_upload(void *dev, const void *host, size_t bytes);
+/* uvgx-synth-v1 (kind 0 moving objects, 1 flat, 2 noise; kvazzup_amd/synth.py is the statement) as packed I420 into d_i420 (w*h*3/2 bytes) */
+KVZ_PUBLIC int kvzx_harness_synth_frame(void *d_i420, int kind, uint32_t seed, int w, int h, int t);
+/* sum of squared differences of the luma planes of a packed picture (pitch w) and a pitched one; < 0 on failure */
+KVZ_PUBLIC double kvzx_harness_luma_sse(const void *d_a, const void *d_b, int w, int h, int pitch_b);
+/* HBM peak in GB/s from the device properties (2 x memory clock x bus width / 8); 0 when the runtime does not report them */
+KVZ_PUBLIC double kvzx_harness_hbm_peak_gbs(int device);
+KVZ_PUBLIC int kvzx_harness_device_info(int device, char *name, int name_cap, int *cus, int *clock_mhz, int *mem_clock_mhz, int *bus_bits);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,7 @@ class KvzConfig(C.Structure):
                 ("intra_bits", C.c_int32), ("me_max_steps", C.c_int32), ("fast_residual_cost_limit", C.c_int32),
                 ("pu_depth_inter_min", C.c_int32), ("pu_depth_inter_max", C.c_int32), ("pu_depth_intra_min", C.c_int32), ("pu_depth_intra_max", C.c_int32),
                 ("me_range", C.c_int32), ("gpu_device", C.c_int32), ("recon_output", C.c_int32), ("intra_satd", C.c_int32),
-                ("band_row0", C.c_int32), ("band_rows", C.c_int32), ("gpu_entropy", C.c_int32)]
+                ("band_row0", C.c_int32), ("band_rows", C.c_int32), ("input_hold", C.c_int32), ("null_input_poll", C.c_int32), ("gpu_entropy", C.c_int32)]
 
 
 class KvzRoi(C.Structure):
@@ -101,7 +101,7 @@ class OpenHevcFrame(C.Structure):
 
 ENCODER_EXPORTS = ["kvz_api_get", "kvzx_version", "kvzx_rgb32_to_yuv420", "kvzx_rgb32_to_yuv420_device", "kvzx_yuv420_to_rgb32", "kvzx_yuv420_to_rgb32_device", "uvgx_pipeline_flush", "kvzx_device_count", "kvzx_encoder_encode_device", "kvzx_encoder_encode_host",
                    "kvzx_encoder_coded_size", "kvzx_encoder_download_recon", "kvzx_encoder_recon_device", "kvzx_encoder_debug_copy",
-                   "kvzx_encoder_set_profiling", "kvzx_encoder_kernel_times", "kvzx_encoder_kernel_name", "kvzx_encoder_last_bins"]
+                   "kvzx_encoder_set_profiling", "kvzx_encoder_kernel_times", "kvzx_encoder_kernel_name", "kvzx_encoder_last_bins", "kvzx_encoder_pending"]
 DECODER_EXPORTS = ["libOpenHevcInit", "libOpenHevcStartDecoder", "libOpenHevcDecode", "libOpenHevcGetPictureInfo",
                    "libOpenHevcGetPictureSize2", "libOpenHevcGetOutput", "libOpenHevcGetOutputCpy", "libOpenHevcSetCheckMD5",
                    "libOpenHevcSetDebugMode", "libOpenHevcSetTemporalLayer_id", "libOpenHevcSetNoCropping", "libOpenHevcSetActiveDecoders",

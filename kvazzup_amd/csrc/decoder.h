@@ -210,7 +210,7 @@ class Decoder {
   int alloc_slot();
 
   int device_; bool started_ = false;
-  hipStream_t stream_up_ = nullptr; hipEvent_t up_done_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // upload of the next picture's input block beside the current picture's kernels
+  hipStream_t stream_up_ = nullptr; hipEvent_t up_done_[9] = {};   // upload of the next picture's input block beside the current picture's kernels
   hipStream_t stream_ = nullptr, stream_dl_ = nullptr;       // reconstruction; download of finished pictures (behind the picture's event, beside the next picture's kernels)
   std::shared_ptr<const DecSps> sps_[16]; DecPps pps_[64]; uint32_t vps_fps_num_ = 0, vps_fps_den_ = 0;
   int w_ = 0, h_ = 0, pw_ = 0, ph_ = 0;
@@ -232,7 +232,7 @@ class Decoder {
   // Frame-threaded mode keeps up to gpu_depth_ pictures queued on the GPU (launched, not yet completed): a picture's way through upload, kernels
   // and the copy back to the host is ~0.2 ms at 1080p, and with only one picture launched ahead of the one being waited for the calling thread
   // sat out most of that for every picture.  The output lag stays `frame_threads` pictures: the parse ring gives up what the GPU queue takes.
-  static constexpr int kMaxGpuDepth = 4;
+  static constexpr int kMaxGpuDepth = 8;
   int gpu_depth_ = 1; std::deque<PicJob *> gpu_q_;
   uint8_t *d_in_[kMaxGpuDepth + 1] = {}; size_t d_in_cap_[kMaxGpuDepth + 1] = {};   // device copies of PicJob::h_in: the pictures in flight take turns
   int16_t *resid_[3] = {nullptr, nullptr, nullptr};         // intra residuals between k_dec_intra_resid and k_dec_intra
@@ -241,7 +241,7 @@ class Decoder {
   // download mode: page-locked output buffers take turns -- one is what libOpenHevcGetOutput last handed out (valid until the next
   // decode call, openhevcfilter.cpp:218-229 copies at once), one receives the picture whose kernels are running, queued behind them on
   // the download stream at launch, so the copy over PCIe overlaps the next picture's kernels instead of stalling the calling thread
-  static constexpr int kOutRing = 6;      // (pictures queued on the GPU + the one handed out + the one being launched)
+  static constexpr int kOutRing = 10;     // (pictures queued on the GPU + the one handed out + the one being launched)
   uint8_t *h_out_[kOutRing] = {}; size_t h_out_cap_ = 0;
   void describe_output(const PicJob &job, DecodedPicture &o, int buf) const;
   int queue_download(PicJob &job);

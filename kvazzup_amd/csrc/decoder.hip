@@ -802,6 +802,7 @@ Decoder::~Decoder()
   free_buffers();
   for (auto &o : ready_q_) if (o.dev) hipFree(o.dev);
   if (cur_owned_.dev) hipFree(cur_owned_.dev);
+  if (stream_dl_ != stream_up_) stream_release(stream_dl_, device_, 'L', 'l');
   stream_release(stream_up_, device_, 'U', prio_up_);
   for (auto &e : up_done_) if (e) hipEventDestroy(e);
   if (h_err_) hipHostFree(h_err_);
@@ -831,6 +832,7 @@ bool Decoder::start(std::string *error)
   // level over four hardware queues; with encoder and decoder in one process every further stream shares a queue with one that matters.
   HIP_TRY(stream_acquire(&stream_up_, device_, 'U', prio_up_));
   stream_dl_ = stream_up_;
+  if (const char *e = getenv("KVAZZUP_AMD_DL")) if (!strcmp(e, "own")) HIP_TRY(stream_acquire(&stream_dl_, device_, 'L', 'l'));   // experiment: downloads on a stream of their own at the lowest priority level (its own pool of hardware queues)
   for (auto &e : up_done_) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   // the kernels' error word (a wavefront that gave up waiting ORs a flag in) lives in host memory the device writes straight into, like the
   // encoder's: looked at when a picture completes, no copy (a copy queued on the download stream waited behind the pictures' own downloads)
@@ -892,7 +894,7 @@ bool Decoder::ensure_buffers(int w, int h)
   free_buffers();
   if (jobs_.empty()) {
     const char *e = getenv("KVAZZUP_AMD_DEC_GPU_DEPTH");
-    gpu_depth_ = e ? atoi(e) : (frame_threads_ >= 4 ? 3 : 1);
+    gpu_depth_ = e ? atoi(e) : (frame_threads_ >= 4 ? (frame_threads_ >= 24 ? 8 : (frame_threads_ >= 12 ? 4 : 3)) : 1);      // (an intra picture's chain is ~1.5 ms at 1080p: ten picture intervals)
     if (gpu_depth_ > kMaxGpuDepth) gpu_depth_ = kMaxGpuDepth;
     if (gpu_depth_ > frame_threads_ - 1) gpu_depth_ = frame_threads_ - 1;
     if (gpu_depth_ < 1 || band_nrows_ > 0) gpu_depth_ = 1;
@@ -1465,15 +1467,19 @@ int Decoder::finish_oldest()
     if (job.parse_ms > t_parse_max_) t_parse_max_ = job.parse_ms;
     // the next picture's kernels are queued BEFORE an earlier picture is waited for: the GPU goes from one to the other without
     // this thread's launch latency in between
+    tl("dlaunch0", job.pts);
     rc_launch = job.rc < 0 ? job.rc : launch_gpu(job);
+    tl("dlaunch1", job.pts);
     launched = rc_launch >= 0;
   }
   int produced = 0;
   { const int rc = start_ready_downloads(); if (rc < 0) return rc; }
+  tl("ddl", 0);
   // frame-threaded mode: gpu_depth_ pictures stay queued on the GPU; a call that launches nothing (end of sequence / drain) takes one out
   if (!gpu_q_.empty() && (!launched || (int)gpu_q_.size() > gpu_depth_)) {
     PicJob *j = gpu_q_.front(); gpu_q_.pop_front();
     const int rc = complete_gpu(*j);
+    tl("dcomplete", j->pts);
     if (rc < 0) return rc;
     produced = 1;
   }

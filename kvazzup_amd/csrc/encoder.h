@@ -72,6 +72,8 @@ class Encoder {
   bool encode_device(const uint8_t *d_i420, EncodedPicture *out);
   // owf >= 1: outputs the picture still in flight, if any (kvz_api encoder_encode with pic_in == NULL)
   bool flush(EncodedPicture *out);
+  // like flush, but never waits: outputs the oldest picture in flight only if it has already been finished
+  bool poll(EncodedPicture *out);
   // delta-QP map for the following pictures (kvz_picture.roi, kvazaarfilter.cpp:423-431): w x h int8 cells spread uniformly over
   // the picture, clamped to [-12, 12]; w == 0 removes it.  Needs cfg.qp_in_cu.  Statement: roi_targets() in oracle/hevc_enc.c.
   void set_roi(int w, int h, const int8_t *map);
@@ -124,6 +126,7 @@ class Encoder {
   static constexpr int kInRing = 12;
   uint8_t *d_in_[kInRing] = {};          // packed input (device)
   uint8_t *h_in_[kInRing] = {};          // pinned host staging
+  hipStream_t stream_h2d_ = nullptr;
   hipEvent_t ev_h2d_[kInRing] = {}, ev_pad_[kInRing] = {}; bool pad_pending_[kInRing] = {}, h2d_pending_[kInRing] = {};
   long in_count_ = 0;
   hipStream_t stream_rec_ = nullptr;     // download of reconstructions the caller asks for (encoder_encode's pic_out)
@@ -181,7 +184,7 @@ class Encoder {
     uint8_t *h_out = nullptr, *d_out = nullptr; uint32_t *h_sub = nullptr, *d_sub = nullptr;   // host-mapped: substream bytes; [3][nsub] offset, length, bins
     hipStream_t ent_stream = nullptr; hipEvent_t tok_ev = nullptr; uint32_t gen = 0;
     hipEvent_t done = nullptr, rec_done = nullptr;       // tokens / substreams delivered (stream_tok_ / ent_stream) / reconstruction final (stream_)
-    int poc = 0, rec_idx = 0, set = 0, qp = 0; bool intra = false, write_ps = false;
+    int poc = 0, rec_idx = 0, set = 0, qp = 0; bool intra = false, write_ps = false; long pic_idx = 0;
     std::vector<EvPair> ev; size_t ev_used = 0;
     EncodedPicture result; bool ready = false, ok = true;   // owf >= 2: filled by the background thread
   };

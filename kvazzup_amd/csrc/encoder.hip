@@ -226,6 +226,7 @@ Encoder::~Encoder()
     if (sl.rec_done) hipEventDestroy(sl.rec_done);
   }
   if (in_done_) hipEventDestroy(in_done_);
+  if (stream_h2d_ && stream_h2d_ != stream_in_) stream_release(stream_h2d_, cfg_.device, 'H', 'l');
   for (int k = 0; k < kInRing; k++) { hipFree(d_in_[k]); if (h_in_[k]) hipHostFree(h_in_[k]); if (ev_h2d_[k]) hipEventDestroy(ev_h2d_[k]); if (ev_pad_[k]) hipEventDestroy(ev_pad_[k]); }
   stream_release(stream_rec_, cfg_.device, 'R', 'n');
   for (int c = 0; c < 3; c++) { for (int k = 0; k < kSets; k++) { hipFree(src_[k][c]); hipFree(coef_[k][c]); } for (int b = 0; b < 10; b++) hipFree(rec_[b][c]); }
@@ -278,10 +279,13 @@ bool Encoder::upload_and_submit(const uint8_t *y, const uint8_t *u, const uint8_
 {
   const size_t ny = (size_t)cfg_.width * cfg_.height, bytes = ny * 3 / 2;
   const int k = (int)(in_count_++ % kInRing);
-  // The copy rides on the input stream itself, ahead of the picture's input kernel: a stream of its own would be one more stream than the
-  // device has hardware queues for (HIP spreads the streams of a priority level over four), and whichever stream it ended up sharing a
-  // queue with -- measured: the input stream behind the tokenizer's -- was serialised behind that stream's event waits.
-  hipStream_t stream_h2d_ = stream_in_;
+  // The copy rides on the input stream itself, ahead of the picture's input kernel.  HIP spreads the streams of one priority level over four
+  // hardware queues, and at the default level those are taken (tokenizer, input, decoder, decoder transfers): a fifth stream there shares a
+  // queue with one of them and is serialised behind that stream's event waits (measured: the input stream behind the tokenizer's, 3700 instead
+  // of 5200 frames/s at 1080p); a stream at the lowest level (KVAZZUP_AMD_H2D=own) has a queue to itself and measured no better for the
+  // encoder alone, worse with the decoder beside it.
+  static const bool h2d_on_in = [] { const char *e = getenv("KVAZZUP_AMD_H2D"); return !e || strcmp(e, "own"); }();
+  if (!stream_h2d_) { if (h2d_on_in) stream_h2d_ = stream_in_; else HIP_CHECK(stream_acquire(&stream_h2d_, cfg_.device, 'H', 'l')); }
   if (!d_in_[k]) {
     HIP_CHECK(hipMalloc(&d_in_[k], bytes));
     HIP_CHECK(hipEventCreateWithFlags(&ev_h2d_[k], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_pad_[k], hipEventDisableTiming));
@@ -298,7 +302,8 @@ bool Encoder::upload_and_submit(const uint8_t *y, const uint8_t *u, const uint8_
     pad_pending_[k] = false;
   }
   HIP_CHECK(hipMemcpyAsync(d_in_[k], src, bytes, hipMemcpyHostToDevice, stream_h2d_));
-  HIP_CHECK(hipEventRecord(ev_h2d_[k], stream_h2d_)); h2d_pending_[k] = true;      // (for the staging buffer's next user)
+  HIP_CHECK(hipEventRecord(ev_h2d_[k], stream_h2d_)); h2d_pending_[k] = true;
+  if (stream_h2d_ != stream_in_) HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_h2d_[k], 0));
   { Tick tk; if (!submit(d_in_[k], k)) return false; t_submit_ += tk.ms(); }
   in_pending_ = false;                               // (nobody but this ring reads d_in_[k])
   return true;
@@ -338,6 +343,7 @@ bool Encoder::encode_device(const uint8_t *d_i420, EncodedPicture *out)
 // owf >= 2: hand the picture to the submitter thread, then finish the oldest picture in flight if the pipeline is full
 bool Encoder::enqueue(const uint8_t *src, bool host, EncodedPicture *out)
 {
+  tl("enq", accepted_);
   SubmitJob j; j.src = src; j.host = host; j.roi = roi_; j.roi_w = roi_w_; j.roi_h = roi_h_; j.slot = (int)(accepted_ % nslots_);
   { std::lock_guard<std::mutex> l(bm_); slot_[j.slot].ready = false; slot_[j.slot].ok = true; }
   accepted_++;
@@ -359,10 +365,12 @@ void Encoder::submitter()
       j = std::move(sq_.front()); sq_.pop_front(); sbusy_ = true;
     }
     roi_sub_.swap(j.roi); roi_sub_w_ = j.roi_w; roi_sub_h_ = j.roi_h;
+    tl("sub0", submitted_);
     const size_t ny = (size_t)cfg_.width * cfg_.height;
     bool ok;
     if (j.host) ok = upload_and_submit(j.src, j.src + ny, j.src + ny + ny / 4, true);
     else { Tick tk; ok = submit(j.src, -1); t_submit_ += tk.ms(); in_pending_ = false; }
+    tl("sub1", submitted_ - 1);
     if (!ok) {                                       // nothing was queued for this picture: its slot reports the failure
       { std::lock_guard<std::mutex> l(bm_); slot_[j.slot].ok = false; slot_[j.slot].ready = true; }
       bcv_.notify_all();
@@ -383,6 +391,20 @@ bool Encoder::flush(EncodedPicture *out)
   out->valid = false; out->au.clear();
   if (!pending()) return true;
   HIP_CHECK(hipSetDevice(cfg_.device));
+  return collect(out);
+}
+
+bool Encoder::poll(EncodedPicture *out)
+{
+  out->valid = false; out->au.clear();
+  if (!pending()) return true;
+  Slot &sl = slot_[collected_ % nslots_];
+  if (depth_ >= 2) { std::lock_guard<std::mutex> l(bm_); if (!sl.ready) return true; }
+  else {
+    HIP_CHECK(hipSetDevice(cfg_.device));
+    if (sub_thread_.joinable()) drain_submitter();
+    if (hipEventQuery(sl.done) != hipSuccess || hipEventQuery(sl.rec_done) != hipSuccess) return true;
+  }
   return collect(out);
 }
 
@@ -507,7 +529,7 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   } else
   HIP_CHECK(hipEventRecord(sl.done, stream_tok_));
   HIP_CHECK(hipEventRecord(sl.rec_done, stream_));
-  sl.poc = poc_; sl.intra = intra; sl.rec_idx = cur_idx_; sl.set = set_; sl.qp = qp_cur_; sl.write_ps = false;
+  sl.pic_idx = submitted_; sl.poc = poc_; sl.intra = intra; sl.rec_idx = cur_idx_; sl.set = set_; sl.qp = qp_cur_; sl.write_ps = false;
   if (intra) {
     sl.write_ps = (intra_count_ == 0) || (cfg_.vps_period > 0 && (intra_count_ % cfg_.vps_period) == 0);
     intra_count_++;
@@ -525,6 +547,8 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
 bool Encoder::collect(EncodedPicture *out)
 {
   Slot &sl = slot_[collected_ % nslots_];
+  tl("col0", collected_);
+  struct OnExit { long p; ~OnExit() { tl("col1", p); } } on_exit_{collected_};
   collected_++;
   bool ok;
   if (depth_ >= 2) {
@@ -548,7 +572,9 @@ void Encoder::background(int worker)
     int idx;
     { std::unique_lock<std::mutex> l(bm_); bcv_.wait(l, [&] { return bquit_ || !bq_.empty(); }); if (bq_.empty()) return; idx = bq_.front(); bq_.pop_front(); }
     Slot &sl = slot_[idx];
+    tl("bg0", sl.pic_idx);
     const bool ok = finish_slot(sl, &sl.result, worker);
+    tl("bg1", sl.pic_idx);
     { std::lock_guard<std::mutex> l(bm_); sl.ok = ok; sl.ready = true; }
     bcv_.notify_all();
   }
@@ -574,6 +600,7 @@ bool Encoder::finish_slot(Slot &sl, EncodedPicture *out, int worker)
     }
     sl.ev_used = 0;
   }
+  tl("gpudone", sl.pic_idx);
   // ---- serial half of entropy coding: host threads turn the bins into the WPP substreams
   const int nsub = (cfg_.wpp ? rows_ : cfg_.tile_rows) * cfg_.tile_cols;
   uint64_t bins = 0;
@@ -594,6 +621,7 @@ bool Encoder::finish_slot(Slot &sl, EncodedPicture *out, int worker)
     coder->code_picture(sl.h_tok_dense, sl.h_tok_count, sl.h_tok_off, cw_ / 64, rows_, cfg_.wpp != 0, cfg_.tile_rows, sl.intra ? 0 : 1, sl.qp, rows_out, &bins, cfg_.tile_cols);
   }
   const double ar = tk_ar.ms();
+  tl("arith", sl.pic_idx);
   if (profiling_ && !cfg_.entropy_gpu) { std::lock_guard<std::mutex> l(stat_m_); k_ms_[K_HOST_ARITH] += ar; k_n_[K_HOST_ARITH]++; }
   { std::lock_guard<std::mutex> l(stat_m_); t_arith_ += ar; }
   // ---- access unit assembly (host): parameter sets with IDR pictures, then the slice NAL

@@ -310,6 +310,7 @@ void KvazaarFilter::feedInput(std::unique_ptr<Data> input) // kvazaarfilter.cpp:
     return;
   }
   lastInputOnDevice_ = false;
+  kvzx::tl("feed0", pts_);
   kvz_picture *inputPic = getNextPic();
   const size_t ny = (size_t)input->vInfo->width * input->vInfo->height;
   const uint8_t *in = input->data ? input->data.get() : input->host_view;
@@ -326,6 +327,7 @@ void KvazaarFilter::feedInput(std::unique_ptr<Data> input) // kvazaarfilter.cpp:
     memcpy(inputPic->v, &(in[ny + ny / 4]), ny / 4);
   }
   input->host_view = nullptr;
+  kvzx::tl("copied", pts_);
   inputPic->pts = pts_;
   ++pts_;
   if (config_->target_bitrate == 0) {
@@ -359,7 +361,10 @@ void KvazaarFilter::drain()
     } else {
       kvz_picture *recon_pic = nullptr; kvz_data_chunk *data_out = nullptr; uint32_t len_out = 0;
       api_->encoder_encode(enc_, nullptr, &data_out, &len_out, &recon_pic, nullptr, &frame_info);
-      if (!data_out) break;
+      if (!data_out) {
+        if (config_->null_input_poll && kvzx_encoder_pending(enc_) > 0) { std::this_thread::sleep_for(std::chrono::microseconds(50)); continue; }   // (null-input=poll: not finished yet)
+        break;
+      }
       parseEncodedFrame(data_out, len_out, recon_pic);
     }
   }
@@ -453,7 +458,9 @@ void OpenHEVCFilter::process()                             // openhevcfilter.cpp
       bool vcl = nalType <= 31;
       if ((vpsReceived_ && spsReceived_ && ppsReceived_) || !vcl) {
         discardedFrames_ = 0;
+        kvzx::tl("dec0", (long)input->presentationTimestamp);
         int gotPicture = libOpenHevcDecode(handle_, input->data.get(), (int)input->data_size, input->presentationTimestamp);
+        kvzx::tl("dec1", (long)input->presentationTimestamp);
         if (vcl) decodingFrames_.push_front(std::move(input));
         if (gotPicture <= -1) fprintf(stderr, "OpenHEVCFilter: error while decoding (%d)\n", kvzx_decoder_last_error(handle_));
         else if (gotPicture > 0) sendDecodedOutput(gotPicture);
@@ -490,7 +497,9 @@ void OpenHEVCFilter::sendDecodedOutput(int &gotPicture)    // openhevcfilter.cpp
       return;
     }
     uint32_t finalDataSize = (uint32_t)(W * H + W * H / 2);
+    kvzx::tl("out0", (long)decodedFrame->presentationTimestamp);
     std::unique_ptr<uint8_t[]> yuv_frame(new uint8_t[finalDataSize]);
+    kvzx::tl("alloc", (long)decodedFrame->presentationTimestamp);
     uint8_t *pY = yuv_frame.get(), *pU = yuv_frame.get() + W * H, *pV = yuv_frame.get() + W * H + W * H / 4;
     uint32_t s_stride = (uint32_t)openHevcFrame.frameInfo.nYPitch, qs_stride = (uint32_t)openHevcFrame.frameInfo.nUPitch / 2;
     uint32_t d_stride = (uint32_t)W / 2, dd_stride = (uint32_t)W;
@@ -511,7 +520,9 @@ void OpenHEVCFilter::sendDecodedOutput(int &gotPicture)    // openhevcfilter.cpp
     }
     decodedFrame->data_size = finalDataSize;
     decodedFrame->data = std::move(yuv_frame);
+    kvzx::tl("out1", (long)decodedFrame->presentationTimestamp);
     sendOutput(std::move(decodedFrame));
+    kvzx::tl("out2", 0);
   }
 }
 

@@ -13,6 +13,8 @@
 #include <pthread.h>
 #include <climits>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #include <linux/futex.h>
 #include <sys/prctl.h>
 #include <sys/syscall.h>
@@ -43,6 +45,32 @@ template <class Query> inline bool nap_until(Query &&done, int nap_us = 25)
     std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
   }
 }
+
+// KVAZZUP_AMD_TIMELINE=<file>: a host-side timeline -- (time, thread, what, picture) records from the encoder's and decoder's threads,
+// written out when the process ends; tools/host_timeline.py turns it into per-stage latencies.  Off: one predictable branch per call.
+struct Timeline {
+  struct Rec { uint64_t ns; uint32_t tid; char what[12]; long pic; };
+  std::vector<Rec> recs; std::atomic<size_t> n{0}; const char *path = nullptr;
+  static Timeline &get() { static Timeline *t = new Timeline(); return *t; }
+  Timeline() { path = getenv("KVAZZUP_AMD_TIMELINE"); if (path) { recs.resize(1 << 21); atexit([] { Timeline::get().dump(); }); } }
+  void add(const char *what, long pic)
+  {
+    if (!path) return;
+    const size_t i = n.fetch_add(1, std::memory_order_relaxed);
+    if (i >= recs.size()) return;
+    Rec &r = recs[i];
+    r.ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    r.tid = (uint32_t)syscall(SYS_gettid); strncpy(r.what, what, sizeof(r.what) - 1); r.what[sizeof(r.what) - 1] = 0; r.pic = pic;
+  }
+  void dump()
+  {
+    FILE *f = fopen(path, "w"); if (!f) return;
+    const size_t m = n.load() < recs.size() ? n.load() : recs.size();
+    for (size_t i = 0; i < m; i++) fprintf(f, "%llu %u %s %ld\n", (unsigned long long)recs[i].ns, recs[i].tid, recs[i].what, recs[i].pic);
+    fclose(f);
+  }
+};
+inline void tl(const char *what, long pic) { Timeline::get().add(what, pic); }
 
 class OrderedPool {
  public:

@@ -172,6 +172,11 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
   INT_OPT("gpu", gpu_device, 0, 64)
   BOOL_OPT("recon-output", recon_output)
   BOOL_OPT("input-hold", input_hold)
+  if (n == "null-input") {
+    if (!strcmp(value, "drain")) { cfg->null_input_poll = 0; return 1; }
+    if (!strcmp(value, "poll")) { cfg->null_input_poll = 1; return 1; }
+    return 0;
+  }
   INT_OPT("band-row0", band_row0, 0, 4096)
   INT_OPT("band-rows", band_rows, 0, 4096)
   BOOL_OPT("rdoq", rdoq_enable) BOOL_OPT("signhide", signhide_enable) BOOL_OPT("smp", smp_enable) BOOL_OPT("amp", amp_enable)
@@ -360,7 +365,11 @@ int encoder_encode(kvz_encoder *e, kvz_picture *pic_in, kvz_data_chunk **data_ou
   if (!e) return 0;
   EncodedPicture ep;
   if (!pic_in) {
-    if (!e->impl->flush(&ep)) return 0;
+    // NULL input: Kvazaar waits for the oldest picture in flight and returns it.  uvgComm calls this in a loop after EVERY picture that
+    // produced output (kvazaarfilter.cpp:440-448), which with that meaning empties the pipeline each time: video/OWF pictures go in
+    // back to back, then all of them are waited for.  "null-input=poll" (settable through uvgComm's custom-parameter list) makes the call
+    // return only pictures that are already finished -- the loop then collects what is there and the pipeline stays full.
+    if (!(e->cfg.null_input_poll ? e->impl->poll(&ep) : e->impl->flush(&ep))) return 0;
   } else {
     if (pic_in->width != e->cfg.width || pic_in->height != e->cfg.height || !pic_in->y || !pic_in->u || !pic_in->v) return 0;
     // delta-QP map of this picture (kvazaarfilter.cpp:423-431); honoured when set-qp-in-cu enabled the signalling
@@ -459,6 +468,7 @@ const char *kvzx_encoder_kernel_name(int id)
   return (id >= 0 && id < kvzx::K_COUNT) ? names[id] : nullptr;
 }
 uint64_t kvzx_encoder_last_bins(kvz_encoder *e) { return e ? e->last_bins : 0; }
+int kvzx_encoder_pending(kvz_encoder *e) { return e ? e->impl->pending() : 0; }
 void kvzx_encoder_set_roi(kvz_encoder *e, int w, int h, const int8_t *map) { if (e) e->impl->set_roi(w, h, map); }
 
 // ---- tile-row split of one picture over several encoders (include/kvazzup_amd.h) ----

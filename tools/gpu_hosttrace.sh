@@ -3,7 +3,9 @@
 # tools/gpu_hosttrace.sh <workload>
 R=${GRAFT_REPO_ROOT:-$PWD}; wl=${1:-1080p}
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/htr
-if [ "$wl" = "notorch" ]; then
+if [ "$wl" = "enconly" ]; then
+HOST_ONLY=1 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/htr -o p -- python3 $R/scratch/enconly.py > /tmp/htr.log 2>&1
+elif [ "$wl" = "notorch" ]; then
 HOST_ONLY=1 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/htr -o p -- python3 $R/scratch/notorch.py > /tmp/htr.log 2>&1
 else
 KVAZZUP_BENCH_NOPROF=1 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/htr -o p -- python3 $R/bench.py --workload $wl --host-io --no-cpu-baseline --no-secondary --steps 3 --warmup 1 --repeats 1 > /tmp/htr.log 2>&1
@@ -39,7 +41,7 @@ for s, e, n, b in ev:
 for k, a in sorted(st.items(), key=lambda kv: -kv[1][1]):
     print("%-44s n %5d  avg %8.1f us  max %8.1f us  total %7.2f ms  %s" % (k, a[0], a[1] / a[0] / 1e3, a[3] / 1e3, a[1] / 1e6, ("%.1f GB/s" % (a[2] / a[1])) if a[2] else ""))
 # a 600 us excerpt from the middle of the window, as a timeline
-mid = t0 + (t1 - t0) // 2
+mid = t0 + (t1 - t0) * 3 // 4
 print("--- timeline excerpt (us from the excerpt's start)")
 for s, e, n, b in ev:
     if s >= mid and s < mid + 900_000: print("%8.1f .. %8.1f  %-40s %s" % ((s - mid) / 1e3, (e - mid) / 1e3, n, b or ""))

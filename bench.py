@@ -162,7 +162,8 @@ def cpu_baseline(w, h, frames, me_range, cores):
 # ---------------------------------------------------------------------------------------------------------------
 def launch_ranks(n, argv):
     """--gpus N without a torch.distributed environment: N fresh processes, one per rank (this process has not imported torch
-    or touched the GPU); rank 0 prints the line."""
+    or touched the GPU); rank 0 prints the line.  A rank that dies takes the others with it: they would otherwise sit in a
+    barrier until the process group's timeout."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
@@ -171,9 +172,27 @@ def launch_ranks(n, argv):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live and rc == 0:
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                rc = max(rc, abs(code))
+        time.sleep(0.05)
+    for p in live:                                   # a rank failed: stop the rest
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(10)
+        except subprocess.TimeoutExpired:
+            p.kill()
     return rc
+
+
+def stream_seed(cfg_index, rank):
+    """every rank codes its own synthetic stream (uvgx-synth-v1: seed = 0x5EED0000 + configuration, shifted per stream)"""
+    return 0x5EED0000 + cfg_index + 16 * rank
 
 
 def init_dist(world, local_rank):
@@ -218,13 +237,13 @@ class StreamRanks:
     stays dormant (with torch.cuda initialised this library would run on torch's copy, whose device-to-host copies are blit kernels that
     slow every kernel beside them -- DESIGN.md section 6).  With one rank torch is not imported at all."""
 
-    def __init__(self, world, local_rank):
+    def __init__(self, world, local_rank, need_device=True):
         from kvazzup_amd import _native
         self.lib = _native.load_library()                     # before any import of torch
         ndev = self.lib.kvzx_device_count()
-        if ndev < 1:
+        if ndev < 1 and need_device:                          # (need_device=False: the CPU test of the process-group plumbing)
             raise RuntimeError("no GPU visible: this library has no CPU fallback")
-        self.dev_index = local_rank % ndev
+        self.dev_index = local_rank % max(1, ndev)
         self.backend, self.dist, self.torch = None, None, None
         if world > 1:
             import datetime
@@ -408,9 +427,9 @@ def run_stream(args, wl, steps, warmup, ranks, rank, world, quality, host_io=Fal
     budget = float(os.environ.get("KVAZZUP_BENCH_CPU_BUDGET", 0)) or cpu_budget(world)
     if budget < 13.0:                                # not enough host CPU for the full thread complement: shrink the pools
         D = max(1, min(D, int(budget * 0.45 + 0.5)))
-        os.environ["KVAZZUP_AMD_ENTROPY_THREADS"] = str(max(2, min(16, int(budget * 0.4))))
-        os.environ["KVAZZUP_AMD_PARSE_THREADS"] = str(max(1, min(16, int(budget * 0.4))))       # (row-parallel parser of the synchronous decoder)
-    seed = 0x5EED0000 + wl["cfg_index"] + 16 * rank
+        os.environ.setdefault("KVAZZUP_AMD_ENTROPY_THREADS", str(max(2, min(16, int(budget * 0.4)))))
+        os.environ.setdefault("KVAZZUP_AMD_PARSE_THREADS", str(max(1, min(16, int(budget * 0.4)))))       # (row-parallel parser of the synchronous decoder)
+    seed = stream_seed(wl["cfg_index"], rank)
     # synthetic clip generated directly in HBM (inputs resident before the timed region)
     nclip = CLIP_FRAMES
     dclip = DeviceClip(ranks.lib, dev_index, seed, w, h, nclip)

@@ -46,8 +46,9 @@ def test_config1_plain_1080p_p64_qp32_matches_oracle(gpu):
 def test_config1_long_run_two_idrs(gpu, owf, threads):
     """130 pictures of the 1080p / period-64 workload through the pipelined filters (owf 3 with 12 frame threads; the benchmark's
     owf 6 with 24: all eight working sets of the encoder in rotation, pictures queued behind the intra pictures' chains):
-    three IDRs; every decoded picture equals what a fresh synchronous decoder produces from the same access units, and the
-    first pictures equal the checker's"""
+    three IDRs; EVERY access unit is decoded by the checker's decoder and every picture the pipelined HIP decoder delivered equals the
+    checker's (second and third IDR, the rotation of the encoder's eight working sets and the owf queueing included); the first
+    pictures' access units also equal the checker encoder's"""
     from kvazzup_amd import synth
     from kvazzup_amd.codec import Decoder
     from kvazzup_amd.pipeline import Pipeline
@@ -70,23 +71,23 @@ def test_config1_long_run_two_idrs(gpu, owf, threads):
     assert [a[1] for a in aus] == list(range(n)) and [d["pts"] for d in dec] == list(range(n))
     idr = [t for t in range(n) if (aus[t][0][4] >> 1) == 32]                  # access units that start with a VPS
     assert idr == [0, 64, 128], idr
-    gd = Decoder()
+    od = orc.OracleDecoder()
     oe = orc.OracleEncoder(w, h, qp=32, period=64, me_range=16)
     try:
         for t in range(n):
-            got = gd.decode_au(aus[t][0], t)
-            assert len(got) == 1 and np.array_equal(got[0]["i420"], dec[t]["i420"]), t
+            ref = od.decode_au(aus[t][0], t)
+            assert len(ref) == 1 and np.array_equal(ref[0]["i420"], dec[t]["i420"]), "picture %d differs from the checker's decoder" % t
             if t < 3:
                 assert oe.encode(frames[t]) == aus[t][0], t
                 assert np.array_equal(oe.recon(), dec[t]["i420"]), t
     finally:
-        gd.close(); oe.close()
+        od.close(); oe.close()
 
 
 @pytest.mark.gpu
 def test_config0_all_intra_1080p_30_pictures(gpu):
-    """BASELINE configs[0]: 1080p, period = 1, 30 pictures through KvazaarFilter' -> wire -> OpenHEVCFilter'; the first two
-    against the checker, all of them closed loop (decoded == a second decoder's output, PSNR sane)"""
+    """BASELINE configs[0]: 1080p, period = 1, 30 pictures through KvazaarFilter' -> wire -> OpenHEVCFilter'; the first two access units
+    against the checker's encoder, ALL thirty decoded by the checker's decoder and compared with what the HIP decoder delivered (PSNR sane)"""
     from kvazzup_amd.codec import Decoder
     from kvazzup_amd.pipeline import Pipeline
     w, h, n = 1920, 1080, 30
@@ -99,15 +100,16 @@ def test_config0_all_intra_1080p_30_pictures(gpu):
     dec = [pl.pop_decoded() for _ in range(n)]
     pl.close()
     oe = orc.OracleEncoder(w, h, qp=32, period=1, me_range=16)
-    gd = Decoder()
+    od = orc.OracleDecoder()
+    gd = od                                                                   # (closed in the finally clause below)
     try:
         for t in range(n):
             assert (aus[t][0][4] >> 1) == 32, t                               # every picture an IDR with parameter sets (vps-period 1)
             if t < 2:
                 assert oe.encode(frames[t]) == aus[t][0], t
                 assert np.array_equal(oe.recon(), dec[t]["i420"]), t
-            got = gd.decode_au(aus[t][0], t)
-            assert len(got) == 1 and np.array_equal(got[0]["i420"], dec[t]["i420"]), t
+            ref = od.decode_au(aus[t][0], t)
+            assert len(ref) == 1 and np.array_equal(ref[0]["i420"], dec[t]["i420"]), "picture %d differs from the checker's decoder" % t
             mse = np.mean((frames[t][:w * h].astype(float) - dec[t]["i420"][:w * h]) ** 2)
             assert 10 * np.log10(255.0 ** 2 / mse) > 33, t
     finally:
@@ -141,6 +143,23 @@ def test_config3_two_streams_concurrently_on_one_gpu(gpu):
             assert np.array_equal(d["i420"], oe.recon()), (k, t)
         oe.close()
         pl.close()
+
+
+@pytest.mark.gpu
+def test_config3_bench_command_with_two_ranks(gpu):
+    """BASELINE configs[3] the way the driver runs it: `bench.py --gpus 2` (launch_ranks -> StreamRanks -> run_stream -> max over ranks), the two
+    ranks sharing the test box's one GPU over gloo, one intra period each; the line must say two streams and carry a sane whole-job rate"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--repeats", "1",
+                        "--no-cpu-baseline", "--no-host-boundary"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "device error" not in r.stderr, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["streams"] == 2 and line["config"]["collective_backend"] == "gloo"
+    assert line["metric"] == "hevc_encode_decode_fps" and line["unit"] == "frames/s" and line["steps"] == 1
+    assert 100.0 < line["value"] < 100000.0, line["value"]
+    assert abs(line["value"] - 2 * 64 / (line["ms_per_step"] / 1e3)) < 1.0          # whole-job frames per second: both ranks' pictures over the slowest rank's time
+    assert 30.0 < line["config"]["psnr_y"] < 50.0
 
 
 @pytest.mark.gpu

@@ -1,5 +1,5 @@
 """Synthetic clips (numpy / torch twins of oracle/synth.c) and the one-stream-per-rank sharding that
-bench.py uses for N > 1 (BASELINE configs[3]: independent streams, no collective on the data path)."""
+bench.py uses for N > 1 (BASELINE configs[3]: independent streams, no collective on the data path): bench.py's own code, on CPU."""
 import os
 import subprocess
 import sys
@@ -25,32 +25,25 @@ def test_synth_twins_agree(kind):
 
 
 WORKER = r'''
-import os, sys, time
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
-import torch, torch.distributed as dist
-import numpy as np, hashlib
-import orc
-from kvazzup_amd import sharding
-dist.init_process_group("gloo")
-rank, world = dist.get_rank(), dist.get_world_size()
-seed = sharding.stream_seed(2, rank)
-w, h, frames = 192, 128, 4
-e = orc.OracleEncoder(w, h, qp=32, period=64, me_range=4); d = orc.OracleDecoder()
-t0 = time.perf_counter(); n = 0; dig = hashlib.md5()
-for t in range(frames):
-    au = e.encode(orc.synth_frame(0, seed, w, h, t)); dig.update(au)
-    n += len(d.decode_au(au, t))
-elapsed = time.perf_counter() - t0
-tot, worst = sharding.aggregate(n, elapsed, dist)
-digs = [None] * world
-dist.all_gather_object(digs, dig.hexdigest())
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import bench
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+ranks = bench.StreamRanks(world, int(os.environ["LOCAL_RANK"]), need_device=False)     # bench.py's own process-group plumbing, without a GPU
+assert ranks.backend == "gloo"
+ranks.sync()                                                    # the barrier that brackets the timed region
+worst = ranks.sync(1.0 + rank)                                  # max over ranks of the elapsed time
+seeds = [bench.stream_seed(2, r) for r in range(world)]
+ranks.sync()
 if rank == 0:
-    print("RESULT", tot, worst >= elapsed - 1e-9, len(set(digs)), world)
-dist.destroy_process_group()
+    print("RESULT", worst, len(set(seeds)), world)
+ranks.close()
 '''
 
 
 def test_two_rank_stream_sharding_gloo(tmp_path):
+    """the path `bench.py --gpus 2` takes between its ranks (StreamRanks: gloo process group, barrier, max over ranks; one stream seed per
+    rank), world size 2 on CPU.  The same command end to end, codecs included, runs in tests/test_gpu_configs.py."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
@@ -58,6 +51,18 @@ def test_two_rank_stream_sharding_gloo(tmp_path):
                           "--master-port", "29541", str(script), ROOT], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0].split()
-    assert int(line[1]) == 8            # 2 ranks x 4 pictures: whole-job count
-    assert line[2] == "True"            # the reported time is the slowest rank's
-    assert int(line[3]) == 2            # the two ranks coded different streams
+    assert float(line[1]) == 2.0        # the reported time is the slowest rank's
+    assert int(line[2]) == 2            # the two ranks code different streams
+    assert int(line[3]) == 2
+
+
+def test_launch_ranks_stops_the_job_when_a_rank_dies(tmp_path):
+    """bench.py --gpus N starts its ranks itself; a rank that fails must end the job (exit code != 0) instead of leaving the others in a
+    barrier.  Here (no GPU) every rank fails at once: the launcher returns promptly with their exit code."""
+    import time
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=120)
+    import kvazzup_amd
+    if kvazzup_amd.load_library().kvzx_device_count() == 0:
+        assert out.returncode != 0 and time.time() - t0 < 100, (out.returncode, out.stderr[-500:])

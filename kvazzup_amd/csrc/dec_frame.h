@@ -56,7 +56,7 @@ struct DecFrame {
   const DecTu *tus; const uint32_t *lev;
   int ntu;                  // transform blocks in tus[]
   int16_t *resid[3];        // residual of the intra transform blocks up to 16x16 (k_dec_intra_resid -> k_dec_intra), plane-shaped like rec[]
-  const uint8_t *ctu_tile;  // tile id of every CTU (raster)
+  const uint8_t *ctu_tile;  // per CTU (raster): (tile row mod 16) << 4 | (tile column mod 16) -- distinct for adjacent tiles, which is all the kernels compare
   uint8_t *rec[3];          // the picture being reconstructed (and deblocked in place)
   uint8_t *out[3];          // SAO output (== rec planes of the picture buffer when SAO runs from a work picture)
   const uint8_t *ref[KVZ_DEC_MAX_REFS][3];   // picture buffers by slot

@@ -299,7 +299,7 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, bool sign_hid
       if (lev[j] == base) {
         int prefix = 0;
         while (prefix < 32 && c.bypass()) prefix++;
-        if (prefix >= 32) return false;
+        if (prefix - 3 + rice > 16) return false;              // (9.3.3.11: an 8-bit stream's escape suffix has at most 16 bits; anything longer is not a level, and the shifts below must not see it)
         int rem = prefix <= 3 ? (prefix << rice) + (int)c.bypass_bits(rice)
                               : (((1 << (prefix - 3)) + 3 - 1) << rice) + (int)c.bypass_bits(prefix - 3 + rice);
         lev[j] = base + rem;
@@ -507,8 +507,8 @@ struct SliceParser {
     if (!gt0) return 0;
     if (!gt1) return 1;
     int k = 1, v = 0;
-    while (k < 32 && c.bypass()) { v += 1 << k; k++; }
-    if (k >= 32) { err = DEC_ERR_INVALID; return 0; }
+    while (k < 17 && c.bypass()) { v += 1 << k; k++; }           // (EG1 prefix: a vector difference fits 16 bits, 7.4.9.9 -- at most 15 ones follow the first order bit)
+    if (k >= 17) { err = DEC_ERR_INVALID; return 0; }
     return v + (int)c.bypass_bits(k) + 2;
   }
 
@@ -1100,9 +1100,9 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     if (r.err || p.num_ref_idx_default > 15 || p.cb_qp_offset < -12 || p.cb_qp_offset > 12 || p.cr_qp_offset < -12 || p.cr_qp_offset > 12) return last_error_ = DEC_ERR_INVALID;
     p.dependent_slices = dep;
     if (cip || wp || wbp || tqb) return last_error_ = DEC_ERR_UNSUPPORTED;   // constrained intra, weighted prediction, lossless
-    if (tiles) {                                                 // supported: up to 15 x 15 tiles; loop filter across tiles on
+    if (tiles) {                                                 // supported: the level limits of 20 columns x 22 rows (A.4.2); loop filter across tiles on
       const int cols = r.ue() + 1, rows = r.ue() + 1; p.uniform_tiles = r.get(1);
-      if (cols > 15 || rows > 15) return last_error_ = DEC_ERR_UNSUPPORTED;           // (tile ids are bytes)
+      if (cols > 20 || rows > 22) return last_error_ = DEC_ERR_UNSUPPORTED;
       if (!p.uniform_tiles) {
         for (int k = 0; k < cols - 1; k++) { p.col_width[k] = (int)r.ue() + 1; if (p.col_width[k] > 1024) return last_error_ = DEC_ERR_INVALID; }
         for (int k = 0; k < rows - 1; k++) { p.row_height[k] = (int)r.ue() + 1; if (p.row_height[k] > 1024) return last_error_ = DEC_ERR_INVALID; }
@@ -1153,7 +1153,15 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     if (p.dependent_slices) dependent = r.get(1) != 0;
     seg_address = r.get(bits);
     if (!asm_active_ || pps_id != asm_pps_id_ || nal_type != asm_nal_type_) return DEC_ERR_INVALID;      // a segment without its picture's first one (lost), or of another picture
-  } else if (asm_active_) asm_active_ = false;                   // the previous picture never got its last segment: it is dropped
+  } else if (asm_active_) {
+    // The previous picture never got its last segment (lost, or its first segment's extent was guessed wrong -- see append_segment): it
+    // is dropped.  That must not pass unnoticed: the error code is left for kvzx_decoder_last_error and said once on stderr, while this
+    // NAL unit -- a new picture -- is decoded normally.
+    asm_active_ = false;
+    last_error_ = DEC_ERR_INVALID;
+    static bool said = false;
+    if (!said) { said = true; fprintf(stderr, "kvazzup_amd: decoder dropped a picture whose slice segments did not complete before the next picture began\n"); }
+  }
   PicJob *const open_job = first_seg ? nullptr : &jobs_[(size_t)(job_head_ % jobs_.size())];
   if (dependent && open_job->pps.tile_cols > 1) { asm_active_ = false; return DEC_ERR_UNSUPPORTED; }     // (with tile columns: whole pictures or slices of whole tiles)
   if (dependent) {
@@ -1284,7 +1292,9 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   }
   for (int cy = 0, t = 0; cy < hc; cy++) {
     while (cy >= pp.row_bd[t + 1]) t++;
-    for (int tc = 0; tc < pp.tile_cols; tc++) memset(job.ctu_tile + (size_t)cy * wc + pp.col_bd[tc], t * pp.tile_cols + tc, (size_t)(pp.col_bd[tc + 1] - pp.col_bd[tc]));
+    // the kernels only ever ask whether two ADJACENT CTUs (side by side, above, diagonal) lie in the same tile: (row mod 16, column mod 16)
+    // tells adjacent tiles apart in one byte for any grid (a row-major index would need 20 x 22 = 440 values)
+    for (int tc = 0; tc < pp.tile_cols; tc++) memset(job.ctu_tile + (size_t)cy * wc + pp.col_bd[tc], ((t & 15) << 4) | (tc & 15), (size_t)(pp.col_bd[tc + 1] - pp.col_bd[tc]));
   }
   // the substreams in decoding order (6.5.1 tile scan): tile after tile; with WPP every CTB row of a tile is one
   job.geom.clear();

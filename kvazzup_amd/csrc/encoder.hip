@@ -626,7 +626,9 @@ bool Encoder::finish_slot(Slot &sl, EncodedPicture *out, int worker)
   { std::lock_guard<std::mutex> l(stat_m_); t_arith_ += ar; }
   // ---- access unit assembly (host): parameter sets with IDR pictures, then the slice NAL
   out->valid = true; out->poc = sl.poc; out->qp = sl.qp; out->is_intra = sl.intra; out->bins = bins;
-  { Tick tk; assemble_access_unit(out->au, sp_, sl.intra, sl.poc, sl.write_ps, rows_out, nsub, sl.qp - cfg_.qp); const double a = tk.ms(); std::lock_guard<std::mutex> l(stat_m_); t_asm_ += a; }
+  bool assembled;
+  { Tick tk; assembled = assemble_access_unit(out->au, sp_, sl.intra, sl.poc, sl.write_ps, rows_out, nsub, sl.qp - cfg_.qp); const double a = tk.ms(); std::lock_guard<std::mutex> l(stat_m_); t_asm_ += a; }
+  if (!assembled) { fprintf(stderr, "kvazzup_amd: %d substreams do not fit the tile grid\n", nsub); out->valid = false; return false; }
   return true;
 }
 

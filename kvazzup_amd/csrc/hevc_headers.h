@@ -161,8 +161,8 @@ inline void append_nal(std::vector<uint8_t> &out, int nal_type, const uint8_t *r
 }
 
 // One access unit: [VPS SPS PPS] + slice NAL whose data are the `nsub` substreams (CTU rows with
-// WPP, otherwise one) rows[r].
-inline void assemble_access_unit(std::vector<uint8_t> &au, const StreamParams &sp, bool idr, int poc, bool write_ps,
+// WPP, otherwise one) rows[r].  false (and an empty access unit): the substream count does not fit the tiling.
+inline bool assemble_access_unit(std::vector<uint8_t> &au, const StreamParams &sp, bool idr, int poc, bool write_ps,
                                  const std::vector<std::vector<uint8_t>> &rows, int nsub, int slice_qp_delta = 0)
 {
   au.clear();
@@ -182,7 +182,7 @@ inline void assemble_access_unit(std::vector<uint8_t> &au, const StreamParams &s
       const int cy0 = tile_row_first(hc, sp.tile_rows, tr), cy1 = tile_row_first(hc, sp.tile_rows, tr + 1), cx0 = tile_col_first(wc, sp.tile_cols, tc);
       for (int cy = cy0; cy < (sp.wpp ? cy1 : cy0 + 1); cy++) { tile_first.push_back(cy == cy0); addr_of.push_back(cy * wc + cx0); }
     }
-  if ((int)tile_first.size() != nsub) return;                      // (the caller's substream count does not fit the tiling)
+  if ((int)tile_first.size() != nsub) { au.clear(); return false; }   // the caller's substream count does not fit the tiling: no access unit rather than one without a slice
   for (int s0 = 0; s0 < nsub;) {
     int n = nsub - s0, addr = s0 ? addr_of[(size_t)s0] : -1;
     if (sp.slices == 1) n = 1;
@@ -195,6 +195,7 @@ inline void assemble_access_unit(std::vector<uint8_t> &au, const StreamParams &s
     append_nal(au, idr ? 19 : 1, sh.data().data(), sh.data().size());
     s0 += n;
   }
+  return true;
 }
 
 }  // namespace kvzx

@@ -514,7 +514,7 @@ int kvzx_assemble_access_unit(const kvz_config *cfg, int idr, int poc, int write
   size_t o = 0;
   for (int k = 0; k < nsub; k++) { rows[(size_t)k].assign(data + o, data + o + sizes[k]); o += sizes[k]; }
   std::vector<uint8_t> au;
-  kvzx::assemble_access_unit(au, sp, idr != 0, poc, write_parameter_sets != 0, rows, nsub, slice_qp - cfg->qp);
+  if (!kvzx::assemble_access_unit(au, sp, idr != 0, poc, write_parameter_sets != 0, rows, nsub, slice_qp - cfg->qp)) return 0;
   *len_out = (uint32_t)au.size();
   if (au.size() > cap) return 0;
   memcpy(out, au.data(), au.size());

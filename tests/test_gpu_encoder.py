@@ -142,6 +142,8 @@ def test_slices_option_matches_oracle(gpu, cfg):
     dict(w=448, h=320, dims="2x3", cols=2, rows=3, frames=4, qp=30, period=1, kind=0, wpp=0, slices=2),             # all intra: the wavefront stops at tile borders
     dict(w=1920, h=1080, dims="4x4", cols=4, rows=4, frames=3, qp=32, period=64, kind=0),                           # BASELINE configs[1] size
     dict(w=640, h=384, dims="2x2", cols=2, rows=2, frames=24, qp=32, period=16, kind=0, bitrate=600000),            # rate control v2 over a tile grid
+    dict(w=1920, h=1080, dims="16x16", cols=16, rows=16, frames=3, qp=32, period=64, kind=0),                       # uvgComm's largest tile dimension default at 1080p: a real 16 x 16 grid (30 x 17 CTUs), 256 tiles
+    dict(w=3840, h=2160, dims="20x22", cols=20, rows=22, frames=2, qp=32, period=64, kind=0),                       # the level limit (A.4.2) at 4K: 440 tiles, more than a byte of tile ids
 ])
 def test_tile_grid_matches_oracle(gpu, cfg):
     """kvazaar tiles=CxR with columns (uvgComm video/Tiles + video/tileDimensions, kvazaarfilter.cpp:196-202; the defaults "2x2" .. "16x16" all

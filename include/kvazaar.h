@@ -81,19 +81,20 @@ typedef struct kvz_config {
   int32_t framerate_denom;
   int32_t deblock_enable;     /* "deblock" */
   enum kvz_sao sao_type;      /* "sao": off, or full (edge and band offsets) */
-  int32_t rdoq_enable, signhide_enable, smp_enable, amp_enable;
+  int32_t rdoq_enable, signhide_enable;   /* "rdoq", "signhide": rate-distortion optimised quantisation ("uvgx RDOQ v1") and sign data hiding in the quantiser (oracle/hevc_enc.c) */
+  int32_t smp_enable, amp_enable;         /* recorded; config_parse rejects the value 1 (2NxN / Nx2N / AMP inter partitions are not searched) */
   int32_t rdo;                /* "rd" */
   int32_t full_intra_search, trskip_enable, tr_depth_intra;
-  enum kvz_ime_algorithm ime_algorithm;   /* "me": recorded; the GPU search is always exhaustive */
+  enum kvz_ime_algorithm ime_algorithm;   /* "me": recorded; the GPU search is always exhaustive over +-me_range (a superset of what any of Kvazaar's patterns visits) */
   int32_t fme_level;          /* "subme" (0: integer samples only) */
   int32_t bipred;
   int32_t deblock_beta, deblock_tc;
   int32_t ref_frames;         /* "ref" */
-  int32_t tiles_width_count, tiles_height_count;   /* "tiles" WxH (parsed, not implemented: must be 1x1) */
+  int32_t tiles_width_count, tiles_height_count;   /* "tiles" CxR: C tile columns x R tile rows, uniform spacing, at most 20 x 22 (a grid finer than the CTU grid is cut down to it) */
   int32_t wpp;                /* "wpp" */
   int32_t owf;                /* "owf": pictures in flight; output is delayed by this many calls */
-  int32_t slices;             /* "slices": enum kvz_slices bit mask (parsed; one slice per picture) */
-  int32_t threads;            /* "threads": accepted and ignored (the GPU does the work) */
+  int32_t slices;             /* "slices": enum kvz_slices: wpp = a dependent slice segment per CTU row (needs wpp), tiles = an independent slice per tile; one NAL unit each */
+  int32_t threads;            /* "threads": host threads of the arithmetic-coding stage (-1 / "auto": 16; 0: the calling thread only) */
   int32_t cpuid;
   int32_t lossless;           /* must be 0 */
   int32_t tmvp_enable;
@@ -101,9 +102,9 @@ typedef struct kvz_config {
   int32_t mv_rdo;
   int32_t calc_psnr;
   enum kvz_mv_constraint mv_constraint;
-  enum kvz_hash hash;         /* decoded picture hash SEI: only KVZ_HASH_NONE */
+  enum kvz_hash hash;         /* "hash": decoded picture hash SEI after every picture: none, checksum or md5 (D.3.19), computed from the reconstruction on the device */
   int32_t cu_split_termination, me_early_termination, intra_rdo_et, early_skip;
-  int32_t target_bitrate;     /* rate control: only 0 (constant QP) is implemented */
+  int32_t target_bitrate;     /* "bitrate" in bits per second: 0 = constant QP; > 0 = this library's rate control (picture level; with rc_algorithm lambda / oba also between groups of CTU rows, decided on the device) */
   enum kvz_rc_algorithm rc_algorithm;
   int32_t max_merge;
   int32_t gop_len, gop_lowdelay;      /* "gop": lp-g<len>d<depth>t<layers> accepted; one reference is used */

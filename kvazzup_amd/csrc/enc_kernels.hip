@@ -10,18 +10,20 @@
 //   k_vaq_stats/apply  per-CTU luma variance -> delta QP (vaq only)
 //   k_me            one workgroup per 32x32 luma block (XCD-aware order): early termination on the co-located block, else the
 //                   search window staged in LDS, v_qsad_pk_u16_u8 on quads x pairs of candidates, wave min of (cost << 13 | index)
-//   k_inter_recon   one workgroup per 32x32 block: MC, residual, DCT (32x32: MFMA i8), quant, dequant, IDCT, reconstruction;
-//                   <true>: decoder (levels given; fractional vectors through a separable LDS pass; short path without residual)
+//   k_inter_recon   one workgroup per 32x32 block: MC, residual, DCT (32x32: MFMA i8), quant, dequant, IDCT, reconstruction
+//                   (two forms: with fractional vectors -- subme > 0, separable LDS passes -- and without)
 //   k_inter_signal  one thread per 16x16 block: merge / skip / AMVP signalling
-//   k_intra_analyse one workgroup per 32x32 block: 35-mode SAD search on source samples
-//   k_intra_recon   one 256-thread workgroup per (CTU, colour plane), coupled by progress counters with 8x8 granularity
+//   k_intra_analyse one workgroup per 32x32 region: 35-mode search on source samples, cost = 8x8 Hadamard sums on the matrix cores
+//                   (intra-satd, default) or SAD; work item = (16x16 tile, mode, kind) on one wave
+//   k_intra_recon   four waves per (CTU, colour plane), one intra block per WAVE and no workgroup barrier in the chain (transforms on
+//                   v_mfma_f32_16x16x16_f16, references over DPP / ds_bpermute); CTUs coupled by progress counters with 8x8 granularity
 //   k_qp_first/chain  per-CTU QP bookkeeping (cu_qp_delta)
 //   k_deblock_tile  one workgroup per 64x64 tile shifted by (-4, -4): vertical then horizontal edges in LDS
 //                   (k_deblock_v / k_deblock_h: one thread per 4-sample edge segment, band mode of the tile-row split)
 //   k_sao           one workgroup per CTU: statistics + decision (encoder) and the filter
 //   k_tokenize      one wave per 16x16 unit (and colour component): binarisation + context selection -> bins as 16-bit tokens;
 //   k_tok_compact   restores coding order per CTU, dense copy to host-mapped memory for the host arithmetic coder
-//   k_scatter_levels  decoder: packed level words -> plane-shaped level arrays
+// (the decoder's kernels live in dec_kernels.hip, the fractional-sample search in subpel_kernels.hip, rate control in rc_kernels.hip)
 #include <hip/hip_runtime.h>
 #include "hevc_core.h"
 #include "enc_kernels.h"

@@ -50,6 +50,9 @@ KVZ_PUBLIC int kvzx_encoder_pending(kvz_encoder *enc);         /* pictures hande
  * or the environment variable KVAZZUP_AMD_DEVICE) */
 KVZ_PUBLIC int kvzx_decoder_set_device(OpenHevc_Handle h, int device);
 KVZ_PUBLIC int kvzx_decoder_last_error(OpenHevc_Handle h);
+/* with libOpenHevcSetCheckMD5(h, 1): decoded picture hash SEI messages (MD5 / checksum, H.265 D.2.19) compared so far and how many did not
+ * match the picture as decoded (each mismatch also sets the last error to -4 and is said on stderr; the picture is still handed out) */
+KVZ_PUBLIC void kvzx_decoder_hash_stats(OpenHevc_Handle h, int *checked, int *mismatch);
 /* device pointers (pitch = coded width [/2]) of the picture returned by the last libOpenHevcGetOutput */
 KVZ_PUBLIC int kvzx_decoder_output_device(OpenHevc_Handle h, const void **planes /*[3]*/, int *pitches /*[3]*/);
 /* when 0, libOpenHevcDecode leaves the picture in HBM and libOpenHevcGetOutput returns NULL planes */

@@ -106,7 +106,7 @@ DECODER_EXPORTS = ["libOpenHevcInit", "libOpenHevcStartDecoder", "libOpenHevcDec
                    "libOpenHevcGetPictureSize2", "libOpenHevcGetOutput", "libOpenHevcGetOutputCpy", "libOpenHevcSetCheckMD5",
                    "libOpenHevcSetDebugMode", "libOpenHevcSetTemporalLayer_id", "libOpenHevcSetNoCropping", "libOpenHevcSetActiveDecoders",
                    "libOpenHevcSetViewLayers", "libOpenHevcClose", "libOpenHevcFlush", "libOpenHevcVersion",
-                   "kvzx_decoder_set_device", "kvzx_decoder_last_error", "kvzx_decoder_output_device", "kvzx_decoder_set_download", "kvzx_decoder_set_output_hold", "kvzx_decoder_set_profiling",
+                   "kvzx_decoder_set_device", "kvzx_decoder_last_error", "kvzx_decoder_hash_stats", "kvzx_decoder_output_device", "kvzx_decoder_set_download", "kvzx_decoder_set_output_hold", "kvzx_decoder_set_profiling",
                    "kvzx_decoder_kernel_times", "kvzx_decoder_kernel_name", "kvzx_decoder_debug_copy",
                    "kvzx_decoder_set_band", "kvzx_decoder_band_halo_bytes", "kvzx_decoder_band_export", "kvzx_decoder_band_import", "kvzx_decoder_band_deblock", "kvzx_decoder_band_finish", "kvzx_decoder_band_ready"]
 
@@ -153,6 +153,8 @@ def load_library():
         L.libOpenHevcVersion.argtypes = [C.c_void_p]
         L.kvzx_decoder_set_device.argtypes = [C.c_void_p, C.c_int]
         L.kvzx_decoder_last_error.argtypes = [C.c_void_p]
+        L.kvzx_decoder_hash_stats.argtypes = [C.c_void_p, _P(C.c_int), _P(C.c_int)]
+        L.kvzx_decoder_hash_stats.restype = None
         L.kvzx_decoder_output_device.argtypes = [C.c_void_p, _P(C.c_void_p), _P(C.c_int)]
         L.kvzx_decoder_set_download.argtypes = [C.c_void_p, C.c_int]
         L.kvzx_decoder_set_band.argtypes = [C.c_void_p, C.c_int, C.c_int]

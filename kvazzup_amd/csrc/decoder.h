@@ -131,6 +131,9 @@ class Decoder {
   void get_kernel_times(double *ms, uint64_t *launches, bool reset);
   bool debug_copy(const char *what, void *dst, size_t bytes);
   int last_error() const { return last_error_; }
+  // libOpenHevcSetCheckMD5: decoded picture hash SEI messages (MD5 or checksum) are compared with the pictures as decoded here
+  void set_check_hash(bool on) { check_hash_ = on; }
+  void hash_stats(int *checked, int *mismatch) const { if (checked) *checked = hash_checked_; if (mismatch) *mismatch = hash_mismatch_; }
   void flush() {}
   int pending() const { return (int)(job_head_ - job_tail_) + (gpu_job_ ? 1 : 0) + (int)gpu_q_.size(); }
 
@@ -169,6 +172,7 @@ class Decoder {
     bool any_intra = false, any_inter = false, across_slices = true;
     std::atomic<int> state{0}; int rc = 0; double parse_ms = 0;
     hipEvent_t done = nullptr;                                   // recorded behind the picture's last kernel
+    std::vector<uint8_t> expect_hash;                            // payload of the picture's decoded picture hash SEI (libOpenHevcSetCheckMD5), empty: none
     long launch_idx = 0;                                         // count of pictures launched before this one
     hipEvent_t dl_done = nullptr; int dl_buf = -1;               // download mode: the picture's copy into host buffer dl_buf, queued behind `done` on the download stream
     struct EvPair { hipEvent_t a, b; int id; }; std::vector<EvPair> ev; size_t ev_used = 0;     // kernel timing (set_profiling)
@@ -195,6 +199,9 @@ class Decoder {
   bool ensure_buffers(int w, int h);
   void free_buffers();
   int decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t pts);
+  int hash_sei(const uint8_t *rbsp, size_t len);
+  int verify_hash(const PicJob &job, const std::vector<uint8_t> &want);
+  bool check_hash_ = false; int hash_checked_ = 0, hash_mismatch_ = 0;
   int parse_job(PicJob &job, bool row_parallel);
   int parse_substream(PicJob &job, int sub, const uint8_t *data, size_t len, SubOut &out);
   int finish_oldest();

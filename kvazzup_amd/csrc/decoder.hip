@@ -5,12 +5,13 @@
 #include <cstdlib>
 #include <cstring>
 #include "stream_pool.h"
+#include "pic_hash.h"
 #include "decoder.h"
 
 namespace kvzx {
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "kvazzup_amd: %s failed: %s\n", #expr, hipGetErrorString(e_)); return false; } } while (0)
-enum { DEC_ERR_INVALID = -1, DEC_ERR_UNSUPPORTED = -2, DEC_ERR_GPU = -3 };
+enum { DEC_ERR_INVALID = -1, DEC_ERR_UNSUPPORTED = -2, DEC_ERR_GPU = -3, DEC_ERR_HASH = -4 };      // (-4: a decoded picture hash SEI did not match, libOpenHevcSetCheckMD5)
 enum { PM_INTER = 0, PM_INTRA = 1, PM_SKIP = 2, PM_NONE = 255 };
 enum { PART_2Nx2N = 0, PART_2NxN, PART_Nx2N, PART_NxN, PART_2NxnU, PART_2NxnD, PART_nLx2N, PART_nRx2N };
 
@@ -1126,11 +1127,55 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     return 0;
   }
   if (nal_type == 36 || nal_type == 37) { int rc = finish_oldest(); if (rc < 0) last_error_ = rc; return rc; }   // EOS / EOB: drain one delayed picture
-  if (nal_type > 31) return 0;                                    // AUD / SEI / ...
+  if (nal_type == 40 && check_hash_) return hash_sei(rbsp_.data(), n);       // suffix SEI: decoded picture hash (libOpenHevcSetCheckMD5)
+  if (nal_type > 31) return 0;                                    // AUD / other SEI / ...
   if (!(nal_type <= 9 || (nal_type >= 19 && nal_type <= 21))) return last_error_ = DEC_ERR_UNSUPPORTED;      // (BLA pictures, reserved types)
   int rc = decode_slice(rbsp_.data(), n, nal_type, pts);
   if (rc < 0) last_error_ = rc;
   return rc;
+}
+
+// Decoded picture hash SEI (D.2.19, payload type 132) with libOpenHevcSetCheckMD5(h, 1): the message follows its picture's last slice
+// segment.  Frame-threaded decoder: the picture is still in the ring -- the expected hashes travel with its job and are compared when the
+// picture completes.  Synchronous decoder: the picture has just been output and still sits untouched in its buffer -- compared at once.
+int Decoder::hash_sei(const uint8_t *rbsp, size_t len)
+{
+  BitReader r(rbsp, len);
+  while (r.pos + 16 <= len * 8 && !r.err) {
+    int type = 0, size = 0, b;
+    do { b = (int)r.get(8); type += b; } while (b == 255 && !r.err);
+    do { b = (int)r.get(8); size += b; } while (b == 255 && !r.err);
+    if (r.err || r.pos + (size_t)size * 8 > len * 8) break;
+    if (type != 132 || size < 1) { for (int k = 0; k < size; k++) r.get(8); continue; }
+    std::vector<uint8_t> want((size_t)size);
+    for (int k = 0; k < size; k++) want[(size_t)k] = (uint8_t)r.get(8);
+    const int ht = want[0];
+    if ((ht != 0 && ht != 2) || size != 1 + 3 * (ht == 0 ? 16 : 4)) continue;      // (CRC: not checked)
+    if (job_head_ == 0) continue;
+    PicJob &job = jobs_[(size_t)((job_head_ - 1) % (long)jobs_.size())];
+    if (frame_threads_ > 1 || band_nrows_ > 0) { job.expect_hash = std::move(want); continue; }
+    const int rc = verify_hash(job, want);
+    if (rc < 0) return last_error_ = rc;
+  }
+  return 0;
+}
+
+// the picture of `job` (complete on the device) against the hashes of its SEI message; the samples come down once more for it
+int Decoder::verify_hash(const PicJob &job, const std::vector<uint8_t> &want)
+{
+  const size_t npx = (size_t)pw_ * ph_;
+  std::vector<uint8_t> pic(npx * 3 / 2);
+  if (hipSetDevice(device_) != hipSuccess || hipMemcpy(pic.data(), dpb_[job.slot].plane[0], pic.size(), hipMemcpyDeviceToHost) != hipSuccess) return DEC_ERR_GPU;
+  const uint8_t *pl[3] = {pic.data(), pic.data() + npx, pic.data() + npx + npx / 4};
+  const size_t pitch[3] = {(size_t)pw_, (size_t)pw_ / 2, (size_t)pw_ / 2};
+  const std::vector<uint8_t> got = picture_hash_payload(want[0], pl, pitch, w_, h_);
+  hash_checked_++;
+  if (got != want) {
+    hash_mismatch_++;
+    fprintf(stderr, "kvazzup_amd: decoded picture hash mismatch (POC %d)\n", job.sh.poc);
+    return DEC_ERR_HASH;
+  }
+  return 0;
 }
 
 int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t pts)
@@ -1272,7 +1317,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   // like OpenHEVC's frame threading; temporal motion prediction makes a picture's parser follow the collocated
   // picture's parser row by row (ColMotion::row_done).
   PicJob &job = jobs_[(size_t)(job_head_ % jobs_.size())];
-  job.rbsp.clear(); job.data_off = 0; job.data_len = 0; job.sub_start.clear();
+  job.rbsp.clear(); job.data_off = 0; job.data_len = 0; job.sub_start.clear(); job.expect_hash.clear();
   job.seg_end_row.assign((size_t)hc, 0); job.row_restart.assign((size_t)hc, SIZE_MAX);
   job.across_slices = across_slices;
   job.sh = sh; job.sps = sps_ref; job.pps = pp; job.pts = pts;
@@ -1567,6 +1612,11 @@ int Decoder::complete_gpu(PicJob &job)
     t_sync_ += tk.ms();
   }
   if (*h_err_) { fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x\n", *h_err_); return DEC_ERR_GPU; }
+  if (!job.expect_hash.empty()) {                  // libOpenHevcSetCheckMD5: the picture's hash SEI arrived while it was in the ring
+    const std::vector<uint8_t> want = std::move(job.expect_hash); job.expect_hash.clear();
+    const int rc = verify_hash(job, want);
+    if (rc < 0) last_error_ = rc;                   // (the picture is still handed out: the application decides, as with OpenHEVC)
+  }
   if (job.ev_used) {
     for (size_t i = 0; i < job.ev_used; i++) { float ms = 0; hipEventElapsedTime(&ms, job.ev[i].a, job.ev[i].b); k_ms_[job.ev[i].id] += ms; k_n_[job.ev[i].id]++; }
     job.ev_used = 0;

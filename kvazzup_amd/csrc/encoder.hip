@@ -7,6 +7,7 @@
 #include "encoder.h"
 #include "enc_kernels.h"
 #include "stream_pool.h"
+#include "pic_hash.h"
 
 namespace kvzx {
 
@@ -47,6 +48,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   }
   if (const char *e = getenv("KVAZZUP_AMD_ENTROPY")) cfg.entropy_gpu = strcmp(e, "gpu") == 0;    // A/B knob: host | gpu
   if (cfg.band_rows > 0) cfg.entropy_gpu = 0;               // (band mode hands its substreams to the caller from the host pool)
+  if (cfg.band_rows > 0) cfg.hash = 0;                      // (a band encoder holds a part of the picture only)
   cfg_ = cfg;
   qp_cur_ = cfg.qp;
   int ndev = 0;
@@ -629,6 +631,21 @@ bool Encoder::finish_slot(Slot &sl, EncodedPicture *out, int worker)
   bool assembled;
   { Tick tk; assembled = assemble_access_unit(out->au, sp_, sl.intra, sl.poc, sl.write_ps, rows_out, nsub, sl.qp - cfg_.qp); const double a = tk.ms(); std::lock_guard<std::mutex> l(stat_m_); t_asm_ += a; }
   if (!assembled) { fprintf(stderr, "kvazzup_amd: %d substreams do not fit the tile grid\n", nsub); out->valid = false; return false; }
+  if (cfg_.hash) {
+    // decoded picture hash SEI: the picture's reconstruction (coded size, after the loop filters) comes down once more for it -- a
+    // verification aid, not part of the hot path (uvgComm sets hash = none).  The ring entry is not written again before this picture is output.
+    const size_t npx = (size_t)cw_ * ch_;
+    std::vector<uint8_t> pic(npx * 3 / 2);
+    const uint8_t *pl[3] = {pic.data(), pic.data() + npx, pic.data() + npx + npx / 4};
+    const size_t pitch[3] = {(size_t)cw_, (size_t)cw_ / 2, (size_t)cw_ / 2};
+    for (int c = 0; c < 3; c++) HIP_CHECK(hipMemcpy(const_cast<uint8_t *>(pl[c]), rec_[sl.rec_idx][c], c ? npx / 4 : npx, hipMemcpyDeviceToHost));
+    const std::vector<uint8_t> payload = picture_hash_payload(cfg_.hash == 2 ? 0 : 2, pl, pitch, cw_, ch_);
+    BitWriter sei;
+    sei.put(132, 8); sei.put((uint32_t)payload.size(), 8);
+    sei.bytes(payload.data(), payload.size());
+    sei.trailing();
+    append_nal(out->au, 40, sei.data().data(), sei.data().size());      // SUFFIX_SEI_NUT
+  }
   return true;
 }
 

@@ -194,6 +194,8 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
   }
   if (n == "hash") {
     if (!strcmp(value, "none")) { cfg->hash = KVZ_HASH_NONE; return 1; }
+    if (!strcmp(value, "checksum")) { cfg->hash = KVZ_HASH_CHECKSUM; return 1; }
+    if (!strcmp(value, "md5")) { cfg->hash = KVZ_HASH_MD5; return 1; }
     return 0;
   }
   if (n == "pu-depth-inter" || n == "pu-depth-intra") {
@@ -300,6 +302,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.subme = cfg->fme_level < 0 ? 0 : (cfg->fme_level > 4 ? 4 : cfg->fme_level);
   ec.entropy_gpu = cfg->gpu_entropy != 0;
   ec.input_hold = cfg->input_hold != 0;
+  ec.hash = cfg->hash == KVZ_HASH_MD5 ? 2 : (cfg->hash == KVZ_HASH_CHECKSUM ? 1 : 0);
   ec.vaq = cfg->vaq > 0 ? cfg->vaq : 0;
   ec.qp_in_cu = (cfg->set_qp_in_cu || ec.vaq > 0) ? 1 : 0;
   ec.sao = cfg->sao_type == KVZ_SAO_FULL;

@@ -91,7 +91,7 @@ void libOpenHevcGetPictureInfo(OpenHevc_Handle hh, OpenHevc_FrameInfo *info)
   if (h->have_pic) fill_info(h->pic, info, true); else memset(info, 0, sizeof(*info));
 }
 void libOpenHevcGetPictureSize2(OpenHevc_Handle hh, OpenHevc_FrameInfo *info) { libOpenHevcGetPictureInfo(hh, info); }
-void libOpenHevcSetCheckMD5(OpenHevc_Handle, int) {}
+void libOpenHevcSetCheckMD5(OpenHevc_Handle hh, int val) { Handle *h = H(hh); if (h && h->dec) h->dec->set_check_hash(val != 0); }
 void libOpenHevcSetDebugMode(OpenHevc_Handle, int) {}
 void libOpenHevcSetTemporalLayer_id(OpenHevc_Handle, int) {}
 void libOpenHevcSetNoCropping(OpenHevc_Handle, int) {}
@@ -117,6 +117,7 @@ int kvzx_decoder_set_device(OpenHevc_Handle hh, int device)
   h->dec->set_frame_threads(ft);
   return 1;
 }
+void kvzx_decoder_hash_stats(OpenHevc_Handle hh, int *checked, int *mismatch) { Handle *h = H(hh); if (h) h->dec->hash_stats(checked, mismatch); }
 int kvzx_decoder_last_error(OpenHevc_Handle hh) { Handle *h = H(hh); return h ? h->dec->last_error() : -1; }
 int kvzx_decoder_output_device(OpenHevc_Handle hh, const void **planes, int *pitches)
 {

@@ -2,6 +2,7 @@
  * used as the CPU checker for the decode half of the hot path
  * (/root/reference/src/media/processing/openhevcfilter.cpp:103-239). */
 #include "hevc_dec.h"
+#include "hevc_hash.h"
 #include "hevc_bits.h"
 #include "hevc_cabac.h"
 #include "hevc_ps.h"
@@ -33,6 +34,8 @@ struct orc_decoder {
   pixel *predeblock[3]; size_t predeblock_cap;
   orc_pic *out_queue[MAX_DPB + 1]; int out_n;
   orc_pic *last_output;
+  orc_pic *last_finished;                 /* the picture finish_picture() completed last: what a decoded picture hash SEI behind it refers to */
+  int hash_checked, hash_mismatch;        /* decoded picture hash SEI messages seen / that did not match the decoded picture */
   uint8_t *rbsp; size_t rbsp_cap;
   int64_t cur_pts;
   /* tile / slice maps for the current picture */
@@ -721,6 +724,7 @@ static int build_ref_list(orc_decoder *d)
 static void finish_picture(orc_decoder *d)
 {
   orc_pic *pic = d->cur;
+  d->last_finished = pic;
   const orc_sps *s = d->s;
   for (int ci = 0; ci < 3; ci++) {
     size_t n = (size_t)(ci ? s->width / 2 : s->width) * (ci ? s->height / 2 : s->height);
@@ -844,7 +848,28 @@ int orc_dec_decode_nal(orc_decoder *d, const uint8_t *data, size_t len, int64_t 
   if (nal_type == NAL_VPS) { orc_vps v; int r = orc_parse_vps(&br, &v); if (r) return r; d->vps[v.vps_id] = v; return 0; }
   if (nal_type == NAL_SPS) { orc_sps s; int r = orc_parse_sps(&br, &s); if (r) return r; if (s.pcm_enabled) return ERR_UNSUPPORTED; d->sps[s.sps_id] = s; return 0; }
   if (nal_type == NAL_PPS) { orc_pps p; int r = orc_parse_pps(&br, &p); if (r) return r; d->pps[p.pps_id] = p; return 0; }
-  if (nal_type > 31) return 0;                        /* AUD, SEI, EOS, ... ignored */
+  if (nal_type == 40 && d->last_finished) {           /* suffix SEI: a decoded picture hash (D.2.19) of the picture just finished is checked */
+    while (br.pos + 16 <= rlen * 8 && !br.error) {
+      int type = 0, size = 0, b;
+      do { b = (int)orc_br_get(&br, 8); type += b; } while (b == 255 && !br.error);
+      do { b = (int)orc_br_get(&br, 8); size += b; } while (b == 255 && !br.error);
+      if (br.error || br.pos + (size_t)size * 8 > rlen * 8) break;
+      if (type == 132 && size >= 1) {
+        const int ht = (int)orc_br_get(&br, 8), nb = ht <= 2 ? orc_hash_bytes(ht) : 0;
+        if (nb && size == 1 + 3 * nb) {
+          uint8_t want[3][16], got[3][16]; memset(want, 0, sizeof(want));
+          for (int c = 0; c < 3; c++) for (int i = 0; i < nb; i++) want[c][i] = (uint8_t)orc_br_get(&br, 8);
+          const orc_pic *pic = d->last_finished;
+          const pixel *pl[3] = { pic->plane[0], pic->plane[1], pic->plane[2] };
+          orc_picture_hash(ht, pl, pic->stride, pic->w, pic->h, got);
+          d->hash_checked++;
+          if (memcmp(want, got, sizeof(want))) d->hash_mismatch++;
+        } else br.pos += (size_t)(size - 1) * 8;
+      } else br.pos += (size_t)size * 8;
+    }
+    return 0;
+  }
+  if (nal_type > 31) return 0;                        /* AUD, other SEI, EOS, ... ignored */
   if ((nal_type > NAL_TRAIL_R + 8 && nal_type < NAL_BLA_W_LP) || nal_type > NAL_CRA) return 0;   /* reserved */
   free(d->sh.entry_point_offset); d->sh.entry_point_offset = NULL;
   d->nal_type = nal_type;
@@ -867,6 +892,8 @@ int orc_dec_decode_nal(orc_decoder *d, const uint8_t *data, size_t len, int64_t 
   if (d->ctbs_decoded >= d->s->pic_w_ctbs * d->s->pic_h_ctbs) { finish_picture(d); return d->out_n > 0 ? 1 : 0; }
   return 0;
 }
+
+void orc_dec_hash_stats(orc_decoder *d, int *checked, int *mismatch) { if (checked) *checked = d->hash_checked; if (mismatch) *mismatch = d->hash_mismatch; }
 
 int orc_dec_get_frame(orc_decoder *d, orc_dec_frame *out)
 {

@@ -29,6 +29,9 @@ void orc_dec_close(orc_decoder *d);
  * Returns <0 on error/unsupported, 0 when no picture became available, 1 when one did. */
 int orc_dec_decode_nal(orc_decoder *d, const uint8_t *data, size_t len, int64_t pts);
 int orc_dec_get_frame(orc_decoder *d, orc_dec_frame *out);   /* 1 = filled, 0 = none */
+/* decoded picture hash SEI messages (D.2.19: MD5, CRC or checksum, in a suffix SEI NAL unit behind the picture) met so far, and how many
+ * of them did NOT match the picture as decoded here: a stream that carries them verifies itself */
+void orc_dec_hash_stats(orc_decoder *d, int *checked, int *mismatch);
 /* debug: copy of the last picture before deblocking (same geometry as coded picture) */
 const pixel *orc_dec_predeblock_plane(orc_decoder *d, int c);
 #ifdef __cplusplus

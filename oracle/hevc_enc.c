@@ -2,6 +2,7 @@
  * algorithm the HIP path implements (encode half of the hot path,
  * /root/reference/src/media/processing/kvazaarfilter.cpp:374-484). */
 #include "hevc_enc.h"
+#include "hevc_hash.h"
 #include "hevc_bits.h"
 #include "hevc_cabac.h"
 #include "hevc_ps.h"
@@ -1102,11 +1103,31 @@ size_t orc_enc_encode(orc_encoder *e, const pixel *y, const pixel *u, const pixe
     e->intra_count++;
   }
   write_picture(e, write_ps);
+  if (e->cfg.hash) {
+    /* decoded picture hash SEI (D.2.19): suffix SEI NAL unit (type 40) behind the picture's last slice segment; payload type 132, then
+     * hash_type (0 MD5, 2 checksum) and one hash per colour component over the whole decoded picture (coded size, after the loop filters) */
+    const int type = e->cfg.hash == 2 ? 0 : 2, nb = orc_hash_bytes(type);
+    uint8_t hv[3][16];
+    const pixel *pl[3] = { e->cur->plane[0], e->cur->plane[1], e->cur->plane[2] };
+    orc_picture_hash(type, pl, e->cur->stride, e->cw, e->ch, hv);
+    orc_bitw sei; orc_bw_init(&sei);
+    orc_bw_put(&sei, 132, 8); orc_bw_put(&sei, (uint32_t)(1 + 3 * nb), 8); orc_bw_put(&sei, (uint32_t)type, 8);
+    for (int c = 0; c < 3; c++) for (int i = 0; i < nb; i++) orc_bw_put(&sei, hv[c][i], 8);
+    orc_bw_trailing(&sei);
+    orc_write_nal(&e->au, 40, 0, sei.buf, sei.len, 1);
+    orc_bw_free(&sei);
+  }
   e->rc_bytes[e->frame_idx & 7] = (uint32_t)e->au.len;
   e->frame_idx++;
   orc_pic *t = e->cur; e->cur = e->ref; e->ref = t;     /* e->ref now holds the picture just coded */
   *au = e->au.buf;
   return e->au.len;
+}
+
+int orc_enc_set_option(orc_encoder *e, const char *name, int value)
+{
+  if (!strcmp(name, "hash")) { e->cfg.hash = value; return 1; }
+  return 0;
 }
 
 void orc_enc_get_debug(orc_encoder *e, orc_enc_debug *d)

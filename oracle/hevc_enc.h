@@ -62,6 +62,7 @@ typedef struct {
                                * in hevc_enc.c): 0 off (Kvazaar's ultrafast), 1 half-sample positions left/right/above/below, 2 + the four
                                * half-sample diagonals, 3 + quarter-sample left/right/above/below of the best so far, 4 + its quarter-sample
                                * diagonals; candidates are compared by SATD (8x8 Hadamard) + lambda * vector bits */
+  int hash;                   /* kvazaar hash: 0 none, 1 checksum, 2 md5 -- a decoded picture hash SEI (D.2.19, suffix SEI NAL unit) after every picture's slices */
 } orc_enc_config;
 
 typedef struct {
@@ -80,6 +81,8 @@ typedef struct {
 } orc_enc_debug;
 
 void orc_enc_default_config(orc_enc_config *c);
+/* options added after the packed open calls ran out of bits: by name, before the first picture.  "hash" 0/1/2.  Returns 1 when known. */
+int orc_enc_set_option(orc_encoder *e, const char *name, int value);
 orc_encoder *orc_enc_open(const orc_enc_config *c);
 void orc_enc_close(orc_encoder *e);
 /* Encodes one picture given as three packed planes (stride = width, width/2).  The returned

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""tests/golden/make_streams.py -- writes the self-verifying Annex-B streams under tests/golden/streams/ (run on a GPU box:
+`gpurun -- python tests/golden/make_streams.py gpurun_out/streams`, then copy the directory here).
+
+Every stream of the HIP encoder carries a decoded picture hash SEI (hash=md5, H.265 D.2.19) behind each picture, so ANY conforming decoder
+verifies it without this repository: `ffmpeg -i x.hevc -f null -` complains on a mismatch, tools/verify_external.sh also compares the
+per-picture MD5 of the cropped output (`-f framemd5`) with index.json.  The synthesiser's streams (oracle/hevc_gen.c: tools this encoder
+does not use) carry no SEI; index.json holds their pictures' MD5 as the checker decodes them."""
+import hashlib, json, os, sys
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np
+import orc
+
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(R, "tests", "golden", "streams")
+os.makedirs(out, exist_ok=True)
+W, H, N, SEED = 416, 240, 10, 0x5EED0002
+HIP = {   # name: kvz_api options (all with hash=md5)
+    "hip_plain_qp32_p8": (("qp", 32), ("period", 8), ("me-range", 16)),
+    "hip_tiles2x2_qp30": (("qp", 30), ("period", 8), ("me-range", 16), ("tiles", "2x2")),
+    "hip_slices_wpp_qp32": (("qp", 32), ("period", 8), ("me-range", 16), ("slices", "wpp")),
+    "hip_subme4_sao_qp28": (("qp", 28), ("period", 8), ("me-range", 16), ("subme", 4), ("sao", "full")),
+    "hip_rc_400k": (("qp", 32), ("period", 8), ("me-range", 16), ("bitrate", 400000), ("rc-algorithm", "lambda")),
+    "hip_vaq_roi_qp32": (("qp", 32), ("period", 8), ("me-range", 16), ("vaq", 8)),
+}
+index = {}
+if "--no-hip" not in sys.argv:
+    from kvazzup_amd.codec import Encoder
+    for name, opts in HIP.items():
+        br = dict(opts).get("bitrate", 0)
+        e = Encoder(W, H, options=opts, fields={"hash": 2, "target_bitrate": br})
+        assert not e.rejected, (name, e.rejected)
+        od = orc.OracleDecoder()
+        stream, md5s = b"", []
+        for t in range(N):
+            au, rec = e.encode(orc.synth_frame(0, SEED, W, H, t))
+            fr = od.decode_au(au, t)
+            assert len(fr) == 1 and np.array_equal(fr[0]["i420"], rec), (name, t)      # the checker decodes it to the encoder's reconstruction
+            stream += au; md5s.append(hashlib.md5(rec.tobytes()).hexdigest())
+        assert od.hash_stats() == (N, 0), (name, od.hash_stats())                      # ... and finds every hash SEI correct
+        e.close(); od.close()
+        open(os.path.join(out, name + ".hevc"), "wb").write(stream)
+        index[name] = {"width": W, "height": H, "pictures": N, "bytes": len(stream), "hash_sei": "md5", "source": "HIP encoder (kvz_api), options %s" % dict(opts),
+                       "frame_md5": md5s}
+# the synthesiser (CPU): a Kvazaar-shaped stream (lp-g4d3t1-like references, intra CUs in P pictures) and one with every tool switched on
+GEN = {
+    "gen_kvazaar_shaped": dict(seed=9, density=30, intra_period=8, num_refs=3, tmvp=0, amp=0, sao=0, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
+                               qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=0, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0),
+    "gen_everything_on": dict(seed=23, density=30, intra_period=8, num_refs=4, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=1, cabac_init=1, wpp=1, tile_rows=1, tile_cols=1,
+                              qp_delta=2, chroma_qp_offsets=1, deblock_mode=3, intra_in_p=20, all_part_modes=1, chroma_modes=1, nxn_intra=1, slices=0, big_mvd=0),
+}
+for name, cfg in GEN.items():
+    g = orc.OracleGen(W, H, **cfg)
+    od = orc.OracleDecoder()
+    stream, md5s = b"", []
+    for t in range(6):
+        au = g.picture()
+        stream += au
+        for fr in od.decode_au(au, t):
+            md5s.append(hashlib.md5(fr["i420"].tobytes()).hexdigest())
+    g.close(); od.close()
+    assert len(md5s) == 6, (name, len(md5s))
+    open(os.path.join(out, name + ".hevc"), "wb").write(stream)
+    index[name] = {"width": W, "height": H, "pictures": len(md5s), "bytes": len(stream), "hash_sei": None, "source": "oracle/hevc_gen.c (stream synthesiser), %s" % cfg, "frame_md5": md5s}
+json.dump(index, open(os.path.join(out, "index.json"), "w"), indent=1, sort_keys=True)
+print({k: v["bytes"] for k, v in index.items()}, "total", sum(v["bytes"] for v in index.values()))

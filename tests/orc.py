@@ -82,6 +82,12 @@ class OracleEncoder:
             raise RuntimeError("orc_enc_open failed")
         self.buf = np.empty(w * h * 3 + (1 << 20), dtype=np.uint8)
 
+    def set_option(self, name, value):
+        """options by name (oracle/hevc_enc.h orc_enc_set_option): "hash" 0 none / 1 checksum / 2 md5, ..."""
+        lib().orc_enc_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        if not lib().orc_enc_set_option(self.p, name.encode(), int(value)):
+            raise ValueError("oracle encoder: unknown option %s" % name)
+
     def set_roi(self, rw, rh, deltas):
         """delta-QP map (kvz_picture.roi): rw x rh int8 cells over the picture; rw = 0 removes it"""
         a = np.ascontiguousarray(deltas, dtype=np.int8) if rw else np.zeros(1, np.int8)
@@ -153,6 +159,13 @@ class OracleDecoder:
         i420 = np.concatenate([p.reshape(-1) for p in planes])
         return {"i420": i420, "width": f.width, "height": f.height, "poc": f.poc, "pts": f.pts,
                 "fps": (f.fps_num, f.fps_den), "slice_type": f.slice_type}
+
+    def hash_stats(self):
+        """(decoded picture hash SEI messages checked, of which mismatching)"""
+        a, b = C.c_int(), C.c_int()
+        lib().orc_dec_hash_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib().orc_dec_hash_stats(self.p, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def decode_au(self, au, pts=0):
         """feed every NAL of an access unit; returns list of decoded frames"""

@@ -251,12 +251,32 @@ struct InterFracLds {
   alignas(16) int ltmp[4][23 * 16];        // (32-bit on purpose: with int16 entries hipcc 7.2 mis-extends the upper halves of the packed loads)
 };
 
+// Level adjustment ("uvgx RDOQ v1" / sign data hiding, hevc_core.h adjust_group) of a block whose levels lie row-major in lev[n * n] and
+// whose quantiser remainders lie in aux[n * n]: thread `t` of the block's threads takes the coefficient groups t, t + nthreads, ...
+__device__ __forceinline__ void adjust_block_lds(int16_t *lev, const int16_t *aux, int n, int pitch, int scan_idx, int rdoq, int signhide, int t, int nthreads)
+{
+  const int nsb = n >> 2, ngroups = nsb * nsb;
+  for (int gi = t; gi < ngroups; gi += nthreads) {
+    const int xs = gi % nsb, ys = gi / nsb;
+    int16_t lv[16]; uint16_t ax[16]; int at[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int xp = scan_idx == 0 ? kDiag4x[k] : (scan_idx == 1 ? (k & 3) : (k >> 2)), yp = scan_idx == 0 ? kDiag4y[k] : (scan_idx == 1 ? (k >> 2) : (k & 3));
+      at[k] = ((ys << 2) + yp) * pitch + (xs << 2) + xp;
+      lv[k] = lev[at[k]]; ax[k] = (uint16_t)aux[((ys << 2) + yp) * n + (xs << 2) + xp];
+    }
+    adjust_group(lv, ax, gi == 0, rdoq, signhide);
+#pragma unroll
+    for (int k = 0; k < 16; k++) lev[at[k]] = lv[k];
+  }
+}
+
 // The four transform stages of `NTU` blocks of n = 1 << L2 held TU-major in s.A (encoder: residual, row-major;
 // decoder: dequantised levels, transposed), NTU * XF<L2, OPL>::LANES == 256.  Encoder: levels go to `coef`
 // for blocks that have any, *nz gets one bit per block.  Ends with the residual added into s.px.
 //   px_index(tu, y, x) -> index of sample (x, y) of block tu in s.px;  coef_at(tu, y, x) -> its level in the plane
 template <bool DEC, int L2, int OPL, class PX, class CI>
-__device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *nz, PX px_index, CI coef_at, int tid)
+__device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *nz, PX px_index, CI coef_at, int tid, int adj = 0)
 {
   constexpr int N = 1 << L2, G = XF<L2, OPL>::G, LPT = XF<L2, OPL>::LANES;
   const int tu = tid / LPT, l = tid % LPT, rp = l / G, g = l % G;
@@ -269,12 +289,33 @@ __device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *n
     xf_sums<L2, OPL>(B, Mf, rp, g, acc);
     const int shift = L2 + 6, rnd = 1 << (shift - 1);
     bool any = false;
+    if (adj) {
+      // rdoq / signhide (bit 0 / bit 1 of adj): levels and quantiser remainders go to B and A in the block's own layout, a pass over the
+      // 4x4 coefficient groups adjusts the levels (one thread per group), then every thread takes its levels back
+      __syncthreads();                                           // (all threads are done reading B: xf_sums)
+#pragma unroll
+      for (int o = 0; o < OPL; o++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const int c = clip3(-32768, 32767, (acc[e][o] + rnd) >> shift);
+          uint16_t ax;
+          B[(g * OPL + o) * N + 2 * rp + e] = (int16_t)quant_level_aux(c, qp, L2, 0, &ax);
+          A[(g * OPL + o) * N + 2 * rp + e] = (int16_t)ax;
+        }
+      __syncthreads();
+      adjust_block_lds(B, A, N, N, 0, adj & 1, adj & 2, l, LPT);
+      __syncthreads();
+#pragma unroll
+      for (int o = 0; o < OPL; o++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) lv[e][o] = B[(g * OPL + o) * N + 2 * rp + e];
+      __syncthreads();                                           // (A still holds remainders other threads' groups have read: all done now)
+    }
 #pragma unroll
     for (int o = 0; o < OPL; o++)
 #pragma unroll
       for (int e = 0; e < 2; e++) {
-        int c = clip3(-32768, 32767, (acc[e][o] + rnd) >> shift);
-        lv[e][o] = quant_level(c, qp, L2, 0);
+        if (!adj) { int c = clip3(-32768, 32767, (acc[e][o] + rnd) >> shift); lv[e][o] = quant_level(c, qp, L2, 0); }
         any |= lv[e][o] != 0;
         A[(2 * rp + e) * N + g * OPL + o] = (int16_t)dequant_coef(lv[e][o], qp, L2);        // transposed: [column][row]
       }
@@ -305,7 +346,7 @@ __device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *n
 
 // The 32x32 luma block of a 32x32 CU: same contract as inter_transform<DEC, 5, .>
 template <bool DEC>
-__device__ __forceinline__ void inter_transform_32(InterLds &s, int qp, uint32_t *nz, int16_t *coef, int cw, int tid)
+__device__ __forceinline__ void inter_transform_32(InterLds &s, int qp, uint32_t *nz, int16_t *coef, int cw, int tid, int adj = 0)
 {
   const int wave = tid >> 6, lane = tid & 63;
   const int j = (wave & 1) * 16 + (lane & 15), i0 = (wave >> 1) * 16 + (lane >> 4) * 4;   // result column, first of four result rows
@@ -317,10 +358,25 @@ __device__ __forceinline__ void inter_transform_32(InterLds &s, int qp, uint32_t
       int acc[4];
       mfma_tile_sums(s.B, s.M8[0], s.rowsum[0], wave, lane, acc);                          // forward columns: coefficient (row j, columns i0 ..)
       bool any = false;
+      if (adj) {                                                                           // rdoq / signhide: see inter_transform
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int c = clip3(-32768, 32767, (acc[r] + 1024) >> 11);
+          uint16_t ax;
+          s.B[j * 32 + i0 + r] = (int16_t)quant_level_aux(c, qp, 5, 0, &ax);
+          s.A[j * 32 + i0 + r] = (int16_t)ax;
+        }
+        __syncthreads();
+        adjust_block_lds(s.B, s.A, 32, 32, 0, adj & 1, adj & 2, tid, 256);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; r++) lv[r] = s.B[j * 32 + i0 + r];
+        __syncthreads();
+      }
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int c = clip3(-32768, 32767, (acc[r] + 1024) >> 11);
-        lv[r] = quant_level(c, qp, 5, 0);
+        if (!adj) { const int c = clip3(-32768, 32767, (acc[r] + 1024) >> 11); lv[r] = quant_level(c, qp, 5, 0); }
         any |= lv[r] != 0;
         s.A[(i0 + r) * 32 + j] = (int16_t)dequant_coef(lv[r], qp, 5);                      // transposed: [column][row]
       }
@@ -359,6 +415,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FRAC ? 5 : 
   const bool split = f.cu_log2[bi0] == 4;
   const int cw2 = f.cw >> 1, ch2 = f.ch >> 1;
   const int qp = ctu_quant_qp(f, x0, y0), qpc = kChromaQp[qp];       // the 32x32 block lies inside one CTU
+  const int adj = DEC ? 0 : ((f.rdoq ? 1 : 0) | (f.signhide ? 2 : 0));    // level adjustment behind the quantiser (hevc_core.h adjust_group)
   // Decoder: most blocks of an inter picture carry no residual at all -- they skip the matrices, the transform stages and all
   // but two barriers (prediction straight to the picture).  `coded` is uniform over the workgroup.
   const bool coded = DEC ? __syncthreads_or(tid < 16 ? (int)(f.cu_cbf[b8idx(f, x0 + (tid & 3) * 8, y0 + (tid >> 2) * 8)] & 7) : 0) != 0 : true;
@@ -438,8 +495,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FRAC ? 5 : 
     auto px16 = [](int tu, int y, int x) { return ((tu >> 1) * 16 + y) * 32 + (tu & 1) * 16 + x; };
     const int cw = f.cw; int16_t *base = f.coef[0] + (size_t)y0 * cw + x0;
     auto ci16 = [=](int tu, int y, int x) { return base + (size_t)((tu >> 1) * 16 + y) * cw + (tu & 1) * 16 + x; };
-    if (split) inter_transform<DEC, 4, 2>(s, qp, &s.nz[0], px16, ci16, tid);
-    else inter_transform_32<DEC>(s, qp, &s.nz[0], base, cw, tid);
+    if (split) inter_transform<DEC, 4, 2>(s, qp, &s.nz[0], px16, ci16, tid, adj);
+    else inter_transform_32<DEC>(s, qp, &s.nz[0], base, cw, tid, adj);
     *(uint32_t *)&f.rec[0][(size_t)(y0 + (tid >> 3)) * f.cw + x0 + (tid & 7) * 4] = *(const uint32_t *)&s.px[(tid >> 3) * 32 + (tid & 7) * 4];
   }
   // ---- chroma: reference windows of the eight 8x8 sub-blocks (plane x quadrant) -> LDS; mv in 1/8 samples
@@ -495,8 +552,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FRAC ? 5 : 
     int16_t *cb = f.coef[1] + base, *cr = f.coef[2] + base;
     auto ci1 = [=](int tu, int y, int x) { return (tu ? cr : cb) + (size_t)y * cw2 + x; };
     auto ci4 = [=](int tu, int y, int x) { return ((tu >> 2) ? cr : cb) + (size_t)(((tu >> 1) & 1) * 8 + y) * cw2 + (tu & 1) * 8 + x; };
-    if (split) inter_transform<DEC, 3, 1>(s, qpc, &s.nz[1], px4, ci4, tid);
-    else inter_transform<DEC, 4, 1>(s, qpc, &s.nz[1], px1, ci1, tid);
+    if (split) inter_transform<DEC, 3, 1>(s, qpc, &s.nz[1], px4, ci4, tid, adj);
+    else inter_transform<DEC, 4, 1>(s, qpc, &s.nz[1], px1, ci1, tid, adj);
   }
   if (tid < 128) {
     const int pl = tid >> 6, y = (tid >> 2) & 15, x = (tid & 3) * 4;
@@ -767,7 +824,7 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
 // Returns whether the block has non-zero levels.
 template <int L2>
 __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratch &ws, const IntraBlk &d, int cidx, int S, const QuantConst &q,
-                                                 uint8_t *gdst, int gp, int lane, uint32_t *publish)
+                                                 uint8_t *gdst, int gp, int lane, uint32_t *publish, int adj = 0)
 {
   constexpr int N = 1 << L2;
   const int P = 16 + 2 * S, g = lane >> 4, c = lane & 15, rx = d.rx, ry = d.ry;
@@ -790,7 +847,29 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
   mfma16_data_b(ta, y, co);
   PROF(6);
   bool nz = false;
-  if (active) {
+  if (adj) {
+    // rdoq / signhide (bit 0 / bit 1): levels to s.lev, quantiser remainders to the wave's scratch, one lane per 4x4 coefficient group adjusts
+    // the levels (hevc_core.h adjust_group), then every lane takes its levels back -- all inside the wave, no workgroup barrier
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int cf = clip3(-32768, 32767, (co[r] + (1 << (L2 + 5))) >> (L2 + 6));
+        const uint32_t a = (uint32_t)iabs(cf), prod = a * (uint32_t)q.qscale;
+        const int lvm = imin((int)((prod + (uint32_t)q.qoff) >> q.qshift), 32767);
+        const int du = clip3(-256, 511, (int)(prod >> (q.qshift - 8)) - (lvm << 8));
+        s.lev[(ry + 4 * g + r) * S + rx + c] = (int16_t)(cf < 0 ? -lvm : lvm);
+        ws.tr[(4 * g + r) * N + c] = (int16_t)((du + 256) | (cf < 0 ? 0x8000 : 0));
+      }
+    }
+    wave_sync();
+    adjust_block_lds(&s.lev[ry * S + rx], ws.tr, N, S, intra_scan_idx(1, L2, cidx, d.mode), adj & 1, adj & 2, lane, 64);
+    wave_sync();
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) { const int lv = s.lev[(ry + 4 * g + r) * S + rx + c]; nz |= lv != 0; dq[r] = dequant_coef_q(lv, q); }
+    }
+    wave_sync();                                              // (ws.tr is free again for the inverse transform)
+  } else if (active) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int cf = clip3(-32768, 32767, (co[r] + (1 << (L2 + 5))) >> (L2 + 6));
@@ -847,6 +926,7 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   // order, where the right ends of the upper rows would hold the slots the lower left needs.
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wc = f.cw >> 6, c = (int)blockIdx.x % 3, ctu = (int)f.intra_order[blockIdx.x / 3];
   const int row = ctu / wc, cx = ctu % wc;
+  const int adj = (f.rdoq ? 1 : 0) | (f.signhide ? 2 : 0);      // level adjustment behind the quantiser (hevc_core.h adjust_group)
   const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, P = 16 + 2 * S;
   uint32_t *my = f.sync + (size_t)ctu * 3 + c;
   for (int i = tid; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];
@@ -911,9 +991,9 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     first = false;
     bool cbf;
     switch (d.l2) {
-      case 2: cbf = intra_block_wave<2>(s, ws, d, c, S, q8, grec, pw, lane, nullptr); break;
-      case 3: cbf = intra_block_wave<3>(s, ws, d, c, S, c ? q16 : q8, grec, pw, lane, nullptr); break;
-      default: cbf = intra_block_wave<4>(s, ws, d, c, S, q16, grec, pw, lane, nullptr); break;
+      case 2: cbf = intra_block_wave<2>(s, ws, d, c, S, q8, grec, pw, lane, nullptr, adj); break;
+      case 3: cbf = intra_block_wave<3>(s, ws, d, c, S, c ? q16 : q8, grec, pw, lane, nullptr, adj); break;
+      default: cbf = intra_block_wave<4>(s, ws, d, c, S, q16, grec, pw, lane, nullptr, adj); break;
     }
     const uint2 cvu = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)cv.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)cv.y));
     chain_mark_done(ch, cvu, lane);
@@ -1332,7 +1412,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) vo
         int n_l = 0;
         if (lane <= last_sb) {
           TokCount t; t.tabs = &tabs; t.n = 0;
-          enc_subblock(t, dg, lane, last_sb, last_pos, prev_g1, l2, ci, scan);
+          enc_subblock(t, dg, lane, last_sb, last_pos, prev_g1, l2, ci, scan, f.signhide);
           n_l = t.n;
         }
         // offsets in coding order: sub-block last_sb first, then downwards
@@ -1350,7 +1430,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) vo
           for (int i = lane; i < hn; i += 64) dst[i] = hdr[i];
           if (lane <= last_sb && n_l) {                               // pass 2: the same emitters, now writing at the final offsets
             TokOut t; t.tabs = &tabs; t.p = dst + hn + off; t.n = 0; t.cap = n_l;
-            enc_subblock(t, dg, lane, last_sb, last_pos, prev_g1, l2, ci, scan);
+            enc_subblock(t, dg, lane, last_sb, last_pos, prev_g1, l2, ci, scan, f.signhide);
           }
           if (staged) {
             wave_sync();

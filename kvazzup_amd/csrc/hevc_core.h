@@ -19,6 +19,7 @@ KVZ_HD int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v)
 KVZ_HD int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 KVZ_HD int ilog2(unsigned v) { int n = 0; while (v > 1) { v >>= 1; n++; } return n; }
 KVZ_HD int kv_clz32(uint32_t v) { return __builtin_clz(v); }            // v != 0
+KVZ_HD int kv_ctz32(uint32_t v) { return __builtin_ctz(v); }            // v != 0
 
 // ---------------------------------------------------------------------------------------------
 // Frame state shared by all encoder kernels.  All pointers are device memory (or host memory in
@@ -42,6 +43,7 @@ struct EncFrame {
   int satd;                 // intra mode search: SATD (8x8 Hadamard) instead of SAD
   int me_early;             // me-early-termination: blocks that match the co-located reference block to within 64 * lambda_q4 are not searched
   int subme;                // fractional-sample refinement level 0..4 (k_subpel)
+  int rdoq, signhide;       // kvazaar rdoq / signhide: the level-adjustment pass behind the quantiser (adjust_group) and sign_data_hiding_enabled_flag
   int slices;               // 1: a slice segment ends with every CTU row, 2: with every tile (kvazaar slices=wpp / tiles): what k_tokenize closes a CTU with
   int mv_frame;             // mv-constraint: 0 none, 1 the displaced block stays inside the picture, 2 the same with a 4-sample margin on odd displacements
   int tile_rows;            // 1: no tiles; n: n tile rows, uniform spacing (6.5.1)
@@ -524,7 +526,7 @@ KVZ_HD bool subblock_g1_any(const CoreTabs *, const TuDigest &d, int i, int)
 // All syntax elements of sub-block i (coded_sub_block_flag .. coeff_abs_level_remaining).
 // prev_g1: the previous non-empty sub-block in coding order ended with greater1Ctx == 0.
 template <class S>
-KVZ_HD void enc_subblock(S &c, const TuDigest &d, int i, int last_sb, int last_pos, bool prev_g1, int log2, int cidx, int scan_idx)
+KVZ_HD void enc_subblock(S &c, const TuDigest &d, int i, int last_sb, int last_pos, bool prev_g1, int log2, int cidx, int scan_idx, int sign_hiding = 0)
 {
   const int sbl = log2 - 2, nsb = 1 << sbl;
   const CoreTabs *t = c.tabs;
@@ -580,7 +582,10 @@ KVZ_HD void enc_subblock(S &c, const TuDigest &d, int i, int last_sb, int last_p
     }
   }
   if (g1idx >= 0) cabac_bin(c, CTX_GT2 + (cidx ? 4 : 0) + ctx_set, g2);
-  cabac_bypass_bits(c, signs, nsig);
+  // sign_data_hiding (7.3.8.11): the sign of the group's first coefficient in scan order -- the last one collected above -- is not sent
+  // when it lies more than three positions below the group's last one
+  if (sign_hiding && (31 - kv_clz32(m)) - kv_ctz32(m) > 3) cabac_bypass_bits(c, signs >> 1, nsig - 1);
+  else cabac_bypass_bits(c, signs, nsig);
   int rice = 0, j = 0;
   for (uint32_t mm = m; mm; j++) {
     const int k = 31 - kv_clz32(mm); mm ^= 1u << k;
@@ -606,23 +611,23 @@ KVZ_HD void enc_cu_qp_delta(S &c, int d)
 }
 
 template <class S>
-KVZ_HD void enc_residual_digest(S &c, const TuDigest &d, int log2, int cidx, int scan_idx)
+KVZ_HD void enc_residual_digest(S &c, const TuDigest &d, int log2, int cidx, int scan_idx, int sign_hiding = 0)
 {
   int last_sb, last_pos;
   enc_last_pos(c, d, log2, cidx, scan_idx, last_sb, last_pos);
   bool prev_g1 = false;
   for (int i = last_sb; i >= 0; i--) {
-    enc_subblock(c, d, i, last_sb, last_pos, prev_g1, log2, cidx, scan_idx);
+    enc_subblock(c, d, i, last_sb, last_pos, prev_g1, log2, cidx, scan_idx, sign_hiding);
     if (d.mask[i]) prev_g1 = subblock_g1_any(c.tabs, d, i, scan_idx);
   }
 }
 
 template <class S>
-KVZ_HD void enc_residual(S &c, const int16_t *lv, int stride, int log2, int cidx, int scan_idx)
+KVZ_HD void enc_residual(S &c, const int16_t *lv, int stride, int log2, int cidx, int scan_idx, int sign_hiding = 0)
 {
   TuDigest d;
   digest_build_serial(c.tabs, d, lv, stride, log2, scan_idx);
-  enc_residual_digest(c, d, log2, cidx, scan_idx);
+  enc_residual_digest(c, d, log2, cidx, scan_idx, sign_hiding);
 }
 
 KVZ_HD int intra_scan_idx(int intra, int log2, int cidx, int mode)
@@ -778,10 +783,10 @@ KVZ_HD void enc_ctu(const EncFrame &f, CabacEnc &c, int cx, int cy)
     CuRec cu = v.at(x0, y0);
     enc_split_flags(v, c, f.cw, f.chp, x0, y0, z, cu.log2);
     int cbf = enc_cu_header(v, c, f.cw, f.chp, f.is_intra != 0, x0, y0, cu);
-    if (cbf & 1) enc_residual(c, f.coef[0] + y0 * f.cw + x0, f.cw, cu.log2, 0, intra_scan_idx(cu.intra, cu.log2, 0, cu.intra_mode));
+    if (cbf & 1) enc_residual(c, f.coef[0] + y0 * f.cw + x0, f.cw, cu.log2, 0, intra_scan_idx(cu.intra, cu.log2, 0, cu.intra_mode), f.signhide);
     for (int ci = 1; ci <= 2; ci++)
       if ((cbf >> ci) & 1)
-        enc_residual(c, f.coef[ci] + (y0 >> 1) * (f.cw >> 1) + (x0 >> 1), f.cw >> 1, cu.log2 - 1, ci, intra_scan_idx(cu.intra, cu.log2 - 1, ci, cu.intra_mode));
+        enc_residual(c, f.coef[ci] + (y0 >> 1) * (f.cw >> 1) + (x0 >> 1), f.cw >> 1, cu.log2 - 1, ci, intra_scan_idx(cu.intra, cu.log2 - 1, ci, cu.intra_mode), f.signhide);
     z += 1 << (2 * (cu.log2 - 3));
   }
 }
@@ -1030,6 +1035,57 @@ KVZ_HD int quant_level(int coef, int qp, int log2n, int intra)
   if (q > 32767) q = 32767;
   return (int)(coef < 0 ? -q : q);
 }
+// The quantiser with what the level-adjustment pass needs beside the level: aux = 256 + du in bits 0..9 -- du = the part of the coefficient
+// the level does not account for, in 1/256 quantiser steps -- and bit 15 = the coefficient is negative (statement: oracle/hevc_transform.h)
+KVZ_HD int quant_level_aux(int coef, int qp, int log2n, int intra, uint16_t *aux)
+{
+  int shift = 14 + qp / 6 + (15 - 8 - log2n);
+  int64_t off = (int64_t)(intra ? 171 : 85) << (shift - 9);
+  int a = coef < 0 ? -coef : coef;
+  int64_t prod = (int64_t)a * kQuantScale[qp % 6];
+  int64_t q = (prod + off) >> shift;
+  if (q > 32767) q = 32767;
+  int64_t du = (prod >> (shift - 8)) - (q << 8);
+  if (du < -256) du = -256;
+  if (du > 511) du = 511;
+  *aux = (uint16_t)((du + 256) | (coef < 0 ? 0x8000 : 0));
+  return (int)(coef < 0 ? -q : q);
+}
+
+// "uvgx RDOQ v1" and sign data hiding on ONE 4x4 coefficient group (statement of record: orc_adjust_levels, oracle/hevc_transform.h): lv[k], aux[k]
+// = level and quantiser remainder at scan position k of the group, dc_group = it is the block's first group.  Returns the non-zero levels left.
+KVZ_HD int adjust_group(int16_t (&lv)[16], const uint16_t (&aux)[16], bool dc_group, int rdoq, int signhide)
+{
+  int nz = 0; bool ones = true;
+  for (int k = 0; k < 16; k++) if (lv[k]) { nz++; if (lv[k] != 1 && lv[k] != -1) ones = false; }
+  if (rdoq && !dc_group && nz >= 1 && nz <= 2 && ones) {
+    int benefit = 0;
+    for (int k = 0; k < 16; k++) if (lv[k]) benefit += 2 * (int)(aux[k] & 0x3ff) - 256;      // 2 u - 256, u = du + 256
+    if (benefit < 92 * nz + 92) { for (int k = 0; k < 16; k++) lv[k] = 0; nz = 0; }
+  }
+  if (signhide && nz >= 2) {
+    int first = -1, last = -1, sum = 0;
+    for (int k = 0; k < 16; k++) if (lv[k]) { if (first < 0) first = k; last = k; sum += lv[k] < 0 ? -lv[k] : lv[k]; }
+    if (last - first >= 4 && (sum & 1) != (lv[first] < 0 ? 1 : 0)) {
+      int best = -1, best_cost = 1 << 30, best_change = 0;
+      for (int k = 15; k >= 0; k--) {
+        const int a = lv[k] < 0 ? -lv[k] : lv[k], du = (int)(aux[k] & 0x3ff) - 256;
+        int up, down; bool ok_up, ok_down;
+        if (a) { ok_up = a < 32767; up = 256 - 2 * du + 23; ok_down = !(a == 1 && (k == first || k == last)); down = 256 + 2 * du - (a == 1 ? 69 : 23); }
+        else { ok_up = k > first; up = 256 - 2 * du + 80; ok_down = false; down = 0; }
+        if (ok_up && up < best_cost) { best_cost = up; best = k; best_change = 1; }
+        if (ok_down && down < best_cost) { best_cost = down; best = k; best_change = -1; }
+      }
+      if (best >= 0) {
+        const int a = lv[best] < 0 ? -lv[best] : lv[best];
+        if (a == 0) { lv[best] = (int16_t)((aux[best] >> 15) ? -1 : 1); nz++; }
+        else { const int na = a + best_change; lv[best] = (int16_t)(lv[best] < 0 ? -na : na); if (na == 0) nz--; }
+      }
+    }
+  }
+  return nz;
+}
+
 KVZ_HD int dequant_coef(int level, int qp, int log2n)
 {
   int bd = 8 + log2n - 5;

@@ -31,6 +31,7 @@ struct StreamParams {
   int tile_rows = 1;        // tile_rows * tile_cols > 1: tiles_enabled_flag, uniform spacing, loop filter across tiles on
   int tile_cols = 1;
   int sao = 0;              // sample_adaptive_offset_enabled_flag; every slice: slice_sao_luma_flag = slice_sao_chroma_flag = 1
+  int signhide = 0;         // sign_data_hiding_enabled_flag
   int slices = 0;           // kvazaar slices: 1 = "wpp", a dependent slice segment per CTU row (dependent_slice_segments_enabled_flag); 2 = "tiles", a slice per tile
 };
 
@@ -86,7 +87,7 @@ inline void write_sps(BitWriter &w, const StreamParams &s)
 inline void write_pps(BitWriter &w, const StreamParams &s)
 {
   w.ue(0); w.ue(0);
-  w.bit(s.slices == 1); w.bit(0); w.put(0, 3); w.bit(0); w.bit(0);   // dependent_slice_segments_enabled_flag, output_flag_present, extra header bits, sign hiding, cabac_init_present
+  w.bit(s.slices == 1); w.bit(0); w.put(0, 3); w.bit(s.signhide != 0); w.bit(0);   // dependent_slice_segments_enabled_flag, output_flag_present, extra header bits, sign_data_hiding_enabled_flag, cabac_init_present
   w.ue(0); w.ue(0);
   w.se(s.qp - 26);
   w.bit(0); w.bit(0); w.bit(s.qp_in_cu != 0);                    // constrained intra, transform skip, cu_qp_delta

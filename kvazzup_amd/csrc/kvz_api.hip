@@ -76,9 +76,11 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
     // One GPU tool set serves every preset; what the presets above ultrafast add from it is SAO and the fractional-sample
     // motion refinement (Kvazaar's preset table, as recalled in SURVEY.md appendix A: sao off and subme 0 at ultrafast only;
     // subme 2 at superfast / veryfast, 4 from faster on).  Later options ("sao", "subme") override, as in Kvazaar.
+    // rdoq from medium on, signhide from slow on (as recalled from Kvazaar's table, which ties both to its slower presets)
     for (int i = 0; i < 10; i++) if (!strcmp(value, presets[i])) {
       cfg->sao_type = i ? KVZ_SAO_FULL : KVZ_SAO_OFF;
       cfg->fme_level = i == 0 ? 0 : (i <= 2 ? 2 : 4);
+      cfg->rdoq_enable = i >= 5; cfg->signhide_enable = i >= 6;
       return 1;
     }
     return 0;
@@ -163,8 +165,8 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
     return 0;
   }
   INT_OPT("subme", fme_level, 0, 4)
-  INT_OPT("rd", rdo, 0, 3)
-  INT_OPT("ref", ref_frames, 1, 15)
+  INT_OPT("rd", rdo, 0, 1)                       // (0 / 1: decisions by SAD / SATD as here; the full-RDO levels 2 and 3 are rejected)
+  INT_OPT("ref", ref_frames, 1, 1)               // (one reference picture)
   INT_OPT("max-merge", max_merge, 1, 5)
   INT_OPT("me-steps", me_max_steps, -1, 1 << 20)
   INT_OPT("fast-residual-cost", fast_residual_cost_limit, 0, 51)
@@ -179,11 +181,16 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
   }
   INT_OPT("band-row0", band_row0, 0, 4096)
   INT_OPT("band-rows", band_rows, 0, 4096)
-  BOOL_OPT("rdoq", rdoq_enable) BOOL_OPT("signhide", signhide_enable) BOOL_OPT("smp", smp_enable) BOOL_OPT("amp", amp_enable)
-  BOOL_OPT("bipred", bipred) BOOL_OPT("tmvp", tmvp_enable) BOOL_OPT("transform-skip", trskip_enable)
-  BOOL_OPT("full-intra-search", full_intra_search) BOOL_OPT("mv-rdo", mv_rdo) BOOL_OPT("rdoq-skip", rdoq_skip)
-  BOOL_OPT("early-skip", early_skip) BOOL_OPT("intra-rdo-et", intra_rdo_et) BOOL_OPT("lossless", lossless)
-  BOOL_OPT("set-qp-in-cu", set_qp_in_cu) BOOL_OPT("psnr", calc_psnr) BOOL_OPT("cpuid", cpuid) BOOL_OPT("implicit-rdpcm", implicit_rdpcm)
+  BOOL_OPT("rdoq", rdoq_enable) BOOL_OPT("signhide", signhide_enable)
+  // Tools this encoder does not have: switching one ON is rejected -- config_parse's return value is all uvgComm's custom-parameter list
+  // reports back (kvazaarfilter.cpp:363-367) --, switching it off is accepted.
+#define OFF_ONLY(key, field) if (n == key) { if (!parse_bool(value, &iv)) return 0; cfg->field = 0; return iv ? 0 : 1; }
+  OFF_ONLY("smp", smp_enable) OFF_ONLY("amp", amp_enable) OFF_ONLY("bipred", bipred) OFF_ONLY("tmvp", tmvp_enable) OFF_ONLY("transform-skip", trskip_enable)
+  OFF_ONLY("full-intra-search", full_intra_search) OFF_ONLY("mv-rdo", mv_rdo) OFF_ONLY("implicit-rdpcm", implicit_rdpcm) OFF_ONLY("intra-rdo-et", intra_rdo_et)
+  OFF_ONLY("lossless", lossless)
+#undef OFF_ONLY
+  BOOL_OPT("rdoq-skip", rdoq_skip) BOOL_OPT("early-skip", early_skip)       // (recorded: the zero-out of "uvgx RDOQ v1" and the skip decision do not depend on them)
+  BOOL_OPT("set-qp-in-cu", set_qp_in_cu) BOOL_OPT("psnr", calc_psnr) BOOL_OPT("cpuid", cpuid)
   if (n == "cu-split-termination") { cfg->cu_split_termination = !strcmp(value, "off"); return (!strcmp(value, "zero") || !strcmp(value, "off")) ? 1 : 0; }
   if (n == "intra-satd") return parse_bool(value, &cfg->intra_satd);
   if (n == "gpu-entropy") return parse_bool(value, &cfg->gpu_entropy);
@@ -302,6 +309,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.subme = cfg->fme_level < 0 ? 0 : (cfg->fme_level > 4 ? 4 : cfg->fme_level);
   ec.entropy_gpu = cfg->gpu_entropy != 0;
   ec.input_hold = cfg->input_hold != 0;
+  ec.rdoq = cfg->rdoq_enable != 0; ec.signhide = cfg->signhide_enable != 0;
   ec.hash = cfg->hash == KVZ_HASH_MD5 ? 2 : (cfg->hash == KVZ_HASH_CHECKSUM ? 1 : 0);
   ec.vaq = cfg->vaq > 0 ? cfg->vaq : 0;
   ec.qp_in_cu = (cfg->set_qp_in_cu || ec.vaq > 0) ? 1 : 0;
@@ -344,7 +352,8 @@ int encoder_headers(kvz_encoder *e, kvz_data_chunk **data_out, uint32_t *len_out
   kvzx::StreamParams sp;
   const EncoderConfig &c = e->impl->config();
   sp.cw = e->impl->coded_width(); sp.ch = e->impl->coded_height(); sp.width = c.width; sp.height = c.height; sp.qp = c.qp;
-  sp.wpp = c.wpp; sp.deblock = c.deblock; sp.fps_num = c.fps_num; sp.fps_den = c.fps_den; sp.tile_rows = c.tile_rows; sp.qp_in_cu = c.qp_in_cu;
+  sp.wpp = c.wpp; sp.deblock = c.deblock; sp.fps_num = c.fps_num; sp.fps_den = c.fps_den; sp.tile_rows = c.tile_rows; sp.tile_cols = c.tile_cols; sp.qp_in_cu = c.qp_in_cu;
+  sp.sao = c.sao; sp.slices = c.slices; sp.signhide = c.signhide;
   std::vector<uint8_t> out;
   kvzx::BitWriter a, b, d;
   kvzx::write_vps(a, sp); kvzx::append_nal(out, 32, a.data().data(), a.data().size());
@@ -512,6 +521,7 @@ int kvzx_assemble_access_unit(const kvz_config *cfg, int idr, int poc, int write
   sp.qp = cfg->qp; sp.wpp = cfg->wpp ? 1 : 0; sp.deblock = cfg->deblock_enable ? 1 : 0; sp.fps_num = cfg->framerate_num; sp.fps_den = cfg->framerate_denom;
   sp.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1; sp.tile_cols = 1; sp.qp_in_cu = (cfg->set_qp_in_cu || cfg->vaq > 0) ? 1 : 0;
   sp.slices = (cfg->slices == KVZ_SLICES_WPP && cfg->wpp) ? 1 : ((cfg->slices == KVZ_SLICES_TILES && sp.tile_rows > 1) ? 2 : 0);
+  sp.signhide = cfg->signhide_enable != 0;
   if (nsub != (sp.wpp ? sp.ch / 64 : sp.tile_rows)) return 0;
   std::vector<std::vector<uint8_t>> rows((size_t)nsub);
   size_t o = 0;

@@ -214,7 +214,8 @@ static void mark_cu(orc_encoder *e, int x0, int y0, int log2, int pred_mode)
 /* residual -> levels (stored plane-shaped) -> reconstruction.  Returns cbf. */
 static int ctu_target_qp(const orc_encoder *e, int x_luma, int y_luma) { return e->ctu_qt[(y_luma >> 6) * (e->cw / 64) + (x_luma >> 6)]; }
 
-static int code_block(orc_encoder *e, int cidx, int x0, int y0, int n, int qp, int intra)
+static int scan_idx_for(int intra, int log2, int cidx, int mode);
+static int code_block(orc_encoder *e, int cidx, int x0, int y0, int n, int qp, int intra, int scan_idx)
 {
   orc_pic *p = e->cur;
   int stride = p->stride[cidx];
@@ -223,7 +224,12 @@ static int code_block(orc_encoder *e, int cidx, int x0, int y0, int n, int qp, i
   int16_t res[32 * 32], cf[32 * 32], lv[32 * 32];
   for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) res[y * n + x] = (int16_t)(src[y * stride + x] - rec[y * stride + x]);
   orc_fwd_transform(res, cf, n, 0);
-  int nz = orc_quant(cf, lv, n, qp, intra);
+  int nz;
+  if (e->cfg.rdoq || e->cfg.signhide) {                        /* "uvgx RDOQ v1" / sign data hiding: a pass over the levels (hevc_transform.h) */
+    uint16_t aux[32 * 32];
+    orc_quant_aux(cf, lv, aux, n, qp, intra);
+    nz = orc_adjust_levels(lv, aux, n, scan_idx, e->cfg.rdoq, e->cfg.signhide);
+  } else nz = orc_quant(cf, lv, n, qp, intra);
   int16_t *cp = e->coef[cidx] + y0 * stride + x0;
   for (int y = 0; y < n; y++) memcpy(cp + y * stride, lv + y * n, sizeof(int16_t) * (size_t)n);
   if (nz) {
@@ -336,13 +342,13 @@ static void intra_recon_cu(orc_encoder *e, int x0, int y0, int log2)
   fill_b4(p, p->intra_mode, x0, y0, n, mode);
   orc_intra_refs(&e->av, p->plane[0], p->stride[0], 0, x0, y0, n, left, top);
   orc_intra_predict(left, top, n, 0, mode, 1, p->plane[0] + y0 * p->stride[0] + x0, p->stride[0]);
-  int cbf = code_block(e, 0, x0, y0, n, qpl, 1);
+  int cbf = code_block(e, 0, x0, y0, n, qpl, 1, scan_idx_for(1, log2, 0, mode));
   fill_b4(p, p->tu_nz, x0, y0, n, cbf);
   for (int c = 1; c <= 2; c++) {
     int cx = x0 / 2, cy = y0 / 2, cn = n / 2;
     orc_intra_refs(&e->av, p->plane[c], p->stride[c], c, cx, cy, cn, left, top);
     orc_intra_predict(left, top, cn, c, mode, 1, p->plane[c] + cy * p->stride[c] + cx, p->stride[c]);
-    cbf |= code_block(e, c, cx, cy, cn, qpc, 1) << c;
+    cbf |= code_block(e, c, cx, cy, cn, qpc, 1, scan_idx_for(1, log2 - 1, c, mode)) << c;
   }
   set_cu(e, e->cu_cbf, x0, y0, n, cbf);
   set_cu(e, e->cu_intra, x0, y0, n, 1);
@@ -536,13 +542,13 @@ static void inter_recon_cu(orc_encoder *e, int x0, int y0, int log2)
   }
   orc_mc_luma(r->plane[0], r->stride[0], r->w, r->h, x0, y0, n, n, mv[0], mv[1], tmp, 32);
   orc_pred_uni(tmp, 32, p->plane[0] + y0 * p->stride[0] + x0, p->stride[0], n, n);
-  int cbf = code_block(e, 0, x0, y0, n, ctu_target_qp(e, x0, y0), 0);
+  int cbf = code_block(e, 0, x0, y0, n, ctu_target_qp(e, x0, y0), 0, 0);
   fill_b4(p, p->tu_nz, x0, y0, n, cbf);
   for (int c = 1; c <= 2; c++) {
     int cx = x0 / 2, cy = y0 / 2, cn = n / 2;
     orc_mc_chroma(r->plane[c], r->stride[c], r->w / 2, r->h / 2, cx, cy, cn, cn, mv[0], mv[1], tmp, 32);
     orc_pred_uni(tmp, 32, p->plane[c] + cy * p->stride[c] + cx, p->stride[c], cn, cn);
-    cbf |= code_block(e, c, cx, cy, cn, qpc, 0) << c;
+    cbf |= code_block(e, c, cx, cy, cn, qpc, 0, 0) << c;
   }
   set_cu(e, e->cu_cbf, x0, y0, n, cbf);
   set_cu(e, e->cu_intra, x0, y0, n, 0);
@@ -682,7 +688,7 @@ static void enc_abs_remaining(orc_cabac_enc *c, int v, int rice)
 static const uint8_t ctx_idx_map_4x4[16] = { 0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8 };
 
 /* 7.3.8.11 residual_coding for a block with at least one non-zero level; lv is plane-shaped */
-static void enc_residual(orc_cabac_enc *c, const int16_t *lv, int stride, int log2, int cidx, int scan_idx)
+static void enc_residual(orc_cabac_enc *c, const int16_t *lv, int stride, int log2, int cidx, int scan_idx, int sign_hiding)
 {
   int sb_log2 = log2 - 2, nsb = 1 << sb_log2;
   const uint8_t *sbx = orc_scan_x[scan_idx][sb_log2], *sby = orc_scan_y[scan_idx][sb_log2];
@@ -751,7 +757,12 @@ static void enc_residual(orc_cabac_enc *c, const int16_t *lv, int stride, int lo
       }
     }
     if (last_g1_pos != -1) orc_cenc_bin(c, CTX_GT2 + (cidx ? 4 : 0) + ctx_set, orc_abs(v[last_g1_pos]) > 2);
-    for (int k = 15; k >= 0; k--) if (v[k]) orc_cenc_bypass(c, v[k] < 0);      /* sign_data_hiding off */
+    /* sign_data_hiding (7.3.8.11): the sign of the group's first coefficient in scan order is not sent when it lies more than three
+     * positions below the last one (in the block's last group: below the last significant position) */
+    int first_sig = 16, last_sig = -1;
+    for (int k = 0; k < 16; k++) if (v[k]) { if (first_sig == 16) first_sig = k; last_sig = k; }
+    const int hidden = sign_hiding && last_sig - first_sig > 3;
+    for (int k = 15; k >= 0; k--) if (v[k] && !(hidden && k == first_sig)) orc_cenc_bypass(c, v[k] < 0);
     int num_sig = 0, rice = 0;
     for (int k = 15; k >= 0; k--) if (v[k]) {
       int a = orc_abs(v[k]);
@@ -869,10 +880,10 @@ static void enc_cu(orc_encoder *e, orc_cabac_enc *c, int x0, int y0, int log2)
       if (a) orc_cenc_bypass(c, d < 0);
     }
   }
-  if (cbf & 1) enc_residual(c, e->coef[0] + y0 * e->cw + x0, e->cw, log2, 0, scan_idx_for(intra, log2, 0, mode));
+  if (cbf & 1) enc_residual(c, e->coef[0] + y0 * e->cw + x0, e->cw, log2, 0, scan_idx_for(intra, log2, 0, mode), e->cfg.signhide);
   for (int ci = 1; ci <= 2; ci++)
     if ((cbf >> ci) & 1)
-      enc_residual(c, e->coef[ci] + (y0 / 2) * (e->cw / 2) + x0 / 2, e->cw / 2, log2 - 1, ci, scan_idx_for(intra, log2 - 1, ci, mode));
+      enc_residual(c, e->coef[ci] + (y0 / 2) * (e->cw / 2) + x0 / 2, e->cw / 2, log2 - 1, ci, scan_idx_for(intra, log2 - 1, ci, mode), e->cfg.signhide);
   (void)n;
 }
 
@@ -1127,6 +1138,8 @@ size_t orc_enc_encode(orc_encoder *e, const pixel *y, const pixel *u, const pixe
 int orc_enc_set_option(orc_encoder *e, const char *name, int value)
 {
   if (!strcmp(name, "hash")) { e->cfg.hash = value; return 1; }
+  if (!strcmp(name, "rdoq")) { e->cfg.rdoq = value != 0; return 1; }
+  if (!strcmp(name, "signhide")) { e->cfg.signhide = value != 0; e->pps.sign_data_hiding = e->cfg.signhide; return 1; }
   return 0;
 }
 

@@ -68,6 +68,72 @@ int orc_quant(const int16_t *coeff, int16_t *level, int n, int qp, int intra)
   return nz;
 }
 
+int orc_quant_aux(const int16_t *coeff, int16_t *level, uint16_t *aux, int n, int qp, int intra)
+{
+  int l2 = orc_log2((unsigned)n);
+  int shift = 14 + qp / 6 + (15 - 8 - l2);
+  int64_t off = (int64_t)(intra ? 171 : 85) << (shift - 9);
+  int f = orc_quant_scale[qp % 6], nz = 0;
+  for (int i = 0; i < n * n; i++) {
+    int c = coeff[i], a = c < 0 ? -c : c;
+    int64_t q = ((int64_t)a * f + off) >> shift;
+    if (q > 32767) q = 32767;
+    int64_t du = (((int64_t)a * f) >> (shift - 8)) - (q << 8);
+    if (du < -256) du = -256;
+    if (du > 511) du = 511;
+    level[i] = (int16_t)(c < 0 ? -q : q);
+    aux[i] = (uint16_t)((du + 256) | (c < 0 ? 0x8000 : 0));
+    nz += (q != 0);
+  }
+  return nz;
+}
+
+int orc_adjust_levels(int16_t *level, const uint16_t *aux, int n, int scan_idx, int rdoq, int signhide)
+{
+  const int nsb = n >> 2;
+  const uint8_t *px = orc_scan_x[scan_idx][2], *py = orc_scan_y[scan_idx][2];
+  int nz_total = 0;
+  for (int ys = 0; ys < nsb; ys++) for (int xs = 0; xs < nsb; xs++) {
+    int16_t *lv[16]; int du[16], neg[16], nz = 0, ones = 1;
+    for (int k = 0; k < 16; k++) {
+      const int i = ((ys << 2) + py[k]) * n + (xs << 2) + px[k];
+      lv[k] = &level[i]; du[k] = (int)(aux[i] & 0x3ff) - 256; neg[k] = aux[i] >> 15;
+      if (*lv[k]) { nz++; if (*lv[k] != 1 && *lv[k] != -1) ones = 0; }
+    }
+    if (rdoq && (xs | ys) && nz >= 1 && nz <= 2 && ones) {
+      int benefit = 0;
+      for (int k = 0; k < 16; k++) if (*lv[k]) benefit += 2 * (du[k] + 256) - 256;
+      if (benefit < 92 * nz + 92) { for (int k = 0; k < 16; k++) *lv[k] = 0; nz = 0; }
+    }
+    if (signhide && nz >= 2) {
+      int first = -1, last = -1, sum = 0;
+      for (int k = 0; k < 16; k++) if (*lv[k]) { if (first < 0) first = k; last = k; sum += orc_abs(*lv[k]); }
+      if (last - first >= 4 && (sum & 1) != (*lv[first] < 0)) {
+        /* what moving one level by one costs: the change of the squared error in 1/256 step^2 (the level is off by d = du / 256 steps:
+         * up 1 - 2 d, down 1 + 2 d) plus lambda times the bins gained or lost, lambda / step^2 = 0.09: one bin for a step between
+         * non-zero magnitudes (23), three for a +-1 that goes (69), three and a half for one that appears (80) */
+        int best = -1, best_cost = 1 << 30, best_change = 0;
+        for (int k = 15; k >= 0; k--) {
+          const int a = orc_abs(*lv[k]);
+          int cost[2], ok[2];                               /* [0] up, [1] down */
+          if (a) {
+            ok[0] = a < 32767; cost[0] = 256 - 2 * du[k] + 23;
+            ok[1] = !(a == 1 && (k == first || k == last)); cost[1] = 256 + 2 * du[k] - (a == 1 ? 69 : 23);
+          } else { ok[0] = k > first; cost[0] = 256 - 2 * du[k] + 80; ok[1] = 0; cost[1] = 0; }
+          for (int o = 0; o < 2; o++) if (ok[o] && cost[o] < best_cost) { best_cost = cost[o]; best = k; best_change = o ? -1 : 1; }
+        }
+        if (best >= 0) {
+          const int a = orc_abs(*lv[best]);
+          if (a == 0) { *lv[best] = (int16_t)(neg[best] ? -1 : 1); nz++; }
+          else { const int na = a + best_change; *lv[best] = (int16_t)(*lv[best] < 0 ? -na : na); if (na == 0) nz--; }
+        }
+      }
+    }
+    nz_total += nz;
+  }
+  return nz_total;
+}
+
 /* H.265 8.6.3 with m = 16 (scaling_list_enabled_flag == 0): bdShift = BitDepth + log2N - 5 */
 void orc_dequant(const int16_t *level, int16_t *coeff, int n, int qp)
 {

@@ -457,3 +457,52 @@ def test_reopened_instances_reuse_streams_and_code_identically(gpu):
         else:
             assert aus == first[0]
             assert all(np.array_equal(a, b) for a, b in zip(pics, first[1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(w=416, h=240, qp=30, period=4, rdoq=1, signhide=1, frames=8, kind=0),
+    dict(w=416, h=240, qp=24, period=64, rdoq=0, signhide=1, frames=6, kind=0),                 # sign hiding alone, mostly P pictures
+    dict(w=416, h=240, qp=34, period=1, rdoq=1, signhide=0, frames=3, kind=0),                  # the zero-out alone, all intra (horizontal / vertical scans in 8x8 blocks)
+    dict(w=320, h=192, qp=22, period=2, rdoq=1, signhide=1, frames=4, kind=2),                  # noise: every coefficient group busy, big levels
+    dict(w=640, h=368, qp=30, period=8, rdoq=1, signhide=1, frames=6, kind=0, subme=4, sao=1, tiles="2x2"),
+    dict(w=1920, h=1080, qp=32, period=64, rdoq=1, signhide=1, frames=3, kind=0),               # BASELINE configs[1] size: 32x32 transforms on the matrix cores
+])
+def test_rdoq_and_sign_hiding_match_oracle(gpu, cfg):
+    """kvazaar rdoq / signhide (row f4): "uvgx RDOQ v1" and sign data hiding in the quantiser epilogue of k_inter_recon / k_intra_recon, the hidden
+    sign left out by the tokenizer, sign_data_hiding_enabled_flag in the PPS -- access units and reconstruction equal the checker's, and both
+    decoders (which derive the hidden signs from the parities) return the reconstruction"""
+    from kvazzup_amd.codec import Decoder, Encoder
+    w, h = cfg["w"], cfg["h"]
+    tiles = cfg.get("tiles", "1x1"); tc, tr = [int(v) for v in tiles.split("x")]
+    oe = orc.OracleEncoder(w, h, qp=cfg["qp"], period=cfg["period"], me_range=8, subme=cfg.get("subme", 0), sao=cfg.get("sao", 0), tile_rows=tr, tile_cols=tc)
+    oe.set_option("rdoq", cfg["rdoq"]); oe.set_option("signhide", cfg["signhide"])
+    ge = Encoder(w, h, options=(("qp", cfg["qp"]), ("period", cfg["period"]), ("me-range", 8), ("rdoq", cfg["rdoq"]), ("signhide", cfg["signhide"]),
+                                ("subme", cfg.get("subme", 0)), ("sao", "full" if cfg.get("sao") else "off")) + ((("tiles", tiles),) if tiles != "1x1" else ()))
+    assert not ge.rejected, ge.rejected
+    gd = Decoder(); od = orc.OracleDecoder()
+    for t in range(cfg["frames"]):
+        frame = orc.synth_frame(cfg["kind"], SEED, w, h, t)
+        au, rec = ge.encode(frame)
+        want = oe.encode(frame)
+        assert au == want, (t, len(au), len(want), _diagnose(oe.debug(), ge.debug_all()))
+        assert np.array_equal(rec, oe.recon()), t
+        got = gd.decode_au(au, t); ref = od.decode_au(au, t)
+        assert len(got) == 1 and np.array_equal(got[0]["i420"], rec), t
+        assert len(ref) == 1 and np.array_equal(ref[0]["i420"], rec), t
+    for x in (ge, gd, oe, od):
+        x.close()
+
+
+@pytest.mark.gpu
+def test_presets_switch_rdoq_and_sign_hiding_on(gpu):
+    """preset medium and above: rdoq; slow and above: signhide too (config_parse), and the stream says so in its PPS"""
+    from kvazzup_amd.codec import Encoder
+    for preset, rd, sh in (("ultrafast", 0, 0), ("fast", 0, 0), ("medium", 1, 0), ("slow", 1, 1), ("placebo", 1, 1)):
+        e = Encoder(256, 128, options=(("preset", preset),))
+        assert (e.cfg.contents.rdoq_enable, e.cfg.contents.signhide_enable) == (rd, sh), preset
+        e.close()
+    # tools that do not exist are refused when switched on, accepted when switched off (kvazaarfilter.cpp:363-367 logs the refusal)
+    e = Encoder(256, 128, options=(("amp", 1), ("smp", 0), ("bipred", 1), ("tmvp", 0), ("rd", 2), ("ref", 3), ("mv-rdo", 1), ("full-intra-search", 0)))
+    assert sorted(e.rejected) == ["amp", "bipred", "mv-rdo", "rd", "ref"], e.rejected
+    e.close()

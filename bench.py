@@ -559,6 +559,63 @@ def run_stream(args, wl, steps, warmup, ranks, rank, world, quality, host_io=Fal
     return out
 
 
+def multi_stream(args, wl, K, steps, ranks):
+    """K independent streams (a K-party call) on ONE GPU at the same time, each through its own KvazaarFilter' -> WireAdapter -> OpenHEVCFilter' chain
+    (own encoder, decoder, HIP streams, host threads): what the GPU sustains when it is not waiting for one stream's chain of dependent kernels.
+    The host side is divided between the streams (decoder frame threads, coder threads).  Returns the aggregate frames/s and each stream's."""
+    import threading
+    from kvazzup_amd.pipeline import Pipeline
+    w, h = wl["w"], wl["h"]
+    budget = float(os.environ.get("KVAZZUP_BENCH_CPU_BUDGET", 0)) or cpu_budget(1)
+    D = max(2, min(24, int(budget * 0.9 / K)))
+    threads = max(2, min(16, int(budget * 0.5 / K)))
+    clips = [DeviceClip(ranks.lib, ranks.dev_index, stream_seed(wl["cfg_index"], k), w, h, PERIOD) for k in range(K)]
+    pls = [Pipeline(w, h, settings={"video/QP": 32, "video/Intra": PERIOD, "video/VPS": 1, "uvgx/gpu": ranks.dev_index, "uvgx/decoderDownload": 0, "video/kvzThreads": threads,
+                                    "video/OWF": args.owf, "video/OPENHEVC_threads": D, "video/OH_parallelization": "Frame"},
+                    custom=(("me-range", args.me_range), ("gpu", ranks.dev_index), ("input-hold", "1")), loopback=True, keep_outputs=False) for _ in range(K)]
+    gate = threading.Barrier(K + 1)
+    elapsed = [0.0] * K
+
+    def body(k):
+        pl, clip = pls[k], clips[k].ptr
+
+        def run(npic):
+            last = pl.pushed + npic
+            while pl.pushed < last:
+                if not pl.push_device_paced(clip[pl.pushed % PERIOD], 6, 120000):
+                    raise RuntimeError("pipeline stalled")
+            pl.flush()
+            if not pl.wait(last, 120000):
+                raise RuntimeError("pipeline did not deliver")
+        run(PERIOD)                                     # warm-up: one period
+        gate.wait()
+        t0 = time.perf_counter()
+        run(steps * PERIOD)
+        elapsed[k] = time.perf_counter() - t0
+        gate.wait()
+
+    ths = [threading.Thread(target=body, args=(k,)) for k in range(K)]
+    for t in ths:
+        t.start()
+    gate.wait()
+    cpu0, t0 = time.process_time(), time.perf_counter()
+    gate.wait()
+    wall = time.perf_counter() - t0
+    cores = (time.process_time() - cpu0) / wall
+    for t in ths:
+        t.join()
+    for pl in pls:
+        st = pl.stats()
+        if st["decoded_pictures"] != pl.pushed or st["dropped"]:
+            raise RuntimeError("a stream lost pictures: %r" % (st,))
+        pl.close()
+    for c in clips:
+        c.close()
+    npic = steps * PERIOD
+    return {"streams": K, "value": round(K * npic / max(elapsed), 1), "unit": "frames/s (all streams together)", "per_stream": [round(npic / e, 1) for e in elapsed],
+            "steps_per_stream": steps, "decoder_frame_threads_per_stream": D, "coder_threads_per_stream": threads, "host_cpu_cores_busy": round(cores, 2)}
+
+
 def roofline_of(m, steps, me_range, workload_key):
     """dominant kernel = largest share of the timed region: average launch time x launches in the region (the events sample
     every n-th picture, so the launch counts come from the picture types, not from the samples)"""
@@ -611,6 +668,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=3, help="the K-step timed region is run this many times; `value` is the median run (BASELINE.md: median of 3)")
     ap.add_argument("--no-host-boundary", action="store_true", help="skip the `host_boundary` legs (host I420 in through kvz_api->encoder_encode, decoded I420 out into host memory)")
     ap.add_argument("--host-io", action="store_true", help="profiling aid: the MAIN run goes through the host boundary (then `value` is the host-boundary rate and no separate leg is run)")
+    ap.add_argument("--streams-per-gpu", default="", help="comma-separated K, e.g. 2,4: K independent streams at once on the one GPU, each with its own filter chain in this process (aggregate frames/s); off by default: "
+                         "with HIP's four hardware queues per priority level the streams of several pipelines share queues and serialise (DESIGN.md section 6; GPU_MAX_HW_QUEUES=8 lifts two streams from 3100 to 5700 frames/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-decode", action="store_true", help="8k-tilesplit: skip the split decoder's leg (reported as `secondary`)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 4K line (configs[2], the north-star target) that a 1080p run appends as `secondary`")
@@ -682,6 +741,14 @@ def main():
     hostb = None
     if not args.no_host_boundary:
         hostb = host_leg(wl, args.steps, args.warmup, world * args.steps * PERIOD / m["elapsed"])
+    multi = None
+    if world == 1 and args.streams_per_gpu and not args.host_io:
+        multi = []
+        for K in [int(v) for v in args.streams_per_gpu.split(",") if v.strip()]:
+            try:
+                multi.append(multi_stream(args, wl, K, max(2, args.steps // 2), ranks))
+            except Exception as e:
+                multi.append({"streams": K, "error": str(e)})
     sec = None
     sec_host = None
     if world == 1 and args.workload == "1080p" and not args.no_secondary:
@@ -717,6 +784,7 @@ def main():
                        "output": "Annex-B AU on host + decoded I420 in " + ("host memory" if args.host_io else "HBM"),
                        "repeats": args.repeats, "runs_fps": m["runs_fps"], "value_is": "median run of `repeats` (BASELINE.md timing rule)"},
             "host_boundary": hostb,
+            "streams_per_gpu": multi,
             "device": device_info,
             "roofline": roof,
             "kernels_us": kernels_us,

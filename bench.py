@@ -638,12 +638,15 @@ def roofline_of(m, steps, me_range, workload_key):
     # HBM traffic per launch: from the committed PMC passes of this same command (rocprofv3 --pmc cannot run inside the bench);
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  null when no pass exists.
     traffic, traffic_src = None, None
-    for rnd in ("r02", "r01"):
+    mfma = None
+    for rnd in ("r03", "r02", "r01"):
         try:
             name = "profiles/%s_pmc_traffic_%s.json" % (rnd, workload_key)
             pmc = json.load(open(os.path.join(ROOT, name)))
             traffic = pmc["kernels"][dom]["traffic_bytes"]
             traffic_src = name
+            # matrix-core utilisation of the kernels that use them (same counter passes: SQ_VALU_MFMA_BUSY_CYCLES / (duration x clock x SIMDs))
+            mfma = {k: v["mfma_util"] for k, v in pmc["kernels"].items() if v.get("mfma_util")} or None
             break
         except Exception:
             pass
@@ -655,6 +658,7 @@ def roofline_of(m, steps, me_range, workload_key):
     # every kernel against the HBM roofline (algorithmic bytes of one launch / its average duration)
     per_kernel = {k: round(algorithmic_bytes(k, cw, ch, me_range) / (kt[k][0] / kt[k][1] / 1e3) / 1e9 / HBM_PEAK_GBS, 5) for k in kern}
     roof["frac_by_kernel"] = per_kernel
+    roof["mfma_util_by_kernel"] = mfma                 # north_star: "MFMA utilisation against gfx950 peak" -- the transforms and Hadamard sums are small products between LDS phases
     return roof, kernels_us, share
 
 

@@ -822,7 +822,7 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
 
 // One plane of one CU on one wave (kernel_common.h "One intra block per WAVE"): block of n = 1 << L2 component samples.
 // Returns whether the block has non-zero levels.
-template <int L2>
+template <int L2, bool ADJ>
 __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratch &ws, const IntraBlk &d, int cidx, int S, const QuantConst &q,
                                                  uint8_t *gdst, int gp, int lane, uint32_t *publish, int adj = 0)
 {
@@ -847,7 +847,7 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
   mfma16_data_b(ta, y, co);
   PROF(6);
   bool nz = false;
-  if (adj) {
+  if (ADJ) {
     // rdoq / signhide (bit 0 / bit 1): levels to s.lev, quantiser remainders to the wave's scratch, one lane per 4x4 coefficient group adjusts
     // the levels (hevc_core.h adjust_group), then every lane takes its levels back -- all inside the wave, no workgroup barrier
     if (active) {
@@ -911,6 +911,7 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
 #ifndef KVZ_INTRA_WAVES
 #define KVZ_INTRA_WAVES 4
 #endif
+template <bool ADJ>       // ADJ: rdoq / signhide -- a kernel of its own, so that the plain chain (every step of it is on the critical path) stays as it was
 __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f)
 {
   constexpr int W = KVZ_INTRA_WAVES, T = 64 * W;
@@ -991,9 +992,9 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     first = false;
     bool cbf;
     switch (d.l2) {
-      case 2: cbf = intra_block_wave<2>(s, ws, d, c, S, q8, grec, pw, lane, nullptr, adj); break;
-      case 3: cbf = intra_block_wave<3>(s, ws, d, c, S, c ? q16 : q8, grec, pw, lane, nullptr, adj); break;
-      default: cbf = intra_block_wave<4>(s, ws, d, c, S, q16, grec, pw, lane, nullptr, adj); break;
+      case 2: cbf = intra_block_wave<2, ADJ>(s, ws, d, c, S, q8, grec, pw, lane, nullptr, adj); break;
+      case 3: cbf = intra_block_wave<3, ADJ>(s, ws, d, c, S, c ? q16 : q8, grec, pw, lane, nullptr, adj); break;
+      default: cbf = intra_block_wave<4, ADJ>(s, ws, d, c, S, q16, grec, pw, lane, nullptr, adj); break;
     }
     const uint2 cvu = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)cv.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)cv.y));
     chain_mark_done(ch, cvu, lane);
@@ -1821,7 +1822,11 @@ void launch_inter_signal(const EncFrame &f, hipStream_t st)
   hipLaunchKernelGGL(k_inter_signal, dim3((n + 63) / 64), dim3(64), 0, st, f);      // (a latency chain per thread: small workgroups spread it over all compute units)
 }
 void launch_intra_analyse(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_analyse, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f); }
-void launch_intra_recon(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_recon, dim3(3 * (f.cw / 64) * band_rows(f)), dim3(64 * KVZ_INTRA_WAVES), 0, st, f); }
+void launch_intra_recon(const EncFrame &f, hipStream_t st)
+{
+  if (f.rdoq || f.signhide) hipLaunchKernelGGL(k_intra_recon<true>, dim3(3 * (f.cw / 64) * band_rows(f)), dim3(64 * KVZ_INTRA_WAVES), 0, st, f);
+  else hipLaunchKernelGGL(k_intra_recon<false>, dim3(3 * (f.cw / 64) * band_rows(f)), dim3(64 * KVZ_INTRA_WAVES), 0, st, f);
+}
 void launch_qp_resolve(const EncFrame &f, hipStream_t st)
 {
   if (!f.ctu_qy) return;

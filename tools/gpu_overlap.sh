@@ -2,7 +2,7 @@
 # how much the kernels of the pipeline's streams overlap on the GPU: tools/gpu_overlap.sh <workload>   (kernel trace of a short bench run, analysed on the box)
 R=${GRAFT_REPO_ROOT:-$PWD}; wl=${1:-4k}
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/ovl
-KVAZZUP_BENCH_NOPROF=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ovl -o p -- python3 $R/bench.py --workload $wl --no-cpu-baseline --no-secondary --steps 3 --warmup 1 > /tmp/ovl.log 2>&1
+KVAZZUP_BENCH_NOPROF=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ovl -o p -- python3 $R/bench.py --workload $wl --no-cpu-baseline --no-secondary --no-host-boundary --repeats 1 --steps 3 --warmup 1 > /tmp/ovl.log 2>&1
 tail -c 300 /tmp/ovl.log | head -c 200; echo
 f=$(find /tmp/ovl -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'

@@ -10,8 +10,9 @@ passes=${PMC_PASSES:-"fetch:FETCH_SIZE write:WRITE_SIZE mfma:SQ_VALU_MFMA_BUSY_C
 mkdir -p $out
 for pass in $passes; do
   name=${pass%%:*}; ctr=${pass##*:}
-  KVAZZUP_BENCH_NOPROF=1 KVAZZUP_BENCH_HOST_SYNTH=1 timeout -k 5 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$name -o p -- \
-    python3 $R/bench.py --workload $wl --no-cpu-baseline --no-secondary --steps 1 --warmup 1 --owf 0 --decoder-frame-threads 1 "$@" > $out.$name.log 2>&1 || echo "pass $name failed (rc $?)"
+  extra=""; [ "$name" = "mfma" ] && extra="--subme 4"        # (the MFMA pass also runs the fractional-sample search: k_subpel's Hadamard products)
+  KVAZZUP_BENCH_NOPROF=1 timeout -k 5 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$name -o p -- \
+    python3 $R/bench.py --workload $wl --no-cpu-baseline --no-secondary --no-host-boundary --repeats 1 --steps 1 --warmup 1 --owf 0 --decoder-frame-threads 1 $extra "$@" > $out.$name.log 2>&1 || echo "pass $name failed (rc $?)"
 done
 python3 $R/tools/pmc_summarise.py $out $wl > $R/gpurun_out/pmc_traffic_$wl.json && tail -c 600 $R/gpurun_out/pmc_traffic_$wl.json
 rm -rf $out      # (per-dispatch counter tables are large: gpurun brings back at most 64 MiB)

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
       f.cu_log2[i] = 5; f.cu_intra[i] = 0; f.cu_mv[i * 2] = 0; f.cu_mv[i * 2 + 1] = 0;
       f.cu_mvp_idx[i] = 0;                               // mark for k_subpel: not searched (k_inter_signal writes the real value later)
     }
+    if (f.intra_p && tid < 4) f.me_cost16[((y0 >> 4) + (tid >> 1)) * (f.cw >> 4) + (x0 >> 4) + (tid & 1)] = 0;      // never an intra candidate
     return;
   }
   __syncthreads();                                                     // (red[] is about to be re-initialised)
@@ -186,6 +187,8 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
     f.cu_mvp_idx[i] = 1;                                 // mark for k_subpel: searched
     f.cu_mv[i * 2] = (int16_t)(((int)(ci % W) - R) * 4);
     f.cu_mv[i * 2 + 1] = (int16_t)(((int)(ci / W) - R) * 4);
+    // intra-in-P: the inter cost of the block's 16x16 quarters -- what the search found for a quarter, or a quarter of the 32x32 block's cost
+    if (f.intra_p && tid < 4) f.me_cost16[((y0 >> 4) + (tid >> 1)) * (f.cw >> 4) + (x0 >> 4) + (tid & 1)] = split ? red[tid] >> 13 : ((red[4] >> 13) + 2) >> 2;
   }
 }
 
@@ -241,6 +244,7 @@ struct InterLds {
   alignas(16) uint8_t win[2][4][11 * 12];  // chroma reference windows: plane x 8x8 sub-block, 11 x 11 samples each
   uint32_t nz[2];
   int mv[4][2];
+  int intra_q[4];                          // intra-in-P: the 16x16 quarter is an intra unit
   alignas(16) int8_t M8[2][32 * 32];       // the 32-point matrix and its transpose as int8: MFMA B operands
   int rowsum[2][32];                       // sum over m of M8[.][j][m]
 };
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FRAC ? 5 : 
   int bx_, by_; xcd_block_2d(bx_, by_);
   const int x0 = bx_ * 32, y0 = by_ * 32 + f.row0 * 64;
   const int bi0 = b8idx(f, x0, y0);
-  const bool split = f.cu_log2[bi0] == 4;
+  const bool split = f.cu_log2[bi0] != 5;                              // (four 16x16 units: with intra-in-P a quarter may also be an intra unit, 16x16 or four 8x8)
   const int cw2 = f.cw >> 1, ch2 = f.ch >> 1;
   const int qp = ctu_quant_qp(f, x0, y0), qpc = kChromaQp[qp];       // the 32x32 block lies inside one CTU
   const int adj = DEC ? 0 : ((f.rdoq ? 1 : 0) | (f.signhide ? 2 : 0));    // level adjustment behind the quantiser (hevc_core.h adjust_group)
@@ -431,6 +435,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FRAC ? 5 : 
   if (tid < 4) {
     int bi = b8idx(f, x0 + (tid & 1) * 16, y0 + (tid >> 1) * 16);
     s.mv[tid][0] = f.cu_mv[bi * 2]; s.mv[tid][1] = f.cu_mv[bi * 2 + 1];
+    // intra-in-P: a quarter that is an intra unit gets no residual here (levels, cbf and reconstruction are k_intra_recon's, which runs behind this kernel)
+    s.intra_q[tid] = (!DEC && f.intra_p && split) ? f.cu_intra[bi] : 0;
   }
   __syncthreads();
   // ---- luma with fractional vectors (the encoder's with subme > 0): window -> LDS, horizontal pass -> LDS
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FRAC ? 5 : 
     } else {
       const uint32_t s4 = *(const uint32_t *)&f.src[0][g];
       int r[4];
-      for (int i = 0; i < 4; i++) r[i] = (int)((s4 >> (8 * i)) & 255) - (int)((p4 >> (8 * i)) & 255);
+      for (int i = 0; i < 4; i++) r[i] = s.intra_q[k] ? 0 : (int)((s4 >> (8 * i)) & 255) - (int)((p4 >> (8 * i)) & 255);
       *(uint2 *)&A[ty * n + tx] = make_uint2(pack_i16(r[0], r[1]), pack_i16(r[2], r[3]));
     }
   }
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FRAC ? 5 : 
       }
     } else {
       const uint32_t s2 = *(const uint16_t *)&f.src[1 + pl][g];
-      *(uint32_t *)&A[ty * cn + tx] = pack_i16((int)(s2 & 255) - p0, (int)(s2 >> 8) - p1);
+      *(uint32_t *)&A[ty * cn + tx] = s.intra_q[sub] ? 0u : pack_i16((int)(s2 & 255) - p0, (int)(s2 >> 8) - p1);
     }
   }
   if (!coded) return;                          // (decoder only; the encoder's cbf bookkeeping below never applies)
@@ -576,6 +582,7 @@ __global__ __launch_bounds__(256) void k_inter_signal(EncFrame f)
   int x0 = (bx % w16) * 16, y0 = (bx / w16) * 16 + f.row0 * 64;
   int cl = f.cu_log2[b8idx(f, x0, y0)];
   if (cl == 5 && ((x0 | y0) & 31)) return;              // not the first 16x16 of a 32x32 CU
+  if (f.cu_intra[b8idx(f, x0, y0)]) return;             // an intra unit in a P picture (intra-in-P)
   decide_signalling(f, x0, y0, cl);
 }
 
@@ -719,12 +726,28 @@ __device__ __forceinline__ void analyse_tile_satd(const AnalyseLds &s, int tile,
   q[3] = (uint32_t)__builtin_amdgcn_readlane((int)a, 40) + (uint32_t)__builtin_amdgcn_readlane((int)a, 56);
 }
 
+#define INTRA_P_GATE 24       // intra-in-P: a quarter is a candidate when its inter cost exceeds this many lambda_q4 (oracle/hevc_enc.c)
+#define INTRA_P_BITS 16       // ... and goes intra when the intra cost plus this many bins is below the inter cost
+// PP = false: intra pictures.  PP = true ("uvgx intra-in-P v1"): launched behind k_me in a P picture; a region none of whose quarters'
+// inter cost is above the gate leaves at once (nearly all of them), the others are analysed like an intra picture's and the quarters
+// that come out cheaper as intra blocks are turned into intra units.
+template <bool PP>
 __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
 {
   __shared__ AnalyseLds s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bx_, by_; xcd_block_2d(bx_, by_);
   const int X0 = bx_ * 32, Y0 = by_ * 32 + f.row0 * 64;
+  uint32_t icost[4] = {0, 0, 0, 0}; bool cand[4] = {false, false, false, false};
+  if (PP) {
+    if (!((bx_ | by_) & 1) && tid < 3) f.sync[(size_t)((Y0 >> 6) * (f.cw >> 6) + (X0 >> 6)) * 3 + tid] = 0;      // the progress counters k_intra_recon<.., true> starts from
+    bool any = false;
+    for (int k = 0; k < 4; k++) {
+      icost[k] = f.me_cost16[((Y0 >> 4) + (k >> 1)) * (f.cw >> 4) + (X0 >> 4) + (k & 1)];
+      cand[k] = icost[k] > (uint32_t)INTRA_P_GATE * (uint32_t)f.lambda_q4; any |= cand[k];
+    }
+    if (!any) return;
+  }
   const uint8_t *src = f.src[0];
   *(uint32_t *)&s.src[tid * 4] = *(const uint32_t *)&src[(size_t)(Y0 + (tid >> 3)) * f.cw + X0 + (tid & 7) * 4];
   // ---- references of the 21 blocks from the source picture (8.4.4.2.2 substitution as an index clamp: the available
@@ -805,14 +828,24 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
   // ---- bottom-up split decision for this 32x32 block: thread per 8x8 cell
   if (tid < 16) {
     const uint32_t pen = ((uint32_t)f.lambda_q4 * SPLIT_BITS) >> 4;
-    bool split16[4];
+    bool split16[4], chosen = false;
     for (int k = 0; k < 4; k++) {
       uint32_t c8 = pen;
       for (int j = 0; j < 4; j++) c8 += s.bestc[((k >> 1) * 2 + (j >> 1)) * 4 + (k & 1) * 2 + (j & 1)];
       split16[k] = c8 < s.bestc[16 + k];
+      if (PP) {                                                  // intra-in-P: the quarter goes intra when that is cheaper than what the search found
+        const uint32_t cintra = (split16[k] ? c8 : s.bestc[16 + k]) + (((uint32_t)f.lambda_q4 * INTRA_P_BITS) >> 4);
+        cand[k] = cand[k] && cintra < icost[k];
+        chosen |= cand[k];
+      }
     }
     const int bx = tid & 3, by = tid >> 2, k = (by >> 1) * 2 + (bx >> 1);
     const int i = ((Y0 >> 3) + by) * (f.cw >> 3) + (X0 >> 3) + bx;
+    if (PP) {
+      if (!chosen) return;
+      if (!cand[k]) { f.cu_log2[i] = 4; return; }              // an inter quarter beside an intra one: a 16x16 unit with the vector it has
+      f.cu_mv[i * 2] = 0; f.cu_mv[i * 2 + 1] = 0;
+    }
     int l2, mode;
     if (!split16[k]) { l2 = 4; mode = s.bestm[16 + k]; }
     else { l2 = 3; mode = s.bestm[tid]; }
@@ -911,7 +944,11 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
 #ifndef KVZ_INTRA_WAVES
 #define KVZ_INTRA_WAVES 4
 #endif
-template <bool ADJ>       // ADJ: rdoq / signhide -- a kernel of its own, so that the plain chain (every step of it is on the critical path) stays as it was
+// ADJ: rdoq / signhide -- a kernel of its own, so that the plain chain (every step of it is on the critical path) stays as it was.
+// PP: the intra units of a P picture (intra-in-P), launched behind k_inter_recon: a CTU without intra units (nearly all) publishes 64
+// and leaves; in the others the inter units count as finished from the start, the CTU picture in LDS starts as the inter
+// reconstruction left it, and only the intra units' levels and cbf bits are written.
+template <bool ADJ, bool PP>
 __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f)
 {
   constexpr int W = KVZ_INTRA_WAVES, T = 64 * W;
@@ -930,6 +967,12 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   const int adj = (f.rdoq ? 1 : 0) | (f.signhide ? 2 : 0);      // level adjustment behind the quantiser (hevc_core.h adjust_group)
   const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, P = 16 + 2 * S;
   uint32_t *my = f.sync + (size_t)ctu * 3 + c;
+  uint64_t im = ~0ull;                                      // the CTU's 8x8 units (z-order) that belong to intra coding units
+  if (PP) {
+    int zx, zy; ctu_z_to_xy(lane, zx, zy);
+    im = __ballot(f.cu_intra[b8idx(f, cx * 64 + zx * 8, row * 64 + zy * 8)] != 0);      // (every wave for itself: no barrier in front of the exit)
+    if (!im) { if (tid == 0) __hip_atomic_store(my, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+  }
   for (int i = tid; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];
   const int qpl = ctu_quant_qp(f, cx * 64, row * 64), qp = c ? kChromaQp[qpl] : qpl;
   const int hc = f.ch >> 6;
@@ -937,14 +980,19 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   nb.nb_up = row > 0 && !tile_row_starts_at(hc, f.tile_rows, row); nb.nb_left = cx > 0 && !tile_col_starts_at(wc, f.tile_cols, cx);
   nb.nb_ur = nb.nb_up && cx + 1 < wc && !tile_col_starts_at(wc, f.tile_cols, cx + 1); nb.nb_ul = nb.nb_up && nb.nb_left;
   nb.pl = my - 3; nb.pu = my - 3 * wc; nb.pur = nb.pu + 3; nb.pul = nb.pu - 3;
-  chain_init(ch, nb, 0u, 0u);
+  chain_init(ch, nb, (uint32_t)~im, (uint32_t)(~im >> 32));
+  if (PP && tid == 0) {                                     // the leading run of inter units is progress the neighbours may see at once
+    const int prefix = __builtin_ctzll(im);
+    const uint32_t m = prefix >= 60 ? 60u : (prefix >= 56 ? 56u : (prefix >= 48 ? 48u : (prefix >= 44 ? 44u : (prefix >= 32 ? 32u : (prefix >= 24 ? 24u : 0u)))));
+    if (m) { ch.published = m; __hip_atomic_store(my, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  }
   // ---- everything the chain needs to know about the CTU's coding units, one lane per 8x8 unit (z-order), compacted into a list
   if (wave == 0) {
     int zx, zy; ctu_z_to_xy(lane, zx, zy);
     const int X = cx * 64 + zx * 8, Y = row * 64 + zy * 8, bi = b8idx(f, X, Y);
     const int l2 = f.cu_log2[bi], mode = f.cu_intra_mode[bi], n = 1 << (l2 - sh), nl = 1 << l2, su = nl >> 3;
     cu_cbf_s[lane] = 0;
-    const bool start = (lane & (su * su - 1)) == 0;
+    const bool start = (lane & (su * su - 1)) == 0 && ((im >> lane) & 1);
     const uint64_t starts = __ballot(start);
     const int k = __popcll(starts & ((1ull << lane) - 1ull));
     if (start) {
@@ -970,7 +1018,11 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   uint8_t *plane = f.rec[c];
   uint8_t *grec = plane + (size_t)(row * S) * pw + cx * S;
   int16_t *gcoef = f.coef[c] + (size_t)(row * S) * pw + cx * S;
-  for (int k = tid; k < S * S / 16; k += T) { int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&s.src[y * S + xq * 16] = *(const uint4 *)&gsrc[(size_t)y * pw + xq * 16]; }
+  for (int k = tid; k < S * S / 16; k += T) {
+    int y = k / (S / 16), xq = k % (S / 16);
+    *(uint4 *)&s.src[y * S + xq * 16] = *(const uint4 *)&gsrc[(size_t)y * pw + xq * 16];
+    if (PP) *(uint4 *)&s.pic[(y + 1) * P + 16 + xq * 16] = *(const uint4 *)&grec[(size_t)y * pw + xq * 16];      // the CTU as k_inter_recon left it
+  }
   if (f.trace && tid == 0) f.trace[((size_t)ctu * 3 + c) * 8 + 0] = wall_clock64();
   __syncthreads();
   const int nblk = (int)nblk_s;
@@ -1010,7 +1062,11 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (unacked.x | unacked.y) chain_ack_publish(ch, unacked, my, lane);
   __syncthreads();
-  for (int k = tid; k < S * S / 8; k += T) { int y = k / (S / 8), xq = k % (S / 8); *(uint4 *)&gcoef[(size_t)y * pw + xq * 8] = *(const uint4 *)&s.lev[y * S + xq * 8]; }
+  for (int k = tid; k < S * S / 8; k += T) {
+    int y = k / (S / 8), xq = k % (S / 8);
+    if (PP && !((im >> kv_zunit8(((xq * 8) << sh) >> 3, (y << sh) >> 3)) & 1)) continue;       // (an inter unit's levels are k_inter_recon's)
+    *(uint4 *)&gcoef[(size_t)y * pw + xq * 8] = *(const uint4 *)&s.lev[y * S + xq * 8];
+  }
   if (tid < 64 && cu_cbf_s[tid]) {
     int zx, zy; ctu_z_to_xy(tid, zx, zy);
     const int bi = b8idx(f, cx * 64 + zx * 8, row * 64 + zy * 8);
@@ -1821,11 +1877,21 @@ void launch_inter_signal(const EncFrame &f, hipStream_t st)
   int n = (f.cw / 16) * (band_rows(f) * 4);
   hipLaunchKernelGGL(k_inter_signal, dim3((n + 63) / 64), dim3(64), 0, st, f);      // (a latency chain per thread: small workgroups spread it over all compute units)
 }
-void launch_intra_analyse(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_intra_analyse, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f); }
+void launch_intra_analyse(const EncFrame &f, hipStream_t st)
+{
+  if (f.is_intra) hipLaunchKernelGGL(k_intra_analyse<false>, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f);
+  else hipLaunchKernelGGL(k_intra_analyse<true>, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f);       // intra-in-P, behind k_me
+}
 void launch_intra_recon(const EncFrame &f, hipStream_t st)
 {
-  if (f.rdoq || f.signhide) hipLaunchKernelGGL(k_intra_recon<true>, dim3(3 * (f.cw / 64) * band_rows(f)), dim3(64 * KVZ_INTRA_WAVES), 0, st, f);
-  else hipLaunchKernelGGL(k_intra_recon<false>, dim3(3 * (f.cw / 64) * band_rows(f)), dim3(64 * KVZ_INTRA_WAVES), 0, st, f);
+  const dim3 grid(3 * (f.cw / 64) * band_rows(f)), block(64 * KVZ_INTRA_WAVES);
+  const bool adj = f.rdoq || f.signhide;
+  if (!f.is_intra) {                                                                                            // intra-in-P, behind k_inter_recon
+    if (adj) hipLaunchKernelGGL((k_intra_recon<true, true>), grid, block, 0, st, f); else hipLaunchKernelGGL((k_intra_recon<false, true>), grid, block, 0, st, f);
+    return;
+  }
+  if (adj) hipLaunchKernelGGL((k_intra_recon<true, false>), grid, block, 0, st, f);
+  else hipLaunchKernelGGL((k_intra_recon<false, false>), grid, block, 0, st, f);
 }
 void launch_qp_resolve(const EncFrame &f, hipStream_t st)
 {

@@ -48,6 +48,7 @@ struct EncoderConfig {
   int input_hold = 0;         // "input-hold" (extension): 1 = the caller leaves a DEVICE input picture unchanged until that picture's access unit has been returned --
                               // what the kvz_api contract already demands of host pictures (kvazaarfilter.cpp:76-88); encode_device then returns without waiting for the input stage
   int rdoq = 0;               // kvazaar "rdoq": "uvgx RDOQ v1" -- sparse high-frequency coefficient groups are dropped when that is cheaper (oracle/hevc_transform.h orc_adjust_levels)
+  int intra_in_p = 0;         // "intra-in-p": intra coding units in P pictures ("uvgx intra-in-P v1", oracle/hevc_enc.c me_block32); not with rc_bands / band mode
   int signhide = 0;           // kvazaar "signhide": sign_data_hiding_enabled_flag; the quantiser makes the parity of every eligible coefficient group say the hidden sign
   int hash = 0;               // kvazaar "hash": 1 checksum, 2 md5 -- a decoded picture hash SEI (D.2.19) behind every picture's slices, from the reconstruction downloaded for it
   int entropy_gpu = 0;        // arithmetic coder: 1 = on the GPU (k_cabac_rows, cabac_kernels.hip), 0 = host thread pool (entropy_host.h); band mode always uses the host pool
@@ -173,7 +174,7 @@ class Encoder {
   uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; int tok_nctu_ = 0;
   size_t tok_dense_cap_ = 0;
   std::vector<std::vector<uint8_t>> band_subs_; uint64_t band_bins_ = 0; bool band_coded_ = false;   // band mode: between phase 2a and 2b
-  uint32_t *sync_ = nullptr; uint32_t *intra_order_ = nullptr; uint32_t *err_ = nullptr; unsigned long long *trace_ = nullptr;
+  uint32_t *sync_ = nullptr; uint32_t *me_cost16_ = nullptr; uint32_t *intra_order_ = nullptr; uint32_t *err_ = nullptr; unsigned long long *trace_ = nullptr;
   // one slot per picture in flight: the host-visible results of its kernels and what collect() needs to finish it
   struct EvPair { hipEvent_t a, b; KernelId id; };
   struct Slot {

@@ -27,6 +27,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   if (cfg.vaq > 0) cfg.qp_in_cu = 1;                       // the deltas travel as cu_qp_delta
   if (cfg.bitrate <= 0 || cfg.band_rows > 0) cfg.rc_bands = 0;
   if ((cfg.slices == 1 && !cfg.wpp) || (cfg.slices == 2 && cfg.tile_rows * cfg.tile_cols < 2) || (cfg.slices == 1 && cfg.tile_cols > 1) || cfg.slices < 0 || cfg.slices > 2) cfg.slices = 0;
+  if (cfg.rc_bands > 0 || cfg.band_rows > 0) cfg.intra_in_p = 0;     // (intra-in-P runs behind the whole picture's inter reconstruction: not with the CTU-row groups of rate control v2, not in band mode)
   if (cfg.rc_bands > 0) cfg.qp_in_cu = 1;                  // ... and so do the steps of rate control v2
 
   const char *prio = getenv("KVAZZUP_AMD_PRIO"); if (!prio || strlen(prio) < 4) prio = "hnnn";   // main, tokenizer, input, decoder: the chain the next picture waits for is the urgent one (+6 % at 1080p; any explicit priority also gives the stream a hardware queue of its own)
@@ -146,6 +147,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   }
   HIP_OK(hipEventCreateWithFlags(&in_done_, hipEventDisableTiming));
   HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * rows_ * (cw_ / 64) * 3));       // one progress counter per CTU and colour plane
+  if (cfg.intra_in_p) HIP_OK(hipMalloc(&me_cost16_, sizeof(uint32_t) * (cw_ / 16) * (ch_ / 16)));      // k_me's inter cost per 16x16 block (intra-in-P)
   {
     // dispatch order of the intra reconstruction's workgroups: the CTUs of the rows this instance codes, by anti-diagonal cx + 2 cy
     const int wc = cw_ / 64, r0 = cfg.band_rows > 0 ? cfg.band_row0 : 0, nr = cfg.band_rows > 0 ? cfg.band_rows : rows_;
@@ -169,7 +171,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   f_.tile_rows = cfg.tile_rows; f_.tile_cols = cfg.tile_cols; f_.chp = pack_height(ch_, cfg.tile_rows, cfg.tile_cols);
   f_.row0 = cfg.band_rows > 0 ? cfg.band_row0 : 0; f_.nrows = cfg.band_rows > 0 ? cfg.band_rows : 0;
   f_.qp = cfg.qp; f_.qpc = kChromaQp[cfg.qp]; f_.lambda_q4 = kLambdaQ4[cfg.qp]; f_.range = cfg.me_range;
-  f_.rdoq = cfg.rdoq; f_.signhide = cfg.signhide;
+  f_.rdoq = cfg.rdoq; f_.signhide = cfg.signhide; f_.intra_p = cfg.intra_in_p; f_.me_cost16 = me_cost16_;
   f_.wpp = cfg.wpp; f_.mv_frame = cfg.mv_frame; f_.me_early = cfg.me_early; f_.satd = cfg.satd; f_.subme = cfg.subme; f_.slices = cfg.slices;
   bind_set(0);
   uint8_t *p = intra_scratch_;
@@ -245,7 +247,7 @@ Encoder::~Encoder()
   stream_release(stream_in_, cfg_.device, 'I', prio_[2]);
   hipFree(intra_scratch_);
   delete entropy_; delete entropy2_;
-  hipFree(trace_); hipFree(intra_order_); hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(sync_); hipFree(err_);
+  hipFree(trace_); hipFree(intra_order_); hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(sync_); hipFree(me_cost16_); hipFree(err_);
   stream_release(stream_, cfg_.device, 'M', prio_[0]);
 }
 
@@ -489,6 +491,8 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     timed(K_INTRA_RECON, stream_, [&] { launch_intra_recon(f, stream_); });
   } else {
     timed(K_ME, stream_, [&] { launch_me(f, stream_); });
+    // intra-in-P: quarters whose inter cost is high are priced as intra blocks and may become intra units (the launch leaves at once where none is)
+    if (cfg_.intra_in_p) timed(K_INTRA_ANALYSE, stream_, [&] { launch_intra_analyse(f, stream_); });
     if (cfg_.subme > 0) timed(K_SUBPEL, stream_, [&] { launch_subpel(f, stream_); });
     if (rc_state_) {
       // rate control v2: the CTU rows in groups, the next group's QP decided on the device from the levels of the groups before
@@ -502,6 +506,8 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
       }
     } else
     timed(K_INTER_RECON, stream_, [&] { launch_inter_recon(f, stream_); });
+    // ... and are reconstructed behind every inter unit (their reference samples may lie in inter units anywhere around them)
+    if (cfg_.intra_in_p) timed(K_INTRA_RECON, stream_, [&] { launch_intra_recon(f, stream_); });
   }
   launch_qp_resolve(f, stream_);                                 // per-CTU QP: which CU carries the delta, QpY for deblocking
   HIP_CHECK(hipEventRecord(ev_signalled_, stream_));             // levels, cbf and motion of the picture are final

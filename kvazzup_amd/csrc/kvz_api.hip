@@ -173,7 +173,7 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
   INT_OPT("me-range", me_range, 1, 32)
   INT_OPT("gpu", gpu_device, 0, 64)
   BOOL_OPT("recon-output", recon_output)
-  BOOL_OPT("input-hold", input_hold)
+  BOOL_OPT("input-hold", input_hold) BOOL_OPT("intra-in-p", intra_in_p)
   if (n == "null-input") {
     if (!strcmp(value, "drain")) { cfg->null_input_poll = 0; return 1; }
     if (!strcmp(value, "poll")) { cfg->null_input_poll = 1; return 1; }
@@ -309,7 +309,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.subme = cfg->fme_level < 0 ? 0 : (cfg->fme_level > 4 ? 4 : cfg->fme_level);
   ec.entropy_gpu = cfg->gpu_entropy != 0;
   ec.input_hold = cfg->input_hold != 0;
-  ec.rdoq = cfg->rdoq_enable != 0; ec.signhide = cfg->signhide_enable != 0;
+  ec.rdoq = cfg->rdoq_enable != 0; ec.signhide = cfg->signhide_enable != 0; ec.intra_in_p = cfg->intra_in_p != 0;
   ec.hash = cfg->hash == KVZ_HASH_MD5 ? 2 : (cfg->hash == KVZ_HASH_CHECKSUM ? 1 : 0);
   ec.vaq = cfg->vaq > 0 ? cfg->vaq : 0;
   ec.qp_in_cu = (cfg->set_qp_in_cu || ec.vaq > 0) ? 1 : 0;

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(512) void k_subpel(EncFrame f)
   unsigned long long *tr = f.trace ? f.trace + (size_t)((y0 >> 5) * (f.cw >> 5) + (x0 >> 5)) * 8 : nullptr;
 #define SP_STAMP(k) do { if (tr && tid == 0) tr[k] = wall_clock64(); } while (0)
   SP_STAMP(0);
-  const bool split = f.cu_log2[bi0] == 4;
+  const bool split = f.cu_log2[bi0] != 5;                   // (four 16x16 units; with intra-in-P some of them may be intra units, whose waves only keep the barriers company)
   const int X = x0 + (w & 1) * 16, Y = y0 + (w >> 1) * 16;  // this wave's quadrant
   const int bq = b8idx(f, X, Y);
   const int mvx0 = f.cu_mv[bq * 2], mvy0 = f.cu_mv[bq * 2 + 1], ix = mvx0 >> 2, iy = mvy0 >> 2;    // integer vector (multiples of 4)
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(512) void k_subpel(EncFrame f)
     __syncthreads();                                        // (s.satd and the planes are rewritten by the next step)
     SP_STAMP(4 + step * 3);
   }
-  if (part == 0 && lane < 4) {
+  if (part == 0 && lane < 4 && !(split && f.cu_intra[bq])) {
     const int i = b8idx(f, X + (lane & 1) * 8, Y + (lane >> 1) * 8);
     f.cu_mv[i * 2] = (int16_t)cx; f.cu_mv[i * 2 + 1] = (int16_t)cy;
   }

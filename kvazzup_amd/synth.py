@@ -104,3 +104,15 @@ def frame_torch(kind, seed, w, h, t, device):
         m = (dx >= 0) & (dx < s // 2) & (dy >= 0) & (dy < s // 2)
         u = torch.where(m, ub + 8 * k, u)
     return torch.cat([y.reshape(-1), u.to(torch.uint8).reshape(-1), vv.to(torch.uint8).reshape(-1)])
+
+
+def scene_cut_frame(seed, w, h, t, cut):
+    """the moving-objects clip with a scene cut at picture `cut`: from there on the picture is the clip's mirror image (left-right and
+    up-down) 400 pictures later -- nothing of it is in the reference picture.  Used for the intra-in-P tests and numbers."""
+    if t < cut:
+        return frame(MOVING, seed, w, h, t)
+    f = frame(MOVING, seed ^ 0x00C0FFEE, w, h, t + 400)
+    y = f[:w * h].reshape(h, w)[::-1, ::-1]
+    u = f[w * h:w * h + w * h // 4].reshape(h // 2, w // 2)[::-1, ::-1]
+    v = f[w * h + w * h // 4:].reshape(h // 2, w // 2)[::-1, ::-1]
+    return np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)]).astype(np.uint8)

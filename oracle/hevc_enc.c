@@ -14,6 +14,8 @@
 #include "hevc_mvpred.h"
 #include "hevc_sao.h"
 
+#define INTRA_P_GATE 24       /* intra-in-P: a quarter is a candidate when its inter cost exceeds this many lambda_q4 */
+#define INTRA_P_BITS 16       /* ... and goes intra when the intra cost plus this many bins is below the inter cost */
 #define SPLIT_BITS 8          /* rate charged for splitting a CU one level, in bins */
 #define ME_PAD 64             /* padding of the reference copy used by the motion search */
 
@@ -51,6 +53,7 @@ struct orc_encoder {
   int tile_col_bd[34];                 /* first CTB column of tile column j, j = 0 .. tile_cols */
   orc_sao_params *sao; pixel *sao_in[3];   /* cfg.sao: parameters of every CTU; copy of the deblocked picture */
   int is_intra;
+  int intra_p_ready;                   /* intra-in-P: the source-based intra analysis of this picture has been run (lazily, by the first candidate block) */
   uint64_t bins;
 };
 
@@ -358,7 +361,7 @@ static void intra_recon_cu(orc_encoder *e, int x0, int y0, int log2)
 static void intra_recon_tree(orc_encoder *e, int x0, int y0, int log2)
 {
   int cl = e->cu_log2[b8i(e, x0, y0)];
-  if (cl >= log2) { intra_recon_cu(e, x0, y0, log2); return; }
+  if (cl >= log2) { if (e->is_intra || e->cu_intra[b8i(e, x0, y0)]) intra_recon_cu(e, x0, y0, log2); return; }      /* (P pictures: the intra units only) */
   int h = 1 << (log2 - 1);
   intra_recon_tree(e, x0, y0, log2 - 1); intra_recon_tree(e, x0 + h, y0, log2 - 1);
   intra_recon_tree(e, x0, y0 + h, log2 - 1); intra_recon_tree(e, x0 + h, y0 + h, log2 - 1);
@@ -457,7 +460,7 @@ static void me_block32(orc_encoder *e, int x0, int y0)
       s0 += sad16(e->src[0] + by * e->cw + bx, e->cw, e->refpad + (size_t)(by + ME_PAD) * st + bx + ME_PAD, st);
     }
     if (s0 <= 64u * lam) {
-      set_cu(e, e->cu_log2, x0, y0, 32, 5);
+      set_cu(e, e->cu_log2, x0, y0, 32, 5); set_cu(e, e->cu_intra, x0, y0, 32, 0);
       for (int y = y0; y < y0 + 32; y += 8) for (int x = x0; x < x0 + 32; x += 8) { e->cu_mv[b8i(e, x, y) * 2] = 0; e->cu_mv[b8i(e, x, y) * 2 + 1] = 0; }
       return;
     }
@@ -508,9 +511,48 @@ static void me_block32(orc_encoder *e, int x0, int y0)
       e->cu_mv[b8i(e, x, y) * 2] = (int16_t)(((ci % W) - R) * 4); e->cu_mv[b8i(e, x, y) * 2 + 1] = (int16_t)(((ci / W) - R) * 4);
     }
   }
-  if (e->cfg.subme > 0) {                                        /* fractional-sample refinement of the CUs just decided */
+  set_cu(e, e->cu_intra, x0, y0, 32, 0);
+  if (e->cfg.intra_in_p && e->cfg.rc_bands == 0) {
+    /* "uvgx intra-in-P v1".  Inter cost of a 16x16 quarter = what the search found for it (split) or a quarter of the 32x32 block's cost;
+     * quarters above the gate are priced as intra blocks by the intra picture's analysis (source neighbours: nothing depends on other
+     * blocks' decisions) and go intra when that is cheaper by INTRA_P_BITS bins.  A block with an intra quarter is coded as four 16x16
+     * units (the inter ones keep their vectors; an intra quarter is one 16x16 or four 8x8 intra units). */
+    uint32_t ic[4]; int any = 0, cand[4];
+    for (int k = 0; k < 4; k++) {
+      ic[k] = csplit < (best32 >> 13) ? best16[k] >> 13 : ((best32 >> 13) + 2) >> 2;
+      cand[k] = ic[k] > INTRA_P_GATE * lam; any |= cand[k];
+    }
+    if (any) {
+      if (!e->intra_p_ready) { intra_analyse_size(e, 8, e->im8, e->ic8); intra_analyse_size(e, 16, e->im16, e->ic16); e->intra_p_ready = 1; }
+      int w8 = e->cw / 8, w16 = e->cw / 16, chosen = 0, sp16[4];
+      for (int k = 0; k < 4; k++) {
+        int x16 = x0 / 16 + (k & 1), y16 = y0 / 16 + (k >> 1);
+        uint32_t c8 = pen;
+        for (int j = 0; j < 4; j++) c8 += e->ic8[(y16 * 2 + (j >> 1)) * w8 + x16 * 2 + (j & 1)];
+        uint32_t c16 = e->ic16[y16 * w16 + x16];
+        sp16[k] = c8 < c16;
+        uint32_t cintra = (sp16[k] ? c8 : c16) + ((lam * INTRA_P_BITS) >> 4);
+        cand[k] = cand[k] && cintra < ic[k];
+        chosen |= cand[k];
+      }
+      if (chosen) {
+        for (int k = 0; k < 4; k++) {
+          int bx = x0 + (k & 1) * 16, by = y0 + (k >> 1) * 16, x16 = bx / 16, y16 = by / 16;
+          if (!cand[k]) { set_cu(e, e->cu_log2, bx, by, 16, 4); continue; }
+          set_cu(e, e->cu_intra, bx, by, 16, 1);
+          for (int y = by; y < by + 16; y += 8) for (int x = bx; x < bx + 16; x += 8) { e->cu_mv[b8i(e, x, y) * 2] = 0; e->cu_mv[b8i(e, x, y) * 2 + 1] = 0; }
+          if (!sp16[k]) { set_cu(e, e->cu_log2, bx, by, 16, 4); set_cu(e, e->cu_intra_mode, bx, by, 16, e->im16[y16 * w16 + x16]); }
+          else for (int j = 0; j < 4; j++) {
+            int x8 = x16 * 2 + (j & 1), y8 = y16 * 2 + (j >> 1);
+            e->cu_log2[y8 * w8 + x8] = 3; e->cu_intra_mode[y8 * w8 + x8] = e->im8[y8 * w8 + x8];
+          }
+        }
+      }
+    }
+  }
+  if (e->cfg.subme > 0) {                                        /* fractional-sample refinement of the (inter) CUs just decided */
     if (e->cu_log2[b8i(e, x0, y0)] == 5) subme_refine(e, x0, y0, 32, ty0, ty1);
-    else for (int k = 0; k < 4; k++) subme_refine(e, x0 + (k & 1) * 16, y0 + (k >> 1) * 16, 16, ty0, ty1);
+    else for (int k = 0; k < 4; k++) if (!e->cu_intra[b8i(e, x0 + (k & 1) * 16, y0 + (k >> 1) * 16)]) subme_refine(e, x0 + (k & 1) * 16, y0 + (k >> 1) * 16, 16, ty0, ty1);
   }
   if (e->cfg.test_mv_jitter && e->cfg.tile_rows == 1) {          /* test hook: fractional vectors for the decoder tests */
     for (int y = y0; y < y0 + 32; y += 8) for (int x = x0; x < x0 + 32; x += 8) {
@@ -621,9 +663,11 @@ static void rc_picture_start(orc_encoder *e)
   e->rc_ratio_valid = 1;
 }
 
+static void intra_recon_tree(orc_encoder *e, int x0, int y0, int log2);
 static void encode_inter_picture(orc_encoder *e)
 {
   build_refpad(e);
+  e->intra_p_ready = 0;
   for (int y = 0; y < e->ch; y += 32) for (int x = 0; x < e->cw; x += 32) me_block32(e, x, y);
   /* Reconstruction, in rc_bands groups of CTU rows when rate control v2 is on: after each group the level cost so far is priced
    * against the share of the picture's target the rows done are entitled to, and the next group's QP follows (rc_band_decide). */
@@ -635,7 +679,7 @@ static void encode_inter_picture(orc_encoder *e)
       int r0 = (b * hc) / nb, r1 = ((b + 1) * hc) / nb;
       for (int y = r0 * 64; y < r1 * 64; y += 32) for (int x = 0; x < e->cw; x += 32) {
         if (e->cu_log2[b8i(e, x, y)] == 5) inter_recon_cu(e, x, y, 5);
-        else for (int k = 0; k < 4; k++) inter_recon_cu(e, x + (k & 1) * 16, y + (k >> 1) * 16, 4);
+        else for (int k = 0; k < 4; k++) if (!e->cu_intra[b8i(e, x + (k & 1) * 16, y + (k >> 1) * 16)]) inter_recon_cu(e, x + (k & 1) * 16, y + (k >> 1) * 16, 4);
       }
       if (e->cfg.rc_bands > 0) {
         for (int cy = r0; cy < r1; cy++) for (int cx = 0; cx < wc; cx++) cost += rc_ctu_cost(e, cx, cy);
@@ -648,9 +692,16 @@ static void encode_inter_picture(orc_encoder *e)
     }
     if (e->cfg.rc_bands > 0) { e->rc_cost[e->frame_idx & 7] = cost; e->rc_cost_valid[e->frame_idx & 7] = 1; }
   }
+  /* intra coding units of the P picture: after every inter unit (their reference samples may lie in inter units anywhere around them),
+   * CTU by CTU in decoding order, z-order inside the CTU */
+  if (e->intra_p_ready) {
+    for (int tr = 0; tr < e->cfg.tile_rows; tr++) for (int tc = 0; tc < e->cfg.tile_cols; tc++)
+      for (int cy = e->tile_row_bd[tr]; cy < e->tile_row_bd[tr + 1]; cy++)
+        for (int cx = e->tile_col_bd[tc]; cx < e->tile_col_bd[tc + 1]; cx++) intra_recon_tree(e, cx * 64, cy * 64, 6);
+  }
   for (int y = 0; y < e->ch; y += 32) for (int x = 0; x < e->cw; x += 32) {
     if (e->cu_log2[b8i(e, x, y)] == 5) inter_decide_signalling(e, x, y, 5);
-    else for (int k = 0; k < 4; k++) inter_decide_signalling(e, x + (k & 1) * 16, y + (k >> 1) * 16, 4);
+    else for (int k = 0; k < 4; k++) if (!e->cu_intra[b8i(e, x + (k & 1) * 16, y + (k >> 1) * 16)]) inter_decide_signalling(e, x + (k & 1) * 16, y + (k >> 1) * 16, 4);
   }
 }
 
@@ -1138,6 +1189,7 @@ size_t orc_enc_encode(orc_encoder *e, const pixel *y, const pixel *u, const pixe
 int orc_enc_set_option(orc_encoder *e, const char *name, int value)
 {
   if (!strcmp(name, "hash")) { e->cfg.hash = value; return 1; }
+  if (!strcmp(name, "intra-in-p")) { e->cfg.intra_in_p = value != 0; return 1; }
   if (!strcmp(name, "rdoq")) { e->cfg.rdoq = value != 0; return 1; }
   if (!strcmp(name, "signhide")) { e->cfg.signhide = value != 0; e->pps.sign_data_hiding = e->cfg.signhide; return 1; }
   return 0;

@@ -64,6 +64,8 @@ typedef struct {
                                * diagonals; candidates are compared by SATD (8x8 Hadamard) + lambda * vector bits */
   int rdoq;                   /* kvazaar rdoq: "uvgx RDOQ v1" -- sparse high-frequency coefficient groups are dropped when that is cheaper (orc_adjust_levels, hevc_transform.h) */
   int signhide;               /* kvazaar signhide: sign_data_hiding_enabled_flag; the quantiser makes the parity of every eligible coefficient group say the hidden sign */
+  int intra_in_p;             /* 1: "uvgx intra-in-P v1" -- intra coding units in P pictures (hevc_enc.c intra_p_decide): a 16x16 quarter of a searched 32x32 block whose inter cost
+                               * is above 24 lambda is priced as an intra block (the intra picture's source-based analysis) and coded intra when that is cheaper; ignored with rc_bands */
   int hash;                   /* kvazaar hash: 0 none, 1 checksum, 2 md5 -- a decoded picture hash SEI (D.2.19, suffix SEI NAL unit) after every picture's slices */
 } orc_enc_config;
 
@@ -83,7 +85,7 @@ typedef struct {
 } orc_enc_debug;
 
 void orc_enc_default_config(orc_enc_config *c);
-/* options added after the packed open calls ran out of bits: by name, before the first picture.  "hash" 0/1/2, "rdoq" 0/1, "signhide" 0/1.  Returns 1 when known. */
+/* options added after the packed open calls ran out of bits: by name, before the first picture.  "hash" 0/1/2, "rdoq" 0/1, "signhide" 0/1, "intra-in-p" 0/1.  Returns 1 when known. */
 int orc_enc_set_option(orc_encoder *e, const char *name, int value);
 orc_encoder *orc_enc_open(const orc_enc_config *c);
 void orc_enc_close(orc_encoder *e);

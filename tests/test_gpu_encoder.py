@@ -495,6 +495,42 @@ def test_rdoq_and_sign_hiding_match_oracle(gpu, cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(w=416, h=240, qp=32, frames=8, cut=3),
+    dict(w=416, h=240, qp=27, frames=7, cut=2, subme=4, sao=1, rdoq=1, signhide=1),
+    dict(w=640, h=368, qp=30, frames=6, cut=2, subme=2, tiles="2x2"),
+    dict(w=1920, h=1080, qp=32, frames=4, cut=2),                  # BASELINE configs[1] size
+])
+def test_intra_units_in_p_pictures_match_oracle(gpu, cfg):
+    """intra-in-p (row f4): a scene cut inside a GOP -- k_me's 16x16 costs, k_intra_analyse<P> decisions, k_intra_recon<.., P> behind k_inter_recon;
+    access units and reconstruction equal the checker's, both decoders return the reconstruction, and the P picture at the cut does carry intra units"""
+    from kvazzup_amd import synth
+    from kvazzup_amd.codec import Decoder, Encoder
+    w, h = cfg["w"], cfg["h"]
+    tiles = cfg.get("tiles", "1x1"); tc, tr = [int(v) for v in tiles.split("x")]
+    oe = orc.OracleEncoder(w, h, qp=cfg["qp"], period=64, me_range=8, subme=cfg.get("subme", 0), sao=cfg.get("sao", 0), tile_rows=tr, tile_cols=tc)
+    oe.set_option("intra-in-p", 1); oe.set_option("rdoq", cfg.get("rdoq", 0)); oe.set_option("signhide", cfg.get("signhide", 0))
+    ge = Encoder(w, h, options=(("qp", cfg["qp"]), ("period", 64), ("me-range", 8), ("intra-in-p", 1), ("rdoq", cfg.get("rdoq", 0)), ("signhide", cfg.get("signhide", 0)),
+                                ("subme", cfg.get("subme", 0)), ("sao", "full" if cfg.get("sao") else "off")) + ((("tiles", tiles),) if tiles != "1x1" else ()))
+    assert not ge.rejected, ge.rejected
+    gd = Decoder(); od = orc.OracleDecoder()
+    intra_units = []
+    for t in range(cfg["frames"]):
+        frame = synth.scene_cut_frame(SEED, w, h, t, cfg["cut"])
+        au, rec = ge.encode(frame)
+        want = oe.encode(frame)
+        assert au == want, (t, len(au), len(want), _diagnose(oe.debug(), ge.debug_all()))
+        assert np.array_equal(rec, oe.recon()), t
+        got = gd.decode_au(au, t); ref = od.decode_au(au, t)
+        assert len(got) == 1 and np.array_equal(got[0]["i420"], rec), t
+        assert len(ref) == 1 and np.array_equal(ref[0]["i420"], rec), t
+        intra_units.append(int(np.count_nonzero(ge.debug_all()["cu_intra"])))
+    assert intra_units[cfg["cut"]] > 0 and intra_units[0] > 0, intra_units           # (picture 0 is the IDR picture)
+    for x in (ge, gd, oe, od):
+        x.close()
+
+
+@pytest.mark.gpu
 def test_presets_switch_rdoq_and_sign_hiding_on(gpu):
     """preset medium and above: rdoq; slow and above: signhide too (config_parse), and the stream says so in its PPS"""
     from kvazzup_amd.codec import Encoder

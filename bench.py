@@ -445,7 +445,7 @@ def run_stream(args, wl, steps, warmup, ranks, rank, world, quality, host_io=Fal
               "video/OWF": args.owf, "video/OPENHEVC_threads": D, "video/OH_parallelization": "Frame" if D > 1 else "Slice"}
         st.update(extra_settings or {})
         return Pipeline(w, h, settings=st,
-                        custom=(("me-range", args.me_range), ("gpu", dev_index)) + ((("sao", "full"),) if args.sao else ()) + ((("me-early-termination", "off"),) if args.full_search else ()) + ((("intra-satd", "0"),) if args.intra_sad else ()) + ((("gpu-entropy", "1"),) if args.gpu_entropy else ()) + ((("subme", str(args.subme)),) if args.subme else ()) + tuple(extra_custom),
+                        custom=(("me-range", args.me_range), ("gpu", dev_index)) + ((("sao", "full"),) if args.sao else ()) + ((("me-early-termination", "off"),) if args.full_search else ()) + ((("intra-satd", "0"),) if args.intra_sad else ()) + ((("gpu-entropy", "1"),) if args.gpu_entropy else ()) + ((("subme", str(args.subme)),) if args.subme else ()) + tuple(tuple(kv.split("=", 1)) for kv in args.custom) + tuple(extra_custom),
                         loopback=True, keep_outputs=keep)
 
     # source -> KvazaarFilter -> WireAdapter -> OpenHEVCFilter -> sink, one thread per filter (csrc/filters.hip)
@@ -674,6 +674,8 @@ def main():
     ap.add_argument("--host-io", action="store_true", help="profiling aid: the MAIN run goes through the host boundary (then `value` is the host-boundary rate and no separate leg is run)")
     ap.add_argument("--streams-per-gpu", default="", help="comma-separated K, e.g. 2,4: K independent streams at once on the one GPU, each with its own filter chain in this process (aggregate frames/s); off by default: "
                          "with HIP's four hardware queues per priority level the streams of several pipelines share queues and serialise (DESIGN.md section 6; GPU_MAX_HW_QUEUES=8 lifts two streams from 3100 to 5700 frames/s)")
+    ap.add_argument("--custom", action="append", default=[], metavar="KEY=VALUE", help="extra kvazaar option for the encoder of every leg (uvgComm's custom-parameter list, kvazaarfilter.cpp:355-368), e.g. --custom intra-in-p=1")
+    ap.add_argument("--no-preset-line", action="store_true", help="skip the `default_mode` line: uvgComm's own default encoder settings for this size (defaultsettings.cpp:287-316: preset veryfast, 1 Mbit/s) instead of the benchmark's fixed-QP ultrafast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-decode", action="store_true", help="8k-tilesplit: skip the split decoder's leg (reported as `secondary`)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 4K line (configs[2], the north-star target) that a 1080p run appends as `secondary`")
@@ -766,6 +768,21 @@ def main():
         except Exception as e:       # the headline line must not be lost to the secondary one
             sec = {"error": str(e)}
 
+    preset_line = None
+    if world == 1 and args.workload == "1080p" and not args.no_secondary and not args.no_preset_line:
+        # uvgComm's default mode for a stream of this complexity class (defaultsettings.cpp:300-316): preset veryfast (here: sao full, subme 2, intra-in-p),
+        # rate control at 1 Mbit/s (kvazaarfilter.cpp:223-228 -> rc-algorithm lambda: "uvgx rate control v2")
+        try:
+            psteps = max(1, min(args.steps, args.secondary_steps))
+            pm = run_stream(args, wl, psteps, min(2, max(1, args.warmup)), ranks, rank, world, quality=True, extra_custom=resident,
+                            extra_settings={"video/Preset": "veryfast", "video/bitrate": 1000000})
+            preset_line = {"settings": {"video/Preset": "veryfast", "video/bitrate": 1000000}, "value": round(pm["pictures"] / pm["elapsed"], 3), "unit": "frames/s",
+                           "steps": psteps, "runs_fps": pm["runs_fps"], "bits_per_picture": round(8 * pm["bytes_per_picture"], 1),
+                           "kbit_per_s_at_30fps": round(8 * pm["bytes_per_picture"] * 30 / 1e3, 1), "psnr_y": pm["psnr_y"],
+                           "host_cpu_cores_busy": round(pm["host_cores"], 2), "kernels_us": roofline_of(pm, psteps, args.me_range, args.workload)[1]}
+        except Exception as e:
+            preset_line = {"error": str(e)}
+
     if rank == 0:
         npic = args.steps * PERIOD
         fps = world * npic / m["elapsed"]
@@ -789,6 +806,7 @@ def main():
                        "repeats": args.repeats, "runs_fps": m["runs_fps"], "value_is": "median run of `repeats` (BASELINE.md timing rule)"},
             "host_boundary": hostb,
             "streams_per_gpu": multi,
+            "default_mode": preset_line,
             "device": device_info,
             "roofline": roof,
             "kernels_us": kernels_us,

@@ -48,7 +48,7 @@ struct EncoderConfig {
   int input_hold = 0;         // "input-hold" (extension): 1 = the caller leaves a DEVICE input picture unchanged until that picture's access unit has been returned --
                               // what the kvz_api contract already demands of host pictures (kvazaarfilter.cpp:76-88); encode_device then returns without waiting for the input stage
   int rdoq = 0;               // kvazaar "rdoq": "uvgx RDOQ v1" -- sparse high-frequency coefficient groups are dropped when that is cheaper (oracle/hevc_transform.h orc_adjust_levels)
-  int intra_in_p = 0;         // "intra-in-p": intra coding units in P pictures ("uvgx intra-in-P v1", oracle/hevc_enc.c me_block32); not with rc_bands / band mode
+  int intra_in_p = 0;         // "intra-in-p": intra coding units in P pictures ("uvgx intra-in-P v1", oracle/hevc_enc.c me_block32); not in band mode
   int signhide = 0;           // kvazaar "signhide": sign_data_hiding_enabled_flag; the quantiser makes the parity of every eligible coefficient group say the hidden sign
   int hash = 0;               // kvazaar "hash": 1 checksum, 2 md5 -- a decoded picture hash SEI (D.2.19) behind every picture's slices, from the reconstruction downloaded for it
   int entropy_gpu = 0;        // arithmetic coder: 1 = on the GPU (k_cabac_rows, cabac_kernels.hip), 0 = host thread pool (entropy_host.h); band mode always uses the host pool

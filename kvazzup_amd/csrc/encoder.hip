@@ -27,7 +27,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   if (cfg.vaq > 0) cfg.qp_in_cu = 1;                       // the deltas travel as cu_qp_delta
   if (cfg.bitrate <= 0 || cfg.band_rows > 0) cfg.rc_bands = 0;
   if ((cfg.slices == 1 && !cfg.wpp) || (cfg.slices == 2 && cfg.tile_rows * cfg.tile_cols < 2) || (cfg.slices == 1 && cfg.tile_cols > 1) || cfg.slices < 0 || cfg.slices > 2) cfg.slices = 0;
-  if (cfg.rc_bands > 0 || cfg.band_rows > 0) cfg.intra_in_p = 0;     // (intra-in-P runs behind the whole picture's inter reconstruction: not with the CTU-row groups of rate control v2, not in band mode)
+  if (cfg.band_rows > 0) cfg.intra_in_p = 0;               // (intra-in-P runs behind the whole picture's inter reconstruction: not in band mode, where a picture is coded in parts by several instances)
   if (cfg.rc_bands > 0) cfg.qp_in_cu = 1;                  // ... and so do the steps of rate control v2
 
   const char *prio = getenv("KVAZZUP_AMD_PRIO"); if (!prio || strlen(prio) < 4) prio = "hnnn";   // main, tokenizer, input, decoder: the chain the next picture waits for is the urgent one (+6 % at 1080p; any explicit priority also gives the stream a hardware queue of its own)

@@ -512,10 +512,10 @@ static void me_block32(orc_encoder *e, int x0, int y0)
     }
   }
   set_cu(e, e->cu_intra, x0, y0, 32, 0);
-  if (e->cfg.intra_in_p && e->cfg.rc_bands == 0) {
+  if (e->cfg.intra_in_p) {
     /* "uvgx intra-in-P v1".  Inter cost of a 16x16 quarter = what the search found for it (split) or a quarter of the 32x32 block's cost;
      * quarters above the gate are priced as intra blocks by the intra picture's analysis (source neighbours: nothing depends on other
-     * blocks' decisions) and go intra when that is cheaper by INTRA_P_BITS bins.  A block with an intra quarter is coded as four 16x16
+     * blocks' decisions) and go intra when that is cheaper by INTRA_P_BITS bins (lam: the picture's lambda, also under rate control v2).  A block with an intra quarter is coded as four 16x16
      * units (the inter ones keep their vectors; an intra quarter is one 16x16 or four 8x8 intra units). */
     uint32_t ic[4]; int any = 0, cand[4];
     for (int k = 0; k < 4; k++) {
@@ -679,7 +679,15 @@ static void encode_inter_picture(orc_encoder *e)
       int r0 = (b * hc) / nb, r1 = ((b + 1) * hc) / nb;
       for (int y = r0 * 64; y < r1 * 64; y += 32) for (int x = 0; x < e->cw; x += 32) {
         if (e->cu_log2[b8i(e, x, y)] == 5) inter_recon_cu(e, x, y, 5);
-        else for (int k = 0; k < 4; k++) if (!e->cu_intra[b8i(e, x + (k & 1) * 16, y + (k >> 1) * 16)]) inter_recon_cu(e, x + (k & 1) * 16, y + (k >> 1) * 16, 4);
+        else for (int k = 0; k < 4; k++) {
+          int qx = x + (k & 1) * 16, qy = y + (k >> 1) * 16;
+          if (!e->cu_intra[b8i(e, qx, qy)]) { inter_recon_cu(e, qx, qy, 4); continue; }
+          /* an intra quarter: no levels yet (they come behind the whole picture's inter units; rate control v2 prices the groups without them) */
+          for (int pl = 0; pl < 3; pl++) {
+            int sh = pl ? 1 : 0, pw = e->cw >> sh, n = 16 >> sh;
+            for (int r = 0; r < n; r++) memset(e->coef[pl] + (size_t)((qy >> sh) + r) * pw + (qx >> sh), 0, sizeof(int16_t) * n);
+          }
+        }
       }
       if (e->cfg.rc_bands > 0) {
         for (int cy = r0; cy < r1; cy++) for (int cx = 0; cx < wc; cx++) cost += rc_ctu_cost(e, cx, cy);

@@ -500,6 +500,7 @@ def test_rdoq_and_sign_hiding_match_oracle(gpu, cfg):
     dict(w=416, h=240, qp=27, frames=7, cut=2, subme=4, sao=1, rdoq=1, signhide=1),
     dict(w=640, h=368, qp=30, frames=6, cut=2, subme=2, tiles="2x2"),
     dict(w=1920, h=1080, qp=32, frames=4, cut=2),                  # BASELINE configs[1] size
+    dict(w=640, h=384, qp=32, frames=12, cut=6, bitrate=600000, sao=1, subme=2),      # rate control v2 (uvgComm's default mode sets a bitrate): the row groups are priced without the intra units
 ])
 def test_intra_units_in_p_pictures_match_oracle(gpu, cfg):
     """intra-in-p (row f4): a scene cut inside a GOP -- k_me's 16x16 costs, k_intra_analyse<P> decisions, k_intra_recon<.., P> behind k_inter_recon;
@@ -508,10 +509,12 @@ def test_intra_units_in_p_pictures_match_oracle(gpu, cfg):
     from kvazzup_amd.codec import Decoder, Encoder
     w, h = cfg["w"], cfg["h"]
     tiles = cfg.get("tiles", "1x1"); tc, tr = [int(v) for v in tiles.split("x")]
-    oe = orc.OracleEncoder(w, h, qp=cfg["qp"], period=64, me_range=8, subme=cfg.get("subme", 0), sao=cfg.get("sao", 0), tile_rows=tr, tile_cols=tc)
+    br = cfg.get("bitrate", 0)
+    oe = orc.OracleEncoder(w, h, qp=cfg["qp"], period=64, me_range=8, subme=cfg.get("subme", 0), sao=cfg.get("sao", 0), tile_rows=tr, tile_cols=tc, bitrate=br, rc_bands=4 if br else 0)
     oe.set_option("intra-in-p", 1); oe.set_option("rdoq", cfg.get("rdoq", 0)); oe.set_option("signhide", cfg.get("signhide", 0))
     ge = Encoder(w, h, options=(("qp", cfg["qp"]), ("period", 64), ("me-range", 8), ("intra-in-p", 1), ("rdoq", cfg.get("rdoq", 0)), ("signhide", cfg.get("signhide", 0)),
-                                ("subme", cfg.get("subme", 0)), ("sao", "full" if cfg.get("sao") else "off")) + ((("tiles", tiles),) if tiles != "1x1" else ()))
+                                ("subme", cfg.get("subme", 0)), ("sao", "full" if cfg.get("sao") else "off")) + ((("tiles", tiles),) if tiles != "1x1" else ())
+                 + ((("bitrate", br), ("rc-algorithm", "lambda")) if br else ()), fields={"target_bitrate": br})
     assert not ge.rejected, ge.rejected
     gd = Decoder(); od = orc.OracleDecoder()
     intra_units = []

@@ -614,6 +614,17 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
     bd.nb_left = cx > 0 && f.ctu_tile[ctu - 1] == tile; bd.nb_up = cy > 0 && f.ctu_tile[ctu - f.wc] == tile;
     bd.nb_ur = cy > 0 && cx + 1 < f.wc && f.ctu_tile[ctu - f.wc + 1] == tile; bd.nb_ul = cy > 0 && cx > 0 && f.ctu_tile[ctu - f.wc - 1] == tile;
     bd.pl = my - 3; bd.pu = my - 3 * f.wc; bd.pur = bd.pu + 3; bd.pul = bd.pu - 3;
+    // which of the neighbours' edge units are intra units (a P picture's inter blocks are final before this kernel starts: nothing to wait
+    // for there) -- lanes 0-7: the left CTU's right column, 8-15 / 16-23: the bottom rows of the upper / upper-right CTU, 24: the corner
+    const int g = lane >> 3, u = lane & 7;
+    int X = -1, Y = -1;
+    if (g == 0 && bd.nb_left) { X = cx * 64 - 8; Y = cy * 64 + u * 8; }
+    else if (g == 1 && bd.nb_up) { X = cx * 64 + u * 8; Y = cy * 64 - 8; }
+    else if (g == 2 && bd.nb_ur) { X = (cx + 1) * 64 + u * 8; Y = cy * 64 - 8; }
+    else if (lane == 24 && bd.nb_ul) { X = cx * 64 - 8; Y = cy * 64 - 8; }
+    const bool in = X >= 0 && X < f.w && Y < f.h && f.b4[(size_t)(Y >> 2) * (f.pw >> 2) + (X >> 2)].ref_idx < 0;
+    const uint64_t m = __ballot(in);
+    bd.il = (uint32_t)m & 0xffu; bd.iu = (uint32_t)(m >> 8) & 0xffu; bd.iur = (uint32_t)(m >> 16) & 0xffu; bd.iul = (uint32_t)(m >> 24) & 1u;
   }
   borders_begin(bd, bc4);                                  // (its barrier also publishes blk[] / dq[])
   // what a block needs from memory is fetched one block ahead -- its residual samples (blocks up to 16x16: k_dec_intra_resid), or the

@@ -732,8 +732,10 @@ __device__ __forceinline__ void analyse_tile_satd(const AnalyseLds &s, int tile,
 // inter cost is above the gate leaves at once (nearly all of them), the others are analysed like an intra picture's and the quarters
 // that come out cheaper as intra blocks are turned into intra units.
 template <bool PP>
-__global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
+__global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
 {
+  // (PP: few regions get past the gate, so what counts is how long ONE of them takes, not how many fit on the chip: sixteen waves share its items)
+  constexpr int T = PP ? 1024 : 256, NW = T / 64;
   __shared__ AnalyseLds s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bx_, by_; xcd_block_2d(bx_, by_);
@@ -749,10 +751,10 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
     if (!any) return;
   }
   const uint8_t *src = f.src[0];
-  *(uint32_t *)&s.src[tid * 4] = *(const uint32_t *)&src[(size_t)(Y0 + (tid >> 3)) * f.cw + X0 + (tid & 7) * 4];
+  if (tid < 256) *(uint32_t *)&s.src[tid * 4] = *(const uint32_t *)&src[(size_t)(Y0 + (tid >> 3)) * f.cw + X0 + (tid & 7) * 4];
   // ---- references of the 21 blocks from the source picture (8.4.4.2.2 substitution as an index clamp: the available
   // groups are contiguous in scan order; availability by picture bounds and z-scan order)
-  for (int e = tid; e < 16 * 33 + 4 * 65; e += 256) {
+  for (int e = tid; e < 16 * 33 + 4 * 65; e += T) {
     int b, i, l2;
     if (e < 16 * 33) { b = e / 33; i = e - b * 33; l2 = 3; } else { int r = e - 16 * 33; b = 16 + r / 65; i = r % 65; l2 = 4; }
     const int n = 1 << l2, bi = b < 16 ? b : b - 16, nb = 32 >> l2;
@@ -770,7 +772,7 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
   }
   __syncthreads();
   // ---- filtered references (8.4.4.2.3) and DC values
-  for (int e = tid; e < 16 * 33 + 4 * 65; e += 256) {
+  for (int e = tid; e < 16 * 33 + 4 * 65; e += T) {
     int b, i, l2;
     if (e < 16 * 33) { b = e / 33; i = e - b * 33; l2 = 3; } else { int r = e - 16 * 33; b = 16 + r / 65; i = r % 65; l2 = 4; }
     const int n = 1 << l2;
@@ -793,8 +795,9 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
   __syncthreads();
   // ---- cost of every (block, mode): 8x8 Hadamard sums, (sum + 2) >> 2 per 8x8 block (oracle/hevc_enc.c satd_block()), or SADs
   if (f.satd) {
-    for (int item = wave; item < 4 * 35 * 2; item += 4) {
+    for (int item = wave; item < 4 * 35 * 2; item += NW) {
       const int kind = item & 1, tile = (item >> 1) & 3, mode = item >> 3;
+      if (PP && !cand[tile]) continue;                          // (intra-in-P: only the quarters above the gate are priced)
       uint32_t q[4];
       analyse_tile_satd(s, tile, kind, mode, lane, q);
       if (lane == 0) {
@@ -806,8 +809,9 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
       }
     }
   } else
-  for (int item = wave; item < 20 * 35; item += 4) {
+  for (int item = wave; item < 20 * 35; item += NW) {
     const int b = item / 35, mode = item - b * 35;
+    if (PP && !cand[b < 16 ? (b >> 3) * 2 + ((b >> 1) & 1) : b - 16]) continue;
     uint32_t c;
     if (b < 16) c = analyse_item<3>(s, b, (b & 3) * 8, (b >> 2) * 8, mode, lane);
     else c = analyse_item<4>(s, b, ((b - 16) & 1) * 16, ((b - 16) >> 1) * 16, mode, lane);
@@ -821,8 +825,10 @@ __global__ __launch_bounds__(256) void k_intra_analyse(EncFrame f)
     const int l2 = tid < 16 ? 3 : 4, n = 1 << l2, bi = tid < 16 ? tid : tid - 16, nb = 32 >> l2;
     const int x0 = X0 + (bi % nb) * n, y0 = Y0 + (bi / nb) * n;
     const int bw = f.cw >> l2, ib = (y0 >> l2) * bw + (x0 >> l2);
-    if (l2 == 3) { f.im8[ib] = (uint8_t)bm; f.ic8[ib] = bc; }
-    else { f.im16[ib] = (uint8_t)bm; f.ic16[ib] = bc; }
+    if (!PP) {
+      if (l2 == 3) { f.im8[ib] = (uint8_t)bm; f.ic8[ib] = bc; }
+      else { f.im16[ib] = (uint8_t)bm; f.ic16[ib] = bc; }
+    }
   }
   __syncthreads();
   // ---- bottom-up split decision for this 32x32 block: thread per 8x8 cell
@@ -980,6 +986,18 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   nb.nb_up = row > 0 && !tile_row_starts_at(hc, f.tile_rows, row); nb.nb_left = cx > 0 && !tile_col_starts_at(wc, f.tile_cols, cx);
   nb.nb_ur = nb.nb_up && cx + 1 < wc && !tile_col_starts_at(wc, f.tile_cols, cx + 1); nb.nb_ul = nb.nb_up && nb.nb_left;
   nb.pl = my - 3; nb.pu = my - 3 * wc; nb.pur = nb.pu + 3; nb.pul = nb.pu - 3;
+  if (PP) {
+    // which of the neighbours' edge units are intra units (kernel_common.h IntraBorders: the inter units around are final, nothing to wait for
+    // there) -- lanes 0-7: the left CTU's right column, 8-15 / 16-23: the bottom rows of the upper / upper-right CTU, 24: the corner
+    const int g = lane >> 3, u = lane & 7;
+    int X = -1, Y = -1;
+    if (g == 0 && nb.nb_left) { X = cx * 64 - 8; Y = row * 64 + u * 8; }
+    else if (g == 1 && nb.nb_up) { X = cx * 64 + u * 8; Y = row * 64 - 8; }
+    else if (g == 2 && nb.nb_ur) { X = (cx + 1) * 64 + u * 8; Y = row * 64 - 8; }
+    else if (lane == 24 && nb.nb_ul) { X = cx * 64 - 8; Y = row * 64 - 8; }
+    const uint64_t m = __ballot(X >= 0 && f.cu_intra[b8idx(f, X < 0 ? 0 : X, Y < 0 ? 0 : Y)] != 0);
+    nb.il = (uint32_t)m & 0xffu; nb.iu = (uint32_t)(m >> 8) & 0xffu; nb.iur = (uint32_t)(m >> 16) & 0xffu; nb.iul = (uint32_t)(m >> 24) & 1u;
+  }
   chain_init(ch, nb, (uint32_t)~im, (uint32_t)(~im >> 32));
   if (PP && tid == 0) {                                     // the leading run of inter units is progress the neighbours may see at once
     const int prefix = __builtin_ctzll(im);
@@ -1880,7 +1898,7 @@ void launch_inter_signal(const EncFrame &f, hipStream_t st)
 void launch_intra_analyse(const EncFrame &f, hipStream_t st)
 {
   if (f.is_intra) hipLaunchKernelGGL(k_intra_analyse<false>, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f);
-  else hipLaunchKernelGGL(k_intra_analyse<true>, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f);       // intra-in-P, behind k_me
+  else hipLaunchKernelGGL(k_intra_analyse<true>, dim3(f.cw / 32, band_rows(f) * 2), dim3(1024), 0, st, f);       // intra-in-P, behind k_me
 }
 void launch_intra_recon(const EncFrame &f, hipStream_t st)
 {

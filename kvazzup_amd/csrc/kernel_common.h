@@ -189,9 +189,21 @@ __device__ __forceinline__ int kv_units_right(uint32_t p) { return p >= 64 ? 8 :
 
 // The borders of a CTU picture in LDS (row 0 / column 15 of the padded layout, pitch lp) are filled piecewise from the neighbouring
 // CTUs' samples in the picture, as far as those CTUs' progress allows.
+// Pictures that mix intra and inter blocks (P pictures: the inter blocks are final before the intra kernel starts): a block waits for a
+// neighbouring CTU only as far as the edge units it reads ARE intra units -- masks over the eight 8x8 units of the neighbour's right
+// column (il) / bottom row (iu, iur) and its corner unit (iul); all ones in an intra picture.  kv_edge_need: the progress value at which
+// the intra units among edge units 0 .. last are final, 0 when there is none (nothing to wait for).
+__device__ __forceinline__ uint32_t kv_edge_need(uint32_t mask, int last, bool column)
+{
+  mask &= (2u << last) - 1u;
+  if (!mask) return 0u;
+  const int top = 31 - __builtin_clz(mask);
+  return (uint32_t)(column ? kv_zunit8(7, top) : kv_zunit8(top, 7)) + 1u;
+}
 struct IntraBorders {
   const uint32_t *pl, *pu, *pur, *pul;       // progress counters of the left / upper / upper-right / upper-left CTU (same plane)
   bool nb_left, nb_up, nb_ur, nb_ul;         // which of them exist (inside the picture, same tile)
+  uint32_t il = 0xffu, iu = 0xffu, iur = 0xffu, iul = 1u;
   uint32_t seen_l, seen_u, seen_ur, seen_ul;
   int top_loaded, left_loaded; bool corner_loaded;
 };
@@ -218,7 +230,7 @@ __device__ __forceinline__ void borders_need(IntraBorders &b, uint8_t *pic, int 
   if (rx == 0 && b.nb_left) {
     const int need = imin(S, ry + 2 * n);
     if (need > b.left_loaded) {
-      b.seen_l = wait_wt(b.pl, (uint32_t)kv_zunit8(7, ((need - 1) << sh) >> 3) + 1, b.seen_l, bcast, err);
+      b.seen_l = wait_wt(b.pl, kv_edge_need(b.il, ((need - 1) << sh) >> 3, true), b.seen_l, bcast, err);
       const int upto = imax(need, imin(S, kv_units_right(b.seen_l) * (8 >> sh)));
       for (int i = b.left_loaded + tid; i < upto; i += nthreads) pic[(i + 1) * lp + 15] = (uint8_t)ld_l2_u8(plane + (size_t)(cy * S + i) * gp + cx * S - 1);
       b.left_loaded = upto; loaded = true;
@@ -229,11 +241,11 @@ __device__ __forceinline__ void borders_need(IntraBorders &b, uint8_t *pic, int 
     if (need > b.top_loaded) {
       int upto = need;
       if (b.top_loaded < S) {
-        b.seen_u = wait_wt(b.pu, (uint32_t)kv_zunit8(((imin(S, need) - 1) << sh) >> 3, 7) + 1, b.seen_u, bcast, err);
+        b.seen_u = wait_wt(b.pu, kv_edge_need(b.iu, ((imin(S, need) - 1) << sh) >> 3, false), b.seen_u, bcast, err);
         upto = imax(upto, imin(imin(S, lim), kv_units_bottom(b.seen_u) * (8 >> sh)));
       }
       if (need > S) {
-        b.seen_ur = wait_wt(b.pur, (uint32_t)kv_zunit8(((need - S - 1) << sh) >> 3, 7) + 1, b.seen_ur, bcast, err);
+        b.seen_ur = wait_wt(b.pur, kv_edge_need(b.iur, ((need - S - 1) << sh) >> 3, false), b.seen_ur, bcast, err);
         upto = imax(upto, imin(lim, S + kv_units_bottom(b.seen_ur) * (8 >> sh)));
       }
       // (both ends are multiples of 4: block sizes, CTU sizes and picture widths are)
@@ -242,7 +254,7 @@ __device__ __forceinline__ void borders_need(IntraBorders &b, uint8_t *pic, int 
     }
   }
   if (rx == 0 && ry == 0 && b.nb_ul && !b.corner_loaded) {
-    b.seen_ul = wait_wt(b.pul, 64u, b.seen_ul, bcast, err);
+    b.seen_ul = wait_wt(b.pul, b.iul ? 64u : 0u, b.seen_ul, bcast, err);
     if (tid == 0) pic[15] = (uint8_t)ld_l2_u8(plane + (size_t)(cy * S - 1) * gp + cx * S - 1);
     b.corner_loaded = true; loaded = true;
   }
@@ -276,6 +288,7 @@ struct IntraChain {
 struct IntraNeighbours {
   const uint32_t *pl, *pu, *pur, *pul;       // progress counters of the left / upper / upper-right / upper-left CTU (same plane)
   bool nb_left, nb_up, nb_ur, nb_ul;         // which of them exist (inside the picture, same tile)
+  uint32_t il = 0xffu, iu = 0xffu, iur = 0xffu, iul = 1u;      // (IntraBorders: the neighbours' edge units that are intra units)
 };
 __device__ __forceinline__ uint32_t lds_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int lds_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -315,7 +328,7 @@ __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNei
   if (rx == 0 && b.nb_left) {
     const int need = imin(S, ry + 2 * n), have = __builtin_amdgcn_readfirstlane(lds_load(&ch.left_loaded));
     if (need > have) {
-      const uint32_t seen = wave_wait_wt(b.pl, (uint32_t)kv_zunit8(7, ((need - 1) << sh) >> 3) + 1, &ch.seen_l, err, lane);
+      const uint32_t seen = wave_wait_wt(b.pl, kv_edge_need(b.il, ((need - 1) << sh) >> 3, true), &ch.seen_l, err, lane);
       const int upto = imax(need, imin(S, kv_units_right(seen) * (8 >> sh)));
       for (int i = have + lane; i < upto; i += 64) pic[(i + 1) * lp + 15] = (uint8_t)ld_l2_u8(plane + (size_t)(cy * S + i) * gp + cx * S - 1);
       wave_sync();
@@ -327,11 +340,11 @@ __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNei
     if (need > have) {
       int upto = need;
       if (have < S) {
-        const uint32_t seen = wave_wait_wt(b.pu, (uint32_t)kv_zunit8(((imin(S, need) - 1) << sh) >> 3, 7) + 1, &ch.seen_u, err, lane);
+        const uint32_t seen = wave_wait_wt(b.pu, kv_edge_need(b.iu, ((imin(S, need) - 1) << sh) >> 3, false), &ch.seen_u, err, lane);
         upto = imax(upto, imin(imin(S, lim), kv_units_bottom(seen) * (8 >> sh)));
       }
       if (need > S) {
-        const uint32_t seen = wave_wait_wt(b.pur, (uint32_t)kv_zunit8(((need - S - 1) << sh) >> 3, 7) + 1, &ch.seen_ur, err, lane);
+        const uint32_t seen = wave_wait_wt(b.pur, kv_edge_need(b.iur, ((need - S - 1) << sh) >> 3, false), &ch.seen_ur, err, lane);
         upto = imax(upto, imin(lim, S + kv_units_bottom(seen) * (8 >> sh)));
       }
       // (both ends are multiples of 4: block sizes, CTU sizes and picture widths are)
@@ -341,7 +354,7 @@ __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNei
     }
   }
   if (rx == 0 && ry == 0 && b.nb_ul && !__builtin_amdgcn_readfirstlane(lds_load(&ch.corner_loaded))) {
-    wave_wait_wt(b.pul, 64u, &ch.seen_ul, err, lane);
+    wave_wait_wt(b.pul, b.iul ? 64u : 0u, &ch.seen_ul, err, lane);
     if (lane == 0) { pic[15] = (uint8_t)ld_l2_u8(plane + (size_t)(cy * S - 1) * gp + cx * S - 1); }
     wave_sync();
     if (lane == 0) atomicMax(&ch.corner_loaded, 1);

@@ -77,10 +77,13 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
     // motion refinement (Kvazaar's preset table, as recalled in SURVEY.md appendix A: sao off and subme 0 at ultrafast only;
     // subme 2 at superfast / veryfast, 4 from faster on).  Later options ("sao", "subme") override, as in Kvazaar.
     // rdoq from medium on, signhide from slow on (as recalled from Kvazaar's table, which ties both to its slower presets)
+    // intra-in-p: Kvazaar codes intra units in P pictures at every preset; here from superfast on -- the intra units of a P picture are a
+    // dependency chain on the GPU (k_intra_recon<.., P>: measured 2.8x fewer pictures/s on the benchmark clip for 13 % fewer bits, DESIGN.md
+    // section 2), so the fastest preset keeps the all-inter P pictures the benchmark was defined with; "intra-in-p=1" switches it on there too
     for (int i = 0; i < 10; i++) if (!strcmp(value, presets[i])) {
       cfg->sao_type = i ? KVZ_SAO_FULL : KVZ_SAO_OFF;
       cfg->fme_level = i == 0 ? 0 : (i <= 2 ? 2 : 4);
-      cfg->rdoq_enable = i >= 5; cfg->signhide_enable = i >= 6;
+      cfg->rdoq_enable = i >= 5; cfg->signhide_enable = i >= 6; cfg->intra_in_p = i >= 1;
       return 1;
     }
     return 0;

@@ -22,9 +22,12 @@ HIP = {   # name: kvz_api options (all with hash=md5)
     "hip_subme4_sao_qp28": (("qp", 28), ("period", 8), ("me-range", 16), ("subme", 4), ("sao", "full")),
     "hip_rc_400k": (("qp", 32), ("period", 8), ("me-range", 16), ("bitrate", 400000), ("rc-algorithm", "lambda")),
     "hip_vaq_roi_qp32": (("qp", 32), ("period", 8), ("me-range", 16), ("vaq", 8)),
+    # a scene cut at picture 4 of the first GOP: intra units in P pictures, rdoq, sign data hiding (preset slow's tool set)
+    "hip_scenecut_slow_qp30": (("qp", 30), ("period", 8), ("me-range", 16), ("preset", "slow")),
 }
 index = {}
 if "--no-hip" not in sys.argv:
+    from kvazzup_amd import synth
     from kvazzup_amd.codec import Encoder
     for name, opts in HIP.items():
         br = dict(opts).get("bitrate", 0)
@@ -33,7 +36,7 @@ if "--no-hip" not in sys.argv:
         od = orc.OracleDecoder()
         stream, md5s = b"", []
         for t in range(N):
-            au, rec = e.encode(orc.synth_frame(0, SEED, W, H, t))
+            au, rec = e.encode(synth.scene_cut_frame(SEED, W, H, t, 4) if "scenecut" in name else orc.synth_frame(0, SEED, W, H, t))
             fr = od.decode_au(au, t)
             assert len(fr) == 1 and np.array_equal(fr[0]["i420"], rec), (name, t)      # the checker decodes it to the encoder's reconstruction
             stream += au; md5s.append(hashlib.md5(rec.tobytes()).hexdigest())

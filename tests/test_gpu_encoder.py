@@ -535,11 +535,11 @@ def test_intra_units_in_p_pictures_match_oracle(gpu, cfg):
 
 @pytest.mark.gpu
 def test_presets_switch_rdoq_and_sign_hiding_on(gpu):
-    """preset medium and above: rdoq; slow and above: signhide too (config_parse), and the stream says so in its PPS"""
+    """preset medium and above: rdoq; slow and above: signhide too; superfast and above: intra units in P pictures (config_parse)"""
     from kvazzup_amd.codec import Encoder
-    for preset, rd, sh in (("ultrafast", 0, 0), ("fast", 0, 0), ("medium", 1, 0), ("slow", 1, 1), ("placebo", 1, 1)):
+    for preset, rd, sh, ip in (("ultrafast", 0, 0, 0), ("superfast", 0, 0, 1), ("fast", 0, 0, 1), ("medium", 1, 0, 1), ("slow", 1, 1, 1), ("placebo", 1, 1, 1)):
         e = Encoder(256, 128, options=(("preset", preset),))
-        assert (e.cfg.contents.rdoq_enable, e.cfg.contents.signhide_enable) == (rd, sh), preset
+        assert (e.cfg.contents.rdoq_enable, e.cfg.contents.signhide_enable, e.cfg.contents.intra_in_p) == (rd, sh, ip), preset
         e.close()
     # tools that do not exist are refused when switched on, accepted when switched off (kvazaarfilter.cpp:363-367 logs the refusal)
     e = Encoder(256, 128, options=(("amp", 1), ("smp", 0), ("bipred", 1), ("tmvp", 0), ("rd", 2), ("ref", 3), ("mv-rdo", 1), ("full-intra-search", 0)))

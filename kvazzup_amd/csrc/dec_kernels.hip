@@ -555,14 +555,24 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
   __shared__ DecIntraLds s;
   __shared__ IntraWaveScratch ws;
   __shared__ uint32_t bcast, bc4[4];
-  const int lane = threadIdx.x, ctu = (int)f.intra_order[blockIdx.x / 3], c = (int)blockIdx.x % 3, cx = ctu % f.wc, cy = ctu / f.wc;
+  // (enc_kernels.hip k_intra_recon: the launch has as many workgroups as the wavefront keeps busy, each takes the next (CTU, plane) in
+  // anti-diagonal order from a ticket counter -- f.progress[3 * CTUs] -- so that the chain does not park a workgroup per (CTU, plane) on the chip)
+  const int lane = threadIdx.x;
+  const uint32_t nticket = 3u * (uint32_t)f.wc * (uint32_t)(f.nrows > 0 ? f.nrows : f.hc);
+  for (;;) {
+  __syncthreads();
+  uint32_t ticket = 0;
+  if (lane == 0) ticket = atomicAdd(f.progress + (size_t)3 * f.wc * f.hc, 1u);
+  ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+  if (ticket >= nticket) break;
+  const int ctu = (int)f.intra_order[ticket / 3u], c = (int)(ticket % 3u), cx = ctu % f.wc, cy = ctu / f.wc;
   const int sh = c ? 1 : 0, S = 64 >> sh, cpitch = f.pw >> sh, wC = f.w >> sh, hC = f.h >> sh;
   uint32_t *my = f.progress + (size_t)ctu * 3 + c;
   const TuRange ct = f.ctu[ctu];
   const int count = (int)(ct.count & 0xffffffu);
   if (!((ct.count >> (24 + c)) & 1)) {                  // no intra block of this plane in the CTU: nothing to wait for, nothing written
     if (lane == 0) __hip_atomic_store(my, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
+    continue;
   }
   for (int i = lane; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];
   uint8_t *plane = f.rec[c];
@@ -673,6 +683,7 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
     }
   }
   publish_wt(my, 64u);
+  }
 }
 
 // =============================================================================================
@@ -867,7 +878,13 @@ __global__ __launch_bounds__(256) void k_dec_sao(DecFrame f)
 static inline int dec_rows(const DecFrame &f) { return f.nrows > 0 ? f.nrows : f.hc; }
 void launch_dec_inter(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_inter, dim3(f.wc * 2, dec_rows(f) * 2), dim3(256), 0, st, f); }
 void launch_dec_intra_resid(const DecFrame &f, hipStream_t st) { if (f.ntu > 0) hipLaunchKernelGGL(k_dec_intra_resid, dim3((f.ntu + 3) / 4), dim3(256), 0, st, f); }
-void launch_dec_intra(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_intra, dim3(f.wc * dec_rows(f) * 3), dim3(64), 0, st, f); }     // (f.intra_order lists the band's CTUs)
+void launch_dec_intra(const DecFrame &f, hipStream_t st)
+{
+  // as many one-wave workgroups as three anti-diagonals of the CTU wavefront hold, in three planes (k_dec_intra: tickets; f.intra_order lists the band's CTUs)
+  static const int diags = getenv("KVAZZUP_AMD_INTRA_DIAGS") ? atoi(getenv("KVAZZUP_AMD_INTRA_DIAGS")) : 3;      // (measurement aid; 0: a workgroup per (CTU, plane))
+  const int nr = dec_rows(f), diag = nr < (f.wc + 1) / 2 ? nr : (f.wc + 1) / 2, all = f.wc * nr * 3, want = diags > 0 ? 3 * diags * diag + 32 : all;
+  hipLaunchKernelGGL(k_dec_intra, dim3(want < all ? want : all), dim3(64), 0, st, f);
+}
 void launch_dec_deblock(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_deblock, dim3(f.wc * dec_rows(f)), dim3(256), 0, st, f); }
 void launch_dec_sao(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_sao, dim3(f.wc * f.hc), dim3(256), 0, st, f); }
 

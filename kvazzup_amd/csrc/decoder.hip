@@ -367,11 +367,25 @@ struct SliceParser {
     for (int y = y0; y < y0 + bh && y < h; y += 4) memset(arr + bi(x0, y), v, (size_t)cols);
   }
   // one record for every 4x4 unit of a rectangle
-  void fill_recs(int x0, int y0, int bw, int bh, const B4Rec &r)
+  // cu_edges: the rectangle is a whole coding block -- its top row and left column get the coding block's edge flags in the same pass (a
+  // read-modify-write of the column afterwards waits for every one of the stores just issued: it was the hottest line of the parser)
+  bool cu_edges_done = false;
+  void fill_recs(int x0, int y0, int bw, int bh, const B4Rec &r, bool cu_edges = false)
   {
     uint64_t v; memcpy(&v, &r, 8);
     const int cols = imin(bw, w - x0) >> 2;
-    for (int y = y0; y < y0 + bh && y < h; y += 4) { uint64_t *p = (uint64_t *)&b4[bi(x0, y)]; for (int i = 0; i < cols; i++) p[i] = v; }
+    if (!cu_edges) { for (int y = y0; y < y0 + bh && y < h; y += 4) { uint64_t *p = (uint64_t *)&b4[bi(x0, y)]; for (int i = 0; i < cols; i++) p[i] = v; } return; }
+    B4Rec e = r;
+    e.flags |= B4_EDGE_V | B4_TU_V; uint64_t vl; memcpy(&vl, &e, 8);                    // first column
+    e.flags = r.flags | B4_EDGE_H | B4_TU_H; uint64_t vt; memcpy(&vt, &e, 8);           // first row
+    e.flags |= B4_EDGE_V | B4_TU_V; uint64_t vc; memcpy(&vc, &e, 8);                    // the corner
+    for (int y = y0; y < y0 + bh && y < h; y += 4) {
+      uint64_t *p = (uint64_t *)&b4[bi(x0, y)];
+      const bool top = y == y0;
+      if (cols > 0) p[0] = top ? vc : vl;
+      for (int i = 1; i < cols; i++) p[i] = top ? vt : v;
+    }
+    cu_edges_done = true;
   }
   void emit_tu(const DecTu &td)
   {
@@ -547,7 +561,7 @@ struct SliceParser {
       if (top < ref_y0 || bot > ref_y1) err = DEC_ERR_UNSUPPORTED;
     }
     B4Rec r; r.mvx = (int16_t)mvx; r.mvy = (int16_t)mvy; r.ref_idx = (int8_t)ref_idx; r.flags = 0; r.qp_y = (int8_t)qp_y; r.slot = job.ref_slot[ref_idx];
-    fill_recs(xp, yp, bw, bh, r);
+    fill_recs(xp, yp, bw, bh, r, bw == ncbs && bh == ncbs);
     if (bw != ncbs || bh != ncbs) {                          // prediction block edges inside the coding block (deblocking); the block's own are set by coding_unit
       for (int i = 0; i < bh && yp + i < h; i += 4) b4[bi(xp, yp + i)].flags |= B4_EDGE_V;
       for (int i = 0; i < bw && xp + i < w; i += 4) b4[bi(xp + i, yp)].flags |= B4_EDGE_H;
@@ -652,7 +666,7 @@ struct SliceParser {
       const int l = avail(x0, y0, x0 - 1, y0) && pm[b8(x0 - 1, y0)] == PM_SKIP, a = avail(x0, y0, x0, y0 - 1) && pm[b8(x0, y0 - 1)] == PM_SKIP;
       skip = c.bin(CTX_SKIP + l + a);
     }
-    part_mode = PART_2Nx2N; intra_split = false;
+    part_mode = PART_2Nx2N; intra_split = false; cu_edges_done = false;
     int rqt_root_cbf = 1, merge_2nx2n = 0;
     fill_cu8(ctd, x0, y0, n, depth);
     qp_y = (qp_y_pred + cu_qp_delta_val + 52) % 52;          // CuQpDeltaVal of the quantisation group so far
@@ -715,7 +729,7 @@ struct SliceParser {
         if (icpm == 4) chroma_mode = intra_modes[0];
         else { chroma_mode = cm[icpm]; if (chroma_mode == intra_modes[0]) chroma_mode = 34; }
         B4Rec r; r.mvx = 0; r.mvy = 0; r.ref_idx = -1; r.flags = 0; r.qp_y = (int8_t)qp_y; r.slot = 0;
-        fill_recs(x0, y0, n, n, r);
+        fill_recs(x0, y0, n, n, r, true);
         job.any_intra = true;
       } else {
         const int hh = n / 2, q = n / 4; int mf = 0;
@@ -733,7 +747,7 @@ struct SliceParser {
       }
     }
     if (err) return;
-    {                                                      // coding block edges are transform and prediction edges
+    if (!cu_edges_done) {                                  // coding block edges are transform and prediction edges (a block of one prediction block: written with its records)
       B4Rec *const r0 = &b4[bi(x0, y0)];
       const int rows = (imin(n, h - y0) + 3) >> 2, cols = (imin(n, w - x0) + 3) >> 2;
       for (int i = 0; i < rows; i++) r0[(size_t)i * b4w].flags |= B4_EDGE_V | B4_TU_V;
@@ -910,7 +924,7 @@ bool Decoder::ensure_buffers(int w, int h)
   }
   h_out_cap_ = npx * 3 / 2;                              // (allocated by the first picture that is downloaded)
   for (int i = 0; i <= gpu_depth_; i++) { d_in_cap_[i] = fixed_bytes() + (1 << 20); HIP_TRY(hipMalloc(&d_in_[i], d_in_cap_[i])); }
-  HIP_TRY(hipMalloc(&progress_, sizeof(uint32_t) * 3 * (size_t)(pw_ / 64) * (ph_ / 64)));
+  HIP_TRY(hipMalloc(&progress_, sizeof(uint32_t) * (3 * (size_t)(pw_ / 64) * (ph_ / 64) + 1)));      // (+ k_dec_intra's ticket counter)
   {
     // dispatch order of k_dec_intra's workgroups: CTUs by anti-diagonal cx + 2 cy (every CTU a block depends on comes earlier)
     const int wc = pw_ / 64, hc = ph_ / 64;
@@ -1825,7 +1839,7 @@ int Decoder::launch_gpu(PicJob &job)
   if (dpb_[job.slot].last_dl) { if (hipStreamWaitEvent(stream_, dpb_[job.slot].last_dl, 0) != hipSuccess) return DEC_ERR_GPU; dpb_[job.slot].last_dl = nullptr; }
   if (job.any_inter) timed(DK_INTER, [&] { launch_dec_inter(f, stream_); });
   if (job.any_intra) {
-    if (hipMemsetAsync(progress_, 0, sizeof(uint32_t) * 3 * (size_t)f.wc * f.hc, stream_) != hipSuccess) return DEC_ERR_GPU;
+    if (hipMemsetAsync(progress_, 0, sizeof(uint32_t) * (3 * (size_t)f.wc * f.hc + 1), stream_) != hipSuccess) return DEC_ERR_GPU;
     timed(DK_INTRA, [&] { launch_dec_intra_resid(f, stream_); launch_dec_intra(f, stream_); });
   }
   if (band_nrows_ > 0) { band_f_ = f; band_din_ = d_in_; }       // deblocking follows the halo exchange (band_deblock)

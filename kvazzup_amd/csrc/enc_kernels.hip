@@ -743,6 +743,7 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
   uint32_t icost[4] = {0, 0, 0, 0}; bool cand[4] = {false, false, false, false};
   if (PP) {
     if (!((bx_ | by_) & 1) && tid < 3) f.sync[(size_t)((Y0 >> 6) * (f.cw >> 6) + (X0 >> 6)) * 3 + tid] = 0;      // the progress counters k_intra_recon<.., true> starts from
+    if (bx_ == 0 && by_ == 0 && tid == 3) f.sync[(size_t)3 * (f.cw >> 6) * (f.ch >> 6)] = 0;                      // ... and its ticket counter
     bool any = false;
     for (int k = 0; k < 4; k++) {
       icost[k] = f.me_cost16[((Y0 >> 4) + (k >> 1)) * (f.cw >> 4) + (X0 >> 4) + (k & 1)];
@@ -963,12 +964,26 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   __shared__ IntraChain ch;
   __shared__ IntraBlk blk[64];                              // the CTU's coding units in z-order
   __shared__ uint2 dep[64], cover[64];                      // per coding unit: units it waits for, units it finishes
-  __shared__ uint32_t nblk_s;
+  __shared__ uint32_t nblk_s, ticket_s;
   __shared__ uint8_t cu_cbf_s[64];
   // Workgroups are dispatched in blockIdx order and a picture has more of them than fit on the chip at once, so they are numbered
   // the way the wavefront advances (f.intra_order: by cx + 2 cy -- every CTU a block depends on comes earlier) instead of in raster
   // order, where the right ends of the upper rows would hold the slots the lower left needs.
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wc = f.cw >> 6, c = (int)blockIdx.x % 3, ctu = (int)f.intra_order[blockIdx.x / 3];
+  // ... and a workgroup does not belong to one (CTU, plane): the launch has only as many workgroups as the wavefront keeps busy (a few
+  // anti-diagonals of CTUs), each taking the next (CTU, plane) in that order from a ticket counter when it is done with the last.
+  // Whatever a workgroup waits for has a lower ticket, so it is held by a workgroup that runs or is finished.  The point is what the
+  // OTHER kernels on the GPU get: a workgroup per (CTU, plane) parks 1500 waiting workgroups with 30 KB of LDS each on the chip for the
+  // 1.6 ms the chain takes, and the decoder's (or, beside k_dec_intra, the encoder's) P pictures stand still until it is over.
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wc = f.cw >> 6;
+  const uint32_t nticket = 3u * (uint32_t)wc * (uint32_t)band_rows(f);
+  uint32_t *const ticket_ctr = f.sync + (size_t)3 * wc * (f.ch >> 6);
+  for (;;) {
+  __syncthreads();                                          // (everybody is done with the last (CTU, plane): LDS and the ticket word are free)
+  if (tid == 0) ticket_s = atomicAdd(ticket_ctr, 1u);
+  __syncthreads();
+  const uint32_t ticket = ticket_s;
+  if (ticket >= nticket) break;
+  const int c = (int)(ticket % 3u), ctu = (int)f.intra_order[ticket / 3u];
   const int row = ctu / wc, cx = ctu % wc;
   const int adj = (f.rdoq ? 1 : 0) | (f.signhide ? 2 : 0);      // level adjustment behind the quantiser (hevc_core.h adjust_group)
   const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, P = 16 + 2 * S;
@@ -977,7 +992,7 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   if (PP) {
     int zx, zy; ctu_z_to_xy(lane, zx, zy);
     im = __ballot(f.cu_intra[b8idx(f, cx * 64 + zx * 8, row * 64 + zy * 8)] != 0);      // (every wave for itself: no barrier in front of the exit)
-    if (!im) { if (tid == 0) __hip_atomic_store(my, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    if (!im) { if (tid == 0) __hip_atomic_store(my, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
   }
   for (int i = tid; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];
   const int qpl = ctu_quant_qp(f, cx * 64, row * 64), qp = c ? kChromaQp[qpl] : qpl;
@@ -1092,6 +1107,7 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   }
   if (tid == 0) __hip_atomic_fetch_max(my, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (every wave has drained its stores: the barrier above)
   if (f.trace && tid == 0) { unsigned long long *t = f.trace + ((size_t)ctu * 3 + c) * 8; t[2] = wall_clock64(); t[7] = (unsigned long long)nblk; }
+  }
 }
 
 // =============================================================================================
@@ -1902,7 +1918,10 @@ void launch_intra_analyse(const EncFrame &f, hipStream_t st)
 }
 void launch_intra_recon(const EncFrame &f, hipStream_t st)
 {
-  const dim3 grid(3 * (f.cw / 64) * band_rows(f)), block(64 * KVZ_INTRA_WAVES);
+  // as many workgroups as three anti-diagonals of the CTU wavefront hold, in three planes (k_intra_recon: tickets)
+  static const int diags = getenv("KVAZZUP_AMD_INTRA_DIAGS") ? atoi(getenv("KVAZZUP_AMD_INTRA_DIAGS")) : 3;      // (measurement aid; 0: a workgroup per (CTU, plane))
+  const int wc = f.cw / 64, nr = band_rows(f), diag = nr < (wc + 1) / 2 ? nr : (wc + 1) / 2, want = diags > 0 ? 3 * diags * diag + 32 : 3 * wc * nr;
+  const dim3 grid(want < 3 * wc * nr ? want : 3 * wc * nr), block(64 * KVZ_INTRA_WAVES);
   const bool adj = f.rdoq || f.signhide;
   if (!f.is_intra) {                                                                                            // intra-in-P, behind k_inter_recon
     if (adj) hipLaunchKernelGGL((k_intra_recon<true, true>), grid, block, 0, st, f); else hipLaunchKernelGGL((k_intra_recon<false, true>), grid, block, 0, st, f);

@@ -146,7 +146,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     HIP_OK(hipEventCreateWithFlags(&sl.rec_done, hipEventDisableTiming));
   }
   HIP_OK(hipEventCreateWithFlags(&in_done_, hipEventDisableTiming));
-  HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * rows_ * (cw_ / 64) * 3));       // one progress counter per CTU and colour plane
+  HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 1)));       // one progress counter per CTU and colour plane, and the ticket counter of k_intra_recon's workgroups
   if (cfg.intra_in_p) HIP_OK(hipMalloc(&me_cost16_, sizeof(uint32_t) * (cw_ / 16) * (ch_ / 16)));      // k_me's inter cost per 16x16 block (intra-in-P)
   {
     // dispatch order of the intra reconstruction's workgroups: the CTUs of the rows this instance codes, by anti-diagonal cx + 2 cy
@@ -486,7 +486,7 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   if (!upload_qp_targets()) return false;
   if (rc_state_) launch_rc_begin(rc_state_, frame_idx_ >= 3 ? 8u * rc_bytes_[(frame_idx_ - 3) & 7] : 0u, (frame_idx_ - 3) & 7, frame_idx_ >= 3, stream_);
   if (intra) {
-    HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * rows_ * (cw_ / 64) * 3, stream_));
+    HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 1), stream_));
     HIP_CHECK(hipMemsetAsync(f_.cu_cbf, 0, (size_t)f_.b8w * f_.b8h, stream_));     // the three plane waves OR their bit in
     timed(K_INTRA_RECON, stream_, [&] { launch_intra_recon(f, stream_); });
   } else {
@@ -700,7 +700,7 @@ bool Encoder::band_phase1(const uint8_t *d_i420)
   launch_pad_input(d_i420, cfg_.width, cfg_.height, src_[0][0], src_[0][1], src_[0][2], cw_, ch_, stream_);
   if (band_intra_) {
     launch_intra_analyse(f, stream_);
-    HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * rows_ * (cw_ / 64) * 3, stream_));
+    HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 1), stream_));
     HIP_CHECK(hipMemsetAsync(f_.cu_cbf + (size_t)f.row0 * 8 * f.b8w, 0, (size_t)f.b8w * 8 * band_rows(f), stream_));
     launch_intra_recon(f, stream_);
   } else {

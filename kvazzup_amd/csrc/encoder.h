@@ -127,7 +127,7 @@ class Encoder {
   // stream of its own -- picture t + 1 travels over PCIe while the kernels of picture t run -- and, for callers whose planes are not
   // page-locked, a ring of pinned staging buffers (allocated on first use).  Twelve entries: more than the pictures that can be in flight
   // (owf <= 8 plus the submitter's hand), so a copy never waits in the copy engine's queue for its buffer's previous reader.
-  static constexpr int kInRing = 12;
+  static constexpr int kInRing = 20;
   uint8_t *d_in_[kInRing] = {};          // packed input (device)
   uint8_t *h_in_[kInRing] = {};          // pinned host staging
   hipStream_t stream_h2d_ = nullptr;
@@ -140,7 +140,8 @@ class Encoder {
   static constexpr int kSets = 8;
   uint8_t *src_[kSets][3] = {};         // padded source planes
   // reconstruction ring: the picture being coded, its reference, and (owf >= 2) the one still waiting to be output
-  uint8_t *rec_[10][3] = {};
+  static constexpr int kMaxDepth = 16;    // pictures in flight behind the one being submitted (owf), at most
+  uint8_t *rec_[kMaxDepth + 4][3] = {};
   bool spin_wait_ = false;      // KVAZZUP_AMD_SPIN: poll the GPU instead of napping between queries
   int nrec_ = 3;                // reconstruction ring: the picture being written, its reference, and the ones whose output is still owed (owf)
   int cur_idx_ = 0, ref_idx_ = 2, out_idx_ = 2;
@@ -168,6 +169,9 @@ class Encoder {
   uint8_t *work_[3] = {nullptr, nullptr, nullptr};   // SAO on: the picture up to deblocking (rec_[] then holds the filtered pictures)
   SaoParams *sao_[kSets] = {};            // per CTU, one array per set
   hipEvent_t ev_sao_ = nullptr;
+  // An intra picture depends on no other picture: its chain (1.6 ms at 1080p, twenty picture intervals) is queued on a stream of its own the moment the
+  // picture is accepted, beside the P pictures in front of it that the main stream is still working through; the next P picture waits for ev_idr_done_.
+  hipStream_t stream_idr_ = nullptr; hipEvent_t ev_idr_done_ = nullptr; bool idr_pending_ = false, idr_side_ = false;
   hipEvent_t ev_signalled_ = nullptr, ev_tok_done_[kSets] = {}; bool tok_pending_[kSets] = {};
   void bind_set(int k);
   uint8_t *intra_scratch_ = nullptr;
@@ -192,7 +196,7 @@ class Encoder {
     std::vector<EvPair> ev; size_t ev_used = 0;
     EncodedPicture result; bool ready = false, ok = true;   // owf >= 2: filled by the background thread
   };
-  Slot slot_[10]; Slot *cur_slot_ = nullptr; int nslots_ = 1, depth_ = 0;
+  Slot slot_[kMaxDepth + 2]; Slot *cur_slot_ = nullptr; int nslots_ = 1, depth_ = 0;
   size_t stage_cap_ = 0, out_cap_ = 0;
   std::thread bg_[2]; std::mutex bm_; std::condition_variable bcv_; std::deque<int> bq_; bool bquit_ = false;
   std::mutex stat_m_;

@@ -64,8 +64,8 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   // 3 the gain is buffering: while an intra picture's chain holds the main stream (1.6 ms at 1080p, ten picture intervals) the coder threads
   // work off the pictures queued before it (1080p, host-bound: owf 3 -> 4 measured +4 %; more changes nothing).  The GPU arithmetic coder
   // is a longer stage than the host pool (a substream is one serial chain) and profits from up to 8.
-  depth_ = cfg.owf >= 3 && cfg.bitrate == 0 ? (cfg.owf > 8 ? 8 : cfg.owf) : (cfg.owf >= 2 ? 2 : (cfg.owf == 1 ? 1 : 0));
-  nrec_ = depth_ + 1 < 3 ? 3 : depth_ + 1;
+  depth_ = cfg.owf >= 3 && cfg.bitrate == 0 ? (cfg.owf > kMaxDepth ? kMaxDepth : cfg.owf) : (cfg.owf >= 2 ? 2 : (cfg.owf == 1 ? 1 : 0));
+  nrec_ = depth_ + 2 < 3 ? 3 : depth_ + 2;              // (+ 1: an intra picture is written ahead of its turn, beside the P pictures in front of it, which still read theirs)
   prio_[0] = prio[0]; prio_[1] = prio[1]; prio_[2] = prio[2];
   HIP_OK(stream_acquire(&stream_, cfg.device, 'M', prio_[0]));
   const size_t npx = (size_t)cw_ * ch_, nb8 = npx / 64, in_bytes = (size_t)cfg.width * cfg.height * 3 / 2;
@@ -100,6 +100,17 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   HIP_OK(stream_acquire(&stream_in_, cfg.device, 'I', prio_[2]));
   for (int k = 0; k < kSets; k++) HIP_OK(hipEventCreateWithFlags(&ev_src_free_[k], hipEventDisableTiming));
   HIP_OK(hipEventCreateWithFlags(&ev_signalled_, hipEventDisableTiming));
+  // the intra pictures' own stream: where the chain shares nothing with the P pictures' kernels (no SAO work picture, no intra units in P pictures
+  // -- they use the same progress counters --, no per-CTU QP upload, no row groups) and pictures are queued ahead at all
+  idr_side_ = depth_ >= 2 && !cfg.sao && !cfg.intra_in_p && !cfg.qp_in_cu && cfg.rc_bands == 0 && cfg.band_rows == 0 && !getenv("KVAZZUP_AMD_IDR_INLINE");
+  if (idr_side_) {
+    // ... which is the INPUT stream: the pictures behind an intra picture need it anyway, so their input stages lose nothing by queueing behind
+    // its chain, and a further stream would share a hardware queue with one that matters (HIP spreads a priority level's streams over four;
+    // measured with a stream of its own: no gain at the default level, half the rate at any other -- KVAZZUP_AMD_IDR_PRIO)
+    const char *lv = getenv("KVAZZUP_AMD_IDR_PRIO");
+    if (lv) HIP_OK(stream_acquire(&stream_idr_, cfg.device, 'X', lv[0])); else stream_idr_ = stream_in_;
+    HIP_OK(hipEventCreateWithFlags(&ev_idr_done_, hipEventDisableTiming));
+  }
   // intra scratch: ic8 (nb8 u32) | ic16 (nb8/4 u32) | ic32 (nb8/16 u32) | im8 | im16 | im32
   size_t isz = nb8 * 4 + nb8 + nb8 / 4 + nb8 + nb8 / 4 + nb8 / 16 + 64;
   HIP_OK(hipMalloc(&intra_scratch_, isz));
@@ -214,6 +225,7 @@ Encoder::~Encoder()
   bcv_.notify_all();
   for (auto &t : bg_) if (t.joinable()) t.join();
   if (stream_) hipStreamSynchronize(stream_);
+  if (stream_idr_ && stream_idr_ != stream_in_) hipStreamSynchronize(stream_idr_);
   if (stream_tok_) hipStreamSynchronize(stream_tok_);
   if (stream_in_) hipStreamSynchronize(stream_in_);
   for (Slot &sl : slot_) {
@@ -234,7 +246,7 @@ Encoder::~Encoder()
   if (stream_h2d_ && stream_h2d_ != stream_in_) stream_release(stream_h2d_, cfg_.device, 'H', 'l');
   for (int k = 0; k < kInRing; k++) { hipFree(d_in_[k]); if (h_in_[k]) hipHostFree(h_in_[k]); if (ev_h2d_[k]) hipEventDestroy(ev_h2d_[k]); if (ev_pad_[k]) hipEventDestroy(ev_pad_[k]); }
   stream_release(stream_rec_, cfg_.device, 'R', 'n');
-  for (int c = 0; c < 3; c++) { for (int k = 0; k < kSets; k++) { hipFree(src_[k][c]); hipFree(coef_[k][c]); } for (int b = 0; b < 10; b++) hipFree(rec_[b][c]); }
+  for (int c = 0; c < 3; c++) { for (int k = 0; k < kSets; k++) { hipFree(src_[k][c]); hipFree(coef_[k][c]); } for (int b = 0; b < kMaxDepth + 4; b++) hipFree(rec_[b][c]); }
   hipFree(vaq_act_); hipFree(vaq_sum_); hipFree(rc_state_);
   for (int k = 0; k < kSets; k++) { hipFree(ctu_qt_[k]); hipFree(ctu_qy_[k]); hipFree(ctu_delta_[k]); hipFree(ctu_first_[k]); if (h_ctu_qt_[k]) hipHostFree(h_ctu_qt_[k]); }
   for (int k = 0; k < kSets; k++) { hipFree(cu_bytes_[k]); hipFree(cu_mv_[k]); hipFree(cu_mvd_[k]); if (ev_tok_done_[k]) hipEventDestroy(ev_tok_done_[k]); }
@@ -245,6 +257,8 @@ Encoder::~Encoder()
   for (int k = 0; k < kSets; k++) if (ev_src_free_[k]) hipEventDestroy(ev_src_free_[k]);
   stream_release(stream_tok_, cfg_.device, 'T', prio_[1]);
   stream_release(stream_in_, cfg_.device, 'I', prio_[2]);
+  if (stream_idr_ && stream_idr_ != stream_in_) { const char *lv = getenv("KVAZZUP_AMD_IDR_PRIO"); stream_release(stream_idr_, cfg_.device, 'X', lv ? lv[0] : 'n'); }
+  if (ev_idr_done_) hipEventDestroy(ev_idr_done_);
   hipFree(intra_scratch_);
   delete entropy_; delete entropy2_;
   hipFree(trace_); hipFree(intra_order_); hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(sync_); hipFree(me_cost16_); hipFree(err_);
@@ -471,6 +485,10 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err; f_.ent_cursors = sl.g_cursors;
   f_.tok_cursor = (uint32_t *)tok_count_ + (size_t)(frame_idx_ & 1) * tok_nctu_; f_.tok_cursor_next = (uint32_t *)tok_count_ + (size_t)((frame_idx_ + 1) & 1) * tok_nctu_;
   const EncFrame f = f_;
+  // the stream this picture's chain runs on: an intra picture's own (encoder.h stream_idr_), else the main stream -- behind the last intra picture's chain
+  const bool side = intra && idr_side_;
+  const hipStream_t ms = side ? stream_idr_ : stream_;
+  if (!side && idr_pending_) { HIP_CHECK(hipStreamWaitEvent(stream_, ev_idr_done_, 0)); idr_pending_ = false; }
   if (src_busy_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_src_free_[set_], 0)); src_busy_[set_] = false; }   // the last picture that used this set (t - kSets) has been reconstructed
   timed(K_PAD, stream_in_, [&] { launch_pad_input(d_i420, w, h, src_[set_][0], src_[set_][1], src_[set_][2], cw_, ch_, stream_in_); });
   if (in_ring >= 0) { HIP_CHECK(hipEventRecord(ev_pad_[in_ring], stream_in_)); pad_pending_[in_ring] = true; }
@@ -481,14 +499,14 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     timed(K_INTRA_ANALYSE, stream_in_, [&] { launch_intra_analyse(f, stream_in_); });
   }
   HIP_CHECK(hipEventRecord(in_done_, stream_in_)); in_pending_ = true;
-  HIP_CHECK(hipStreamWaitEvent(stream_, in_done_, 0));
-  if (tok_pending_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_, ev_tok_done_[set_], 0)); tok_pending_[set_] = false; }   // the tokenizer of the set's previous picture is done with it
+  HIP_CHECK(hipStreamWaitEvent(ms, in_done_, 0));
+  if (tok_pending_[set_]) { HIP_CHECK(hipStreamWaitEvent(ms, ev_tok_done_[set_], 0)); tok_pending_[set_] = false; }   // the tokenizer of the set's previous picture is done with it
   if (!upload_qp_targets()) return false;
   if (rc_state_) launch_rc_begin(rc_state_, frame_idx_ >= 3 ? 8u * rc_bytes_[(frame_idx_ - 3) & 7] : 0u, (frame_idx_ - 3) & 7, frame_idx_ >= 3, stream_);
   if (intra) {
-    HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 1), stream_));
-    HIP_CHECK(hipMemsetAsync(f_.cu_cbf, 0, (size_t)f_.b8w * f_.b8h, stream_));     // the three plane waves OR their bit in
-    timed(K_INTRA_RECON, stream_, [&] { launch_intra_recon(f, stream_); });
+    HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 1), ms));
+    HIP_CHECK(hipMemsetAsync(f_.cu_cbf, 0, (size_t)f_.b8w * f_.b8h, ms));     // the three plane waves OR their bit in
+    timed(K_INTRA_RECON, ms, [&] { launch_intra_recon(f, ms); });
   } else {
     timed(K_ME, stream_, [&] { launch_me(f, stream_); });
     // intra-in-P: quarters whose inter cost is high are priced as intra blocks and may become intra units (the launch leaves at once where none is)
@@ -509,13 +527,14 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     // ... and are reconstructed behind every inter unit (their reference samples may lie in inter units anywhere around them)
     if (cfg_.intra_in_p) timed(K_INTRA_RECON, stream_, [&] { launch_intra_recon(f, stream_); });
   }
-  launch_qp_resolve(f, stream_);                                 // per-CTU QP: which CU carries the delta, QpY for deblocking
-  HIP_CHECK(hipEventRecord(ev_signalled_, stream_));             // levels, cbf and motion of the picture are final
-  if (cfg_.deblock) timed(K_DEBLOCK, stream_, [&] { launch_deblock(f, stream_); });
-  if (cfg_.sao) { timed(K_SAO, stream_, [&] { launch_sao(f, stream_); }); HIP_CHECK(hipEventRecord(ev_sao_, stream_)); }
+  launch_qp_resolve(f, ms);                                      // per-CTU QP: which CU carries the delta, QpY for deblocking
+  HIP_CHECK(hipEventRecord(ev_signalled_, ms));                  // levels, cbf and motion of the picture are final
+  if (cfg_.deblock) timed(K_DEBLOCK, ms, [&] { launch_deblock(f, ms); });
+  if (cfg_.sao) { timed(K_SAO, ms, [&] { launch_sao(f, ms); }); HIP_CHECK(hipEventRecord(ev_sao_, ms)); }
   // Last reader of this set on the main stream: k_sao reads the source picture for its statistics, deblocking the CU records.
   // Input padding and intra analysis of the next picture with this set (input stream) overwrite both and wait for this event.
-  HIP_CHECK(hipEventRecord(ev_src_free_[set_], stream_)); src_busy_[set_] = true;
+  HIP_CHECK(hipEventRecord(ev_src_free_[set_], ms)); src_busy_[set_] = true;
+  if (side) { HIP_CHECK(hipEventRecord(ev_idr_done_, ms)); idr_pending_ = true; }
   HIP_CHECK(hipStreamWaitEvent(stream_tok_, ev_signalled_, 0));
   if (!intra) timed(K_INTER_SIGNAL, stream_tok_, [&] { launch_inter_signal(f, stream_tok_); });
   if (cfg_.sao) HIP_CHECK(hipStreamWaitEvent(stream_tok_, ev_sao_, 0));      // the tokenizer codes the CTUs' SAO parameters
@@ -537,7 +556,7 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     HIP_CHECK(hipEventRecord(sl.done, sl.ent_stream));
   } else
   HIP_CHECK(hipEventRecord(sl.done, stream_tok_));
-  HIP_CHECK(hipEventRecord(sl.rec_done, stream_));
+  HIP_CHECK(hipEventRecord(sl.rec_done, ms));
   sl.pic_idx = submitted_; sl.poc = poc_; sl.intra = intra; sl.rec_idx = cur_idx_; sl.set = set_; sl.qp = qp_cur_; sl.write_ps = false;
   if (intra) {
     sl.write_ps = (intra_count_ == 0) || (cfg_.vps_period > 0 && (intra_count_ % cfg_.vps_period) == 0);

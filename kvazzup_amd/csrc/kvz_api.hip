@@ -298,7 +298,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   EncoderConfig ec;
   ec.width = cfg->width; ec.height = cfg->height; ec.qp = cfg->qp; ec.intra_period = cfg->intra_period; ec.vps_period = cfg->vps_period;
   ec.me_range = cfg->me_range; ec.fps_num = cfg->framerate_num; ec.fps_den = cfg->framerate_denom;
-  ec.wpp = cfg->wpp ? 1 : 0; ec.deblock = cfg->deblock_enable ? 1 : 0; ec.device = cfg->gpu_device; ec.owf = cfg->owf > 8 ? 8 : cfg->owf;
+  ec.wpp = cfg->wpp ? 1 : 0; ec.deblock = cfg->deblock_enable ? 1 : 0; ec.device = cfg->gpu_device; ec.owf = cfg->owf > 16 ? 16 : cfg->owf;
   ec.tile_rows = cfg->tiles_height_count > 1 ? cfg->tiles_height_count : 1;
   ec.tile_cols = cfg->tiles_width_count > 1 ? cfg->tiles_width_count : 1;
   // a grid finer than the CTU grid (uvgComm's "16x16" at 1080p: 17 CTU rows) is coded with as many tiles as there are CTUs in that direction

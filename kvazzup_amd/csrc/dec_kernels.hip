@@ -543,7 +543,8 @@ __device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveSc
   if (active) {
     const uint32_t o = (uint32_t)pred[0] | ((uint32_t)pred[1] << 8) | ((uint32_t)pred[2] << 16) | ((uint32_t)pred[3] << 24);
     *(uint32_t *)&s.pic[(ry + c + 1) * DI_P + 16 + rx + 4 * g] = o;
-    st_wt_u32(gdst + (size_t)(ry + c) * gp + rx + 4 * g, o);             // write-through: the neighbouring CTUs' workgroups read it from the picture
+    // write-through, and only where a neighbouring CTU's workgroup will read (IB_EDGE); the rest of the CTU goes out in full lines at the end (k_dec_intra)
+    if (d.flags & IB_EDGE) st_wt_u32(gdst + (size_t)(ry + c) * gp + rx + 4 * g, o);
   }
   wave_sync();
 }
@@ -610,7 +611,8 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
     IntraBlk d;
     d.rx = (uint8_t)rx; d.ry = (uint8_t)ry; d.lo = (uint8_t)lo; d.hi = (uint8_t)hi; d.mode = t.mode; d.l2 = t.log2;
     d.flags = (uint8_t)((intra_filter_needed(N, c ? 1 : 0, t.mode) ? IB_FILT : 0) | ((rx == 0 || ry == 0) ? IB_BORDER : 0) |
-                        (kv_intra_milestone(zu) > kv_intra_milestone(zprev) ? IB_PUBLISH : 0) | (t.count ? IB_LEVELS : 0) | ((t.flags & TU_TSKIP) ? IB_TSKIP : 0));
+                        (kv_intra_milestone(zu) > kv_intra_milestone(zprev) ? IB_PUBLISH : 0) | (t.count ? IB_LEVELS : 0) | ((t.flags & TU_TSKIP) ? IB_TSKIP : 0) |
+                        ((rx + N >= S || ry + N >= S) ? IB_EDGE : 0));
     d.xf = (uint8_t)((t.log2 == 2 && (t.flags & TU_DST)) ? XF16_DST4 : (t.log2 - 1) & 3);
     d.angle = (int16_t)kIntraAngle[t.mode]; d.inv = (int16_t)kInvAngle[t.mode];
     d.zu = (uint16_t)zu; d.next = 0;
@@ -682,6 +684,9 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
       }
     }
   }
+  // the CTU's samples -> the picture, in whole lines (the chain stored only what neighbouring workgroups read)
+  __syncthreads();
+  for (int i = lane; i < S * S / 16; i += T) { const int y = i / (S / 16), xq = i % (S / 16); *(uint4 *)&gdst[(size_t)y * cpitch + xq * 16] = *(const uint4 *)&s.pic[(y + 1) * DI_P + 16 + xq * 16]; }
   publish_wt(my, 64u);
   }
 }

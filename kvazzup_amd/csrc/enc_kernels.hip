@@ -934,7 +934,8 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
   if (active) {
     const uint32_t o = (uint32_t)pred[0] | ((uint32_t)pred[1] << 8) | ((uint32_t)pred[2] << 16) | ((uint32_t)pred[3] << 24);
     *(uint32_t *)&s.pic[(ry + c + 1) * P + 16 + rx + 4 * g] = o;
-    st_wt_u32(gdst + (size_t)(ry + c) * gp + rx + 4 * g, o);             // write-through: the neighbouring CTUs' workgroups read it from the picture
+    // write-through, and only where a neighbouring CTU's workgroup will read (IB_EDGE): the rest of the CTU goes out in full lines at the end
+    if (d.flags & IB_EDGE) st_wt_u32(gdst + (size_t)(ry + c) * gp + rx + 4 * g, o);
   }
   wave_sync();
   PROF(9);
@@ -1037,7 +1038,7 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
       // of this block's size, which either precedes this block in z-order or does not; the available groups are contiguous
       d.lo = (uint8_t)(aBL ? 0 : (aL ? n : 2 * n + 1)); d.hi = (uint8_t)(aTR ? 4 * n : (aT ? 3 * n : (aL ? 2 * n - 1 : 0)));      // (nothing available: lo = 2n + 1 > hi = 0)
       d.mode = (uint8_t)mode; d.l2 = (uint8_t)(l2 - sh);
-      d.flags = (uint8_t)((intra_filter_needed(n, c ? 1 : 0, mode) ? IB_FILT : 0) | ((zx == 0 || zy == 0) ? IB_BORDER : 0));
+      d.flags = (uint8_t)((intra_filter_needed(n, c ? 1 : 0, mode) ? IB_FILT : 0) | ((zx == 0 || zy == 0) ? IB_BORDER : 0) | ((zx + su == 8 || zy + su == 8) ? IB_EDGE : 0));
       d.xf = (uint8_t)((l2 - sh == 2 && c == 0) ? XF16_DST4 : l2 - sh - 1);
       d.angle = (int16_t)kIntraAngle[mode]; d.inv = (int16_t)kInvAngle[mode];
       d.zu = (uint16_t)lane; d.next = (uint16_t)(lane + su * su);
@@ -1062,7 +1063,7 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   const QuantConst q8 = quant_const(qp, 3 - sh, 1), q16 = quant_const(qp, 4 - sh, 1);      // (coding units are 8x8 or 16x16)
   IntraWaveScratch &ws = wss[wave];
   uint2 unacked = make_uint2(0u, 0u);                       // units this wave has finished but not yet drained its stores for
-  bool first = true;
+  bool first = true, prev_stored = false;
   for (;;) {
     int k = 0;
     if (lane == 0) k = (int)atomicAdd(&ch.claim, 1u);
@@ -1084,17 +1085,20 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     const uint2 cvu = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)cv.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)cv.y));
     chain_mark_done(ch, cvu, lane);
     // the stores of the block BEFORE this one have had this block's computation to be acknowledged: report them now
+    const bool stored = (d.flags & IB_EDGE) != 0;
     if (unacked.x | unacked.y) {
-      // (this block's own store was issued last: wait for all but the most recent store instruction)
-      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      // (if this block stored, its store was issued last: wait for all but the most recent store instruction; a block that did not store has nothing to wait for)
+      if (prev_stored) { if (stored) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
       chain_ack_publish(ch, unacked, my, lane);
     }
-    unacked = cvu;
+    unacked = cvu; prev_stored = stored;
     if (cbf && (int)d.zu + lane < (int)d.next) cu_cbf_s[d.zu + lane] = 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (unacked.x | unacked.y) chain_ack_publish(ch, unacked, my, lane);
   __syncthreads();
+  // the CTU's samples -> the picture, in whole lines (the chain itself stored only what neighbouring workgroups read; PP: the inter units' samples are what they were)
+  for (int k = tid; k < S * S / 16; k += T) { const int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&grec[(size_t)y * pw + xq * 16] = *(const uint4 *)&s.pic[(y + 1) * P + 16 + xq * 16]; }
   for (int k = tid; k < S * S / 8; k += T) {
     int y = k / (S / 8), xq = k % (S / 8);
     if (PP && !((im >> kv_zunit8(((xq * 8) << sh) >> 3, (y << sh) >> 3)) & 1)) continue;       // (an inter unit's levels are k_inter_recon's)

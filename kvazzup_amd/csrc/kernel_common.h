@@ -632,7 +632,8 @@ struct alignas(16) IntraBlk {
 enum { IB_FILT = 1,          // the filtered reference samples are used (8.4.4.2.3)
        IB_BORDER = 2,        // the block touches the CTU's left or upper border (the neighbouring CTUs' samples may have to be waited for)
        IB_PUBLISH = 4,       // progress `zu` is worth publishing before this block (a neighbour may be waiting for it)
-       IB_LEVELS = 8, IB_TSKIP = 16 };      // decoder: the block has levels; transform_skip_flag
+       IB_LEVELS = 8, IB_TSKIP = 16,        // decoder: the block has levels; transform_skip_flag
+       IB_EDGE = 32 };       // the block holds samples of the CTU's right column or bottom row -- the only ones another workgroup ever reads: they are stored write-through as soon as the block is done, everything else goes to the picture with the CTU's final copy
 __device__ __forceinline__ IntraBlk wave_uniform(const IntraBlk *p)
 {
   const uint4 u = *(const uint4 *)p;

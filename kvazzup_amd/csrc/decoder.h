@@ -204,6 +204,7 @@ class Decoder {
   bool check_hash_ = false; int hash_checked_ = 0, hash_mismatch_ = 0;
   int parse_job(PicJob &job, bool row_parallel);
   int parse_substream(PicJob &job, int sub, const uint8_t *data, size_t len, SubOut &out);
+  int close_open_picture();
   int finish_oldest();
   void drop_pending();
   // layout of the input block
@@ -225,7 +226,7 @@ class Decoder {
   int w_ = 0, h_ = 0, pw_ = 0, ph_ = 0;
   std::vector<PicJob> jobs_; int frame_threads_ = 1; long job_head_ = 0, job_tail_ = 0;
   // a picture arriving in several slice segment NAL units: its job is filled segment by segment and submitted with the last one
-  bool asm_active_ = false; int asm_subs_ = 0, asm_rows_ = 0, asm_pps_id_ = 0, asm_nal_type_ = 0; bool asm_irap_ = false;
+  bool asm_active_ = false, asm_guessed_one_row_ = false; int asm_subs_ = 0, asm_rows_ = 0, asm_pps_id_ = 0, asm_nal_type_ = 0; bool asm_irap_ = false;
   int submit_job(PicJob &job, int nal_type, bool irap);
   int append_segment_tiles(PicJob &job, size_t bitpos, const uint8_t *rbsp, size_t len, const DecPps &p, const DecPps &pp, int wc, int hc, int address);
   int append_segment(PicJob &job, size_t bitpos, const uint8_t *rbsp, size_t len, const DecPps &p, const DecPps &pp, int wc, int hc, int address, int64_t pts);

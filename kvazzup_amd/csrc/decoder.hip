@@ -1046,6 +1046,7 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     rbsp_[n++] = data[k]; zeros = data[k] == 0 ? zeros + 1 : 0;
   }
   BitReader r(rbsp_.data(), n);
+  if (asm_active_ && asm_guessed_one_row_ && nal_type >= 32 && nal_type <= 40 && nal_type != 38) { const int rc = close_open_picture(); if (rc < 0) return rc; }   // (what can only open the next access unit, or end the sequence)
   if (nal_type == 32) {                                          // VPS: only the timing information is used
     r.get(4); r.get(2); r.get(6); int msl = r.get(3); r.get(1); r.get(16);
     if (!skip_ptl(r, msl)) return last_error_ = DEC_ERR_INVALID;
@@ -1192,6 +1193,32 @@ int Decoder::verify_hash(const PicJob &job, const std::vector<uint8_t> &want)
   return 0;
 }
 
+// A picture whose last slice segment has not arrived when something that can only belong to the NEXT access unit turns up (a first slice
+// segment, a parameter set, an access unit delimiter, a prefix SEI, the end of the sequence).  Either its first segment's extent was guessed
+// wrong -- a one-tile picture without WPP whose PPS allows dependent slice segments is taken to begin with a one-row segment
+// (append_segment), but the flag does not forbid whole pictures in one segment: then the segment IS the picture, it ends where its
+// end_of_slice_segment_flag says and is submitted now, ahead of the NAL unit at hand -- or segments were lost and the picture is dropped,
+// which must not pass unnoticed: the error code is left for kvzx_decoder_last_error and said once on stderr.
+int Decoder::close_open_picture()
+{
+  if (!asm_active_) return 0;
+  asm_active_ = false;
+  PicJob &old = jobs_[(size_t)(job_head_ % jobs_.size())];
+  const int old_hc = (h_ + 63) / 64;
+  if (asm_guessed_one_row_ && asm_rows_ == 1 && old_hc > 1) {
+    asm_guessed_one_row_ = false;
+    old.seg_end_row[0] = 0; old.seg_end_row[(size_t)(old_hc - 1)] = 1;
+    const int rc = submit_job(old, asm_nal_type_, asm_irap_);
+    if (rc < 0) { last_error_ = rc; return 0; }
+    if (rc > 0 && pic_ready_ && !queue_current_output()) return last_error_ = DEC_ERR_GPU;     // (handed out first, by the next call: the NAL unit at hand may produce a picture of its own)
+    return 0;
+  }
+  last_error_ = DEC_ERR_INVALID;
+  static bool said = false;
+  if (!said) { said = true; fprintf(stderr, "kvazzup_amd: decoder dropped a picture whose slice segments did not complete before the next picture began\n"); }
+  return 0;
+}
+
 int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t pts)
 {
   BitReader r(rbsp, len);
@@ -1213,13 +1240,9 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     seg_address = r.get(bits);
     if (!asm_active_ || pps_id != asm_pps_id_ || nal_type != asm_nal_type_) return DEC_ERR_INVALID;      // a segment without its picture's first one (lost), or of another picture
   } else if (asm_active_) {
-    // The previous picture never got its last segment (lost, or its first segment's extent was guessed wrong -- see append_segment): it
-    // is dropped.  That must not pass unnoticed: the error code is left for kvzx_decoder_last_error and said once on stderr, while this
-    // NAL unit -- a new picture -- is decoded normally.
-    asm_active_ = false;
-    last_error_ = DEC_ERR_INVALID;
-    static bool said = false;
-    if (!said) { said = true; fprintf(stderr, "kvazzup_amd: decoder dropped a picture whose slice segments did not complete before the next picture began\n"); }
+    // the previous picture never got its last segment: close_open_picture() submits or drops it; this NAL unit -- a new picture -- is decoded normally
+    const int rc = close_open_picture();
+    if (rc < 0) return rc;
   }
   PicJob *const open_job = first_seg ? nullptr : &jobs_[(size_t)(job_head_ % jobs_.size())];
   if (dependent && open_job->pps.tile_cols > 1) { asm_active_ = false; return DEC_ERR_UNSUPPORTED; }     // (with tile columns: whole pictures or slices of whole tiles)
@@ -1366,7 +1389,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   job.seg_end_sub.assign(job.geom.size(), 0);
   if (job.own) { job.own->cols = pp.tile_cols; job.own->row_cols.reset(new std::atomic<uint8_t>[(size_t)hc]); for (int k = 0; k < hc; k++) job.own->row_cols[(size_t)k].store(0, std::memory_order_relaxed); }
   job.rc = 0; job.any_intra = job.any_inter = false;
-  asm_active_ = true; asm_rows_ = 0; asm_subs_ = 0; asm_pps_id_ = pps_id; asm_nal_type_ = nal_type; asm_irap_ = irap;
+  asm_active_ = true; asm_guessed_one_row_ = false; asm_rows_ = 0; asm_subs_ = 0; asm_pps_id_ = pps_id; asm_nal_type_ = nal_type; asm_irap_ = irap;
   return append_segment(job, r.pos, rbsp, len, p, pp, wc, hc, 0, pts);
 }
 
@@ -1407,6 +1430,7 @@ int Decoder::append_segment(PicJob &job, size_t bitpos, const uint8_t *rbsp, siz
     if (!mid_substream && nss == 1 && pp.tile_rows == 1 && row0 == 0) {
       // one tile, no WPP: the first segment's length is unknown as well: the whole picture unless dependent segments follow
       rows = p.dependent_slices ? 1 : hc;
+      asm_guessed_one_row_ = p.dependent_slices != 0;
     } else if (!mid_substream && nss == 1 && p.dependent_slices) rows = 1;      // a tile begun by one row; the rest follows as dependent segments
   }
   if (rows < 1 || row0 + rows > hc) return fail(DEC_ERR_INVALID);

@@ -342,3 +342,39 @@ def test_frame_threaded_decoder_survives_corrupted_streams(gpu):
     for k, t in enumerate((3, 4, 5)):
         assert np.array_equal(out[k]["i420"], recs[t]), t
     gd.close(); oe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frame_threads", [False, True])
+def test_whole_pictures_in_one_segment_with_dependent_segments_enabled(gpu, frame_threads):
+    """a PPS with dependent_slice_segments_enabled_flag = 1 does not oblige the stream to use dependent segments: a one-tile picture without WPP
+    sent as ONE segment has the same first slice header as one that begins a row-by-row sequence.  The decoder takes it for the latter until the
+    next access unit begins, then decodes the segment as the whole picture it is (close_open_picture) instead of dropping it."""
+    from kvazzup_amd.codec import Decoder
+    w, h = 320, 192
+    oe = orc.OracleEncoder(w, h, qp=30, period=4, me_range=8, wpp=0)
+    gd = Decoder(threads=4 if frame_threads else 1, frame_threads=frame_threads); od = orc.OracleDecoder()
+    got, want = [], []
+    for t in range(6):
+        au = bytearray(oe.encode(orc.synth_frame(0, SEED, w, h, t)))
+        pos = 0
+        for nal in orc.split_nals(bytes(au)):
+            if (nal[4] >> 1) & 63 == 34:
+                au[pos + 6] |= 0x20          # pps_pic_parameter_set_id ue(0), pps_seq_parameter_set_id ue(0), dependent_slice_segments_enabled_flag
+            pos += len(nal)
+        want.append(oe.recon())
+        ref = od.decode_au(bytes(au), t)
+        assert len(ref) == 1 and np.array_equal(ref[0]["i420"], want[-1]), t      # the checker reads the segment to its end_of_slice_segment_flag
+        got += gd.decode_au(bytes(au), t)
+    got += gd.drain() if frame_threads else []
+    if not frame_threads:
+        eos = bytes([0, 0, 0, 1, 36 << 1, 1])
+        f = gd.decode_nal(eos)
+        if f is not None:
+            got.append(f)
+    assert len(got) == 6, len(got)
+    for t in range(6):
+        assert np.array_equal(got[t]["i420"], want[t]), t
+    assert gd.lib.kvzx_decoder_last_error(gd.h) == 0
+    for x in (oe, gd, od):
+        x.close()

@@ -406,8 +406,10 @@ __device__ __forceinline__ void inter_transform_32(InterLds &s, int qp, uint32_t
 
 // DEC = false: encoder (residual from the source picture, levels written out).
 // DEC = true: decoder (levels and cbf given, prediction + residual only).
-template <bool DEC, bool FRAC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FRAC ? 5 : 8))) void k_inter_recon(EncFrame f)
+// ADJ: rdoq / signhide -- a kernel of its own: the plain form fits eight workgroups per compute unit in 64 registers, and with the level adjustment compiled
+// in it no longer did (159 registers spilled, 14 MB of scratch writes per 1080p launch, 23 -> 28 us -- found in the PMC pass, not in a test).
+template <bool DEC, bool FRAC, bool ADJ = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || ADJ) ? 5 : 8))) void k_inter_recon(EncFrame f)
 {
   __shared__ InterLds s;
   InterFracLds *fr = nullptr;
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FRAC ? 5 : 
   const bool split = f.cu_log2[bi0] != 5;                              // (four 16x16 units: with intra-in-P a quarter may also be an intra unit, 16x16 or four 8x8)
   const int cw2 = f.cw >> 1, ch2 = f.ch >> 1;
   const int qp = ctu_quant_qp(f, x0, y0), qpc = kChromaQp[qp];       // the 32x32 block lies inside one CTU
-  const int adj = DEC ? 0 : ((f.rdoq ? 1 : 0) | (f.signhide ? 2 : 0));    // level adjustment behind the quantiser (hevc_core.h adjust_group)
+  const int adj = (DEC || !ADJ) ? 0 : ((f.rdoq ? 1 : 0) | (f.signhide ? 2 : 0));    // level adjustment behind the quantiser (hevc_core.h adjust_group)
   // Decoder: most blocks of an inter picture carry no residual at all -- they skip the matrices, the transform stages and all
   // but two barriers (prediction straight to the picture).  `coded` is uniform over the workgroup.
   const bool coded = DEC ? __syncthreads_or(tid < 16 ? (int)(f.cu_cbf[b8idx(f, x0 + (tid & 3) * 8, y0 + (tid >> 2) * 8)] & 7) : 0) != 0 : true;
@@ -1907,8 +1909,12 @@ void launch_me(const EncFrame &f, hipStream_t st)
 }
 void launch_inter_recon(const EncFrame &f, hipStream_t st)
 {
-  if (f.subme > 0) hipLaunchKernelGGL((k_inter_recon<false, true>), dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f);
-  else hipLaunchKernelGGL((k_inter_recon<false, false>), dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f);     // integer vectors only
+  const dim3 grid(f.cw / 32, band_rows(f) * 2);
+  if (f.rdoq || f.signhide) {
+    if (f.subme > 0) hipLaunchKernelGGL((k_inter_recon<false, true, true>), grid, dim3(256), 0, st, f);
+    else hipLaunchKernelGGL((k_inter_recon<false, false, true>), grid, dim3(256), 0, st, f);
+  } else if (f.subme > 0) hipLaunchKernelGGL((k_inter_recon<false, true>), grid, dim3(256), 0, st, f);
+  else hipLaunchKernelGGL((k_inter_recon<false, false>), grid, dim3(256), 0, st, f);     // integer vectors only
 }
 void launch_inter_signal(const EncFrame &f, hipStream_t st)
 {

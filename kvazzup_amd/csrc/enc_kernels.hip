@@ -32,6 +32,8 @@
 namespace kvzx {
 
 #define SPLIT_BITS 8
+#define INTRA_P_GATE 24       // intra-in-P: a quarter is a candidate when its inter cost exceeds this many lambda_q4 (oracle/hevc_enc.c)
+#define INTRA_P_BITS 16       // ... and goes intra when the intra cost plus this many bins is below the inter cost
 
 // =============================================================================================
 // Motion estimation
@@ -189,6 +191,12 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
     f.cu_mv[i * 2 + 1] = (int16_t)(((int)(ci / W) - R) * 4);
     // intra-in-P: the inter cost of the block's 16x16 quarters -- what the search found for a quarter, or a quarter of the 32x32 block's cost
     if (f.intra_p && tid < 4) f.me_cost16[((y0 >> 4) + (tid >> 1)) * (f.cw >> 4) + (x0 >> 4) + (tid & 1)] = split ? red[tid] >> 13 : ((red[4] >> 13) + 2) >> 2;
+    if (f.intra_p && tid == 0) {
+      // ... and the block joins the list k_intra_analyse<P> works through when a quarter is above the gate (f.me_cand: count, then block indices)
+      bool any = false;
+      for (int k = 0; k < 4; k++) any |= (split ? red[k] >> 13 : ((red[4] >> 13) + 2) >> 2) > (uint32_t)INTRA_P_GATE * lam;
+      if (any) f.me_cand[1 + atomicAdd(&f.me_cand[0], 1u)] = (uint32_t)((y0 >> 5) * (f.cw >> 5) + (x0 >> 5));
+    }
   }
 }
 
@@ -728,8 +736,6 @@ __device__ __forceinline__ void analyse_tile_satd(const AnalyseLds &s, int tile,
   q[3] = (uint32_t)__builtin_amdgcn_readlane((int)a, 40) + (uint32_t)__builtin_amdgcn_readlane((int)a, 56);
 }
 
-#define INTRA_P_GATE 24       // intra-in-P: a quarter is a candidate when its inter cost exceeds this many lambda_q4 (oracle/hevc_enc.c)
-#define INTRA_P_BITS 16       // ... and goes intra when the intra cost plus this many bins is below the inter cost
 // PP = false: intra pictures.  PP = true ("uvgx intra-in-P v1"): launched behind k_me in a P picture; a region none of whose quarters'
 // inter cost is above the gate leaves at once (nearly all of them), the others are analysed like an intra picture's and the quarters
 // that come out cheaper as intra blocks are turned into intra units.
@@ -740,18 +746,21 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
   constexpr int T = PP ? 1024 : 256, NW = T / 64;
   __shared__ AnalyseLds s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bx_, by_; xcd_block_2d(bx_, by_);
+  int bx_ = 0, by_ = 0;
+  if (!PP) xcd_block_2d(bx_, by_);
+  // PP: a fixed number of workgroups works through the list of blocks k_me found above the gate (f.me_cand); the first things they do is
+  // zero what k_intra_recon<.., true> starts from: the progress counters of every CTU and the ticket counter behind them
+  const uint32_t ncand = PP ? f.me_cand[0] : 1u;
+  if (PP) for (uint32_t i = blockIdx.x * T + tid; i < 3u * (uint32_t)(f.cw >> 6) * (uint32_t)(f.ch >> 6) + 1u; i += gridDim.x * T) f.sync[i] = 0;      // (the word behind the ticket counter says whether the picture has an intra unit at all: set below, zeroed by k_deblock_tile)
+  for (uint32_t item = PP ? blockIdx.x : 0u; item < ncand; item += PP ? gridDim.x : 1u) {
+  if (PP) { __syncthreads(); const uint32_t r = f.me_cand[1 + item]; bx_ = (int)(r % (uint32_t)(f.cw >> 5)); by_ = (int)(r / (uint32_t)(f.cw >> 5)); }      // (the barrier: LDS of the last block is free)
   const int X0 = bx_ * 32, Y0 = by_ * 32 + f.row0 * 64;
   uint32_t icost[4] = {0, 0, 0, 0}; bool cand[4] = {false, false, false, false};
   if (PP) {
-    if (!((bx_ | by_) & 1) && tid < 3) f.sync[(size_t)((Y0 >> 6) * (f.cw >> 6) + (X0 >> 6)) * 3 + tid] = 0;      // the progress counters k_intra_recon<.., true> starts from
-    if (bx_ == 0 && by_ == 0 && tid == 3) f.sync[(size_t)3 * (f.cw >> 6) * (f.ch >> 6)] = 0;                      // ... and its ticket counter
-    bool any = false;
     for (int k = 0; k < 4; k++) {
       icost[k] = f.me_cost16[((Y0 >> 4) + (k >> 1)) * (f.cw >> 4) + (X0 >> 4) + (k & 1)];
-      cand[k] = icost[k] > (uint32_t)INTRA_P_GATE * (uint32_t)f.lambda_q4; any |= cand[k];
+      cand[k] = icost[k] > (uint32_t)INTRA_P_GATE * (uint32_t)f.lambda_q4;
     }
-    if (!any) return;
   }
   const uint8_t *src = f.src[0];
   if (tid < 256) *(uint32_t *)&s.src[tid * 4] = *(const uint32_t *)&src[(size_t)(Y0 + (tid >> 3)) * f.cw + X0 + (tid & 7) * 4];
@@ -850,15 +859,17 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
     }
     const int bx = tid & 3, by = tid >> 2, k = (by >> 1) * 2 + (bx >> 1);
     const int i = ((Y0 >> 3) + by) * (f.cw >> 3) + (X0 >> 3) + bx;
-    if (PP) {
-      if (!chosen) return;
-      if (!cand[k]) { f.cu_log2[i] = 4; return; }              // an inter quarter beside an intra one: a 16x16 unit with the vector it has
-      f.cu_mv[i * 2] = 0; f.cu_mv[i * 2 + 1] = 0;
+    if (PP && chosen && tid == 0) f.sync[(size_t)3 * (f.cw >> 6) * (f.ch >> 6) + 1] = 1u;
+    if (PP && !chosen) { }                                      // the block stays as the search left it
+    else if (PP && !cand[k]) f.cu_log2[i] = 4;                  // an inter quarter beside an intra one: a 16x16 unit with the vector it has
+    else {
+      if (PP) { f.cu_mv[i * 2] = 0; f.cu_mv[i * 2 + 1] = 0; }
+      int l2, mode;
+      if (!split16[k]) { l2 = 4; mode = s.bestm[16 + k]; }
+      else { l2 = 3; mode = s.bestm[tid]; }
+      f.cu_log2[i] = (uint8_t)l2; f.cu_intra_mode[i] = (uint8_t)mode; f.cu_intra[i] = 1; f.cu_flags[i] = 0;
     }
-    int l2, mode;
-    if (!split16[k]) { l2 = 4; mode = s.bestm[16 + k]; }
-    else { l2 = 3; mode = s.bestm[tid]; }
-    f.cu_log2[i] = (uint8_t)l2; f.cu_intra_mode[i] = (uint8_t)mode; f.cu_intra[i] = 1; f.cu_flags[i] = 0;
+  }
   }
 }
 
@@ -980,11 +991,15 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wc = f.cw >> 6;
   const uint32_t nticket = 3u * (uint32_t)wc * (uint32_t)band_rows(f);
   uint32_t *const ticket_ctr = f.sync + (size_t)3 * wc * (f.ch >> 6);
-  for (;;) {
+  if (PP && !ticket_ctr[1]) return;                         // no intra unit in this P picture (k_intra_analyse<true> says): nothing to do
+  for (bool once = true;; once = false) {
+  // (PP: a workgroup per (CTU, plane), in dispatch order -- nearly all of them find nothing to do, and a ticket would only add a round trip)
+  if (PP) { if (!once) break; } else {
   __syncthreads();                                          // (everybody is done with the last (CTU, plane): LDS and the ticket word are free)
   if (tid == 0) ticket_s = atomicAdd(ticket_ctr, 1u);
   __syncthreads();
-  const uint32_t ticket = ticket_s;
+  }
+  const uint32_t ticket = PP ? blockIdx.x : ticket_s;
   if (ticket >= nticket) break;
   const int c = (int)(ticket % 3u), ctu = (int)f.intra_order[ticket / 3u];
   const int row = ctu / wc, cx = ctu % wc;
@@ -1172,6 +1187,7 @@ __global__ __launch_bounds__(256) void k_deblock_tile(EncFrame f)
   // strength needs, fetched in one go beside the samples instead of per edge segment
   __shared__ uint8_t r_log2[100], r_intra[100], r_cbf[100]; __shared__ uint32_t r_mv[100];
   const int tid = threadIdx.x, wc = f.cw >> 6, hc = f.ch >> 6;
+  if (f.me_cand && blockIdx.x == 0 && tid == 0) { f.me_cand[0] = 0; f.sync[(size_t)3 * wc * hc + 1] = 0; }      // intra-in-P: the next picture's k_me starts its list of candidate blocks from nothing, its "has intra units" word from zero
   const int lin = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), tx = lin % wc, tyi = lin / wc;
   const int X0 = tx * 64 - 4, Y0 = tyi * 64 - 4, CX0 = X0 >> 1, CY0 = Y0 >> 1, cw2 = f.cw >> 1;
   const int TW = tx == wc - 1 ? 68 : 64, TH = tyi == hc - 1 ? 68 : 64;
@@ -1924,7 +1940,7 @@ void launch_inter_signal(const EncFrame &f, hipStream_t st)
 void launch_intra_analyse(const EncFrame &f, hipStream_t st)
 {
   if (f.is_intra) hipLaunchKernelGGL(k_intra_analyse<false>, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f);
-  else hipLaunchKernelGGL(k_intra_analyse<true>, dim3(f.cw / 32, band_rows(f) * 2), dim3(1024), 0, st, f);       // intra-in-P, behind k_me
+  else hipLaunchKernelGGL(k_intra_analyse<true>, dim3(128), dim3(1024), 0, st, f);       // intra-in-P, behind k_me: 128 workgroups share the candidate list
 }
 void launch_intra_recon(const EncFrame &f, hipStream_t st)
 {
@@ -1934,7 +1950,9 @@ void launch_intra_recon(const EncFrame &f, hipStream_t st)
   const dim3 grid(want < 3 * wc * nr ? want : 3 * wc * nr), block(64 * KVZ_INTRA_WAVES);
   const bool adj = f.rdoq || f.signhide;
   if (!f.is_intra) {                                                                                            // intra-in-P, behind k_inter_recon
-    if (adj) hipLaunchKernelGGL((k_intra_recon<true, true>), grid, block, 0, st, f); else hipLaunchKernelGGL((k_intra_recon<false, true>), grid, block, 0, st, f);
+    // (a workgroup per (CTU, plane) here: nearly all of them find no intra unit, and a workgroup that checks nine tickets in turn pays nine memory round trips)
+    const dim3 all(3 * wc * nr);
+    if (adj) hipLaunchKernelGGL((k_intra_recon<true, true>), all, block, 0, st, f); else hipLaunchKernelGGL((k_intra_recon<false, true>), all, block, 0, st, f);
     return;
   }
   if (adj) hipLaunchKernelGGL((k_intra_recon<true, false>), grid, block, 0, st, f);

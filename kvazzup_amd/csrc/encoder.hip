@@ -157,8 +157,8 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     HIP_OK(hipEventCreateWithFlags(&sl.rec_done, hipEventDisableTiming));
   }
   HIP_OK(hipEventCreateWithFlags(&in_done_, hipEventDisableTiming));
-  HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 1)));       // one progress counter per CTU and colour plane, and the ticket counter of k_intra_recon's workgroups
-  if (cfg.intra_in_p) HIP_OK(hipMalloc(&me_cost16_, sizeof(uint32_t) * (cw_ / 16) * (ch_ / 16)));      // k_me's inter cost per 16x16 block (intra-in-P)
+  HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 2))); HIP_OK(hipMemset(sync_, 0, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 2)));       // one progress counter per CTU and colour plane, and the ticket counter of k_intra_recon's workgroups
+  if (cfg.intra_in_p) { const size_t n16 = (size_t)(cw_ / 16) * (ch_ / 16); HIP_OK(hipMalloc(&me_cost16_, sizeof(uint32_t) * (n16 + 1 + n16 / 4))); HIP_OK(hipMemset(me_cost16_, 0, sizeof(uint32_t) * (n16 + 1 + n16 / 4))); }      // k_me's inter cost per 16x16 block (intra-in-P)
   {
     // dispatch order of the intra reconstruction's workgroups: the CTUs of the rows this instance codes, by anti-diagonal cx + 2 cy
     const int wc = cw_ / 64, r0 = cfg.band_rows > 0 ? cfg.band_row0 : 0, nr = cfg.band_rows > 0 ? cfg.band_rows : rows_;
@@ -182,7 +182,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   f_.tile_rows = cfg.tile_rows; f_.tile_cols = cfg.tile_cols; f_.chp = pack_height(ch_, cfg.tile_rows, cfg.tile_cols);
   f_.row0 = cfg.band_rows > 0 ? cfg.band_row0 : 0; f_.nrows = cfg.band_rows > 0 ? cfg.band_rows : 0;
   f_.qp = cfg.qp; f_.qpc = kChromaQp[cfg.qp]; f_.lambda_q4 = kLambdaQ4[cfg.qp]; f_.range = cfg.me_range;
-  f_.rdoq = cfg.rdoq; f_.signhide = cfg.signhide; f_.intra_p = cfg.intra_in_p; f_.me_cost16 = me_cost16_;
+  f_.rdoq = cfg.rdoq; f_.signhide = cfg.signhide; f_.intra_p = cfg.intra_in_p; f_.me_cost16 = me_cost16_; f_.me_cand = me_cost16_ ? me_cost16_ + (size_t)(cw_ / 16) * (ch_ / 16) : nullptr;
   f_.wpp = cfg.wpp; f_.mv_frame = cfg.mv_frame; f_.me_early = cfg.me_early; f_.satd = cfg.satd; f_.subme = cfg.subme; f_.slices = cfg.slices;
   bind_set(0);
   uint8_t *p = intra_scratch_;
@@ -526,6 +526,7 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     timed(K_INTER_RECON, stream_, [&] { launch_inter_recon(f, stream_); });
     // ... and are reconstructed behind every inter unit (their reference samples may lie in inter units anywhere around them)
     if (cfg_.intra_in_p) timed(K_INTRA_RECON, stream_, [&] { launch_intra_recon(f, stream_); });
+    if (cfg_.intra_in_p && !cfg_.deblock) { HIP_CHECK(hipMemsetAsync(f_.me_cand, 0, sizeof(uint32_t), stream_)); HIP_CHECK(hipMemsetAsync(sync_ + rows_ * (cw_ / 64) * 3 + 1, 0, sizeof(uint32_t), stream_)); }      // (k_deblock_tile does it otherwise)
   }
   launch_qp_resolve(f, ms);                                      // per-CTU QP: which CU carries the delta, QpY for deblocking
   HIP_CHECK(hipEventRecord(ev_signalled_, ms));                  // levels, cbf and motion of the picture are final

@@ -92,6 +92,7 @@ class Encoder {
   bool band_phase2(std::vector<std::vector<uint8_t>> *substreams, EncodedPicture *info);      // = band_phase2a + band_phase2b
   bool band_phase2a();                                            // what needs no halo: inner horizontal edges, tokenizer, arithmetic coder (may run beside the exchange, BEFORE band_import_halo)
   bool band_phase2b(std::vector<std::vector<uint8_t>> *substreams, EncodedPicture *info);     // after band_import_halo: the band's two boundary edges; hands out the substreams
+  int rc_delay() const { return rc_delay_; }
   int pending() const { return (int)(accepted_ - collected_); }
   // cropped reconstruction of the last coded picture -> host planes (stride = width)
   bool download_recon(uint8_t *y, uint8_t *u, uint8_t *v);
@@ -143,6 +144,7 @@ class Encoder {
   static constexpr int kMaxDepth = 16;    // pictures in flight behind the one being submitted (owf), at most
   uint8_t *rec_[kMaxDepth + 4][3] = {};
   bool spin_wait_ = false;      // KVAZZUP_AMD_SPIN: poll the GPU instead of napping between queries
+  int rc_delay_ = 3;            // rate control: pictures between a picture and the access unit size booked before it (3 .. 7)
   int nrec_ = 3;                // reconstruction ring: the picture being written, its reference, and the ones whose output is still owed (owf)
   int cur_idx_ = 0, ref_idx_ = 2, out_idx_ = 2;
   // Two sets of everything the tokenizer reads (levels and CU records): picture t is tokenised on the second stream

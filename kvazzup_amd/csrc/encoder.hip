@@ -64,7 +64,10 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   // 3 the gain is buffering: while an intra picture's chain holds the main stream (1.6 ms at 1080p, ten picture intervals) the coder threads
   // work off the pictures queued before it (1080p, host-bound: owf 3 -> 4 measured +4 %; more changes nothing).  The GPU arithmetic coder
   // is a longer stage than the host pool (a substream is one serial chain) and profits from up to 8.
-  depth_ = cfg.owf >= 3 && cfg.bitrate == 0 ? (cfg.owf > kMaxDepth ? kMaxDepth : cfg.owf) : (cfg.owf >= 2 ? 2 : (cfg.owf == 1 ? 1 : 0));
+  // With a bitrate the controller books picture t - rc_delay_ before picture t, rc_delay_ = pictures in flight + 1 (3 .. 7: the size ring holds eight):
+  // a pipelined encoder then decides exactly like a synchronous one with the same delay (oracle/hevc_enc.c rate_control, "rc-delay").
+  depth_ = cfg.owf >= 3 ? (cfg.bitrate == 0 ? (cfg.owf > kMaxDepth ? kMaxDepth : cfg.owf) : (cfg.owf > 6 ? 6 : cfg.owf)) : (cfg.owf >= 2 ? 2 : (cfg.owf == 1 ? 1 : 0));
+  rc_delay_ = cfg.bitrate > 0 && depth_ + 1 > 3 && cfg.band_rows == 0 ? depth_ + 1 : 3;
   nrec_ = depth_ + 2 < 3 ? 3 : depth_ + 2;              // (+ 1: an intra picture is written ahead of its turn, beside the P pictures in front of it, which still read theirs)
   prio_[0] = prio[0]; prio_[1] = prio[1]; prio_[2] = prio[2];
   HIP_OK(stream_acquire(&stream_, cfg.device, 'M', prio_[0]));
@@ -452,9 +455,9 @@ bool Encoder::upload_qp_targets()
 // picture-level rate control: the statement of record is rate_control() in oracle/hevc_enc.c
 void Encoder::rate_control()
 {
-  if (cfg_.bitrate <= 0 || frame_idx_ < 3) return;
+  if (cfg_.bitrate <= 0 || frame_idx_ < rc_delay_) return;
   const int64_t T = ((int64_t)cfg_.bitrate * cfg_.fps_den) / (cfg_.fps_num > 0 ? cfg_.fps_num : 1);
-  const int64_t trend = (int64_t)8 * rc_bytes_[(frame_idx_ - 3) & 7] - T;
+  const int64_t trend = (int64_t)8 * rc_bytes_[(frame_idx_ - rc_delay_) & 7] - T;
   rc_debt_ += trend;
   int step = 0;
   if (rc_debt_ > 4 * T && trend > 0) step = rc_debt_ > 16 * T ? 2 : 1;
@@ -502,7 +505,7 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   HIP_CHECK(hipStreamWaitEvent(ms, in_done_, 0));
   if (tok_pending_[set_]) { HIP_CHECK(hipStreamWaitEvent(ms, ev_tok_done_[set_], 0)); tok_pending_[set_] = false; }   // the tokenizer of the set's previous picture is done with it
   if (!upload_qp_targets()) return false;
-  if (rc_state_) launch_rc_begin(rc_state_, frame_idx_ >= 3 ? 8u * rc_bytes_[(frame_idx_ - 3) & 7] : 0u, (frame_idx_ - 3) & 7, frame_idx_ >= 3, stream_);
+  if (rc_state_) launch_rc_begin(rc_state_, frame_idx_ >= rc_delay_ ? 8u * rc_bytes_[(frame_idx_ - rc_delay_) & 7] : 0u, (frame_idx_ - rc_delay_) & 7, frame_idx_ >= rc_delay_, stream_);
   if (intra) {
     HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 1), ms));
     HIP_CHECK(hipMemsetAsync(f_.cu_cbf, 0, (size_t)f_.b8w * f_.b8h, ms));     // the three plane waves OR their bit in

@@ -652,8 +652,9 @@ static int rc_band_decide(int off, uint32_t cost, uint32_t ratio_q8, int64_t T, 
  * groups, its bits per unit of level cost update the ratio (new = (3 * old + measured + 2) >> 2; the first measurement is taken as is) */
 static void rc_picture_start(orc_encoder *e)
 {
-  if (e->cfg.rc_bands <= 0 || e->frame_idx < 3) return;
-  int s3 = (e->frame_idx - 3) & 7;
+  const int D = e->cfg.rc_delay >= 3 && e->cfg.rc_delay <= 7 ? e->cfg.rc_delay : 3;
+  if (e->cfg.rc_bands <= 0 || e->frame_idx < D) return;
+  int s3 = (e->frame_idx - D) & 7;
   if (!e->rc_cost_valid[s3]) return;
   e->rc_cost_valid[s3] = 0;
   uint64_t r = ((uint64_t)8 * e->rc_bytes[s3] << 8) / (e->rc_cost[s3] ? e->rc_cost[s3] : 1);
@@ -1045,9 +1046,10 @@ static void write_picture(orc_encoder *e, int write_ps)
  * on the wrong side of T -- which damps the oscillation the delay would otherwise cause.  QP stays in [10, 51]. */
 static void rate_control(orc_encoder *e)
 {
-  if (e->cfg.bitrate <= 0 || e->frame_idx < 3) return;
+  const int D = e->cfg.rc_delay >= 3 && e->cfg.rc_delay <= 7 ? e->cfg.rc_delay : 3;      /* (the delay: three pictures unless "rc-delay" says 4 .. 7 -- an encoder with more pictures in flight) */
+  if (e->cfg.bitrate <= 0 || e->frame_idx < D) return;
   const int64_t T = ((int64_t)e->cfg.bitrate * e->cfg.fps_den) / (e->cfg.fps_num > 0 ? e->cfg.fps_num : 1);
-  const int64_t trend = (int64_t)8 * e->rc_bytes[(e->frame_idx - 3) & 7] - T;
+  const int64_t trend = (int64_t)8 * e->rc_bytes[(e->frame_idx - D) & 7] - T;
   e->rc_debt += trend;
   int step = 0;
   if (e->rc_debt > 4 * T && trend > 0) step = e->rc_debt > 16 * T ? 2 : 1;
@@ -1198,6 +1200,7 @@ int orc_enc_set_option(orc_encoder *e, const char *name, int value)
 {
   if (!strcmp(name, "hash")) { e->cfg.hash = value; return 1; }
   if (!strcmp(name, "intra-in-p")) { e->cfg.intra_in_p = value != 0; return 1; }
+  if (!strcmp(name, "rc-delay")) { if (value < 3 || value > 7) return 0; e->cfg.rc_delay = value; return 1; }
   if (!strcmp(name, "rdoq")) { e->cfg.rdoq = value != 0; return 1; }
   if (!strcmp(name, "signhide")) { e->cfg.signhide = value != 0; e->pps.sign_data_hiding = e->cfg.signhide; return 1; }
   return 0;

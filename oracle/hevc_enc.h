@@ -64,6 +64,7 @@ typedef struct {
                                * diagonals; candidates are compared by SATD (8x8 Hadamard) + lambda * vector bits */
   int rdoq;                   /* kvazaar rdoq: "uvgx RDOQ v1" -- sparse high-frequency coefficient groups are dropped when that is cheaper (orc_adjust_levels, hevc_transform.h) */
   int signhide;               /* kvazaar signhide: sign_data_hiding_enabled_flag; the quantiser makes the parity of every eligible coefficient group say the hidden sign */
+  int rc_delay;               /* rate control: the size of access unit t - rc_delay is what is booked before picture t (0 = 3: the form of rounds 1-2; 3 .. 7: an encoder with rc_delay - 1 pictures in flight decides like a synchronous one with the same delay) */
   int intra_in_p;             /* 1: "uvgx intra-in-P v1" -- intra coding units in P pictures (hevc_enc.c intra_p_decide): a 16x16 quarter of a searched 32x32 block whose inter cost
                                * is above 24 lambda is priced as an intra block (the intra picture's source-based analysis) and coded intra when that is cheaper; ignored with rc_bands */
   int hash;                   /* kvazaar hash: 0 none, 1 checksum, 2 md5 -- a decoded picture hash SEI (D.2.19, suffix SEI NAL unit) after every picture's slices */

@@ -220,7 +220,8 @@ def test_owf_lags_output_and_flushes(gpu, owf):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("w,h,bitrate,owf,opts", [(320, 192, 200000, 0, {}), (640, 384, 900000, 2, {}), (640, 384, 400000, 1, dict(sao=1, subme=2)), (448, 320, 600000, 2, dict(vaq=6, tile_rows=2)),
-                                                  (1920, 1080, 3000000, 2, {})])
+                                                  (1920, 1080, 3000000, 2, {}),
+                                                  (640, 384, 900000, 6, {}), (640, 384, 500000, 4, dict(sao=1, subme=2)), (1920, 1080, 3000000, 6, dict(sao=1, subme=2))])     # owf > 2: the delay follows the pictures in flight (rc-delay)
 def test_rate_control_v2_matches_the_checker(gpu, w, h, bitrate, owf, opts):
     """rc-algorithm lambda (what uvgComm sets with its bitrate, kvazaarfilter.cpp:223-228): "uvgx rate control v2" -- the picture-level
     controller plus feedback inside the picture: a P picture's CTU rows are reconstructed in four groups and the QP of the next group is
@@ -230,6 +231,8 @@ def test_rate_control_v2_matches_the_checker(gpu, w, h, bitrate, owf, opts):
     frames = 24 if w >= 1920 else 48
     clip = [orc.synth_frame(0, SEED, w, h, t) for t in range(frames)]
     oe = orc.OracleEncoder(w, h, qp=32, period=16, me_range=8, bitrate=bitrate, rc_bands=4, **opts)
+    if owf > 2:
+        oe.set_option("rc-delay", min(owf, 6) + 1)        # the controller books picture t - (pictures in flight + 1): the synchronous checker with the same delay decides alike
     want = [oe.encode(f) for f in clip]
     o = (("qp", 32), ("period", 16), ("me-range", 8), ("owf", owf), ("bitrate", bitrate), ("rc-algorithm", "lambda"), ("sao", "full" if opts.get("sao") else "off"),
          ("subme", opts.get("subme", 0)), ("tiles", "1x%d" % opts.get("tile_rows", 1))) + ((("vaq", opts["vaq"]),) if opts.get("vaq") else ())

@@ -322,3 +322,31 @@ def test_intra_units_in_p_pictures_closed_loop(subme, sao, tiles, adj, bitrate):
     b1, s1, u1 = run(1)
     assert u0[1:] == [0] * (n - 1) and u1[cut] > 100, (u0, u1)
     assert (bitrate or b1 < b0) and s1 < s0, (b0, b1, s0, s1)          # (under rate control the bytes are the controller's business)
+
+
+def test_rate_control_delay_option():
+    """orc_enc_set_option "rc-delay" 3 .. 7: the access unit booked before picture t is t - delay (an encoder with delay - 1 pictures in flight); 3 is the default form,
+    other delays give a different but equally decodable stream at the target rate"""
+    w, h, bitrate, n = 320, 192, 250000, 40
+    sizes = {}
+    for delay in (0, 3, 7):
+        oe = orc.OracleEncoder(w, h, qp=32, period=16, me_range=8, bitrate=bitrate, rc_bands=4)
+        if delay:
+            oe.set_option("rc-delay", delay)
+        od = orc.OracleDecoder()
+        aus = []
+        for t in range(n):
+            au = oe.encode(orc.synth_frame(0, 11, w, h, t))
+            fr = od.decode_au(au, t)
+            assert len(fr) == 1 and np.array_equal(fr[0]["i420"], oe.recon()), (delay, t)
+            aus.append(au)
+        sizes[delay] = aus
+        kbps = sum(len(a) for a in aus) * 8 * 30 / n / 1000
+        assert 0.6 * bitrate / 1000 < kbps < 1.5 * bitrate / 1000, (delay, kbps)
+        oe.close(); od.close()
+    assert sizes[0] == sizes[3] and sizes[7] != sizes[3]
+    oe = orc.OracleEncoder(w, h, bitrate=bitrate)
+    for bad in (2, 8):
+        with pytest.raises(ValueError):
+            oe.set_option("rc-delay", bad)
+    oe.close()

@@ -194,19 +194,21 @@ def test_gpu_arithmetic_coder_pipelined(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("owf", [1, 2, 3, 4, 8])
-def test_owf_lags_output_and_flushes(gpu, owf):
+@pytest.mark.parametrize("owf,period", [(1, 4), (2, 4), (3, 4), (4, 4), (8, 4), (12, 4), (16, 4), (16, 1), (6, 2), (20, 3)])
+def test_owf_lags_output_and_flushes(gpu, owf, period):
     """video/OWF = n (kvazaarfilter.cpp:193): the access unit returned by call t is picture t - n (n >= 2: the
-    host coding stage runs on background threads; n = 3 .. 8 keep that many pictures in flight), NULL pictures flush the rest; the bytes and
-    reconstructions are those of the synchronous encoder."""
+    host coding stage runs on background threads; n = 3 .. 16 keep that many pictures in flight, more are taken as 16), NULL pictures flush the rest; the bytes and
+    reconstructions are those of the synchronous encoder.  With a short intra period several intra pictures are in flight at once, each started on the input
+    stream beside the P pictures in front of it (period 1: nothing but)."""
     from kvazzup_amd.codec import Encoder
-    w, h, frames = 320, 192, 7 + owf
+    w, h, frames = 320, 192, 7 + min(owf, 16) + (12 if owf >= 12 else 0)
     clip = [orc.synth_frame(0, SEED, w, h, t) for t in range(frames)]
-    opts = (("qp", 30), ("period", 4), ("me-range", 8))
+    opts = (("qp", 30), ("period", period), ("me-range", 8))
     e0 = Encoder(w, h, options=opts)
     want = [e0.encode(f) for f in clip]
     e0.close()
     e1 = Encoder(w, h, options=opts + (("owf", owf),))
+    owf = min(owf, 16)
     got = [e1.encode(f) for f in clip]
     assert got[:owf] == [(None, None)] * owf
     for _ in range(owf):

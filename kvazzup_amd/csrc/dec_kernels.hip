@@ -560,6 +560,7 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
   // anti-diagonal order from a ticket counter -- f.progress[3 * CTUs] -- so that the chain does not park a workgroup per (CTU, plane) on the chip)
   const int lane = threadIdx.x;
   const uint32_t nticket = 3u * (uint32_t)f.wc * (uint32_t)(f.nrows > 0 ? f.nrows : f.hc);
+  for (int i = lane; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];      // the transforms' matrix operands: once per workgroup, not per (CTU, plane)
   for (;;) {
   __syncthreads();
   uint32_t ticket = 0;
@@ -575,7 +576,6 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
     if (lane == 0) __hip_atomic_store(my, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     continue;
   }
-  for (int i = lane; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];
   uint8_t *plane = f.rec[c];
   // the CTU as the inter kernel left it (its inter blocks are final, the intra ones get written below) -> LDS
   {

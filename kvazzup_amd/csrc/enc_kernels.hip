@@ -992,6 +992,7 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   const uint32_t nticket = 3u * (uint32_t)wc * (uint32_t)band_rows(f);
   uint32_t *const ticket_ctr = f.sync + (size_t)3 * wc * (f.ch >> 6);
   if (PP && !ticket_ctr[1]) return;                         // no intra unit in this P picture (k_intra_analyse<true> says): nothing to do
+  for (int i = tid; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];      // the transforms' matrix operands: once per workgroup, not per (CTU, plane)
   for (bool once = true;; once = false) {
   // (PP: a workgroup per (CTU, plane), in dispatch order -- nearly all of them find nothing to do, and a ticket would only add a round trip)
   if (PP) { if (!once) break; } else {
@@ -1012,7 +1013,6 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     im = __ballot(f.cu_intra[b8idx(f, cx * 64 + zx * 8, row * 64 + zy * 8)] != 0);      // (every wave for itself: no barrier in front of the exit)
     if (!im) { if (tid == 0) __hip_atomic_store(my, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
   }
-  for (int i = tid; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];
   const int qpl = ctu_quant_qp(f, cx * 64, row * 64), qp = c ? kChromaQp[qpl] : qpl;
   const int hc = f.ch >> 6;
   IntraNeighbours nb;

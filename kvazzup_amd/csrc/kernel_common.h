@@ -313,8 +313,10 @@ __device__ __forceinline__ uint32_t wave_wait_wt(const uint32_t *ctr, uint32_t n
   if (v >= need) return v;
   uint32_t spins = 0;
   while ((v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
-    if (++spins < 16) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(16);
-    if (spins > (1u << 22)) { if (lane == 0) atomicOr(err, 1u); v = 64; break; }           // bounded spin: never hang the GPU
+    // (every poll is a read that goes to memory: 100 waiting waves polling flat out were most of the kernel's HBM reads.  A wave that has waited long is far
+    // from its turn -- the wavefront takes tens of microseconds to reach it -- and can afford to look less often)
+    if (++spins < 16) __builtin_amdgcn_s_sleep(1); else if (spins < 64) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
+    if (spins > (1u << 21)) { if (lane == 0) atomicOr(err, 1u); v = 64; break; }           // bounded spin: never hang the GPU
   }
   v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
   if (lane == 0) atomicMax(seen, v);

@@ -363,10 +363,12 @@ def test_random_tool_combinations_match_oracle(gpu, seed):
     cfg = dict(qp=int(rng.integers(8, 46)), period=int(rng.choice([1, 2, 3, 5, 64])), me_range=int(rng.choice([1, 4, 8, 16, 32])),
                wpp=int(rng.integers(0, 2)), deblock=int(rng.integers(0, 2)), tile_rows=int(rng.integers(1, min(hc, 3) + 1)),
                sao=int(rng.integers(0, 2)), qp_in_cu=int(rng.integers(0, 2)), bitrate=int(rng.choice([0, 0, 0, 150000, 2000000])), mv_frame=int(rng.choice([0, 0, 1, 2])), vaq=int(rng.choice([0, 0, 3, 12])), me_early=int(rng.integers(0, 2)))
-    owf = int(rng.choice([0, 1, 2, 3]))
+    owf = int(rng.choice([0, 1, 2, 3, 5]))
     kind = int(rng.choice([0, 2]))
-    frames = 9 if cfg["bitrate"] else 5              # (the rate controller starts moving the QP at the fourth picture)
+    frames = (9 if owf < 3 else 12) if cfg["bitrate"] else 5              # (the rate controller starts moving the QP behind its delay)
     oe = orc.OracleEncoder(w, h, **cfg)
+    if cfg["bitrate"] and owf >= 3:
+        oe.set_option("rc-delay", owf + 1)             # the feedback delay follows the pictures in flight (encoder.hip rc_delay_)
     od = orc.OracleDecoder()
     ge = Encoder(w, h, options=(("qp", cfg["qp"]), ("period", cfg["period"]), ("me-range", cfg["me_range"]), ("wpp", cfg["wpp"]),
                                 ("deblock", cfg["deblock"]), ("tiles", "1x%d" % cfg["tile_rows"]), ("sao", "full" if cfg["sao"] else "off"),

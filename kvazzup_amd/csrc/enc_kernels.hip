@@ -1004,6 +1004,9 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   if (ticket >= nticket) break;
   const int c = (int)(ticket % 3u), ctu = (int)f.intra_order[ticket / 3u];
   const int row = ctu / wc, cx = ctu % wc;
+#ifdef KVZ_PROF
+  if (threadIdx.x == 0) { for (int k = 0; k < 15; k++) g_prof[k] = 0; g_prof[15] = clock64(); }
+#endif
   const int adj = (f.rdoq ? 1 : 0) | (f.signhide ? 2 : 0);      // level adjustment behind the quantiser (hevc_core.h adjust_group)
   const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, P = 16 + 2 * S;
   uint32_t *my = f.sync + (size_t)ctu * 3 + c;
@@ -1086,11 +1089,14 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     if (lane == 0) k = (int)atomicAdd(&ch.claim, 1u);
     k = __builtin_amdgcn_readfirstlane(k);
     if (k >= nblk) break;
+    PROF(1);                                                // claim
     const IntraBlk d = wave_uniform(&blk[k]);              // (wave-uniform: what is derived from it runs on the scalar unit)
     const uint2 dp = dep[k], cv = cover[k];
     chain_wait_done(ch, make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)dp.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)dp.y)), f.err, lane);
     // the neighbouring CTUs' samples this block reads: wait for them, copy them into the borders of the CTU picture
+    PROF(2);                                                // waiting for the units this block reads
     if (d.flags & IB_BORDER) borders_need_wave(ch, nb, s.pic, P, plane, pw, cx, row, S, sh, 2 * S, d.rx, d.ry, 1 << d.l2, f.err, lane);
+    PROF(3);                                                // neighbouring CTUs: waits and copies
     if (f.trace && first && k == 0 && lane == 0) f.trace[((size_t)ctu * 3 + c) * 8 + 1] = wall_clock64();
     first = false;
     bool cbf;
@@ -1109,6 +1115,10 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
       chain_ack_publish(ch, unacked, my, lane);
     }
     unacked = cvu; prev_stored = stored;
+    PROF(10);                                               // mark / acknowledge / publish
+#ifdef KVZ_PROF
+    if (threadIdx.x == 0) g_prof[14] += 1;                   // blocks wave 0 did
+#endif
     if (cbf && (int)d.zu + lane < (int)d.next) cu_cbf_s[d.zu + lane] = 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1128,6 +1138,9 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   }
   if (tid == 0) __hip_atomic_fetch_max(my, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (every wave has drained its stores: the barrier above)
   if (f.trace && tid == 0) { unsigned long long *t = f.trace + ((size_t)ctu * 3 + c) * 8; t[2] = wall_clock64(); t[7] = (unsigned long long)nblk; }
+#ifdef KVZ_PROF
+  if (f.trace && tid == 0 && c == 0) for (int k = 0; k < 16; k++) f.trace[(size_t)wc * (f.ch >> 6) * 24 + (size_t)ctu * 16 + k] = (unsigned long long)g_prof[k];
+#endif
   }
 }
 

@@ -1077,13 +1077,12 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     *(uint4 *)&s.src[y * S + xq * 16] = *(const uint4 *)&gsrc[(size_t)y * pw + xq * 16];
     if (PP) *(uint4 *)&s.pic[(y + 1) * P + 16 + xq * 16] = *(const uint4 *)&grec[(size_t)y * pw + xq * 16];      // the CTU as k_inter_recon left it
   }
-  if (f.trace && tid == 0) f.trace[((size_t)ctu * 3 + c) * 8 + 0] = wall_clock64();
+  if (f.trace && tid == 0) { unsigned long long *t = f.trace + ((size_t)ctu * 3 + c) * 8; t[0] = wall_clock64(); t[3] = 0; t[4] = 0; }
   __syncthreads();
   const int nblk = (int)nblk_s;
   const QuantConst q8 = quant_const(qp, 3 - sh, 1), q16 = quant_const(qp, 4 - sh, 1);      // (coding units are 8x8 or 16x16)
   IntraWaveScratch &ws = wss[wave];
-  uint2 unacked = make_uint2(0u, 0u);                       // units this wave has finished but not yet drained its stores for
-  bool first = true, prev_stored = false;
+  bool first = true;
   for (;;) {
     int k = 0;
     if (lane == 0) k = (int)atomicAdd(&ch.claim, 1u);
@@ -1107,14 +1106,13 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     }
     const uint2 cvu = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)cv.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)cv.y));
     chain_mark_done(ch, cvu, lane);
-    // the stores of the block BEFORE this one have had this block's computation to be acknowledged: report them now
-    const bool stored = (d.flags & IB_EDGE) != 0;
-    if (unacked.x | unacked.y) {
-      // (if this block stored, its store was issued last: wait for all but the most recent store instruction; a block that did not store has nothing to wait for)
-      if (prev_stored) { if (stored) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-      chain_ack_publish(ch, unacked, my, lane);
-    }
-    unacked = cvu; prev_stored = stored;
+    // Acknowledge at once: a block that stored nothing (not on the CTU's edge) is final as it stands; one that did waits for its stores here.  The wait
+    // is this wave's alone -- the next block of the chain is another wave's, which goes on as soon as the units are marked -- and the neighbouring CTU gets
+    // the progress value when it is true, not one block later.  (The one-wave form of round 2 deferred the acknowledgement behind the wave's NEXT block to
+    // hide the store latency; with four waves that block may be one the wave has to wait for, and the neighbour waited with it: publish(24) came 19 us
+    // after the CTU's first block where its six blocks take 12.)
+    if (d.flags & IB_EDGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    chain_ack_publish(ch, cvu, my, lane, f.trace ? f.trace + ((size_t)ctu * 3 + c) * 8 : nullptr);
     PROF(10);                                               // mark / acknowledge / publish
 #ifdef KVZ_PROF
     if (threadIdx.x == 0) g_prof[14] += 1;                   // blocks wave 0 did
@@ -1122,7 +1120,6 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     if (cbf && (int)d.zu + lane < (int)d.next) cu_cbf_s[d.zu + lane] = 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (unacked.x | unacked.y) chain_ack_publish(ch, unacked, my, lane);
   __syncthreads();
   // the CTU's samples -> the picture, in whole lines (the chain itself stored only what neighbouring workgroups read; PP: the inter units' samples are what they were)
   for (int k = tid; k < S * S / 16; k += T) { const int y = k / (S / 16), xq = k % (S / 16); *(uint4 *)&grec[(size_t)y * pw + xq * 16] = *(const uint4 *)&s.pic[(y + 1) * P + 16 + xq * 16]; }

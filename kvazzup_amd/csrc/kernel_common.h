@@ -327,39 +327,52 @@ __device__ __forceinline__ uint32_t wave_wait_wt(const uint32_t *ctr, uint32_t n
 __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNeighbours &b, uint8_t *pic, int lp, const uint8_t *plane, int gp, int cx, int cy, int S, int sh,
                                                   int lim_w, int rx, int ry, int n, uint32_t *err, int lane)
 {
+  // What is missing of the three borders is decided first, the neighbours' progress awaited, and then ALL the loads are issued before the
+  // first of them is waited for: the first block of a CTU needs its left column, its top row and its corner, and three memory round trips one
+  // after the other were a tenth of the wavefront's step (S <= 64: one byte per lane covers a column, one dword per lane a row and a half).
+  int haveL = 0, uptoL = 0, haveT = 0, uptoT = 0;
+  bool doC = false;
   if (rx == 0 && b.nb_left) {
-    const int need = imin(S, ry + 2 * n), have = __builtin_amdgcn_readfirstlane(lds_load(&ch.left_loaded));
-    if (need > have) {
+    const int need = imin(S, ry + 2 * n);
+    haveL = __builtin_amdgcn_readfirstlane(lds_load(&ch.left_loaded));
+    if (need > haveL) {
       const uint32_t seen = wave_wait_wt(b.pl, kv_edge_need(b.il, ((need - 1) << sh) >> 3, true), &ch.seen_l, err, lane);
-      const int upto = imax(need, imin(S, kv_units_right(seen) * (8 >> sh)));
-      for (int i = have + lane; i < upto; i += 64) pic[(i + 1) * lp + 15] = (uint8_t)ld_l2_u8(plane + (size_t)(cy * S + i) * gp + cx * S - 1);
-      wave_sync();
-      if (lane == 0) atomicMax(&ch.left_loaded, upto);
+      uptoL = imax(need, imin(S, kv_units_right(seen) * (8 >> sh)));
     }
   }
   if (ry == 0 && b.nb_up) {
-    const int lim = imin(lim_w, b.nb_ur ? 2 * S : S), need = imin(lim, rx + 2 * n), have = __builtin_amdgcn_readfirstlane(lds_load(&ch.top_loaded));
-    if (need > have) {
-      int upto = need;
-      if (have < S) {
+    const int lim = imin(lim_w, b.nb_ur ? 2 * S : S), need = imin(lim, rx + 2 * n);
+    haveT = __builtin_amdgcn_readfirstlane(lds_load(&ch.top_loaded));
+    if (need > haveT) {
+      uptoT = need;
+      if (haveT < S) {
         const uint32_t seen = wave_wait_wt(b.pu, kv_edge_need(b.iu, ((imin(S, need) - 1) << sh) >> 3, false), &ch.seen_u, err, lane);
-        upto = imax(upto, imin(imin(S, lim), kv_units_bottom(seen) * (8 >> sh)));
+        uptoT = imax(uptoT, imin(imin(S, lim), kv_units_bottom(seen) * (8 >> sh)));
       }
       if (need > S) {
         const uint32_t seen = wave_wait_wt(b.pur, kv_edge_need(b.iur, ((need - S - 1) << sh) >> 3, false), &ch.seen_ur, err, lane);
-        upto = imax(upto, imin(lim, S + kv_units_bottom(seen) * (8 >> sh)));
+        uptoT = imax(uptoT, imin(lim, S + kv_units_bottom(seen) * (8 >> sh)));
       }
-      // (both ends are multiples of 4: block sizes, CTU sizes and picture widths are)
-      for (int i = have + 4 * lane; i < upto; i += 4 * 64) *(uint32_t *)&pic[16 + i] = ld_l2_u32(plane + (size_t)(cy * S - 1) * gp + cx * S + i);
-      wave_sync();
-      if (lane == 0) atomicMax(&ch.top_loaded, upto);
     }
   }
   if (rx == 0 && ry == 0 && b.nb_ul && !__builtin_amdgcn_readfirstlane(lds_load(&ch.corner_loaded))) {
     wave_wait_wt(b.pul, b.iul ? 64u : 0u, &ch.seen_ul, err, lane);
-    if (lane == 0) { pic[15] = (uint8_t)ld_l2_u8(plane + (size_t)(cy * S - 1) * gp + cx * S - 1); }
-    wave_sync();
-    if (lane == 0) atomicMax(&ch.corner_loaded, 1);
+    doC = true;
+  }
+  // ---- the loads, all in flight together (both ends of the row piece are multiples of 4: block sizes, CTU sizes and picture widths are)
+  const int iL = haveL + lane, iT = haveT + 4 * lane;
+  uint32_t vL = 0, vT = 0, vC = 0;
+  if (iL < uptoL) vL = ld_l2_u8(plane + (size_t)(cy * S + iL) * gp + cx * S - 1);
+  if (iT < uptoT) vT = ld_l2_u32(plane + (size_t)(cy * S - 1) * gp + cx * S + iT);
+  if (doC && lane == 0) vC = ld_l2_u8(plane + (size_t)(cy * S - 1) * gp + cx * S - 1);
+  if (iL < uptoL) pic[(iL + 1) * lp + 15] = (uint8_t)vL;
+  if (iT < uptoT) *(uint32_t *)&pic[16 + iT] = vT;
+  if (doC && lane == 0) pic[15] = (uint8_t)vC;
+  wave_sync();
+  if (lane == 0) {
+    if (uptoL > haveL) atomicMax(&ch.left_loaded, uptoL);
+    if (uptoT > haveT) atomicMax(&ch.top_loaded, uptoT);
+    if (doC) atomicMax(&ch.corner_loaded, 1);
   }
   wave_sync();
 }
@@ -402,7 +415,7 @@ __device__ __forceinline__ void chain_mark_done(IntraChain &ch, uint2 cover, int
 }
 // after the wave has drained its stores (s_waitcnt vmcnt(0)): the units in `cover` are final in memory; publishes the progress value
 // the leading run of acknowledged units amounts to when it passes a value neighbours wait for
-__device__ __forceinline__ void chain_ack_publish(IntraChain &ch, uint2 cover, uint32_t *ctr, int lane)
+__device__ __forceinline__ void chain_ack_publish(IntraChain &ch, uint2 cover, uint32_t *ctr, int lane, unsigned long long *tr = nullptr)
 {
   if (lane != 0) return;
   if (cover.x) atomicOr(&ch.acked[0], cover.x);
@@ -410,7 +423,10 @@ __device__ __forceinline__ void chain_ack_publish(IntraChain &ch, uint2 cover, u
   const uint32_t a0 = lds_load(&ch.acked[0]), a1 = lds_load(&ch.acked[1]);     // (re-read after both updates: whoever completes the masks sees them complete)
   const int prefix = a0 != ~0u ? __builtin_ctz(~a0) : 32 + (a1 != ~0u ? __builtin_ctz(~a1) : 32);
   const uint32_t m = prefix >= 64 ? 64u : (prefix >= 60 ? 60u : (prefix >= 56 ? 56u : (prefix >= 48 ? 48u : (prefix >= 44 ? 44u : (prefix >= 32 ? 32u : (prefix >= 24 ? 24u : 0u))))));
-  if (m && atomicMax(&ch.published, m) < m) __hip_atomic_fetch_max(ctr, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (m && atomicMax(&ch.published, m) < m) {
+    __hip_atomic_fetch_max(ctr, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tr) { if (m >= 24 && !tr[3]) tr[3] = wall_clock64(); if (m >= 44 && !tr[4]) tr[4] = wall_clock64(); }      // (tools/intra_timeline.py: when the values the right / lower-left neighbour starts on went out)
+  }
 }
 
 // thread layout of one block inside a workgroup of T threads (64: one wave, 256: four): OPL outputs per thread so that

@@ -26,11 +26,11 @@ for c in range(3):
     print("  first-block time along row 0 (every 4th CTU):", np.round(fb[0, ::4]).astype(int).tolist())
     print("  first-block time down column 0:", np.round(fb[:, 0]).astype(int).tolist())
     nb = tr[:, :, c, 7].astype(float)
-    print("  per CTU: blocks %.1f; us in border waits %.1f, in blocks %.1f (%.2f per block), (slot 5 %.1f), in publishes %.1f" %
-          (nb.mean(), tr[:, :, c, 3].mean() / 100, tr[:, :, c, 4].mean() / 100, (tr[:, :, c, 4] / np.maximum(nb, 1)).mean() / 100, tr[:, :, c, 5].mean() / 100, tr[:, :, c, 6].mean() / 100))
-    p32 = us[:, :, c, 5]
-    print("  hand-off: first block after the left neighbour's publish(32): mean %.1f us, median %.1f; publish(32) after own first block: mean %.1f us" %
-          ((fb[:, 1:] - p32[:, :-1]).mean(), np.median(fb[:, 1:] - p32[:, :-1]), (p32 - fb).mean()))
+    p24, p44 = us[:, :, c, 3], us[:, :, c, 4]
+    ok = (tr[:, :-1, c, 3] > 0)
+    print("  per CTU: blocks %.1f; own first block -> publish(24): mean %.1f us, -> publish(44): mean %.1f us" % (nb.mean(), (p24 - fb)[tr[:, :, c, 3] > 0].mean(), (p44 - fb)[tr[:, :, c, 4] > 0].mean()))
+    print("  hand-off: first block after the left neighbour's publish(24): mean %.1f us, median %.1f; after the upper-right neighbour's publish(44): mean %.1f us, median %.1f" %
+          ((fb[:, 1:] - p24[:, :-1])[ok].mean(), np.median((fb[:, 1:] - p24[:, :-1])[ok]), (fb[1:, :-1] - p44[:-1, 1:]).mean(), np.median(fb[1:, :-1] - p44[:-1, 1:])))
     print("  lag to the left neighbour's first block, mean %.1f us; to the upper neighbour's, mean %.1f us" %
           ((fb[:, 1:] - fb[:, :-1]).mean(), (fb[1:, :] - fb[:-1, :]).mean()))
 d = None

@@ -963,7 +963,7 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
 // neighbour is done, not when it is complete -- and the neighbours' samples are copied into the CTU picture's borders piecewise, as
 // far as their progress allows.  (The decoder's k_dec_intra is the same scheme driven by the transform-block list.)
 #ifndef KVZ_INTRA_WAVES
-#define KVZ_INTRA_WAVES 4
+#define KVZ_INTRA_WAVES 8          // (measured at 1080p: 2 waves 1.58 ms, 4: 1.41, 8: 1.36 -- a wave that has just finished a block spends a microsecond on its bookkeeping before it can take the next)
 #endif
 // ADJ: rdoq / signhide -- a kernel of its own, so that the plain chain (every step of it is on the critical path) stays as it was.
 // PP: the intra units of a P picture (intra-in-P), launched behind k_inter_recon: a CTU without intra units (nearly all) publishes 64
@@ -1111,6 +1111,9 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     // the progress value when it is true, not one block later.  (The one-wave form of round 2 deferred the acknowledgement behind the wave's NEXT block to
     // hide the store latency; with four waves that block may be one the wave has to wait for, and the neighbour waited with it: publish(24) came 19 us
     // after the CTU's first block where its six blocks take 12.)
+#ifndef KVZ_PROF
+    if (f.trace && c == 0 && lane == 0 && k < 16) f.trace[(size_t)wc * (f.ch >> 6) * 56 + (size_t)ctu * 16 + k] = wall_clock64() | ((unsigned long long)d.l2 << 60);      // (tools/intra_timeline.py: when the luma blocks of the CTU were done)
+#endif
     if (d.flags & IB_EDGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     chain_ack_publish(ch, cvu, my, lane, f.trace ? f.trace + ((size_t)ctu * 3 + c) * 8 : nullptr);
     PROF(10);                                               // mark / acknowledge / publish

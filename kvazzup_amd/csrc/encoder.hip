@@ -171,7 +171,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     HIP_OK(hipMemcpy(intra_order_, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice));
   }
   HIP_OK(hipMalloc(&err_, sizeof(uint32_t))); HIP_OK(hipMemset(err_, 0, sizeof(uint32_t)));
-  if (getenv("KVAZZUP_AMD_INTRA_TRACE")) { HIP_OK(hipMalloc(&trace_, sizeof(unsigned long long) * (rows_ * (cw_ / 64) * 56))); HIP_OK(hipMemset(trace_, 0, sizeof(unsigned long long) * (rows_ * (cw_ / 64) * 56))); }
+  if (getenv("KVAZZUP_AMD_INTRA_TRACE")) { HIP_OK(hipMalloc(&trace_, sizeof(unsigned long long) * (rows_ * (cw_ / 64) * 72))); HIP_OK(hipMemset(trace_, 0, sizeof(unsigned long long) * (rows_ * (cw_ / 64) * 72))); }
   int eth = cfg.entropy_threads;
   if (const char *e = getenv("KVAZZUP_AMD_ENTROPY_THREADS")) eth = atoi(e) < 1 ? 1 : atoi(e);     // tuning knob (containers with a small CPU quota)
   if (cfg.entropy_gpu) { entropy_ = nullptr; entropy2_ = nullptr; }
@@ -844,7 +844,7 @@ bool Encoder::debug_copy(const char *what, void *dst, size_t bytes)
   for (int i = 0; i < 7; i++) if (w == names[i]) { src = cu_bytes_[out_set_] + i * nb8; have = nb8; }
   if (w == "cu_mv") { src = cu_mv_[out_set_]; have = nb8 * 4; }
   if (w == "cu_mvd") { src = cu_mvd_[out_set_]; have = nb8 * 4; }
-  if (w == "trace" && trace_) { src = trace_; have = sizeof(unsigned long long) * (rows_ * (cw_ / 64) * 56); }
+  if (w == "trace" && trace_) { src = trace_; have = sizeof(unsigned long long) * (rows_ * (cw_ / 64) * 72); }
   for (int c = 0; c < 3; c++) {
     size_t n = c ? npx / 4 : npx;
     if (w == std::string("coef") + char('0' + c)) { src = coef_[out_set_][c]; have = n * 2; }

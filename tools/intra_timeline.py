@@ -14,7 +14,7 @@ e = Encoder(w, h, options=(("qp", 32), ("period", 1), ("me-range", 16)))
 for t in range(3):
     e.encode(synth.frame(synth.MOVING, 0x5EED0002, w, h, t))
 wc, hc = (w + 63) // 64, (h + 63) // 64
-buf = np.zeros(wc * hc * 40, dtype=np.uint64)
+buf = np.zeros(wc * hc * 72, dtype=np.uint64)
 assert e.lib.kvzx_encoder_debug_copy(e.enc, b"trace", buf.ctypes.data, buf.nbytes)
 tr = buf[:wc * hc * 24].reshape(hc, wc, 3, 8).astype(np.int64)
 t0 = tr[..., 0].min()
@@ -33,6 +33,13 @@ for c in range(3):
           ((fb[:, 1:] - p24[:, :-1])[ok].mean(), np.median((fb[:, 1:] - p24[:, :-1])[ok]), (fb[1:, :-1] - p44[:-1, 1:]).mean(), np.median(fb[1:, :-1] - p44[:-1, 1:])))
     print("  lag to the left neighbour's first block, mean %.1f us; to the upper neighbour's, mean %.1f us" %
           ((fb[:, 1:] - fb[:, :-1]).mean(), (fb[1:, :] - fb[:-1, :]).mean()))
+# when the first sixteen luma blocks of some CTUs in the middle of the picture were done (us after the CTU's first block started)
+blk = buf[wc * hc * 56:].reshape(hc, wc, 16)
+print("luma block completion times after the CTU's first block began (block size in brackets), three CTUs of the middle rows:")
+for (ry, rx) in ((hc // 2, wc // 2), (hc // 2, wc // 2 + 3), (hc // 2 + 1, wc // 3)):
+    ts = [(int(v & ((1 << 60) - 1)) - int(tr[ry, rx, 0, 1])) / 100.0 for v in blk[ry, rx] if v]
+    sz = [1 << int(v >> 60) for v in blk[ry, rx] if v]
+    print("  CTU (%d, %d): " % (rx, ry) + " ".join("%.1f[%d]" % (t, n) for t, n in zip(ts, sz)))
 d = None
 lib = e.lib
 import ctypes

@@ -332,6 +332,27 @@ __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNei
   // after the other were a tenth of the wavefront's step (S <= 64: one byte per lane covers a column, one dword per lane a row and a half).
   int haveL = 0, uptoL = 0, haveT = 0, uptoT = 0;
   bool doC = false;
+  if (rx == 0 && ry == 0 && (b.nb_left || b.nb_up)) {
+    // The CTU's first block waits for three neighbours (left column, top row, corner).  They are polled TOGETHER, lanes 0 .. 3 one counter each, until all
+    // are far enough: waiting for the left one first and then finding out with a poll each that the upper ones were done long ago put two memory round
+    // trips on the wavefront's step.  (The wave_wait_wt calls below then find what they need in the cache.)
+    const int nL = imin(S, 2 * n), limT = imin(lim_w, b.nb_ur ? 2 * S : S), nT = imin(limT, 2 * n);
+    uint32_t want = 0;
+    if (lane == 0 && b.nb_left) want = kv_edge_need(b.il, ((nL - 1) << sh) >> 3, true);
+    if (lane == 1 && b.nb_up) want = kv_edge_need(b.iu, ((imin(S, nT) - 1) << sh) >> 3, false);
+    if (lane == 2 && b.nb_up && nT > S) want = kv_edge_need(b.iur, ((nT - S - 1) << sh) >> 3, false);
+    if (lane == 3 && b.nb_ul) want = b.iul ? 64u : 0u;
+    const uint32_t *p = lane == 0 ? b.pl : (lane == 1 ? b.pu : (lane == 2 ? b.pur : b.pul));
+    uint32_t v = lane < 4 ? lds_load(&ch.seen_l + lane) : 0u, spins = 0;
+    while (__ballot(lane < 4 && v < want) != 0) {
+      if (lane < 4 && v < want) v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__ballot(lane < 4 && v < want) == 0) break;
+      if (++spins < 16) __builtin_amdgcn_s_sleep(1); else if (spins < 64) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
+      if (spins > (1u << 21)) { if (lane == 0) atomicOr(err, 1u); v = 64; break; }
+    }
+    if (lane < 4 && want) atomicMax(&ch.seen_l + lane, v);
+    wave_sync();
+  }
   if (rx == 0 && b.nb_left) {
     const int need = imin(S, ry + 2 * n);
     haveL = __builtin_amdgcn_readfirstlane(lds_load(&ch.left_loaded));

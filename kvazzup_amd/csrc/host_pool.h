@@ -172,8 +172,11 @@ class CopyPool {
   {
     int seen = gen_.load(std::memory_order_acquire);
     for (;;) {
-      // a short spin first: at several thousand pictures per second the next job is ~100 us away and a futex wake-up costs a good part of that
-      for (int spins = 0; gen_.load(std::memory_order_acquire) == seen && spins < 2000; spins++) __builtin_ia32_pause();
+      // a short spin first -- at several thousand pictures per second the next job is ~100 us away and a futex wake-up costs a good part of that -- but SHORT:
+      // the host is what this pipeline runs out of, and helpers that spin half the time between jobs took cores from the parsers (2000 pauses: 4 500-5 000
+      // frames/s through the host boundary on one box, 200: 4 900-5 400, none: 4 700-4 900)
+      static const int spin_max = [] { const char *e = getenv("KVAZZUP_AMD_COPY_SPIN"); return e ? atoi(e) : 200; }();
+      for (int spins = 0; gen_.load(std::memory_order_acquire) == seen && spins < spin_max; spins++) __builtin_ia32_pause();
       while (gen_.load(std::memory_order_acquire) == seen) futex_wait(gen_, seen);
       seen = gen_.load(std::memory_order_acquire);
       if (quit_.load(std::memory_order_acquire)) return;

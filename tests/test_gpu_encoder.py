@@ -365,13 +365,19 @@ def test_random_tool_combinations_match_oracle(gpu, seed):
                sao=int(rng.integers(0, 2)), qp_in_cu=int(rng.integers(0, 2)), bitrate=int(rng.choice([0, 0, 0, 150000, 2000000])), mv_frame=int(rng.choice([0, 0, 1, 2])), vaq=int(rng.choice([0, 0, 3, 12])), me_early=int(rng.integers(0, 2)))
     owf = int(rng.choice([0, 1, 2, 3, 5]))
     kind = int(rng.choice([0, 2]))
+    # (drawn after everything the earlier rounds' sweeps drew, so that their configurations stay what they were)
+    extra = dict(subme=int(rng.choice([0, 0, 2, 4])), tile_cols=int(rng.choice([1, 1, 2])) if w >= 256 else 1)
+    tools = dict(intra_in_p=int(rng.integers(0, 2)), rdoq=int(rng.integers(0, 2)), signhide=int(rng.integers(0, 2)))
+    cfg.update(extra)
     frames = (9 if owf < 3 else 12) if cfg["bitrate"] else 5              # (the rate controller starts moving the QP behind its delay)
     oe = orc.OracleEncoder(w, h, **cfg)
     if cfg["bitrate"] and owf >= 3:
         oe.set_option("rc-delay", owf + 1)             # the feedback delay follows the pictures in flight (encoder.hip rc_delay_)
+    oe.set_option("intra-in-p", tools["intra_in_p"]); oe.set_option("rdoq", tools["rdoq"]); oe.set_option("signhide", tools["signhide"])
     od = orc.OracleDecoder()
     ge = Encoder(w, h, options=(("qp", cfg["qp"]), ("period", cfg["period"]), ("me-range", cfg["me_range"]), ("wpp", cfg["wpp"]),
-                                ("deblock", cfg["deblock"]), ("tiles", "1x%d" % cfg["tile_rows"]), ("sao", "full" if cfg["sao"] else "off"),
+                                ("deblock", cfg["deblock"]), ("tiles", "%dx%d" % (cfg["tile_cols"], cfg["tile_rows"])), ("sao", "full" if cfg["sao"] else "off"),
+                                ("subme", cfg["subme"]), ("intra-in-p", tools["intra_in_p"]), ("rdoq", tools["rdoq"]), ("signhide", tools["signhide"]),
                                 ("set-qp-in-cu", cfg["qp_in_cu"]), ("owf", owf),
                                 ("mv-constraint", ("none", "frame", "frametilemargin")[cfg["mv_frame"]])) + ((("vaq", cfg["vaq"]),) if cfg["vaq"] else ()) + (("me-early-termination", "on" if cfg["me_early"] else "off"),), fields={"target_bitrate": cfg["bitrate"]})
     assert not ge.rejected, (cfg, ge.rejected)
@@ -397,8 +403,8 @@ def test_random_tool_combinations_match_oracle(gpu, seed):
             got.append(out)
     assert len(got) == frames, (cfg, owf, len(got))
     for t in range(frames):
-        assert got[t][0] == want[t][0], (cfg, owf, t, len(got[t][0]), len(want[t][0]))
-        assert np.array_equal(got[t][1], want[t][1]), (cfg, owf, t)
+        assert got[t][0] == want[t][0], (cfg, tools, owf, t, len(got[t][0]), len(want[t][0]))
+        assert np.array_equal(got[t][1], want[t][1]), (cfg, tools, owf, t)
         dec = gd.decode_au(got[t][0], t)
         ref = od.decode_au(want[t][0], t)
         assert len(dec) == 1 and len(ref) == 1 and np.array_equal(dec[0]["i420"], ref[0]["i420"]) and np.array_equal(dec[0]["i420"], want[t][1]), (cfg, t)

@@ -20,6 +20,7 @@ Prints ONE JSON line on rank 0 (see the contract in the task description / DESIG
 import argparse
 import json
 import os
+import resource
 import subprocess
 import sys
 import time
@@ -502,6 +503,7 @@ def run_stream(args, wl, steps, warmup, ranks, rank, world, quality, host_io=Fal
         sync()
         cpu0 = time.process_time()
         thr0 = _throttled_us()
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         if _sampler is not None:
             _sampler.cpu_sampler_begin()
         t0 = time.perf_counter()
@@ -513,7 +515,9 @@ def run_stream(args, wl, steps, warmup, ranks, rank, world, quality, host_io=Fal
             _sampler.cpu_sampler_end()
         # throttled: summed over the job's threads: > 0 means the CPU quota, not the GPU, set the pace for a while; host cores: CPU
         # seconds of all threads of this rank per second of the timed region
-        reps.append({"elapsed": sync(el), "throttled_ms": (_throttled_us() - thr0) / 1e3, "host_cores": (time.process_time() - cpu0) / el})
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        reps.append({"elapsed": sync(el), "throttled_ms": (_throttled_us() - thr0) / 1e3, "host_cores": (time.process_time() - cpu0) / el,
+                     "minflt": (ru1.ru_minflt - ru0.ru_minflt) / (steps * PERIOD), "sys_share": (ru1.ru_stime - ru0.ru_stime) / max(1e-9, (ru1.ru_stime - ru0.ru_stime) + (ru1.ru_utime - ru0.ru_utime))})
     if _thr0 is not None:                                       # KVAZZUP_BENCH_THREADS=1: CPU time per thread over the timed regions (stderr)
         _thr1 = _thread_cpu()
         tot = sum(r["elapsed"] for r in reps)
@@ -534,7 +538,7 @@ def run_stream(args, wl, steps, warmup, ranks, rank, world, quality, host_io=Fal
     pl.close()
 
     out = {"elapsed": elapsed, "pictures": npic, "cw": cw, "ch": ch, "kt": kt, "busy": busy, "bytes_per_picture": nbytes / nall, "D": D,
-           "host_cores": host_cores, "budget": budget, "throttled_ms": throttled_ms, "psnr_y": None,
+           "host_cores": host_cores, "budget": budget, "throttled_ms": throttled_ms, "psnr_y": None, "minflt": med["minflt"], "sys_share": med["sys_share"],
            "runs_fps": [round(world * npic / r["elapsed"], 1) for r in reps]}
     if quality:
         # Quality of what was just timed (untimed pass): one intra period through a second pipeline with the decoded pictures
@@ -738,7 +742,7 @@ def main():
         pic = wl_["w"] * wl_["h"] * 3 // 2
         return {"value": round(fps_h, 3), "unit": "frames/s", "runs": hb["runs_fps"], "of_resident": round(fps_h / resident, 4),
                 "h2d_GBps": round(fps_h * pic / 1e9 / world, 2), "d2h_GBps": round(fps_h * pic / 1e9 / world, 2),
-                "host_cpu_cores_busy": round(hb["host_cores"], 2),
+                "host_cpu_cores_busy": round(hb["host_cores"], 2), "minor_page_faults_per_picture": round(hb["minflt"], 1), "cpu_time_in_kernel": round(hb["sys_share"], 3),
                 "filter_busy_ms_per_picture": {"KvazaarFilter": hb["busy"][0], "WireAdapter": hb["busy"][1], "OpenHEVCFilter": hb["busy"][2]},
                 "boundary": "host I420 -> KvazaarFilter' (memcpy into a page-locked kvz_picture, kvz_api->encoder_encode; custom parameters recon-output=0: uvgComm frees the "
                             "reconstruction unread, kvazaarfilter.cpp:476; null-input=poll: the loop at :440-448 collects finished pictures without emptying the pipeline) -> access units -> OpenHEVCFilter' (libOpenHevcDecode / GetOutput, row copy into host "
@@ -800,7 +804,7 @@ def main():
                        "intra_period": PERIOD, "qp": 32, "me_range": args.me_range, "streams": world, "collective_backend": backend,
                        "bits_per_picture": round(8 * m["bytes_per_picture"], 1), "psnr_y": m["psnr_y"],
                        "decoder_frame_threads": m["D"], "owf": args.owf, "gpu_entropy": bool(args.gpu_entropy), "subme": args.subme, "sao": bool(args.sao), "me_early_termination": not args.full_search, "intra_satd": not args.intra_sad,
-                       "host_cpu_cores_busy": round(m["host_cores"], 2), "host_cpu_budget_cores": round(m["budget"], 1), "host_cpu_throttled_ms": round(m["throttled_ms"], 1),
+                       "host_cpu_cores_busy": round(m["host_cores"], 2), "minor_page_faults_per_picture": round(m["minflt"], 1), "cpu_time_in_kernel": round(m["sys_share"], 3), "host_cpu_budget_cores": round(m["budget"], 1), "host_cpu_throttled_ms": round(m["throttled_ms"], 1),
                        "input": "host I420 through kvz_api->encoder_encode" if args.host_io else "I420 resident in HBM",
                        "output": "Annex-B AU on host + decoded I420 in " + ("host memory" if args.host_io else "HBM"),
                        "repeats": args.repeats, "runs_fps": m["runs_fps"], "value_is": "median run of `repeats` (BASELINE.md timing rule)"},

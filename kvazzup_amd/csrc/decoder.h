@@ -251,7 +251,7 @@ class Decoder {
   // download mode: page-locked output buffers take turns -- one is what libOpenHevcGetOutput last handed out (valid until the next
   // decode call, openhevcfilter.cpp:218-229 copies at once), one receives the picture whose kernels are running, queued behind them on
   // the download stream at launch, so the copy over PCIe overlaps the next picture's kernels instead of stalling the calling thread
-  static constexpr int kOutRing = 10;     // (pictures queued on the GPU + the one handed out + the one being launched)
+  static constexpr int kOutRing = 16;     // (pictures queued on the GPU + the one handed out + the one being launched + six the caller may still be copying out of: OpenHEVCFilter's output stage)
   uint8_t *h_out_[kOutRing] = {}; size_t h_out_cap_ = 0;
   void describe_output(const PicJob &job, DecodedPicture &o, int buf) const;
   int queue_download(PicJob &job);

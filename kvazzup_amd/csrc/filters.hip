@@ -401,7 +401,12 @@ enum OHThreadType { OH_THREAD_FRAME = 1, OH_THREAD_SLICE = 2, OH_THREAD_FRAMESLI
 
 OpenHEVCFilter::OpenHEVCFilter(uint32_t sessionID, Stats *stats, const Settings *settings)
     : Filter(std::to_string(sessionID), "OpenHEVC", stats, DT_HEVCVIDEO, DT_YUV420VIDEO), settings_(settings), sessionID_(sessionID) {}
-OpenHEVCFilter::~OpenHEVCFilter() { stop(); if (handle_) uninit(); }
+OpenHEVCFilter::~OpenHEVCFilter()
+{
+  stop();
+  if (outThread_.joinable()) { { std::lock_guard<std::mutex> l(outM_); outQuit_ = true; } outCv_.notify_all(); outThread_.join(); }     // (what is queued is still copied and sent: the frames' memory lives until uninit)
+  if (handle_) uninit();
+}
 
 bool OpenHEVCFilter::init()                                // openhevcfilter.cpp:28-74
 {
@@ -419,6 +424,7 @@ bool OpenHEVCFilter::init()                                // openhevcfilter.cpp
   libOpenHevcSetViewLayers(handle_, 0);
   download_ = atoi(get("uvgx/decoderDownload", "1").c_str()) != 0;
   { const int n = atoi(get("uvgx/copyThreads", "4").c_str()); copy_.reset(n > 1 && download_ ? new kvzx::CopyPool(n > 16 ? 16 : n) : nullptr); }
+  asyncOut_ = atoi(get("uvgx/asyncOutput", "1").c_str()) != 0;
   if (!download_) kvzx_decoder_set_download(handle_, 0);   // extension: leave decoded pictures in HBM
   decodingFrames_.clear();
   maxBufferSize_ = -1;                                     // no buffer limit (openhevcfilter.cpp:68)
@@ -496,26 +502,60 @@ void OpenHEVCFilter::sendDecodedOutput(int &gotPicture)    // openhevcfilter.cpp
       sendOutput(std::move(decodedFrame));
       return;
     }
+    OutJob job;
+    job.y = (const uint8_t *)openHevcFrame.pvY; job.u = (const uint8_t *)openHevcFrame.pvU; job.v = (const uint8_t *)openHevcFrame.pvV;
+    job.s_stride = (uint32_t)openHevcFrame.frameInfo.nYPitch; job.qs_stride = (uint32_t)openHevcFrame.frameInfo.nUPitch / 2; job.W = W; job.H = H;
+    job.frame = std::move(decodedFrame);
+    if (!asyncOut_) { copyOut(job); return; }
+    if (!outThread_.joinable()) outThread_ = std::thread([this] { kvzx::name_this_thread("kvzx-dec-out"); outputStage(); });
+    std::unique_lock<std::mutex> l(outM_);
+    outSpace_.wait(l, [this] { return outQ_.size() < 3; });
+    outQ_.push_back(std::move(job));
+    outCv_.notify_one();
+  }
+}
+
+void OpenHEVCFilter::outputStage()
+{
+  for (;;) {
+    OutJob job;
+    {
+      std::unique_lock<std::mutex> l(outM_);
+      outCv_.wait(l, [this] { return outQuit_ || !outQ_.empty(); });
+      if (outQ_.empty()) return;
+      job = std::move(outQ_.front());                      // (stays counted until the copy is done: the queue bound is what keeps the frame's memory valid)
+    }
+    copyOut(job);
+    { std::lock_guard<std::mutex> l(outM_); outQ_.pop_front(); }
+    outSpace_.notify_one();
+  }
+}
+
+void OpenHEVCFilter::copyOut(OutJob &job)                  // the copy of openhevcfilter.cpp:206-235
+{
+  std::unique_ptr<Data> decodedFrame = std::move(job.frame);
+  const int W = job.W, H = job.H;
+  {
     uint32_t finalDataSize = (uint32_t)(W * H + W * H / 2);
     kvzx::tl("out0", (long)decodedFrame->presentationTimestamp);
     std::unique_ptr<uint8_t[]> yuv_frame(new uint8_t[finalDataSize]);
     kvzx::tl("alloc", (long)decodedFrame->presentationTimestamp);
     uint8_t *pY = yuv_frame.get(), *pU = yuv_frame.get() + W * H, *pV = yuv_frame.get() + W * H + W * H / 4;
-    uint32_t s_stride = (uint32_t)openHevcFrame.frameInfo.nYPitch, qs_stride = (uint32_t)openHevcFrame.frameInfo.nUPitch / 2;
+    uint32_t s_stride = job.s_stride, qs_stride = job.qs_stride;
     uint32_t d_stride = (uint32_t)W / 2, dd_stride = (uint32_t)W;
     if (copy_) {                                           // the same rows (openhevcfilter.cpp:212-229), shared between cores
       pieces_.clear();
-      kvzx::CopyPool::add_plane(pieces_, pY, (const uint8_t *)openHevcFrame.pvY, dd_stride, (size_t)H, dd_stride, s_stride);
-      kvzx::CopyPool::add_plane(pieces_, pU, (const uint8_t *)openHevcFrame.pvU, d_stride, (size_t)((H + 1) / 2), d_stride, 2 * qs_stride);
-      kvzx::CopyPool::add_plane(pieces_, pV, (const uint8_t *)openHevcFrame.pvV, d_stride, (size_t)((H + 1) / 2), d_stride, 2 * qs_stride);
+      kvzx::CopyPool::add_plane(pieces_, pY, job.y, dd_stride, (size_t)H, dd_stride, s_stride);
+      kvzx::CopyPool::add_plane(pieces_, pU, job.u, d_stride, (size_t)((H + 1) / 2), d_stride, 2 * qs_stride);
+      kvzx::CopyPool::add_plane(pieces_, pV, job.v, d_stride, (size_t)((H + 1) / 2), d_stride, 2 * qs_stride);
       copy_->run(pieces_);
     } else
     for (int i = 0; i < H; i++) {
-      memcpy(pY, (uint8_t *)openHevcFrame.pvY + i * s_stride, dd_stride);
+      memcpy(pY, job.y + (size_t)i * s_stride, dd_stride);
       pY += dd_stride;
       if (!(i % 2)) {
-        memcpy(pU, (uint8_t *)openHevcFrame.pvU + i * qs_stride, d_stride); pU += d_stride;
-        memcpy(pV, (uint8_t *)openHevcFrame.pvV + i * qs_stride, d_stride); pV += d_stride;
+        memcpy(pU, job.u + (size_t)i * qs_stride, d_stride); pU += d_stride;
+        memcpy(pV, job.v + (size_t)i * qs_stride, d_stride); pV += d_stride;
       }
     }
     decodedFrame->data_size = finalDataSize;
@@ -684,6 +724,23 @@ static int push(UvgxPipeline *p, const uint8_t *host, const void *dev, int w, in
 }
 KVZ_PUBLIC int uvgx_pipeline_push_host(void *pp, const uint8_t *i420, int w, int h, int fn, int fd, int64_t pts) { return pp && i420 ? push((UvgxPipeline *)pp, i420, nullptr, w, h, fn, fd, pts) : 0; }
 KVZ_PUBLIC int uvgx_pipeline_push_device(void *pp, const void *d_i420, int w, int h, int fn, int fd, int64_t pts) { return pp && d_i420 ? push((UvgxPipeline *)pp, nullptr, d_i420, w, h, fn, fd, pts) : 0; }
+
+// measurement aid: an access unit straight into the receiving side (WireAdapter -> OpenHEVCFilter), paced like the sources above; size 0 = flush marker
+KVZ_PUBLIC int uvgx_pipeline_push_encoded(void *pp, const uint8_t *au, uint32_t size, int64_t pts, uint32_t max_backlog, int timeout_ms)
+{
+  UvgxPipeline *p = (UvgxPipeline *)pp;
+  if (!p || !p->wire || !p->dec) return 0;
+  std::unique_ptr<Data> d(new Data);
+  d->source = DS_REMOTE; d->type = DT_HEVCVIDEO; d->creationTimestamp = now_ms(); d->presentationTimestamp = pts;
+  if (!size) d->flush_marker = true;
+  else {
+    if (!p->dec->waitBufferedBelow(max_backlog, timeout_ms)) return 0;
+    d->data_size = size; d->data.reset(new uint8_t[size]); memcpy(d->data.get(), au, size);
+    d->vInfo.reset(new VideoInfo);
+  }
+  p->wire->putInput(std::move(d));
+  return 1;
+}
 
 // wait until `n` pictures have left the last filter (decoder when looped back, else encoder); 1 = reached
 KVZ_PUBLIC int uvgx_pipeline_wait(void *pp, uint64_t n, int timeout_ms)

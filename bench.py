@@ -445,6 +445,8 @@ def run_stream(args, wl, steps, warmup, ranks, rank, world, quality, host_io=Fal
         st = {"video/QP": 32, "video/Intra": PERIOD, "video/VPS": 1, "uvgx/gpu": dev_index, "uvgx/decoderDownload": int(download),
               "video/OWF": args.owf, "video/OPENHEVC_threads": D, "video/OH_parallelization": "Frame" if D > 1 else "Slice"}
         st.update(extra_settings or {})
+        if os.environ.get("KVAZZUP_BENCH_COPY_THREADS"):
+            st["uvgx/copyThreads"] = os.environ["KVAZZUP_BENCH_COPY_THREADS"]       # (measurement aid: helpers of the filters' picture copies, default 4)
         return Pipeline(w, h, settings=st,
                         custom=(("me-range", args.me_range), ("gpu", dev_index)) + ((("sao", "full"),) if args.sao else ()) + ((("me-early-termination", "off"),) if args.full_search else ()) + ((("intra-satd", "0"),) if args.intra_sad else ()) + ((("gpu-entropy", "1"),) if args.gpu_entropy else ()) + ((("subme", str(args.subme)),) if args.subme else ()) + tuple(tuple(kv.split("=", 1)) for kv in args.custom) + tuple(extra_custom),
                         loopback=True, keep_outputs=keep)

@@ -350,3 +350,21 @@ def test_rate_control_delay_option():
         with pytest.raises(ValueError):
             oe.set_option("rc-delay", bad)
     oe.close()
+
+
+def test_checker_decodes_one_segment_pictures_when_dependent_segments_are_enabled():
+    """dependent_slice_segments_enabled_flag = 1 in the PPS with every picture sent as ONE segment (no WPP, one tile): the checker's decoder reads the segment to its
+    end_of_slice_segment_flag (the HIP decoder's case for this: tests/test_gpu_decoder.py::test_whole_pictures_in_one_segment_with_dependent_segments_enabled)"""
+    w, h = 320, 192
+    oe = orc.OracleEncoder(w, h, qp=30, period=4, me_range=8, wpp=0)
+    od = orc.OracleDecoder()
+    for t in range(6):
+        au = bytearray(oe.encode(orc.synth_frame(0, 5, w, h, t)))
+        pos = 0
+        for nal in orc.split_nals(bytes(au)):
+            if (nal[4] >> 1) & 63 == 34:
+                au[pos + 6] |= 0x20
+            pos += len(nal)
+        fr = od.decode_au(bytes(au), t)
+        assert len(fr) == 1 and np.array_equal(fr[0]["i420"], oe.recon()), t
+    oe.close(); od.close()

@@ -165,6 +165,7 @@ class OpenHEVCFilter : public Filter {
   void uninit();
   void updateSettings() override;
   OpenHevc_Handle handle() { return handle_; }
+  void finishOutput();
 
  protected:
   void process() override;

@@ -404,8 +404,19 @@ OpenHEVCFilter::OpenHEVCFilter(uint32_t sessionID, Stats *stats, const Settings 
 OpenHEVCFilter::~OpenHEVCFilter()
 {
   stop();
-  if (outThread_.joinable()) { { std::lock_guard<std::mutex> l(outM_); outQuit_ = true; } outCv_.notify_all(); outThread_.join(); }     // (what is queued is still copied and sent: the frames' memory lives until uninit)
+  finishOutput();
   if (handle_) uninit();
+}
+
+// the output stage's thread copies and sends what is still queued, then ends (the frames' memory lives until uninit).  Whoever owns what the
+// output callbacks touch calls this before that goes away (uvgx_pipeline_destroy).
+void OpenHEVCFilter::finishOutput()
+{
+  if (!outThread_.joinable()) return;
+  { std::lock_guard<std::mutex> l(outM_); outQuit_ = true; }
+  outCv_.notify_all();
+  outThread_.join();
+  outQuit_ = false;
 }
 
 bool OpenHEVCFilter::init()                                // openhevcfilter.cpp:28-74
@@ -824,7 +835,7 @@ KVZ_PUBLIC void uvgx_pipeline_destroy(void *pp)
   if (!p) return;
   p->enc->stop();
   if (p->wire) p->wire->stop();
-  if (p->dec) p->dec->stop();
+  if (p->dec) { p->dec->stop(); p->dec->finishOutput(); }
   if (p->rgb) p->rgb->stop();
   delete p;
 }

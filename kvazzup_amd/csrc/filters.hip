@@ -455,6 +455,7 @@ void OpenHEVCFilter::updateSettings()                      // openhevcfilter.cpp
   auto get = [&](const char *k, const char *d) { auto it = settings_->find(k); return it == settings_->end() ? std::string(d) : it->second; };
   if (atoi(get("video/OPENHEVC_threads", "1").c_str()) != threads_ || get("video/OH_parallelization", "Slice") != parallelizationMode_) {
     std::lock_guard<std::mutex> l(settingsMutex_);
+    finishOutput();                                        // (pictures still being copied out live in the decoder that is about to go)
     uninit();
     init();
   }

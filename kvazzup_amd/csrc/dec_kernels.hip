@@ -490,6 +490,8 @@ __global__ __launch_bounds__(256) void k_dec_intra_resid(DecFrame f)
 {
   __shared__ IntraWaveScratch wsv[4];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, idx = (int)blockIdx.x * 4 + wv;
+  // (the progress counters and the ticket counter k_dec_intra starts from: this kernel runs in front of it on the same stream, a memset of their own was a launch)
+  if (blockIdx.x == 0) for (int i = threadIdx.x; i < 3 * f.wc * f.hc + 1; i += 256) f.progress[i] = 0;
   if (idx >= f.ntu) return;
   const DecTu d = f.tus[idx];
   if (!(d.flags & TU_INTRA) || !d.count || d.log2 > 4) return;

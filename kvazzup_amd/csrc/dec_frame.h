@@ -66,6 +66,7 @@ struct DecFrame {
   uint32_t *err;
   int8_t cb_qp_offset, cr_qp_offset;       // pps_cb/cr_qp_offset (deblocking uses these, 8.7.2.5.5)
   int8_t beta_offset, tc_offset;           // slice_beta_offset_div2 * 2, slice_tc_offset_div2 * 2
+  uint8_t intra_direct;     // k_dec_intra: a workgroup per (CTU, plane) in dispatch order instead of tickets (pictures that are mostly inter: nearly every (CTU, plane) has nothing to do, and a ticket is a memory round trip)
   uint8_t strong_intra, tiles;             // strong_intra_smoothing_enabled_flag; more than one tile
   uint8_t pad_[2];
 };

@@ -563,11 +563,15 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
   const int lane = threadIdx.x;
   const uint32_t nticket = 3u * (uint32_t)f.wc * (uint32_t)(f.nrows > 0 ? f.nrows : f.hc);
   for (int i = lane; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];      // the transforms' matrix operands: once per workgroup, not per (CTU, plane)
-  for (;;) {
-  __syncthreads();
-  uint32_t ticket = 0;
-  if (lane == 0) ticket = atomicAdd(f.progress + (size_t)3 * f.wc * f.hc, 1u);
-  ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+  for (bool once = true;; once = false) {
+  uint32_t ticket = blockIdx.x;
+  if (f.intra_direct) { if (!once) break; }
+  else {
+    __syncthreads();
+    ticket = 0;
+    if (lane == 0) ticket = atomicAdd(f.progress + (size_t)3 * f.wc * f.hc, 1u);
+    ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+  }
   if (ticket >= nticket) break;
   const int ctu = (int)f.intra_order[ticket / 3u], c = (int)(ticket % 3u), cx = ctu % f.wc, cy = ctu / f.wc;
   const int sh = c ? 1 : 0, S = 64 >> sh, cpitch = f.pw >> sh, wC = f.w >> sh, hC = f.h >> sh;
@@ -889,7 +893,7 @@ void launch_dec_intra(const DecFrame &f, hipStream_t st)
 {
   // as many one-wave workgroups as three anti-diagonals of the CTU wavefront hold, in three planes (k_dec_intra: tickets; f.intra_order lists the band's CTUs)
   static const int diags = getenv("KVAZZUP_AMD_INTRA_DIAGS") ? atoi(getenv("KVAZZUP_AMD_INTRA_DIAGS")) : 3;      // (measurement aid; 0: a workgroup per (CTU, plane))
-  const int nr = dec_rows(f), diag = nr < (f.wc + 1) / 2 ? nr : (f.wc + 1) / 2, all = f.wc * nr * 3, want = diags > 0 ? 3 * diags * diag + 32 : all;
+  const int nr = dec_rows(f), diag = nr < (f.wc + 1) / 2 ? nr : (f.wc + 1) / 2, all = f.wc * nr * 3, want = (diags > 0 && !f.intra_direct) ? 3 * diags * diag + 32 : all;
   hipLaunchKernelGGL(k_dec_intra, dim3(want < all ? want : all), dim3(64), 0, st, f);
 }
 void launch_dec_deblock(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_deblock, dim3(f.wc * dec_rows(f)), dim3(256), 0, st, f); }

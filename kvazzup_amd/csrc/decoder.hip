@@ -1851,6 +1851,7 @@ int Decoder::launch_gpu(PicJob &job)
   f.progress = progress_; f.intra_order = intra_order_; f.err = err_;
   f.cb_qp_offset = (int8_t)job.pps.cb_qp_offset; f.cr_qp_offset = (int8_t)job.pps.cr_qp_offset;
   f.beta_offset = (int8_t)(2 * job.sh.beta_offset_div2); f.tc_offset = (int8_t)(2 * job.sh.tc_offset_div2);
+  f.intra_direct = job.any_inter ? 1 : 0;                 // (a picture with inter blocks: few (CTU, plane) pairs hold intra blocks)
   f.strong_intra = (uint8_t)job.sps->strong_intra; f.tiles = job.pps.tile_rows > 1 || job.pps.tile_cols > 1;
   if (band_nrows_ > 0) {
     // a band starts and ends on tile boundaries of full-width tiles; no SAO, no temporal prediction (what the split encoder writes)

@@ -61,6 +61,7 @@ struct DecFrame {
   uint8_t *out[3];          // SAO output (== rec planes of the picture buffer when SAO runs from a work picture)
   const uint8_t *ref[KVZ_DEC_MAX_REFS][3];   // picture buffers by slot
   const SaoParams *sao;     // per CTU; NULL = off
+  uint8_t *edge_col[3];     // k_dec_intra: per plane [CTU][64 >> (plane != 0)] the right column of the CTU's intra blocks (kernel_common.h IB_EDGE_R)
   uint32_t *progress;       // intra wavefront: [CTU][plane] = 8x8 luma units of the CTU whose intra blocks are final
   const uint32_t *intra_order;  // CTU handled by the k-th workgroup triple of k_dec_intra: anti-diagonal order (enc_kernels.hip k_intra_recon)
   uint32_t *err;

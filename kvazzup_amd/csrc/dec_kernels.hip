@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void k_dec_intra_resid(DecFrame f)
 // residual samples (k_dec_intra_resid), loaded by the caller one block ahead
 template <int L2>
 __device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveScratch &ws, const IntraBlk &d, bool luma,
-                                                     uint8_t *gdst, int gp, int lane, uint2 rres, uint32_t *publish)
+                                                     uint8_t *gdst, int gp, int lane, uint2 rres, uint32_t *publish, uint8_t *ecol)
 {
   constexpr int N = 1 << L2;
   const int g = lane >> 4, c = lane & 15, rx = d.rx, ry = d.ry;
@@ -547,6 +547,7 @@ __device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveSc
     *(uint32_t *)&s.pic[(ry + c + 1) * DI_P + 16 + rx + 4 * g] = o;
     // write-through, and only where a neighbouring CTU's workgroup will read (IB_EDGE); the rest of the CTU goes out in full lines at the end (k_dec_intra)
     if (d.flags & IB_EDGE) st_wt_u32(gdst + (size_t)(ry + c) * gp + rx + 4 * g, o);
+    if ((d.flags & IB_EDGE_R) && g == (N >> 2) - 1) st_wt_u8(ecol + ry + c, o >> 24);      // the block's last column, one byte per row, for the right neighbour's left border
   }
   wave_sync();
 }
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
     d.rx = (uint8_t)rx; d.ry = (uint8_t)ry; d.lo = (uint8_t)lo; d.hi = (uint8_t)hi; d.mode = t.mode; d.l2 = t.log2;
     d.flags = (uint8_t)((intra_filter_needed(N, c ? 1 : 0, t.mode) ? IB_FILT : 0) | ((rx == 0 || ry == 0) ? IB_BORDER : 0) |
                         (kv_intra_milestone(zu) > kv_intra_milestone(zprev) ? IB_PUBLISH : 0) | (t.count ? IB_LEVELS : 0) | ((t.flags & TU_TSKIP) ? IB_TSKIP : 0) |
-                        ((rx + N >= S || ry + N >= S) ? IB_EDGE : 0));
+                        ((rx + N >= S || ry + N >= S) ? IB_EDGE : 0) | ((rx + N >= S) ? IB_EDGE_R : 0));
     d.xf = (uint8_t)((t.log2 == 2 && (t.flags & TU_DST)) ? XF16_DST4 : (t.log2 - 1) & 3);
     d.angle = (int16_t)kIntraAngle[t.mode]; d.inv = (int16_t)kInvAngle[t.mode];
     d.zu = (uint16_t)zu; d.next = 0;
@@ -632,6 +633,7 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
     bd.nb_left = cx > 0 && f.ctu_tile[ctu - 1] == tile; bd.nb_up = cy > 0 && f.ctu_tile[ctu - f.wc] == tile;
     bd.nb_ur = cy > 0 && cx + 1 < f.wc && f.ctu_tile[ctu - f.wc + 1] == tile; bd.nb_ul = cy > 0 && cx > 0 && f.ctu_tile[ctu - f.wc - 1] == tile;
     bd.pl = my - 3; bd.pu = my - 3 * f.wc; bd.pur = bd.pu + 3; bd.pul = bd.pu - 3;
+    bd.ecol_left = f.edge_col[c] + (size_t)(ctu - 1) * S;
     // which of the neighbours' edge units are intra units (a P picture's inter blocks are final before this kernel starts: nothing to wait
     // for there) -- lanes 0-7: the left CTU's right column, 8-15 / 16-23: the bottom rows of the upper / upper-right CTU, 24: the corner
     const int g = lane >> 3, u = lane & 7;
@@ -665,6 +667,7 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
   };
   fetch_ahead(0);
   uint8_t *gdst = plane + (size_t)(cy * S) * cpitch + cx * S;
+  uint8_t *const ecol = f.edge_col[c] + (size_t)ctu * S;
   for (int k = 0; k < nlist; k++) {
     const IntraBlk d = wave_uniform(&s.blk[k]);            // (wave-uniform: what is derived from it runs on the scalar unit)
     uint32_t wreg[4];
@@ -676,9 +679,9 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
     if (pub && d.l2 > 4) { publish_wt(my, (uint32_t)d.zu); pub = nullptr; }       // (32x32 blocks: the workgroup-shaped code publishes ahead)
     if (d.flags & IB_BORDER) borders_need(bd, s.pic, DI_P, plane, cpitch, cx, cy, S, sh, wC - cx * S, d.rx, d.ry, 1 << d.l2, &bcast, f.err, lane, T);
     switch (d.l2) {
-      case 2: dec_intra_block_wave<2>(s, ws, d, c == 0, gdst, cpitch, lane, rres, pub); break;
-      case 3: dec_intra_block_wave<3>(s, ws, d, c == 0, gdst, cpitch, lane, rres, pub); break;
-      case 4: dec_intra_block_wave<4>(s, ws, d, c == 0, gdst, cpitch, lane, rres, pub); break;
+      case 2: dec_intra_block_wave<2>(s, ws, d, c == 0, gdst, cpitch, lane, rres, pub, ecol); break;
+      case 3: dec_intra_block_wave<3>(s, ws, d, c == 0, gdst, cpitch, lane, rres, pub, ecol); break;
+      case 4: dec_intra_block_wave<4>(s, ws, d, c == 0, gdst, cpitch, lane, rres, pub, ecol); break;
       default: {
         DecTu t;
         const uint32_t *q = (const uint32_t *)&s.list[k];
@@ -687,6 +690,7 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
         for (int i = 0; i < 4; i++) u[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q[i]);
         memcpy(&t, u, sizeof(t));
         dec_intra_block<5, T>(f, s, t, c, cx, cy, d.rx, d.ry, lane, wreg);
+        if (d.flags & IB_EDGE_R) { __syncthreads(); if (lane < 32) st_wt_u8(ecol + d.ry + lane, s.pic[(d.ry + lane + 1) * DI_P + 16 + d.rx + 31]); }      // (a 32x32 block on the CTU's right edge: its last column from the CTU picture in LDS)
       }
     }
   }

@@ -877,7 +877,7 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
 // Returns whether the block has non-zero levels.
 template <int L2, bool ADJ>
 __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratch &ws, const IntraBlk &d, int cidx, int S, const QuantConst &q,
-                                                 uint8_t *gdst, int gp, int lane, uint32_t *publish, int adj = 0)
+                                                 uint8_t *gdst, int gp, int lane, uint32_t *publish, int adj = 0, uint8_t *ecol = nullptr)
 {
   constexpr int N = 1 << L2;
   const int P = 16 + 2 * S, g = lane >> 4, c = lane & 15, rx = d.rx, ry = d.ry;
@@ -949,6 +949,7 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
     *(uint32_t *)&s.pic[(ry + c + 1) * P + 16 + rx + 4 * g] = o;
     // write-through, and only where a neighbouring CTU's workgroup will read (IB_EDGE): the rest of the CTU goes out in full lines at the end
     if (d.flags & IB_EDGE) st_wt_u32(gdst + (size_t)(ry + c) * gp + rx + 4 * g, o);
+    if ((d.flags & IB_EDGE_R) && g == (N >> 2) - 1) st_wt_u8(ecol + ry + c, o >> 24);      // the block's last column, one byte per row
   }
   wave_sync();
   PROF(9);
@@ -1022,6 +1023,8 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   nb.nb_up = row > 0 && !tile_row_starts_at(hc, f.tile_rows, row); nb.nb_left = cx > 0 && !tile_col_starts_at(wc, f.tile_cols, cx);
   nb.nb_ur = nb.nb_up && cx + 1 < wc && !tile_col_starts_at(wc, f.tile_cols, cx + 1); nb.nb_ul = nb.nb_up && nb.nb_left;
   nb.pl = my - 3; nb.pu = my - 3 * wc; nb.pur = nb.pu + 3; nb.pul = nb.pu - 3;
+  uint8_t *const ecol = f.edge_col[c] + (size_t)ctu * S;       // this CTU's right column for its right neighbour (IB_EDGE_R)
+  nb.ecol_left = ecol - S;
   if (PP) {
     // which of the neighbours' edge units are intra units (kernel_common.h IntraBorders: the inter units around are final, nothing to wait for
     // there) -- lanes 0-7: the left CTU's right column, 8-15 / 16-23: the bottom rows of the upper / upper-right CTU, 24: the corner
@@ -1058,7 +1061,7 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
       // of this block's size, which either precedes this block in z-order or does not; the available groups are contiguous
       d.lo = (uint8_t)(aBL ? 0 : (aL ? n : 2 * n + 1)); d.hi = (uint8_t)(aTR ? 4 * n : (aT ? 3 * n : (aL ? 2 * n - 1 : 0)));      // (nothing available: lo = 2n + 1 > hi = 0)
       d.mode = (uint8_t)mode; d.l2 = (uint8_t)(l2 - sh);
-      d.flags = (uint8_t)((intra_filter_needed(n, c ? 1 : 0, mode) ? IB_FILT : 0) | ((zx == 0 || zy == 0) ? IB_BORDER : 0) | ((zx + su == 8 || zy + su == 8) ? IB_EDGE : 0));
+      d.flags = (uint8_t)((intra_filter_needed(n, c ? 1 : 0, mode) ? IB_FILT : 0) | ((zx == 0 || zy == 0) ? IB_BORDER : 0) | ((zy + su == 8) ? IB_EDGE : 0) | ((zx + su == 8) ? IB_EDGE_R : 0));
       d.xf = (uint8_t)((l2 - sh == 2 && c == 0) ? XF16_DST4 : l2 - sh - 1);
       d.angle = (int16_t)kIntraAngle[mode]; d.inv = (int16_t)kInvAngle[mode];
       d.zu = (uint16_t)lane; d.next = (uint16_t)(lane + su * su);
@@ -1100,9 +1103,9 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     first = false;
     bool cbf;
     switch (d.l2) {
-      case 2: cbf = intra_block_wave<2, ADJ>(s, ws, d, c, S, q8, grec, pw, lane, nullptr, adj); break;
-      case 3: cbf = intra_block_wave<3, ADJ>(s, ws, d, c, S, c ? q16 : q8, grec, pw, lane, nullptr, adj); break;
-      default: cbf = intra_block_wave<4, ADJ>(s, ws, d, c, S, q16, grec, pw, lane, nullptr, adj); break;
+      case 2: cbf = intra_block_wave<2, ADJ>(s, ws, d, c, S, q8, grec, pw, lane, nullptr, adj, ecol); break;
+      case 3: cbf = intra_block_wave<3, ADJ>(s, ws, d, c, S, c ? q16 : q8, grec, pw, lane, nullptr, adj, ecol); break;
+      default: cbf = intra_block_wave<4, ADJ>(s, ws, d, c, S, q16, grec, pw, lane, nullptr, adj, ecol); break;
     }
     const uint2 cvu = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)cv.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)cv.y));
     chain_mark_done(ch, cvu, lane);
@@ -1114,7 +1117,7 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
 #ifndef KVZ_PROF
     if (f.trace && c == 0 && lane == 0 && k < 16) f.trace[(size_t)wc * (f.ch >> 6) * 56 + (size_t)ctu * 16 + k] = wall_clock64() | ((unsigned long long)d.l2 << 60);      // (tools/intra_timeline.py: when the luma blocks of the CTU were done)
 #endif
-    if (d.flags & IB_EDGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (d.flags & (IB_EDGE | IB_EDGE_R)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     chain_ack_publish(ch, cvu, my, lane, f.trace ? f.trace + ((size_t)ctu * 3 + c) * 8 : nullptr);
     PROF(10);                                               // mark / acknowledge / publish
 #ifdef KVZ_PROF

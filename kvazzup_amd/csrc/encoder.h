@@ -180,7 +180,7 @@ class Encoder {
   uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; int tok_nctu_ = 0;
   size_t tok_dense_cap_ = 0;
   std::vector<std::vector<uint8_t>> band_subs_; uint64_t band_bins_ = 0; bool band_coded_ = false;   // band mode: between phase 2a and 2b
-  uint32_t *sync_ = nullptr; uint32_t *me_cost16_ = nullptr; uint32_t *intra_order_ = nullptr; uint32_t *err_ = nullptr; unsigned long long *trace_ = nullptr;
+  uint32_t *sync_ = nullptr; uint32_t *me_cost16_ = nullptr; uint8_t *edge_col_ = nullptr; uint32_t *intra_order_ = nullptr; uint32_t *err_ = nullptr; unsigned long long *trace_ = nullptr;
   // one slot per picture in flight: the host-visible results of its kernels and what collect() needs to finish it
   struct EvPair { hipEvent_t a, b; KernelId id; };
   struct Slot {

@@ -170,6 +170,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     HIP_OK(hipMalloc(&intra_order_, sizeof(uint32_t) * order.size()));
     HIP_OK(hipMemcpy(intra_order_, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice));
   }
+  { const size_t nctu = (size_t)(cw_ / 64) * rows_; HIP_OK(hipMalloc(&edge_col_, nctu * 128)); }      // the CTUs' right columns (k_intra_recon)
   HIP_OK(hipMalloc(&err_, sizeof(uint32_t))); HIP_OK(hipMemset(err_, 0, sizeof(uint32_t)));
   if (getenv("KVAZZUP_AMD_INTRA_TRACE")) { HIP_OK(hipMalloc(&trace_, sizeof(unsigned long long) * (rows_ * (cw_ / 64) * 72))); HIP_OK(hipMemset(trace_, 0, sizeof(unsigned long long) * (rows_ * (cw_ / 64) * 72))); }
   int eth = cfg.entropy_threads;
@@ -193,6 +194,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   f_.im8 = p; p += nb8; f_.im16 = p; p += nb8 / 4; f_.im32 = p;
   f_.tok_buf = tok_buf_; f_.tok_cap = tok_cap_; f_.tok_cursor = (uint32_t *)tok_count_; f_.tok_cursor_next = (uint32_t *)tok_count_ + tok_nctu_; f_.tok_seg = tok_seg_;
   f_.tok_dense_cap = (uint32_t)tok_dense_cap_;
+  { const size_t nctu = (size_t)(cw_ / 64) * rows_; f_.edge_col[0] = edge_col_; f_.edge_col[1] = edge_col_ + nctu * 64; f_.edge_col[2] = edge_col_ + nctu * 96; }
   f_.sync = sync_; f_.err = err_; f_.trace = trace_; f_.intra_order = intra_order_;
 
   sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp; sp_.tile_rows = cfg.tile_rows; sp_.tile_cols = cfg.tile_cols; sp_.qp_in_cu = cfg.qp_in_cu; sp_.sao = cfg.sao; sp_.slices = cfg.slices; sp_.signhide = cfg.signhide;
@@ -264,7 +266,7 @@ Encoder::~Encoder()
   if (ev_idr_done_) hipEventDestroy(ev_idr_done_);
   hipFree(intra_scratch_);
   delete entropy_; delete entropy2_;
-  hipFree(trace_); hipFree(intra_order_); hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(sync_); hipFree(me_cost16_); hipFree(err_);
+  hipFree(trace_); hipFree(intra_order_); hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(sync_); hipFree(me_cost16_); hipFree(edge_col_); hipFree(err_);
   stream_release(stream_, cfg_.device, 'M', prio_[0]);
 }
 

@@ -137,6 +137,7 @@ template <int L2, int OPL> struct XF { static constexpr int N = 1 << L2, G = N /
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void st_wt_u32(void *p, uint32_t v) { __hip_atomic_store((uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_wt_u64(void *p, uint64_t v) { __hip_atomic_store((uint64_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_wt_u8(void *p, uint32_t v) { __hip_atomic_store((uint8_t *)p, (uint8_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t ld_l2_u32(const void *p) { return __hip_atomic_load((const uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t ld_l2_u8(const void *p) { return __hip_atomic_load((const uint8_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // every thread of the workgroup calls it after its write-through stores
@@ -204,6 +205,7 @@ struct IntraBorders {
   const uint32_t *pl, *pu, *pur, *pul;       // progress counters of the left / upper / upper-right / upper-left CTU (same plane)
   bool nb_left, nb_up, nb_ur, nb_ul;         // which of them exist (inside the picture, same tile)
   uint32_t il = 0xffu, iu = 0xffu, iur = 0xffu, iul = 1u;
+  const uint8_t *ecol_left = nullptr;        // the left CTU's entry of the edge-column array (IB_EDGE_R), or null
   uint32_t seen_l, seen_u, seen_ur, seen_ul;
   int top_loaded, left_loaded; bool corner_loaded;
 };
@@ -232,7 +234,8 @@ __device__ __forceinline__ void borders_need(IntraBorders &b, uint8_t *pic, int 
     if (need > b.left_loaded) {
       b.seen_l = wait_wt(b.pl, kv_edge_need(b.il, ((need - 1) << sh) >> 3, true), b.seen_l, bcast, err);
       const int upto = imax(need, imin(S, kv_units_right(b.seen_l) * (8 >> sh)));
-      for (int i = b.left_loaded + tid; i < upto; i += nthreads) pic[(i + 1) * lp + 15] = (uint8_t)ld_l2_u8(plane + (size_t)(cy * S + i) * gp + cx * S - 1);
+      for (int i = b.left_loaded + tid; i < upto; i += nthreads)
+        pic[(i + 1) * lp + 15] = (uint8_t)((b.ecol_left && ((b.il >> ((i << sh) >> 3)) & 1u)) ? ld_l2_u8(b.ecol_left + i) : ld_l2_u8(plane + (size_t)(cy * S + i) * gp + cx * S - 1));
       b.left_loaded = upto; loaded = true;
     }
   }
@@ -289,6 +292,7 @@ struct IntraNeighbours {
   const uint32_t *pl, *pu, *pur, *pul;       // progress counters of the left / upper / upper-right / upper-left CTU (same plane)
   bool nb_left, nb_up, nb_ur, nb_ul;         // which of them exist (inside the picture, same tile)
   uint32_t il = 0xffu, iu = 0xffu, iur = 0xffu, iul = 1u;      // (IntraBorders: the neighbours' edge units that are intra units)
+  const uint8_t *ecol_left = nullptr;        // the left CTU's entry of the edge-column array (IB_EDGE_R), or null: its right column is read from the picture
 };
 __device__ __forceinline__ uint32_t lds_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int lds_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -383,7 +387,7 @@ __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNei
   // ---- the loads, all in flight together (both ends of the row piece are multiples of 4: block sizes, CTU sizes and picture widths are)
   const int iL = haveL + lane, iT = haveT + 4 * lane;
   uint32_t vL = 0, vT = 0, vC = 0;
-  if (iL < uptoL) vL = ld_l2_u8(plane + (size_t)(cy * S + iL) * gp + cx * S - 1);
+  if (iL < uptoL) vL = (b.ecol_left && ((b.il >> ((iL << sh) >> 3)) & 1u)) ? ld_l2_u8(b.ecol_left + iL) : ld_l2_u8(plane + (size_t)(cy * S + iL) * gp + cx * S - 1);
   if (iT < uptoT) vT = ld_l2_u32(plane + (size_t)(cy * S - 1) * gp + cx * S + iT);
   if (doC && lane == 0) vC = ld_l2_u8(plane + (size_t)(cy * S - 1) * gp + cx * S - 1);
   if (iL < uptoL) pic[(iL + 1) * lp + 15] = (uint8_t)vL;
@@ -672,7 +676,8 @@ enum { IB_FILT = 1,          // the filtered reference samples are used (8.4.4.2
        IB_BORDER = 2,        // the block touches the CTU's left or upper border (the neighbouring CTUs' samples may have to be waited for)
        IB_PUBLISH = 4,       // progress `zu` is worth publishing before this block (a neighbour may be waiting for it)
        IB_LEVELS = 8, IB_TSKIP = 16,        // decoder: the block has levels; transform_skip_flag
-       IB_EDGE = 32 };       // the block holds samples of the CTU's right column or bottom row -- the only ones another workgroup ever reads: they are stored write-through as soon as the block is done, everything else goes to the picture with the CTU's final copy
+       IB_EDGE_R = 64,       // the block holds samples of the CTU's right column: they also go, one byte per row, to the CTU's entry of the edge-column array -- the right neighbour reads its left border there in ONE transaction instead of one per picture line
+       IB_EDGE = 32 };       // the block holds samples of the CTU's bottom row (encoder; decoder: or right column) -- the only ones another workgroup ever reads: they are stored write-through as soon as the block is done, everything else goes to the picture with the CTU's final copy
 __device__ __forceinline__ IntraBlk wave_uniform(const IntraBlk *p)
 {
   const uint4 u = *(const uint4 *)p;

@@ -545,8 +545,9 @@ __device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveSc
   if (active) {
     const uint32_t o = (uint32_t)pred[0] | ((uint32_t)pred[1] << 8) | ((uint32_t)pred[2] << 16) | ((uint32_t)pred[3] << 24);
     *(uint32_t *)&s.pic[(ry + c + 1) * DI_P + 16 + rx + 4 * g] = o;
-    // write-through, and only where a neighbouring CTU's workgroup will read (IB_EDGE); the rest of the CTU goes out in full lines at the end (k_dec_intra)
-    if (d.flags & IB_EDGE) st_wt_u32(gdst + (size_t)(ry + c) * gp + rx + 4 * g, o);
+    // write-through, and only what a neighbouring CTU's workgroup will read -- the CTU's last row (IB_EDGE: the block ends on it) and its last column
+    // (below) --; the rest of the CTU goes out in full lines at the end (k_dec_intra)
+    if ((d.flags & IB_EDGE) && c == N - 1) st_wt_u32(gdst + (size_t)(ry + c) * gp + rx + 4 * g, o);
     if ((d.flags & IB_EDGE_R) && g == (N >> 2) - 1) st_wt_u8(ecol + ry + c, o >> 24);      // the block's last column, one byte per row, for the right neighbour's left border
   }
   wave_sync();
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
     d.rx = (uint8_t)rx; d.ry = (uint8_t)ry; d.lo = (uint8_t)lo; d.hi = (uint8_t)hi; d.mode = t.mode; d.l2 = t.log2;
     d.flags = (uint8_t)((intra_filter_needed(N, c ? 1 : 0, t.mode) ? IB_FILT : 0) | ((rx == 0 || ry == 0) ? IB_BORDER : 0) |
                         (kv_intra_milestone(zu) > kv_intra_milestone(zprev) ? IB_PUBLISH : 0) | (t.count ? IB_LEVELS : 0) | ((t.flags & TU_TSKIP) ? IB_TSKIP : 0) |
-                        ((rx + N >= S || ry + N >= S) ? IB_EDGE : 0) | ((rx + N >= S) ? IB_EDGE_R : 0));
+                        ((ry + N >= S) ? IB_EDGE : 0) | ((rx + N >= S) ? IB_EDGE_R : 0));
     d.xf = (uint8_t)((t.log2 == 2 && (t.flags & TU_DST)) ? XF16_DST4 : (t.log2 - 1) & 3);
     d.angle = (int16_t)kIntraAngle[t.mode]; d.inv = (int16_t)kInvAngle[t.mode];
     d.zu = (uint16_t)zu; d.next = 0;

@@ -947,8 +947,9 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
   if (active) {
     const uint32_t o = (uint32_t)pred[0] | ((uint32_t)pred[1] << 8) | ((uint32_t)pred[2] << 16) | ((uint32_t)pred[3] << 24);
     *(uint32_t *)&s.pic[(ry + c + 1) * P + 16 + rx + 4 * g] = o;
-    // write-through, and only where a neighbouring CTU's workgroup will read (IB_EDGE): the rest of the CTU goes out in full lines at the end
-    if (d.flags & IB_EDGE) st_wt_u32(gdst + (size_t)(ry + c) * gp + rx + 4 * g, o);
+    // write-through, and only what a neighbouring CTU's workgroup will read -- the CTU's LAST ROW (IB_EDGE: the block ends on it) and, below, its last
+    // column --: the rest of the CTU goes out in full lines at the end
+    if ((d.flags & IB_EDGE) && c == N - 1) st_wt_u32(gdst + (size_t)(ry + c) * gp + rx + 4 * g, o);
     if ((d.flags & IB_EDGE_R) && g == (N >> 2) - 1) st_wt_u8(ecol + ry + c, o >> 24);      // the block's last column, one byte per row
   }
   wave_sync();

@@ -677,7 +677,7 @@ enum { IB_FILT = 1,          // the filtered reference samples are used (8.4.4.2
        IB_PUBLISH = 4,       // progress `zu` is worth publishing before this block (a neighbour may be waiting for it)
        IB_LEVELS = 8, IB_TSKIP = 16,        // decoder: the block has levels; transform_skip_flag
        IB_EDGE_R = 64,       // the block holds samples of the CTU's right column: they also go, one byte per row, to the CTU's entry of the edge-column array -- the right neighbour reads its left border there in ONE transaction instead of one per picture line
-       IB_EDGE = 32 };       // the block holds samples of the CTU's bottom row (encoder; decoder: or right column) -- the only ones another workgroup ever reads: they are stored write-through as soon as the block is done, everything else goes to the picture with the CTU's final copy
+       IB_EDGE = 32 };       // the block ends on the CTU's bottom row: that row is stored write-through (the CTUs below read it, and the corner) -- the only ones another workgroup ever reads: they are stored write-through as soon as the block is done, everything else goes to the picture with the CTU's final copy
 __device__ __forceinline__ IntraBlk wave_uniform(const IntraBlk *p)
 {
   const uint4 u = *(const uint4 *)p;

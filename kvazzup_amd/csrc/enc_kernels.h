@@ -18,10 +18,8 @@ void launch_deblock_v(const EncFrame &f, hipStream_t st);   // vertical edges of
 void launch_deblock_h(const EncFrame &f, hipStream_t st, int part = 0);   // part: 0 all horizontal edges of the band, 1 the inner ones, 2 its two boundary edges
 void launch_tokenize(const EncFrame &f, hipStream_t st);    // k_tokenize: bins of every CTU into its slot, pieces in completion order
 void launch_tok_compact(const EncFrame &f, hipStream_t st); // k_tok_compact: coding order restored, dense copy to host-mapped memory
-// rate control v2 (rc_kernels.hip): device-side state and the two kernels around the groups of CTU rows of a P picture
-struct RcState { uint32_t ratio_q8, ratio_valid, cost_sofar, arrived; int32_t off; uint32_t cost[8], cost_valid[8]; };
-void launch_rc_begin(RcState *rc, uint32_t bits3, int slot3, int have3, hipStream_t st);
-void launch_rc_band(const EncFrame &f, RcState *rc, long long T, int rows_total, int r2, int slot, hipStream_t st);   // f.row0 / f.nrows: the group just reconstructed; r2: end of the next one
+// rate control v2 (rc_kernels.hip; the groups of CTU rows themselves: k_inter_recon's RC form, EncFrame::rc)
+void launch_rc_begin(RcState *rc, uint32_t bits3, int slot3, int have3, hipStream_t st);      // before a P picture's k_inter_recon (EncFrame::rc)
 // k_cabac_rows (cabac_kernels.hip): the arithmetic coder proper on the GPU, one wave per substream
 struct CabacRowsArgs {
   const uint16_t *tok; const int32_t *count; const uint32_t *off;   // dense tokens (device): CTU i has count[i] tokens at tok + off[i]

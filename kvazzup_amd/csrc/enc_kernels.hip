@@ -253,6 +253,7 @@ struct InterLds {
   uint32_t nz[2];
   int mv[4][2];
   int intra_q[4];                          // intra-in-P: the 16x16 quarter is an intra unit
+  int rc_qp, rc_last; uint32_t rc_part[4]; // rate control v2 inside the launch (k_inter_recon<.., RC>)
   alignas(16) int8_t M8[2][32 * 32];       // the 32-point matrix and its transpose as int8: MFMA B operands
   int rowsum[2][32];                       // sum over m of M8[.][j][m]
 };
@@ -287,8 +288,12 @@ __device__ __forceinline__ void adjust_block_lds(int16_t *lev, const int16_t *au
 // decoder: dequantised levels, transposed), NTU * XF<L2, OPL>::LANES == 256.  Encoder: levels go to `coef`
 // for blocks that have any, *nz gets one bit per block.  Ends with the residual added into s.px.
 //   px_index(tu, y, x) -> index of sample (x, y) of block tu in s.px;  coef_at(tu, y, x) -> its level in the plane
-template <bool DEC, int L2, int OPL, class PX, class CI>
-__device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *nz, PX px_index, CI coef_at, int tid, int adj = 0)
+//   RC (rate control v2 inside the launch): qp_late() is called between the forward transform and the quantiser -- it waits for the QP if it has to --
+//   and the cost of the levels (3 + 2 floor(log2 |level|) each) is added to `cost`
+struct NoLateQp { __device__ int operator()() const { return 0; } };
+__device__ __forceinline__ uint32_t rc_level_cost(int lv) { return lv ? 3u + 2u * (uint32_t)(31 - __builtin_clz((unsigned)iabs(lv))) : 0u; }
+template <bool DEC, int L2, int OPL, bool RC = false, class PX, class CI, class QL = NoLateQp>
+__device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *nz, PX px_index, CI coef_at, int tid, int adj = 0, QL qp_late = QL(), uint32_t *cost = nullptr)
 {
   constexpr int N = 1 << L2, G = XF<L2, OPL>::G, LPT = XF<L2, OPL>::LANES;
   const int tu = tid / LPT, l = tid % LPT, rp = l / G, g = l % G;
@@ -299,6 +304,7 @@ __device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *n
     __syncthreads();
     int acc[2][OPL], lv[2][OPL];
     xf_sums<L2, OPL>(B, Mf, rp, g, acc);
+    if constexpr (RC) qp = qp_late();
     const int shift = L2 + 6, rnd = 1 << (shift - 1);
     bool any = false;
     if (adj) {
@@ -329,6 +335,7 @@ __device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *n
       for (int e = 0; e < 2; e++) {
         if (!adj) { int c = clip3(-32768, 32767, (acc[e][o] + rnd) >> shift); lv[e][o] = quant_level(c, qp, L2, 0); }
         any |= lv[e][o] != 0;
+        if constexpr (RC) *cost += rc_level_cost(lv[e][o]);
         A[(2 * rp + e) * N + g * OPL + o] = (int16_t)dequant_coef(lv[e][o], qp, L2);        // transposed: [column][row]
       }
     if (any) atomicOr(nz, 1u << tu);
@@ -357,8 +364,8 @@ __device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *n
 }
 
 // The 32x32 luma block of a 32x32 CU: same contract as inter_transform<DEC, 5, .>
-template <bool DEC>
-__device__ __forceinline__ void inter_transform_32(InterLds &s, int qp, uint32_t *nz, int16_t *coef, int cw, int tid, int adj = 0)
+template <bool DEC, bool RC = false, class QL = NoLateQp>
+__device__ __forceinline__ void inter_transform_32(InterLds &s, int qp, uint32_t *nz, int16_t *coef, int cw, int tid, int adj = 0, QL qp_late = QL(), uint32_t *cost = nullptr)
 {
   const int wave = tid >> 6, lane = tid & 63;
   const int j = (wave & 1) * 16 + (lane & 15), i0 = (wave >> 1) * 16 + (lane >> 4) * 4;   // result column, first of four result rows
@@ -369,6 +376,7 @@ __device__ __forceinline__ void inter_transform_32(InterLds &s, int qp, uint32_t
     {
       int acc[4];
       mfma_tile_sums(s.B, s.M8[0], s.rowsum[0], wave, lane, acc);                          // forward columns: coefficient (row j, columns i0 ..)
+      if constexpr (RC) qp = qp_late();
       bool any = false;
       if (adj) {                                                                           // rdoq / signhide: see inter_transform
         __syncthreads();
@@ -390,6 +398,7 @@ __device__ __forceinline__ void inter_transform_32(InterLds &s, int qp, uint32_t
       for (int r = 0; r < 4; r++) {
         if (!adj) { const int c = clip3(-32768, 32767, (acc[r] + 1024) >> 11); lv[r] = quant_level(c, qp, 5, 0); }
         any |= lv[r] != 0;
+        if constexpr (RC) *cost += rc_level_cost(lv[r]);
         s.A[(i0 + r) * 32 + j] = (int16_t)dequant_coef(lv[r], qp, 5);                      // transposed: [column][row]
       }
       if (any) atomicOr(nz, 1u);
@@ -412,23 +421,95 @@ __device__ __forceinline__ void inter_transform_32(InterLds &s, int qp, uint32_t
   __syncthreads();
 }
 
+// Rate control v2, the tail of a workgroup of k_inter_recon<.., RC>: its level cost joins its group's (one atomic: arrivals << 40 | cost), and the workgroup
+// that completes the group decides for the next one (statement: rc_band_decide() in oracle/hevc_enc.c) -- prices the rows done against their share of the
+// picture's target, moves the running QP step and publishes it in RcState::decided: bits 0..3 the number of groups decided, bits 4 + 3 (g - 1) .. the step
+// of group g, biased by 3.  The per-CTU QP array is left alone while workgroups may still read it: the workgroup that completes the LAST group applies
+// every group's step to it (for k_qp_first / k_qp_chain, deblocking and k_intra_recon) and files the picture's cost for k_rc_begin of a later picture.
+__device__ __forceinline__ int rc_word_step(uint32_t word, int grp) { return grp > 0 ? (int)((word >> (4 + 3 * (grp - 1))) & 7u) - 3 : 0; }
+__device__ __forceinline__ void rc_group_done(const EncFrame &f, InterLds &s, int grp, uint32_t cost, int tid)
+{
+  RcState *rc = f.rc;
+  const int rows = f.ch >> 6, wc = f.cw >> 6, nb = f.rc_nb;
+  const int r0 = (grp * rows) / nb, r1 = ((grp + 1) * rows) / nb;
+  cost = wave_sum_u32(cost);
+  if ((tid & 63) == 0) s.rc_part[tid >> 6] = cost;
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned long long mine = (unsigned long long)s.rc_part[0] + s.rc_part[1] + s.rc_part[2] + s.rc_part[3];
+    const unsigned long long old = atomicAdd(&rc->acc[grp * KVZ_RC_ACC_STRIDE], (1ull << 40) | mine);
+    const bool last = (old >> 40) == (unsigned long long)((r1 - r0) * 2 * (f.cw >> 5)) - 1ull;
+    uint32_t word = 0;
+    if (last) {
+      // (cost_sofar and the word were left by the group before, whose decision this workgroup has waited for)
+      const uint32_t total = ld_l2_u32(&rc->cost_sofar) + (uint32_t)((old & ((1ull << 40) - 1)) + mine);
+      word = ld_l2_u32(&rc->decided);
+      if (grp + 1 < nb) {
+        int off = rc_word_step(word, grp);
+        if (ld_l2_u32(&rc->ratio_valid)) {
+          const unsigned long long est = ((unsigned long long)total * ld_l2_u32(&rc->ratio_q8)) >> 8, tgt = ((unsigned long long)f.rc_target * (unsigned long long)r1) / (unsigned long long)rows;
+          if (est * 8 > tgt * 9) off++; else if (est * 8 < tgt * 7) off--;
+          off = clip3(-3, 3, off);
+        }
+        st_wt_u32(&rc->cost_sofar, total);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_wt_u32(&rc->decided, (word & ~15u) | (uint32_t)(grp + 1) | ((uint32_t)(off + 3) << (4 + 3 * grp)));
+      } else { rc->cost[f.rc_slot] = total; rc->cost_valid[f.rc_slot] = 1; }
+    }
+    s.rc_last = (last && grp + 1 == nb) ? 1 : 0; s.rc_qp = (int)word;
+  }
+  __syncthreads();
+  if (!s.rc_last) return;
+  // every other workgroup of the launch is done: the steps go into the QP array
+  const uint32_t word = (uint32_t)s.rc_qp;
+  int8_t *qt = const_cast<int8_t *>(f.ctu_qt);
+  for (int g = 1; g < nb; g++) {
+    const int off = rc_word_step(word, g);
+    if (off) for (int i = ((g * rows) / nb) * wc + tid; i < (((g + 1) * rows) / nb) * wc; i += 256) qt[i] = (int8_t)clip3(0, 51, (int)qt[i] + off);
+  }
+}
+
 // DEC = false: encoder (residual from the source picture, levels written out).
 // DEC = true: decoder (levels and cbf given, prediction + residual only).
 // ADJ: rdoq / signhide -- a kernel of its own: the plain form fits eight workgroups per compute unit in 64 registers, and with the level adjustment compiled
 // in it no longer did (159 registers spilled, 14 MB of scratch writes per 1080p launch, 23 -> 28 us -- found in the PMC pass, not in a test).
-template <bool DEC, bool FRAC, bool ADJ = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || ADJ) ? 5 : 8))) void k_inter_recon(EncFrame f)
+// RC (encoder, rate control v2): the CTU rows in f.rc_nb groups, the QP of a group decided by the last workgroup of the group before it.  Workgroups are
+// dispatched in the order of their linear index (rows top to bottom here: no XCD permutation), so every workgroup of a group is resident or done when one of
+// the next group starts to wait -- the wait cannot starve what it waits for (the intra chains' argument).
+template <bool DEC, bool FRAC, bool ADJ = false, bool RC = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || ADJ || RC) ? 5 : 8))) void k_inter_recon(EncFrame f)
 {
   __shared__ InterLds s;
   InterFracLds *fr = nullptr;
   if constexpr (FRAC) { __shared__ InterFracLds fr_s; fr = &fr_s; }
   const int tid = threadIdx.x;
-  int bx_, by_; xcd_block_2d(bx_, by_);
+  int bx_, by_;
+  if (RC) { bx_ = (int)blockIdx.x; by_ = (int)blockIdx.y; } else xcd_block_2d(bx_, by_);
   const int x0 = bx_ * 32, y0 = by_ * 32 + f.row0 * 64;
   const int bi0 = b8idx(f, x0, y0);
   const bool split = f.cu_log2[bi0] != 5;                              // (four 16x16 units: with intra-in-P a quarter may also be an intra unit, 16x16 or four 8x8)
   const int cw2 = f.cw >> 1, ch2 = f.ch >> 1;
-  const int qp = ctu_quant_qp(f, x0, y0), qpc = kChromaQp[qp];       // the 32x32 block lies inside one CTU
+  int grp = 0;                                                         // RC: the group of CTU rows this block belongs to: rows [g * rows / nb, (g + 1) * rows / nb)
+  if (RC) { const int rows = f.ch >> 6; while (grp + 1 < f.rc_nb && (y0 >> 6) >= ((grp + 1) * rows) / f.rc_nb) grp++; }
+  int qp = ctu_quant_qp(f, x0, y0), qpc = kChromaQp[qp];             // the 32x32 block lies inside one CTU (RC, groups behind the first: before the group's step)
+  uint32_t rc_cost = 0;
+  // RC: called by the luma transform in front of its quantiser -- the CTU's QP once the group before this one has decided (rc_group_done): the word
+  // that counts the decided groups carries their QP steps as well, so the wait costs one trip to memory
+  auto qp_late = [&]() -> int {
+    if (RC && grp > 0) {
+      if (tid == 0) {
+        uint32_t spins = 0, v;
+        while (((v = ld_l2_u32(&f.rc->decided)) & 15u) < (uint32_t)grp) {
+          __builtin_amdgcn_s_sleep(24);                                  // (~0.6 us: hundreds of workgroups poll this word, and the polls travel to memory)
+          if (++spins > (1u << 22)) { atomicOr(f.err, 1u); break; }      // bounded spin: never hang the GPU
+        }
+        s.rc_qp = clip3(0, 51, qp + rc_word_step(v, grp));
+      }
+      __syncthreads();
+      qp = s.rc_qp; qpc = kChromaQp[qp];
+    }
+    return qp;
+  };
   const int adj = (DEC || !ADJ) ? 0 : ((f.rdoq ? 1 : 0) | (f.signhide ? 2 : 0));    // level adjustment behind the quantiser (hevc_core.h adjust_group)
   // Decoder: most blocks of an inter picture carry no residual at all -- they skip the matrices, the transform stages and all
   // but two barriers (prediction straight to the picture).  `coded` is uniform over the workgroup.
@@ -506,21 +587,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || AD
       *(uint2 *)&A[ty * n + tx] = make_uint2(pack_i16(r[0], r[1]), pack_i16(r[2], r[3]));
     }
   }
+  // ---- chroma: reference windows of the eight 8x8 sub-blocks (plane x quadrant) -> LDS; mv in 1/8 samples
+  auto chroma_windows = [&]() {
+    for (int i = tid; i < 8 * 121; i += 256) {
+      const int w8 = i / 121, r = i - w8 * 121, wy = r / 11, wx = r - wy * 11, pl = w8 >> 2, sub = w8 & 3, k = split ? sub : 0;
+      const int xi = (x0 >> 1) + (sub & 1) * 8 + (s.mv[k][0] >> 3) + wx - 1, yi = (y0 >> 1) + (sub >> 1) * 8 + (s.mv[k][1] >> 3) + wy - 1;
+      s.win[pl][sub][wy * 12 + wx] = f.ref[1 + pl][(size_t)clip3(0, ch2 - 1, yi) * cw2 + clip3(0, cw2 - 1, xi)];
+    }
+  };
+  // RC: everything chroma reads from memory is fetched in front of the luma transform, where a workgroup may wait for its QP -- behind the wait it is on the
+  // path from one group's decision to the next
+  uint32_t src_c = 0;
+  if (RC) {
+    chroma_windows();
+    src_c = *(const uint16_t *)&f.src[1 + (tid >> 7)][(size_t)((y0 >> 1) + ((tid >> 3) & 15)) * cw2 + (x0 >> 1) + (tid & 7) * 2];
+  }
   if (coded) {
     __syncthreads();
     auto px16 = [](int tu, int y, int x) { return ((tu >> 1) * 16 + y) * 32 + (tu & 1) * 16 + x; };
     const int cw = f.cw; int16_t *base = f.coef[0] + (size_t)y0 * cw + x0;
     auto ci16 = [=](int tu, int y, int x) { return base + (size_t)((tu >> 1) * 16 + y) * cw + (tu & 1) * 16 + x; };
-    if (split) inter_transform<DEC, 4, 2>(s, qp, &s.nz[0], px16, ci16, tid, adj);
-    else inter_transform_32<DEC>(s, qp, &s.nz[0], base, cw, tid, adj);
+    if (split) inter_transform<DEC, 4, 2, RC>(s, qp, &s.nz[0], px16, ci16, tid, adj, qp_late, &rc_cost);
+    else inter_transform_32<DEC, RC>(s, qp, &s.nz[0], base, cw, tid, adj, qp_late, &rc_cost);
     *(uint32_t *)&f.rec[0][(size_t)(y0 + (tid >> 3)) * f.cw + x0 + (tid & 7) * 4] = *(const uint32_t *)&s.px[(tid >> 3) * 32 + (tid & 7) * 4];
   }
-  // ---- chroma: reference windows of the eight 8x8 sub-blocks (plane x quadrant) -> LDS; mv in 1/8 samples
-  for (int i = tid; i < 8 * 121; i += 256) {
-    const int w8 = i / 121, r = i - w8 * 121, wy = r / 11, wx = r - wy * 11, pl = w8 >> 2, sub = w8 & 3, k = split ? sub : 0;
-    const int xi = (x0 >> 1) + (sub & 1) * 8 + (s.mv[k][0] >> 3) + wx - 1, yi = (y0 >> 1) + (sub >> 1) * 8 + (s.mv[k][1] >> 3) + wy - 1;
-    s.win[pl][sub][wy * 12 + wx] = f.ref[1 + pl][(size_t)clip3(0, ch2 - 1, yi) * cw2 + clip3(0, cw2 - 1, xi)];
-  }
+  if (!RC) chroma_windows();
   __syncthreads();                           // (also: every thread has copied its luma samples out of s.px)
   {
     // two samples per thread; the separable 4-tap form with the {0, 64, 0, 0} filter at fraction 0 covers every case of
@@ -555,7 +646,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || AD
         A[(tx + 1) * cn + ty] = (int16_t)dequant_coef((int16_t)(l2v >> 16), qpc, cl2);
       }
     } else {
-      const uint32_t s2 = *(const uint16_t *)&f.src[1 + pl][g];
+      const uint32_t s2 = RC ? src_c : *(const uint16_t *)&f.src[1 + pl][g];
       *(uint32_t *)&A[ty * cn + tx] = s.intra_q[sub] ? 0u : pack_i16((int)(s2 & 255) - p0, (int)(s2 >> 8) - p1);
     }
   }
@@ -568,8 +659,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || AD
     int16_t *cb = f.coef[1] + base, *cr = f.coef[2] + base;
     auto ci1 = [=](int tu, int y, int x) { return (tu ? cr : cb) + (size_t)y * cw2 + x; };
     auto ci4 = [=](int tu, int y, int x) { return ((tu >> 2) ? cr : cb) + (size_t)(((tu >> 1) & 1) * 8 + y) * cw2 + (tu & 1) * 8 + x; };
-    if (split) inter_transform<DEC, 3, 1>(s, qpc, &s.nz[1], px4, ci4, tid, adj);
-    else inter_transform<DEC, 4, 1>(s, qpc, &s.nz[1], px1, ci1, tid, adj);
+    auto qpc_known = [&]() -> int { return qpc; };
+    if (split) inter_transform<DEC, 3, 1, RC>(s, qpc, &s.nz[1], px4, ci4, tid, adj, qpc_known, &rc_cost);
+    else inter_transform<DEC, 4, 1, RC>(s, qpc, &s.nz[1], px1, ci1, tid, adj, qpc_known, &rc_cost);
   }
   if (tid < 128) {
     const int pl = tid >> 6, y = (tid >> 2) & 15, x = (tid & 3) * 4;
@@ -582,6 +674,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || AD
     else cbf |= (int)(s.nz[1] & 1) << 1 | (int)((s.nz[1] >> 1) & 1) << 2;
     f.cu_cbf[b8idx(f, x0 + bx * 8, y0 + by * 8)] = (uint8_t)cbf;
   }
+  if constexpr (RC) rc_group_done(f, s, grp, rc_cost, tid);
 }
 
 __global__ __launch_bounds__(256) void k_inter_signal(EncFrame f)
@@ -1943,7 +2036,13 @@ void launch_me(const EncFrame &f, hipStream_t st)
 void launch_inter_recon(const EncFrame &f, hipStream_t st)
 {
   const dim3 grid(f.cw / 32, band_rows(f) * 2);
-  if (f.rdoq || f.signhide) {
+  if (f.rc) {                                  // rate control v2: the groups of CTU rows inside the one launch
+    const int k = ((f.rdoq || f.signhide) ? 2 : 0) | (f.subme > 0 ? 1 : 0);
+    if (k == 3) hipLaunchKernelGGL((k_inter_recon<false, true, true, true>), grid, dim3(256), 0, st, f);
+    else if (k == 2) hipLaunchKernelGGL((k_inter_recon<false, false, true, true>), grid, dim3(256), 0, st, f);
+    else if (k == 1) hipLaunchKernelGGL((k_inter_recon<false, true, false, true>), grid, dim3(256), 0, st, f);
+    else hipLaunchKernelGGL((k_inter_recon<false, false, false, true>), grid, dim3(256), 0, st, f);
+  } else if (f.rdoq || f.signhide) {
     if (f.subme > 0) hipLaunchKernelGGL((k_inter_recon<false, true, true>), grid, dim3(256), 0, st, f);
     else hipLaunchKernelGGL((k_inter_recon<false, false, true>), grid, dim3(256), 0, st, f);
   } else if (f.subme > 0) hipLaunchKernelGGL((k_inter_recon<false, true>), grid, dim3(256), 0, st, f);

@@ -26,6 +26,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   EncoderConfig cfg = cfg_in;
   if (cfg.vaq > 0) cfg.qp_in_cu = 1;                       // the deltas travel as cu_qp_delta
   if (cfg.bitrate <= 0 || cfg.band_rows > 0) cfg.rc_bands = 0;
+  if (cfg.rc_bands > 8) cfg.rc_bands = 8;                  // (RcState::acc)
   if ((cfg.slices == 1 && !cfg.wpp) || (cfg.slices == 2 && cfg.tile_rows * cfg.tile_cols < 2) || (cfg.slices == 1 && cfg.tile_cols > 1) || cfg.slices < 0 || cfg.slices > 2) cfg.slices = 0;
   if (cfg.band_rows > 0) cfg.intra_in_p = 0;               // (intra-in-P runs behind the whole picture's inter reconstruction: not in band mode, where a picture is coded in parts by several instances)
   if (cfg.rc_bands > 0) cfg.qp_in_cu = 1;                  // ... and so do the steps of rate control v2
@@ -518,15 +519,11 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     if (cfg_.intra_in_p) timed(K_INTRA_ANALYSE, stream_, [&] { launch_intra_analyse(f, stream_); });
     if (cfg_.subme > 0) timed(K_SUBPEL, stream_, [&] { launch_subpel(f, stream_); });
     if (rc_state_) {
-      // rate control v2: the CTU rows in groups, the next group's QP decided on the device from the levels of the groups before
-      const int nb = cfg_.rc_bands < rows_ ? cfg_.rc_bands : rows_;
-      const long long T = ((long long)cfg_.bitrate * cfg_.fps_den) / (cfg_.fps_num > 0 ? cfg_.fps_num : 1);
-      for (int b = 0; b < nb; b++) {
-        EncFrame fb = f;
-        fb.row0 = (b * rows_) / nb; fb.nrows = ((b + 1) * rows_) / nb - fb.row0;
-        timed(K_INTER_RECON, stream_, [&] { launch_inter_recon(fb, stream_); });
-        launch_rc_band(fb, rc_state_, T, rows_, b + 1 < nb ? ((b + 2) * rows_) / nb : fb.row0 + fb.nrows, frame_idx_ & 7, stream_);
-      }
+      // rate control v2: the CTU rows in groups inside the one launch, the next group's QP decided on the device from the levels of the groups before
+      EncFrame fb = f;
+      fb.rc = rc_state_; fb.rc_nb = cfg_.rc_bands < rows_ ? cfg_.rc_bands : rows_; fb.rc_slot = frame_idx_ & 7;
+      fb.rc_target = ((long long)cfg_.bitrate * cfg_.fps_den) / (cfg_.fps_num > 0 ? cfg_.fps_num : 1);
+      timed(K_INTER_RECON, stream_, [&] { launch_inter_recon(fb, stream_); });
     } else
     timed(K_INTER_RECON, stream_, [&] { launch_inter_recon(f, stream_); });
     // ... and are reconstructed behind every inter unit (their reference samples may lie in inter units anywhere around them)

@@ -35,6 +35,19 @@ struct SaoParams {
   int8_t offset[3][4];
 };
 
+
+// rate control v2, device-side state (rc_kernels.hip; statement of record: rc_band_decide() / rc_picture_start() in oracle/hevc_enc.c).
+// acc[g]: arrivals << 40 | level cost of group g's workgroups (ONE atomic per workgroup: the one that completes the count has the group's cost);
+// decided: number of groups whose QP is final (bits 0..3; group 0 from the start) and the QP steps of groups 1.. (3 bits each, biased by 3) -- what a
+// waiting workgroup needs in the one word it polls; cost_sofar: the levels priced so far.
+// (`decided` is polled by every waiting workgroup and acc[g] takes an atomic from every workgroup of group g: each on a 128-byte line of its own --
+// with all of them in one line the polls queued in front of the atomics and the launch took 130 us instead of 90.)
+#define KVZ_RC_ACC_STRIDE 16
+struct RcState {
+  uint32_t ratio_q8, ratio_valid, cost_sofar; uint32_t cost[8], cost_valid[8];
+  alignas(128) uint32_t decided;
+  alignas(128) unsigned long long acc[8 * KVZ_RC_ACC_STRIDE];
+};
 struct EncFrame {
   int cw, ch, b8w, b8h;
   int qp, qpc, lambda_q4, range;
@@ -80,6 +93,9 @@ struct EncFrame {
   uint32_t *sync;               // [CTU][plane] progress counters (intra reconstruction wavefront: finished 8x8 units of the CTU)
   uint32_t *err;                // device-side error flags
   const uint32_t *intra_order;  // CTU (raster index) handled by the k-th workgroup triple of k_intra_recon: anti-diagonal wavefront order
+  // rate control v2 (NULL = off): k_inter_recon reconstructs the CTU rows in rc_nb groups inside ONE launch -- a group's workgroups price their levels, the last
+  // of them decides the next group's QP step, and that group's workgroups, prediction and forward transform done, wait for the decision in front of the quantiser
+  RcState *rc; long long rc_target; int rc_nb, rc_slot;      // rc_target: bits for the picture; rc_slot: where the picture's level cost is filed (picture index & 7)
   unsigned long long *trace;    // KVAZZUP_AMD_INTRA_TRACE: per (CTU, plane) 8 words {start, first block, end, time in border waits, blocks, stores, publishes, number of blocks} of k_intra_recon, 100 MHz ticks; else NULL
 };
 

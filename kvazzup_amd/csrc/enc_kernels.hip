@@ -740,7 +740,9 @@ struct AnalyseLds {
   int dc[21];
   uint32_t cost[21][35];
   uint32_t bestc[21]; int bestm[21];
+  int last;                                // intra-in-P: this workgroup is the last of its region's to arrive
 };
+__device__ __forceinline__ int an_tile_of(int b) { return b < 16 ? (b >> 3) * 2 + ((b >> 1) & 1) : b - 16; }      // the 16x16 quarter block b (0..19) lies in
 __device__ __forceinline__ int an_roff(int b) { return b < 16 ? b * 36 : (b < 20 ? 16 * 36 + (b - 16) * 68 : 16 * 36 + 4 * 68); }
 
 template <int L2>
@@ -845,8 +847,13 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
   // zero what k_intra_recon<.., true> starts from: the progress counters of every CTU and the ticket counter behind them
   const uint32_t ncand = PP ? f.me_cand[0] : 1u;
   if (PP) for (uint32_t i = blockIdx.x * T + tid; i < 3u * (uint32_t)(f.cw >> 6) * (uint32_t)(f.ch >> 6) + 1u; i += gridDim.x * T) f.sync[i] = 0;      // (the word behind the ticket counter says whether the picture has an intra unit at all: set below, zeroed by k_deblock_tile)
-  for (uint32_t item = PP ? blockIdx.x : 0u; item < ncand; item += PP ? gridDim.x : 1u) {
-  if (PP) { __syncthreads(); const uint32_t r = f.me_cand[1 + item]; bx_ = (int)(r % (uint32_t)(f.cw >> 5)); by_ = (int)(r / (uint32_t)(f.cw >> 5)); }      // (the barrier: LDS of the last block is free)
+  // PP: a work item is one QUARTER of a listed block (a quarter's 70 (size, mode) prices over sixteen waves are a third of the latency of the block's 280:
+  // 43 -> 16 us for the launch); the quarters' workgroups leave their best prices in f.ip_scratch, and the last of a block's to arrive takes the decision
+  for (uint32_t item = PP ? blockIdx.x : 0u; item < (PP ? 4u * ncand : 1u); item += PP ? gridDim.x : 1u) {
+  const int mytile = PP ? (int)(item & 3u) : -1;
+  const uint32_t ci = PP ? item >> 2 : 0u;
+  auto mine = [&](int b) { return !PP || an_tile_of(b) == mytile; };
+  if (PP) { __syncthreads(); const uint32_t r = f.me_cand[1 + ci]; bx_ = (int)(r % (uint32_t)(f.cw >> 5)); by_ = (int)(r / (uint32_t)(f.cw >> 5)); }      // (the barrier: LDS of the last item is free)
   const int X0 = bx_ * 32, Y0 = by_ * 32 + f.row0 * 64;
   uint32_t icost[4] = {0, 0, 0, 0}; bool cand[4] = {false, false, false, false};
   if (PP) {
@@ -854,6 +861,7 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
       icost[k] = f.me_cost16[((Y0 >> 4) + (k >> 1)) * (f.cw >> 4) + (X0 >> 4) + (k & 1)];
       cand[k] = icost[k] > (uint32_t)INTRA_P_GATE * (uint32_t)f.lambda_q4;
     }
+    if (!cand[mytile]) continue;                                // (only the quarters above the gate are priced)
   }
   const uint8_t *src = f.src[0];
   if (tid < 256) *(uint32_t *)&s.src[tid * 4] = *(const uint32_t *)&src[(size_t)(Y0 + (tid >> 3)) * f.cw + X0 + (tid & 7) * 4];
@@ -862,6 +870,7 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
   for (int e = tid; e < 16 * 33 + 4 * 65; e += T) {
     int b, i, l2;
     if (e < 16 * 33) { b = e / 33; i = e - b * 33; l2 = 3; } else { int r = e - 16 * 33; b = 16 + r / 65; i = r % 65; l2 = 4; }
+    if (!mine(b)) continue;
     const int n = 1 << l2, bi = b < 16 ? b : b - 16, nb = 32 >> l2;
     const int x0 = X0 + (bi % nb) * n, y0 = Y0 + (bi / nb) * n;
     const bool aL = avail64(f.cw, f.chp, x0, y0, x0 - 1, y0), aT = avail64(f.cw, f.chp, x0, y0, x0, y0 - 1);
@@ -880,6 +889,7 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
   for (int e = tid; e < 16 * 33 + 4 * 65; e += T) {
     int b, i, l2;
     if (e < 16 * 33) { b = e / 33; i = e - b * 33; l2 = 3; } else { int r = e - 16 * 33; b = 16 + r / 65; i = r % 65; l2 = 4; }
+    if (!mine(b)) continue;
     const int n = 1 << l2;
     const uint8_t *R = s.R[0] + an_roff(b);
     int fv = R[i];
@@ -890,7 +900,7 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
     }
     s.R[1][an_roff(b) + i] = (uint8_t)fv;
   }
-  if (tid < 20) {
+  if (tid < 20 && mine(tid)) {
     const int l2 = tid < 16 ? 3 : 4, n = 1 << l2;
     const uint8_t *R = s.R[0] + an_roff(tid);
     int a = n;
@@ -900,9 +910,9 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
   __syncthreads();
   // ---- cost of every (block, mode): 8x8 Hadamard sums, (sum + 2) >> 2 per 8x8 block (oracle/hevc_enc.c satd_block()), or SADs
   if (f.satd) {
-    for (int item = wave; item < 4 * 35 * 2; item += NW) {
+    for (int j = wave; j < (PP ? 35 * 2 : 4 * 35 * 2); j += NW) {
+      const int item = PP ? ((j >> 1) << 3) | (mytile << 1) | (j & 1) : j;
       const int kind = item & 1, tile = (item >> 1) & 3, mode = item >> 3;
-      if (PP && !cand[tile]) continue;                          // (intra-in-P: only the quarters above the gate are priced)
       uint32_t q[4];
       analyse_tile_satd(s, tile, kind, mode, lane, q);
       if (lane == 0) {
@@ -914,19 +924,20 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
       }
     }
   } else
-  for (int item = wave; item < 20 * 35; item += NW) {
-    const int b = item / 35, mode = item - b * 35;
-    if (PP && !cand[b < 16 ? (b >> 3) * 2 + ((b >> 1) & 1) : b - 16]) continue;
+  for (int j = wave; j < (PP ? 5 * 35 : 20 * 35); j += NW) {
+    int b = j / 35; const int mode = j - b * 35;
+    if (PP) b = b < 4 ? (mytile >> 1) * 8 + (mytile & 1) * 2 + (b >> 1) * 4 + (b & 1) : 16 + mytile;      // the quarter's four 8x8 blocks and its 16x16 block
     uint32_t c;
     if (b < 16) c = analyse_item<3>(s, b, (b & 3) * 8, (b >> 2) * 8, mode, lane);
     else c = analyse_item<4>(s, b, ((b - 16) & 1) * 16, ((b - 16) >> 1) * 16, mode, lane);
     if (lane == 0) s.cost[b][mode] = c;
   }
   __syncthreads();
-  if (tid < 20) {
+  if (tid < 20 && mine(tid)) {
     uint32_t bc = 0xffffffffu; int bm = 0;
     for (int m = 0; m < 35; m++) if (s.cost[tid][m] < bc) { bc = s.cost[tid][m]; bm = m; }
     s.bestc[tid] = bc; s.bestm[tid] = bm;
+    if (PP && cand[0] + cand[1] + cand[2] + cand[3] > 1) st_wt_u64(&f.ip_scratch[(size_t)ci * 20 + tid], (uint64_t)bc | ((uint64_t)bm << 32));      // for the block's other quarters
     const int l2 = tid < 16 ? 3 : 4, n = 1 << l2, bi = tid < 16 ? tid : tid - 16, nb = 32 >> l2;
     const int x0 = X0 + (bi % nb) * n, y0 = Y0 + (bi / nb) * n;
     const int bw = f.cw >> l2, ib = (y0 >> l2) * bw + (x0 >> l2);
@@ -934,6 +945,19 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
       if (l2 == 3) { f.im8[ib] = (uint8_t)bm; f.ic8[ib] = bc; }
       else { f.im16[ib] = (uint8_t)bm; f.ic16[ib] = bc; }
     }
+  }
+  if (PP && cand[0] + cand[1] + cand[2] + cand[3] > 1) {
+    // the block's other quarters above the gate are other workgroups': the last one to arrive has everybody's prices (write-through stores, drained
+    // before the count goes up; read past the caches) and decides -- nobody waits
+    if (tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+      const bool last = atomicAdd(&f.ip_arrive[ci], 1u) == (uint32_t)(cand[0] + cand[1] + cand[2] + cand[3]) - 1u;
+      if (last) f.ip_arrive[ci] = 0;                          // (for the next picture)
+      s.last = last ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s.last) continue;
+    if (tid < 20 && !mine(tid) && cand[an_tile_of(tid)]) { const uint64_t v = ld_l2_u64(&f.ip_scratch[(size_t)ci * 20 + tid]); s.bestc[tid] = (uint32_t)v; s.bestm[tid] = (int)(v >> 32); }
   }
   __syncthreads();
   // ---- bottom-up split decision for this 32x32 block: thread per 8x8 cell
@@ -2056,7 +2080,7 @@ void launch_inter_signal(const EncFrame &f, hipStream_t st)
 void launch_intra_analyse(const EncFrame &f, hipStream_t st)
 {
   if (f.is_intra) hipLaunchKernelGGL(k_intra_analyse<false>, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f);
-  else hipLaunchKernelGGL(k_intra_analyse<true>, dim3(128), dim3(1024), 0, st, f);       // intra-in-P, behind k_me: 128 workgroups share the candidate list
+  else hipLaunchKernelGGL(k_intra_analyse<true>, dim3(512), dim3(1024), 0, st, f);       // intra-in-P, behind k_me: 512 workgroups (two per compute unit) share the candidate list, a quarter of a listed block at a time
 }
 void launch_intra_recon(const EncFrame &f, hipStream_t st)
 {

@@ -162,7 +162,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   }
   HIP_OK(hipEventCreateWithFlags(&in_done_, hipEventDisableTiming));
   HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 2))); HIP_OK(hipMemset(sync_, 0, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 2)));       // one progress counter per CTU and colour plane, and the ticket counter of k_intra_recon's workgroups
-  if (cfg.intra_in_p) { const size_t n16 = (size_t)(cw_ / 16) * (ch_ / 16); HIP_OK(hipMalloc(&me_cost16_, sizeof(uint32_t) * (n16 + 1 + n16 / 4))); HIP_OK(hipMemset(me_cost16_, 0, sizeof(uint32_t) * (n16 + 1 + n16 / 4))); }      // k_me's inter cost per 16x16 block (intra-in-P)
+  if (cfg.intra_in_p) { const size_t n16 = (size_t)(cw_ / 16) * (ch_ / 16); HIP_OK(hipMalloc(&me_cost16_, sizeof(uint32_t) * (n16 + 2 + n16 / 4 + n16 / 4 + (n16 / 4) * 40))); HIP_OK(hipMemset(me_cost16_, 0, sizeof(uint32_t) * (n16 + 2 + n16 / 4 + n16 / 4 + (n16 / 4) * 40))); }      // k_me's inter cost per 16x16 block (intra-in-P)
   {
     // dispatch order of the intra reconstruction's workgroups: the CTUs of the rows this instance codes, by anti-diagonal cx + 2 cy
     const int wc = cw_ / 64, r0 = cfg.band_rows > 0 ? cfg.band_row0 : 0, nr = cfg.band_rows > 0 ? cfg.band_rows : rows_;
@@ -188,6 +188,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   f_.row0 = cfg.band_rows > 0 ? cfg.band_row0 : 0; f_.nrows = cfg.band_rows > 0 ? cfg.band_rows : 0;
   f_.qp = cfg.qp; f_.qpc = kChromaQp[cfg.qp]; f_.lambda_q4 = kLambdaQ4[cfg.qp]; f_.range = cfg.me_range;
   f_.rdoq = cfg.rdoq; f_.signhide = cfg.signhide; f_.intra_p = cfg.intra_in_p; f_.me_cost16 = me_cost16_; f_.me_cand = me_cost16_ ? me_cost16_ + (size_t)(cw_ / 16) * (ch_ / 16) : nullptr;
+  if (me_cost16_) { const size_t n16 = (size_t)(cw_ / 16) * (ch_ / 16); f_.ip_arrive = f_.me_cand + 1 + n16 / 4; f_.ip_scratch = (uint64_t *)(me_cost16_ + ((n16 + 1 + n16 / 4 + n16 / 4 + 1) & ~(size_t)1)); }      // (8-byte aligned)
   f_.wpp = cfg.wpp; f_.mv_frame = cfg.mv_frame; f_.me_early = cfg.me_early; f_.satd = cfg.satd; f_.subme = cfg.subme; f_.slices = cfg.slices;
   bind_set(0);
   uint8_t *p = intra_scratch_;

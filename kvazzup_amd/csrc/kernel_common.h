@@ -139,6 +139,7 @@ __device__ __forceinline__ void st_wt_u32(void *p, uint32_t v) { __hip_atomic_st
 __device__ __forceinline__ void st_wt_u64(void *p, uint64_t v) { __hip_atomic_store((uint64_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_wt_u8(void *p, uint32_t v) { __hip_atomic_store((uint8_t *)p, (uint8_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t ld_l2_u32(const void *p) { return __hip_atomic_load((const uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t ld_l2_u64(const void *p) { return __hip_atomic_load((const uint64_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t ld_l2_u8(const void *p) { return __hip_atomic_load((const uint8_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // every thread of the workgroup calls it after its write-through stores
 __device__ __forceinline__ void publish_wt(uint32_t *ctr, uint32_t value)

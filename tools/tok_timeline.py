@@ -1,6 +1,6 @@
 """Where k_tokenize's and k_tok_compact's time goes (KVAZZUP_AMD_INTRA_TRACE=1): 100 MHz stamps per CTU.  k_tok_compact: start, place in
 the dense array known, table staged, order restored, tokens copied.  k_tokenize: start of the CTU's first unit, start and end of its last
-unit (the one that closes the CTU).  GPU box only:  python tools/tok_timeline.py [w h]"""
+unit (the one that closes the CTU).  GPU box only:  python tools/tok_timeline.py [w h [pictures]]   (pictures = 1: the stamps are the intra picture's)"""
 import os, sys
 os.environ["KVAZZUP_AMD_INTRA_TRACE"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,8 @@ from kvazzup_amd.codec import Encoder
 
 w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
 e = Encoder(w, h, options=(("qp", 32), ("period", 64), ("me-range", 16)))
-for t in range(5):
+npic = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+for t in range(npic):
     e.encode(synth.frame(synth.MOVING, 0x5EED0002, w, h, t))
 wc, hc = (w + 63) // 64, (h + 63) // 64
 buf = np.zeros(wc * hc * 56, dtype=np.uint64)
@@ -32,7 +33,7 @@ print("k_tokenize: span %.1f us; first-unit starts spread over %.1f us, last-uni
 print("  the closing unit's wave: mean %.2f us, median %.2f, max %.2f" % ((k[:, 2] - k[:, 1]).mean(), np.median(k[:, 2] - k[:, 1]), (k[:, 2] - k[:, 1]).max()))
 srt = np.sort(k[:, 1])
 print("  last-unit start times, deciles (us):", " ".join("%.1f" % srt[int(q * (len(srt) - 1) / 10)] for q in range(11)))
-for name, o, npic in (("P pictures", 0, 4), ("the IDR picture", 6, 1)):
+for name, o, npic in (("P pictures", 0, max(1, npic - 1)), ("the IDR picture", 6, 1)):
     print("k_tokenize waves, %s (per picture):" % name)
     for k, cls in enumerate(("left at once", "header only", "with residual")):
         n, ticks = cen[o + 2 * k], cen[o + 2 * k + 1]

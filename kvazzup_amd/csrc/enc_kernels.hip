@@ -2131,11 +2131,12 @@ void launch_vaq(const EncFrame &f, int vaq, int *act, int *sum, hipStream_t st)
 void launch_sao(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_sao<false>, dim3((f.cw / 64) * (f.ch / 64)), dim3(256), 0, st, f); }
 void launch_tokenize(const EncFrame &f, hipStream_t st)
 {
-  // One wave per unit and colour component keeps the longest wave short: right while the grid is a few waves per SIMD and the
-  // kernel lasts as long as its slowest wave.  On large pictures the waves that only find out they have nothing to do dominate:
-  // there one wave per unit takes the three components in turn (76 vs 137 us at 2160p; 51 vs 32 us at 1080p).
+  // One wave per unit and colour component keeps the longest wave short: the kernel lasts as long as its slowest wave.  (One wave per unit that takes
+  // the three components in turn was the faster form at 2160p while a wave that finds nothing to do cost what it did in round 1 -- 76 vs 137 us; with
+  // today's early exit it is the slower one there as well: 66 vs 55 us per launch at 2160p, 51 vs 31 us at 1080p, a luma wave + a chroma wave per unit 60 /
+  // 35 us -- and is kept for pictures beyond that, where nothing has been measured.)
   const int units = (f.cw / 16) * band_rows(f) * 4;
-  if (units >= 16384) hipLaunchKernelGGL((k_tokenize<true, 1>), dim3(f.cw / 16, band_rows(f) * 4), dim3(64), 0, st, f);
+  if (units >= 65536) hipLaunchKernelGGL((k_tokenize<true, 1>), dim3(f.cw / 16, band_rows(f) * 4), dim3(64), 0, st, f);
   else hipLaunchKernelGGL((k_tokenize<false, 1>), dim3(f.cw / 16, band_rows(f) * 4, 3), dim3(64), 0, st, f);     // (tok_cursor is zero: the previous picture's k_tok_compact left it so)
 }
 void launch_tok_compact(const EncFrame &f, hipStream_t st)

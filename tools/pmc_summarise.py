@@ -16,7 +16,7 @@ def short(name):
     if not m:
         return None
     k = m.group(1)
-    return {"k_deblock_tile": "k_deblock"}.get(k, k)     # (bench.py's name for the encoder's deblocking kernel; k_tokenize<true> is the all-components variant of the same kernel)
+    return {"k_deblock_tile": "k_deblock"}.get(k, k)     # (bench.py's name for the encoder's deblocking kernel; k_tokenize<true> is the all-components variant of the same kernel, pictures beyond 4K)
 
 
 def per_kernel(pass_name, counter):

@@ -424,7 +424,7 @@ def run_stream(args, wl, steps, warmup, ranks, rank, world, quality, host_io=Fal
     w, h = wl["w"], wl["h"]
     # pictures parsed concurrently (video/OPENHEVC_threads): the ring has to cover the parse of an intra picture -- ~10 ms on one core at
     # 4K, where twelve pictures pass in 6 ms (measured: 2090 frames/s with 12, 2390 with 24; 1080p, 3.5 ms per intra picture: 5900-6170 / 6500-6700)
-    D = max(1, args.decoder_frame_threads or 24)
+    D = max(1, args.decoder_frame_threads or 32)      # (round 3, end: 32 against 24: 8 430-8 580 against 8 240-8 350 frames/s at 1080p, 3 150-3 170 against 2 910-3 100 at 4K, two alternating runs each)
     budget = float(os.environ.get("KVAZZUP_BENCH_CPU_BUDGET", 0)) or cpu_budget(world)
     if budget < 13.0:                                # not enough host CPU for the full thread complement: shrink the pools
         D = max(1, min(D, int(budget * 0.45 + 0.5)))
@@ -689,7 +689,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=12, help="pictures per core in the cpu_baseline sample")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--decoder-frame-threads", type=int, default=0,
-                    help="OpenHEVC 'Frame' parallelisation (uvgComm setting video/OH_parallelization): pictures parsed concurrently; 1 = off; 0 (default) = 24")
+                    help="OpenHEVC 'Frame' parallelisation (uvgComm setting video/OH_parallelization): pictures parsed concurrently; 1 = off; 0 (default) = 32")
     ap.add_argument("--profile-every", type=int, default=8, help="kernel timing with HIP events on every n-th picture")
     ap.add_argument("--intra-sad", action="store_true", help="intra-satd=0: the intra mode search compares SADs instead of 8x8 Hadamard sums (for the quality / rate comparison in DESIGN.md)")
     ap.add_argument("--full-search", action="store_true", help="me-early-termination=off: every 32x32 block is searched exhaustively (the k_me issue-rate roofline is reported for this case)")

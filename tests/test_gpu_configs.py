@@ -42,10 +42,10 @@ def test_config1_plain_1080p_p64_qp32_matches_oracle(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("owf,threads", [(3, 12), (6, 24), (12, 24)])
+@pytest.mark.parametrize("owf,threads", [(3, 12), (6, 32), (12, 24)])
 def test_config1_long_run_two_idrs(gpu, owf, threads):
     """130 pictures of the 1080p / period-64 workload through the pipelined filters (owf 3 with 12 frame threads; the benchmark's
-    owf 6 with 24: all eight working sets of the encoder in rotation, pictures queued behind the intra pictures' chains):
+    owf 6 with 32: all eight working sets of the encoder in rotation, pictures queued behind the intra pictures' chains):
     three IDRs; EVERY access unit is decoded by the checker's decoder and every picture the pipelined HIP decoder delivered equals the
     checker's (second and third IDR, the rotation of the encoder's eight working sets and the owf queueing included); the first
     pictures' access units also equal the checker encoder's"""

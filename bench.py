@@ -573,7 +573,8 @@ def multi_stream(args, wl, K, steps, ranks):
     from kvazzup_amd.pipeline import Pipeline
     w, h = wl["w"], wl["h"]
     budget = float(os.environ.get("KVAZZUP_BENCH_CPU_BUDGET", 0)) or cpu_budget(1)
-    D = max(2, min(24, int(budget * 0.9 / K)))
+    # the parse ring has to cover an intra picture's parse (3.5 ms at 1080p): 32 pictures at one stream's full rate, 32 / K at a K-th of it
+    D = int(os.environ.get("KVAZZUP_BENCH_MULTI_D", 0)) or max(2, min(32, 32 // K))
     threads = max(2, min(16, int(budget * 0.5 / K)))
     clips = [DeviceClip(ranks.lib, ranks.dev_index, stream_seed(wl["cfg_index"], k), w, h, PERIOD) for k in range(K)]
     pls = [Pipeline(w, h, settings={"video/QP": 32, "video/Intra": PERIOD, "video/VPS": 1, "uvgx/gpu": ranks.dev_index, "uvgx/decoderDownload": 0, "video/kvzThreads": threads,

@@ -1,20 +1,32 @@
-// kvazzup_amd/csrc/stream_pool.h -- HIP streams that outlive the encoder / decoder instance that used them.
+// kvazzup_amd/csrc/stream_pool.h -- the process's HIP streams, one per (device, role), shared by every encoder / decoder instance.
 // HIP maps streams onto four hardware queues per priority level, handed out in creation order, and which of this library's streams end
-// up sharing a queue decides 15-20 % of the pipeline's rate ("Hardware queues").  A process that closes an
-// instance and opens another -- uvgComm re-initialises its filters on every settings change (kvazaarfilter.cpp:91-119) -- would get
-// streams one turn further round the queues each time.  So streams are kept by role when an instance closes and handed to the next
-// instance that asks for the same role on the same device: it inherits the queue layout of its predecessor.
+// up sharing a queue decides 15-20 % of the pipeline's rate ("Hardware queues").  uvgComm runs several codec
+// instances in ONE process -- one OpenHEVCFilter per peer beside the shared KvazaarFilter (filtergraph.cpp:347-351,561-589) -- and
+// re-initialises them on every settings change (kvazaarfilter.cpp:91-119).  If every instance created streams of its own, the second
+// instance's streams would alias the first one's hardware queues and be serialised behind its event waits (round 3: two pipelines in a
+// process ran at 3 100 frames/s together against 8 400 for one).  So a stream belongs to a ROLE, not to an instance:
+//   * an instance that asks for a role another open instance already holds gets THE SAME stream (use count up) -- at most one stream per
+//     role and device however many instances are open; work of different instances is ordered on it like work of one instance,
+//     cross-stream dependencies stay events (an event wait only ever names work queued earlier, so the order of enqueueing is a
+//     topological order of every dependency: sharing cannot deadlock);
+//   * when the last user closes, the stream is kept and handed to the next instance that asks for the role: a re-created encoder /
+//     decoder inherits the queue layout of its predecessor.
+// Exclusive roles (never shared while open): 'E', the GPU arithmetic coder's per-picture streams -- their kernels last milliseconds and
+// must run side by side.  KVAZZUP_AMD_SHARE_STREAMS=0 makes every role exclusive (round 3's behaviour; measurement aid).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 
 namespace kvzx {
 
 struct StreamPool {
-  struct Idle { int device; char role, level; hipStream_t st; };
+  struct Entry { int device; char role, level; hipStream_t st; int users; };
   std::mutex m;
-  std::vector<Idle> idle;
+  std::vector<Entry> all;
+  bool share;
+  StreamPool() { const char *e = getenv("KVAZZUP_AMD_SHARE_STREAMS"); share = !(e && e[0] == '0'); }
   static StreamPool &get() { static StreamPool p; return p; }
 };
 
@@ -23,25 +35,38 @@ struct StreamPool {
 inline hipError_t stream_acquire(hipStream_t *st, int device, char role, char level)
 {
   StreamPool &p = StreamPool::get();
-  {
-    std::lock_guard<std::mutex> l(p.m);
-    for (size_t i = 0; i < p.idle.size(); i++)
-      if (p.idle[i].device == device && p.idle[i].role == role && p.idle[i].level == level) { *st = p.idle[i].st; p.idle.erase(p.idle.begin() + (long)i); return hipSuccess; }
-  }
+  const bool exclusive = !p.share || role == 'E';
+  std::lock_guard<std::mutex> l(p.m);
+  for (auto &e : p.all)
+    if (e.device == device && e.role == role && e.level == level && (e.users == 0 || !exclusive)) { e.users++; *st = e.st; return hipSuccess; }
   int lo = 0, hi = 0;
   hipDeviceGetStreamPriorityRange(&lo, &hi);            // (hi is the numerically smallest = most urgent)
-  if (level == 'h') return hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi);
-  if (level == 'l') return hipStreamCreateWithPriority(st, hipStreamNonBlocking, lo);
-  return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+  hipError_t rc;
+  if (level == 'h') rc = hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi);
+  else if (level == 'l') rc = hipStreamCreateWithPriority(st, hipStreamNonBlocking, lo);
+  else rc = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+  if (rc == hipSuccess) p.all.push_back({device, role, level, *st, 1});
+  return rc;
 }
 inline void stream_release(hipStream_t st, int device, char role, char level)
 {
   if (!st) return;
+  (void)role; (void)level;
   hipSetDevice(device);
-  hipStreamSynchronize(st);
+  hipStreamSynchronize(st);                             // (the closing instance's work; other users' work queued before now as well)
   StreamPool &p = StreamPool::get();
   std::lock_guard<std::mutex> l(p.m);
-  p.idle.push_back({device, role, level, st});
+  for (auto &e : p.all)
+    if (e.st == st && e.users > 0) { e.users--; return; }
+}
+
+// streams of a role currently open by more than one instance on this device?  (the batched-launch layer only engages then)
+inline int stream_users(hipStream_t st)
+{
+  StreamPool &p = StreamPool::get();
+  std::lock_guard<std::mutex> l(p.m);
+  for (auto &e : p.all) if (e.st == st) return e.users;
+  return 0;
 }
 
 }  // namespace kvzx

@@ -601,14 +601,36 @@ def multi_stream(args, wl, K, steps, ranks):
         elapsed[k] = time.perf_counter() - t0
         gate.wait()
 
+    import ctypes as C
+    lib = ranks.lib
+    lib.kvzx_batch_stats.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]
+    lib.kvzx_batch_kernel_name.restype = C.c_char_p
     ths = [threading.Thread(target=body, args=(k,)) for k in range(K)]
     for t in ths:
         t.start()
     gate.wait()
+    if not os.environ.get("KVAZZUP_BENCH_NOPROF"):
+        for pl in pls:
+            lib.kvzx_decoder_set_profiling(pl.decoder_handle(), args.profile_every)
+    lib.kvzx_batch_stats(ranks.dev_index, None, None, None, None, None, None, 1)
     cpu0, t0 = time.process_time(), time.perf_counter()
     gate.wait()
     wall = time.perf_counter() - t0
     cores = (time.process_time() - cpu0) / wall
+    nb, npics = C.c_uint64(), C.c_uint64()
+    sizes, bms, bln, bfr = (C.c_uint64 * 9)(), (C.c_double * 4)(), (C.c_uint64 * 4)(), (C.c_uint64 * 4)()
+    nk = lib.kvzx_batch_stats(ranks.dev_index, C.byref(nb), C.byref(npics), sizes, bms, bln, bfr, 0)
+    # the decoders' submission layer (csrc/batch.h): pictures per launch, and the batched kernels against the HBM roofline -- algorithmic bytes of
+    # the pictures in a launch over the launch's duration, beside the single-picture kernels' fractions in `roofline.frac_by_kernel`
+    cw, ch = (w + 63) // 64 * 64, (h + 63) // 64 * 64
+    batched = {}
+    for i in range(nk):
+        if bln[i]:
+            name = lib.kvzx_batch_kernel_name(i).decode()
+            us, per = bms[i] / bln[i] * 1e3, bfr[i] / bln[i]
+            single = {"k_dec_inter_n": "k_dec_inter", "k_dec_intra_n": "k_dec_intra", "k_dec_deblock_n": "k_dec_deblock", "k_dec_sao_n": "k_dec_sao"}[name]
+            batched[name] = {"avg_launch_us": round(us, 2), "pictures_per_launch": round(per, 2), "us_per_picture": round(us / per, 2),
+                             "hbm_frac": round(algorithmic_bytes(single, cw, ch, args.me_range) * per / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
     for t in ths:
         t.join()
     for pl in pls:
@@ -620,7 +642,9 @@ def multi_stream(args, wl, K, steps, ranks):
         c.close()
     npic = steps * PERIOD
     return {"streams": K, "value": round(K * npic / max(elapsed), 1), "unit": "frames/s (all streams together)", "per_stream": [round(npic / e, 1) for e in elapsed],
-            "steps_per_stream": steps, "decoder_frame_threads_per_stream": D, "coder_threads_per_stream": threads, "host_cpu_cores_busy": round(cores, 2)}
+            "steps_per_stream": steps, "decoder_frame_threads_per_stream": D, "coder_threads_per_stream": threads, "host_cpu_cores_busy": round(cores, 2),
+            "decoder_batches": {"launches": nb.value, "pictures": npics.value, "pictures_per_batch": round(npics.value / max(1, nb.value), 3),
+                                "batches_by_size": {str(n): sizes[n] for n in range(1, 9) if sizes[n]}, "kernels": batched}}
 
 
 def roofline_of(m, steps, me_range, workload_key):

@@ -65,6 +65,14 @@ KVZ_PUBLIC void kvzx_decoder_set_profiling(OpenHevc_Handle h, int every);
 KVZ_PUBLIC int kvzx_decoder_kernel_times(OpenHevc_Handle h, double *ms, uint64_t *launches, int reset);
 KVZ_PUBLIC const char *kvzx_decoder_kernel_name(int id);
 KVZ_PUBLIC int kvzx_decoder_debug_copy(OpenHevc_Handle h, const char *what, void *dst, size_t bytes);
+/* ---- several decoders in one process on one device (uvgComm: one OpenHEVCFilter per peer, filtergraph.cpp:561-589): their pictures are launched by
+ * the device's submission layer, same kernels of different decoders' pictures as ONE launch (csrc/batch.h).  Statistics since the last reset:
+ * sizes[n] = batches of n pictures (n = 0..8, 9 entries); per kernel (kvzx_batch_kernel_name: 4 of them) the profiled batches' time, launches and
+ * pictures (profiling as set with kvzx_decoder_set_profiling on any of the decoders).  Returns the number of kernels. */
+KVZ_PUBLIC int kvzx_batch_stats(int device, uint64_t *batches, uint64_t *pictures, uint64_t *sizes /*[9]*/, double *ms /*[4]*/, uint64_t *launches /*[4]*/, uint64_t *frames /*[4]*/, int reset);
+KVZ_PUBLIC const char *kvzx_batch_kernel_name(int id);
+/* measurement aid: while held, the submission layer launches nothing and the decoders' pictures pile up; releasing launches them in full batches */
+KVZ_PUBLIC void kvzx_batch_hold(int device, int on);
 
 /* ---- tile-row split of ONE picture over several encoders, one per GPU / process (BASELINE configs[4]).
  * Every encoder is opened with the same configuration plus "tiles" = 1xN and "band-row0" / "band-rows" (CTU rows, whole

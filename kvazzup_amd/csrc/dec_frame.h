@@ -72,6 +72,17 @@ struct DecFrame {
   uint8_t pad_[2];
 };
 
+// Several pictures in ONE launch (batch.h: pictures of different decoder instances that are ready at the same time): the kernel argument is
+// a table of frame descriptors in DEVICE memory -- each picture's DecFrame travels at the end of the fixed part of its input block -- and
+// the workgroups' share-out: frame i owns workgroups [first[i], first[i + 1]) of the one-dimensional grid (every share a multiple of 8, so
+// that a workgroup's index inside its share still names its XCD; the padding workgroups leave at once).
+#define KVZ_DEC_BATCH_MAX 8
+struct DecBatch {
+  const DecFrame *f[KVZ_DEC_BATCH_MAX];
+  uint32_t first[KVZ_DEC_BATCH_MAX + 1];      // unused entries = first[n]
+  uint32_t count[KVZ_DEC_BATCH_MAX];          // workgroups of frame i that have work (<= its share)
+};
+
 // z-order index (0..63) of the 8x8 luma unit at (xi, yi) of a CTU, xi, yi in 0..7
 KVZ_HD int zunit8(int xi, int yi)
 {

@@ -21,6 +21,13 @@
 
 namespace kvzx {
 
+// A kernel body runs on a frame descriptor that is either the kernel's argument (DecFrame) or lies in device memory and is read through the
+// constant address space (CDecFrame: the batched kernels, see the end of this file); Wg = the workgroup's index inside its frame's share of
+// the grid and the number of workgroups of that share which have work.
+#define KVZ_CONST_AS __attribute__((address_space(4)))
+typedef const KVZ_CONST_AS DecFrame CDecFrame;
+struct Wg { int id, n; };
+
 __device__ __forceinline__ int zorder3(int x, int y)      // 3 + 3 bits
 {
   int z = 0;
@@ -118,11 +125,13 @@ __device__ __forceinline__ void dec_itx_class(DecInterLds &s, int16_t *C0, uint3
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_dec_inter(DecFrame f)
+template <class F> __device__ __forceinline__ void dec_inter_body(const F &f, const Wg wg)
 {
   __shared__ DecInterLds s;
   const int tid = threadIdx.x;
-  int bx, by; xcd_block_2d(bx, by);
+  if (wg.id >= wg.n) return;
+  const int gx = f.wc * 2, lin0 = xcd_contiguous(wg.id, wg.n);
+  int by = lin0 / gx; const int bx = lin0 - by * gx;
   by += f.row0 * 2;                                          // (band of CTU rows: the grid covers f.nrows of them)
   const int x0 = bx * 32, y0 = by * 32;
   if (x0 >= f.w || y0 >= f.h) return;
@@ -355,7 +364,7 @@ struct DecIntraLds {
 };
 
 // 6.4.1 for one slice: inside the picture, same tile, not later in z-scan order (luma locations)
-__device__ __forceinline__ bool dec_avail(const DecFrame &f, int xc, int yc, int xn, int yn)
+template <class F> __device__ __forceinline__ bool dec_avail(const F &f, int xc, int yc, int xn, int yn)
 {
   if (xn < 0 || yn < 0 || xn >= f.w || yn >= f.h) return false;
   if (f.tiles && f.ctu_tile[(yn >> 6) * f.wc + (xn >> 6)] != f.ctu_tile[(yc >> 6) * f.wc + (xc >> 6)]) return false;
@@ -363,8 +372,8 @@ __device__ __forceinline__ bool dec_avail(const DecFrame &f, int xc, int yc, int
 }
 
 // one intra transform block of plane c: N x N samples at (rx, ry) of the CTU (component samples); its borders are in s.pic
-template <int L2, int T>
-__device__ __forceinline__ void dec_intra_block(const DecFrame &f, DecIntraLds &s, const DecTu &d, int c, int cx, int cy, int rx, int ry, int lane, const uint32_t (&wreg)[4])
+template <int L2, int T, class F>
+__device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, const DecTu &d, int c, int cx, int cy, int rx, int ry, int lane, const uint32_t (&wreg)[4])
 {
   constexpr int N = XW<L2, T>::N, OPL = XW<L2, T>::OPL, G = XW<L2, T>::G;
   const int sh = c ? 1 : 0, S = 64 >> sh, nl = N << sh, cpitch = f.pw >> sh, wC = f.w >> sh, hC = f.h >> sh;
@@ -486,12 +495,12 @@ __device__ __forceinline__ void dec_intra_block(const DecFrame &f, DecIntraLds &
 // transform block (levels -> dequantised coefficients -> the two inverse stages on the matrix cores, or the transform-skip shift),
 // into plane-shaped int16 arrays.  The dependency chain of k_dec_intra then only predicts, adds and stores.  (32x32 blocks stay
 // with the chain's workgroup-shaped code.)  Lane (g, c) owns the four samples x = 4g .. 4g + 3 of row c, as in the chain.
-__global__ __launch_bounds__(256) void k_dec_intra_resid(DecFrame f)
+template <class F> __device__ __forceinline__ void dec_intra_resid_body(const F &f, const Wg wg)
 {
   __shared__ IntraWaveScratch wsv[4];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, idx = (int)blockIdx.x * 4 + wv;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, idx = wg.id * 4 + wv;
   // (the progress counters and the ticket counter k_dec_intra starts from: this kernel runs in front of it on the same stream, a memset of their own was a launch)
-  if (blockIdx.x == 0) for (int i = threadIdx.x; i < 3 * f.wc * f.hc + 1; i += 256) f.progress[i] = 0;
+  if (wg.id == 0) for (int i = threadIdx.x; i < 3 * f.wc * f.hc + 1; i += 256) f.progress[i] = 0;
   if (idx >= f.ntu) return;
   const DecTu d = f.tus[idx];
   if (!(d.flags & TU_INTRA) || !d.count || d.log2 > 4) return;
@@ -554,7 +563,7 @@ __device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveSc
 }
 
 // One workgroup (one wave) per (CTU, colour plane)
-__global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
+template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, const Wg wg)
 {
   constexpr int T = 64;
   __shared__ DecIntraLds s;
@@ -563,10 +572,11 @@ __global__ __launch_bounds__(64) void k_dec_intra(DecFrame f)
   // (enc_kernels.hip k_intra_recon: the launch has as many workgroups as the wavefront keeps busy, each takes the next (CTU, plane) in
   // anti-diagonal order from a ticket counter -- f.progress[3 * CTUs] -- so that the chain does not park a workgroup per (CTU, plane) on the chip)
   const int lane = threadIdx.x;
+  if (wg.id >= wg.n) return;
   const uint32_t nticket = 3u * (uint32_t)f.wc * (uint32_t)(f.nrows > 0 ? f.nrows : f.hc);
   for (int i = lane; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];      // the transforms' matrix operands: once per workgroup, not per (CTU, plane)
   for (bool once = true;; once = false) {
-  uint32_t ticket = blockIdx.x;
+  uint32_t ticket = (uint32_t)wg.id;
   if (f.intra_direct) { if (!once) break; }
   else {
     __syncthreads();
@@ -715,14 +725,15 @@ __device__ __forceinline__ int dec_bs(const B4Rec &p, const B4Rec &q, bool tu_ed
   return 0;
 }
 
-__global__ __launch_bounds__(256) void k_dec_deblock(DecFrame f)
+template <class F> __device__ __forceinline__ void dec_deblock_body(const F &f, const Wg wg)
 {
   constexpr int P = 80, PC = 48;                           // LDS pitches (enc_kernels.hip k_deblock_tile: same tile geometry and I/O)
   __shared__ __attribute__((aligned(16))) uint8_t ty_[68 * P];
   __shared__ __attribute__((aligned(16))) uint8_t tc_[2][34 * PC];
   __shared__ B4Rec recs[18 * 18];                          // the tile's 4x4 records and one ring: units -1 .. 16 in both directions
   const int tid = threadIdx.x, wc = f.wc, hc = f.hc, b4w = f.pw >> 2;
-  const int lin = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), tx = lin % wc, tyi = lin / wc + f.row0;
+  if (wg.id >= wg.n) return;
+  const int lin = xcd_contiguous(wg.id, wg.n), tx = lin % wc, tyi = lin / wc + f.row0;
   const int X0 = tx * 64 - 4, Y0 = tyi * 64 - 4, CX0 = X0 >> 1, CY0 = Y0 >> 1, cw2 = f.pw >> 1;
   const int TW = tx == wc - 1 ? 68 : 64, TH = tyi == hc - 1 ? 68 : 64;
   for (int i = tid; i < 18 * 18; i += 256) {
@@ -821,10 +832,11 @@ __device__ __forceinline__ int dsao_edge_idx(int c, int a, int b)
   return e == 2 ? 0 : (e < 2 ? e + 1 : e);
 }
 
-__global__ __launch_bounds__(256) void k_dec_sao(DecFrame f)
+template <class F> __device__ __forceinline__ void dec_sao_body(const F &f, const Wg wg)
 {
   __shared__ DecSaoLds s;
-  const int tid = threadIdx.x, wc = f.wc, ctu = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), cx = ctu % wc, cy = ctu / wc;
+  if (wg.id >= wg.n) return;
+  const int tid = threadIdx.x, wc = f.wc, ctu = xcd_contiguous(wg.id, wg.n), cx = ctu % wc, cy = ctu / wc;
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     const int sh = c ? 1 : 0, l2n = 6 - sh, n = 1 << l2n, pitch_g = f.pw >> sh, pwid = f.w >> sh, phei = f.h >> sh, X0 = cx * n, Y0 = cy * n;
@@ -891,17 +903,80 @@ __global__ __launch_bounds__(256) void k_dec_sao(DecFrame f)
 // =============================================================================================
 // launch wrappers
 // =============================================================================================
+// the single-picture kernels: the frame is the kernel argument
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_dec_inter(DecFrame f) { dec_inter_body(f, Wg{(int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y)}); }
+__global__ __launch_bounds__(256) void k_dec_intra_resid(DecFrame f) { dec_intra_resid_body(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
+__global__ __launch_bounds__(64) void k_dec_intra(DecFrame f) { dec_intra_body(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
+__global__ __launch_bounds__(256) void k_dec_deblock(DecFrame f) { dec_deblock_body(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
+__global__ __launch_bounds__(256) void k_dec_sao(DecFrame f) { dec_sao_body(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
+
+// the batched kernels (dec_frame.h DecBatch): a workgroup finds its frame by its index (wave-uniform: scalar compares), then runs the same body
+// on the frame descriptor where it lies in device memory -- read through the constant address space, i.e. with scalar loads on demand,
+// exactly as a kernel argument is
+__device__ __forceinline__ int batch_frame(const DecBatch &b, Wg &wg)
+{
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < KVZ_DEC_BATCH_MAX; k++) i += blockIdx.x >= b.first[k] ? 1 : 0;
+  wg.id = (int)(blockIdx.x - b.first[i]); wg.n = (int)b.count[i];
+  return i;
+}
+#define KVZ_BATCH_FRAME(b) Wg wg; const CDecFrame &f = *(const CDecFrame *)(b).f[batch_frame(b, wg)]
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_dec_inter_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_inter_body(f, wg); }
+__global__ __launch_bounds__(256) void k_dec_intra_resid_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_intra_resid_body(f, wg); }
+__global__ __launch_bounds__(64) void k_dec_intra_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_intra_body(f, wg); }
+__global__ __launch_bounds__(256) void k_dec_deblock_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_deblock_body(f, wg); }
+__global__ __launch_bounds__(256) void k_dec_sao_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_sao_body(f, wg); }
+
+// =============================================================================================
+// launch wrappers
+// =============================================================================================
 static inline int dec_rows(const DecFrame &f) { return f.nrows > 0 ? f.nrows : f.hc; }
-void launch_dec_inter(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_inter, dim3(f.wc * 2, dec_rows(f) * 2), dim3(256), 0, st, f); }
-void launch_dec_intra_resid(const DecFrame &f, hipStream_t st) { if (f.ntu > 0) hipLaunchKernelGGL(k_dec_intra_resid, dim3((f.ntu + 3) / 4), dim3(256), 0, st, f); }
-void launch_dec_intra(const DecFrame &f, hipStream_t st)
+static inline int dec_intra_wgs(const DecFrame &f)
 {
   // as many one-wave workgroups as three anti-diagonals of the CTU wavefront hold, in three planes (k_dec_intra: tickets; f.intra_order lists the band's CTUs)
   static const int diags = getenv("KVAZZUP_AMD_INTRA_DIAGS") ? atoi(getenv("KVAZZUP_AMD_INTRA_DIAGS")) : 3;      // (measurement aid; 0: a workgroup per (CTU, plane))
   const int nr = dec_rows(f), diag = nr < (f.wc + 1) / 2 ? nr : (f.wc + 1) / 2, all = f.wc * nr * 3, want = (diags > 0 && !f.intra_direct) ? 3 * diags * diag + 32 : all;
-  hipLaunchKernelGGL(k_dec_intra, dim3(want < all ? want : all), dim3(64), 0, st, f);
+  return want < all ? want : all;
 }
+void launch_dec_inter(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_inter, dim3(f.wc * 2, dec_rows(f) * 2), dim3(256), 0, st, f); }
+void launch_dec_intra_resid(const DecFrame &f, hipStream_t st) { if (f.ntu > 0) hipLaunchKernelGGL(k_dec_intra_resid, dim3((f.ntu + 3) / 4), dim3(256), 0, st, f); }
+void launch_dec_intra(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_intra, dim3(dec_intra_wgs(f)), dim3(64), 0, st, f); }
 void launch_dec_deblock(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_deblock, dim3(f.wc * dec_rows(f)), dim3(256), 0, st, f); }
 void launch_dec_sao(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_sao, dim3(f.wc * f.hc), dim3(256), 0, st, f); }
+
+// share-out of a batched launch: wgs(frame) workgroups for every frame with a device descriptor, each share rounded up to a multiple of 8
+template <class W> static uint32_t batch_layout(DecBatch &b, const DecFrame *const *h, const DecFrame *const *d, int n, W &&wgs)
+{
+  uint32_t at = 0;
+  for (int i = 0; i < KVZ_DEC_BATCH_MAX; i++) {
+    b.first[i] = at; b.f[i] = nullptr; b.count[i] = 0;
+    if (i < n && d[i]) { b.f[i] = d[i]; b.count[i] = (uint32_t)wgs(*h[i]); at += (b.count[i] + 7u) & ~7u; }
+  }
+  b.first[KVZ_DEC_BATCH_MAX] = at;
+  return at;
+}
+void launch_dec_inter_n(const DecFrame *const *h, const DecFrame *const *d, int n, hipStream_t st)
+{
+  DecBatch b; const uint32_t total = batch_layout(b, h, d, n, [](const DecFrame &f) { return f.wc * 2 * dec_rows(f) * 2; });
+  if (total) hipLaunchKernelGGL(k_dec_inter_n, dim3(total), dim3(256), 0, st, b);
+}
+void launch_dec_intra_n(const DecFrame *const *h, const DecFrame *const *d, int n, hipStream_t st)
+{
+  DecBatch b; uint32_t total = batch_layout(b, h, d, n, [](const DecFrame &f) { return (f.ntu + 3) / 4; });
+  if (total) hipLaunchKernelGGL(k_dec_intra_resid_n, dim3(total), dim3(256), 0, st, b);
+  total = batch_layout(b, h, d, n, [](const DecFrame &f) { return dec_intra_wgs(f); });
+  if (total) hipLaunchKernelGGL(k_dec_intra_n, dim3(total), dim3(64), 0, st, b);
+}
+void launch_dec_deblock_n(const DecFrame *const *h, const DecFrame *const *d, int n, hipStream_t st)
+{
+  DecBatch b; const uint32_t total = batch_layout(b, h, d, n, [](const DecFrame &f) { return f.wc * dec_rows(f); });
+  if (total) hipLaunchKernelGGL(k_dec_deblock_n, dim3(total), dim3(256), 0, st, b);
+}
+void launch_dec_sao_n(const DecFrame *const *h, const DecFrame *const *d, int n, hipStream_t st)
+{
+  DecBatch b; const uint32_t total = batch_layout(b, h, d, n, [](const DecFrame &f) { return f.wc * f.hc; });
+  if (total) hipLaunchKernelGGL(k_dec_sao_n, dim3(total), dim3(256), 0, st, b);
+}
 
 }  // namespace kvzx

@@ -32,6 +32,7 @@
 #include "host_pool.h"
 #include "dec_frame.h"
 #include "dec_kernels.h"
+#include "batch.h"
 
 namespace kvzx {
 
@@ -172,6 +173,7 @@ class Decoder {
     bool any_intra = false, any_inter = false, across_slices = true;
     std::atomic<int> state{0}; int rc = 0; double parse_ms = 0;
     hipEvent_t done = nullptr;                                   // recorded behind the picture's last kernel
+    std::atomic<int> launched{1};                                // 0 while the picture waits in the device's submission layer (batch.h): `done` has not been recorded yet
     std::vector<uint8_t> expect_hash;                            // payload of the picture's decoded picture hash SEI (libOpenHevcSetCheckMD5), empty: none
     long launch_idx = 0;                                         // count of pictures launched before this one
     hipEvent_t dl_done = nullptr; int dl_buf = -1;               // download mode: the picture's copy into host buffer dl_buf, queued behind `done` on the download stream
@@ -212,12 +214,15 @@ class Decoder {
   size_t off_ctu() const { return off_region() + (size_t)(pw_ / 32) * (ph_ / 32) * sizeof(TuRange); }
   size_t off_tile() const { return off_ctu() + (size_t)(pw_ / 64) * (ph_ / 64) * sizeof(TuRange); }
   size_t off_sao() const { return (off_tile() + (size_t)(pw_ / 64) * (ph_ / 64) + 15) & ~(size_t)15; }
-  size_t fixed_bytes() const { return (off_sao() + (size_t)(pw_ / 64) * (ph_ / 64) * sizeof(SaoParams) + 15) & ~(size_t)15; }
+  size_t off_frame() const { return (off_sao() + (size_t)(pw_ / 64) * (ph_ / 64) * sizeof(SaoParams) + 63) & ~(size_t)63; }     // the picture's DecFrame, for launches that read it from device memory (batch.h)
+  size_t fixed_bytes() const { return (off_frame() + sizeof(DecFrame) + 15) & ~(size_t)15; }
   bool grow_job_input(PicJob &job, size_t bytes);
   void bind_job(PicJob &job);
   int launch_gpu(PicJob &job);
   int complete_gpu(PicJob &job);
   int alloc_slot();
+  void sync_main();                       // everything this decoder has submitted has run (the submission layer's queue included)
+  bool batch_attached_ = false, batch_used_ = false;
 
   int device_; bool started_ = false;
   hipStream_t stream_up_ = nullptr; hipEvent_t up_done_[9] = {};   // upload of the next picture's input block beside the current picture's kernels

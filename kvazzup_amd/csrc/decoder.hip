@@ -795,7 +795,7 @@ struct SliceParser {
 // Pictures still being parsed by frame workers are waited for and dropped (close / resolution change).
 void Decoder::drop_pending()
 {
-  if (gpu_job_ || !gpu_q_.empty()) { hipStreamSynchronize(stream_); if (stream_dl_) hipStreamSynchronize(stream_dl_); }
+  if (gpu_job_ || !gpu_q_.empty()) { sync_main(); if (stream_dl_) hipStreamSynchronize(stream_dl_); }
   if (gpu_job_) { gpu_job_->ev_used = 0; gpu_job_->dl_buf = -1; gpu_job_ = nullptr; }
   for (PicJob *j : gpu_q_) { j->ev_used = 0; j->dl_buf = -1; }
   gpu_q_.clear();
@@ -806,12 +806,19 @@ void Decoder::drop_pending()
   }
 }
 
+void Decoder::sync_main()
+{
+  if (batch_used_) { DecBatcher::get(device_).drain(this); batch_used_ = false; }
+  hipStreamSynchronize(stream_);
+}
+
 Decoder::~Decoder()
 {
   if (getenv("KVAZZUP_AMD_TRACE")) fprintf(stderr, "kvazzup_amd decoder thread ms: nal %.1f  wait_parse %.1f  stage %.1f  gpu_api %.1f  gpu_sync %.1f  longest parse %.2f  (pictures %ld)\n", t_nal_, t_wait_, t_stage_, t_api_, t_sync_, t_parse_max_, job_tail_);
   drop_pending();
   workers_.reset();
-  if (stream_) hipStreamSynchronize(stream_);
+  if (stream_) sync_main();
+  if (batch_attached_) { DecBatcher::get(device_).detach(); batch_attached_ = false; }
   if (h_err_ && *h_err_) fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x (last picture)\n", *h_err_);
   for (auto &j : jobs_) { for (auto &e : j.ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); } if (j.done) hipEventDestroy(j.done); if (j.dl_done) hipEventDestroy(j.dl_done); }
   free_buffers();
@@ -854,6 +861,7 @@ bool Decoder::start(std::string *error)
   HIP_TRY(hipHostMalloc(&h_err_, sizeof(uint32_t), hipHostMallocMapped));
   *h_err_ = 0;
   { void *dp = nullptr; HIP_TRY(hipHostGetDevicePointer(&dp, h_err_, 0)); err_ = (uint32_t *)dp; }
+  DecBatcher::get(device_).attach(stream_); batch_attached_ = true;
   started_ = true;
   return true;
 }
@@ -905,7 +913,7 @@ bool Decoder::ensure_buffers(int w, int h)
     if (rc < 0 || (rc > 0 && pic_ready_ && !queue_current_output())) { drop_pending(); break; }
   }
   drop_pending();
-  hipStreamSynchronize(stream_);
+  sync_main();
   free_buffers();
   if (jobs_.empty()) {
     const char *e = getenv("KVAZZUP_AMD_DEC_GPU_DEPTH");
@@ -1625,6 +1633,7 @@ int Decoder::start_ready_downloads()
   if (!download_) return 0;
   for (PicJob *j : gpu_q_) {
     if (j->dl_buf >= 0) continue;
+    if (!j->launched.load(std::memory_order_acquire)) break;      // (still in the submission layer's queue: its event has not been recorded)
     const hipError_t r = hipEventQuery(j->done);
     if (r == hipErrorNotReady) break;
     if (r != hipSuccess) return DEC_ERR_GPU;
@@ -1638,6 +1647,7 @@ int Decoder::complete_gpu(PicJob &job)
 {
   {
     Tick tk;
+    while (!job.launched.load(std::memory_order_acquire)) futex_wait(job.launched, 0);      // (batch.h: the submitter thread records job.done)
     auto wait = [&](hipEvent_t ev) {
       if (frame_threads_ > 1 && !spin_wait_)    // the output lags anyway: nap between queries instead of polling (see nap_until)
         return nap_until([&] { hipError_t r = hipEventQuery(ev); return r == hipSuccess ? 1 : (r == hipErrorNotReady ? 0 : -1); });
@@ -1838,8 +1848,6 @@ int Decoder::launch_gpu(PicJob &job)
     d_in_cap_[ib] = bytes + bytes / 2;
     if (hipMalloc(&d_in_, d_in_cap_[ib]) != hipSuccess) { d_in_ = nullptr; d_in_cap_[ib] = 0; return DEC_ERR_GPU; }
   }
-  if (hipMemcpyAsync(d_in_, job.h_in, bytes, hipMemcpyHostToDevice, stream_up_) != hipSuccess) return DEC_ERR_GPU;
-  if (hipEventRecord(up_done_[ib], stream_up_) != hipSuccess || hipStreamWaitEvent(stream_, up_done_[ib], 0) != hipSuccess) return DEC_ERR_GPU;
   DecFrame f; memset(&f, 0, sizeof(f));
   f.w = w_; f.h = h_; f.pw = pw_; f.ph = ph_; f.wc = (w_ + 63) / 64; f.hc = (h_ + 63) / 64;
   f.b4 = (const B4Rec *)d_in_; f.region = (const TuRange *)(d_in_ + off_region()); f.ctu = (const TuRange *)(d_in_ + off_ctu());
@@ -1862,6 +1870,30 @@ int Decoder::launch_gpu(PicJob &job)
     if (!ok || !top || !bottom) return DEC_ERR_UNSUPPORTED;
     f.row0 = band_row0_; f.nrows = band_nrows_;
   }
+  // Several decoders open on this device: the picture goes to the device's submission layer (batch.h), which launches the waiting pictures of
+  // all of them together; its descriptor travels inside the input block.  One decoder: it launches for itself, frame by value.
+  DecBatcher &batcher = DecBatcher::get(device_);
+  const bool batched = band_nrows_ == 0 && batch_attached_ && batcher.active();
+  if (!batched && batch_used_) { batcher.drain(this); batch_used_ = false; }       // (the other decoder has just closed: what this one still has queued there comes first)
+  if (batched) memcpy(job.h_in + off_frame(), &f, sizeof(f));
+  if (hipMemcpyAsync(d_in_, job.h_in, bytes, hipMemcpyHostToDevice, stream_up_) != hipSuccess) return DEC_ERR_GPU;
+  if (hipEventRecord(up_done_[ib], stream_up_) != hipSuccess) return DEC_ERR_GPU;
+  if (batched) {
+    DecBatchItem it;
+    it.f = f; it.d_f = (const DecFrame *)(d_in_ + off_frame());
+    it.inter = job.any_inter; it.intra = job.any_intra; it.deblock = !job.sh.deblock_disabled; it.sao = sao;
+    it.wait0 = up_done_[ib]; it.wait1 = dpb_[job.slot].last_dl; dpb_[job.slot].last_dl = nullptr;
+    it.done = job.done; it.launched = &job.launched; it.owner = this; it.profile = prof_now_;
+    job.launched.store(0, std::memory_order_relaxed);
+    job.dl_buf = -1; job.launch_idx = launched_;
+    batcher.submit(it);
+    batch_used_ = true;
+    t_api_ += tk_api.ms();
+    launched_++;
+    gpu_q_.push_back(&job);
+    return 0;
+  }
+  if (hipStreamWaitEvent(stream_, up_done_[ib], 0) != hipSuccess) return DEC_ERR_GPU;
   // the buffer the picture is built in: the copy to the host of the picture last reconstructed there (queued, maybe not yet run) comes first
   if (dpb_[job.slot].last_dl) { if (hipStreamWaitEvent(stream_, dpb_[job.slot].last_dl, 0) != hipSuccess) return DEC_ERR_GPU; dpb_[job.slot].last_dl = nullptr; }
   if (job.any_inter) timed(DK_INTER, [&] { launch_dec_inter(f, stream_); });

@@ -162,6 +162,22 @@ int kvzx_decoder_kernel_times(OpenHevc_Handle hh, double *ms, uint64_t *launches
   for (int i = 0; i < kvzx::DK_COUNT; i++) { if (ms) ms[i] = m[i]; if (launches) launches[i] = n[i]; }
   return kvzx::DK_COUNT;
 }
+int kvzx_batch_stats(int device, uint64_t *batches, uint64_t *pictures, uint64_t *sizes, double *ms, uint64_t *launches, uint64_t *frames, int reset)
+{
+  kvzx::BatchStats st;
+  kvzx::DecBatcher::get(device).get_stats(&st, reset != 0);
+  if (batches) *batches = st.batches;
+  if (pictures) *pictures = st.pictures;
+  if (sizes) for (int i = 0; i <= KVZ_DEC_BATCH_MAX; i++) sizes[i] = st.by_size[i];
+  for (int i = 0; i < kvzx::BK_COUNT; i++) { if (ms) ms[i] = st.ms[i]; if (launches) launches[i] = st.launches[i]; if (frames) frames[i] = st.frames[i]; }
+  return kvzx::BK_COUNT;
+}
+const char *kvzx_batch_kernel_name(int id)
+{
+  static const char *names[kvzx::BK_COUNT] = {"k_dec_inter_n", "k_dec_intra_n", "k_dec_deblock_n", "k_dec_sao_n"};
+  return (id >= 0 && id < kvzx::BK_COUNT) ? names[id] : nullptr;
+}
+void kvzx_batch_hold(int device, int on) { kvzx::DecBatcher::get(device).hold(on != 0); }
 const char *kvzx_decoder_kernel_name(int id)
 {
   static const char *names[kvzx::DK_COUNT] = {"k_dec_inter", "k_dec_intra", "k_dec_deblock", "host_cabac_parse", "k_dec_sao"};

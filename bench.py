@@ -703,7 +703,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=3, help="the K-step timed region is run this many times; `value` is the median run (BASELINE.md: median of 3)")
     ap.add_argument("--no-host-boundary", action="store_true", help="skip the `host_boundary` legs (host I420 in through kvz_api->encoder_encode, decoded I420 out into host memory)")
     ap.add_argument("--host-io", action="store_true", help="profiling aid: the MAIN run goes through the host boundary (then `value` is the host-boundary rate and no separate leg is run)")
-    ap.add_argument("--streams-per-gpu", default="", help="comma-separated K, e.g. 2,4: K independent streams at once on the one GPU, each with its own filter chain in this process (aggregate frames/s); off by default: "
+    ap.add_argument("--streams-per-gpu", default="2,4", help="comma-separated K, e.g. 2,4: K independent streams at once on the one GPU, each with its own filter chain in this process (aggregate frames/s); off by default: "
                          "with HIP's four hardware queues per priority level the streams of several pipelines share queues and serialise (DESIGN.md section 6; GPU_MAX_HW_QUEUES=8 lifts two streams from 3100 to 5700 frames/s)")
     ap.add_argument("--custom", action="append", default=[], metavar="KEY=VALUE", help="extra kvazaar option for the encoder of every leg (uvgComm's custom-parameter list, kvazaarfilter.cpp:355-368), e.g. --custom intra-in-p=1")
     ap.add_argument("--no-preset-line", action="store_true", help="skip the `default_mode` line: uvgComm's own default encoder settings for this size (defaultsettings.cpp:287-316: preset veryfast, 1 Mbit/s) instead of the benchmark's fixed-QP ultrafast")

@@ -236,6 +236,14 @@ class Decoder {
   int append_segment_tiles(PicJob &job, size_t bitpos, const uint8_t *rbsp, size_t len, const DecPps &p, const DecPps &pp, int wc, int hc, int address);
   int append_segment(PicJob &job, size_t bitpos, const uint8_t *rbsp, size_t len, const DecPps &p, const DecPps &pp, int wc, int hc, int address, int64_t pts);
   std::deque<OwnedPic> ready_q_; OwnedPic cur_owned_;       // pictures completed ahead of their turn (resolution change), the one last handed out
+  // Frame memory handed out by get_picture stays valid while kOutHold further NAL units are decoded -- a caller may copy it out on a stage of its
+  // own (OpenHEVCFilter's output thread) -- also across a resolution change: the host output buffers and the owned pictures that such a change
+  // retires are only freed kOutHold calls later.
+  static constexpr int kOutHold = 8;
+  long nal_calls_ = 0;
+  std::deque<std::pair<long, uint8_t *>> retired_out_;      // (call count at retirement, page-locked buffer)
+  std::deque<std::pair<long, OwnedPic>> retired_owned_;
+  void free_retired(bool all);
   int decode_nal_inner(const uint8_t *data, size_t len, int64_t pts);
   bool queue_current_output();
   std::unique_ptr<FrameWorkers> workers_;

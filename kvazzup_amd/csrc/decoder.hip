@@ -822,6 +822,7 @@ Decoder::~Decoder()
   if (h_err_ && *h_err_) fprintf(stderr, "kvazzup_amd: decoder device error flags 0x%x (last picture)\n", *h_err_);
   for (auto &j : jobs_) { for (auto &e : j.ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); } if (j.done) hipEventDestroy(j.done); if (j.dl_done) hipEventDestroy(j.dl_done); }
   free_buffers();
+  free_retired(true);
   for (auto &o : ready_q_) if (o.dev) hipFree(o.dev);
   if (cur_owned_.dev) hipFree(cur_owned_.dev);
   if (stream_dl_ != stream_up_) stream_release(stream_dl_, device_, 'L', 'l');
@@ -870,7 +871,7 @@ void Decoder::free_buffers()
 {
   for (auto &j : jobs_) { if (j.h_in) hipHostFree(j.h_in); j.h_in = nullptr; j.h_in_cap = 0; j.col.reset(); j.own.reset(); }
   if (stream_dl_) hipStreamSynchronize(stream_dl_);
-  for (auto &p : h_out_) { if (p) hipHostFree(p); p = nullptr; }
+  for (auto &p : h_out_) { if (p) retired_out_.emplace_back(nal_calls_, p); p = nullptr; }      // (freed kOutHold calls later: free_retired)
   for (auto &p : d_in_) { hipFree(p); p = nullptr; }
   for (auto &c : d_in_cap_) c = 0;
   hipFree(progress_); hipFree(edge_col_); edge_col_ = nullptr; hipFree(intra_order_); intra_order_ = nullptr;
@@ -908,7 +909,7 @@ bool Decoder::ensure_buffers(int w, int h)
   if (w == w_ && h == h_) return true;
   // Resolution change (a new SPS took effect at this IRAP picture): what the ring still holds is completed now and queued -- the
   // following calls hand it out one picture at a time, as a software decoder's bumping process would -- before the buffers go
-  while (w_ && (gpu_job_ || !gpu_q_.empty() || job_tail_ != job_head_)) {
+  while (w_ && (!gpu_q_.empty() || job_tail_ != job_head_)) {      // (a band decoder's picture between its reconstruction and band_finish -- gpu_job_ -- is not finish_oldest's to complete: drop_pending below lets it go)
     const int rc = finish_oldest();
     if (rc < 0 || (rc > 0 && pic_ready_ && !queue_current_output())) { drop_pending(); break; }
   }
@@ -987,13 +988,22 @@ void Decoder::get_kernel_times(double *ms, uint64_t *launches, bool reset)
 // One picture out per call at most (the libOpenHevcDecode contract).  Pictures that were completed ahead of their turn -- the ring's
 // contents at a resolution change -- are handed out first, one per call, in order; a picture this call itself completes meanwhile joins
 // the end of that queue.
+void Decoder::free_retired(bool all)
+{
+  while (!retired_out_.empty() && (all || nal_calls_ - retired_out_.front().first > kOutHold)) { hipHostFree(retired_out_.front().second); retired_out_.pop_front(); }
+  while (!retired_owned_.empty() && (all || nal_calls_ - retired_owned_.front().first > kOutHold)) { if (retired_owned_.front().second.dev) hipFree(retired_owned_.front().second.dev); retired_owned_.pop_front(); }
+}
+
 int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
 {
+  nal_calls_++;
+  if (!retired_out_.empty() || !retired_owned_.empty()) free_retired(false);
   const int rc = decode_nal_inner(data, len, pts);
   if (ready_q_.empty()) return rc;
   if (rc < 0) return rc;
   if (pic_ready_ && !queue_current_output()) return last_error_ = DEC_ERR_GPU;
-  if (cur_owned_.dev) { hipFree(cur_owned_.dev); cur_owned_.dev = nullptr; }
+  if (cur_owned_.dev || !cur_owned_.host.empty()) retired_owned_.emplace_back(nal_calls_, std::move(cur_owned_));      // (the caller may still be copying it out)
+  cur_owned_ = OwnedPic();
   cur_owned_ = std::move(ready_q_.front());
   ready_q_.pop_front();
   out_ = cur_owned_.pic;
@@ -1613,7 +1623,7 @@ void Decoder::describe_output(const PicJob &job, DecodedPicture &o, int buf) con
 // kernels are KNOWN to have finished (the caller has seen job.done): the copy command then carries no dependency, the copy engine takes
 // it at once and nothing waits inside a hardware queue.  (Copies that waited on an event in the stream were executed by the runtime as
 // blit kernels, four per picture with a barrier each; a kernel that stores across PCIe -- tried too -- slows every kernel running beside it
-// by a factor of two to ten, tools: scratch/pcie4.hip.  The copy engine disturbs nothing.)
+// by a factor of two to ten, tools/measure/pcie_copy_vs_kernels.hip.  The copy engine disturbs nothing.)
 int Decoder::queue_download(PicJob &job)
 {
   job.dl_buf = (int)(job.launch_idx % kOutRing);

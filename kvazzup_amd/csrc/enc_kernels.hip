@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256) void k_inter_signal(EncFrame f)
 // packed pair.  Quantisation and dequantisation are the epilogue of the second forward stage, the
 // reconstruction is the epilogue of the last inverse stage.
 // =============================================================================================
-#ifdef KVZ_PROF     // scratch/intra_bench.hip: cycle attribution inside the chain (never defined in the product build)
+#ifdef KVZ_PROF     // tools/intra_prof.py: cycle attribution inside the chain (never defined in the product build)
 __shared__ long long g_prof[16];
 #define PROF(k) do { if (threadIdx.x == 0) { long long t_ = clock64(); g_prof[k] += t_ - g_prof[15]; g_prof[15] = t_; } } while (0)
 #else

@@ -299,7 +299,7 @@ void Encoder::get_kernel_times(double *ms, uint64_t *launches, bool reset)
 // run; the input stage of picture t (stream_in_) waits for that copy.  The ring is longer than the pictures that can be in flight, so the
 // buffer's previous reader (the input stage of picture t - kInRing) has long finished and the copy command carries no dependency: the copy
 // engine takes it at once.  (A copy waiting inside the engine's queue holds up every copy behind it, the decoder's included; the input
-// kernel reading the host picture itself across PCIe -- tried -- slows the kernels running beside it 2-10x, scratch/pcie4.hip.)
+// kernel reading the host picture itself across PCIe -- tried -- slows the kernels running beside it 2-10x, tools/measure/pcie_copy_vs_kernels.hip.)
 // Nothing here waits on the calling thread except a staging buffer coming free (callers without page-locked planes).
 bool Encoder::upload_and_submit(const uint8_t *y, const uint8_t *u, const uint8_t *v, bool pinned)
 {
@@ -387,9 +387,10 @@ void Encoder::submitter()
       std::unique_lock<std::mutex> l(sm_);
       sbusy_ = false; scv_.notify_all();
       scv_.wait(l, [&] { return squit_ || !sq_.empty(); });
-      if (sq_.empty()) return;
+      if (squit_ || sq_.empty()) return;               // (closing: what is still queued reads caller pictures that may be gone -- it is dropped, nobody collects it)
       j = std::move(sq_.front()); sq_.pop_front(); sbusy_ = true;
     }
+    const long before = submitted_;
     roi_sub_.swap(j.roi); roi_sub_w_ = j.roi_w; roi_sub_h_ = j.roi_h;
     tl("sub0", submitted_);
     const size_t ny = (size_t)cfg_.width * cfg_.height;
@@ -398,6 +399,7 @@ void Encoder::submitter()
     else { Tick tk; ok = submit(j.src, -1); t_submit_ += tk.ms(); in_pending_ = false; }
     tl("sub1", submitted_ - 1);
     if (!ok) {                                       // nothing was queued for this picture: its slot reports the failure
+      if (submitted_ == before) submitted_++;        // (the slots are numbered by pictures accepted: a picture that failed still took its turn)
       { std::lock_guard<std::mutex> l(bm_); slot_[j.slot].ok = false; slot_[j.slot].ready = true; }
       bcv_.notify_all();
     }

@@ -93,13 +93,16 @@ class OrderedPool {
   void run(int n, const std::function<void(int)> &fn)
   {
     while (active_.load(std::memory_order_acquire) != 0) std::this_thread::yield();   // stragglers of the previous job
+    // A helper woken for the previous job may not have counted itself into active_ yet.  The task counter is therefore made invalid first:
+    // whatever such a helper fetches before the new job is published lies beyond any total, and it is published (next_ = 0) last.
+    next_.store(1 << 30, std::memory_order_release);
     fn_ = &fn;
     done_.store(0, std::memory_order_relaxed);
     total_.store(n, std::memory_order_relaxed);
     next_.store(0, std::memory_order_release);
     if (n > 1 && !workers_.empty()) { { std::lock_guard<std::mutex> l(m_); gen_++; } cv_.notify_all(); }
     drain();
-    for (int d; (d = done_.load(std::memory_order_acquire)) != n;) futex_wait(done_, d);      // (the worker that finishes the last task wakes it)
+    for (int d; (d = done_.load(std::memory_order_acquire)) < n;) futex_wait(done_, d);      // (the worker that finishes the last task wakes it)
   }
 
  private:
@@ -158,6 +161,7 @@ class CopyPool {
   {
     if (workers_.empty() || pieces.size() < 2) { for (const Piece &p : pieces) one(p); return; }
     while (active_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();      // stragglers of the previous job
+    next_.store(1 << 30, std::memory_order_release);                                   // (as in OrderedPool::run: invalid until the new job is published)
     job_ = &pieces;
     done_.store(0, std::memory_order_relaxed);
     total_.store((int)pieces.size(), std::memory_order_relaxed);
@@ -165,7 +169,7 @@ class CopyPool {
     gen_.fetch_add(1, std::memory_order_acq_rel); futex_wake_all(gen_);
     drain();
     const int n = (int)pieces.size();
-    for (int spins = 0; done_.load(std::memory_order_acquire) != n; spins++) { if (spins < 4000) __builtin_ia32_pause(); else std::this_thread::yield(); }
+    for (int spins = 0; done_.load(std::memory_order_acquire) < n; spins++) { if (spins < 4000) __builtin_ia32_pause(); else std::this_thread::yield(); }
   }
 
  private:

@@ -17,6 +17,7 @@ def _bind(lib):
     lib.uvgx_pipeline_push_device_paced.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint32, C.c_int]
     lib.uvgx_pipeline_push_host_paced.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint32, C.c_int, C.c_int]
     lib.uvgx_pipeline_flush.argtypes = [C.c_void_p]
+    lib.uvgx_pipeline_push_encoded.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int64, C.c_uint32, C.c_int]
     lib.uvgx_pipeline_encoder_backlog.restype = C.c_uint32
     lib.uvgx_pipeline_encoder_backlog.argtypes = [C.c_void_p]
     lib.uvgx_pipeline_pop_encoded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int64)]
@@ -82,6 +83,13 @@ class Pipeline:
         ok = self.lib.uvgx_pipeline_push_host_paced(self.p, i420.ctypes.data, self.w, self.h, self.fps[0], self.fps[1], self.pushed if pts is None else pts, max_backlog, timeout_ms, int(borrow))
         self.pushed += 1 if ok else 0
         return bool(ok)
+
+    def push_encoded(self, au, pts=0, max_backlog=40, timeout_ms=60000):
+        """an access unit straight into the receiving side (WireAdapter -> OpenHEVCFilter), as a peer's stream arrives; None = flush marker"""
+        if au is None:
+            return bool(self.lib.uvgx_pipeline_push_encoded(self.p, None, 0, 0, 0, 0))
+        au = bytes(au)
+        return bool(self.lib.uvgx_pipeline_push_encoded(self.p, au, len(au), pts, max_backlog, timeout_ms))
 
     def flush(self):
         """everything pushed so far comes out without further input (harness only); the next picture pushed should be an IDR"""

@@ -63,6 +63,34 @@ def test_decoder_follows_a_resolution_change(gpu, threads, frame):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 6])
+def test_resolution_change_through_the_filter_with_its_output_stage(gpu, threads):
+    """the same mid-call resolution changes through OpenHEVCFilter' with its asynchronous output stage (uvgx/asyncOutput = 1: pictures are copied
+    out of the decoder's frame memory on a thread of their own while later NAL units are already being decoded): frame memory a resolution
+    change retires -- the host output buffers, the pictures completed ahead of their turn -- must stay valid until the copies are done"""
+    from kvazzup_amd.codec import Encoder
+    from kvazzup_amd.pipeline import Pipeline
+    pl = Pipeline(640, 384, settings={"video/OPENHEVC_threads": threads, "video/OH_parallelization": "Frame" if threads > 1 else "Slice", "uvgx/asyncOutput": 1})
+    want, t = [], 0
+    for rep in range(3):
+        for (w, h) in ((320, 192), (640, 384), (200, 120)):
+            ge = Encoder(w, h, options=(("qp", 30), ("period", 64), ("me-range", 8)))
+            for k in range(4):
+                au, rec = ge.encode(orc.synth_frame(0, SEED + w + rep, w, h, k))
+                want.append((w, h, rec))
+                assert pl.push_encoded(au, t)
+                t += 1
+            ge.close()
+    pl.push_encoded(None)
+    assert pl.wait(len(want), 120000), pl.stats()
+    for i, (w, h, rec) in enumerate(want):
+        g = pl.pop_decoded()
+        assert g is not None and (g["width"], g["height"], g["pts"]) == (w, h, i), (i, g and (g["width"], g["height"], g["pts"]))
+        assert np.array_equal(g["i420"], rec), i
+    pl.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [
     dict(w=128, h=64, frames=2, qp=32, period=1, me_range=8, kind=0),
     dict(w=256, h=192, frames=5, qp=32, period=64, me_range=16, kind=0),

@@ -1,12 +1,12 @@
 #!/bin/bash
 # the host-boundary leg under the kernel + memory-copy trace: how long the PCIe copies take beside the kernels, and what each queue does
-# tools/gpu_hosttrace.sh <workload>
+# tools/gpu_hosttrace.sh <workload | enconly | deconly>   (enconly / deconly: tools/measure/encoder_only.py / decoder_only.py, host pictures)
 R=${GRAFT_REPO_ROOT:-$PWD}; wl=${1:-1080p}
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/htr
 if [ "$wl" = "enconly" ]; then
-HOST_ONLY=1 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/htr -o p -- python3 $R/scratch/enconly.py > /tmp/htr.log 2>&1
-elif [ "$wl" = "notorch" ]; then
-HOST_ONLY=1 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/htr -o p -- python3 $R/scratch/notorch.py > /tmp/htr.log 2>&1
+HOST_ONLY=1 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/htr -o p -- python3 $R/tools/measure/encoder_only.py > /tmp/htr.log 2>&1
+elif [ "$wl" = "deconly" ]; then
+HOST_ONLY=1 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/htr -o p -- python3 $R/tools/measure/decoder_only.py > /tmp/htr.log 2>&1
 else
 KVAZZUP_BENCH_NOPROF=1 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/htr -o p -- python3 $R/bench.py --workload $wl --host-io --no-cpu-baseline --no-secondary --steps 3 --warmup 1 --repeats 1 > /tmp/htr.log 2>&1
 fi

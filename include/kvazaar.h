@@ -124,7 +124,7 @@ typedef struct kvz_config {
   int32_t band_row0, band_rows; /* "band-row0", "band-rows": tile-row split over several encoders (kvazzup_amd.h, kvzx_encoder_band_*); 0 rows = whole picture */
   int32_t input_hold;         /* "input-hold": 1 = the caller leaves a DEVICE input picture (kvzx_encoder_encode_device) unchanged until that picture's access unit has come back, as the kvz_picture contract demands of host pictures; the call then returns without waiting for the input stage (0, default: the buffer may be reused when the call returns) */
   int32_t null_input_poll;    /* "null-input": "drain" (default, Kvazaar's meaning: encoder_encode with pic_in == NULL waits for the oldest picture in flight) or "poll" (it returns a picture only if one has already been finished and never waits: what the loop at kvazaarfilter.cpp:440-448 needs to keep video/OWF pictures in flight instead of emptying the pipeline after every picture) */
-  int32_t intra_in_p;         /* "intra-in-p": intra coding units in P pictures ("uvgx intra-in-P v1": a 16x16 quarter whose motion-search cost is high is priced as an intra block from the source picture and coded intra when that is cheaper -- scene cuts, uncovered background); under rate control v2 the row groups are priced without the intra units' levels; ignored in band mode */
+  int32_t intra_in_p;         /* "intra-in-p" 0 / 1 / 2: intra coding units in P pictures, 1 = 16x16 units only (presets superfast .. fast), 2 = 16x16 and 8x8 units (medium and slower) ("uvgx intra-in-P v1": a 16x16 quarter whose motion-search cost is high is priced as an intra block from the source picture and coded intra when that is cheaper -- scene cuts, uncovered background); under rate control v2 the row groups are priced without the intra units' levels; ignored in band mode */
   int32_t gpu_entropy;        /* "gpu-entropy": 1 = the arithmetic coder runs on the GPU too (k_cabac_rows: no host coder threads, 2-4 ms more latency per picture), 0 (default) = host thread pool sized by "threads" */
 } kvz_config;
 

@@ -37,7 +37,7 @@
 namespace kvzx {
 
 // DK_HOST_PARSE is not a kernel: wall time of the host CABAC parsing stage
-enum DecKernelId { DK_INTER = 0, DK_INTRA, DK_DEBLOCK, DK_HOST_PARSE, DK_SAO, DK_COUNT };
+enum DecKernelId { DK_INTER = 0, DK_INTRA, DK_DEBLOCK, DK_HOST_PARSE, DK_SAO, DK_INTRA_P, DK_COUNT };      // (DK_INTRA_P: the intra blocks of a picture that also has inter blocks)
 
 // short-term reference picture set (7.4.8): negative deltas first (closest first), then positive ones
 struct StRps { int n_neg = 0, n_pos = 0; int dpoc[16]; uint8_t used[16]; };

@@ -1908,7 +1908,7 @@ int Decoder::launch_gpu(PicJob &job)
   if (dpb_[job.slot].last_dl) { if (hipStreamWaitEvent(stream_, dpb_[job.slot].last_dl, 0) != hipSuccess) return DEC_ERR_GPU; dpb_[job.slot].last_dl = nullptr; }
   if (job.any_inter) timed(DK_INTER, [&] { launch_dec_inter(f, stream_); });
   if (job.any_intra) {
-    timed(DK_INTRA, [&] { launch_dec_intra_resid(f, stream_); launch_dec_intra(f, stream_); });
+    timed(job.any_inter ? DK_INTRA_P : DK_INTRA, [&] { launch_dec_intra_resid(f, stream_); launch_dec_intra(f, stream_); });
   }
   if (band_nrows_ > 0) { band_f_ = f; band_din_ = d_in_; }       // deblocking follows the halo exchange (band_deblock)
   else if (!job.sh.deblock_disabled) timed(DK_DEBLOCK, [&] { launch_dec_deblock(f, stream_); });

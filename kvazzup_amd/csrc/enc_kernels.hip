@@ -910,8 +910,9 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
   __syncthreads();
   // ---- cost of every (block, mode): 8x8 Hadamard sums, (sum + 2) >> 2 per 8x8 block (oracle/hevc_enc.c satd_block()), or SADs
   if (f.satd) {
-    for (int j = wave; j < (PP ? 35 * 2 : 4 * 35 * 2); j += NW) {
-      const int item = PP ? ((j >> 1) << 3) | (mytile << 1) | (j & 1) : j;
+    const bool no8 = PP && f.intra_p == 1;                          // intra-in-p = 1: 16x16 intra units only -- the 8x8 blocks are not priced
+    for (int j = wave; j < (PP ? (no8 ? 35 : 35 * 2) : 4 * 35 * 2); j += NW) {
+      const int item = PP ? (no8 ? (j << 3) | (mytile << 1) : ((j >> 1) << 3) | (mytile << 1) | (j & 1)) : j;
       const int kind = item & 1, tile = (item >> 1) & 3, mode = item >> 3;
       uint32_t q[4];
       analyse_tile_satd(s, tile, kind, mode, lane, q);
@@ -924,9 +925,10 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
       }
     }
   } else
-  for (int j = wave; j < (PP ? 5 * 35 : 20 * 35); j += NW) {
+  for (int j = wave; j < (PP ? (f.intra_p == 1 ? 35 : 5 * 35) : 20 * 35); j += NW) {
     int b = j / 35; const int mode = j - b * 35;
-    if (PP) b = b < 4 ? (mytile >> 1) * 8 + (mytile & 1) * 2 + (b >> 1) * 4 + (b & 1) : 16 + mytile;      // the quarter's four 8x8 blocks and its 16x16 block
+    if (PP && f.intra_p == 1) b = 16 + mytile;
+    else if (PP) b = b < 4 ? (mytile >> 1) * 8 + (mytile & 1) * 2 + (b >> 1) * 4 + (b & 1) : 16 + mytile;      // the quarter's four 8x8 blocks and its 16x16 block
     uint32_t c;
     if (b < 16) c = analyse_item<3>(s, b, (b & 3) * 8, (b >> 2) * 8, mode, lane);
     else c = analyse_item<4>(s, b, ((b - 16) & 1) * 16, ((b - 16) >> 1) * 16, mode, lane);
@@ -967,7 +969,7 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
     for (int k = 0; k < 4; k++) {
       uint32_t c8 = pen;
       for (int j = 0; j < 4; j++) c8 += s.bestc[((k >> 1) * 2 + (j >> 1)) * 4 + (k & 1) * 2 + (j & 1)];
-      split16[k] = c8 < s.bestc[16 + k];
+      split16[k] = !(PP && f.intra_p == 1) && c8 < s.bestc[16 + k];
       if (PP) {                                                  // intra-in-P: the quarter goes intra when that is cheaper than what the search found
         const uint32_t cintra = (split16[k] ? c8 : s.bestc[16 + k]) + (((uint32_t)f.lambda_q4 * INTRA_P_BITS) >> 4);
         cand[k] = cand[k] && cintra < icost[k];
@@ -1302,6 +1304,38 @@ __global__ __launch_bounds__(256) void k_qp_chain(EncFrame f)                // 
   if (!have) qy = prev;
   f.ctu_qy[ctu] = (int8_t)qy;
   f.ctu_delta[ctu] = (int8_t)(have ? qy - prev : 0);
+}
+
+// The two kernels above as ONE launch where the chain of a CTU never leaves its CTU row -- WPP (uvgComm's default, kvazaarfilter.cpp:194): the QpY prediction
+// restarts with the slice QP at every CTU row of a tile.  A workgroup per CTU row: its waves find the rows' first coded units (one CTU per wave at a time), then
+// a thread per CTU walks back along the row inside its tile.  Same results as k_qp_first + k_qp_chain (the launch is one of ten on a P picture's chain in
+// uvgComm's default mode, each worth ~6 us whatever it does).
+__global__ __launch_bounds__(256) void k_qp_rows(EncFrame f)
+{
+  __shared__ uint8_t first_s[256];                           // (a CTU row: at most 16384 / 64 CTUs)
+  const int wc = f.cw >> 6, cy = blockIdx.x + f.row0, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int xi, yi; ctu_z_to_xy(lane, xi, yi);
+  for (int cx = wave; cx < wc; cx += 4) {
+    const int x = cx * 64 + xi * 8, y = cy * 64 + yi * 8, bi = b8idx(f, x, y), n = 1 << f.cu_log2[bi];
+    const bool coded_origin = !((x | y) & (n - 1)) && f.cu_cbf[bi] != 0;
+    const uint64_t m = __ballot(coded_origin);
+    if (lane == 0) { const uint8_t v = (uint8_t)(m ? __builtin_ctzll(m) : 64); first_s[cx] = v; f.ctu_first[cy * wc + cx] = v; }
+  }
+  __syncthreads();
+  for (int cx = threadIdx.x; cx < wc; cx += 256) {
+    const int ctu = cy * wc + cx;
+    const int tc = tile_col_of(wc, f.tile_cols, cx), cx0 = tile_col_first(wc, f.tile_cols, tc);
+    int qy = f.qp, prev = f.qp; bool have = false;
+    for (int x = cx; x >= cx0; x--) {
+      if (first_s[x] < 64) {
+        if (x == cx) { qy = f.ctu_qt[ctu]; have = true; }
+        else { prev = f.ctu_qt[cy * wc + x]; break; }
+      }
+    }
+    if (!have) qy = prev;
+    f.ctu_qy[ctu] = (int8_t)qy;
+    f.ctu_delta[ctu] = (int8_t)(have ? qy - prev : 0);
+  }
 }
 
 // =============================================================================================
@@ -2102,6 +2136,7 @@ void launch_qp_resolve(const EncFrame &f, hipStream_t st)
 {
   if (!f.ctu_qy) return;
   const int n = (f.cw / 64) * band_rows(f);
+  if (f.wpp && f.cw / 64 <= 256) { hipLaunchKernelGGL(k_qp_rows, dim3(band_rows(f)), dim3(256), 0, st, f); return; }
   hipLaunchKernelGGL(k_qp_first, dim3(n), dim3(64), 0, st, f);
   hipLaunchKernelGGL(k_qp_chain, dim3((n + 255) / 256), dim3(256), 0, st, f);
 }

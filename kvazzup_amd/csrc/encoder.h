@@ -19,7 +19,7 @@
 namespace kvzx {
 
 // K_HOST_ARITH is not a kernel: wall time of the host arithmetic-coding stage (entropy_host.h)
-enum KernelId { K_PAD = 0, K_ME, K_INTER_RECON, K_INTER_SIGNAL, K_INTRA_ANALYSE, K_INTRA_RECON, K_DEBLOCK, K_TOKENIZE, K_HOST_ARITH, K_SAO, K_TOK_COMPACT, K_CABAC_ROWS, K_SUBPEL, K_COUNT };
+enum KernelId { K_PAD = 0, K_ME, K_INTER_RECON, K_INTER_SIGNAL, K_INTRA_ANALYSE, K_INTRA_RECON, K_DEBLOCK, K_TOKENIZE, K_HOST_ARITH, K_SAO, K_TOK_COMPACT, K_CABAC_ROWS, K_SUBPEL, K_INTRA_ANALYSE_P, K_INTRA_RECON_P, K_COUNT };      // (.._P: the intra units of a P picture, intra-in-p)
 
 struct EncoderConfig {
   int width = 0, height = 0;
@@ -48,7 +48,7 @@ struct EncoderConfig {
   int input_hold = 0;         // "input-hold" (extension): 1 = the caller leaves a DEVICE input picture unchanged until that picture's access unit has been returned --
                               // what the kvz_api contract already demands of host pictures (kvazaarfilter.cpp:76-88); encode_device then returns without waiting for the input stage
   int rdoq = 0;               // kvazaar "rdoq": "uvgx RDOQ v1" -- sparse high-frequency coefficient groups are dropped when that is cheaper (oracle/hevc_transform.h orc_adjust_levels)
-  int intra_in_p = 0;         // "intra-in-p": intra coding units in P pictures ("uvgx intra-in-P v1", oracle/hevc_enc.c me_block32); not in band mode
+  int intra_in_p = 0;         // "intra-in-p" 0 / 1 (16x16 units only) / 2 (16x16 and 8x8): intra coding units in P pictures ("uvgx intra-in-P v1", oracle/hevc_enc.c me_block32); not in band mode
   int signhide = 0;           // kvazaar "signhide": sign_data_hiding_enabled_flag; the quantiser makes the parity of every eligible coefficient group say the hidden sign
   int hash = 0;               // kvazaar "hash": 1 checksum, 2 md5 -- a decoded picture hash SEI (D.2.19) behind every picture's slices, from the reconstruction downloaded for it
   int entropy_gpu = 0;        // arithmetic coder: 1 = on the GPU (k_cabac_rows, cabac_kernels.hip), 0 = host thread pool (entropy_host.h); band mode always uses the host pool
@@ -157,9 +157,12 @@ class Encoder {
   std::vector<int8_t> roi_; int roi_w_ = 0, roi_h_ = 0;           // as set by the caller (set_roi)
   std::vector<int8_t> roi_sub_; int roi_sub_w_ = 0, roi_sub_h_ = 0;   // the map of the picture being submitted (it travels with the picture to the submitter thread)
   int8_t *ctu_qt_[kSets] = {}, *ctu_qy_[kSets] = {}, *ctu_delta_[kSets] = {}; uint8_t *ctu_first_[kSets] = {};   // per set
-  int8_t *h_ctu_qt_[kSets] = {};   // pinned staging of the target map
+  int8_t *h_ctu_qt_[kSets] = {};   // pinned staging of the picture's ROI deltas, one per CTU
+  int8_t *ctu_roi_[kSets] = {};    // ... and their device copies (uploaded on the input stream when the picture brings a map)
+  bool stage_roi(hipStream_t st);  // the picture's ROI deltas -> ctu_roi_[set_] on `st`; roi_dev_ = that array or NULL (no map)
+  const int8_t *roi_dev_ = nullptr;
   int *vaq_act_ = nullptr, *vaq_sum_ = nullptr; // VAQ: activity of every CTU, its sum over the picture
-  bool upload_qp_targets();
+  bool picture_begin();            // launch_picture_begin on the main stream (+ the VAQ kernels)
   int qp_cur_ = 0; int64_t rc_debt_ = 0; uint32_t rc_bytes_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t rc_known_ = 0;   // rate control state (calling thread)
   void rate_control();
   RcState *rc_state_ = nullptr;                 // rate control v2: device-side state

@@ -11,6 +11,11 @@
 
 namespace kvzx {
 
+// Events that only order this library's streams among themselves (never waited for or queried by the host): no system-scope fence when they complete --
+// the default makes every record write back and invalidate the caches for the host's benefit, a bubble of its own in a chain of 10-50 us kernels.
+// KVAZZUP_AMD_EVENT_FENCE=1 restores the default (measurement aid).
+static const unsigned kDeviceEvent = hipEventDisableTiming | (getenv("KVAZZUP_AMD_EVENT_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
+
 #define HIP_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { if (error) *error = std::string(#expr) + ": " + hipGetErrorString(e_); return false; } } while (0)
 #define HIP_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "kvazzup_amd: %s failed: %s\n", #expr, hipGetErrorString(e_)); return false; } } while (0)
 
@@ -84,26 +89,27 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     HIP_OK(hipMalloc(&cu_bytes_[k], nb8 * 7)); HIP_OK(hipMemset(cu_bytes_[k], 0, nb8 * 7));
     HIP_OK(hipMalloc(&cu_mv_[k], nb8 * 2 * sizeof(int16_t))); HIP_OK(hipMemset(cu_mv_[k], 0, nb8 * 2 * sizeof(int16_t)));
     HIP_OK(hipMalloc(&cu_mvd_[k], nb8 * 2 * sizeof(int16_t))); HIP_OK(hipMemset(cu_mvd_[k], 0, nb8 * 2 * sizeof(int16_t)));
-    HIP_OK(hipEventCreateWithFlags(&ev_tok_done_[k], hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ev_tok_done_[k], kDeviceEvent));
   }
   if (cfg.qp_in_cu) {
     const size_t nctu = (size_t)(cw_ / 64) * rows_;
     for (int k = 0; k < kSets; k++) {
       HIP_OK(hipMalloc(&ctu_qt_[k], nctu)); HIP_OK(hipMalloc(&ctu_qy_[k], nctu)); HIP_OK(hipMalloc(&ctu_delta_[k], nctu)); HIP_OK(hipMalloc(&ctu_first_[k], nctu));
       HIP_OK(hipHostMalloc(&h_ctu_qt_[k], nctu, hipHostMallocDefault));
+      HIP_OK(hipMalloc(&ctu_roi_[k], nctu));
     }
     if (cfg.vaq > 0) { HIP_OK(hipMalloc(&vaq_act_, nctu * sizeof(int))); HIP_OK(hipMalloc(&vaq_sum_, sizeof(int))); }
   }
   if (cfg.sao) {
     for (int c = 0; c < 3; c++) HIP_OK(hipMalloc(&work_[c], c ? npx / 4 : npx));
     for (int k = 0; k < kSets; k++) HIP_OK(hipMalloc(&sao_[k], sizeof(SaoParams) * (size_t)(cw_ / 64) * rows_));
-    HIP_OK(hipEventCreateWithFlags(&ev_sao_, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ev_sao_, kDeviceEvent));
   }
   if (cfg.rc_bands > 0) { HIP_OK(hipMalloc(&rc_state_, sizeof(RcState))); HIP_OK(hipMemset(rc_state_, 0, sizeof(RcState))); }
   HIP_OK(stream_acquire(&stream_tok_, cfg.device, 'T', prio_[1]));
   HIP_OK(stream_acquire(&stream_in_, cfg.device, 'I', prio_[2]));
-  for (int k = 0; k < kSets; k++) HIP_OK(hipEventCreateWithFlags(&ev_src_free_[k], hipEventDisableTiming));
-  HIP_OK(hipEventCreateWithFlags(&ev_signalled_, hipEventDisableTiming));
+  for (int k = 0; k < kSets; k++) HIP_OK(hipEventCreateWithFlags(&ev_src_free_[k], kDeviceEvent));
+  HIP_OK(hipEventCreateWithFlags(&ev_signalled_, kDeviceEvent));
   // the intra pictures' own stream: where the chain shares nothing with the P pictures' kernels (no SAO work picture, no intra units in P pictures
   // -- they use the same progress counters --, no per-CTU QP upload, no row groups) and pictures are queued ahead at all
   idr_side_ = depth_ >= 2 && !cfg.sao && !cfg.intra_in_p && !cfg.qp_in_cu && cfg.rc_bands == 0 && cfg.band_rows == 0 && !getenv("KVAZZUP_AMD_IDR_INLINE");
@@ -113,7 +119,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     // measured with a stream of its own: no gain at the default level, half the rate at any other -- KVAZZUP_AMD_IDR_PRIO)
     const char *lv = getenv("KVAZZUP_AMD_IDR_PRIO");
     if (lv) HIP_OK(stream_acquire(&stream_idr_, cfg.device, 'X', lv[0])); else stream_idr_ = stream_in_;
-    HIP_OK(hipEventCreateWithFlags(&ev_idr_done_, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ev_idr_done_, kDeviceEvent));
   }
   // intra scratch: ic8 (nb8 u32) | ic16 (nb8/4 u32) | ic32 (nb8/16 u32) | im8 | im16 | im32
   size_t isz = nb8 * 4 + nb8 + nb8 / 4 + nb8 + nb8 / 4 + nb8 / 16 + 64;
@@ -160,7 +166,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&sl.rec_done, hipEventDisableTiming));
   }
-  HIP_OK(hipEventCreateWithFlags(&in_done_, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&in_done_, kDeviceEvent));
   HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 2))); HIP_OK(hipMemset(sync_, 0, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 2)));       // one progress counter per CTU and colour plane, and the ticket counter of k_intra_recon's workgroups
   if (cfg.intra_in_p) { const size_t n16 = (size_t)(cw_ / 16) * (ch_ / 16); HIP_OK(hipMalloc(&me_cost16_, sizeof(uint32_t) * (n16 + 2 + n16 / 4 + n16 / 4 + (n16 / 4) * 40))); HIP_OK(hipMemset(me_cost16_, 0, sizeof(uint32_t) * (n16 + 2 + n16 / 4 + n16 / 4 + (n16 / 4) * 40))); }      // k_me's inter cost per 16x16 block (intra-in-P)
   {
@@ -255,7 +261,7 @@ Encoder::~Encoder()
   stream_release(stream_rec_, cfg_.device, 'R', 'n');
   for (int c = 0; c < 3; c++) { for (int k = 0; k < kSets; k++) { hipFree(src_[k][c]); hipFree(coef_[k][c]); } for (int b = 0; b < kMaxDepth + 4; b++) hipFree(rec_[b][c]); }
   hipFree(vaq_act_); hipFree(vaq_sum_); hipFree(rc_state_);
-  for (int k = 0; k < kSets; k++) { hipFree(ctu_qt_[k]); hipFree(ctu_qy_[k]); hipFree(ctu_delta_[k]); hipFree(ctu_first_[k]); if (h_ctu_qt_[k]) hipHostFree(h_ctu_qt_[k]); }
+  for (int k = 0; k < kSets; k++) { hipFree(ctu_qt_[k]); hipFree(ctu_qy_[k]); hipFree(ctu_delta_[k]); hipFree(ctu_first_[k]); if (h_ctu_qt_[k]) hipHostFree(h_ctu_qt_[k]); hipFree(ctu_roi_[k]); }
   for (int k = 0; k < kSets; k++) { hipFree(cu_bytes_[k]); hipFree(cu_mv_[k]); hipFree(cu_mvd_[k]); if (ev_tok_done_[k]) hipEventDestroy(ev_tok_done_[k]); }
   for (int c = 0; c < 3; c++) hipFree(work_[c]);
   for (int k = 0; k < kSets; k++) hipFree(sao_[k]);
@@ -443,18 +449,28 @@ void Encoder::set_roi(int w, int h, const int8_t *map)
 }
 
 // target QP of every CTU of the picture being submitted (set set_): host map -> pinned -> device, on stream_
-bool Encoder::upload_qp_targets()
+// Per-CTU quantiser targets (cu_qp_delta): target = clip(picture QP + ROI delta), with VAQ the device adds its own delta.  The ROI deltas of the picture's map
+// (kvz_picture.roi, spread over the CTU grid here) go up on `st` -- the INPUT stream, ahead of the event the main stream waits for anyway -- and only when
+// the picture brings a map; the targets themselves are written by the kernel at the head of the picture's chain (k_picture_begin).  Nothing is copied on
+// the main stream: a 510-byte copy there cost every picture of uvgComm's default mode a ~28 us bubble.
+bool Encoder::stage_roi(hipStream_t st)
 {
-  if (!cfg_.qp_in_cu) return true;
+  roi_dev_ = nullptr;
+  if (!cfg_.qp_in_cu || roi_sub_.empty()) return true;
   const int wc = cw_ / 64, hc = rows_;
   int8_t *h = h_ctu_qt_[set_];
-  for (int cy = 0; cy < hc; cy++) for (int cx = 0; cx < wc; cx++) {
-    int d = 0;
-    if (!roi_sub_.empty()) d = clip3(-12, 12, (int)roi_sub_[(size_t)(cy * roi_sub_h_ / hc) * roi_sub_w_ + (cx * roi_sub_w_ / wc)]);
-    h[cy * wc + cx] = (int8_t)(cfg_.vaq > 0 ? d : clip3(0, 51, qp_cur_ + d));      // with VAQ the device adds its delta and the picture QP
-  }
-  HIP_CHECK(hipMemcpyAsync(ctu_qt_[set_], h, (size_t)wc * hc, hipMemcpyHostToDevice, stream_));
-  if (cfg_.vaq > 0) launch_vaq(f_, cfg_.vaq, vaq_act_, vaq_sum_, stream_);          // (f_.qp, f_.src and f_.ctu_qt of this picture are set; the source is padded: stream_ waits for in_done_)
+  for (int cy = 0; cy < hc; cy++) for (int cx = 0; cx < wc; cx++)
+    h[cy * wc + cx] = (int8_t)clip3(-12, 12, (int)roi_sub_[(size_t)(cy * roi_sub_h_ / hc) * roi_sub_w_ + (cx * roi_sub_w_ / wc)]);
+  HIP_CHECK(hipMemcpyAsync(ctu_roi_[set_], h, (size_t)wc * hc, hipMemcpyHostToDevice, st));
+  roi_dev_ = ctu_roi_[set_];
+  return true;
+}
+bool Encoder::picture_begin()
+{
+  const bool have = frame_idx_ >= rc_delay_;
+  launch_picture_begin(rc_state_, have ? 8u * rc_bytes_[(frame_idx_ - rc_delay_) & 7] : 0u, (frame_idx_ - rc_delay_) & 7, have ? 1 : 0,
+                       cfg_.qp_in_cu ? ctu_qt_[set_] : nullptr, roi_dev_, (cw_ / 64) * rows_, qp_cur_, cfg_.vaq > 0 ? 1 : 0, stream_);
+  if (cfg_.qp_in_cu && cfg_.vaq > 0) launch_vaq(f_, cfg_.vaq, vaq_act_, vaq_sum_, stream_);          // (f_.qp, f_.src and f_.ctu_qt of this picture are set; the source is padded: stream_ waits for in_done_)
   return true;
 }
 
@@ -507,11 +523,11 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     if (tok_pending_[set_]) HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_tok_done_[set_], 0));
     timed(K_INTRA_ANALYSE, stream_in_, [&] { launch_intra_analyse(f, stream_in_); });
   }
+  if (!stage_roi(stream_in_)) return false;
   HIP_CHECK(hipEventRecord(in_done_, stream_in_)); in_pending_ = true;
   HIP_CHECK(hipStreamWaitEvent(ms, in_done_, 0));
   if (tok_pending_[set_]) { HIP_CHECK(hipStreamWaitEvent(ms, ev_tok_done_[set_], 0)); tok_pending_[set_] = false; }   // the tokenizer of the set's previous picture is done with it
-  if (!upload_qp_targets()) return false;
-  if (rc_state_) launch_rc_begin(rc_state_, frame_idx_ >= rc_delay_ ? 8u * rc_bytes_[(frame_idx_ - rc_delay_) & 7] : 0u, (frame_idx_ - rc_delay_) & 7, frame_idx_ >= rc_delay_, stream_);
+  if (!picture_begin()) return false;
   if (intra) {
     HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 1), ms));
     HIP_CHECK(hipMemsetAsync(f_.cu_cbf, 0, (size_t)f_.b8w * f_.b8h, ms));     // the three plane waves OR their bit in
@@ -519,7 +535,7 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   } else {
     timed(K_ME, stream_, [&] { launch_me(f, stream_); });
     // intra-in-P: quarters whose inter cost is high are priced as intra blocks and may become intra units (the launch leaves at once where none is)
-    if (cfg_.intra_in_p) timed(K_INTRA_ANALYSE, stream_, [&] { launch_intra_analyse(f, stream_); });
+    if (cfg_.intra_in_p) timed(K_INTRA_ANALYSE_P, stream_, [&] { launch_intra_analyse(f, stream_); });
     if (cfg_.subme > 0) timed(K_SUBPEL, stream_, [&] { launch_subpel(f, stream_); });
     if (rc_state_) {
       // rate control v2: the CTU rows in groups inside the one launch, the next group's QP decided on the device from the levels of the groups before
@@ -530,20 +546,21 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     } else
     timed(K_INTER_RECON, stream_, [&] { launch_inter_recon(f, stream_); });
     // ... and are reconstructed behind every inter unit (their reference samples may lie in inter units anywhere around them)
-    if (cfg_.intra_in_p) timed(K_INTRA_RECON, stream_, [&] { launch_intra_recon(f, stream_); });
+    if (cfg_.intra_in_p) timed(K_INTRA_RECON_P, stream_, [&] { launch_intra_recon(f, stream_); });
     if (cfg_.intra_in_p && !cfg_.deblock) { HIP_CHECK(hipMemsetAsync(f_.me_cand, 0, sizeof(uint32_t), stream_)); HIP_CHECK(hipMemsetAsync(sync_ + rows_ * (cw_ / 64) * 3 + 1, 0, sizeof(uint32_t), stream_)); }      // (k_deblock_tile does it otherwise)
   }
   launch_qp_resolve(f, ms);                                      // per-CTU QP: which CU carries the delta, QpY for deblocking
-  HIP_CHECK(hipEventRecord(ev_signalled_, ms));                  // levels, cbf and motion of the picture are final
+  // levels, cbf and motion of the picture are final: the tokenizer's stream may start.  With SAO it waits for the filter anyway (the CTUs' SAO parameters
+  // are coded) -- then no event is recorded in the middle of the chain (an event between two kernels of a stream costs the chain ~7 us)
+  if (!cfg_.sao) HIP_CHECK(hipEventRecord(ev_signalled_, ms));
   if (cfg_.deblock) timed(K_DEBLOCK, ms, [&] { launch_deblock(f, ms); });
   if (cfg_.sao) { timed(K_SAO, ms, [&] { launch_sao(f, ms); }); HIP_CHECK(hipEventRecord(ev_sao_, ms)); }
   // Last reader of this set on the main stream: k_sao reads the source picture for its statistics, deblocking the CU records.
   // Input padding and intra analysis of the next picture with this set (input stream) overwrite both and wait for this event.
   HIP_CHECK(hipEventRecord(ev_src_free_[set_], ms)); src_busy_[set_] = true;
   if (side) { HIP_CHECK(hipEventRecord(ev_idr_done_, ms)); idr_pending_ = true; }
-  HIP_CHECK(hipStreamWaitEvent(stream_tok_, ev_signalled_, 0));
+  HIP_CHECK(hipStreamWaitEvent(stream_tok_, cfg_.sao ? ev_sao_ : ev_signalled_, 0));
   if (!intra) timed(K_INTER_SIGNAL, stream_tok_, [&] { launch_inter_signal(f, stream_tok_); });
-  if (cfg_.sao) HIP_CHECK(hipStreamWaitEvent(stream_tok_, ev_sao_, 0));      // the tokenizer codes the CTUs' SAO parameters
   timed(K_TOKENIZE, stream_tok_, [&] { launch_tokenize(f, stream_tok_); });
   timed(K_TOK_COMPACT, stream_tok_, [&] { launch_tok_compact(f, stream_tok_); });
   HIP_CHECK(hipEventRecord(ev_tok_done_[set_], stream_tok_)); tok_pending_[set_] = true;
@@ -562,7 +579,9 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     HIP_CHECK(hipEventRecord(sl.done, sl.ent_stream));
   } else
   HIP_CHECK(hipEventRecord(sl.done, stream_tok_));
-  HIP_CHECK(hipEventRecord(sl.rec_done, ms));
+  // reconstruction final: with SAO the tokenizer's stream waited for the filter -- the chain's last kernel --, so sl.done already says it (and a record the
+  // host can inspect ends with a system-scope fence: one fewer at the end of every picture's chain)
+  if (!cfg_.sao) HIP_CHECK(hipEventRecord(sl.rec_done, ms));
   sl.pic_idx = submitted_; sl.poc = poc_; sl.intra = intra; sl.rec_idx = cur_idx_; sl.set = set_; sl.qp = qp_cur_; sl.write_ps = false;
   if (intra) {
     sl.write_ps = (intra_count_ == 0) || (cfg_.vps_period > 0 && (intra_count_ % cfg_.vps_period) == 0);
@@ -720,7 +739,7 @@ bool Encoder::band_phase1(const uint8_t *d_i420)
   if (cfg_.band_rows <= 0 || !d_i420) return false;
   if (!band_picture_setup()) return false;
   roi_sub_ = roi_; roi_sub_w_ = roi_w_; roi_sub_h_ = roi_h_;
-  if (!upload_qp_targets()) return false;
+  if (!stage_roi(stream_) || !picture_begin()) return false;
   const EncFrame f = f_;
   launch_pad_input(d_i420, cfg_.width, cfg_.height, src_[0][0], src_[0][1], src_[0][2], cw_, ch_, stream_);
   if (band_intra_) {

@@ -79,11 +79,13 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
     // rdoq from medium on, signhide from slow on (as recalled from Kvazaar's table, which ties both to its slower presets)
     // intra-in-p: Kvazaar codes intra units in P pictures at every preset; here from superfast on -- the intra units of a P picture are a
     // dependency chain on the GPU (k_intra_recon<.., P>: measured 2.8x fewer pictures/s on the benchmark clip for 13 % fewer bits, DESIGN.md
-    // section 2), so the fastest preset keeps the all-inter P pictures the benchmark was defined with; "intra-in-p=1" switches it on there too
+    // section 2), so the fastest preset keeps the all-inter P pictures the benchmark was defined with; "intra-in-p=1" switches it on there too.
+    // Two levels (round 4): 1 = 16x16 intra units only (superfast .. fast: a CTU of 8x8 intra units is twice the wavefront steps of one of 16x16 units in the
+    // encoder's and the decoder's chain), 2 = 16x16 and 8x8 units (medium and slower)
     for (int i = 0; i < 10; i++) if (!strcmp(value, presets[i])) {
       cfg->sao_type = i ? KVZ_SAO_FULL : KVZ_SAO_OFF;
       cfg->fme_level = i == 0 ? 0 : (i <= 2 ? 2 : 4);
-      cfg->rdoq_enable = i >= 5; cfg->signhide_enable = i >= 6; cfg->intra_in_p = i >= 1;
+      cfg->rdoq_enable = i >= 5; cfg->signhide_enable = i >= 6; cfg->intra_in_p = i >= 5 ? 2 : (i >= 1 ? 1 : 0);
       return 1;
     }
     return 0;
@@ -176,7 +178,7 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
   INT_OPT("me-range", me_range, 1, 32)
   INT_OPT("gpu", gpu_device, 0, 64)
   BOOL_OPT("recon-output", recon_output)
-  BOOL_OPT("input-hold", input_hold) BOOL_OPT("intra-in-p", intra_in_p)
+  BOOL_OPT("input-hold", input_hold) INT_OPT("intra-in-p", intra_in_p, 0, 2)
   if (n == "null-input") {
     if (!strcmp(value, "drain")) { cfg->null_input_poll = 0; return 1; }
     if (!strcmp(value, "poll")) { cfg->null_input_poll = 1; return 1; }
@@ -312,7 +314,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.subme = cfg->fme_level < 0 ? 0 : (cfg->fme_level > 4 ? 4 : cfg->fme_level);
   ec.entropy_gpu = cfg->gpu_entropy != 0;
   ec.input_hold = cfg->input_hold != 0;
-  ec.rdoq = cfg->rdoq_enable != 0; ec.signhide = cfg->signhide_enable != 0; ec.intra_in_p = cfg->intra_in_p != 0;
+  ec.rdoq = cfg->rdoq_enable != 0; ec.signhide = cfg->signhide_enable != 0; ec.intra_in_p = cfg->intra_in_p;
   ec.hash = cfg->hash == KVZ_HASH_MD5 ? 2 : (cfg->hash == KVZ_HASH_CHECKSUM ? 1 : 0);
   ec.vaq = cfg->vaq > 0 ? cfg->vaq : 0;
   ec.qp_in_cu = (cfg->set_qp_in_cu || ec.vaq > 0) ? 1 : 0;
@@ -479,7 +481,7 @@ int kvzx_encoder_kernel_times(kvz_encoder *e, double *ms, uint64_t *launches, in
 }
 const char *kvzx_encoder_kernel_name(int id)
 {
-  static const char *names[kvzx::K_COUNT] = {"k_pad_input", "k_me", "k_inter_recon", "k_inter_signal", "k_intra_analyse", "k_intra_recon", "k_deblock", "k_tokenize", "host_arith_coder", "k_sao", "k_tok_compact", "k_cabac_rows", "k_subpel"};
+  static const char *names[kvzx::K_COUNT] = {"k_pad_input", "k_me", "k_inter_recon", "k_inter_signal", "k_intra_analyse", "k_intra_recon", "k_deblock", "k_tokenize", "host_arith_coder", "k_sao", "k_tok_compact", "k_cabac_rows", "k_subpel", "k_intra_analyse<P>", "k_intra_recon<P>"};
   return (id >= 0 && id < kvzx::K_COUNT) ? names[id] : nullptr;
 }
 uint64_t kvzx_encoder_last_bins(kvz_encoder *e) { return e ? e->last_bins : 0; }

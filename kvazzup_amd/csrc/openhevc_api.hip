@@ -180,7 +180,7 @@ const char *kvzx_batch_kernel_name(int id)
 void kvzx_batch_hold(int device, int on) { kvzx::DecBatcher::get(device).hold(on != 0); }
 const char *kvzx_decoder_kernel_name(int id)
 {
-  static const char *names[kvzx::DK_COUNT] = {"k_dec_inter", "k_dec_intra", "k_dec_deblock", "host_cabac_parse", "k_dec_sao"};
+  static const char *names[kvzx::DK_COUNT] = {"k_dec_inter", "k_dec_intra", "k_dec_deblock", "host_cabac_parse", "k_dec_sao", "k_dec_intra<P>"};
   return (id >= 0 && id < kvzx::DK_COUNT) ? names[id] : nullptr;
 }
 int kvzx_decoder_debug_copy(OpenHevc_Handle hh, const char *what, void *dst, size_t bytes)

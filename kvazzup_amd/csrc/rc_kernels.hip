@@ -17,10 +17,16 @@
 
 namespace kvzx {
 
-// before the picture's k_inter_recon: the groups' counters back to zero; the access unit of a few pictures ago has been sized (bits3), and if that picture was coded in groups
-// its bits per unit of level cost update the ratio
-__global__ void k_rc_begin(RcState *rc, uint32_t bits3, int slot3, int have3)
+// The head of a picture's chain on the main stream, ONE launch (round 3: a one-thread kernel for the rate control state plus a host-to-device copy of the
+// per-CTU target QPs queued on the main stream -- 5 us + a ~28 us bubble in front of every picture of uvgComm's default mode):
+//   * rate control v2 (rc != NULL): the groups' counters back to zero; the access unit of a few pictures ago has been sized (bits3), and if that picture was
+//     coded in groups its bits per unit of level cost update the ratio;
+//   * cu_qp_delta (ctu_qt != NULL): every CTU's target QP = clip(picture QP + ROI delta) -- with VAQ the ROI delta alone, k_vaq_apply adds the rest.  The ROI
+//     deltas (per CTU, already spread over the CTU grid) were uploaded on the input stream when the picture brought a map; NULL = no map.
+__global__ __launch_bounds__(256) void k_picture_begin(RcState *rc, uint32_t bits3, int slot3, int have3, int8_t *ctu_qt, const int8_t *roi, int nctu, int qp, int vaq)
 {
+  if (ctu_qt) for (int i = threadIdx.x; i < nctu; i += 256) { const int d = roi ? roi[i] : 0; ctu_qt[i] = (int8_t)(vaq ? d : clip3(0, 51, qp + d)); }
+  if (!rc || threadIdx.x) return;
   rc->cost_sofar = 0; rc->decided = 0;
   for (int g = 0; g < 8; g++) rc->acc[g * KVZ_RC_ACC_STRIDE] = 0;
   if (!have3 || !rc->cost_valid[slot3]) return;
@@ -33,5 +39,8 @@ __global__ void k_rc_begin(RcState *rc, uint32_t bits3, int slot3, int have3)
   rc->ratio_valid = 1;
 }
 
-void launch_rc_begin(RcState *rc, uint32_t bits3, int slot3, int have3, hipStream_t st) { hipLaunchKernelGGL(k_rc_begin, dim3(1), dim3(1), 0, st, rc, bits3, slot3, have3); }
+void launch_picture_begin(RcState *rc, uint32_t bits3, int slot3, int have3, int8_t *ctu_qt, const int8_t *roi, int nctu, int qp, int vaq, hipStream_t st)
+{
+  if (rc || ctu_qt) hipLaunchKernelGGL(k_picture_begin, dim3(1), dim3(256), 0, st, rc, bits3, slot3, have3, ctu_qt, roi, nctu, qp, vaq);
+}
 }  // namespace kvzx

@@ -523,14 +523,14 @@ static void me_block32(orc_encoder *e, int x0, int y0)
       cand[k] = ic[k] > INTRA_P_GATE * lam; any |= cand[k];
     }
     if (any) {
-      if (!e->intra_p_ready) { intra_analyse_size(e, 8, e->im8, e->ic8); intra_analyse_size(e, 16, e->im16, e->ic16); e->intra_p_ready = 1; }
+      if (!e->intra_p_ready) { if (e->cfg.intra_in_p >= 2) intra_analyse_size(e, 8, e->im8, e->ic8); intra_analyse_size(e, 16, e->im16, e->ic16); e->intra_p_ready = 1; }
       int w8 = e->cw / 8, w16 = e->cw / 16, chosen = 0, sp16[4];
       for (int k = 0; k < 4; k++) {
         int x16 = x0 / 16 + (k & 1), y16 = y0 / 16 + (k >> 1);
         uint32_t c8 = pen;
-        for (int j = 0; j < 4; j++) c8 += e->ic8[(y16 * 2 + (j >> 1)) * w8 + x16 * 2 + (j & 1)];
+        if (e->cfg.intra_in_p >= 2) for (int j = 0; j < 4; j++) c8 += e->ic8[(y16 * 2 + (j >> 1)) * w8 + x16 * 2 + (j & 1)];
         uint32_t c16 = e->ic16[y16 * w16 + x16];
-        sp16[k] = c8 < c16;
+        sp16[k] = e->cfg.intra_in_p >= 2 && c8 < c16;          /* level 1: one 16x16 intra unit per quarter, no 8x8 units (the fast presets: a CTU of 8x8 intra units is twice the wavefront steps in the encoder's and the decoder's chain) */
         uint32_t cintra = (sp16[k] ? c8 : c16) + ((lam * INTRA_P_BITS) >> 4);
         cand[k] = cand[k] && cintra < ic[k];
         chosen |= cand[k];
@@ -1199,7 +1199,7 @@ size_t orc_enc_encode(orc_encoder *e, const pixel *y, const pixel *u, const pixe
 int orc_enc_set_option(orc_encoder *e, const char *name, int value)
 {
   if (!strcmp(name, "hash")) { e->cfg.hash = value; return 1; }
-  if (!strcmp(name, "intra-in-p")) { e->cfg.intra_in_p = value != 0; return 1; }
+  if (!strcmp(name, "intra-in-p")) { e->cfg.intra_in_p = value < 0 ? 0 : (value > 2 ? 2 : value); return 1; }      /* 0 off, 1: 16x16 intra units in P pictures, 2: 16x16 and 8x8 */
   if (!strcmp(name, "rc-delay")) { if (value < 3 || value > 7) return 0; e->cfg.rc_delay = value; return 1; }
   if (!strcmp(name, "rdoq")) { e->cfg.rdoq = value != 0; return 1; }
   if (!strcmp(name, "signhide")) { e->cfg.signhide = value != 0; e->pps.sign_data_hiding = e->cfg.signhide; return 1; }

@@ -53,8 +53,9 @@ def test_kvz_api_table_and_config_parsing(lib):
     assert c.sao_type == 0                                   # ultrafast: SAO off
     assert (c.width, c.height, c.framerate_num, c.framerate_denom, c.qp, c.intra_period, c.vps_period, c.owf, c.wpp) == (1920, 1080, 30, 1, 32, 64, 1, 2, 1)
     assert ok("preset", "medium") == 1 and cfg.contents.sao_type == 3     # presets above ultrafast: SAO full ...
-    assert cfg.contents.intra_in_p == 1 and cfg.contents.rdoq_enable == 1 and cfg.contents.signhide_enable == 0      # ... intra units in P pictures, rdoq from medium on
-    assert ok("intra-in-p", "0") == 1 and cfg.contents.intra_in_p == 0 and ok("intra-in-p", "1") == 1
+    assert cfg.contents.intra_in_p == 2 and cfg.contents.rdoq_enable == 1 and cfg.contents.signhide_enable == 0      # ... intra units in P pictures, rdoq from medium on
+    assert ok("intra-in-p", "0") == 1 and cfg.contents.intra_in_p == 0 and ok("intra-in-p", "1") == 1 and ok("intra-in-p", "2") == 1 and ok("intra-in-p", "3") == 0
+    assert ok("preset", "veryfast") == 1 and cfg.contents.intra_in_p == 1      # the fast presets: 16x16 intra units only
     assert ok("sao", "off") == 1 and cfg.contents.sao_type == 0           # ... unless a later option says otherwise
     assert ok("preset", "ultrafast") == 1 and cfg.contents.sao_type == 0 and cfg.contents.intra_in_p == 0
     # rejected: unknown names and values outside the implemented tool set (kvazaarfilter.cpp:363-367 logs these)

@@ -368,7 +368,7 @@ def test_random_tool_combinations_match_oracle(gpu, seed):
     kind = int(rng.choice([0, 2]))
     # (drawn after everything the earlier rounds' sweeps drew, so that their configurations stay what they were)
     extra = dict(subme=int(rng.choice([0, 0, 2, 4])), tile_cols=int(rng.choice([1, 1, 2])) if w >= 256 else 1)
-    tools = dict(intra_in_p=int(rng.integers(0, 2)), rdoq=int(rng.integers(0, 2)), signhide=int(rng.integers(0, 2)))
+    tools = dict(intra_in_p=int(rng.integers(0, 3)), rdoq=int(rng.integers(0, 2)), signhide=int(rng.integers(0, 2)))
     cfg.update(extra)
     frames = (9 if owf < 3 else 12) if cfg["bitrate"] else 5              # (the rate controller starts moving the QP behind its delay)
     oe = orc.OracleEncoder(w, h, **cfg)
@@ -510,10 +510,12 @@ def test_rdoq_and_sign_hiding_match_oracle(gpu, cfg):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [
-    dict(w=416, h=240, qp=32, frames=8, cut=3),
-    dict(w=416, h=240, qp=27, frames=7, cut=2, subme=4, sao=1, rdoq=1, signhide=1),
-    dict(w=640, h=368, qp=30, frames=6, cut=2, subme=2, tiles="2x2"),
-    dict(w=1920, h=1080, qp=32, frames=4, cut=2),                  # BASELINE configs[1] size
+    dict(w=416, h=240, qp=32, frames=8, cut=3, level=2),
+    dict(w=416, h=240, qp=32, frames=6, cut=3),                    # level 1: 16x16 intra units only (the fast presets)
+    dict(w=416, h=240, qp=27, frames=7, cut=2, subme=4, sao=1, rdoq=1, signhide=1, level=2),
+    dict(w=640, h=368, qp=30, frames=6, cut=2, subme=2, tiles="2x2", level=2),
+    dict(w=1920, h=1080, qp=32, frames=4, cut=2, level=2),          # BASELINE configs[1] size
+    dict(w=1920, h=1080, qp=32, frames=3, cut=1),
     dict(w=640, h=384, qp=32, frames=12, cut=6, bitrate=600000, sao=1, subme=2),      # rate control v2 (uvgComm's default mode sets a bitrate): the row groups are priced without the intra units
 ])
 def test_intra_units_in_p_pictures_match_oracle(gpu, cfg):
@@ -525,8 +527,9 @@ def test_intra_units_in_p_pictures_match_oracle(gpu, cfg):
     tiles = cfg.get("tiles", "1x1"); tc, tr = [int(v) for v in tiles.split("x")]
     br = cfg.get("bitrate", 0)
     oe = orc.OracleEncoder(w, h, qp=cfg["qp"], period=64, me_range=8, subme=cfg.get("subme", 0), sao=cfg.get("sao", 0), tile_rows=tr, tile_cols=tc, bitrate=br, rc_bands=4 if br else 0)
-    oe.set_option("intra-in-p", 1); oe.set_option("rdoq", cfg.get("rdoq", 0)); oe.set_option("signhide", cfg.get("signhide", 0))
-    ge = Encoder(w, h, options=(("qp", cfg["qp"]), ("period", 64), ("me-range", 8), ("intra-in-p", 1), ("rdoq", cfg.get("rdoq", 0)), ("signhide", cfg.get("signhide", 0)),
+    lvl = cfg.get("level", 1)
+    oe.set_option("intra-in-p", lvl); oe.set_option("rdoq", cfg.get("rdoq", 0)); oe.set_option("signhide", cfg.get("signhide", 0))
+    ge = Encoder(w, h, options=(("qp", cfg["qp"]), ("period", 64), ("me-range", 8), ("intra-in-p", lvl), ("rdoq", cfg.get("rdoq", 0)), ("signhide", cfg.get("signhide", 0)),
                                 ("subme", cfg.get("subme", 0)), ("sao", "full" if cfg.get("sao") else "off")) + ((("tiles", tiles),) if tiles != "1x1" else ())
                  + ((("bitrate", br), ("rc-algorithm", "lambda")) if br else ()), fields={"target_bitrate": br})
     assert not ge.rejected, ge.rejected
@@ -551,7 +554,7 @@ def test_intra_units_in_p_pictures_match_oracle(gpu, cfg):
 def test_presets_switch_rdoq_and_sign_hiding_on(gpu):
     """preset medium and above: rdoq; slow and above: signhide too; superfast and above: intra units in P pictures (config_parse)"""
     from kvazzup_amd.codec import Encoder
-    for preset, rd, sh, ip in (("ultrafast", 0, 0, 0), ("superfast", 0, 0, 1), ("fast", 0, 0, 1), ("medium", 1, 0, 1), ("slow", 1, 1, 1), ("placebo", 1, 1, 1)):
+    for preset, rd, sh, ip in (("ultrafast", 0, 0, 0), ("superfast", 0, 0, 1), ("fast", 0, 0, 1), ("medium", 1, 0, 2), ("slow", 1, 1, 2), ("placebo", 1, 1, 2)):
         e = Encoder(256, 128, options=(("preset", preset),))
         assert (e.cfg.contents.rdoq_enable, e.cfg.contents.signhide_enable, e.cfg.contents.intra_in_p) == (rd, sh, ip), preset
         e.close()

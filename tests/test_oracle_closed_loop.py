@@ -319,9 +319,11 @@ def test_intra_units_in_p_pictures_closed_loop(subme, sao, tiles, adj, bitrate):
         oe.close(); od.close()
         return nbytes, sse, units
     b0, s0, u0 = run(0)
-    b1, s1, u1 = run(1)
-    assert u0[1:] == [0] * (n - 1) and u1[cut] > 100, (u0, u1)
+    b1, s1, u1 = run(1)                                                 # 16x16 intra units only (the fast presets)
+    b2, s2, u2 = run(2)                                                 # 16x16 and 8x8 units
+    assert u0[1:] == [0] * (n - 1) and u1[cut] > 100 and u2[cut] > 100, (u0, u1, u2)
     assert (bitrate or b1 < b0) and s1 < s0, (b0, b1, s0, s1)          # (under rate control the bytes are the controller's business)
+    assert (bitrate or b2 < b0) and s2 < s0, (b0, b2, s0, s2)
 
 
 def test_rate_control_delay_option():

@@ -6,7 +6,8 @@ import numpy as np, orc
 from kvazzup_amd.codec import Encoder, Decoder
 w, h = 1920, 1080
 frames = [orc.synth_frame(0, 0x5EED0001, w, h, t) for t in range(16)]
-e = Encoder(w, h, options=(("preset", "veryfast"), ("qp", 32), ("period", 64), ("me-range", 16), ("owf", 0), ("bitrate", 1000000), ("rc-algorithm", "lambda")), fields={"target_bitrate": 1000000})
+extra = tuple(tuple(a.split("=", 1)) for a in sys.argv[1:])      # e.g. intra-in-p=2
+e = Encoder(w, h, options=(("preset", "veryfast"),) + extra + (("qp", 32), ("period", 64), ("me-range", 16), ("owf", 0), ("bitrate", 1000000), ("rc-algorithm", "lambda")), fields={"target_bitrate": 1000000})
 d = Decoder()
 e.set_profiling(True); d.set_profiling(True)
 for t, f in enumerate(frames):

@@ -48,6 +48,7 @@ struct orc_decoder {
   orc_cabac_dec cabac; orc_ctx wpp_ctx[CTX_COUNT];
   orc_avail_ctx av;
   int cu_transquant_bypass;
+  int scaling_on; uint8_t sfac[4][6][1024];     /* scaling factors of the active lists (PPS, else SPS, else default), per size and matrix; scaling_on = scaling_list_enabled_flag */
   int is_cu_qp_delta_coded, cu_qp_delta_val;
   int qp_y, last_qp_y, qg_x, qg_y, qp_y_pred;
   int intra_chroma_pred_mode;
@@ -218,7 +219,7 @@ static void recon_tb(orc_decoder *d, int cidx, int x0, int y0, int log2, const i
   if (d->cu_transquant_bypass) {
     memcpy(res, level, sizeof(int16_t) * (size_t)n * n);
   } else {
-    orc_dequant(level, coeff, n, qp);
+    orc_dequant_m(level, coeff, n, qp, d->scaling_on ? d->sfac[log2 - 2][orc_scaling_matrix_id(log2 - 2, cidx, d->cu_pred_mode != MODE_INTRA)] : NULL);
     if (ts) { for (int i = 0; i < n * n; i++) res[i] = (int16_t)((((int)coeff[i] << 7) + (1 << 11)) >> 12); }
     else orc_inv_transform(coeff, res, n, dst_mode);
   }
@@ -882,6 +883,11 @@ int orc_dec_decode_nal(orc_decoder *d, const uint8_t *data, size_t len, int64_t 
     r = start_picture(d);
     if (r <= 0) return r;
   } else if (!d->pic_active) return 0;
+  d->scaling_on = d->s->scaling_list_enabled;
+  if (d->scaling_on) {                                 /* 7.4.5: the PPS's lists when it carries any, else the SPS's (the default ones without data) */
+    const orc_scaling_lists *sl = d->p->scaling_list_data_present ? &d->p->scaling : &d->s->scaling;
+    for (int sz = 0; sz < 4; sz++) for (int m = 0; m < (sz == 3 ? 2 : 6); m++) orc_scaling_factor(sl, sz, m, d->sfac[sz][m]);
+  }
   r = build_ref_list(d);
   if (r) { d->pic_active = 0; d->cur->is_ref = 0; d->cur->needed_for_output = 0; return r; }
   d->err = 0;

@@ -34,7 +34,7 @@ struct orc_gen {
   int slice_is_intra;
   /* coding-unit state */
   int cu_qp_delta_coded, log2_qg;
-  int cu_pred_mode, part_mode, intra_split, max_trafo_depth;
+  int cu_pred_mode, part_mode, intra_split, max_trafo_depth, cu_bypass;
   int intra_modes[4], chroma_mode;
 };
 
@@ -61,6 +61,28 @@ void orc_gen_default_config(orc_gen_config *c)
   memset(c, 0xff, sizeof(*c));             /* every switch -1: drawn from the seed */
   c->width = 416; c->height = 240; c->seed = 1; c->intra_period = 8; c->qp = 30;
   c->density = 30;
+}
+
+/* scaling_list_data() with every way of coding a list: the default lists (pred_mode 0, delta 0), a copy of an earlier matrix of the size (delta > 0),
+ * explicit entries (a random walk through 1..255 with the occasional jump to an extreme) */
+static void gen_scaling(orc_gen *g, orc_scaling_lists *sl, uint8_t pred_mode[4][6], uint8_t pred_delta[4][6])
+{
+  orc_scaling_default(sl);
+  for (int s = 0; s < 4; s++)
+    for (int m = 0; m < (s == 3 ? 2 : 6); m++) {
+      const int r = rrange(g, 0, 99);
+      pred_mode[s][m] = 0; pred_delta[s][m] = 0;
+      if (r < 25) continue;                                             /* the default list */
+      if (r < 45 && m > 0) { pred_delta[s][m] = (uint8_t)rrange(g, 1, m); continue; }   /* a copy (the parser takes the referenced list as it stands) */
+      pred_mode[s][m] = 1;
+      int v = rrange(g, 8, 40);
+      if (s >= 2) sl->dc[s - 2][m] = (uint8_t)rrange(g, 1, 255);
+      for (int i = 0; i < (s == 0 ? 16 : 64); i++) {
+        if (rpct(g, 3)) v = rpct(g, 50) ? 1 : 255;
+        else v = orc_clip3(1, 255, v + rrange(g, -6, 10));
+        sl->list[s][m][i] = (uint8_t)v;
+      }
+    }
 }
 
 orc_gen *orc_gen_open(const orc_gen_config *cfg)
@@ -97,6 +119,8 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   if (c->min_cu_log2 > c->max_cu_log2) c->min_cu_log2 = c->max_cu_log2;
   c->uniform_tiles = pick(g, c->uniform_tiles, 0, 1);
   c->big_mvd = pick(g, c->big_mvd, 0, 1);
+  if (c->tq_bypass < 0) c->tq_bypass = 0;
+  if (c->scaling_lists < 0 || c->scaling_lists > 4) c->scaling_lists = 0;
   const int wc = (cfg->width + 63) / 64, hc = (cfg->height + 63) / 64;
   if (c->tile_rows > hc) c->tile_rows = hc;
   if (c->tile_rows < 1) c->tile_rows = 1;
@@ -109,6 +133,8 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   s->log2_min_cb = 3; s->log2_diff_max_min_cb = 3; s->log2_min_tb = 2; s->log2_diff_max_min_tb = 3;
   s->max_th_depth_inter = c->th_depth_inter; s->max_th_depth_intra = c->th_depth_intra;
   s->amp_enabled = c->amp; s->sao_enabled = c->sao;
+  s->scaling_list_enabled = c->scaling_lists > 0; s->scaling_list_data_present = c->scaling_lists == 2 || c->scaling_lists == 4;
+  if (s->scaling_list_data_present) gen_scaling(g, &s->scaling, s->sl_pred_mode, s->sl_pred_delta);
   s->num_st_rps = 0;
   s->temporal_mvp_enabled = c->tmvp; s->strong_intra_smoothing = c->strong_intra;
   s->vui_present = 1; s->vui_timing_present = 1; s->vui_num_units_in_tick = 1; s->vui_time_scale = 30;
@@ -119,6 +145,9 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   p->sign_data_hiding = c->sign_hiding; p->cabac_init_present = c->cabac_init;
   p->num_ref_idx_l0_default = rrange(g, 1, c->num_refs); p->num_ref_idx_l1_default = 1; p->init_qp = cfg->qp;
   p->transform_skip_enabled = c->transform_skip;
+  p->transquant_bypass_enabled = c->tq_bypass > 0;
+  p->scaling_list_data_present = c->scaling_lists >= 3;
+  if (p->scaling_list_data_present) gen_scaling(g, &p->scaling, p->sl_pred_mode, p->sl_pred_delta);
   p->cu_qp_delta_enabled = c->qp_delta > 0; p->diff_cu_qp_delta_depth = c->qp_delta > 0 ? c->qp_delta - 1 : 0;
   if (c->chroma_qp_offsets) { p->cb_qp_offset = rrange(g, -4, 4); p->cr_qp_offset = rrange(g, -4, 4); p->slice_chroma_qp_offsets_present = rpct(g, 50); }
   p->entropy_coding_sync_enabled = c->wpp; p->loop_filter_across_slices = 1;
@@ -217,7 +246,7 @@ static void gen_residual(orc_gen *g, int log2, int cidx, int scan_idx)
   const uint8_t *sbx = orc_scan_x[scan_idx][sb_log2], *sby = orc_scan_y[scan_idx][sb_log2];
   const uint8_t *px = orc_scan_x[scan_idx][2], *py = orc_scan_y[scan_idx][2];
   uint8_t csbf[8][8]; memset(csbf, 0, sizeof(csbf));
-  if (g->pps.transform_skip_enabled && log2 <= 2) orc_cenc_bin(c, CTX_TS_FLAG + (cidx ? 1 : 0), rpct(g, 30));
+  if (g->pps.transform_skip_enabled && !g->cu_bypass && log2 <= 2) orc_cenc_bin(c, CTX_TS_FLAG + (cidx ? 1 : 0), rpct(g, 30));
   /* the last significant coefficient: mostly in the low-frequency corner */
   int last_sb, last_pos;
   if (rpct(g, 60) || nsb == 1) { last_sb = 0; last_pos = rrange(g, 0, 15); }
@@ -285,7 +314,7 @@ static void gen_residual(orc_gen *g, int log2, int cidx, int scan_idx)
       first_sig = k;
     }
     if (last_g1_pos != -1) orc_cenc_bin(c, CTX_GT2 + (cidx ? 4 : 0) + ctx_set, absv[last_g1_pos] > 2);
-    int sign_hidden = g->pps.sign_data_hiding && (last_sig - first_sig > 3);
+    int sign_hidden = g->pps.sign_data_hiding && !g->cu_bypass && (last_sig - first_sig > 3);
     for (int k = 15; k >= 0; k--) if (sig[k] && (!sign_hidden || k != first_sig)) orc_cenc_bypass(c, (int)(rnd(g) & 1u));
     int num_sig = 0, rice = 0;
     for (int k = 15; k >= 0; k--) if (sig[k]) {
@@ -428,6 +457,8 @@ static void gen_coding_unit(orc_gen *g, int x0, int y0, int log2cb, int ct_depth
   const orc_sps *s = &g->sps;
   const int n = 1 << log2cb;
   int skip = 0;
+  g->cu_bypass = 0;
+  if (g->pps.transquant_bypass_enabled) { g->cu_bypass = rpct(g, g->cfg.tq_bypass); orc_cenc_bin(c, CTX_TQ_BYPASS, g->cu_bypass); }      /* 7.3.8.5: first in the coding unit */
   if (!g->slice_is_intra) {
     int l = orc_available(&g->av, x0, y0, x0 - 1, y0) && pic->pred_mode[b4(pic, x0 - 1, y0)] == MODE_SKIP;
     int a = orc_available(&g->av, x0, y0, x0, y0 - 1) && pic->pred_mode[b4(pic, x0, y0 - 1)] == MODE_SKIP;

@@ -42,6 +42,8 @@ typedef struct {
                                * slice; 1 = a DEPENDENT slice segment per CTU row (kvazaar slices=wpp; here with or without WPP); 2 = an independent
                                * slice per tile (kvazaar slices=tiles; one slice when there are no tiles) */
   int tile_cols;              /* tile columns (uniform spacing), 1 (also -1) = none; with columns the slice forms are 0 and 2 */
+  int tq_bypass;              /* probability (%) of cu_transquant_bypass_flag = 1; > 0 sets transquant_bypass_enabled_flag (-1 = 0: existing seeds keep their streams) */
+  int scaling_lists;          /* 0 (also -1) scaling_list_enabled_flag = 0; 1 enabled with the default lists; 2 lists in the SPS; 3 default in the SPS, lists in the PPS; 4 both */
 } orc_gen_config;
 
 void orc_gen_default_config(orc_gen_config *c);    /* everything random, 416x240 */

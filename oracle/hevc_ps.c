@@ -91,7 +91,11 @@ void orc_write_sps(orc_bitw *w, const orc_sps *s)
   orc_bw_ue(w, (uint32_t)s->log2_diff_max_min_tb);
   orc_bw_ue(w, (uint32_t)s->max_th_depth_inter);
   orc_bw_ue(w, (uint32_t)s->max_th_depth_intra);
-  orc_bw_put(w, 0, 1);                 /* scaling_list_enabled_flag */
+  orc_bw_put(w, (uint32_t)s->scaling_list_enabled, 1);
+  if (s->scaling_list_enabled) {
+    orc_bw_put(w, (uint32_t)s->scaling_list_data_present, 1);
+    if (s->scaling_list_data_present) orc_scaling_write(w, &s->scaling, s->sl_pred_mode, s->sl_pred_delta);
+  }
   orc_bw_put(w, (uint32_t)s->amp_enabled, 1);
   orc_bw_put(w, (uint32_t)s->sao_enabled, 1);
   orc_bw_put(w, 0, 1);                 /* pcm_enabled_flag */
@@ -165,7 +169,8 @@ void orc_write_pps(orc_bitw *w, const orc_pps *p)
     orc_bw_put(w, (uint32_t)p->pps_deblocking_disabled, 1);
     if (!p->pps_deblocking_disabled) { orc_bw_se(w, p->pps_beta_offset_div2); orc_bw_se(w, p->pps_tc_offset_div2); }
   }
-  orc_bw_put(w, 0, 1);                 /* pps_scaling_list_data_present_flag */
+  orc_bw_put(w, (uint32_t)p->scaling_list_data_present, 1);
+  if (p->scaling_list_data_present) orc_scaling_write(w, &p->scaling, p->sl_pred_mode, p->sl_pred_delta);
   orc_bw_put(w, (uint32_t)p->lists_modification_present, 1);
   orc_bw_ue(w, (uint32_t)p->log2_parallel_merge_level - 2);
   orc_bw_put(w, (uint32_t)p->slice_header_extension_present, 1);
@@ -386,7 +391,11 @@ int orc_parse_sps(orc_bitr *r, orc_sps *s)
   s->max_th_depth_inter = (int)orc_br_ue(r);
   s->max_th_depth_intra = (int)orc_br_ue(r);
   s->scaling_list_enabled = (int)orc_br_get(r, 1);
-  if (s->scaling_list_enabled) return -2;                    /* unsupported */
+  if (s->scaling_list_enabled) {
+    orc_scaling_default(&s->scaling);
+    s->scaling_list_data_present = (int)orc_br_get(r, 1);
+    if (s->scaling_list_data_present && orc_scaling_parse(r, &s->scaling) < 0) return -1;
+  }
   s->amp_enabled = (int)orc_br_get(r, 1);
   s->sao_enabled = (int)orc_br_get(r, 1);
   s->pcm_enabled = (int)orc_br_get(r, 1);
@@ -476,7 +485,7 @@ int orc_parse_pps(orc_bitr *r, orc_pps *p)
     if (!p->pps_deblocking_disabled) { p->pps_beta_offset_div2 = orc_br_se(r); p->pps_tc_offset_div2 = orc_br_se(r); }
   }
   p->scaling_list_data_present = (int)orc_br_get(r, 1);
-  if (p->scaling_list_data_present) return -2;
+  if (p->scaling_list_data_present) { orc_scaling_default(&p->scaling); if (orc_scaling_parse(r, &p->scaling) < 0) return -1; }
   p->lists_modification_present = (int)orc_br_get(r, 1);
   p->log2_parallel_merge_level = (int)orc_br_ue(r) + 2;
   p->slice_header_extension_present = (int)orc_br_get(r, 1);

@@ -6,6 +6,7 @@
 #define ORC_HEVC_PS_H
 #include "hevc_common.h"
 #include "hevc_bits.h"
+#include "hevc_scaling.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -35,6 +36,9 @@ typedef struct {
   int log2_min_cb, log2_diff_max_min_cb, log2_min_tb, log2_diff_max_min_tb;
   int max_th_depth_inter, max_th_depth_intra;
   int scaling_list_enabled, amp_enabled, sao_enabled, pcm_enabled;
+  int scaling_list_data_present;                       /* sps_scaling_list_data_present_flag: else the default lists (Tables 7-5 / 7-6) */
+  orc_scaling_lists scaling;                           /* the SPS's lists (the default ones without data) */
+  uint8_t sl_pred_mode[4][6], sl_pred_delta[4][6];     /* writer only: how every list is coded (hevc_scaling.h orc_scaling_write) */
   int pcm_bit_depth_luma, pcm_bit_depth_chroma, log2_min_pcm_cb, log2_diff_max_min_pcm_cb, pcm_loop_filter_disabled;
   int num_st_rps; orc_st_rps st_rps[65];
   int long_term_ref_pics_present;
@@ -63,6 +67,8 @@ typedef struct {
   int deblocking_filter_control_present, deblocking_filter_override_enabled;
   int pps_deblocking_disabled, pps_beta_offset_div2, pps_tc_offset_div2;
   int scaling_list_data_present, lists_modification_present;
+  orc_scaling_lists scaling;                           /* pps_scaling_list_data: overrides the SPS's lists */
+  uint8_t sl_pred_mode[4][6], sl_pred_delta[4][6];     /* writer only */
   int log2_parallel_merge_level;
   int slice_header_extension_present;
 } orc_pps;

@@ -134,17 +134,20 @@ int orc_adjust_levels(int16_t *level, const uint16_t *aux, int n, int scan_idx, 
   return nz_total;
 }
 
-/* H.265 8.6.3 with m = 16 (scaling_list_enabled_flag == 0): bdShift = BitDepth + log2N - 5 */
-void orc_dequant(const int16_t *level, int16_t *coeff, int n, int qp)
+/* H.265 8.6.4.2: d = Clip3(-32768, 32767, (level * m[x][y] * levelScale[qP % 6] << (qP / 6)) + (1 << (bdShift - 1))) >> bdShift),
+ * bdShift = BitDepth + log2N - 5; m = the scaling factors of the block (hevc_scaling.h, n x n raster) or NULL: 16 everywhere
+ * (scaling_list_enabled_flag == 0) */
+void orc_dequant_m(const int16_t *level, int16_t *coeff, int n, int qp, const uint8_t *m)
 {
   int l2 = orc_log2((unsigned)n);
   int bd = 8 + l2 - 5;
   int scale = orc_level_scale[qp % 6] << (qp / 6);
   for (int i = 0; i < n * n; i++) {
-    int64_t v = ((int64_t)level[i] * 16 * scale + ((int64_t)1 << (bd - 1))) >> bd;
+    int64_t v = ((int64_t)level[i] * (m ? m[i] : 16) * scale + ((int64_t)1 << (bd - 1))) >> bd;
     coeff[i] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
   }
 }
+void orc_dequant(const int16_t *level, int16_t *coeff, int n, int qp) { orc_dequant_m(level, coeff, n, qp, NULL); }
 
 int orc_chroma_qp(int qp_y, int offset)
 {

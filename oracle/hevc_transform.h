@@ -14,6 +14,7 @@ void orc_inv_transform(const int16_t *coeff, int16_t *resid, int n, int dst_mode
 /* returns number of non-zero levels */
 int  orc_quant(const int16_t *coeff, int16_t *level, int n, int qp, int intra);
 void orc_dequant(const int16_t *level, int16_t *coeff, int n, int qp);
+void orc_dequant_m(const int16_t *level, int16_t *coeff, int n, int qp, const uint8_t *m);   /* m: n x n scaling factors (hevc_scaling.h) or NULL = flat 16 */
 /* The quantiser with what the level-adjustment pass needs beside the levels: aux[i] = 256 + du in bits 0..9, where du = (|c| * scale >> (shift - 8))
  * - (|level| << 8) is the part of the coefficient the level does not account for, in 1/256 quantiser steps (-0.34 .. 0.84 steps with the
  * dead-zone rounding), and bit 15 = the coefficient is negative. */

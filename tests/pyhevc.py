@@ -7,7 +7,7 @@ compares reconstructed pictures with oracle/hevc_dec.c bit for bit.
 
 Scope: 8-bit 4:2:0, CTB 16..64, one slice per picture, I and P slices, tile rows and columns, WPP, every CU size and
 partitioning, transform trees, several reference pictures (short-term RPS), TMVP, cu_qp_delta, sign data hiding, transform
-skip, deblocking with offsets, SAO.  No B slices, PCM, scaling lists, long-term pictures, weighted prediction.
+skip, deblocking with offsets, SAO, scaling lists (default / SPS / PPS), cu_transquant_bypass.  No B slices, PCM, long-term pictures, weighted prediction.
 Normative tables are typed here per syntax element (initValue: Tables 9-5 .. 9-37); rangeTabLps and the state transition
 tables, the transform matrices and the interpolation filters are passed in by the caller (tests take them from the KAT-checked
 oracle tables: tests/test_oracle_kat.py), so that this file holds logic rather than 400 more typed constants."""
@@ -156,6 +156,77 @@ def parse_st_rps(r, idx, num, sets):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------- scaling lists (7.3.4, 7.4.5)
+# Table 7-6 as the symmetric 8x8 matrices it lists in diagonal scan order (intra: matrixId 0..2, inter: 3..5)
+DEFAULT_INTRA_8x8 = [[16, 16, 16, 16, 17, 18, 21, 24], [16, 16, 16, 16, 17, 19, 22, 25], [16, 16, 17, 18, 20, 22, 25, 29], [16, 16, 18, 21, 24, 27, 31, 36],
+                     [17, 17, 20, 24, 30, 35, 41, 47], [18, 19, 22, 27, 35, 44, 54, 65], [21, 22, 25, 31, 41, 54, 70, 88], [24, 25, 29, 36, 47, 65, 88, 115]]
+DEFAULT_INTER_8x8 = [[16, 16, 16, 16, 17, 18, 20, 24], [16, 16, 16, 17, 18, 20, 24, 25], [16, 16, 17, 18, 20, 24, 25, 28], [16, 17, 18, 20, 24, 25, 28, 33],
+                     [17, 18, 20, 24, 25, 28, 33, 41], [18, 20, 24, 25, 28, 33, 41, 54], [20, 24, 25, 28, 33, 41, 54, 71], [24, 25, 28, 33, 41, 54, 71, 91]]
+
+
+def _diag(n):
+    """up-right diagonal scan of an n x n block (6.5.3): list of (x, y)"""
+    out, x, y = [], 0, 0
+    while len(out) < n * n:
+        while y >= 0:
+            if x < n and y < n:
+                out.append((x, y))
+            y -= 1
+            x += 1
+        y, x = x, 0
+    return out
+
+
+def default_list(size_id, matrix_id):
+    """(ScalingList entries in diagonal scan order, dc) of Tables 7-5 / 7-6"""
+    if size_id == 0:
+        return [16] * 16, 16
+    inter = matrix_id >= (1 if size_id == 3 else 3)
+    mat = DEFAULT_INTER_8x8 if inter else DEFAULT_INTRA_8x8
+    return [mat[y][x] for (x, y) in _diag(8)], 16
+
+
+def default_scaling_lists():
+    return {(s, m): default_list(s, m) for s in range(4) for m in range(2 if s == 3 else 6)}
+
+
+def parse_scaling_list_data(r, lists):
+    for s in range(4):
+        for m in range(2 if s == 3 else 6):
+            if not r.u(1):                                   # scaling_list_pred_mode_flag
+                delta = r.ue()
+                if delta > m:
+                    raise ValueError("scaling_list_pred_matrix_id_delta")
+                lists[(s, m)] = default_list(s, m) if delta == 0 else lists[(s, m - delta)]
+            else:
+                nxt, dc = 8, 16
+                if s >= 2:
+                    dc = r.se() + 8
+                    nxt = dc
+                coefs = []
+                for _ in range(16 if s == 0 else 64):
+                    nxt = (nxt + r.se() + 256) % 256
+                    coefs.append(nxt)
+                lists[(s, m)] = (coefs, dc)
+
+
+def scaling_factor(lists, size_id, matrix_id):
+    """m[y, x] of 8.6.4.2 for an (4 << size_id)-square transform block (7.4.5)"""
+    n = 4 << size_id
+    coefs, dc = lists[(size_id, matrix_id)]
+    m = np.zeros((n, n), np.int64)
+    if size_id == 0:
+        for i, (x, y) in enumerate(_diag(4)):
+            m[y, x] = coefs[i]
+        return m
+    rep = n >> 3
+    for i, (x, y) in enumerate(_diag(8)):
+        m[y * rep:(y + 1) * rep, x * rep:(x + 1) * rep] = coefs[i]
+    if size_id >= 2:
+        m[0, 0] = dc
+    return m
+
+
 def parse_sps(rbsp):
     r = Bits(rbsp)
     r.u(16)
@@ -184,8 +255,11 @@ def parse_sps(rbsp):
     s["max_tb"] = s["min_tb"] + r.ue()
     s["th_inter"] = r.ue()
     s["th_intra"] = r.ue()
+    s["scaling"] = None                      # ScalingList per (sizeId, matrixId) when scaling_list_enabled_flag
     if r.u(1):
-        raise ValueError("scaling lists")
+        s["scaling"] = default_scaling_lists()
+        if r.u(1):                           # sps_scaling_list_data_present_flag
+            parse_scaling_list_data(r, s["scaling"])
     s["amp"] = r.u(1)
     s["sao"] = r.u(1)
     if r.u(1):
@@ -222,8 +296,9 @@ def parse_pps(rbsp):
     p["cb_off"] = r.se()
     p["cr_off"] = r.se()
     p["slice_chroma_off"] = r.u(1)
-    if r.u(1) or r.u(1) or r.u(1):
-        raise ValueError("weighted prediction / transquant bypass")
+    if r.u(1) or r.u(1):
+        raise ValueError("weighted prediction")
+    p["tq_bypass"] = r.u(1)
     p["tiles"] = r.u(1)
     p["wpp"] = r.u(1)
     p["tile_rows"] = p["tile_cols"] = 1
@@ -248,8 +323,10 @@ def parse_pps(rbsp):
         if not p["dbk_disabled"]:
             p["beta"] = 2 * r.se()
             p["tc"] = 2 * r.se()
-    if r.u(1):
-        raise ValueError("scaling list data")
+    p["scaling"] = None
+    if r.u(1):                               # pps_scaling_list_data_present_flag
+        p["scaling"] = default_scaling_lists()
+        parse_scaling_list_data(r, p["scaling"])
     if r.u(1):
         raise ValueError("lists modification")
     p["par_mrg"] = r.ue() + 2
@@ -280,6 +357,7 @@ INIT = {
     "mvd_gt1": (None, [198], [198]),
     "qp_delta": ([154, 154], [154, 154], [154, 154]),
     "ts_flag": ([139, 139], [139, 139], [139, 139]),
+    "tq_bypass": ([154], [154], [154]),
     "last_x": ([110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63],
                [125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108],
                [125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79, 108, 123, 93]),
@@ -631,6 +709,10 @@ class SliceDecoder:
         self.intra_mode = np.full((b4h, b4w), 1, np.int8)                   # luma intra prediction mode per 4x4 (DC when not intra)
         self.qp_y = np.zeros((b4h, b4w), np.int32)
         self.tu_nz = np.zeros((b4h, b4w), np.int8)                          # luma transform block has non-zero coefficients
+        self.bypass = np.zeros((b4h, b4w), np.int8)                         # cu_transquant_bypass_flag: the loop filters leave these samples alone
+        self.cu_bypass = 0
+        # the active scaling lists (7.4.5): the PPS's when it carries any, else the SPS's (the default ones without data); None: flat 16
+        self.scaling = None if sps["scaling"] is None else (pps["scaling"] if pps["scaling"] is not None else sps["scaling"])
         self.edge_v = np.zeros((b4h, b4w), np.int8)                         # 1: PU edge, 2: TU edge on the left side of this 4x4
         self.edge_h = np.zeros((b4h, b4w), np.int8)
         self.sao = {}
@@ -835,6 +917,9 @@ class SliceDecoder:
         my0, my1, mx0, mx1 = y0 >> m, min((y0 + n + (1 << m) - 1) >> m, self.mch), x0 >> m, min((x0 + n + (1 << m) - 1) >> m, self.mcw)
         self.cu_qp_pred = self.qp_pred(x0, y0)
         skip = 0
+        self.cu_bypass = c.bin("tq_bypass") if self.pps["tq_bypass"] else 0
+        if self.cu_bypass:
+            self.bypass[y0 >> 2:(y0 + n) >> 2, x0 >> 2:(x0 + n) >> 2] = 1
         if not sh["intra"]:
             inc = 0
             if self.avail(x0, y0, x0 - 1, y0) and self.cu_skip[y0 >> m, (x0 - 1) >> m]:
@@ -1287,7 +1372,7 @@ class SliceDecoder:
         c, pps = self.c, self.pps
         n = 1 << log2
         tskip = 0
-        if pps["tskip"] and log2 == 2:
+        if pps["tskip"] and log2 == 2 and not self.cu_bypass:
             tskip = c.bin("ts_flag", 1 if cidx else 0)
         if cidx == 0:
             off, shift = 3 * (log2 - 2) + ((log2 - 1) >> 2), (log2 + 1) >> 2
@@ -1385,7 +1470,7 @@ class SliceDecoder:
                     g1_state += 1
             if first_g1 >= 0 and c.bin("gt2", ctx_set + (4 if cidx else 0)):
                 absv[first_g1] = 3
-            hidden = pps["sign_hiding"] and (positions[0] - positions[-1] > 3)
+            hidden = pps["sign_hiding"] and not self.cu_bypass and (positions[0] - positions[-1] > 3)
             nsign = len(positions) - 1 if hidden else len(positions)
             signs = [c.bypass() for _ in range(nsign)]
             rice = 0
@@ -1412,9 +1497,15 @@ class SliceDecoder:
                 coef[(ys << 2) + yp, (xs << 2) + xp] = min(max(v, -32768), 32767)
         if self.dec.trace is not None:
             self.dec.trace.append(("tu", cidx, log2, [int(v) for v in coef.reshape(-1)]))
-        # ---- scaling (8.6.4.2, flat) and transformation (8.6.4.2 / 8.6.2)
+        if self.cu_bypass:                   # 8.6.2: the residual is the level array itself
+            return coef
+        # ---- scaling (8.6.4.2: m = 16, or the scaling factors of the active lists) and transformation (8.6.4.2 / 8.6.2)
         bd = log2 + 3
-        d = np.clip((coef * 16 * (LEVEL_SCALE[qp % 6] << (qp // 6)) + (1 << (bd - 1))) >> bd, -32768, 32767)
+        mfac = 16
+        if self.scaling is not None:
+            inter = 0 if self.cu_intra else 1
+            mfac = scaling_factor(self.scaling, log2 - 2, (inter if log2 == 5 else 3 * inter + cidx))
+        d = np.clip((coef * mfac * (LEVEL_SCALE[qp % 6] << (qp // 6)) + (1 << (bd - 1))) >> bd, -32768, 32767)
         if tskip:
             return ((d << 7) + 2048) >> 12
         m = np.array(self.t["dst"], np.int64) if dst else np.array(self.t["dct"], np.int64)[::(32 >> log2), :n][:n]
@@ -1555,6 +1646,14 @@ class SliceDecoder:
                 def px(k, i):          # sample i of line k: i = -4..-1 are p3..p0, 0..3 are q0..q3
                     return (y + k, x + i) if vertical else (y + i, x + k)
                 g = lambda k, i: int(Y[px(k, i)])
+                keep_p, keep_q = self.bypass[yp >> 2, xp >> 2], self.bypass[y >> 2, x >> 2]      # cu_transquant_bypass on either side: that side stays as it is
+
+                class _Side:           # writes to a side that is not to be modified are dropped
+                    def __setitem__(_s, key, val, Y=Y, keep_p=keep_p, keep_q=keep_q, x=x, y=y, vertical=vertical):
+                        on_p = (key[1] < x) if vertical else (key[0] < y)
+                        if not (keep_p if on_p else keep_q):
+                            Y[key] = val
+                YW = _Side()
                 dp0 = abs(g(0, -3) - 2 * g(0, -2) + g(0, -1)); dp3 = abs(g(3, -3) - 2 * g(3, -2) + g(3, -1))
                 dq0 = abs(g(0, 2) - 2 * g(0, 1) + g(0, 0)); dq3 = abs(g(3, 2) - 2 * g(3, 1) + g(3, 0))
                 if dp0 + dq0 + dp3 + dq3 >= beta:
@@ -1569,24 +1668,24 @@ class SliceDecoder:
                     p3, p2, p1, p0, q0, q1, q2, q3 = (g(k, i) for i in range(-4, 4))
                     if strong:
                         cl = lambda v, o: min(max(v, o - 2 * tc), o + 2 * tc)
-                        Y[px(k, -1)] = cl((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3, p0)
-                        Y[px(k, -2)] = cl((p2 + p1 + p0 + q0 + 2) >> 2, p1)
-                        Y[px(k, -3)] = cl((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3, p2)
-                        Y[px(k, 0)] = cl((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3, q0)
-                        Y[px(k, 1)] = cl((p0 + q0 + q1 + q2 + 2) >> 2, q1)
-                        Y[px(k, 2)] = cl((p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3, q2)
+                        YW[px(k, -1)] = cl((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3, p0)
+                        YW[px(k, -2)] = cl((p2 + p1 + p0 + q0 + 2) >> 2, p1)
+                        YW[px(k, -3)] = cl((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3, p2)
+                        YW[px(k, 0)] = cl((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3, q0)
+                        YW[px(k, 1)] = cl((p0 + q0 + q1 + q2 + 2) >> 2, q1)
+                        YW[px(k, 2)] = cl((p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3, q2)
                     else:
                         d = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4
                         if abs(d) < tc * 10:
                             d = min(max(d, -tc), tc)
-                            Y[px(k, -1)] = min(max(p0 + d, 0), 255)
-                            Y[px(k, 0)] = min(max(q0 - d, 0), 255)
+                            YW[px(k, -1)] = min(max(p0 + d, 0), 255)
+                            YW[px(k, 0)] = min(max(q0 - d, 0), 255)
                             if dep:
                                 dp = min(max((((p2 + p0 + 1) >> 1) - p1 + d) >> 1, -(tc >> 1)), tc >> 1)
-                                Y[px(k, -2)] = min(max(p1 + dp, 0), 255)
+                                YW[px(k, -2)] = min(max(p1 + dp, 0), 255)
                             if deq:
                                 dq = min(max((((q2 + q0 + 1) >> 1) - q1 - d) >> 1, -(tc >> 1)), tc >> 1)
-                                Y[px(k, 1)] = min(max(q1 + dq, 0), 255)
+                                YW[px(k, 1)] = min(max(q1 + dq, 0), 255)
             # chroma: edges on the 8-sample chroma grid, boundary strength 2 only
             for (x, y), bs in bs_map.items():
                 if bs != 2 or x >= self.w or y >= self.h:
@@ -1604,8 +1703,10 @@ class SliceDecoder:
                         pos = lambda i: (yc + k, xc + i) if vertical else (yc + i, xc + k)
                         p1, p0, q0, q1 = (int(C_[pos(i)]) for i in (-2, -1, 0, 1))
                         d = min(max((((q0 - p0) << 2) + p1 - q1 + 4) >> 3, -tc), tc)
-                        C_[pos(-1)] = min(max(p0 + d, 0), 255)
-                        C_[pos(0)] = min(max(q0 - d, 0), 255)
+                        if not self.bypass[yp >> 2, xp >> 2]:
+                            C_[pos(-1)] = min(max(p0 + d, 0), 255)
+                        if not self.bypass[y >> 2, x >> 2]:
+                            C_[pos(0)] = min(max(q0 - d, 0), 255)
 
     # ------------------------------------------------------------------------------------------- SAO (8.7.3)
     def apply_sao(self):
@@ -1641,3 +1742,10 @@ class SliceDecoder:
                                 e = 0 if e == 2 else e + 1
                             if e:
                                 out[y, x] = min(max(v + off[e - 1], 0), 255)
+        # 8.7.3: samples of coding units with cu_transquant_bypass_flag are not modified
+        if self.bypass.any():
+            for ci in range(3):
+                k = 4 >> (1 if ci else 0)
+                hh, ww = src[ci].shape
+                keep = np.kron(self.bypass, np.ones((k, k), np.int8))[:hh, :ww].astype(bool)
+                pic.planes[ci][keep] = src[ci][keep]

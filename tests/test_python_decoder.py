@@ -22,7 +22,7 @@ def test_context_init_values_agree_with_the_checker_and_the_product():
     """the per-syntax-element initValue tables typed in pyhevc.py against the checker's table (its own context order)"""
     init = table(3, np.uint8, (3, 154)).astype(int)
     # order of the checker's / product's context indices (hevc_core.h CTX_*)
-    order = [("sao_merge", 1), ("sao_type", 1), ("split_cu", 3), (None, 1), ("skip", 3), ("pred_mode", 1), ("part_mode", 4), ("prev_intra", 1),
+    order = [("sao_merge", 1), ("sao_type", 1), ("split_cu", 3), ("tq_bypass", 1), ("skip", 3), ("pred_mode", 1), ("part_mode", 4), ("prev_intra", 1),
              ("chroma_mode", 1), ("rqt_root", 1), ("merge_flag", 1), ("merge_idx", 1), (None, 5), ("ref_idx", 2), ("mvp", 1), ("split_tf", 3),
              ("cbf_luma", 2), ("cbf_chroma", 4), ("mvd_gt0", 1), ("mvd_gt1", 1), ("qp_delta", 2), ("ts_flag", 2), ("last_x", 18), ("last_y", 18),
              ("csbf", 4), ("sig", 42), ("gt1", 24), ("gt2", 6)]
@@ -118,6 +118,28 @@ def test_generator_everything_on():
                         wpp=1, tile_rows=2, th_depth_inter=2, th_depth_intra=2, qp_delta=2, chroma_qp_offsets=1, deblock_mode=2, par_mrg_level=3,
                         intra_in_p=25, all_part_modes=1, chroma_modes=1, nxn_intra=1, big_mvd=1)
     aus = [gen.picture() for _ in range(6)]
+    gen.close()
+    compare(aus)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(scaling_lists=1),                                                   # scaling_list_enabled_flag with the default lists: Kvazaar's `scaling-list default` (uvgComm's checkbox)
+    dict(scaling_lists=2, th_depth_inter=2, th_depth_intra=2, nxn_intra=1),  # lists in the SPS (explicit, copied, default), every block size
+    dict(scaling_lists=3, transform_skip=1),                                 # default in the SPS, the PPS's lists override them; 4x4 transform-skip blocks are scaled too
+    dict(scaling_lists=4, max_cu_log2=6, density=20),                        # both; 32x32 blocks
+    dict(tq_bypass=35),                                                      # cu_transquant_bypass_flag: the residual is the level array
+    dict(tq_bypass=50, sao=1, sign_hiding=1, transform_skip=1, deblock_mode=2, intra_in_p=30),   # ... and the loop filters leave those samples alone
+    dict(tq_bypass=100, sao=1),                                              # a lossless stream (Kvazaar's `lossless`, uvgComm's checkbox)
+    dict(scaling_lists=4, tq_bypass=25, qp_delta=2, chroma_qp_offsets=1),
+], ids=lambda kw: "-".join("%s%s" % (k[:4], v) for k, v in kw.items()))
+def test_generator_scaling_lists_and_transquant_bypass(kw):
+    """the two tools behind uvgComm's "scaling list" and "lossless" checkboxes (kvazaarfilter.cpp:235-244), read from the standard's text a second
+    time: scaling_list_data with its three ways of coding a list, the scaling factors of 7.4.5, cu_transquant_bypass in parse, reconstruction,
+    deblocking and SAO"""
+    cfg = dict(width=200, height=136, seed=91, density=35, num_refs=2, tmvp=1)
+    cfg.update(kw)
+    gen = orc.OracleGen(**cfg)
+    aus = [gen.picture() for _ in range(5)]
     gen.close()
     compare(aus)
 

@@ -21,7 +21,8 @@ struct B4Rec {
   int8_t qp_y;             // QpY of the coding unit (8.6.1)
   uint8_t slot;            // picture buffer of the reference picture: two indices naming one picture share it (8.7.2.4 compares pictures)
 };
-enum { B4_NZ = 1,          // the luma transform block covering this 4x4 has non-zero coefficients
+enum { B4_BYPASS = 32,      // cu_transquant_bypass_flag: the loop filters leave this block's samples as they are (8.7.2.5.7, 8.7.3)
+       B4_NZ = 1,          // the luma transform block covering this 4x4 has non-zero coefficients
        B4_EDGE_V = 2,      // the left edge of this 4x4 is a transform-block or prediction-block edge
        B4_TU_V = 4,        //   ... a transform-block edge
        B4_EDGE_H = 8, B4_TU_H = 16 };      // the same for the top edge
@@ -38,7 +39,20 @@ struct DecTu {
   uint16_t count;          // non-zero levels: `count` words (raster position inside the block << 16 | level & 0xffff) from word `offset`
   uint32_t offset;
 };
-enum { TU_INTRA = 1, TU_TSKIP = 2, TU_DST = 4 };
+enum { TU_INTRA = 1, TU_TSKIP = 2, TU_DST = 4, TU_BYPASS = 8 };      // TU_BYPASS: cu_transquant_bypass_flag -- the residual is the level array itself (8.6.2)
+
+// Scaling factors m[x][y] of 8.6.4.2 for the active scaling lists (7.4.5; host: decoder.hip build_scaling), one byte per coefficient, raster inside the block
+// (index = the level word's position field): [6][16] 4x4 | [6][64] 8x8 | [6][256] 16x16 | [2][1024] 32x32; matrix = 3 * inter + plane (32x32: inter)
+#define KVZ_SCALING_BYTES 4064
+KVZ_HD int scaling_offset(int log2n, int plane, int inter)
+{
+  switch (log2n) {
+    case 2: return (3 * inter + plane) * 16;
+    case 3: return 96 + (3 * inter + plane) * 64;
+    case 4: return 480 + (3 * inter + plane) * 256;
+    default: return 2016 + inter * 1024;
+  }
+}
 
 struct TuRange { uint32_t first, count; };
 
@@ -69,7 +83,9 @@ struct DecFrame {
   int8_t beta_offset, tc_offset;           // slice_beta_offset_div2 * 2, slice_tc_offset_div2 * 2
   uint8_t intra_direct;     // k_dec_intra: a workgroup per (CTU, plane) in dispatch order instead of tickets (pictures that are mostly inter: nearly every (CTU, plane) has nothing to do, and a ticket is a memory round trip)
   uint8_t strong_intra, tiles;             // strong_intra_smoothing_enabled_flag; more than one tile
-  uint8_t pad_[2];
+  uint8_t tq_bypass;        // the picture may hold coding units with cu_transquant_bypass_flag (B4_BYPASS / TU_BYPASS): the loop filters look at the flags
+  uint8_t pad_[1];
+  const uint8_t *scaling;   // KVZ_SCALING_BYTES scaling factors (scaling_list_enabled_flag), NULL: flat 16
 };
 
 // Several pictures in ONE launch (batch.h: pictures of different decoder instances that are ready at the same time): the kernel argument is

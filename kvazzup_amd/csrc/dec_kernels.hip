@@ -28,6 +28,15 @@ namespace kvzx {
 typedef const KVZ_CONST_AS DecFrame CDecFrame;
 struct Wg { int id, n; };
 
+// level -> coefficient of one transform block (8.6.4.2): flat scaling, the scaling factor of the position (scaling lists), or -- coding units with
+// cu_transquant_bypass_flag -- the level itself, which then IS the residual sample (8.6.2)
+template <class F> __device__ __forceinline__ int dec_dequant(const F &f, const DecTu &d, int pos, int level)
+{
+  if (d.flags & TU_BYPASS) return level;
+  if (f.scaling) return dequant_coef_m(level, d.qp, d.log2, f.scaling[scaling_offset(d.log2, d.plane, (d.flags & TU_INTRA) ? 0 : 1) + pos]);
+  return dequant_coef(level, d.qp, d.log2);
+}
+
 __device__ __forceinline__ int zorder3(int x, int y)      // 3 + 3 bits
 {
   int z = 0;
@@ -183,7 +192,7 @@ template <class F> __device__ __forceinline__ void dec_inter_body(const F &f, co
     s.td[t] = d;
     if (d.count) {
       my_coded = true;
-      if (!(d.flags & TU_TSKIP)) {
+      if (!(d.flags & (TU_TSKIP | TU_BYPASS))) {
         const int cls = d.log2 - 2;
         int blk;
         if (d.plane == 0) blk = zorder3((d.x - x0) >> 2, (d.y - y0) >> 2) >> (2 * cls);
@@ -304,11 +313,11 @@ template <class F> __device__ __forceinline__ void dec_inter_body(const F &f, co
       const DecTu d = s.td[lo];
       const uint32_t wd = f.lev[d.offset + (i - s.tstart[lo])];
       const int n = 1 << d.log2, pos = (int)(wd >> 16) & (n * n - 1), row = pos >> d.log2, col = pos & (n - 1);
-      const int coef = dequant_coef((int16_t)(wd & 0xffffu), d.qp, d.log2);
+      const int coef = dec_dequant(f, d, pos, (int16_t)(wd & 0xffffu));
       const int lx = d.plane ? d.x - (x0 >> 1) : d.x - x0, ly = d.plane ? d.y - (y0 >> 1) : d.y - y0;
-      if (d.flags & TU_TSKIP) {                           // 8.6.4.2 with transform_skip_flag: residual = coefficient << 7, then the common shift
+      if (d.flags & (TU_TSKIP | TU_BYPASS)) {             // 8.6.4.2 with transform_skip_flag: residual = coefficient << 7, then the common shift; transquant bypass: the level
         uint8_t *q = d.plane ? &s.px[1024 + (d.plane - 1) * 256 + (ly + row) * 16 + lx + col] : &s.px[(ly + row) * 32 + lx + col];
-        *q = (uint8_t)clip8(*q + (((coef << 7) + 2048) >> 12));
+        *q = (uint8_t)clip8(*q + ((d.flags & TU_BYPASS) ? coef : (((coef << 7) + 2048) >> 12)));
       } else {
         const int base = d.plane ? 1024 + (d.plane - 1) * 256 + zorder3(lx >> 2, ly >> 2) * 16 : zorder3(lx >> 2, ly >> 2) * 16;
         s.C[base + col * n + row] = (int16_t)coef;
@@ -381,7 +390,7 @@ __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, cons
   const bool filt = intra_filter_needed(N, cidx, mode);
   const int Xc = cx * S + rx, Yc = cy * S + ry, X = Xc << sh, Y = Yc << sh;
   // (the block's first 4 T level words arrive in wreg: loaded by the caller one block ahead)
-  const bool has = d.count != 0, tskip = (d.flags & TU_TSKIP) != 0;
+  const bool has = d.count != 0, bypass = (d.flags & TU_BYPASS) != 0, tskip = (d.flags & TU_TSKIP) != 0 || bypass;
   // ---- reference samples (8.4.4.2.2) and their filtered version (8.4.4.2.3).  The available samples are contiguous in scan
   // order (one slice, tiles are full-width rows), so the substitution process is a clamp of the scan index into [lo, hi].
   {
@@ -418,7 +427,7 @@ __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, cons
     __syncthreads();
     auto put = [&](uint32_t wd) {
       const int pos = (int)(wd >> 16) & (N * N - 1), row = pos >> L2, col = pos & (N - 1);
-      s.A[col * N + row] = (int16_t)dequant_coef((int16_t)(wd & 0xffffu), d.qp, L2);
+      s.A[col * N + row] = (int16_t)dec_dequant(f, d, pos, (int16_t)(wd & 0xffffu));
     };
 #pragma unroll
     for (int k = 0; k < 4; k++) if (lane + k * T < (int)d.count) put(wreg[k]);
@@ -464,7 +473,7 @@ __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, cons
 #pragma unroll
         for (int e = 0; e < 2; e++)
 #pragma unroll
-          for (int o = 0; o < OPL; o++) pred[e][o] = clip8(pred[e][o] + ((((int)s.A[(g * OPL + o) * N + 2 * rp + e] << 7) + 2048) >> 12));
+          for (int o = 0; o < OPL; o++) { const int a = s.A[(g * OPL + o) * N + 2 * rp + e]; pred[e][o] = clip8(pred[e][o] + (bypass ? a : (((a << 7) + 2048) >> 12))); }
       }
     } else {
       const int16_t *Mt = s.M[1] + ((L2 == 2 && (d.flags & TU_DST)) ? KV_DST_OFFSET : matrix_offset(L2));
@@ -512,11 +521,15 @@ template <class F> __device__ __forceinline__ void dec_intra_resid_body(const F 
   for (int i = lane; i < (int)d.count; i += 64) {
     const uint32_t wd = f.lev[d.offset + i];
     const int pos = (int)(wd >> 16) & (N * N - 1);
-    ws.tr[(pos & (N - 1)) * 16 + (pos >> L2)] = (int16_t)dequant_coef_p((int16_t)(wd & 0xffffu), dqc);
+    const int lv = (int16_t)(wd & 0xffffu);
+    ws.tr[(pos & (N - 1)) * 16 + (pos >> L2)] = (int16_t)((f.scaling || (d.flags & TU_BYPASS)) ? dec_dequant(f, d, pos, lv) : dequant_coef_p(lv, dqc));
   }
   wave_sync();
   int res[4];
-  if (d.flags & TU_TSKIP) {
+  if (d.flags & TU_BYPASS) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) res[r] = ws.tr[(4 * g + r) * 16 + c];                                  // transquant bypass: the residual is the level
+  } else if (d.flags & TU_TSKIP) {
 #pragma unroll
     for (int r = 0; r < 4; r++) res[r] = (((int)ws.tr[(4 * g + r) * 16 + c] << 7) + 2048) >> 12;      // residual (x = 4g + r, y = c) = level at row c, column 4g + r
   } else {
@@ -787,6 +800,22 @@ template <class F> __device__ __forceinline__ void dec_deblock_body(const F &f, 
     }
   }
   __syncthreads();
+  // coding units with cu_transquant_bypass_flag are not modified by the filter (8.7.2.5.7: nDp / nDq = 0).  The picture in memory still holds the unfiltered
+  // samples (this kernel writes at its end): their units are fetched again after each pass.
+  auto restore_bypass = [&]() {
+    for (int i = tid; i < 17 * 17; i += 256) {
+      const int uy = i / 17, ux = i - uy * 17;                    // unit inside the tile: luma (4 ux, 4 uy) from (X0, Y0)
+      if (4 * ux >= TW || 4 * uy >= TH) continue;
+      const int gx = X0 + 4 * ux, gy = Y0 + 4 * uy;
+      if (gx < 0 || gy < 0 || gx >= f.w || gy >= f.h) continue;
+      if (!(recs[uy * 18 + ux].flags & B4_BYPASS)) continue;      // (recs: units -1 .. 16 of the CTU = units 0 .. 17 of the tile shifted by one unit)
+      for (int r = 0; r < 4; r++) *(uint32_t *)&ty_[(4 * uy + r) * P + 4 * ux] = *(const uint32_t *)&f.rec[0][(size_t)(gy + r) * f.pw + gx];
+      for (int pl = 0; pl < 2; pl++)
+        for (int r = 0; r < 2; r++) *(uint16_t *)&tc_[pl][(2 * uy + r) * PC + 2 * ux + 2] = *(const uint16_t *)&f.rec[1 + pl][(size_t)((gy >> 1) + r) * cw2 + (gx >> 1)];
+    }
+    __syncthreads();
+  };
+  if (f.tq_bypass) restore_bypass();
   // ---- horizontal edges on the vertically filtered samples
   if (bsh) {
     const int y = tyi * 64 + (tid & 7) * 8, x = X0 + (tid >> 3) * 4;
@@ -798,6 +827,7 @@ template <class F> __device__ __forceinline__ void dec_deblock_body(const F &f, 
     }
   }
   __syncthreads();
+  if (f.tq_bypass) restore_bypass();
   for (int i = tid; i < TH * 5; i += 256) {
     const int y = i / 5, k = i - y * 5, x = k * 16, gx = X0 + x, gy = Y0 + y;
     if (gy < 0 || x >= TW) continue;
@@ -894,6 +924,13 @@ template <class F> __device__ __forceinline__ void dec_sao_body(const F &f, cons
           o |= (uint32_t)(k ? clip8(v + off[k - 1]) : v) << (8 * i);
         }
         out = o;
+      }
+      if (f.tq_bypass) {                                                        // 8.7.3: samples of coding units with cu_transquant_bypass_flag are not modified
+        const int lx = (X0 + x4) << sh, ly = (Y0 + y) << sh, b4w = f.pw >> 2;
+        const bool k0 = (f.b4[(size_t)(ly >> 2) * b4w + (lx >> 2)].flags & B4_BYPASS) != 0;
+        const bool k1 = c ? (f.b4[(size_t)(ly >> 2) * b4w + (lx >> 2) + 1].flags & B4_BYPASS) != 0 : k0;      // (four chroma samples span two luma units)
+        if (k0) out = (out & 0xffff0000u) | (row[1] & 0x0000ffffu);
+        if (k1) out = (out & 0x0000ffffu) | (row[1] & 0xffff0000u);
       }
       *(uint32_t *)&f.out[c][(size_t)(Y0 + y) * pitch_g + X0 + x4] = out;
     }

@@ -11,11 +11,12 @@
 // slices, every CU size and partitioning (AMP included), intra CUs in P pictures, NxN intra, all chroma
 // prediction modes, transform trees, several reference pictures (RPS in the SPS or the slice header, inter RPS prediction),
 // temporal motion vector prediction, merge levels, cu_qp_delta at any quantisation-group size, chroma QP offsets, sign data
-// hiding, transform skip, deblocking offsets / overrides, SAO, WPP, tile grids up to the level limit of 20 columns x 22 rows (uniform or
+// hiding, transform skip, scaling lists (default, SPS and PPS scaling_list_data), cu_transquant_bypass (lossless coding units), deblocking offsets /
+// overrides, SAO, WPP, tile grids up to the level limit of 20 columns x 22 rows (uniform or
 // explicit spacing), pictures in several slice segments the two ways Kvazaar cuts them (a dependent slice segment per CTU row with WPP, an
 // independent slice per tile).  Rejected with a negative return value (kvzx_decoder_last_error): B slices, slice segments that are
 // neither whole CTU rows nor whole tiles, loop_filter_across_tiles_enabled_flag = 0, long-term references, reference list modification,
-// weighted prediction, scaling lists, PCM, lossless coding, constrained intra prediction, other CTB / CB / TB sizes.
+// weighted prediction, PCM, constrained intra prediction, other CTB / CB / TB sizes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -50,6 +51,9 @@ struct DecSps {
   int num_st_rps = 0; StRps st_rps[65];
   uint32_t fps_num = 0, fps_den = 0;
   int strong_intra = 0, sao = 0, tmvp = 0, amp = 0, th_depth_inter = 0, th_depth_intra = 0;
+  // scaling_list_enabled_flag: the scaling factors (dec_frame.h KVZ_SCALING_BYTES) of the SPS's lists -- the default ones (Tables 7-5 / 7-6) without
+  // sps_scaling_list_data; NULL: flat.  What uvgComm's "scaling list" checkbox switches on in a peer's Kvazaar (kvazaarfilter.cpp:235-242).
+  std::shared_ptr<const std::vector<uint8_t>> scaling;
 };
 struct DecPps {
   bool valid = false;
@@ -63,6 +67,8 @@ struct DecPps {
   int uniform_tiles = 1, row_height[33], col_width[33];
   int deblock_control = 0, deblock_override = 0, deblock_disabled = 0, beta_offset_div2 = 0, tc_offset_div2 = 0, loop_filter_across_slices = 1;
   int par_mrg_level = 2;
+  int tq_bypass = 0;                                   // transquant_bypass_enabled_flag (a peer's Kvazaar with `lossless`, kvazaarfilter.cpp:244)
+  std::shared_ptr<const std::vector<uint8_t>> scaling; // pps_scaling_list_data: these factors instead of the SPS's
 };
 
 struct DecodedPicture {
@@ -214,7 +220,8 @@ class Decoder {
   size_t off_ctu() const { return off_region() + (size_t)(pw_ / 32) * (ph_ / 32) * sizeof(TuRange); }
   size_t off_tile() const { return off_ctu() + (size_t)(pw_ / 64) * (ph_ / 64) * sizeof(TuRange); }
   size_t off_sao() const { return (off_tile() + (size_t)(pw_ / 64) * (ph_ / 64) + 15) & ~(size_t)15; }
-  size_t off_frame() const { return (off_sao() + (size_t)(pw_ / 64) * (ph_ / 64) * sizeof(SaoParams) + 63) & ~(size_t)63; }     // the picture's DecFrame, for launches that read it from device memory (batch.h)
+  size_t off_scaling() const { return (off_sao() + (size_t)(pw_ / 64) * (ph_ / 64) * sizeof(SaoParams) + 63) & ~(size_t)63; }     // KVZ_SCALING_BYTES scaling factors (pictures with scaling lists)
+  size_t off_frame() const { return (off_scaling() + KVZ_SCALING_BYTES + 63) & ~(size_t)63; }     // the picture's DecFrame, for launches that read it from device memory (batch.h)
   size_t fixed_bytes() const { return (off_frame() + sizeof(DecFrame) + 15) & ~(size_t)15; }
   bool grow_job_input(PicJob &job, size_t bytes);
   void bind_job(PicJob &job);

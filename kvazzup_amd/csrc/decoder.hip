@@ -370,6 +370,7 @@ struct SliceParser {
   // cu_edges: the rectangle is a whole coding block -- its top row and left column get the coding block's edge flags in the same pass (a
   // read-modify-write of the column afterwards waits for every one of the stores just issued: it was the hottest line of the parser)
   bool cu_edges_done = false;
+  int cu_bypass = 0;                                       // cu_transquant_bypass_flag of the coding unit being parsed
   void fill_recs(int x0, int y0, int bw, int bh, const B4Rec &r, bool cu_edges = false)
   {
     uint64_t v; memcpy(&v, &r, 8);
@@ -560,7 +561,7 @@ struct SliceParser {
       const int bot = imax(yp + bh + (mvy >> 2) + (fy ? 4 : 0), 2 * ((yp >> 1) + (bh >> 1) + (mvy >> 3) + (fc ? 2 : 0)));
       if (top < ref_y0 || bot > ref_y1) err = DEC_ERR_UNSUPPORTED;
     }
-    B4Rec r; r.mvx = (int16_t)mvx; r.mvy = (int16_t)mvy; r.ref_idx = (int8_t)ref_idx; r.flags = 0; r.qp_y = (int8_t)qp_y; r.slot = job.ref_slot[ref_idx];
+    B4Rec r; r.mvx = (int16_t)mvx; r.mvy = (int16_t)mvy; r.ref_idx = (int8_t)ref_idx; r.flags = (uint8_t)(cu_bypass ? B4_BYPASS : 0); r.qp_y = (int8_t)qp_y; r.slot = job.ref_slot[ref_idx];
     fill_recs(xp, yp, bw, bh, r, bw == ncbs && bh == ncbs);
     if (bw != ncbs || bh != ncbs) {                          // prediction block edges inside the coding block (deblocking); the block's own are set by coding_unit
       for (int i = 0; i < bh && yp + i < h; i += 4) b4[bi(xp, yp + i)].flags |= B4_EDGE_V;
@@ -589,11 +590,11 @@ struct SliceParser {
     const int lmode = intra ? im[bi(x0, y0)] : 0;
     if (intra || cbf_luma) {
       td.x = (uint16_t)x0; td.y = (uint16_t)y0; td.plane = 0; td.log2 = (uint8_t)log2; td.mode = (uint8_t)lmode; td.qp = (int8_t)qp_y;
-      td.flags = (uint8_t)((intra ? TU_INTRA : 0) | ((intra && log2 == 2) ? TU_DST : 0));
+      td.flags = (uint8_t)((intra ? TU_INTRA : 0) | ((intra && log2 == 2) ? TU_DST : 0) | (cu_bypass ? TU_BYPASS : 0));
       td.offset = (uint32_t)out.levels.size(); td.count = 0;
       if (cbf_luma) {
         int ts;
-        if (!parse_residual(c, log2, 0, intra_scan_idx(intra, log2, 0, lmode), pps.sign_hiding != 0, pps.tskip != 0, &ts, out.levels)) { err = DEC_ERR_INVALID; return; }
+        if (!parse_residual(c, log2, 0, intra_scan_idx(intra, log2, 0, lmode), pps.sign_hiding != 0 && !cu_bypass, pps.tskip != 0 && !cu_bypass, &ts, out.levels)) { err = DEC_ERR_INVALID; return; }
         td.count = (uint16_t)(out.levels.size() - td.offset);
         if (ts) td.flags |= TU_TSKIP;
         for (int y = y0; y < y0 + n && y < h; y += 4) for (int x = x0; x < x0 + n && x < w; x += 4) b4[bi(x, y)].flags |= B4_NZ;
@@ -608,11 +609,11 @@ struct SliceParser {
         if (!intra && !cbf) continue;
         td.x = (uint16_t)cx; td.y = (uint16_t)cy; td.plane = (uint8_t)ci; td.log2 = (uint8_t)clog2; td.mode = (uint8_t)chroma_mode;
         td.qp = (int8_t)kChromaQp[clip3(0, 57, qp_y + (ci == 1 ? sh.cb_qp_offset : sh.cr_qp_offset))];
-        td.flags = (uint8_t)(intra ? TU_INTRA : 0);
+        td.flags = (uint8_t)((intra ? TU_INTRA : 0) | (cu_bypass ? TU_BYPASS : 0));
         td.offset = (uint32_t)out.levels.size(); td.count = 0;
         if (cbf) {
           int ts;
-          if (!parse_residual(c, clog2, ci, intra_scan_idx(intra, clog2, ci, chroma_mode), pps.sign_hiding != 0, pps.tskip != 0, &ts, out.levels)) { err = DEC_ERR_INVALID; return; }
+          if (!parse_residual(c, clog2, ci, intra_scan_idx(intra, clog2, ci, chroma_mode), pps.sign_hiding != 0 && !cu_bypass, pps.tskip != 0 && !cu_bypass, &ts, out.levels)) { err = DEC_ERR_INVALID; return; }
           td.count = (uint16_t)(out.levels.size() - td.offset);
           if (ts) td.flags |= TU_TSKIP;
         }
@@ -662,6 +663,7 @@ struct SliceParser {
   {
     const int n = 1 << log2cb;
     int skip = 0;
+    cu_bypass = pps.tq_bypass ? c.bin(CTX_TQ_BYPASS) : 0;      // cu_transquant_bypass_flag (7.3.8.5: first in the coding unit)
     if (!sh.is_intra) {
       const int l = avail(x0, y0, x0 - 1, y0) && pm[b8(x0 - 1, y0)] == PM_SKIP, a = avail(x0, y0, x0, y0 - 1) && pm[b8(x0, y0 - 1)] == PM_SKIP;
       skip = c.bin(CTX_SKIP + l + a);
@@ -728,7 +730,7 @@ struct SliceParser {
         static const int cm[4] = {0, 26, 10, 1};
         if (icpm == 4) chroma_mode = intra_modes[0];
         else { chroma_mode = cm[icpm]; if (chroma_mode == intra_modes[0]) chroma_mode = 34; }
-        B4Rec r; r.mvx = 0; r.mvy = 0; r.ref_idx = -1; r.flags = 0; r.qp_y = (int8_t)qp_y; r.slot = 0;
+        B4Rec r; r.mvx = 0; r.mvy = 0; r.ref_idx = -1; r.flags = (uint8_t)(cu_bypass ? B4_BYPASS : 0); r.qp_y = (int8_t)qp_y; r.slot = 0;
         fill_recs(x0, y0, n, n, r, true);
         job.any_intra = true;
       } else {
@@ -1044,6 +1046,65 @@ bool Decoder::queue_current_output()
   return true;
 }
 
+// ------------------------------------------------------------------------------------------ scaling lists (7.3.4, 7.4.5)
+namespace {
+// Table 7-6: the default 8x8 lists (symmetric matrices, here in raster order); Table 7-5: 16 everywhere
+const uint8_t kScalingIntra8[64] = {16, 16, 16, 16, 17, 18, 21, 24, 16, 16, 16, 16, 17, 19, 22, 25, 16, 16, 17, 18, 20, 22, 25, 29, 16, 16, 18, 21, 24, 27, 31, 36,
+                                    17, 17, 20, 24, 30, 35, 41, 47, 18, 19, 22, 27, 35, 44, 54, 65, 21, 22, 25, 31, 41, 54, 70, 88, 24, 25, 29, 36, 47, 65, 88, 115};
+const uint8_t kScalingInter8[64] = {16, 16, 16, 16, 17, 18, 20, 24, 16, 16, 16, 17, 18, 20, 24, 25, 16, 16, 17, 18, 20, 24, 25, 28, 16, 17, 18, 20, 24, 25, 28, 33,
+                                    17, 18, 20, 24, 25, 28, 33, 41, 18, 20, 24, 25, 28, 33, 41, 54, 20, 24, 25, 28, 33, 41, 54, 71, 24, 25, 28, 33, 41, 54, 71, 91};
+// the lists as coded: 8x8 rasters (4x4 for size 0) + the DC entries of the 16x16 / 32x32 lists
+struct ScalingLists { uint8_t m[4][6][64]; uint8_t dc[2][6]; };
+void scaling_default_one(ScalingLists &sl, int s, int m)
+{
+  if (s == 0) memset(sl.m[0][m], 16, 16);
+  else memcpy(sl.m[s][m], (s == 3 ? m >= 1 : m >= 3) ? kScalingInter8 : kScalingIntra8, 64);
+  if (s >= 2) sl.dc[s - 2][m] = 16;
+}
+// scaling_list_data(): every list either the default one, a copy of an earlier list of its size, or 16 / 64 entries in diagonal scan order
+bool parse_scaling_list_data(BitReader &r, ScalingLists &sl)
+{
+  const ScanTabs &st = scan_tabs();
+  for (int s = 0; s < 4; s++)
+    for (int m = 0; m < (s == 3 ? 2 : 6); m++) {
+      if (!r.get(1)) {
+        const uint32_t delta = r.ue();
+        if (delta > (uint32_t)m) return false;
+        if (delta == 0) scaling_default_one(sl, s, m);
+        else { memcpy(sl.m[s][m], sl.m[s][m - (int)delta], 64); if (s >= 2) sl.dc[s - 2][m] = sl.dc[s - 2][m - (int)delta]; }
+      } else {
+        int next = 8;
+        if (s >= 2) { const int dc = r.se(); if (dc < -7 || dc > 247) return false; next = dc + 8; sl.dc[s - 2][m] = (uint8_t)next; }
+        const int l2 = s == 0 ? 2 : 3, n = 1 << l2;
+        for (int i = 0; i < n * n; i++) {
+          const int d = r.se();
+          if (d < -128 || d > 127) return false;
+          next = (next + d + 256) & 255;
+          if (!next) return false;
+          sl.m[s][m][st.y[0][l2][i] * n + st.x[0][l2][i]] = (uint8_t)next;      // diagonal scan position i -> (x, y)
+        }
+      }
+      if (r.err) return false;
+    }
+  return true;
+}
+// 7.4.5: the factors of every block size as rasters (dec_frame.h scaling_offset): 16x16 / 32x32 repeat the 8x8 entries 2 x 2 / 4 x 4 times, DC apart
+std::shared_ptr<const std::vector<uint8_t>> build_scaling(const ScalingLists &sl)
+{
+  auto out = std::make_shared<std::vector<uint8_t>>((size_t)KVZ_SCALING_BYTES);
+  uint8_t *p = out->data();
+  for (int s = 0; s < 4; s++)
+    for (int m = 0; m < (s == 3 ? 2 : 6); m++) {
+      const int n = 4 << s, rep = s == 0 ? 1 : n >> 3, src_n = s == 0 ? 4 : 8;
+      uint8_t *q = p + scaling_offset(s + 2, s == 3 ? 0 : m % 3, s == 3 ? m : m / 3);
+      for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) q[y * n + x] = sl.m[s][m][(y / rep) * src_n + x / rep];
+      if (s >= 2) q[0] = sl.dc[s - 2][m];
+    }
+  return out;
+}
+ScalingLists scaling_defaults() { ScalingLists sl; memset(&sl, 16, sizeof(sl)); for (int s = 0; s < 4; s++) for (int m = 0; m < (s == 3 ? 2 : 6); m++) scaling_default_one(sl, s, m); return sl; }
+}  // namespace
+
 int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
 {
   Tick tk_nal;
@@ -1092,10 +1153,15 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     for (int k = oi ? 0 : msl; k <= msl; k++) { r.ue(); r.ue(); r.ue(); }
     int log2_min_cb = r.ue() + 3, diff_cb = r.ue(), log2_min_tb = r.ue() + 2, diff_tb = r.ue();
     s.th_depth_inter = r.ue(); s.th_depth_intra = r.ue();
-    int scaling = r.get(1); s.amp = r.get(1); s.sao = r.get(1); int pcm = r.get(1);
+    if (r.get(1)) {                                             // scaling_list_enabled_flag: the default lists, or sps_scaling_list_data
+      ScalingLists sl = scaling_defaults();
+      if (r.get(1) && !parse_scaling_list_data(r, sl)) return last_error_ = DEC_ERR_INVALID;
+      s.scaling = build_scaling(sl);
+    }
+    s.amp = r.get(1); s.sao = r.get(1); int pcm = r.get(1);
     if (r.err) return last_error_ = DEC_ERR_INVALID;
     // coding geometry: CTB 64, coding blocks 8..64, transform blocks 4..32 -- what Kvazaar always writes
-    if (scaling || pcm || log2_min_cb != 3 || diff_cb != 3 || log2_min_tb != 2 || diff_tb != 3 || s.th_depth_inter > 4 || s.th_depth_intra > 4)
+    if (pcm || log2_min_cb != 3 || diff_cb != 3 || log2_min_tb != 2 || diff_tb != 3 || s.th_depth_inter > 4 || s.th_depth_intra > 4)
       return last_error_ = DEC_ERR_UNSUPPORTED;
     s.num_st_rps = r.ue();
     if (s.num_st_rps > 64) return last_error_ = DEC_ERR_INVALID;
@@ -1134,7 +1200,8 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     p.wpp = r.get(1);
     if (r.err || p.num_ref_idx_default > 15 || p.cb_qp_offset < -12 || p.cb_qp_offset > 12 || p.cr_qp_offset < -12 || p.cr_qp_offset > 12) return last_error_ = DEC_ERR_INVALID;
     p.dependent_slices = dep;
-    if (cip || wp || wbp || tqb) return last_error_ = DEC_ERR_UNSUPPORTED;   // constrained intra, weighted prediction, lossless
+    if (cip || wp || wbp) return last_error_ = DEC_ERR_UNSUPPORTED;   // constrained intra, weighted prediction
+    p.tq_bypass = tqb;
     if (tiles) {                                                 // supported: the level limits of 20 columns x 22 rows (A.4.2); loop filter across tiles on
       const int cols = r.ue() + 1, rows = r.ue() + 1; p.uniform_tiles = r.get(1);
       if (cols > 20 || rows > 22) return last_error_ = DEC_ERR_UNSUPPORTED;
@@ -1152,7 +1219,11 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
       p.deblock_disabled = r.get(1);
       if (!p.deblock_disabled) { p.beta_offset_div2 = r.se(); p.tc_offset_div2 = r.se(); }
     }
-    if (r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;      // scaling list data
+    if (r.get(1)) {                                              // pps_scaling_list_data: instead of the SPS's lists
+      ScalingLists sl = scaling_defaults();
+      if (!parse_scaling_list_data(r, sl)) return last_error_ = DEC_ERR_INVALID;
+      p.scaling = build_scaling(sl);
+    }
     if (r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;      // lists_modification_present_flag
     p.par_mrg_level = (int)r.ue() + 2;
     p.header_extension = r.get(1);
@@ -1873,6 +1944,12 @@ int Decoder::launch_gpu(PicJob &job)
   f.beta_offset = (int8_t)(2 * job.sh.beta_offset_div2); f.tc_offset = (int8_t)(2 * job.sh.tc_offset_div2);
   f.intra_direct = job.any_inter ? 1 : 0;                 // (a picture with inter blocks: few (CTU, plane) pairs hold intra blocks)
   f.strong_intra = (uint8_t)job.sps->strong_intra; f.tiles = job.pps.tile_rows > 1 || job.pps.tile_cols > 1;
+  f.tq_bypass = (uint8_t)job.pps.tq_bypass;
+  // scaling lists: the picture's factors (the PPS's lists when it carries any, else the SPS's) ride in the input block
+  const std::vector<uint8_t> *sc = job.pps.scaling ? job.pps.scaling.get() : job.sps->scaling.get();
+  if (!job.sps->scaling) sc = nullptr;                     // (scaling_list_enabled_flag = 0: a PPS's lists are not used)
+  f.scaling = nullptr;
+  if (sc) { memcpy(job.h_in + off_scaling(), sc->data(), KVZ_SCALING_BYTES); f.scaling = d_in_ + off_scaling(); }
   if (band_nrows_ > 0) {
     // a band starts and ends on tile boundaries of full-width tiles; no SAO, no temporal prediction (what the split encoder writes)
     bool ok = !sao && !job.sps->tmvp && job.pps.tile_cols == 1 && frame_threads_ == 1, top = false, bottom = false;

@@ -1107,6 +1107,14 @@ KVZ_HD int adjust_group(int16_t (&lv)[16], const uint16_t (&aux)[16], bool dc_gr
   return nz;
 }
 
+// ... with the scaling factor m of the coefficient's position (scaling lists); m = 16 is the flat case below
+KVZ_HD int dequant_coef_m(int level, int qp, int log2n, int m)
+{
+  int bd = 8 + log2n - 5;
+  int scale = kLevelScale[qp % 6] << (qp / 6);
+  int64_t v = ((int64_t)level * m * scale + ((int64_t)1 << (bd - 1))) >> bd;
+  return (int)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+}
 KVZ_HD int dequant_coef(int level, int qp, int log2n)
 {
   int bd = 8 + log2n - 5;

@@ -65,6 +65,16 @@ PLAIN = dict(num_refs=1, tmvp=0, amp=0, sao=0, strong_intra=1, sign_hiding=0, tr
     dict(cabac_init=1),
     dict(wpp=0), dict(wpp=0, tile_rows=3), dict(wpp=1, tile_rows=2, uniform_tiles=0),
     dict(big_mvd=1),
+    # a peer whose uvgComm has the "scaling list" / "lossless" boxes ticked (kvazaarfilter.cpp:235-244), and what else those syntax elements allow
+    dict(scaling_lists=1),                              # scaling_list_enabled_flag, default lists (Kvazaar `scaling-list default`)
+    dict(scaling_lists=1, max_cu_log2=6, intra_in_p=30, nxn_intra=1, th_depth_inter=2, th_depth_intra=2),      # ... every block size, intra and inter matrices
+    dict(scaling_lists=2, intra_in_p=25, th_depth_inter=2, th_depth_intra=2, transform_skip=1, nxn_intra=1),   # lists in the SPS; 4x4 transform-skip blocks are scaled
+    dict(scaling_lists=3, max_cu_log2=6, intra_in_p=25),                                                      # default in the SPS, the PPS's lists
+    dict(scaling_lists=4, qp_delta=2, chroma_qp_offsets=1, th_depth_inter=1),
+    dict(tq_bypass=35, intra_in_p=30, th_depth_inter=2, th_depth_intra=2, nxn_intra=1),                        # cu_transquant_bypass_flag on some coding units
+    dict(tq_bypass=50, sao=1, sign_hiding=1, transform_skip=1, intra_in_p=30, max_cu_log2=6),                  # ... beside SAO, sign hiding, transform skip: the loop filters keep out
+    dict(tq_bypass=100, sao=1, intra_in_p=20),                                                                # a lossless stream (Kvazaar `lossless`)
+    dict(tq_bypass=30, scaling_lists=4, deblock_mode=2, qp_delta=3),
 ])
 def test_feature_matches_oracle(gpu, feature):
     """one tool at a time on top of a plain stream; 416x240 (partial CTUs on both axes), 6 pictures"""
@@ -79,6 +89,26 @@ def test_random_streams_match_oracle(gpu, seed):
     sizes = [(416, 240), (352, 288), (200, 136), (64, 64), (24, 16), (648, 360)]
     w, h = sizes[seed % len(sizes)]
     run_stream(w, h, 8, seed=seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(100, 112))
+def test_random_streams_with_scaling_lists_and_transquant_bypass(gpu, seed):
+    """every other switch drawn from the seed; scaling lists in all five forms, no / some / all coding units bypassing transform and quantisation"""
+    sizes = [(416, 240), (352, 288), (200, 136), (648, 360)]
+    w, h = sizes[seed % len(sizes)]
+    run_stream(w, h, 6, seed=seed, scaling_lists=seed % 5, tq_bypass=(0, 25, 100)[seed % 3], threads=3 if seed & 1 else 1, frame_threads=bool(seed & 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(scaling_lists=1), dict(tq_bypass=100), dict(scaling_lists=3, tq_bypass=15, sao=1)])
+def test_kvazaar_shaped_stream_1080p_scaling_list_and_lossless(gpu, kw):
+    """1080p in the shape a Kvazaar peer sends, with uvgComm's "scaling list" box ticked (`scaling-list default`), with `lossless`, and with both tools mixed"""
+    cfg = dict(num_refs=3, tmvp=1, strong_intra=0, sign_hiding=1, wpp=1, tile_rows=1, intra_in_p=15, all_part_modes=0, amp=0, sao=0, qp_delta=0, deblock_mode=0,
+               th_depth_inter=0, th_depth_intra=0, max_cu_log2=6, min_cu_log2=3, nxn_intra=1, chroma_modes=1, transform_skip=0, cabac_init=0, chroma_qp_offsets=0,
+               par_mrg_level=2, big_mvd=0, uniform_tiles=1)
+    cfg.update(kw)
+    run_stream(1920, 1080, 4, seed=12, **cfg)
 
 
 @pytest.mark.gpu

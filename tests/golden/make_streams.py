@@ -26,6 +26,8 @@ HIP = {   # name: kvz_api options (all with hash=md5)
     "hip_scenecut_slow_qp30": (("qp", 30), ("period", 8), ("me-range", 16), ("preset", "slow")),
 }
 index = {}
+if "--no-hip" in sys.argv and os.path.exists(os.path.join(out, "index.json")):
+    index = json.load(open(os.path.join(out, "index.json")))      # (CPU only: the HIP encoder's streams stay as they are)
 if "--no-hip" not in sys.argv:
     from kvazzup_amd import synth
     from kvazzup_amd.codec import Encoder
@@ -51,6 +53,15 @@ GEN = {
                                qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=0, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0),
     "gen_everything_on": dict(seed=23, density=30, intra_period=8, num_refs=4, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=1, cabac_init=1, wpp=1, tile_rows=1, tile_cols=1,
                               qp_delta=2, chroma_qp_offsets=1, deblock_mode=3, intra_in_p=20, all_part_modes=1, chroma_modes=1, nxn_intra=1, slices=0, big_mvd=0),
+    # round 4: what a peer with uvgComm's "scaling list" / "lossless" boxes ticked sends (kvazaarfilter.cpp:235-244), and the general form of both tools
+    "gen_scaling_list_default": dict(seed=31, density=30, intra_period=8, num_refs=3, tmvp=0, amp=0, sao=0, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
+                                     qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=0, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, scaling_lists=1),
+    "gen_scaling_lists_sps_pps": dict(seed=32, density=30, intra_period=8, num_refs=2, tmvp=1, sao=1, sign_hiding=1, transform_skip=1, wpp=1, tile_rows=1, tile_cols=1,
+                                      qp_delta=2, intra_in_p=20, nxn_intra=1, th_depth_inter=2, th_depth_intra=2, max_cu_log2=6, slices=0, big_mvd=0, scaling_lists=4),
+    "gen_lossless": dict(seed=33, density=30, intra_period=8, num_refs=3, tmvp=0, amp=0, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
+                         qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=0, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, tq_bypass=100),
+    "gen_transquant_bypass_mixed": dict(seed=34, density=30, intra_period=8, num_refs=2, tmvp=1, sao=1, sign_hiding=1, transform_skip=1, wpp=1, tile_rows=1, tile_cols=1,
+                                        qp_delta=2, deblock_mode=2, intra_in_p=25, nxn_intra=1, th_depth_inter=1, th_depth_intra=1, slices=0, big_mvd=0, tq_bypass=35),
 }
 for name, cfg in GEN.items():
     g = orc.OracleGen(W, H, **cfg)

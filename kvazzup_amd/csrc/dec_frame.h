@@ -41,19 +41,6 @@ struct DecTu {
 };
 enum { TU_INTRA = 1, TU_TSKIP = 2, TU_DST = 4, TU_BYPASS = 8 };      // TU_BYPASS: cu_transquant_bypass_flag -- the residual is the level array itself (8.6.2)
 
-// Scaling factors m[x][y] of 8.6.4.2 for the active scaling lists (7.4.5; host: decoder.hip build_scaling), one byte per coefficient, raster inside the block
-// (index = the level word's position field): [6][16] 4x4 | [6][64] 8x8 | [6][256] 16x16 | [2][1024] 32x32; matrix = 3 * inter + plane (32x32: inter)
-#define KVZ_SCALING_BYTES 4064
-KVZ_HD int scaling_offset(int log2n, int plane, int inter)
-{
-  switch (log2n) {
-    case 2: return (3 * inter + plane) * 16;
-    case 3: return 96 + (3 * inter + plane) * 64;
-    case 4: return 480 + (3 * inter + plane) * 256;
-    default: return 2016 + inter * 1024;
-  }
-}
-
 struct TuRange { uint32_t first, count; };
 
 #define KVZ_DEC_MAX_REFS 16

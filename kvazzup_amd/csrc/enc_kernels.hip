@@ -292,11 +292,13 @@ __device__ __forceinline__ void adjust_block_lds(int16_t *lev, const int16_t *au
 //   and the cost of the levels (3 + 2 floor(log2 |level|) each) is added to `cost`
 struct NoLateQp { __device__ int operator()() const { return 0; } };
 __device__ __forceinline__ uint32_t rc_level_cost(int lv) { return lv ? 3u + 2u * (uint32_t)(31 - __builtin_clz((unsigned)iabs(lv))) : 0u; }
+//   mtab: the scaling factors of this block size and plane for inter blocks (`scaling-list default`), NULL: flat
 template <bool DEC, int L2, int OPL, bool RC = false, class PX, class CI, class QL = NoLateQp>
-__device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *nz, PX px_index, CI coef_at, int tid, int adj = 0, QL qp_late = QL(), uint32_t *cost = nullptr)
+__device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *nz, PX px_index, CI coef_at, int tid, int adj = 0, QL qp_late = QL(), uint32_t *cost = nullptr, const uint8_t *mtab0 = nullptr, int tu_per_plane = 1 << 30)
 {
   constexpr int N = 1 << L2, G = XF<L2, OPL>::G, LPT = XF<L2, OPL>::LANES;
   const int tu = tid / LPT, l = tid % LPT, rp = l / G, g = l % G;
+  const uint8_t *mtab = mtab0 ? mtab0 + (tu / tu_per_plane) * N * N : nullptr;      // (the chroma call holds Cb and Cr blocks: their matrices follow one another)
   int16_t *A = s.A + tu * N * N, *B = s.B + tu * N * N;
   if (!DEC) {
     const int16_t *Mf = s.M[0] + matrix_offset(L2);
@@ -317,7 +319,7 @@ __device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *n
         for (int e = 0; e < 2; e++) {
           const int c = clip3(-32768, 32767, (acc[e][o] + rnd) >> shift);
           uint16_t ax;
-          B[(g * OPL + o) * N + 2 * rp + e] = (int16_t)quant_level_aux(c, qp, L2, 0, &ax);
+          B[(g * OPL + o) * N + 2 * rp + e] = (int16_t)quant_level_aux(c, qp, L2, 0, &ax, mtab ? mtab[(g * OPL + o) * N + 2 * rp + e] : 16);
           A[(g * OPL + o) * N + 2 * rp + e] = (int16_t)ax;
         }
       __syncthreads();
@@ -333,10 +335,11 @@ __device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *n
     for (int o = 0; o < OPL; o++)
 #pragma unroll
       for (int e = 0; e < 2; e++) {
-        if (!adj) { int c = clip3(-32768, 32767, (acc[e][o] + rnd) >> shift); lv[e][o] = quant_level(c, qp, L2, 0); }
+        const int m = mtab ? mtab[(g * OPL + o) * N + 2 * rp + e] : 16;
+        if (!adj) { int c = clip3(-32768, 32767, (acc[e][o] + rnd) >> shift); lv[e][o] = quant_level(c, qp, L2, 0, m); }
         any |= lv[e][o] != 0;
         if constexpr (RC) *cost += rc_level_cost(lv[e][o]);
-        A[(2 * rp + e) * N + g * OPL + o] = (int16_t)dequant_coef(lv[e][o], qp, L2);        // transposed: [column][row]
+        A[(2 * rp + e) * N + g * OPL + o] = (int16_t)dequant_coef(lv[e][o], qp, L2, m);     // transposed: [column][row]
       }
     if (any) atomicOr(nz, 1u << tu);
     __syncthreads();
@@ -365,7 +368,7 @@ __device__ __forceinline__ void inter_transform(InterLds &s, int qp, uint32_t *n
 
 // The 32x32 luma block of a 32x32 CU: same contract as inter_transform<DEC, 5, .>
 template <bool DEC, bool RC = false, class QL = NoLateQp>
-__device__ __forceinline__ void inter_transform_32(InterLds &s, int qp, uint32_t *nz, int16_t *coef, int cw, int tid, int adj = 0, QL qp_late = QL(), uint32_t *cost = nullptr)
+__device__ __forceinline__ void inter_transform_32(InterLds &s, int qp, uint32_t *nz, int16_t *coef, int cw, int tid, int adj = 0, QL qp_late = QL(), uint32_t *cost = nullptr, const uint8_t *mtab = nullptr)
 {
   const int wave = tid >> 6, lane = tid & 63;
   const int j = (wave & 1) * 16 + (lane & 15), i0 = (wave >> 1) * 16 + (lane >> 4) * 4;   // result column, first of four result rows
@@ -384,7 +387,7 @@ __device__ __forceinline__ void inter_transform_32(InterLds &s, int qp, uint32_t
         for (int r = 0; r < 4; r++) {
           const int c = clip3(-32768, 32767, (acc[r] + 1024) >> 11);
           uint16_t ax;
-          s.B[j * 32 + i0 + r] = (int16_t)quant_level_aux(c, qp, 5, 0, &ax);
+          s.B[j * 32 + i0 + r] = (int16_t)quant_level_aux(c, qp, 5, 0, &ax, mtab ? mtab[j * 32 + i0 + r] : 16);
           s.A[j * 32 + i0 + r] = (int16_t)ax;
         }
         __syncthreads();
@@ -396,10 +399,11 @@ __device__ __forceinline__ void inter_transform_32(InterLds &s, int qp, uint32_t
       }
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        if (!adj) { const int c = clip3(-32768, 32767, (acc[r] + 1024) >> 11); lv[r] = quant_level(c, qp, 5, 0); }
+        const int m = mtab ? mtab[j * 32 + i0 + r] : 16;
+        if (!adj) { const int c = clip3(-32768, 32767, (acc[r] + 1024) >> 11); lv[r] = quant_level(c, qp, 5, 0, m); }
         any |= lv[r] != 0;
         if constexpr (RC) *cost += rc_level_cost(lv[r]);
-        s.A[(i0 + r) * 32 + j] = (int16_t)dequant_coef(lv[r], qp, 5);                      // transposed: [column][row]
+        s.A[(i0 + r) * 32 + j] = (int16_t)dequant_coef(lv[r], qp, 5, m);                   // transposed: [column][row]
       }
       if (any) atomicOr(nz, 1u);
     }
@@ -607,8 +611,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || AD
     auto px16 = [](int tu, int y, int x) { return ((tu >> 1) * 16 + y) * 32 + (tu & 1) * 16 + x; };
     const int cw = f.cw; int16_t *base = f.coef[0] + (size_t)y0 * cw + x0;
     auto ci16 = [=](int tu, int y, int x) { return base + (size_t)((tu >> 1) * 16 + y) * cw + (tu & 1) * 16 + x; };
-    if (split) inter_transform<DEC, 4, 2, RC>(s, qp, &s.nz[0], px16, ci16, tid, adj, qp_late, &rc_cost);
-    else inter_transform_32<DEC, RC>(s, qp, &s.nz[0], base, cw, tid, adj, qp_late, &rc_cost);
+    if (split) inter_transform<DEC, 4, 2, RC>(s, qp, &s.nz[0], px16, ci16, tid, adj, qp_late, &rc_cost, f.scaling ? f.scaling + scaling_offset(4, 0, 1) : nullptr, 4);
+    else inter_transform_32<DEC, RC>(s, qp, &s.nz[0], base, cw, tid, adj, qp_late, &rc_cost, f.scaling ? f.scaling + scaling_offset(5, 0, 1) : nullptr);
     *(uint32_t *)&f.rec[0][(size_t)(y0 + (tid >> 3)) * f.cw + x0 + (tid & 7) * 4] = *(const uint32_t *)&s.px[(tid >> 3) * 32 + (tid & 7) * 4];
   }
   if (!RC) chroma_windows();
@@ -660,8 +664,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || AD
     auto ci1 = [=](int tu, int y, int x) { return (tu ? cr : cb) + (size_t)y * cw2 + x; };
     auto ci4 = [=](int tu, int y, int x) { return ((tu >> 2) ? cr : cb) + (size_t)(((tu >> 1) & 1) * 8 + y) * cw2 + (tu & 1) * 8 + x; };
     auto qpc_known = [&]() -> int { return qpc; };
-    if (split) inter_transform<DEC, 3, 1, RC>(s, qpc, &s.nz[1], px4, ci4, tid, adj, qpc_known, &rc_cost);
-    else inter_transform<DEC, 4, 1, RC>(s, qpc, &s.nz[1], px1, ci1, tid, adj, qpc_known, &rc_cost);
+    if (split) inter_transform<DEC, 3, 1, RC>(s, qpc, &s.nz[1], px4, ci4, tid, adj, qpc_known, &rc_cost, f.scaling ? f.scaling + scaling_offset(3, 1, 1) : nullptr, 4);
+    else inter_transform<DEC, 4, 1, RC>(s, qpc, &s.nz[1], px1, ci1, tid, adj, qpc_known, &rc_cost, f.scaling ? f.scaling + scaling_offset(4, 1, 1) : nullptr, 1);
   }
   if (tid < 128) {
     const int pl = tid >> 6, y = (tid >> 2) & 15, x = (tid & 3) * 4;
@@ -996,7 +1000,7 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
 // Returns whether the block has non-zero levels.
 template <int L2, bool ADJ>
 __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratch &ws, const IntraBlk &d, int cidx, int S, const QuantConst &q,
-                                                 uint8_t *gdst, int gp, int lane, uint32_t *publish, int adj = 0, uint8_t *ecol = nullptr)
+                                                 uint8_t *gdst, int gp, int lane, uint32_t *publish, int adj = 0, uint8_t *ecol = nullptr, const uint8_t *mtab = nullptr)
 {
   constexpr int N = 1 << L2;
   const int P = 16 + 2 * S, g = lane >> 4, c = lane & 15, rx = d.rx, ry = d.ry;
@@ -1026,7 +1030,7 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int cf = clip3(-32768, 32767, (co[r] + (1 << (L2 + 5))) >> (L2 + 6));
-        const uint32_t a = (uint32_t)iabs(cf), prod = a * (uint32_t)q.qscale;
+        const uint32_t a = (uint32_t)iabs(cf), prod = a * (uint32_t)(mtab ? (q.qscale << 4) / mtab[(4 * g + r) * N + c] : q.qscale);
         const int lvm = imin((int)((prod + (uint32_t)q.qoff) >> q.qshift), 32767);
         const int du = clip3(-256, 511, (int)(prod >> (q.qshift - 8)) - (lvm << 8));
         s.lev[(ry + 4 * g + r) * S + rx + c] = (int16_t)(cf < 0 ? -lvm : lvm);
@@ -1038,16 +1042,16 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
     wave_sync();
     if (active) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) { const int lv = s.lev[(ry + 4 * g + r) * S + rx + c]; nz |= lv != 0; dq[r] = dequant_coef_q(lv, q); }
+      for (int r = 0; r < 4; r++) { const int lv = s.lev[(ry + 4 * g + r) * S + rx + c]; nz |= lv != 0; dq[r] = mtab ? dequant_coef_qm(lv, q, mtab[(4 * g + r) * N + c]) : dequant_coef_q(lv, q); }
     }
     wave_sync();                                              // (ws.tr is free again for the inverse transform)
   } else if (active) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int cf = clip3(-32768, 32767, (co[r] + (1 << (L2 + 5))) >> (L2 + 6));
-      const int lv = quant_level_q(cf, q);
+      const int lv = mtab ? quant_level_qm(cf, q, mtab[(4 * g + r) * N + c], nullptr) : quant_level_q(cf, q);
       nz |= lv != 0;
-      dq[r] = dequant_coef_q(lv, q);
+      dq[r] = mtab ? dequant_coef_qm(lv, q, mtab[(4 * g + r) * N + c]) : dequant_coef_q(lv, q);
       s.lev[(ry + 4 * g + r) * S + rx + c] = (int16_t)lv;
     }
   }
@@ -1090,7 +1094,8 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
 // PP: the intra units of a P picture (intra-in-P), launched behind k_inter_recon: a CTU without intra units (nearly all) publishes 64
 // and leaves; in the others the inter units count as finished from the start, the CTU picture in LDS starts as the inter
 // reconstruction left it, and only the intra units' levels and cbf bits are written.
-template <bool ADJ, bool PP>
+// SCAL: `scaling-list default` -- a form of its own for the same reason as ADJ (the per-position factors cost the plain chain 30 registers when they are a run-time branch)
+template <bool ADJ, bool PP, bool SCAL = false>
 __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f)
 {
   constexpr int W = KVZ_INTRA_WAVES, T = 64 * W;
@@ -1223,9 +1228,9 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     first = false;
     bool cbf;
     switch (d.l2) {
-      case 2: cbf = intra_block_wave<2, ADJ>(s, ws, d, c, S, q8, grec, pw, lane, nullptr, adj, ecol); break;
-      case 3: cbf = intra_block_wave<3, ADJ>(s, ws, d, c, S, c ? q16 : q8, grec, pw, lane, nullptr, adj, ecol); break;
-      default: cbf = intra_block_wave<4, ADJ>(s, ws, d, c, S, q16, grec, pw, lane, nullptr, adj, ecol); break;
+      case 2: cbf = intra_block_wave<2, ADJ>(s, ws, d, c, S, q8, grec, pw, lane, nullptr, adj, ecol, SCAL ? f.scaling + scaling_offset(2, c, 0) : nullptr); break;
+      case 3: cbf = intra_block_wave<3, ADJ>(s, ws, d, c, S, c ? q16 : q8, grec, pw, lane, nullptr, adj, ecol, SCAL ? f.scaling + scaling_offset(3, c, 0) : nullptr); break;
+      default: cbf = intra_block_wave<4, ADJ>(s, ws, d, c, S, q16, grec, pw, lane, nullptr, adj, ecol, SCAL ? f.scaling + scaling_offset(4, c, 0) : nullptr); break;
     }
     const uint2 cvu = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)cv.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)cv.y));
     chain_mark_done(ch, cvu, lane);
@@ -2126,10 +2131,12 @@ void launch_intra_recon(const EncFrame &f, hipStream_t st)
   if (!f.is_intra) {                                                                                            // intra-in-P, behind k_inter_recon
     // (a workgroup per (CTU, plane) here: nearly all of them find no intra unit, and a workgroup that checks nine tickets in turn pays nine memory round trips)
     const dim3 all(3 * wc * nr);
-    if (adj) hipLaunchKernelGGL((k_intra_recon<true, true>), all, block, 0, st, f); else hipLaunchKernelGGL((k_intra_recon<false, true>), all, block, 0, st, f);
+    if (f.scaling) { if (adj) hipLaunchKernelGGL((k_intra_recon<true, true, true>), all, block, 0, st, f); else hipLaunchKernelGGL((k_intra_recon<false, true, true>), all, block, 0, st, f); }
+    else if (adj) hipLaunchKernelGGL((k_intra_recon<true, true>), all, block, 0, st, f); else hipLaunchKernelGGL((k_intra_recon<false, true>), all, block, 0, st, f);
     return;
   }
-  if (adj) hipLaunchKernelGGL((k_intra_recon<true, false>), grid, block, 0, st, f);
+  if (f.scaling) { if (adj) hipLaunchKernelGGL((k_intra_recon<true, false, true>), grid, block, 0, st, f); else hipLaunchKernelGGL((k_intra_recon<false, false, true>), grid, block, 0, st, f); }
+  else if (adj) hipLaunchKernelGGL((k_intra_recon<true, false>), grid, block, 0, st, f);
   else hipLaunchKernelGGL((k_intra_recon<false, false>), grid, block, 0, st, f);
 }
 void launch_qp_resolve(const EncFrame &f, hipStream_t st)

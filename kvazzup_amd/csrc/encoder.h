@@ -47,6 +47,7 @@ struct EncoderConfig {
   int sao = 0;                // kvazaar "sao": sample adaptive offset, parameters by "uvgx SAO decision v1" (oracle/hevc_sao.c)
   int input_hold = 0;         // "input-hold" (extension): 1 = the caller leaves a DEVICE input picture unchanged until that picture's access unit has been returned --
                               // what the kvz_api contract already demands of host pictures (kvazaarfilter.cpp:76-88); encode_device then returns without waiting for the input stage
+  int scaling_list = 0;       // kvazaar "scaling-list default": scaling_list_enabled_flag with the default lists (oracle/hevc_scaling.c); quantiser scale per position (qscale << 4) / m
   int rdoq = 0;               // kvazaar "rdoq": "uvgx RDOQ v1" -- sparse high-frequency coefficient groups are dropped when that is cheaper (oracle/hevc_transform.h orc_adjust_levels)
   int intra_in_p = 0;         // "intra-in-p" 0 / 1 (16x16 units only) / 2 (16x16 and 8x8): intra coding units in P pictures ("uvgx intra-in-P v1", oracle/hevc_enc.c me_block32); not in band mode
   int signhide = 0;           // kvazaar "signhide": sign_data_hiding_enabled_flag; the quantiser makes the parity of every eligible coefficient group say the hidden sign
@@ -180,6 +181,7 @@ class Encoder {
   hipEvent_t ev_signalled_ = nullptr, ev_tok_done_[kSets] = {}; bool tok_pending_[kSets] = {};
   void bind_set(int k);
   uint8_t *intra_scratch_ = nullptr;
+  uint8_t *d_scaling_ = nullptr;          // scaling-list default: KVZ_SCALING_BYTES scaling factors
   uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; int tok_nctu_ = 0;
   size_t tok_dense_cap_ = 0;
   std::vector<std::vector<uint8_t>> band_subs_; uint64_t band_bins_ = 0; bool band_coded_ = false;   // band mode: between phase 2a and 2b

@@ -7,6 +7,7 @@
 #include "encoder.h"
 #include "enc_kernels.h"
 #include "stream_pool.h"
+#include "scaling_tables.h"
 #include "pic_hash.h"
 
 namespace kvzx {
@@ -193,6 +194,12 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   f_.tile_rows = cfg.tile_rows; f_.tile_cols = cfg.tile_cols; f_.chp = pack_height(ch_, cfg.tile_rows, cfg.tile_cols);
   f_.row0 = cfg.band_rows > 0 ? cfg.band_row0 : 0; f_.nrows = cfg.band_rows > 0 ? cfg.band_rows : 0;
   f_.qp = cfg.qp; f_.qpc = kChromaQp[cfg.qp]; f_.lambda_q4 = kLambdaQ4[cfg.qp]; f_.range = cfg.me_range;
+  if (cfg.scaling_list) {                                 // `scaling-list default`: the default lists' factors, once
+    uint8_t tab[KVZ_SCALING_BYTES];
+    scaling_factors(scaling_defaults(), tab);
+    HIP_OK(hipMalloc(&d_scaling_, KVZ_SCALING_BYTES)); HIP_OK(hipMemcpy(d_scaling_, tab, KVZ_SCALING_BYTES, hipMemcpyHostToDevice));
+  }
+  f_.scaling = d_scaling_;
   f_.rdoq = cfg.rdoq; f_.signhide = cfg.signhide; f_.intra_p = cfg.intra_in_p; f_.me_cost16 = me_cost16_; f_.me_cand = me_cost16_ ? me_cost16_ + (size_t)(cw_ / 16) * (ch_ / 16) : nullptr;
   if (me_cost16_) { const size_t n16 = (size_t)(cw_ / 16) * (ch_ / 16); f_.ip_arrive = f_.me_cand + 1 + n16 / 4; f_.ip_scratch = (uint64_t *)(me_cost16_ + ((n16 + 1 + n16 / 4 + n16 / 4 + 1) & ~(size_t)1)); }      // (8-byte aligned)
   f_.wpp = cfg.wpp; f_.mv_frame = cfg.mv_frame; f_.me_early = cfg.me_early; f_.satd = cfg.satd; f_.subme = cfg.subme; f_.slices = cfg.slices;
@@ -205,7 +212,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   { const size_t nctu = (size_t)(cw_ / 64) * rows_; f_.edge_col[0] = edge_col_; f_.edge_col[1] = edge_col_ + nctu * 64; f_.edge_col[2] = edge_col_ + nctu * 96; }
   f_.sync = sync_; f_.err = err_; f_.trace = trace_; f_.intra_order = intra_order_;
 
-  sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp; sp_.tile_rows = cfg.tile_rows; sp_.tile_cols = cfg.tile_cols; sp_.qp_in_cu = cfg.qp_in_cu; sp_.sao = cfg.sao; sp_.slices = cfg.slices; sp_.signhide = cfg.signhide;
+  sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp; sp_.tile_rows = cfg.tile_rows; sp_.tile_cols = cfg.tile_cols; sp_.qp_in_cu = cfg.qp_in_cu; sp_.sao = cfg.sao; sp_.slices = cfg.slices; sp_.signhide = cfg.signhide; sp_.scaling_list = cfg.scaling_list;
   sp_.deblock = cfg.deblock; sp_.fps_num = cfg.fps_num; sp_.fps_den = cfg.fps_den;
   HIP_OK(hipStreamSynchronize(stream_));
   HIP_OK(hipDeviceSynchronize());
@@ -272,7 +279,7 @@ Encoder::~Encoder()
   stream_release(stream_in_, cfg_.device, 'I', prio_[2]);
   if (stream_idr_ && stream_idr_ != stream_in_) { const char *lv = getenv("KVAZZUP_AMD_IDR_PRIO"); stream_release(stream_idr_, cfg_.device, 'X', lv ? lv[0] : 'n'); }
   if (ev_idr_done_) hipEventDestroy(ev_idr_done_);
-  hipFree(intra_scratch_);
+  hipFree(intra_scratch_); hipFree(d_scaling_);
   delete entropy_; delete entropy2_;
   hipFree(trace_); hipFree(intra_order_); hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(sync_); hipFree(me_cost16_); hipFree(edge_col_); hipFree(err_);
   stream_release(stream_, cfg_.device, 'M', prio_[0]);

@@ -36,6 +36,20 @@ struct SaoParams {
 };
 
 
+// Scaling factors m[x][y] of 8.6.4.2 for the active scaling lists (7.4.5; host: decoder.hip build_scaling), one byte per coefficient, raster inside the block
+// (index = the level word's position field): [6][16] 4x4 | [6][64] 8x8 | [6][256] 16x16 | [2][1024] 32x32; matrix = 3 * inter + plane (32x32: inter)
+#define KVZ_SCALING_BYTES 4064
+KVZ_HD int scaling_offset(int log2n, int plane, int inter)
+{
+  switch (log2n) {
+    case 2: return (3 * inter + plane) * 16;
+    case 3: return 96 + (3 * inter + plane) * 64;
+    case 4: return 480 + (3 * inter + plane) * 256;
+    default: return 2016 + inter * 1024;
+  }
+}
+
+
 // rate control v2, device-side state (rc_kernels.hip; statement of record: rc_band_decide() / rc_picture_start() in oracle/hevc_enc.c).
 // acc[g]: arrivals << 40 | level cost of group g's workgroups (ONE atomic per workgroup: the one that completes the count has the group's cost);
 // decided: number of groups whose QP is final (bits 0..3; group 0 from the start) and the QP steps of groups 1.. (3 bits each, biased by 3) -- what a
@@ -56,6 +70,7 @@ struct EncFrame {
   int satd;                 // intra mode search: SATD (8x8 Hadamard) instead of SAD
   int me_early;             // me-early-termination: blocks that match the co-located reference block to within 64 * lambda_q4 are not searched
   int subme;                // fractional-sample refinement level 0..4 (k_subpel)
+  const uint8_t *scaling;   // `scaling-list default`: KVZ_SCALING_BYTES scaling factors of the default lists (dec_frame.h scaling_offset), NULL: flat
   int intra_p;              // "uvgx intra-in-P v1": intra coding units in P pictures (statement: oracle/hevc_enc.c me_block32); me_cost16 = k_me's inter cost of every 16x16 block (0: not searched)
   uint32_t *me_cost16;
   uint8_t *edge_col[3];     // k_intra_recon: per plane [CTU][S] the CTU's right column of reconstructed samples (kernel_common.h IB_EDGE_R)
@@ -1047,23 +1062,26 @@ KVZ_HD bool is_cu_edge_h(const EncFrame &f, int x, int y) { return (y & ((1 << f
 // ---------------------------------------------------------------------------------------------
 // scalar quantiser / dequantiser (flat scaling; see oracle/hevc_transform.c for the statement)
 // ---------------------------------------------------------------------------------------------
-KVZ_HD int quant_level(int coef, int qp, int log2n, int intra)
+// m: the scaling factor of the coefficient's position (8.6.4.2; `scaling-list default`), 16 = flat.  The forward scale of a position is the flat one times
+// 16 / m, as Kvazaar's (and HM's) quantisation matrices are built: (quantScales[qp % 6] << 4) / m.  Statement: oracle/hevc_transform.c orc_quant.
+KVZ_HD int quant_scale_m(int qp, int m) { return (kQuantScale[qp % 6] << 4) / m; }
+KVZ_HD int quant_level(int coef, int qp, int log2n, int intra, int m = 16)
 {
   int shift = 14 + qp / 6 + (15 - 8 - log2n);
   int64_t off = (int64_t)(intra ? 171 : 85) << (shift - 9);
   int a = coef < 0 ? -coef : coef;
-  int64_t q = ((int64_t)a * kQuantScale[qp % 6] + off) >> shift;
+  int64_t q = ((int64_t)a * quant_scale_m(qp, m) + off) >> shift;
   if (q > 32767) q = 32767;
   return (int)(coef < 0 ? -q : q);
 }
 // The quantiser with what the level-adjustment pass needs beside the level: aux = 256 + du in bits 0..9 -- du = the part of the coefficient
 // the level does not account for, in 1/256 quantiser steps -- and bit 15 = the coefficient is negative (statement: oracle/hevc_transform.h)
-KVZ_HD int quant_level_aux(int coef, int qp, int log2n, int intra, uint16_t *aux)
+KVZ_HD int quant_level_aux(int coef, int qp, int log2n, int intra, uint16_t *aux, int m = 16)
 {
   int shift = 14 + qp / 6 + (15 - 8 - log2n);
   int64_t off = (int64_t)(intra ? 171 : 85) << (shift - 9);
   int a = coef < 0 ? -coef : coef;
-  int64_t prod = (int64_t)a * kQuantScale[qp % 6];
+  int64_t prod = (int64_t)a * quant_scale_m(qp, m);
   int64_t q = (prod + off) >> shift;
   if (q > 32767) q = 32767;
   int64_t du = (prod >> (shift - 8)) - (q << 8);
@@ -1114,6 +1132,10 @@ KVZ_HD int dequant_coef_m(int level, int qp, int log2n, int m)
   int scale = kLevelScale[qp % 6] << (qp / 6);
   int64_t v = ((int64_t)level * m * scale + ((int64_t)1 << (bd - 1))) >> bd;
   return (int)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+}
+KVZ_HD int dequant_coef(int level, int qp, int log2n, int m)      // (the encoder's call sites: m = 16 without scaling lists)
+{
+  return dequant_coef_m(level, qp, log2n, m);
 }
 KVZ_HD int dequant_coef(int level, int qp, int log2n)
 {

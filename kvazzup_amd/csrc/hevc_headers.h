@@ -32,6 +32,7 @@ struct StreamParams {
   int tile_cols = 1;
   int sao = 0;              // sample_adaptive_offset_enabled_flag; every slice: slice_sao_luma_flag = slice_sao_chroma_flag = 1
   int signhide = 0;         // sign_data_hiding_enabled_flag
+  int scaling_list = 0;     // scaling_list_enabled_flag = 1, no sps_scaling_list_data: the default lists
   int slices = 0;           // kvazaar slices: 1 = "wpp", a dependent slice segment per CTU row (dependent_slice_segments_enabled_flag); 2 = "tiles", a slice per tile
 };
 
@@ -73,7 +74,8 @@ inline void write_sps(BitWriter &w, const StreamParams &s)
   w.bit(1); w.ue(1); w.ue(0); w.ue(0);
   w.ue(0); w.ue(3); w.ue(0); w.ue(3);                            // CB 8..64, TB 4..32
   w.ue(0); w.ue(0);                                              // transform hierarchy depths
-  w.bit(0); w.bit(0); w.bit(s.sao != 0); w.bit(0);               // scaling list, amp, sao, pcm
+  w.bit(s.scaling_list != 0); if (s.scaling_list) w.bit(0);       // scaling_list_enabled_flag (sps_scaling_list_data_present_flag = 0: Tables 7-5 / 7-6)
+  w.bit(0); w.bit(s.sao != 0); w.bit(0);                          // amp, sao, pcm
   w.ue(1); w.ue(1); w.ue(0); w.ue(0); w.bit(1);                  // one short-term RPS: previous picture
   w.bit(0); w.bit(0); w.bit(1);                                  // long-term, tmvp, strong intra smoothing
   w.bit(1);                                                      // VUI: timing only

@@ -821,6 +821,24 @@ __device__ __forceinline__ int dequant_coef_q(int level, const QuantConst &q)   
   return clip3(-32768, 32767, (((level * q.dscale) << q.dsa) + q.drnd) >> q.dsb);
 }
 
+// The same two with the scaling factor m of the coefficient's position (`scaling-list default`: m = 16 .. 115).  Forward scale (qscale << 4) / m <= qscale,
+// so the product stays inside 32 bits as above; the dequantiser is 8.6.4.2 as written: (level * m * levelScale << qp / 6) >> bdShift with
+// qp / 6 - bdShift = qshift - 24 (quant_const: qshift = 14 + qp / 6 + 7 - log2 n, bdShift = log2 n + 3).
+__device__ __forceinline__ int quant_level_qm(int coef, const QuantConst &q, int m, int *du)
+{
+  const uint32_t a = (uint32_t)iabs(coef), prod = a * (uint32_t)((q.qscale << 4) / m);
+  const int lv = imin((int)((prod + (uint32_t)q.qoff) >> q.qshift), 32767);
+  if (du) *du = clip3(-256, 511, (int)(prod >> (q.qshift - 8)) - (lv << 8));
+  return coef < 0 ? -lv : lv;
+}
+__device__ __forceinline__ int dequant_coef_qm(int level, const QuantConst &q, int m)
+{
+  const int k = q.qshift - 24;
+  const long long v = (long long)level * m * q.dscale;
+  const long long r = k >= 0 ? v << k : (v + (1ll << (-k - 1))) >> -k;
+  return (int)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+}
+
 // the dequantiser's constants of one block in one word (decoder: per transform block, worked out ahead of the chain)
 __device__ __forceinline__ uint32_t dequant_pack(int qp, int log2n)
 {

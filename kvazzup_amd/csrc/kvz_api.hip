@@ -142,7 +142,8 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
   }
   if (n == "scaling-list") {
     if (!strcmp(value, "off") || !strcmp(value, "0")) { cfg->scaling_list = KVZ_SCALING_LIST_OFF; return 1; }
-    return 0;
+    if (!strcmp(value, "default")) { cfg->scaling_list = KVZ_SCALING_LIST_DEFAULT; return 1; }      // scaling_list_enabled_flag with the default lists (Tables 7-5 / 7-6): quantiser and dequantiser per position
+    return 0;                                      // "custom" (a cqmfile) is not implemented
   }
   if (n == "mv-constraint") {
     if (!*value || !strcmp(value, "none")) { cfg->mv_constraint = KVZ_MV_CONSTRAIN_NONE; return 1; }
@@ -296,7 +297,6 @@ kvz_data_chunk *make_chunks(const uint8_t *data, size_t len)
 kvz_encoder *encoder_open(const kvz_config *cfg)
 {
   if (!cfg) return nullptr;
-  if (cfg->lossless) { fprintf(stderr, "kvazzup_amd: lossless coding is not implemented\n"); return nullptr; }
   EncoderConfig ec;
   ec.width = cfg->width; ec.height = cfg->height; ec.qp = cfg->qp; ec.intra_period = cfg->intra_period; ec.vps_period = cfg->vps_period;
   ec.me_range = cfg->me_range; ec.fps_num = cfg->framerate_num; ec.fps_den = cfg->framerate_denom;
@@ -314,6 +314,10 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.subme = cfg->fme_level < 0 ? 0 : (cfg->fme_level > 4 ? 4 : cfg->fme_level);
   ec.entropy_gpu = cfg->gpu_entropy != 0;
   ec.input_hold = cfg->input_hold != 0;
+  ec.scaling_list = cfg->scaling_list == KVZ_SCALING_LIST_DEFAULT;
+  // kvz_config.lossless (uvgComm writes the field itself, kvazaarfilter.cpp:244, so a refusal could only be a failed encoder_open = no video at all):
+  // transform / quantiser bypass is not implemented in the encoder -- the call goes on at the finest quantiser instead, and says so once
+  if (cfg->lossless) { fprintf(stderr, "kvazzup_amd: lossless coding is not implemented in the encoder; coding at QP 0 instead\n"); ec.qp = 0; }
   ec.rdoq = cfg->rdoq_enable != 0; ec.signhide = cfg->signhide_enable != 0; ec.intra_in_p = cfg->intra_in_p;
   ec.hash = cfg->hash == KVZ_HASH_MD5 ? 2 : (cfg->hash == KVZ_HASH_CHECKSUM ? 1 : 0);
   ec.vaq = cfg->vaq > 0 ? cfg->vaq : 0;

@@ -26,6 +26,7 @@ const uint16_t orc_lambda_q4[52] = {
 
 struct orc_encoder {
   orc_enc_config cfg;
+  uint8_t sfac[4][6][1024];            /* scaling-list default: the default lists' scaling factors per size and matrix */
   int cw, ch, b8w, b8h;
   int frame_idx, poc, intra_count;
   int qp;                              /* QP of the picture being coded (== cfg.qp without rate control) */
@@ -227,16 +228,18 @@ static int code_block(orc_encoder *e, int cidx, int x0, int y0, int n, int qp, i
   int16_t res[32 * 32], cf[32 * 32], lv[32 * 32];
   for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) res[y * n + x] = (int16_t)(src[y * stride + x] - rec[y * stride + x]);
   orc_fwd_transform(res, cf, n, 0);
+  /* `scaling-list default`: the scaling factors of the block's size, colour component and prediction mode (the default lists, hevc_scaling.c) */
+  const uint8_t *m = e->cfg.scaling_list ? e->sfac[orc_log2((unsigned)n) - 2][orc_scaling_matrix_id(orc_log2((unsigned)n) - 2, cidx, !intra)] : NULL;
   int nz;
   if (e->cfg.rdoq || e->cfg.signhide) {                        /* "uvgx RDOQ v1" / sign data hiding: a pass over the levels (hevc_transform.h) */
     uint16_t aux[32 * 32];
-    orc_quant_aux(cf, lv, aux, n, qp, intra);
+    orc_quant_aux_m(cf, lv, aux, n, qp, intra, m);
     nz = orc_adjust_levels(lv, aux, n, scan_idx, e->cfg.rdoq, e->cfg.signhide);
-  } else nz = orc_quant(cf, lv, n, qp, intra);
+  } else nz = orc_quant_m(cf, lv, n, qp, intra, m);
   int16_t *cp = e->coef[cidx] + y0 * stride + x0;
   for (int y = 0; y < n; y++) memcpy(cp + y * stride, lv + y * n, sizeof(int16_t) * (size_t)n);
   if (nz) {
-    orc_dequant(lv, cf, n, qp);
+    orc_dequant_m(lv, cf, n, qp, m);
     orc_inv_transform(cf, res, n, 0);
     for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) rec[y * stride + x] = (pixel)orc_clip_pixel(rec[y * stride + x] + res[y * n + x]);
   }
@@ -1201,6 +1204,12 @@ int orc_enc_set_option(orc_encoder *e, const char *name, int value)
   if (!strcmp(name, "hash")) { e->cfg.hash = value; return 1; }
   if (!strcmp(name, "intra-in-p")) { e->cfg.intra_in_p = value < 0 ? 0 : (value > 2 ? 2 : value); return 1; }      /* 0 off, 1: 16x16 intra units in P pictures, 2: 16x16 and 8x8 */
   if (!strcmp(name, "rc-delay")) { if (value < 3 || value > 7) return 0; e->cfg.rc_delay = value; return 1; }
+  if (!strcmp(name, "scaling-list")) {                  /* 1: `scaling-list default` -- takes effect with the next parameter sets (set it before the first picture) */
+    e->cfg.scaling_list = value != 0; e->sps.scaling_list_enabled = e->cfg.scaling_list; e->sps.scaling_list_data_present = 0;
+    orc_scaling_default(&e->sps.scaling);
+    for (int sz = 0; sz < 4; sz++) for (int mi = 0; mi < (sz == 3 ? 2 : 6); mi++) orc_scaling_factor(&e->sps.scaling, sz, mi, e->sfac[sz][mi]);
+    return 1;
+  }
   if (!strcmp(name, "rdoq")) { e->cfg.rdoq = value != 0; return 1; }
   if (!strcmp(name, "signhide")) { e->cfg.signhide = value != 0; e->pps.sign_data_hiding = e->cfg.signhide; return 1; }
   return 0;

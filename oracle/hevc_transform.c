@@ -52,6 +52,45 @@ void orc_inv_transform(const int16_t *coeff, int16_t *resid, int n, int dst_mode
 /* Encoder scalar quantiser with dead zone (HM/Kvazaar convention, flat scaling):
  * level = sign * ((|c| * f[qp%6] + offset) >> (14 + qp/6 + ts)), ts = 15 - BitDepth - log2N,
  * offset = (171 intra | 85 inter) << (shift - 9). */
+/* With scaling lists (`scaling-list default`; m: the n x n scaling factors of hevc_scaling.h, NULL = flat 16): the forward scale of a position is
+ * (f[qp%6] << 4) / m -- how Kvazaar (and HM) build their quantisation matrices from the lists --, the dequantiser is the normative one. */
+int orc_quant_m(const int16_t *coeff, int16_t *level, int n, int qp, int intra, const uint8_t *m)
+{
+  int l2 = orc_log2((unsigned)n);
+  int shift = 14 + qp / 6 + (15 - 8 - l2);
+  int64_t off = (int64_t)(intra ? 171 : 85) << (shift - 9);
+  int nz = 0;
+  for (int i = 0; i < n * n; i++) {
+    int f = (orc_quant_scale[qp % 6] << 4) / (m ? m[i] : 16);
+    int c = coeff[i], a = c < 0 ? -c : c;
+    int64_t q = ((int64_t)a * f + off) >> shift;
+    if (q > 32767) q = 32767;
+    level[i] = (int16_t)(c < 0 ? -q : q);
+    nz += (q != 0);
+  }
+  return nz;
+}
+int orc_quant_aux_m(const int16_t *coeff, int16_t *level, uint16_t *aux, int n, int qp, int intra, const uint8_t *m)
+{
+  int l2 = orc_log2((unsigned)n);
+  int shift = 14 + qp / 6 + (15 - 8 - l2);
+  int64_t off = (int64_t)(intra ? 171 : 85) << (shift - 9);
+  int nz = 0;
+  for (int i = 0; i < n * n; i++) {
+    int f = (orc_quant_scale[qp % 6] << 4) / (m ? m[i] : 16);
+    int c = coeff[i], a = c < 0 ? -c : c;
+    int64_t q = ((int64_t)a * f + off) >> shift;
+    if (q > 32767) q = 32767;
+    int64_t du = (((int64_t)a * f) >> (shift - 8)) - (q << 8);
+    if (du < -256) du = -256;
+    if (du > 511) du = 511;
+    level[i] = (int16_t)(c < 0 ? -q : q);
+    aux[i] = (uint16_t)((du + 256) | (c < 0 ? 0x8000 : 0));
+    nz += (q != 0);
+  }
+  return nz;
+}
+
 int orc_quant(const int16_t *coeff, int16_t *level, int n, int qp, int intra)
 {
   int l2 = orc_log2((unsigned)n);

@@ -19,6 +19,9 @@ void orc_dequant_m(const int16_t *level, int16_t *coeff, int n, int qp, const ui
  * - (|level| << 8) is the part of the coefficient the level does not account for, in 1/256 quantiser steps (-0.34 .. 0.84 steps with the
  * dead-zone rounding), and bit 15 = the coefficient is negative. */
 int  orc_quant_aux(const int16_t *coeff, int16_t *level, uint16_t *aux, int n, int qp, int intra);
+/* ... with the scaling factors m of the block (hevc_scaling.h; NULL = flat): forward scale (f << 4) / m per position */
+int  orc_quant_m(const int16_t *coeff, int16_t *level, int n, int qp, int intra, const uint8_t *m);
+int  orc_quant_aux_m(const int16_t *coeff, int16_t *level, uint16_t *aux, int n, int qp, int intra, const uint8_t *m);
 /* "uvgx RDOQ v1" and sign data hiding: one pass over the levels of a transform block, one 4x4 coefficient group at a time (scan_idx 0 diagonal,
  * 1 horizontal, 2 vertical: the scan the block will be coded with).  Per group, in this order:
  *   rdoq: a group other than the block's DC group whose non-zero levels are one or two +-1 is dropped when that costs less than coding it:

@@ -24,6 +24,8 @@ HIP = {   # name: kvz_api options (all with hash=md5)
     "hip_vaq_roi_qp32": (("qp", 32), ("period", 8), ("me-range", 16), ("vaq", 8)),
     # a scene cut at picture 4 of the first GOP: intra units in P pictures, rdoq, sign data hiding (preset slow's tool set)
     "hip_scenecut_slow_qp30": (("qp", 30), ("period", 8), ("me-range", 16), ("preset", "slow")),
+    # round 4: uvgComm's "scaling list" checkbox (kvazaarfilter.cpp:235-242): scaling_list_enabled_flag with the default lists
+    "hip_scaling_list_default_qp30": (("qp", 30), ("period", 8), ("me-range", 16), ("scaling-list", "default"), ("subme", 2)),
 }
 index = {}
 if "--no-hip" in sys.argv and os.path.exists(os.path.join(out, "index.json")):

@@ -58,8 +58,9 @@ def test_kvz_api_table_and_config_parsing(lib):
     assert ok("preset", "veryfast") == 1 and cfg.contents.intra_in_p == 1      # the fast presets: 16x16 intra units only
     assert ok("sao", "off") == 1 and cfg.contents.sao_type == 0           # ... unless a later option says otherwise
     assert ok("preset", "ultrafast") == 1 and cfg.contents.sao_type == 0 and cfg.contents.intra_in_p == 0
+    assert ok("scaling-list", "default") == 1 and cfg.contents.scaling_list == 2 and ok("scaling-list", "off") == 1 and cfg.contents.scaling_list == 0      # uvgComm's checkbox (kvazaarfilter.cpp:235-242)
     # rejected: unknown names and values outside the implemented tool set (kvazaarfilter.cpp:363-367 logs these)
-    for k, v in (("no-such-option", "1"), ("qp", "99"), ("input-res", "axb"), ("tiles", "0x2"), ("scaling-list", "default"), ("gop", "8"), ("preset", "warp9"), ("sao", "edge")):
+    for k, v in (("no-such-option", "1"), ("qp", "99"), ("input-res", "axb"), ("tiles", "0x2"), ("scaling-list", "custom"), ("gop", "8"), ("preset", "warp9"), ("sao", "edge")):
         assert ok(k, v) == 0, (k, v)
     c.target_bitrate = 0
     c.mv_constraint = 4

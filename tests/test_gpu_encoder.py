@@ -551,6 +551,62 @@ def test_intra_units_in_p_pictures_match_oracle(gpu, cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(w=416, h=240, qp=32, frames=5, period=4),
+    dict(w=416, h=240, qp=27, frames=5, period=64, subme=4, sao=1, rdoq=1, signhide=1, intra_in_p=2, cut=3),
+    dict(w=640, h=368, qp=30, frames=4, period=64, tiles="2x2", subme=2),
+    dict(w=640, h=384, qp=32, frames=8, period=64, bitrate=500000, sao=1, subme=2, intra_in_p=1, cut=4),      # uvgComm's default mode + the scaling-list box
+    dict(w=1920, h=1080, qp=32, frames=3, period=64),                # BASELINE configs[1] size
+])
+def test_scaling_list_default_matches_oracle(gpu, cfg):
+    """`scaling-list default` (uvgComm's "scaling list" checkbox, kvazaarfilter.cpp:235-242): SPS scaling_list_enabled_flag with the default lists, per-position
+    quantiser and dequantiser in k_inter_recon and k_intra_recon<.., SCAL>; access units and reconstruction equal the checker's, both decoders return it"""
+    from kvazzup_amd import synth
+    from kvazzup_amd.codec import Decoder, Encoder
+    w, h = cfg["w"], cfg["h"]
+    tiles = cfg.get("tiles", "1x1"); tc, tr = [int(v) for v in tiles.split("x")]
+    br = cfg.get("bitrate", 0)
+    oe = orc.OracleEncoder(w, h, qp=cfg["qp"], period=cfg["period"], me_range=8, subme=cfg.get("subme", 0), sao=cfg.get("sao", 0), tile_rows=tr, tile_cols=tc, bitrate=br, rc_bands=4 if br else 0)
+    oe.set_option("scaling-list", 1); oe.set_option("intra-in-p", cfg.get("intra_in_p", 0)); oe.set_option("rdoq", cfg.get("rdoq", 0)); oe.set_option("signhide", cfg.get("signhide", 0))
+    ge = Encoder(w, h, options=(("qp", cfg["qp"]), ("period", cfg["period"]), ("me-range", 8), ("scaling-list", "default"), ("intra-in-p", cfg.get("intra_in_p", 0)),
+                                ("rdoq", cfg.get("rdoq", 0)), ("signhide", cfg.get("signhide", 0)), ("subme", cfg.get("subme", 0)), ("sao", "full" if cfg.get("sao") else "off"))
+                 + ((("tiles", tiles),) if tiles != "1x1" else ()) + ((("bitrate", br), ("rc-algorithm", "lambda")) if br else ()), fields={"target_bitrate": br})
+    assert not ge.rejected, ge.rejected
+    gd = Decoder(); od = orc.OracleDecoder()
+    for t in range(cfg["frames"]):
+        frame = synth.scene_cut_frame(SEED, w, h, t, cfg["cut"]) if "cut" in cfg else orc.synth_frame(0, SEED, w, h, t)
+        au, rec = ge.encode(frame)
+        want = oe.encode(frame)
+        assert au == want, (t, len(au), len(want), _diagnose(oe.debug(), ge.debug_all()))
+        assert np.array_equal(rec, oe.recon()), t
+        got = gd.decode_au(au, t); ref = od.decode_au(au, t)
+        assert len(got) == 1 and np.array_equal(got[0]["i420"], rec), t
+        assert len(ref) == 1 and np.array_equal(ref[0]["i420"], rec), t
+    for x in (ge, gd, oe, od):
+        x.close()
+
+
+@pytest.mark.gpu
+def test_lossless_field_does_not_end_the_call(gpu):
+    """uvgComm writes kvz_config.lossless itself (kvazaarfilter.cpp:244): the encoder has no transform / quantiser bypass, but the call must go on --
+    encoder_open succeeds and the stream is coded at the finest quantiser (QP 0), decodable and identical to the checker's at that QP"""
+    from kvazzup_amd.codec import Decoder, Encoder
+    w, h = 256, 128
+    ge = Encoder(w, h, options=(("qp", 32), ("period", 64), ("me-range", 8)), fields={"lossless": 1})
+    oe = orc.OracleEncoder(w, h, qp=0, period=64, me_range=8)
+    gd = Decoder()
+    for t in range(3):
+        frame = orc.synth_frame(0, SEED, w, h, t)
+        au, rec = ge.encode(frame)
+        assert au == oe.encode(frame), t
+        out = gd.decode_au(au, t)
+        assert len(out) == 1 and np.array_equal(out[0]["i420"], rec), t
+        assert float(np.mean((rec[:w * h].astype(np.int32) - frame[:w * h]) ** 2)) < 1.0, t      # QP 0: all but lossless
+    for x in (ge, gd, oe):
+        x.close()
+
+
+@pytest.mark.gpu
 def test_presets_switch_rdoq_and_sign_hiding_on(gpu):
     """preset medium and above: rdoq; slow and above: signhide too; superfast and above: intra units in P pictures (config_parse)"""
     from kvazzup_amd.codec import Encoder

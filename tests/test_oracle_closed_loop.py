@@ -326,6 +326,27 @@ def test_intra_units_in_p_pictures_closed_loop(subme, sao, tiles, adj, bitrate):
     assert (bitrate or b2 < b0) and s2 < s0, (b0, b2, s0, s2)
 
 
+@pytest.mark.parametrize("adj,sao,bitrate", [(0, 0, 0), (1, 1, 0), (0, 1, 300000)])
+def test_scaling_list_default_closed_loop(adj, sao, bitrate):
+    """`scaling-list default` (uvgComm's checkbox, kvazaarfilter.cpp:235-242): scaling_list_enabled_flag with the default lists -- the quantiser scales every
+    position by 16 / m, the normative dequantiser by m; every picture decodes to the encoder's reconstruction, and the high frequencies cost fewer bits"""
+    w, h, n = 320, 192, 6
+    def run(on):
+        oe = orc.OracleEncoder(w, h, qp=30, period=4, me_range=8, sao=sao, bitrate=bitrate, rc_bands=4 if bitrate else 0)
+        oe.set_option("scaling-list", on); oe.set_option("rdoq", adj); oe.set_option("signhide", adj); oe.set_option("intra-in-p", 2)
+        od = orc.OracleDecoder()
+        nbytes = 0
+        for t in range(n):
+            au = oe.encode(orc.synth_frame(0, 11, w, h, t))
+            fr = od.decode_au(au, t)
+            assert len(fr) == 1 and np.array_equal(fr[0]["i420"], oe.recon()), (on, t)
+            nbytes += len(au)
+        oe.close(); od.close()
+        return nbytes
+    b0, b1 = run(0), run(1)
+    assert bitrate or b1 < b0, (b0, b1)
+
+
 def test_rate_control_delay_option():
     """orc_enc_set_option "rc-delay" 3 .. 7: the access unit booked before picture t is t - delay (an encoder with delay - 1 pictures in flight); 3 is the default form,
     other delays give a different but equally decodable stream at the target rate"""

@@ -701,7 +701,13 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
     fetch_ahead(k + 1);
     uint32_t *pub = (d.flags & IB_PUBLISH) ? my : nullptr;
     if (pub && d.l2 > 4) { publish_wt(my, (uint32_t)d.zu); pub = nullptr; }       // (32x32 blocks: the workgroup-shaped code publishes ahead)
-    if (d.flags & IB_BORDER) borders_need(bd, s.pic, DI_P, plane, cpitch, cx, cy, S, sh, wC - cx * S, d.rx, d.ry, 1 << d.l2, &bcast, f.err, lane, T);
+    if (d.flags & IB_BORDER) {
+      // (a neighbouring CTU is waited for only as far as the block's MODE reads it: hevc_core.h intra_uses_* -- any stream; this project's encoder keeps the blocks
+      // on a CTU's left edge and its above-right corner block to the modes that make these waits short, "intra-chain")
+      const int n = 1 << d.l2, ci = c ? 1 : 0;
+      const int nl2 = ((intra_uses_below_left(d.l2, ci) >> d.mode) & 1) ? 2 * n : n, nt2 = ((intra_uses_above_right(d.l2, ci) >> d.mode) & 1) ? 2 * n : n;
+      borders_need(bd, s.pic, DI_P, plane, cpitch, cx, cy, S, sh, wC - cx * S, d.rx, d.ry, n, &bcast, f.err, lane, T, nl2, nt2);
+    }
     switch (d.l2) {
       case 2: dec_intra_block_wave<2>(s, ws, d, c == 0, gdst, cpitch, lane, rres, pub, ecol); break;
       case 3: dec_intra_block_wave<3>(s, ws, d, c == 0, gdst, cpitch, lane, rres, pub, ecol); break;

@@ -941,7 +941,14 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
   __syncthreads();
   if (tid < 20 && mine(tid)) {
     uint32_t bc = 0xffffffffu; int bm = 0;
-    for (int m = 0; m < 35; m++) if (s.cost[tid][m] < bc) { bc = s.cost[tid][m]; bm = m; }
+    uint64_t excl = 0;                                       // "intra-chain": modes this block may not take (statement: intra_analyse_size(), oracle/hevc_enc.c)
+    if (f.intra_chain) {
+      const int l2b = tid < 16 ? 3 : 4, nb_ = 1 << l2b, bib = tid < 16 ? tid : tid - 16, nbb = 32 >> l2b;
+      const int xb = X0 + (bib % nbb) * nb_, yb = Y0 + (bib / nbb) * nb_;
+      if ((yb & 63) == 0 && ((xb + nb_) & 63) == 0 && avail64(f.cw, f.chp, xb, yb, xb + nb_, yb - 1)) excl |= intra_uses_above_right(l2b, 0);      // the CTU's above-right corner block
+      if ((xb & 63) == 0 && avail64(f.cw, f.chp, xb, yb, xb - 1, yb + nb_)) excl |= intra_uses_below_left(l2b, 0);                                  // a block on the CTU's left edge
+    }
+    for (int m = 0; m < 35; m++) if (!((excl >> m) & 1) && s.cost[tid][m] < bc) { bc = s.cost[tid][m]; bm = m; }
     s.bestc[tid] = bc; s.bestm[tid] = bm;
     if (PP && cand[0] + cand[1] + cand[2] + cand[3] > 1) st_wt_u64(&f.ip_scratch[(size_t)ci * 20 + tid], (uint64_t)bc | ((uint64_t)bm << 32));      // for the block's other quarters
     const int l2 = tid < 16 ? 3 : 4, n = 1 << l2, bi = tid < 16 ? tid : tid - 16, nb = 32 >> l2;
@@ -1222,7 +1229,13 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     chain_wait_done(ch, make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)dp.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)dp.y)), f.err, lane);
     // the neighbouring CTUs' samples this block reads: wait for them, copy them into the borders of the CTU picture
     PROF(2);                                                // waiting for the units this block reads
-    if (d.flags & IB_BORDER) borders_need_wave(ch, nb, s.pic, P, plane, pw, cx, row, S, sh, 2 * S, d.rx, d.ry, 1 << d.l2, f.err, lane);
+    if (d.flags & IB_BORDER) {
+      // the neighbouring CTUs are waited for only as far as the block's MODE reads them (hevc_core.h intra_uses_*): with "intra-chain" the left-edge blocks never
+      // read the left CTU's below-left samples and the above-right CTU is not read at all
+      const int n = 1 << d.l2;
+      const int nl2 = ((intra_uses_below_left(d.l2, c) >> d.mode) & 1) ? 2 * n : n, nt2 = ((intra_uses_above_right(d.l2, c) >> d.mode) & 1) ? 2 * n : n;
+      borders_need_wave(ch, nb, s.pic, P, plane, pw, cx, row, S, sh, 2 * S, d.rx, d.ry, n, f.err, lane, nl2, nt2);
+    }
     PROF(3);                                                // neighbouring CTUs: waits and copies
     if (f.trace && first && k == 0 && lane == 0) f.trace[((size_t)ctu * 3 + c) * 8 + 1] = wall_clock64();
     first = false;

@@ -47,6 +47,7 @@ struct EncoderConfig {
   int sao = 0;                // kvazaar "sao": sample adaptive offset, parameters by "uvgx SAO decision v1" (oracle/hevc_sao.c)
   int input_hold = 0;         // "input-hold" (extension): 1 = the caller leaves a DEVICE input picture unchanged until that picture's access unit has been returned --
                               // what the kvz_api contract already demands of host pictures (kvazaarfilter.cpp:76-88); encode_device then returns without waiting for the input stage
+  int intra_chain = 1;        // "intra-chain": left-edge blocks / the above-right corner block of a CTU keep to the modes that do not read the neighbouring CTU's below-left / above-right samples (oracle/hevc_enc.c intra_analyse_size)
   int scaling_list = 0;       // kvazaar "scaling-list default": scaling_list_enabled_flag with the default lists (oracle/hevc_scaling.c); quantiser scale per position (qscale << 4) / m
   int rdoq = 0;               // kvazaar "rdoq": "uvgx RDOQ v1" -- sparse high-frequency coefficient groups are dropped when that is cheaper (oracle/hevc_transform.h orc_adjust_levels)
   int intra_in_p = 0;         // "intra-in-p" 0 / 1 (16x16 units only) / 2 (16x16 and 8x8): intra coding units in P pictures ("uvgx intra-in-P v1", oracle/hevc_enc.c me_block32); not in band mode

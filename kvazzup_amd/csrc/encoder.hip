@@ -199,7 +199,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     scaling_factors(scaling_defaults(), tab);
     HIP_OK(hipMalloc(&d_scaling_, KVZ_SCALING_BYTES)); HIP_OK(hipMemcpy(d_scaling_, tab, KVZ_SCALING_BYTES, hipMemcpyHostToDevice));
   }
-  f_.scaling = d_scaling_;
+  f_.scaling = d_scaling_; f_.intra_chain = cfg.intra_chain;
   f_.rdoq = cfg.rdoq; f_.signhide = cfg.signhide; f_.intra_p = cfg.intra_in_p; f_.me_cost16 = me_cost16_; f_.me_cand = me_cost16_ ? me_cost16_ + (size_t)(cw_ / 16) * (ch_ / 16) : nullptr;
   if (me_cost16_) { const size_t n16 = (size_t)(cw_ / 16) * (ch_ / 16); f_.ip_arrive = f_.me_cand + 1 + n16 / 4; f_.ip_scratch = (uint64_t *)(me_cost16_ + ((n16 + 1 + n16 / 4 + n16 / 4 + 1) & ~(size_t)1)); }      // (8-byte aligned)
   f_.wpp = cfg.wpp; f_.mv_frame = cfg.mv_frame; f_.me_early = cfg.me_early; f_.satd = cfg.satd; f_.subme = cfg.subme; f_.slices = cfg.slices;

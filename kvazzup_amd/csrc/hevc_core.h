@@ -71,6 +71,7 @@ struct EncFrame {
   int me_early;             // me-early-termination: blocks that match the co-located reference block to within 64 * lambda_q4 are not searched
   int subme;                // fractional-sample refinement level 0..4 (k_subpel)
   const uint8_t *scaling;   // `scaling-list default`: KVZ_SCALING_BYTES scaling factors of the default lists (dec_frame.h scaling_offset), NULL: flat
+  int intra_chain;          // "intra-chain" (default on): blocks on a CTU's left edge / its above-right corner block choose among the modes that do not read the left CTU's below-left / the above-right CTU's samples
   int intra_p;              // "uvgx intra-in-P v1": intra coding units in P pictures (statement: oracle/hevc_enc.c me_block32); me_cost16 = k_me's inter cost of every 16x16 block (0: not searched)
   uint32_t *me_cost16;
   uint8_t *edge_col[3];     // k_intra_recon: per plane [CTU][S] the CTU's right column of reconstructed samples (kernel_common.h IB_EDGE_R)
@@ -914,6 +915,15 @@ KVZ_HD void decide_signalling(const EncFrame &f, int x0, int y0, int log2)
 
 // ---------------------------------------------------------------------------------------------
 // Intra sample prediction (H.265 8.4.4.2).  `left[0]` = `top[0]` = p[-1][-1], left[1+i] = p[-1][i],
+// Which intra prediction modes read the block's ABOVE-RIGHT reference samples p[x][-1], x >= n, or its BELOW-LEFT ones p[-1][y], y >= n -- directly or through
+// the [1 2 1] reference filter (8.4.4.2.3-6); bit m = mode m does.  Found by perturbing the reference samples of the checker's predictor and confirmed the
+// same way for this file's and the Python decoder's (tests/test_intra_dependencies.py).  Luma 16x16 / 32x32 filter more modes than the smaller blocks.
+// Used twice: the intra chains wait for a neighbouring CTU only as far as the block's mode reads it, and the encoder keeps the blocks whose above-right /
+// below-left samples lie in ANOTHER CTU to the modes that do not read them ("intra-chain") -- the CTU wavefront's lags shrink.
+// (luma 32x32: every filtered mode -- all but DC, 10 and 26 -- may read both far corners, p[63][-1] and p[-1][63], through the strong filter)
+KVZ_HD uint64_t intra_uses_above_right(int log2n, int cidx) { return cidx == 0 && log2n == 4 ? 0x7f9f80001ull : (cidx == 0 && log2n == 5 ? 0x7fbfffbfdull : 0x7f8000001ull); }
+KVZ_HD uint64_t intra_uses_below_left(int log2n, int cidx) { return cidx == 0 && log2n == 4 ? 0x3f3fdull : (cidx == 0 && log2n == 5 ? 0x7fbfffbfdull : 0x3fdull); }
+
 // top[1+i] = p[i][-1], i < 2n.  The arrays passed to intra_pred_sample() are the ones selected by
 // the filtering decision of 8.4.4.2.3.
 // ---------------------------------------------------------------------------------------------

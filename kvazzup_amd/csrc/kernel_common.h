@@ -227,11 +227,15 @@ __device__ __forceinline__ void borders_begin(IntraBorders &b, uint32_t *bc4)
 // lim_w: samples of the row above that exist (picture width, upper-right CTU); plane / gp: the picture plane and its pitch;
 // (cx, cy): CTU coordinates in units of S.  Ends with a barrier when anything was loaded.
 __device__ __forceinline__ void borders_need(IntraBorders &b, uint8_t *pic, int lp, const uint8_t *plane, int gp, int cx, int cy, int S, int sh,
-                                             int lim_w, int rx, int ry, int n, uint32_t *bcast, uint32_t *err, int tid, int nthreads)
+                                             int lim_w, int rx, int ry, int n, uint32_t *bcast, uint32_t *err, int tid, int nthreads, int nl2 = -1, int nt2 = -1)
 {
+  // nl2 / nt2: rows of the left border / samples of the row above the block's mode reads from (rx, ry) on: 2 n, or n when the mode does not use the
+  // below-left / above-right samples (hevc_core.h intra_uses_below_left / intra_uses_above_right)
+  if (nl2 < 0) nl2 = 2 * n;
+  if (nt2 < 0) nt2 = 2 * n;
   bool loaded = false;
   if (rx == 0 && b.nb_left) {
-    const int need = imin(S, ry + 2 * n);
+    const int need = imin(S, ry + nl2);
     if (need > b.left_loaded) {
       b.seen_l = wait_wt(b.pl, kv_edge_need(b.il, ((need - 1) << sh) >> 3, true), b.seen_l, bcast, err);
       const int upto = imax(need, imin(S, kv_units_right(b.seen_l) * (8 >> sh)));
@@ -241,7 +245,7 @@ __device__ __forceinline__ void borders_need(IntraBorders &b, uint8_t *pic, int 
     }
   }
   if (ry == 0 && b.nb_up) {
-    const int lim = imin(lim_w, b.nb_ur ? 2 * S : S), need = imin(lim, rx + 2 * n);
+    const int lim = imin(lim_w, b.nb_ur ? 2 * S : S), need = imin(lim, rx + nt2);
     if (need > b.top_loaded) {
       int upto = need;
       if (b.top_loaded < S) {
@@ -330,8 +334,9 @@ __device__ __forceinline__ uint32_t wave_wait_wt(const uint32_t *ctr, uint32_t n
 // wave-level borders_need(): the borders the block at (rx, ry), size n, reads are in LDS when it returns.  Two waves may copy
 // overlapping pieces (the same bytes); the *_loaded marks only ever grow.
 __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNeighbours &b, uint8_t *pic, int lp, const uint8_t *plane, int gp, int cx, int cy, int S, int sh,
-                                                  int lim_w, int rx, int ry, int n, uint32_t *err, int lane)
+                                                  int lim_w, int rx, int ry, int n, uint32_t *err, int lane, int nl2, int nt2)
 {
+  // (nl2 / nt2: as in borders_need)
   // What is missing of the three borders is decided first, the neighbours' progress awaited, and then ALL the loads are issued before the
   // first of them is waited for: the first block of a CTU needs its left column, its top row and its corner, and three memory round trips one
   // after the other were a tenth of the wavefront's step (S <= 64: one byte per lane covers a column, one dword per lane a row and a half).
@@ -341,7 +346,7 @@ __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNei
     // The CTU's first block waits for three neighbours (left column, top row, corner).  They are polled TOGETHER, lanes 0 .. 3 one counter each, until all
     // are far enough: waiting for the left one first and then finding out with a poll each that the upper ones were done long ago put two memory round
     // trips on the wavefront's step.  (The wave_wait_wt calls below then find what they need in the cache.)
-    const int nL = imin(S, 2 * n), limT = imin(lim_w, b.nb_ur ? 2 * S : S), nT = imin(limT, 2 * n);
+    const int nL = imin(S, nl2), limT = imin(lim_w, b.nb_ur ? 2 * S : S), nT = imin(limT, nt2);
     uint32_t want = 0;
     if (lane == 0 && b.nb_left) want = kv_edge_need(b.il, ((nL - 1) << sh) >> 3, true);
     if (lane == 1 && b.nb_up) want = kv_edge_need(b.iu, ((imin(S, nT) - 1) << sh) >> 3, false);
@@ -359,7 +364,7 @@ __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNei
     wave_sync();
   }
   if (rx == 0 && b.nb_left) {
-    const int need = imin(S, ry + 2 * n);
+    const int need = imin(S, ry + nl2);
     haveL = __builtin_amdgcn_readfirstlane(lds_load(&ch.left_loaded));
     if (need > haveL) {
       const uint32_t seen = wave_wait_wt(b.pl, kv_edge_need(b.il, ((need - 1) << sh) >> 3, true), &ch.seen_l, err, lane);
@@ -367,7 +372,7 @@ __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNei
     }
   }
   if (ry == 0 && b.nb_up) {
-    const int lim = imin(lim_w, b.nb_ur ? 2 * S : S), need = imin(lim, rx + 2 * n);
+    const int lim = imin(lim_w, b.nb_ur ? 2 * S : S), need = imin(lim, rx + nt2);
     haveT = __builtin_amdgcn_readfirstlane(lds_load(&ch.top_loaded));
     if (need > haveT) {
       uptoT = need;

@@ -46,7 +46,7 @@ int config_init(kvz_config *cfg)
   cfg->me_range = 16; cfg->gpu_device = 0; cfg->recon_output = 1;
   cfg->threads = -1;                                    // auto, as in Kvazaar
   cfg->me_early_termination = 1;                        // on, as in Kvazaar
-  cfg->intra_satd = 1; cfg->gpu_entropy = 0;
+  cfg->intra_satd = 1; cfg->gpu_entropy = 0; cfg->intra_chain = 1;
   return 1;
 }
 
@@ -179,7 +179,7 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
   INT_OPT("me-range", me_range, 1, 32)
   INT_OPT("gpu", gpu_device, 0, 64)
   BOOL_OPT("recon-output", recon_output)
-  BOOL_OPT("input-hold", input_hold) INT_OPT("intra-in-p", intra_in_p, 0, 2)
+  BOOL_OPT("intra-chain", intra_chain) BOOL_OPT("input-hold", input_hold) INT_OPT("intra-in-p", intra_in_p, 0, 2)
   if (n == "null-input") {
     if (!strcmp(value, "drain")) { cfg->null_input_poll = 0; return 1; }
     if (!strcmp(value, "poll")) { cfg->null_input_poll = 1; return 1; }
@@ -314,7 +314,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.subme = cfg->fme_level < 0 ? 0 : (cfg->fme_level > 4 ? 4 : cfg->fme_level);
   ec.entropy_gpu = cfg->gpu_entropy != 0;
   ec.input_hold = cfg->input_hold != 0;
-  ec.scaling_list = cfg->scaling_list == KVZ_SCALING_LIST_DEFAULT;
+  ec.scaling_list = cfg->scaling_list == KVZ_SCALING_LIST_DEFAULT; ec.intra_chain = cfg->intra_chain != 0;
   // kvz_config.lossless (uvgComm writes the field itself, kvazaarfilter.cpp:244, so a refusal could only be a failed encoder_open = no video at all):
   // transform / quantiser bypass is not implemented in the encoder -- the call goes on at the finest quantiser instead, and says so once
   if (cfg->lossless) { fprintf(stderr, "kvazzup_amd: lossless coding is not implemented in the encoder; coding at QP 0 instead\n"); ec.qp = 0; }

@@ -62,7 +62,7 @@ void orc_enc_default_config(orc_enc_config *c)
 {
   memset(c, 0, sizeof(*c));
   c->qp = 32; c->intra_period = 64; c->vps_period = 1; c->search_range = 16;
-  c->fps_num = 30; c->fps_den = 1; c->wpp = 1; c->deblock = 1; c->tile_rows = 1; c->me_early = 1; c->satd = 1;
+  c->fps_num = 30; c->fps_den = 1; c->wpp = 1; c->deblock = 1; c->tile_rows = 1; c->me_early = 1; c->satd = 1; c->intra_chain = 1;
 }
 
 int orc_mvd_bits(int q)
@@ -293,7 +293,19 @@ static void intra_analyse_size(orc_encoder *e, int n, uint8_t *best_mode, uint32
       int x0 = bx * n, y0 = by * n;
       orc_intra_refs(&e->av, e->src[0], e->cw, 0, x0, y0, n, left, top);
       uint32_t bc = 0xffffffffu; int bm = 0;
+      /* "intra-chain" (default on): the reconstruction chain of an intra picture advances CTU by CTU along a wavefront whose lags are set by the samples a
+       * CTU's blocks read from ANOTHER CTU beyond their own row / column of it -- the left CTU's below-left samples for the blocks on the CTU's left edge (they make
+       * it wait for three quarters of the left CTU instead of three eighths) and the above-right CTU's samples for the CTU's above-right corner block (they make a
+       * CTU row follow the row above at almost two CTUs' distance instead of one).  Those blocks choose among the modes that do not read these samples, directly or
+       * through the reference filter (the masks: tests/test_intra_dependencies.py): 4 of a CTU's 16 blocks lose planar and about a third of the angular modes. */
+      uint64_t excl = 0;
+      if (e->cfg.intra_chain) {
+        const uint64_t tr = n == 16 ? 0x7f9f80001ull : 0x7f8000001ull, bl = n == 16 ? 0x3f3fdull : 0x3fdull;      /* luma 16x16 / 8x8: modes reading p[x][-1], x >= n / p[-1][y], y >= n */
+        if ((y0 & 63) == 0 && ((x0 + n) & 63) == 0 && orc_available(&e->av, x0, y0, x0 + n, y0 - 1)) excl |= tr;
+        if ((x0 & 63) == 0 && orc_available(&e->av, x0, y0, x0 - 1, y0 + n)) excl |= bl;
+      }
       for (int m = 0; m < 35; m++) {
+        if ((excl >> m) & 1) continue;
         orc_intra_predict(left, top, n, 0, m, 1, pred, n);
         uint32_t c = e->cfg.satd ? satd_block(e->src[0] + y0 * e->cw + x0, e->cw, pred, n, n) : sad_block(e->src[0] + y0 * e->cw + x0, e->cw, pred, n, n);
         if (c < bc) { bc = c; bm = m; }
@@ -1210,6 +1222,7 @@ int orc_enc_set_option(orc_encoder *e, const char *name, int value)
     for (int sz = 0; sz < 4; sz++) for (int mi = 0; mi < (sz == 3 ? 2 : 6); mi++) orc_scaling_factor(&e->sps.scaling, sz, mi, e->sfac[sz][mi]);
     return 1;
   }
+  if (!strcmp(name, "intra-chain")) { e->cfg.intra_chain = value != 0; return 1; }
   if (!strcmp(name, "rdoq")) { e->cfg.rdoq = value != 0; return 1; }
   if (!strcmp(name, "signhide")) { e->cfg.signhide = value != 0; e->pps.sign_data_hiding = e->cfg.signhide; return 1; }
   return 0;

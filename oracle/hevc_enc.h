@@ -62,6 +62,7 @@ typedef struct {
                                * in hevc_enc.c): 0 off (Kvazaar's ultrafast), 1 half-sample positions left/right/above/below, 2 + the four
                                * half-sample diagonals, 3 + quarter-sample left/right/above/below of the best so far, 4 + its quarter-sample
                                * diagonals; candidates are compared by SATD (8x8 Hadamard) + lambda * vector bits */
+  int intra_chain;            /* "intra-chain" (default 1): mode restriction for the blocks whose below-left / above-right samples lie in another CTU (intra_analyse_size) */
   int scaling_list;           /* kvazaar scaling-list default: scaling_list_enabled_flag with the default lists; quantiser scale (f << 4) / m per position (orc_quant_m) */
   int rdoq;                   /* kvazaar rdoq: "uvgx RDOQ v1" -- sparse high-frequency coefficient groups are dropped when that is cheaper (orc_adjust_levels, hevc_transform.h) */
   int signhide;               /* kvazaar signhide: sign_data_hiding_enabled_flag; the quantiser makes the parity of every eligible coefficient group say the hidden sign */

@@ -180,6 +180,9 @@ int hc_encode_au_tokens(HcFrame *h, uint8_t *out, int cap, unsigned long long *n
 }
 
 // Intra prediction of one n x n block from explicit reference arrays (left/top as in hevc_core.h)
+// hevc_core.h intra_uses_above_right / intra_uses_below_left: the masks the intra chains and the encoder's "intra-chain" mode restriction use
+uint64_t hc_intra_uses(int log2n, int cidx, int below_left) { return below_left ? intra_uses_below_left(log2n, cidx) : intra_uses_above_right(log2n, cidx); }
+
 void hc_intra_predict(const uint8_t *left, const uint8_t *top, int n, int cidx, int mode, uint8_t *pred)
 {
   int l2 = ilog2((unsigned)n);

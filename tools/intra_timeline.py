@@ -10,7 +10,7 @@ from kvazzup_amd import synth
 from kvazzup_amd.codec import Encoder
 
 w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
-e = Encoder(w, h, options=(("qp", 32), ("period", 1), ("me-range", 16)))
+e = Encoder(w, h, options=(("qp", 32), ("period", 1), ("me-range", 16), ("intra-chain", os.environ.get("INTRA_CHAIN", "1"))))
 for t in range(3):
     e.encode(synth.frame(synth.MOVING, 0x5EED0002, w, h, t))
 wc, hc = (w + 63) // 64, (h + 63) // 64

@@ -192,7 +192,7 @@ def main():
     multi = None
     if single and args.streams_per_gpu and not args.host_io:
         multi = []
-        for k in [int(v) for v in args.streams_per_gpu.split(",") if v.strip()]:
+        for k in [int(v) for v in args.streams_per_gpu.split(",") if v.strip().isdigit() and int(v) > 1]:      # ('' / 0 / none: off)
             try:
                 leg = multi_stream(args, wl, k, max(2, args.steps // 2), ranks)
                 leg["of_single_stream"] = round(leg["value"] / fps, 4)

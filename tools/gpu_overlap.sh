@@ -1,8 +1,10 @@
 #!/bin/bash
-# how much the kernels of the pipeline's streams overlap on the GPU: tools/gpu_overlap.sh <workload>   (kernel trace of a short bench run, analysed on the box)
-R=${GRAFT_REPO_ROOT:-$PWD}; wl=${1:-4k}
+# how much the kernels of the pipeline's streams overlap on the GPU: tools/gpu_overlap.sh <workload> [streams]   (kernel trace of a short bench run, analysed on the box;
+# streams = K: the window analysed is the K-pipelines-in-one-process leg -- the longest run of kernels of the trace -- instead of the single stream's)
+R=${GRAFT_REPO_ROOT:-$PWD}; wl=${1:-4k}; K=${2:-}
+if [ -n "$K" ]; then multi="--streams-per-gpu $K --steps 2"; echo "== $wl, $K pipelines in one process"; else multi="--streams-per-gpu 0 --steps 3"; echo "== $wl, one pipeline"; fi
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/ovl
-KVAZZUP_BENCH_NOPROF=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ovl -o p -- python3 $R/bench.py --workload $wl --no-cpu-baseline --no-secondary --no-host-boundary --repeats 1 --steps 3 --warmup 1 > /tmp/ovl.log 2>&1
+KVAZZUP_BENCH_NOPROF=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/ovl -o p -- python3 $R/bench.py --workload $wl --no-cpu-baseline --no-secondary --no-host-boundary --no-preset-line --repeats 1 --warmup 1 $multi > /tmp/ovl.log 2>&1
 tail -c 300 /tmp/ovl.log | head -c 200; echo
 f=$(find /tmp/ovl -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'

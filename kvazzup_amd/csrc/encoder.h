@@ -164,7 +164,7 @@ class Encoder {
   bool stage_roi(hipStream_t st);  // the picture's ROI deltas -> ctu_roi_[set_] on `st`; roi_dev_ = that array or NULL (no map)
   const int8_t *roi_dev_ = nullptr;
   int *vaq_act_ = nullptr, *vaq_sum_ = nullptr; // VAQ: activity of every CTU, its sum over the picture
-  bool picture_begin();            // launch_picture_begin on the main stream (+ the VAQ kernels)
+  bool picture_begin(hipStream_t qt_stream);   // launch_picture_begin: the rate control state on the main stream (picture order), the per-CTU targets on the picture's own stream (+ the VAQ kernels)
   int qp_cur_ = 0; int64_t rc_debt_ = 0; uint32_t rc_bytes_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t rc_known_ = 0;   // rate control state (calling thread)
   void rate_control();
   RcState *rc_state_ = nullptr;                 // rate control v2: device-side state
@@ -179,6 +179,9 @@ class Encoder {
   // An intra picture depends on no other picture: its chain (1.6 ms at 1080p, twenty picture intervals) is queued on a stream of its own the moment the
   // picture is accepted, beside the P pictures in front of it that the main stream is still working through; the next P picture waits for ev_idr_done_.
   hipStream_t stream_idr_ = nullptr; hipEvent_t ev_idr_done_ = nullptr; bool idr_pending_ = false, idr_side_ = false;
+  // ... with its own copies of what the P pictures' kernels also use while it runs beside them (round 4: the side chain also with SAO, intra units in P
+  // pictures, per-CTU QPs and rate control v2 -- uvgComm's default mode): progress counters + ticket word, the CTUs' edge columns, the SAO work picture
+  uint32_t *sync_idr_ = nullptr; uint8_t *edge_col_idr_ = nullptr; uint8_t *work_idr_[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_signalled_ = nullptr, ev_tok_done_[kSets] = {}; bool tok_pending_[kSets] = {};
   void bind_set(int k);
   uint8_t *intra_scratch_ = nullptr;

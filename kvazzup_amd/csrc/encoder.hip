@@ -113,8 +113,14 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   HIP_OK(hipEventCreateWithFlags(&ev_signalled_, kDeviceEvent));
   // the intra pictures' own stream: where the chain shares nothing with the P pictures' kernels (no SAO work picture, no intra units in P pictures
   // -- they use the same progress counters --, no per-CTU QP upload, no row groups) and pictures are queued ahead at all
-  idr_side_ = depth_ >= 2 && !cfg.sao && !cfg.intra_in_p && !cfg.qp_in_cu && cfg.rc_bands == 0 && cfg.band_rows == 0 && !getenv("KVAZZUP_AMD_IDR_INLINE");
+  // (round 4: SAO, intra units in P pictures, per-CTU QPs and the row groups of rate control v2 no longer keep it on the main stream -- the side chain has its own
+  // progress counters, edge columns and SAO work picture; VAQ still does: its activity scratch is shared)
+  idr_side_ = depth_ >= 2 && cfg.vaq == 0 && cfg.band_rows == 0 && !getenv("KVAZZUP_AMD_IDR_INLINE");
   if (idr_side_) {
+    const size_t nsync = (size_t)rows_ * (cw_ / 64) * 3 + 2, nctu_ = (size_t)(cw_ / 64) * rows_;
+    HIP_OK(hipMalloc(&sync_idr_, sizeof(uint32_t) * nsync)); HIP_OK(hipMemset(sync_idr_, 0, sizeof(uint32_t) * nsync));
+    HIP_OK(hipMalloc(&edge_col_idr_, nctu_ * 128));
+    if (cfg.sao) { const size_t npx_ = (size_t)cw_ * ch_; for (int c = 0; c < 3; c++) HIP_OK(hipMalloc(&work_idr_[c], c ? npx_ / 4 : npx_)); }
     // ... which is the INPUT stream: the pictures behind an intra picture need it anyway, so their input stages lose nothing by queueing behind
     // its chain, and a further stream would share a hardware queue with one that matters (HIP spreads a priority level's streams over four;
     // measured with a stream of its own: no gain at the default level, half the rate at any other -- KVAZZUP_AMD_IDR_PRIO)
@@ -270,7 +276,8 @@ Encoder::~Encoder()
   hipFree(vaq_act_); hipFree(vaq_sum_); hipFree(rc_state_);
   for (int k = 0; k < kSets; k++) { hipFree(ctu_qt_[k]); hipFree(ctu_qy_[k]); hipFree(ctu_delta_[k]); hipFree(ctu_first_[k]); if (h_ctu_qt_[k]) hipHostFree(h_ctu_qt_[k]); hipFree(ctu_roi_[k]); }
   for (int k = 0; k < kSets; k++) { hipFree(cu_bytes_[k]); hipFree(cu_mv_[k]); hipFree(cu_mvd_[k]); if (ev_tok_done_[k]) hipEventDestroy(ev_tok_done_[k]); }
-  for (int c = 0; c < 3; c++) hipFree(work_[c]);
+  for (int c = 0; c < 3; c++) { hipFree(work_[c]); hipFree(work_idr_[c]); }
+  hipFree(sync_idr_); hipFree(edge_col_idr_);
   for (int k = 0; k < kSets; k++) hipFree(sao_[k]);
   if (ev_sao_) hipEventDestroy(ev_sao_);
   if (ev_signalled_) hipEventDestroy(ev_signalled_);
@@ -472,11 +479,19 @@ bool Encoder::stage_roi(hipStream_t st)
   roi_dev_ = ctu_roi_[set_];
   return true;
 }
-bool Encoder::picture_begin()
+bool Encoder::picture_begin(hipStream_t qt_stream)
 {
   const bool have = frame_idx_ >= rc_delay_;
-  launch_picture_begin(rc_state_, have ? 8u * rc_bytes_[(frame_idx_ - rc_delay_) & 7] : 0u, (frame_idx_ - rc_delay_) & 7, have ? 1 : 0,
-                       cfg_.qp_in_cu ? ctu_qt_[set_] : nullptr, roi_dev_, (cw_ / 64) * rows_, qp_cur_, cfg_.vaq > 0 ? 1 : 0, stream_);
+  const uint32_t bits3 = have ? 8u * rc_bytes_[(frame_idx_ - rc_delay_) & 7] : 0u;
+  const int slot3 = (frame_idx_ - rc_delay_) & 7, n = (cw_ / 64) * rows_;
+  int8_t *qt = cfg_.qp_in_cu ? ctu_qt_[set_] : nullptr;
+  if (qt_stream == stream_) launch_picture_begin(rc_state_, bits3, slot3, have ? 1 : 0, qt, roi_dev_, n, qp_cur_, cfg_.vaq > 0 ? 1 : 0, stream_);
+  else {
+    // an intra picture on its side stream: the rate control state is updated in PICTURE ORDER on the main stream (between the P pictures' row groups, which
+    // run there), the picture's own per-CTU targets on its own stream
+    launch_picture_begin(rc_state_, bits3, slot3, have ? 1 : 0, nullptr, nullptr, 0, qp_cur_, 0, stream_);
+    launch_picture_begin(nullptr, 0, 0, 0, qt, roi_dev_, n, qp_cur_, 0, qt_stream);
+  }
   if (cfg_.qp_in_cu && cfg_.vaq > 0) launch_vaq(f_, cfg_.vaq, vaq_act_, vaq_sum_, stream_);          // (f_.qp, f_.src and f_.ctu_qt of this picture are set; the source is padded: stream_ waits for in_done_)
   return true;
 }
@@ -516,10 +531,21 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   for (int c = 0; c < 3; c++) { f_.rec[c] = cfg_.sao ? work_[c] : rec_[cur_idx_][c]; f_.sao_out[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
   f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err; f_.ent_cursors = sl.g_cursors;
   f_.tok_cursor = (uint32_t *)tok_count_ + (size_t)(frame_idx_ & 1) * tok_nctu_; f_.tok_cursor_next = (uint32_t *)tok_count_ + (size_t)((frame_idx_ + 1) & 1) * tok_nctu_;
-  const EncFrame f = f_;
   // the stream this picture's chain runs on: an intra picture's own (encoder.h stream_idr_), else the main stream -- behind the last intra picture's chain
   const bool side = intra && idr_side_;
   const hipStream_t ms = side ? stream_idr_ : stream_;
+  if (side) {                                               // beside the P pictures still on the main stream: nothing of theirs is touched
+    const size_t nctu = (size_t)(cw_ / 64) * rows_;
+    f_.sync = sync_idr_; f_.me_cand = nullptr;              // (me_cand NULL: the picture's deblocking kernel leaves the P pictures' candidate list and "has intra units" word alone)
+    f_.edge_col[0] = edge_col_idr_; f_.edge_col[1] = edge_col_idr_ + nctu * 64; f_.edge_col[2] = edge_col_idr_ + nctu * 96;
+    if (cfg_.sao) for (int c = 0; c < 3; c++) f_.rec[c] = work_idr_[c];
+  }
+  const EncFrame f = f_;
+  if (side) {                                               // (f_ goes back to the shared arrays for the pictures that follow)
+    const size_t nctu = (size_t)(cw_ / 64) * rows_;
+    f_.sync = sync_; f_.me_cand = me_cost16_ ? me_cost16_ + (size_t)(cw_ / 16) * (ch_ / 16) : nullptr;
+    f_.edge_col[0] = edge_col_; f_.edge_col[1] = edge_col_ + nctu * 64; f_.edge_col[2] = edge_col_ + nctu * 96;
+  }
   if (!side && idr_pending_) { HIP_CHECK(hipStreamWaitEvent(stream_, ev_idr_done_, 0)); idr_pending_ = false; }
   if (src_busy_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_src_free_[set_], 0)); src_busy_[set_] = false; }   // the last picture that used this set (t - kSets) has been reconstructed
   timed(K_PAD, stream_in_, [&] { launch_pad_input(d_i420, w, h, src_[set_][0], src_[set_][1], src_[set_][2], cw_, ch_, stream_in_); });
@@ -534,9 +560,9 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   HIP_CHECK(hipEventRecord(in_done_, stream_in_)); in_pending_ = true;
   HIP_CHECK(hipStreamWaitEvent(ms, in_done_, 0));
   if (tok_pending_[set_]) { HIP_CHECK(hipStreamWaitEvent(ms, ev_tok_done_[set_], 0)); tok_pending_[set_] = false; }   // the tokenizer of the set's previous picture is done with it
-  if (!picture_begin()) return false;
+  if (!picture_begin(ms)) return false;
   if (intra) {
-    HIP_CHECK(hipMemsetAsync(sync_, 0, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 1), ms));
+    HIP_CHECK(hipMemsetAsync(f.sync, 0, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 1), ms));
     HIP_CHECK(hipMemsetAsync(f_.cu_cbf, 0, (size_t)f_.b8w * f_.b8h, ms));     // the three plane waves OR their bit in
     timed(K_INTRA_RECON, ms, [&] { launch_intra_recon(f, ms); });
   } else {
@@ -746,7 +772,7 @@ bool Encoder::band_phase1(const uint8_t *d_i420)
   if (cfg_.band_rows <= 0 || !d_i420) return false;
   if (!band_picture_setup()) return false;
   roi_sub_ = roi_; roi_sub_w_ = roi_w_; roi_sub_h_ = roi_h_;
-  if (!stage_roi(stream_) || !picture_begin()) return false;
+  if (!stage_roi(stream_) || !picture_begin(stream_)) return false;
   const EncFrame f = f_;
   launch_pad_input(d_i420, cfg_.width, cfg_.height, src_[0][0], src_[0][1], src_[0][2], cw_, ch_, stream_);
   if (band_intra_) {

@@ -196,6 +196,42 @@ def test_config4_eight_ranks_share_the_gpu(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("owf", [3, 6])
+def test_default_mode_pipelined_with_intra_pictures_on_the_side_stream(gpu, owf):
+    """uvgComm's default mode (preset veryfast: SAO, subme 2, 16x16 intra units in P pictures; 1 Mbit/s with rc-algorithm lambda: per-CTU QPs and the row groups
+    of rate control v2) with pictures in flight and an intra period of 12: every intra picture's chain runs on the side stream BESIDE the P pictures in front
+    of it -- its own progress counters, edge columns and SAO work picture, the rate control state updated in picture order on the main stream -- and the access
+    units are still the synchronous checker's (rc-delay = pictures in flight + 1)"""
+    from kvazzup_amd import synth
+    from kvazzup_amd.codec import Decoder, Encoder
+    w, h, n, period, br = 1280, 720, 40, 12, 1000000
+    ge = Encoder(w, h, options=(("preset", "veryfast"), ("qp", 32), ("period", period), ("me-range", 16), ("owf", owf), ("bitrate", br), ("rc-algorithm", "lambda")),
+                 fields={"target_bitrate": br})
+    assert not ge.rejected, ge.rejected
+    oe = orc.OracleEncoder(w, h, qp=32, period=period, me_range=16, sao=1, subme=2, bitrate=br, rc_bands=4)
+    oe.set_option("intra-in-p", 1); oe.set_option("rc-delay", min(owf, 6) + 1)
+    od = orc.OracleDecoder(); gd = Decoder(threads=4, frame_threads=True)
+    frames = [synth.scene_cut_frame(SEED, w, h, t, 17) for t in range(n)]
+    aus = []
+    for t in range(n + owf + 1):
+        out = ge.encode(frames[t] if t < n else None, want_recon=False)      # (None: pic_in == NULL hands out a picture still in flight)
+        if out[0]:
+            aus.append(out[0])
+    assert len(aus) == n, len(aus)
+    got = []
+    for t in range(n):
+        want = oe.encode(frames[t])
+        assert aus[t] == want, (t, len(aus[t]), len(want))
+        ref = od.decode_au(aus[t], t)
+        assert len(ref) == 1 and np.array_equal(ref[0]["i420"], oe.recon()), t
+        got += gd.decode_au(aus[t], t)
+    got += gd.drain()
+    assert len(got) == n
+    for x in (ge, gd, oe, od):
+        x.close()
+
+
+@pytest.mark.gpu
 def test_pipelined_encoder_with_sao_on_device_path_matches_oracle(gpu):
     """owf = 3 with sao = full at 1080p, pictures handed over in HBM back to back: k_sao of picture t reads the source picture while
     the input stage already prepares picture t + 2 -- the access units must still be the checker's (synchronous) ones"""

@@ -42,9 +42,16 @@ for q, rs in sorted(byq.items(), key=lambda kv: -len(kv[1])):
     print("queue %s: %d kernels, busy %.1f %% of the window" % (q, len(rs), 100.0 * busy / (t1 - t0)))
     for n, a in sorted(st.items(), key=lambda kv: -kv[1][1]):
         print("   %-36s n %5d  avg %8.1f us  gap in front %7.1f us" % (n, a[0], a[1] / a[0] / 1e3, a[2] / max(1, a[3]) / 1e3))
-# a 1 ms excerpt from the last quarter of the window as a timeline (all queues and the copies)
+# a 1 ms excerpt from the last quarter of the window as a timeline (all queues and the copies) -- or, CHAIN_GAPS_AT_IDR=1, from 0.4 ms before the window's second intra picture's chain
+import os
 mid = t0 + (t1 - t0) * 3 // 4
+if os.environ.get("CHAIN_GAPS_AT_IDR"):
+    idr = [r for r in rows if r[2].startswith("k_intra_recon<false, false")]
+    if len(idr) > 1: mid = idr[1][0] - 400_000
+    span = 2_400_000
+else:
+    span = 1_000_000
 print("--- timeline excerpt (us from its start; queue)")
 for s, e, n, q in sorted(rows + [c for c in copies if t0 <= c[0] <= t1]):
-    if mid <= s < mid + 1_000_000: print("%8.1f .. %8.1f  q%-5s %s" % ((s - mid) / 1e3, (e - mid) / 1e3, q, n))
+    if mid <= s < mid + span: print("%8.1f .. %8.1f  q%-5s %s" % ((s - mid) / 1e3, (e - mid) / 1e3, q, n))
 PY

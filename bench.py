@@ -14,6 +14,7 @@ What the one JSON line carries besides `value` (every leg can be switched off):
                    batched launches (csrc/batch.h)
   secondary        the 4K workload (BASELINE configs[2], the north-star target), with its own host_boundary
   default_mode     uvgComm's own default settings for the size (preset veryfast, 1 Mbit/s)
+  all_intra        every picture an IDR (BASELINE configs[0] on the GPU path): the intra chains' rate
   roofline         the dominant kernel against the HBM peak (+ every kernel's fraction), cpu_baseline: oracle/ on all host cores
 
 --gpus N (N > 1) without a torch.distributed environment: this process launches N fresh rank processes (before anything
@@ -148,6 +149,18 @@ def default_mode_leg(args, ranks, rank, world, wl):
             "psnr_y": pm["psnr_y"], "host_cpu_cores_busy": round(pm["host_cores"], 2), "kernels_us": roofline_of(pm, steps, args.me_range, args.workload)[1]}
 
 
+def all_intra_leg(args, ranks, rank, world, wl):
+    """BASELINE configs[0] on the GPU path: every picture an IDR (video/Intra = 1) -- the intra chains' own rate (k_intra_analyse, k_intra_recon, k_dec_intra per picture)"""
+    steps = 2
+    try:
+        m = run_stream(args, wl, steps, 1, ranks, rank, world, quality=True, extra_custom=RESIDENT, extra_settings={"video/Intra": 1})
+    except Exception as e:                           # noqa: BLE001
+        return {"error": str(e)}
+    kt = {k: round(v[0] / v[1] * 1e3, 2) for k, v in m["kt"].items() if v[1]}
+    return {"settings": {"video/Intra": 1}, "value": round(m["pictures"] / m["elapsed"], 3), "unit": "frames/s", "pictures": m["pictures"], "runs_fps": m["runs_fps"],
+            "bits_per_picture": round(8 * m["bytes_per_picture"], 1), "psnr_y": m["psnr_y"], "host_cpu_cores_busy": round(m["host_cores"], 2), "kernels_us": kt}
+
+
 def valu_roofline(args, m):
     """The motion search is integer VALU work, not streaming: its own ceiling is the issue rate of v_qsad_pk_u16_u8 (four 4-sample SADs per lane;
     measured ~24 cycles per wave instruction on gfx950, tools/qsad_bench.hip -> profiles/r02_qsad_bench.txt): 1024 SIMDs x 2.4 GHz / 24 x 64 lanes
@@ -201,6 +214,7 @@ def main():
                 multi.append({"streams": k, "error": str(e)})
     sec = secondary_leg(args, ranks, rank, world) if headline_1080p else None
     preset_line = default_mode_leg(args, ranks, rank, world, wl) if headline_1080p and not args.no_preset_line else None
+    intra_line = all_intra_leg(args, ranks, rank, world, wl) if headline_1080p and not args.no_preset_line else None
 
     if rank == 0:
         roof, kernels_us, share = roofline_of(m, args.steps, args.me_range, args.workload)
@@ -227,6 +241,7 @@ def main():
             "host_boundary": hostb,
             "streams_per_gpu": multi,
             "default_mode": preset_line,
+            "all_intra": intra_line,
             "device": device_info,
             "roofline": roof,
             "kernels_us": kernels_us,

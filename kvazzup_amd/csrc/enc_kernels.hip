@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
 // Returns whether the block has non-zero levels.
 template <int L2, bool ADJ>
 __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratch &ws, const IntraBlk &d, int cidx, int S, const QuantConst &q,
-                                                 uint8_t *gdst, int gp, int lane, uint32_t *publish, int adj = 0, uint8_t *ecol = nullptr, const uint8_t *mtab = nullptr)
+                                                 uint8_t *gdst, int gp, int lane, uint32_t *publish, int adj = 0, uint32_t *ecol = nullptr, const uint8_t *mtab = nullptr, uint32_t gen = 0)
 {
   constexpr int N = 1 << L2;
   const int P = 16 + 2 * S, g = lane >> 4, c = lane & 15, rx = d.rx, ry = d.ry;
@@ -1080,7 +1080,7 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
     // write-through, and only what a neighbouring CTU's workgroup will read -- the CTU's LAST ROW (IB_EDGE: the block ends on it) and, below, its last
     // column --: the rest of the CTU goes out in full lines at the end
     if ((d.flags & IB_EDGE) && c == N - 1) st_wt_u32(gdst + (size_t)(ry + c) * gp + rx + 4 * g, o);
-    if ((d.flags & IB_EDGE_R) && g == (N >> 2) - 1) st_wt_u8(ecol + ry + c, o >> 24);      // the block's last column, one byte per row
+    if ((d.flags & IB_EDGE_R) && g == (N >> 2) - 1) st_wt_u32(ecol + ry + c, (o >> 24) | (gen << 8));      // the block's last column, a self-validating word per row (sample | generation): nobody waits for these stores
   }
   wave_sync();
   PROF(9);
@@ -1155,8 +1155,8 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   nb.nb_up = row > 0 && !tile_row_starts_at(hc, f.tile_rows, row); nb.nb_left = cx > 0 && !tile_col_starts_at(wc, f.tile_cols, cx);
   nb.nb_ur = nb.nb_up && cx + 1 < wc && !tile_col_starts_at(wc, f.tile_cols, cx + 1); nb.nb_ul = nb.nb_up && nb.nb_left;
   nb.pl = my - 3; nb.pu = my - 3 * wc; nb.pur = nb.pu + 3; nb.pul = nb.pu - 3;
-  uint8_t *const ecol = f.edge_col[c] + (size_t)ctu * S;       // this CTU's right column for its right neighbour (IB_EDGE_R)
-  nb.ecol_left = ecol - S;
+  uint32_t *const ecol = f.edge_col[c] + (size_t)ctu * S;      // this CTU's right column for its right neighbour (IB_EDGE_R)
+  nb.ecol_left = ecol - S; nb.gen = f.chain_gen;
   if (PP) {
     // which of the neighbours' edge units are intra units (kernel_common.h IntraBorders: the inter units around are final, nothing to wait for
     // there) -- lanes 0-7: the left CTU's right column, 8-15 / 16-23: the bottom rows of the upper / upper-right CTU, 24: the corner
@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
       d.angle = (int16_t)kIntraAngle[mode]; d.inv = (int16_t)kInvAngle[mode];
       d.zu = (uint16_t)lane; d.next = (uint16_t)(lane + su * su);
       blk[k] = d;
-      dep[k] = chain_dependencies(zx, zy, su);
+      dep[k] = chain_dependencies(zx, zy, su, ((intra_uses_below_left(l2 - sh, c ? 1 : 0) >> mode) & 1) != 0, ((intra_uses_above_right(l2 - sh, c ? 1 : 0) >> mode) & 1) != 0);
       cover[k] = chain_cover(lane, su);
     }
     if (lane == 0) nblk_s = (uint32_t)__popcll(starts);
@@ -1241,9 +1241,9 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     first = false;
     bool cbf;
     switch (d.l2) {
-      case 2: cbf = intra_block_wave<2, ADJ>(s, ws, d, c, S, q8, grec, pw, lane, nullptr, adj, ecol, SCAL ? f.scaling + scaling_offset(2, c, 0) : nullptr); break;
-      case 3: cbf = intra_block_wave<3, ADJ>(s, ws, d, c, S, c ? q16 : q8, grec, pw, lane, nullptr, adj, ecol, SCAL ? f.scaling + scaling_offset(3, c, 0) : nullptr); break;
-      default: cbf = intra_block_wave<4, ADJ>(s, ws, d, c, S, q16, grec, pw, lane, nullptr, adj, ecol, SCAL ? f.scaling + scaling_offset(4, c, 0) : nullptr); break;
+      case 2: cbf = intra_block_wave<2, ADJ>(s, ws, d, c, S, q8, grec, pw, lane, nullptr, adj, ecol, SCAL ? f.scaling + scaling_offset(2, c, 0) : nullptr, f.chain_gen); break;
+      case 3: cbf = intra_block_wave<3, ADJ>(s, ws, d, c, S, c ? q16 : q8, grec, pw, lane, nullptr, adj, ecol, SCAL ? f.scaling + scaling_offset(3, c, 0) : nullptr, f.chain_gen); break;
+      default: cbf = intra_block_wave<4, ADJ>(s, ws, d, c, S, q16, grec, pw, lane, nullptr, adj, ecol, SCAL ? f.scaling + scaling_offset(4, c, 0) : nullptr, f.chain_gen); break;
     }
     const uint2 cvu = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)cv.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)cv.y));
     chain_mark_done(ch, cvu, lane);
@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
 #ifndef KVZ_PROF
     if (f.trace && c == 0 && lane == 0 && k < 16) f.trace[(size_t)wc * (f.ch >> 6) * 56 + (size_t)ctu * 16 + k] = wall_clock64() | ((unsigned long long)d.l2 << 60);      // (tools/intra_timeline.py: when the luma blocks of the CTU were done)
 #endif
-    if (d.flags & (IB_EDGE | IB_EDGE_R)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (d.flags & IB_EDGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the bottom row's write-through stores, which the CTUs below read from the picture behind the progress value; the right column's tagged words need no wait)
     chain_ack_publish(ch, cvu, my, lane, f.trace ? f.trace + ((size_t)ctu * 3 + c) * 8 : nullptr);
     PROF(10);                                               // mark / acknowledge / publish
 #ifdef KVZ_PROF

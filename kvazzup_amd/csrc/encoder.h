@@ -164,6 +164,7 @@ class Encoder {
   bool stage_roi(hipStream_t st);  // the picture's ROI deltas -> ctu_roi_[set_] on `st`; roi_dev_ = that array or NULL (no map)
   const int8_t *roi_dev_ = nullptr;
   int *vaq_act_ = nullptr, *vaq_sum_ = nullptr; // VAQ: activity of every CTU, its sum over the picture
+  uint32_t next_chain_gen();
   bool picture_begin(hipStream_t qt_stream);   // launch_picture_begin: the rate control state on the main stream (picture order), the per-CTU targets on the picture's own stream (+ the VAQ kernels)
   int qp_cur_ = 0; int64_t rc_debt_ = 0; uint32_t rc_bytes_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t rc_known_ = 0;   // rate control state (calling thread)
   void rate_control();
@@ -181,7 +182,7 @@ class Encoder {
   hipStream_t stream_idr_ = nullptr; hipEvent_t ev_idr_done_ = nullptr; bool idr_pending_ = false, idr_side_ = false;
   // ... with its own copies of what the P pictures' kernels also use while it runs beside them (round 4: the side chain also with SAO, intra units in P
   // pictures, per-CTU QPs and rate control v2 -- uvgComm's default mode): progress counters + ticket word, the CTUs' edge columns, the SAO work picture
-  uint32_t *sync_idr_ = nullptr; uint8_t *edge_col_idr_ = nullptr; uint8_t *work_idr_[3] = {nullptr, nullptr, nullptr};
+  uint32_t *sync_idr_ = nullptr; uint32_t *edge_col_idr_ = nullptr; uint32_t chain_gen_ = 0; uint8_t *work_idr_[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_signalled_ = nullptr, ev_tok_done_[kSets] = {}; bool tok_pending_[kSets] = {};
   void bind_set(int k);
   uint8_t *intra_scratch_ = nullptr;
@@ -189,7 +190,7 @@ class Encoder {
   uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; int tok_nctu_ = 0;
   size_t tok_dense_cap_ = 0;
   std::vector<std::vector<uint8_t>> band_subs_; uint64_t band_bins_ = 0; bool band_coded_ = false;   // band mode: between phase 2a and 2b
-  uint32_t *sync_ = nullptr; uint32_t *me_cost16_ = nullptr; uint8_t *edge_col_ = nullptr; uint32_t *intra_order_ = nullptr; uint32_t *err_ = nullptr; unsigned long long *trace_ = nullptr;
+  uint32_t *sync_ = nullptr; uint32_t *me_cost16_ = nullptr; uint32_t *edge_col_ = nullptr; uint32_t *intra_order_ = nullptr; uint32_t *err_ = nullptr; unsigned long long *trace_ = nullptr;
   // one slot per picture in flight: the host-visible results of its kernels and what collect() needs to finish it
   struct EvPair { hipEvent_t a, b; KernelId id; };
   struct Slot {

@@ -119,7 +119,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   if (idr_side_) {
     const size_t nsync = (size_t)rows_ * (cw_ / 64) * 3 + 2, nctu_ = (size_t)(cw_ / 64) * rows_;
     HIP_OK(hipMalloc(&sync_idr_, sizeof(uint32_t) * nsync)); HIP_OK(hipMemset(sync_idr_, 0, sizeof(uint32_t) * nsync));
-    HIP_OK(hipMalloc(&edge_col_idr_, nctu_ * 128));
+    HIP_OK(hipMalloc(&edge_col_idr_, nctu_ * 128 * sizeof(uint32_t))); HIP_OK(hipMemset(edge_col_idr_, 0, nctu_ * 128 * sizeof(uint32_t)));
     if (cfg.sao) { const size_t npx_ = (size_t)cw_ * ch_; for (int c = 0; c < 3; c++) HIP_OK(hipMalloc(&work_idr_[c], c ? npx_ / 4 : npx_)); }
     // ... which is the INPUT stream: the pictures behind an intra picture need it anyway, so their input stages lose nothing by queueing behind
     // its chain, and a further stream would share a hardware queue with one that matters (HIP spreads a priority level's streams over four;
@@ -184,7 +184,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     HIP_OK(hipMalloc(&intra_order_, sizeof(uint32_t) * order.size()));
     HIP_OK(hipMemcpy(intra_order_, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice));
   }
-  { const size_t nctu = (size_t)(cw_ / 64) * rows_; HIP_OK(hipMalloc(&edge_col_, nctu * 128)); }      // the CTUs' right columns (k_intra_recon)
+  { const size_t nctu = (size_t)(cw_ / 64) * rows_; HIP_OK(hipMalloc(&edge_col_, nctu * 128 * sizeof(uint32_t))); HIP_OK(hipMemset(edge_col_, 0, nctu * 128 * sizeof(uint32_t))); }      // (tagged words: generation 0 = never written)      // the CTUs' right columns (k_intra_recon)
   HIP_OK(hipMalloc(&err_, sizeof(uint32_t))); HIP_OK(hipMemset(err_, 0, sizeof(uint32_t)));
   if (getenv("KVAZZUP_AMD_INTRA_TRACE")) { HIP_OK(hipMalloc(&trace_, sizeof(unsigned long long) * (rows_ * (cw_ / 64) * 72))); HIP_OK(hipMemset(trace_, 0, sizeof(unsigned long long) * (rows_ * (cw_ / 64) * 72))); }
   int eth = cfg.entropy_threads;
@@ -479,6 +479,19 @@ bool Encoder::stage_roi(hipStream_t st)
   roi_dev_ = ctu_roi_[set_];
   return true;
 }
+// generation of the picture's intra chain launch (the tag of the edge-column words, kernel_common.h IntraNeighbours): 1 .. 2^24 - 1; when the counter
+// wraps, both arrays go back to "never written" on the streams that use them
+uint32_t Encoder::next_chain_gen()
+{
+  if (++chain_gen_ >= (1u << 24)) {
+    const size_t bytes = (size_t)(cw_ / 64) * rows_ * 128 * sizeof(uint32_t);
+    hipMemsetAsync(edge_col_, 0, bytes, stream_);
+    if (edge_col_idr_) hipMemsetAsync(edge_col_idr_, 0, bytes, stream_idr_);
+    chain_gen_ = 1;
+  }
+  return chain_gen_;
+}
+
 bool Encoder::picture_begin(hipStream_t qt_stream)
 {
   const bool have = frame_idx_ >= rc_delay_;
@@ -534,6 +547,7 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   // the stream this picture's chain runs on: an intra picture's own (encoder.h stream_idr_), else the main stream -- behind the last intra picture's chain
   const bool side = intra && idr_side_;
   const hipStream_t ms = side ? stream_idr_ : stream_;
+  f_.chain_gen = next_chain_gen();
   if (side) {                                               // beside the P pictures still on the main stream: nothing of theirs is touched
     const size_t nctu = (size_t)(cw_ / 64) * rows_;
     f_.sync = sync_idr_; f_.me_cand = nullptr;              // (me_cand NULL: the picture's deblocking kernel leaves the P pictures' candidate list and "has intra units" word alone)
@@ -773,6 +787,7 @@ bool Encoder::band_phase1(const uint8_t *d_i420)
   if (!band_picture_setup()) return false;
   roi_sub_ = roi_; roi_sub_w_ = roi_w_; roi_sub_h_ = roi_h_;
   if (!stage_roi(stream_) || !picture_begin(stream_)) return false;
+  f_.chain_gen = next_chain_gen();
   const EncFrame f = f_;
   launch_pad_input(d_i420, cfg_.width, cfg_.height, src_[0][0], src_[0][1], src_[0][2], cw_, ch_, stream_);
   if (band_intra_) {

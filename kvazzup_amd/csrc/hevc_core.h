@@ -74,7 +74,8 @@ struct EncFrame {
   int intra_chain;          // "intra-chain" (default on): blocks on a CTU's left edge / its above-right corner block choose among the modes that do not read the left CTU's below-left / the above-right CTU's samples
   int intra_p;              // "uvgx intra-in-P v1": intra coding units in P pictures (statement: oracle/hevc_enc.c me_block32); me_cost16 = k_me's inter cost of every 16x16 block (0: not searched)
   uint32_t *me_cost16;
-  uint8_t *edge_col[3];     // k_intra_recon: per plane [CTU][S] the CTU's right column of reconstructed samples (kernel_common.h IB_EDGE_R)
+  uint32_t *edge_col[3];    // k_intra_recon: per plane [CTU][S] the CTU's right column of reconstructed samples as self-validating words, sample | chain_gen << 8 (kernel_common.h IB_EDGE_R, IntraNeighbours)
+  uint32_t chain_gen;       // generation of this launch of the intra chain (1 .. 2^24 - 1; the arrays are cleared when it wraps)
   uint32_t *ip_arrive; uint64_t *ip_scratch;      // k_intra_analyse<P>: per listed block the number of its quarters' workgroups that are done (back to zero when the last has arrived) and their best (cost | mode << 32) per block size and position [listed block][20]
   uint32_t *me_cand;        // ... and the 32x32 blocks with a quarter above the gate: [0] their count (k_deblock_tile zeroes it for the next picture), [1 ..] their raster indices
   int rdoq, signhide;       // kvazaar rdoq / signhide: the level-adjustment pass behind the quantiser (adjust_group) and sign_data_hiding_enabled_flag

@@ -297,7 +297,12 @@ struct IntraNeighbours {
   const uint32_t *pl, *pu, *pur, *pul;       // progress counters of the left / upper / upper-right / upper-left CTU (same plane)
   bool nb_left, nb_up, nb_ur, nb_ul;         // which of them exist (inside the picture, same tile)
   uint32_t il = 0xffu, iu = 0xffu, iur = 0xffu, iul = 1u;      // (IntraBorders: the neighbours' edge units that are intra units)
-  const uint8_t *ecol_left = nullptr;        // the left CTU's entry of the edge-column array (IB_EDGE_R), or null: its right column is read from the picture
+  // The left CTU's entry of the edge-column array (IB_EDGE_R), or null: its right column is read from the picture.  Round 4: the entries are SELF-VALIDATING
+  // words, sample | launch generation << 8 -- the right neighbour polls the words themselves until they carry this launch's generation.  The producer
+  // neither waits for these stores nor publishes anything for them, and the consumer's poll IS its load: the horizontal hop of the CTU wavefront loses the
+  // producer's store drain and one memory round trip of the consumer.  (The upper neighbours' bottom rows still travel through the picture + progress counters.)
+  const uint32_t *ecol_left = nullptr;
+  uint32_t gen = 0;
 };
 __device__ __forceinline__ uint32_t lds_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int lds_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -348,7 +353,7 @@ __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNei
     // trips on the wavefront's step.  (The wave_wait_wt calls below then find what they need in the cache.)
     const int nL = imin(S, nl2), limT = imin(lim_w, b.nb_ur ? 2 * S : S), nT = imin(limT, nt2);
     uint32_t want = 0;
-    if (lane == 0 && b.nb_left) want = kv_edge_need(b.il, ((nL - 1) << sh) >> 3, true);
+    (void)nL;                                              // (the left column is polled through its tagged words below)
     if (lane == 1 && b.nb_up) want = kv_edge_need(b.iu, ((imin(S, nT) - 1) << sh) >> 3, false);
     if (lane == 2 && b.nb_up && nT > S) want = kv_edge_need(b.iur, ((nT - S - 1) << sh) >> 3, false);
     if (lane == 3 && b.nb_ul) want = b.iul ? 64u : 0u;
@@ -366,10 +371,7 @@ __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNei
   if (rx == 0 && b.nb_left) {
     const int need = imin(S, ry + nl2);
     haveL = __builtin_amdgcn_readfirstlane(lds_load(&ch.left_loaded));
-    if (need > haveL) {
-      const uint32_t seen = wave_wait_wt(b.pl, kv_edge_need(b.il, ((need - 1) << sh) >> 3, true), &ch.seen_l, err, lane);
-      uptoL = imax(need, imin(S, kv_units_right(seen) * (8 >> sh)));
-    }
+    if (need > haveL) uptoL = need;                         // (no progress counter: the rows' own words say when they are there)
   }
   if (ry == 0 && b.nb_up) {
     const int lim = imin(lim_w, b.nb_ur ? 2 * S : S), need = imin(lim, rx + nt2);
@@ -393,9 +395,21 @@ __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNei
   // ---- the loads, all in flight together (both ends of the row piece are multiples of 4: block sizes, CTU sizes and picture widths are)
   const int iL = haveL + lane, iT = haveT + 4 * lane;
   uint32_t vL = 0, vT = 0, vC = 0;
-  if (iL < uptoL) vL = (b.ecol_left && ((b.il >> ((iL << sh) >> 3)) & 1u)) ? ld_l2_u8(b.ecol_left + iL) : ld_l2_u8(plane + (size_t)(cy * S + iL) * gp + cx * S - 1);
+  // left column: rows of intra units come from the left CTU's tagged edge words (polled until they are this launch's), rows of a P picture's inter units
+  // from the picture, which is final
+  const bool rowL = iL < uptoL, tagged = rowL && b.ecol_left && ((b.il >> ((iL << sh) >> 3)) & 1u);
+  if (rowL) vL = tagged ? ld_l2_u32(b.ecol_left + iL) : ld_l2_u8(plane + (size_t)(cy * S + iL) * gp + cx * S - 1);
   if (iT < uptoT) vT = ld_l2_u32(plane + (size_t)(cy * S - 1) * gp + cx * S + iT);
   if (doC && lane == 0) vC = ld_l2_u8(plane + (size_t)(cy * S - 1) * gp + cx * S - 1);
+  if (__ballot(tagged) != 0) {
+    uint32_t spins = 0;
+    while (__ballot(tagged && (vL >> 8) != b.gen) != 0) {
+      if (++spins < 16) __builtin_amdgcn_s_sleep(1); else if (spins < 64) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
+      if (spins > (1u << 21)) { if (lane == 0) atomicOr(err, 1u); break; }           // bounded spin: never hang the GPU
+      if (tagged && (vL >> 8) != b.gen) vL = ld_l2_u32(b.ecol_left + iL);
+    }
+    vL &= 255u;
+  }
   if (iL < uptoL) pic[(iL + 1) * lp + 15] = (uint8_t)vL;
   if (iT < uptoT) *(uint32_t *)&pic[16 + iT] = vT;
   if (doC && lane == 0) pic[15] = (uint8_t)vC;
@@ -410,7 +424,9 @@ __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNei
 // 8x8 luma units (bits in z-order) the block with its first unit at (ux, uy), su x su units, reads reference samples from inside its
 // own CTU: the units left, below-left, above, above-right and above-left of it that precede it in z-order (inside a CTU:
 // precedes = available)
-__device__ __forceinline__ uint2 chain_dependencies(int ux, int uy, int su)
+// bl / tr: whether the block's MODE reads its below-left / above-right samples (hevc_core.h intra_uses_*): a unit nothing is read from is not waited for --
+// e.g. the third 16x16 block of a CTU's top row then only waits for the second, not for the two blocks of the row below that precede it in z-order
+__device__ __forceinline__ uint2 chain_dependencies(int ux, int uy, int su, bool bl = true, bool tr = true)
 {
   const int z0 = kv_zunit8(ux, uy);
   uint32_t m0 = 0, m1 = 0;
@@ -420,7 +436,8 @@ __device__ __forceinline__ uint2 chain_dependencies(int ux, int uy, int su)
     if (z >= z0) return;
     if (z < 32) m0 |= 1u << z; else m1 |= 1u << (z - 32);
   };
-  for (int i = -1; i < 2 * su; i++) { add(ux - 1, uy + i); add(ux + i, uy - 1); }
+  for (int i = -1; i < (bl ? 2 * su : su); i++) add(ux - 1, uy + i);
+  for (int i = -1; i < (tr ? 2 * su : su); i++) add(ux + i, uy - 1);
   return make_uint2(m0, m1);
 }
 __device__ __forceinline__ uint2 chain_cover(int z0, int su)     // the su x su units starting at z0: a contiguous run in z-order

@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
 // Returns whether the block has non-zero levels.
 template <int L2, bool ADJ>
 __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratch &ws, const IntraBlk &d, int cidx, int S, const QuantConst &q,
-                                                 uint8_t *gdst, int gp, int lane, uint32_t *publish, int adj = 0, uint32_t *ecol = nullptr, const uint8_t *mtab = nullptr, uint32_t gen = 0)
+                                                 int lane, int adj, uint32_t *ecol, unsigned long long *erow, uint32_t gen, const uint8_t *mtab = nullptr)
 {
   constexpr int N = 1 << L2;
   const int P = 16 + 2 * S, g = lane >> 4, c = lane & 15, rx = d.rx, ry = d.ry;
@@ -1070,17 +1070,13 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
     for (int r = 0; r < 4; r++) pred[r] = clip8(pred[r] + res[r]);
   }
   PROF(8);
-  // A progress value that is due before this block (d.zu: everything in front of it is final) is published HERE: the write-through
-  // stores of the blocks in front have had this block's whole computation to be acknowledged, so the wait costs nothing, where
-  // publishing ahead of the block would stall the chain for a memory round trip (kernel_common.h, fence-free hand-off).
-  if (publish) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) __hip_atomic_store(publish, (uint32_t)d.zu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   if (active) {
     const uint32_t o = (uint32_t)pred[0] | ((uint32_t)pred[1] << 8) | ((uint32_t)pred[2] << 16) | ((uint32_t)pred[3] << 24);
     *(uint32_t *)&s.pic[(ry + c + 1) * P + 16 + rx + 4 * g] = o;
-    // write-through, and only what a neighbouring CTU's workgroup will read -- the CTU's LAST ROW (IB_EDGE: the block ends on it) and, below, its last
-    // column --: the rest of the CTU goes out in full lines at the end
-    if ((d.flags & IB_EDGE) && c == N - 1) st_wt_u32(gdst + (size_t)(ry + c) * gp + rx + 4 * g, o);
-    if ((d.flags & IB_EDGE_R) && g == (N >> 2) - 1) st_wt_u32(ecol + ry + c, (o >> 24) | (gen << 8));      // the block's last column, a self-validating word per row (sample | generation): nobody waits for these stores
+    // what a neighbouring CTU's workgroup will read -- the CTU's last row (IB_EDGE) and last column (IB_EDGE_R) -- leaves at once, as self-validating
+    // words nobody waits for (kernel_common.h IntraNeighbours); the CTU itself goes to the picture in full lines at the end
+    if ((d.flags & IB_EDGE) && c == N - 1) st_wt_u64(erow + ((rx + 4 * g) >> 2), (unsigned long long)o | ((unsigned long long)gen << 32));      // the block's last row, four samples and the generation per word
+    if ((d.flags & IB_EDGE_R) && g == (N >> 2) - 1) st_wt_u32(ecol + ry + c, (o >> 24) | (gen << 8));      // the block's last column, one sample and the generation per word
   }
   wave_sync();
   PROF(9);
@@ -1089,17 +1085,17 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
 
 // One workgroup of KVZ_INTRA_WAVES waves per (CTU, colour plane).  The CTU's coding units form a list in z-order; a wave takes the
 // next one, waits until the 8x8 units its reference samples lie in are final (kernel_common.h IntraChain: independent quadrants
-// run side by side), reconstructs it and marks its units.  CTUs are coupled by progress counters that count the CTU's leading
-// run of finished 8x8 luma units (f.sync: [CTU][plane]), published at the values neighbours wait for.  A block waits only for the
-// part of the left / upper / upper-right CTU it reads -- with coding units of at most 16x16 a CTU starts when half of its left
-// neighbour is done, not when it is complete -- and the neighbours' samples are copied into the CTU picture's borders piecewise, as
-// far as their progress allows.  (The decoder's k_dec_intra is the same scheme driven by the transform-block list.)
+// run side by side), reconstructs it and marks its units.  CTUs are coupled by the samples themselves: a CTU's right column and bottom
+// row leave as tagged words (f.edge_col / f.edge_row, kernel_common.h IntraNeighbours) the moment the block that holds them is done, and a
+// block of the neighbouring CTU polls exactly the words its MODE reads -- a CTU starts when the two or three blocks of its left and upper
+// neighbours its first block reads are done, not when a counted prefix of them is.  (Rounds 2-3 published progress counters per CTU; the
+// decoder's k_dec_intra still does, driven by the transform-block list.)
 #ifndef KVZ_INTRA_WAVES
 #define KVZ_INTRA_WAVES 8          // (measured at 1080p: 2 waves 1.58 ms, 4: 1.41, 8: 1.36 -- a wave that has just finished a block spends a microsecond on its bookkeeping before it can take the next)
 #endif
 // ADJ: rdoq / signhide -- a kernel of its own, so that the plain chain (every step of it is on the critical path) stays as it was.
-// PP: the intra units of a P picture (intra-in-P), launched behind k_inter_recon: a CTU without intra units (nearly all) publishes 64
-// and leaves; in the others the inter units count as finished from the start, the CTU picture in LDS starts as the inter
+// PP: the intra units of a P picture (intra-in-P), launched behind k_inter_recon: a CTU without intra units (nearly all) leaves at
+// once; in the others the inter units count as finished from the start, the CTU picture in LDS starts as the inter
 // reconstruction left it, and only the intra units' levels and cbf bits are written.
 // SCAL: `scaling-list default` -- a form of its own for the same reason as ADJ (the per-position factors cost the plain chain 30 registers when they are a run-time branch)
 template <bool ADJ, bool PP, bool SCAL = false>
@@ -1142,21 +1138,21 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
 #endif
   const int adj = (f.rdoq ? 1 : 0) | (f.signhide ? 2 : 0);      // level adjustment behind the quantiser (hevc_core.h adjust_group)
   const int sh = c ? 1 : 0, S = 64 >> sh, pw = f.cw >> sh, P = 16 + 2 * S;
-  uint32_t *my = f.sync + (size_t)ctu * 3 + c;
   uint64_t im = ~0ull;                                      // the CTU's 8x8 units (z-order) that belong to intra coding units
   if (PP) {
     int zx, zy; ctu_z_to_xy(lane, zx, zy);
     im = __ballot(f.cu_intra[b8idx(f, cx * 64 + zx * 8, row * 64 + zy * 8)] != 0);      // (every wave for itself: no barrier in front of the exit)
-    if (!im) { if (tid == 0) __hip_atomic_store(my, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
+    if (!im) continue;                                      // (its samples are k_inter_recon's and final: the neighbours read them from the picture)
   }
   const int qpl = ctu_quant_qp(f, cx * 64, row * 64), qp = c ? kChromaQp[qpl] : qpl;
   const int hc = f.ch >> 6;
   IntraNeighbours nb;
   nb.nb_up = row > 0 && !tile_row_starts_at(hc, f.tile_rows, row); nb.nb_left = cx > 0 && !tile_col_starts_at(wc, f.tile_cols, cx);
   nb.nb_ur = nb.nb_up && cx + 1 < wc && !tile_col_starts_at(wc, f.tile_cols, cx + 1); nb.nb_ul = nb.nb_up && nb.nb_left;
-  nb.pl = my - 3; nb.pu = my - 3 * wc; nb.pur = nb.pu + 3; nb.pul = nb.pu - 3;
   uint32_t *const ecol = f.edge_col[c] + (size_t)ctu * S;      // this CTU's right column for its right neighbour (IB_EDGE_R)
   nb.ecol_left = ecol - S; nb.gen = f.chain_gen;
+  unsigned long long *const erow = f.edge_row[c] + (size_t)ctu * (S >> 2);     // this CTU's bottom row for the CTUs below (IB_EDGE)
+  nb.erow_up = erow - (size_t)wc * (S >> 2); nb.erow_ur = nb.erow_up + (S >> 2); nb.erow_ul = nb.erow_up - (S >> 2);
   if (PP) {
     // which of the neighbours' edge units are intra units (kernel_common.h IntraBorders: the inter units around are final, nothing to wait for
     // there) -- lanes 0-7: the left CTU's right column, 8-15 / 16-23: the bottom rows of the upper / upper-right CTU, 24: the corner
@@ -1169,12 +1165,7 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     const uint64_t m = __ballot(X >= 0 && f.cu_intra[b8idx(f, X < 0 ? 0 : X, Y < 0 ? 0 : Y)] != 0);
     nb.il = (uint32_t)m & 0xffu; nb.iu = (uint32_t)(m >> 8) & 0xffu; nb.iur = (uint32_t)(m >> 16) & 0xffu; nb.iul = (uint32_t)(m >> 24) & 1u;
   }
-  chain_init(ch, nb, (uint32_t)~im, (uint32_t)(~im >> 32));
-  if (PP && tid == 0) {                                     // the leading run of inter units is progress the neighbours may see at once
-    const int prefix = __builtin_ctzll(im);
-    const uint32_t m = prefix >= 60 ? 60u : (prefix >= 56 ? 56u : (prefix >= 48 ? 48u : (prefix >= 44 ? 44u : (prefix >= 32 ? 32u : (prefix >= 24 ? 24u : 0u)))));
-    if (m) { ch.published = m; __hip_atomic_store(my, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  }
+  chain_init(ch, (uint32_t)~im, (uint32_t)(~im >> 32));
   // ---- everything the chain needs to know about the CTU's coding units, one lane per 8x8 unit (z-order), compacted into a list
   if (wave == 0) {
     int zx, zy; ctu_z_to_xy(lane, zx, zy);
@@ -1226,9 +1217,9 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     PROF(1);                                                // claim
     const IntraBlk d = wave_uniform(&blk[k]);              // (wave-uniform: what is derived from it runs on the scalar unit)
     const uint2 dp = dep[k], cv = cover[k];
-    chain_wait_done(ch, make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)dp.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)dp.y)), f.err, lane);
-    // the neighbouring CTUs' samples this block reads: wait for them, copy them into the borders of the CTU picture
-    PROF(2);                                                // waiting for the units this block reads
+    // The neighbouring CTUs' samples this block reads come FIRST: they do not depend on this CTU's own blocks, so the memory round trip that fetches them
+    // (and the poll, when the neighbour is not there yet) runs while the blocks in front of this one are still being coded, instead of behind them on the
+    // chain's critical path -- three of the four blocks of a CTU's top row paid it there.
     if (d.flags & IB_BORDER) {
       // the neighbouring CTUs are waited for only as far as the block's MODE reads them (hevc_core.h intra_uses_*): with "intra-chain" the left-edge blocks never
       // read the left CTU's below-left samples and the above-right CTU is not read at all
@@ -1236,28 +1227,23 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
       const int nl2 = ((intra_uses_below_left(d.l2, c) >> d.mode) & 1) ? 2 * n : n, nt2 = ((intra_uses_above_right(d.l2, c) >> d.mode) & 1) ? 2 * n : n;
       borders_need_wave(ch, nb, s.pic, P, plane, pw, cx, row, S, sh, 2 * S, d.rx, d.ry, n, f.err, lane, nl2, nt2);
     }
-    PROF(3);                                                // neighbouring CTUs: waits and copies
+    PROF(2);                                                // neighbouring CTUs: waits and copies
+    chain_wait_done(ch, make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)dp.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)dp.y)), f.err, lane);
+    PROF(3);                                                // waiting for the units of this CTU the block reads
     if (f.trace && first && k == 0 && lane == 0) f.trace[((size_t)ctu * 3 + c) * 8 + 1] = wall_clock64();
     first = false;
     bool cbf;
     switch (d.l2) {
-      case 2: cbf = intra_block_wave<2, ADJ>(s, ws, d, c, S, q8, grec, pw, lane, nullptr, adj, ecol, SCAL ? f.scaling + scaling_offset(2, c, 0) : nullptr, f.chain_gen); break;
-      case 3: cbf = intra_block_wave<3, ADJ>(s, ws, d, c, S, c ? q16 : q8, grec, pw, lane, nullptr, adj, ecol, SCAL ? f.scaling + scaling_offset(3, c, 0) : nullptr, f.chain_gen); break;
-      default: cbf = intra_block_wave<4, ADJ>(s, ws, d, c, S, q16, grec, pw, lane, nullptr, adj, ecol, SCAL ? f.scaling + scaling_offset(4, c, 0) : nullptr, f.chain_gen); break;
+      case 2: cbf = intra_block_wave<2, ADJ>(s, ws, d, c, S, q8, lane, adj, ecol, erow, f.chain_gen, SCAL ? f.scaling + scaling_offset(2, c, 0) : nullptr); break;
+      case 3: cbf = intra_block_wave<3, ADJ>(s, ws, d, c, S, c ? q16 : q8, lane, adj, ecol, erow, f.chain_gen, SCAL ? f.scaling + scaling_offset(3, c, 0) : nullptr); break;
+      default: cbf = intra_block_wave<4, ADJ>(s, ws, d, c, S, q16, lane, adj, ecol, erow, f.chain_gen, SCAL ? f.scaling + scaling_offset(4, c, 0) : nullptr); break;
     }
     const uint2 cvu = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)cv.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)cv.y));
     chain_mark_done(ch, cvu, lane);
-    // Acknowledge at once: a block that stored nothing (not on the CTU's edge) is final as it stands; one that did waits for its stores here.  The wait
-    // is this wave's alone -- the next block of the chain is another wave's, which goes on as soon as the units are marked -- and the neighbouring CTU gets
-    // the progress value when it is true, not one block later.  (The one-wave form of round 2 deferred the acknowledgement behind the wave's NEXT block to
-    // hide the store latency; with four waves that block may be one the wave has to wait for, and the neighbour waited with it: publish(24) came 19 us
-    // after the CTU's first block where its six blocks take 12.)
 #ifndef KVZ_PROF
     if (f.trace && c == 0 && lane == 0 && k < 16) f.trace[(size_t)wc * (f.ch >> 6) * 56 + (size_t)ctu * 16 + k] = wall_clock64() | ((unsigned long long)d.l2 << 60);      // (tools/intra_timeline.py: when the luma blocks of the CTU were done)
 #endif
-    if (d.flags & IB_EDGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the bottom row's write-through stores, which the CTUs below read from the picture behind the progress value; the right column's tagged words need no wait)
-    chain_ack_publish(ch, cvu, my, lane, f.trace ? f.trace + ((size_t)ctu * 3 + c) * 8 : nullptr);
-    PROF(10);                                               // mark / acknowledge / publish
+    PROF(10);                                               // mark
 #ifdef KVZ_PROF
     if (threadIdx.x == 0) g_prof[14] += 1;                   // blocks wave 0 did
 #endif
@@ -1277,7 +1263,6 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     const int bi = b8idx(f, cx * 64 + zx * 8, row * 64 + zy * 8);
     atomicOr((uint32_t *)(f.cu_cbf + (bi & ~3)), (1u << c) << (8 * (bi & 3)));   // the three planes own one bit each of the byte
   }
-  if (tid == 0) __hip_atomic_fetch_max(my, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (every wave has drained its stores: the barrier above)
   if (f.trace && tid == 0) { unsigned long long *t = f.trace + ((size_t)ctu * 3 + c) * 8; t[2] = wall_clock64(); t[7] = (unsigned long long)nblk; }
 #ifdef KVZ_PROF
   if (f.trace && tid == 0 && c == 0) for (int k = 0; k < 16; k++) f.trace[(size_t)wc * (f.ch >> 6) * 24 + (size_t)ctu * 16 + k] = (unsigned long long)g_prof[k];

@@ -182,7 +182,7 @@ class Encoder {
   hipStream_t stream_idr_ = nullptr; hipEvent_t ev_idr_done_ = nullptr; bool idr_pending_ = false, idr_side_ = false;
   // ... with its own copies of what the P pictures' kernels also use while it runs beside them (round 4: the side chain also with SAO, intra units in P
   // pictures, per-CTU QPs and rate control v2 -- uvgComm's default mode): progress counters + ticket word, the CTUs' edge columns, the SAO work picture
-  uint32_t *sync_idr_ = nullptr; uint32_t *edge_col_idr_ = nullptr; uint32_t chain_gen_ = 0; uint8_t *work_idr_[3] = {nullptr, nullptr, nullptr};
+  uint32_t *sync_idr_ = nullptr; uint32_t *edge_col_idr_ = nullptr; uint32_t chain_gen_ = 0; unsigned long long *edge_row_ = nullptr, *edge_row_idr_ = nullptr; uint8_t *work_idr_[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_signalled_ = nullptr, ev_tok_done_[kSets] = {}; bool tok_pending_[kSets] = {};
   void bind_set(int k);
   uint8_t *intra_scratch_ = nullptr;

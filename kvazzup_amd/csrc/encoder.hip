@@ -120,6 +120,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     const size_t nsync = (size_t)rows_ * (cw_ / 64) * 3 + 2, nctu_ = (size_t)(cw_ / 64) * rows_;
     HIP_OK(hipMalloc(&sync_idr_, sizeof(uint32_t) * nsync)); HIP_OK(hipMemset(sync_idr_, 0, sizeof(uint32_t) * nsync));
     HIP_OK(hipMalloc(&edge_col_idr_, nctu_ * 128 * sizeof(uint32_t))); HIP_OK(hipMemset(edge_col_idr_, 0, nctu_ * 128 * sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&edge_row_idr_, nctu_ * 32 * 8)); HIP_OK(hipMemset(edge_row_idr_, 0, nctu_ * 32 * 8));
     if (cfg.sao) { const size_t npx_ = (size_t)cw_ * ch_; for (int c = 0; c < 3; c++) HIP_OK(hipMalloc(&work_idr_[c], c ? npx_ / 4 : npx_)); }
     // ... which is the INPUT stream: the pictures behind an intra picture need it anyway, so their input stages lose nothing by queueing behind
     // its chain, and a further stream would share a hardware queue with one that matters (HIP spreads a priority level's streams over four;
@@ -180,11 +181,13 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     // dispatch order of the intra reconstruction's workgroups: the CTUs of the rows this instance codes, by anti-diagonal cx + 2 cy
     const int wc = cw_ / 64, r0 = cfg.band_rows > 0 ? cfg.band_row0 : 0, nr = cfg.band_rows > 0 ? cfg.band_rows : rows_;
     std::vector<uint32_t> order;
-    for (int d = 0; d < wc + 2 * nr; d++) for (int cy = 0; cy < nr; cy++) { const int cx = d - 2 * cy; if (cx >= 0 && cx < wc) order.push_back((uint32_t)((r0 + cy) * wc + cx)); }
+    const int slope = getenv("KVAZZUP_AMD_INTRA_SLOPE") ? atoi(getenv("KVAZZUP_AMD_INTRA_SLOPE")) : 2;
+    for (int d = 0; d < wc + slope * nr; d++) for (int cy = 0; cy < nr; cy++) { const int cx = d - slope * cy; if (cx >= 0 && cx < wc) order.push_back((uint32_t)((r0 + cy) * wc + cx)); }
     HIP_OK(hipMalloc(&intra_order_, sizeof(uint32_t) * order.size()));
     HIP_OK(hipMemcpy(intra_order_, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice));
   }
-  { const size_t nctu = (size_t)(cw_ / 64) * rows_; HIP_OK(hipMalloc(&edge_col_, nctu * 128 * sizeof(uint32_t))); HIP_OK(hipMemset(edge_col_, 0, nctu * 128 * sizeof(uint32_t))); }      // (tagged words: generation 0 = never written)      // the CTUs' right columns (k_intra_recon)
+  { const size_t nctu = (size_t)(cw_ / 64) * rows_; HIP_OK(hipMalloc(&edge_col_, nctu * 128 * sizeof(uint32_t))); HIP_OK(hipMemset(edge_col_, 0, nctu * 128 * sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&edge_row_, nctu * 32 * 8)); HIP_OK(hipMemset(edge_row_, 0, nctu * 32 * 8)); }      // (tagged words: generation 0 = never written)      // the CTUs' right columns (k_intra_recon)
   HIP_OK(hipMalloc(&err_, sizeof(uint32_t))); HIP_OK(hipMemset(err_, 0, sizeof(uint32_t)));
   if (getenv("KVAZZUP_AMD_INTRA_TRACE")) { HIP_OK(hipMalloc(&trace_, sizeof(unsigned long long) * (rows_ * (cw_ / 64) * 72))); HIP_OK(hipMemset(trace_, 0, sizeof(unsigned long long) * (rows_ * (cw_ / 64) * 72))); }
   int eth = cfg.entropy_threads;
@@ -215,7 +218,8 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   f_.im8 = p; p += nb8; f_.im16 = p; p += nb8 / 4; f_.im32 = p;
   f_.tok_buf = tok_buf_; f_.tok_cap = tok_cap_; f_.tok_cursor = (uint32_t *)tok_count_; f_.tok_cursor_next = (uint32_t *)tok_count_ + tok_nctu_; f_.tok_seg = tok_seg_;
   f_.tok_dense_cap = (uint32_t)tok_dense_cap_;
-  { const size_t nctu = (size_t)(cw_ / 64) * rows_; f_.edge_col[0] = edge_col_; f_.edge_col[1] = edge_col_ + nctu * 64; f_.edge_col[2] = edge_col_ + nctu * 96; }
+  { const size_t nctu = (size_t)(cw_ / 64) * rows_; f_.edge_col[0] = edge_col_; f_.edge_col[1] = edge_col_ + nctu * 64; f_.edge_col[2] = edge_col_ + nctu * 96;
+    f_.edge_row[0] = edge_row_; f_.edge_row[1] = edge_row_ + nctu * 16; f_.edge_row[2] = edge_row_ + nctu * 24; }
   f_.sync = sync_; f_.err = err_; f_.trace = trace_; f_.intra_order = intra_order_;
 
   sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp; sp_.tile_rows = cfg.tile_rows; sp_.tile_cols = cfg.tile_cols; sp_.qp_in_cu = cfg.qp_in_cu; sp_.sao = cfg.sao; sp_.slices = cfg.slices; sp_.signhide = cfg.signhide; sp_.scaling_list = cfg.scaling_list;
@@ -277,7 +281,7 @@ Encoder::~Encoder()
   for (int k = 0; k < kSets; k++) { hipFree(ctu_qt_[k]); hipFree(ctu_qy_[k]); hipFree(ctu_delta_[k]); hipFree(ctu_first_[k]); if (h_ctu_qt_[k]) hipHostFree(h_ctu_qt_[k]); hipFree(ctu_roi_[k]); }
   for (int k = 0; k < kSets; k++) { hipFree(cu_bytes_[k]); hipFree(cu_mv_[k]); hipFree(cu_mvd_[k]); if (ev_tok_done_[k]) hipEventDestroy(ev_tok_done_[k]); }
   for (int c = 0; c < 3; c++) { hipFree(work_[c]); hipFree(work_idr_[c]); }
-  hipFree(sync_idr_); hipFree(edge_col_idr_);
+  hipFree(sync_idr_); hipFree(edge_col_idr_); hipFree(edge_row_); hipFree(edge_row_idr_);
   for (int k = 0; k < kSets; k++) hipFree(sao_[k]);
   if (ev_sao_) hipEventDestroy(ev_sao_);
   if (ev_signalled_) hipEventDestroy(ev_signalled_);
@@ -485,8 +489,8 @@ uint32_t Encoder::next_chain_gen()
 {
   if (++chain_gen_ >= (1u << 24)) {
     const size_t bytes = (size_t)(cw_ / 64) * rows_ * 128 * sizeof(uint32_t);
-    hipMemsetAsync(edge_col_, 0, bytes, stream_);
-    if (edge_col_idr_) hipMemsetAsync(edge_col_idr_, 0, bytes, stream_idr_);
+    hipMemsetAsync(edge_col_, 0, bytes, stream_); hipMemsetAsync(edge_row_, 0, bytes / 2, stream_);
+    if (edge_col_idr_) { hipMemsetAsync(edge_col_idr_, 0, bytes, stream_idr_); hipMemsetAsync(edge_row_idr_, 0, bytes / 2, stream_idr_); }
     chain_gen_ = 1;
   }
   return chain_gen_;
@@ -552,6 +556,7 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     const size_t nctu = (size_t)(cw_ / 64) * rows_;
     f_.sync = sync_idr_; f_.me_cand = nullptr;              // (me_cand NULL: the picture's deblocking kernel leaves the P pictures' candidate list and "has intra units" word alone)
     f_.edge_col[0] = edge_col_idr_; f_.edge_col[1] = edge_col_idr_ + nctu * 64; f_.edge_col[2] = edge_col_idr_ + nctu * 96;
+    f_.edge_row[0] = edge_row_idr_; f_.edge_row[1] = edge_row_idr_ + nctu * 16; f_.edge_row[2] = edge_row_idr_ + nctu * 24;
     if (cfg_.sao) for (int c = 0; c < 3; c++) f_.rec[c] = work_idr_[c];
   }
   const EncFrame f = f_;
@@ -559,6 +564,7 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     const size_t nctu = (size_t)(cw_ / 64) * rows_;
     f_.sync = sync_; f_.me_cand = me_cost16_ ? me_cost16_ + (size_t)(cw_ / 16) * (ch_ / 16) : nullptr;
     f_.edge_col[0] = edge_col_; f_.edge_col[1] = edge_col_ + nctu * 64; f_.edge_col[2] = edge_col_ + nctu * 96;
+    f_.edge_row[0] = edge_row_; f_.edge_row[1] = edge_row_ + nctu * 16; f_.edge_row[2] = edge_row_ + nctu * 24;
   }
   if (!side && idr_pending_) { HIP_CHECK(hipStreamWaitEvent(stream_, ev_idr_done_, 0)); idr_pending_ = false; }
   if (src_busy_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_src_free_[set_], 0)); src_busy_[set_] = false; }   // the last picture that used this set (t - kSets) has been reconstructed

@@ -282,59 +282,34 @@ __device__ __forceinline__ void wave_sync()
 // blocks its reference samples lie in; in z-order that leaves independent chains -- the quadrant right of a finished quadrant
 // and the one below it, at every level -- so a CTU of sixty-four 8x8 blocks has a critical path of 36 blocks, not 64.  Waves take
 // blocks from the list in order (so whatever a wave waits for has been taken by another wave), wait on a mask of finished 8x8
-// units in LDS, and keep a second mask of units whose write-through stores have been acknowledged: its leading run of ones is
-// the progress the neighbouring CTUs may see.
+// units in LDS.  What the NEIGHBOURING CTUs read -- the CTU's right column and bottom row -- leaves as self-validating words
+// (IntraNeighbours), so there is no progress counter, no acknowledgement of stores and nothing to publish (rounds 2 and 3 had all three).
 // ---------------------------------------------------------------------------------------------
 struct IntraChain {
   uint32_t done[2];            // bit z: the 8x8 luma unit z (z-order) is final in the CTU picture in LDS
-  uint32_t acked[2];           // ... and in the picture in memory (the storing wave has drained its stores)
   uint32_t claim;              // next list entry to be handed to a wave
-  uint32_t published;          // last progress value given to the neighbouring CTUs
   int left_loaded, top_loaded, corner_loaded;       // how much of the borders has been copied into the CTU picture
-  uint32_t seen_l, seen_u, seen_ur, seen_ul;        // last observed progress of the neighbouring CTUs
 };
 struct IntraNeighbours {
-  const uint32_t *pl, *pu, *pur, *pul;       // progress counters of the left / upper / upper-right / upper-left CTU (same plane)
   bool nb_left, nb_up, nb_ur, nb_ul;         // which of them exist (inside the picture, same tile)
   uint32_t il = 0xffu, iu = 0xffu, iur = 0xffu, iul = 1u;      // (IntraBorders: the neighbours' edge units that are intra units)
   // The left CTU's entry of the edge-column array (IB_EDGE_R), or null: its right column is read from the picture.  Round 4: the entries are SELF-VALIDATING
   // words, sample | launch generation << 8 -- the right neighbour polls the words themselves until they carry this launch's generation.  The producer
-  // neither waits for these stores nor publishes anything for them, and the consumer's poll IS its load: the horizontal hop of the CTU wavefront loses the
-  // producer's store drain and one memory round trip of the consumer.  (The upper neighbours' bottom rows still travel through the picture + progress counters.)
+  // neither waits for these stores nor publishes anything for them, and the consumer's poll IS its load: the hop of the CTU wavefront loses the
+  // producer's store drain and one memory round trip of the consumer.
   const uint32_t *ecol_left = nullptr;
   uint32_t gen = 0;
+  // ... and the same for the upper neighbours' BOTTOM ROWS: per CTU S / 4 words {four samples, generation} -- the upper, upper-right and upper-left CTU's
+  // entries (the corner is the last sample of the upper-left one), or null: read from the picture
+  const unsigned long long *erow_up = nullptr, *erow_ur = nullptr, *erow_ul = nullptr;
 };
 __device__ __forceinline__ uint32_t lds_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int lds_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// thread 0 .. n of the workgroup; followed by a barrier in the caller
-__device__ __forceinline__ void chain_init(IntraChain &ch, const IntraNeighbours &nb, uint32_t done0, uint32_t done1)
+// thread 0 of the workgroup; followed by a barrier in the caller
+__device__ __forceinline__ void chain_init(IntraChain &ch, uint32_t done0, uint32_t done1)
 {
-  if (threadIdx.x == 0) {
-    ch.done[0] = done0; ch.done[1] = done1; ch.acked[0] = done0; ch.acked[1] = done1; ch.claim = 0; ch.published = 0;
-    ch.left_loaded = 0; ch.top_loaded = 0; ch.corner_loaded = 0;
-  }
-  if (threadIdx.x < 4) {
-    const uint32_t *p = threadIdx.x == 0 ? nb.pl : (threadIdx.x == 1 ? nb.pu : (threadIdx.x == 2 ? nb.pur : nb.pul));
-    const bool on = threadIdx.x == 0 ? nb.nb_left : (threadIdx.x == 1 ? nb.nb_up : (threadIdx.x == 2 ? nb.nb_ur : nb.nb_ul));
-    (&ch.seen_l)[threadIdx.x] = on ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-  }
-}
-// one wave waits until *ctr >= need (last observed value cached in LDS for everybody); returns the value seen
-__device__ __forceinline__ uint32_t wave_wait_wt(const uint32_t *ctr, uint32_t need, uint32_t *seen, uint32_t *err, int lane)
-{
-  uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_load(seen));
-  if (v >= need) return v;
-  uint32_t spins = 0;
-  while ((v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
-    // (every poll is a read that goes to memory: 100 waiting waves polling flat out were most of the kernel's HBM reads.  A wave that has waited long is far
-    // from its turn -- the wavefront takes tens of microseconds to reach it -- and can afford to look less often)
-    if (++spins < 16) __builtin_amdgcn_s_sleep(1); else if (spins < 64) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
-    if (spins > (1u << 21)) { if (lane == 0) atomicOr(err, 1u); v = 64; break; }           // bounded spin: never hang the GPU
-  }
-  v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-  if (lane == 0) atomicMax(seen, v);
-  return v;
+  if (threadIdx.x == 0) { ch.done[0] = done0; ch.done[1] = done1; ch.claim = 0; ch.left_loaded = 0; ch.top_loaded = 0; ch.corner_loaded = 0; }
 }
 // wave-level borders_need(): the borders the block at (rx, ry), size n, reads are in LDS when it returns.  Two waves may copy
 // overlapping pieces (the same bytes); the *_loaded marks only ever grow.
@@ -342,77 +317,58 @@ __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNei
                                                   int lim_w, int rx, int ry, int n, uint32_t *err, int lane, int nl2, int nt2)
 {
   // (nl2 / nt2: as in borders_need)
-  // What is missing of the three borders is decided first, the neighbours' progress awaited, and then ALL the loads are issued before the
-  // first of them is waited for: the first block of a CTU needs its left column, its top row and its corner, and three memory round trips one
-  // after the other were a tenth of the wavefront's step (S <= 64: one byte per lane covers a column, one dword per lane a row and a half).
+  // Round 4: nothing is waited for through progress counters any more.  What a neighbouring CTU's INTRA units contribute arrives as self-validating words
+  // (IntraNeighbours: the left CTU's right column one sample per word, the upper CTUs' bottom rows four samples per word, each with the launch's generation)
+  // which are simply loaded again until they carry this launch's tag; what its inter units contribute (P pictures) is final in the picture.  All loads of
+  // the left column, the top row and the corner are in flight together, and the poll is the load.
   int haveL = 0, uptoL = 0, haveT = 0, uptoT = 0;
   bool doC = false;
-  if (rx == 0 && ry == 0 && (b.nb_left || b.nb_up)) {
-    // The CTU's first block waits for three neighbours (left column, top row, corner).  They are polled TOGETHER, lanes 0 .. 3 one counter each, until all
-    // are far enough: waiting for the left one first and then finding out with a poll each that the upper ones were done long ago put two memory round
-    // trips on the wavefront's step.  (The wave_wait_wt calls below then find what they need in the cache.)
-    const int nL = imin(S, nl2), limT = imin(lim_w, b.nb_ur ? 2 * S : S), nT = imin(limT, nt2);
-    uint32_t want = 0;
-    (void)nL;                                              // (the left column is polled through its tagged words below)
-    if (lane == 1 && b.nb_up) want = kv_edge_need(b.iu, ((imin(S, nT) - 1) << sh) >> 3, false);
-    if (lane == 2 && b.nb_up && nT > S) want = kv_edge_need(b.iur, ((nT - S - 1) << sh) >> 3, false);
-    if (lane == 3 && b.nb_ul) want = b.iul ? 64u : 0u;
-    const uint32_t *p = lane == 0 ? b.pl : (lane == 1 ? b.pu : (lane == 2 ? b.pur : b.pul));
-    uint32_t v = lane < 4 ? lds_load(&ch.seen_l + lane) : 0u, spins = 0;
-    while (__ballot(lane < 4 && v < want) != 0) {
-      if (lane < 4 && v < want) v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__ballot(lane < 4 && v < want) == 0) break;
-      if (++spins < 16) __builtin_amdgcn_s_sleep(1); else if (spins < 64) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
-      if (spins > (1u << 21)) { if (lane == 0) atomicOr(err, 1u); v = 64; break; }
-    }
-    if (lane < 4 && want) atomicMax(&ch.seen_l + lane, v);
-    wave_sync();
-  }
+  (void)n;
   if (rx == 0 && b.nb_left) {
     const int need = imin(S, ry + nl2);
     haveL = __builtin_amdgcn_readfirstlane(lds_load(&ch.left_loaded));
-    if (need > haveL) uptoL = need;                         // (no progress counter: the rows' own words say when they are there)
+    if (need > haveL) uptoL = need;
   }
   if (ry == 0 && b.nb_up) {
     const int lim = imin(lim_w, b.nb_ur ? 2 * S : S), need = imin(lim, rx + nt2);
     haveT = __builtin_amdgcn_readfirstlane(lds_load(&ch.top_loaded));
-    if (need > haveT) {
-      uptoT = need;
-      if (haveT < S) {
-        const uint32_t seen = wave_wait_wt(b.pu, kv_edge_need(b.iu, ((imin(S, need) - 1) << sh) >> 3, false), &ch.seen_u, err, lane);
-        uptoT = imax(uptoT, imin(imin(S, lim), kv_units_bottom(seen) * (8 >> sh)));
-      }
-      if (need > S) {
-        const uint32_t seen = wave_wait_wt(b.pur, kv_edge_need(b.iur, ((need - S - 1) << sh) >> 3, false), &ch.seen_ur, err, lane);
-        uptoT = imax(uptoT, imin(lim, S + kv_units_bottom(seen) * (8 >> sh)));
-      }
-    }
+    if (need > haveT) uptoT = need;
   }
-  if (rx == 0 && ry == 0 && b.nb_ul && !__builtin_amdgcn_readfirstlane(lds_load(&ch.corner_loaded))) {
-    wave_wait_wt(b.pul, b.iul ? 64u : 0u, &ch.seen_ul, err, lane);
-    doC = true;
-  }
-  // ---- the loads, all in flight together (both ends of the row piece are multiples of 4: block sizes, CTU sizes and picture widths are)
+  if (rx == 0 && ry == 0 && b.nb_ul && !__builtin_amdgcn_readfirstlane(lds_load(&ch.corner_loaded))) doC = true;
+  // (both ends of the row piece are multiples of 4: block sizes, CTU sizes and picture widths are)
   const int iL = haveL + lane, iT = haveT + 4 * lane;
-  uint32_t vL = 0, vT = 0, vC = 0;
-  // left column: rows of intra units come from the left CTU's tagged edge words (polled until they are this launch's), rows of a P picture's inter units
-  // from the picture, which is final
-  const bool rowL = iL < uptoL, tagged = rowL && b.ecol_left && ((b.il >> ((iL << sh) >> 3)) & 1u);
-  if (rowL) vL = tagged ? ld_l2_u32(b.ecol_left + iL) : ld_l2_u8(plane + (size_t)(cy * S + iL) * gp + cx * S - 1);
-  if (iT < uptoT) vT = ld_l2_u32(plane + (size_t)(cy * S - 1) * gp + cx * S + iT);
-  if (doC && lane == 0) vC = ld_l2_u8(plane + (size_t)(cy * S - 1) * gp + cx * S - 1);
-  if (__ballot(tagged) != 0) {
-    uint32_t spins = 0;
-    while (__ballot(tagged && (vL >> 8) != b.gen) != 0) {
-      if (++spins < 16) __builtin_amdgcn_s_sleep(1); else if (spins < 64) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
-      if (spins > (1u << 21)) { if (lane == 0) atomicOr(err, 1u); break; }           // bounded spin: never hang the GPU
-      if (tagged && (vL >> 8) != b.gen) vL = ld_l2_u32(b.ecol_left + iL);
-    }
-    vL &= 255u;
+  const bool rowL = iL < uptoL, tagL = rowL && b.ecol_left && ((b.il >> ((iL << sh) >> 3)) & 1u);
+  const bool colT = iT < uptoT;
+  bool tagT = false; const unsigned long long *wT = nullptr;
+  if (colT) {
+    if (iT < S) { tagT = b.erow_up && ((b.iu >> ((iT << sh) >> 3)) & 1u); wT = b.erow_up + (iT >> 2); }
+    else { tagT = b.erow_ur && ((b.iur >> (((iT - S) << sh) >> 3)) & 1u); wT = b.erow_ur + ((iT - S) >> 2); }
   }
-  if (iL < uptoL) pic[(iL + 1) * lp + 15] = (uint8_t)vL;
-  if (iT < uptoT) *(uint32_t *)&pic[16 + iT] = vT;
-  if (doC && lane == 0) pic[15] = (uint8_t)vC;
+  const bool cornC = doC && lane == 0, tagC = cornC && b.erow_ul && b.iul;
+  uint32_t vL = 0, vT = 0, vC = 0;
+  unsigned long long qT = 0, qC = 0;
+  if (rowL) vL = tagL ? ld_l2_u32(b.ecol_left + iL) : ld_l2_u8(plane + (size_t)(cy * S + iL) * gp + cx * S - 1);
+  if (colT) { if (tagT) qT = ld_l2_u64(wT); else vT = ld_l2_u32(plane + (size_t)(cy * S - 1) * gp + cx * S + iT); }
+  if (cornC) { if (tagC) qC = ld_l2_u64(b.erow_ul + (S >> 2) - 1); else vC = ld_l2_u8(plane + (size_t)(cy * S - 1) * gp + cx * S - 1); }
+  {
+    const unsigned long long gen = b.gen;
+    uint32_t spins = 0;
+    for (;;) {
+      const bool pL = tagL && (vL >> 8) != b.gen, pT = tagT && (qT >> 32) != gen, pC = tagC && (qC >> 32) != gen;
+      if (__ballot(pL || pT || pC) == 0) break;
+      if (++spins < 16) __builtin_amdgcn_s_sleep(1); else if (spins < 64) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(32);
+      if (spins > (1u << 21)) { if (lane == 0) atomicOr(err, 1u); break; }           // bounded spin: never hang the GPU
+      if (pL) vL = ld_l2_u32(b.ecol_left + iL);
+      if (pT) qT = ld_l2_u64(wT);
+      if (pC) qC = ld_l2_u64(b.erow_ul + (S >> 2) - 1);
+    }
+    if (tagL) vL &= 255u;
+    if (tagT) vT = (uint32_t)qT;
+    if (tagC) vC = (uint32_t)(qC >> 24) & 255u;              // (the upper-left CTU's bottom-right sample: byte 3 of its last word)
+  }
+  if (rowL) pic[(iL + 1) * lp + 15] = (uint8_t)vL;
+  if (colT) *(uint32_t *)&pic[16 + iT] = vT;
+  if (cornC) pic[15] = (uint8_t)vC;
   wave_sync();
   if (lane == 0) {
     if (uptoL > haveL) atomicMax(&ch.left_loaded, uptoL);
@@ -461,22 +417,6 @@ __device__ __forceinline__ void chain_mark_done(IntraChain &ch, uint2 cover, int
   wave_sync();                                              // (the block's samples are in the CTU picture before the mark)
   if (lane == 0) { if (cover.x) atomicOr(&ch.done[0], cover.x); if (cover.y) atomicOr(&ch.done[1], cover.y); }
 }
-// after the wave has drained its stores (s_waitcnt vmcnt(0)): the units in `cover` are final in memory; publishes the progress value
-// the leading run of acknowledged units amounts to when it passes a value neighbours wait for
-__device__ __forceinline__ void chain_ack_publish(IntraChain &ch, uint2 cover, uint32_t *ctr, int lane, unsigned long long *tr = nullptr)
-{
-  if (lane != 0) return;
-  if (cover.x) atomicOr(&ch.acked[0], cover.x);
-  if (cover.y) atomicOr(&ch.acked[1], cover.y);
-  const uint32_t a0 = lds_load(&ch.acked[0]), a1 = lds_load(&ch.acked[1]);     // (re-read after both updates: whoever completes the masks sees them complete)
-  const int prefix = a0 != ~0u ? __builtin_ctz(~a0) : 32 + (a1 != ~0u ? __builtin_ctz(~a1) : 32);
-  const uint32_t m = prefix >= 64 ? 64u : (prefix >= 60 ? 60u : (prefix >= 56 ? 56u : (prefix >= 48 ? 48u : (prefix >= 44 ? 44u : (prefix >= 32 ? 32u : (prefix >= 24 ? 24u : 0u))))));
-  if (m && atomicMax(&ch.published, m) < m) {
-    __hip_atomic_fetch_max(ctr, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tr) { if (m >= 24 && !tr[3]) tr[3] = wall_clock64(); if (m >= 44 && !tr[4]) tr[4] = wall_clock64(); }      // (tools/intra_timeline.py: when the values the right / lower-left neighbour starts on went out)
-  }
-}
-
 // thread layout of one block inside a workgroup of T threads (64: one wave, 256: four): OPL outputs per thread so that
 // (n / 2) row pairs x (n / OPL) output groups fit
 template <int L2, int T> struct XW {

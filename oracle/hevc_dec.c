@@ -29,6 +29,9 @@ struct orc_decoder {
   int prev_tid0_poc;
   int seen_irap;
   orc_pic *ref_list0[16]; int ref_poc[16]; int num_ref;
+  orc_pic *ref_list1[16]; int ref_poc1[16]; int num_ref1;     /* RefPicList1 (B slices) */
+  int no_backward_pred;                   /* NoBackwardPredFlag, 8.5.3.2.9 */
+  int cvs;                                /* coded video sequences started so far (output order: sequence after sequence, POC inside one) */
   int ctbs_decoded; int pic_active;
   uint8_t *bs_v, *bs_h; size_t bs_cap;
   pixel *predeblock[3]; size_t predeblock_cap;
@@ -371,30 +374,62 @@ static int decode_mvd_comp_abs(orc_decoder *d, int gt0, int gt1)
   return v + 2;
 }
 
-static void mc_pu(orc_decoder *d, int xp, int yp, int w, int h, const int16_t mv[2], int ref_idx)
+/* 8.5.3.3: the prediction block from one list (default weighted prediction of a single 14-bit array) or from both (their rounded average) */
+static void mc_pu(orc_decoder *d, int xp, int yp, int w, int h, const orc_mvinfo *m)
 {
-  orc_pic *pic = d->cur, *ref = d->ref_list0[ref_idx];
-  int16_t tmp[64 * 64];
-  orc_mc_luma(ref->plane[0], ref->stride[0], ref->w, ref->h, xp, yp, w, h, mv[0], mv[1], tmp, 64);
-  orc_pred_uni(tmp, 64, pic->plane[0] + yp * pic->stride[0] + xp, pic->stride[0], w, h);
-  for (int ci = 1; ci <= 2; ci++) {
-    orc_mc_chroma(ref->plane[ci], ref->stride[ci], ref->w / 2, ref->h / 2, xp / 2, yp / 2, w / 2, h / 2, mv[0], mv[1], tmp, 64);
-    orc_pred_uni(tmp, 64, pic->plane[ci] + (yp / 2) * pic->stride[ci] + xp / 2, pic->stride[ci], w / 2, h / 2);
+  orc_pic *pic = d->cur;
+  const orc_pic *r0 = m->ref_idx >= 0 ? d->ref_list0[m->ref_idx] : NULL, *r1 = m->ref_idx1 >= 0 ? d->ref_list1[m->ref_idx1] : NULL;
+  static int16_t t0[64 * 64], t1[64 * 64];
+  for (int ci = 0; ci < 3; ci++) {
+    const int sh = ci ? 1 : 0, X = xp >> sh, Y = yp >> sh, W = w >> sh, H = h >> sh;
+    if (r0) { if (ci) orc_mc_chroma(r0->plane[ci], r0->stride[ci], r0->w / 2, r0->h / 2, X, Y, W, H, m->mv[0], m->mv[1], t0, 64);
+              else orc_mc_luma(r0->plane[0], r0->stride[0], r0->w, r0->h, X, Y, W, H, m->mv[0], m->mv[1], t0, 64); }
+    if (r1) { if (ci) orc_mc_chroma(r1->plane[ci], r1->stride[ci], r1->w / 2, r1->h / 2, X, Y, W, H, m->mv1[0], m->mv1[1], t1, 64);
+              else orc_mc_luma(r1->plane[0], r1->stride[0], r1->w, r1->h, X, Y, W, H, m->mv1[0], m->mv1[1], t1, 64); }
+    pixel *dst = pic->plane[ci] + Y * pic->stride[ci] + X;
+    if (r0 && r1) orc_pred_bi(t0, t1, 64, dst, pic->stride[ci], W, H);
+    else orc_pred_uni(r0 ? t0 : t1, 64, dst, pic->stride[ci], W, H);
   }
+}
+
+/* mvd_coding() (7.3.8.9) -> one vector difference */
+static void decode_mvd(orc_decoder *d, int mvd[2])
+{
+  orc_cabac_dec *c = &d->cabac;
+  int gt0x = orc_cdec_bin(c, CTX_MVD_GT0), gt0y = orc_cdec_bin(c, CTX_MVD_GT0);
+  int gt1x = gt0x ? orc_cdec_bin(c, CTX_MVD_GT1) : 0, gt1y = gt0y ? orc_cdec_bin(c, CTX_MVD_GT1) : 0;
+  mvd[0] = decode_mvd_comp_abs(d, gt0x, gt1x); if (gt0x && orc_cdec_bypass(c)) mvd[0] = -mvd[0];
+  mvd[1] = decode_mvd_comp_abs(d, gt0y, gt1y); if (gt0y && orc_cdec_bypass(c)) mvd[1] = -mvd[1];
+}
+static int decode_ref_idx(orc_decoder *d, int num_active)
+{
+  orc_cabac_dec *c = &d->cabac;
+  int ref_idx = 0;
+  const int mx = num_active - 1;
+  while (ref_idx < mx && ref_idx < 2 && orc_cdec_bin(c, CTX_REF_IDX + ref_idx)) ref_idx++;
+  if (ref_idx == 2) while (ref_idx < mx && orc_cdec_bypass(c)) ref_idx++;
+  return ref_idx;
 }
 
 static void prediction_unit(orc_decoder *d, int xcb, int ycb, int ncbs, int xp, int yp, int w, int h, int part_idx, int skip, int *merge_flag_out)
 {
   orc_cabac_dec *c = &d->cabac;
   orc_pic *pic = d->cur;
-  orc_mvpred_ctx mc;
+  const int is_b = d->sh.slice_type == SLICE_B;
+  orc_mvpred_ctx mc; memset(&mc, 0, sizeof(mc));
   mc.pic = pic; mc.av = d->av; mc.log2_par_mrg_level = d->p->log2_parallel_merge_level;
   mc.max_num_merge_cand = d->sh.max_num_merge_cand; mc.num_ref_idx = d->sh.num_ref_idx_l0;
   mc.cur_poc = pic->poc; memcpy(mc.ref_poc, d->ref_poc, sizeof(mc.ref_poc));
-  mc.col = (d->sh.slice_temporal_mvp_enabled && d->sh.collocated_ref_idx < d->num_ref) ? d->ref_list0[d->sh.collocated_ref_idx] : NULL;
+  mc.is_b = is_b; mc.num_ref_idx1 = d->sh.num_ref_idx_l1; memcpy(mc.ref_poc1, d->ref_poc1, sizeof(mc.ref_poc1));
+  mc.collocated_from_l0 = d->sh.collocated_from_l0; mc.no_backward_pred = d->no_backward_pred;
+  mc.col = NULL;
+  if (d->sh.slice_temporal_mvp_enabled) {                  /* 8.5.3.2.8: the collocated picture out of list 1 when a B slice says so */
+    if (is_b && !d->sh.collocated_from_l0) { if (d->sh.collocated_ref_idx < d->num_ref1) mc.col = d->ref_list1[d->sh.collocated_ref_idx]; }
+    else if (d->sh.collocated_ref_idx < d->num_ref) mc.col = d->ref_list0[d->sh.collocated_ref_idx];
+  }
   int merge = skip ? 1 : orc_cdec_bin(c, CTX_MERGE_FLAG);
   if (merge_flag_out) *merge_flag_out = merge;
-  int16_t mv[2]; int ref_idx = 0;
+  orc_mvinfo m; memset(&m, 0, sizeof(m)); m.ref_idx = m.ref_idx1 = -1;
   if (merge) {
     int idx = 0;
     if (d->sh.max_num_merge_cand > 1) {
@@ -402,34 +437,42 @@ static void prediction_unit(orc_decoder *d, int xcb, int ycb, int ncbs, int xp, 
     }
     orc_mvcand cand[5];
     orc_merge_candidates(&mc, xcb, ycb, ncbs, xp, yp, w, h, part_idx, d->part_mode, cand);
-    mv[0] = cand[idx].mv[0]; mv[1] = cand[idx].mv[1]; ref_idx = cand[idx].ref_idx;
+    m = cand[idx];
+    if (m.ref_idx >= 0 && m.ref_idx1 >= 0 && w + h == 12) { m.ref_idx1 = -1; m.mv1[0] = m.mv1[1] = 0; }      /* 8.5.3.2.2 step 9: 8x4 / 4x8 blocks are never bi-predicted */
   } else {
-    if (d->sh.num_ref_idx_l0 > 1) {
-      int mx = d->sh.num_ref_idx_l0 - 1;
-      while (ref_idx < mx && ref_idx < 2 && orc_cdec_bin(c, CTX_REF_IDX + ref_idx)) ref_idx++;
-      if (ref_idx == 2) while (ref_idx < mx && orc_cdec_bypass(c)) ref_idx++;
+    /* inter_pred_idc (9.3.4.2): "both lists" is asked first (context = coding quadtree depth) unless the block is 8x4 / 4x8, then which list */
+    int idc = 0;                                           /* 0 PRED_L0, 1 PRED_L1, 2 PRED_BI */
+    if (is_b) {
+      if (w + h != 12 && orc_cdec_bin(c, CTX_INTER_PRED_IDC + pic->ct_depth[b4(pic, xcb, ycb)])) idc = 2;
+      else idc = orc_cdec_bin(c, CTX_INTER_PRED_IDC + 4);
     }
-    int gt0x = orc_cdec_bin(c, CTX_MVD_GT0), gt0y = orc_cdec_bin(c, CTX_MVD_GT0);
-    int gt1x = gt0x ? orc_cdec_bin(c, CTX_MVD_GT1) : 0, gt1y = gt0y ? orc_cdec_bin(c, CTX_MVD_GT1) : 0;
-    int mvdx = decode_mvd_comp_abs(d, gt0x, gt1x); if (gt0x && orc_cdec_bypass(c)) mvdx = -mvdx;
-    int mvdy = decode_mvd_comp_abs(d, gt0y, gt1y); if (gt0y && orc_cdec_bypass(c)) mvdy = -mvdy;
-    int mvp = orc_cdec_bin(c, CTX_MVP_FLAG);
-    int16_t cand[2][2];
-    orc_amvp_candidates(&mc, xcb, ycb, ncbs, xp, yp, w, h, part_idx, ref_idx, cand);
-    /* 8.5.3.2.6: uLX = (mvp + mvd + 2^16) % 2^16, wrapped to int16 */
-    mv[0] = (int16_t)(uint16_t)(cand[mvp][0] + mvdx);
-    mv[1] = (int16_t)(uint16_t)(cand[mvp][1] + mvdy);
+    int mvd[2], mvp; int16_t cand[2][2];
+    if (idc != 1) {
+      m.ref_idx = (int8_t)(d->sh.num_ref_idx_l0 > 1 ? decode_ref_idx(d, d->sh.num_ref_idx_l0) : 0);
+      decode_mvd(d, mvd);
+      mvp = orc_cdec_bin(c, CTX_MVP_FLAG);
+      if (m.ref_idx >= d->num_ref) { d->err = ERR_INVALID; return; }
+      orc_amvp_candidates_lx(&mc, xcb, ycb, ncbs, xp, yp, w, h, part_idx, 0, m.ref_idx, cand);
+      /* 8.5.3.2.6: uLX = (mvp + mvd + 2^16) % 2^16, wrapped to int16 */
+      m.mv[0] = (int16_t)(uint16_t)(cand[mvp][0] + mvd[0]); m.mv[1] = (int16_t)(uint16_t)(cand[mvp][1] + mvd[1]);
+    }
+    if (idc != 0) {
+      m.ref_idx1 = (int8_t)(d->sh.num_ref_idx_l1 > 1 ? decode_ref_idx(d, d->sh.num_ref_idx_l1) : 0);
+      if (d->sh.mvd_l1_zero && idc == 2) mvd[0] = mvd[1] = 0; else decode_mvd(d, mvd);
+      mvp = orc_cdec_bin(c, CTX_MVP_FLAG);
+      if (m.ref_idx1 >= d->num_ref1) { d->err = ERR_INVALID; return; }
+      orc_amvp_candidates_lx(&mc, xcb, ycb, ncbs, xp, yp, w, h, part_idx, 1, m.ref_idx1, cand);
+      m.mv1[0] = (int16_t)(uint16_t)(cand[mvp][0] + mvd[0]); m.mv1[1] = (int16_t)(uint16_t)(cand[mvp][1] + mvd[1]);
+    }
   }
-  if (ref_idx >= d->num_ref || !d->ref_list0[ref_idx]) { d->err = ERR_INVALID; return; }
+  if (m.ref_idx < 0 && m.ref_idx1 < 0) { d->err = ERR_INVALID; return; }
+  if ((m.ref_idx >= 0 && (m.ref_idx >= d->num_ref || !d->ref_list0[m.ref_idx])) || (m.ref_idx1 >= 0 && (m.ref_idx1 >= d->num_ref1 || !d->ref_list1[m.ref_idx1]))) { d->err = ERR_INVALID; return; }
   for (int y = yp; y < yp + h; y += 4)
-    for (int x = xp; x < xp + w; x += 4) {
-      orc_mvinfo *m = &pic->mvf[b4(pic, x, y)];
-      m->mv[0] = mv[0]; m->mv[1] = mv[1]; m->ref_idx = (int8_t)ref_idx;
-    }
+    for (int x = xp; x < xp + w; x += 4) pic->mvf[b4(pic, x, y)] = m;
   /* prediction block edges for deblocking */
   for (int i = 0; i < h; i += 4) pic->edge_v[b4(pic, xp, yp + i)] |= 2;
   for (int i = 0; i < w; i += 4) pic->edge_h[b4(pic, xp + i, yp)] |= 2;
-  mc_pu(d, xp, yp, w, h, mv, ref_idx);
+  mc_pu(d, xp, yp, w, h, &m);
 }
 
 /* ------------------------------------------------------------------ coding unit */
@@ -647,6 +690,24 @@ static void setup_tiles(orc_decoder *d)
   d->sao_used = 0;
 }
 
+/* C.5.2.4 "bumping": of the pictures waiting for output the one with the smallest POC goes out */
+static int waiting_for_output(const orc_decoder *d)
+{
+  int n = 0;
+  for (int i = 0; i < MAX_DPB; i++) n += d->dpb[i].in_use && d->dpb[i].needed_for_output && !d->dpb[i].out_queued;
+  return n;
+}
+static void bump(orc_decoder *d)
+{
+  orc_pic *best = NULL;
+  for (int i = 0; i < MAX_DPB; i++) {
+    orc_pic *q = &d->dpb[i];
+    if (q->in_use && q->needed_for_output && !q->out_queued && (!best || q->poc < best->poc)) best = q;
+  }
+  if (best && d->out_n < MAX_DPB + 1) { best->out_queued = 1; d->out_queue[d->out_n++] = best; }
+}
+void orc_dec_flush(orc_decoder *d) { if (d->pic_active) return; while (waiting_for_output(d)) bump(d); }
+
 static int start_picture(orc_decoder *d)
 {
   const orc_sps *s = d->s; orc_slice_hdr *sh = &d->sh;
@@ -668,12 +729,14 @@ static int start_picture(orc_decoder *d)
   if (idr) {
     for (int i = 0; i < MAX_DPB; i++) d->dpb[i].is_ref = 0;
   }
+  /* C.5.2.2: an IRAP picture that starts a coded video sequence (no_output_of_prior_pics_flag 0) empties the DPB in output order first */
+  if (idr || !d->seen_irap) { while (waiting_for_output(d)) bump(d); d->cvs++; }
   d->seen_irap = 1;
   d->prev_tid0_poc = poc;      /* TemporalId 0 only in this oracle's streams; RASL/RADL not produced */
   d->cur = alloc_pic(d, s->width, s->height);
   if (!d->cur) return ERR_INVALID;
   d->cur->poc = poc; d->cur->pts = d->cur_pts;
-  d->cur->is_ref = 1; d->cur->needed_for_output = sh->pic_output_flag;
+  d->cur->is_ref = 1; d->cur->needed_for_output = 0; d->cur->out_queued = 0;
   /* 8.3.2 reference picture set: everything not in the RPS is marked unused */
   if (!idr) {
     for (int i = 0; i < MAX_DPB; i++) {
@@ -684,7 +747,15 @@ static int start_picture(orc_decoder *d)
       for (int k = 0; k < sh->st_rps.num_positive; k++) if (q->poc == poc + sh->st_rps.delta_poc_s1[k]) keep = 1;
       if (!keep) q->is_ref = 0;
     }
+    /* C.5.2.2: room for the current picture -- more pictures waiting than may be reordered, or no free picture buffer */
+    for (;;) {
+      int full = 0;
+      for (int i = 0; i < MAX_DPB; i++) { const orc_pic *q = &d->dpb[i]; full += q != d->cur && q->in_use && (q->is_ref || (q->needed_for_output && !q->out_queued)); }
+      const int w = waiting_for_output(d);
+      if (w > 0 && (w > s->max_num_reorder || full >= s->max_dec_pic_buffering)) bump(d); else break;
+    }
   }
+  d->cur->needed_for_output = sh->pic_output_flag;
   size_t need_v = (size_t)(s->width / 8) * (s->height / 4), need_h = (size_t)(s->width / 4) * (s->height / 8);
   if (need_v + need_h > d->bs_cap) {
     d->bs_v = (uint8_t *)realloc(d->bs_v, need_v); d->bs_h = (uint8_t *)realloc(d->bs_h, need_h); d->bs_cap = need_v + need_h;
@@ -702,23 +773,38 @@ static int start_picture(orc_decoder *d)
   return 1;
 }
 
+/* 8.3.4: RefPicList0 = the used pictures before the current one (nearest first), then those after it, repeated until the list is full; RefPicList1
+ * the other way round.  No list modification, no long-term pictures. */
 static int build_ref_list(orc_decoder *d)
 {
   orc_slice_hdr *sh = &d->sh;
-  d->num_ref = 0;
-  if (sh->slice_type == SLICE_I) { for (int i = 0; i < 16; i++) d->cur->ref_poc_list[i] = d->cur->poc; return 0; }
-  orc_pic *cand[32]; int nc = 0;
+  d->num_ref = d->num_ref1 = 0; d->no_backward_pred = 1;
+  for (int i = 0; i < 16; i++) d->cur->ref_poc_list[i] = d->cur->ref_poc_list1[i] = d->cur->poc;      /* unused entries: never compared */
+  if (sh->slice_type == SLICE_I) return 0;
+  orc_pic *before[16], *after[16]; int nb = 0, na = 0;
   int poc = d->cur->poc;
-  for (int k = 0; k < sh->st_rps.num_negative; k++) if (sh->st_rps.used_s0[k]) cand[nc++] = find_poc(d, poc + sh->st_rps.delta_poc_s0[k]);
-  for (int k = 0; k < sh->st_rps.num_positive; k++) if (sh->st_rps.used_s1[k]) cand[nc++] = find_poc(d, poc + sh->st_rps.delta_poc_s1[k]);
+  for (int k = 0; k < sh->st_rps.num_negative; k++) if (sh->st_rps.used_s0[k]) before[nb++] = find_poc(d, poc + sh->st_rps.delta_poc_s0[k]);
+  for (int k = 0; k < sh->st_rps.num_positive; k++) if (sh->st_rps.used_s1[k]) after[na++] = find_poc(d, poc + sh->st_rps.delta_poc_s1[k]);
+  const int nc = nb + na;
   if (nc == 0) return ERR_INVALID;
   for (int i = 0; i < sh->num_ref_idx_l0; i++) {
-    d->ref_list0[i] = cand[i % nc];
+    const int k = i % nc;
+    d->ref_list0[i] = k < nb ? before[k] : after[k - nb];
     if (!d->ref_list0[i]) return ERR_INVALID;      /* missing reference picture */
-    d->ref_poc[i] = d->ref_list0[i]->poc;
+    d->ref_poc[i] = d->cur->ref_poc_list[i] = d->ref_list0[i]->poc;
+    if (d->ref_poc[i] > poc) d->no_backward_pred = 0;
   }
   d->num_ref = sh->num_ref_idx_l0;
-  for (int i = 0; i < 16; i++) d->cur->ref_poc_list[i] = i < d->num_ref ? d->ref_poc[i] : d->cur->poc;   /* unused entries: never compared */
+  if (sh->slice_type == SLICE_B) {
+    for (int i = 0; i < sh->num_ref_idx_l1; i++) {
+      const int k = i % nc;
+      d->ref_list1[i] = k < na ? after[k] : before[k - na];
+      if (!d->ref_list1[i]) return ERR_INVALID;
+      d->ref_poc1[i] = d->cur->ref_poc_list1[i] = d->ref_list1[i]->poc;
+      if (d->ref_poc1[i] > poc) d->no_backward_pred = 0;
+    }
+    d->num_ref1 = sh->num_ref_idx_l1;
+  }
   return 0;
 }
 
@@ -757,7 +843,7 @@ static void finish_picture(orc_decoder *d)
     orc_sao_picture(&sc);
   }
   d->pic_active = 0;
-  if (pic->needed_for_output) d->out_queue[d->out_n++] = pic;   /* low-delay streams: output order == decode order */
+  while (waiting_for_output(d) > s->max_num_reorder) bump(d);   /* C.5.2.3: a low-delay stream (no reordering) hands every picture on at once */
 }
 
 /* ------------------------------------------------------------------ slice data 7.3.8.1 */
@@ -877,7 +963,6 @@ int orc_dec_decode_nal(orc_decoder *d, const uint8_t *data, size_t len, int64_t 
   int r = orc_parse_slice_header(&br, &d->sh, nal_type, d->sps, d->pps);
   if (r) return r;
   d->p = &d->pps[d->sh.pps_id]; d->s = &d->sps[d->p->sps_id];
-  if (d->sh.slice_type == SLICE_B) return ERR_UNSUPPORTED;
   if (d->sh.first_slice_segment_in_pic) {
     if (d->pic_active) finish_picture(d);             /* previous picture was incomplete */
     r = start_picture(d);
@@ -891,7 +976,7 @@ int orc_dec_decode_nal(orc_decoder *d, const uint8_t *data, size_t len, int64_t 
   r = build_ref_list(d);
   if (r) { d->pic_active = 0; d->cur->is_ref = 0; d->cur->needed_for_output = 0; return r; }
   d->err = 0;
-  d->last_slice_type = d->sh.slice_type;
+  d->last_slice_type = d->sh.slice_type; d->cur->slice_type = d->sh.slice_type;
   size_t hdr_bytes = br.pos >> 3;
   r = decode_slice_data(d, d->rbsp + hdr_bytes, rlen - hdr_bytes);
   if (r) { d->pic_active = 0; d->cur->is_ref = 0; d->cur->needed_for_output = 0; return r; }
@@ -907,7 +992,7 @@ int orc_dec_get_frame(orc_decoder *d, orc_dec_frame *out)
   orc_pic *pic = d->out_queue[0];
   for (int i = 1; i < d->out_n; i++) d->out_queue[i - 1] = d->out_queue[i];
   d->out_n--;
-  pic->needed_for_output = 0;
+  pic->needed_for_output = 0; pic->out_queued = 0;
   d->last_output = pic;
   const orc_sps *s = d->s;
   int cl = s->conf_win_flag ? s->conf_left * 2 : 0, cr = s->conf_win_flag ? s->conf_right * 2 : 0;
@@ -919,7 +1004,7 @@ int orc_dec_get_frame(orc_decoder *d, orc_dec_frame *out)
   out->plane[2] = pic->plane[2] + (ct / 2) * pic->stride[2] + cl / 2;
   for (int i = 0; i < 3; i++) out->stride[i] = pic->stride[i];
   out->poc = pic->poc; out->pts = pic->pts;
-  out->slice_type = d->last_slice_type;
+  out->slice_type = pic->slice_type;
   const orc_vps *v = &d->vps[s->vps_id];
   out->fps_num = out->fps_den = 0;
   if (s->vui_timing_present) { out->fps_num = s->vui_time_scale; out->fps_den = s->vui_num_units_in_tick; }

@@ -615,7 +615,7 @@ static void inter_recon_cu(orc_encoder *e, int x0, int y0, int log2)
 static void inter_decide_signalling(orc_encoder *e, int x0, int y0, int log2)
 {
   orc_pic *p = e->cur; int n = 1 << log2, bi = b8i(e, x0, y0);
-  orc_mvpred_ctx mc; memset(&mc, 0, sizeof(mc));
+  orc_mvpred_ctx mc; memset(&mc, 0, sizeof(mc)); mc.collocated_from_l0 = 1;
   mc.pic = p; mc.av = e->av; mc.log2_par_mrg_level = 2; mc.max_num_merge_cand = 5; mc.num_ref_idx = 1;
   mc.cur_poc = e->poc; mc.ref_poc[0] = e->poc - 1;
   int16_t mvx = e->cu_mv[bi * 2], mvy = e->cu_mv[bi * 2 + 1];

@@ -31,6 +31,9 @@ struct orc_gen {
   orc_cabac_enc c;
   orc_bitw au;
   int frame_idx, poc, since_idr;
+  int hist_poc[8], hist_n;            /* POCs of the pictures decoded since the IDR, newest first (the reference picture set is the first num_refs of them) */
+  int gop_order[8];                   /* cfg.gop > 1: POC offsets inside a group in decoding order */
+  int slice_is_b;
   int slice_is_intra;
   /* coding-unit state */
   int cu_qp_delta_coded, log2_qg;
@@ -121,6 +124,8 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   c->big_mvd = pick(g, c->big_mvd, 0, 1);
   if (c->tq_bypass < 0) c->tq_bypass = 0;
   if (c->scaling_lists < 0 || c->scaling_lists > 4) c->scaling_lists = 0;
+  if (c->b_slices < 0) c->b_slices = 0;
+  if (c->gop != 2 && c->gop != 4 && c->gop != 8) c->gop = 0;
   const int wc = (cfg->width + 63) / 64, hc = (cfg->height + 63) / 64;
   if (c->tile_rows > hc) c->tile_rows = hc;
   if (c->tile_rows < 1) c->tile_rows = 1;
@@ -130,6 +135,15 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   s->chroma_format_idc = 1; s->width = cfg->width; s->height = cfg->height;
   s->bit_depth_luma = s->bit_depth_chroma = 8; s->log2_max_poc_lsb = pick(g, -1, 4, 8);
   s->max_dec_pic_buffering = c->num_refs + 1; s->max_num_reorder = 0;
+  if (c->gop) {
+    /* decoding order of a group: the last picture, then the middle of every interval, depth first */
+    int n = 0, lo[8], hi[8], sp = 0;
+    g->gop_order[n++] = c->gop; lo[sp] = 0; hi[sp] = c->gop; sp++;
+    while (sp) { sp--; const int a = lo[sp], b = hi[sp], m = (a + b) / 2; if (m == a) continue; g->gop_order[n++] = m; lo[sp] = m; hi[sp] = b; sp++; lo[sp] = a; hi[sp] = m; sp++; }
+    int lg = 0; while ((1 << lg) < c->gop) lg++;
+    s->max_num_reorder = lg; s->max_dec_pic_buffering = c->num_refs + lg + 2;      /* (roomy: output is driven by the reorder count alone) */
+    if (s->log2_max_poc_lsb < 6) s->log2_max_poc_lsb = 6;
+  }
   s->log2_min_cb = 3; s->log2_diff_max_min_cb = 3; s->log2_min_tb = 2; s->log2_diff_max_min_tb = 3;
   s->max_th_depth_inter = c->th_depth_inter; s->max_th_depth_intra = c->th_depth_intra;
   s->amp_enabled = c->amp; s->sao_enabled = c->sao;
@@ -425,28 +439,47 @@ static void put_merge_idx(orc_gen *g)
   orc_cenc_bin(c, CTX_MERGE_IDX, idx > 0);
   if (idx > 0) for (int i = 1; i < mx - 1; i++) { orc_cenc_bypass(c, idx > i); if (idx <= i) break; }
 }
-static void gen_prediction_unit(orc_gen *g, int skip, int *merge_out)
+static void gen_ref_idx(orc_gen *g, int num_active)
 {
   orc_cabac_enc *c = &g->c;
-  int merge = 1;
-  if (!skip) { merge = rpct(g, 45); orc_cenc_bin(c, CTX_MERGE_FLAG, merge); }
-  if (merge_out) *merge_out = merge;
-  if (merge) { put_merge_idx(g); return; }
-  if (g->sh.num_ref_idx_l0 > 1) {
-    const int mx = g->sh.num_ref_idx_l0 - 1, ref = rrange(g, 0, mx);
-    for (int i = 0; i < mx; i++) {                         /* truncated Rice, cMax = mx: first two bins context coded */
-      const int b = ref > i;
-      if (i < 2) orc_cenc_bin(c, CTX_REF_IDX + i, b); else orc_cenc_bypass(c, b);
-      if (!b) break;
-    }
+  if (num_active <= 1) return;
+  const int mx = num_active - 1, ref = rrange(g, 0, mx);
+  for (int i = 0; i < mx; i++) {                           /* truncated Rice, cMax = mx: first two bins context coded */
+    const int b = ref > i;
+    if (i < 2) orc_cenc_bin(c, CTX_REF_IDX + i, b); else orc_cenc_bypass(c, b);
+    if (!b) break;
   }
+}
+static void gen_mvd(orc_gen *g)
+{
+  orc_cabac_enc *c = &g->c;
   const int dx = draw_mvd(g), dy = draw_mvd(g), ax = orc_abs(dx), ay = orc_abs(dy);
   orc_cenc_bin(c, CTX_MVD_GT0, ax > 0); orc_cenc_bin(c, CTX_MVD_GT0, ay > 0);
   if (ax > 0) orc_cenc_bin(c, CTX_MVD_GT1, ax > 1);
   if (ay > 0) orc_cenc_bin(c, CTX_MVD_GT1, ay > 1);
   if (ax > 0) { if (ax > 1) put_mvd_comp_rest(c, ax); orc_cenc_bypass(c, dx < 0); }
   if (ay > 0) { if (ay > 1) put_mvd_comp_rest(c, ay); orc_cenc_bypass(c, dy < 0); }
-  orc_cenc_bin(c, CTX_MVP_FLAG, (int)(rnd(g) & 1u));
+}
+/* prediction_unit() of a w x h prediction block in a coding block of quadtree depth ct_depth (7.3.8.6) */
+static void gen_prediction_unit(orc_gen *g, int skip, int *merge_out, int w, int h, int ct_depth)
+{
+  orc_cabac_enc *c = &g->c;
+  int merge = 1;
+  if (!skip) { merge = rpct(g, 45); orc_cenc_bin(c, CTX_MERGE_FLAG, merge); }
+  if (merge_out) *merge_out = merge;
+  if (merge) { put_merge_idx(g); return; }
+  int idc = 0;                                             /* inter_pred_idc: 0 PRED_L0, 1 PRED_L1, 2 PRED_BI (never for 8x4 / 4x8) */
+  if (g->slice_is_b) {
+    idc = (w + h != 12 && rpct(g, 40)) ? 2 : (int)(rnd(g) & 1u);
+    if (w + h != 12) orc_cenc_bin(c, CTX_INTER_PRED_IDC + ct_depth, idc == 2);
+    if (idc != 2) orc_cenc_bin(c, CTX_INTER_PRED_IDC + 4, idc);
+  }
+  if (idc != 1) { gen_ref_idx(g, g->sh.num_ref_idx_l0); gen_mvd(g); orc_cenc_bin(c, CTX_MVP_FLAG, (int)(rnd(g) & 1u)); }
+  if (idc != 0) {
+    gen_ref_idx(g, g->sh.num_ref_idx_l1);
+    if (!(g->sh.mvd_l1_zero && idc == 2)) gen_mvd(g);
+    orc_cenc_bin(c, CTX_MVP_FLAG, (int)(rnd(g) & 1u));
+  }
 }
 
 /* ------------------------------------------------------------------ coding unit, 7.3.8.5 */
@@ -471,7 +504,7 @@ static void gen_coding_unit(orc_gen *g, int x0, int y0, int log2cb, int ct_depth
   if (skip) {
     g->cu_pred_mode = MODE_INTER;
     fill4(pic, pic->pred_mode, x0, y0, n, n, MODE_SKIP);
-    gen_prediction_unit(g, 1, NULL);
+    gen_prediction_unit(g, 1, NULL, n, n, ct_depth);
     rqt_root_cbf = 0;
   } else {
     g->cu_pred_mode = MODE_INTRA;
@@ -557,7 +590,20 @@ static void gen_coding_unit(orc_gen *g, int x0, int y0, int log2cb, int ct_depth
     } else {
       int mf = 0;
       const int npu = (g->part_mode == PART_2Nx2N) ? 1 : (g->part_mode == PART_NxN ? 4 : 2);
-      for (int i = 0; i < npu; i++) gen_prediction_unit(g, 0, i == 0 ? &merge_2nx2n : &mf);
+      for (int i = 0; i < npu; i++) {
+        int pw = n, ph = n;                                /* size of prediction block i */
+        switch (g->part_mode) {
+          case PART_2NxN: ph = n / 2; break;
+          case PART_Nx2N: pw = n / 2; break;
+          case PART_NxN: pw = ph = n / 2; break;
+          case PART_2NxnU: ph = i == 0 ? n / 4 : n - n / 4; break;
+          case PART_2NxnD: ph = i == 0 ? n - n / 4 : n / 4; break;
+          case PART_nLx2N: pw = i == 0 ? n / 4 : n - n / 4; break;
+          case PART_nRx2N: pw = i == 0 ? n - n / 4 : n / 4; break;
+          default: break;
+        }
+        gen_prediction_unit(g, 0, i == 0 ? &merge_2nx2n : &mf, pw, ph, ct_depth);
+      }
       if (!(g->part_mode == PART_2Nx2N && merge_2nx2n)) { rqt_root_cbf = rpct(g, 65); orc_cenc_bin(c, CTX_RQT_ROOT_CBF, rqt_root_cbf); }
     }
   }
@@ -630,9 +676,11 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
   memset(sh, 0, sizeof(*sh));
   sh->first_slice_segment_in_pic = 1; sh->pic_output_flag = 1;
   g->slice_is_intra = idr || g->since_idr == 0 || rpct(g, 8);
-  sh->slice_type = g->slice_is_intra ? SLICE_I : SLICE_P;
+  g->slice_is_b = !g->slice_is_intra && g->cfg.b_slices > 0 && rpct(g, g->cfg.b_slices);
+  sh->slice_type = g->slice_is_intra ? SLICE_I : (g->slice_is_b ? SLICE_B : SLICE_P);
   sh->poc_lsb = g->poc & ((1 << s->log2_max_poc_lsb) - 1);
-  if (!idr) {
+  sh->num_ref_idx_l1 = p->num_ref_idx_l1_default;
+  if (!idr && !g->cfg.gop && !g->cfg.b_slices) {
     /* reference picture set in the slice header, the way Kvazaar writes it: the previous pictures back to the IDR, at most num_refs */
     const int nneg = ORC_MIN(g->cfg.num_refs, g->since_idr);
     sh->short_term_ref_pic_set_sps_flag = 0;
@@ -643,8 +691,26 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
     sh->slice_temporal_mvp_enabled = s->temporal_mvp_enabled ? rpct(g, 80) : 0;
     sh->collocated_from_l0 = 1;
     sh->collocated_ref_idx = (sh->slice_temporal_mvp_enabled && !g->slice_is_intra) ? rrange(g, 0, sh->num_ref_idx_l0 - 1) : 0;
+  } else if (!idr) {
+    /* the general form (B slices, reordered groups): the set is the last num_refs pictures in DECODING order, which lie on both sides of the current
+     * one once pictures are reordered -- the ones before it in output order nearest first (S0), then the ones after it (S1) */
+    const int nh = ORC_MIN(g->cfg.num_refs, g->hist_n);
+    int neg[8], pos[8], nn = 0, np = 0;
+    for (int i = 0; i < nh; i++) { if (g->hist_poc[i] < g->poc) neg[nn++] = g->hist_poc[i]; else pos[np++] = g->hist_poc[i]; }
+    for (int i = 1; i < nn; i++) for (int j = i; j > 0 && neg[j] > neg[j - 1]; j--) { const int t = neg[j]; neg[j] = neg[j - 1]; neg[j - 1] = t; }
+    for (int i = 1; i < np; i++) for (int j = i; j > 0 && pos[j] < pos[j - 1]; j--) { const int t = pos[j]; pos[j] = pos[j - 1]; pos[j - 1] = t; }
+    sh->short_term_ref_pic_set_sps_flag = 0;
+    sh->st_rps.num_negative = nn; sh->st_rps.num_positive = np;
+    int used = 0;
+    for (int i = 0; i < nn; i++) { sh->st_rps.delta_poc_s0[i] = neg[i] - g->poc; sh->st_rps.used_s0[i] = rpct(g, 85); used += sh->st_rps.used_s0[i]; }
+    for (int i = 0; i < np; i++) { sh->st_rps.delta_poc_s1[i] = pos[i] - g->poc; sh->st_rps.used_s1[i] = rpct(g, 85); used += sh->st_rps.used_s1[i]; }
+    if (!used) { if (nn) sh->st_rps.used_s0[0] = 1; else sh->st_rps.used_s1[0] = 1; used = 1; }
+    sh->num_ref_idx_l0 = g->slice_is_intra ? p->num_ref_idx_l0_default : rrange(g, 1, ORC_MIN(4, used + 1));
+    if (g->slice_is_b) { sh->num_ref_idx_l1 = rrange(g, 1, ORC_MIN(4, used + 1)); sh->mvd_l1_zero = rpct(g, 30); }
+    sh->slice_temporal_mvp_enabled = s->temporal_mvp_enabled ? rpct(g, 80) : 0;
+    sh->collocated_from_l0 = g->slice_is_b ? (int)(rnd(g) & 1u) : 1;
+    sh->collocated_ref_idx = (sh->slice_temporal_mvp_enabled && !g->slice_is_intra) ? rrange(g, 0, (sh->collocated_from_l0 ? sh->num_ref_idx_l0 : sh->num_ref_idx_l1) - 1) : 0;
   } else sh->num_ref_idx_l0 = p->num_ref_idx_l0_default;
-  sh->num_ref_idx_l1 = p->num_ref_idx_l1_default;
   sh->cabac_init_flag = p->cabac_init_present ? rpct(g, 50) : 0;
   sh->max_num_merge_cand = rrange(g, 1, 5);
   sh->slice_qp_delta = rrange(g, -4, 4);
@@ -665,7 +731,7 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
   subs = (orc_bitw *)calloc((size_t)nsub, sizeof(orc_bitw));
   int *seg_first = (int *)calloc((size_t)nsub + 1, sizeof(int)), *seg_addr = (int *)calloc((size_t)nsub + 1, sizeof(int)), nseg = 0;   /* slice segments: first substream, CTB address */
   orc_ctx saved[CTX_COUNT];
-  const int init_type = g->slice_is_intra ? 0 : (sh->cabac_init_flag ? 2 : 1);
+  const int init_type = g->slice_is_intra ? 0 : (g->slice_is_b ? (sh->cabac_init_flag ? 1 : 2) : (sh->cabac_init_flag ? 2 : 1));      /* 9.3.2.2: cabac_init_flag swaps the P and B tables */
   int sub = -1;
   orc_pic_reset_side(&g->side);
   memset(&g->c, 0, sizeof(g->c));
@@ -726,8 +792,15 @@ size_t orc_gen_picture(orc_gen *g, const uint8_t **au)
 {
   const int period = g->cfg.intra_period;
   const int idr = (g->frame_idx == 0) || (period > 0 && (g->frame_idx % period) == 0);
-  if (idr) { g->poc = 0; g->since_idr = 0; } else { g->poc++; g->since_idr++; }
+  if (idr) { g->poc = 0; g->since_idr = 0; g->hist_n = 0; }
+  else {
+    g->since_idr++;
+    if (g->cfg.gop) { const int k = g->since_idr - 1; g->poc = (k / g->cfg.gop) * g->cfg.gop + g->gop_order[k % g->cfg.gop]; }
+    else g->poc++;
+  }
   write_picture(g, idr, idr);
+  for (int i = ORC_MIN(g->hist_n, 7); i > 0; i--) g->hist_poc[i] = g->hist_poc[i - 1];
+  g->hist_poc[0] = g->poc; if (g->hist_n < 8) g->hist_n++;
   g->frame_idx++;
   *au = g->au.buf;
   return g->au.len;

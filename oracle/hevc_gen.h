@@ -44,6 +44,11 @@ typedef struct {
   int tile_cols;              /* tile columns (uniform spacing), 1 (also -1) = none; with columns the slice forms are 0 and 2 */
   int tq_bypass;              /* probability (%) of cu_transquant_bypass_flag = 1; > 0 sets transquant_bypass_enabled_flag (-1 = 0: existing seeds keep their streams) */
   int scaling_lists;          /* 0 (also -1) scaling_list_enabled_flag = 0; 1 enabled with the default lists; 2 lists in the SPS; 3 default in the SPS, lists in the PPS; 4 both */
+  int b_slices;               /* probability (%) that an inter picture is a B slice (both lists, bi-prediction, mvd_l1_zero_flag, collocated_from_l0_flag drawn per
+                               * slice); 0 (also -1): P slices only -- what a Kvazaar peer sends with bipred=1 (kvazaarfilter.cpp:351-371) */
+  int gop;                    /* 0 (also -1, 1): decoding order = output order; 2, 4 or 8: pictures come in groups of this size, the last one first and the ones in
+                               * between in the order of a binary hierarchy (8 4 2 1 3 6 5 7), with references on both sides: output REORDERING
+                               * (sps_max_num_reorder_pics = log2 of the size), what gop=8 makes Kvazaar write */
 } orc_gen_config;
 
 void orc_gen_default_config(orc_gen_config *c);    /* everything random, 416x240 */

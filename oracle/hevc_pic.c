@@ -32,7 +32,7 @@ void orc_pic_reset_side(orc_pic *p)
   memset(p->pred_mode, 255, n); memset(p->ct_depth, 0, n); memset(p->intra_mode, 1, n);
   memset(p->qp_y, 0, n); memset(p->tu_nz, 0, n); memset(p->edge_v, 0, n); memset(p->edge_h, 0, n);
   memset(p->no_filter, 0, n);
-  for (size_t i = 0; i < n; i++) { p->mvf[i].mv[0] = p->mvf[i].mv[1] = 0; p->mvf[i].ref_idx = -1; p->mvf[i].pad = 0; }
+  for (size_t i = 0; i < n; i++) { p->mvf[i].mv[0] = p->mvf[i].mv[1] = 0; p->mvf[i].ref_idx = -1; p->mvf[i].ref_idx1 = -1; p->mvf[i].mv1[0] = p->mvf[i].mv1[1] = 0; }
 }
 
 static int bs_pair(const orc_pic *p, int ip, int iq, int edge_bits)
@@ -40,10 +40,24 @@ static int bs_pair(const orc_pic *p, int ip, int iq, int edge_bits)
   if (p->pred_mode[ip] == MODE_INTRA || p->pred_mode[iq] == MODE_INTRA) return 2;
   if ((edge_bits & 1) && (p->tu_nz[ip] || p->tu_nz[iq])) return 1;
   const orc_mvinfo *a = &p->mvf[ip], *b = &p->mvf[iq];
-  /* uni-prediction from list 0 only in this oracle: compare reference picture and mv */
-  if (p->ref_poc_list[a->ref_idx & 15] != p->ref_poc_list[b->ref_idx & 15]) return 1;      /* different reference pictures (two indices may name one picture) */
-  if (orc_abs(a->mv[0] - b->mv[0]) >= 4 || orc_abs(a->mv[1] - b->mv[1]) >= 4) return 1;
-  return 0;
+  /* 8.7.2.4: the motion of each side as a set of (reference PICTURE, vector) pairs -- which list an index belongs to does not matter, and two indices
+   * may name one picture */
+  int na = 0, nb = 0, pa[2], pb[2]; const int16_t *va[2], *vb[2];
+  if (a->ref_idx >= 0) { pa[na] = p->ref_poc_list[a->ref_idx & 15]; va[na++] = a->mv; }
+  if (a->ref_idx1 >= 0) { pa[na] = p->ref_poc_list1[a->ref_idx1 & 15]; va[na++] = a->mv1; }
+  if (b->ref_idx >= 0) { pb[nb] = p->ref_poc_list[b->ref_idx & 15]; vb[nb++] = b->mv; }
+  if (b->ref_idx1 >= 0) { pb[nb] = p->ref_poc_list1[b->ref_idx1 & 15]; vb[nb++] = b->mv1; }
+#define FAR(u, v) (orc_abs((u)[0] - (v)[0]) >= 4 || orc_abs((u)[1] - (v)[1]) >= 4)
+  if (na != nb) return 1;                                                  /* different number of motion vectors */
+  if (na == 1) return (pa[0] != pb[0] || FAR(va[0], vb[0])) ? 1 : 0;
+  if (!((pa[0] == pb[0] && pa[1] == pb[1]) || (pa[0] == pb[1] && pa[1] == pb[0]))) return 1;      /* different reference pictures */
+  if (pa[0] != pa[1]) {                                                    /* two pictures: the vectors that point into the same picture are compared */
+    if (pa[0] == pb[0]) return (FAR(va[0], vb[0]) || FAR(va[1], vb[1])) ? 1 : 0;
+    return (FAR(va[0], vb[1]) || FAR(va[1], vb[0])) ? 1 : 0;
+  }
+  /* both vectors of both sides point into one picture: either pairing may match */
+  return ((FAR(va[0], vb[0]) || FAR(va[1], vb[1])) && (FAR(va[0], vb[1]) || FAR(va[1], vb[0]))) ? 1 : 0;
+#undef FAR
 }
 
 void orc_compute_bs(const orc_pic *p, uint8_t *bs_v, uint8_t *bs_h)

@@ -9,8 +9,9 @@ extern "C" {
 
 typedef struct {
   int16_t mv[2];        /* L0 motion vector, quarter luma samples */
-  int8_t  ref_idx;      /* L0 reference index, -1 = not inter predicted */
-  int8_t  pad;
+  int8_t  ref_idx;      /* L0 reference index, -1 = list 0 not used (predFlagL0 == 0) */
+  int8_t  ref_idx1;     /* L1 reference index, -1 = list 1 not used (always in I and P slices); both -1 = not inter predicted */
+  int16_t mv1[2];       /* L1 motion vector */
 } orc_mvinfo;
 
 typedef struct {
@@ -18,6 +19,8 @@ typedef struct {
   pixel *plane[3]; int stride[3];
   int poc;
   int is_ref, needed_for_output, in_use;
+  int slice_type;                    /* decoder: of the picture's (last) slice */
+  int out_queued;                    /* decoder: the picture has left the DPB's output process (C.5.2.4) and waits for the caller to fetch it */
   int64_t pts;
   /* per 4x4 luma block side info, stride b4_stride */
   int b4_w, b4_h;
@@ -31,6 +34,7 @@ typedef struct {
   orc_mvinfo *mvf;
   int ref_poc_list[16];              /* POC of RefPicList0[i] of the (single) slice of this picture: boundary strength compares reference PICTURES
                                       * (8.7.2.4), temporal motion vector prediction scales by POC distances (8.5.3.2.9) */
+  int ref_poc_list1[16];             /* ... of RefPicList1[i] (B slices) */
 } orc_pic;
 
 int  orc_pic_alloc(orc_pic *p, int w, int h);

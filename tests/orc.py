@@ -174,11 +174,23 @@ class OracleDecoder:
             r = self.decode_nal(nal, pts)
             if r < 0:
                 raise RuntimeError("oracle decoder error %d" % r)
-            if r > 0:
+            while r > 0:                      # (pictures come in output order: one NAL unit may release several, or none)
                 fr = self.get_frame()
-                if fr is not None:
-                    frames.append(fr)
+                if fr is None:
+                    break
+                frames.append(fr)
         return frames
+
+    def flush(self):
+        """end of stream: the pictures still held back for reordering, in output order"""
+        lib().orc_dec_flush.argtypes = [C.c_void_p]
+        lib().orc_dec_flush(self.p)
+        frames = []
+        while True:
+            fr = self.get_frame()
+            if fr is None:
+                return frames
+            frames.append(fr)
 
     def close(self):
         if self.p:
@@ -192,7 +204,7 @@ class OracleDecoder:
 GEN_FIELDS = ("width", "height", "seed", "intra_period", "qp", "density", "num_refs", "tmvp", "amp", "sao", "strong_intra", "sign_hiding",
               "transform_skip", "cabac_init", "wpp", "tile_rows", "uniform_tiles", "th_depth_inter", "th_depth_intra", "qp_delta",
               "chroma_qp_offsets", "deblock_mode", "par_mrg_level", "intra_in_p", "all_part_modes", "chroma_modes", "nxn_intra",
-              "max_cu_log2", "min_cu_log2", "big_mvd", "slices", "tile_cols", "tq_bypass", "scaling_lists")
+              "max_cu_log2", "min_cu_log2", "big_mvd", "slices", "tile_cols", "tq_bypass", "scaling_lists", "b_slices", "gop")
 
 
 class OracleGen:

@@ -1,13 +1,13 @@
-"""tests/pyhevc.py -- TEST-ONLY second decoder: H.265 Main profile I / P pictures in plain Python + numpy, written from the
+"""tests/pyhevc.py -- TEST-ONLY second decoder: H.265 Main profile I / P / B pictures in plain Python + numpy, written from the
 standard's text independently of oracle/ (C) and of kvazzup_amd/csrc (HIP + host C++).  It exists so that the checker is
 not the only reading of the syntax layer: CABAC context selection (residual_coding, split / skip / part_mode / cbf ...),
 merge and AMVP candidate derivation, cu_qp_delta and the QpY predictor, intra mode derivation, the transform tree, SAO
 syntax, deblocking decisions.  tests/test_python_decoder.py decodes the checker's and the generator's streams with it and
 compares reconstructed pictures with oracle/hevc_dec.c bit for bit.
 
-Scope: 8-bit 4:2:0, CTB 16..64, one slice per picture, I and P slices, tile rows and columns, WPP, every CU size and
+Scope: 8-bit 4:2:0, CTB 16..64, one slice per picture, I, P and B slices (bi-prediction, output in POC order), tile rows and columns, WPP, every CU size and
 partitioning, transform trees, several reference pictures (short-term RPS), TMVP, cu_qp_delta, sign data hiding, transform
-skip, deblocking with offsets, SAO, scaling lists (default / SPS / PPS), cu_transquant_bypass.  No B slices, PCM, long-term pictures, weighted prediction.
+skip, deblocking with offsets, SAO, scaling lists (default / SPS / PPS), cu_transquant_bypass.  No PCM, long-term pictures, weighted prediction.
 Normative tables are typed here per syntax element (initValue: Tables 9-5 .. 9-37); rangeTabLps and the state transition
 tables, the transform matrices and the interpolation filters are passed in by the caller (tests take them from the KAT-checked
 oracle tables: tests/test_oracle_kat.py), so that this file holds logic rather than 400 more typed constants."""
@@ -286,7 +286,7 @@ def parse_pps(rbsp):
     p["sign_hiding"] = r.u(1)
     p["cabac_init_present"] = r.u(1)
     p["nref_default"] = r.ue() + 1
-    r.ue()
+    p["nref1_default"] = r.ue() + 1
     p["init_qp"] = 26 + r.se()
     if r.u(1):
         raise ValueError("constrained intra")
@@ -349,6 +349,7 @@ INIT = {
     "merge_flag": (None, [110], [154]),
     "merge_idx": (None, [122], [137]),
     "ref_idx": (None, [153, 153], [153, 153]),
+    "inter_pred_idc": (None, [95, 79, 63, 31, 31], [95, 79, 63, 31, 31]),
     "mvp": (None, [168], [168]),
     "split_tf": ([153, 138, 138], [124, 138, 94], [224, 167, 122]),
     "cbf_luma": ([111, 141], [153, 111], [153, 111]),
@@ -521,9 +522,9 @@ class Picture:
         self.planes = [np.zeros((h, w), np.int32), np.zeros((h // 2, w // 2), np.int32), np.zeros((h // 2, w // 2), np.int32)]
         self.poc = 0
         b4w, b4h = (w + 3) // 4, (h + 3) // 4
-        self.mv = np.zeros((b4h, b4w, 2), np.int32)
-        self.ref_idx = np.full((b4h, b4w), -1, np.int32)        # -1: intra / not inter
-        self.ref_poc = np.zeros((b4h, b4w), np.int32)           # POC of the reference picture (for deblocking and TMVP)
+        self.mv = np.zeros((b4h, b4w, 2, 2), np.int32)          # [list][x, y]
+        self.ref_idx = np.full((b4h, b4w, 2), -1, np.int32)     # per list; -1: the list is not used (both: intra / not inter)
+        self.ref_poc = np.zeros((b4h, b4w, 2), np.int32)        # POC of the reference picture (for deblocking and TMVP)
         self.is_ref = True
 
 
@@ -537,12 +538,15 @@ class Decoder:
         self.dpb = []
         self.prev_poc_tid0 = 0
         self.out = []
+        self.cvs = 0            # coded video sequences started so far
         self.trace = None       # optional list: ("cu", x, y, log2, pred_mode, part), ("tu", cidx, x, y, log2, [levels...]) ...
 
     # ------------------------------------------------------------------------------------------- NAL level
     def decode(self, stream):
+        """the pictures in OUTPUT order (C.5.2): coded video sequence after coded video sequence, by picture order count inside one"""
         for nal in split_nals(stream):
             self.decode_nal(nal)
+        self.out.sort(key=lambda o: (o["cvs"], o["poc"]))       # (stable; a stream without reordering is in this order already)
         return self.out
 
     def decode_nal(self, nal):
@@ -570,11 +574,9 @@ class Decoder:
         sps = self.sps[pps["sps"]]
         r.u(pps["extra_bits"])
         slice_type = r.ue()          # 0 B, 1 P, 2 I
-        if slice_type == 0:
-            raise ValueError("B slice")
         if pps["output_flag"]:
             r.u(1)
-        sh = {"type": slice_type, "intra": slice_type == 2}
+        sh = {"type": slice_type, "intra": slice_type == 2, "b": slice_type == 0}
         rps = []
         poc = 0
         if not idr:
@@ -602,18 +604,28 @@ class Decoder:
         if sps["sao"]:
             sh["sao_luma"] = r.u(1)
             sh["sao_chroma"] = r.u(1)
-        sh["nref"] = 0
+        sh["nref"] = sh["nref1"] = 0
         sh["cabac_init"] = 0
         sh["col_idx"] = 0
+        sh["col_l0"] = 1
+        sh["mvd_l1_zero"] = 0
         sh["max_merge"] = 5
-        if slice_type == 1:
+        if slice_type != 2:                                        # 7.3.6.1
             sh["nref"] = pps["nref_default"]
+            sh["nref1"] = pps["nref1_default"] if sh["b"] else 0
             if r.u(1):
                 sh["nref"] = r.ue() + 1
+                if sh["b"]:
+                    sh["nref1"] = r.ue() + 1
+            if sh["b"]:
+                sh["mvd_l1_zero"] = r.u(1)
             if pps["cabac_init_present"]:
                 sh["cabac_init"] = r.u(1)
-            if sh["tmvp"] and sh["nref"] > 1:
-                sh["col_idx"] = r.ue()
+            if sh["tmvp"]:
+                if sh["b"]:
+                    sh["col_l0"] = r.u(1)
+                if (sh["nref"] if sh["col_l0"] else sh["nref1"]) > 1:
+                    sh["col_idx"] = r.ue()
             sh["max_merge"] = 5 - r.ue()
         sh["qp"] = pps["init_qp"] + r.se()
         sh["cb_off"] = sh["cr_off"] = 0
@@ -673,8 +685,13 @@ class Decoder:
         for p in self.dpb:
             p.is_ref = p.poc in keep
         self.dpb = [p for p in self.dpb if p.is_ref]
-        cand = [next(p for p in self.dpb if p.poc == q) for q in before + after]
-        refs = [cand[i % len(cand)] for i in range(sh["nref"])] if sh["nref"] else []
+        by_poc = lambda q: next(p for p in self.dpb if p.poc == q)
+        # 8.3.4: list 0 starts with the pictures before the current one, list 1 with the ones after it; short lists repeat
+        c0 = [by_poc(q) for q in before + after]
+        c1 = [by_poc(q) for q in after + before]
+        refs = [[c0[i % len(c0)] for i in range(sh["nref"])] if sh["nref"] else [], [c1[i % len(c1)] for i in range(sh["nref1"])] if sh["nref1"] else []]
+        if idr or self.cvs == 0:
+            self.cvs += 1
         pic = Picture(sps["w"], sps["h"])
         pic.poc = poc
         sh["poc"] = poc
@@ -687,7 +704,7 @@ class Decoder:
         y = pic.planes[0][ct:sps["h"] - cb, cl:sps["w"] - cr_]
         u = pic.planes[1][ct // 2:(sps["h"] - cb) // 2, cl // 2:(sps["w"] - cr_) // 2]
         v = pic.planes[2][ct // 2:(sps["h"] - cb) // 2, cl // 2:(sps["w"] - cr_) // 2]
-        self.out.append({"poc": poc, "i420": np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)]).astype(np.uint8),
+        self.out.append({"poc": poc, "cvs": self.cvs, "i420": np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)]).astype(np.uint8),
                          "width": y.shape[1], "height": y.shape[0]})
 
 
@@ -759,7 +776,7 @@ class SliceDecoder:
     # ------------------------------------------------------------------------------------------- slice data (7.3.8.1)
     def run(self):
         sh, pps = self.sh, self.pps
-        init_type = 0 if sh["intra"] else (2 if sh["cabac_init"] else 1)
+        init_type = 0 if sh["intra"] else ((1 if sh["cabac_init"] else 2) if sh["b"] else (2 if sh["cabac_init"] else 1))      # 9.3.2.2
         self.c = Cabac(self.t, self.data, init_type, sh["qp"])
         c = self.c
         sub = 0
@@ -982,7 +999,7 @@ class SliceDecoder:
                 if self.chroma_pred_mode == modes[0]:
                     self.chroma_pred_mode = 34
             self.luma_modes = modes
-            self.pic.ref_idx[y0 >> 2:(y0 + n) >> 2, x0 >> 2:(x0 + n) >> 2] = -1
+            self.pic.ref_idx[y0 >> 2:(y0 + n) >> 2, x0 >> 2:(x0 + n) >> 2, :] = -1
             rqt = 1
         else:
             self.inter_cu(x0, y0, log2, part)
@@ -1078,46 +1095,76 @@ class SliceDecoder:
             self.mark_edges(x0 + dx, y0 + dy, pw, ph, 1)
 
     def pred_unit(self, xcb, ycb, ncb, xpb, ypb, pw, ph, part_idx, part, merge, midx):
+        """motion of one prediction block as (mv0x, mv0y, ref0, mv1x, mv1y, ref1), a reference index of -1 = the list is not used"""
         c, sh = self.c, self.sh
         if merge:
-            mvx, mvy, ref = self.merge_candidates(xcb, ycb, ncb, xpb, ypb, pw, ph, part_idx, part)[midx]
+            m = self.merge_candidates(xcb, ycb, ncb, xpb, ypb, pw, ph, part_idx, part)[midx]
+            if m[2] >= 0 and m[5] >= 0 and pw + ph == 12:          # 8.5.3.2.2: no bi-prediction of 8x4 / 4x8 blocks
+                m = (m[0], m[1], m[2], 0, 0, -1)
         else:
-            ref = 0
-            if sh["nref"] > 1:
-                if c.bin("ref_idx", 0):
-                    ref = 1
-                    if sh["nref"] > 2 and c.bin("ref_idx", 1):
-                        ref = 2
-                        while ref < sh["nref"] - 1 and c.bypass():
-                            ref += 1
-            gx, gy = c.bin("mvd_gt0"), c.bin("mvd_gt0")
-            g1x = c.bin("mvd_gt1") if gx else 0
-            g1y = c.bin("mvd_gt1") if gy else 0
+            idc = 0                                                 # 0: list 0, 1: list 1, 2: both (9.3.4.2)
+            if sh["b"]:
+                depth = int(self.cu_depth[ycb >> self.sps["min_cb"], xcb >> self.sps["min_cb"]])
+                if pw + ph != 12 and c.bin("inter_pred_idc", depth):
+                    idc = 2
+                else:
+                    idc = c.bin("inter_pred_idc", 4)
 
-            def rest(g0, g1):
-                if not g0:
-                    return 0
-                a = 1
-                if g1:
-                    k = 1
-                    v = 0
-                    while c.bypass():                      # EG1 prefix
-                        v += 1 << k
-                        k += 1
-                    v += c.bypass_bits(k)
-                    a = v + 2
-                return -a if c.bypass() else a
-            dx = rest(gx, g1x)
-            dy = rest(gy, g1y)
-            mvp = c.bin("mvp")
-            px, py = self.amvp_candidates(xcb, ycb, ncb, xpb, ypb, pw, ph, part_idx, ref)[mvp]
+            def ref_index(n):
+                ref = 0
+                if n > 1 and c.bin("ref_idx", 0):
+                    ref = 1
+                    if n > 2 and c.bin("ref_idx", 1):
+                        ref = 2
+                        while ref < n - 1 and c.bypass():
+                            ref += 1
+                return ref
+
+            def mvd():
+                gx, gy = c.bin("mvd_gt0"), c.bin("mvd_gt0")
+                g1x = c.bin("mvd_gt1") if gx else 0
+                g1y = c.bin("mvd_gt1") if gy else 0
+
+                def rest(g0, g1):
+                    if not g0:
+                        return 0
+                    a = 1
+                    if g1:
+                        k = 1
+                        v = 0
+                        while c.bypass():                      # EG1 prefix
+                            v += 1 << k
+                            k += 1
+                        v += c.bypass_bits(k)
+                        a = v + 2
+                    return -a if c.bypass() else a
+                return rest(gx, g1x), rest(gy, g1y)
             wrap = lambda v: ((v + 32768) & 65535) - 32768
-            mvx, mvy = wrap(px + dx), wrap(py + dy)
+            m = [0, 0, -1, 0, 0, -1]
+            for X in (0, 1):
+                if idc == 1 - X:                                   # PRED_L1 skips list 0, PRED_L0 skips list 1
+                    continue
+                ref = ref_index(sh["nref1"] if X else sh["nref"])
+                dx, dy = (0, 0) if (X == 1 and sh["mvd_l1_zero"] and idc == 2) else mvd()
+                mvp = c.bin("mvp")
+                px, py = self.amvp_candidates(xcb, ycb, ncb, xpb, ypb, pw, ph, part_idx, X, ref)[mvp]
+                m[3 * X:3 * X + 3] = [wrap(px + dx), wrap(py + dy), ref]
+            m = tuple(m)
         pic = self.pic
-        pic.mv[ypb >> 2:(ypb + ph) >> 2, xpb >> 2:(xpb + pw) >> 2] = (mvx, mvy)
-        pic.ref_idx[ypb >> 2:(ypb + ph) >> 2, xpb >> 2:(xpb + pw) >> 2] = ref
-        pic.ref_poc[ypb >> 2:(ypb + ph) >> 2, xpb >> 2:(xpb + pw) >> 2] = self.refs[ref].poc
-        self.motion_compensate(xpb, ypb, pw, ph, mvx, mvy, self.refs[ref])
+        ys, xs = slice(ypb >> 2, (ypb + ph) >> 2), slice(xpb >> 2, (xpb + pw) >> 2)
+        for X in (0, 1):
+            ref = m[3 * X + 2]
+            pic.mv[ys, xs, X] = (m[3 * X], m[3 * X + 1]) if ref >= 0 else (0, 0)
+            pic.ref_idx[ys, xs, X] = ref
+            pic.ref_poc[ys, xs, X] = self.refs[X][ref].poc if ref >= 0 else 0
+        preds = [self.motion_compensate(xpb, ypb, pw, ph, m[3 * X], m[3 * X + 1], self.refs[X][m[3 * X + 2]]) for X in (0, 1) if m[3 * X + 2] >= 0]
+        for ci in range(3):
+            sx = 1 if ci else 0
+            if len(preds) == 2:                                    # 8.5.3.3.4.2: the rounded mean of the two 14-bit predictions
+                v = (preds[0][ci] + preds[1][ci] + 64) >> 7
+            else:
+                v = (preds[0][ci] + 32) >> 6
+            self.pic.planes[ci][ypb >> sx:(ypb + ph) >> sx, xpb >> sx:(xpb + pw) >> sx] = np.clip(v, 0, 255)
 
     # 6.4.2 prediction block availability
     def pb_avail(self, xcb, ycb, ncb, xpb, ypb, pw, ph, part_idx, xn, yn):
@@ -1132,24 +1179,36 @@ class SliceDecoder:
         return a
 
     def motion(self, x, y):
-        return (int(self.pic.mv[y >> 2, x >> 2, 0]), int(self.pic.mv[y >> 2, x >> 2, 1]), int(self.pic.ref_idx[y >> 2, x >> 2]))
+        """(mv0x, mv0y, ref0, mv1x, mv1y, ref1) of the 4x4 block at (x, y); the vector of an unused list reads as zero"""
+        mv, ri = self.pic.mv[y >> 2, x >> 2], self.pic.ref_idx[y >> 2, x >> 2]
+        return (int(mv[0, 0]), int(mv[0, 1]), int(ri[0]), int(mv[1, 0]), int(mv[1, 1]), int(ri[1]))
 
-    def temporal(self, xpb, ypb, pw, ph, ref_idx):
-        """8.5.3.2.8: P slices, list 0 only; returns (mvx, mvy) or None"""
-        if not self.sh["tmvp"]:
+    def temporal(self, xpb, ypb, pw, ph, X, ref_idx):
+        """8.5.3.2.8: temporal candidate of list X for reference index ref_idx; returns (mvx, mvy) or None"""
+        sh = self.sh
+        if not sh["tmvp"]:
             return None
-        col = self.refs[self.sh["col_idx"]]
-        cur_diff = self.sh["poc"] - self.refs[ref_idx].poc
+        col = self.refs[0 if (not sh["b"] or sh["col_l0"]) else 1][sh["col_idx"]]
+        cur_diff = sh["poc"] - self.refs[X][ref_idx].poc
+        # NoBackwardPredFlag: no picture of either list comes after the current one in output order
+        no_backward = all(p.poc <= sh["poc"] for lst in self.refs for p in lst)
         for k, (x, y) in enumerate([(xpb + pw, ypb + ph), (xpb + (pw >> 1), ypb + (ph >> 1))]):
             if k == 0 and not ((ypb >> self.ctb_log2) == (y >> self.ctb_log2) and y < self.h and x < self.w):
                 continue
             x, y = (x >> 4) << 4, (y >> 4) << 4
             if x >= self.w or y >= self.h:
                 continue
-            if col.ref_idx[y >> 2, x >> 2] < 0:
+            ri = col.ref_idx[y >> 2, x >> 2]
+            if ri[0] < 0 and ri[1] < 0:
                 continue
-            mvx, mvy = int(col.mv[y >> 2, x >> 2, 0]), int(col.mv[y >> 2, x >> 2, 1])
-            col_diff = col.poc - int(col.ref_poc[y >> 2, x >> 2])
+            if ri[0] < 0:
+                L = 1
+            elif ri[1] < 0:
+                L = 0
+            else:
+                L = X if no_backward else sh["col_l0"]            # (8.5.3.2.9: "mvCol ... set equal to mvLNCol ... with N being the value of collocated_from_l0_flag")
+            mvx, mvy = int(col.mv[y >> 2, x >> 2, L, 0]), int(col.mv[y >> 2, x >> 2, L, 1])
+            col_diff = col.poc - int(col.ref_poc[y >> 2, x >> 2, L])
             if col_diff != cur_diff and col_diff != 0:
                 mvx, mvy = self.scale(mvx, mvy, col_diff, cur_diff)
             return (mvx, mvy)
@@ -1170,6 +1229,7 @@ class SliceDecoder:
 
     def merge_candidates(self, xcb, ycb, ncb, xpb, ypb, pw, ph, part_idx, part):
         lvl = self.pps["par_mrg"]
+        sh = self.sh
         if lvl > 2 and ncb == 8:
             xpb, ypb, pw, ph, part_idx, part = xcb, ycb, ncb, ncb, 0, PART_2Nx2N
         par = lambda xn, yn: (xpb >> lvl) == (xn >> lvl) and (ypb >> lvl) == (yn >> lvl)
@@ -1198,59 +1258,82 @@ class SliceDecoder:
             (int(av["A1"]) + int(b1_in) + int(b0_in) + int(a0_in) != 4)
         if b2_in:
             out.append(mo["B2"])
-        mx = self.sh["max_merge"]
+        mx = sh["max_merge"]
+        out = out[:mx]
         if len(out) < mx:
-            t = self.temporal(xpb, ypb, pw, ph, 0)
-            if t is not None:
-                out.append((t[0], t[1], 0))
+            t0 = self.temporal(xpb, ypb, pw, ph, 0, 0)
+            t1 = self.temporal(xpb, ypb, pw, ph, 1, 0) if sh["b"] else None
+            if t0 is not None or t1 is not None:
+                out.append(((t0 or (0, 0))[0], (t0 or (0, 0))[1], 0 if t0 is not None else -1, (t1 or (0, 0))[0], (t1 or (0, 0))[1], 0 if t1 is not None else -1))
+        if sh["b"] and 1 < len(out) < mx:
+            # 8.5.3.2.4: pairs (l0Cand, l1Cand) in the order of Table 8-7
+            orig = len(out)
+            pairs = [(0, 1), (1, 0), (0, 2), (2, 0), (1, 2), (2, 1), (0, 3), (3, 0), (1, 3), (3, 1), (2, 3), (3, 2)]
+            for i0, i1 in pairs[:orig * (orig - 1)]:
+                if len(out) == mx:
+                    break
+                a, b = out[i0], out[i1]
+                if a[2] < 0 or b[5] < 0:
+                    continue
+                if self.refs[0][a[2]].poc == self.refs[1][b[5]].poc and (a[0], a[1]) == (b[3], b[4]):
+                    continue
+                out.append((a[0], a[1], a[2], b[3], b[4], b[5]))
         z = 0
+        nz = min(sh["nref"], sh["nref1"]) if sh["b"] else sh["nref"]
         while len(out) < mx:
-            out.append((0, 0, z if z < self.sh["nref"] else 0))
+            r = z if z < nz else 0
+            out.append((0, 0, r, 0, 0, r if sh["b"] else -1))
             z += 1
         return out
 
-    def amvp_candidates(self, xcb, ycb, ncb, xpb, ypb, pw, ph, part_idx, ref_idx):
-        target = self.refs[ref_idx].poc
+    def amvp_candidates(self, xcb, ycb, ncb, xpb, ypb, pw, ph, part_idx, X, ref_idx):
+        target = self.refs[X][ref_idx].poc
         cur = self.sh["poc"]
         a_pos = [(xpb - 1, ypb + ph), (xpb - 1, ypb + ph - 1)]
         b_pos = [(xpb + pw, ypb - 1), (xpb + pw - 1, ypb - 1), (xpb - 1, ypb - 1)]
         av_a = [self.pb_avail(xcb, ycb, ncb, xpb, ypb, pw, ph, part_idx, x, y) for x, y in a_pos]
         av_b = [self.pb_avail(xcb, ycb, ncb, xpb, ypb, pw, ph, part_idx, x, y) for x, y in b_pos]
         is_scaled = av_a[0] or av_a[1]
+
+        def vectors(pos):
+            """the neighbour's vectors as (mvx, mvy, POC of the picture they point into), list X's first"""
+            mo = self.motion(*pos)
+            return [(mo[3 * L], mo[3 * L + 1], self.refs[L][mo[3 * L + 2]].poc) for L in (X, 1 - X) if mo[3 * L + 2] >= 0]
+
+        def same_picture(pos):
+            for mx, my, poc in vectors(pos):
+                if poc == target:
+                    return (mx, my)
+            return None
+
+        def any_picture(pos):
+            for mx, my, poc in vectors(pos):
+                return (mx, my) if poc == target else self.scale(mx, my, cur - poc, cur - target)
+            return None
         a = b = None
         for k in range(2):
             if av_a[k] and a is None:
-                mx, my, r = self.motion(*a_pos[k])
-                if self.refs[r].poc == target:
-                    a = (mx, my)
+                a = same_picture(a_pos[k])
         for k in range(2):
             if av_a[k] and a is None:
-                mx, my, r = self.motion(*a_pos[k])
-                a = (mx, my)
-                if self.refs[r].poc != target:
-                    a = self.scale(mx, my, cur - self.refs[r].poc, cur - target)
+                a = any_picture(a_pos[k])
         for k in range(3):
             if av_b[k] and b is None:
-                mx, my, r = self.motion(*b_pos[k])
-                if self.refs[r].poc == target:
-                    b = (mx, my)
+                b = same_picture(b_pos[k])
         if not is_scaled and b is not None and a is None:
             a = b
         if not is_scaled:
             b = None
             for k in range(3):
                 if av_b[k] and b is None:
-                    mx, my, r = self.motion(*b_pos[k])
-                    b = (mx, my)
-                    if self.refs[r].poc != target:
-                        b = self.scale(mx, my, cur - self.refs[r].poc, cur - target)
+                    b = any_picture(b_pos[k])
         out = []
         if a is not None:
             out.append(a)
         if b is not None and not (a is not None and a == b):
             out.append(b)
         if len(out) < 2:
-            t = self.temporal(xpb, ypb, pw, ph, ref_idx)
+            t = self.temporal(xpb, ypb, pw, ph, X, ref_idx)
             if t is not None:
                 out.append(t)
         while len(out) < 2:
@@ -1259,6 +1342,7 @@ class SliceDecoder:
 
     # ------------------------------------------------------------------------------------------- 8.5.3.3 sample interpolation
     def motion_compensate(self, x0, y0, pw, ph, mvx, mvy, ref):
+        """the three planes' prediction sample arrays at 14-bit precision (8.5.3.3.3), before the weighted sample prediction"""
         lf, cf = self.t["luma_filter"], self.t["chroma_filter"]
 
         def fetch(plane, xs, ys):
@@ -1280,11 +1364,10 @@ class SliceDecoder:
                 return sum(int(filt[fy][k]) * cols[k:k + h] for k in range(taps))
             tmp = sum(int(filt[fx][k]) * win[:, k:k + w] for k in range(taps))
             return sum(int(filt[fy][k]) * tmp[k:k + h] for k in range(taps)) >> 6
-        p = interp(ref.planes[0], x0 + (mvx >> 2), y0 + (mvy >> 2), mvx & 3, mvy & 3, pw, ph, lf, 8)
-        self.pic.planes[0][y0:y0 + ph, x0:x0 + pw] = np.clip((p + 32) >> 6, 0, 255)
+        out = [interp(ref.planes[0], x0 + (mvx >> 2), y0 + (mvy >> 2), mvx & 3, mvy & 3, pw, ph, lf, 8)]
         for ci in (1, 2):
-            p = interp(ref.planes[ci], (x0 >> 1) + (mvx >> 3), (y0 >> 1) + (mvy >> 3), mvx & 7, mvy & 7, pw >> 1, ph >> 1, cf, 4)
-            self.pic.planes[ci][y0 >> 1:(y0 + ph) >> 1, x0 >> 1:(x0 + pw) >> 1] = np.clip((p + 32) >> 6, 0, 255)
+            out.append(interp(ref.planes[ci], (x0 >> 1) + (mvx >> 3), (y0 >> 1) + (mvy >> 3), mvx & 7, mvy & 7, pw >> 1, ph >> 1, cf, 4))
+        return out
 
     # ------------------------------------------------------------------------------------------- transform tree (7.3.8.8)
     def transform_tree(self, x0, y0, xb, yb, log2, depth, blk, pcb, pcr, intra_split, cu_log2):
@@ -1610,17 +1693,28 @@ class SliceDecoder:
         sh = self.sh
         Y = pic.planes[0]
 
+        def motion_set(x, y):
+            """the block's motion as a list of (reference picture, mvx, mvy) -- 8.7.2.4 looks at pictures, not at lists or indices"""
+            return [(int(pic.ref_poc[y >> 2, x >> 2, L]), int(pic.mv[y >> 2, x >> 2, L, 0]), int(pic.mv[y >> 2, x >> 2, L, 1]))
+                    for L in (0, 1) if pic.ref_idx[y >> 2, x >> 2, L] >= 0]
+
         def bs_of(xq, yq, xp, yp, tu_edge):
-            if pic.ref_idx[yq >> 2, xq >> 2] < 0 or pic.ref_idx[yp >> 2, xp >> 2] < 0:
+            q, p_ = motion_set(xq, yq), motion_set(xp, yp)
+            if not q or not p_:
                 return 2
             if tu_edge and (self.tu_nz[yq >> 2, xq >> 2] or self.tu_nz[yp >> 2, xp >> 2]):
                 return 1
-            if pic.ref_poc[yq >> 2, xq >> 2] != pic.ref_poc[yp >> 2, xp >> 2]:
-                return 1
-            mq, mp = pic.mv[yq >> 2, xq >> 2], pic.mv[yp >> 2, xp >> 2]
-            if abs(int(mq[0]) - int(mp[0])) >= 4 or abs(int(mq[1]) - int(mp[1])) >= 4:
-                return 1
-            return 0
+            if len(q) != len(p_) or sorted(m[0] for m in q) != sorted(m[0] for m in p_):
+                return 1                                               # a different number of vectors, or different reference pictures
+            far = lambda a, b: abs(a[1] - b[1]) >= 4 or abs(a[2] - b[2]) >= 4
+            if len(q) == 1:
+                return 1 if far(q[0], p_[0]) else 0
+            if q[0][0] != q[1][0]:                                     # two pictures: each vector against the other block's vector into the same picture
+                other = p_ if p_[0][0] == q[0][0] else [p_[1], p_[0]]
+                return 1 if far(q[0], other[0]) or far(q[1], other[1]) else 0
+            straight = far(q[0], p_[0]) or far(q[1], p_[1])            # both vectors into one picture: either pairing may be the close one
+            crossed = far(q[0], p_[1]) or far(q[1], p_[0])
+            return 1 if straight and crossed else 0
         for vertical in (True, False):
             edges = self.edge_v if vertical else self.edge_h
             bs_map = {}

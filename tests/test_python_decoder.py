@@ -23,7 +23,7 @@ def test_context_init_values_agree_with_the_checker_and_the_product():
     init = table(3, np.uint8, (3, 154)).astype(int)
     # order of the checker's / product's context indices (hevc_core.h CTX_*)
     order = [("sao_merge", 1), ("sao_type", 1), ("split_cu", 3), ("tq_bypass", 1), ("skip", 3), ("pred_mode", 1), ("part_mode", 4), ("prev_intra", 1),
-             ("chroma_mode", 1), ("rqt_root", 1), ("merge_flag", 1), ("merge_idx", 1), (None, 5), ("ref_idx", 2), ("mvp", 1), ("split_tf", 3),
+             ("chroma_mode", 1), ("rqt_root", 1), ("merge_flag", 1), ("merge_idx", 1), ("inter_pred_idc", 5), ("ref_idx", 2), ("mvp", 1), ("split_tf", 3),
              ("cbf_luma", 2), ("cbf_chroma", 4), ("mvd_gt0", 1), ("mvd_gt1", 1), ("qp_delta", 2), ("ts_flag", 2), ("last_x", 18), ("last_y", 18),
              ("csbf", 4), ("sig", 42), ("gt1", 24), ("gt2", 6)]
     at = 0
@@ -44,6 +44,7 @@ def decode_both(aus):
     want = []
     for au in aus:
         want += od.decode_au(au)
+    want += od.flush()                       # (pictures held back for reordering)
     od.close()
     pd = pyhevc.Decoder(tabs())
     for au in aus:
@@ -153,3 +154,33 @@ def test_generator_tile_columns(cols, rows, wpp, uniform):
     aus = [gen.picture() for _ in range(4)]
     gen.close()
     compare(aus)
+
+
+B_CASES = [
+    dict(b_slices=70),                                                       # low-delay B: both lists hold the same pictures (Kvazaar bipred=1 with its default low-delay GOP)
+    dict(b_slices=60, gop=4, tmvp=1),                                        # groups of four, decoded 4 2 1 3: references on both sides, collocated pictures out of either list
+    dict(b_slices=50, gop=8, num_refs=4, tmvp=1, amp=1, all_part_modes=1),   # Kvazaar gop=8: three pictures held back for output; 8x4 / 4x8 blocks (never bi-predicted)
+    dict(b_slices=80, gop=2, num_refs=3, tmvp=1, par_mrg_level=4, cabac_init=1),
+    dict(b_slices=0, gop=4, num_refs=3, tmvp=1),                             # reordered P pictures: a P slice whose collocated block is... still uni-predicted, but forward references exist
+    dict(b_slices=100, gop=8, num_refs=4, tmvp=1, sao=1, qp_delta=2, wpp=1, tile_rows=2, intra_in_p=15),
+]
+
+
+@pytest.mark.parametrize("kw", B_CASES, ids=lambda kw: "-".join("%s%s" % (k[:3], v) for k, v in kw.items()))
+@pytest.mark.parametrize("seed", (301, 302, 303))
+def test_generator_b_slices_and_reordering(kw, seed):
+    """B slices as a uvgComm peer produces them through Kvazaar's custom parameters (bipred=1, gop=8 -- kvazaarfilter.cpp:351-371), read from the
+    standard's text a second time: inter_pred_idc, the two reference lists, mvd_l1_zero_flag, merge candidates with the combined bi-predictive
+    and two-list zero candidates, AMVP across lists, the temporal candidate out of a bi-predicted collocated block (NoBackwardPredFlag,
+    collocated_from_l0_flag), the rounded average of two 14-bit predictions, boundary strength with two vectors per side, and pictures handed
+    out in POC order rather than decoding order"""
+    cfg = dict(width=136 + 8 * (seed % 9), height=72 + 8 * (seed % 5), seed=seed, density=25, intra_period=9)
+    cfg.update(kw)
+    gen = orc.OracleGen(**cfg)
+    aus = [gen.picture() for _ in range(11)]
+    gen.close()
+    want, got = decode_both(aus)
+    compare(aus)
+    assert [f["poc"] for f in want] == sorted(f["poc"] for f in want[:9]) + sorted(f["poc"] for f in want[9:])      # output order: by POC inside each coded video sequence
+    if kw["b_slices"]:
+        assert any(f["slice_type"] == 0 for f in want)

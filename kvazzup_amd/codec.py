@@ -235,14 +235,21 @@ class Decoder:
         return [f for f in (self.decode_nal(n, pts) for n in split_nals(au)) if f is not None]
 
     def drain(self):
-        """frame threads: end-of-sequence NAL units hand out the pictures still held back"""
+        """end-of-sequence NAL units hand out the pictures still held back: by the frame threads' ring, and -- a stream whose SPS allows
+        reordering (B pictures in groups) -- by the output process, which lets go of them in POC order"""
         out = []
-        if self.frame_threads:
-            eos = bytes([0, 0, 0, 1, 36 << 1, 1])
-            for _ in range(self.threads + 1):
-                f = self.decode_nal(eos)
-                if f is not None:
-                    out.append(f)
+        ring = (self.threads + 1) if self.frame_threads else 1
+        eos = bytes([0, 0, 0, 1, 36 << 1, 1])
+        misses = 0
+        for _ in range(ring + 20):                  # (ring + sps_max_num_reorder_pics <= 15 + slack)
+            f = self.decode_nal(eos)
+            if f is not None:
+                out.append(f)
+                misses = 0
+            else:
+                misses += 1
+                if misses > ring:
+                    break
         return out
 
     def output_device(self):

@@ -16,12 +16,17 @@ namespace kvzx {
 // (8.7.2.4) -- transform / prediction block edges on the 8x8 grid, "transform block has coefficients", QpY
 struct B4Rec {
   int16_t mvx, mvy;        // quarter luma samples
-  int8_t ref_idx;          // index into RefPicList0; -1 = intra (host: also what merge candidates compare, 8.5.3.2.3)
+  int8_t ref_idx;          // index into RefPicList0; -1 = intra (host: also what merge candidates compare, 8.5.3.2.3).  B slices: >= 0 = inter, the vector and
+                           // slot are those of list 0 when it is used, else list 1's (a uni-predicted block is the same to the kernels either way)
   uint8_t flags;           // B4_*
   int8_t qp_y;             // QpY of the coding unit (8.6.1)
   uint8_t slot;            // picture buffer of the reference picture: two indices naming one picture share it (8.7.2.4 compares pictures)
 };
-enum { B4_BYPASS = 32,      // cu_transquant_bypass_flag: the loop filters leave this block's samples as they are (8.7.2.5.7, 8.7.3)
+// the SECOND motion of a bi-predicted block (B4_BI; B slices): the list-1 vector and its picture buffer.  An array of its own beside b4[], present
+// only in pictures that hold such a block -- P pictures, every picture of a default Kvazaar peer, never pay for it
+struct B4L1 { int16_t mvx, mvy; uint8_t slot; uint8_t pad[3]; };
+enum { B4_BI = 64,          // bi-predicted: b4x[] holds the second vector (B4Rec: list 0's)
+       B4_BYPASS = 32,      // cu_transquant_bypass_flag: the loop filters leave this block's samples as they are (8.7.2.5.7, 8.7.3)
        B4_NZ = 1,          // the luma transform block covering this 4x4 has non-zero coefficients
        B4_EDGE_V = 2,      // the left edge of this 4x4 is a transform-block or prediction-block edge
        B4_TU_V = 4,        //   ... a transform-block edge
@@ -52,6 +57,7 @@ struct DecFrame {
   int wc, hc;               // CTUs (64 x 64) per row / column, partial ones included
   int row0, nrows;          // band of CTU rows the launch works on (nrows == 0: the whole picture): tile-row split over several decoders
   const B4Rec *b4;          // [ph / 4][pw / 4]
+  const B4L1 *b4x;          // [ph / 4][pw / 4] second vectors of the B4_BI blocks, NULL: the picture has none
   const TuRange *region;      // per 32x32 luma region (raster, pitch 2 * wc): {first transform block, count} in tus[]
   const TuRange *ctu;        // per CTU (raster): {first transform block, count | intra-planes mask << 24}
   const DecTu *tus; const uint32_t *lev;

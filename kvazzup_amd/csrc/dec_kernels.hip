@@ -74,6 +74,33 @@ __device__ __forceinline__ int mc_luma_px(const uint8_t *p, int pitch, int w, in
   }
   return clip8((v + 32) >> 6);
 }
+// the same sample at the 14-bit precision of 8.5.3.3.3, before the weighted sample prediction: what bi-prediction averages (8.5.3.3.4.2)
+__device__ __forceinline__ int mc_luma_14(const uint8_t *p, int pitch, int w, int h, int x, int y, int mvx, int mvy)
+{
+  const int xf = mvx & 3, yf = mvy & 3, xi = x + (mvx >> 2), yi = y + (mvy >> 2);
+  int v = 0;
+  if (!xf && !yf) return refpx(p, pitch, w, h, xi, yi) << 6;
+  if (!yf) { for (int i = 0; i < 8; i++) v += kLumaFilter[xf][i] * refpx(p, pitch, w, h, xi + i - 3, yi); return v; }
+  if (!xf) { for (int i = 0; i < 8; i++) v += kLumaFilter[yf][i] * refpx(p, pitch, w, h, xi, yi + i - 3); return v; }
+  for (int j = 0; j < 8; j++) {
+    int t = 0;
+    for (int i = 0; i < 8; i++) t += kLumaFilter[xf][i] * refpx(p, pitch, w, h, xi + i - 3, yi + j - 3);
+    v += kLumaFilter[yf][j] * t;
+  }
+  return v >> 6;
+}
+// ... and a chroma sample (vector in 1/8 samples; the separable form with the {0, 64, 0, 0} filter at fraction 0 is exact for every case)
+__device__ __forceinline__ int mc_chroma_14(const uint8_t *p, int pitch, int w, int h, int x, int y, int mvx, int mvy)
+{
+  const int xf = mvx & 7, yf = mvy & 7, xi = x + (mvx >> 3) - 1, yi = y + (mvy >> 3) - 1;
+  int v = 0;
+  for (int j = 0; j < 4; j++) {
+    int t = 0;
+    for (int i = 0; i < 4; i++) t += kChromaFilter[xf][i] * refpx(p, pitch, w, h, xi + i, yi + j);
+    v += kChromaFilter[yf][j] * t;
+  }
+  return v >> 6;
+}
 // four luma samples (x .. x + 3, y) with one INTEGER vector, packed little-endian
 __device__ __forceinline__ uint32_t mc_luma4_int(const uint8_t *p, int pitch, int w, int h, int x, int y, int mvx, int mvy)
 {
@@ -101,6 +128,7 @@ struct DecInterLds {
   alignas(16) int8_t M8[32 * 32]; int rowsum[32];        // transposed 32-point matrix as int8 + its row sums (MFMA operands)
   alignas(16) uint8_t px[1024 + 512];                    // prediction, then reconstruction: luma 32x32 raster; Cb, Cr 16x16 each
   B4Rec recs[64];
+  B4L1 recx[64];                                         // the second vectors of the region's bi-predicted blocks (B4_BI; pictures with f.b4x)
   uint8_t cflag[16];                                     // per 8x8 cell: bit0 inter, bit1 one motion for the whole cell, bit2 fractional luma vector
   alignas(16) uint8_t lwin[16][15 * 16];                 // fractional luma: per cell the 15 x 15 reference window ...
   int ltmp[16][15 * 8];                                  // ... and its horizontally filtered rows (32-bit: see enc_kernels.hip InterLds)
@@ -152,6 +180,7 @@ template <class F> __device__ __forceinline__ void dec_inter_body(const F &f, co
     B4Rec r; r.mvx = 0; r.mvy = 0; r.ref_idx = -1; r.flags = 0; r.qp_y = 0; r.slot = 0;
     if (X < f.w && Y < f.h) r = f.b4[(size_t)(Y >> 2) * b4w + (X >> 2)];
     s.recs[tid] = r;
+    if (f.b4x && (r.flags & B4_BI)) s.recx[tid] = f.b4x[(size_t)(Y >> 2) * b4w + (X >> 2)];
   }
   if (tid >= 64 && tid < 80) ((uint32_t *)s.mask)[tid - 64] = 0;
   __syncthreads();
@@ -160,7 +189,7 @@ template <class F> __device__ __forceinline__ void dec_inter_body(const F &f, co
   {
     const B4Rec r0 = s.recs[0];
     bool same = true;
-    if (tid < 64) { const B4Rec r = s.recs[tid]; same = r.ref_idx == r0.ref_idx && r.slot == r0.slot && r.mvx == 0 && r.mvy == 0; }
+    if (tid < 64) { const B4Rec r = s.recs[tid]; same = r.ref_idx == r0.ref_idx && r.slot == r0.slot && r.mvx == 0 && r.mvy == 0 && !(r.flags & B4_BI); }
     if (__syncthreads_and(same) && r0.ref_idx >= 0 && reg.count == 0) {
       const int slot = r0.slot & 15;
       {
@@ -183,7 +212,8 @@ template <class F> __device__ __forceinline__ void dec_inter_body(const F &f, co
     const bool uni = a.mvx == b.mvx && a.mvx == c.mvx && a.mvx == d.mvx && a.mvy == b.mvy && a.mvy == c.mvy && a.mvy == d.mvy &&
                      a.slot == b.slot && a.slot == c.slot && a.slot == d.slot;
     const bool frac = ((a.mvx | a.mvy | b.mvx | b.mvy | c.mvx | c.mvy | d.mvx | d.mvy) & 3) != 0;
-    s.cflag[tid] = (uint8_t)((inter ? 1 : 0) | (uni ? 2 : 0) | (frac ? 4 : 0));
+    const bool bi = ((a.flags | b.flags | c.flags | d.flags) & B4_BI) != 0;      // a cell with a bi-predicted block takes the general path below (bit 3), none of the window forms
+    s.cflag[tid] = (uint8_t)(bi ? ((inter ? 1 : 0) | 8) : ((inter ? 1 : 0) | (uni ? 2 : 0) | (frac ? 4 : 0)));
   }
   if (tid >= 64 && tid - 64 < ntu) {
     const int t = tid - 64;
@@ -232,7 +262,21 @@ template <class F> __device__ __forceinline__ void dec_inter_body(const F &f, co
     const int y = tid >> 3, x = (tid & 7) * 4, cell = (y >> 3) * 4 + (x >> 3), cf = s.cflag[cell];
     const B4Rec m = s.recs[(y >> 2) * 8 + (x >> 2)];
     uint32_t p4 = 0;
-    if (cf & 1) {
+    if (cf & 8) {
+      // B pictures: every 4x4 unit by itself, each sample at 14 bits from one list or the rounded mean of both (8.5.3.3.4.2)
+      if (m.ref_idx >= 0) {
+        const uint8_t *r0 = f.ref[m.slot & 15][0];
+        const bool bi = (m.flags & B4_BI) != 0;
+        const B4L1 m1 = s.recx[(y >> 2) * 8 + (x >> 2)];
+        const uint8_t *r1 = f.ref[m1.slot & 15][0];
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) {
+          const int a = mc_luma_14(r0, f.pw, f.w, f.h, x0 + x + i, y0 + y, m.mvx, m.mvy);
+          const int v = bi ? (a + mc_luma_14(r1, f.pw, f.w, f.h, x0 + x + i, y0 + y, m1.mvx, m1.mvy) + 64) >> 7 : (a + 32) >> 6;
+          p4 |= (uint32_t)clip8(v) << (8 * i);
+        }
+      }
+    } else if (cf & 1) {
       const uint8_t *rp = f.ref[m.slot & 15][0];
       if (!((m.mvx | m.mvy) & 3)) p4 = mc_luma4_int(rp, f.pw, f.w, f.h, x0 + x, y0 + y, m.mvx, m.mvy);
       else if ((cf & 6) == 6) {
@@ -271,7 +315,20 @@ template <class F> __device__ __forceinline__ void dec_inter_body(const F &f, co
     const int pl = tid >> 7, y = (tid >> 3) & 15, x = (tid & 7) * 2, cell = (y >> 2) * 4 + (x >> 2), cf = s.cflag[cell];
     const B4Rec m = s.recs[(y >> 1) * 8 + (x >> 1)];
     int p0 = 0, p1 = 0;
-    if (cf & 1) {
+    if (cf & 8) {
+      if (m.ref_idx >= 0) {
+        const bool bi = (m.flags & B4_BI) != 0;
+        const B4L1 m1 = s.recx[(y >> 1) * 8 + (x >> 1)];
+        const uint8_t *r0 = f.ref[m.slot & 15][1 + pl], *r1 = f.ref[m1.slot & 15][1 + pl];
+        int v[2];
+#pragma unroll 1
+        for (int i = 0; i < 2; i++) {
+          const int a = mc_chroma_14(r0, cpitch, wC, hC, (x0 >> 1) + x + i, (y0 >> 1) + y, m.mvx, m.mvy);
+          v[i] = clip8(bi ? (a + mc_chroma_14(r1, cpitch, wC, hC, (x0 >> 1) + x + i, (y0 >> 1) + y, m1.mvx, m1.mvy) + 64) >> 7 : (a + 32) >> 6);
+        }
+        p0 = v[0]; p1 = v[1];
+      }
+    } else if (cf & 1) {
       const int xf = m.mvx & 7, yf = m.mvy & 7;
       int v0 = 0, v1 = 0;
       const uint8_t *rp = f.ref[m.slot & 15][1 + pl];
@@ -735,13 +792,25 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
 // Deblocking (8.7.2): both passes in one launch, one workgroup per 64x64 tile shifted by (-4, -4) against the CTU grid
 // (enc_kernels.hip k_deblock_tile has the geometry argument); boundary strengths from the 4x4 records
 // =============================================================================================
-__device__ __forceinline__ int dec_bs(const B4Rec &p, const B4Rec &q, bool tu_edge)
+// px / qx: where the second vectors of p / q are when they are bi-predicted (B4_BI; B pictures)
+__device__ __forceinline__ int dec_bs(const B4Rec &p, const B4Rec &q, bool tu_edge, const B4L1 *px = nullptr, const B4L1 *qx = nullptr)
 {
   if (p.ref_idx < 0 || q.ref_idx < 0) return 2;
   if (tu_edge && ((p.flags | q.flags) & B4_NZ)) return 1;
-  if (p.slot != q.slot) return 1;                          // different reference pictures
-  if (iabs(p.mvx - q.mvx) >= 4 || iabs(p.mvy - q.mvy) >= 4) return 1;
-  return 0;
+  if ((p.flags ^ q.flags) & B4_BI) return 1;              // a different number of motion vectors
+  if (!(p.flags & B4_BI)) {
+    if (p.slot != q.slot) return 1;                        // different reference pictures (8.7.2.4 looks at pictures: which list or index names them does not matter)
+    if (iabs(p.mvx - q.mvx) >= 4 || iabs(p.mvy - q.mvy) >= 4) return 1;
+    return 0;
+  }
+  const B4L1 p1 = *px, q1 = *qx;
+  auto far = [](int ax, int ay, int bx, int by) { return iabs(ax - bx) >= 4 || iabs(ay - by) >= 4; };
+  const bool straight = p.slot == q.slot && p1.slot == q1.slot, crossed = p.slot == q1.slot && p1.slot == q.slot;
+  if (!straight && !crossed) return 1;                     // different reference pictures
+  if (p.slot != p1.slot)                                   // two pictures: the vectors into the same picture are compared
+    return straight ? (far(p.mvx, p.mvy, q.mvx, q.mvy) || far(p1.mvx, p1.mvy, q1.mvx, q1.mvy)) : (far(p.mvx, p.mvy, q1.mvx, q1.mvy) || far(p1.mvx, p1.mvy, q.mvx, q.mvy));
+  // all four vectors point into one picture: either pairing may be the close one
+  return (far(p.mvx, p.mvy, q.mvx, q.mvy) || far(p1.mvx, p1.mvy, q1.mvx, q1.mvy)) && (far(p.mvx, p.mvy, q1.mvx, q1.mvy) || far(p1.mvx, p1.mvy, q.mvx, q.mvy));
 }
 
 template <class F> __device__ __forceinline__ void dec_deblock_body(const F &f, const Wg wg)
@@ -771,7 +840,7 @@ template <class F> __device__ __forceinline__ void dec_deblock_body(const F &f, 
     if (x > 0 && x < f.w && y >= 0 && y < f.h) {
       const int uq = unit(x, y);
       const B4Rec q = recs[uq], p = recs[uq - 1];
-      if (q.flags & B4_EDGE_V) { bsv = dec_bs(p, q, (q.flags & B4_TU_V) != 0); qpv = (p.qp_y + q.qp_y + 1) >> 1; }
+      if (q.flags & B4_EDGE_V) { const B4L1 *qx = f.b4x ? f.b4x + (size_t)(y >> 2) * b4w + (x >> 2) : nullptr; bsv = dec_bs(p, q, (q.flags & B4_TU_V) != 0, qx - 1, qx); qpv = (p.qp_y + q.qp_y + 1) >> 1; }
     }
   }
   if (tid < 8 * (TW / 4)) {
@@ -779,7 +848,7 @@ template <class F> __device__ __forceinline__ void dec_deblock_body(const F &f, 
     if (y > 0 && y < f.h && x >= 0 && x < f.w) {
       const int uq = unit(x, y);
       const B4Rec q = recs[uq], p = recs[uq - 18];
-      if (q.flags & B4_EDGE_H) { bsh = dec_bs(p, q, (q.flags & B4_TU_H) != 0); qph = (p.qp_y + q.qp_y + 1) >> 1; }
+      if (q.flags & B4_EDGE_H) { const B4L1 *qx = f.b4x ? f.b4x + (size_t)(y >> 2) * b4w + (x >> 2) : nullptr; bsh = dec_bs(p, q, (q.flags & B4_TU_H) != 0, qx - b4w, qx); qph = (p.qp_y + q.qp_y + 1) >> 1; }
     }
   }
   if (!__syncthreads_or(bsv | bsh)) return;

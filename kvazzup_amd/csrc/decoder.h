@@ -50,6 +50,7 @@ struct DecSps {
   int log2_max_poc_lsb = 8;
   int num_st_rps = 0; StRps st_rps[65];
   uint32_t fps_num = 0, fps_den = 0;
+  int num_reorder = 0;                // sps_max_num_reorder_pics of the highest sub-layer: pictures that may precede a picture in decoding order and follow it in output order
   int strong_intra = 0, sao = 0, tmvp = 0, amp = 0, th_depth_inter = 0, th_depth_intra = 0;
   // scaling_list_enabled_flag: the scaling factors (dec_frame.h KVZ_SCALING_BYTES) of the SPS's lists -- the default ones (Tables 7-5 / 7-6) without
   // sps_scaling_list_data; NULL: flat.  What uvgComm's "scaling list" checkbox switches on in a peer's Kvazaar (kvazaarfilter.cpp:235-242).
@@ -58,7 +59,7 @@ struct DecSps {
 struct DecPps {
   bool valid = false;
   int sps_id = 0;
-  int sign_hiding = 0, cabac_init_present = 0, num_ref_idx_default = 1, init_qp = 26, tskip = 0;
+  int sign_hiding = 0, cabac_init_present = 0, num_ref_idx_default = 1, num_ref_idx1_default = 1, init_qp = 26, tskip = 0;
   int dependent_slices = 0;
   int cu_qp_delta = 0, qp_delta_depth = 0, cb_qp_offset = 0, cr_qp_offset = 0, slice_chroma_offsets = 0;
   int output_flag_present = 0, extra_header_bits = 0, header_extension = 0;
@@ -77,6 +78,7 @@ struct DecodedPicture {
   const uint8_t *host[3] = {nullptr, nullptr, nullptr}; int host_pitch[3] = {0, 0, 0};
   const uint8_t *dev[3] = {nullptr, nullptr, nullptr}; int dev_pitch[3] = {0, 0, 0};
   int poc = 0; int64_t pts = 0; uint32_t fps_num = 0, fps_den = 0; bool is_intra = false;
+  int cvs = 0, num_reorder = 0;       // coded video sequence the picture belongs to (a running count); its SPS's sps_max_num_reorder_pics
 };
 
 // a finished picture that owns its samples: what is still in the frame-threaded ring when the stream changes its resolution is
@@ -109,7 +111,7 @@ class FrameWorkers {
 // motion of its top-left 4x4.  Written by the picture's parser row by row, read by the parsers of following pictures (which may
 // run concurrently under frame threading: row_done[] orders them).
 struct ColMotion {
-  struct Mv { int16_t mvx, mvy; int32_t ref_poc; int32_t inter; };
+  struct Mv { int16_t mv[2][2]; int32_t ref_poc[2]; uint8_t used; uint8_t pad[3]; };      // per list: vector, POC of the picture it points into; used: bit L = list L predicts the block (0: intra)
   int w16 = 0, h16 = 0, hc = 0, poc = 0;
   std::vector<Mv> mv;
   std::unique_ptr<std::atomic<uint8_t>[]> row_done;      // per CTU row
@@ -148,7 +150,8 @@ class Decoder {
   struct SubOut { std::vector<uint32_t> levels; std::vector<DecTu> tus; int rc = 0; };     // one per substream
   struct alignas(64) Progress { std::atomic<int> v{0}; char pad[60]; };   // one cache line per row: no false sharing between pollers
   struct SliceHdr {
-    bool is_intra = false; int poc = 0;
+    bool is_intra = false, is_b = false; int poc = 0;
+    int num_ref_idx1 = 0, mvd_l1_zero = 0, collocated_from_l0 = 1;      // B slices: num_ref_idx_l1_active, mvd_l1_zero_flag, collocated_from_l0_flag
     int tmvp = 0, collocated_ref_idx = 0, sao_luma = 0, sao_chroma = 0, num_ref_idx = 1, cabac_init_flag = 0, max_merge = 5;
     int slice_qp = 26, cb_qp_offset = 0, cr_qp_offset = 0;      // offsets: PPS + slice
     int deblock_disabled = 0, beta_offset_div2 = 0, tc_offset_div2 = 0;
@@ -167,7 +170,14 @@ class Decoder {
     SliceHdr sh; std::shared_ptr<const DecSps> sps; DecPps pps;  // (a later SPS / PPS NAL may replace the table entry while this picture is still being parsed: the job keeps the SPS it was coded with alive, the PPS by value)
     int64_t pts = 0; int crop[4] = {0, 0, 0, 0}; uint32_t fps_num = 0, fps_den = 0;
     int slot = 0;                                                // picture buffer this picture is reconstructed into
+    int cvs = 0;                                                 // the coded video sequence it belongs to (output order)
     int nref = 0; int ref_poc[16]; uint8_t ref_slot[16];        // RefPicList0
+    int nref1 = 0; int ref_poc1[16]; uint8_t ref_slot1[16];     // RefPicList1 (B slices)
+    bool no_backward = true;                                     // NoBackwardPredFlag (8.5.3.2.9): no entry of either list follows the picture in output order
+    // B slices: the two-list motion of every 4x4 block as the parser's own derivations read it (merge, AMVP); what the kernels need of it goes
+    // into the B4Rec (the first used list's vector and picture) and, for bi-predicted blocks (B4_BI), the second vector here
+    struct MvF { int16_t mv[2][2]; int8_t ref[2]; };
+    std::vector<MvF> mvf; std::vector<B4L1> b4x; std::atomic<int> any_bi{0};
     std::shared_ptr<ColMotion> col, own;                         // collocated picture's motion (NULL: no temporal candidates); this picture's
     // the pinned input block (dec_frame.h) and the host views into it
     uint8_t *h_in = nullptr; size_t h_in_cap = 0; size_t ntu = 0, nlev = 0;
@@ -243,6 +253,12 @@ class Decoder {
   int append_segment_tiles(PicJob &job, size_t bitpos, const uint8_t *rbsp, size_t len, const DecPps &p, const DecPps &pp, int wc, int hc, int address);
   int append_segment(PicJob &job, size_t bitpos, const uint8_t *rbsp, size_t len, const DecPps &p, const DecPps &pp, int wc, int hc, int address, int64_t pts);
   std::deque<OwnedPic> ready_q_; OwnedPic cur_owned_;       // pictures completed ahead of their turn (resolution change), the one last handed out
+  // Output order (C.5.2): a stream whose SPS allows reordering (sps_max_num_reorder_pics > 0: B pictures in groups, Kvazaar gop=8) has its pictures
+  // copied out as they are completed and handed on by POC -- the smallest of those waiting once more than the SPS's count wait, all of a coded
+  // video sequence before the next one's first, the rest one per call when the stream ends.  A low-delay stream (the count is 0) never enters this.
+  struct Waiting { OwnedPic pic; int cvs; };
+  std::deque<Waiting> reorder_q_; int cvs_ = 0, reorder_ = 0;
+  bool pop_reordered(bool flush);
   // Frame memory handed out by get_picture stays valid while kOutHold further NAL units are decoded -- a caller may copy it out on a stage of its
   // own (OpenHEVCFilter's output thread) -- also across a resolution change: the host output buffers and the owned pictures that such a change
   // retires are only freed kOutHold calls later.

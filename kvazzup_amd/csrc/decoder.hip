@@ -410,8 +410,19 @@ struct SliceParser {
   }
   static bool same_motion(const B4Rec &a, const B4Rec &b) { return a.ref_idx == b.ref_idx && a.mvx == b.mvx && a.mvy == b.mvy; }
 
-  // temporal candidate (8.5.3.2.8, 8.5.3.2.9); collocated pictures of P streams carry list-0 motion only
-  bool temporal_mv(int xpb, int ypb, int npbw, int npbh, int ref_idx, int &mvx, int &mvy)
+  // temporal candidate of list X (8.5.3.2.8, 8.5.3.2.9).  The collocated block may be bi-predicted (a B picture): of its two vectors the one of list X
+  // counts when no reference picture of this slice follows it in output order, else the one of list collocated_from_l0_flag.
+  inline int list_poc(int L, int idx) const { return L ? job.ref_poc1[idx & 15] : job.ref_poc[idx & 15]; }
+  static void scale_by(int &mvx, int &mvy, int td_, int tb_)
+  {
+    const int td = clip3(-128, 127, td_), tb = clip3(-128, 127, tb_);
+    if (td == 0) return;
+    const int tx = (16384 + (iabs(td) >> 1)) / td, dsf = clip3(-4096, 4095, (tb * tx + 32) >> 6);
+    const int px = dsf * mvx, py = dsf * mvy;
+    mvx = clip3(-32768, 32767, (px < 0 ? -1 : 1) * ((iabs(px) + 127) >> 8));
+    mvy = clip3(-32768, 32767, (py < 0 ? -1 : 1) * ((iabs(py) + 127) >> 8));
+  }
+  bool temporal_mv(int xpb, int ypb, int npbw, int npbh, int X, int ref_idx, int &mvx, int &mvy)
   {
     ColMotion *col = job.col.get();
     if (!col) return false;
@@ -428,17 +439,11 @@ struct SliceParser {
       x >>= 4; y >>= 4;
       if (x >= col->w16 || y >= col->h16) continue;
       const ColMotion::Mv &m = col->mv[(size_t)y * col->w16 + x];
-      if (!m.inter) continue;
-      const int col_diff = col->poc - m.ref_poc, cur_diff = sh.poc - job.ref_poc[ref_idx];
-      mvx = m.mvx; mvy = m.mvy;
-      if (col_diff != cur_diff && col_diff != 0) {
-        const int td = clip3(-128, 127, col_diff), tb = clip3(-128, 127, cur_diff);
-        const int tx = (16384 + (iabs(td) >> 1)) / td;
-        const int dsf = clip3(-4096, 4095, (tb * tx + 32) >> 6);
-        const int px = dsf * mvx, py = dsf * mvy;
-        mvx = clip3(-32768, 32767, (px < 0 ? -1 : 1) * ((iabs(px) + 127) >> 8));
-        mvy = clip3(-32768, 32767, (py < 0 ? -1 : 1) * ((iabs(py) + 127) >> 8));
-      }
+      if (!m.used) continue;
+      const int L = m.used == 2 ? 1 : (m.used == 1 ? 0 : (job.no_backward ? X : sh.collocated_from_l0));
+      const int col_diff = col->poc - m.ref_poc[L], cur_diff = sh.poc - list_poc(X, ref_idx);
+      mvx = m.mv[L][0]; mvy = m.mv[L][1];
+      if (col_diff != cur_diff && col_diff != 0) scale_by(mvx, mvy, col_diff, cur_diff);
       return true;
     }
     return false;
@@ -476,7 +481,7 @@ struct SliceParser {
     if (avB0) add(B0);
     if (avA0) add(A0);
     if (avB2) add(B2);
-    if (n < maxc) { int tx, ty; if (temporal_mv(xpb, ypb, npbw, npbh, 0, tx, ty)) { cand[n].mvx = tx; cand[n].mvy = ty; cand[n].ref_idx = 0; n++; } }
+    if (n < maxc) { int tx, ty; if (temporal_mv(xpb, ypb, npbw, npbh, 0, 0, tx, ty)) { cand[n].mvx = tx; cand[n].mvy = ty; cand[n].ref_idx = 0; n++; } }
     for (int zi = 0; n < maxc; n++, zi++) { cand[n].mvx = cand[n].mvy = 0; cand[n].ref_idx = zi < sh.num_ref_idx ? zi : 0; }     // 8.5.3.2.5, P slices
   }
 
@@ -515,9 +520,176 @@ struct SliceParser {
     int n = 0;
     if (flagA) { cand[n][0] = ax; cand[n][1] = ay; n++; }
     if (flagB && !(flagA && ax == bx && ay == by)) { cand[n][0] = bx; cand[n][1] = by; n++; }
-    if (n < 2) { int tx, ty; if (temporal_mv(xpb, ypb, npbw, npbh, ref_idx, tx, ty)) { cand[n][0] = tx; cand[n][1] = ty; n++; } }
+    if (n < 2) { int tx, ty; if (temporal_mv(xpb, ypb, npbw, npbh, 0, ref_idx, tx, ty)) { cand[n][0] = tx; cand[n][1] = ty; n++; } }
     for (; n < 2; n++) cand[n][0] = cand[n][1] = 0;
   }
+
+  // ---------------------------------------------------------------- B slices: the same derivations over two-list motion (job.mvf)
+  typedef Decoder::PicJob::MvF MvF;
+  MvF *mvf = nullptr;                                      // [ph / 4][pw / 4], B slices only
+  static bool same_motion_b(const MvF &a, const MvF &b)
+  {
+    if (a.ref[0] != b.ref[0] || a.ref[1] != b.ref[1]) return false;
+    if (a.ref[0] >= 0 && (a.mv[0][0] != b.mv[0][0] || a.mv[0][1] != b.mv[0][1])) return false;
+    if (a.ref[1] >= 0 && (a.mv[1][0] != b.mv[1][0] || a.mv[1][1] != b.mv[1][1])) return false;
+    return true;
+  }
+  // 8.5.3.2.2 - 8.5.3.2.5 for a B slice: spatial candidates, the temporal one for both lists, combined bi-predictive candidates, two-list zero candidates
+  void merge_candidates_b(int xcb, int ycb, int ncbs, int xpb, int ypb, int npbw, int npbh, int part_idx, int pmode, MvF *cand)
+  {
+    const int lvl = pps.par_mrg_level;
+    int n = 0;
+    if (lvl > 2 && ncbs == 8) { xpb = xcb; ypb = ycb; npbw = npbh = ncbs; part_idx = 0; pmode = PART_2Nx2N; }
+    auto par = [&](int xn, int yn) { return ((xpb >> lvl) == (xn >> lvl)) && ((ypb >> lvl) == (yn >> lvl)); };
+    const int xa1 = xpb - 1, ya1 = ypb + npbh - 1, xb1 = xpb + npbw - 1, yb1 = ypb - 1, xb0 = xpb + npbw, yb0 = ypb - 1;
+    const int xa0 = xpb - 1, ya0 = ypb + npbh, xb2 = xpb - 1, yb2 = ypb - 1;
+    const bool part1 = part_idx == 1;
+    const bool nbA1 = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xa1, ya1) && !par(xa1, ya1) &&
+                      !(part1 && (pmode == PART_Nx2N || pmode == PART_nLx2N || pmode == PART_nRx2N));
+    const bool nbB1 = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xb1, yb1) && !par(xb1, yb1) &&
+                      !(part1 && (pmode == PART_2NxN || pmode == PART_2NxnU || pmode == PART_2NxnD));
+    const bool nbB0 = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xb0, yb0) && !par(xb0, yb0);
+    const bool nbA0 = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xa0, ya0) && !par(xa0, ya0);
+    const bool nbB2 = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xb2, yb2) && !par(xb2, yb2);
+    MvF zero; memset(&zero, 0, sizeof(zero)); zero.ref[0] = zero.ref[1] = -1;
+    const MvF &A1 = nbA1 ? mvf[bi(xa1, ya1)] : zero, &B1 = nbB1 ? mvf[bi(xb1, yb1)] : zero, &B0 = nbB0 ? mvf[bi(xb0, yb0)] : zero;
+    const MvF &A0 = nbA0 ? mvf[bi(xa0, ya0)] : zero, &B2 = nbB2 ? mvf[bi(xb2, yb2)] : zero;
+    const bool avA1 = nbA1, avB1 = nbB1 && !(nbA1 && same_motion_b(A1, B1)), avB0 = nbB0 && !(nbB1 && same_motion_b(B1, B0));
+    const bool avA0 = nbA0 && !(nbA1 && same_motion_b(A1, A0));
+    const bool avB2 = nbB2 && !(nbA1 && same_motion_b(A1, B2)) && !(nbB1 && same_motion_b(B1, B2)) && ((int)avA0 + avA1 + avB0 + avB1 != 4);
+    const int maxc = sh.max_merge;
+    auto add = [&](const MvF &m) { if (n < maxc) cand[n++] = m; };
+    if (avA1) add(A1);
+    if (avB1) add(B1);
+    if (avB0) add(B0);
+    if (avA0) add(A0);
+    if (avB2) add(B2);
+    if (n < maxc) {
+      int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+      const bool f0 = temporal_mv(xpb, ypb, npbw, npbh, 0, 0, x0, y0), f1 = temporal_mv(xpb, ypb, npbw, npbh, 1, 0, x1, y1);
+      if (f0 || f1) {
+        MvF &t = cand[n++];
+        t.mv[0][0] = (int16_t)x0; t.mv[0][1] = (int16_t)y0; t.ref[0] = f0 ? 0 : -1;
+        t.mv[1][0] = (int16_t)x1; t.mv[1][1] = (int16_t)y1; t.ref[1] = f1 ? 0 : -1;
+      }
+    }
+    if (n > 1 && n < maxc) {                               // 8.5.3.2.4: list-0 motion of one candidate with list-1 motion of another (Table 8-7), unless they are one prediction
+      static const uint8_t l0c[12] = {0, 1, 0, 2, 1, 2, 0, 3, 1, 3, 2, 3}, l1c[12] = {1, 0, 2, 0, 2, 1, 3, 0, 3, 1, 3, 2};
+      const int norig = n;
+      for (int comb = 0; comb < norig * (norig - 1) && n < maxc; comb++) {
+        const MvF &p0 = cand[l0c[comb]], &p1 = cand[l1c[comb]];
+        if (p0.ref[0] < 0 || p1.ref[1] < 0) continue;
+        if (list_poc(0, p0.ref[0]) == list_poc(1, p1.ref[1]) && p0.mv[0][0] == p1.mv[1][0] && p0.mv[0][1] == p1.mv[1][1]) continue;
+        MvF &t = cand[n++];
+        t.mv[0][0] = p0.mv[0][0]; t.mv[0][1] = p0.mv[0][1]; t.ref[0] = p0.ref[0];
+        t.mv[1][0] = p1.mv[1][0]; t.mv[1][1] = p1.mv[1][1]; t.ref[1] = p1.ref[1];
+      }
+    }
+    const int nrefs = imin(sh.num_ref_idx, sh.num_ref_idx1);
+    for (int zi = 0; n < maxc; n++, zi++) { MvF &t = cand[n]; memset(&t, 0, sizeof(t)); t.ref[0] = t.ref[1] = (int8_t)(zi < nrefs ? zi : 0); }
+  }
+  // 8.5.3.2.6 / 8.5.3.2.7 for list X of a B slice: a neighbour's vector into the target picture from either of its lists (its list X first), else any of
+  // its vectors scaled by the ratio of the POC distances
+  void amvp_candidates_b(int xcb, int ycb, int ncbs, int xpb, int ypb, int npbw, int npbh, int part_idx, int X, int ref_idx, int cand[2][2])
+  {
+    const int xa[2] = {xpb - 1, xpb - 1}, ya[2] = {ypb + npbh, ypb + npbh - 1};                       // A0, A1
+    const int xb[3] = {xpb + npbw, xpb + npbw - 1, xpb - 1}, yb[3] = {ypb - 1, ypb - 1, ypb - 1};     // B0, B1, B2
+    bool avA[2], avB[3];
+    for (int k = 0; k < 2; k++) avA[k] = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xa[k], ya[k]);
+    for (int k = 0; k < 3; k++) avB[k] = pb_avail(xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xb[k], yb[k]);
+    const bool is_scaled = avA[0] || avA[1];
+    bool flagA = false, flagB = false; int ax = 0, ay = 0, bx = 0, by = 0;
+    const int target = list_poc(X, ref_idx), Y = X ^ 1;
+    auto same_pic = [&](const MvF &m, int &vx, int &vy) {
+      for (int L : {X, Y}) if (m.ref[L] >= 0 && list_poc(L, m.ref[L]) == target) { vx = m.mv[L][0]; vy = m.mv[L][1]; return true; }
+      return false;
+    };
+    auto any_pic = [&](const MvF &m, int &vx, int &vy) {
+      for (int L : {X, Y}) if (m.ref[L] >= 0) {
+        vx = m.mv[L][0]; vy = m.mv[L][1];
+        const int poc = list_poc(L, m.ref[L]);
+        if (poc != target) scale_by(vx, vy, sh.poc - poc, sh.poc - target);
+        return true;
+      }
+      return false;
+    };
+    for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) flagA = same_pic(mvf[bi(xa[k], ya[k])], ax, ay);
+    for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) flagA = any_pic(mvf[bi(xa[k], ya[k])], ax, ay);
+    for (int k = 0; k < 3 && !flagB; k++) if (avB[k]) flagB = same_pic(mvf[bi(xb[k], yb[k])], bx, by);
+    if (!is_scaled && flagB) { flagA = true; ax = bx; ay = by; }
+    if (!is_scaled) {
+      flagB = false;
+      for (int k = 0; k < 3 && !flagB; k++) if (avB[k]) flagB = any_pic(mvf[bi(xb[k], yb[k])], bx, by);
+    }
+    int n = 0;
+    if (flagA) { cand[n][0] = ax; cand[n][1] = ay; n++; }
+    if (flagB && !(flagA && ax == bx && ay == by)) { cand[n][0] = bx; cand[n][1] = by; n++; }
+    if (n < 2) { int tx, ty; if (temporal_mv(xpb, ypb, npbw, npbh, X, ref_idx, tx, ty)) { cand[n][0] = tx; cand[n][1] = ty; n++; } }
+    for (; n < 2; n++) cand[n][0] = cand[n][1] = 0;
+  }
+  int parse_ref_idx(int num_active)
+  {
+    int ref_idx = 0;
+    const int mx = num_active - 1;
+    while (ref_idx < mx && ref_idx < 2 && c.bin(CTX_REF_IDX + ref_idx)) ref_idx++;
+    if (ref_idx == 2) while (ref_idx < mx && c.bypass()) ref_idx++;
+    return ref_idx;
+  }
+  void parse_mvd(int &dx, int &dy)
+  {
+    const int g0x = c.bin(CTX_MVD_GT0), g0y = c.bin(CTX_MVD_GT0);
+    const int g1x = g0x ? c.bin(CTX_MVD_GT1) : 0, g1y = g0y ? c.bin(CTX_MVD_GT1) : 0;
+    dx = mvd_abs(g0x, g1x); if (g0x && c.bypass()) dx = -dx;
+    dy = mvd_abs(g0y, g1y); if (g0y && c.bypass()) dy = -dy;
+  }
+  // prediction_unit() of a B slice (7.3.8.6): inter_pred_idc, a reference index / vector difference / predictor flag per used list
+  void prediction_unit_b(int xcb, int ycb, int ncbs, int xp, int yp, int bw, int bh, int part_idx, bool skip, int *merge_out)
+  {
+    const int merge = skip ? 1 : c.bin(CTX_MERGE_FLAG);
+    if (merge_out) *merge_out = merge;
+    MvF m; memset(&m, 0, sizeof(m)); m.ref[0] = m.ref[1] = -1;
+    if (merge) {
+      int idx = 0;
+      if (sh.max_merge > 1 && c.bin(CTX_MERGE_IDX)) { idx = 1; while (idx < sh.max_merge - 1 && c.bypass()) idx++; }
+      MvF cand[5];
+      merge_candidates_b(xcb, ycb, ncbs, xp, yp, bw, bh, part_idx, part_mode, cand);
+      m = cand[idx];
+      if (m.ref[0] >= 0 && m.ref[1] >= 0 && bw + bh == 12) { m.ref[1] = -1; m.mv[1][0] = m.mv[1][1] = 0; }      // 8x4 / 4x8 blocks are never bi-predicted
+    } else {
+      int idc;                                             // 0 PRED_L0, 1 PRED_L1, 2 PRED_BI (9.3.4.2: "both" is asked first, with the coding quadtree depth as context, unless the block is 8x4 / 4x8)
+      if (bw + bh != 12 && c.bin(CTX_INTER_PRED_IDC + ctd[b8(xcb, ycb)])) idc = 2;
+      else idc = c.bin(CTX_INTER_PRED_IDC + 4);
+      for (int X = 0; X < 2; X++) {
+        if (idc == 1 - X) continue;
+        const int na = X ? sh.num_ref_idx1 : sh.num_ref_idx;
+        const int ref_idx = na > 1 ? parse_ref_idx(na) : 0;
+        int dx = 0, dy = 0;
+        if (!(X == 1 && sh.mvd_l1_zero && idc == 2)) parse_mvd(dx, dy);
+        const int mvp = c.bin(CTX_MVP_FLAG);
+        if (ref_idx >= (X ? job.nref1 : job.nref)) { err = DEC_ERR_INVALID; return; }
+        int cand[2][2];
+        amvp_candidates_b(xcb, ycb, ncbs, xp, yp, bw, bh, part_idx, X, ref_idx, cand);
+        m.mv[X][0] = (int16_t)(uint16_t)(cand[mvp][0] + dx); m.mv[X][1] = (int16_t)(uint16_t)(cand[mvp][1] + dy);      // 8.5.3.2.6: modulo 2^16
+        m.ref[X] = (int8_t)ref_idx;
+      }
+    }
+    if ((m.ref[0] < 0 && m.ref[1] < 0) || m.ref[0] >= job.nref || m.ref[1] >= job.nref1) { err = DEC_ERR_INVALID; return; }
+    if (ref_y1 != (1 << 30) || ref_y0 != -(1 << 30)) { err = DEC_ERR_UNSUPPORTED; return; }      // (band mode is the split encoder's streams: P pictures)
+    const int P = m.ref[0] >= 0 ? 0 : 1;                   // the list whose motion rides in the B4Rec
+    const bool bi = m.ref[0] >= 0 && m.ref[1] >= 0;
+    B4Rec r; r.mvx = m.mv[P][0]; r.mvy = m.mv[P][1]; r.ref_idx = m.ref[P]; r.flags = (uint8_t)((cu_bypass ? B4_BYPASS : 0) | (bi ? B4_BI : 0)); r.qp_y = (int8_t)qp_y;
+    r.slot = P ? job.ref_slot1[m.ref[1]] : job.ref_slot[m.ref[0]];
+    fill_recs(xp, yp, bw, bh, r, bw == ncbs && bh == ncbs);
+    B4L1 x; x.mvx = m.mv[1][0]; x.mvy = m.mv[1][1]; x.slot = bi ? job.ref_slot1[m.ref[1]] : 0; x.pad[0] = x.pad[1] = x.pad[2] = 0;
+    const int cols = imin(bw, w - xp) >> 2;
+    for (int y = yp; y < yp + bh && y < h; y += 4) { const int i0 = bi_(xp, y); for (int i = 0; i < cols; i++) { mvf[i0 + i] = m; if (bi) job.b4x[(size_t)(i0 + i)] = x; } }
+    if (bi) job.any_bi.store(1, std::memory_order_relaxed);
+    if (bw != ncbs || bh != ncbs) {                          // prediction block edges inside the coding block (deblocking)
+      for (int i = 0; i < bh && yp + i < h; i += 4) b4[bi_(xp, yp + i)].flags |= B4_EDGE_V;
+      for (int i = 0; i < bw && xp + i < w; i += 4) b4[bi_(xp + i, yp)].flags |= B4_EDGE_H;
+    }
+  }
+  inline int bi_(int x, int y) const { return (y >> 2) * b4w + (x >> 2); }      // (bi() under a name that does not collide with the local `bi`)
 
   int mvd_abs(int gt0, int gt1)
   {
@@ -531,6 +703,7 @@ struct SliceParser {
 
   void prediction_unit(int xcb, int ycb, int ncbs, int xp, int yp, int bw, int bh, int part_idx, bool skip, int *merge_out)
   {
+    if (sh.is_b) { prediction_unit_b(xcb, ycb, ncbs, xp, yp, bw, bh, part_idx, skip, merge_out); return; }
     const int merge = skip ? 1 : c.bin(CTX_MERGE_FLAG);
     if (merge_out) *merge_out = merge;
     int mvx, mvy, ref_idx = 0;
@@ -827,6 +1000,7 @@ Decoder::~Decoder()
   free_buffers();
   free_retired(true);
   for (auto &o : ready_q_) if (o.dev) hipFree(o.dev);
+  for (auto &w : reorder_q_) if (w.pic.dev) hipFree(w.pic.dev);
   if (cur_owned_.dev) hipFree(cur_owned_.dev);
   if (stream_dl_ != stream_up_) stream_release(stream_dl_, device_, 'L', 'l');
   stream_release(stream_up_, device_, 'U', prio_up_);
@@ -1002,9 +1176,22 @@ int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
   nal_calls_++;
   if (!retired_out_.empty() || !retired_owned_.empty()) free_retired(false);
   const int rc = decode_nal_inner(data, len, pts);
+  // ---- output order (C.5.2).  A picture of a stream that may reorder (its SPS says how many pictures may overtake one) is copied out of the ring as
+  // it completes and waits in reorder_q_; the smallest POC of the oldest coded video sequence goes out once more pictures wait than may overtake it,
+  // or a later sequence has begun, or the stream has ended (EOS / EOB with nothing left in the pipeline).  One picture per call, as ever.
+  if (rc >= 0 && ((pic_ready_ && out_.num_reorder > 0) || !reorder_q_.empty())) {
+    if (pic_ready_) {
+      const int cvs = out_.cvs; reorder_ = out_.num_reorder;
+      if (!queue_current_output()) return last_error_ = DEC_ERR_GPU;
+      reorder_q_.push_back(Waiting{std::move(ready_q_.back()), cvs}); ready_q_.pop_back();
+    }
+    const bool eos = len >= 2 && [&] { size_t i = 0; while (i + 2 < len && data[i] == 0) i++; const uint8_t *q = (i >= 2 && i < len && data[i] == 1) ? data + i + 1 : data; const int t = (q[0] >> 1) & 0x3f; return t == 36 || t == 37; }();
+    if (!pop_reordered(eos && pending() == 0)) return 0;
+  } else {
   if (ready_q_.empty()) return rc;
   if (rc < 0) return rc;
   if (pic_ready_ && !queue_current_output()) return last_error_ = DEC_ERR_GPU;
+  }
   if (cur_owned_.dev || !cur_owned_.host.empty()) retired_owned_.emplace_back(nal_calls_, std::move(cur_owned_));      // (the caller may still be copying it out)
   cur_owned_ = OwnedPic();
   cur_owned_ = std::move(ready_q_.front());
@@ -1017,6 +1204,25 @@ int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
   }
   pic_ready_ = true;
   return 1;
+}
+
+// C.5.2.4: of the waiting pictures of the oldest coded video sequence the one with the smallest POC becomes the next of ready_q_ -- when more of
+// them wait than may overtake a picture, when a later sequence has begun, or when the stream is over
+bool Decoder::pop_reordered(bool flush)
+{
+  if (reorder_q_.empty()) return false;
+  int first_cvs = reorder_q_.front().cvs, n = 0; size_t best = 0;
+  for (const Waiting &w : reorder_q_) if (w.cvs < first_cvs) first_cvs = w.cvs;
+  bool later = false;
+  for (size_t i = 0; i < reorder_q_.size(); i++) {
+    const Waiting &w = reorder_q_[i];
+    if (w.cvs != first_cvs) { later = true; continue; }
+    if (n++ == 0 || w.pic.pic.poc < reorder_q_[best].pic.pic.poc) best = i;
+  }
+  if (!(flush || later || n > reorder_)) return false;
+  ready_q_.push_back(std::move(reorder_q_[best].pic));
+  reorder_q_.erase(reorder_q_.begin() + (long)best);
+  return true;
 }
 
 // the picture complete_gpu() just made the output, copied into storage of its own at the end of the queue
@@ -1129,7 +1335,8 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     s.log2_max_poc_lsb = r.ue() + 4;
     if (s.log2_max_poc_lsb > 16) return last_error_ = DEC_ERR_INVALID;
     int oi = r.get(1);
-    for (int k = oi ? 0 : msl; k <= msl; k++) { r.ue(); r.ue(); r.ue(); }
+    for (int k = oi ? 0 : msl; k <= msl; k++) { r.ue(); s.num_reorder = r.ue(); r.ue(); }      // (max_dec_pic_buffering, max_num_reorder_pics, max_latency_increase: the highest sub-layer's stay)
+    if (s.num_reorder < 0 || s.num_reorder > 15) return last_error_ = DEC_ERR_INVALID;
     int log2_min_cb = r.ue() + 3, diff_cb = r.ue(), log2_min_tb = r.ue() + 2, diff_tb = r.ue();
     s.th_depth_inter = r.ue(); s.th_depth_intra = r.ue();
     if (r.get(1)) {                                             // scaling_list_enabled_flag: the default lists, or sps_scaling_list_data
@@ -1170,14 +1377,14 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     if (id > 63 || p.sps_id > 15) return last_error_ = DEC_ERR_INVALID;
     int dep = r.get(1); p.output_flag_present = r.get(1); p.extra_header_bits = r.get(3); p.sign_hiding = r.get(1);
     p.cabac_init_present = r.get(1);
-    p.num_ref_idx_default = (int)r.ue() + 1; r.ue();
+    p.num_ref_idx_default = (int)r.ue() + 1; p.num_ref_idx1_default = (int)r.ue() + 1;
     p.init_qp = 26 + r.se();
     int cip = r.get(1); p.tskip = r.get(1); p.cu_qp_delta = r.get(1);
     if (p.cu_qp_delta) { p.qp_delta_depth = r.ue(); if (p.qp_delta_depth > 3) return last_error_ = DEC_ERR_INVALID; }
     p.cb_qp_offset = r.se(); p.cr_qp_offset = r.se(); p.slice_chroma_offsets = r.get(1);
     int wp = r.get(1), wbp = r.get(1), tqb = r.get(1), tiles = r.get(1);
     p.wpp = r.get(1);
-    if (r.err || p.num_ref_idx_default > 15 || p.cb_qp_offset < -12 || p.cb_qp_offset > 12 || p.cr_qp_offset < -12 || p.cr_qp_offset > 12) return last_error_ = DEC_ERR_INVALID;
+    if (r.err || p.num_ref_idx_default > 15 || p.num_ref_idx1_default > 15 || p.cb_qp_offset < -12 || p.cb_qp_offset > 12 || p.cr_qp_offset < -12 || p.cr_qp_offset > 12) return last_error_ = DEC_ERR_INVALID;
     p.dependent_slices = dep;
     if (cip || wp || wbp) return last_error_ = DEC_ERR_UNSUPPORTED;   // constrained intra, weighted prediction
     p.tq_bypass = tqb;
@@ -1322,9 +1529,9 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   }
   for (int k = 0; k < p.extra_header_bits; k++) r.get(1);
   const int slice_type = r.ue();
-  if (slice_type != 1 && slice_type != 2) return r.err ? DEC_ERR_INVALID : DEC_ERR_UNSUPPORTED;      // B slices
+  if (slice_type < 0 || slice_type > 2) return DEC_ERR_INVALID;
   SliceHdr sh;
-  sh.is_intra = slice_type == 2;
+  sh.is_intra = slice_type == 2; sh.is_b = slice_type == 0;
   if (p.output_flag_present) r.get(1);
   StRps rps;
   if (!idr) {
@@ -1345,12 +1552,17 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     if (s.tmvp) sh.tmvp = r.get(1);
   }
   if (s.sao) { sh.sao_luma = r.get(1); sh.sao_chroma = r.get(1); }
-  sh.num_ref_idx = p.num_ref_idx_default;
+  sh.num_ref_idx = p.num_ref_idx_default; sh.num_ref_idx1 = sh.is_b ? p.num_ref_idx1_default : 0;
   if (!sh.is_intra) {
-    if (r.get(1)) sh.num_ref_idx = (int)r.ue() + 1;
-    if (sh.num_ref_idx < 1 || sh.num_ref_idx > 15) return DEC_ERR_INVALID;
+    if (r.get(1)) { sh.num_ref_idx = (int)r.ue() + 1; if (sh.is_b) sh.num_ref_idx1 = (int)r.ue() + 1; }
+    if (sh.num_ref_idx < 1 || sh.num_ref_idx > 15 || (sh.is_b && (sh.num_ref_idx1 < 1 || sh.num_ref_idx1 > 15))) return DEC_ERR_INVALID;
+    if (sh.is_b) sh.mvd_l1_zero = r.get(1);
     if (p.cabac_init_present) sh.cabac_init_flag = r.get(1);
-    if (sh.tmvp && sh.num_ref_idx > 1) { sh.collocated_ref_idx = r.ue(); if (sh.collocated_ref_idx >= sh.num_ref_idx) return DEC_ERR_INVALID; }
+    if (sh.tmvp) {
+      if (sh.is_b) sh.collocated_from_l0 = r.get(1);
+      const int n = sh.collocated_from_l0 ? sh.num_ref_idx : sh.num_ref_idx1;
+      if (n > 1) { sh.collocated_ref_idx = r.ue(); if (sh.collocated_ref_idx < 0 || sh.collocated_ref_idx >= n) return DEC_ERR_INVALID; }
+    }
     sh.max_merge = 5 - (int)r.ue();
     if (sh.max_merge < 1 || sh.max_merge > 5) return DEC_ERR_INVALID;
   }
@@ -1388,7 +1600,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   if (!first_seg) {
     // an independent slice of a picture under way: the same slice parameters as the first (what this decoder keeps per picture)
     const SliceHdr &a = open_job->sh;
-    if (sh.is_intra != a.is_intra || sh.poc != a.poc || sh.tmvp != a.tmvp || sh.collocated_ref_idx != a.collocated_ref_idx || sh.sao_luma != a.sao_luma ||
+    if (sh.is_intra != a.is_intra || sh.is_b != a.is_b || sh.num_ref_idx1 != a.num_ref_idx1 || sh.mvd_l1_zero != a.mvd_l1_zero || sh.collocated_from_l0 != a.collocated_from_l0 || sh.poc != a.poc || sh.tmvp != a.tmvp || sh.collocated_ref_idx != a.collocated_ref_idx || sh.sao_luma != a.sao_luma ||
         sh.sao_chroma != a.sao_chroma || sh.num_ref_idx != a.num_ref_idx || sh.cabac_init_flag != a.cabac_init_flag || sh.max_merge != a.max_merge ||
         sh.slice_qp != a.slice_qp || sh.cb_qp_offset != a.cb_qp_offset || sh.cr_qp_offset != a.cr_qp_offset || sh.deblock_disabled != a.deblock_disabled ||
         sh.beta_offset_div2 != a.beta_offset_div2 || sh.tc_offset_div2 != a.tc_offset_div2 || !across_slices) return DEC_ERR_UNSUPPORTED;
@@ -1399,21 +1611,31 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   // ---- reference picture set (8.3.2) and RefPicList0 (8.3.4): pictures not in the set stop being references
   if (idr) for (auto &d : dpb_) d.is_ref = false;
   int nref = 0, ref_poc[16]; uint8_t ref_slot[16];
+  int nref1 = 0, ref_poc1[16]; uint8_t ref_slot1[16];
+  bool no_backward = true;
   if (!idr) {
-    int cand_slot[16], nc = 0;
+    int cand_slot[16], nc = 0, nbefore = 0;             // the used pictures: those before the current one in output order (nearest first), then those after it
     bool keep[KVZ_DEC_MAX_REFS] = {false};
     for (int k = 0; k < rps.n_neg + rps.n_pos; k++) {
       const int poc = sh.poc + rps.dpoc[k];
       int found = -1;
       for (int q = 0; q < KVZ_DEC_MAX_REFS; q++) if (dpb_[q].is_ref && dpb_[q].used && dpb_[q].poc == poc) found = q;
       if (found >= 0) keep[found] = true;
-      if (rps.used[k]) { if (found < 0 && !sh.is_intra) return DEC_ERR_INVALID; if (found >= 0 && nc < 16) cand_slot[nc++] = found; }      // a missing reference picture (lost access unit)
+      if (rps.used[k]) { if (found < 0 && !sh.is_intra) return DEC_ERR_INVALID; if (found >= 0 && nc < 16) { cand_slot[nc++] = found; if (k < rps.n_neg) nbefore = nc; } }      // a missing reference picture (lost access unit)
     }
     for (int q = 0; q < KVZ_DEC_MAX_REFS; q++) if (!keep[q]) dpb_[q].is_ref = false;
     if (!sh.is_intra) {
       if (nc == 0) return DEC_ERR_INVALID;
+      // 8.3.4: RefPicList0 = before, after, repeated; RefPicList1 = after, before, repeated
       nref = sh.num_ref_idx;
-      for (int k = 0; k < nref; k++) { ref_slot[k] = (uint8_t)cand_slot[k % nc]; ref_poc[k] = dpb_[ref_slot[k]].poc; }
+      for (int k = 0; k < nref; k++) { ref_slot[k] = (uint8_t)cand_slot[k % nc]; ref_poc[k] = dpb_[ref_slot[k]].poc; if (ref_poc[k] > sh.poc) no_backward = false; }
+      nref1 = sh.is_b ? sh.num_ref_idx1 : 0;
+      const int nafter = nc - nbefore;
+      for (int k = 0; k < nref1; k++) {
+        const int q = k % nc;
+        ref_slot1[k] = (uint8_t)cand_slot[q < nafter ? nbefore + q : q - nafter]; ref_poc1[k] = dpb_[ref_slot1[k]].poc;
+        if (ref_poc1[k] > sh.poc) no_backward = false;
+      }
     }
   }
   const int slot = alloc_slot();
@@ -1431,8 +1653,19 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   job.fps_num = s.fps_num ? s.fps_num : vps_fps_num_; job.fps_den = s.fps_num ? s.fps_den : vps_fps_den_;
   job.slot = slot; job.nref = nref;
   for (int k = 0; k < 16; k++) { job.ref_poc[k] = k < nref ? ref_poc[k] : sh.poc; job.ref_slot[k] = k < nref ? ref_slot[k] : 0; }
+  if (idr || (irap && !seen_irap_)) cvs_++;                     // a new coded video sequence: its pictures follow ALL of the last one's in output order
+  job.cvs = cvs_;
+  job.nref1 = nref1; job.no_backward = no_backward;
+  for (int k = 0; k < 16; k++) { job.ref_poc1[k] = k < nref1 ? ref_poc1[k] : sh.poc; job.ref_slot1[k] = k < nref1 ? ref_slot1[k] : 0; }
   job.col.reset();
-  if (sh.tmvp && !sh.is_intra) job.col = dpb_[ref_slot[sh.collocated_ref_idx]].motion;
+  if (sh.tmvp && !sh.is_intra) job.col = dpb_[(sh.is_b && !sh.collocated_from_l0) ? ref_slot1[sh.collocated_ref_idx] : ref_slot[sh.collocated_ref_idx]].motion;      // 8.5.3.2.8
+  job.any_bi.store(0, std::memory_order_relaxed);
+  if (sh.is_b) {                                                 // two-list motion for the parser's derivations, second vectors for the kernels
+    const size_t nb4 = (size_t)(pw_ / 4) * (ph_ / 4);
+    PicJob::MvF none; memset(&none, 0, sizeof(none)); none.ref[0] = none.ref[1] = -1;
+    job.mvf.assign(nb4, none);
+    if (job.b4x.size() != nb4) job.b4x.assign(nb4, B4L1());
+  }
   job.own.reset();
   if (s.tmvp) {                                                  // (only streams with temporal prediction ever read it)
     job.own = std::make_shared<ColMotion>();
@@ -1659,7 +1892,7 @@ void Decoder::describe_output(const PicJob &job, DecodedPicture &o, int buf) con
   o = DecodedPicture();
   o.coded_w = w_; o.coded_h = h_;
   o.width = w_ - job.crop[0] - job.crop[1]; o.height = h_ - job.crop[2] - job.crop[3];
-  o.poc = job.sh.poc; o.pts = job.pts; o.is_intra = job.sh.is_intra;
+  o.poc = job.sh.poc; o.pts = job.pts; o.is_intra = job.sh.is_intra; o.cvs = job.cvs; o.num_reorder = job.sps->num_reorder;
   o.fps_num = job.fps_num; o.fps_den = job.fps_den;
   for (int c = 0; c < 3; c++) {
     const int pw = c ? pw_ / 2 : pw_, ox = c ? job.crop[0] / 2 : job.crop[0], oy = c ? job.crop[2] / 2 : job.crop[2];
@@ -1744,6 +1977,7 @@ int Decoder::complete_gpu(PicJob &job)
 int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t len, SubOut &out)
 {
   SliceParser sp(job, out, pw_);
+  if (job.sh.is_b) sp.mvf = job.mvf.data();
   const int wc = sp.wc;
   const DecPps &pps = job.pps; const SliceHdr &sh = job.sh;
   const bool wpp = pps.wpp != 0;
@@ -1764,7 +1998,7 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
     }
     return seen_above < (1 << 29);                     // >= 1 << 29: that row failed
   };
-  const int init_type = sh.is_intra ? 0 : (sh.cabac_init_flag ? 2 : 1);
+  const int init_type = sh.is_intra ? 0 : (sh.is_b ? (sh.cabac_init_flag ? 1 : 2) : (sh.cabac_init_flag ? 2 : 1));      // 9.3.2.2: cabac_init_flag swaps the P and the B tables
   CabacDec &c = sp.c;
   c.start(data, len);
   // 9.3.1: the first CTB of a tile initialises the contexts; a WPP row takes them over from the row above after its second
@@ -1819,9 +2053,15 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
     if (!own) continue;
     for (int y16 = cy * 4; y16 < cy * 4 + 4 && y16 < own->h16; y16++)
       for (int x16 = cx0 * 4; x16 < cx1 * 4 && x16 < own->w16; x16++) {
-        const B4Rec &m = job.b4[(size_t)(y16 * 4) * (pw_ / 4) + x16 * 4];
+        const size_t i4 = (size_t)(y16 * 4) * (pw_ / 4) + x16 * 4;
+        const B4Rec &m = job.b4[i4];
         ColMotion::Mv &o = own->mv[(size_t)y16 * own->w16 + x16];
-        o.inter = m.ref_idx >= 0; o.mvx = m.mvx; o.mvy = m.mvy; o.ref_poc = m.ref_idx >= 0 ? job.ref_poc[m.ref_idx & 15] : 0;
+        memset(&o, 0, sizeof(o));
+        if (m.ref_idx < 0) continue;                           // intra
+        if (sh.is_b) {
+          const PicJob::MvF &f = job.mvf[i4];
+          for (int L = 0; L < 2; L++) if (f.ref[L] >= 0) { o.used |= (uint8_t)(1 << L); o.mv[L][0] = f.mv[L][0]; o.mv[L][1] = f.mv[L][1]; o.ref_poc[L] = L ? job.ref_poc1[f.ref[L] & 15] : job.ref_poc[f.ref[L] & 15]; }
+        } else { o.used = 1; o.mv[0][0] = m.mvx; o.mv[0][1] = m.mvy; o.ref_poc[0] = job.ref_poc[m.ref_idx & 15]; }
       }
     if (own->row_cols[(size_t)cy].fetch_add(1, std::memory_order_acq_rel) + 1 >= own->cols) own->row_done[(size_t)cy].store(1, std::memory_order_release);
   }
@@ -1867,7 +2107,11 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
   size_t ntu = 0, nlev = 0;
   for (auto &r : job.subs) { if (r.rc < 0) return r.rc; ntu += r.tus.size(); nlev += r.levels.size(); }
   const size_t tu_off = fixed_bytes(), lev_off = (tu_off + ntu * sizeof(DecTu) + 15) & ~(size_t)15;
-  if (!grow_job_input(job, lev_off + nlev * sizeof(uint32_t))) return DEC_ERR_GPU;
+  // (a picture with bi-predicted blocks: their second vectors ride behind the level words)
+  const bool bi = job.sh.is_b && job.any_bi.load(std::memory_order_relaxed) != 0;
+  const size_t x_off = (lev_off + nlev * sizeof(uint32_t) + 15) & ~(size_t)15, x_bytes = bi ? job.b4x.size() * sizeof(B4L1) : 0;
+  if (!grow_job_input(job, x_off + x_bytes)) return DEC_ERR_GPU;
+  if (bi) memcpy(job.h_in + x_off, job.b4x.data(), x_bytes);
   DecTu *tus = (DecTu *)(job.h_in + tu_off); uint32_t *lev = (uint32_t *)(job.h_in + lev_off);
   size_t t = 0, l = 0;
   for (int r = 0; r < nsub; r++) {
@@ -1893,7 +2137,9 @@ int Decoder::launch_gpu(PicJob &job)
   if (hipSetDevice(device_) != hipSuccess) return DEC_ERR_GPU;
   const size_t ntu = job.ntu, nlev = job.nlev;
   const size_t tu_off = fixed_bytes(), lev_off = (tu_off + ntu * sizeof(DecTu) + 15) & ~(size_t)15;
-  const size_t bytes = lev_off + nlev * sizeof(uint32_t);
+  const bool bi = job.sh.is_b && job.any_bi.load(std::memory_order_relaxed) != 0;
+  const size_t x_off = (lev_off + nlev * sizeof(uint32_t) + 15) & ~(size_t)15;
+  const size_t bytes = bi ? x_off + job.b4x.size() * sizeof(B4L1) : lev_off + nlev * sizeof(uint32_t);
   prof_now_ = profiling_ && (launched_ % prof_every_) == 0;
   timed_job_ = &job; job.ev_used = 0;
   if (!job.done && hipEventCreateWithFlags(&job.done, hipEventDisableTiming) != hipSuccess) return DEC_ERR_GPU;
@@ -1910,7 +2156,7 @@ int Decoder::launch_gpu(PicJob &job)
   }
   DecFrame f; memset(&f, 0, sizeof(f));
   f.w = w_; f.h = h_; f.pw = pw_; f.ph = ph_; f.wc = (w_ + 63) / 64; f.hc = (h_ + 63) / 64;
-  f.b4 = (const B4Rec *)d_in_; f.region = (const TuRange *)(d_in_ + off_region()); f.ctu = (const TuRange *)(d_in_ + off_ctu());
+  f.b4 = (const B4Rec *)d_in_; f.b4x = bi ? (const B4L1 *)(d_in_ + x_off) : nullptr; f.region = (const TuRange *)(d_in_ + off_region()); f.ctu = (const TuRange *)(d_in_ + off_ctu());
   f.ctu_tile = d_in_ + off_tile(); f.tus = (const DecTu *)(d_in_ + tu_off); f.lev = (const uint32_t *)(d_in_ + lev_off); f.ntu = (int)ntu;
   for (int c = 0; c < 3; c++) f.resid[c] = resid_[c];
   const bool sao = job.sh.sao_luma || job.sh.sao_chroma;      // the picture is then built in work_ and filtered into its buffer

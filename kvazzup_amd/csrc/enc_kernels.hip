@@ -1219,7 +1219,8 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     const uint2 dp = dep[k], cv = cover[k];
     // The neighbouring CTUs' samples this block reads come FIRST: they do not depend on this CTU's own blocks, so the memory round trip that fetches them
     // (and the poll, when the neighbour is not there yet) runs while the blocks in front of this one are still being coded, instead of behind them on the
-    // chain's critical path -- three of the four blocks of a CTU's top row paid it there.
+    // chain's critical path -- three of the four blocks of a CTU's top row paid it there.  (A form that looks once and polls only when the block's turn has
+    // come -- tried because a two-process run beside the test suite crawled, which turned out to have another cause -- is 6 % slower: 0.71 against 0.67 ms.)
     if (d.flags & IB_BORDER) {
       // the neighbouring CTUs are waited for only as far as the block's MODE reads them (hevc_core.h intra_uses_*): with "intra-chain" the left-edge blocks never
       // read the left CTU's below-left samples and the above-right CTU is not read at all

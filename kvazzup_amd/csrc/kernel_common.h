@@ -313,8 +313,9 @@ __device__ __forceinline__ void chain_init(IntraChain &ch, uint32_t done0, uint3
 }
 // wave-level borders_need(): the borders the block at (rx, ry), size n, reads are in LDS when it returns.  Two waves may copy
 // overlapping pieces (the same bytes); the *_loaded marks only ever grow.
-__device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNeighbours &b, uint8_t *pic, int lp, const uint8_t *plane, int gp, int cx, int cy, int S, int sh,
-                                                  int lim_w, int rx, int ry, int n, uint32_t *err, int lane, int nl2, int nt2)
+// try_only (a measurement aid): ONE look -- when something is not there yet nothing is copied and false comes back
+__device__ __forceinline__ bool borders_need_wave(IntraChain &ch, const IntraNeighbours &b, uint8_t *pic, int lp, const uint8_t *plane, int gp, int cx, int cy, int S, int sh,
+                                                  int lim_w, int rx, int ry, int n, uint32_t *err, int lane, int nl2, int nt2, bool try_only = false)
 {
   // (nl2 / nt2: as in borders_need)
   // Round 4: nothing is waited for through progress counters any more.  What a neighbouring CTU's INTRA units contribute arrives as self-validating words
@@ -356,6 +357,7 @@ __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNei
     for (;;) {
       const bool pL = tagL && (vL >> 8) != b.gen, pT = tagT && (qT >> 32) != gen, pC = tagC && (qC >> 32) != gen;
       if (__ballot(pL || pT || pC) == 0) break;
+      if (try_only) return false;
       if (++spins < 16) __builtin_amdgcn_s_sleep(1); else if (spins < 64) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(32);
       if (spins > (1u << 21)) { if (lane == 0) atomicOr(err, 1u); break; }           // bounded spin: never hang the GPU
       if (pL) vL = ld_l2_u32(b.ecol_left + iL);
@@ -376,6 +378,7 @@ __device__ __forceinline__ void borders_need_wave(IntraChain &ch, const IntraNei
     if (doC) atomicMax(&ch.corner_loaded, 1);
   }
   wave_sync();
+  return true;
 }
 // 8x8 luma units (bits in z-order) the block with its first unit at (ux, uy), su x su units, reads reference samples from inside its
 // own CTU: the units left, below-left, above, above-right and above-left of it that precede it in z-order (inside a CTU:

@@ -13,17 +13,20 @@ def run_stream(w, h, pictures, threads=1, frame_threads=False, **cfg):
     g = orc.OracleGen(w, h, **cfg)
     od = orc.OracleDecoder()
     gd = Decoder(threads=threads, frame_threads=frame_threads) if frame_threads else Decoder()
-    refs, got = [], []
+    refs, got, pocs = [], [], []
     try:
+        reorder = g.config.get("gop", 0) > 1              # (pictures come out in POC order, later than they go in)
         for t in range(pictures):
             au = g.picture()
             r = od.decode_au(au, t)
-            assert len(r) == 1, (t, g.config)
-            refs.append(r[0]["i420"])
+            assert reorder or len(r) == 1, (t, g.config)
+            refs += [f["i420"] for f in r]
+            pocs += [f["poc"] for f in r]
             got += gd.decode_au(au, t)
-        if frame_threads:
+        refs += [f["i420"] for f in od.flush()]
+        if frame_threads or reorder:
             got += gd.drain()
-        assert len(got) == pictures, (len(got), g.config)
+        assert len(got) == pictures and len(refs) == pictures, (len(got), len(refs), g.config)
         for t in range(pictures):
             assert got[t]["width"] == w and got[t]["height"] == h
             if not np.array_equal(got[t]["i420"], refs[t]):
@@ -212,3 +215,45 @@ def test_tile_columns(gpu, cols, rows, wpp, slices, frame, uniform):
 def test_tile_grid_1080p(gpu):
     """1080p in 4 x 4 tiles with WPP inside the tiles (68 substreams per picture), a slice per tile"""
     run_stream(1920, 1080, 4, seed=6, density=25, num_refs=2, tmvp=1, wpp=1, tile_cols=4, tile_rows=4, slices=2, intra_in_p=10, max_cu_log2=5, sao=1)
+
+
+B_FEATURES = [
+    dict(b_slices=70),                                                      # low-delay B (Kvazaar bipred=1 with its default GOP): both lists hold the same pictures
+    dict(b_slices=70, num_refs=3, tmvp=1),                                  # ... temporal candidates out of bi-predicted collocated blocks
+    dict(b_slices=100, num_refs=2, all_part_modes=1, amp=1),                # every partitioning: 8x4 / 4x8 blocks are never bi-predicted
+    dict(b_slices=60, gop=4, num_refs=3, tmvp=1),                           # groups of four (decoded 4 2 1 3): references on both sides, output reordering
+    dict(b_slices=50, gop=8, num_refs=4, tmvp=1, par_mrg_level=4),          # Kvazaar gop=8
+    dict(b_slices=80, gop=2, num_refs=2, tmvp=1, cabac_init=1, intra_in_p=20),
+    dict(b_slices=0, gop=4, num_refs=3, tmvp=1),                            # P pictures in reordered groups
+    dict(b_slices=60, gop=8, num_refs=4, tmvp=1, sao=1, qp_delta=2, deblock_mode=2, th_depth_inter=2, wpp=0, tile_rows=2, big_mvd=1),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("feature", B_FEATURES, ids=lambda kw: "-".join("%s%s" % (k[:3], v) for k, v in kw.items()))
+@pytest.mark.parametrize("frame", [False, True])
+def test_b_slices_and_output_reordering(gpu, feature, frame):
+    """what a uvgComm peer sends once `bipred=1` / `gop=8` sit in its custom-parameter list (kvazaarfilter.cpp:351-371) and OpenHEVC simply decodes
+    (openhevcfilter.cpp:145): B slices -- two reference lists, bi-prediction, the merge and AMVP derivations over both lists, temporal candidates out
+    of bi-predicted blocks, boundary strength with two vectors a side -- and pictures handed out in POC order, not decoding order"""
+    cfg = dict(PLAIN)
+    cfg.update(feature)
+    run_stream(416, 240, 19, threads=4 if frame else 1, frame_threads=frame, seed=41, intra_period=13, density=25, **cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(300, 316))
+def test_random_b_streams_match_oracle(gpu, seed):
+    """every other switch drawn from the seed"""
+    sizes = [(416, 240), (352, 288), (200, 136), (648, 360)]
+    w, h = sizes[seed % len(sizes)]
+    run_stream(w, h, 12, seed=seed, b_slices=(40, 70, 100)[seed % 3], gop=(0, 2, 4, 8)[(seed // 3) % 4], intra_period=9,
+               threads=3 if seed & 1 else 1, frame_threads=bool(seed & 1))
+
+
+@pytest.mark.gpu
+def test_b_pictures_1080p_gop8(gpu):
+    """1080p, Kvazaar gop=8 shape: hierarchical B pictures, four reference pictures, TMVP, WPP"""
+    run_stream(1920, 1080, 10, seed=21, b_slices=80, gop=8, num_refs=4, tmvp=1, strong_intra=0, sign_hiding=1, wpp=1, tile_rows=1, intra_in_p=10,
+               all_part_modes=1, amp=0, sao=1, qp_delta=0, deblock_mode=0, th_depth_inter=1, th_depth_intra=1, max_cu_log2=6, min_cu_log2=3, nxn_intra=1,
+               chroma_modes=1, transform_skip=0, cabac_init=0, chroma_qp_offsets=0, par_mrg_level=2, big_mvd=0, uniform_tiles=1, density=20)

@@ -1,7 +1,7 @@
 // kvazzup_amd/csrc/dec_frame.h -- what the host half of the decoder (CABAC parse, decoder.hip) hands to the device half
 // (dec_kernels.hip) for one picture.  The decoder sits behind libOpenHevcDecode, which uvgComm feeds with any peer's
 // stream (/root/reference/src/media/processing/openhevcfilter.cpp:134-172), so the layout is general for Main-profile
-// I / P pictures: any coding quadtree with CTB 64 and minimum CB 8, every partitioning, transform trees down to 4x4,
+// I / P / B pictures: any coding quadtree with CTB 64 and minimum CB 8, every partitioning, transform trees down to 4x4,
 // several reference pictures, coded sizes that are multiples of 8.
 //
 // Everything lives in ONE pinned host block per picture that goes to the GPU in one copy:

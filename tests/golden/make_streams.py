@@ -64,18 +64,26 @@ GEN = {
                          qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=0, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, tq_bypass=100),
     "gen_transquant_bypass_mixed": dict(seed=34, density=30, intra_period=8, num_refs=2, tmvp=1, sao=1, sign_hiding=1, transform_skip=1, wpp=1, tile_rows=1, tile_cols=1,
                                         qp_delta=2, deblock_mode=2, intra_in_p=25, nxn_intra=1, th_depth_inter=1, th_depth_intra=1, slices=0, big_mvd=0, tq_bypass=35),
+    # round 4: B slices, what `bipred=1` / `gop=8` in a peer's custom-parameter list make Kvazaar write (kvazaarfilter.cpp:351-371).  frame_md5 is in OUTPUT order
+    "gen_b_lowdelay": dict(seed=35, density=25, intra_period=8, num_refs=3, tmvp=1, amp=0, sao=0, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
+                           qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=80),
+    "gen_b_gop8": dict(seed=36, density=25, intra_period=16, num_refs=4, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
+                       qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=70, gop=8),
 }
 for name, cfg in GEN.items():
     g = orc.OracleGen(W, H, **cfg)
     od = orc.OracleDecoder()
     stream, md5s = b"", []
-    for t in range(6):
+    npic = 12 if cfg.get("gop") else 6
+    for t in range(npic):
         au = g.picture()
         stream += au
         for fr in od.decode_au(au, t):
             md5s.append(hashlib.md5(fr["i420"].tobytes()).hexdigest())
+    for fr in od.flush():                                  # (pictures held back for reordering)
+        md5s.append(hashlib.md5(fr["i420"].tobytes()).hexdigest())
     g.close(); od.close()
-    assert len(md5s) == 6, (name, len(md5s))
+    assert len(md5s) == npic, (name, len(md5s))
     open(os.path.join(out, name + ".hevc"), "wb").write(stream)
     index[name] = {"width": W, "height": H, "pictures": len(md5s), "bytes": len(stream), "hash_sei": None, "source": "oracle/hevc_gen.c (stream synthesiser), %s" % cfg, "frame_md5": md5s}
 json.dump(index, open(os.path.join(out, "index.json"), "w"), indent=1, sort_keys=True)

@@ -42,6 +42,8 @@ def test_checker_decodes_golden_stream(name):
         for fr in od.decode_au(au, t):
             assert (fr["width"], fr["height"]) == (meta["width"], meta["height"])
             md5s.append(hashlib.md5(fr["i420"].tobytes()).hexdigest())
+    for fr in od.flush():                                   # (a stream with reordering: the last pictures leave when it ends)
+        md5s.append(hashlib.md5(fr["i420"].tobytes()).hexdigest())
     assert md5s == meta["frame_md5"]
     checked, bad = od.hash_stats()
     assert bad == 0 and checked == (meta["pictures"] if meta["hash_sei"] else 0)
@@ -49,7 +51,7 @@ def test_checker_decodes_golden_stream(name):
 
 
 def test_golden_streams_are_small_enough_to_live_in_the_repository():
-    assert sum(m["bytes"] for m in INDEX.values()) <= 400 * 1024          # (fourteen streams since round 4)
+    assert sum(m["bytes"] for m in INDEX.values()) <= 440 * 1024          # (sixteen streams since round 4)
     assert sum(1 for m in INDEX.values() if m["hash_sei"] == "md5") >= 5
 
 

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
   const int R = f.range, W = 2 * R + 1, WW = 32 + 2 * R;
   const uint8_t *ref = f.ref[0], *src = f.src[0];
   const uint32_t lam = (uint32_t)f.lambda_q4;
+  if (f.pb_on && blockIdx.x == 0 && blockIdx.y == 0) picture_begin_body(f.pb_rc, f.pb_bits3, f.pb_slot3, f.pb_have3, f.pb_qt, f.pb_roi, f.pb_nctu, f.qp, 0, tid, nthreads);      // (nothing in this launch reads what it writes: k_inter_recon is the first)
   // the block itself, and (me-early-termination) its SAD against the co-located block of the reference: a block that differs
   // from it by no more than quantisation noise is coded unsplit with the zero vector, without a search
   if (tid == 0) red[0] = 0;

@@ -165,7 +165,7 @@ class Encoder {
   const int8_t *roi_dev_ = nullptr;
   int *vaq_act_ = nullptr, *vaq_sum_ = nullptr; // VAQ: activity of every CTU, its sum over the picture
   uint32_t next_chain_gen();
-  bool picture_begin(hipStream_t qt_stream);   // launch_picture_begin: the rate control state on the main stream (picture order), the per-CTU targets on the picture's own stream (+ the VAQ kernels)
+  bool picture_begin(hipStream_t qt_stream, EncFrame *fold = nullptr);     // fold: a P picture without VAQ -- the work rides in the picture's k_me launch (EncFrame::pb_*) instead of a launch of its own   // launch_picture_begin: the rate control state on the main stream (picture order), the per-CTU targets on the picture's own stream (+ the VAQ kernels)
   int qp_cur_ = 0; int64_t rc_debt_ = 0; uint32_t rc_bytes_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t rc_known_ = 0;   // rate control state (calling thread)
   void rate_control();
   RcState *rc_state_ = nullptr;                 // rate control v2: device-side state
@@ -176,7 +176,7 @@ class Encoder {
   hipEvent_t ev_src_free_[kSets] = {}; bool src_busy_[kSets] = {};
   uint8_t *work_[3] = {nullptr, nullptr, nullptr};   // SAO on: the picture up to deblocking (rec_[] then holds the filtered pictures)
   SaoParams *sao_[kSets] = {};            // per CTU, one array per set
-  hipEvent_t ev_sao_ = nullptr;
+
   // An intra picture depends on no other picture: its chain (1.6 ms at 1080p, twenty picture intervals) is queued on a stream of its own the moment the
   // picture is accepted, beside the P pictures in front of it that the main stream is still working through; the next P picture waits for ev_idr_done_.
   hipStream_t stream_idr_ = nullptr; hipEvent_t ev_idr_done_ = nullptr; bool idr_pending_ = false, idr_side_ = false;

@@ -104,7 +104,6 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   if (cfg.sao) {
     for (int c = 0; c < 3; c++) HIP_OK(hipMalloc(&work_[c], c ? npx / 4 : npx));
     for (int k = 0; k < kSets; k++) HIP_OK(hipMalloc(&sao_[k], sizeof(SaoParams) * (size_t)(cw_ / 64) * rows_));
-    HIP_OK(hipEventCreateWithFlags(&ev_sao_, kDeviceEvent));
   }
   if (cfg.rc_bands > 0) { HIP_OK(hipMalloc(&rc_state_, sizeof(RcState))); HIP_OK(hipMemset(rc_state_, 0, sizeof(RcState))); }
   HIP_OK(stream_acquire(&stream_tok_, cfg.device, 'T', prio_[1]));
@@ -283,7 +282,6 @@ Encoder::~Encoder()
   for (int c = 0; c < 3; c++) { hipFree(work_[c]); hipFree(work_idr_[c]); }
   hipFree(sync_idr_); hipFree(edge_col_idr_); hipFree(edge_row_); hipFree(edge_row_idr_);
   for (int k = 0; k < kSets; k++) hipFree(sao_[k]);
-  if (ev_sao_) hipEventDestroy(ev_sao_);
   if (ev_signalled_) hipEventDestroy(ev_signalled_);
   for (int k = 0; k < kSets; k++) if (ev_src_free_[k]) hipEventDestroy(ev_src_free_[k]);
   stream_release(stream_tok_, cfg_.device, 'T', prio_[1]);
@@ -496,12 +494,17 @@ uint32_t Encoder::next_chain_gen()
   return chain_gen_;
 }
 
-bool Encoder::picture_begin(hipStream_t qt_stream)
+bool Encoder::picture_begin(hipStream_t qt_stream, EncFrame *fold)
 {
   const bool have = frame_idx_ >= rc_delay_;
   const uint32_t bits3 = have ? 8u * rc_bytes_[(frame_idx_ - rc_delay_) & 7] : 0u;
   const int slot3 = (frame_idx_ - rc_delay_) & 7, n = (cw_ / 64) * rows_;
   int8_t *qt = cfg_.qp_in_cu ? ctu_qt_[set_] : nullptr;
+  if (fold && qt_stream == stream_ && cfg_.vaq == 0) {
+    fold->pb_on = (rc_state_ || qt) ? 1 : 0; fold->pb_rc = rc_state_; fold->pb_qt = qt; fold->pb_roi = roi_dev_; fold->pb_bits3 = bits3; fold->pb_nctu = n;
+    fold->pb_slot3 = (int8_t)slot3; fold->pb_have3 = have ? 1 : 0;
+    return true;
+  }
   if (qt_stream == stream_) launch_picture_begin(rc_state_, bits3, slot3, have ? 1 : 0, qt, roi_dev_, n, qp_cur_, cfg_.vaq > 0 ? 1 : 0, stream_);
   else {
     // an intra picture on its side stream: the rate control state is updated in PICTURE ORDER on the main stream (between the P pictures' row groups, which
@@ -570,23 +573,25 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   if (src_busy_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_src_free_[set_], 0)); src_busy_[set_] = false; }   // the last picture that used this set (t - kSets) has been reconstructed
   timed(K_PAD, stream_in_, [&] { launch_pad_input(d_i420, w, h, src_[set_][0], src_[set_][1], src_[set_][2], cw_, ch_, stream_in_); });
   if (in_ring >= 0) { HIP_CHECK(hipEventRecord(ev_pad_[in_ring], stream_in_)); pad_pending_[in_ring] = true; }
+  // The tokenizer of the set's previous picture must be done with the set's CU arrays before this picture writes them: the INPUT stream waits for it (the
+  // event is long past when it gets there), so that the main stream's one wait for in_done_ says both -- a wait of its own in front of every picture's chain
+  // cost the chain a barrier packet, a few microseconds with nothing running.
+  if (tok_pending_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_tok_done_[set_], 0)); tok_pending_[set_] = false; }
   if (intra) {
-    // The intra decisions need the source picture only: they run on the input stream, beside what is left of picture t - 1
-    // on the main stream (they write the CU arrays of this set: the tokenizer of the set's previous picture must be done with them).
-    if (tok_pending_[set_]) HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_tok_done_[set_], 0));
+    // The intra decisions need the source picture only: they run on the input stream, beside what is left of picture t - 1 on the main stream.
     timed(K_INTRA_ANALYSE, stream_in_, [&] { launch_intra_analyse(f, stream_in_); });
   }
   if (!stage_roi(stream_in_)) return false;
   HIP_CHECK(hipEventRecord(in_done_, stream_in_)); in_pending_ = true;
-  HIP_CHECK(hipStreamWaitEvent(ms, in_done_, 0));
-  if (tok_pending_[set_]) { HIP_CHECK(hipStreamWaitEvent(ms, ev_tok_done_[set_], 0)); tok_pending_[set_] = false; }   // the tokenizer of the set's previous picture is done with it
-  if (!picture_begin(ms)) return false;
+  HIP_CHECK(hipStreamWaitEvent(ms, in_done_, 0));      // (measured by leaving it out: 8 of the ~28 us between a picture's last kernel and the next one's first; the rest is the record behind k_sao that two other streams wait for)
+  EncFrame fm = f;                                               // (the picture's first kernel may carry the head of the chain)
+  if (!picture_begin(ms, intra ? nullptr : &fm)) return false;
   if (intra) {
     HIP_CHECK(hipMemsetAsync(f.sync, 0, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 1), ms));
     HIP_CHECK(hipMemsetAsync(f_.cu_cbf, 0, (size_t)f_.b8w * f_.b8h, ms));     // the three plane waves OR their bit in
     timed(K_INTRA_RECON, ms, [&] { launch_intra_recon(f, ms); });
   } else {
-    timed(K_ME, stream_, [&] { launch_me(f, stream_); });
+    timed(K_ME, stream_, [&] { launch_me(fm, stream_); });
     // intra-in-P: quarters whose inter cost is high are priced as intra blocks and may become intra units (the launch leaves at once where none is)
     if (cfg_.intra_in_p) timed(K_INTRA_ANALYSE_P, stream_, [&] { launch_intra_analyse(f, stream_); });
     if (cfg_.subme > 0) timed(K_SUBPEL, stream_, [&] { launch_subpel(f, stream_); });
@@ -607,12 +612,12 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   // are coded) -- then no event is recorded in the middle of the chain (an event between two kernels of a stream costs the chain ~7 us)
   if (!cfg_.sao) HIP_CHECK(hipEventRecord(ev_signalled_, ms));
   if (cfg_.deblock) timed(K_DEBLOCK, ms, [&] { launch_deblock(f, ms); });
-  if (cfg_.sao) { timed(K_SAO, ms, [&] { launch_sao(f, ms); }); HIP_CHECK(hipEventRecord(ev_sao_, ms)); }
+  if (cfg_.sao) timed(K_SAO, ms, [&] { launch_sao(f, ms); });      // (ONE event behind the chain's last kernel says "SAO done" and "the set is free": every record in the chain is a packet the next picture waits behind)
   // Last reader of this set on the main stream: k_sao reads the source picture for its statistics, deblocking the CU records.
   // Input padding and intra analysis of the next picture with this set (input stream) overwrite both and wait for this event.
   HIP_CHECK(hipEventRecord(ev_src_free_[set_], ms)); src_busy_[set_] = true;
   if (side) { HIP_CHECK(hipEventRecord(ev_idr_done_, ms)); idr_pending_ = true; }
-  HIP_CHECK(hipStreamWaitEvent(stream_tok_, cfg_.sao ? ev_sao_ : ev_signalled_, 0));
+  HIP_CHECK(hipStreamWaitEvent(stream_tok_, cfg_.sao ? ev_src_free_[set_] : ev_signalled_, 0));
   if (!intra) timed(K_INTER_SIGNAL, stream_tok_, [&] { launch_inter_signal(f, stream_tok_); });
   timed(K_TOKENIZE, stream_tok_, [&] { launch_tokenize(f, stream_tok_); });
   timed(K_TOK_COMPACT, stream_tok_, [&] { launch_tok_compact(f, stream_tok_); });

@@ -114,6 +114,8 @@ struct EncFrame {
   const uint32_t *intra_order;  // CTU (raster index) handled by the k-th workgroup triple of k_intra_recon: anti-diagonal wavefront order
   // rate control v2 (NULL = off): k_inter_recon reconstructs the CTU rows in rc_nb groups inside ONE launch -- a group's workgroups price their levels, the last
   // of them decides the next group's QP step, and that group's workgroups, prediction and forward transform done, wait for the decision in front of the quantiser
+  // the head of a P picture's chain folded into its first kernel (k_me; pb_on): what k_picture_begin does for the pictures that start otherwise
+  RcState *pb_rc; int8_t *pb_qt; const int8_t *pb_roi; uint32_t pb_bits3; int pb_nctu; int8_t pb_on, pb_slot3, pb_have3, pb_pad;
   RcState *rc; long long rc_target; int rc_nb, rc_slot;      // rc_target: bits for the picture; rc_slot: where the picture's level cost is filed (picture index & 7)
   unsigned long long *trace;    // KVAZZUP_AMD_INTRA_TRACE: per (CTU, plane) 8 words {start, first block, end, time in border waits, blocks, stores, publishes, number of blocks} of k_intra_recon, 100 MHz ticks; else NULL
 };

@@ -129,6 +129,25 @@ __device__ __forceinline__ void load_matrices(int16_t (*M)[KV_MATRIX_ENTRIES], i
 template <int L2, int OPL> struct XF { static constexpr int N = 1 << L2, G = N / OPL, LANES = (N / 2) * G; };
 
 
+// The head of a picture's chain (rc_kernels.hip k_picture_begin; a P picture without VAQ: the first workgroup of k_me -- a launch of its own cost the chain
+// its 6 us and the gap in front of it): rate control v2's counters back to zero and its ratio updated from the access unit sized meanwhile, every CTU's target QP.
+// Called by all `nthreads` threads of ONE workgroup.
+__device__ __forceinline__ void picture_begin_body(RcState *rc, uint32_t bits3, int slot3, int have3, int8_t *ctu_qt, const int8_t *roi, int nctu, int qp, int vaq, int tid, int nthreads)
+{
+  if (ctu_qt) for (int i = tid; i < nctu; i += nthreads) { const int d = roi ? roi[i] : 0; ctu_qt[i] = (int8_t)(vaq ? d : clip3(0, 51, qp + d)); }
+  if (!rc || tid) return;
+  rc->cost_sofar = 0; rc->decided = 0;
+  for (int g = 0; g < 8; g++) rc->acc[g * KVZ_RC_ACC_STRIDE] = 0;
+  if (!have3 || !rc->cost_valid[slot3]) return;
+  rc->cost_valid[slot3] = 0;
+  const uint32_t c = rc->cost[slot3];
+  unsigned long long r = ((unsigned long long)bits3 << 8) / (c ? c : 1u);
+  if (r > (1u << 20)) r = 1u << 20;
+  if (r < 1) r = 1;
+  rc->ratio_q8 = rc->ratio_valid ? (uint32_t)((3ull * rc->ratio_q8 + r + 2) >> 2) : (uint32_t)r;
+  rc->ratio_valid = 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fence-free hand-off between workgroups inside a launch (cdna_hip_programming.md section 6, Guideline 16, recipe R1): the
 // producer stores its payload WRITE-THROUGH (agent-scope relaxed atomic stores = `sc1`), every storing wave drains its stores,

@@ -25,20 +25,8 @@ namespace kvzx {
 //     deltas (per CTU, already spread over the CTU grid) were uploaded on the input stream when the picture brought a map; NULL = no map.
 __global__ __launch_bounds__(256) void k_picture_begin(RcState *rc, uint32_t bits3, int slot3, int have3, int8_t *ctu_qt, const int8_t *roi, int nctu, int qp, int vaq)
 {
-  if (ctu_qt) for (int i = threadIdx.x; i < nctu; i += 256) { const int d = roi ? roi[i] : 0; ctu_qt[i] = (int8_t)(vaq ? d : clip3(0, 51, qp + d)); }
-  if (!rc || threadIdx.x) return;
-  rc->cost_sofar = 0; rc->decided = 0;
-  for (int g = 0; g < 8; g++) rc->acc[g * KVZ_RC_ACC_STRIDE] = 0;
-  if (!have3 || !rc->cost_valid[slot3]) return;
-  rc->cost_valid[slot3] = 0;
-  const uint32_t c = rc->cost[slot3];
-  unsigned long long r = ((unsigned long long)bits3 << 8) / (c ? c : 1u);
-  if (r > (1u << 20)) r = 1u << 20;
-  if (r < 1) r = 1;
-  rc->ratio_q8 = rc->ratio_valid ? (uint32_t)((3ull * rc->ratio_q8 + r + 2) >> 2) : (uint32_t)r;
-  rc->ratio_valid = 1;
+  picture_begin_body(rc, bits3, slot3, have3, ctu_qt, roi, nctu, qp, vaq, (int)threadIdx.x, 256);
 }
-
 void launch_picture_begin(RcState *rc, uint32_t bits3, int slot3, int have3, int8_t *ctu_qt, const int8_t *roi, int nctu, int qp, int vaq, hipStream_t st)
 {
   if (rc || ctu_qt) hipLaunchKernelGGL(k_picture_begin, dim3(1), dim3(256), 0, st, rc, bits3, slot3, have3, ctu_qt, roi, nctu, qp, vaq);

@@ -1,0 +1,52 @@
+// What an event record behind a kernel that has just WRITTEN a picture costs the stream's next kernel: the record is an agent-scope release -- the L2s'
+// dirty lines go out first.  A chain of (writer kernel, [record], reader kernel) on one stream, another stream waiting for the record;
+// plain stores against nontemporal ones.  hipcc --offload-arch=gfx950 -O2 -o tools/measure/record_after_writer tools/measure/record_after_writer.hip
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdio.h>
+#include <chrono>
+template <bool NT> __global__ void writer(uint4 *p, size_t n, unsigned v)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    typedef unsigned v4 __attribute__((ext_vector_type(4)));
+    v4 x = {v, v + 1, v + 2, (unsigned)i};
+    if (NT) __builtin_nontemporal_store(x, (v4 *)&p[i]); else *(v4 *)&p[i] = x;
+  }
+}
+__global__ void reader(const uint4 *p, size_t n, unsigned *out)
+{
+  unsigned a = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a += p[i].x;
+  if (a == 0x12345678u) *out = a;
+}
+__global__ void tiny(unsigned *out) { if (threadIdx.x == 9999) *out = 1; }
+int main()
+{
+  hipStream_t b, c; hipStreamCreate(&b); hipStreamCreate(&c);
+  const size_t bytes = 6u << 20, n = bytes / 16;
+  uint4 *p; unsigned *out; hipMalloc(&p, bytes); hipMalloc(&out, 4);
+  hipEvent_t ev; hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence);
+  const int N = 300;
+  const char *names[6] = {"no record", "record, nobody waits", "record + another stream waiting behind it", "hipExtLaunchKernelGGL stop event + waiter", "record with default flags + waiter", "record, waiter enqueued one iteration later"};
+  hipEvent_t evd; hipEventCreateWithFlags(&evd, hipEventDisableTiming);
+  hipEvent_t ring[4]; for (auto &e : ring) hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence);
+  for (int mode = 0; mode < 6; mode++) {
+    hipDeviceSynchronize();
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < N; i++) {
+      if (mode == 3) hipExtLaunchKernelGGL(writer<false>, dim3(2048), dim3(256), 0, b, nullptr, ev, 0, p, n, (unsigned)i);
+      else hipLaunchKernelGGL(writer<false>, dim3(2048), dim3(256), 0, b, p, n, (unsigned)i);
+      if (mode == 1 || mode == 2) hipEventRecord(ev, b);
+      if (mode == 4) hipEventRecord(evd, b);
+      if (mode == 5) hipEventRecord(ring[i & 3], b);
+      if (mode == 2 || mode == 3) { hipStreamWaitEvent(c, ev, 0); hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, c, out); }
+      if (mode == 4) { hipStreamWaitEvent(c, evd, 0); hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, c, out); }
+      if (mode == 5 && i) { hipStreamWaitEvent(c, ring[(i - 1) & 3], 0); hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, c, out); }
+      hipLaunchKernelGGL(reader, dim3(2048), dim3(256), 0, b, p, n, out);
+    }
+    hipStreamSynchronize(b); hipStreamSynchronize(c);
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    printf("%-50s %7.2f us per (writer + reader)\n", names[mode], us / N);
+  }
+  return 0;
+}

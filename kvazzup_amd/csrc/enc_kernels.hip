@@ -428,8 +428,8 @@ __device__ __forceinline__ void inter_transform_32(InterLds &s, int qp, uint32_t
 
 // Rate control v2, the tail of a workgroup of k_inter_recon<.., RC>: its level cost joins its group's (one atomic: arrivals << 40 | cost), and the workgroup
 // that completes the group decides for the next one (statement: rc_band_decide() in oracle/hevc_enc.c) -- prices the rows done against their share of the
-// picture's target, moves the running QP step and publishes it in RcState::decided: bits 0..3 the number of groups decided, bits 4 + 3 (g - 1) .. the step
-// of group g, biased by 3.  The per-CTU QP array is left alone while workgroups may still read it: the workgroup that completes the LAST group applies
+// picture's target, moves the running QP step and publishes it -- the step of the group AFTER THE NEXT (round 4: one group of lag, so that no group waits
+// for the one right in front of it) -- in RcState::decided: bits 0..3 the number of groups closed, bits 4 + 3 (g - 1) .. the step of group g, biased by 3.  The per-CTU QP array is left alone while workgroups may still read it: the workgroup that completes the LAST group applies
 // every group's step to it (for k_qp_first / k_qp_chain, deblocking and k_intra_recon) and files the picture's cost for k_rc_begin of a later picture.
 __device__ __forceinline__ int rc_word_step(uint32_t word, int grp) { return grp > 0 ? (int)((word >> (4 + 3 * (grp - 1))) & 7u) - 3 : 0; }
 __device__ __forceinline__ void rc_group_done(const EncFrame &f, InterLds &s, int grp, uint32_t cost, int tid)
@@ -446,19 +446,28 @@ __device__ __forceinline__ void rc_group_done(const EncFrame &f, InterLds &s, in
     const bool last = (old >> 40) == (unsigned long long)((r1 - r0) * 2 * (f.cw >> 5)) - 1ull;
     uint32_t word = 0;
     if (last) {
-      // (cost_sofar and the word were left by the group before, whose decision this workgroup has waited for)
+      // The groups are processed in order: cost_sofar and the word are what the group before this one left -- whose workgroups this group did NOT wait
+      // for (a group waits for the one before the last, see k_inter_recon), so the one thread that closes this group does (rarely long: that group
+      // started earlier).
+      if (grp > 0) { uint32_t spins = 0; while ((ld_l2_u32(&rc->decided) & 15u) < (uint32_t)grp) { __builtin_amdgcn_s_sleep(8); if (++spins > (1u << 22)) { atomicOr(f.err, 1u); break; } } }
       const uint32_t total = ld_l2_u32(&rc->cost_sofar) + (uint32_t)((old & ((1ull << 40) - 1)) + mine);
       word = ld_l2_u32(&rc->decided);
       if (grp + 1 < nb) {
-        int off = rc_word_step(word, grp);
-        if (ld_l2_u32(&rc->ratio_valid)) {
-          const unsigned long long est = ((unsigned long long)total * ld_l2_u32(&rc->ratio_q8)) >> 8, tgt = ((unsigned long long)f.rc_target * (unsigned long long)r1) / (unsigned long long)rows;
-          if (est * 8 > tgt * 9) off++; else if (est * 8 < tgt * 7) off--;
-          off = clip3(-3, 3, off);
+        // the step of group grp + 2: the running step (that of group grp + 1, decided a group ago; groups 0 and 1: none) moved by what groups 0 .. grp cost
+        if (grp == 0) word |= 3u << 4;                        // (group 1's step, biased: 0)
+        if (grp + 2 < nb) {
+          int off = rc_word_step(word, grp + 1);
+          if (ld_l2_u32(&rc->ratio_valid)) {
+            const unsigned long long est = ((unsigned long long)total * ld_l2_u32(&rc->ratio_q8)) >> 8, tgt = ((unsigned long long)f.rc_target * (unsigned long long)r1) / (unsigned long long)rows;
+            if (est * 8 > tgt * 9) off++; else if (est * 8 < tgt * 7) off--;
+            off = clip3(-3, 3, off);
+          }
+          word |= (uint32_t)(off + 3) << (4 + 3 * (grp + 1));
         }
         st_wt_u32(&rc->cost_sofar, total);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        st_wt_u32(&rc->decided, (word & ~15u) | (uint32_t)(grp + 1) | ((uint32_t)(off + 3) << (4 + 3 * grp)));
+        word = (word & ~15u) | (uint32_t)(grp + 1);
+        st_wt_u32(&rc->decided, word);
       } else { rc->cost[f.rc_slot] = total; rc->cost_valid[f.rc_slot] = 1; }
     }
     s.rc_last = (last && grp + 1 == nb) ? 1 : 0; s.rc_qp = (int)word;
@@ -501,10 +510,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || AD
   // RC: called by the luma transform in front of its quantiser -- the CTU's QP once the group before this one has decided (rc_group_done): the word
   // that counts the decided groups carries their QP steps as well, so the wait costs one trip to memory
   auto qp_late = [&]() -> int {
-    if (RC && grp > 0) {
+    if (RC && grp > 1) {                                             // (groups 0 and 1 run at the picture's QP; group g's step was decided when group g - 2 closed)
       if (tid == 0) {
         uint32_t spins = 0, v;
-        while (((v = ld_l2_u32(&f.rc->decided)) & 15u) < (uint32_t)grp) {
+        while (((v = ld_l2_u32(&f.rc->decided)) & 15u) + 1u < (uint32_t)grp) {
           __builtin_amdgcn_s_sleep(24);                                  // (~0.6 us: hundreds of workgroups poll this word, and the polls travel to memory)
           if (++spins > (1u << 22)) { atomicOr(f.err, 1u); break; }      // bounded spin: never hang the GPU
         }

@@ -686,9 +686,12 @@ static void encode_inter_picture(orc_encoder *e)
   e->intra_p_ready = 0;
   for (int y = 0; y < e->ch; y += 32) for (int x = 0; x < e->cw; x += 32) me_block32(e, x, y);
   /* Reconstruction, in rc_bands groups of CTU rows when rate control v2 is on: after each group the level cost so far is priced
-   * against the share of the picture's target the rows done are entitled to, and the next group's QP follows (rc_band_decide). */
+   * against the share of the picture's target the rows done are entitled to, and the QP of the group AFTER THE NEXT follows (rc_band_decide;
+   * round 4: one group of lag -- groups 0 and 1 run at the picture's QP, group b + 2 at the running step moved by what groups 0 .. b cost --, so
+   * that a group never waits for the group right in front of it: four strictly serial groups were 56 us of a 1080p picture's chain, against 27) */
   {
-    int hc = e->ch / 64, wc = e->cw / 64, nb = e->cfg.rc_bands > 0 ? (e->cfg.rc_bands < hc ? e->cfg.rc_bands : hc) : 1, off = 0;
+    int hc = e->ch / 64, wc = e->cw / 64, nb = e->cfg.rc_bands > 0 ? (e->cfg.rc_bands < hc ? e->cfg.rc_bands : hc) : 1;
+    int offs[16]; memset(offs, 0, sizeof(offs));
     uint32_t cost = 0;
     const int64_t T = e->cfg.bitrate > 0 ? ((int64_t)e->cfg.bitrate * e->cfg.fps_den) / (e->cfg.fps_num > 0 ? e->cfg.fps_num : 1) : 0;
     for (int b = 0; b < nb; b++) {
@@ -707,10 +710,10 @@ static void encode_inter_picture(orc_encoder *e)
       }
       if (e->cfg.rc_bands > 0) {
         for (int cy = r0; cy < r1; cy++) for (int cx = 0; cx < wc; cx++) cost += rc_ctu_cost(e, cx, cy);
-        if (b + 1 < nb) {
-          off = rc_band_decide(off, cost, e->rc_ratio_valid ? e->rc_ratio_q8 : 0, T, r1, hc);
-          int r2 = ((b + 2) * hc) / nb;
-          for (int cy = r1; cy < r2; cy++) for (int cx = 0; cx < wc; cx++) e->ctu_qt[cy * wc + cx] = (int8_t)orc_clip3(0, 51, e->ctu_qt[cy * wc + cx] + off);
+        if (b + 2 < nb) {
+          const int off = offs[b + 2] = rc_band_decide(offs[b + 1], cost, e->rc_ratio_valid ? e->rc_ratio_q8 : 0, T, r1, hc);
+          const int r2 = ((b + 2) * hc) / nb, r3 = ((b + 3) * hc) / nb;
+          for (int cy = r2; cy < r3; cy++) for (int cx = 0; cx < wc; cx++) e->ctu_qt[cy * wc + cx] = (int8_t)orc_clip3(0, 51, e->ctu_qt[cy * wc + cx] + off);
         }
       }
     }

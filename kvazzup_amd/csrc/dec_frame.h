@@ -68,8 +68,11 @@ struct DecFrame {
   uint8_t *out[3];          // SAO output (== rec planes of the picture buffer when SAO runs from a work picture)
   const uint8_t *ref[KVZ_DEC_MAX_REFS][3];   // picture buffers by slot
   const SaoParams *sao;     // per CTU; NULL = off
-  uint8_t *edge_col[3];     // k_dec_intra: per plane [CTU][64 >> (plane != 0)] the right column of the CTU's intra blocks (kernel_common.h IB_EDGE_R)
-  uint32_t *progress;       // intra wavefront: [CTU][plane] = 8x8 luma units of the CTU whose intra blocks are final
+  // k_dec_intra's hand-off between CTUs (kernel_common.h IntraNeighbours): per plane and CTU the right column / bottom row of its intra blocks as
+  // self-validating words -- one sample | chain_gen << 8 per row, four samples | chain_gen << 32 per four columns -- that the neighbouring CTU's wave
+  // polls until they carry this launch's generation
+  uint32_t *edge_col[3]; unsigned long long *edge_row[3]; uint32_t chain_gen;
+  uint32_t *progress;       // k_dec_intra's ticket counter, at [3 * CTUs] (the per-CTU progress counters in front of it are no longer used)
   const uint32_t *intra_order;  // CTU handled by the k-th workgroup triple of k_dec_intra: anti-diagonal order (enc_kernels.hip k_intra_recon)
   uint32_t *err;
   int8_t cb_qp_offset, cr_qp_offset;       // pps_cb/cr_qp_offset (deblocking uses these, 8.7.2.5.5)

@@ -442,7 +442,7 @@ template <int L2, int T, class F>
 __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, const DecTu &d, int c, int cx, int cy, int rx, int ry, int lane, const uint32_t (&wreg)[4])
 {
   constexpr int N = XW<L2, T>::N, OPL = XW<L2, T>::OPL, G = XW<L2, T>::G;
-  const int sh = c ? 1 : 0, S = 64 >> sh, nl = N << sh, cpitch = f.pw >> sh, wC = f.w >> sh, hC = f.h >> sh;
+  const int sh = c ? 1 : 0, S = 64 >> sh, nl = N << sh, wC = f.w >> sh, hC = f.h >> sh;
   const int mode = d.mode, cidx = c ? 1 : 0;
   const bool filt = intra_filter_needed(N, cidx, mode);
   const int Xc = cx * S + rx, Yc = cy * S + ry, X = Xc << sh, Y = Yc << sh;
@@ -553,8 +553,8 @@ __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, cons
       for (int o = 0; o < OPL; o++) s.pic[(ry + 2 * rp + e + 1) * DI_P + 16 + rx + g * OPL + o] = (uint8_t)pred[e][o];
   }
   __syncthreads();
-  // block -> picture, write-through: neighbouring CTUs' workgroups read it from there (kernel_common.h, fence-free hand-off)
-  store_block_wt(f.rec[c] + (size_t)Yc * cpitch + Xc, cpitch, &s.pic[(ry + 1) * DI_P + 16 + rx], DI_P, N, lane, T);
+  // (the block stays in the CTU picture in LDS: the caller hands its last column / row to the neighbouring CTUs as tagged words, and the CTU goes to the
+  // picture in full lines at the end)
 }
 
 // The residual of an intra transform block does not depend on its prediction: all of a picture's are computed at once, one wave per
@@ -607,7 +607,7 @@ template <class F> __device__ __forceinline__ void dec_intra_resid_body(const F 
 // residual samples (k_dec_intra_resid), loaded by the caller one block ahead
 template <int L2>
 __device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveScratch &ws, const IntraBlk &d, bool luma,
-                                                     uint8_t *gdst, int gp, int lane, uint2 rres, uint32_t *publish, uint8_t *ecol)
+                                                     int lane, uint2 rres, uint32_t *ecol, unsigned long long *erow, uint32_t gen)
 {
   constexpr int N = 1 << L2;
   const int g = lane >> 4, c = lane & 15, rx = d.rx, ry = d.ry;
@@ -619,15 +619,13 @@ __device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveSc
 #pragma unroll
     for (int r = 0; r < 4; r++) pred[r] = clip8(pred[r] + res[r]);
   }
-  // (a progress value due before this block is published here, behind the block's computation: enc_kernels.hip intra_block_wave)
-  if (publish) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) __hip_atomic_store(publish, (uint32_t)d.zu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   if (active) {
     const uint32_t o = (uint32_t)pred[0] | ((uint32_t)pred[1] << 8) | ((uint32_t)pred[2] << 16) | ((uint32_t)pred[3] << 24);
     *(uint32_t *)&s.pic[(ry + c + 1) * DI_P + 16 + rx + 4 * g] = o;
-    // write-through, and only what a neighbouring CTU's workgroup will read -- the CTU's last row (IB_EDGE: the block ends on it) and its last column
-    // (below) --; the rest of the CTU goes out in full lines at the end (k_dec_intra)
-    if ((d.flags & IB_EDGE) && c == N - 1) st_wt_u32(gdst + (size_t)(ry + c) * gp + rx + 4 * g, o);
-    if ((d.flags & IB_EDGE_R) && g == (N >> 2) - 1) st_wt_u8(ecol + ry + c, o >> 24);      // the block's last column, one byte per row, for the right neighbour's left border
+    // what a neighbouring CTU's wave will read -- the CTU's last row (IB_EDGE) and last column (IB_EDGE_R) -- leaves at once, as self-validating words
+    // nobody waits for (kernel_common.h IntraNeighbours; round 4, as in the encoder's chain); the CTU itself goes to the picture in full lines at the end
+    if ((d.flags & IB_EDGE) && c == N - 1) st_wt_u64(erow + ((rx + 4 * g) >> 2), (unsigned long long)o | ((unsigned long long)gen << 32));
+    if ((d.flags & IB_EDGE_R) && g == (N >> 2) - 1) st_wt_u32(ecol + ry + c, (o >> 24) | (gen << 8));
   }
   wave_sync();
 }
@@ -638,7 +636,7 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
   constexpr int T = 64;
   __shared__ DecIntraLds s;
   __shared__ IntraWaveScratch ws;
-  __shared__ uint32_t bcast, bc4[4];
+  __shared__ IntraChain ch;                               // (its border watermarks: the one wave of this workgroup is the only user)
   // (enc_kernels.hip k_intra_recon: the launch has as many workgroups as the wavefront keeps busy, each takes the next (CTU, plane) in
   // anti-diagonal order from a ticket counter -- f.progress[3 * CTUs] -- so that the chain does not park a workgroup per (CTU, plane) on the chip)
   const int lane = threadIdx.x;
@@ -657,13 +655,9 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
   if (ticket >= nticket) break;
   const int ctu = (int)f.intra_order[ticket / 3u], c = (int)(ticket % 3u), cx = ctu % f.wc, cy = ctu / f.wc;
   const int sh = c ? 1 : 0, S = 64 >> sh, cpitch = f.pw >> sh, wC = f.w >> sh, hC = f.h >> sh;
-  uint32_t *my = f.progress + (size_t)ctu * 3 + c;
   const TuRange ct = f.ctu[ctu];
   const int count = (int)(ct.count & 0xffffffu);
-  if (!((ct.count >> (24 + c)) & 1)) {                  // no intra block of this plane in the CTU: nothing to wait for, nothing written
-    if (lane == 0) __hip_atomic_store(my, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    continue;
-  }
+  if (!((ct.count >> (24 + c)) & 1)) continue;          // no intra block of this plane in the CTU: nothing to wait for, nothing written
   uint8_t *plane = f.rec[c];
   // the CTU as the inter kernel left it (its inter blocks are final, the intra ones get written below) -> LDS
   {
@@ -694,12 +688,10 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
     const int nTR = (aT && dec_avail(f, X, Y, X + nl, Y - 1)) ? imin(N, wC - (Xc + N)) : 0;
     const int lo = aL ? N - nBL : (aTL ? 2 * N : 2 * N + 1), hi = aT ? 3 * N + nTR : (aTL ? 2 * N : (aL ? 2 * N - 1 : 0));
     const int zu = zunit8((rx << sh) >> 3, (ry << sh) >> 3);
-    int zprev = 0;
-    if (k > 0) { const DecTu p = s.list[k - 1]; zprev = zunit8(((p.x - cx * S) << sh) >> 3, ((p.y - cy * S) << sh) >> 3); }
     IntraBlk d;
     d.rx = (uint8_t)rx; d.ry = (uint8_t)ry; d.lo = (uint8_t)lo; d.hi = (uint8_t)hi; d.mode = t.mode; d.l2 = t.log2;
     d.flags = (uint8_t)((intra_filter_needed(N, c ? 1 : 0, t.mode) ? IB_FILT : 0) | ((rx == 0 || ry == 0) ? IB_BORDER : 0) |
-                        (kv_intra_milestone(zu) > kv_intra_milestone(zprev) ? IB_PUBLISH : 0) | (t.count ? IB_LEVELS : 0) | ((t.flags & TU_TSKIP) ? IB_TSKIP : 0) |
+                        (t.count ? IB_LEVELS : 0) | ((t.flags & TU_TSKIP) ? IB_TSKIP : 0) |
                         ((ry + N >= S) ? IB_EDGE : 0) | ((rx + N >= S) ? IB_EDGE_R : 0));
     d.xf = (uint8_t)((t.log2 == 2 && (t.flags & TU_DST)) ? XF16_DST4 : (t.log2 - 1) & 3);
     d.angle = (int16_t)kIntraAngle[t.mode]; d.inv = (int16_t)kInvAngle[t.mode];
@@ -708,13 +700,15 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
     any32 |= t.log2 == 5;
   }
   if (__ballot(any32) != 0) load_matrices(s.M, 0, KV_MATRIX_ENTRIES, lane, T);
-  IntraBorders bd;
+  IntraNeighbours bd;
+  uint32_t *const ecol = f.edge_col[c] + (size_t)ctu * S;                              // this CTU's right column / bottom row for its neighbours
+  unsigned long long *const erow = f.edge_row[c] + (size_t)ctu * (S >> 2);
   {
     const int tile = f.ctu_tile[ctu];
     bd.nb_left = cx > 0 && f.ctu_tile[ctu - 1] == tile; bd.nb_up = cy > 0 && f.ctu_tile[ctu - f.wc] == tile;
     bd.nb_ur = cy > 0 && cx + 1 < f.wc && f.ctu_tile[ctu - f.wc + 1] == tile; bd.nb_ul = cy > 0 && cx > 0 && f.ctu_tile[ctu - f.wc - 1] == tile;
-    bd.pl = my - 3; bd.pu = my - 3 * f.wc; bd.pur = bd.pu + 3; bd.pul = bd.pu - 3;
-    bd.ecol_left = f.edge_col[c] + (size_t)(ctu - 1) * S;
+    bd.ecol_left = ecol - S; bd.gen = f.chain_gen;
+    bd.erow_up = erow - (size_t)f.wc * (S >> 2); bd.erow_ur = bd.erow_up + (S >> 2); bd.erow_ul = bd.erow_up - (S >> 2);
     // which of the neighbours' edge units are intra units (a P picture's inter blocks are final before this kernel starts: nothing to wait
     // for there) -- lanes 0-7: the left CTU's right column, 8-15 / 16-23: the bottom rows of the upper / upper-right CTU, 24: the corner
     const int g = lane >> 3, u = lane & 7;
@@ -727,7 +721,8 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
     const uint64_t m = __ballot(in);
     bd.il = (uint32_t)m & 0xffu; bd.iu = (uint32_t)(m >> 8) & 0xffu; bd.iur = (uint32_t)(m >> 16) & 0xffu; bd.iul = (uint32_t)(m >> 24) & 1u;
   }
-  borders_begin(bd, bc4);                                  // (its barrier also publishes blk[] / dq[])
+  chain_init(ch, 0u, 0u);
+  __syncthreads();                                         // (also publishes blk[])
   // what a block needs from memory is fetched one block ahead -- its residual samples (blocks up to 16x16: k_dec_intra_resid), or the
   // first level words of a 32x32 block: the loads of block k + 1 are in flight while block k is reconstructed
   uint32_t wnext[4] = {0, 0, 0, 0};
@@ -748,7 +743,6 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
   };
   fetch_ahead(0);
   uint8_t *gdst = plane + (size_t)(cy * S) * cpitch + cx * S;
-  uint8_t *const ecol = f.edge_col[c] + (size_t)ctu * S;
   for (int k = 0; k < nlist; k++) {
     const IntraBlk d = wave_uniform(&s.blk[k]);            // (wave-uniform: what is derived from it runs on the scalar unit)
     uint32_t wreg[4];
@@ -756,19 +750,17 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
     for (int q = 0; q < 4; q++) wreg[q] = wnext[q];
     const uint2 rres = rnext;
     fetch_ahead(k + 1);
-    uint32_t *pub = (d.flags & IB_PUBLISH) ? my : nullptr;
-    if (pub && d.l2 > 4) { publish_wt(my, (uint32_t)d.zu); pub = nullptr; }       // (32x32 blocks: the workgroup-shaped code publishes ahead)
     if (d.flags & IB_BORDER) {
       // (a neighbouring CTU is waited for only as far as the block's MODE reads it: hevc_core.h intra_uses_* -- any stream; this project's encoder keeps the blocks
       // on a CTU's left edge and its above-right corner block to the modes that make these waits short, "intra-chain")
       const int n = 1 << d.l2, ci = c ? 1 : 0;
       const int nl2 = ((intra_uses_below_left(d.l2, ci) >> d.mode) & 1) ? 2 * n : n, nt2 = ((intra_uses_above_right(d.l2, ci) >> d.mode) & 1) ? 2 * n : n;
-      borders_need(bd, s.pic, DI_P, plane, cpitch, cx, cy, S, sh, wC - cx * S, d.rx, d.ry, n, &bcast, f.err, lane, T, nl2, nt2);
+      borders_need_wave(ch, bd, s.pic, DI_P, plane, cpitch, cx, cy, S, sh, wC - cx * S, d.rx, d.ry, n, f.err, lane, nl2, nt2);
     }
     switch (d.l2) {
-      case 2: dec_intra_block_wave<2>(s, ws, d, c == 0, gdst, cpitch, lane, rres, pub, ecol); break;
-      case 3: dec_intra_block_wave<3>(s, ws, d, c == 0, gdst, cpitch, lane, rres, pub, ecol); break;
-      case 4: dec_intra_block_wave<4>(s, ws, d, c == 0, gdst, cpitch, lane, rres, pub, ecol); break;
+      case 2: dec_intra_block_wave<2>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen); break;
+      case 3: dec_intra_block_wave<3>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen); break;
+      case 4: dec_intra_block_wave<4>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen); break;
       default: {
         DecTu t;
         const uint32_t *q = (const uint32_t *)&s.list[k];
@@ -777,14 +769,16 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
         for (int i = 0; i < 4; i++) u[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q[i]);
         memcpy(&t, u, sizeof(t));
         dec_intra_block<5, T>(f, s, t, c, cx, cy, d.rx, d.ry, lane, wreg);
-        if (d.flags & IB_EDGE_R) { __syncthreads(); if (lane < 32) st_wt_u8(ecol + d.ry + lane, s.pic[(d.ry + lane + 1) * DI_P + 16 + d.rx + 31]); }      // (a 32x32 block on the CTU's right edge: its last column from the CTU picture in LDS)
+        // (a 32x32 block on the CTU's right edge / bottom: its last column / row from the CTU picture in LDS, tagged like the small blocks')
+        if (d.flags & (IB_EDGE_R | IB_EDGE)) __syncthreads();
+        if ((d.flags & IB_EDGE_R) && lane < 32) st_wt_u32(ecol + d.ry + lane, (uint32_t)s.pic[(d.ry + lane + 1) * DI_P + 16 + d.rx + 31] | (f.chain_gen << 8));
+        if ((d.flags & IB_EDGE) && lane < 8) st_wt_u64(erow + ((d.rx + 4 * lane) >> 2), (unsigned long long)*(const uint32_t *)&s.pic[(d.ry + 32) * DI_P + 16 + d.rx + 4 * lane] | ((unsigned long long)f.chain_gen << 32));
       }
     }
   }
   // the CTU's samples -> the picture, in whole lines (the chain stored only what neighbouring workgroups read)
   __syncthreads();
   for (int i = lane; i < S * S / 16; i += T) { const int y = i / (S / 16), xq = i % (S / 16); *(uint4 *)&gdst[(size_t)y * cpitch + xq * 16] = *(const uint4 *)&s.pic[(y + 1) * DI_P + 16 + xq * 16]; }
-  publish_wt(my, 64u);
   }
 }
 

@@ -283,7 +283,7 @@ class Decoder {
   uint8_t *d_in_[kMaxGpuDepth + 1] = {}; size_t d_in_cap_[kMaxGpuDepth + 1] = {};   // device copies of PicJob::h_in: the pictures in flight take turns
   int16_t *resid_[3] = {nullptr, nullptr, nullptr};         // intra residuals between k_dec_intra_resid and k_dec_intra
   uint8_t *work_[3] = {nullptr, nullptr, nullptr};          // pictures with SAO: reconstruction and deblocking happen here, the filter writes into the slot
-  uint8_t *edge_col_ = nullptr;
+  uint32_t *edge_col_ = nullptr; unsigned long long *edge_row_ = nullptr; uint32_t chain_gen_ = 0;      // k_dec_intra's tagged hand-off words (dec_frame.h), the generation of the last launch
   uint32_t *progress_ = nullptr, *intra_order_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
   // download mode: page-locked output buffers take turns -- one is what libOpenHevcGetOutput last handed out (valid until the next
   // decode call, openhevcfilter.cpp:218-229 copies at once), one receives the picture whose kernels are running, queued behind them on

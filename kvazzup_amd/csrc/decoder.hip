@@ -1051,7 +1051,7 @@ void Decoder::free_buffers()
   for (auto &p : h_out_) { if (p) retired_out_.emplace_back(nal_calls_, p); p = nullptr; }      // (freed kOutHold calls later: free_retired)
   for (auto &p : d_in_) { hipFree(p); p = nullptr; }
   for (auto &c : d_in_cap_) c = 0;
-  hipFree(progress_); hipFree(edge_col_); edge_col_ = nullptr; hipFree(intra_order_); intra_order_ = nullptr;
+  hipFree(progress_); hipFree(edge_col_); edge_col_ = nullptr; hipFree(edge_row_); edge_row_ = nullptr; hipFree(intra_order_); intra_order_ = nullptr;
   for (auto &p : dpb_) { hipFree(p.plane[0]); p = DpbPic(); }      // (a buffer's three planes are one allocation)
   for (int c = 0; c < 3; c++) { hipFree(work_[c]); work_[c] = nullptr; hipFree(resid_[c]); resid_[c] = nullptr; }
   progress_ = nullptr;
@@ -1111,7 +1111,9 @@ bool Decoder::ensure_buffers(int w, int h)
   h_out_cap_ = npx * 3 / 2;                              // (allocated by the first picture that is downloaded)
   for (int i = 0; i <= gpu_depth_; i++) { d_in_cap_[i] = fixed_bytes() + (1 << 20); HIP_TRY(hipMalloc(&d_in_[i], d_in_cap_[i])); }
   HIP_TRY(hipMalloc(&progress_, sizeof(uint32_t) * (3 * (size_t)(pw_ / 64) * (ph_ / 64) + 1)));
-  HIP_TRY(hipMalloc(&edge_col_, (size_t)(pw_ / 64) * (ph_ / 64) * 128));      // the CTUs' right columns (k_dec_intra)      // (+ k_dec_intra's ticket counter)
+  { const size_t nctu = (size_t)(pw_ / 64) * (ph_ / 64);          // tagged words: generation 0 = never written
+    HIP_TRY(hipMalloc(&edge_col_, nctu * 128 * sizeof(uint32_t))); HIP_TRY(hipMemset(edge_col_, 0, nctu * 128 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&edge_row_, nctu * 32 * 8)); HIP_TRY(hipMemset(edge_row_, 0, nctu * 32 * 8)); chain_gen_ = 0; }      // the CTUs' right columns (k_dec_intra)      // (+ k_dec_intra's ticket counter)
   {
     // dispatch order of k_dec_intra's workgroups: CTUs by anti-diagonal cx + 2 cy (every CTU a block depends on comes earlier)
     const int wc = pw_ / 64, hc = ph_ / 64;
@@ -2164,7 +2166,17 @@ int Decoder::launch_gpu(PicJob &job)
   for (int k = 0; k < KVZ_DEC_MAX_REFS; k++) for (int c = 0; c < 3; c++) f.ref[k][c] = dpb_[k].plane[c];
   f.sao = sao ? (const SaoParams *)(d_in_ + off_sao()) : nullptr;
   f.progress = progress_; f.intra_order = intra_order_; f.err = err_;
-  { const size_t nctu = (size_t)f.wc * f.hc; f.edge_col[0] = edge_col_; f.edge_col[1] = edge_col_ + nctu * 64; f.edge_col[2] = edge_col_ + nctu * 96; }
+  { const size_t nctu = (size_t)f.wc * f.hc; f.edge_col[0] = edge_col_; f.edge_col[1] = edge_col_ + nctu * 64; f.edge_col[2] = edge_col_ + nctu * 96;
+    f.edge_row[0] = edge_row_; f.edge_row[1] = edge_row_ + nctu * 16; f.edge_row[2] = edge_row_ + nctu * 24; }
+  if (job.any_intra) {                                     // a generation of its own for every launch of the chain: 1 .. 2^24 - 1; at the wrap both arrays go back to "never written"
+    if (++chain_gen_ >= (1u << 24)) {
+      const size_t nctu = (size_t)(pw_ / 64) * (ph_ / 64);
+      sync_main();                                         // (everything this decoder has submitted has run: nothing reads the words while they are cleared)
+      if (hipMemset(edge_col_, 0, nctu * 128 * sizeof(uint32_t)) != hipSuccess || hipMemset(edge_row_, 0, nctu * 32 * 8) != hipSuccess) return DEC_ERR_GPU;
+      chain_gen_ = 1;
+    }
+    f.chain_gen = chain_gen_;
+  }
   f.cb_qp_offset = (int8_t)job.pps.cb_qp_offset; f.cr_qp_offset = (int8_t)job.pps.cr_qp_offset;
   f.beta_offset = (int8_t)(2 * job.sh.beta_offset_div2); f.tc_offset = (int8_t)(2 * job.sh.tc_offset_div2);
   f.intra_direct = job.any_inter ? 1 : 0;                 // (a picture with inter blocks: few (CTU, plane) pairs hold intra blocks)

@@ -304,6 +304,13 @@ __device__ __forceinline__ void wave_sync()
 // units in LDS.  What the NEIGHBOURING CTUs read -- the CTU's right column and bottom row -- leaves as self-validating words
 // (IntraNeighbours), so there is no progress counter, no acknowledgement of stores and nothing to publish (rounds 2 and 3 had all three).
 // ---------------------------------------------------------------------------------------------
+// bounds of the chain's spins (they only ever end a launch that would otherwise hang; -DKVZ_POLL_LIMIT_LOG2=12 -DKVZ_WAIT_LIMIT_LOG2=12 makes a broken chain fail fast)
+#ifndef KVZ_POLL_LIMIT_LOG2
+#define KVZ_POLL_LIMIT_LOG2 21
+#endif
+#ifndef KVZ_WAIT_LIMIT_LOG2
+#define KVZ_WAIT_LIMIT_LOG2 24
+#endif
 struct IntraChain {
   uint32_t done[2];            // bit z: the 8x8 luma unit z (z-order) is final in the CTU picture in LDS
   uint32_t claim;              // next list entry to be handed to a wave
@@ -378,7 +385,7 @@ __device__ __forceinline__ bool borders_need_wave(IntraChain &ch, const IntraNei
       if (__ballot(pL || pT || pC) == 0) break;
       if (try_only) return false;
       if (++spins < 16) __builtin_amdgcn_s_sleep(1); else if (spins < 64) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(32);
-      if (spins > (1u << 21)) { if (lane == 0) atomicOr(err, 1u); break; }           // bounded spin: never hang the GPU
+      if (spins > (1u << KVZ_POLL_LIMIT_LOG2)) { if (lane == 0) atomicOr(err, 1u); break; }           // bounded spin: never hang the GPU
       if (pL) vL = ld_l2_u32(b.ecol_left + iL);
       if (pT) qT = ld_l2_u64(wT);
       if (pC) qC = ld_l2_u64(b.erow_ul + (S >> 2) - 1);
@@ -431,7 +438,7 @@ __device__ __forceinline__ void chain_wait_done(const IntraChain &ch, uint2 dep,
     const uint32_t d0 = lds_load(&ch.done[0]), d1 = lds_load(&ch.done[1]);
     if ((d0 & dep.x) == dep.x && (d1 & dep.y) == dep.y) break;
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1u << 24)) { if (lane == 0) atomicOr(err, 2u); break; }
+    if (++spins > (1u << KVZ_WAIT_LIMIT_LOG2)) { if (lane == 0) atomicOr(err, 2u); break; }
   }
 }
 __device__ __forceinline__ void chain_mark_done(IntraChain &ch, uint2 cover, int lane)

@@ -438,6 +438,8 @@ template <class F> __device__ __forceinline__ bool dec_avail(const F &f, int xc,
 }
 
 // one intra transform block of plane c: N x N samples at (rx, ry) of the CTU (component samples); its borders are in s.pic
+// the threads of one block's team: a workgroup of T threads, or -- T = 64 -- ONE wave of a larger workgroup (whose LDS instructions execute in order)
+template <int T> __device__ __forceinline__ void tsync() { if (T == 64) wave_sync(); else __syncthreads(); }
 template <int L2, int T, class F>
 __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, const DecTu &d, int c, int cx, int cy, int rx, int ry, int lane, const uint32_t (&wreg)[4])
 {
@@ -481,7 +483,7 @@ __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, cons
   // ---- levels -> dequantised coefficients, transposed ([column][row])
   if (has) {
     for (int i = lane; i < N * N / 2; i += T) ((uint32_t *)s.A)[i] = 0;
-    __syncthreads();
+    tsync<T>();
     auto put = [&](uint32_t wd) {
       const int pos = (int)(wd >> 16) & (N * N - 1), row = pos >> L2, col = pos & (N - 1);
       s.A[col * N + row] = (int16_t)dec_dequant(f, d, pos, (int16_t)(wd & 0xffffu));
@@ -490,7 +492,7 @@ __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, cons
     for (int k = 0; k < 4; k++) if (lane + k * T < (int)d.count) put(wreg[k]);
     for (int i = lane + 4 * T; i < (int)d.count; i += T) put(f.lev[d.offset + i]);
   }
-  __syncthreads();
+  tsync<T>();
   const uint8_t *R = s.R[filt ? 1 : 0] + 3;
   int dcv = 0;
   if (mode == 1) {
@@ -535,7 +537,7 @@ __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, cons
     } else {
       const int16_t *Mt = s.M[1] + ((L2 == 2 && (d.flags & TU_DST)) ? KV_DST_OFFSET : matrix_offset(L2));
       if (active) xf_stage<L2, OPL>(s.A, s.B, Mt, 7, rp, g);
-      __syncthreads();
+      tsync<T>();
       if (active) {
         int acc[2][OPL];
         xf_sums<L2, OPL>(s.B, Mt, rp, g, acc);
@@ -552,7 +554,7 @@ __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, cons
 #pragma unroll
       for (int o = 0; o < OPL; o++) s.pic[(ry + 2 * rp + e + 1) * DI_P + 16 + rx + g * OPL + o] = (uint8_t)pred[e][o];
   }
-  __syncthreads();
+  tsync<T>();
   // (the block stays in the CTU picture in LDS: the caller hands its last column / row to the neighbouring CTUs as tagged words, and the CTU goes to the
   // picture in full lines at the end)
 }
@@ -630,27 +632,39 @@ __device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveSc
   wave_sync();
 }
 
-// One workgroup (one wave) per (CTU, colour plane)
+// One workgroup of KVZ_DEC_INTRA_WAVES waves per (CTU, colour plane) -- round 4: the encoder's chain (enc_kernels.hip k_intra_recon, kernel_common.h
+// IntraChain) driven by the transform-block list.  The plane's intra blocks form ITEMS in decoding order: a block of 8x8 luma samples or more is one, the
+// four 4x4 luma blocks of an 8x8 unit are one (they read each other).  A wave takes the next item, fetches the neighbouring CTUs' samples it reads (tagged
+// words), waits until the 8x8 units of its own CTU it reads are final -- by the blocks' MODES where that is cheap to say: items whose quadrants do not
+// depend on each other run side by side --, predicts, adds the residual (k_dec_intra_resid) and marks its units.  (Rounds 2-3: one wave per (CTU, plane),
+// every block behind the one before it.)
+#ifndef KVZ_DEC_INTRA_WAVES
+#define KVZ_DEC_INTRA_WAVES 4
+#endif
 template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, const Wg wg)
 {
-  constexpr int T = 64;
+  constexpr int W = KVZ_DEC_INTRA_WAVES, T = 64 * W;
   __shared__ DecIntraLds s;
-  __shared__ IntraWaveScratch ws;
-  __shared__ IntraChain ch;                               // (its border watermarks: the one wave of this workgroup is the only user)
+  __shared__ IntraWaveScratch wss[W];
+  __shared__ IntraChain ch;
+  __shared__ uint16_t item_first[257];                     // list index of every item's first block (+ the end)
+  __shared__ uint2 item_dep[256], item_cover[256];         // per item: the units of this CTU it waits for, the units it finishes
+  __shared__ uint32_t nitems_s, ticket_s, im_s[2], lock32;
   // (enc_kernels.hip k_intra_recon: the launch has as many workgroups as the wavefront keeps busy, each takes the next (CTU, plane) in
   // anti-diagonal order from a ticket counter -- f.progress[3 * CTUs] -- so that the chain does not park a workgroup per (CTU, plane) on the chip)
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (wg.id >= wg.n) return;
   const uint32_t nticket = 3u * (uint32_t)f.wc * (uint32_t)(f.nrows > 0 ? f.nrows : f.hc);
-  for (int i = lane; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];      // the transforms' matrix operands: once per workgroup, not per (CTU, plane)
+  for (int i = tid; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];      // the transforms' matrix operands: once per workgroup, not per (CTU, plane)
+  if (tid == 0) lock32 = 0;
   for (bool once = true;; once = false) {
   uint32_t ticket = (uint32_t)wg.id;
   if (f.intra_direct) { if (!once) break; }
   else {
+    __syncthreads();                                        // (everybody is done with the last (CTU, plane): LDS and the ticket word are free)
+    if (tid == 0) ticket_s = atomicAdd(f.progress + (size_t)3 * f.wc * f.hc, 1u);
     __syncthreads();
-    ticket = 0;
-    if (lane == 0) ticket = atomicAdd(f.progress + (size_t)3 * f.wc * f.hc, 1u);
-    ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+    ticket = ticket_s;
   }
   if (ticket >= nticket) break;
   const int ctu = (int)f.intra_order[ticket / 3u], c = (int)(ticket % 3u), cx = ctu % f.wc, cy = ctu / f.wc;
@@ -662,25 +676,43 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
   // the CTU as the inter kernel left it (its inter blocks are final, the intra ones get written below) -> LDS
   {
     const uint8_t *src = plane + (size_t)(cy * S) * cpitch + cx * S;
-    for (int i = lane; i < S * S / 16; i += T) { const int y = i / (S / 16), xq = i % (S / 16); *(uint4 *)&s.pic[(y + 1) * DI_P + 16 + xq * 16] = *(const uint4 *)&src[(size_t)y * cpitch + xq * 16]; }
+    for (int i = tid; i < S * S / 16; i += T) { const int y = i / (S / 16), xq = i % (S / 16); *(uint4 *)&s.pic[(y + 1) * DI_P + 16 + xq * 16] = *(const uint4 *)&src[(size_t)y * cpitch + xq * 16]; }
   }
-  // this plane's intra blocks, compacted in order (one pass over the CTU's list, 64 descriptors at a time)
-  int nlist = 0;
-  for (int base = 0; base < count; base += 64) {
-    DecTu d; d.plane = 255; d.flags = 0;
-    if (base + lane < count) d = f.tus[ct.first + base + lane];
-    const bool keep = d.plane == c && (d.flags & TU_INTRA);
-    const uint64_t m = __ballot(keep);
-    const int at = nlist + __popcll(m & ((1ull << lane) - 1ull));
-    if (keep && at < 256) s.list[at] = d;
-    nlist += __popcll(m);
+  // this plane's intra blocks, compacted in order (wave 0: one pass over the CTU's list, 64 descriptors at a time), and the items they form
+  if (wave == 0) {
+    int nlist = 0;
+    for (int base = 0; base < count; base += 64) {
+      DecTu d; d.plane = 255; d.flags = 0;
+      if (base + lane < count) d = f.tus[ct.first + base + lane];
+      const bool keep = d.plane == c && (d.flags & TU_INTRA);
+      const uint64_t m = __ballot(keep);
+      const int at = nlist + __popcll(m & ((1ull << lane) - 1ull));
+      if (keep && at < 256) s.list[at] = d;
+      nlist += __popcll(m);
+    }
+    nlist = nlist > 256 ? 256 : nlist;
+    wave_sync();
+    int nitems = 0;
+    for (int base = 0; base < nlist; base += 64) {
+      const int k = base + lane;
+      bool starts = false;
+      if (k < nlist) {
+        const DecTu t = s.list[k];
+        starts = true;
+        if (c == 0 && t.log2 == 2 && k > 0) { const DecTu p = s.list[k - 1]; starts = !(p.log2 == 2 && (p.x >> 3) == (t.x >> 3) && (p.y >> 3) == (t.y >> 3)); }      // a 4x4 luma block inside the unit of the block before it
+      }
+      const uint64_t m = __ballot(starts);
+      if (starts) item_first[nitems + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)k;
+      nitems += __popcll(m);
+    }
+    if (lane == 0) { item_first[nitems] = (uint16_t)nlist; nitems_s = (uint32_t)nitems; im_s[0] = 0; im_s[1] = 0; }
   }
-  nlist = nlist > 256 ? 256 : nlist;
   __syncthreads();
-  // ---- what the chain needs to know about each block, one lane per block: position, available reference samples (8.4.4.2.2:
+  const int nitems = (int)nitems_s, nlist = (int)item_first[nitems];
+  // ---- what the chain needs to know about each block, one thread per block: position, available reference samples (8.4.4.2.2:
   // contiguous in scan order for one slice with full-width tiles), the mode's constants
   bool any32 = false;
-  for (int k = lane; k < nlist; k += T) {
+  for (int k = tid; k < nlist; k += T) {
     const DecTu t = s.list[k];
     const int N = 1 << t.log2, nl = N << sh, Xc = t.x, Yc = t.y, X = Xc << sh, Y = Yc << sh, rx = Xc - cx * S, ry = Yc - cy * S;
     const bool aL = dec_avail(f, X, Y, X - 1, Y), aT = dec_avail(f, X, Y, X, Y - 1), aTL = aL && aT && dec_avail(f, X, Y, X - 1, Y - 1);
@@ -699,7 +731,21 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
     s.blk[k] = d;
     any32 |= t.log2 == 5;
   }
-  if (__ballot(any32) != 0) load_matrices(s.M, 0, KV_MATRIX_ENTRIES, lane, T);
+  // ... and about each item: the 8x8 luma units it covers and the units of this CTU its blocks read (kernel_common.h chain_dependencies: by the block's
+  // mode for a block of its own; everything around for the four 4x4 blocks of a unit -- a superset is as good, it only has to precede in z-order)
+  for (int i = tid; i < nitems; i += T) {
+    const DecTu t = s.list[item_first[i]];
+    const bool quad = item_first[i + 1] - item_first[i] > 1;
+    const int rx = t.x - cx * S, ry = t.y - cy * S, ux = (rx << sh) >> 3, uy = (ry << sh) >> 3, su = quad ? 1 : imax(1, ((1 << t.log2) << sh) >> 3);
+    const int ci = c ? 1 : 0;
+    const bool bl = quad || t.log2 == 2 || ((intra_uses_below_left(t.log2, ci) >> t.mode) & 1) != 0, tr = quad || t.log2 == 2 || ((intra_uses_above_right(t.log2, ci) >> t.mode) & 1) != 0;
+    item_dep[i] = chain_dependencies(ux, uy, su, bl, tr);
+    const uint2 cv = chain_cover(zunit8(ux, uy), su);
+    item_cover[i] = cv;
+    if (cv.x) atomicOr(&im_s[0], cv.x);
+    if (cv.y) atomicOr(&im_s[1], cv.y);
+  }
+  if (__syncthreads_or(any32)) load_matrices(s.M, 0, KV_MATRIX_ENTRIES, tid, T);
   IntraNeighbours bd;
   uint32_t *const ecol = f.edge_col[c] + (size_t)ctu * S;                              // this CTU's right column / bottom row for its neighbours
   unsigned long long *const erow = f.edge_row[c] + (size_t)ctu * (S >> 2);
@@ -710,7 +756,7 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
     bd.ecol_left = ecol - S; bd.gen = f.chain_gen;
     bd.erow_up = erow - (size_t)f.wc * (S >> 2); bd.erow_ur = bd.erow_up + (S >> 2); bd.erow_ul = bd.erow_up - (S >> 2);
     // which of the neighbours' edge units are intra units (a P picture's inter blocks are final before this kernel starts: nothing to wait
-    // for there) -- lanes 0-7: the left CTU's right column, 8-15 / 16-23: the bottom rows of the upper / upper-right CTU, 24: the corner
+    // for there) -- lanes 0-7: the left CTU's right column, 8-15 / 16-23: the bottom rows of the upper / upper-right CTU, 24: the corner (every wave for itself)
     const int g = lane >> 3, u = lane & 7;
     int X = -1, Y = -1;
     if (g == 0 && bd.nb_left) { X = cx * 64 - 8; Y = cy * 64 + u * 8; }
@@ -721,64 +767,74 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
     const uint64_t m = __ballot(in);
     bd.il = (uint32_t)m & 0xffu; bd.iu = (uint32_t)(m >> 8) & 0xffu; bd.iur = (uint32_t)(m >> 16) & 0xffu; bd.iul = (uint32_t)(m >> 24) & 1u;
   }
-  chain_init(ch, 0u, 0u);
-  __syncthreads();                                         // (also publishes blk[])
-  // what a block needs from memory is fetched one block ahead -- its residual samples (blocks up to 16x16: k_dec_intra_resid), or the
-  // first level words of a 32x32 block: the loads of block k + 1 are in flight while block k is reconstructed
-  uint32_t wnext[4] = {0, 0, 0, 0};
-  uint2 rnext = make_uint2(0u, 0u);
+  chain_init(ch, ~im_s[0], ~im_s[1]);                      // (units no intra block of this plane covers -- inter units, units outside the picture -- are final from the start)
+  __syncthreads();                                         // (also publishes blk[] and the items)
   const int16_t *rplane = f.resid[c] + (size_t)(cy * S) * cpitch + cx * S;
-  auto fetch_ahead = [&](int k) {
-    if (k >= nlist) return;
-    const int l2 = s.blk[k].l2;
-    if (!(s.blk[k].flags & IB_LEVELS)) return;
-    if (l2 > 4) {
-      const uint32_t off = s.list[k].offset; const int cnt = s.list[k].count;
+  IntraWaveScratch &ws = wss[wave];
+  for (int rounds = 0;; rounds++) {
+    int it = 0;
+    if (lane == 0) it = (int)atomicAdd(&ch.claim, 1u);
+    it = __builtin_amdgcn_readfirstlane(it);
+    if (it >= nitems) break;
+    // (bounded like every loop of the chain: a CTU has at most 256 items.  The bound is also what keeps this loop honest -- as `for (;;)` with the atomic claim as
+    // its only exit the compiled kernel never left it, on the GPU, for any picture; with the counter it does)
+    if (rounds > 300) { if (lane == 0) atomicOr(f.err, 4u); break; }
+    const int k0 = (int)item_first[it], k1 = (int)item_first[it + 1];
+    const uint2 dp = item_dep[it], cv = item_cover[it];
+    for (int k = k0; k < k1; k++) {
+      const IntraBlk d = wave_uniform(&s.blk[k]);          // (wave-uniform: what is derived from it runs on the scalar unit)
+      // what the block needs from memory is asked for first: its residual samples (blocks up to 16x16: k_dec_intra_resid) or the first level words of a
+      // 32x32 block, then the neighbouring CTUs' samples -- all of it arrives while the wave waits for the blocks in front of it
+      uint32_t wreg[4] = {0, 0, 0, 0};
+      uint2 rres = make_uint2(0u, 0u);
+      if (d.flags & IB_LEVELS) {
+        if (d.l2 > 4) {
+          const uint32_t off = s.list[k].offset; const int cnt = s.list[k].count;
 #pragma unroll
-      for (int q = 0; q < 4; q++) if (lane + q * T < cnt) wnext[q] = f.lev[off + lane + q * T];
-    } else {
-      const int n = 1 << l2, g = lane >> 4, r = lane & 15;
-      if (r < n && 4 * g < n) rnext = *(const uint2 *)&rplane[(size_t)(s.blk[k].ry + r) * cpitch + s.blk[k].rx + 4 * g];
-    }
-  };
-  fetch_ahead(0);
-  uint8_t *gdst = plane + (size_t)(cy * S) * cpitch + cx * S;
-  for (int k = 0; k < nlist; k++) {
-    const IntraBlk d = wave_uniform(&s.blk[k]);            // (wave-uniform: what is derived from it runs on the scalar unit)
-    uint32_t wreg[4];
+          for (int q = 0; q < 4; q++) if (lane + q * 64 < cnt) wreg[q] = f.lev[off + lane + q * 64];
+        } else {
+          const int n = 1 << d.l2, g = lane >> 4, r = lane & 15;
+          if (r < n && 4 * g < n) rres = *(const uint2 *)&rplane[(size_t)(d.ry + r) * cpitch + d.rx + 4 * g];
+        }
+      }
+      if (d.flags & IB_BORDER) {
+        // (a neighbouring CTU is waited for only as far as the block's MODE reads it: hevc_core.h intra_uses_* -- any stream; this project's encoder keeps the blocks
+        // on a CTU's left edge and its above-right corner block to the modes that make these waits short, "intra-chain")
+        const int n = 1 << d.l2, ci = c ? 1 : 0;
+        const int nl2 = ((intra_uses_below_left(d.l2, ci) >> d.mode) & 1) ? 2 * n : n, nt2 = ((intra_uses_above_right(d.l2, ci) >> d.mode) & 1) ? 2 * n : n;
+        borders_need_wave(ch, bd, s.pic, DI_P, plane, cpitch, cx, cy, S, sh, wC - cx * S, d.rx, d.ry, n, f.err, lane, nl2, nt2);
+      }
+      if (k == k0) chain_wait_done(ch, make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)dp.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)dp.y)), f.err, lane);
+      switch (d.l2) {
+        case 2: dec_intra_block_wave<2>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen); break;
+        case 3: dec_intra_block_wave<3>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen); break;
+        case 4: dec_intra_block_wave<4>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen); break;
+        default: {
+          // a 32x32 block: the wave runs the workgroup-shaped code of the other sizes' predecessor by itself; its scratch arrays (s.A, s.B, s.R) exist
+          // once per workgroup, so one 32x32 block at a time
+          if (lane == 0) { while (atomicCAS(&lock32, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(2); }
+          wave_sync();
+          DecTu t;
+          const uint32_t *q = (const uint32_t *)&s.list[k];
+          uint32_t u[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) wreg[q] = wnext[q];
-    const uint2 rres = rnext;
-    fetch_ahead(k + 1);
-    if (d.flags & IB_BORDER) {
-      // (a neighbouring CTU is waited for only as far as the block's MODE reads it: hevc_core.h intra_uses_* -- any stream; this project's encoder keeps the blocks
-      // on a CTU's left edge and its above-right corner block to the modes that make these waits short, "intra-chain")
-      const int n = 1 << d.l2, ci = c ? 1 : 0;
-      const int nl2 = ((intra_uses_below_left(d.l2, ci) >> d.mode) & 1) ? 2 * n : n, nt2 = ((intra_uses_above_right(d.l2, ci) >> d.mode) & 1) ? 2 * n : n;
-      borders_need_wave(ch, bd, s.pic, DI_P, plane, cpitch, cx, cy, S, sh, wC - cx * S, d.rx, d.ry, n, f.err, lane, nl2, nt2);
-    }
-    switch (d.l2) {
-      case 2: dec_intra_block_wave<2>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen); break;
-      case 3: dec_intra_block_wave<3>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen); break;
-      case 4: dec_intra_block_wave<4>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen); break;
-      default: {
-        DecTu t;
-        const uint32_t *q = (const uint32_t *)&s.list[k];
-        uint32_t u[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) u[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q[i]);
-        memcpy(&t, u, sizeof(t));
-        dec_intra_block<5, T>(f, s, t, c, cx, cy, d.rx, d.ry, lane, wreg);
-        // (a 32x32 block on the CTU's right edge / bottom: its last column / row from the CTU picture in LDS, tagged like the small blocks')
-        if (d.flags & (IB_EDGE_R | IB_EDGE)) __syncthreads();
-        if ((d.flags & IB_EDGE_R) && lane < 32) st_wt_u32(ecol + d.ry + lane, (uint32_t)s.pic[(d.ry + lane + 1) * DI_P + 16 + d.rx + 31] | (f.chain_gen << 8));
-        if ((d.flags & IB_EDGE) && lane < 8) st_wt_u64(erow + ((d.rx + 4 * lane) >> 2), (unsigned long long)*(const uint32_t *)&s.pic[(d.ry + 32) * DI_P + 16 + d.rx + 4 * lane] | ((unsigned long long)f.chain_gen << 32));
+          for (int i = 0; i < 4; i++) u[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q[i]);
+          memcpy(&t, u, sizeof(t));
+          dec_intra_block<5, 64>(f, s, t, c, cx, cy, d.rx, d.ry, lane, wreg);
+          // (on the CTU's right edge / bottom: its last column / row from the CTU picture in LDS, tagged like the small blocks')
+          if ((d.flags & IB_EDGE_R) && lane < 32) st_wt_u32(ecol + d.ry + lane, (uint32_t)s.pic[(d.ry + lane + 1) * DI_P + 16 + d.rx + 31] | (f.chain_gen << 8));
+          if ((d.flags & IB_EDGE) && lane < 8) st_wt_u64(erow + ((d.rx + 4 * lane) >> 2), (unsigned long long)*(const uint32_t *)&s.pic[(d.ry + 32) * DI_P + 16 + d.rx + 4 * lane] | ((unsigned long long)f.chain_gen << 32));
+          wave_sync();
+          if (lane == 0) __hip_atomic_store(&lock32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
     }
+    chain_mark_done(ch, make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)cv.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)cv.y)), lane);
   }
   // the CTU's samples -> the picture, in whole lines (the chain stored only what neighbouring workgroups read)
   __syncthreads();
-  for (int i = lane; i < S * S / 16; i += T) { const int y = i / (S / 16), xq = i % (S / 16); *(uint4 *)&gdst[(size_t)y * cpitch + xq * 16] = *(const uint4 *)&s.pic[(y + 1) * DI_P + 16 + xq * 16]; }
+  uint8_t *gdst = plane + (size_t)(cy * S) * cpitch + cx * S;
+  for (int i = tid; i < S * S / 16; i += T) { const int y = i / (S / 16), xq = i % (S / 16); *(uint4 *)&gdst[(size_t)y * cpitch + xq * 16] = *(const uint4 *)&s.pic[(y + 1) * DI_P + 16 + xq * 16]; }
   }
 }
 
@@ -1012,7 +1068,7 @@ template <class F> __device__ __forceinline__ void dec_sao_body(const F &f, cons
 // the single-picture kernels: the frame is the kernel argument
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_dec_inter(DecFrame f) { dec_inter_body(f, Wg{(int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y)}); }
 __global__ __launch_bounds__(256) void k_dec_intra_resid(DecFrame f) { dec_intra_resid_body(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
-__global__ __launch_bounds__(64) void k_dec_intra(DecFrame f) { dec_intra_body(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
+__global__ __launch_bounds__(64 * KVZ_DEC_INTRA_WAVES) void k_dec_intra(DecFrame f) { dec_intra_body(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
 __global__ __launch_bounds__(256) void k_dec_deblock(DecFrame f) { dec_deblock_body(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
 __global__ __launch_bounds__(256) void k_dec_sao(DecFrame f) { dec_sao_body(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
 
@@ -1030,7 +1086,7 @@ __device__ __forceinline__ int batch_frame(const DecBatch &b, Wg &wg)
 #define KVZ_BATCH_FRAME(b) Wg wg; const CDecFrame &f = *(const CDecFrame *)(b).f[batch_frame(b, wg)]
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_dec_inter_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_inter_body(f, wg); }
 __global__ __launch_bounds__(256) void k_dec_intra_resid_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_intra_resid_body(f, wg); }
-__global__ __launch_bounds__(64) void k_dec_intra_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_intra_body(f, wg); }
+__global__ __launch_bounds__(64 * KVZ_DEC_INTRA_WAVES) void k_dec_intra_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_intra_body(f, wg); }
 __global__ __launch_bounds__(256) void k_dec_deblock_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_deblock_body(f, wg); }
 __global__ __launch_bounds__(256) void k_dec_sao_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_sao_body(f, wg); }
 
@@ -1047,7 +1103,7 @@ static inline int dec_intra_wgs(const DecFrame &f)
 }
 void launch_dec_inter(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_inter, dim3(f.wc * 2, dec_rows(f) * 2), dim3(256), 0, st, f); }
 void launch_dec_intra_resid(const DecFrame &f, hipStream_t st) { if (f.ntu > 0) hipLaunchKernelGGL(k_dec_intra_resid, dim3((f.ntu + 3) / 4), dim3(256), 0, st, f); }
-void launch_dec_intra(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_intra, dim3(dec_intra_wgs(f)), dim3(64), 0, st, f); }
+void launch_dec_intra(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_intra, dim3(dec_intra_wgs(f)), dim3(64 * KVZ_DEC_INTRA_WAVES), 0, st, f); }
 void launch_dec_deblock(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_deblock, dim3(f.wc * dec_rows(f)), dim3(256), 0, st, f); }
 void launch_dec_sao(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_sao, dim3(f.wc * f.hc), dim3(256), 0, st, f); }
 
@@ -1072,7 +1128,7 @@ void launch_dec_intra_n(const DecFrame *const *h, const DecFrame *const *d, int 
   DecBatch b; uint32_t total = batch_layout(b, h, d, n, [](const DecFrame &f) { return (f.ntu + 3) / 4; });
   if (total) hipLaunchKernelGGL(k_dec_intra_resid_n, dim3(total), dim3(256), 0, st, b);
   total = batch_layout(b, h, d, n, [](const DecFrame &f) { return dec_intra_wgs(f); });
-  if (total) hipLaunchKernelGGL(k_dec_intra_n, dim3(total), dim3(64), 0, st, b);
+  if (total) hipLaunchKernelGGL(k_dec_intra_n, dim3(total), dim3(64 * KVZ_DEC_INTRA_WAVES), 0, st, b);
 }
 void launch_dec_deblock_n(const DecFrame *const *h, const DecFrame *const *d, int n, hipStream_t st)
 {

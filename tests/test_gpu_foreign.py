@@ -257,3 +257,29 @@ def test_b_pictures_1080p_gop8(gpu):
     run_stream(1920, 1080, 10, seed=21, b_slices=80, gop=8, num_refs=4, tmvp=1, strong_intra=0, sign_hiding=1, wpp=1, tile_rows=1, intra_in_p=10,
                all_part_modes=1, amp=0, sao=1, qp_delta=0, deblock_mode=0, th_depth_inter=1, th_depth_intra=1, max_cu_log2=6, min_cu_log2=3, nxn_intra=1,
                chroma_modes=1, transform_skip=0, cabac_init=0, chroma_qp_offsets=0, par_mrg_level=2, big_mvd=0, uniform_tiles=1, density=20)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 6])
+def test_b_stream_through_the_filter_graph(gpu, threads):
+    """the receiving side of a call as uvgComm builds it -- WireAdapter -> OpenHEVCFilter' (one libOpenHevcDecode per NAL unit, at most one picture out per
+    call, its output stage on a thread of its own) -- fed a peer's gop-8 B stream: the pictures arrive complete, in output order, and the stream's end
+    (end-of-sequence NAL units) lets the held-back ones out"""
+    from kvazzup_amd.pipeline import Pipeline
+    w, h, n = 416, 240, 21
+    g = orc.OracleGen(w, h, seed=77, intra_period=17, density=25, b_slices=70, gop=8, num_refs=4, tmvp=1, sao=1, wpp=1)
+    od = orc.OracleDecoder()
+    pl = Pipeline(w, h, settings={"video/OPENHEVC_threads": threads, "video/OH_parallelization": "Frame" if threads > 1 else "Slice", "uvgx/asyncOutput": 1})
+    want = []
+    for t in range(n):
+        au = g.picture()
+        want += [f["i420"] for f in od.decode_au(au, t)]
+        assert pl.push_encoded(au, t)
+    want += [f["i420"] for f in od.flush()]
+    pl.push_encoded(None)
+    assert len(want) == n and pl.wait(n, 120000), pl.stats()
+    for i in range(n):
+        got = pl.pop_decoded()
+        assert got is not None and (got["width"], got["height"]) == (w, h), i
+        assert np.array_equal(got["i420"], want[i]), i
+    pl.close(); od.close(); g.close()

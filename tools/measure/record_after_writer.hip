@@ -27,10 +27,11 @@ int main()
   uint4 *p; unsigned *out; hipMalloc(&p, bytes); hipMalloc(&out, 4);
   hipEvent_t ev; hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence);
   const int N = 300;
-  const char *names[6] = {"no record", "record, nobody waits", "record + another stream waiting behind it", "hipExtLaunchKernelGGL stop event + waiter", "record with default flags + waiter", "record, waiter enqueued one iteration later"};
+  uint32_t *flag = nullptr; if (hipExtMallocWithFlags((void **)&flag, 8, hipMallocSignalMemory) != hipSuccess) { printf("no signal memory\n"); hipMalloc((void **)&flag, 8); } hipMemset(flag, 0, 8);
+  const char *names[8] = {"no record", "record, nobody waits", "record + another stream waiting behind it", "hipExtLaunchKernelGGL stop event + waiter", "record with default flags + waiter", "record, waiter enqueued one iteration later", "hipStreamWriteValue32 + hipStreamWaitValue32 on another stream", "hipStreamWriteValue32, nobody waits"};
   hipEvent_t evd; hipEventCreateWithFlags(&evd, hipEventDisableTiming);
   hipEvent_t ring[4]; for (auto &e : ring) hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence);
-  for (int mode = 0; mode < 6; mode++) {
+  for (int mode = 0; mode < 8; mode++) {
     hipDeviceSynchronize();
     auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < N; i++) {
@@ -42,6 +43,8 @@ int main()
       if (mode == 2 || mode == 3) { hipStreamWaitEvent(c, ev, 0); hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, c, out); }
       if (mode == 4) { hipStreamWaitEvent(c, evd, 0); hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, c, out); }
       if (mode == 5 && i) { hipStreamWaitEvent(c, ring[(i - 1) & 3], 0); hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, c, out); }
+      if (mode >= 6) { if (hipStreamWriteValue32(b, flag, 1000u * mode + (unsigned)i + 1u, 0) != hipSuccess) { printf("write value failed\n"); return 1; } }
+      if (mode == 6) { if (hipStreamWaitValue32(c, flag, 1000u * mode + (unsigned)i + 1u, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) { printf("wait value failed\n"); return 1; } hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, c, out); }
       hipLaunchKernelGGL(reader, dim3(2048), dim3(256), 0, b, p, n, out);
     }
     hipStreamSynchronize(b); hipStreamSynchronize(c);

@@ -114,7 +114,9 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   // -- they use the same progress counters --, no per-CTU QP upload, no row groups) and pictures are queued ahead at all
   // (round 4: SAO, intra units in P pictures, per-CTU QPs and the row groups of rate control v2 no longer keep it on the main stream -- the side chain has its own
   // progress counters, edge columns and SAO work picture; VAQ still does: its activity scratch is shared)
-  idr_side_ = depth_ >= 2 && cfg.vaq == 0 && cfg.band_rows == 0 && !getenv("KVAZZUP_AMD_IDR_INLINE");
+  // (not when every picture is an intra picture: then the chains ARE the main stream's work, and the next picture's analysis belongs beside them on the
+  // input stream, not behind them -- all-intra 1080p 940 -> 1 300 frames/s)
+  idr_side_ = depth_ >= 2 && cfg.vaq == 0 && cfg.band_rows == 0 && cfg.intra_period != 1 && !getenv("KVAZZUP_AMD_IDR_INLINE");
   if (idr_side_) {
     const size_t nsync = (size_t)rows_ * (cw_ / 64) * 3 + 2, nctu_ = (size_t)(cw_ / 64) * rows_;
     HIP_OK(hipMalloc(&sync_idr_, sizeof(uint32_t) * nsync)); HIP_OK(hipMemset(sync_idr_, 0, sizeof(uint32_t) * nsync));

@@ -19,7 +19,8 @@ void launch_deblock_h(const EncFrame &f, hipStream_t st, int part = 0);   // par
 void launch_tokenize(const EncFrame &f, hipStream_t st);    // k_tokenize: bins of every CTU into its slot, pieces in completion order
 void launch_tok_compact(const EncFrame &f, hipStream_t st); // k_tok_compact: coding order restored, dense copy to host-mapped memory
 // rate control v2 (rc_kernels.hip; the groups of CTU rows themselves: k_inter_recon's RC form, EncFrame::rc)
-void launch_picture_begin(RcState *rc, uint32_t bits3, int slot3, int have3, int8_t *ctu_qt, const int8_t *roi, int nctu, int qp, int vaq, hipStream_t st);      // head of a picture's chain: rate control state (rc != NULL) and the per-CTU target QPs (ctu_qt != NULL) in one launch
+void launch_picture_begin(RcState *rc, uint32_t bits3, int slot3, int have3, int8_t *ctu_qt, const int8_t *roi, int nctu, int qp, int vaq, hipStream_t st,
+                          void *zero_a = nullptr, size_t bytes_a = 0, void *zero_b = nullptr, size_t bytes_b = 0);      // head of a picture's chain: rate control state (rc != NULL) and the per-CTU target QPs (ctu_qt != NULL) in one launch
 // k_cabac_rows (cabac_kernels.hip): the arithmetic coder proper on the GPU, one wave per substream
 struct CabacRowsArgs {
   const uint16_t *tok; const int32_t *count; const uint32_t *off;   // dense tokens (device): CTU i has count[i] tokens at tok + off[i]

@@ -165,7 +165,7 @@ class Encoder {
   const int8_t *roi_dev_ = nullptr;
   int *vaq_act_ = nullptr, *vaq_sum_ = nullptr; // VAQ: activity of every CTU, its sum over the picture
   uint32_t next_chain_gen();
-  bool picture_begin(hipStream_t qt_stream, EncFrame *fold = nullptr);     // fold: a P picture without VAQ -- the work rides in the picture's k_me launch (EncFrame::pb_*) instead of a launch of its own   // launch_picture_begin: the rate control state on the main stream (picture order), the per-CTU targets on the picture's own stream (+ the VAQ kernels)
+  bool picture_begin(hipStream_t qt_stream, EncFrame *fold = nullptr, bool zero = false);     // fold: a P picture without VAQ -- the work rides in the picture's k_me launch (EncFrame::pb_*) instead of a launch of its own   // launch_picture_begin: the rate control state on the main stream (picture order), the per-CTU targets on the picture's own stream (+ the VAQ kernels)
   int qp_cur_ = 0; int64_t rc_debt_ = 0; uint32_t rc_bytes_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t rc_known_ = 0;   // rate control state (calling thread)
   void rate_control();
   RcState *rc_state_ = nullptr;                 // rate control v2: device-side state

@@ -118,7 +118,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   // input stream, not behind them -- all-intra 1080p 940 -> 1 300 frames/s)
   idr_side_ = depth_ >= 2 && cfg.vaq == 0 && cfg.band_rows == 0 && cfg.intra_period != 1 && !getenv("KVAZZUP_AMD_IDR_INLINE");
   if (idr_side_) {
-    const size_t nsync = (size_t)rows_ * (cw_ / 64) * 3 + 2, nctu_ = (size_t)(cw_ / 64) * rows_;
+    const size_t nsync = ((size_t)rows_ * (cw_ / 64) * 3 + 2 + 3) & ~(size_t)3, nctu_ = (size_t)(cw_ / 64) * rows_;
     HIP_OK(hipMalloc(&sync_idr_, sizeof(uint32_t) * nsync)); HIP_OK(hipMemset(sync_idr_, 0, sizeof(uint32_t) * nsync));
     HIP_OK(hipMalloc(&edge_col_idr_, nctu_ * 128 * sizeof(uint32_t))); HIP_OK(hipMemset(edge_col_idr_, 0, nctu_ * 128 * sizeof(uint32_t)));
     HIP_OK(hipMalloc(&edge_row_idr_, nctu_ * 32 * 8)); HIP_OK(hipMemset(edge_row_idr_, 0, nctu_ * 32 * 8));
@@ -176,7 +176,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     HIP_OK(hipEventCreateWithFlags(&sl.rec_done, hipEventDisableTiming));
   }
   HIP_OK(hipEventCreateWithFlags(&in_done_, kDeviceEvent));
-  HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 2))); HIP_OK(hipMemset(sync_, 0, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 2)));       // one progress counter per CTU and colour plane, and the ticket counter of k_intra_recon's workgroups
+  HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * ((rows_ * (cw_ / 64) * 3 + 2 + 3) & ~3))); HIP_OK(hipMemset(sync_, 0, sizeof(uint32_t) * ((rows_ * (cw_ / 64) * 3 + 2 + 3) & ~3)));      // (a multiple of 16 bytes: k_picture_begin zeroes it in 16-byte pieces)       // one progress counter per CTU and colour plane, and the ticket counter of k_intra_recon's workgroups
   if (cfg.intra_in_p) { const size_t n16 = (size_t)(cw_ / 16) * (ch_ / 16); HIP_OK(hipMalloc(&me_cost16_, sizeof(uint32_t) * (n16 + 2 + n16 / 4 + n16 / 4 + (n16 / 4) * 40))); HIP_OK(hipMemset(me_cost16_, 0, sizeof(uint32_t) * (n16 + 2 + n16 / 4 + n16 / 4 + (n16 / 4) * 40))); }      // k_me's inter cost per 16x16 block (intra-in-P)
   {
     // dispatch order of the intra reconstruction's workgroups: the CTUs of the rows this instance codes, by anti-diagonal cx + 2 cy
@@ -496,7 +496,7 @@ uint32_t Encoder::next_chain_gen()
   return chain_gen_;
 }
 
-bool Encoder::picture_begin(hipStream_t qt_stream, EncFrame *fold)
+bool Encoder::picture_begin(hipStream_t qt_stream, EncFrame *fold, bool zero)
 {
   const bool have = frame_idx_ >= rc_delay_;
   const uint32_t bits3 = have ? 8u * rc_bytes_[(frame_idx_ - rc_delay_) & 7] : 0u;
@@ -507,12 +507,16 @@ bool Encoder::picture_begin(hipStream_t qt_stream, EncFrame *fold)
     fold->pb_slot3 = (int8_t)slot3; fold->pb_have3 = have ? 1 : 0;
     return true;
   }
-  if (qt_stream == stream_) launch_picture_begin(rc_state_, bits3, slot3, have ? 1 : 0, qt, roi_dev_, n, qp_cur_, cfg_.vaq > 0 ? 1 : 0, stream_);
+  // (an intra picture, `zero`: the launch also takes the chain's two arrays back to zero -- the ticket counter's array with the "has intra units" word of the
+  // P pictures behind it, which no P picture has pending while an intra picture starts on these arrays, and the CU cbf bits)
+  void *za = zero ? (void *)f_.sync : nullptr, *zb = zero ? (void *)f_.cu_cbf : nullptr;
+  const size_t na = zero ? sizeof(uint32_t) * (((size_t)rows_ * (cw_ / 64) * 3 + 2 + 3) & ~(size_t)3) : 0, nb = zero ? (size_t)f_.b8w * f_.b8h : 0;
+  if (qt_stream == stream_) launch_picture_begin(rc_state_, bits3, slot3, have ? 1 : 0, qt, roi_dev_, n, qp_cur_, cfg_.vaq > 0 ? 1 : 0, stream_, za, na, zb, nb);
   else {
     // an intra picture on its side stream: the rate control state is updated in PICTURE ORDER on the main stream (between the P pictures' row groups, which
     // run there), the picture's own per-CTU targets on its own stream
     launch_picture_begin(rc_state_, bits3, slot3, have ? 1 : 0, nullptr, nullptr, 0, qp_cur_, 0, stream_);
-    launch_picture_begin(nullptr, 0, 0, 0, qt, roi_dev_, n, qp_cur_, 0, qt_stream);
+    launch_picture_begin(nullptr, 0, 0, 0, qt, roi_dev_, n, qp_cur_, 0, qt_stream, za, na, zb, nb);
   }
   if (cfg_.qp_in_cu && cfg_.vaq > 0) launch_vaq(f_, cfg_.vaq, vaq_act_, vaq_sum_, stream_);          // (f_.qp, f_.src and f_.ctu_qt of this picture are set; the source is padded: stream_ waits for in_done_)
   return true;
@@ -587,10 +591,9 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   HIP_CHECK(hipEventRecord(in_done_, stream_in_)); in_pending_ = true;
   HIP_CHECK(hipStreamWaitEvent(ms, in_done_, 0));      // (measured by leaving it out: 8 of the ~28 us between a picture's last kernel and the next one's first; the rest is the record behind k_sao that two other streams wait for)
   EncFrame fm = f;                                               // (the picture's first kernel may carry the head of the chain)
-  if (!picture_begin(ms, intra ? nullptr : &fm)) return false;
+  if (intra) { const uint32_t *keep = f_.sync; f_.sync = f.sync; const bool ok = picture_begin(ms, nullptr, true); f_.sync = const_cast<uint32_t *>(keep); if (!ok) return false; }      // (f.sync: the side stream's array when the picture runs there; f_ is back on the shared one)
+  else if (!picture_begin(ms, &fm)) return false;
   if (intra) {
-    HIP_CHECK(hipMemsetAsync(f.sync, 0, sizeof(uint32_t) * (rows_ * (cw_ / 64) * 3 + 1), ms));
-    HIP_CHECK(hipMemsetAsync(f_.cu_cbf, 0, (size_t)f_.b8w * f_.b8h, ms));     // the three plane waves OR their bit in
     timed(K_INTRA_RECON, ms, [&] { launch_intra_recon(f, ms); });
   } else {
     timed(K_ME, stream_, [&] { launch_me(fm, stream_); });

@@ -23,12 +23,21 @@ namespace kvzx {
 //     coded in groups its bits per unit of level cost update the ratio;
 //   * cu_qp_delta (ctu_qt != NULL): every CTU's target QP = clip(picture QP + ROI delta) -- with VAQ the ROI delta alone, k_vaq_apply adds the rest.  The ROI
 //     deltas (per CTU, already spread over the CTU grid) were uploaded on the input stream when the picture brought a map; NULL = no map.
-__global__ __launch_bounds__(256) void k_picture_begin(RcState *rc, uint32_t bits3, int slot3, int have3, int8_t *ctu_qt, const int8_t *roi, int nctu, int qp, int vaq)
+//   * an intra picture: the two arrays its chain starts from (the ticket counter's array, the CU cbf bits the three plane waves OR into) go back to zero
+//     here -- two memsets of their own were two more launches in front of every intra picture's chain
+__global__ __launch_bounds__(256) void k_picture_begin(RcState *rc, uint32_t bits3, int slot3, int have3, int8_t *ctu_qt, const int8_t *roi, int nctu, int qp, int vaq,
+                                                       uint4 *zero_a, int na16, uint4 *zero_b, int nb16)
 {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = threadIdx.x; i < na16; i += 256) zero_a[i] = z;
+  for (int i = threadIdx.x; i < nb16; i += 256) zero_b[i] = z;
   picture_begin_body(rc, bits3, slot3, have3, ctu_qt, roi, nctu, qp, vaq, (int)threadIdx.x, 256);
 }
-void launch_picture_begin(RcState *rc, uint32_t bits3, int slot3, int have3, int8_t *ctu_qt, const int8_t *roi, int nctu, int qp, int vaq, hipStream_t st)
+void launch_picture_begin(RcState *rc, uint32_t bits3, int slot3, int have3, int8_t *ctu_qt, const int8_t *roi, int nctu, int qp, int vaq, hipStream_t st,
+                          void *zero_a, size_t bytes_a, void *zero_b, size_t bytes_b)
 {
-  if (rc || ctu_qt) hipLaunchKernelGGL(k_picture_begin, dim3(1), dim3(256), 0, st, rc, bits3, slot3, have3, ctu_qt, roi, nctu, qp, vaq);
+  // (bytes_a / bytes_b: multiples of 16 -- the caller rounds its arrays' sizes up when it allocates them)
+  if (rc || ctu_qt || bytes_a || bytes_b)
+    hipLaunchKernelGGL(k_picture_begin, dim3(1), dim3(256), 0, st, rc, bits3, slot3, have3, ctu_qt, roi, nctu, qp, vaq, (uint4 *)zero_a, (int)(bytes_a / 16), (uint4 *)zero_b, (int)(bytes_b / 16));
 }
 }  // namespace kvzx

@@ -490,7 +490,8 @@ __device__ __forceinline__ void rc_group_done(const EncFrame &f, InterLds &s, in
 // RC (encoder, rate control v2): the CTU rows in f.rc_nb groups, the QP of a group decided by the last workgroup of the group before it.  Workgroups are
 // dispatched in the order of their linear index (rows top to bottom here: no XCD permutation), so every workgroup of a group is resident or done when one of
 // the next group starts to wait -- the wait cannot starve what it waits for (the intra chains' argument).
-template <bool DEC, bool FRAC, bool ADJ = false, bool RC = false>
+// LL: `lossless` (cu_transquant_bypass): the residual itself goes to the level planes, sample by sample, and the reconstruction is the source
+template <bool DEC, bool FRAC, bool ADJ = false, bool RC = false, bool LL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || ADJ || RC) ? 5 : 8))) void k_inter_recon(EncFrame f)
 {
   __shared__ InterLds s;
@@ -598,7 +599,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || AD
       const uint32_t s4 = *(const uint32_t *)&f.src[0][g];
       int r[4];
       for (int i = 0; i < 4; i++) r[i] = s.intra_q[k] ? 0 : (int)((s4 >> (8 * i)) & 255) - (int)((p4 >> (8 * i)) & 255);
-      *(uint2 *)&A[ty * n + tx] = make_uint2(pack_i16(r[0], r[1]), pack_i16(r[2], r[3]));
+      if constexpr (LL) {
+        *(uint2 *)&f.coef[0][g] = make_uint2(pack_i16(r[0], r[1]), pack_i16(r[2], r[3]));
+        if (r[0] | r[1] | r[2] | r[3]) atomicOr(&s.nz[0], 1u << tu);
+        if (!s.intra_q[k]) *(uint32_t *)&s.px[y * 32 + x] = s4;
+      } else *(uint2 *)&A[ty * n + tx] = make_uint2(pack_i16(r[0], r[1]), pack_i16(r[2], r[3]));
     }
   }
   // ---- chroma: reference windows of the eight 8x8 sub-blocks (plane x quadrant) -> LDS; mv in 1/8 samples
@@ -621,7 +626,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || AD
     auto px16 = [](int tu, int y, int x) { return ((tu >> 1) * 16 + y) * 32 + (tu & 1) * 16 + x; };
     const int cw = f.cw; int16_t *base = f.coef[0] + (size_t)y0 * cw + x0;
     auto ci16 = [=](int tu, int y, int x) { return base + (size_t)((tu >> 1) * 16 + y) * cw + (tu & 1) * 16 + x; };
-    if (split) inter_transform<DEC, 4, 2, RC>(s, qp, &s.nz[0], px16, ci16, tid, adj, qp_late, &rc_cost, f.scaling ? f.scaling + scaling_offset(4, 0, 1) : nullptr, 4);
+    if constexpr (LL) { }
+    else if (split) inter_transform<DEC, 4, 2, RC>(s, qp, &s.nz[0], px16, ci16, tid, adj, qp_late, &rc_cost, f.scaling ? f.scaling + scaling_offset(4, 0, 1) : nullptr, 4);
     else inter_transform_32<DEC, RC>(s, qp, &s.nz[0], base, cw, tid, adj, qp_late, &rc_cost, f.scaling ? f.scaling + scaling_offset(5, 0, 1) : nullptr);
     *(uint32_t *)&f.rec[0][(size_t)(y0 + (tid >> 3)) * f.cw + x0 + (tid & 7) * 4] = *(const uint32_t *)&s.px[(tid >> 3) * 32 + (tid & 7) * 4];
   }
@@ -661,7 +667,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || AD
       }
     } else {
       const uint32_t s2 = RC ? src_c : *(const uint16_t *)&f.src[1 + pl][g];
-      *(uint32_t *)&A[ty * cn + tx] = s.intra_q[sub] ? 0u : pack_i16((int)(s2 & 255) - p0, (int)(s2 >> 8) - p1);
+      const uint32_t r2 = s.intra_q[sub] ? 0u : pack_i16((int)(s2 & 255) - p0, (int)(s2 >> 8) - p1);
+      if constexpr (LL) {
+        *(uint32_t *)&f.coef[1 + pl][g] = r2;
+        if (r2) atomicOr(&s.nz[1], 1u << tu);
+        if (!s.intra_q[sub]) *(uint16_t *)&s.px[pl * 256 + y * 16 + x] = (uint16_t)s2;
+      } else *(uint32_t *)&A[ty * cn + tx] = r2;
     }
   }
   if (!coded) return;                          // (decoder only; the encoder's cbf bookkeeping below never applies)
@@ -674,7 +685,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || AD
     auto ci1 = [=](int tu, int y, int x) { return (tu ? cr : cb) + (size_t)y * cw2 + x; };
     auto ci4 = [=](int tu, int y, int x) { return ((tu >> 2) ? cr : cb) + (size_t)(((tu >> 1) & 1) * 8 + y) * cw2 + (tu & 1) * 8 + x; };
     auto qpc_known = [&]() -> int { return qpc; };
-    if (split) inter_transform<DEC, 3, 1, RC>(s, qpc, &s.nz[1], px4, ci4, tid, adj, qpc_known, &rc_cost, f.scaling ? f.scaling + scaling_offset(3, 1, 1) : nullptr, 4);
+    if constexpr (LL) { }
+    else if (split) inter_transform<DEC, 3, 1, RC>(s, qpc, &s.nz[1], px4, ci4, tid, adj, qpc_known, &rc_cost, f.scaling ? f.scaling + scaling_offset(3, 1, 1) : nullptr, 4);
     else inter_transform<DEC, 4, 1, RC>(s, qpc, &s.nz[1], px1, ci1, tid, adj, qpc_known, &rc_cost, f.scaling ? f.scaling + scaling_offset(4, 1, 1) : nullptr, 1);
   }
   if (tid < 128) {
@@ -1015,7 +1027,7 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
 
 // One plane of one CU on one wave (kernel_common.h "One intra block per WAVE"): block of n = 1 << L2 component samples.
 // Returns whether the block has non-zero levels.
-template <int L2, bool ADJ>
+template <int L2, bool ADJ, bool LL = false>
 __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratch &ws, const IntraBlk &d, int cidx, int S, const QuantConst &q,
                                                  int lane, int adj, uint32_t *ecol, unsigned long long *erow, uint32_t gen, const uint8_t *mtab = nullptr)
 {
@@ -1030,6 +1042,16 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
     for (int r = 0; r < 4; r++) res[r] = (int)((s4 >> (8 * r)) & 255u) - pred[r];
   }
   PROF(5);
+  bool cbf;
+  if constexpr (LL) {
+    // cu_transquant_bypass (EncFrame.lossless): the levels ARE the residual, sample by sample, and the reconstruction is the source
+    bool nzl = false;
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) { s.lev[(ry + c) * S + rx + 4 * g + r] = (int16_t)res[r]; nzl |= res[r] != 0; pred[r] += res[r]; }
+    }
+    cbf = __ballot(nzl) != 0;
+  } else {
   // ---- forward rows, forward columns, quantiser; levels -> s.lev, dequantised coefficients stay in registers
   const XfLaneF16 &xl = s.xf[d.xf][lane];
   const kv_f16x4 ta = kv_h4(xl.ta), tb = kv_h4(xl.tb);
@@ -1072,12 +1094,13 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
       s.lev[(ry + 4 * g + r) * S + rx + c] = (int16_t)lv;
     }
   }
-  const bool cbf = __ballot(nz) != 0;
+  cbf = __ballot(nz) != 0;
   PROF(7);
   if (cbf) {
     wave_inverse16(ws, tb, dq, g, c, res);
 #pragma unroll
     for (int r = 0; r < 4; r++) pred[r] = clip8(pred[r] + res[r]);
+  }
   }
   PROF(8);
   if (active) {
@@ -1108,7 +1131,8 @@ __device__ __forceinline__ bool intra_block_wave(IntraCtuLds &s, IntraWaveScratc
 // once; in the others the inter units count as finished from the start, the CTU picture in LDS starts as the inter
 // reconstruction left it, and only the intra units' levels and cbf bits are written.
 // SCAL: `scaling-list default` -- a form of its own for the same reason as ADJ (the per-position factors cost the plain chain 30 registers when they are a run-time branch)
-template <bool ADJ, bool PP, bool SCAL = false>
+// LL: `lossless` -- see intra_block_wave
+template <bool ADJ, bool PP, bool SCAL = false, bool LL = false>
 __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f)
 {
   constexpr int W = KVZ_INTRA_WAVES, T = 64 * W;
@@ -1245,9 +1269,9 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
     first = false;
     bool cbf;
     switch (d.l2) {
-      case 2: cbf = intra_block_wave<2, ADJ>(s, ws, d, c, S, q8, lane, adj, ecol, erow, f.chain_gen, SCAL ? f.scaling + scaling_offset(2, c, 0) : nullptr); break;
-      case 3: cbf = intra_block_wave<3, ADJ>(s, ws, d, c, S, c ? q16 : q8, lane, adj, ecol, erow, f.chain_gen, SCAL ? f.scaling + scaling_offset(3, c, 0) : nullptr); break;
-      default: cbf = intra_block_wave<4, ADJ>(s, ws, d, c, S, q16, lane, adj, ecol, erow, f.chain_gen, SCAL ? f.scaling + scaling_offset(4, c, 0) : nullptr); break;
+      case 2: cbf = intra_block_wave<2, ADJ, LL>(s, ws, d, c, S, q8, lane, adj, ecol, erow, f.chain_gen, SCAL ? f.scaling + scaling_offset(2, c, 0) : nullptr); break;
+      case 3: cbf = intra_block_wave<3, ADJ, LL>(s, ws, d, c, S, c ? q16 : q8, lane, adj, ecol, erow, f.chain_gen, SCAL ? f.scaling + scaling_offset(3, c, 0) : nullptr); break;
+      default: cbf = intra_block_wave<4, ADJ, LL>(s, ws, d, c, S, q16, lane, adj, ecol, erow, f.chain_gen, SCAL ? f.scaling + scaling_offset(4, c, 0) : nullptr); break;
     }
     const uint2 cvu = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)cv.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)cv.y));
     chain_mark_done(ch, cvu, lane);
@@ -1672,7 +1696,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) vo
         enc_sao(t, f.sao[ctu], hl ? &f.sao[ctu - 1] : nullptr, hu ? &f.sao[ctu - wc] : nullptr);     // (read where they lie: a local copy indexed at run time would live in scratch memory)
       }
       enc_split_flags(v, t, f.cw, f.chp, x0, y0, z, cu.log2);
-      enc_cu_header(v, t, f.cw, f.chp, f.is_intra != 0, x0, y0, cu);
+      enc_cu_header(v, t, f.cw, f.chp, f.is_intra != 0, x0, y0, cu, f.lossless != 0);
       // the quantisation group's (= CTU's) delta QP goes with its first CU that has residual, right after the cbf flags
       if (f.ctu_qy && !(cu.flags & CU_SKIP) && cu.cbf && z == f.ctu_first[ctu]) enc_cu_qp_delta(t, f.ctu_delta[ctu]);
       hdr_n = t.n;
@@ -2117,6 +2141,9 @@ void launch_inter_recon(const EncFrame &f, hipStream_t st)
   } else if (f.rdoq || f.signhide) {
     if (f.subme > 0) hipLaunchKernelGGL((k_inter_recon<false, true, true>), grid, dim3(256), 0, st, f);
     else hipLaunchKernelGGL((k_inter_recon<false, false, true>), grid, dim3(256), 0, st, f);
+  } else if (f.lossless) {
+    if (f.subme > 0) hipLaunchKernelGGL((k_inter_recon<false, true, false, false, true>), grid, dim3(256), 0, st, f);
+    else hipLaunchKernelGGL((k_inter_recon<false, false, false, false, true>), grid, dim3(256), 0, st, f);
   } else if (f.subme > 0) hipLaunchKernelGGL((k_inter_recon<false, true>), grid, dim3(256), 0, st, f);
   else hipLaunchKernelGGL((k_inter_recon<false, false>), grid, dim3(256), 0, st, f);     // integer vectors only
 }
@@ -2140,11 +2167,13 @@ void launch_intra_recon(const EncFrame &f, hipStream_t st)
   if (!f.is_intra) {                                                                                            // intra-in-P, behind k_inter_recon
     // (a workgroup per (CTU, plane) here: nearly all of them find no intra unit, and a workgroup that checks nine tickets in turn pays nine memory round trips)
     const dim3 all(3 * wc * nr);
+    if (f.lossless) { hipLaunchKernelGGL((k_intra_recon<false, true, false, true>), all, block, 0, st, f); return; }
     if (f.scaling) { if (adj) hipLaunchKernelGGL((k_intra_recon<true, true, true>), all, block, 0, st, f); else hipLaunchKernelGGL((k_intra_recon<false, true, true>), all, block, 0, st, f); }
     else if (adj) hipLaunchKernelGGL((k_intra_recon<true, true>), all, block, 0, st, f); else hipLaunchKernelGGL((k_intra_recon<false, true>), all, block, 0, st, f);
     return;
   }
-  if (f.scaling) { if (adj) hipLaunchKernelGGL((k_intra_recon<true, false, true>), grid, block, 0, st, f); else hipLaunchKernelGGL((k_intra_recon<false, false, true>), grid, block, 0, st, f); }
+  if (f.lossless) hipLaunchKernelGGL((k_intra_recon<false, false, false, true>), grid, block, 0, st, f);
+  else if (f.scaling) { if (adj) hipLaunchKernelGGL((k_intra_recon<true, false, true>), grid, block, 0, st, f); else hipLaunchKernelGGL((k_intra_recon<false, false, true>), grid, block, 0, st, f); }
   else if (adj) hipLaunchKernelGGL((k_intra_recon<true, false>), grid, block, 0, st, f);
   else hipLaunchKernelGGL((k_intra_recon<false, false>), grid, block, 0, st, f);
 }

@@ -37,6 +37,7 @@ struct EncoderConfig {
   int qp_in_cu = 0;           // kvazaar "set-qp-in-cu": cu_qp_delta_enabled_flag; a delta-QP map (set_roi, kvz_picture.roi) then gives every CTU its own QP
   int bitrate = 0;            // bits per second; 0 = constant QP, > 0 = "uvgx rate control v1" (oracle/hevc_enc.c rate_control())
   int slices = 0;             // kvazaar "slices": 1 = wpp (a dependent slice segment per CTU row; needs wpp), 2 = tiles (an independent slice per tile); one NAL unit per segment
+  int lossless = 0;           // kvz_config.lossless: cu_transquant_bypass in every coding unit (no deblocking, SAO, RDOQ, sign hiding or rate control with it)
   int rc_bands = 0;           // with bitrate > 0: "uvgx rate control v2" -- a P picture's CTU rows are reconstructed in this many groups and the QP follows the level cost
                               // between them, on the device (rc_kernels.hip; statement rc_band_decide() in oracle/hevc_enc.c); 0 = picture level only (v1); implies qp_in_cu
   int satd = 1;               // intra mode search cost: 8x8 Hadamard sums (1) or SAD (0)

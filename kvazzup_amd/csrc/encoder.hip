@@ -31,6 +31,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
 {
   EncoderConfig cfg = cfg_in;
   if (cfg.vaq > 0) cfg.qp_in_cu = 1;                       // the deltas travel as cu_qp_delta
+  if (cfg.lossless) { cfg.deblock = 0; cfg.sao = 0; cfg.rdoq = 0; cfg.signhide = 0; cfg.bitrate = 0; cfg.rc_bands = 0; }      // (oracle/hevc_enc.c "lossless")
   if (cfg.bitrate <= 0 || cfg.band_rows > 0) cfg.rc_bands = 0;
   if (cfg.rc_bands > 8) cfg.rc_bands = 8;                  // (RcState::acc)
   if ((cfg.slices == 1 && !cfg.wpp) || (cfg.slices == 2 && cfg.tile_rows * cfg.tile_cols < 2) || (cfg.slices == 1 && cfg.tile_cols > 1) || cfg.slices < 0 || cfg.slices > 2) cfg.slices = 0;
@@ -210,7 +211,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     HIP_OK(hipMalloc(&d_scaling_, KVZ_SCALING_BYTES)); HIP_OK(hipMemcpy(d_scaling_, tab, KVZ_SCALING_BYTES, hipMemcpyHostToDevice));
   }
   f_.scaling = d_scaling_; f_.intra_chain = cfg.intra_chain;
-  f_.rdoq = cfg.rdoq; f_.signhide = cfg.signhide; f_.intra_p = cfg.intra_in_p; f_.me_cost16 = me_cost16_; f_.me_cand = me_cost16_ ? me_cost16_ + (size_t)(cw_ / 16) * (ch_ / 16) : nullptr;
+  f_.lossless = cfg.lossless; f_.rdoq = cfg.rdoq; f_.signhide = cfg.signhide; f_.intra_p = cfg.intra_in_p; f_.me_cost16 = me_cost16_; f_.me_cand = me_cost16_ ? me_cost16_ + (size_t)(cw_ / 16) * (ch_ / 16) : nullptr;
   if (me_cost16_) { const size_t n16 = (size_t)(cw_ / 16) * (ch_ / 16); f_.ip_arrive = f_.me_cand + 1 + n16 / 4; f_.ip_scratch = (uint64_t *)(me_cost16_ + ((n16 + 1 + n16 / 4 + n16 / 4 + 1) & ~(size_t)1)); }      // (8-byte aligned)
   f_.wpp = cfg.wpp; f_.mv_frame = cfg.mv_frame; f_.me_early = cfg.me_early; f_.satd = cfg.satd; f_.subme = cfg.subme; f_.slices = cfg.slices;
   bind_set(0);
@@ -223,7 +224,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     f_.edge_row[0] = edge_row_; f_.edge_row[1] = edge_row_ + nctu * 16; f_.edge_row[2] = edge_row_ + nctu * 24; }
   f_.sync = sync_; f_.err = err_; f_.trace = trace_; f_.intra_order = intra_order_;
 
-  sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp; sp_.tile_rows = cfg.tile_rows; sp_.tile_cols = cfg.tile_cols; sp_.qp_in_cu = cfg.qp_in_cu; sp_.sao = cfg.sao; sp_.slices = cfg.slices; sp_.signhide = cfg.signhide; sp_.scaling_list = cfg.scaling_list;
+  sp_.cw = cw_; sp_.ch = ch_; sp_.width = cfg.width; sp_.height = cfg.height; sp_.qp = cfg.qp; sp_.wpp = cfg.wpp; sp_.tile_rows = cfg.tile_rows; sp_.tile_cols = cfg.tile_cols; sp_.qp_in_cu = cfg.qp_in_cu; sp_.sao = cfg.sao; sp_.slices = cfg.slices; sp_.signhide = cfg.signhide; sp_.scaling_list = cfg.scaling_list; sp_.tq_bypass = cfg.lossless;
   sp_.deblock = cfg.deblock; sp_.fps_num = cfg.fps_num; sp_.fps_den = cfg.fps_den;
   HIP_OK(hipStreamSynchronize(stream_));
   HIP_OK(hipDeviceSynchronize());

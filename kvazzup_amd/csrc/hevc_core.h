@@ -71,6 +71,7 @@ struct EncFrame {
   int me_early;             // me-early-termination: blocks that match the co-located reference block to within 64 * lambda_q4 are not searched
   int subme;                // fractional-sample refinement level 0..4 (k_subpel)
   const uint8_t *scaling;   // `scaling-list default`: KVZ_SCALING_BYTES scaling factors of the default lists (dec_frame.h scaling_offset), NULL: flat
+  int lossless;             // `lossless`: cu_transquant_bypass in every coding unit -- levels = residual samples, reconstruction = source (no transform, no quantiser)
   int intra_chain;          // "intra-chain" (default on): blocks on a CTU's left edge / its above-right corner block choose among the modes that do not read the left CTU's below-left / the above-right CTU's samples
   int intra_p;              // "uvgx intra-in-P v1": intra coding units in P pictures (statement: oracle/hevc_enc.c me_block32); me_cost16 = k_me's inter cost of every 16x16 block (0: not searched)
   uint32_t *me_cost16;
@@ -763,9 +764,10 @@ KVZ_HD void enc_split_flags(const V &v, S &c, int cw, int ch, int x0, int y0, in
 // coding_unit() up to and including the cbf flags of its single transform unit (7.3.8.5-7.3.8.10).
 // Returns the cbf bits (bit0 Y, bit1 Cb, bit2 Cr) whose residual_coding() must follow, 0 if none.
 template <class V, class S>
-KVZ_HD int enc_cu_header(const V &v, S &c, int cw, int ch, bool pic_intra, int x0, int y0, const CuRec &cu)
+KVZ_HD int enc_cu_header(const V &v, S &c, int cw, int ch, bool pic_intra, int x0, int y0, const CuRec &cu, bool bypass = false)
 {
   const int intra = cu.intra, flags = cu.flags, cbf = cu.cbf, log2 = cu.log2;
+  if (bypass) cabac_bin(c, CTX_TQ_BYPASS, 1);                  // cu_transquant_bypass_flag (`lossless`: the PPS enables it and every coding unit sets it), first in the coding unit
   if (!pic_intra) {
     int l = avail64(cw, ch, x0, y0, x0 - 1, y0) && (v.at(x0 - 1, y0).flags & CU_SKIP);
     int a = avail64(cw, ch, x0, y0, x0, y0 - 1) && (v.at(x0, y0 - 1).flags & CU_SKIP);
@@ -823,7 +825,7 @@ KVZ_HD void enc_ctu(const EncFrame &f, CabacEnc &c, int cx, int cy)
     int x0 = cx + xi * 8, y0 = cy + yi * 8;
     CuRec cu = v.at(x0, y0);
     enc_split_flags(v, c, f.cw, f.chp, x0, y0, z, cu.log2);
-    int cbf = enc_cu_header(v, c, f.cw, f.chp, f.is_intra != 0, x0, y0, cu);
+    int cbf = enc_cu_header(v, c, f.cw, f.chp, f.is_intra != 0, x0, y0, cu, f.lossless != 0);
     if (cbf & 1) enc_residual(c, f.coef[0] + y0 * f.cw + x0, f.cw, cu.log2, 0, intra_scan_idx(cu.intra, cu.log2, 0, cu.intra_mode), f.signhide);
     for (int ci = 1; ci <= 2; ci++)
       if ((cbf >> ci) & 1)

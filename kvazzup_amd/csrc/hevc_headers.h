@@ -33,6 +33,7 @@ struct StreamParams {
   int sao = 0;              // sample_adaptive_offset_enabled_flag; every slice: slice_sao_luma_flag = slice_sao_chroma_flag = 1
   int signhide = 0;         // sign_data_hiding_enabled_flag
   int scaling_list = 0;     // scaling_list_enabled_flag = 1, no sps_scaling_list_data: the default lists
+  int tq_bypass = 0;        // transquant_bypass_enabled_flag (`lossless`: every coding unit sets cu_transquant_bypass_flag)
   int slices = 0;           // kvazaar slices: 1 = "wpp", a dependent slice segment per CTU row (dependent_slice_segments_enabled_flag); 2 = "tiles", a slice per tile
 };
 
@@ -95,7 +96,7 @@ inline void write_pps(BitWriter &w, const StreamParams &s)
   w.bit(0); w.bit(0); w.bit(s.qp_in_cu != 0);                    // constrained intra, transform skip, cu_qp_delta
   if (s.qp_in_cu) w.ue(0);                                       // diff_cu_qp_delta_depth
   w.se(0); w.se(0); w.bit(0);
-  w.bit(0); w.bit(0); w.bit(0);
+  w.bit(0); w.bit(0); w.bit(s.tq_bypass != 0);                  // weighted_pred, weighted_bipred, transquant_bypass_enabled
   w.bit(s.tile_rows > 1 || s.tile_cols > 1); w.bit(s.wpp);       // tiles, entropy_coding_sync
   if (s.tile_rows > 1 || s.tile_cols > 1) { w.ue((uint32_t)s.tile_cols - 1); w.ue((uint32_t)s.tile_rows - 1); w.bit(1); w.bit(1); }   // columns - 1, rows - 1, uniform spacing, loop filter across tiles
   w.bit(1);                                                      // loop filter across slices

@@ -187,13 +187,12 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
   }
   INT_OPT("band-row0", band_row0, 0, 4096)
   INT_OPT("band-rows", band_rows, 0, 4096)
-  BOOL_OPT("rdoq", rdoq_enable) BOOL_OPT("signhide", signhide_enable)
+  BOOL_OPT("rdoq", rdoq_enable) BOOL_OPT("signhide", signhide_enable) BOOL_OPT("lossless", lossless)
   // Tools this encoder does not have: switching one ON is rejected -- config_parse's return value is all uvgComm's custom-parameter list
   // reports back (kvazaarfilter.cpp:363-367) --, switching it off is accepted.
 #define OFF_ONLY(key, field) if (n == key) { if (!parse_bool(value, &iv)) return 0; cfg->field = 0; return iv ? 0 : 1; }
   OFF_ONLY("smp", smp_enable) OFF_ONLY("amp", amp_enable) OFF_ONLY("bipred", bipred) OFF_ONLY("tmvp", tmvp_enable) OFF_ONLY("transform-skip", trskip_enable)
   OFF_ONLY("full-intra-search", full_intra_search) OFF_ONLY("mv-rdo", mv_rdo) OFF_ONLY("implicit-rdpcm", implicit_rdpcm) OFF_ONLY("intra-rdo-et", intra_rdo_et)
-  OFF_ONLY("lossless", lossless)
 #undef OFF_ONLY
   BOOL_OPT("rdoq-skip", rdoq_skip) BOOL_OPT("early-skip", early_skip)       // (recorded: the zero-out of "uvgx RDOQ v1" and the skip decision do not depend on them)
   BOOL_OPT("set-qp-in-cu", set_qp_in_cu) BOOL_OPT("psnr", calc_psnr) BOOL_OPT("cpuid", cpuid)
@@ -315,9 +314,8 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   ec.entropy_gpu = cfg->gpu_entropy != 0;
   ec.input_hold = cfg->input_hold != 0;
   ec.scaling_list = cfg->scaling_list == KVZ_SCALING_LIST_DEFAULT; ec.intra_chain = cfg->intra_chain != 0;
-  // kvz_config.lossless (uvgComm writes the field itself, kvazaarfilter.cpp:244, so a refusal could only be a failed encoder_open = no video at all):
-  // transform / quantiser bypass is not implemented in the encoder -- the call goes on at the finest quantiser instead, and says so once
-  if (cfg->lossless) { fprintf(stderr, "kvazzup_amd: lossless coding is not implemented in the encoder; coding at QP 0 instead\n"); ec.qp = 0; }
+  // kvz_config.lossless (uvgComm writes the field itself, kvazaarfilter.cpp:244): cu_transquant_bypass in every coding unit (round 4, second half)
+  ec.lossless = cfg->lossless != 0;
   ec.rdoq = cfg->rdoq_enable != 0; ec.signhide = cfg->signhide_enable != 0; ec.intra_in_p = cfg->intra_in_p;
   ec.hash = cfg->hash == KVZ_HASH_MD5 ? 2 : (cfg->hash == KVZ_HASH_CHECKSUM ? 1 : 0);
   ec.vaq = cfg->vaq > 0 ? cfg->vaq : 0;

@@ -227,6 +227,12 @@ static int code_block(orc_encoder *e, int cidx, int x0, int y0, int n, int qp, i
   const pixel *src = e->src[cidx] + y0 * stride + x0;
   int16_t res[32 * 32], cf[32 * 32], lv[32 * 32];
   for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) res[y * n + x] = (int16_t)(src[y * stride + x] - rec[y * stride + x]);
+  if (e->cfg.lossless) {                                       /* cu_transquant_bypass: the level at (x, y) is the residual sample at (x, y) (7.3.8.11, 8.6.2) */
+    int16_t *cp = e->coef[cidx] + y0 * stride + x0;
+    int any = 0;
+    for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) { cp[y * stride + x] = res[y * n + x]; any |= res[y * n + x] != 0; rec[y * stride + x] = src[y * stride + x]; }
+    return any;
+  }
   orc_fwd_transform(res, cf, n, 0);
   /* `scaling-list default`: the scaling factors of the block's size, colour component and prediction mode (the default lists, hevc_scaling.c) */
   const uint8_t *m = e->cfg.scaling_list ? e->sfac[orc_log2((unsigned)n) - 2][orc_scaling_matrix_id(orc_log2((unsigned)n) - 2, cidx, !intra)] : NULL;
@@ -888,6 +894,7 @@ static void enc_cu(orc_encoder *e, orc_cabac_enc *c, int x0, int y0, int log2)
   orc_pic *p = e->cur;
   int bi = b8i(e, x0, y0), n = 1 << log2;
   int intra = e->cu_intra[bi], flags = e->cu_flags[bi], cbf = e->cu_cbf[bi];
+  if (e->pps.transquant_bypass_enabled) orc_cenc_bin(c, CTX_TQ_BYPASS, e->cfg.lossless ? 1 : 0);      /* cu_transquant_bypass_flag: first in the coding unit (7.3.8.5) */
   if (!e->is_intra) {
     int l = orc_available(&e->av, x0, y0, x0 - 1, y0) && p->pred_mode[(y0 >> 2) * p->b4_w + ((x0 - 1) >> 2)] == MODE_SKIP;
     int a = orc_available(&e->av, x0, y0, x0, y0 - 1) && p->pred_mode[((y0 - 1) >> 2) * p->b4_w + (x0 >> 2)] == MODE_SKIP;
@@ -1226,6 +1233,15 @@ int orc_enc_set_option(orc_encoder *e, const char *name, int value)
     return 1;
   }
   if (!strcmp(name, "intra-chain")) { e->cfg.intra_chain = value != 0; return 1; }
+  if (!strcmp(name, "lossless")) {                     /* (set it before the first picture: the PPS says transquant_bypass_enabled_flag) */
+    if (!value) return e->cfg.lossless == 0;
+    e->cfg.lossless = 1; e->pps.transquant_bypass_enabled = 1;
+    e->cfg.deblock = 0; e->pps.deblocking_filter_control_present = 1; e->pps.pps_deblocking_disabled = 1;
+    e->cfg.sao = 0; e->sps.sao_enabled = 0;
+    e->cfg.rdoq = 0; e->cfg.signhide = 0; e->pps.sign_data_hiding = 0;
+    e->cfg.bitrate = 0; e->cfg.rc_bands = 0;
+    return 1;
+  }
   if (!strcmp(name, "rdoq")) { e->cfg.rdoq = value != 0; return 1; }
   if (!strcmp(name, "signhide")) { e->cfg.signhide = value != 0; e->pps.sign_data_hiding = e->cfg.signhide; return 1; }
   return 0;

@@ -370,17 +370,20 @@ def test_random_tool_combinations_match_oracle(gpu, seed):
     extra = dict(subme=int(rng.choice([0, 0, 2, 4])), tile_cols=int(rng.choice([1, 1, 2])) if w >= 256 else 1)
     tools = dict(intra_in_p=int(rng.integers(0, 3)), rdoq=int(rng.integers(0, 2)), signhide=int(rng.integers(0, 2)))
     cfg.update(extra)
+    lossless = int(rng.integers(0, 4) == 0)          # (round 4: a quarter of the seeds with uvgComm's "lossless" box on top of whatever else they drew)
     frames = (9 if owf < 3 else 12) if cfg["bitrate"] else 5              # (the rate controller starts moving the QP behind its delay)
     oe = orc.OracleEncoder(w, h, **cfg)
     if cfg["bitrate"] and owf >= 3:
         oe.set_option("rc-delay", owf + 1)             # the feedback delay follows the pictures in flight (encoder.hip rc_delay_)
     oe.set_option("intra-in-p", tools["intra_in_p"]); oe.set_option("rdoq", tools["rdoq"]); oe.set_option("signhide", tools["signhide"])
+    if lossless:
+        oe.set_option("lossless", 1)
     od = orc.OracleDecoder()
     ge = Encoder(w, h, options=(("qp", cfg["qp"]), ("period", cfg["period"]), ("me-range", cfg["me_range"]), ("wpp", cfg["wpp"]),
                                 ("deblock", cfg["deblock"]), ("tiles", "%dx%d" % (cfg["tile_cols"], cfg["tile_rows"])), ("sao", "full" if cfg["sao"] else "off"),
                                 ("subme", cfg["subme"]), ("intra-in-p", tools["intra_in_p"]), ("rdoq", tools["rdoq"]), ("signhide", tools["signhide"]),
                                 ("set-qp-in-cu", cfg["qp_in_cu"]), ("owf", owf),
-                                ("mv-constraint", ("none", "frame", "frametilemargin")[cfg["mv_frame"]])) + ((("vaq", cfg["vaq"]),) if cfg["vaq"] else ()) + (("me-early-termination", "on" if cfg["me_early"] else "off"),), fields={"target_bitrate": cfg["bitrate"]})
+                                ("mv-constraint", ("none", "frame", "frametilemargin")[cfg["mv_frame"]])) + ((("vaq", cfg["vaq"]),) if cfg["vaq"] else ()) + (("me-early-termination", "on" if cfg["me_early"] else "off"),) + ((("lossless", 1),) if lossless else ()), fields={"target_bitrate": cfg["bitrate"]})
     assert not ge.rejected, (cfg, ge.rejected)
     gd = Decoder()
     roi = None
@@ -404,7 +407,7 @@ def test_random_tool_combinations_match_oracle(gpu, seed):
             got.append(out)
     assert len(got) == frames, (cfg, owf, len(got))
     for t in range(frames):
-        assert got[t][0] == want[t][0], (cfg, tools, owf, t, len(got[t][0]), len(want[t][0]))
+        assert got[t][0] == want[t][0], (cfg, tools, lossless, owf, t, len(got[t][0]), len(want[t][0]))
         assert np.array_equal(got[t][1], want[t][1]), (cfg, tools, owf, t)
         dec = gd.decode_au(got[t][0], t)
         ref = od.decode_au(want[t][0], t)
@@ -586,23 +589,43 @@ def test_scaling_list_default_matches_oracle(gpu, cfg):
         x.close()
 
 
+LOSSLESS_CASES = [
+    dict(w=256, h=128, qp=32, frames=3, period=64, how="field"),                                        # uvgComm's way: kvz_config.lossless written directly
+    dict(w=192, h=128, qp=27, frames=3, period=1, how="option"),                                        # all intra
+    dict(w=416, h=240, qp=32, frames=6, period=64, subme=4, intra_in_p=2, cut=3, how="option"),         # quarter-sample vectors, intra units in P pictures, a scene cut
+    dict(w=640, h=384, qp=37, frames=4, period=64, subme=2, sao=1, bitrate=500000, how="field"),        # the boxes that lossless switches off again (SAO, rate control)
+    dict(w=1920, h=1088, qp=32, frames=3, period=64, how="field"),
+]
+
+
 @pytest.mark.gpu
-def test_lossless_field_does_not_end_the_call(gpu):
-    """uvgComm writes kvz_config.lossless itself (kvazaarfilter.cpp:244): the encoder has no transform / quantiser bypass, but the call must go on --
-    encoder_open succeeds and the stream is coded at the finest quantiser (QP 0), decodable and identical to the checker's at that QP"""
+@pytest.mark.parametrize("cfg", LOSSLESS_CASES, ids=lambda c: "%dx%d_p%d_%s" % (c["w"], c["h"], c["period"], c["how"]))
+def test_lossless_is_lossless_and_matches_the_checker(gpu, cfg):
+    """uvgComm's "lossless" box (kvz_config.lossless, kvazaarfilter.cpp:244): every coding unit with cu_transquant_bypass_flag, the residual coded sample
+    by sample (k_intra_recon<.., LL>, k_inter_recon<.., LL>).  The access units equal the checker's byte for byte, and what the three decoders make of them
+    IS the source picture."""
+    from kvazzup_amd import synth
     from kvazzup_amd.codec import Decoder, Encoder
-    w, h = 256, 128
-    ge = Encoder(w, h, options=(("qp", 32), ("period", 64), ("me-range", 8)), fields={"lossless": 1})
-    oe = orc.OracleEncoder(w, h, qp=0, period=64, me_range=8)
-    gd = Decoder()
-    for t in range(3):
-        frame = orc.synth_frame(0, SEED, w, h, t)
+    w, h = cfg["w"], cfg["h"]
+    opts = [("qp", cfg["qp"]), ("period", cfg["period"]), ("me-range", 8), ("subme", cfg.get("subme", 0)), ("intra-in-p", cfg.get("intra_in_p", 0)),
+            ("sao", cfg.get("sao", 0)), ("bitrate", cfg.get("bitrate", 0))]
+    if cfg["how"] == "option":
+        ge = Encoder(w, h, options=tuple(opts + [("lossless", 1)]))
+    else:
+        ge = Encoder(w, h, options=tuple(opts), fields={"lossless": 1})
+    oe = orc.OracleEncoder(w, h, qp=cfg["qp"], period=cfg["period"], me_range=8, subme=cfg.get("subme", 0), sao=cfg.get("sao", 0), bitrate=cfg.get("bitrate", 0))
+    oe.set_option("intra-in-p", cfg.get("intra_in_p", 0)); oe.set_option("lossless", 1)
+    gd = Decoder(); od = orc.OracleDecoder()
+    for t in range(cfg["frames"]):
+        frame = synth.scene_cut_frame(SEED, w, h, t, cfg["cut"]) if "cut" in cfg else orc.synth_frame(0, SEED, w, h, t)
         au, rec = ge.encode(frame)
-        assert au == oe.encode(frame), t
-        out = gd.decode_au(au, t)
-        assert len(out) == 1 and np.array_equal(out[0]["i420"], rec), t
-        assert float(np.mean((rec[:w * h].astype(np.int32) - frame[:w * h]) ** 2)) < 1.0, t      # QP 0: all but lossless
-    for x in (ge, gd, oe):
+        want = oe.encode(frame)
+        assert au == want, (t, len(au), len(want), _diagnose(oe.debug(), ge.debug_all()))
+        assert np.array_equal(rec, frame), t
+        got = gd.decode_au(au, t); ref = od.decode_au(au, t)
+        assert len(got) == 1 and np.array_equal(got[0]["i420"], frame), t
+        assert len(ref) == 1 and np.array_equal(ref[0]["i420"], frame), t
+    for x in (ge, gd, oe, od):
         x.close()
 
 

@@ -41,6 +41,29 @@ def test_filter_chain_matches_oracle(gpu, w, h, qp, period, tile_rows):
 
 
 @pytest.mark.gpu
+def test_filter_chain_with_the_lossless_box_ticked(gpu):
+    """uvgComm's `video/lossless` (videosettings.cpp:188 -> kvazaarfilter.cpp:244): what leaves the OpenHEVCFilter mirror IS what went into the KvazaarFilter mirror"""
+    from kvazzup_amd.pipeline import Pipeline
+    w, h, frames = 416, 240, 6
+    oe = orc.OracleEncoder(w, h, qp=32, period=64, me_range=16)
+    oe.set_option("lossless", 1)
+    pl = Pipeline(w, h, settings={"video/QP": 32, "video/Intra": 64, "video/lossless": 1}, custom=(("me-range", 16),))
+    try:
+        clip = [orc.synth_frame(0, SEED, w, h, t) for t in range(frames)]
+        for f in clip:
+            pl.push(f)
+        assert pl.wait(frames, 60000)
+        for t in range(frames):
+            au_g, pts = pl.pop_encoded()
+            assert pts == t and au_g == oe.encode(clip[t]), "AU %d differs" % t
+            d = pl.pop_decoded()
+            assert d["pts"] == t and np.array_equal(d["i420"], clip[t]), "picture %d is not the source" % t
+    finally:
+        pl.close()
+        oe.close()
+
+
+@pytest.mark.gpu
 def test_encoder_rejects_mismatching_input_and_unknown_option(gpu):
     from kvazzup_amd.pipeline import Pipeline
     pl = Pipeline(256, 128, custom=(("no-such-option", 1),))     # logged as invalid custom parameter, like kvazaarfilter.cpp:363-367

@@ -85,6 +85,24 @@ def test_checker_encoder_streams(c):
     compare(aus)
 
 
+@pytest.mark.parametrize("c", [dict(w=192, h=128, qp=32, period=64, subme=0, iip=0, tile_rows=1, frames=4),
+                               dict(w=128, h=128, qp=27, period=1, subme=0, iip=0, tile_rows=2, frames=2),
+                               dict(w=256, h=128, qp=30, period=64, subme=4, iip=2, tile_rows=1, frames=4)], ids=lambda c: "%dx%d-p%d" % (c["w"], c["h"], c["period"]))
+def test_checker_encoder_lossless(c):
+    """`lossless` (oracle/hevc_enc.h, uvgComm's check box kvazaarfilter.cpp:244): cu_transquant_bypass everywhere -- the checker's decoder and the decoder
+    written from the standard's text both return the SOURCE pictures"""
+    e = orc.OracleEncoder(c["w"], c["h"], qp=c["qp"], period=c["period"], me_range=8, subme=c["subme"], tile_rows=c["tile_rows"], sao=1, deblock=1)
+    e.set_option("intra-in-p", c["iip"]); e.set_option("lossless", 1)
+    src = [orc.synth_frame(0 if t < 2 else 2, 0x5EED0010, c["w"], c["h"], t) for t in range(c["frames"])]     # (a change of content: intra units in P pictures)
+    aus = [e.encode(f) for f in src]
+    e.close()
+    want, got = decode_both(aus)
+    assert len(want) == len(got) == len(src)
+    for t, f in enumerate(src):
+        assert np.array_equal(want[t]["i420"], f), t
+        assert np.array_equal(got[t]["i420"], f), t
+
+
 GEN = [
     dict(width=64, height=64, seed=11, pictures=2),
     dict(width=136, height=72, seed=12, pictures=3),

@@ -1882,6 +1882,7 @@ __global__ __launch_bounds__(256) void k_pad_input(const uint8_t *in, int w, int
 // three components.  Encoder: statistics against the source picture and "uvgx SAO decision v1" (statement of record:
 // oracle/hevc_sao.c), parameters out; decoder: parameters in.  Both: the filtered CTU goes to the output picture.
 // =============================================================================================
+#define KVZ_SAO_THREADS 1024   // (a CTU's workgroup is alone on its compute unit in uvgComm's default mode: four waves per SIMD hide what one wave waited for -- tools/sao_timeline.py)
 struct SaoLds {
   // the deblocked CTU with a one-sample border, one padded picture per component: sample (x, y), x and y in -1 .. n, at
   // [(y + 1) * pitch + 4 + x]; pitch 72 / 40 keeps the CTB's own samples dword aligned
@@ -1900,11 +1901,68 @@ __device__ __forceinline__ int sao_edge_idx(int c, int a, int b)
 __device__ __forceinline__ int sao_rdiv(int a, int b) { return b == 0 ? 0 : (a >= 0 ? (2 * a + b) / (2 * b) : -((-2 * a + b) / (2 * b))); }
 __device__ __forceinline__ int sao_off_bins(int o) { const int a = o < 0 ? -o : o; return a < 7 ? a + 1 : 7; }
 
+// Statistics of one piece of a column of a CTB (ROWS rows from row ys of column x) with the 3 x 3 neighbourhood in registers.  Edge classes: per class one
+// 64-bit accumulator with four 16-bit fields (sum of d + 256 per category) and one 32-bit accumulator with four 8-bit counts, reduced over the
+// wave with DPP at the end -- one LDS atomic per wave and statistic.  Bands: runs of equal band index along the column are summed in registers and
+// flushed when the band changes.  o8: the source samples of the piece (fetched by the caller long before).
+template <int ROWS>
+__device__ __forceinline__ void sao_stats_column(SaoLds &s, int c, const uint8_t *w, int pitch, int x, int ys, bool okh, int Y0, int ph, const int *o8, int tid)
+{
+  const uint8_t *col = w + 4 + x - 1;                                   // column x - 1 of window row 0 (= sample row -1)
+  int r0[3], r1[3], r2[3];
+  for (int k = 0; k < 3; k++) { r0[k] = col[ys * pitch + k]; r1[k] = col[(ys + 1) * pitch + k]; }
+  uint64_t sacc[4] = {0, 0, 0, 0}; uint32_t cacc[4] = {0, 0, 0, 0};
+  int run_b = -1, run_n = 0, run_s = 0;
+#pragma unroll
+  for (int j = 0; j < ROWS; j++) {
+    const int y = ys + j;
+    for (int k = 0; k < 3; k++) r2[k] = col[(y + 2) * pitch + k];
+    const int v = r1[1], d = o8[j] - v, b = v >> 3;
+    if (b != run_b) {
+      if (run_n) { atomicAdd(&s.bn[c][run_b], run_n); atomicAdd(&s.bs[c][run_b], run_s); }
+      run_b = b; run_n = 0; run_s = 0;
+    }
+    run_n++; run_s += d;
+    const bool okv = Y0 + y - 1 >= 0 && Y0 + y + 1 < ph;
+    const int ka = okh ? sao_edge_idx(v, r1[0], r1[2]) : 0, kb = okv ? sao_edge_idx(v, r0[1], r2[1]) : 0;
+    const int kc = (okh && okv) ? sao_edge_idx(v, r0[0], r2[2]) : 0, kd = (okh && okv) ? sao_edge_idx(v, r0[2], r2[0]) : 0;
+    const int kk[4] = {ka, kb, kc, kd};
+#pragma unroll
+    for (int e = 0; e < 4; e++) if (kk[e]) { sacc[e] += (uint64_t)(uint32_t)(d + 256) << (16 * (kk[e] - 1)); cacc[e] += 1u << (8 * (kk[e] - 1)); }
+    for (int k = 0; k < 3; k++) { r0[k] = r1[k]; r1[k] = r2[k]; }
+  }
+  if (run_n) { atomicAdd(&s.bn[c][run_b], run_n); atomicAdd(&s.bs[c][run_b], run_s); }
+#pragma unroll
+  for (int e = 0; e < 4; e++)
+#pragma unroll
+    for (int k = 1; k <= 4; k++) {
+      // one reduction for both: the wave's count (<= 64 * ROWS) above bit 20, its biased sum (<= 64 * ROWS * 511) below
+      const uint32_t cnt = (cacc[e] >> (8 * (k - 1))) & 0xffu, sum = (uint32_t)(sacc[e] >> (16 * (k - 1))) & 0xffffu;
+      const uint32_t r = wave_sum_u32((cnt << 20) | sum), N = r >> 20, S = r & 0xfffffu;
+      if ((tid & 63) == 0) { atomicAdd(&s.en[c][e][k], (int)N); atomicAdd(&s.es[c][e][k], (int)S - 256 * (int)N); }
+    }
+}
+
 template <bool DEC>
-__global__ __launch_bounds__(256) void k_sao(EncFrame f)
+__global__ __launch_bounds__(KVZ_SAO_THREADS) void k_sao(EncFrame f)
 {
   __shared__ SaoLds s;
   const int tid = threadIdx.x, wc = f.cw >> 6, ctu = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), cx = ctu % wc, cy = ctu / wc;
+  unsigned long long *tr = (!DEC && f.trace && tid == 0) ? f.trace + (size_t)wc * (f.ch >> 6) * 56 + (size_t)ctu * 16 : nullptr;      // (tools/sao_timeline.py)
+#define SAO_STAMP(k) do { if (tr) tr[k] = wall_clock64(); } while (0)
+  SAO_STAMP(0);
+  constexpr int T = KVZ_SAO_THREADS;
+  // the source samples of this thread's pieces of columns (sao_stats_column): in flight while the window is fetched
+  const int lx = tid & 63, lys = (tid >> 6) * 4;                                         // luma: column lx, rows lys .. lys + 3
+  const int cc = 1 + (tid >> 9), cxx = tid & 31, cys = ((tid & 511) >> 5) * 2;           // chroma component cc: column cxx, rows cys, cys + 1
+  int o8l[4] = {0, 0, 0, 0}, o8c[2] = {0, 0};
+  if (!DEC) {
+    const uint8_t *ol = f.src[0] + (size_t)(cy * 64 + lys) * f.cw + cx * 64 + lx, *oc = f.src[cc] + (size_t)(cy * 32 + cys) * (f.cw >> 1) + cx * 32 + cxx;
+#pragma unroll
+    for (int j = 0; j < 4; j++) o8l[j] = ol[(size_t)j * f.cw];
+#pragma unroll
+    for (int j = 0; j < 2; j++) o8c[j] = oc[(size_t)j * (f.cw >> 1)];
+  }
   // ---- window: the CTB's samples as dwords, the border ring byte by byte (clamped at the picture edges; those samples are
   // never used: a neighbour outside the picture switches the edge offset off)
 #pragma unroll
@@ -1913,11 +1971,11 @@ __global__ __launch_bounds__(256) void k_sao(EncFrame f)
     uint8_t *w = c ? s.winc[c - 1] : s.win; const int pitch = c ? 40 : 72;
     const uint8_t *src = f.rec[c];
 #pragma unroll
-    for (int i = tid; i < n * n / 4; i += 256) {
+    for (int i = tid; i < n * n / 4; i += T) {
       const int y = i >> (l2n - 2), x = (i & ((n >> 2) - 1)) * 4;
       *(uint32_t *)&w[(y + 1) * pitch + 4 + x] = *(const uint32_t *)&src[(size_t)(Y0 + y) * pw + X0 + x];
     }
-    for (int q = tid; q < 4 * n + 4; q += 256) {
+    for (int q = tid; q < 4 * n + 4; q += T) {
       int x, y;
       if (q < n + 2) { x = q - 1; y = -1; } else if (q < 2 * n + 4) { x = q - (n + 2) - 1; y = n; }
       else if (q < 3 * n + 4) { x = -1; y = q - (2 * n + 4); } else { x = n; y = q - (3 * n + 4); }
@@ -1925,58 +1983,15 @@ __global__ __launch_bounds__(256) void k_sao(EncFrame f)
     }
   }
   if (DEC) { if (tid == 0) s.p = f.sao[ctu]; }
-  else for (int i = tid; i < (int)((sizeof(s.en) + sizeof(s.es) + sizeof(s.bn) + sizeof(s.bs)) / sizeof(int)); i += 256) (&s.en[0][0][0])[i] = 0;
+  else for (int i = tid; i < (int)((sizeof(s.en) + sizeof(s.es) + sizeof(s.bn) + sizeof(s.bs)) / sizeof(int)); i += T) (&s.en[0][0][0])[i] = 0;
   __syncthreads();
+  SAO_STAMP(1);
   if (!DEC) {
-    // Statistics.  A thread walks down a piece of a column of the CTB (luma 16 rows, chroma 4) with the 3 x 3 neighbourhood
-    // in registers.  Edge classes: per class one 64-bit accumulator with four 16-bit fields (sum of d + 256 per category) and
-    // one 32-bit accumulator with four 8-bit counts, reduced over the wave with DPP at the end -- one LDS atomic per wave and
-    // statistic.  Bands: runs of equal band index along the column are summed in registers and flushed when the band changes.
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const int sh = c ? 1 : 0, l2n = 6 - sh, n = 1 << l2n, pw = f.cw >> sh, ph = f.ch >> sh, X0 = cx * n, Y0 = cy * n;
-      const uint8_t *w = c ? s.winc[c - 1] : s.win; const int pitch = c ? 40 : 72;
-      const int rows = c ? 4 : 16, x = tid & (n - 1), ys = (tid >> l2n) * rows;
-      const bool okh = X0 + x - 1 >= 0 && X0 + x + 1 < pw;
-      const uint8_t *col = w + 4 + x - 1;                                   // column x - 1 of window row 0 (= sample row -1)
-      int r0[3], r1[3], r2[3];
-      for (int k = 0; k < 3; k++) { r0[k] = col[ys * pitch + k]; r1[k] = col[(ys + 1) * pitch + k]; }
-      uint64_t sacc[4] = {0, 0, 0, 0}; uint32_t cacc[4] = {0, 0, 0, 0};
-      int run_b = -1, run_n = 0, run_s = 0;
-      const uint8_t *org = f.src[c] + (size_t)(Y0 + ys) * pw + X0 + x;
-      int o8[16];                                                           // the source column: all loads in flight at once
-#pragma unroll
-      for (int j = 0; j < rows; j++) o8[j] = org[(size_t)j * pw];
-#pragma unroll
-      for (int j = 0; j < rows; j++) {
-        const int y = ys + j;
-        for (int k = 0; k < 3; k++) r2[k] = col[(y + 2) * pitch + k];
-        const int v = r1[1], d = o8[j] - v, b = v >> 3;
-        if (b != run_b) {
-          if (run_n) { atomicAdd(&s.bn[c][run_b], run_n); atomicAdd(&s.bs[c][run_b], run_s); }
-          run_b = b; run_n = 0; run_s = 0;
-        }
-        run_n++; run_s += d;
-        const bool okv = Y0 + y - 1 >= 0 && Y0 + y + 1 < ph;
-        const int ka = okh ? sao_edge_idx(v, r1[0], r1[2]) : 0, kb = okv ? sao_edge_idx(v, r0[1], r2[1]) : 0;
-        const int kc = (okh && okv) ? sao_edge_idx(v, r0[0], r2[2]) : 0, kd = (okh && okv) ? sao_edge_idx(v, r0[2], r2[0]) : 0;
-        const int kk[4] = {ka, kb, kc, kd};
-#pragma unroll
-        for (int e = 0; e < 4; e++) if (kk[e]) { sacc[e] += (uint64_t)(uint32_t)(d + 256) << (16 * (kk[e] - 1)); cacc[e] += 1u << (8 * (kk[e] - 1)); }
-        for (int k = 0; k < 3; k++) { r0[k] = r1[k]; r1[k] = r2[k]; }
-      }
-      if (run_n) { atomicAdd(&s.bn[c][run_b], run_n); atomicAdd(&s.bs[c][run_b], run_s); }
-#pragma unroll
-      for (int e = 0; e < 4; e++)
-#pragma unroll
-        for (int k = 1; k <= 4; k++) {
-          // one reduction for both: the wave's count (<= 1024) above bit 20, its biased sum (<= 64 * 16 * 511) below
-          const uint32_t cnt = (cacc[e] >> (8 * (k - 1))) & 0xffu, sum = (uint32_t)(sacc[e] >> (16 * (k - 1))) & 0xffffu;
-          const uint32_t r = wave_sum_u32((cnt << 20) | sum), N = r >> 20, S = r & 0xfffffu;
-          if ((tid & 63) == 0) { atomicAdd(&s.en[c][e][k], (int)N); atomicAdd(&s.es[c][e][k], (int)S - 256 * (int)N); }
-        }
-    }
+    // Statistics: sao_stats_column -- the luma CTB's columns in pieces of four rows over all 1024 threads, then both chroma CTBs' in pieces of two
+    sao_stats_column<4>(s, 0, s.win, 72, lx, lys, cx * 64 + lx - 1 >= 0 && cx * 64 + lx + 1 < f.cw, cy * 64, f.ch, o8l, tid);
+    sao_stats_column<2>(s, cc, s.winc[cc - 1], 40, cxx, cys, cx * 32 + cxx - 1 >= 0 && cx * 32 + cxx + 1 < (f.cw >> 1), cy * 32, f.ch >> 1, o8c, tid);
     __syncthreads();
+    SAO_STAMP(2);
     if (tid < 48) {                                       // edge offsets: component x class x category
       const int c = tid >> 4, e = (tid >> 2) & 3, k = (tid & 3) + 1, N = s.en[c][e][k], S = s.es[c][e][k];
       int o = sao_rdiv(S, N);
@@ -2005,6 +2020,7 @@ __global__ __launch_bounds__(256) void k_sao(EncFrame f)
       s.cand_dist[c][j] = dist; s.cand_bins[c][j] = bins;
     }
     __syncthreads();
+    SAO_STAMP(3);
     if (tid == 0) {
       const long long l2 = (long long)f.lambda_q4 * f.lambda_q4;
       int pick[2] = {0, 0};
@@ -2030,6 +2046,7 @@ __global__ __launch_bounds__(256) void k_sao(EncFrame f)
     }
   }
   __syncthreads();
+  SAO_STAMP(4);
   // ---- the filter: four samples of a row per thread, the rows above and below as 6-byte spans (samples x - 1 .. x + 4)
 #pragma unroll
   for (int c = 0; c < 3; c++) {
@@ -2039,7 +2056,7 @@ __global__ __launch_bounds__(256) void k_sao(EncFrame f)
     int off[4];
     for (int k = 0; k < 4; k++) off[k] = s.p.offset[c][k];
 #pragma unroll
-    for (int q = tid; q < n * n / 4; q += 256) {
+    for (int q = tid; q < n * n / 4; q += T) {
       const int y = q >> (l2n - 2), x4 = (q & ((n >> 2) - 1)) * 4;
       const uint32_t *row = (const uint32_t *)&w[(y + 1) * pitch + x4];        // dword holding samples x4 - 4 .. x4 - 1
       uint32_t out = row[1];
@@ -2072,6 +2089,8 @@ __global__ __launch_bounds__(256) void k_sao(EncFrame f)
       *(uint32_t *)&f.sao_out[c][(size_t)(Y0 + y) * pw + X0 + x4] = out;
     }
   }
+  SAO_STAMP(5);
+#undef SAO_STAMP
 }
 
 // =============================================================================================
@@ -2208,7 +2227,7 @@ void launch_vaq(const EncFrame &f, int vaq, int *act, int *sum, hipStream_t st)
   hipLaunchKernelGGL(k_vaq_stats, dim3(nctu), dim3(256), 0, st, f, act, sum);
   hipLaunchKernelGGL(k_vaq_apply, dim3((nctu + 255) / 256), dim3(256), 0, st, f, vaq, (const int *)act, (const int *)sum, nctu);
 }
-void launch_sao(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_sao<false>, dim3((f.cw / 64) * (f.ch / 64)), dim3(256), 0, st, f); }
+void launch_sao(const EncFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_sao<false>, dim3((f.cw / 64) * (f.ch / 64)), dim3(KVZ_SAO_THREADS), 0, st, f); }
 void launch_tokenize(const EncFrame &f, hipStream_t st)
 {
   // One wave per unit and colour component keeps the longest wave short: the kernel lasts as long as its slowest wave.  (One wave per unit that takes

@@ -1888,7 +1888,7 @@ struct SaoLds {
   // [(y + 1) * pitch + 4 + x]; pitch 72 / 40 keeps the CTB's own samples dword aligned
   alignas(4) uint8_t win[66 * 72];
   alignas(4) uint8_t winc[2][34 * 40];
-  int en[3][4][5], es[3][4][5], bn[3][32], bs[3][32];
+  int en[3][4][5], es[3][4][5], bn[3][32][16], bs[3][32][16];      // (band statistics in 16 copies, by lane: neighbouring columns mostly fall into the same band, and LDS atomics on one address go one after the other)
   int eo_off[3][4][4], eo_dist[3][4][4], bo_off[3][32], bo_gain[3][32];
   int cand_dist[3][5], cand_bins[3][5], cand_band[3];
   SaoParams p;
@@ -1901,43 +1901,50 @@ __device__ __forceinline__ int sao_edge_idx(int c, int a, int b)
 __device__ __forceinline__ int sao_rdiv(int a, int b) { return b == 0 ? 0 : (a >= 0 ? (2 * a + b) / (2 * b) : -((-2 * a + b) / (2 * b))); }
 __device__ __forceinline__ int sao_off_bins(int o) { const int a = o < 0 ? -o : o; return a < 7 ? a + 1 : 7; }
 
-// Statistics of one piece of a column of a CTB (ROWS rows from row ys of column x) with the 3 x 3 neighbourhood in registers.  Edge classes: per class one
-// 64-bit accumulator with four 16-bit fields (sum of d + 256 per category) and one 32-bit accumulator with four 8-bit counts, reduced over the
-// wave with DPP at the end -- one LDS atomic per wave and statistic.  Bands: runs of equal band index along the column are summed in registers and
-// flushed when the band changes.  o8: the source samples of the piece (fetched by the caller long before).
+// Statistics of one piece of a column of a CTB (ROWS rows from row ys of column x) with the 3 x 3 neighbourhood in registers.  Edge classes: four packed
+// accumulators (see inside), reduced over the wave with DPP at the end -- one LDS atomic per wave and statistic.  Bands: runs of equal band index along the
+// column are summed in registers and flushed when the band changes.  o8: the source samples of the piece (fetched by the caller long before).
 template <int ROWS>
 __device__ __forceinline__ void sao_stats_column(SaoLds &s, int c, const uint8_t *w, int pitch, int x, int ys, bool okh, int Y0, int ph, const int *o8, int tid)
 {
+  // the sign of a difference as med3(d, -1, 1); the edge index e = 2 + sign(c - a) + sign(c - b) is 0, 1 / 3, 4 for the categories 1, 2 / 3, 4 (2: none)
+  auto sgn = [](int d) { return d > 1 ? 1 : (d < -1 ? -1 : d); };
   const uint8_t *col = w + 4 + x - 1;                                   // column x - 1 of window row 0 (= sample row -1)
   int r0[3], r1[3], r2[3];
   for (int k = 0; k < 3; k++) { r0[k] = col[ys * pitch + k]; r1[k] = col[(ys + 1) * pitch + k]; }
-  uint64_t sacc[4] = {0, 0, 0, 0}; uint32_t cacc[4] = {0, 0, 0, 0};
+  // per class one 64-bit accumulator with four 16-bit fields, one per category: sum of (d + 256) + 2048 per sample -- the count rides above the sum
+  // (ROWS <= 4: sum <= 4 * 511 < 2048)
+  uint64_t acc[4] = {0, 0, 0, 0};
   int run_b = -1, run_n = 0, run_s = 0;
+  int s_up = sgn(r1[1] - r0[1]);                                        // sign(c - above) of the row to come
 #pragma unroll
   for (int j = 0; j < ROWS; j++) {
     const int y = ys + j;
     for (int k = 0; k < 3; k++) r2[k] = col[(y + 2) * pitch + k];
     const int v = r1[1], d = o8[j] - v, b = v >> 3;
     if (b != run_b) {
-      if (run_n) { atomicAdd(&s.bn[c][run_b], run_n); atomicAdd(&s.bs[c][run_b], run_s); }
+      if (run_n) { atomicAdd(&s.bn[c][run_b][tid & 15], run_n); atomicAdd(&s.bs[c][run_b][tid & 15], run_s); }
       run_b = b; run_n = 0; run_s = 0;
     }
     run_n++; run_s += d;
     const bool okv = Y0 + y - 1 >= 0 && Y0 + y + 1 < ph;
-    const int ka = okh ? sao_edge_idx(v, r1[0], r1[2]) : 0, kb = okv ? sao_edge_idx(v, r0[1], r2[1]) : 0;
-    const int kc = (okh && okv) ? sao_edge_idx(v, r0[0], r2[2]) : 0, kd = (okh && okv) ? sao_edge_idx(v, r0[2], r2[0]) : 0;
-    const int kk[4] = {ka, kb, kc, kd};
+    const int s_dn = sgn(v - r2[1]);
+    const int ea = okh ? 2 + sgn(v - r1[0]) + sgn(v - r1[2]) : 2, eb = okv ? 2 + s_up + s_dn : 2;
+    const int ec = (okh && okv) ? 2 + sgn(v - r0[0]) + sgn(v - r2[2]) : 2, ed = (okh && okv) ? 2 + sgn(v - r0[2]) + sgn(v - r2[0]) : 2;
+    const int ee[4] = {ea, eb, ec, ed};
+    const uint32_t val = (uint32_t)(d + 256 + 2048);
 #pragma unroll
-    for (int e = 0; e < 4; e++) if (kk[e]) { sacc[e] += (uint64_t)(uint32_t)(d + 256) << (16 * (kk[e] - 1)); cacc[e] += 1u << (8 * (kk[e] - 1)); }
+    for (int e = 0; e < 4; e++) acc[e] += (uint64_t)(ee[e] == 2 ? 0u : val) << (16 * (ee[e] - (ee[e] > 2)));
+    s_up = -s_dn;                                                       // the next row's sign(c - above)
     for (int k = 0; k < 3; k++) { r0[k] = r1[k]; r1[k] = r2[k]; }
   }
-  if (run_n) { atomicAdd(&s.bn[c][run_b], run_n); atomicAdd(&s.bs[c][run_b], run_s); }
+  if (run_n) { atomicAdd(&s.bn[c][run_b][tid & 15], run_n); atomicAdd(&s.bs[c][run_b][tid & 15], run_s); }
 #pragma unroll
   for (int e = 0; e < 4; e++)
 #pragma unroll
     for (int k = 1; k <= 4; k++) {
       // one reduction for both: the wave's count (<= 64 * ROWS) above bit 20, its biased sum (<= 64 * ROWS * 511) below
-      const uint32_t cnt = (cacc[e] >> (8 * (k - 1))) & 0xffu, sum = (uint32_t)(sacc[e] >> (16 * (k - 1))) & 0xffffu;
+      const uint32_t fld = (uint32_t)(acc[e] >> (16 * (k - 1))) & 0xffffu, cnt = fld >> 11, sum = fld & 2047u;
       const uint32_t r = wave_sum_u32((cnt << 20) | sum), N = r >> 20, S = r & 0xfffffu;
       if ((tid & 63) == 0) { atomicAdd(&s.en[c][e][k], (int)N); atomicAdd(&s.es[c][e][k], (int)S - 256 * (int)N); }
     }
@@ -1998,7 +2005,10 @@ __global__ __launch_bounds__(KVZ_SAO_THREADS) void k_sao(EncFrame f)
       o = k <= 2 ? clip3(0, 7, o) : clip3(-7, 0, o);
       s.eo_off[c][e][k - 1] = o; s.eo_dist[c][e][k - 1] = N * o * o - 2 * o * S;
     } else if (tid >= 64 && tid < 160) {                  // band offsets: component x band
-      const int c = (tid - 64) >> 5, b = (tid - 64) & 31, N = s.bn[c][b], S = s.bs[c][b];
+      const int c = (tid - 64) >> 5, b = (tid - 64) & 31;
+      int N = 0, S = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) { N += s.bn[c][b][k]; S += s.bs[c][b][k]; }
       const int o = clip3(-7, 7, sao_rdiv(S, N));
       s.bo_off[c][b] = o; s.bo_gain[c][b] = N * o * o - 2 * o * S;
     }

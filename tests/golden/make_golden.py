@@ -23,12 +23,20 @@ CASES = [
     dict(w=320, h=256, qp=27, period=4, me_range=8, kind=0, seed=0x5EED0009, wpp=1, deblock=1, frames=5, tile_rows=2, subme=2),
     dict(w=448, h=320, qp=30, period=4, me_range=8, kind=0, seed=0x5EED000A, wpp=1, deblock=1, frames=5, tile_rows=2, tile_cols=2, slices=2, sao=1),
     dict(w=320, h=256, qp=30, period=64, me_range=8, kind=0, seed=0x5EED000B, wpp=1, deblock=1, frames=4, slices=1),
+    # round 4: uvgComm's "lossless" and "scaling list" boxes (kvazaarfilter.cpp:235-244)
+    dict(w=320, h=240, qp=32, period=64, me_range=8, kind=0, seed=0x5EED000C, wpp=1, deblock=1, frames=4, subme=2, lossless=1),
+    dict(w=192, h=128, qp=27, period=1, me_range=8, kind=2, seed=0x5EED000D, wpp=1, deblock=1, frames=2, tile_rows=2, lossless=1),
+    dict(w=320, h=240, qp=30, period=64, me_range=8, kind=0, seed=0x5EED000E, wpp=1, deblock=1, frames=4, sao=1, scaling_list=1),
 ]
 
 out = {"generator": "tests/golden/make_golden.py", "source": "oracle/ (CPU checker)", "cases": []}
 for c in CASES:
     e = orc.OracleEncoder(c["w"], c["h"], qp=c["qp"], period=c["period"], me_range=c["me_range"], wpp=c["wpp"], deblock=c["deblock"],
                            tile_rows=c.get("tile_rows", 1), sao=c.get("sao", 0), subme=c.get("subme", 0), tile_cols=c.get("tile_cols", 1), slices=c.get("slices", 0))
+    if c.get("scaling_list"):
+        e.set_option("scaling-list", 1)
+    if c.get("lossless"):
+        e.set_option("lossless", 1)
     frames = []
     for t in range(c["frames"]):
         au = e.encode(orc.synth_frame(c["kind"], c["seed"], c["w"], c["h"], t))

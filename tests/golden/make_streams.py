@@ -26,28 +26,37 @@ HIP = {   # name: kvz_api options (all with hash=md5)
     "hip_scenecut_slow_qp30": (("qp", 30), ("period", 8), ("me-range", 16), ("preset", "slow")),
     # round 4: uvgComm's "scaling list" checkbox (kvazaarfilter.cpp:235-242): scaling_list_enabled_flag with the default lists
     "hip_scaling_list_default_qp30": (("qp", 30), ("period", 8), ("me-range", 16), ("scaling-list", "default"), ("subme", 2)),
+    # ... and its "lossless" checkbox (:244): cu_transquant_bypass_flag everywhere; a smaller, shorter clip -- lossless pictures are large
+    "hip_lossless": (("qp", 32), ("period", 8), ("me-range", 16), ("lossless", 1), ("subme", 2)),
 }
+SHAPE = {"hip_lossless": (192, 128, 4)}      # (width, height, pictures) where not W, H, N
 index = {}
-if "--no-hip" in sys.argv and os.path.exists(os.path.join(out, "index.json")):
+only = [a[len("--only="):] for a in sys.argv if a.startswith("--only=")]      # --only=<name>: just these streams of the HIP encoder (the others, and the synthesiser's, stay)
+if (only or "--no-hip" in sys.argv) and os.path.exists(os.path.join(out, "index.json")):
     index = json.load(open(os.path.join(out, "index.json")))      # (CPU only: the HIP encoder's streams stay as they are)
 if "--no-hip" not in sys.argv:
     from kvazzup_amd import synth
     from kvazzup_amd.codec import Encoder
     for name, opts in HIP.items():
         br = dict(opts).get("bitrate", 0)
-        e = Encoder(W, H, options=opts, fields={"hash": 2, "target_bitrate": br})
+        w_, h_, n_ = SHAPE.get(name, (W, H, N))
+        if only and name not in only:
+            continue
+        e = Encoder(w_, h_, options=opts, fields={"hash": 2, "target_bitrate": br})
         assert not e.rejected, (name, e.rejected)
         od = orc.OracleDecoder()
         stream, md5s = b"", []
-        for t in range(N):
-            au, rec = e.encode(synth.scene_cut_frame(SEED, W, H, t, 4) if "scenecut" in name else orc.synth_frame(0, SEED, W, H, t))
+        for t in range(n_):
+            src = synth.scene_cut_frame(SEED, w_, h_, t, 4) if "scenecut" in name else orc.synth_frame(0, SEED, w_, h_, t)
+            au, rec = e.encode(src)
+            assert not dict(opts).get("lossless") or np.array_equal(rec, src), (name, t)
             fr = od.decode_au(au, t)
             assert len(fr) == 1 and np.array_equal(fr[0]["i420"], rec), (name, t)      # the checker decodes it to the encoder's reconstruction
             stream += au; md5s.append(hashlib.md5(rec.tobytes()).hexdigest())
-        assert od.hash_stats() == (N, 0), (name, od.hash_stats())                      # ... and finds every hash SEI correct
+        assert od.hash_stats() == (n_, 0), (name, od.hash_stats())                      # ... and finds every hash SEI correct
         e.close(); od.close()
         open(os.path.join(out, name + ".hevc"), "wb").write(stream)
-        index[name] = {"width": W, "height": H, "pictures": N, "bytes": len(stream), "hash_sei": "md5", "source": "HIP encoder (kvz_api), options %s" % dict(opts),
+        index[name] = {"width": w_, "height": h_, "pictures": n_, "bytes": len(stream), "hash_sei": "md5", "source": "HIP encoder (kvz_api), options %s" % dict(opts),
                        "frame_md5": md5s}
 # the synthesiser (CPU): a Kvazaar-shaped stream (lp-g4d3t1-like references, intra CUs in P pictures) and one with every tool switched on
 GEN = {
@@ -70,7 +79,7 @@ GEN = {
     "gen_b_gop8": dict(seed=36, density=25, intra_period=16, num_refs=4, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                        qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=70, gop=8),
 }
-for name, cfg in GEN.items():
+for name, cfg in ({} if only else GEN).items():
     g = orc.OracleGen(W, H, **cfg)
     od = orc.OracleDecoder()
     stream, md5s = b"", []

@@ -21,7 +21,8 @@ def test_golden_streams(gpu):
         c = case["config"]
         ge = Encoder(c["w"], c["h"], options=(("qp", c["qp"]), ("period", c["period"]), ("me-range", c["me_range"]), ("wpp", c["wpp"]), ("deblock", c["deblock"]),
                                             ("tiles", "%dx%d" % (c.get("tile_cols", 1), c.get("tile_rows", 1))), ("sao", "full" if c.get("sao") else "off"), ("subme", c.get("subme", 0)),
-                                            ("slices", ("none", "wpp", "tiles")[c.get("slices", 0)])))
+                                            ("slices", ("none", "wpp", "tiles")[c.get("slices", 0)]))
+                                            + ((("lossless", 1),) if c.get("lossless") else ()) + ((("scaling-list", "default"),) if c.get("scaling_list") else ()))
         gd = Decoder()
         for t, want in enumerate(case["frames"]):
             au, rec = ge.encode(synth.frame(c["kind"], c["seed"], c["w"], c["h"], t))

@@ -116,6 +116,10 @@ def test_golden_fixture():
         c = case["config"]
         e = orc.OracleEncoder(c["w"], c["h"], qp=c["qp"], period=c["period"], me_range=c["me_range"], wpp=c["wpp"], deblock=c["deblock"],
                                 tile_rows=c.get("tile_rows", 1), sao=c.get("sao", 0), subme=c.get("subme", 0), tile_cols=c.get("tile_cols", 1), slices=c.get("slices", 0))
+        if c.get("scaling_list"):
+            e.set_option("scaling-list", 1)
+        if c.get("lossless"):
+            e.set_option("lossless", 1)
         for t, want in enumerate(case["frames"]):
             au = e.encode(orc.synth_frame(c["kind"], c["seed"], c["w"], c["h"], t))
             assert hashlib.md5(au).hexdigest() == want["au_md5"], (c, t)

@@ -19,6 +19,23 @@ __global__ void reader(const uint4 *p, size_t n, unsigned *out)
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a += p[i].x;
   if (a == 0x12345678u) *out = a;
 }
+// the writer that says "done" by itself: every workgroup releases its stores (agent scope) and counts itself; the last one stores the flag (system scope) --
+// no packet between this kernel and the stream's next one
+__global__ void writer_flag(uint4 *p, size_t n, unsigned v, unsigned *count, uint32_t *flag, unsigned value)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    typedef unsigned v4 __attribute__((ext_vector_type(4)));
+    v4 x = {v, v + 1, v + 2, (unsigned)i};
+    *(v4 *)&p[i] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // (no fence per workgroup: on gfx950 an agent-scope release writes the XCD's whole L2 back -- 2048 of them made this kernel 54 us; what the waiter reads
+    // must leave with write-through stores instead, or be final before this kernel started)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (__hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) { __hip_atomic_store(count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+  }
+}
 __global__ void tiny(unsigned *out) { if (threadIdx.x == 9999) *out = 1; }
 int main()
 {
@@ -28,22 +45,27 @@ int main()
   hipEvent_t ev; hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence);
   const int N = 300;
   uint32_t *flag = nullptr; if (hipExtMallocWithFlags((void **)&flag, 8, hipMallocSignalMemory) != hipSuccess) { printf("no signal memory\n"); hipMalloc((void **)&flag, 8); } hipMemset(flag, 0, 8);
-  const char *names[8] = {"no record", "record, nobody waits", "record + another stream waiting behind it", "hipExtLaunchKernelGGL stop event + waiter", "record with default flags + waiter", "record, waiter enqueued one iteration later", "hipStreamWriteValue32 + hipStreamWaitValue32 on another stream", "hipStreamWriteValue32, nobody waits"};
+  const char *names[13] = {"no record", "record, nobody waits", "record + another stream waiting behind it", "hipExtLaunchKernelGGL stop event + waiter", "record with default flags + waiter", "record, waiter enqueued one iteration later", "hipStreamWriteValue32 + hipStreamWaitValue32 on another stream", "hipStreamWriteValue32, nobody waits", "flag stored by the writer's last workgroup + hipStreamWaitValue32 on another stream", "flag stored by the writer's last workgroup, nobody waits", "512 workgroups: no record", "512 workgroups: record + waiter", "512 workgroups: flag by the last workgroup + hipStreamWaitValue32"};
+  unsigned *count; hipMalloc(&count, 4); hipMemset(count, 0, 4);
   hipEvent_t evd; hipEventCreateWithFlags(&evd, hipEventDisableTiming);
   hipEvent_t ring[4]; for (auto &e : ring) hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence);
-  for (int mode = 0; mode < 8; mode++) {
+  for (int mode = 0; mode < 13; mode++) {
     hipDeviceSynchronize();
     auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < N; i++) {
-      if (mode == 3) hipExtLaunchKernelGGL(writer<false>, dim3(2048), dim3(256), 0, b, nullptr, ev, 0, p, n, (unsigned)i);
+      if (mode == 10 || mode == 11) hipLaunchKernelGGL(writer<false>, dim3(512), dim3(256), 0, b, p, n, (unsigned)i);
+      else if (mode == 12) hipLaunchKernelGGL(writer_flag, dim3(512), dim3(256), 0, b, p, n, (unsigned)i, count, flag, 1000u * mode + (unsigned)i + 1u);
+      else if (mode >= 8) hipLaunchKernelGGL(writer_flag, dim3(2048), dim3(256), 0, b, p, n, (unsigned)i, count, flag, 1000u * mode + (unsigned)i + 1u);
+      else if (mode == 3) hipExtLaunchKernelGGL(writer<false>, dim3(2048), dim3(256), 0, b, nullptr, ev, 0, p, n, (unsigned)i);
       else hipLaunchKernelGGL(writer<false>, dim3(2048), dim3(256), 0, b, p, n, (unsigned)i);
-      if (mode == 1 || mode == 2) hipEventRecord(ev, b);
+      if (mode == 1 || mode == 2 || mode == 11) hipEventRecord(ev, b);
       if (mode == 4) hipEventRecord(evd, b);
       if (mode == 5) hipEventRecord(ring[i & 3], b);
-      if (mode == 2 || mode == 3) { hipStreamWaitEvent(c, ev, 0); hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, c, out); }
+      if (mode == 2 || mode == 3 || mode == 11) { hipStreamWaitEvent(c, ev, 0); hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, c, out); }
       if (mode == 4) { hipStreamWaitEvent(c, evd, 0); hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, c, out); }
       if (mode == 5 && i) { hipStreamWaitEvent(c, ring[(i - 1) & 3], 0); hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, c, out); }
-      if (mode >= 6) { if (hipStreamWriteValue32(b, flag, 1000u * mode + (unsigned)i + 1u, 0) != hipSuccess) { printf("write value failed\n"); return 1; } }
+      if (mode == 8 || mode == 12) { if (hipStreamWaitValue32(c, flag, 1000u * mode + (unsigned)i + 1u, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) { printf("wait value failed\n"); return 1; } hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, c, out); }
+      if (mode == 6 || mode == 7) { if (hipStreamWriteValue32(b, flag, 1000u * mode + (unsigned)i + 1u, 0) != hipSuccess) { printf("write value failed\n"); return 1; } }
       if (mode == 6) { if (hipStreamWaitValue32(c, flag, 1000u * mode + (unsigned)i + 1u, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) { printf("wait value failed\n"); return 1; } hipLaunchKernelGGL(tiny, dim3(1), dim3(64), 0, c, out); }
       hipLaunchKernelGGL(reader, dim3(2048), dim3(256), 0, b, p, n, out);
     }

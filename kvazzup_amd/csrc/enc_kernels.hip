@@ -1636,6 +1636,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) vo
   unsigned long long *census = f.trace ? f.trace + (size_t)wc * hc * 40 + (size_t)ctu * 16 + (f.is_intra ? 6 : 0) : nullptr;
   const unsigned long long t_begin = census ? wall_clock64() : 0;
   int wave_class = 1;
+  // phases of a luma wave that codes ONE coding unit with residual (tools/tok_phases.py; a build with EXTRA=-DKVZ_TOK_PHASES -- nine time stamps
+  // held in registers cost the kernel 88 scalar spills): ticks per phase summed per CTU, slot 15 counts the waves
+#ifdef KVZ_TOK_PHASES
+  unsigned long long *ph = (f.trace && comp == 0 && !f.is_intra) ? f.trace + (size_t)wc * hc * 56 + (size_t)ctu * 16 : nullptr;
+  unsigned long long ph_t[9]; int ph_n = 0;
+#define TOK_PH() do { if (ph && ph_n < 9) ph_t[ph_n++] = wall_clock64(); } while (0)
+#define TOK_PH_SYNC() wave_sync()
+#else
+#define TOK_PH() do { } while (0)
+#define TOK_PH_SYNC() do { } while (0)
+#endif
+  TOK_PH();
   auto mine = [&](int piece) { return ALLC || ((piece == 16 || (piece & 3) == 3) ? 0 : (piece & 3)) == comp; };   // table entries this wave writes
   if (!(comp == 0 && z4 == 15)) {
     const int g0 = (uy * 2) * f.b8w + ux * 2, l0 = f.cu_log2[g0];
@@ -1651,6 +1663,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) vo
       return;
     }
   }
+  TOK_PH();                                                        // 1: the unit has something to say
   core_tabs_fill_entry(tabs, lane);
   if (lane < TOK_PIECES) { seg[lane][0] = 0; seg[lane][1] = 0; }
   if (lane == 0) hdr_n = 0;
@@ -1667,6 +1680,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) vo
     tile[lane] = r;
   }
   wave_sync();
+  TOK_PH();                                                        // 2: tables and the 3 x 3 records in LDS
   uint16_t *slot = f.tok_buf + (size_t)ctu * f.tok_cap;
   int np = 0;                                          // piece being produced (wave-uniform): CU k, component c -> 4k + c; 16 = terminators
   // reserve `total` tokens of the CTU's slot for piece np; all lanes get the offset (or ~0u when the slot is full)
@@ -1701,6 +1715,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) vo
       if (f.ctu_qy && !(cu.flags & CU_SKIP) && cu.cbf && z == f.ctu_first[ctu]) enc_cu_qp_delta(t, f.ctu_delta[ctu]);
       hdr_n = t.n;
     }
+    TOK_PH_SYNC(); TOK_PH();                                       // 3: lane 0 has the header bins
     const int cbf = (cu.flags & CU_SKIP) ? 0 : cu.cbf;          // wave-uniform
     for (int ci = ALLC ? 0 : comp; ci < (ALLC ? 3 : comp + 1); ci++) {   // the CU's transform blocks: luma, Cb, Cr (ALLC) or this wave's component
       np = 4 * k + ci;
@@ -1710,6 +1725,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) vo
         const int px = ci ? (x0 >> 1) : x0, py = ci ? (y0 >> 1) : y0;
         const int scan = intra_scan_idx(cu.intra, l2, ci, cu.intra_mode);
         digest_build_wave(&tabs, dg, f.coef[ci] + py * pw + px, pw, l2, scan, lane);   // ends with a barrier
+        TOK_PH();                                                  // 4: digest
         const uint64_t sbm = dg.sbmask;
         const int last_sb = 63 - __builtin_clzll(sbm);
         const int last_pos = 31 - __builtin_clz((uint32_t)dg.mask[last_sb]);
@@ -1742,7 +1758,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) vo
         wave_sync();                                              // hdr_n of lane 0 visible
         const int hn = hdr_n > TOK_HDR_CAP ? TOK_HDR_CAP : hdr_n, total = hn + body;
         if (hdr_n > TOK_HDR_CAP && lane == 0) atomicOr(f.err, 8u);
+        TOK_PH();                                                  // 5: last position, greater1 carry, count pass, offsets
         const uint32_t o = reserve(total);
+        TOK_PH();                                                  // 6: place reserved
         if (o != ~0u) {
           const bool staged = total <= TOK_ARENA;
           uint16_t *dst = staged ? arena : slot + o;
@@ -1757,6 +1775,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) vo
           }
         }
         wave_sync();
+        TOK_PH();                                                  // 7: tokens written
         if (lane == 0) hdr_n = 0;
       }
       wave_sync();
@@ -1789,6 +1808,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) vo
     uint32_t *e = f.tok_seg + ((size_t)(ctu * 16 + z4) * TOK_PIECES + lane) * 2;
     e[0] = seg[lane][0]; e[1] = seg[lane][1];
   }
+  TOK_PH();                                                        // 8: table entries out
+#ifdef KVZ_TOK_PHASES
+  if (ph && lane == 0 && ph_n == 9 && ncu == 1 && wave_class == 2) { for (int k = 0; k < 8; k++) atomicAdd(&ph[k], ph_t[k + 1] - ph_t[k]); atomicAdd(&ph[15], 1ull); }
+#endif
+#undef TOK_PH
+#undef TOK_PH_SYNC
   if (tr && z4 == 15) tr[7] = wall_clock64();
   if (census && lane == 0) { atomicAdd(&census[wave_class * 2], 1ull); atomicAdd(&census[wave_class * 2 + 1], wall_clock64() - t_begin); }
 }

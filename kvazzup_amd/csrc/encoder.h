@@ -208,10 +208,18 @@ class Encoder {
     int poc = 0, rec_idx = 0, set = 0, qp = 0; bool intra = false, write_ps = false; long pic_idx = 0;
     std::vector<EvPair> ev; size_t ev_used = 0;
     EncodedPicture result; bool ready = false, ok = true;   // owf >= 2: filled by the background thread
+    EncFrame f_tok{}; bool prof = false;                    // tok_deferred_: what the tokenizer's launches need, kept until the launcher thread makes them
   };
   Slot slot_[kMaxDepth + 2]; Slot *cur_slot_ = nullptr; int nslots_ = 1, depth_ = 0;
   size_t stage_cap_ = 0, out_cap_ = 0;
   std::thread bg_[2]; std::mutex bm_; std::condition_variable bcv_; std::deque<int> bq_; bool bquit_ = false;
+  // SAO (owf 2..7): the tokenizer of a picture needs the filter's parameters, i.e. the END of the picture's chain.  An event on the main stream that another
+  // stream is already waiting for costs the stream's next kernel -- the next picture's k_me -- 12-25 us; one that only the host looks at costs 1-2 us
+  // (tools/measure/record_after_writer.hip).  So a thread of its own watches the chains' events and launches a picture's tokenizer when its chain is done.
+  bool tok_deferred_ = false; std::thread tok_thread_; std::mutex tm_; std::condition_variable tcv_; std::deque<int> tq_; bool tquit_ = false;
+  void tok_launcher();
+  bool launch_tokenizer(Slot &sl, const EncFrame &f, bool intra, bool wait_on_stream, bool prof);
+  void timed_slot(Slot &sl, bool prof, KernelId id, hipStream_t st, const std::function<void()> &launch);
   std::mutex stat_m_;
   long submitted_ = 0, collected_ = 0, accepted_ = 0;    // pictures whose kernels have been queued / whose access unit has been returned / taken from the caller
   // owf >= 2: the output lags anyway, so the calling thread (uvgComm's encoder filter thread) only hands the picture over; a submitter thread makes the

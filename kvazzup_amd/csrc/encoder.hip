@@ -228,6 +228,8 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   sp_.deblock = cfg.deblock; sp_.fps_num = cfg.fps_num; sp_.fps_den = cfg.fps_den;
   HIP_OK(hipStreamSynchronize(stream_));
   HIP_OK(hipDeviceSynchronize());
+  tok_deferred_ = depth_ >= 2 && cfg.sao && !cfg.entropy_gpu && cfg.band_rows == 0 && cfg.owf <= kSets - 1 && !getenv("KVAZZUP_AMD_TOK_INLINE");
+  if (tok_deferred_) tok_thread_ = std::thread([this] { name_this_thread("kvzx-enc-tok"); tok_launcher(); });
   if (depth_ >= 2) { bg_[0] = std::thread([this] { name_this_thread("kvzx-enc-bg0"); background(0); }); if (entropy2_) bg_[1] = std::thread([this] { name_this_thread("kvzx-enc-bg1"); background(1); }); }
   if (depth_ >= 2 && cfg.band_rows == 0 && !getenv("KVAZZUP_AMD_SYNC_SUBMIT")) sub_thread_ = std::thread([this] { name_this_thread("kvzx-enc-sub"); submitter(); });
   return true;
@@ -253,6 +255,9 @@ Encoder::~Encoder()
   { std::lock_guard<std::mutex> l(sm_); squit_ = true; }
   scv_.notify_all();
   if (sub_thread_.joinable()) sub_thread_.join();
+  { std::lock_guard<std::mutex> l(tm_); tquit_ = true; }
+  tcv_.notify_all();
+  if (tok_thread_.joinable()) tok_thread_.join();           // (what it still had queued has gone to the workers)
   { std::lock_guard<std::mutex> l(bm_); bquit_ = true; }
   bcv_.notify_all();
   for (auto &t : bg_) if (t.joinable()) t.join();
@@ -297,10 +302,10 @@ Encoder::~Encoder()
   stream_release(stream_, cfg_.device, 'M', prio_[0]);
 }
 
-void Encoder::timed(KernelId id, hipStream_t st, const std::function<void()> &launch)
+void Encoder::timed(KernelId id, hipStream_t st, const std::function<void()> &launch) { timed_slot(*cur_slot_, prof_now_, id, st, launch); }
+void Encoder::timed_slot(Slot &sl, bool prof, KernelId id, hipStream_t st, const std::function<void()> &launch)
 {
-  if (!prof_now_) { launch(); return; }
-  Slot &sl = *cur_slot_;
+  if (!prof) { launch(); return; }
   if (sl.ev_used == sl.ev.size()) {
     EvPair p; hipEventCreate(&p.a); hipEventCreate(&p.b); p.id = id; sl.ev.push_back(p);
   }
@@ -623,13 +628,13 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   // Input padding and intra analysis of the next picture with this set (input stream) overwrite both and wait for this event.
   HIP_CHECK(hipEventRecord(ev_src_free_[set_], ms)); src_busy_[set_] = true;
   if (side) { HIP_CHECK(hipEventRecord(ev_idr_done_, ms)); idr_pending_ = true; }
-  HIP_CHECK(hipStreamWaitEvent(stream_tok_, cfg_.sao ? ev_src_free_[set_] : ev_signalled_, 0));
-  if (!intra) timed(K_INTER_SIGNAL, stream_tok_, [&] { launch_inter_signal(f, stream_tok_); });
-  timed(K_TOKENIZE, stream_tok_, [&] { launch_tokenize(f, stream_tok_); });
-  timed(K_TOK_COMPACT, stream_tok_, [&] { launch_tok_compact(f, stream_tok_); });
-  HIP_CHECK(hipEventRecord(ev_tok_done_[set_], stream_tok_)); tok_pending_[set_] = true;
+  sl.set = set_;
+  if (tok_deferred_) { sl.f_tok = f; sl.prof = prof_now_; }          // (encoder.h tok_deferred_: the launcher thread makes these launches when the chain is done)
+  else if (!launch_tokenizer(sl, f, intra, true, prof_now_)) return false;
+  tok_pending_[set_] = true;
   // the slot is complete when both streams are: the tokens (stream_tok_) and the reconstruction (stream_)
-  if (cfg_.entropy_gpu) {
+  if (tok_deferred_) { }
+  else if (cfg_.entropy_gpu) {
     // arithmetic coding on the slot's own stream, behind the compaction: the coders of several pictures run side by side
     HIP_CHECK(hipEventRecord(sl.tok_ev, stream_tok_));
     HIP_CHECK(hipStreamWaitEvent(sl.ent_stream, sl.tok_ev, 0));
@@ -654,11 +659,44 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   frame_idx_++;
   ref_idx_ = cur_idx_; cur_idx_ = (cur_idx_ + 1) % nrec_;      // rec_[ref_idx_] holds the picture just submitted
   submitted_++;
-  if (depth_ >= 2) {
+  if (tok_deferred_) {
+    { std::lock_guard<std::mutex> l(bm_); sl.ready = false; }
+    { std::lock_guard<std::mutex> l(tm_); tq_.push_back((int)((submitted_ - 1) % nslots_)); }
+    tcv_.notify_all();
+  } else if (depth_ >= 2) {
     { std::lock_guard<std::mutex> l(bm_); sl.ready = false; bq_.push_back((int)((submitted_ - 1) % nslots_)); }
     bcv_.notify_all();
   }
   return true;
+}
+
+// the tokenizer's three launches of one picture (stream_tok_) and the events behind them
+bool Encoder::launch_tokenizer(Slot &sl, const EncFrame &f, bool intra, bool wait_on_stream, bool prof)
+{
+  if (wait_on_stream) HIP_CHECK(hipStreamWaitEvent(stream_tok_, cfg_.sao ? ev_src_free_[sl.set] : ev_signalled_, 0));
+  if (!intra) timed_slot(sl, prof, K_INTER_SIGNAL, stream_tok_, [&] { launch_inter_signal(f, stream_tok_); });
+  timed_slot(sl, prof, K_TOKENIZE, stream_tok_, [&] { launch_tokenize(f, stream_tok_); });
+  timed_slot(sl, prof, K_TOK_COMPACT, stream_tok_, [&] { launch_tok_compact(f, stream_tok_); });
+  HIP_CHECK(hipEventRecord(ev_tok_done_[sl.set], stream_tok_));
+  if (tok_deferred_) HIP_CHECK(hipEventRecord(sl.done, stream_tok_));
+  return true;
+}
+
+// encoder.h tok_deferred_: pictures in submission order -- wait (on the host, in naps) for the picture's chain, launch its tokenizer, hand the slot to the workers
+void Encoder::tok_launcher()
+{
+  hipSetDevice(cfg_.device);
+  for (;;) {
+    int idx;
+    { std::unique_lock<std::mutex> l(tm_); tcv_.wait(l, [&] { return tquit_ || !tq_.empty(); }); if (tq_.empty()) return; idx = tq_.front(); tq_.pop_front(); }
+    Slot &sl = slot_[idx];
+    hipEvent_t e = ev_src_free_[sl.set];                   // recorded behind the chain's last kernel (k_sao); not recorded again before this picture has been collected (owf < kSets)
+    nap_until([&] { hipError_t r = hipEventQuery(e); return r == hipSuccess ? 1 : (r == hipErrorNotReady ? 0 : -1); });
+    tl("tok0", sl.pic_idx);
+    if (!launch_tokenizer(sl, sl.f_tok, sl.intra, false, sl.prof)) fprintf(stderr, "kvazzup_amd: the tokenizer of picture %ld could not be launched\n", sl.pic_idx);
+    { std::lock_guard<std::mutex> l(bm_); bq_.push_back(idx); }
+    bcv_.notify_all();
+  }
 }
 
 bool Encoder::collect(EncodedPicture *out)

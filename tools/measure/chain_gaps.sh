@@ -34,14 +34,15 @@ print("window %.2f ms, %d kernels" % ((t1 - t0) / 1e6, len(rows)))
 byq = collections.defaultdict(list)
 for r in rows: byq[r[3]].append(r)
 for q, rs in sorted(byq.items(), key=lambda kv: -len(kv[1])):
-    st = collections.defaultdict(lambda: [0, 0, 0, 0])
+    st = collections.defaultdict(lambda: [0, 0, 0, 0, []])
     busy = 0
     for i, (s, e, n, _) in enumerate(rs):
         a = st[n]; a[0] += 1; a[1] += e - s; busy += e - s
-        if i: g = s - rs[i - 1][1]; a[2] += max(0, g); a[3] += 1
+        if i: g = s - rs[i - 1][1]; a[2] += max(0, g); a[3] += 1; a[4].append(max(0, g))
     print("queue %s: %d kernels, busy %.1f %% of the window" % (q, len(rs), 100.0 * busy / (t1 - t0)))
     for n, a in sorted(st.items(), key=lambda kv: -kv[1][1]):
-        print("   %-36s n %5d  avg %8.1f us  gap in front %7.1f us" % (n, a[0], a[1] / a[0] / 1e3, a[2] / max(1, a[3]) / 1e3))
+        gs = sorted(a[4]) or [0]
+        print("   %-36s n %5d  avg %8.1f us  gap in front %7.1f us (median %.1f, 90 %% %.1f, max %.1f)" % (n, a[0], a[1] / a[0] / 1e3, a[2] / max(1, a[3]) / 1e3, gs[len(gs) // 2] / 1e3, gs[len(gs) * 9 // 10] / 1e3, gs[-1] / 1e3))
 # a 1 ms excerpt from the last quarter of the window as a timeline (all queues and the copies) -- or, CHAIN_GAPS_AT_IDR=1, from 0.4 ms before the window's second intra picture's chain
 import os
 mid = t0 + (t1 - t0) * 3 // 4

@@ -352,6 +352,32 @@ def test_sao_matches_oracle(gpu, cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("owf,bitrate", [(2, 600000), (4, 600000), (7, 600000), (7, 0), (8, 0), (12, 0)])
+def test_sao_pipelined_at_every_depth_matches_oracle(gpu, owf, bitrate):
+    """SAO with pictures in flight: owf 2..7 start a picture's tokenizer from the launcher thread once its chain is done (encoder.h tok_deferred_), deeper
+    pipelines queue it behind the chain's event; intra pictures every 5 (the side stream), a bit rate (the row groups), 20 pictures so that every set and slot
+    is used more than once (with a bit rate at most six pictures are in flight, without one as many as owf says) -- access units and reconstructions against
+    the checker, in order"""
+    from kvazzup_amd.codec import Encoder
+    w, h, frames = 448, 320, 20
+    oe = orc.OracleEncoder(w, h, qp=30, period=5, me_range=8, sao=1, subme=2, bitrate=bitrate)
+    if bitrate and owf >= 3:
+        oe.set_option("rc-delay", min(owf, 6) + 1)
+    ge = Encoder(w, h, options=(("qp", 30), ("period", 5), ("me-range", 8), ("sao", "full"), ("subme", 2), ("owf", owf)), fields={"target_bitrate": bitrate})
+    got = []
+    for t in range(frames + owf):
+        out = ge.encode(orc.synth_frame(0, SEED, w, h, t) if t < frames else None)
+        if out[0] is not None:
+            got.append(out)
+    assert len(got) == frames
+    for t in range(frames):
+        want = oe.encode(orc.synth_frame(0, SEED, w, h, t))
+        assert got[t][0] == want, (owf, t, len(got[t][0]), len(want))
+        assert np.array_equal(got[t][1], oe.recon()), (owf, t)
+    ge.close(); oe.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("KVZ_SWEEP_SEEDS", "16")))))
 def test_random_tool_combinations_match_oracle(gpu, seed):
     """a seeded sweep over tool combinations (size, QP, period, range, WPP, tile rows, SAO, deblocking, delta-QP map, output

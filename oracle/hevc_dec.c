@@ -387,6 +387,19 @@ static void mc_pu(orc_decoder *d, int xp, int yp, int w, int h, const orc_mvinfo
     if (r1) { if (ci) orc_mc_chroma(r1->plane[ci], r1->stride[ci], r1->w / 2, r1->h / 2, X, Y, W, H, m->mv1[0], m->mv1[1], t1, 64);
               else orc_mc_luma(r1->plane[0], r1->stride[0], r1->w, r1->h, X, Y, W, H, m->mv1[0], m->mv1[1], t1, 64); }
     pixel *dst = pic->plane[ci] + Y * pic->stride[ci] + X;
+    if (d->sh.weighted) {
+      /* explicit weighted sample prediction (8.5.3.3.4.3) on the 14-bit arrays; shift1 = 14 - bitDepth = 6 */
+      const int c = ci, log2wd = d->sh.wp_log2wd[ci ? 1 : 0] + 6;
+      const int w0 = r0 ? d->sh.wp_w[0][m->ref_idx][c] : 0, o0 = r0 ? d->sh.wp_o[0][m->ref_idx][c] : 0;
+      const int w1 = r1 ? d->sh.wp_w[1][m->ref_idx1][c] : 0, o1 = r1 ? d->sh.wp_o[1][m->ref_idx1][c] : 0;
+      for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+        int v;
+        if (r0 && r1) v = (t0[y * 64 + x] * w0 + t1[y * 64 + x] * w1 + ((o0 + o1 + 1) << log2wd)) >> (log2wd + 1);
+        else if (r0) v = ((t0[y * 64 + x] * w0 + (1 << (log2wd - 1))) >> log2wd) + o0;
+        else v = ((t1[y * 64 + x] * w1 + (1 << (log2wd - 1))) >> log2wd) + o1;
+        dst[y * pic->stride[ci] + x] = (pixel)(v < 0 ? 0 : (v > 255 ? 255 : v));
+      }
+    } else
     if (r0 && r1) orc_pred_bi(t0, t1, 64, dst, pic->stride[ci], W, H);
     else orc_pred_uni(r0 ? t0 : t1, 64, dst, pic->stride[ci], W, H);
   }

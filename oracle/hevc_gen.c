@@ -125,6 +125,7 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   if (c->tq_bypass < 0) c->tq_bypass = 0;
   if (c->scaling_lists < 0 || c->scaling_lists > 4) c->scaling_lists = 0;
   if (c->b_slices < 0) c->b_slices = 0;
+  if (c->weighted < 0) c->weighted = 0;
   if (c->gop != 2 && c->gop != 4 && c->gop != 8) c->gop = 0;
   const int wc = (cfg->width + 63) / 64, hc = (cfg->height + 63) / 64;
   if (c->tile_rows > hc) c->tile_rows = hc;
@@ -160,6 +161,7 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   p->num_ref_idx_l0_default = rrange(g, 1, c->num_refs); p->num_ref_idx_l1_default = 1; p->init_qp = cfg->qp;
   p->transform_skip_enabled = c->transform_skip;
   p->transquant_bypass_enabled = c->tq_bypass > 0;
+  p->weighted_pred = p->weighted_bipred = c->weighted > 0;
   p->scaling_list_data_present = c->scaling_lists >= 3;
   if (p->scaling_list_data_present) gen_scaling(g, &p->scaling, p->sl_pred_mode, p->sl_pred_delta);
   p->cu_qp_delta_enabled = c->qp_delta > 0; p->diff_cu_qp_delta_depth = c->qp_delta > 0 ? c->qp_delta - 1 : 0;
@@ -712,6 +714,30 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
     sh->collocated_ref_idx = (sh->slice_temporal_mvp_enabled && !g->slice_is_intra) ? rrange(g, 0, (sh->collocated_from_l0 ? sh->num_ref_idx_l0 : sh->num_ref_idx_l1) - 1) : 0;
   } else sh->num_ref_idx_l0 = p->num_ref_idx_l0_default;
   sh->cabac_init_flag = p->cabac_init_present ? rpct(g, 50) : 0;
+  sh->weighted = 0;
+  if (!g->slice_is_intra && g->cfg.weighted > 0) {
+    /* pred_weight_table(): denominators 0 .. 7, weights and offsets over their whole ranges now and then, mostly near the defaults (a fade) */
+    sh->weighted = 1;
+    memset(sh->luma_weight_flag, 0, sizeof(sh->luma_weight_flag)); memset(sh->chroma_weight_flag, 0, sizeof(sh->chroma_weight_flag));
+    sh->luma_log2_weight_denom = rrange(g, 0, 7);
+    sh->delta_chroma_log2_weight_denom = rrange(g, 0, 7) - sh->luma_log2_weight_denom;
+    for (int l = 0; l < (g->slice_is_b ? 2 : 1); l++) for (int i = 0; i < (l ? sh->num_ref_idx_l1 : sh->num_ref_idx_l0); i++) {
+      const int wide = rpct(g, 15);
+      if (rpct(g, g->cfg.weighted)) {
+        sh->luma_weight_flag[l][i] = 1;
+        sh->delta_luma_weight[l][i] = (int16_t)(wide ? rrange(g, -128, 127) : rrange(g, -6, 6));
+        sh->luma_offset[l][i] = (int16_t)(wide ? rrange(g, -128, 127) : rrange(g, -10, 10));
+      }
+      if (rpct(g, g->cfg.weighted)) {
+        sh->chroma_weight_flag[l][i] = 1;
+        for (int j = 0; j < 2; j++) {
+          sh->delta_chroma_weight[l][i][j] = (int16_t)(wide ? rrange(g, -128, 127) : rrange(g, -6, 6));
+          sh->delta_chroma_offset[l][i][j] = (int16_t)(wide ? rrange(g, -512, 511) : rrange(g, -20, 20));
+        }
+      }
+    }
+    orc_derive_pred_weights(sh);
+  }
   sh->max_num_merge_cand = rrange(g, 1, 5);
   sh->slice_qp_delta = rrange(g, -4, 4);
   sh->slice_qp = p->init_qp + sh->slice_qp_delta;

@@ -49,6 +49,8 @@ typedef struct {
   int gop;                    /* 0 (also -1, 1): decoding order = output order; 2, 4 or 8: pictures come in groups of this size, the last one first and the ones in
                                * between in the order of a binary hierarchy (8 4 2 1 3 6 5 7), with references on both sides: output REORDERING
                                * (sps_max_num_reorder_pics = log2 of the size), what gop=8 makes Kvazaar write */
+  int weighted;               /* probability (%) that a reference index of an inter slice gets explicit luma / chroma weights; > 0 sets weighted_pred_flag and
+                               * weighted_bipred_flag (pred_weight_table() in every P / B slice header): what x265 writes by default (weightp) -- 0 (also -1): off */
 } orc_gen_config;
 
 void orc_gen_default_config(orc_gen_config *c);    /* everything random, 416x240 */

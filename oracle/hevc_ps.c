@@ -216,6 +216,20 @@ void orc_write_slice_header(orc_bitw *w, const orc_slice_hdr *h, const orc_sps *
         if ((h->collocated_from_l0 && h->num_ref_idx_l0 > 1) || (!h->collocated_from_l0 && h->num_ref_idx_l1 > 1))
           orc_bw_ue(w, (uint32_t)h->collocated_ref_idx);
       }
+      if ((p->weighted_pred && h->slice_type == SLICE_P) || (p->weighted_bipred && h->slice_type == SLICE_B)) {
+        /* pred_weight_table(): the flags of a list first, then the values of the entries whose flags are set (single layer: every entry's POC differs from the picture's) */
+        orc_bw_ue(w, (uint32_t)h->luma_log2_weight_denom);
+        orc_bw_se(w, h->delta_chroma_log2_weight_denom);
+        for (int l = 0; l < (h->slice_type == SLICE_B ? 2 : 1); l++) {
+          const int n = l ? h->num_ref_idx_l1 : h->num_ref_idx_l0;
+          for (int i = 0; i < n; i++) orc_bw_put(w, h->luma_weight_flag[l][i], 1);
+          for (int i = 0; i < n; i++) orc_bw_put(w, h->chroma_weight_flag[l][i], 1);
+          for (int i = 0; i < n; i++) {
+            if (h->luma_weight_flag[l][i]) { orc_bw_se(w, h->delta_luma_weight[l][i]); orc_bw_se(w, h->luma_offset[l][i]); }
+            if (h->chroma_weight_flag[l][i]) for (int j = 0; j < 2; j++) { orc_bw_se(w, h->delta_chroma_weight[l][i][j]); orc_bw_se(w, h->delta_chroma_offset[l][i][j]); }
+          }
+        }
+      }
       orc_bw_ue(w, (uint32_t)(5 - h->max_num_merge_cand));
     }
     orc_bw_se(w, h->slice_qp_delta);
@@ -496,6 +510,23 @@ int orc_parse_pps(orc_bitr *r, orc_pps *p)
 
 /* *h holds the previous slice segment's header on entry (entry_point_offset already released by the caller): a dependent slice
  * segment (7.3.6.1) takes over everything but its address and its entry points from it */
+/* 7.4.7.3: LumaWeightLX, luma_offset_lX, ChromaWeightLX, ChromaOffsetLX (8-bit video: no scaling of the offsets) */
+void orc_derive_pred_weights(orc_slice_hdr *h)
+{
+  const int ld = h->luma_log2_weight_denom, cd = ld + h->delta_chroma_log2_weight_denom;
+  h->wp_log2wd[0] = ld; h->wp_log2wd[1] = cd;
+  for (int l = 0; l < 2; l++) for (int i = 0; i < 16; i++) {
+    h->wp_w[l][i][0] = (int16_t)((1 << ld) + (h->luma_weight_flag[l][i] ? h->delta_luma_weight[l][i] : 0));
+    h->wp_o[l][i][0] = (int16_t)(h->luma_weight_flag[l][i] ? h->luma_offset[l][i] : 0);
+    for (int j = 0; j < 2; j++) {
+      const int w = (1 << cd) + (h->chroma_weight_flag[l][i] ? h->delta_chroma_weight[l][i][j] : 0);
+      int o = 0;
+      if (h->chroma_weight_flag[l][i]) { o = 128 + h->delta_chroma_offset[l][i][j] - ((128 * w) >> cd); o = o < -128 ? -128 : (o > 127 ? 127 : o); }
+      h->wp_w[l][i][1 + j] = (int16_t)w; h->wp_o[l][i][1 + j] = (int16_t)o;
+    }
+  }
+}
+
 int orc_parse_slice_header(orc_bitr *r, orc_slice_hdr *h, int nal_type, const orc_sps *sps_tab, const orc_pps *pps_tab)
 {
   const orc_slice_hdr prev = *h;
@@ -556,7 +587,32 @@ int orc_parse_slice_header(orc_bitr *r, orc_slice_hdr *h, int nal_type, const or
       if ((h->collocated_from_l0 && h->num_ref_idx_l0 > 1) || (!h->collocated_from_l0 && h->num_ref_idx_l1 > 1))
         h->collocated_ref_idx = (int)orc_br_ue(r);
     }
-    if ((p->weighted_pred && h->slice_type == SLICE_P) || (p->weighted_bipred && h->slice_type == SLICE_B)) return -2;
+    h->weighted = 0;
+    if ((p->weighted_pred && h->slice_type == SLICE_P) || (p->weighted_bipred && h->slice_type == SLICE_B)) {
+      h->weighted = 1;
+      memset(h->luma_weight_flag, 0, sizeof(h->luma_weight_flag)); memset(h->chroma_weight_flag, 0, sizeof(h->chroma_weight_flag));
+      h->luma_log2_weight_denom = (int)orc_br_ue(r);
+      h->delta_chroma_log2_weight_denom = orc_br_se(r);
+      if (h->luma_log2_weight_denom > 7 || h->luma_log2_weight_denom + h->delta_chroma_log2_weight_denom < 0 || h->luma_log2_weight_denom + h->delta_chroma_log2_weight_denom > 7) return -1;
+      for (int l = 0; l < (h->slice_type == SLICE_B ? 2 : 1); l++) {
+        const int n = l ? h->num_ref_idx_l1 : h->num_ref_idx_l0;
+        for (int i = 0; i < n; i++) h->luma_weight_flag[l][i] = (uint8_t)orc_br_get(r, 1);
+        for (int i = 0; i < n; i++) h->chroma_weight_flag[l][i] = (uint8_t)orc_br_get(r, 1);
+        for (int i = 0; i < n; i++) {
+          if (h->luma_weight_flag[l][i]) {
+            const int dw = orc_br_se(r), lo = orc_br_se(r);
+            if (dw < -128 || dw > 127 || lo < -128 || lo > 127) return -1;
+            h->delta_luma_weight[l][i] = (int16_t)dw; h->luma_offset[l][i] = (int16_t)lo;
+          }
+          if (h->chroma_weight_flag[l][i]) for (int j = 0; j < 2; j++) {
+            const int dw = orc_br_se(r), dof = orc_br_se(r);
+            if (dw < -128 || dw > 127 || dof < -512 || dof > 511) return -1;
+            h->delta_chroma_weight[l][i][j] = (int16_t)dw; h->delta_chroma_offset[l][i][j] = (int16_t)dof;
+          }
+        }
+      }
+      orc_derive_pred_weights(h);
+    }
     h->max_num_merge_cand = 5 - (int)orc_br_ue(r);
     if (h->max_num_merge_cand < 1 || h->max_num_merge_cand > 5) return -1;
   }

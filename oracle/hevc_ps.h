@@ -90,7 +90,16 @@ typedef struct {
   int loop_filter_across_slices;
   int num_entry_points; uint32_t *entry_point_offset;   /* offset_minus1 + 1, malloc'ed by parser */
   int slice_qp;
+  /* pred_weight_table() (7.3.6.3), present when the PPS says weighted_pred_flag (P slices) / weighted_bipred_flag (B slices): the syntax elements ... */
+  int weighted;                                          /* the table is present: explicit weighted sample prediction for every block of the slice (8.5.3.3.4.3) */
+  int luma_log2_weight_denom, delta_chroma_log2_weight_denom;
+  uint8_t luma_weight_flag[2][16], chroma_weight_flag[2][16];
+  int16_t delta_luma_weight[2][16], luma_offset[2][16], delta_chroma_weight[2][16][2], delta_chroma_offset[2][16][2];
+  /* ... and what 7.4.7.3 derives from them: weights and offsets per list, reference index and component (0 luma, 1 Cb, 2 Cr) */
+  int wp_log2wd[2];                                      /* luma / chroma denominators (without the 14 - bitDepth of the formula) */
+  int16_t wp_w[2][16][3], wp_o[2][16][3];
 } orc_slice_hdr;
+void orc_derive_pred_weights(orc_slice_hdr *h);        /* wp_* from the syntax elements */
 
 void orc_write_vps(orc_bitw *w, const orc_vps *v, const orc_sps *s);
 void orc_write_sps(orc_bitw *w, const orc_sps *s);

@@ -7,7 +7,7 @@ compares reconstructed pictures with oracle/hevc_dec.c bit for bit.
 
 Scope: 8-bit 4:2:0, CTB 16..64, one slice per picture, I, P and B slices (bi-prediction, output in POC order), tile rows and columns, WPP, every CU size and
 partitioning, transform trees, several reference pictures (short-term RPS), TMVP, cu_qp_delta, sign data hiding, transform
-skip, deblocking with offsets, SAO, scaling lists (default / SPS / PPS), cu_transquant_bypass.  No PCM, long-term pictures, weighted prediction.
+skip, deblocking with offsets, SAO, scaling lists (default / SPS / PPS), cu_transquant_bypass, explicit weighted prediction.  No PCM, long-term pictures.
 Normative tables are typed here per syntax element (initValue: Tables 9-5 .. 9-37); rangeTabLps and the state transition
 tables, the transform matrices and the interpolation filters are passed in by the caller (tests take them from the KAT-checked
 oracle tables: tests/test_oracle_kat.py), so that this file holds logic rather than 400 more typed constants."""
@@ -296,8 +296,8 @@ def parse_pps(rbsp):
     p["cb_off"] = r.se()
     p["cr_off"] = r.se()
     p["slice_chroma_off"] = r.u(1)
-    if r.u(1) or r.u(1):
-        raise ValueError("weighted prediction")
+    p["weighted_pred"] = r.u(1)
+    p["weighted_bipred"] = r.u(1)
     p["tq_bypass"] = r.u(1)
     p["tiles"] = r.u(1)
     p["wpp"] = r.u(1)
@@ -577,6 +577,7 @@ class Decoder:
         if pps["output_flag"]:
             r.u(1)
         sh = {"type": slice_type, "intra": slice_type == 2, "b": slice_type == 0}
+        self.last_sh = sh                                          # (for tests that look at what a stream carries)
         rps = []
         poc = 0
         if not idr:
@@ -626,6 +627,32 @@ class Decoder:
                     sh["col_l0"] = r.u(1)
                 if (sh["nref"] if sh["col_l0"] else sh["nref1"]) > 1:
                     sh["col_idx"] = r.ue()
+            sh["wp"] = None
+            if (pps["weighted_bipred"] if sh["b"] else pps["weighted_pred"]):
+                # pred_weight_table() (7.3.6.3) and the variables 7.4.7.3 derives: sh["wp"][X][i] = ((w, o) luma, (w, o) Cb, (w, o) Cr)
+                ld = r.ue()
+                cd = ld + r.se()
+                wp = []
+                for X in range(2 if sh["b"] else 1):
+                    n = sh["nref1"] if X else sh["nref"]
+                    lf = [r.u(1) for _ in range(n)]
+                    cf = [r.u(1) for _ in range(n)]
+                    ent = []
+                    for i in range(n):
+                        lw, lo = 1 << ld, 0
+                        if lf[i]:
+                            lw += r.se()
+                            lo = r.se()
+                        ch = []
+                        for j in range(2):
+                            cw, co = 1 << cd, 0
+                            if cf[i]:
+                                cw += r.se()
+                                co = min(max(128 + r.se() - ((128 * cw) >> cd), -128), 127)
+                            ch.append((cw, co))
+                        ent.append(((lw, lo), ch[0], ch[1]))
+                    wp.append(ent)
+                sh["wp"] = (ld, cd, wp)
             sh["max_merge"] = 5 - r.ue()
         sh["qp"] = pps["init_qp"] + r.se()
         sh["cb_off"] = sh["cr_off"] = 0
@@ -1158,9 +1185,17 @@ class SliceDecoder:
             pic.ref_idx[ys, xs, X] = ref
             pic.ref_poc[ys, xs, X] = self.refs[X][ref].poc if ref >= 0 else 0
         preds = [self.motion_compensate(xpb, ypb, pw, ph, m[3 * X], m[3 * X + 1], self.refs[X][m[3 * X + 2]]) for X in (0, 1) if m[3 * X + 2] >= 0]
+        wp = self.sh.get("wp")
         for ci in range(3):
             sx = 1 if ci else 0
-            if len(preds) == 2:                                    # 8.5.3.3.4.2: the rounded mean of the two 14-bit predictions
+            if wp:                                                 # 8.5.3.3.4.3: explicit weights on the 14-bit predictions (shift1 = 6 at 8 bits)
+                log2wd = (wp[1] if ci else wp[0]) + 6
+                wo = [wp[2][X][m[3 * X + 2]][ci] for X in (0, 1) if m[3 * X + 2] >= 0]
+                if len(preds) == 2:
+                    v = (preds[0][ci].astype(np.int64) * wo[0][0] + preds[1][ci].astype(np.int64) * wo[1][0] + ((wo[0][1] + wo[1][1] + 1) << log2wd)) >> (log2wd + 1)
+                else:
+                    v = ((preds[0][ci].astype(np.int64) * wo[0][0] + (1 << (log2wd - 1))) >> log2wd) + wo[0][1]
+            elif len(preds) == 2:                                    # 8.5.3.3.4.2: the rounded mean of the two 14-bit predictions
                 v = (preds[0][ci] + preds[1][ci] + 64) >> 7
             else:
                 v = (preds[0][ci] + 32) >> 6

@@ -202,3 +202,32 @@ def test_generator_b_slices_and_reordering(kw, seed):
     assert [f["poc"] for f in want] == sorted(f["poc"] for f in want[:9]) + sorted(f["poc"] for f in want[9:])      # output order: by POC inside each coded video sequence
     if kw["b_slices"]:
         assert any(f["slice_type"] == 0 for f in want)
+
+
+W_CASES = [
+    dict(weighted=60, num_refs=3, tmvp=1),                                   # P slices: what x265 writes by default (weightp) when it detects a fade
+    dict(weighted=50, b_slices=70, num_refs=4, tmvp=1, gop=4),               # B slices: weights on both lists, the bi-predictive form with both offsets
+    dict(weighted=100, b_slices=50, num_refs=2, amp=1, all_part_modes=1, sao=1),
+]
+
+
+@pytest.mark.parametrize("kw", W_CASES, ids=lambda kw: "-".join("%s%s" % (k[:3], v) for k, v in kw.items()))
+@pytest.mark.parametrize("seed", (401, 402, 403))
+def test_generator_weighted_prediction(kw, seed):
+    """explicit weighted sample prediction (pred_weight_table() 7.3.6.3, the derived weights 7.4.7.3, the sample formulas 8.5.3.3.4.3), read from the
+    standard's text a second time: denominators 0..7, weights and offsets over their whole ranges, uni- and bi-predicted blocks"""
+    cfg = dict(width=136 + 8 * (seed % 9), height=72 + 8 * (seed % 5), seed=seed, density=25, intra_period=9)
+    cfg.update(kw)
+    gen = orc.OracleGen(**cfg)
+    aus = [gen.picture() for _ in range(10)]
+    gen.close()
+    compare(aus)
+    pd = pyhevc.Decoder(tabs())
+    seen = 0
+    for au in aus:
+        pd.decode(au)
+        wp = pd.last_sh.get("wp")
+        if wp:
+            ld, cd, lists = wp
+            seen += sum(1 for ent in lists for e in ent if e[0] != (1 << ld, 0) or e[1] != (1 << cd, 0) or e[2] != (1 << cd, 0))
+    assert seen > 0                                                          # (the streams do carry weights that differ from the defaults)

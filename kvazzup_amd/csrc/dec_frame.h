@@ -24,8 +24,11 @@ struct B4Rec {
 };
 // the SECOND motion of a bi-predicted block (B4_BI; B slices): the list-1 vector and its picture buffer.  An array of its own beside b4[], present
 // only in pictures that hold such a block -- P pictures, every picture of a default Kvazaar peer, never pay for it
-struct B4L1 { int16_t mvx, mvy; uint8_t slot; uint8_t pad[3]; };
-enum { B4_BI = 64,          // bi-predicted: b4x[] holds the second vector (B4Rec: list 0's)
+struct B4L1 { int16_t mvx, mvy; uint8_t slot; uint8_t pad[3]; };      // pad[0], pad[1]: B4_WT -- entries of the weight table (DecWt: list * 16 + index) of the first / the second motion
+// explicit weighted prediction (pred_weight_table(), 7.4.7.3): weight and offset per list, reference index and colour component
+struct DecWt { int16_t w[3], o[3]; };
+enum { B4_WT = 128,        // a slice with pred_weight_table(): b4x[] holds the block's weight table entries (and the second vector when B4_BI is set too)
+       B4_BI = 64,          // bi-predicted: b4x[] holds the second vector (B4Rec: list 0's)
        B4_BYPASS = 32,      // cu_transquant_bypass_flag: the loop filters leave this block's samples as they are (8.7.2.5.7, 8.7.3)
        B4_NZ = 1,          // the luma transform block covering this 4x4 has non-zero coefficients
        B4_EDGE_V = 2,      // the left edge of this 4x4 is a transform-block or prediction-block edge
@@ -57,7 +60,8 @@ struct DecFrame {
   int wc, hc;               // CTUs (64 x 64) per row / column, partial ones included
   int row0, nrows;          // band of CTU rows the launch works on (nrows == 0: the whole picture): tile-row split over several decoders
   const B4Rec *b4;          // [ph / 4][pw / 4]
-  const B4L1 *b4x;          // [ph / 4][pw / 4] second vectors of the B4_BI blocks, NULL: the picture has none
+  const B4L1 *b4x;          // [ph / 4][pw / 4] second vectors of the B4_BI blocks (weight entries of the B4_WT blocks), NULL: the picture has none
+  const DecWt *wt; uint8_t wt_log2[2];      // explicit weighted prediction: 32 entries (list * 16 + index), luma / chroma denominators; NULL: default weights
   const TuRange *region;      // per 32x32 luma region (raster, pitch 2 * wc): {first transform block, count} in tus[]
   const TuRange *ctu;        // per CTU (raster): {first transform block, count | intra-planes mask << 24}
   const DecTu *tus; const uint32_t *lev;

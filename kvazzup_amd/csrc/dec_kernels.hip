@@ -180,7 +180,7 @@ template <class F> __device__ __forceinline__ void dec_inter_body(const F &f, co
     B4Rec r; r.mvx = 0; r.mvy = 0; r.ref_idx = -1; r.flags = 0; r.qp_y = 0; r.slot = 0;
     if (X < f.w && Y < f.h) r = f.b4[(size_t)(Y >> 2) * b4w + (X >> 2)];
     s.recs[tid] = r;
-    if (f.b4x && (r.flags & B4_BI)) s.recx[tid] = f.b4x[(size_t)(Y >> 2) * b4w + (X >> 2)];
+    if (f.b4x && (r.flags & (B4_BI | B4_WT))) s.recx[tid] = f.b4x[(size_t)(Y >> 2) * b4w + (X >> 2)];
   }
   if (tid >= 64 && tid < 80) ((uint32_t *)s.mask)[tid - 64] = 0;
   __syncthreads();
@@ -189,7 +189,7 @@ template <class F> __device__ __forceinline__ void dec_inter_body(const F &f, co
   {
     const B4Rec r0 = s.recs[0];
     bool same = true;
-    if (tid < 64) { const B4Rec r = s.recs[tid]; same = r.ref_idx == r0.ref_idx && r.slot == r0.slot && r.mvx == 0 && r.mvy == 0 && !(r.flags & B4_BI); }
+    if (tid < 64) { const B4Rec r = s.recs[tid]; same = r.ref_idx == r0.ref_idx && r.slot == r0.slot && r.mvx == 0 && r.mvy == 0 && !(r.flags & (B4_BI | B4_WT)); }
     if (__syncthreads_and(same) && r0.ref_idx >= 0 && reg.count == 0) {
       const int slot = r0.slot & 15;
       {
@@ -212,7 +212,7 @@ template <class F> __device__ __forceinline__ void dec_inter_body(const F &f, co
     const bool uni = a.mvx == b.mvx && a.mvx == c.mvx && a.mvx == d.mvx && a.mvy == b.mvy && a.mvy == c.mvy && a.mvy == d.mvy &&
                      a.slot == b.slot && a.slot == c.slot && a.slot == d.slot;
     const bool frac = ((a.mvx | a.mvy | b.mvx | b.mvy | c.mvx | c.mvy | d.mvx | d.mvy) & 3) != 0;
-    const bool bi = ((a.flags | b.flags | c.flags | d.flags) & B4_BI) != 0;      // a cell with a bi-predicted block takes the general path below (bit 3), none of the window forms
+    const bool bi = ((a.flags | b.flags | c.flags | d.flags) & (B4_BI | B4_WT)) != 0;      // a cell with a bi-predicted or explicitly weighted block takes the general path below (bit 3), none of the window forms
     s.cflag[tid] = (uint8_t)(bi ? ((inter ? 1 : 0) | 8) : ((inter ? 1 : 0) | (uni ? 2 : 0) | (frac ? 4 : 0)));
   }
   if (tid >= 64 && tid - 64 < ntu) {
@@ -269,10 +269,16 @@ template <class F> __device__ __forceinline__ void dec_inter_body(const F &f, co
         const bool bi = (m.flags & B4_BI) != 0;
         const B4L1 m1 = s.recx[(y >> 2) * 8 + (x >> 2)];
         const uint8_t *r1 = f.ref[m1.slot & 15][0];
+        // explicit weights (8.5.3.3.4.3; f.wt): w0, o0 and w1, o1 from the table entries the record names; log2WD = denominator + 14 - 8
+        const bool wt = f.wt && (m.flags & B4_WT);
+        const int lw = f.wt_log2[0] + 6, w0 = wt ? f.wt[m1.pad[0] & 31].w[0] : 0, o0 = wt ? f.wt[m1.pad[0] & 31].o[0] : 0, w1 = wt ? f.wt[m1.pad[1] & 31].w[0] : 0, o1 = wt ? f.wt[m1.pad[1] & 31].o[0] : 0;
 #pragma unroll 1
         for (int i = 0; i < 4; i++) {
           const int a = mc_luma_14(r0, f.pw, f.w, f.h, x0 + x + i, y0 + y, m.mvx, m.mvy);
-          const int v = bi ? (a + mc_luma_14(r1, f.pw, f.w, f.h, x0 + x + i, y0 + y, m1.mvx, m1.mvy) + 64) >> 7 : (a + 32) >> 6;
+          const int b = bi ? mc_luma_14(r1, f.pw, f.w, f.h, x0 + x + i, y0 + y, m1.mvx, m1.mvy) : 0;
+          int v;
+          if (wt) v = bi ? (a * w0 + b * w1 + ((o0 + o1 + 1) << lw)) >> (lw + 1) : ((a * w0 + (1 << (lw - 1))) >> lw) + o0;
+          else v = bi ? (a + b + 64) >> 7 : (a + 32) >> 6;
           p4 |= (uint32_t)clip8(v) << (8 * i);
         }
       }
@@ -321,10 +327,14 @@ template <class F> __device__ __forceinline__ void dec_inter_body(const F &f, co
         const B4L1 m1 = s.recx[(y >> 1) * 8 + (x >> 1)];
         const uint8_t *r0 = f.ref[m.slot & 15][1 + pl], *r1 = f.ref[m1.slot & 15][1 + pl];
         int v[2];
+        const bool wt = f.wt && (m.flags & B4_WT);
+        const int lw = f.wt_log2[1] + 6, w0 = wt ? f.wt[m1.pad[0] & 31].w[1 + pl] : 0, o0 = wt ? f.wt[m1.pad[0] & 31].o[1 + pl] : 0, w1 = wt ? f.wt[m1.pad[1] & 31].w[1 + pl] : 0, o1 = wt ? f.wt[m1.pad[1] & 31].o[1 + pl] : 0;
 #pragma unroll 1
         for (int i = 0; i < 2; i++) {
           const int a = mc_chroma_14(r0, cpitch, wC, hC, (x0 >> 1) + x + i, (y0 >> 1) + y, m.mvx, m.mvy);
-          v[i] = clip8(bi ? (a + mc_chroma_14(r1, cpitch, wC, hC, (x0 >> 1) + x + i, (y0 >> 1) + y, m1.mvx, m1.mvy) + 64) >> 7 : (a + 32) >> 6);
+          const int b = bi ? mc_chroma_14(r1, cpitch, wC, hC, (x0 >> 1) + x + i, (y0 >> 1) + y, m1.mvx, m1.mvy) : 0;
+          if (wt) v[i] = clip8(bi ? (a * w0 + b * w1 + ((o0 + o1 + 1) << lw)) >> (lw + 1) : ((a * w0 + (1 << (lw - 1))) >> lw) + o0);
+          else v[i] = clip8(bi ? (a + b + 64) >> 7 : (a + 32) >> 6);
         }
         p0 = v[0]; p1 = v[1];
       }

@@ -677,13 +677,14 @@ struct SliceParser {
     if (ref_y1 != (1 << 30) || ref_y0 != -(1 << 30)) { err = DEC_ERR_UNSUPPORTED; return; }      // (band mode is the split encoder's streams: P pictures)
     const int P = m.ref[0] >= 0 ? 0 : 1;                   // the list whose motion rides in the B4Rec
     const bool bi = m.ref[0] >= 0 && m.ref[1] >= 0;
-    B4Rec r; r.mvx = m.mv[P][0]; r.mvy = m.mv[P][1]; r.ref_idx = m.ref[P]; r.flags = (uint8_t)((cu_bypass ? B4_BYPASS : 0) | (bi ? B4_BI : 0)); r.qp_y = (int8_t)qp_y;
+    B4Rec r; r.mvx = m.mv[P][0]; r.mvy = m.mv[P][1]; r.ref_idx = m.ref[P]; r.flags = (uint8_t)((cu_bypass ? B4_BYPASS : 0) | (bi ? B4_BI : 0) | (sh.weighted ? B4_WT : 0)); r.qp_y = (int8_t)qp_y;
     r.slot = P ? job.ref_slot1[m.ref[1]] : job.ref_slot[m.ref[0]];
     fill_recs(xp, yp, bw, bh, r, bw == ncbs && bh == ncbs);
-    B4L1 x; x.mvx = m.mv[1][0]; x.mvy = m.mv[1][1]; x.slot = bi ? job.ref_slot1[m.ref[1]] : 0; x.pad[0] = x.pad[1] = x.pad[2] = 0;
+    B4L1 x; x.mvx = m.mv[1][0]; x.mvy = m.mv[1][1]; x.slot = bi ? job.ref_slot1[m.ref[1]] : 0; x.pad[0] = (uint8_t)(P * 16 + m.ref[P]); x.pad[1] = (uint8_t)(bi ? 16 + m.ref[1] : 0); x.pad[2] = 0;
     const int cols = imin(bw, w - xp) >> 2;
-    for (int y = yp; y < yp + bh && y < h; y += 4) { const int i0 = bi_(xp, y); for (int i = 0; i < cols; i++) { mvf[i0 + i] = m; if (bi) job.b4x[(size_t)(i0 + i)] = x; } }
-    if (bi) job.any_bi.store(1, std::memory_order_relaxed);
+    const bool ext = bi || sh.weighted;                    // the block has an entry in b4x[]
+    for (int y = yp; y < yp + bh && y < h; y += 4) { const int i0 = bi_(xp, y); for (int i = 0; i < cols; i++) { mvf[i0 + i] = m; if (ext) job.b4x[(size_t)(i0 + i)] = x; } }
+    if (ext) job.any_bi.store(1, std::memory_order_relaxed);
     if (bw != ncbs || bh != ncbs) {                          // prediction block edges inside the coding block (deblocking)
       for (int i = 0; i < bh && yp + i < h; i += 4) b4[bi_(xp, yp + i)].flags |= B4_EDGE_V;
       for (int i = 0; i < bw && xp + i < w; i += 4) b4[bi_(xp + i, yp)].flags |= B4_EDGE_H;
@@ -735,8 +736,14 @@ struct SliceParser {
       const int bot = imax(yp + bh + (mvy >> 2) + (fy ? 4 : 0), 2 * ((yp >> 1) + (bh >> 1) + (mvy >> 3) + (fc ? 2 : 0)));
       if (top < ref_y0 || bot > ref_y1) err = DEC_ERR_UNSUPPORTED;
     }
-    B4Rec r; r.mvx = (int16_t)mvx; r.mvy = (int16_t)mvy; r.ref_idx = (int8_t)ref_idx; r.flags = (uint8_t)(cu_bypass ? B4_BYPASS : 0); r.qp_y = (int8_t)qp_y; r.slot = job.ref_slot[ref_idx];
+    B4Rec r; r.mvx = (int16_t)mvx; r.mvy = (int16_t)mvy; r.ref_idx = (int8_t)ref_idx; r.flags = (uint8_t)((cu_bypass ? B4_BYPASS : 0) | (sh.weighted ? B4_WT : 0)); r.qp_y = (int8_t)qp_y; r.slot = job.ref_slot[ref_idx];
     fill_recs(xp, yp, bw, bh, r, bw == ncbs && bh == ncbs);
+    if (sh.weighted) {                                       // explicit weights: the block's table entry rides where B pictures keep their second vectors
+      B4L1 x; x.mvx = 0; x.mvy = 0; x.slot = 0; x.pad[0] = (uint8_t)ref_idx; x.pad[1] = x.pad[2] = 0;
+      const int cols = imin(bw, w - xp) >> 2;
+      for (int y = yp; y < yp + bh && y < h; y += 4) { const int i0 = bi(xp, y); for (int i = 0; i < cols; i++) job.b4x[(size_t)(i0 + i)] = x; }
+      job.any_bi.store(1, std::memory_order_relaxed);
+    }
     if (bw != ncbs || bh != ncbs) {                          // prediction block edges inside the coding block (deblocking); the block's own are set by coding_unit
       for (int i = 0; i < bh && yp + i < h; i += 4) b4[bi(xp, yp + i)].flags |= B4_EDGE_V;
       for (int i = 0; i < bw && xp + i < w; i += 4) b4[bi(xp + i, yp)].flags |= B4_EDGE_H;
@@ -1388,7 +1395,8 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     p.wpp = r.get(1);
     if (r.err || p.num_ref_idx_default > 15 || p.num_ref_idx1_default > 15 || p.cb_qp_offset < -12 || p.cb_qp_offset > 12 || p.cr_qp_offset < -12 || p.cr_qp_offset > 12) return last_error_ = DEC_ERR_INVALID;
     p.dependent_slices = dep;
-    if (cip || wp || wbp) return last_error_ = DEC_ERR_UNSUPPORTED;   // constrained intra, weighted prediction
+    if (cip) return last_error_ = DEC_ERR_UNSUPPORTED;               // constrained intra prediction
+    p.weighted_pred = wp; p.weighted_bipred = wbp;
     p.tq_bypass = tqb;
     if (tiles) {                                                 // supported: the level limits of 20 columns x 22 rows (A.4.2); loop filter across tiles on
       const int cols = r.ue() + 1, rows = r.ue() + 1; p.uniform_tiles = r.get(1);
@@ -1565,6 +1573,35 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
       const int n = sh.collocated_from_l0 ? sh.num_ref_idx : sh.num_ref_idx1;
       if (n > 1) { sh.collocated_ref_idx = r.ue(); if (sh.collocated_ref_idx < 0 || sh.collocated_ref_idx >= n) return DEC_ERR_INVALID; }
     }
+    if (sh.is_b ? p.weighted_bipred : p.weighted_pred) {
+      // pred_weight_table() (7.3.6.3; one layer: every entry's picture differs from the current one, so every flag is there) and 7.4.7.3
+      sh.weighted = true;
+      const int ld = (int)r.ue(), cd = ld + r.se();
+      if (ld < 0 || ld > 7 || cd < 0 || cd > 7) return DEC_ERR_INVALID;
+      sh.wt_log2[0] = (uint8_t)ld; sh.wt_log2[1] = (uint8_t)cd;
+      for (int k = 0; k < 32; k++) { sh.wt[k].w[0] = (int16_t)(1 << ld); sh.wt[k].w[1] = sh.wt[k].w[2] = (int16_t)(1 << cd); sh.wt[k].o[0] = sh.wt[k].o[1] = sh.wt[k].o[2] = 0; }
+      for (int l = 0; l < (sh.is_b ? 2 : 1); l++) {
+        const int n = l ? sh.num_ref_idx1 : sh.num_ref_idx;
+        uint32_t lf = 0, cf = 0;
+        for (int i = 0; i < n; i++) lf |= (uint32_t)r.get(1) << i;
+        for (int i = 0; i < n; i++) cf |= (uint32_t)r.get(1) << i;
+        for (int i = 0; i < n; i++) {
+          DecWt &e = sh.wt[l * 16 + i];
+          if ((lf >> i) & 1) {
+            const int dw = r.se(), lo = r.se();
+            if (dw < -128 || dw > 127 || lo < -128 || lo > 127) return DEC_ERR_INVALID;
+            e.w[0] = (int16_t)((1 << ld) + dw); e.o[0] = (int16_t)lo;
+          }
+          if ((cf >> i) & 1) for (int j = 0; j < 2; j++) {
+            const int dw = r.se(), dof = r.se();
+            if (dw < -128 || dw > 127 || dof < -512 || dof > 511) return DEC_ERR_INVALID;
+            const int w = (1 << cd) + dw;
+            e.w[1 + j] = (int16_t)w; e.o[1 + j] = (int16_t)clip3(-128, 127, 128 + dof - ((128 * w) >> cd));
+          }
+        }
+      }
+      if (r.err) return DEC_ERR_INVALID;
+    }
     sh.max_merge = 5 - (int)r.ue();
     if (sh.max_merge < 1 || sh.max_merge > 5) return DEC_ERR_INVALID;
   }
@@ -1605,7 +1642,8 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     if (sh.is_intra != a.is_intra || sh.is_b != a.is_b || sh.num_ref_idx1 != a.num_ref_idx1 || sh.mvd_l1_zero != a.mvd_l1_zero || sh.collocated_from_l0 != a.collocated_from_l0 || sh.poc != a.poc || sh.tmvp != a.tmvp || sh.collocated_ref_idx != a.collocated_ref_idx || sh.sao_luma != a.sao_luma ||
         sh.sao_chroma != a.sao_chroma || sh.num_ref_idx != a.num_ref_idx || sh.cabac_init_flag != a.cabac_init_flag || sh.max_merge != a.max_merge ||
         sh.slice_qp != a.slice_qp || sh.cb_qp_offset != a.cb_qp_offset || sh.cr_qp_offset != a.cr_qp_offset || sh.deblock_disabled != a.deblock_disabled ||
-        sh.beta_offset_div2 != a.beta_offset_div2 || sh.tc_offset_div2 != a.tc_offset_div2 || !across_slices) return DEC_ERR_UNSUPPORTED;
+        sh.beta_offset_div2 != a.beta_offset_div2 || sh.tc_offset_div2 != a.tc_offset_div2 || !across_slices ||
+        sh.weighted != a.weighted || (sh.weighted && (memcmp(sh.wt, a.wt, sizeof(sh.wt)) || sh.wt_log2[0] != a.wt_log2[0] || sh.wt_log2[1] != a.wt_log2[1]))) return DEC_ERR_UNSUPPORTED;
     return append_segment(*open_job, r.pos, rbsp, len, p, pp, wc, hc, seg_address, pts);
   }
   if (!sh.is_intra && !seen_irap_) return DEC_ERR_INVALID;       // nothing to predict from before the first random access point
@@ -1666,6 +1704,9 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     const size_t nb4 = (size_t)(pw_ / 4) * (ph_ / 4);
     PicJob::MvF none; memset(&none, 0, sizeof(none)); none.ref[0] = none.ref[1] = -1;
     job.mvf.assign(nb4, none);
+    if (job.b4x.size() != nb4) job.b4x.assign(nb4, B4L1());
+  } else if (sh.weighted) {                                      // a P slice with pred_weight_table(): the blocks' weight table entries
+    const size_t nb4 = (size_t)(pw_ / 4) * (ph_ / 4);
     if (job.b4x.size() != nb4) job.b4x.assign(nb4, B4L1());
   }
   job.own.reset();
@@ -2110,7 +2151,7 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
   for (auto &r : job.subs) { if (r.rc < 0) return r.rc; ntu += r.tus.size(); nlev += r.levels.size(); }
   const size_t tu_off = fixed_bytes(), lev_off = (tu_off + ntu * sizeof(DecTu) + 15) & ~(size_t)15;
   // (a picture with bi-predicted blocks: their second vectors ride behind the level words)
-  const bool bi = job.sh.is_b && job.any_bi.load(std::memory_order_relaxed) != 0;
+  const bool bi = (job.sh.is_b || job.sh.weighted) && job.any_bi.load(std::memory_order_relaxed) != 0;
   const size_t x_off = (lev_off + nlev * sizeof(uint32_t) + 15) & ~(size_t)15, x_bytes = bi ? job.b4x.size() * sizeof(B4L1) : 0;
   if (!grow_job_input(job, x_off + x_bytes)) return DEC_ERR_GPU;
   if (bi) memcpy(job.h_in + x_off, job.b4x.data(), x_bytes);
@@ -2139,7 +2180,7 @@ int Decoder::launch_gpu(PicJob &job)
   if (hipSetDevice(device_) != hipSuccess) return DEC_ERR_GPU;
   const size_t ntu = job.ntu, nlev = job.nlev;
   const size_t tu_off = fixed_bytes(), lev_off = (tu_off + ntu * sizeof(DecTu) + 15) & ~(size_t)15;
-  const bool bi = job.sh.is_b && job.any_bi.load(std::memory_order_relaxed) != 0;
+  const bool bi = (job.sh.is_b || job.sh.weighted) && job.any_bi.load(std::memory_order_relaxed) != 0;
   const size_t x_off = (lev_off + nlev * sizeof(uint32_t) + 15) & ~(size_t)15;
   const size_t bytes = bi ? x_off + job.b4x.size() * sizeof(B4L1) : lev_off + nlev * sizeof(uint32_t);
   prof_now_ = profiling_ && (launched_ % prof_every_) == 0;
@@ -2187,6 +2228,8 @@ int Decoder::launch_gpu(PicJob &job)
   if (!job.sps->scaling) sc = nullptr;                     // (scaling_list_enabled_flag = 0: a PPS's lists are not used)
   f.scaling = nullptr;
   if (sc) { memcpy(job.h_in + off_scaling(), sc->data(), KVZ_SCALING_BYTES); f.scaling = d_in_ + off_scaling(); }
+  f.wt = nullptr;
+  if (job.sh.weighted && bi) { memcpy(job.h_in + off_wt(), job.sh.wt, sizeof(job.sh.wt)); f.wt = (const DecWt *)(d_in_ + off_wt()); f.wt_log2[0] = job.sh.wt_log2[0]; f.wt_log2[1] = job.sh.wt_log2[1]; }
   if (band_nrows_ > 0) {
     // a band starts and ends on tile boundaries of full-width tiles; no SAO, no temporal prediction (what the split encoder writes)
     bool ok = !sao && !job.sps->tmvp && job.pps.tile_cols == 1 && frame_threads_ == 1, top = false, bottom = false;

@@ -186,10 +186,10 @@ class OpenHEVCFilter : public Filter {
   // The row copy out of the decoder's frame (openhevcfilter.cpp:212-229) as a stage of its own (uvgx/asyncOutput, default 1): the filter thread
   // hands the frame's description on and goes back to the next NAL unit; pictures leave in order.  The frame's memory stays valid for six
   // further decode calls here (Decoder::kOutRing), not just until the next one as with OpenHEVC, and at most three copies are pending.
-  struct OutJob { std::unique_ptr<Data> frame; const uint8_t *y, *u, *v; uint32_t s_stride, qs_stride; int W, H; };
+  struct OutJob { std::unique_ptr<Data> frame; const uint8_t *y, *u, *v; uint32_t s_stride, qs_stride; int W, H; long call_no = 0; };      // call_no: the decode call that handed the picture out
   void copyOut(OutJob &job);
   void outputStage();
-  std::thread outThread_; std::mutex outM_; std::condition_variable outCv_, outSpace_; std::deque<OutJob> outQ_; bool outQuit_ = false, asyncOut_ = true;
+  std::thread outThread_; std::mutex outM_; std::condition_variable outCv_, outSpace_; std::deque<OutJob> outQ_; bool outQuit_ = false, asyncOut_ = true; long decodeCalls_ = 0;
 };
 
 // Row f1: the conversion filter the graph inserts after the decoder (yuvtorgb32.cpp:29-64).  Host pictures go through

@@ -477,6 +477,15 @@ void OpenHEVCFilter::process()                             // openhevcfilter.cpp
       if ((vpsReceived_ && spsReceived_ && ppsReceived_) || !vcl) {
         discardedFrames_ = 0;
         kvzx::tl("dec0", (long)input->presentationTimestamp);
+        if (asyncOut_) {
+          // A picture's memory stays valid for a number of further decode CALLS (Decoder::kOutHold / kOutRing), whether or not they return pictures -- and at the
+          // end of a stream many do not (end-of-sequence units while the frame threads finish).  So a call waits while the oldest copy still pending is of a
+          // picture handed out five calls ago: the output stage may lag by pictures, never by calls.  (Found as 27 wrong bytes at the start of one picture of a
+          // reordered stream under a loaded host: the copy read a buffer the allocator had taken back.)
+          std::unique_lock<std::mutex> l(outM_);
+          outSpace_.wait(l, [this] { return outQ_.empty() || decodeCalls_ - outQ_.front().call_no < 5; });
+        }
+        decodeCalls_++;
         int gotPicture = libOpenHevcDecode(handle_, input->data.get(), (int)input->data_size, input->presentationTimestamp);
         kvzx::tl("dec1", (long)input->presentationTimestamp);
         if (vcl) decodingFrames_.push_front(std::move(input));
@@ -517,7 +526,7 @@ void OpenHEVCFilter::sendDecodedOutput(int &gotPicture)    // openhevcfilter.cpp
     OutJob job;
     job.y = (const uint8_t *)openHevcFrame.pvY; job.u = (const uint8_t *)openHevcFrame.pvU; job.v = (const uint8_t *)openHevcFrame.pvV;
     job.s_stride = (uint32_t)openHevcFrame.frameInfo.nYPitch; job.qs_stride = (uint32_t)openHevcFrame.frameInfo.nUPitch / 2; job.W = W; job.H = H;
-    job.frame = std::move(decodedFrame);
+    job.frame = std::move(decodedFrame); job.call_no = decodeCalls_;
     if (!asyncOut_) { copyOut(job); return; }
     if (!outThread_.joinable()) outThread_ = std::thread([this] { kvzx::name_this_thread("kvzx-dec-out"); outputStage(); });
     std::unique_lock<std::mutex> l(outM_);

@@ -252,6 +252,26 @@ def test_random_b_streams_match_oracle(gpu, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(400, 424))
+def test_random_weighted_streams_match_oracle(gpu, seed):
+    """explicit weighted prediction (pred_weight_table(): what x265 writes by default, `weightp`) in P and B slices, every other switch drawn from the seed:
+    weights and offsets per list, reference index and component on the 14-bit predictions (8.5.3.3.4.3), uni- and bi-predicted blocks, with and without
+    frame threads"""
+    sizes = [(416, 240), (352, 288), (200, 136), (648, 360)]
+    w, h = sizes[seed % len(sizes)]
+    run_stream(w, h, 12, seed=seed, weighted=(40, 70, 100)[seed % 3], b_slices=(0, 60, 100)[(seed // 3) % 3], gop=(0, 0, 4, 8)[(seed // 2) % 4], intra_period=9,
+               threads=3 if seed & 1 else 1, frame_threads=bool(seed & 1))
+
+
+@pytest.mark.gpu
+def test_weighted_pictures_1080p(gpu):
+    """1080p P and B pictures with explicit weights, four reference pictures, TMVP, WPP"""
+    run_stream(1920, 1080, 8, seed=23, weighted=70, b_slices=50, gop=0, num_refs=4, tmvp=1, strong_intra=0, sign_hiding=1, wpp=1, tile_rows=1, intra_in_p=10,
+               all_part_modes=1, amp=1, sao=1, qp_delta=0, deblock_mode=0, th_depth_inter=1, th_depth_intra=1, max_cu_log2=6, min_cu_log2=3, nxn_intra=1,
+               chroma_modes=1, transform_skip=0, cabac_init=0, chroma_qp_offsets=0, par_mrg_level=2, big_mvd=0, uniform_tiles=1, density=20)
+
+
+@pytest.mark.gpu
 def test_b_pictures_1080p_gop8(gpu):
     """1080p, Kvazaar gop=8 shape: hierarchical B pictures, four reference pictures, TMVP, WPP"""
     run_stream(1920, 1080, 10, seed=21, b_slices=80, gop=8, num_refs=4, tmvp=1, strong_intra=0, sign_hiding=1, wpp=1, tile_rows=1, intra_in_p=10,
@@ -281,7 +301,7 @@ def test_b_stream_through_the_filter_graph(gpu, threads):
     for i in range(n):
         got = pl.pop_decoded()
         assert got is not None and (got["width"], got["height"]) == (w, h), i
-        assert np.array_equal(got["i420"], want[i]), i
+        assert np.array_equal(got["i420"], want[i]), (i, [k for k in range(n) if np.array_equal(got["i420"], want[k])], int(np.flatnonzero(got["i420"] != want[i])[0]), int(np.count_nonzero(got["i420"] != want[i])))
     pl.close(); od.close(); g.close()
 
 

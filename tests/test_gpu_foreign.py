@@ -306,14 +306,15 @@ def test_b_stream_through_the_filter_graph(gpu, threads):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("weighted", [0, 60])
 @pytest.mark.parametrize("frame", [False, True])
-def test_decoder_survives_corrupted_b_streams(gpu, frame):
+def test_decoder_survives_corrupted_b_streams(gpu, frame, weighted):
     """bit flips, truncations and garbage in B pictures of reordered groups: every call returns (a picture, nothing, or an error code), nothing
     hangs or crashes -- vectors, reference indices and list sizes out of a damaged slice never reach a kernel unchecked --, and from the next
     clean IDR picture on the output is the checker's again, in output order"""
     from kvazzup_amd.codec import Decoder, split_nals
     w, h, period = 200, 136, 9
-    g = orc.OracleGen(w, h, seed=91, intra_period=period, density=30, b_slices=70, gop=4, num_refs=3, tmvp=1, sao=1, wpp=1, all_part_modes=1)
+    g = orc.OracleGen(w, h, seed=91, intra_period=period, density=30, b_slices=70, gop=4, num_refs=3, tmvp=1, sao=1, wpp=1, all_part_modes=1, weighted=weighted)      # (weighted: pred_weight_table() in the damaged slice headers too)
     aus = [g.picture() for _ in range(3 * period)]
     g.close()
     od = orc.OracleDecoder()

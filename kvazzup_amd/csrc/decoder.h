@@ -15,7 +15,7 @@
 // overrides, SAO, WPP, tile grids up to the level limit of 20 columns x 22 rows (uniform or
 // explicit spacing), pictures in several slice segments the two ways Kvazaar cuts them (a dependent slice segment per CTU row with WPP, an
 // independent slice per tile).  Rejected with a negative return value (kvzx_decoder_last_error): slice segments that are
-// neither whole CTU rows nor whole tiles, loop_filter_across_tiles_enabled_flag = 0, long-term references, reference list modification,
+// neither whole CTU rows nor whole tiles, loop_filter_across_tiles_enabled_flag = 0, long-term references,
 // PCM, constrained intra prediction, other CTB / CB / TB sizes.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -62,7 +62,7 @@ struct DecPps {
   int sign_hiding = 0, cabac_init_present = 0, num_ref_idx_default = 1, num_ref_idx1_default = 1, init_qp = 26, tskip = 0;
   int dependent_slices = 0;
   int cu_qp_delta = 0, qp_delta_depth = 0, cb_qp_offset = 0, cr_qp_offset = 0, slice_chroma_offsets = 0;
-  int weighted_pred = 0, weighted_bipred = 0;
+  int weighted_pred = 0, weighted_bipred = 0, lists_mod = 0;
   int output_flag_present = 0, extra_header_bits = 0, header_extension = 0;
   int wpp = 0, tile_rows = 1, row_bd[34];   // tile row i covers CTB rows [row_bd[i], row_bd[i + 1]); filled at slice time when uniform
   int tile_cols = 1, col_bd[34];            // tile column j covers CTB columns [col_bd[j], col_bd[j + 1])
@@ -156,6 +156,7 @@ class Decoder {
     int tmvp = 0, collocated_ref_idx = 0, sao_luma = 0, sao_chroma = 0, num_ref_idx = 1, cabac_init_flag = 0, max_merge = 5;
     int slice_qp = 26, cb_qp_offset = 0, cr_qp_offset = 0;      // offsets: PPS + slice
     int deblock_disabled = 0, beta_offset_div2 = 0, tc_offset_div2 = 0;
+    uint8_t list_mod[2] = {0, 0}, list_entry[2][16] = {};      // ref_pic_lists_modification() (7.3.6.2): entries of the temporary lists (8.3.4)
     bool weighted = false; uint8_t wt_log2[2] = {0, 0}; DecWt wt[32] = {};      // pred_weight_table() (7.3.6.3) as derived by 7.4.7.3: entry list * 16 + index
   };
   // everything one picture needs between its slice header and its reconstruction

@@ -1420,7 +1420,7 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
       if (!parse_scaling_list_data(r, sl)) return last_error_ = DEC_ERR_INVALID;
       p.scaling = build_scaling(sl);
     }
-    if (r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;      // lists_modification_present_flag
+    p.lists_mod = r.get(1);                                       // lists_modification_present_flag
     p.par_mrg_level = (int)r.ue() + 2;
     p.header_extension = r.get(1);
     if (r.err || p.par_mrg_level > 6 || p.beta_offset_div2 < -6 || p.beta_offset_div2 > 6 || p.tc_offset_div2 < -6 || p.tc_offset_div2 > 6) return last_error_ = DEC_ERR_INVALID;
@@ -1566,6 +1566,17 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   if (!sh.is_intra) {
     if (r.get(1)) { sh.num_ref_idx = (int)r.ue() + 1; if (sh.is_b) sh.num_ref_idx1 = (int)r.ue() + 1; }
     if (sh.num_ref_idx < 1 || sh.num_ref_idx > 15 || (sh.is_b && (sh.num_ref_idx1 < 1 || sh.num_ref_idx1 > 15))) return DEC_ERR_INVALID;
+    if (p.lists_mod) {                                            // ref_pic_lists_modification(): NumPicTotalCurr = the set's used pictures (no long-term ones)
+      int total = 0;
+      for (int k = 0; k < rps.n_neg + rps.n_pos; k++) total += rps.used[k] ? 1 : 0;
+      if (total > 1) {
+        int bits = 0; while ((1 << bits) < total) bits++;
+        for (int l = 0; l < (sh.is_b ? 2 : 1); l++) {
+          sh.list_mod[l] = (uint8_t)r.get(1);
+          if (sh.list_mod[l]) for (int i = 0; i < (l ? sh.num_ref_idx1 : sh.num_ref_idx); i++) { const int e = r.get(bits); if (e >= total) return DEC_ERR_INVALID; sh.list_entry[l][i] = (uint8_t)e; }
+        }
+      }
+    }
     if (sh.is_b) sh.mvd_l1_zero = r.get(1);
     if (p.cabac_init_present) sh.cabac_init_flag = r.get(1);
     if (sh.tmvp) {
@@ -1643,6 +1654,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
         sh.sao_chroma != a.sao_chroma || sh.num_ref_idx != a.num_ref_idx || sh.cabac_init_flag != a.cabac_init_flag || sh.max_merge != a.max_merge ||
         sh.slice_qp != a.slice_qp || sh.cb_qp_offset != a.cb_qp_offset || sh.cr_qp_offset != a.cr_qp_offset || sh.deblock_disabled != a.deblock_disabled ||
         sh.beta_offset_div2 != a.beta_offset_div2 || sh.tc_offset_div2 != a.tc_offset_div2 || !across_slices ||
+        memcmp(sh.list_mod, a.list_mod, 2) || memcmp(sh.list_entry, a.list_entry, sizeof(sh.list_entry)) ||
         sh.weighted != a.weighted || (sh.weighted && (memcmp(sh.wt, a.wt, sizeof(sh.wt)) || sh.wt_log2[0] != a.wt_log2[0] || sh.wt_log2[1] != a.wt_log2[1]))) return DEC_ERR_UNSUPPORTED;
     return append_segment(*open_job, r.pos, rbsp, len, p, pp, wc, hc, seg_address, pts);
   }
@@ -1668,11 +1680,12 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
       if (nc == 0) return DEC_ERR_INVALID;
       // 8.3.4: RefPicList0 = before, after, repeated; RefPicList1 = after, before, repeated
       nref = sh.num_ref_idx;
-      for (int k = 0; k < nref; k++) { ref_slot[k] = (uint8_t)cand_slot[k % nc]; ref_poc[k] = dpb_[ref_slot[k]].poc; if (ref_poc[k] > sh.poc) no_backward = false; }
+      // (a modified list names entries of the temporary list; nc = NumPicTotalCurr here: a used picture that is missing ended the call above)
+      for (int k = 0; k < nref; k++) { ref_slot[k] = (uint8_t)cand_slot[sh.list_mod[0] ? imin(sh.list_entry[0][k], nc - 1) : k % nc]; ref_poc[k] = dpb_[ref_slot[k]].poc; if (ref_poc[k] > sh.poc) no_backward = false; }
       nref1 = sh.is_b ? sh.num_ref_idx1 : 0;
       const int nafter = nc - nbefore;
       for (int k = 0; k < nref1; k++) {
-        const int q = k % nc;
+        const int q = sh.list_mod[1] ? imin(sh.list_entry[1][k], nc - 1) : k % nc;
         ref_slot1[k] = (uint8_t)cand_slot[q < nafter ? nbefore + q : q - nafter]; ref_poc1[k] = dpb_[ref_slot1[k]].poc;
         if (ref_poc1[k] > sh.poc) no_backward = false;
       }

@@ -801,7 +801,7 @@ static int build_ref_list(orc_decoder *d)
   const int nc = nb + na;
   if (nc == 0) return ERR_INVALID;
   for (int i = 0; i < sh->num_ref_idx_l0; i++) {
-    const int k = i % nc;
+    const int k = sh->rpl_mod_flag[0] ? sh->list_entry[0][i] : i % nc;      /* 8.3.4: an entry of the temporary list (before, after, before, ...) */
     d->ref_list0[i] = k < nb ? before[k] : after[k - nb];
     if (!d->ref_list0[i]) return ERR_INVALID;      /* missing reference picture */
     d->ref_poc[i] = d->cur->ref_poc_list[i] = d->ref_list0[i]->poc;
@@ -810,7 +810,7 @@ static int build_ref_list(orc_decoder *d)
   d->num_ref = sh->num_ref_idx_l0;
   if (sh->slice_type == SLICE_B) {
     for (int i = 0; i < sh->num_ref_idx_l1; i++) {
-      const int k = i % nc;
+      const int k = sh->rpl_mod_flag[1] ? sh->list_entry[1][i] : i % nc;
       d->ref_list1[i] = k < na ? after[k] : before[k - na];
       if (!d->ref_list1[i]) return ERR_INVALID;
       d->ref_poc1[i] = d->cur->ref_poc_list1[i] = d->ref_list1[i]->poc;

@@ -126,6 +126,7 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   if (c->scaling_lists < 0 || c->scaling_lists > 4) c->scaling_lists = 0;
   if (c->b_slices < 0) c->b_slices = 0;
   if (c->weighted < 0) c->weighted = 0;
+  if (c->list_mod < 0) c->list_mod = 0;
   if (c->gop != 2 && c->gop != 4 && c->gop != 8) c->gop = 0;
   const int wc = (cfg->width + 63) / 64, hc = (cfg->height + 63) / 64;
   if (c->tile_rows > hc) c->tile_rows = hc;
@@ -162,6 +163,7 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   p->transform_skip_enabled = c->transform_skip;
   p->transquant_bypass_enabled = c->tq_bypass > 0;
   p->weighted_pred = p->weighted_bipred = c->weighted > 0;
+  p->lists_modification_present = c->list_mod > 0;
   p->scaling_list_data_present = c->scaling_lists >= 3;
   if (p->scaling_list_data_present) gen_scaling(g, &p->scaling, p->sl_pred_mode, p->sl_pred_delta);
   p->cu_qp_delta_enabled = c->qp_delta > 0; p->diff_cu_qp_delta_depth = c->qp_delta > 0 ? c->qp_delta - 1 : 0;
@@ -714,6 +716,16 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
     sh->collocated_ref_idx = (sh->slice_temporal_mvp_enabled && !g->slice_is_intra) ? rrange(g, 0, (sh->collocated_from_l0 ? sh->num_ref_idx_l0 : sh->num_ref_idx_l1) - 1) : 0;
   } else sh->num_ref_idx_l0 = p->num_ref_idx_l0_default;
   sh->cabac_init_flag = p->cabac_init_present ? rpct(g, 50) : 0;
+  sh->rpl_mod_flag[0] = sh->rpl_mod_flag[1] = 0;
+  if (!g->slice_is_intra && p->lists_modification_present) {
+    int total = 0;
+    for (int i = 0; i < sh->st_rps.num_negative; i++) total += sh->st_rps.used_s0[i];
+    for (int i = 0; i < sh->st_rps.num_positive; i++) total += sh->st_rps.used_s1[i];
+    if (total > 1) for (int l = 0; l < (g->slice_is_b ? 2 : 1); l++) if (rpct(g, g->cfg.list_mod)) {
+      sh->rpl_mod_flag[l] = 1;
+      for (int i = 0; i < (l ? sh->num_ref_idx_l1 : sh->num_ref_idx_l0); i++) sh->list_entry[l][i] = (uint8_t)rrange(g, 0, total - 1);
+    }
+  }
   sh->weighted = 0;
   if (!g->slice_is_intra && g->cfg.weighted > 0) {
     /* pred_weight_table(): denominators 0 .. 7, weights and offsets over their whole ranges now and then, mostly near the defaults (a fade) */

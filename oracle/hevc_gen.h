@@ -51,6 +51,8 @@ typedef struct {
                                * (sps_max_num_reorder_pics = log2 of the size), what gop=8 makes Kvazaar write */
   int weighted;               /* probability (%) that a reference index of an inter slice gets explicit luma / chroma weights; > 0 sets weighted_pred_flag and
                                * weighted_bipred_flag (pred_weight_table() in every P / B slice header): what x265 writes by default (weightp) -- 0 (also -1): off */
+  int list_mod;               /* probability (%) that a reference list of an inter slice is modified (ref_pic_lists_modification(): the entries of the initial list
+                               * in any order, repeats allowed); > 0 sets lists_modification_present_flag -- 0 (also -1): off */
 } orc_gen_config;
 
 void orc_gen_default_config(orc_gen_config *c);    /* everything random, 416x240 */

@@ -209,6 +209,18 @@ void orc_write_slice_header(orc_bitw *w, const orc_slice_hdr *h, const orc_sps *
         orc_bw_ue(w, (uint32_t)h->num_ref_idx_l0 - 1);
         if (h->slice_type == SLICE_B) orc_bw_ue(w, (uint32_t)h->num_ref_idx_l1 - 1);
       }
+      {
+        int num_pic_total = 0;
+        for (int i = 0; i < h->st_rps.num_negative; i++) num_pic_total += h->st_rps.used_s0[i];
+        for (int i = 0; i < h->st_rps.num_positive; i++) num_pic_total += h->st_rps.used_s1[i];
+        if (p->lists_modification_present && num_pic_total > 1) {
+          const int bits = ceil_log2((unsigned)num_pic_total);
+          for (int l = 0; l < (h->slice_type == SLICE_B ? 2 : 1); l++) {
+            orc_bw_put(w, (uint32_t)h->rpl_mod_flag[l], 1);
+            if (h->rpl_mod_flag[l]) for (int i = 0; i < (l ? h->num_ref_idx_l1 : h->num_ref_idx_l0); i++) orc_bw_put(w, h->list_entry[l][i], bits);
+          }
+        }
+      }
       if (h->slice_type == SLICE_B) orc_bw_put(w, (uint32_t)h->mvd_l1_zero, 1);
       if (p->cabac_init_present) orc_bw_put(w, (uint32_t)h->cabac_init_flag, 1);
       if (h->slice_temporal_mvp_enabled) {
@@ -579,7 +591,17 @@ int orc_parse_slice_header(orc_bitr *r, orc_slice_hdr *h, int nal_type, const or
     int num_pic_total = 0;
     for (int i = 0; i < h->st_rps.num_negative; i++) num_pic_total += h->st_rps.used_s0[i];
     for (int i = 0; i < h->st_rps.num_positive; i++) num_pic_total += h->st_rps.used_s1[i];
-    if (p->lists_modification_present && num_pic_total > 1) return -2;   /* ref_pic_lists_modification: unsupported */
+    h->rpl_mod_flag[0] = h->rpl_mod_flag[1] = 0;
+    if (p->lists_modification_present && num_pic_total > 1) {              /* ref_pic_lists_modification() */
+      const int bits = ceil_log2((unsigned)num_pic_total);
+      for (int l = 0; l < (h->slice_type == SLICE_B ? 2 : 1); l++) {
+        h->rpl_mod_flag[l] = (int)orc_br_get(r, 1);
+        if (h->rpl_mod_flag[l]) for (int i = 0; i < (l ? h->num_ref_idx_l1 : h->num_ref_idx_l0); i++) {
+          h->list_entry[l][i] = (uint8_t)orc_br_get(r, bits);
+          if (h->list_entry[l][i] >= num_pic_total) return -1;
+        }
+      }
+    }
     if (h->slice_type == SLICE_B) h->mvd_l1_zero = (int)orc_br_get(r, 1);
     if (p->cabac_init_present) h->cabac_init_flag = (int)orc_br_get(r, 1);
     if (h->slice_temporal_mvp_enabled) {

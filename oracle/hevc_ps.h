@@ -90,6 +90,9 @@ typedef struct {
   int loop_filter_across_slices;
   int num_entry_points; uint32_t *entry_point_offset;   /* offset_minus1 + 1, malloc'ed by parser */
   int slice_qp;
+  /* ref_pic_lists_modification() (7.3.6.2; PPS lists_modification_present_flag, more than one picture in the reference picture set): entries of the
+   * temporary list (8.3.4) in the order the slice wants them */
+  int rpl_mod_flag[2]; uint8_t list_entry[2][16];
   /* pred_weight_table() (7.3.6.3), present when the PPS says weighted_pred_flag (P slices) / weighted_bipred_flag (B slices): the syntax elements ... */
   int weighted;                                          /* the table is present: explicit weighted sample prediction for every block of the slice (8.5.3.3.4.3) */
   int luma_log2_weight_denom, delta_chroma_log2_weight_denom;

@@ -79,6 +79,8 @@ GEN = {
     # explicit weighted prediction (pred_weight_table()): what an x265 peer writes by default (weightp), in P and B slices
     "gen_weighted": dict(seed=37, density=25, intra_period=8, num_refs=3, tmvp=1, amp=0, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                          qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=40, weighted=60),
+    "gen_list_modification": dict(seed=38, density=25, intra_period=8, num_refs=4, tmvp=1, amp=0, sao=0, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
+                                  qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=40, list_mod=70),
     "gen_b_gop8": dict(seed=36, density=25, intra_period=16, num_refs=4, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                        qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=70, gop=8),
 }

@@ -327,8 +327,7 @@ def parse_pps(rbsp):
     if r.u(1):                               # pps_scaling_list_data_present_flag
         p["scaling"] = default_scaling_lists()
         parse_scaling_list_data(r, p["scaling"])
-    if r.u(1):
-        raise ValueError("lists modification")
+    p["lists_mod"] = r.u(1)
     p["par_mrg"] = r.ue() + 2
     p["sh_ext"] = r.u(1)
     return p
@@ -618,6 +617,13 @@ class Decoder:
                 sh["nref"] = r.ue() + 1
                 if sh["b"]:
                     sh["nref1"] = r.ue() + 1
+            sh["list_entry"] = [None, None]
+            total = sum(1 for _, used in rps if used)                  # NumPicTotalCurr (no long-term pictures)
+            if pps["lists_mod"] and total > 1:                         # ref_pic_lists_modification() (7.3.6.2)
+                bits = (total - 1).bit_length()
+                for X in range(2 if sh["b"] else 1):
+                    if r.u(1):
+                        sh["list_entry"][X] = [r.u(bits) for _ in range(sh["nref1"] if X else sh["nref"])]
             if sh["b"]:
                 sh["mvd_l1_zero"] = r.u(1)
             if pps["cabac_init_present"]:
@@ -716,7 +722,9 @@ class Decoder:
         # 8.3.4: list 0 starts with the pictures before the current one, list 1 with the ones after it; short lists repeat
         c0 = [by_poc(q) for q in before + after]
         c1 = [by_poc(q) for q in after + before]
-        refs = [[c0[i % len(c0)] for i in range(sh["nref"])] if sh["nref"] else [], [c1[i % len(c1)] for i in range(sh["nref1"])] if sh["nref1"] else []]
+        le = sh.get("list_entry") or [None, None]                    # (a modified list: entries of the temporary list in the slice's order)
+        refs = [[c0[le[0][i] if le[0] else i % len(c0)] for i in range(sh["nref"])] if sh["nref"] else [],
+                [c1[le[1][i] if le[1] else i % len(c1)] for i in range(sh["nref1"])] if sh["nref1"] else []]
         if idr or self.cvs == 0:
             self.cvs += 1
         pic = Picture(sps["w"], sps["h"])

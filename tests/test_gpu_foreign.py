@@ -264,6 +264,17 @@ def test_random_weighted_streams_match_oracle(gpu, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(500, 516))
+def test_random_streams_with_modified_reference_lists_match_oracle(gpu, seed):
+    """ref_pic_lists_modification() (7.3.6.2 / 8.3.4) in P and B slices, with and without weights (their table is indexed through the modified lists) and
+    temporal candidates (so is the collocated picture), every other switch drawn from the seed"""
+    sizes = [(416, 240), (352, 288), (200, 136), (648, 360)]
+    w, h = sizes[seed % len(sizes)]
+    run_stream(w, h, 12, seed=seed, list_mod=(50, 80, 100)[seed % 3], num_refs=4, b_slices=(0, 60, 100)[(seed // 3) % 3], gop=(0, 0, 4, 8)[(seed // 2) % 4], intra_period=9,
+               weighted=(0, 50)[(seed // 4) % 2], threads=3 if seed & 1 else 1, frame_threads=bool(seed & 1))
+
+
+@pytest.mark.gpu
 def test_weighted_pictures_1080p(gpu):
     """1080p P and B pictures with explicit weights, four reference pictures, TMVP, WPP"""
     run_stream(1920, 1080, 8, seed=23, weighted=70, b_slices=50, gop=0, num_refs=4, tmvp=1, strong_intra=0, sign_hiding=1, wpp=1, tile_rows=1, intra_in_p=10,

@@ -231,3 +231,23 @@ def test_generator_weighted_prediction(kw, seed):
             ld, cd, lists = wp
             seen += sum(1 for ent in lists for e in ent if e[0] != (1 << ld, 0) or e[1] != (1 << cd, 0) or e[2] != (1 << cd, 0))
     assert seen > 0                                                          # (the streams do carry weights that differ from the defaults)
+
+
+@pytest.mark.parametrize("kw", [dict(list_mod=70, num_refs=4, tmvp=1), dict(list_mod=60, b_slices=70, num_refs=4, tmvp=1, gop=4, weighted=40),
+                                dict(list_mod=100, b_slices=50, num_refs=3, gop=8)], ids=lambda kw: "-".join("%s%s" % (k[:3], v) for k, v in kw.items()))
+@pytest.mark.parametrize("seed", (501, 502, 503))
+def test_generator_reference_list_modification(kw, seed):
+    """ref_pic_lists_modification() (7.3.6.2, 8.3.4): the slice orders the entries of the initial lists as it likes (repeats included), in P and B slices, with
+    temporal candidates and weights indexed by the modified lists"""
+    cfg = dict(width=136 + 8 * (seed % 9), height=72 + 8 * (seed % 5), seed=seed, density=25, intra_period=9)
+    cfg.update(kw)
+    gen = orc.OracleGen(**cfg)
+    aus = [gen.picture() for _ in range(12)]
+    gen.close()
+    compare(aus)
+    pd = pyhevc.Decoder(tabs())
+    seen = 0
+    for au in aus:
+        pd.decode(au)
+        seen += sum(1 for e in (pd.last_sh.get("list_entry") or []) if e)
+    assert seen > 0                                                          # (the streams do modify lists)

@@ -18,7 +18,10 @@ def lib():
     global _LIB
     if _LIB is None:
         d = os.path.join(ROOT, "tests", "hostcheck")
-        subprocess.run(["make", "-s", "-C", d], check=True, stdout=subprocess.DEVNULL)
+        import fcntl
+        with open(os.path.join(d, ".build.lock"), "w") as lk:      # (pytest -n: several workers reach this at once, and a half-linked library must not be loaded)
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            subprocess.run(["make", "-s", "-C", d], check=True, stdout=subprocess.DEVNULL)
         L = C.CDLL(os.path.join(d, "build", "libhostcheck.so"))
         L.hc_encode_au.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.hc_encode_au_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]

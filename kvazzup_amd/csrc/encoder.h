@@ -208,7 +208,7 @@ class Encoder {
     int poc = 0, rec_idx = 0, set = 0, qp = 0; bool intra = false, write_ps = false; long pic_idx = 0;
     std::vector<EvPair> ev; size_t ev_used = 0;
     EncodedPicture result; bool ready = false, ok = true;   // owf >= 2: filled by the background thread
-    EncFrame f_tok{}; bool prof = false;                    // tok_deferred_: what the tokenizer's launches need, kept until the launcher thread makes them
+    EncFrame f_tok{}; bool prof = false, tok_failed = false;                    // tok_deferred_: what the tokenizer's launches need, kept until the launcher thread makes them
   };
   Slot slot_[kMaxDepth + 2]; Slot *cur_slot_ = nullptr; int nslots_ = 1, depth_ = 0;
   size_t stage_cap_ = 0, out_cap_ = 0;

@@ -693,7 +693,8 @@ void Encoder::tok_launcher()
     hipEvent_t e = ev_src_free_[sl.set];                   // recorded behind the chain's last kernel (k_sao); not recorded again before this picture has been collected (owf < kSets)
     nap_until([&] { hipError_t r = hipEventQuery(e); return r == hipSuccess ? 1 : (r == hipErrorNotReady ? 0 : -1); });
     tl("tok0", sl.pic_idx);
-    if (!launch_tokenizer(sl, sl.f_tok, sl.intra, false, sl.prof)) fprintf(stderr, "kvazzup_amd: the tokenizer of picture %ld could not be launched\n", sl.pic_idx);
+    sl.tok_failed = !launch_tokenizer(sl, sl.f_tok, sl.intra, false, sl.prof);      // (finish_slot then fails the picture instead of coding whatever the slot held before)
+    if (sl.tok_failed) fprintf(stderr, "kvazzup_amd: the tokenizer of picture %ld could not be launched\n", sl.pic_idx);
     { std::lock_guard<std::mutex> l(bm_); bq_.push_back(idx); }
     bcv_.notify_all();
   }
@@ -738,6 +739,7 @@ void Encoder::background(int worker)
 bool Encoder::finish_slot(Slot &sl, EncodedPicture *out, int worker)
 {
   out->valid = false; out->au.clear();
+  if (sl.tok_failed) { sl.tok_failed = false; return false; }
   {
     Tick tk;
     if (depth_ >= 2 && !spin_wait_) {          // background worker: naps between queries (see nap_until)

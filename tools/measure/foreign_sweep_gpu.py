@@ -1,4 +1,4 @@
-"""one-off sweep: random synthesiser streams (every switch from the seed, scaling lists / transquant bypass / B slices mixed in) through the HIP decoder against the
+"""one-off sweep: random synthesiser streams (every switch from the seed, scaling lists / transquant bypass / B slices / explicit weights / modified reference lists mixed in) through the HIP decoder against the
 checker.  GPU box only: python tools/measure/foreign_sweep_gpu.py [first seed] [count]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +12,7 @@ for seed in range(first, first + count):
     kw = dict(seed=seed, threads=4 if seed % 3 == 0 else 1, frame_threads=seed % 3 == 0)
     if seed % 4 == 1: kw.update(scaling_lists=seed % 5, tq_bypass=(0, 25, 100)[seed % 3])
     if seed % 4 == 2: kw.update(b_slices=(40, 100)[seed % 2], gop=(0, 4, 8)[seed % 3])
+    if seed % 4 == 3: kw.update(b_slices=(0, 50, 100)[seed % 3], gop=(0, 4, 8)[(seed // 3) % 3], weighted=(0, 40, 100)[(seed // 2) % 3], list_mod=(0, 60, 100)[(seed // 5) % 3], num_refs=4)
     try:
         T.run_stream(w, h, 8, **kw)
     except BaseException as e:      # noqa: BLE001

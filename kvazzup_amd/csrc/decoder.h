@@ -157,7 +157,8 @@ class Decoder {
     int slice_qp = 26, cb_qp_offset = 0, cr_qp_offset = 0;      // offsets: PPS + slice
     int deblock_disabled = 0, beta_offset_div2 = 0, tc_offset_div2 = 0;
     uint8_t list_mod[2] = {0, 0}, list_entry[2][16] = {};      // ref_pic_lists_modification() (7.3.6.2): entries of the temporary lists (8.3.4)
-    bool weighted = false; uint8_t wt_log2[2] = {0, 0}; DecWt wt[32] = {};      // pred_weight_table() (7.3.6.3) as derived by 7.4.7.3: entry list * 16 + index
+    bool weighted = false; uint8_t wt_log2[2] = {0, 0}; DecWt wt[32] = {};
+    uint32_t wt_explicit = 0;                                        // bit list * 16 + index: the entry's weights or offsets differ from the defaults (with the defaults the explicit formulas ARE the default ones)      // pred_weight_table() (7.3.6.3) as derived by 7.4.7.3: entry list * 16 + index
   };
   // everything one picture needs between its slice header and its reconstruction
   struct PicJob {

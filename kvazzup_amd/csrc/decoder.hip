@@ -677,12 +677,14 @@ struct SliceParser {
     if (ref_y1 != (1 << 30) || ref_y0 != -(1 << 30)) { err = DEC_ERR_UNSUPPORTED; return; }      // (band mode is the split encoder's streams: P pictures)
     const int P = m.ref[0] >= 0 ? 0 : 1;                   // the list whose motion rides in the B4Rec
     const bool bi = m.ref[0] >= 0 && m.ref[1] >= 0;
-    B4Rec r; r.mvx = m.mv[P][0]; r.mvy = m.mv[P][1]; r.ref_idx = m.ref[P]; r.flags = (uint8_t)((cu_bypass ? B4_BYPASS : 0) | (bi ? B4_BI : 0) | (sh.weighted ? B4_WT : 0)); r.qp_y = (int8_t)qp_y;
+    // explicit weights only where an entry the block uses differs from the defaults: ((p 2^d + 2^(d + 5)) >> (d + 6)) = (p + 32) >> 6 and the mean likewise
+    const bool wtd = sh.weighted && (((m.ref[0] >= 0) && ((sh.wt_explicit >> m.ref[0]) & 1)) || ((m.ref[1] >= 0) && ((sh.wt_explicit >> (16 + m.ref[1])) & 1)));
+    B4Rec r; r.mvx = m.mv[P][0]; r.mvy = m.mv[P][1]; r.ref_idx = m.ref[P]; r.flags = (uint8_t)((cu_bypass ? B4_BYPASS : 0) | (bi ? B4_BI : 0) | (wtd ? B4_WT : 0)); r.qp_y = (int8_t)qp_y;
     r.slot = P ? job.ref_slot1[m.ref[1]] : job.ref_slot[m.ref[0]];
     fill_recs(xp, yp, bw, bh, r, bw == ncbs && bh == ncbs);
     B4L1 x; x.mvx = m.mv[1][0]; x.mvy = m.mv[1][1]; x.slot = bi ? job.ref_slot1[m.ref[1]] : 0; x.pad[0] = (uint8_t)(P * 16 + m.ref[P]); x.pad[1] = (uint8_t)(bi ? 16 + m.ref[1] : 0); x.pad[2] = 0;
     const int cols = imin(bw, w - xp) >> 2;
-    const bool ext = bi || sh.weighted;                    // the block has an entry in b4x[]
+    const bool ext = bi || wtd;                            // the block has an entry in b4x[]
     for (int y = yp; y < yp + bh && y < h; y += 4) { const int i0 = bi_(xp, y); for (int i = 0; i < cols; i++) { mvf[i0 + i] = m; if (ext) job.b4x[(size_t)(i0 + i)] = x; } }
     if (ext) job.any_bi.store(1, std::memory_order_relaxed);
     if (bw != ncbs || bh != ncbs) {                          // prediction block edges inside the coding block (deblocking)
@@ -736,9 +738,9 @@ struct SliceParser {
       const int bot = imax(yp + bh + (mvy >> 2) + (fy ? 4 : 0), 2 * ((yp >> 1) + (bh >> 1) + (mvy >> 3) + (fc ? 2 : 0)));
       if (top < ref_y0 || bot > ref_y1) err = DEC_ERR_UNSUPPORTED;
     }
-    B4Rec r; r.mvx = (int16_t)mvx; r.mvy = (int16_t)mvy; r.ref_idx = (int8_t)ref_idx; r.flags = (uint8_t)((cu_bypass ? B4_BYPASS : 0) | (sh.weighted ? B4_WT : 0)); r.qp_y = (int8_t)qp_y; r.slot = job.ref_slot[ref_idx];
+    B4Rec r; r.mvx = (int16_t)mvx; r.mvy = (int16_t)mvy; r.ref_idx = (int8_t)ref_idx; r.flags = (uint8_t)((cu_bypass ? B4_BYPASS : 0) | ((sh.weighted && ((sh.wt_explicit >> ref_idx) & 1)) ? B4_WT : 0)); r.qp_y = (int8_t)qp_y; r.slot = job.ref_slot[ref_idx];
     fill_recs(xp, yp, bw, bh, r, bw == ncbs && bh == ncbs);
-    if (sh.weighted) {                                       // explicit weights: the block's table entry rides where B pictures keep their second vectors
+    if (r.flags & B4_WT) {                                       // explicit weights: the block's table entry rides where B pictures keep their second vectors
       B4L1 x; x.mvx = 0; x.mvy = 0; x.slot = 0; x.pad[0] = (uint8_t)ref_idx; x.pad[1] = x.pad[2] = 0;
       const int cols = imin(bw, w - xp) >> 2;
       for (int y = yp; y < yp + bh && y < h; y += 4) { const int i0 = bi(xp, y); for (int i = 0; i < cols; i++) job.b4x[(size_t)(i0 + i)] = x; }
@@ -1612,6 +1614,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
         }
       }
       if (r.err) return DEC_ERR_INVALID;
+      for (int k = 0; k < 32; k++) { const DecWt &e = sh.wt[k]; if (e.w[0] != (1 << ld) || e.w[1] != (1 << cd) || e.w[2] != (1 << cd) || e.o[0] || e.o[1] || e.o[2]) sh.wt_explicit |= 1u << k; }
     }
     sh.max_merge = 5 - (int)r.ue();
     if (sh.max_merge < 1 || sh.max_merge > 5) return DEC_ERR_INVALID;
@@ -1655,7 +1658,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
         sh.slice_qp != a.slice_qp || sh.cb_qp_offset != a.cb_qp_offset || sh.cr_qp_offset != a.cr_qp_offset || sh.deblock_disabled != a.deblock_disabled ||
         sh.beta_offset_div2 != a.beta_offset_div2 || sh.tc_offset_div2 != a.tc_offset_div2 || !across_slices ||
         memcmp(sh.list_mod, a.list_mod, 2) || memcmp(sh.list_entry, a.list_entry, sizeof(sh.list_entry)) ||
-        sh.weighted != a.weighted || (sh.weighted && (memcmp(sh.wt, a.wt, sizeof(sh.wt)) || sh.wt_log2[0] != a.wt_log2[0] || sh.wt_log2[1] != a.wt_log2[1]))) return DEC_ERR_UNSUPPORTED;
+        sh.wt_explicit != a.wt_explicit || sh.weighted != a.weighted || (sh.weighted && (memcmp(sh.wt, a.wt, sizeof(sh.wt)) || sh.wt_log2[0] != a.wt_log2[0] || sh.wt_log2[1] != a.wt_log2[1]))) return DEC_ERR_UNSUPPORTED;
     return append_segment(*open_job, r.pos, rbsp, len, p, pp, wc, hc, seg_address, pts);
   }
   if (!sh.is_intra && !seen_irap_) return DEC_ERR_INVALID;       // nothing to predict from before the first random access point

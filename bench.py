@@ -15,6 +15,9 @@ What the one JSON line carries besides `value` (every leg can be switched off):
   secondary        the 4K workload (BASELINE configs[2], the north-star target), with its own host_boundary
   default_mode     uvgComm's own default settings for the size (preset veryfast, 1 Mbit/s)
   all_intra        every picture an IDR (BASELINE configs[0] on the GPU path): the intra chains' rate
+  uvgcomm_defaults the same boundary with NO custom parameter and uvgComm's default OWF / threads (what an unmodified uvgComm.ini gets)
+  latency_us       encoding delay and total delay per picture (p50 / p99) at a camera-paced source, at uvgComm's defaults and at the throughput setting
+  bounds           the flat and noise clips of SURVEY 8(d): frames/s, bits per picture
   roofline         the dominant kernel against the HBM peak (+ every kernel's fraction), cpu_baseline: oracle/ on all host cores
 
 --gpus N (N > 1) without a torch.distributed environment: this process launches N fresh rank processes (before anything
@@ -36,7 +39,7 @@ sys.path.insert(0, ROOT)
 from tools.benchkit import workloads as W                                                            # noqa: E402
 from tools.benchkit.workloads import PERIOD, WORKLOADS, HOST_CUSTOM, stream_seed                    # noqa: E402,F401
 from tools.benchkit.host import StreamRanks, launch_ranks, cpu_budget, cpu_baseline, cpu_worker     # noqa: E402,F401
-from tools.benchkit.stream import run_stream, multi_stream                                          # noqa: E402
+from tools.benchkit.stream import run_stream, multi_stream, latency_run                                          # noqa: E402
 from tools.benchkit.report import roofline_of                                                       # noqa: E402
 from tools.benchkit.tilesplit_bench import tilesplit_main                                           # noqa: E402
 
@@ -51,7 +54,8 @@ BOUNDARY_TEXT = (
 VALUE_IS = (
     "median run of `repeats`; pictures enter RESIDENT IN HBM and the decoded pictures stay there (the bench contract: inputs in HBM "
     "when the timed region starts) -- the rate through the reference's own host-in / host-out boundary (BASELINE.md: upload included) "
-    "is `host_boundary.value`, measured by the same command")
+    "is `host_boundary.value`, and the rate an unmodified uvgComm.ini gets (no custom parameter, default OWF / threads) `uvgcomm_defaults.value`: the "
+    "three stand side by side in `rates`, all measured by this one command")
 
 
 def parse_args():
@@ -71,6 +75,9 @@ def parse_args():
                     help="extra kvazaar option for the encoder of every leg (uvgComm's custom-parameter list, kvazaarfilter.cpp:355-368)")
     ap.add_argument("--no-preset-line", action="store_true", help="skip the `default_mode` leg (preset veryfast, 1 Mbit/s: defaultsettings.cpp:287-316)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the `latency_us` legs (paced source, uvgComm's OWF / thread defaults)")
+    ap.add_argument("--no-bounds", action="store_true", help="skip the `bounds` leg (the flat and noise clips of SURVEY 8(d))")
+    ap.add_argument("--latency-fps", type=int, default=60, help="source rate of the latency legs (pictures per second)")
     ap.add_argument("--no-split-decode", action="store_true", help="8k-tilesplit: skip the split decoder's leg (reported as `secondary`)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 4K line (configs[2]) that a 1080p run appends as `secondary`")
     ap.add_argument("--secondary-steps", type=int, default=8)
@@ -128,11 +135,13 @@ def secondary_leg(args, ranks, rank, world):
     except Exception as e:                           # noqa: BLE001
         return {"workload": WORKLOADS["4k"]["name"], "error": str(e)}
     hostb = None if args.no_host_boundary else host_leg(args, ranks, rank, world, WORKLOADS["4k"], steps, 1, sec["pictures"] / sec["elapsed"])
+    lat = None if args.no_latency else latency_leg(args, ranks, WORKLOADS["4k"], 30, 64)
+    bare = None if args.no_host_boundary else uvgcomm_default_leg(args, ranks, rank, world, WORKLOADS["4k"], 1)
     roof, kern, _ = roofline_of(sec, steps, args.me_range, "4k")
     return {"workload": WORKLOADS["4k"]["name"], "value": round(sec["pictures"] / sec["elapsed"], 3), "unit": "frames/s",
             "steps": steps, "pictures_per_step": PERIOD, "ms_per_step": round(sec["elapsed"] / steps * 1e3, 4),
             "bits_per_picture": round(8 * sec["bytes_per_picture"], 1), "psnr_y": sec["psnr_y"], "runs_fps": sec["runs_fps"],
-            "host_boundary": hostb, "host_cpu_cores_busy": round(sec["host_cores"], 2), "roofline": roof, "kernels_us": kern}
+            "host_boundary": hostb, "uvgcomm_defaults": bare, "latency_us": lat, "host_cpu_cores_busy": round(sec["host_cores"], 2), "roofline": roof, "kernels_us": kern}
 
 
 def default_mode_leg(args, ranks, rank, world, wl):
@@ -159,6 +168,64 @@ def all_intra_leg(args, ranks, rank, world, wl):
     kt = {k: round(v[0] / v[1] * 1e3, 2) for k, v in m["kt"].items() if v[1]}
     return {"settings": {"video/Intra": 1}, "value": round(m["pictures"] / m["elapsed"], 3), "unit": "frames/s", "pictures": m["pictures"], "runs_fps": m["runs_fps"],
             "bits_per_picture": round(8 * m["bytes_per_picture"], 1), "psnr_y": m["psnr_y"], "host_cpu_cores_busy": round(m["host_cores"], 2), "kernels_us": kt}
+
+
+# uvgComm's own operating points for threads / OWF (defaultsettings.cpp:182-237: up to 16 hardware threads OWF 0, 1..4 OpenHEVC threads of type "Slice";
+# more: OWF 1-2) beside the setting the throughput legs run at
+LATENCY_POINTS = (
+    ("uvgcomm_default_owf0", {"video/OWF": 0, "video/OPENHEVC_threads": 4, "video/OH_parallelization": "Slice"}, (), 0),
+    ("uvgcomm_owf2", {"video/OWF": 2, "video/OPENHEVC_threads": 4, "video/OH_parallelization": "Slice"}, (), 2),
+    ("throughput_setting", None, HOST_CUSTOM, None),
+)
+
+
+def latency_leg(args, ranks, wl, source_fps, npic=96):
+    """`latency_us`: what uvgComm shows its user -- encoding delay (kvazaarfilter.cpp:478-479) and total delay (displayfilter.cpp:113-115) -- per picture in
+    microseconds, p50 / p99, at a camera-paced source through the reference's own host boundary, for uvgComm's default thread / OWF settings (no custom
+    parameter) and for the setting the throughput legs use (owf, frame threads, the two custom parameters)"""
+    out = {"source_fps": source_fps, "boundary": "host I420 in, decoded I420 out into host memory; the source hands over one picture every 1/source_fps s"}
+    for name, st, custom, tail in LATENCY_POINTS:
+        if st is None:
+            D = max(1, args.decoder_frame_threads or 32)
+            st = {"video/OWF": args.owf, "video/OPENHEVC_threads": D, "video/OH_parallelization": "Frame"}
+            tail = args.owf + D
+        custom = tuple(custom) + ((("me-range", args.me_range),) if args.me_range != 16 else ()) + ((("gpu", ranks.dev_index),) if ranks.dev_index else ())
+        try:
+            r = latency_run(args, wl, ranks, st, custom, source_fps, npic if tail < npic // 2 else npic + tail, tail)
+            r["settings"] = st; r["custom_parameters"] = dict(custom)
+            out[name] = r
+        except Exception as e:                       # noqa: BLE001
+            out[name] = {"error": str(e)}
+    return out
+
+
+def uvgcomm_default_leg(args, ranks, rank, world, wl, steps):
+    """the rate an UNMODIFIED uvgComm.ini gets: no custom parameter (encoder_encode(NULL) waits for the oldest picture, Kvazaar's meaning: the loop at
+    kvazaarfilter.cpp:440-448 empties the pipeline after every input; the reconstruction is returned as :435-448,476 expect), uvgComm's default threads
+    for a 16-thread host (defaultsettings.cpp:206-214: OWF 0, four OpenHEVC threads of type "Slice"), host I420 in and out"""
+    st = {"video/OWF": 0, "video/OPENHEVC_threads": 4, "video/OH_parallelization": "Slice"}
+    try:
+        m = run_stream(args, wl, steps, 1, ranks, rank, world, quality=False, host_io=True, extra_settings=st, bare=True, repeats=1)
+    except Exception as e:                           # noqa: BLE001
+        return {"error": str(e)}
+    return {"value": round(world * m["pictures"] / m["elapsed"], 3), "unit": "frames/s", "settings": st, "custom_parameters": {},
+            "host_cpu_cores_busy": round(m["host_cores"], 2),
+            "what": "host I420 -> KvazaarFilter' -> WireAdapter' -> OpenHEVCFilter' -> host I420 with uvgComm's default settings and an empty custom-parameter list; "
+                    "one picture in flight at a time (OWF 0, synchronous decoder)"}
+
+
+def bounds_leg(args, ranks, rank, world, wl):
+    """SURVEY 8(d)'s bound clips through the headline path (resident input, the headline's settings): `flat` (all samples 128: everything skipped) and
+    `noise` (iid bytes: every block searched, dense coefficients) -- frames/s and bits per picture"""
+    out = {}
+    for kind, name in ((1, "flat"), (2, "noise")):
+        try:
+            m = run_stream(args, wl, 2, 1, ranks, rank, world, quality=False, extra_custom=RESIDENT, kind=kind, repeats=1)
+            out[name] = {"value": round(world * m["pictures"] / m["elapsed"], 3), "unit": "frames/s", "bits_per_picture": round(8 * m["bytes_per_picture"], 1),
+                         "host_cpu_cores_busy": round(m["host_cores"], 2), "kernels_us": {k: round(v[0] / v[1] * 1e3, 2) for k, v in m["kt"].items() if v[1]}}
+        except Exception as e:                       # noqa: BLE001
+            out[name] = {"error": str(e)}
+    return out
 
 
 def valu_roofline(args, m):
@@ -212,6 +279,10 @@ def main():
                 multi.append(leg)
             except Exception as e:                   # noqa: BLE001
                 multi.append({"streams": k, "error": str(e)})
+    side = single and not args.host_io
+    bare = uvgcomm_default_leg(args, ranks, rank, world, wl, 2) if side and not args.no_host_boundary else None
+    lat = latency_leg(args, ranks, wl, args.latency_fps) if side and not args.no_latency else None
+    bounds = bounds_leg(args, ranks, rank, world, wl) if side and not args.no_bounds else None
     sec = secondary_leg(args, ranks, rank, world) if headline_1080p else None
     preset_line = default_mode_leg(args, ranks, rank, world, wl) if headline_1080p and not args.no_preset_line else None
     intra_line = all_intra_leg(args, ranks, rank, world, wl) if headline_1080p and not args.no_preset_line else None
@@ -238,7 +309,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(m["elapsed"] / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": config,
+            "rates": {"resident": round(fps, 3), "host_boundary": (hostb or {}).get("value"), "uvgcomm_defaults": (bare or {}).get("value"), "unit": "frames/s",
+                      "note": "`value` = resident (the bench contract: inputs in HBM when the timed region starts); host_boundary = the reference's host-in / host-out "
+                              "boundary with the two custom parameters; uvgcomm_defaults = the same boundary with uvgComm's default settings and no custom parameter"},
             "host_boundary": hostb,
+            "uvgcomm_defaults": bare,
+            "latency_us": lat,
+            "bounds": bounds,
             "streams_per_gpu": multi,
             "default_mode": preset_line,
             "all_intra": intra_line,

@@ -158,6 +158,11 @@ KVZ_PUBLIC int uvgx_pipeline_pop_decoded(void *p, uint8_t *buf, uint32_t cap, ui
 KVZ_PUBLIC void uvgx_pipeline_stats(void *p, uint64_t *out8);
 KVZ_PUBLIC void uvgx_pipeline_busy_ms(void *p, double *out3);   /* time inside process(): encoder, wire adapter, decoder filter */
 KVZ_PUBLIC void uvgx_pipeline_avg_queue(void *p, double *out3); /* inputs found buffered by an arriving input, averaged: encoder, wire adapter, decoder filter */
+/* per-picture delays in microseconds (what uvgComm's statistics window shows: kvazaarfilter.cpp:478-479 encoding delay, displayfilter.cpp:113-115 total
+   delay).  which 0: picture pushed -> access unit out of the encoder filter; 1: -> decoded picture out of the last filter.  Returns the samples held since
+   the last reset (up to `cap` copied, in output order). */
+KVZ_PUBLIC uint32_t uvgx_pipeline_latency_us(void *p, int which, uint32_t *out, uint32_t cap, int reset);
+KVZ_PUBLIC void uvgx_pipeline_delay_stats(void *p, double *out8);  /* the filters' own histograms: count, mean, p50, p99 of the encoding delay; the same of the total delay */
 KVZ_PUBLIC void *uvgx_pipeline_encoder(void *p);     /* kvz_encoder* of the KvazaarFilter */
 KVZ_PUBLIC void *uvgx_pipeline_decoder(void *p);     /* OpenHevc_Handle of the OpenHEVCFilter (NULL without loop-back) */
 KVZ_PUBLIC void uvgx_pipeline_destroy(void *p);

@@ -62,7 +62,8 @@ class DecBatcher {
   void run();
   void launch(DecBatchItem *items, int n);
   int device_;
-  bool enabled_ = true;
+  bool enabled_ = true, configured_ = true;    // configured_: KVAZZUP_AMD_BATCH and shared role streams; enabled_: that, and every attached decoder on one stream
+  std::mutex life_;                            // attach / detach, whole calls
   std::atomic<int> users_{0};
   hipStream_t stream_ = nullptr;
   std::mutex m_; std::condition_variable cv_, idle_cv_;

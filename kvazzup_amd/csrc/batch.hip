@@ -19,32 +19,38 @@ DecBatcher &DecBatcher::get(int device)
   if (!b) {
     b = new DecBatcher(device);
     const char *e = getenv("KVAZZUP_AMD_BATCH");
-    b->enabled_ = !(e && e[0] == '0') && StreamPool::get().share;      // (without shared role streams every decoder has a stream of its own: nothing to batch on)
+    b->configured_ = !(e && e[0] == '0') && StreamPool::get().share;      // (without shared role streams every decoder has a stream of its own: nothing to batch on)
+    b->enabled_ = b->configured_;
   }
   return *b;
 }
 
+// attach / detach are serialised by life_ from their first to their last line: a decoder that opens while the last one is closing waits until the
+// old submitter thread has been joined and quit_ is clear again (it used to be able to start a thread that still saw quit_, launched what was queued
+// and left -- running_ true, nobody behind it, every later picture waiting for ever in complete_gpu).
 void DecBatcher::attach(hipStream_t st)
 {
+  std::lock_guard<std::mutex> life(life_);
   std::lock_guard<std::mutex> l(m_);
-  if (users_.load() == 0) stream_ = st;
+  if (users_.load() == 0) { stream_ = st; enabled_ = configured_; }      // (a mismatch among earlier users is forgotten once all of them have closed)
   else if (st != stream_) enabled_ = false;            // decoders on different streams (priority levels set apart by hand): every one launches for itself
   users_.fetch_add(1);
 }
 
 void DecBatcher::detach()
 {
+  std::lock_guard<std::mutex> life(life_);
   std::thread t;
   {
     std::unique_lock<std::mutex> l(m_);
     if (users_.fetch_sub(1) != 1) return;
-    // the last decoder of the device closes: the submitter thread goes with it
+    // the last decoder of the device closes: the submitter thread goes with it (nobody can submit: no decoder is attached, none can attach before this returns)
     quit_ = true; cv_.notify_all();
-    t = std::move(th_); running_ = false;
+    t = std::move(th_);
   }
   if (t.joinable()) t.join();
   std::lock_guard<std::mutex> l(m_);
-  quit_ = false;
+  quit_ = false; running_ = false;
   hipSetDevice(device_);
   for (auto &p : prof_) for (int k = 0; k < BK_COUNT; k++) { if (p.a[k]) { hipEventDestroy(p.a[k]); hipEventDestroy(p.b[k]); p.a[k] = p.b[k] = nullptr; } p.pending = false; }
   inflight_.clear();

@@ -25,6 +25,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -271,6 +272,10 @@ class Decoder {
   long nal_calls_ = 0;
   std::deque<std::pair<long, uint8_t *>> retired_out_;      // (call count at retirement, page-locked buffer)
   std::deque<std::pair<long, OwnedPic>> retired_owned_;
+  // device buffers of OwnedPic copies, kept for the next picture of the same size (queue_current_output)
+  static constexpr size_t kOwnedPoolMax = 24;
+  std::vector<std::pair<size_t, uint8_t *>> owned_pool_; std::map<const uint8_t *, size_t> owned_bytes_; hipEvent_t owned_ev_ = nullptr;
+  uint8_t *owned_alloc(size_t bytes); void owned_release(uint8_t *p); bool stash_current_output();
   void free_retired(bool all);
   int decode_nal_inner(const uint8_t *data, size_t len, int64_t pts);
   bool queue_current_output();

@@ -1011,6 +1011,8 @@ Decoder::~Decoder()
   for (auto &o : ready_q_) if (o.dev) hipFree(o.dev);
   for (auto &w : reorder_q_) if (w.pic.dev) hipFree(w.pic.dev);
   if (cur_owned_.dev) hipFree(cur_owned_.dev);
+  for (auto &b : owned_pool_) hipFree(b.second);
+  if (owned_ev_) hipEventDestroy(owned_ev_);
   if (stream_dl_ != stream_up_) stream_release(stream_dl_, device_, 'L', 'l');
   stream_release(stream_up_, device_, 'U', prio_up_);
   for (auto &e : up_done_) if (e) hipEventDestroy(e);
@@ -1097,8 +1099,9 @@ bool Decoder::ensure_buffers(int w, int h)
   // following calls hand it out one picture at a time, as a software decoder's bumping process would -- before the buffers go
   while (w_ && (!gpu_q_.empty() || job_tail_ != job_head_)) {      // (a band decoder's picture between its reconstruction and band_finish -- gpu_job_ -- is not finish_oldest's to complete: drop_pending below lets it go)
     const int rc = finish_oldest();
-    if (rc < 0 || (rc > 0 && pic_ready_ && !queue_current_output())) { drop_pending(); break; }
+    if (rc < 0 || (rc > 0 && pic_ready_ && !stash_current_output())) { drop_pending(); break; }
   }
+  while (w_ && pop_reordered(true)) {}                     // a new sequence follows: what waited for later pictures of the old one leaves in POC order, one picture per call
   drop_pending();
   sync_main();
   free_buffers();
@@ -1179,7 +1182,7 @@ void Decoder::get_kernel_times(double *ms, uint64_t *launches, bool reset)
 void Decoder::free_retired(bool all)
 {
   while (!retired_out_.empty() && (all || nal_calls_ - retired_out_.front().first > kOutHold)) { hipHostFree(retired_out_.front().second); retired_out_.pop_front(); }
-  while (!retired_owned_.empty() && (all || nal_calls_ - retired_owned_.front().first > kOutHold)) { if (retired_owned_.front().second.dev) hipFree(retired_owned_.front().second.dev); retired_owned_.pop_front(); }
+  while (!retired_owned_.empty() && (all || nal_calls_ - retired_owned_.front().first > kOutHold)) { if (all) { if (retired_owned_.front().second.dev) hipFree(retired_owned_.front().second.dev); } else owned_release(retired_owned_.front().second.dev); retired_owned_.pop_front(); }
 }
 
 int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
@@ -1191,13 +1194,19 @@ int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
   // it completes and waits in reorder_q_; the smallest POC of the oldest coded video sequence goes out once more pictures wait than may overtake it,
   // or a later sequence has begun, or the stream has ended (EOS / EOB with nothing left in the pipeline).  One picture per call, as ever.
   if (rc >= 0 && ((pic_ready_ && out_.num_reorder > 0) || !reorder_q_.empty())) {
-    if (pic_ready_) {
+    if (pic_ready_ && out_.num_reorder == 0) {
+      // a sequence that does not reorder behind one that did: everything still waiting precedes this picture -- all of it moves to ready_q_ at once
+      // (in order), the picture behind it; every later call, parameter sets included, hands one out, so the lag the old sequence needed drains
+      // instead of staying until the end of the stream
+      while (pop_reordered(true)) {}
+      if (!queue_current_output()) return last_error_ = DEC_ERR_GPU;
+    } else if (pic_ready_) {
       const int cvs = out_.cvs; reorder_ = out_.num_reorder;
       if (!queue_current_output()) return last_error_ = DEC_ERR_GPU;
       reorder_q_.push_back(Waiting{std::move(ready_q_.back()), cvs}); ready_q_.pop_back();
     }
     const bool eos = len >= 2 && [&] { size_t i = 0; while (i + 2 < len && data[i] == 0) i++; const uint8_t *q = (i >= 2 && i < len && data[i] == 1) ? data + i + 1 : data; const int t = (q[0] >> 1) & 0x3f; return t == 36 || t == 37; }();
-    if (!pop_reordered(eos && pending() == 0)) return 0;
+    if (ready_q_.empty() && !pop_reordered(eos && pending() == 0)) return 0;
   } else {
   if (ready_q_.empty()) return rc;
   if (rc < 0) return rc;
@@ -1236,7 +1245,26 @@ bool Decoder::pop_reordered(bool flush)
   return true;
 }
 
-// the picture complete_gpu() just made the output, copied into storage of its own at the end of the queue
+// the picture complete_gpu() just made the output, copied into storage of its own at the end of the queue.  The device copy comes from a small pool
+// of buffers (a hipMalloc / hipFree per picture of a reordering stream synchronised the whole device -- every other encoder and decoder of the
+// process with it) and is made by the download stream, which this thread waits for by event.
+uint8_t *Decoder::owned_alloc(size_t bytes)
+{
+  for (size_t i = 0; i < owned_pool_.size(); i++) if (owned_pool_[i].first == bytes) { uint8_t *p = owned_pool_[i].second; owned_pool_.erase(owned_pool_.begin() + (long)i); return p; }
+  if (!owned_pool_.empty()) { owned_bytes_.erase(owned_pool_.front().second); hipFree(owned_pool_.front().second); owned_pool_.erase(owned_pool_.begin()); }      // (another size: the stream changed its resolution -- the oldest stale buffer goes)
+  uint8_t *p = nullptr;
+  if (hipSetDevice(device_) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  owned_bytes_[p] = bytes;
+  return p;
+}
+void Decoder::owned_release(uint8_t *p)
+{
+  if (!p) return;
+  auto it = owned_bytes_.find(p);
+  if (it != owned_bytes_.end() && owned_pool_.size() < kOwnedPoolMax) { owned_pool_.emplace_back(it->second, p); return; }
+  if (it != owned_bytes_.end()) owned_bytes_.erase(it);
+  hipFree(p);
+}
 bool Decoder::queue_current_output()
 {
   OwnedPic o;
@@ -1250,17 +1278,32 @@ bool Decoder::queue_current_output()
   {
     // the device view: a dense copy (pitch = width), so that device-resident consumers keep working across the re-allocation
     const size_t ny = (size_t)out_.width * out_.height;
-    if (hipMalloc(&o.dev, ny * 3 / 2) != hipSuccess) return false;
+    o.dev = owned_alloc(ny * 3 / 2);
+    if (!o.dev) return false;
     size_t off = 0;
+    hipStream_t st = stream_dl_ ? stream_dl_ : stream_;
     for (int c = 0; c < 3; c++) {
       const int w = c ? out_.width / 2 : out_.width, h = c ? out_.height / 2 : out_.height;
-      if (hipMemcpy2D(o.dev + off, (size_t)w, out_.dev[c], (size_t)out_.dev_pitch[c], (size_t)w, (size_t)h, hipMemcpyDeviceToDevice) != hipSuccess) { hipFree(o.dev); return false; }
+      if (hipMemcpy2DAsync(o.dev + off, (size_t)w, out_.dev[c], (size_t)out_.dev_pitch[c], (size_t)w, (size_t)h, hipMemcpyDeviceToDevice, st) != hipSuccess) { owned_release(o.dev); return false; }
       o.pic.dev[c] = o.dev + off; o.pic.dev_pitch[c] = w;
       off += (size_t)w * h;
     }
+    // (the picture's kernels are complete -- complete_gpu saw its event --, so the copies depend on nothing in another stream)
+    if (!owned_ev_ && hipEventCreateWithFlags(&owned_ev_, hipEventDisableTiming) != hipSuccess) { owned_release(o.dev); return false; }
+    if (hipEventRecord(owned_ev_, st) != hipSuccess || hipEventSynchronize(owned_ev_) != hipSuccess) { owned_release(o.dev); return false; }
   }
   ready_q_.push_back(std::move(o));
   pic_ready_ = false;
+  return true;
+}
+
+// queue_current_output() for a picture completed AHEAD of its turn (the ring emptied at a resolution change, a picture closed by the next one's first
+// NAL unit): a stream that reorders keeps its output order -- the picture joins reorder_q_ with its sequence and POC like any other.
+bool Decoder::stash_current_output()
+{
+  const int cvs = out_.cvs, nr = out_.num_reorder;
+  if (!queue_current_output()) return false;
+  if (nr > 0 || !reorder_q_.empty()) { if (nr > 0) reorder_ = nr; reorder_q_.push_back(Waiting{std::move(ready_q_.back()), cvs}); ready_q_.pop_back(); }
   return true;
 }
 
@@ -1498,7 +1541,7 @@ int Decoder::close_open_picture()
     old.seg_end_row[0] = 0; old.seg_end_row[(size_t)(old_hc - 1)] = 1;
     const int rc = submit_job(old, asm_nal_type_, asm_irap_);
     if (rc < 0) { last_error_ = rc; return 0; }
-    if (rc > 0 && pic_ready_ && !queue_current_output()) return last_error_ = DEC_ERR_GPU;     // (handed out first, by the next call: the NAL unit at hand may produce a picture of its own)
+    if (rc > 0 && pic_ready_ && !stash_current_output()) return last_error_ = DEC_ERR_GPU;     // (handed out first, by the next call: the NAL unit at hand may produce a picture of its own)
     return 0;
   }
   last_error_ = DEC_ERR_INVALID;
@@ -2229,7 +2272,8 @@ int Decoder::launch_gpu(PicJob &job)
     if (++chain_gen_ >= (1u << 24)) {
       const size_t nctu = (size_t)(pw_ / 64) * (ph_ / 64);
       sync_main();                                         // (everything this decoder has submitted has run: nothing reads the words while they are cleared)
-      if (hipMemset(edge_col_, 0, nctu * 128 * sizeof(uint32_t)) != hipSuccess || hipMemset(edge_row_, 0, nctu * 32 * 8) != hipSuccess) return DEC_ERR_GPU;
+      // (on the consuming stream: the decoder's streams are non-blocking, nothing would order the next chain behind a clear on the null stream)
+      if (hipMemsetAsync(edge_col_, 0, nctu * 128 * sizeof(uint32_t), stream_) != hipSuccess || hipMemsetAsync(edge_row_, 0, nctu * 32 * 8, stream_) != hipSuccess) return DEC_ERR_GPU;
       chain_gen_ = 1;
     }
     f.chain_gen = chain_gen_;

@@ -691,10 +691,12 @@ void Encoder::tok_launcher()
     { std::unique_lock<std::mutex> l(tm_); tcv_.wait(l, [&] { return tquit_ || !tq_.empty(); }); if (tq_.empty()) return; idx = tq_.front(); tq_.pop_front(); }
     Slot &sl = slot_[idx];
     hipEvent_t e = ev_src_free_[sl.set];                   // recorded behind the chain's last kernel (k_sao); not recorded again before this picture has been collected (owf < kSets)
-    nap_until([&] { hipError_t r = hipEventQuery(e); return r == hipSuccess ? 1 : (r == hipErrorNotReady ? 0 : -1); });
+    const bool chain_ok = nap_until([&] { hipError_t r = hipEventQuery(e); return r == hipSuccess ? 1 : (r == hipErrorNotReady ? 0 : -1); });
     tl("tok0", sl.pic_idx);
-    sl.tok_failed = !launch_tokenizer(sl, sl.f_tok, sl.intra, false, sl.prof);      // (finish_slot then fails the picture instead of coding whatever the slot held before)
-    if (sl.tok_failed) fprintf(stderr, "kvazzup_amd: the tokenizer of picture %ld could not be launched\n", sl.pic_idx);
+    // (a failed query -- device fault, the chain's last kernel failed -- means the CU and SAO arrays are not final: the picture fails like one whose
+    // tokenizer could not be launched, finish_slot never codes what the slot held)
+    sl.tok_failed = !chain_ok || !launch_tokenizer(sl, sl.f_tok, sl.intra, false, sl.prof);
+    if (sl.tok_failed) fprintf(stderr, chain_ok ? "kvazzup_amd: the tokenizer of picture %ld could not be launched\n" : "kvazzup_amd: the kernels of picture %ld failed; it is not entropy coded\n", sl.pic_idx);
     { std::lock_guard<std::mutex> l(bm_); bq_.push_back(idx); }
     bcv_.notify_all();
   }

@@ -48,6 +48,9 @@ struct Data {
   std::unique_ptr<uint8_t[]> data;
   uint32_t data_size = 0;
   int64_t creationTimestamp = -1, presentationTimestamp = -1;
+  // extension: creationTimestamp at microsecond resolution on the steady clock (the reference's field is whole milliseconds of wall time,
+  // filter.cpp initializeData): what the delay statistics below are computed from; travels with the picture through encoder, wire and decoder
+  int64_t creationUs = -1;
   std::unique_ptr<VideoInfo> vInfo;
   // extension (not in the reference): picture already resident in HBM (packed I420); data stays empty
   const void *device_data = nullptr;
@@ -60,14 +63,25 @@ struct Data {
   bool flush_marker = false;
 };
 
+// delays in microseconds as a histogram: bucket b holds delays in [16 * 2^(b/4), 16 * 2^((b+1)/4)) us -- quarter octaves from 16 us to ~1 s
+struct DelayHist {
+  static constexpr int kBuckets = 64;
+  std::atomic<uint64_t> n[kBuckets] = {}, count{0}, sumUs{0}, maxUs{0};
+  void add(int64_t us);
+  double percentile(double q) const;                 // upper edge of the bucket that holds the q-quantile (q in 0..1), us
+};
 // Counterpart of StatisticsInterface (src/statisticsinterface.h:40,52,59): only what the two filters report
 struct Stats {
   std::atomic<uint64_t> encodedPackets{0}, encodedBytes{0}, receivedPackets{0}, receivedBytes{0}, droppedPackets{0};
   std::atomic<uint64_t> encodingDelaySumMs{0};
+  // what uvgComm shows its user (kvazaarfilter.cpp:478-479 addEncodedPacket's delay; displayfilter.cpp:113-115 totalDelay), here per picture in us:
+  // input accepted by the encoder filter -> access unit sent on; -> decoded picture leaving the decoder filter
+  DelayHist encodingDelayUs, totalDelayUs;
 };
 
 using Settings = std::map<std::string, std::string>;
 int64_t now_ms();
+int64_t now_us();                                   // steady clock
 
 class Filter {
  public:

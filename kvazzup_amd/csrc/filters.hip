@@ -14,6 +14,38 @@ int64_t now_ms()
   return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
 }
 
+int64_t now_us()
+{
+  return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void DelayHist::add(int64_t us)
+{
+  if (us < 0) us = 0;
+  int b = 0;
+  if (us >= 16) {                                          // quarter octaves: 4 * log2(us / 16)
+    const int lg = 63 - __builtin_clzll((unsigned long long)us);      // floor(log2 us) >= 4
+    const uint64_t frac = ((uint64_t)us << 2 >> lg) & 3;               // the two bits below the leading one
+    b = (lg - 4) * 4 + (int)frac;
+    if (b >= kBuckets) b = kBuckets - 1;
+  }
+  n[b]++; count++; sumUs += (uint64_t)us;
+  uint64_t m = maxUs.load(std::memory_order_relaxed);
+  while ((uint64_t)us > m && !maxUs.compare_exchange_weak(m, (uint64_t)us, std::memory_order_relaxed)) {}
+}
+double DelayHist::percentile(double q) const
+{
+  const uint64_t total = count.load();
+  if (!total) return 0.0;
+  const uint64_t want = (uint64_t)(q * (double)(total - 1)) + 1;
+  uint64_t acc = 0;
+  for (int b = 0; b < kBuckets; b++) {
+    acc += n[b].load();
+    if (acc >= want) { const int lg = b / 4 + 4, fr = b % 4; return (double)(1ull << lg) * (1.0 + (fr + 1) / 4.0); }
+  }
+  return (double)maxUs.load();
+}
+
 // ----------------------------------------------------------------------------------------------- Filter
 Filter::Filter(std::string id, std::string name, Stats *stats, DataType input, DataType output)
     : id_(std::move(id)), name_(std::move(name)), stats_(stats), input_(input), output_(output) {}
@@ -95,7 +127,7 @@ Data *Filter::deepDataCopy(const Data *o)
 {
   Data *c = new Data;
   c->source = o->source; c->type = o->type; c->data_size = o->data_size;
-  c->creationTimestamp = o->creationTimestamp; c->presentationTimestamp = o->presentationTimestamp;
+  c->creationTimestamp = o->creationTimestamp; c->presentationTimestamp = o->presentationTimestamp; c->creationUs = o->creationUs;
   c->device_data = o->device_data; c->flush_marker = o->flush_marker; c->host_view = o->host_view;
   for (int i = 0; i < 3; i++) { c->device_planes[i] = o->device_planes[i]; c->device_pitch[i] = o->device_pitch[i]; }
   if (o->data) { c->data.reset(new uint8_t[o->data_size]); memcpy(c->data.get(), o->data.get(), o->data_size); }
@@ -305,7 +337,7 @@ void KvazaarFilter::feedInput(std::unique_ptr<Data> input) // kvazaarfilter.cpp:
     encodingFrames_.pop_back();
     std::unique_ptr<uint8_t[]> hevc_frame(new uint8_t[n]);
     memcpy(hevc_frame.get(), au_.data(), n);
-    if (getStats()) { getStats()->encodingDelaySumMs += (uint64_t)(now_ms() - info.data->creationTimestamp); getStats()->encodedPackets++; getStats()->encodedBytes += n; }
+    if (getStats()) { getStats()->encodingDelaySumMs += (uint64_t)(now_ms() - info.data->creationTimestamp); if (info.data->creationUs >= 0) getStats()->encodingDelayUs.add(now_us() - info.data->creationUs); getStats()->encodedPackets++; getStats()->encodedBytes += n; }
     sendEncodedFrame(std::move(info.data), std::move(hevc_frame), n);
     return;
   }
@@ -356,7 +388,7 @@ void KvazaarFilter::drain()
       encodingFrames_.pop_back();
       std::unique_ptr<uint8_t[]> hevc_frame(new uint8_t[n]);
       memcpy(hevc_frame.get(), au_.data(), n);
-      if (getStats()) { getStats()->encodingDelaySumMs += (uint64_t)(now_ms() - info.data->creationTimestamp); getStats()->encodedPackets++; getStats()->encodedBytes += n; }
+      if (getStats()) { getStats()->encodingDelaySumMs += (uint64_t)(now_ms() - info.data->creationTimestamp); if (info.data->creationUs >= 0) getStats()->encodingDelayUs.add(now_us() - info.data->creationUs); getStats()->encodedPackets++; getStats()->encodedBytes += n; }
       sendEncodedFrame(std::move(info.data), std::move(hevc_frame), n);
     } else {
       kvz_picture *recon_pic = nullptr; kvz_data_chunk *data_out = nullptr; uint32_t len_out = 0;
@@ -384,7 +416,7 @@ void KvazaarFilter::parseEncodedFrame(kvz_data_chunk *data_out, uint32_t len_out
   }
   api_->chunk_free(data_out);
   api_->picture_free(recon_pic);
-  if (getStats()) { getStats()->encodingDelaySumMs += (uint64_t)(now_ms() - info.data->creationTimestamp); getStats()->encodedPackets++; getStats()->encodedBytes += len_out; }
+  if (getStats()) { getStats()->encodingDelaySumMs += (uint64_t)(now_ms() - info.data->creationTimestamp); if (info.data->creationUs >= 0) getStats()->encodingDelayUs.add(now_us() - info.data->creationUs); getStats()->encodedPackets++; getStats()->encodedBytes += len_out; }
   sendEncodedFrame(std::move(info.data), std::move(hevc_frame), dataWritten);
 }
 
@@ -520,6 +552,7 @@ void OpenHEVCFilter::sendDecodedOutput(int &gotPicture)    // openhevcfilter.cpp
       for (int i = 0; i < 3; i++) { decodedFrame->device_planes[i] = planes[i]; decodedFrame->device_pitch[i] = pitches[i]; }
       decodedFrame->data.reset();
       decodedFrame->data_size = 0;
+      if (getStats() && decodedFrame->creationUs >= 0) getStats()->totalDelayUs.add(now_us() - decodedFrame->creationUs);
       sendOutput(std::move(decodedFrame));
       return;
     }
@@ -582,6 +615,7 @@ void OpenHEVCFilter::copyOut(OutJob &job)                  // the copy of openhe
     decodedFrame->data_size = finalDataSize;
     decodedFrame->data = std::move(yuv_frame);
     kvzx::tl("out1", (long)decodedFrame->presentationTimestamp);
+    if (getStats() && decodedFrame->creationUs >= 0) getStats()->totalDelayUs.add(now_us() - decodedFrame->creationUs);
     sendOutput(std::move(decodedFrame));
     kvzx::tl("out2", 0);
   }
@@ -614,7 +648,7 @@ void WireAdapter::process()
       nal->data_size = starts[k + 1] - starts[k];
       nal->data.reset(new uint8_t[nal->data_size]);
       memcpy(nal->data.get(), p + starts[k], nal->data_size);
-      nal->creationTimestamp = input->creationTimestamp;
+      nal->creationTimestamp = input->creationTimestamp; nal->creationUs = input->creationUs;
       nal->presentationTimestamp = input->presentationTimestamp;
       nal->vInfo.reset(new VideoInfo);                     // resolution unknown until decoded (filter.cpp initializeData)
       sendOutput(std::move(nal));
@@ -676,6 +710,7 @@ struct UvgxPipeline {
   std::mutex m; std::condition_variable cv;
   std::deque<std::unique_ptr<Data>> encoded, decoded;
   uint64_t n_encoded = 0, n_decoded = 0, decoded_bytes = 0;
+  std::vector<uint32_t> lat_enc, lat_total;              // per picture, us: pushed -> access unit out of the encoder filter; -> decoded picture out of the last filter
   bool keep = true, loopback = true;
 };
 
@@ -698,8 +733,10 @@ KVZ_PUBLIC void *uvgx_pipeline_create(const char *settings_text, int loopback_de
   if (!p->enc->init()) { delete p; return nullptr; }
   p->enc->addDataOutCallback([p](std::unique_ptr<Data> d) {
     if (d->flush_marker) return;
+    const int64_t lat = d->creationUs >= 0 ? now_us() - d->creationUs : -1;
     std::lock_guard<std::mutex> l(p->m);
     p->n_encoded++;
+    if (lat >= 0 && p->lat_enc.size() < (1u << 20)) p->lat_enc.push_back((uint32_t)(lat > 0xffffffffll ? 0xffffffffll : lat));
     if (p->keep) p->encoded.push_back(std::move(d));
     p->cv.notify_all();
   });
@@ -717,8 +754,10 @@ KVZ_PUBLIC void *uvgx_pipeline_create(const char *settings_text, int loopback_de
       last = p->rgb.get();
     }
     last->addDataOutCallback([p](std::unique_ptr<Data> d) {
+      const int64_t lat = d->creationUs >= 0 ? now_us() - d->creationUs : -1;
       std::lock_guard<std::mutex> l(p->m);
       p->n_decoded++; p->decoded_bytes += d->data_size;
+      if (lat >= 0 && p->lat_total.size() < (1u << 20)) p->lat_total.push_back((uint32_t)(lat > 0xffffffffll ? 0xffffffffll : lat));
       if (p->keep) p->decoded.push_back(std::move(d));
       p->cv.notify_all();
     });
@@ -734,7 +773,7 @@ static int push(UvgxPipeline *p, const uint8_t *host, const void *dev, int w, in
 {
   std::unique_ptr<Data> d(new Data);
   d->source = DS_LOCAL; d->type = DT_YUV420VIDEO;
-  d->creationTimestamp = now_ms(); d->presentationTimestamp = pts;
+  d->creationTimestamp = now_ms(); d->creationUs = now_us(); d->presentationTimestamp = pts;
   d->vInfo.reset(new VideoInfo);
   d->vInfo->width = (int16_t)w; d->vInfo->height = (int16_t)h; d->vInfo->framerateNumerator = fn; d->vInfo->framerateDenominator = fd;
   if (host && borrow) { d->data_size = (uint32_t)(w * h * 3 / 2); d->host_view = host; }
@@ -826,6 +865,31 @@ KVZ_PUBLIC void uvgx_pipeline_stats(void *pp, uint64_t *out)
   std::lock_guard<std::mutex> l(p->m);
   out[0] = p->stats.encodedPackets; out[1] = p->stats.encodedBytes; out[2] = p->stats.receivedPackets; out[3] = p->stats.receivedBytes;
   out[4] = p->stats.droppedPackets; out[5] = p->n_decoded; out[6] = p->stats.encodingDelaySumMs; out[7] = p->enc->inputDiscarded();
+}
+// Delay samples of the pictures that have come out since the last reset, in the order they came out, microseconds.  which 0: encoding delay (picture
+// pushed -> access unit out of KvazaarFilter', what kvazaarfilter.cpp:478-479 reports), 1: total delay (-> decoded picture out of the last filter,
+// displayfilter.cpp:113-115).  Returns the number of samples held; up to `cap` are copied.
+KVZ_PUBLIC uint32_t uvgx_pipeline_latency_us(void *pp, int which, uint32_t *out, uint32_t cap, int reset)
+{
+  UvgxPipeline *p = (UvgxPipeline *)pp;
+  if (!p) return 0;
+  std::lock_guard<std::mutex> l(p->m);
+  std::vector<uint32_t> &v = which ? p->lat_total : p->lat_enc;
+  const uint32_t n = (uint32_t)v.size();
+  if (out) for (uint32_t i = 0; i < n && i < cap; i++) out[i] = v[i];
+  if (reset) v.clear();
+  return n;
+}
+// the filters' own statistics (uvgx::Stats histograms): out[0..3] = count, mean, p50, p99 of the encoding delay, out[4..7] of the total delay (us)
+KVZ_PUBLIC void uvgx_pipeline_delay_stats(void *pp, double *out8)
+{
+  UvgxPipeline *p = (UvgxPipeline *)pp;
+  const DelayHist *h[2] = {&p->stats.encodingDelayUs, &p->stats.totalDelayUs};
+  for (int k = 0; k < 2; k++) {
+    const uint64_t c = h[k]->count.load();
+    out8[4 * k] = (double)c; out8[4 * k + 1] = c ? (double)h[k]->sumUs.load() / (double)c : 0.0;
+    out8[4 * k + 2] = h[k]->percentile(0.5); out8[4 * k + 3] = h[k]->percentile(0.99);
+  }
 }
 KVZ_PUBLIC void uvgx_pipeline_busy_ms(void *pp, double *out3)
 {

@@ -25,6 +25,9 @@ def _bind(lib):
                                               C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     lib.uvgx_pipeline_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.uvgx_pipeline_busy_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.uvgx_pipeline_latency_us.restype = C.c_uint32
+    lib.uvgx_pipeline_latency_us.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_uint32, C.c_int]
+    lib.uvgx_pipeline_delay_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.uvgx_pipeline_encoder.restype = C.c_void_p
     lib.uvgx_pipeline_encoder.argtypes = [C.c_void_p]
     lib.uvgx_pipeline_decoder.restype = C.c_void_p
@@ -122,6 +125,20 @@ class Pipeline:
         out = (C.c_double * 3)()
         self.lib.uvgx_pipeline_busy_ms(self.p, out)
         return tuple(float(v) for v in out)
+
+    def latency_us(self, which, reset=True):
+        """per-picture delays in microseconds since the last reset, in output order: which 0 = encoding delay (pushed -> access unit out of the
+        encoder filter, kvazaarfilter.cpp:478-479), 1 = total delay (-> decoded picture out of the last filter, displayfilter.cpp:113-115)"""
+        n = self.lib.uvgx_pipeline_latency_us(self.p, which, None, 0, 0)
+        buf = (C.c_uint32 * max(1, n))()
+        n = min(n, self.lib.uvgx_pipeline_latency_us(self.p, which, buf, n, int(reset)))
+        return np.frombuffer(buf, dtype=np.uint32, count=n).copy()
+
+    def delay_stats(self):
+        """the filters' own delay histograms (uvgx::Stats): {'encoding': (count, mean, p50, p99), 'total': (...)} in microseconds"""
+        out = (C.c_double * 8)()
+        self.lib.uvgx_pipeline_delay_stats(self.p, out)
+        return {"encoding": tuple(out[0:4]), "total": tuple(out[4:8])}
 
     def encoder_handle(self):
         return self.lib.uvgx_pipeline_encoder(self.p)

@@ -277,3 +277,52 @@ def test_pipelined_encoder_with_sao_on_device_path_matches_oracle(gpu):
         ge.close(); oe.close()
         for p in dptrs:
             hip.hipFree(p)
+
+
+@pytest.mark.gpu
+def test_config2_4k_decode_matches_the_checkers_decoder(gpu):
+    """BASELINE configs[2] size on the DECODER side (the bench's `secondary` leg times it): 3840x2160, IDR + 2 P of the plain workload, then one
+    default-mode picture pair (preset veryfast: SAO, fractional search, intra units in P pictures) -- every picture of the HIP decoder equals
+    oracle/hevc_dec.c's, sample for sample (and the encoder's reconstruction: closed loop at 4K)"""
+    from kvazzup_amd.codec import Decoder, Encoder
+    w, h = 3840, 2160
+    for name, opts, frames in (("plain", (("qp", 32), ("period", 64), ("me-range", 16)), 3),
+                               ("default-mode", (("preset", "veryfast"), ("qp", 32), ("period", 64), ("me-range", 16)), 2)):
+        ge = Encoder(w, h, options=opts)
+        assert not ge.rejected, ge.rejected
+        od = orc.OracleDecoder()
+        gd = Decoder()
+        try:
+            for t in range(frames):
+                au, rec = ge.encode(orc.synth_frame(0, SEED, w, h, t))
+                ref = od.decode_au(au, t); got = gd.decode_au(au, t)
+                assert len(ref) == 1 and len(got) == 1, (name, t)
+                assert np.array_equal(got[0]["i420"], ref[0]["i420"]), "%s: 4K picture %d differs from the checker's decoder" % (name, t)
+                assert np.array_equal(got[0]["i420"], rec), "%s: 4K picture %d differs from the encoder's reconstruction" % (name, t)
+        finally:
+            ge.close(); gd.close(); od.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,name", [(1, "flat"), (2, "noise")])
+def test_bound_clips_1080p_through_the_filter_chain(gpu, kind, name):
+    """SURVEY 8(d)'s two bound clips at BASELINE configs[1]'s shape through KvazaarFilter' -> WireAdapter -> OpenHEVCFilter': `flat` (everything
+    skipped: substreams of a few bytes) and `noise` (every block searched, dense coefficients, ~10x the bins of the moving-objects clip).  Access
+    units == the checker encoder's, decoded pictures == its reconstruction, 4 pictures (IDR + 3 P)"""
+    from kvazzup_amd.pipeline import Pipeline
+    w, h, frames = 1920, 1080, 4
+    oe = orc.OracleEncoder(w, h, qp=32, period=64, me_range=16)
+    pl = Pipeline(w, h, settings={"video/QP": 32, "video/Intra": 64}, custom=(("me-range", 16),))
+    try:
+        clip = [orc.synth_frame(kind, SEED, w, h, t) for t in range(frames)]
+        for f in clip:
+            pl.push(f)
+        assert pl.wait(frames, 120000)
+        for t in range(frames):
+            au_o = oe.encode(clip[t])
+            au_g, pts = pl.pop_encoded()
+            assert pts == t and au_g == au_o, "%s: AU %d differs (%d vs %d bytes)" % (name, t, len(au_g), len(au_o))
+            d = pl.pop_decoded()
+            assert d["pts"] == t and np.array_equal(d["i420"], oe.recon()), "%s: decoded picture %d differs from the reconstruction" % (name, t)
+    finally:
+        pl.close(); oe.close()

@@ -15,12 +15,14 @@ from .workloads import PERIOD, CLIP_FRAMES, DeviceClip, algorithmic_bytes, strea
 from .host import cpu_budget, _throttled_us, _thread_cpu
 
 
-def run_stream(args, wl, steps, warmup, ranks, rank, world, quality, host_io=False, extra_custom=(), extra_settings=None):
+def run_stream(args, wl, steps, warmup, ranks, rank, world, quality, host_io=False, extra_custom=(), extra_settings=None, kind=0, bare=False, repeats=None):
     """K = steps intra periods of one stream through KvazaarFilter' -> WireAdapter -> OpenHEVCFilter' on this rank's GPU, timed
     args.repeats times (median of 3 runs); every repetition starts and ends on an empty, flushed pipeline.
     host_io: the reference's own boundary -- pictures enter as HOST I420 through kvz_api->encoder_encode(kvz_picture*) (the filter's
     memcpy into the kvz_picture included, kvazaarfilter.cpp:410-438) and leave through libOpenHevcGetOutput + the filter's row copy into
     host memory (openhevcfilter.cpp:192-239): PCIe both ways inside the timed region.
+    kind: the synthetic clip (0 moving objects, 1 flat, 2 noise -- SURVEY 8(d)'s bounds).  bare: NO custom parameter at all reaches the encoder (uvgComm's
+    INI list "parameters" empty: the workload's search range and device are the defaults anyway) -- what an unmodified uvgComm.ini gets.
     Returns a dict of measurements.  sync(value=None) = barrier / max over ranks."""
     from kvazzup_amd.pipeline import Pipeline
     import ctypes as C
@@ -37,7 +39,7 @@ def run_stream(args, wl, steps, warmup, ranks, rank, world, quality, host_io=Fal
     seed = stream_seed(wl["cfg_index"], rank)
     # synthetic clip generated directly in HBM (inputs resident before the timed region)
     nclip = CLIP_FRAMES
-    dclip = DeviceClip(ranks.lib, dev_index, seed, w, h, nclip)
+    dclip = DeviceClip(ranks.lib, dev_index, seed, w, h, nclip, kind=kind)
     clip = dclip.ptr
     host_clip = [dclip.host(t) for t in range(nclip)] if host_io else None       # pageable host memory, as a camera filter's frames are
 
@@ -51,6 +53,10 @@ def run_stream(args, wl, steps, warmup, ranks, rank, world, quality, host_io=Fal
         st.update(extra_settings or {})
         if os.environ.get("KVAZZUP_BENCH_COPY_THREADS"):
             st["uvgx/copyThreads"] = os.environ["KVAZZUP_BENCH_COPY_THREADS"]       # (measurement aid: helpers of the filters' picture copies, default 4)
+        if bare:
+            if args.me_range != 16 or dev_index != 0:
+                raise RuntimeError("the bare leg needs the defaults (me-range 16, device 0)")
+            return Pipeline(w, h, settings=st, custom=(), loopback=True, keep_outputs=keep)
         return Pipeline(w, h, settings=st,
                         custom=(("me-range", args.me_range), ("gpu", dev_index)) + ((("sao", "full"),) if args.sao else ()) + ((("me-early-termination", "off"),) if args.full_search else ()) + ((("intra-satd", "0"),) if args.intra_sad else ()) + ((("gpu-entropy", "1"),) if args.gpu_entropy else ()) + ((("subme", str(args.subme)),) if args.subme else ()) + tuple(tuple(kv.split("=", 1)) for kv in args.custom) + tuple(extra_custom),
                         loopback=True, keep_outputs=keep)
@@ -104,7 +110,7 @@ def run_stream(args, wl, steps, warmup, ranks, rank, world, quality, host_io=Fal
     if os.environ.get("CPU_SAMPLER_REGION"):                  # tools/cpu_sampler.c preloaded: sample the timed regions only
         _sampler = C.CDLL(None)
     reps = []
-    for rep in range(max(1, args.repeats)):
+    for rep in range(max(1, repeats or args.repeats)):
         device_sync()                                          # the pipeline is empty: everything pushed so far has been decoded
         sync()
         cpu0 = time.process_time()
@@ -167,6 +173,60 @@ def run_stream(args, wl, steps, warmup, ranks, rank, world, quality, host_io=Fal
         out["psnr_y"] = round(sum(ps) / len(ps), 3)
     dclip.close()
     return out
+
+
+def latency_run(args, wl, ranks, settings, custom, source_fps, npic, drop_tail):
+    """Per-picture delays at a PACED source (a camera: one picture every 1 / source_fps s, host I420 in, decoded I420 out into host memory -- the
+    reference's boundary): encoding delay (picture handed to KvazaarFilter' -> access unit sent on; what kvazaarfilter.cpp:478-479 books) and total delay
+    (-> decoded picture out of OpenHEVCFilter'; displayfilter.cpp:113-115), microseconds.  The last `drop_tail` pictures only leave with the flush that ends
+    the run (video/OWF, frame threads) and are not counted.  Returns {'encoding_delay_us': {p50, p99, mean, max}, 'total_delay_us': {...}, ...}."""
+    import numpy as np
+    from kvazzup_amd.pipeline import Pipeline
+    w, h = wl["w"], wl["h"]
+    dclip = DeviceClip(ranks.lib, ranks.dev_index, stream_seed(wl["cfg_index"], 0), w, h, PERIOD)
+    host_clip = [dclip.host(t) for t in range(PERIOD)]
+    st = {"video/QP": 32, "video/Intra": PERIOD, "video/VPS": 1, "uvgx/gpu": ranks.dev_index, "uvgx/decoderDownload": 1}
+    st.update(settings)
+    pl = Pipeline(w, h, settings=st, custom=custom, loopback=True, keep_outputs=False)
+    try:
+        for t in range(PERIOD):                              # warm-up: one period at full speed, flushed
+            if not pl.push_host_paced(host_clip[t], 6, 120000):
+                raise RuntimeError("latency leg: pipeline stalled")
+        pl.flush()
+        if not pl.wait(PERIOD, 120000):
+            raise RuntimeError("latency leg: warm-up did not deliver")
+        pl.latency_us(0), pl.latency_us(1)                   # (reset)
+        period = 1.0 / source_fps
+        t_next = time.perf_counter()
+        late = 0
+        for t in range(npic):
+            now = time.perf_counter()
+            if now < t_next:
+                time.sleep(t_next - now)
+            elif now - t_next > period:
+                late += 1
+            if not pl.push_host_paced(host_clip[t % PERIOD], 9, 120000):
+                raise RuntimeError("latency leg: pipeline stalled")
+            t_next += period
+        time.sleep(2 * period)
+        pl.flush()
+        if not pl.wait(PERIOD + npic, 120000):
+            raise RuntimeError("latency leg: pipeline did not deliver: %r" % (pl.stats(),))
+        enc, tot = pl.latency_us(0), pl.latency_us(1)
+        stt = pl.stats()
+        if stt["dropped"]:
+            raise RuntimeError("latency leg: the filters dropped pictures: %r" % (stt,))
+    finally:
+        pl.close()
+        dclip.close()
+    keep = max(1, npic - drop_tail)
+
+    def summary(a):
+        a = np.asarray(a[:keep], dtype=np.float64)
+        if not len(a):
+            return None
+        return {"p50": round(float(np.percentile(a, 50)), 1), "p99": round(float(np.percentile(a, 99)), 1), "mean": round(float(a.mean()), 1), "max": round(float(a.max()), 1)}
+    return {"encoding_delay_us": summary(enc), "total_delay_us": summary(tot), "pictures": keep, "source_fps": source_fps, "source_late": late}
 
 
 def multi_stream(args, wl, K, steps, ranks):

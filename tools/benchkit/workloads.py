@@ -62,7 +62,7 @@ def stream_seed(cfg_index, rank):
 class DeviceClip:
     """the synthetic clip in device memory (kvzx_harness_*: generated on the GPU, no tensor library)"""
 
-    def __init__(self, lib, dev_index, seed, w, h, frames):
+    def __init__(self, lib, dev_index, seed, w, h, frames, kind=0):
         import ctypes as C
         lib.kvzx_harness_alloc.restype = C.c_void_p
         lib.kvzx_harness_alloc.argtypes = [C.c_int, C.c_size_t]
@@ -73,7 +73,7 @@ class DeviceClip:
         self.ptr = []
         for t in range(frames):
             p = lib.kvzx_harness_alloc(dev_index, self.n)
-            if not p or not lib.kvzx_harness_synth_frame(p, 0, seed & 0xFFFFFFFF, w, h, t):
+            if not p or not lib.kvzx_harness_synth_frame(p, kind, seed & 0xFFFFFFFF, w, h, t):
                 raise RuntimeError("device clip: allocation or synthesis failed")
             self.ptr.append(p)
         if not lib.kvzx_harness_sync(dev_index):

@@ -50,6 +50,12 @@ KVZ_PUBLIC int kvzx_encoder_pending(kvz_encoder *enc);         /* pictures hande
  * or the environment variable KVAZZUP_AMD_DEVICE) */
 KVZ_PUBLIC int kvzx_decoder_set_device(OpenHevc_Handle h, int device);
 KVZ_PUBLIC int kvzx_decoder_last_error(OpenHevc_Handle h);
+/* Test / measurement hook, not a decoding mode: before libOpenHevcStartDecoder.  The decoder then runs its HOST half only (NAL units, parameter sets, slice
+ * headers, the CABAC slice-data parser with `parse_threads` row threads), touches no device and never outputs a picture (libOpenHevcDecode returns 0 or an
+ * error).  kvzx_decoder_parse_probe_stats: out5 = pictures parsed, transform blocks, level words, FNV-1a digest of everything the parser produced, 0;
+ * parse_ms = time spent in the slice-data parser. */
+KVZ_PUBLIC int kvzx_decoder_set_parse_only(OpenHevc_Handle h, int parse_threads);
+KVZ_PUBLIC int kvzx_decoder_parse_probe_stats(OpenHevc_Handle h, uint64_t *out5, double *parse_ms);
 /* with libOpenHevcSetCheckMD5(h, 1): decoded picture hash SEI messages (MD5 / checksum, H.265 D.2.19) compared so far and how many did not
  * match the picture as decoded (each mismatch also sets the last error to -4 and is said on stderr; the picture is still handed out) */
 KVZ_PUBLIC void kvzx_decoder_hash_stats(OpenHevc_Handle h, int *checked, int *mismatch);

@@ -134,6 +134,14 @@ class Decoder {
   int decode_nal(const uint8_t *data, size_t len, int64_t pts);
   bool get_picture(DecodedPicture *out);   // the picture announced by the last decode_nal() == 1
   void set_download(bool on) { download_ = on; }
+  // Test / measurement hook, never a decoding mode: the host half alone -- NAL units, parameter sets, slice headers and the CABAC slice-data parser run,
+  // nothing is allocated on or sent to a device, no picture ever comes out (decode_nal returns 0 for every picture).  What the parser produced is
+  // summarised by parse_probe_stats: pictures, transform blocks, level words, a 64-bit FNV-1a digest over every picture's records / tables / blocks /
+  // levels (the bytes launch_gpu would upload, fixed part minus the descriptor) and the time spent in parse_job.  CPU tests pin the parser's output with it
+  // (tests/test_parser_probe.py); tools/measure/parse_rate.py times the parser where there is no GPU.
+  void set_parse_only() { if (jobs_.empty() && !started_) parse_only_ = true; }
+  struct ProbeStats { uint64_t pictures = 0, tus = 0, levels = 0, digest = 0xcbf29ce484222325ull, bins = 0; double parse_ms = 0; };
+  ProbeStats parse_probe_stats() const { return probe_; }
   // device-resident output (set_download(false)): the planes handed out stay untouched while the next `n` pictures are decoded
   // (they may be read as reference pictures, never written); default 2
   void set_output_hold(int n) { output_hold_ = n < 1 ? 1 : (n > 8 ? 8 : n); }
@@ -248,6 +256,7 @@ class Decoder {
   bool batch_attached_ = false, batch_used_ = false;
 
   int device_; bool started_ = false;
+  bool parse_only_ = false; ProbeStats probe_; void probe_book(PicJob &job, double ms);
   hipStream_t stream_up_ = nullptr; hipEvent_t up_done_[9] = {};   // upload of the next picture's input block beside the current picture's kernels
   hipStream_t stream_ = nullptr, stream_dl_ = nullptr;       // reconstruction; download of finished pictures (behind the picture's event, beside the next picture's kernels)
   std::shared_ptr<const DecSps> sps_[16]; DecPps pps_[64]; uint32_t vps_fps_num_ = 0, vps_fps_den_ = 0;

@@ -80,7 +80,10 @@ bool parse_st_rps(BitReader &r, int idx, int num_in_sps, const StRps *all, StRps
 // Arithmetic decoder with the offset kept scaled in a 64-bit register: value = offset << bits | next
 // `bits` stream bits, so a renormalisation by n is just bits -= n and the stream is touched 32 bits at
 // a time.  Context variable = pStateIdx << 1 | valMps with precomputed transitions.
-struct StateTabs { uint8_t next_mps[128], next_lps[128]; uint8_t next[128][2]; uint8_t lps[128][4]; };    // next[variable][LPS decoded], lps[variable][(range >> 6) & 3]
+// next[variable][LPS decoded], lps[variable][(range >> 6) & 3]; lpsn[variable][q] = the LPS range already renormalised (bits 0..8) | its shift << 16: an LPS
+// range's renormalisation depends on the table entry alone, so it is looked up with it instead of counted (a leading-zero count, a subtraction and a shift
+// less on the range's dependency chain); an MPS range (>= 128) is shifted by one at most
+struct StateTabs { uint8_t next_mps[128], next_lps[128]; uint8_t next[128][2]; uint8_t lps[128][4]; uint32_t lpsn[128][4]; };
 const StateTabs &state_tabs()               // (function-local statics: initialised once, thread-safe -- parse workers race to the first call)
 {
   static const StateTabs t = [] {
@@ -90,55 +93,50 @@ const StateTabs &state_tabs()               // (function-local statics: initiali
       t.next_mps[s] = (uint8_t)(((st < 62 ? st + 1 : st) << 1) | mps);
       t.next_lps[s] = (uint8_t)((kNextLps[st] << 1) | (st == 0 ? mps ^ 1 : mps));
       t.next[s][0] = t.next_mps[s]; t.next[s][1] = t.next_lps[s];
-      for (int q = 0; q < 4; q++) t.lps[s][q] = kRangeLps[st][q];
+      for (int q = 0; q < 4; q++) { t.lps[s][q] = kRangeLps[st][q]; const int n = __builtin_clz((uint32_t)kRangeLps[st][q]) - 23; t.lpsn[s][q] = ((uint32_t)kRangeLps[st][q] << n) | ((uint32_t)n << 16) | ((uint32_t)kRangeLps[st][q] << 24); }
     }
     return t;
   }();
   return t;
 }
-struct CabacDec {
-  const uint8_t *buf = nullptr, *p = nullptr, *end = nullptr;   // the substream; reads past `end` deliver zeros (a malformed NAL cannot walk off the buffer)
+// The decoder's registers apart from the context variables: a function that decodes many bins in a row (parse_residual) works on a LOCAL copy -- a local
+// whose address never leaves the function lives in registers, while the members of an object reached through a reference are re-loaded and written back
+// around every context store (measured on the parser alone, tools/measure/parse_rate.py: 11.3 -> see HISTORY.md ns per bin at 1080p / QP 32).
+struct CabacRegs {
+  const uint8_t *p = nullptr, *end = nullptr;                   // next unread byte, end of the substream; reads past `end` deliver zeros (a malformed NAL cannot walk off the buffer)
   uint64_t value = 0; int bits = 0;
   uint32_t range = 510; uint32_t past = 0;                      // 32-bit words fetched beyond the end
   const StateTabs *st = nullptr;
-  // 16-bit entries: a byte store may alias anything, which would make the compiler reload value / bits / range from the struct
-  // after every context update; a uint16_t store cannot alias them
-  uint16_t ctx[CTX_COUNT];
-  void load_ctx(const uint8_t *src) { for (int i = 0; i < CTX_COUNT; i++) ctx[i] = src[i]; }
-  void save_ctx(uint8_t *dst) const { for (int i = 0; i < CTX_COUNT; i++) dst[i] = (uint8_t)ctx[i]; }
-  inline uint32_t word()
+  uint16_t *ctx = nullptr;                                      // 16-bit entries: a byte store may alias anything; a uint16_t store cannot alias the fields above
+  // (every member function is forced inline: one call with `this` would pin a local copy to the stack)
+  static __attribute__((noinline)) uint32_t word_tail(const uint8_t *p, const uint8_t *end) { uint32_t w = 0; for (int i = 0; i < 4; i++) w = (w << 8) | (p + i < end ? p[i] : 0u); return w; }
+  __attribute__((always_inline)) inline uint32_t word()
   {
     uint32_t w;
-    if (p + 4 <= end) w = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
-    else { w = 0; for (int i = 0; i < 4; i++) w = (w << 8) | (p + i < end ? p[i] : 0u); past++; }
+    if (__builtin_expect(p + 4 <= end, 1)) { memcpy(&w, p, 4); w = __builtin_bswap32(w); }
+    else { w = word_tail(p, end); past++; }
     p += 4;
     return w;
   }
-  inline void refill() { if (bits < 16) { value = (value << 32) | word(); bits += 32; } }
+  __attribute__((always_inline)) inline void refill() { if (__builtin_expect(bits < 16, 0)) { value = (value << 32) | word(); bits += 32; } }
   bool overrun() const { return past > 3; }
-  void start(const uint8_t *b, size_t l)
-  {
-    buf = b; p = b; end = b + l; past = 0; st = &state_tabs(); range = 510;
-    value = word(); bits = 32 - 9;
-    refill();
-  }
-  inline int bin(int ci)
+  __attribute__((always_inline)) inline int bin(int ci)
   {
     // (both outcomes are computed and selected: the bin values of sig / greater1 flags are close to coin flips for a branch predictor)
     const uint32_t s = ctx[ci];
-    const uint32_t lps = st->lps[s][(range >> 6) & 3];
-    const uint32_t rmps = range - lps;
+    const uint32_t e = st->lpsn[s][(range >> 6) & 3];     // LPS range: as it is (bits 24..31), renormalised (bits 0..8), its shift (bits 16..19)
+    const uint32_t rmps = range - (e >> 24);
     const uint64_t scaled = (uint64_t)rmps << bits;
     const bool isl = value >= scaled;
     value -= isl ? scaled : 0;
-    const uint32_t r = isl ? lps : rmps;
+    const uint32_t nm = (rmps >> 8) ^ 1u;                 // an MPS range is in [128, 510]: one shift when below 256
+    range = isl ? (e & 0x1ffu) : (rmps << nm);
+    bits -= (int)(isl ? ((e >> 16) & 15u) : nm);
     ctx[ci] = st->next[s][isl];
-    const int n = __builtin_clz(r) - 23;                  // renormalisation: r in [1, 510] -> [256, 510]
-    range = r << n; bits -= n;
     refill();
     return (int)((s & 1u) ^ (uint32_t)isl);
   }
-  inline int bypass()
+  __attribute__((always_inline)) inline int bypass()
   {
     bits--;
     const uint64_t scaled = (uint64_t)range << bits;
@@ -149,7 +147,7 @@ struct CabacDec {
   }
   // n bypass bins at once: they are the n-bit quotient of value by range << (bits - n) (binary long division, one step per
   // bin); refill() keeps bits >= 16, so up to 16 bins go in one division
-  inline uint32_t bypass_bits(int n)
+  __attribute__((always_inline)) inline uint32_t bypass_bits(int n)
   {
     uint32_t v = 0;
     while (n > 0) {
@@ -167,13 +165,51 @@ struct CabacDec {
     }
     return v;
   }
-  int terminate()
+  // the unary prefix of coeff_abs_level_remaining (up to `max` ones, then a zero): bypass bins are the bits of the quotient value / (range << k), so the
+  // run of ones is read off one division instead of one compare per bin
+  __attribute__((always_inline)) inline int bypass_ones(int max)
+  {
+    int n = 0;
+    while (n < max) {
+      const int m = max - n < 8 ? max - n : 8;
+      // the next m bypass bins, without consuming them: q = value / (range << (bits - m))
+      const uint64_t scaled = (uint64_t)range << (bits - m);
+      const uint64_t q = value / scaled;                   // < 2^m
+      const int ones = __builtin_clz((uint32_t)(~q << (32 - m)) | (1u << (31 - m)));      // leading ones of the m-bit pattern
+      if (ones < m) {                                       // a zero among them: consume the ones and the zero
+        const int take = ones + 1;
+        bits -= take;
+        const uint64_t sc2 = (uint64_t)range << bits;
+        value -= (q >> (m - take)) * sc2;
+        refill();
+        return n + ones;
+      }
+      bits -= m; value -= q * scaled; refill();
+      n += m;
+    }
+    return n;
+  }
+  __attribute__((always_inline)) inline int terminate()
   {
     range -= 2;
     if (value >= ((uint64_t)range << bits)) return 1;
     if (range < 256) { range <<= 1; bits--; }
     refill();
     return 0;
+  }
+};
+struct CabacDec : CabacRegs {
+  const uint8_t *buf = nullptr;                                 // the substream
+  uint16_t ctx_store[CTX_COUNT];
+  CabacDec() { ctx = ctx_store; }
+  CabacDec(const CabacDec &) = delete;
+  void load_ctx(const uint8_t *src) { for (int i = 0; i < CTX_COUNT; i++) ctx_store[i] = src[i]; }
+  void save_ctx(uint8_t *dst) const { for (int i = 0; i < CTX_COUNT; i++) dst[i] = (uint8_t)ctx_store[i]; }
+  void start(const uint8_t *b, size_t l)
+  {
+    buf = b; p = b; end = b + l; past = 0; st = &state_tabs(); range = 510; ctx = ctx_store;
+    value = word(); bits = 32 - 9;
+    refill();
   }
   // bytes from the start of the substream up to and including the byte holding the last consumed bit (after a terminating bin == 1:
   // 9.3.2.5 reads rbsp_trailing / alignment, i.e. the arithmetic codeword ends at the byte boundary after the 7 bits it consumed last)
@@ -232,7 +268,33 @@ void parse_sao(CabacDec &c, SaoParams &p, const SaoParams *left, const SaoParams
 }
 
 // residual_coding() (7.3.8.11): appends (raster position << 16 | level) words; *tskip receives transform_skip_flag
-bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, bool sign_hiding, bool ts_enabled, int *tskip, std::vector<uint32_t> &out)
+// The two loops that decode most of a picture's bins, as functions of their own: inside parse_residual the compiler has no registers left for the decoder's
+// (x86-64: sixteen for a function with thirty live values) and keeps them on the stack -- a store and a load on every bin's dependency chain; here they are
+// the only live state.
+__attribute__((noinline)) uint32_t sig_flag_run(CabacRegs &cr, const uint8_t *pk, int base, int k0)       // sig_coeff_flag of scan positions k0 .. 1
+{
+  CabacRegs c = cr;
+  uint32_t sig = 0;
+  for (int k = k0; k >= 1; k--) sig |= (uint32_t)c.bin(base + pk[k]) << k;
+  cr.p = c.p; cr.value = c.value; cr.bits = c.bits; cr.range = c.range; cr.past = c.past;
+  return sig;
+}
+// coeff_abs_level_greater1_flag of the first (up to eight) coefficients of a sub-block: bit j of the result = flag of coefficient j; *c1_io: greater1Ctx
+__attribute__((noinline)) uint32_t greater1_run(CabacRegs &cr, int ctx_base, int n, int *c1_io)
+{
+  CabacRegs c = cr;
+  uint32_t g = 0; int c1 = *c1_io;
+  for (int j = 0; j < n; j++) {
+    const int g1 = c.bin(ctx_base + c1);
+    g |= (uint32_t)g1 << j;
+    if (g1) c1 = 0; else if (c1 > 0 && c1 < 3) c1++;
+  }
+  *c1_io = c1;
+  cr.p = c.p; cr.value = c.value; cr.bits = c.bits; cr.range = c.range; cr.past = c.past;
+  return g;
+}
+
+__attribute__((always_inline)) inline bool parse_residual_regs(CabacRegs &c, int log2, int cidx, int scan_idx, bool sign_hiding, bool ts_enabled, int *tskip, std::vector<uint32_t> &out)
 {
   const ScanTabs &S = scan_tabs();
   const int n = 1 << log2, sbl = log2 - 2, nsb = 1 << sbl;
@@ -271,7 +333,7 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, bool sign_hid
     {
       const int k0 = (i == last_sb) ? last_pos - 1 : 15;
       const int base = sig_base + sig_off;
-      for (int k = k0; k >= 1; k--) sig |= (uint32_t)c.bin(base + pk[k]) << k;      // (position 0 apart: no per-flag conditions in this loop)
+      if (k0 >= 1) sig |= sig_flag_run(c, pk, base, k0);      // (position 0 apart: no per-flag conditions in that loop)
       if (k0 >= 0) {
         if (infer_dc && !(sig >> 1)) sig |= 1u;            // every other flag of a coded sub-block zero: inferred
         else sig |= (uint32_t)c.bin((i == 0 && log2 != 2) ? sig_base : base + pk[0]);      // (the DC coefficient of the block has its own context)
@@ -284,10 +346,9 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, bool sign_hid
     int pos[16], lev[16], nsig = 0, g1idx = -1;
     for (uint32_t m = sig; m;) { const int k = 31 - __builtin_clz(m); pos[nsig++] = k; m &= ~(1u << k); }     // highest scan position first
     for (int j = 0; j < nsig; j++) lev[j] = 1;
-    for (int j = 0; j < nsig && j < 8; j++) {
-      int g1 = c.bin(CTX_GT1 + (cidx ? 16 : 0) + ctx_set * 4 + c1);
-      if (g1) { lev[j] = 2; c1 = 0; if (g1idx < 0) g1idx = j; }
-      else if (c1 > 0 && c1 < 3) c1++;
+    {
+      const uint32_t g = greater1_run(c, CTX_GT1 + (cidx ? 16 : 0) + ctx_set * 4, nsig < 8 ? nsig : 8, &c1);
+      if (g) { g1idx = __builtin_ctz(g); for (uint32_t m = g; m; m &= m - 1) lev[__builtin_ctz(m)] = 2; }
     }
     if (g1idx >= 0 && c.bin(CTX_GT2 + (cidx ? 4 : 0) + ctx_set)) lev[g1idx] = 3;
     // sign_data_hiding (7.3.8.11, 9.3.4.3): the sign of the sub-block's first coefficient in scan order is not sent when its
@@ -321,6 +382,14 @@ bool parse_residual(CabacDec &c, int log2, int cidx, int scan_idx, bool sign_hid
     if (c.overrun()) return false;
   }
   return !c.overrun();
+}
+
+bool parse_residual(CabacDec &cd, int log2, int cidx, int scan_idx, bool sign_hiding, bool ts_enabled, int *tskip, std::vector<uint32_t> &out)
+{
+  CabacRegs c = cd;                                        // the decoder's registers in locals for the whole block (CabacRegs)
+  const bool ok = parse_residual_regs(c, log2, cidx, scan_idx, sign_hiding, ts_enabled, tskip, out);
+  static_cast<CabacRegs &>(cd) = c;
+  return ok;
 }
 
 // ------------------------------------------------------------------------------------------ slice data (7.3.8) of one substream
@@ -1000,6 +1069,7 @@ void Decoder::sync_main()
 Decoder::~Decoder()
 {
   if (getenv("KVAZZUP_AMD_TRACE")) fprintf(stderr, "kvazzup_amd decoder thread ms: nal %.1f  wait_parse %.1f  stage %.1f  gpu_api %.1f  gpu_sync %.1f  longest parse %.2f  (pictures %ld)\n", t_nal_, t_wait_, t_stage_, t_api_, t_sync_, t_parse_max_, job_tail_);
+  if (parse_only_) { for (auto &j : jobs_) free(j.h_in); return; }
   drop_pending();
   workers_.reset();
   if (stream_) sync_main();
@@ -1022,6 +1092,7 @@ Decoder::~Decoder()
 
 bool Decoder::start(std::string *error)
 {
+  if (parse_only_) { frame_threads_ = 1; started_ = true; return true; }      // (set_parse_only: the host half alone, no device)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_) {
     if (error) *error = "no usable HIP device (this library has no CPU fallback)";
@@ -1082,9 +1153,17 @@ void Decoder::bind_job(PicJob &job)
 bool Decoder::grow_job_input(PicJob &job, size_t bytes)
 {
   if (bytes <= job.h_in_cap) return true;
-  if (hipSetDevice(device_) != hipSuccess) return false;
   const size_t cap = bytes + bytes / 2;
   uint8_t *p = nullptr;
+  if (parse_only_) {
+    p = (uint8_t *)aligned_alloc(64, (cap + 63) & ~(size_t)63);
+    if (!p) return false;
+    if (job.h_in) { memcpy(p, job.h_in, fixed_bytes() < job.h_in_cap ? fixed_bytes() : job.h_in_cap); free(job.h_in); }
+    job.h_in = p; job.h_in_cap = cap;
+    bind_job(job);
+    return true;
+  }
+  if (hipSetDevice(device_) != hipSuccess) return false;
   if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return false;
   if (job.h_in) { memcpy(p, job.h_in, fixed_bytes() < job.h_in_cap ? fixed_bytes() : job.h_in_cap); hipHostFree(job.h_in); }
   job.h_in = p; job.h_in_cap = cap;
@@ -1097,11 +1176,26 @@ bool Decoder::ensure_buffers(int w, int h)
   if (w == w_ && h == h_) return true;
   // Resolution change (a new SPS took effect at this IRAP picture): what the ring still holds is completed now and queued -- the
   // following calls hand it out one picture at a time, as a software decoder's bumping process would -- before the buffers go
-  while (w_ && (!gpu_q_.empty() || job_tail_ != job_head_)) {      // (a band decoder's picture between its reconstruction and band_finish -- gpu_job_ -- is not finish_oldest's to complete: drop_pending below lets it go)
+  while (!parse_only_ && w_ && (!gpu_q_.empty() || job_tail_ != job_head_)) {      // (a band decoder's picture between its reconstruction and band_finish -- gpu_job_ -- is not finish_oldest's to complete: drop_pending below lets it go)
     const int rc = finish_oldest();
     if (rc < 0 || (rc > 0 && pic_ready_ && !stash_current_output())) { drop_pending(); break; }
   }
-  while (w_ && pop_reordered(true)) {}                     // a new sequence follows: what waited for later pictures of the old one leaves in POC order, one picture per call
+  while (!parse_only_ && w_ && pop_reordered(true)) {}                     // a new sequence follows: what waited for later pictures of the old one leaves in POC order, one picture per call
+  if (parse_only_) {
+    for (auto &j : jobs_) { free(j.h_in); j.h_in = nullptr; j.h_in_cap = 0; }
+    if (jobs_.empty()) jobs_ = std::vector<PicJob>(3);
+    gpu_depth_ = 1;
+    w_ = w; h_ = h; pw_ = (w + 63) & ~63; ph_ = (h + 63) & ~63;
+    const size_t nb4 = (size_t)pw_ * ph_ / 16;
+    for (auto &j : jobs_) {
+      if (!grow_job_input(j, fixed_bytes() + (1 << 16))) return false;
+      memset(j.h_in, 0, fixed_bytes());
+      j.pred_mode.assign(nb4 / 4, PM_NONE); j.ct_depth.assign(nb4 / 4, 0); j.intra_mode.assign(nb4, 1);
+    }
+    for (auto &d : dpb_) { d = DpbPic(); d.plane[0] = (uint8_t *)(uintptr_t)64; }      // (never dereferenced: slots are only book-keeping here)
+    seen_irap_ = false;
+    return true;
+  }
   drop_pending();
   sync_main();
   free_buffers();
@@ -1150,6 +1244,7 @@ int Decoder::alloc_slot()
   for (int s = 0; s < KVZ_DEC_MAX_REFS; s++) {
     DpbPic &p = dpb_[s];
     if (p.is_ref || job_head_ - p.decode_idx <= output_hold_ + (gpu_depth_ - 1)) continue;      // (pictures queued on the GPU behind the one handed out may already write their buffers)
+    if (!p.plane[0] && parse_only_) p.plane[0] = (uint8_t *)(uintptr_t)64;
     if (!p.plane[0]) {
       const size_t npx = (size_t)pw_ * ph_;
       if (hipSetDevice(device_) != hipSuccess) return -1;
@@ -1499,6 +1594,7 @@ int Decoder::hash_sei(const uint8_t *rbsp, size_t len)
     if ((ht != 0 && ht != 2) || size != 1 + 3 * (ht == 0 ? 16 : 4)) continue;      // (CRC: not checked)
     if (job_head_ == 0) continue;
     PicJob &job = jobs_[(size_t)((job_head_ - 1) % (long)jobs_.size())];
+    if (parse_only_) continue;
     if (frame_threads_ > 1 || band_nrows_ > 0) { job.expect_hash = std::move(want); continue; }
     const int rc = verify_hash(job, want);
     if (rc < 0) return last_error_ = rc;
@@ -1918,6 +2014,15 @@ int Decoder::submit_job(PicJob &job, int nal_type, bool irap)
   if (cur_tid_ == 0 && (nal_type > 9 || ((nal_type & 1) && nal_type < 6))) prev_poc_ = sh.poc;   // prevTid0Pic (8.3.1): TemporalId 0, not RASL / RADL / sub-layer non-reference
   if (irap) seen_irap_ = true;
   job_head_++;
+  if (parse_only_) {
+    auto t0 = std::chrono::steady_clock::now();
+    job.rc = parse_job(job, parse_threads_ > 1);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    job_tail_ = job_head_;
+    if (job.rc < 0) return job.rc;
+    probe_book(job, ms);
+    return 0;
+  }
   if (frame_threads_ == 1) {
     auto t0 = std::chrono::steady_clock::now();
     job.rc = parse_job(job, true);
@@ -1947,12 +2052,25 @@ int Decoder::submit_job(PicJob &job, int nal_type, bool irap)
   return finish_oldest();
 }
 
+// set_parse_only: what launch_gpu would upload for this picture, folded into the running digest
+void Decoder::probe_book(PicJob &job, double ms)
+{
+  const size_t tu_off = fixed_bytes(), lev_off = (tu_off + job.ntu * sizeof(DecTu) + 15) & ~(size_t)15;
+  uint64_t d = probe_.digest;
+  auto fold = [&](const uint8_t *p, size_t n) { for (size_t i = 0; i < n; i++) { d ^= p[i]; d *= 0x100000001b3ull; } };
+  fold(job.h_in, off_scaling());                                              // records, region / CTU tables, tile ids, SAO parameters
+  fold(job.h_in + tu_off, job.ntu * sizeof(DecTu));
+  fold(job.h_in + lev_off, job.nlev * sizeof(uint32_t));
+  probe_.digest = d; probe_.pictures++; probe_.tus += job.ntu; probe_.levels += job.nlev; probe_.parse_ms += ms;
+}
+
 // Waits for the oldest submitted picture to be parsed, reconstructs it on the GPU and makes it the output.
 // Output stage.  Synchronous mode (frame_threads_ == 1): the picture just parsed is reconstructed and output.
 // Frame-threaded mode: first the picture launched by the previous call is completed and becomes the output,
 // then the oldest parsed picture is launched -- its kernels run while this thread goes on parsing headers.
 int Decoder::finish_oldest()
 {
+  if (parse_only_) return 0;
   int rc_launch = 0;
   bool launched = false;
   if (job_head_ != job_tail_) {

@@ -118,6 +118,24 @@ int kvzx_decoder_set_device(OpenHevc_Handle hh, int device)
   return 1;
 }
 void kvzx_decoder_hash_stats(OpenHevc_Handle hh, int *checked, int *mismatch) { Handle *h = H(hh); if (h) h->dec->hash_stats(checked, mismatch); }
+// test / measurement hook (decoder.h set_parse_only): before libOpenHevcStartDecoder; the decoder then parses and never outputs a picture
+int kvzx_decoder_set_parse_only(OpenHevc_Handle hh, int parse_threads)
+{
+  Handle *h = H(hh);
+  if (!h || h->started) return 0;
+  h->dec->set_parse_only();
+  h->dec->set_parse_threads(parse_threads < 1 ? 1 : parse_threads);
+  return 1;
+}
+int kvzx_decoder_parse_probe_stats(OpenHevc_Handle hh, uint64_t *out5, double *parse_ms)
+{
+  Handle *h = H(hh);
+  if (!h) return 0;
+  const Decoder::ProbeStats st = h->dec->parse_probe_stats();
+  if (out5) { out5[0] = st.pictures; out5[1] = st.tus; out5[2] = st.levels; out5[3] = st.digest; out5[4] = st.bins; }
+  if (parse_ms) *parse_ms = st.parse_ms;
+  return 1;
+}
 int kvzx_decoder_last_error(OpenHevc_Handle hh) { Handle *h = H(hh); return h ? h->dec->last_error() : -1; }
 int kvzx_decoder_output_device(OpenHevc_Handle hh, const void **planes, int *pitches)
 {

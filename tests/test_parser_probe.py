@@ -1,0 +1,36 @@
+"""CPU: the PRODUCT's slice-data parser (kvazzup_amd/csrc/decoder.hip -- NAL units, parameter sets, slice headers, CABAC parse, merge / AMVP derivation)
+through its parse-only hook (no device, no picture out): what it produces for the nineteen committed golden streams and for ten streams the checker's
+encoder writes here equals, byte for byte (FNV-1a digest over every picture's 4x4 records, tables, transform blocks and level words), what the parser
+produced when the whole GPU suite last compared the decoder with the checker's (tests/golden/parser_digests.json, make_parser_digests.py) -- with one
+row thread and with four (the WPP hand-over between rows)."""
+import json
+import os
+
+import pytest
+
+import parser_probe as PP
+
+WANT = json.load(open(os.path.join(PP.HERE, "golden", "parser_digests.json")))
+
+
+@pytest.mark.parametrize("name", sorted(WANT))
+def test_parser_output_is_pinned(name):
+    nals = dict(PP.golden_cases())[name] if name.startswith("golden_") else PP.encoded_case(name)
+    assert PP.probe(nals, 1) == WANT[name]
+    assert PP.probe(nals, 4) == WANT[name]
+
+
+def test_every_case_has_a_digest():
+    assert sorted(WANT) == sorted(n for n, _ in PP.golden_cases()) + sorted(n for n, *_ in PP.ENCODED) or set(WANT) == {n for n, _ in PP.golden_cases()} | {n for n, *_ in PP.ENCODED}
+
+
+def test_the_hook_never_outputs_a_picture_and_refuses_after_start():
+    import ctypes as C
+    lib = PP._lib()
+    h = lib.libOpenHevcInit(1, 2)
+    assert lib.kvzx_decoder_set_parse_only(h, 1) == 1
+    assert lib.libOpenHevcStartDecoder(h) == 0
+    assert lib.kvzx_decoder_set_parse_only(h, 1) == 0          # too late
+    nals = PP.encoded_case("enc_flat_all_skip")
+    assert all(lib.libOpenHevcDecode(h, n, len(n), 0) == 0 for n in nals)
+    lib.libOpenHevcClose(h)

@@ -66,7 +66,7 @@ def parse_args():
     ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--me-range", type=int, default=16)
     ap.add_argument("--repeats", type=int, default=3, help="the timed region is run this many times; `value` is the median run (BASELINE.md: median of 3)")
-    ap.add_argument("--no-host-boundary", action="store_true", help="skip the `host_boundary` legs")
+    ap.add_argument("--no-host-boundary", action="store_true", help="skip the `host_boundary` legs -- and with them `uvgcomm_defaults`, `latency_us` and `bounds` (what tools/*.sh profile is the headline leg)")
     ap.add_argument("--host-io", action="store_true", help="profiling aid: the MAIN run goes through the host boundary")
     ap.add_argument("--streams-per-gpu", default="2,4",
                     help="comma-separated K: K independent streams at once on the one GPU, each with its own filter chain in this process "
@@ -92,7 +92,10 @@ def parse_args():
     ap.add_argument("--gpu-entropy", action="store_true", help="gpu-entropy=1: the arithmetic coder on the GPU (k_cabac_rows) instead of the host pool")
     ap.add_argument("--sao", action="store_true", help="kvazaar sao=full (off at the ultrafast preset the headline workload uses)")
     ap.add_argument("--owf", type=int, default=6, help="uvgComm setting video/OWF (kvazaar owf): pictures in flight in the encoder")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.no_host_boundary or a.host_io:
+        a.no_latency = a.no_bounds = True
+    return a
 
 
 def device_figures(ranks):

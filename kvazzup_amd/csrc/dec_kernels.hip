@@ -718,7 +718,7 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
     if (lane == 0) { item_first[nitems] = (uint16_t)nlist; nitems_s = (uint32_t)nitems; im_s[0] = 0; im_s[1] = 0; }
   }
   __syncthreads();
-  const int nitems = (int)nitems_s, nlist = (int)item_first[nitems];
+  const int nitems = wave_uniform_int((int)nitems_s), nlist = (int)item_first[nitems];      // (nitems bounds the claim loop: uniform by construction, kernel_common.h chain_claim)
   // ---- what the chain needs to know about each block, one thread per block: position, available reference samples (8.4.4.2.2:
   // contiguous in scan order for one slice with full-width tiles), the mode's constants
   bool any32 = false;
@@ -782,12 +782,11 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
   const int16_t *rplane = f.resid[c] + (size_t)(cy * S) * cpitch + cx * S;
   IntraWaveScratch &ws = wss[wave];
   for (int rounds = 0;; rounds++) {
-    int it = 0;
-    if (lane == 0) it = (int)atomicAdd(&ch.claim, 1u);
-    it = __builtin_amdgcn_readfirstlane(it);
+    const int it = chain_claim(ch, lane);
     if (it >= nitems) break;
-    // (bounded like every loop of the chain: a CTU has at most 256 items.  The bound is also what keeps this loop honest -- as `for (;;)` with the atomic claim as
-    // its only exit the compiled kernel never left it, on the GPU, for any picture; with the counter it does)
+    // (bounded like every loop of the chain: a CTU has at most 256 items.  Round 4 needed the counter for another reason: with `nitems` in a vector register
+    // the loop written as `for (;;)` was compiled into one the wave never left -- kernel_common.h chain_claim has the story; the bound is scalar now and
+    // either spelling is a plain scalar loop, checked in the listing)
     if (rounds > 300) { if (lane == 0) atomicOr(f.err, 4u); break; }
     const int k0 = (int)item_first[it], k1 = (int)item_first[it + 1];
     const uint2 dp = item_dep[it], cv = item_cover[it];

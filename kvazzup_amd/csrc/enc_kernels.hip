@@ -703,16 +703,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || AD
   if constexpr (RC) rc_group_done(f, s, grp, rc_cost, tid);
 }
 
+// One thread per 8x8 unit: it derives the signalling of the CU it lies in and writes its OWN five entries -- every unit of a CU (4 of a 16x16, 16 of a
+// 32x32) derives the same values from the same few bytes (cache hits), so nobody loops over a CU's units storing single bytes, the stores of a wave are
+// consecutive, and the picture is four times as many threads: the kernel is two rounds of loads deep instead of a serial walk per 16x16 block
+// (round 4: a thread per 16x16 block, 32 workgroups at 1080p, 22 us).
 __global__ __launch_bounds__(256) void k_inter_signal(EncFrame f)
 {
-  int bx = blockIdx.x * blockDim.x + threadIdx.x;       // 16x16 block index
-  int w16 = f.cw >> 4, h16 = band_rows(f) * 4;
-  if (bx >= w16 * h16) return;
-  int x0 = (bx % w16) * 16, y0 = (bx / w16) * 16 + f.row0 * 64;
-  int cl = f.cu_log2[b8idx(f, x0, y0)];
-  if (cl == 5 && ((x0 | y0) & 31)) return;              // not the first 16x16 of a 32x32 CU
-  if (f.cu_intra[b8idx(f, x0, y0)]) return;             // an intra unit in a P picture (intra-in-P)
-  decide_signalling(f, x0, y0, cl);
+  const int w8 = f.cw >> 3, h8 = band_rows(f) * 8;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w8 * h8) return;
+  const int x = (i % w8) * 8, y = (i / w8) * 8 + f.row0 * 64, g = b8idx(f, x, y);
+  const int cl = f.cu_log2[g];
+  if (f.cu_intra[g]) return;                            // an intra unit in a P picture (intra-in-P)
+  const int n = 1 << cl;
+  const CuSignal r = decide_signalling_values(f, x & ~(n - 1), y & ~(n - 1), cl);
+  f.cu_flags[g] = (uint8_t)r.flags; f.cu_merge_idx[g] = (uint8_t)r.midx; f.cu_mvp_idx[g] = (uint8_t)r.mvp;
+  *reinterpret_cast<uint32_t *>(&f.cu_mvd[g * 2]) = ((uint32_t)r.mvdx & 0xffffu) | ((uint32_t)r.mvdy << 16);
 }
 
 // =============================================================================================
@@ -1239,14 +1245,12 @@ __global__ __launch_bounds__(64 * KVZ_INTRA_WAVES) void k_intra_recon(EncFrame f
   }
   if (f.trace && tid == 0) { unsigned long long *t = f.trace + ((size_t)ctu * 3 + c) * 8; t[0] = wall_clock64(); t[3] = 0; t[4] = 0; }
   __syncthreads();
-  const int nblk = (int)nblk_s;
+  const int nblk = wave_uniform_int((int)nblk_s);         // (bounds the claim loop: uniform by construction, kernel_common.h chain_claim)
   const QuantConst q8 = quant_const(qp, 3 - sh, 1), q16 = quant_const(qp, 4 - sh, 1);      // (coding units are 8x8 or 16x16)
   IntraWaveScratch &ws = wss[wave];
   bool first = true;
   for (;;) {
-    int k = 0;
-    if (lane == 0) k = (int)atomicAdd(&ch.claim, 1u);
-    k = __builtin_amdgcn_readfirstlane(k);
+    const int k = chain_claim(ch, lane);
     if (k >= nblk) break;
     PROF(1);                                                // claim
     const IntraBlk d = wave_uniform(&blk[k]);              // (wave-uniform: what is derived from it runs on the scalar unit)
@@ -2203,7 +2207,7 @@ void launch_inter_recon(const EncFrame &f, hipStream_t st)
 }
 void launch_inter_signal(const EncFrame &f, hipStream_t st)
 {
-  int n = (f.cw / 16) * (band_rows(f) * 4);
+  int n = (f.cw / 8) * (band_rows(f) * 8);
   hipLaunchKernelGGL(k_inter_signal, dim3((n + 63) / 64), dim3(64), 0, st, f);      // (a latency chain per thread: small workgroups spread it over all compute units)
 }
 void launch_intra_analyse(const EncFrame &f, hipStream_t st)

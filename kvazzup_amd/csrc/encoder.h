@@ -65,6 +65,7 @@ struct EncodedPicture {
   std::vector<uint8_t> au;
   int poc = 0, qp = 0; bool is_intra = false;
   uint64_t bins = 0;
+  bool recon_delivered = false;   // the reconstruction has been copied into the planes given to set_recon_sink
 };
 
 class Encoder {
@@ -99,6 +100,11 @@ class Encoder {
   int pending() const { return (int)(accepted_ - collected_); }
   // cropped reconstruction of the last coded picture -> host planes (stride = width)
   bool download_recon(uint8_t *y, uint8_t *u, uint8_t *v);
+  // Where the reconstruction of the NEXT picture handed to encode_host goes (page-locked planes, width x height dense; kvz_api's pic_out): the copy is
+  // queued behind the picture's chain when the picture is submitted and runs beside its tokenizer and arithmetic coder -- collect() returns when both
+  // are done -- instead of as a synchronous download after the access unit is finished (0.13 ms of a 0.52 ms encoding delay at 1080p, 0.5 of 4.7 at 4K
+  // with uvgComm's default OWF 0).  Call before encode_host; nullptr: no copy.
+  void set_recon_sink(uint8_t *y, uint8_t *u, uint8_t *v) { sink_[0] = y; sink_[1] = u; sink_[2] = v; }
   // debug: copy an internal device array of the last coded picture to the host
   //   "cu_log2","cu_intra","cu_flags","cu_merge_idx","cu_mvp_idx","cu_intra_mode","cu_cbf" (b8 bytes),
   //   "cu_mv" (b8 * 2 int16), "coef0..2" (int16 planes), "rec0..2" (coded planes), "src0..2"
@@ -205,6 +211,7 @@ class Encoder {
     uint8_t *h_out = nullptr, *d_out = nullptr; uint32_t *h_sub = nullptr, *d_sub = nullptr;   // host-mapped: substream bytes; [3][nsub] offset, length, bins
     hipStream_t ent_stream = nullptr; hipEvent_t tok_ev = nullptr; uint32_t gen = 0;
     hipEvent_t done = nullptr, rec_done = nullptr;       // tokens / substreams delivered (stream_tok_ / ent_stream) / reconstruction final (stream_)
+    hipEvent_t sink_done = nullptr; bool has_sink = false; // set_recon_sink: the reconstruction's copy into the caller's picture (stream_rec_)
     int poc = 0, rec_idx = 0, set = 0, qp = 0; bool intra = false, write_ps = false; long pic_idx = 0;
     std::vector<EvPair> ev; size_t ev_used = 0;
     EncodedPicture result; bool ready = false, ok = true;   // owf >= 2: filled by the background thread
@@ -225,7 +232,8 @@ class Encoder {
   // owf >= 2: the output lags anyway, so the calling thread (uvgComm's encoder filter thread) only hands the picture over; a submitter thread makes the
   // ~20 HIP calls that queue its copy and kernels (~0.1 ms per picture, which at 1080p was most of what that thread had time for).  Applies where the
   // input stays valid without the call waiting for it: page-locked host pictures (contract) and device pictures with input-hold.
-  struct SubmitJob { const uint8_t *src = nullptr; bool host = false; std::vector<int8_t> roi; int roi_w = 0, roi_h = 0; int slot = 0; };
+  struct SubmitJob { const uint8_t *src = nullptr; bool host = false; std::vector<int8_t> roi; int roi_w = 0, roi_h = 0; int slot = 0; uint8_t *sink[3] = {nullptr, nullptr, nullptr}; };
+  uint8_t *sink_[3] = {nullptr, nullptr, nullptr}, *sink_sub_[3] = {nullptr, nullptr, nullptr};      // as set by the caller / of the picture being submitted
   std::thread sub_thread_; std::mutex sm_; std::condition_variable scv_; std::deque<SubmitJob> sq_; bool squit_ = false, sbusy_ = false;
   void submitter();
   void drain_submitter();

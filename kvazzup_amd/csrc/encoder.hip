@@ -267,6 +267,7 @@ Encoder::~Encoder()
   if (stream_in_) hipStreamSynchronize(stream_in_);
   for (Slot &sl : slot_) {
     for (auto &e : sl.ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    if (sl.sink_done) { hipEventSynchronize(sl.sink_done); hipEventDestroy(sl.sink_done); }
     if (sl.h_tok_dense) hipHostFree(sl.h_tok_dense);
     if (sl.h_tok_count) hipHostFree(sl.h_tok_count);
     if (sl.h_err) hipHostFree(sl.h_err);
@@ -375,7 +376,10 @@ bool Encoder::encode_host(const uint8_t *y, const uint8_t *u, const uint8_t *v, 
   drain_submitter();
   accepted_++;
   roi_sub_ = roi_; roi_sub_w_ = roi_w_; roi_sub_h_ = roi_h_;
+  for (int c = 0; c < 3; c++) { sink_sub_[c] = sink_[c]; sink_[c] = nullptr; }
+  tl("up0", submitted_);
   if (!upload_and_submit(y, u, v, pinned)) { accepted_--; return false; }
+  tl("sub1", submitted_ - 1);
   return pending() > depth_ ? collect(out) : true;
 }
 
@@ -401,6 +405,7 @@ bool Encoder::enqueue(const uint8_t *src, bool host, EncodedPicture *out)
 {
   tl("enq", accepted_);
   SubmitJob j; j.src = src; j.host = host; j.roi = roi_; j.roi_w = roi_w_; j.roi_h = roi_h_; j.slot = (int)(accepted_ % nslots_);
+  for (int c = 0; c < 3; c++) { j.sink[c] = sink_[c]; sink_[c] = nullptr; }
   { std::lock_guard<std::mutex> l(bm_); slot_[j.slot].ready = false; slot_[j.slot].ok = true; }
   accepted_++;
   { std::lock_guard<std::mutex> l(sm_); sq_.push_back(std::move(j)); }
@@ -422,6 +427,7 @@ void Encoder::submitter()
     }
     const long before = submitted_;
     roi_sub_.swap(j.roi); roi_sub_w_ = j.roi_w; roi_sub_h_ = j.roi_h;
+    for (int c = 0; c < 3; c++) sink_sub_[c] = j.sink[c];
     tl("sub0", submitted_);
     const size_t ny = (size_t)cfg_.width * cfg_.height;
     bool ok;
@@ -651,6 +657,21 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   // reconstruction final: with SAO the tokenizer's stream waited for the filter -- the chain's last kernel --, so sl.done already says it (and a record the
   // host can inspect ends with a system-scope fence: one fewer at the end of every picture's chain)
   if (!cfg_.sao) HIP_CHECK(hipEventRecord(sl.rec_done, ms));
+  sl.has_sink = false;
+  if (sink_sub_[0] && in_ring >= 0) {                      // (host pictures only: set_recon_sink)
+    // the reconstruction is final behind the chain's last kernel: rec_done, with SAO the event behind the filter
+    if (!stream_rec_) HIP_CHECK(stream_acquire(&stream_rec_, cfg_.device, 'R', 'n'));
+    if (!sl.sink_done) HIP_CHECK(hipEventCreateWithFlags(&sl.sink_done, hipEventDisableTiming));
+    HIP_CHECK(hipStreamWaitEvent(stream_rec_, cfg_.sao ? ev_src_free_[set_] : sl.rec_done, 0));
+    for (int c = 0; c < 3; c++) {
+      const int pw = c ? w / 2 : w, ph = c ? h / 2 : h, cp = c ? cw_ / 2 : cw_;
+      if (pw == cp) HIP_CHECK(hipMemcpyAsync(sink_sub_[c], rec_[cur_idx_][c], (size_t)pw * ph, hipMemcpyDeviceToHost, stream_rec_));
+      else HIP_CHECK(hipMemcpy2DAsync(sink_sub_[c], (size_t)pw, rec_[cur_idx_][c], (size_t)cp, (size_t)pw, (size_t)ph, hipMemcpyDeviceToHost, stream_rec_));
+    }
+    HIP_CHECK(hipEventRecord(sl.sink_done, stream_rec_));
+    sl.has_sink = true;
+  }
+  sink_sub_[0] = sink_sub_[1] = sink_sub_[2] = nullptr;
   sl.pic_idx = submitted_; sl.poc = poc_; sl.intra = intra; sl.rec_idx = cur_idx_; sl.set = set_; sl.qp = qp_cur_; sl.write_ps = false;
   if (intra) {
     sl.write_ps = (intra_count_ == 0) || (cfg_.vps_period > 0 && (intra_count_ % cfg_.vps_period) == 0);
@@ -740,7 +761,9 @@ void Encoder::background(int worker)
 
 bool Encoder::finish_slot(Slot &sl, EncodedPicture *out, int worker)
 {
-  out->valid = false; out->au.clear();
+  out->valid = false; out->au.clear(); out->recon_delivered = false;
+  // (whatever way this function is left: the copy into the caller's reconstruction picture is not in flight any more -- the caller frees it on failure)
+  struct SinkGuard { Slot &s; ~SinkGuard() { if (s.has_sink) { hipEventSynchronize(s.sink_done); s.has_sink = false; } } } sink_guard_{sl};
   if (sl.tok_failed) { sl.tok_failed = false; return false; }
   {
     Tick tk;
@@ -788,6 +811,13 @@ bool Encoder::finish_slot(Slot &sl, EncodedPicture *out, int worker)
   bool assembled;
   { Tick tk; assembled = assemble_access_unit(out->au, sp_, sl.intra, sl.poc, sl.write_ps, rows_out, nsub, sl.qp - cfg_.qp); const double a = tk.ms(); std::lock_guard<std::mutex> l(stat_m_); t_asm_ += a; }
   if (!assembled) { fprintf(stderr, "kvazzup_amd: %d substreams do not fit the tile grid\n", nsub); out->valid = false; return false; }
+  out->recon_delivered = false;
+  if (sl.has_sink) {                                       // the reconstruction's copy into the caller's picture: queued at submission, long done by now
+    tl("rec0", sl.pic_idx);
+    HIP_CHECK(hipEventSynchronize(sl.sink_done));
+    tl("rec1", sl.pic_idx);
+    sl.has_sink = false; out->recon_delivered = true;
+  }
   if (cfg_.hash) {
     // decoded picture hash SEI: the picture's reconstruction (coded size, after the loop filters) comes down once more for it -- a
     // verification aid, not part of the hot path (uvgComm sets hash = none).  The ring entry is not written again before this picture is output.

@@ -894,23 +894,32 @@ KVZ_HD void amvp_cand_list(const EncFrame &f, int x0, int y0, int n, int px[2], 
   while (np < 2) { px[np] = 0; py[np] = 0; np++; }
 }
 
-KVZ_HD void decide_signalling(const EncFrame &f, int x0, int y0, int log2)
+// the signalling of the inter CU at (x0, y0): merge (+ skip) with the first candidate that equals its vector, else AMVP with the cheaper predictor
+struct CuSignal { int flags, midx, mvp, mvdx, mvdy; };
+KVZ_HD CuSignal decide_signalling_values(const EncFrame &f, int x0, int y0, int log2)
 {
   const int n = 1 << log2, bi = b8idx(f, x0, y0);
   const int mvx = f.cu_mv[bi * 2], mvy = f.cu_mv[bi * 2 + 1];
   int cmx[5], cmy[5];
   merge_cand_list(f, x0, y0, n, cmx, cmy);
-  int flags = 0, midx = 0, mvp = 0, mvdx = 0, mvdy = 0;
-  for (int k = 0; k < 5; k++) if (cmx[k] == mvx && cmy[k] == mvy) { flags = CU_MERGE; midx = k; break; }
-  if (flags && f.cu_cbf[bi] == 0) flags |= CU_SKIP;
-  if (!flags) {
+  CuSignal r; r.flags = 0; r.midx = 0; r.mvp = 0; r.mvdx = 0; r.mvdy = 0;
+  for (int k = 4; k >= 0; k--) if (cmx[k] == mvx && cmy[k] == mvy) { r.flags = CU_MERGE; r.midx = k; }      // (the first match wins)
+  if (r.flags && f.cu_cbf[bi] == 0) r.flags |= CU_SKIP;
+  if (!r.flags) {
     int px[2], py[2];
     amvp_cand_list(f, x0, y0, n, px, py);
     int b0 = mvd_bits(mvx - px[0]) + mvd_bits(mvy - py[0]);
     int b1 = mvd_bits(mvx - px[1]) + mvd_bits(mvy - py[1]);
-    mvp = b1 < b0;
-    mvdx = mvx - px[mvp]; mvdy = mvy - py[mvp];
+    r.mvp = b1 < b0;
+    r.mvdx = mvx - px[r.mvp]; r.mvdy = mvy - py[r.mvp];
   }
+  return r;
+}
+KVZ_HD void decide_signalling(const EncFrame &f, int x0, int y0, int log2)
+{
+  const int n = 1 << log2;
+  const CuSignal r = decide_signalling_values(f, x0, y0, log2);
+  const int flags = r.flags, midx = r.midx, mvp = r.mvp, mvdx = r.mvdx, mvdy = r.mvdy;
   for (int y = y0; y < y0 + n; y += 8)
     for (int x = x0; x < x0 + n; x += 8) {
       int i = b8idx(f, x, y);

@@ -332,6 +332,22 @@ struct IntraNeighbours {
 __device__ __forceinline__ uint32_t lds_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int lds_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// The next entry of the workgroup's claim counter, for the whole wave.  RULE for every loop a wave runs as a whole (claim loops, polls): the values that steer it
+// -- the claimed index AND the bound it is compared with -- must be uniform BY CONSTRUCTION (readfirstlane / kernel arguments), never "uniform because every
+// lane loaded the same LDS word".  The compiler takes a compare against a vector register for a divergent exit and rebuilds the loop with execution masks; with
+// the `if (lane == 0) atomic` of the next round folded into that rebuilt loop it produced, for k_dec_intra's loop written as `for (;;)`, an inner loop that
+// lane 0 LEAVES to do the atomic while lanes 1..63 go round again with the initial value 0 in their copy of the index -- readfirstlane then reads lane 1's 0,
+// the wave codes item 0 for ever (profiles/r05_claim_loop_isa.txt has both listings).  With a scalar bound the exit is s_cmp + s_cbranch_scc and the loop stays
+// a plain scalar loop in either spelling.
+__device__ __forceinline__ int chain_claim(IntraChain &ch, int lane)
+{
+  __builtin_amdgcn_wave_barrier();                        // (convergent, emits nothing: the block that tests `lane == 0` cannot be copied into the loop's latch)
+  int k = 0;
+  if (lane == 0) k = (int)atomicAdd(&ch.claim, 1u);
+  return __builtin_amdgcn_readfirstlane(k);
+}
+__device__ __forceinline__ int wave_uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // thread 0 of the workgroup; followed by a barrier in the caller
 __device__ __forceinline__ void chain_init(IntraChain &ch, uint32_t done0, uint32_t done1)
 {

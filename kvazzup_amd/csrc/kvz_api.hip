@@ -22,6 +22,7 @@ struct kvz_encoder {
   uint64_t last_bins;
   int warned_rc;
   std::deque<kvz_picture *> *in_flight;      // source pictures whose output has not been returned yet (owf >= 1)
+  std::deque<kvz_picture *> *in_flight_recon; // their reconstruction pictures (pic_out), allocated when the source went in: the encoder copies into them behind the picture's kernels (Encoder::set_recon_sink); NULL entries: none wanted
 };
 
 namespace {
@@ -331,7 +332,7 @@ kvz_encoder *encoder_open(const kvz_config *cfg)
   Encoder *impl = Encoder::create(ec, &err);
   if (!impl) { fprintf(stderr, "kvazzup_amd: encoder_open failed: %s\n", err.c_str()); return nullptr; }
   kvz_encoder *e = new kvz_encoder();
-  e->impl = impl; e->cfg = *cfg; e->last_bins = 0; e->warned_rc = 0; e->in_flight = new std::deque<kvz_picture *>();
+  e->impl = impl; e->cfg = *cfg; e->last_bins = 0; e->warned_rc = 0; e->in_flight = new std::deque<kvz_picture *>(); e->in_flight_recon = new std::deque<kvz_picture *>();
   return e;
 }
 void encoder_close(kvz_encoder *e)
@@ -340,6 +341,8 @@ void encoder_close(kvz_encoder *e)
   delete e->impl;
   for (kvz_picture *p : *e->in_flight) picture_free(p);
   delete e->in_flight;
+  for (kvz_picture *p : *e->in_flight_recon) picture_free(p);
+  delete e->in_flight_recon;
   delete e;
 }
 
@@ -394,22 +397,35 @@ int encoder_encode(kvz_encoder *e, kvz_picture *pic_in, kvz_data_chunk **data_ou
     // delta-QP map of this picture (kvazaarfilter.cpp:423-431); honoured when set-qp-in-cu enabled the signalling
     if (pic_in->roi.roi_array && pic_in->roi.width > 0 && pic_in->roi.height > 0) e->impl->set_roi(pic_in->roi.width, pic_in->roi.height, pic_in->roi.roi_array);
     else e->impl->set_roi(0, 0, nullptr);
-    if (!e->impl->encode_host(pic_in->y, pic_in->u, pic_in->v, &ep, pic_in->y == pic_in->fulldata_buf && is_pinned(pic_in->fulldata_buf))) return 0;
+    // the picture's reconstruction (pic_out, kvazaarfilter.cpp:435-448,476): its memory is handed to the encoder WITH the source, so that it is filled
+    // behind the picture's kernels, beside the entropy coding, not by a download of its own after the access unit is done
+    kvz_picture *rec = nullptr;
+    const bool pinned_in = pic_in->y == pic_in->fulldata_buf && is_pinned(pic_in->fulldata_buf);
+    if (pic_out && e->cfg.recon_output) {
+      rec = picture_alloc(e->cfg.width, e->cfg.height);
+      if (rec && is_pinned(rec->fulldata_buf)) e->impl->set_recon_sink(rec->y, rec->u, rec->v);
+    }
+    if (!e->impl->encode_host(pic_in->y, pic_in->u, pic_in->v, &ep, pinned_in)) { e->impl->set_recon_sink(nullptr, nullptr, nullptr); picture_free(rec); return 0; }
     pic_in->refcount++;
     e->in_flight->push_back(pic_in);
+    e->in_flight_recon->push_back(rec);
   }
   if (!ep.valid) return 1;
   kvz_picture *src = e->in_flight->front();
   e->in_flight->pop_front();
+  kvz_picture *rec = e->in_flight_recon->front();
+  e->in_flight_recon->pop_front();
   e->last_bins = ep.bins;
   bool ok = true;
   if (data_out) { *data_out = make_chunks(ep.au.data(), ep.au.size()); ok = *data_out != nullptr; }
   if (len_out) *len_out = (uint32_t)ep.au.size();
   if (ok && pic_out && e->cfg.recon_output) {
-    kvz_picture *r = picture_alloc(e->cfg.width, e->cfg.height);
-    if (!r || !e->impl->download_recon(r->y, r->u, r->v)) { picture_free(r); ok = false; }
+    kvz_picture *r = rec ? rec : picture_alloc(e->cfg.width, e->cfg.height);
+    rec = nullptr;
+    if (!r || (!ep.recon_delivered && !e->impl->download_recon(r->y, r->u, r->v))) { picture_free(r); ok = false; }      // (not delivered: the picture was not page-locked, or came in before pic_out was asked for)
     else { r->pts = src->pts; r->dts = src->dts; *pic_out = r; }
   }
+  picture_free(rec);
   if (src_out && ok) *src_out = src; else picture_free(src);
   fill_info(e, ep, info_out);
   return ok ? 1 : 0;

@@ -850,23 +850,30 @@ KVZ_HD int mvd_bits(int q)
 }
 
 struct NbMv { bool ok; int mx, my; };
-KVZ_HD NbMv nb_mv(const EncFrame &f, int xc, int yc, int xn, int yn)
+// where the derivations below read a CU's record from: the frame's arrays (host tests, band encoder) or a tile of them staged in LDS (k_inter_signal)
+struct MvRec { int intra, mx, my, cbf; };
+struct FrameMvView {
+  const EncFrame &f;
+  KVZ_HD MvRec at(int x, int y) const { const int i = b8idx(f, x, y); MvRec r; r.intra = f.cu_intra[i]; r.mx = f.cu_mv[i * 2]; r.my = f.cu_mv[i * 2 + 1]; r.cbf = f.cu_cbf[i]; return r; }
+};
+template <class V>
+KVZ_HD NbMv nb_mv(const V &v, int cw, int chp, int xc, int yc, int xn, int yn)
 {
   // Straight-line on purpose: the record is loaded whether or not the neighbour exists (the CU's own one stands in), so the loads of
   // all five neighbours of a CU are in flight together instead of ten dependent round trips (k_inter_signal: 4K 24 -> 9 us).
-  const bool av = avail64(f.cw, f.chp, xc, yc, xn, yn);
-  const int i = av ? b8idx(f, xn, yn) : b8idx(f, xc, yc);
-  const int intra = f.cu_intra[i], mx = f.cu_mv[i * 2], my = f.cu_mv[i * 2 + 1];
-  NbMv r; r.ok = av && !intra; r.mx = r.ok ? mx : 0; r.my = r.ok ? my : 0;
+  const bool av = avail64(cw, chp, xc, yc, xn, yn);
+  const MvRec m = v.at(av ? xn : xc, av ? yn : yc);
+  NbMv r; r.ok = av && !m.intra; r.mx = r.ok ? m.mx : 0; r.my = r.ok ? m.my : 0;
   return r;
 }
 KVZ_HD bool same_mv(const NbMv &a, const NbMv &b) { return a.mx == b.mx && a.my == b.my; }
 
 // the five merge candidates (8.5.3.2.2-8.5.3.2.5) of the 2Nx2N PU at (x0, y0), size n
-KVZ_HD void merge_cand_list(const EncFrame &f, int x0, int y0, int n, int cmx[5], int cmy[5])
+template <class V>
+KVZ_HD void merge_cand_list(const V &v, int cw, int chp, int x0, int y0, int n, int cmx[5], int cmy[5])
 {
-  NbMv A1 = nb_mv(f, x0, y0, x0 - 1, y0 + n - 1), B1 = nb_mv(f, x0, y0, x0 + n - 1, y0 - 1);
-  NbMv B0 = nb_mv(f, x0, y0, x0 + n, y0 - 1), A0 = nb_mv(f, x0, y0, x0 - 1, y0 + n), B2 = nb_mv(f, x0, y0, x0 - 1, y0 - 1);
+  NbMv A1 = nb_mv(v, cw, chp, x0, y0, x0 - 1, y0 + n - 1), B1 = nb_mv(v, cw, chp, x0, y0, x0 + n - 1, y0 - 1);
+  NbMv B0 = nb_mv(v, cw, chp, x0, y0, x0 + n, y0 - 1), A0 = nb_mv(v, cw, chp, x0, y0, x0 - 1, y0 + n), B2 = nb_mv(v, cw, chp, x0, y0, x0 - 1, y0 - 1);
   bool fA1 = A1.ok;
   bool fB1 = B1.ok && !(A1.ok && same_mv(A1, B1));
   bool fB0 = B0.ok && !(B1.ok && same_mv(B1, B0));
@@ -880,11 +887,13 @@ KVZ_HD void merge_cand_list(const EncFrame &f, int x0, int y0, int n, int cmx[5]
   if (fB2 && nc < 5) { cmx[nc] = B2.mx; cmy[nc] = B2.my; nc++; }
   while (nc < 5) { cmx[nc] = 0; cmy[nc] = 0; nc++; }        // zero candidates (refIdx 0 for one reference)
 }
+KVZ_HD void merge_cand_list(const EncFrame &f, int x0, int y0, int n, int cmx[5], int cmy[5]) { FrameMvView v{f}; merge_cand_list(v, f.cw, f.chp, x0, y0, n, cmx, cmy); }
 // the two AMVP candidates (8.5.3.2.6-8.5.3.2.7); every neighbour refers to the same picture
-KVZ_HD void amvp_cand_list(const EncFrame &f, int x0, int y0, int n, int px[2], int py[2])
+template <class V>
+KVZ_HD void amvp_cand_list(const V &v, int cw, int chp, int x0, int y0, int n, int px[2], int py[2])
 {
-  NbMv A0 = nb_mv(f, x0, y0, x0 - 1, y0 + n), A1 = nb_mv(f, x0, y0, x0 - 1, y0 + n - 1);
-  NbMv B0 = nb_mv(f, x0, y0, x0 + n, y0 - 1), B1 = nb_mv(f, x0, y0, x0 + n - 1, y0 - 1), B2 = nb_mv(f, x0, y0, x0 - 1, y0 - 1);
+  NbMv A0 = nb_mv(v, cw, chp, x0, y0, x0 - 1, y0 + n), A1 = nb_mv(v, cw, chp, x0, y0, x0 - 1, y0 + n - 1);
+  NbMv B0 = nb_mv(v, cw, chp, x0, y0, x0 + n, y0 - 1), B1 = nb_mv(v, cw, chp, x0, y0, x0 + n - 1, y0 - 1), B2 = nb_mv(v, cw, chp, x0, y0, x0 - 1, y0 - 1);
   bool haveA = A0.ok || A1.ok, haveB = B0.ok || B1.ok || B2.ok;
   NbMv a = A0.ok ? A0 : A1, b = B0.ok ? B0 : (B1.ok ? B1 : B2);
   if (!haveA && haveB) { a = b; haveA = true; }          // isScaledFlag == 0: A takes B's vector
@@ -893,21 +902,24 @@ KVZ_HD void amvp_cand_list(const EncFrame &f, int x0, int y0, int n, int px[2], 
   if (haveB && !(haveA && a.mx == b.mx && a.my == b.my)) { px[np] = b.mx; py[np] = b.my; np++; }
   while (np < 2) { px[np] = 0; py[np] = 0; np++; }
 }
+KVZ_HD void amvp_cand_list(const EncFrame &f, int x0, int y0, int n, int px[2], int py[2]) { FrameMvView v{f}; amvp_cand_list(v, f.cw, f.chp, x0, y0, n, px, py); }
 
 // the signalling of the inter CU at (x0, y0): merge (+ skip) with the first candidate that equals its vector, else AMVP with the cheaper predictor
 struct CuSignal { int flags, midx, mvp, mvdx, mvdy; };
-KVZ_HD CuSignal decide_signalling_values(const EncFrame &f, int x0, int y0, int log2)
+template <class V>
+KVZ_HD CuSignal decide_signalling_values(const V &v, int cw, int chp, int x0, int y0, int log2)
 {
-  const int n = 1 << log2, bi = b8idx(f, x0, y0);
-  const int mvx = f.cu_mv[bi * 2], mvy = f.cu_mv[bi * 2 + 1];
+  const int n = 1 << log2;
+  const MvRec own = v.at(x0, y0);
+  const int mvx = own.mx, mvy = own.my;
   int cmx[5], cmy[5];
-  merge_cand_list(f, x0, y0, n, cmx, cmy);
+  merge_cand_list(v, cw, chp, x0, y0, n, cmx, cmy);
   CuSignal r; r.flags = 0; r.midx = 0; r.mvp = 0; r.mvdx = 0; r.mvdy = 0;
   for (int k = 4; k >= 0; k--) if (cmx[k] == mvx && cmy[k] == mvy) { r.flags = CU_MERGE; r.midx = k; }      // (the first match wins)
-  if (r.flags && f.cu_cbf[bi] == 0) r.flags |= CU_SKIP;
+  if (r.flags && own.cbf == 0) r.flags |= CU_SKIP;
   if (!r.flags) {
     int px[2], py[2];
-    amvp_cand_list(f, x0, y0, n, px, py);
+    amvp_cand_list(v, cw, chp, x0, y0, n, px, py);
     int b0 = mvd_bits(mvx - px[0]) + mvd_bits(mvy - py[0]);
     int b1 = mvd_bits(mvx - px[1]) + mvd_bits(mvy - py[1]);
     r.mvp = b1 < b0;
@@ -915,6 +927,7 @@ KVZ_HD CuSignal decide_signalling_values(const EncFrame &f, int x0, int y0, int 
   }
   return r;
 }
+KVZ_HD CuSignal decide_signalling_values(const EncFrame &f, int x0, int y0, int log2) { FrameMvView v{f}; return decide_signalling_values(v, f.cw, f.chp, x0, y0, log2); }
 KVZ_HD void decide_signalling(const EncFrame &f, int x0, int y0, int log2)
 {
   const int n = 1 << log2;

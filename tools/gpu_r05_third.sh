@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 5, third GPU call: pool wake-up A/B, the suite on the LDS-tile k_inter_signal + futex pool, OWF-0 timelines, isolated kernel stats, short bench
+R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
+( cd tools/measure/pool_wake && g++ -O2 -std=c++17 -pthread -DOLD -o /tmp/pool_old pool_wake.cpp && g++ -O2 -std=c++17 -pthread -o /tmp/pool_new pool_wake.cpp ) 2>&1 | tail -3
+{ for t in 4 16; do for g in 16000 300; do /tmp/pool_old $t $g 50; /tmp/pool_new $t $g 50; done; done; } > gpurun_out/r05_pool_wake.txt 2>&1; cat gpurun_out/r05_pool_wake.txt
+timeout 2400 python -m pytest tests -m gpu -x -q -n 3 2>&1 | tail -4
+timeout 300 python tools/measure/owf0_timeline.py 1080p 60 > gpurun_out/r05_owf0_timeline.txt 2>&1; timeout 300 python tools/measure/owf0_timeline.py 4k 30 >> gpurun_out/r05_owf0_timeline.txt 2>&1; cat gpurun_out/r05_owf0_timeline.txt
+bash tools/kstats_iso.sh 1080p r05b_iso1080p --streams-per-gpu 0 --no-preset-line 2>&1 | tail -16
+timeout 900 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --streams-per-gpu 0 > gpurun_out/r05_bench_third.json 2> gpurun_out/r05_bench_third.err; echo "bench rc $?"
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r05_bench_third.json'))
+print('rates',d.get('rates'))
+l=d.get('latency_us') or {}
+for k in ('uvgcomm_default_owf0',):
+    print(k, (l.get(k) or {}).get('encoding_delay_us'), (l.get(k) or {}).get('total_delay_us'))
+s=d.get('secondary') or {}
+print('4k', s.get('value'), (s.get('uvgcomm_defaults') or {}).get('value'), ((s.get('latency_us') or {}).get('uvgcomm_default_owf0') or {}))
+print('all_intra', (d.get('all_intra') or {}).get('value'), 'default_mode', (d.get('default_mode') or {}).get('value'), 'flat', ((d.get('bounds') or {}).get('flat') or {}).get('value'))
+print(d['kernels_us'])
+PY

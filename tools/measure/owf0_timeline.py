@@ -22,6 +22,16 @@ STAGES = ["feed0", "copied", "up0", "sub1", "gpudone", "arith", "rec0", "rec1", 
 def main():
     wl = WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "1080p"]
     fps = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+    if "--child" not in sys.argv:
+        # (the timeline is written when the process that recorded it ends: the run is a child process, this one reads its file)
+        import subprocess
+        if os.path.exists(TL):
+            os.remove(TL)
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), sys.argv[1] if len(sys.argv) > 1 else "1080p", str(fps), "--child"], capture_output=True, text=True)
+        sys.stderr.write(out.stderr[-2000:])
+        lat = [l for l in out.stdout.split("\n") if l.startswith("LAT ")]
+        report(wl, fps, [float(v) for v in lat[0].split()[1:]] if lat else [0, 0])
+        return
     ranks = StreamRanks(1, 0)
     w, h = wl["w"], wl["h"]
     clip = DeviceClip(ranks.lib, ranks.dev_index, stream_seed(wl["cfg_index"], 0), w, h, PERIOD)
@@ -40,6 +50,10 @@ def main():
     assert pl.wait(n, 120000)
     enc, tot = pl.latency_us(0), pl.latency_us(1)
     pl.close(); clip.close(); ranks.close()
+    print("LAT %.1f %.1f" % (sorted(enc[PERIOD:])[len(enc[PERIOD:]) // 2], sorted(tot[PERIOD:])[len(tot[PERIOD:]) // 2]))
+
+
+def report(wl, fps, lat):
     ev = collections.defaultdict(dict)
     for line in open(TL):
         ns, tid, what, pic = line.split()
@@ -53,7 +67,7 @@ def main():
                 d.setdefault(what, int(ns))
     pics = [p for p in sorted(ev) if p >= PERIOD + 1 and p % PERIOD != 0 and all(s in ev[p] for s in ("feed0", "col1", "out1"))]      # P pictures of the second period
     print("%s at %g pictures/s, OWF 0, Slice/4, no custom parameter: %d P pictures; encoding delay p50 %.0f us, total delay p50 %.0f us" % (
-        wl["name"], fps, len(pics), sorted(enc[PERIOD:])[len(enc[PERIOD:]) // 2], sorted(tot[PERIOD:])[len(tot[PERIOD:]) // 2]))
+        wl["name"], fps, len(pics), lat[0], lat[1]))
     have = [s for s in STAGES if all(s in ev[p] for p in pics)]
     print("median microseconds between consecutive stages (P pictures):")
     for a, b in zip(have[:-1], have[1:]):

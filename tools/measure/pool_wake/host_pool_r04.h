@@ -85,8 +85,8 @@ class OrderedPool {
   }
   ~OrderedPool()
   {
-    quit_.store(true, std::memory_order_release);
-    gen_.fetch_add(1, std::memory_order_acq_rel); futex_wake_all(gen_);
+    { std::lock_guard<std::mutex> l(m_); quit_ = true; gen_++; }
+    cv_.notify_all();
     for (auto &t : workers_) t.join();
   }
   // Runs fn(0) .. fn(n - 1); returns when all have finished.
@@ -100,11 +100,7 @@ class OrderedPool {
     done_.store(0, std::memory_order_relaxed);
     total_.store(n, std::memory_order_relaxed);
     next_.store(0, std::memory_order_release);
-    // The helpers sleep on the generation word itself and are woken TOGETHER by one futex call.  (Until round 5 they slept on a condition variable: a
-    // notify_all hands the waiters to the variable's mutex one after the other -- helper k started a wake-up latency after helper k - 1, and a picture's
-    // seventeen-row parse, whose rows follow each other at two CTUs' distance, was over before the fourth helper had its first row: the "row-parallel"
-    // parser of the synchronous decoder ran at one thread's speed, 0.81 ms of a 1.5 ms total delay at 1080p -- tools/measure/owf0_timeline.py.)
-    if (n > 1 && !workers_.empty()) { gen_.fetch_add(1, std::memory_order_acq_rel); futex_wake_all(gen_); }
+    if (n > 1 && !workers_.empty()) { { std::lock_guard<std::mutex> l(m_); gen_++; } cv_.notify_all(); }
     drain();
     for (int d; (d = done_.load(std::memory_order_acquire)) < n;) futex_wait(done_, d);      // (the worker that finishes the last task wakes it)
   }
@@ -112,13 +108,9 @@ class OrderedPool {
  private:
   void worker()
   {
-    int seen = gen_.load(std::memory_order_acquire);
+    uint64_t seen = 0;
     for (;;) {
-      // (a short spin first: at thousands of pictures per second the next job is tens of microseconds away and a futex wake-up costs as much)
-      for (int spins = 0; gen_.load(std::memory_order_acquire) == seen && spins < 200; spins++) __builtin_ia32_pause();
-      while (gen_.load(std::memory_order_acquire) == seen) futex_wait(gen_, seen);
-      seen = gen_.load(std::memory_order_acquire);
-      if (quit_.load(std::memory_order_acquire)) return;
+      { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return gen_ != seen; }); seen = gen_; if (quit_) return; }
       drain();
     }
   }
@@ -134,7 +126,8 @@ class OrderedPool {
     active_.fetch_sub(1, std::memory_order_acq_rel);
   }
   std::vector<std::thread> workers_;
-  std::atomic<int> gen_{0}; std::atomic<bool> quit_{false};
+  std::mutex m_; std::condition_variable cv_;
+  uint64_t gen_ = 0; bool quit_ = false;
   const std::function<void(int)> *fn_ = nullptr;
   std::atomic<int> next_{1 << 30}, total_{0}, done_{0}, active_{0};
 };

@@ -157,7 +157,9 @@ class Decoder {
   int pending() const { return (int)(job_head_ - job_tail_) + (gpu_job_ ? 1 : 0) + (int)gpu_q_.size(); }
 
   // ---- per-picture state shared with the slice-data parser (decoder.hip)
-  struct SubOut { std::vector<uint32_t> levels; std::vector<DecTu> tus; int rc = 0; };     // one per substream
+  // one per substream.  Two cache lines each: the rows of a picture are parsed side by side, every one appending to ITS vectors all the time -- with the
+  // vectors' headers of neighbouring rows in one cache line (56-byte objects back to back) each append invalidated the line under the neighbour's hands
+  struct alignas(128) SubOut { std::vector<uint32_t> levels; std::vector<DecTu> tus; int rc = 0; };
   struct alignas(64) Progress { std::atomic<int> v{0}; char pad[60]; };   // one cache line per row: no false sharing between pollers
   struct SliceHdr {
     bool is_intra = false, is_b = false; int poc = 0;
@@ -199,7 +201,8 @@ class Decoder {
     std::vector<uint8_t> pred_mode, ct_depth, intra_mode;
     std::vector<SubOut> subs; std::vector<uint8_t> wpp_saved;
     std::unique_ptr<Progress[]> row_progress; int row_progress_n = 0;
-    bool any_intra = false, any_inter = false, across_slices = true;
+    alignas(64) bool any_intra = false; bool any_inter = false;        // (set by the rows' parsers: a line of their own, written once -- the parsers test before they store)
+    alignas(64) bool across_slices = true;
     std::atomic<int> state{0}; int rc = 0; double parse_ms = 0;
     hipEvent_t done = nullptr;                                   // recorded behind the picture's last kernel
     std::atomic<int> launched{1};                                // 0 while the picture waits in the device's submission layer (batch.h): `done` has not been recorded yet

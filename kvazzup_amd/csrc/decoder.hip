@@ -755,7 +755,7 @@ struct SliceParser {
     const int cols = imin(bw, w - xp) >> 2;
     const bool ext = bi || wtd;                            // the block has an entry in b4x[]
     for (int y = yp; y < yp + bh && y < h; y += 4) { const int i0 = bi_(xp, y); for (int i = 0; i < cols; i++) { mvf[i0 + i] = m; if (ext) job.b4x[(size_t)(i0 + i)] = x; } }
-    if (ext) job.any_bi.store(1, std::memory_order_relaxed);
+    if (ext) if (!job.any_bi.load(std::memory_order_relaxed)) job.any_bi.store(1, std::memory_order_relaxed);
     if (bw != ncbs || bh != ncbs) {                          // prediction block edges inside the coding block (deblocking)
       for (int i = 0; i < bh && yp + i < h; i += 4) b4[bi_(xp, yp + i)].flags |= B4_EDGE_V;
       for (int i = 0; i < bw && xp + i < w; i += 4) b4[bi_(xp + i, yp)].flags |= B4_EDGE_H;
@@ -813,7 +813,7 @@ struct SliceParser {
       B4L1 x; x.mvx = 0; x.mvy = 0; x.slot = 0; x.pad[0] = (uint8_t)ref_idx; x.pad[1] = x.pad[2] = 0;
       const int cols = imin(bw, w - xp) >> 2;
       for (int y = yp; y < yp + bh && y < h; y += 4) { const int i0 = bi(xp, y); for (int i = 0; i < cols; i++) job.b4x[(size_t)(i0 + i)] = x; }
-      job.any_bi.store(1, std::memory_order_relaxed);
+      if (!job.any_bi.load(std::memory_order_relaxed)) job.any_bi.store(1, std::memory_order_relaxed);
     }
     if (bw != ncbs || bh != ncbs) {                          // prediction block edges inside the coding block (deblocking); the block's own are set by coding_unit
       for (int i = 0; i < bh && yp + i < h; i += 4) b4[bi(xp, yp + i)].flags |= B4_EDGE_V;
@@ -929,7 +929,7 @@ struct SliceParser {
       fill_cu8(pm, x0, y0, n, PM_SKIP);
       prediction_unit(x0, y0, n, x0, y0, n, n, 0, true, nullptr);
       rqt_root_cbf = 0;
-      job.any_inter = true;
+      if (!job.any_inter) job.any_inter = true;
     } else {
       cu_pred_mode = PM_INTRA;
       if (!sh.is_intra) cu_pred_mode = c.bin(CTX_PRED_MODE) ? PM_INTRA : PM_INTER;
@@ -984,7 +984,7 @@ struct SliceParser {
         else { chroma_mode = cm[icpm]; if (chroma_mode == intra_modes[0]) chroma_mode = 34; }
         B4Rec r; r.mvx = 0; r.mvy = 0; r.ref_idx = -1; r.flags = (uint8_t)(cu_bypass ? B4_BYPASS : 0); r.qp_y = (int8_t)qp_y; r.slot = 0;
         fill_recs(x0, y0, n, n, r, true);
-        job.any_intra = true;
+        if (!job.any_intra) job.any_intra = true;
       } else {
         const int hh = n / 2, q = n / 4; int mf = 0;
         switch (part_mode) {
@@ -997,7 +997,7 @@ struct SliceParser {
           default: prediction_unit(x0, y0, n, x0, y0, n - q, n, 0, false, &mf); prediction_unit(x0, y0, n, x0 + n - q, y0, q, n, 1, false, &mf); break;     // nRx2N
         }
         if (!(part_mode == PART_2Nx2N && merge_2nx2n)) rqt_root_cbf = c.bin(CTX_RQT_ROOT_CBF);
-        job.any_inter = true;
+        if (!job.any_inter) job.any_inter = true;
       }
     }
     if (err) return;
@@ -2197,6 +2197,8 @@ int Decoder::complete_gpu(PicJob &job)
 int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t len, SubOut &out)
 {
   SliceParser sp(job, out, pw_);
+  tl("row0", sub);
+  struct RowEnd { int s; ~RowEnd() { tl("row1", s); } } row_end_{sub};
   if (job.sh.is_b) sp.mvf = job.mvf.data();
   const int wc = sp.wc;
   const DecPps &pps = job.pps; const SliceHdr &sh = job.sh;

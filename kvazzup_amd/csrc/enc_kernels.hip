@@ -1581,19 +1581,46 @@ struct TileView {
   __device__ CuRec at(int x, int y) const { return tile[((y >> 3) - by0) * 3 + ((x >> 3) - bx0)]; }
 };
 
-__device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d, const int16_t *lv, int stride, int log2, int scan_idx, int lane)
+// The tokenizer's tables as constants of the code object (round 5; until then every wave computed them -- a dozen dependent loads from the constant tables,
+// 2 us of a 17 us wave): CoreTabs as the host code has it, and the sig_coeff_flag context patterns by SCAN POSITION -- sigk[scan][pattern][k] =
+// sigpat[pattern][pos4[scan][k]], pattern 4 = the 4x4 block's map -- so that a sub-block's sixteen patterns are one 16-byte LDS read.
+struct alignas(16) TokTabs { uint8_t sigk[3][5][16]; };
+constexpr CoreTabs make_core_tabs() { CoreTabs t{}; for (int i = 0; i < 64; i++) core_tabs_fill_entry(t, i); return t; }
+constexpr TokTabs make_tok_tabs()
+{
+  const CoreTabs c = make_core_tabs();
+  TokTabs t{};
+  for (int sc = 0; sc < 3; sc++) for (int k = 0; k < 16; k++) {
+    for (int pc = 0; pc < 4; pc++) t.sigk[sc][pc][k] = c.sigpat[pc][c.pos4[sc][k]];
+    t.sigk[sc][4][k] = c.ctxmap4x4[c.pos4[sc][k]];
+  }
+  return t;
+}
+static __device__ const CoreTabs g_core_tabs = make_core_tabs();
+static __device__ const TokTabs g_tok_tabs = make_tok_tabs();
+static_assert(sizeof(CoreTabs) % 4 == 0 && sizeof(TokTabs) % 16 == 0, "copied by dwords / 16-byte words");
+
+// A lane's 4x4 sub-block in registers: its sixteen levels in scan order as int16 pairs and the significance mask (bit k = scan position k).  Everything the
+// tokenizer does with a sub-block -- two passes over its coefficients -- reads these eight registers with compile-time indices (the loops below are unrolled
+// over the sixteen positions) instead of a dependent LDS read per coefficient and pass (round 4: 10 of a wave's 17.7 us, profiles/r04_tok_phases.txt).
+struct SbRegs { uint32_t w[8]; uint32_t m; };
+__device__ __forceinline__ int sb_level(const SbRegs &r, int k) { return (int)(int16_t)(uint16_t)(r.w[k >> 1] >> ((k & 1) * 16)); }      // k: a compile-time constant where it matters
+
+__device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d, const int16_t *lv, int stride, int log2, int scan_idx, int lane, SbRegs &sb)
 {
   const int sbl = log2 - 2, nsb2 = 1 << (2 * sbl);
   d.csbf[lane] = 0;
   wave_sync();
   bool nz = false;
+  sb.m = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) sb.w[k] = 0;
   if (lane < nsb2) {
     int xs, ys; scan_pos(t, scan_idx, sbl, lane, xs, ys);
     const int16_t *p = lv + (ys << 2) * stride + (xs << 2);
     uint2 r0 = *reinterpret_cast<const uint2 *>(p), r1 = *reinterpret_cast<const uint2 *>(p + stride);
     uint2 r2 = *reinterpret_cast<const uint2 *>(p + 2 * stride), r3 = *reinterpret_cast<const uint2 *>(p + 3 * stride);
-    // the lane's 32 bytes of the digest: first the sub-block in raster order, then, read back through the scan table,
-    // the same levels in scan order (all reads are done before the first write of the second form)
+    // the lane's 32 bytes of the digest's scratch: the sub-block in raster order, read back through the scan table in scan order
     uint2 *dst = reinterpret_cast<uint2 *>(&d.scan[lane * 16]);
     dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
     const uint8_t *pos = t->pos4[scan_idx];
@@ -1601,16 +1628,85 @@ __device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d
     uint32_t m = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) { v[k] = d.scan[lane * 16 + pos[k]]; if (v[k]) m |= 1u << k; }
-    uint32_t *d32 = reinterpret_cast<uint32_t *>(&d.scan[lane * 16]);
 #pragma unroll
-    for (int k = 0; k < 8; k++) d32[k] = ((uint32_t)v[2 * k] & 0xffffu) | ((uint32_t)v[2 * k + 1] << 16);
+    for (int k = 0; k < 8; k++) sb.w[k] = ((uint32_t)v[2 * k] & 0xffffu) | ((uint32_t)v[2 * k + 1] << 16);
+    sb.m = m;
     d.mask[lane] = (uint16_t)m;
     nz = m != 0;
     if (nz) d.csbf[ys * 8 + xs] = 1;
   }
-  uint64_t sb = __ballot(nz);
-  if (lane == 0) d.sbmask = sb;
+  uint64_t sb64 = __ballot(nz);
+  if (lane == 0) d.sbmask = sb64;
   wave_sync();
+}
+
+// subblock_g1_any() from registers: one of the sub-block's first eight coefficients in coding order has |level| > 1
+__device__ __forceinline__ bool sb_g1_any(const SbRegs &r)
+{
+  bool any = false; int seen = 0;
+#pragma unroll
+  for (int k = 15; k >= 0; k--) if ((r.m >> k) & 1) { const int v = sb_level(r, k); if (seen < 8 && (v > 1 || v < -1)) any = true; seen++; }
+  return any;
+}
+
+// enc_subblock() (hevc_core.h: the statement both forms follow, and the one the host tests drive) for a sub-block held in registers.  sk: the sixteen context
+// patterns of the sub-block's scan positions (TokTabs::sigk row, four dwords).
+template <class S>
+__device__ __forceinline__ void enc_subblock_regs(S &c, const TuDigest &d, const SbRegs &r, const uint32_t (&sk)[4], int i, int last_sb, int last_pos, bool prev_g1, int log2, int cidx, int scan_idx, int sign_hiding)
+{
+  const int sbl = log2 - 2, nsb = 1 << sbl;
+  int xs, ys; scan_pos(c.tabs, scan_idx, sbl, i, xs, ys);
+  const int right = (xs < nsb - 1) ? d.csbf[ys * 8 + xs + 1] : 0;
+  const int below = (ys < nsb - 1) ? d.csbf[(ys + 1) * 8 + xs] : 0;
+  const uint32_t m = r.m;
+  int coded = m != 0, infer_dc = 0;
+  if (i < last_sb && i > 0) {
+    cabac_bin(c, CTX_CSBF + ((right | below) ? 1 : 0) + (cidx ? 2 : 0), coded);
+    infer_dc = 1;
+  } else coded = 1;                        // inferred 1 for the last and the DC sub-block
+  if (!coded) return;
+  const int sigbase = CTX_SIG + (cidx ? 27 : 0);
+  const int off = log2 == 2 ? 0 : (cidx == 0 ? ((i > 0 ? 3 : 0) + ((log2 == 3) ? ((scan_idx == 0) ? 9 : 15) : 21)) : ((log2 == 3) ? 9 : 12));
+  const int start = (i == last_sb) ? last_pos - 1 : 15;
+  if constexpr (sink_counts_only<S>::value) {
+    if (start >= 0) c.n += start + 1 - ((infer_dc && (m >> 1) == 0) ? 1 : 0);
+  } else {
+#pragma unroll
+    for (int k = 15; k >= 1; k--) if (k <= start) cabac_bin(c, sigbase + (int)((sk[k >> 2] >> ((k & 3) * 8)) & 0xffu) + off, (int)((m >> k) & 1));
+    if (start >= 0 && !(infer_dc && (m >> 1) == 0))                 // (position 0: not sent when every other flag of a coded sub-block is zero; the block's DC coefficient has its own context)
+      cabac_bin(c, sigbase + ((i == 0 && log2 != 2) ? 0 : (int)(sk[0] & 0xffu) + off), (int)(m & 1));
+  }
+  if (!m) return;
+  int ctx_set = (i > 0 && cidx == 0) ? 2 : 0;
+  if (prev_g1) ctx_set++;
+  int c1 = 1, nsig = 0, g1idx = -1, g2 = 0;
+  uint32_t signs = 0;
+#pragma unroll
+  for (int k = 15; k >= 0; k--) if ((m >> k) & 1) {
+    const int v = sb_level(r, k), a = v < 0 ? -v : v;
+    signs = (signs << 1) | (v < 0 ? 1u : 0u);
+    if (nsig < 8) {
+      const int g1 = a > 1;
+      cabac_bin(c, CTX_GT1 + (cidx ? 16 : 0) + ctx_set * 4 + c1, g1);
+      if (g1) { c1 = 0; if (g1idx < 0) { g1idx = nsig; g2 = a > 2; } }
+      else if (c1 > 0 && c1 < 3) c1++;
+    }
+    nsig++;
+  }
+  if (g1idx >= 0) cabac_bin(c, CTX_GT2 + (cidx ? 4 : 0) + ctx_set, g2);
+  if (sign_hiding && (31 - __builtin_clz(m)) - __builtin_ctz(m) > 3) cabac_bypass_bits(c, signs >> 1, nsig - 1);
+  else cabac_bypass_bits(c, signs, nsig);
+  int rice = 0, j = 0;
+#pragma unroll
+  for (int k = 15; k >= 0; k--) if ((m >> k) & 1) {
+    const int v = sb_level(r, k), a = v < 0 ? -v : v;
+    const int base = (j < 8) ? ((j == g1idx) ? 3 : 2) : 1;
+    if (a >= base) {
+      enc_abs_remaining(c, a - base, rice);
+      if (a > 3 * (1 << rice)) rice = imin(rice + 1, 4);
+    }
+    j++;
+  }
 }
 
 #define TOK_HDR_CAP 192        // split flags + CU header + last-position bins waiting for the piece they open
@@ -1631,8 +1727,13 @@ __device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d
 // emitters writes the tokens at their final offsets -- through a small LDS arena when the piece
 // fits, which keeps the kernel at ~10 KB of LDS per wave.  k_tok_compact restores coding order
 // from the (offset, length) table [ctu][unit][piece].
+// waves per SIMD the register budget is cut for: six (80 registers) spilled eight of them once a sub-block's levels stayed in registers (round 5); five (102) holds all
+#ifndef KVZ_TOK_WAVES
+#define KVZ_TOK_WAVES 5
+#endif
 struct alignas(16) TokWave {
   TuDigest dg;
+  TokTabs tk;
   CoreTabs tabs;
   CuRec tile[9];
   uint16_t hdr[TOK_HDR_CAP];
@@ -1642,7 +1743,7 @@ struct alignas(16) TokWave {
   uint32_t seg[TOK_PIECES][2];
 };
 template <bool ALLC, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) void k_tokenize(EncFrame f)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(KVZ_TOK_WAVES))) void k_tokenize(EncFrame f)
 {
   __shared__ TokWave tw[NW];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1690,7 +1791,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) vo
     }
   }
   TOK_PH();                                                        // 1: the unit has something to say
-  core_tabs_fill_entry(tabs, lane);
+  for (int i = lane; i < (int)(sizeof(CoreTabs) / 4); i += 64) reinterpret_cast<uint32_t *>(&tabs)[i] = reinterpret_cast<const uint32_t *>(&g_core_tabs)[i];
+  if (lane < (int)(sizeof(TokTabs) / 16)) reinterpret_cast<uint4 *>(&W.tk)[lane] = reinterpret_cast<const uint4 *>(&g_tok_tabs)[lane];
   if (lane < TOK_PIECES) { seg[lane][0] = 0; seg[lane][1] = 0; }
   if (lane == 0) hdr_n = 0;
   const int bx0 = ux * 2 - 1, by0 = uy * 2 - 1;
@@ -1750,7 +1852,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) vo
         const int l2 = ci ? cu.log2 - 1 : cu.log2, pw = ci ? (f.cw >> 1) : f.cw;
         const int px = ci ? (x0 >> 1) : x0, py = ci ? (y0 >> 1) : y0;
         const int scan = intra_scan_idx(cu.intra, l2, ci, cu.intra_mode);
-        digest_build_wave(&tabs, dg, f.coef[ci] + py * pw + px, pw, l2, scan, lane);   // ends with a barrier
+        SbRegs sb;
+        digest_build_wave(&tabs, dg, f.coef[ci] + py * pw + px, pw, l2, scan, lane, sb);   // ends with a barrier
         TOK_PH();                                                  // 4: digest
         const uint64_t sbm = dg.sbmask;
         const int last_sb = 63 - __builtin_clzll(sbm);
@@ -1762,18 +1865,27 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) vo
         }
         // greater1 context-set carry: sub-block i inherits from the next non-empty sub-block above it
         const bool nzsb = (sbm >> lane) & 1;
-        const bool g1 = nzsb && subblock_g1_any(&tabs, dg, lane, scan);
+        const bool g1 = nzsb && sb_g1_any(sb);
         const uint64_t g1m = __ballot(g1);
         bool prev_g1 = false;
         if (lane <= last_sb) {
           uint64_t above = (lane < 63) ? (sbm >> (lane + 1)) : 0;      // non-empty sub-blocks coded before this one
           if (above) { int j = lane + 1 + __builtin_ctzll(above); prev_g1 = (g1m >> j) & 1; }
         }
+        // the sub-block's sixteen sig_coeff_flag context patterns: by the neighbouring sub-blocks' coded flags, or the 4x4 block's own map
+        uint32_t sk[4] = {0, 0, 0, 0};
+        if (lane <= last_sb) {
+          const int sbl = l2 - 2, nsb = 1 << sbl;
+          int xs, ys; scan_pos(&tabs, scan, sbl, lane, xs, ys);
+          const int right = (xs < nsb - 1) ? dg.csbf[ys * 8 + xs + 1] : 0, below = (ys < nsb - 1) ? dg.csbf[(ys + 1) * 8 + xs] : 0;
+          const uint4 q = *reinterpret_cast<const uint4 *>(W.tk.sigk[scan][l2 == 2 ? 4 : (right | (below << 1))]);
+          sk[0] = q.x; sk[1] = q.y; sk[2] = q.z; sk[3] = q.w;
+        }
         // pass 1: count
         int n_l = 0;
         if (lane <= last_sb) {
           TokCount t; t.tabs = &tabs; t.n = 0;
-          enc_subblock(t, dg, lane, last_sb, last_pos, prev_g1, l2, ci, scan, f.signhide);
+          enc_subblock_regs(t, dg, sb, sk, lane, last_sb, last_pos, prev_g1, l2, ci, scan, f.signhide);
           n_l = t.n;
         }
         // offsets in coding order: sub-block last_sb first, then downwards
@@ -1793,7 +1905,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(6))) vo
           for (int i = lane; i < hn; i += 64) dst[i] = hdr[i];
           if (lane <= last_sb && n_l) {                               // pass 2: the same emitters, now writing at the final offsets
             TokOut t; t.tabs = &tabs; t.p = dst + hn + off; t.n = 0; t.cap = n_l;
-            enc_subblock(t, dg, lane, last_sb, last_pos, prev_g1, l2, ci, scan, f.signhide);
+            enc_subblock_regs(t, dg, sb, sk, lane, last_sb, last_pos, prev_g1, l2, ci, scan, f.signhide);
           }
           if (staged) {
             wave_sync();

@@ -233,7 +233,7 @@ struct CoreTabs {
   uint8_t pos4[3][16];               // scan position k of a 4x4 block -> x | y << 2 (= raster index), per scan_idx
   uint8_t sigpat[4][16];             // sig_coeff_flag context pattern (9.3.4.2.5) by prev_csbf and raster position
 };
-KVZ_HD void core_tabs_fill_entry(CoreTabs &t, int i)     // i in [0, 64): callers may spread i over lanes
+KVZ_HD constexpr void core_tabs_fill_entry(CoreTabs &t, int i)     // i in [0, 64): callers may spread i over lanes
 {
   t.lps4[i] = (uint32_t)kRangeLps[i][0] | ((uint32_t)kRangeLps[i][1] << 8) | ((uint32_t)kRangeLps[i][2] << 16) | ((uint32_t)kRangeLps[i][3] << 24);
   t.next_lps[i] = kNextLps[i];

@@ -73,6 +73,19 @@ def report(wl, fps, lat):
     for a, b in zip(have[:-1], have[1:]):
         d = sorted((ev[p][b] - ev[p][a]) / 1e3 for p in pics)
         print("  %-9s -> %-9s %8.1f   (p90 %8.1f)" % (a, b, d[len(d) // 2], d[len(d) * 9 // 10]))
+    # the rows of one picture's parse (row0 / row1 records carry the substream's index; the picture is the one whose dec0 .. dlaunch0 window they fall in)
+    rows = []
+    for line in open(TL):
+        ns, tid, what, pic = line.split()
+        if what in ("row0", "row1"):
+            rows.append((int(ns), int(tid), what, int(pic)))
+    if rows and pics:
+        p = pics[len(pics) // 2]
+        a, b = ev[p]["dec0"], ev[p]["dlaunch0"]
+        st = {r[3]: (r[0], r[1]) for r in rows if r[2] == "row0" and a <= r[0] <= b}
+        en = {r[3]: r[0] for r in rows if r[2] == "row1" and a <= r[0] <= b}
+        print("rows of picture %d's parse (us from dec0; %d threads took part):" % (p, len({v[1] for v in st.values()})))
+        print("  " + "  ".join("%d:%.0f-%.0f" % (k, (st[k][0] - a) / 1e3, (en.get(k, b) - a) / 1e3) for k in sorted(st)))
     d = sorted((ev[p]["out1"] - ev[p]["feed0"]) / 1e3 for p in pics)
     print("  feed0 -> out1 %8.1f (p90 %.1f)" % (d[len(d) // 2], d[len(d) * 9 // 10]))
     print("stages: feed0 filter has the input | copied memcpy into the kvz_picture done | up0 encoder_encode entered | sub1 upload + kernels queued | gpudone tokens on the host |"

@@ -226,6 +226,114 @@ __global__ __launch_bounds__(64) void k_cabac_rows(CabacRowsArgs a)
   if (lane == 0) { a.sub_off[blockIdx.x] = o2; a.sub_len[blockIdx.x] = failed ? ~0u : c.pos; a.sub_bins[blockIdx.x] = c.nbins; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Measurement aid (KVAZZUP_AMD_PARSE_PROBE=1 with gpu-entropy=1; profiles/r05_gpu_parse_ab.txt): the arithmetic DECODER of 9.3.4.3 as a wave-scalar
+// program, the mirror image of k_cabac_rows -- the lower bound of what parsing slice data on the GPU would cost per bin.  One wave per substream decodes
+// the bytes k_cabac_rows just wrote, with the context of every bin taken from the substream's own token list (a real parser has to derive it from the
+// syntax: more instructions per bin, never fewer) and checks every decoded bin against the token's value; mismatches are counted (none may occur).
+// Registers as in k_cabac_rows: contexts four to a lane, rangeTabLps and both state transitions one lane per state; the substream's bytes arrive 256 at a
+// time (one dword per lane) and are taken out with v_readlane.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_cabac_decode_probe(CabacRowsArgs a, uint32_t *mismatch)
+{
+  const int lane = threadIdx.x;
+  const int r = a.first_sub + (int)blockIdx.x;
+  const int first_cy = a.wpp ? r : tile_row_first(a.hc, a.tile_rows, r);
+  const int ncy = a.wpp ? 1 : tile_row_first(a.hc, a.tile_rows, r + 1) - first_cy;
+  const int nctu = ncy * a.wc, ctu0 = first_cy * a.wc;
+  const uint32_t len = a.sub_len[blockIdx.x];
+  if (len == ~0u || len == 0) return;
+  const uint32_t *bytes = (const uint32_t *)(a.out + a.sub_off[blockIdx.x]);      // (substreams start on 16-byte boundaries of the output buffer)
+  const uint32_t lpsv = (uint32_t)kRangeLps[lane][0] | ((uint32_t)kRangeLps[lane][1] << 8) | ((uint32_t)kRangeLps[lane][2] << 16) | ((uint32_t)kRangeLps[lane][3] << 24);
+  const uint32_t nlpsv = kNextLps[lane];
+  uint32_t ctxv = 0;
+  const bool fresh = !a.wpp || tile_row_starts_at(a.hc, a.tile_rows, r);
+  if (fresh) {
+    const int qp = clip3(0, 51, a.qp);
+    for (int k = 0; k < 4; k++) {
+      const int i = lane * 4 + k;
+      if (i < CTX_COUNT) {
+        const int v = kCabacInit[a.init_type][i];
+        const int slope = (v >> 4) * 5 - 45, offs = ((v & 15) << 3) - 16;
+        const int pre = clip3(1, 126, ((slope * qp) >> 4) + offs);
+        const int mps = pre <= 63 ? 0 : 1;
+        ctxv |= (uint32_t)(((mps ? pre - 64 : 63 - pre) << 1) | mps) << (8 * k);
+      }
+    }
+  } else if (lane < 40) ctxv = ld_l2_u32(a.ctx_save + (size_t)(r - 1) * 40 + lane);      // (k_cabac_rows of this picture has finished: every row's hand-over copy is there)
+  // ---- the bitstream: dword `w` of the substream, big-endian bits; wv holds dwords [wbase, wbase + 64)
+  uint32_t wbase = 0, wv = (wbase + lane) * 4 < len + 3 ? bytes[wbase + lane] : 0;
+  uint32_t nextw = 0;                                    // next dword to take
+  auto take_word = [&]() -> uint32_t {
+    if (nextw - wbase >= 64) { wbase += 64; wv = (wbase + lane) * 4 < len + 3 ? bytes[wbase + lane] : 0; }
+    const uint32_t w = rl(wv, nextw - wbase); nextw++;
+    return __builtin_bswap32(w);
+  };
+  // value = ivlOffset scaled by 2^bits, followed by `bits` not yet consumed stream bits (the host decoder's form, decoder.hip CabacRegs)
+  unsigned long long value = take_word(); int bits = 32 - 9; uint32_t range = 510;
+  { value = (value << 32) | take_word(); bits += 32; }
+  uint32_t bad = 0, nbins = 0;
+  int cx = 0, i0 = 0;
+  int n = a.count[ctu0]; uint32_t base = a.off[ctu0];
+  uint32_t tokv = (i0 + lane < n) ? a.tok[base + i0 + lane] : 0;
+  while (cx < nctu) {
+    int ncx = cx, ni0 = i0 + 64, nn = n; uint32_t nbase = base;
+    if (ni0 >= n) {
+      ncx = cx + 1; ni0 = 0;
+      while (ncx < nctu) { nn = a.count[ctu0 + ncx]; nbase = a.off[ctu0 + ncx]; if (nn > 0) break; ncx++; }
+    }
+    uint32_t tokn = 0;
+    if (ncx < nctu && ni0 + lane < nn) tokn = a.tok[nbase + ni0 + lane];
+    const int m = n - i0 < 64 ? n - i0 : 64;
+    for (int j = 0; j < m; j++) {
+      const uint32_t t = rl(tokv, (uint32_t)j);
+      if (!(t & 0x8000u)) {
+        const uint32_t ci = t >> 1, cl = ci >> 2, sh = (ci & 3) * 8;
+        const uint32_t w = rl(ctxv, cl), s = (w >> sh) & 0xffu, st = s >> 1;
+        const uint32_t lps = (rl(lpsv, st) >> (((range >> 6) & 3) * 8)) & 0xffu;
+        nbins++;
+        range -= lps;
+        const unsigned long long scaled = (unsigned long long)range << bits;
+        uint32_t ns, bin;
+        if (value >= scaled) {                              // least probable symbol
+          value -= scaled; bin = (s & 1u) ^ 1u;
+          const int nb = __builtin_clz(lps) - 23;
+          range = lps << nb; bits -= nb;
+          ns = (rl(nlpsv, st) << 1) | ((s & 1u) ^ (st == 0 ? 1u : 0u));
+        } else {
+          bin = s & 1u;
+          ns = s + (st < 62 ? 2u : 0u);
+          if (range < 256) { range <<= 1; bits--; }
+        }
+        ctxv = wl((w & ~(0xffu << sh)) | (ns << sh), cl, ctxv);
+        bad += bin != (t & 1u);
+      } else if (!(t & 0x4000u)) {
+        const int nb = (int)((t >> 10) & 15) + 1;
+        nbins += (uint32_t)nb;
+        uint32_t v = 0;
+        for (int k = 0; k < nb; k++) { bits--; const unsigned long long scaled = (unsigned long long)range << bits; v <<= 1; if (value >= scaled) { value -= scaled; v |= 1u; } }
+        bad += v != (t & ((1u << nb) - 1u));
+      } else {
+        nbins++;
+        range -= 2;
+        uint32_t bin = 0;
+        if (value >= ((unsigned long long)range << bits)) bin = 1;
+        else if (range < 256) { range <<= 1; bits--; }
+        bad += bin != (t & 1u);
+      }
+      if (bits < 16) { value = (value << 32) | take_word(); bits += 32; }
+    }
+    if (i0 + 64 >= n) { n = nn; base = nbase; }
+    cx = ncx; i0 = ni0; tokv = tokn;
+  }
+  if (lane == 0) { atomicAdd(mismatch, bad); atomicAdd(mismatch + 1, nbins); }
+}
+
+void launch_cabac_decode_probe(const CabacRowsArgs &a, int nsub, uint32_t *mismatch, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_cabac_decode_probe, dim3(nsub), dim3(64), 0, st, a, mismatch);
+}
+
 void launch_cabac_rows(const CabacRowsArgs &a, int nsub, hipStream_t st)
 {
   hipLaunchKernelGGL(k_cabac_rows, dim3(nsub), dim3(64), 0, st, a);

@@ -157,8 +157,10 @@ class Decoder {
   int pending() const { return (int)(job_head_ - job_tail_) + (gpu_job_ ? 1 : 0) + (int)gpu_q_.size(); }
 
   // ---- per-picture state shared with the slice-data parser (decoder.hip)
-  // one per substream.  Two cache lines each: the rows of a picture are parsed side by side, every one appending to ITS vectors all the time -- with the
-  // vectors' headers of neighbouring rows in one cache line (56-byte objects back to back) each append invalidated the line under the neighbour's hands
+  // one per substream.  Two cache lines each: the rows of a picture are parsed side by side, every one appending to ITS vectors all the time -- the
+  // vectors' headers of neighbouring rows do not share a cache line.  (What limits the row-parallel parse is WPP itself: a row may not start before the row
+  // above has finished two CTUs, and where a clip's bins sit in a few CTUs per row -- the benchmark's moving objects fill the left quarter -- those two CTUs
+  // are most of a row: seventeen rows of a 1080p P picture end 55 us apart, 0.8 ms in all, as long as one thread takes -- tools/measure/owf0_timeline.py.)
   struct alignas(128) SubOut { std::vector<uint32_t> levels; std::vector<DecTu> tus; int rc = 0; };
   struct alignas(64) Progress { std::atomic<int> v{0}; char pad[60]; };   // one cache line per row: no false sharing between pollers
   struct SliceHdr {

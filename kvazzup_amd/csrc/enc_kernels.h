@@ -34,4 +34,5 @@ struct CabacRowsArgs {
   int wc, hc, wpp, tile_rows, init_type, qp, first_sub;
 };
 void launch_cabac_rows(const CabacRowsArgs &a, int nsub, hipStream_t st);
+void launch_cabac_decode_probe(const CabacRowsArgs &a, int nsub, uint32_t *mismatch, hipStream_t st);      // measurement aid (cabac_kernels.hip)
 }  // namespace kvzx

@@ -703,42 +703,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || AD
   if constexpr (RC) rc_group_done(f, s, grp, rc_cost, tid);
 }
 
-// One workgroup per CTU.  The CU records the derivations read -- the CTU's 8 x 8 units and one ring of units around them -- are fetched into LDS in ONE round
-// of independent loads (a thread per record: size, intra flag, cbf, vector); then a thread per 8x8 unit derives the signalling of the CU it lies in from
-// LDS alone and writes its own five entries.  Every unit of a CU derives the same values, so nobody loops over a CU storing single bytes.
-// (Round 4: a thread per 16x16 block reading global memory as it went -- five dependent round trips, 22 us at 1080p on a part whose launch floor is 5.)
-struct SignalTile {
-  uint32_t mv[10 * 10]; uint8_t log2[10 * 10], intra[10 * 10], cbf[10 * 10];       // unit (ux, uy) of the CTU, -1 .. 8 each way, at (uy + 1) * 10 + ux + 1
-  int X0, Y0;
-  __device__ MvRec at(int x, int y) const
-  {
-    const int i = (((y - Y0) >> 3) + 1) * 10 + ((x - X0) >> 3) + 1;
-    MvRec r; r.intra = intra[i]; r.mx = (int)(int16_t)(mv[i] & 0xffffu); r.my = (int)(int16_t)(mv[i] >> 16); r.cbf = cbf[i];
-    return r;
-  }
-};
-__global__ __launch_bounds__(128) void k_inter_signal(EncFrame f)
+// One thread per 8x8 unit: it derives the signalling of the CU it lies in and writes its OWN five entries -- every unit of a CU (4 of a 16x16, 16 of a
+// 32x32) derives the same values from the same few bytes (cache hits), so nobody loops over a CU's units storing single bytes and a wave's stores are
+// consecutive.  Measured in isolation at 1080p (profiles/r05_iso1080p_kernel_stats.csv and HISTORY.md): a thread per 16x16 block (round 4) 22 us; this form
+// 20-21 us; one workgroup per CTU with the records staged in LDS by one round of loads 28-32 us (slower: twice the waves, a barrier) -- the kernel is
+// neither bound by its round trips to memory nor by its instruction count; what it costs is mostly being a launch of its own on the tokenizer's stream.
+__global__ __launch_bounds__(64) void k_inter_signal(EncFrame f)
 {
-  __shared__ SignalTile t;
-  const int wc = f.cw >> 6, tid = threadIdx.x;
-  const int cx = blockIdx.x % wc, cy = blockIdx.x / wc + f.row0, X0 = cx * 64, Y0 = cy * 64;
-  if (tid == 0) { t.X0 = X0; t.Y0 = Y0; }
-  if (tid < 100) {
-    const int x = X0 + (tid % 10 - 1) * 8, y = Y0 + (tid / 10 - 1) * 8;
-    uint32_t mv = 0; int l2 = 0, in = 1, cb = 0;            // outside the picture: never asked for (avail64 says no first); "intra" keeps it harmless
-    if (x >= 0 && y >= 0 && x < f.cw && y < (f.chp & 0xfffff)) {
-      const int g = b8idx(f, x, y);
-      l2 = f.cu_log2[g]; in = f.cu_intra[g]; cb = f.cu_cbf[g]; mv = *reinterpret_cast<const uint32_t *>(&f.cu_mv[g * 2]);
-    }
-    t.mv[tid] = mv; t.log2[tid] = (uint8_t)l2; t.intra[tid] = (uint8_t)in; t.cbf[tid] = (uint8_t)cb;
-  }
-  __syncthreads();
-  if (tid >= 64) return;
-  const int x = X0 + (tid & 7) * 8, y = Y0 + (tid >> 3) * 8, i = ((tid >> 3) + 1) * 10 + (tid & 7) + 1;
-  if (t.intra[i]) return;                               // an intra unit in a P picture (intra-in-P)
-  const int cl = t.log2[i], n = 1 << cl;
-  const CuSignal r = decide_signalling_values(t, f.cw, f.chp, x & ~(n - 1), y & ~(n - 1), cl);
-  const int g = b8idx(f, x, y);
+  const int w8 = f.cw >> 3, h8 = band_rows(f) * 8;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w8 * h8) return;
+  const int x = (i % w8) * 8, y = (i / w8) * 8 + f.row0 * 64, g = b8idx(f, x, y);
+  const int cl = f.cu_log2[g];
+  if (f.cu_intra[g]) return;                            // an intra unit in a P picture (intra-in-P)
+  const int n = 1 << cl;
+  const CuSignal r = decide_signalling_values(f, x & ~(n - 1), y & ~(n - 1), cl);
   f.cu_flags[g] = (uint8_t)r.flags; f.cu_merge_idx[g] = (uint8_t)r.midx; f.cu_mvp_idx[g] = (uint8_t)r.mvp;
   *reinterpret_cast<uint32_t *>(&f.cu_mvd[g * 2]) = ((uint32_t)r.mvdx & 0xffffu) | ((uint32_t)r.mvdy << 16);
 }
@@ -2341,7 +2320,8 @@ void launch_inter_recon(const EncFrame &f, hipStream_t st)
 }
 void launch_inter_signal(const EncFrame &f, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_inter_signal, dim3((f.cw / 64) * band_rows(f)), dim3(128), 0, st, f);
+  const int n = (f.cw / 8) * (band_rows(f) * 8);
+  hipLaunchKernelGGL(k_inter_signal, dim3((n + 63) / 64), dim3(64), 0, st, f);
 }
 void launch_intra_analyse(const EncFrame &f, hipStream_t st)
 {

@@ -144,6 +144,7 @@ class Encoder {
   hipEvent_t ev_h2d_[kInRing] = {}, ev_pad_[kInRing] = {}; bool pad_pending_[kInRing] = {}, h2d_pending_[kInRing] = {};
   long in_count_ = 0;
   hipStream_t stream_rec_ = nullptr;     // download of reconstructions the caller asks for (encoder_encode's pic_out)
+  uint32_t *probe_words_ = nullptr;      // KVAZZUP_AMD_PARSE_PROBE: {wrong bins, bins} of k_cabac_decode_probe
   // Per-picture working sets (padded source planes, level planes, CU arrays, per-CTU QP arrays, SAO parameters): kSets of them take turns, so the
   // host can queue kSets - 1 pictures' kernels ahead of the one the GPU is working on without waiting for a set to come free (with two sets
   // the input stage of picture t waited for the reconstruction of t - 2, and the calling thread with it: the main stream ran dry between pictures)

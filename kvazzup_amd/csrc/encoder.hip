@@ -251,6 +251,12 @@ void Encoder::bind_set(int k)
 
 Encoder::~Encoder()
 {
+  if (probe_words_) {
+    uint32_t w[2] = {0, 0};
+    hipDeviceSynchronize(); hipMemcpy(w, probe_words_, sizeof(w), hipMemcpyDeviceToHost);
+    fprintf(stderr, "kvazzup_amd parse probe: %u bins decoded on the GPU, %u differ from the token list\n", w[1], w[0]);
+    hipFree(probe_words_);
+  }
   if (getenv("KVAZZUP_AMD_TRACE")) fprintf(stderr, "kvazzup_amd encoder thread ms: submit %.1f  wait_gpu %.1f  arith %.1f  assemble %.1f  wait_input %.1f  (pictures %ld)\n", t_submit_, t_wait_, t_arith_, t_asm_, t_in_, collected_);
   { std::lock_guard<std::mutex> l(sm_); squit_ = true; }
   scv_.notify_all();
@@ -651,6 +657,13 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     a.ctx_save = sl.g_ctx_save; a.ctx_ready = sl.g_ctx_ready; a.gen = ++sl.gen; a.err = err_;
     a.wc = cw_ / 64; a.hc = rows_; a.wpp = cfg_.wpp; a.tile_rows = cfg_.tile_rows; a.init_type = intra ? 0 : 1; a.qp = qp_cur_; a.first_sub = 0;
     timed(K_CABAC_ROWS, sl.ent_stream, [&] { launch_cabac_rows(a, nsub, sl.ent_stream); });
+    // measurement aid (KVAZZUP_AMD_PARSE_PROBE=1): the decoder's mirror of the coder over the substreams just written -- what arithmetic DECODING costs a wave
+    // per bin on this GPU, the lower bound of a slice-data parser there (cabac_kernels.hip k_cabac_decode_probe; the count of wrong bins must stay 0)
+    static const bool parse_probe = getenv("KVAZZUP_AMD_PARSE_PROBE") != nullptr;
+    if (parse_probe) {
+      if (!probe_words_) { HIP_CHECK(hipMalloc(&probe_words_, 2 * sizeof(uint32_t))); HIP_CHECK(hipMemset(probe_words_, 0, 2 * sizeof(uint32_t))); }
+      launch_cabac_decode_probe(a, nsub, probe_words_, sl.ent_stream);
+    }
     HIP_CHECK(hipEventRecord(sl.done, sl.ent_stream));
   } else
   HIP_CHECK(hipEventRecord(sl.done, stream_tok_));

@@ -868,12 +868,20 @@ KVZ_HD NbMv nb_mv(const V &v, int cw, int chp, int xc, int yc, int xn, int yn)
 }
 KVZ_HD bool same_mv(const NbMv &a, const NbMv &b) { return a.mx == b.mx && a.my == b.my; }
 
-// the five merge candidates (8.5.3.2.2-8.5.3.2.5) of the 2Nx2N PU at (x0, y0), size n
+// the five spatial neighbours of the 2Nx2N PU at (x0, y0), size n, that both the merge and the AMVP derivation read (8.5.3.2.3, 8.5.3.2.7)
+struct FiveNb { NbMv A0, A1, B0, B1, B2; };
 template <class V>
-KVZ_HD void merge_cand_list(const V &v, int cw, int chp, int x0, int y0, int n, int cmx[5], int cmy[5])
+KVZ_HD FiveNb five_neighbours(const V &v, int cw, int chp, int x0, int y0, int n)
 {
-  NbMv A1 = nb_mv(v, cw, chp, x0, y0, x0 - 1, y0 + n - 1), B1 = nb_mv(v, cw, chp, x0, y0, x0 + n - 1, y0 - 1);
-  NbMv B0 = nb_mv(v, cw, chp, x0, y0, x0 + n, y0 - 1), A0 = nb_mv(v, cw, chp, x0, y0, x0 - 1, y0 + n), B2 = nb_mv(v, cw, chp, x0, y0, x0 - 1, y0 - 1);
+  FiveNb q;
+  q.A1 = nb_mv(v, cw, chp, x0, y0, x0 - 1, y0 + n - 1); q.B1 = nb_mv(v, cw, chp, x0, y0, x0 + n - 1, y0 - 1);
+  q.B0 = nb_mv(v, cw, chp, x0, y0, x0 + n, y0 - 1); q.A0 = nb_mv(v, cw, chp, x0, y0, x0 - 1, y0 + n); q.B2 = nb_mv(v, cw, chp, x0, y0, x0 - 1, y0 - 1);
+  return q;
+}
+// the five merge candidates (8.5.3.2.2-8.5.3.2.5)
+KVZ_HD void merge_cand_list(const FiveNb &q, int cmx[5], int cmy[5])
+{
+  const NbMv &A1 = q.A1, &B1 = q.B1, &B0 = q.B0, &A0 = q.A0, &B2 = q.B2;
   bool fA1 = A1.ok;
   bool fB1 = B1.ok && !(A1.ok && same_mv(A1, B1));
   bool fB0 = B0.ok && !(B1.ok && same_mv(B1, B0));
@@ -887,13 +895,11 @@ KVZ_HD void merge_cand_list(const V &v, int cw, int chp, int x0, int y0, int n, 
   if (fB2 && nc < 5) { cmx[nc] = B2.mx; cmy[nc] = B2.my; nc++; }
   while (nc < 5) { cmx[nc] = 0; cmy[nc] = 0; nc++; }        // zero candidates (refIdx 0 for one reference)
 }
-KVZ_HD void merge_cand_list(const EncFrame &f, int x0, int y0, int n, int cmx[5], int cmy[5]) { FrameMvView v{f}; merge_cand_list(v, f.cw, f.chp, x0, y0, n, cmx, cmy); }
+KVZ_HD void merge_cand_list(const EncFrame &f, int x0, int y0, int n, int cmx[5], int cmy[5]) { FrameMvView v{f}; merge_cand_list(five_neighbours(v, f.cw, f.chp, x0, y0, n), cmx, cmy); }
 // the two AMVP candidates (8.5.3.2.6-8.5.3.2.7); every neighbour refers to the same picture
-template <class V>
-KVZ_HD void amvp_cand_list(const V &v, int cw, int chp, int x0, int y0, int n, int px[2], int py[2])
+KVZ_HD void amvp_cand_list(const FiveNb &q, int px[2], int py[2])
 {
-  NbMv A0 = nb_mv(v, cw, chp, x0, y0, x0 - 1, y0 + n), A1 = nb_mv(v, cw, chp, x0, y0, x0 - 1, y0 + n - 1);
-  NbMv B0 = nb_mv(v, cw, chp, x0, y0, x0 + n, y0 - 1), B1 = nb_mv(v, cw, chp, x0, y0, x0 + n - 1, y0 - 1), B2 = nb_mv(v, cw, chp, x0, y0, x0 - 1, y0 - 1);
+  const NbMv &A1 = q.A1, &B1 = q.B1, &B0 = q.B0, &A0 = q.A0, &B2 = q.B2;
   bool haveA = A0.ok || A1.ok, haveB = B0.ok || B1.ok || B2.ok;
   NbMv a = A0.ok ? A0 : A1, b = B0.ok ? B0 : (B1.ok ? B1 : B2);
   if (!haveA && haveB) { a = b; haveA = true; }          // isScaledFlag == 0: A takes B's vector
@@ -902,7 +908,7 @@ KVZ_HD void amvp_cand_list(const V &v, int cw, int chp, int x0, int y0, int n, i
   if (haveB && !(haveA && a.mx == b.mx && a.my == b.my)) { px[np] = b.mx; py[np] = b.my; np++; }
   while (np < 2) { px[np] = 0; py[np] = 0; np++; }
 }
-KVZ_HD void amvp_cand_list(const EncFrame &f, int x0, int y0, int n, int px[2], int py[2]) { FrameMvView v{f}; amvp_cand_list(v, f.cw, f.chp, x0, y0, n, px, py); }
+KVZ_HD void amvp_cand_list(const EncFrame &f, int x0, int y0, int n, int px[2], int py[2]) { FrameMvView v{f}; amvp_cand_list(five_neighbours(v, f.cw, f.chp, x0, y0, n), px, py); }
 
 // the signalling of the inter CU at (x0, y0): merge (+ skip) with the first candidate that equals its vector, else AMVP with the cheaper predictor
 struct CuSignal { int flags, midx, mvp, mvdx, mvdy; };
@@ -912,14 +918,15 @@ KVZ_HD CuSignal decide_signalling_values(const V &v, int cw, int chp, int x0, in
   const int n = 1 << log2;
   const MvRec own = v.at(x0, y0);
   const int mvx = own.mx, mvy = own.my;
+  const FiveNb q = five_neighbours(v, cw, chp, x0, y0, n);      // (once for both derivations: ten availability tests and record fetches were most of k_inter_signal's code)
   int cmx[5], cmy[5];
-  merge_cand_list(v, cw, chp, x0, y0, n, cmx, cmy);
+  merge_cand_list(q, cmx, cmy);
   CuSignal r; r.flags = 0; r.midx = 0; r.mvp = 0; r.mvdx = 0; r.mvdy = 0;
   for (int k = 4; k >= 0; k--) if (cmx[k] == mvx && cmy[k] == mvy) { r.flags = CU_MERGE; r.midx = k; }      // (the first match wins)
   if (r.flags && own.cbf == 0) r.flags |= CU_SKIP;
   if (!r.flags) {
     int px[2], py[2];
-    amvp_cand_list(v, cw, chp, x0, y0, n, px, py);
+    amvp_cand_list(q, px, py);
     int b0 = mvd_bits(mvx - px[0]) + mvd_bits(mvy - py[0]);
     int b1 = mvd_bits(mvx - px[1]) + mvd_bits(mvy - py[1]);
     r.mvp = b1 < b0;

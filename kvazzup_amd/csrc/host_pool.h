@@ -100,10 +100,9 @@ class OrderedPool {
     done_.store(0, std::memory_order_relaxed);
     total_.store(n, std::memory_order_relaxed);
     next_.store(0, std::memory_order_release);
-    // The helpers sleep on the generation word itself and are woken TOGETHER by one futex call.  (Until round 5 they slept on a condition variable: a
-    // notify_all hands the waiters to the variable's mutex one after the other -- helper k started a wake-up latency after helper k - 1, and a picture's
-    // seventeen-row parse, whose rows follow each other at two CTUs' distance, was over before the fourth helper had its first row: the "row-parallel"
-    // parser of the synchronous decoder ran at one thread's speed, 0.81 ms of a 1.5 ms total delay at 1080p -- tools/measure/owf0_timeline.py.)
+    // The helpers sleep on the generation word itself and are woken together by one futex call (until round 5: a condition variable; measured on the
+    // MI355X box's EPYC 9575F, tools/measure/pool_wake, no difference -- seventeen chained 50 us tasks take ~150 us with sixteen threads either way,
+    // the last helper starts ~60 us after the call -- this form is the simpler one and spins briefly before it sleeps).
     if (n > 1 && !workers_.empty()) { gen_.fetch_add(1, std::memory_order_acq_rel); futex_wake_all(gen_); }
     drain();
     for (int d; (d = done_.load(std::memory_order_acquire)) < n;) futex_wait(done_, d);      // (the worker that finishes the last task wakes it)

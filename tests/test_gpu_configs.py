@@ -163,6 +163,17 @@ def test_config3_bench_command_with_two_ranks(gpu):
         # bench processes, never).  That is the box's state, not this command's: try again when the neighbours have moved on.
         if line["value"] > 100.0:
             break
+        # (evidence for the crawl, kept where the GPU run's scratch files are brought back from: what the bench itself measured about its host side)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "two_rank_crawl.jsonl"), "a") as fh:
+                c = line["config"]
+                fh.write(json.dumps({"attempt": attempt, "value": line["value"], "ms_per_step": line["ms_per_step"], "host_cpu_cores_busy": c.get("host_cpu_cores_busy"),
+                                     "host_cpu_throttled_ms": c.get("host_cpu_throttled_ms"), "host_cpu_budget_cores": c.get("host_cpu_budget_cores"),
+                                     "kernels_us": line.get("kernels_us"), "loadavg": open("/proc/loadavg").read().split()[:3],
+                                     "cpu_stat": open("/sys/fs/cgroup/cpu.stat").read().split() if os.path.exists("/sys/fs/cgroup/cpu.stat") else None}) + "\n")
+        except Exception:
+            pass
         time.sleep(20)
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["streams"] == 2 and line["config"]["collective_backend"] == "gloo"
     assert line["metric"] == "hevc_encode_decode_fps" and line["unit"] == "frames/s" and line["steps"] == 4

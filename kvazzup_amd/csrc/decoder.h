@@ -296,7 +296,8 @@ class Decoder {
   std::unique_ptr<FrameWorkers> workers_;
   // decoded picture buffer: slot = device planes + what reference marking needs
   struct DpbPic { uint8_t *plane[3] = {nullptr, nullptr, nullptr}; int poc = 0; bool is_ref = false, used = false; long decode_idx = -1000; std::shared_ptr<ColMotion> motion;
-                  hipEvent_t last_dl = nullptr; };     // download mode: the copy of the picture last reconstructed here (a later picture's kernels wait for it before they write the buffer)
+                  hipEvent_t last_dl = nullptr;
+                  hipEvent_t last_use = nullptr; bool last_use_alt = false; };      // (two chains, below: the last picture that read or wrote the buffer, and the stream it ran on)     // download mode: the copy of the picture last reconstructed here (a later picture's kernels wait for it before they write the buffer)
   DpbPic dpb_[KVZ_DEC_MAX_REFS];
   // device side
   // Frame-threaded mode keeps up to gpu_depth_ pictures queued on the GPU (launched, not yet completed): a picture's way through upload, kernels
@@ -309,6 +310,13 @@ class Decoder {
   uint8_t *work_[3] = {nullptr, nullptr, nullptr};          // pictures with SAO: reconstruction and deblocking happen here, the filter writes into the slot
   uint32_t *edge_col_ = nullptr; unsigned long long *edge_row_ = nullptr; uint32_t chain_gen_ = 0;      // k_dec_intra's tagged hand-off words (dec_frame.h), the generation of the last launch
   uint32_t *progress_ = nullptr, *intra_order_ = nullptr, *err_ = nullptr; uint32_t *h_err_ = nullptr;
+  // A picture without inter blocks depends on no other picture, and its chain (k_dec_intra: 0.55 ms at 1080p) keeps a few dozen compute units busy: with the
+  // frame-threaded decoder such pictures ALTERNATE between the decoder's stream and a second one with chain arrays of its own, so that two chains run side by
+  // side (an all-intra stream, BASELINE configs[0]: the decoder's rate was 1 / chain).  Pictures that read or overwrite a buffer last used on the other stream
+  // wait for that picture's event.
+  hipStream_t stream_alt_ = nullptr; bool alt_ok_ = false; long intra_seq_ = 0;
+  uint32_t *progress_alt_ = nullptr, *edge_col_alt_ = nullptr; unsigned long long *edge_row_alt_ = nullptr; int16_t *resid_alt_[3] = {nullptr, nullptr, nullptr}; uint8_t *work_alt_[3] = {nullptr, nullptr, nullptr};
+  bool ensure_alt();
   // download mode: page-locked output buffers take turns -- one is what libOpenHevcGetOutput last handed out (valid until the next
   // decode call, openhevcfilter.cpp:218-229 copies at once), one receives the picture whose kernels are running, queued behind them on
   // the download stream at launch, so the copy over PCIe overlaps the next picture's kernels instead of stalling the calling thread
@@ -335,7 +343,7 @@ class Decoder {
   std::unique_ptr<OrderedPool> pool_; int parse_threads_ = 16; std::mutex pool_mutex_;   // (frame workers: one picture at a time on the row pool)
   PicJob *timed_job_ = nullptr;
   double k_ms_[DK_COUNT] = {0}; uint64_t k_n_[DK_COUNT] = {0};
-  template <class F> void timed(int id, F &&launch);
+  template <class F> void timed(int id, F &&launch, hipStream_t st = nullptr);
 };
 
 }  // namespace kvzx

@@ -1064,6 +1064,7 @@ void Decoder::sync_main()
 {
   if (batch_used_) { DecBatcher::get(device_).drain(this); batch_used_ = false; }
   hipStreamSynchronize(stream_);
+  if (stream_alt_) hipStreamSynchronize(stream_alt_);
 }
 
 Decoder::~Decoder()
@@ -1087,6 +1088,7 @@ Decoder::~Decoder()
   stream_release(stream_up_, device_, 'U', prio_up_);
   for (auto &e : up_done_) if (e) hipEventDestroy(e);
   if (h_err_) hipHostFree(h_err_);
+  if (stream_alt_) stream_release(stream_alt_, device_, 'E', prio_);
   stream_release(stream_, device_, 'D', prio_);
 }
 
@@ -1134,6 +1136,12 @@ void Decoder::free_buffers()
   for (auto &p : d_in_) { hipFree(p); p = nullptr; }
   for (auto &c : d_in_cap_) c = 0;
   hipFree(progress_); hipFree(edge_col_); edge_col_ = nullptr; hipFree(edge_row_); edge_row_ = nullptr; hipFree(intra_order_); intra_order_ = nullptr;
+  if (stream_alt_) {
+    hipStreamSynchronize(stream_alt_);
+    hipFree(progress_alt_); progress_alt_ = nullptr; hipFree(edge_col_alt_); edge_col_alt_ = nullptr; hipFree(edge_row_alt_); edge_row_alt_ = nullptr;
+    for (int c = 0; c < 3; c++) { hipFree(resid_alt_[c]); resid_alt_[c] = nullptr; hipFree(work_alt_[c]); work_alt_[c] = nullptr; }
+    stream_release(stream_alt_, device_, 'E', prio_); stream_alt_ = nullptr;
+  }
   for (auto &p : dpb_) { hipFree(p.plane[0]); p = DpbPic(); }      // (a buffer's three planes are one allocation)
   for (int c = 0; c < 3; c++) { hipFree(work_[c]); work_[c] = nullptr; hipFree(resid_[c]); resid_[c] = nullptr; }
   progress_ = nullptr;
@@ -1256,13 +1264,27 @@ int Decoder::alloc_slot()
   return -1;
 }
 
-template <class F> void Decoder::timed(int id, F &&launch)
+template <class F> void Decoder::timed(int id, F &&launch, hipStream_t st)
 {
   if (!prof_now_) { launch(); return; }
+  if (!st) st = stream_;
   PicJob &j = *timed_job_;
   if (j.ev_used == j.ev.size()) { PicJob::EvPair p; hipEventCreate(&p.a); hipEventCreate(&p.b); p.id = id; j.ev.push_back(p); }
   PicJob::EvPair &p = j.ev[j.ev_used++]; p.id = id;
-  hipEventRecord(p.a, stream_); launch(); hipEventRecord(p.b, stream_);
+  hipEventRecord(p.a, st); launch(); hipEventRecord(p.b, st);
+}
+// the second chain's stream and arrays (decoder.h stream_alt_), on first use
+bool Decoder::ensure_alt()
+{
+  if (stream_alt_) return true;
+  if (hipSetDevice(device_) != hipSuccess) return false;
+  const size_t nctu = (size_t)(pw_ / 64) * (ph_ / 64), npx = (size_t)pw_ * ph_;
+  HIP_TRY(stream_acquire(&stream_alt_, device_, 'E', prio_));
+  HIP_TRY(hipMalloc(&progress_alt_, sizeof(uint32_t) * (3 * nctu + 1))); HIP_TRY(hipMemset(progress_alt_, 0, sizeof(uint32_t) * (3 * nctu + 1)));
+  HIP_TRY(hipMalloc(&edge_col_alt_, nctu * 128 * sizeof(uint32_t))); HIP_TRY(hipMemset(edge_col_alt_, 0, nctu * 128 * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&edge_row_alt_, nctu * 32 * 8)); HIP_TRY(hipMemset(edge_row_alt_, 0, nctu * 32 * 8));
+  for (int c = 0; c < 3; c++) { HIP_TRY(hipMalloc(&resid_alt_[c], sizeof(int16_t) * (c ? npx / 4 : npx))); HIP_TRY(hipMalloc(&work_alt_[c], c ? npx / 4 : npx)); }
+  return true;
 }
 void Decoder::get_kernel_times(double *ms, uint64_t *launches, bool reset)
 {
@@ -2380,20 +2402,29 @@ int Decoder::launch_gpu(PicJob &job)
   f.w = w_; f.h = h_; f.pw = pw_; f.ph = ph_; f.wc = (w_ + 63) / 64; f.hc = (h_ + 63) / 64;
   f.b4 = (const B4Rec *)d_in_; f.b4x = bi ? (const B4L1 *)(d_in_ + x_off) : nullptr; f.region = (const TuRange *)(d_in_ + off_region()); f.ctu = (const TuRange *)(d_in_ + off_ctu());
   f.ctu_tile = d_in_ + off_tile(); f.tus = (const DecTu *)(d_in_ + tu_off); f.lev = (const uint32_t *)(d_in_ + lev_off); f.ntu = (int)ntu;
-  for (int c = 0; c < 3; c++) f.resid[c] = resid_[c];
+  // which chain: a picture without inter blocks, every other one of them, with the frame-threaded decoder on its own (decoder.h stream_alt_)
+  DecBatcher &batcher = DecBatcher::get(device_);
+  const bool batched = band_nrows_ == 0 && batch_attached_ && batcher.active();
+  static const bool alt_off = getenv("KVAZZUP_AMD_DEC_ONE_CHAIN") != nullptr;
+  bool alt = !alt_off && !batched && band_nrows_ == 0 && frame_threads_ > 1 && gpu_depth_ > 1 && job.any_intra && !job.any_inter && ((intra_seq_++) & 1);
+  if (alt && !ensure_alt()) alt = false;
+  const hipStream_t st = alt ? stream_alt_ : stream_;
+  for (int c = 0; c < 3; c++) f.resid[c] = alt ? resid_alt_[c] : resid_[c];
   const bool sao = job.sh.sao_luma || job.sh.sao_chroma;      // the picture is then built in work_ and filtered into its buffer
-  for (int c = 0; c < 3; c++) { f.rec[c] = sao ? work_[c] : dpb_[job.slot].plane[c]; f.out[c] = dpb_[job.slot].plane[c]; }
+  for (int c = 0; c < 3; c++) { f.rec[c] = sao ? (alt ? work_alt_[c] : work_[c]) : dpb_[job.slot].plane[c]; f.out[c] = dpb_[job.slot].plane[c]; }
   for (int k = 0; k < KVZ_DEC_MAX_REFS; k++) for (int c = 0; c < 3; c++) f.ref[k][c] = dpb_[k].plane[c];
   f.sao = sao ? (const SaoParams *)(d_in_ + off_sao()) : nullptr;
-  f.progress = progress_; f.intra_order = intra_order_; f.err = err_;
-  { const size_t nctu = (size_t)f.wc * f.hc; f.edge_col[0] = edge_col_; f.edge_col[1] = edge_col_ + nctu * 64; f.edge_col[2] = edge_col_ + nctu * 96;
-    f.edge_row[0] = edge_row_; f.edge_row[1] = edge_row_ + nctu * 16; f.edge_row[2] = edge_row_ + nctu * 24; }
+  f.progress = alt ? progress_alt_ : progress_; f.intra_order = intra_order_; f.err = err_;
+  { const size_t nctu = (size_t)f.wc * f.hc; uint32_t *ec = alt ? edge_col_alt_ : edge_col_; unsigned long long *er = alt ? edge_row_alt_ : edge_row_;
+    f.edge_col[0] = ec; f.edge_col[1] = ec + nctu * 64; f.edge_col[2] = ec + nctu * 96;
+    f.edge_row[0] = er; f.edge_row[1] = er + nctu * 16; f.edge_row[2] = er + nctu * 24; }
   if (job.any_intra) {                                     // a generation of its own for every launch of the chain: 1 .. 2^24 - 1; at the wrap both arrays go back to "never written"
     if (++chain_gen_ >= (1u << 24)) {
       const size_t nctu = (size_t)(pw_ / 64) * (ph_ / 64);
       sync_main();                                         // (everything this decoder has submitted has run: nothing reads the words while they are cleared)
       // (on the consuming stream: the decoder's streams are non-blocking, nothing would order the next chain behind a clear on the null stream)
       if (hipMemsetAsync(edge_col_, 0, nctu * 128 * sizeof(uint32_t), stream_) != hipSuccess || hipMemsetAsync(edge_row_, 0, nctu * 32 * 8, stream_) != hipSuccess) return DEC_ERR_GPU;
+      if (stream_alt_ && (hipMemsetAsync(edge_col_alt_, 0, nctu * 128 * sizeof(uint32_t), stream_alt_) != hipSuccess || hipMemsetAsync(edge_row_alt_, 0, nctu * 32 * 8, stream_alt_) != hipSuccess)) return DEC_ERR_GPU;
       chain_gen_ = 1;
     }
     f.chain_gen = chain_gen_;
@@ -2419,9 +2450,8 @@ int Decoder::launch_gpu(PicJob &job)
   }
   // Several decoders open on this device: the picture goes to the device's submission layer (batch.h), which launches the waiting pictures of
   // all of them together; its descriptor travels inside the input block.  One decoder: it launches for itself, frame by value.
-  DecBatcher &batcher = DecBatcher::get(device_);
-  const bool batched = band_nrows_ == 0 && batch_attached_ && batcher.active();
-  if (!batched && batch_used_) { batcher.drain(this); batch_used_ = false; }       // (the other decoder has just closed: what this one still has queued there comes first)
+  if (!batched && batch_used_) { batcher.drain(this); batch_used_ = false; }
+  if (batched && stream_alt_) hipStreamSynchronize(stream_alt_);      // (another decoder has opened: from here on the submission layer launches on the shared stream; the second chain's last pictures first)       // (the other decoder has just closed: what this one still has queued there comes first)
   if (batched) memcpy(job.h_in + off_frame(), &f, sizeof(f));
   if (hipMemcpyAsync(d_in_, job.h_in, bytes, hipMemcpyHostToDevice, stream_up_) != hipSuccess) return DEC_ERR_GPU;
   if (hipEventRecord(up_done_[ib], stream_up_) != hipSuccess) return DEC_ERR_GPU;
@@ -2440,17 +2470,29 @@ int Decoder::launch_gpu(PicJob &job)
     gpu_q_.push_back(&job);
     return 0;
   }
-  if (hipStreamWaitEvent(stream_, up_done_[ib], 0) != hipSuccess) return DEC_ERR_GPU;
+  if (hipStreamWaitEvent(st, up_done_[ib], 0) != hipSuccess) return DEC_ERR_GPU;
   // the buffer the picture is built in: the copy to the host of the picture last reconstructed there (queued, maybe not yet run) comes first
-  if (dpb_[job.slot].last_dl) { if (hipStreamWaitEvent(stream_, dpb_[job.slot].last_dl, 0) != hipSuccess) return DEC_ERR_GPU; dpb_[job.slot].last_dl = nullptr; }
-  if (job.any_inter) timed(DK_INTER, [&] { launch_dec_inter(f, stream_); });
+  if (dpb_[job.slot].last_dl) { if (hipStreamWaitEvent(st, dpb_[job.slot].last_dl, 0) != hipSuccess) return DEC_ERR_GPU; dpb_[job.slot].last_dl = nullptr; }
+  // two chains: whatever this picture writes (its buffer) or reads (its reference pictures) was last touched by a picture on the OTHER stream -> after that one
+  if (stream_alt_) {
+    auto after = [&](DpbPic &d) { return !(d.last_use && d.last_use_alt != alt) || hipStreamWaitEvent(st, d.last_use, 0) == hipSuccess; };
+    if (!after(dpb_[job.slot])) return DEC_ERR_GPU;
+    for (int k = 0; k < job.nref; k++) if (!after(dpb_[job.ref_slot[k]])) return DEC_ERR_GPU;
+    for (int k = 0; k < job.nref1; k++) if (!after(dpb_[job.ref_slot1[k]])) return DEC_ERR_GPU;
+  }
+  if (job.any_inter) timed(DK_INTER, [&] { launch_dec_inter(f, st); }, st);
   if (job.any_intra) {
-    timed(job.any_inter ? DK_INTRA_P : DK_INTRA, [&] { launch_dec_intra_resid(f, stream_); launch_dec_intra(f, stream_); });
+    timed(job.any_inter ? DK_INTRA_P : DK_INTRA, [&] { launch_dec_intra_resid(f, st); launch_dec_intra(f, st); }, st);
   }
   if (band_nrows_ > 0) { band_f_ = f; band_din_ = d_in_; }       // deblocking follows the halo exchange (band_deblock)
-  else if (!job.sh.deblock_disabled) timed(DK_DEBLOCK, [&] { launch_dec_deblock(f, stream_); });
-  if (sao) timed(DK_SAO, [&] { launch_dec_sao(f, stream_); });
-  if (hipEventRecord(job.done, stream_) != hipSuccess) return DEC_ERR_GPU;
+  else if (!job.sh.deblock_disabled) timed(DK_DEBLOCK, [&] { launch_dec_deblock(f, st); }, st);
+  if (sao) timed(DK_SAO, [&] { launch_dec_sao(f, st); }, st);
+  if (hipEventRecord(job.done, st) != hipSuccess) return DEC_ERR_GPU;
+  // (the picture's event now stands for the last use of its buffer and of every buffer it read; a job's event is recorded again only when its ring entry is
+  // reused -- by a later picture, whose kernels are queued behind this one's on one of the two streams or wait for it through these same marks)
+  dpb_[job.slot].last_use = job.done; dpb_[job.slot].last_use_alt = alt;
+  for (int k = 0; k < job.nref; k++) { dpb_[job.ref_slot[k]].last_use = job.done; dpb_[job.ref_slot[k]].last_use_alt = alt; }
+  for (int k = 0; k < job.nref1; k++) { dpb_[job.ref_slot1[k]].last_use = job.done; dpb_[job.ref_slot1[k]].last_use_alt = alt; }
   job.dl_buf = -1; job.launch_idx = launched_;
   t_api_ += tk_api.ms();
   launched_++;

@@ -187,7 +187,7 @@ class Encoder {
 
   // An intra picture depends on no other picture: its chain (1.6 ms at 1080p, twenty picture intervals) is queued on a stream of its own the moment the
   // picture is accepted, beside the P pictures in front of it that the main stream is still working through; the next P picture waits for ev_idr_done_.
-  hipStream_t stream_idr_ = nullptr; hipEvent_t ev_idr_done_ = nullptr; bool idr_pending_ = false, idr_side_ = false;
+  hipStream_t stream_idr_ = nullptr; hipEvent_t ev_idr_done_ = nullptr; bool idr_pending_ = false, idr_side_ = false, all_intra_alt_ = false;
   // ... with its own copies of what the P pictures' kernels also use while it runs beside them (round 4: the side chain also with SAO, intra units in P
   // pictures, per-CTU QPs and rate control v2 -- uvgComm's default mode): progress counters + ticket word, the CTUs' edge columns, the SAO work picture
   uint32_t *sync_idr_ = nullptr; uint32_t *edge_col_idr_ = nullptr; uint32_t chain_gen_ = 0; unsigned long long *edge_row_ = nullptr, *edge_row_idr_ = nullptr; uint8_t *work_idr_[3] = {nullptr, nullptr, nullptr};

@@ -118,7 +118,11 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   // (not when every picture is an intra picture: then the chains ARE the main stream's work, and the next picture's analysis belongs beside them on the
   // input stream, not behind them -- all-intra 1080p 940 -> 1 300 frames/s)
   idr_side_ = depth_ >= 2 && cfg.vaq == 0 && cfg.band_rows == 0 && cfg.intra_period != 1 && !getenv("KVAZZUP_AMD_IDR_INLINE");
-  if (idr_side_) {
+  // Every picture an intra picture (BASELINE configs[0]): no picture depends on another, and one chain keeps a few dozen compute units busy for 0.7 ms --
+  // the pictures ALTERNATE between the main stream with its arrays and a second stream with the side chain's (round 5: all-intra 1080p was bound by
+  // one chain after the other, 1 / (0.67 + 0.03 ms)).  The second stream is one of its own here: the input stream carries every picture's analysis.
+  all_intra_alt_ = depth_ >= 2 && cfg.vaq == 0 && cfg.band_rows == 0 && cfg.intra_period == 1 && !getenv("KVAZZUP_AMD_IDR_INLINE");
+  if (idr_side_ || all_intra_alt_) {
     const size_t nsync = ((size_t)rows_ * (cw_ / 64) * 3 + 2 + 3) & ~(size_t)3, nctu_ = (size_t)(cw_ / 64) * rows_;
     HIP_OK(hipMalloc(&sync_idr_, sizeof(uint32_t) * nsync)); HIP_OK(hipMemset(sync_idr_, 0, sizeof(uint32_t) * nsync));
     HIP_OK(hipMalloc(&edge_col_idr_, nctu_ * 128 * sizeof(uint32_t))); HIP_OK(hipMemset(edge_col_idr_, 0, nctu_ * 128 * sizeof(uint32_t)));
@@ -128,7 +132,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
     // its chain, and a further stream would share a hardware queue with one that matters (HIP spreads a priority level's streams over four;
     // measured with a stream of its own: no gain at the default level, half the rate at any other -- KVAZZUP_AMD_IDR_PRIO)
     const char *lv = getenv("KVAZZUP_AMD_IDR_PRIO");
-    if (lv) HIP_OK(stream_acquire(&stream_idr_, cfg.device, 'X', lv[0])); else stream_idr_ = stream_in_;
+    if (lv || all_intra_alt_) HIP_OK(stream_acquire(&stream_idr_, cfg.device, 'X', lv ? lv[0] : prio_[0])); else stream_idr_ = stream_in_;
     HIP_OK(hipEventCreateWithFlags(&ev_idr_done_, kDeviceEvent));
   }
   // intra scratch: ic8 (nb8 u32) | ic16 (nb8/4 u32) | ic32 (nb8/16 u32) | im8 | im16 | im32
@@ -301,7 +305,7 @@ Encoder::~Encoder()
   for (int k = 0; k < kSets; k++) if (ev_src_free_[k]) hipEventDestroy(ev_src_free_[k]);
   stream_release(stream_tok_, cfg_.device, 'T', prio_[1]);
   stream_release(stream_in_, cfg_.device, 'I', prio_[2]);
-  if (stream_idr_ && stream_idr_ != stream_in_) { const char *lv = getenv("KVAZZUP_AMD_IDR_PRIO"); stream_release(stream_idr_, cfg_.device, 'X', lv ? lv[0] : 'n'); }
+  if (stream_idr_ && stream_idr_ != stream_in_) { const char *lv = getenv("KVAZZUP_AMD_IDR_PRIO"); stream_release(stream_idr_, cfg_.device, 'X', lv ? lv[0] : (all_intra_alt_ ? prio_[0] : 'n')); }
   if (ev_idr_done_) hipEventDestroy(ev_idr_done_);
   hipFree(intra_scratch_); hipFree(d_scaling_);
   delete entropy_; delete entropy2_;
@@ -576,7 +580,7 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err; f_.ent_cursors = sl.g_cursors;
   f_.tok_cursor = (uint32_t *)tok_count_ + (size_t)(frame_idx_ & 1) * tok_nctu_; f_.tok_cursor_next = (uint32_t *)tok_count_ + (size_t)((frame_idx_ + 1) & 1) * tok_nctu_;
   // the stream this picture's chain runs on: an intra picture's own (encoder.h stream_idr_), else the main stream -- behind the last intra picture's chain
-  const bool side = intra && idr_side_;
+  const bool side = intra && (idr_side_ || (all_intra_alt_ && (frame_idx_ & 1)));
   const hipStream_t ms = side ? stream_idr_ : stream_;
   f_.chain_gen = next_chain_gen();
   if (side) {                                               // beside the P pictures still on the main stream: nothing of theirs is touched
@@ -593,6 +597,7 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     f_.edge_col[0] = edge_col_; f_.edge_col[1] = edge_col_ + nctu * 64; f_.edge_col[2] = edge_col_ + nctu * 96;
     f_.edge_row[0] = edge_row_; f_.edge_row[1] = edge_row_ + nctu * 16; f_.edge_row[2] = edge_row_ + nctu * 24;
   }
+  if (all_intra_alt_) idr_pending_ = false;                 // (alternating intra pictures: the main stream's next picture has nothing to do with the side stream's last)
   if (!side && idr_pending_) { HIP_CHECK(hipStreamWaitEvent(stream_, ev_idr_done_, 0)); idr_pending_ = false; }
   if (src_busy_[set_]) { HIP_CHECK(hipStreamWaitEvent(stream_in_, ev_src_free_[set_], 0)); src_busy_[set_] = false; }   // the last picture that used this set (t - kSets) has been reconstructed
   timed(K_PAD, stream_in_, [&] { launch_pad_input(d_i420, w, h, src_[set_][0], src_[set_][1], src_[set_][2], cw_, ch_, stream_in_); });

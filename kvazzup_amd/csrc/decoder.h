@@ -314,7 +314,7 @@ class Decoder {
   // frame-threaded decoder such pictures ALTERNATE between the decoder's stream and a second one with chain arrays of its own, so that two chains run side by
   // side (an all-intra stream, BASELINE configs[0]: the decoder's rate was 1 / chain).  Pictures that read or overwrite a buffer last used on the other stream
   // wait for that picture's event.
-  hipStream_t stream_alt_ = nullptr; bool alt_ok_ = false; long intra_seq_ = 0;
+  hipStream_t stream_alt_ = nullptr; char alt_prio_ = 'n'; long intra_seq_ = 0;
   uint32_t *progress_alt_ = nullptr, *edge_col_alt_ = nullptr; unsigned long long *edge_row_alt_ = nullptr; int16_t *resid_alt_[3] = {nullptr, nullptr, nullptr}; uint8_t *work_alt_[3] = {nullptr, nullptr, nullptr};
   bool ensure_alt();
   // download mode: page-locked output buffers take turns -- one is what libOpenHevcGetOutput last handed out (valid until the next

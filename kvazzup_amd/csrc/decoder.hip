@@ -1088,7 +1088,7 @@ Decoder::~Decoder()
   stream_release(stream_up_, device_, 'U', prio_up_);
   for (auto &e : up_done_) if (e) hipEventDestroy(e);
   if (h_err_) hipHostFree(h_err_);
-  if (stream_alt_) stream_release(stream_alt_, device_, 'E', prio_);
+  if (stream_alt_) stream_release(stream_alt_, device_, 'E', alt_prio_);
   stream_release(stream_, device_, 'D', prio_);
 }
 
@@ -1140,7 +1140,7 @@ void Decoder::free_buffers()
     hipStreamSynchronize(stream_alt_);
     hipFree(progress_alt_); progress_alt_ = nullptr; hipFree(edge_col_alt_); edge_col_alt_ = nullptr; hipFree(edge_row_alt_); edge_row_alt_ = nullptr;
     for (int c = 0; c < 3; c++) { hipFree(resid_alt_[c]); resid_alt_[c] = nullptr; hipFree(work_alt_[c]); work_alt_[c] = nullptr; }
-    stream_release(stream_alt_, device_, 'E', prio_); stream_alt_ = nullptr;
+    stream_release(stream_alt_, device_, 'E', alt_prio_); stream_alt_ = nullptr;
   }
   for (auto &p : dpb_) { hipFree(p.plane[0]); p = DpbPic(); }      // (a buffer's three planes are one allocation)
   for (int c = 0; c < 3; c++) { hipFree(work_[c]); work_[c] = nullptr; hipFree(resid_[c]); resid_[c] = nullptr; }
@@ -1279,7 +1279,11 @@ bool Decoder::ensure_alt()
   if (stream_alt_) return true;
   if (hipSetDevice(device_) != hipSuccess) return false;
   const size_t nctu = (size_t)(pw_ / 64) * (ph_ / 64), npx = (size_t)pw_ * ph_;
-  HIP_TRY(stream_acquire(&stream_alt_, device_, 'E', prio_));
+  // the second chain's priority level = its pool of hardware queues: the LOWEST level, where nothing else of this library lives (measured, all-intra 1080p with
+  // the encoder's second chain at the main stream's level: second decoder chain at the default level 1 563 frames/s -- the level's four queues are taken by
+  // tokenizer, input, decoder and transfers --, at the high level 1 681, at the low one 1 724; one chain each side: 1 279)
+  { const char *e = getenv("KVAZZUP_AMD_DEC_ALT_PRIO"); alt_prio_ = e ? e[0] : 'l'; }
+  HIP_TRY(stream_acquire(&stream_alt_, device_, 'E', alt_prio_));
   HIP_TRY(hipMalloc(&progress_alt_, sizeof(uint32_t) * (3 * nctu + 1))); HIP_TRY(hipMemset(progress_alt_, 0, sizeof(uint32_t) * (3 * nctu + 1)));
   HIP_TRY(hipMalloc(&edge_col_alt_, nctu * 128 * sizeof(uint32_t))); HIP_TRY(hipMemset(edge_col_alt_, 0, nctu * 128 * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&edge_row_alt_, nctu * 32 * 8)); HIP_TRY(hipMemset(edge_row_alt_, 0, nctu * 32 * 8));

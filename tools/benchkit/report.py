@@ -35,7 +35,7 @@ def roofline_of(m, steps, me_range, workload_key):
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  null when no pass exists.
     traffic, traffic_src = None, None
     mfma = None
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         try:
             name = "profiles/%s_pmc_traffic_%s.json" % (rnd, workload_key)
             pmc = json.load(open(os.path.join(ROOT, name)))

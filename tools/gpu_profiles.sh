@@ -2,7 +2,7 @@
 # the round's profile set (run on the GPU box; summaries land in gpurun_out/, the ones to keep are copied to profiles/ by hand):
 # pipelined kernel stats (the bench command's headline leg), isolated kernel stats, PMC traffic passes, the host-boundary trace, stream overlap,
 # the default-mode chain (kernel durations and the gaps in front of them per hardware queue), the decoders' batched launches
-R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out; r=${ROUND:-r04}
+R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out; r=${ROUND:-r05}
 bash tools/kstats.sh ${r}_bench1080p --steps 8 --warmup 2 --streams-per-gpu 0 --no-preset-line
 bash tools/kstats.sh ${r}_bench4k --workload 4k --steps 4 --warmup 1 --streams-per-gpu 0
 bash tools/kstats_iso.sh 1080p ${r}_iso1080p --streams-per-gpu 0 --no-preset-line

@@ -157,10 +157,11 @@ def test_config3_bench_command_with_two_ranks(gpu):
         assert r.returncode == 0, r.stderr[-3000:]
         assert "device error" not in r.stderr, r.stderr[-3000:]
         line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-        # Under `pytest -n 3` this command shares the GPU with three test processes that keep the HIP streams of everything they have run so far: with
-        # enough user queues alive on one device the driver oversubscribes its run list and time-slices the PROCESSES -- kernel times stay what they
-        # are, the host sits idle, and a step takes seconds (10 - 30 frames/s, seen in 60 % of the suite's parallel runs; alone, or beside three other
-        # bench processes, never).  That is the box's state, not this command's: try again when the neighbours have moved on.
+        # Beside OTHER PROCESSES THAT ARE RUNNING GPU TESTS (pytest -n 3) this command has been seen to crawl at 8 - 30 frames/s with normal kernel times and an
+        # idle host (two of six parallel suite runs in round 5).  What it is NOT (tools/measure/two_rank_neighbours.sh, queue_share/, profiles/r05_two_rank_*.txt):
+        # neighbours that merely hold HIP contexts and streams (2 625 against 3 376 frames/s alone), neighbours that burn the job's CPU quota (2 257, throttled),
+        # or the number of hardware queues as such (a hop between two streams costs 13.5 us alone, 36 - 53 us beside four processes with eight streams each).
+        # Alone -- the way the driver runs the suite -- it never happened.  Two more attempts once the neighbours have moved on; then the rate is asserted.
         if line["value"] > 100.0:
             break
         # (evidence for the crawl, kept where the GPU run's scratch files are brought back from: what the bench itself measured about its host side)
@@ -177,12 +178,9 @@ def test_config3_bench_command_with_two_ranks(gpu):
         time.sleep(20)
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["streams"] == 2 and line["config"]["collective_backend"] == "gloo"
     assert line["metric"] == "hevc_encode_decode_fps" and line["unit"] == "frames/s" and line["steps"] == 4
-    # (the rate itself is the bench's business, not a parity condition: a run that crawled three times beside busy neighbours is reported, not failed --
-    # every structural condition, the device-error checks and the PSNR still hold for it)
-    if line["value"] <= 100.0:
-        import warnings
-        warnings.warn("two-rank bench at %.1f frames/s after three attempts: the GPU's run list is oversubscribed by neighbouring processes" % line["value"])
-    assert 1.0 < line["value"] < 100000.0, (line["value"], line["config"].get("host_cpu_cores_busy"))
+    # two ranks time-slicing one GPU run at a third of one rank's rate, not at a three-hundredth: three attempts at 8 - 30 frames/s are a failure
+    # (gpurun_out/two_rank_crawl.jsonl then holds what the bench measured about its host side during each of them)
+    assert 100.0 < line["value"] < 100000.0, (line["value"], line["config"].get("host_cpu_cores_busy"), line["config"].get("host_cpu_throttled_ms"))
     assert "error flags" not in r.stderr, r.stderr[-3000:]
     assert abs(line["value"] - 2 * 64 / (line["ms_per_step"] / 1e3)) < 1.0          # whole-job frames per second: both ranks' pictures over the slowest rank's time
     assert 30.0 < line["config"]["psnr_y"] < 50.0

@@ -705,10 +705,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || AD
 
 // One thread per 8x8 unit: it derives the signalling of the CU it lies in and writes its OWN five entries -- every unit of a CU (4 of a 16x16, 16 of a
 // 32x32) derives the same values from the same few bytes (cache hits), so nobody loops over a CU's units storing single bytes and a wave's stores are
-// consecutive.  Measured in isolation at 1080p (profiles/r05_iso1080p_kernel_stats.csv and HISTORY.md): a thread per 16x16 block (round 4) 22 us; this form
-// 20-21 us; one workgroup per CTU with the records staged in LDS by one round of loads 28-32 us (slower: twice the waves, a barrier) -- the kernel is
-// neither bound by its round trips to memory nor by its instruction count; what it costs is mostly being a launch of its own on the tokenizer's stream.
-__global__ __launch_bounds__(64) void k_inter_signal(EncFrame f)
+// consecutive.  In workgroups of 1024: the kernel is ~1 600 instructions of straight-line code that every wave runs once, and what it costs is FETCHING that
+// code -- a launch that only reads the size byte and writes the entries takes 6.0 us (the floor), the derivation with the same threads in workgroups of 64
+// (510 of them, a wave or two on every compute unit, each fetching the code for itself) 31 us, in workgroups of 256 13.8 - 21 us, 512 10.9, 1024 10.0
+// (profiles/r05_inter_signal_variants.txt; one box, isolated).  Round 4's form (a thread per 16x16 block, 128 workgroups of 64): 22 us; staging the records
+// in LDS, one workgroup per CTU: 28 - 32 us (twice the waves, a barrier) -- it was never the round trips to memory.
+__global__ __launch_bounds__(1024) void k_inter_signal(EncFrame f)
 {
   const int w8 = f.cw >> 3, h8 = band_rows(f) * 8;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2321,7 +2323,7 @@ void launch_inter_recon(const EncFrame &f, hipStream_t st)
 void launch_inter_signal(const EncFrame &f, hipStream_t st)
 {
   const int n = (f.cw / 8) * (band_rows(f) * 8);
-  hipLaunchKernelGGL(k_inter_signal, dim3((n + 63) / 64), dim3(64), 0, st, f);
+  hipLaunchKernelGGL(k_inter_signal, dim3((n + 1023) / 1024), dim3(1024), 0, st, f);
 }
 void launch_intra_analyse(const EncFrame &f, hipStream_t st)
 {

@@ -1243,6 +1243,7 @@ bool Decoder::ensure_buffers(int w, int h)
   // a picture buffer: Y | Cb | Cr back to back in one allocation (the whole picture goes to the host in ONE copy)
   for (int s = 0; s < 6; s++) { HIP_TRY(hipMalloc(&dpb_[s].plane[0], npx * 3 / 2)); HIP_TRY(hipMemset(dpb_[s].plane[0], 128, npx * 3 / 2)); dpb_[s].plane[1] = dpb_[s].plane[0] + npx; dpb_[s].plane[2] = dpb_[s].plane[1] + npx / 4; }
   seen_irap_ = false;
+  HIP_TRY(hipDeviceSynchronize());                       // (the clears above ran on the null stream: done before anything is queued on the decoder's non-blocking streams)
   return true;
 }
 
@@ -1258,6 +1259,7 @@ int Decoder::alloc_slot()
       if (hipSetDevice(device_) != hipSuccess) return -1;
       if (hipMalloc(&p.plane[0], npx * 3 / 2) != hipSuccess) { p.plane[0] = nullptr; return -1; }
       hipMemset(p.plane[0], 128, npx * 3 / 2); p.plane[1] = p.plane[0] + npx; p.plane[2] = p.plane[1] + npx / 4;
+      hipDeviceSynchronize();                              // (a clear on the null stream is ordered with nothing on the decoder's non-blocking streams; a buffer is added at most ten times)
     }
     return s;
   }
@@ -1284,9 +1286,11 @@ bool Decoder::ensure_alt()
   // tokenizer, input, decoder and transfers --, at the high level 1 681, at the low one 1 724; one chain each side: 1 279)
   { const char *e = getenv("KVAZZUP_AMD_DEC_ALT_PRIO"); alt_prio_ = e ? e[0] : 'l'; }
   HIP_TRY(stream_acquire(&stream_alt_, device_, 'E', alt_prio_));
-  HIP_TRY(hipMalloc(&progress_alt_, sizeof(uint32_t) * (3 * nctu + 1))); HIP_TRY(hipMemset(progress_alt_, 0, sizeof(uint32_t) * (3 * nctu + 1)));
-  HIP_TRY(hipMalloc(&edge_col_alt_, nctu * 128 * sizeof(uint32_t))); HIP_TRY(hipMemset(edge_col_alt_, 0, nctu * 128 * sizeof(uint32_t)));
-  HIP_TRY(hipMalloc(&edge_row_alt_, nctu * 32 * 8)); HIP_TRY(hipMemset(edge_row_alt_, 0, nctu * 32 * 8));
+  // (cleared ON the stream that is about to use them: the decoder's streams are non-blocking, a clear on the null stream is ordered with nothing -- the first
+  // picture of the second chain had its hand-off words zeroed under its hands, every wait in it gave up: error flags 3, found by the serial suite)
+  HIP_TRY(hipMalloc(&progress_alt_, sizeof(uint32_t) * (3 * nctu + 1))); HIP_TRY(hipMemsetAsync(progress_alt_, 0, sizeof(uint32_t) * (3 * nctu + 1), stream_alt_));
+  HIP_TRY(hipMalloc(&edge_col_alt_, nctu * 128 * sizeof(uint32_t))); HIP_TRY(hipMemsetAsync(edge_col_alt_, 0, nctu * 128 * sizeof(uint32_t), stream_alt_));
+  HIP_TRY(hipMalloc(&edge_row_alt_, nctu * 32 * 8)); HIP_TRY(hipMemsetAsync(edge_row_alt_, 0, nctu * 32 * 8, stream_alt_));
   for (int c = 0; c < 3; c++) { HIP_TRY(hipMalloc(&resid_alt_[c], sizeof(int16_t) * (c ? npx / 4 : npx))); HIP_TRY(hipMalloc(&work_alt_[c], c ? npx / 4 : npx)); }
   return true;
 }

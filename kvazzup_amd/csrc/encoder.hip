@@ -233,6 +233,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   HIP_OK(hipStreamSynchronize(stream_));
   HIP_OK(hipDeviceSynchronize());
   tok_deferred_ = depth_ >= 2 && cfg.sao && !cfg.entropy_gpu && cfg.band_rows == 0 && cfg.owf <= kSets - 1 && !getenv("KVAZZUP_AMD_TOK_INLINE");
+  HIP_OK(hipDeviceSynchronize());                        // (every clear above ran on the null stream: done before anything is queued on the encoder's non-blocking streams)
   if (tok_deferred_) tok_thread_ = std::thread([this] { name_this_thread("kvzx-enc-tok"); tok_launcher(); });
   if (depth_ >= 2) { bg_[0] = std::thread([this] { name_this_thread("kvzx-enc-bg0"); background(0); }); if (entropy2_) bg_[1] = std::thread([this] { name_this_thread("kvzx-enc-bg1"); background(1); }); }
   if (depth_ >= 2 && cfg.band_rows == 0 && !getenv("KVAZZUP_AMD_SYNC_SUBMIT")) sub_thread_ = std::thread([this] { name_this_thread("kvzx-enc-sub"); submitter(); });

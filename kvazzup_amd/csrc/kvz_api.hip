@@ -265,13 +265,19 @@ void picture_free(kvz_picture *pic)
 {
   if (!pic) return;
   if (--pic->refcount > 0) return;
-  bool pinned, kept = false;
+  bool pinned;
+  void *evicted = nullptr;
   {
     PinnedSet &ps = pinned_set(); std::lock_guard<std::mutex> l(ps.m);
     pinned = ps.s.erase(pic->fulldata_buf) != 0;
-    if (pinned && ps.spare.size() < 16) { ps.spare.emplace_back((size_t)pic->width * pic->height, pic->fulldata_buf); kept = true; }
+    if (pinned) {
+      // newest last; the OLDEST spare goes when there are sixteen (round 5: a full list of 1080p spares left by earlier encoders kept every 4K picture of a
+      // later one out -- each reconstruction picture was page-locked and released again, 3 ms apiece: 4K at uvgComm's defaults 421 -> 235 frames/s)
+      ps.spare.emplace_back((size_t)pic->width * pic->height, pic->fulldata_buf);
+      if (ps.spare.size() > 16) { evicted = ps.spare.front().second; ps.spare.erase(ps.spare.begin()); }
+    }
   }
-  if (pinned) { if (!kept) hipHostFree(pic->fulldata_buf); } else free(pic->fulldata_buf);
+  if (pinned) { if (evicted) hipHostFree(evicted); } else free(pic->fulldata_buf);
   free(pic);      // roi.roi_array belongs to the caller (kvazaarfilter.cpp:53,459-463)
 }
 void chunk_free(kvz_data_chunk *chunk)

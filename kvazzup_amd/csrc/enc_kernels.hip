@@ -1587,6 +1587,7 @@ static_assert(sizeof(CoreTabs) % 4 == 0 && sizeof(TokTabs) % 16 == 0, "copied by
 struct SbRegs { uint32_t w[8]; uint32_t m; };
 __device__ __forceinline__ int sb_level(const SbRegs &r, int k) { return (int)(int16_t)(uint16_t)(r.w[k >> 1] >> ((k & 1) * 16)); }      // k: a compile-time constant where it matters
 
+template <bool KEEP_LDS>
 __device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d, const int16_t *lv, int stride, int log2, int scan_idx, int lane, SbRegs &sb)
 {
   const int sbl = log2 - 2, nsb2 = 1 << (2 * sbl);
@@ -1611,6 +1612,11 @@ __device__ __forceinline__ void digest_build_wave(const CoreTabs *t, TuDigest &d
     for (int k = 0; k < 16; k++) { v[k] = d.scan[lane * 16 + pos[k]]; if (v[k]) m |= 1u << k; }
 #pragma unroll
     for (int k = 0; k < 8; k++) sb.w[k] = ((uint32_t)v[2 * k] & 0xffffu) | ((uint32_t)v[2 * k + 1] << 16);
+    if (KEEP_LDS) {                                        // (all reads of the raster form are done: the scan-order form takes its place for enc_subblock())
+      uint32_t *d32 = reinterpret_cast<uint32_t *>(&d.scan[lane * 16]);
+#pragma unroll
+      for (int k = 0; k < 8; k++) d32[k] = sb.w[k];
+    }
     sb.m = m;
     d.mask[lane] = (uint16_t)m;
     nz = m != 0;
@@ -1694,15 +1700,16 @@ __device__ __forceinline__ void enc_subblock_regs(S &c, const TuDigest &d, const
 #define TOK_ARENA 512          // tokens of one piece staged in LDS (larger pieces are written straight to the slot)
 #define TOK_PIECES 17          // pieces one unit can produce: 4 CUs x (header-only | one per coded component) + the CTU's terminating bins
 
-// One wave per 16x16 luma block ("unit") and colour component (the luma wave also codes the CU headers) -- or, ALLC, one
-// wave per unit that takes the three components in turn.  Every wave works on its own, with its own LDS state and no workgroup barrier
+// One wave per 16x16 luma block ("unit") and ROLE -- luma, Cb, Cr, and (round 5) the CU HEADERS on a wave of their own: the header bins are a serial
+// walk on one lane (3.3 us), which the luma wave -- the longest one -- no longer carries in front of its transform block -- or, ALLC, one
+// wave per unit that takes the roles in turn.  Every wave works on its own, with its own LDS state and no workgroup barrier
 // (NW waves per workgroup: NW = 4, the units of a 32x32 quadrant, was measured and is no faster than NW = 1 -- the kernel is bound by
 // the number of waves to start and by its longest waves, not by workgroup dispatch; more waves per SIMD is: six -- 79 registers, the
 // most that needs no scratch memory; eight spill, 5 MB of extra traffic per 1080p picture -- 4K 73 -> 67 us, profiles/r02_tokenizer_timeline.txt).
 // A unit owns the CU that starts at its origin (32x32 or
 // 16x16) or the four 8x8 CUs inside it; units covered by a 32x32 CU that starts elsewhere emit
-// nothing.  The tokens leave the unit in PIECES: one per coded transform block (preceded by whatever
-// header bins are pending), or the header alone for a CU without residual.  For each piece the
+// nothing.  The tokens leave the unit in PIECES, four per CU in coding order: its header (split flags, CU header, cu_qp_delta; the CTU's SAO syntax in
+// front of the first), then one per coded transform block (luma -- led by its last-position bins --, Cb, Cr); piece 16: the CTU's terminating bins.  For each piece the
 // lanes first COUNT the tokens of their 4x4 sub-blocks (the emitters run with a zero-capacity
 // sink), the piece reserves its place in the CTU's slot with one atomicAdd, and a second run of the
 // emitters writes the tokens at their final offsets -- through a small LDS arena when the piece
@@ -1723,22 +1730,29 @@ struct alignas(16) TokWave {
   uint32_t piece_off;
   uint32_t seg[TOK_PIECES][2];
 };
-template <bool ALLC, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(KVZ_TOK_WAVES))) void k_tokenize(EncFrame f)
+// HDRW: the headers on a wave of their own (grid z = 4); else the luma wave carries them (z = 3).  REGS: a sub-block's levels in registers through both passes
+// (enc_subblock_regs: sixteen exec-masked positions per pass) or in LDS (hevc_core.h enc_subblock: a dependent LDS read per significant level).  At 1080p the
+// kernel is as long as its longest wave and both help (31 -> 27.7 -> 24.2 us); at 2160p it is bound by the number of waves and of instructions, and both cost
+// (55 -> 60 -> 63 us): pictures of more than 16 384 units keep round 4's form.
+template <bool ALLC, int NW, bool HDRW = true, bool REGS = true>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(REGS ? KVZ_TOK_WAVES : 6))) void k_tokenize(EncFrame f)
 {
   __shared__ TokWave tw[NW];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   TokWave &W = tw[wv];
   CuRec *tile = W.tile; TuDigest &dg = W.dg; CoreTabs &tabs = W.tabs; uint16_t *hdr = W.hdr, *arena = W.arena;
   int &hdr_n = W.hdr_n; uint32_t &piece_off = W.piece_off; uint32_t (&seg)[TOK_PIECES][2] = W.seg;
+  // comp: 0 luma, 1 Cb, 2 Cr, 3 the headers and the CTU's terminating bins (ALLC: 0 stands for all of them)
   const int ux = NW == 4 ? blockIdx.x * 2 + (wv & 1) : blockIdx.x, uy = NW == 4 ? (blockIdx.y + f.row0 * 2) * 2 + (wv >> 1) : blockIdx.y + f.row0 * 4, comp = ALLC ? 0 : (int)blockIdx.z, wc = f.cw >> 6, hc = f.ch >> 6;
+  const int hdr_comp = HDRW ? 3 : 0;
+  const bool hdr_role = ALLC || comp == hdr_comp;
   const int cx = ux >> 2, cy = uy >> 2, ctu = cy * wc + cx;
   const int X0 = ux * 16, Y0 = uy * 16;
   int z4 = 0;                                          // z-order index of the unit inside its CTU
   for (int b = 0; b < 2; b++) z4 |= (((ux & 3) >> b) & 1) << (2 * b) | (((uy & 3) >> b) & 1) << (2 * b + 1);
   // Most waves of an inter picture have nothing to say (units inside a 32x32 CU that starts elsewhere, chroma of CUs without
   // chroma residual): they find that out from a few bytes and leave with their table entries zeroed.
-  unsigned long long *tr = (f.trace && comp == 0 && lane == 0 && (z4 == 0 || z4 == 15)) ? f.trace + (size_t)wc * hc * 32 + (size_t)ctu * 8 : nullptr;   // (tools/tok_timeline.py)
+  unsigned long long *tr = (f.trace && hdr_role && lane == 0 && (z4 == 0 || z4 == 15)) ? f.trace + (size_t)wc * hc * 32 + (size_t)ctu * 8 : nullptr;   // (tools/tok_timeline.py)
   if (tr) tr[z4 == 0 ? 5 : 6] = wall_clock64();
   // wave census (tools/tok_timeline.py): per class {left at once, header only, with residual} x {P, I}: waves and 10 ns ticks
   unsigned long long *census = f.trace ? f.trace + (size_t)wc * hc * 40 + (size_t)ctu * 16 + (f.is_intra ? 6 : 0) : nullptr;
@@ -1756,11 +1770,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(KVZ_TOK
 #define TOK_PH_SYNC() do { } while (0)
 #endif
   TOK_PH();
-  auto mine = [&](int piece) { return ALLC || ((piece == 16 || (piece & 3) == 3) ? 0 : (piece & 3)) == comp; };   // table entries this wave writes
-  if (!(comp == 0 && z4 == 15)) {
+  // table entries this wave writes: piece 4k + 0 the header of CU k (and piece 16, the terminators): the header role; 4k + 1 + c: component c
+  auto mine = [&](int piece) { return ALLC || ((piece == 16 || (piece & 3) == 0) ? hdr_comp : (piece & 3) - 1) == comp; };
+  if (!(hdr_role && z4 == 15)) {
     const int g0 = (uy * 2) * f.b8w + ux * 2, l0 = f.cu_log2[g0];
     bool work = !(l0 == 5 && ((X0 | Y0) & 31));
-    if (!ALLC && work && comp) {
+    if (!ALLC && work && comp != hdr_comp) {              // a component's wave (that does not also carry the headers): one of the unit's CUs has residual of it
       bool c = false;
       if (lane < (l0 == 3 ? 4 : 1)) { const int g = g0 + (lane >> 1) * f.b8w + (lane & 1); c = !(f.cu_flags[g] & CU_SKIP) && ((f.cu_cbf[g] >> comp) & 1); }
       work = __ballot(c) != 0;
@@ -1812,7 +1827,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(KVZ_TOK
     const CuRec cu = v.at(x0, y0);
     int z = 0;                                         // z-order index (8x8 units) of the CU origin inside the CTU
     for (int b = 0; b < 3; b++) z |= ((((x0 & 63) >> 3) >> b) & 1) << (2 * b) | ((((y0 & 63) >> 3) >> b) & 1) << (2 * b + 1);
-    if (lane == 0 && comp == 0) {
+    if (lane == 0 && hdr_role) {
       TokOut t; t.tabs = &tabs; t.p = hdr; t.n = 0; t.cap = TOK_HDR_CAP;
       if (f.sao && z4 == 0 && k == 0) {                 // coding_tree_unit() starts with sao()
         const bool hl = cx > 0 && !tile_col_starts_at(wc, f.tile_cols, cx), hu = cy > 0 && !tile_row_starts_at(hc, f.tile_rows, cy);
@@ -1825,16 +1840,27 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(KVZ_TOK
       hdr_n = t.n;
     }
     TOK_PH_SYNC(); TOK_PH();                                       // 3: lane 0 has the header bins
+    if (hdr_role) {                                                 // the CU's header: piece 4k + 0
+      np = 4 * k;
+      wave_sync();
+      const int hn = hdr_n > TOK_HDR_CAP ? TOK_HDR_CAP : hdr_n;
+      if (hdr_n > TOK_HDR_CAP && lane == 0) atomicOr(f.err, 8u);
+      const uint32_t o = reserve(hn);
+      if (o != ~0u) for (int i = lane; i < hn; i += 64) slot[o + i] = hdr[i];
+      wave_sync();
+      if (lane == 0) hdr_n = 0;
+      wave_sync();
+    }
     const int cbf = (cu.flags & CU_SKIP) ? 0 : cu.cbf;          // wave-uniform
-    for (int ci = ALLC ? 0 : comp; ci < (ALLC ? 3 : comp + 1); ci++) {   // the CU's transform blocks: luma, Cb, Cr (ALLC) or this wave's component
-      np = 4 * k + ci;
+    for (int ci = (ALLC || comp == 3) ? 0 : comp; ci < (ALLC ? 3 : (comp == 3 ? 0 : comp + 1)); ci++) {   // the CU's transform blocks: luma, Cb, Cr (ALLC) or this wave's component (a wave that only carries headers: none)
+      np = 4 * k + 1 + ci;
       if ((cbf >> ci) & 1) {
         wave_class = 2;
         const int l2 = ci ? cu.log2 - 1 : cu.log2, pw = ci ? (f.cw >> 1) : f.cw;
         const int px = ci ? (x0 >> 1) : x0, py = ci ? (y0 >> 1) : y0;
         const int scan = intra_scan_idx(cu.intra, l2, ci, cu.intra_mode);
         SbRegs sb;
-        digest_build_wave(&tabs, dg, f.coef[ci] + py * pw + px, pw, l2, scan, lane, sb);   // ends with a barrier
+        digest_build_wave<!REGS>(&tabs, dg, f.coef[ci] + py * pw + px, pw, l2, scan, lane, sb);   // ends with a barrier
         TOK_PH();                                                  // 4: digest
         const uint64_t sbm = dg.sbmask;
         const int last_sb = 63 - __builtin_clzll(sbm);
@@ -1866,7 +1892,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(KVZ_TOK
         int n_l = 0;
         if (lane <= last_sb) {
           TokCount t; t.tabs = &tabs; t.n = 0;
-          enc_subblock_regs(t, dg, sb, sk, lane, last_sb, last_pos, prev_g1, l2, ci, scan, f.signhide);
+          if (REGS) enc_subblock_regs(t, dg, sb, sk, lane, last_sb, last_pos, prev_g1, l2, ci, scan, f.signhide);
+          else enc_subblock(t, dg, lane, last_sb, last_pos, prev_g1, l2, ci, scan, f.signhide);
           n_l = t.n;
         }
         // offsets in coding order: sub-block last_sb first, then downwards
@@ -1886,7 +1913,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(KVZ_TOK
           for (int i = lane; i < hn; i += 64) dst[i] = hdr[i];
           if (lane <= last_sb && n_l) {                               // pass 2: the same emitters, now writing at the final offsets
             TokOut t; t.tabs = &tabs; t.p = dst + hn + off; t.n = 0; t.cap = n_l;
-            enc_subblock_regs(t, dg, sb, sk, lane, last_sb, last_pos, prev_g1, l2, ci, scan, f.signhide);
+            if (REGS) enc_subblock_regs(t, dg, sb, sk, lane, last_sb, last_pos, prev_g1, l2, ci, scan, f.signhide);
+            else enc_subblock(t, dg, lane, last_sb, last_pos, prev_g1, l2, ci, scan, f.signhide);
           }
           if (staged) {
             wave_sync();
@@ -1898,17 +1926,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(KVZ_TOK
         if (lane == 0) hdr_n = 0;
       }
       wave_sync();
-      if (ci == 0 && hdr_n) {                                        // CU without luma residual: the header is its own piece (4k + 0)
-        const int hn = hdr_n > TOK_HDR_CAP ? TOK_HDR_CAP : hdr_n;
-        const uint32_t o = reserve(hn);
-        if (o != ~0u) for (int i = lane; i < hn; i += 64) slot[o + i] = hdr[i];
-        wave_sync();
-        if (lane == 0) hdr_n = 0;
-        wave_sync();
-      }
     }
   }
-  if (z4 == 15 && comp == 0) {                                      // the last unit of the CTU closes it
+  if (z4 == 15 && hdr_role) {                                       // the last unit of the CTU closes it
     const bool last = (cy == hc - 1 && cx == wc - 1);
     const bool row_end = tile_col_ends_at(wc, f.tile_cols, cx);                                   // last CTU of its row inside the tile
     const bool sub_end = row_end && (f.wpp || tile_row_ends_at(hc, f.tile_rows, cy));
@@ -2390,7 +2410,8 @@ void launch_tokenize(const EncFrame &f, hipStream_t st)
   // 35 us -- and is kept for pictures beyond that, where nothing has been measured.)
   const int units = (f.cw / 16) * band_rows(f) * 4;
   if (units >= 65536) hipLaunchKernelGGL((k_tokenize<true, 1>), dim3(f.cw / 16, band_rows(f) * 4), dim3(64), 0, st, f);
-  else hipLaunchKernelGGL((k_tokenize<false, 1>), dim3(f.cw / 16, band_rows(f) * 4, 3), dim3(64), 0, st, f);     // (tok_cursor is zero: the previous picture's k_tok_compact left it so)
+  else if (units > 16384) hipLaunchKernelGGL((k_tokenize<false, 1, false, false>), dim3(f.cw / 16, band_rows(f) * 4, 3), dim3(64), 0, st, f);     // (z: luma + headers, Cb, Cr)
+  else hipLaunchKernelGGL((k_tokenize<false, 1, true>), dim3(f.cw / 16, band_rows(f) * 4, 4), dim3(64), 0, st, f);     // (z: luma, Cb, Cr, headers; tok_cursor is zero: the previous picture's k_tok_compact left it so)
 }
 void launch_tok_compact(const EncFrame &f, hipStream_t st)
 {

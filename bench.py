@@ -163,7 +163,7 @@ def default_mode_leg(args, ranks, rank, world, wl):
 
 def all_intra_leg(args, ranks, rank, world, wl):
     """BASELINE configs[0] on the GPU path: every picture an IDR (video/Intra = 1) -- the intra chains' own rate (k_intra_analyse, k_intra_recon, k_dec_intra per picture)"""
-    steps = 2
+    steps = 8                                        # (512 pictures, a quarter of a second: two periods were mostly the pipeline filling and draining -- tools/measure/all_intra_sides.py)
     try:
         m = run_stream(args, wl, steps, 1, ranks, rank, world, quality=True, extra_custom=RESIDENT, extra_settings={"video/Intra": 1})
     except Exception as e:                           # noqa: BLE001

@@ -776,6 +776,8 @@ struct AnalyseLds {
   uint32_t cost[21][35];
   uint32_t bestc[21]; int bestm[21];
   int last;                                // intra-in-P: this workgroup is the last of its region's to arrive
+  alignas(16) uint8_t srcT[32 * 32];       // src transposed (the horizontal modes' tiles: analyse_tile_satd)
+  alignas(16) uint8_t ext[16][4 * 32];     // per wave: the reference samples of the item's block(s) as the array its mode walks along (analyse_tile_satd)
 };
 __device__ __forceinline__ int an_tile_of(int b) { return b < 16 ? (b >> 3) * 2 + ((b >> 1) & 1) : b - 16; }      // the 16x16 quarter block b (0..19) lies in
 __device__ __forceinline__ int an_roff(int b) { return b < 16 ? b * 36 : (b < 20 ? 16 * 36 + (b - 16) * 68 : 16 * 36 + 4 * 68); }
@@ -808,35 +810,81 @@ __device__ __forceinline__ uint32_t analyse_item(const AnalyseLds &s, int b, int
 //   Y = D H16^T    (A = the differences, lane (g, c) = (lane >> 4, lane & 15) owns x = 4g .. 4g + 3 of row y = c)
 //   Z = H16 Y      (B = Y, which the first product leaves in exactly the operand layout the second one reads)
 // on v_mfma_f32_16x16x16_f16 -- exact: |D| <= 255, |Y| <= 2040 < 2^11, |Z| <= 16320.  q[k] = sum |Z| over quadrant k (raster).
-__device__ __forceinline__ void analyse_tile_satd(const AnalyseLds &s, int tile, int kind, int mode, int lane, uint32_t (&q)[4])
+__device__ __forceinline__ void analyse_tile_satd(AnalyseLds &s, int wave, int tile, int kind, int mode, int lane, uint32_t (&q)[4])
 {
   const int g = lane >> 4, c = lane & 15, tx = (tile & 1) * 16, ty = (tile >> 1) * 16;
-  const int angle = kIntraAngle[mode], inv = kInvAngle[mode];
-  const bool vert = mode >= 18;
   int d[4];
-  {
+  if (mode < 2) {
+    // planar and DC (2 of 35 items): sample by sample
     const uint32_t s4 = *(const uint32_t *)&s.src[(ty + c) * 32 + tx + 4 * g];
     if (kind == 0) {
       const int b = 16 + tile;
       const uint8_t *R = s.R[intra_filter_needed(16, 0, mode) ? 1 : 0] + an_roff(b);
-      const bool e2 = mode == 26 || mode == 10;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int x = 4 * g + r, y = c;
-        const int p = mode == 0 ? pred_planar<4>(R, x, y) : (mode == 1 ? pred_dc<4>(R, true, s.dc[b], x, y) : pred_angular<4>(R, vert, e2, angle, inv, x, y));
+        const int p = mode == 0 ? pred_planar<4>(R, x, y) : pred_dc<4>(R, true, s.dc[b], x, y);
         d[r] = (int)((s4 >> (8 * r)) & 255u) - p;
       }
     } else {
       const int b = ((ty >> 3) + (c >> 3)) * 4 + (tx >> 3) + (g >> 1);
       const uint8_t *R = s.R[intra_filter_needed(8, 0, mode) ? 1 : 0] + an_roff(b);
-      const bool e2 = mode == 26 || mode == 10;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int x = (4 * g + r) & 7, y = c & 7;
-        const int p = mode == 0 ? pred_planar<3>(R, x, y) : (mode == 1 ? pred_dc<3>(R, true, s.dc[b], x, y) : pred_angular<3>(R, vert, e2, angle, inv, x, y));
+        const int p = mode == 0 ? pred_planar<3>(R, x, y) : pred_dc<3>(R, true, s.dc[b], x, y);
         d[r] = (int)((s4 >> (8 * r)) & 255u) - p;
       }
     }
+  } else {
+    // The 33 angular modes, all in the VERTICAL form: a horizontal mode predicts the transposed block from the left column the way a vertical mode predicts
+    // the block from the row above (8.4.4.2.6 is symmetric in x and y), and the Hadamard cost of a transposed difference block is the cost of the block
+    // (H D' H = (H D H)' for the symmetric H) -- so the tile is taken from the transposed copy of the source, and the quadrant sums q[1], q[2] change places
+    // at the end.  Per item the wave first lays the block's reference samples out as the ONE array the mode walks along, ext[N + k] = ref[k] for
+    // k = -N .. 2N + 1 (negative k: the other side's samples projected with the inverse angle), N bytes in front of the corner; then lane (g, c) -- row c,
+    // samples 4g .. 4g + 3 -- needs ONE offset and ONE fraction (both depend on the row only), five consecutive bytes of ext (one aligned 8-byte read, a
+    // byte shift) and four blends: no branch, no sign test per sample, no multiplication by the inverse angle outside the lay-out.
+    const int ai = kAngInv.v[mode], angle = (int)(int16_t)(ai & 0xffff), inv = ai >> 16;
+    const bool vert = mode >= 18, e2 = mode == 26 || mode == 10;
+    const int sgn = vert ? 1 : -1;
+    uint8_t *ext = s.ext[wave];
+    const uint32_t s4 = vert ? *(const uint32_t *)&s.src[(ty + c) * 32 + tx + 4 * g] : *(const uint32_t *)&s.srcT[(tx + c) * 32 + ty + 4 * g];
+    wave_sync();                                              // (the last item's reads of ext are done)
+    int row, x0, N;
+    const uint8_t *Rl, *el;                                   // the lane's block: its reference array, its ext
+    if (kind == 0) {
+      const uint8_t *R = s.R[intra_filter_needed(16, 0, mode) ? 1 : 0] + an_roff(16 + tile);
+      const int k = lane - 16;
+      const int idx = k >= 0 ? imin(k, 32) : imax(-((k * inv + 128) >> 8), -32);
+      ext[lane] = R[32 + sgn * idx];
+      row = c; x0 = 4 * g; N = 16; Rl = R; el = ext;
+    } else {
+      const uint8_t *R0 = s.R[intra_filter_needed(8, 0, mode) ? 1 : 0];
+#pragma unroll
+      for (int hh = 0; hh < 2; hh++) {
+        const int e = lane + 64 * hh, slot = e >> 5, k = (e & 31) - 8;       // slot: the quadrant (sy', sx') of the tile as the lanes see it
+        const int sx = vert ? (slot & 1) : (slot >> 1), sy = vert ? (slot >> 1) : (slot & 1);
+        const uint8_t *R = R0 + an_roff(((ty >> 3) + sy) * 4 + (tx >> 3) + sx);
+        const int idx = k >= 0 ? imin(k, 16) : imax(-((k * inv + 128) >> 8), -16);
+        ext[e] = R[16 + sgn * idx];
+      }
+      const int slot = (c >> 3) * 2 + (g >> 1);
+      const int sx = vert ? (slot & 1) : (slot >> 1), sy = vert ? (slot >> 1) : (slot & 1);
+      row = c & 7; x0 = (4 * g) & 7; N = 8; Rl = R0 + an_roff(((ty >> 3) + sy) * 4 + (tx >> 3) + sx); el = ext + slot * 32;
+    }
+    wave_sync();
+    const int t = (row + 1) * angle, fr = t & 31, j0 = N + x0 + (t >> 5) + 1;
+    const uint32_t *w = (const uint32_t *)(el + (j0 & ~3));
+    const uint32_t lo = w[0], hi = w[1];
+    const uint32_t sh = (uint32_t)(j0 & 3);
+    const uint32_t b03 = __builtin_amdgcn_alignbyte(hi, lo, sh), b4 = (hi >> (8 * sh)) & 255u;
+    int B[5] = {(int)(b03 & 255u), (int)((b03 >> 8) & 255u), (int)((b03 >> 16) & 255u), (int)(b03 >> 24), (int)b4};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int p = (32 * B[r] + fr * (B[r + 1] - B[r]) + 16) >> 5;
+      d[r] = (int)((s4 >> (8 * r)) & 255u) - p;
+    }
+    if (e2 && x0 == 0) d[0] = (int)(s4 & 255u) - clip8(Rl[2 * N + sgn] + ((Rl[2 * N - sgn * (1 + row)] - Rl[2 * N]) >> 1));      // (8.4.4.2.6: the edge of the pure vertical / horizontal mode)
   }
   // H16[c][4g + r]: zero across the two 8x8 blocks, else the sign of the natural-ordered Hadamard matrix, (-1)^popcount(i & j)
   kv_f16x4 h;
@@ -864,6 +912,7 @@ __device__ __forceinline__ void analyse_tile_satd(const AnalyseLds &s, int tile,
   q[1] = (uint32_t)__builtin_amdgcn_readlane((int)a, 8) + (uint32_t)__builtin_amdgcn_readlane((int)a, 24);
   q[2] = (uint32_t)__builtin_amdgcn_readlane((int)a, 32) + (uint32_t)__builtin_amdgcn_readlane((int)a, 48);
   q[3] = (uint32_t)__builtin_amdgcn_readlane((int)a, 40) + (uint32_t)__builtin_amdgcn_readlane((int)a, 56);
+  if (mode >= 2 && mode < 18) { const uint32_t t_ = q[1]; q[1] = q[2]; q[2] = t_; }      // (a horizontal mode's tile was transposed)
 }
 
 // PP = false: intra pictures.  PP = true ("uvgx intra-in-P v1"): launched behind k_me in a P picture; a region none of whose quarters'
@@ -875,7 +924,7 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
   // (PP: few regions get past the gate, so what counts is how long ONE of them takes, not how many fit on the chip: sixteen waves share its items)
   constexpr int T = PP ? 1024 : 256, NW = T / 64;
   __shared__ AnalyseLds s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (a scalar: item, mode, kind and tile of the search loops are wave-uniform, and the compiler cannot know)
   int bx_ = 0, by_ = 0;
   if (!PP) xcd_block_2d(bx_, by_);
   // PP: a fixed number of workgroups works through the list of blocks k_me found above the gate (f.me_cand); the first things they do is
@@ -920,7 +969,13 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
     s.R[0][an_roff(b) + i] = (uint8_t)v;
   }
   __syncthreads();
-  // ---- filtered references (8.4.4.2.3) and DC values
+  // ---- filtered references (8.4.4.2.3) and DC values; the source block transposed (analyse_tile_satd)
+  if (f.satd && tid < 256) {
+    const uint32_t v = *(const uint32_t *)&s.src[tid * 4];
+    const int y = tid >> 3, x = (tid & 7) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; r++) s.srcT[(x + r) * 32 + y] = (uint8_t)(v >> (8 * r));
+  }
   for (int e = tid; e < 16 * 33 + 4 * 65; e += T) {
     int b, i, l2;
     if (e < 16 * 33) { b = e / 33; i = e - b * 33; l2 = 3; } else { int r = e - 16 * 33; b = 16 + r / 65; i = r % 65; l2 = 4; }
@@ -950,7 +1005,7 @@ __global__ __launch_bounds__(PP ? 1024 : 256) void k_intra_analyse(EncFrame f)
       const int item = PP ? (no8 ? (j << 3) | (mytile << 1) : ((j >> 1) << 3) | (mytile << 1) | (j & 1)) : j;
       const int kind = item & 1, tile = (item >> 1) & 3, mode = item >> 3;
       uint32_t q[4];
-      analyse_tile_satd(s, tile, kind, mode, lane, q);
+      analyse_tile_satd(s, wave, tile, kind, mode, lane, q);
       if (lane == 0) {
         if (kind == 0) s.cost[16 + tile][mode] = ((q[0] + 2) >> 2) + ((q[1] + 2) >> 2) + ((q[2] + 2) >> 2) + ((q[3] + 2) >> 2);
         else {
@@ -2347,7 +2402,15 @@ void launch_inter_signal(const EncFrame &f, hipStream_t st)
 }
 void launch_intra_analyse(const EncFrame &f, hipStream_t st)
 {
-  if (f.is_intra) hipLaunchKernelGGL(k_intra_analyse<false>, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), 0, st, f);
+  // An intra picture's mode search is the one throughput-bound kernel of the pipeline: 2 040 independent workgroups at 1080p, all of them resident at once if
+  // nothing stops them -- eight waves on every SIMD of the chip, i.e. EVERY wave slot, for the length of the launch, and whatever else is queued beside it
+  // (the P pictures in front of an IDR, the other pictures' chains of an all-intra stream) cannot start a workgroup until one of the search's retires.  Dynamic
+  // LDS it does not use caps it at kAnalysePerCu workgroups per compute unit (160 KB of LDS each), which leaves the other slots to everybody else.
+  // Measured (profiles/r05_analyse_cap.txt; 4K, pipelined, worst launch of 504): k_me 948 -> 135 us, k_tok_compact 881 -> 59, k_inter_signal 540 -> 280 with a cap of 4;
+  // the search itself 156 -> 173 us at 1080p (197 at 3); the encoder alone on an all-intra stream 2 450 -> 2 750 frames/s.  KVAZZUP_AMD_ANALYSE_PER_CU=0: no cap.
+  static const int per_cu = getenv("KVAZZUP_AMD_ANALYSE_PER_CU") ? atoi(getenv("KVAZZUP_AMD_ANALYSE_PER_CU")) : 4;
+  const size_t pad = per_cu > 1 && per_cu < 8 ? (size_t)(160 * 1024 / (per_cu + 1) + 1024 - 9264) & ~(size_t)255 : 0;
+  if (f.is_intra) hipLaunchKernelGGL(k_intra_analyse<false>, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), pad, st, f);
   else hipLaunchKernelGGL(k_intra_analyse<true>, dim3(512), dim3(1024), 0, st, f);       // intra-in-P, behind k_me: 512 workgroups (two per compute unit) share the candidate list, a quarter of a listed block at a time
 }
 void launch_intra_recon(const EncFrame &f, hipStream_t st)

@@ -111,8 +111,12 @@ class OrderedPool {
  private:
   void worker()
   {
-    int seen = gen_.load(std::memory_order_acquire);
+    // (the generation the pool was BUILT with, not the one this thread finds when it first runs: a helper that starts after run() -- or after the destructor --
+    // has already moved the word on would otherwise sleep on a value nobody changes again, and the destructor's join would never return.  Seen with a pool that
+    // lived for one all-skip picture on a slow machine: tests/test_parser_probe.py.)
+    int seen = 0;
     for (;;) {
+      if (quit_.load(std::memory_order_acquire)) return;
       // (a short spin first: at thousands of pictures per second the next job is tens of microseconds away and a futex wake-up costs as much)
       for (int spins = 0; gen_.load(std::memory_order_acquire) == seen && spins < 200; spins++) __builtin_ia32_pause();
       while (gen_.load(std::memory_order_acquire) == seen) futex_wait(gen_, seen);
@@ -204,8 +208,12 @@ class CopyPool {
   }
   void worker()
   {
-    int seen = gen_.load(std::memory_order_acquire);
+    // (the generation the pool was BUILT with, not the one this thread finds when it first runs: a helper that starts after run() -- or after the destructor --
+    // has already moved the word on would otherwise sleep on a value nobody changes again, and the destructor's join would never return.  Seen with a pool that
+    // lived for one all-skip picture on a slow machine: tests/test_parser_probe.py.)
+    int seen = 0;
     for (;;) {
+      if (quit_.load(std::memory_order_acquire)) return;
       // a short spin first -- at several thousand pictures per second the next job is ~100 us away and a futex wake-up costs a good part of that -- but SHORT:
       // the host is what this pipeline runs out of, and helpers that spin half the time between jobs took cores from the parsers (2000 pauses: 4 500-5 000
       // frames/s through the host boundary on one box, 200: 4 900-5 400, none: 4 700-4 900)

@@ -20,23 +20,37 @@
 #include <time.h>
 
 #define MAX_SAMPLES (1 << 21)
-static struct { uint64_t pc; int tid; } *g_s;
+static struct { uint64_t pc, caller; int tid; } *g_s;      /* caller: for a sample outside the measured library, the first word on the thread's stack that points into it (0: none) */
+static volatile uint64_t g_lib_lo, g_lib_hi;               /* the measured library's executable mapping (CPU_SAMPLER_LIB, default "libkvazzup_amd"): found by cpu_sampler_begin() */
 static volatile long g_n;
 static volatile int g_on;                  /* samples are kept only between begin and end (or always, without CPU_SAMPLER_REGION) */
 
+static __thread uint64_t t_stack_hi __attribute__((tls_model("initial-exec")));
 static void on_prof(int sig, siginfo_t *si, void *uc_)
 {
   (void)sig; (void)si;
   ucontext_t *uc = (ucontext_t *)uc_;
   if (!g_on) return;
   long i = __sync_fetch_and_add(&g_n, 1);
-  if (i < MAX_SAMPLES) { g_s[i].pc = (uint64_t)uc->uc_mcontext.gregs[REG_RIP]; g_s[i].tid = (int)syscall(SYS_gettid); }
+  if (i >= MAX_SAMPLES) return;
+  const uint64_t pc = (uint64_t)uc->uc_mcontext.gregs[REG_RIP], lo = g_lib_lo, hi = g_lib_hi;
+  uint64_t caller = 0;
+  if (hi && !(pc >= lo && pc < hi)) {
+    /* no unwinder in a signal handler: the innermost return address into the library is, nearly always, the first stack word that points into its code */
+    const uint64_t *sp = (const uint64_t *)uc->uc_mcontext.gregs[REG_RSP];
+    const uint64_t top = t_stack_hi;                                    /* (this thread's stack ends there: arm_this_thread()) */
+    if ((uint64_t)sp < top && top - (uint64_t)sp < (64u << 20))
+    for (int k = 0; k < 2048 && (uint64_t)(sp + k + 1) <= top; k++) { const uint64_t v = sp[k]; if (v >= lo && v < hi) { caller = v; break; } }
+  }
+  g_s[i].pc = pc; g_s[i].caller = caller; g_s[i].tid = (int)syscall(SYS_gettid);
 }
 
 /* ---- per-thread timers */
 static long sample_ns(void) { const char *us = getenv("CPU_SAMPLER_US"); return (us ? atol(us) : 500) * 1000L; }
 static void arm_this_thread(void)
 {
+  pthread_attr_t at;
+  if (pthread_getattr_np(pthread_self(), &at) == 0) { void *lo = NULL; size_t sz = 0; if (pthread_attr_getstack(&at, &lo, &sz) == 0) t_stack_hi = (uint64_t)lo + sz; pthread_attr_destroy(&at); }
   struct sigevent sev; memset(&sev, 0, sizeof(sev));
   sev.sigev_notify = SIGEV_THREAD_ID; sev.sigev_signo = SIGPROF;
   sev._sigev_un._tid = (int)syscall(SYS_gettid);
@@ -71,6 +85,13 @@ void cpu_sampler_begin(void)
   struct sigaction sa; memset(&sa, 0, sizeof(sa));          /* (a library may have replaced the handler) */
   sa.sa_sigaction = on_prof; sa.sa_flags = SA_SIGINFO | SA_RESTART;
   sigaction(SIGPROF, &sa, NULL);
+  const char *want = getenv("CPU_SAMPLER_LIB"); if (!want) want = "libkvazzup_amd";
+  FILE *m = fopen("/proc/self/maps", "r");
+  if (m) {
+    char line[1024];
+    while (fgets(line, sizeof(line), m)) if (strstr(line, "r-xp") && strstr(line, want)) { unsigned long long a, b; if (sscanf(line, "%llx-%llx", &a, &b) == 2) { g_lib_lo = a; g_lib_hi = b; } break; }
+    fclose(m);
+  }
   g_n = 0; g_on = 1;
 }
 
@@ -95,6 +116,6 @@ __attribute__((destructor)) static void sampler_stop(void)
   if (m) { char line[1024]; while (fgets(line, sizeof(line), m)) if (strstr(line, " r-xp ") || strstr(line, "r-xp")) fprintf(o, "M %s", line); fclose(m); }
   long n = g_n < MAX_SAMPLES ? g_n : MAX_SAMPLES;
   /* thread names while the threads may still exist; samples of threads that are gone keep their id */
-  for (long i = 0; i < n; i++) fprintf(o, "S %llx %d\n", (unsigned long long)g_s[i].pc, g_s[i].tid);
+  for (long i = 0; i < n; i++) fprintf(o, "S %llx %d %llx\n", (unsigned long long)g_s[i].pc, g_s[i].tid, (unsigned long long)g_s[i].caller);
   fclose(o);
 }

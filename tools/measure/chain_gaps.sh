@@ -5,6 +5,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}; mode=${1:-default}; shift
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/gaps
 extra=""
 [ "$mode" = "default" ] && extra="--custom preset=veryfast --custom bitrate=1000000 --custom rc-algorithm=lambda"
+[ "$mode" = "intra" ] && extra="--custom period=1"
 KVAZZUP_BENCH_NOPROF=1 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/gaps -o p -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-host-boundary --streams-per-gpu 0 --repeats 1 --steps 3 --warmup 1 $extra "$@" > /tmp/gaps.log 2>&1
 tail -c 300 /tmp/gaps.log | head -c 250; echo
 f=$(find /tmp/gaps -name "*kernel_trace.csv" | head -1); m=$(find /tmp/gaps -name "*memory_copy_trace.csv" | head -1)

@@ -34,3 +34,17 @@ def test_the_hook_never_outputs_a_picture_and_refuses_after_start():
     nals = PP.encoded_case("enc_flat_all_skip")
     assert all(lib.libOpenHevcDecode(h, n, len(n), 0) == 0 for n in nals)
     lib.libOpenHevcClose(h)
+
+
+def test_short_lived_row_pools_close():
+    """a decoder whose row pool lives for one all-skip picture: helpers that first run after the destructor's wake-up used to sleep on a generation word
+    nobody changed again and libOpenHevcClose never returned (csrc/host_pool.h OrderedPool::worker)"""
+    lib = PP._lib()
+    nals = PP.encoded_case("enc_flat_all_skip")
+    for _ in range(40):
+        h = lib.libOpenHevcInit(1, 2)
+        assert lib.kvzx_decoder_set_parse_only(h, 8) == 1
+        assert lib.libOpenHevcStartDecoder(h) == 0
+        for n in nals[:3]:
+            assert lib.libOpenHevcDecode(h, n, len(n), 0) >= 0
+        lib.libOpenHevcClose(h)

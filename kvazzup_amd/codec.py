@@ -198,6 +198,8 @@ class Decoder:
     def decode_nal(self, nal, pts=0):
         """returns None or a dict with the packed I420 picture (the row-wise copy of sendDecodedOutput)"""
         nal = bytes(nal)
+        if len(nal) < 6:                     # not a NAL unit (csrc/filters.hip OpenHEVCFilter::process drops it the same way)
+            return None
         t = nal[4] >> 1
         self.vps |= t == 32
         self.sps |= t == 33

@@ -24,7 +24,9 @@ struct BitReader {
   BitReader(const uint8_t *b, size_t len) : p(b), n(len) {}
   uint32_t bit() { if (pos >= n * 8) { err = true; pos++; return 0; } uint32_t b = (p[pos >> 3] >> (7 - (pos & 7))) & 1; pos++; return b; }
   uint32_t get(int k) { uint32_t v = 0; for (int i = 0; i < k; i++) v = (v << 1) | bit(); return v; }
-  uint32_t ue() { int z = 0; while (!bit()) { if (++z > 32 || err) { err = true; return 0; } } return z ? ((1u << z) - 1) + get(z) : 0; }
+  // (at most 30 leading zeros: the value stays below 2^31, so that every `(int)r.ue()` and `r.ue() + 1` below is a non-negative int and the callers' upper-bound
+  // checks are range checks -- a 32-bit code word used to come out as a NEGATIVE index that passed `id > 63`; found by tools/fuzz_parser.py under ASan)
+  uint32_t ue() { int z = 0; while (!bit()) { if (++z > 30 || err) { err = true; return 0; } } return z ? ((1u << z) - 1) + get(z) : 0; }
   int32_t se() { uint32_t k = ue(); return (k & 1) ? (int32_t)((k + 1) >> 1) : -(int32_t)(k >> 1); }
 };
 
@@ -66,7 +68,7 @@ bool parse_st_rps(BitReader &r, int idx, int num_in_sps, const StRps *all, StRps
     for (int j = 0; j < n1; j++) { out.dpoc[n0 + j] = s1[j]; out.used[n0 + j] = (uint8_t)u1[j]; }
   } else {
     const int nneg = (int)r.ue(), npos = (int)r.ue();
-    if (nneg + npos > 16 || r.err) return false;
+    if (nneg > 16 || npos > 16 || nneg + npos > 16 || r.err) return false;
     out.n_neg = nneg; out.n_pos = npos;
     int prev = 0;
     for (int j = 0; j < nneg; j++) { prev -= (int)r.ue() + 1; out.dpoc[j] = prev; out.used[j] = (uint8_t)r.get(1); }
@@ -1509,7 +1511,11 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     int id = r.ue(); if (id > 15) return last_error_ = DEC_ERR_INVALID;
     if (r.ue() != 1) return last_error_ = DEC_ERR_UNSUPPORTED;   // 4:2:0 only
     s.width = r.ue(); s.height = r.ue();
-    if (r.get(1)) { s.crop_l = 2 * r.ue(); s.crop_r = 2 * r.ue(); s.crop_t = 2 * r.ue(); s.crop_b = 2 * r.ue(); }
+    if (r.get(1)) {
+      const uint32_t cl = r.ue(), cr = r.ue(), ct = r.ue(), cb = r.ue();
+      if (cl > 8192 || cr > 8192 || ct > 8192 || cb > 8192) return last_error_ = DEC_ERR_INVALID;
+      s.crop_l = 2 * (int)cl; s.crop_r = 2 * (int)cr; s.crop_t = 2 * (int)ct; s.crop_b = 2 * (int)cb;
+    }
     if (r.ue() != 0 || r.ue() != 0) return last_error_ = DEC_ERR_UNSUPPORTED;   // 8 bit only
     s.log2_max_poc_lsb = r.ue() + 4;
     if (s.log2_max_poc_lsb > 16) return last_error_ = DEC_ERR_INVALID;
@@ -1558,6 +1564,7 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     p.cabac_init_present = r.get(1);
     p.num_ref_idx_default = (int)r.ue() + 1; p.num_ref_idx1_default = (int)r.ue() + 1;
     p.init_qp = 26 + r.se();
+    if (p.init_qp < 0 || p.init_qp > 51) return last_error_ = DEC_ERR_INVALID;
     int cip = r.get(1); p.tskip = r.get(1); p.cu_qp_delta = r.get(1);
     if (p.cu_qp_delta) { p.qp_delta_depth = r.ue(); if (p.qp_delta_depth > 3) return last_error_ = DEC_ERR_INVALID; }
     p.cb_qp_offset = r.se(); p.cr_qp_offset = r.se(); p.slice_chroma_offsets = r.get(1);
@@ -1687,7 +1694,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   const bool first_seg = r.get(1) != 0;
   if (irap) r.get(1);
   const int pps_id = r.ue();
-  if (pps_id > 63 || !pps_[pps_id].valid || !sps_[pps_[pps_id].sps_id] || !sps_[pps_[pps_id].sps_id]->valid) return DEC_ERR_INVALID;
+  if (pps_id < 0 || pps_id > 63 || !pps_[pps_id].valid || !sps_[pps_[pps_id].sps_id] || !sps_[pps_[pps_id].sps_id]->valid) return DEC_ERR_INVALID;
   const DecPps &p = pps_[pps_id]; const std::shared_ptr<const DecSps> sps_ref = sps_[p.sps_id]; const DecSps &s = *sps_ref;
   bool dependent = false; int seg_address = 0;
   if (!first_seg) {

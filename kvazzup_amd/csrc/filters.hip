@@ -498,6 +498,7 @@ void OpenHEVCFilter::process()                             // openhevcfilter.cpp
   std::unique_ptr<Data> input = getInput();
   while (input) {
     if (getStats()) { getStats()->receivedPackets++; getStats()->receivedBytes += input->data_size; }
+    if (!input->data || input->data_size < 6) { input = getInput(); continue; }      // (not a NAL unit -- nothing behind the start code; the reference reads buff[4] whatever the size, openhevcfilter.cpp:114)
     {
       std::lock_guard<std::mutex> l(settingsMutex_);
       const unsigned char *buff = input->data.get();

@@ -2,6 +2,8 @@
 // extensions (include/kvazzup_amd.h) on top of kvzx::Encoder.
 // Drop-in for the calls uvgComm makes at /root/reference/src/media/processing/kvazaarfilter.cpp:
 // 145-299 (configuration), 407-449 (encode loop), 456-476 (chunk / recon hand-back), 313-329 (close).
+#include <cerrno>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -59,8 +61,8 @@ bool parse_bool(const char *v, int *out)
 }
 bool parse_int(const char *v, int *out)
 {
-  char *end = nullptr; long x = strtol(v, &end, 10);
-  if (end == v || *end) return false;
+  char *end = nullptr; errno = 0; long x = strtol(v, &end, 10);
+  if (end == v || *end || errno == ERANGE || x < INT_MIN || x > INT_MAX) return false;      // (a number that does not fit is not a value of any option)
   *out = (int)x; return true;
 }
 
@@ -92,15 +94,26 @@ int config_parse(kvz_config *cfg, const char *name, const char *value)
     return 0;
   }
   if (n == "input-res") {
-    int w = 0, h = 0;
-    if (sscanf(value, "%dx%d", &w, &h) != 2 || w <= 0 || h <= 0) return 0;
-    cfg->width = w; cfg->height = h; return 1;
+    // "<w>x<h>", both within what encoder_open takes (16 384: hevc sizes here are 16-bit quantities, filter.h:61-62 VideoInfo)
+    char *e1 = nullptr, *e2 = nullptr; errno = 0;
+    const long w = strtol(value, &e1, 10);
+    if (e1 == value || *e1 != 'x' || errno == ERANGE) return 0;
+    const long h = strtol(e1 + 1, &e2, 10);
+    if (e2 == e1 + 1 || *e2 || errno == ERANGE || w <= 0 || h <= 0 || w > 16384 || h > 16384) return 0;
+    cfg->width = (int)w; cfg->height = (int)h; return 1;
   }
   if (n == "input-fps") {
-    int a = 0, b = 1;
-    if (sscanf(value, "%d/%d", &a, &b) == 2 && a > 0 && b > 0) { cfg->framerate_num = a; cfg->framerate_denom = b; cfg->framerate = (double)a / b; return 1; }
-    double f = atof(value);
-    if (f <= 0) return 0;
+    // "<num>/<den>" (kvazaarfilter.cpp:174) or a decimal number; either way a rate between 0 and a million pictures per second
+    char *e1 = nullptr, *e2 = nullptr; errno = 0;
+    const long a = strtol(value, &e1, 10);
+    if (e1 != value && *e1 == '/') {
+      const long b = strtol(e1 + 1, &e2, 10);
+      if (e2 == e1 + 1 || *e2 || errno == ERANGE || a <= 0 || b <= 0 || a > 1000000000L || b > 1000000000L || a / b > 1000000) return 0;
+      cfg->framerate_num = (int)a; cfg->framerate_denom = (int)b; cfg->framerate = (double)a / (double)b; return 1;
+    }
+    char *e3 = nullptr;
+    const double f = strtod(value, &e3);
+    if (e3 == value || *e3 || !(f > 0) || !(f <= 1000000.0)) return 0;
     cfg->framerate = f; cfg->framerate_num = (int)(f * 1000 + 0.5); cfg->framerate_denom = 1000;
     if (cfg->framerate_num % 1000 == 0) { cfg->framerate_num /= 1000; cfg->framerate_denom = 1; }
     return 1;

@@ -68,6 +68,31 @@ def test_kvz_api_table_and_config_parsing(lib):
     assert api.config_destroy(cfg) == 1
 
 
+def test_config_parse_takes_any_string(lib):
+    """config_parse is what uvgComm's free-form "custom parameters" reach (kvazaarfilter.cpp:302-311, 363-367): every name and value -- empty, huge, negative,
+    non-numeric, not UTF-8 -- is answered with 1 or 0, and what was accepted leaves the fields uvgComm reads inside their ranges"""
+    import random
+    api = lib.kvz_api_get(8).contents
+    names = ["preset", "input-res", "input-fps", "threads", "owf", "wpp", "tiles", "slices", "qp", "period", "vps-period", "rc-algorithm", "intra-bits", "gop",
+             "scaling-list", "mv-constraint", "vaq", "bitrate", "sao", "deblock", "subme", "me-range", "rdoq", "signhide", "lossless", "intra-in-p", "hash", "gpu",
+             "me-early-termination", "intra-satd", "input-hold", "recon-output", "null-input", "gpu-entropy", "roi", "cqmfile", "", "x" * 300]
+    values = ["", "0", "1", "-1", "2147483647", "-2147483648", "99999999999999999999", "1e9", "0x10", "on", "off", "true", "lambda", "oba", "wpp", "tiles",
+              "ultrafast", "placebo", "1920x1080", "0x0", "65536x65536", "-8x-8", "16x16", "7x7", "30/1", "1/0", "0/0", "-30/-1", "lp-g4d3t1", "8", "none", "frame",
+              "frametilemargin", "full", "edge", "band", "default", "custom", "2x2", "20x22", "21x1", "1x23", "a" * 5000, "\xff\xfe"]
+    rng = random.Random(7)
+    cfg = api.config_alloc()
+    assert api.config_init(cfg) == 1
+    for _ in range(6000):
+        k = rng.choice(names) if rng.random() < 0.9 else "".join(chr(rng.randrange(1, 256)) for _ in range(rng.randrange(1, 12)))
+        v = rng.choice(values) if rng.random() < 0.8 else "".join(chr(rng.randrange(1, 256)) for _ in range(rng.randrange(0, 40)))
+        rc = api.config_parse(cfg, k.encode("latin-1"), v.encode("latin-1"))
+        assert rc in (0, 1), (k, v, rc)
+        c = cfg.contents
+        assert 0 <= c.qp <= 51 and c.intra_period >= 0 and 0 <= c.owf <= 64 and c.wpp in (0, 1), (k, v, c.qp, c.intra_period, c.owf, c.wpp)
+        assert 0 <= c.width <= 16384 and 0 <= c.height <= 16384 and c.framerate_num >= 0 and c.framerate_denom >= 0, (k, v, c.width, c.height, c.framerate_num, c.framerate_denom)
+    assert api.config_destroy(cfg) == 1
+
+
 def test_pictures_and_chunks(lib):
     api = lib.kvz_api_get(8).contents
     pic = api.picture_alloc(64, 48)

@@ -893,21 +893,28 @@ __device__ __forceinline__ void analyse_tile_satd(AnalyseLds &s, int wave, int t
     const int j = 4 * g + r;
     h[r] = ((c ^ j) & 8) ? (_Float16)0.f : ((__builtin_popcount((unsigned)(c & j & 7)) & 1) ? (_Float16)-1.f : (_Float16)1.f);
   }
-  int y[4], z[4];
-  mfma16_data_a(d, h, y);
-  kv_f16x4 yb;
+  // Both products and the sum of magnitudes stay in floating point -- every value is an integer below 2^17, exact in f32, and Y (|y| <= 2040) is exact in
+  // f16 --: the first product's result goes back in as packed halves (v_cvt_pkrtz: two per instruction, nothing to round), the magnitudes are source
+  // modifiers of the adds, and ONE conversion per lane is left, after the lane sums (was 4 + 4 + 4 conversions and 8 integer abs steps per item: 154 -> 142 us).
+  // (Tried and dropped: the 18 modes that never reach behind the corner reading their five reference bytes straight from R[] instead of laying out ext[] --
+  // 142 -> 154 us: two code paths in the item loop cost more than the lay-out they save.)
+  kv_f16x4 da;
 #pragma unroll
-  for (int r = 0; r < 4; r++) yb[r] = (_Float16)(short)y[r];
+  for (int r = 0; r < 4; r++) da[r] = (_Float16)(short)d[r];
   const kv_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const kv_f32x4 yf = __builtin_amdgcn_mfma_f32_16x16x16f16(da, h, zero, 0, 0, 0);
+  typedef __fp16 kv_h2_ __attribute__((ext_vector_type(2)));
+  const kv_h2_ y01 = __builtin_amdgcn_cvt_pkrtz(yf[0], yf[1]), y23 = __builtin_amdgcn_cvt_pkrtz(yf[2], yf[3]);
+  struct { kv_h2_ lo, hi; } ypk = {y01, y23};
+  const kv_f16x4 yb = __builtin_bit_cast(kv_f16x4, ypk);
   const kv_f32x4 zf = __builtin_amdgcn_mfma_f32_16x16x16f16(h, yb, zero, 0, 0, 0);
-  uint32_t a = 0;
-#pragma unroll
-  for (int r = 0; r < 4; r++) { z[r] = (int)zf[r]; a += (uint32_t)iabs(z[r]); }
+  float af = (__builtin_fabsf(zf[0]) + __builtin_fabsf(zf[1])) + (__builtin_fabsf(zf[2]) + __builtin_fabsf(zf[3]));
   // sums over the 8-lane groups (three DPP steps), then the two groups of each quadrant: output (u = 4g + r, v = c) lies in quadrant
   // (u >= 8) * 2 + (v >= 8)
-  a += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1, 0xf, 0xf, false);
-  a += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x4E, 0xf, 0xf, false);
-  a += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x141, 0xf, 0xf, false);
+  af += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, af), 0xB1, 0xf, 0xf, false));
+  af += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, af), 0x4E, 0xf, 0xf, false));
+  af += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, af), 0x141, 0xf, 0xf, false));
+  const uint32_t a = (uint32_t)af;
   q[0] = (uint32_t)__builtin_amdgcn_readlane((int)a, 0) + (uint32_t)__builtin_amdgcn_readlane((int)a, 16);
   q[1] = (uint32_t)__builtin_amdgcn_readlane((int)a, 8) + (uint32_t)__builtin_amdgcn_readlane((int)a, 24);
   q[2] = (uint32_t)__builtin_amdgcn_readlane((int)a, 32) + (uint32_t)__builtin_amdgcn_readlane((int)a, 48);

@@ -195,6 +195,10 @@ class Decoder {
     // into the B4Rec (the first used list's vector and picture) and, for bi-predicted blocks (B4_BI), the second vector here
     struct MvF { int16_t mv[2][2]; int8_t ref[2]; };
     std::vector<MvF> mvf; std::vector<B4L1> b4x; std::atomic<int> any_bi{0};
+    // One picture at a time (uvgComm's default "Slice" threading): a CTU row's 4x4 records go up as soon as the row is parsed, beside the parsing of the rows
+    // below -- the megabyte (4K: four) of records is then on the device when the parse ends, and what submit_job uploads is the tables, transform blocks and
+    // levels.  early_dst: the input buffer this picture will be launched from (nullptr: no early upload); early_rows: rows whose copy was queued.
+    uint8_t *early_dst = nullptr; std::atomic<int> early_rows{0};
     std::shared_ptr<ColMotion> col, own;                         // collocated picture's motion (NULL: no temporal candidates); this picture's
     // the pinned input block (dec_frame.h) and the host views into it
     uint8_t *h_in = nullptr; size_t h_in_cap = 0; size_t ntu = 0, nlev = 0;

@@ -1175,7 +1175,11 @@ bool Decoder::grow_job_input(PicJob &job, size_t bytes)
   }
   if (hipSetDevice(device_) != hipSuccess) return false;
   if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return false;
-  if (job.h_in) { memcpy(p, job.h_in, fixed_bytes() < job.h_in_cap ? fixed_bytes() : job.h_in_cap); hipHostFree(job.h_in); }
+  if (job.h_in) {
+    memcpy(p, job.h_in, fixed_bytes() < job.h_in_cap ? fixed_bytes() : job.h_in_cap);
+    if (job.early_rows.load(std::memory_order_acquire) > 0) hipStreamSynchronize(stream_up_);      // (rows of records on their way up read the old block)
+    hipHostFree(job.h_in);
+  }
   job.h_in = p; job.h_in_cap = cap;
   bind_job(job);
   return true;
@@ -2062,6 +2066,13 @@ int Decoder::submit_job(PicJob &job, int nal_type, bool irap)
   }
   if (frame_threads_ == 1) {
     auto t0 = std::chrono::steady_clock::now();
+    job.early_dst = nullptr; job.early_rows.store(0, std::memory_order_relaxed);
+    {
+      // (decoder.h PicJob::early_dst; the buffer is the one launch_gpu will pick -- nothing is launched between here and there)
+      static const bool early_off = [] { const char *e = getenv("KVAZZUP_AMD_DEC_EARLY_UP"); return e && atoi(e) == 0; }();
+      const int ib = (int)(launched_ % (gpu_depth_ + 1));
+      if (!early_off && gpu_depth_ == 1 && band_nrows_ == 0 && job.pps.tile_cols == 1 && !(batch_attached_ && DecBatcher::get(device_).active()) && d_in_[ib] && d_in_cap_[ib] >= fixed_bytes()) job.early_dst = d_in_[ib];
+    }
     job.rc = parse_job(job, true);
     if (profiling_) { k_ms_[DK_HOST_PARSE] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); k_n_[DK_HOST_PARSE]++; }
     job.state.store(2, std::memory_order_release);
@@ -2308,6 +2319,12 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
       if (end != (seg_last ? 1 : 0)) return seg_last ? DEC_ERR_INVALID : DEC_ERR_UNSUPPORTED;      // (a segment that ends elsewhere: not whole CTU rows / tiles)
       if (!seg_last && cx == cx1 - 1 && (wpp || tile_ends_at(cy)) && !c.terminate()) return DEC_ERR_INVALID;   // end_of_subset_one_bit
     }
+    if (job.early_dst) {
+      // the row's 4x4 records are final (a coding unit writes inside its own CTU only): up they go, from whichever thread parsed the row
+      const size_t rowb = (size_t)16 * (pw_ / 4) * sizeof(B4Rec), off = (size_t)cy * rowb;
+      if (hipSetDevice(device_) == hipSuccess && hipMemcpyAsync(job.early_dst + off, job.h_in + off, rowb, hipMemcpyHostToDevice, stream_up_) == hipSuccess)
+        job.early_rows.fetch_add(1, std::memory_order_acq_rel);
+    }
     // this CTB row's motion (the tile's columns of it) as later pictures see it (one entry per 16x16 block)
     if (!own) continue;
     for (int y16 = cy * 4; y16 < cy * 4 + 4 && y16 < own->h16; y16++)
@@ -2409,6 +2426,7 @@ int Decoder::launch_gpu(PicJob &job)
   const int ib = (int)(launched_ % (gpu_depth_ + 1));
   uint8_t *&d_in_ = this->d_in_[ib];
   if (bytes > d_in_cap_[ib]) {
+    if (job.early_dst) { hipStreamSynchronize(stream_up_); job.early_dst = nullptr; }      // (the rows that went up early went into the buffer being replaced)
     hipFree(d_in_);
     d_in_cap_[ib] = bytes + bytes / 2;
     if (hipMalloc(&d_in_, d_in_cap_[ib]) != hipSuccess) { d_in_ = nullptr; d_in_cap_[ib] = 0; return DEC_ERR_GPU; }
@@ -2468,7 +2486,10 @@ int Decoder::launch_gpu(PicJob &job)
   if (!batched && batch_used_) { batcher.drain(this); batch_used_ = false; }
   if (batched && stream_alt_) hipStreamSynchronize(stream_alt_);      // (another decoder has opened: from here on the submission layer launches on the shared stream; the second chain's last pictures first)       // (the other decoder has just closed: what this one still has queued there comes first)
   if (batched) memcpy(job.h_in + off_frame(), &f, sizeof(f));
-  if (hipMemcpyAsync(d_in_, job.h_in, bytes, hipMemcpyHostToDevice, stream_up_) != hipSuccess) return DEC_ERR_GPU;
+  // (PicJob::early_dst: the records of every CTU row are on the device already -- queued on this stream by the row parsers -- when all rows made it)
+  const size_t up_from = (!batched && job.early_dst && job.early_dst == d_in_ && job.early_rows.load(std::memory_order_acquire) == f.hc) ? off_region() : 0;
+  job.early_dst = nullptr;
+  if (hipMemcpyAsync(d_in_ + up_from, job.h_in + up_from, bytes - up_from, hipMemcpyHostToDevice, stream_up_) != hipSuccess) return DEC_ERR_GPU;
   if (hipEventRecord(up_done_[ib], stream_up_) != hipSuccess) return DEC_ERR_GPU;
   if (batched) {
     DecBatchItem it;

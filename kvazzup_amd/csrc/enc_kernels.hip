@@ -2423,7 +2423,8 @@ void launch_intra_analyse(const EncFrame &f, hipStream_t st)
 void launch_intra_recon(const EncFrame &f, hipStream_t st)
 {
   // as many workgroups as three anti-diagonals of the CTU wavefront hold, in three planes (k_intra_recon: tickets)
-  static const int diags = getenv("KVAZZUP_AMD_INTRA_DIAGS") ? atoi(getenv("KVAZZUP_AMD_INTRA_DIAGS")) : 3;      // (measurement aid; 0: a workgroup per (CTU, plane))
+  static const int diags_env = getenv("KVAZZUP_AMD_INTRA_DIAGS") ? atoi(getenv("KVAZZUP_AMD_INTRA_DIAGS")) : -1;      // (measurement aid; 0: a workgroup per (CTU, plane))
+  const int diags = diags_env >= 0 ? diags_env : (f.chain_diags ? f.chain_diags : 3);
   const int wc = f.cw / 64, nr = band_rows(f), diag = nr < (wc + 1) / 2 ? nr : (wc + 1) / 2, want = diags > 0 ? 3 * diags * diag + 32 : 3 * wc * nr;
   const dim3 grid(want < 3 * wc * nr ? want : 3 * wc * nr), block(64 * KVZ_INTRA_WAVES);
   const bool adj = f.rdoq || f.signhide;

@@ -48,3 +48,29 @@ def test_short_lived_row_pools_close():
         for n in nals[:3]:
             assert lib.libOpenHevcDecode(h, n, len(n), 0) >= 0
         lib.libOpenHevcClose(h)
+
+
+def test_exp_golomb_fields_beyond_31_bits_are_refused():
+    """slice_pic_parameter_set_id written as a code word with 32 leading zeros: used to come out of BitReader::ue as a negative int that passed `pps_id > 63`
+    and indexed the PPS table in front of its first entry (found by tools/fuzz_parser.py under AddressSanitizer)"""
+    lib = PP._lib()
+    nals = PP.encoded_case("enc_flat_all_skip")
+    params = [n for n in nals if (n[4] >> 1) in (32, 33, 34)]
+    assert len(params) >= 3
+    for zeros in (31, 32, 33, 40, 64):
+        bits = "1" + "0" * zeros + "1" + "1" * 40                      # first_slice_segment_in_pic_flag, then the code word
+        bits += "0" * (-len(bits) % 8)
+        payload = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+        # (emulation prevention: runs of zero bytes in the payload get their 0x03)
+        out, z = bytearray(), 0
+        for b in payload:
+            if z >= 2 and b <= 3:
+                out.append(3); z = 0
+            out.append(b); z = z + 1 if b == 0 else 0
+        slice_nal = b"\x00\x00\x00\x01" + bytes([1 << 1, 1]) + bytes(out)      # TRAIL_R, layer 0, temporal id 0
+        h = lib.libOpenHevcInit(1, 2)
+        assert lib.kvzx_decoder_set_parse_only(h, 1) == 1 and lib.libOpenHevcStartDecoder(h) == 0
+        for n in params:
+            assert lib.libOpenHevcDecode(h, n, len(n), 0) == 0
+        assert lib.libOpenHevcDecode(h, slice_nal, len(slice_nal), 0) < 0, zeros
+        lib.libOpenHevcClose(h)

@@ -45,9 +45,16 @@ def mutate(rng, nals):
             out.insert(i, bytearray(n))
         elif kind < 0.94 and len(out) > 1:                         # ... swapped with another
             j = rng.randrange(len(out)); out[i], out[j] = out[j], out[i]
-        else:                                                      # the NAL header itself (type, layer, temporal id)
+        elif kind < 0.97:                                          # the NAL header itself (type, layer, temporal id)
             if len(n) > 5:
                 n[4 + rng.randrange(2)] = rng.randrange(256)
+        elif len(n) > hdr + 2:                                     # a run of zero BITS spliced into the head (parameter sets, slice headers): an Exp-Golomb field of any size, wherever it lands
+            head = min(len(n), hdr + 40)
+            bits = "".join("{:08b}".format(b) for b in n[hdr:head])
+            at = rng.randrange(len(bits))
+            bits = bits[:at] + "0" * rng.choice((8, 16, 24, 30, 31, 32, 33, 48)) + "1" + bits[at:]
+            bits += "0" * (-len(bits) % 8)
+            n[hdr:head] = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
     return [bytes(n) for n in out if len(n) > 4]
 
 

@@ -1488,13 +1488,21 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
   const int nal_type = (data[0] >> 1) & 0x3f, layer = ((data[0] & 1) << 5) | (data[1] >> 3);
   if (layer != 0) return 0;
   cur_tid_ = (data[1] & 7) - 1;
-  rbsp_.assign(len + 32, 0);
+  if (rbsp_.size() < len + 32) rbsp_.resize(len + 32);
   epb_.clear();
+  // emulation prevention bytes out (7.4.2; hevc_headers.h append_nal is the inverse): the bytes between zero bytes in one piece
   size_t n = 0; int zeros = 0;
-  for (size_t k = 2; k < len; k++) {
-    if (zeros >= 2 && data[k] == 3) { zeros = 0; epb_.push_back(n); continue; }
-    rbsp_[n++] = data[k]; zeros = data[k] == 0 ? zeros + 1 : 0;
+  for (size_t k = 2; k < len;) {
+    if (zeros == 0) {
+      const uint8_t *z = (const uint8_t *)memchr(data + k, 0, len - k);
+      const size_t m = z ? (size_t)(z - (data + k)) : len - k;
+      memcpy(rbsp_.data() + n, data + k, m); n += m; k += m;
+      if (k >= len) break;
+    }
+    if (zeros >= 2 && data[k] == 3) { zeros = 0; epb_.push_back(n); k++; continue; }
+    rbsp_[n++] = data[k]; zeros = data[k] == 0 ? zeros + 1 : 0; k++;
   }
+  memset(rbsp_.data() + n, 0, 32);                          // (readers may look a few bytes past the end)
   BitReader r(rbsp_.data(), n);
   if (asm_active_ && asm_guessed_one_row_ && nal_type >= 32 && nal_type <= 40 && nal_type != 38) { const int rc = close_open_picture(); if (rc < 0) return rc; }   // (what can only open the next access unit, or end the sequence)
   if (nal_type == 32) {                                          // VPS: only the timing information is used

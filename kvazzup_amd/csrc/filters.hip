@@ -641,7 +641,12 @@ void WireAdapter::process()
     }
     const uint8_t *p = input->data.get(); const uint32_t n = input->data_size;
     std::vector<uint32_t> starts;
-    for (uint32_t i = 0; i + 3 < n; i++) if (p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 0 && p[i + 3] == 1) { starts.push_back(i); i += 3; }
+    for (uint32_t i = 0; i + 3 < n;) {                     // 00 00 00 01: from zero byte to zero byte (memchr), not byte by byte
+      const uint8_t *z = (const uint8_t *)memchr(p + i, 0, n - 3 - i);
+      if (!z) break;
+      i = (uint32_t)(z - p);
+      if (p[i + 1] == 0 && p[i + 2] == 0 && p[i + 3] == 1) { starts.push_back(i); i += 4; } else i++;
+    }
     starts.push_back(n);
     for (size_t k = 0; k + 1 < starts.size(); k++) {
       std::unique_ptr<Data> nal(new Data);

@@ -4,6 +4,7 @@
 // (/root/reference/src/media/processing/kvazaarfilter.cpp:435-438,469-474 consume its chunks).
 #pragma once
 #include <stdint.h>
+#include <cstring>
 #include <vector>
 
 namespace kvzx {
@@ -106,12 +107,20 @@ inline void write_pps(BitWriter &w, const StreamParams &s)
   w.trailing();
 }
 
+// Emulation prevention (7.4.2): arithmetic-coded data holds a zero byte every ~256 bytes, so the bytes between zero bytes are found with memchr and moved
+// in one piece, and only the zero runs (and the byte behind them) go through the byte-by-byte rule (round 5: these loops and the decoder's inverse were
+// ~3 % of the host's time at a byte per iteration).
 inline size_t escaped_size(const uint8_t *p, size_t n)
 {
-  size_t out = 0; int zeros = 0;
-  for (size_t i = 0; i < n; i++) {
+  size_t out = n, i = 0; int zeros = 0;
+  while (i < n) {
+    if (zeros == 0) {
+      const uint8_t *z = (const uint8_t *)memchr(p + i, 0, n - i);
+      if (!z) break;
+      i = (size_t)(z - p);
+    }
     if (zeros >= 2 && p[i] <= 3) { out++; zeros = 0; }
-    out++; zeros = p[i] == 0 ? zeros + 1 : 0;
+    zeros = p[i] == 0 ? zeros + 1 : 0; i++;
   }
   return out;
 }
@@ -156,11 +165,18 @@ inline void append_nal(std::vector<uint8_t> &out, int nal_type, const uint8_t *r
 {
   out.push_back(0); out.push_back(0); out.push_back(0); out.push_back(1);
   out.push_back((uint8_t)(nal_type << 1)); out.push_back(1);
-  int zeros = 0;
-  for (size_t i = 0; i < n; i++) {
+  out.reserve(out.size() + n + n / 128 + 16);
+  int zeros = 0; size_t i = 0;
+  while (i < n) {
+    if (zeros == 0) {                                       // up to the next zero byte in one piece
+      const uint8_t *z = (const uint8_t *)memchr(rbsp + i, 0, n - i);
+      const size_t k = z ? (size_t)(z - (rbsp + i)) : n - i;
+      out.insert(out.end(), rbsp + i, rbsp + i + k); i += k;
+      if (i >= n) break;
+    }
     if (zeros >= 2 && rbsp[i] <= 3) { out.push_back(3); zeros = 0; }
     out.push_back(rbsp[i]);
-    zeros = rbsp[i] == 0 ? zeros + 1 : 0;
+    zeros = rbsp[i] == 0 ? zeros + 1 : 0; i++;
   }
 }
 

@@ -308,13 +308,16 @@ def main():
             "repeats": args.repeats, "runs_fps": m["runs_fps"], "value_is": VALUE_IS,
         }
         out = {
+            "rates": None,                               # (filled below; first key so that the tail of a truncated line still shows it)
             "metric": "hevc_encode_decode_fps", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(m["elapsed"] / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": config,
-            "rates": {"resident": round(fps, 3), "host_boundary": (hostb or {}).get("value"), "uvgcomm_defaults": (bare or {}).get("value"), "unit": "frames/s",
+        }
+        out["rates"] = {"resident": round(fps, 3), "host_boundary": (hostb or {}).get("value"), "uvgcomm_defaults": (bare or {}).get("value"), "unit": "frames/s",
                       "note": "`value` = resident (the bench contract: inputs in HBM when the timed region starts); host_boundary = the reference's host-in / host-out "
-                              "boundary with the two custom parameters; uvgcomm_defaults = the same boundary with uvgComm's default settings and no custom parameter"},
+                              "boundary with the two custom parameters; uvgcomm_defaults = the same boundary with uvgComm's default settings and no custom parameter"}
+        out.update({
             "host_boundary": hostb,
             "uvgcomm_defaults": bare,
             "latency_us": lat,
@@ -327,7 +330,7 @@ def main():
             "kernels_us": kernels_us,
             "filter_busy_ms_per_picture": {"KvazaarFilter": m["busy"][0], "WireAdapter": m["busy"][1], "OpenHEVCFilter": m["busy"][2]},
             "kernel_share_of_step": share,
-        }
+        })
         if sec is not None:
             out["secondary"] = sec
         if args.full_search and "k_me" in m["kt"] and m["kt"]["k_me"][1]:

@@ -35,12 +35,14 @@ def roofline_of(m, steps, me_range, workload_key):
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950.  null when no pass exists.
     traffic, traffic_src = None, None
     mfma = None
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    pmc_kernels = {}
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         try:
             name = "profiles/%s_pmc_traffic_%s.json" % (rnd, workload_key)
             pmc = json.load(open(os.path.join(ROOT, name)))
             traffic = pmc["kernels"][dom]["traffic_bytes"]
             traffic_src = name
+            pmc_kernels = pmc["kernels"]
             # matrix-core utilisation of the kernels that use them (same counter passes: SQ_VALU_MFMA_BUSY_CYCLES / (duration x clock x SIMDs))
             mfma = {k: v["mfma_util"] for k, v in pmc["kernels"].items() if v.get("mfma_util")} or None
             break
@@ -54,5 +56,13 @@ def roofline_of(m, steps, me_range, workload_key):
     # every kernel against the HBM roofline (algorithmic bytes of one launch / its average duration)
     per_kernel = {k: round(algorithmic_bytes(k, cw, ch, me_range) / (kt[k][0] / kt[k][1] / 1e3) / 1e9 / W.HBM_PEAK_GBS, 5) for k in kern}
     roof["frac_by_kernel"] = per_kernel
+    # the same fractions from the COUNTERS (HBM bytes of a launch in the committed PMC pass / this run's event time / peak) and what a launch moves
+    # over what it must: > 1 = re-reads (polling, windows that fall out of L2), < 1 = the "algorithmic" figure counts bytes that L2 serves (overlapping windows)
+    def pmc_name(k):
+        return "k_deblock" if k == "k_deblock_tile" else k
+    tr = {k: pmc_kernels[pmc_name(k)]["traffic_bytes"] for k in kern if pmc_name(k) in pmc_kernels and pmc_kernels[pmc_name(k)].get("traffic_bytes")}
+    roof["frac_traffic_by_kernel"] = {k: round(b / (kt[k][0] / kt[k][1] / 1e3) / 1e9 / W.HBM_PEAK_GBS, 5) for k, b in tr.items()} or None
+    roof["traffic_over_algorithmic"] = {k: round(b / algorithmic_bytes(k, cw, ch, me_range), 2) for k, b in tr.items()} or None
+    roof["frac_traffic"] = (roof["frac_traffic_by_kernel"] or {}).get(dom)
     roof["mfma_util_by_kernel"] = mfma                 # north_star: "MFMA utilisation against gfx950 peak" -- the transforms and Hadamard sums are small products between LDS phases
     return roof, kernels_us, share

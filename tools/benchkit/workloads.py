@@ -29,8 +29,8 @@ HBM_PEAK_SOURCE = "MI355X_MICROARCH.md (the runtime reported no memory clock / b
 def algorithmic_bytes(kernel, cw, ch, me_range):
     """Compulsory bytes of ONE launch, P = coded luma samples."""
     P = cw * ch
-    if kernel == "k_me":                          # current block once + its search window once, per 32x32 block
-        return (P // 1024) * (1024 + (32 + 2 * me_range) ** 2)
+    if kernel == "k_me":                          # SURVEY 8(d): "CTU pixels once + search-window pixels once per CTU, (64+2r)^2"
+        return (P // 4096) * (4096 + (64 + 2 * me_range) ** 2)
     if kernel in ("k_inter_recon", "k_dec_inter", "k_inter_recon<dec>"):
         return int(4.5 * P) if kernel == "k_inter_recon" else int(3.0 * P)
     if kernel in ("k_intra_recon<P>", "k_dec_intra<P>", "k_intra_analyse<P>"):      # a P picture's few intra units: priced like the whole picture's pass they are a part of

@@ -68,7 +68,7 @@ def parse_args():
     ap.add_argument("--repeats", type=int, default=3, help="the timed region is run this many times; `value` is the median run (BASELINE.md: median of 3)")
     ap.add_argument("--no-host-boundary", action="store_true", help="skip the `host_boundary` legs -- and with them `uvgcomm_defaults`, `latency_us` and `bounds` (what tools/*.sh profile is the headline leg)")
     ap.add_argument("--host-io", action="store_true", help="profiling aid: the MAIN run goes through the host boundary")
-    ap.add_argument("--streams-per-gpu", default="2,4",
+    ap.add_argument("--streams-per-gpu", default="2,4,8",
                     help="comma-separated K: K independent streams at once on the one GPU, each with its own filter chain in this process "
                          "(aggregate frames/s; the instances share the device's HIP streams by role and the decoders' pictures are launched in batches); '' = off")
     ap.add_argument("--custom", action="append", default=[], metavar="KEY=VALUE",
@@ -156,9 +156,18 @@ def default_mode_leg(args, ranks, rank, world, wl):
         pm = run_stream(args, wl, steps, min(2, max(1, args.warmup)), ranks, rank, world, quality=True, extra_custom=RESIDENT, extra_settings=settings)
     except Exception as e:                           # noqa: BLE001
         return {"error": str(e)}
+    # A/B of "uvgx search pipelining v1" (kvazaar.h me_source; on at this preset): the same leg with the integer search on the reconstruction, i.e. k_me and
+    # k_intra_analyse<P> back in the chain -- rate, bits and PSNR side by side (the RD tolerance the option is held to: tests/test_oracle_closed_loop.py)
+    ab = None
+    try:
+        p0 = run_stream(args, wl, steps, 1, ranks, rank, world, quality=True, extra_custom=RESIDENT + (("me-source", "0"),), extra_settings=settings, repeats=1)
+        ab = {"custom_parameters": {"me-source": "0"}, "value": round(p0["pictures"] / p0["elapsed"], 3), "bits_per_picture": round(8 * p0["bytes_per_picture"], 1), "psnr_y": p0["psnr_y"]}
+    except Exception as e:                           # noqa: BLE001
+        ab = {"error": str(e)}
     return {"settings": settings, "value": round(pm["pictures"] / pm["elapsed"], 3), "unit": "frames/s", "steps": steps, "runs_fps": pm["runs_fps"],
             "bits_per_picture": round(8 * pm["bytes_per_picture"], 1), "kbit_per_s_at_30fps": round(8 * pm["bytes_per_picture"] * 30 / 1e3, 1),
-            "psnr_y": pm["psnr_y"], "host_cpu_cores_busy": round(pm["host_cores"], 2), "kernels_us": roofline_of(pm, steps, args.me_range, args.workload)[1]}
+            "psnr_y": pm["psnr_y"], "host_cpu_cores_busy": round(pm["host_cores"], 2), "kernels_us": roofline_of(pm, steps, args.me_range, args.workload)[1],
+            "search_on_reconstruction": ab}
 
 
 def all_intra_leg(args, ranks, rank, world, wl):
@@ -303,6 +312,12 @@ def main():
             "me_early_termination": not args.full_search, "intra_satd": not args.intra_sad,
             "host_cpu_cores_busy": round(m["host_cores"], 2), "minor_page_faults_per_picture": round(m["minflt"], 1),
             "cpu_time_in_kernel": round(m["sys_share"], 3), "host_cpu_budget_cores": round(m["budget"], 1), "host_cpu_throttled_ms": round(m["throttled_ms"], 1),
+            # what the host allows: this rank's share of the node's CPU quota over the CPU time a picture costs (both codecs' entropy coding runs on host
+            # threads) -- when `value` sits at this ceiling the curve over --gpus N is flat because the ranks divide one quota, not because of the GPUs
+            "host_cpu_ceiling": {"budget_cores_per_rank": round(m["budget"], 2), "cpu_ms_per_picture": round(m["host_cores"] * m["elapsed"] / npic * 1e3, 4),
+                                 "predicted_ceiling_fps": round(world * m["budget"] / max(1e-9, m["host_cores"] * m["elapsed"] / npic), 1),
+                                 "at_ceiling": bool(m["host_cores"] >= 0.9 * m["budget"]),
+                                 "is": "ranks x budget_cores_per_rank / CPU seconds per picture (rank 0's; cgroup cpu.max or the visible cores, divided by the ranks of the node)"},
             "input": "host I420 through kvz_api->encoder_encode" if args.host_io else "I420 resident in HBM",
             "output": "Annex-B AU on host + decoded I420 in " + ("host memory" if args.host_io else "HBM"),
             "repeats": args.repeats, "runs_fps": m["runs_fps"], "value_is": VALUE_IS,

@@ -127,6 +127,7 @@ typedef struct kvz_config {
   int32_t intra_in_p;         /* "intra-in-p" 0 / 1 / 2: intra coding units in P pictures, 1 = 16x16 units only (presets superfast .. fast), 2 = 16x16 and 8x8 units (medium and slower) ("uvgx intra-in-P v1": a 16x16 quarter whose motion-search cost is high is priced as an intra block from the source picture and coded intra when that is cheaper -- scene cuts, uncovered background); under rate control v2 the row groups are priced without the intra units' levels; ignored in band mode */
   int32_t gpu_entropy;        /* "gpu-entropy": 1 = the arithmetic coder runs on the GPU too (k_cabac_rows: no host coder threads, 2-4 ms more latency per picture), 0 (default) = host thread pool sized by "threads" */
   int32_t intra_chain;        /* "intra-chain" (default 1): the blocks of a CTU whose below-left / above-right reference samples lie in ANOTHER CTU (its left-edge blocks, its above-right corner block) choose among the intra modes that do not read those samples: the CTU wavefront of the reconstruction chain (k_intra_recon, and k_dec_intra on the receiving side) advances in shorter lags; 0 = all 35 modes everywhere */
+  int32_t me_source;          /* "me-source" 0 / 1 ("uvgx search pipelining v1"): the integer motion search of a P picture looks at the previous INPUT picture instead of the reference picture's reconstruction, so it depends on nothing the previous picture's reconstruction loop produces and runs beside it on the GPU (fractional refinement, motion compensation and everything behind them use the reconstruction as ever).  On at the presets superfast .. fast, whose subme >= 2 refinement against the reconstruction makes up for it (oracle, 640x384 / 720p: -0.6 .. +0.2 % bits, -0.01 .. -0.02 dB); off at ultrafast (no refinement there: +1.1 .. 1.4 % bits, -0.17 dB) and from medium on; ignored in band mode */
 } kvz_config;
 
 /* Picture.  y/u/v are planar 8-bit with stride == width (chroma width/2), as uvgComm assumes

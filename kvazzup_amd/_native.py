@@ -38,7 +38,7 @@ class KvzConfig(C.Structure):
                 ("intra_bits", C.c_int32), ("me_max_steps", C.c_int32), ("fast_residual_cost_limit", C.c_int32),
                 ("pu_depth_inter_min", C.c_int32), ("pu_depth_inter_max", C.c_int32), ("pu_depth_intra_min", C.c_int32), ("pu_depth_intra_max", C.c_int32),
                 ("me_range", C.c_int32), ("gpu_device", C.c_int32), ("recon_output", C.c_int32), ("intra_satd", C.c_int32),
-                ("band_row0", C.c_int32), ("band_rows", C.c_int32), ("input_hold", C.c_int32), ("null_input_poll", C.c_int32), ("intra_in_p", C.c_int32), ("gpu_entropy", C.c_int32), ("intra_chain", C.c_int32)]
+                ("band_row0", C.c_int32), ("band_rows", C.c_int32), ("input_hold", C.c_int32), ("null_input_poll", C.c_int32), ("intra_in_p", C.c_int32), ("gpu_entropy", C.c_int32), ("intra_chain", C.c_int32), ("me_source", C.c_int32)]
 
 
 class KvzRoi(C.Structure):

@@ -139,7 +139,7 @@ class Decoder {
   // summarised by parse_probe_stats: pictures, transform blocks, level words, a 64-bit FNV-1a digest over every picture's records / tables / blocks /
   // levels (the bytes launch_gpu would upload, fixed part minus the descriptor) and the time spent in parse_job.  CPU tests pin the parser's output with it
   // (tests/test_parser_probe.py); tools/measure/parse_rate.py times the parser where there is no GPU.
-  void set_parse_only() { if (jobs_.empty() && !started_) parse_only_ = true; }
+  bool set_parse_only() { if (jobs_.empty() && !started_) parse_only_ = true; return parse_only_; }      // (false: declined -- the decoder has been started)
   struct ProbeStats { uint64_t pictures = 0, tus = 0, levels = 0, digest = 0xcbf29ce484222325ull, bins = 0; double parse_ms = 0; };
   ProbeStats parse_probe_stats() const { return probe_; }
   // device-resident output (set_download(false)): the planes handed out stay untouched while the next `n` pictures are decoded
@@ -293,7 +293,7 @@ class Decoder {
   // device buffers of OwnedPic copies, kept for the next picture of the same size (queue_current_output)
   static constexpr size_t kOwnedPoolMax = 24;
   std::vector<std::pair<size_t, uint8_t *>> owned_pool_; std::map<const uint8_t *, size_t> owned_bytes_; hipEvent_t owned_ev_ = nullptr;
-  uint8_t *owned_alloc(size_t bytes); void owned_release(uint8_t *p); bool stash_current_output();
+  uint8_t *owned_alloc(size_t bytes); void owned_release(uint8_t *p); void owned_free(uint8_t *p); bool stash_current_output();
   void free_retired(bool all);
   int decode_nal_inner(const uint8_t *data, size_t len, int64_t pts);
   bool queue_current_output();
@@ -318,7 +318,7 @@ class Decoder {
   // frame-threaded decoder such pictures ALTERNATE between the decoder's stream and a second one with chain arrays of its own, so that two chains run side by
   // side (an all-intra stream, BASELINE configs[0]: the decoder's rate was 1 / chain).  Pictures that read or overwrite a buffer last used on the other stream
   // wait for that picture's event.
-  hipStream_t stream_alt_ = nullptr; char alt_prio_ = 'n'; long intra_seq_ = 0;
+  hipStream_t stream_alt_ = nullptr; char alt_prio_ = 'n'; long intra_seq_ = 0; bool alt_failed_ = false;      // (stream_alt_ is set LAST by ensure_alt: non-NULL = every array of the second chain exists)
   uint32_t *progress_alt_ = nullptr, *edge_col_alt_ = nullptr; unsigned long long *edge_row_alt_ = nullptr; int16_t *resid_alt_[3] = {nullptr, nullptr, nullptr}; uint8_t *work_alt_[3] = {nullptr, nullptr, nullptr};
   bool ensure_alt();
   // download mode: page-locked output buffers take turns -- one is what libOpenHevcGetOutput last handed out (valid until the next

@@ -167,30 +167,6 @@ struct CabacRegs {
     }
     return v;
   }
-  // the unary prefix of coeff_abs_level_remaining (up to `max` ones, then a zero): bypass bins are the bits of the quotient value / (range << k), so the
-  // run of ones is read off one division instead of one compare per bin
-  __attribute__((always_inline)) inline int bypass_ones(int max)
-  {
-    int n = 0;
-    while (n < max) {
-      const int m = max - n < 8 ? max - n : 8;
-      // the next m bypass bins, without consuming them: q = value / (range << (bits - m))
-      const uint64_t scaled = (uint64_t)range << (bits - m);
-      const uint64_t q = value / scaled;                   // < 2^m
-      const int ones = __builtin_clz((uint32_t)(~q << (32 - m)) | (1u << (31 - m)));      // leading ones of the m-bit pattern
-      if (ones < m) {                                       // a zero among them: consume the ones and the zero
-        const int take = ones + 1;
-        bits -= take;
-        const uint64_t sc2 = (uint64_t)range << bits;
-        value -= (q >> (m - take)) * sc2;
-        refill();
-        return n + ones;
-      }
-      bits -= m; value -= q * scaled; refill();
-      n += m;
-    }
-    return n;
-  }
   __attribute__((always_inline)) inline int terminate()
   {
     range -= 2;
@@ -1081,10 +1057,11 @@ Decoder::~Decoder()
   for (auto &j : jobs_) { for (auto &e : j.ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); } if (j.done) hipEventDestroy(j.done); if (j.dl_done) hipEventDestroy(j.dl_done); }
   free_buffers();
   free_retired(true);
-  for (auto &o : ready_q_) if (o.dev) hipFree(o.dev);
-  for (auto &w : reorder_q_) if (w.pic.dev) hipFree(w.pic.dev);
-  if (cur_owned_.dev) hipFree(cur_owned_.dev);
-  for (auto &b : owned_pool_) hipFree(b.second);
+  for (auto &o : ready_q_) owned_free(o.dev);
+  for (auto &w : reorder_q_) owned_free(w.pic.dev);
+  owned_free(cur_owned_.dev);
+  for (auto &b : owned_pool_) owned_free(b.second);
+  owned_pool_.clear();
   if (owned_ev_) hipEventDestroy(owned_ev_);
   if (stream_dl_ != stream_up_) stream_release(stream_dl_, device_, 'L', 'l');
   stream_release(stream_up_, device_, 'U', prio_up_);
@@ -1144,6 +1121,7 @@ void Decoder::free_buffers()
     for (int c = 0; c < 3; c++) { hipFree(resid_alt_[c]); resid_alt_[c] = nullptr; hipFree(work_alt_[c]); work_alt_[c] = nullptr; }
     stream_release(stream_alt_, device_, 'E', alt_prio_); stream_alt_ = nullptr;
   }
+  alt_failed_ = false;                                       // (another picture size: the second chain's arrays may fit now)
   for (auto &p : dpb_) { hipFree(p.plane[0]); p = DpbPic(); }      // (a buffer's three planes are one allocation)
   for (int c = 0; c < 3; c++) { hipFree(work_[c]); work_[c] = nullptr; hipFree(resid_[c]); resid_[c] = nullptr; }
   progress_ = nullptr;
@@ -1285,19 +1263,39 @@ template <class F> void Decoder::timed(int id, F &&launch, hipStream_t st)
 bool Decoder::ensure_alt()
 {
   if (stream_alt_) return true;
+  if (alt_failed_) return false;                             // (it did not fit once: the intra-only pictures keep to the one chain instead of trying again for every picture)
   if (hipSetDevice(device_) != hipSuccess) return false;
   const size_t nctu = (size_t)(pw_ / 64) * (ph_ / 64), npx = (size_t)pw_ * ph_;
   // the second chain's priority level = its pool of hardware queues: the LOWEST level, where nothing else of this library lives (measured, all-intra 1080p with
   // the encoder's second chain at the main stream's level: second decoder chain at the default level 1 563 frames/s -- the level's four queues are taken by
   // tokenizer, input, decoder and transfers --, at the high level 1 681, at the low one 1 724; one chain each side: 1 279)
   { const char *e = getenv("KVAZZUP_AMD_DEC_ALT_PRIO"); alt_prio_ = e ? e[0] : 'l'; }
-  HIP_TRY(stream_acquire(&stream_alt_, device_, 'E', alt_prio_));
-  // (cleared ON the stream that is about to use them: the decoder's streams are non-blocking, a clear on the null stream is ordered with nothing -- the first
-  // picture of the second chain had its hand-off words zeroed under its hands, every wait in it gave up: error flags 3, found by the serial suite)
-  HIP_TRY(hipMalloc(&progress_alt_, sizeof(uint32_t) * (3 * nctu + 1))); HIP_TRY(hipMemsetAsync(progress_alt_, 0, sizeof(uint32_t) * (3 * nctu + 1), stream_alt_));
-  HIP_TRY(hipMalloc(&edge_col_alt_, nctu * 128 * sizeof(uint32_t))); HIP_TRY(hipMemsetAsync(edge_col_alt_, 0, nctu * 128 * sizeof(uint32_t), stream_alt_));
-  HIP_TRY(hipMalloc(&edge_row_alt_, nctu * 32 * 8)); HIP_TRY(hipMemsetAsync(edge_row_alt_, 0, nctu * 32 * 8, stream_alt_));
-  for (int c = 0; c < 3; c++) { HIP_TRY(hipMalloc(&resid_alt_[c], sizeof(int16_t) * (c ? npx / 4 : npx))); HIP_TRY(hipMalloc(&work_alt_[c], c ? npx / 4 : npx)); }
+  // Everything is built in locals and handed to the members in one piece: stream_alt_ != NULL is what launch_gpu takes for "the second chain exists", so a
+  // half-built state (a failed allocation at 4K) must never be visible -- on any failure what was allocated is freed and the stream released.
+  hipStream_t st = nullptr;
+  uint32_t *prog = nullptr, *ecol = nullptr; unsigned long long *erow = nullptr; int16_t *res[3] = {nullptr, nullptr, nullptr}; uint8_t *wrk[3] = {nullptr, nullptr, nullptr};
+  auto build = [&]() -> bool {
+    HIP_TRY(stream_acquire(&st, device_, 'E', alt_prio_));
+    // (cleared ON the stream that is about to use them: the decoder's streams are non-blocking, a clear on the null stream is ordered with nothing -- the first
+    // picture of the second chain had its hand-off words zeroed under its hands, every wait in it gave up: error flags 3, found by the serial suite)
+    HIP_TRY(hipMalloc(&prog, sizeof(uint32_t) * (3 * nctu + 1))); HIP_TRY(hipMemsetAsync(prog, 0, sizeof(uint32_t) * (3 * nctu + 1), st));
+    HIP_TRY(hipMalloc(&ecol, nctu * 128 * sizeof(uint32_t))); HIP_TRY(hipMemsetAsync(ecol, 0, nctu * 128 * sizeof(uint32_t), st));
+    HIP_TRY(hipMalloc(&erow, nctu * 32 * 8)); HIP_TRY(hipMemsetAsync(erow, 0, nctu * 32 * 8, st));
+    for (int c = 0; c < 3; c++) { HIP_TRY(hipMalloc(&res[c], sizeof(int16_t) * (c ? npx / 4 : npx))); HIP_TRY(hipMalloc(&wrk[c], c ? npx / 4 : npx)); }
+    return true;
+  };
+  if (!build()) {
+    if (st) hipStreamSynchronize(st);                        // (a clear may be queued on it)
+    hipFree(prog); hipFree(ecol); hipFree(erow);
+    for (int c = 0; c < 3; c++) { hipFree(res[c]); hipFree(wrk[c]); }
+    if (st) stream_release(st, device_, 'E', alt_prio_);
+    (void)hipGetLastError();
+    alt_failed_ = true;
+    return false;
+  }
+  progress_alt_ = prog; edge_col_alt_ = ecol; edge_row_alt_ = erow;
+  for (int c = 0; c < 3; c++) { resid_alt_[c] = res[c]; work_alt_[c] = wrk[c]; }
+  stream_alt_ = st;
   return true;
 }
 void Decoder::get_kernel_times(double *ms, uint64_t *launches, bool reset)
@@ -1313,7 +1311,7 @@ void Decoder::get_kernel_times(double *ms, uint64_t *launches, bool reset)
 void Decoder::free_retired(bool all)
 {
   while (!retired_out_.empty() && (all || nal_calls_ - retired_out_.front().first > kOutHold)) { hipHostFree(retired_out_.front().second); retired_out_.pop_front(); }
-  while (!retired_owned_.empty() && (all || nal_calls_ - retired_owned_.front().first > kOutHold)) { if (all) { if (retired_owned_.front().second.dev) hipFree(retired_owned_.front().second.dev); } else owned_release(retired_owned_.front().second.dev); retired_owned_.pop_front(); }
+  while (!retired_owned_.empty() && (all || nal_calls_ - retired_owned_.front().first > kOutHold)) { if (all) owned_free(retired_owned_.front().second.dev); else owned_release(retired_owned_.front().second.dev); retired_owned_.pop_front(); }
 }
 
 int Decoder::decode_nal(const uint8_t *data, size_t len, int64_t pts)
@@ -1382,7 +1380,8 @@ bool Decoder::pop_reordered(bool flush)
 uint8_t *Decoder::owned_alloc(size_t bytes)
 {
   for (size_t i = 0; i < owned_pool_.size(); i++) if (owned_pool_[i].first == bytes) { uint8_t *p = owned_pool_[i].second; owned_pool_.erase(owned_pool_.begin() + (long)i); return p; }
-  if (!owned_pool_.empty()) { owned_bytes_.erase(owned_pool_.front().second); hipFree(owned_pool_.front().second); owned_pool_.erase(owned_pool_.begin()); }      // (another size: the stream changed its resolution -- the oldest stale buffer goes)
+  for (auto &b : owned_pool_) owned_free(b.second);      // (another size: the stream changed its resolution -- every pooled buffer of the old size goes at once: at 4K two dozen of them are 288 MB)
+  owned_pool_.clear();
   uint8_t *p = nullptr;
   if (hipSetDevice(device_) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) return nullptr;
   owned_bytes_[p] = bytes;
@@ -1392,8 +1391,15 @@ void Decoder::owned_release(uint8_t *p)
 {
   if (!p) return;
   auto it = owned_bytes_.find(p);
-  if (it != owned_bytes_.end() && owned_pool_.size() < kOwnedPoolMax) { owned_pool_.emplace_back(it->second, p); return; }
-  if (it != owned_bytes_.end()) owned_bytes_.erase(it);
+  if (it != owned_bytes_.end() && owned_pool_.size() < kOwnedPoolMax && (owned_pool_.empty() || owned_pool_.front().first == it->second)) { owned_pool_.emplace_back(it->second, p); return; }      // (the pool holds ONE size: owned_alloc empties it when another one is asked for)
+  owned_free(p);
+}
+// every hipFree of an owned buffer comes through here: the address leaves the size map with it (a stale entry would pool a later allocation at the same
+// address under the wrong size)
+void Decoder::owned_free(uint8_t *p)
+{
+  if (!p) return;
+  owned_bytes_.erase(p);
   hipFree(p);
 }
 bool Decoder::queue_current_output()

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_me(EncFrame f)
   int bx_, by_; xcd_block_2d(bx_, by_);
   const int x0 = bx_ * 32, y0 = by_ * 32 + f.row0 * 64;
   const int R = f.range, W = 2 * R + 1, WW = 32 + 2 * R;
-  const uint8_t *ref = f.ref[0], *src = f.src[0];
+  const uint8_t *ref = f.me_ref, *src = f.src[0];
   const uint32_t lam = (uint32_t)f.lambda_q4;
   if (f.pb_on && blockIdx.x == 0 && blockIdx.y == 0) picture_begin_body(f.pb_rc, f.pb_bits3, f.pb_slot3, f.pb_have3, f.pb_qt, f.pb_roi, f.pb_nctu, f.qp, 0, tid, nthreads);      // (nothing in this launch reads what it writes: k_inter_recon is the first)
   // the block itself, and (me-early-termination) its SAD against the co-located block of the reference: a block that differs

@@ -52,6 +52,7 @@ struct EncoderConfig {
   int scaling_list = 0;       // kvazaar "scaling-list default": scaling_list_enabled_flag with the default lists (oracle/hevc_scaling.c); quantiser scale per position (qscale << 4) / m
   int rdoq = 0;               // kvazaar "rdoq": "uvgx RDOQ v1" -- sparse high-frequency coefficient groups are dropped when that is cheaper (oracle/hevc_transform.h orc_adjust_levels)
   int intra_in_p = 0;         // "intra-in-p" 0 / 1 (16x16 units only) / 2 (16x16 and 8x8): intra coding units in P pictures ("uvgx intra-in-P v1", oracle/hevc_enc.c me_block32); not in band mode
+  int me_source = 0;          // "me-source" ("uvgx search pipelining v1", oracle/hevc_enc.c build_refpad): the integer search looks at the previous input picture; k_me (and k_intra_analyse<P>) of picture t + 1 then run on the input stream beside picture t's chain; not in band mode
   int signhide = 0;           // kvazaar "signhide": sign_data_hiding_enabled_flag; the quantiser makes the parity of every eligible coefficient group say the hidden sign
   int hash = 0;               // kvazaar "hash": 1 checksum, 2 md5 -- a decoded picture hash SEI (D.2.19) behind every picture's slices, from the reconstruction downloaded for it
   int entropy_gpu = 0;        // arithmetic coder: 1 = on the GPU (k_cabac_rows, cabac_kernels.hip), 0 = host thread pool (entropy_host.h); band mode always uses the host pool
@@ -98,6 +99,10 @@ class Encoder {
   bool band_phase2b(std::vector<std::vector<uint8_t>> *substreams, EncodedPicture *info);     // after band_import_halo: the band's two boundary edges; hands out the substreams
   int rc_delay() const { return rc_delay_; }
   int pending() const { return (int)(accepted_ - collected_); }
+  // pictures taken from the caller / pictures whose turn to be returned has come (also when collecting one FAILED): what the C ABI pairs its queues of source and
+  // reconstruction pictures with (kvz_api.hip encoder_encode)
+  long accepted_count() const { return accepted_; }
+  long collected_count() const { return collected_; }
   // cropped reconstruction of the last coded picture -> host planes (stride = width)
   bool download_recon(uint8_t *y, uint8_t *u, uint8_t *v);
   // Where the reconstruction of the NEXT picture handed to encode_host goes (page-locked planes, width x height dense; kvz_api's pic_out): the copy is
@@ -198,6 +203,9 @@ class Encoder {
   uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; int tok_nctu_ = 0;
   size_t tok_dense_cap_ = 0;
   std::vector<std::vector<uint8_t>> band_subs_; uint64_t band_bins_ = 0; bool band_coded_ = false;   // band mode: between phase 2a and 2b
+  // me-source: k_me and k_intra_analyse<P> of the pictures ahead run on the input stream while the main stream is still in an earlier picture's chain, so what
+  // they write -- the 16x16 costs, the candidate list, the quarters' scratch, the P pictures' progress counters with the "has intra units" word -- exists per working set
+  bool me_ahead_ = false; uint32_t *me_block_[kSets] = {}; uint32_t *sync_set_[kSets] = {}; int prev_set_ = 0;
   uint32_t *sync_ = nullptr; uint32_t *me_cost16_ = nullptr; uint32_t *edge_col_ = nullptr; uint32_t *intra_order_ = nullptr; uint32_t *err_ = nullptr; unsigned long long *trace_ = nullptr;
   // one slot per picture in flight: the host-visible results of its kernels and what collect() needs to finish it
   struct EvPair { hipEvent_t a, b; KernelId id; };

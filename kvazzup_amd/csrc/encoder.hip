@@ -37,6 +37,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   if ((cfg.slices == 1 && !cfg.wpp) || (cfg.slices == 2 && cfg.tile_rows * cfg.tile_cols < 2) || (cfg.slices == 1 && cfg.tile_cols > 1) || cfg.slices < 0 || cfg.slices > 2) cfg.slices = 0;
   if (cfg.band_rows > 0) cfg.intra_in_p = 0;               // (intra-in-P runs behind the whole picture's inter reconstruction: not in band mode, where a picture is coded in parts by several instances)
   if (cfg.rc_bands > 0) cfg.qp_in_cu = 1;                  // ... and so do the steps of rate control v2
+  if (cfg.band_rows > 0) cfg.me_source = 0;                // (a band's search window reaches into the neighbouring bands' rows: the halo carries reconstruction rows, not source rows)
 
   const char *prio = getenv("KVAZZUP_AMD_PRIO"); if (!prio || strlen(prio) < 4) prio = "hnnn";   // main, tokenizer, input, decoder: the chain the next picture waits for is the urgent one (+6 % at 1080p; any explicit priority also gives the stream a hardware queue of its own)
 
@@ -183,6 +184,11 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   HIP_OK(hipEventCreateWithFlags(&in_done_, kDeviceEvent));
   HIP_OK(hipMalloc(&sync_, sizeof(uint32_t) * ((rows_ * (cw_ / 64) * 3 + 2 + 3) & ~3))); HIP_OK(hipMemset(sync_, 0, sizeof(uint32_t) * ((rows_ * (cw_ / 64) * 3 + 2 + 3) & ~3)));      // (a multiple of 16 bytes: k_picture_begin zeroes it in 16-byte pieces)       // one progress counter per CTU and colour plane, and the ticket counter of k_intra_recon's workgroups
   if (cfg.intra_in_p) { const size_t n16 = (size_t)(cw_ / 16) * (ch_ / 16); HIP_OK(hipMalloc(&me_cost16_, sizeof(uint32_t) * (n16 + 2 + n16 / 4 + n16 / 4 + (n16 / 4) * 40))); HIP_OK(hipMemset(me_cost16_, 0, sizeof(uint32_t) * (n16 + 2 + n16 / 4 + n16 / 4 + (n16 / 4) * 40))); }      // k_me's inter cost per 16x16 block (intra-in-P)
+  me_ahead_ = cfg.me_source != 0;
+  if (me_ahead_ && cfg.intra_in_p) {                       // (encoder.h me_block_: one block of these and one array of progress counters per working set)
+    const size_t n16 = (size_t)(cw_ / 16) * (ch_ / 16), nme = sizeof(uint32_t) * (n16 + 2 + n16 / 4 + n16 / 4 + (n16 / 4) * 40), nsy = sizeof(uint32_t) * ((rows_ * (cw_ / 64) * 3 + 2 + 3) & ~3);
+    for (int k = 0; k < kSets; k++) { HIP_OK(hipMalloc(&me_block_[k], nme)); HIP_OK(hipMemset(me_block_[k], 0, nme)); HIP_OK(hipMalloc(&sync_set_[k], nsy)); HIP_OK(hipMemset(sync_set_[k], 0, nsy)); }
+  }
   {
     // dispatch order of the intra reconstruction's workgroups: the CTUs of the rows this instance codes, by anti-diagonal cx + 2 cy
     const int wc = cw_ / 64, r0 = cfg.band_rows > 0 ? cfg.band_row0 : 0, nr = cfg.band_rows > 0 ? cfg.band_rows : rows_;
@@ -310,6 +316,7 @@ Encoder::~Encoder()
   if (ev_idr_done_) hipEventDestroy(ev_idr_done_);
   hipFree(intra_scratch_); hipFree(d_scaling_);
   delete entropy_; delete entropy2_;
+  for (int k = 0; k < kSets; k++) { hipFree(me_block_[k]); hipFree(sync_set_[k]); }
   hipFree(trace_); hipFree(intra_order_); hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(sync_); hipFree(me_cost16_); hipFree(edge_col_); hipFree(err_);
   stream_release(stream_, cfg_.device, 'M', prio_[0]);
 }
@@ -578,6 +585,16 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   f_.qp = qp_cur_; f_.qpc = kChromaQp[qp_cur_]; f_.lambda_q4 = kLambdaQ4[qp_cur_];
   f_.is_intra = intra; f_.poc = poc_;
   for (int c = 0; c < 3; c++) { f_.rec[c] = cfg_.sao ? work_[c] : rec_[cur_idx_][c]; f_.sao_out[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
+  // me-source: the search looks at the previous input picture (still in its working set: the set is not padded into again before kSets - 1 more pictures have
+  // gone through the input stream, behind this picture's k_me), and what the search and the intra pricing behind it write is the set's own
+  const bool ahead = me_ahead_ && !intra;
+  f_.me_ref = ahead ? src_[prev_set_][0] : f_.ref[0];
+  auto bind_me_block = [&](uint32_t *base, uint32_t *sy) {
+    const size_t n16 = (size_t)(cw_ / 16) * (ch_ / 16);
+    f_.me_cost16 = base; f_.me_cand = base ? base + n16 : nullptr; f_.sync = sy;
+    if (base) { f_.ip_arrive = f_.me_cand + 1 + n16 / 4; f_.ip_scratch = (uint64_t *)(base + ((n16 + 1 + n16 / 4 + n16 / 4 + 1) & ~(size_t)1)); }
+  };
+  if (ahead && me_block_[set_]) bind_me_block(me_block_[set_], sync_set_[set_]);
   f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err; f_.ent_cursors = sl.g_cursors;
   f_.tok_cursor = (uint32_t *)tok_count_ + (size_t)(frame_idx_ & 1) * tok_nctu_; f_.tok_cursor_next = (uint32_t *)tok_count_ + (size_t)((frame_idx_ + 1) & 1) * tok_nctu_;
   // the stream this picture's chain runs on: an intra picture's own (encoder.h stream_idr_), else the main stream -- behind the last intra picture's chain
@@ -593,6 +610,7 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     if (cfg_.sao) for (int c = 0; c < 3; c++) f_.rec[c] = work_idr_[c];
   }
   const EncFrame f = f_;
+  if (ahead && me_block_[set_]) bind_me_block(me_cost16_, sync_);      // (f_ goes back to the shared arrays: intra pictures, band mode)
   if (side) {                                               // (f_ goes back to the shared arrays for the pictures that follow)
     const size_t nctu = (size_t)(cw_ / 64) * rows_;
     f_.sync = sync_; f_.me_cand = me_cost16_ ? me_cost16_ + (size_t)(cw_ / 16) * (ch_ / 16) : nullptr;
@@ -612,19 +630,26 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     // The intra decisions need the source picture only: they run on the input stream, beside what is left of picture t - 1 on the main stream.
     timed(K_INTRA_ANALYSE, stream_in_, [&] { launch_intra_analyse(f, stream_in_); });
   }
+  if (ahead) {
+    // "uvgx search pipelining v1": the search needs the two input pictures only, the pricing of its expensive quarters as intra blocks the search and the source --
+    // both run HERE, on the input stream, beside what the main stream still has of the pictures in front (k_me 31-34 us and k_intra_analyse<P> 19-24 us at
+    // 1080p leave the chain the next picture waits for; the head of the chain, when there is one, is a launch of its own on the main stream)
+    timed(K_ME, stream_in_, [&] { launch_me(f, stream_in_); });
+    if (cfg_.intra_in_p) timed(K_INTRA_ANALYSE_P, stream_in_, [&] { launch_intra_analyse(f, stream_in_); });
+  }
   if (!stage_roi(stream_in_)) return false;
   HIP_CHECK(hipEventRecord(in_done_, stream_in_)); in_pending_ = true;
   HIP_CHECK(hipStreamWaitEvent(ms, in_done_, 0));      // (measured by leaving it out: 8 of the ~28 us between a picture's last kernel and the next one's first; the rest is the record behind k_sao that two other streams wait for)
   EncFrame fm = f;                                               // (the picture's first kernel may carry the head of the chain)
   if (intra) { const uint32_t *keep = f_.sync; f_.sync = f.sync; const bool ok = picture_begin(ms, nullptr, true); f_.sync = const_cast<uint32_t *>(keep); if (!ok) return false; }      // (f.sync: the side stream's array when the picture runs there; f_ is back on the shared one)
-  else if (!picture_begin(ms, &fm)) return false;
+  else if (!picture_begin(ms, ahead && cfg_.subme == 0 ? nullptr : &fm)) return false;      // (the search ahead on the input stream: the chain's head rides in k_subpel, or is a launch of its own without one)
   if (intra) {
     timed(K_INTRA_RECON, ms, [&] { launch_intra_recon(f, ms); });
   } else {
-    timed(K_ME, stream_, [&] { launch_me(fm, stream_); });
+    if (!ahead) timed(K_ME, stream_, [&] { launch_me(fm, stream_); });
     // intra-in-P: quarters whose inter cost is high are priced as intra blocks and may become intra units (the launch leaves at once where none is)
-    if (cfg_.intra_in_p) timed(K_INTRA_ANALYSE_P, stream_, [&] { launch_intra_analyse(f, stream_); });
-    if (cfg_.subme > 0) timed(K_SUBPEL, stream_, [&] { launch_subpel(f, stream_); });
+    if (cfg_.intra_in_p && !ahead) timed(K_INTRA_ANALYSE_P, stream_, [&] { launch_intra_analyse(f, stream_); });
+    if (cfg_.subme > 0) timed(K_SUBPEL, stream_, [&] { launch_subpel(ahead ? fm : f, stream_); });
     if (rc_state_) {
       // rate control v2: the CTU rows in groups inside the one launch, the next group's QP decided on the device from the levels of the groups before
       EncFrame fb = f;
@@ -635,7 +660,7 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     timed(K_INTER_RECON, stream_, [&] { launch_inter_recon(f, stream_); });
     // ... and are reconstructed behind every inter unit (their reference samples may lie in inter units anywhere around them)
     if (cfg_.intra_in_p) timed(K_INTRA_RECON_P, stream_, [&] { launch_intra_recon(f, stream_); });
-    if (cfg_.intra_in_p && !cfg_.deblock) { HIP_CHECK(hipMemsetAsync(f_.me_cand, 0, sizeof(uint32_t), stream_)); HIP_CHECK(hipMemsetAsync(sync_ + rows_ * (cw_ / 64) * 3 + 1, 0, sizeof(uint32_t), stream_)); }      // (k_deblock_tile does it otherwise)
+    if (cfg_.intra_in_p && !cfg_.deblock) { HIP_CHECK(hipMemsetAsync(f.me_cand, 0, sizeof(uint32_t), stream_)); HIP_CHECK(hipMemsetAsync(f.sync + rows_ * (cw_ / 64) * 3 + 1, 0, sizeof(uint32_t), stream_)); }      // (k_deblock_tile does it otherwise)
   }
   launch_qp_resolve(f, ms);                                      // per-CTU QP: which CU carries the delta, QpY for deblocking
   // levels, cbf and motion of the picture are final: the tokenizer's stream may start.  With SAO it waits for the filter anyway (the CTUs' SAO parameters
@@ -697,7 +722,7 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
     sl.write_ps = (intra_count_ == 0) || (cfg_.vps_period > 0 && (intra_count_ % cfg_.vps_period) == 0);
     intra_count_++;
   }
-  frame_idx_++;
+  frame_idx_++; prev_set_ = set_;
   ref_idx_ = cur_idx_; cur_idx_ = (cur_idx_ + 1) % nrec_;      // rec_[ref_idx_] holds the picture just submitted
   submitted_++;
   if (tok_deferred_) {
@@ -881,6 +906,7 @@ bool Encoder::band_picture_setup()
   f_.qp = qp_cur_; f_.qpc = kChromaQp[qp_cur_]; f_.lambda_q4 = kLambdaQ4[qp_cur_];
   f_.is_intra = band_intra_; f_.poc = poc_;
   for (int c = 0; c < 3; c++) { f_.rec[c] = rec_[cur_idx_][c]; f_.ref[c] = rec_[ref_idx_][c]; }
+  f_.me_ref = f_.ref[0];
   Slot &sl = slot_[0];
   f_.tok_dense = sl.d_tok_dense; f_.tok_count_out = sl.d_tok_count; f_.tok_off_out = sl.d_tok_off; f_.err_out = sl.d_err;
   f_.tok_cursor = (uint32_t *)tok_count_ + (size_t)(frame_idx_ & 1) * tok_nctu_; f_.tok_cursor_next = (uint32_t *)tok_count_ + (size_t)((frame_idx_ + 1) & 1) * tok_nctu_;

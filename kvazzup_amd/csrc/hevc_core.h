@@ -91,6 +91,7 @@ struct EncFrame {
   const uint8_t *src[3];
   uint8_t *rec[3];
   const uint8_t *ref[3];
+  const uint8_t *me_ref;    // the luma plane k_me searches: ref[0], or (me-source) the previous picture's padded source plane
   int16_t *coef[3];
   uint8_t *cu_log2, *cu_intra, *cu_flags, *cu_merge_idx, *cu_mvp_idx, *cu_intra_mode, *cu_cbf;
   int16_t *cu_mv, *cu_mvd;      // [b8][2]

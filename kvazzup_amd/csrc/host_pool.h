@@ -92,10 +92,13 @@ class OrderedPool {
   // Runs fn(0) .. fn(n - 1); returns when all have finished.
   void run(int n, const std::function<void(int)> &fn)
   {
-    while (active_.load(std::memory_order_acquire) != 0) std::this_thread::yield();   // stragglers of the previous job
-    // A helper woken for the previous job may not have counted itself into active_ yet.  The task counter is therefore made invalid first:
-    // whatever such a helper fetches before the new job is published lies beyond any total, and it is published (next_ = 0) last.
-    next_.store(1 << 30, std::memory_order_release);
+    // A helper woken for the previous job may not have counted itself into active_ yet (late helpers are expected: they start from generation 0).  The task
+    // counter is therefore made invalid FIRST and the stragglers waited for SECOND: a helper that counted itself in before the check below is waited for (what
+    // it fetched is compared with the OLD total, still in place); one that counts itself in after it can only fetch values of at least 1 << 30, beyond any
+    // total.  (The other order left a window: a helper between the check and the store fetched the old counter value -- at least the old total -- and
+    // compared it with the NEW total; a job with more tasks than that, e.g. after a resolution change, ran one of its tasks twice.)  Published (next_ = 0) last.
+    next_.store(1 << 30, std::memory_order_seq_cst);
+    while (active_.load(std::memory_order_seq_cst) != 0) std::this_thread::yield();   // stragglers of the previous job
     fn_ = &fn;
     done_.store(0, std::memory_order_relaxed);
     total_.store(n, std::memory_order_relaxed);
@@ -127,9 +130,9 @@ class OrderedPool {
   }
   void drain()
   {
-    active_.fetch_add(1, std::memory_order_acq_rel);
+    active_.fetch_add(1, std::memory_order_seq_cst);      // (seq_cst with the fetch below and run()'s store / check: either run() sees this helper or the helper sees run()'s invalid counter)
     for (;;) {
-      int r = next_.fetch_add(1, std::memory_order_acq_rel);
+      int r = next_.fetch_add(1, std::memory_order_seq_cst);
       if (r >= total_.load(std::memory_order_acquire)) break;
       (*fn_)(r);
       if (done_.fetch_add(1, std::memory_order_acq_rel) + 1 == total_.load(std::memory_order_acquire)) futex_wake_all(done_);
@@ -170,8 +173,8 @@ class CopyPool {
   void run(const std::vector<Piece> &pieces)
   {
     if (workers_.empty() || pieces.size() < 2) { for (const Piece &p : pieces) one(p); return; }
-    while (active_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();      // stragglers of the previous job
-    next_.store(1 << 30, std::memory_order_release);                                   // (as in OrderedPool::run: invalid until the new job is published)
+    next_.store(1 << 30, std::memory_order_seq_cst);                                   // (as in OrderedPool::run: the counter invalid FIRST, then the stragglers -- see there)
+    while (active_.load(std::memory_order_seq_cst) != 0) __builtin_ia32_pause();      // stragglers of the previous job
     job_ = &pieces;
     done_.store(0, std::memory_order_relaxed);
     total_.store((int)pieces.size(), std::memory_order_relaxed);
@@ -227,9 +230,9 @@ class CopyPool {
   }
   void drain()
   {
-    active_.fetch_add(1, std::memory_order_acq_rel);
+    active_.fetch_add(1, std::memory_order_seq_cst);
     for (;;) {
-      const int r = next_.fetch_add(1, std::memory_order_acq_rel);
+      const int r = next_.fetch_add(1, std::memory_order_seq_cst);
       if (r >= total_.load(std::memory_order_acquire)) break;
       one((*job_)[(size_t)r]);
       done_.fetch_add(1, std::memory_order_acq_rel);

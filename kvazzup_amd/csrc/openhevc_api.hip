@@ -123,7 +123,7 @@ int kvzx_decoder_set_parse_only(OpenHevc_Handle hh, int parse_threads)
 {
   Handle *h = H(hh);
   if (!h || h->started) return 0;
-  h->dec->set_parse_only();
+  if (!h->dec->set_parse_only()) return 0;                // (the decoder declined: it has been started)
   h->dec->set_parse_threads(parse_threads < 1 ? 1 : parse_threads);
   return 1;
 }

@@ -160,6 +160,9 @@ __global__ __launch_bounds__(512) void k_subpel(EncFrame f)
   int bx_, by_; xcd_block_2d(bx_, by_);
   const int x0 = bx_ * 32, y0 = by_ * 32 + f.row0 * 64;
   const int bi0 = b8idx(f, x0, y0);
+  // me-source: the search ran ahead on the input stream, so this launch is the first of the picture's chain and carries its head as k_me does otherwise
+  // (nothing here reads what it writes -- rate control state, the CTUs' target QPs: k_inter_recon is the first)
+  if (f.pb_on && blockIdx.x == 0 && blockIdx.y == 0) picture_begin_body(f.pb_rc, f.pb_bits3, f.pb_slot3, f.pb_have3, f.pb_qt, f.pb_roi, f.pb_nctu, f.qp, 0, tid, 512);
   if (!f.cu_mvp_idx[bi0]) return;                           // k_me's mark: the block was not searched (me-early-termination)
   // KVAZZUP_AMD_INTRA_TRACE (tools/subpel_timeline.py): eight 100 MHz stamps per block
   unsigned long long *tr = f.trace ? f.trace + (size_t)((y0 >> 5) * (f.cw >> 5) + (x0 >> 5)) * 8 : nullptr;

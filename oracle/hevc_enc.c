@@ -37,6 +37,7 @@ struct orc_encoder {
   orc_vps vps; orc_sps sps; orc_pps pps;
   orc_pic pics[2]; orc_pic *cur, *ref;
   pixel *src[3];
+  pixel *prev_src;                     /* cfg.me_source: the luma plane of the previous input picture (padded to the coded size), NULL until the option is set */
   int16_t *coef[3];
   pixel *predeblock[3];
   pixel *refpad; int refpad_stride;
@@ -168,7 +169,7 @@ void orc_enc_close(orc_encoder *e)
   if (!e) return;
   for (int i = 0; i < 2; i++) orc_pic_free(&e->pics[i]);
   for (int i = 0; i < 3; i++) { free(e->src[i]); free(e->coef[i]); free(e->predeblock[i]); }
-  free(e->refpad); free(e->sao); for (int i = 0; i < 3; i++) free(e->sao_in[i]);
+  free(e->refpad); free(e->prev_src); free(e->sao); for (int i = 0; i < 3; i++) free(e->sao_in[i]);
   free(e->cu_log2); free(e->cu_intra); free(e->cu_flags); free(e->cu_merge_idx); free(e->cu_mvp_idx);
   free(e->cu_intra_mode); free(e->cu_cbf); free(e->cu_mv); free(e->cu_mvd); free(e->bs_v); free(e->bs_h);
   free(e->im8); free(e->im16); free(e->im32); free(e->ic8); free(e->ic16); free(e->ic32);
@@ -397,11 +398,17 @@ static void encode_intra_picture(orc_encoder *e)
 }
 
 /* ------------------------------------------------------------------ inter pictures */
+/* The picture the integer search looks at: the reference picture's reconstruction, or -- "uvgx search pipelining v1", option me-source -- the previous
+ * INPUT picture: then the search of picture t + 1 depends on nothing picture t's reconstruction loop produces and the two run side by side (what hardware
+ * encoders do).  Only the search moves: early termination, the 32x32 / 16x16 costs and the intra-in-P gate are priced on that picture; fractional
+ * refinement (subme), motion compensation and everything behind them use the reconstruction as before. */
 static void build_refpad(orc_encoder *e)
 {
   int st = e->refpad_stride;
+  const pixel *plane = e->cfg.me_source && e->prev_src ? e->prev_src : e->ref->plane[0];
+  const int pstride = e->cfg.me_source && e->prev_src ? e->cw : e->ref->stride[0];
   for (int y = -ME_PAD; y < e->ch + ME_PAD; y++) {
-    const pixel *srow = e->ref->plane[0] + (size_t)orc_clip3(0, e->ch - 1, y) * e->ref->stride[0];
+    const pixel *srow = plane + (size_t)orc_clip3(0, e->ch - 1, y) * pstride;
     pixel *drow = e->refpad + (size_t)(y + ME_PAD) * st;
     for (int x = -ME_PAD; x < e->cw + ME_PAD; x++) drow[x + ME_PAD] = srow[orc_clip3(0, e->cw - 1, x)];
   }
@@ -1217,6 +1224,10 @@ size_t orc_enc_encode(orc_encoder *e, const pixel *y, const pixel *u, const pixe
   e->rc_bytes[e->frame_idx & 7] = (uint32_t)e->au.len;
   e->frame_idx++;
   orc_pic *t = e->cur; e->cur = e->ref; e->ref = t;     /* e->ref now holds the picture just coded */
+  if (e->cfg.me_source) {                               /* the next picture's search looks at this input picture */
+    if (!e->prev_src) e->prev_src = (pixel *)malloc((size_t)e->cw * e->ch);
+    memcpy(e->prev_src, e->src[0], (size_t)e->cw * e->ch);
+  }
   *au = e->au.buf;
   return e->au.len;
 }
@@ -1242,6 +1253,7 @@ int orc_enc_set_option(orc_encoder *e, const char *name, int value)
     e->cfg.bitrate = 0; e->cfg.rc_bands = 0;
     return 1;
   }
+  if (!strcmp(name, "me-source")) { e->cfg.me_source = value != 0; return 1; }      /* the integer search on the previous input picture (build_refpad) */
   if (!strcmp(name, "rdoq")) { e->cfg.rdoq = value != 0; return 1; }
   if (!strcmp(name, "signhide")) { e->cfg.signhide = value != 0; e->pps.sign_data_hiding = e->cfg.signhide; return 1; }
   return 0;

@@ -70,6 +70,8 @@ typedef struct {
   int intra_in_p;             /* 1: "uvgx intra-in-P v1" -- intra coding units in P pictures (hevc_enc.c intra_p_decide): a 16x16 quarter of a searched 32x32 block whose inter cost
                                * is above 24 lambda is priced as an intra block (the intra picture's source-based analysis) and coded intra when that is cheaper; ignored with rc_bands */
   int hash;                   /* kvazaar hash: 0 none, 1 checksum, 2 md5 -- a decoded picture hash SEI (D.2.19, suffix SEI NAL unit) after every picture's slices */
+  int me_source;              /* "uvgx search pipelining v1" (option me-source): the integer motion search looks at the previous INPUT picture instead of the
+                               * reference picture's reconstruction (build_refpad() in hevc_enc.c); prediction always uses the reconstruction */
   int lossless;               /* kvazaar lossless (uvgComm's check box, kvazaarfilter.cpp:244): every coding unit with cu_transquant_bypass_flag -- the residual IS the
                                * level array, the reconstruction is the source picture; the decisions (modes, vectors, splits) are the lossy encoder's; no deblocking, no
                                * SAO (they would leave these samples alone anyway, 8.7.2.5.7 / 8.7.3), no RDOQ, no sign hiding, no rate control */

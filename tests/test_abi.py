@@ -55,9 +55,11 @@ def test_kvz_api_table_and_config_parsing(lib):
     assert ok("preset", "medium") == 1 and cfg.contents.sao_type == 3     # presets above ultrafast: SAO full ...
     assert cfg.contents.intra_in_p == 2 and cfg.contents.rdoq_enable == 1 and cfg.contents.signhide_enable == 0      # ... intra units in P pictures, rdoq from medium on
     assert ok("intra-in-p", "0") == 1 and cfg.contents.intra_in_p == 0 and ok("intra-in-p", "1") == 1 and ok("intra-in-p", "2") == 1 and ok("intra-in-p", "3") == 0
+    assert cfg.contents.me_source == 0                                         # medium: the search on the reconstruction
     assert ok("preset", "veryfast") == 1 and cfg.contents.intra_in_p == 1      # the fast presets: 16x16 intra units only
+    assert cfg.contents.me_source == 1 and ok("me-source", "0") == 1 and cfg.contents.me_source == 0 and ok("me-source", "1") == 1 and ok("me-source", "2") == 0      # ... and the search on the input picture ("uvgx search pipelining v1")
     assert ok("sao", "off") == 1 and cfg.contents.sao_type == 0           # ... unless a later option says otherwise
-    assert ok("preset", "ultrafast") == 1 and cfg.contents.sao_type == 0 and cfg.contents.intra_in_p == 0
+    assert ok("preset", "ultrafast") == 1 and cfg.contents.sao_type == 0 and cfg.contents.intra_in_p == 0 and cfg.contents.me_source == 0
     assert ok("scaling-list", "default") == 1 and cfg.contents.scaling_list == 2 and ok("scaling-list", "off") == 1 and cfg.contents.scaling_list == 0      # uvgComm's checkbox (kvazaarfilter.cpp:235-242)
     # rejected: unknown names and values outside the implemented tool set (kvazaarfilter.cpp:363-367 logs these)
     for k, v in (("no-such-option", "1"), ("qp", "99"), ("input-res", "axb"), ("tiles", "0x2"), ("scaling-list", "custom"), ("gop", "8"), ("preset", "warp9"), ("sao", "edge")):
@@ -75,7 +77,7 @@ def test_config_parse_takes_any_string(lib):
     api = lib.kvz_api_get(8).contents
     names = ["preset", "input-res", "input-fps", "threads", "owf", "wpp", "tiles", "slices", "qp", "period", "vps-period", "rc-algorithm", "intra-bits", "gop",
              "scaling-list", "mv-constraint", "vaq", "bitrate", "sao", "deblock", "subme", "me-range", "rdoq", "signhide", "lossless", "intra-in-p", "hash", "gpu",
-             "me-early-termination", "intra-satd", "input-hold", "recon-output", "null-input", "gpu-entropy", "roi", "cqmfile", "", "x" * 300]
+             "me-early-termination", "intra-satd", "me-source", "input-hold", "recon-output", "null-input", "gpu-entropy", "roi", "cqmfile", "", "x" * 300]
     values = ["", "0", "1", "-1", "2147483647", "-2147483648", "99999999999999999999", "1e9", "0x10", "on", "off", "true", "lambda", "oba", "wpp", "tiles",
               "ultrafast", "placebo", "1920x1080", "0x0", "65536x65536", "-8x-8", "16x16", "7x7", "30/1", "1/0", "0/0", "-30/-1", "lp-g4d3t1", "8", "none", "frame",
               "frametilemargin", "full", "edge", "band", "default", "custom", "2x2", "20x22", "21x1", "1x23", "a" * 5000, "\xff\xfe"]

@@ -146,6 +146,42 @@ def test_config3_two_streams_concurrently_on_one_gpu(gpu):
 
 
 @pytest.mark.gpu
+def test_config3_eight_party_call_on_one_gpu(gpu):
+    """BASELINE configs[3] in its own shape, inside ONE process as uvgComm runs it (filtergraph.cpp:561-589: one OpenHEVCFilter per peer): eight independent
+    1080p streams, each with its own KvazaarFilter' -> WireAdapter -> OpenHEVCFilter' chain, all at once on the one GPU -- eight decoders posting to the
+    submission layer (csrc/batch.h: their pictures leave in shared launches), eight encoders on the shared streams.  Every access unit of every stream equals
+    the checker encoder's, every decoded picture its reconstruction."""
+    from kvazzup_amd.pipeline import Pipeline
+    w, h, n, K = 1920, 1080, 5, 8
+    seeds = [SEED + 16 * k for k in range(K)]
+    pls = [Pipeline(w, h, settings={"video/QP": 32, "video/Intra": 64, "video/OWF": 2, "video/OPENHEVC_threads": 2, "video/OH_parallelization": "Frame", "video/kvzThreads": 2},
+                    custom=(("me-range", 16),)) for _ in seeds]
+    clips = [[orc.synth_frame(0, s, w, h, t) for t in range(n)] for s in seeds]
+    try:
+        for t in range(n):
+            for k, pl in enumerate(pls):
+                pl.push(clips[k][t], t)
+        for pl in pls:
+            pl.flush()
+        for pl in pls:
+            assert pl.wait(n, 240000), pl.stats()
+        for k, pl in enumerate(pls):
+            oe = orc.OracleEncoder(w, h, qp=32, period=64, me_range=16)
+            try:
+                for t in range(n):
+                    au, pts = pl.pop_encoded()
+                    d = pl.pop_decoded()
+                    assert pts == t and d["pts"] == t, (k, t)
+                    assert au == oe.encode(clips[k][t]), "stream %d: access unit %d differs from the checker's" % (k, t)
+                    assert np.array_equal(d["i420"], oe.recon()), "stream %d: decoded picture %d differs from the reconstruction" % (k, t)
+            finally:
+                oe.close()
+    finally:
+        for pl in pls:
+            pl.close()
+
+
+@pytest.mark.gpu
 def test_config3_bench_command_with_two_ranks(gpu):
     """BASELINE configs[3] the way the driver runs it: `bench.py --gpus 2` (launch_ranks -> StreamRanks -> run_stream -> max over ranks), the two
     ranks sharing the test box's one GPU over gloo, four intra periods each at full rate (the processes time-slice the GPU: no wait in the intra chains may
@@ -231,7 +267,7 @@ def test_default_mode_pipelined_with_intra_pictures_on_the_side_stream(gpu, owf)
                  fields={"target_bitrate": br})
     assert not ge.rejected, ge.rejected
     oe = orc.OracleEncoder(w, h, qp=32, period=period, me_range=16, sao=1, subme=2, bitrate=br, rc_bands=4)
-    oe.set_option("intra-in-p", 1); oe.set_option("rc-delay", min(owf, 6) + 1)
+    oe.set_option("intra-in-p", 1); oe.set_option("rc-delay", min(owf, 6) + 1); oe.set_option("me-source", 1)      # (preset veryfast: the search on the input picture)
     od = orc.OracleDecoder(); gd = Decoder(threads=4, frame_threads=True)
     frames = [synth.scene_cut_frame(SEED, w, h, t, 17) for t in range(n)]
     aus = []

@@ -391,3 +391,36 @@ def test_checker_decodes_one_segment_pictures_when_dependent_segments_are_enable
         fr = od.decode_au(bytes(au), t)
         assert len(fr) == 1 and np.array_equal(fr[0]["i420"], oe.recon()), t
     oe.close(); od.close()
+
+
+@pytest.mark.parametrize("subme,sao,intra_in_p,bitrate", [(0, 0, 0, 0), (2, 1, 1, 0), (4, 0, 2, 0), (2, 1, 1, 400000)])
+def test_search_on_the_input_picture_closed_loop_and_its_rd_tolerance(subme, sao, intra_in_p, bitrate):
+    """"uvgx search pipelining v1" (orc_enc_set_option "me-source", kvazaar.h me_source): the integer search looks at the previous INPUT picture.  Every picture
+    still decodes to the encoder's reconstruction (only decisions move, prediction uses the reconstruction), the vectors do change, and the price stays inside
+    the STATED TOLERANCE: with a fractional refinement behind the search (subme >= 2: the presets that switch the option on) within +-2 % bits and 0.1 dB of the
+    search on the reconstruction; without one (the option by hand at ultrafast) within +3 % bits and 0.3 dB"""
+    w, h, n = 640, 384, 8
+    def run(on):
+        oe = orc.OracleEncoder(w, h, qp=32, period=64, me_range=16, subme=subme, sao=sao, bitrate=bitrate, rc_bands=4 if bitrate else 0)
+        oe.set_option("me-source", on); oe.set_option("intra-in-p", intra_in_p)
+        od = orc.OracleDecoder()
+        nbytes = 0; sse = 0.0; mvs = []
+        for t in range(n):
+            f = orc.synth_frame(0, 0x5EED0002, w, h, t)
+            au = oe.encode(f)
+            fr = od.decode_au(au, t)
+            assert len(fr) == 1 and np.array_equal(fr[0]["i420"], oe.recon()), (on, t)
+            mvs.append(oe.debug()["cu_mv"].copy())
+            if t:
+                nbytes += len(au); sse += float(np.mean((oe.recon()[:w * h].astype(np.float64) - f[:w * h]) ** 2))
+        oe.close(); od.close()
+        return nbytes, 10 * np.log10(255 * 255 / (sse / (n - 1))), mvs
+    b0, p0, m0 = run(0)
+    b1, p1, m1 = run(1)
+    assert np.array_equal(m0[0], m1[0]) and any(not np.array_equal(a, b) for a, b in zip(m0[1:], m1[1:]))      # the IDR is the same picture; the search does change
+    if bitrate:
+        assert abs(p1 - p0) < 0.3, (p0, p1)                            # (under rate control the bytes are the controller's business)
+    elif subme >= 2:
+        assert abs(b1 - b0) <= 0.02 * b0 and p1 > p0 - 0.1, (b0, b1, p0, p1)
+    else:
+        assert b1 <= 1.03 * b0 and p1 > p0 - 0.3, (b0, b1, p0, p1)

@@ -8,7 +8,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 w, h, owf, br = 640, 368, 6, 600000
 ge = Encoder(w, h, options=(("preset", "veryfast"), ("qp", 32), ("period", 64), ("me-range", 16), ("owf", owf), ("bitrate", br), ("rc-algorithm", "lambda")), fields={"target_bitrate": br})      # (the field is what uvgComm writes, kvazaarfilter.cpp:223)
 oe = orc.OracleEncoder(w, h, qp=32, period=64, me_range=16, sao=1, subme=2, bitrate=br, rc_bands=4)
-oe.set_option("intra-in-p", 1); oe.set_option("rc-delay", owf + 1)
+oe.set_option("intra-in-p", 1); oe.set_option("rc-delay", owf + 1); oe.set_option("me-source", 1)
 got = []
 for t in range(N + owf):
     out = ge.encode(orc.synth_frame(0 if (t // 200) % 2 == 0 else 2, 0x5EED0002 + t // 200, w, h, t) if t < N else None)

@@ -26,14 +26,7 @@ struct StreamPool {
   std::mutex m;
   std::vector<Entry> all;
   bool share;
-  // KVAZZUP_AMD_COMPACT_STREAMS=1: every shared role of a device on ONE stream (one hardware queue per process).  For a GPU that several PROCESSES keep busy
-  // at once: the scheduler firmware keeps only so many hardware queues mapped and time-slices the rest, so a process with eight queues beside three others with
-  // eight busy queues each waits for a slice at every cross-stream hop of a picture (~10 of them) -- `bench.py --gpus 2` on one GPU fell from 3 300 to 520
-  // frames/s beside short kernels on 24 foreign queues and to 46 beside long ones, the "crawl" of rounds 4-5 (profiles/r06_crawl_root_cause.txt); neighbours
-  // with ONE queue each, whatever they run, cost nothing.  Dependencies stay events recorded in enqueue order, so one stream is always a valid schedule; what
-  // is given up is the overlap between the roles.  Off by default: one process per GPU -- uvgComm's topology, and the bench's -- wants the overlap.
-  bool compact;
-  StreamPool() { const char *e = getenv("KVAZZUP_AMD_SHARE_STREAMS"); share = !(e && e[0] == '0'); const char *c = getenv("KVAZZUP_AMD_COMPACT_STREAMS"); compact = c && c[0] == '1'; }
+  StreamPool() { const char *e = getenv("KVAZZUP_AMD_SHARE_STREAMS"); share = !(e && e[0] == '0'); }
   static StreamPool &get() { static StreamPool p; return p; }
 };
 
@@ -43,7 +36,6 @@ inline hipError_t stream_acquire(hipStream_t *st, int device, char role, char le
 {
   StreamPool &p = StreamPool::get();
   const bool exclusive = !p.share || role == 'E';
-  if (p.compact && !exclusive) { role = 'M'; level = 'n'; }      // (see StreamPool::compact)
   std::lock_guard<std::mutex> l(p.m);
   for (auto &e : p.all)
     if (e.device == device && e.role == role && e.level == level && (e.users == 0 || !exclusive)) { e.users++; *st = e.st; return hipSuccess; }

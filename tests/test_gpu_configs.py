@@ -190,7 +190,8 @@ def test_config3_bench_command_with_two_ranks(gpu):
     # (Rounds 4-5 saw this command crawl at 8 - 30 frames/s beside pytest -n 3 workers and retried it.  Root cause, round 6 (tools/measure/crawl_root_cause.sh,
     # profiles/r06_crawl_root_cause.txt): hardware-queue oversubscription ACROSS PROCESSES -- beside three foreign processes with eight busy streams each the
     # two ranks fall from 3 300 to 520 frames/s (short foreign kernels) or 46 (long ones), beside the same three with ONE stream each, chain kernels or not,
-    # to nothing less; the spin-waits of the intra chains are not it.  KVAZZUP_AMD_COMPACT_STREAMS=1 / GPU_MAX_HW_QUEUES are the knobs for a shared GPU.  The
+    # to nothing less; the spin-waits of the intra chains are not it.  GPU_MAX_HW_QUEUES=2 (the HIP runtime's own knob) is what helps on a GPU shared between
+    # processes: 1 894 instead of 717 frames/s beside short foreign kernels, 444 instead of 41 beside long ones, at 22 % of the rate alone.  The
     # driver runs the suite alone: one attempt, the rate asserted.)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--repeats", "1",
                         "--no-cpu-baseline", "--no-host-boundary"], capture_output=True, text=True, timeout=600)

@@ -714,14 +714,45 @@ __global__ __launch_bounds__(1024) void k_inter_signal(EncFrame f)
 {
   const int w8 = f.cw >> 3, h8 = band_rows(f) * 8;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= w8 * h8) return;
-  const int x = (i % w8) * 8, y = (i / w8) * 8 + f.row0 * 64, g = b8idx(f, x, y);
+  const bool valid = i < w8 * h8;
+  const int x = valid ? (i % w8) * 8 : 0, y = valid ? (i / w8) * 8 + f.row0 * 64 : 0, g = b8idx(f, x, y);
   const int cl = f.cu_log2[g];
-  if (f.cu_intra[g]) return;                            // an intra unit in a P picture (intra-in-P)
-  const int n = 1 << cl;
-  const CuSignal r = decide_signalling_values(f, x & ~(n - 1), y & ~(n - 1), cl);
-  f.cu_flags[g] = (uint8_t)r.flags; f.cu_merge_idx[g] = (uint8_t)r.midx; f.cu_mvp_idx[g] = (uint8_t)r.mvp;
-  *reinterpret_cast<uint32_t *>(&f.cu_mvd[g * 2]) = ((uint32_t)r.mvdx & 0xffffu) | ((uint32_t)r.mvdy << 16);
+  const bool intra = f.cu_intra[g] != 0;                // an intra unit in a P picture (intra-in-P)
+  int flags = 0;
+  if (valid && !intra) {
+    const int n = 1 << cl;
+    const CuSignal r = decide_signalling_values(f, x & ~(n - 1), y & ~(n - 1), cl);
+    flags = r.flags;
+    f.cu_flags[g] = (uint8_t)r.flags; f.cu_merge_idx[g] = (uint8_t)r.midx; f.cu_mvp_idx[g] = (uint8_t)r.mvp;
+    *reinterpret_cast<uint32_t *>(&f.cu_mvd[g * 2]) = ((uint32_t)r.mvdx & 0xffffu) | ((uint32_t)r.mvdy << 16);
+  }
+  // The tokenizer's work list (EncFrame::tok_list): of a P picture's 4 x units (unit, role) pairs nine in ten have nothing to say -- units inside a 32x32 coding
+  // unit that starts elsewhere, colour components without residual -- and a wave each to find that out WAS k_tokenize's launch (32 640 waves at 1080p, 130 000
+  // at 2160p).  The thread at a 16x16 unit's origin knows all of it: the unit's coding unit(s), this very thread's skip decision, the cbf bits (final: the
+  // reconstruction is behind us).  Roles: 0 luma, 1 Cb, 2 Cr, 3 headers (and, for the CTU's last unit, its terminating bins).  One atomic per wave.
+  if (f.tok_list) {
+    uint32_t roles = 0;
+    if (valid && !((x | y) & 15)) {
+      const bool owner = !(cl == 5 && ((x | y) & 31));
+      if (owner || ((x & 63) == 48 && (y & 63) == 48)) roles |= 8u;
+      if (owner) {
+        uint32_t cbf = 0;
+        if (cl == 3) { cbf = f.cu_cbf[g] | f.cu_cbf[g + 1] | f.cu_cbf[g + w8] | f.cu_cbf[g + w8 + 1]; }      // four 8x8 coding units (intra units: never skipped)
+        else if (!(flags & CU_SKIP)) cbf = f.cu_cbf[g];
+        roles |= cbf & 7u;
+      }
+    }
+    const int lane = threadIdx.x & 63, nr = __builtin_popcount(roles);
+    int pre = nr;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(pre, o); if (lane >= o) pre += t; }
+    const int total = __shfl(pre, 63);
+    uint32_t base = 0;
+    if (lane == 63 && total) base = atomicAdd(&f.tok_list[0], (uint32_t)total);
+    base = (uint32_t)__shfl((int)base, 63);
+    uint32_t o = base + (uint32_t)(pre - nr);
+    const uint32_t unit = (uint32_t)((y >> 4) * (f.cw >> 4) + (x >> 4));
+    for (uint32_t m = roles; m; m &= m - 1) f.tok_list[1 + o++] = (unit << 2) | (uint32_t)__builtin_ctz(m);
+  }
 }
 
 // =============================================================================================
@@ -1796,16 +1827,14 @@ struct alignas(16) TokWave {
 // (enc_subblock_regs: sixteen exec-masked positions per pass) or in LDS (hevc_core.h enc_subblock: a dependent LDS read per significant level).  At 1080p the
 // kernel is as long as its longest wave and both help (31 -> 27.7 -> 24.2 us); at 2160p it is bound by the number of waves and of instructions, and both cost
 // (55 -> 60 -> 63 us): pictures of more than 16 384 units keep round 4's form.
-template <bool ALLC, int NW, bool HDRW = true, bool REGS = true>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(REGS ? KVZ_TOK_WAVES : 6))) void k_tokenize(EncFrame f)
+// one (unit, role) of k_tokenize on one wave.  have_tabs: the wave's tables are in LDS already (the list form: a wave's second item and later)
+template <bool ALLC, bool HDRW, bool REGS>
+__device__ __forceinline__ void tok_unit(const EncFrame &f, TokWave &W, const int ux, const int uy, const int comp, const int lane, const bool have_tabs)
 {
-  __shared__ TokWave tw[NW];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  TokWave &W = tw[wv];
   CuRec *tile = W.tile; TuDigest &dg = W.dg; CoreTabs &tabs = W.tabs; uint16_t *hdr = W.hdr, *arena = W.arena;
   int &hdr_n = W.hdr_n; uint32_t &piece_off = W.piece_off; uint32_t (&seg)[TOK_PIECES][2] = W.seg;
   // comp: 0 luma, 1 Cb, 2 Cr, 3 the headers and the CTU's terminating bins (ALLC: 0 stands for all of them)
-  const int ux = NW == 4 ? blockIdx.x * 2 + (wv & 1) : blockIdx.x, uy = NW == 4 ? (blockIdx.y + f.row0 * 2) * 2 + (wv >> 1) : blockIdx.y + f.row0 * 4, comp = ALLC ? 0 : (int)blockIdx.z, wc = f.cw >> 6, hc = f.ch >> 6;
+  const int wc = f.cw >> 6, hc = f.ch >> 6;
   const int hdr_comp = HDRW ? 3 : 0;
   const bool hdr_role = ALLC || comp == hdr_comp;
   const int cx = ux >> 2, cy = uy >> 2, ctu = cy * wc + cx;
@@ -1849,8 +1878,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(REGS ? 
     }
   }
   TOK_PH();                                                        // 1: the unit has something to say
-  for (int i = lane; i < (int)(sizeof(CoreTabs) / 4); i += 64) reinterpret_cast<uint32_t *>(&tabs)[i] = reinterpret_cast<const uint32_t *>(&g_core_tabs)[i];
-  if (lane < (int)(sizeof(TokTabs) / 16)) reinterpret_cast<uint4 *>(&W.tk)[lane] = reinterpret_cast<const uint4 *>(&g_tok_tabs)[lane];
+  if (!have_tabs) {
+    for (int i = lane; i < (int)(sizeof(CoreTabs) / 4); i += 64) reinterpret_cast<uint32_t *>(&tabs)[i] = reinterpret_cast<const uint32_t *>(&g_core_tabs)[i];
+    if (lane < (int)(sizeof(TokTabs) / 16)) reinterpret_cast<uint4 *>(&W.tk)[lane] = reinterpret_cast<const uint4 *>(&g_tok_tabs)[lane];
+  }
   if (lane < TOK_PIECES) { seg[lane][0] = 0; seg[lane][1] = 0; }
   if (lane == 0) hdr_n = 0;
   const int bx0 = ux * 2 - 1, by0 = uy * 2 - 1;
@@ -2018,6 +2049,29 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(REGS ? 
   if (tr && z4 == 15) tr[7] = wall_clock64();
   if (census && lane == 0) { atomicAdd(&census[wave_class * 2], 1ull); atomicAdd(&census[wave_class * 2 + 1], wall_clock64() - t_begin); }
 }
+// LIST (P pictures, whole pictures; round 6): the launch is a fixed number of waves that work off k_inter_signal's list of (unit, role) pairs with something to
+// say (EncFrame::tok_list) instead of a wave per pair -- the pairs that are not listed keep the zero table entries k_tok_compact leaves behind.  The kernel was
+// the time to start 32 640 waves (130 000 at 2160p) of which nine in ten left at once, plus its longest wave; now it is its longest wave.
+template <bool ALLC, int NW, bool HDRW = true, bool REGS = true, bool LIST = false>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(REGS ? (LIST ? 3 : KVZ_TOK_WAVES) : 6))) void k_tokenize(EncFrame f)      // (the list form: few waves, each with work -- the registers it wants: at five waves per SIMD the item loop spilled 23)
+{
+  __shared__ TokWave tw[NW];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  TokWave &W = tw[wv];
+  if constexpr (LIST) {
+    const uint32_t count = f.tok_list[0], uw = (uint32_t)(f.cw >> 4);
+    bool have = false;
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
+      const uint32_t v = f.tok_list[1 + it], unit = v >> 2;
+      tok_unit<ALLC, HDRW, REGS>(f, W, (int)(unit % uw), (int)(unit / uw), (int)(v & 3u), lane, have);
+      have = true;
+      wave_sync();
+    }
+  } else {
+    const int ux = NW == 4 ? blockIdx.x * 2 + (wv & 1) : blockIdx.x, uy = NW == 4 ? (blockIdx.y + f.row0 * 2) * 2 + (wv >> 1) : blockIdx.y + f.row0 * 4, comp = ALLC ? 0 : (int)blockIdx.z;
+    tok_unit<ALLC, HDRW, REGS>(f, W, ux, uy, comp, lane, false);
+  }
+}
 
 // one workgroup per CTU: the pieces of its 16 units in z-order, piece after piece -> the dense token array (CTUs in coding order)
 // (tok_count_out[ctu] < 0 tells the host that the CTU did not fit or its table was inconsistent)
@@ -2042,9 +2096,12 @@ __global__ __launch_bounds__(256) void k_tok_compact(EncFrame f)
   __syncthreads();
   const uint32_t base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
   TC_STAMP(1);
+  // the CTU's table goes to LDS and back to zero in global memory: the next picture's tokenizer may be the list form, whose waves only write the entries of
+  // the (unit, role) pairs that have something to say -- every other entry must read "no tokens"
+  uint32_t *tab = f.tok_seg + (size_t)ctu * NSEG * 2;
+  for (int i = tid; i < NSEG; i += 256) { const uint2 e = *reinterpret_cast<const uint2 *>(&tab[i * 2]); soff[i] = e.x; start[i] = e.y; *reinterpret_cast<uint2 *>(&tab[i * 2]) = make_uint2(0u, 0u); }        // start[] holds lengths for now
+  if (f.tok_list && blockIdx.x == 0 && tid == 0) f.tok_list[0] = 0;      // (the list has been worked off: k_tokenize ran before this launch on the same stream)
   if (base + n > f.tok_dense_cap) { if (tid == 0) f.tok_count_out[ctu] = -1; return; }
-  const uint32_t *tab = f.tok_seg + (size_t)ctu * NSEG * 2;
-  for (int i = tid; i < NSEG; i += 256) { soff[i] = tab[i * 2]; start[i] = tab[i * 2 + 1]; }        // start[] holds lengths for now
   __syncthreads();
   TC_STAMP(2);
   if (tid < 16) { uint32_t a = 0; for (int p = 0; p < TOK_PIECES; p++) { uint32_t l = start[tid * TOK_PIECES + p]; start[tid * TOK_PIECES + p] = a; a += l; } utot[tid] = a; }
@@ -2480,6 +2537,15 @@ void launch_tokenize(const EncFrame &f, hipStream_t st)
   // today's early exit it is the slower one there as well: 66 vs 55 us per launch at 2160p, 51 vs 31 us at 1080p, a luma wave + a chroma wave per unit 60 /
   // 35 us -- and is kept for pictures beyond that, where nothing has been measured.)
   const int units = (f.cw / 16) * band_rows(f) * 4;
+  // Measured (profiles/r06_tok_list_ab.txt, isolated): 2160p 49.1 against 56.9 us -- there the grid form is bound by the 130 000 waves it starts --, 1080p 27.4
+  // against 24.1 us: there both forms last as long as their longest wave, and the list form's is the longer one (three waves per SIMD's worth of registers).
+  // So: the list from 16 384 units on.  KVAZZUP_AMD_TOK_LIST=1 forces it everywhere (tests), =0 switches it off (A/B).
+  static const int list_mode = [] { const char *e = getenv("KVAZZUP_AMD_TOK_LIST"); return e ? atoi(e) : -1; }();
+  if (!f.is_intra && f.tok_list && f.nrows == 0 && units < 65536 && (list_mode > 0 || (list_mode < 0 && units > 16384))) {
+    // the list form: as many waves as a picture of this size usually has pairs to say something about (half the units; a busier picture's waves take several)
+    hipLaunchKernelGGL((k_tokenize<false, 1, true, true, true>), dim3(units / 2 < 256 ? 256 : units / 2), dim3(64), 0, st, f);
+    return;
+  }
   if (units >= 65536) hipLaunchKernelGGL((k_tokenize<true, 1>), dim3(f.cw / 16, band_rows(f) * 4), dim3(64), 0, st, f);
   else if (units > 16384) hipLaunchKernelGGL((k_tokenize<false, 1, false, false>), dim3(f.cw / 16, band_rows(f) * 4, 3), dim3(64), 0, st, f);     // (z: luma + headers, Cb, Cr)
   else hipLaunchKernelGGL((k_tokenize<false, 1, true>), dim3(f.cw / 16, band_rows(f) * 4, 4), dim3(64), 0, st, f);     // (z: luma, Cb, Cr, headers; tok_cursor is zero: the previous picture's k_tok_compact left it so)

@@ -200,7 +200,7 @@ class Encoder {
   void bind_set(int k);
   uint8_t *intra_scratch_ = nullptr;
   uint8_t *d_scaling_ = nullptr;          // scaling-list default: KVZ_SCALING_BYTES scaling factors
-  uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; int tok_nctu_ = 0;
+  uint16_t *tok_buf_ = nullptr; int tok_cap_ = 0; int32_t *tok_count_ = nullptr; uint32_t *tok_seg_ = nullptr; uint32_t *tok_list_ = nullptr; int tok_nctu_ = 0;
   size_t tok_dense_cap_ = 0;
   std::vector<std::vector<uint8_t>> band_subs_; uint64_t band_bins_ = 0; bool band_coded_ = false;   // band mode: between phase 2a and 2b
   // me-source: k_me and k_intra_analyse<P> of the pictures ahead run on the input stream while the main stream is still in an earlier picture's chain, so what

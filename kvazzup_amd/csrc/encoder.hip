@@ -144,6 +144,8 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   HIP_OK(hipMalloc(&tok_buf_, (size_t)nctu * tok_cap_ * sizeof(uint16_t)));
   HIP_OK(hipMalloc(&tok_count_, sizeof(uint32_t) * nctu * 2));        // two sets of cursors take turns (k_tok_compact)
   HIP_OK(hipMalloc(&tok_seg_, sizeof(uint32_t) * nctu * 16 * 17 * 2));       // [ctu][unit][piece] {offset, length}
+  HIP_OK(hipMemset(tok_seg_, 0, sizeof(uint32_t) * nctu * 16 * 17 * 2));     // (all "no tokens": the list form of k_tokenize writes only the entries that have some; k_tok_compact zeroes behind itself)
+  if (cfg.band_rows == 0) { HIP_OK(hipMalloc(&tok_list_, sizeof(uint32_t) * (1 + (size_t)nctu * 16 * 4))); HIP_OK(hipMemset(tok_list_, 0, sizeof(uint32_t) * (1 + (size_t)nctu * 16 * 4))); }      // (unit, role) pairs with something to say, P pictures (hevc_core.h EncFrame::tok_list)
   HIP_OK(hipMemset(tok_count_, 0, sizeof(uint32_t) * nctu * 2)); tok_nctu_ = nctu;
   tok_dense_cap_ = (size_t)nctu * tok_cap_;
   if (tok_dense_cap_ > ((size_t)1 << 27)) tok_dense_cap_ = (size_t)1 << 27;
@@ -228,7 +230,7 @@ bool Encoder::init(const EncoderConfig &cfg_in, std::string *error)
   uint8_t *p = intra_scratch_;
   f_.ic8 = (uint32_t *)p; p += nb8 * 4; f_.ic16 = (uint32_t *)p; p += nb8; f_.ic32 = (uint32_t *)p; p += nb8 / 4;
   f_.im8 = p; p += nb8; f_.im16 = p; p += nb8 / 4; f_.im32 = p;
-  f_.tok_buf = tok_buf_; f_.tok_cap = tok_cap_; f_.tok_cursor = (uint32_t *)tok_count_; f_.tok_cursor_next = (uint32_t *)tok_count_ + tok_nctu_; f_.tok_seg = tok_seg_;
+  f_.tok_buf = tok_buf_; f_.tok_cap = tok_cap_; f_.tok_cursor = (uint32_t *)tok_count_; f_.tok_cursor_next = (uint32_t *)tok_count_ + tok_nctu_; f_.tok_seg = tok_seg_; f_.tok_list = tok_list_;
   f_.tok_dense_cap = (uint32_t)tok_dense_cap_;
   { const size_t nctu = (size_t)(cw_ / 64) * rows_; f_.edge_col[0] = edge_col_; f_.edge_col[1] = edge_col_ + nctu * 64; f_.edge_col[2] = edge_col_ + nctu * 96;
     f_.edge_row[0] = edge_row_; f_.edge_row[1] = edge_row_ + nctu * 16; f_.edge_row[2] = edge_row_ + nctu * 24; }
@@ -317,7 +319,7 @@ Encoder::~Encoder()
   hipFree(intra_scratch_); hipFree(d_scaling_);
   delete entropy_; delete entropy2_;
   for (int k = 0; k < kSets; k++) { hipFree(me_block_[k]); hipFree(sync_set_[k]); }
-  hipFree(trace_); hipFree(intra_order_); hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(sync_); hipFree(me_cost16_); hipFree(edge_col_); hipFree(err_);
+  hipFree(trace_); hipFree(intra_order_); hipFree(tok_buf_); hipFree(tok_count_); hipFree(tok_seg_); hipFree(tok_list_); hipFree(sync_); hipFree(me_cost16_); hipFree(edge_col_); hipFree(err_);
   stream_release(stream_, cfg_.device, 'M', prio_[0]);
 }
 

@@ -101,6 +101,7 @@ struct EncFrame {
   // (tok_cursor: tokens used per slot, tok_seg: [ctu][unit][piece] {offset, length}), the
   // prefix sum of the per-CTU counts and the dense z-ordered copy the host arithmetic coder reads
   // (tok_dense / tok_count_out live in host-mapped pinned memory)
+  uint32_t *tok_list;           // P pictures (whole pictures): the (16x16 unit, role) pairs that have something to say -- [0] their count, [1 ..] unit << 2 | role; written by k_inter_signal, worked off by k_tokenize's list form, count zeroed by k_tok_compact.  NULL: every (unit, role) gets a wave
   uint16_t *tok_buf; int tok_cap; uint32_t *tok_cursor; uint32_t *tok_seg; uint32_t *tok_cursor_next;   // tok_cursor_next: the NEXT picture's cursors (two arrays take turns), zeroed by this picture's k_tok_compact
   uint16_t *tok_dense; uint32_t tok_dense_cap; int32_t *tok_count_out; uint32_t *tok_off_out; uint32_t *err_out;   // host-mapped pinned (host arithmetic coder) or, but for err_out, device memory (k_cabac_rows)
   uint32_t *ent_cursors;        // k_cabac_rows' two output cursors (NULL with the host coder): k_tok_compact zeroes them for the launch that follows

@@ -492,7 +492,13 @@ __device__ __forceinline__ void rc_group_done(const EncFrame &f, InterLds &s, in
 // the next group starts to wait -- the wait cannot starve what it waits for (the intra chains' argument).
 // LL: `lossless` (cu_transquant_bypass): the residual itself goes to the level planes, sample by sample, and the reconstruction is the source
 template <bool DEC, bool FRAC, bool ADJ = false, bool RC = false, bool LL = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || ADJ || RC) ? 5 : 8))) void k_inter_recon(EncFrame f)
+// waves per SIMD the fractional / rate-control forms are held to: 7 (72 registers, one spilled in the rate-control form) -- their 22 KB of LDS allow seven workgroups
+// per compute unit, 78 registers only six; default mode 5 450-5 530 -> 5 580-5 660 frames/s, the launch 51.3 -> 49.3 us (profiles/r06_recon_waves_ab.txt).  The forms
+// with the level-adjustment pass (ADJ: rdoq / signhide) keep 5: they spill at anything tighter.
+#ifndef KVZ_RECON_WAVES
+#define KVZ_RECON_WAVES 7
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FRAC || ADJ || RC) ? (ADJ ? 5 : KVZ_RECON_WAVES) : 8))) void k_inter_recon(EncFrame f)
 {
   __shared__ InterLds s;
   InterFracLds *fr = nullptr;

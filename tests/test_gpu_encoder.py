@@ -397,6 +397,7 @@ def test_random_tool_combinations_match_oracle(gpu, seed):
     tools = dict(intra_in_p=int(rng.integers(0, 3)), rdoq=int(rng.integers(0, 2)), signhide=int(rng.integers(0, 2)))
     cfg.update(extra)
     lossless = int(rng.integers(0, 4) == 0)          # (round 4: a quarter of the seeds with uvgComm's "lossless" box on top of whatever else they drew)
+    me_source = int(rng.integers(0, 2))               # (round 6, drawn last: half of the seeds with the search on the input picture -- k_me / k_intra_analyse<P> ahead on the input stream -- on top of whatever else they drew)
     frames = (9 if owf < 3 else 12) if cfg["bitrate"] else 5              # (the rate controller starts moving the QP behind its delay)
     oe = orc.OracleEncoder(w, h, **cfg)
     if cfg["bitrate"] and owf >= 3:
@@ -404,11 +405,12 @@ def test_random_tool_combinations_match_oracle(gpu, seed):
     oe.set_option("intra-in-p", tools["intra_in_p"]); oe.set_option("rdoq", tools["rdoq"]); oe.set_option("signhide", tools["signhide"])
     if lossless:
         oe.set_option("lossless", 1)
+    oe.set_option("me-source", me_source)
     od = orc.OracleDecoder()
     ge = Encoder(w, h, options=(("qp", cfg["qp"]), ("period", cfg["period"]), ("me-range", cfg["me_range"]), ("wpp", cfg["wpp"]),
                                 ("deblock", cfg["deblock"]), ("tiles", "%dx%d" % (cfg["tile_cols"], cfg["tile_rows"])), ("sao", "full" if cfg["sao"] else "off"),
                                 ("subme", cfg["subme"]), ("intra-in-p", tools["intra_in_p"]), ("rdoq", tools["rdoq"]), ("signhide", tools["signhide"]),
-                                ("set-qp-in-cu", cfg["qp_in_cu"]), ("owf", owf),
+                                ("set-qp-in-cu", cfg["qp_in_cu"]), ("owf", owf), ("me-source", me_source),
                                 ("mv-constraint", ("none", "frame", "frametilemargin")[cfg["mv_frame"]])) + ((("vaq", cfg["vaq"]),) if cfg["vaq"] else ()) + (("me-early-termination", "on" if cfg["me_early"] else "off"),) + ((("lossless", 1),) if lossless else ()), fields={"target_bitrate": cfg["bitrate"]})
     assert not ge.rejected, (cfg, ge.rejected)
     gd = Decoder()
@@ -433,7 +435,7 @@ def test_random_tool_combinations_match_oracle(gpu, seed):
             got.append(out)
     assert len(got) == frames, (cfg, owf, len(got))
     for t in range(frames):
-        assert got[t][0] == want[t][0], (cfg, tools, lossless, owf, t, len(got[t][0]), len(want[t][0]))
+        assert got[t][0] == want[t][0], (cfg, tools, lossless, me_source, owf, t, len(got[t][0]), len(want[t][0]))
         assert np.array_equal(got[t][1], want[t][1]), (cfg, tools, owf, t)
         dec = gd.decode_au(got[t][0], t)
         ref = od.decode_au(want[t][0], t)

@@ -128,7 +128,10 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   if (c->weighted < 0) c->weighted = 0;
   if (c->list_mod < 0) c->list_mod = 0;
   if (c->gop != 2 && c->gop != 4 && c->gop != 8) c->gop = 0;
-  const int wc = (cfg->width + 63) / 64, hc = (cfg->height + 63) / 64;
+  if (c->ctb_log2 != 4 && c->ctb_log2 != 5) c->ctb_log2 = 6;           /* (never drawn: -1 is 64, the streams of the earlier rounds stay what they were) */
+  if (c->max_cu_log2 > c->ctb_log2) c->max_cu_log2 = c->ctb_log2;
+  if (c->min_cu_log2 > c->max_cu_log2) c->min_cu_log2 = c->max_cu_log2;
+  const int ctbs = 1 << c->ctb_log2, wc = (cfg->width + ctbs - 1) / ctbs, hc = (cfg->height + ctbs - 1) / ctbs;
   if (c->tile_rows > hc) c->tile_rows = hc;
   if (c->tile_rows < 1) c->tile_rows = 1;
 
@@ -146,7 +149,7 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
     s->max_num_reorder = lg; s->max_dec_pic_buffering = c->num_refs + lg + 2;      /* (roomy: output is driven by the reorder count alone) */
     if (s->log2_max_poc_lsb < 6) s->log2_max_poc_lsb = 6;
   }
-  s->log2_min_cb = 3; s->log2_diff_max_min_cb = 3; s->log2_min_tb = 2; s->log2_diff_max_min_tb = 3;
+  s->log2_min_cb = 3; s->log2_diff_max_min_cb = c->ctb_log2 - 3; s->log2_min_tb = 2; s->log2_diff_max_min_tb = c->ctb_log2 < 5 ? c->ctb_log2 - 2 : 3;      /* (MaxTbLog2SizeY <= Min(CtbLog2SizeY, 5)) */
   s->max_th_depth_inter = c->th_depth_inter; s->max_th_depth_intra = c->th_depth_intra;
   s->amp_enabled = c->amp; s->sao_enabled = c->sao;
   s->scaling_list_enabled = c->scaling_lists > 0; s->scaling_list_data_present = c->scaling_lists == 2 || c->scaling_lists == 4;
@@ -200,9 +203,9 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   }
   if (orc_pic_alloc(&g->side, cfg->width, cfg->height)) { free(g); return NULL; }
   memset(&g->av, 0, sizeof(g->av));
-  g->av.pic_w = cfg->width; g->av.pic_h = cfg->height; g->av.ctb_log2 = 6; g->av.pic_w_ctbs = wc; g->av.ctb_tile = g->ctb_tile;
+  g->av.pic_w = cfg->width; g->av.pic_h = cfg->height; g->av.ctb_log2 = c->ctb_log2; g->av.pic_w_ctbs = wc; g->av.ctb_tile = g->ctb_tile;
   g->sao = (orc_sao_params *)calloc((size_t)wc * hc, sizeof(orc_sao_params));
-  g->log2_qg = 6 - p->diff_cu_qp_delta_depth;
+  g->log2_qg = c->ctb_log2 - p->diff_cu_qp_delta_depth;
   orc_bw_init(&g->au);
   return g;
 }
@@ -796,7 +799,7 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
           draw_sao(g, sp, left, up, sh->sao_luma, sh->sao_chroma);
           orc_sao_write(&g->c, sp, left, up, sh->sao_luma, sh->sao_chroma);
         }
-        gen_coding_quadtree(g, cx * 64, cy * 64, 6, 0);
+        gen_coding_quadtree(g, cx << s->ctb_log2, cy << s->ctb_log2, s->ctb_log2, 0);
         if (wpp && cx == x0 + 1) memcpy(saved, g->c.ctx, sizeof(saved));
         const int last = (tr == g->nrows_t - 1 && tc == cols - 1 && tile_end && cx == x1 - 1);
         const int sub_end = cx == x1 - 1 && (row_subs || tile_end);

@@ -53,6 +53,8 @@ typedef struct {
                                * weighted_bipred_flag (pred_weight_table() in every P / B slice header): what x265 writes by default (weightp) -- 0 (also -1): off */
   int list_mod;               /* probability (%) that a reference list of an inter slice is modified (ref_pic_lists_modification(): the entries of the initial list
                                * in any order, repeats allowed); > 0 sets lists_modification_present_flag -- 0 (also -1): off */
+  int ctb_log2;               /* CtbLog2SizeY: 6 (also -1 / 0: the streams of rounds 1-5), 5 or 4 -- what encoders other than Kvazaar choose (hardware encoders: 32 or 16);
+                               * MinCbLog2SizeY stays 3; max_cu_log2 is capped to it */
 } orc_gen_config;
 
 void orc_gen_default_config(orc_gen_config *c);    /* everything random, 416x240 */

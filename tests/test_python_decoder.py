@@ -251,3 +251,20 @@ def test_generator_reference_list_modification(kw, seed):
         pd.decode(au)
         seen += sum(1 for e in (pd.last_sh.get("list_entry") or []) if e)
     assert seen > 0                                                          # (the streams do modify lists)
+
+
+@pytest.mark.parametrize("ctb_log2", [5, 4])
+@pytest.mark.parametrize("seed,kw", [(3, dict(wpp=1, sao=1, intra_in_p=20, nxn_intra=1, tmvp=1, num_refs=2)),
+                                     (7, dict(wpp=0, sao=1, tile_rows=2, tile_cols=2, qp_delta=2, intra_in_p=30, tmvp=1, num_refs=3, all_part_modes=1, amp=1)),
+                                     (11, dict(b_slices=60, gop=4, tmvp=1, sao=0, deblock_mode=2, wpp=1)),
+                                     (17, dict(scaling_lists=2, tq_bypass=20, transform_skip=1, sign_hiding=1)),
+                                     (19, dict(qp_delta=4, chroma_qp_offsets=1, wpp=1, tile_rows=3))])
+def test_coding_tree_blocks_of_32_and_16_samples(ctb_log2, seed, kw):
+    """round 6: the synthesiser writes streams with CtbLog2SizeY 5 and 4 (what encoders other than Kvazaar choose: z-scan availability by CTB raster order,
+    WPP rows, SAO parameters, quantisation groups, the intra mode's above candidate and the collocated block's row all per CTB of that size) -- the two
+    independently written decoders must agree on every picture before the HIP decoder is held to either"""
+    g = orc.OracleGen(328, 200, seed=seed, ctb_log2=ctb_log2, slices=0, **kw)
+    assert g.config["ctb_log2"] == ctb_log2 and g.config["max_cu_log2"] <= ctb_log2
+    aus = [g.picture() for _ in range(5)]
+    g.close()
+    compare(aus)

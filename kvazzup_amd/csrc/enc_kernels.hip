@@ -2479,7 +2479,7 @@ void launch_intra_analyse(const EncFrame &f, hipStream_t st)
   // Measured (profiles/r05_analyse_cap.txt; 4K, pipelined, worst launch of 504): k_me 948 -> 135 us, k_tok_compact 881 -> 59, k_inter_signal 540 -> 280 with a cap of 4;
   // the search itself 156 -> 173 us at 1080p (197 at 3); the encoder alone on an all-intra stream 2 450 -> 2 750 frames/s.  KVAZZUP_AMD_ANALYSE_PER_CU=0: no cap.
   static const int per_cu = getenv("KVAZZUP_AMD_ANALYSE_PER_CU") ? atoi(getenv("KVAZZUP_AMD_ANALYSE_PER_CU")) : 4;
-  const size_t pad = per_cu > 1 && per_cu < 8 ? (size_t)(160 * 1024 / (per_cu + 1) + 1024 - 9264) & ~(size_t)255 : 0;
+  const size_t pad = per_cu > 1 && per_cu < 8 && !f.analyse_alone ? (size_t)(160 * 1024 / (per_cu + 1) + 1024 - 9264) & ~(size_t)255 : 0;
   if (f.is_intra) hipLaunchKernelGGL(k_intra_analyse<false>, dim3(f.cw / 32, band_rows(f) * 2), dim3(256), pad, st, f);
   else hipLaunchKernelGGL(k_intra_analyse<true>, dim3(512), dim3(1024), 0, st, f);       // intra-in-P, behind k_me: 512 workgroups (two per compute unit) share the candidate list, a quarter of a listed block at a time
 }

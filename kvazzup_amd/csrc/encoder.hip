@@ -603,6 +603,7 @@ bool Encoder::submit(const uint8_t *d_i420, int in_ring)
   const bool side = intra && (idr_side_ || (all_intra_alt_ && (frame_idx_ & 1)));
   const hipStream_t ms = side ? stream_idr_ : stream_;
   f_.chain_gen = next_chain_gen();
+  f_.analyse_alone = depth_ < 2 ? 1 : 0;                     // (a synchronous encoder: the cap that keeps the search from holding every wave slot protects nobody -- 185 -> 142 us of an intra picture's encoding delay at 1080p)
   f_.chain_diags = all_intra_alt_ ? 2 : 0;                  // (two pictures' chains side by side: two anti-diagonals of workgroups each -- all-intra 2 030 -> 2 110 frames/s; a lone chain is 2.5 % slower with two, 670 -> 687 us: profiles/r05_intra_diags.txt)
   if (side) {                                               // beside the P pictures still on the main stream: nothing of theirs is touched
     const size_t nctu = (size_t)(cw_ / 64) * rows_;

@@ -78,6 +78,7 @@ struct EncFrame {
   uint32_t *edge_col[3];    // k_intra_recon: per plane [CTU][S] the CTU's right column of reconstructed samples as self-validating words, sample | chain_gen << 8 (kernel_common.h IB_EDGE_R, IntraNeighbours)
   unsigned long long *edge_row[3];   // ... and per plane [CTU][S / 4] the CTU's bottom row: words of four samples | chain_gen << 32
   uint32_t chain_gen;       // generation of this launch of the intra chain (1 .. 2^24 - 1; the arrays are cleared when it wraps)
+  int analyse_alone;        // 1: nothing else is queued beside this intra picture's mode search (owf 0 / 1: one picture at a time) -- the search takes the whole chip instead of kAnalysePerCu workgroups per compute unit
   int chain_diags;          // how many anti-diagonals of workgroups k_intra_recon is launched with (0: the default, three; two when two pictures' chains run side by side)
   uint32_t *ip_arrive; uint64_t *ip_scratch;      // k_intra_analyse<P>: per listed block the number of its quarters' workgroups that are done (back to zero when the last has arrived) and their best (cost | mode << 32) per block size and position [listed block][20]
   uint32_t *me_cand;        // ... and the 32x32 blocks with a quarter above the gate: [0] their count (k_deblock_tile zeroes it for the next picture), [1 ..] their raster indices

@@ -57,21 +57,23 @@ struct TuRange { uint32_t first, count; };
 struct DecFrame {
   int w, h;                 // coded luma size (multiples of 8)
   int pw, ph;               // luma pitch and allocated rows (multiples of 64); chroma planes pw / 2 x ph / 2
-  int wc, hc;               // CTUs (64 x 64) per row / column, partial ones included
+  int wc, hc;               // 64x64 tiles of the picture per row / column, partial ones included: the grids of the region, deblocking and SAO kernels (= the CTUs of a stream with 64x64 CTBs)
+  int ctb_log2, cwc, chc;   // CtbLog2SizeY (6, 5 or 4) and the picture in CODING TREE BLOCKS: the intra chain's work units, ctu[], ctu_tile[], sao[], the edge words (round 6; cwc == wc, chc == hc at 64)
+  const uint32_t *tu_index; // CTBs smaller than 64: region[] names a run of this list of indices into tus[] (a region's blocks are no run of tus[] there); NULL: a run of tus[] itself
   int row0, nrows;          // band of CTU rows the launch works on (nrows == 0: the whole picture): tile-row split over several decoders
   const B4Rec *b4;          // [ph / 4][pw / 4]
   const B4L1 *b4x;          // [ph / 4][pw / 4] second vectors of the B4_BI blocks (weight entries of the B4_WT blocks), NULL: the picture has none
   const DecWt *wt; uint8_t wt_log2[2];      // explicit weighted prediction: 32 entries (list * 16 + index), luma / chroma denominators; NULL: default weights
   const TuRange *region;      // per 32x32 luma region (raster, pitch 2 * wc): {first transform block, count} in tus[]
-  const TuRange *ctu;        // per CTU (raster): {first transform block, count | intra-planes mask << 24}
+  const TuRange *ctu;        // per CTB (raster, pitch cwc): {first transform block, count | intra-planes mask << 24}
   const DecTu *tus; const uint32_t *lev;
   int ntu;                  // transform blocks in tus[]
   int16_t *resid[3];        // residual of the intra transform blocks up to 16x16 (k_dec_intra_resid -> k_dec_intra), plane-shaped like rec[]
-  const uint8_t *ctu_tile;  // per CTU (raster): (tile row mod 16) << 4 | (tile column mod 16) -- distinct for adjacent tiles, which is all the kernels compare
+  const uint8_t *ctu_tile;  // per CTB (raster, pitch cwc): (tile row mod 16) << 4 | (tile column mod 16) -- distinct for adjacent tiles, which is all the kernels compare
   uint8_t *rec[3];          // the picture being reconstructed (and deblocked in place)
   uint8_t *out[3];          // SAO output (== rec planes of the picture buffer when SAO runs from a work picture)
   const uint8_t *ref[KVZ_DEC_MAX_REFS][3];   // picture buffers by slot
-  const SaoParams *sao;     // per CTU; NULL = off
+  const SaoParams *sao;     // per CTB (raster, pitch cwc); NULL = off
   // k_dec_intra's hand-off between CTUs (kernel_common.h IntraNeighbours): per plane and CTU the right column / bottom row of its intra blocks as
   // self-validating words -- one sample | chain_gen << 8 per row, four samples | chain_gen << 32 per four columns -- that the neighbouring CTU's wave
   // polls until they carry this launch's generation

@@ -217,7 +217,7 @@ template <class F> __device__ __forceinline__ void dec_inter_body(const F &f, co
   }
   if (tid >= 64 && tid - 64 < ntu) {
     const int t = tid - 64;
-    DecTu d = f.tus[reg.first + t];
+    DecTu d = f.tus[f.tu_index ? f.tu_index[reg.first + t] : reg.first + t];
     if (d.flags & TU_INTRA) d.count = 0;                       // the intra kernel's business
     s.td[t] = d;
     if (d.count) {
@@ -443,8 +443,9 @@ struct DecIntraLds {
 template <class F> __device__ __forceinline__ bool dec_avail(const F &f, int xc, int yc, int xn, int yn)
 {
   if (xn < 0 || yn < 0 || xn >= f.w || yn >= f.h) return false;
-  if (f.tiles && f.ctu_tile[(yn >> 6) * f.wc + (xn >> 6)] != f.ctu_tile[(yc >> 6) * f.wc + (xc >> 6)]) return false;
-  return zaddr64(xn, yn, f.wc) <= zaddr64(xc, yc, f.wc);
+  const int l = f.ctb_log2;
+  if (f.tiles && f.ctu_tile[(yn >> l) * f.cwc + (xn >> l)] != f.ctu_tile[(yc >> l) * f.cwc + (xc >> l)]) return false;
+  return zaddr_ctb(xn, yn, f.cwc, l) <= zaddr_ctb(xc, yc, f.cwc, l);
 }
 
 // one intra transform block of plane c: N x N samples at (rx, ry) of the CTU (component samples); its borders are in s.pic
@@ -454,7 +455,7 @@ template <int L2, int T, class F>
 __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, const DecTu &d, int c, int cx, int cy, int rx, int ry, int lane, const uint32_t (&wreg)[4])
 {
   constexpr int N = XW<L2, T>::N, OPL = XW<L2, T>::OPL, G = XW<L2, T>::G;
-  const int sh = c ? 1 : 0, S = 64 >> sh, nl = N << sh, wC = f.w >> sh, hC = f.h >> sh;
+  const int sh = c ? 1 : 0, S = (1 << f.ctb_log2) >> sh, nl = N << sh, wC = f.w >> sh, hC = f.h >> sh;
   const int mode = d.mode, cidx = c ? 1 : 0;
   const bool filt = intra_filter_needed(N, cidx, mode);
   const int Xc = cx * S + rx, Yc = cy * S + ry, X = Xc << sh, Y = Yc << sh;
@@ -578,7 +579,7 @@ template <class F> __device__ __forceinline__ void dec_intra_resid_body(const F 
   __shared__ IntraWaveScratch wsv[4];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, idx = wg.id * 4 + wv;
   // (the progress counters and the ticket counter k_dec_intra starts from: this kernel runs in front of it on the same stream, a memset of their own was a launch)
-  if (wg.id == 0) for (int i = threadIdx.x; i < 3 * f.wc * f.hc + 1; i += 256) f.progress[i] = 0;
+  if (wg.id == 0) for (int i = threadIdx.x; i < 3 * f.cwc * f.chc + 1; i += 256) f.progress[i] = 0;
   if (idx >= f.ntu) return;
   const DecTu d = f.tus[idx];
   if (!(d.flags & TU_INTRA) || !d.count || d.log2 > 4) return;
@@ -664,7 +665,7 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
   // anti-diagonal order from a ticket counter -- f.progress[3 * CTUs] -- so that the chain does not park a workgroup per (CTU, plane) on the chip)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (wg.id >= wg.n) return;
-  const uint32_t nticket = 3u * (uint32_t)f.wc * (uint32_t)(f.nrows > 0 ? f.nrows : f.hc);
+  const uint32_t nticket = 3u * (uint32_t)f.cwc * (uint32_t)(f.nrows > 0 ? f.nrows : f.chc);      // (bands -- nrows > 0 -- exist for 64x64 CTBs only)
   for (int i = tid; i < 4 * 64; i += T) ((uint4 *)s.xf)[i] = ((const uint4 *)g_xf16.t)[i];      // the transforms' matrix operands: once per workgroup, not per (CTU, plane)
   if (tid == 0) lock32 = 0;
   for (bool once = true;; once = false) {
@@ -672,13 +673,13 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
   if (f.intra_direct) { if (!once) break; }
   else {
     __syncthreads();                                        // (everybody is done with the last (CTU, plane): LDS and the ticket word are free)
-    if (tid == 0) ticket_s = atomicAdd(f.progress + (size_t)3 * f.wc * f.hc, 1u);
+    if (tid == 0) ticket_s = atomicAdd(f.progress + (size_t)3 * f.cwc * f.chc, 1u);
     __syncthreads();
     ticket = ticket_s;
   }
   if (ticket >= nticket) break;
-  const int ctu = (int)f.intra_order[ticket / 3u], c = (int)(ticket % 3u), cx = ctu % f.wc, cy = ctu / f.wc;
-  const int sh = c ? 1 : 0, S = 64 >> sh, cpitch = f.pw >> sh, wC = f.w >> sh, hC = f.h >> sh;
+  const int ctu = (int)f.intra_order[ticket / 3u], c = (int)(ticket % 3u), cx = ctu % f.cwc, cy = ctu / f.cwc;
+  const int sh = c ? 1 : 0, CTB = 1 << f.ctb_log2, S = CTB >> sh, cpitch = f.pw >> sh, wC = f.w >> sh, hC = f.h >> sh;      // (the work unit is the stream's coding tree block: 64, 32 or 16 luma samples a side)
   const TuRange ct = f.ctu[ctu];
   const int count = (int)(ct.count & 0xffffffu);
   if (!((ct.count >> (24 + c)) & 1)) continue;          // no intra block of this plane in the CTU: nothing to wait for, nothing written
@@ -686,7 +687,8 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
   // the CTU as the inter kernel left it (its inter blocks are final, the intra ones get written below) -> LDS
   {
     const uint8_t *src = plane + (size_t)(cy * S) * cpitch + cx * S;
-    for (int i = tid; i < S * S / 16; i += T) { const int y = i / (S / 16), xq = i % (S / 16); *(uint4 *)&s.pic[(y + 1) * DI_P + 16 + xq * 16] = *(const uint4 *)&src[(size_t)y * cpitch + xq * 16]; }
+    if (S >= 16) for (int i = tid; i < S * S / 16; i += T) { const int y = i / (S / 16), xq = i % (S / 16); *(uint4 *)&s.pic[(y + 1) * DI_P + 16 + xq * 16] = *(const uint4 *)&src[(size_t)y * cpitch + xq * 16]; }
+    else if (tid < S) *(uint2 *)&s.pic[(tid + 1) * DI_P + 16] = *(const uint2 *)&src[(size_t)tid * cpitch];      // (the 8x8 chroma block of a 16x16 CTB)
   }
   // this plane's intra blocks, compacted in order (wave 0: one pass over the CTU's list, 64 descriptors at a time), and the items they form
   if (wave == 0) {
@@ -761,18 +763,19 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
   unsigned long long *const erow = f.edge_row[c] + (size_t)ctu * (S >> 2);
   {
     const int tile = f.ctu_tile[ctu];
-    bd.nb_left = cx > 0 && f.ctu_tile[ctu - 1] == tile; bd.nb_up = cy > 0 && f.ctu_tile[ctu - f.wc] == tile;
-    bd.nb_ur = cy > 0 && cx + 1 < f.wc && f.ctu_tile[ctu - f.wc + 1] == tile; bd.nb_ul = cy > 0 && cx > 0 && f.ctu_tile[ctu - f.wc - 1] == tile;
+    bd.nb_left = cx > 0 && f.ctu_tile[ctu - 1] == tile; bd.nb_up = cy > 0 && f.ctu_tile[ctu - f.cwc] == tile;
+    bd.nb_ur = cy > 0 && cx + 1 < f.cwc && f.ctu_tile[ctu - f.cwc + 1] == tile; bd.nb_ul = cy > 0 && cx > 0 && f.ctu_tile[ctu - f.cwc - 1] == tile;
     bd.ecol_left = ecol - S; bd.gen = f.chain_gen;
-    bd.erow_up = erow - (size_t)f.wc * (S >> 2); bd.erow_ur = bd.erow_up + (S >> 2); bd.erow_ul = bd.erow_up - (S >> 2);
+    bd.erow_up = erow - (size_t)f.cwc * (S >> 2); bd.erow_ur = bd.erow_up + (S >> 2); bd.erow_ul = bd.erow_up - (S >> 2);
     // which of the neighbours' edge units are intra units (a P picture's inter blocks are final before this kernel starts: nothing to wait
     // for there) -- lanes 0-7: the left CTU's right column, 8-15 / 16-23: the bottom rows of the upper / upper-right CTU, 24: the corner (every wave for itself)
     const int g = lane >> 3, u = lane & 7;
     int X = -1, Y = -1;
-    if (g == 0 && bd.nb_left) { X = cx * 64 - 8; Y = cy * 64 + u * 8; }
-    else if (g == 1 && bd.nb_up) { X = cx * 64 + u * 8; Y = cy * 64 - 8; }
-    else if (g == 2 && bd.nb_ur) { X = (cx + 1) * 64 + u * 8; Y = cy * 64 - 8; }
-    else if (lane == 24 && bd.nb_ul) { X = cx * 64 - 8; Y = cy * 64 - 8; }
+    const bool uin = u * 8 < CTB;                            // (a CTB of 32 / 16 samples has four / two edge units, not eight)
+    if (g == 0 && bd.nb_left && uin) { X = cx * CTB - 8; Y = cy * CTB + u * 8; }
+    else if (g == 1 && bd.nb_up && uin) { X = cx * CTB + u * 8; Y = cy * CTB - 8; }
+    else if (g == 2 && bd.nb_ur && uin) { X = (cx + 1) * CTB + u * 8; Y = cy * CTB - 8; }
+    else if (lane == 24 && bd.nb_ul) { X = cx * CTB - 8; Y = cy * CTB - 8; }
     const bool in = X >= 0 && X < f.w && Y < f.h && f.b4[(size_t)(Y >> 2) * (f.pw >> 2) + (X >> 2)].ref_idx < 0;
     const uint64_t m = __ballot(in);
     bd.il = (uint32_t)m & 0xffu; bd.iu = (uint32_t)(m >> 8) & 0xffu; bd.iur = (uint32_t)(m >> 16) & 0xffu; bd.iul = (uint32_t)(m >> 24) & 1u;
@@ -843,7 +846,8 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
   // the CTU's samples -> the picture, in whole lines (the chain stored only what neighbouring workgroups read)
   __syncthreads();
   uint8_t *gdst = plane + (size_t)(cy * S) * cpitch + cx * S;
-  for (int i = tid; i < S * S / 16; i += T) { const int y = i / (S / 16), xq = i % (S / 16); *(uint4 *)&gdst[(size_t)y * cpitch + xq * 16] = *(const uint4 *)&s.pic[(y + 1) * DI_P + 16 + xq * 16]; }
+  if (S >= 16) for (int i = tid; i < S * S / 16; i += T) { const int y = i / (S / 16), xq = i % (S / 16); *(uint4 *)&gdst[(size_t)y * cpitch + xq * 16] = *(const uint4 *)&s.pic[(y + 1) * DI_P + 16 + xq * 16]; }
+  else if (tid < S) *(uint2 *)&gdst[(size_t)tid * cpitch] = *(const uint2 *)&s.pic[(tid + 1) * DI_P + 16];
   }
 }
 
@@ -988,7 +992,7 @@ template <class F> __device__ __forceinline__ void dec_deblock_body(const F &f, 
 struct DecSaoLds {
   alignas(4) uint8_t win[66 * 72];
   alignas(4) uint8_t winc[2][34 * 40];
-  SaoParams p;
+  SaoParams p[16];                     // the parameters of the tile's coding tree blocks: one (64x64 CTBs), four (32x32) or sixteen (16x16)
 };
 __device__ __forceinline__ int dsao_edge_idx(int c, int a, int b)
 {
@@ -1018,19 +1022,29 @@ template <class F> __device__ __forceinline__ void dec_sao_body(const F &f, cons
       w[(y + 1) * pitch + 4 + x] = src[(size_t)clip3(0, phei - 1, Y0 + y) * pitch_g + clip3(0, pwid - 1, X0 + x)];
     }
   }
-  if (tid == 0) s.p = f.sao[ctu];
+  // the 64x64 tile's coding tree blocks (raster inside the tile): their parameters; blocks outside the picture never get a sample filtered
+  const int cl = f.ctb_log2, per = 64 >> cl;
+  if (tid < per * per) {
+    const int ccx = cx * per + tid % per, ccy = cy * per + tid / per;
+    if (ccx < f.cwc && ccy < f.chc) s.p[tid] = f.sao[ccy * f.cwc + ccx];
+  }
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     const int sh = c ? 1 : 0, l2n = 6 - sh, n = 1 << l2n, pitch_g = f.pw >> sh, pwid = f.w >> sh, phei = f.h >> sh, X0 = cx * n, Y0 = cy * n;
     const uint8_t *w = c ? s.winc[c - 1] : s.win; const int pitch = c ? 40 : 72;
-    const int type = s.p.type[c], e = s.p.eo_class[c], bp = s.p.band_pos[c];
+    int type = s.p[0].type[c], e = s.p[0].eo_class[c], bp = s.p[0].band_pos[c];
     int off[4];
-    for (int k = 0; k < 4; k++) off[k] = s.p.offset[c][k];
+    for (int k = 0; k < 4; k++) off[k] = s.p[0].offset[c][k];
 #pragma unroll
     for (int q = tid; q < n * n / 4; q += 256) {
       const int y = q >> (l2n - 2), x4 = (q & ((n >> 2) - 1)) * 4;
       if (Y0 + y >= phei || X0 + x4 >= pwid) continue;                          // partial CTU: outside the picture
+      if (cl != 6) {                                                            // (CTBs smaller than the tile: the four samples' own block's parameters)
+        const SaoParams &P = s.p[(((y << sh) >> cl) * per) + ((x4 << sh) >> cl)];
+        type = P.type[c]; e = P.eo_class[c]; bp = P.band_pos[c];
+        for (int k = 0; k < 4; k++) off[k] = P.offset[c][k];
+      }
       const uint32_t *row = (const uint32_t *)&w[(y + 1) * pitch + x4];
       uint32_t out = row[1];
       if (type == 1) {
@@ -1107,7 +1121,7 @@ static inline int dec_intra_wgs(const DecFrame &f)
 {
   // as many one-wave workgroups as three anti-diagonals of the CTU wavefront hold, in three planes (k_dec_intra: tickets; f.intra_order lists the band's CTUs)
   static const int diags = getenv("KVAZZUP_AMD_INTRA_DIAGS") ? atoi(getenv("KVAZZUP_AMD_INTRA_DIAGS")) : 3;      // (measurement aid; 0: a workgroup per (CTU, plane))
-  const int nr = dec_rows(f), diag = nr < (f.wc + 1) / 2 ? nr : (f.wc + 1) / 2, all = f.wc * nr * 3, want = (diags > 0 && !f.intra_direct) ? 3 * diags * diag + 32 : all;
+  const int nr = f.nrows > 0 ? f.nrows : f.chc, diag = nr < (f.cwc + 1) / 2 ? nr : (f.cwc + 1) / 2, all = f.cwc * nr * 3, want = (diags > 0 && !f.intra_direct) ? 3 * diags * diag + 32 : all;
   return want < all ? want : all;
 }
 void launch_dec_inter(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_inter, dim3(f.wc * 2, dec_rows(f) * 2), dim3(256), 0, st, f); }

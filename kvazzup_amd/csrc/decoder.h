@@ -53,6 +53,7 @@ struct DecSps {
   uint32_t fps_num = 0, fps_den = 0;
   int num_reorder = 0;                // sps_max_num_reorder_pics of the highest sub-layer: pictures that may precede a picture in decoding order and follow it in output order
   int strong_intra = 0, sao = 0, tmvp = 0, amp = 0, th_depth_inter = 0, th_depth_intra = 0;
+  int ctb_log2 = 6;                   // CtbLog2SizeY: 6 (every Kvazaar stream), 5 or 4 (round 6: other encoders' streams); MinCbLog2SizeY 3, transform blocks 4 .. min(32, CTB)
   // scaling_list_enabled_flag: the scaling factors (dec_frame.h KVZ_SCALING_BYTES) of the SPS's lists -- the default ones (Tables 7-5 / 7-6) without
   // sps_scaling_list_data; NULL: flat.  What uvgComm's "scaling list" checkbox switches on in a peer's Kvazaar (kvazaarfilter.cpp:235-242).
   std::shared_ptr<const std::vector<uint8_t>> scaling;
@@ -236,7 +237,7 @@ class Decoder {
   int ph() const { return ph_; }
 
  private:
-  bool ensure_buffers(int w, int h);
+  bool ensure_buffers(int w, int h, int ctb_log2);
   void free_buffers();
   int decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t pts);
   int hash_sei(const uint8_t *rbsp, size_t len);
@@ -250,9 +251,11 @@ class Decoder {
   // layout of the input block
   size_t off_region() const { return (size_t)(pw_ / 4) * (ph_ / 4) * sizeof(B4Rec); }
   size_t off_ctu() const { return off_region() + (size_t)(pw_ / 32) * (ph_ / 32) * sizeof(TuRange); }
-  size_t off_tile() const { return off_ctu() + (size_t)(pw_ / 64) * (ph_ / 64) * sizeof(TuRange); }
-  size_t off_sao() const { return (off_tile() + (size_t)(pw_ / 64) * (ph_ / 64) + 15) & ~(size_t)15; }
-  size_t off_scaling() const { return (off_sao() + (size_t)(pw_ / 64) * (ph_ / 64) * sizeof(SaoParams) + 63) & ~(size_t)63; }     // KVZ_SCALING_BYTES scaling factors (pictures with scaling lists)
+  // (the tables per coding tree block -- transform-block range, tile id, SAO parameters -- have one entry per CTB of the stream's size: ctbl_ = CtbLog2SizeY)
+  size_t nctb() const { return (size_t)(pw_ >> ctbl_) * (ph_ >> ctbl_); }
+  size_t off_tile() const { return off_ctu() + nctb() * sizeof(TuRange); }
+  size_t off_sao() const { return (off_tile() + nctb() + 15) & ~(size_t)15; }
+  size_t off_scaling() const { return (off_sao() + nctb() * sizeof(SaoParams) + 63) & ~(size_t)63; }     // KVZ_SCALING_BYTES scaling factors (pictures with scaling lists)
   size_t off_wt() const { return (off_scaling() + KVZ_SCALING_BYTES + 63) & ~(size_t)63; }       // 32 DecWt (pictures with pred_weight_table())
   size_t off_frame() const { return (off_wt() + 32 * sizeof(DecWt) + 63) & ~(size_t)63; }     // the picture's DecFrame, for launches that read it from device memory (batch.h)
   size_t fixed_bytes() const { return (off_frame() + sizeof(DecFrame) + 15) & ~(size_t)15; }
@@ -269,7 +272,7 @@ class Decoder {
   hipStream_t stream_up_ = nullptr; hipEvent_t up_done_[9] = {};   // upload of the next picture's input block beside the current picture's kernels
   hipStream_t stream_ = nullptr, stream_dl_ = nullptr;       // reconstruction; download of finished pictures (behind the picture's event, beside the next picture's kernels)
   std::shared_ptr<const DecSps> sps_[16]; DecPps pps_[64]; uint32_t vps_fps_num_ = 0, vps_fps_den_ = 0;
-  int w_ = 0, h_ = 0, pw_ = 0, ph_ = 0;
+  int w_ = 0, h_ = 0, pw_ = 0, ph_ = 0; int ctbl_ = 6;      // ctbl_: CtbLog2SizeY of the active sequence (the padded size stays a multiple of 64: the kernels that tile the picture do so in 64x64 / 32x32 pieces whatever the CTB)
   std::vector<PicJob> jobs_; int frame_threads_ = 1; long job_head_ = 0, job_tail_ = 0;
   // a picture arriving in several slice segment NAL units: its job is filled segment by segment and submitted with the last one
   bool asm_active_ = false, asm_guessed_one_row_ = false; int asm_subs_ = 0, asm_rows_ = 0, asm_pps_id_ = 0, asm_nal_type_ = 0; bool asm_irap_ = false;

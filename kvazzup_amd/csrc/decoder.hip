@@ -377,7 +377,7 @@ struct SliceParser {
   Decoder::PicJob &job; Decoder::SubOut &out;
   const DecSps &sps; const DecPps &pps; const Decoder::SliceHdr &sh;
   CabacDec c;
-  const int w, h, b4w, b8w, wc, hc;
+  const int w, h, b4w, b8w, ctbl, wc, hc;      // ctbl: CtbLog2SizeY; wc, hc: the picture in coding tree blocks
   B4Rec *b4; uint8_t *pm, *ctd, *im;     // pm, ctd: per 8x8 (the minimum coding block); im: per 4x4 (NxN parts)
   int ref_y0 = -(1 << 30), ref_y1 = 1 << 30;                              // band mode: the luma rows of a reference picture this decoder holds (the picture's outer edges open)
   int tile_y0 = 0, tile_y1 = 1 << 30, tile_x0 = 0, tile_x1 = 1 << 30;    // luma rows / columns of the tile being parsed: nothing outside is available (other tiles may be parsed concurrently)
@@ -389,9 +389,9 @@ struct SliceParser {
   uint32_t ctu_intra_mask = 0;
 
   SliceParser(Decoder::PicJob &j, Decoder::SubOut &o, int pw)
-      : job(j), out(o), sps(*j.sps), pps(j.pps), sh(j.sh), w(j.sps->width), h(j.sps->height), b4w(pw / 4), b8w(pw / 8), wc((j.sps->width + 63) / 64),
-        hc((j.sps->height + 63) / 64), b4(j.b4), pm(j.pred_mode.data()), ctd(j.ct_depth.data()), im(j.intra_mode.data())
-  { log2_qg = 6 - pps.qp_delta_depth; }
+      : job(j), out(o), sps(*j.sps), pps(j.pps), sh(j.sh), w(j.sps->width), h(j.sps->height), b4w(pw / 4), b8w(pw / 8), ctbl(j.sps->ctb_log2), wc((j.sps->width + (1 << j.sps->ctb_log2) - 1) >> j.sps->ctb_log2),
+        hc((j.sps->height + (1 << j.sps->ctb_log2) - 1) >> j.sps->ctb_log2), b4(j.b4), pm(j.pred_mode.data()), ctd(j.ct_depth.data()), im(j.intra_mode.data())
+  { log2_qg = ctbl - pps.qp_delta_depth; }
 
   inline int bi(int x, int y) const { return (y >> 2) * b4w + (x >> 2); }
   inline int b8(int x, int y) const { return (y >> 3) * b8w + (x >> 3); }
@@ -439,7 +439,7 @@ struct SliceParser {
   void emit_tu(const DecTu &td)
   {
     const int X = td.plane ? td.x * 2 : td.x, Y = td.plane ? td.y * 2 : td.y;
-    TuRange &r = job.region[(Y >> 5) * (2 * wc) + (X >> 5)];
+    TuRange &r = job.region[(Y >> 5) * (b4w >> 3) + (X >> 5)];      // (32x32 regions of the padded picture)
     if (!r.count) r.first = (uint32_t)out.tus.size();
     r.count++;
     out.tus.push_back(td);
@@ -473,7 +473,7 @@ struct SliceParser {
   {
     ColMotion *col = job.col.get();
     if (!col) return false;
-    const int cy = ypb >> 6;
+    const int cy = ypb >> ctbl;
     if (cy < col->hc) {                                  // the collocated picture may still be in the hands of its own parser (frame threads)
       std::atomic<uint8_t> &d = col->row_done[(size_t)cy];
       int spins = 0;
@@ -482,7 +482,7 @@ struct SliceParser {
     const int cand[2][2] = {{xpb + npbw, ypb + npbh}, {xpb + (npbw >> 1), ypb + (npbh >> 1)}};
     for (int k = 0; k < 2; k++) {
       int x = cand[k][0], y = cand[k][1];
-      if (k == 0 && !((ypb >> 6) == (y >> 6) && y < h && x < w)) continue;      // bottom right: same CTB row, inside the picture
+      if (k == 0 && !((ypb >> ctbl) == (y >> ctbl) && y < h && x < w)) continue;      // bottom right: same CTB row, inside the picture
       x >>= 4; y >>= 4;
       if (x >= col->w16 || y >= col->h16) continue;
       const ColMotion::Mv &m = col->mv[(size_t)y * col->w16 + x];
@@ -860,7 +860,7 @@ struct SliceParser {
     if (log2 <= 5 && log2 > 2 && depth < max_trafo_depth && !(intra_split && depth == 0)) split = c.bin(CTX_SPLIT_TRANSFORM + 5 - log2);
     else {
       const bool inter_split = sps.th_depth_inter == 0 && cu_pred_mode == PM_INTER && part_mode != PART_2Nx2N && depth == 0;
-      split = (log2 > 5 || (intra_split && depth == 0) || inter_split) ? 1 : 0;
+      split = (log2 > imin(5, ctbl) || (intra_split && depth == 0) || inter_split) ? 1 : 0;      // (MaxTbLog2SizeY = min(5, CtbLog2SizeY): checked against the SPS)
     }
     int cbf_cb = 0, cbf_cr = 0;
     if (log2 > 2) {
@@ -933,7 +933,7 @@ struct SliceParser {
             const int xp = x0 + i * pb, yp = y0 + j * pb;
             int ca = 1, cb = 1;                                   // 8.4.2 candidate modes
             if (avail(xp, yp, xp - 1, yp) && pm[b8(xp - 1, yp)] == PM_INTRA) ca = im[bi(xp - 1, yp)];
-            if (avail(xp, yp, xp, yp - 1) && pm[b8(xp, yp - 1)] == PM_INTRA && (yp - 1) >= ((yp >> 6) << 6)) cb = im[bi(xp, yp - 1)];
+            if (avail(xp, yp, xp, yp - 1) && pm[b8(xp, yp - 1)] == PM_INTRA && (yp - 1) >= ((yp >> ctbl) << ctbl)) cb = im[bi(xp, yp - 1)];
             int cand[3];
             if (ca == cb) {
               if (ca < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
@@ -1007,8 +1007,8 @@ struct SliceParser {
     if (pps.cu_qp_delta && log2cb >= log2_qg) {            // a quantisation group starts here (7.3.8.4, 8.6.1)
       qp_delta_coded = false; cu_qp_delta_val = 0;
       int qa = last_qp_y, qb = last_qp_y;
-      if (avail(x0, y0, x0 - 1, y0) && ((x0 - 1) >> 6) == (x0 >> 6)) qa = b4[bi(x0 - 1, y0)].qp_y;
-      if (avail(x0, y0, x0, y0 - 1) && ((y0 - 1) >> 6) == (y0 >> 6)) qb = b4[bi(x0, y0 - 1)].qp_y;
+      if (avail(x0, y0, x0 - 1, y0) && ((x0 - 1) >> ctbl) == (x0 >> ctbl)) qa = b4[bi(x0 - 1, y0)].qp_y;
+      if (avail(x0, y0, x0, y0 - 1) && ((y0 - 1) >> ctbl) == (y0 >> ctbl)) qb = b4[bi(x0, y0 - 1)].qp_y;
       qp_y_pred = (qa + qb + 1) >> 1;
     }
     if (split) {
@@ -1163,9 +1163,9 @@ bool Decoder::grow_job_input(PicJob &job, size_t bytes)
   return true;
 }
 
-bool Decoder::ensure_buffers(int w, int h)
+bool Decoder::ensure_buffers(int w, int h, int ctb_log2)
 {
-  if (w == w_ && h == h_) return true;
+  if (w == w_ && h == h_ && ctb_log2 == ctbl_) return true;
   // Resolution change (a new SPS took effect at this IRAP picture): what the ring still holds is completed now and queued -- the
   // following calls hand it out one picture at a time, as a software decoder's bumping process would -- before the buffers go
   while (!parse_only_ && w_ && (!gpu_q_.empty() || job_tail_ != job_head_)) {      // (a band decoder's picture between its reconstruction and band_finish -- gpu_job_ -- is not finish_oldest's to complete: drop_pending below lets it go)
@@ -1177,7 +1177,7 @@ bool Decoder::ensure_buffers(int w, int h)
     for (auto &j : jobs_) { free(j.h_in); j.h_in = nullptr; j.h_in_cap = 0; }
     if (jobs_.empty()) jobs_ = std::vector<PicJob>(3);
     gpu_depth_ = 1;
-    w_ = w; h_ = h; pw_ = (w + 63) & ~63; ph_ = (h + 63) & ~63;
+    w_ = w; h_ = h; pw_ = (w + 63) & ~63; ph_ = (h + 63) & ~63; ctbl_ = ctb_log2;
     const size_t nb4 = (size_t)pw_ * ph_ / 16;
     for (auto &j : jobs_) {
       if (!grow_job_input(j, fixed_bytes() + (1 << 16))) return false;
@@ -1199,7 +1199,7 @@ bool Decoder::ensure_buffers(int w, int h)
     if (gpu_depth_ < 1 || band_nrows_ > 0) gpu_depth_ = 1;
     jobs_ = std::vector<PicJob>((size_t)frame_threads_ + 2);   // the pictures being parsed and queued on the GPU (frame_threads_ of them), the one being handed out, the one being filled
   }
-  w_ = w; h_ = h; pw_ = (w + 63) & ~63; ph_ = (h + 63) & ~63;
+  w_ = w; h_ = h; pw_ = (w + 63) & ~63; ph_ = (h + 63) & ~63; ctbl_ = ctb_log2;
   const size_t npx = (size_t)pw_ * ph_, nb4 = npx / 16;
   for (auto &j : jobs_) {
     if (!grow_job_input(j, fixed_bytes() + (1 << 16))) return false;
@@ -1208,13 +1208,13 @@ bool Decoder::ensure_buffers(int w, int h)
   }
   h_out_cap_ = npx * 3 / 2;                              // (allocated by the first picture that is downloaded)
   for (int i = 0; i <= gpu_depth_; i++) { d_in_cap_[i] = fixed_bytes() + (1 << 20); HIP_TRY(hipMalloc(&d_in_[i], d_in_cap_[i])); }
-  HIP_TRY(hipMalloc(&progress_, sizeof(uint32_t) * (3 * (size_t)(pw_ / 64) * (ph_ / 64) + 1)));
-  { const size_t nctu = (size_t)(pw_ / 64) * (ph_ / 64);          // tagged words: generation 0 = never written
-    HIP_TRY(hipMalloc(&edge_col_, nctu * 128 * sizeof(uint32_t))); HIP_TRY(hipMemset(edge_col_, 0, nctu * 128 * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&edge_row_, nctu * 32 * 8)); HIP_TRY(hipMemset(edge_row_, 0, nctu * 32 * 8)); chain_gen_ = 0; }      // the CTUs' right columns (k_dec_intra)      // (+ k_dec_intra's ticket counter)
+  HIP_TRY(hipMalloc(&progress_, sizeof(uint32_t) * (3 * nctb() + 1)));
+  { const size_t ec = nctb() * (size_t)(2 << ctbl_), er = nctb() * (size_t)(2 << ctbl_) / 4;          // per CTB of S luma samples a side: S + 2 x S / 2 column words, a quarter as many row words; tagged words: generation 0 = never written
+    HIP_TRY(hipMalloc(&edge_col_, ec * sizeof(uint32_t))); HIP_TRY(hipMemset(edge_col_, 0, ec * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&edge_row_, er * 8)); HIP_TRY(hipMemset(edge_row_, 0, er * 8)); chain_gen_ = 0; }      // the CTUs' right columns (k_dec_intra)      // (+ k_dec_intra's ticket counter)
   {
     // dispatch order of k_dec_intra's workgroups: CTUs by anti-diagonal cx + 2 cy (every CTU a block depends on comes earlier)
-    const int wc = pw_ / 64, hc = ph_ / 64;
+    const int wc = (w_ + (1 << ctbl_) - 1) >> ctbl_, hc = (h_ + (1 << ctbl_) - 1) >> ctbl_;      // (the picture's coding tree blocks -- with CTBs smaller than 64 fewer than the padded size holds)
     std::vector<uint32_t> order;
     const int r0 = band_nrows_ > 0 ? band_row0_ : 0, nr = band_nrows_ > 0 ? band_nrows_ : hc;      // (band mode: this decoder's CTU rows)
     if (r0 < 0 || r0 + nr > hc) return false;
@@ -1265,7 +1265,7 @@ bool Decoder::ensure_alt()
   if (stream_alt_) return true;
   if (alt_failed_) return false;                             // (it did not fit once: the intra-only pictures keep to the one chain instead of trying again for every picture)
   if (hipSetDevice(device_) != hipSuccess) return false;
-  const size_t nctu = (size_t)(pw_ / 64) * (ph_ / 64), npx = (size_t)pw_ * ph_;
+  const size_t nctu = nctb(), ecw = nctu * (size_t)(2 << ctbl_), npx = (size_t)pw_ * ph_;
   // the second chain's priority level = its pool of hardware queues: the LOWEST level, where nothing else of this library lives (measured, all-intra 1080p with
   // the encoder's second chain at the main stream's level: second decoder chain at the default level 1 563 frames/s -- the level's four queues are taken by
   // tokenizer, input, decoder and transfers --, at the high level 1 681, at the low one 1 724; one chain each side: 1 279)
@@ -1279,8 +1279,8 @@ bool Decoder::ensure_alt()
     // (cleared ON the stream that is about to use them: the decoder's streams are non-blocking, a clear on the null stream is ordered with nothing -- the first
     // picture of the second chain had its hand-off words zeroed under its hands, every wait in it gave up: error flags 3, found by the serial suite)
     HIP_TRY(hipMalloc(&prog, sizeof(uint32_t) * (3 * nctu + 1))); HIP_TRY(hipMemsetAsync(prog, 0, sizeof(uint32_t) * (3 * nctu + 1), st));
-    HIP_TRY(hipMalloc(&ecol, nctu * 128 * sizeof(uint32_t))); HIP_TRY(hipMemsetAsync(ecol, 0, nctu * 128 * sizeof(uint32_t), st));
-    HIP_TRY(hipMalloc(&erow, nctu * 32 * 8)); HIP_TRY(hipMemsetAsync(erow, 0, nctu * 32 * 8, st));
+    HIP_TRY(hipMalloc(&ecol, ecw * sizeof(uint32_t))); HIP_TRY(hipMemsetAsync(ecol, 0, ecw * sizeof(uint32_t), st));
+    HIP_TRY(hipMalloc(&erow, ecw / 4 * 8)); HIP_TRY(hipMemsetAsync(erow, 0, ecw / 4 * 8, st));
     for (int c = 0; c < 3; c++) { HIP_TRY(hipMalloc(&res[c], sizeof(int16_t) * (c ? npx / 4 : npx))); HIP_TRY(hipMalloc(&wrk[c], c ? npx / 4 : npx)); }
     return true;
   };
@@ -1549,9 +1549,10 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     }
     s.amp = r.get(1); s.sao = r.get(1); int pcm = r.get(1);
     if (r.err) return last_error_ = DEC_ERR_INVALID;
-    // coding geometry: CTB 64, coding blocks 8..64, transform blocks 4..32 -- what Kvazaar always writes
-    if (pcm || log2_min_cb != 3 || diff_cb != 3 || log2_min_tb != 2 || diff_tb != 3 || s.th_depth_inter > 4 || s.th_depth_intra > 4)
+    // coding geometry: CTB 64 (what Kvazaar always writes), 32 or 16 (round 6: other encoders); coding blocks from 8, transform blocks 4 .. min(32, CTB)
+    if (pcm || log2_min_cb != 3 || diff_cb < 1 || diff_cb > 3 || log2_min_tb != 2 || diff_tb != imin(3, diff_cb + 1) || s.th_depth_inter > 4 || s.th_depth_intra > 4)
       return last_error_ = DEC_ERR_UNSUPPORTED;
+    s.ctb_log2 = 3 + diff_cb;
     s.num_st_rps = r.ue();
     if (s.num_st_rps > 64) return last_error_ = DEC_ERR_INVALID;
     for (int k = 0; k < s.num_st_rps; k++) if (!parse_st_rps(r, k, s.num_st_rps, s.st_rps, s.st_rps[k])) return last_error_ = DEC_ERR_INVALID;
@@ -1686,7 +1687,7 @@ int Decoder::close_open_picture()
   if (!asm_active_) return 0;
   asm_active_ = false;
   PicJob &old = jobs_[(size_t)(job_head_ % jobs_.size())];
-  const int old_hc = (h_ + 63) / 64;
+  const int old_hc = (h_ + (1 << ctbl_) - 1) >> ctbl_;
   if (asm_guessed_one_row_ && asm_rows_ == 1 && old_hc > 1) {
     asm_guessed_one_row_ = false;
     old.seg_end_row[0] = 0; old.seg_end_row[(size_t)(old_hc - 1)] = 1;
@@ -1716,7 +1717,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   const DecPps &p = pps_[pps_id]; const std::shared_ptr<const DecSps> sps_ref = sps_[p.sps_id]; const DecSps &s = *sps_ref;
   bool dependent = false; int seg_address = 0;
   if (!first_seg) {
-    const int nctb = ((s.width + 63) / 64) * ((s.height + 63) / 64);
+    const int ctbs = 1 << s.ctb_log2, nctb = ((s.width + ctbs - 1) >> s.ctb_log2) * ((s.height + ctbs - 1) >> s.ctb_log2);
     int bits = 0; while ((1 << bits) < nctb) bits++;
     if (p.dependent_slices) dependent = r.get(1) != 0;
     seg_address = r.get(bits);
@@ -1730,7 +1731,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   if (dependent && open_job->pps.tile_cols > 1) { asm_active_ = false; return DEC_ERR_UNSUPPORTED; }     // (with tile columns: whole pictures or slices of whole tiles)
   if (dependent) {
     // 7.3.6.1: everything but the address and the entry points is taken over from the slice's first segment
-    const int wc = (s.width + 63) / 64, hc = (s.height + 63) / 64;
+    const int wc = (s.width + (1 << s.ctb_log2) - 1) >> s.ctb_log2, hc = (s.height + (1 << s.ctb_log2) - 1) >> s.ctb_log2;
     return append_segment(*open_job, r.pos, rbsp, len, p, open_job->pps, wc, hc, seg_address, pts);
   }
   for (int k = 0; k < p.extra_header_bits; k++) r.get(1);
@@ -1826,7 +1827,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   }
   bool across_slices = p.loop_filter_across_slices != 0;
   if (p.loop_filter_across_slices && (!sh.deblock_disabled || sh.sao_luma || sh.sao_chroma)) across_slices = r.get(1) != 0;
-  const int wc = (s.width + 63) / 64, hc = (s.height + 63) / 64;
+  const int wc = (s.width + (1 << s.ctb_log2) - 1) >> s.ctb_log2, hc = (s.height + (1 << s.ctb_log2) - 1) >> s.ctb_log2;      // the picture in coding tree blocks
   if (p.tile_rows > hc) return DEC_ERR_INVALID;
   DecPps pp = p;                                                 // tile row boundaries (6.5.1) for this picture size
   pp.row_bd[0] = 0;
@@ -1856,7 +1857,8 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     return append_segment(*open_job, r.pos, rbsp, len, p, pp, wc, hc, seg_address, pts);
   }
   if (!sh.is_intra && !seen_irap_) return DEC_ERR_INVALID;       // nothing to predict from before the first random access point
-  if (!ensure_buffers(s.width, s.height)) return DEC_ERR_GPU;
+  if (band_nrows_ > 0 && s.ctb_log2 != 6) return DEC_ERR_UNSUPPORTED;      // (the tile-row split hands over bands of 64-sample rows)
+  if (!ensure_buffers(s.width, s.height, s.ctb_log2)) return DEC_ERR_GPU;
   // ---- reference picture set (8.3.2) and RefPicList0 (8.3.4): pictures not in the set stop being references
   if (idr) for (auto &d : dpb_) d.is_ref = false;
   int nref = 0, ref_poc[16]; uint8_t ref_slot[16];
@@ -2294,7 +2296,7 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
     c.load_ctx(&job.wpp_saved[((size_t)(first_cy - 1) * cols + g.tc) * CTX_COUNT]);
   }
   sp.last_qp_y = sh.slice_qp;                          // qPY_PREV at the start of a slice, a tile, a CTB row with WPP (8.6.1)
-  sp.tile_y0 = g.tile_cy0 * 64; sp.tile_y1 = g.tile_cy1 * 64; sp.tile_x0 = cx0 * 64; sp.tile_x1 = cx1 * 64;
+  sp.tile_y0 = g.tile_cy0 << ctbl_; sp.tile_y1 = g.tile_cy1 << ctbl_; sp.tile_x0 = cx0 << ctbl_; sp.tile_x1 = cx1 << ctbl_;
   if (band_nrows_ > 0) {
     if (band_row0_ > 0) sp.ref_y0 = band_row0_ * 64 - 4;
     if (band_row0_ + band_nrows_ < (h_ + 63) / 64) sp.ref_y1 = (band_row0_ + band_nrows_) * 64;
@@ -2318,7 +2320,7 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
         const SaoParams *left = cx > cx0 ? s - 1 : nullptr, *up = (cy > 0 && !tile_starts_at(cy)) ? s - wc : nullptr;
         parse_sao(c, *s, left, up, sh.sao_luma != 0, sh.sao_chroma != 0);
       }
-      sp.coding_quadtree(cx * 64, cy * 64, 6, 0);
+      sp.coding_quadtree(cx << ctbl_, cy << ctbl_, ctbl_, 0);
       if (sp.err) return sp.err;
       if (c.overrun()) return DEC_ERR_INVALID;
       job.ctu[ctu].first = tu0;
@@ -2335,14 +2337,15 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
     }
     if (job.early_dst) {
       // the row's 4x4 records are final (a coding unit writes inside its own CTU only): up they go, from whichever thread parsed the row
-      const size_t rowb = (size_t)16 * (pw_ / 4) * sizeof(B4Rec), off = (size_t)cy * rowb;
+      const size_t rowb = (size_t)(4 << (ctbl_ - 4)) * (pw_ / 4) * sizeof(B4Rec), off = (size_t)cy * rowb;      // (a CTB row: CTB / 4 rows of records)
       if (hipSetDevice(device_) == hipSuccess && hipMemcpyAsync(job.early_dst + off, job.h_in + off, rowb, hipMemcpyHostToDevice, stream_up_) == hipSuccess)
         job.early_rows.fetch_add(1, std::memory_order_acq_rel);
     }
     // this CTB row's motion (the tile's columns of it) as later pictures see it (one entry per 16x16 block)
     if (!own) continue;
-    for (int y16 = cy * 4; y16 < cy * 4 + 4 && y16 < own->h16; y16++)
-      for (int x16 = cx0 * 4; x16 < cx1 * 4 && x16 < own->w16; x16++) {
+    const int per16 = 1 << (ctbl_ - 4);                     // 16x16 blocks a CTB is wide
+    for (int y16 = cy * per16; y16 < (cy + 1) * per16 && y16 < own->h16; y16++)
+      for (int x16 = cx0 * per16; x16 < cx1 * per16 && x16 < own->w16; x16++) {
         const size_t i4 = (size_t)(y16 * 4) * (pw_ / 4) + x16 * 4;
         const B4Rec &m = job.b4[i4];
         ColMotion::Mv &o = own->mv[(size_t)y16 * own->w16 + x16];
@@ -2361,7 +2364,7 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
 int Decoder::parse_job(PicJob &job, bool row_parallel)
 {
   const uint8_t *data = job.rbsp.data() + job.data_off; const size_t len = job.data_len;
-  const int wc = (w_ + 63) / 64, hc = (h_ + 63) / 64, nsub = (int)job.geom.size(), cols = job.pps.tile_cols;
+  const int wc = (w_ + (1 << ctbl_) - 1) >> ctbl_, hc = (h_ + (1 << ctbl_) - 1) >> ctbl_, nsub = (int)job.geom.size(), cols = job.pps.tile_cols;
   auto release_all = [&] { if (job.own) for (int r = 0; r < hc; r++) job.own->row_done[(size_t)r].store(1, std::memory_order_release); };   // never leave a later picture's parser waiting
   if ((int)job.sub_start.size() != nsub) { release_all(); return DEC_ERR_INVALID; }
   for (int r = 0; r < nsub; r++) if (job.sub_start[(size_t)r] >= len) { release_all(); return DEC_ERR_INVALID; }
@@ -2371,7 +2374,7 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
   if (!job.row_progress || job.row_progress_n < hc * cols) { job.row_progress.reset(new Progress[(size_t)hc * cols]); job.row_progress_n = hc * cols; }
   for (int r = 0; r < hc * cols; r++) job.row_progress[(size_t)r].v.store(0, std::memory_order_relaxed);
   memset(job.region, 0, (size_t)(pw_ / 32) * (ph_ / 32) * sizeof(TuRange));
-  memset(job.ctu, 0, (size_t)(pw_ / 64) * (ph_ / 64) * sizeof(TuRange));
+  memset(job.ctu, 0, nctb() * sizeof(TuRange));
   memset(job.pred_mode.data(), PM_NONE, job.pred_mode.size());
   auto one = [&](int r) {
     if (band_nrows_ > 0 && (job.geom[(size_t)r].cy0 < band_row0_ || job.geom[(size_t)r].cy1 > band_row0_ + band_nrows_)) { job.subs[(size_t)r].rc = 0; return; }   // another decoder's rows
@@ -2400,7 +2403,10 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
   // (a picture with bi-predicted blocks: their second vectors ride behind the level words)
   const bool bi = (job.sh.is_b || job.sh.weighted) && job.any_bi.load(std::memory_order_relaxed) != 0;
   const size_t x_off = (lev_off + nlev * sizeof(uint32_t) + 15) & ~(size_t)15, x_bytes = bi ? job.b4x.size() * sizeof(B4L1) : 0;
-  if (!grow_job_input(job, x_off + x_bytes)) return DEC_ERR_GPU;
+  // CTBs smaller than 64: a 32x32 region's transform blocks are no run of the list any more (CTB 16: four CTBs of two CTB rows, i.e. of two substreams) -- the
+  // regions get a list of INDICES into it, behind everything else in the block (DecFrame::tu_index)
+  const size_t i_off = (x_off + x_bytes + 15) & ~(size_t)15, i_bytes = ctbl_ < 6 ? ntu * sizeof(uint32_t) : 0;
+  if (!grow_job_input(job, i_off + i_bytes)) return DEC_ERR_GPU;
   if (bi) memcpy(job.h_in + x_off, job.b4x.data(), x_bytes);
   DecTu *tus = (DecTu *)(job.h_in + tu_off); uint32_t *lev = (uint32_t *)(job.h_in + lev_off);
   size_t t = 0, l = 0;
@@ -2410,12 +2416,22 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
     if (t) {
       for (int cy = cy0; cy < cy1; cy++) {
         for (int cx = cx0; cx < cx1; cx++) if (job.ctu[cy * wc + cx].count & 0xffffffu) job.ctu[cy * wc + cx].first += (uint32_t)t;
-        for (int ry = 2 * cy; ry < 2 * cy + 2; ry++) for (int rx = 2 * cx0; rx < 2 * cx1; rx++) { TuRange &g = job.region[ry * 2 * wc + rx]; if (g.count) g.first += (uint32_t)t; }
+        if (ctbl_ == 6) for (int ry = 2 * cy; ry < 2 * cy + 2; ry++) for (int rx = 2 * cx0; rx < 2 * cx1; rx++) { TuRange &g = job.region[ry * 2 * wc + rx]; if (g.count) g.first += (uint32_t)t; }
       }
     }
     for (DecTu td : so.tus) { td.offset += (uint32_t)l; tus[t++] = td; }
     if (!so.levels.empty()) memcpy(lev + l, so.levels.data(), so.levels.size() * sizeof(uint32_t));
     l += so.levels.size();
+  }
+  if (ctbl_ < 6) {
+    const int rw = pw_ >> 5, nreg = rw * (ph_ >> 5);
+    auto region_of = [&](const DecTu &d) { const int X = d.plane ? d.x * 2 : d.x, Y = d.plane ? d.y * 2 : d.y; return (Y >> 5) * rw + (X >> 5); };
+    for (int g = 0; g < nreg; g++) { job.region[g].first = 0; job.region[g].count = 0; }
+    for (size_t k = 0; k < ntu; k++) job.region[region_of(tus[k])].count++;
+    uint32_t at = 0;
+    for (int g = 0; g < nreg; g++) { job.region[g].first = at; at += job.region[g].count; job.region[g].count = 0; }
+    uint32_t *idx = (uint32_t *)(job.h_in + i_off);
+    for (size_t k = 0; k < ntu; k++) { TuRange &g = job.region[region_of(tus[k])]; idx[g.first + g.count++] = (uint32_t)k; }      // (list order = decoding order inside a region)
   }
   job.ntu = ntu; job.nlev = nlev;
   return 0;
@@ -2429,7 +2445,8 @@ int Decoder::launch_gpu(PicJob &job)
   const size_t tu_off = fixed_bytes(), lev_off = (tu_off + ntu * sizeof(DecTu) + 15) & ~(size_t)15;
   const bool bi = (job.sh.is_b || job.sh.weighted) && job.any_bi.load(std::memory_order_relaxed) != 0;
   const size_t x_off = (lev_off + nlev * sizeof(uint32_t) + 15) & ~(size_t)15;
-  const size_t bytes = bi ? x_off + job.b4x.size() * sizeof(B4L1) : lev_off + nlev * sizeof(uint32_t);
+  const size_t i_off = (x_off + (bi ? job.b4x.size() * sizeof(B4L1) : 0) + 15) & ~(size_t)15;      // (parse_job: the regions' index list of a stream with CTBs smaller than 64)
+  const size_t bytes = ctbl_ < 6 ? i_off + ntu * sizeof(uint32_t) : (bi ? x_off + job.b4x.size() * sizeof(B4L1) : lev_off + nlev * sizeof(uint32_t));
   prof_now_ = profiling_ && (launched_ % prof_every_) == 0;
   timed_job_ = &job; job.ev_used = 0;
   if (!job.done && hipEventCreateWithFlags(&job.done, hipEventDisableTiming) != hipSuccess) return DEC_ERR_GPU;
@@ -2446,7 +2463,9 @@ int Decoder::launch_gpu(PicJob &job)
     if (hipMalloc(&d_in_, d_in_cap_[ib]) != hipSuccess) { d_in_ = nullptr; d_in_cap_[ib] = 0; return DEC_ERR_GPU; }
   }
   DecFrame f; memset(&f, 0, sizeof(f));
-  f.w = w_; f.h = h_; f.pw = pw_; f.ph = ph_; f.wc = (w_ + 63) / 64; f.hc = (h_ + 63) / 64;
+  f.w = w_; f.h = h_; f.pw = pw_; f.ph = ph_; f.wc = (w_ + 63) / 64; f.hc = (h_ + 63) / 64;      // (wc, hc: the picture in 64x64 tiles -- what the region, deblocking and SAO grids are made of)
+  f.ctb_log2 = ctbl_; f.cwc = (w_ + (1 << ctbl_) - 1) >> ctbl_; f.chc = (h_ + (1 << ctbl_) - 1) >> ctbl_;      // ... and in coding tree blocks: the intra chain's work units, the tile ids, the SAO parameters
+  f.tu_index = ctbl_ < 6 ? (const uint32_t *)(d_in_ + i_off) : nullptr;
   f.b4 = (const B4Rec *)d_in_; f.b4x = bi ? (const B4L1 *)(d_in_ + x_off) : nullptr; f.region = (const TuRange *)(d_in_ + off_region()); f.ctu = (const TuRange *)(d_in_ + off_ctu());
   f.ctu_tile = d_in_ + off_tile(); f.tus = (const DecTu *)(d_in_ + tu_off); f.lev = (const uint32_t *)(d_in_ + lev_off); f.ntu = (int)ntu;
   // which chain: a picture without inter blocks, every other one of them, with the frame-threaded decoder on its own (decoder.h stream_alt_)
@@ -2462,12 +2481,12 @@ int Decoder::launch_gpu(PicJob &job)
   for (int k = 0; k < KVZ_DEC_MAX_REFS; k++) for (int c = 0; c < 3; c++) f.ref[k][c] = dpb_[k].plane[c];
   f.sao = sao ? (const SaoParams *)(d_in_ + off_sao()) : nullptr;
   f.progress = alt ? progress_alt_ : progress_; f.intra_order = intra_order_; f.err = err_;
-  { const size_t nctu = (size_t)f.wc * f.hc; uint32_t *ec = alt ? edge_col_alt_ : edge_col_; unsigned long long *er = alt ? edge_row_alt_ : edge_row_;
-    f.edge_col[0] = ec; f.edge_col[1] = ec + nctu * 64; f.edge_col[2] = ec + nctu * 96;
-    f.edge_row[0] = er; f.edge_row[1] = er + nctu * 16; f.edge_row[2] = er + nctu * 24; }
+  { const size_t nctu = (size_t)f.cwc * f.chc, S = (size_t)1 << ctbl_; uint32_t *ec = alt ? edge_col_alt_ : edge_col_; unsigned long long *er = alt ? edge_row_alt_ : edge_row_;
+    f.edge_col[0] = ec; f.edge_col[1] = ec + nctu * S; f.edge_col[2] = ec + nctu * (S + S / 2);      // per CTB: S words (luma), S / 2 (Cb), S / 2 (Cr)
+    f.edge_row[0] = er; f.edge_row[1] = er + nctu * (S / 4); f.edge_row[2] = er + nctu * (S / 4 + S / 8); }
   if (job.any_intra) {                                     // a generation of its own for every launch of the chain: 1 .. 2^24 - 1; at the wrap both arrays go back to "never written"
     if (++chain_gen_ >= (1u << 24)) {
-      const size_t nctu = (size_t)(pw_ / 64) * (ph_ / 64);
+      const size_t nctu = nctb() * (size_t)(2 << ctbl_) / 128;      // (in units of the 128 words a 64x64 CTB has)
       sync_main();                                         // (everything this decoder has submitted has run: nothing reads the words while they are cleared)
       // (on the consuming stream: the decoder's streams are non-blocking, nothing would order the next chain behind a clear on the null stream)
       if (hipMemsetAsync(edge_col_, 0, nctu * 128 * sizeof(uint32_t), stream_) != hipSuccess || hipMemsetAsync(edge_row_, 0, nctu * 32 * 8, stream_) != hipSuccess) return DEC_ERR_GPU;
@@ -2501,7 +2520,7 @@ int Decoder::launch_gpu(PicJob &job)
   if (batched && stream_alt_) hipStreamSynchronize(stream_alt_);      // (another decoder has opened: from here on the submission layer launches on the shared stream; the second chain's last pictures first)       // (the other decoder has just closed: what this one still has queued there comes first)
   if (batched) memcpy(job.h_in + off_frame(), &f, sizeof(f));
   // (PicJob::early_dst: the records of every CTU row are on the device already -- queued on this stream by the row parsers -- when all rows made it)
-  const size_t up_from = (!batched && job.early_dst && job.early_dst == d_in_ && job.early_rows.load(std::memory_order_acquire) == f.hc) ? off_region() : 0;
+  const size_t up_from = (!batched && job.early_dst && job.early_dst == d_in_ && job.early_rows.load(std::memory_order_acquire) == f.chc) ? off_region() : 0;
   job.early_dst = nullptr;
   if (hipMemcpyAsync(d_in_ + up_from, job.h_in + up_from, bytes - up_from, hipMemcpyHostToDevice, stream_up_) != hipSuccess) return DEC_ERR_GPU;
   if (hipEventRecord(up_done_[ib], stream_up_) != hipSuccess) return DEC_ERR_GPU;

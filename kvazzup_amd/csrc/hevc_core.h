@@ -150,6 +150,15 @@ KVZ_HD uint32_t zaddr64(int x, int y, int w_ctbs)
   yi = (yi | (yi << 2)) & 0x33u; yi = (yi | (yi << 1)) & 0x55u;
   return (ctb << 8) | xi | (yi << 1);
 }
+// ... for coding tree blocks of 1 << ctbl samples (the decoder: any of 64, 32, 16)
+KVZ_HD uint32_t zaddr_ctb(int x, int y, int w_ctbs, int ctbl)
+{
+  const uint32_t ctb = (uint32_t)((y >> ctbl) * w_ctbs + (x >> ctbl)), m = (1u << ctbl) - 1u;
+  uint32_t xi = ((uint32_t)x & m) >> 2, yi = ((uint32_t)y & m) >> 2;
+  xi = (xi | (xi << 2)) & 0x33u; xi = (xi | (xi << 1)) & 0x55u;
+  yi = (yi | (yi << 2)) & 0x33u; yi = (yi | (yi << 1)) & 0x55u;
+  return (ctb << 8) | xi | (yi << 1);
+}
 // Tiles are full-width rows with uniform spacing: tile row i starts at CTB row (i * hc) / T (6.5.1).
 KVZ_HD int tile_row_of(int hc, int T, int cy) { return ((cy + 1) * T - 1) / hc; }
 KVZ_HD int tile_row_first(int hc, int T, int i) { return (i * hc) / T; }

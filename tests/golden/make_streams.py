@@ -81,10 +81,18 @@ GEN = {
                          qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=40, weighted=60),
     "gen_list_modification": dict(seed=38, density=25, intra_period=8, num_refs=4, tmvp=1, amp=0, sao=0, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                                   qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=40, list_mod=70),
+    # round 6: coding tree blocks of 32 and 16 samples -- what encoders other than Kvazaar write (hardware encoders) --, tiles whose boundaries fall inside a 64x64
+    # area, SAO, intra blocks in P pictures, temporal prediction
+    "gen_ctb32": dict(seed=41, density=30, intra_period=8, num_refs=2, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=0, tile_rows=2, tile_cols=2,
+                      qp_delta=2, deblock_mode=0, intra_in_p=20, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, ctb_log2=5),
+    "gen_ctb16": dict(seed=42, density=30, intra_period=8, num_refs=2, tmvp=1, amp=0, sao=1, sign_hiding=0, transform_skip=1, wpp=1, tile_rows=1, tile_cols=1,
+                      qp_delta=1, deblock_mode=2, intra_in_p=20, all_part_modes=1, nxn_intra=1, max_cu_log2=4, min_cu_log2=3, slices=0, big_mvd=0, ctb_log2=4),
     "gen_b_gop8": dict(seed=36, density=25, intra_period=16, num_refs=4, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                        qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=70, gop=8),
 }
 for name, cfg in ({} if only else GEN).items():
+    if "--new-only" in sys.argv and name in index and os.path.exists(os.path.join(out, name + ".hevc")):
+        continue                                              # (--new-only: streams that exist stay byte for byte what they are)
     g = orc.OracleGen(W, H, **cfg)
     od = orc.OracleDecoder()
     stream, md5s = b"", []

@@ -1,5 +1,5 @@
 """CPU: the PRODUCT's slice-data parser (kvazzup_amd/csrc/decoder.hip -- NAL units, parameter sets, slice headers, CABAC parse, merge / AMVP derivation)
-through its parse-only hook (no device, no picture out): what it produces for the nineteen committed golden streams and for ten streams the checker's
+through its parse-only hook (no device, no picture out): what it produces for the committed golden streams (twenty-one since round 6: two with 32- and 16-sample coding tree blocks) and for ten streams the checker's
 encoder writes here equals, byte for byte (FNV-1a digest over every picture's 4x4 records, tables, transform blocks and level words), what the parser
 produced when the whole GPU suite last compared the decoder with the checker's (tests/golden/parser_digests.json, make_parser_digests.py) -- with one
 row thread and with four (the WPP hand-over between rows)."""

@@ -7,16 +7,17 @@
 // intra prediction, dequantisation + inverse transforms, reconstruction, deblocking, SAO (dec_kernels.hip).
 //
 // Supported streams: what a Main-profile encoder in a video call produces and OpenHEVC would be asked to decode -- 8-bit 4:2:0,
-// CTB 64 / minimum CB 8 / transform blocks 4..32 (Kvazaar's fixed geometry), coded sizes that are multiples of 8, I, P and B
+// CTB 64 (Kvazaar's fixed geometry), 32 or 16 / minimum CB 8 / transform blocks 4..min(32, CTB), coded sizes that are multiples of 8, I, P and B
 // slices (both reference lists, bi-prediction, pictures handed out in POC order), every CU size and partitioning (AMP included), intra CUs in P pictures, NxN intra, all chroma
 // prediction modes, transform trees, several reference pictures (RPS in the SPS or the slice header, inter RPS prediction),
 // temporal motion vector prediction, merge levels, cu_qp_delta at any quantisation-group size, chroma QP offsets, sign data
 // hiding, transform skip, scaling lists (default, SPS and PPS scaling_list_data), cu_transquant_bypass (lossless coding units), deblocking offsets /
 // overrides, SAO, WPP, tile grids up to the level limit of 20 columns x 22 rows (uniform or
-// explicit spacing), pictures in several slice segments the two ways Kvazaar cuts them (a dependent slice segment per CTU row with WPP, an
-// independent slice per tile).  Rejected with a negative return value (kvzx_decoder_last_error): slice segments that are
-// neither whole CTU rows nor whole tiles, loop_filter_across_tiles_enabled_flag = 0, long-term references,
-// PCM, constrained intra prediction, other CTB / CB / TB sizes.
+// explicit spacing), pictures in several slice segments: the two ways Kvazaar cuts them (a dependent slice segment per CTU row with WPP, an
+// independent slice per tile) and -- one-tile pictures -- segments that begin at ANY coding tree block, independent slices (own SliceQpY) and dependent
+// segments mixed (an MTU per slice, N row groups: PicJob::ctb_cut).  Rejected with a negative return value (kvzx_decoder_last_error): several slices
+// inside a tile of a picture with tiles, slices of one picture that differ in more than SliceQpY, loop filters switched off across slices or tiles,
+// long-term references, PCM, constrained intra prediction, minimum CB 16, > 255 slices in a picture.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

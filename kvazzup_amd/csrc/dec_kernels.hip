@@ -466,10 +466,15 @@ __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, cons
   {
     const bool aL = dec_avail(f, X, Y, X - 1, Y), aT = dec_avail(f, X, Y, X, Y - 1), aTL = aL && aT && dec_avail(f, X, Y, X - 1, Y - 1);
     const int nBL = (aL && dec_avail(f, X, Y, X - 1, Y + nl)) ? imin(N, hC - (Yc + N)) : 0;
-    const int nTR = (aT && dec_avail(f, X, Y, X + nl, Y - 1)) ? imin(N, wC - (Xc + N)) : 0;
-    const int lo = aL ? N - nBL : (aTL ? 2 * N : 2 * N + 1), hi = aT ? 3 * N + nTR : (aTL ? 2 * N : (aL ? 2 * N - 1 : -1));
+    const int nTR = ((aT || f.tiles) && dec_avail(f, X, Y, X + nl, Y - 1)) ? imin(N, wC - (Xc + N)) : 0;      // (a slice that begins with the block above-right: available without the one above)
+    // ... two runs of available samples, [lo, 2N - 1] (lo = 2N: none) and [lob, hi]: the slice begins with the block above (the corner belongs to another) or with the
+    // one above-right; a sample of the gap takes the last one of the run before it, or the first one there is (8.4.4.2.2)
+    const bool hole = f.tiles && ((!aT && nTR > 0) || (aL && aT && !aTL));
+    const int lob = aT ? 2 * N + 1 : 3 * N + 1;
+    const int lo = aL ? N - nBL : (aTL || hole ? 2 * N : 2 * N + 1), hi = aT || hole ? 3 * N + nTR : (aTL ? 2 * N : (aL ? 2 * N - 1 : -1));
     auto fetch = [&](int i) -> int {
-      const int j = imin(imax(i, lo), hi);
+      int j = imin(imax(i, lo), hi);
+      if (hole && j < lob) j = lo < 2 * N ? imin(j, 2 * N - 1) : lob;
       const int col = j < 2 * N ? rx - 1 : rx + j - 2 * N - 1, rowp = j < 2 * N ? ry + 2 * N - j : ry;    // rowp = y + 1
       return s.pic[rowp * DI_P + 16 + col];
     };
@@ -626,7 +631,7 @@ __device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveSc
   const int g = lane >> 4, c = lane & 15, rx = d.rx, ry = d.ry;
   const bool active = c < N && 4 * g < N;
   int pred[4];
-  wave_intra_predict<L2>(s.pic, DI_P, ws, d, luma, lane, g, c, pred);
+  wave_intra_predict<L2, true>(s.pic, DI_P, ws, d, luma, lane, g, c, pred);
   if (d.flags & IB_LEVELS) {
     const int res[4] = {(int)(int16_t)(rres.x & 0xffffu), (int)(int16_t)(rres.x >> 16), (int)(int16_t)(rres.y & 0xffffu), (int)(int16_t)(rres.y >> 16)};
 #pragma unroll
@@ -729,15 +734,16 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
     const int N = 1 << t.log2, nl = N << sh, Xc = t.x, Yc = t.y, X = Xc << sh, Y = Yc << sh, rx = Xc - cx * S, ry = Yc - cy * S;
     const bool aL = dec_avail(f, X, Y, X - 1, Y), aT = dec_avail(f, X, Y, X, Y - 1), aTL = aL && aT && dec_avail(f, X, Y, X - 1, Y - 1);
     const int nBL = (aL && dec_avail(f, X, Y, X - 1, Y + nl)) ? imin(N, hC - (Yc + N)) : 0;
-    const int nTR = (aT && dec_avail(f, X, Y, X + nl, Y - 1)) ? imin(N, wC - (Xc + N)) : 0;
-    const int lo = aL ? N - nBL : (aTL ? 2 * N : 2 * N + 1), hi = aT ? 3 * N + nTR : (aTL ? 2 * N : (aL ? 2 * N - 1 : 0));
+    const int nTR = ((aT || f.tiles) && dec_avail(f, X, Y, X + nl, Y - 1)) ? imin(N, wC - (Xc + N)) : 0;      // (a slice that begins with the block above-right: available without the one above)
+    const bool hole = f.tiles && ((!aT && nTR > 0) || (aL && aT && !aTL));      // (two runs of available samples: kernel_common.h IB_HOLE)
+    const int lo = aL ? N - nBL : (aTL || hole ? 2 * N : 2 * N + 1), hi = aT || hole ? 3 * N + nTR : (aTL ? 2 * N : (aL ? 2 * N - 1 : 0));
     const int zu = zunit8((rx << sh) >> 3, (ry << sh) >> 3);
     IntraBlk d;
     d.rx = (uint8_t)rx; d.ry = (uint8_t)ry; d.lo = (uint8_t)lo; d.hi = (uint8_t)hi; d.mode = t.mode; d.l2 = t.log2;
     d.flags = (uint8_t)((intra_filter_needed(N, c ? 1 : 0, t.mode) ? IB_FILT : 0) | ((rx == 0 || ry == 0) ? IB_BORDER : 0) |
-                        (t.count ? IB_LEVELS : 0) | ((t.flags & TU_TSKIP) ? IB_TSKIP : 0) |
+                        (t.count ? IB_LEVELS : 0) | ((t.flags & TU_TSKIP) ? IB_TSKIP : 0) | (hole ? IB_HOLE : 0) |
                         ((ry + N >= S) ? IB_EDGE : 0) | ((rx + N >= S) ? IB_EDGE_R : 0));
-    d.xf = (uint8_t)((t.log2 == 2 && (t.flags & TU_DST)) ? XF16_DST4 : (t.log2 - 1) & 3);
+    d.xf = (uint8_t)(hole ? (aT ? 2 * N + 1 : 3 * N + 1) : 0);      // (the decoder's chain adds residuals computed elsewhere: the field is the second run's start of an IB_HOLE block)
     d.angle = (int16_t)kIntraAngle[t.mode]; d.inv = (int16_t)kInvAngle[t.mode];
     d.zu = (uint16_t)zu; d.next = 0;
     s.blk[k] = d;
@@ -813,7 +819,7 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
         // (a neighbouring CTU is waited for only as far as the block's MODE reads it: hevc_core.h intra_uses_* -- any stream; this project's encoder keeps the blocks
         // on a CTU's left edge and its above-right corner block to the modes that make these waits short, "intra-chain")
         const int n = 1 << d.l2, ci = c ? 1 : 0;
-        const int nl2 = ((intra_uses_below_left(d.l2, ci) >> d.mode) & 1) ? 2 * n : n, nt2 = ((intra_uses_above_right(d.l2, ci) >> d.mode) & 1) ? 2 * n : n;
+        const int nl2 = ((intra_uses_below_left(d.l2, ci) >> d.mode) & 1) ? 2 * n : n, nt2 = (((intra_uses_above_right(d.l2, ci) >> d.mode) & 1) || (d.flags & IB_HOLE)) ? 2 * n : n;      // (IB_HOLE: the samples above may be copies of the first one above-right)
         borders_need_wave(ch, bd, s.pic, DI_P, plane, cpitch, cx, cy, S, sh, wC - cx * S, d.rx, d.ry, n, f.err, lane, nl2, nt2);
       }
       if (k == k0) chain_wait_done(ch, make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)dp.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)dp.y)), f.err, lane);

@@ -7,16 +7,17 @@
 // intra prediction, dequantisation + inverse transforms, reconstruction, deblocking, SAO (dec_kernels.hip).
 //
 // Supported streams: what a Main-profile encoder in a video call produces and OpenHEVC would be asked to decode -- 8-bit 4:2:0,
-// CTB 64 / minimum CB 8 / transform blocks 4..32 (Kvazaar's fixed geometry), coded sizes that are multiples of 8, I, P and B
+// CTB 64 (Kvazaar's fixed geometry), 32 or 16 / minimum CB 8 / transform blocks 4..min(32, CTB), coded sizes that are multiples of 8, I, P and B
 // slices (both reference lists, bi-prediction, pictures handed out in POC order), every CU size and partitioning (AMP included), intra CUs in P pictures, NxN intra, all chroma
 // prediction modes, transform trees, several reference pictures (RPS in the SPS or the slice header, inter RPS prediction),
 // temporal motion vector prediction, merge levels, cu_qp_delta at any quantisation-group size, chroma QP offsets, sign data
 // hiding, transform skip, scaling lists (default, SPS and PPS scaling_list_data), cu_transquant_bypass (lossless coding units), deblocking offsets /
 // overrides, SAO, WPP, tile grids up to the level limit of 20 columns x 22 rows (uniform or
-// explicit spacing), pictures in several slice segments the two ways Kvazaar cuts them (a dependent slice segment per CTU row with WPP, an
-// independent slice per tile).  Rejected with a negative return value (kvzx_decoder_last_error): slice segments that are
-// neither whole CTU rows nor whole tiles, loop_filter_across_tiles_enabled_flag = 0, long-term references,
-// PCM, constrained intra prediction, other CTB / CB / TB sizes.
+// explicit spacing), pictures in several slice segments: the two ways Kvazaar cuts them (a dependent slice segment per CTU row with WPP, an
+// independent slice per tile) and -- one-tile pictures -- segments that begin at ANY coding tree block, independent slices (own SliceQpY) and dependent
+// segments mixed (an MTU per slice, N row groups: PicJob::ctb_cut).  Rejected with a negative return value (kvzx_decoder_last_error): several slices
+// inside a tile of a picture with tiles, slices of one picture that differ in more than SliceQpY, loop filters switched off across slices or tiles,
+// long-term references, PCM, constrained intra prediction, minimum CB 16, > 255 slices in a picture.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -185,6 +186,16 @@ class Decoder {
     // with tile columns: whether a slice segment ends with substream k (seg_end_row is per CTU row and only used without tile columns)
     struct SubGeom { int cy0, cy1, cx0, cx1, tile_cy0, tile_cy1, tc; };
     std::vector<SubGeom> geom; std::vector<uint8_t> seg_end_sub;
+    // FREE slices (round 6; one tile): slice segments that begin at any coding tree block, independent slices inside the tile -- what an encoder that cuts
+    // slices by bytes or block counts sends.  Per coding tree block (raster): ctb_cut bit 0 an independent slice begins here, bit 1 a dependent segment,
+    // bit 2 a segment ENDS with this block; ctb_data: where the beginning segment's bytes start in rbsp; ctb_slice: the block's slice (counted from 0; it
+    // also rides in ctu_tile[] for the kernels' availability tests); slice_qps: SliceQpY by slice; ds_saved: the context states a segment left behind at the
+    // end of a CTB row (WPP: the next row's parser may need them, 9.3.1).  All empty: one slice, or Kvazaar's slices (whole rows / whole tiles).
+    std::vector<uint8_t> ctb_cut, ctb_slice; std::vector<size_t> ctb_data; std::vector<int8_t> slice_qps; std::vector<uint8_t> ds_saved;
+    // a one-tile picture submitted because its segments COVER it row by row: whether the last one really ends with the picture is not in any header.  The parser
+    // says so when it does not (DEC_SEG_ENDS_EARLY), and the synchronous decoder then takes the picture back and waits for the rest of its access unit (submit_job).
+    bool ambiguous_end = false;
+    struct Undo { int poc = 0, prev_poc = 0; bool is_ref = false, used = false, seen_irap = false; long decode_idx = 0; std::shared_ptr<ColMotion> motion; } undo;      // what submit_job changed
     SliceHdr sh; std::shared_ptr<const DecSps> sps; DecPps pps;  // (a later SPS / PPS NAL may replace the table entry while this picture is still being parsed: the job keeps the SPS it was coded with alive, the PPS by value)
     int64_t pts = 0; int crop[4] = {0, 0, 0, 0}; uint32_t fps_num = 0, fps_den = 0;
     int slot = 0;                                                // picture buffer this picture is reconstructed into
@@ -246,6 +257,12 @@ class Decoder {
   int parse_job(PicJob &job, bool row_parallel);
   int parse_substream(PicJob &job, int sub, const uint8_t *data, size_t len, SubOut &out);
   int close_open_picture();
+  int close_free_picture(PicJob &job);
+  void take_back_job(PicJob &job);
+  // the slice segments of the picture being assembled, as they arrived (one tile): kept beside the row bookkeeping of Kvazaar's forms, which is dropped the moment a
+  // segment turns up that those forms do not have (asm_free_) -- the picture is then put together from this list when the access unit ends
+  struct FreeSeg { int address; bool dependent; int slice_qp; std::vector<size_t> subs; };
+  std::vector<FreeSeg> asm_segs_; bool asm_free_ = false, free_stream_ = false; bool asm_cur_dependent_ = false; int asm_cur_qp_ = 26;
   int finish_oldest();
   void drop_pending();
   // layout of the input block

@@ -12,7 +12,7 @@
 namespace kvzx {
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "kvazzup_amd: %s failed: %s\n", #expr, hipGetErrorString(e_)); return false; } } while (0)
-enum { DEC_ERR_INVALID = -1, DEC_ERR_UNSUPPORTED = -2, DEC_ERR_GPU = -3, DEC_ERR_HASH = -4 };      // (-4: a decoded picture hash SEI did not match, libOpenHevcSetCheckMD5)
+enum { DEC_ERR_INVALID = -1, DEC_ERR_UNSUPPORTED = -2, DEC_ERR_GPU = -3, DEC_ERR_HASH = -4, DEC_SEG_ENDS_EARLY = -100 /* internal: PicJob::ambiguous_end */ };      // (-4: a decoded picture hash SEI did not match, libOpenHevcSetCheckMD5)
 enum { PM_INTER = 0, PM_INTRA = 1, PM_SKIP = 2, PM_NONE = 255 };
 enum { PART_2Nx2N = 0, PART_2NxN, PART_Nx2N, PART_NxN, PART_2NxnU, PART_2NxnD, PART_nLx2N, PART_nRx2N };
 
@@ -381,6 +381,8 @@ struct SliceParser {
   B4Rec *b4; uint8_t *pm, *ctd, *im;     // pm, ctd: per 8x8 (the minimum coding block); im: per 4x4 (NxN parts)
   int ref_y0 = -(1 << 30), ref_y1 = 1 << 30;                              // band mode: the luma rows of a reference picture this decoder holds (the picture's outer edges open)
   int tile_y0 = 0, tile_y1 = 1 << 30, tile_x0 = 0, tile_x1 = 1 << 30;    // luma rows / columns of the tile being parsed: nothing outside is available (other tiles may be parsed concurrently)
+  const uint8_t *slice_of = nullptr; int cur_slice = 0;                  // pictures of several slices inside a tile (PicJob::ctb_slice): the slice of every coding tree block, the one being parsed
+  int slice_qp = 26;                                                      // SliceQpY of the slice being parsed
   int err = 0;
   // quantisation (8.6.1)
   int qp_y = 0, qp_y_pred = 0, last_qp_y = 0, cu_qp_delta_val = 0, log2_qg = 6; bool qp_delta_coded = false;
@@ -395,13 +397,13 @@ struct SliceParser {
 
   inline int bi(int x, int y) const { return (y >> 2) * b4w + (x >> 2); }
   inline int b8(int x, int y) const { return (y >> 3) * b8w + (x >> 3); }
-  // 6.4.1 (one slice per picture, tiles are full-width rows): inside the picture, inside the tile, already decoded.  "Already
+  // 6.4.1: inside the picture, inside the tile, in the same slice (slice_of: pictures with several slices inside a tile), already decoded.  "Already
   // decoded" is read off the prediction-mode array, which starts every picture as PM_NONE: in decoding order a block is marked
   // when its coding unit starts, and the WPP row hand-over (two CTUs behind the row above, parse_substream) guarantees that every
   // neighbour that precedes the current block in z-scan order has been parsed while none that follows it has been.
   inline bool avail(int, int, int xn, int yn) const
   {
-    return xn >= tile_x0 && yn >= tile_y0 && xn < w && yn < h && yn < tile_y1 && xn < tile_x1 && pm[b8(xn, yn)] != PM_NONE;
+    return xn >= tile_x0 && yn >= tile_y0 && xn < w && yn < h && yn < tile_y1 && xn < tile_x1 && pm[b8(xn, yn)] != PM_NONE && (!slice_of || slice_of[(yn >> ctbl) * wc + (xn >> ctbl)] == cur_slice);
   }
   // coding-unit wide values of the per-8x8 arrays
   void fill_cu8(uint8_t *arr, int x0, int y0, int n, int v)
@@ -1510,7 +1512,7 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
   }
   memset(rbsp_.data() + n, 0, 32);                          // (readers may look a few bytes past the end)
   BitReader r(rbsp_.data(), n);
-  if (asm_active_ && asm_guessed_one_row_ && nal_type >= 32 && nal_type <= 40 && nal_type != 38) { const int rc = close_open_picture(); if (rc < 0) return rc; }   // (what can only open the next access unit, or end the sequence)
+  if (asm_active_ && (asm_guessed_one_row_ || asm_free_) && nal_type >= 32 && nal_type <= 40 && nal_type != 38) { const int rc = close_open_picture(); if (rc < 0) return rc; }   // (what can only open the next access unit, or end the sequence)
   if (nal_type == 32) {                                          // VPS: only the timing information is used
     r.get(4); r.get(2); r.get(6); int msl = r.get(3); r.get(1); r.get(16);
     if (!skip_ptl(r, msl)) return last_error_ = DEC_ERR_INVALID;
@@ -1682,12 +1684,67 @@ int Decoder::verify_hash(const PicJob &job, const std::vector<uint8_t> &want)
 // (append_segment), but the flag does not forbid whole pictures in one segment: then the segment IS the picture, it ends where its
 // end_of_slice_segment_flag says and is submitted now, ahead of the NAL unit at hand -- or segments were lost and the picture is dropped,
 // which must not pass unnoticed: the error code is left for kvzx_decoder_last_error and said once on stderr.
+// A picture of free slices (append_segment) when its access unit has ended: every segment ends where the next begins, the last one with the picture.  What
+// the parser needs per coding tree block -- which slice, whether a segment begins or ends there, where its bytes are -- is laid out here; the substreams
+// stay what they are for any one-tile picture (a CTB row each with WPP, else the picture), a segment that begins inside one restarts the arithmetic decoder there.
+int Decoder::close_free_picture(PicJob &job)
+{
+  const int wc = (w_ + (1 << ctbl_) - 1) >> ctbl_, hc = (h_ + (1 << ctbl_) - 1) >> ctbl_, total = wc * hc, n = (int)asm_segs_.size();
+  const bool wpp = job.pps.wpp != 0;
+  if (n < 1 || asm_segs_[0].address != 0 || asm_segs_[0].dependent) return DEC_ERR_INVALID;
+  if (n == 1 && frame_threads_ == 1) free_stream_ = false;      // (one segment: the stream may be back to whole pictures -- the synchronous decoder can afford to find out, submit_job take_back)
+  if (n == 1) {
+    // the whole picture in one segment: the layout of Kvazaar's forms -- nothing per coding tree block, the parser's availability tests as they were
+    if ((int)asm_segs_[0].subs.size() != (wpp ? hc : 1)) return DEC_ERR_INVALID;
+    job.ctb_cut.clear(); job.ctb_slice.clear(); job.ctb_data.clear(); job.slice_qps.clear();
+    job.sub_start = asm_segs_[0].subs;
+    job.seg_end_row.assign((size_t)hc, 0); job.seg_end_row[(size_t)hc - 1] = 1; job.row_restart.assign((size_t)hc, SIZE_MAX);
+    job.seg_end_sub.assign(job.geom.size(), 0);
+    return 0;
+  }
+  job.ctb_cut.assign((size_t)total, 0); job.ctb_slice.assign((size_t)total, 0); job.ctb_data.assign((size_t)total, SIZE_MAX); job.slice_qps.clear();
+  job.sub_start.assign(wpp ? (size_t)hc : 1, SIZE_MAX);
+  job.seg_end_row.assign((size_t)hc, 0); job.row_restart.assign((size_t)hc, SIZE_MAX);
+  int slice = -1;
+  for (int k = 0; k < n; k++) {
+    const FreeSeg &sg = asm_segs_[(size_t)k];
+    const int a = sg.address, e = k + 1 < n ? asm_segs_[(size_t)k + 1].address : total;
+    if (a < 0 || e <= a || e > total || sg.subs.empty()) return DEC_ERR_INVALID;
+    if (!sg.dependent) { if (++slice > 255) return DEC_ERR_UNSUPPORTED; job.slice_qps.push_back((int8_t)sg.slice_qp); }      // (the kernels tell slices apart by a byte per block)
+    job.ctb_cut[(size_t)a] |= sg.dependent ? 2 : 1; job.ctb_cut[(size_t)e - 1] |= 4; job.ctb_data[(size_t)a] = sg.subs[0];
+    memset(job.ctb_slice.data() + a, slice, (size_t)(e - a));
+    const int rows = (e - 1) / wc - a / wc + 1;
+    if (wpp) {
+      if ((int)sg.subs.size() != rows) return DEC_ERR_INVALID;      // (an entry point per CTB row the segment goes on into)
+      for (int q = 0; q < rows; q++) if (q > 0 || a % wc == 0) job.sub_start[(size_t)(a / wc + q)] = sg.subs[(size_t)q];
+    } else {
+      if (sg.subs.size() != 1) return DEC_ERR_INVALID;
+      if (k == 0) job.sub_start[0] = sg.subs[0];
+    }
+  }
+  for (size_t q = 0; q < job.sub_start.size(); q++) if (job.sub_start[q] == SIZE_MAX || (q > 0 && job.sub_start[q] <= job.sub_start[q - 1])) return DEC_ERR_INVALID;
+  if (wpp) job.ds_saved.assign((size_t)hc * CTX_COUNT, 0);
+  for (int cy = 0; cy < hc; cy++) memcpy(job.ctu_tile + (size_t)cy * wc, job.ctb_slice.data() + (size_t)cy * wc, (size_t)wc);      // (one tile: the byte the kernels compare between adjacent blocks is the slice's)
+  job.sh.slice_qp = job.slice_qps[0];
+  job.seg_end_sub.assign(job.geom.size(), 0);
+  return 0;
+}
+
 int Decoder::close_open_picture()
 {
   if (!asm_active_) return 0;
   asm_active_ = false;
   PicJob &old = jobs_[(size_t)(job_head_ % jobs_.size())];
   const int old_hc = (h_ + (1 << ctbl_) - 1) >> ctbl_;
+  if (asm_free_) {
+    asm_free_ = false;
+    int rc = close_free_picture(old);
+    old.ambiguous_end = false;
+    if (rc >= 0) rc = submit_job(old, asm_nal_type_, asm_irap_);
+    if (rc < 0) { last_error_ = rc; return 0; }
+    if (rc > 0 && pic_ready_ && !stash_current_output()) return last_error_ = DEC_ERR_GPU;
+    return 0;
+  }
   if (asm_guessed_one_row_ && asm_rows_ == 1 && old_hc > 1) {
     asm_guessed_one_row_ = false;
     old.seg_end_row[0] = 0; old.seg_end_row[(size_t)(old_hc - 1)] = 1;
@@ -1721,6 +1778,22 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     int bits = 0; while ((1 << bits) < nctb) bits++;
     if (p.dependent_slices) dependent = r.get(1) != 0;
     seg_address = r.get(bits);
+    if (!asm_active_ && frame_threads_ > 1 && !parse_only_ && job_head_ > job_tail_ && pps_id == asm_pps_id_ && nal_type == asm_nal_type_) {
+      // frame threads: the picture this segment may belong to is with a worker -- submitted because its segments covered it row by row (PicJob::ambiguous_end).
+      // The worker's verdict is waited for (a parse that ends early is a short one): "its last segment ends before the picture does" takes the picture back,
+      // open again, and this segment joins it.
+      PicJob &last = jobs_[(size_t)((job_head_ - 1) % jobs_.size())];
+      if (last.ambiguous_end) {
+        for (int st; (st = last.state.load(std::memory_order_acquire)) == 1;) futex_wait(last.state, st);
+        if (last.state.load(std::memory_order_acquire) == 2 && last.rc == DEC_SEG_ENDS_EARLY) take_back_job(last);
+      }
+    }
+    if (!asm_active_ && p.tile_cols == 1 && p.tile_rows == 1 && (!dependent || seg_address % ((s.width + ctbs - 1) >> s.ctb_log2) != 0)) {
+      // no picture is open, and this is no segment of Kvazaar's forms (a dependent segment per CTU row): the stream cuts its pictures into slices as it likes -- its
+      // first picture went off as one segment (where a picture without WPP ends is not in its first segment's header).  From here on a picture of this stream is put
+      // together from its segments when its access unit ends (append_segment, close_free_picture); this one is lost.
+      free_stream_ = true;
+    }
     if (!asm_active_ || pps_id != asm_pps_id_ || nal_type != asm_nal_type_) return DEC_ERR_INVALID;      // a segment without its picture's first one (lost), or of another picture
   } else if (asm_active_) {
     // the previous picture never got its last segment: close_open_picture() submits or drops it; this NAL unit -- a new picture -- is decoded normally
@@ -1731,6 +1804,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   if (dependent && open_job->pps.tile_cols > 1) { asm_active_ = false; return DEC_ERR_UNSUPPORTED; }     // (with tile columns: whole pictures or slices of whole tiles)
   if (dependent) {
     // 7.3.6.1: everything but the address and the entry points is taken over from the slice's first segment
+    asm_cur_dependent_ = true;
     const int wc = (s.width + (1 << s.ctb_log2) - 1) >> s.ctb_log2, hc = (s.height + (1 << s.ctb_log2) - 1) >> s.ctb_log2;
     return append_segment(*open_job, r.pos, rbsp, len, p, open_job->pps, wc, hc, seg_address, pts);
   }
@@ -1850,10 +1924,11 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     const SliceHdr &a = open_job->sh;
     if (sh.is_intra != a.is_intra || sh.is_b != a.is_b || sh.num_ref_idx1 != a.num_ref_idx1 || sh.mvd_l1_zero != a.mvd_l1_zero || sh.collocated_from_l0 != a.collocated_from_l0 || sh.poc != a.poc || sh.tmvp != a.tmvp || sh.collocated_ref_idx != a.collocated_ref_idx || sh.sao_luma != a.sao_luma ||
         sh.sao_chroma != a.sao_chroma || sh.num_ref_idx != a.num_ref_idx || sh.cabac_init_flag != a.cabac_init_flag || sh.max_merge != a.max_merge ||
-        sh.slice_qp != a.slice_qp || sh.cb_qp_offset != a.cb_qp_offset || sh.cr_qp_offset != a.cr_qp_offset || sh.deblock_disabled != a.deblock_disabled ||
+        (sh.slice_qp != a.slice_qp && (pp.tile_cols > 1 || pp.tile_rows > 1)) || sh.cb_qp_offset != a.cb_qp_offset || sh.cr_qp_offset != a.cr_qp_offset || sh.deblock_disabled != a.deblock_disabled ||
         sh.beta_offset_div2 != a.beta_offset_div2 || sh.tc_offset_div2 != a.tc_offset_div2 || !across_slices ||
         memcmp(sh.list_mod, a.list_mod, 2) || memcmp(sh.list_entry, a.list_entry, sizeof(sh.list_entry)) ||
         sh.wt_explicit != a.wt_explicit || sh.weighted != a.weighted || (sh.weighted && (memcmp(sh.wt, a.wt, sizeof(sh.wt)) || sh.wt_log2[0] != a.wt_log2[0] || sh.wt_log2[1] != a.wt_log2[1]))) return DEC_ERR_UNSUPPORTED;
+    asm_cur_dependent_ = false; asm_cur_qp_ = sh.slice_qp;      // (inside one tile a slice may have its own SliceQpY: free slices, close_free_picture)
     return append_segment(*open_job, r.pos, rbsp, len, p, pp, wc, hc, seg_address, pts);
   }
   if (!sh.is_intra && !seen_irap_) return DEC_ERR_INVALID;       // nothing to predict from before the first random access point
@@ -1947,6 +2022,8 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   if (job.own) { job.own->cols = pp.tile_cols; job.own->row_cols.reset(new std::atomic<uint8_t>[(size_t)hc]); for (int k = 0; k < hc; k++) job.own->row_cols[(size_t)k].store(0, std::memory_order_relaxed); }
   job.rc = 0; job.any_intra = job.any_inter = false;
   asm_active_ = true; asm_guessed_one_row_ = false; asm_rows_ = 0; asm_subs_ = 0; asm_pps_id_ = pps_id; asm_nal_type_ = nal_type; asm_irap_ = irap;
+  asm_segs_.clear(); asm_free_ = false; asm_cur_dependent_ = false; asm_cur_qp_ = sh.slice_qp; job.ambiguous_end = false;
+  job.ctb_cut.clear(); job.ctb_slice.clear(); job.ctb_data.clear(); job.slice_qps.clear();
   return append_segment(job, r.pos, rbsp, len, p, pp, wc, hc, 0, pts);
 }
 
@@ -1959,7 +2036,22 @@ int Decoder::append_segment(PicJob &job, size_t bitpos, const uint8_t *rbsp, siz
   BitReader r(rbsp, len); r.pos = bitpos;
   auto fail = [&](int rc) { asm_active_ = false; return rc; };
   if (pp.tile_cols > 1) return append_segment_tiles(job, r.pos, rbsp, len, p, pp, wc, hc, address);
-  if (address != asm_rows_ * wc) return fail(address % wc ? DEC_ERR_UNSUPPORTED : DEC_ERR_INVALID);     // whole CTU rows, in order
+  // One tile: a segment that Kvazaar's forms do not have -- one that begins inside a CTB row, an independent slice behind the picture's first -- makes the picture
+  // (and the stream: free_stream_) one of FREE slices: its segments are only collected here; where each ends is where the next begins, and the picture is put
+  // together when its access unit ends (close_free_picture).
+  const bool one_tile = pp.tile_rows == 1;
+  // (frame threads: a picture whose segments turn out not to reach its end is with a worker by then; it is taken back when the segment that shows as much arrives
+  // -- decode_slice -- unless the ring has handed it on already.  A picture without WPP, whose first segment says nothing at all about how far it reaches, does not
+  // take that chance: it always waits for the end of its access unit there -- the next NAL unit, one more picture of delay on top of the ring's; a picture that
+  // then has ONE segment is parsed as ever, close_free_picture)
+  const bool wait_always = one_tile && frame_threads_ > 1 && !p.wpp && band_nrows_ == 0 && !parse_only_;
+  if (one_tile && !asm_free_ && (wait_always || free_stream_ || (!asm_segs_.empty() && !asm_cur_dependent_) || address % wc != 0 || (!p.wpp && address != asm_rows_ * wc))) {      // (without WPP no header says how many rows a segment has: one that begins elsewhere than guessed is no loss)
+    if (band_nrows_ > 0) return fail(DEC_ERR_UNSUPPORTED);
+    asm_free_ = true;
+    if (!wait_always) free_stream_ = true;
+  }
+  if (!asm_free_ && address != asm_rows_ * wc) return fail(address % wc ? DEC_ERR_UNSUPPORTED : DEC_ERR_INVALID);     // whole CTU rows, in order
+  if (asm_free_ && (address >= wc * hc || (asm_segs_.empty() ? address != 0 : address <= asm_segs_.back().address))) return fail(DEC_ERR_INVALID);
   std::vector<uint32_t> entry;
   if (p.wpp || p.tile_rows > 1) {
     const int nep = r.ue();
@@ -1974,7 +2066,8 @@ int Decoder::append_segment(PicJob &job, size_t bitpos, const uint8_t *rbsp, siz
   const int nss = (int)entry.size() + 1, row0 = asm_rows_;
   int rows = 0;
   bool mid_substream = false;                                    // no WPP, and the segment does not start a tile: it continues the tile's substream
-  if (p.wpp) rows = nss;
+  if (asm_free_) { if (nss > hc || (!p.wpp && nss != 1)) return fail(DEC_ERR_INVALID); }
+  else if (p.wpp) rows = nss;
   else {
     int t = 0; while (t < pp.tile_rows && pp.row_bd[t] != row0) t++;
     if (t < pp.tile_rows) { if (t + nss > pp.tile_rows) return fail(DEC_ERR_INVALID); rows = pp.row_bd[t + nss] - row0; }
@@ -1990,14 +2083,13 @@ int Decoder::append_segment(PicJob &job, size_t bitpos, const uint8_t *rbsp, siz
       asm_guessed_one_row_ = p.dependent_slices != 0;
     } else if (!mid_substream && nss == 1 && p.dependent_slices) rows = 1;      // a tile begun by one row; the rest follows as dependent segments
   }
-  if (rows < 1 || row0 + rows > hc) return fail(DEC_ERR_INVALID);
+  if (!asm_free_ && (rows < 1 || row0 + rows > hc)) return fail(DEC_ERR_INVALID);
   // Substream starts inside the unescaped slice data.  entry_point offsets count bytes of the NAL
   // unit payload INCLUDING emulation prevention bytes (7.4.7.1); epb_[] holds, for every removed
   // byte, how many unescaped payload bytes preceded it.
   const size_t hdr = r.pos >> 3, base = job.rbsp.size();
   if (hdr > len) return fail(DEC_ERR_INVALID);
-  if (mid_substream) job.row_restart[(size_t)row0] = base;
-  else job.sub_start.push_back(base);
+  std::vector<size_t> starts(1, base);                           // where the segment's substreams begin in job.rbsp
   {
     size_t esc = hdr;                                            // escaped offset of the slice data in the payload
     for (size_t k = 0; k < epb_.size(); k++) if (epb_[k] < hdr) esc++;
@@ -2005,15 +2097,23 @@ int Decoder::append_segment(PicJob &job, size_t bitpos, const uint8_t *rbsp, siz
       esc += e;
       size_t removed = 0;
       for (size_t k = 0; k < epb_.size(); k++) if (epb_[k] + k < esc) removed++;     // epb k sits at escaped offset epb_[k] + k
-      job.sub_start.push_back(base + esc - removed - hdr);
+      starts.push_back(base + esc - removed - hdr);
     }
   }
   job.rbsp.insert(job.rbsp.end(), rbsp + hdr, rbsp + len);
   job.data_off = 0; job.data_len = job.rbsp.size();
+  if (one_tile) {
+    if (asm_segs_.size() >= 1024) return fail(DEC_ERR_UNSUPPORTED);
+    asm_segs_.push_back(FreeSeg{address, asm_cur_dependent_, asm_cur_qp_, starts});
+  }
+  if (asm_free_) return 0;                                       // (the access unit's end closes the picture: decode_nal_inner, close_open_picture)
+  if (mid_substream) job.row_restart[(size_t)row0] = base;
+  else job.sub_start.insert(job.sub_start.end(), starts.begin(), starts.end());
   asm_rows_ = row0 + rows;
   job.seg_end_row[(size_t)(asm_rows_ - 1)] = 1;
   if (asm_rows_ < hc) return 0;                                  // more segments to come: no output for this NAL unit
   asm_active_ = false;
+  job.ambiguous_end = one_tile && band_nrows_ == 0;
   return submit_job(job, asm_nal_type_, asm_irap_);
 }
 
@@ -2063,10 +2163,24 @@ int Decoder::append_segment_tiles(PicJob &job, size_t bitpos, const uint8_t *rbs
   return submit_job(job, asm_nal_type_, asm_irap_);
 }
 
+void Decoder::take_back_job(PicJob &job)
+{
+  DpbPic &d = dpb_[job.slot];
+  d.poc = job.undo.poc; d.is_ref = job.undo.is_ref; d.used = job.undo.used; d.decode_idx = job.undo.decode_idx; d.motion = job.undo.motion; prev_poc_ = job.undo.prev_poc; seen_irap_ = job.undo.seen_irap;
+  job.undo.motion.reset();
+  job_head_--; job.state.store(0, std::memory_order_relaxed); job.rc = 0; job.early_dst = nullptr;
+  asm_active_ = true; asm_free_ = free_stream_ = true;
+}
+
 int Decoder::submit_job(PicJob &job, int nal_type, bool irap)
 {
   const SliceHdr &sh = job.sh;
   DpbPic &d = dpb_[job.slot];
+  // (PicJob::ambiguous_end: when the picture's last segment ends before the picture does, more segments are to come -- everything is put back as it was before
+  // the call and the picture is open again, as one of free slices; append_segment collects the rest, the end of the access unit closes it.  The synchronous decoder
+  // knows at once; with frame threads the worker finds out and decode_slice looks when the next segment arrives.)
+  job.undo.poc = d.poc; job.undo.prev_poc = prev_poc_; job.undo.is_ref = d.is_ref; job.undo.used = d.used; job.undo.seen_irap = seen_irap_; job.undo.decode_idx = d.decode_idx; job.undo.motion = d.motion;
+  auto take_back = [&] { take_back_job(job); return 0; };
   d.poc = sh.poc; d.is_ref = true; d.used = true; d.decode_idx = job_head_; d.motion = job.own;
   if (cur_tid_ == 0 && (nal_type > 9 || ((nal_type & 1) && nal_type < 6))) prev_poc_ = sh.poc;   // prevTid0Pic (8.3.1): TemporalId 0, not RASL / RADL / sub-layer non-reference
   if (irap) seen_irap_ = true;
@@ -2075,6 +2189,7 @@ int Decoder::submit_job(PicJob &job, int nal_type, bool irap)
     auto t0 = std::chrono::steady_clock::now();
     job.rc = parse_job(job, parse_threads_ > 1);
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (job.rc == DEC_SEG_ENDS_EARLY) return take_back();
     job_tail_ = job_head_;
     if (job.rc < 0) return job.rc;
     probe_book(job, ms);
@@ -2090,6 +2205,7 @@ int Decoder::submit_job(PicJob &job, int nal_type, bool irap)
       if (!early_off && gpu_depth_ == 1 && band_nrows_ == 0 && job.pps.tile_cols == 1 && !(batch_attached_ && DecBatcher::get(device_).active()) && d_in_[ib] && d_in_cap_[ib] >= fixed_bytes()) job.early_dst = d_in_[ib];
     }
     job.rc = parse_job(job, true);
+    if (job.rc == DEC_SEG_ENDS_EARLY) { if (job.early_dst) hipStreamSynchronize(stream_up_); return take_back(); }
     if (profiling_) { k_ms_[DK_HOST_PARSE] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); k_n_[DK_HOST_PARSE]++; }
     job.state.store(2, std::memory_order_release);
   } else {
@@ -2120,6 +2236,13 @@ int Decoder::submit_job(PicJob &job, int nal_type, bool irap)
 void Decoder::probe_book(PicJob &job, double ms)
 {
   const size_t tu_off = fixed_bytes(), lev_off = (tu_off + job.ntu * sizeof(DecTu) + 15) & ~(size_t)15;
+  if (const char *dump = getenv("KVAZZUP_AMD_PROBE_DUMP")) {      // (debugging aid: every picture's 4x4 records and intra modes, rows of pw / 4, appended to the file)
+    if (FILE *fp = fopen(dump, "ab")) {
+      const int32_t hdr[4] = {pw_ / 4, ph_ / 4, w_ / 4, h_ / 4};
+      fwrite(hdr, sizeof(hdr), 1, fp); fwrite(job.b4, sizeof(B4Rec), (size_t)(pw_ / 4) * (ph_ / 4), fp); fwrite(job.intra_mode.data(), 1, (size_t)(pw_ / 4) * (ph_ / 4), fp);
+      fclose(fp);
+    }
+  }
   uint64_t d = probe_.digest;
   auto fold = [&](const uint8_t *p, size_t n) { for (size_t i = 0; i < n; i++) { d ^= p[i]; d *= 0x100000001b3ull; } };
   fold(job.h_in, off_scaling());                                              // records, region / CTU tables, tile ids, SAO parameters
@@ -2147,7 +2270,7 @@ int Decoder::finish_oldest()
     // the next picture's kernels are queued BEFORE an earlier picture is waited for: the GPU goes from one to the other without
     // this thread's launch latency in between
     tl("dlaunch0", job.pts);
-    rc_launch = job.rc < 0 ? job.rc : launch_gpu(job);
+    rc_launch = job.rc < 0 ? (job.rc == DEC_SEG_ENDS_EARLY ? DEC_ERR_UNSUPPORTED : job.rc) : launch_gpu(job);      // (a picture whose last segment ended early and whose rest never came)
     tl("dlaunch1", job.pts);
     launched = rc_launch >= 0;
   }
@@ -2287,15 +2410,26 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
   const int init_type = sh.is_intra ? 0 : (sh.is_b ? (sh.cabac_init_flag ? 1 : 2) : (sh.cabac_init_flag ? 2 : 1));      // 9.3.2.2: cabac_init_flag swaps the P and the B tables
   CabacDec &c = sp.c;
   c.start(data, len);
+  // free slices (PicJob::ctb_cut; one tile): the slice of every coding tree block, its SliceQpY
+  const bool free_slices = !job.ctb_cut.empty();
+  sp.slice_qp = sh.slice_qp;
+  if (free_slices) { sp.slice_of = job.ctb_slice.data(); sp.cur_slice = job.ctb_slice[(size_t)first_cy * wc + cx0]; sp.slice_qp = job.slice_qps[(size_t)sp.cur_slice]; }
+  auto init_contexts = [&] { uint8_t init[CTX_COUNT]; cabac_init_contexts(init, init_type, sp.slice_qp); c.load_ctx(init); };
   // 9.3.1: the first CTB of a tile initialises the contexts; a WPP row takes them over from the row above after its second
-  // CTB when that CTB exists (pictures one CTB wide: it does not, and the row initialises afresh)
-  if (!wpp || tile_starts_at(first_cy) || tw < 2) {
-    { uint8_t init[CTX_COUNT]; cabac_init_contexts(init, init_type, sh.slice_qp); c.load_ctx(init); }
+  // CTB when that CTB exists (pictures one CTB wide: it does not, and the row initialises afresh) -- and is AVAILABLE: with free slices it may
+  // belong to another slice; then a dependent segment that begins with this row goes on where the segment before it stopped (the end of the row
+  // above), anything else initialises
+  if (!wpp || tile_starts_at(first_cy) || tw < 2) init_contexts();
+  else if (free_slices && job.ctb_slice[(size_t)(first_cy - 1) * wc + cx0 + 1] != sp.cur_slice) {
+    if (job.ctb_cut[(size_t)first_cy * wc + cx0] & 2) {
+      if (!wait_above(first_cy, tw)) return DEC_ERR_INVALID;
+      c.load_ctx(&job.ds_saved[(size_t)(first_cy - 1) * CTX_COUNT]);
+    } else init_contexts();
   } else {
     if (!wait_above(first_cy, 2)) return DEC_ERR_INVALID;
     c.load_ctx(&job.wpp_saved[((size_t)(first_cy - 1) * cols + g.tc) * CTX_COUNT]);
   }
-  sp.last_qp_y = sh.slice_qp;                          // qPY_PREV at the start of a slice, a tile, a CTB row with WPP (8.6.1)
+  sp.last_qp_y = sp.slice_qp;                          // qPY_PREV at the start of a slice, a tile, a CTB row with WPP (8.6.1)
   sp.tile_y0 = g.tile_cy0 << ctbl_; sp.tile_y1 = g.tile_cy1 << ctbl_; sp.tile_x0 = cx0 << ctbl_; sp.tile_x1 = cx1 << ctbl_;
   if (band_nrows_ > 0) {
     if (band_row0_ > 0) sp.ref_y0 = band_row0_ * 64 - 4;
@@ -2312,12 +2446,28 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
     for (int cx = cx0; cx < cx1; cx++) {
       if (!wait_above(cy, cx - cx0 + 2)) return DEC_ERR_INVALID;
       const int ctu = cy * wc + cx;
+      const uint8_t cut = free_slices ? job.ctb_cut[(size_t)ctu] : 0;
+      if (cut & 3) {
+        // a slice segment begins with this block: its own arithmetic codeword (the substream's first block: started above); an independent slice is a new
+        // slice for every availability rule, starts from the initial context states and from its own SliceQpY; a dependent one goes on with the states at hand
+        if (cx != cx0 || cy != first_cy) {
+          const uint8_t *q = job.rbsp.data() + job.data_off + job.ctb_data[(size_t)ctu];
+          if (q < data || q >= data + len) return DEC_ERR_INVALID;
+          c.start(q, (size_t)(data + len - q));
+        }
+        if (cut & 1) {
+          sp.cur_slice = job.ctb_slice[(size_t)ctu]; sp.slice_qp = job.slice_qps[(size_t)sp.cur_slice];
+          init_contexts();
+          sp.last_qp_y = sp.slice_qp;
+        }
+      }
       const uint32_t tu0 = (uint32_t)out.tus.size();
       sp.ctu_intra_mask = 0;
-      if (!pps.cu_qp_delta) { sp.qp_y_pred = sh.slice_qp; sp.cu_qp_delta_val = 0; }
+      if (!pps.cu_qp_delta) { sp.qp_y_pred = sp.slice_qp; sp.cu_qp_delta_val = 0; }
       if (sh.sao_luma || sh.sao_chroma) {                  // sao() (7.3.8.3) opens the CTU
         SaoParams *s = &job.sao[ctu];
         const SaoParams *left = cx > cx0 ? s - 1 : nullptr, *up = (cy > 0 && !tile_starts_at(cy)) ? s - wc : nullptr;
+        if (free_slices) { if (left && job.ctb_slice[(size_t)ctu - 1] != sp.cur_slice) left = nullptr; if (up && job.ctb_slice[(size_t)ctu - wc] != sp.cur_slice) up = nullptr; }      // (merging stays inside the slice)
         parse_sao(c, *s, left, up, sh.sao_luma != 0, sh.sao_chroma != 0);
       }
       sp.coding_quadtree(cx << ctbl_, cy << ctbl_, ctbl_, 0);
@@ -2327,12 +2477,13 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
       job.ctu[ctu].count = ((uint32_t)out.tus.size() - tu0) | (sp.ctu_intra_mask << 24);
       if (out.tus.size() - tu0 >= (1u << 24)) return DEC_ERR_INVALID;
       if (wpp && cx == cx0 + 1) c.save_ctx(&job.wpp_saved[((size_t)cy * cols + g.tc) * CTX_COUNT]);
+      if ((cut & 4) && wpp && cx == cx1 - 1) c.save_ctx(&job.ds_saved[(size_t)cy * CTX_COUNT]);      // (a segment ends with the row: what a dependent segment that begins the next row may have to go on with)
       if (wpp) job.row_progress[(size_t)cy * cols + g.tc].v.store(cx - cx0 + 1, std::memory_order_release);
       // end_of_slice_segment_flag: 1 exactly where the picture's slice segments end (decode_slice noted the rows; one segment: the
       // last CTU of the picture); inside a segment a substream ends with end_of_subset_one_bit
-      const bool seg_last = cx == cx1 - 1 && (cols > 1 ? (cy == g.cy1 - 1 && job.seg_end_sub[(size_t)sub]) : job.seg_end_row[(size_t)cy] != 0);
+      const bool seg_last = free_slices ? (cut & 4) != 0 : cx == cx1 - 1 && (cols > 1 ? (cy == g.cy1 - 1 && job.seg_end_sub[(size_t)sub]) : job.seg_end_row[(size_t)cy] != 0);
       const int end = c.terminate();
-      if (end != (seg_last ? 1 : 0)) return seg_last ? DEC_ERR_INVALID : DEC_ERR_UNSUPPORTED;      // (a segment that ends elsewhere: not whole CTU rows / tiles)
+      if (end != (seg_last ? 1 : 0)) return seg_last ? DEC_ERR_INVALID : (job.ambiguous_end ? DEC_SEG_ENDS_EARLY : DEC_ERR_UNSUPPORTED);      // (a segment that ends elsewhere: not whole CTU rows / tiles)
       if (!seg_last && cx == cx1 - 1 && (wpp || tile_ends_at(cy)) && !c.terminate()) return DEC_ERR_INVALID;   // end_of_subset_one_bit
     }
     if (job.early_dst) {
@@ -2498,7 +2649,7 @@ int Decoder::launch_gpu(PicJob &job)
   f.cb_qp_offset = (int8_t)job.pps.cb_qp_offset; f.cr_qp_offset = (int8_t)job.pps.cr_qp_offset;
   f.beta_offset = (int8_t)(2 * job.sh.beta_offset_div2); f.tc_offset = (int8_t)(2 * job.sh.tc_offset_div2);
   f.intra_direct = job.any_inter ? 1 : 0;                 // (a picture with inter blocks: few (CTU, plane) pairs hold intra blocks)
-  f.strong_intra = (uint8_t)job.sps->strong_intra; f.tiles = job.pps.tile_rows > 1 || job.pps.tile_cols > 1;
+  f.strong_intra = (uint8_t)job.sps->strong_intra; f.tiles = job.pps.tile_rows > 1 || job.pps.tile_cols > 1 || job.slice_qps.size() > 1;
   f.tq_bypass = (uint8_t)job.pps.tq_bypass;
   // scaling lists: the picture's factors (the PPS's lists when it carries any, else the SPS's) ride in the input block
   const std::vector<uint8_t> *sc = job.pps.scaling ? job.pps.scaling.get() : job.sps->scaling.get();

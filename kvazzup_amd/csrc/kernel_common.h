@@ -372,7 +372,7 @@ __device__ __forceinline__ bool borders_need_wave(IntraChain &ch, const IntraNei
     haveL = __builtin_amdgcn_readfirstlane(lds_load(&ch.left_loaded));
     if (need > haveL) uptoL = need;
   }
-  if (ry == 0 && b.nb_up) {
+  if (ry == 0 && (b.nb_up || b.nb_ur)) {                 // (decoder, several slices inside a tile: the block above-right may be the only one there is -- the row piece above is then copied with it, unused)
     const int lim = imin(lim_w, b.nb_ur ? 2 * S : S), need = imin(lim, rx + nt2);
     haveT = __builtin_amdgcn_readfirstlane(lds_load(&ch.top_loaded));
     if (need > haveT) uptoT = need;
@@ -685,6 +685,9 @@ enum { IB_FILT = 1,          // the filtered reference samples are used (8.4.4.2
        IB_PUBLISH = 4,       // progress `zu` is worth publishing before this block (a neighbour may be waiting for it)
        IB_LEVELS = 8, IB_TSKIP = 16,        // decoder: the block has levels; transform_skip_flag
        IB_EDGE_R = 64,       // the block holds samples of the CTU's right column: they also go, one byte per row, to the CTU's entry of the edge-column array -- the right neighbour reads its left border there in ONE transaction instead of one per picture line
+       IB_HOLE = 128,        // decoder, pictures of several slices inside a tile: the available reference samples are TWO runs, [lo, 2N - 1] (the left part; lo = 2N: none) and
+                             // [xf, hi] -- xf = 2N + 1: the slice begins with the coding tree block above, the corner sample belongs to another; xf = 3N + 1: it begins
+                             // with the block above-right (IntraBlk::xf holds the second run's start there: the decoder's chain has no use for a transform table)
        IB_EDGE = 32 };       // the block ends on the CTU's bottom row: that row is stored write-through (the CTUs below read it, and the corner) -- the only ones another workgroup ever reads: they are stored write-through as soon as the block is done, everything else goes to the picture with the CTU's final copy
 __device__ __forceinline__ IntraBlk wave_uniform(const IntraBlk *p)
 {
@@ -701,15 +704,17 @@ __device__ __forceinline__ IntraBlk wave_uniform(const IntraBlk *p)
 // scan order (the substitution process of 8.4.4.2.2 is a clamp of the scan index into [lo, hi]; the [1 2 1] filter takes its
 // neighbours over DPP); what the mode reads is then laid out in ws.R -- the scan-order array for planar and DC, ref[] with the
 // projected side samples for the angular modes (lanes fetch their entry from the lane that holds it: ds_bpermute).
-template <int L2>
+template <int L2, bool HOLES = false>
 __device__ __forceinline__ void wave_intra_predict(const uint8_t *pic, int P, IntraWaveScratch &ws, const IntraBlk &d, bool luma, int lane, int g, int c, int (&pred)[4])
 {
   constexpr int N = 1 << L2;
   const int rx = d.rx, ry = d.ry, lo = d.lo, hi = d.hi, mode = d.mode;
+  const bool hole = HOLES && (d.flags & IB_HOLE) != 0;      // (two available runs with a gap between them: a sample of the gap takes the last one of the run before it, 8.4.4.2.2)
   int v = 128, last = 128;
   if (hi >= lo) {
     auto at = [&](int i) -> int {
-      const int j = imin(imax(i, lo), hi);
+      int j = imin(imax(i, lo), hi);
+      if (hole && j < d.xf) j = lo < 2 * N ? imin(j, 2 * N - 1) : d.xf;
       const bool left = j < 2 * N;
       return (left ? ry + 2 * N - j : ry) * P + 16 + (left ? rx - 1 : rx + j - 2 * N - 1);
     };

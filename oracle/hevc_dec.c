@@ -890,6 +890,7 @@ static int decode_slice_data(orc_decoder *d, const uint8_t *data, size_t len)
     } else if (p->entropy_coding_sync_enabled && row_start) {
       int xt = ((cx + 1) << s->ctb_log2), yt = ((cy - 1) << s->ctb_log2);
       if (orc_available(&d->av, cx << s->ctb_log2, cy << s->ctb_log2, xt, yt)) memcpy(d->cabac.ctx, d->wpp_ctx, sizeof(d->wpp_ctx));
+      else if (first && sh->dependent_slice_segment && wc >= 2) memcpy(d->cabac.ctx, d->ds_ctx, sizeof(d->ds_ctx));    /* (9.3.1, the nesting of the 2nd edition on; HM: TDecSlice loads the segment-end state first, the row-start rule overrides it only when T is available) */
       else orc_cabac_init_contexts(d->cabac.ctx, init_type, sh->slice_qp);
       new_qg_row = 1;
     }
@@ -997,6 +998,18 @@ int orc_dec_decode_nal(orc_decoder *d, const uint8_t *data, size_t len, int64_t 
   return 0;
 }
 
+/* test aid: the side information of the picture finished last, per 4x4 luma block (raster, b4_w per row) -- returns the number of blocks */
+int orc_dec_debug_side(orc_decoder *d, int16_t *mv, int8_t *ref, uint8_t *pm, uint8_t *im, int8_t *qp)
+{
+  const orc_pic *p = d->last_finished;
+  if (!p) return 0;
+  const int n = p->b4_w * p->b4_h;
+  for (int i = 0; i < n; i++) {
+    mv[2 * i] = p->mvf[i].mv[0]; mv[2 * i + 1] = p->mvf[i].mv[1]; ref[i] = p->mvf[i].ref_idx;
+    pm[i] = p->pred_mode[i]; im[i] = p->intra_mode[i]; qp[i] = p->qp_y[i];
+  }
+  return n;
+}
 void orc_dec_hash_stats(orc_decoder *d, int *checked, int *mismatch) { if (checked) *checked = d->hash_checked; if (mismatch) *mismatch = d->hash_mismatch; }
 
 int orc_dec_get_frame(orc_decoder *d, orc_dec_frame *out)

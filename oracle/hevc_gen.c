@@ -172,11 +172,12 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   p->cu_qp_delta_enabled = c->qp_delta > 0; p->diff_cu_qp_delta_depth = c->qp_delta > 0 ? c->qp_delta - 1 : 0;
   if (c->chroma_qp_offsets) { p->cb_qp_offset = rrange(g, -4, 4); p->cr_qp_offset = rrange(g, -4, 4); p->slice_chroma_qp_offsets_present = rpct(g, 50); }
   p->entropy_coding_sync_enabled = c->wpp; p->loop_filter_across_slices = 1;
-  if (c->slices < 0 || c->slices > 2) c->slices = 0;
+  if (c->slices < 0 || c->slices > 3) c->slices = 0;
   if (c->tile_cols < 1) c->tile_cols = 1;
   if (c->tile_cols > wc) c->tile_cols = wc;
+  if (c->slices == 3) c->tile_cols = c->tile_rows = 1;                  /* (free slices: one tile) */
   if (c->tile_cols > 1 && c->slices == 1) c->slices = 0;
-  p->dependent_slice_segments_enabled = c->slices == 1;
+  p->dependent_slice_segments_enabled = c->slices == 1 || (c->slices == 3 && rpct(g, 60));
   p->num_tile_columns = 1; p->num_tile_rows = 1; p->uniform_spacing = 1;
   p->deblocking_filter_control_present = c->deblock_mode != 0;
   p->pps_deblocking_disabled = c->deblock_mode == 1;
@@ -204,6 +205,7 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   if (orc_pic_alloc(&g->side, cfg->width, cfg->height)) { free(g); return NULL; }
   memset(&g->av, 0, sizeof(g->av));
   g->av.pic_w = cfg->width; g->av.pic_h = cfg->height; g->av.ctb_log2 = c->ctb_log2; g->av.pic_w_ctbs = wc; g->av.ctb_tile = g->ctb_tile;
+  if (c->slices == 3) { g->ctb_slice = (int32_t *)calloc((size_t)wc * hc, sizeof(int32_t)); g->av.ctb_slice = g->ctb_slice; }
   g->sao = (orc_sao_params *)calloc((size_t)wc * hc, sizeof(orc_sao_params));
   g->log2_qg = c->ctb_log2 - p->diff_cu_qp_delta_depth;
   orc_bw_init(&g->au);
@@ -213,7 +215,7 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
 void orc_gen_close(orc_gen *g)
 {
   if (!g) return;
-  orc_pic_free(&g->side); free(g->ctb_tile); free(g->sao); orc_bw_free(&g->au); free(g);
+  orc_pic_free(&g->side); free(g->ctb_tile); free(g->ctb_slice); free(g->sao); orc_bw_free(&g->au); free(g);
 }
 void orc_gen_get_config(const orc_gen *g, orc_gen_config *out) { *out = g->cfg; }
 
@@ -666,6 +668,88 @@ static void draw_sao(orc_gen *g, orc_sao_params *p, const orc_sao_params *left, 
   /* identical to a merge candidate by accident: the writer would code a merge -- fine, same parameters */
 }
 
+/* cfg.slices == 3: slice segments that begin at ANY coding tree block (one tile): what encoders that cut slices by bytes or by block counts send (an MTU per
+ * slice), with independent slices of whole rows as a special case.  Every cut starts a new arithmetic codeword; an independent slice initialises the contexts,
+ * has its own slice_qp_delta and is a new slice for every availability rule (6.4.1: prediction, context selection, merge candidates, SAO merging stop at its
+ * border); a dependent segment goes on with the contexts the segment before it ended with -- unless it starts a CTB row under WPP, where 9.3.1 looks at the
+ * block above-right first.  With WPP a row start inside a segment is an entry point as ever. */
+static void write_free_slices(orc_gen *g, int nal)
+{
+  const orc_sps *s = &g->sps; const orc_pps *p = &g->pps; orc_slice_hdr *sh = &g->sh;
+  const int wc = s->pic_w_ctbs, hc = s->pic_h_ctbs, total = wc * hc, wpp = p->entropy_coding_sync_enabled, ctb = s->ctb_log2;
+  const int init_type = g->slice_is_intra ? 0 : (g->slice_is_b ? (sh->cabac_init_flag ? 1 : 2) : (sh->cabac_init_flag ? 2 : 1));
+  const int qpd0 = sh->slice_qp_delta;
+  orc_bitw *subs = (orc_bitw *)calloc((size_t)total + hc + 1, sizeof(orc_bitw));
+  uint8_t *cut = (uint8_t *)calloc((size_t)total + 1, 1);         /* 0 no segment starts at this block, 1 an independent slice, 2 a dependent segment */
+  int *seg_first = (int *)calloc((size_t)total + 2, sizeof(int)), *seg_addr = (int *)calloc((size_t)total + 2, sizeof(int)), *seg_qpd = (int *)calloc((size_t)total + 2, sizeof(int));
+  int nseg = 0, nsub = 0;
+  const int target = rrange(g, 1, 7);                             /* cuts per picture, about; three in ten wait for the next row start */
+  cut[0] = 1;
+  for (int a = 1, snap = 0; a < total; a++) {
+    int c = 0;
+    if ((int)(rnd(g) % (uint32_t)total) < target) { if (rpct(g, 30) && a % wc) snap = 1; else c = 1; }
+    if (a % wc == 0 && (snap || rpct(g, 6))) { c = 1; snap = 0; }
+    if (c) cut[a] = (uint8_t)((p->dependent_slice_segments_enabled && rpct(g, 50)) ? 2 : 1);
+  }
+  orc_ctx saved[CTX_COUNT];
+  int slice_addr = 0, slice_qp = sh->slice_qp;
+  orc_pic_reset_side(&g->side);
+  memset(&g->c, 0, sizeof(g->c));
+  for (int a = 0; a < total; a++) {
+    const int cx = a % wc, cy = a / wc;
+    if (cut[a]) {
+      if (cut[a] == 1) {
+        slice_addr = a;
+        if (a > 0) { slice_qp = sh->slice_qp + rrange(g, -2, 2); if (slice_qp < 0) slice_qp = 0; if (slice_qp > 51) slice_qp = 51; }
+      }
+      seg_first[nseg] = nsub; seg_addr[nseg] = a; seg_qpd[nseg] = slice_qp - p->init_qp; nseg++;
+    }
+    g->ctb_slice[a] = slice_addr;
+    if (cut[a] || (wpp && cx == 0)) {
+      orc_bw_init(&subs[nsub]);
+      orc_cenc_start(&g->c, &subs[nsub]);
+      nsub++;
+      if (cut[a] == 1) orc_cabac_init_contexts(g->c.ctx, init_type, slice_qp);
+      else if (wpp && cx == 0) {
+        if (orc_available(&g->av, cx << ctb, cy << ctb, (cx + 1) << ctb, (cy - 1) << ctb)) memcpy(g->c.ctx, saved, sizeof(saved));
+        else if (!cut[a] || wc < 2) orc_cabac_init_contexts(g->c.ctx, init_type, slice_qp);
+        /* (a dependent segment whose above-right block is not available: the contexts the previous segment ended with -- still in g->c.ctx; pictures one block
+         * wide initialise, as HM does) */
+      }
+    }
+    if (sh->sao_luma || sh->sao_chroma) {
+      orc_sao_params *sp = &g->sao[a];
+      const orc_sao_params *left = (cx > 0 && g->ctb_slice[a - 1] == slice_addr) ? sp - 1 : NULL, *up = (cy > 0 && g->ctb_slice[a - wc] == slice_addr) ? sp - wc : NULL;
+      draw_sao(g, sp, left, up, sh->sao_luma, sh->sao_chroma);
+      orc_sao_write(&g->c, sp, left, up, sh->sao_luma, sh->sao_chroma);
+    }
+    gen_coding_quadtree(g, cx << ctb, cy << ctb, ctb, 0);
+    if (wpp && cx == 1) memcpy(saved, g->c.ctx, sizeof(saved));
+    const int seg_end = a + 1 == total || cut[a + 1], sub_end = wpp && cx == wc - 1;
+    orc_cenc_terminate(&g->c, seg_end);                           /* end_of_slice_segment_flag */
+    if (!seg_end && sub_end) orc_cenc_terminate(&g->c, 1);        /* end_of_subset_one_bit */
+    if (seg_end || sub_end) orc_bw_align_zero(g->c.bw);
+  }
+  seg_first[nseg] = nsub;
+  orc_bitw hdr;
+  for (int k = 0; k < nseg; k++) {
+    const int s0 = seg_first[k], n = seg_first[k + 1] - s0;
+    uint32_t *ep = (uint32_t *)calloc((size_t)n, sizeof(uint32_t));
+    sh->first_slice_segment_in_pic = k == 0; sh->slice_segment_address = seg_addr[k]; sh->dependent_slice_segment = cut[seg_addr[k]] == 2;
+    sh->slice_qp_delta = seg_qpd[k]; sh->slice_qp = p->init_qp + seg_qpd[k];
+    sh->num_entry_points = n - 1; sh->entry_point_offset = ep;
+    for (int i = 0; i < n - 1; i++) ep[i] = (uint32_t)orc_escaped_size(subs[s0 + i].buf, subs[s0 + i].len);
+    orc_bw_init(&hdr);
+    orc_write_slice_header(&hdr, sh, s, p, nal);
+    for (int i = 0; i < n; i++) { orc_bw_bytes(&hdr, subs[s0 + i].buf, subs[s0 + i].len); orc_bw_free(&subs[s0 + i]); }
+    orc_write_nal(&g->au, nal, 0, hdr.buf, hdr.len, 1);
+    orc_bw_free(&hdr); free(ep);
+  }
+  sh->slice_qp_delta = qpd0; sh->slice_qp = p->init_qp + qpd0;
+  free(subs); free(cut); free(seg_first); free(seg_addr); free(seg_qpd);
+  sh->entry_point_offset = NULL;
+}
+
 /* ------------------------------------------------------------------ one picture */
 static void write_picture(orc_gen *g, int idr, int write_ps)
 {
@@ -767,6 +851,7 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
   if (s->sao_enabled) { sh->sao_luma = rpct(g, 80); sh->sao_chroma = rpct(g, 80); }
   /* ---- slice data: one substream per CTU row with WPP (or with a slice segment per row), else one per tile */
   const int wpp = p->entropy_coding_sync_enabled, slices = g->cfg.slices;
+  if (slices == 3) { write_free_slices(g, nal); return; }
   const int row_subs = wpp || slices == 1, cols = g->ncols_t;
   const int nsub = (row_subs ? hc : g->nrows_t) * cols;
   subs = (orc_bitw *)calloc((size_t)nsub, sizeof(orc_bitw));

@@ -40,7 +40,9 @@ typedef struct {
   int big_mvd;                /* 1 % of the vector differences are huge (reference blocks far outside the picture) */
   int slices;                 /* slice segments per picture, the two ways Kvazaar cuts them (uvgComm video/Slices, kvazaarfilter.cpp:205-215): 0 (also -1) one
                                * slice; 1 = a DEPENDENT slice segment per CTU row (kvazaar slices=wpp; here with or without WPP); 2 = an independent
-                               * slice per tile (kvazaar slices=tiles; one slice when there are no tiles) */
+                               * slice per tile (kvazaar slices=tiles; one slice when there are no tiles); 3 = FREE slices (one tile): segments that begin at
+                               * any coding tree block, independent slices (own slice_qp_delta) and -- six streams in ten -- dependent segments mixed, with or
+                               * without WPP: what an encoder that cuts slices by bytes or block counts sends */
   int tile_cols;              /* tile columns (uniform spacing), 1 (also -1) = none; with columns the slice forms are 0 and 2 */
   int tq_bypass;              /* probability (%) of cu_transquant_bypass_flag = 1; > 0 sets transquant_bypass_enabled_flag (-1 = 0: existing seeds keep their streams) */
   int scaling_lists;          /* 0 (also -1) scaling_list_enabled_flag = 0; 1 enabled with the default lists; 2 lists in the SPS; 3 default in the SPS, lists in the PPS; 4 both */

@@ -45,7 +45,7 @@ def probe(nals, threads):
     assert lib.kvzx_decoder_set_parse_only(h, threads) == 1
     assert lib.libOpenHevcStartDecoder(h) == 0
     try:
-        for t, n in enumerate(nals):
+        for t, n in enumerate(list(nals) + [bytes([0, 0, 0, 1, 36 << 1, 1])]):      # (end of sequence: a picture of free slices is complete when its access unit has ended)
             rc = lib.libOpenHevcDecode(h, n, len(n), t)
             assert rc == 0, "NAL %d: libOpenHevcDecode returned %d (error %d)" % (t, rc, lib.kvzx_decoder_last_error(h))
         out = (C.c_uint64 * 5)()

@@ -279,8 +279,7 @@ def parse_pps(rbsp):
     r = Bits(rbsp)
     r.u(16)
     p = {"id": r.ue(), "sps": r.ue()}
-    if r.u(1):
-        raise ValueError("dependent slices")
+    p["dep"] = r.u(1)                        # dependent_slice_segments_enabled_flag
     p["output_flag"] = r.u(1)
     p["extra_bits"] = r.u(3)
     p["sign_hiding"] = r.u(1)
@@ -535,6 +534,7 @@ class Decoder:
         self.sps = {}
         self.pps = {}
         self.dpb = []
+        self.cur = None         # the picture whose slice segments are still arriving (its SliceDecoder)
         self.prev_poc_tid0 = 0
         self.out = []
         self.cvs = 0            # coded video sequences started so far
@@ -565,12 +565,27 @@ class Decoder:
         r.u(16)
         irap = 16 <= nal_type <= 23
         idr = nal_type in (19, 20)
-        if not r.u(1):
-            raise ValueError("several slices per picture")
+        first = r.u(1)
         if irap:
             r.u(1)
         pps = self.pps[r.ue()]
         sps = self.sps[pps["sps"]]
+        dependent, address = 0, 0
+        if not first:                                              # 7.3.6.1: a further slice segment of the picture under way
+            if pps["dep"]:
+                dependent = r.u(1)
+            wc, hc = -(-sps["w"] >> sps["ctb"]), -(-sps["h"] >> sps["ctb"])
+            address = r.u(max(1, (wc * hc - 1).bit_length()))
+            if self.cur is None or pps["tile_rows"] > 1 or pps["tile_cols"] > 1:
+                raise ValueError("slice segment without its picture, or several slices in a picture with tiles")
+        if dependent:
+            sh = dict(self.cur.sh)                                 # everything but the entry points is the slice's first segment's
+            rps, poc = None, sh["poc"]
+        else:
+            sh, rps, poc = self.slice_header_body(r, sps, pps, nal_type, idr)
+        self.finish_header_and_decode(r, rbsp, nal, nal_type, idr, first, dependent, address, sps, pps, sh, rps, poc)
+
+    def slice_header_body(self, r, sps, pps, nal_type, idr):
         r.u(pps["extra_bits"])
         slice_type = r.ue()          # 0 B, 1 P, 2 I
         if pps["output_flag"]:
@@ -673,7 +688,11 @@ class Decoder:
                 sh["beta"] = 2 * r.se()
                 sh["tc"] = 2 * r.se()
         if pps["lf_slices"] and (sh["sao_luma"] or sh["sao_chroma"] or not sh["dbk_disabled"]):
-            r.u(1)
+            if not r.u(1):
+                raise ValueError("no loop filter across slices")
+        return sh, rps, poc
+
+    def finish_header_and_decode(self, r, rbsp, nal, nal_type, idr, first, dependent, address, sps, pps, sh, rps, poc):
         entry = []
         if pps["tiles"] or pps["wpp"]:
             n = r.ue()
@@ -707,6 +726,20 @@ class Decoder:
             for e in entry:
                 acc += e
                 starts.append(rbsp_before[acc] - hdr)
+        if not first:
+            # a further segment of the picture under way (one tile): an independent slice brings its own header (its SliceQpY), the picture's state goes on
+            sl = self.cur
+            if not dependent:
+                for k in ("type", "nref", "nref1", "tmvp", "sao_luma", "sao_chroma", "cabac_init", "max_merge", "dbk_disabled", "beta", "tc", "cb_off", "cr_off", "col_idx", "col_l0", "mvd_l1_zero"):
+                    if sh[k] != sl.sh[k]:
+                        raise ValueError("slices of one picture with different " + k)
+                sh["poc"] = poc
+                sl.sh = sh
+            if sl.run_segment(data, starts, address, dependent):
+                self.picture_done(sl, sps, nal_type)
+            return
+        if self.cur is not None:
+            raise ValueError("a picture's slice segments did not complete")
         # ---- reference picture set (8.3.2) and list (8.3.4)
         for p in self.dpb:
             p.is_ref = False
@@ -731,7 +764,20 @@ class Decoder:
         pic.poc = poc
         sh["poc"] = poc
         sl = SliceDecoder(self, sps, pps, sh, pic, refs, data, starts)
-        sl.run()
+        if pps["tile_rows"] > 1 or pps["tile_cols"] > 1:
+            sl.run()                                               # tiles: one slice per picture
+            sl.loop_filters()
+            self.picture_done(sl, sps, nal_type, filtered=True)
+        else:
+            self.cur = sl
+            if sl.run_segment(data, starts, 0, 0):
+                self.picture_done(sl, sps, nal_type)
+
+    def picture_done(self, sl, sps, nal_type, filtered=False):
+        if not filtered:
+            sl.loop_filters()
+        self.cur = None
+        pic, poc = sl.pic, sl.sh["poc"]
         self.dpb.append(pic)
         if not (nal_type <= 14 and (nal_type & 1) == 0) and not (6 <= nal_type <= 9):
             self.prev_poc_tid0 = poc           # TemporalId 0 assumed; RASL / RADL / sub-layer non-reference pictures excluded
@@ -768,6 +814,9 @@ class SliceDecoder:
         self.edge_v = np.zeros((b4h, b4w), np.int8)                         # 1: PU edge, 2: TU edge on the left side of this 4x4
         self.edge_h = np.zeros((b4h, b4w), np.int8)
         self.sao = {}
+        self.c = None
+        self.ctb_slice = [-1] * (self.wc * self.hc)                         # SliceAddrRs of every coding tree block decoded so far
+        self.slice_addr, self.ctbs_done, self.wpp_saved, self.ds_saved = 0, 0, None, None
         # tile rows (6.5.1)
         tr = pps["tile_rows"]
         if pps["uniform"]:
@@ -806,6 +855,8 @@ class SliceDecoder:
             return False
         if self.tile_of_row[yn >> self.ctb_log2] != self.tile_of_row[yc >> self.ctb_log2] or self.tile_of_col[xn >> self.ctb_log2] != self.tile_of_col[xc >> self.ctb_log2]:
             return False
+        if self.ctb_slice[(yn >> self.ctb_log2) * self.wc + (xn >> self.ctb_log2)] != self.ctb_slice[(yc >> self.ctb_log2) * self.wc + (xc >> self.ctb_log2)]:
+            return False                                                    # another slice (free slices, one tile; run() leaves every entry at -1)
         return self.zaddr(xn, yn) <= self.zaddr(xc, yc) and self.cu_pred[yn >> self.sps["min_cb"], xn >> self.sps["min_cb"]] >= 0
 
     # ------------------------------------------------------------------------------------------- slice data (7.3.8.1)
@@ -861,10 +912,64 @@ class SliceDecoder:
                     break
             if done:
                 break
-        if not sh["dbk_disabled"]:
+
+    def loop_filters(self):
+        if not self.sh["dbk_disabled"]:
             self.deblock()
-        if sh["sao_luma"] or sh["sao_chroma"]:
+        if self.sh["sao_luma"] or self.sh["sao_chroma"]:
             self.apply_sao()
+
+    # ------------------------------------------------------------------------------------------- slice data of ONE segment of a one-tile picture
+    def run_segment(self, data, starts, address, dependent):
+        """the coding tree blocks from `address` on until end_of_slice_segment_flag; True when the picture is complete.  9.3.1: an independent slice initialises the
+        context variables (with its SliceQpY); under WPP a CTB row starts from the states behind the second block of the row above when that block is AVAILABLE
+        (6.4.1: same slice), else -- a dependent segment that begins there -- from the states the previous segment ended with, else afresh; a dependent segment
+        that begins anywhere else goes on with the previous segment's states.  8.6.1: the QP predictor starts again with a slice and with a CTB row under WPP."""
+        sh, pps, wc = self.sh, self.pps, self.wc
+        total = wc * self.hc
+        init_type = 0 if sh["intra"] else ((1 if sh["cabac_init"] else 2) if sh["b"] else (2 if sh["cabac_init"] else 1))      # 9.3.2.2
+        if self.c is None:
+            self.c = Cabac(self.t, data, init_type, sh["qp"])
+        c = self.c
+        c.init_type, c.qp = init_type, sh["qp"]
+        c.start(data)
+        if not dependent:
+            self.slice_addr = address
+        a, sub, first = address, 0, True
+        while True:
+            if a >= total:
+                raise ValueError("slice segment runs past the picture")
+            cx, cy = a % wc, a // wc
+            self.ctb_slice[a] = self.slice_addr
+            if first and not dependent:
+                c.init_contexts()
+                self.last_qp = sh["qp"]
+            elif pps["wpp"] and cx == 0:
+                if cy > 0 and wc >= 2 and self.ctb_slice[a - wc + 1] == self.slice_addr:
+                    c.load(self.wpp_saved)
+                elif first and dependent and wc >= 2:
+                    c.load(self.ds_saved)
+                else:
+                    c.init_contexts()
+                self.last_qp = sh["qp"]
+            elif first and dependent:
+                c.load(self.ds_saved)
+            first = False
+            self.ctu(cx, cy)
+            end = c.terminate()
+            if pps["wpp"] and cx == 1:
+                self.wpp_saved = c.save()
+            a += 1
+            self.ctbs_done += 1
+            if end:
+                self.ds_saved = c.save()
+                break
+            if pps["wpp"] and a % wc == 0:
+                if not c.terminate():
+                    raise ValueError("end_of_subset_one_bit")
+                sub += 1
+                c.start(data[starts[sub]:] if sub < len(starts) else data[c.end_substream():])
+        return self.ctbs_done >= total
 
     def ctu(self, cx, cy):
         x0, y0 = cx << self.ctb_log2, cy << self.ctb_log2
@@ -875,8 +980,9 @@ class SliceDecoder:
     # ------------------------------------------------------------------------------------------- SAO syntax (7.3.8.3)
     def parse_sao(self, cx, cy):
         c = self.c
-        left = cx > 0 and self.tile_of_col[cx - 1] == self.tile_of_col[cx]
-        up = cy > 0 and self.tile_of_row[cy - 1] == self.tile_of_row[cy]
+        a = cy * self.wc + cx
+        left = cx > 0 and self.tile_of_col[cx - 1] == self.tile_of_col[cx] and self.ctb_slice[a - 1] == self.ctb_slice[a]
+        up = cy > 0 and self.tile_of_row[cy - 1] == self.tile_of_row[cy] and self.ctb_slice[a - self.wc] == self.ctb_slice[a]
         if left and c.bin("sao_merge"):
             self.sao[(cx, cy)] = self.sao[(cx - 1, cy)]
             return

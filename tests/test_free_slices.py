@@ -1,0 +1,73 @@
+"""CPU: pictures of FREE slices (round 6) -- slice segments that begin at any coding tree block, independent slices and dependent segments mixed, with and without
+WPP (oracle/hevc_gen.c, slices = 3).  The synthesiser and the checker's decoder agree on every stream (a wrong context state or availability anywhere ends in a
+parse error or a wrong picture count); the PRODUCT's parser (parse-only hook: csrc/decoder.hip's assembly of a picture from its segments, the take-back of a picture
+whose first segment only looked whole, its slice-data parser) accepts the same streams and produces the same records with one row thread and with four.  The
+pictures themselves are compared on the GPU box (tests/test_gpu_slices.py) and by the second decoder (tests/test_python_decoder.py::test_free_slices)."""
+import pytest
+
+import orc
+import parser_probe as PP
+
+
+def stream(seed, wpp, ctb_log2, n=5, w=192, h=128, **kw):
+    g = orc.OracleGen(w, h, seed=seed, slices=3, wpp=wpp, ctb_log2=ctb_log2, **kw)
+    aus = [g.picture() for _ in range(n)]
+    g.close()
+    return aus
+
+
+@pytest.mark.parametrize("ctb_log2", [6, 4])
+@pytest.mark.parametrize("wpp", [0, 1])
+def test_checker_decodes_what_the_synthesiser_writes(wpp, ctb_log2):
+    segments = 0
+    for seed in range(1, 25):
+        aus = stream(seed, wpp, ctb_log2)
+        od = orc.OracleDecoder()
+        n = sum(len(od.decode_au(au, t)) for t, au in enumerate(aus)) + len(od.flush())
+        od.close()
+        assert n == len(aus), seed
+        segments += sum(1 for au in aus for nal in orc.split_nals(au) if ((nal[4] >> 1) & 63) < 32)
+    assert segments > 24 * 5 * 2                                   # (more than two segments per picture on average)
+
+
+@pytest.mark.parametrize("ctb_log2", [6, 5, 4])
+@pytest.mark.parametrize("wpp", [0, 1])
+def test_product_parser_accepts_them_with_one_and_four_row_threads(wpp, ctb_log2):
+    for seed in range(1, 13):
+        nals = [n for au in stream(seed, wpp, ctb_log2) for n in orc.split_nals(au)]
+        a, b = PP.probe(nals, 1), PP.probe(nals, 4)
+        assert a == b and a["pictures"] == 5, (seed, a, b)
+
+
+def test_a_stream_that_turns_to_free_slices_and_back():
+    """one decoder: whole pictures, then free slices (the first such picture is taken back when its first segment -- submitted as the whole picture -- ends early),
+    Kvazaar's dependent segment per CTU row, whole pictures again: every picture is parsed, none twice"""
+    nals = []
+    for k, slices in enumerate((0, 3, 1, 3, 0)):
+        g = orc.OracleGen(192, 128, seed=60 + k, slices=slices, wpp=k & 1, intra_period=4)
+        for _ in range(4):
+            nals += list(orc.split_nals(g.picture()))
+        g.close()
+    assert PP.probe(nals, 1)["pictures"] == 20 and PP.probe(nals, 3)["pictures"] == 20
+
+
+def test_a_lost_segment_is_an_error_not_a_wrong_picture():
+    """the second of a picture's segments removed: where the first ends is then where the THIRD begins -- the parser finds end_of_slice_segment_flag elsewhere"""
+    import ctypes as C
+    lib = PP._lib()
+    for seed in range(1, 30):
+        aus = stream(seed, 0, 6, n=1)
+        nals = list(orc.split_nals(aus[0]))
+        vcl = [i for i, n in enumerate(nals) if ((n[4] >> 1) & 63) < 32]
+        if len(vcl) < 3:
+            continue
+        del nals[vcl[1]]
+        h = lib.libOpenHevcInit(1, 2)
+        assert lib.kvzx_decoder_set_parse_only(h, 1) == 1 and lib.libOpenHevcStartDecoder(h) == 0
+        rcs = [lib.libOpenHevcDecode(h, n, len(n), 0) for n in nals + [bytes([0, 0, 0, 1, 36 << 1, 1])]]
+        out = (C.c_uint64 * 5)()
+        lib.kvzx_decoder_parse_probe_stats(h, out, None)
+        lib.libOpenHevcClose(h)
+        assert int(out[0]) == 0 and lib is not None, (seed, rcs)      # no picture was booked
+        return
+    pytest.skip("no picture with three segments among the seeds")

@@ -268,3 +268,20 @@ def test_coding_tree_blocks_of_32_and_16_samples(ctb_log2, seed, kw):
     aus = [g.picture() for _ in range(5)]
     g.close()
     compare(aus)
+
+
+@pytest.mark.parametrize("wpp", [0, 1])
+@pytest.mark.parametrize("seed,kw", [(3, dict(sao=1, intra_in_p=30, nxn_intra=1)),
+                                     (7, dict(qp_delta=2, intra_in_p=30, tmvp=1, num_refs=3, all_part_modes=1, amp=1)),
+                                     (11, dict(intra_period=1, strong_intra=0, chroma_modes=1)),
+                                     (13, dict(ctb_log2=4, sao=1, intra_in_p=20, cabac_init=1)),
+                                     (19, dict(ctb_log2=5, qp_delta=3, chroma_qp_offsets=1, deblock_mode=2))])
+def test_free_slices(wpp, seed, kw):
+    """round 6: slice segments that begin at any coding tree block, independent slices (own slice_qp_delta) and dependent segments mixed (oracle/hevc_gen.c,
+    slices = 3) -- availability by slice (prediction, context selection, merge candidates, SAO merging), the context variables at the start of a segment and of
+    a CTB row under WPP (9.3.1), the QP predictor per slice: the two independently written decoders must agree before the HIP decoder is held to either"""
+    g = orc.OracleGen(200, 136, seed=seed, slices=3, wpp=wpp, **kw)
+    aus = [g.picture() for _ in range(4)]
+    g.close()
+    assert max(sum(1 for n in orc.split_nals(au) if ((n[4] >> 1) & 63) < 32) for au in aus) > 1      # (more than one slice segment in some picture)
+    compare(aus)

@@ -2327,7 +2327,10 @@ int Decoder::queue_download(PicJob &job)
   return hipEventRecord(job.dl_done, stream_dl_) == hipSuccess ? 0 : DEC_ERR_GPU;
 }
 
-// frame-threaded download mode: start the copy of every queued picture whose kernels have finished (oldest first)
+// frame-threaded download mode: start the copy of every queued picture whose kernels have finished (oldest first).  (Queueing the copy at launch instead, behind
+// the picture's event on the download stream, was measured in round 6 and HALVES the host-boundary rate -- 3 200 against 6 290 frames/s at 1080p, 1 060 against
+// 1 995 at 4K: hipMemcpyAsync to the host behind an unresolved hipStreamWaitEvent holds the calling thread, 135 ms of launches instead of 22 per 384 pictures;
+// profiles/r06_dl_at_launch_ab.txt.)
 int Decoder::start_ready_downloads()
 {
   if (!download_) return 0;

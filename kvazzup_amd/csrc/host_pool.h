@@ -41,6 +41,8 @@ template <class Query> inline bool nap_until(Query &&done, int nap_us = 25)
   // (a thread's sleeps are rounded up by its timer slack, 50 us by default -- three times the nap; 2 us makes a nap a nap)
   static thread_local const bool slack_set = (prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0), true);
   (void)slack_set;
+  static const int nap_env = [] { const char *e = getenv("KVAZZUP_AMD_NAP_US"); return e ? atoi(e) : 0; }();      // (measurement aid)
+  if (nap_env > 0) nap_us = nap_env;
   for (;;) {
     const int r = done();                    // 1 done, 0 not yet, < 0 error
     if (r) return r > 0;

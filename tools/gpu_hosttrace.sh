@@ -40,6 +40,18 @@ for s, e, n, b in ev:
     a = st[key]; a[0] += 1; a[1] += e - s; a[2] += b; a[3] = max(a[3], e - s)
 for k, a in sorted(st.items(), key=lambda kv: -kv[1][1]):
     print("%-44s n %5d  avg %8.1f us  max %8.1f us  total %7.2f ms  %s" % (k, a[0], a[1] / a[0] / 1e3, a[3] / 1e3, a[1] / 1e6, ("%.1f GB/s" % (a[2] / a[1])) if a[2] else ""))
+# do the copy engines run side by side?  sum of the copies' durations against the time at least one copy runs, per direction and together
+def union(iv):
+    iv = sorted(iv); tot = 0; cs, ce = None, None
+    for s, e in iv:
+        if ce is None or s > ce:
+            if ce is not None: tot += ce - cs
+            cs, ce = s, e
+        else: ce = max(ce, e)
+    return tot + ((ce - cs) if ce is not None else 0)
+h2d = [(s, e) for s, e, n, b in ev if n.startswith("C ") and "HOST_TO_DEV" in n]; d2h = [(s, e) for s, e, n, b in ev if n.startswith("C ") and "DEVICE_TO_HO" in n]
+print("copies: H2D sum %.2f ms union %.2f ms | D2H sum %.2f ms union %.2f ms | both: sum %.2f ms union %.2f ms (window %.2f ms)"
+      % (sum(e - s for s, e in h2d) / 1e6, union(h2d) / 1e6, sum(e - s for s, e in d2h) / 1e6, union(d2h) / 1e6, sum(e - s for s, e in h2d + d2h) / 1e6, union(h2d + d2h) / 1e6, (t1 - t0) / 1e6))
 # a 600 us excerpt from the middle of the window, as a timeline
 mid = t0 + (t1 - t0) * 3 // 4
 print("--- timeline excerpt (us from the excerpt's start)")

@@ -7,7 +7,7 @@
 // intra prediction, dequantisation + inverse transforms, reconstruction, deblocking, SAO (dec_kernels.hip).
 //
 // Supported streams: what a Main-profile encoder in a video call produces and OpenHEVC would be asked to decode -- 8-bit 4:2:0,
-// CTB 64 (Kvazaar's fixed geometry), 32 or 16 / minimum CB 8 / transform blocks 4..min(32, CTB), coded sizes that are multiples of 8, I, P and B
+// CTB 64 (Kvazaar's fixed geometry), 32 or 16 / minimum CB 8 (Kvazaar's), 16 or 32 / transform blocks 4..min(32, CTB), coded sizes that are multiples of 8, I, P and B
 // slices (both reference lists, bi-prediction, pictures handed out in POC order), every CU size and partitioning (AMP included), intra CUs in P pictures, NxN intra, all chroma
 // prediction modes, transform trees, several reference pictures (RPS in the SPS or the slice header, inter RPS prediction),
 // temporal motion vector prediction, merge levels, cu_qp_delta at any quantisation-group size, chroma QP offsets, sign data
@@ -17,7 +17,7 @@
 // independent slice per tile) and -- one-tile pictures -- segments that begin at ANY coding tree block, independent slices (own SliceQpY) and dependent
 // segments mixed (an MTU per slice, N row groups: PicJob::ctb_cut).  Rejected with a negative return value (kvzx_decoder_last_error): several slices
 // inside a tile of a picture with tiles, slices of one picture that differ in more than SliceQpY, loop filters switched off across slices or tiles,
-// long-term references, PCM, constrained intra prediction, minimum CB 16, > 255 slices in a picture.
+// long-term references, PCM, constrained intra prediction, > 255 slices in a picture.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -54,7 +54,8 @@ struct DecSps {
   uint32_t fps_num = 0, fps_den = 0;
   int num_reorder = 0;                // sps_max_num_reorder_pics of the highest sub-layer: pictures that may precede a picture in decoding order and follow it in output order
   int strong_intra = 0, sao = 0, tmvp = 0, amp = 0, th_depth_inter = 0, th_depth_intra = 0;
-  int ctb_log2 = 6;                   // CtbLog2SizeY: 6 (every Kvazaar stream), 5 or 4 (round 6: other encoders' streams); MinCbLog2SizeY 3, transform blocks 4 .. min(32, CTB)
+  int ctb_log2 = 6;                   // CtbLog2SizeY: 6 (every Kvazaar stream), 5 or 4 (round 6: other encoders' streams); transform blocks 4 .. min(32, CTB)
+  int min_cb_log2 = 3;                // MinCbLog2SizeY: 3 (every Kvazaar stream), 4 or 5
   // scaling_list_enabled_flag: the scaling factors (dec_frame.h KVZ_SCALING_BYTES) of the SPS's lists -- the default ones (Tables 7-5 / 7-6) without
   // sps_scaling_list_data; NULL: flat.  What uvgComm's "scaling list" checkbox switches on in a peer's Kvazaar (kvazaarfilter.cpp:235-242).
   std::shared_ptr<const std::vector<uint8_t>> scaling;

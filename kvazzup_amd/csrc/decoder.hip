@@ -377,7 +377,7 @@ struct SliceParser {
   Decoder::PicJob &job; Decoder::SubOut &out;
   const DecSps &sps; const DecPps &pps; const Decoder::SliceHdr &sh;
   CabacDec c;
-  const int w, h, b4w, b8w, ctbl, wc, hc;      // ctbl: CtbLog2SizeY; wc, hc: the picture in coding tree blocks
+  const int w, h, b4w, b8w, ctbl, mincb, wc, hc;      // ctbl: CtbLog2SizeY; mincb: MinCbLog2SizeY (3, 4 or 5); wc, hc: the picture in coding tree blocks
   B4Rec *b4; uint8_t *pm, *ctd, *im;     // pm, ctd: per 8x8 (the minimum coding block); im: per 4x4 (NxN parts)
   int ref_y0 = -(1 << 30), ref_y1 = 1 << 30;                              // band mode: the luma rows of a reference picture this decoder holds (the picture's outer edges open)
   int tile_y0 = 0, tile_y1 = 1 << 30, tile_x0 = 0, tile_x1 = 1 << 30;    // luma rows / columns of the tile being parsed: nothing outside is available (other tiles may be parsed concurrently)
@@ -391,7 +391,7 @@ struct SliceParser {
   uint32_t ctu_intra_mask = 0;
 
   SliceParser(Decoder::PicJob &j, Decoder::SubOut &o, int pw)
-      : job(j), out(o), sps(*j.sps), pps(j.pps), sh(j.sh), w(j.sps->width), h(j.sps->height), b4w(pw / 4), b8w(pw / 8), ctbl(j.sps->ctb_log2), wc((j.sps->width + (1 << j.sps->ctb_log2) - 1) >> j.sps->ctb_log2),
+      : job(j), out(o), sps(*j.sps), pps(j.pps), sh(j.sh), w(j.sps->width), h(j.sps->height), b4w(pw / 4), b8w(pw / 8), ctbl(j.sps->ctb_log2), mincb(j.sps->min_cb_log2), wc((j.sps->width + (1 << j.sps->ctb_log2) - 1) >> j.sps->ctb_log2),
         hc((j.sps->height + (1 << j.sps->ctb_log2) - 1) >> j.sps->ctb_log2), b4(j.b4), pm(j.pred_mode.data()), ctd(j.ct_depth.data()), im(j.intra_mode.data())
   { log2_qg = ctbl - pps.qp_delta_depth; }
 
@@ -913,10 +913,14 @@ struct SliceParser {
     } else {
       cu_pred_mode = PM_INTRA;
       if (!sh.is_intra) cu_pred_mode = c.bin(CTX_PRED_MODE) ? PM_INTRA : PM_INTER;
-      if (cu_pred_mode != PM_INTRA || log2cb == 3) {
+      if (cu_pred_mode != PM_INTRA || log2cb == mincb) {
         if (cu_pred_mode == PM_INTRA) part_mode = c.bin(CTX_PART_MODE) ? PART_2Nx2N : PART_NxN;
         else if (c.bin(CTX_PART_MODE)) part_mode = PART_2Nx2N;
-        else if (log2cb == 3) part_mode = c.bin(CTX_PART_MODE + 1) ? PART_2NxN : PART_Nx2N;            // (NxN inter is not allowed at 8x8)
+        else if (log2cb == mincb) {                          // 9.3.3.7 at the minimum size: 01 2NxN, 00 Nx2N at 8x8 (no NxN there); above it 01, 001, 000 = NxN
+          if (c.bin(CTX_PART_MODE + 1)) part_mode = PART_2NxN;
+          else if (log2cb == 3) part_mode = PART_Nx2N;
+          else part_mode = c.bin(CTX_PART_MODE + 2) ? PART_Nx2N : PART_NxN;
+        }
         else if (!sps.amp) part_mode = c.bin(CTX_PART_MODE + 1) ? PART_2NxN : PART_Nx2N;
         else {
           const int horiz = c.bin(CTX_PART_MODE + 1);
@@ -974,6 +978,9 @@ struct SliceParser {
           case PART_2NxnU: prediction_unit(x0, y0, n, x0, y0, n, q, 0, false, &mf); prediction_unit(x0, y0, n, x0, y0 + q, n, n - q, 1, false, &mf); break;
           case PART_2NxnD: prediction_unit(x0, y0, n, x0, y0, n, n - q, 0, false, &mf); prediction_unit(x0, y0, n, x0, y0 + n - q, n, q, 1, false, &mf); break;
           case PART_nLx2N: prediction_unit(x0, y0, n, x0, y0, q, n, 0, false, &mf); prediction_unit(x0, y0, n, x0 + q, y0, n - q, n, 1, false, &mf); break;
+          case PART_NxN:                                       // (a minimum coding block above 8 samples: four square prediction blocks in z-order)
+            for (int k = 0; k < 4; k++) prediction_unit(x0, y0, n, x0 + (k & 1) * hh, y0 + (k >> 1) * hh, hh, hh, k, false, &mf);
+            break;
           default: prediction_unit(x0, y0, n, x0, y0, n - q, n, 0, false, &mf); prediction_unit(x0, y0, n, x0 + n - q, y0, q, n, 1, false, &mf); break;     // nRx2N
         }
         if (!(part_mode == PART_2Nx2N && merge_2nx2n)) rqt_root_cbf = c.bin(CTX_RQT_ROOT_CBF);
@@ -1002,10 +1009,10 @@ struct SliceParser {
     if (err) return;
     const int n = 1 << log2cb;
     int split;
-    if (x0 + n <= w && y0 + n <= h && log2cb > 3) {
+    if (x0 + n <= w && y0 + n <= h && log2cb > mincb) {
       const int l = avail(x0, y0, x0 - 1, y0) && ctd[b8(x0 - 1, y0)] > depth, a = avail(x0, y0, x0, y0 - 1) && ctd[b8(x0, y0 - 1)] > depth;
       split = c.bin(CTX_SPLIT_CU + l + a);
-    } else split = log2cb > 3;
+    } else split = log2cb > mincb;
     if (pps.cu_qp_delta && log2cb >= log2_qg) {            // a quantisation group starts here (7.3.8.4, 8.6.1)
       qp_delta_coded = false; cu_qp_delta_val = 0;
       int qa = last_qp_y, qb = last_qp_y;
@@ -1551,10 +1558,11 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     }
     s.amp = r.get(1); s.sao = r.get(1); int pcm = r.get(1);
     if (r.err) return last_error_ = DEC_ERR_INVALID;
-    // coding geometry: CTB 64 (what Kvazaar always writes), 32 or 16 (round 6: other encoders); coding blocks from 8, transform blocks 4 .. min(32, CTB)
-    if (pcm || log2_min_cb != 3 || diff_cb < 1 || diff_cb > 3 || log2_min_tb != 2 || diff_tb != imin(3, diff_cb + 1) || s.th_depth_inter > 4 || s.th_depth_intra > 4)
+    // coding geometry: CTB 64 (what Kvazaar always writes), 32 or 16 (round 6: other encoders); coding blocks from 8 (Kvazaar), 16 or 32 up; transform blocks 4 .. min(32, CTB)
+    if (log2_min_cb < 3 || log2_min_cb > 5 || diff_cb < 0 || diff_cb > 3) return last_error_ = DEC_ERR_INVALID;
+    s.ctb_log2 = log2_min_cb + diff_cb; s.min_cb_log2 = log2_min_cb;
+    if (pcm || s.ctb_log2 < 4 || s.ctb_log2 > 6 || log2_min_tb != 2 || diff_tb != imin(3, s.ctb_log2 - 2) || s.th_depth_inter > 4 || s.th_depth_intra > 4)
       return last_error_ = DEC_ERR_UNSUPPORTED;
-    s.ctb_log2 = 3 + diff_cb;
     s.num_st_rps = r.ue();
     if (s.num_st_rps > 64) return last_error_ = DEC_ERR_INVALID;
     for (int k = 0; k < s.num_st_rps; k++) if (!parse_st_rps(r, k, s.num_st_rps, s.st_rps, s.st_rps[k])) return last_error_ = DEC_ERR_INVALID;
@@ -1572,6 +1580,7 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     }
     if (r.err) return last_error_ = DEC_ERR_INVALID;
     // sizes: multiples of the minimum coding block; the upper bound is the encoder's (and keeps every index inside 32 bits)
+    if ((s.width & ((1 << s.min_cb_log2) - 1)) || (s.height & ((1 << s.min_cb_log2) - 1))) return last_error_ = DEC_ERR_INVALID;      // (7.4.3.2.1: multiples of MinCbSizeY)
     if ((s.width & 7) || (s.height & 7) || s.width < 16 || s.height < 16 || s.width > 16384 || s.height > 16384) return last_error_ = DEC_ERR_UNSUPPORTED;
     if (s.crop_l + s.crop_r >= s.width || s.crop_t + s.crop_b >= s.height) return last_error_ = DEC_ERR_INVALID;
     s.valid = true; sps_[id] = std::make_shared<const DecSps>(s);      // (a new object: pictures still being parsed keep the one they were coded with)
@@ -1933,6 +1942,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   }
   if (!sh.is_intra && !seen_irap_) return DEC_ERR_INVALID;       // nothing to predict from before the first random access point
   if (band_nrows_ > 0 && s.ctb_log2 != 6) return DEC_ERR_UNSUPPORTED;      // (the tile-row split hands over bands of 64-sample rows)
+  if (p.cu_qp_delta && p.qp_delta_depth > s.ctb_log2 - s.min_cb_log2) return DEC_ERR_INVALID;      // (7.4.3.3.1: a quantisation group is no smaller than the minimum coding block)
   if (!ensure_buffers(s.width, s.height, s.ctb_log2)) return DEC_ERR_GPU;
   // ---- reference picture set (8.3.2) and RefPicList0 (8.3.4): pictures not in the set stop being references
   if (idr) for (auto &d : dpb_) d.is_ref = false;

@@ -131,6 +131,11 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   if (c->ctb_log2 != 4 && c->ctb_log2 != 5) c->ctb_log2 = 6;           /* (never drawn: -1 is 64, the streams of the earlier rounds stay what they were) */
   if (c->max_cu_log2 > c->ctb_log2) c->max_cu_log2 = c->ctb_log2;
   if (c->min_cu_log2 > c->max_cu_log2) c->min_cu_log2 = c->max_cu_log2;
+  if (c->min_cb_log2 != 4 && c->min_cb_log2 != 5) c->min_cb_log2 = 3;   /* (never drawn) */
+  if (c->min_cb_log2 > c->ctb_log2 || (cfg->width & ((1 << c->min_cb_log2) - 1)) || (cfg->height & ((1 << c->min_cb_log2) - 1))) c->min_cb_log2 = 3;
+  if (c->min_cu_log2 < c->min_cb_log2) c->min_cu_log2 = c->min_cb_log2;
+  if (c->max_cu_log2 < c->min_cu_log2) c->max_cu_log2 = c->min_cu_log2;
+  if (c->qp_delta - 1 > c->ctb_log2 - c->min_cb_log2) c->qp_delta = c->ctb_log2 - c->min_cb_log2 + 1;      /* (diff_cu_qp_delta_depth <= log2_diff_max_min_luma_coding_block_size) */
   const int ctbs = 1 << c->ctb_log2, wc = (cfg->width + ctbs - 1) / ctbs, hc = (cfg->height + ctbs - 1) / ctbs;
   if (c->tile_rows > hc) c->tile_rows = hc;
   if (c->tile_rows < 1) c->tile_rows = 1;
@@ -149,7 +154,7 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
     s->max_num_reorder = lg; s->max_dec_pic_buffering = c->num_refs + lg + 2;      /* (roomy: output is driven by the reorder count alone) */
     if (s->log2_max_poc_lsb < 6) s->log2_max_poc_lsb = 6;
   }
-  s->log2_min_cb = 3; s->log2_diff_max_min_cb = c->ctb_log2 - 3; s->log2_min_tb = 2; s->log2_diff_max_min_tb = c->ctb_log2 < 5 ? c->ctb_log2 - 2 : 3;      /* (MaxTbLog2SizeY <= Min(CtbLog2SizeY, 5)) */
+  s->log2_min_cb = c->min_cb_log2; s->log2_diff_max_min_cb = c->ctb_log2 - c->min_cb_log2; s->log2_min_tb = 2; s->log2_diff_max_min_tb = c->ctb_log2 < 5 ? c->ctb_log2 - 2 : 3;      /* (MaxTbLog2SizeY <= Min(CtbLog2SizeY, 5)) */
   s->max_th_depth_inter = c->th_depth_inter; s->max_th_depth_intra = c->th_depth_intra;
   s->amp_enabled = c->amp; s->sao_enabled = c->sao;
   s->scaling_list_enabled = c->scaling_lists > 0; s->scaling_list_data_present = c->scaling_lists == 2 || c->scaling_lists == 4;
@@ -529,7 +534,7 @@ static void gen_coding_unit(orc_gen *g, int x0, int y0, int log2cb, int ct_depth
       } else {
         int pm = PART_2Nx2N;
         if (g->cfg.all_part_modes && rpct(g, 50)) {
-          if (log2cb == s->log2_min_cb) pm = rpct(g, 50) ? PART_2NxN : PART_Nx2N;      /* (NxN needs min CB > 8) */
+          if (log2cb == s->log2_min_cb) pm = (log2cb > 3 && rpct(g, 34)) ? PART_NxN : (rpct(g, 50) ? PART_2NxN : PART_Nx2N);      /* (NxN: a minimum coding block above 8 samples) */
           else if (!s->amp_enabled) pm = rpct(g, 50) ? PART_2NxN : PART_Nx2N;
           else { static const int m[6] = { PART_2NxN, PART_Nx2N, PART_2NxnU, PART_2NxnD, PART_nLx2N, PART_nRx2N }; pm = m[rrange(g, 0, 5)]; }
         }
@@ -539,7 +544,8 @@ static void gen_coding_unit(orc_gen *g, int x0, int y0, int log2cb, int ct_depth
           orc_cenc_bin(c, CTX_PART_MODE, 0);
           const int horiz = (pm == PART_2NxN || pm == PART_2NxnU || pm == PART_2NxnD);
           if (log2cb == s->log2_min_cb) {
-            orc_cenc_bin(c, CTX_PART_MODE + 1, horiz);             /* log2 == 3: '01' 2NxN, '00' Nx2N */
+            orc_cenc_bin(c, CTX_PART_MODE + 1, horiz);             /* log2 == 3: '01' 2NxN, '00' Nx2N; above: '01' 2NxN, '001' Nx2N, '000' NxN */
+            if (!horiz && log2cb > 3) orc_cenc_bin(c, CTX_PART_MODE + 2, pm == PART_Nx2N);
           } else if (!s->amp_enabled) orc_cenc_bin(c, CTX_PART_MODE + 1, horiz);
           else {
             orc_cenc_bin(c, CTX_PART_MODE + 1, horiz);

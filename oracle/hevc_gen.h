@@ -56,7 +56,9 @@ typedef struct {
   int list_mod;               /* probability (%) that a reference list of an inter slice is modified (ref_pic_lists_modification(): the entries of the initial list
                                * in any order, repeats allowed); > 0 sets lists_modification_present_flag -- 0 (also -1): off */
   int ctb_log2;               /* CtbLog2SizeY: 6 (also -1 / 0: the streams of rounds 1-5), 5 or 4 -- what encoders other than Kvazaar choose (hardware encoders: 32 or 16);
-                               * MinCbLog2SizeY stays 3; max_cu_log2 is capped to it */
+                               * max_cu_log2 is capped to it */
+  int min_cb_log2;            /* MinCbLog2SizeY: 3 (also -1 / 0: every stream of the earlier rounds), 4 or 5 -- no coding unit below 16 / 32 samples; taken back to 3 when the
+                               * picture size is no multiple of it or it exceeds the CTB.  At the minimum size above 8 an inter unit may be cut into four (PART_NxN) */
 } orc_gen_config;
 
 void orc_gen_default_config(orc_gen_config *c);    /* everything random, 416x240 */

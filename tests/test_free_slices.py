@@ -71,3 +71,19 @@ def test_a_lost_segment_is_an_error_not_a_wrong_picture():
         assert int(out[0]) == 0 and lib is not None, (seed, rcs)      # no picture was booked
         return
     pytest.skip("no picture with three segments among the seeds")
+
+
+@pytest.mark.parametrize("min_cb,ctb,w,h", [(4, 6, 208, 144), (4, 4, 208, 144), (5, 6, 192, 128), (5, 5, 192, 128)])
+def test_minimum_coding_blocks_of_16_and_32_samples(min_cb, ctb, w, h):
+    """MinCbLog2SizeY 4 / 5 (round 6): the synthesiser, the checker's decoder and the product's parser (one row thread and four) on the same streams"""
+    for seed in range(1, 11):
+        g = orc.OracleGen(w, h, seed=seed, min_cb_log2=min_cb, ctb_log2=ctb, slices=3 if seed % 3 == 0 else 0, all_part_modes=1)
+        assert g.config["min_cb_log2"] == min_cb
+        aus = [g.picture() for _ in range(4)]
+        g.close()
+        od = orc.OracleDecoder()
+        assert sum(len(od.decode_au(au, t)) for t, au in enumerate(aus)) + len(od.flush()) == 4, seed
+        od.close()
+        nals = [n for au in aus for n in orc.split_nals(au)]
+        a, b = PP.probe(nals, 1), PP.probe(nals, 4)
+        assert a == b and a["pictures"] == 4, (seed, a, b)

@@ -285,3 +285,18 @@ def test_free_slices(wpp, seed, kw):
     g.close()
     assert max(sum(1 for n in orc.split_nals(au) if ((n[4] >> 1) & 63) < 32) for au in aus) > 1      # (more than one slice segment in some picture)
     compare(aus)
+
+
+@pytest.mark.parametrize("seed,min_cb,ctb,w,h,kw", [(5, 5, 6, 192, 128, dict(all_part_modes=1, amp=1, intra_in_p=20, sao=1)),
+                                                    (7, 4, 4, 208, 144, dict(all_part_modes=1, nxn_intra=1, intra_in_p=30, qp_delta=1)),
+                                                    (9, 4, 5, 208, 144, dict(all_part_modes=1, tmvp=1, num_refs=2, slices=3)),
+                                                    (11, 5, 5, 192, 128, dict(all_part_modes=1, nxn_intra=1, intra_in_p=40)),
+                                                    (13, 4, 6, 208, 144, dict(all_part_modes=1, nxn_intra=1, intra_in_p=30, th_depth_inter=2, th_depth_intra=2))])
+def test_minimum_coding_blocks_of_16_and_32_samples(seed, min_cb, ctb, w, h, kw):
+    """round 6: MinCbLog2SizeY 4 / 5 -- no split flag at that size, the partitioning's binarisation at the minimum size (inter NxN above 8x8), intra NxN with larger
+    prediction blocks: the two independently written decoders must agree before the HIP decoder is held to either"""
+    g = orc.OracleGen(w, h, seed=seed, min_cb_log2=min_cb, ctb_log2=ctb, **kw)
+    assert g.config["min_cb_log2"] == min_cb
+    aus = [g.picture() for _ in range(4)]
+    g.close()
+    compare(aus)

@@ -74,6 +74,9 @@ struct DecFrame {
   uint8_t *out[3];          // SAO output (== rec planes of the picture buffer when SAO runs from a work picture)
   const uint8_t *ref[KVZ_DEC_MAX_REFS][3];   // picture buffers by slot
   const SaoParams *sao;     // per CTB (raster, pitch cwc); NULL = off
+  const uint8_t *ctu_nb;    // per CTB (raster, pitch cwc), NULL = no boundary inside the picture is closed to the in-loop filters: bit k = the samples of the neighbouring CTB k
+                            // (NW N NE W E SW S SE = 0 .. 7) may be used -- a slice with slice_loop_filter_across_slices_enabled_flag = 0, tiles with
+                            // loop_filter_across_tiles_enabled_flag = 0 (Kvazaar's).  SAO looks here; for deblocking the host has taken the edge marks off the records
   // k_dec_intra's hand-off between CTUs (kernel_common.h IntraNeighbours): per plane and CTU the right column / bottom row of its intra blocks as
   // self-validating words -- one sample | chain_gen << 8 per row, four samples | chain_gen << 32 per four columns -- that the neighbouring CTU's wave
   // polls until they carry this launch's generation

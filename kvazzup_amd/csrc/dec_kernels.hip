@@ -1065,6 +1065,19 @@ template <class F> __device__ __forceinline__ void dec_sao_body(const F &f, cons
         const int dq = pitch >> 2;
         const uint64_t mid = span(row), up = span(row - dq), dn = span(row + dq);
         const bool okv = Y0 + y - 1 >= 0 && Y0 + y + 1 < phei;
+        // closed slice / tile boundaries (DecFrame::ctu_nb): the four samples lie in one coding tree block; a neighbour across a closed boundary of it leaves the
+        // sample as it is (8.7.3.2: edgeIdx 0)
+        uint32_t nbm = 0xffu; int px = 0, py = 0, S = 0;
+        if (f.ctu_nb) {
+          nbm = f.ctu_nb[((((Y0 + y) << sh) >> cl)) * f.cwc + (((X0 + x4) << sh) >> cl)];
+          S = (1 << cl) >> sh; px = (X0 + x4) & (S - 1); py = (Y0 + y) & (S - 1);
+        }
+        auto usable = [&](int i, int dx, int dy) -> bool {
+          const int cdx = (dx < 0 && px + i == 0) ? -1 : ((dx > 0 && px + i == S - 1) ? 1 : 0), cdy = (dy < 0 && py == 0) ? -1 : ((dy > 0 && py == S - 1) ? 1 : 0);
+          if (!cdx && !cdy) return true;
+          const int k = (cdy + 1) * 3 + cdx + 1;
+          return ((nbm >> (k > 4 ? k - 1 : k)) & 1u) != 0;
+        };
         uint32_t o = 0;
         for (int i = 0; i < 4; i++) {
           const int v = (int)((mid >> (8 * (i + 1))) & 255);
@@ -1074,6 +1087,10 @@ template <class F> __device__ __forceinline__ void dec_sao_body(const F &f, cons
           else if (e == 1) { a = (int)((up >> (8 * (i + 1))) & 255); b = (int)((dn >> (8 * (i + 1))) & 255); ok = okv; }
           else if (e == 2) { a = (int)((up >> (8 * i)) & 255); b = (int)((dn >> (8 * (i + 2))) & 255); ok = okh && okv; }
           else { a = (int)((up >> (8 * (i + 2))) & 255); b = (int)((dn >> (8 * i)) & 255); ok = okh && okv; }
+          if (nbm != 0xffu) {
+            const int dxa = (e == 1) ? 0 : (e == 3 ? 1 : -1), dya = (e == 0) ? 0 : -1;      // Table 8-12: the first neighbour; the second one is opposite
+            ok = ok && usable(i, dxa, dya) && usable(i, -dxa, -dya);
+          }
           const int k = ok ? dsao_edge_idx(v, a, b) : 0;
           o |= (uint32_t)(k ? clip8(v + off[k - 1]) : v) << (8 * i);
         }

@@ -13,10 +13,10 @@
 // temporal motion vector prediction, merge levels, cu_qp_delta at any quantisation-group size, chroma QP offsets, sign data
 // hiding, transform skip, scaling lists (default, SPS and PPS scaling_list_data), cu_transquant_bypass (lossless coding units), deblocking offsets /
 // overrides, SAO, WPP, tile grids up to the level limit of 20 columns x 22 rows (uniform or
-// explicit spacing), pictures in several slice segments: the two ways Kvazaar cuts them (a dependent slice segment per CTU row with WPP, an
+// explicit spacing; in-loop filtering across tile and slice boundaries on or off -- Kvazaar switches it off), pictures in several slice segments: the two ways Kvazaar cuts them (a dependent slice segment per CTU row with WPP, an
 // independent slice per tile) and -- one-tile pictures -- segments that begin at ANY coding tree block, independent slices (own SliceQpY) and dependent
 // segments mixed (an MTU per slice, N row groups: PicJob::ctb_cut).  Rejected with a negative return value (kvzx_decoder_last_error): several slices
-// inside a tile of a picture with tiles, slices of one picture that differ in more than SliceQpY, loop filters switched off across slices or tiles,
+// inside a tile of a picture with tiles, slices of one picture that differ in more than SliceQpY and the loop filter flag,
 // long-term references, PCM, constrained intra prediction, > 255 slices in a picture.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -71,7 +71,7 @@ struct DecPps {
   int wpp = 0, tile_rows = 1, row_bd[34];   // tile row i covers CTB rows [row_bd[i], row_bd[i + 1]); filled at slice time when uniform
   int tile_cols = 1, col_bd[34];            // tile column j covers CTB columns [col_bd[j], col_bd[j + 1])
   int uniform_tiles = 1, row_height[33], col_width[33];
-  int deblock_control = 0, deblock_override = 0, deblock_disabled = 0, beta_offset_div2 = 0, tc_offset_div2 = 0, loop_filter_across_slices = 1;
+  int deblock_control = 0, deblock_override = 0, deblock_disabled = 0, beta_offset_div2 = 0, tc_offset_div2 = 0, loop_filter_across_slices = 1, across_tiles = 1;
   int par_mrg_level = 2;
   int tq_bypass = 0;                                   // transquant_bypass_enabled_flag (a peer's Kvazaar with `lossless`, kvazaarfilter.cpp:244)
   std::shared_ptr<const std::vector<uint8_t>> scaling; // pps_scaling_list_data: these factors instead of the SPS's
@@ -196,6 +196,9 @@ class Decoder {
     // a one-tile picture submitted because its segments COVER it row by row: whether the last one really ends with the picture is not in any header.  The parser
     // says so when it does not (DEC_SEG_ENDS_EARLY), and the synchronous decoder then takes the picture back and waits for the rest of its access unit (submit_job).
     bool ambiguous_end = false;
+    // some boundary inside the picture is closed to the in-loop filters (loop_filter_across_tiles_enabled_flag = 0 with tiles; a slice with
+    // slice_loop_filter_across_slices_enabled_flag = 0): lf_slices = the picture's independent slices (first block, flag)
+    bool lf_restricted = false; std::vector<std::pair<int, uint8_t>> lf_slices;
     struct Undo { int poc = 0, prev_poc = 0; bool is_ref = false, used = false, seen_irap = false; long decode_idx = 0; std::shared_ptr<ColMotion> motion; } undo;      // what submit_job changed
     SliceHdr sh; std::shared_ptr<const DecSps> sps; DecPps pps;  // (a later SPS / PPS NAL may replace the table entry while this picture is still being parsed: the job keeps the SPS it was coded with alive, the PPS by value)
     int64_t pts = 0; int crop[4] = {0, 0, 0, 0}; uint32_t fps_num = 0, fps_den = 0;
@@ -264,6 +267,12 @@ class Decoder {
   // segment turns up that those forms do not have (asm_free_) -- the picture is then put together from this list when the access unit ends
   struct FreeSeg { int address; bool dependent; int slice_qp; std::vector<size_t> subs; };
   std::vector<FreeSeg> asm_segs_; bool asm_free_ = false, free_stream_ = false; bool asm_cur_dependent_ = false; int asm_cur_qp_ = 26;
+  // in-loop filtering across slice and tile boundaries: the independent slices of the picture being assembled -- first coding tree block, slice_loop_filter_across_
+  // slices_enabled_flag -- in every form a picture's slices come in; build_lf_map turns them (and the PPS's tile flag) into PicJob::lf_restricted / the map the
+  // parser's last step writes for the kernels (DecFrame::ctu_nb)
+  struct LfSlice { int address; bool across; };
+  std::vector<LfSlice> asm_lf_;
+  void note_lf_restrictions(PicJob &job);
   int finish_oldest();
   void drop_pending();
   // layout of the input block
@@ -276,7 +285,8 @@ class Decoder {
   size_t off_scaling() const { return (off_sao() + nctb() * sizeof(SaoParams) + 63) & ~(size_t)63; }     // KVZ_SCALING_BYTES scaling factors (pictures with scaling lists)
   size_t off_wt() const { return (off_scaling() + KVZ_SCALING_BYTES + 63) & ~(size_t)63; }       // 32 DecWt (pictures with pred_weight_table())
   size_t off_frame() const { return (off_wt() + 32 * sizeof(DecWt) + 63) & ~(size_t)63; }     // the picture's DecFrame, for launches that read it from device memory (batch.h)
-  size_t fixed_bytes() const { return (off_frame() + sizeof(DecFrame) + 15) & ~(size_t)15; }
+  size_t off_nb() const { return (off_frame() + sizeof(DecFrame) + 15) & ~(size_t)15; }      // per CTB: the neighbouring CTBs the in-loop filters may use (DecFrame::ctu_nb; pictures with closed boundaries)
+  size_t fixed_bytes() const { return (off_nb() + nctb() + 15) & ~(size_t)15; }
   bool grow_job_input(PicJob &job, size_t bytes);
   void bind_job(PicJob &job);
   int launch_gpu(PicJob &job);

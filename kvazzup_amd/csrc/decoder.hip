@@ -1612,7 +1612,7 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
         for (int k = 0; k < cols - 1; k++) { p.col_width[k] = (int)r.ue() + 1; if (p.col_width[k] > 1024) return last_error_ = DEC_ERR_INVALID; }
         for (int k = 0; k < rows - 1; k++) { p.row_height[k] = (int)r.ue() + 1; if (p.row_height[k] > 1024) return last_error_ = DEC_ERR_INVALID; }
       }
-      if (!r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;   // loop_filter_across_tiles_enabled_flag
+      p.across_tiles = r.get(1);                                 // loop_filter_across_tiles_enabled_flag (Kvazaar writes 0: its tiles are filtered one by one)
       p.tile_rows = rows; p.tile_cols = cols;
     }
     p.loop_filter_across_slices = r.get(1);
@@ -1934,10 +1934,11 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     if (sh.is_intra != a.is_intra || sh.is_b != a.is_b || sh.num_ref_idx1 != a.num_ref_idx1 || sh.mvd_l1_zero != a.mvd_l1_zero || sh.collocated_from_l0 != a.collocated_from_l0 || sh.poc != a.poc || sh.tmvp != a.tmvp || sh.collocated_ref_idx != a.collocated_ref_idx || sh.sao_luma != a.sao_luma ||
         sh.sao_chroma != a.sao_chroma || sh.num_ref_idx != a.num_ref_idx || sh.cabac_init_flag != a.cabac_init_flag || sh.max_merge != a.max_merge ||
         (sh.slice_qp != a.slice_qp && (pp.tile_cols > 1 || pp.tile_rows > 1)) || sh.cb_qp_offset != a.cb_qp_offset || sh.cr_qp_offset != a.cr_qp_offset || sh.deblock_disabled != a.deblock_disabled ||
-        sh.beta_offset_div2 != a.beta_offset_div2 || sh.tc_offset_div2 != a.tc_offset_div2 || !across_slices ||
+        sh.beta_offset_div2 != a.beta_offset_div2 || sh.tc_offset_div2 != a.tc_offset_div2 ||
         memcmp(sh.list_mod, a.list_mod, 2) || memcmp(sh.list_entry, a.list_entry, sizeof(sh.list_entry)) ||
         sh.wt_explicit != a.wt_explicit || sh.weighted != a.weighted || (sh.weighted && (memcmp(sh.wt, a.wt, sizeof(sh.wt)) || sh.wt_log2[0] != a.wt_log2[0] || sh.wt_log2[1] != a.wt_log2[1]))) return DEC_ERR_UNSUPPORTED;
     asm_cur_dependent_ = false; asm_cur_qp_ = sh.slice_qp;      // (inside one tile a slice may have its own SliceQpY: free slices, close_free_picture)
+    asm_lf_.push_back(LfSlice{seg_address, across_slices});
     return append_segment(*open_job, r.pos, rbsp, len, p, pp, wc, hc, seg_address, pts);
   }
   if (!sh.is_intra && !seen_irap_) return DEC_ERR_INVALID;       // nothing to predict from before the first random access point
@@ -2033,6 +2034,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   job.rc = 0; job.any_intra = job.any_inter = false;
   asm_active_ = true; asm_guessed_one_row_ = false; asm_rows_ = 0; asm_subs_ = 0; asm_pps_id_ = pps_id; asm_nal_type_ = nal_type; asm_irap_ = irap;
   asm_segs_.clear(); asm_free_ = false; asm_cur_dependent_ = false; asm_cur_qp_ = sh.slice_qp; job.ambiguous_end = false;
+  asm_lf_.clear(); asm_lf_.push_back(LfSlice{0, across_slices}); job.lf_restricted = false; job.lf_slices.clear();
   job.ctb_cut.clear(); job.ctb_slice.clear(); job.ctb_data.clear(); job.slice_qps.clear();
   return append_segment(job, r.pos, rbsp, len, p, pp, wc, hc, 0, pts);
 }
@@ -2182,8 +2184,21 @@ void Decoder::take_back_job(PicJob &job)
   asm_active_ = true; asm_free_ = free_stream_ = true;
 }
 
+// closed boundaries inside the picture?  (7.4.3.3.1 loop_filter_across_tiles_enabled_flag = 0 with more than one tile; 7.4.7.1 a slice with
+// slice_loop_filter_across_slices_enabled_flag = 0 in a picture of several slices.)  The picture's slices go with the job; parse_job lays the map out.
+void Decoder::note_lf_restrictions(PicJob &job)
+{
+  bool closed = (job.pps.tile_rows > 1 || job.pps.tile_cols > 1) && !job.pps.across_tiles;
+  if (asm_lf_.size() > 1) for (const LfSlice &s : asm_lf_) closed |= !s.across;
+  job.lf_restricted = closed && band_nrows_ == 0;
+  job.lf_slices.clear();
+  if (job.lf_restricted) for (const LfSlice &s : asm_lf_) job.lf_slices.emplace_back(s.address, (uint8_t)s.across);
+}
+
 int Decoder::submit_job(PicJob &job, int nal_type, bool irap)
 {
+  note_lf_restrictions(job);
+  if (job.lf_slices.empty() && band_nrows_ > 0 && (job.pps.tile_rows > 1 || job.pps.tile_cols > 1) && !job.pps.across_tiles) return DEC_ERR_UNSUPPORTED;      // (the tile-row split exchanges halos FOR the filters)
   const SliceHdr &sh = job.sh;
   DpbPic &d = dpb_[job.slot];
   // (PicJob::ambiguous_end: when the picture's last segment ends before the picture does, more segments are to come -- everything is put back as it was before
@@ -2212,7 +2227,7 @@ int Decoder::submit_job(PicJob &job, int nal_type, bool irap)
       // (decoder.h PicJob::early_dst; the buffer is the one launch_gpu will pick -- nothing is launched between here and there)
       static const bool early_off = [] { const char *e = getenv("KVAZZUP_AMD_DEC_EARLY_UP"); return e && atoi(e) == 0; }();
       const int ib = (int)(launched_ % (gpu_depth_ + 1));
-      if (!early_off && gpu_depth_ == 1 && band_nrows_ == 0 && job.pps.tile_cols == 1 && !(batch_attached_ && DecBatcher::get(device_).active()) && d_in_[ib] && d_in_cap_[ib] >= fixed_bytes()) job.early_dst = d_in_[ib];
+      if (!early_off && gpu_depth_ == 1 && band_nrows_ == 0 && job.pps.tile_cols == 1 && !job.lf_restricted && !(batch_attached_ && DecBatcher::get(device_).active()) && d_in_[ib] && d_in_cap_[ib] >= fixed_bytes()) job.early_dst = d_in_[ib];      // (lf_restricted: parse_job's last step still changes records)
     }
     job.rc = parse_job(job, true);
     if (job.rc == DEC_SEG_ENDS_EARLY) { if (job.early_dst) hipStreamSynchronize(stream_up_); return take_back(); }
@@ -2598,6 +2613,44 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
     for (size_t k = 0; k < ntu; k++) { TuRange &g = job.region[region_of(tus[k])]; idx[g.first + g.count++] = (uint32_t)k; }      // (list order = decoding order inside a region)
   }
   job.ntu = ntu; job.nlev = nlev;
+  if (job.lf_restricted) {
+    // ---- closed slice / tile boundaries (PicJob::lf_restricted).  Every coding tree block's slice: the slices are runs of the DECODING order (tile after tile), so the
+    // walk goes through the substreams' geometry; then per block which of its eight neighbours the in-loop filters may use -- not across a tile boundary when the
+    // PPS says so, not across a slice boundary when the LATER of the two slices says so (its left and upper boundaries are the closed ones, 7.4.7.1).  SAO reads the
+    // map; deblocking needs none: an edge on a closed boundary is no edge (8.7.2.3 filterEdgeFlag = 0), its marks come off the records here.
+    const int n = wc * hc;
+    std::vector<int> order((size_t)n, 0), slice((size_t)n, 0);
+    {
+      int ts = 0, cur = -1; size_t next = 0;
+      for (const PicJob::SubGeom &g : job.geom)
+        for (int cy = g.cy0; cy < g.cy1; cy++)
+          for (int cx = g.cx0; cx < g.cx1; cx++) {
+            const int a = cy * wc + cx;
+            while (next < job.lf_slices.size() && job.lf_slices[next].first == a) { cur = (int)next; next++; }      // (a slice begins with this block)
+            order[(size_t)a] = ts++; slice[(size_t)a] = cur < 0 ? 0 : cur;
+          }
+      if (next != job.lf_slices.size()) return DEC_ERR_INVALID;                      // (a slice that begins where no substream's walk comes by)
+    }
+    uint8_t *nb = job.h_in + off_nb();
+    const int per = 1 << (ctbl_ - 2), b4w = pw_ / 4;
+    for (int cy = 0; cy < hc; cy++)
+      for (int cx = 0; cx < wc; cx++) {
+        const int c = cy * wc + cx; uint8_t m = 0xff;
+        for (int dy = -1; dy <= 1; dy++)
+          for (int dx = -1; dx <= 1; dx++) {
+            const int nx = cx + dx, ny = cy + dy;
+            if ((!dx && !dy) || nx < 0 || ny < 0 || nx >= wc || ny >= hc) continue;
+            const int q = ny * wc + nx, later = order[(size_t)q] > order[(size_t)c] ? q : c;
+            const bool closed = (job.ctu_tile[c] != job.ctu_tile[q] && !job.pps.across_tiles && job.ctb_cut.empty()) ||      // (free slices: the byte holds the slice, there is one tile)
+                                (slice[(size_t)c] != slice[(size_t)q] && !job.lf_slices[(size_t)slice[(size_t)later]].second);
+            const int k = (dy + 1) * 3 + (dx + 1);
+            if (closed) m &= (uint8_t)~(1u << (k > 4 ? k - 1 : k));
+          }
+        nb[c] = m;
+        if (!(m & (1u << 3))) for (int k = 0; k < per && (cy * per + k) * 4 < h_; k++) job.b4[(size_t)(cy * per + k) * b4w + cx * per].flags &= (uint8_t)~(B4_EDGE_V | B4_TU_V);      // W
+        if (!(m & (1u << 1))) for (int k = 0; k < per && (cx * per + k) * 4 < w_; k++) job.b4[(size_t)(cy * per) * b4w + cx * per + k].flags &= (uint8_t)~(B4_EDGE_H | B4_TU_H);      // N
+      }
+  }
   return 0;
 }
 
@@ -2644,6 +2697,7 @@ int Decoder::launch_gpu(PicJob &job)
   for (int c = 0; c < 3; c++) { f.rec[c] = sao ? (alt ? work_alt_[c] : work_[c]) : dpb_[job.slot].plane[c]; f.out[c] = dpb_[job.slot].plane[c]; }
   for (int k = 0; k < KVZ_DEC_MAX_REFS; k++) for (int c = 0; c < 3; c++) f.ref[k][c] = dpb_[k].plane[c];
   f.sao = sao ? (const SaoParams *)(d_in_ + off_sao()) : nullptr;
+  f.ctu_nb = job.lf_restricted ? d_in_ + off_nb() : nullptr;
   f.progress = alt ? progress_alt_ : progress_; f.intra_order = intra_order_; f.err = err_;
   { const size_t nctu = (size_t)f.cwc * f.chc, S = (size_t)1 << ctbl_; uint32_t *ec = alt ? edge_col_alt_ : edge_col_; unsigned long long *er = alt ? edge_row_alt_ : edge_row_;
     f.edge_col[0] = ec; f.edge_col[1] = ec + nctu * S; f.edge_col[2] = ec + nctu * (S + S / 2);      // per CTB: S words (luma), S / 2 (Cb), S / 2 (Cr)

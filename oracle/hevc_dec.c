@@ -44,6 +44,8 @@ struct orc_decoder {
   /* tile / slice maps for the current picture */
   orc_sao_params *sao; int sao_used; pixel *sao_in[3];
   int32_t *ctb_slice; int16_t *ctb_tile; int *ts_to_rs, *rs_to_ts; int *tile_first_x; size_t ctb_cap;
+  uint8_t *ctb_lfx, *ctb_nb;              /* per CTB: slice_loop_filter_across_slices_enabled_flag of its slice; the neighbouring CTBs the in-loop filters may use (finish_picture) */
+  int lf_restricted;                      /* some slice of the picture has that flag 0 */
   int slice_addr_rs;                      /* SliceAddrRs: address of the slice (= its first, independent segment) being decoded */
   orc_ctx ds_ctx[CTX_COUNT];              /* TableStateIdxDs: contexts at the end of the previous slice segment (9.3.2.2) */
   int col_bd[34], row_bd[34];
@@ -82,7 +84,7 @@ void orc_dec_close(orc_decoder *d)
   free(d->bs_v); free(d->bs_h); free(d->rbsp);
   for (int i = 0; i < 3; i++) free(d->predeblock[i]);
   free(d->sao); for (int i = 0; i < 3; i++) free(d->sao_in[i]);
-  free(d->ctb_slice); free(d->ctb_tile); free(d->ts_to_rs); free(d->rs_to_ts); free(d->tile_first_x);
+  free(d->ctb_slice); free(d->ctb_tile); free(d->ts_to_rs); free(d->rs_to_ts); free(d->tile_first_x); free(d->ctb_lfx); free(d->ctb_nb);
   free(d->sh.entry_point_offset);
   free(d);
 }
@@ -674,6 +676,7 @@ static void setup_tiles(orc_decoder *d)
     d->sao = (orc_sao_params *)realloc(d->sao, n * sizeof(orc_sao_params));
     d->ctb_slice = (int32_t *)realloc(d->ctb_slice, n * sizeof(int32_t));
     d->ctb_tile = (int16_t *)realloc(d->ctb_tile, n * sizeof(int16_t));
+    d->ctb_lfx = (uint8_t *)realloc(d->ctb_lfx, n); d->ctb_nb = (uint8_t *)realloc(d->ctb_nb, n);
     d->ts_to_rs = (int *)realloc(d->ts_to_rs, n * sizeof(int));
     d->rs_to_ts = (int *)realloc(d->rs_to_ts, n * sizeof(int));
     d->tile_first_x = (int *)realloc(d->tile_first_x, n * sizeof(int));
@@ -700,6 +703,7 @@ static void setup_tiles(orc_decoder *d)
           ts++;
         }
   for (size_t i = 0; i < n; i++) d->ctb_slice[i] = -1;
+  d->lf_restricted = 0;
   d->sao_used = 0;
 }
 
@@ -830,6 +834,29 @@ static void finish_picture(orc_decoder *d)
     size_t n = (size_t)(ci ? s->width / 2 : s->width) * (ci ? s->height / 2 : s->height);
     memcpy(d->predeblock[ci], pic->plane[ci], n);
   }
+  /* in-loop filtering across slice and tile boundaries (7.4.3.3.1 loop_filter_across_tiles_enabled_flag, 7.4.7.1 slice_loop_filter_across_slices_enabled_flag: the
+   * left and upper boundaries of the slice that has it, i.e. of two slices the LATER one's flag): per CTB, which neighbouring CTBs' samples may be used.  Deblocking
+   * (8.7.2.3 filterEdgeFlag) then does not see the edges on a closed boundary at all; SAO (8.7.3.2) leaves a sample alone whose neighbour lies across one. */
+  const uint8_t *nb_map = NULL;
+  if (d->lf_restricted || (d->p->tiles_enabled && !d->p->loop_filter_across_tiles)) {
+    const int wc = s->pic_w_ctbs, hc = s->pic_h_ctbs, cu = (1 << s->ctb_log2) >> 2;
+    for (int cy = 0; cy < hc; cy++) for (int cx = 0; cx < wc; cx++) {
+      const int c = cy * wc + cx; uint8_t m = 0xff;
+      for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+        const int nx = cx + dx, ny = cy + dy;
+        if ((!dx && !dy) || nx < 0 || ny < 0 || nx >= wc || ny >= hc) continue;
+        const int n = ny * wc + nx, later = d->rs_to_ts[n] > d->rs_to_ts[c] ? n : c;
+        if ((d->ctb_tile[c] != d->ctb_tile[n] && !d->p->loop_filter_across_tiles) || (d->ctb_slice[c] != d->ctb_slice[n] && !d->ctb_lfx[later])) m &= (uint8_t)~(1u << orc_lf_neighbour_bit(dx, dy));
+      }
+      d->ctb_nb[c] = m;
+      for (int k = 0; k < cu; k++) {
+        const int ux = cx * cu, uy = cy * cu;
+        if (!((m >> orc_lf_neighbour_bit(-1, 0)) & 1) && uy + k < pic->b4_h && ux < pic->b4_w) pic->edge_v[(uy + k) * pic->b4_w + ux] = 0;
+        if (!((m >> orc_lf_neighbour_bit(0, -1)) & 1) && ux + k < pic->b4_w && uy < pic->b4_h) pic->edge_h[uy * pic->b4_w + ux + k] = 0;
+      }
+    }
+    nb_map = d->ctb_nb;
+  }
   if (!d->sh.slice_deblocking_disabled) {
     orc_deblock_ctx db; memset(&db, 0, sizeof(db));
     orc_compute_bs(pic, d->bs_v, d->bs_h);
@@ -846,7 +873,7 @@ static void finish_picture(orc_decoder *d)
     orc_sao_ctx sc; memset(&sc, 0, sizeof(sc));
     sc.w = pic->w; sc.h = pic->h; sc.ctb_log2 = s->ctb_log2; sc.pic_w_ctbs = s->pic_w_ctbs; sc.params = d->sao;
     sc.ctb_slice = d->ctb_slice; sc.ctb_tile = d->ctb_tile;
-    sc.across_slices = d->sh.loop_filter_across_slices; sc.across_tiles = d->p->loop_filter_across_tiles;
+    sc.across_slices = 1; sc.across_tiles = 1; sc.ctb_nb = nb_map;
     sc.no_filter = pic->no_filter; sc.nf_stride = pic->b4_w;
     for (int i = 0; i < 3; i++) {
       size_t n = (size_t)pic->stride[i] * (i ? pic->h / 2 : pic->h);
@@ -881,6 +908,7 @@ static int decode_slice_data(orc_decoder *d, const uint8_t *data, size_t len)
     int first_in_tile = (ts == 0) || d->ctb_tile[rs] != d->ctb_tile[d->ts_to_rs[ts - 1]];
     int row_start = (cx == d->tile_first_x[rs]);
     d->ctb_slice[rs] = slice_addr;
+    d->ctb_lfx[rs] = (uint8_t)sh->loop_filter_across_slices; if (!sh->loop_filter_across_slices) d->lf_restricted = 1;
     int new_qg_row = 0;
     if ((first && !sh->dependent_slice_segment) || first_in_tile) {
       orc_cabac_init_contexts(d->cabac.ctx, init_type, sh->slice_qp);

@@ -176,7 +176,8 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   if (p->scaling_list_data_present) gen_scaling(g, &p->scaling, p->sl_pred_mode, p->sl_pred_delta);
   p->cu_qp_delta_enabled = c->qp_delta > 0; p->diff_cu_qp_delta_depth = c->qp_delta > 0 ? c->qp_delta - 1 : 0;
   if (c->chroma_qp_offsets) { p->cb_qp_offset = rrange(g, -4, 4); p->cr_qp_offset = rrange(g, -4, 4); p->slice_chroma_qp_offsets_present = rpct(g, 50); }
-  p->entropy_coding_sync_enabled = c->wpp; p->loop_filter_across_slices = 1;
+  if (c->lf_across < 0 || c->lf_across > 2) c->lf_across = 0;
+  p->entropy_coding_sync_enabled = c->wpp; p->loop_filter_across_slices = c->lf_across == 0 ? 1 : (c->lf_across == 2 ? 0 : rpct(g, 70));
   if (c->slices < 0 || c->slices > 3) c->slices = 0;
   if (c->tile_cols < 1) c->tile_cols = 1;
   if (c->tile_cols > wc) c->tile_cols = wc;
@@ -193,7 +194,7 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   for (int i = 0; i <= c->tile_rows; i++) g->row_bd[i] = (i * hc) / c->tile_rows;
   for (int i = 0; i <= c->tile_cols; i++) g->col_bd[i] = (i * wc) / c->tile_cols;
   if (c->tile_rows > 1 || c->tile_cols > 1) {
-    p->tiles_enabled = 1; p->num_tile_rows = c->tile_rows; p->num_tile_columns = c->tile_cols; p->loop_filter_across_tiles = 1; p->uniform_spacing = c->uniform_tiles;
+    p->tiles_enabled = 1; p->num_tile_rows = c->tile_rows; p->num_tile_columns = c->tile_cols; p->loop_filter_across_tiles = c->lf_across == 0 ? 1 : (c->lf_across == 2 ? 0 : rpct(g, 50)); p->uniform_spacing = c->uniform_tiles;
     if (!c->uniform_tiles) for (int i = 0; i < c->tile_cols - 1; i++) p->column_width[i] = g->col_bd[i + 1] - g->col_bd[i];   /* (explicit widths, the uniform values) */
     if (!c->uniform_tiles) {                                /* explicit row heights: a random monotone partition */
       int left = hc;
@@ -698,7 +699,8 @@ static void write_free_slices(orc_gen *g, int nal)
     if (c) cut[a] = (uint8_t)((p->dependent_slice_segments_enabled && rpct(g, 50)) ? 2 : 1);
   }
   orc_ctx saved[CTX_COUNT];
-  int slice_addr = 0, slice_qp = sh->slice_qp;
+  int slice_addr = 0, slice_qp = sh->slice_qp, slice_lf = sh->loop_filter_across_slices;
+  int *seg_lf = (int *)calloc((size_t)total + 2, sizeof(int));
   orc_pic_reset_side(&g->side);
   memset(&g->c, 0, sizeof(g->c));
   for (int a = 0; a < total; a++) {
@@ -708,7 +710,8 @@ static void write_free_slices(orc_gen *g, int nal)
         slice_addr = a;
         if (a > 0) { slice_qp = sh->slice_qp + rrange(g, -2, 2); if (slice_qp < 0) slice_qp = 0; if (slice_qp > 51) slice_qp = 51; }
       }
-      seg_first[nseg] = nsub; seg_addr[nseg] = a; seg_qpd[nseg] = slice_qp - p->init_qp; nseg++;
+      if (cut[a] == 1 && a > 0 && g->cfg.lf_across == 1 && p->loop_filter_across_slices) slice_lf = rpct(g, 50);
+      seg_first[nseg] = nsub; seg_addr[nseg] = a; seg_qpd[nseg] = slice_qp - p->init_qp; seg_lf[nseg] = slice_lf; nseg++;
     }
     g->ctb_slice[a] = slice_addr;
     if (cut[a] || (wpp && cx == 0)) {
@@ -742,7 +745,7 @@ static void write_free_slices(orc_gen *g, int nal)
     const int s0 = seg_first[k], n = seg_first[k + 1] - s0;
     uint32_t *ep = (uint32_t *)calloc((size_t)n, sizeof(uint32_t));
     sh->first_slice_segment_in_pic = k == 0; sh->slice_segment_address = seg_addr[k]; sh->dependent_slice_segment = cut[seg_addr[k]] == 2;
-    sh->slice_qp_delta = seg_qpd[k]; sh->slice_qp = p->init_qp + seg_qpd[k];
+    sh->slice_qp_delta = seg_qpd[k]; sh->slice_qp = p->init_qp + seg_qpd[k]; sh->loop_filter_across_slices = seg_lf[k];
     sh->num_entry_points = n - 1; sh->entry_point_offset = ep;
     for (int i = 0; i < n - 1; i++) ep[i] = (uint32_t)orc_escaped_size(subs[s0 + i].buf, subs[s0 + i].len);
     orc_bw_init(&hdr);
@@ -752,7 +755,7 @@ static void write_free_slices(orc_gen *g, int nal)
     orc_bw_free(&hdr); free(ep);
   }
   sh->slice_qp_delta = qpd0; sh->slice_qp = p->init_qp + qpd0;
-  free(subs); free(cut); free(seg_first); free(seg_addr); free(seg_qpd);
+  free(subs); free(cut); free(seg_first); free(seg_addr); free(seg_qpd); free(seg_lf);
   sh->entry_point_offset = NULL;
 }
 
@@ -853,7 +856,7 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
     sh->slice_deblocking_disabled = rpct(g, 25);
     if (!sh->slice_deblocking_disabled) { sh->beta_offset_div2 = rrange(g, -6, 6); sh->tc_offset_div2 = rrange(g, -6, 6); }
   }
-  sh->loop_filter_across_slices = 1;
+  sh->loop_filter_across_slices = p->loop_filter_across_slices ? (g->cfg.lf_across ? rpct(g, 50) : 1) : 0;      /* (absent from the header: the PPS's value, 7.4.7.1) */
   if (s->sao_enabled) { sh->sao_luma = rpct(g, 80); sh->sao_chroma = rpct(g, 80); }
   /* ---- slice data: one substream per CTU row with WPP (or with a slice segment per row), else one per tile */
   const int wpp = p->entropy_coding_sync_enabled, slices = g->cfg.slices;
@@ -908,6 +911,7 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
     const int s0 = seg_first[k], n = seg_first[k + 1] - s0;
     uint32_t *ep = (uint32_t *)calloc((size_t)n, sizeof(uint32_t));
     sh->first_slice_segment_in_pic = k == 0; sh->slice_segment_address = seg_addr[k]; sh->dependent_slice_segment = (k > 0 && slices == 1);
+    if (k > 0 && slices == 2 && g->cfg.lf_across == 1 && p->loop_filter_across_slices) sh->loop_filter_across_slices = rpct(g, 50);      /* (a slice per tile: each its own flag) */
     sh->num_entry_points = n - 1; sh->entry_point_offset = ep;
     for (int i = 0; i < n - 1; i++) ep[i] = (uint32_t)orc_escaped_size(subs[s0 + i].buf, subs[s0 + i].len);
     orc_bw_init(&hdr);

@@ -57,6 +57,9 @@ typedef struct {
                                * in any order, repeats allowed); > 0 sets lists_modification_present_flag -- 0 (also -1): off */
   int ctb_log2;               /* CtbLog2SizeY: 6 (also -1 / 0: the streams of rounds 1-5), 5 or 4 -- what encoders other than Kvazaar choose (hardware encoders: 32 or 16);
                                * max_cu_log2 is capped to it */
+  int lf_across;              /* in-loop filtering across slice and tile boundaries: 0 (also -1: every stream of the earlier rounds) everywhere on; 1 = drawn -- half of the
+                               * streams with tiles switch it off across tiles (loop_filter_across_tiles_enabled_flag = 0: what Kvazaar writes), and where the PPS allows
+                               * it every slice draws its slice_loop_filter_across_slices_enabled_flag; 2 = everything off */
   int min_cb_log2;            /* MinCbLog2SizeY: 3 (also -1 / 0: every stream of the earlier rounds), 4 or 5 -- no coding unit below 16 / 32 samples; taken back to 3 when the
                                * picture size is no multiple of it or it exceeds the CTB.  At the minimum size above 8 an inter unit may be cut into four (PART_NxN) */
 } orc_gen_config;

@@ -9,6 +9,10 @@ const int8_t orc_sao_eo_dy[4][2] = { { 0, 0 }, { -1, 1 }, { -1, 1 }, { -1, 1 } }
 static int neighbour_usable(const orc_sao_ctx *s, int ctb, int nctb)
 {
   if (ctb == nctb) return 1;
+  if (s->ctb_nb) {
+    const int w = s->pic_w_ctbs, dx = nctb % w - ctb % w, dy = nctb / w - ctb / w;
+    return (s->ctb_nb[ctb] >> orc_lf_neighbour_bit(dx, dy)) & 1;
+  }
   if (s->ctb_slice && s->ctb_slice[ctb] != s->ctb_slice[nctb] && !s->across_slices) return 0;
   if (s->ctb_tile && s->ctb_tile[ctb] != s->ctb_tile[nctb] && !s->across_tiles) return 0;
   return 1;

@@ -28,9 +28,14 @@ typedef struct {
   /* samples of another slice / tile are used only when filtering across is enabled (NULL arrays: one slice, one tile) */
   const int32_t *ctb_slice; const int16_t *ctb_tile;
   int across_slices, across_tiles;
+  /* ... or, when not NULL, per CTB the neighbouring CTBs whose samples the in-loop filters may use (orc_lf_neighbour_bit: 8 bits), which replaces the four fields
+   * above: slice_loop_filter_across_slices_enabled_flag is a property of each slice, and of two slices the LATER one's flag decides (7.4.7.1) */
+  const uint8_t *ctb_nb;
   const uint8_t *no_filter; int nf_stride;   /* per 4x4 luma block: pcm / transquant-bypass samples stay untouched; may be NULL */
 } orc_sao_ctx;
 
+/* bit of the neighbouring CTB at (dx, dy), each -1 .. 1 and not both 0, in a ctb_nb entry: NW N NE W E SW S SE = 0 .. 7 */
+static inline int orc_lf_neighbour_bit(int dx, int dy) { const int k = (dy + 1) * 3 + (dx + 1); return k > 4 ? k - 1 : k; }
 /* 8.7.3: every CTB of the picture */
 void orc_sao_picture(const orc_sao_ctx *s);
 /* 8.7.3.2 edgeIdx for a sample and its two neighbours (0: none, 1..4) */

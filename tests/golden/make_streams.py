@@ -96,6 +96,10 @@ GEN = {
     # round 6: a minimum coding block of 16 samples (MinCbLog2SizeY 4): inter units cut into four (PART_NxN), intra NxN with 8x8 prediction blocks
     "gen_min_cb16": dict(seed=57, density=30, intra_period=8, num_refs=2, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                          qp_delta=1, deblock_mode=0, intra_in_p=25, all_part_modes=1, nxn_intra=1, max_cu_log2=6, min_cu_log2=4, slices=0, big_mvd=0, min_cb_log2=4),
+    # round 6: what a Kvazaar peer with uvgComm's tiles + slices=tiles settings sends as far as the loop filters go: loop_filter_across_tiles_enabled_flag = 0,
+    # pps_loop_filter_across_slices_enabled_flag = 0 (Kvazaar filters its tiles one by one), a slice per tile; SAO and deblocking on
+    "gen_closed_tiles": dict(seed=59, density=30, intra_period=8, num_refs=2, tmvp=1, amp=0, sao=1, sign_hiding=1, transform_skip=0, wpp=0, tile_rows=2, tile_cols=2,
+                             qp_delta=0, deblock_mode=0, intra_in_p=20, all_part_modes=1, nxn_intra=1, max_cu_log2=6, min_cu_log2=3, slices=2, big_mvd=0, lf_across=2),
     "gen_b_gop8": dict(seed=36, density=25, intra_period=16, num_refs=4, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                        qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=70, gop=8),
 }

@@ -687,9 +687,9 @@ class Decoder:
             if not sh["dbk_disabled"]:
                 sh["beta"] = 2 * r.se()
                 sh["tc"] = 2 * r.se()
+        sh["lf_across"] = pps["lf_slices"]                         # slice_loop_filter_across_slices_enabled_flag: the PPS's value unless sent
         if pps["lf_slices"] and (sh["sao_luma"] or sh["sao_chroma"] or not sh["dbk_disabled"]):
-            if not r.u(1):
-                raise ValueError("no loop filter across slices")
+            sh["lf_across"] = r.u(1)
         return sh, rps, poc
 
     def finish_header_and_decode(self, r, rbsp, nal, nal_type, idr, first, dependent, address, sps, pps, sh, rps, poc):
@@ -817,6 +817,9 @@ class SliceDecoder:
         self.c = None
         self.ctb_slice = [-1] * (self.wc * self.hc)                         # SliceAddrRs of every coding tree block decoded so far
         self.slice_addr, self.ctbs_done, self.wpp_saved, self.ds_saved = 0, 0, None, None
+        self.ctb_order = [0] * (self.wc * self.hc)                          # decoding order of the coding tree blocks
+        self.ctb_lf = [1] * (self.wc * self.hc)                             # slice_loop_filter_across_slices_enabled_flag of each block's slice
+        self.n_ctb = 0
         # tile rows (6.5.1)
         tr = pps["tile_rows"]
         if pps["uniform"]:
@@ -971,8 +974,30 @@ class SliceDecoder:
                 c.start(data[starts[sub]:] if sub < len(starts) else data[c.end_substream():])
         return self.ctbs_done >= total
 
+    def lf_ok(self, xq, yq, xp, yp):
+        """may an in-loop filter working on luma location q use the sample at p?  7.4.3.3.1: not across a tile boundary when loop_filter_across_tiles_enabled_flag
+        is 0; 7.4.7.1: slice_loop_filter_across_slices_enabled_flag = 0 closes the left and upper boundary of the slice that carries it -- of two slices, the boundary
+        between them belongs to the one decoded later"""
+        cq = (yq >> self.ctb_log2) * self.wc + (xq >> self.ctb_log2)
+        cp = (yp >> self.ctb_log2) * self.wc + (xp >> self.ctb_log2)
+        if cq == cp:
+            return True
+        tq = (self.tile_of_row[yq >> self.ctb_log2], self.tile_of_col[xq >> self.ctb_log2])
+        tp = (self.tile_of_row[yp >> self.ctb_log2], self.tile_of_col[xp >> self.ctb_log2])
+        if tq != tp and not self.pps["lf_tiles"]:
+            return False
+        if self.ctb_slice[cq] != self.ctb_slice[cp]:
+            later = cq if self.ctb_order[cq] > self.ctb_order[cp] else cp
+            if not self.ctb_lf[later]:
+                return False
+        return True
+
     def ctu(self, cx, cy):
         x0, y0 = cx << self.ctb_log2, cy << self.ctb_log2
+        a = cy * self.wc + cx
+        self.ctb_order[a] = self.n_ctb
+        self.n_ctb += 1
+        self.ctb_lf[a] = self.sh["lf_across"]
         if self.sh["sao_luma"] or self.sh["sao_chroma"]:
             self.parse_sao(cx, cy)
         self.quadtree(x0, y0, self.ctb_log2, 0)
@@ -1874,6 +1899,8 @@ class SliceDecoder:
                     if not kind or (vertical and (x == 0 or x & 7)) or (not vertical and (y == 0 or y & 7)):
                         continue
                     xp, yp = (x - 1, y) if vertical else (x, y - 1)
+                    if not self.lf_ok(x, y, xp, yp):
+                        continue                                           # 8.7.2.3 filterEdgeFlag = 0: a closed slice / tile boundary
                     bs = bs_of(x, y, xp, yp, kind == 2)
                     if bs:
                         bs_map[(x, y)] = bs
@@ -1979,6 +2006,9 @@ class SliceDecoder:
                             xa, ya, xb, yb = x - dx, y - dy, x + dx, y + dy
                             if xa < 0 or ya < 0 or xb < 0 or yb < 0 or xa >= ww or xb >= ww or ya >= hh or yb >= hh:
                                 continue
+                            shc = 1 if ci else 0
+                            if not (self.lf_ok(x << shc, y << shc, xa << shc, ya << shc) and self.lf_ok(x << shc, y << shc, xb << shc, yb << shc)):
+                                continue                                   # 8.7.3.2: a neighbour across a closed boundary: edgeIdx 0
                             v = int(plane[y, x])
                             e = 2 + (v > plane[ya, xa]) - (v < plane[ya, xa]) + (v > plane[yb, xb]) - (v < plane[yb, xb])
                             if e in (0, 1, 2):

@@ -87,3 +87,27 @@ def test_minimum_coding_blocks_of_16_and_32_samples(min_cb, ctb, w, h):
         nals = [n for au in aus for n in orc.split_nals(au)]
         a, b = PP.probe(nals, 1), PP.probe(nals, 4)
         assert a == b and a["pictures"] == 4, (seed, a, b)
+
+
+@pytest.mark.parametrize("layout", [dict(slices=3, wpp=0), dict(slices=3, wpp=1), dict(slices=2, tile_rows=2, tile_cols=2, wpp=0), dict(slices=0, tile_rows=3, tile_cols=2, wpp=1), dict(slices=2, tile_rows=2, tile_cols=1)])
+def test_boundaries_closed_to_the_loop_filters(layout):
+    """loop_filter_across_tiles_enabled_flag / slice_loop_filter_across_slices_enabled_flag drawn (lf_across = 1) or all off (2): the synthesiser, the checker's decoder
+    and the product's parser (which takes the edge marks off the records along closed boundaries and lays out the neighbour map) on the same streams; the flags change
+    what the checker decodes"""
+    import numpy as np
+    changed = 0
+    for seed in range(1, 9):
+        pics = {}
+        for lf in (0, 1, 2):
+            g = orc.OracleGen(256, 192, seed=seed, lf_across=lf, sao=1, **layout)
+            aus = [g.picture() for _ in range(3)]
+            g.close()
+            od = orc.OracleDecoder()
+            pics[lf] = [f["i420"] for t, au in enumerate(aus) for f in od.decode_au(au, t)] + [f["i420"] for f in od.flush()]
+            od.close()
+            assert len(pics[lf]) == 3
+            nals = [n for au in aus for n in orc.split_nals(au)]
+            a, b = PP.probe(nals, 1), PP.probe(nals, 3)
+            assert a == b and a["pictures"] == 3, (seed, lf, a, b)
+        changed += any(not np.array_equal(x, y) for x, y in zip(pics[0], pics[2]))
+    assert changed >= 6

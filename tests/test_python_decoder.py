@@ -300,3 +300,15 @@ def test_minimum_coding_blocks_of_16_and_32_samples(seed, min_cb, ctb, w, h, kw)
     aus = [g.picture() for _ in range(4)]
     g.close()
     compare(aus)
+
+
+@pytest.mark.parametrize("lf", [1, 2])
+@pytest.mark.parametrize("seed,kw", [(3, dict(slices=3, wpp=0)), (5, dict(slices=3, wpp=1)), (7, dict(slices=0, tile_rows=2, tile_cols=2, wpp=0)), (9, dict(slices=0, tile_rows=3, tile_cols=1, wpp=1))])
+def test_boundaries_closed_to_the_loop_filters(lf, seed, kw):
+    """round 6: loop_filter_across_tiles_enabled_flag = 0 (what Kvazaar writes with tiles) and slice_loop_filter_across_slices_enabled_flag = 0 per slice -- deblocking
+    skips the edges on a closed boundary (8.7.2.3), SAO the samples whose neighbour lies across one (8.7.3.2); of two slices the later one's flag decides (7.4.7.1).
+    pyhevc asks per sample pair (lf_ok), the checker per coding tree block and neighbour: two restatements that must agree"""
+    g = orc.OracleGen(200, 136, seed=seed, lf_across=lf, sao=1, intra_in_p=20, **kw)
+    aus = [g.picture() for _ in range(3)]
+    g.close()
+    compare(aus)

@@ -2498,7 +2498,16 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
         if (free_slices) { if (left && job.ctb_slice[(size_t)ctu - 1] != sp.cur_slice) left = nullptr; if (up && job.ctb_slice[(size_t)ctu - wc] != sp.cur_slice) up = nullptr; }      // (merging stays inside the slice)
         parse_sao(c, *s, left, up, sh.sao_luma != 0, sh.sao_chroma != 0);
       }
+      // (measurement aid, tools/measure/wpp_critical_path.py: KVAZZUP_AMD_CTU_DUMP=<file> -- picture, row, column, nanoseconds of every coding tree unit's parse)
+      static const char *const ctu_dump = getenv("KVAZZUP_AMD_CTU_DUMP");
+      std::chrono::steady_clock::time_point ctu_t0;
+      if (__builtin_expect(ctu_dump != nullptr, 0)) ctu_t0 = std::chrono::steady_clock::now();
       sp.coding_quadtree(cx << ctbl_, cy << ctbl_, ctbl_, 0);
+      if (__builtin_expect(ctu_dump != nullptr, 0)) {
+        const long ns = (long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - ctu_t0).count();
+        static FILE *const fp = fopen(ctu_dump, "w"); static std::mutex m;
+        if (fp) { std::lock_guard<std::mutex> l(m); fprintf(fp, "%d %d %d %ld\n", job.sh.poc, cy, cx, ns); fflush(fp); }
+      }
       if (sp.err) return sp.err;
       if (c.overrun()) return DEC_ERR_INVALID;
       job.ctu[ctu].first = tu0;

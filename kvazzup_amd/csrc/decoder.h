@@ -161,9 +161,10 @@ class Decoder {
 
   // ---- per-picture state shared with the slice-data parser (decoder.hip)
   // one per substream.  Two cache lines each: the rows of a picture are parsed side by side, every one appending to ITS vectors all the time -- the
-  // vectors' headers of neighbouring rows do not share a cache line.  (What limits the row-parallel parse is WPP itself: a row may not start before the row
-  // above has finished two CTUs, and where a clip's bins sit in a few CTUs per row -- the benchmark's moving objects fill the left quarter -- those two CTUs
-  // are most of a row: seventeen rows of a 1080p P picture end 55 us apart, 0.8 ms in all, as long as one thread takes -- tools/measure/owf0_timeline.py.)
+  // vectors' headers of neighbouring rows do not share a cache line.  (What limits the row-parallel parse is WPP itself: a unit can start when its left neighbour
+  // and the unit above-right are done, and a picture takes as long as the heaviest path through that graph.  The benchmark's moving objects are a few very heavy
+  // units stacked over several rows -- ten of a 1080p P picture's 510 units hold a quarter of its parse -- and the heaviest path is two thirds of the whole: 1.4-1.6x
+  // at best with any number of threads, tools/measure/wpp_critical_path.py, profiles/r06_wpp_critical_path.txt; seventeen rows end 55 us apart, owf0_timeline.py.)
   struct alignas(128) SubOut { std::vector<uint32_t> levels; std::vector<DecTu> tus; int rc = 0; };
   struct alignas(64) Progress { std::atomic<int> v{0}; char pad[60]; };   // one cache line per row: no false sharing between pollers
   struct SliceHdr {

@@ -457,7 +457,7 @@ __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, cons
   constexpr int N = XW<L2, T>::N, OPL = XW<L2, T>::OPL, G = XW<L2, T>::G;
   const int sh = c ? 1 : 0, S = (1 << f.ctb_log2) >> sh, nl = N << sh, wC = f.w >> sh, hC = f.h >> sh;
   const int mode = d.mode, cidx = c ? 1 : 0;
-  const bool filt = intra_filter_needed(N, cidx, mode);
+  const bool filt = mode < 35 && intra_filter_needed(N, cidx, mode);      // (mode 35: a PCM unit, no prediction)
   const int Xc = cx * S + rx, Yc = cy * S + ry, X = Xc << sh, Y = Yc << sh;
   // (the block's first 4 T level words arrive in wreg: loaded by the caller one block ahead)
   const bool has = d.count != 0, bypass = (d.flags & TU_BYPASS) != 0, tskip = (d.flags & TU_TSKIP) != 0 || bypass;
@@ -533,6 +533,11 @@ __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, cons
       for (int e = 0; e < 2; e++)
 #pragma unroll
         for (int o = 0; o < OPL; o++) pred[e][o] = pred_dc<L2>(R, edge, dcv, g * OPL + o, 2 * rp + e);
+    } else if (mode == 35) {
+#pragma unroll
+      for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int o = 0; o < OPL; o++) pred[e][o] = 0;
     } else {
       const int angle = kIntraAngle[mode], inv = kInvAngle[mode];
       const bool vert = mode >= 18, e2 = edge && (mode == 26 || mode == 10);
@@ -740,11 +745,11 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
     const int zu = zunit8((rx << sh) >> 3, (ry << sh) >> 3);
     IntraBlk d;
     d.rx = (uint8_t)rx; d.ry = (uint8_t)ry; d.lo = (uint8_t)lo; d.hi = (uint8_t)hi; d.mode = t.mode; d.l2 = t.log2;
-    d.flags = (uint8_t)((intra_filter_needed(N, c ? 1 : 0, t.mode) ? IB_FILT : 0) | ((rx == 0 || ry == 0) ? IB_BORDER : 0) |
+    d.flags = (uint8_t)(((t.mode < 35 && intra_filter_needed(N, c ? 1 : 0, t.mode)) ? IB_FILT : 0) | ((rx == 0 || ry == 0) ? IB_BORDER : 0) |
                         (t.count ? IB_LEVELS : 0) | ((t.flags & TU_TSKIP) ? IB_TSKIP : 0) | (hole ? IB_HOLE : 0) |
                         ((ry + N >= S) ? IB_EDGE : 0) | ((rx + N >= S) ? IB_EDGE_R : 0));
     d.xf = (uint8_t)(hole ? (aT ? 2 * N + 1 : 3 * N + 1) : 0);      // (the decoder's chain adds residuals computed elsewhere: the field is the second run's start of an IB_HOLE block)
-    d.angle = (int16_t)kIntraAngle[t.mode]; d.inv = (int16_t)kInvAngle[t.mode];
+    d.angle = (int16_t)(t.mode < 35 ? kIntraAngle[t.mode] : 0); d.inv = (int16_t)(t.mode < 35 ? kInvAngle[t.mode] : 0);      // (mode 35: a PCM unit, no prediction)
     d.zu = (uint16_t)zu; d.next = 0;
     s.blk[k] = d;
     any32 |= t.log2 == 5;

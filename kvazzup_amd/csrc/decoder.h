@@ -11,13 +11,13 @@
 // slices (both reference lists, bi-prediction, pictures handed out in POC order), every CU size and partitioning (AMP included), intra CUs in P pictures, NxN intra, all chroma
 // prediction modes, transform trees, several reference pictures (RPS in the SPS or the slice header, inter RPS prediction),
 // temporal motion vector prediction, merge levels, cu_qp_delta at any quantisation-group size, chroma QP offsets, sign data
-// hiding, transform skip, scaling lists (default, SPS and PPS scaling_list_data), cu_transquant_bypass (lossless coding units), deblocking offsets /
+// hiding, transform skip, scaling lists (default, SPS and PPS scaling_list_data), cu_transquant_bypass (lossless coding units), PCM coding units, deblocking offsets /
 // overrides, SAO, WPP, tile grids up to the level limit of 20 columns x 22 rows (uniform or
 // explicit spacing; in-loop filtering across tile and slice boundaries on or off -- Kvazaar switches it off), pictures in several slice segments: the two ways Kvazaar cuts them (a dependent slice segment per CTU row with WPP, an
 // independent slice per tile) and -- one-tile pictures -- segments that begin at ANY coding tree block, independent slices (own SliceQpY) and dependent
 // segments mixed (an MTU per slice, N row groups: PicJob::ctb_cut).  Rejected with a negative return value (kvzx_decoder_last_error): several slices
 // inside a tile of a picture with tiles, slices of one picture that differ in more than SliceQpY and the loop filter flag,
-// long-term references, PCM, constrained intra prediction, > 255 slices in a picture.
+// long-term references, constrained intra prediction, > 255 slices in a picture.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -56,6 +56,7 @@ struct DecSps {
   int strong_intra = 0, sao = 0, tmvp = 0, amp = 0, th_depth_inter = 0, th_depth_intra = 0;
   int ctb_log2 = 6;                   // CtbLog2SizeY: 6 (every Kvazaar stream), 5 or 4 (round 6: other encoders' streams); transform blocks 4 .. min(32, CTB)
   int min_cb_log2 = 3;                // MinCbLog2SizeY: 3 (every Kvazaar stream), 4 or 5
+  int pcm_depth[2] = {0, 0}, pcm_min_log2 = 0, pcm_max_log2 = 0, pcm_no_filter = 0;      // pcm_enabled_flag: PcmBitDepthY / C (0: no PCM), Log2MinIpcmCbSizeY .. Log2MaxIpcmCbSizeY, pcm_loop_filter_disabled_flag
   // scaling_list_enabled_flag: the scaling factors (dec_frame.h KVZ_SCALING_BYTES) of the SPS's lists -- the default ones (Tables 7-5 / 7-6) without
   // sps_scaling_list_data; NULL: flat.  What uvgComm's "scaling list" checkbox switches on in a peer's Kvazaar (kvazaarfilter.cpp:235-242).
   std::shared_ptr<const std::vector<uint8_t>> scaling;

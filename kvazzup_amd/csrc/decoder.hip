@@ -929,6 +929,32 @@ struct SliceParser {
         }
       }
       fill_cu8(pm, x0, y0, n, cu_pred_mode);
+      if (cu_pred_mode == PM_INTRA && part_mode == PART_2Nx2N && sps.pcm_depth[0] && log2cb >= sps.pcm_min_log2 && log2cb <= sps.pcm_max_log2 && c.terminate()) {
+        // pcm_flag = 1 (7.3.8.5, 7.3.8.7): the arithmetic codeword has ended; zero bits to the byte boundary, the samples at their bit depths, and the arithmetic
+        // decoder starts again behind them with the contexts as they are (9.3.2.5).  For the kernels the unit is an intra unit of one transform block per plane
+        // whose "levels" ARE the samples (shifted up to 8 bits) -- the residual path of cu_transquant_bypass_flag -- over a prediction of zero (mode 35: none);
+        // for its neighbours its mode is DC (8.4.2); pcm_loop_filter_disabled_flag keeps the loop filters off it the way the bypass flag does.
+        const uint8_t *q = c.buf + c.bytes_consumed();
+        const size_t need = ((size_t)n * n * sps.pcm_depth[0] + (size_t)n * n / 2 * sps.pcm_depth[1]) / 8;
+        if (q > c.end || need > (size_t)(c.end - q)) { err = DEC_ERR_INVALID; return; }
+        BitReader pr(q, need);
+        for (int ci = 0; ci < 3; ci++) {
+          const int shp = ci ? 1 : 0, m = n >> shp, depth = sps.pcm_depth[ci ? 1 : 0];
+          DecTu td; td.pad = 0; td.x = (uint16_t)(x0 >> shp); td.y = (uint16_t)(y0 >> shp); td.plane = (uint8_t)ci; td.log2 = (uint8_t)(log2cb - shp); td.mode = 35; td.qp = 0;
+          td.flags = (uint8_t)(TU_INTRA | TU_BYPASS); td.offset = (uint32_t)out.levels.size();
+          for (int y = 0; y < m; y++)
+            for (int x = 0; x < m; x++) { const uint32_t v = pr.get(depth) << (8 - depth); if (v) out.levels.push_back((uint32_t)((y * m + x) << 16) | v); }
+          td.count = (uint16_t)(out.levels.size() - td.offset);
+          emit_tu(td);
+          ctu_intra_mask |= 1u << ci;
+        }
+        c.start(q + need, (size_t)(c.end - (q + need)));
+        fill_u8(im, x0, y0, n, n, 1);
+        B4Rec r; r.mvx = 0; r.mvy = 0; r.ref_idx = -1; r.flags = (uint8_t)((cu_bypass || sps.pcm_no_filter) ? B4_BYPASS : 0); r.qp_y = (int8_t)qp_y; r.slot = 0;
+        fill_recs(x0, y0, n, n, r, true);
+        if (!job.any_intra) job.any_intra = true;
+        rqt_root_cbf = 0;
+      } else
       if (cu_pred_mode == PM_INTRA) {
         intra_split = part_mode == PART_NxN;
         const int parts = intra_split ? 2 : 1, pb = n / parts;
@@ -1556,12 +1582,17 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
       if (r.get(1) && !parse_scaling_list_data(r, sl)) return last_error_ = DEC_ERR_INVALID;
       s.scaling = build_scaling(sl);
     }
-    s.amp = r.get(1); s.sao = r.get(1); int pcm = r.get(1);
+    s.amp = r.get(1); s.sao = r.get(1);
+    if (r.get(1)) {                                               // pcm_enabled_flag
+      s.pcm_depth[0] = (int)r.get(4) + 1; s.pcm_depth[1] = (int)r.get(4) + 1;
+      s.pcm_min_log2 = (int)r.ue() + 3; s.pcm_max_log2 = s.pcm_min_log2 + (int)r.ue(); s.pcm_no_filter = r.get(1);
+      if (r.err || s.pcm_depth[0] > 8 || s.pcm_depth[1] > 8 || s.pcm_min_log2 < log2_min_cb || s.pcm_max_log2 > imin(5, log2_min_cb + diff_cb)) return last_error_ = DEC_ERR_INVALID;
+    }
     if (r.err) return last_error_ = DEC_ERR_INVALID;
     // coding geometry: CTB 64 (what Kvazaar always writes), 32 or 16 (round 6: other encoders); coding blocks from 8 (Kvazaar), 16 or 32 up; transform blocks 4 .. min(32, CTB)
     if (log2_min_cb < 3 || log2_min_cb > 5 || diff_cb < 0 || diff_cb > 3) return last_error_ = DEC_ERR_INVALID;
     s.ctb_log2 = log2_min_cb + diff_cb; s.min_cb_log2 = log2_min_cb;
-    if (pcm || s.ctb_log2 < 4 || s.ctb_log2 > 6 || log2_min_tb != 2 || diff_tb != imin(3, s.ctb_log2 - 2) || s.th_depth_inter > 4 || s.th_depth_intra > 4)
+    if (s.ctb_log2 < 4 || s.ctb_log2 > 6 || log2_min_tb != 2 || diff_tb != imin(3, s.ctb_log2 - 2) || s.th_depth_inter > 4 || s.th_depth_intra > 4)
       return last_error_ = DEC_ERR_UNSUPPORTED;
     s.num_st_rps = r.ue();
     if (s.num_st_rps > 64) return last_error_ = DEC_ERR_INVALID;
@@ -2726,7 +2757,7 @@ int Decoder::launch_gpu(PicJob &job)
   f.beta_offset = (int8_t)(2 * job.sh.beta_offset_div2); f.tc_offset = (int8_t)(2 * job.sh.tc_offset_div2);
   f.intra_direct = job.any_inter ? 1 : 0;                 // (a picture with inter blocks: few (CTU, plane) pairs hold intra blocks)
   f.strong_intra = (uint8_t)job.sps->strong_intra; f.tiles = job.pps.tile_rows > 1 || job.pps.tile_cols > 1 || job.slice_qps.size() > 1;
-  f.tq_bypass = (uint8_t)job.pps.tq_bypass;
+  f.tq_bypass = (uint8_t)(job.pps.tq_bypass || (job.sps->pcm_depth[0] && job.sps->pcm_no_filter));      // (units the loop filters keep out of: B4_BYPASS records)
   // scaling lists: the picture's factors (the PPS's lists when it carries any, else the SPS's) ride in the input block
   const std::vector<uint8_t> *sc = job.pps.scaling ? job.pps.scaling.get() : job.sps->scaling.get();
   if (!job.sps->scaling) sc = nullptr;                     // (scaling_list_enabled_flag = 0: a PPS's lists are not used)

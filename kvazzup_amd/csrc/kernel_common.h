@@ -710,6 +710,7 @@ __device__ __forceinline__ void wave_intra_predict(const uint8_t *pic, int P, In
   constexpr int N = 1 << L2;
   const int rx = d.rx, ry = d.ry, lo = d.lo, hi = d.hi, mode = d.mode;
   const bool hole = HOLES && (d.flags & IB_HOLE) != 0;      // (two available runs with a gap between them: a sample of the gap takes the last one of the run before it, 8.4.4.2.2)
+  if (HOLES && mode == 35) { pred[0] = pred[1] = pred[2] = pred[3] = 0; return; }      // (decoder: a PCM unit -- its "residual" is the samples themselves)
   int v = 128, last = 128;
   if (hi >= lo) {
     auto at = [&](int i) -> int {

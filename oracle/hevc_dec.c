@@ -541,6 +541,36 @@ static void coding_unit(orc_decoder *d, int x0, int y0, int log2cb, int ct_depth
       }
     }
     fill_b4_u8(pic, pic->pred_mode, x0, y0, n, n, d->cu_pred_mode);
+    if (d->cu_pred_mode == MODE_INTRA && d->part_mode == PART_2Nx2N && s->pcm_enabled && log2cb >= s->log2_min_pcm_cb && log2cb <= s->log2_min_pcm_cb + s->log2_diff_max_min_pcm_cb &&
+        orc_cdec_terminate(c)) {
+      /* pcm_flag = 1 (7.3.8.5, 7.3.8.7): the arithmetic codeword has ended; pcm_alignment_zero_bits, then the samples -- 8.4.4.1? no prediction, no residual:
+       * recSamples = pcm_sample << (BitDepth - PcmBitDepth) -- and the arithmetic decoder starts again behind them with the contexts as they are (9.3.2.5).
+       * IntraPredModeY of the unit is DC for its neighbours (8.4.2); QpY is the predicted one (no cu_qp_delta); pcm_loop_filter_disabled_flag keeps the loop filters off
+       * its samples like cu_transquant_bypass_flag does */
+      const uint8_t *base = c->br.buf; const size_t blen = c->br.len; size_t pos = orc_cdec_bytes_consumed(c);
+      const size_t need = ((size_t)n * n * s->pcm_bit_depth_luma + (size_t)n * n / 2 * s->pcm_bit_depth_chroma) / 8;
+      if (pos + need > blen) { d->err = ERR_INVALID; return; }
+      orc_bitr pr; orc_br_init(&pr, base + pos, need);
+      for (int ci = 0; ci < 3; ci++) {
+        const int sh2 = ci ? 1 : 0, m = n >> sh2, depth = ci ? s->pcm_bit_depth_chroma : s->pcm_bit_depth_luma;
+        for (int y = 0; y < m; y++) for (int x = 0; x < m; x++) {
+          const int v = (int)orc_br_get(&pr, depth) << (8 - depth);
+          if (((y0 >> sh2) + y) < (pic->h >> sh2) && ((x0 >> sh2) + x) < (pic->w >> sh2)) pic->plane[ci][((y0 >> sh2) + y) * pic->stride[ci] + (x0 >> sh2) + x] = (pixel)v;
+        }
+      }
+      orc_cdec_start(c, base + pos + need, blen - pos - need);
+      fill_b4_u8(pic, pic->intra_mode, x0, y0, n, n, 1);
+      if (s->pcm_loop_filter_disabled) fill_b4_u8(pic, pic->no_filter, x0, y0, n, n, 1);
+      for (int i = 0; i < n; i += 4) {
+        if (y0 + i < pic->h) pic->edge_v[b4(pic, x0, y0 + i)] |= 3;
+        if (x0 + i < pic->w) pic->edge_h[b4(pic, x0 + i, y0)] |= 3;
+      }
+      d->qp_y = (d->qp_y_pred + d->cu_qp_delta_val + 52) % 52;
+      for (int y = y0; y < y0 + n && y < pic->h; y += 4)
+        for (int x = x0; x < x0 + n && x < pic->w; x += 4) { pic->qp_y[b4(pic, x, y)] = (int8_t)d->qp_y; pic->tu_nz[b4(pic, x, y)] = 0; }
+      d->last_qp_y = d->qp_y;
+      return;
+    }
     if (d->cu_pred_mode == MODE_INTRA) {
       d->intra_split = (d->part_mode == PART_NxN);
       int parts = d->intra_split ? 2 : 1, pb = n / parts;
@@ -947,7 +977,7 @@ static int decode_slice_data(orc_decoder *d, const uint8_t *data, size_t len)
     if ((p->tiles_enabled && tile_change) ||
         (p->entropy_coding_sync_enabled && (tile_change || (nrs % wc) == d->tile_first_x[nrs]))) {
       if (!orc_cdec_terminate(&d->cabac)) return ERR_INVALID;     /* end_of_subset_one_bit */
-      pos += orc_cdec_bytes_consumed(&d->cabac);
+      pos = (size_t)(d->cabac.br.buf - data) + orc_cdec_bytes_consumed(&d->cabac);      /* (a PCM unit has moved the decoder's window on: its start is no longer the substream's) */
       if (pos >= len) return ERR_INVALID;
       orc_ctx keep[CTX_COUNT]; memcpy(keep, d->cabac.ctx, sizeof(keep));
       orc_cdec_start(&d->cabac, data + pos, len - pos);
@@ -975,7 +1005,7 @@ int orc_dec_decode_nal(orc_decoder *d, const uint8_t *data, size_t len, int64_t 
   orc_bitr br; orc_br_init(&br, d->rbsp, rlen);
   d->cur_pts = pts;
   if (nal_type == NAL_VPS) { orc_vps v; int r = orc_parse_vps(&br, &v); if (r) return r; d->vps[v.vps_id] = v; return 0; }
-  if (nal_type == NAL_SPS) { orc_sps s; int r = orc_parse_sps(&br, &s); if (r) return r; if (s.pcm_enabled) return ERR_UNSUPPORTED; d->sps[s.sps_id] = s; return 0; }
+  if (nal_type == NAL_SPS) { orc_sps s; int r = orc_parse_sps(&br, &s); if (r) return r; d->sps[s.sps_id] = s; return 0; }
   if (nal_type == NAL_PPS) { orc_pps p; int r = orc_parse_pps(&br, &p); if (r) return r; d->pps[p.pps_id] = p; return 0; }
   if (nal_type == 40 && d->last_finished) {           /* suffix SEI: a decoded picture hash (D.2.19) of the picture just finished is checked */
     while (br.pos + 16 <= rlen * 8 && !br.error) {

@@ -157,6 +157,12 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   s->log2_min_cb = c->min_cb_log2; s->log2_diff_max_min_cb = c->ctb_log2 - c->min_cb_log2; s->log2_min_tb = 2; s->log2_diff_max_min_tb = c->ctb_log2 < 5 ? c->ctb_log2 - 2 : 3;      /* (MaxTbLog2SizeY <= Min(CtbLog2SizeY, 5)) */
   s->max_th_depth_inter = c->th_depth_inter; s->max_th_depth_intra = c->th_depth_intra;
   s->amp_enabled = c->amp; s->sao_enabled = c->sao;
+  if (c->pcm > 0) {
+    s->pcm_enabled = 1; s->pcm_bit_depth_luma = rrange(g, 1, 8); s->pcm_bit_depth_chroma = rrange(g, 1, 8);
+    s->log2_min_pcm_cb = rrange(g, 3, ORC_MIN(5, c->ctb_log2)); s->log2_diff_max_min_pcm_cb = rrange(g, 0, ORC_MIN(5, c->ctb_log2) - s->log2_min_pcm_cb);
+    if (s->log2_min_pcm_cb < c->min_cb_log2) { s->log2_min_pcm_cb = c->min_cb_log2; s->log2_diff_max_min_pcm_cb = rrange(g, 0, ORC_MIN(5, c->ctb_log2) - s->log2_min_pcm_cb); }      /* (7.4.3.2.1: Log2MinIpcmCbSizeY in MinCbLog2SizeY .. Min(CtbLog2SizeY, 5)) */
+    s->pcm_loop_filter_disabled = rpct(g, 50);
+  }
   s->scaling_list_enabled = c->scaling_lists > 0; s->scaling_list_data_present = c->scaling_lists == 2 || c->scaling_lists == 4;
   if (s->scaling_list_data_present) gen_scaling(g, &s->scaling, s->sl_pred_mode, s->sl_pred_delta);
   s->num_st_rps = 0;
@@ -177,6 +183,7 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   p->cu_qp_delta_enabled = c->qp_delta > 0; p->diff_cu_qp_delta_depth = c->qp_delta > 0 ? c->qp_delta - 1 : 0;
   if (c->chroma_qp_offsets) { p->cb_qp_offset = rrange(g, -4, 4); p->cr_qp_offset = rrange(g, -4, 4); p->slice_chroma_qp_offsets_present = rpct(g, 50); }
   if (c->lf_across < 0 || c->lf_across > 2) c->lf_across = 0;
+  if (c->pcm < 0) c->pcm = 0;
   p->entropy_coding_sync_enabled = c->wpp; p->loop_filter_across_slices = c->lf_across == 0 ? 1 : (c->lf_across == 2 ? 0 : rpct(g, 70));
   if (c->slices < 0 || c->slices > 3) c->slices = 0;
   if (c->tile_cols < 1) c->tile_cols = 1;
@@ -558,6 +565,20 @@ static void gen_coding_unit(orc_gen *g, int x0, int y0, int log2cb, int ct_depth
       }
     }
     fill4(pic, pic->pred_mode, x0, y0, n, n, g->cu_pred_mode);
+    if (g->cu_pred_mode == MODE_INTRA && g->part_mode == PART_2Nx2N && s->pcm_enabled && log2cb >= s->log2_min_pcm_cb && log2cb <= s->log2_min_pcm_cb + s->log2_diff_max_min_pcm_cb) {
+      /* pcm_flag (a terminating bin); a PCM unit: the arithmetic codeword ends (its last bit is 1), zero bits to the byte boundary, the samples at their bit depths,
+       * and the coder starts again with the contexts as they are (9.3.2.5).  For the syntax around it the unit is an intra unit in DC mode (8.4.2) */
+      const int pcm = rpct(g, g->cfg.pcm);
+      orc_cenc_terminate(c, pcm);
+      if (pcm) {
+        orc_bw_align_zero(c->bw);
+        for (int i = 0; i < n * n; i++) orc_bw_put(c->bw, rnd(g) & ((1u << s->pcm_bit_depth_luma) - 1), s->pcm_bit_depth_luma);
+        for (int i = 0; i < n * n / 2; i++) orc_bw_put(c->bw, rnd(g) & ((1u << s->pcm_bit_depth_chroma) - 1), s->pcm_bit_depth_chroma);
+        orc_cenc_start(c, c->bw);
+        fill4(pic, pic->intra_mode, x0, y0, n, n, 1);
+        return;
+      }
+    }
     if (g->cu_pred_mode == MODE_INTRA) {
       g->intra_split = (g->part_mode == PART_NxN);
       const int parts = g->intra_split ? 2 : 1, pb = n / parts;

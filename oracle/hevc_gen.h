@@ -57,6 +57,8 @@ typedef struct {
                                * in any order, repeats allowed); > 0 sets lists_modification_present_flag -- 0 (also -1): off */
   int ctb_log2;               /* CtbLog2SizeY: 6 (also -1 / 0: the streams of rounds 1-5), 5 or 4 -- what encoders other than Kvazaar choose (hardware encoders: 32 or 16);
                                * max_cu_log2 is capped to it */
+  int pcm;                    /* probability (%) that an intra 2Nx2N coding unit of 8 .. 32 samples is a PCM unit (pcm_flag, raw samples at drawn bit depths, the arithmetic coder
+                               * restarted behind them); > 0 sets pcm_enabled_flag, pcm_loop_filter_disabled_flag drawn -- 0 (also -1): off */
   int lf_across;              /* in-loop filtering across slice and tile boundaries: 0 (also -1: every stream of the earlier rounds) everywhere on; 1 = drawn -- half of the
                                * streams with tiles switch it off across tiles (loop_filter_across_tiles_enabled_flag = 0: what Kvazaar writes), and where the PPS allows
                                * it every slice draws its slice_loop_filter_across_slices_enabled_flag; 2 = everything off */

@@ -98,7 +98,12 @@ void orc_write_sps(orc_bitw *w, const orc_sps *s)
   }
   orc_bw_put(w, (uint32_t)s->amp_enabled, 1);
   orc_bw_put(w, (uint32_t)s->sao_enabled, 1);
-  orc_bw_put(w, 0, 1);                 /* pcm_enabled_flag */
+  orc_bw_put(w, (uint32_t)s->pcm_enabled, 1);
+  if (s->pcm_enabled) {
+    orc_bw_put(w, (uint32_t)s->pcm_bit_depth_luma - 1, 4); orc_bw_put(w, (uint32_t)s->pcm_bit_depth_chroma - 1, 4);
+    orc_bw_ue(w, (uint32_t)s->log2_min_pcm_cb - 3); orc_bw_ue(w, (uint32_t)s->log2_diff_max_min_pcm_cb);
+    orc_bw_put(w, (uint32_t)s->pcm_loop_filter_disabled, 1);
+  }
   orc_bw_ue(w, (uint32_t)s->num_st_rps);
   for (int i = 0; i < s->num_st_rps; i++) write_st_rps(w, &s->st_rps[i], i);
   orc_bw_put(w, 0, 1);                 /* long_term_ref_pics_present_flag */

@@ -100,6 +100,9 @@ GEN = {
     # pps_loop_filter_across_slices_enabled_flag = 0 (Kvazaar filters its tiles one by one), a slice per tile; SAO and deblocking on
     "gen_closed_tiles": dict(seed=59, density=30, intra_period=8, num_refs=2, tmvp=1, amp=0, sao=1, sign_hiding=1, transform_skip=0, wpp=0, tile_rows=2, tile_cols=2,
                              qp_delta=0, deblock_mode=0, intra_in_p=20, all_part_modes=1, nxn_intra=1, max_cu_log2=6, min_cu_log2=3, slices=2, big_mvd=0, lf_across=2),
+    # round 6: PCM coding units (raw samples at 1 .. 8 bits inside the arithmetic codeword, which ends in front of them and starts again behind them)
+    "gen_pcm": dict(seed=61, density=30, intra_period=8, num_refs=2, tmvp=1, amp=0, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
+                    qp_delta=1, deblock_mode=0, intra_in_p=35, all_part_modes=1, nxn_intra=1, max_cu_log2=4, min_cu_log2=3, slices=0, big_mvd=0, pcm=5),
     "gen_b_gop8": dict(seed=36, density=25, intra_period=16, num_refs=4, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                        qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=70, gop=8),
 }

@@ -262,8 +262,11 @@ def parse_sps(rbsp):
             parse_scaling_list_data(r, s["scaling"])
     s["amp"] = r.u(1)
     s["sao"] = r.u(1)
-    if r.u(1):
-        raise ValueError("pcm")
+    s["pcm"] = None
+    if r.u(1):                               # pcm_enabled_flag: sample bit depths, the coding block sizes that may be PCM, pcm_loop_filter_disabled_flag
+        dl, dc = r.u(4) + 1, r.u(4) + 1
+        lo = r.ue() + 3
+        s["pcm"] = {"depth": (dl, dc), "min": lo, "max": lo + r.ue(), "no_filter": r.u(1)}
     n = r.ue()
     s["rps"] = []
     for i in range(n):
@@ -1135,6 +1138,30 @@ class SliceDecoder:
         self.mark_edges(x0, y0, n, n, 2)
         self.cu_intra = intra
         self.cu_part = part
+        pcm = sps["pcm"]
+        if intra and part == PART_2Nx2N and pcm and pcm["min"] <= log2 <= pcm["max"] and c.terminate():
+            # pcm_flag (7.3.8.5) = 1: the arithmetic codeword ends here; zero bits up to the byte boundary, pcm_sample() (7.3.8.7), and the arithmetic decoder starts
+            # again behind the samples with the context variables as they are (9.3.2.5).  8.4.4.1: the samples ARE the reconstruction, shifted up to 8 bits.
+            off = c.end_substream()
+            rb = Bits(c.d[off:])
+            for ci in range(3):
+                mm = n >> (1 if ci else 0)
+                depth = pcm["depth"][1 if ci else 0]
+                xs, ys = x0 >> (1 if ci else 0), y0 >> (1 if ci else 0)
+                for y in range(mm):
+                    for x in range(mm):
+                        v = rb.u(depth) << (8 - depth)
+                        if ys + y < self.pic.planes[ci].shape[0] and xs + x < self.pic.planes[ci].shape[1]:
+                            self.pic.planes[ci][ys + y, xs + x] = v
+            assert rb.pos % 8 == 0
+            c.start(c.d[off + rb.pos // 8:])
+            self.intra_mode[y0 >> 2:(y0 + n) >> 2, x0 >> 2:(x0 + n) >> 2] = 1      # DC for the neighbours' candidate lists (8.4.2)
+            self.pic.ref_idx[y0 >> 2:(y0 + n) >> 2, x0 >> 2:(x0 + n) >> 2, :] = -1
+            if pcm["no_filter"]:
+                self.bypass[y0 >> 2:(y0 + n) >> 2, x0 >> 2:(x0 + n) >> 2] = 1       # pcm_loop_filter_disabled_flag: deblocking and SAO leave the samples alone
+            self.decoded4[y0 >> 2:(y0 + n) >> 2, x0 >> 2:(x0 + n) >> 2] = 1
+            self.last_qp = self.cur_qp
+            return
         if intra:
             nparts = 4 if part == PART_NxN else 1
             pn = n >> 1 if part == PART_NxN else n

@@ -111,3 +111,19 @@ def test_boundaries_closed_to_the_loop_filters(layout):
             assert a == b and a["pictures"] == 3, (seed, lf, a, b)
         changed += any(not np.array_equal(x, y) for x, y in zip(pics[0], pics[2]))
     assert changed >= 6
+
+
+@pytest.mark.parametrize("kw", [dict(wpp=0), dict(wpp=1), dict(wpp=1, slices=3), dict(wpp=0, tile_rows=2, tile_cols=2, slices=0), dict(intra_period=1, ctb_log2=4)])
+def test_pcm_coding_units(kw):
+    """PCM units (round 6): the synthesiser, the checker's decoder and the product's parser (which restarts its arithmetic decoder behind the samples and hands them to
+    the kernels as the levels of a transquant-bypass block over no prediction) on the same streams, one row thread and four"""
+    for seed in range(1, 13):
+        g = orc.OracleGen(192, 128, seed=seed, pcm=30, intra_in_p=40, **kw)
+        aus = [g.picture() for _ in range(4)]
+        g.close()
+        od = orc.OracleDecoder()
+        assert sum(len(od.decode_au(au, t)) for t, au in enumerate(aus)) + len(od.flush()) == 4, seed
+        od.close()
+        nals = [n for au in aus for n in orc.split_nals(au)]
+        a, b = PP.probe(nals, 1), PP.probe(nals, 4)
+        assert a == b and a["pictures"] == 4, (seed, a, b)

@@ -312,3 +312,15 @@ def test_boundaries_closed_to_the_loop_filters(lf, seed, kw):
     aus = [g.picture() for _ in range(3)]
     g.close()
     compare(aus)
+
+
+@pytest.mark.parametrize("seed,kw", [(3, dict(wpp=0)), (4, dict(wpp=1, sao=1)), (5, dict(wpp=1, slices=3)), (6, dict(wpp=0, tile_rows=2, tile_cols=2, slices=0, sao=1)), (7, dict(intra_period=1, max_cu_log2=6)),
+                                     (8, dict(ctb_log2=4, qp_delta=1))])
+def test_pcm_coding_units(seed, kw):
+    """round 6: pcm_flag (a terminating bin), pcm_alignment_zero_bits, the samples at PcmBitDepthY / C, the arithmetic decoder started again behind them with the
+    contexts as they are (9.3.2.5); the unit is DC for its neighbours' candidate lists, its QpY the predicted one, pcm_loop_filter_disabled_flag keeps deblocking and
+    SAO off its samples -- the two independently written decoders must agree before the HIP decoder is held to either"""
+    g = orc.OracleGen(200, 136, seed=seed, pcm=30, intra_in_p=40, **kw)
+    aus = [g.picture() for _ in range(3)]
+    g.close()
+    compare(aus)

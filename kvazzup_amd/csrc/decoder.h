@@ -9,7 +9,7 @@
 // Supported streams: what a Main-profile encoder in a video call produces and OpenHEVC would be asked to decode -- 8-bit 4:2:0,
 // CTB 64 (Kvazaar's fixed geometry), 32 or 16 / minimum CB 8 (Kvazaar's), 16 or 32 / transform blocks 4..min(32, CTB), coded sizes that are multiples of 8, I, P and B
 // slices (both reference lists, bi-prediction, pictures handed out in POC order), every CU size and partitioning (AMP included), intra CUs in P pictures, NxN intra, all chroma
-// prediction modes, transform trees, several reference pictures (RPS in the SPS or the slice header, inter RPS prediction),
+// prediction modes, transform trees, several reference pictures (RPS in the SPS or the slice header, inter RPS prediction), long-term reference pictures,
 // temporal motion vector prediction, merge levels, cu_qp_delta at any quantisation-group size, chroma QP offsets, sign data
 // hiding, transform skip, scaling lists (default, SPS and PPS scaling_list_data), cu_transquant_bypass (lossless coding units), PCM coding units, deblocking offsets /
 // overrides, SAO, WPP, tile grids up to the level limit of 20 columns x 22 rows (uniform or
@@ -17,7 +17,7 @@
 // independent slice per tile) and -- one-tile pictures -- segments that begin at ANY coding tree block, independent slices (own SliceQpY) and dependent
 // segments mixed (an MTU per slice, N row groups: PicJob::ctb_cut).  Rejected with a negative return value (kvzx_decoder_last_error): several slices
 // inside a tile of a picture with tiles, slices of one picture that differ in more than SliceQpY and the loop filter flag,
-// long-term references, constrained intra prediction, > 255 slices in a picture.
+// constrained intra prediction, > 255 slices in a picture.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -56,6 +56,7 @@ struct DecSps {
   int strong_intra = 0, sao = 0, tmvp = 0, amp = 0, th_depth_inter = 0, th_depth_intra = 0;
   int ctb_log2 = 6;                   // CtbLog2SizeY: 6 (every Kvazaar stream), 5 or 4 (round 6: other encoders' streams); transform blocks 4 .. min(32, CTB)
   int min_cb_log2 = 3;                // MinCbLog2SizeY: 3 (every Kvazaar stream), 4 or 5
+  int num_lt_sps = -1; uint16_t lt_lsb_sps[32] = {}; uint8_t lt_used_sps[32] = {};      // long_term_ref_pics_present_flag (-1: not set): the SPS's candidates
   int pcm_depth[2] = {0, 0}, pcm_min_log2 = 0, pcm_max_log2 = 0, pcm_no_filter = 0;      // pcm_enabled_flag: PcmBitDepthY / C (0: no PCM), Log2MinIpcmCbSizeY .. Log2MaxIpcmCbSizeY, pcm_loop_filter_disabled_flag
   // scaling_list_enabled_flag: the scaling factors (dec_frame.h KVZ_SCALING_BYTES) of the SPS's lists -- the default ones (Tables 7-5 / 7-6) without
   // sps_scaling_list_data; NULL: flat.  What uvgComm's "scaling list" checkbox switches on in a peer's Kvazaar (kvazaarfilter.cpp:235-242).
@@ -117,7 +118,7 @@ class FrameWorkers {
 // motion of its top-left 4x4.  Written by the picture's parser row by row, read by the parsers of following pictures (which may
 // run concurrently under frame threading: row_done[] orders them).
 struct ColMotion {
-  struct Mv { int16_t mv[2][2]; int32_t ref_poc[2]; uint8_t used; uint8_t pad[3]; };      // per list: vector, POC of the picture it points into; used: bit L = list L predicts the block (0: intra)
+  struct Mv { int16_t mv[2][2]; int32_t ref_poc[2]; uint8_t used; uint8_t lt; uint8_t pad[2]; };      // per list: vector, POC of the picture it points into; used: bit L = list L predicts the block (0: intra); lt: bit L = that picture was a long-term reference picture then (8.5.3.2.9)
   int w16 = 0, h16 = 0, hc = 0, poc = 0;
   std::vector<Mv> mv;
   std::unique_ptr<std::atomic<uint8_t>[]> row_done;      // per CTU row
@@ -208,6 +209,7 @@ class Decoder {
     int cvs = 0;                                                 // the coded video sequence it belongs to (output order)
     int nref = 0; int ref_poc[16]; uint8_t ref_slot[16];        // RefPicList0
     int nref1 = 0; int ref_poc1[16]; uint8_t ref_slot1[16];     // RefPicList1 (B slices)
+    uint8_t ref_lt[16] = {}, ref_lt1[16] = {};                  // the entry is a long-term reference picture (8.3.2: no vector scaling, 8.5.3.2.7 / 8.5.3.2.9)
     bool no_backward = true;                                     // NoBackwardPredFlag (8.5.3.2.9): no entry of either list follows the picture in output order
     // B slices: the two-list motion of every 4x4 block as the parser's own derivations read it (merge, AMVP); what the kernels need of it goes
     // into the B4Rec (the first used list's vector and picture) and, for bi-predicted blocks (B4_BI), the second vector here
@@ -332,7 +334,8 @@ class Decoder {
   bool queue_current_output();
   std::unique_ptr<FrameWorkers> workers_;
   // decoded picture buffer: slot = device planes + what reference marking needs
-  struct DpbPic { uint8_t *plane[3] = {nullptr, nullptr, nullptr}; int poc = 0; bool is_ref = false, used = false; long decode_idx = -1000; std::shared_ptr<ColMotion> motion;
+  struct DpbPic { uint8_t *plane[3] = {nullptr, nullptr, nullptr}; int poc = 0; bool is_ref = false, used = false, is_lt = false;      // is_lt: marked "used for long-term reference" (8.3.2)
+                  long decode_idx = -1000; std::shared_ptr<ColMotion> motion;
                   hipEvent_t last_dl = nullptr;
                   hipEvent_t last_use = nullptr; bool last_use_alt = false; };      // (two chains, below: the last picture that read or wrote the buffer, and the stream it ran on)     // download mode: the copy of the picture last reconstructed here (a later picture's kernels wait for it before they write the buffer)
   DpbPic dpb_[KVZ_DEC_MAX_REFS];

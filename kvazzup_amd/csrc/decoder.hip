@@ -462,6 +462,7 @@ struct SliceParser {
   // temporal candidate of list X (8.5.3.2.8, 8.5.3.2.9).  The collocated block may be bi-predicted (a B picture): of its two vectors the one of list X
   // counts when no reference picture of this slice follows it in output order, else the one of list collocated_from_l0_flag.
   inline int list_poc(int L, int idx) const { return L ? job.ref_poc1[idx & 15] : job.ref_poc[idx & 15]; }
+  inline bool list_lt(int L, int idx) const { return (L ? job.ref_lt1[idx & 15] : job.ref_lt[idx & 15]) != 0; }      // the entry is a long-term reference picture
   static void scale_by(int &mvx, int &mvy, int td_, int tb_)
   {
     const int td = clip3(-128, 127, td_), tb = clip3(-128, 127, tb_);
@@ -490,9 +491,11 @@ struct SliceParser {
       const ColMotion::Mv &m = col->mv[(size_t)y * col->w16 + x];
       if (!m.used) continue;
       const int L = m.used == 2 ? 1 : (m.used == 1 ? 0 : (job.no_backward ? X : sh.collocated_from_l0));
+      const bool cur_lt = list_lt(X, ref_idx);
+      if ((((m.lt >> L) & 1) != 0) != cur_lt) continue;      // 8.5.3.2.9: one of the two reference pictures long-term, the other not: no candidate from this block
       const int col_diff = col->poc - m.ref_poc[L], cur_diff = sh.poc - list_poc(X, ref_idx);
       mvx = m.mv[L][0]; mvy = m.mv[L][1];
-      if (col_diff != cur_diff && col_diff != 0) scale_by(mvx, mvy, col_diff, cur_diff);
+      if (!cur_lt && col_diff != cur_diff && col_diff != 0) scale_by(mvx, mvy, col_diff, cur_diff);      // (long-term: taken as it is)
       return true;
     }
     return false;
@@ -554,16 +557,18 @@ struct SliceParser {
     const bool is_scaled = avA[0] || avA[1];
     bool flagA = false, flagB = false; int ax = 0, ay = 0, bx = 0, by = 0;
     const int target = job.ref_poc[ref_idx];
+    const bool tlt = job.ref_lt[ref_idx & 15] != 0;          // (8.5.3.2.7 step 7: a vector into ANOTHER picture counts when that picture and the target are both long-term -- as it is -- or both short-term -- scaled)
     for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) { const B4Rec &m = b4[bi(xa[k], ya[k])]; if (job.ref_poc[m.ref_idx & 15] == target) { flagA = true; ax = m.mvx; ay = m.mvy; } }
-    for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) { const B4Rec &m = b4[bi(xa[k], ya[k])]; flagA = true; ax = m.mvx; ay = m.mvy; scale_mv(ax, ay, m.ref_idx & 15, ref_idx); }
+    for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) { const B4Rec &m = b4[bi(xa[k], ya[k])]; if ((job.ref_lt[m.ref_idx & 15] != 0) != tlt) continue; flagA = true; ax = m.mvx; ay = m.mvy; if (!tlt) scale_mv(ax, ay, m.ref_idx & 15, ref_idx); }
     for (int k = 0; k < 3 && !flagB; k++) if (avB[k]) { const B4Rec &m = b4[bi(xb[k], yb[k])]; if (job.ref_poc[m.ref_idx & 15] == target) { flagB = true; bx = m.mvx; by = m.mvy; } }
     if (!is_scaled && flagB) { flagA = true; ax = bx; ay = by; }
     if (!is_scaled) {
       flagB = false;
       for (int k = 0; k < 3 && !flagB; k++) if (avB[k]) {
         const B4Rec &m = b4[bi(xb[k], yb[k])];
+        if ((job.ref_lt[m.ref_idx & 15] != 0) != tlt) continue;
         flagB = true; bx = m.mvx; by = m.mvy;
-        if (job.ref_poc[m.ref_idx & 15] != target) scale_mv(bx, by, m.ref_idx & 15, ref_idx);
+        if (!tlt && job.ref_poc[m.ref_idx & 15] != target) scale_mv(bx, by, m.ref_idx & 15, ref_idx);
       }
     }
     int n = 0;
@@ -653,11 +658,12 @@ struct SliceParser {
       for (int L : {X, Y}) if (m.ref[L] >= 0 && list_poc(L, m.ref[L]) == target) { vx = m.mv[L][0]; vy = m.mv[L][1]; return true; }
       return false;
     };
+    const bool tlt = list_lt(X, ref_idx);
     auto any_pic = [&](const MvF &m, int &vx, int &vy) {
-      for (int L : {X, Y}) if (m.ref[L] >= 0) {
+      for (int L : {X, Y}) if (m.ref[L] >= 0 && list_lt(L, m.ref[L]) == tlt) {
         vx = m.mv[L][0]; vy = m.mv[L][1];
         const int poc = list_poc(L, m.ref[L]);
-        if (poc != target) scale_by(vx, vy, sh.poc - poc, sh.poc - target);
+        if (!tlt && poc != target) scale_by(vx, vy, sh.poc - poc, sh.poc - target);
         return true;
       }
       return false;
@@ -1597,7 +1603,11 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     s.num_st_rps = r.ue();
     if (s.num_st_rps > 64) return last_error_ = DEC_ERR_INVALID;
     for (int k = 0; k < s.num_st_rps; k++) if (!parse_st_rps(r, k, s.num_st_rps, s.st_rps, s.st_rps[k])) return last_error_ = DEC_ERR_INVALID;
-    if (r.get(1)) return last_error_ = DEC_ERR_UNSUPPORTED;      // long-term references
+    if (r.get(1)) {                                               // long_term_ref_pics_present_flag: candidates by POC LSBs
+      s.num_lt_sps = (int)r.ue();
+      if (s.num_lt_sps > 32) return last_error_ = DEC_ERR_INVALID;
+      for (int k = 0; k < s.num_lt_sps; k++) { s.lt_lsb_sps[k] = (uint16_t)r.get(s.log2_max_poc_lsb); s.lt_used_sps[k] = (uint8_t)r.get(1); }
+    }
     s.tmvp = r.get(1);
     s.strong_intra = r.get(1);
     if (r.get(1)) {                                               // VUI: timing only
@@ -1855,6 +1865,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   sh.is_intra = slice_type == 2; sh.is_b = slice_type == 0;
   if (p.output_flag_present) r.get(1);
   StRps rps;
+  int nlt = 0, lt_lsb[16] = {}, lt_cycle[16] = {}; bool lt_used[16] = {}, lt_msb[16] = {};
   if (!idr) {
     const int lsb = r.get(s.log2_max_poc_lsb), max_lsb = 1 << s.log2_max_poc_lsb;
     const int prev_lsb = prev_poc_ & (max_lsb - 1), prev_msb = prev_poc_ - prev_lsb;
@@ -1870,6 +1881,22 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
       if (idx >= s.num_st_rps) return DEC_ERR_INVALID;
       rps = s.st_rps[idx];
     } else if (!parse_st_rps(r, s.num_st_rps, s.num_st_rps, s.st_rps, rps)) return DEC_ERR_INVALID;
+    if (s.num_lt_sps >= 0) {
+      // long-term reference pictures (7.3.6.1): candidates of the SPS by index, then explicit ones; DeltaPocMsbCycleLt accumulates inside each group (7-52)
+      const int n_sps = s.num_lt_sps > 0 ? (int)r.ue() : 0, n_pics = (int)r.ue();
+      if (r.err || n_sps < 0 || n_sps > s.num_lt_sps || n_pics < 0 || n_sps + n_pics > 16) return DEC_ERR_INVALID;
+      nlt = n_sps + n_pics;
+      int bits = 0; while ((1 << bits) < s.num_lt_sps) bits++;
+      for (int k = 0; k < nlt; k++) {
+        if (k < n_sps) { const int idx = bits ? (int)r.get(bits) : 0; if (idx >= s.num_lt_sps) return DEC_ERR_INVALID; lt_lsb[k] = s.lt_lsb_sps[idx]; lt_used[k] = s.lt_used_sps[idx] != 0; }
+        else { lt_lsb[k] = (int)r.get(s.log2_max_poc_lsb); lt_used[k] = r.get(1) != 0; }
+        lt_msb[k] = r.get(1) != 0;
+        const int delta = lt_msb[k] ? (int)r.ue() : 0;
+        if (delta < 0 || delta > (1 << 20)) return DEC_ERR_INVALID;
+        lt_cycle[k] = delta + ((k == 0 || k == n_sps) ? 0 : lt_cycle[k - 1]);
+      }
+      if (r.err) return DEC_ERR_INVALID;
+    }
     if (s.tmvp) sh.tmvp = r.get(1);
   }
   if (s.sao) { sh.sao_luma = r.get(1); sh.sao_chroma = r.get(1); }
@@ -1877,9 +1904,10 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   if (!sh.is_intra) {
     if (r.get(1)) { sh.num_ref_idx = (int)r.ue() + 1; if (sh.is_b) sh.num_ref_idx1 = (int)r.ue() + 1; }
     if (sh.num_ref_idx < 1 || sh.num_ref_idx > 15 || (sh.is_b && (sh.num_ref_idx1 < 1 || sh.num_ref_idx1 > 15))) return DEC_ERR_INVALID;
-    if (p.lists_mod) {                                            // ref_pic_lists_modification(): NumPicTotalCurr = the set's used pictures (no long-term ones)
+    if (p.lists_mod) {                                            // ref_pic_lists_modification(): NumPicTotalCurr = the set's used pictures, short-term and long-term
       int total = 0;
       for (int k = 0; k < rps.n_neg + rps.n_pos; k++) total += rps.used[k] ? 1 : 0;
+      for (int k = 0; k < nlt; k++) total += lt_used[k] ? 1 : 0;
       if (total > 1) {
         int bits = 0; while ((1 << bits) < total) bits++;
         for (int l = 0; l < (sh.is_b ? 2 : 1); l++) {
@@ -1978,31 +2006,47 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   if (!ensure_buffers(s.width, s.height, s.ctb_log2)) return DEC_ERR_GPU;
   // ---- reference picture set (8.3.2) and RefPicList0 (8.3.4): pictures not in the set stop being references
   if (idr) for (auto &d : dpb_) d.is_ref = false;
-  int nref = 0, ref_poc[16]; uint8_t ref_slot[16];
-  int nref1 = 0, ref_poc1[16]; uint8_t ref_slot1[16];
+  int nref = 0, ref_poc[16]; uint8_t ref_slot[16], ref_lt[16] = {};
+  int nref1 = 0, ref_poc1[16]; uint8_t ref_slot1[16], ref_lt1[16] = {};
   bool no_backward = true;
   if (!idr) {
-    int cand_slot[16], nc = 0, nbefore = 0;             // the used pictures: those before the current one in output order (nearest first), then those after it
+    int cand_slot[32], nc = 0, nbefore = 0;             // the used pictures: those before the current one in output order (nearest first), then those after it, then the long-term ones
     bool keep[KVZ_DEC_MAX_REFS] = {false};
+    // the long-term entries first, among all reference pictures (8.3.2): by the POC's LSBs, or by the whole POC when delta_poc_msb_present_flag says how many LSB
+    // cycles back -- what they name is a long-term reference picture from now on; the short-term entries name pictures among the rest
+    int lt_slot[16], nl = 0;
+    const int max_lsb = 1 << s.log2_max_poc_lsb;
+    for (int k = 0; k < nlt; k++) {
+      const int full = sh.poc - lt_cycle[k] * max_lsb - (sh.poc & (max_lsb - 1)) + lt_lsb[k];
+      int found = -1;
+      for (int q = 0; q < KVZ_DEC_MAX_REFS; q++) if (dpb_[q].is_ref && dpb_[q].used && (lt_msb[k] ? dpb_[q].poc == full : (dpb_[q].poc & (max_lsb - 1)) == lt_lsb[k])) found = q;
+      if (found >= 0) { keep[found] = true; dpb_[found].is_lt = true; }
+      if (lt_used[k]) { if (found < 0 && !sh.is_intra) return DEC_ERR_INVALID; if (found >= 0) lt_slot[nl++] = found; }
+    }
     for (int k = 0; k < rps.n_neg + rps.n_pos; k++) {
       const int poc = sh.poc + rps.dpoc[k];
       int found = -1;
-      for (int q = 0; q < KVZ_DEC_MAX_REFS; q++) if (dpb_[q].is_ref && dpb_[q].used && dpb_[q].poc == poc) found = q;
+      for (int q = 0; q < KVZ_DEC_MAX_REFS; q++) if (dpb_[q].is_ref && dpb_[q].used && !dpb_[q].is_lt && dpb_[q].poc == poc) found = q;
       if (found >= 0) keep[found] = true;
       if (rps.used[k]) { if (found < 0 && !sh.is_intra) return DEC_ERR_INVALID; if (found >= 0 && nc < 16) { cand_slot[nc++] = found; if (k < rps.n_neg) nbefore = nc; } }      // a missing reference picture (lost access unit)
     }
     for (int q = 0; q < KVZ_DEC_MAX_REFS; q++) if (!keep[q]) dpb_[q].is_ref = false;
     if (!sh.is_intra) {
-      if (nc == 0) return DEC_ERR_INVALID;
-      // 8.3.4: RefPicList0 = before, after, repeated; RefPicList1 = after, before, repeated
+      const int nst = nc;                                 // (the short-term part of the temporary lists)
+      for (int k = 0; k < nl && nc < 32; k++) cand_slot[nc++] = lt_slot[k];
+      if (nc == 0 || nc > 16) return DEC_ERR_INVALID;
+      // 8.3.4: RefPicList0 = before, after, long-term, repeated; RefPicList1 = after, before, long-term, repeated
       nref = sh.num_ref_idx;
       // (a modified list names entries of the temporary list; nc = NumPicTotalCurr here: a used picture that is missing ended the call above)
-      for (int k = 0; k < nref; k++) { ref_slot[k] = (uint8_t)cand_slot[sh.list_mod[0] ? imin(sh.list_entry[0][k], nc - 1) : k % nc]; ref_poc[k] = dpb_[ref_slot[k]].poc; if (ref_poc[k] > sh.poc) no_backward = false; }
+      for (int k = 0; k < nref; k++) {
+        const int q = sh.list_mod[0] ? imin(sh.list_entry[0][k], nc - 1) : k % nc;
+        ref_slot[k] = (uint8_t)cand_slot[q]; ref_lt[k] = (uint8_t)(q >= nst); ref_poc[k] = dpb_[ref_slot[k]].poc; if (ref_poc[k] > sh.poc) no_backward = false;
+      }
       nref1 = sh.is_b ? sh.num_ref_idx1 : 0;
-      const int nafter = nc - nbefore;
+      const int nafter = nst - nbefore;
       for (int k = 0; k < nref1; k++) {
         const int q = sh.list_mod[1] ? imin(sh.list_entry[1][k], nc - 1) : k % nc;
-        ref_slot1[k] = (uint8_t)cand_slot[q < nafter ? nbefore + q : q - nafter]; ref_poc1[k] = dpb_[ref_slot1[k]].poc;
+        ref_slot1[k] = (uint8_t)cand_slot[q >= nst ? q : (q < nafter ? nbefore + q : q - nafter)]; ref_lt1[k] = (uint8_t)(q >= nst); ref_poc1[k] = dpb_[ref_slot1[k]].poc;
         if (ref_poc1[k] > sh.poc) no_backward = false;
       }
     }
@@ -2021,7 +2065,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   job.crop[0] = s.crop_l; job.crop[1] = s.crop_r; job.crop[2] = s.crop_t; job.crop[3] = s.crop_b;
   job.fps_num = s.fps_num ? s.fps_num : vps_fps_num_; job.fps_den = s.fps_num ? s.fps_den : vps_fps_den_;
   job.slot = slot; job.nref = nref;
-  for (int k = 0; k < 16; k++) { job.ref_poc[k] = k < nref ? ref_poc[k] : sh.poc; job.ref_slot[k] = k < nref ? ref_slot[k] : 0; }
+  for (int k = 0; k < 16; k++) { job.ref_poc[k] = k < nref ? ref_poc[k] : sh.poc; job.ref_slot[k] = k < nref ? ref_slot[k] : 0; job.ref_lt[k] = k < nref ? ref_lt[k] : 0; job.ref_lt1[k] = k < nref1 ? ref_lt1[k] : 0; }
   if (idr || (irap && !seen_irap_)) cvs_++;                     // a new coded video sequence: its pictures follow ALL of the last one's in output order
   job.cvs = cvs_;
   job.nref1 = nref1; job.no_backward = no_backward;
@@ -2237,7 +2281,7 @@ int Decoder::submit_job(PicJob &job, int nal_type, bool irap)
   // knows at once; with frame threads the worker finds out and decode_slice looks when the next segment arrives.)
   job.undo.poc = d.poc; job.undo.prev_poc = prev_poc_; job.undo.is_ref = d.is_ref; job.undo.used = d.used; job.undo.seen_irap = seen_irap_; job.undo.decode_idx = d.decode_idx; job.undo.motion = d.motion;
   auto take_back = [&] { take_back_job(job); return 0; };
-  d.poc = sh.poc; d.is_ref = true; d.used = true; d.decode_idx = job_head_; d.motion = job.own;
+  d.poc = sh.poc; d.is_ref = true; d.used = true; d.is_lt = false; d.decode_idx = job_head_; d.motion = job.own;
   if (cur_tid_ == 0 && (nal_type > 9 || ((nal_type & 1) && nal_type < 6))) prev_poc_ = sh.poc;   // prevTid0Pic (8.3.1): TemporalId 0, not RASL / RADL / sub-layer non-reference
   if (irap) seen_irap_ = true;
   job_head_++;
@@ -2572,8 +2616,8 @@ int Decoder::parse_substream(PicJob &job, int sub, const uint8_t *data, size_t l
         if (m.ref_idx < 0) continue;                           // intra
         if (sh.is_b) {
           const PicJob::MvF &f = job.mvf[i4];
-          for (int L = 0; L < 2; L++) if (f.ref[L] >= 0) { o.used |= (uint8_t)(1 << L); o.mv[L][0] = f.mv[L][0]; o.mv[L][1] = f.mv[L][1]; o.ref_poc[L] = L ? job.ref_poc1[f.ref[L] & 15] : job.ref_poc[f.ref[L] & 15]; }
-        } else { o.used = 1; o.mv[0][0] = m.mvx; o.mv[0][1] = m.mvy; o.ref_poc[0] = job.ref_poc[m.ref_idx & 15]; }
+          for (int L = 0; L < 2; L++) if (f.ref[L] >= 0) { o.used |= (uint8_t)(1 << L); o.mv[L][0] = f.mv[L][0]; o.mv[L][1] = f.mv[L][1]; o.ref_poc[L] = L ? job.ref_poc1[f.ref[L] & 15] : job.ref_poc[f.ref[L] & 15]; if ((L ? job.ref_lt1 : job.ref_lt)[f.ref[L] & 15]) o.lt |= (uint8_t)(1 << L); }
+        } else { o.used = 1; o.mv[0][0] = m.mvx; o.mv[0][1] = m.mvy; o.ref_poc[0] = job.ref_poc[m.ref_idx & 15]; o.lt = job.ref_lt[m.ref_idx & 15] ? 1 : 0; }
       }
     if (own->row_cols[(size_t)cy].fetch_add(1, std::memory_order_acq_rel) + 1 >= own->cols) own->row_done[(size_t)cy].store(1, std::memory_order_release);
   }

@@ -434,7 +434,7 @@ static void prediction_unit(orc_decoder *d, int xcb, int ycb, int ncbs, int xp, 
   orc_mvpred_ctx mc; memset(&mc, 0, sizeof(mc));
   mc.pic = pic; mc.av = d->av; mc.log2_par_mrg_level = d->p->log2_parallel_merge_level;
   mc.max_num_merge_cand = d->sh.max_num_merge_cand; mc.num_ref_idx = d->sh.num_ref_idx_l0;
-  mc.cur_poc = pic->poc; memcpy(mc.ref_poc, d->ref_poc, sizeof(mc.ref_poc));
+  mc.cur_poc = pic->poc; memcpy(mc.ref_poc, d->ref_poc, sizeof(mc.ref_poc)); memcpy(mc.ref_lt, pic->ref_lt_list, 16); memcpy(mc.ref_lt1, pic->ref_lt_list1, 16);
   mc.is_b = is_b; mc.num_ref_idx1 = d->sh.num_ref_idx_l1; memcpy(mc.ref_poc1, d->ref_poc1, sizeof(mc.ref_poc1));
   mc.collocated_from_l0 = d->sh.collocated_from_l0; mc.no_backward_pred = d->no_backward_pred;
   mc.col = NULL;
@@ -783,15 +783,23 @@ static int start_picture(orc_decoder *d)
   d->cur = alloc_pic(d, s->width, s->height);
   if (!d->cur) return ERR_INVALID;
   d->cur->poc = poc; d->cur->pts = d->cur_pts;
-  d->cur->is_ref = 1; d->cur->needed_for_output = 0; d->cur->out_queued = 0;
+  d->cur->is_ref = 1; d->cur->is_lt = 0; d->cur->needed_for_output = 0; d->cur->out_queued = 0;
   /* 8.3.2 reference picture set: everything not in the RPS is marked unused */
   if (!idr) {
     for (int i = 0; i < MAX_DPB; i++) {
       orc_pic *q = &d->dpb[i];
       if (!q->in_use || !q->is_ref || q == d->cur) continue;
       int keep = 0;
-      for (int k = 0; k < sh->st_rps.num_negative; k++) if (q->poc == poc + sh->st_rps.delta_poc_s0[k]) keep = 1;
-      for (int k = 0; k < sh->st_rps.num_positive; k++) if (q->poc == poc + sh->st_rps.delta_poc_s1[k]) keep = 1;
+      /* 8.3.2: the long-term entries first, among ALL reference pictures -- by the POC's LSBs, or by the whole POC when delta_poc_msb_present_flag says how many
+       * LSB cycles back; what they name is a long-term reference picture from now on.  Then the short-term entries among the rest. */
+      for (int k = 0; k < sh->num_lt; k++) {
+        const int full = poc - sh->lt_msb_cycle[k] * max_lsb - (poc & (max_lsb - 1)) + sh->lt_poc_lsb[k];
+        if (sh->lt_msb_present[k] ? q->poc == full : (q->poc & (max_lsb - 1)) == sh->lt_poc_lsb[k]) { keep = 1; q->is_lt = 1; }
+      }
+      if (!keep && !q->is_lt) {
+        for (int k = 0; k < sh->st_rps.num_negative; k++) if (q->poc == poc + sh->st_rps.delta_poc_s0[k]) keep = 1;
+        for (int k = 0; k < sh->st_rps.num_positive; k++) if (q->poc == poc + sh->st_rps.delta_poc_s1[k]) keep = 1;
+      }
       if (!keep) q->is_ref = 0;
     }
     /* C.5.2.2: room for the current picture -- more pictures waiting than may be reordered, or no free picture buffer */
@@ -828,16 +836,28 @@ static int build_ref_list(orc_decoder *d)
   d->num_ref = d->num_ref1 = 0; d->no_backward_pred = 1;
   for (int i = 0; i < 16; i++) d->cur->ref_poc_list[i] = d->cur->ref_poc_list1[i] = d->cur->poc;      /* unused entries: never compared */
   if (sh->slice_type == SLICE_I) return 0;
-  orc_pic *before[16], *after[16]; int nb = 0, na = 0;
+  orc_pic *before[16], *after[16], *lt[16]; int nb = 0, na = 0, nl = 0;
   int poc = d->cur->poc;
-  for (int k = 0; k < sh->st_rps.num_negative; k++) if (sh->st_rps.used_s0[k]) before[nb++] = find_poc(d, poc + sh->st_rps.delta_poc_s0[k]);
-  for (int k = 0; k < sh->st_rps.num_positive; k++) if (sh->st_rps.used_s1[k]) after[na++] = find_poc(d, poc + sh->st_rps.delta_poc_s1[k]);
-  const int nc = nb + na;
-  if (nc == 0) return ERR_INVALID;
+  const int max_lsb = 1 << d->s->log2_max_poc_lsb;
+  for (int k = 0; k < sh->st_rps.num_negative && nb < 16; k++) if (sh->st_rps.used_s0[k]) { before[nb] = find_poc(d, poc + sh->st_rps.delta_poc_s0[k]); if (before[nb] && before[nb]->is_lt) before[nb] = NULL; nb++; }
+  for (int k = 0; k < sh->st_rps.num_positive && na < 16; k++) if (sh->st_rps.used_s1[k]) { after[na] = find_poc(d, poc + sh->st_rps.delta_poc_s1[k]); if (after[na] && after[na]->is_lt) after[na] = NULL; na++; }
+  for (int k = 0; k < sh->num_lt && nl < 16; k++) if (sh->lt_used[k]) {      /* RefPicSetLtCurr (8.3.2) */
+    const int full = poc - sh->lt_msb_cycle[k] * max_lsb - (poc & (max_lsb - 1)) + sh->lt_poc_lsb[k];
+    lt[nl] = NULL;
+    for (int i = 0; i < MAX_DPB; i++) {
+      orc_pic *q = &d->dpb[i];
+      if (q->in_use && q->is_ref && q->is_lt && q != d->cur && (sh->lt_msb_present[k] ? q->poc == full : (q->poc & (max_lsb - 1)) == sh->lt_poc_lsb[k])) lt[nl] = q;
+    }
+    nl++;
+  }
+  const int nc = nb + na + nl;
+  if (nc == 0 || nc > 16) return ERR_INVALID;
+  memset(d->cur->ref_lt_list, 0, sizeof(d->cur->ref_lt_list)); memset(d->cur->ref_lt_list1, 0, sizeof(d->cur->ref_lt_list1));
   for (int i = 0; i < sh->num_ref_idx_l0; i++) {
-    const int k = sh->rpl_mod_flag[0] ? sh->list_entry[0][i] : i % nc;      /* 8.3.4: an entry of the temporary list (before, after, before, ...) */
-    d->ref_list0[i] = k < nb ? before[k] : after[k - nb];
+    const int k = sh->rpl_mod_flag[0] ? sh->list_entry[0][i] : i % nc;      /* 8.3.4: an entry of the temporary list (before, after, long-term, before, ...) */
+    d->ref_list0[i] = k < nb ? before[k] : (k < nb + na ? after[k - nb] : lt[k - nb - na]);
     if (!d->ref_list0[i]) return ERR_INVALID;      /* missing reference picture */
+    d->cur->ref_lt_list[i] = (uint8_t)(k >= nb + na);
     d->ref_poc[i] = d->cur->ref_poc_list[i] = d->ref_list0[i]->poc;
     if (d->ref_poc[i] > poc) d->no_backward_pred = 0;
   }
@@ -845,8 +865,9 @@ static int build_ref_list(orc_decoder *d)
   if (sh->slice_type == SLICE_B) {
     for (int i = 0; i < sh->num_ref_idx_l1; i++) {
       const int k = sh->rpl_mod_flag[1] ? sh->list_entry[1][i] : i % nc;
-      d->ref_list1[i] = k < na ? after[k] : before[k - na];
+      d->ref_list1[i] = k < na ? after[k] : (k < na + nb ? before[k - na] : lt[k - na - nb]);
       if (!d->ref_list1[i]) return ERR_INVALID;
+      d->cur->ref_lt_list1[i] = (uint8_t)(k >= na + nb);
       d->ref_poc1[i] = d->cur->ref_poc_list1[i] = d->ref_list1[i]->poc;
       if (d->ref_poc1[i] > poc) d->no_backward_pred = 0;
     }

@@ -34,6 +34,7 @@ struct orc_gen {
   int hist_poc[8], hist_n;            /* POCs of the pictures decoded since the IDR, newest first (the reference picture set is the first num_refs of them) */
   int gop_order[8];                   /* cfg.gop > 1: POC offsets inside a group in decoding order */
   int slice_is_b;
+  int lt_alive, lt_marked;            /* long_term: the sequence's first picture (POC 0) is still in the reference picture set / has become a long-term reference picture */
   int slice_is_intra;
   /* coding-unit state */
   int cu_qp_delta_coded, log2_qg;
@@ -166,6 +167,10 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   s->scaling_list_enabled = c->scaling_lists > 0; s->scaling_list_data_present = c->scaling_lists == 2 || c->scaling_lists == 4;
   if (s->scaling_list_data_present) gen_scaling(g, &s->scaling, s->sl_pred_mode, s->sl_pred_delta);
   s->num_st_rps = 0;
+  if (c->long_term > 0) {                                   /* candidates in the SPS: POC LSB 0 (the sequence's first picture), used by the current picture or only kept */
+    s->long_term_ref_pics_present = 1; s->num_lt_sps = rrange(g, 0, 2);
+    for (int i = 0; i < s->num_lt_sps; i++) { s->lt_poc_lsb_sps[i] = 0; s->lt_used_sps[i] = (uint8_t)(i == 0); }
+  }
   s->temporal_mvp_enabled = c->tmvp; s->strong_intra_smoothing = c->strong_intra;
   s->vui_present = 1; s->vui_timing_present = 1; s->vui_num_units_in_tick = 1; s->vui_time_scale = 30;
   orc_sps_derive(s);
@@ -184,6 +189,7 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   if (c->chroma_qp_offsets) { p->cb_qp_offset = rrange(g, -4, 4); p->cr_qp_offset = rrange(g, -4, 4); p->slice_chroma_qp_offsets_present = rpct(g, 50); }
   if (c->lf_across < 0 || c->lf_across > 2) c->lf_across = 0;
   if (c->pcm < 0) c->pcm = 0;
+  if (c->long_term < 0 || c->gop || c->b_slices > 0) c->long_term = 0;
   p->entropy_coding_sync_enabled = c->wpp; p->loop_filter_across_slices = c->lf_across == 0 ? 1 : (c->lf_across == 2 ? 0 : rpct(g, 70));
   if (c->slices < 0 || c->slices > 3) c->slices = 0;
   if (c->tile_cols < 1) c->tile_cols = 1;
@@ -803,11 +809,32 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
   sh->num_ref_idx_l1 = p->num_ref_idx_l1_default;
   if (!idr && !g->cfg.gop && !g->cfg.b_slices) {
     /* reference picture set in the slice header, the way Kvazaar writes it: the previous pictures back to the IDR, at most num_refs */
-    const int nneg = ORC_MIN(g->cfg.num_refs, g->since_idr);
+    int nneg = ORC_MIN(g->cfg.num_refs, g->since_idr);
+    int lt_used = 0;
+    if (s->long_term_ref_pics_present && g->since_idr >= 1) {
+      /* the sequence's first picture (POC 0; in this branch POC = pictures since the IDR) as a long-term reference picture: marked at once now and then, else
+       * when it is about to leave the short-term window; from then on it is no short-term picture any more, and it stays until a slice stops naming it */
+      if (g->lt_alive && !g->lt_marked && (g->since_idr > g->cfg.num_refs || (g->since_idr >= 2 && rpct(g, 30)))) g->lt_marked = 1;
+      if (g->lt_alive && g->lt_marked && rpct(g, 4)) g->lt_alive = 0;
+      if (g->lt_marked) nneg = ORC_MIN(nneg, g->since_idr - 1);
+      if (!g->lt_marked && g->since_idr > g->cfg.num_refs) g->lt_alive = 0;
+      if (g->lt_alive && g->lt_marked) {
+        const int want_used = rpct(g, 70), max_lsb = 1 << s->log2_max_poc_lsb;
+        int via_sps = -1;
+        for (int i = 0; i < s->num_lt_sps; i++) if (s->lt_used_sps[i] == want_used && rpct(g, 60)) via_sps = i;
+        sh->num_long_term_sps = via_sps >= 0; sh->num_long_term_pics = via_sps < 0; sh->num_lt = 1;
+        sh->lt_idx_sps[0] = via_sps >= 0 ? via_sps : 0; sh->lt_poc_lsb[0] = 0; sh->lt_used[0] = (uint8_t)want_used;
+        sh->lt_msb_present[0] = (uint8_t)(g->poc >= max_lsb || rpct(g, 40));      /* (needed once another picture may share the LSBs) */
+        sh->lt_msb_cycle_delta[0] = sh->lt_msb_cycle[0] = sh->lt_msb_present[0] ? g->poc >> s->log2_max_poc_lsb : 0;
+        lt_used = want_used;
+      }
+    }
     sh->short_term_ref_pic_set_sps_flag = 0;
     sh->st_rps.num_negative = nneg;
     int used = 0;
     for (int i = 0; i < nneg; i++) { sh->st_rps.delta_poc_s0[i] = -(i + 1); sh->st_rps.used_s0[i] = (i == 0) ? 1 : rpct(g, 85); used += sh->st_rps.used_s0[i]; }
+    used += lt_used;
+    if (!used) { sh->lt_used[0] = 1; lt_used = used = 1; if (sh->num_long_term_sps) { sh->num_long_term_sps = 0; sh->num_long_term_pics = 1; } }      /* (nothing short-term left -- the picture behind the IDR after an early marking: the long-term one is used) */
     sh->num_ref_idx_l0 = g->slice_is_intra ? p->num_ref_idx_l0_default : rrange(g, 1, ORC_MIN(4, used + 1));   /* (more entries than pictures: the list wraps) */
     sh->slice_temporal_mvp_enabled = s->temporal_mvp_enabled ? rpct(g, 80) : 0;
     sh->collocated_from_l0 = 1;
@@ -838,6 +865,7 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
     int total = 0;
     for (int i = 0; i < sh->st_rps.num_negative; i++) total += sh->st_rps.used_s0[i];
     for (int i = 0; i < sh->st_rps.num_positive; i++) total += sh->st_rps.used_s1[i];
+    for (int i = 0; i < sh->num_lt; i++) total += sh->lt_used[i];
     if (total > 1) for (int l = 0; l < (g->slice_is_b ? 2 : 1); l++) if (rpct(g, g->cfg.list_mod)) {
       sh->rpl_mod_flag[l] = 1;
       for (int i = 0; i < (l ? sh->num_ref_idx_l1 : sh->num_ref_idx_l0); i++) sh->list_entry[l][i] = (uint8_t)rrange(g, 0, total - 1);
@@ -949,7 +977,7 @@ size_t orc_gen_picture(orc_gen *g, const uint8_t **au)
 {
   const int period = g->cfg.intra_period;
   const int idr = (g->frame_idx == 0) || (period > 0 && (g->frame_idx % period) == 0);
-  if (idr) { g->poc = 0; g->since_idr = 0; g->hist_n = 0; }
+  if (idr) { g->poc = 0; g->since_idr = 0; g->hist_n = 0; g->lt_alive = 1; g->lt_marked = 0; }
   else {
     g->since_idr++;
     if (g->cfg.gop) { const int k = g->since_idr - 1; g->poc = (k / g->cfg.gop) * g->cfg.gop + g->gop_order[k % g->cfg.gop]; }

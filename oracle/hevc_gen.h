@@ -57,6 +57,9 @@ typedef struct {
                                * in any order, repeats allowed); > 0 sets lists_modification_present_flag -- 0 (also -1): off */
   int ctb_log2;               /* CtbLog2SizeY: 6 (also -1 / 0: the streams of rounds 1-5), 5 or 4 -- what encoders other than Kvazaar choose (hardware encoders: 32 or 16);
                                * max_cu_log2 is capped to it */
+  int long_term;              /* > 0: long-term reference pictures (P streams without reordering: the sequence's first picture becomes a long-term reference picture -- at once in a
+                               * third of the cases, else when it leaves the short-term window -- and stays one until dropped; named through the SPS's candidates or explicitly,
+                               * with and without delta_poc_msb_present_flag, used by the current picture or only kept) -- 0 (also -1): off */
   int pcm;                    /* probability (%) that an intra 2Nx2N coding unit of 8 .. 32 samples is a PCM unit (pcm_flag, raw samples at drawn bit depths, the arithmetic coder
                                * restarted behind them); > 0 sets pcm_enabled_flag, pcm_loop_filter_disabled_flag drawn -- 0 (also -1): off */
   int lf_across;              /* in-loop filtering across slice and tile boundaries: 0 (also -1: every stream of the earlier rounds) everywhere on; 1 = drawn -- half of the

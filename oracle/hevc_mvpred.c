@@ -17,6 +17,7 @@ static const orc_mvinfo *mvat(const orc_mvpred_ctx *c, int x, int y) { return &c
 static int mi_ref(const orc_mvinfo *m, int l) { return l ? m->ref_idx1 : m->ref_idx; }
 static const int16_t *mi_mv(const orc_mvinfo *m, int l) { return l ? m->mv1 : m->mv; }
 static int list_poc(const orc_mvpred_ctx *c, int l, int idx) { return l ? c->ref_poc1[idx & 15] : c->ref_poc[idx & 15]; }
+static int list_lt(const orc_mvpred_ctx *c, int l, int idx) { return l ? c->ref_lt1[idx & 15] : c->ref_lt[idx & 15]; }
 /* "the same motion vectors and the same reference indices" (8.5.3.2.3): per list, the vector of a list that is not used does not count */
 static int same_motion(const orc_mvinfo *a, const orc_mvinfo *b)
 {
@@ -57,9 +58,11 @@ static int temporal_mv(const orc_mvpred_ctx *c, int xpb, int ypb, int npbw, int 
     int l;
     if (m->ref_idx < 0) l = 1; else if (m->ref_idx1 < 0) l = 0; else l = c->no_backward_pred ? X : c->collocated_from_l0;
     const int col_ref_poc = l ? col->ref_poc_list1[m->ref_idx1 & 15] : col->ref_poc_list[m->ref_idx & 15];
+    const int col_lt = l ? col->ref_lt_list1[m->ref_idx1 & 15] : col->ref_lt_list[m->ref_idx & 15], cur_lt = list_lt(c, X, ref_idx);
+    if (col_lt != cur_lt) continue;                              /* 8.5.3.2.9: one of the two reference pictures long-term, the other not: no candidate from this block */
     const int col_poc_diff = col->poc - col_ref_poc, cur_poc_diff = c->cur_poc - list_poc(c, X, ref_idx);
     mv[0] = mi_mv(m, l)[0]; mv[1] = mi_mv(m, l)[1];
-    if (col_poc_diff != cur_poc_diff && col_poc_diff != 0) scale_by(mv, col_poc_diff, cur_poc_diff);
+    if (!cur_lt && col_poc_diff != cur_poc_diff && col_poc_diff != 0) scale_by(mv, col_poc_diff, cur_poc_diff);      /* (long-term: taken as it is) */
     return 1;
   }
   return 0;
@@ -147,7 +150,9 @@ void orc_amvp_candidates_lx(const orc_mvpred_ctx *c, int xcb, int ycb, int ncbs,
   for (int k = 0; k < 3; k++) avB[k] = pb_available(c, xcb, ycb, ncbs, xpb, ypb, npbw, npbh, part_idx, xb[k], yb[k]);
   int is_scaled = avA[0] || avA[1];
   int flagA = 0, flagB = 0; int16_t mvA[2] = {0, 0}, mvB[2] = {0, 0};
-  const int target_poc = list_poc(c, X, ref_idx), Y = !X;
+  const int target_poc = list_poc(c, X, ref_idx), Y = !X, target_lt = list_lt(c, X, ref_idx);
+  /* (8.5.3.2.7 step 7: a neighbour's vector into ANOTHER picture counts when that picture and the target are both long-term -- then as it is -- or both short-term -- scaled) */
+#define LT_MATCH(m, L) (mi_ref(m, L) >= 0 && list_lt(c, L, mi_ref(m, L)) == target_lt)
   /* a neighbour's vector that points into the target picture: list X first, then list Y (8.5.3.2.7 steps 3 / 5 of the A and B derivations) */
 #define SAME_PIC(m, L) (mi_ref(m, L) >= 0 && list_poc(c, L, mi_ref(m, L)) == target_poc)
 #define TAKE(dst, m, L) do { (dst)[0] = mi_mv(m, L)[0]; (dst)[1] = mi_mv(m, L)[1]; } while (0)
@@ -158,8 +163,8 @@ void orc_amvp_candidates_lx(const orc_mvpred_ctx *c, int xcb, int ycb, int ncbs,
   /* A: then any reference picture, scaled by the ratio of the POC distances */
   for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) {
     const orc_mvinfo *m = mvat(c, xa[k], ya[k]);
-    const int L = mi_ref(m, X) >= 0 ? X : (mi_ref(m, Y) >= 0 ? Y : -1);
-    if (L >= 0) { flagA = 1; TAKE(mvA, m, L); scale_by(mvA, c->cur_poc - list_poc(c, L, mi_ref(m, L)), c->cur_poc - target_poc); }
+    const int L = LT_MATCH(m, X) ? X : (LT_MATCH(m, Y) ? Y : -1);
+    if (L >= 0) { flagA = 1; TAKE(mvA, m, L); if (!target_lt) scale_by(mvA, c->cur_poc - list_poc(c, L, mi_ref(m, L)), c->cur_poc - target_poc); }
   }
   /* B: same reference picture */
   for (int k = 0; k < 3 && !flagB; k++) if (avB[k]) {
@@ -171,16 +176,17 @@ void orc_amvp_candidates_lx(const orc_mvpred_ctx *c, int xcb, int ycb, int ncbs,
     flagB = 0;
     for (int k = 0; k < 3 && !flagB; k++) if (avB[k]) {
       const orc_mvinfo *m = mvat(c, xb[k], yb[k]);
-      const int L = mi_ref(m, X) >= 0 ? X : (mi_ref(m, Y) >= 0 ? Y : -1);
+      const int L = LT_MATCH(m, X) ? X : (LT_MATCH(m, Y) ? Y : -1);
       if (L >= 0) {
         flagB = 1; TAKE(mvB, m, L);
         const int poc = list_poc(c, L, mi_ref(m, L));
-        if (poc != target_poc) scale_by(mvB, c->cur_poc - poc, c->cur_poc - target_poc);
+        if (!target_lt && poc != target_poc) scale_by(mvB, c->cur_poc - poc, c->cur_poc - target_poc);
       }
     }
   }
 #undef SAME_PIC
 #undef TAKE
+#undef LT_MATCH
   int n = 0;
   if (flagA) { cand[n][0] = mvA[0]; cand[n][1] = mvA[1]; n++; }
   if (flagB && !(flagA && mvA[0] == mvB[0] && mvA[1] == mvB[1])) { cand[n][0] = mvB[0]; cand[n][1] = mvB[1]; n++; }

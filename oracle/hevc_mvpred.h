@@ -20,6 +20,7 @@ typedef struct {
   int is_b, num_ref_idx1; int ref_poc1[16];   /* slice_type == B, num_ref_idx_l1_active, POC of RefPicList1 entries */
   int collocated_from_l0;        /* collocated_from_l0_flag (1 in P slices) */
   int no_backward_pred;          /* NoBackwardPredFlag (8.5.3.2.9): no entry of either list follows the current picture in output order */
+  uint8_t ref_lt[16], ref_lt1[16];   /* the entry is a long-term reference picture (all 0: none -- the encoder's context) */
 } orc_mvpred_ctx;
 
 typedef orc_mvinfo orc_mvcand;   /* mv / ref_idx: list 0, mv1 / ref_idx1: list 1; an index of -1 = the list is not used */

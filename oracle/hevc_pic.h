@@ -35,6 +35,8 @@ typedef struct {
   int ref_poc_list[16];              /* POC of RefPicList0[i] of the (single) slice of this picture: boundary strength compares reference PICTURES
                                       * (8.7.2.4), temporal motion vector prediction scales by POC distances (8.5.3.2.9) */
   int ref_poc_list1[16];             /* ... of RefPicList1[i] (B slices) */
+  int is_lt;                         /* decoder: marked "used for long-term reference" (8.3.2) */
+  uint8_t ref_lt_list[16], ref_lt_list1[16];   /* RefPicListX[i] was a long-term reference picture when this picture was the current one (LongTermRefPic of 8.5.3.2.9) */
 } orc_pic;
 
 int  orc_pic_alloc(orc_pic *p, int w, int h);

@@ -106,7 +106,11 @@ void orc_write_sps(orc_bitw *w, const orc_sps *s)
   }
   orc_bw_ue(w, (uint32_t)s->num_st_rps);
   for (int i = 0; i < s->num_st_rps; i++) write_st_rps(w, &s->st_rps[i], i);
-  orc_bw_put(w, 0, 1);                 /* long_term_ref_pics_present_flag */
+  orc_bw_put(w, (uint32_t)s->long_term_ref_pics_present, 1);
+  if (s->long_term_ref_pics_present) {
+    orc_bw_ue(w, (uint32_t)s->num_lt_sps);
+    for (int i = 0; i < s->num_lt_sps; i++) { orc_bw_put(w, (uint32_t)s->lt_poc_lsb_sps[i], s->log2_max_poc_lsb); orc_bw_put(w, s->lt_used_sps[i], 1); }
+  }
   orc_bw_put(w, (uint32_t)s->temporal_mvp_enabled, 1);
   orc_bw_put(w, (uint32_t)s->strong_intra_smoothing, 1);
   orc_bw_put(w, (uint32_t)s->vui_present, 1);
@@ -203,6 +207,16 @@ void orc_write_slice_header(orc_bitw *w, const orc_slice_hdr *h, const orc_sps *
       orc_bw_put(w, (uint32_t)h->short_term_ref_pic_set_sps_flag, 1);
       if (!h->short_term_ref_pic_set_sps_flag) write_st_rps(w, &h->st_rps, s->num_st_rps);
       else if (s->num_st_rps > 1) orc_bw_put(w, (uint32_t)h->short_term_rps_idx, ceil_log2((unsigned)s->num_st_rps));
+      if (s->long_term_ref_pics_present) {
+        if (s->num_lt_sps > 0) orc_bw_ue(w, (uint32_t)h->num_long_term_sps);
+        orc_bw_ue(w, (uint32_t)h->num_long_term_pics);
+        for (int i = 0; i < h->num_long_term_sps + h->num_long_term_pics; i++) {
+          if (i < h->num_long_term_sps) { if (s->num_lt_sps > 1) orc_bw_put(w, (uint32_t)h->lt_idx_sps[i], ceil_log2((unsigned)s->num_lt_sps)); }
+          else { orc_bw_put(w, (uint32_t)h->lt_poc_lsb[i], s->log2_max_poc_lsb); orc_bw_put(w, h->lt_used[i], 1); }
+          orc_bw_put(w, h->lt_msb_present[i], 1);
+          if (h->lt_msb_present[i]) orc_bw_ue(w, (uint32_t)h->lt_msb_cycle_delta[i]);
+        }
+      }
       if (s->temporal_mvp_enabled) orc_bw_put(w, (uint32_t)h->slice_temporal_mvp_enabled, 1);
     }
     if (s->sao_enabled) { orc_bw_put(w, (uint32_t)h->sao_luma, 1); orc_bw_put(w, (uint32_t)h->sao_chroma, 1); }
@@ -218,6 +232,7 @@ void orc_write_slice_header(orc_bitw *w, const orc_slice_hdr *h, const orc_sps *
         int num_pic_total = 0;
         for (int i = 0; i < h->st_rps.num_negative; i++) num_pic_total += h->st_rps.used_s0[i];
         for (int i = 0; i < h->st_rps.num_positive; i++) num_pic_total += h->st_rps.used_s1[i];
+        for (int i = 0; i < h->num_long_term_sps + h->num_long_term_pics; i++) num_pic_total += h->lt_used[i];
         if (p->lists_modification_present && num_pic_total > 1) {
           const int bits = ceil_log2((unsigned)num_pic_total);
           for (int l = 0; l < (h->slice_type == SLICE_B ? 2 : 1); l++) {
@@ -442,7 +457,12 @@ int orc_parse_sps(orc_bitr *r, orc_sps *s)
   for (int i = 0; i < s->num_st_rps; i++)
     if (parse_st_rps(r, &s->st_rps[i], i, s->num_st_rps, s->st_rps)) return -1;
   s->long_term_ref_pics_present = (int)orc_br_get(r, 1);
-  if (s->long_term_ref_pics_present) return -2;              /* unsupported */
+  s->num_lt_sps = 0;
+  if (s->long_term_ref_pics_present) {
+    s->num_lt_sps = (int)orc_br_ue(r);
+    if (s->num_lt_sps > 32) return -1;
+    for (int i = 0; i < s->num_lt_sps; i++) { s->lt_poc_lsb_sps[i] = (int)orc_br_get(r, s->log2_max_poc_lsb); s->lt_used_sps[i] = (uint8_t)orc_br_get(r, 1); }
+  }
   s->temporal_mvp_enabled = (int)orc_br_get(r, 1);
   s->strong_intra_smoothing = (int)orc_br_get(r, 1);
   s->vui_present = (int)orc_br_get(r, 1);
@@ -582,6 +602,23 @@ int orc_parse_slice_header(orc_bitr *r, orc_slice_hdr *h, int nal_type, const or
       if (h->short_term_rps_idx >= s->num_st_rps) return -1;
       h->st_rps = s->st_rps[h->short_term_rps_idx];
     }
+    h->num_long_term_sps = h->num_long_term_pics = h->num_lt = 0;
+    if (s->long_term_ref_pics_present) {
+      if (s->num_lt_sps > 0) h->num_long_term_sps = (int)orc_br_ue(r);
+      h->num_long_term_pics = (int)orc_br_ue(r);
+      if (h->num_long_term_sps < 0 || h->num_long_term_sps > s->num_lt_sps || h->num_long_term_pics < 0 || h->num_long_term_sps + h->num_long_term_pics > 16) return -1;
+      h->num_lt = h->num_long_term_sps + h->num_long_term_pics;
+      for (int i = 0; i < h->num_lt; i++) {
+        if (i < h->num_long_term_sps) {
+          h->lt_idx_sps[i] = s->num_lt_sps > 1 ? (int)orc_br_get(r, ceil_log2((unsigned)s->num_lt_sps)) : 0;
+          if (h->lt_idx_sps[i] >= s->num_lt_sps) return -1;
+          h->lt_poc_lsb[i] = s->lt_poc_lsb_sps[h->lt_idx_sps[i]]; h->lt_used[i] = s->lt_used_sps[h->lt_idx_sps[i]];
+        } else { h->lt_poc_lsb[i] = (int)orc_br_get(r, s->log2_max_poc_lsb); h->lt_used[i] = (uint8_t)orc_br_get(r, 1); }
+        h->lt_msb_present[i] = (uint8_t)orc_br_get(r, 1);
+        h->lt_msb_cycle_delta[i] = h->lt_msb_present[i] ? (int)orc_br_ue(r) : 0;
+        h->lt_msb_cycle[i] = h->lt_msb_cycle_delta[i] + ((i == 0 || i == h->num_long_term_sps) ? 0 : h->lt_msb_cycle[i - 1]);      /* (7-52) */
+      }
+    }
     if (s->temporal_mvp_enabled) h->slice_temporal_mvp_enabled = (int)orc_br_get(r, 1);
   }
   if (s->sao_enabled) { h->sao_luma = (int)orc_br_get(r, 1); h->sao_chroma = (int)orc_br_get(r, 1); }
@@ -596,6 +633,7 @@ int orc_parse_slice_header(orc_bitr *r, orc_slice_hdr *h, int nal_type, const or
     int num_pic_total = 0;
     for (int i = 0; i < h->st_rps.num_negative; i++) num_pic_total += h->st_rps.used_s0[i];
     for (int i = 0; i < h->st_rps.num_positive; i++) num_pic_total += h->st_rps.used_s1[i];
+    for (int i = 0; i < h->num_lt; i++) num_pic_total += h->lt_used[i];
     h->rpl_mod_flag[0] = h->rpl_mod_flag[1] = 0;
     if (p->lists_modification_present && num_pic_total > 1) {              /* ref_pic_lists_modification() */
       const int bits = ceil_log2((unsigned)num_pic_total);

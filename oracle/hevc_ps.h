@@ -42,6 +42,7 @@ typedef struct {
   int pcm_bit_depth_luma, pcm_bit_depth_chroma, log2_min_pcm_cb, log2_diff_max_min_pcm_cb, pcm_loop_filter_disabled;
   int num_st_rps; orc_st_rps st_rps[65];
   int long_term_ref_pics_present;
+  int num_lt_sps; int lt_poc_lsb_sps[32]; uint8_t lt_used_sps[32];      /* num_long_term_ref_pics_sps candidates: lt_ref_pic_poc_lsb_sps, used_by_curr_pic_lt_sps_flag */
   int temporal_mvp_enabled, strong_intra_smoothing;
   int vui_present, vui_timing_present; uint32_t vui_num_units_in_tick, vui_time_scale;
   /* derived */
@@ -80,6 +81,12 @@ typedef struct {
   int poc_lsb;
   int short_term_ref_pic_set_sps_flag, short_term_rps_idx;
   orc_st_rps st_rps;                       /* active RPS (copied from SPS or parsed) */
+  /* long-term reference pictures (7.3.6.1; SPS long_term_ref_pics_present_flag): num_lt entries = num_long_term_sps candidates of the SPS (lt_idx_sps) followed by
+   * num_long_term_pics explicit ones (poc_lsb_lt, used_by_curr_pic_lt_flag), each with delta_poc_msb_present_flag [+ delta_poc_msb_cycle_lt].  The parser resolves
+   * them: lt_poc_lsb / lt_used (from the SPS for the first kind), lt_msb_cycle = DeltaPocMsbCycleLt (7-52: the cycles accumulate inside each of the two groups) */
+  int num_long_term_sps, num_long_term_pics, num_lt;
+  int lt_idx_sps[16], lt_poc_lsb[16], lt_msb_cycle[16]; uint8_t lt_used[16], lt_msb_present[16];
+  int lt_msb_cycle_delta[16];                /* writer: delta_poc_msb_cycle_lt as coded */
   int slice_temporal_mvp_enabled;
   int sao_luma, sao_chroma;
   int num_ref_idx_l0, num_ref_idx_l1;

@@ -103,6 +103,9 @@ GEN = {
     # round 6: PCM coding units (raw samples at 1 .. 8 bits inside the arithmetic codeword, which ends in front of them and starts again behind them)
     "gen_pcm": dict(seed=61, density=30, intra_period=8, num_refs=2, tmvp=1, amp=0, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                     qp_delta=1, deblock_mode=0, intra_in_p=35, all_part_modes=1, nxn_intra=1, max_cu_log2=4, min_cu_log2=3, slices=0, big_mvd=0, pcm=5),
+    # round 6: long-term reference pictures (the sequence's first picture kept as one: SPS candidates and explicit entries, LSBs only and with the MSB cycles)
+    "gen_long_term": dict(seed=63, density=20, intra_period=16, num_refs=3, tmvp=1, amp=0, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
+                          qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=0, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, long_term=1),
     "gen_b_gop8": dict(seed=36, density=25, intra_period=16, num_refs=4, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                        qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=70, gop=8),
 }
@@ -112,7 +115,7 @@ for name, cfg in ({} if only else GEN).items():
     g = orc.OracleGen(W, H, **cfg)
     od = orc.OracleDecoder()
     stream, md5s = b"", []
-    npic = 12 if cfg.get("gop") else 6
+    npic = 12 if cfg.get("gop") or cfg.get("long_term") else 6
     for t in range(npic):
         au = g.picture()
         stream += au

@@ -271,8 +271,9 @@ def parse_sps(rbsp):
     s["rps"] = []
     for i in range(n):
         s["rps"].append(parse_st_rps(r, i, n, s["rps"]))
+    s["lt"] = None                           # long_term_ref_pics_present_flag: the SPS's candidates (POC LSBs, used_by_curr_pic_lt_sps_flag)
     if r.u(1):
-        raise ValueError("long-term")
+        s["lt"] = [(r.u(s["poc_bits"]), r.u(1)) for _ in range(r.ue())]
     s["tmvp"] = r.u(1)
     s["strong"] = r.u(1)
     return s
@@ -526,7 +527,9 @@ class Picture:
         self.mv = np.zeros((b4h, b4w, 2, 2), np.int32)          # [list][x, y]
         self.ref_idx = np.full((b4h, b4w, 2), -1, np.int32)     # per list; -1: the list is not used (both: intra / not inter)
         self.ref_poc = np.zeros((b4h, b4w, 2), np.int32)        # POC of the reference picture (for deblocking and TMVP)
+        self.ref_lt = np.zeros((b4h, b4w, 2), np.int8)          # ... was a long-term reference picture when this picture was decoded (LongTermRefPic of 8.5.3.2.9)
         self.is_ref = True
+        self.is_lt = False                                      # marked "used for long-term reference"
 
 
 class Decoder:
@@ -617,6 +620,21 @@ class Decoder:
                 n = len(sps["rps"])
                 bits = (n - 1).bit_length() if n > 1 else 0
                 rps = sps["rps"][r.u(bits) if bits else 0]
+        sh["lt"] = []                                              # (POC LSBs, used by the current picture, delta_poc_msb_present_flag, DeltaPocMsbCycleLt)
+        if sps["lt"] is not None and not idr:
+            n_sps = r.ue() if sps["lt"] else 0
+            n_pics = r.ue()
+            cycle = 0
+            for i in range(n_sps + n_pics):
+                if i < n_sps:
+                    k = r.u((len(sps["lt"]) - 1).bit_length()) if len(sps["lt"]) > 1 else 0
+                    lsb, used = sps["lt"][k]
+                else:
+                    lsb, used = r.u(sps["poc_bits"]), r.u(1)
+                present = r.u(1)
+                delta = r.ue() if present else 0
+                cycle = delta if i in (0, n_sps) else cycle + delta   # (7-52)
+                sh["lt"].append((lsb, used, present, cycle))
         sh["tmvp"] = r.u(1) if (sps["tmvp"] and not idr) else 0
         sh["sao_luma"] = sh["sao_chroma"] = 0
         if sps["sao"]:
@@ -636,7 +654,7 @@ class Decoder:
                 if sh["b"]:
                     sh["nref1"] = r.ue() + 1
             sh["list_entry"] = [None, None]
-            total = sum(1 for _, used in rps if used)                  # NumPicTotalCurr (no long-term pictures)
+            total = sum(1 for _, used in rps if used) + sum(1 for e in sh["lt"] if e[1])      # NumPicTotalCurr
             if pps["lists_mod"] and total > 1:                         # ref_pic_lists_modification() (7.3.6.2)
                 bits = (total - 1).bit_length()
                 for X in range(2 if sh["b"] else 1):
@@ -751,13 +769,27 @@ class Decoder:
         before = [poc + d for d, used in rps if d < 0 and used]
         after = [poc + d for d, used in rps if d > 0 and used]
         keep = [poc + d for d, _ in rps]
+        # 8.3.2: the long-term entries first, among all pictures still in the buffer -- by the POC's LSBs, or by the whole POC when delta_poc_msb_present_flag is set;
+        # what they name is a long-term reference picture from now on; the short-term entries name pictures among the rest
+        mx = 1 << sps["poc_bits"]
+        lt_curr = []
         for p in self.dpb:
-            p.is_ref = p.poc in keep
+            p.keep_lt = False
+        for lsb, used, present, cycle in sh.get("lt", []):
+            full = poc - cycle * mx - (poc & (mx - 1)) + lsb
+            hit = [p for p in self.dpb if (p.poc == full if present else (p.poc & (mx - 1)) == lsb)]
+            for p in hit:
+                p.is_lt = True
+                p.keep_lt = True
+            if used:
+                lt_curr.append(hit[0])
+        for p in self.dpb:
+            p.is_ref = p.keep_lt or (not p.is_lt and p.poc in keep)
         self.dpb = [p for p in self.dpb if p.is_ref]
-        by_poc = lambda q: next(p for p in self.dpb if p.poc == q)
-        # 8.3.4: list 0 starts with the pictures before the current one, list 1 with the ones after it; short lists repeat
-        c0 = [by_poc(q) for q in before + after]
-        c1 = [by_poc(q) for q in after + before]
+        by_poc = lambda q: next(p for p in self.dpb if p.poc == q and not p.is_lt)
+        # 8.3.4: list 0 starts with the pictures before the current one, list 1 with the ones after it, the long-term ones close both; short lists repeat
+        c0 = [by_poc(q) for q in before + after] + lt_curr
+        c1 = [by_poc(q) for q in after + before] + lt_curr
         le = sh.get("list_entry") or [None, None]                    # (a modified list: entries of the temporary list in the slice's order)
         refs = [[c0[le[0][i] if le[0] else i % len(c0)] for i in range(sh["nref"])] if sh["nref"] else [],
                 [c1[le[1][i] if le[1] else i % len(c1)] for i in range(sh["nref1"])] if sh["nref1"] else []]
@@ -1350,6 +1382,7 @@ class SliceDecoder:
             pic.mv[ys, xs, X] = (m[3 * X], m[3 * X + 1]) if ref >= 0 else (0, 0)
             pic.ref_idx[ys, xs, X] = ref
             pic.ref_poc[ys, xs, X] = self.refs[X][ref].poc if ref >= 0 else 0
+            pic.ref_lt[ys, xs, X] = 1 if ref >= 0 and self.refs[X][ref].is_lt else 0
         preds = [self.motion_compensate(xpb, ypb, pw, ph, m[3 * X], m[3 * X + 1], self.refs[X][m[3 * X + 2]]) for X in (0, 1) if m[3 * X + 2] >= 0]
         wp = self.sh.get("wp")
         for ci in range(3):
@@ -1409,8 +1442,11 @@ class SliceDecoder:
             else:
                 L = X if no_backward else sh["col_l0"]            # (8.5.3.2.9: "mvCol ... set equal to mvLNCol ... with N being the value of collocated_from_l0_flag")
             mvx, mvy = int(col.mv[y >> 2, x >> 2, L, 0]), int(col.mv[y >> 2, x >> 2, L, 1])
+            cur_lt = self.refs[X][ref_idx].is_lt
+            if bool(col.ref_lt[y >> 2, x >> 2, L]) != cur_lt:
+                continue                                           # 8.5.3.2.9: one reference picture long-term, the other not: nothing from this block
             col_diff = col.poc - int(col.ref_poc[y >> 2, x >> 2, L])
-            if col_diff != cur_diff and col_diff != 0:
+            if not cur_lt and col_diff != cur_diff and col_diff != 0:
                 mvx, mvy = self.scale(mvx, mvy, col_diff, cur_diff)
             return (mvx, mvy)
         return None
@@ -1496,20 +1532,24 @@ class SliceDecoder:
         av_b = [self.pb_avail(xcb, ycb, ncb, xpb, ypb, pw, ph, part_idx, x, y) for x, y in b_pos]
         is_scaled = av_a[0] or av_a[1]
 
+        target_lt = self.refs[X][ref_idx].is_lt
+
         def vectors(pos):
-            """the neighbour's vectors as (mvx, mvy, POC of the picture they point into), list X's first"""
+            """the neighbour's vectors as (mvx, mvy, POC of the picture they point into, that picture is a long-term one), list X's first"""
             mo = self.motion(*pos)
-            return [(mo[3 * L], mo[3 * L + 1], self.refs[L][mo[3 * L + 2]].poc) for L in (X, 1 - X) if mo[3 * L + 2] >= 0]
+            return [(mo[3 * L], mo[3 * L + 1], self.refs[L][mo[3 * L + 2]].poc, self.refs[L][mo[3 * L + 2]].is_lt) for L in (X, 1 - X) if mo[3 * L + 2] >= 0]
 
         def same_picture(pos):
-            for mx, my, poc in vectors(pos):
+            for mx, my, poc, _ in vectors(pos):
                 if poc == target:
                     return (mx, my)
             return None
 
         def any_picture(pos):
-            for mx, my, poc in vectors(pos):
-                return (mx, my) if poc == target else self.scale(mx, my, cur - poc, cur - target)
+            # 8.5.3.2.7 step 7: a vector into another picture counts when that picture and the target are both long-term (taken as it is) or both short-term (scaled)
+            for mx, my, poc, lt in vectors(pos):
+                if lt == target_lt:
+                    return (mx, my) if (poc == target or lt) else self.scale(mx, my, cur - poc, cur - target)
             return None
         a = b = None
         for k in range(2):

@@ -127,3 +127,19 @@ def test_pcm_coding_units(kw):
         nals = [n for au in aus for n in orc.split_nals(au)]
         a, b = PP.probe(nals, 1), PP.probe(nals, 4)
         assert a == b and a["pictures"] == 4, (seed, a, b)
+
+
+@pytest.mark.parametrize("kw", [dict(num_refs=1), dict(num_refs=3, tmvp=1), dict(num_refs=2, tmvp=1, list_mod=50), dict(num_refs=4, tmvp=1, wpp=0)])
+def test_long_term_reference_pictures(kw):
+    """long-term reference pictures (round 6): the synthesiser, the checker's decoder and the product's parser on the same streams (22 pictures: the POC's LSBs wrap
+    when the stream drew four of them), one row thread and four"""
+    for seed in range(1, 11):
+        g = orc.OracleGen(192, 128, seed=seed, long_term=1, intra_period=32, **kw)
+        aus = [g.picture() for _ in range(22)]
+        g.close()
+        od = orc.OracleDecoder()
+        assert sum(len(od.decode_au(au, t)) for t, au in enumerate(aus)) + len(od.flush()) == 22, seed
+        od.close()
+        nals = [n for au in aus for n in orc.split_nals(au)]
+        a, b = PP.probe(nals, 1), PP.probe(nals, 4)
+        assert a == b and a["pictures"] == 22, (seed, a, b)

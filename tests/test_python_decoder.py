@@ -324,3 +324,15 @@ def test_pcm_coding_units(seed, kw):
     aus = [g.picture() for _ in range(3)]
     g.close()
     compare(aus)
+
+
+@pytest.mark.parametrize("seed,kw", [(3, dict(num_refs=1)), (4, dict(num_refs=3, tmvp=1)), (5, dict(num_refs=2, tmvp=1, list_mod=50)), (6, dict(num_refs=4, tmvp=1, wpp=0, all_part_modes=1))])
+def test_long_term_reference_pictures(seed, kw):
+    """round 6: long_term_ref_pics_present_flag -- candidates of the SPS (lt_idx_sps) and explicit entries (poc_lsb_lt), delta_poc_msb_present_flag / the accumulated
+    cycles (7-52), marking (8.3.2: the long-term entries first, among all reference pictures), the lists closing with RefPicSetLtCurr (8.3.4), and the vector rules:
+    a spatial neighbour's vector into another picture counts when both pictures are long-term (as it is) or both short-term (scaled), the temporal candidate likewise
+    (8.5.3.2.7, 8.5.3.2.9) -- the two independently written decoders must agree before the HIP decoder is held to either"""
+    g = orc.OracleGen(136, 72, seed=seed, long_term=1, intra_period=32, density=20, **kw)
+    aus = [g.picture() for _ in range(20)]
+    g.close()
+    compare(aus)

@@ -451,7 +451,7 @@ template <class F> __device__ __forceinline__ bool dec_avail(const F &f, int xc,
 // one intra transform block of plane c: N x N samples at (rx, ry) of the CTU (component samples); its borders are in s.pic
 // the threads of one block's team: a workgroup of T threads, or -- T = 64 -- ONE wave of a larger workgroup (whose LDS instructions execute in order)
 template <int T> __device__ __forceinline__ void tsync() { if (T == 64) wave_sync(); else __syncthreads(); }
-template <int L2, int T, class F>
+template <int L2, int T, bool CIP, class F>
 __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, const DecTu &d, int c, int cx, int cy, int rx, int ry, int lane, const uint32_t (&wreg)[4])
 {
   constexpr int N = XW<L2, T>::N, OPL = XW<L2, T>::OPL, G = XW<L2, T>::G;
@@ -472,20 +472,49 @@ __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, cons
     const bool hole = f.tiles && ((!aT && nTR > 0) || (aL && aT && !aTL));
     const int lob = aT ? 2 * N + 1 : 3 * N + 1;
     const int lo = aL ? N - nBL : (aTL || hole ? 2 * N : 2 * N + 1), hi = aT || hole ? 3 * N + nTR : (aTL ? 2 * N : (aL ? 2 * N - 1 : -1));
+    // constrained_intra_pred_flag: available in the usual sense AND in an intra-coded block, per unit of four samples (a 4x4 record); unit u of the scan order = samples
+    // 4u .. 4u + 3 of the left column (u < N / 2), the corner (u = N / 2), samples 2N + 1 + 4 (u - N / 2 - 1) .. of the row above.  8.4.4.2.2: a sample of a unit
+    // that does not count takes the last sample of the nearest counting unit before it, the ones in front of the first counting unit its first sample.
+    unsigned long long cipm = ~0ull;
+    if (CIP) {
+      constexpr int NU = N / 2;                            // units of the left column (2N samples); the row above has as many
+      const int u = lane, i0 = u < NU ? 4 * u : (u == NU ? 2 * N : 2 * N + 1 + 4 * (u - NU - 1));
+      bool av = false;
+      if (u <= 2 * NU) {
+        const bool sp = hole ? ((i0 >= lo && i0 < 2 * N) || (i0 >= lob && i0 <= hi)) : (i0 >= lo && i0 <= hi);
+        if (sp) {
+          const int px = i0 <= 2 * N ? Xc - 1 : Xc + i0 - 2 * N - 1, py = i0 < 2 * N ? Yc + 2 * N - 1 - i0 : Yc - 1;
+          av = f.b4[(size_t)((py << sh) >> 2) * (f.pw >> 2) + ((px << sh) >> 2)].ref_idx < 0;
+        }
+      }
+      cipm = __ballot(av);
+    }
     auto fetch = [&](int i) -> int {
       int j = imin(imax(i, lo), hi);
       if (hole && j < lob) j = lo < 2 * N ? imin(j, 2 * N - 1) : lob;
+      if (CIP) {
+        constexpr int NU = N / 2;
+        const int ii = imin(imax(i, 0), 4 * N), u = ii < 2 * N ? ii >> 2 : (ii == 2 * N ? NU : NU + 1 + ((ii - 2 * N - 1) >> 2));
+        auto first_of = [&](int q) { return q < NU ? 4 * q : (q == NU ? 2 * N : 2 * N + 1 + 4 * (q - NU - 1)); };
+        if ((cipm >> u) & 1ull) j = ii;
+        else {
+          const unsigned long long below = u ? cipm & (~0ull >> (64 - u)) : 0ull;
+          if (below) { const int q = 63 - __builtin_clzll(below); j = q == NU ? 2 * N : first_of(q) + 3; }
+          else j = first_of(__builtin_ctzll(cipm | (1ull << 63)));      // (cipm == 0: no reference sample at all -- the callers' 128)
+        }
+      }
       const int col = j < 2 * N ? rx - 1 : rx + j - 2 * N - 1, rowp = j < 2 * N ? ry + 2 * N - j : ry;    // rowp = y + 1
       return s.pic[rowp * DI_P + 16 + col];
     };
     int c0 = 0, e0 = 0, e1 = 0; bool strong = false;
-    if (filt && N == 32 && hi >= 0 && f.strong_intra) {
+    if (filt && N == 32 && (CIP ? cipm != 0 : hi >= 0) && f.strong_intra) {
       c0 = fetch(2 * N); e0 = fetch(0); e1 = fetch(4 * N);
       strong = iabs(c0 + e1 - 2 * fetch(3 * N)) < 8 && iabs(c0 + e0 - 2 * fetch(N)) < 8;
     }
+    const bool any_ref = CIP ? cipm != 0 : (hi >= lo && hi >= 0);
     for (int i = lane; i <= 4 * N; i += T) {
       int v = 128, fv = 128;
-      if (hi >= lo && hi >= 0) {
+      if (any_ref) {
         v = fetch(i); fv = v;
         if (filt && i != 0 && i != 4 * N) {
           if (strong) { if (i != 2 * N) { int k = i < 2 * N ? 2 * N - i : i - 2 * N; fv = ((64 - k) * c0 + k * (i < 2 * N ? e0 : e1) + 32) >> 6; } }
@@ -630,13 +659,13 @@ template <class F> __device__ __forceinline__ void dec_intra_resid_body(const F 
 // residual samples (k_dec_intra_resid), loaded by the caller one block ahead
 template <int L2>
 __device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveScratch &ws, const IntraBlk &d, bool luma,
-                                                     int lane, uint2 rres, uint32_t *ecol, unsigned long long *erow, uint32_t gen)
+                                                     int lane, uint2 rres, uint32_t *ecol, unsigned long long *erow, uint32_t gen, const CipCtx *cip)
 {
   constexpr int N = 1 << L2;
   const int g = lane >> 4, c = lane & 15, rx = d.rx, ry = d.ry;
   const bool active = c < N && 4 * g < N;
   int pred[4];
-  wave_intra_predict<L2, true>(s.pic, DI_P, ws, d, luma, lane, g, c, pred);
+  wave_intra_predict<L2, true>(s.pic, DI_P, ws, d, luma, lane, g, c, pred, cip);
   if (d.flags & IB_LEVELS) {
     const int res[4] = {(int)(int16_t)(rres.x & 0xffffu), (int)(int16_t)(rres.x >> 16), (int)(int16_t)(rres.y & 0xffffu), (int)(int16_t)(rres.y >> 16)};
 #pragma unroll
@@ -662,7 +691,7 @@ __device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveSc
 #ifndef KVZ_DEC_INTRA_WAVES
 #define KVZ_DEC_INTRA_WAVES 4
 #endif
-template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, const Wg wg)
+template <bool CIP, class F> __device__ __forceinline__ void dec_intra_body(const F &f, const Wg wg)
 {
   constexpr int W = KVZ_DEC_INTRA_WAVES, T = 64 * W;
   __shared__ DecIntraLds s;
@@ -761,7 +790,8 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
     const bool quad = item_first[i + 1] - item_first[i] > 1;
     const int rx = t.x - cx * S, ry = t.y - cy * S, ux = (rx << sh) >> 3, uy = (ry << sh) >> 3, su = quad ? 1 : imax(1, ((1 << t.log2) << sh) >> 3);
     const int ci = c ? 1 : 0;
-    const bool bl = quad || t.log2 == 2 || ((intra_uses_below_left(t.log2, ci) >> t.mode) & 1) != 0, tr = quad || t.log2 == 2 || ((intra_uses_above_right(t.log2, ci) >> t.mode) & 1) != 0;
+    // (constrained intra prediction: a sample that does not count takes its value from wherever the nearest counting one is -- any block may read any of its borders)
+    const bool bl = quad || t.log2 == 2 || CIP || ((intra_uses_below_left(t.log2, ci) >> t.mode) & 1) != 0, tr = quad || t.log2 == 2 || CIP || ((intra_uses_above_right(t.log2, ci) >> t.mode) & 1) != 0;
     item_dep[i] = chain_dependencies(ux, uy, su, bl, tr);
     const uint2 cv = chain_cover(zunit8(ux, uy), su);
     item_cover[i] = cv;
@@ -824,14 +854,16 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
         // (a neighbouring CTU is waited for only as far as the block's MODE reads it: hevc_core.h intra_uses_* -- any stream; this project's encoder keeps the blocks
         // on a CTU's left edge and its above-right corner block to the modes that make these waits short, "intra-chain")
         const int n = 1 << d.l2, ci = c ? 1 : 0;
-        const int nl2 = ((intra_uses_below_left(d.l2, ci) >> d.mode) & 1) ? 2 * n : n, nt2 = (((intra_uses_above_right(d.l2, ci) >> d.mode) & 1) || (d.flags & IB_HOLE)) ? 2 * n : n;      // (IB_HOLE: the samples above may be copies of the first one above-right)
+        const int nl2 = (((intra_uses_below_left(d.l2, ci) >> d.mode) & 1) || CIP) ? 2 * n : n, nt2 = (((intra_uses_above_right(d.l2, ci) >> d.mode) & 1) || (d.flags & IB_HOLE) || CIP) ? 2 * n : n;      // (IB_HOLE: the samples above may be copies of the first one above-right)
         borders_need_wave(ch, bd, s.pic, DI_P, plane, cpitch, cx, cy, S, sh, wC - cx * S, d.rx, d.ry, n, f.err, lane, nl2, nt2);
       }
       if (k == k0) chain_wait_done(ch, make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)dp.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)dp.y)), f.err, lane);
+      CipCtx cipc; const CipCtx *cip = nullptr;
+      if (CIP) { cipc.ridx = (const int8_t *)f.b4 + 4; cipc.b4w = f.pw >> 2; cipc.xl = cx * S + d.rx; cipc.yl = cy * S + d.ry; cipc.sh = sh; cip = &cipc; }      // (constrained intra prediction: B4Rec::ref_idx, byte 4 of a record)
       switch (d.l2) {
-        case 2: dec_intra_block_wave<2>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen); break;
-        case 3: dec_intra_block_wave<3>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen); break;
-        case 4: dec_intra_block_wave<4>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen); break;
+        case 2: dec_intra_block_wave<2>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen, cip); break;
+        case 3: dec_intra_block_wave<3>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen, cip); break;
+        case 4: dec_intra_block_wave<4>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen, cip); break;
         default: {
           // a 32x32 block: the wave runs the workgroup-shaped code of the other sizes' predecessor by itself; its scratch arrays (s.A, s.B, s.R) exist
           // once per workgroup, so one 32x32 block at a time
@@ -843,7 +875,7 @@ template <class F> __device__ __forceinline__ void dec_intra_body(const F &f, co
 #pragma unroll
           for (int i = 0; i < 4; i++) u[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q[i]);
           memcpy(&t, u, sizeof(t));
-          dec_intra_block<5, 64>(f, s, t, c, cx, cy, d.rx, d.ry, lane, wreg);
+          dec_intra_block<5, 64, CIP>(f, s, t, c, cx, cy, d.rx, d.ry, lane, wreg);
           // (on the CTU's right edge / bottom: its last column / row from the CTU picture in LDS, tagged like the small blocks')
           if ((d.flags & IB_EDGE_R) && lane < 32) st_wt_u32(ecol + d.ry + lane, (uint32_t)s.pic[(d.ry + lane + 1) * DI_P + 16 + d.rx + 31] | (f.chain_gen << 8));
           if ((d.flags & IB_EDGE) && lane < 8) st_wt_u64(erow + ((d.rx + 4 * lane) >> 2), (unsigned long long)*(const uint32_t *)&s.pic[(d.ry + 32) * DI_P + 16 + d.rx + 4 * lane] | ((unsigned long long)f.chain_gen << 32));
@@ -1119,7 +1151,10 @@ template <class F> __device__ __forceinline__ void dec_sao_body(const F &f, cons
 // the single-picture kernels: the frame is the kernel argument
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_dec_inter(DecFrame f) { dec_inter_body(f, Wg{(int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y)}); }
 __global__ __launch_bounds__(256) void k_dec_intra_resid(DecFrame f) { dec_intra_resid_body(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
-__global__ __launch_bounds__(64 * KVZ_DEC_INTRA_WAVES) void k_dec_intra(DecFrame f) { dec_intra_body(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
+__global__ __launch_bounds__(64 * KVZ_DEC_INTRA_WAVES) void k_dec_intra(DecFrame f) { dec_intra_body<false>(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
+// ... with constrained_intra_pred_flag (DecFrame::cip): reference samples of blocks that are not intra-coded do not count -- a form of its own: the general substitution
+// costs the chain 37 registers
+__global__ __launch_bounds__(64 * KVZ_DEC_INTRA_WAVES) void k_dec_intra_cip(DecFrame f) { dec_intra_body<true>(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
 __global__ __launch_bounds__(256) void k_dec_deblock(DecFrame f) { dec_deblock_body(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
 __global__ __launch_bounds__(256) void k_dec_sao(DecFrame f) { dec_sao_body(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
 
@@ -1137,7 +1172,7 @@ __device__ __forceinline__ int batch_frame(const DecBatch &b, Wg &wg)
 #define KVZ_BATCH_FRAME(b) Wg wg; const CDecFrame &f = *(const CDecFrame *)(b).f[batch_frame(b, wg)]
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_dec_inter_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_inter_body(f, wg); }
 __global__ __launch_bounds__(256) void k_dec_intra_resid_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_intra_resid_body(f, wg); }
-__global__ __launch_bounds__(64 * KVZ_DEC_INTRA_WAVES) void k_dec_intra_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_intra_body(f, wg); }
+__global__ __launch_bounds__(64 * KVZ_DEC_INTRA_WAVES) void k_dec_intra_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_intra_body<false>(f, wg); }
 __global__ __launch_bounds__(256) void k_dec_deblock_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_deblock_body(f, wg); }
 __global__ __launch_bounds__(256) void k_dec_sao_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_sao_body(f, wg); }
 
@@ -1154,7 +1189,11 @@ static inline int dec_intra_wgs(const DecFrame &f)
 }
 void launch_dec_inter(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_inter, dim3(f.wc * 2, dec_rows(f) * 2), dim3(256), 0, st, f); }
 void launch_dec_intra_resid(const DecFrame &f, hipStream_t st) { if (f.ntu > 0) hipLaunchKernelGGL(k_dec_intra_resid, dim3((f.ntu + 3) / 4), dim3(256), 0, st, f); }
-void launch_dec_intra(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_intra, dim3(dec_intra_wgs(f)), dim3(64 * KVZ_DEC_INTRA_WAVES), 0, st, f); }
+void launch_dec_intra(const DecFrame &f, hipStream_t st)
+{
+  if (f.cip) hipLaunchKernelGGL(k_dec_intra_cip, dim3(dec_intra_wgs(f)), dim3(64 * KVZ_DEC_INTRA_WAVES), 0, st, f);
+  else hipLaunchKernelGGL(k_dec_intra, dim3(dec_intra_wgs(f)), dim3(64 * KVZ_DEC_INTRA_WAVES), 0, st, f);
+}
 void launch_dec_deblock(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_deblock, dim3(f.wc * dec_rows(f)), dim3(256), 0, st, f); }
 void launch_dec_sao(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_sao, dim3(f.wc * f.hc), dim3(256), 0, st, f); }
 

@@ -11,13 +11,13 @@
 // slices (both reference lists, bi-prediction, pictures handed out in POC order), every CU size and partitioning (AMP included), intra CUs in P pictures, NxN intra, all chroma
 // prediction modes, transform trees, several reference pictures (RPS in the SPS or the slice header, inter RPS prediction), long-term reference pictures,
 // temporal motion vector prediction, merge levels, cu_qp_delta at any quantisation-group size, chroma QP offsets, sign data
-// hiding, transform skip, scaling lists (default, SPS and PPS scaling_list_data), cu_transquant_bypass (lossless coding units), PCM coding units, deblocking offsets /
+// hiding, transform skip, scaling lists (default, SPS and PPS scaling_list_data), cu_transquant_bypass (lossless coding units), PCM coding units, constrained intra prediction, deblocking offsets /
 // overrides, SAO, WPP, tile grids up to the level limit of 20 columns x 22 rows (uniform or
 // explicit spacing; in-loop filtering across tile and slice boundaries on or off -- Kvazaar switches it off), pictures in several slice segments: the two ways Kvazaar cuts them (a dependent slice segment per CTU row with WPP, an
 // independent slice per tile) and -- one-tile pictures -- segments that begin at ANY coding tree block, independent slices (own SliceQpY) and dependent
 // segments mixed (an MTU per slice, N row groups: PicJob::ctb_cut).  Rejected with a negative return value (kvzx_decoder_last_error): several slices
 // inside a tile of a picture with tiles, slices of one picture that differ in more than SliceQpY and the loop filter flag,
-// constrained intra prediction, > 255 slices in a picture.
+// > 255 slices in a picture.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -73,7 +73,7 @@ struct DecPps {
   int wpp = 0, tile_rows = 1, row_bd[34];   // tile row i covers CTB rows [row_bd[i], row_bd[i + 1]); filled at slice time when uniform
   int tile_cols = 1, col_bd[34];            // tile column j covers CTB columns [col_bd[j], col_bd[j + 1])
   int uniform_tiles = 1, row_height[33], col_width[33];
-  int deblock_control = 0, deblock_override = 0, deblock_disabled = 0, beta_offset_div2 = 0, tc_offset_div2 = 0, loop_filter_across_slices = 1, across_tiles = 1;
+  int deblock_control = 0, deblock_override = 0, deblock_disabled = 0, beta_offset_div2 = 0, tc_offset_div2 = 0, loop_filter_across_slices = 1, across_tiles = 1, cip = 0;
   int par_mrg_level = 2;
   int tq_bypass = 0;                                   // transquant_bypass_enabled_flag (a peer's Kvazaar with `lossless`, kvazaarfilter.cpp:244)
   std::shared_ptr<const std::vector<uint8_t>> scaling; // pps_scaling_list_data: these factors instead of the SPS's

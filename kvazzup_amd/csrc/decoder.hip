@@ -1643,7 +1643,7 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     p.wpp = r.get(1);
     if (r.err || p.num_ref_idx_default > 15 || p.num_ref_idx1_default > 15 || p.cb_qp_offset < -12 || p.cb_qp_offset > 12 || p.cr_qp_offset < -12 || p.cr_qp_offset > 12) return last_error_ = DEC_ERR_INVALID;
     p.dependent_slices = dep;
-    if (cip) return last_error_ = DEC_ERR_UNSUPPORTED;               // constrained intra prediction
+    p.cip = cip;                                                 // constrained_intra_pred_flag: the kernels' business (reference samples of blocks that are not intra-coded do not count)
     p.weighted_pred = wp; p.weighted_bipred = wbp;
     p.tq_bypass = tqb;
     if (tiles) {                                                 // supported: the level limits of 20 columns x 22 rows (A.4.2); loop filter across tiles on
@@ -2771,7 +2771,7 @@ int Decoder::launch_gpu(PicJob &job)
   f.ctu_tile = d_in_ + off_tile(); f.tus = (const DecTu *)(d_in_ + tu_off); f.lev = (const uint32_t *)(d_in_ + lev_off); f.ntu = (int)ntu;
   // which chain: a picture without inter blocks, every other one of them, with the frame-threaded decoder on its own (decoder.h stream_alt_)
   DecBatcher &batcher = DecBatcher::get(device_);
-  const bool batched = band_nrows_ == 0 && batch_attached_ && batcher.active();
+  const bool batched = band_nrows_ == 0 && batch_attached_ && batcher.active() && !(job.pps.cip && job.any_inter && job.any_intra);      // (constrained intra prediction: the chain's own form, k_dec_intra_cip -- launched by this decoder itself)
   static const bool alt_off = getenv("KVAZZUP_AMD_DEC_ONE_CHAIN") != nullptr;
   bool alt = !alt_off && !batched && band_nrows_ == 0 && frame_threads_ > 1 && gpu_depth_ > 1 && job.any_intra && !job.any_inter && ((intra_seq_++) & 1);
   if (alt && !ensure_alt()) alt = false;
@@ -2801,6 +2801,7 @@ int Decoder::launch_gpu(PicJob &job)
   f.beta_offset = (int8_t)(2 * job.sh.beta_offset_div2); f.tc_offset = (int8_t)(2 * job.sh.tc_offset_div2);
   f.intra_direct = job.any_inter ? 1 : 0;                 // (a picture with inter blocks: few (CTU, plane) pairs hold intra blocks)
   f.strong_intra = (uint8_t)job.sps->strong_intra; f.tiles = job.pps.tile_rows > 1 || job.pps.tile_cols > 1 || job.slice_qps.size() > 1;
+  f.cip = (uint8_t)(job.pps.cip && job.any_inter);      // (a picture without inter blocks: every neighbour is intra)
   f.tq_bypass = (uint8_t)(job.pps.tq_bypass || (job.sps->pcm_depth[0] && job.sps->pcm_no_filter));      // (units the loop filters keep out of: B4_BYPASS records)
   // scaling lists: the picture's factors (the PPS's lists when it carries any, else the SPS's) ride in the input block
   const std::vector<uint8_t> *sc = job.pps.scaling ? job.pps.scaling.get() : job.sps->scaling.get();

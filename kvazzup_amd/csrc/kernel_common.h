@@ -704,14 +704,40 @@ __device__ __forceinline__ IntraBlk wave_uniform(const IntraBlk *p)
 // scan order (the substitution process of 8.4.4.2.2 is a clamp of the scan index into [lo, hi]; the [1 2 1] filter takes its
 // neighbours over DPP); what the mode reads is then laid out in ws.R -- the scan-order array for planar and DC, ref[] with the
 // projected side samples for the angular modes (lanes fetch their entry from the lane that holds it: ds_bpermute).
+// constrained intra prediction (decoder): what wave_intra_predict needs to ask whether a neighbouring sample belongs to an intra-coded block -- the 4x4 records'
+// reference indices (ridx[8 * unit] < 0: intra; a record is 8 bytes), the block's place in its plane
+struct CipCtx { const int8_t *ridx; int b4w; int xl, yl, sh; };
 template <int L2, bool HOLES = false>
-__device__ __forceinline__ void wave_intra_predict(const uint8_t *pic, int P, IntraWaveScratch &ws, const IntraBlk &d, bool luma, int lane, int g, int c, int (&pred)[4])
+__device__ __forceinline__ void wave_intra_predict(const uint8_t *pic, int P, IntraWaveScratch &ws, const IntraBlk &d, bool luma, int lane, int g, int c, int (&pred)[4], const CipCtx *cip = nullptr)
 {
   constexpr int N = 1 << L2;
   const int rx = d.rx, ry = d.ry, lo = d.lo, hi = d.hi, mode = d.mode;
   const bool hole = HOLES && (d.flags & IB_HOLE) != 0;      // (two available runs with a gap between them: a sample of the gap takes the last one of the run before it, 8.4.4.2.2)
   if (HOLES && mode == 35) { pred[0] = pred[1] = pred[2] = pred[3] = 0; return; }      // (decoder: a PCM unit -- its "residual" is the samples themselves)
   int v = 128, last = 128;
+  if (HOLES && cip) {
+    // constrained_intra_pred_flag: a sample is a reference sample when it is available in the usual sense AND its block is intra-coded -- any pattern along the two
+    // borders.  8.4.4.2.2 as it stands: a sample that is not available takes the nearest available one BEFORE it in scan order, the ones in front of the first
+    // available one take that one.  Lane i holds sample i; the ballot is the availability; the source lane comes from its bits.
+    auto avail = [&](int i) -> bool {
+      const bool sp = i <= 4 * N && (hole ? ((i >= lo && i < 2 * N) || (i >= (int)d.xf && i <= hi)) : (i >= lo && i <= hi));
+      if (!sp) return false;
+      const int px = i <= 2 * N ? cip->xl - 1 : cip->xl + i - 2 * N - 1, py = i < 2 * N ? cip->yl + 2 * N - 1 - i : cip->yl - 1;
+      return cip->ridx[8 * ((size_t)((py << cip->sh) >> 2) * cip->b4w + ((px << cip->sh) >> 2))] < 0;
+    };
+    auto pos = [&](int j) -> int { const bool left = j < 2 * N; return (left ? ry + 2 * N - j : ry) * P + 16 + (left ? rx - 1 : rx + j - 2 * N - 1); };
+    const bool av = avail(lane);
+    const unsigned long long m = __ballot(av);
+    const bool av64 = N == 16 && avail(64);
+    const int own = av ? pic[pos(lane)] : 0, own64 = av64 ? pic[pos(64)] : 0;
+    if (m || av64) {
+      const unsigned long long below = lane ? m & (~0ull >> (64 - lane)) : 0ull;
+      const int src = av ? lane : (below ? 63 - __builtin_clzll(below) : (m ? __builtin_ctzll(m) : 64));
+      v = __builtin_amdgcn_ds_bpermute(4 * (src & 63), own);
+      if (src == 64) v = own64;
+      if (N == 16) last = av64 ? own64 : __builtin_amdgcn_readlane(own, 63 - __builtin_clzll(m | 1ull));      // (not available: the nearest one before it -- m != 0 here or av64 held)
+    }
+  } else
   if (hi >= lo) {
     auto at = [&](int i) -> int {
       int j = imin(imax(i, lo), hi);

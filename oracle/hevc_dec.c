@@ -44,6 +44,7 @@ struct orc_decoder {
   /* tile / slice maps for the current picture */
   orc_sao_params *sao; int sao_used; pixel *sao_in[3];
   int32_t *ctb_slice; int16_t *ctb_tile; int *ts_to_rs, *rs_to_ts; int *tile_first_x; size_t ctb_cap;
+  uint8_t *intra4; size_t intra4_cap;     /* constrained intra prediction: per 4x4 luma block of the current picture, 1 = intra */
   uint8_t *ctb_lfx, *ctb_nb;              /* per CTB: slice_loop_filter_across_slices_enabled_flag of its slice; the neighbouring CTBs the in-loop filters may use (finish_picture) */
   int lf_restricted;                      /* some slice of the picture has that flag 0 */
   int slice_addr_rs;                      /* SliceAddrRs: address of the slice (= its first, independent segment) being decoded */
@@ -84,7 +85,7 @@ void orc_dec_close(orc_decoder *d)
   free(d->bs_v); free(d->bs_h); free(d->rbsp);
   for (int i = 0; i < 3; i++) free(d->predeblock[i]);
   free(d->sao); for (int i = 0; i < 3; i++) free(d->sao_in[i]);
-  free(d->ctb_slice); free(d->ctb_tile); free(d->ts_to_rs); free(d->rs_to_ts); free(d->tile_first_x); free(d->ctb_lfx); free(d->ctb_nb);
+  free(d->ctb_slice); free(d->ctb_tile); free(d->ts_to_rs); free(d->rs_to_ts); free(d->tile_first_x); free(d->ctb_lfx); free(d->ctb_nb); free(d->intra4);
   free(d->sh.entry_point_offset);
   free(d);
 }
@@ -238,6 +239,12 @@ static void intra_pred_tb(orc_decoder *d, int cidx, int x0, int y0, int log2, in
   orc_pic *pic = d->cur;
   int n = 1 << log2;
   pixel left[65 + 64], top[65 + 64];
+  if (d->p->constrained_intra_pred) {
+    /* constrained_intra_pred_flag (8.4.4.2.2): a neighbouring sample of a block that is not intra-coded is marked "not available" -- for the reference samples only;
+     * the substitution process is the usual one.  intra4: per 4x4 luma block, 1 = intra (coding_unit keeps it) */
+    orc_avail_ctx av = d->av; av.usable4 = d->intra4; av.usable_stride = pic->b4_w;
+    orc_intra_refs(&av, pic->plane[cidx], pic->stride[cidx], cidx, x0, y0, n, left, top);
+  } else
   orc_intra_refs(&d->av, pic->plane[cidx], pic->stride[cidx], cidx, x0, y0, n, left, top);
   orc_intra_predict(left, top, n, cidx, mode, d->s->strong_intra_smoothing,
                     pic->plane[cidx] + y0 * pic->stride[cidx] + x0, pic->stride[cidx]);
@@ -541,6 +548,7 @@ static void coding_unit(orc_decoder *d, int x0, int y0, int log2cb, int ct_depth
       }
     }
     fill_b4_u8(pic, pic->pred_mode, x0, y0, n, n, d->cu_pred_mode);
+    if (d->cu_pred_mode == MODE_INTRA) fill_b4_u8(pic, d->intra4, x0, y0, n, n, 1);
     if (d->cu_pred_mode == MODE_INTRA && d->part_mode == PART_2Nx2N && s->pcm_enabled && log2cb >= s->log2_min_pcm_cb && log2cb <= s->log2_min_pcm_cb + s->log2_diff_max_min_pcm_cb &&
         orc_cdec_terminate(c)) {
       /* pcm_flag = 1 (7.3.8.5, 7.3.8.7): the arithmetic codeword has ended; pcm_alignment_zero_bits, then the samples -- 8.4.4.1? no prediction, no residual:
@@ -822,6 +830,7 @@ static int start_picture(orc_decoder *d)
     d->predeblock[2] = (pixel *)realloc(d->predeblock[2], pc / 4);
     d->predeblock_cap = pc;
   }
+  { const size_t n4 = (size_t)d->cur->b4_w * d->cur->b4_h; if (n4 > d->intra4_cap) { d->intra4 = (uint8_t *)realloc(d->intra4, n4); d->intra4_cap = n4; } memset(d->intra4, 0, n4); }
   setup_tiles(d);
   d->ctbs_decoded = 0;
   d->pic_active = 1;

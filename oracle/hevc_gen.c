@@ -177,7 +177,7 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   orc_vps *v = &g->vps; memset(v, 0, sizeof(*v));
   v->timing_info_present = 1; v->num_units_in_tick = 1; v->time_scale = 30;
   orc_pps *p = &g->pps; memset(p, 0, sizeof(*p));
-  p->sign_data_hiding = c->sign_hiding; p->cabac_init_present = c->cabac_init;
+  p->sign_data_hiding = c->sign_hiding; p->cabac_init_present = c->cabac_init; if (c->cip != 1) c->cip = 0; p->constrained_intra_pred = c->cip;
   p->num_ref_idx_l0_default = rrange(g, 1, c->num_refs); p->num_ref_idx_l1_default = 1; p->init_qp = cfg->qp;
   p->transform_skip_enabled = c->transform_skip;
   p->transquant_bypass_enabled = c->tq_bypass > 0;

@@ -57,6 +57,7 @@ typedef struct {
                                * in any order, repeats allowed); > 0 sets lists_modification_present_flag -- 0 (also -1): off */
   int ctb_log2;               /* CtbLog2SizeY: 6 (also -1 / 0: the streams of rounds 1-5), 5 or 4 -- what encoders other than Kvazaar choose (hardware encoders: 32 or 16);
                                * max_cu_log2 is capped to it */
+  int cip;                    /* 1: constrained_intra_pred_flag (samples of blocks that are not intra-coded are no reference samples) -- 0 (also -1): off */
   int long_term;              /* > 0: long-term reference pictures (P streams without reordering: the sequence's first picture becomes a long-term reference picture -- at once in a
                                * third of the cases, else when it leaves the short-term window -- and stays one until dropped; named through the SPS's candidates or explicitly,
                                * with and without delta_poc_msb_present_flag, used by the current picture or only kept) -- 0 (also -1): off */

@@ -106,6 +106,9 @@ GEN = {
     # round 6: long-term reference pictures (the sequence's first picture kept as one: SPS candidates and explicit entries, LSBs only and with the MSB cycles)
     "gen_long_term": dict(seed=63, density=20, intra_period=16, num_refs=3, tmvp=1, amp=0, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                           qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=0, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, long_term=1),
+    # round 6: constrained intra prediction (intra blocks among inter ones take no reference samples from them)
+    "gen_cip": dict(seed=67, density=25, intra_period=8, num_refs=2, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
+                    qp_delta=0, deblock_mode=0, intra_in_p=45, all_part_modes=1, nxn_intra=1, max_cu_log2=6, min_cu_log2=3, slices=0, big_mvd=0, cip=1),
     "gen_b_gop8": dict(seed=36, density=25, intra_period=16, num_refs=4, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                        qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=70, gop=8),
 }

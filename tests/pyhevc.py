@@ -291,8 +291,7 @@ def parse_pps(rbsp):
     p["nref_default"] = r.ue() + 1
     p["nref1_default"] = r.ue() + 1
     p["init_qp"] = 26 + r.se()
-    if r.u(1):
-        raise ValueError("constrained intra")
+    p["cip"] = r.u(1)                        # constrained_intra_pred_flag
     p["tskip"] = r.u(1)
     p["cu_qp_delta"] = r.u(1)
     p["qg_depth"] = r.ue() if p["cu_qp_delta"] else 0
@@ -1849,6 +1848,8 @@ class SliceDecoder:
                 return None
             if not self.decoded4[ly >> 2, lx >> 2]:
                 return None
+            if self.pps["cip"] and self.cu_pred[ly >> self.sps["min_cb"], lx >> self.sps["min_cb"]] != 1:
+                return None                                        # 8.4.4.2.2: constrained_intra_pred_flag -- a sample of a block that is not intra-coded is no reference sample
             return int(plane[yn, xn])
         # scan order of 8.4.4.2.2: p[-1][2n - 1] up to p[-1][-1], then p[0][-1] .. p[2n - 1][-1]
         coords = [(x0 - 1, y0 + 2 * n - 1 - i) for i in range(2 * n)] + [(x0 - 1, y0 - 1)] + [(x0 + i, y0 - 1) for i in range(2 * n)]

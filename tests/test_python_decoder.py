@@ -336,3 +336,14 @@ def test_long_term_reference_pictures(seed, kw):
     aus = [g.picture() for _ in range(20)]
     g.close()
     compare(aus)
+
+
+@pytest.mark.parametrize("seed,kw", [(3, dict(wpp=0)), (4, dict(wpp=1, nxn_intra=1, chroma_modes=1)), (5, dict(wpp=1, slices=3)), (6, dict(wpp=0, all_part_modes=1, amp=1, max_cu_log2=6, strong_intra=1)), (7, dict(ctb_log2=4, pcm=20))])
+def test_constrained_intra_prediction(seed, kw):
+    """round 6: constrained_intra_pred_flag -- a neighbouring sample of a block that is not intra-coded is marked "not available" for intra prediction (8.4.4.2.2), the
+    substitution process runs over whatever pattern that leaves; nothing else changes (the candidate modes, the inter blocks).  The two independently written decoders
+    must agree before the HIP decoder is held to either; the flag changes every P picture of these streams"""
+    g = orc.OracleGen(200, 136, seed=seed, cip=1, intra_in_p=45, **kw)
+    aus = [g.picture() for _ in range(4)]
+    g.close()
+    compare(aus)

@@ -30,7 +30,7 @@ def main():
     feature = eval(sys.argv[1]) if len(sys.argv) > 1 else {}
     cfg = dict(PLAIN); cfg.update(feature)
     w, h, n = 416, 240, 6
-    g = orc.OracleGen(w, h, seed=int(os.environ.get("SEED", "11")), slices=3, **cfg)
+    g = orc.OracleGen(w, h, seed=int(os.environ.get("SEED", "11")), slices=int(os.environ.get("SLICES", "3")), **cfg)
     ctb = 1 << g.config["ctb_log2"]
     wc, hc = (w + ctb - 1) // ctb, (h + ctb - 1) // ctb
     nb = max(1, (wc * hc - 1).bit_length())

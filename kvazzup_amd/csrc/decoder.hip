@@ -1892,7 +1892,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
         else { lt_lsb[k] = (int)r.get(s.log2_max_poc_lsb); lt_used[k] = r.get(1) != 0; }
         lt_msb[k] = r.get(1) != 0;
         const int delta = lt_msb[k] ? (int)r.ue() : 0;
-        if (delta < 0 || delta > (1 << 20)) return DEC_ERR_INVALID;
+        if (delta < 0 || delta > (1 << 20) || lt_cycle[k ? k - 1 : 0] > (1 << 24)) return DEC_ERR_INVALID;
         lt_cycle[k] = delta + ((k == 0 || k == n_sps) ? 0 : lt_cycle[k - 1]);
       }
       if (r.err) return DEC_ERR_INVALID;
@@ -2017,7 +2017,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     int lt_slot[16], nl = 0;
     const int max_lsb = 1 << s.log2_max_poc_lsb;
     for (int k = 0; k < nlt; k++) {
-      const int full = sh.poc - lt_cycle[k] * max_lsb - (sh.poc & (max_lsb - 1)) + lt_lsb[k];
+      const long long full = (long long)sh.poc - (long long)lt_cycle[k] * max_lsb - (sh.poc & (max_lsb - 1)) + lt_lsb[k];      // (64 bits: a hostile cycle count must not wrap into a POC that exists)
       int found = -1;
       for (int q = 0; q < KVZ_DEC_MAX_REFS; q++) if (dpb_[q].is_ref && dpb_[q].used && (lt_msb[k] ? dpb_[q].poc == full : (dpb_[q].poc & (max_lsb - 1)) == lt_lsb[k])) found = q;
       if (found >= 0) { keep[found] = true; dpb_[found].is_lt = true; }

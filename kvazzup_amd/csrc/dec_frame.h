@@ -88,9 +88,9 @@ struct DecFrame {
   int8_t beta_offset, tc_offset;           // slice_beta_offset_div2 * 2, slice_tc_offset_div2 * 2
   uint8_t intra_direct;     // k_dec_intra: a workgroup per (CTU, plane) in dispatch order instead of tickets (pictures that are mostly inter: nearly every (CTU, plane) has nothing to do, and a ticket is a memory round trip)
   uint8_t strong_intra, tiles;             // strong_intra_smoothing_enabled_flag; more than one tile
+  uint8_t general;                         // the picture may hold what the chain's plain form has no code for: several slices or tiles (reference samples in two runs), PCM units
   uint8_t cip;                             // constrained_intra_pred_flag: neighbouring samples of blocks that are not intra-coded are "not available" as reference samples (8.4.4.2.2)
   uint8_t tq_bypass;        // the picture may hold coding units with cu_transquant_bypass_flag (B4_BYPASS / TU_BYPASS): the loop filters look at the flags
-  uint8_t pad_[1];
   const uint8_t *scaling;   // KVZ_SCALING_BYTES scaling factors (scaling_list_enabled_flag), NULL: flat 16
 };
 

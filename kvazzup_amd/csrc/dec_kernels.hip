@@ -451,13 +451,13 @@ template <class F> __device__ __forceinline__ bool dec_avail(const F &f, int xc,
 // one intra transform block of plane c: N x N samples at (rx, ry) of the CTU (component samples); its borders are in s.pic
 // the threads of one block's team: a workgroup of T threads, or -- T = 64 -- ONE wave of a larger workgroup (whose LDS instructions execute in order)
 template <int T> __device__ __forceinline__ void tsync() { if (T == 64) wave_sync(); else __syncthreads(); }
-template <int L2, int T, bool CIP, class F>
+template <int L2, int T, bool CIP, bool GEN, class F>
 __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, const DecTu &d, int c, int cx, int cy, int rx, int ry, int lane, const uint32_t (&wreg)[4])
 {
   constexpr int N = XW<L2, T>::N, OPL = XW<L2, T>::OPL, G = XW<L2, T>::G;
   const int sh = c ? 1 : 0, S = (1 << f.ctb_log2) >> sh, nl = N << sh, wC = f.w >> sh, hC = f.h >> sh;
   const int mode = d.mode, cidx = c ? 1 : 0;
-  const bool filt = mode < 35 && intra_filter_needed(N, cidx, mode);      // (mode 35: a PCM unit, no prediction)
+  const bool filt = (!GEN || mode < 35) && intra_filter_needed(N, cidx, mode);      // (mode 35: a PCM unit, no prediction)
   const int Xc = cx * S + rx, Yc = cy * S + ry, X = Xc << sh, Y = Yc << sh;
   // (the block's first 4 T level words arrive in wreg: loaded by the caller one block ahead)
   const bool has = d.count != 0, bypass = (d.flags & TU_BYPASS) != 0, tskip = (d.flags & TU_TSKIP) != 0 || bypass;
@@ -469,7 +469,7 @@ __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, cons
     const int nTR = ((aT || f.tiles) && dec_avail(f, X, Y, X + nl, Y - 1)) ? imin(N, wC - (Xc + N)) : 0;      // (a slice that begins with the block above-right: available without the one above)
     // ... two runs of available samples, [lo, 2N - 1] (lo = 2N: none) and [lob, hi]: the slice begins with the block above (the corner belongs to another) or with the
     // one above-right; a sample of the gap takes the last one of the run before it, or the first one there is (8.4.4.2.2)
-    const bool hole = f.tiles && ((!aT && nTR > 0) || (aL && aT && !aTL));
+    const bool hole = GEN && f.tiles && ((!aT && nTR > 0) || (aL && aT && !aTL));
     const int lob = aT ? 2 * N + 1 : 3 * N + 1;
     const int lo = aL ? N - nBL : (aTL || hole ? 2 * N : 2 * N + 1), hi = aT || hole ? 3 * N + nTR : (aTL ? 2 * N : (aL ? 2 * N - 1 : -1));
     // constrained_intra_pred_flag: available in the usual sense AND in an intra-coded block, per unit of four samples (a 4x4 record); unit u of the scan order = samples
@@ -562,7 +562,7 @@ __device__ __forceinline__ void dec_intra_block(const F &f, DecIntraLds &s, cons
       for (int e = 0; e < 2; e++)
 #pragma unroll
         for (int o = 0; o < OPL; o++) pred[e][o] = pred_dc<L2>(R, edge, dcv, g * OPL + o, 2 * rp + e);
-    } else if (mode == 35) {
+    } else if (GEN && mode == 35) {
 #pragma unroll
       for (int e = 0; e < 2; e++)
 #pragma unroll
@@ -657,7 +657,7 @@ template <class F> __device__ __forceinline__ void dec_intra_resid_body(const F 
 
 // one intra transform block of at most 16x16 samples on one wave (kernel_common.h "One intra block per WAVE"); `rres`: the lane's four
 // residual samples (k_dec_intra_resid), loaded by the caller one block ahead
-template <int L2>
+template <int L2, bool GEN>
 __device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveScratch &ws, const IntraBlk &d, bool luma,
                                                      int lane, uint2 rres, uint32_t *ecol, unsigned long long *erow, uint32_t gen, const CipCtx *cip)
 {
@@ -665,7 +665,7 @@ __device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveSc
   const int g = lane >> 4, c = lane & 15, rx = d.rx, ry = d.ry;
   const bool active = c < N && 4 * g < N;
   int pred[4];
-  wave_intra_predict<L2, true>(s.pic, DI_P, ws, d, luma, lane, g, c, pred, cip);
+  wave_intra_predict<L2, GEN>(s.pic, DI_P, ws, d, luma, lane, g, c, pred, cip);
   if (d.flags & IB_LEVELS) {
     const int res[4] = {(int)(int16_t)(rres.x & 0xffffu), (int)(int16_t)(rres.x >> 16), (int)(int16_t)(rres.y & 0xffffu), (int)(int16_t)(rres.y >> 16)};
 #pragma unroll
@@ -691,7 +691,7 @@ __device__ __forceinline__ void dec_intra_block_wave(DecIntraLds &s, IntraWaveSc
 #ifndef KVZ_DEC_INTRA_WAVES
 #define KVZ_DEC_INTRA_WAVES 4
 #endif
-template <bool CIP, class F> __device__ __forceinline__ void dec_intra_body(const F &f, const Wg wg)
+template <bool CIP, bool GEN, class F> __device__ __forceinline__ void dec_intra_body(const F &f, const Wg wg)
 {
   constexpr int W = KVZ_DEC_INTRA_WAVES, T = 64 * W;
   __shared__ DecIntraLds s;
@@ -769,16 +769,16 @@ template <bool CIP, class F> __device__ __forceinline__ void dec_intra_body(cons
     const bool aL = dec_avail(f, X, Y, X - 1, Y), aT = dec_avail(f, X, Y, X, Y - 1), aTL = aL && aT && dec_avail(f, X, Y, X - 1, Y - 1);
     const int nBL = (aL && dec_avail(f, X, Y, X - 1, Y + nl)) ? imin(N, hC - (Yc + N)) : 0;
     const int nTR = ((aT || f.tiles) && dec_avail(f, X, Y, X + nl, Y - 1)) ? imin(N, wC - (Xc + N)) : 0;      // (a slice that begins with the block above-right: available without the one above)
-    const bool hole = f.tiles && ((!aT && nTR > 0) || (aL && aT && !aTL));      // (two runs of available samples: kernel_common.h IB_HOLE)
+    const bool hole = GEN && f.tiles && ((!aT && nTR > 0) || (aL && aT && !aTL));      // (two runs of available samples: kernel_common.h IB_HOLE)
     const int lo = aL ? N - nBL : (aTL || hole ? 2 * N : 2 * N + 1), hi = aT || hole ? 3 * N + nTR : (aTL ? 2 * N : (aL ? 2 * N - 1 : 0));
     const int zu = zunit8((rx << sh) >> 3, (ry << sh) >> 3);
     IntraBlk d;
     d.rx = (uint8_t)rx; d.ry = (uint8_t)ry; d.lo = (uint8_t)lo; d.hi = (uint8_t)hi; d.mode = t.mode; d.l2 = t.log2;
-    d.flags = (uint8_t)(((t.mode < 35 && intra_filter_needed(N, c ? 1 : 0, t.mode)) ? IB_FILT : 0) | ((rx == 0 || ry == 0) ? IB_BORDER : 0) |
+    d.flags = (uint8_t)((((!GEN || t.mode < 35) && intra_filter_needed(N, c ? 1 : 0, t.mode)) ? IB_FILT : 0) | ((rx == 0 || ry == 0) ? IB_BORDER : 0) |
                         (t.count ? IB_LEVELS : 0) | ((t.flags & TU_TSKIP) ? IB_TSKIP : 0) | (hole ? IB_HOLE : 0) |
                         ((ry + N >= S) ? IB_EDGE : 0) | ((rx + N >= S) ? IB_EDGE_R : 0));
     d.xf = (uint8_t)(hole ? (aT ? 2 * N + 1 : 3 * N + 1) : 0);      // (the decoder's chain adds residuals computed elsewhere: the field is the second run's start of an IB_HOLE block)
-    d.angle = (int16_t)(t.mode < 35 ? kIntraAngle[t.mode] : 0); d.inv = (int16_t)(t.mode < 35 ? kInvAngle[t.mode] : 0);      // (mode 35: a PCM unit, no prediction)
+    d.angle = (int16_t)((!GEN || t.mode < 35) ? kIntraAngle[t.mode] : 0); d.inv = (int16_t)((!GEN || t.mode < 35) ? kInvAngle[t.mode] : 0);      // (mode 35: a PCM unit, no prediction)
     d.zu = (uint16_t)zu; d.next = 0;
     s.blk[k] = d;
     any32 |= t.log2 == 5;
@@ -854,16 +854,16 @@ template <bool CIP, class F> __device__ __forceinline__ void dec_intra_body(cons
         // (a neighbouring CTU is waited for only as far as the block's MODE reads it: hevc_core.h intra_uses_* -- any stream; this project's encoder keeps the blocks
         // on a CTU's left edge and its above-right corner block to the modes that make these waits short, "intra-chain")
         const int n = 1 << d.l2, ci = c ? 1 : 0;
-        const int nl2 = (((intra_uses_below_left(d.l2, ci) >> d.mode) & 1) || CIP) ? 2 * n : n, nt2 = (((intra_uses_above_right(d.l2, ci) >> d.mode) & 1) || (d.flags & IB_HOLE) || CIP) ? 2 * n : n;      // (IB_HOLE: the samples above may be copies of the first one above-right)
+        const int nl2 = (((intra_uses_below_left(d.l2, ci) >> d.mode) & 1) || CIP) ? 2 * n : n, nt2 = (((intra_uses_above_right(d.l2, ci) >> d.mode) & 1) || (GEN && (d.flags & IB_HOLE)) || CIP) ? 2 * n : n;      // (IB_HOLE: the samples above may be copies of the first one above-right)
         borders_need_wave(ch, bd, s.pic, DI_P, plane, cpitch, cx, cy, S, sh, wC - cx * S, d.rx, d.ry, n, f.err, lane, nl2, nt2);
       }
       if (k == k0) chain_wait_done(ch, make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)dp.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)dp.y)), f.err, lane);
       CipCtx cipc; const CipCtx *cip = nullptr;
       if (CIP) { cipc.ridx = (const int8_t *)f.b4 + 4; cipc.b4w = f.pw >> 2; cipc.xl = cx * S + d.rx; cipc.yl = cy * S + d.ry; cipc.sh = sh; cip = &cipc; }      // (constrained intra prediction: B4Rec::ref_idx, byte 4 of a record)
       switch (d.l2) {
-        case 2: dec_intra_block_wave<2>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen, cip); break;
-        case 3: dec_intra_block_wave<3>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen, cip); break;
-        case 4: dec_intra_block_wave<4>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen, cip); break;
+        case 2: dec_intra_block_wave<2, GEN>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen, cip); break;
+        case 3: dec_intra_block_wave<3, GEN>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen, cip); break;
+        case 4: dec_intra_block_wave<4, GEN>(s, ws, d, c == 0, lane, rres, ecol, erow, f.chain_gen, cip); break;
         default: {
           // a 32x32 block: the wave runs the workgroup-shaped code of the other sizes' predecessor by itself; its scratch arrays (s.A, s.B, s.R) exist
           // once per workgroup, so one 32x32 block at a time
@@ -875,7 +875,7 @@ template <bool CIP, class F> __device__ __forceinline__ void dec_intra_body(cons
 #pragma unroll
           for (int i = 0; i < 4; i++) u[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q[i]);
           memcpy(&t, u, sizeof(t));
-          dec_intra_block<5, 64, CIP>(f, s, t, c, cx, cy, d.rx, d.ry, lane, wreg);
+          dec_intra_block<5, 64, CIP, GEN>(f, s, t, c, cx, cy, d.rx, d.ry, lane, wreg);
           // (on the CTU's right edge / bottom: its last column / row from the CTU picture in LDS, tagged like the small blocks')
           if ((d.flags & IB_EDGE_R) && lane < 32) st_wt_u32(ecol + d.ry + lane, (uint32_t)s.pic[(d.ry + lane + 1) * DI_P + 16 + d.rx + 31] | (f.chain_gen << 8));
           if ((d.flags & IB_EDGE) && lane < 8) st_wt_u64(erow + ((d.rx + 4 * lane) >> 2), (unsigned long long)*(const uint32_t *)&s.pic[(d.ry + 32) * DI_P + 16 + d.rx + 4 * lane] | ((unsigned long long)f.chain_gen << 32));
@@ -1151,10 +1151,13 @@ template <class F> __device__ __forceinline__ void dec_sao_body(const F &f, cons
 // the single-picture kernels: the frame is the kernel argument
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_dec_inter(DecFrame f) { dec_inter_body(f, Wg{(int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y)}); }
 __global__ __launch_bounds__(256) void k_dec_intra_resid(DecFrame f) { dec_intra_resid_body(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
-__global__ __launch_bounds__(64 * KVZ_DEC_INTRA_WAVES) void k_dec_intra(DecFrame f) { dec_intra_body<false>(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
+// three forms of the chain: the plain one (one slice, one tile, no PCM: reference samples are one run, 209 registers), the general one (DecFrame::general: two runs,
+// PCM units), and the one for constrained intra prediction (DecFrame::cip: any pattern)
+__global__ __launch_bounds__(64 * KVZ_DEC_INTRA_WAVES) void k_dec_intra(DecFrame f) { dec_intra_body<false, false>(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
+__global__ __launch_bounds__(64 * KVZ_DEC_INTRA_WAVES) void k_dec_intra_gen(DecFrame f) { dec_intra_body<false, true>(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
 // ... with constrained_intra_pred_flag (DecFrame::cip): reference samples of blocks that are not intra-coded do not count -- a form of its own: the general substitution
 // costs the chain 37 registers
-__global__ __launch_bounds__(64 * KVZ_DEC_INTRA_WAVES) void k_dec_intra_cip(DecFrame f) { dec_intra_body<true>(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
+__global__ __launch_bounds__(64 * KVZ_DEC_INTRA_WAVES) void k_dec_intra_cip(DecFrame f) { dec_intra_body<true, true>(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
 __global__ __launch_bounds__(256) void k_dec_deblock(DecFrame f) { dec_deblock_body(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
 __global__ __launch_bounds__(256) void k_dec_sao(DecFrame f) { dec_sao_body(f, Wg{(int)blockIdx.x, (int)gridDim.x}); }
 
@@ -1172,7 +1175,8 @@ __device__ __forceinline__ int batch_frame(const DecBatch &b, Wg &wg)
 #define KVZ_BATCH_FRAME(b) Wg wg; const CDecFrame &f = *(const CDecFrame *)(b).f[batch_frame(b, wg)]
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_dec_inter_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_inter_body(f, wg); }
 __global__ __launch_bounds__(256) void k_dec_intra_resid_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_intra_resid_body(f, wg); }
-__global__ __launch_bounds__(64 * KVZ_DEC_INTRA_WAVES) void k_dec_intra_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_intra_body<false>(f, wg); }
+__global__ __launch_bounds__(64 * KVZ_DEC_INTRA_WAVES) void k_dec_intra_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_intra_body<false, false>(f, wg); }
+__global__ __launch_bounds__(64 * KVZ_DEC_INTRA_WAVES) void k_dec_intra_gen_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_intra_body<false, true>(f, wg); }
 __global__ __launch_bounds__(256) void k_dec_deblock_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_deblock_body(f, wg); }
 __global__ __launch_bounds__(256) void k_dec_sao_n(DecBatch b) { KVZ_BATCH_FRAME(b); dec_sao_body(f, wg); }
 
@@ -1192,6 +1196,7 @@ void launch_dec_intra_resid(const DecFrame &f, hipStream_t st) { if (f.ntu > 0) 
 void launch_dec_intra(const DecFrame &f, hipStream_t st)
 {
   if (f.cip) hipLaunchKernelGGL(k_dec_intra_cip, dim3(dec_intra_wgs(f)), dim3(64 * KVZ_DEC_INTRA_WAVES), 0, st, f);
+  else if (f.general) hipLaunchKernelGGL(k_dec_intra_gen, dim3(dec_intra_wgs(f)), dim3(64 * KVZ_DEC_INTRA_WAVES), 0, st, f);
   else hipLaunchKernelGGL(k_dec_intra, dim3(dec_intra_wgs(f)), dim3(64 * KVZ_DEC_INTRA_WAVES), 0, st, f);
 }
 void launch_dec_deblock(const DecFrame &f, hipStream_t st) { hipLaunchKernelGGL(k_dec_deblock, dim3(f.wc * dec_rows(f)), dim3(256), 0, st, f); }
@@ -1218,7 +1223,10 @@ void launch_dec_intra_n(const DecFrame *const *h, const DecFrame *const *d, int 
   DecBatch b; uint32_t total = batch_layout(b, h, d, n, [](const DecFrame &f) { return (f.ntu + 3) / 4; });
   if (total) hipLaunchKernelGGL(k_dec_intra_resid_n, dim3(total), dim3(256), 0, st, b);
   total = batch_layout(b, h, d, n, [](const DecFrame &f) { return dec_intra_wgs(f); });
-  if (total) hipLaunchKernelGGL(k_dec_intra_n, dim3(total), dim3(64 * KVZ_DEC_INTRA_WAVES), 0, st, b);
+  bool general = false;
+  for (int i = 0; i < n; i++) general |= h[i]->general != 0;
+  if (total && general) hipLaunchKernelGGL(k_dec_intra_gen_n, dim3(total), dim3(64 * KVZ_DEC_INTRA_WAVES), 0, st, b);
+  else if (total) hipLaunchKernelGGL(k_dec_intra_n, dim3(total), dim3(64 * KVZ_DEC_INTRA_WAVES), 0, st, b);
 }
 void launch_dec_deblock_n(const DecFrame *const *h, const DecFrame *const *d, int n, hipStream_t st)
 {

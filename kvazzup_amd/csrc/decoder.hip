@@ -2801,6 +2801,7 @@ int Decoder::launch_gpu(PicJob &job)
   f.beta_offset = (int8_t)(2 * job.sh.beta_offset_div2); f.tc_offset = (int8_t)(2 * job.sh.tc_offset_div2);
   f.intra_direct = job.any_inter ? 1 : 0;                 // (a picture with inter blocks: few (CTU, plane) pairs hold intra blocks)
   f.strong_intra = (uint8_t)job.sps->strong_intra; f.tiles = job.pps.tile_rows > 1 || job.pps.tile_cols > 1 || job.slice_qps.size() > 1;
+  f.general = (uint8_t)(job.pps.tile_rows > 1 || job.pps.tile_cols > 1 || job.slice_qps.size() > 1 || job.sps->pcm_depth[0] != 0);
   f.cip = (uint8_t)(job.pps.cip && job.any_inter);      // (a picture without inter blocks: every neighbour is intra)
   f.tq_bypass = (uint8_t)(job.pps.tq_bypass || (job.sps->pcm_depth[0] && job.sps->pcm_no_filter));      // (units the loop filters keep out of: B4_BYPASS records)
   // scaling lists: the picture's factors (the PPS's lists when it carries any, else the SPS's) ride in the input block

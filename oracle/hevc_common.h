@@ -42,7 +42,7 @@ enum { SLICE_B = 0, SLICE_P = 1, SLICE_I = 2 };
 enum { MODE_INTER = 0, MODE_INTRA = 1, MODE_SKIP = 2 };
 enum { PART_2Nx2N = 0, PART_2NxN = 1, PART_Nx2N = 2, PART_NxN = 3,
        PART_2NxnU = 4, PART_2NxnD = 5, PART_nLx2N = 6, PART_nRx2N = 7 };
-enum { NAL_TRAIL_N = 0, NAL_TRAIL_R = 1, NAL_BLA_W_LP = 16, NAL_IDR_W_RADL = 19, NAL_IDR_N_LP = 20,
+enum { NAL_TRAIL_N = 0, NAL_TRAIL_R = 1, NAL_RADL_N = 6, NAL_RADL_R = 7, NAL_RASL_N = 8, NAL_RASL_R = 9, NAL_BLA_W_LP = 16, NAL_BLA_W_RADL = 17, NAL_BLA_N_LP = 18, NAL_IDR_W_RADL = 19, NAL_IDR_N_LP = 20,
        NAL_CRA = 21, NAL_RSV_IRAP_VCL23 = 23, NAL_VPS = 32, NAL_SPS = 33, NAL_PPS = 34,
        NAL_AUD = 35, NAL_EOS = 36, NAL_EOB = 37, NAL_FD = 38, NAL_SEI_PREFIX = 39, NAL_SEI_SUFFIX = 40 };
 

@@ -28,6 +28,8 @@ struct orc_decoder {
   int nal_type;
   int prev_tid0_poc;
   int seen_irap;
+  int after_eos;                          /* an end of sequence NAL unit came: the next picture starts a coded video sequence (a CRA picture then has NoRaslOutputFlag = 1) */
+  int skip_rasl;                          /* NoRaslOutputFlag of the last IRAP picture: its RASL pictures are not decoded (8.1.3) */
   orc_pic *ref_list0[16]; int ref_poc[16]; int num_ref;
   orc_pic *ref_list1[16]; int ref_poc1[16]; int num_ref1;     /* RefPicList1 (B slices) */
   int no_backward_pred;                   /* NoBackwardPredFlag, 8.5.3.2.9 */
@@ -768,26 +770,40 @@ static int start_picture(orc_decoder *d)
   const orc_sps *s = d->s; orc_slice_hdr *sh = &d->sh;
   int irap = d->nal_type >= NAL_BLA_W_LP && d->nal_type <= NAL_RSV_IRAP_VCL23;
   int idr = d->nal_type == NAL_IDR_W_RADL || d->nal_type == NAL_IDR_N_LP;
+  const int bla = d->nal_type >= NAL_BLA_W_LP && d->nal_type <= NAL_BLA_N_LP;
   if (!d->seen_irap && !irap) return 0;           /* cannot start decoding before a random access point */
+  /* 8.1.3: NoRaslOutputFlag -- an IDR or BLA picture, or a CRA picture that is the first of the stream or follows an end of sequence NAL unit.  The RASL
+   * pictures associated with such a picture predict from pictures that are not there: they are not decoded and not output */
+  const int no_rasl_out = idr || bla || (irap && (!d->seen_irap || d->after_eos));
+  if (irap) d->skip_rasl = no_rasl_out;
+  if ((d->nal_type == NAL_RASL_N || d->nal_type == NAL_RASL_R) && d->skip_rasl) return 0;
   /* 8.3.1 picture order count */
   int poc;
   int max_lsb = 1 << s->log2_max_poc_lsb;
   if (idr) poc = 0;
   else {
     int prev_lsb = d->prev_tid0_poc & (max_lsb - 1), prev_msb = d->prev_tid0_poc - prev_lsb, msb;
-    if (irap && !d->seen_irap) msb = 0;
+    if (irap && no_rasl_out) msb = 0;
     else if (sh->poc_lsb < prev_lsb && prev_lsb - sh->poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
     else if (sh->poc_lsb > prev_lsb && sh->poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
     else msb = prev_msb;
     poc = msb + sh->poc_lsb;
   }
-  if (idr) {
+  if (no_rasl_out) {                              /* 8.3.2: every reference picture in the DPB is marked unused */
     for (int i = 0; i < MAX_DPB; i++) d->dpb[i].is_ref = 0;
   }
-  /* C.5.2.2: an IRAP picture that starts a coded video sequence (no_output_of_prior_pics_flag 0) empties the DPB in output order first */
-  if (idr || !d->seen_irap) { while (waiting_for_output(d)) bump(d); d->cvs++; }
-  d->seen_irap = 1;
-  d->prev_tid0_poc = poc;      /* TemporalId 0 only in this oracle's streams; RASL/RADL not produced */
+  /* C.5.2.2: an IRAP picture that starts a coded video sequence empties the DPB first -- in output order, or (no_output_of_prior_pics_flag of an IDR or BLA
+   * picture) without output of what still waits.  (A CRA picture gets here behind an end of sequence NAL unit only, which has output everything: see orc_dec_decode_nal.) */
+  if (no_rasl_out) {
+    if (d->seen_irap && !d->after_eos && (idr || bla) && sh->no_output_of_prior_pics) {
+      for (int i = 0; i < MAX_DPB; i++) { orc_pic *q = &d->dpb[i]; if (q->in_use && !q->out_queued) q->needed_for_output = 0; }
+    }
+    while (waiting_for_output(d)) bump(d);
+    d->cvs++;
+  }
+  d->seen_irap = 1; d->after_eos = 0;
+  /* prevTidOPic (8.3.1): TemporalId 0 (all there is here) and no RASL, RADL or sub-layer non-reference picture */
+  if (d->nal_type >= NAL_BLA_W_LP || ((d->nal_type & 1) && d->nal_type < NAL_RADL_N)) d->prev_tid0_poc = poc;
   d->cur = alloc_pic(d, s->width, s->height);
   if (!d->cur) return ERR_INVALID;
   d->cur->poc = poc; d->cur->pts = d->cur_pts;
@@ -1025,7 +1041,7 @@ int orc_dec_decode_nal(orc_decoder *d, const uint8_t *data, size_t len, int64_t 
   size_t i = 0;
   while (i + 2 < len && data[i] == 0) i++;
   if (i >= 2 && i < len && data[i] == 1) { data += i + 1; len -= i + 1; }
-  if (len < 3) return ERR_INVALID;
+  if (len < 2) return ERR_INVALID;
   if (data[0] & 0x80) return ERR_INVALID;
   int nal_type = (data[0] >> 1) & 0x3f;
   int layer = ((data[0] & 1) << 5) | (data[1] >> 3);
@@ -1058,7 +1074,15 @@ int orc_dec_decode_nal(orc_decoder *d, const uint8_t *data, size_t len, int64_t 
     }
     return 0;
   }
-  if (nal_type > 31) return 0;                        /* AUD, other SEI, EOS, ... ignored */
+  if (nal_type == NAL_EOS || nal_type == NAL_EOB) {
+    /* the coded video sequence ends: what still waits goes out now (a decoder at the end of a call would not keep pictures back for a sequence that may never
+     * come), and the picture that follows starts a sequence whatever its type */
+    if (d->pic_active) finish_picture(d);
+    while (waiting_for_output(d)) bump(d);
+    d->after_eos = 1;
+    return d->out_n > 0 ? 1 : 0;
+  }
+  if (nal_type > 31) return 0;                        /* AUD, other SEI, ... ignored */
   if ((nal_type > NAL_TRAIL_R + 8 && nal_type < NAL_BLA_W_LP) || nal_type > NAL_CRA) return 0;   /* reserved */
   free(d->sh.entry_point_offset); d->sh.entry_point_offset = NULL;
   d->nal_type = nal_type;

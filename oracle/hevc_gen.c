@@ -31,6 +31,8 @@ struct orc_gen {
   orc_cabac_enc c;
   orc_bitw au;
   int frame_idx, poc, since_idr;
+  int hist_cls[8];                    /* open_gop: 1 = decoded before the last CRA picture, or a RASL picture -- nothing a RADL picture may use */
+  int cra_poc, cra_split, cur_nal;    /* open_gop: POC of the last CRA picture (-1: none since the IDR), the POC below which its leading pictures are RASL; the picture's NAL unit type */
   int hist_poc[8], hist_n;            /* POCs of the pictures decoded since the IDR, newest first (the reference picture set is the first num_refs of them) */
   int gop_order[8];                   /* cfg.gop > 1: POC offsets inside a group in decoding order */
   int slice_is_b;
@@ -152,7 +154,7 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
     g->gop_order[n++] = c->gop; lo[sp] = 0; hi[sp] = c->gop; sp++;
     while (sp) { sp--; const int a = lo[sp], b = hi[sp], m = (a + b) / 2; if (m == a) continue; g->gop_order[n++] = m; lo[sp] = m; hi[sp] = b; sp++; lo[sp] = a; hi[sp] = m; sp++; }
     int lg = 0; while ((1 << lg) < c->gop) lg++;
-    s->max_num_reorder = lg; s->max_dec_pic_buffering = c->num_refs + lg + 2;      /* (roomy: output is driven by the reorder count alone) */
+    s->max_num_reorder = lg; s->max_dec_pic_buffering = c->num_refs + lg + 2 + (c->open_gop == 1);      /* (roomy: output is driven by the reorder count alone) */
     if (s->log2_max_poc_lsb < 6) s->log2_max_poc_lsb = 6;
   }
   s->log2_min_cb = c->min_cb_log2; s->log2_diff_max_min_cb = c->ctb_log2 - c->min_cb_log2; s->log2_min_tb = 2; s->log2_diff_max_min_tb = c->ctb_log2 < 5 ? c->ctb_log2 - 2 : 3;      /* (MaxTbLog2SizeY <= Min(CtbLog2SizeY, 5)) */
@@ -190,6 +192,9 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   if (c->lf_across < 0 || c->lf_across > 2) c->lf_across = 0;
   if (c->pcm < 0) c->pcm = 0;
   if (c->long_term < 0 || c->gop || c->b_slices > 0) c->long_term = 0;
+  if (c->open_gop != 1 || !c->gop) c->open_gop = 0;
+  if (c->hidden_pics < 0) c->hidden_pics = 0;
+  p->output_flag_present = c->hidden_pics > 0;
   p->entropy_coding_sync_enabled = c->wpp; p->loop_filter_across_slices = c->lf_across == 0 ? 1 : (c->lf_across == 2 ? 0 : rpct(g, 70));
   if (c->slices < 0 || c->slices > 3) c->slices = 0;
   if (c->tile_cols < 1) c->tile_cols = 1;
@@ -792,7 +797,7 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
   orc_bitw ps, hdr, *subs;
   const orc_sps *s = &g->sps; orc_pps *p = &g->pps; orc_slice_hdr *sh = &g->sh;
   const int wc = s->pic_w_ctbs, hc = s->pic_h_ctbs;
-  const int nal = idr ? NAL_IDR_W_RADL : NAL_TRAIL_R;
+  const int nal = g->cur_nal, cra = nal == NAL_CRA, radl = nal == NAL_RADL_R;
   g->au.len = 0; g->au.nbits = 0; g->au.cur = 0;
   if (write_ps) {
     orc_bw_init(&ps); orc_write_vps(&ps, &g->vps, &g->sps); orc_write_nal(&g->au, NAL_VPS, 0, ps.buf, ps.len, 1); orc_bw_free(&ps);
@@ -801,8 +806,8 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
   }
   /* ---- slice header */
   memset(sh, 0, sizeof(*sh));
-  sh->first_slice_segment_in_pic = 1; sh->pic_output_flag = 1;
-  g->slice_is_intra = idr || g->since_idr == 0 || rpct(g, 8);
+  sh->first_slice_segment_in_pic = 1; sh->pic_output_flag = p->output_flag_present ? !rpct(g, g->cfg.hidden_pics) : 1;
+  g->slice_is_intra = idr || cra || g->since_idr == 0 || rpct(g, 8);
   g->slice_is_b = !g->slice_is_intra && g->cfg.b_slices > 0 && rpct(g, g->cfg.b_slices);
   sh->slice_type = g->slice_is_intra ? SLICE_I : (g->slice_is_b ? SLICE_B : SLICE_P);
   sh->poc_lsb = g->poc & ((1 << s->log2_max_poc_lsb) - 1);
@@ -843,16 +848,26 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
     /* the general form (B slices, reordered groups): the set is the last num_refs pictures in DECODING order, which lie on both sides of the current
      * one once pictures are reordered -- the ones before it in output order nearest first (S0), then the ones after it (S1) */
     const int nh = ORC_MIN(g->cfg.num_refs, g->hist_n);
-    int neg[8], pos[8], nn = 0, np = 0;
-    for (int i = 0; i < nh; i++) { if (g->hist_poc[i] < g->poc) neg[nn++] = g->hist_poc[i]; else pos[np++] = g->hist_poc[i]; }
-    for (int i = 1; i < nn; i++) for (int j = i; j > 0 && neg[j] > neg[j - 1]; j--) { const int t = neg[j]; neg[j] = neg[j - 1]; neg[j - 1] = t; }
-    for (int i = 1; i < np; i++) for (int j = i; j > 0 && pos[j] < pos[j - 1]; j--) { const int t = pos[j]; pos[j] = pos[j - 1]; pos[j - 1] = t; }
+    int neg[8], pos[8], nn = 0, np = 0, nbad[8], pbad[8];
+    int has_cra = 0;
+    for (int i = 0; i < nh; i++) { if (g->hist_poc[i] < g->poc) { nbad[nn] = g->hist_cls[i]; neg[nn++] = g->hist_poc[i]; } else { pbad[np] = g->hist_cls[i]; pos[np++] = g->hist_poc[i]; } has_cra |= g->hist_poc[i] == g->cra_poc; }
+    if (g->cra_poc >= 0 && g->poc < g->cra_poc && !has_cra) { pbad[np] = 0; pos[np++] = g->cra_poc; }      /* a leading picture keeps its CRA picture: all that the trailing pictures may start from */
+    for (int i = 1; i < nn; i++) for (int j = i; j > 0 && neg[j] > neg[j - 1]; j--) { int t = neg[j]; neg[j] = neg[j - 1]; neg[j - 1] = t; t = nbad[j]; nbad[j] = nbad[j - 1]; nbad[j - 1] = t; }
+    for (int i = 1; i < np; i++) for (int j = i; j > 0 && pos[j] < pos[j - 1]; j--) { int t = pos[j]; pos[j] = pos[j - 1]; pos[j - 1] = t; t = pbad[j]; pbad[j] = pbad[j - 1]; pbad[j - 1] = t; }
     sh->short_term_ref_pic_set_sps_flag = 0;
     sh->st_rps.num_negative = nn; sh->st_rps.num_positive = np;
     int used = 0;
     for (int i = 0; i < nn; i++) { sh->st_rps.delta_poc_s0[i] = neg[i] - g->poc; sh->st_rps.used_s0[i] = rpct(g, 85); used += sh->st_rps.used_s0[i]; }
     for (int i = 0; i < np; i++) { sh->st_rps.delta_poc_s1[i] = pos[i] - g->poc; sh->st_rps.used_s1[i] = rpct(g, 85); used += sh->st_rps.used_s1[i]; }
-    if (!used) { if (nn) sh->st_rps.used_s0[0] = 1; else sh->st_rps.used_s1[0] = 1; used = 1; }
+    if (radl) {
+      /* a RADL picture predicts from its CRA picture and other RADL pictures only (the rest of the set stays, unused: RASL pictures that follow may need it) */
+      int ok = -1; used = 0;
+      for (int i = 0; i < nn; i++) { if (nbad[i]) sh->st_rps.used_s0[i] = 0; else if (ok < 0) ok = i; used += sh->st_rps.used_s0[i]; }
+      for (int i = 0; i < np; i++) { if (pbad[i]) sh->st_rps.used_s1[i] = 0; else if (ok < 0) ok = 8 + i; used += sh->st_rps.used_s1[i]; }
+      if (!used && ok >= 0) { if (ok < 8) sh->st_rps.used_s0[ok] = 1; else sh->st_rps.used_s1[ok - 8] = 1; used = 1; }
+      if (!used) { g->slice_is_intra = 1; g->slice_is_b = 0; sh->slice_type = SLICE_I; used = 1; }      /* (the CRA picture is out of reach: an intra picture) */
+    }
+    else if (!used) { if (nn) sh->st_rps.used_s0[0] = 1; else if (np) sh->st_rps.used_s1[0] = 1; else { g->slice_is_intra = 1; g->slice_is_b = 0; sh->slice_type = SLICE_I; } used = 1; }
     sh->num_ref_idx_l0 = g->slice_is_intra ? p->num_ref_idx_l0_default : rrange(g, 1, ORC_MIN(4, used + 1));
     if (g->slice_is_b) { sh->num_ref_idx_l1 = rrange(g, 1, ORC_MIN(4, used + 1)); sh->mvd_l1_zero = rpct(g, 30); }
     sh->slice_temporal_mvp_enabled = s->temporal_mvp_enabled ? rpct(g, 80) : 0;
@@ -977,15 +992,30 @@ size_t orc_gen_picture(orc_gen *g, const uint8_t **au)
 {
   const int period = g->cfg.intra_period;
   const int idr = (g->frame_idx == 0) || (period > 0 && (g->frame_idx % period) == 0);
-  if (idr) { g->poc = 0; g->since_idr = 0; g->hist_n = 0; g->lt_alive = 1; g->lt_marked = 0; }
+  int cra = 0;
+  if (idr) { g->poc = 0; g->since_idr = 0; g->hist_n = 0; g->lt_alive = 1; g->lt_marked = 0; g->cra_poc = -1; }
   else {
     g->since_idr++;
-    if (g->cfg.gop) { const int k = g->since_idr - 1; g->poc = (k / g->cfg.gop) * g->cfg.gop + g->gop_order[k % g->cfg.gop]; }
+    if (g->cfg.gop) { const int k = g->since_idr - 1; g->poc = (k / g->cfg.gop) * g->cfg.gop + g->gop_order[k % g->cfg.gop]; cra = g->cfg.open_gop && k % g->cfg.gop == 0 && rpct(g, 45); }
     else g->poc++;
   }
-  write_picture(g, idr, idr);
-  for (int i = ORC_MIN(g->hist_n, 7); i > 0; i--) g->hist_poc[i] = g->hist_poc[i - 1];
-  g->hist_poc[0] = g->poc; if (g->hist_n < 8) g->hist_n++;
+  /* open_gop: the picture a group starts with (its last one in output order) is a CRA picture now and then -- the group's other pictures are its LEADING pictures: RASL
+   * below a drawn POC (they may predict from anything), RADL from there on (from the CRA picture and from each other only; 7.4.2.2: RASL before RADL in output order) */
+  g->cur_nal = idr ? NAL_IDR_W_RADL : NAL_TRAIL_R;
+  if (!idr && g->cra_poc >= 0 && g->poc > g->cra_poc) {
+    /* 8.3.2: a trailing picture of a CRA picture, and the next CRA picture too, have nothing in their sets that precedes that CRA picture in decoding or
+     * output order -- those pictures leave for good */
+    int n = 0;
+    for (int i = 0; i < g->hist_n; i++) if (g->hist_poc[i] >= g->cra_poc) { g->hist_poc[n] = g->hist_poc[i]; g->hist_cls[n] = g->hist_cls[i]; n++; }
+    g->hist_n = n;
+  }
+  if (cra) {
+    g->cur_nal = NAL_CRA; g->cra_poc = g->poc; g->cra_split = g->poc - g->cfg.gop + 1 + rrange(g, 0, g->cfg.gop - 1);
+    for (int i = 0; i < g->hist_n; i++) g->hist_cls[i] = 1;
+  } else if (!idr && g->cra_poc >= 0 && g->poc < g->cra_poc) g->cur_nal = g->poc < g->cra_split ? NAL_RASL_R : NAL_RADL_R;
+  write_picture(g, idr, idr || cra);
+  for (int i = ORC_MIN(g->hist_n, 7); i > 0; i--) { g->hist_poc[i] = g->hist_poc[i - 1]; g->hist_cls[i] = g->hist_cls[i - 1]; }
+  g->hist_poc[0] = g->poc; g->hist_cls[0] = g->cur_nal == NAL_RASL_R; if (g->hist_n < 8) g->hist_n++;
   g->frame_idx++;
   *au = g->au.buf;
   return g->au.len;

@@ -68,6 +68,9 @@ typedef struct {
                                * it every slice draws its slice_loop_filter_across_slices_enabled_flag; 2 = everything off */
   int min_cb_log2;            /* MinCbLog2SizeY: 3 (also -1 / 0: every stream of the earlier rounds), 4 or 5 -- no coding unit below 16 / 32 samples; taken back to 3 when the
                                * picture size is no multiple of it or it exceeds the CTB.  At the minimum size above 8 an inter unit may be cut into four (PART_NxN) */
+  int open_gop;               /* 1 (with gop > 1): groups that start with a CRA picture instead of following an IDR picture's lead -- their other pictures are RASL / RADL leading
+                               * pictures, the parameter sets are repeated: a decoder may start there (RASL pictures dropped), a splicer may call the picture BLA -- 0 (also -1): off */
+  int hidden_pics;            /* probability (%) of pic_output_flag = 0 (a picture that is decoded and referenced but never handed out); > 0 sets output_flag_present_flag -- 0 (also -1): off */
 } orc_gen_config;
 
 void orc_gen_default_config(orc_gen_config *c);    /* everything random, 416x240 */

@@ -543,6 +543,9 @@ class Decoder:
         self.prev_poc_tid0 = 0
         self.out = []
         self.cvs = 0            # coded video sequences started so far
+        self.after_eos = False  # an end of sequence NAL unit came: the next picture starts a coded video sequence
+        self.skip_rasl = False  # NoRaslOutputFlag of the last IRAP picture (8.1.3): its RASL pictures are dropped
+        self.skipping = False   # inside a dropped picture: its further slice segments go the same way
         self.trace = None       # optional list: ("cu", x, y, log2, pred_mode, part), ("tu", cidx, x, y, log2, [levels...]) ...
 
     # ------------------------------------------------------------------------------------------- NAL level
@@ -561,6 +564,8 @@ class Decoder:
         elif t == 34:
             p = parse_pps(unescape(nal))
             self.pps[p["id"]] = p
+        elif t in (36, 37):
+            self.after_eos = True
         elif t <= 21 and (t <= 9 or t >= 16):
             self.decode_slice(nal, t)
 
@@ -576,6 +581,15 @@ class Decoder:
         pps = self.pps[r.ue()]
         sps = self.sps[pps["sps"]]
         dependent, address = 0, 0
+        if first:
+            # 8.1.3: IDR and BLA pictures, and a CRA picture that opens the stream or follows an end of sequence NAL unit, start a coded video sequence
+            # (NoRaslOutputFlag = 1); the RASL pictures that belong to such a picture refer to pictures that do not exist -- dropped
+            self.no_rasl_out = idr or nal_type in (16, 17, 18) or (irap and (self.cvs == 0 or self.after_eos))
+            if irap:
+                self.skip_rasl = self.no_rasl_out
+            self.skipping = (nal_type in (8, 9) and self.skip_rasl) or (self.cvs == 0 and not irap)
+        if self.skipping:
+            return
         if not first:                                              # 7.3.6.1: a further slice segment of the picture under way
             if pps["dep"]:
                 dependent = r.u(1)
@@ -593,9 +607,8 @@ class Decoder:
     def slice_header_body(self, r, sps, pps, nal_type, idr):
         r.u(pps["extra_bits"])
         slice_type = r.ue()          # 0 B, 1 P, 2 I
-        if pps["output_flag"]:
-            r.u(1)
-        sh = {"type": slice_type, "intra": slice_type == 2, "b": slice_type == 0}
+        shown = r.u(1) if pps["output_flag"] else 1
+        sh = {"type": slice_type, "intra": slice_type == 2, "b": slice_type == 0, "shown": shown}
         self.last_sh = sh                                          # (for tests that look at what a stream carries)
         rps = []
         poc = 0
@@ -610,7 +623,7 @@ class Decoder:
                 msb = pmsb - mx
             else:
                 msb = pmsb
-            if nal_type in (16, 17, 18):
+            if 16 <= nal_type <= 23 and self.no_rasl_out:
                 msb = 0
             poc = msb + lsb
             if not r.u(1):
@@ -763,8 +776,9 @@ class Decoder:
         # ---- reference picture set (8.3.2) and list (8.3.4)
         for p in self.dpb:
             p.is_ref = False
-        if idr:
-            self.dpb = []
+        if self.no_rasl_out and 16 <= nal_type <= 23:
+            self.dpb = []                                              # 8.3.2: nothing that came before is a reference picture any more
+            rps = [(d, 0) for d, _ in rps]                             # (what a CRA or BLA picture's set names is for its RASL pictures)
         before = [poc + d for d, used in rps if d < 0 and used]
         after = [poc + d for d, used in rps if d > 0 and used]
         keep = [poc + d for d, _ in rps]
@@ -792,8 +806,9 @@ class Decoder:
         le = sh.get("list_entry") or [None, None]                    # (a modified list: entries of the temporary list in the slice's order)
         refs = [[c0[le[0][i] if le[0] else i % len(c0)] for i in range(sh["nref"])] if sh["nref"] else [],
                 [c1[le[1][i] if le[1] else i % len(c1)] for i in range(sh["nref1"])] if sh["nref1"] else []]
-        if idr or self.cvs == 0:
+        if self.no_rasl_out and 16 <= nal_type <= 23:
             self.cvs += 1
+        self.after_eos = False
         pic = Picture(sps["w"], sps["h"])
         pic.poc = poc
         sh["poc"] = poc
@@ -819,6 +834,8 @@ class Decoder:
         y = pic.planes[0][ct:sps["h"] - cb, cl:sps["w"] - cr_]
         u = pic.planes[1][ct // 2:(sps["h"] - cb) // 2, cl // 2:(sps["w"] - cr_) // 2]
         v = pic.planes[2][ct // 2:(sps["h"] - cb) // 2, cl // 2:(sps["w"] - cr_) // 2]
+        if not sl.sh["shown"]:
+            return                                                     # pic_output_flag = 0: decoded, kept as a reference, never handed out
         self.out.append({"poc": poc, "cvs": self.cvs, "i420": np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)]).astype(np.uint8),
                          "width": y.shape[1], "height": y.shape[0]})
 

@@ -1,0 +1,168 @@
+"""Random access into a stream, CPU side: CRA pictures with RASL / RADL leading pictures, BLA pictures, end of sequence NAL units,
+pic_output_flag (8.1.3, 8.3.1, 8.3.2, C.5.2.2) -- what a decoder meets when it joins a stream at a random access point that is no
+IDR picture, or reads one a splicer has cut (the reference hands every NAL unit it receives to libOpenHevcDecode,
+/root/reference/src/media/processing/openhevcfilter.cpp:134-172; a Kvazaar peer sends IDR pictures only, other senders do not).
+
+The checker's decoder against PROPERTIES of the streams -- a decode that starts at a CRA picture shows exactly the full decode's
+pictures from there on minus that picture's RASL pictures, bit for bit; a CRA picture renamed BLA, or behind an end of sequence
+NAL unit, does the same to the pictures that follow while everything before it still comes out -- and against the second,
+independently written decoder (tests/pyhevc.py).  The product's decoder meets the same streams in tests/test_gpu_random_access.py."""
+import numpy as np
+import pytest
+
+import orc
+import pyhevc
+from test_python_decoder import tabs
+
+EOS = bytes([0, 0, 0, 1, 36 << 1, 1])
+
+
+def nal_type(nal):
+    i = 0
+    while nal[i] == 0:
+        i += 1
+    return (nal[i + 1] >> 1) & 63
+
+
+def vcl_type(au):
+    return next(t for t in (nal_type(n) for n in orc.split_nals(au)) if t < 32)
+
+
+def rename(au, old, new):
+    """the access unit with its slice NAL units of type `old` called `new` (the type sits in bits 1..6 of the header's first byte)"""
+    out = bytearray()
+    for n in orc.split_nals(au):
+        n = bytearray(n)
+        i = 0
+        while n[i] == 0:
+            i += 1
+        if (n[i + 1] >> 1) & 63 == old:
+            n[i + 1] = (n[i + 1] & 0x81) | (new << 1)
+        out += n
+    return bytes(out)
+
+
+def stream(seed, n=36, **kw):
+    cfg = dict(gop=(2, 4, 8)[seed % 3], open_gop=1, intra_period=48, b_slices=50, num_refs=1 + seed % 4)
+    cfg.update(kw)
+    g = orc.OracleGen(64, 64, seed=seed, **cfg)
+    aus = [g.picture() for _ in range(n)]
+    g.close()
+    return aus
+
+
+def oracle_pictures(aus, first_pts=0):
+    """(pts, picture) in output order; the pts is the access unit's index"""
+    d = orc.OracleDecoder()
+    out = []
+    for k, au in enumerate(aus):
+        out += d.decode_au(au, pts=first_pts + k)
+    out += d.flush()
+    d.close()
+    return [(f["pts"], f["i420"]) for f in out]
+
+
+def rasl_of(types, k):
+    """indices of the RASL pictures that belong to the CRA picture at index k"""
+    out = []
+    for i in range(k + 1, len(types)):
+        if 16 <= types[i] <= 23:
+            break
+        if types[i] in (8, 9):
+            out.append(i)
+    return out
+
+
+def same(a, b):
+    assert [p for p, _ in a] == [p for p, _ in b]
+    for (p, x), (_, y) in zip(a, b):
+        assert np.array_equal(x, y), p
+
+
+@pytest.mark.parametrize("seed", (1, 2, 3, 4, 6, 7, 9, 10, 11, 12, 13))
+def test_decoding_from_a_cra_picture_drops_its_rasl_pictures_and_nothing_else(seed):
+    aus = stream(seed)
+    types = [vcl_type(a) for a in aus]
+    cras = [i for i, t in enumerate(types) if t == 21]
+    assert cras
+    full = oracle_pictures(aus)
+    assert len(full) == len(aus)
+    for k in cras:
+        drop = set(rasl_of(types, k))
+        want = [(p, x) for p, x in full if p >= k and p not in drop]
+        same(oracle_pictures(aus[k:], first_pts=k), want)
+
+
+@pytest.mark.parametrize("bla", (16, 17, 18))
+@pytest.mark.parametrize("seed", (1, 2, 3, 6))
+def test_a_cra_picture_renamed_bla(seed, bla):
+    """what a splicer does (BLA_W_LP as it is; BLA_W_RADL with the RASL pictures removed; BLA_N_LP with every leading picture removed): the pictures before it come
+    out untouched, the ones behind it as a decode that starts there gives them"""
+    aus = stream(seed)
+    types = [vcl_type(a) for a in aus]
+    full = oracle_pictures(aus)
+    for k in [i for i, t in enumerate(types) if t == 21][:3]:
+        drop = set(rasl_of(types, k))
+        if bla == 18:
+            drop |= {i for i in range(k + 1, len(types)) if types[i] in (6, 7) and all(not 16 <= t <= 23 for t in types[k + 1:i])}
+        cut = [rename(a, 21, bla) if i == k else a for i, a in enumerate(aus) if bla == 16 or i not in drop]
+        pts = [i for i in range(len(aus)) if bla == 16 or i not in drop]
+        d = orc.OracleDecoder()
+        got = []
+        for p, au in zip(pts, cut):
+            got += d.decode_au(au, pts=p)
+        got += d.flush()
+        d.close()
+        want = [(p, x) for p, x in full if p not in drop]
+        # (the sequence the BLA picture starts follows ALL of the one before it in output order: what was decoded before the cut precedes what came behind it)
+        want = [e for e in want if e[0] < k] + [e for e in want if e[0] >= k]
+        same([(f["pts"], f["i420"]) for f in got], want)
+
+
+@pytest.mark.parametrize("seed", (1, 4, 10))
+def test_an_end_of_sequence_nal_unit_makes_the_next_cra_picture_a_starting_point(seed):
+    aus = stream(seed)
+    types = [vcl_type(a) for a in aus]
+    full = oracle_pictures(aus)
+    for k in [i for i, t in enumerate(types) if t == 21][:3]:
+        drop = set(rasl_of(types, k))
+        got = oracle_pictures(aus[:k] + [EOS + aus[k]] + aus[k + 1:])
+        want = [(p, x) for p, x in full if p not in drop]
+        want = [e for e in want if e[0] < k] + [e for e in want if e[0] >= k]
+        same(got, want)
+
+
+@pytest.mark.parametrize("seed", (2, 3, 7))
+def test_pictures_with_pic_output_flag_zero_are_referenced_but_not_shown(seed):
+    shown = oracle_pictures(stream(seed, n=30, hidden_pics=35))
+    assert 10 < len(shown) < 30
+    # without reordering: the shown pictures are in decoding order, the others leave a gap in the time stamps
+    g = orc.OracleGen(64, 64, seed=seed, hidden_pics=35, intra_period=10)
+    aus = [g.picture() for _ in range(30)]
+    g.close()
+    low_delay = oracle_pictures(aus)
+    pts = [p for p, _ in low_delay]
+    assert pts == sorted(pts) and 10 < len(pts) < 30
+
+
+def python_pictures(aus):
+    d = pyhevc.Decoder(tabs())
+    for au in aus:
+        for nal in pyhevc.split_nals(au):
+            d.decode_nal(nal)
+    d.out.sort(key=lambda o: (o["cvs"], o["poc"]))
+    return d.out
+
+
+@pytest.mark.parametrize("seed,kw", [(1, {}), (2, {"hidden_pics": 30}), (3, {"wpp": 1, "slices": 1}), (6, {"tmvp": 1, "hidden_pics": 20})])
+def test_the_python_decoder_agrees(seed, kw):
+    aus = stream(seed, n=22, **kw)
+    types = [vcl_type(a) for a in aus]
+    k = next(i for i, t in enumerate(types) if t == 21)
+    cases = [aus, aus[k:], [rename(a, 21, 16) if i == k else a for i, a in enumerate(aus)], aus[:k] + [EOS + aus[k]] + aus[k + 1:]]
+    for c in cases:
+        want = [x for _, x in oracle_pictures(c)]
+        got = python_pictures(c)
+        assert len(want) == len(got) > 0
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b["i420"])

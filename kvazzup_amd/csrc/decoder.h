@@ -171,6 +171,7 @@ class Decoder {
   struct alignas(64) Progress { std::atomic<int> v{0}; char pad[60]; };   // one cache line per row: no false sharing between pollers
   struct SliceHdr {
     bool is_intra = false, is_b = false; int poc = 0;
+    bool no_output = false;                                              // pic_output_flag = 0: decoded and kept as a reference, never handed out
     int num_ref_idx1 = 0, mvd_l1_zero = 0, collocated_from_l0 = 1;      // B slices: num_ref_idx_l1_active, mvd_l1_zero_flag, collocated_from_l0_flag
     int tmvp = 0, collocated_ref_idx = 0, sao_luma = 0, sao_chroma = 0, num_ref_idx = 1, cabac_init_flag = 0, max_merge = 5;
     int slice_qp = 26, cb_qp_offset = 0, cr_qp_offset = 0;      // offsets: PPS + slice
@@ -373,6 +374,9 @@ class Decoder {
   bool spin_wait_ = false;                // KVAZZUP_AMD_SPIN: poll the GPU instead of napping between queries
   PicJob *gpu_job_ = nullptr;             // picture whose kernels are in flight (frame-threaded mode)
   int prev_poc_ = 0, cur_tid_ = 0; bool seen_irap_ = false;
+  bool after_eos_ = false;       // an end of sequence / end of bitstream NAL unit came: the next picture starts a coded video sequence (a CRA picture then has NoRaslOutputFlag = 1, 8.1.3)
+  bool cur_no_rasl_ = false;     // NoRaslOutputFlag of the picture whose slice headers are being read (decided with its first segment)
+  bool skip_rasl_ = false;       // NoRaslOutputFlag of the last IRAP picture: the RASL pictures that belong to it refer to pictures that are not there -- their NAL units are dropped
   bool download_ = true, profiling_ = false, prof_now_ = false; int prof_every_ = 1;
   bool pic_ready_ = false; DecodedPicture out_;
   int last_error_ = 0;

@@ -1675,10 +1675,10 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     p.valid = true; pps_[id] = p;
     return 0;
   }
-  if (nal_type == 36 || nal_type == 37) { int rc = finish_oldest(); if (rc < 0) last_error_ = rc; return rc; }   // EOS / EOB: drain one delayed picture
+  if (nal_type == 36 || nal_type == 37) { after_eos_ = true; int rc = finish_oldest(); if (rc < 0) last_error_ = rc; return rc; }   // EOS / EOB: drain one delayed picture; whatever picture follows starts a sequence
   if (nal_type == 40 && check_hash_) return hash_sei(rbsp_.data(), n);       // suffix SEI: decoded picture hash (libOpenHevcSetCheckMD5)
   if (nal_type > 31) return 0;                                    // AUD / other SEI / ...
-  if (!(nal_type <= 9 || (nal_type >= 19 && nal_type <= 21))) return last_error_ = DEC_ERR_UNSUPPORTED;      // (BLA pictures, reserved types)
+  if (!(nal_type <= 9 || (nal_type >= 16 && nal_type <= 21))) return last_error_ = DEC_ERR_UNSUPPORTED;      // (reserved types)
   int rc = decode_slice(rbsp_.data(), n, nal_type, pts);
   if (rc < 0) last_error_ = rc;
   return rc;
@@ -1818,7 +1818,13 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   // Supported: segments that arrive in order and consist of whole CTU rows (WPP) or whole tiles; independent slices repeat the first
   // one's header (the picture keeps one set of slice parameters).  The job is filled segment by segment and submitted with the last.
   const bool first_seg = r.get(1) != 0;
-  if (irap) r.get(1);
+  if (irap) r.get(1);                                            // no_output_of_prior_pics_flag (read, the pictures are handed out all the same)
+  if ((nal_type == 8 || nal_type == 9) && skip_rasl_) {
+    // a RASL picture of an IRAP picture that starts a coded video sequence (8.1.3: decoding began there, or a splicer called it BLA, or an end of sequence
+    // NAL unit precedes it): it predicts from pictures of the sequence before, which are not there -- not decoded, not output
+    if (first_seg && asm_active_) return close_open_picture();
+    return 0;
+  }
   const int pps_id = r.ue();
   if (pps_id < 0 || pps_id > 63 || !pps_[pps_id].valid || !sps_[pps_[pps_id].sps_id] || !sps_[pps_[pps_id].sps_id]->valid) return DEC_ERR_INVALID;
   const DecPps &p = pps_[pps_id]; const std::shared_ptr<const DecSps> sps_ref = sps_[p.sps_id]; const DecSps &s = *sps_ref;
@@ -1863,7 +1869,11 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   if (slice_type < 0 || slice_type > 2) return DEC_ERR_INVALID;
   SliceHdr sh;
   sh.is_intra = slice_type == 2; sh.is_b = slice_type == 0;
-  if (p.output_flag_present) r.get(1);
+  if (p.output_flag_present) sh.no_output = r.get(1) == 0;
+  // 8.1.3 NoRaslOutputFlag: an IDR or BLA picture, or a CRA picture that is the first one decoded or follows an end of sequence NAL unit, starts a coded video
+  // sequence -- POC MSBs from zero, no reference picture survives, its RASL pictures are dropped.  (first_seg: an open picture has been closed above, seen_irap_ is current.)
+  if (first_seg) { cur_no_rasl_ = irap && (idr || nal_type <= 18 || !seen_irap_ || after_eos_); if (irap) skip_rasl_ = cur_no_rasl_; after_eos_ = false; }
+  const bool no_rasl_out = cur_no_rasl_;
   StRps rps;
   int nlt = 0, lt_lsb[16] = {}, lt_cycle[16] = {}; bool lt_used[16] = {}, lt_msb[16] = {};
   if (!idr) {
@@ -1872,7 +1882,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
     int msb = prev_msb;
     if (lsb < prev_lsb && prev_lsb - lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
     else if (lsb > prev_lsb && lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
-    if (irap && !seen_irap_) msb = 0;
+    if (no_rasl_out) msb = 0;
     sh.poc = msb + lsb;
     if (r.get(1)) {
       int idx = 0, bits = 0; while ((1 << bits) < s.num_st_rps) bits++;
@@ -2005,7 +2015,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   if (p.cu_qp_delta && p.qp_delta_depth > s.ctb_log2 - s.min_cb_log2) return DEC_ERR_INVALID;      // (7.4.3.3.1: a quantisation group is no smaller than the minimum coding block)
   if (!ensure_buffers(s.width, s.height, s.ctb_log2)) return DEC_ERR_GPU;
   // ---- reference picture set (8.3.2) and RefPicList0 (8.3.4): pictures not in the set stop being references
-  if (idr) for (auto &d : dpb_) d.is_ref = false;
+  if (no_rasl_out) for (auto &d : dpb_) d.is_ref = false;         // (8.3.2; what a CRA or BLA picture's set names is for its RASL pictures)
   int nref = 0, ref_poc[16]; uint8_t ref_slot[16], ref_lt[16] = {};
   int nref1 = 0, ref_poc1[16]; uint8_t ref_slot1[16], ref_lt1[16] = {};
   bool no_backward = true;
@@ -2066,7 +2076,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   job.fps_num = s.fps_num ? s.fps_num : vps_fps_num_; job.fps_den = s.fps_num ? s.fps_den : vps_fps_den_;
   job.slot = slot; job.nref = nref;
   for (int k = 0; k < 16; k++) { job.ref_poc[k] = k < nref ? ref_poc[k] : sh.poc; job.ref_slot[k] = k < nref ? ref_slot[k] : 0; job.ref_lt[k] = k < nref ? ref_lt[k] : 0; job.ref_lt1[k] = k < nref1 ? ref_lt1[k] : 0; }
-  if (idr || (irap && !seen_irap_)) cvs_++;                     // a new coded video sequence: its pictures follow ALL of the last one's in output order
+  if (no_rasl_out) cvs_++;                     // a new coded video sequence: its pictures follow ALL of the last one's in output order
   job.cvs = cvs_;
   job.nref1 = nref1; job.no_backward = no_backward;
   for (int k = 0; k < 16; k++) { job.ref_poc1[k] = k < nref1 ? ref_poc1[k] : sh.poc; job.ref_slot1[k] = k < nref1 ? ref_slot1[k] : 0; }
@@ -2383,10 +2393,10 @@ int Decoder::finish_oldest()
     const int rc = complete_gpu(*j);
     tl("dcomplete", j->pts);
     if (rc < 0) return rc;
-    produced = 1;
+    produced = rc;
   }
   if (rc_launch < 0) return rc_launch;
-  if (frame_threads_ == 1 && !gpu_q_.empty()) { PicJob *j = gpu_q_.front(); gpu_q_.pop_front(); const int rc = complete_gpu(*j); if (rc < 0) return rc; produced = 1; }
+  if (frame_threads_ == 1 && !gpu_q_.empty()) { PicJob *j = gpu_q_.front(); gpu_q_.pop_front(); const int rc = complete_gpu(*j); if (rc < 0) return rc; produced |= rc; }
   return produced;
 }
 
@@ -2473,6 +2483,7 @@ int Decoder::complete_gpu(PicJob &job)
     for (size_t i = 0; i < job.ev_used; i++) { float ms = 0; hipEventElapsedTime(&ms, job.ev[i].a, job.ev[i].b); k_ms_[job.ev[i].id] += ms; k_n_[job.ev[i].id]++; }
     job.ev_used = 0;
   }
+  if (job.sh.no_output) { job.dl_buf = -1; return 0; }      // pic_output_flag = 0 (7.4.7.1): reconstructed -- later pictures predict from it -- and never handed out
   describe_output(job, out_, download_ ? job.dl_buf : -1);
   out_slot_ = job.slot;
   job.dl_buf = -1;

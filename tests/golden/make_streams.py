@@ -109,6 +109,11 @@ GEN = {
     # round 6: constrained intra prediction (intra blocks among inter ones take no reference samples from them)
     "gen_cip": dict(seed=67, density=25, intra_period=8, num_refs=2, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                     qp_delta=0, deblock_mode=0, intra_in_p=45, all_part_modes=1, nxn_intra=1, max_cu_log2=6, min_cu_log2=3, slices=0, big_mvd=0, cip=1),
+    # round 6: random access points that are no IDR pictures -- CRA pictures with RADL and RASL leading pictures, the parameter sets repeated there (a decoder may
+    # start at any of them and must drop the RASL pictures; tests cut this stream there), and pictures with pic_output_flag = 0
+    "gen_open_gop": dict(seed=74, density=20, intra_period=32, num_refs=3, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
+                         qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=0, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=60, gop=4,
+                         open_gop=1, hidden_pics=12),
     "gen_b_gop8": dict(seed=36, density=25, intra_period=16, num_refs=4, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                        qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=70, gop=8),
 }
@@ -118,7 +123,7 @@ for name, cfg in ({} if only else GEN).items():
     g = orc.OracleGen(W, H, **cfg)
     od = orc.OracleDecoder()
     stream, md5s = b"", []
-    npic = 12 if cfg.get("gop") or cfg.get("long_term") else 6
+    npic = 16 if cfg.get("open_gop") else 12 if cfg.get("gop") or cfg.get("long_term") else 6
     for t in range(npic):
         au = g.picture()
         stream += au
@@ -127,7 +132,7 @@ for name, cfg in ({} if only else GEN).items():
     for fr in od.flush():                                  # (pictures held back for reordering)
         md5s.append(hashlib.md5(fr["i420"].tobytes()).hexdigest())
     g.close(); od.close()
-    assert len(md5s) == npic, (name, len(md5s))
+    assert len(md5s) == npic or (cfg.get("hidden_pics") and npic - 6 < len(md5s) < npic), (name, len(md5s))      # (hidden_pics: some pictures are not output)
     open(os.path.join(out, name + ".hevc"), "wb").write(stream)
     index[name] = {"width": W, "height": H, "pictures": len(md5s), "bytes": len(stream), "hash_sei": None, "source": "oracle/hevc_gen.c (stream synthesiser), %s" % cfg, "frame_md5": md5s}
 json.dump(index, open(os.path.join(out, "index.json"), "w"), indent=1, sort_keys=True)

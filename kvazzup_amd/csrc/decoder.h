@@ -86,6 +86,7 @@ struct DecodedPicture {
   const uint8_t *dev[3] = {nullptr, nullptr, nullptr}; int dev_pitch[3] = {0, 0, 0};
   int poc = 0; int64_t pts = 0; uint32_t fps_num = 0, fps_den = 0; bool is_intra = false;
   int cvs = 0, num_reorder = 0;       // coded video sequence the picture belongs to (a running count); its SPS's sps_max_num_reorder_pics
+  uint64_t serial = 0;                // the picture's number in decoding order (Decoder::vwait_: which waiting pictures an IDR / BLA picture discards)
 };
 
 // a finished picture that owns its samples: what is still in the frame-threaded ring when the stream changes its resolution is
@@ -203,11 +204,13 @@ class Decoder {
     // some boundary inside the picture is closed to the in-loop filters (loop_filter_across_tiles_enabled_flag = 0 with tiles; a slice with
     // slice_loop_filter_across_slices_enabled_flag = 0): lf_slices = the picture's independent slices (first block, flag)
     bool lf_restricted = false; std::vector<std::pair<int, uint8_t>> lf_slices;
-    struct Undo { int poc = 0, prev_poc = 0; bool is_ref = false, used = false, seen_irap = false; long decode_idx = 0; std::shared_ptr<ColMotion> motion; } undo;      // what submit_job changed
+    struct Undo { int poc = 0, prev_poc = 0; bool is_ref = false, used = false, seen_irap = false; long decode_idx = 0; std::shared_ptr<ColMotion> motion; std::vector<std::pair<uint64_t, int>> vwait; } undo;      // what submit_job changed
     SliceHdr sh; std::shared_ptr<const DecSps> sps; DecPps pps;  // (a later SPS / PPS NAL may replace the table entry while this picture is still being parsed: the job keeps the SPS it was coded with alive, the PPS by value)
     int64_t pts = 0; int crop[4] = {0, 0, 0, 0}; uint32_t fps_num = 0, fps_den = 0;
     int slot = 0;                                                // picture buffer this picture is reconstructed into
     int cvs = 0;                                                 // the coded video sequence it belongs to (output order)
+    uint64_t serial = 0;                                         // number in decoding order
+    bool starts_cvs = false, discard_prior = false;              // NoRaslOutputFlag (8.1.3); ... and no_output_of_prior_pics_flag in force (C.5.2.2)
     int nref = 0; int ref_poc[16]; uint8_t ref_slot[16];        // RefPicList0
     int nref1 = 0; int ref_poc1[16]; uint8_t ref_slot1[16];     // RefPicList1 (B slices)
     uint8_t ref_lt[16] = {}, ref_lt1[16] = {};                  // the entry is a long-term reference picture (8.3.2: no vector scaling, 8.5.3.2.7 / 8.5.3.2.9)
@@ -375,6 +378,11 @@ class Decoder {
   PicJob *gpu_job_ = nullptr;             // picture whose kernels are in flight (frame-threaded mode)
   int prev_poc_ = 0, cur_tid_ = 0; bool seen_irap_ = false;
   bool after_eos_ = false;       // an end of sequence / end of bitstream NAL unit came: the next picture starts a coded video sequence (a CRA picture then has NoRaslOutputFlag = 1, 8.1.3)
+  // C.5.2.2's bookkeeping in DECODING order, kept at submit time: the pictures that are "needed for output" and have not had their turn -- (serial, POC).  The pictures
+  // themselves complete later (frame threads) and leave through reorder_q_ by the same counting rule; this list exists so that an IDR / BLA picture with
+  // no_output_of_prior_pics_flag discards exactly the pictures the standard's process would still hold at that instant, whatever the threads' timing.
+  std::vector<std::pair<uint64_t, int>> vwait_; std::vector<uint64_t> discarded_; uint64_t pic_serial_ = 0;
+  bool cur_discard_ = false;     // the picture whose headers are being read empties the buffer without output (decided with its first segment)
   bool cur_no_rasl_ = false;     // NoRaslOutputFlag of the picture whose slice headers are being read (decided with its first segment)
   bool skip_rasl_ = false;       // NoRaslOutputFlag of the last IRAP picture: the RASL pictures that belong to it refer to pictures that are not there -- their NAL units are dropped
   bool download_ = true, profiling_ = false, prof_now_ = false; int prof_every_ = 1;

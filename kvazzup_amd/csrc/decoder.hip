@@ -1675,7 +1675,7 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
     p.valid = true; pps_[id] = p;
     return 0;
   }
-  if (nal_type == 36 || nal_type == 37) { after_eos_ = true; int rc = finish_oldest(); if (rc < 0) last_error_ = rc; return rc; }   // EOS / EOB: drain one delayed picture; whatever picture follows starts a sequence
+  if (nal_type == 36 || nal_type == 37) { after_eos_ = true; vwait_.clear(); int rc = finish_oldest(); if (rc < 0) last_error_ = rc; return rc; }   // EOS / EOB: drain one delayed picture; whatever picture follows starts a sequence
   if (nal_type == 40 && check_hash_) return hash_sei(rbsp_.data(), n);       // suffix SEI: decoded picture hash (libOpenHevcSetCheckMD5)
   if (nal_type > 31) return 0;                                    // AUD / other SEI / ...
   if (!(nal_type <= 9 || (nal_type >= 16 && nal_type <= 21))) return last_error_ = DEC_ERR_UNSUPPORTED;      // (reserved types)
@@ -1818,7 +1818,7 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   // Supported: segments that arrive in order and consist of whole CTU rows (WPP) or whole tiles; independent slices repeat the first
   // one's header (the picture keeps one set of slice parameters).  The job is filled segment by segment and submitted with the last.
   const bool first_seg = r.get(1) != 0;
-  if (irap) r.get(1);                                            // no_output_of_prior_pics_flag (read, the pictures are handed out all the same)
+  const bool prior_flag = irap && r.get(1) != 0;                 // no_output_of_prior_pics_flag
   if ((nal_type == 8 || nal_type == 9) && skip_rasl_) {
     // a RASL picture of an IRAP picture that starts a coded video sequence (8.1.3: decoding began there, or a splicer called it BLA, or an end of sequence
     // NAL unit precedes it): it predicts from pictures of the sequence before, which are not there -- not decoded, not output
@@ -1872,7 +1872,13 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   if (p.output_flag_present) sh.no_output = r.get(1) == 0;
   // 8.1.3 NoRaslOutputFlag: an IDR or BLA picture, or a CRA picture that is the first one decoded or follows an end of sequence NAL unit, starts a coded video
   // sequence -- POC MSBs from zero, no reference picture survives, its RASL pictures are dropped.  (first_seg: an open picture has been closed above, seen_irap_ is current.)
-  if (first_seg) { cur_no_rasl_ = irap && (idr || nal_type <= 18 || !seen_irap_ || after_eos_); if (irap) skip_rasl_ = cur_no_rasl_; after_eos_ = false; }
+  if (first_seg) {
+    cur_no_rasl_ = irap && (idr || nal_type <= 18 || !seen_irap_ || after_eos_); if (irap) skip_rasl_ = cur_no_rasl_;
+    // C.5.2.2: an IDR or BLA picture that is not the first one empties the buffer WITHOUT output when its flag says so (a CRA picture gets here behind an end of
+    // sequence NAL unit only, which has put out everything already)
+    cur_discard_ = cur_no_rasl_ && prior_flag && nal_type != 21 && seen_irap_ && !after_eos_;
+    after_eos_ = false;
+  }
   const bool no_rasl_out = cur_no_rasl_;
   StRps rps;
   int nlt = 0, lt_lsb[16] = {}, lt_cycle[16] = {}; bool lt_used[16] = {}, lt_msb[16] = {};
@@ -2076,7 +2082,8 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   job.fps_num = s.fps_num ? s.fps_num : vps_fps_num_; job.fps_den = s.fps_num ? s.fps_den : vps_fps_den_;
   job.slot = slot; job.nref = nref;
   for (int k = 0; k < 16; k++) { job.ref_poc[k] = k < nref ? ref_poc[k] : sh.poc; job.ref_slot[k] = k < nref ? ref_slot[k] : 0; job.ref_lt[k] = k < nref ? ref_lt[k] : 0; job.ref_lt1[k] = k < nref1 ? ref_lt1[k] : 0; }
-  if (no_rasl_out) cvs_++;                     // a new coded video sequence: its pictures follow ALL of the last one's in output order
+  if (no_rasl_out) cvs_++;
+  job.starts_cvs = no_rasl_out; job.discard_prior = cur_discard_;                     // a new coded video sequence: its pictures follow ALL of the last one's in output order
   job.cvs = cvs_;
   job.nref1 = nref1; job.no_backward = no_backward;
   for (int k = 0; k < 16; k++) { job.ref_poc1[k] = k < nref1 ? ref_poc1[k] : sh.poc; job.ref_slot1[k] = k < nref1 ? ref_slot1[k] : 0; }
@@ -2264,6 +2271,7 @@ void Decoder::take_back_job(PicJob &job)
 {
   DpbPic &d = dpb_[job.slot];
   d.poc = job.undo.poc; d.is_ref = job.undo.is_ref; d.used = job.undo.used; d.decode_idx = job.undo.decode_idx; d.motion = job.undo.motion; prev_poc_ = job.undo.prev_poc; seen_irap_ = job.undo.seen_irap;
+  vwait_ = std::move(job.undo.vwait);
   job.undo.motion.reset();
   job_head_--; job.state.store(0, std::memory_order_relaxed); job.rc = 0; job.early_dst = nullptr;
   asm_active_ = true; asm_free_ = free_stream_ = true;
@@ -2294,6 +2302,24 @@ int Decoder::submit_job(PicJob &job, int nal_type, bool irap)
   d.poc = sh.poc; d.is_ref = true; d.used = true; d.is_lt = false; d.decode_idx = job_head_; d.motion = job.own;
   if (cur_tid_ == 0 && (nal_type > 9 || ((nal_type & 1) && nal_type < 6))) prev_poc_ = sh.poc;   // prevTid0Pic (8.3.1): TemporalId 0, not RASL / RADL / sub-layer non-reference
   if (irap) seen_irap_ = true;
+  {
+    // output bookkeeping in decoding order (C.5.2.2, C.5.2.3; Decoder::vwait_)
+    job.undo.vwait = vwait_; job.serial = ++pic_serial_;
+    const int nr = job.sps->num_reorder;
+    auto bump = [&] { size_t b = 0; for (size_t i = 1; i < vwait_.size(); i++) if (vwait_[i].second < vwait_[b].second) b = i; vwait_.erase(vwait_.begin() + (long)b); };
+    if (job.starts_cvs) {
+      if (job.discard_prior && !vwait_.empty()) {
+        for (const auto &v : vwait_) discarded_.push_back(v.first);
+        for (size_t i = 0; i < reorder_q_.size();) {             // (the ones that have completed wait here; the others find their number in discarded_ when they complete)
+          if (std::find(discarded_.begin(), discarded_.end(), reorder_q_[i].pic.pic.serial) != discarded_.end()) { owned_release(reorder_q_[i].pic.dev); reorder_q_.erase(reorder_q_.begin() + (long)i); }
+          else i++;
+        }
+        if (discarded_.size() > 64) discarded_.erase(discarded_.begin(), discarded_.end() - 64);
+      }
+      vwait_.clear();
+    } else while ((int)vwait_.size() > nr) bump();
+    if (!sh.no_output) { vwait_.emplace_back(job.serial, sh.poc); while ((int)vwait_.size() > nr) bump(); }
+  }
   job_head_++;
   if (parse_only_) {
     auto t0 = std::chrono::steady_clock::now();
@@ -2409,7 +2435,7 @@ void Decoder::describe_output(const PicJob &job, DecodedPicture &o, int buf) con
   o = DecodedPicture();
   o.coded_w = w_; o.coded_h = h_;
   o.width = w_ - job.crop[0] - job.crop[1]; o.height = h_ - job.crop[2] - job.crop[3];
-  o.poc = job.sh.poc; o.pts = job.pts; o.is_intra = job.sh.is_intra; o.cvs = job.cvs; o.num_reorder = job.sps->num_reorder;
+  o.poc = job.sh.poc; o.pts = job.pts; o.is_intra = job.sh.is_intra; o.cvs = job.cvs; o.num_reorder = job.sps->num_reorder; o.serial = job.serial;
   o.fps_num = job.fps_num; o.fps_den = job.fps_den;
   for (int c = 0; c < 3; c++) {
     const int pw = c ? pw_ / 2 : pw_, ox = c ? job.crop[0] / 2 : job.crop[0], oy = c ? job.crop[2] / 2 : job.crop[2];
@@ -2484,6 +2510,7 @@ int Decoder::complete_gpu(PicJob &job)
     job.ev_used = 0;
   }
   if (job.sh.no_output) { job.dl_buf = -1; return 0; }      // pic_output_flag = 0 (7.4.7.1): reconstructed -- later pictures predict from it -- and never handed out
+  if (!discarded_.empty() && std::find(discarded_.begin(), discarded_.end(), job.serial) != discarded_.end()) { job.dl_buf = -1; return 0; }      // (an IDR / BLA picture behind it said so: C.5.2.2)
   describe_output(job, out_, download_ ? job.dl_buf : -1);
   out_slot_ = job.slot;
   job.dl_buf = -1;

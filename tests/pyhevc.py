@@ -248,7 +248,9 @@ def parse_sps(rbsp):
     s["poc_bits"] = r.ue() + 4
     present = r.u(1)
     for _ in range(0 if present else max_sub, max_sub + 1):
-        r.ue(); r.ue(); r.ue()
+        r.ue()
+        s["reorder"] = r.ue()                # sps_max_num_reorder_pics of the highest sub-layer: how many pictures may wait for their turn (C.5.2)
+        r.ue()
     s["min_cb"] = r.ue() + 3
     s["ctb"] = s["min_cb"] + r.ue()
     s["min_tb"] = r.ue() + 2
@@ -546,14 +548,25 @@ class Decoder:
         self.after_eos = False  # an end of sequence NAL unit came: the next picture starts a coded video sequence
         self.skip_rasl = False  # NoRaslOutputFlag of the last IRAP picture (8.1.3): its RASL pictures are dropped
         self.skipping = False   # inside a dropped picture: its further slice segments go the same way
+        self.waiting = []       # decoded pictures that wait for their turn in output order (C.5.2.2 "needed for output")
         self.trace = None       # optional list: ("cu", x, y, log2, pred_mode, part), ("tu", cidx, x, y, log2, [levels...]) ...
 
     # ------------------------------------------------------------------------------------------- NAL level
     def decode(self, stream):
-        """the pictures in OUTPUT order (C.5.2): coded video sequence after coded video sequence, by picture order count inside one"""
+        """feeds the NAL units of `stream`; self.out collects the pictures in OUTPUT order (C.5.2: a picture leaves when more pictures wait than may overtake it, when a
+        new coded video sequence begins, or with flush())"""
         for nal in split_nals(stream):
             self.decode_nal(nal)
-        self.out.sort(key=lambda o: (o["cvs"], o["poc"]))       # (stable; a stream without reordering is in this order already)
+        return self.out                                            # (what has had its turn so far; flush() at the end of the stream)
+
+    def bump(self):
+        """C.5.2.4: the waiting picture with the smallest picture order count is output"""
+        k = min(range(len(self.waiting)), key=lambda i: self.waiting[i]["poc"])
+        self.out.append(self.waiting.pop(k))
+
+    def flush(self):
+        while self.waiting:
+            self.bump()
         return self.out
 
     def decode_nal(self, nal):
@@ -566,6 +579,7 @@ class Decoder:
             self.pps[p["id"]] = p
         elif t in (36, 37):
             self.after_eos = True
+            self.flush()                                           # (the sequence is over: nothing waits for pictures that will not come)
         elif t <= 21 and (t <= 9 or t >= 16):
             self.decode_slice(nal, t)
 
@@ -577,7 +591,7 @@ class Decoder:
         idr = nal_type in (19, 20)
         first = r.u(1)
         if irap:
-            r.u(1)
+            no_prior = r.u(1)                                      # no_output_of_prior_pics_flag
         pps = self.pps[r.ue()]
         sps = self.sps[pps["sps"]]
         dependent, address = 0, 0
@@ -587,6 +601,8 @@ class Decoder:
             self.no_rasl_out = idr or nal_type in (16, 17, 18) or (irap and (self.cvs == 0 or self.after_eos))
             if irap:
                 self.skip_rasl = self.no_rasl_out
+                # C.5.2.2: an IDR or BLA picture with no_output_of_prior_pics_flag empties the buffer WITHOUT output of what still waits; otherwise what waits goes first
+                self.drop_prior = bool(no_prior) and nal_type != 21 and self.cvs > 0 and not self.after_eos
             self.skipping = (nal_type in (8, 9) and self.skip_rasl) or (self.cvs == 0 and not irap)
         if self.skipping:
             return
@@ -808,6 +824,12 @@ class Decoder:
                 [c1[le[1][i] if le[1] else i % len(c1)] for i in range(sh["nref1"])] if sh["nref1"] else []]
         if self.no_rasl_out and 16 <= nal_type <= 23:
             self.cvs += 1
+            if self.drop_prior:
+                self.waiting = []
+            self.flush()
+        else:
+            while len(self.waiting) > sps["reorder"]:              # C.5.2.2: room for the current picture
+                self.bump()
         self.after_eos = False
         pic = Picture(sps["w"], sps["h"])
         pic.poc = poc
@@ -836,8 +858,10 @@ class Decoder:
         v = pic.planes[2][ct // 2:(sps["h"] - cb) // 2, cl // 2:(sps["w"] - cr_) // 2]
         if not sl.sh["shown"]:
             return                                                     # pic_output_flag = 0: decoded, kept as a reference, never handed out
-        self.out.append({"poc": poc, "cvs": self.cvs, "i420": np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)]).astype(np.uint8),
+        self.waiting.append({"poc": poc, "cvs": self.cvs, "i420": np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)]).astype(np.uint8),
                          "width": y.shape[1], "height": y.shape[0]})
+        while len(self.waiting) > sps["reorder"]:                  # C.5.2.3: more pictures wait than may overtake one
+            self.bump()
 
 
 class SliceDecoder:

@@ -127,3 +127,22 @@ def test_random_streams_with_random_access_points(gpu, seed):
     for k in cras[:2]:
         both(aus[k:], range(k, len(aus)), threads, threads > 1)
         both([rename(a, 21, 16) if i == k else a for i, a in enumerate(aus)], range(len(aus)), threads, threads > 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 3, 8])
+@pytest.mark.parametrize("seed", range(1, 9))
+def test_no_output_of_prior_pics_flag(gpu, seed, threads):
+    """C.5.2.2: IDR pictures (and a CRA picture called BLA) whose flag says that what still waits for its turn is not to be shown -- exactly the pictures the standard's
+    process holds at that instant disappear, whatever the frame threads' timing"""
+    from test_random_access import discard_prior
+    g = orc.OracleGen(416, 240, seed=seed, gop=(2, 4, 8)[seed % 3], open_gop=seed & 1, intra_period=7 + seed % 4, b_slices=50, num_refs=1 + seed % 4, tmvp=1,
+                      hidden_pics=(0, 10)[seed % 2], slices=(0, 1, 3)[seed % 3])
+    aus = [g.picture() for _ in range(32)]
+    g.close()
+    types = [vcl_type(a) for a in aus]
+    cras = [i for i, t in enumerate(types) if t == 21]
+    plain = both(aus, range(len(aus)), threads, threads > 1)
+    cut = [discard_prior(rename(a, 21, 16)) if cras and i == cras[-1] else discard_prior(a) for i, a in enumerate(aus)]
+    shown = both(cut, range(len(aus)), threads, threads > 1)
+    assert len(shown) < len(plain)

@@ -49,7 +49,7 @@ def decode_both(aus):
     pd = pyhevc.Decoder(tabs())
     for au in aus:
         pd.decode(au)
-    return want, pd.out
+    return want, pd.flush()
 
 
 def compare(aus):

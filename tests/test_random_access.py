@@ -150,8 +150,7 @@ def python_pictures(aus):
     for au in aus:
         for nal in pyhevc.split_nals(au):
             d.decode_nal(nal)
-    d.out.sort(key=lambda o: (o["cvs"], o["poc"]))
-    return d.out
+    return d.flush()
 
 
 @pytest.mark.parametrize("seed,kw", [(1, {}), (2, {"hidden_pics": 30}), (3, {"wpp": 1, "slices": 1}), (6, {"tmvp": 1, "hidden_pics": 20})])
@@ -166,3 +165,60 @@ def test_the_python_decoder_agrees(seed, kw):
         assert len(want) == len(got) > 0
         for a, b in zip(want, got):
             assert np.array_equal(a, b["i420"])
+
+
+def discard_prior(au):
+    """the access unit with no_output_of_prior_pics_flag = 1 in its IDR / BLA slice NAL units (the second bit of the slice segment header)"""
+    out = bytearray()
+    for n in orc.split_nals(au):
+        n = bytearray(n)
+        i = 0
+        while n[i] == 0:
+            i += 1
+        if 16 <= (n[i + 1] >> 1) & 63 <= 20:
+            n[i + 3] |= 0x40
+        out += n
+    return bytes(out)
+
+
+@pytest.mark.parametrize("seed", (1, 2, 3, 4, 5, 6))
+def test_no_output_of_prior_pics_flag_discards_what_still_waits(seed):
+    """C.5.2.2: an IDR or BLA picture with the flag empties the buffer without output -- the pictures of the sequence before that had not had their turn yet (at most
+    sps_max_num_reorder_pics of them, the last ones in output order) are never seen; a CRA picture ignores the flag"""
+    aus = stream(seed, n=30, intra_period=7 + seed % 3, open_gop=seed & 1)
+    types = [vcl_type(a) for a in aus]
+    idrs = [i for i, t in enumerate(types) if t == 19 and i > 0]
+    assert idrs
+    full = oracle_pictures(aus)
+    got = oracle_pictures([discard_prior(a) for a in aus])
+    kept = [p for p, _ in got]
+    assert len(kept) < len(full) and [p for p, _ in full if p in kept] == kept            # (the same order, some pictures missing)
+    lg = {2: 1, 4: 2, 8: 3}[(2, 4, 8)[seed % 3]]
+    for a, b in zip([0] + idrs, idrs + [len(aus)]):
+        lost = [p for p, _ in full if a <= p < b and p not in kept]
+        assert len(lost) <= (lg if b < len(aus) else 0)                                   # (nothing is lost at the end of the stream)
+        tail = [p for p, _ in full if a <= p < b][len([p for p, _ in full if a <= p < b]) - len(lost):]
+        assert lost == tail                                                               # (the sequence's last pictures in output order)
+    same(got, [e for e in full if e[0] in kept])
+    want = [x for _, x in got]
+    py = python_pictures([discard_prior(a) for a in aus])
+    assert len(py) == len(want)
+    for x, y in zip(want, py):
+        assert np.array_equal(x, y["i420"])
+
+
+@pytest.mark.parametrize("seed", (1, 2, 3, 6))
+def test_a_bla_picture_with_no_output_of_prior_pics_flag(seed):
+    aus = stream(seed, n=30)
+    types = [vcl_type(a) for a in aus]
+    for k in [i for i, t in enumerate(types) if t == 21][1:3]:
+        cut = [discard_prior(rename(a, 21, 16)) if i == k else a for i, a in enumerate(aus)]
+        plain = oracle_pictures([rename(a, 21, 16) if i == k else a for i, a in enumerate(aus)])
+        got = oracle_pictures(cut)
+        kept = [p for p, _ in got]
+        assert [p for p, _ in plain if p in kept] == kept and all(p < k for p, _ in plain if p not in kept)
+        same(got, [e for e in plain if e[0] in kept])
+        py = python_pictures(cut)
+        assert len(py) == len(got)
+        for (_, x), y in zip(got, py):
+            assert np.array_equal(x, y["i420"])

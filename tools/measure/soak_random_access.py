@@ -7,7 +7,7 @@ R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import orc
 from test_gpu_everything import drawn
 from test_gpu_random_access import both
-from test_random_access import EOS, rename, vcl_type
+from test_random_access import EOS, discard_prior, rename, vcl_type
 a, b = int(sys.argv[1]) if len(sys.argv) > 1 else 1, int(sys.argv[2]) if len(sys.argv) > 2 else 300
 bad, cuts = [], 0
 for seed in range(a, b + 1):
@@ -23,11 +23,18 @@ for seed in range(a, b + 1):
     th = 1 + 2 * (seed % 3)
     try:
         both(aus, range(len(aus)), th, th > 1)
+        if seed % 4 == 0:
+            kw2 = dict(kw, intra_period=7 + seed % 5)
+            g = orc.OracleGen(w, h, seed=seed, **kw2)
+            short = [discard_prior(g.picture()) for _ in range(20)]      # (IDR pictures in the middle of groups, no_output_of_prior_pics_flag = 1)
+            g.close()
+            both(short, range(len(short)), th, th > 1)
         for k in cras[:1]:
             cuts += 1
             both(aus[k:], range(k, len(aus)), th, th > 1)
             both([rename(x, 21, 16) if i == k else x for i, x in enumerate(aus)], range(len(aus)), th, th > 1)
             both(aus[:k] + [EOS + aus[k]] + aus[k + 1:], range(len(aus)), th, th > 1)
+            both([discard_prior(rename(x, 21, 16)) if i == k else x for i, x in enumerate(aus)], range(len(aus)), th, th > 1)
     except BaseException as e:      # (pytest.fail raises an outcome exception)
         bad.append(seed); print("seed", seed, (w, h), kw, cras, str(e)[:300], flush=True)
 print("%d streams (%d with a CRA picture: cut, renamed, behind an end of sequence), %d differ %s" % (b - a + 1, cuts, len(bad), bad))

@@ -15,7 +15,9 @@
 // overrides, SAO, WPP, tile grids up to the level limit of 20 columns x 22 rows (uniform or
 // explicit spacing; in-loop filtering across tile and slice boundaries on or off -- Kvazaar switches it off), pictures in several slice segments: the two ways Kvazaar cuts them (a dependent slice segment per CTU row with WPP, an
 // independent slice per tile) and -- one-tile pictures -- segments that begin at ANY coding tree block, independent slices (own SliceQpY) and dependent
-// segments mixed (an MTU per slice, N row groups: PicJob::ctb_cut).  Rejected with a negative return value (kvzx_decoder_last_error): several slices
+// segments mixed (an MTU per slice, N row groups: PicJob::ctb_cut).  Random access (8.1.3, C.5.2.2): decoding may begin at a CRA picture -- its RASL pictures are
+// dropped, its RADL pictures decoded --, BLA pictures and end of sequence NAL units start a coded video sequence, pic_output_flag = 0 keeps a picture in,
+// no_output_of_prior_pics_flag discards what still waits (Decoder::vwait_).  Rejected with a negative return value (kvzx_decoder_last_error): several slices
 // inside a tile of a picture with tiles, slices of one picture that differ in more than SliceQpY and the loop filter flag,
 // > 255 slices in a picture.
 #pragma once

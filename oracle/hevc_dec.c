@@ -28,6 +28,7 @@ struct orc_decoder {
   int nal_type;
   int prev_tid0_poc;
   int seen_irap;
+  int tid;                                /* TemporalId of the NAL unit at hand */
   int after_eos;                          /* an end of sequence NAL unit came: the next picture starts a coded video sequence (a CRA picture then has NoRaslOutputFlag = 1) */
   int skip_rasl;                          /* NoRaslOutputFlag of the last IRAP picture: its RASL pictures are not decoded (8.1.3) */
   orc_pic *ref_list0[16]; int ref_poc[16]; int num_ref;
@@ -802,8 +803,8 @@ static int start_picture(orc_decoder *d)
     d->cvs++;
   }
   d->seen_irap = 1; d->after_eos = 0;
-  /* prevTidOPic (8.3.1): TemporalId 0 (all there is here) and no RASL, RADL or sub-layer non-reference picture */
-  if (d->nal_type >= NAL_BLA_W_LP || ((d->nal_type & 1) && d->nal_type < NAL_RADL_N)) d->prev_tid0_poc = poc;
+  /* prevTid0Pic (8.3.1): TemporalId 0 and no RASL, RADL or sub-layer non-reference picture */
+  if (d->tid == 0 && (d->nal_type >= NAL_BLA_W_LP || ((d->nal_type & 1) && d->nal_type < NAL_RADL_N))) d->prev_tid0_poc = poc;
   d->cur = alloc_pic(d, s->width, s->height);
   if (!d->cur) return ERR_INVALID;
   d->cur->poc = poc; d->cur->pts = d->cur_pts;
@@ -1046,6 +1047,7 @@ int orc_dec_decode_nal(orc_decoder *d, const uint8_t *data, size_t len, int64_t 
   int nal_type = (data[0] >> 1) & 0x3f;
   int layer = ((data[0] & 1) << 5) | (data[1] >> 3);
   if (layer != 0) return 0;
+  d->tid = (data[1] & 7) - 1;
   if (len > d->rbsp_cap) { d->rbsp = (uint8_t *)realloc(d->rbsp, len); d->rbsp_cap = len; }
   size_t rlen = orc_unescape(data + 2, len - 2, d->rbsp, NULL, 0, NULL);
   orc_bitr br; orc_br_init(&br, d->rbsp, rlen);

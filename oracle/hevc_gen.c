@@ -31,6 +31,7 @@ struct orc_gen {
   orc_cabac_enc c;
   orc_bitw au;
   int frame_idx, poc, since_idr;
+  int hist_tid[8], layers, cur_tid;   /* temporal_layers: TemporalId of the pictures in hist_poc; number of sub-layers (0: off); the current picture's */
   int hist_cls[8];                    /* open_gop: 1 = decoded before the last CRA picture, or a RASL picture -- nothing a RADL picture may use */
   int cra_poc, cra_split, cur_nal;    /* open_gop: POC of the last CRA picture (-1: none since the IDR), the POC below which its leading pictures are RASL; the picture's NAL unit type */
   int hist_poc[8], hist_n;            /* POCs of the pictures decoded since the IDR, newest first (the reference picture set is the first num_refs of them) */
@@ -193,6 +194,12 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   if (c->pcm < 0) c->pcm = 0;
   if (c->long_term < 0 || c->gop || c->b_slices > 0) c->long_term = 0;
   if (c->open_gop != 1 || !c->gop) c->open_gop = 0;
+  if (c->temporal_layers != 1 || !c->gop) c->temporal_layers = 0;
+  if (c->temporal_layers) {
+    int lg = 0; while ((1 << lg) < c->gop) lg++;
+    g->layers = lg + 1; s->max_sub_layers = lg + 1;
+    s->sl_ordering_absent = rpct(g, 50); s->sl_present = (int)(rnd(g) & 0x3fffu);
+  }
   if (c->hidden_pics < 0) c->hidden_pics = 0;
   p->output_flag_present = c->hidden_pics > 0;
   p->entropy_coding_sync_enabled = c->wpp; p->loop_filter_across_slices = c->lf_across == 0 ? 1 : (c->lf_across == 2 ? 0 : rpct(g, 70));
@@ -783,7 +790,7 @@ static void write_free_slices(orc_gen *g, int nal)
     orc_bw_init(&hdr);
     orc_write_slice_header(&hdr, sh, s, p, nal);
     for (int i = 0; i < n; i++) { orc_bw_bytes(&hdr, subs[s0 + i].buf, subs[s0 + i].len); orc_bw_free(&subs[s0 + i]); }
-    orc_write_nal(&g->au, nal, 0, hdr.buf, hdr.len, 1);
+    orc_write_nal(&g->au, nal, g->cur_tid, hdr.buf, hdr.len, 1);
     orc_bw_free(&hdr); free(ep);
   }
   sh->slice_qp_delta = qpd0; sh->slice_qp = p->init_qp + qpd0;
@@ -797,7 +804,7 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
   orc_bitw ps, hdr, *subs;
   const orc_sps *s = &g->sps; orc_pps *p = &g->pps; orc_slice_hdr *sh = &g->sh;
   const int wc = s->pic_w_ctbs, hc = s->pic_h_ctbs;
-  const int nal = g->cur_nal, cra = nal == NAL_CRA, radl = nal == NAL_RADL_R;
+  const int nal = g->cur_nal, cra = nal == NAL_CRA, radl = nal == NAL_RADL_R || nal == NAL_RADL_N;
   g->au.len = 0; g->au.nbits = 0; g->au.cur = 0;
   if (write_ps) {
     orc_bw_init(&ps); orc_write_vps(&ps, &g->vps, &g->sps); orc_write_nal(&g->au, NAL_VPS, 0, ps.buf, ps.len, 1); orc_bw_free(&ps);
@@ -850,7 +857,12 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
     const int nh = ORC_MIN(g->cfg.num_refs, g->hist_n);
     int neg[8], pos[8], nn = 0, np = 0, nbad[8], pbad[8];
     int has_cra = 0;
-    for (int i = 0; i < nh; i++) { if (g->hist_poc[i] < g->poc) { nbad[nn] = g->hist_cls[i]; neg[nn++] = g->hist_poc[i]; } else { pbad[np] = g->hist_cls[i]; pos[np++] = g->hist_poc[i]; } has_cra |= g->hist_poc[i] == g->cra_poc; }
+    /* "bad": not to be predicted from -- for a RADL picture what came before its CRA picture and RASL pictures; with sub-layers what has a higher TemporalId */
+    for (int i = 0; i < nh; i++) {
+      const int bad = (radl && g->hist_cls[i]) || (g->layers && g->hist_tid[i] > g->cur_tid);
+      if (g->hist_poc[i] < g->poc) { nbad[nn] = bad; neg[nn++] = g->hist_poc[i]; } else { pbad[np] = bad; pos[np++] = g->hist_poc[i]; }
+      has_cra |= g->hist_poc[i] == g->cra_poc;
+    }
     if (g->cra_poc >= 0 && g->poc < g->cra_poc && !has_cra) { pbad[np] = 0; pos[np++] = g->cra_poc; }      /* a leading picture keeps its CRA picture: all that the trailing pictures may start from */
     for (int i = 1; i < nn; i++) for (int j = i; j > 0 && neg[j] > neg[j - 1]; j--) { int t = neg[j]; neg[j] = neg[j - 1]; neg[j - 1] = t; t = nbad[j]; nbad[j] = nbad[j - 1]; nbad[j - 1] = t; }
     for (int i = 1; i < np; i++) for (int j = i; j > 0 && pos[j] < pos[j - 1]; j--) { int t = pos[j]; pos[j] = pos[j - 1]; pos[j - 1] = t; t = pbad[j]; pbad[j] = pbad[j - 1]; pbad[j - 1] = t; }
@@ -859,8 +871,9 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
     int used = 0;
     for (int i = 0; i < nn; i++) { sh->st_rps.delta_poc_s0[i] = neg[i] - g->poc; sh->st_rps.used_s0[i] = rpct(g, 85); used += sh->st_rps.used_s0[i]; }
     for (int i = 0; i < np; i++) { sh->st_rps.delta_poc_s1[i] = pos[i] - g->poc; sh->st_rps.used_s1[i] = rpct(g, 85); used += sh->st_rps.used_s1[i]; }
-    if (radl) {
-      /* a RADL picture predicts from its CRA picture and other RADL pictures only (the rest of the set stays, unused: RASL pictures that follow may need it) */
+    if (radl || g->layers) {
+      /* a RADL picture predicts from its CRA picture and other RADL pictures only (the rest of the set stays, unused: RASL pictures that follow may need it);
+       * no picture predicts from a higher sub-layer */
       int ok = -1; used = 0;
       for (int i = 0; i < nn; i++) { if (nbad[i]) sh->st_rps.used_s0[i] = 0; else if (ok < 0) ok = i; used += sh->st_rps.used_s0[i]; }
       for (int i = 0; i < np; i++) { if (pbad[i]) sh->st_rps.used_s1[i] = 0; else if (ok < 0) ok = 8 + i; used += sh->st_rps.used_s1[i]; }
@@ -981,7 +994,7 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
     orc_bw_init(&hdr);
     orc_write_slice_header(&hdr, sh, s, p, nal);
     for (int i = 0; i < n; i++) { orc_bw_bytes(&hdr, subs[s0 + i].buf, subs[s0 + i].len); orc_bw_free(&subs[s0 + i]); }
-    orc_write_nal(&g->au, nal, 0, hdr.buf, hdr.len, 1);
+    orc_write_nal(&g->au, nal, g->cur_tid, hdr.buf, hdr.len, 1);
     orc_bw_free(&hdr); free(ep);
   }
   free(subs); free(seg_first); free(seg_addr);
@@ -1006,16 +1019,28 @@ size_t orc_gen_picture(orc_gen *g, const uint8_t **au)
     /* 8.3.2: a trailing picture of a CRA picture, and the next CRA picture too, have nothing in their sets that precedes that CRA picture in decoding or
      * output order -- those pictures leave for good */
     int n = 0;
-    for (int i = 0; i < g->hist_n; i++) if (g->hist_poc[i] >= g->cra_poc) { g->hist_poc[n] = g->hist_poc[i]; g->hist_cls[n] = g->hist_cls[i]; n++; }
+    for (int i = 0; i < g->hist_n; i++) if (g->hist_poc[i] >= g->cra_poc) { g->hist_poc[n] = g->hist_poc[i]; g->hist_cls[n] = g->hist_cls[i]; g->hist_tid[n] = g->hist_tid[i]; n++; }
     g->hist_n = n;
   }
   if (cra) {
     g->cur_nal = NAL_CRA; g->cra_poc = g->poc; g->cra_split = g->poc - g->cfg.gop + 1 + rrange(g, 0, g->cfg.gop - 1);
     for (int i = 0; i < g->hist_n; i++) g->hist_cls[i] = 1;
   } else if (!idr && g->cra_poc >= 0 && g->poc < g->cra_poc) g->cur_nal = g->poc < g->cra_split ? NAL_RASL_R : NAL_RADL_R;
+  /* temporal_layers: a picture's place in its group is its sub-layer (the group's last picture 0, the middle one 1, ...); the top layer's pictures are predicted from
+   * by nobody -- sub-layer non-reference pictures (the _N types), which never enter the reference picture sets */
+  g->cur_tid = 0;
+  int leaf = 0;
+  if (g->layers && !idr) {
+    const int o = (g->since_idr - 1) % g->cfg.gop, off = g->gop_order[o] % g->cfg.gop;
+    if (off) { int z = 0; while (!((off >> z) & 1)) z++; g->cur_tid = g->layers - 1 - z; }
+    leaf = g->cur_tid == g->layers - 1;
+    if (leaf) g->cur_nal -= 1;                                   /* TRAIL_R -> TRAIL_N, RASL_R -> RASL_N, RADL_R -> RADL_N */
+  }
   write_picture(g, idr, idr || cra);
-  for (int i = ORC_MIN(g->hist_n, 7); i > 0; i--) { g->hist_poc[i] = g->hist_poc[i - 1]; g->hist_cls[i] = g->hist_cls[i - 1]; }
-  g->hist_poc[0] = g->poc; g->hist_cls[0] = g->cur_nal == NAL_RASL_R; if (g->hist_n < 8) g->hist_n++;
+  if (!leaf) {
+    for (int i = ORC_MIN(g->hist_n, 7); i > 0; i--) { g->hist_poc[i] = g->hist_poc[i - 1]; g->hist_cls[i] = g->hist_cls[i - 1]; g->hist_tid[i] = g->hist_tid[i - 1]; }
+    g->hist_poc[0] = g->poc; g->hist_cls[0] = g->cur_nal == NAL_RASL_R; g->hist_tid[0] = g->cur_tid; if (g->hist_n < 8) g->hist_n++;
+  }
   g->frame_idx++;
   *au = g->au.buf;
   return g->au.len;

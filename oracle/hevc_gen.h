@@ -71,6 +71,9 @@ typedef struct {
   int open_gop;               /* 1 (with gop > 1): groups that start with a CRA picture instead of following an IDR picture's lead -- their other pictures are RASL / RADL leading
                                * pictures, the parameter sets are repeated: a decoder may start there (RASL pictures dropped), a splicer may call the picture BLA -- 0 (also -1): off */
   int hidden_pics;            /* probability (%) of pic_output_flag = 0 (a picture that is decoded and referenced but never handed out); > 0 sets output_flag_present_flag -- 0 (also -1): off */
+  int temporal_layers;        /* 1 (with gop > 1): the hierarchy's levels are temporal sub-layers -- TemporalId in the NAL unit headers, sps / vps_max_sub_layers_minus1 > 0 with drawn
+                               * sub_layer_profile / level_present flags and ordering info for every sub-layer or the highest only, the top layer's pictures sub-layer non-reference
+                               * pictures (TRAIL_N, RASL_N, RADL_N), no picture predicts from a higher sub-layer: what Kvazaar's gop=8 sends -- 0 (also -1): off */
 } orc_gen_config;
 
 void orc_gen_default_config(orc_gen_config *c);    /* everything random, 416x240 */

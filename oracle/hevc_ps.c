@@ -2,20 +2,42 @@
 #include "hevc_ps.h"
 
 /* ------------------------------------------------------------------ writer */
-static void write_ptl(orc_bitw *w, int profile_idc, int level_idc)
+static void write_ptl_general(orc_bitw *w, int profile_idc)
 {
-  /* 7.3.3 profile_tier_level(1, 0) */
-  orc_bw_put(w, 0, 2);                 /* general_profile_space */
-  orc_bw_put(w, 0, 1);                 /* general_tier_flag */
+  orc_bw_put(w, 0, 2);                 /* profile_space */
+  orc_bw_put(w, 0, 1);                 /* tier_flag */
   orc_bw_put(w, (uint32_t)profile_idc, 5);
   for (int j = 0; j < 32; j++) orc_bw_put(w, (j == profile_idc || (profile_idc == 1 && j == 2)) ? 1 : 0, 1);
-  orc_bw_put(w, 1, 1);                 /* general_progressive_source_flag */
-  orc_bw_put(w, 0, 1);                 /* general_interlaced_source_flag */
-  orc_bw_put(w, 0, 1);                 /* general_non_packed_constraint_flag */
-  orc_bw_put(w, 1, 1);                 /* general_frame_only_constraint_flag */
+  orc_bw_put(w, 1, 1);                 /* progressive_source_flag */
+  orc_bw_put(w, 0, 1);                 /* interlaced_source_flag */
+  orc_bw_put(w, 0, 1);                 /* non_packed_constraint_flag */
+  orc_bw_put(w, 1, 1);                 /* frame_only_constraint_flag */
   orc_bw_put(w, 0, 32); orc_bw_put(w, 0, 11);   /* 43 reserved zero bits */
-  orc_bw_put(w, 0, 1);                 /* general_inbld_flag / reserved */
+  orc_bw_put(w, 0, 1);                 /* inbld_flag / reserved */
+}
+static void write_ptl(orc_bitw *w, int profile_idc, int level_idc, int max_sub_layers_minus1, int sl_present)
+{
+  /* 7.3.3 profile_tier_level(1, maxNumSubLayersMinus1) */
+  write_ptl_general(w, profile_idc);
   orc_bw_put(w, (uint32_t)level_idc, 8);
+  for (int i = 0; i < max_sub_layers_minus1; i++) orc_bw_put(w, (uint32_t)(sl_present >> (2 * i)) & 3u, 2);      /* sub_layer_profile_present_flag, sub_layer_level_present_flag */
+  if (max_sub_layers_minus1 > 0) for (int i = max_sub_layers_minus1; i < 8; i++) orc_bw_put(w, 0, 2);
+  for (int i = 0; i < max_sub_layers_minus1; i++) {
+    if ((sl_present >> (2 * i)) & 2) write_ptl_general(w, profile_idc);
+    if ((sl_present >> (2 * i)) & 1) orc_bw_put(w, (uint32_t)level_idc, 8);
+  }
+}
+/* sub_layer_ordering_info: every sub-layer's values (non-decreasing, the highest one's are the stream's) or the highest one's only */
+static void write_ordering_info(orc_bitw *w, const orc_sps *s)
+{
+  const int n = s->max_sub_layers > 1 ? s->max_sub_layers : 1;
+  orc_bw_put(w, s->sl_ordering_absent ? 0 : 1, 1);
+  for (int i = s->sl_ordering_absent ? n - 1 : 0; i < n; i++) {
+    const int less = n - 1 - i;
+    orc_bw_ue(w, (uint32_t)(s->max_dec_pic_buffering - less > 1 ? s->max_dec_pic_buffering - less : 1) - 1);
+    orc_bw_ue(w, (uint32_t)(s->max_num_reorder - less > 0 ? s->max_num_reorder - less : 0));
+    orc_bw_ue(w, (uint32_t)s->max_latency_increase_plus1);
+  }
 }
 
 void orc_write_vps(orc_bitw *w, const orc_vps *v, const orc_sps *s)
@@ -23,14 +45,12 @@ void orc_write_vps(orc_bitw *w, const orc_vps *v, const orc_sps *s)
   orc_bw_put(w, (uint32_t)v->vps_id, 4);
   orc_bw_put(w, 3, 2);                 /* vps_base_layer_internal_flag, vps_base_layer_available_flag */
   orc_bw_put(w, 0, 6);                 /* vps_max_layers_minus1 */
-  orc_bw_put(w, 0, 3);                 /* vps_max_sub_layers_minus1 */
-  orc_bw_put(w, 1, 1);                 /* vps_temporal_id_nesting_flag */
+  const int msl = s->max_sub_layers > 1 ? s->max_sub_layers - 1 : 0;
+  orc_bw_put(w, (uint32_t)msl, 3);     /* vps_max_sub_layers_minus1 */
+  orc_bw_put(w, msl ? 0 : 1, 1);       /* vps_temporal_id_nesting_flag */
   orc_bw_put(w, 0xffff, 16);
-  write_ptl(w, s->general_profile_idc, s->general_level_idc);
-  orc_bw_put(w, 1, 1);                 /* vps_sub_layer_ordering_info_present_flag */
-  orc_bw_ue(w, (uint32_t)s->max_dec_pic_buffering - 1);
-  orc_bw_ue(w, (uint32_t)s->max_num_reorder);
-  orc_bw_ue(w, (uint32_t)s->max_latency_increase_plus1);
+  write_ptl(w, s->general_profile_idc, s->general_level_idc, msl, s->sl_present);
+  write_ordering_info(w, s);           /* vps_sub_layer_ordering_info_present_flag ... */
   orc_bw_put(w, 0, 6);                 /* vps_max_layer_id */
   orc_bw_ue(w, 0);                     /* vps_num_layer_sets_minus1 */
   orc_bw_put(w, (uint32_t)v->timing_info_present, 1);
@@ -66,9 +86,10 @@ static void write_st_rps(orc_bitw *w, const orc_st_rps *r, int idx)
 void orc_write_sps(orc_bitw *w, const orc_sps *s)
 {
   orc_bw_put(w, (uint32_t)s->vps_id, 4);
-  orc_bw_put(w, 0, 3);                 /* sps_max_sub_layers_minus1 */
-  orc_bw_put(w, 1, 1);                 /* sps_temporal_id_nesting_flag */
-  write_ptl(w, s->general_profile_idc, s->general_level_idc);
+  const int msl = s->max_sub_layers > 1 ? s->max_sub_layers - 1 : 0;
+  orc_bw_put(w, (uint32_t)msl, 3);     /* sps_max_sub_layers_minus1 */
+  orc_bw_put(w, msl ? 0 : 1, 1);       /* sps_temporal_id_nesting_flag */
+  write_ptl(w, s->general_profile_idc, s->general_level_idc, msl, s->sl_present);
   orc_bw_ue(w, (uint32_t)s->sps_id);
   orc_bw_ue(w, (uint32_t)s->chroma_format_idc);
   orc_bw_ue(w, (uint32_t)s->width);
@@ -81,10 +102,7 @@ void orc_write_sps(orc_bitw *w, const orc_sps *s)
   orc_bw_ue(w, (uint32_t)s->bit_depth_luma - 8);
   orc_bw_ue(w, (uint32_t)s->bit_depth_chroma - 8);
   orc_bw_ue(w, (uint32_t)s->log2_max_poc_lsb - 4);
-  orc_bw_put(w, 1, 1);                 /* sps_sub_layer_ordering_info_present_flag */
-  orc_bw_ue(w, (uint32_t)s->max_dec_pic_buffering - 1);
-  orc_bw_ue(w, (uint32_t)s->max_num_reorder);
-  orc_bw_ue(w, (uint32_t)s->max_latency_increase_plus1);
+  write_ordering_info(w, s);           /* sps_sub_layer_ordering_info_present_flag ... */
   orc_bw_ue(w, (uint32_t)s->log2_min_cb - 3);
   orc_bw_ue(w, (uint32_t)s->log2_diff_max_min_cb);
   orc_bw_ue(w, (uint32_t)s->log2_min_tb - 2);

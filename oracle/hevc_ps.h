@@ -26,6 +26,8 @@ typedef struct {
 typedef struct {
   int valid;
   int sps_id, vps_id, max_sub_layers;
+  int sl_ordering_absent;                  /* writer: sps/vps_sub_layer_ordering_info_present_flag = 0 (only the highest sub-layer's values are sent) */
+  int sl_present;                          /* writer: bit 2i / 2i+1 = sub_layer_profile_present_flag[i] / sub_layer_level_present_flag[i] */
   int general_profile_idc, general_level_idc;
   int chroma_format_idc;
   int width, height;                       /* pic_width/height_in_luma_samples */

@@ -114,6 +114,10 @@ GEN = {
     "gen_open_gop": dict(seed=74, density=20, intra_period=32, num_refs=3, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                          qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=0, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=60, gop=4,
                          open_gop=1, hidden_pics=12),
+    # round 6: temporal sub-layers (TemporalId 0 .. 3 over a group of eight, parameter sets with sub-layer syntax, sub-layer non-reference pictures): what Kvazaar's gop=8 sends
+    "gen_sub_layers": dict(seed=81, density=20, intra_period=32, num_refs=3, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
+                           qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=0, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=60, gop=8,
+                           temporal_layers=1),
     "gen_b_gop8": dict(seed=36, density=25, intra_period=16, num_refs=4, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                        qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=70, gop=8),
 }

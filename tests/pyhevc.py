@@ -581,6 +581,7 @@ class Decoder:
             self.after_eos = True
             self.flush()                                           # (the sequence is over: nothing waits for pictures that will not come)
         elif t <= 21 and (t <= 9 or t >= 16):
+            self.tid = (nal[1] & 7) - 1
             self.decode_slice(nal, t)
 
     def decode_slice(self, nal, nal_type):
@@ -850,8 +851,8 @@ class Decoder:
         self.cur = None
         pic, poc = sl.pic, sl.sh["poc"]
         self.dpb.append(pic)
-        if not (nal_type <= 14 and (nal_type & 1) == 0) and not (6 <= nal_type <= 9):
-            self.prev_poc_tid0 = poc           # TemporalId 0 assumed; RASL / RADL / sub-layer non-reference pictures excluded
+        if self.tid == 0 and not (nal_type <= 14 and (nal_type & 1) == 0) and not (6 <= nal_type <= 9):
+            self.prev_poc_tid0 = poc           # prevTid0Pic (8.3.1): TemporalId 0; RASL / RADL / sub-layer non-reference pictures excluded
         cl, cr_, ct, cb = sps["crop"]
         y = pic.planes[0][ct:sps["h"] - cb, cl:sps["w"] - cr_]
         u = pic.planes[1][ct // 2:(sps["h"] - cb) // 2, cl // 2:(sps["w"] - cr_) // 2]

@@ -146,3 +146,19 @@ def test_no_output_of_prior_pics_flag(gpu, seed, threads):
     cut = [discard_prior(rename(a, 21, 16)) if cras and i == cras[-1] else discard_prior(a) for i, a in enumerate(aus)]
     shown = both(cut, range(len(aus)), threads, threads > 1)
     assert len(shown) < len(plain)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("seed", range(1, 9))
+def test_temporal_sub_layers(gpu, seed, threads):
+    """TemporalId in the NAL unit headers, parameter sets with sub-layers, sub-layer non-reference pictures (what Kvazaar's gop=8 sends) -- the whole stream, and the
+    stream a middlebox has thinned to its lower sub-layers"""
+    from test_random_access import layered, tid_of
+    aus = layered(seed, n=28, w=416, h=240, slices=(0, 1, 3)[seed % 3], hidden_pics=(0, 10)[seed & 1])
+    tids = [tid_of(a) for a in aus]
+    both(aus, range(len(aus)), threads, threads > 1)
+    for keep in range(max(tids)):
+        k = [i for i in range(len(aus)) if tids[i] <= keep]
+        shown = both([aus[i] for i in k], k, threads, threads > 1)
+        assert shown and set(shown) <= set(k)

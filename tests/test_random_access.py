@@ -222,3 +222,65 @@ def test_a_bla_picture_with_no_output_of_prior_pics_flag(seed):
         assert len(py) == len(got)
         for (_, x), y in zip(got, py):
             assert np.array_equal(x, y["i420"])
+
+
+def tid_of(au):
+    """TemporalId of the access unit's slice NAL units"""
+    for n in orc.split_nals(au):
+        i = 0
+        while n[i] == 0:
+            i += 1
+        if (n[i + 1] >> 1) & 63 < 32:
+            return (n[i + 2] & 7) - 1
+    raise ValueError("no slice")
+
+
+def layered(seed, n=26, w=64, h=64, **kw):
+    cfg = dict(gop=(2, 4, 8)[seed % 3], temporal_layers=1, open_gop=seed & 1, intra_period=24, b_slices=50, num_refs=1 + seed % 4, tmvp=1)
+    cfg.update(kw)
+    g = orc.OracleGen(w, h, seed=seed, **cfg)
+    aus = [g.picture() for _ in range(n)]
+    g.close()
+    return aus
+
+
+@pytest.mark.parametrize("seed", range(1, 9))
+def test_temporal_sub_layers(seed):
+    """TemporalId in the NAL unit headers, parameter sets with sub-layers (profile_tier_level's sub-layer part, ordering info for all sub-layers or the highest),
+    sub-layer non-reference pictures: both decoders agree; and -- the point of sub-layers -- the stream without its upper layers, from any layer up, decodes to the
+    same pictures minus the ones taken out (8.3.1: the picture order count follows the TemporalId 0 pictures alone)"""
+    aus = layered(seed)
+    tids = [tid_of(a) for a in aus]
+    top = max(tids)
+    assert top == {2: 1, 4: 2, 8: 3}[(2, 4, 8)[seed % 3]] and tids[0] == 0
+    full = oracle_pictures(aus)
+    assert len(full) == len(aus)
+    py = python_pictures(aus)
+    for (_, x), y in zip(full, py):
+        assert np.array_equal(x, y["i420"])
+    for keep in range(top):                      # sub-layers 0 .. keep stay
+        d = orc.OracleDecoder()
+        got = []
+        for k, au in enumerate(aus):
+            if tids[k] <= keep:
+                got += d.decode_au(au, pts=k)
+        got += d.flush()
+        d.close()
+        same([(f["pts"], f["i420"]) for f in got], [e for e in full if tids[e[0]] <= keep])
+    thin = python_pictures([a for k, a in enumerate(aus) if tids[k] < top])
+    want = [x for p, x in full if tids[p] < top]
+    assert len(thin) == len(want)
+    for x, y in zip(want, thin):
+        assert np.array_equal(x, y["i420"])
+
+
+def test_the_products_parser_reads_sub_layer_syntax():
+    """(CPU: the host half alone through the parse-only hook -- every picture parsed, with and without the upper sub-layers)"""
+    import parser_probe as PP
+    for seed in (1, 2, 3):
+        aus = layered(seed, w=128, h=64)
+        tids = [tid_of(a) for a in aus]
+        for keep in range(max(tids) + 1):
+            nals = [n for k, a in enumerate(aus) if tids[k] <= keep for n in orc.split_nals(a)]
+            for threads in (0, 3):
+                assert PP.probe(nals, threads)["pictures"] == sum(t <= keep for t in tids)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/measure/soak_random_access.py [first seed] [last seed]: streams with CRA / RASL / RADL pictures and hidden pictures on top of tests/test_gpu_everything.py's
+"""tools/measure/soak_random_access.py [first seed] [last seed]: streams with CRA / RASL / RADL pictures, hidden pictures and (every other pair of seeds) temporal sub-layers on top of tests/test_gpu_everything.py's
 draw of every other option, read whole, from their first CRA picture on, with that picture called BLA and with an end of sequence NAL unit before it (GPU box);
 prints the seeds where the HIP decoder and the checker disagree."""
 import os, sys
@@ -14,7 +14,7 @@ for seed in range(a, b + 1):
     w, h, kw = drawn(seed)
     for k in ("long_term", "gop", "b_slices", "intra_period"):
         kw.pop(k, None)
-    kw.update(gop=(2, 4, 8)[seed % 3], open_gop=1, b_slices=(0, 50)[seed & 1], intra_period=48, hidden_pics=(0, 0, 12)[seed % 3], tmvp=1)
+    kw.update(gop=(2, 4, 8)[seed % 3], open_gop=1, b_slices=(0, 50)[seed & 1], intra_period=48, hidden_pics=(0, 0, 12)[seed % 3], tmvp=1, temporal_layers=(seed >> 1) & 1)
     g = orc.OracleGen(w, h, seed=seed, **kw)
     aus = [g.picture() for _ in range(20)]
     g.close()

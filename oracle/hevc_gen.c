@@ -179,6 +179,16 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   orc_sps_derive(s);
   orc_vps *v = &g->vps; memset(v, 0, sizeof(*v));
   v->timing_info_present = 1; v->num_units_in_tick = 1; v->time_scale = 30;
+  if (c->vui_extras != 1) c->vui_extras = 0;
+  if (c->vui_extras) {
+    s->vui_extras = (int)(rnd(g) & 0x3ffu);
+    switch (rrange(g, 0, 3)) {          /* where the picture rate is said */
+      case 0: v->timing_info_present = 0; s->vui_time_scale = 25; break;                              /* the VUI alone */
+      case 1: s->vui_timing_present = 0; v->time_scale = 24; break;                                    /* the VPS alone (a VUI without timing) */
+      case 2: v->time_scale = 50; s->vui_time_scale = 60000; s->vui_num_units_in_tick = 1001; break;   /* both, and they differ: the VUI's counts */
+      default: s->vui_present = 0; v->timing_info_present = 0; break;                                  /* nowhere */
+    }
+  }
   orc_pps *p = &g->pps; memset(p, 0, sizeof(*p));
   p->sign_data_hiding = c->sign_hiding; p->cabac_init_present = c->cabac_init; if (c->cip != 1) c->cip = 0; p->constrained_intra_pred = c->cip;
   p->num_ref_idx_l0_default = rrange(g, 1, c->num_refs); p->num_ref_idx_l1_default = 1; p->init_qp = cfg->qp;

@@ -74,6 +74,9 @@ typedef struct {
   int temporal_layers;        /* 1 (with gop > 1): the hierarchy's levels are temporal sub-layers -- TemporalId in the NAL unit headers, sps / vps_max_sub_layers_minus1 > 0 with drawn
                                * sub_layer_profile / level_present flags and ordering info for every sub-layer or the highest only, the top layer's pictures sub-layer non-reference
                                * pictures (TRAIL_N, RASL_N, RADL_N), no picture predicts from a higher sub-layer: what Kvazaar's gop=8 sends -- 0 (also -1): off */
+  int vui_extras;             /* 1: the VUI's optional parts drawn (extended aspect ratio, overscan, video signal type with colour description, chroma sample location, default
+                               * display window, POC-proportional timing, bitstream restriction -- what x265 writes by default), and the timing information in the VUI, in the
+                               * VPS alone, in both (different rates: the VUI's counts) or nowhere -- 0 (also -1): timing in the VUI only */
 } orc_gen_config;
 
 void orc_gen_default_config(orc_gen_config *c);    /* everything random, 416x240 */

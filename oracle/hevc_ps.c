@@ -133,23 +133,31 @@ void orc_write_sps(orc_bitw *w, const orc_sps *s)
   orc_bw_put(w, (uint32_t)s->strong_intra_smoothing, 1);
   orc_bw_put(w, (uint32_t)s->vui_present, 1);
   if (s->vui_present) {
-    /* E.2.1 vui_parameters(): only timing info is signalled */
-    orc_bw_put(w, 0, 1);   /* aspect_ratio_info_present_flag */
-    orc_bw_put(w, 0, 1);   /* overscan_info_present_flag */
-    orc_bw_put(w, 0, 1);   /* video_signal_type_present_flag */
-    orc_bw_put(w, 0, 1);   /* chroma_loc_info_present_flag */
-    orc_bw_put(w, 0, 1);   /* neutral_chroma_indication_flag */
-    orc_bw_put(w, 0, 1);   /* field_seq_flag */
-    orc_bw_put(w, 0, 1);   /* frame_field_info_present_flag */
-    orc_bw_put(w, 0, 1);   /* default_display_window_flag */
+    /* E.2.1 vui_parameters(): the timing info is what a decoder here uses; the optional parts (vui_extras) are there to be skipped correctly */
+    const int x = s->vui_extras;
+    orc_bw_put(w, x & 1, 1);           /* aspect_ratio_info_present_flag */
+    if (x & 1) { orc_bw_put(w, 255, 8); orc_bw_put(w, 40, 16); orc_bw_put(w, 33, 16); }      /* EXTENDED_SAR */
+    orc_bw_put(w, (x >> 1) & 1, 1);    /* overscan_info_present_flag */
+    if (x & 2) orc_bw_put(w, 1, 1);
+    orc_bw_put(w, (x >> 2) & 1, 1);    /* video_signal_type_present_flag */
+    if (x & 4) { orc_bw_put(w, 5, 3); orc_bw_put(w, 1, 1); orc_bw_put(w, 1, 1); orc_bw_put(w, 1, 8); orc_bw_put(w, 13, 8); orc_bw_put(w, 1, 8); }
+    orc_bw_put(w, (x >> 3) & 1, 1);    /* chroma_loc_info_present_flag */
+    if (x & 8) { orc_bw_ue(w, 2); orc_bw_ue(w, 3); }
+    orc_bw_put(w, (x >> 7) & 1, 1);    /* neutral_chroma_indication_flag */
+    orc_bw_put(w, 0, 1);               /* field_seq_flag */
+    orc_bw_put(w, (x >> 9) & 1, 1);    /* frame_field_info_present_flag */
+    orc_bw_put(w, (x >> 4) & 1, 1);    /* default_display_window_flag */
+    if (x & 16) { orc_bw_ue(w, 1); orc_bw_ue(w, 2); orc_bw_ue(w, 0); orc_bw_ue(w, 3); }
     orc_bw_put(w, (uint32_t)s->vui_timing_present, 1);
     if (s->vui_timing_present) {
       orc_bw_put(w, s->vui_num_units_in_tick, 32);
       orc_bw_put(w, s->vui_time_scale, 32);
-      orc_bw_put(w, 0, 1); /* vui_poc_proportional_to_timing_flag */
-      orc_bw_put(w, 0, 1); /* vui_hrd_parameters_present_flag */
+      orc_bw_put(w, (x >> 6) & 1, 1);  /* vui_poc_proportional_to_timing_flag */
+      if (x & 64) orc_bw_ue(w, 0);     /* vui_num_ticks_poc_diff_one_minus1 */
+      orc_bw_put(w, 0, 1);             /* vui_hrd_parameters_present_flag */
     }
-    orc_bw_put(w, 0, 1);   /* bitstream_restriction_flag */
+    orc_bw_put(w, (x >> 5) & 1, 1);    /* bitstream_restriction_flag */
+    if (x & 32) { orc_bw_put(w, 0, 1); orc_bw_put(w, 1, 1); orc_bw_put(w, 0, 1); orc_bw_ue(w, 0); orc_bw_ue(w, 2); orc_bw_ue(w, 1); orc_bw_ue(w, 15); orc_bw_ue(w, 15); }
   }
   orc_bw_put(w, 0, 1);                 /* sps_extension_present_flag */
   orc_bw_trailing(w);

@@ -47,6 +47,8 @@ typedef struct {
   int num_lt_sps; int lt_poc_lsb_sps[32]; uint8_t lt_used_sps[32];      /* num_long_term_ref_pics_sps candidates: lt_ref_pic_poc_lsb_sps, used_by_curr_pic_lt_sps_flag */
   int temporal_mvp_enabled, strong_intra_smoothing;
   int vui_present, vui_timing_present; uint32_t vui_num_units_in_tick, vui_time_scale;
+  int vui_extras;                          /* writer: bits 0..5 = aspect ratio (extended SAR), overscan, video signal type with colour description, chroma sample location,
+                                            * default display window, bitstream restriction; bit 6 = vui_poc_proportional_to_timing_flag; bits 7..9 = the three single flags */
   /* derived */
   int ctb_log2, ctb_size, pic_w_ctbs, pic_h_ctbs, log2_max_tb;
 } orc_sps;

@@ -162,3 +162,29 @@ def test_temporal_sub_layers(gpu, seed, threads):
         k = [i for i in range(len(aus)) if tids[i] <= keep]
         shown = both([aus[i] for i in k], k, threads, threads > 1)
         assert shown and set(shown) <= set(k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(1, 13))
+def test_optional_vui_parts_and_where_the_picture_rate_is_said(gpu, seed):
+    """x265 fills the VUI (aspect ratio, video signal type, bitstream restriction ...); the picture rate may be in the VUI, in the VPS, in both or nowhere: the rate
+    libOpenHevcGetPictureInfo reports (OpenHEVCFilter takes it for the frame's rate, openhevcfilter.cpp:183-200) is the checker's"""
+    from kvazzup_amd.codec import Decoder
+    g = orc.OracleGen(208, 144, seed=seed, vui_extras=1, intra_period=4, temporal_layers=seed & 1, gop=(0, 4)[seed & 1])
+    aus = [g.picture() for _ in range(6)]
+    g.close()
+    od, gd = orc.OracleDecoder(), Decoder()
+    want, got = [], []
+    try:
+        for t, au in enumerate(aus):
+            want += od.decode_au(au, t)
+            got += gd.decode_au(au, t)
+        want += od.flush()
+        got += gd.drain()
+    finally:
+        gd.close()
+        od.close()
+    assert len(got) == len(want) == 6
+    for a, b in zip(got, want):
+        assert np.array_equal(a["i420"], b["i420"])
+        assert tuple(a["fps"]) == tuple(b["fps"]) or (b["fps"] == (0, 0) and a["fps"][0] == 0), (a["fps"], b["fps"])

@@ -284,3 +284,25 @@ def test_the_products_parser_reads_sub_layer_syntax():
             nals = [n for k, a in enumerate(aus) if tids[k] <= keep for n in orc.split_nals(a)]
             for threads in (0, 3):
                 assert PP.probe(nals, threads)["pictures"] == sum(t <= keep for t in tids)
+
+
+@pytest.mark.parametrize("seed", range(1, 9))
+def test_optional_vui_parts_and_where_the_picture_rate_is_said(seed):
+    """the VUI's optional parts in front of the timing information (extended aspect ratio, overscan, video signal type, chroma location, default display window), POC
+    proportional timing and the bitstream restriction behind it; the rate in the VUI, the VPS, both or nowhere: the decoders skip what they do not use and agree"""
+    g = orc.OracleGen(64, 64, seed=seed, vui_extras=1, intra_period=4, temporal_layers=seed & 1, gop=(0, 4)[seed & 1])
+    aus = [g.picture() for _ in range(6)]
+    g.close()
+    d = orc.OracleDecoder()
+    fr = []
+    for a in aus:
+        fr += d.decode_au(a)
+    fr += d.flush()
+    d.close()
+    assert len(fr) == 6 and len({f["fps"] for f in fr}) == 1
+    py = python_pictures(aus)
+    assert len(py) == 6
+    for a, b in zip(fr, py):
+        assert np.array_equal(a["i420"], b["i420"])
+    import parser_probe as PP
+    assert PP.probe([n for a in aus for n in orc.split_nals(a)], 0)["pictures"] == 6

@@ -92,6 +92,7 @@ static void gen_scaling(orc_gen *g, orc_scaling_lists *sl, uint8_t pred_mode[4][
     }
 }
 
+static void gen_sps_rps(orc_gen *g, orc_sps *s);
 orc_gen *orc_gen_open(const orc_gen_config *cfg)
 {
   if (cfg->width < 16 || cfg->height < 16 || (cfg->width & 7) || (cfg->height & 7)) return NULL;
@@ -170,6 +171,8 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   s->scaling_list_enabled = c->scaling_lists > 0; s->scaling_list_data_present = c->scaling_lists == 2 || c->scaling_lists == 4;
   if (s->scaling_list_data_present) gen_scaling(g, &s->scaling, s->sl_pred_mode, s->sl_pred_delta);
   s->num_st_rps = 0;
+  if (c->rps_forms != 1) c->rps_forms = 0;
+  if (c->rps_forms) gen_sps_rps(g, s);
   if (c->long_term > 0) {                                   /* candidates in the SPS: POC LSB 0 (the sequence's first picture), used by the current picture or only kept */
     s->long_term_ref_pics_present = 1; s->num_lt_sps = rrange(g, 0, 2);
     for (int i = 0; i < s->num_lt_sps; i++) { s->lt_poc_lsb_sps[i] = 0; s->lt_used_sps[i] = (uint8_t)(i == 0); }
@@ -808,6 +811,81 @@ static void write_free_slices(orc_gen *g, int nal)
   sh->entry_point_offset = NULL;
 }
 
+/* ------------------------------------------------------------------ reference picture sets by prediction (7.3.7, 7.4.8)
+ * `t` holds a set in its explicit form (nearest first on either side); can it be derived from `ref` moved by d?  Every entry of t must be an entry of ref plus d, or d
+ * itself; the flags say which of those are taken and which of the taken ones the picture uses.  On success the coded form is filled in. */
+static int rps_try_inter(orc_st_rps *t, const orc_st_rps *ref, int d)
+{
+  const int nd = ref->num_negative + ref->num_positive;
+  int hit = 0;
+  if (d == 0 || d < -32768 || d > 32768) return 0;
+  for (int j = 0; j <= nd; j++) {
+    const int e = (j < ref->num_negative ? ref->delta_poc_s0[j] : j < nd ? ref->delta_poc_s1[j - ref->num_negative] : 0) + d;
+    t->used_flag[j] = 0; t->use_delta[j] = 0;
+    for (int i = 0; i < t->num_negative; i++) if (t->delta_poc_s0[i] == e) { t->used_flag[j] = (uint8_t)t->used_s0[i]; t->use_delta[j] = 1; hit++; }
+    for (int i = 0; i < t->num_positive; i++) if (t->delta_poc_s1[i] == e) { t->used_flag[j] = (uint8_t)t->used_s1[i]; t->use_delta[j] = 1; hit++; }
+  }
+  if (hit != t->num_negative + t->num_positive) return 0;
+  t->inter = 1; t->delta_rps = d; t->nflags = nd + 1;
+  return 1;
+}
+static int rps_same(const orc_st_rps *a, const orc_st_rps *b)
+{
+  if (a->num_negative != b->num_negative || a->num_positive != b->num_positive) return 0;
+  for (int i = 0; i < a->num_negative; i++) if (a->delta_poc_s0[i] != b->delta_poc_s0[i] || a->used_s0[i] != b->used_s0[i]) return 0;
+  for (int i = 0; i < a->num_positive; i++) if (a->delta_poc_s1[i] != b->delta_poc_s1[i] || a->used_s1[i] != b->used_s1[i]) return 0;
+  return 1;
+}
+/* the candidate sets of the SPS: the first one explicit, the others explicit or predicted from the one before (in the SPS that is the only choice) */
+static void gen_sps_rps(orc_gen *g, orc_sps *s)
+{
+  const int n = rrange(g, 2, 6);
+  memset(s->st_rps, 0, sizeof(s->st_rps[0]) * (size_t)n);
+  s->st_rps[0].num_negative = 1; s->st_rps[0].delta_poc_s0[0] = -1; s->st_rps[0].used_s0[0] = 1;
+  for (int k = 1; k < n; k++) {
+    orc_st_rps *t = &s->st_rps[k]; const orc_st_rps *ref = &s->st_rps[k - 1];
+    if (rpct(g, 65)) {
+      /* predicted: the entries of the set before moved by d, and d itself, some of them dropped */
+      static const int ds[6] = { -1, -1, -2, 1, 2, -4 };
+      const int d = ds[rrange(g, 0, 5)], nd = ref->num_negative + ref->num_positive;
+      int val[17], m = 0;
+      for (int j = 0; j <= nd; j++) {
+        const int e = (j < ref->num_negative ? ref->delta_poc_s0[j] : j < nd ? ref->delta_poc_s1[j - ref->num_negative] : 0) + d;
+        if (e != 0 && (rpct(g, 80) || (j == nd && m == 0))) val[m++] = e;
+      }
+      for (int i = 1; i < m; i++) for (int j = i; j > 0 && val[j] > val[j - 1]; j--) { const int x = val[j]; val[j] = val[j - 1]; val[j - 1] = x; }      /* descending */
+      for (int i = 0; i < m; i++) if (val[i] < 0) { t->delta_poc_s0[t->num_negative] = val[i]; t->used_s0[t->num_negative++] = rpct(g, 85); }
+      for (int i = m - 1; i >= 0; i--) if (val[i] > 0) { t->delta_poc_s1[t->num_positive] = val[i]; t->used_s1[t->num_positive++] = rpct(g, 85); }
+      if (t->num_negative + t->num_positive > 0 && t->num_negative + t->num_positive <= 6 && rps_try_inter(t, ref, d)) continue;
+      memset(t, 0, sizeof(*t));
+    }
+    t->num_negative = rrange(g, 1, 3); t->num_positive = rrange(g, 0, 2);
+    for (int i = 0, at = 0; i < t->num_negative; i++) { at -= rrange(g, 1, 3); t->delta_poc_s0[i] = at; t->used_s0[i] = rpct(g, 85); }
+    for (int i = 0, at = 0; i < t->num_positive; i++) { at += rrange(g, 1, 3); t->delta_poc_s1[i] = at; t->used_s1[i] = rpct(g, 85); }
+  }
+  s->num_st_rps = n;
+}
+/* the slice's set is in sh->st_rps, explicit: name a candidate of the SPS that equals it, or predict it from one, where that can be done */
+static void choose_rps_form(orc_gen *g, orc_slice_hdr *sh, const orc_sps *s)
+{
+  orc_st_rps *t = &sh->st_rps;
+  if (!g->cfg.rps_forms || s->num_st_rps == 0) return;
+  for (int k = 0; k < s->num_st_rps; k++) if (rps_same(t, &s->st_rps[k]) && rpct(g, 80)) { sh->short_term_ref_pic_set_sps_flag = 1; sh->short_term_rps_idx = k; return; }
+  if (t->num_negative + t->num_positive == 0 || !rpct(g, 80)) return;
+  const int k0 = rrange(g, 0, s->num_st_rps - 1);
+  for (int kk = 0; kk < s->num_st_rps; kk++) {
+    const int k = (k0 + kk) % s->num_st_rps; const orc_st_rps *ref = &s->st_rps[k];
+    const int nd = ref->num_negative + ref->num_positive;
+    for (int i = 0; i < t->num_negative + t->num_positive; i++) {
+      const int tv = i < t->num_negative ? t->delta_poc_s0[i] : t->delta_poc_s1[i - t->num_negative];
+      for (int j = 0; j <= nd; j++) {
+        const int rv = j < ref->num_negative ? ref->delta_poc_s0[j] : j < nd ? ref->delta_poc_s1[j - ref->num_negative] : 0;
+        if (rps_try_inter(t, ref, tv - rv)) { t->delta_idx_minus1 = s->num_st_rps - 1 - k; return; }
+      }
+    }
+  }
+}
+
 /* ------------------------------------------------------------------ one picture */
 static void write_picture(orc_gen *g, int idr, int write_ps)
 {
@@ -857,6 +935,7 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
     for (int i = 0; i < nneg; i++) { sh->st_rps.delta_poc_s0[i] = -(i + 1); sh->st_rps.used_s0[i] = (i == 0) ? 1 : rpct(g, 85); used += sh->st_rps.used_s0[i]; }
     used += lt_used;
     if (!used) { sh->lt_used[0] = 1; lt_used = used = 1; if (sh->num_long_term_sps) { sh->num_long_term_sps = 0; sh->num_long_term_pics = 1; } }      /* (nothing short-term left -- the picture behind the IDR after an early marking: the long-term one is used) */
+    choose_rps_form(g, sh, s);
     sh->num_ref_idx_l0 = g->slice_is_intra ? p->num_ref_idx_l0_default : rrange(g, 1, ORC_MIN(4, used + 1));   /* (more entries than pictures: the list wraps) */
     sh->slice_temporal_mvp_enabled = s->temporal_mvp_enabled ? rpct(g, 80) : 0;
     sh->collocated_from_l0 = 1;
@@ -891,6 +970,7 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
       if (!used) { g->slice_is_intra = 1; g->slice_is_b = 0; sh->slice_type = SLICE_I; used = 1; }      /* (the CRA picture is out of reach: an intra picture) */
     }
     else if (!used) { if (nn) sh->st_rps.used_s0[0] = 1; else if (np) sh->st_rps.used_s1[0] = 1; else { g->slice_is_intra = 1; g->slice_is_b = 0; sh->slice_type = SLICE_I; } used = 1; }
+    choose_rps_form(g, sh, s);
     sh->num_ref_idx_l0 = g->slice_is_intra ? p->num_ref_idx_l0_default : rrange(g, 1, ORC_MIN(4, used + 1));
     if (g->slice_is_b) { sh->num_ref_idx_l1 = rrange(g, 1, ORC_MIN(4, used + 1)); sh->mvd_l1_zero = rpct(g, 30); }
     sh->slice_temporal_mvp_enabled = s->temporal_mvp_enabled ? rpct(g, 80) : 0;

@@ -77,6 +77,10 @@ typedef struct {
   int vui_extras;             /* 1: the VUI's optional parts drawn (extended aspect ratio, overscan, video signal type with colour description, chroma sample location, default
                                * display window, POC-proportional timing, bitstream restriction -- what x265 writes by default), and the timing information in the VUI, in the
                                * VPS alone, in both (different rates: the VUI's counts) or nowhere -- 0 (also -1): timing in the VUI only */
+  int rps_forms;              /* 1: every way a short-term reference picture set can be written (7.3.7) -- candidate sets in the SPS, explicit or predicted from the set before;
+                               * a slice names a candidate (short_term_ref_pic_set_sps_flag) when its set equals one, else codes its set by inter RPS prediction from a
+                               * candidate where that is possible (delta_idx_minus1, delta_rps, used_by_curr_pic_flag / use_delta_flag), else explicitly: what HM's
+                               * configurations do -- 0 (also -1): always explicit in the slice header, as Kvazaar writes */
 } orc_gen_config;
 
 void orc_gen_default_config(orc_gen_config *c);    /* everything random, 416x240 */

@@ -64,9 +64,16 @@ void orc_write_vps(orc_bitw *w, const orc_vps *v, const orc_sps *s)
   orc_bw_trailing(w);
 }
 
-static void write_st_rps(orc_bitw *w, const orc_st_rps *r, int idx)
+static void write_st_rps(orc_bitw *w, const orc_st_rps *r, int idx, int num_in_sps)
 {
-  if (idx != 0) orc_bw_put(w, 0, 1);   /* inter_ref_pic_set_prediction_flag */
+  if (idx != 0) orc_bw_put(w, r->inter ? 1 : 0, 1);   /* inter_ref_pic_set_prediction_flag */
+  if (idx != 0 && r->inter) {
+    if (idx == num_in_sps) orc_bw_ue(w, (uint32_t)r->delta_idx_minus1);
+    orc_bw_put(w, r->delta_rps < 0, 1);
+    orc_bw_ue(w, (uint32_t)(r->delta_rps < 0 ? -r->delta_rps : r->delta_rps) - 1);
+    for (int j = 0; j < r->nflags; j++) { orc_bw_put(w, r->used_flag[j], 1); if (!r->used_flag[j]) orc_bw_put(w, r->use_delta[j], 1); }
+    return;
+  }
   orc_bw_ue(w, (uint32_t)r->num_negative);
   orc_bw_ue(w, (uint32_t)r->num_positive);
   int prev = 0;
@@ -123,7 +130,7 @@ void orc_write_sps(orc_bitw *w, const orc_sps *s)
     orc_bw_put(w, (uint32_t)s->pcm_loop_filter_disabled, 1);
   }
   orc_bw_ue(w, (uint32_t)s->num_st_rps);
-  for (int i = 0; i < s->num_st_rps; i++) write_st_rps(w, &s->st_rps[i], i);
+  for (int i = 0; i < s->num_st_rps; i++) write_st_rps(w, &s->st_rps[i], i, s->num_st_rps);
   orc_bw_put(w, (uint32_t)s->long_term_ref_pics_present, 1);
   if (s->long_term_ref_pics_present) {
     orc_bw_ue(w, (uint32_t)s->num_lt_sps);
@@ -231,7 +238,7 @@ void orc_write_slice_header(orc_bitw *w, const orc_slice_hdr *h, const orc_sps *
     if (nal_type != NAL_IDR_W_RADL && nal_type != NAL_IDR_N_LP) {
       orc_bw_put(w, (uint32_t)h->poc_lsb, s->log2_max_poc_lsb);
       orc_bw_put(w, (uint32_t)h->short_term_ref_pic_set_sps_flag, 1);
-      if (!h->short_term_ref_pic_set_sps_flag) write_st_rps(w, &h->st_rps, s->num_st_rps);
+      if (!h->short_term_ref_pic_set_sps_flag) write_st_rps(w, &h->st_rps, s->num_st_rps, s->num_st_rps);
       else if (s->num_st_rps > 1) orc_bw_put(w, (uint32_t)h->short_term_rps_idx, ceil_log2((unsigned)s->num_st_rps));
       if (s->long_term_ref_pics_present) {
         if (s->num_lt_sps > 0) orc_bw_ue(w, (uint32_t)h->num_long_term_sps);

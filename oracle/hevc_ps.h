@@ -15,6 +15,10 @@ typedef struct {
   int num_negative, num_positive;
   int delta_poc_s0[16], used_s0[16];    /* negative pics: delta (negative numbers) */
   int delta_poc_s1[16], used_s1[16];
+  /* writer only: the set coded by inter RPS prediction (7.3.7) -- from the set delta_idx_minus1 + 1 before it, moved by delta_rps, one used_by_curr_pic_flag /
+   * use_delta_flag pair per entry of that set and one more for delta_rps itself.  The fields above hold what it derives to. */
+  int inter, delta_idx_minus1, delta_rps, nflags;
+  uint8_t used_flag[33], use_delta[33];
 } orc_st_rps;
 
 typedef struct {

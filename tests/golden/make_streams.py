@@ -118,6 +118,11 @@ GEN = {
     "gen_sub_layers": dict(seed=81, density=20, intra_period=32, num_refs=3, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                            qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=0, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=60, gop=8,
                            temporal_layers=1),
+    # round 6: the reference picture sets written every way 7.3.7 allows (SPS candidates explicit and predicted; slices that name a candidate, predict from one, write
+    # their own), the VUI's optional parts in front of the timing information
+    "gen_rps_forms": dict(seed=85, density=15, intra_period=32, num_refs=3, tmvp=1, amp=0, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
+                          qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=0, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=60, gop=4,
+                          rps_forms=1, vui_extras=1),
     "gen_b_gop8": dict(seed=36, density=25, intra_period=16, num_refs=4, tmvp=1, amp=1, sao=1, sign_hiding=1, transform_skip=0, wpp=1, tile_rows=1, tile_cols=1,
                        qp_delta=0, deblock_mode=0, intra_in_p=10, all_part_modes=1, nxn_intra=1, max_cu_log2=5, min_cu_log2=3, slices=0, big_mvd=0, b_slices=70, gop=8),
 }

@@ -98,9 +98,13 @@ def parse_ptl(r, max_sub):
             r.u(8)
 
 
+RPS_FORMS = {"inter_sps": 0, "inter_slice": 0, "explicit_sps": 0, "explicit_slice": 0, "named": 0}      # (for tests: how the streams wrote their sets)
+
+
 def parse_st_rps(r, idx, num, sets):
     """7.3.7 / 7.4.8: returns list of (delta_poc, used) sorted: negatives closest first, then positives closest first"""
     inter = r.u(1) if idx != 0 else 0
+    RPS_FORMS["inter_sps" if inter and idx != num else "inter_slice" if inter else "explicit_sps" if idx != num else "explicit_slice"] += 1
     if inter:
         delta_idx = r.ue() + 1 if idx == num else 1
         ref = sets[idx - delta_idx]
@@ -649,6 +653,7 @@ class Decoder:
                 n = len(sps["rps"])
                 bits = (n - 1).bit_length() if n > 1 else 0
                 rps = sps["rps"][r.u(bits) if bits else 0]
+                RPS_FORMS["named"] += 1
         sh["lt"] = []                                              # (POC LSBs, used by the current picture, delta_poc_msb_present_flag, DeltaPocMsbCycleLt)
         if sps["lt"] is not None and not idr:
             n_sps = r.ue() if sps["lt"] else 0

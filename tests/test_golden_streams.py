@@ -51,7 +51,7 @@ def test_checker_decodes_golden_stream(name):
 
 
 def test_golden_streams_are_small_enough_to_live_in_the_repository():
-    assert sum(m["bytes"] for m in INDEX.values()) <= 900 * 1024          # (thirty streams since round 6)
+    assert sum(m["bytes"] for m in INDEX.values()) <= 900 * 1024          # (thirty-one streams since round 6)
     assert sum(1 for m in INDEX.values() if m["hash_sei"] == "md5") >= 5
 
 

@@ -188,3 +188,19 @@ def test_optional_vui_parts_and_where_the_picture_rate_is_said(gpu, seed):
     for a, b in zip(got, want):
         assert np.array_equal(a["i420"], b["i420"])
         assert tuple(a["fps"]) == tuple(b["fps"]) or (b["fps"] == (0, 0) and a["fps"][0] == 0), (a["fps"], b["fps"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 3])
+@pytest.mark.parametrize("seed", range(1, 13))
+def test_every_way_to_write_a_reference_picture_set(gpu, seed, threads):
+    """candidate sets in the SPS (explicit or predicted), slices that name one, predict from one or write their own (7.3.7): HM-style streams"""
+    kw = dict(rps_forms=1, num_refs=1 + seed % 4, intra_period=16, tmvp=1)
+    if seed & 1:
+        kw.update(gop=(2, 4, 8)[seed % 3], b_slices=50, open_gop=(seed >> 1) & 1, temporal_layers=(seed >> 2) & 1)
+    else:
+        kw.update(long_term=(seed >> 1) & 1)
+    g = orc.OracleGen(416, 240, seed=seed, **kw)
+    aus = [g.picture() for _ in range(24)]
+    g.close()
+    assert len(both(aus, range(len(aus)), threads, threads > 1)) == len(aus)

@@ -306,3 +306,27 @@ def test_optional_vui_parts_and_where_the_picture_rate_is_said(seed):
         assert np.array_equal(a["i420"], b["i420"])
     import parser_probe as PP
     assert PP.probe([n for a in aus for n in orc.split_nals(a)], 0)["pictures"] == 6
+
+
+@pytest.mark.parametrize("seed", range(1, 13))
+def test_every_way_to_write_a_reference_picture_set(seed):
+    """7.3.7: candidate sets in the SPS (explicit, or predicted from the set before), slices that name a candidate, slices that predict their set from a candidate
+    (delta_idx_minus1, delta_rps, used_by_curr_pic_flag / use_delta_flag), slices that write it out -- in low-delay streams and in reordered ones, where the sets
+    have entries on both sides.  Three parsers written from the standard's text (the checker, the Python decoder, the product through the parse-only hook) read what
+    the synthesiser's writer -- the derivation run backwards -- produced, and the pictures agree"""
+    import parser_probe as PP
+    kw = dict(rps_forms=1, num_refs=1 + seed % 4, intra_period=16)
+    if seed & 1:
+        kw.update(gop=(2, 4, 8)[seed % 3], b_slices=50, open_gop=(seed >> 1) & 1, temporal_layers=(seed >> 2) & 1)
+    g = orc.OracleGen(64, 64, seed=seed, **kw)
+    aus = [g.picture() for _ in range(20)]
+    g.close()
+    before = dict(pyhevc.RPS_FORMS)
+    want = oracle_pictures(aus)
+    got = python_pictures(aus)
+    assert len(want) == len(got) == len(aus)
+    for (_, x), y in zip(want, got):
+        assert np.array_equal(x, y["i420"])
+    seen = {k: pyhevc.RPS_FORMS[k] - before[k] for k in before}
+    assert seen["inter_sps"] + seen["explicit_sps"] >= 2 and seen["inter_slice"] + seen["named"] > 0, seen
+    assert PP.probe([n for a in aus for n in orc.split_nals(a)], 0)["pictures"] == len(aus)

@@ -172,6 +172,8 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
   if (s->scaling_list_data_present) gen_scaling(g, &s->scaling, s->sl_pred_mode, s->sl_pred_delta);
   s->num_st_rps = 0;
   if (c->rps_forms != 1) c->rps_forms = 0;
+  if (c->hdr_extras != 1) c->hdr_extras = 0;
+  if (c->hdr_extras) s->ext_data = rrange(g, 0, 3);
   if (c->rps_forms) gen_sps_rps(g, s);
   if (c->long_term > 0) {                                   /* candidates in the SPS: POC LSB 0 (the sequence's first picture), used by the current picture or only kept */
     s->long_term_ref_pics_present = 1; s->num_lt_sps = rrange(g, 0, 2);
@@ -193,6 +195,7 @@ orc_gen *orc_gen_open(const orc_gen_config *cfg)
     }
   }
   orc_pps *p = &g->pps; memset(p, 0, sizeof(*p));
+  if (c->hdr_extras == 1) { p->num_extra_slice_header_bits = rrange(g, 0, 2); p->slice_header_extension_present = rrange(g, 0, 5); p->ext_data = rrange(g, 0, 3); }
   p->sign_data_hiding = c->sign_hiding; p->cabac_init_present = c->cabac_init; if (c->cip != 1) c->cip = 0; p->constrained_intra_pred = c->cip;
   p->num_ref_idx_l0_default = rrange(g, 1, c->num_refs); p->num_ref_idx_l1_default = 1; p->init_qp = cfg->qp;
   p->transform_skip_enabled = c->transform_skip;
@@ -886,6 +889,22 @@ static void choose_rps_form(orc_gen *g, orc_slice_hdr *sh, const orc_sps *s)
   }
 }
 
+/* an SEI message no decoder needs (user_data_unregistered, payload type 5: sixteen bytes of identifier and a few more), and a filler data NAL unit */
+static void gen_unknown_sei(orc_gen *g, int nal_type)
+{
+  uint8_t b[40]; const int n = 16 + rrange(g, 0, 12); int k = 0;
+  b[k++] = 5; b[k++] = (uint8_t)n;
+  for (int i = 0; i < n; i++) b[k++] = (uint8_t)(rnd(g) & 0xff);
+  b[k++] = 0x80;
+  orc_write_nal(&g->au, nal_type, g->cur_tid, b, (size_t)k, 1);
+}
+static void gen_au_tail(orc_gen *g)
+{
+  if (!g->cfg.hdr_extras) return;
+  if (rpct(g, 30)) { uint8_t b[12]; const int n = rrange(g, 1, 10); memset(b, 0xff, (size_t)n); b[n] = 0x80; orc_write_nal(&g->au, NAL_FD, g->cur_tid, b, (size_t)n + 1, 1); }
+  if (rpct(g, 40)) gen_unknown_sei(g, NAL_SEI_SUFFIX);
+}
+
 /* ------------------------------------------------------------------ one picture */
 static void write_picture(orc_gen *g, int idr, int write_ps)
 {
@@ -894,11 +913,13 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
   const int wc = s->pic_w_ctbs, hc = s->pic_h_ctbs;
   const int nal = g->cur_nal, cra = nal == NAL_CRA, radl = nal == NAL_RADL_R || nal == NAL_RADL_N;
   g->au.len = 0; g->au.nbits = 0; g->au.cur = 0;
+  if (g->cfg.hdr_extras && rpct(g, 50)) { const uint8_t aud[1] = { (uint8_t)((idr ? 0 : 2) << 5 | 0x10) }; orc_write_nal(&g->au, NAL_AUD, g->cur_tid, aud, 1, 1); }      /* pic_type, rbsp trailing bits */
   if (write_ps) {
     orc_bw_init(&ps); orc_write_vps(&ps, &g->vps, &g->sps); orc_write_nal(&g->au, NAL_VPS, 0, ps.buf, ps.len, 1); orc_bw_free(&ps);
     orc_bw_init(&ps); orc_write_sps(&ps, &g->sps); orc_write_nal(&g->au, NAL_SPS, 0, ps.buf, ps.len, 1); orc_bw_free(&ps);
     orc_bw_init(&ps); orc_write_pps(&ps, &g->pps); orc_write_nal(&g->au, NAL_PPS, 0, ps.buf, ps.len, 1); orc_bw_free(&ps);
   }
+  if (g->cfg.hdr_extras && rpct(g, 50)) gen_unknown_sei(g, NAL_SEI_PREFIX);
   /* ---- slice header */
   memset(sh, 0, sizeof(*sh));
   sh->first_slice_segment_in_pic = 1; sh->pic_output_flag = p->output_flag_present ? !rpct(g, g->cfg.hidden_pics) : 1;
@@ -1027,7 +1048,7 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
   if (s->sao_enabled) { sh->sao_luma = rpct(g, 80); sh->sao_chroma = rpct(g, 80); }
   /* ---- slice data: one substream per CTU row with WPP (or with a slice segment per row), else one per tile */
   const int wpp = p->entropy_coding_sync_enabled, slices = g->cfg.slices;
-  if (slices == 3) { write_free_slices(g, nal); return; }
+  if (slices == 3) { write_free_slices(g, nal); gen_au_tail(g); return; }
   const int row_subs = wpp || slices == 1, cols = g->ncols_t;
   const int nsub = (row_subs ? hc : g->nrows_t) * cols;
   subs = (orc_bitw *)calloc((size_t)nsub, sizeof(orc_bitw));
@@ -1089,6 +1110,7 @@ static void write_picture(orc_gen *g, int idr, int write_ps)
   }
   free(subs); free(seg_first); free(seg_addr);
   sh->entry_point_offset = NULL;
+  gen_au_tail(g);
 }
 
 size_t orc_gen_picture(orc_gen *g, const uint8_t **au)

@@ -81,6 +81,8 @@ typedef struct {
                                * a slice names a candidate (short_term_ref_pic_set_sps_flag) when its set equals one, else codes its set by inter RPS prediction from a
                                * candidate where that is possible (delta_idx_minus1, delta_rps, used_by_curr_pic_flag / use_delta_flag), else explicitly: what HM's
                                * configurations do -- 0 (also -1): always explicit in the slice header, as Kvazaar writes */
+  int hdr_extras;             /* 1: what a decoder has to step over -- slice_reserved_flag bits (num_extra_slice_header_bits), slice segment header extension bytes, SPS / PPS
+                               * extension data, access unit delimiters, prefix and suffix SEI messages a decoder does not know, filler data NAL units -- 0 (also -1): none */
 } orc_gen_config;
 
 void orc_gen_default_config(orc_gen_config *c);    /* everything random, 416x240 */

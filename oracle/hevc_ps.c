@@ -166,7 +166,11 @@ void orc_write_sps(orc_bitw *w, const orc_sps *s)
     orc_bw_put(w, (x >> 5) & 1, 1);    /* bitstream_restriction_flag */
     if (x & 32) { orc_bw_put(w, 0, 1); orc_bw_put(w, 1, 1); orc_bw_put(w, 0, 1); orc_bw_ue(w, 0); orc_bw_ue(w, 2); orc_bw_ue(w, 1); orc_bw_ue(w, 15); orc_bw_ue(w, 15); }
   }
-  orc_bw_put(w, 0, 1);                 /* sps_extension_present_flag */
+  orc_bw_put(w, s->ext_data > 0, 1);   /* sps_extension_present_flag */
+  if (s->ext_data > 0) {               /* range, multilayer, 3D extension flags 0; sps_extension_4bits set: sps_extension_data_flag to the end -- "decoders shall ignore" */
+    orc_bw_put(w, 0, 3); orc_bw_put(w, 1, 1); orc_bw_put(w, 5, 4);
+    for (int i = 0; i < s->ext_data; i++) orc_bw_put(w, (uint32_t)(0xA5 + 37 * i) & 0xff, 8);
+  }
   orc_bw_trailing(w);
 }
 
@@ -215,8 +219,12 @@ void orc_write_pps(orc_bitw *w, const orc_pps *p)
   if (p->scaling_list_data_present) orc_scaling_write(w, &p->scaling, p->sl_pred_mode, p->sl_pred_delta);
   orc_bw_put(w, (uint32_t)p->lists_modification_present, 1);
   orc_bw_ue(w, (uint32_t)p->log2_parallel_merge_level - 2);
-  orc_bw_put(w, (uint32_t)p->slice_header_extension_present, 1);
-  orc_bw_put(w, 0, 1);                 /* pps_extension_present_flag */
+  orc_bw_put(w, p->slice_header_extension_present != 0, 1);
+  orc_bw_put(w, p->ext_data > 0, 1);   /* pps_extension_present_flag */
+  if (p->ext_data > 0) {
+    orc_bw_put(w, 0, 3); orc_bw_put(w, 1, 1); orc_bw_put(w, 9, 4);
+    for (int i = 0; i < p->ext_data; i++) orc_bw_put(w, (uint32_t)(0x3C + 91 * i) & 0xff, 8);
+  }
   orc_bw_trailing(w);
 }
 
@@ -232,7 +240,7 @@ void orc_write_slice_header(orc_bitw *w, const orc_slice_hdr *h, const orc_sps *
     orc_bw_put(w, (uint32_t)h->slice_segment_address, ceil_log2((unsigned)(s->pic_w_ctbs * s->pic_h_ctbs)));
   }
   if (!h->dependent_slice_segment) {
-    for (int i = 0; i < p->num_extra_slice_header_bits; i++) orc_bw_put(w, 0, 1);
+    for (int i = 0; i < p->num_extra_slice_header_bits; i++) orc_bw_put(w, (uint32_t)(h->slice_qp_delta + i) & 1, 1);      /* slice_reserved_flag[]: any value */
     orc_bw_ue(w, (uint32_t)h->slice_type);
     if (p->output_flag_present) orc_bw_put(w, (uint32_t)h->pic_output_flag, 1);
     if (nal_type != NAL_IDR_W_RADL && nal_type != NAL_IDR_N_LP) {
@@ -317,7 +325,11 @@ void orc_write_slice_header(orc_bitw *w, const orc_slice_hdr *h, const orc_sps *
       for (int i = 0; i < h->num_entry_points; i++) orc_bw_put(w, h->entry_point_offset[i] - 1, len);
     }
   }
-  if (p->slice_header_extension_present) orc_bw_ue(w, 0);
+  if (p->slice_header_extension_present) {     /* slice_segment_header_extension_length and that many bytes of any value */
+    const int n = p->slice_header_extension_present - 1;
+    orc_bw_ue(w, (uint32_t)n);
+    for (int i = 0; i < n; i++) orc_bw_put(w, (uint32_t)(h->slice_segment_address * 7 + 0x11 * i + 1) & 0xff, 8);
+  }
   orc_bw_trailing(w);   /* byte_alignment() */
 }
 

@@ -51,6 +51,7 @@ typedef struct {
   int num_lt_sps; int lt_poc_lsb_sps[32]; uint8_t lt_used_sps[32];      /* num_long_term_ref_pics_sps candidates: lt_ref_pic_poc_lsb_sps, used_by_curr_pic_lt_sps_flag */
   int temporal_mvp_enabled, strong_intra_smoothing;
   int vui_present, vui_timing_present; uint32_t vui_num_units_in_tick, vui_time_scale;
+  int ext_data;                            /* writer: as orc_pps.ext_data, for the SPS */
   int vui_extras;                          /* writer: bits 0..5 = aspect ratio (extended SAR), overscan, video signal type with colour description, chroma sample location,
                                             * default display window, bitstream restriction; bit 6 = vui_poc_proportional_to_timing_flag; bits 7..9 = the three single flags */
   /* derived */
@@ -61,6 +62,7 @@ typedef struct {
   int valid;
   int pps_id, sps_id;
   int dependent_slice_segments_enabled, output_flag_present, num_extra_slice_header_bits;
+  int ext_data;                            /* writer: > 0 = pps_extension_present_flag with pps_extension_4bits set and this many bytes of extension data (to be ignored, 7.4.3.3.1) */
   int sign_data_hiding, cabac_init_present;
   int num_ref_idx_l0_default, num_ref_idx_l1_default;
   int init_qp;                              /* 26 + init_qp_minus26 */

@@ -204,7 +204,7 @@ class OracleDecoder:
 GEN_FIELDS = ("width", "height", "seed", "intra_period", "qp", "density", "num_refs", "tmvp", "amp", "sao", "strong_intra", "sign_hiding",
               "transform_skip", "cabac_init", "wpp", "tile_rows", "uniform_tiles", "th_depth_inter", "th_depth_intra", "qp_delta",
               "chroma_qp_offsets", "deblock_mode", "par_mrg_level", "intra_in_p", "all_part_modes", "chroma_modes", "nxn_intra",
-              "max_cu_log2", "min_cu_log2", "big_mvd", "slices", "tile_cols", "tq_bypass", "scaling_lists", "b_slices", "gop", "weighted", "list_mod", "ctb_log2", "cip", "long_term", "pcm", "lf_across", "min_cb_log2", "open_gop", "hidden_pics", "temporal_layers", "vui_extras", "rps_forms")
+              "max_cu_log2", "min_cu_log2", "big_mvd", "slices", "tile_cols", "tq_bypass", "scaling_lists", "b_slices", "gop", "weighted", "list_mod", "ctb_log2", "cip", "long_term", "pcm", "lf_across", "min_cb_log2", "open_gop", "hidden_pics", "temporal_layers", "vui_extras", "rps_forms", "hdr_extras")
 
 
 class OracleGen:

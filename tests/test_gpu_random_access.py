@@ -2,7 +2,7 @@
 as its start (the RASL pictures are dropped, 8.1.3), the same picture called BLA by a splicer (BLA_W_LP, BLA_W_RADL, BLA_N_LP), an end of sequence NAL unit in
 front of it, and pictures with pic_output_flag = 0 (decoded, referenced, never handed out).  The synthesiser writes the streams (open_gop, hidden_pics); the
 cuts are made here.  The HIP decoder must hand out the checker's pictures -- the same ones, in the same order, bit for bit; tests/test_random_access.py holds the
-checker itself to the properties of such streams."""
+checker itself to the properties of such streams.  Further down, as there: temporal sub-layers, VUI parts, reference picture set forms, ignorable syntax."""
 import numpy as np
 import pytest
 
@@ -202,5 +202,20 @@ def test_every_way_to_write_a_reference_picture_set(gpu, seed, threads):
         kw.update(long_term=(seed >> 1) & 1)
     g = orc.OracleGen(416, 240, seed=seed, **kw)
     aus = [g.picture() for _ in range(24)]
+    g.close()
+    assert len(both(aus, range(len(aus)), threads, threads > 1)) == len(aus)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 3])
+@pytest.mark.parametrize("seed", range(1, 13))
+def test_what_a_decoder_steps_over(gpu, seed, threads):
+    """slice_reserved_flag bits, slice segment header extension bytes, SPS / PPS extension data, access unit delimiters, unknown SEI messages, filler data -- also between
+    the pictures of free slices, which the next access unit's first NAL unit closes (an access unit delimiter or a prefix SEI message does, filler data does not)"""
+    kw = dict(hdr_extras=1, intra_period=6, slices=(0, 1, 3, 2)[seed % 4], tmvp=1)
+    if seed % 4 == 3:
+        kw.update(tile_rows=2, tile_cols=2, wpp=0)
+    g = orc.OracleGen(416, 240, seed=seed, **kw)
+    aus = [g.picture() for _ in range(14)]
     g.close()
     assert len(both(aus, range(len(aus)), threads, threads > 1)) == len(aus)

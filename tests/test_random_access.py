@@ -6,7 +6,11 @@ IDR picture, or reads one a splicer has cut (the reference hands every NAL unit 
 The checker's decoder against PROPERTIES of the streams -- a decode that starts at a CRA picture shows exactly the full decode's
 pictures from there on minus that picture's RASL pictures, bit for bit; a CRA picture renamed BLA, or behind an end of sequence
 NAL unit, does the same to the pictures that follow while everything before it still comes out -- and against the second,
-independently written decoder (tests/pyhevc.py).  The product's decoder meets the same streams in tests/test_gpu_random_access.py."""
+independently written decoder (tests/pyhevc.py).  The product's decoder meets the same streams in tests/test_gpu_random_access.py.
+
+Further down: stream-level syntax the decoders had parsers for and no stream of -- temporal sub-layers (and the stream thinned to its lower layers), the VUI's optional
+parts, every way to write a reference picture set (inter RPS prediction), and what a decoder steps over (reserved header bits, header extension bytes, parameter set
+extension data, access unit delimiters, unknown SEI messages, filler data)."""
 import numpy as np
 import pytest
 
@@ -330,3 +334,29 @@ def test_every_way_to_write_a_reference_picture_set(seed):
     seen = {k: pyhevc.RPS_FORMS[k] - before[k] for k in before}
     assert seen["inter_sps"] + seen["explicit_sps"] >= 2 and seen["inter_slice"] + seen["named"] > 0, seen
     assert PP.probe([n for a in aus for n in orc.split_nals(a)], 0)["pictures"] == len(aus)
+
+
+@pytest.mark.parametrize("seed", range(1, 13))
+def test_what_a_decoder_steps_over(seed):
+    """slice_reserved_flag bits, slice segment header extension bytes (in dependent segments too), SPS / PPS extension data, access unit delimiters, SEI messages no
+    decoder knows in front of and behind the picture, filler data: nothing of it changes a sample"""
+    import parser_probe as PP
+    kw = dict(hdr_extras=1, intra_period=6, slices=(0, 1, 3, 0)[seed % 4], tile_rows=1, tile_cols=1)
+    if seed % 4 == 3:
+        kw.update(tile_rows=2, tile_cols=2, wpp=0)             # (the Python decoder reads a picture with tiles as one slice)
+    g = orc.OracleGen(128, 128, seed=seed, **kw)
+    aus = [g.picture() for _ in range(8)]
+    g.close()
+    types = {nal_type(n) for a in aus for n in orc.split_nals(a)}
+    assert {35, 38, 39, 40} <= types
+    want = oracle_pictures(aus)
+    got = python_pictures(aus)
+    assert len(want) == len(got) == len(aus)
+    for (_, x), y in zip(want, got):
+        assert np.array_equal(x, y["i420"])
+    # the same pictures as without the extras? (the extras draw from the same random sequence, so the streams differ; what can be said: stripping the NAL units
+    # a decoder ignores changes nothing)
+    bare = [b"".join(n for n in orc.split_nals(a) if nal_type(n) not in (35, 38, 39, 40)) for a in aus]
+    same(oracle_pictures(bare), want)
+    for threads in (0, 3):
+        assert PP.probe([n for a in aus for n in orc.split_nals(a)], threads)["pictures"] == len(aus)

@@ -14,7 +14,7 @@ for seed in range(a, b + 1):
     w, h, kw = drawn(seed)
     for k in ("long_term", "gop", "b_slices", "intra_period"):
         kw.pop(k, None)
-    kw.update(gop=(2, 4, 8)[seed % 3], open_gop=1, b_slices=(0, 50)[seed & 1], intra_period=48, hidden_pics=(0, 0, 12)[seed % 3], tmvp=1, temporal_layers=(seed >> 1) & 1, rps_forms=(seed >> 2) & 1, vui_extras=(seed >> 3) & 1)
+    kw.update(gop=(2, 4, 8)[seed % 3], open_gop=1, b_slices=(0, 50)[seed & 1], intra_period=48, hidden_pics=(0, 0, 12)[seed % 3], tmvp=1, temporal_layers=(seed >> 1) & 1, rps_forms=(seed >> 2) & 1, vui_extras=(seed >> 3) & 1, hdr_extras=(seed >> 1) & (seed >> 2) & 1)
     g = orc.OracleGen(w, h, seed=seed, **kw)
     aus = [g.picture() for _ in range(20)]
     g.close()

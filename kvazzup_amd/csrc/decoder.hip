@@ -1273,6 +1273,19 @@ bool Decoder::ensure_buffers(int w, int h, int ctb_log2)
 }
 
 // a picture buffer for the picture about to be decoded: not a reference any more and, if it was output, output long enough ago
+// Concealment v1 (decoder.h): the buffer that stands in for a reference picture that never arrived.  Marked like the real one would be; its samples are set when
+// the picture that asked for it is launched (the GPU may still be reading the buffer's former picture for older pictures that are in flight).
+int Decoder::conceal_ref(int poc, bool is_lt)
+{
+  const int s = alloc_slot();
+  if (s < 0) return -1;
+  DpbPic &d = dpb_[s];
+  d.poc = poc; d.is_ref = true; d.used = true; d.is_lt = is_lt; d.motion.reset();      // (decode_idx stays: the buffer was old enough to be taken and is no picture anybody waits for -- free again the moment no set names it)
+  pending_conceal_.push_back(s);
+  if (concealed_++ < 3) fprintf(stderr, "kvazzup_amd: decoder: reference picture with POC %d never arrived -- a grey picture stands in (libavcodec does the same)\n", poc);
+  return s;
+}
+
 int Decoder::alloc_slot()
 {
   for (int s = 0; s < KVZ_DEC_MAX_REFS; s++) {
@@ -2036,6 +2049,11 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
       const long long full = (long long)sh.poc - (long long)lt_cycle[k] * max_lsb - (sh.poc & (max_lsb - 1)) + lt_lsb[k];      // (64 bits: a hostile cycle count must not wrap into a POC that exists)
       int found = -1;
       for (int q = 0; q < KVZ_DEC_MAX_REFS; q++) if (dpb_[q].is_ref && dpb_[q].used && (lt_msb[k] ? dpb_[q].poc == full : (dpb_[q].poc & (max_lsb - 1)) == lt_lsb[k])) found = q;
+      if (found < 0 && lt_used[k] && !sh.is_intra) {               // lost on the way: a grey picture stands in (known by its LSBs alone: the nearest POC before the current one that has them)
+        long long at = full; if (!lt_msb[k]) { at = (long long)sh.poc - (sh.poc & (max_lsb - 1)) + lt_lsb[k]; if (at >= sh.poc) at -= max_lsb; }
+        found = conceal_ref((int)at, true);
+        if (found < 0) return DEC_ERR_INVALID;
+      }
       if (found >= 0) { keep[found] = true; dpb_[found].is_lt = true; }
       if (lt_used[k]) { if (found < 0 && !sh.is_intra) return DEC_ERR_INVALID; if (found >= 0) lt_slot[nl++] = found; }
     }
@@ -2043,6 +2061,11 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
       const int poc = sh.poc + rps.dpoc[k];
       int found = -1;
       for (int q = 0; q < KVZ_DEC_MAX_REFS; q++) if (dpb_[q].is_ref && dpb_[q].used && !dpb_[q].is_lt && dpb_[q].poc == poc) found = q;
+      if (found < 0 && rps.used[k] && !sh.is_intra) {
+        bool lt_has_it = false;                                  // (a long-term picture of that POC is no short-term entry's picture: that stays an error)
+        for (int q = 0; q < KVZ_DEC_MAX_REFS; q++) lt_has_it |= dpb_[q].is_ref && dpb_[q].used && dpb_[q].is_lt && dpb_[q].poc == poc;
+        if (!lt_has_it) found = conceal_ref(poc, false);
+      }
       if (found >= 0) keep[found] = true;
       if (rps.used[k]) { if (found < 0 && !sh.is_intra) return DEC_ERR_INVALID; if (found >= 0 && nc < 16) { cand_slot[nc++] = found; if (k < rps.n_neg) nbefore = nc; } }      // a missing reference picture (lost access unit)
     }
@@ -2083,7 +2106,8 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
   job.slot = slot; job.nref = nref;
   for (int k = 0; k < 16; k++) { job.ref_poc[k] = k < nref ? ref_poc[k] : sh.poc; job.ref_slot[k] = k < nref ? ref_slot[k] : 0; job.ref_lt[k] = k < nref ? ref_lt[k] : 0; job.ref_lt1[k] = k < nref1 ? ref_lt1[k] : 0; }
   if (no_rasl_out) cvs_++;
-  job.starts_cvs = no_rasl_out; job.discard_prior = cur_discard_;                     // a new coded video sequence: its pictures follow ALL of the last one's in output order
+  job.starts_cvs = no_rasl_out; job.discard_prior = cur_discard_;
+  job.conceal = std::move(pending_conceal_); pending_conceal_.clear();                     // a new coded video sequence: its pictures follow ALL of the last one's in output order
   job.cvs = cvs_;
   job.nref1 = nref1; job.no_backward = no_backward;
   for (int k = 0; k < 16; k++) { job.ref_poc1[k] = k < nref1 ? ref_poc1[k] : sh.poc; job.ref_slot1[k] = k < nref1 ? ref_slot1[k] : 0; }
@@ -2780,6 +2804,16 @@ int Decoder::parse_job(PicJob &job, bool row_parallel)
 int Decoder::launch_gpu(PicJob &job)
 {
   if (hipSetDevice(device_) != hipSuccess) return DEC_ERR_GPU;
+  if (!job.conceal.empty()) {
+    // buffers that stand in for lost reference pictures (conceal_ref): grey BEFORE this picture's kernels and AFTER everything older has left the GPU -- older pictures in
+    // flight may still read what the buffers held.  A loss is rare: the device is simply drained (pictures handed to the submission layer are launched first).
+    for (PicJob *j : gpu_q_) while (!j->launched.load(std::memory_order_acquire)) futex_wait(j->launched, 0);
+    if (hipDeviceSynchronize() != hipSuccess) return DEC_ERR_GPU;
+    const size_t npx = (size_t)pw_ * ph_;
+    for (int s : job.conceal) if (dpb_[s].plane[0] && hipMemset(dpb_[s].plane[0], 128, npx * 3 / 2) != hipSuccess) return DEC_ERR_GPU;
+    if (hipDeviceSynchronize() != hipSuccess) return DEC_ERR_GPU;
+    job.conceal.clear();
+  }
   const size_t ntu = job.ntu, nlev = job.nlev;
   const size_t tu_off = fixed_bytes(), lev_off = (tu_off + ntu * sizeof(DecTu) + 15) & ~(size_t)15;
   const bool bi = (job.sh.is_b || job.sh.weighted) && job.any_bi.load(std::memory_order_relaxed) != 0;

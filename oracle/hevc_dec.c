@@ -29,6 +29,7 @@ struct orc_decoder {
   int prev_tid0_poc;
   int seen_irap;
   int tid;                                /* TemporalId of the NAL unit at hand */
+  int concealed;                          /* missing reference pictures replaced so far (missing_ref) */
   int after_eos;                          /* an end of sequence NAL unit came: the next picture starts a coded video sequence (a CRA picture then has NoRaslOutputFlag = 1) */
   int skip_rasl;                          /* NoRaslOutputFlag of the last IRAP picture: its RASL pictures are not decoded (8.1.3) */
   orc_pic *ref_list0[16]; int ref_poc[16]; int num_ref;
@@ -856,6 +857,21 @@ static int start_picture(orc_decoder *d)
 
 /* 8.3.4: RefPicList0 = the used pictures before the current one (nearest first), then those after it, repeated until the list is full; RefPicList1
  * the other way round.  No list modification, no long-term pictures. */
+/* A picture the reference picture set says the current picture predicts from is not there -- its access unit never arrived (the streams come over RTP).  What a
+ * decoder does then is not the standard's business; this project's rule ("concealment v1", the one libavcodec's -- and so OpenHEVC's -- generate_missing_ref follows):
+ * a picture of mid-grey samples with the missing picture order count stands in, without motion (a block of it gives no temporal candidate), never output, and decoding
+ * goes on.  The product's decoder does the same (csrc/decoder.hip conceal_ref). */
+static orc_pic *missing_ref(orc_decoder *d, int poc, int is_lt)
+{
+  orc_pic *p = alloc_pic(d, d->s->width, d->s->height);
+  if (!p) return NULL;
+  orc_pic_reset_side(p);
+  for (int c = 0; c < 3; c++) memset(p->plane[c], 128, (size_t)p->stride[c] * (size_t)(c ? p->h / 2 : p->h));
+  p->poc = poc; p->pts = 0; p->is_ref = 1; p->is_lt = is_lt; p->needed_for_output = 0; p->out_queued = 0; p->slice_type = SLICE_I;
+  d->concealed++;
+  return p;
+}
+
 static int build_ref_list(orc_decoder *d)
 {
   orc_slice_hdr *sh = &d->sh;
@@ -865,14 +881,26 @@ static int build_ref_list(orc_decoder *d)
   orc_pic *before[16], *after[16], *lt[16]; int nb = 0, na = 0, nl = 0;
   int poc = d->cur->poc;
   const int max_lsb = 1 << d->s->log2_max_poc_lsb;
-  for (int k = 0; k < sh->st_rps.num_negative && nb < 16; k++) if (sh->st_rps.used_s0[k]) { before[nb] = find_poc(d, poc + sh->st_rps.delta_poc_s0[k]); if (before[nb] && before[nb]->is_lt) before[nb] = NULL; nb++; }
-  for (int k = 0; k < sh->st_rps.num_positive && na < 16; k++) if (sh->st_rps.used_s1[k]) { after[na] = find_poc(d, poc + sh->st_rps.delta_poc_s1[k]); if (after[na] && after[na]->is_lt) after[na] = NULL; na++; }
+  for (int k = 0; k < sh->st_rps.num_negative && nb < 16; k++) if (sh->st_rps.used_s0[k]) {
+    before[nb] = find_poc(d, poc + sh->st_rps.delta_poc_s0[k]);
+    if (!before[nb]) before[nb] = missing_ref(d, poc + sh->st_rps.delta_poc_s0[k], 0); else if (before[nb]->is_lt) before[nb] = NULL;
+    nb++;
+  }
+  for (int k = 0; k < sh->st_rps.num_positive && na < 16; k++) if (sh->st_rps.used_s1[k]) {
+    after[na] = find_poc(d, poc + sh->st_rps.delta_poc_s1[k]);
+    if (!after[na]) after[na] = missing_ref(d, poc + sh->st_rps.delta_poc_s1[k], 0); else if (after[na]->is_lt) after[na] = NULL;
+    na++;
+  }
   for (int k = 0; k < sh->num_lt && nl < 16; k++) if (sh->lt_used[k]) {      /* RefPicSetLtCurr (8.3.2) */
     const int full = poc - sh->lt_msb_cycle[k] * max_lsb - (poc & (max_lsb - 1)) + sh->lt_poc_lsb[k];
     lt[nl] = NULL;
     for (int i = 0; i < MAX_DPB; i++) {
       orc_pic *q = &d->dpb[i];
       if (q->in_use && q->is_ref && q->is_lt && q != d->cur && (sh->lt_msb_present[k] ? q->poc == full : (q->poc & (max_lsb - 1)) == sh->lt_poc_lsb[k])) lt[nl] = q;
+    }
+    if (!lt[nl]) {      /* (known by its LSBs alone: the nearest picture order count before the current one that has them) */
+      int at = full; if (!sh->lt_msb_present[k]) { at = poc - (poc & (max_lsb - 1)) + sh->lt_poc_lsb[k]; if (at >= poc) at -= max_lsb; }
+      lt[nl] = missing_ref(d, at, 1);
     }
     nl++;
   }
@@ -1124,6 +1152,7 @@ int orc_dec_debug_side(orc_decoder *d, int16_t *mv, int8_t *ref, uint8_t *pm, ui
   }
   return n;
 }
+int orc_dec_concealed(const orc_decoder *d) { return d->concealed; }
 void orc_dec_hash_stats(orc_decoder *d, int *checked, int *mismatch) { if (checked) *checked = d->hash_checked; if (mismatch) *mismatch = d->hash_mismatch; }
 
 int orc_dec_get_frame(orc_decoder *d, orc_dec_frame *out)

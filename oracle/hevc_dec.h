@@ -34,6 +34,7 @@ void orc_dec_flush(orc_decoder *d);                            /* end of stream:
 /* decoded picture hash SEI messages (D.2.19: MD5, CRC or checksum, in a suffix SEI NAL unit behind the picture) met so far, and how many
  * of them did NOT match the picture as decoded here: a stream that carries them verifies itself */
 void orc_dec_hash_stats(orc_decoder *d, int *checked, int *mismatch);
+int orc_dec_concealed(const orc_decoder *d);      /* reference pictures that were missing (lost access units) and replaced by grey ones so far */
 int orc_dec_debug_side(orc_decoder *d, int16_t *mv, int8_t *ref, uint8_t *pm, uint8_t *im, int8_t *qp);
 /* debug: copy of the last picture before deblocking (same geometry as coded picture) */
 const pixel *orc_dec_predeblock_plane(orc_decoder *d, int c);

@@ -167,6 +167,11 @@ class OracleDecoder:
         lib().orc_dec_hash_stats(self.p, C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def concealed(self):
+        """reference pictures that were missing and replaced by grey ones so far"""
+        lib().orc_dec_concealed.argtypes = [C.c_void_p]
+        return lib().orc_dec_concealed(self.p)
+
     def decode_au(self, au, pts=0):
         """feed every NAL of an access unit; returns list of decoded frames"""
         frames = []

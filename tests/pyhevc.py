@@ -817,14 +817,26 @@ class Decoder:
                 p.is_lt = True
                 p.keep_lt = True
             if used:
-                lt_curr.append(hit[0])
+                if not hit and not sh["intra"]:
+                    at = full
+                    if not present:
+                        at = poc - (poc & (mx - 1)) + lsb
+                        if at >= poc:
+                            at -= mx
+                    hit = [self.missing_ref(sps, at, True)]
+                    hit[0].keep_lt = True
+                lt_curr.append(hit[0] if hit else None)
         for p in self.dpb:
             p.is_ref = p.keep_lt or (not p.is_lt and p.poc in keep)
         self.dpb = [p for p in self.dpb if p.is_ref]
-        by_poc = lambda q: next(p for p in self.dpb if p.poc == q and not p.is_lt)
+        def by_poc(q):
+            for p in self.dpb:
+                if p.poc == q and not p.is_lt:
+                    return p
+            return self.missing_ref(sps, q, False)
         # 8.3.4: list 0 starts with the pictures before the current one, list 1 with the ones after it, the long-term ones close both; short lists repeat
-        c0 = [by_poc(q) for q in before + after] + lt_curr
-        c1 = [by_poc(q) for q in after + before] + lt_curr
+        c0 = [] if sh["intra"] else [by_poc(q) for q in before + after] + lt_curr
+        c1 = [] if sh["intra"] else [by_poc(q) for q in after + before] + lt_curr
         le = sh.get("list_entry") or [None, None]                    # (a modified list: entries of the temporary list in the slice's order)
         refs = [[c0[le[0][i] if le[0] else i % len(c0)] for i in range(sh["nref"])] if sh["nref"] else [],
                 [c1[le[1][i] if le[1] else i % len(c1)] for i in range(sh["nref1"])] if sh["nref1"] else []]
@@ -849,6 +861,17 @@ class Decoder:
             self.cur = sl
             if sl.run_segment(data, starts, 0, 0):
                 self.picture_done(sl, sps, nal_type)
+
+    def missing_ref(self, sps, poc, is_lt):
+        """a reference picture that never arrived (its access unit was lost): a mid-grey picture with its picture order count stands in, without motion, never
+        output -- this project's concealment rule, the one libavcodec's generate_missing_ref follows; not the standard's business"""
+        pic = Picture(sps["w"], sps["h"])
+        for pl in pic.planes:
+            pl[:] = 128
+        pic.poc, pic.is_ref, pic.is_lt, pic.keep_lt = poc, True, is_lt, False
+        self.dpb.append(pic)
+        self.concealed = getattr(self, "concealed", 0) + 1
+        return pic
 
     def picture_done(self, sl, sps, nal_type, filtered=False):
         if not filtered:

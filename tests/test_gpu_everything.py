@@ -99,6 +99,16 @@ def test_decoder_survives_corrupted_streams_of_the_new_kinds(gpu, frame, kw):
             got += gd.decode_au(aus[t], t)
         except RuntimeError:
             pass                                          # (what the damage left behind may fail once more before the IDR takes over)
-    got += gd.drain()
+    eos, quiet = bytes([0, 0, 0, 1, 36 << 1, 1]), 0
+    for _ in range(80):                                   # (a damaged picture still in the frame threads' ring fails when its turn comes: one error per such picture)
+        try:
+            f = gd.decode_nal(eos)
+        except RuntimeError:
+            continue
+        quiet = 0 if f is not None else quiet + 1
+        if f is not None:
+            got.append(f)
+        elif quiet > 8:
+            break
     gd.close()
     assert len(got) >= period and all(np.array_equal(a["i420"], b) for a, b in zip(got[-period:], want)), len(got)

@@ -2810,6 +2810,8 @@ int Decoder::launch_gpu(PicJob &job)
     for (PicJob *j : gpu_q_) while (!j->launched.load(std::memory_order_acquire)) futex_wait(j->launched, 0);
     if (hipDeviceSynchronize() != hipSuccess) return DEC_ERR_GPU;
     const size_t npx = (size_t)pw_ * ph_;
+    // (unconditionally: headers run ahead of launches -- by now a LATER picture may have been given the buffer, which is fine, it launches after this one and
+    // overwrites it; a list inherited from a header that failed names buffers that are still stand-ins or have become this picture's own)
     for (int s : job.conceal) if (dpb_[s].plane[0] && hipMemset(dpb_[s].plane[0], 128, npx * 3 / 2) != hipSuccess) return DEC_ERR_GPU;
     if (hipDeviceSynchronize() != hipSuccess) return DEC_ERR_GPU;
     job.conceal.clear();

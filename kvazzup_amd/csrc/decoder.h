@@ -212,7 +212,7 @@ class Decoder {
     int slot = 0;                                                // picture buffer this picture is reconstructed into
     int cvs = 0;                                                 // the coded video sequence it belongs to (output order)
     uint64_t serial = 0;                                         // number in decoding order
-    std::vector<int> conceal;                                    // picture buffers that stand in for reference pictures that never arrived: filled with grey before this picture's kernels (launch_gpu)
+    std::vector<std::pair<int, int>> conceal;                    // (buffer, source buffer or -1): buffers that stand in for reference pictures that never arrived, filled before this picture's kernels (launch_gpu)
     bool starts_cvs = false, discard_prior = false;              // NoRaslOutputFlag (8.1.3); ... and no_output_of_prior_pics_flag in force (C.5.2.2)
     int nref = 0; int ref_poc[16]; uint8_t ref_slot[16];        // RefPicList0
     int nref1 = 0; int ref_poc1[16]; uint8_t ref_slot1[16];     // RefPicList1 (B slices)
@@ -385,10 +385,11 @@ class Decoder {
   // themselves complete later (frame threads) and leave through reorder_q_ by the same counting rule; this list exists so that an IDR / BLA picture with
   // no_output_of_prior_pics_flag discards exactly the pictures the standard's process would still hold at that instant, whatever the threads' timing.
   std::vector<std::pair<uint64_t, int>> vwait_; std::vector<uint64_t> discarded_; uint64_t pic_serial_ = 0;
-  // Concealment v1: a picture the reference picture set says the current one predicts from is not there (its access unit was lost on the way): a buffer of mid-grey
-  // samples with its picture order count stands in -- no motion, never output -- and decoding goes on, as libavcodec's (OpenHEVC's) generate_missing_ref does.  The
-  // checker follows the same rule (oracle/hevc_dec.c missing_ref).  The slots wait here for the picture that needed them; its launch fills them.
-  int conceal_ref(int poc, bool is_lt); std::vector<int> pending_conceal_; uint64_t concealed_ = 0;
+  // Concealment v2: a picture the reference picture set says the current one predicts from is not there (its access unit was lost on the way): a buffer with its
+  // picture order count stands in -- no motion, never output -- and decoding goes on.  Its samples: a copy of the reference picture nearest in output order among
+  // those the DPB held when the current picture arrived (of two equally near the earlier one), mid-grey when there is none (libavcodec's generate_missing_ref always takes grey).
+  // The checker follows the same rule (oracle/hevc_dec.c missing_ref).  The buffers wait here for the picture that needed them; its launch fills them.
+  int conceal_ref(int poc, bool is_lt); std::vector<std::pair<int, int>> pending_conceal_; uint64_t concealed_ = 0;
   bool cur_discard_ = false;     // the picture whose headers are being read empties the buffer without output (decided with its first segment)
   bool cur_no_rasl_ = false;     // NoRaslOutputFlag of the picture whose slice headers are being read (decided with its first segment)
   bool skip_rasl_ = false;       // NoRaslOutputFlag of the last IRAP picture: the RASL pictures that belong to it refer to pictures that are not there -- their NAL units are dropped

@@ -1281,8 +1281,8 @@ int Decoder::conceal_ref(int poc, bool is_lt)
   if (s < 0) return -1;
   DpbPic &d = dpb_[s];
   d.poc = poc; d.is_ref = true; d.used = true; d.is_lt = is_lt; d.motion.reset();      // (decode_idx stays: the buffer was old enough to be taken and is no picture anybody waits for -- free again the moment no set names it)
-  pending_conceal_.push_back(s);
-  if (concealed_++ < 3) fprintf(stderr, "kvazzup_amd: decoder: reference picture with POC %d never arrived -- a grey picture stands in (libavcodec does the same)\n", poc);
+  pending_conceal_.emplace_back(s, -2);                           // (-2: the source is chosen once the reference picture set has been applied, decode_slice)
+  if (concealed_++ < 3) fprintf(stderr, "kvazzup_amd: decoder: reference picture with POC %d never arrived -- the nearest reference picture (or a grey one) stands in\n", poc);
   return s;
 }
 
@@ -2069,6 +2069,20 @@ int Decoder::decode_slice(const uint8_t *rbsp, size_t len, int nal_type, int64_t
       if (found >= 0) keep[found] = true;
       if (rps.used[k]) { if (found < 0 && !sh.is_intra) return DEC_ERR_INVALID; if (found >= 0 && nc < 16) { cand_slot[nc++] = found; if (k < rps.n_neg) nbefore = nc; } }      // a missing reference picture (lost access unit)
     }
+    // stand-ins made above (conceal_ref): each a copy of the reference picture nearest in output order among those the DPB holds NOW, before this picture's set is
+    // applied (with one reference picture per picture the set names the lost picture and nothing else), of two equally near the earlier one; no stand-in of this
+    // same picture is a source.  (The source may be dropped by the set and become this picture's own buffer: the copy runs before the picture's kernels.)
+    std::vector<int> fresh;
+    for (const auto &c : pending_conceal_) if (c.second == -2) fresh.push_back(c.first);
+    for (auto &c : pending_conceal_) if (c.second == -2) {
+      int best = -1;
+      for (int q = 0; q < KVZ_DEC_MAX_REFS; q++) {
+        if (!dpb_[q].is_ref || !dpb_[q].used || std::find(fresh.begin(), fresh.end(), q) != fresh.end()) continue;
+        const long long dq = llabs((long long)dpb_[q].poc - dpb_[c.first].poc), db = best < 0 ? 0 : llabs((long long)dpb_[best].poc - dpb_[c.first].poc);
+        if (best < 0 || dq < db || (dq == db && dpb_[q].poc < dpb_[best].poc)) best = q;
+      }
+      c.second = best;                                            // (-1: none -- grey)
+    }
     for (int q = 0; q < KVZ_DEC_MAX_REFS; q++) if (!keep[q]) dpb_[q].is_ref = false;
     if (!sh.is_intra) {
       const int nst = nc;                                 // (the short-term part of the temporary lists)
@@ -2812,7 +2826,11 @@ int Decoder::launch_gpu(PicJob &job)
     const size_t npx = (size_t)pw_ * ph_;
     // (unconditionally: headers run ahead of launches -- by now a LATER picture may have been given the buffer, which is fine, it launches after this one and
     // overwrites it; a list inherited from a header that failed names buffers that are still stand-ins or have become this picture's own)
-    for (int s : job.conceal) if (dpb_[s].plane[0] && hipMemset(dpb_[s].plane[0], 128, npx * 3 / 2) != hipSuccess) return DEC_ERR_GPU;
+    for (const auto &c : job.conceal) {
+      uint8_t *dst = dpb_[c.first].plane[0], *src = c.second >= 0 ? dpb_[c.second].plane[0] : nullptr;
+      if (!dst) continue;
+      if ((src && src != dst ? hipMemcpy(dst, src, npx * 3 / 2, hipMemcpyDeviceToDevice) : hipMemset(dst, 128, npx * 3 / 2)) != hipSuccess) return DEC_ERR_GPU;
+    }
     if (hipDeviceSynchronize() != hipSuccess) return DEC_ERR_GPU;
     job.conceal.clear();
   }

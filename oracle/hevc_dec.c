@@ -29,6 +29,7 @@ struct orc_decoder {
   int prev_tid0_poc;
   int seen_irap;
   int tid;                                /* TemporalId of the NAL unit at hand */
+  uint8_t pre_ref[MAX_DPB];               /* the reference pictures of the DPB as the current picture found it, before its reference picture set was applied (missing_ref) */
   int concealed;                          /* missing reference pictures replaced so far (missing_ref) */
   int after_eos;                          /* an end of sequence NAL unit came: the next picture starts a coded video sequence (a CRA picture then has NoRaslOutputFlag = 1) */
   int skip_rasl;                          /* NoRaslOutputFlag of the last IRAP picture: its RASL pictures are not decoded (8.1.3) */
@@ -699,7 +700,7 @@ static orc_pic *alloc_pic(orc_decoder *d, int w, int h)
 {
   for (int i = 0; i < MAX_DPB; i++) {
     orc_pic *p = &d->dpb[i];
-    if (p->in_use && (p->is_ref || p->needed_for_output || p == d->last_output)) continue;
+    if (p->in_use && (p->is_ref || p->needed_for_output || p == d->last_output || d->pre_ref[i])) continue;      /* (pre_ref: still a source for stand-ins of the picture being started) */
     if (p->plane[0] && (p->w != w || p->h != h)) orc_pic_free(p);
     if (!p->plane[0]) { if (orc_pic_alloc(p, w, h)) return NULL; }
     else orc_pic_reset_side(p);
@@ -770,6 +771,7 @@ void orc_dec_flush(orc_decoder *d) { if (d->pic_active) return; while (waiting_f
 static int start_picture(orc_decoder *d)
 {
   const orc_sps *s = d->s; orc_slice_hdr *sh = &d->sh;
+  for (int i = 0; i < MAX_DPB; i++) { d->dpb[i].stand_in_fresh = 0; d->pre_ref[i] = (uint8_t)(d->dpb[i].in_use && d->dpb[i].is_ref); }
   int irap = d->nal_type >= NAL_BLA_W_LP && d->nal_type <= NAL_RSV_IRAP_VCL23;
   int idr = d->nal_type == NAL_IDR_W_RADL || d->nal_type == NAL_IDR_N_LP;
   const int bla = d->nal_type >= NAL_BLA_W_LP && d->nal_type <= NAL_BLA_N_LP;
@@ -858,16 +860,30 @@ static int start_picture(orc_decoder *d)
 /* 8.3.4: RefPicList0 = the used pictures before the current one (nearest first), then those after it, repeated until the list is full; RefPicList1
  * the other way round.  No list modification, no long-term pictures. */
 /* A picture the reference picture set says the current picture predicts from is not there -- its access unit never arrived (the streams come over RTP).  What a
- * decoder does then is not the standard's business; this project's rule ("concealment v1", the one libavcodec's -- and so OpenHEVC's -- generate_missing_ref follows):
- * a picture of mid-grey samples with the missing picture order count stands in, without motion (a block of it gives no temporal candidate), never output, and decoding
- * goes on.  The product's decoder does the same (csrc/decoder.hip conceal_ref). */
+ * decoder does then is not the standard's business; this project's rule ("concealment v2"): a stand-in with the missing picture order count joins the DPB, marked as
+ * the real picture would be, without motion (a block of it gives no temporal candidate), never output, and decoding goes on.  Its samples are a COPY of the reference
+ * picture that is nearest in output order among those the DPB held when the current picture arrived -- before its reference picture set was applied: with one
+ * reference picture per picture, as Kvazaar codes by default, the set names the lost picture and nothing else -- of two equally near the earlier one: the repeated
+ * frame a viewer hardly notices; mid-grey when there is none (libavcodec's generate_missing_ref always takes grey).  The product's decoder does the same
+ * (csrc/decoder.hip conceal_ref). */
 static orc_pic *missing_ref(orc_decoder *d, int poc, int is_lt)
 {
+  const orc_pic *src = NULL;
+  for (int i = 0; i < MAX_DPB; i++) {
+    const orc_pic *q = &d->dpb[i];
+    if (!d->pre_ref[i] || q == d->cur || q->stand_in_fresh) continue;
+    const int dq = q->poc > poc ? q->poc - poc : poc - q->poc, ds = src ? (src->poc > poc ? src->poc - poc : poc - src->poc) : 0;
+    if (!src || dq < ds || (dq == ds && q->poc < src->poc)) src = q;
+  }
+  if (getenv("ORC_CONCEAL_GREY")) src = NULL;      /* (measurement aid: what the grey rule would show, HISTORY.md) */
   orc_pic *p = alloc_pic(d, d->s->width, d->s->height);
   if (!p) return NULL;
   orc_pic_reset_side(p);
-  for (int c = 0; c < 3; c++) memset(p->plane[c], 128, (size_t)p->stride[c] * (size_t)(c ? p->h / 2 : p->h));
-  p->poc = poc; p->pts = 0; p->is_ref = 1; p->is_lt = is_lt; p->needed_for_output = 0; p->out_queued = 0; p->slice_type = SLICE_I;
+  for (int c = 0; c < 3; c++) {
+    const size_t n = (size_t)p->stride[c] * (size_t)(c ? p->h / 2 : p->h);
+    if (src) memcpy(p->plane[c], src->plane[c], n); else memset(p->plane[c], 128, n);
+  }
+  p->poc = poc; p->pts = 0; p->is_ref = 1; p->is_lt = is_lt; p->needed_for_output = 0; p->out_queued = 0; p->slice_type = SLICE_I; p->stand_in_fresh = 1;
   d->concealed++;
   return p;
 }

@@ -19,6 +19,7 @@ typedef struct {
   pixel *plane[3]; int stride[3];
   int poc;
   int is_ref, needed_for_output, in_use;
+  int stand_in_fresh;                     /* made by missing_ref for the picture being started: no source for another stand-in of the same picture */
   int slice_type;                    /* decoder: of the picture's (last) slice */
   int out_queued;                    /* decoder: the picture has left the DPB's output process (C.5.2.4) and waits for the caller to fetch it */
   int64_t pts;

@@ -796,8 +796,10 @@ class Decoder:
         if self.cur is not None:
             raise ValueError("a picture's slice segments did not complete")
         # ---- reference picture set (8.3.2) and list (8.3.4)
+        self.pre_refs = list(self.dpb)                                 # (what the DPB held when this picture arrived: the sources of stand-ins, missing_ref)
         for p in self.dpb:
             p.is_ref = False
+            p.fresh = False
         if self.no_rasl_out and 16 <= nal_type <= 23:
             self.dpb = []                                              # 8.3.2: nothing that came before is a reference picture any more
             rps = [(d, 0) for d, _ in rps]                             # (what a CRA or BLA picture's set names is for its RASL pictures)
@@ -823,12 +825,12 @@ class Decoder:
                         at = poc - (poc & (mx - 1)) + lsb
                         if at >= poc:
                             at -= mx
-                    hit = [self.missing_ref(sps, at, True)]
-                    hit[0].keep_lt = True
+                    hit = [("missing", at)]                            # (its stand-in is made once the set has been applied: it copies a picture the set keeps)
                 lt_curr.append(hit[0] if hit else None)
         for p in self.dpb:
             p.is_ref = p.keep_lt or (not p.is_lt and p.poc in keep)
         self.dpb = [p for p in self.dpb if p.is_ref]
+        lt_curr = [self.missing_ref(sps, e[1], True) if isinstance(e, tuple) else e for e in lt_curr]
         def by_poc(q):
             for p in self.dpb:
                 if p.poc == q and not p.is_lt:
@@ -863,12 +865,20 @@ class Decoder:
                 self.picture_done(sl, sps, nal_type)
 
     def missing_ref(self, sps, poc, is_lt):
-        """a reference picture that never arrived (its access unit was lost): a mid-grey picture with its picture order count stands in, without motion, never
-        output -- this project's concealment rule, the one libavcodec's generate_missing_ref follows; not the standard's business"""
+        """a reference picture that never arrived (its access unit was lost): a stand-in with its picture order count joins the DPB, without motion, never output --
+        a copy of the reference picture nearest in output order among those the DPB held when the current picture arrived (of two equally near the earlier one), mid-grey
+        when there is none.  This project's concealment
+        rule (oracle/hevc_dec.c missing_ref); not the standard's business"""
         pic = Picture(sps["w"], sps["h"])
-        for pl in pic.planes:
-            pl[:] = 128
-        pic.poc, pic.is_ref, pic.is_lt, pic.keep_lt = poc, True, is_lt, False
+        cands = [p for p in self.pre_refs if not getattr(p, "fresh", False)]
+        if cands:
+            src = min(cands, key=lambda p: (abs(p.poc - poc), p.poc))
+            for dst, pl in zip(pic.planes, src.planes):
+                dst[:] = pl
+        else:
+            for pl in pic.planes:
+                pl[:] = 128
+        pic.poc, pic.is_ref, pic.is_lt, pic.keep_lt, pic.fresh = poc, True, is_lt, False, True
         self.dpb.append(pic)
         self.concealed = getattr(self, "concealed", 0) + 1
         return pic

@@ -1,7 +1,7 @@
 """Access units that never arrive (the streams come over RTP, /root/reference/src/media/delivery/uvgrtpreceiver.cpp:86-112 hands on what it got): a picture the
 reference picture set says the current one predicts from is not there.  What a decoder does then is not the standard's business.  This project's rule
-("concealment v1", the one libavcodec's -- OpenHEVC's -- generate_missing_ref follows): a picture of mid-grey samples with the missing picture order count stands
-in, without motion, never output, and decoding goes on; the next IDR picture cleans up.  The checker (oracle/hevc_dec.c missing_ref), the Python decoder and the
+("concealment v2"; libavcodec's -- OpenHEVC's -- generate_missing_ref puts a grey picture there): a copy of the nearest reference picture the DPB holds, with the
+missing picture order count, stands in, without motion, never output, and decoding goes on; the next IDR picture cleans up.  The checker (oracle/hevc_dec.c missing_ref), the Python decoder and the
 product (csrc/decoder.hip conceal_ref; GPU side: tests/test_gpu_lost_pictures.py) follow it -- the pictures behind a loss are wrong, and the same wrong everywhere."""
 import numpy as np
 import pytest

@@ -225,8 +225,14 @@ class YUVtoRGB32 : public Filter {
 class WireAdapter : public Filter {
  public:
   WireAdapter(std::string id, Stats *stats) : Filter(std::move(id), "WireAdapter", stats, DT_HEVCVIDEO, DT_HEVCVIDEO) { maxBufferSize_ = -1; }
+  // harness setting uvgx/wireLossEvery = n > 0: every n-th access unit is lost on the way (never one with parameter sets or an IRAP picture) -- what a UDP path does;
+  // the decoder conceals (csrc/decoder.h) and the chain keeps delivering.  lost(): how many went.
+  void setLossEvery(int n) { lossEvery_ = n; }
+  uint64_t lost() const { return lost_.load(); }
  protected:
   void process() override;
+ private:
+  int lossEvery_ = 0; uint64_t seen_ = 0; std::atomic<uint64_t> lost_{0};
 };
 
 }  // namespace uvgx

@@ -648,6 +648,11 @@ void WireAdapter::process()
       if (p[i + 1] == 0 && p[i + 2] == 0 && p[i + 3] == 1) { starts.push_back(i); i += 4; } else i++;
     }
     starts.push_back(n);
+    if (lossEvery_ > 0) {
+      bool precious = false;                                 // parameter sets, IRAP pictures
+      for (size_t k = 0; k + 1 < starts.size(); k++) { const int t = (p[starts[k] + 4] >> 1) & 0x3f; precious |= (t >= 16 && t <= 23) || (t >= 32 && t <= 34); }
+      if (!precious && ++seen_ % (uint64_t)lossEvery_ == 0) { lost_.fetch_add(1); input = getInput(); continue; }
+    }
     for (size_t k = 0; k + 1 < starts.size(); k++) {
       std::unique_ptr<Data> nal(new Data);
       nal->source = DS_REMOTE; nal->type = DT_HEVCVIDEO;
@@ -748,6 +753,7 @@ KVZ_PUBLIC void *uvgx_pipeline_create(const char *settings_text, int loopback_de
   });
   if (p->loopback) {
     p->wire.reset(new WireAdapter("uvgx", &p->stats));
+    { auto it = p->settings.find("uvgx/wireLossEvery"); if (it != p->settings.end()) p->wire->setLossEvery(atoi(it->second.c_str())); }
     p->dec.reset(new OpenHEVCFilter(1, &p->stats, &p->settings));
     if (!p->dec->init()) { delete p; return nullptr; }
     p->enc->addOutConnection(p->wire.get());

@@ -55,3 +55,41 @@ def test_losses_in_a_stream_of_the_hip_encoder(gpu, threads):
     cut = [(t, a) for t, a in enumerate(aus) if t % 16 == 0 or t % 3 != 1]
     assert len(cut) < len(aus)
     run(cut, threads)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("every", [4, 7])
+def test_the_filter_chain_keeps_delivering_over_a_lossy_wire(gpu, every):
+    """KvazaarFilter' -> wire -> OpenHEVCFilter' with every n-th access unit lost between them (harness setting uvgx/wireLossEvery; never an IDR picture): the chain
+    delivers every picture that arrived, and they are the checker's decode of the same NAL units"""
+    from kvazzup_amd.pipeline import Pipeline
+    w, h, frames, period = 416, 240, 40, 16
+    pl = Pipeline(w, h, settings={"video/QP": 30, "video/Intra": period, "uvgx/wireLossEvery": every}, custom=(("me-range", 16),))
+    od = orc.OracleDecoder()
+    try:
+        clip = [np.ascontiguousarray(orc.synth_frame(0, 0x5EED0008, w, h, t)) for t in range(frames)]
+        for f in clip:                                              # (paced: a uvgComm filter drops inputs that find its buffer full -- not the loss this test is about)
+            assert pl.push_host_paced(f, max_backlog=4)
+        lost = (frames - len(range(0, frames, period))) // every
+        assert lost >= 4 and pl.wait(frames - lost, 60000)
+        seen, arrived = 0, []
+        for t in range(frames):                                     # (the harness's rule, applied to the access units as they left the encoder)
+            au, pts = pl.pop_encoded()
+            assert pts == t
+            if t % period != 0:
+                seen += 1
+                if seen % every == 0:
+                    continue
+            arrived.append((t, au))
+        assert len(arrived) == frames - lost
+        for t, au in arrived:
+            want = od.decode_au(au, t)
+            assert len(want) == 1
+            d = pl.pop_decoded()
+            assert d["pts"] == t and np.array_equal(d["i420"], want[0]["i420"]), "picture %d" % t
+        assert od.concealed() > 0
+        st = pl.stats()
+        assert st["decoded_pictures"] == frames - lost
+    finally:
+        pl.close()
+        od.close()

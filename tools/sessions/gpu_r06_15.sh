@@ -4,5 +4,5 @@
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
 { timeout 1500 python tools/measure/soak_default_mode.py 3000 2>&1 | tail -3
   timeout 1200 python tools/measure/soak_all_intra.py 2>&1 | tail -3
-  KVZ_FUZZ_TRIALS=20000 timeout 1500 python -m pytest tests/test_gpu_decoder.py tests/test_gpu_foreign.py -q -n 3 -k "corrupt or hostile or fuzz or garbage or truncat" 2>&1 | tail -3
+  KVZ_FUZZ_TRIALS=20000 timeout 1500 python -m pytest tests/test_gpu_decoder.py tests/test_gpu_foreign.py tests/test_gpu_everything.py -q -n 3 -k "corrupt or hostile or fuzz or garbage or truncat" 2>&1 | tail -3
 } > gpurun_out/r06_soaks.txt 2>&1; cat gpurun_out/r06_soaks.txt

@@ -177,7 +177,7 @@ class Decoder:
 
     OH_THREAD_FRAME, OH_THREAD_SLICE = 1, 2
 
-    def __init__(self, threads=1, download=True, device=None, frame_threads=False):
+    def __init__(self, threads=1, download=True, device=None, frame_threads=False, temporal_layer=7):
         self.lib = N.load_library()
         self.threads, self.frame_threads = threads, bool(frame_threads) and threads > 1
         self.h = self.lib.libOpenHevcInit(threads, self.OH_THREAD_FRAME if frame_threads else self.OH_THREAD_SLICE)
@@ -187,7 +187,7 @@ class Decoder:
             self.lib.libOpenHevcClose(self.h)
             self.h = None
             raise RuntimeError("libOpenHevcStartDecoder failed (no usable HIP device? there is no CPU fallback)")
-        self.lib.libOpenHevcSetTemporalLayer_id(self.h, 0)
+        self.lib.libOpenHevcSetTemporalLayer_id(self.h, int(temporal_layer))      # (the highest sub-layer decoded: OpenHEVC's default 7 = all; uvgComm's filter passes 0, openhevcfilter.cpp:54)
         self.lib.libOpenHevcSetActiveDecoders(self.h, 0)
         self.lib.libOpenHevcSetViewLayers(self.h, 0)
         self.download = download

@@ -1548,6 +1548,7 @@ int Decoder::decode_nal_inner(const uint8_t *data, size_t len, int64_t pts)
   const int nal_type = (data[0] >> 1) & 0x3f, layer = ((data[0] & 1) << 5) | (data[1] >> 3);
   if (layer != 0) return 0;
   cur_tid_ = (data[1] & 7) - 1;
+  if (nal_type < 32 && cur_tid_ > max_tid_) return 0;            // (set_max_temporal_id: a sub-layer the caller does not want)
   if (rbsp_.size() < len + 32) rbsp_.resize(len + 32);
   epb_.clear();
   // emulation prevention bytes out (7.4.2; hevc_headers.h append_nal is the inverse): the bytes between zero bytes in one piece

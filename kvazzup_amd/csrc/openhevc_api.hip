@@ -93,7 +93,7 @@ void libOpenHevcGetPictureInfo(OpenHevc_Handle hh, OpenHevc_FrameInfo *info)
 void libOpenHevcGetPictureSize2(OpenHevc_Handle hh, OpenHevc_FrameInfo *info) { libOpenHevcGetPictureInfo(hh, info); }
 void libOpenHevcSetCheckMD5(OpenHevc_Handle hh, int val) { Handle *h = H(hh); if (h && h->dec) h->dec->set_check_hash(val != 0); }
 void libOpenHevcSetDebugMode(OpenHevc_Handle, int) {}
-void libOpenHevcSetTemporalLayer_id(OpenHevc_Handle, int) {}
+void libOpenHevcSetTemporalLayer_id(OpenHevc_Handle hh, int val) { Handle *h = H(hh); if (h && h->dec) h->dec->set_max_temporal_id(val); }
 void libOpenHevcSetNoCropping(OpenHevc_Handle, int) {}
 void libOpenHevcSetActiveDecoders(OpenHevc_Handle, int) {}
 void libOpenHevcSetViewLayers(OpenHevc_Handle, int) {}

@@ -219,3 +219,32 @@ def test_what_a_decoder_steps_over(gpu, seed, threads):
     aus = [g.picture() for _ in range(14)]
     g.close()
     assert len(both(aus, range(len(aus)), threads, threads > 1)) == len(aus)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("seed", range(1, 7))
+def test_the_highest_sub_layer_to_decode_can_be_set(gpu, seed, threads):
+    """libOpenHevcSetTemporalLayer_id(h, k): the WHOLE stream goes in, the slice NAL units of the sub-layers above k are dropped inside -- the pictures are those of the
+    stream thinned by hand.  (OpenHEVC's default is 7; uvgComm's filter passes 0, openhevcfilter.cpp:54 -- a peer's gop=8 stream plays at its base layer's rate there.)"""
+    from kvazzup_amd.codec import Decoder
+    from test_random_access import layered, tid_of
+    aus = layered(seed, n=28, w=416, h=240)
+    tids = [tid_of(a) for a in aus]
+    for keep in range(max(tids) + 1):
+        od = orc.OracleDecoder()
+        gd = Decoder(threads=threads, frame_threads=threads > 1, temporal_layer=keep)
+        want, got = [], []
+        try:
+            for t, au in enumerate(aus):
+                if tids[t] <= keep:
+                    want += od.decode_au(au, t)
+                got += gd.decode_au(au, t)
+            want += od.flush()
+            got += gd.drain()
+        finally:
+            gd.close()
+            od.close()
+        assert [f["pts"] for f in got] == [f["pts"] for f in want] and len(got) == sum(t <= keep for t in tids)
+        for a, b in zip(got, want):
+            assert np.array_equal(a["i420"], b["i420"]), (keep, a["pts"])

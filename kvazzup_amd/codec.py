@@ -177,7 +177,7 @@ class Decoder:
 
     OH_THREAD_FRAME, OH_THREAD_SLICE = 1, 2
 
-    def __init__(self, threads=1, download=True, device=None, frame_threads=False, temporal_layer=7):
+    def __init__(self, threads=1, download=True, device=None, frame_threads=False, temporal_layer=7, no_cropping=False):
         self.lib = N.load_library()
         self.threads, self.frame_threads = threads, bool(frame_threads) and threads > 1
         self.h = self.lib.libOpenHevcInit(threads, self.OH_THREAD_FRAME if frame_threads else self.OH_THREAD_SLICE)
@@ -189,6 +189,8 @@ class Decoder:
             raise RuntimeError("libOpenHevcStartDecoder failed (no usable HIP device? there is no CPU fallback)")
         self.lib.libOpenHevcSetTemporalLayer_id(self.h, int(temporal_layer))      # (the highest sub-layer decoded: OpenHEVC's default 7 = all; uvgComm's filter passes 0, openhevcfilter.cpp:54)
         self.lib.libOpenHevcSetActiveDecoders(self.h, 0)
+        if no_cropping:
+            self.lib.libOpenHevcSetNoCropping(self.h, 1)                # (pictures at their coded size: the conformance window is not applied)
         self.lib.libOpenHevcSetViewLayers(self.h, 0)
         self.download = download
         if not download:

@@ -162,6 +162,7 @@ class Decoder {
   void set_check_hash(bool on) { check_hash_ = on; }
   // libOpenHevcSetTemporalLayer_id: the highest temporal sub-layer that is decoded -- slice NAL units with a higher TemporalId are dropped (nothing of the layers below
   // predicts from them, 8.1.3 sub-bitstream extraction).  OpenHEVC's default is 7 (everything); uvgComm passes 0 (openhevcfilter.cpp:54), and its own sender codes one layer.
+  void set_no_cropping(bool on) { no_crop_ = on; }      // libOpenHevcSetNoCropping: pictures are handed out at their coded size, the conformance window is not applied
   void set_max_temporal_id(int t) { max_tid_ = t < 0 ? 0 : (t > 7 ? 7 : t); }
   void hash_stats(int *checked, int *mismatch) const { if (checked) *checked = hash_checked_; if (mismatch) *mismatch = hash_mismatch_; }
   void flush() {}
@@ -383,7 +384,7 @@ class Decoder {
   bool spin_wait_ = false;                // KVAZZUP_AMD_SPIN: poll the GPU instead of napping between queries
   PicJob *gpu_job_ = nullptr;             // picture whose kernels are in flight (frame-threaded mode)
   int prev_poc_ = 0, cur_tid_ = 0; bool seen_irap_ = false;
-  int max_tid_ = 7;
+  int max_tid_ = 7; bool no_crop_ = false;
   bool after_eos_ = false;       // an end of sequence / end of bitstream NAL unit came: the next picture starts a coded video sequence (a CRA picture then has NoRaslOutputFlag = 1, 8.1.3)
   // C.5.2.2's bookkeeping in DECODING order, kept at submit time: the pictures that are "needed for output" and have not had their turn -- (serial, POC).  The pictures
   // themselves complete later (frame threads) and leave through reorder_q_ by the same counting rule; this list exists so that an IDR / BLA picture with

@@ -94,7 +94,7 @@ void libOpenHevcGetPictureSize2(OpenHevc_Handle hh, OpenHevc_FrameInfo *info) { 
 void libOpenHevcSetCheckMD5(OpenHevc_Handle hh, int val) { Handle *h = H(hh); if (h && h->dec) h->dec->set_check_hash(val != 0); }
 void libOpenHevcSetDebugMode(OpenHevc_Handle, int) {}
 void libOpenHevcSetTemporalLayer_id(OpenHevc_Handle hh, int val) { Handle *h = H(hh); if (h && h->dec) h->dec->set_max_temporal_id(val); }
-void libOpenHevcSetNoCropping(OpenHevc_Handle, int) {}
+void libOpenHevcSetNoCropping(OpenHevc_Handle hh, int val) { Handle *h = H(hh); if (h && h->dec) h->dec->set_no_cropping(val != 0); }
 void libOpenHevcSetActiveDecoders(OpenHevc_Handle, int) {}
 void libOpenHevcSetViewLayers(OpenHevc_Handle, int) {}
 void libOpenHevcFlush(OpenHevc_Handle hh) { Handle *h = H(hh); if (h && h->dec) h->dec->flush(); }

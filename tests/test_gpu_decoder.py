@@ -406,3 +406,27 @@ def test_whole_pictures_in_one_segment_with_dependent_segments_enabled(gpu, fram
     assert gd.lib.kvzx_decoder_last_error(gd.h) == 0
     for x in (oe, gd, od):
         x.close()
+
+
+@pytest.mark.gpu
+def test_no_cropping_hands_out_the_coded_picture(gpu):
+    """libOpenHevcSetNoCropping(h, 1): the conformance window is not applied -- the picture comes at its coded size, the cropped picture is its top left part"""
+    from kvazzup_amd.codec import Decoder
+    w, h = 200, 136
+    oe = orc.OracleEncoder(w, h, qp=32, period=4, me_range=8)
+    aus = [oe.encode(orc.synth_frame(0, 0x5EED0009, w, h, t)) for t in range(5)]
+    oe.close()
+    plain, full = Decoder(), Decoder(no_cropping=True)
+    try:
+        for t, au in enumerate(aus):
+            a, b = plain.decode_au(au, t), full.decode_au(au, t)
+            assert len(a) == len(b) == 1
+            a, b = a[0], b[0]
+            assert (a["width"], a["height"]) == (w, h) and b["width"] >= w and b["height"] >= h and b["width"] % 8 == 0 and b["height"] % 8 == 0 and (b["width"], b["height"]) != (w, h)
+            W, H = b["width"], b["height"]
+            ya, yb = a["i420"][:w * h].reshape(h, w), b["i420"][:W * H].reshape(H, W)
+            assert np.array_equal(ya, yb[:h, :w])
+            ua, ub = a["i420"][w * h:w * h * 5 // 4].reshape(h // 2, w // 2), b["i420"][W * H:W * H * 5 // 4].reshape(H // 2, W // 2)
+            assert np.array_equal(ua, ub[:h // 2, :w // 2])
+    finally:
+        plain.close(); full.close()

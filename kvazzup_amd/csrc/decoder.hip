@@ -1273,7 +1273,7 @@ bool Decoder::ensure_buffers(int w, int h, int ctb_log2)
 }
 
 // a picture buffer for the picture about to be decoded: not a reference any more and, if it was output, output long enough ago
-// Concealment v1 (decoder.h): the buffer that stands in for a reference picture that never arrived.  Marked like the real one would be; its samples are set when
+// Concealment v2 (decoder.h): the buffer that stands in for a reference picture that never arrived.  Marked like the real one would be; its samples are set when
 // the picture that asked for it is launched (the GPU may still be reading the buffer's former picture for older pictures that are in flight).
 int Decoder::conceal_ref(int poc, bool is_lt)
 {

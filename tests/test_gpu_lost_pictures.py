@@ -1,4 +1,4 @@
-"""GPU side of tests/test_lost_pictures.py: access units lost on the way -- the HIP decoder puts a copy of the nearest reference picture (a grey one when it has none) where a reference picture is missing (concealment v1,
+"""GPU side of tests/test_lost_pictures.py: access units lost on the way -- the HIP decoder puts a copy of the nearest reference picture (a grey one when it has none) where a reference picture is missing (concealment v2,
 decoder.h) and goes on; every picture it hands out, wrong as the ones behind a loss are, is the checker's bit for bit; nothing but the lost pictures is missing.
 Before round 6's last day every picture up to the next IDR picture was answered with an error code -- two seconds of frozen video per lost packet at uvgComm's
 intra period of 64."""

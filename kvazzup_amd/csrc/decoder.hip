@@ -1817,6 +1817,19 @@ int Decoder::close_open_picture()
     if (rc > 0 && pic_ready_ && !stash_current_output()) return last_error_ = DEC_ERR_GPU;     // (handed out first, by the next call: the NAL unit at hand may produce a picture of its own)
     return 0;
   }
+  if (old.pps.tile_rows == 1 && old.pps.tile_cols == 1 && band_nrows_ == 0 && asm_segs_.size() > 1) {
+    // One tile, and the rows counted so far do not make the picture: they were counted on guesses -- without WPP no header says how far a segment reaches, a
+    // dependent segment at a row's start was taken for that one row (the form Kvazaar's slices=wpp has WITH WPP).  The stream cuts its pictures as it likes after
+    // all (it had looked like whole pictures again: close_free_picture's single-segment rule): the segments are all here, each ends where the next begins, the last
+    // one with the picture.  If one was lost instead, the parser finds a segment ending early and the picture fails there.
+    asm_guessed_one_row_ = false;
+    int rc = close_free_picture(old);
+    old.ambiguous_end = false;
+    if (rc >= 0) { free_stream_ = true; rc = submit_job(old, asm_nal_type_, asm_irap_); }
+    if (rc < 0) { last_error_ = rc; return 0; }
+    if (rc > 0 && pic_ready_ && !stash_current_output()) return last_error_ = DEC_ERR_GPU;
+    return 0;
+  }
   last_error_ = DEC_ERR_INVALID;
   static bool said = false;
   if (!said) { said = true; fprintf(stderr, "kvazzup_amd: decoder dropped a picture whose slice segments did not complete before the next picture began\n"); }

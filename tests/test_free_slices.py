@@ -143,3 +143,18 @@ def test_long_term_reference_pictures(kw):
         nals = [n for au in aus for n in orc.split_nals(au)]
         a, b = PP.probe(nals, 1), PP.probe(nals, 4)
         assert a == b and a["pictures"] == 22, (seed, a, b)
+
+
+def test_a_segment_at_a_rows_start_behind_a_whole_picture():
+    """(soak seed 1578) A stream of free slices without WPP: after a picture that came in ONE segment the synchronous decoder takes the stream for whole pictures again;
+    the next picture's second segment happens to begin exactly where a CTB row does and reaches to the picture's end -- counted as one row (Kvazaar's form), the
+    picture looked incomplete and was dropped.  It is read as a picture of free slices when its access unit ends.  The product's host half through the parse-only
+    hook: every picture parsed."""
+    import parser_probe as PP
+    g = orc.OracleGen(64, 64, seed=1578, intra_period=16, tmvp=1, ctb_log2=4, min_cb_log2=3, cip=0, pcm=0, lf_across=2, intra_in_p=30, slices=3, gop=4, b_slices=0, open_gop=0,
+                      temporal_layers=1, rps_forms=1)
+    aus = [g.picture() for _ in range(24)]
+    g.close()
+    nals = [n for a in aus for n in orc.split_nals(a)]
+    for threads in (0, 3):
+        assert PP.probe(nals, threads)["pictures"] == 24

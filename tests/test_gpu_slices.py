@@ -66,3 +66,15 @@ def test_a_stream_turns_to_free_slices_and_back(gpu):
             g.close(); od.close()
     finally:
         gd.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 3])
+def test_a_segment_at_a_rows_start_behind_a_whole_picture(gpu, threads):
+    """(soak seed 1578; tests/test_free_slices.py has the story) the pictures are the checker's"""
+    from test_gpu_random_access import both
+    g = orc.OracleGen(64, 64, seed=1578, intra_period=16, tmvp=1, ctb_log2=4, min_cb_log2=3, cip=0, pcm=0, lf_across=2, intra_in_p=30, slices=3, gop=4, b_slices=0, open_gop=0,
+                      temporal_layers=1, rps_forms=1)
+    aus = [g.picture() for _ in range(24)]
+    g.close()
+    assert len(both(aus, range(24), threads, threads > 1)) == 24

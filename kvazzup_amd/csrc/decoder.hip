@@ -2460,6 +2460,9 @@ int Decoder::finish_oldest()
     // this thread's launch latency in between
     tl("dlaunch0", job.pts);
     rc_launch = job.rc < 0 ? (job.rc == DEC_SEG_ENDS_EARLY ? DEC_ERR_UNSUPPORTED : job.rc) : launch_gpu(job);      // (a picture whose last segment ended early and whose rest never came)
+    // a picture that could not be parsed (damaged on the way) is never reconstructed: its buffer is no reference picture -- the pictures that name it find it
+    // missing and get a stand-in (conceal_ref) instead of whatever the buffer held.  (Frame threads: pictures submitted before this was known keep the buffer.)
+    if (job.rc < 0 && dpb_[job.slot].is_ref && dpb_[job.slot].poc == job.sh.poc && dpb_[job.slot].decode_idx == job_tail_ - 1) dpb_[job.slot].is_ref = false;
     tl("dlaunch1", job.pts);
     launched = rc_launch >= 0;
   }

@@ -7,6 +7,9 @@
  *   libOpenHevcInit(threads, type)          openhevcfilter.cpp:36-47   (type: 1 frame, 2 slice, 3 both)
  *   libOpenHevcStartDecoder                 openhevcfilter.cpp:49      (-1 = failure)
  *   libOpenHevcSetTemporalLayer_id / SetActiveDecoders / SetViewLayers   openhevcfilter.cpp:54-56
+ *       (SetTemporalLayer_id: the highest temporal sub-layer decoded, OpenHEVC's default 7 = all -- slice NAL units above it are dropped; uvgComm passes 0.
+ *        SetActiveDecoders / SetViewLayers: layered extensions, no effect here -- NAL units of nuh_layer_id > 0 are dropped.  SetNoCropping: pictures at their
+ *        coded size.  SetCheckMD5: decoded picture hash SEI messages are compared.  SetDebugMode: no effect.)
  *   libOpenHevcVersion                      openhevcfilter.cpp:64
  *   libOpenHevcDecode(h, nal, len, pts)     openhevcfilter.cpp:145-146 (<0 error, 0 none, >0 picture)
  *   libOpenHevcGetOutput(h, got, &frame)    openhevcfilter.cpp:195     (>0 = frame filled)
